@@ -1,0 +1,165 @@
+"""oracle -- TEST INFRASTRUCTURE ONLY.
+
+ctypes binding of oracle/liboracle.so (the plain-C CPU restatement of the reference's
+pairing path, oracle/pbc_oracle.c) plus helpers for the golden vector files written by
+oracle/_ref/ref_tool (the unmodified reference compiled by oracle/Makefile).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this
+package.  pbc_amd/ (the product) never does.
+"""
+import ctypes
+import os
+import struct
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "liboracle.so")
+REF_TOOL = os.path.join(_HERE, "_ref", "ref_tool")
+
+
+def build(force=False):
+    """Compile the C restatement (and, where /root/reference exists, oracle/_ref)."""
+    if force or not os.path.exists(_LIB) or \
+            os.path.getmtime(_LIB) < os.path.getmtime(os.path.join(_HERE, "pbc_oracle.c")):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "oracle"])
+    if os.path.isdir("/root/reference/arith") and (force or not os.path.exists(REF_TOOL)):
+        subprocess.check_call(["make", "-s", "-j8", "-C", _HERE, "ref"])
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = ctypes.CDLL(_LIB)
+        vp, cp, sz, ci = ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int
+        L.oracle_pairing_init.argtypes = [ctypes.POINTER(vp), cp, sz]
+        L.oracle_pairing_clear.argtypes = [vp]
+        for f in ("oracle_type", "oracle_len_G1", "oracle_len_G2", "oracle_len_GT"):
+            getattr(L, f).argtypes = [vp]
+        L.oracle_pairing_batch.argtypes = [vp, vp, vp, vp, sz]
+        L.oracle_prod_pairing_batch.argtypes = [vp, vp, vp, vp, sz, ci]
+        L.oracle_fq_op.argtypes = [vp, ci, vp, vp, vp, sz]
+        L.oracle_gt_mul.argtypes = [vp, vp, vp, vp, sz]
+        L.oracle_gt_pow.argtypes = [vp, vp, vp, sz, vp, sz]
+        L.oracle_g_mul.argtypes = [vp, ci, vp, vp, sz, vp, sz]
+        L.oracle_counters.argtypes = [ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64), ci]
+        _lib = L
+    return _lib
+
+
+def _ptr(a):
+    return a.ctypes.data_as(ctypes.c_void_p) if a is not None else None
+
+
+def _u8(a):
+    return np.ascontiguousarray(a, dtype=np.uint8)
+
+
+class OraclePairing:
+    """CPU oracle for one parameter set (mirrors pairing_t)."""
+
+    def __init__(self, param_text):
+        if isinstance(param_text, str):
+            param_text = param_text.encode()
+        self._h = ctypes.c_void_p()
+        if lib().oracle_pairing_init(ctypes.byref(self._h), param_text, len(param_text)):
+            raise ValueError("oracle_pairing_init failed")
+        self.type = chr(lib().oracle_type(self._h))
+        self.len_G1 = lib().oracle_len_G1(self._h)
+        self.len_G2 = lib().oracle_len_G2(self._h)
+        self.len_GT = lib().oracle_len_GT(self._h)
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().oracle_pairing_clear(self._h)
+        except Exception:
+            pass
+
+    def pairing_batch(self, g1, g2):
+        g1, g2 = _u8(g1), _u8(g2)
+        n = g1.size // self.len_G1
+        out = np.empty((n, self.len_GT), np.uint8)
+        if lib().oracle_pairing_batch(self._h, _ptr(g1), _ptr(g2), _ptr(out), n):
+            raise RuntimeError("oracle_pairing_batch failed")
+        return out
+
+    def prod_pairing_batch(self, g1, g2, k):
+        g1, g2 = _u8(g1), _u8(g2)
+        n = g1.size // (self.len_G1 * k)
+        out = np.empty((n, self.len_GT), np.uint8)
+        if lib().oracle_prod_pairing_batch(self._h, _ptr(g1), _ptr(g2), _ptr(out), n, k):
+            raise RuntimeError("oracle_prod_pairing_batch failed")
+        return out
+
+    def fq_op(self, op, a, b=None):
+        a = _u8(a)
+        b = _u8(b) if b is not None else None
+        L = self.len_G1 // 2 if self.type == "a" else None
+        n = a.size // L
+        out = np.empty((n, L), np.uint8)
+        if lib().oracle_fq_op(self._h, op, _ptr(a), _ptr(b), _ptr(out), n):
+            raise RuntimeError("oracle_fq_op failed")
+        return out
+
+    def gt_mul(self, a, b):
+        a, b = _u8(a), _u8(b)
+        n = a.size // self.len_GT
+        out = np.empty((n, self.len_GT), np.uint8)
+        if lib().oracle_gt_mul(self._h, _ptr(a), _ptr(b), _ptr(out), n):
+            raise RuntimeError("oracle_gt_mul failed")
+        return out
+
+    def gt_pow(self, a, e):
+        """a: (n, lenGT) bytes; e: (n, elen) big-endian exponent bytes."""
+        a, e = _u8(a), _u8(e)
+        n = a.size // self.len_GT
+        elen = e.size // n
+        out = np.empty((n, self.len_GT), np.uint8)
+        if lib().oracle_gt_pow(self._h, _ptr(a), _ptr(e), elen, _ptr(out), n):
+            raise RuntimeError("oracle_gt_pow failed")
+        return out
+
+    def g_mul(self, group, pts, e):
+        pts, e = _u8(pts), _u8(e)
+        L = self.len_G1 if group == 1 else self.len_G2
+        n = pts.size // L
+        elen = e.size // n
+        out = np.empty((n, L), np.uint8)
+        if lib().oracle_g_mul(self._h, group, _ptr(pts), _ptr(e), elen, _ptr(out), n):
+            raise RuntimeError("oracle_g_mul failed")
+        return out
+
+
+def counters(reset=False):
+    m, i = ctypes.c_uint64(), ctypes.c_uint64()
+    lib().oracle_counters(ctypes.byref(m), ctypes.byref(i), int(reset))
+    return m.value, i.value
+
+
+class Vec:
+    """A golden vector file written by ref_tool gen/kat (layout: oracle/ref_harness.c)."""
+
+    def __init__(self, path):
+        raw = open(path, "rb").read()
+        assert raw[:8] == b"PBCVEC01", path
+        t, n, k, l1, l2, lt = struct.unpack("<6I", raw[8:32])
+        self.type, self.n, self.k, self.len1, self.len2, self.lenT = chr(t), n, k, l1, l2, lt
+        off = 32
+        a = np.frombuffer(raw, np.uint8)
+        self.g1 = a[off:off + n * k * l1].reshape(n * k, l1).copy(); off += n * k * l1
+        self.g2 = a[off:off + n * k * l2].reshape(n * k, l2).copy(); off += n * k * l2
+        self.gt = a[off:off + n * lt].reshape(n, lt).copy(); off += n * lt
+        assert off == len(raw), path
+
+
+def ref_gen(param_path, mode, n, k, seed, out_path):
+    """Run the compiled reference to produce a vector file (needs oracle/_ref/ref_tool)."""
+    subprocess.check_call([REF_TOOL, "gen", param_path, mode, str(n), str(k), str(seed), out_path],
+                          stderr=subprocess.DEVNULL)
+    return Vec(out_path)

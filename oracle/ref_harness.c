@@ -1,0 +1,208 @@
+/*
+ * ref_harness.c -- TEST INFRASTRUCTURE ONLY (never shipped, never on the product path).
+ *
+ * A small driver that links against the *unmodified* reference PBC library
+ * (compiled from /root/reference by oracle/Makefile into oracle/_ref/) and
+ *   gen   : emits binary vector files  (inputs in element_to_bytes format +
+ *           GT outputs of element_pairing / element_prod_pairing)
+ *   kat   : re-checks the reference's only pairing known-answer test
+ *           (pbc/pairing_test.pbc:3-10) through the C API
+ *   bench : times element_pairing / element_prod_pairing on the host cores
+ *           (loop shaped like benchmark/benchmark.c:70-99), one forked
+ *           worker per requested core (PBC is not thread safe).
+ *
+ * Vector file layout (little endian):
+ *   char magic[8] = "PBCVEC01"; u32 type_char; u32 n; u32 k; u32 len1; u32 len2; u32 lenT;
+ *   u8 in1[n*k*len1]; u8 in2[n*k*len2]; u8 out[n*lenT];
+ * Unit u (0..n-1) uses terms u*k .. u*k+k-1; k==1 -> element_pairing,
+ * k>1 -> element_prod_pairing.
+ *
+ * Input distributions (mode):
+ *   chain  : P0=from_hash(G1,"pbc-mi355x/P0"), Q0=from_hash(G2,"pbc-mi355x/Q0"),
+ *            P_i=(i+1)P0, Q_i=(i+1)Q0 by repeated element_add
+ *   random : pbc_random_set_deterministic(seed) BEFORE pairing_init, element_random
+ *   edge   : random, but a few units get an identity (off-curve bytes) input
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdint.h>
+#include <unistd.h>
+#include <sys/wait.h>
+#include <sys/time.h>
+#include <gmp.h>
+#include "pbc.h"
+
+static double now(void) {
+  struct timeval tv;
+  gettimeofday(&tv, NULL);
+  return tv.tv_sec + 1e-6 * tv.tv_usec;
+}
+
+static char *slurp(const char *path, size_t *len) {
+  FILE *fp = fopen(path, "rb");
+  if (!fp) { perror(path); exit(2); }
+  char *buf = malloc(1 << 16);
+  *len = fread(buf, 1, (1 << 16) - 1, fp);
+  buf[*len] = 0;
+  fclose(fp);
+  return buf;
+}
+
+static void init_pairing(pairing_t pairing, const char *path, char *type_out) {
+  size_t len;
+  char *s = slurp(path, &len);
+  if (pairing_init_set_buf(pairing, s, len)) { fprintf(stderr, "pairing init failed\n"); exit(2); }
+  const char *t = strstr(s, "type ");
+  *type_out = t ? t[5] : '?';
+  free(s);
+}
+
+static void w32(FILE *fp, uint32_t v) { fwrite(&v, 4, 1, fp); }
+
+static int cmd_gen(int argc, char **argv) {
+  if (argc < 7) { fprintf(stderr, "gen <param> <chain|random|edge> <n> <k> <seed> <out>\n"); return 2; }
+  const char *param = argv[1], *mode = argv[2];
+  int n = atoi(argv[3]), k = atoi(argv[4]);
+  unsigned seed = (unsigned) atoi(argv[5]);
+  const char *outp = argv[6];
+  pairing_t pairing;
+  char type;
+  pbc_random_set_deterministic(seed);
+  init_pairing(pairing, param, &type);
+  int l1 = pairing_length_in_bytes_G1(pairing);
+  int l2 = pairing_length_in_bytes_G2(pairing);
+  int lt = pairing_length_in_bytes_GT(pairing);
+  size_t tot = (size_t) n * k;
+  unsigned char *b1 = calloc(tot, l1), *b2 = calloc(tot, l2), *bo = calloc(n, lt);
+  element_t *P = malloc(sizeof(element_t) * k), *Q = malloc(sizeof(element_t) * k);
+  element_t P0, Q0, out;
+  element_init_G1(P0, pairing); element_init_G2(Q0, pairing); element_init_GT(out, pairing);
+  for (int j = 0; j < k; j++) { element_init_G1(P[j], pairing); element_init_G2(Q[j], pairing); }
+  int chain = !strcmp(mode, "chain"), edge = !strcmp(mode, "edge");
+  element_t Pc, Qc;
+  element_init_G1(Pc, pairing); element_init_G2(Qc, pairing);
+  if (chain) {
+    element_from_hash(P0, "pbc-mi355x/P0", 13);
+    element_from_hash(Q0, "pbc-mi355x/Q0", 13);
+    element_set(Pc, P0); element_set(Qc, Q0);
+  }
+  for (int u = 0; u < n; u++) {
+    for (int j = 0; j < k; j++) {
+      size_t idx = (size_t) u * k + j;
+      if (chain) {
+        element_set(P[j], Pc); element_set(Q[j], Qc);
+        element_add(Pc, Pc, P0); element_add(Qc, Qc, Q0);
+      } else {
+        element_random(P[j]); element_random(Q[j]);
+      }
+      element_to_bytes(b1 + idx * l1, P[j]);
+      element_to_bytes(b2 + idx * l2, Q[j]);
+      if (edge && (u % 5 == 1) && j == (u / 5) % k) {
+        /* an off-curve encoding: deserialises to O (ecc/curve.c:618-621) */
+        unsigned char *t = (u % 2) ? b1 + idx * l1 : b2 + idx * l2;
+        int L = (u % 2) ? l1 : l2;
+        t[L - 1] ^= 1;
+        if (u % 2) element_from_bytes(P[j], t); else element_from_bytes(Q[j], t);
+      }
+    }
+    if (k == 1) element_pairing(out, P[0], Q[0]);
+    else element_prod_pairing(out, P, Q, k);
+    element_to_bytes(bo + (size_t) u * lt, out);
+  }
+  FILE *fp = fopen(outp, "wb");
+  if (!fp) { perror(outp); return 2; }
+  fwrite("PBCVEC01", 1, 8, fp);
+  w32(fp, (uint32_t) type); w32(fp, n); w32(fp, k); w32(fp, l1); w32(fp, l2); w32(fp, lt);
+  fwrite(b1, l1, tot, fp); fwrite(b2, l2, tot, fp); fwrite(bo, lt, n, fp);
+  fclose(fp);
+  fprintf(stderr, "wrote %s: type %c n=%d k=%d len=%d/%d/%d\n", outp, type, n, k, l1, l2, lt);
+  return 0;
+}
+
+/* pbc/pairing_test.pbc:3-10, restated through the C API */
+static int cmd_kat(int argc, char **argv) {
+  if (argc < 2) return 2;
+  pairing_t pairing; char type;
+  init_pairing(pairing, argv[1], &type);
+  element_t g, h, e, want;
+  element_init_G1(g, pairing); element_init_G2(h, pairing);
+  element_init_GT(e, pairing); element_init_GT(want, pairing);
+  element_set_str(g, "[2382389466570123849673299401984867521337122094157231907755149435707124249269394670242462497382963719723036281844079382411446883273020125104982896098602669, 2152768906589770702756591740710760107878949212304343787392475836859241438597588807103470081101790991563152395601123682809718038151417122294066319979967168]", 10);
+  element_set_str(h, "[5832612417453786541700129157230442590988122495898645678468800815872828277169950107203266157735206975228912899931278160262081308603240860553459187732968543, 5825590786822892934138376868455818413990615826926356662470129700411774690868351658310187202553513693344017463065909279569624651155563430675084173630054336]", 10);
+  element_set_str(want, "[1352478452661998164151215014828915385601138645645403926287105573769451214277485326392786454433874957123922454604362337349978217917242114505658729401276644, 2809858014072341042857607405424304552357466023841122154308055820747972163307396014445308786731013691659356362568425895483877936945589613445697089590886519]", 10);
+  element_pairing(e, g, h);
+  int ok = !element_cmp(e, want);
+  printf("KAT %s\n", ok ? "PASS" : "FAIL");
+  if (argc >= 3) { /* dump g,h,e bytes as a 1-unit vector file */
+    FILE *fp = fopen(argv[2], "wb");
+    int l1 = pairing_length_in_bytes_G1(pairing), l2 = pairing_length_in_bytes_G2(pairing), lt = pairing_length_in_bytes_GT(pairing);
+    unsigned char buf[1024];
+    fwrite("PBCVEC01", 1, 8, fp);
+    w32(fp, type); w32(fp, 1); w32(fp, 1); w32(fp, l1); w32(fp, l2); w32(fp, lt);
+    element_to_bytes(buf, g); fwrite(buf, 1, l1, fp);
+    element_to_bytes(buf, h); fwrite(buf, 1, l2, fp);
+    element_to_bytes(buf, want); fwrite(buf, 1, lt, fp);
+    fclose(fp);
+  }
+  return ok ? 0 : 1;
+}
+
+/* bench <param> <n_per_worker> <k> <workers>  -> prints JSON */
+static int cmd_bench(int argc, char **argv) {
+  if (argc < 5) { fprintf(stderr, "bench <param> <n> <k> <workers>\n"); return 2; }
+  int n = atoi(argv[2]), k = atoi(argv[3]), workers = atoi(argv[4]);
+  int fds[256][2];
+  if (workers > 256) workers = 256;
+  double t_all0 = now();
+  for (int w = 0; w < workers; w++) {
+    if (pipe(fds[w])) return 2;
+    pid_t pid = fork();
+    if (pid == 0) {
+      close(fds[w][0]);
+      pairing_t pairing; char type;
+      init_pairing(pairing, argv[1], &type);
+      element_t *P = malloc(sizeof(element_t) * k), *Q = malloc(sizeof(element_t) * k);
+      element_t P0, Q0, out;
+      element_init_G1(P0, pairing); element_init_G2(Q0, pairing); element_init_GT(out, pairing);
+      element_from_hash(P0, "pbc-mi355x/P0", 13);
+      element_from_hash(Q0, "pbc-mi355x/Q0", 13);
+      for (int j = 0; j < k; j++) {
+        element_init_G1(P[j], pairing); element_init_G2(Q[j], pairing);
+        element_mul_si(P[j], P0, j + 1 + w); element_mul_si(Q[j], Q0, j + 1 + w);
+      }
+      double t0 = now();
+      for (int i = 0; i < n; i++) {
+        if (k == 1) element_pairing(out, P[0], Q[0]);
+        else element_prod_pairing(out, P, Q, k);
+        /* step inputs like benchmark/benchmark.c does (fresh inputs every iteration) */
+        element_add(P[i % k], P[i % k], P0);
+        element_add(Q[i % k], Q[i % k], Q0);
+      }
+      double dt = now() - t0;
+      if (write(fds[w][1], &dt, sizeof dt) != sizeof dt) _exit(3);
+      _exit(0);
+    }
+    close(fds[w][1]);
+  }
+  double sum_rate = 0, max_dt = 0;
+  for (int w = 0; w < workers; w++) {
+    double dt = 0;
+    if (read(fds[w][0], &dt, sizeof dt) != sizeof dt) { fprintf(stderr, "worker %d failed\n", w); return 3; }
+    sum_rate += n / dt;
+    if (dt > max_dt) max_dt = dt;
+  }
+  while (wait(NULL) > 0) {}
+  double wall = now() - t_all0;
+  printf("{\"units_per_s\": %.3f, \"per_core\": %.3f, \"workers\": %d, \"n_per_worker\": %d, \"k\": %d, \"max_worker_s\": %.4f, \"wall_s\": %.4f}\n",
+         sum_rate, sum_rate / workers, workers, n, k, max_dt, wall);
+  return 0;
+}
+
+int main(int argc, char **argv) {
+  if (argc < 2) { fprintf(stderr, "usage: ref_tool gen|kat|bench ...\n"); return 2; }
+  if (!strcmp(argv[1], "gen")) return cmd_gen(argc - 1, argv + 1);
+  if (!strcmp(argv[1], "kat")) return cmd_kat(argc - 1, argv + 1);
+  if (!strcmp(argv[1], "bench")) return cmd_bench(argc - 1, argv + 1);
+  return 2;
+}

@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""bench.py -- pairings/sec on a 2^20-pair Type-A (a.param) batch per MI355X.
+
+Contract (see the task statement): `python bench.py --gpus N --steps K --warmup W`; for N>1 it
+is launched under torch.distributed.run, one rank per GPU.  One "step" = one pass of the
+hot path (one batched element_pairing launch) over one 2^20-pair batch that is already
+resident in HBM.  Weak scaling: every rank owns its own 2^20-pair shard (range split, no
+data-path collective; torch.distributed is used only for the barrier and the max-over-ranks
+clock).  Rank 0 prints ONE JSON line.
+
+Inputs: synthetic but valid group elements -- all (P_i, Q_j), i,j < 1024, from the
+committed fixture tests/golden/a_chain1024.vec (P_i=(i+1)P0, Q_j=(j+1)Q0);
+2^20 distinct pairs.  Before timing, the diagonal of one result batch is compared with the
+reference's own outputs stored in the fixture (bit-exact) -- a wrong kernel cannot post a
+number.
+"""
+import argparse
+import json
+import os
+import struct
+import subprocess
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import pbc_amd  # noqa: E402  (the product; raises if libpbc_hip.so is missing)
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def load_vec(path):
+    raw = open(path, "rb").read()
+    assert raw[:8] == b"PBCVEC01"
+    t, n, k, l1, l2, lt = struct.unpack("<6I", raw[8:32])
+    a = np.frombuffer(raw, np.uint8)
+    off = 32
+    g1 = a[off:off + n * k * l1].reshape(n * k, l1); off += n * k * l1
+    g2 = a[off:off + n * k * l2].reshape(n * k, l2); off += n * k * l2
+    gt = a[off:off + n * lt].reshape(n, lt)
+    return g1.copy(), g2.copy(), gt.copy()
+
+
+def cpu_baseline(param_path):
+    """PBC+GMP (the unmodified reference compiled into oracle/_ref) on the host cores, on a
+    bounded sample of the same workload; falls back to the single-core C port."""
+    import oracle  # checker/baseline only -- never on the measured GPU path
+    cores = os.cpu_count() or 1
+    tool = oracle.REF_TOOL
+    per_worker = 4096
+    if os.path.exists(tool):
+        try:
+            out = subprocess.run([tool, "bench", param_path, str(per_worker), "1", str(cores)],
+                                 capture_output=True, text=True, timeout=300)
+            j = json.loads(out.stdout.strip().splitlines()[-1])
+            return {"value": round(j["units_per_s"], 1), "unit": "pairings/s", "cores": cores,
+                    "kind": "reference",
+                    "sample": "%d element_pairing calls per worker x %d forked workers (a.param), %.1f s wall"
+                              % (per_worker, cores, j["wall_s"]),
+                    "per_core": round(j["per_core"], 1)}
+        except Exception as e:  # noqa: BLE001
+            sys.stderr.write("cpu_baseline: ref_tool failed (%r), using the C port\n" % (e,))
+    O = oracle.OraclePairing(open(param_path).read())
+    g1, g2, _ = load_vec(os.path.join(ROOT, "tests", "golden", "a_chain1024.vec"))
+    t0 = time.time()
+    O.pairing_batch(g1, g2)
+    dt = time.time() - t0
+    return {"value": round(1024 / dt, 1), "unit": "pairings/s", "cores": 1, "kind": "port",
+            "sample": "1024 pairings, single thread, oracle/pbc_oracle.c"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--log2n", type=int, default=20, help="pairs per GPU per step (default 2^20)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run" % args.gpus)
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    param_path = os.path.join(ROOT, "pbc_amd", "param", "a.param")
+    pairing = pbc_amd.Pairing(open(param_path).read())
+    n = 1 << args.log2n
+    g1, g2, gt_ref = load_vec(os.path.join(ROOT, "tests", "golden", "a_chain1024.vec"))
+    D = 1024
+    side_i = min(D, n)                    # n = side_i * side_j distinct (P_i, Q_j) pairs
+    side_j = max(1, n // side_i)
+    assert side_i * side_j == n and side_j <= D
+    # rank r uses a rotated set of Q's so that shards differ
+    rot = (rank * 131) % D
+    d1 = torch.from_numpy(g1[:side_i]).cuda()
+    d2 = torch.from_numpy(np.roll(g2, -rot, axis=0)[:side_j]).cuda()
+    G1 = d1[:, None, :].expand(side_i, side_j, 128).reshape(n, 128).contiguous()
+    G2 = d2[None, :, :].expand(side_i, side_j, 128).reshape(n, 128).contiguous()
+    GT = torch.empty(n, 128, dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.current_stream()
+
+    def step():
+        pairing.element_pairing_dev(GT.data_ptr(), G1.data_ptr(), G2.data_ptr(), n, stream.cuda_stream)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    # correctness gate: with rot == 0 unit (i, i) is e(P_i, Q_i), stored by the reference
+    if args.warmup == 0:
+        step()
+        torch.cuda.synchronize()
+    if rot == 0:
+        m = min(side_i, side_j)
+        idx = torch.arange(m, device="cuda") * (side_j + 1)
+        got = GT[idx].cpu().numpy()
+        if not np.array_equal(got, gt_ref[:m]):
+            sys.exit("bench.py: GPU results differ from the reference fixture -- refusing to time")
+
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    sync_all()
+    t0 = time.perf_counter()
+    for a, b in evs:
+        a.record(stream)
+        step()
+        b.record(stream)
+    sync_all()
+    dt = time.perf_counter() - t0
+    kern_ms = [a.elapsed_time(b) for a, b in evs]
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        total_units = n * world * args.steps
+        value = total_units / dt
+        avg_kern_s = sum(kern_ms) / len(kern_ms) * 1e-3
+        macs_per_unit = pairing.algorithmic_macs_per_unit(1)
+        # measured integer multiply-add peak of this chip (register-only v_mad_u64_u32 probe)
+        peak_macs, _ = pbc_amd.int_mac_peak(0, 4000)
+        achieved_macs = n * macs_per_unit / avg_kern_s
+        alg_bytes = n * (128 + 128 + 128)
+        out = {
+            "metric": "pairings/sec on 2^20-batch Type-A (a.param)",
+            "value": round(value, 1),
+            "unit": "pairings/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32 limbs (512-bit Montgomery Fq, bit-exact integer)",
+            "data": "synthetic: 2^20 distinct (P_i,Q_j) pairs from tests/golden/a_chain1024.vec, resident in HBM",
+            "config": {"workload": "Type A (a.param) element_pairing, 2^%d pairs per GPU per step" % args.log2n,
+                       "pairs_per_gpu": n, "global_batch": n * world, "parallelism": "range-split x%d, no collectives" % world},
+            "roofline": {
+                "bound": "valu-int32-mac",   # integer VALU throughput bounds this path, not HBM/MFMA
+                "achieved": round(achieved_macs / 1e12, 4),
+                "peak": round(peak_macs / 1e12, 4),
+                "unit": "TMAC/s (32x32->64 bit)",
+                "frac": round(achieved_macs / peak_macs, 4),
+                "traffic": None,
+                "kernel": "a_pairing_kernel<16>",
+                "kernel_ms": round(avg_kern_s * 1e3, 3),
+                "algorithmic_macs_per_pairing": macs_per_unit,
+                "hbm": {"achieved": round(alg_bytes / avg_kern_s / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(alg_bytes / avg_kern_s / 1e9 / HBM_PEAK_GBS, 6),
+                        "algorithmic_bytes_per_pairing": 384},
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(param_path)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,89 @@
+/*
+ * pbc_hip.h -- C-ABI of libpbc_hip.so: the MI355X (gfx950) batched bilinear-pairing engine.
+ *
+ * This is the drop-in boundary for PBC's pairing hot path.  Every entry point takes plain
+ * pointers and sizes; group elements cross the boundary in PBC's own element_to_bytes /
+ * element_from_bytes wire format:
+ *     F_q      fixed-width big-endian canonical residue      (arith/montfp.c:487-517)
+ *     F_q^2    re || im                                       (arith/fieldquadratic.c:323-337)
+ *     polymod  c0 || ... || c(n-1)                            (arith/poly.c:718-752)
+ *     point    x || y, off-curve bytes deserialise to O       (ecc/curve.c:603-623)
+ *     GT       the underlying extension-field element          (ecc/pairing.c:175-185)
+ * so a PBC maintainer binds it with element_to_bytes/element_from_bytes only
+ * (see INTEGRATION.md for the stub that installs these behind pairing->map /
+ * pairing->prod_pairings).
+ *
+ * All functions return 0 on success, non-zero on failure (pairing_init_set_buf
+ * convention, ecc/pairing.c:88-98); pbc_hip_last_error() gives the message.  A
+ * pbc_hip_pairing_t is not re-entrant: one batch call at a time per object.
+ */
+#ifndef PBC_HIP_H
+#define PBC_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pbc_hip_pairing_s pbc_hip_pairing_t;
+
+/* Replaces pairing_init_set_buf / pairing_init_set_str (include/pbc_pairing.h:95-102,
+ * ecc/pairing.c:88-106): parse a PBC parameter text ("type a" / "type d" / "type f" ...),
+ * derive the per-curve constants (a_init_pairing ecc/a_param.c:1431-1472) and bind the
+ * object to the calling thread's current HIP device.  len == 0 means strlen(param). */
+int pbc_hip_pairing_init_set_buf(pbc_hip_pairing_t **out, const char *param, size_t len);
+/* Replaces pairing_clear (include/pbc_pairing.h:109-116). */
+void pbc_hip_pairing_clear(pbc_hip_pairing_t *p);
+
+/* 'a', 'd' or 'f' (the "type" key, ecc/param.c:172-205). */
+int pbc_hip_pairing_type(const pbc_hip_pairing_t *p);
+/* Replace pairing_length_in_bytes_{G1,G2,GT} (include/pbc_pairing.h:183-238). */
+int pbc_hip_pairing_length_in_bytes_G1(const pbc_hip_pairing_t *p);
+int pbc_hip_pairing_length_in_bytes_G2(const pbc_hip_pairing_t *p);
+int pbc_hip_pairing_length_in_bytes_GT(const pbc_hip_pairing_t *p);
+
+/* Batched element_pairing (include/pbc_pairing.h:141-145 -> pairing_apply :118-135 ->
+ * pairing->map = a_pairing_proj, ecc/a_param.c:1053-1198):
+ *     gt[i] = to_bytes( e( from_bytes_G1(g1[i]), from_bytes_G2(g2[i]) ) ),  i < n
+ * including the identity short-circuit (an input that deserialises to O gives GT's 1).
+ * Host buffers, AoS: g1 is n*len_G1 bytes, g2 n*len_G2, gt n*len_GT. */
+int pbc_hip_element_pairing_batch(pbc_hip_pairing_t *p, uint8_t *gt, const uint8_t *g1,
+                                  const uint8_t *g2, size_t n);
+/* Same with device-resident buffers, enqueued on `stream` (a hipStream_t; NULL = default
+ * stream).  Asynchronous: returns after the launch. */
+int pbc_hip_element_pairing_batch_dev(pbc_hip_pairing_t *p, void *d_gt, const void *d_g1,
+                                      const void *d_g2, size_t n, void *stream);
+
+/* Batched element_prod_pairing (include/pbc_pairing.h:153-171 -> pairing->prod_pairings =
+ * a_pairings_affine, ecc/a_param.c:1283-1383): n products of k terms each,
+ *     gt[u] = to_bytes( prod_{j<k} e(g1[u*k+j], g2[u*k+j]) ),
+ * with the reference's rule that ANY identity input makes the whole product 1 (:161-168). */
+int pbc_hip_element_prod_pairing_batch(pbc_hip_pairing_t *p, uint8_t *gt, const uint8_t *g1,
+                                       const uint8_t *g2, size_t n, int k);
+int pbc_hip_element_prod_pairing_batch_dev(pbc_hip_pairing_t *p, void *d_gt, const void *d_g1,
+                                           const void *d_g2, size_t n, int k, void *stream);
+
+/* Batched base-field operations on canonical bytes: the arith/montfp.c semantics the
+ * kernels are built on (mont_mul :334-377, fp_add/sub/double/halve/neg :220-330,
+ * fp_invert :401-422), exposed so they can be checked differentially the way
+ * guru/checkfp.c does.  op: 0 mul, 1 add, 2 sub, 3 invert, 4 neg, 5 halve, 6 double.
+ * Host buffers of n*len_Fq bytes each (b may be NULL for unary ops). */
+int pbc_hip_fq_op_batch(pbc_hip_pairing_t *p, int op, uint8_t *c, const uint8_t *a,
+                        const uint8_t *b, size_t n);
+int pbc_hip_length_in_bytes_Fq(const pbc_hip_pairing_t *p);
+
+/* Register-only integer multiply-add micro-benchmark (the measured int-MAC roofline,
+ * SURVEY.md 8d): runs `iters` dependent-chain-free v_mad_u64_u32 per lane on the whole
+ * chip and returns MAC/s.  variant selects the instruction mix (see csrc/pbc_hip.hip). */
+int pbc_hip_int_mac_peak(int variant, int iters, double *mac_per_s, double *ms);
+
+/* Algorithmic work model used for the roofline: reference F_q multiplications
+ * per unit x (2N^2+N) 32-bit MACs. */
+double pbc_hip_algorithmic_macs_per_unit(const pbc_hip_pairing_t *p, int k);
+
+const char *pbc_hip_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

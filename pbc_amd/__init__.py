@@ -1,0 +1,178 @@
+"""pbc_amd -- MI355X-native batched bilinear pairings behind PBC's pairing API.
+
+The product is ``libpbc_hip.so`` (hand-written HIP for gfx950, C-ABI in
+``include/pbc_hip.h``).  This package is only the thin Python host mirror used by the
+tests and the benchmark: it loads the shared object with ctypes and exposes a ``Pairing``
+object shaped like the reference's ``pairing_t`` (``pairing_init_set_buf``,
+``pairing_length_in_bytes_*``, ``element_pairing`` / ``element_prod_pairing`` over
+batches of ``element_to_bytes`` records).
+
+There is no CPU fallback: if the HIP library is missing or no GPU is present, calls fail
+loudly.
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpbc_hip.so")
+PARAM_DIR = os.path.join(_HERE, "param")
+
+_lib = None
+
+
+class PbcHipError(RuntimeError):
+    pass
+
+
+def build(force=False):
+    """Compile libpbc_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    srcs = [os.path.join(_HERE, "csrc", f) for f in os.listdir(os.path.join(_HERE, "csrc"))]
+    srcs.append(os.path.join(_HERE, "..", "include", "pbc_hip.h"))
+    stale = (not os.path.exists(LIB_PATH)) or any(
+        os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-s", "-C", _HERE])
+    return LIB_PATH
+
+
+def lib():
+    """The loaded C-ABI library (raises if it has not been built: no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise PbcHipError("%s is missing: run `make -C pbc_amd` (or __graft_entry__.build())" % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        vp, cp, sz, ci = ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int
+        L.pbc_hip_pairing_init_set_buf.argtypes = [ctypes.POINTER(vp), cp, sz]
+        L.pbc_hip_pairing_clear.argtypes = [vp]
+        L.pbc_hip_pairing_clear.restype = None
+        for f in ("pbc_hip_pairing_type", "pbc_hip_pairing_length_in_bytes_G1",
+                  "pbc_hip_pairing_length_in_bytes_G2", "pbc_hip_pairing_length_in_bytes_GT",
+                  "pbc_hip_length_in_bytes_Fq"):
+            getattr(L, f).argtypes = [vp]
+        L.pbc_hip_element_pairing_batch.argtypes = [vp, vp, vp, vp, sz]
+        L.pbc_hip_element_pairing_batch_dev.argtypes = [vp, vp, vp, vp, sz, vp]
+        L.pbc_hip_element_prod_pairing_batch.argtypes = [vp, vp, vp, vp, sz, ci]
+        L.pbc_hip_element_prod_pairing_batch_dev.argtypes = [vp, vp, vp, vp, sz, ci, vp]
+        L.pbc_hip_fq_op_batch.argtypes = [vp, ci, vp, vp, vp, sz]
+        L.pbc_hip_int_mac_peak.argtypes = [ci, ci, ctypes.POINTER(ctypes.c_double),
+                                           ctypes.POINTER(ctypes.c_double)]
+        L.pbc_hip_algorithmic_macs_per_unit.argtypes = [vp, ci]
+        L.pbc_hip_algorithmic_macs_per_unit.restype = ctypes.c_double
+        L.pbc_hip_last_error.restype = cp
+        _lib = L
+    return _lib
+
+
+#: every symbol include/pbc_hip.h declares (checked by the CPU test-suite)
+EXPORTS = (
+    "pbc_hip_pairing_init_set_buf", "pbc_hip_pairing_clear", "pbc_hip_pairing_type",
+    "pbc_hip_pairing_length_in_bytes_G1", "pbc_hip_pairing_length_in_bytes_G2",
+    "pbc_hip_pairing_length_in_bytes_GT", "pbc_hip_element_pairing_batch",
+    "pbc_hip_element_pairing_batch_dev", "pbc_hip_element_prod_pairing_batch",
+    "pbc_hip_element_prod_pairing_batch_dev", "pbc_hip_fq_op_batch",
+    "pbc_hip_length_in_bytes_Fq", "pbc_hip_int_mac_peak",
+    "pbc_hip_algorithmic_macs_per_unit", "pbc_hip_last_error",
+)
+
+
+def _err():
+    m = lib().pbc_hip_last_error()
+    return m.decode() if m else "unknown error"
+
+
+def param_text(name):
+    """Stock parameter sets shipped with the reference (param/a.param, d159.param, f.param)."""
+    with open(os.path.join(PARAM_DIR, name + ".param")) as fh:
+        return fh.read()
+
+
+def _np_ptr(a):
+    return ctypes.c_void_p(a.ctypes.data) if a is not None else None
+
+
+class Pairing:
+    """Mirror of ``pairing_t``: built from a PBC parameter text, applied to batches.
+
+    Host-side calls take/return numpy uint8 arrays of ``element_to_bytes`` records;
+    ``*_dev`` calls take raw device pointers (e.g. ``torch.Tensor.data_ptr()``) and a
+    HIP stream handle and only enqueue work.
+    """
+
+    def __init__(self, param):
+        if isinstance(param, str):
+            param = param.encode()
+        self._h = ctypes.c_void_p()
+        if lib().pbc_hip_pairing_init_set_buf(ctypes.byref(self._h), param, len(param)):
+            self._h = None
+            raise PbcHipError("pairing_init_set_buf: " + _err())
+        L = lib()
+        self.type = chr(L.pbc_hip_pairing_type(self._h))
+        self.length_in_bytes_G1 = L.pbc_hip_pairing_length_in_bytes_G1(self._h)
+        self.length_in_bytes_G2 = L.pbc_hip_pairing_length_in_bytes_G2(self._h)
+        self.length_in_bytes_GT = L.pbc_hip_pairing_length_in_bytes_GT(self._h)
+        self.length_in_bytes_Fq = L.pbc_hip_length_in_bytes_Fq(self._h)
+
+    def clear(self):
+        if getattr(self, "_h", None):
+            lib().pbc_hip_pairing_clear(self._h)
+            self._h = None
+
+    __del__ = clear
+
+    # ---- element_pairing over a batch -------------------------------------------------
+    def element_pairing(self, g1, g2):
+        import numpy as np
+        g1 = np.ascontiguousarray(g1, dtype=np.uint8)
+        g2 = np.ascontiguousarray(g2, dtype=np.uint8)
+        n = g1.size // self.length_in_bytes_G1
+        if g1.size != n * self.length_in_bytes_G1 or g2.size != n * self.length_in_bytes_G2:
+            raise ValueError("g1/g2 sizes do not describe the same number of elements")
+        gt = np.empty((n, self.length_in_bytes_GT), np.uint8)
+        if lib().pbc_hip_element_pairing_batch(self._h, _np_ptr(gt), _np_ptr(g1), _np_ptr(g2), n):
+            raise PbcHipError("element_pairing: " + _err())
+        return gt
+
+    def element_pairing_dev(self, d_gt, d_g1, d_g2, n, stream=0):
+        if lib().pbc_hip_element_pairing_batch_dev(self._h, d_gt, d_g1, d_g2, n, stream):
+            raise PbcHipError("element_pairing_dev: " + _err())
+
+    # ---- element_prod_pairing over a batch of k-term products -------------------------
+    def element_prod_pairing(self, g1, g2, k):
+        import numpy as np
+        g1 = np.ascontiguousarray(g1, dtype=np.uint8)
+        g2 = np.ascontiguousarray(g2, dtype=np.uint8)
+        n = g1.size // (self.length_in_bytes_G1 * k)
+        if g1.size != n * k * self.length_in_bytes_G1 or g2.size != n * k * self.length_in_bytes_G2:
+            raise ValueError("g1/g2 sizes do not describe n*k elements")
+        gt = np.empty((n, self.length_in_bytes_GT), np.uint8)
+        if lib().pbc_hip_element_prod_pairing_batch(self._h, _np_ptr(gt), _np_ptr(g1), _np_ptr(g2), n, k):
+            raise PbcHipError("element_prod_pairing: " + _err())
+        return gt
+
+    def element_prod_pairing_dev(self, d_gt, d_g1, d_g2, n, k, stream=0):
+        if lib().pbc_hip_element_prod_pairing_batch_dev(self._h, d_gt, d_g1, d_g2, n, k, stream):
+            raise PbcHipError("element_prod_pairing_dev: " + _err())
+
+    # ---- diagnostics ------------------------------------------------------------------
+    def fq_op(self, op, a, b=None):
+        import numpy as np
+        a = np.ascontiguousarray(a, dtype=np.uint8)
+        b = np.ascontiguousarray(b, dtype=np.uint8) if b is not None else None
+        n = a.size // self.length_in_bytes_Fq
+        c = np.empty((n, self.length_in_bytes_Fq), np.uint8)
+        if lib().pbc_hip_fq_op_batch(self._h, op, _np_ptr(c), _np_ptr(a), _np_ptr(b), n):
+            raise PbcHipError("fq_op: " + _err())
+        return c
+
+    def algorithmic_macs_per_unit(self, k=1):
+        return lib().pbc_hip_algorithmic_macs_per_unit(self._h, k)
+
+
+def int_mac_peak(variant=0, iters=2000):
+    """Register-only instruction-throughput probe; returns (lane-ops per second, ms)."""
+    r, ms = ctypes.c_double(), ctypes.c_double()
+    if lib().pbc_hip_int_mac_peak(variant, iters, ctypes.byref(r), ctypes.byref(ms)):
+        raise PbcHipError("int_mac_peak: " + _err())
+    return r.value, ms.value

@@ -1,0 +1,243 @@
+// fp.cuh -- fixed-width, register-resident Montgomery arithmetic in F_q for gfx950.
+//
+// Replaces the reference's GMP-backed arith/montfp.c (mont_mul :334-364, fp_add/sub/
+// double/halve/neg :220-330, fp_invert :401-422, fp_to/from_bytes :487-517) with
+// N x 32-bit limbs held in VGPRs, one field element per lane.  The modulus and the
+// Montgomery constants are wave-uniform (__constant__ memory -> scalar loads -> SGPRs).
+//
+// Representation: little-endian limbs, Montgomery radix R = 2^(32 N), values always
+// fully reduced to [0, q).  The radix is private: all exchange with the host / the
+// reference is in canonical big-endian bytes (SURVEY.md "Key facts").
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pbc {
+
+template <int N>
+struct FpK {            // wave-uniform field constants (field_init_mont_fp, montfp.c:533-600)
+  uint32_t p[N];        // modulus q
+  uint32_t one[N];      // R mod q
+  uint32_t r2[N];       // R^2 mod q
+  uint32_t pm2[N];      // q - 2 (Fermat exponent)
+  uint32_t ninv;        // -q^-1 mod 2^32
+  uint32_t pbits;       // bit length of q
+};
+
+template <int N>
+struct fp {
+  uint32_t v[N];
+};
+
+#define PBC_DEV __device__ __forceinline__
+
+// The constants live in __constant__ memory so that every read is a scalar load from a
+// compile-time address (provably wave-uniform -> SGPR operands of the MACs).  One set per
+// limb count; the host uploads them with hipMemcpyToSymbolAsync on the launch stream.
+__constant__ FpK<16> c_fpk16;     // 512-bit moduli (Type A a.param)
+__constant__ FpK<5> c_fpk5;       // 160-bit moduli (Type D d159, Type F)
+template <int N> PBC_DEV const FpK<N> &fpk();
+template <> PBC_DEV const FpK<16> &fpk<16>() { return c_fpk16; }
+template <> PBC_DEV const FpK<5> &fpk<5>() { return c_fpk5; }
+
+// acc(96 bit: a0,a1,a2) += x*y.  One quarter-rate 32x32+64 multiply-add whose carry-out
+// feeds the top word: the two-instruction MAC the whole engine is built from.
+PBC_DEV void mac_vv(uint32_t &a0, uint32_t &a1, uint32_t &a2, uint32_t x, uint32_t y) {
+  uint64_t acc = ((uint64_t) a1 << 32) | a0;
+  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"
+      : "+v"(acc), "+v"(a2) : "v"(x), "v"(y) : "vcc");
+  a0 = (uint32_t) acc; a1 = (uint32_t) (acc >> 32);
+}
+// same, second factor wave-uniform (an SGPR: the modulus limbs)
+PBC_DEV void mac_vs(uint32_t &a0, uint32_t &a1, uint32_t &a2, uint32_t x, uint32_t y) {
+  uint64_t acc = ((uint64_t) a1 << 32) | a0;
+  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"
+      : "+v"(acc), "+v"(a2) : "v"(x), "s"(y) : "vcc");
+  a0 = (uint32_t) acc; a1 = (uint32_t) (acc >> 32);
+}
+// acc += 2*x*y is NOT used (no spare bits at 512/512); squaring doubles the cross sum instead.
+
+// r = (carry:t) >= p ? t - p : t      (final correction of add / mul)
+// __builtin_addc/__builtin_subc lower to v_addc_co_u32 / v_subb_co_u32 chains.
+template <int N>
+PBC_DEV void fp_cond_sub(fp<N> &r, const uint32_t *t, uint32_t carry) {
+  const FpK<N> &K = fpk<N>();
+  uint32_t d[N];
+  uint32_t bw = 0;
+#pragma unroll
+  for (int i = 0; i < N; i++) d[i] = __builtin_subc(t[i], K.p[i], bw, &bw);
+  bool ge = (carry != 0) | (bw == 0);
+#pragma unroll
+  for (int i = 0; i < N; i++) r.v[i] = ge ? d[i] : t[i];
+}
+
+// Montgomery product r = a*b/R mod q, product-scanning (column-wise) form with a 96-bit
+// column accumulator: 2N^2 MACs + N v_mul_lo_u32, no per-row carry ripple.
+// Same value as mont_mul (arith/montfp.c:334-364).  Accepts a < R unreduced if b < q.
+template <int N>
+PBC_DEV void fp_mul_inl(fp<N> &r, const fp<N> &a, const fp<N> &b) {
+  const FpK<N> &K = fpk<N>();
+  uint32_t m[N], t[N];
+  uint32_t a0 = 0, a1 = 0, a2 = 0;
+#pragma unroll
+  for (int c = 0; c < N; c++) {
+#pragma unroll
+    for (int i = 0; i <= c; i++) mac_vv(a0, a1, a2, a.v[i], b.v[c - i]);
+#pragma unroll
+    for (int i = 0; i < c; i++) mac_vs(a0, a1, a2, m[i], K.p[c - i]);
+    m[c] = a0 * K.ninv;
+    mac_vs(a0, a1, a2, m[c], K.p[0]);
+    a0 = a1; a1 = a2; a2 = 0;
+  }
+#pragma unroll
+  for (int c = N; c < 2 * N; c++) {
+#pragma unroll
+    for (int i = c - N + 1; i < N; i++) mac_vv(a0, a1, a2, a.v[i], b.v[c - i]);
+#pragma unroll
+    for (int i = c - N + 1; i < N; i++) mac_vs(a0, a1, a2, m[i], K.p[c - i]);
+    t[c - N] = a0;
+    a0 = a1; a1 = a2; a2 = 0;
+  }
+  fp_cond_sub<N>(r, t, a0);
+}
+
+// Out-of-line instances: one copy of the ~1100-instruction body per kernel keeps the Miller
+// loop inside the instruction cache.  Arguments/results travel in VGPRs.
+template <int N>
+__device__ __noinline__ fp<N> fp_mul_fn(fp<N> a, fp<N> b) {
+  fp<N> r;
+  fp_mul_inl<N>(r, a, b);
+  return r;
+}
+
+template <int N>
+PBC_DEV void fp_mul(fp<N> &r, const fp<N> &a, const fp<N> &b) {
+  r = fp_mul_fn<N>(a, b);
+}
+// The reference has no dedicated Fq squaring (generic_square = mul(a,a), arith/field.c:383).
+template <int N>
+PBC_DEV void fp_sqr(fp<N> &r, const fp<N> &a) {
+  r = fp_mul_fn<N>(a, a);
+}
+
+// fp_add (montfp.c:220-250)
+template <int N>
+PBC_DEV void fp_add(fp<N> &r, const fp<N> &a, const fp<N> &b) {
+  uint32_t t[N];
+  uint32_t c = 0;
+#pragma unroll
+  for (int i = 0; i < N; i++) t[i] = __builtin_addc(a.v[i], b.v[i], c, &c);
+  fp_cond_sub<N>(r, t, c);
+}
+// fp_double (montfp.c:252-270)
+template <int N>
+PBC_DEV void fp_dbl(fp<N> &r, const fp<N> &a) {
+  uint32_t t[N];
+#pragma unroll
+  for (int i = 0; i < N; i++) t[i] = i ? __builtin_amdgcn_alignbit(a.v[i], a.v[i - 1], 31) : a.v[0] << 1;
+  fp_cond_sub<N>(r, t, a.v[N - 1] >> 31);
+}
+// fp_sub (montfp.c:282-316)
+template <int N>
+PBC_DEV void fp_sub(fp<N> &r, const fp<N> &a, const fp<N> &b) {
+  const FpK<N> &K = fpk<N>();
+  uint32_t d[N];
+  uint32_t bw = 0;
+#pragma unroll
+  for (int i = 0; i < N; i++) d[i] = __builtin_subc(a.v[i], b.v[i], bw, &bw);
+  uint32_t mask = 0u - bw;      // add q back when the subtraction borrowed
+  uint32_t c = 0;
+#pragma unroll
+  for (int i = 0; i < N; i++) r.v[i] = __builtin_addc(d[i], K.p[i] & mask, c, &c);
+}
+template <int N>
+PBC_DEV bool fp_is0(const fp<N> &a) {
+  uint32_t x = 0;
+#pragma unroll
+  for (int i = 0; i < N; i++) x |= a.v[i];
+  return x == 0;
+}
+template <int N>
+PBC_DEV bool fp_eq(const fp<N> &a, const fp<N> &b) {
+  uint32_t x = 0;
+#pragma unroll
+  for (int i = 0; i < N; i++) x |= a.v[i] ^ b.v[i];
+  return x == 0;
+}
+// fp_neg (montfp.c:318-330): 0 stays 0
+template <int N>
+PBC_DEV void fp_neg(fp<N> &r, const fp<N> &a) {
+  const FpK<N> &K = fpk<N>();
+  uint32_t mask = fp_is0<N>(a) ? 0u : 0xffffffffu;
+  uint32_t bw = 0;
+#pragma unroll
+  for (int i = 0; i < N; i++) r.v[i] = __builtin_subc(K.p[i] & mask, a.v[i], bw, &bw);
+}
+// fp_halve (montfp.c:272-280): a/2 = (a + (a odd ? q : 0)) >> 1
+template <int N>
+PBC_DEV void fp_halve(fp<N> &r, const fp<N> &a) {
+  const FpK<N> &K = fpk<N>();
+  uint32_t mask = 0u - (a.v[0] & 1);
+  uint32_t t[N];
+  uint32_t c = 0;
+#pragma unroll
+  for (int i = 0; i < N; i++) t[i] = __builtin_addc(a.v[i], K.p[i] & mask, c, &c);
+#pragma unroll
+  for (int i = 0; i < N; i++) r.v[i] = __builtin_amdgcn_alignbit(i + 1 < N ? t[i + 1] : c, t[i], 1);
+}
+template <int N>
+PBC_DEV void fp_set(fp<N> &r, const uint32_t *w) {
+#pragma unroll
+  for (int i = 0; i < N; i++) r.v[i] = w[i];
+}
+template <int N>
+PBC_DEV void fp_cmov(fp<N> &r, const fp<N> &a, bool take) {
+#pragma unroll
+  for (int i = 0; i < N; i++) r.v[i] = take ? a.v[i] : r.v[i];
+}
+
+// a^-1 = a^(q-2): Fermat ladder, uniform control flow (the exponent is a curve constant).
+// fp_invert in the reference (montfp.c:401-422) uses mpz_invert; the inverse is unique,
+// so the residue is identical.  0 -> 0.
+template <int N>
+__device__ __noinline__ fp<N> fp_inv_fn(fp<N> a) {
+  const FpK<N> &K = fpk<N>();
+  fp<N> r;
+  fp_set<N>(r, K.one);
+  for (int i = (int) K.pbits - 1; i >= 0; i--) {
+    fp_sqr<N>(r, r);
+    if ((K.pm2[i >> 5] >> (i & 31)) & 1) fp_mul<N>(r, r, a);
+  }
+  return r;
+}
+template <int N>
+PBC_DEV void fp_inv(fp<N> &r, const fp<N> &a) {
+  r = fp_inv_fn<N>(a);
+}
+
+// Wire format: fixed-width big-endian canonical residue (fp_from_bytes montfp.c:498-517,
+// fp_to_bytes :487-496 + pbc_mpz_out_raw_n field.c:629-638).  nbytes == 4N for all
+// supported parameter sets (64 for a.param, 20 for d159/f).
+template <int N>
+PBC_DEV void fp_load_be(fp<N> &r, const uint8_t *src) {
+  const FpK<N> &K = fpk<N>();
+  fp<N> t;
+  const uint32_t *w = reinterpret_cast<const uint32_t *>(src);
+#pragma unroll
+  for (int i = 0; i < N; i++) t.v[N - 1 - i] = __builtin_bswap32(w[i]);
+  fp<N> r2;
+  fp_set<N>(r2, K.r2);
+  fp_mul<N>(r, t, r2);            // x -> x R mod q (reduces x >= q as well)
+}
+template <int N>
+PBC_DEV void fp_store_be(uint8_t *dst, const fp<N> &a) {
+  fp<N> one, t;
+#pragma unroll
+  for (int i = 0; i < N; i++) one.v[i] = (i == 0);
+  fp_mul<N>(t, a, one);           // a R^-1: canonical residue
+  uint32_t *w = reinterpret_cast<uint32_t *>(dst);
+#pragma unroll
+  for (int i = 0; i < N; i++) w[i] = __builtin_bswap32(t.v[N - 1 - i]);
+}
+
+}  // namespace pbc

@@ -1,0 +1,109 @@
+// hostbn.h -- tiny host-side multi-precision helpers used once per pairing_init to derive
+// the per-curve constants the kernels keep in __constant__ memory (R mod q, R^2 mod q,
+// -q^-1 mod 2^32, q-2, cofactor words).  The reference derives the same constants with GMP
+// in field_init_mont_fp (arith/montfp.c:533-600); the product has no GMP dependency.
+// Also: parser for PBC's "key value" .param text (ecc/param.c:100-170).
+#pragma once
+#include <stdint.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+namespace pbc_host {
+
+struct Big {                              // little-endian 32-bit words, normalised (no high zeros)
+  std::vector<uint32_t> w;
+
+  void trim() { while (!w.empty() && w.back() == 0) w.pop_back(); }
+  bool is_zero() const { return w.empty(); }
+  int bits() const {
+    if (w.empty()) return 0;
+    uint32_t t = w.back();
+    int b = 0;
+    while (t) { b++; t >>= 1; }
+    return (int) (w.size() - 1) * 32 + b;
+  }
+  int bit(int i) const { return (size_t) (i >> 5) < w.size() ? (w[i >> 5] >> (i & 31)) & 1 : 0; }
+  static bool from_dec(Big &r, const std::string &s) {
+    r.w.clear();
+    if (s.empty()) return false;
+    for (char ch : s) {
+      if (ch < '0' || ch > '9') return false;
+      uint64_t c = (uint64_t) (ch - '0');
+      for (auto &x : r.w) { c += (uint64_t) x * 10; x = (uint32_t) c; c >>= 32; }
+      if (c) r.w.push_back((uint32_t) c);
+    }
+    r.trim();
+    return true;
+  }
+  static int cmp(const Big &a, const Big &b) {
+    if (a.w.size() != b.w.size()) return a.w.size() < b.w.size() ? -1 : 1;
+    for (size_t i = a.w.size(); i-- > 0;)
+      if (a.w[i] != b.w[i]) return a.w[i] < b.w[i] ? -1 : 1;
+    return 0;
+  }
+  void sub(const Big &b) {                 // this -= b, requires this >= b
+    uint64_t bw = 0;
+    for (size_t i = 0; i < w.size(); i++) {
+      uint64_t d = (uint64_t) w[i] - (i < b.w.size() ? b.w[i] : 0) - bw;
+      w[i] = (uint32_t) d;
+      bw = (d >> 63) & 1;
+    }
+    trim();
+  }
+  void shl1() {
+    uint32_t c = 0;
+    for (auto &x : w) { uint32_t n = x >> 31; x = (x << 1) | c; c = n; }
+    if (c) w.push_back(c);
+  }
+  void sub_small(uint32_t v) { Big b; if (v) b.w.push_back(v); sub(b); }
+  // 2^k mod m by k modular doublings of 1
+  static Big pow2_mod(int k, const Big &m) {
+    Big r; r.w.push_back(1);
+    for (int i = 0; i < k; i++) { r.shl1(); if (cmp(r, m) >= 0) r.sub(m); }
+    return r;
+  }
+  void to_words(uint32_t *out, int n) const {
+    for (int i = 0; i < n; i++) out[i] = (size_t) i < w.size() ? w[i] : 0;
+  }
+};
+
+inline uint32_t neg_inv32(uint32_t p0) {   // -p^-1 mod 2^32 (Newton)
+  uint32_t x = 1;
+  for (int i = 0; i < 6; i++) x *= 2u - p0 * x;
+  return 0u - x;
+}
+
+// "key value" lines; returns false if the key is absent
+inline bool param_lookup(const char *txt, size_t len, const char *key, std::string &val) {
+  size_t klen = strlen(key), i = 0;
+  while (i < len) {
+    size_t ls = i;
+    while (i < len && txt[i] != '\n') i++;
+    size_t le = i;
+    if (i < len) i++;
+    while (ls < le && (txt[ls] == ' ' || txt[ls] == '\t')) ls++;
+    if (le - ls > klen && !memcmp(txt + ls, key, klen) && (txt[ls + klen] == ' ' || txt[ls + klen] == '\t')) {
+      size_t vs = ls + klen;
+      while (vs < le && (txt[vs] == ' ' || txt[vs] == '\t')) vs++;
+      size_t ve = le;
+      while (ve > vs && (txt[ve - 1] == ' ' || txt[ve - 1] == '\r' || txt[ve - 1] == '\t')) ve--;
+      val.assign(txt + vs, ve - vs);
+      return true;
+    }
+  }
+  return false;
+}
+inline bool param_big(const char *txt, size_t len, const char *key, Big &out) {
+  std::string v;
+  return param_lookup(txt, len, key, v) && Big::from_dec(out, v);
+}
+inline bool param_int(const char *txt, size_t len, const char *key, int &out) {
+  std::string v;
+  if (!param_lookup(txt, len, key, v)) return false;
+  out = atoi(v.c_str());
+  return true;
+}
+
+}  // namespace pbc_host

@@ -1,0 +1,472 @@
+// pbc_hip.hip -- kernels + C-ABI of libpbc_hip.so (see include/pbc_hip.h).
+//
+// gfx950 only.  Host side: parameter parsing and constant derivation (hostbn.h), device
+// buffer management, launches.  Device side: one pairing per lane (pairing_a.cuh).
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+
+#include "../../include/pbc_hip.h"
+#include "fp.cuh"
+#include "hostbn.h"
+#include "pairing_a.cuh"
+
+using namespace pbc;
+
+// ---------------------------------------------------------------------------------------
+// error plumbing (pbc_error-style: message to stderr is left to the caller)
+// ---------------------------------------------------------------------------------------
+static thread_local char g_err[512];
+static int fail(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+  return 1;
+}
+#define HIP_TRY(x)                                                                   \
+  do {                                                                               \
+    hipError_t e_ = (x);                                                             \
+    if (e_ != hipSuccess) return fail("%s: %s", #x, hipGetErrorString(e_));          \
+  } while (0)
+extern "C" const char *pbc_hip_last_error(void) { return g_err; }
+
+// ---------------------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------------------
+constexpr int kBlock = 128;
+
+// One Type-A pairing per lane.  g1/g2/gt are AoS in wire format (128 B each for a.param);
+// per-lane 16-byte loads of a 128-byte record: every byte of every fetched line is used.
+template <int N>
+__global__ void __launch_bounds__(kBlock) a_pairing_kernel(uint8_t *gt, const uint8_t *g1,
+                                                            const uint8_t *g2, size_t n) {
+  size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
+  size_t ld = idx < n ? idx : n - 1;          // tail lanes recompute the last unit, no store
+  constexpr int L = 8 * N;
+  __attribute__((aligned(16))) uint8_t out[L];
+  __shared__ uint32_t lds_q[2 * N * kBlock];   // Q of every lane, limb-major: conflict-free
+  a_pairing_lane<N>(out, g1 + ld * L, g2 + ld * L, lds_q + threadIdx.x, kBlock);
+  if (idx < n) {
+    uint4 *dst = reinterpret_cast<uint4 *>(gt + idx * L);
+    const uint4 *src = reinterpret_cast<const uint4 *>(out);
+#pragma unroll
+    for (int i = 0; i < L / 16; i++) dst[i] = src[i];
+  }
+}
+
+// Batched F_q operations on wire bytes (differential check of the limb arithmetic).
+template <int N>
+__global__ void __launch_bounds__(kBlock) fq_op_kernel(int op, uint8_t *c, const uint8_t *a,
+                                                        const uint8_t *b, size_t n) {
+  size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
+  if (idx >= n) return;
+  constexpr int L = 4 * N;
+  fp<N> x, y, z;
+  fp_load_be<N>(x, a + idx * L);
+  if (b) fp_load_be<N>(y, b + idx * L); else y = x;
+  switch (op) {
+    case 0: fp_mul<N>(z, x, y); break;
+    case 1: fp_add<N>(z, x, y); break;
+    case 2: fp_sub<N>(z, x, y); break;
+    case 3: fp_inv<N>(z, x); break;
+    case 4: fp_neg<N>(z, x); break;
+    case 5: fp_halve<N>(z, x); break;
+    default: fp_dbl<N>(z, x); break;
+  }
+  fp_store_be<N>(c + idx * L, z);
+}
+
+// ---- register-only instruction-throughput probes (the measured integer roofline) --------
+#define REP8(x) x x x x x x x x
+template <int V>
+__global__ void __launch_bounds__(256) probe_kernel(uint32_t *sink, int iters, uint32_t seed) {
+  uint32_t t = threadIdx.x + seed;
+  uint64_t a0 = t, a1 = t + 1, a2 = t + 2, a3 = t + 3, a4 = t + 4, a5 = t + 5, a6 = t + 6, a7 = t + 7;
+  uint32_t x = t * 2654435761u + 12345u, y = t ^ 0x9e3779b9u, c0 = 0, c1 = 0;
+  double d0 = t, d1 = t + 1.5, d2 = t + 2.5, d3 = t + 3.5, dx = 1.0000001, dy = 0.9999999;
+  for (int i = 0; i < iters; i++) {
+    if constexpr (V == 0) {            // 8 independent v_mad_u64_u32 chains
+      REP8(asm volatile("v_mad_u64_u32 %0, vcc, %8, %9, %0\n\tv_mad_u64_u32 %1, vcc, %8, %9, %1\n\t"
+                        "v_mad_u64_u32 %2, vcc, %8, %9, %2\n\tv_mad_u64_u32 %3, vcc, %8, %9, %3\n\t"
+                        "v_mad_u64_u32 %4, vcc, %8, %9, %4\n\tv_mad_u64_u32 %5, vcc, %8, %9, %5\n\t"
+                        "v_mad_u64_u32 %6, vcc, %8, %9, %6\n\tv_mad_u64_u32 %7, vcc, %8, %9, %7"
+                        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
+                        : "v"(x), "v"(y) : "vcc");)
+    } else if constexpr (V == 1) {     // the engine's MAC: mad + addc, one dependent chain
+      REP8(asm volatile("v_mad_u64_u32 %0, vcc, %3, %4, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+                        "v_mad_u64_u32 %0, vcc, %3, %4, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+                        "v_mad_u64_u32 %0, vcc, %3, %4, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+                        "v_mad_u64_u32 %0, vcc, %3, %4, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+                        "v_mad_u64_u32 %0, vcc, %3, %4, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+                        "v_mad_u64_u32 %0, vcc, %3, %4, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+                        "v_mad_u64_u32 %0, vcc, %3, %4, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+                        "v_mad_u64_u32 %0, vcc, %3, %4, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"
+                        : "+v"(a0), "+v"(c0), "+v"(c1) : "v"(x), "v"(y) : "vcc");)
+    } else if constexpr (V == 2) {     // v_mul_lo_u32
+      REP8(asm volatile("v_mul_lo_u32 %0, %0, %8\n\tv_mul_lo_u32 %1, %1, %8\n\tv_mul_lo_u32 %2, %2, %8\n\t"
+                        "v_mul_lo_u32 %3, %3, %8\n\tv_mul_lo_u32 %4, %4, %8\n\tv_mul_lo_u32 %5, %5, %8\n\t"
+                        "v_mul_lo_u32 %6, %6, %8\n\tv_mul_lo_u32 %7, %7, %8"
+                        : "+v"(*(uint32_t *) &a0), "+v"(*(uint32_t *) &a1), "+v"(*(uint32_t *) &a2),
+                          "+v"(*(uint32_t *) &a3), "+v"(*(uint32_t *) &a4), "+v"(*(uint32_t *) &a5),
+                          "+v"(*(uint32_t *) &a6), "+v"(*(uint32_t *) &a7) : "v"(x));)
+    } else if constexpr (V == 3) {     // v_mul_hi_u32
+      REP8(asm volatile("v_mul_hi_u32 %0, %0, %8\n\tv_mul_hi_u32 %1, %1, %8\n\tv_mul_hi_u32 %2, %2, %8\n\t"
+                        "v_mul_hi_u32 %3, %3, %8\n\tv_mul_hi_u32 %4, %4, %8\n\tv_mul_hi_u32 %5, %5, %8\n\t"
+                        "v_mul_hi_u32 %6, %6, %8\n\tv_mul_hi_u32 %7, %7, %8"
+                        : "+v"(*(uint32_t *) &a0), "+v"(*(uint32_t *) &a1), "+v"(*(uint32_t *) &a2),
+                          "+v"(*(uint32_t *) &a3), "+v"(*(uint32_t *) &a4), "+v"(*(uint32_t *) &a5),
+                          "+v"(*(uint32_t *) &a6), "+v"(*(uint32_t *) &a7) : "v"(x));)
+    } else if constexpr (V == 4) {     // v_dot2_u32_u16
+      REP8(asm volatile("v_dot2_u32_u16 %0, %8, %9, %0\n\tv_dot2_u32_u16 %1, %8, %9, %1\n\t"
+                        "v_dot2_u32_u16 %2, %8, %9, %2\n\tv_dot2_u32_u16 %3, %8, %9, %3\n\t"
+                        "v_dot2_u32_u16 %4, %8, %9, %4\n\tv_dot2_u32_u16 %5, %8, %9, %5\n\t"
+                        "v_dot2_u32_u16 %6, %8, %9, %6\n\tv_dot2_u32_u16 %7, %8, %9, %7"
+                        : "+v"(*(uint32_t *) &a0), "+v"(*(uint32_t *) &a1), "+v"(*(uint32_t *) &a2),
+                          "+v"(*(uint32_t *) &a3), "+v"(*(uint32_t *) &a4), "+v"(*(uint32_t *) &a5),
+                          "+v"(*(uint32_t *) &a6), "+v"(*(uint32_t *) &a7) : "v"(x), "v"(y));)
+    } else if constexpr (V == 5) {     // v_fma_f64, 4 chains x 2
+      REP8(asm volatile("v_fma_f64 %0, %4, %5, %0\n\tv_fma_f64 %1, %4, %5, %1\n\tv_fma_f64 %2, %4, %5, %2\n\t"
+                        "v_fma_f64 %3, %4, %5, %3\n\tv_fma_f64 %0, %4, %5, %0\n\tv_fma_f64 %1, %4, %5, %1\n\t"
+                        "v_fma_f64 %2, %4, %5, %2\n\tv_fma_f64 %3, %4, %5, %3"
+                        : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3) : "v"(dx), "v"(dy));)
+    } else if constexpr (V == 6) {     // v_addc_co_u32 chain
+      REP8(asm volatile("v_add_co_u32 %0, vcc, %0, %8\n\tv_addc_co_u32 %1, vcc, %1, %8, vcc\n\t"
+                        "v_addc_co_u32 %2, vcc, %2, %8, vcc\n\tv_addc_co_u32 %3, vcc, %3, %8, vcc\n\t"
+                        "v_addc_co_u32 %4, vcc, %4, %8, vcc\n\tv_addc_co_u32 %5, vcc, %5, %8, vcc\n\t"
+                        "v_addc_co_u32 %6, vcc, %6, %8, vcc\n\tv_addc_co_u32 %7, vcc, %7, %8, vcc"
+                        : "+v"(*(uint32_t *) &a0), "+v"(*(uint32_t *) &a1), "+v"(*(uint32_t *) &a2),
+                          "+v"(*(uint32_t *) &a3), "+v"(*(uint32_t *) &a4), "+v"(*(uint32_t *) &a5),
+                          "+v"(*(uint32_t *) &a6), "+v"(*(uint32_t *) &a7) : "v"(x) : "vcc");)
+    } else if constexpr (V == 7) {     // v_mad_u32_u24
+      REP8(asm volatile("v_mad_u32_u24 %0, %8, %9, %0\n\tv_mad_u32_u24 %1, %8, %9, %1\n\t"
+                        "v_mad_u32_u24 %2, %8, %9, %2\n\tv_mad_u32_u24 %3, %8, %9, %3\n\t"
+                        "v_mad_u32_u24 %4, %8, %9, %4\n\tv_mad_u32_u24 %5, %8, %9, %5\n\t"
+                        "v_mad_u32_u24 %6, %8, %9, %6\n\tv_mad_u32_u24 %7, %8, %9, %7"
+                        : "+v"(*(uint32_t *) &a0), "+v"(*(uint32_t *) &a1), "+v"(*(uint32_t *) &a2),
+                          "+v"(*(uint32_t *) &a3), "+v"(*(uint32_t *) &a4), "+v"(*(uint32_t *) &a5),
+                          "+v"(*(uint32_t *) &a6), "+v"(*(uint32_t *) &a7) : "v"(x), "v"(y));)
+    } else if constexpr (V == 8) {     // v_lshl_add_u64 (64-bit add)
+      REP8(asm volatile("v_lshl_add_u64 %0, %0, 0, %8\n\tv_lshl_add_u64 %1, %1, 0, %8\n\t"
+                        "v_lshl_add_u64 %2, %2, 0, %8\n\tv_lshl_add_u64 %3, %3, 0, %8\n\t"
+                        "v_lshl_add_u64 %4, %4, 0, %8\n\tv_lshl_add_u64 %5, %5, 0, %8\n\t"
+                        "v_lshl_add_u64 %6, %6, 0, %8\n\tv_lshl_add_u64 %7, %7, 0, %8"
+                        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
+                        : "v"(a0 ^ 0x12345));)
+    } else if constexpr (V == 9) {     // v_dot4_u32_u8
+      REP8(asm volatile("v_dot4_u32_u8 %0, %8, %9, %0\n\tv_dot4_u32_u8 %1, %8, %9, %1\n\t"
+                        "v_dot4_u32_u8 %2, %8, %9, %2\n\tv_dot4_u32_u8 %3, %8, %9, %3\n\t"
+                        "v_dot4_u32_u8 %4, %8, %9, %4\n\tv_dot4_u32_u8 %5, %8, %9, %5\n\t"
+                        "v_dot4_u32_u8 %6, %8, %9, %6\n\tv_dot4_u32_u8 %7, %8, %9, %7"
+                        : "+v"(*(uint32_t *) &a0), "+v"(*(uint32_t *) &a1), "+v"(*(uint32_t *) &a2),
+                          "+v"(*(uint32_t *) &a3), "+v"(*(uint32_t *) &a4), "+v"(*(uint32_t *) &a5),
+                          "+v"(*(uint32_t *) &a6), "+v"(*(uint32_t *) &a7) : "v"(x), "v"(y));)
+    } else if constexpr (V == 10) {    // mad + addc with an s_nop 0 after each pair (compiler's asm pad)
+      REP8(asm volatile("v_mad_u64_u32 %0, vcc, %3, %4, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\ts_nop 0\n\t"
+                        "v_mad_u64_u32 %0, vcc, %3, %4, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\ts_nop 0\n\t"
+                        "v_mad_u64_u32 %0, vcc, %3, %4, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\ts_nop 0\n\t"
+                        "v_mad_u64_u32 %0, vcc, %3, %4, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\ts_nop 0\n\t"
+                        "v_mad_u64_u32 %0, vcc, %3, %4, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\ts_nop 0\n\t"
+                        "v_mad_u64_u32 %0, vcc, %3, %4, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\ts_nop 0\n\t"
+                        "v_mad_u64_u32 %0, vcc, %3, %4, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\ts_nop 0\n\t"
+                        "v_mad_u64_u32 %0, vcc, %3, %4, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\ts_nop 0"
+                        : "+v"(a0), "+v"(c0), "+v"(c1) : "v"(x), "v"(y) : "vcc");)
+    } else if constexpr (V == 11) {    // v_mad_u32_u16
+      REP8(asm volatile("v_mad_u32_u16 %0, %8, %9, %0\n\tv_mad_u32_u16 %1, %8, %9, %1\n\t"
+                        "v_mad_u32_u16 %2, %8, %9, %2\n\tv_mad_u32_u16 %3, %8, %9, %3\n\t"
+                        "v_mad_u32_u16 %4, %8, %9, %4\n\tv_mad_u32_u16 %5, %8, %9, %5\n\t"
+                        "v_mad_u32_u16 %6, %8, %9, %6\n\tv_mad_u32_u16 %7, %8, %9, %7"
+                        : "+v"(*(uint32_t *) &a0), "+v"(*(uint32_t *) &a1), "+v"(*(uint32_t *) &a2),
+                          "+v"(*(uint32_t *) &a3), "+v"(*(uint32_t *) &a4), "+v"(*(uint32_t *) &a5),
+                          "+v"(*(uint32_t *) &a6), "+v"(*(uint32_t *) &a7) : "v"(x), "v"(y));)
+    } else if constexpr (V == 12) {    // v_add_u32 (full-rate reference)
+      REP8(asm volatile("v_add_u32 %0, %0, %8\n\tv_add_u32 %1, %1, %8\n\tv_add_u32 %2, %2, %8\n\t"
+                        "v_add_u32 %3, %3, %8\n\tv_add_u32 %4, %4, %8\n\tv_add_u32 %5, %5, %8\n\t"
+                        "v_add_u32 %6, %6, %8\n\tv_add_u32 %7, %7, %8"
+                        : "+v"(*(uint32_t *) &a0), "+v"(*(uint32_t *) &a1), "+v"(*(uint32_t *) &a2),
+                          "+v"(*(uint32_t *) &a3), "+v"(*(uint32_t *) &a4), "+v"(*(uint32_t *) &a5),
+                          "+v"(*(uint32_t *) &a6), "+v"(*(uint32_t *) &a7) : "v"(x));)
+    } else if constexpr (V == 13) {    // v_mad_u64_u32 with an SGPR factor (modulus limb form)
+      REP8(asm volatile("v_mad_u64_u32 %0, vcc, %8, %9, %0\n\tv_mad_u64_u32 %1, vcc, %8, %9, %1\n\t"
+                        "v_mad_u64_u32 %2, vcc, %8, %9, %2\n\tv_mad_u64_u32 %3, vcc, %8, %9, %3\n\t"
+                        "v_mad_u64_u32 %4, vcc, %8, %9, %4\n\tv_mad_u64_u32 %5, vcc, %8, %9, %5\n\t"
+                        "v_mad_u64_u32 %6, vcc, %8, %9, %6\n\tv_mad_u64_u32 %7, vcc, %8, %9, %7"
+                        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
+                        : "v"(x), "s"(seed) : "vcc");)
+    }
+  }
+  uint64_t r = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7 ^ c0 ^ c1;
+  r ^= (uint64_t) (d0 + d1 + d2 + d3);
+  if (r == 0x1234567887654321ull) sink[0] = (uint32_t) r;   // never true in practice: keeps the chains live
+}
+
+// ---------------------------------------------------------------------------------------
+// host object
+// ---------------------------------------------------------------------------------------
+struct pbc_hip_pairing_s {
+  int type;
+  int device;
+  int nlimb;                 // 32-bit limbs of F_q
+  int len_fq, len1, len2, lenT;
+  FpK<16> k16;
+  FpK<5> k5;
+  AConst a;
+  double fq_muls_single;     // reference F_q multiplication count per pairing (work model)
+};
+
+template <int N>
+static int fill_fpk(FpK<N> &K, const pbc_host::Big &q) {
+  using pbc_host::Big;
+  if (q.bits() > 32 * N || q.bits() <= 32 * (N - 1) || !(q.w[0] & 1)) return 1;
+  memset(&K, 0, sizeof K);
+  q.to_words(K.p, N);
+  Big::pow2_mod(32 * N, q).to_words(K.one, N);
+  Big::pow2_mod(64 * N, q).to_words(K.r2, N);
+  Big pm2 = q;
+  pm2.sub_small(2);
+  pm2.to_words(K.pm2, N);
+  K.ninv = pbc_host::neg_inv32(K.p[0]);
+  K.pbits = (uint32_t) q.bits();
+  return 0;
+}
+
+// a_init_pairing (ecc/a_param.c:1431-1472) + pbc_param_init_a (:1489-1502)
+static int init_type_a(pbc_hip_pairing_s *P, const char *txt, size_t len) {
+  using namespace pbc_host;
+  Big q, r, h;
+  int exp2, exp1, sign1, sign0;
+  if (!param_big(txt, len, "q", q) || !param_big(txt, len, "r", r) || !param_big(txt, len, "h", h) ||
+      !param_int(txt, len, "exp2", exp2) || !param_int(txt, len, "exp1", exp1) ||
+      !param_int(txt, len, "sign1", sign1) || !param_int(txt, len, "sign0", sign0))
+    return fail("type a: missing q/r/h/exp2/exp1/sign1/sign0");
+  if (fill_fpk<16>(P->k16, q)) return fail("type a: only 481..512-bit q is supported by this build (got %d bits)", q.bits());
+  if (h.bits() > 512 || h.is_zero()) return fail("type a: bad cofactor");
+  if ((q.w[0] & 3) != 3) return fail("type a: q must be 3 mod 4");
+  if (exp1 <= 0 || exp2 <= exp1) return fail("type a: bad exp1/exp2");
+  memset(&P->a, 0, sizeof P->a);
+  h.to_words(P->a.h, 16);
+  P->a.hbits = h.bits();
+  P->a.exp2 = exp2;
+  P->a.exp1 = exp1;
+  P->a.sign1 = sign1;
+  P->nlimb = 16;
+  P->len_fq = (q.bits() + 7) / 8;
+  if (P->len_fq != 64) return fail("type a: q must serialise to 64 bytes");
+  P->len1 = P->len2 = P->lenT = 2 * P->len_fq;
+  P->fq_muls_single = 4392.0;            // SURVEY.md 8d (instrumented reference, a.param)
+  return 0;
+}
+
+extern "C" int pbc_hip_pairing_init_set_buf(pbc_hip_pairing_t **out, const char *param, size_t len) {
+  if (!out || !param) return fail("null argument");
+  if (!len) len = strlen(param);
+  std::string type;
+  if (!pbc_host::param_lookup(param, len, "type", type)) return fail("unknown pairing type (no 'type' key)");
+  pbc_hip_pairing_s *P = new pbc_hip_pairing_s();
+  int rc;
+  if (type == "a") {
+    P->type = 'a';
+    rc = init_type_a(P, param, len);
+  } else {
+    rc = fail("pairing type '%s' is not built into libpbc_hip yet", type.c_str());
+  }
+  if (!rc) {
+    // bind to the caller's current device; without one the object still parses/validates
+    // parameters (host logic), and every batch call fails loudly -- there is no CPU path.
+    if (hipGetDevice(&P->device) != hipSuccess) P->device = -1;
+  }
+  if (rc) {
+    delete P;
+    return 1;
+  }
+  *out = P;
+  return 0;
+}
+extern "C" void pbc_hip_pairing_clear(pbc_hip_pairing_t *p) { delete p; }
+extern "C" int pbc_hip_pairing_type(const pbc_hip_pairing_t *p) { return p->type; }
+extern "C" int pbc_hip_pairing_length_in_bytes_G1(const pbc_hip_pairing_t *p) { return p->len1; }
+extern "C" int pbc_hip_pairing_length_in_bytes_G2(const pbc_hip_pairing_t *p) { return p->len2; }
+extern "C" int pbc_hip_pairing_length_in_bytes_GT(const pbc_hip_pairing_t *p) { return p->lenT; }
+extern "C" int pbc_hip_length_in_bytes_Fq(const pbc_hip_pairing_t *p) { return p->len_fq; }
+
+extern "C" double pbc_hip_algorithmic_macs_per_unit(const pbc_hip_pairing_t *p, int k) {
+  double n = p->nlimb;
+  double per_mul = 2 * n * n + n;
+  if (p->type == 'a' && k > 1) {
+    // a_pairings_affine (a_param.c:1283-1383): measured 41377 for k=16;
+    // general k: exp2*(2 + k*(5+3+ ~8)) ... use the measured affine model 2543*k + 689
+    return (2543.0 * k + 689.0) * per_mul;
+  }
+  return p->fq_muls_single * per_mul;
+}
+
+// constants -> __constant__ memory, ordered on the launch stream
+static int upload_constants(pbc_hip_pairing_s *P, hipStream_t s) {
+  if (P->nlimb == 16)
+    HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_fpk16), &P->k16, sizeof P->k16, 0, hipMemcpyHostToDevice, s));
+  else
+    HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_fpk5), &P->k5, sizeof P->k5, 0, hipMemcpyHostToDevice, s));
+  if (P->type == 'a')
+    HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_a), &P->a, sizeof P->a, 0, hipMemcpyHostToDevice, s));
+  return 0;
+}
+
+extern "C" int pbc_hip_element_pairing_batch_dev(pbc_hip_pairing_t *P, void *d_gt, const void *d_g1,
+                                                 const void *d_g2, size_t n, void *stream) {
+  if (!P) return fail("null pairing");
+  if (P->device < 0) return fail("no HIP device: libpbc_hip has no CPU fallback");
+  if (!n) return 0;
+  hipStream_t s = (hipStream_t) stream;
+  if (upload_constants(P, s)) return 1;
+  unsigned grid = (unsigned) ((n + kBlock - 1) / kBlock);
+  if (P->type == 'a') {
+    hipLaunchKernelGGL(a_pairing_kernel<16>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
+                       (const uint8_t *) d_g1, (const uint8_t *) d_g2, n);
+  } else {
+    return fail("unsupported type");
+  }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// host-buffer convenience path: H2D, kernel, D2H on a private stream
+static int run_host(pbc_hip_pairing_s *P, uint8_t *gt, const uint8_t *g1, const uint8_t *g2, size_t n,
+                    int k) {
+  if (P->device < 0) return fail("no HIP device: libpbc_hip has no CPU fallback");
+  if (!n) return 0;
+  size_t b1 = n * (size_t) k * P->len1, b2 = n * (size_t) k * P->len2, bt = n * (size_t) P->lenT;
+  void *d1 = nullptr, *d2 = nullptr, *dt = nullptr;
+  hipStream_t s;
+  HIP_TRY(hipSetDevice(P->device));
+  HIP_TRY(hipStreamCreate(&s));
+  int rc = 0;
+  do {
+    if (hipMalloc(&d1, b1) != hipSuccess || hipMalloc(&d2, b2) != hipSuccess || hipMalloc(&dt, bt) != hipSuccess) {
+      rc = fail("hipMalloc failed for a batch of %zu units", n);
+      break;
+    }
+    if (hipMemcpyAsync(d1, g1, b1, hipMemcpyHostToDevice, s) != hipSuccess ||
+        hipMemcpyAsync(d2, g2, b2, hipMemcpyHostToDevice, s) != hipSuccess) {
+      rc = fail("H2D copy failed");
+      break;
+    }
+    rc = k == 1 ? pbc_hip_element_pairing_batch_dev(P, dt, d1, d2, n, s)
+                : pbc_hip_element_prod_pairing_batch_dev(P, dt, d1, d2, n, k, s);
+    if (rc) break;
+    if (hipMemcpyAsync(gt, dt, bt, hipMemcpyDeviceToHost, s) != hipSuccess) {
+      rc = fail("D2H copy failed");
+      break;
+    }
+    hipError_t e = hipStreamSynchronize(s);
+    if (e != hipSuccess) rc = fail("kernel failed: %s", hipGetErrorString(e));
+  } while (0);
+  if (d1) (void) hipFree(d1);
+  if (d2) (void) hipFree(d2);
+  if (dt) (void) hipFree(dt);
+  (void) hipStreamDestroy(s);
+  return rc;
+}
+
+extern "C" int pbc_hip_element_pairing_batch(pbc_hip_pairing_t *P, uint8_t *gt, const uint8_t *g1,
+                                             const uint8_t *g2, size_t n) {
+  if (!P) return fail("null pairing");
+  return run_host(P, gt, g1, g2, n, 1);
+}
+
+extern "C" int pbc_hip_element_prod_pairing_batch_dev(pbc_hip_pairing_t *P, void *d_gt, const void *d_g1,
+                                                      const void *d_g2, size_t n, int k, void *stream) {
+  (void) d_gt; (void) d_g1; (void) d_g2; (void) n; (void) stream;
+  if (!P) return fail("null pairing");
+  if (k == 1) return pbc_hip_element_pairing_batch_dev(P, d_gt, d_g1, d_g2, n, stream);
+  return fail("element_prod_pairing kernel not built yet");
+}
+extern "C" int pbc_hip_element_prod_pairing_batch(pbc_hip_pairing_t *P, uint8_t *gt, const uint8_t *g1,
+                                                  const uint8_t *g2, size_t n, int k) {
+  if (!P) return fail("null pairing");
+  if (k < 1) return fail("k must be >= 1");
+  return run_host(P, gt, g1, g2, n, k);
+}
+
+extern "C" int pbc_hip_fq_op_batch(pbc_hip_pairing_t *P, int op, uint8_t *c, const uint8_t *a,
+                                   const uint8_t *b, size_t n) {
+  if (!P) return fail("null pairing");
+  if (P->device < 0) return fail("no HIP device: libpbc_hip has no CPU fallback");
+  if (!n) return 0;
+  if (op < 0 || op > 6) return fail("bad op");
+  size_t bytes = n * (size_t) P->len_fq;
+  void *da = nullptr, *db = nullptr, *dc = nullptr;
+  HIP_TRY(hipSetDevice(P->device));
+  HIP_TRY(hipMalloc(&da, bytes));
+  HIP_TRY(hipMalloc(&dc, bytes));
+  HIP_TRY(hipMemcpy(da, a, bytes, hipMemcpyHostToDevice));
+  if (b) {
+    HIP_TRY(hipMalloc(&db, bytes));
+    HIP_TRY(hipMemcpy(db, b, bytes, hipMemcpyHostToDevice));
+  }
+  if (upload_constants(P, 0)) return 1;
+  unsigned grid = (unsigned) ((n + kBlock - 1) / kBlock);
+  if (P->nlimb == 16)
+    hipLaunchKernelGGL(fq_op_kernel<16>, dim3(grid), dim3(kBlock), 0, 0, op, (uint8_t *) dc,
+                       (const uint8_t *) da, (const uint8_t *) db, n);
+  else
+    return fail("unsupported limb count");
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(c, dc, bytes, hipMemcpyDeviceToHost));
+  (void) hipFree(da);
+  (void) hipFree(dc);
+  if (db) (void) hipFree(db);
+  return 0;
+}
+
+template <int V>
+static int run_probe(int iters, double *rate, double *ms_out, double ops_per_iter) {
+  uint32_t *sink;
+  HIP_TRY(hipMalloc(&sink, 64));
+  int dev;
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDevice(&dev));
+  HIP_TRY(hipGetDeviceProperties(&prop, dev));
+  int grid = prop.multiProcessorCount * 8;
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  hipLaunchKernelGGL(probe_kernel<V>, dim3(grid), dim3(256), 0, 0, sink, iters / 4 + 1, 1u);
+  HIP_TRY(hipEventRecord(e0, 0));
+  hipLaunchKernelGGL(probe_kernel<V>, dim3(grid), dim3(256), 0, 0, sink, iters, 3u);
+  HIP_TRY(hipEventRecord(e1, 0));
+  HIP_TRY(hipEventSynchronize(e1));
+  float ms;
+  HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+  double total = (double) grid * 256.0 * (double) iters * ops_per_iter;
+  *rate = total / (ms * 1e-3);
+  *ms_out = ms;
+  (void) hipFree(sink);
+  (void) hipEventDestroy(e0);
+  (void) hipEventDestroy(e1);
+  return 0;
+}
+
+// variant -> lane-instructions per loop iteration (8 REPs x 8 instructions; V1/V10 count MACs)
+extern "C" int pbc_hip_int_mac_peak(int variant, int iters, double *rate, double *ms) {
+  switch (variant) {
+    case 0: return run_probe<0>(iters, rate, ms, 64);
+    case 1: return run_probe<1>(iters, rate, ms, 64);
+    case 2: return run_probe<2>(iters, rate, ms, 64);
+    case 3: return run_probe<3>(iters, rate, ms, 64);
+    case 4: return run_probe<4>(iters, rate, ms, 64);
+    case 5: return run_probe<5>(iters, rate, ms, 64);
+    case 6: return run_probe<6>(iters, rate, ms, 64);
+    case 7: return run_probe<7>(iters, rate, ms, 64);
+    case 8: return run_probe<8>(iters, rate, ms, 64);
+    case 9: return run_probe<9>(iters, rate, ms, 64);
+    case 10: return run_probe<10>(iters, rate, ms, 64);
+    case 11: return run_probe<11>(iters, rate, ms, 64);
+    case 12: return run_probe<12>(iters, rate, ms, 64);
+    case 13: return run_probe<13>(iters, rate, ms, 64);
+    default: return fail("unknown probe variant %d", variant);
+  }
+}

@@ -1,0 +1,37 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+
+
+@pytest.fixture(scope="session")
+def a_param_text():
+    with open(os.path.join(ROOT, "pbc_amd", "param", "a.param")) as fh:
+        return fh.read()
+
+
+@pytest.fixture(scope="session")
+def oracle_a(a_param_text):
+    import oracle
+    return oracle.OraclePairing(a_param_text)
+
+
+@pytest.fixture(scope="session")
+def hip_a(a_param_text):
+    """The product: libpbc_hip.so through its C-ABI.  No fallback of any kind."""
+    import pbc_amd
+    return pbc_amd.Pairing(a_param_text)
+
+
+def golden(name):
+    import oracle
+    return oracle.Vec(os.path.join(GOLDEN, name))

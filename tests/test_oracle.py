@@ -1,0 +1,102 @@
+"""CPU tests: the plain-C oracle (oracle/pbc_oracle.c) against the reference's golden
+vectors (tests/golden/*.vec, written by the unmodified reference via oracle/_ref/ref_tool)
+and against the algebraic properties the reference's own tests check
+(pbc/bilinear.test:17-33, pbc/pairing_test.pbc:16-21, guru/prodpairing_test.c:12-31)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from conftest import GOLDEN, golden
+
+
+@pytest.mark.parametrize("name", sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, "a_*.vec"))))
+def test_oracle_matches_reference_vectors(oracle_a, name):
+    v = golden(name)
+    if v.n > 128:                      # keep the CPU suite fast: head, tail and a stride
+        idx = np.r_[0:32, v.n - 32:v.n, 32:v.n - 32:61]
+    else:
+        idx = np.arange(v.n)
+    if v.k == 1:
+        out = oracle_a.pairing_batch(v.g1[idx], v.g2[idx])
+    else:
+        sel = (idx[:, None] * v.k + np.arange(v.k)[None, :]).ravel()
+        out = oracle_a.prod_pairing_batch(v.g1[sel], v.g2[sel], v.k)
+    assert np.array_equal(out, v.gt[idx])
+
+
+def test_kat_pairing_test_pbc(oracle_a):
+    """pbc/pairing_test.pbc:3-10 -- the reference's only pairing known-answer test."""
+    v = golden("a_kat.vec")
+    g = int("2382389466570123849673299401984867521337122094157231907755149435707124249269394670242462497382963719723036281844079382411446883273020125104982896098602669")
+    assert int.from_bytes(v.g1[0, :64].tobytes(), "big") == g
+    want_re = int("1352478452661998164151215014828915385601138645645403926287105573769451214277485326392786454433874957123922454604362337349978217917242114505658729401276644")
+    out = oracle_a.pairing_batch(v.g1, v.g2)
+    assert int.from_bytes(out[0, :64].tobytes(), "big") == want_re
+    assert np.array_equal(out, v.gt)
+
+
+def test_fq_mul_count_matches_survey(oracle_a):
+    """one Type-A pairing = 4392 Fq mul + 4 inversions in the reference
+    algorithm (+6 mul for the two on-curve checks of from_bytes)."""
+    v = golden("a_kat.vec")
+    oracle.counters(reset=True)
+    oracle_a.pairing_batch(v.g1, v.g2)
+    mul, inv = oracle.counters()
+    assert (mul, inv) == (4392 + 6, 4)
+
+
+def _be(x, n):
+    return np.frombuffer(int(x).to_bytes(n, "big"), np.uint8)
+
+
+def test_bilinearity(oracle_a):
+    """pbc/pairing_test.pbc:16-21 / pbc/bilinear.test:24-33: e(aP,bQ) = e(P,Q)^(ab)."""
+    v = golden("a_rand32.vec")
+    a, b = 171583727262251826931173602797951212789946235851, 233634857565210859330459959563397971304462340857
+    r = 730750818665451621361119245571504901405976559617
+    P, Q = v.g1[:2], v.g2[:2]
+    aP = oracle_a.g_mul(1, P, np.tile(_be(a, 20), (2, 1)))
+    bQ = oracle_a.g_mul(2, Q, np.tile(_be(b, 20), (2, 1)))
+    lhs = oracle_a.pairing_batch(aP, bQ)
+    rhs = oracle_a.gt_pow(v.gt[:2], np.tile(_be(a * b % r, 20), (2, 1)))
+    assert np.array_equal(lhs, rhs)
+
+
+def test_identity_and_offcurve(oracle_a):
+    """pairing_apply short-circuit (include/pbc_pairing.h:123-130) + curve_from_bytes
+    mapping off-curve bytes to O (ecc/curve.c:618-621)."""
+    v = golden("a_rand32.vec")
+    g1 = v.g1[:1].copy()
+    g1[0, -1] ^= 1
+    out = oracle_a.pairing_batch(g1, v.g2[:1])
+    one = np.zeros(128, np.uint8)
+    one[63] = 1
+    assert np.array_equal(out[0], one)
+
+
+def test_prod_equals_product_of_pairings(oracle_a):
+    """guru/prodpairing_test.c:12-31, benchmark/multipairing.c:49."""
+    v = golden("a_prod2x8.vec")
+    singles = oracle_a.pairing_batch(v.g1, v.g2)
+    prod = oracle_a.gt_mul(singles[0::2], singles[1::2])
+    assert np.array_equal(prod, v.gt)
+
+
+def test_fq_ops_against_python_ints(oracle_a, a_param_text):
+    """guru/fp_test.c:18-84 restated: Fq add/sub/mul/invert/neg/halve/double vs big ints."""
+    q = int([l.split()[1] for l in a_param_text.splitlines() if l.startswith("q ")][0])
+    rng = np.random.default_rng(1)
+    xs = [int.from_bytes(rng.bytes(64), "big") % q for _ in range(16)] + [0, 1, q - 1]
+    ys = [int.from_bytes(rng.bytes(64), "big") % q for _ in range(16)] + [q - 1, 0, q - 1]
+    A = np.stack([_be(x, 64) for x in xs])
+    B = np.stack([_be(y, 64) for y in ys])
+    exp = {0: lambda x, y: x * y % q, 1: lambda x, y: (x + y) % q, 2: lambda x, y: (x - y) % q,
+           3: lambda x, y: pow(x, q - 2, q), 4: lambda x, y: (-x) % q,
+           5: lambda x, y: x * pow(2, q - 2, q) % q, 6: lambda x, y: 2 * x % q}
+    for op, fn in exp.items():
+        got = oracle_a.fq_op(op, A, B)
+        want = np.stack([_be(fn(x, y), 64) for x, y in zip(xs, ys)])
+        assert np.array_equal(got, want), op

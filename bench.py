@@ -50,17 +50,28 @@ def cpu_baseline(param_path):
     import oracle  # checker/baseline only -- never on the measured GPU path
     cores = os.cpu_count() or 1
     tool = oracle.REF_TOOL
-    per_worker = 4096
     if os.path.exists(tool):
         try:
-            out = subprocess.run([tool, "bench", param_path, str(per_worker), "1", str(cores)],
-                                 capture_output=True, text=True, timeout=300)
-            j = json.loads(out.stdout.strip().splitlines()[-1])
-            return {"value": round(j["units_per_s"], 1), "unit": "pairings/s", "cores": cores,
+            def run(per_worker, workers):
+                out = subprocess.run([tool, "bench", param_path, str(per_worker), "1", str(workers)],
+                                     capture_output=True, text=True, timeout=300)
+                return json.loads(out.stdout.strip().splitlines()[-1])
+            one = run(2048, 1)                       # one core alone (~2 s)
+            per_worker = 1024
+            allc = run(per_worker, cores)            # every logical CPU busy
+            quota = None
+            try:
+                q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+                quota = None if q == "max" else float(q) / float(p)
+            except Exception:  # noqa: BLE001
+                pass
+            return {"value": round(allc["units_per_s"], 1), "unit": "pairings/s", "cores": cores,
                     "kind": "reference",
                     "sample": "%d element_pairing calls per worker x %d forked workers (a.param), %.1f s wall"
-                              % (per_worker, cores, j["wall_s"]),
-                    "per_core": round(j["per_core"], 1)}
+                              % (per_worker, cores, allc["wall_s"]),
+                    "single_core": round(one["units_per_s"], 1),
+                    "per_core_when_all_busy": round(allc["per_core"], 1),
+                    "cgroup_cpu_quota_cores": quota}
         except Exception as e:  # noqa: BLE001
             sys.stderr.write("cpu_baseline: ref_tool failed (%r), using the C port\n" % (e,))
     O = oracle.OraclePairing(open(param_path).read())

@@ -3,6 +3,14 @@ import sys
 
 import pytest
 
+# torch bundles its own HIP runtime: it must be the first one loaded into the process,
+# otherwise (libpbc_hip.so pulling /opt/rocm's libamdhip64 first) torch later reports
+# "No HIP GPUs are available".  The product itself never needs torch.
+try:
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -77,6 +77,12 @@ int pbc_hip_length_in_bytes_Fq(const pbc_hip_pairing_t *p);
  * chip and returns MAC/s.  variant selects the instruction mix (see csrc/pbc_hip.hip). */
 int pbc_hip_int_mac_peak(int variant, int iters, double *mac_per_s, double *ms);
 
+/* 512-bit Montgomery multiplier micro-benchmark: `iters` dependent products per lane with
+ * `waves_per_simd` resident waves; returns F_q products per second.  variant 0: saturated
+ * 32-bit limbs (mad+addc), 1/2: unsaturated 29-bit limbs (one/two accumulators), 3/4: the
+ * dedicated squaring. */
+int pbc_hip_diag_mul_bench(int variant, int iters, int waves_per_simd, double *mul_per_s, double *ms);
+
 /* Algorithmic work model used for the roofline: reference F_q multiplications
  * per unit x (2N^2+N) 32-bit MACs. */
 double pbc_hip_algorithmic_macs_per_unit(const pbc_hip_pairing_t *p, int k);

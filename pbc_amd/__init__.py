@@ -58,6 +58,8 @@ def lib():
         L.pbc_hip_fq_op_batch.argtypes = [vp, ci, vp, vp, vp, sz]
         L.pbc_hip_int_mac_peak.argtypes = [ci, ci, ctypes.POINTER(ctypes.c_double),
                                            ctypes.POINTER(ctypes.c_double)]
+        L.pbc_hip_diag_mul_bench.argtypes = [ci, ci, ci, ctypes.POINTER(ctypes.c_double),
+                                             ctypes.POINTER(ctypes.c_double)]
         L.pbc_hip_algorithmic_macs_per_unit.argtypes = [vp, ci]
         L.pbc_hip_algorithmic_macs_per_unit.restype = ctypes.c_double
         L.pbc_hip_last_error.restype = cp
@@ -73,7 +75,7 @@ EXPORTS = (
     "pbc_hip_element_pairing_batch_dev", "pbc_hip_element_prod_pairing_batch",
     "pbc_hip_element_prod_pairing_batch_dev", "pbc_hip_fq_op_batch",
     "pbc_hip_length_in_bytes_Fq", "pbc_hip_int_mac_peak",
-    "pbc_hip_algorithmic_macs_per_unit", "pbc_hip_last_error",
+    "pbc_hip_algorithmic_macs_per_unit", "pbc_hip_last_error", "pbc_hip_diag_mul_bench",
 )
 
 
@@ -175,4 +177,12 @@ def int_mac_peak(variant=0, iters=2000):
     r, ms = ctypes.c_double(), ctypes.c_double()
     if lib().pbc_hip_int_mac_peak(variant, iters, ctypes.byref(r), ctypes.byref(ms)):
         raise PbcHipError("int_mac_peak: " + _err())
+    return r.value, ms.value
+
+
+def mul_bench(variant, iters=400, waves_per_simd=1):
+    """512-bit multiplier micro-benchmark; returns (F_q products per second, ms)."""
+    r, ms = ctypes.c_double(), ctypes.c_double()
+    if lib().pbc_hip_diag_mul_bench(variant, iters, waves_per_simd, ctypes.byref(r), ctypes.byref(ms)):
+        raise PbcHipError("mul_bench: " + _err())
     return r.value, ms.value

@@ -5,9 +5,10 @@
 // N x 32-bit limbs held in VGPRs, one field element per lane.  The modulus and the
 // Montgomery constants are wave-uniform (__constant__ memory -> scalar loads -> SGPRs).
 //
-// Representation: little-endian limbs, Montgomery radix R = 2^(32 N), values always
-// fully reduced to [0, q).  The radix is private: all exchange with the host / the
-// reference is in canonical big-endian bytes (SURVEY.md "Key facts").
+// Representation: N little-endian 32-bit words per element, Montgomery form, always fully
+// reduced to [0, q).  The Montgomery radix is R = 2^(29 L), L = ceil(32N/29), because the
+// multiplier works on 29-bit limbs (see fp_mul29_inl); the radix is private: all exchange
+// with the host / the reference is in canonical big-endian bytes (SURVEY.md "Key facts").
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -20,8 +21,10 @@ struct FpK {            // wave-uniform field constants (field_init_mont_fp, mon
   uint32_t one[N];      // R mod q
   uint32_t r2[N];       // R^2 mod q
   uint32_t pm2[N];      // q - 2 (Fermat exponent)
-  uint32_t ninv;        // -q^-1 mod 2^32
+  uint32_t ninv;        // -q^-1 mod 2^32   (32-bit-limb product scanning, variant 0)
   uint32_t pbits;       // bit length of q
+  uint32_t p29[(32 * N + 28) / 29];   // q in 29-bit limbs (unsaturated multiplier)
+  uint32_t ninv29;      // -q^-1 mod 2^29
 };
 
 template <int N>
@@ -75,7 +78,7 @@ PBC_DEV void fp_cond_sub(fp<N> &r, const uint32_t *t, uint32_t carry) {
 // column accumulator: 2N^2 MACs + N v_mul_lo_u32, no per-row carry ripple.
 // Same value as mont_mul (arith/montfp.c:334-364).  Accepts a < R unreduced if b < q.
 template <int N>
-PBC_DEV void fp_mul_inl(fp<N> &r, const fp<N> &a, const fp<N> &b) {
+PBC_DEV void fp_mul32_inl(fp<N> &r, const fp<N> &a, const fp<N> &b) {
   const FpK<N> &K = fpk<N>();
   uint32_t m[N], t[N];
   uint32_t a0 = 0, a1 = 0, a2 = 0;
@@ -101,6 +104,159 @@ PBC_DEV void fp_mul_inl(fp<N> &r, const fp<N> &a, const fp<N> &b) {
   fp_cond_sub<N>(r, t, a0);
 }
 
+
+// ---------------------------------------------------------------------------------------
+// Unsaturated multiplier.  Storage stays N saturated 32-bit words (cheap carry-chain
+// add/sub, 32 VGPR arguments per call), but the product is formed on L = ceil(32N/29)
+// limbs of 29 bits with R = 2^(29 L):  a column holds at most 2L products < 2^58, so a
+// plain 64-bit accumulator never overflows (2L * 2^58 < 2^64 for L <= 31) and every MAC is
+// ONE v_mad_u64_u32 -- no carry instruction, no inline asm, free compiler scheduling.
+// Measured on MI355X: v_mad_u64_u32 issues every ~4.2 cycles (3.5 with an SGPR factor)
+// against 7.5 for the mad+addc pair of the saturated form (profiles/r01_probe_v1.txt).
+// ---------------------------------------------------------------------------------------
+template <int N>
+struct Limbs29 {
+  static constexpr int L = (32 * N + 28) / 29;
+  static constexpr uint32_t MASK = (1u << 29) - 1;
+};
+
+template <int N>
+PBC_DEV void to29(uint32_t *l, const fp<N> &a) {
+  constexpr int L = Limbs29<N>::L;
+#pragma unroll
+  for (int i = 0; i < L; i++) {
+    const int bit = 29 * i, j = bit >> 5, sh = bit & 31;
+    uint32_t lo = a.v[j];
+    uint32_t x;
+    if (sh == 0) x = lo;
+    else if (sh + 29 <= 32 || j + 1 >= N) x = lo >> sh;
+    else x = __builtin_amdgcn_alignbit(a.v[j + 1 < N ? j + 1 : j], lo, sh);
+    l[i] = (32 * N - bit >= 29 && sh + 29 != 32) ? (x & Limbs29<N>::MASK) : x;
+  }
+}
+// L normalised limbs (+ the value may reach 2^(32N)) -> N words + carry word
+template <int N>
+PBC_DEV uint32_t from29(uint32_t *w, const uint32_t *l) {
+  constexpr int L = Limbs29<N>::L;
+#pragma unroll
+  for (int j = 0; j <= N; j++) {
+    const int bit = 32 * j, i = bit / 29, o = bit - 29 * i;
+    uint32_t x = 0;
+    if (i < L) x = l[i] >> o;
+    if (i + 1 < L) x |= l[i + 1] << (29 - o);
+    if (58 - o < 32 && i + 2 < L) x |= l[i + 2] << (58 - o);
+    if (j < N) w[j] = x; else return x;
+  }
+  return 0;
+}
+
+// ACC2: split each column over two accumulators (shorter dependent mad chains)
+#define PBC_MAC(i_, X_, Y_)                                         \
+  do {                                                              \
+    if (ACC2 && ((i_) & 1)) acc1 += (uint64_t) (X_) * (Y_);         \
+    else acc += (uint64_t) (X_) * (Y_);                             \
+  } while (0)
+
+template <int N, bool ACC2>
+PBC_DEV void fp_mul29_inl(fp<N> &r, const fp<N> &a, const fp<N> &b) {
+  const FpK<N> &K = fpk<N>();
+  constexpr int L = Limbs29<N>::L;
+  constexpr uint32_t MASK = Limbs29<N>::MASK;
+  uint32_t x[L], y[L], m[L], t[L];
+  to29<N>(x, a);
+  to29<N>(y, b);
+  uint64_t acc = 0, acc1 = 0;
+#pragma unroll
+  for (int k = 0; k < L; k++) {
+#pragma unroll
+    for (int i = 0; i <= k; i++) PBC_MAC(i, x[i], y[k - i]);
+#pragma unroll
+    for (int i = 0; i < k; i++) PBC_MAC(i + 1, m[i], K.p29[k - i]);
+    if (ACC2) { acc += acc1; acc1 = 0; }
+    m[k] = ((uint32_t) acc * K.ninv29) & MASK;
+    acc += (uint64_t) m[k] * K.p29[0];
+    acc >>= 29;
+  }
+#pragma unroll
+  for (int k = L; k < 2 * L; k++) {
+#pragma unroll
+    for (int i = k - L + 1; i < L; i++) PBC_MAC(i, x[i], y[k - i]);
+#pragma unroll
+    for (int i = k - L + 1; i < L; i++) PBC_MAC(i + 1, m[i], K.p29[k - i]);
+    if (ACC2) { acc += acc1; acc1 = 0; }
+    t[k - L] = (uint32_t) acc & MASK;
+    acc >>= 29;
+  }
+  uint32_t w[N];
+  uint32_t carry = from29<N>(w, t);
+  fp_cond_sub<N>(r, w, carry);
+}
+
+// Squaring on the same scheme: the cross products are formed once against a pre-doubled copy
+// (L(L+1)/2 + L^2 MACs instead of 2 L^2).  Column bound: (L/2) 2^59 + 2^58 + L 2^58 < 2^64.
+template <int N, bool ACC2>
+PBC_DEV void fp_sqr29_inl(fp<N> &r, const fp<N> &a) {
+  const FpK<N> &K = fpk<N>();
+  constexpr int L = Limbs29<N>::L;
+  constexpr uint32_t MASK = Limbs29<N>::MASK;
+  uint32_t x[L], x2[L], m[L], t[L];
+  to29<N>(x, a);
+#pragma unroll
+  for (int i = 0; i < L; i++) x2[i] = x[i] << 1;
+  uint64_t acc = 0, acc1 = 0;
+#pragma unroll
+  for (int k = 0; k < L; k++) {
+#pragma unroll
+    for (int i = 0; 2 * i < k; i++) PBC_MAC(i, x[i], x2[k - i]);
+    if ((k & 1) == 0) PBC_MAC(1, x[k / 2], x[k / 2]);
+#pragma unroll
+    for (int i = 0; i < k; i++) PBC_MAC(i, m[i], K.p29[k - i]);
+    if (ACC2) { acc += acc1; acc1 = 0; }
+    m[k] = ((uint32_t) acc * K.ninv29) & MASK;
+    acc += (uint64_t) m[k] * K.p29[0];
+    acc >>= 29;
+  }
+#pragma unroll
+  for (int k = L; k < 2 * L; k++) {
+#pragma unroll
+    for (int i = k - L + 1; 2 * i < k; i++) PBC_MAC(i, x[i], x2[k - i]);
+    if ((k & 1) == 0) PBC_MAC(1, x[k / 2], x[k / 2]);
+#pragma unroll
+    for (int i = k - L + 1; i < L; i++) PBC_MAC(i, m[i], K.p29[k - i]);
+    if (ACC2) { acc += acc1; acc1 = 0; }
+    t[k - L] = (uint32_t) acc & MASK;
+    acc >>= 29;
+  }
+  uint32_t w[N];
+  uint32_t carry = from29<N>(w, t);
+  fp_cond_sub<N>(r, w, carry);
+}
+#undef PBC_MAC
+
+#ifndef PBC_MUL_IMPL
+#define PBC_MUL_IMPL 1      // 0: saturated 32-bit asm MACs, R = 2^(32N); 1/2: unsaturated, R = 2^(29L)
+#endif
+template <int N>
+PBC_DEV void fp_mul_inl(fp<N> &r, const fp<N> &a, const fp<N> &b) {
+#if PBC_MUL_IMPL == 0
+  fp_mul32_inl<N>(r, a, b);
+#elif PBC_MUL_IMPL == 1
+  fp_mul29_inl<N, false>(r, a, b);
+#else
+  fp_mul29_inl<N, true>(r, a, b);
+#endif
+}
+template <int N>
+PBC_DEV void fp_sqr_inl(fp<N> &r, const fp<N> &a) {
+#if PBC_MUL_IMPL == 0
+  fp_mul32_inl<N>(r, a, a);
+#elif PBC_MUL_IMPL == 1
+  fp_sqr29_inl<N, false>(r, a);
+#else
+  fp_sqr29_inl<N, true>(r, a);
+#endif
+}
+
 // Out-of-line instances: one copy of the ~1100-instruction body per kernel keeps the Miller
 // loop inside the instruction cache.  Arguments/results travel in VGPRs.
 template <int N>
@@ -114,10 +270,17 @@ template <int N>
 PBC_DEV void fp_mul(fp<N> &r, const fp<N> &a, const fp<N> &b) {
   r = fp_mul_fn<N>(a, b);
 }
-// The reference has no dedicated Fq squaring (generic_square = mul(a,a), arith/field.c:383).
+// The reference has no dedicated Fq squaring (generic_square = mul(a,a), arith/field.c:383);
+// here it is its own out-of-line body with ~3/4 of the multiply-adds.
+template <int N>
+__device__ __noinline__ fp<N> fp_sqr_fn(fp<N> a) {
+  fp<N> r;
+  fp_sqr_inl<N>(r, a);
+  return r;
+}
 template <int N>
 PBC_DEV void fp_sqr(fp<N> &r, const fp<N> &a) {
-  r = fp_mul_fn<N>(a, a);
+  r = fp_sqr_fn<N>(a);
 }
 
 // fp_add (montfp.c:220-250)

@@ -204,6 +204,26 @@ __global__ void __launch_bounds__(256) probe_kernel(uint32_t *sink, int iters, u
   if (r == 0x1234567887654321ull) sink[0] = (uint32_t) r;   // never true in practice: keeps the chains live
 }
 
+// ---- multiplier micro-benchmark: iters dependent F_q products per lane, nothing else ------
+template <int N, int V>
+__global__ void __launch_bounds__(256) mul_bench_kernel(uint32_t *out, const uint32_t *in, int iters) {
+  int tid = blockIdx.x * 256 + threadIdx.x;
+  int n = gridDim.x * 256;
+  fp<N> x, y;
+#pragma unroll
+  for (int i = 0; i < N; i++) { x.v[i] = in[i * n + tid]; y.v[i] = in[(N + i) * n + tid] | 1; }
+#pragma nounroll
+  for (int it = 0; it < iters; it++) {
+    if constexpr (V == 0) fp_mul32_inl<N>(x, x, y);
+    else if constexpr (V == 1) fp_mul29_inl<N, false>(x, x, y);
+    else if constexpr (V == 2) fp_mul29_inl<N, true>(x, x, y);
+    else if constexpr (V == 3) fp_sqr29_inl<N, false>(x, x);
+    else fp_sqr29_inl<N, true>(x, x);
+  }
+#pragma unroll
+  for (int i = 0; i < N; i++) out[i * n + tid] = x.v[i];
+}
+
 // ---------------------------------------------------------------------------------------
 // host object
 // ---------------------------------------------------------------------------------------
@@ -224,8 +244,19 @@ static int fill_fpk(FpK<N> &K, const pbc_host::Big &q) {
   if (q.bits() > 32 * N || q.bits() <= 32 * (N - 1) || !(q.w[0] & 1)) return 1;
   memset(&K, 0, sizeof K);
   q.to_words(K.p, N);
-  Big::pow2_mod(32 * N, q).to_words(K.one, N);
-  Big::pow2_mod(64 * N, q).to_words(K.r2, N);
+#if PBC_MUL_IMPL == 0
+  const int rbits = 32 * N;
+#else
+  const int rbits = 29 * Limbs29<N>::L;
+#endif
+  Big::pow2_mod(rbits, q).to_words(K.one, N);
+  Big::pow2_mod(2 * rbits, q).to_words(K.r2, N);
+  for (int i = 0; i < Limbs29<N>::L; i++) {
+    uint32_t v = 0;
+    for (int b = 0; b < 29; b++) v |= (uint32_t) q.bit(29 * i + b) << b;
+    K.p29[i] = v;
+  }
+  K.ninv29 = pbc_host::neg_inv32(K.p[0]) & Limbs29<N>::MASK;
   Big pm2 = q;
   pm2.sub_small(2);
   pm2.to_words(K.pm2, N);
@@ -448,6 +479,48 @@ static int run_probe(int iters, double *rate, double *ms_out, double ops_per_ite
   (void) hipEventDestroy(e0);
   (void) hipEventDestroy(e1);
   return 0;
+}
+
+template <int V>
+static int run_mul_bench(int iters, int waves_per_simd, double *rate, double *ms_out) {
+  int dev;
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDevice(&dev));
+  HIP_TRY(hipGetDeviceProperties(&prop, dev));
+  int grid = prop.multiProcessorCount * waves_per_simd;
+  size_t words = (size_t) grid * 256 * 32;
+  uint32_t *in, *out;
+  HIP_TRY(hipMalloc(&in, words * 4));
+  HIP_TRY(hipMalloc(&out, words * 4));
+  HIP_TRY(hipMemset(in, 0x5a, words * 4));
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  hipLaunchKernelGGL((mul_bench_kernel<16, V>), dim3(grid), dim3(256), 0, 0, out, in, iters / 8 + 1);
+  HIP_TRY(hipEventRecord(e0, 0));
+  hipLaunchKernelGGL((mul_bench_kernel<16, V>), dim3(grid), dim3(256), 0, 0, out, in, iters);
+  HIP_TRY(hipEventRecord(e1, 0));
+  HIP_TRY(hipEventSynchronize(e1));
+  float ms;
+  HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+  *rate = (double) grid * 256.0 * iters / (ms * 1e-3);
+  *ms_out = ms;
+  (void) hipFree(in);
+  (void) hipFree(out);
+  (void) hipEventDestroy(e0);
+  (void) hipEventDestroy(e1);
+  return 0;
+}
+extern "C" int pbc_hip_diag_mul_bench(int variant, int iters, int waves_per_simd, double *rate, double *ms) {
+  if (waves_per_simd < 1 || waves_per_simd > 8) return fail("waves_per_simd must be 1..8");
+  switch (variant) {
+    case 0: return run_mul_bench<0>(iters, waves_per_simd, rate, ms);
+    case 1: return run_mul_bench<1>(iters, waves_per_simd, rate, ms);
+    case 2: return run_mul_bench<2>(iters, waves_per_simd, rate, ms);
+    case 3: return run_mul_bench<3>(iters, waves_per_simd, rate, ms);
+    case 4: return run_mul_bench<4>(iters, waves_per_simd, rate, ms);
+    default: return fail("unknown mul variant %d", variant);
+  }
 }
 
 // variant -> lane-instructions per loop iteration (8 REPs x 8 instructions; V1/V10 count MACs)

@@ -14,3 +14,14 @@ for v, nm in names.items():
     res[nm] = {"lane_ops_per_s": r, "ms": ms, "cycles_per_wave_instr_at_2.4GHz": cyc}
     print("%-28s %8.3f T lane-ops/s  %7.2f cyc/wave-instr/SIMD  (%.2f ms)" % (nm, r / 1e12, cyc, ms))
 json.dump(res, open("gpurun_out/probe.json", "w"), indent=1)
+
+mnames = {0: "mul 32-bit sat (mad+addc asm)", 1: "mul 29-bit unsat", 2: "mul 29-bit unsat, 2 acc",
+          3: "sqr 29-bit", 4: "sqr 29-bit, 2 acc"}
+mres = {}
+for v, nm in mnames.items():
+    for wps in (1, 2, 4):
+        r, ms = pbc_amd.mul_bench(v, 300, wps)
+        cyc = 256 * 4 * 2.4e9 / (r / 64.0)
+        mres["%s @%dw" % (nm, wps)] = {"fq_mul_per_s": r, "ms": ms}
+        print("%-32s %d waves/SIMD: %8.3f G mul/s  %8.0f cyc/wave-mul/SIMD @2.4GHz" % (nm, wps, r / 1e9, cyc))
+json.dump(mres, open("gpurun_out/mulbench.json", "w"), indent=1)

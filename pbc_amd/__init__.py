@@ -15,7 +15,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpbc_hip.so")
+# PBC_HIP_LIB selects an experimental build variant (tools/ only); the default is the product.
+LIB_PATH = os.path.join(_HERE, os.environ.get("PBC_HIP_LIB", "libpbc_hip.so"))
 PARAM_DIR = os.path.join(_HERE, "param")
 
 _lib = None

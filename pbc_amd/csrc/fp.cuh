@@ -257,30 +257,61 @@ PBC_DEV void fp_sqr_inl(fp<N> &r, const fp<N> &a) {
 #endif
 }
 
-// Out-of-line instances: one copy of the ~1100-instruction body per kernel keeps the Miller
-// loop inside the instruction cache.  Arguments/results travel in VGPRs.
+// Out-of-line instances: one copy of each ~900-instruction body per kernel keeps the Miller
+// loop inside the instruction cache.  Operands travel as ext_vector values: clang's AMDGPU
+// ABI passes only 16 registers' worth of *aggregates* directly (the second fp<16> struct
+// went through scratch memory, 128 B/lane per call), vectors are always passed in VGPRs.
 template <int N>
-__device__ __noinline__ fp<N> fp_mul_fn(fp<N> a, fp<N> b) {
-  fp<N> r;
-  fp_mul_inl<N>(r, a, b);
-  return r;
+struct vecN {
+  typedef uint32_t type __attribute__((ext_vector_type(N)));
+};
+template <int N>
+PBC_DEV typename vecN<N>::type to_vec(const fp<N> &a) {
+  typename vecN<N>::type v;
+#pragma unroll
+  for (int i = 0; i < N; i++) v[i] = a.v[i];
+  return v;
 }
-
+template <int N>
+PBC_DEV void from_vec(fp<N> &r, typename vecN<N>::type v) {
+#pragma unroll
+  for (int i = 0; i < N; i++) r.v[i] = v[i];
+}
+template <int N>
+static __device__ __noinline__ typename vecN<N>::type fp_mul_fn(typename vecN<N>::type va, typename vecN<N>::type vb) {
+  fp<N> a, b, r;
+  from_vec<N>(a, va);
+  from_vec<N>(b, vb);
+  fp_mul_inl<N>(r, a, b);
+  return to_vec<N>(r);
+}
+#ifndef PBC_INLINE_MUL
+#define PBC_INLINE_MUL 0    // 1: every product inlined at its call site (experiment)
+#endif
 template <int N>
 PBC_DEV void fp_mul(fp<N> &r, const fp<N> &a, const fp<N> &b) {
-  r = fp_mul_fn<N>(a, b);
+#if PBC_INLINE_MUL
+  fp_mul_inl<N>(r, a, b);
+#else
+  from_vec<N>(r, fp_mul_fn<N>(to_vec<N>(a), to_vec<N>(b)));
+#endif
 }
 // The reference has no dedicated Fq squaring (generic_square = mul(a,a), arith/field.c:383);
 // here it is its own out-of-line body with ~3/4 of the multiply-adds.
 template <int N>
-__device__ __noinline__ fp<N> fp_sqr_fn(fp<N> a) {
-  fp<N> r;
+static __device__ __noinline__ typename vecN<N>::type fp_sqr_fn(typename vecN<N>::type va) {
+  fp<N> a, r;
+  from_vec<N>(a, va);
   fp_sqr_inl<N>(r, a);
-  return r;
+  return to_vec<N>(r);
 }
 template <int N>
 PBC_DEV void fp_sqr(fp<N> &r, const fp<N> &a) {
-  r = fp_sqr_fn<N>(a);
+#if PBC_INLINE_MUL
+  fp_sqr_inl<N>(r, a);
+#else
+  from_vec<N>(r, fp_sqr_fn<N>(to_vec<N>(a)));
+#endif
 }
 
 // fp_add (montfp.c:220-250)
@@ -363,19 +394,20 @@ PBC_DEV void fp_cmov(fp<N> &r, const fp<N> &a, bool take) {
 // fp_invert in the reference (montfp.c:401-422) uses mpz_invert; the inverse is unique,
 // so the residue is identical.  0 -> 0.
 template <int N>
-__device__ __noinline__ fp<N> fp_inv_fn(fp<N> a) {
+static __device__ __noinline__ typename vecN<N>::type fp_inv_fn(typename vecN<N>::type va) {
   const FpK<N> &K = fpk<N>();
-  fp<N> r;
+  fp<N> a, r;
+  from_vec<N>(a, va);
   fp_set<N>(r, K.one);
   for (int i = (int) K.pbits - 1; i >= 0; i--) {
     fp_sqr<N>(r, r);
     if ((K.pm2[i >> 5] >> (i & 31)) & 1) fp_mul<N>(r, r, a);
   }
-  return r;
+  return to_vec<N>(r);
 }
 template <int N>
 PBC_DEV void fp_inv(fp<N> &r, const fp<N> &a) {
-  r = fp_inv_fn<N>(a);
+  from_vec<N>(r, fp_inv_fn<N>(to_vec<N>(a)));
 }
 
 // Wire format: fixed-width big-endian canonical residue (fp_from_bytes montfp.c:498-517,

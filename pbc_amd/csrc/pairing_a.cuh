@@ -202,20 +202,20 @@ PBC_DEV void a_final_exp(fp2<N> &out, const fp2<N> &f) {
   fp_halve<N>(out.x, v0);
 }
 
-// Whole pairing for one lane: bytes in (element_to_bytes layout x||y), bytes out (re||im).
+// Miller function f_{r-sign0,P}(phi(Q)) for one lane: bytes in (element_to_bytes layout x||y).
 //
-// Miller loop: plain double-and-add over r - sign0 = 2^exp2 + sign1 2^exp1 (the same
-// divisor the reference builds as f_{2^exp2} * f_{2^exp1}^{sign1} * line, a_param.c:1155-1179;
-// functions with equal divisors over F_q differ by an F_q^* constant, which the final
-// exponentiation removes).  Doing the single addition in place means no saved V1/f1:
-// the live state is f, V and two scratch elements; Q sits in LDS (lds_q: [2][N][lanes]).
+// Plain double-and-add over r - sign0 = 2^exp2 + sign1 2^exp1 (the same divisor the
+// reference builds as f_{2^exp2} * f_{2^exp1}^{sign1} * line, a_param.c:1155-1179; functions
+// with equal divisors over F_q differ by an F_q^* constant, which the final exponentiation
+// removes).  Doing the single addition in place means no saved V1/f1: the live state is f,
+// V and a few scratch elements; Q sits in LDS (lds_q: [2][N][lanes], limb-major).
+// Returns false when an input deserialises to O (off-curve bytes, ecc/curve.c:609-623).
 template <int N>
-PBC_DEV void a_pairing_lane(uint8_t *gt, const uint8_t *g1, const uint8_t *g2, uint32_t *lds_q,
-                            int lds_stride) {
+PBC_DEV bool a_miller_lane(fp2<N> &f, const uint8_t *g1, const uint8_t *g2, uint32_t *lds_q,
+                           int lds_stride) {
   constexpr int NB = 4 * N;
   fp<N> one;
   jac<N> V;
-  fp2<N> f;
   fp_set<N>(one, fpk<N>().one);
   bool valid;
   {
@@ -224,8 +224,6 @@ PBC_DEV void a_pairing_lane(uint8_t *gt, const uint8_t *g1, const uint8_t *g2, u
     fp_load_be<N>(V.Y, g1 + NB);
     fp_load_be<N>(Qx, g2);
     fp_load_be<N>(Qy, g2 + NB);
-    // off-curve input deserialises to O (curve_from_bytes, ecc/curve.c:609-623); a pairing
-    // with O is the GT identity (pairing_apply, include/pbc_pairing.h:123-130)
     valid = a_on_curve<N>(V.X, V.Y) & a_on_curve<N>(Qx, Qy);
 #pragma unroll
     for (int k = 0; k < N; k++) {
@@ -254,15 +252,47 @@ PBC_DEV void a_pairing_lane(uint8_t *gt, const uint8_t *g1, const uint8_t *g2, u
       a_add_step<N>(f, V, x2, y2, Qx, Qy);
     }
   }
-  fp2<N> out;
-  a_final_exp<N>(out, f);
-  if (!valid) {
-    out.x = one;
+  return valid;
+}
+
+template <int N>
+PBC_DEV void a_store_gt(uint8_t *gt, fp2<N> &out, bool valid) {
+  if (!valid) {                        // GT identity (pairing_apply, include/pbc_pairing.h:123-130)
+    fp_set<N>(out.x, fpk<N>().one);
 #pragma unroll
     for (int k = 0; k < N; k++) out.y.v[k] = 0;
   }
   fp_store_be<N>(gt, out.x);
-  fp_store_be<N>(gt + NB, out.y);
+  fp_store_be<N>(gt + 4 * N, out.y);
+}
+
+// element_pairing for one lane (a_pairing_proj + a_tateexp, a_param.c:1053-1198, :285-303)
+template <int N>
+PBC_DEV void a_pairing_lane(uint8_t *gt, const uint8_t *g1, const uint8_t *g2, uint32_t *lds_q,
+                            int lds_stride) {
+  fp2<N> f, out;
+  bool valid = a_miller_lane<N>(f, g1, g2, lds_q, lds_stride);
+  a_final_exp<N>(out, f);
+  a_store_gt<N>(gt, out, valid);
+}
+
+// element_prod_pairing for one lane: prod_j e(P_j, Q_j) with ONE final exponentiation
+// (a_pairings_affine, a_param.c:1283-1383).  The Miller functions are multiplied in F_q^2
+// before the shared final exponentiation; any identity input forces the product to 1
+// (element_prod_pairing, include/pbc_pairing.h:161-168).
+template <int N>
+PBC_DEV void a_prod_pairing_lane(uint8_t *gt, const uint8_t *g1, const uint8_t *g2, int k,
+                                 uint32_t *lds_q, int lds_stride) {
+  constexpr int L = 8 * N;
+  fp2<N> F, out;
+  bool valid = a_miller_lane<N>(F, g1, g2, lds_q, lds_stride);
+  for (int j = 1; j < k; j++) {
+    fp2<N> f;
+    valid &= a_miller_lane<N>(f, g1 + (size_t) j * L, g2 + (size_t) j * L, lds_q, lds_stride);
+    fi_mul<N>(F, F, f);
+  }
+  a_final_exp<N>(out, F);
+  a_store_gt<N>(gt, out, valid);
 }
 
 }  // namespace pbc

@@ -59,6 +59,24 @@ __global__ void __launch_bounds__(kBlock) a_pairing_kernel(uint8_t *gt, const ui
   }
 }
 
+// One k-term product of Type-A pairings per lane (terms of unit u are records u*k .. u*k+k-1).
+template <int N>
+__global__ void __launch_bounds__(kBlock) a_prod_pairing_kernel(uint8_t *gt, const uint8_t *g1,
+                                                                 const uint8_t *g2, size_t n, int k) {
+  size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
+  size_t ld = idx < n ? idx : n - 1;
+  constexpr int L = 8 * N;
+  __attribute__((aligned(16))) uint8_t out[L];
+  __shared__ uint32_t lds_q[2 * N * kBlock];
+  a_prod_pairing_lane<N>(out, g1 + ld * k * L, g2 + ld * k * L, k, lds_q + threadIdx.x, kBlock);
+  if (idx < n) {
+    uint4 *dst = reinterpret_cast<uint4 *>(gt + idx * L);
+    const uint4 *src = reinterpret_cast<const uint4 *>(out);
+#pragma unroll
+    for (int i = 0; i < L / 16; i++) dst[i] = src[i];
+  }
+}
+
 // Batched F_q operations on wire bytes (differential check of the limb arithmetic).
 template <int N>
 __global__ void __launch_bounds__(kBlock) fq_op_kernel(int op, uint8_t *c, const uint8_t *a,
@@ -410,10 +428,22 @@ extern "C" int pbc_hip_element_pairing_batch(pbc_hip_pairing_t *P, uint8_t *gt, 
 
 extern "C" int pbc_hip_element_prod_pairing_batch_dev(pbc_hip_pairing_t *P, void *d_gt, const void *d_g1,
                                                       const void *d_g2, size_t n, int k, void *stream) {
-  (void) d_gt; (void) d_g1; (void) d_g2; (void) n; (void) stream;
   if (!P) return fail("null pairing");
+  if (k < 1) return fail("k must be >= 1");
   if (k == 1) return pbc_hip_element_pairing_batch_dev(P, d_gt, d_g1, d_g2, n, stream);
-  return fail("element_prod_pairing kernel not built yet");
+  if (P->device < 0) return fail("no HIP device: libpbc_hip has no CPU fallback");
+  if (!n) return 0;
+  hipStream_t s = (hipStream_t) stream;
+  if (upload_constants(P, s)) return 1;
+  unsigned grid = (unsigned) ((n + kBlock - 1) / kBlock);
+  if (P->type == 'a') {
+    hipLaunchKernelGGL(a_prod_pairing_kernel<16>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
+                       (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k);
+  } else {
+    return fail("unsupported type");
+  }
+  HIP_TRY(hipGetLastError());
+  return 0;
 }
 extern "C" int pbc_hip_element_prod_pairing_batch(pbc_hip_pairing_t *P, uint8_t *gt, const uint8_t *g1,
                                                   const uint8_t *g2, size_t n, int k) {

@@ -126,3 +126,31 @@ def test_device_pointer_api_and_full_size_batch(hip_a, oracle_a):
     want = oracle_a.pairing_batch(v.g1[ii], v.g2[jj])
     got = M[torch.from_numpy(ii).cuda(), torch.from_numpy(jj).cuda()].cpu().numpy()
     assert np.array_equal(got, want)
+
+
+# ---- element_prod_pairing (a_pairings_affine, ecc/a_param.c:1283-1383) -------------------
+@pytest.mark.parametrize("name", ["a_prod16x4.vec", "a_prod2x8.vec", "a_prod3x10_edge.vec"])
+def test_prod_pairing_matches_reference_vectors(hip_a, name):
+    v = golden(name)
+    assert np.array_equal(hip_a.element_prod_pairing(v.g1, v.g2, v.k), v.gt)
+
+
+def test_prod_pairing_vs_oracle_and_naive_product(hip_a, oracle_a):
+    """benchmark/multipairing.c:49 / guru/prodpairing_test.c: prod == naive product of pairings."""
+    v = golden("a_chain1024.vec")
+    k, n = 5, 37
+    rng = np.random.default_rng(5)
+    i = rng.integers(0, 1024, n * k)
+    j = rng.integers(0, 1024, n * k)
+    got = hip_a.element_prod_pairing(v.g1[i], v.g2[j], k)
+    assert np.array_equal(got, oracle_a.prod_pairing_batch(v.g1[i], v.g2[j], k))
+    singles = hip_a.element_pairing(v.g1[i], v.g2[j]).reshape(n, k, 128)
+    acc = singles[:, 0]
+    for t in range(1, k):
+        acc = oracle_a.gt_mul(acc, singles[:, t])
+    assert np.array_equal(got, acc)
+
+
+def test_prod_pairing_k1_equals_pairing(hip_a):
+    v = golden("a_rand32.vec")
+    assert np.array_equal(hip_a.element_prod_pairing(v.g1, v.g2, 1), v.gt)

@@ -100,7 +100,7 @@ class OraclePairing:
     def fq_op(self, op, a, b=None):
         a = _u8(a)
         b = _u8(b) if b is not None else None
-        L = self.len_G1 // 2 if self.type == "a" else None
+        L = self.len_G1 // 2           # G1 = E(Fq): x || y
         n = a.size // L
         out = np.empty((n, L), np.uint8)
         if lib().oracle_fq_op(self._h, op, _ptr(a), _ptr(b), _ptr(out), n):

@@ -326,8 +326,16 @@ struct oracle_pairing {
   int len1, len2, lenT;
   /* type A (ecc/a_param.c:30-34) */
   int exp2, exp1, sign1;
-  fe ca, cb;             /* curve a=1, b=0 (a_param.c:1450-1452) */
+  fe ca, cb;             /* curve a, b in Fq (A: a=1, b=0, a_param.c:1450-1452) */
+  struct dctx *D;        /* type D (ecc/d_param.c:40-51) */
+  struct fctx *Fx;       /* type F (ecc/f_param.c:35-45) */
 };
+static int init_d(oracle_pairing *P, const char *txt, size_t len);
+static int init_f(oracle_pairing *P, const char *txt, size_t len);
+static int d_pairing_bytes(const oracle_pairing *P, const uint8_t *g1, const uint8_t *g2, uint8_t *gt, int k);
+static int f_pairing_bytes(const oracle_pairing *P, const uint8_t *g1, const uint8_t *g2, uint8_t *gt, int k);
+static int df_gt_mul(const oracle_pairing *P, const uint8_t *a, const uint8_t *b, uint8_t *out);
+static int df_gt_pow(const oracle_pairing *P, const uint8_t *a, const big *e, uint8_t *out);
 
 /* ---------------- param text -> key/value (ecc/param.c:100-170) ---------------- */
 static const char *kv_find(const char *txt, size_t len, const char *key, char *buf, size_t buflen) {
@@ -383,11 +391,13 @@ int oracle_pairing_init(oracle_pairing **out, const char *txt, size_t len) {
   P->type = tb[0];
   int rc = 1;
   if (!strcmp(tb, "a")) rc = init_a(P, txt, len);
+  else if (!strcmp(tb, "d")) rc = init_d(P, txt, len);
+  else if (!strcmp(tb, "f")) rc = init_f(P, txt, len);
   if (rc) { free(P); return 1; }
   *out = P;
   return 0;
 }
-void oracle_pairing_clear(oracle_pairing *p) { free(p); }
+void oracle_pairing_clear(oracle_pairing *p) { if (p) { free(p->D); free(p->Fx); } free(p); }
 int oracle_type(const oracle_pairing *p) { return p->type; }
 int oracle_len_G1(const oracle_pairing *p) { return p->len1; }
 int oracle_len_G2(const oracle_pairing *p) { return p->len2; }
@@ -594,12 +604,20 @@ static void a_pairings_affine(const oracle_pairing *P, fe2 *out, const pt *in1, 
  * (ecc/pairing.c:135-283 mulg wrapper). */
 static void gt_one_bytes(const oracle_pairing *P, uint8_t *out) {
   memset(out, 0, P->lenT);
-  if (P->type == 'a') out[P->Fq.nbytes - 1] = 1;
+  out[P->Fq.nbytes - 1] = 1;          /* the first F_q coordinate is the constant term for A, D and F */
 }
 
 int oracle_pairing_batch(const oracle_pairing *P, const uint8_t *g1, const uint8_t *g2,
                          uint8_t *gt, size_t n) {
   const fpctx *F = &P->Fq;
+  if (P->type == 'd' || P->type == 'f') {
+    for (size_t u = 0; u < n; u++) {
+      int rc = P->type == 'd' ? d_pairing_bytes(P, g1 + u * P->len1, g2 + u * P->len2, gt + u * P->lenT, 1)
+                              : f_pairing_bytes(P, g1 + u * P->len1, g2 + u * P->len2, gt + u * P->lenT, 1);
+      if (rc) return rc;
+    }
+    return 0;
+  }
   if (P->type != 'a') return 1;
   for (size_t u = 0; u < n; u++) {
     pt A, B; fe2 o;
@@ -618,7 +636,16 @@ int oracle_pairing_batch(const oracle_pairing *P, const uint8_t *g1, const uint8
 int oracle_prod_pairing_batch(const oracle_pairing *P, const uint8_t *g1, const uint8_t *g2,
                               uint8_t *gt, size_t n, int k) {
   const fpctx *F = &P->Fq;
-  if (P->type != 'a' || k < 1) return 1;
+  if (k < 1) return 1;
+  if (P->type == 'd' || P->type == 'f') {
+    for (size_t u = 0; u < n; u++) {
+      int rc = P->type == 'd' ? d_pairing_bytes(P, g1 + u * k * P->len1, g2 + u * k * P->len2, gt + u * P->lenT, k)
+                              : f_pairing_bytes(P, g1 + u * k * P->len1, g2 + u * k * P->len2, gt + u * P->lenT, k);
+      if (rc) return rc;
+    }
+    return 0;
+  }
+  if (P->type != 'a') return 1;
   pt *A = malloc(sizeof(pt) * k), *B = malloc(sizeof(pt) * k);
   for (size_t u = 0; u < n; u++) {
     int ident = 0;
@@ -664,6 +691,11 @@ int oracle_fq_op(const oracle_pairing *P, int op, const uint8_t *a, const uint8_
 
 int oracle_gt_mul(const oracle_pairing *P, const uint8_t *a, const uint8_t *b, uint8_t *out, size_t n) {
   const fpctx *F = &P->Fq;
+  if (P->type == 'd' || P->type == 'f') {
+    for (size_t i = 0; i < n; i++)
+      if (df_gt_mul(P, a + i * P->lenT, b + i * P->lenT, out + i * P->lenT)) return 1;
+    return 0;
+  }
   if (P->type != 'a') return 1;
   int L = F->nbytes;
   for (size_t i = 0; i < n; i++) {
@@ -679,6 +711,13 @@ int oracle_gt_mul(const oracle_pairing *P, const uint8_t *a, const uint8_t *b, u
 int oracle_gt_pow(const oracle_pairing *P, const uint8_t *a, const uint8_t *e, size_t elen,
                   uint8_t *out, size_t n) {
   const fpctx *F = &P->Fq;
+  if (P->type == 'd' || P->type == 'f') {
+    for (size_t i = 0; i < n; i++) {
+      big ex; big_from_be(&ex, e + i * elen, elen);
+      if (df_gt_pow(P, a + i * P->lenT, &ex, out + i * P->lenT)) return 1;
+    }
+    return 0;
+  }
   if (P->type != 'a') return 1;
   int L = F->nbytes;
   for (size_t i = 0; i < n; i++) {
@@ -698,8 +737,7 @@ int oracle_gt_pow(const oracle_pairing *P, const uint8_t *a, const uint8_t *e, s
 int oracle_g_mul(const oracle_pairing *P, int group, const uint8_t *ptb, const uint8_t *e,
                  size_t elen, uint8_t *out, size_t n) {
   const fpctx *F = &P->Fq;
-  if (P->type != 'a') return 1;
-  (void) group;                        /* Type A: G1 == G2 == E(Fq) */
+  if (P->type != 'a' && group != 1) return 1;   /* D/F: only G1 = E(Fq) scalar mult is provided */
   for (size_t i = 0; i < n; i++) {
     pt A, R; big ex;
     big_from_be(&ex, e + i * elen, elen);
@@ -708,4 +746,612 @@ int oracle_g_mul(const oracle_pairing *P, int group, const uint8_t *ptb, const u
     pt_to_bytes(F, out + i * P->len1, &R);
   }
   return 0;
+}
+
+
+/* ================================================================== */
+/* Type D (MNT, k = 6), ecc/d_param.c                                  */
+/* ================================================================== */
+/* Fq^3 = Fq[x]/(x^3 + c2 x^2 + c1 x + c0): polymod ring, arith/poly.c (n = 3) */
+typedef struct { fe c[3]; } f3;
+struct dctx {
+  f3 xpwr[2];            /* x^3, x^4 mod f: compute_x_powers (poly.c:1302-1333) */
+  fe nqr;                /* v: Fq6 = Fq3[sqrt(v)], v in Fq (d_param.c:1028-1032) */
+  fe nqrinv, nqrinv2;    /* v^-1, v^-2 (d_param.c:1072-1075; constants of Fq inside Fq3) */
+  f3 xpowq, xpowq2;      /* x^q, x^2q (d_param.c:1044-1050) */
+  fe ta, tb;             /* twist y^2 = x^3 + a v^2 x + b v^3 (curve.c:885-901) */
+  big phikonr;           /* (q^2 - q + 1)/r (d_param.c:1036-1042) */
+};
+
+static void f3_add(const fpctx *F, f3 *r, const f3 *a, const f3 *b) { for (int i = 0; i < 3; i++) fp_add(F, &r->c[i], &a->c[i], &b->c[i]); }
+static void f3_sub(const fpctx *F, f3 *r, const f3 *a, const f3 *b) { for (int i = 0; i < 3; i++) fp_sub(F, &r->c[i], &a->c[i], &b->c[i]); }
+static void f3_dbl(const fpctx *F, f3 *r, const f3 *a) { for (int i = 0; i < 3; i++) fp_dbl(F, &r->c[i], &a->c[i]); }
+static void f3_neg(const fpctx *F, f3 *r, const f3 *a) { for (int i = 0; i < 3; i++) fp_neg(F, &r->c[i], &a->c[i]); }
+static void f3_halve(const fpctx *F, f3 *r, const f3 *a) { for (int i = 0; i < 3; i++) fp_halve(F, &r->c[i], &a->c[i]); }
+/* polymod_const_mul (poly.c:1550-1558) */
+static void f3_mul_fq(const fpctx *F, f3 *r, const f3 *a, const fe *s) { for (int i = 0; i < 3; i++) fp_mul(F, &r->c[i], &a->c[i], s); }
+static int f3_is0(const fpctx *F, const f3 *a) { return fp_is0(F, &a->c[0]) && fp_is0(F, &a->c[1]) && fp_is0(F, &a->c[2]); }
+static int f3_eq(const fpctx *F, const f3 *a, const f3 *b) { return fp_eq(F, &a->c[0], &b->c[0]) && fp_eq(F, &a->c[1], &b->c[1]) && fp_eq(F, &a->c[2], &b->c[2]); }
+static void f3_set_fq(const fpctx *F, f3 *r, const fe *s) { r->c[0] = *s; r->c[1] = F->zero; r->c[2] = F->zero; }
+/* polymod_mul_degree3 (poly.c:910-930): product mod f; the Karatsuba grouping of the
+ * reference gives the same ring element as this schoolbook form. */
+static void f3_mul(const oracle_pairing *P, f3 *r, const f3 *a, const f3 *b) {
+  const fpctx *F = &P->Fq;
+  fe d[5], t;
+  for (int i = 0; i < 5; i++) d[i] = F->zero;
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+    fp_mul(F, &t, &a->c[i], &b->c[j]);
+    fp_add(F, &d[i + j], &d[i + j], &t);
+  }
+  f3 res, p0;
+  res.c[0] = d[0]; res.c[1] = d[1]; res.c[2] = d[2];
+  f3_mul_fq(F, &p0, &P->D->xpwr[0], &d[3]); f3_add(F, &res, &res, &p0);
+  f3_mul_fq(F, &p0, &P->D->xpwr[1], &d[4]); f3_add(F, &res, &res, &p0);
+  *r = res;
+}
+static void f3_sqr(const oracle_pairing *P, f3 *r, const f3 *a) { f3_mul(P, r, a, a); }  /* poly.c:1049-1089 */
+/* a^q for a in Fq3: a0 + a1 x^q + a2 x^2q (the qpower macro, d_param.c:507-527) */
+static void f3_frob(const oracle_pairing *P, f3 *r, const f3 *a) {
+  const fpctx *F = &P->Fq;
+  f3 e2, res;
+  f3_mul_fq(F, &res, &P->D->xpowq, &a->c[1]);
+  f3_mul_fq(F, &e2, &P->D->xpowq2, &a->c[2]);
+  f3_add(F, &res, &res, &e2);
+  fp_add(F, &res.c[0], &res.c[0], &a->c[0]);
+  *r = res;
+}
+/* polymod_invert (poly.c:521-536) is a polynomial extended Euclid; the inverse is unique,
+ * here: a^-1 = a^q a^(q^2) / N(a), N(a) = a a^q a^(q^2) in Fq. */
+static void f3_inv(const oracle_pairing *P, f3 *r, const f3 *a) {
+  const fpctx *F = &P->Fq;
+  f3 t, u, w, n;
+  f3_frob(P, &t, a);
+  f3_frob(P, &u, &t);
+  f3_mul(P, &w, &t, &u);
+  f3_mul(P, &n, a, &w);
+  fe ni; fp_inv(F, &ni, &n.c[0]);
+  f3_mul_fq(F, r, &w, &ni);
+}
+static void f3_pow(const oracle_pairing *P, f3 *r, const f3 *a, const big *e) {
+  const fpctx *F = &P->Fq;
+  f3 acc, base = *a; f3_set_fq(F, &acc, &F->R);
+  for (int i = big_bits(e) - 1; i >= 0; i--) {
+    f3_sqr(P, &acc, &acc);
+    if (big_bit(e, i)) f3_mul(P, &acc, &acc, &base);
+  }
+  *r = acc;
+}
+static void f3_from_bytes(const fpctx *F, f3 *r, const uint8_t *b) { for (int i = 0; i < 3; i++) fp_from_bytes(F, &r->c[i], b + i * F->nbytes); }  /* poly.c:735-752 */
+static void f3_to_bytes(const fpctx *F, uint8_t *b, const f3 *a) { for (int i = 0; i < 3; i++) fp_to_bytes(F, b + i * F->nbytes, &a->c[i]); }    /* poly.c:718-733 */
+
+/* Fq^6 = Fq^3[sqrt(v)]: generic quadratic extension, arith/fieldquadratic.c fq_* */
+typedef struct { f3 x, y; } f6;
+/* fq_mul (fieldquadratic.c:197-233) */
+static void f6_mul(const oracle_pairing *P, f6 *r, const f6 *a, const f6 *b) {
+  const fpctx *F = &P->Fq;
+  f3 e0, e1, e2, rx, ry;
+  f3_add(F, &e0, &a->x, &a->y);
+  f3_add(F, &e1, &b->x, &b->y);
+  f3_mul(P, &e2, &e0, &e1);
+  f3_mul(P, &e0, &a->x, &b->x);
+  f3_mul(P, &e1, &a->y, &b->y);
+  f3_mul_fq(F, &rx, &e1, &P->D->nqr);
+  f3_add(F, &rx, &rx, &e0);
+  f3_sub(F, &e2, &e2, &e0);
+  f3_sub(F, &ry, &e2, &e1);
+  r->x = rx; r->y = ry;
+}
+/* fq_square (fieldquadratic.c:249-269) */
+static void f6_sqr(const oracle_pairing *P, f6 *r, const f6 *a) {
+  const fpctx *F = &P->Fq;
+  f3 e0, e1;
+  f3_sqr(P, &e0, &a->x);
+  f3_sqr(P, &e1, &a->y);
+  f3_mul_fq(F, &e1, &e1, &P->D->nqr);
+  f3_add(F, &e0, &e0, &e1);
+  f3_mul(P, &e1, &a->x, &a->y);
+  f3_dbl(F, &e1, &e1);
+  r->x = e0; r->y = e1;
+}
+/* fq_invert (fieldquadratic.c:290-309) */
+static void f6_inv(const oracle_pairing *P, f6 *r, const f6 *a) {
+  const fpctx *F = &P->Fq;
+  f3 e0, e1;
+  f3_sqr(P, &e0, &a->x);
+  f3_sqr(P, &e1, &a->y);
+  f3_mul_fq(F, &e1, &e1, &P->D->nqr);
+  f3_sub(F, &e0, &e0, &e1);
+  f3_inv(P, &e0, &e0);
+  f3_mul(P, &r->x, &a->x, &e0);
+  f3_neg(F, &e0, &e0);
+  f3_mul(P, &r->y, &a->y, &e0);
+}
+static void f6_one(const fpctx *F, f6 *r) { f3_set_fq(F, &r->x, &F->R); f3_set_fq(F, &r->y, &F->zero); }
+static int f6_is1(const fpctx *F, const f6 *a) { f6 o; f6_one(F, &o); return f3_eq(F, &a->x, &o.x) && f3_is0(F, &a->y); }
+
+/* d_miller_evalfn (d_param.c:99-111) */
+static void d_evalfn(const fpctx *F, f6 *e0, const fe *a, const fe *b, const fe *c, const f3 *Qx, const f3 *Qy) {
+  for (int i = 0; i < 3; i++) {
+    fp_mul(F, &e0->x.c[i], &Qx->c[i], a);
+    fp_mul(F, &e0->y.c[i], &Qy->c[i], b);
+  }
+  fp_add(F, &e0->x.c[0], &e0->x.c[0], c);
+}
+/* cc_miller_no_denom_affine (d_param.c:321-422), the default (d_param.c:1085) */
+static void d_miller(const oracle_pairing *P, f6 *res, const pt *Pp, const f3 *Qx, const f3 *Qy) {
+  const fpctx *F = &P->Fq;
+  f6 v, e0;
+  pt Z = *Pp;
+  fe a, b, c, t0;
+  f6_one(F, &v);
+  int m = big_bits(&P->r);
+  m = m > 2 ? m - 2 : 0;
+  for (;;) {
+    /* do_tangent (d_param.c:344-362) */
+    fp_sqr(F, &a, &Z.x);
+    fp_dbl(F, &t0, &a); fp_add(F, &a, &a, &t0);       /* element_mul_si(a, a, 3) */
+    fp_add(F, &a, &a, &P->ca);
+    fp_neg(F, &a, &a);
+    fp_add(F, &b, &Z.y, &Z.y);
+    fp_mul(F, &t0, &b, &Z.y);
+    fp_mul(F, &c, &a, &Z.x);
+    fp_add(F, &c, &c, &t0);
+    fp_neg(F, &c, &c);
+    d_evalfn(F, &e0, &a, &b, &c, Qx, Qy);
+    f6_mul(P, &v, &v, &e0);
+    if (!m) break;
+    pt_dbl(F, &P->ca, &Z, &Z);
+    if (big_bit(&P->r, m)) {
+      /* do_line (d_param.c:364-379) */
+      fp_sub(F, &b, &Pp->x, &Z.x);
+      fp_sub(F, &a, &Z.y, &Pp->y);
+      fp_mul(F, &t0, &b, &Z.y);
+      fp_mul(F, &c, &a, &Z.x);
+      fp_add(F, &c, &c, &t0);
+      fp_neg(F, &c, &c);
+      d_evalfn(F, &e0, &a, &b, &c, Qx, Qy);
+      f6_mul(P, &v, &v, &e0);
+      pt_add(F, &P->ca, &Z, &Z, Pp);
+    }
+    m--;
+    f6_sqr(P, &v, &v);
+  }
+  *res = v;
+}
+/* lucas_even (d_param.c:441-502), over Fq3 */
+static void d_lucas_even(const oracle_pairing *P, f6 *out, f6 *in, const big *cofactor) {
+  const fpctx *F = &P->Fq;
+  if (f6_is1(F, in)) { *out = *in; return; }
+  f3 t0, t1, v0, v1;
+  f3 *in0 = &in->x, *in1 = &in->y;
+  { fe two; fp_set_ui(F, &two, 2); f3_set_fq(F, &t0, &two); }
+  f3_dbl(F, &t1, in0);
+  v0 = t0; v1 = t1;
+  int j = big_bits(cofactor) - 1;
+  for (;;) {
+    if (!j) {
+      f3_mul(P, &v1, &v0, &v1); f3_sub(F, &v1, &v1, &t1);
+      f3_sqr(P, &v0, &v0);      f3_sub(F, &v0, &v0, &t0);
+      break;
+    }
+    if (big_bit(cofactor, j)) {
+      f3_mul(P, &v0, &v0, &v1); f3_sub(F, &v0, &v0, &t1);
+      f3_sqr(P, &v1, &v1);      f3_sub(F, &v1, &v1, &t0);
+    } else {
+      f3_mul(P, &v1, &v0, &v1); f3_sub(F, &v1, &v1, &t1);
+      f3_sqr(P, &v0, &v0);      f3_sub(F, &v0, &v0, &t0);
+    }
+    j--;
+  }
+  f3_dbl(F, &v0, &v0);
+  f3_mul(P, in0, &t1, &v1);
+  f3_sub(F, in0, in0, &v0);
+  f3_sqr(P, &t1, &t1);
+  f3_sub(F, &t1, &t1, &t0);
+  f3_sub(F, &t1, &t1, &t0);
+  f3_halve(F, &v0, &v1);
+  { f3 ti; f3_inv(P, &ti, &t1); f3_mul(P, &v1, in0, &ti); }   /* element_div */
+  f3_mul(P, &v1, &v1, in1);
+  out->x = v0; out->y = v1;
+}
+/* cc_tatepower, k == 6 branch (d_param.c:505-564) */
+static void d_tatepower(const oracle_pairing *P, f6 *out, f6 *in) {
+  const fpctx *F = &P->Fq;
+  f6 e0, e3;
+  /* qpower(1): e0 = in.x^q + in.y^q sqrt(v) */
+  f3_frob(P, &e0.x, &in->x); f3_frob(P, &e0.y, &in->y);
+  e3 = e0;
+  e0.x = in->x; f3_neg(F, &e0.y, &in->y);
+  f6_mul(P, &e3, &e3, &e0);
+  /* qpower(-1) */
+  f3_frob(P, &e0.x, &in->x); f3_frob(P, &e0.y, &in->y); f3_neg(F, &e0.y, &e0.y);
+  f6_mul(P, &e0, &e0, in);
+  f6_inv(P, &e0, &e0);
+  f6_mul(P, in, &e3, &e0);
+  e0 = *in;
+  d_lucas_even(P, out, &e0, &P->D->phikonr);
+}
+/* curve_is_valid_point / curve_from_bytes over Fq3 for the twist (curve.c:57-77, 609-623) */
+typedef struct { int inf; f3 x, y; } pt3;
+static void d_twist_from_bytes(const oracle_pairing *P, pt3 *Q, const uint8_t *b) {
+  const fpctx *F = &P->Fq;
+  f3 t0, t1;
+  Q->inf = 0;
+  f3_from_bytes(F, &Q->x, b);
+  f3_from_bytes(F, &Q->y, b + 3 * F->nbytes);
+  f3_sqr(P, &t0, &Q->x);
+  fp_add(F, &t0.c[0], &t0.c[0], &P->D->ta);
+  f3_mul(P, &t0, &t0, &Q->x);
+  fp_add(F, &t0.c[0], &t0.c[0], &P->D->tb);
+  f3_sqr(P, &t1, &Q->y);
+  if (!f3_eq(F, &t0, &t1)) Q->inf = 1;
+}
+static void f6_to_bytes(const fpctx *F, uint8_t *b, const f6 *a) { f3_to_bytes(F, b, &a->x); f3_to_bytes(F, b + 3 * F->nbytes, &a->y); }
+static void f6_from_bytes(const fpctx *F, f6 *a, const uint8_t *b) { f3_from_bytes(F, &a->x, b); f3_from_bytes(F, &a->y, b + 3 * F->nbytes); }
+
+/* cc_pairing (d_param.c:570-587) / cc_pairings_affine (:710-736): the product routine
+ * interleaves the k Miller loops (shared squaring, simultaneous inversions); the value is
+ * the product of the k Miller functions, one cc_tatepower. */
+static int d_pairing_bytes(const oracle_pairing *P, const uint8_t *g1, const uint8_t *g2, uint8_t *gt, int k) {
+  const fpctx *F = &P->Fq;
+  f6 acc, m, out;
+  int ident = 0;
+  f6_one(F, &acc);
+  for (int j = 0; j < k; j++) {
+    pt A; pt3 B; f3 Qx, Qy;
+    pt_from_bytes(F, &P->ca, &P->cb, &A, g1 + (size_t) j * P->len1);
+    d_twist_from_bytes(P, &B, g2 + (size_t) j * P->len2);
+    if (A.inf || B.inf) { ident = 1; continue; }
+    f3_mul_fq(F, &Qx, &B.x, &P->D->nqrinv);      /* twist map (x,y) -> (v^-1 x, v^-2 y sqrt(v)) */
+    f3_mul_fq(F, &Qy, &B.y, &P->D->nqrinv2);
+    d_miller(P, &m, &A, &Qx, &Qy);
+    f6_mul(P, &acc, &acc, &m);
+  }
+  if (ident) { gt_one_bytes(P, gt); return 0; }
+  d_tatepower(P, &out, &acc);
+  f6_to_bytes(F, gt, &out);
+  return 0;
+}
+
+/* d_init_pairing (d_param.c:993-1095) + pbc_param_init_d */
+static int init_d(oracle_pairing *P, const char *txt, size_t len) {
+  big a, b, nqr, co[3]; int k;
+  if (kv_big(txt, len, "q", &P->q) || kv_big(txt, len, "r", &P->r) || kv_big(txt, len, "a", &a) ||
+      kv_big(txt, len, "b", &b) || kv_big(txt, len, "nqr", &nqr) || kv_int(txt, len, "k", &k) ||
+      kv_big(txt, len, "coeff0", &co[0]) || kv_big(txt, len, "coeff1", &co[1]) || kv_big(txt, len, "coeff2", &co[2]))
+    return 1;
+  if (k != 6) return 1;
+  if (fp_init(&P->Fq, &P->q)) return 1;
+  const fpctx *F = &P->Fq;
+  struct dctx *D = P->D = calloc(1, sizeof *D);
+  fe cf[3];
+#define SETBIG(dst, src) do { fe t_; memset(&t_, 0, sizeof t_); memcpy(t_.v, (src).v, 8 * F->n); fp_mul(F, &(dst), &t_, &F->R2); } while (0)
+  SETBIG(P->ca, a); SETBIG(P->cb, b); SETBIG(D->nqr, nqr);
+  for (int i = 0; i < 3; i++) SETBIG(cf[i], co[i]);
+  /* x^3 = -(c0 + c1 x + c2 x^2); x^4 = x * x^3 reduced */
+  for (int i = 0; i < 3; i++) fp_neg(F, &D->xpwr[0].c[i], &cf[i]);
+  {
+    f3 *x3 = &D->xpwr[0], *x4 = &D->xpwr[1], t;
+    x4->c[0] = F->zero; x4->c[1] = x3->c[0]; x4->c[2] = x3->c[1];
+    f3_mul_fq(F, &t, x3, &x3->c[2]);
+    f3_add(F, x4, x4, &t);
+  }
+  fp_inv(F, &D->nqrinv, &D->nqr);
+  fp_sqr(F, &D->nqrinv2, &D->nqrinv);
+  /* twist coefficients a v^2, b v^3 (field_reinit_curve_twist, curve.c:885-901) */
+  { fe v2; fp_sqr(F, &v2, &D->nqr); fp_mul(F, &D->ta, &P->ca, &v2); fp_mul(F, &v2, &v2, &D->nqr); fp_mul(F, &D->tb, &P->cb, &v2); }
+  /* xpowq = x^q, xpowq2 = (x^q)^2 */
+  { f3 x; x.c[0] = F->zero; x.c[1] = F->R; x.c[2] = F->zero; f3_pow(P, &D->xpowq, &x, &P->q); f3_sqr(P, &D->xpowq2, &D->xpowq); }
+  /* phikonr = (q^2 - q + 1) / r  -- long division on 'big' */
+  {
+    big z; memset(&z, 0, sizeof z);
+    int n = F->n;
+    for (int i = 0; i < n; i++) { u128 c = 0; for (int j = 0; j < n; j++) { c += (u128) P->q.v[i] * P->q.v[j] + z.v[i + j]; z.v[i + j] = (uint64_t) c; c >>= 64; } z.v[i + n] += (uint64_t) c; }
+    bn_sub(z.v, z.v, P->q.v, BIGL);
+    big one; memset(&one, 0, sizeof one); one.v[0] = 1;
+    bn_add(z.v, z.v, one.v, BIGL);
+    /* z / r by binary long division */
+    big quo, rem; memset(&quo, 0, sizeof quo); memset(&rem, 0, sizeof rem);
+    for (int i = big_bits(&z) - 1; i >= 0; i--) {
+      for (int w = BIGL - 1; w > 0; w--) rem.v[w] = (rem.v[w] << 1) | (rem.v[w - 1] >> 63);
+      rem.v[0] = (rem.v[0] << 1) | (uint64_t) big_bit(&z, i);
+      if (bn_cmp(rem.v, P->r.v, BIGL) >= 0) { bn_sub(rem.v, rem.v, P->r.v, BIGL); quo.v[i / 64] |= 1ull << (i % 64); }
+    }
+    if (!bn_is0(rem.v, BIGL)) return 1;
+    D->phikonr = quo;
+  }
+  P->len1 = 2 * F->nbytes; P->len2 = 6 * F->nbytes; P->lenT = 6 * F->nbytes;
+  return 0;
+}
+
+static int df_gt_mul(const oracle_pairing *P, const uint8_t *a, const uint8_t *b, uint8_t *out);
+static int df_gt_pow(const oracle_pairing *P, const uint8_t *a, const big *e, uint8_t *out);
+
+
+/* ================================================================== */
+/* Type F (BN, k = 12), ecc/f_param.c                                  */
+/* ================================================================== */
+/* Fq2 = Fq[sqrt(beta)] (generic fq_*, fieldquadratic.c); Fq12 = Fq2[x]/(x^6 + alpha) (polymod) */
+typedef struct { fe x, y; } g2;
+typedef struct { g2 c[6]; } f12;
+struct fctx {
+  fe beta;               /* nqr of Fq (f_param.c:345-348) */
+  g2 negalpha;           /* x^6 = negalpha = -(alpha0 + alpha1 sqrt(beta)) (f_param.c:355-361) */
+  g2 negalphainv;
+  g2 xpowq2, xpowq6, xpowq8;   /* x^(q^k) = (this) * x (f_param.c:431-444) */
+  g2 tb;                 /* twist curve y^2 = x^3 + tb, tb = -alpha b (f_param.c:372-381) */
+  big tateexp;           /* (q^4 - q^2 + 1)/r (f_param.c:414-420) */
+};
+
+static void g2_add(const fpctx *F, g2 *r, const g2 *a, const g2 *b) { fp_add(F, &r->x, &a->x, &b->x); fp_add(F, &r->y, &a->y, &b->y); }
+static void __attribute__((unused)) g2_sub(const fpctx *F, g2 *r, const g2 *a, const g2 *b) { fp_sub(F, &r->x, &a->x, &b->x); fp_sub(F, &r->y, &a->y, &b->y); }
+static void __attribute__((unused)) g2_neg(const fpctx *F, g2 *r, const g2 *a) { fp_neg(F, &r->x, &a->x); fp_neg(F, &r->y, &a->y); }
+static int g2_eq(const fpctx *F, const g2 *a, const g2 *b) { return fp_eq(F, &a->x, &b->x) && fp_eq(F, &a->y, &b->y); }
+/* fq_mul (fieldquadratic.c:197-233) */
+static void g2_mul(const oracle_pairing *P, g2 *r, const g2 *a, const g2 *b) {
+  const fpctx *F = &P->Fq;
+  fe e0, e1, e2, rx;
+  fp_add(F, &e0, &a->x, &a->y);
+  fp_add(F, &e1, &b->x, &b->y);
+  fp_mul(F, &e2, &e0, &e1);
+  fp_mul(F, &e0, &a->x, &b->x);
+  fp_mul(F, &e1, &a->y, &b->y);
+  fp_mul(F, &rx, &e1, &P->Fx->beta);
+  fp_add(F, &rx, &rx, &e0);
+  fp_sub(F, &e2, &e2, &e0);
+  fp_sub(F, &r->y, &e2, &e1);
+  r->x = rx;
+}
+/* fq_square (fieldquadratic.c:249-269) */
+static void g2_sqr(const oracle_pairing *P, g2 *r, const g2 *a) {
+  const fpctx *F = &P->Fq;
+  fe e0, e1;
+  fp_sqr(F, &e0, &a->x);
+  fp_sqr(F, &e1, &a->y);
+  fp_mul(F, &e1, &e1, &P->Fx->beta);
+  fp_add(F, &e0, &e0, &e1);
+  fp_mul(F, &e1, &a->x, &a->y);
+  fp_dbl(F, &e1, &e1);
+  r->x = e0; r->y = e1;
+}
+/* fq_invert (fieldquadratic.c:290-309) */
+static void g2_inv(const oracle_pairing *P, g2 *r, const g2 *a) {
+  const fpctx *F = &P->Fq;
+  fe e0, e1;
+  fp_sqr(F, &e0, &a->x);
+  fp_sqr(F, &e1, &a->y);
+  fp_mul(F, &e1, &e1, &P->Fx->beta);
+  fp_sub(F, &e0, &e0, &e1);
+  fp_inv(F, &e0, &e0);
+  fp_mul(F, &r->x, &a->x, &e0);
+  fp_neg(F, &e0, &e0);
+  fp_mul(F, &r->y, &a->y, &e0);
+}
+static void g2_mul_fq(const fpctx *F, g2 *r, const g2 *a, const fe *s) { fp_mul(F, &r->x, &a->x, s); fp_mul(F, &r->y, &a->y, s); }
+static void g2_from_bytes(const fpctx *F, g2 *r, const uint8_t *b) { fp_from_bytes(F, &r->x, b); fp_from_bytes(F, &r->y, b + F->nbytes); }
+static void g2_to_bytes(const fpctx *F, uint8_t *b, const g2 *a) { fp_to_bytes(F, b, &a->x); fp_to_bytes(F, b + F->nbytes, &a->y); }
+static void g2_zero(const fpctx *F, g2 *r) { r->x = F->zero; r->y = F->zero; }
+
+static void f12_one(const fpctx *F, f12 *r) { for (int i = 0; i < 6; i++) g2_zero(F, &r->c[i]); r->c[0].x = F->R; }
+/* polymod_mul (poly.c:1005-1047), n = 6, x^(6+i) = negalpha x^i */
+static void f12_mul(const oracle_pairing *P, f12 *r, const f12 *a, const f12 *b) {
+  const fpctx *F = &P->Fq;
+  g2 d[11], t;
+  for (int i = 0; i < 11; i++) g2_zero(F, &d[i]);
+  for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) {
+    g2_mul(P, &t, &a->c[i], &b->c[j]);
+    g2_add(F, &d[i + j], &d[i + j], &t);
+  }
+  for (int i = 0; i < 5; i++) {
+    g2_mul(P, &t, &d[6 + i], &P->Fx->negalpha);
+    g2_add(F, &d[i], &d[i], &t);
+  }
+  for (int i = 0; i < 6; i++) r->c[i] = d[i];
+}
+static void f12_sqr(const oracle_pairing *P, f12 *r, const f12 *a) { f12_mul(P, r, a, a); }   /* poly.c:1091-1143 */
+/* coefficient-wise Frobenius power: out^(q^k) for even k, x^(q^k) = e x (qpower, f_param.c:257-268) */
+static void f12_qpower(const oracle_pairing *P, f12 *r, const f12 *a, const g2 *e) {
+  g2 epow = *e;
+  f12 res;
+  res.c[0] = a->c[0];
+  g2_mul(P, &res.c[1], &a->c[1], e);
+  for (int i = 2; i < 6; i++) {
+    g2_mul(P, &epow, &epow, e);
+    g2_mul(P, &res.c[i], &a->c[i], &epow);
+  }
+  *r = res;
+}
+/* polymod_invert (poly.c:521-536): unique inverse; here via the norm to Fq2:
+ * sigma = (q^2)-power Frobenius, a^-1 = prod_{i=1..5} sigma^i(a) / N, N = prod_{i=0..5} sigma^i(a) in Fq2 */
+static void f12_inv(const oracle_pairing *P, f12 *r, const f12 *a) {
+  f12 s = *a, t, n;
+  f12_qpower(P, &s, &s, &P->Fx->xpowq2);
+  t = s;
+  for (int i = 2; i <= 5; i++) { f12_qpower(P, &s, &s, &P->Fx->xpowq2); f12_mul(P, &t, &t, &s); }
+  f12_mul(P, &n, a, &t);
+  g2 ni; g2_inv(P, &ni, &n.c[0]);
+  for (int i = 0; i < 6; i++) g2_mul(P, &r->c[i], &t.c[i], &ni);
+}
+static void f12_pow(const oracle_pairing *P, f12 *r, const f12 *a, const big *e) {
+  f12 acc, base = *a; f12_one(&P->Fq, &acc);
+  for (int i = big_bits(e) - 1; i >= 0; i--) {
+    f12_sqr(P, &acc, &acc);
+    if (big_bit(e, i)) f12_mul(P, &acc, &acc, &base);
+  }
+  *r = acc;
+}
+static void f12_to_bytes(const fpctx *F, uint8_t *b, const f12 *a) { for (int i = 0; i < 6; i++) g2_to_bytes(F, b + 2 * i * F->nbytes, &a->c[i]); }
+static void f12_from_bytes(const fpctx *F, f12 *a, const uint8_t *b) { for (int i = 0; i < 6; i++) g2_from_bytes(F, &a->c[i], b + 2 * i * F->nbytes); }
+
+/* f_miller_evalfn (f_param.c:109-149): v <- v * (a Qx x^4 + b Qy x^3 + c) */
+static void f_evalfn(const oracle_pairing *P, f12 *v, const fe *a, const fe *b, const fe *c, const g2 *Qx, const g2 *Qy) {
+  const fpctx *F = &P->Fq;
+  static const int term[6][4] = { {0, 2, 3, 2}, {1, 3, 4, 2}, {2, 4, 5, 2}, {3, 5, 0, 1}, {4, 0, 1, 0}, {5, 1, 2, 0} };
+  f12 e0;
+  for (int t = 0; t < 6; t++) {
+    int i = term[t][0], j = term[t][1], k = term[t][2], flag = term[t][3];
+    g2 e1, e2;
+    g2_mul(P, &e1, &v->c[j], Qx);
+    if (flag == 1) g2_mul(P, &e1, &e1, &P->Fx->negalpha);
+    g2_mul_fq(F, &e1, &e1, a);
+    g2_mul(P, &e2, &v->c[k], Qy);
+    g2_mul_fq(F, &e2, &e2, b);
+    g2_add(F, &e2, &e2, &e1);
+    if (flag == 2) g2_mul(P, &e2, &e2, &P->Fx->negalpha);
+    g2_mul_fq(F, &e1, &v->c[i], c);
+    g2_add(F, &e2, &e2, &e1);
+    e0.c[i] = e2;
+  }
+  *v = e0;
+}
+/* cc_miller_no_denom (f_param.c:97-248) */
+static void f_miller(const oracle_pairing *P, f12 *res, const pt *Pp, const g2 *Qx, const g2 *Qy) {
+  const fpctx *F = &P->Fq;
+  f12 v;
+  pt Z = *Pp;
+  fe a, b, c, t0;
+  f12_one(F, &v);
+  int m = big_bits(&P->r);
+  m = m > 2 ? m - 2 : 0;
+  for (;;) {
+    /* do_tangent (f_param.c:171-184): curve a coefficient is 0 */
+    fp_sqr(F, &a, &Z.x);
+    fp_dbl(F, &t0, &a); fp_add(F, &a, &a, &t0);
+    fp_neg(F, &a, &a);
+    fp_add(F, &b, &Z.y, &Z.y);
+    fp_mul(F, &t0, &b, &Z.y);
+    fp_mul(F, &c, &a, &Z.x);
+    fp_add(F, &c, &c, &t0);
+    fp_neg(F, &c, &c);
+    f_evalfn(P, &v, &a, &b, &c, Qx, Qy);
+    if (!m) break;
+    pt_dbl(F, &P->ca, &Z, &Z);
+    if (big_bit(&P->r, m)) {
+      /* do_line (f_param.c:190-199) */
+      fp_sub(F, &b, &Pp->x, &Z.x);
+      fp_sub(F, &a, &Z.y, &Pp->y);
+      fp_mul(F, &t0, &b, &Z.y);
+      fp_mul(F, &c, &a, &Z.x);
+      fp_add(F, &c, &c, &t0);
+      fp_neg(F, &c, &c);
+      f_evalfn(P, &v, &a, &b, &c, Qx, Qy);
+      pt_add(F, &P->ca, &Z, &Z, Pp);
+    }
+    m--;
+    f12_sqr(P, &v, &v);
+  }
+  *res = v;
+}
+/* f_tateexp (f_param.c:250-283) */
+static void f_tateexp(const oracle_pairing *P, f12 *out) {
+  f12 x, y;
+  f12_qpower(P, &y, out, &P->Fx->xpowq8);
+  f12_qpower(P, &x, out, &P->Fx->xpowq6);
+  f12_mul(P, &y, &y, &x);
+  f12_qpower(P, &x, out, &P->Fx->xpowq2);
+  f12_mul(P, &x, &x, out);
+  f12_inv(P, &x, &x);
+  f12_mul(P, out, &y, &x);
+  f12_pow(P, out, out, &P->Fx->tateexp);
+}
+typedef struct { int inf; g2 x, y; } pt2;
+static void f_twist_from_bytes(const oracle_pairing *P, pt2 *Q, const uint8_t *b) {
+  const fpctx *F = &P->Fq;
+  g2 t0, t1;
+  Q->inf = 0;
+  g2_from_bytes(F, &Q->x, b);
+  g2_from_bytes(F, &Q->y, b + 2 * F->nbytes);
+  g2_sqr(P, &t0, &Q->x);               /* a = 0 */
+  g2_mul(P, &t0, &t0, &Q->x);
+  g2_add(F, &t0, &t0, &P->Fx->tb);
+  g2_sqr(P, &t1, &Q->y);
+  if (!g2_eq(F, &t0, &t1)) Q->inf = 1;
+}
+/* f_pairing (f_param.c:289-311); products: generic_prod_pairings (ecc/pairing.c:35-46) =
+ * product of k full pairings (Type F installs no dedicated prod_pairings). */
+static int f_pairing_bytes(const oracle_pairing *P, const uint8_t *g1, const uint8_t *g2b, uint8_t *gt, int k) {
+  const fpctx *F = &P->Fq;
+  f12 acc, m;
+  int ident = 0;
+  f12_one(F, &acc);
+  for (int j = 0; j < k; j++) {
+    pt A; pt2 B; g2 x, y;
+    pt_from_bytes(F, &P->ca, &P->cb, &A, g1 + (size_t) j * P->len1);
+    f_twist_from_bytes(P, &B, g2b + (size_t) j * P->len2);
+    if (A.inf || B.inf) { ident = 1; continue; }
+    g2_mul(P, &x, &B.x, &P->Fx->negalphainv);
+    g2_mul(P, &y, &B.y, &P->Fx->negalphainv);
+    f_miller(P, &m, &A, &x, &y);
+    f_tateexp(P, &m);
+    f12_mul(P, &acc, &acc, &m);
+  }
+  if (ident) { gt_one_bytes(P, gt); return 0; }
+  f12_to_bytes(F, gt, &acc);
+  return 0;
+}
+
+/* f_init_pairing (f_param.c:335-447) */
+static int init_f(oracle_pairing *P, const char *txt, size_t len) {
+  big b, beta, a0, a1;
+  if (kv_big(txt, len, "q", &P->q) || kv_big(txt, len, "r", &P->r) || kv_big(txt, len, "b", &b) ||
+      kv_big(txt, len, "beta", &beta) || kv_big(txt, len, "alpha0", &a0) || kv_big(txt, len, "alpha1", &a1))
+    return 1;
+  if (fp_init(&P->Fq, &P->q)) return 1;
+  const fpctx *F = &P->Fq;
+  struct fctx *X = P->Fx = calloc(1, sizeof *X);
+  fe fa0, fa1;
+  P->ca = F->zero;
+  SETBIG(P->cb, b); SETBIG(X->beta, beta); SETBIG(fa0, a0); SETBIG(fa1, a1);
+  fp_neg(F, &X->negalpha.x, &fa0);
+  fp_neg(F, &X->negalpha.y, &fa1);
+  g2_inv(P, &X->negalphainv, &X->negalpha);
+  g2_mul_fq(F, &X->tb, &X->negalpha, &P->cb);       /* -alpha0 b - alpha1 b sqrt(beta) */
+  /* tateexp = ((q^2 - 1) q^2 + 1) / r */
+  {
+    int n = F->n;
+    big q2, z; memset(&q2, 0, sizeof q2); memset(&z, 0, sizeof z);
+    for (int i = 0; i < n; i++) { u128 c = 0; for (int j = 0; j < n; j++) { c += (u128) P->q.v[i] * P->q.v[j] + q2.v[i + j]; q2.v[i + j] = (uint64_t) c; c >>= 64; } q2.v[i + n] += (uint64_t) c; }
+    big one; memset(&one, 0, sizeof one); one.v[0] = 1;
+    big q2m1 = q2; bn_sub(q2m1.v, q2m1.v, one.v, BIGL);
+    for (int i = 0; i < 2 * n; i++) { u128 c = 0; for (int j = 0; j < 2 * n; j++) { c += (u128) q2m1.v[i] * q2.v[j] + z.v[i + j]; z.v[i + j] = (uint64_t) c; c >>= 64; } z.v[i + 2 * n] += (uint64_t) c; }
+    bn_add(z.v, z.v, one.v, BIGL);
+    big quo, rem; memset(&quo, 0, sizeof quo); memset(&rem, 0, sizeof rem);
+    for (int i = big_bits(&z) - 1; i >= 0; i--) {
+      for (int w = BIGL - 1; w > 0; w--) rem.v[w] = (rem.v[w] << 1) | (rem.v[w - 1] >> 63);
+      rem.v[0] = (rem.v[0] << 1) | (uint64_t) big_bit(&z, i);
+      if (bn_cmp(rem.v, P->r.v, BIGL) >= 0) { bn_sub(rem.v, rem.v, P->r.v, BIGL); quo.v[i / 64] |= 1ull << (i % 64); }
+    }
+    if (!bn_is0(rem.v, BIGL)) return 1;
+    X->tateexp = quo;
+  }
+  /* xpowq2/6/8: coefficient of x in x^(q^k) (f_param.c:431-444) */
+  {
+    f12 xp; f12_one(F, &xp); xp.c[0].x = F->zero; xp.c[1].x = F->R;
+    for (int i = 1; i <= 8; i++) {
+      f12_pow(P, &xp, &xp, &P->q);
+      if (i == 2) X->xpowq2 = xp.c[1];
+      if (i == 6) X->xpowq6 = xp.c[1];
+      if (i == 8) X->xpowq8 = xp.c[1];
+    }
+  }
+  P->len1 = 2 * F->nbytes; P->len2 = 4 * F->nbytes; P->lenT = 12 * F->nbytes;
+  return 0;
+}
+#undef SETBIG
+
+static int df_gt_mul(const oracle_pairing *P, const uint8_t *a, const uint8_t *b, uint8_t *out) {
+  const fpctx *F = &P->Fq;
+  if (P->type == 'd') { f6 x, y; f6_from_bytes(F, &x, a); f6_from_bytes(F, &y, b); f6_mul(P, &x, &x, &y); f6_to_bytes(F, out, &x); return 0; }
+  if (P->type == 'f') { f12 x, y; f12_from_bytes(F, &x, a); f12_from_bytes(F, &y, b); f12_mul(P, &x, &x, &y); f12_to_bytes(F, out, &x); return 0; }
+  return 1;
+}
+static int df_gt_pow(const oracle_pairing *P, const uint8_t *a, const big *e, uint8_t *out) {
+  const fpctx *F = &P->Fq;
+  if (P->type == 'd') {
+    f6 x, acc; f6_from_bytes(F, &x, a); f6_one(F, &acc);
+    for (int i = big_bits(e) - 1; i >= 0; i--) { f6_sqr(P, &acc, &acc); if (big_bit(e, i)) f6_mul(P, &acc, &acc, &x); }
+    f6_to_bytes(F, out, &acc); return 0;
+  }
+  if (P->type == 'f') { f12 x; f12_from_bytes(F, &x, a); f12_pow(P, &x, &x, e); f12_to_bytes(F, out, &x); return 0; }
+  return 1;
 }

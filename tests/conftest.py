@@ -40,6 +40,28 @@ def hip_a(a_param_text):
     return pbc_amd.Pairing(a_param_text)
 
 
+PARAM_OF = {"a": "a", "d": "d159", "f": "f"}
+
+
+def _param(name):
+    with open(os.path.join(ROOT, "pbc_amd", "param", name + ".param")) as fh:
+        return fh.read()
+
+
+@pytest.fixture(scope="session")
+def oracles():
+    """type letter -> CPU oracle"""
+    import oracle
+    return {t: oracle.OraclePairing(_param(n)) for t, n in PARAM_OF.items()}
+
+
+@pytest.fixture(scope="session")
+def hips():
+    """type letter -> the product (libpbc_hip.so)"""
+    import pbc_amd
+    return {t: pbc_amd.Pairing(_param(n)) for t, n in PARAM_OF.items()}
+
+
 def golden(name):
     import oracle
     return oracle.Vec(os.path.join(GOLDEN, name))

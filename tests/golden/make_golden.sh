@@ -13,3 +13,15 @@ $T gen $A edge   20   1  7 $G/a_edge20.vec    # random + off-curve (-> O) inputs
 $T gen $A random 4   16  5 $G/a_prod16x4.vec  # element_prod_pairing, 16 terms
 $T gen $A chain  8    2  1 $G/a_prod2x8.vec
 $T gen $A edge   10   3  9 $G/a_prod3x10_edge.vec
+D=pbc_amd/param/d159.param
+F=pbc_amd/param/f.param
+$T gen $D chain  256 1  1 $G/d_chain256.vec
+$T gen $D random 32  1 42 $G/d_rand32.vec
+$T gen $D edge   20  1  7 $G/d_edge20.vec
+$T gen $D random 4  16  5 $G/d_prod16x4.vec
+$T gen $D edge   10  3  9 $G/d_prod3x10_edge.vec
+$T gen $F chain  128 1  1 $G/f_chain128.vec
+$T gen $F random 16  1 42 $G/f_rand16.vec
+$T gen $F edge   10  1  7 $G/f_edge10.vec
+$T gen $F random 3   4  5 $G/f_prod4x3.vec
+$T gen $F edge   5   3  9 $G/f_prod3x5_edge.vec

@@ -64,6 +64,39 @@ struct Big {                              // little-endian 32-bit words, normali
     for (int i = 0; i < k; i++) { r.shl1(); if (cmp(r, m) >= 0) r.sub(m); }
     return r;
   }
+  void add_small(uint32_t v) {
+    uint64_t c = v;
+    for (auto &x : w) { c += x; x = (uint32_t) c; c >>= 32; if (!c) break; }
+    if (c) w.push_back((uint32_t) c);
+  }
+  static Big mul(const Big &a, const Big &b) {
+    Big r;
+    r.w.assign(a.w.size() + b.w.size() + 1, 0);
+    for (size_t i = 0; i < a.w.size(); i++) {
+      uint64_t c = 0;
+      for (size_t j = 0; j < b.w.size(); j++) {
+        c += (uint64_t) a.w[i] * b.w[j] + r.w[i + j];
+        r.w[i + j] = (uint32_t) c;
+        c >>= 32;
+      }
+      r.w[i + b.w.size()] += (uint32_t) c;
+    }
+    r.trim();
+    return r;
+  }
+  // quotient of an exact or inexact division (binary long division); rem returned via *rem
+  static Big div(const Big &a, const Big &b, Big *rem = nullptr) {
+    Big q, r;
+    q.w.assign(a.w.size() + 1, 0);
+    for (int i = a.bits() - 1; i >= 0; i--) {
+      r.shl1();
+      if (a.bit(i)) { if (r.w.empty()) r.w.push_back(1); else r.w[0] |= 1; }
+      if (cmp(r, b) >= 0) { r.sub(b); q.w[i >> 5] |= 1u << (i & 31); }
+    }
+    q.trim();
+    if (rem) *rem = r;
+    return q;
+  }
   void to_words(uint32_t *out, int n) const {
     for (int i = 0; i < n; i++) out[i] = (size_t) i < w.size() ? w[i] : 0;
   }

@@ -1,0 +1,451 @@
+// pairing_d.cuh -- Type D (MNT curve y^2 = x^3 + ax + b over F_q, embedding degree k = 6)
+// reduced Tate pairing, one pairing per lane.
+//
+// Computes the same GT value as the reference's cc_pairing (ecc/d_param.c:570-587):
+// twist map, cc_miller_no_denom_affine (:321-422) and cc_tatepower (:505-564, k = 6 branch
+// with lucas_even :441-502), but re-derived for a GPU:
+//   * towers on fixed-width limbs: F_q^3 = F_q[x]/(x^3 + c2 x^2 + c1 x + c0) (the polymod
+//     ring of arith/poly.c with its x^3, x^4 reduction table, :1302-1333) and
+//     F_q^6 = F_q^3[sqrt(v)] (generic quadratic extension, arith/fieldquadratic.c fq_*);
+//   * the Miller loop runs in Jacobian coordinates on E(F_q): the reference's affine loop
+//     costs one F_q inversion per doubling/addition (248 per pairing); the
+//     projective line coefficients differ from the affine ones by factors in F_q^*, which
+//     (q^6-1)/r kills;
+//   * final exponentiation with a single F_q inversion:  m^(q^3-1) = conj(m)^2 / N(m);
+//     raising to q+1 keeps numerator w = u^q u and denominator D = N^q N apart; with
+//     w = A + B sqrt(v) the Lucas parameter is P = 2A/D and the closing division of
+//     lucas_even by P^2 - 4 = 4 v (B/D)^2 folds into D/(v B): one inversion of D*B in
+//     F_q^3, done through the norm to F_q.
+#pragma once
+#include "fp.cuh"
+
+namespace pbc {
+
+constexpr int ND = 5;                  // 160-bit q: 5 x 32-bit words, 6 x 29-bit limbs
+typedef fp<ND> fq;
+
+struct f3 { fq c[3]; };                // c0 + c1 x + c2 x^2
+struct f6 { f3 x, y; };                // x + y sqrt(v)
+
+struct DConst {                        // pptr (ecc/d_param.c:40-51) + curve/field constants
+  uint32_t A[ND], B[ND];               // curve coefficients (Montgomery form)
+  uint32_t xpwr[2][3][ND];             // x^3, x^4 mod f      (poly.c compute_x_powers)
+  uint32_t nqr[ND], nqrinv[ND], nqrinv2[ND];   // v, v^-1, v^-2 (d_param.c:1028-1032, :1072-1075)
+  uint32_t xpowq[3][ND], xpowq2[3][ND];        // x^q, x^2q     (d_param.c:1044-1050)
+  uint32_t ta[ND], tb[ND];             // twist: y^2 = x^3 + a v^2 x + b v^3 (curve.c:885-901)
+  uint32_t r[8];                       // group order (Miller loop bits)
+  uint32_t phik[8];                    // (q^2 - q + 1)/r (d_param.c:1036-1042)
+  int rbits, phikbits;
+};
+__constant__ DConst c_d;
+
+PBC_DEV fq dk(const uint32_t *w) { fq r; fp_set<ND>(r, w); return r; }
+
+// ---- F_q^3 ------------------------------------------------------------------------------
+PBC_DEV void f3_add(f3 &r, const f3 &a, const f3 &b) { for (int i = 0; i < 3; i++) fp_add<ND>(r.c[i], a.c[i], b.c[i]); }
+PBC_DEV void f3_sub(f3 &r, const f3 &a, const f3 &b) { for (int i = 0; i < 3; i++) fp_sub<ND>(r.c[i], a.c[i], b.c[i]); }
+PBC_DEV void f3_dbl(f3 &r, const f3 &a) { for (int i = 0; i < 3; i++) fp_dbl<ND>(r.c[i], a.c[i]); }
+PBC_DEV void f3_neg(f3 &r, const f3 &a) { for (int i = 0; i < 3; i++) fp_neg<ND>(r.c[i], a.c[i]); }
+PBC_DEV void f3_halve(f3 &r, const f3 &a) { for (int i = 0; i < 3; i++) fp_halve<ND>(r.c[i], a.c[i]); }
+// polymod_const_mul (poly.c:1550-1558)
+PBC_DEV void f3_mul_fq(f3 &r, const f3 &a, const fq &s) { for (int i = 0; i < 3; i++) fp_mul<ND>(r.c[i], a.c[i], s); }
+PBC_DEV bool f3_eq(const f3 &a, const f3 &b) { return fp_eq<ND>(a.c[0], b.c[0]) & fp_eq<ND>(a.c[1], b.c[1]) & fp_eq<ND>(a.c[2], b.c[2]); }
+
+// degree-4 product -> reduce with the x^3, x^4 table (polymod_mul_degree3, poly.c:910-930)
+PBC_DEV void f3_reduce(f3 &r, const fq &d0, const fq &d1, const fq &d2, const fq &d3, const fq &d4) {
+  fq t;
+  r.c[0] = d0; r.c[1] = d1; r.c[2] = d2;
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    fp_mul<ND>(t, d3, dk(c_d.xpwr[0][i]));
+    fp_add<ND>(r.c[i], r.c[i], t);
+    fp_mul<ND>(t, d4, dk(c_d.xpwr[1][i]));
+    fp_add<ND>(r.c[i], r.c[i], t);
+  }
+}
+// Karatsuba on three coefficients (kar_poly_2, poly.c:870-907): 6 + 6 F_q products
+PBC_DEV void f3_mul_inl(f3 &r, const f3 &a, const f3 &b) {
+  fq p0, p1, p2, c01, c02, c12, s, t;
+  fp_mul<ND>(p0, a.c[0], b.c[0]);
+  fp_mul<ND>(p1, a.c[1], b.c[1]);
+  fp_mul<ND>(p2, a.c[2], b.c[2]);
+  fp_add<ND>(s, a.c[0], a.c[1]); fp_add<ND>(t, b.c[0], b.c[1]); fp_mul<ND>(c01, s, t);
+  fp_add<ND>(s, a.c[0], a.c[2]); fp_add<ND>(t, b.c[0], b.c[2]); fp_mul<ND>(c02, s, t);
+  fp_add<ND>(s, a.c[1], a.c[2]); fp_add<ND>(t, b.c[1], b.c[2]); fp_mul<ND>(c12, s, t);
+  fp_sub<ND>(c01, c01, p0); fp_sub<ND>(c01, c01, p1);        // x^1
+  fp_sub<ND>(c02, c02, p0); fp_sub<ND>(c02, c02, p2); fp_add<ND>(c02, c02, p1);   // x^2
+  fp_sub<ND>(c12, c12, p1); fp_sub<ND>(c12, c12, p2);        // x^3
+  f3_reduce(r, p0, c01, c02, c12, p2);
+}
+// polymod_square_degree3 (poly.c:1049-1089)
+PBC_DEV void f3_sqr_inl(f3 &r, const f3 &a) {
+  fq s0, s1, s2, m01, m02, m12;
+  fp_sqr<ND>(s0, a.c[0]);
+  fp_sqr<ND>(s1, a.c[1]);
+  fp_sqr<ND>(s2, a.c[2]);
+  fp_mul<ND>(m01, a.c[0], a.c[1]); fp_dbl<ND>(m01, m01);
+  fp_mul<ND>(m02, a.c[0], a.c[2]); fp_dbl<ND>(m02, m02);
+  fp_mul<ND>(m12, a.c[1], a.c[2]); fp_dbl<ND>(m12, m12);
+  fp_add<ND>(m02, m02, s1);
+  f3_reduce(r, s0, m01, m02, m12, s2);
+}
+// Out-of-line F_q^3 product / square (30 / 15 VGPR arguments): one body each keeps the
+// Miller and Lucas loops inside the instruction cache.
+typedef vecN<ND>::type v5;
+PBC_DEV void f3_unpack(f3 &r, v5 c0, v5 c1, v5 c2) { from_vec<ND>(r.c[0], c0); from_vec<ND>(r.c[1], c1); from_vec<ND>(r.c[2], c2); }
+struct f3ret { v5 c0, c1, c2; };
+static __device__ __noinline__ f3ret f3_mul_call(v5 a0, v5 a1, v5 a2, v5 b0, v5 b1, v5 b2) {
+  f3 a, b, r;
+  f3_unpack(a, a0, a1, a2);
+  f3_unpack(b, b0, b1, b2);
+  f3_mul_inl(r, a, b);
+  return f3ret{to_vec<ND>(r.c[0]), to_vec<ND>(r.c[1]), to_vec<ND>(r.c[2])};
+}
+static __device__ __noinline__ f3ret f3_sqr_call(v5 a0, v5 a1, v5 a2) {
+  f3 a, r;
+  f3_unpack(a, a0, a1, a2);
+  f3_sqr_inl(r, a);
+  return f3ret{to_vec<ND>(r.c[0]), to_vec<ND>(r.c[1]), to_vec<ND>(r.c[2])};
+}
+PBC_DEV void f3_mul(f3 &r, const f3 &a, const f3 &b) {
+  f3ret t = f3_mul_call(to_vec<ND>(a.c[0]), to_vec<ND>(a.c[1]), to_vec<ND>(a.c[2]), to_vec<ND>(b.c[0]),
+                        to_vec<ND>(b.c[1]), to_vec<ND>(b.c[2]));
+  f3_unpack(r, t.c0, t.c1, t.c2);
+}
+PBC_DEV void f3_sqr(f3 &r, const f3 &a) {
+  f3ret t = f3_sqr_call(to_vec<ND>(a.c[0]), to_vec<ND>(a.c[1]), to_vec<ND>(a.c[2]));
+  f3_unpack(r, t.c0, t.c1, t.c2);
+}
+
+// a^q on F_q^3 (the qpower macro of cc_tatepower, d_param.c:507-527)
+PBC_DEV void f3_frob(f3 &r, const f3 &a) {
+  f3 res;
+  fq t;
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    fp_mul<ND>(res.c[i], a.c[1], dk(c_d.xpowq[i]));
+    fp_mul<ND>(t, a.c[2], dk(c_d.xpowq2[i]));
+    fp_add<ND>(res.c[i], res.c[i], t);
+  }
+  fp_add<ND>(res.c[0], res.c[0], a.c[0]);
+  r = res;
+}
+// a^-1 = a^q a^(q^2) / N(a), N(a) = a a^q a^(q^2) in F_q  (polymod_invert poly.c:521-536 is a
+// polynomial extended Euclid; the inverse is unique)
+PBC_DEV void f3_inv(f3 &r, const f3 &a) {
+  f3 t, u, w;
+  f3_frob(t, a);
+  f3_frob(u, t);
+  f3_mul(w, t, u);
+  // constant coefficient of a*w
+  fq n, d3, d4, s;
+  fp_mul<ND>(n, a.c[0], w.c[0]);
+  fp_mul<ND>(d3, a.c[1], w.c[2]); fp_mul<ND>(s, a.c[2], w.c[1]); fp_add<ND>(d3, d3, s);
+  fp_mul<ND>(d4, a.c[2], w.c[2]);
+  fp_mul<ND>(s, d3, dk(c_d.xpwr[0][0])); fp_add<ND>(n, n, s);
+  fp_mul<ND>(s, d4, dk(c_d.xpwr[1][0])); fp_add<ND>(n, n, s);
+  fp_inv<ND>(n, n);
+  f3_mul_fq(r, w, n);
+}
+
+// ---- F_q^6 = F_q^3[sqrt(v)] -------------------------------------------------------------
+// fq_mul (fieldquadratic.c:197-233): Karatsuba
+PBC_DEV void f6_mul(f6 &r, const f6 &a, const f6 &b) {
+  f3 e0, e1, e2, t;
+  f3_add(e0, a.x, a.y);
+  f3_add(e1, b.x, b.y);
+  f3_mul(e2, e0, e1);
+  f3_mul(e0, a.x, b.x);
+  f3_mul(e1, a.y, b.y);
+  f3_mul_fq(t, e1, dk(c_d.nqr));
+  f3_add(r.x, t, e0);
+  f3_sub(e2, e2, e0);
+  f3_sub(r.y, e2, e1);
+}
+// fq_square (fieldquadratic.c:249-269); here x^2 + v y^2 = (x + y)(x + v y) - (1 + v) xy
+PBC_DEV void f6_sqr(f6 &r, const f6 &a) {
+  f3 t, s, vy, u;
+  f3_mul(t, a.x, a.y);
+  f3_mul_fq(vy, a.y, dk(c_d.nqr));
+  f3_add(s, a.x, a.y);
+  f3_add(vy, vy, a.x);
+  f3_mul(u, s, vy);
+  f3_sub(u, u, t);
+  f3_mul_fq(s, t, dk(c_d.nqr));
+  f3_sub(r.x, u, s);
+  f3_dbl(r.y, t);
+}
+
+// ---- Miller loop -------------------------------------------------------------------------
+struct djac { fq X, Y, Z, ZZ; };
+
+// l(Q) = (a Qx + c) + (b Qy) sqrt(v) with a, b, c in F_q (d_miller_evalfn, d_param.c:99-111)
+PBC_DEV void d_evalfn(f6 &e0, const fq &a, const fq &b, const fq &c, const f3 &Qx, const f3 &Qy) {
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    fp_mul<ND>(e0.x.c[i], Qx.c[i], a);
+    fp_mul<ND>(e0.y.c[i], Qy.c[i], b);
+  }
+  fp_add<ND>(e0.x.c[0], e0.x.c[0], c);
+}
+// tangent at V (do_tangent d_param.c:344-362, scaled by Z^6 in F_q^*) and V <- 2V:
+//   M = 3X^2 + a Z^4,  a' = -M Z^2,  b' = (2YZ) Z^2,  c' = M X - 2Y^2
+PBC_DEV void d_double_step(f6 &v, djac &V, const f3 &Qx, const f3 &Qy) {
+  fq XX, YY, M, t0, t1, S, Z3, la, lb, lc;
+  fp_sqr<ND>(XX, V.X);
+  fp_sqr<ND>(YY, V.Y);
+  fp_sqr<ND>(t0, V.ZZ);
+  fp_mul<ND>(t0, t0, dk(c_d.A));
+  fp_dbl<ND>(M, XX);
+  fp_add<ND>(M, M, XX);
+  fp_add<ND>(M, M, t0);
+  fp_mul<ND>(la, M, V.ZZ);
+  fp_neg<ND>(la, la);
+  fp_mul<ND>(Z3, V.Y, V.Z);
+  fp_dbl<ND>(Z3, Z3);
+  fp_mul<ND>(lb, Z3, V.ZZ);
+  fp_mul<ND>(lc, M, V.X);
+  fp_dbl<ND>(t1, YY);
+  fp_sub<ND>(lc, lc, t1);
+  f6 e0;
+  d_evalfn(e0, la, lb, lc, Qx, Qy);
+  f6_mul(v, v, e0);
+  fp_mul<ND>(S, V.X, YY);
+  fp_dbl<ND>(S, S);
+  fp_dbl<ND>(S, S);
+  fp_sqr<ND>(t0, YY);
+  fp_dbl<ND>(t0, t0);
+  fp_dbl<ND>(t0, t0);
+  fp_dbl<ND>(t0, t0);
+  fp_sqr<ND>(V.X, M);
+  fp_dbl<ND>(t1, S);
+  fp_sub<ND>(V.X, V.X, t1);
+  fp_sub<ND>(t1, S, V.X);
+  fp_mul<ND>(t1, M, t1);
+  fp_sub<ND>(V.Y, t1, t0);
+  V.Z = Z3;
+  fp_sqr<ND>(V.ZZ, Z3);
+}
+// chord through V and the affine P (do_line d_param.c:364-379, scaled by Z3 = Z H):
+//   H = Px Z^2 - X, R = Py Z^3 - Y;  a' = -R,  b' = Z3,  c' = R Px - Z3 Py;   V <- V + P
+PBC_DEV void d_add_step(f6 &v, djac &V, const fq &Px, const fq &Py, const f3 &Qx, const f3 &Qy) {
+  fq H, R, HH, HHH, t0, t1, Z3, la, lc;
+  fp_mul<ND>(H, Px, V.ZZ);
+  fp_sub<ND>(H, H, V.X);
+  fp_mul<ND>(t0, V.Z, V.ZZ);
+  fp_mul<ND>(R, Py, t0);
+  fp_sub<ND>(R, R, V.Y);
+  fp_mul<ND>(Z3, V.Z, H);
+  fp_neg<ND>(la, R);
+  fp_mul<ND>(lc, R, Px);
+  fp_mul<ND>(t0, Z3, Py);
+  fp_sub<ND>(lc, lc, t0);
+  f6 e0;
+  d_evalfn(e0, la, Z3, lc, Qx, Qy);
+  f6_mul(v, v, e0);
+  fp_sqr<ND>(HH, H);
+  fp_mul<ND>(HHH, HH, H);
+  fp_mul<ND>(t0, V.X, HH);
+  fp_sqr<ND>(t1, R);
+  fp_sub<ND>(t1, t1, HHH);
+  fp_sub<ND>(t1, t1, t0);
+  fp_sub<ND>(t1, t1, t0);
+  fp_sub<ND>(t0, t0, t1);
+  fp_mul<ND>(t0, R, t0);
+  fp_mul<ND>(HHH, V.Y, HHH);
+  fp_sub<ND>(V.Y, t0, HHH);
+  V.X = t1;
+  V.Z = Z3;
+  fp_sqr<ND>(V.ZZ, Z3);
+}
+
+PBC_DEV void f3_load_be(f3 &r, const uint8_t *src) { for (int i = 0; i < 3; i++) fp_load_be<ND>(r.c[i], src + 4 * ND * i); }
+PBC_DEV void f3_store_be(uint8_t *dst, const f3 &a) { for (int i = 0; i < 3; i++) fp_store_be<ND>(dst + 4 * ND * i, a.c[i]); }
+
+// Miller function f_{r,P}(psi(Q)): G1 bytes x||y (2 x 20), G2 bytes x||y over F_q^3 (2 x 60).
+// Returns false when an input deserialises to O (curve_from_bytes, ecc/curve.c:609-623).
+PBC_DEV bool d_miller_lane(f6 &v, const uint8_t *g1, const uint8_t *g2) {
+  constexpr int NB = 4 * ND;
+  fq Px, Py, one;
+  f3 Qx, Qy;
+  fp_set<ND>(one, fpk<ND>().one);
+  fp_load_be<ND>(Px, g1);
+  fp_load_be<ND>(Py, g1 + NB);
+  f3_load_be(Qx, g2);
+  f3_load_be(Qy, g2 + 3 * NB);
+  bool valid;
+  {
+    // curve_is_valid_point (curve.c:57-77): E: y^2 = x^3 + a x + b; twist over F_q^3
+    fq t0, t1;
+    fp_sqr<ND>(t0, Px);
+    fp_add<ND>(t0, t0, dk(c_d.A));
+    fp_mul<ND>(t0, t0, Px);
+    fp_add<ND>(t0, t0, dk(c_d.B));
+    fp_sqr<ND>(t1, Py);
+    valid = fp_eq<ND>(t0, t1);
+    f3 u0, u1;
+    f3_sqr(u0, Qx);
+    fp_add<ND>(u0.c[0], u0.c[0], dk(c_d.ta));
+    f3_mul(u0, u0, Qx);
+    fp_add<ND>(u0.c[0], u0.c[0], dk(c_d.tb));
+    f3_sqr(u1, Qy);
+    valid &= f3_eq(u0, u1);
+  }
+  // twist map (x, y) -> (v^-1 x, v^-2 y sqrt(v))  (cc_pairing, d_param.c:580-582)
+  f3_mul_fq(Qx, Qx, dk(c_d.nqrinv));
+  f3_mul_fq(Qy, Qy, dk(c_d.nqrinv2));
+  djac V;
+  V.X = Px; V.Y = Py; V.Z = one; V.ZZ = one;
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int k = 0; k < ND; k++) { v.x.c[i].v[k] = (i == 0) ? one.v[k] : 0; v.y.c[i].v[k] = 0; }
+  // cc_miller_no_denom_affine (d_param.c:321-422): tangent; [double; line+add]; square
+  for (int m = c_d.rbits - 2;; m--) {
+    d_double_step(v, V, Qx, Qy);
+    if (m <= 0) break;
+    if ((c_d.r[m >> 5] >> (m & 31)) & 1) d_add_step(v, V, Px, Py, Qx, Qy);
+    f6_sqr(v, v);
+  }
+  return valid;
+}
+
+// cc_tatepower (d_param.c:505-564) with one inversion; see the header of this file.
+PBC_DEV void d_final_exp(f6 &out, const f6 &m) {
+  const fq v = dk(c_d.nqr);
+  // u = conj(m)^2 = (a^2 + v b^2) - 2ab sqrt(v),  N = a^2 - v b^2
+  f3 aa, bb, ab, N;
+  f6 u, uq, w;
+  f3_sqr(aa, m.x);
+  f3_sqr(bb, m.y);
+  f3_mul_fq(bb, bb, v);
+  f3_mul(ab, m.x, m.y);
+  f3_add(u.x, aa, bb);
+  f3_sub(N, aa, bb);
+  f3_dbl(u.y, ab);
+  f3_neg(u.y, u.y);
+  // raise numerator and denominator to q + 1:  (x0 + x1 sqrt(v))^q = x0^q - x1^q sqrt(v)
+  f3_frob(uq.x, u.x);
+  f3_frob(uq.y, u.y);
+  f3_neg(uq.y, uq.y);
+  f6_mul(w, uq, u);                    // A + B sqrt(v)
+  f3 D, t, invD, invB;
+  f3_frob(D, N);
+  f3_mul(D, D, N);
+  f3_mul(t, D, w.y);
+  f3_inv(t, t);                        // 1/(D B): the only inversion
+  f3_mul(invD, t, w.y);
+  f3_mul(invB, t, D);
+  f3 h0, P, v0, v1, two;
+  f3_mul(h0, w.x, invD);
+  f3_dbl(P, h0);
+  {
+    fq o; fp_set<ND>(o, fpk<ND>().one); fp_dbl<ND>(o, o);
+#pragma unroll
+    for (int k = 0; k < ND; k++) { two.c[0].v[k] = o.v[k]; two.c[1].v[k] = 0; two.c[2].v[k] = 0; }
+  }
+  v0 = two;
+  v1 = P;
+  // lucas_even ladder (d_param.c:462-482): j == 0 takes the 0-branch
+  for (int j = c_d.phikbits - 1; j >= 0; j--) {
+    bool bit = j ? ((c_d.phik[j >> 5] >> (j & 31)) & 1) : false;
+    f3 mm, s;
+    f3_mul(mm, v0, v1);
+    f3_sub(mm, mm, P);
+    if (bit) { f3_sqr(s, v1); f3_sub(v1, s, two); v0 = mm; }
+    else     { f3_sqr(s, v0); f3_sub(v0, s, two); v1 = mm; }
+  }
+  // cofactor odd: v1 = V_k, v0 = V_{k-1};  out = V_k/2 + (P V_k - 2 V_{k-1})/(P^2-4) * (B/D) sqrt(v)
+  //                                            = V_k/2 + (P V_k - 2 V_{k-1}) D / (4 v B) sqrt(v)
+  f3_mul(t, P, v1);
+  f3_dbl(v0, v0);
+  f3_sub(t, t, v0);
+  f3_mul(t, t, D);
+  f3_mul(t, t, invB);
+  f3_mul_fq(t, t, dk(c_d.nqrinv));
+  f3_halve(t, t);
+  f3_halve(out.y, t);
+  f3_halve(out.x, v1);
+}
+
+PBC_DEV void d_store_gt(uint8_t *gt, f6 &out, bool valid) {
+  if (!valid) {                        // GT identity
+    fq one; fp_set<ND>(one, fpk<ND>().one);
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+      for (int k = 0; k < ND; k++) { out.x.c[i].v[k] = (i == 0) ? one.v[k] : 0; out.y.c[i].v[k] = 0; }
+  }
+  f3_store_be(gt, out.x);
+  f3_store_be(gt + 12 * ND, out.y);
+}
+
+// element_pairing (cc_pairing) / element_prod_pairing (cc_pairings_affine, d_param.c:710-736:
+// product of the Miller functions, ONE cc_tatepower) for one lane
+PBC_DEV void d_prod_pairing_lane(uint8_t *gt, const uint8_t *g1, const uint8_t *g2, int k) {
+  f6 F, out;
+  bool valid = d_miller_lane(F, g1, g2);
+  for (int j = 1; j < k; j++) {
+    f6 f;
+    valid &= d_miller_lane(f, g1 + (size_t) j * 8 * ND, g2 + (size_t) j * 24 * ND);
+    f6_mul(F, F, f);
+  }
+  d_final_exp(out, F);
+  d_store_gt(gt, out, valid);
+}
+
+// ---- device-side derivation of the tower constants (host supplies canonical words) -------
+struct DRaw { uint32_t a[ND], b[ND], coeff[3][ND], nqr[ND], q[ND + 1]; int qbits; };
+
+// stage 1: everything that needs only F_q arithmetic
+__global__ void d_init_stage1(DConst *out, DRaw raw, DConst base) {
+  if (threadIdx.x || blockIdx.x) return;
+  DConst C = base;
+  fq r2, t, a, b, v, cf[3];
+  fp_set<ND>(r2, fpk<ND>().r2);
+  fp_set<ND>(t, raw.a); fp_mul<ND>(a, t, r2);
+  fp_set<ND>(t, raw.b); fp_mul<ND>(b, t, r2);
+  fp_set<ND>(t, raw.nqr); fp_mul<ND>(v, t, r2);
+  for (int i = 0; i < 3; i++) { fp_set<ND>(t, raw.coeff[i]); fp_mul<ND>(cf[i], t, r2); }
+  // x^3 = -(c0 + c1 x + c2 x^2);  x^4 = x * x^3 reduced
+  fq x3[3], x4[3];
+  for (int i = 0; i < 3; i++) fp_neg<ND>(x3[i], cf[i]);
+  fp_mul<ND>(x4[0], x3[2], x3[0]);
+  fp_mul<ND>(t, x3[2], x3[1]); fp_add<ND>(x4[1], x3[0], t);
+  fp_mul<ND>(t, x3[2], x3[2]); fp_add<ND>(x4[2], x3[1], t);
+  fq vi, vi2, v2, ta, tb;
+  fp_inv<ND>(vi, v);
+  fp_sqr<ND>(vi2, vi);
+  fp_sqr<ND>(v2, v);
+  fp_mul<ND>(ta, a, v2);
+  fp_mul<ND>(v2, v2, v);
+  fp_mul<ND>(tb, b, v2);
+  for (int k = 0; k < ND; k++) {
+    C.A[k] = a.v[k]; C.B[k] = b.v[k]; C.nqr[k] = v.v[k]; C.nqrinv[k] = vi.v[k]; C.nqrinv2[k] = vi2.v[k];
+    C.ta[k] = ta.v[k]; C.tb[k] = tb.v[k];
+    for (int i = 0; i < 3; i++) { C.xpwr[0][i][k] = x3[i].v[k]; C.xpwr[1][i][k] = x4[i].v[k]; }
+  }
+  *out = C;
+}
+// stage 2 (c_d now holds stage 1): x^q by square-and-multiply in F_q^3, then its square
+__global__ void d_init_stage2(DConst *out, DRaw raw) {
+  if (threadIdx.x || blockIdx.x) return;
+  DConst C = c_d;
+  f3 acc, x;
+  fq one, zero;
+  fp_set<ND>(one, fpk<ND>().one);
+  for (int k = 0; k < ND; k++) zero.v[k] = 0;
+  acc.c[0] = one; acc.c[1] = zero; acc.c[2] = zero;
+  x.c[0] = zero; x.c[1] = one; x.c[2] = zero;
+  for (int i = raw.qbits - 1; i >= 0; i--) {
+    f3_sqr(acc, acc);
+    if ((raw.q[i >> 5] >> (i & 31)) & 1) f3_mul(acc, acc, x);
+  }
+  f3 sq;
+  f3_sqr(sq, acc);
+  for (int i = 0; i < 3; i++)
+    for (int k = 0; k < ND; k++) { C.xpowq[i][k] = acc.c[i].v[k]; C.xpowq2[i][k] = sq.c[i].v[k]; }
+  *out = C;
+}
+
+}  // namespace pbc

@@ -14,6 +14,7 @@
 #include "fp.cuh"
 #include "hostbn.h"
 #include "pairing_a.cuh"
+#include "pairing_d.cuh"
 
 using namespace pbc;
 
@@ -74,6 +75,23 @@ __global__ void __launch_bounds__(kBlock) a_prod_pairing_kernel(uint8_t *gt, con
     const uint4 *src = reinterpret_cast<const uint4 *>(out);
 #pragma unroll
     for (int i = 0; i < L / 16; i++) dst[i] = src[i];
+  }
+}
+
+// Type D: one k-term product (k = 1: a single pairing) per lane.  G1 records are 40 B, G2
+// 120 B, GT 120 B for d159.param.
+__global__ void __launch_bounds__(kBlock) d_prod_pairing_kernel(uint8_t *gt, const uint8_t *g1,
+                                                                 const uint8_t *g2, size_t n, int k) {
+  size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
+  size_t ld = idx < n ? idx : n - 1;
+  constexpr int L1 = 8 * ND, L2 = 24 * ND, LT = 24 * ND;
+  __attribute__((aligned(4))) uint8_t out[LT];
+  d_prod_pairing_lane(out, g1 + ld * k * L1, g2 + ld * k * L2, k);
+  if (idx < n) {
+    uint32_t *dst = reinterpret_cast<uint32_t *>(gt + idx * LT);
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(out);
+#pragma unroll
+    for (int i = 0; i < LT / 4; i++) dst[i] = src[i];
   }
 }
 
@@ -253,7 +271,11 @@ struct pbc_hip_pairing_s {
   FpK<16> k16;
   FpK<5> k5;
   AConst a;
+  DRaw draw;                 // type D: canonical parameter words for the device-side derivation
+  DConst dconst;             // type D: derived tower constants (filled on first use)
+  bool dev_ready;            // derived constants computed on the device
   double fq_muls_single;     // reference F_q multiplication count per pairing (work model)
+  double fq_muls_prod_a, fq_muls_prod_b;   // products: a*k + b
 };
 
 template <int N>
@@ -307,6 +329,58 @@ static int init_type_a(pbc_hip_pairing_s *P, const char *txt, size_t len) {
   if (P->len_fq != 64) return fail("type a: q must serialise to 64 bytes");
   P->len1 = P->len2 = P->lenT = 2 * P->len_fq;
   P->fq_muls_single = 4392.0;            // SURVEY.md 8d (instrumented reference, a.param)
+  // a_pairings_affine (a_param.c:1283-1383): 41377 F_q products for k = 16;
+  // linear model through (1, 4392-ish) and (16, 41377): 2543 k + 689
+  P->fq_muls_prod_a = 2543.0;
+  P->fq_muls_prod_b = 689.0;
+  return 0;
+}
+
+// d_init_pairing (ecc/d_param.c:993-1095) + pbc_param_init_d: host part (integers only);
+// the tower constants are derived on the device at first use (pairing_d.cuh d_init_stage*).
+static int init_type_d(pbc_hip_pairing_s *P, const char *txt, size_t len) {
+  using namespace pbc_host;
+  Big q, r, a, b, nqr, co[3];
+  int k;
+  if (!param_big(txt, len, "q", q) || !param_big(txt, len, "r", r) || !param_big(txt, len, "a", a) ||
+      !param_big(txt, len, "b", b) || !param_big(txt, len, "nqr", nqr) || !param_int(txt, len, "k", k) ||
+      !param_big(txt, len, "coeff0", co[0]) || !param_big(txt, len, "coeff1", co[1]) ||
+      !param_big(txt, len, "coeff2", co[2]))
+    return fail("type d: missing q/r/a/b/k/coeff0..2/nqr");
+  if (k != 6) return fail("type d: only embedding degree 6 is supported (got %d)", k);
+  if (fill_fpk<5>(P->k5, q)) return fail("type d: only 129..160-bit q is supported by this build (got %d bits)", q.bits());
+  if (Big::cmp(a, q) >= 0 || Big::cmp(b, q) >= 0 || Big::cmp(nqr, q) >= 0) return fail("type d: coefficient >= q");
+  memset(&P->draw, 0, sizeof P->draw);
+  memset(&P->dconst, 0, sizeof P->dconst);
+  a.to_words(P->draw.a, ND);
+  b.to_words(P->draw.b, ND);
+  nqr.to_words(P->draw.nqr, ND);
+  for (int i = 0; i < 3; i++) {
+    if (Big::cmp(co[i], q) >= 0) return fail("type d: coefficient >= q");
+    co[i].to_words(P->draw.coeff[i], ND);
+  }
+  q.to_words(P->draw.q, ND + 1);
+  P->draw.qbits = q.bits();
+  if (r.bits() > 256 || r.bits() < 3) return fail("type d: bad r");
+  r.to_words(P->dconst.r, 8);
+  P->dconst.rbits = r.bits();
+  // phikonr = (q^2 - q + 1)/r (d_param.c:1036-1042)
+  Big z = Big::mul(q, q);
+  z.sub(q);
+  z.add_small(1);
+  Big rem;
+  Big phik = Big::div(z, r, &rem);
+  if (!rem.is_zero() || phik.bits() > 256) return fail("type d: r does not divide q^2 - q + 1");
+  phik.to_words(P->dconst.phik, 8);
+  P->dconst.phikbits = phik.bits();
+  P->nlimb = 5;
+  P->len_fq = (q.bits() + 7) / 8;
+  if (P->len_fq != 20) return fail("type d: q must serialise to 20 bytes");
+  P->len1 = 2 * P->len_fq;
+  P->len2 = P->lenT = 6 * P->len_fq;
+  P->fq_muls_single = 26451.0;           // SURVEY.md 8d (instrumented reference, d159.param)
+  P->fq_muls_prod_a = 26451.0 - 4197.0;  // per-term Miller work + one cc_tatepower (4197)
+  P->fq_muls_prod_b = 4197.0;
   return 0;
 }
 
@@ -320,6 +394,9 @@ extern "C" int pbc_hip_pairing_init_set_buf(pbc_hip_pairing_t **out, const char 
   if (type == "a") {
     P->type = 'a';
     rc = init_type_a(P, param, len);
+  } else if (type == "d") {
+    P->type = 'd';
+    rc = init_type_d(P, param, len);
   } else {
     rc = fail("pairing type '%s' is not built into libpbc_hip yet", type.c_str());
   }
@@ -345,11 +422,7 @@ extern "C" int pbc_hip_length_in_bytes_Fq(const pbc_hip_pairing_t *p) { return p
 extern "C" double pbc_hip_algorithmic_macs_per_unit(const pbc_hip_pairing_t *p, int k) {
   double n = p->nlimb;
   double per_mul = 2 * n * n + n;
-  if (p->type == 'a' && k > 1) {
-    // a_pairings_affine (a_param.c:1283-1383): measured 41377 for k=16;
-    // general k: exp2*(2 + k*(5+3+ ~8)) ... use the measured affine model 2543*k + 689
-    return (2543.0 * k + 689.0) * per_mul;
-  }
+  if (k > 1) return (p->fq_muls_prod_a * k + p->fq_muls_prod_b) * per_mul;
   return p->fq_muls_single * per_mul;
 }
 
@@ -361,6 +434,21 @@ static int upload_constants(pbc_hip_pairing_s *P, hipStream_t s) {
     HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_fpk5), &P->k5, sizeof P->k5, 0, hipMemcpyHostToDevice, s));
   if (P->type == 'a')
     HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_a), &P->a, sizeof P->a, 0, hipMemcpyHostToDevice, s));
+  if (P->type == 'd') {
+    if (!P->dev_ready) {
+      // one-time derivation of the tower constants on the device (two single-lane kernels)
+      DConst *dbuf;
+      HIP_TRY(hipMalloc(&dbuf, sizeof(DConst)));
+      hipLaunchKernelGGL(d_init_stage1, dim3(1), dim3(64), 0, s, dbuf, P->draw, P->dconst);
+      HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_d), dbuf, sizeof(DConst), 0, hipMemcpyDeviceToDevice, s));
+      hipLaunchKernelGGL(d_init_stage2, dim3(1), dim3(64), 0, s, dbuf, P->draw);
+      HIP_TRY(hipMemcpyAsync(&P->dconst, dbuf, sizeof(DConst), hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipStreamSynchronize(s));
+      (void) hipFree(dbuf);
+      P->dev_ready = true;
+    }
+    HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_d), &P->dconst, sizeof P->dconst, 0, hipMemcpyHostToDevice, s));
+  }
   return 0;
 }
 
@@ -375,6 +463,9 @@ extern "C" int pbc_hip_element_pairing_batch_dev(pbc_hip_pairing_t *P, void *d_g
   if (P->type == 'a') {
     hipLaunchKernelGGL(a_pairing_kernel<16>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
                        (const uint8_t *) d_g1, (const uint8_t *) d_g2, n);
+  } else if (P->type == 'd') {
+    hipLaunchKernelGGL(d_prod_pairing_kernel, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
+                       (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, 1);
   } else {
     return fail("unsupported type");
   }
@@ -439,6 +530,9 @@ extern "C" int pbc_hip_element_prod_pairing_batch_dev(pbc_hip_pairing_t *P, void
   if (P->type == 'a') {
     hipLaunchKernelGGL(a_prod_pairing_kernel<16>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
                        (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k);
+  } else if (P->type == 'd') {
+    hipLaunchKernelGGL(d_prod_pairing_kernel, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
+                       (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k);
   } else {
     return fail("unsupported type");
   }
@@ -474,7 +568,8 @@ extern "C" int pbc_hip_fq_op_batch(pbc_hip_pairing_t *P, int op, uint8_t *c, con
     hipLaunchKernelGGL(fq_op_kernel<16>, dim3(grid), dim3(kBlock), 0, 0, op, (uint8_t *) dc,
                        (const uint8_t *) da, (const uint8_t *) db, n);
   else
-    return fail("unsupported limb count");
+    hipLaunchKernelGGL(fq_op_kernel<5>, dim3(grid), dim3(kBlock), 0, 0, op, (uint8_t *) dc,
+                       (const uint8_t *) da, (const uint8_t *) db, n);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpy(c, dc, bytes, hipMemcpyDeviceToHost));
   (void) hipFree(da);

@@ -59,7 +59,12 @@ def oracles():
 def hips():
     """type letter -> the product (libpbc_hip.so)"""
     import pbc_amd
-    return {t: pbc_amd.Pairing(_param(n)) for t, n in PARAM_OF.items()}
+
+    class Lazy(dict):
+        def __missing__(self, t):
+            self[t] = pbc_amd.Pairing(_param(PARAM_OF[t]))   # raises if the type is not built in
+            return self[t]
+    return Lazy()
 
 
 def golden(name):

@@ -154,3 +154,81 @@ def test_prod_pairing_vs_oracle_and_naive_product(hip_a, oracle_a):
 def test_prod_pairing_k1_equals_pairing(hip_a):
     v = golden("a_rand32.vec")
     assert np.array_equal(hip_a.element_prod_pairing(v.g1, v.g2, 1), v.gt)
+
+
+# ---- Types D (d159, MNT k=6) and F (BN k=12): SURVEY.md 8a rows a15-a17 ------------------
+DF_FILES = {
+    "d": dict(single=["d_rand32.vec", "d_edge20.vec", "d_chain256.vec"], prod=["d_prod16x4.vec", "d_prod3x10_edge.vec"],
+              chain="d_chain256.vec", rand="d_rand32.vec"),
+    "f": dict(single=["f_rand16.vec", "f_edge10.vec", "f_chain128.vec"], prod=["f_prod4x3.vec", "f_prod3x5_edge.vec"],
+              chain="f_chain128.vec", rand="f_rand16.vec"),
+}
+
+
+def _types_built(hips):
+    return [t for t in "df" if t in hips]
+
+
+@pytest.mark.parametrize("t", ["d", "f"])
+def test_df_fq_ops_vs_oracle(hips, oracles, t):
+    q = {"d": 625852803282871856053922297323874661378036491717,
+         "f": 205523667896953300194896352429254920972540065223}[t]
+    rng = np.random.default_rng(9)
+    xs = [int.from_bytes(rng.bytes(20), "big") % q for _ in range(500)] + [0, 1, q - 1, 2**160 - 1]
+    ys = [int.from_bytes(rng.bytes(20), "big") % q for _ in range(500)] + [q - 1, 0, q - 1, 2**160 - 1]
+    A = np.stack([_be(x, 20) for x in xs])
+    B = np.stack([_be(y, 20) for y in ys])
+    for op in range(7):
+        got = hips[t].fq_op(op, A, B)
+        want = oracles[t].fq_op(op, A, B)
+        if op == 3:
+            keep = np.array([x % q != 0 for x in xs])
+            got, want = got[keep], want[keep]
+        assert np.array_equal(got, want), "fq op %d" % op
+
+
+@pytest.mark.parametrize("t,name", [(t, n) for t in "df" for n in DF_FILES[t]["single"]])
+def test_df_pairing_matches_reference_vectors(hips, t, name):
+    v = golden(name)
+    assert np.array_equal(hips[t].element_pairing(v.g1, v.g2), v.gt)
+
+
+@pytest.mark.parametrize("t,name", [(t, n) for t in "df" for n in DF_FILES[t]["prod"]])
+def test_df_prod_pairing_matches_reference_vectors(hips, t, name):
+    v = golden(name)
+    assert np.array_equal(hips[t].element_prod_pairing(v.g1, v.g2, v.k), v.gt)
+
+
+@pytest.mark.parametrize("t", ["d", "f"])
+def test_df_cross_pairs_vs_oracle_and_symmetry(hips, oracles, t):
+    """(P_i, Q_j) pairs the fixtures do not hold; e(P_i,Q_j) = e(P_j,Q_i) since P_i=(i+1)P0, Q_j=(j+1)Q0."""
+    v = golden(DF_FILES[t]["chain"])
+    m = 24
+    i, j = np.meshgrid(np.arange(m), np.arange(m), indexing="ij")
+    got = hips[t].element_pairing(v.g1[i.ravel()], v.g2[j.ravel()]).reshape(m, m, -1)
+    assert np.array_equal(got, got.transpose(1, 0, 2))
+    assert np.array_equal(got[np.arange(m), np.arange(m)], v.gt[:m])
+    rng = np.random.default_rng(13)
+    ii, jj = rng.integers(0, m, 12), rng.integers(0, m, 12)
+    assert np.array_equal(got[ii, jj], oracles[t].pairing_batch(v.g1[ii], v.g2[jj]))
+
+
+@pytest.mark.parametrize("t", ["d", "f"])
+@pytest.mark.parametrize("n", [0, 1, 65, 130])
+def test_df_ragged_batch_sizes(hips, t, n):
+    v = golden(DF_FILES[t]["chain"])
+    n = min(n, v.n)
+    out = hips[t].element_pairing(v.g1[:n], v.g2[:n])
+    assert out.shape == (n, hips[t].length_in_bytes_GT)
+    assert np.array_equal(out, v.gt[:n])
+
+
+@pytest.mark.parametrize("t", ["d", "f"])
+def test_df_bilinearity(hips, oracles, t):
+    v = golden(DF_FILES[t]["rand"])
+    a = 3 * 2**90 + 12345
+    P, Q = v.g1[:3], v.g2[:3]
+    aP = oracles[t].g_mul(1, P, np.tile(_be(a, 20), (3, 1)))
+    lhs = hips[t].element_pairing(aP, Q)
+    rhs = oracles[t].gt_pow(hips[t].element_pairing(P, Q), np.tile(_be(a, 20), (3, 1)))
+    assert np.array_equal(lhs, rhs)

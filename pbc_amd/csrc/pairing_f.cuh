@@ -1,0 +1,434 @@
+// pairing_f.cuh -- Type F (Barreto-Naehrig curve y^2 = x^3 + b over F_q, embedding degree 12)
+// reduced Tate pairing, one pairing per lane.
+//
+// Computes the same GT value as the reference's f_pairing (ecc/f_param.c:289-311):
+// untwisting by negalphainv, cc_miller_no_denom (:97-248) with the fused sparse line
+// multiplication f_miller_evalfn (:109-149), and f_tateexp (:250-283: Frobenius easy part,
+// then the (q^4 - q^2 + 1)/r power).  Towers as in the reference so that the output
+// serialises identically:  F_q^2 = F_q[sqrt(beta)] (fieldquadratic.c fq_*),
+// F_q^12 = F_q^2[x]/(x^6 + alpha) with basis 1, x, ..., x^5 (poly.c polymod, n = 6).
+//
+// GPU re-design:
+//   * Jacobian Miller loop on E(F_q) (the reference's affine loop: one F_q inversion per
+//     step, 215 per pairing); projective line coefficients differ by F_q^*
+//     factors which (q^12-1)/r removes;
+//   * the sparse line (a Qx x^4 + b Qy x^3 + c) is pre-multiplied once per step
+//     (a Qx, b Qy and their products with -alpha), then each output coefficient is two
+//     F_q^2 products and one F_q scaling;
+//   * an F_q^12 element is 60 words: it lives in per-lane private memory and the tower
+//     routines are rolled loops over coefficients (compact code, instruction-cache
+//     resident); all arithmetic happens on registers in F_q / F_q^2 granules;
+//   * the hard part of the final exponentiation uses a fixed 4-bit window.
+#pragma once
+#include "fp.cuh"
+#include "pairing_d.cuh"   // ND, fq, dk(), djac
+
+namespace pbc {
+
+struct g2 { fq x, y; };                // x + y sqrt(beta)
+struct f12 { g2 c[6]; };               // sum c_i X^i, X^6 = negalpha
+
+struct FConst {                        // f_pairing_data_s (ecc/f_param.c:35-45)
+  uint32_t B[ND];                      // curve b (Montgomery form)
+  uint32_t beta[ND];                   // nqr of F_q (f_param.c:345-348)
+  uint32_t negalpha[2][ND];            // X^6 (f_param.c:355-361)
+  uint32_t negalphainv[2][ND];
+  uint32_t xpowq2[2][ND], xpowq6[2][ND], xpowq8[2][ND];   // X^(q^k) = (this) X (f_param.c:431-444)
+  uint32_t tb[2][ND];                  // twist: y^2 = x^3 - alpha b (f_param.c:372-381)
+  uint32_t r[8];
+  uint32_t tateexp[16];                // (q^4 - q^2 + 1)/r (f_param.c:414-420)
+  int rbits, tebits;
+};
+__constant__ FConst c_f;
+
+PBC_DEV g2 fk2(const uint32_t (*w)[ND]) { g2 r; fp_set<ND>(r.x, w[0]); fp_set<ND>(r.y, w[1]); return r; }
+
+// ---- F_q^2 = F_q[sqrt(beta)] -------------------------------------------------------------
+PBC_DEV void g2_add(g2 &r, const g2 &a, const g2 &b) { fp_add<ND>(r.x, a.x, b.x); fp_add<ND>(r.y, a.y, b.y); }
+PBC_DEV void g2_sub(g2 &r, const g2 &a, const g2 &b) { fp_sub<ND>(r.x, a.x, b.x); fp_sub<ND>(r.y, a.y, b.y); }
+PBC_DEV void g2_dbl(g2 &r, const g2 &a) { fp_dbl<ND>(r.x, a.x); fp_dbl<ND>(r.y, a.y); }
+PBC_DEV void g2_neg(g2 &r, const g2 &a) { fp_neg<ND>(r.x, a.x); fp_neg<ND>(r.y, a.y); }
+PBC_DEV void g2_mul_fq(g2 &r, const g2 &a, const fq &s) { fp_mul<ND>(r.x, a.x, s); fp_mul<ND>(r.y, a.y, s); }
+PBC_DEV bool g2_eq(const g2 &a, const g2 &b) { return fp_eq<ND>(a.x, b.x) & fp_eq<ND>(a.y, b.y); }
+PBC_DEV void g2_zero(g2 &r) {
+#pragma unroll
+  for (int k = 0; k < ND; k++) { r.x.v[k] = 0; r.y.v[k] = 0; }
+}
+// fq_mul (fieldquadratic.c:197-233): Karatsuba + one product by beta
+PBC_DEV void g2_mul(g2 &r, const g2 &a, const g2 &b) {
+  fq e0, e1, e2, t;
+  fp_add<ND>(e0, a.x, a.y);
+  fp_add<ND>(e1, b.x, b.y);
+  fp_mul<ND>(e2, e0, e1);
+  fp_mul<ND>(e0, a.x, b.x);
+  fp_mul<ND>(e1, a.y, b.y);
+  fp_mul<ND>(t, e1, dk(c_f.beta));
+  fp_sub<ND>(e2, e2, e0);
+  fp_sub<ND>(r.y, e2, e1);
+  fp_add<ND>(r.x, t, e0);
+}
+// fq_square (fieldquadratic.c:249-269)
+PBC_DEV void g2_sqr(g2 &r, const g2 &a) {
+  fq e0, e1, t;
+  fp_sqr<ND>(e0, a.x);
+  fp_sqr<ND>(e1, a.y);
+  fp_mul<ND>(e1, e1, dk(c_f.beta));
+  fp_mul<ND>(t, a.x, a.y);
+  fp_add<ND>(r.x, e0, e1);
+  fp_dbl<ND>(r.y, t);
+}
+// fq_invert (fieldquadratic.c:290-309)
+PBC_DEV void g2_inv(g2 &r, const g2 &a) {
+  fq e0, e1;
+  fp_sqr<ND>(e0, a.x);
+  fp_sqr<ND>(e1, a.y);
+  fp_mul<ND>(e1, e1, dk(c_f.beta));
+  fp_sub<ND>(e0, e0, e1);
+  fp_inv<ND>(e0, e0);
+  fp_mul<ND>(r.x, a.x, e0);
+  fp_neg<ND>(e0, e0);
+  fp_mul<ND>(r.y, a.y, e0);
+}
+PBC_DEV void g2_load_be(g2 &r, const uint8_t *s) { fp_load_be<ND>(r.x, s); fp_load_be<ND>(r.y, s + 4 * ND); }
+PBC_DEV void g2_store_be(uint8_t *d, const g2 &a) { fp_store_be<ND>(d, a.x); fp_store_be<ND>(d + 4 * ND, a.y); }
+
+// ---- F_q^12 = F_q^2[X]/(X^6 + alpha): rolled loops over private-memory coefficients -------
+__device__ __noinline__ void f12_one(f12 *r) {
+  fq one;
+  fp_set<ND>(one, fpk<ND>().one);
+#pragma nounroll
+  for (int i = 0; i < 6; i++) g2_zero(r->c[i]);
+  r->c[0].x = one;
+}
+// polymod_mul (poly.c:1005-1047): schoolbook, X^(6+i) = negalpha X^i
+__device__ __noinline__ void f12_mul(f12 *r, const f12 *a, const f12 *b) {
+  g2 d[11];
+#pragma nounroll
+  for (int i = 0; i < 11; i++) g2_zero(d[i]);
+#pragma nounroll
+  for (int i = 0; i < 6; i++) {
+    g2 ai = a->c[i];
+#pragma nounroll
+    for (int j = 0; j < 6; j++) {
+      g2 t;
+      g2_mul(t, ai, b->c[j]);
+      g2_add(d[i + j], d[i + j], t);
+    }
+  }
+  const g2 na = fk2(c_f.negalpha);
+#pragma nounroll
+  for (int i = 0; i < 6; i++) {
+    g2 t = d[i];
+    if (i < 5) {
+      g2 u;
+      g2_mul(u, d[6 + i], na);
+      g2_add(t, t, u);
+    }
+    r->c[i] = t;
+  }
+}
+// polymod_square (poly.c:1091-1143)
+__device__ __noinline__ void f12_sqr(f12 *r, const f12 *a) {
+  g2 d[11];
+#pragma nounroll
+  for (int i = 0; i < 11; i++) g2_zero(d[i]);
+#pragma nounroll
+  for (int i = 0; i < 6; i++) {
+    g2 ai = a->c[i], t;
+    g2_sqr(t, ai);
+    g2_add(d[2 * i], d[2 * i], t);
+#pragma nounroll
+    for (int j = i + 1; j < 6; j++) {
+      g2_mul(t, ai, a->c[j]);
+      g2_dbl(t, t);
+      g2_add(d[i + j], d[i + j], t);
+    }
+  }
+  const g2 na = fk2(c_f.negalpha);
+#pragma nounroll
+  for (int i = 0; i < 6; i++) {
+    g2 t = d[i];
+    if (i < 5) {
+      g2 u;
+      g2_mul(u, d[6 + i], na);
+      g2_add(t, t, u);
+    }
+    r->c[i] = t;
+  }
+}
+// coefficient-wise even-power Frobenius: out^(q^k), X^(q^k) = e X (qpower, f_param.c:257-268)
+__device__ __noinline__ void f12_qpower(f12 *r, const f12 *a, const uint32_t (*ew)[ND]) {
+  const g2 e = fk2(ew);
+  g2 epow = e;
+  r->c[0] = a->c[0];
+#pragma nounroll
+  for (int i = 1; i < 6; i++) {
+    g2 t;
+    g2_mul(t, a->c[i], epow);
+    r->c[i] = t;
+    g2_mul(epow, epow, e);
+  }
+}
+// polymod_invert (poly.c:521-536): unique inverse; sigma = q^2-power Frobenius,
+// a^-1 = prod_{i=1..5} sigma^i(a) / N,  N = a * prod in F_q^2
+__device__ __noinline__ void f12_inv(f12 *r, const f12 *a) {
+  f12 s, t, n;
+  f12_qpower(&s, a, c_f.xpowq2);
+  t = s;
+#pragma nounroll
+  for (int i = 2; i <= 5; i++) {
+    f12_qpower(&s, &s, c_f.xpowq2);
+    f12_mul(&t, &t, &s);
+  }
+  f12_mul(&n, a, &t);
+  g2 ni;
+  g2_inv(ni, n.c[0]);
+#pragma nounroll
+  for (int i = 0; i < 6; i++) {
+    g2 u;
+    g2_mul(u, t.c[i], ni);
+    r->c[i] = u;
+  }
+}
+
+// v <- v * (a Qx X^4 + b Qy X^3 + c)   (f_miller_evalfn, f_param.c:109-149)
+// out_i = c v_i + [aQx] v_{i-4} + [bQy] v_{i-3}, indices mod 6 with a factor negalpha on wrap
+__device__ __noinline__ void f_line_mul(f12 *v, const fq a, const fq b, const fq c, const g2 *Qx, const g2 *Qy) {
+  g2 aq, bq, aqn, bqn;
+  const g2 na = fk2(c_f.negalpha);
+  g2_mul_fq(aq, *Qx, a);
+  g2_mul_fq(bq, *Qy, b);
+  g2_mul(aqn, aq, na);
+  g2_mul(bqn, bq, na);
+  f12 e0;
+#pragma nounroll
+  for (int i = 0; i < 6; i++) {
+    int j = i + 2, k = i + 3;          // j = i - 4 mod 6, k = i - 3 mod 6
+    bool wj = true, wk = true;         // wrapped (needs negalpha) unless i >= 4 / i >= 3
+    if (j >= 6) { j -= 6; wj = false; }
+    if (k >= 6) { k -= 6; wk = false; }
+    g2 t, u;
+    g2_mul(t, v->c[j], wj ? aqn : aq);
+    g2_mul(u, v->c[k], wk ? bqn : bq);
+    g2_add(t, t, u);
+    g2_mul_fq(u, v->c[i], c);
+    g2_add(t, t, u);
+    e0.c[i] = t;
+  }
+  *v = e0;
+}
+
+// Miller function: G1 bytes x||y (2 x 20), G2 bytes x||y over F_q^2 (2 x 40)
+__device__ __noinline__ bool f_miller_lane(f12 *v, const uint8_t *g1, const uint8_t *g2b) {
+  constexpr int NB = 4 * ND;
+  fq Px, Py, one;
+  g2 Qx, Qy;
+  fp_set<ND>(one, fpk<ND>().one);
+  fp_load_be<ND>(Px, g1);
+  fp_load_be<ND>(Py, g1 + NB);
+  g2_load_be(Qx, g2b);
+  g2_load_be(Qy, g2b + 2 * NB);
+  bool valid;
+  {
+    // curve_is_valid_point (curve.c:57-77): E: y^2 = x^3 + b;  E': y^2 = x^3 - alpha b over F_q^2
+    fq t0, t1;
+    fp_sqr<ND>(t0, Px);
+    fp_mul<ND>(t0, t0, Px);
+    fp_add<ND>(t0, t0, dk(c_f.B));
+    fp_sqr<ND>(t1, Py);
+    valid = fp_eq<ND>(t0, t1);
+    g2 u0, u1;
+    g2_sqr(u0, Qx);
+    g2_mul(u0, u0, Qx);
+    g2_add(u0, u0, fk2(c_f.tb));
+    g2_sqr(u1, Qy);
+    valid &= g2_eq(u0, u1);
+  }
+  // untwist: (x, y) -> (x negalphainv X^4, y negalphainv X^3)  (f_pairing, f_param.c:296-303)
+  {
+    const g2 ni = fk2(c_f.negalphainv);
+    g2_mul(Qx, Qx, ni);
+    g2_mul(Qy, Qy, ni);
+  }
+  djac V;
+  V.X = Px; V.Y = Py; V.Z = one; V.ZZ = one;
+  f12_one(v);
+  // cc_miller_no_denom (f_param.c:216-233): tangent; [double; line+add]; square
+  for (int m = c_f.rbits - 2;; m--) {
+    {
+      // tangent (do_tangent :171-184, a = 0), scaled by Z^6: M = 3X^2,
+      //   a' = -M Z^2, b' = (2YZ) Z^2, c' = M X - 2Y^2;  then V <- 2V
+      fq XX, YY, M, t0, t1, S, Z3, la, lb, lc;
+      fp_sqr<ND>(XX, V.X);
+      fp_sqr<ND>(YY, V.Y);
+      fp_dbl<ND>(M, XX);
+      fp_add<ND>(M, M, XX);
+      fp_mul<ND>(la, M, V.ZZ);
+      fp_neg<ND>(la, la);
+      fp_mul<ND>(Z3, V.Y, V.Z);
+      fp_dbl<ND>(Z3, Z3);
+      fp_mul<ND>(lb, Z3, V.ZZ);
+      fp_mul<ND>(lc, M, V.X);
+      fp_dbl<ND>(t1, YY);
+      fp_sub<ND>(lc, lc, t1);
+      f_line_mul(v, la, lb, lc, &Qx, &Qy);
+      fp_mul<ND>(S, V.X, YY);
+      fp_dbl<ND>(S, S);
+      fp_dbl<ND>(S, S);
+      fp_sqr<ND>(t0, YY);
+      fp_dbl<ND>(t0, t0);
+      fp_dbl<ND>(t0, t0);
+      fp_dbl<ND>(t0, t0);
+      fp_sqr<ND>(V.X, M);
+      fp_dbl<ND>(t1, S);
+      fp_sub<ND>(V.X, V.X, t1);
+      fp_sub<ND>(t1, S, V.X);
+      fp_mul<ND>(t1, M, t1);
+      fp_sub<ND>(V.Y, t1, t0);
+      V.Z = Z3;
+      fp_sqr<ND>(V.ZZ, Z3);
+    }
+    if (m <= 0) break;
+    if ((c_f.r[m >> 5] >> (m & 31)) & 1) {
+      // chord through V and P (do_line :190-199), scaled by Z3 = Z H:
+      //   a' = -R, b' = Z3, c' = R Px - Z3 Py;  V <- V + P
+      fq H, R, HH, HHH, t0, t1, Z3, la, lc;
+      fp_mul<ND>(H, Px, V.ZZ);
+      fp_sub<ND>(H, H, V.X);
+      fp_mul<ND>(t0, V.Z, V.ZZ);
+      fp_mul<ND>(R, Py, t0);
+      fp_sub<ND>(R, R, V.Y);
+      fp_mul<ND>(Z3, V.Z, H);
+      fp_neg<ND>(la, R);
+      fp_mul<ND>(lc, R, Px);
+      fp_mul<ND>(t0, Z3, Py);
+      fp_sub<ND>(lc, lc, t0);
+      f_line_mul(v, la, Z3, lc, &Qx, &Qy);
+      fp_sqr<ND>(HH, H);
+      fp_mul<ND>(HHH, HH, H);
+      fp_mul<ND>(t0, V.X, HH);
+      fp_sqr<ND>(t1, R);
+      fp_sub<ND>(t1, t1, HHH);
+      fp_sub<ND>(t1, t1, t0);
+      fp_sub<ND>(t1, t1, t0);
+      fp_sub<ND>(t0, t0, t1);
+      fp_mul<ND>(t0, R, t0);
+      fp_mul<ND>(HHH, V.Y, HHH);
+      fp_sub<ND>(V.Y, t0, HHH);
+      V.X = t1;
+      V.Z = Z3;
+      fp_sqr<ND>(V.ZZ, Z3);
+    }
+    f12_sqr(v, v);
+  }
+  return valid;
+}
+
+// f_tateexp (f_param.c:250-283)
+__device__ __noinline__ void f_final_exp(f12 *out) {
+  f12 x, y;
+  f12_qpower(&y, out, c_f.xpowq8);
+  f12_qpower(&x, out, c_f.xpowq6);
+  f12_mul(&y, &y, &x);
+  f12_qpower(&x, out, c_f.xpowq2);
+  f12_mul(&x, &x, out);
+  f12_inv(&x, &x);
+  f12_mul(out, &y, &x);
+  // element_pow_mpz(out, out, tateexp): generic_pow_mpz (field.c:14-126) is a sliding window;
+  // any addition chain gives the same group element.  Fixed 4-bit window here.
+  f12 tab[16];
+  f12_one(&tab[0]);
+  tab[1] = *out;
+#pragma nounroll
+  for (int i = 2; i < 16; i++) f12_mul(&tab[i], &tab[i - 1], out);
+  f12 acc;
+  f12_one(&acc);
+  int top = (c_f.tebits + 3) / 4 * 4;
+#pragma nounroll
+  for (int i = top - 4; i >= 0; i -= 4) {
+    if (i != top - 4) {
+      f12_sqr(&acc, &acc);
+      f12_sqr(&acc, &acc);
+      f12_sqr(&acc, &acc);
+      f12_sqr(&acc, &acc);
+    }
+    uint32_t w = (c_f.tateexp[i >> 5] >> (i & 31)) & 15;   // windows never straddle a word
+    if (w) f12_mul(&acc, &acc, &tab[w]);
+  }
+  *out = acc;
+}
+
+// element_pairing (f_pairing) / element_prod_pairing (generic_prod_pairings, ecc/pairing.c:35-46:
+// Type F installs no dedicated product routine; the product of k reduced pairings equals the
+// reduced product of the Miller functions) for one lane
+__device__ void f_prod_pairing_lane(uint8_t *gt, const uint8_t *g1, const uint8_t *g2b, int k) {
+  f12 F;
+  bool valid = f_miller_lane(&F, g1, g2b);
+  for (int j = 1; j < k; j++) {
+    f12 f;
+    valid &= f_miller_lane(&f, g1 + (size_t) j * 8 * ND, g2b + (size_t) j * 16 * ND);
+    f12_mul(&F, &F, &f);
+  }
+  f_final_exp(&F);
+  if (!valid) f12_one(&F);
+#pragma nounroll
+  for (int i = 0; i < 6; i++) g2_store_be(gt + 8 * ND * i, F.c[i]);
+}
+
+// ---- device-side derivation of the tower constants ---------------------------------------
+struct FRaw { uint32_t b[ND], beta[ND], alpha0[ND], alpha1[ND]; uint32_t e6[ND + 1]; int e6bits; };
+
+// stage 1: F_q-level constants and negalpha (beta must be in c_f before any g2_mul)
+__global__ void f_init_stage1(FConst *out, FRaw raw, FConst base) {
+  if (threadIdx.x || blockIdx.x) return;
+  FConst C = base;
+  fq r2, t, b, be, a0, a1;
+  fp_set<ND>(r2, fpk<ND>().r2);
+  fp_set<ND>(t, raw.b); fp_mul<ND>(b, t, r2);
+  fp_set<ND>(t, raw.beta); fp_mul<ND>(be, t, r2);
+  fp_set<ND>(t, raw.alpha0); fp_mul<ND>(a0, t, r2); fp_neg<ND>(a0, a0);
+  fp_set<ND>(t, raw.alpha1); fp_mul<ND>(a1, t, r2); fp_neg<ND>(a1, a1);
+  for (int k = 0; k < ND; k++) {
+    C.B[k] = b.v[k]; C.beta[k] = be.v[k];
+    C.negalpha[0][k] = a0.v[k]; C.negalpha[1][k] = a1.v[k];
+  }
+  *out = C;
+}
+// stage 2 (c_f holds stage 1): negalphainv, twist b, and the Frobenius constants:
+//   X^q = negalpha^((q-1)/6) X =: c X,  X^(q^2) = conj(c) c X = N(c) X,  X^(q^6) = N(c)^3 X,
+//   X^(q^8) = N(c)^4 X   (the reference gets the same values by brute-force powering,
+//   f_param.c:431-444)
+__global__ void f_init_stage2(FConst *out, FRaw raw) {
+  if (threadIdx.x || blockIdx.x) return;
+  FConst C = c_f;
+  const g2 na = fk2(c_f.negalpha);
+  g2 ni, tb, c;
+  g2_inv(ni, na);
+  g2_mul_fq(tb, na, dk(c_f.B));
+  fq one;
+  fp_set<ND>(one, fpk<ND>().one);
+  g2_zero(c);
+  c.x = one;
+  for (int i = raw.e6bits - 1; i >= 0; i--) {
+    g2_sqr(c, c);
+    if ((raw.e6[i >> 5] >> (i & 31)) & 1) g2_mul(c, c, na);
+  }
+  fq n, n2, n3, n4, t;
+  fp_sqr<ND>(n, c.x);
+  fp_sqr<ND>(t, c.y);
+  fp_mul<ND>(t, t, dk(c_f.beta));
+  fp_sub<ND>(n, n, t);                 // N(c) = c conj(c)
+  fp_sqr<ND>(n2, n);
+  fp_mul<ND>(n3, n2, n);
+  fp_sqr<ND>(n4, n2);
+  for (int k = 0; k < ND; k++) {
+    C.negalphainv[0][k] = ni.x.v[k]; C.negalphainv[1][k] = ni.y.v[k];
+    C.tb[0][k] = tb.x.v[k]; C.tb[1][k] = tb.y.v[k];
+    C.xpowq2[0][k] = n.v[k];  C.xpowq2[1][k] = 0;
+    C.xpowq6[0][k] = n3.v[k]; C.xpowq6[1][k] = 0;
+    C.xpowq8[0][k] = n4.v[k]; C.xpowq8[1][k] = 0;
+  }
+  *out = C;
+}
+
+}  // namespace pbc

@@ -15,6 +15,7 @@
 #include "hostbn.h"
 #include "pairing_a.cuh"
 #include "pairing_d.cuh"
+#include "pairing_f.cuh"
 
 using namespace pbc;
 
@@ -87,6 +88,22 @@ __global__ void __launch_bounds__(kBlock) d_prod_pairing_kernel(uint8_t *gt, con
   constexpr int L1 = 8 * ND, L2 = 24 * ND, LT = 24 * ND;
   __attribute__((aligned(4))) uint8_t out[LT];
   d_prod_pairing_lane(out, g1 + ld * k * L1, g2 + ld * k * L2, k);
+  if (idx < n) {
+    uint32_t *dst = reinterpret_cast<uint32_t *>(gt + idx * LT);
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(out);
+#pragma unroll
+    for (int i = 0; i < LT / 4; i++) dst[i] = src[i];
+  }
+}
+
+// Type F: one k-term product (k = 1: a single pairing) per lane.  G1 40 B, G2 80 B, GT 240 B.
+__global__ void __launch_bounds__(kBlock) f_prod_pairing_kernel(uint8_t *gt, const uint8_t *g1,
+                                                                 const uint8_t *g2, size_t n, int k) {
+  size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
+  size_t ld = idx < n ? idx : n - 1;
+  constexpr int L1 = 8 * ND, L2 = 16 * ND, LT = 48 * ND;
+  __attribute__((aligned(4))) uint8_t out[LT];
+  f_prod_pairing_lane(out, g1 + ld * k * L1, g2 + ld * k * L2, k);
   if (idx < n) {
     uint32_t *dst = reinterpret_cast<uint32_t *>(gt + idx * LT);
     const uint32_t *src = reinterpret_cast<const uint32_t *>(out);
@@ -273,6 +290,8 @@ struct pbc_hip_pairing_s {
   AConst a;
   DRaw draw;                 // type D: canonical parameter words for the device-side derivation
   DConst dconst;             // type D: derived tower constants (filled on first use)
+  FRaw fraw;                 // type F: canonical parameter words
+  FConst fconst;             // type F: derived tower constants (filled on first use)
   bool dev_ready;            // derived constants computed on the device
   double fq_muls_single;     // reference F_q multiplication count per pairing (work model)
   double fq_muls_prod_a, fq_muls_prod_b;   // products: a*k + b
@@ -384,6 +403,54 @@ static int init_type_d(pbc_hip_pairing_s *P, const char *txt, size_t len) {
   return 0;
 }
 
+// f_init_pairing (ecc/f_param.c:335-447): host part (integers only)
+static int init_type_f(pbc_hip_pairing_s *P, const char *txt, size_t len) {
+  using namespace pbc_host;
+  Big q, r, b, beta, a0, a1;
+  if (!param_big(txt, len, "q", q) || !param_big(txt, len, "r", r) || !param_big(txt, len, "b", b) ||
+      !param_big(txt, len, "beta", beta) || !param_big(txt, len, "alpha0", a0) || !param_big(txt, len, "alpha1", a1))
+    return fail("type f: missing q/r/b/beta/alpha0/alpha1");
+  if (fill_fpk<5>(P->k5, q)) return fail("type f: only 129..160-bit q is supported by this build (got %d bits)", q.bits());
+  if (Big::cmp(b, q) >= 0 || Big::cmp(beta, q) >= 0 || Big::cmp(a0, q) >= 0 || Big::cmp(a1, q) >= 0)
+    return fail("type f: coefficient >= q");
+  memset(&P->fraw, 0, sizeof P->fraw);
+  memset(&P->fconst, 0, sizeof P->fconst);
+  b.to_words(P->fraw.b, ND);
+  beta.to_words(P->fraw.beta, ND);
+  a0.to_words(P->fraw.alpha0, ND);
+  a1.to_words(P->fraw.alpha1, ND);
+  // (q - 1)/6: X^q = negalpha^((q-1)/6) X
+  Big qm1 = q, six, rem;
+  qm1.sub_small(1);
+  six.w.push_back(6);
+  Big e6 = Big::div(qm1, six, &rem);
+  if (!rem.is_zero()) return fail("type f: q must be 1 mod 6");
+  e6.to_words(P->fraw.e6, ND + 1);
+  P->fraw.e6bits = e6.bits();
+  if (r.bits() > 256 || r.bits() < 3) return fail("type f: bad r");
+  r.to_words(P->fconst.r, 8);
+  P->fconst.rbits = r.bits();
+  // tateexp = ((q^2 - 1) q^2 + 1)/r (f_param.c:414-420)
+  Big q2 = Big::mul(q, q), z = q2;
+  z.sub_small(1);
+  z = Big::mul(z, q2);
+  z.add_small(1);
+  Big te = Big::div(z, r, &rem);
+  if (!rem.is_zero() || te.bits() > 512) return fail("type f: r does not divide q^4 - q^2 + 1");
+  te.to_words(P->fconst.tateexp, 16);
+  P->fconst.tebits = te.bits();
+  P->nlimb = 5;
+  P->len_fq = (q.bits() + 7) / 8;
+  if (P->len_fq != 20) return fail("type f: q must serialise to 20 bytes");
+  P->len1 = 2 * P->len_fq;
+  P->len2 = 4 * P->len_fq;
+  P->lenT = 12 * P->len_fq;
+  P->fq_muls_single = 172887.0;          // SURVEY.md 8d (instrumented reference, f.param)
+  P->fq_muls_prod_a = 172887.0;          // generic_prod_pairings: k full pairings
+  P->fq_muls_prod_b = 0.0;
+  return 0;
+}
+
 extern "C" int pbc_hip_pairing_init_set_buf(pbc_hip_pairing_t **out, const char *param, size_t len) {
   if (!out || !param) return fail("null argument");
   if (!len) len = strlen(param);
@@ -397,6 +464,9 @@ extern "C" int pbc_hip_pairing_init_set_buf(pbc_hip_pairing_t **out, const char 
   } else if (type == "d") {
     P->type = 'd';
     rc = init_type_d(P, param, len);
+  } else if (type == "f") {
+    P->type = 'f';
+    rc = init_type_f(P, param, len);
   } else {
     rc = fail("pairing type '%s' is not built into libpbc_hip yet", type.c_str());
   }
@@ -449,6 +519,20 @@ static int upload_constants(pbc_hip_pairing_s *P, hipStream_t s) {
     }
     HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_d), &P->dconst, sizeof P->dconst, 0, hipMemcpyHostToDevice, s));
   }
+  if (P->type == 'f') {
+    if (!P->dev_ready) {
+      FConst *dbuf;
+      HIP_TRY(hipMalloc(&dbuf, sizeof(FConst)));
+      hipLaunchKernelGGL(f_init_stage1, dim3(1), dim3(64), 0, s, dbuf, P->fraw, P->fconst);
+      HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_f), dbuf, sizeof(FConst), 0, hipMemcpyDeviceToDevice, s));
+      hipLaunchKernelGGL(f_init_stage2, dim3(1), dim3(64), 0, s, dbuf, P->fraw);
+      HIP_TRY(hipMemcpyAsync(&P->fconst, dbuf, sizeof(FConst), hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipStreamSynchronize(s));
+      (void) hipFree(dbuf);
+      P->dev_ready = true;
+    }
+    HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_f), &P->fconst, sizeof P->fconst, 0, hipMemcpyHostToDevice, s));
+  }
   return 0;
 }
 
@@ -465,6 +549,9 @@ extern "C" int pbc_hip_element_pairing_batch_dev(pbc_hip_pairing_t *P, void *d_g
                        (const uint8_t *) d_g1, (const uint8_t *) d_g2, n);
   } else if (P->type == 'd') {
     hipLaunchKernelGGL(d_prod_pairing_kernel, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
+                       (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, 1);
+  } else if (P->type == 'f') {
+    hipLaunchKernelGGL(f_prod_pairing_kernel, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
                        (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, 1);
   } else {
     return fail("unsupported type");
@@ -532,6 +619,9 @@ extern "C" int pbc_hip_element_prod_pairing_batch_dev(pbc_hip_pairing_t *P, void
                        (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k);
   } else if (P->type == 'd') {
     hipLaunchKernelGGL(d_prod_pairing_kernel, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
+                       (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k);
+  } else if (P->type == 'f') {
+    hipLaunchKernelGGL(f_prod_pairing_kernel, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
                        (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k);
   } else {
     return fail("unsupported type");

@@ -83,6 +83,12 @@ int pbc_hip_int_mac_peak(int variant, int iters, double *mac_per_s, double *ms);
  * dedicated squaring. */
 int pbc_hip_diag_mul_bench(int variant, int iters, int waves_per_simd, double *mul_per_s, double *ms);
 
+/* Diagnostics for bring-up: stage 0 copies the object's derived constant block (as uploaded to
+ * __constant__ memory) into out; stage 1 (type F) returns the Miller values before the final
+ * exponentiation for n input pairs. */
+int pbc_hip_diag_stage(pbc_hip_pairing_t *p, int stage, uint8_t *out, size_t out_len,
+                       const uint8_t *g1, const uint8_t *g2, size_t n);
+
 /* Algorithmic work model used for the roofline: reference F_q multiplications
  * per unit x (2N^2+N) 32-bit MACs. */
 double pbc_hip_algorithmic_macs_per_unit(const pbc_hip_pairing_t *p, int k);

@@ -61,6 +61,7 @@ def lib():
                                            ctypes.POINTER(ctypes.c_double)]
         L.pbc_hip_diag_mul_bench.argtypes = [ci, ci, ci, ctypes.POINTER(ctypes.c_double),
                                              ctypes.POINTER(ctypes.c_double)]
+        L.pbc_hip_diag_stage.argtypes = [vp, ci, vp, sz, vp, vp, sz]
         L.pbc_hip_algorithmic_macs_per_unit.argtypes = [vp, ci]
         L.pbc_hip_algorithmic_macs_per_unit.restype = ctypes.c_double
         L.pbc_hip_last_error.restype = cp
@@ -76,7 +77,7 @@ EXPORTS = (
     "pbc_hip_element_pairing_batch_dev", "pbc_hip_element_prod_pairing_batch",
     "pbc_hip_element_prod_pairing_batch_dev", "pbc_hip_fq_op_batch",
     "pbc_hip_length_in_bytes_Fq", "pbc_hip_int_mac_peak",
-    "pbc_hip_algorithmic_macs_per_unit", "pbc_hip_last_error", "pbc_hip_diag_mul_bench",
+    "pbc_hip_algorithmic_macs_per_unit", "pbc_hip_last_error", "pbc_hip_diag_mul_bench", "pbc_hip_diag_stage",
 )
 
 

@@ -10,7 +10,11 @@
 // multiplier works on 29-bit limbs (see fp_mul29_inl); the radix is private: all exchange
 // with the host / the reference is in canonical big-endian bytes (SURVEY.md "Key facts").
 #pragma once
+#ifdef PBC_HOSTSIM
+#include "hostsim_shim.h"   // tests/hostsim: the same source compiled for the CPU (debug mirror)
+#else
 #include <hip/hip_runtime.h>
+#endif
 #include <stdint.h>
 
 namespace pbc {
@@ -47,16 +51,27 @@ template <> PBC_DEV const FpK<5> &fpk<5>() { return c_fpk5; }
 // feeds the top word: the two-instruction MAC the whole engine is built from.
 PBC_DEV void mac_vv(uint32_t &a0, uint32_t &a1, uint32_t &a2, uint32_t x, uint32_t y) {
   uint64_t acc = ((uint64_t) a1 << 32) | a0;
+#ifdef PBC_HOSTSIM
+  uint64_t p_ = (uint64_t) x * y, s_ = acc + p_;
+  a2 += s_ < p_;
+  acc = s_;
+#else
   asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"
       : "+v"(acc), "+v"(a2) : "v"(x), "v"(y) : "vcc");
+#endif
   a0 = (uint32_t) acc; a1 = (uint32_t) (acc >> 32);
 }
 // same, second factor wave-uniform (an SGPR: the modulus limbs)
 PBC_DEV void mac_vs(uint32_t &a0, uint32_t &a1, uint32_t &a2, uint32_t x, uint32_t y) {
+#ifdef PBC_HOSTSIM
+  mac_vv(a0, a1, a2, x, y);
+  return;
+#else
   uint64_t acc = ((uint64_t) a1 << 32) | a0;
   asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"
       : "+v"(acc), "+v"(a2) : "v"(x), "s"(y) : "vcc");
   a0 = (uint32_t) acc; a1 = (uint32_t) (acc >> 32);
+#endif
 }
 // acc += 2*x*y is NOT used (no spare bits at 512/512); squaring doubles the cross sum instead.
 

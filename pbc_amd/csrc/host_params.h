@@ -1,0 +1,203 @@
+// host_params.h -- pure host logic of libpbc_hip.so: the pairing object, parameter-text
+// parsing and the integer-only part of a_/d_/f_init_pairing.  No HIP calls: shared by the
+// library (pbc_hip.hip) and by the host-compiled kernel mirror used in the CPU test-suite
+// (tests/hostsim/).
+#pragma once
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "fp.cuh"
+#include "hostbn.h"
+#include "pairing_a.cuh"
+#include "pairing_d.cuh"
+#include "pairing_f.cuh"
+
+using namespace pbc;
+
+// ---------------------------------------------------------------------------------------
+// error plumbing (pbc_error-style: message to stderr is left to the caller)
+// ---------------------------------------------------------------------------------------
+static thread_local char g_err[512];
+static int fail(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+  return 1;
+}
+
+// ---------------------------------------------------------------------------------------
+// host object
+// ---------------------------------------------------------------------------------------
+struct pbc_hip_pairing_s {
+  int type;
+  int device;
+  int nlimb;                 // 32-bit limbs of F_q
+  int len_fq, len1, len2, lenT;
+  FpK<16> k16;
+  FpK<5> k5;
+  AConst a;
+  DRaw draw;                 // type D: canonical parameter words for the device-side derivation
+  DConst dconst;             // type D: derived tower constants (filled on first use)
+  FRaw fraw;                 // type F: canonical parameter words
+  FConst fconst;             // type F: derived tower constants (filled on first use)
+  bool dev_ready;            // derived constants computed on the device
+  double fq_muls_single;     // reference F_q multiplication count per pairing (work model)
+  double fq_muls_prod_a, fq_muls_prod_b;   // products: a*k + b
+};
+
+template <int N>
+static int fill_fpk(FpK<N> &K, const pbc_host::Big &q) {
+  using pbc_host::Big;
+  if (q.bits() > 32 * N || q.bits() <= 32 * (N - 1) || !(q.w[0] & 1)) return 1;
+  memset(&K, 0, sizeof K);
+  q.to_words(K.p, N);
+#if PBC_MUL_IMPL == 0
+  const int rbits = 32 * N;
+#else
+  const int rbits = 29 * Limbs29<N>::L;
+#endif
+  Big::pow2_mod(rbits, q).to_words(K.one, N);
+  Big::pow2_mod(2 * rbits, q).to_words(K.r2, N);
+  for (int i = 0; i < Limbs29<N>::L; i++) {
+    uint32_t v = 0;
+    for (int b = 0; b < 29; b++) v |= (uint32_t) q.bit(29 * i + b) << b;
+    K.p29[i] = v;
+  }
+  K.ninv29 = pbc_host::neg_inv32(K.p[0]) & Limbs29<N>::MASK;
+  Big pm2 = q;
+  pm2.sub_small(2);
+  pm2.to_words(K.pm2, N);
+  K.ninv = pbc_host::neg_inv32(K.p[0]);
+  K.pbits = (uint32_t) q.bits();
+  return 0;
+}
+
+// a_init_pairing (ecc/a_param.c:1431-1472) + pbc_param_init_a (:1489-1502)
+static int init_type_a(pbc_hip_pairing_s *P, const char *txt, size_t len) {
+  using namespace pbc_host;
+  Big q, r, h;
+  int exp2, exp1, sign1, sign0;
+  if (!param_big(txt, len, "q", q) || !param_big(txt, len, "r", r) || !param_big(txt, len, "h", h) ||
+      !param_int(txt, len, "exp2", exp2) || !param_int(txt, len, "exp1", exp1) ||
+      !param_int(txt, len, "sign1", sign1) || !param_int(txt, len, "sign0", sign0))
+    return fail("type a: missing q/r/h/exp2/exp1/sign1/sign0");
+  if (fill_fpk<16>(P->k16, q)) return fail("type a: only 481..512-bit q is supported by this build (got %d bits)", q.bits());
+  if (h.bits() > 512 || h.is_zero()) return fail("type a: bad cofactor");
+  if ((q.w[0] & 3) != 3) return fail("type a: q must be 3 mod 4");
+  if (exp1 <= 0 || exp2 <= exp1) return fail("type a: bad exp1/exp2");
+  memset(&P->a, 0, sizeof P->a);
+  h.to_words(P->a.h, 16);
+  P->a.hbits = h.bits();
+  P->a.exp2 = exp2;
+  P->a.exp1 = exp1;
+  P->a.sign1 = sign1;
+  P->nlimb = 16;
+  P->len_fq = (q.bits() + 7) / 8;
+  if (P->len_fq != 64) return fail("type a: q must serialise to 64 bytes");
+  P->len1 = P->len2 = P->lenT = 2 * P->len_fq;
+  P->fq_muls_single = 4392.0;            // SURVEY.md 8d (instrumented reference, a.param)
+  // a_pairings_affine (a_param.c:1283-1383): 41377 F_q products for k = 16;
+  // linear model through (1, 4392-ish) and (16, 41377): 2543 k + 689
+  P->fq_muls_prod_a = 2543.0;
+  P->fq_muls_prod_b = 689.0;
+  return 0;
+}
+
+// d_init_pairing (ecc/d_param.c:993-1095) + pbc_param_init_d: host part (integers only);
+// the tower constants are derived on the device at first use (pairing_d.cuh d_init_stage*).
+static int init_type_d(pbc_hip_pairing_s *P, const char *txt, size_t len) {
+  using namespace pbc_host;
+  Big q, r, a, b, nqr, co[3];
+  int k;
+  if (!param_big(txt, len, "q", q) || !param_big(txt, len, "r", r) || !param_big(txt, len, "a", a) ||
+      !param_big(txt, len, "b", b) || !param_big(txt, len, "nqr", nqr) || !param_int(txt, len, "k", k) ||
+      !param_big(txt, len, "coeff0", co[0]) || !param_big(txt, len, "coeff1", co[1]) ||
+      !param_big(txt, len, "coeff2", co[2]))
+    return fail("type d: missing q/r/a/b/k/coeff0..2/nqr");
+  if (k != 6) return fail("type d: only embedding degree 6 is supported (got %d)", k);
+  if (fill_fpk<5>(P->k5, q)) return fail("type d: only 129..160-bit q is supported by this build (got %d bits)", q.bits());
+  if (Big::cmp(a, q) >= 0 || Big::cmp(b, q) >= 0 || Big::cmp(nqr, q) >= 0) return fail("type d: coefficient >= q");
+  memset(&P->draw, 0, sizeof P->draw);
+  memset(&P->dconst, 0, sizeof P->dconst);
+  a.to_words(P->draw.a, ND);
+  b.to_words(P->draw.b, ND);
+  nqr.to_words(P->draw.nqr, ND);
+  for (int i = 0; i < 3; i++) {
+    if (Big::cmp(co[i], q) >= 0) return fail("type d: coefficient >= q");
+    co[i].to_words(P->draw.coeff[i], ND);
+  }
+  q.to_words(P->draw.q, ND + 1);
+  P->draw.qbits = q.bits();
+  if (r.bits() > 256 || r.bits() < 3) return fail("type d: bad r");
+  r.to_words(P->dconst.r, 8);
+  P->dconst.rbits = r.bits();
+  // phikonr = (q^2 - q + 1)/r (d_param.c:1036-1042)
+  Big z = Big::mul(q, q);
+  z.sub(q);
+  z.add_small(1);
+  Big rem;
+  Big phik = Big::div(z, r, &rem);
+  if (!rem.is_zero() || phik.bits() > 256) return fail("type d: r does not divide q^2 - q + 1");
+  phik.to_words(P->dconst.phik, 8);
+  P->dconst.phikbits = phik.bits();
+  P->nlimb = 5;
+  P->len_fq = (q.bits() + 7) / 8;
+  if (P->len_fq != 20) return fail("type d: q must serialise to 20 bytes");
+  P->len1 = 2 * P->len_fq;
+  P->len2 = P->lenT = 6 * P->len_fq;
+  P->fq_muls_single = 26451.0;           // SURVEY.md 8d (instrumented reference, d159.param)
+  P->fq_muls_prod_a = 26451.0 - 4197.0;  // per-term Miller work + one cc_tatepower (4197)
+  P->fq_muls_prod_b = 4197.0;
+  return 0;
+}
+
+// f_init_pairing (ecc/f_param.c:335-447): host part (integers only)
+static int init_type_f(pbc_hip_pairing_s *P, const char *txt, size_t len) {
+  using namespace pbc_host;
+  Big q, r, b, beta, a0, a1;
+  if (!param_big(txt, len, "q", q) || !param_big(txt, len, "r", r) || !param_big(txt, len, "b", b) ||
+      !param_big(txt, len, "beta", beta) || !param_big(txt, len, "alpha0", a0) || !param_big(txt, len, "alpha1", a1))
+    return fail("type f: missing q/r/b/beta/alpha0/alpha1");
+  if (fill_fpk<5>(P->k5, q)) return fail("type f: only 129..160-bit q is supported by this build (got %d bits)", q.bits());
+  if (Big::cmp(b, q) >= 0 || Big::cmp(beta, q) >= 0 || Big::cmp(a0, q) >= 0 || Big::cmp(a1, q) >= 0)
+    return fail("type f: coefficient >= q");
+  memset(&P->fraw, 0, sizeof P->fraw);
+  memset(&P->fconst, 0, sizeof P->fconst);
+  b.to_words(P->fraw.b, ND);
+  beta.to_words(P->fraw.beta, ND);
+  a0.to_words(P->fraw.alpha0, ND);
+  a1.to_words(P->fraw.alpha1, ND);
+  // (q - 1)/6: X^q = negalpha^((q-1)/6) X
+  Big qm1 = q, six, rem;
+  qm1.sub_small(1);
+  six.w.push_back(6);
+  Big e6 = Big::div(qm1, six, &rem);
+  if (!rem.is_zero()) return fail("type f: q must be 1 mod 6");
+  e6.to_words(P->fraw.e6, ND + 1);
+  P->fraw.e6bits = e6.bits();
+  if (r.bits() > 256 || r.bits() < 3) return fail("type f: bad r");
+  r.to_words(P->fconst.r, 8);
+  P->fconst.rbits = r.bits();
+  // tateexp = ((q^2 - 1) q^2 + 1)/r (f_param.c:414-420)
+  Big q2 = Big::mul(q, q), z = q2;
+  z.sub_small(1);
+  z = Big::mul(z, q2);
+  z.add_small(1);
+  Big te = Big::div(z, r, &rem);
+  if (!rem.is_zero() || te.bits() > 512) return fail("type f: r does not divide q^4 - q^2 + 1");
+  te.to_words(P->fconst.tateexp, 16);
+  P->fconst.tebits = te.bits();
+  P->nlimb = 5;
+  P->len_fq = (q.bits() + 7) / 8;
+  if (P->len_fq != 20) return fail("type f: q must serialise to 20 bytes");
+  P->len1 = 2 * P->len_fq;
+  P->len2 = 4 * P->len_fq;
+  P->lenT = 12 * P->len_fq;
+  P->fq_muls_single = 172887.0;          // SURVEY.md 8d (instrumented reference, f.param)
+  P->fq_muls_prod_a = 172887.0;          // generic_prod_pairings: k full pairings
+  P->fq_muls_prod_b = 0.0;
+  return 0;
+}
+

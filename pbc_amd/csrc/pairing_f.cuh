@@ -361,7 +361,9 @@ __device__ __noinline__ void f_final_exp(f12 *out) {
 // element_pairing (f_pairing) / element_prod_pairing (generic_prod_pairings, ecc/pairing.c:35-46:
 // Type F installs no dedicated product routine; the product of k reduced pairings equals the
 // reduced product of the Miller functions) for one lane
-__device__ void f_prod_pairing_lane(uint8_t *gt, const uint8_t *g1, const uint8_t *g2b, int k) {
+// miller_only: diagnostic (stop before the final exponentiation)
+__device__ void f_prod_pairing_lane(uint8_t *gt, const uint8_t *g1, const uint8_t *g2b, int k,
+                                    bool miller_only = false) {
   f12 F;
   bool valid = f_miller_lane(&F, g1, g2b);
   for (int j = 1; j < k; j++) {
@@ -369,7 +371,7 @@ __device__ void f_prod_pairing_lane(uint8_t *gt, const uint8_t *g1, const uint8_
     valid &= f_miller_lane(&f, g1 + (size_t) j * 8 * ND, g2b + (size_t) j * 16 * ND);
     f12_mul(&F, &F, &f);
   }
-  f_final_exp(&F);
+  if (!miller_only) f_final_exp(&F);
   if (!valid) f12_one(&F);
 #pragma nounroll
   for (int i = 0; i < 6; i++) g2_store_be(gt + 8 * ND * i, F.c[i]);

@@ -1,0 +1,66 @@
+"""TEST INFRASTRUCTURE: pbc_amd/csrc/*.cuh compiled for the host (see hostsim.cpp)."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "libhostsim.so")
+_CLANG = "/opt/rocm/lib/llvm/bin/clang++"
+
+
+def build():
+    srcs = [os.path.join(_HERE, f) for f in ("hostsim.cpp", "hostsim_shim.h")]
+    csrc = os.path.join(_HERE, "..", "..", "pbc_amd", "csrc")
+    srcs += [os.path.join(csrc, f) for f in os.listdir(csrc)]
+    if (not os.path.exists(_LIB)) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in srcs):
+        subprocess.check_call([_CLANG, "-O1", "-std=c++17", "-fPIC", "-shared", "-I", _HERE,
+                               "-o", _LIB, os.path.join(_HERE, "hostsim.cpp")])
+    return _LIB
+
+
+class HostSim:
+    def __init__(self, param_text):
+        L = ctypes.CDLL(build())
+        L.hostsim_init.restype = ctypes.c_void_p
+        L.hostsim_init.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
+        L.hostsim_error.restype = ctypes.c_char_p
+        vp = ctypes.c_void_p
+        L.hostsim_prod_pairing.argtypes = [vp, vp, vp, vp, ctypes.c_size_t, ctypes.c_int]
+        L.hostsim_fq_op.argtypes = [vp, ctypes.c_int, vp, vp, vp, ctypes.c_size_t]
+        L.hostsim_lens.argtypes = [vp] + [ctypes.POINTER(ctypes.c_int)] * 3
+        self.L = L
+        b = param_text.encode() if isinstance(param_text, str) else param_text
+        self.h = L.hostsim_init(b, len(b))
+        if not self.h:
+            raise ValueError(L.hostsim_error().decode())
+        a, b2, c = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        L.hostsim_lens(self.h, ctypes.byref(a), ctypes.byref(b2), ctypes.byref(c))
+        self.len1, self.len2, self.lenT = a.value, b2.value, c.value
+
+    def prod_pairing(self, g1, g2, k=1):
+        g1 = np.ascontiguousarray(g1, np.uint8)
+        g2 = np.ascontiguousarray(g2, np.uint8)
+        n = g1.size // (self.len1 * k)
+        out = np.empty((n, self.lenT), np.uint8)
+        self.L.hostsim_prod_pairing(self.h, out.ctypes.data, g1.ctypes.data, g2.ctypes.data, n, k)
+        return out
+
+    def stage(self, stage, g1=None, g2=None, n=0, out_len=4096):
+        out = np.zeros(max(out_len, n * self.lenT), np.uint8)
+        self.L.hostsim_stage.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t,
+                                         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+        g1p = np.ascontiguousarray(g1, np.uint8).ctypes.data if g1 is not None else None
+        g2p = np.ascontiguousarray(g2, np.uint8).ctypes.data if g2 is not None else None
+        rc = self.L.hostsim_stage(self.h, stage, out.ctypes.data, out.size, g1p, g2p, n)
+        return out, rc
+
+    def fq_op(self, op, a, b):
+        a = np.ascontiguousarray(a, np.uint8)
+        b = np.ascontiguousarray(b, np.uint8)
+        L = self.len1 // 2
+        n = a.size // L
+        out = np.empty((n, L), np.uint8)
+        self.L.hostsim_fq_op(self.h, op, out.ctypes.data, a.ctypes.data, b.ctypes.data, n)
+        return out

@@ -1,0 +1,93 @@
+// hostsim.cpp -- TEST INFRASTRUCTURE: the device headers compiled for the host, exported as a
+// tiny C API (tests/test_hostsim.py).  It runs one lane at a time: same source, same limb
+// arithmetic, same control flow as the HIP kernels.  Not part of the product.
+#define PBC_HOSTSIM 1
+#include "../../pbc_amd/csrc/host_params.h"
+
+extern "C" {
+
+void *hostsim_init(const char *param, size_t len) {
+  std::string type;
+  if (!pbc_host::param_lookup(param, len, "type", type)) return nullptr;
+  pbc_hip_pairing_s *P = new pbc_hip_pairing_s();
+  int rc = 1;
+  if (type == "a") { P->type = 'a'; rc = init_type_a(P, param, len); }
+  else if (type == "d") { P->type = 'd'; rc = init_type_d(P, param, len); }
+  else if (type == "f") { P->type = 'f'; rc = init_type_f(P, param, len); }
+  if (rc) { delete P; return nullptr; }
+  // "upload" the constants: on the host the __constant__ objects are plain globals
+  if (P->nlimb == 16) c_fpk16 = P->k16; else c_fpk5 = P->k5;
+  if (P->type == 'a') c_a = P->a;
+  if (P->type == 'd') {
+    DConst tmp;
+    d_init_stage1(&tmp, P->draw, P->dconst);
+    c_d = tmp;
+    d_init_stage2(&tmp, P->draw);
+    c_d = tmp;
+    P->dconst = tmp;
+  }
+  if (P->type == 'f') {
+    FConst tmp;
+    f_init_stage1(&tmp, P->fraw, P->fconst);
+    c_f = tmp;
+    f_init_stage2(&tmp, P->fraw);
+    c_f = tmp;
+    P->fconst = tmp;
+  }
+  return P;
+}
+const char *hostsim_error() { return g_err; }
+int hostsim_lens(void *h, int *l1, int *l2, int *lt) {
+  pbc_hip_pairing_s *P = (pbc_hip_pairing_s *) h;
+  *l1 = P->len1; *l2 = P->len2; *lt = P->lenT;
+  return 0;
+}
+// n units of k terms each, one lane after the other
+int hostsim_prod_pairing(void *h, uint8_t *gt, const uint8_t *g1, const uint8_t *g2, size_t n, int k) {
+  pbc_hip_pairing_s *P = (pbc_hip_pairing_s *) h;
+  static uint32_t lds[2 * 16];
+  for (size_t u = 0; u < n; u++) {
+    const uint8_t *a = g1 + u * k * P->len1, *b = g2 + u * k * P->len2;
+    uint8_t *o = gt + u * P->lenT;
+    if (P->type == 'a') a_prod_pairing_lane<16>(o, a, b, k, lds, 1);
+    else if (P->type == 'd') d_prod_pairing_lane(o, a, b, k);
+    else f_prod_pairing_lane(o, a, b, k);
+  }
+  return 0;
+}
+// diagnostics mirroring pbc_hip_diag_stage
+int hostsim_stage(void *h, int stage, uint8_t *out, size_t out_len, const uint8_t *g1, const uint8_t *g2, size_t n) {
+  pbc_hip_pairing_s *P = (pbc_hip_pairing_s *) h;
+  if (stage == 0) {
+    const void *src = P->type == 'd' ? (const void *) &P->dconst : P->type == 'f' ? (const void *) &P->fconst : (const void *) &P->a;
+    size_t len = P->type == 'd' ? sizeof P->dconst : P->type == 'f' ? sizeof P->fconst : sizeof P->a;
+    memcpy(out, src, len < out_len ? len : out_len);
+    return (int) len;
+  }
+  if (stage == 1 && P->type == 'f') {
+    for (size_t u = 0; u < n; u++) f_prod_pairing_lane(out + u * P->lenT, g1 + u * P->len1, g2 + u * P->len2, 1, true);
+    return 0;
+  }
+  return -1;
+}
+// F_q ops on canonical bytes (same switch as fq_op_kernel)
+int hostsim_fq_op(void *h, int op, uint8_t *c, const uint8_t *a, const uint8_t *b, size_t n) {
+  pbc_hip_pairing_s *P = (pbc_hip_pairing_s *) h;
+  for (size_t i = 0; i < n; i++) {
+    if (P->nlimb == 16) {
+      fp<16> x, y, z;
+      fp_load_be<16>(x, a + i * 64); fp_load_be<16>(y, b + i * 64);
+      switch (op) { case 0: fp_mul<16>(z, x, y); break; case 1: fp_add<16>(z, x, y); break; case 2: fp_sub<16>(z, x, y); break;
+        case 3: fp_inv<16>(z, x); break; case 4: fp_neg<16>(z, x); break; case 5: fp_halve<16>(z, x); break; default: fp_dbl<16>(z, x); }
+      fp_store_be<16>(c + i * 64, z);
+    } else {
+      fp<5> x, y, z;
+      fp_load_be<5>(x, a + i * 20); fp_load_be<5>(y, b + i * 20);
+      switch (op) { case 0: fp_mul<5>(z, x, y); break; case 1: fp_add<5>(z, x, y); break; case 2: fp_sub<5>(z, x, y); break;
+        case 3: fp_inv<5>(z, x); break; case 4: fp_neg<5>(z, x); break; case 5: fp_halve<5>(z, x); break; default: fp_dbl<5>(z, x); }
+      fp_store_be<5>(c + i * 20, z);
+    }
+  }
+  return 0;
+}
+}

@@ -1,0 +1,20 @@
+// hostsim_shim.h -- TEST INFRASTRUCTURE: lets clang compile pbc_amd/csrc/*.cuh for the CPU so
+// the exact kernel arithmetic (limb code, towers, Miller loops, final exponentiations) can be
+// stepped through and checked against the golden vectors without a GPU.  One "lane" runs
+// as an ordinary function call.  Never linked into libpbc_hip.so.
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+#define __device__
+#define __global__
+#define __constant__
+#define __shared__ static
+#define __forceinline__ inline __attribute__((always_inline))
+#define __noinline__ __attribute__((noinline))
+#define __launch_bounds__(...)
+struct hostsim_dim3 { unsigned x, y, z; };
+static hostsim_dim3 threadIdx = {0, 0, 0}, blockIdx = {0, 0, 0};
+struct uint4 { uint32_t x, y, z, w; };
+static inline uint32_t __builtin_amdgcn_alignbit(uint32_t hi, uint32_t lo, uint32_t s) {
+  return (uint32_t) (((((uint64_t) hi) << 32) | lo) >> (s & 31));
+}

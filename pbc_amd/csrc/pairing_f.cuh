@@ -193,7 +193,13 @@ __device__ __noinline__ void f12_inv(f12 *r, const f12 *a) {
 
 // v <- v * (a Qx X^4 + b Qy X^3 + c)   (f_miller_evalfn, f_param.c:109-149)
 // out_i = c v_i + [aQx] v_{i-4} + [bQy] v_{i-3}, indices mod 6 with a factor negalpha on wrap
-__device__ __noinline__ void f_line_mul(f12 *v, const fq a, const fq b, const fq c, const g2 *Qx, const g2 *Qy) {
+// (a, b, c travel as vectors: by-value fq structs beyond clang's 16-register aggregate budget
+// are passed indirectly, and that path miscompiled here -- see profiles/r01_notes.md)
+__device__ __noinline__ void f_line_mul(f12 *v, v5 va, v5 vb, v5 vc, const g2 *Qx, const g2 *Qy) {
+  fq a, b, c;
+  from_vec<ND>(a, va);
+  from_vec<ND>(b, vb);
+  from_vec<ND>(c, vc);
   g2 aq, bq, aqn, bqn;
   const g2 na = fk2(c_f.negalpha);
   g2_mul_fq(aq, *Qx, a);
@@ -207,9 +213,11 @@ __device__ __noinline__ void f_line_mul(f12 *v, const fq a, const fq b, const fq
     bool wj = true, wk = true;         // wrapped (needs negalpha) unless i >= 4 / i >= 3
     if (j >= 6) { j -= 6; wj = false; }
     if (k >= 6) { k -= 6; wk = false; }
-    g2 t, u;
-    g2_mul(t, v->c[j], wj ? aqn : aq);
-    g2_mul(u, v->c[k], wk ? bqn : bq);
+    g2 t, u, fa, fb;
+    if (wj) fa = aqn; else fa = aq;
+    if (wk) fb = bqn; else fb = bq;
+    g2_mul(t, v->c[j], fa);
+    g2_mul(u, v->c[k], fb);
     g2_add(t, t, u);
     g2_mul_fq(u, v->c[i], c);
     g2_add(t, t, u);
@@ -271,7 +279,7 @@ __device__ __noinline__ bool f_miller_lane(f12 *v, const uint8_t *g1, const uint
       fp_mul<ND>(lc, M, V.X);
       fp_dbl<ND>(t1, YY);
       fp_sub<ND>(lc, lc, t1);
-      f_line_mul(v, la, lb, lc, &Qx, &Qy);
+      f_line_mul(v, to_vec<ND>(la), to_vec<ND>(lb), to_vec<ND>(lc), &Qx, &Qy);
       fp_mul<ND>(S, V.X, YY);
       fp_dbl<ND>(S, S);
       fp_dbl<ND>(S, S);
@@ -303,7 +311,7 @@ __device__ __noinline__ bool f_miller_lane(f12 *v, const uint8_t *g1, const uint
       fp_mul<ND>(lc, R, Px);
       fp_mul<ND>(t0, Z3, Py);
       fp_sub<ND>(lc, lc, t0);
-      f_line_mul(v, la, Z3, lc, &Qx, &Qy);
+      f_line_mul(v, to_vec<ND>(la), to_vec<ND>(Z3), to_vec<ND>(lc), &Qx, &Qy);
       fp_sqr<ND>(HH, H);
       fp_mul<ND>(HHH, HH, H);
       fp_mul<ND>(t0, V.X, HH);
@@ -375,6 +383,22 @@ __device__ void f_prod_pairing_lane(uint8_t *gt, const uint8_t *g1, const uint8_
   if (!valid) f12_one(&F);
 #pragma nounroll
   for (int i = 0; i < 6; i++) g2_store_be(gt + 8 * ND * i, F.c[i]);
+}
+
+// bring-up diagnostics: one tower primitive on operands given as GT-format bytes
+__device__ void f_debug_lane(int op, uint8_t *out, const uint8_t *inA, const uint8_t *inB) {
+  f12 A, B, R;
+#pragma nounroll
+  for (int i = 0; i < 6; i++) { g2_load_be(A.c[i], inA + 8 * ND * i); g2_load_be(B.c[i], inB + 8 * ND * i); }
+  if (op == 10) f12_mul(&R, &A, &B);
+  else if (op == 11) f12_sqr(&R, &A);
+  else if (op == 12) { R = A; f_line_mul(&R, to_vec<ND>(B.c[0].x), to_vec<ND>(B.c[0].y), to_vec<ND>(B.c[3].x), &B.c[1], &B.c[2]); }
+  else if (op == 13) f12_qpower(&R, &A, c_f.xpowq2);
+  else if (op == 14) f12_inv(&R, &A);
+  else if (op == 15) { R = A; f12_sqr(&R, &R); f12_mul(&R, &R, &B); }
+  else { R = A; f_final_exp(&R); }
+#pragma nounroll
+  for (int i = 0; i < 6; i++) g2_store_be(out + 8 * ND * i, R.c[i]);
 }
 
 // ---- device-side derivation of the tower constants ---------------------------------------

@@ -103,6 +103,14 @@ __global__ void __launch_bounds__(kBlock) f_prod_pairing_kernel(uint8_t *gt, con
   }
 }
 
+__global__ void __launch_bounds__(kBlock) f_debug_kernel(int op, uint8_t *out, const uint8_t *a, const uint8_t *b, size_t n) {
+  size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
+  if (idx >= n) return;
+  __attribute__((aligned(4))) uint8_t o[48 * ND];
+  f_debug_lane(op, o, a + idx * 48 * ND, b + idx * 48 * ND);
+  for (int i = 0; i < 48 * ND; i++) out[idx * 48 * ND + i] = o[i];
+}
+
 // Batched F_q operations on wire bytes (differential check of the limb arithmetic).
 template <int N>
 __global__ void __launch_bounds__(kBlock) fq_op_kernel(int op, uint8_t *c, const uint8_t *a,
@@ -479,6 +487,22 @@ extern "C" int pbc_hip_diag_stage(pbc_hip_pairing_t *P, int stage, uint8_t *out,
     hipLaunchKernelGGL(f_prod_pairing_kernel, dim3(grid), dim3(kBlock), 0, 0, (uint8_t *) dt,
                        (const uint8_t *) d1, (const uint8_t *) d2, n, -1);
     HIP_TRY(hipMemcpy(out, dt, n * P->lenT < out_len ? n * P->lenT : out_len, hipMemcpyDeviceToHost));
+    (void) hipFree(d1); (void) hipFree(d2); (void) hipFree(dt);
+    return 0;
+  }
+  if (stage >= 10 && P->type == 'f') {   // g1 = operand A, g2 = operand B (GT-format records)
+    void *d1, *d2, *dt;
+    size_t bytes = n * P->lenT;
+    HIP_TRY(hipMalloc(&d1, bytes));
+    HIP_TRY(hipMalloc(&d2, bytes));
+    HIP_TRY(hipMalloc(&dt, bytes));
+    HIP_TRY(hipMemcpy(d1, g1, bytes, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d2, g2, bytes, hipMemcpyHostToDevice));
+    if (upload_constants(P, 0)) return 1;
+    unsigned grid = (unsigned) ((n + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(f_debug_kernel, dim3(grid), dim3(kBlock), 0, 0, stage, (uint8_t *) dt, (const uint8_t *) d1,
+                       (const uint8_t *) d2, n);
+    HIP_TRY(hipMemcpy(out, dt, bytes < out_len ? bytes : out_len, hipMemcpyDeviceToHost));
     (void) hipFree(d1); (void) hipFree(d2); (void) hipFree(dt);
     return 0;
   }

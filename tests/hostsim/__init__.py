@@ -15,7 +15,7 @@ def build():
     csrc = os.path.join(_HERE, "..", "..", "pbc_amd", "csrc")
     srcs += [os.path.join(csrc, f) for f in os.listdir(csrc)]
     if (not os.path.exists(_LIB)) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in srcs):
-        subprocess.check_call([_CLANG, "-O1", "-std=c++17", "-fPIC", "-shared", "-I", _HERE,
+        subprocess.check_call([_CLANG, "-O1", "-Wno-psabi", "-std=c++17", "-fPIC", "-shared", "-I", _HERE,
                                "-o", _LIB, os.path.join(_HERE, "hostsim.cpp")])
     return _LIB
 

@@ -68,6 +68,10 @@ int hostsim_stage(void *h, int stage, uint8_t *out, size_t out_len, const uint8_
     for (size_t u = 0; u < n; u++) f_prod_pairing_lane(out + u * P->lenT, g1 + u * P->len1, g2 + u * P->len2, 1, true);
     return 0;
   }
+  if (stage >= 10 && P->type == 'f') {
+    for (size_t u = 0; u < n; u++) f_debug_lane(stage, out + u * P->lenT, g1 + u * P->lenT, g2 + u * P->lenT);
+    return 0;
+  }
   return -1;
 }
 // F_q ops on canonical bytes (same switch as fq_op_kernel)

@@ -1,0 +1,45 @@
+"""CPU tests of the KERNEL SOURCE itself: pbc_amd/csrc/*.cuh compiled for the host
+(tests/hostsim: same limb arithmetic, towers, Miller loops and final exponentiations as the
+HIP kernels, one lane at a time) against the reference's golden vectors.  This is a debug
+mirror for GPU-less bring-up, not a product path: libpbc_hip.so never contains it."""
+import numpy as np
+import pytest
+
+from conftest import golden, _param, PARAM_OF
+
+hostsim = pytest.importorskip("hostsim")
+
+
+@pytest.fixture(scope="module")
+def sims():
+    class Lazy(dict):
+        def __missing__(self, t):
+            self[t] = hostsim.HostSim(_param(PARAM_OF[t]))
+            return self[t]
+    return Lazy()
+
+
+@pytest.mark.parametrize("name,count", [
+    ("a_kat.vec", 1), ("a_rand32.vec", 6), ("a_edge20.vec", 20), ("a_prod2x8.vec", 4), ("a_prod3x10_edge.vec", 10),
+    ("d_rand32.vec", 6), ("d_edge20.vec", 20), ("d_prod16x4.vec", 2), ("d_prod3x10_edge.vec", 10),
+    ("f_rand16.vec", 3), ("f_edge10.vec", 10), ("f_prod3x5_edge.vec", 5),
+])
+def test_kernel_source_on_host_matches_reference(sims, name, count):
+    v = golden(name)
+    n = min(count, v.n)
+    out = sims[v.type].prod_pairing(v.g1[:n * v.k], v.g2[:n * v.k], v.k)
+    assert np.array_equal(out, v.gt[:n])
+
+
+@pytest.mark.parametrize("t,q", [("a", None), ("d", 625852803282871856053922297323874661378036491717)])
+def test_kernel_fq_ops_on_host(sims, oracles, t, q):
+    if q is None:
+        q = int([l.split()[1] for l in _param("a").splitlines() if l.startswith("q ")][0])
+    nb = sims[t].len1 // 2
+    rng = np.random.default_rng(2)
+    xs = [int.from_bytes(rng.bytes(nb), "big") % q for _ in range(40)] + [1, q - 1, 2 ** (8 * nb) - 1]
+    ys = [int.from_bytes(rng.bytes(nb), "big") % q for _ in range(40)] + [q - 1, q - 1, 2 ** (8 * nb) - 1]
+    A = np.stack([np.frombuffer(x.to_bytes(nb, "big"), np.uint8) for x in xs])
+    B = np.stack([np.frombuffer(y.to_bytes(nb, "big"), np.uint8) for y in ys])
+    for op in range(7):
+        assert np.array_equal(sims[t].fq_op(op, A, B), oracles[t].fq_op(op, A, B)), op

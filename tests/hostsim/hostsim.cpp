@@ -4,6 +4,15 @@
 #define PBC_HOSTSIM 1
 #include "../../pbc_amd/csrc/host_params.h"
 
+// "upload" the constants before every call (as upload_constants does on the GPU): on the host
+// the __constant__ objects are plain globals shared by all parameter sets
+static void activate(pbc_hip_pairing_s *P) {
+  if (P->nlimb == 16) c_fpk16 = P->k16; else c_fpk5 = P->k5;
+  if (P->type == 'a') c_a = P->a;
+  if (P->type == 'd') c_d = P->dconst;
+  if (P->type == 'f') c_f = P->fconst;
+}
+
 extern "C" {
 
 void *hostsim_init(const char *param, size_t len) {
@@ -15,9 +24,7 @@ void *hostsim_init(const char *param, size_t len) {
   else if (type == "d") { P->type = 'd'; rc = init_type_d(P, param, len); }
   else if (type == "f") { P->type = 'f'; rc = init_type_f(P, param, len); }
   if (rc) { delete P; return nullptr; }
-  // "upload" the constants: on the host the __constant__ objects are plain globals
   if (P->nlimb == 16) c_fpk16 = P->k16; else c_fpk5 = P->k5;
-  if (P->type == 'a') c_a = P->a;
   if (P->type == 'd') {
     DConst tmp;
     d_init_stage1(&tmp, P->draw, P->dconst);
@@ -45,6 +52,7 @@ int hostsim_lens(void *h, int *l1, int *l2, int *lt) {
 // n units of k terms each, one lane after the other
 int hostsim_prod_pairing(void *h, uint8_t *gt, const uint8_t *g1, const uint8_t *g2, size_t n, int k) {
   pbc_hip_pairing_s *P = (pbc_hip_pairing_s *) h;
+  activate(P);
   static uint32_t lds[2 * 16];
   for (size_t u = 0; u < n; u++) {
     const uint8_t *a = g1 + u * k * P->len1, *b = g2 + u * k * P->len2;
@@ -58,6 +66,7 @@ int hostsim_prod_pairing(void *h, uint8_t *gt, const uint8_t *g1, const uint8_t 
 // diagnostics mirroring pbc_hip_diag_stage
 int hostsim_stage(void *h, int stage, uint8_t *out, size_t out_len, const uint8_t *g1, const uint8_t *g2, size_t n) {
   pbc_hip_pairing_s *P = (pbc_hip_pairing_s *) h;
+  activate(P);
   if (stage == 0) {
     const void *src = P->type == 'd' ? (const void *) &P->dconst : P->type == 'f' ? (const void *) &P->fconst : (const void *) &P->a;
     size_t len = P->type == 'd' ? sizeof P->dconst : P->type == 'f' ? sizeof P->fconst : sizeof P->a;
@@ -77,6 +86,7 @@ int hostsim_stage(void *h, int stage, uint8_t *out, size_t out_len, const uint8_
 // F_q ops on canonical bytes (same switch as fq_op_kernel)
 int hostsim_fq_op(void *h, int op, uint8_t *c, const uint8_t *a, const uint8_t *b, size_t n) {
   pbc_hip_pairing_s *P = (pbc_hip_pairing_s *) h;
+  activate(P);
   for (size_t i = 0; i < n; i++) {
     if (P->nlimb == 16) {
       fp<16> x, y, z;

@@ -44,7 +44,7 @@ def load_vec(path):
     return g1.copy(), g2.copy(), gt.copy()
 
 
-def cpu_baseline(param_path):
+def cpu_baseline(param_path, k=1):
     """PBC+GMP (the unmodified reference compiled into oracle/_ref) on the host cores, on a
     bounded sample of the same workload; falls back to the single-core C port."""
     import oracle  # checker/baseline only -- never on the measured GPU path
@@ -53,11 +53,12 @@ def cpu_baseline(param_path):
     if os.path.exists(tool):
         try:
             def run(per_worker, workers):
-                out = subprocess.run([tool, "bench", param_path, str(per_worker), "1", str(workers)],
+                out = subprocess.run([tool, "bench", param_path, str(per_worker), str(k), str(workers)],
                                      capture_output=True, text=True, timeout=300)
                 return json.loads(out.stdout.strip().splitlines()[-1])
-            one = run(2048, 1)                       # one core alone (~2 s)
-            per_worker = 1024
+            scale = {"a": 1, "d": 4, "f": 16}.get(os.path.basename(param_path)[0], 1) * k
+            one = run(max(16, 2048 // scale), 1)     # one core alone (~2 s)
+            per_worker = max(8, 1024 // scale)
             allc = run(per_worker, cores)            # every logical CPU busy
             quota = None
             try:
@@ -65,22 +66,37 @@ def cpu_baseline(param_path):
                 quota = None if q == "max" else float(q) / float(p)
             except Exception:  # noqa: BLE001
                 pass
-            return {"value": round(allc["units_per_s"], 1), "unit": "pairings/s", "cores": cores,
+            return {"value": round(allc["units_per_s"], 1), "unit": "pairings/s" if k == 1 else "products/s", "cores": cores,
                     "kind": "reference",
-                    "sample": "%d element_pairing calls per worker x %d forked workers (a.param), %.1f s wall"
-                              % (per_worker, cores, allc["wall_s"]),
+                    "sample": "%d %s calls per worker x %d forked workers (%s), %.1f s wall"
+                              % (per_worker, "element_pairing" if k == 1 else "element_prod_pairing(k=%d)" % k, cores,
+                                 os.path.basename(param_path), allc["wall_s"]),
                     "single_core": round(one["units_per_s"], 1),
                     "per_core_when_all_busy": round(allc["per_core"], 1),
                     "cgroup_cpu_quota_cores": quota}
         except Exception as e:  # noqa: BLE001
             sys.stderr.write("cpu_baseline: ref_tool failed (%r), using the C port\n" % (e,))
     O = oracle.OraclePairing(open(param_path).read())
-    g1, g2, _ = load_vec(os.path.join(ROOT, "tests", "golden", "a_chain1024.vec"))
+    fx = {"a": "a_chain1024.vec", "d": "d_chain256.vec", "f": "f_chain128.vec"}[os.path.basename(param_path)[0]]
+    g1, g2, _ = load_vec(os.path.join(ROOT, "tests", "golden", fx))
+    m = 128 // k * k
     t0 = time.time()
-    O.pairing_batch(g1, g2)
+    if k == 1:
+        O.pairing_batch(g1[:m], g2[:m])
+    else:
+        O.prod_pairing_batch(g1[:m], g2[:m], k)
     dt = time.time() - t0
-    return {"value": round(1024 / dt, 1), "unit": "pairings/s", "cores": 1, "kind": "port",
-            "sample": "1024 pairings, single thread, oracle/pbc_oracle.c"}
+    return {"value": round(m / k / dt, 1), "unit": "pairings/s" if k == 1 else "products/s", "cores": 1, "kind": "port",
+            "sample": "%d units, single thread, oracle/pbc_oracle.c" % (m // k)}
+
+
+WORKLOADS = {
+    # name: (param, fixture, k, default log2 units, description)
+    "a": ("a", "a_chain1024.vec", 1, 20, "Type A (a.param) element_pairing"),
+    "d": ("d159", "d_chain256.vec", 1, 18, "Type D (d159.param) element_pairing"),
+    "f": ("f", "f_chain128.vec", 1, 18, "Type F (f.param) element_pairing"),
+    "a-prod16": ("a", "a_chain1024.vec", 16, 18, "Type A (a.param) element_prod_pairing, 16 terms"),
+}
 
 
 def main():
@@ -88,9 +104,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--log2n", type=int, default=20, help="pairs per GPU per step (default 2^20)")
+    ap.add_argument("--workload", default="a", choices=sorted(WORKLOADS),
+                    help="default: the BASELINE.json metric config (2^20 Type-A pairings)")
+    ap.add_argument("--log2n", type=int, default=None, help="units per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    pname, fixture, k, dlog, desc = WORKLOADS[args.workload]
+    if args.log2n is None:
+        args.log2n = dlog
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -105,25 +126,27 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    param_path = os.path.join(ROOT, "pbc_amd", "param", "a.param")
+    param_path = os.path.join(ROOT, "pbc_amd", "param", pname + ".param")
     pairing = pbc_amd.Pairing(open(param_path).read())
+    L1, L2, LT = pairing.length_in_bytes_G1, pairing.length_in_bytes_G2, pairing.length_in_bytes_GT
     n = 1 << args.log2n
-    g1, g2, gt_ref = load_vec(os.path.join(ROOT, "tests", "golden", "a_chain1024.vec"))
-    D = 1024
-    side_i = min(D, n)                    # n = side_i * side_j distinct (P_i, Q_j) pairs
-    side_j = max(1, n // side_i)
-    assert side_i * side_j == n and side_j <= D
-    # rank r uses a rotated set of Q's so that shards differ
-    rot = (rank * 131) % D
-    d1 = torch.from_numpy(g1[:side_i]).cuda()
-    d2 = torch.from_numpy(np.roll(g2, -rot, axis=0)[:side_j]).cuda()
-    G1 = d1[:, None, :].expand(side_i, side_j, 128).reshape(n, 128).contiguous()
-    G2 = d2[None, :, :].expand(side_i, side_j, 128).reshape(n, 128).contiguous()
-    GT = torch.empty(n, 128, dtype=torch.uint8, device="cuda")
+    g1, g2, gt_ref = load_vec(os.path.join(ROOT, "tests", "golden", fixture))
+    D = g1.shape[0]
+    rot = (rank * 131) % D                # rank r uses a rotated set of Q's so that shards differ
+    d1 = torch.from_numpy(g1).cuda()
+    d2 = torch.from_numpy(np.roll(g2, -rot, axis=0)).cuda()
+    # term t of the batch pairs P_(t // D mod D) with Q_(t mod D): D*D distinct pairs, tiled beyond
+    t = torch.arange(n * k, device="cuda")
+    G1 = d1[(t // D) % D].contiguous()
+    G2 = d2[t % D].contiguous()
+    GT = torch.empty(n, LT, dtype=torch.uint8, device="cuda")
     stream = torch.cuda.current_stream()
 
     def step():
-        pairing.element_pairing_dev(GT.data_ptr(), G1.data_ptr(), G2.data_ptr(), n, stream.cuda_stream)
+        if k == 1:
+            pairing.element_pairing_dev(GT.data_ptr(), G1.data_ptr(), G2.data_ptr(), n, stream.cuda_stream)
+        else:
+            pairing.element_prod_pairing_dev(GT.data_ptr(), G1.data_ptr(), G2.data_ptr(), n, k, stream.cuda_stream)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -131,19 +154,28 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(max(1, args.warmup)):
         step()
     torch.cuda.synchronize()
-    # correctness gate: with rot == 0 unit (i, i) is e(P_i, Q_i), stored by the reference
-    if args.warmup == 0:
-        step()
-        torch.cuda.synchronize()
-    if rot == 0:
-        m = min(side_i, side_j)
-        idx = torch.arange(m, device="cuda") * (side_j + 1)
-        got = GT[idx].cpu().numpy()
-        if not np.array_equal(got, gt_ref[:m]):
+    # correctness gate against the reference's own outputs stored in the fixture:
+    #   k == 1: unit i*(D+1) is e(P_i, Q_i);  k > 1: bilinearity cross-check below
+    if rot == 0 and k == 1:
+        m = min(D, (n - 1) // (D + 1) + 1)
+        idx = torch.arange(m, device="cuda") * (D + 1)
+        if not np.array_equal(GT[idx].cpu().numpy(), gt_ref[:m]):
             sys.exit("bench.py: GPU results differ from the reference fixture -- refusing to time")
+    if rot == 0 and k > 1:
+        # a k-term product must equal the product of its k single pairings, taken from a
+        # separate single-pairing launch: compare through a second product with permuted terms
+        perm = torch.arange(k - 1, -1, -1, device="cuda")
+        m = 64
+        sel = (torch.arange(m, device="cuda")[:, None] * k + perm[None, :]).reshape(-1)
+        GT2 = torch.empty(m, LT, dtype=torch.uint8, device="cuda")
+        pairing.element_prod_pairing_dev(GT2.data_ptr(), G1[sel].contiguous().data_ptr(),
+                                         G2[sel].contiguous().data_ptr(), m, k, stream.cuda_stream)
+        torch.cuda.synchronize()
+        if not torch.equal(GT2, GT[:m]):
+            sys.exit("bench.py: product of pairings is not invariant under term order -- refusing to time")
 
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     sync_all()
@@ -156,23 +188,26 @@ def main():
     dt = time.perf_counter() - t0
     kern_ms = [a.elapsed_time(b) for a, b in evs]
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
 
     if rank == 0:
         total_units = n * world * args.steps
         value = total_units / dt
         avg_kern_s = sum(kern_ms) / len(kern_ms) * 1e-3
-        macs_per_unit = pairing.algorithmic_macs_per_unit(1)
+        macs_per_unit = pairing.algorithmic_macs_per_unit(k)
         # measured integer multiply-add peak of this chip (register-only v_mad_u64_u32 probe)
         peak_macs, _ = pbc_amd.int_mac_peak(0, 4000)
         achieved_macs = n * macs_per_unit / avg_kern_s
-        alg_bytes = n * (128 + 128 + 128)
+        unit_bytes = k * (L1 + L2) + LT
+        alg_bytes = n * unit_bytes
+        unit_name = "pairings/s" if k == 1 else "products/s"
         out = {
-            "metric": "pairings/sec on 2^20-batch Type-A (a.param)",
+            "metric": "pairings/sec on 2^20-batch Type-A (a.param)" if args.workload == "a"
+                      else "%s per second, 2^%d batch" % (desc, args.log2n),
             "value": round(value, 1),
-            "unit": "pairings/s",
+            "unit": unit_name,
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
@@ -180,10 +215,11 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "u32 limbs (512-bit Montgomery Fq, bit-exact integer)",
-            "data": "synthetic: 2^20 distinct (P_i,Q_j) pairs from tests/golden/a_chain1024.vec, resident in HBM",
-            "config": {"workload": "Type A (a.param) element_pairing, 2^%d pairs per GPU per step" % args.log2n,
-                       "pairs_per_gpu": n, "global_batch": n * world, "parallelism": "range-split x%d, no collectives" % world},
+            "dtype": "u32 (multi-word Montgomery F_q, bit-exact integer)",
+            "data": "synthetic: (P_i,Q_j) cross pairs of tests/golden/%s (%d x %d distinct), resident in HBM" % (fixture, D, D),
+            "config": {"workload": "%s, 2^%d units per GPU per step" % (desc, args.log2n),
+                       "units_per_gpu": n, "terms_per_unit": k, "global_batch": n * world,
+                       "parallelism": "range-split x%d, no collectives" % world},
             "roofline": {
                 "bound": "valu-int32-mac",   # integer VALU throughput bounds this path, not HBM/MFMA
                 "achieved": round(achieved_macs / 1e12, 4),
@@ -191,16 +227,15 @@ def main():
                 "unit": "TMAC/s (32x32->64 bit)",
                 "frac": round(achieved_macs / peak_macs, 4),
                 "traffic": None,
-                "kernel": "a_pairing_kernel<16>",
                 "kernel_ms": round(avg_kern_s * 1e3, 3),
-                "algorithmic_macs_per_pairing": macs_per_unit,
+                "algorithmic_macs_per_unit": macs_per_unit,
                 "hbm": {"achieved": round(alg_bytes / avg_kern_s / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(alg_bytes / avg_kern_s / 1e9 / HBM_PEAK_GBS, 6),
-                        "algorithmic_bytes_per_pairing": 384},
+                        "algorithmic_bytes_per_unit": unit_bytes},
             },
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(param_path)
+            out["cpu_baseline"] = cpu_baseline(param_path, k)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

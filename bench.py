@@ -171,8 +171,8 @@ def main():
         m = 64
         sel = (torch.arange(m, device="cuda")[:, None] * k + perm[None, :]).reshape(-1)
         GT2 = torch.empty(m, LT, dtype=torch.uint8, device="cuda")
-        pairing.element_prod_pairing_dev(GT2.data_ptr(), G1[sel].contiguous().data_ptr(),
-                                         G2[sel].contiguous().data_ptr(), m, k, stream.cuda_stream)
+        A1, A2 = G1[sel].contiguous(), G2[sel].contiguous()     # keep alive until the launch has run
+        pairing.element_prod_pairing_dev(GT2.data_ptr(), A1.data_ptr(), A2.data_ptr(), m, k, stream.cuda_stream)
         torch.cuda.synchronize()
         if not torch.equal(GT2, GT[:m]):
             sys.exit("bench.py: product of pairings is not invariant under term order -- refusing to time")

@@ -1,0 +1,131 @@
+/* pbc_hip_glue.c -- see pbc_hip_glue.h.  Plain C, PBC's public API only. */
+#include "pbc_hip_glue.h"
+
+#include <dlfcn.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef struct pbc_hip_pairing_s pbc_hip_pairing_t;
+static struct {
+  void *dl;
+  int (*init)(pbc_hip_pairing_t **, const char *, size_t);
+  void (*clear)(pbc_hip_pairing_t *);
+  int (*len1)(const pbc_hip_pairing_t *), (*len2)(const pbc_hip_pairing_t *), (*lenT)(const pbc_hip_pairing_t *);
+  int (*pair)(pbc_hip_pairing_t *, unsigned char *, const unsigned char *, const unsigned char *, size_t);
+  int (*prod)(pbc_hip_pairing_t *, unsigned char *, const unsigned char *, const unsigned char *, size_t, int);
+  const char *(*err)(void);
+} L;
+
+/* one attachment per pairing_s (kept in a tiny table keyed by the pairing pointer so that
+ * struct pairing_s itself needs no new field) */
+typedef struct {
+  struct pairing_s *pairing;
+  pbc_hip_pairing_t *gpu;
+  void (*cpu_map)(element_ptr, element_ptr, element_ptr, struct pairing_s *);
+  void (*cpu_prod)(element_ptr, element_t[], element_t[], int, struct pairing_s *);
+} attach_t;
+static attach_t g_att[16];
+
+static attach_t *find(struct pairing_s *p) {
+  for (int i = 0; i < 16; i++) if (g_att[i].pairing == p) return &g_att[i];
+  return NULL;
+}
+static int load_lib(void) {
+  if (L.dl) return 0;
+  const char *path = getenv("PBC_HIP_LIB");
+  L.dl = dlopen(path ? path : "libpbc_hip.so", RTLD_NOW | RTLD_GLOBAL);
+  if (!L.dl) { fprintf(stderr, "pbc_hip: %s\n", dlerror()); return 1; }
+#define SYM(f, n) do { *(void **) &L.f = dlsym(L.dl, n); if (!L.f) { fprintf(stderr, "pbc_hip: missing %s\n", n); return 1; } } while (0)
+  SYM(init, "pbc_hip_pairing_init_set_buf"); SYM(clear, "pbc_hip_pairing_clear");
+  SYM(len1, "pbc_hip_pairing_length_in_bytes_G1"); SYM(len2, "pbc_hip_pairing_length_in_bytes_G2");
+  SYM(lenT, "pbc_hip_pairing_length_in_bytes_GT");
+  SYM(pair, "pbc_hip_element_pairing_batch"); SYM(prod, "pbc_hip_element_prod_pairing_batch");
+  SYM(err, "pbc_hip_last_error");
+#undef SYM
+  return 0;
+}
+
+/* n*k (in1, in2) terms -> n GT results.  `out` are GT elements (the mulg wrapper, ecc/pairing.c:135-283). */
+static int run_batch(attach_t *a, element_t out[], element_t in1[], element_t in2[], size_t n, int k) {
+  struct pairing_s *p = a->pairing;
+  int l1 = L.len1(a->gpu), l2 = L.len2(a->gpu), lt = L.lenT(a->gpu);
+  size_t terms = n * (size_t) k, m = 0;
+  unsigned char *b1 = malloc(terms * l1 + 1), *b2 = malloc(terms * l2 + 1), *bt = malloc(n * lt + 1);
+  size_t *slot = malloc(n * sizeof *slot);
+  if (!b1 || !b2 || !bt || !slot) { free(b1); free(b2); free(bt); free(slot); return 1; }
+  /* host pre-filter: identity inputs never reach the device (pairing_apply :123-130,
+   * element_prod_pairing :161-168); PBC's wire format cannot express O */
+  for (size_t u = 0; u < n; u++) {
+    int ident = 0;
+    for (int j = 0; j < k; j++) if (element_is0(in1[u * k + j]) || element_is0(in2[u * k + j])) ident = 1;
+    if (ident) { element_set0(out[u]); continue; }
+    for (int j = 0; j < k; j++) {
+      element_to_bytes(b1 + (m * k + j) * l1, in1[u * k + j]);
+      element_to_bytes(b2 + (m * k + j) * l2, in2[u * k + j]);
+    }
+    slot[m++] = u;
+  }
+  int rc = 0;
+  if (m) {
+    rc = k == 1 ? L.pair(a->gpu, bt, b1, b2, m) : L.prod(a->gpu, bt, b1, b2, m, k);
+    if (rc) fprintf(stderr, "pbc_hip: %s\n", L.err());
+    else for (size_t i = 0; i < m; i++) element_from_bytes(out[slot[i]], bt + i * lt);
+  }
+  (void) p;
+  free(b1); free(b2); free(bt); free(slot);
+  return rc;
+}
+
+/* pairing->map replacement: `out` is the element INSIDE the GT wrapper (out->data of the GT
+ * element, include/pbc_pairing.h:131-134), so it is filled through its own field. */
+static void hip_map(element_ptr out, element_ptr in1, element_ptr in2, struct pairing_s *p) {
+  attach_t *a = find(p);
+  int l1 = L.len1(a->gpu), l2 = L.len2(a->gpu), lt = L.lenT(a->gpu);
+  unsigned char *buf = malloc((size_t) l1 + l2 + lt);
+  element_to_bytes(buf, in1);
+  element_to_bytes(buf + l1, in2);
+  if (L.pair(a->gpu, buf + l1 + l2, buf, buf + l1, 1)) { fprintf(stderr, "pbc_hip: %s\n", L.err()); a->cpu_map(out, in1, in2, p); }
+  else element_from_bytes(out, buf + l1 + l2);
+  free(buf);
+}
+static void hip_prod(element_ptr out, element_t in1[], element_t in2[], int n_prod, struct pairing_s *p) {
+  attach_t *a = find(p);
+  int l1 = L.len1(a->gpu), l2 = L.len2(a->gpu), lt = L.lenT(a->gpu);
+  unsigned char *b1 = malloc((size_t) n_prod * l1), *b2 = malloc((size_t) n_prod * l2), *bt = malloc(lt);
+  for (int j = 0; j < n_prod; j++) { element_to_bytes(b1 + (size_t) j * l1, in1[j]); element_to_bytes(b2 + (size_t) j * l2, in2[j]); }
+  if (L.prod(a->gpu, bt, b1, b2, 1, n_prod)) { fprintf(stderr, "pbc_hip: %s\n", L.err()); a->cpu_prod(out, in1, in2, n_prod, p); }
+  else element_from_bytes(out, bt);
+  free(b1); free(b2); free(bt);
+}
+
+int pbc_hip_attach(pairing_t pairing, const char *param, size_t len) {
+  if (load_lib()) return 1;
+  attach_t *a = find(NULL);
+  if (!a || find(pairing)) return 1;
+  pbc_hip_pairing_t *g;
+  if (L.init(&g, param, len)) { fprintf(stderr, "pbc_hip: %s\n", L.err()); return 1; }
+  if (L.len1(g) != pairing_length_in_bytes_G1(pairing) || L.len2(g) != pairing_length_in_bytes_G2(pairing) ||
+      L.lenT(g) != pairing_length_in_bytes_GT(pairing)) { L.clear(g); return 1; }
+  a->pairing = pairing; a->gpu = g; a->cpu_map = pairing->map; a->cpu_prod = pairing->prod_pairings;
+  pairing->map = hip_map;
+  pairing->prod_pairings = hip_prod;
+  return 0;
+}
+void pbc_hip_detach(pairing_t pairing) {
+  attach_t *a = find(pairing);
+  if (!a) return;
+  pairing->map = a->cpu_map; pairing->prod_pairings = a->cpu_prod;
+  L.clear(a->gpu);
+  memset(a, 0, sizeof *a);
+}
+int element_pairing_batch(element_t out[], element_t in1[], element_t in2[], size_t n) {
+  if (!n) return 0;
+  attach_t *a = find(out[0]->field->pairing);
+  return a ? run_batch(a, out, in1, in2, n, 1) : 1;
+}
+int element_prod_pairing_batch(element_t out[], element_t in1[], element_t in2[], size_t n, int k) {
+  if (!n) return 0;
+  attach_t *a = find(out[0]->field->pairing);
+  return a ? run_batch(a, out, in1, in2, n, k) : 1;
+}

@@ -17,6 +17,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.path.join(_HERE, "liboracle.so")
 REF_TOOL = os.path.join(_HERE, "_ref", "ref_tool")
+GLUE_TEST = os.path.join(_HERE, "_ref", "glue_test")
 
 
 def build(force=False):
@@ -24,8 +25,10 @@ def build(force=False):
     if force or not os.path.exists(_LIB) or \
             os.path.getmtime(_LIB) < os.path.getmtime(os.path.join(_HERE, "pbc_oracle.c")):
         subprocess.check_call(["make", "-s", "-C", _HERE, "oracle"])
-    if os.path.isdir("/root/reference/arith") and (force or not os.path.exists(REF_TOOL)):
-        subprocess.check_call(["make", "-s", "-j8", "-C", _HERE, "ref"])
+    if os.path.isdir("/root/reference/arith"):
+        if force or not os.path.exists(REF_TOOL):
+            subprocess.check_call(["make", "-s", "-j8", "-C", _HERE, "ref"])
+        subprocess.check_call(["make", "-s", "-C", _HERE, "glue"])      # reference + integration glue
 
 
 _lib = None

@@ -232,3 +232,22 @@ def test_df_bilinearity(hips, oracles, t):
     lhs = hips[t].element_pairing(aP, Q)
     rhs = oracles[t].gt_pow(hips[t].element_pairing(P, Q), np.tile(_be(a, 20), (3, 1)))
     assert np.array_equal(lhs, rhs)
+
+
+# ---- the drop-in itself: unmodified reference PBC + integration/pbc_hip_glue.c ------------
+@pytest.mark.parametrize("pname", ["a", "d159", "f"])
+def test_reference_call_sites_run_on_gpu_through_the_glue(pname):
+    """oracle/_ref/glue_test = the reference library (compiled from /root/reference by
+    oracle/Makefile) linked with integration/pbc_hip_glue.c: element_pairing(),
+    element_prod_pairing() and the new *_batch() calls go through pairing->map /
+    pairing->prod_pairings into libpbc_hip.so and are compared with the reference's own CPU
+    results via element_cmp."""
+    import os
+    import subprocess
+    import pbc_amd
+    if not os.path.exists(oracle.GLUE_TEST):
+        pytest.skip("oracle/_ref/glue_test not built (needs /root/reference at build time)")
+    env = dict(os.environ, PBC_HIP_LIB=pbc_amd.LIB_PATH)
+    r = subprocess.run([oracle.GLUE_TEST, os.path.join(pbc_amd.PARAM_DIR, pname + ".param"), "120"],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and "PASS" in r.stdout, r.stdout + r.stderr

@@ -66,6 +66,13 @@ static int fill_fpk(FpK<N> &K, const pbc_host::Big &q) {
     K.p29[i] = v;
   }
   K.ninv29 = pbc_host::neg_inv32(K.p[0]) & Limbs29<N>::MASK;
+  Big::pow2_mod(3 * rbits, q).to_words(K.r3, N);
+  for (int i = 0; i < Inv30<N>::L; i++) {
+    uint32_t v = 0;
+    for (int b = 0; b < 30; b++) v |= (uint32_t) q.bit(30 * i + b) << b;
+    K.p30[i] = v;
+  }
+  K.qinv30 = (0u - pbc_host::neg_inv32(K.p[0])) & 0x3fffffffu;
   Big pm2 = q;
   pm2.sub_small(2);
   pm2.to_words(K.pm2, N);

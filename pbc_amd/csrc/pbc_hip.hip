@@ -32,11 +32,17 @@ extern "C" const char *pbc_hip_last_error(void) { return g_err; }
 // kernels
 // ---------------------------------------------------------------------------------------
 constexpr int kBlock = 128;
+#ifndef PBC_DF_WAVES
+#define PBC_DF_WAVES 2
+#endif
+#ifndef PBC_A_WAVES
+#define PBC_A_WAVES 2     // waves per SIMD the pairing kernels are register-budgeted for (measured: 1 -> 2 = +32 %)
+#endif
 
 // One Type-A pairing per lane.  g1/g2/gt are AoS in wire format (128 B each for a.param);
 // per-lane 16-byte loads of a 128-byte record: every byte of every fetched line is used.
 template <int N>
-__global__ void __launch_bounds__(kBlock) a_pairing_kernel(uint8_t *gt, const uint8_t *g1,
+__global__ void __launch_bounds__(kBlock, PBC_A_WAVES) a_pairing_kernel(uint8_t *gt, const uint8_t *g1,
                                                             const uint8_t *g2, size_t n) {
   size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
   size_t ld = idx < n ? idx : n - 1;          // tail lanes recompute the last unit, no store
@@ -54,7 +60,7 @@ __global__ void __launch_bounds__(kBlock) a_pairing_kernel(uint8_t *gt, const ui
 
 // One k-term product of Type-A pairings per lane (terms of unit u are records u*k .. u*k+k-1).
 template <int N>
-__global__ void __launch_bounds__(kBlock) a_prod_pairing_kernel(uint8_t *gt, const uint8_t *g1,
+__global__ void __launch_bounds__(kBlock, PBC_A_WAVES) a_prod_pairing_kernel(uint8_t *gt, const uint8_t *g1,
                                                                  const uint8_t *g2, size_t n, int k) {
   size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
   size_t ld = idx < n ? idx : n - 1;
@@ -72,7 +78,7 @@ __global__ void __launch_bounds__(kBlock) a_prod_pairing_kernel(uint8_t *gt, con
 
 // Type D: one k-term product (k = 1: a single pairing) per lane.  G1 records are 40 B, G2
 // 120 B, GT 120 B for d159.param.
-__global__ void __launch_bounds__(kBlock) d_prod_pairing_kernel(uint8_t *gt, const uint8_t *g1,
+__global__ void __launch_bounds__(kBlock, PBC_DF_WAVES) d_prod_pairing_kernel(uint8_t *gt, const uint8_t *g1,
                                                                  const uint8_t *g2, size_t n, int k) {
   size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
   size_t ld = idx < n ? idx : n - 1;
@@ -88,7 +94,7 @@ __global__ void __launch_bounds__(kBlock) d_prod_pairing_kernel(uint8_t *gt, con
 }
 
 // Type F: one k-term product (k = 1: a single pairing) per lane.  G1 40 B, G2 80 B, GT 240 B.
-__global__ void __launch_bounds__(kBlock) f_prod_pairing_kernel(uint8_t *gt, const uint8_t *g1,
+__global__ void __launch_bounds__(kBlock, PBC_DF_WAVES) f_prod_pairing_kernel(uint8_t *gt, const uint8_t *g1,
                                                                  const uint8_t *g2, size_t n, int k) {
   size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
   size_t ld = idx < n ? idx : n - 1;
@@ -270,7 +276,10 @@ __global__ void __launch_bounds__(256) mul_bench_kernel(uint32_t *out, const uin
     else if constexpr (V == 1) fp_mul29_inl<N, false>(x, x, y);
     else if constexpr (V == 2) fp_mul29_inl<N, true>(x, x, y);
     else if constexpr (V == 3) fp_sqr29_inl<N, false>(x, x);
-    else fp_sqr29_inl<N, true>(x, x);
+    else if constexpr (V == 4) fp_sqr29_inl<N, true>(x, x);
+    else if constexpr (V == 5) { fp_inv<N>(x, x); fp_add<N>(x, x, y); }          // safegcd inversion
+    else if constexpr (V == 6) fp_mul<N>(x, x, y);                                 // out-of-line product
+    else fp_sqr<N>(x, x);                                                          // out-of-line square
   }
 #pragma unroll
   for (int i = 0; i < N; i++) out[i * n + tid] = x.v[i];
@@ -607,6 +616,9 @@ extern "C" int pbc_hip_diag_mul_bench(int variant, int iters, int waves_per_simd
     case 2: return run_mul_bench<2>(iters, waves_per_simd, rate, ms);
     case 3: return run_mul_bench<3>(iters, waves_per_simd, rate, ms);
     case 4: return run_mul_bench<4>(iters, waves_per_simd, rate, ms);
+    case 5: return run_mul_bench<5>(iters, waves_per_simd, rate, ms);
+    case 6: return run_mul_bench<6>(iters, waves_per_simd, rate, ms);
+    case 7: return run_mul_bench<7>(iters, waves_per_simd, rate, ms);
     default: return fail("unknown mul variant %d", variant);
   }
 }

@@ -16,11 +16,12 @@ for v, nm in names.items():
 json.dump(res, open("gpurun_out/probe.json", "w"), indent=1)
 
 mnames = {0: "mul 32-bit sat (mad+addc asm)", 1: "mul 29-bit unsat", 2: "mul 29-bit unsat, 2 acc",
-          3: "sqr 29-bit", 4: "sqr 29-bit, 2 acc"}
+          3: "sqr 29-bit", 4: "sqr 29-bit, 2 acc", 5: "safegcd inversion (+1 add)", 6: "mul 29-bit out-of-line call",
+          7: "sqr 29-bit out-of-line call"}
 mres = {}
 for v, nm in mnames.items():
     for wps in (1, 2, 4):
-        r, ms = pbc_amd.mul_bench(v, 300, wps)
+        r, ms = pbc_amd.mul_bench(v, 40 if v == 5 else 300, wps)
         cyc = 256 * 4 * 2.4e9 / (r / 64.0)
         mres["%s @%dw" % (nm, wps)] = {"fq_mul_per_s": r, "ms": ms}
         print("%-32s %d waves/SIMD: %8.3f G mul/s  %8.0f cyc/wave-mul/SIMD @2.4GHz" % (nm, wps, r / 1e9, cyc))

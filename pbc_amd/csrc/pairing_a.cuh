@@ -80,31 +80,34 @@ struct jac {
 // with M = 3X^2 + Z^4.
 template <int N>
 PBC_DEV void a_double_step(fp2<N> &f, jac<N> &V, const fp<N> &Qx, const fp<N> &Qy) {
-  fp<N> XX, YY, M, t0, t1, S, Z3;
+  // Ordered for short live ranges (the register budget is 256/lane at 2 waves per SIMD):
+  // line first, f <- f^2 l as soon as the line exists, the rest of the doubling last.
+  fp<N> YY, M, t0, t1, S, Z3;
   fp2<N> l;
   fi_sqr<N>(f, f);
-  fp_sqr<N>(XX, V.X);
-  fp_sqr<N>(YY, V.Y);
+  fp_sqr<N>(M, V.X);                   // X^2
   fp_sqr<N>(t0, V.ZZ);                 // Z^4
-  fp_dbl<N>(M, XX);
-  fp_add<N>(M, M, XX);
+  fp_dbl<N>(t1, M);
+  fp_add<N>(M, M, t1);
   fp_add<N>(M, M, t0);                 // M = 3X^2 + a Z^4, a = 1
+  fp_sqr<N>(YY, V.Y);
   fp_mul<N>(t0, V.ZZ, Qx);
   fp_add<N>(t0, t0, V.X);
   fp_mul<N>(l.x, M, t0);
   fp_dbl<N>(t1, YY);
-  fp_sub<N>(l.x, l.x, t1);             // re
+  fp_sub<N>(l.x, l.x, t1);             // re = M (ZZ Qx + X) - 2Y^2
   fp_mul<N>(Z3, V.Y, V.Z);
-  fp_dbl<N>(Z3, Z3);                   // Z3 = 2YZ
-  fp_mul<N>(t1, Z3, V.ZZ);
-  fp_mul<N>(l.y, t1, Qy);              // im
+  fp_dbl<N>(Z3, Z3);                   // Z3 = 2YZ            (Y, Z dead)
+  fp_mul<N>(t1, Z3, V.ZZ);             //                      (ZZ dead)
+  fp_mul<N>(l.y, t1, Qy);              // im = Z3 ZZ Qy
+  fi_mul<N>(f, f, l);                  //                      (l dead)
   fp_mul<N>(S, V.X, YY);
   fp_dbl<N>(S, S);
-  fp_dbl<N>(S, S);                     // S = 4XY^2
+  fp_dbl<N>(S, S);                     // S = 4XY^2            (X dead)
   fp_sqr<N>(t0, YY);
   fp_dbl<N>(t0, t0);
   fp_dbl<N>(t0, t0);
-  fp_dbl<N>(t0, t0);                   // 8Y^4
+  fp_dbl<N>(t0, t0);                   // 8Y^4                 (YY dead)
   fp_sqr<N>(V.X, M);
   fp_dbl<N>(t1, S);
   fp_sub<N>(V.X, V.X, t1);             // X3 = M^2 - 2S
@@ -113,7 +116,6 @@ PBC_DEV void a_double_step(fp2<N> &f, jac<N> &V, const fp<N> &Qx, const fp<N> &Q
   fp_sub<N>(V.Y, t1, t0);              // Y3 = M(S - X3) - 8Y^4
   V.Z = Z3;
   fp_sqr<N>(V.ZZ, Z3);
-  fi_mul<N>(f, f, l);
 }
 
 // Mixed addition step of the Miller loop: f <- f * l_{V,P}(phi(Q)), V <- V + P, with

@@ -251,6 +251,64 @@ PBC_DEV void fp_sqr29_inl(fp<N> &r, const fp<N> &a) {
 }
 #undef PBC_MAC
 
+// ---------------------------------------------------------------------------------------
+// Limb-domain sum of products (lazy reduction for the extension towers):
+//     r = (x_0 y_0 + ... + x_{T-1} y_{T-1}) / R  mod q,   one Montgomery reduction for T products.
+// Operands and result stay in 29-bit limb form; results are < 2q (normalised limbs) and may be
+// fed straight into further sums.  Column bound: (T L + L) 2^58 < 2^64  ->  T <= 9 for L = 6.
+// Doubled operands (limbs < 2^30) count as two terms.
+// ---------------------------------------------------------------------------------------
+template <int N>
+struct fl {
+  uint32_t l[Limbs29<N>::L];
+};
+template <int N>
+PBC_DEV void to_limbs(fl<N> &r, const fp<N> &a) { to29<N>(r.l, a); }
+template <int N>
+PBC_DEV void limbs_dbl(fl<N> &r, const fl<N> &a) {
+#pragma unroll
+  for (int i = 0; i < Limbs29<N>::L; i++) r.l[i] = a.l[i] << 1;
+}
+// value < 2q in limb form -> fully reduced words
+template <int N>
+PBC_DEV void from_limbs(fp<N> &r, const fl<N> &a) {
+  uint32_t w[N];
+  uint32_t carry = from29<N>(w, a.l);
+  fp_cond_sub<N>(r, w, carry);
+}
+template <int N, int T, int DBL = 0>      // DBL: how many of the T terms have a doubled operand
+PBC_DEV void sop_limbs(fl<N> &r, const fl<N> (&x)[T], const fl<N> (&y)[T]) {
+  const FpK<N> &K = fpk<N>();
+  constexpr int L = Limbs29<N>::L;
+  constexpr uint32_t MASK = Limbs29<N>::MASK;
+  static_assert((T + DBL) * L + L <= 63, "column accumulator would overflow");
+  uint32_t m[L];
+  uint64_t acc = 0;
+#pragma unroll
+  for (int k = 0; k < L; k++) {
+#pragma unroll
+    for (int t = 0; t < T; t++)
+#pragma unroll
+      for (int i = 0; i <= k; i++) acc += (uint64_t) x[t].l[i] * y[t].l[k - i];
+#pragma unroll
+    for (int i = 0; i < k; i++) acc += (uint64_t) m[i] * K.p29[k - i];
+    m[k] = ((uint32_t) acc * K.ninv29) & MASK;
+    acc += (uint64_t) m[k] * K.p29[0];
+    acc >>= 29;
+  }
+#pragma unroll
+  for (int k = L; k < 2 * L; k++) {
+#pragma unroll
+    for (int t = 0; t < T; t++)
+#pragma unroll
+      for (int i = k - L + 1; i < L; i++) acc += (uint64_t) x[t].l[i] * y[t].l[k - i];
+#pragma unroll
+    for (int i = k - L + 1; i < L; i++) acc += (uint64_t) m[i] * K.p29[k - i];
+    r.l[k - L] = (uint32_t) acc & MASK;
+    acc >>= 29;
+  }
+}
+
 #ifndef PBC_MUL_IMPL
 #define PBC_MUL_IMPL 1      // 0: saturated 32-bit asm MACs, R = 2^(32N); 1/2: unsaturated, R = 2^(29L)
 #endif

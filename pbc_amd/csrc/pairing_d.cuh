@@ -51,43 +51,42 @@ PBC_DEV void f3_halve(f3 &r, const f3 &a) { for (int i = 0; i < 3; i++) fp_halve
 PBC_DEV void f3_mul_fq(f3 &r, const f3 &a, const fq &s) { for (int i = 0; i < 3; i++) fp_mul<ND>(r.c[i], a.c[i], s); }
 PBC_DEV bool f3_eq(const f3 &a, const f3 &b) { return fp_eq<ND>(a.c[0], b.c[0]) & fp_eq<ND>(a.c[1], b.c[1]) & fp_eq<ND>(a.c[2], b.c[2]); }
 
-// degree-4 product -> reduce with the x^3, x^4 table (polymod_mul_degree3, poly.c:910-930)
-PBC_DEV void f3_reduce(f3 &r, const fq &d0, const fq &d1, const fq &d2, const fq &d3, const fq &d4) {
-  fq t;
-  r.c[0] = d0; r.c[1] = d1; r.c[2] = d2;
+// F_q^3 product with lazy reduction (polymod_mul_degree3, poly.c:910-930: same ring element):
+//   d3 = a1 b2 + a2 b1,  d4 = a2 b2                       (x^3, x^4 coefficients, reduced once each)
+//   c_k = sum_{i+j=k} a_i b_j + d3 X3_k + d4 X4_k         (one reduction per output coefficient)
+// 15 limb products + 5 Montgomery reductions instead of 12 full products (6 Karatsuba + 6 table).
+PBC_DEV void f3_mul_inl(f3 &r, const f3 &a, const f3 &b) {
+  fl<ND> A[3], B[3], X3[3], X4[3], d3, d4, c;
 #pragma unroll
   for (int i = 0; i < 3; i++) {
-    fp_mul<ND>(t, d3, dk(c_d.xpwr[0][i]));
-    fp_add<ND>(r.c[i], r.c[i], t);
-    fp_mul<ND>(t, d4, dk(c_d.xpwr[1][i]));
-    fp_add<ND>(r.c[i], r.c[i], t);
+    to_limbs<ND>(A[i], a.c[i]);
+    to_limbs<ND>(B[i], b.c[i]);
+    to_limbs<ND>(X3[i], dk(c_d.xpwr[0][i]));
+    to_limbs<ND>(X4[i], dk(c_d.xpwr[1][i]));
   }
+  { const fl<ND> x[2] = {A[1], A[2]}, y[2] = {B[2], B[1]}; sop_limbs<ND, 2>(d3, x, y); }
+  { const fl<ND> x[1] = {A[2]}, y[1] = {B[2]}; sop_limbs<ND, 1>(d4, x, y); }
+  { const fl<ND> x[3] = {A[0], d3, d4}, y[3] = {B[0], X3[0], X4[0]}; sop_limbs<ND, 3>(c, x, y); from_limbs<ND>(r.c[0], c); }
+  { const fl<ND> x[4] = {A[0], A[1], d3, d4}, y[4] = {B[1], B[0], X3[1], X4[1]}; sop_limbs<ND, 4>(c, x, y); from_limbs<ND>(r.c[1], c); }
+  { const fl<ND> x[5] = {A[0], A[1], A[2], d3, d4}, y[5] = {B[2], B[1], B[0], X3[2], X4[2]}; sop_limbs<ND, 5>(c, x, y); from_limbs<ND>(r.c[2], c); }
 }
-// Karatsuba on three coefficients (kar_poly_2, poly.c:870-907): 6 + 6 F_q products
-PBC_DEV void f3_mul_inl(f3 &r, const f3 &a, const f3 &b) {
-  fq p0, p1, p2, c01, c02, c12, s, t;
-  fp_mul<ND>(p0, a.c[0], b.c[0]);
-  fp_mul<ND>(p1, a.c[1], b.c[1]);
-  fp_mul<ND>(p2, a.c[2], b.c[2]);
-  fp_add<ND>(s, a.c[0], a.c[1]); fp_add<ND>(t, b.c[0], b.c[1]); fp_mul<ND>(c01, s, t);
-  fp_add<ND>(s, a.c[0], a.c[2]); fp_add<ND>(t, b.c[0], b.c[2]); fp_mul<ND>(c02, s, t);
-  fp_add<ND>(s, a.c[1], a.c[2]); fp_add<ND>(t, b.c[1], b.c[2]); fp_mul<ND>(c12, s, t);
-  fp_sub<ND>(c01, c01, p0); fp_sub<ND>(c01, c01, p1);        // x^1
-  fp_sub<ND>(c02, c02, p0); fp_sub<ND>(c02, c02, p2); fp_add<ND>(c02, c02, p1);   // x^2
-  fp_sub<ND>(c12, c12, p1); fp_sub<ND>(c12, c12, p2);        // x^3
-  f3_reduce(r, p0, c01, c02, c12, p2);
-}
-// polymod_square_degree3 (poly.c:1049-1089)
+// polymod_square_degree3 (poly.c:1049-1089): d3 = 2 a1 a2, d4 = a2^2,
+//   c0 = a0^2 + ..., c1 = 2 a0 a1 + ..., c2 = 2 a0 a2 + a1^2 + ...
 PBC_DEV void f3_sqr_inl(f3 &r, const f3 &a) {
-  fq s0, s1, s2, m01, m02, m12;
-  fp_sqr<ND>(s0, a.c[0]);
-  fp_sqr<ND>(s1, a.c[1]);
-  fp_sqr<ND>(s2, a.c[2]);
-  fp_mul<ND>(m01, a.c[0], a.c[1]); fp_dbl<ND>(m01, m01);
-  fp_mul<ND>(m02, a.c[0], a.c[2]); fp_dbl<ND>(m02, m02);
-  fp_mul<ND>(m12, a.c[1], a.c[2]); fp_dbl<ND>(m12, m12);
-  fp_add<ND>(m02, m02, s1);
-  f3_reduce(r, s0, m01, m02, m12, s2);
+  fl<ND> A[3], A2[2], X3[3], X4[3], d3, d4, c;
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    to_limbs<ND>(A[i], a.c[i]);
+    to_limbs<ND>(X3[i], dk(c_d.xpwr[0][i]));
+    to_limbs<ND>(X4[i], dk(c_d.xpwr[1][i]));
+  }
+  limbs_dbl<ND>(A2[0], A[0]);
+  limbs_dbl<ND>(A2[1], A[1]);
+  { const fl<ND> x[1] = {A2[1]}, y[1] = {A[2]}; sop_limbs<ND, 1, 1>(d3, x, y); }
+  { const fl<ND> x[1] = {A[2]}, y[1] = {A[2]}; sop_limbs<ND, 1>(d4, x, y); }
+  { const fl<ND> x[3] = {A[0], d3, d4}, y[3] = {A[0], X3[0], X4[0]}; sop_limbs<ND, 3>(c, x, y); from_limbs<ND>(r.c[0], c); }
+  { const fl<ND> x[3] = {A2[0], d3, d4}, y[3] = {A[1], X3[1], X4[1]}; sop_limbs<ND, 3, 1>(c, x, y); from_limbs<ND>(r.c[1], c); }
+  { const fl<ND> x[4] = {A2[0], A[1], d3, d4}, y[4] = {A[2], A[1], X3[2], X4[2]}; sop_limbs<ND, 4, 1>(c, x, y); from_limbs<ND>(r.c[2], c); }
 }
 // Out-of-line F_q^3 product / square (30 / 15 VGPR arguments): one body each keeps the
 // Miller and Lucas loops inside the instruction cache.

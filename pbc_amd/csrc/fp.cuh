@@ -309,6 +309,53 @@ PBC_DEV void sop_limbs(fl<N> &r, const fl<N> (&x)[T], const fl<N> (&y)[T]) {
   }
 }
 
+// Wide accumulator form of the same idea for rolled loops with a run-time number of terms:
+// 2L 64-bit column accumulators take products without any carry handling; one Montgomery
+// reduction at the end.  Capacity: `units` <= 9 for L = 6 (a term with a doubled operand
+// counts as two units): (units + 1) L 2^58 < 2^64.
+template <int N>
+struct wide {
+  uint64_t c[2 * Limbs29<N>::L - 1];
+};
+template <int N>
+PBC_DEV void wide_zero(wide<N> &W) {
+#pragma unroll
+  for (int k = 0; k < 2 * Limbs29<N>::L - 1; k++) W.c[k] = 0;
+}
+template <int N>
+PBC_DEV void wide_mac(wide<N> &W, const fl<N> &x, const fl<N> &y) {
+  constexpr int L = Limbs29<N>::L;
+#pragma unroll
+  for (int i = 0; i < L; i++)
+#pragma unroll
+    for (int j = 0; j < L; j++) W.c[i + j] += (uint64_t) x.l[i] * y.l[j];
+}
+template <int N>
+PBC_DEV void wide_reduce(fl<N> &r, const wide<N> &W) {
+  const FpK<N> &K = fpk<N>();
+  constexpr int L = Limbs29<N>::L;
+  constexpr uint32_t MASK = Limbs29<N>::MASK;
+  uint32_t m[L];
+  uint64_t acc = 0;
+#pragma unroll
+  for (int k = 0; k < L; k++) {
+    acc += W.c[k];
+#pragma unroll
+    for (int i = 0; i < k; i++) acc += (uint64_t) m[i] * K.p29[k - i];
+    m[k] = ((uint32_t) acc * K.ninv29) & MASK;
+    acc += (uint64_t) m[k] * K.p29[0];
+    acc >>= 29;
+  }
+#pragma unroll
+  for (int k = L; k < 2 * L; k++) {
+    if (k < 2 * L - 1) acc += W.c[k];
+#pragma unroll
+    for (int i = k - L + 1; i < L; i++) acc += (uint64_t) m[i] * K.p29[k - i];
+    r.l[k - L] = (uint32_t) acc & MASK;
+    acc >>= 29;
+  }
+}
+
 #ifndef PBC_MUL_IMPL
 #define PBC_MUL_IMPL 1      // 0: saturated 32-bit asm MACs, R = 2^(32N); 1/2: unsaturated, R = 2^(29L)
 #endif

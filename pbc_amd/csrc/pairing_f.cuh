@@ -54,28 +54,47 @@ PBC_DEV void g2_zero(g2 &r) {
 #pragma unroll
   for (int k = 0; k < ND; k++) { r.x.v[k] = 0; r.y.v[k] = 0; }
 }
-// fq_mul (fieldquadratic.c:197-233): Karatsuba + one product by beta
-PBC_DEV void g2_mul(g2 &r, const g2 &a, const g2 &b) {
-  fq e0, e1, e2, t;
-  fp_add<ND>(e0, a.x, a.y);
-  fp_add<ND>(e1, b.x, b.y);
-  fp_mul<ND>(e2, e0, e1);
-  fp_mul<ND>(e0, a.x, b.x);
-  fp_mul<ND>(e1, a.y, b.y);
-  fp_mul<ND>(t, e1, dk(c_f.beta));
-  fp_sub<ND>(e2, e2, e0);
-  fp_sub<ND>(r.y, e2, e1);
-  fp_add<ND>(r.x, t, e0);
+// fq_mul (fieldquadratic.c:197-233), lazily reduced:  t = beta a.y;
+//   re = a.x b.x + t b.y,  im = a.x b.y + a.y b.x     (5 limb products, 3 reductions)
+PBC_DEV void g2_mul_inl(g2 &r, const g2 &a, const g2 &b) {
+  fl<ND> ax, ay, bx, by, be, t, c;
+  to_limbs<ND>(ax, a.x); to_limbs<ND>(ay, a.y);
+  to_limbs<ND>(bx, b.x); to_limbs<ND>(by, b.y);
+  to_limbs<ND>(be, dk(c_f.beta));
+  { const fl<ND> x[1] = {ay}, y[1] = {be}; sop_limbs<ND, 1>(t, x, y); }
+  { const fl<ND> x[2] = {ax, t}, y[2] = {bx, by}; sop_limbs<ND, 2>(c, x, y); from_limbs<ND>(r.x, c); }
+  { const fl<ND> x[2] = {ax, ay}, y[2] = {by, bx}; sop_limbs<ND, 2>(c, x, y); from_limbs<ND>(r.y, c); }
 }
-// fq_square (fieldquadratic.c:249-269)
+// fq_square (fieldquadratic.c:249-269): re = a.x^2 + beta a.y^2, im = 2 a.x a.y
+PBC_DEV void g2_sqr_inl(g2 &r, const g2 &a) {
+  fl<ND> ax, ay, ax2, be, t, c;
+  to_limbs<ND>(ax, a.x); to_limbs<ND>(ay, a.y);
+  to_limbs<ND>(be, dk(c_f.beta));
+  limbs_dbl<ND>(ax2, ax);
+  { const fl<ND> x[1] = {ay}, y[1] = {be}; sop_limbs<ND, 1>(t, x, y); }
+  { const fl<ND> x[2] = {ax, t}, y[2] = {ax, ay}; sop_limbs<ND, 2>(c, x, y); from_limbs<ND>(r.x, c); }
+  { const fl<ND> x[1] = {ax2}, y[1] = {ay}; sop_limbs<ND, 1, 1>(c, x, y); from_limbs<ND>(r.y, c); }
+}
+struct g2ret { v5 x, y; };
+static __device__ __noinline__ g2ret g2_mul_call(v5 ax, v5 ay, v5 bx, v5 by) {
+  g2 a, b, r;
+  from_vec<ND>(a.x, ax); from_vec<ND>(a.y, ay); from_vec<ND>(b.x, bx); from_vec<ND>(b.y, by);
+  g2_mul_inl(r, a, b);
+  return g2ret{to_vec<ND>(r.x), to_vec<ND>(r.y)};
+}
+static __device__ __noinline__ g2ret g2_sqr_call(v5 ax, v5 ay) {
+  g2 a, r;
+  from_vec<ND>(a.x, ax); from_vec<ND>(a.y, ay);
+  g2_sqr_inl(r, a);
+  return g2ret{to_vec<ND>(r.x), to_vec<ND>(r.y)};
+}
+PBC_DEV void g2_mul(g2 &r, const g2 &a, const g2 &b) {
+  g2ret t = g2_mul_call(to_vec<ND>(a.x), to_vec<ND>(a.y), to_vec<ND>(b.x), to_vec<ND>(b.y));
+  from_vec<ND>(r.x, t.x); from_vec<ND>(r.y, t.y);
+}
 PBC_DEV void g2_sqr(g2 &r, const g2 &a) {
-  fq e0, e1, t;
-  fp_sqr<ND>(e0, a.x);
-  fp_sqr<ND>(e1, a.y);
-  fp_mul<ND>(e1, e1, dk(c_f.beta));
-  fp_mul<ND>(t, a.x, a.y);
-  fp_add<ND>(r.x, e0, e1);
-  fp_dbl<ND>(r.y, t);
+  g2ret t = g2_sqr_call(to_vec<ND>(a.x), to_vec<ND>(a.y));
+  from_vec<ND>(r.x, t.x); from_vec<ND>(r.y, t.y);
 }
 // fq_invert (fieldquadratic.c:290-309)
 PBC_DEV void g2_inv(g2 &r, const g2 &a) {
@@ -100,21 +119,28 @@ __device__ __noinline__ void f12_one(f12 *r) {
   for (int i = 0; i < 6; i++) g2_zero(r->c[i]);
   r->c[0].x = one;
 }
-// polymod_mul (poly.c:1005-1047): schoolbook, X^(6+i) = negalpha X^i
-__device__ __noinline__ void f12_mul(f12 *r, const f12 *a, const f12 *b) {
-  g2 d[11];
-#pragma nounroll
-  for (int i = 0; i < 11; i++) g2_zero(d[i]);
+// Limb forms of the six coefficients of an operand: x, y and beta*y (needed by every product)
+struct f12l { fl<ND> x[6], y[6], by[6]; };
+__device__ __noinline__ void f12_to_limbs(f12l *L, const f12 *a, bool with_by) {
+  fl<ND> be;
+  to_limbs<ND>(be, dk(c_f.beta));
 #pragma nounroll
   for (int i = 0; i < 6; i++) {
-    g2 ai = a->c[i];
-#pragma nounroll
-    for (int j = 0; j < 6; j++) {
-      g2 t;
-      g2_mul(t, ai, b->c[j]);
-      g2_add(d[i + j], d[i + j], t);
+    fl<ND> x, y;
+    to_limbs<ND>(x, a->c[i].x);
+    to_limbs<ND>(y, a->c[i].y);
+    L->x[i] = x;
+    L->y[i] = y;
+    if (with_by) {
+      fl<ND> t;
+      const fl<ND> xx[1] = {y}, yy[1] = {be};
+      sop_limbs<ND, 1>(t, xx, yy);
+      L->by[i] = t;
     }
   }
+}
+// d (11 coefficients of the degree-10 product) -> r = d mod (X^6 - negalpha)
+__device__ __noinline__ void f12_fold(f12 *r, const g2 *d) {
   const g2 na = fk2(c_f.negalpha);
 #pragma nounroll
   for (int i = 0; i < 6; i++) {
@@ -127,34 +153,99 @@ __device__ __noinline__ void f12_mul(f12 *r, const f12 *a, const f12 *b) {
     r->c[i] = t;
   }
 }
-// polymod_square (poly.c:1091-1143)
-__device__ __noinline__ void f12_sqr(f12 *r, const f12 *a) {
+// polymod_mul (poly.c:1005-1047): schoolbook over the coefficients, X^(6+i) = negalpha X^i.
+// Coefficient k of the product:  re = sum_{i+j=k} a_i.x b_j.x + (beta a_i.y) b_j.y,
+//                                im = sum_{i+j=k} a_i.x b_j.y + a_i.y b_j.x
+// accumulated UNREDUCED in wide column accumulators (up to 4 pairs = 8 products per Montgomery
+// reduction instead of one reduction per F_q product).
+__device__ __noinline__ void f12_mul(f12 *r, const f12 *a, const f12 *b) {
+  f12l A, B;
+  f12_to_limbs(&A, a, true);
+  f12_to_limbs(&B, b, false);
   g2 d[11];
 #pragma nounroll
-  for (int i = 0; i < 11; i++) g2_zero(d[i]);
+  for (int k = 0; k < 11; k++) {
+    const int lo = k > 5 ? k - 5 : 0, hi = k < 5 ? k : 5;
+    g2 acc;
+    g2_zero(acc);
+    wide<ND> Wx, Wy;
+    wide_zero<ND>(Wx);
+    wide_zero<ND>(Wy);
+    int cnt = 0;
 #pragma nounroll
-  for (int i = 0; i < 6; i++) {
-    g2 ai = a->c[i], t;
-    g2_sqr(t, ai);
-    g2_add(d[2 * i], d[2 * i], t);
-#pragma nounroll
-    for (int j = i + 1; j < 6; j++) {
-      g2_mul(t, ai, a->c[j]);
-      g2_dbl(t, t);
-      g2_add(d[i + j], d[i + j], t);
+    for (int i = lo; i <= hi; i++) {
+      const int j = k - i;
+      const fl<ND> ax = A.x[i], ay = A.y[i], aby = A.by[i], bx = B.x[j], by = B.y[j];
+      wide_mac<ND>(Wx, ax, bx);
+      wide_mac<ND>(Wx, aby, by);
+      wide_mac<ND>(Wy, ax, by);
+      wide_mac<ND>(Wy, ay, bx);
+      if (++cnt == 4 || i == hi) {
+        fl<ND> t;
+        fq u;
+        wide_reduce<ND>(t, Wx); from_limbs<ND>(u, t); fp_add<ND>(acc.x, acc.x, u);
+        wide_reduce<ND>(t, Wy); from_limbs<ND>(u, t); fp_add<ND>(acc.y, acc.y, u);
+        wide_zero<ND>(Wx);
+        wide_zero<ND>(Wy);
+        cnt = 0;
+      }
     }
+    d[k] = acc;
   }
-  const g2 na = fk2(c_f.negalpha);
+  f12_fold(r, d);
+}
+// polymod_square (poly.c:1091-1143): cross terms once with a doubled operand, squares once.
+// A cross pair is 2 doubled products per accumulator (4 capacity units), a square pair 2 units.
+__device__ __noinline__ void f12_sqr(f12 *r, const f12 *a) {
+  f12l A;
+  f12_to_limbs(&A, a, true);
+  g2 d[11];
 #pragma nounroll
-  for (int i = 0; i < 6; i++) {
-    g2 t = d[i];
-    if (i < 5) {
-      g2 u;
-      g2_mul(u, d[6 + i], na);
-      g2_add(t, t, u);
+  for (int k = 0; k < 11; k++) {
+    const int lo = k > 5 ? k - 5 : 0, hi = k < 5 ? k : 5;
+    g2 acc;
+    g2_zero(acc);
+    wide<ND> Wx, Wy;
+    wide_zero<ND>(Wx);
+    wide_zero<ND>(Wy);
+    int units = 0;
+#pragma nounroll
+    for (int i = lo; 2 * i <= k; i++) {
+      const int j = k - i;
+      const fl<ND> ax = A.x[i], ay = A.y[i], aby = A.by[i];
+      if (i == j) {
+        // a_i^2: re = x^2 + (beta y) y, im = 2 x y
+        fl<ND> ax2;
+        limbs_dbl<ND>(ax2, ax);
+        wide_mac<ND>(Wx, ax, ax);
+        wide_mac<ND>(Wx, aby, ay);
+        wide_mac<ND>(Wy, ax2, ay);
+        units += 2;
+      } else {
+        // 2 a_i a_j
+        fl<ND> bx2, by2;
+        limbs_dbl<ND>(bx2, A.x[j]);
+        limbs_dbl<ND>(by2, A.y[j]);
+        wide_mac<ND>(Wx, ax, bx2);
+        wide_mac<ND>(Wx, aby, by2);
+        wide_mac<ND>(Wy, ax, by2);
+        wide_mac<ND>(Wy, ay, bx2);
+        units += 4;
+      }
+      const bool last = (2 * (i + 1) > k);
+      if (units >= 6 || last) {
+        fl<ND> t;
+        fq u;
+        wide_reduce<ND>(t, Wx); from_limbs<ND>(u, t); fp_add<ND>(acc.x, acc.x, u);
+        wide_reduce<ND>(t, Wy); from_limbs<ND>(u, t); fp_add<ND>(acc.y, acc.y, u);
+        wide_zero<ND>(Wx);
+        wide_zero<ND>(Wy);
+        units = 0;
+      }
     }
-    r->c[i] = t;
+    d[k] = acc;
   }
+  f12_fold(r, d);
 }
 // coefficient-wise even-power Frobenius: out^(q^k), X^(q^k) = e X (qpower, f_param.c:257-268)
 __device__ __noinline__ void f12_qpower(f12 *r, const f12 *a, const uint32_t (*ew)[ND]) {

@@ -196,6 +196,48 @@ static int init_type_f(pbc_hip_pairing_s *P, const char *txt, size_t len) {
   if (!rem.is_zero() || te.bits() > 512) return fail("type f: r does not divide q^4 - q^2 + 1");
   te.to_words(P->fconst.tateexp, 16);
   P->fconst.tebits = te.bits();
+  // Recognise the BN family (genfparam / f_param.c:70-95): q = 36x^4 + 36x^3 + 24x^2 + 6x + 1
+  // with x of either sign, r = 36x^4 + 36x^3 + 18x^2 + 6x + 1.  Binary search on |x|.
+  {
+    auto poly = [](uint64_t ax, int sign, unsigned c2) {      // 36x^4 +- 36x^3 + c2 x^2 +- 6x + 1
+      Big x, t, acc;
+      x.w = {(uint32_t) ax, (uint32_t) (ax >> 32)};
+      x.trim();
+      Big x2 = Big::mul(x, x), x3 = Big::mul(x2, x), x4 = Big::mul(x2, x2);
+      auto times = [](const Big &a, uint32_t k) { Big kk; kk.w.push_back(k); return Big::mul(a, kk); };
+      auto add = [](Big a, const Big &b) {
+        uint64_t c = 0;
+        if (a.w.size() < b.w.size()) a.w.resize(b.w.size(), 0);
+        for (size_t i = 0; i < a.w.size(); i++) { c += (uint64_t) a.w[i] + (i < b.w.size() ? b.w[i] : 0); a.w[i] = (uint32_t) c; c >>= 32; }
+        if (c) a.w.push_back((uint32_t) c);
+        return a;
+      };
+      acc = add(times(x4, 36), times(x2, c2));
+      acc.add_small(1);
+      Big odd = add(times(x3, 36), times(x, 6));
+      if (sign > 0) acc = add(acc, odd); else acc.sub(odd);
+      return acc;
+    };
+    P->fconst.bn_ok = 0;
+    for (int sign = 1; sign >= -1 && !P->fconst.bn_ok; sign -= 2) {
+      uint64_t lo = 2, hi = (uint64_t) 1 << 62;
+      // q ~ 36 x^4  ->  x < 2^((bits+3)/4)
+      hi = (uint64_t) 1 << ((q.bits() + 3) / 4);
+      while (lo < hi) {
+        uint64_t mid = lo + (hi - lo) / 2;
+        if (Big::cmp(poly(mid, sign, 24), q) < 0) lo = mid + 1; else hi = mid;
+      }
+      if (Big::cmp(poly(lo, sign, 24), q) == 0 && Big::cmp(poly(lo, sign, 18), r) == 0) {
+        P->fconst.bn_ok = 1;
+        P->fconst.bn_xneg = sign < 0;
+        P->fconst.bn_x[0] = (uint32_t) lo;
+        P->fconst.bn_x[1] = (uint32_t) (lo >> 32);
+        int nb = 0;
+        for (uint64_t t = lo; t; t >>= 1) nb++;
+        P->fconst.bn_xbits = nb;
+      }
+    }
+  }
   P->nlimb = 5;
   P->len_fq = (q.bits() + 7) / 8;
   if (P->len_fq != 20) return fail("type f: q must serialise to 20 bytes");

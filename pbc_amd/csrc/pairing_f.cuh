@@ -38,6 +38,12 @@ struct FConst {                        // f_pairing_data_s (ecc/f_param.c:35-45)
   uint32_t r[8];
   uint32_t tateexp[16];                // (q^4 - q^2 + 1)/r (f_param.c:414-420)
   int rbits, tebits;
+  // BN structure (f_param.c:70-95 tryplusx/tryminusx): q = 36x^4+36x^3+24x^2+6x+1,
+  // r = 36x^4+36x^3+18x^2+6x+1.  When the host recognises it, the hard part uses the
+  // x-chain instead of a 472-bit power.
+  uint32_t gamma[2][ND];               // X^q = gamma X, gamma = negalpha^((q-1)/6)
+  uint32_t bn_x[2];                    // |x|
+  int bn_ok, bn_xneg, bn_xbits;
 };
 __constant__ FConst c_f;
 
@@ -423,6 +429,35 @@ __device__ __noinline__ bool f_miller_lane(f12 *v, const uint8_t *g1, const uint
   return valid;
 }
 
+// a^q: conjugate the F_q^2 coefficients and scale by gamma^i (X^q = gamma X)
+__device__ __noinline__ void f12_frob(f12 *r, const f12 *a) {
+  const g2 gm = fk2(c_f.gamma);
+  g2 gpow = gm;
+  {
+    g2 t = a->c[0];
+    fp_neg<ND>(t.y, t.y);
+    r->c[0] = t;
+  }
+#pragma nounroll
+  for (int i = 1; i < 6; i++) {
+    g2 t = a->c[i], u;
+    fp_neg<ND>(t.y, t.y);
+    g2_mul(u, t, gpow);
+    r->c[i] = u;
+    g2_mul(gpow, gpow, gm);
+  }
+}
+// a^|x| by square-and-multiply (wave-uniform bits)
+__device__ __noinline__ void f12_pow_x(f12 *r, const f12 *a) {
+  f12 acc = *a;
+#pragma nounroll
+  for (int i = c_f.bn_xbits - 2; i >= 0; i--) {
+    f12_sqr(&acc, &acc);
+    if ((c_f.bn_x[i >> 5] >> (i & 31)) & 1) f12_mul(&acc, &acc, a);
+  }
+  *r = acc;
+}
+
 // f_tateexp (f_param.c:250-283)
 __device__ __noinline__ void f_final_exp(f12 *out) {
   f12 x, y;
@@ -433,8 +468,62 @@ __device__ __noinline__ void f_final_exp(f12 *out) {
   f12_mul(&x, &x, out);
   f12_inv(&x, &x);
   f12_mul(out, &y, &x);
-  // element_pow_mpz(out, out, tateexp): generic_pow_mpz (field.c:14-126) is a sliding window;
-  // any addition chain gives the same group element.  Fixed 4-bit window here.
+  if (c_f.bn_ok) {
+    // Hard part out^((q^4-q^2+1)/r) for BN parameters.  With l3 = 1, l2 = 6x^2+1,
+    // l1 = -36x^3-18x^2-12x+1, l0 = -36x^3-30x^2-18x-2 the exponent equals
+    // l0 + l1 q + l2 q^2 + l3 q^3 (checked by the host for the actual q, r), evaluated with the
+    // vector chain  y0 y1^2 y2^6 y3^12 y4^18 y5^30 y6^36  (Scott et al., "On the final
+    // exponentiation for calculating pairings on ordinary elliptic curves").  After the easy
+    // part `out` is in the cyclotomic subgroup, where inversion is the q^6 Frobenius.
+    // The reference raises to the same integer with generic_pow_mpz (field.c:14-126).
+    f12 fx, fx2, fx3, t0, t1, y0, y2, y3, y4, y5, y6;
+    f12_pow_x(&fx, out);
+    if (c_f.bn_xneg) f12_qpower(&fx, &fx, c_f.xpowq6);
+    f12_pow_x(&fx2, &fx);
+    if (c_f.bn_xneg) f12_qpower(&fx2, &fx2, c_f.xpowq6);
+    f12_pow_x(&fx3, &fx2);
+    if (c_f.bn_xneg) f12_qpower(&fx3, &fx3, c_f.xpowq6);
+    // y0 = f^q f^(q^2) f^(q^3)
+    f12_frob(&t0, out);
+    f12_qpower(&t1, out, c_f.xpowq2);
+    f12_mul(&y0, &t0, &t1);
+    f12_frob(&t0, &t1);
+    f12_mul(&y0, &y0, &t0);
+    // y2 = (f^(x^2))^(q^2)
+    f12_qpower(&y2, &fx2, c_f.xpowq2);
+    // y3 = 1 / (f^x)^q
+    f12_frob(&y3, &fx);
+    f12_qpower(&y3, &y3, c_f.xpowq6);
+    // y4 = 1 / (f^x (f^(x^2))^q)
+    f12_frob(&t0, &fx2);
+    f12_mul(&y4, &t0, &fx);
+    f12_qpower(&y4, &y4, c_f.xpowq6);
+    // y5 = 1 / f^(x^2)
+    f12_qpower(&y5, &fx2, c_f.xpowq6);
+    // y6 = 1 / (f^(x^3) (f^(x^3))^q)
+    f12_frob(&t0, &fx3);
+    f12_mul(&y6, &t0, &fx3);
+    f12_qpower(&y6, &y6, c_f.xpowq6);
+    // y1 = 1/f
+    f12_qpower(&x, out, c_f.xpowq6);
+    // T0 = y6^2 y4 y5;  T1 = y3 y5 T0;  T0 = T0 y2;  T1 = (T1^2 T0)^2;  T0 = T1 y1;  T1 = T1 y0
+    f12_sqr(&t0, &y6);
+    f12_mul(&t0, &t0, &y4);
+    f12_mul(&t0, &t0, &y5);
+    f12_mul(&t1, &y3, &y5);
+    f12_mul(&t1, &t1, &t0);
+    f12_mul(&t0, &t0, &y2);
+    f12_sqr(&t1, &t1);
+    f12_mul(&t1, &t1, &t0);
+    f12_sqr(&t1, &t1);
+    f12_mul(&t0, &t1, &x);
+    f12_mul(&t1, &t1, &y0);
+    f12_sqr(&t0, &t0);
+    f12_mul(out, &t0, &t1);
+    return;
+  }
+  // generic parameters: element_pow_mpz(out, out, tateexp); generic_pow_mpz (field.c:14-126) is
+  // a sliding window; any addition chain gives the same group element.  Fixed 4-bit window.
   f12 tab[16];
   f12_one(&tab[0]);
   tab[1] = *out;
@@ -544,6 +633,7 @@ __global__ void f_init_stage2(FConst *out, FRaw raw) {
     C.xpowq2[0][k] = n.v[k];  C.xpowq2[1][k] = 0;
     C.xpowq6[0][k] = n3.v[k]; C.xpowq6[1][k] = 0;
     C.xpowq8[0][k] = n4.v[k]; C.xpowq8[1][k] = 0;
+    C.gamma[0][k] = c.x.v[k]; C.gamma[1][k] = c.y.v[k];
   }
   *out = C;
 }

@@ -219,7 +219,9 @@ static int init_type_f(pbc_hip_pairing_s *P, const char *txt, size_t len) {
       return acc;
     };
     P->fconst.bn_ok = 0;
-    for (int sign = 1; sign >= -1 && !P->fconst.bn_ok; sign -= 2) {
+    int no_bn = 0;                       // "hip_no_bn 1" in the parameter text forces the generic power
+    param_int(txt, len, "hip_no_bn", no_bn);
+    for (int sign = 1; sign >= -1 && !P->fconst.bn_ok && !no_bn; sign -= 2) {
       uint64_t lo = 2, hi = (uint64_t) 1 << 62;
       // q ~ 36 x^4  ->  x < 2^((bits+3)/4)
       hi = (uint64_t) 1 << ((q.bits() + 3) / 4);

@@ -251,3 +251,67 @@ def test_reference_call_sites_run_on_gpu_through_the_glue(pname):
     r = subprocess.run([oracle.GLUE_TEST, os.path.join(pbc_amd.PARAM_DIR, pname + ".param"), "120"],
                        capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0 and "PASS" in r.stdout, r.stdout + r.stderr
+
+
+def test_f_generic_hard_part_on_gpu():
+    """Non-BN Type-F parameters use the fixed-window power; force it on f.param."""
+    import pbc_amd
+    from conftest import _param
+    v = golden("f_rand16.vec")
+    P = pbc_amd.Pairing(_param("f") + "hip_no_bn 1\n")
+    assert np.array_equal(P.element_pairing(v.g1, v.g2), v.gt)
+
+
+@pytest.mark.parametrize("t,log2n", [("d", 18), ("f", 18)])
+def test_df_full_size_batch_properties(hips, t, log2n):
+    """BASELINE configs 3/4: 2^18 pairings in one launch on device-resident buffers.  All
+    (P_i, Q_j) of the chain fixture, tiled: e(P_i,Q_j) = e(P0,Q0)^((i+1)(j+1)) = e(P_j,Q_i), so the
+    DxD result matrix is symmetric, every tile repeats it, and its diagonal is the fixture."""
+    import torch
+    v = golden(DF_FILES[t]["chain"])
+    P = hips[t]
+    D = v.n
+    n = 1 << log2n
+    L1, L2, LT = P.length_in_bytes_G1, P.length_in_bytes_G2, P.length_in_bytes_GT
+    g1 = torch.from_numpy(v.g1).cuda()
+    g2 = torch.from_numpy(v.g2).cuda()
+    idx = torch.arange(n, device="cuda")
+    G1 = g1[(idx // D) % D].contiguous()
+    G2 = g2[idx % D].contiguous()
+    GT = torch.empty(n, LT, dtype=torch.uint8, device="cuda")
+    P.element_pairing_dev(GT.data_ptr(), G1.data_ptr(), G2.data_ptr(), n, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    M = GT.reshape(n // (D * D), D, D, LT)
+    assert torch.equal(M[0], M[0].transpose(0, 1))
+    for rep in range(1, M.shape[0]):
+        assert torch.equal(M[rep], M[0])
+    assert np.array_equal(M[0][torch.arange(D), torch.arange(D)].cpu().numpy(), v.gt)
+
+
+def test_a_prod16_full_size_batch_properties(hip_a, oracle_a):
+    """BASELINE config 5: 2^18 products of 16 Type-A pairings in one launch.  Size-independent
+    checks: reversing the 16 terms of every product must not change a single output byte, and a
+    seeded sample equals the oracle's a_pairings_affine."""
+    import torch
+    v = golden("a_chain1024.vec")
+    k, n, D = 16, 1 << 18, 1024
+    g1 = torch.from_numpy(v.g1).cuda()
+    g2 = torch.from_numpy(v.g2).cuda()
+    t = torch.arange(n * k, device="cuda")
+    i1, i2 = (t * 7 + t // D) % D, (t * 13 + 5) % D
+    G1, G2 = g1[i1].contiguous(), g2[i2].contiguous()
+    rev = (torch.arange(n, device="cuda")[:, None] * k + torch.arange(k - 1, -1, -1, device="cuda")[None, :]).reshape(-1)
+    R1, R2 = G1[rev].contiguous(), G2[rev].contiguous()
+    A = torch.empty(n, 128, dtype=torch.uint8, device="cuda")
+    B = torch.empty(n, 128, dtype=torch.uint8, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    hip_a.element_prod_pairing_dev(A.data_ptr(), G1.data_ptr(), G2.data_ptr(), n, k, s)
+    hip_a.element_prod_pairing_dev(B.data_ptr(), R1.data_ptr(), R2.data_ptr(), n, k, s)
+    torch.cuda.synchronize()
+    assert torch.equal(A, B)
+    rng = np.random.default_rng(17)
+    us = rng.integers(0, n, 6)
+    for u in us:
+        sl = slice(int(u) * k, int(u) * k + k)
+        want = oracle_a.prod_pairing_batch(G1[sl].cpu().numpy(), G2[sl].cpu().numpy(), k)
+        assert np.array_equal(A[int(u)].cpu().numpy(), want[0])

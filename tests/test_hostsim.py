@@ -43,3 +43,11 @@ def test_kernel_fq_ops_on_host(sims, oracles, t, q):
     B = np.stack([np.frombuffer(y.to_bytes(nb, "big"), np.uint8) for y in ys])
     for op in range(7):
         assert np.array_equal(sims[t].fq_op(op, A, B), oracles[t].fq_op(op, A, B)), op
+
+
+def test_type_f_generic_hard_part_on_host():
+    """f.param is a BN curve and takes the x-chain; the generic fixed-window power over
+    (q^4-q^2+1)/r (any Type-F parameters) must give the same bytes."""
+    v = golden("f_rand16.vec")
+    sim = hostsim.HostSim(_param("f") + "hip_no_bn 1\n")
+    assert np.array_equal(sim.prod_pairing(v.g1[:2], v.g2[:2], 1), v.gt[:2])

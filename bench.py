@@ -110,6 +110,7 @@ WORKLOADS = {
     "d": ("d159", "d_chain256.vec", 1, 18, "Type D (d159.param) element_pairing"),
     "f": ("f", "f_chain128.vec", 1, 18, "Type F (f.param) element_pairing"),
     "a-prod16": ("a", "a_chain1024.vec", 16, 18, "Type A (a.param) element_prod_pairing, 16 terms"),
+    "a-pp": ("a", "a_chain1024.vec", 1, 20, "Type A (a.param) pairing_pp_apply, fixed first argument"),
 }
 
 
@@ -156,8 +157,12 @@ def main():
     GT = torch.empty(n, LT, dtype=torch.uint8, device="cuda")
     stream = torch.cuda.current_stream()
 
+    pp = pairing.pp_init(g1[0]) if args.workload == "a-pp" else None
+
     def step():
-        if k == 1:
+        if pp is not None:
+            pp.apply_dev(GT.data_ptr(), G2.data_ptr(), n, stream.cuda_stream)
+        elif k == 1:
             pairing.element_pairing_dev(GT.data_ptr(), G1.data_ptr(), G2.data_ptr(), n, stream.cuda_stream)
         else:
             pairing.element_prod_pairing_dev(GT.data_ptr(), G1.data_ptr(), G2.data_ptr(), n, k, stream.cuda_stream)
@@ -173,7 +178,16 @@ def main():
     torch.cuda.synchronize()
     # correctness gate against the reference's own outputs stored in the fixture:
     #   k == 1: unit i*(D+1) is e(P_i, Q_i);  k > 1: bilinearity cross-check below
-    if rot == 0 and k == 1:
+    if pp is not None:
+        if not np.array_equal(GT[0].cpu().numpy(), gt_ref[0]):     # unit 0 is e(P_0, Q_0)
+            sys.exit("bench.py: pp_apply differs from the reference fixture -- refusing to time")
+        chk = torch.empty(256, LT, dtype=torch.uint8, device="cuda")
+        P0 = d1[:1].expand(256, L1).contiguous()
+        pairing.element_pairing_dev(chk.data_ptr(), P0.data_ptr(), G2[:256].contiguous().data_ptr(), 256, stream.cuda_stream)
+        torch.cuda.synchronize()
+        if not torch.equal(chk, GT[:256]):
+            sys.exit("bench.py: pp_apply differs from element_pairing -- refusing to time")
+    elif rot == 0 and k == 1:
         m = min(D, (n - 1) // (D + 1) + 1)
         idx = torch.arange(m, device="cuda") * (D + 1)
         if not np.array_equal(GT[idx].cpu().numpy(), gt_ref[:m]):
@@ -211,6 +225,8 @@ def main():
         value = total_units / dt
         avg_kern_s = sum(kern_ms) / len(kern_ms) * 1e-3
         macs_per_unit = pairing.algorithmic_macs_per_unit(k)
+        if pp is not None:
+            macs_per_unit = 1838.0 * 528     # reference a_pairing_pp_apply: 1838 F_q products
         # measured integer multiply-add peak of this chip (register-only v_mad_u64_u32 probe)
         peak_macs, _ = pbc_amd.int_mac_peak(0, 4000)
         achieved_macs = n * macs_per_unit / avg_kern_s

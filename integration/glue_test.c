@@ -41,6 +41,34 @@ int main(int argc, char **argv) {
   }
   element_prod_pairing(gprod, P + 8, Q + 8, K);
   if (element_cmp(gprod, cprod)) { printf("element_prod_pairing mismatch\n"); fails++; }
+  /* 1b. preprocessed pairings through pairing->pp_init/pp_apply (type A) */
+  if (strstr(text, "type a")) {
+    pairing_pp_t pp;
+    pairing_pp_init(pp, P[0], pairing);
+    for (size_t i = 0; i < 6 && i < n; i++) {
+      element_t c2;
+      element_init_GT(c2, pairing);
+      pairing_pp_apply(gpu[i], Q[i], pp);
+      pbc_hip_detach(pairing);
+      element_pairing(c2, P[0], Q[i]);                    /* CPU reference */
+      if (pbc_hip_attach(pairing, text, len)) return 1;
+      if (element_cmp(gpu[i], c2)) { printf("pairing_pp_apply mismatch at %zu\n", i); fails++; }
+      element_clear(c2);
+    }
+    pairing_pp_clear(pp);
+    pairing_pp_init(pp, P[1], pairing);
+    if (pairing_pp_apply_batch(gpu, Q, 12 < n ? 12 : n, pp)) { printf("pp batch failed\n"); fails++; }
+    pairing_pp_clear(pp);
+    pbc_hip_detach(pairing);
+    for (size_t i = 0; i < 12 && i < n; i++) {
+      element_t c2;
+      element_init_GT(c2, pairing);
+      element_pairing(c2, P[1], Q[i]);
+      if (element_cmp(gpu[i], c2)) { printf("pp batch mismatch at %zu\n", i); fails++; }
+      element_clear(c2);
+    }
+    if (pbc_hip_attach(pairing, text, len)) return 1;
+  }
   /* 2. the batch entry points */
   if (element_pairing_batch(gpu, P, Q, n)) { printf("batch call failed\n"); fails++; }
   for (size_t i = 0; i < n; i++) if (element_cmp(gpu[i], cpu[i])) { printf("batch mismatch at %zu\n", i); fails++; break; }

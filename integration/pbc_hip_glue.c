@@ -15,6 +15,9 @@ static struct {
   int (*pair)(pbc_hip_pairing_t *, unsigned char *, const unsigned char *, const unsigned char *, size_t);
   int (*prod)(pbc_hip_pairing_t *, unsigned char *, const unsigned char *, const unsigned char *, size_t, int);
   const char *(*err)(void);
+  int (*pp_init)(void **, pbc_hip_pairing_t *, const unsigned char *);
+  void (*pp_clear)(void *);
+  int (*pp_apply)(void *, unsigned char *, const unsigned char *, size_t);
 } L;
 
 /* one attachment per pairing_s (kept in a tiny table keyed by the pairing pointer so that
@@ -24,6 +27,9 @@ typedef struct {
   pbc_hip_pairing_t *gpu;
   void (*cpu_map)(element_ptr, element_ptr, element_ptr, struct pairing_s *);
   void (*cpu_prod)(element_ptr, element_t[], element_t[], int, struct pairing_s *);
+  void (*cpu_pp_init)(pairing_pp_t, element_t, struct pairing_s *);
+  void (*cpu_pp_clear)(pairing_pp_t);
+  void (*cpu_pp_apply)(element_t, element_t, pairing_pp_t);
 } attach_t;
 static attach_t g_att[16];
 
@@ -42,6 +48,8 @@ static int load_lib(void) {
   SYM(lenT, "pbc_hip_pairing_length_in_bytes_GT");
   SYM(pair, "pbc_hip_element_pairing_batch"); SYM(prod, "pbc_hip_element_prod_pairing_batch");
   SYM(err, "pbc_hip_last_error");
+  SYM(pp_init, "pbc_hip_pairing_pp_init"); SYM(pp_clear, "pbc_hip_pairing_pp_clear");
+  SYM(pp_apply, "pbc_hip_pairing_pp_apply_batch");
 #undef SYM
   return 0;
 }
@@ -99,6 +107,47 @@ static void hip_prod(element_ptr out, element_t in1[], element_t in2[], int n_pr
   free(b1); free(b2); free(bt);
 }
 
+/* pairing->pp_init / pp_apply / pp_clear replacements (include/pbc_pairing.h:39-41, 54-89).
+ * p->data holds the GPU handle.  Installed for type A only. */
+static void hip_pp_init(pairing_pp_t p, element_t in1, struct pairing_s *pairing) {
+  attach_t *a = find(pairing);
+  unsigned char *buf = malloc(L.len1(a->gpu));
+  void *h = NULL;
+  element_to_bytes(buf, in1);
+  if (L.pp_init(&h, a->gpu, buf)) { fprintf(stderr, "pbc_hip: %s\n", L.err()); h = NULL; }
+  p->data = h;
+  free(buf);
+}
+static void hip_pp_clear(pairing_pp_t p) { if (p->data) L.pp_clear(p->data); }
+static void hip_pp_apply(element_t out, element_t in2, pairing_pp_t p) {
+  attach_t *a = find(p->pairing);
+  int l2 = L.len2(a->gpu), lt = L.lenT(a->gpu);
+  unsigned char *buf = malloc((size_t) l2 + lt);
+  element_to_bytes(buf, in2);
+  if (!p->data || L.pp_apply(p->data, buf + l2, buf, 1)) fprintf(stderr, "pbc_hip: pp_apply failed\n");
+  else element_from_bytes(out, buf + l2);
+  free(buf);
+}
+/* outs[i] = e(P, in2[i]) for the P given to pairing_pp_init: pairing_pp_apply over a batch */
+int pairing_pp_apply_batch(element_t out[], element_t in2[], size_t n, pairing_pp_t p) {
+  if (!n) return 0;
+  if (!p->pairing) { for (size_t i = 0; i < n; i++) element_set0(out[i]); return 0; }   /* P was O */
+  attach_t *a = find(p->pairing);
+  if (!a || !p->data) return 1;
+  int l2 = L.len2(a->gpu), lt = L.lenT(a->gpu);
+  unsigned char *b2 = malloc(n * l2 + 1), *bt = malloc(n * lt + 1);
+  size_t *slot = malloc(n * sizeof *slot), m = 0;
+  for (size_t i = 0; i < n; i++) {
+    if (element_is0(in2[i])) { element_set0(out[i]); continue; }
+    element_to_bytes(b2 + m * l2, in2[i]);
+    slot[m++] = i;
+  }
+  int rc = m ? L.pp_apply(p->data, bt, b2, m) : 0;
+  if (!rc) for (size_t i = 0; i < m; i++) element_from_bytes(out[slot[i]], bt + i * lt);
+  free(b2); free(bt); free(slot);
+  return rc;
+}
+
 int pbc_hip_attach(pairing_t pairing, const char *param, size_t len) {
   if (load_lib()) return 1;
   attach_t *a = find(NULL);
@@ -108,14 +157,19 @@ int pbc_hip_attach(pairing_t pairing, const char *param, size_t len) {
   if (L.len1(g) != pairing_length_in_bytes_G1(pairing) || L.len2(g) != pairing_length_in_bytes_G2(pairing) ||
       L.lenT(g) != pairing_length_in_bytes_GT(pairing)) { L.clear(g); return 1; }
   a->pairing = pairing; a->gpu = g; a->cpu_map = pairing->map; a->cpu_prod = pairing->prod_pairings;
+  a->cpu_pp_init = pairing->pp_init; a->cpu_pp_clear = pairing->pp_clear; a->cpu_pp_apply = pairing->pp_apply;
   pairing->map = hip_map;
   pairing->prod_pairings = hip_prod;
+  if (strstr(param, "type a") && !strstr(param, "type a1")) {
+    pairing->pp_init = hip_pp_init; pairing->pp_clear = hip_pp_clear; pairing->pp_apply = hip_pp_apply;
+  }
   return 0;
 }
 void pbc_hip_detach(pairing_t pairing) {
   attach_t *a = find(pairing);
   if (!a) return;
   pairing->map = a->cpu_map; pairing->prod_pairings = a->cpu_prod;
+  pairing->pp_init = a->cpu_pp_init; pairing->pp_clear = a->cpu_pp_clear; pairing->pp_apply = a->cpu_pp_apply;
   L.clear(a->gpu);
   memset(a, 0, sizeof *a);
 }

@@ -29,4 +29,7 @@ int element_pairing_batch(element_t out[], element_t in1[], element_t in2[], siz
 /* out[u] = prod_{j<k} e(in1[u*k+j], in2[u*k+j]) -- element_prod_pairing semantics per product
  * (any identity input => 1, include/pbc_pairing.h:153-171). */
 int element_prod_pairing_batch(element_t out[], element_t in1[], element_t in2[], size_t n, int k);
+/* out[i] = e(P, in2[i]) for the P a pairing_pp_t was initialised with (pairing_pp_init after
+ * pbc_hip_attach): pairing_pp_apply (include/pbc_pairing.h:79-89) over a batch.  Type A. */
+int pairing_pp_apply_batch(element_t out[], element_t in2[], size_t n, pairing_pp_t p);
 #endif

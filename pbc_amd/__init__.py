@@ -62,6 +62,11 @@ def lib():
         L.pbc_hip_diag_mul_bench.argtypes = [ci, ci, ci, ctypes.POINTER(ctypes.c_double),
                                              ctypes.POINTER(ctypes.c_double)]
         L.pbc_hip_diag_stage.argtypes = [vp, ci, vp, sz, vp, vp, sz]
+        L.pbc_hip_pairing_pp_init.argtypes = [ctypes.POINTER(vp), vp, vp]
+        L.pbc_hip_pairing_pp_clear.argtypes = [vp]
+        L.pbc_hip_pairing_pp_clear.restype = None
+        L.pbc_hip_pairing_pp_apply_batch.argtypes = [vp, vp, vp, sz]
+        L.pbc_hip_pairing_pp_apply_batch_dev.argtypes = [vp, vp, vp, sz, vp]
         L.pbc_hip_algorithmic_macs_per_unit.argtypes = [vp, ci]
         L.pbc_hip_algorithmic_macs_per_unit.restype = ctypes.c_double
         L.pbc_hip_last_error.restype = cp
@@ -78,6 +83,8 @@ EXPORTS = (
     "pbc_hip_element_prod_pairing_batch_dev", "pbc_hip_fq_op_batch",
     "pbc_hip_length_in_bytes_Fq", "pbc_hip_int_mac_peak",
     "pbc_hip_algorithmic_macs_per_unit", "pbc_hip_last_error", "pbc_hip_diag_mul_bench", "pbc_hip_diag_stage",
+    "pbc_hip_pairing_pp_init", "pbc_hip_pairing_pp_clear", "pbc_hip_pairing_pp_apply_batch",
+    "pbc_hip_pairing_pp_apply_batch_dev",
 )
 
 
@@ -159,6 +166,11 @@ class Pairing:
         if lib().pbc_hip_element_prod_pairing_batch_dev(self._h, d_gt, d_g1, d_g2, n, k, stream):
             raise PbcHipError("element_prod_pairing_dev: " + _err())
 
+    # ---- preprocessed pairings (pairing_pp_init / pairing_pp_apply) ----------------------
+    def pp_init(self, g1):
+        """Mirror of pairing_pp_init: returns a PairingPP bound to the fixed first argument."""
+        return PairingPP(self, g1)
+
     # ---- diagnostics ------------------------------------------------------------------
     def fq_op(self, op, a, b=None):
         import numpy as np
@@ -172,6 +184,42 @@ class Pairing:
 
     def algorithmic_macs_per_unit(self, k=1):
         return lib().pbc_hip_algorithmic_macs_per_unit(self._h, k)
+
+
+class PairingPP:
+    """Mirror of pairing_pp_t (include/pbc_pairing.h:10-15, 54-89)."""
+
+    def __init__(self, pairing, g1):
+        import numpy as np
+        self.pairing = pairing
+        g1 = np.ascontiguousarray(g1, dtype=np.uint8).reshape(-1)
+        if g1.size != pairing.length_in_bytes_G1:
+            raise ValueError("g1 must be one G1 record")
+        self._h = ctypes.c_void_p()
+        if lib().pbc_hip_pairing_pp_init(ctypes.byref(self._h), pairing._h, _np_ptr(g1)):
+            self._h = None
+            raise PbcHipError("pairing_pp_init: " + _err())
+
+    def apply(self, g2):
+        """pairing_pp_apply over a batch of second arguments."""
+        import numpy as np
+        g2 = np.ascontiguousarray(g2, dtype=np.uint8)
+        n = g2.size // self.pairing.length_in_bytes_G2
+        gt = np.empty((n, self.pairing.length_in_bytes_GT), np.uint8)
+        if lib().pbc_hip_pairing_pp_apply_batch(self._h, _np_ptr(gt), _np_ptr(g2), n):
+            raise PbcHipError("pairing_pp_apply: " + _err())
+        return gt
+
+    def apply_dev(self, d_gt, d_g2, n, stream=0):
+        if lib().pbc_hip_pairing_pp_apply_batch_dev(self._h, d_gt, d_g2, n, stream):
+            raise PbcHipError("pairing_pp_apply_dev: " + _err())
+
+    def clear(self):
+        if getattr(self, "_h", None):
+            lib().pbc_hip_pairing_pp_clear(self._h)
+            self._h = None
+
+    __del__ = clear
 
 
 def int_mac_peak(variant=0, iters=2000):

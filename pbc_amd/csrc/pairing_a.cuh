@@ -268,6 +268,134 @@ PBC_DEV void a_store_gt(uint8_t *gt, fp2<N> &out, bool valid) {
   fp_store_be<N>(gt + 4 * N, out.y);
 }
 
+// ---- preprocessed pairings: pairing_pp_init / pairing_pp_apply (include/pbc_pairing.h:54-89) ----
+// a_pairing_pp_init (a_param.c:149-220) stores the line coefficients of every Miller step for a
+// fixed first argument; a_pairing_pp_apply (:317-360) then needs no point arithmetic.  Here the
+// table holds, per step, (cA, cB, cC) with  line(Q) = (cA Qx + cC) + i (cB Qy)  in the same
+// projective scaling the full kernel uses: doubling  cA = M ZZ, cB = Z3 ZZ, cC = M X - 2Y^2;
+// addition  cA = R, cB = Z3, cC = R x2 - Z3 y2.  Layout: [exp2 + 1][3][N] words (Montgomery form),
+// entry exp2 is the addition step.  The table is wave-uniform data for the apply kernel.
+template <int N>
+PBC_DEV void a_pp_store(uint32_t *tab, int idx, const fp<N> &cA, const fp<N> &cB, const fp<N> &cC) {
+#pragma unroll
+  for (int k = 0; k < N; k++) {
+    tab[(idx * 3 + 0) * N + k] = cA.v[k];
+    tab[(idx * 3 + 1) * N + k] = cB.v[k];
+    tab[(idx * 3 + 2) * N + k] = cC.v[k];
+  }
+}
+// one lane: returns false when g1 deserialises to O (then every pp_apply result is 1,
+// pairing_pp_init include/pbc_pairing.h:54-61)
+template <int N>
+PBC_DEV bool a_pp_init_lane(uint32_t *tab, const uint8_t *g1) {
+  constexpr int NB = 4 * N;
+  fp<N> one, x2, y2;
+  jac<N> V;
+  fp_set<N>(one, fpk<N>().one);
+  fp_load_be<N>(x2, g1);
+  fp_load_be<N>(y2, g1 + NB);
+  bool valid = a_on_curve<N>(x2, y2);
+  V.X = x2; V.Y = y2; V.Z = one; V.ZZ = one;
+  int slot = 0;
+  for (int i = c_a.exp2 - 1; i >= 0; i--, slot++) {
+    fp<N> XX, YY, M, t0, t1, S, Z3, cA, cB, cC;
+    fp_sqr<N>(XX, V.X);
+    fp_sqr<N>(YY, V.Y);
+    fp_sqr<N>(t0, V.ZZ);
+    fp_dbl<N>(M, XX);
+    fp_add<N>(M, M, XX);
+    fp_add<N>(M, M, t0);
+    fp_mul<N>(cA, M, V.ZZ);
+    fp_mul<N>(Z3, V.Y, V.Z);
+    fp_dbl<N>(Z3, Z3);
+    fp_mul<N>(cB, Z3, V.ZZ);
+    fp_mul<N>(cC, M, V.X);
+    fp_dbl<N>(t1, YY);
+    fp_sub<N>(cC, cC, t1);
+    a_pp_store<N>(tab, slot, cA, cB, cC);
+    fp_mul<N>(S, V.X, YY);
+    fp_dbl<N>(S, S);
+    fp_dbl<N>(S, S);
+    fp_sqr<N>(t0, YY);
+    fp_dbl<N>(t0, t0);
+    fp_dbl<N>(t0, t0);
+    fp_dbl<N>(t0, t0);
+    fp_sqr<N>(V.X, M);
+    fp_dbl<N>(t1, S);
+    fp_sub<N>(V.X, V.X, t1);
+    fp_sub<N>(t1, S, V.X);
+    fp_mul<N>(t1, M, t1);
+    fp_sub<N>(V.Y, t1, t0);
+    V.Z = Z3;
+    fp_sqr<N>(V.ZZ, Z3);
+    if (i == c_a.exp1) {
+      fp<N> yy = y2, H, R, HH, HHH, cC2;
+      if (c_a.sign1 < 0) fp_neg<N>(yy, yy);
+      fp_mul<N>(H, x2, V.ZZ);
+      fp_sub<N>(H, H, V.X);
+      fp_mul<N>(t0, V.Z, V.ZZ);
+      fp_mul<N>(R, yy, t0);
+      fp_sub<N>(R, R, V.Y);
+      fp_mul<N>(Z3, V.Z, H);
+      fp_mul<N>(cC2, R, x2);
+      fp_mul<N>(t0, Z3, yy);
+      fp_sub<N>(cC2, cC2, t0);
+      a_pp_store<N>(tab, c_a.exp2, R, Z3, cC2);
+      fp_sqr<N>(HH, H);
+      fp_mul<N>(HHH, HH, H);
+      fp_mul<N>(t0, V.X, HH);
+      fp_sqr<N>(t1, R);
+      fp_sub<N>(t1, t1, HHH);
+      fp_sub<N>(t1, t1, t0);
+      fp_sub<N>(t1, t1, t0);
+      fp_sub<N>(t0, t0, t1);
+      fp_mul<N>(t0, R, t0);
+      fp_mul<N>(HHH, V.Y, HHH);
+      fp_sub<N>(V.Y, t0, HHH);
+      V.X = t1;
+      V.Z = Z3;
+      fp_sqr<N>(V.ZZ, Z3);
+    }
+  }
+  return valid;
+}
+template <int N>
+PBC_DEV void a_pp_line(fp2<N> &f, const uint32_t *tab, int idx, const fp<N> &Qx, const fp<N> &Qy) {
+  fp<N> cA, cB, cC;
+  fp2<N> l;
+#pragma unroll
+  for (int k = 0; k < N; k++) {
+    cA.v[k] = tab[(idx * 3 + 0) * N + k];
+    cB.v[k] = tab[(idx * 3 + 1) * N + k];
+    cC.v[k] = tab[(idx * 3 + 2) * N + k];
+  }
+  fp_mul<N>(l.x, cA, Qx);
+  fp_add<N>(l.x, l.x, cC);
+  fp_mul<N>(l.y, cB, Qy);
+  fi_mul<N>(f, f, l);
+}
+// pairing_pp_apply for one lane: 7 F_q products per Miller step instead of 18
+template <int N>
+PBC_DEV void a_pp_apply_lane(uint8_t *gt, const uint32_t *tab, bool p_valid, const uint8_t *g2) {
+  constexpr int NB = 4 * N;
+  fp<N> Qx, Qy;
+  fp2<N> f, out;
+  fp_load_be<N>(Qx, g2);
+  fp_load_be<N>(Qy, g2 + NB);
+  bool valid = p_valid & a_on_curve<N>(Qx, Qy);
+  fp_set<N>(f.x, fpk<N>().one);
+#pragma unroll
+  for (int k = 0; k < N; k++) f.y.v[k] = 0;
+  int slot = 0;
+  for (int i = c_a.exp2 - 1; i >= 0; i--, slot++) {
+    fi_sqr<N>(f, f);
+    a_pp_line<N>(f, tab, slot, Qx, Qy);
+    if (i == c_a.exp1) a_pp_line<N>(f, tab, c_a.exp2, Qx, Qy);
+  }
+  a_final_exp<N>(out, f);
+  a_store_gt<N>(gt, out, valid);
+}
+
 // element_pairing for one lane (a_pairing_proj + a_tateexp, a_param.c:1053-1198, :285-303)
 template <int N>
 PBC_DEV void a_pairing_lane(uint8_t *gt, const uint8_t *g1, const uint8_t *g2, uint32_t *lds_q,

@@ -76,6 +76,30 @@ __global__ void __launch_bounds__(kBlock, PBC_A_WAVES) a_prod_pairing_kernel(uin
   }
 }
 
+// pairing_pp_init: ONE lane derives the line-coefficient table of a fixed first argument.
+template <int N>
+__global__ void a_pp_init_kernel(uint32_t *tab, uint32_t *valid, const uint8_t *g1) {
+  if (threadIdx.x || blockIdx.x) return;
+  *valid = a_pp_init_lane<N>(tab, g1) ? 1u : 0u;
+}
+// pairing_pp_apply over a batch of second arguments, one per lane; the table is uniform data.
+template <int N>
+__global__ void __launch_bounds__(kBlock, PBC_A_WAVES) a_pp_apply_kernel(uint8_t *gt, const uint32_t *__restrict__ tab,
+                                                                          const uint32_t *__restrict__ valid,
+                                                                          const uint8_t *g2, size_t n) {
+  size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
+  size_t ld = idx < n ? idx : n - 1;
+  constexpr int L = 8 * N;
+  __attribute__((aligned(16))) uint8_t out[L];
+  a_pp_apply_lane<N>(out, tab, *valid != 0, g2 + ld * L);
+  if (idx < n) {
+    uint4 *dst = reinterpret_cast<uint4 *>(gt + idx * L);
+    const uint4 *src = reinterpret_cast<const uint4 *>(out);
+#pragma unroll
+    for (int i = 0; i < L / 16; i++) dst[i] = src[i];
+  }
+}
+
 // Type D: one k-term product (k = 1: a single pairing) per lane.  G1 records are 40 B, G2
 // 120 B, GT 120 B for d159.param.
 __global__ void __launch_bounds__(kBlock, PBC_DF_WAVES) d_prod_pairing_kernel(uint8_t *gt, const uint8_t *g1,
@@ -468,6 +492,66 @@ extern "C" int pbc_hip_element_prod_pairing_batch(pbc_hip_pairing_t *P, uint8_t 
   if (!P) return fail("null pairing");
   if (k < 1) return fail("k must be >= 1");
   return run_host(P, gt, g1, g2, n, k);
+}
+
+// ---- preprocessed pairings ---------------------------------------------------------------
+struct pbc_hip_pp_s {
+  pbc_hip_pairing_s *P;
+  uint32_t *tab;      // device: [exp2 + 1][3][16] words
+  uint32_t *valid;    // device flag: first argument was a finite curve point
+};
+extern "C" int pbc_hip_pairing_pp_init(pbc_hip_pp_t **out, pbc_hip_pairing_t *P, const uint8_t *g1) {
+  if (!out || !P || !g1) return fail("null argument");
+  if (P->device < 0) return fail("no HIP device: libpbc_hip has no CPU fallback");
+  if (P->type != 'a') return fail("pairing_pp is built for type a only (other types: use element_pairing)");
+  pbc_hip_pp_s *pp = new pbc_hip_pp_s();
+  pp->P = P;
+  void *dg1 = nullptr;
+  size_t words = (size_t) (P->a.exp2 + 1) * 3 * 16;
+  if (hipSetDevice(P->device) != hipSuccess || hipMalloc(&pp->tab, words * 4) != hipSuccess ||
+      hipMalloc(&pp->valid, 4) != hipSuccess || hipMalloc(&dg1, P->len1) != hipSuccess ||
+      hipMemcpy(dg1, g1, P->len1, hipMemcpyHostToDevice) != hipSuccess || upload_constants(P, 0)) {
+    delete pp;
+    return fail("pairing_pp_init: device setup failed");
+  }
+  hipLaunchKernelGGL(a_pp_init_kernel<16>, dim3(1), dim3(64), 0, 0, pp->tab, pp->valid, (const uint8_t *) dg1);
+  hipError_t e = hipDeviceSynchronize();
+  (void) hipFree(dg1);
+  if (e != hipSuccess) { delete pp; return fail("pairing_pp_init kernel: %s", hipGetErrorString(e)); }
+  *out = pp;
+  return 0;
+}
+extern "C" void pbc_hip_pairing_pp_clear(pbc_hip_pp_t *pp) {
+  if (!pp) return;
+  (void) hipFree(pp->tab);
+  (void) hipFree(pp->valid);
+  delete pp;
+}
+extern "C" int pbc_hip_pairing_pp_apply_batch_dev(pbc_hip_pp_t *pp, void *d_gt, const void *d_g2, size_t n, void *stream) {
+  if (!pp) return fail("null pp");
+  if (!n) return 0;
+  hipStream_t s = (hipStream_t) stream;
+  if (upload_constants(pp->P, s)) return 1;
+  unsigned grid = (unsigned) ((n + kBlock - 1) / kBlock);
+  hipLaunchKernelGGL(a_pp_apply_kernel<16>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt, pp->tab, pp->valid,
+                     (const uint8_t *) d_g2, n);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+extern "C" int pbc_hip_pairing_pp_apply_batch(pbc_hip_pp_t *pp, uint8_t *gt, const uint8_t *g2, size_t n) {
+  if (!pp) return fail("null pp");
+  if (!n) return 0;
+  pbc_hip_pairing_s *P = pp->P;
+  void *d2 = nullptr, *dt = nullptr;
+  HIP_TRY(hipSetDevice(P->device));
+  HIP_TRY(hipMalloc(&d2, n * P->len2));
+  HIP_TRY(hipMalloc(&dt, n * P->lenT));
+  HIP_TRY(hipMemcpy(d2, g2, n * P->len2, hipMemcpyHostToDevice));
+  int rc = pbc_hip_pairing_pp_apply_batch_dev(pp, dt, d2, n, 0);
+  if (!rc && hipMemcpy(gt, dt, n * P->lenT, hipMemcpyDeviceToHost) != hipSuccess) rc = fail("D2H copy failed");
+  (void) hipFree(d2);
+  (void) hipFree(dt);
+  return rc;
 }
 
 // diagnostics: stage 0 -> the derived constant block of the object (after device init);

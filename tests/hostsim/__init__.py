@@ -47,6 +47,16 @@ class HostSim:
         self.L.hostsim_prod_pairing(self.h, out.ctypes.data, g1.ctypes.data, g2.ctypes.data, n, k)
         return out
 
+    def pp(self, g1, g2):
+        g1 = np.ascontiguousarray(g1, np.uint8)
+        g2 = np.ascontiguousarray(g2, np.uint8)
+        n = g2.size // self.len2
+        out = np.empty((n, self.lenT), np.uint8)
+        self.L.hostsim_pp.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_size_t]
+        if self.L.hostsim_pp(self.h, out.ctypes.data, g1.ctypes.data, g2.ctypes.data, n):
+            raise RuntimeError("hostsim_pp failed")
+        return out
+
     def stage(self, stage, g1=None, g2=None, n=0, out_len=4096):
         out = np.zeros(max(out_len, n * self.lenT), np.uint8)
         self.L.hostsim_stage.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t,

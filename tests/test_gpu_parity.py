@@ -315,3 +315,24 @@ def test_a_prod16_full_size_batch_properties(hip_a, oracle_a):
         sl = slice(int(u) * k, int(u) * k + k)
         want = oracle_a.prod_pairing_batch(G1[sl].cpu().numpy(), G2[sl].cpu().numpy(), k)
         assert np.array_equal(A[int(u)].cpu().numpy(), want[0])
+
+
+# ---- preprocessed pairings: pairing_pp_init / pairing_pp_apply ------
+def test_pairing_pp_matches_element_pairing(hip_a, oracle_a):
+    v = golden("a_chain1024.vec")
+    for pi in (0, 7):
+        pp = hip_a.pp_init(v.g1[pi])
+        Q = v.g2[:300].copy()
+        Q[5, 127] ^= 1                                    # identity second argument
+        got = pp.apply(Q)
+        want = hip_a.element_pairing(np.tile(v.g1[pi], (300, 1)), Q)
+        assert np.array_equal(got, want)
+        assert np.array_equal(got[pi], v.gt[pi])           # e(P_i, Q_i) from the reference fixture
+        assert np.array_equal(got[:8], oracle_a.pairing_batch(np.tile(v.g1[pi], (8, 1)), Q[:8]))
+        pp.clear()
+    bad = v.g1[3].copy()
+    bad[1] ^= 8
+    pp = hip_a.pp_init(bad)                                # first argument deserialises to O
+    one = np.zeros(128, np.uint8)
+    one[63] = 1
+    assert np.array_equal(pp.apply(v.g2[:3]), np.tile(one, (3, 1)))

@@ -51,3 +51,16 @@ def test_type_f_generic_hard_part_on_host():
     v = golden("f_rand16.vec")
     sim = hostsim.HostSim(_param("f") + "hip_no_bn 1\n")
     assert np.array_equal(sim.prod_pairing(v.g1[:2], v.g2[:2], 1), v.gt[:2])
+
+
+def test_pairing_pp_on_host(sims, oracles):
+    """pairing_pp_init + pairing_pp_apply give element_pairing's bytes (a_param.c:149-220, :317-360)."""
+    v = golden("a_chain1024.vec")
+    P = v.g1[5]
+    Q = v.g2[:6].copy()
+    Q[2, 127] ^= 1                                         # off-curve second argument -> 1
+    want = oracles["a"].pairing_batch(np.tile(P, (6, 1)), Q)
+    assert np.array_equal(sims["a"].pp(P, Q), want)
+    bad = P.copy(); bad[100] ^= 4                          # off-curve first argument -> all 1
+    one = np.zeros(128, np.uint8); one[63] = 1
+    assert np.array_equal(sims["a"].pp(bad, Q), np.tile(one, (6, 1)))

@@ -76,6 +76,23 @@ void pbc_hip_pairing_pp_clear(pbc_hip_pp_t *pp);
 int pbc_hip_pairing_pp_apply_batch(pbc_hip_pp_t *pp, uint8_t *gt, const uint8_t *g2, size_t n);
 int pbc_hip_pairing_pp_apply_batch_dev(pbc_hip_pp_t *pp, void *d_gt, const void *d_g2, size_t n, void *stream);
 
+/* Batched group operations next to the pairing (the callers' other hot loops: example/bls.c
+ * signs with element_pow_zn and checks with GT products).  Scalars are Z_r elements in
+ * element_to_bytes form: big-endian, pbc_hip_pairing_length_in_bytes_Zr() bytes
+ * (pairing_length_in_bytes_Zr, include/pbc_pairing.h:235-238), values < r.
+ *   element_mul_zn / element_pow_zn on G1, G2 (include/pbc_field.h:311, :374 ->
+ *     generic_pow_mpz arith/field.c:113-126 over curve_mul ecc/curve.c:153-207):
+ *     out[i] = [zr[i]] in[i]; group = 1 or 2 (G2 only for the symmetric type a).  The point at
+ *     infinity (only reachable from off-curve input or a zero scalar) is written as zero bytes.
+ *   element_mul on GT (include/pbc_field.h:280 -> mulg wrapper ecc/pairing.c:135-283);
+ *   element_pow_zn on GT. */
+int pbc_hip_pairing_length_in_bytes_Zr(const pbc_hip_pairing_t *p);
+int pbc_hip_element_mul_zn_batch(pbc_hip_pairing_t *p, int group, uint8_t *out, const uint8_t *in,
+                                 const uint8_t *zr, size_t n);
+int pbc_hip_element_mul_GT_batch(pbc_hip_pairing_t *p, uint8_t *out, const uint8_t *a, const uint8_t *b, size_t n);
+int pbc_hip_element_pow_zn_GT_batch(pbc_hip_pairing_t *p, uint8_t *out, const uint8_t *a, const uint8_t *zr,
+                                    size_t n);
+
 /* Batched base-field operations on canonical bytes: the arith/montfp.c semantics the
  * kernels are built on (mont_mul :334-377, fp_add/sub/double/halve/neg :220-330,
  * fp_invert :401-422), exposed so they can be checked differentially the way

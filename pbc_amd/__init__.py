@@ -62,6 +62,10 @@ def lib():
         L.pbc_hip_diag_mul_bench.argtypes = [ci, ci, ci, ctypes.POINTER(ctypes.c_double),
                                              ctypes.POINTER(ctypes.c_double)]
         L.pbc_hip_diag_stage.argtypes = [vp, ci, vp, sz, vp, vp, sz]
+        L.pbc_hip_pairing_length_in_bytes_Zr.argtypes = [vp]
+        L.pbc_hip_element_mul_zn_batch.argtypes = [vp, ci, vp, vp, vp, sz]
+        L.pbc_hip_element_mul_GT_batch.argtypes = [vp, vp, vp, vp, sz]
+        L.pbc_hip_element_pow_zn_GT_batch.argtypes = [vp, vp, vp, vp, sz]
         L.pbc_hip_pairing_pp_init.argtypes = [ctypes.POINTER(vp), vp, vp]
         L.pbc_hip_pairing_pp_clear.argtypes = [vp]
         L.pbc_hip_pairing_pp_clear.restype = None
@@ -84,7 +88,8 @@ EXPORTS = (
     "pbc_hip_length_in_bytes_Fq", "pbc_hip_int_mac_peak",
     "pbc_hip_algorithmic_macs_per_unit", "pbc_hip_last_error", "pbc_hip_diag_mul_bench", "pbc_hip_diag_stage",
     "pbc_hip_pairing_pp_init", "pbc_hip_pairing_pp_clear", "pbc_hip_pairing_pp_apply_batch",
-    "pbc_hip_pairing_pp_apply_batch_dev",
+    "pbc_hip_pairing_pp_apply_batch_dev", "pbc_hip_pairing_length_in_bytes_Zr",
+    "pbc_hip_element_mul_zn_batch", "pbc_hip_element_mul_GT_batch", "pbc_hip_element_pow_zn_GT_batch",
 )
 
 
@@ -124,6 +129,7 @@ class Pairing:
         self.length_in_bytes_G2 = L.pbc_hip_pairing_length_in_bytes_G2(self._h)
         self.length_in_bytes_GT = L.pbc_hip_pairing_length_in_bytes_GT(self._h)
         self.length_in_bytes_Fq = L.pbc_hip_length_in_bytes_Fq(self._h)
+        self.length_in_bytes_Zr = L.pbc_hip_pairing_length_in_bytes_Zr(self._h)
 
     def clear(self):
         if getattr(self, "_h", None):
@@ -165,6 +171,45 @@ class Pairing:
     def element_prod_pairing_dev(self, d_gt, d_g1, d_g2, n, k, stream=0):
         if lib().pbc_hip_element_prod_pairing_batch_dev(self._h, d_gt, d_g1, d_g2, n, k, stream):
             raise PbcHipError("element_prod_pairing_dev: " + _err())
+
+    # ---- group operations ------------------------------------------------------------------
+    def _scalars(self, zr, n):
+        import numpy as np
+        zr = np.ascontiguousarray(zr, dtype=np.uint8)
+        if zr.size != n * self.length_in_bytes_Zr:
+            raise ValueError("scalars must be n records of length_in_bytes_Zr big-endian bytes")
+        return zr
+
+    def element_mul_zn(self, group, pts, zr):
+        """out[i] = [zr[i]] pts[i] in G1 (group=1) or G2 (group=2, type a)."""
+        import numpy as np
+        pts = np.ascontiguousarray(pts, dtype=np.uint8)
+        n = pts.size // self.length_in_bytes_G1
+        zr = self._scalars(zr, n)
+        out = np.empty((n, self.length_in_bytes_G1), np.uint8)
+        if lib().pbc_hip_element_mul_zn_batch(self._h, group, _np_ptr(out), _np_ptr(pts), _np_ptr(zr), n):
+            raise PbcHipError("element_mul_zn: " + _err())
+        return out
+
+    def element_mul_GT(self, a, b):
+        import numpy as np
+        a = np.ascontiguousarray(a, dtype=np.uint8)
+        b = np.ascontiguousarray(b, dtype=np.uint8)
+        n = a.size // self.length_in_bytes_GT
+        out = np.empty((n, self.length_in_bytes_GT), np.uint8)
+        if lib().pbc_hip_element_mul_GT_batch(self._h, _np_ptr(out), _np_ptr(a), _np_ptr(b), n):
+            raise PbcHipError("element_mul_GT: " + _err())
+        return out
+
+    def element_pow_zn_GT(self, a, zr):
+        import numpy as np
+        a = np.ascontiguousarray(a, dtype=np.uint8)
+        n = a.size // self.length_in_bytes_GT
+        zr = self._scalars(zr, n)
+        out = np.empty((n, self.length_in_bytes_GT), np.uint8)
+        if lib().pbc_hip_element_pow_zn_GT_batch(self._h, _np_ptr(out), _np_ptr(a), _np_ptr(zr), n):
+            raise PbcHipError("element_pow_zn_GT: " + _err())
+        return out
 
     # ---- preprocessed pairings (pairing_pp_init / pairing_pp_apply) ----------------------
     def pp_init(self, g1):

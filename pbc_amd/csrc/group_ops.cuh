@@ -1,0 +1,226 @@
+// group_ops.cuh -- batched group operations next to the pairing path:
+// scalar multiplication in G1 / G2 = E(F_q) and products / powers in GT, one element per lane.
+//
+// Reference: element_mul_zn / element_pow_zn (include/pbc_field.h:311, :374) ->
+// field->mul_mpz / pow_mpz = generic_pow_mpz (arith/field.c:113-126, sliding window) over the
+// group law curve_mul / curve_double (ecc/curve.c:102-207, affine, one inversion per step), and
+// element_mul on GT (the mulg wrapper, ecc/pairing.c:135-283 -> fi_mul / fq_mul / polymod_mul).
+// Group elements are unique, so any addition chain gives the same bytes.  Here: Jacobian
+// double-and-always-add with a per-lane select (lanes hold different scalars; control flow stays
+// wave-uniform), one safegcd inversion at the end.
+#pragma once
+#include "fp.cuh"
+#include "pairing_a.cuh"
+#include "pairing_d.cuh"
+#include "pairing_f.cuh"
+
+namespace pbc {
+
+struct CurveK {                        // E: y^2 = x^3 + a x + b over F_q (Montgomery words)
+  uint32_t a[16], b[16];
+  int a_is_zero;
+};
+__constant__ CurveK c_curve;
+
+// bit i of a big-endian scalar of zlen bytes
+PBC_DEV uint32_t zr_bit(const uint8_t *z, int zlen, int i) { return (z[zlen - 1 - (i >> 3)] >> (i & 7)) & 1; }
+
+// out = [k] P for P = (x, y) bytes; off-curve P is O (curve_from_bytes); O serialises as zeros.
+template <int N>
+PBC_DEV void g_mul_lane(uint8_t *out, const uint8_t *in, const uint8_t *z, int zlen) {
+  constexpr int NB = 4 * N;
+  fp<N> one, ca, cb, x2, y2;
+  fp_set<N>(one, fpk<N>().one);
+  fp_set<N>(ca, c_curve.a);
+  fp_set<N>(cb, c_curve.b);
+  fp_load_be<N>(x2, in);
+  fp_load_be<N>(y2, in + NB);
+  bool valid;
+  {
+    fp<N> t0, t1;
+    fp_sqr<N>(t0, x2);
+    fp_add<N>(t0, t0, ca);
+    fp_mul<N>(t0, t0, x2);
+    fp_add<N>(t0, t0, cb);
+    fp_sqr<N>(t1, y2);
+    valid = fp_eq<N>(t0, t1);
+  }
+  fp<N> X = one, Y = one, Z;           // accumulator R, starts at O (Z = 0)
+#pragma unroll
+  for (int k = 0; k < N; k++) Z.v[k] = 0;
+  for (int i = 8 * zlen - 1; i >= 0; i--) {
+    // R <- 2R  (dbl-2007-bl shape; Z = 0 stays 0)
+    {
+      fp<N> XX, YY, ZZ, M, S, t0, t1, Z3;
+      fp_sqr<N>(XX, X);
+      fp_sqr<N>(YY, Y);
+      fp_sqr<N>(ZZ, Z);
+      fp_dbl<N>(M, XX);
+      fp_add<N>(M, M, XX);
+      if (!c_curve.a_is_zero) {
+        fp_sqr<N>(t0, ZZ);
+        fp_mul<N>(t0, t0, ca);
+        fp_add<N>(M, M, t0);
+      }
+      fp_mul<N>(Z3, Y, Z);
+      fp_dbl<N>(Z3, Z3);
+      fp_mul<N>(S, X, YY);
+      fp_dbl<N>(S, S);
+      fp_dbl<N>(S, S);
+      fp_sqr<N>(t0, YY);
+      fp_dbl<N>(t0, t0);
+      fp_dbl<N>(t0, t0);
+      fp_dbl<N>(t0, t0);
+      fp_sqr<N>(X, M);
+      fp_dbl<N>(t1, S);
+      fp_sub<N>(X, X, t1);
+      fp_sub<N>(t1, S, X);
+      fp_mul<N>(t1, M, t1);
+      fp_sub<N>(Y, t1, t0);
+      Z = Z3;
+    }
+    // T <- R + P (mixed); selected per lane when the scalar bit is set
+    {
+      fp<N> ZZ, H, R, HH, HHH, t0, t1, X3, Y3, Z3;
+      fp_sqr<N>(ZZ, Z);
+      fp_mul<N>(H, x2, ZZ);
+      fp_sub<N>(H, H, X);
+      fp_mul<N>(t0, Z, ZZ);
+      fp_mul<N>(R, y2, t0);
+      fp_sub<N>(R, R, Y);
+      fp_mul<N>(Z3, Z, H);
+      fp_sqr<N>(HH, H);
+      fp_mul<N>(HHH, HH, H);
+      fp_mul<N>(t0, X, HH);
+      fp_sqr<N>(X3, R);
+      fp_sub<N>(X3, X3, HHH);
+      fp_sub<N>(X3, X3, t0);
+      fp_sub<N>(X3, X3, t0);
+      fp_sub<N>(t0, t0, X3);
+      fp_mul<N>(t0, R, t0);
+      fp_mul<N>(t1, Y, HHH);
+      fp_sub<N>(Y3, t0, t1);
+      bool bit = zr_bit(z, zlen, i) != 0;
+      // R = O: R + P = P.   R = -P (H = 0, R != 0): the sum is O  (Z3 = Z H = 0 already).
+      // (R = P with a set bit would need a doubling: impossible for scalars < r.)
+      bool inf = fp_is0<N>(Z);
+      bool take_p = bit & inf;
+      bool take_t = bit & !inf;
+      fp_cmov<N>(X, X3, take_t);
+      fp_cmov<N>(Y, Y3, take_t);
+      fp_cmov<N>(Z, Z3, take_t);
+      fp_cmov<N>(X, x2, take_p);
+      fp_cmov<N>(Y, y2, take_p);
+      fp_cmov<N>(Z, one, take_p);
+    }
+  }
+  // to affine: x = X/Z^2, y = Y/Z^3
+  fp<N> zi, zi2, ax, ay;
+  bool is_inf = fp_is0<N>(Z) | !valid;
+  fp_inv<N>(zi, Z);
+  fp_sqr<N>(zi2, zi);
+  fp_mul<N>(ax, X, zi2);
+  fp_mul<N>(zi2, zi2, zi);
+  fp_mul<N>(ay, Y, zi2);
+  if (is_inf) {
+#pragma unroll
+    for (int k = 0; k < N; k++) { ax.v[k] = 0; ay.v[k] = 0; }
+  }
+  fp_store_be<N>(out, ax);
+  fp_store_be<N>(out + NB, ay);
+}
+
+// ---- GT ------------------------------------------------------------------------------------
+// Type A: F_q^2
+template <int N>
+PBC_DEV void a_gt_load(fp2<N> &r, const uint8_t *s) { fp_load_be<N>(r.x, s); fp_load_be<N>(r.y, s + 4 * N); }
+template <int N>
+PBC_DEV void a_gt_store(uint8_t *d, const fp2<N> &a) { fp_store_be<N>(d, a.x); fp_store_be<N>(d + 4 * N, a.y); }
+template <int N>
+PBC_DEV void a_gt_mul_lane(uint8_t *out, const uint8_t *a, const uint8_t *b) {
+  fp2<N> x, y;
+  a_gt_load<N>(x, a);
+  a_gt_load<N>(y, b);
+  fi_mul<N>(x, x, y);
+  a_gt_store<N>(out, x);
+}
+template <int N>
+PBC_DEV void a_gt_pow_lane(uint8_t *out, const uint8_t *a, const uint8_t *z, int zlen) {
+  fp2<N> x, acc, t;
+  a_gt_load<N>(x, a);
+  fp_set<N>(acc.x, fpk<N>().one);
+#pragma unroll
+  for (int k = 0; k < N; k++) acc.y.v[k] = 0;
+  for (int i = 8 * zlen - 1; i >= 0; i--) {
+    fi_sqr<N>(acc, acc);
+    fi_mul<N>(t, acc, x);
+    bool bit = zr_bit(z, zlen, i) != 0;
+    fp_cmov<N>(acc.x, t.x, bit);
+    fp_cmov<N>(acc.y, t.y, bit);
+  }
+  a_gt_store<N>(out, acc);
+}
+// Type D: F_q^6
+PBC_DEV void d_gt_load(f6 &r, const uint8_t *s) { f3_load_be(r.x, s); f3_load_be(r.y, s + 12 * ND); }
+PBC_DEV void d_gt_store(uint8_t *d, const f6 &a) { f3_store_be(d, a.x); f3_store_be(d + 12 * ND, a.y); }
+PBC_DEV void d_gt_mul_lane(uint8_t *out, const uint8_t *a, const uint8_t *b) {
+  f6 x, y;
+  d_gt_load(x, a);
+  d_gt_load(y, b);
+  f6_mul(x, x, y);
+  d_gt_store(out, x);
+}
+PBC_DEV void d_gt_pow_lane(uint8_t *out, const uint8_t *a, const uint8_t *z, int zlen) {
+  f6 x, acc, t;
+  d_gt_load(x, a);
+  fq one;
+  fp_set<ND>(one, fpk<ND>().one);
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int k = 0; k < ND; k++) { acc.x.c[i].v[k] = (i == 0) ? one.v[k] : 0; acc.y.c[i].v[k] = 0; }
+  for (int i = 8 * zlen - 1; i >= 0; i--) {
+    f6_sqr(acc, acc);
+    f6_mul(t, acc, x);
+    bool bit = zr_bit(z, zlen, i) != 0;
+#pragma unroll
+    for (int c = 0; c < 3; c++) { fp_cmov<ND>(acc.x.c[c], t.x.c[c], bit); fp_cmov<ND>(acc.y.c[c], t.y.c[c], bit); }
+  }
+  d_gt_store(out, acc);
+}
+// Type F: F_q^12 (private-memory objects)
+__device__ void f_gt_load(f12 *r, const uint8_t *s) {
+#pragma nounroll
+  for (int i = 0; i < 6; i++) g2_load_be(r->c[i], s + 8 * ND * i);
+}
+__device__ void f_gt_store(uint8_t *d, const f12 *a) {
+#pragma nounroll
+  for (int i = 0; i < 6; i++) g2_store_be(d + 8 * ND * i, a->c[i]);
+}
+__device__ void f_gt_mul_lane(uint8_t *out, const uint8_t *a, const uint8_t *b) {
+  f12 x, y;
+  f_gt_load(&x, a);
+  f_gt_load(&y, b);
+  f12_mul(&x, &x, &y);
+  f_gt_store(out, &x);
+}
+__device__ void f_gt_pow_lane(uint8_t *out, const uint8_t *a, const uint8_t *z, int zlen) {
+  f12 x, acc, t;
+  f_gt_load(&x, a);
+  f12_one(&acc);
+  for (int i = 8 * zlen - 1; i >= 0; i--) {
+    f12_sqr(&acc, &acc);
+    f12_mul(&t, &acc, &x);
+    bool bit = zr_bit(z, zlen, i) != 0;
+#pragma nounroll
+    for (int c = 0; c < 6; c++) {
+      g2 u = acc.c[c], w = t.c[c];
+      fp_cmov<ND>(u.x, w.x, bit);
+      fp_cmov<ND>(u.y, w.y, bit);
+      acc.c[c] = u;
+    }
+  }
+  f_gt_store(out, &acc);
+}
+
+}  // namespace pbc

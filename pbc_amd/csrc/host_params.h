@@ -12,6 +12,7 @@
 #include "pairing_a.cuh"
 #include "pairing_d.cuh"
 #include "pairing_f.cuh"
+#include "group_ops.cuh"
 
 using namespace pbc;
 
@@ -43,6 +44,7 @@ struct pbc_hip_pairing_s {
   FRaw fraw;                 // type F: canonical parameter words
   FConst fconst;             // type F: derived tower constants (filled on first use)
   bool dev_ready;            // derived constants computed on the device
+  int len_zr;                // bytes of a Z_r scalar (pairing_length_in_bytes_Zr)
   double fq_muls_single;     // reference F_q multiplication count per pairing (work model)
   double fq_muls_prod_a, fq_muls_prod_b;   // products: a*k + b
 };
@@ -104,6 +106,7 @@ static int init_type_a(pbc_hip_pairing_s *P, const char *txt, size_t len) {
   P->len_fq = (q.bits() + 7) / 8;
   if (P->len_fq != 64) return fail("type a: q must serialise to 64 bytes");
   P->len1 = P->len2 = P->lenT = 2 * P->len_fq;
+  P->len_zr = (r.bits() + 7) / 8;
   P->fq_muls_single = 4392.0;            // SURVEY.md 8d (instrumented reference, a.param)
   // a_pairings_affine (a_param.c:1283-1383): 41377 F_q products for k = 16;
   // linear model through (1, 4392-ish) and (16, 41377): 2543 k + 689
@@ -154,6 +157,7 @@ static int init_type_d(pbc_hip_pairing_s *P, const char *txt, size_t len) {
   if (P->len_fq != 20) return fail("type d: q must serialise to 20 bytes");
   P->len1 = 2 * P->len_fq;
   P->len2 = P->lenT = 6 * P->len_fq;
+  P->len_zr = (r.bits() + 7) / 8;
   P->fq_muls_single = 26451.0;           // SURVEY.md 8d (instrumented reference, d159.param)
   P->fq_muls_prod_a = 26451.0 - 4197.0;  // per-term Miller work + one cc_tatepower (4197)
   P->fq_muls_prod_b = 4197.0;
@@ -246,9 +250,24 @@ static int init_type_f(pbc_hip_pairing_s *P, const char *txt, size_t len) {
   P->len1 = 2 * P->len_fq;
   P->len2 = 4 * P->len_fq;
   P->lenT = 12 * P->len_fq;
+  P->len_zr = (r.bits() + 7) / 8;
   P->fq_muls_single = 172887.0;          // SURVEY.md 8d (instrumented reference, f.param)
   P->fq_muls_prod_a = 172887.0;          // generic_prod_pairings: k full pairings
   P->fq_muls_prod_b = 0.0;
   return 0;
 }
 
+
+// E(F_q) coefficients of the pairing's G1 curve for the group-operation kernels (Montgomery words)
+static void fill_curve(const pbc_hip_pairing_s *P, CurveK &C) {
+  memset(&C, 0, sizeof C);
+  if (P->type == 'a') {                 // y^2 = x^3 + x (a_param.c:1450-1452)
+    memcpy(C.a, P->k16.one, sizeof P->k16.one);
+  } else if (P->type == 'd') {
+    memcpy(C.a, P->dconst.A, sizeof P->dconst.A);
+    memcpy(C.b, P->dconst.B, sizeof P->dconst.B);
+  } else {                              // y^2 = x^3 + b (f_param.c:365-367)
+    memcpy(C.b, P->fconst.B, sizeof P->fconst.B);
+    C.a_is_zero = 1;
+  }
+}

@@ -141,6 +141,30 @@ __global__ void __launch_bounds__(kBlock) f_debug_kernel(int op, uint8_t *out, c
   for (int i = 0; i < 48 * ND; i++) out[idx * 48 * ND + i] = o[i];
 }
 
+// ---- group operations (one element per lane) -------------------------------------------------
+template <int N>
+__global__ void __launch_bounds__(kBlock, 2) g_mul_kernel(uint8_t *out, const uint8_t *in, const uint8_t *z,
+                                                           int zlen, size_t n) {
+  size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
+  if (idx >= n) return;
+  g_mul_lane<N>(out + idx * 8 * N, in + idx * 8 * N, z + idx * zlen, zlen);
+}
+// op 0: out = a * b in GT;  op 1: out = a ^ z
+__global__ void __launch_bounds__(kBlock, 2) gt_op_kernel(int type, int op, uint8_t *out, const uint8_t *a,
+                                                           const uint8_t *b, int lenT, int zlen, size_t n) {
+  size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
+  if (idx >= n) return;
+  uint8_t *o = out + idx * lenT;
+  const uint8_t *x = a + idx * lenT;
+  if (type == 'a') {
+    if (op == 0) a_gt_mul_lane<16>(o, x, b + idx * lenT); else a_gt_pow_lane<16>(o, x, b + idx * zlen, zlen);
+  } else if (type == 'd') {
+    if (op == 0) d_gt_mul_lane(o, x, b + idx * lenT); else d_gt_pow_lane(o, x, b + idx * zlen, zlen);
+  } else {
+    if (op == 0) f_gt_mul_lane(o, x, b + idx * lenT); else f_gt_pow_lane(o, x, b + idx * zlen, zlen);
+  }
+}
+
 // Batched F_q operations on wire bytes (differential check of the limb arithmetic).
 template <int N>
 __global__ void __launch_bounds__(kBlock) fq_op_kernel(int op, uint8_t *c, const uint8_t *a,
@@ -391,6 +415,11 @@ static int upload_constants(pbc_hip_pairing_s *P, hipStream_t s) {
     }
     HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_f), &P->fconst, sizeof P->fconst, 0, hipMemcpyHostToDevice, s));
   }
+  {
+    CurveK C;
+    fill_curve(P, C);
+    HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_curve), &C, sizeof C, 0, hipMemcpyHostToDevice, s));
+  }
   return 0;
 }
 
@@ -492,6 +521,67 @@ extern "C" int pbc_hip_element_prod_pairing_batch(pbc_hip_pairing_t *P, uint8_t 
   if (!P) return fail("null pairing");
   if (k < 1) return fail("k must be >= 1");
   return run_host(P, gt, g1, g2, n, k);
+}
+
+// ---- group operations ------------------------------------------------------------------------
+extern "C" int pbc_hip_pairing_length_in_bytes_Zr(const pbc_hip_pairing_t *p) { return p->len_zr; }
+
+// three device buffers in, one out: shared host path for the group-operation entry points
+static int run_group(pbc_hip_pairing_s *P, int what, int group, uint8_t *out, const uint8_t *a, const uint8_t *b,
+                     size_t n) {
+  if (P->device < 0) return fail("no HIP device: libpbc_hip has no CPU fallback");
+  if (!n) return 0;
+  size_t la, lb, lo;
+  if (what == 0) {                     // G mul_zn
+    if (group != 1 && !(group == 2 && P->type == 'a'))
+      return fail("scalar multiplication is built for G1 (and G2 of the symmetric type a)");
+    la = lo = (size_t) P->len1;
+    lb = (size_t) P->len_zr;
+  } else if (what == 1) {              // GT mul
+    la = lb = lo = (size_t) P->lenT;
+  } else {                             // GT pow
+    la = lo = (size_t) P->lenT;
+    lb = (size_t) P->len_zr;
+  }
+  void *da = nullptr, *db = nullptr, *d_o = nullptr;
+  HIP_TRY(hipSetDevice(P->device));
+  HIP_TRY(hipMalloc(&da, n * la));
+  HIP_TRY(hipMalloc(&db, n * lb));
+  HIP_TRY(hipMalloc(&d_o, n * lo));
+  HIP_TRY(hipMemcpy(da, a, n * la, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(db, b, n * lb, hipMemcpyHostToDevice));
+  if (upload_constants(P, 0)) return 1;
+  unsigned grid = (unsigned) ((n + kBlock - 1) / kBlock);
+  if (what == 0) {
+    if (P->nlimb == 16)
+      hipLaunchKernelGGL(g_mul_kernel<16>, dim3(grid), dim3(kBlock), 0, 0, (uint8_t *) d_o, (const uint8_t *) da,
+                         (const uint8_t *) db, P->len_zr, n);
+    else
+      hipLaunchKernelGGL(g_mul_kernel<5>, dim3(grid), dim3(kBlock), 0, 0, (uint8_t *) d_o, (const uint8_t *) da,
+                         (const uint8_t *) db, P->len_zr, n);
+  } else {
+    hipLaunchKernelGGL(gt_op_kernel, dim3(grid), dim3(kBlock), 0, 0, P->type, what - 1, (uint8_t *) d_o,
+                       (const uint8_t *) da, (const uint8_t *) db, P->lenT, P->len_zr, n);
+  }
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(out, d_o, n * lo, hipMemcpyDeviceToHost));
+  (void) hipFree(da); (void) hipFree(db); (void) hipFree(d_o);
+  return 0;
+}
+extern "C" int pbc_hip_element_mul_zn_batch(pbc_hip_pairing_t *P, int group, uint8_t *out, const uint8_t *in,
+                                            const uint8_t *zr, size_t n) {
+  if (!P) return fail("null pairing");
+  return run_group(P, 0, group, out, in, zr, n);
+}
+extern "C" int pbc_hip_element_mul_GT_batch(pbc_hip_pairing_t *P, uint8_t *out, const uint8_t *a, const uint8_t *b,
+                                            size_t n) {
+  if (!P) return fail("null pairing");
+  return run_group(P, 1, 0, out, a, b, n);
+}
+extern "C" int pbc_hip_element_pow_zn_GT_batch(pbc_hip_pairing_t *P, uint8_t *out, const uint8_t *a,
+                                               const uint8_t *zr, size_t n) {
+  if (!P) return fail("null pairing");
+  return run_group(P, 2, 0, out, a, zr, n);
 }
 
 // ---- preprocessed pairings ---------------------------------------------------------------

@@ -57,6 +57,16 @@ class HostSim:
             raise RuntimeError("hostsim_pp failed")
         return out
 
+    def group(self, what, a, b):
+        a = np.ascontiguousarray(a, np.uint8)
+        b = np.ascontiguousarray(b, np.uint8)
+        la = self.len1 if what == 0 else self.lenT
+        n = a.size // la
+        out = np.empty((n, la), np.uint8)
+        self.L.hostsim_group.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 3 + [ctypes.c_size_t]
+        self.L.hostsim_group(self.h, what, out.ctypes.data, a.ctypes.data, b.ctypes.data, n)
+        return out
+
     def stage(self, stage, g1=None, g2=None, n=0, out_len=4096):
         out = np.zeros(max(out_len, n * self.lenT), np.uint8)
         self.L.hostsim_stage.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t,

@@ -11,6 +11,9 @@ static void activate(pbc_hip_pairing_s *P) {
   if (P->type == 'a') c_a = P->a;
   if (P->type == 'd') c_d = P->dconst;
   if (P->type == 'f') c_f = P->fconst;
+  CurveK C;
+  fill_curve(P, C);
+  c_curve = C;
 }
 
 extern "C" {
@@ -71,6 +74,24 @@ int hostsim_pp(void *h, uint8_t *gt, const uint8_t *g1, const uint8_t *g2, size_
   static uint32_t tab[512 * 3 * 16];
   bool v = a_pp_init_lane<16>(tab, g1);
   for (size_t u = 0; u < n; u++) a_pp_apply_lane<16>(gt + u * P->lenT, tab, v, g2 + u * P->len2);
+  return 0;
+}
+// group operations: what 0 = G mul_zn, 1 = GT mul, 2 = GT pow
+int hostsim_group(void *h, int what, uint8_t *out, const uint8_t *a, const uint8_t *b, size_t n) {
+  pbc_hip_pairing_s *P = (pbc_hip_pairing_s *) h;
+  activate(P);
+  for (size_t i = 0; i < n; i++) {
+    if (what == 0) {
+      if (P->nlimb == 16) g_mul_lane<16>(out + i * P->len1, a + i * P->len1, b + i * P->len_zr, P->len_zr);
+      else g_mul_lane<5>(out + i * P->len1, a + i * P->len1, b + i * P->len_zr, P->len_zr);
+    } else {
+      uint8_t *o = out + i * P->lenT;
+      const uint8_t *x = a + i * P->lenT, *y = b + i * (what == 1 ? P->lenT : P->len_zr);
+      if (P->type == 'a') { if (what == 1) a_gt_mul_lane<16>(o, x, y); else a_gt_pow_lane<16>(o, x, y, P->len_zr); }
+      else if (P->type == 'd') { if (what == 1) d_gt_mul_lane(o, x, y); else d_gt_pow_lane(o, x, y, P->len_zr); }
+      else { if (what == 1) f_gt_mul_lane(o, x, y); else f_gt_pow_lane(o, x, y, P->len_zr); }
+    }
+  }
   return 0;
 }
 // diagnostics mirroring pbc_hip_diag_stage

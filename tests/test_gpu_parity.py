@@ -336,3 +336,39 @@ def test_pairing_pp_matches_element_pairing(hip_a, oracle_a):
     one = np.zeros(128, np.uint8)
     one[63] = 1
     assert np.array_equal(pp.apply(v.g2[:3]), np.tile(one, (3, 1)))
+
+
+# ---- group operations: element_mul_zn on G1/G2, element_mul / pow_zn on GT ----
+R_OF = {"a": R_A, "d": 208617601094290618684641029477488665211553761021,
+        "f": 205523667896953300194895899082072403858390252929}
+
+
+@pytest.mark.parametrize("t,name", [("a", "a_rand32.vec"), ("d", "d_rand32.vec"), ("f", "f_rand16.vec")])
+def test_group_ops_vs_oracle(hips, oracles, t, name):
+    v = golden(name)
+    n = min(v.n, 16)
+    rng = np.random.default_rng(23)
+    ks = [int.from_bytes(rng.bytes(20), "big") % R_OF[t] for _ in range(n - 2)] + [1, R_OF[t] - 1]
+    Z = np.stack([_be(k, 20) for k in ks])
+    H, O = hips[t], oracles[t]
+    assert H.length_in_bytes_Zr == 20
+    assert np.array_equal(H.element_mul_zn(1, v.g1[:n], Z), O.g_mul(1, v.g1[:n], Z))
+    if t == "a":
+        assert np.array_equal(H.element_mul_zn(2, v.g2[:n], Z), O.g_mul(2, v.g2[:n], Z))
+    a, b = v.gt[:n], np.roll(v.gt[:n], 1, axis=0)
+    assert np.array_equal(H.element_mul_GT(a, b), O.gt_mul(a, b))
+    assert np.array_equal(H.element_pow_zn_GT(a, Z), O.gt_pow(a, Z))
+
+
+@pytest.mark.parametrize("t,name,n", [("a", "a_chain1024.vec", 1024), ("d", "d_chain256.vec", 256), ("f", "f_chain128.vec", 128)])
+def test_bilinearity_entirely_on_gpu(hips, t, name, n):
+    """pbc/bilinear.test:24-33 with every operation on the device: e([a]P, Q) == e(P, Q)^a,
+    two independent kernel paths (curve scalar multiplication + pairing vs pairing + GT power)."""
+    v = golden(name)
+    H = hips[t]
+    rng = np.random.default_rng(29)
+    Z = np.stack([_be(int.from_bytes(rng.bytes(20), "big") % R_OF[t], 20) for _ in range(n)])
+    aP = H.element_mul_zn(1, v.g1[:n], Z)
+    lhs = H.element_pairing(aP, v.g2[:n])
+    rhs = H.element_pow_zn_GT(v.gt[:n], Z)                 # v.gt = e(P_i, Q_i) from the reference
+    assert np.array_equal(lhs, rhs)

@@ -64,3 +64,18 @@ def test_pairing_pp_on_host(sims, oracles):
     bad = P.copy(); bad[100] ^= 4                          # off-curve first argument -> all 1
     one = np.zeros(128, np.uint8); one[63] = 1
     assert np.array_equal(sims["a"].pp(bad, Q), np.tile(one, (6, 1)))
+
+
+@pytest.mark.parametrize("t,name", [("a", "a_rand32.vec"), ("d", "d_rand32.vec"), ("f", "f_rand16.vec")])
+def test_group_ops_on_host(sims, oracles, t, name):
+    """element_mul_zn on G1, element_mul / element_pow_zn on GT vs the oracle."""
+    v = golden(name)
+    rng = np.random.default_rng(21)
+    n = 3
+    r = {"a": 730750818665451621361119245571504901405976559617, "d": 208617601094290618684641029477488665211553761021,
+         "f": 205523667896953300194895899082072403858390252929}[t]
+    ks = [int.from_bytes(rng.bytes(20), "big") % r for _ in range(n - 1)] + [1]
+    Z = np.stack([np.frombuffer(k.to_bytes(20, "big"), np.uint8) for k in ks])
+    assert np.array_equal(sims[t].group(0, v.g1[:n], Z), oracles[t].g_mul(1, v.g1[:n], Z))
+    assert np.array_equal(sims[t].group(1, v.gt[:n], v.gt[n:2 * n]), oracles[t].gt_mul(v.gt[:n], v.gt[n:2 * n]))
+    assert np.array_equal(sims[t].group(2, v.gt[:n], Z), oracles[t].gt_pow(v.gt[:n], Z))

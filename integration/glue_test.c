@@ -62,6 +62,25 @@ int main(int argc, char **argv) {
     for (size_t i = 0; i < 12 && i < n; i++)
       if (element_cmp(gpu[i], cpp1[i])) { printf("pp batch mismatch at %zu\n", i); fails++; }
   }
+  /* 1c. group operations: G1 scalar multiplication and GT powers vs the CPU */
+  {
+    size_t m = n < 24 ? n : 24;
+    element_t *zr = malloc(sizeof(element_t) * m), *o1 = malloc(sizeof(element_t) * m), *ot = malloc(sizeof(element_t) * m);
+    for (size_t i = 0; i < m; i++) {
+      element_init_Zr(zr[i], pairing); element_random(zr[i]);
+      element_init_G1(o1[i], pairing); element_init_GT(ot[i], pairing);
+    }
+    if (element_pow_zn_batch(o1, P, zr, m) || element_pow_zn_batch(ot, cpu, zr, m)) { printf("pow_zn batch failed\n"); fails++; }
+    for (size_t i = 0; i < m; i++) {
+      element_t c1, ct;
+      element_init_G1(c1, pairing); element_init_GT(ct, pairing);
+      element_pow_zn(c1, P[i], zr[i]);
+      element_pow_zn(ct, cpu[i], zr[i]);
+      if (element_cmp(c1, o1[i])) { printf("G1 pow_zn mismatch at %zu\n", i); fails++; }
+      if (element_cmp(ct, ot[i])) { printf("GT pow_zn mismatch at %zu\n", i); fails++; }
+      element_clear(c1); element_clear(ct);
+    }
+  }
   /* 2. the batch entry points */
   if (element_pairing_batch(gpu, P, Q, n)) { printf("batch call failed\n"); fails++; }
   for (size_t i = 0; i < n; i++) if (element_cmp(gpu[i], cpu[i])) { printf("batch mismatch at %zu\n", i); fails++; break; }

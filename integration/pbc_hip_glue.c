@@ -18,6 +18,10 @@ static struct {
   int (*pp_init)(void **, pbc_hip_pairing_t *, const unsigned char *);
   void (*pp_clear)(void *);
   int (*pp_apply)(void *, unsigned char *, const unsigned char *, size_t);
+  int (*lenZr)(const pbc_hip_pairing_t *);
+  int (*mul_zn)(pbc_hip_pairing_t *, int, unsigned char *, const unsigned char *, const unsigned char *, size_t);
+  int (*gt_mul)(pbc_hip_pairing_t *, unsigned char *, const unsigned char *, const unsigned char *, size_t);
+  int (*gt_pow)(pbc_hip_pairing_t *, unsigned char *, const unsigned char *, const unsigned char *, size_t);
 } L;
 
 /* one attachment per pairing_s (kept in a tiny table keyed by the pairing pointer so that
@@ -50,6 +54,8 @@ static int load_lib(void) {
   SYM(err, "pbc_hip_last_error");
   SYM(pp_init, "pbc_hip_pairing_pp_init"); SYM(pp_clear, "pbc_hip_pairing_pp_clear");
   SYM(pp_apply, "pbc_hip_pairing_pp_apply_batch");
+  SYM(lenZr, "pbc_hip_pairing_length_in_bytes_Zr"); SYM(mul_zn, "pbc_hip_element_mul_zn_batch");
+  SYM(gt_mul, "pbc_hip_element_mul_GT_batch"); SYM(gt_pow, "pbc_hip_element_pow_zn_GT_batch");
 #undef SYM
   return 0;
 }
@@ -145,6 +151,32 @@ int pairing_pp_apply_batch(element_t out[], element_t in2[], size_t n, pairing_p
   int rc = m ? L.pp_apply(p->data, bt, b2, m) : 0;
   if (!rc) for (size_t i = 0; i < m; i++) element_from_bytes(out[slot[i]], bt + i * lt);
   free(b2); free(bt); free(slot);
+  return rc;
+}
+
+/* out[i] = in[i]^zr[i] (element_pow_zn / element_mul_zn, include/pbc_field.h:311,374) for
+ * elements of G1, of G2 when the pairing is symmetric, or of GT; identity inputs stay identity. */
+int element_pow_zn_batch(element_t out[], element_t in[], element_t zr[], size_t n) {
+  if (!n) return 0;
+  struct pairing_s *p = in[0]->field->pairing;
+  attach_t *a = find(p);
+  if (!a) return 1;
+  int is_gt = in[0]->field == p->GT;
+  int group = in[0]->field == p->G1 ? 1 : (in[0]->field == p->G2 ? 2 : 0);
+  if (!is_gt && !group) return 1;
+  int le = element_length_in_bytes(in[0]), lz = L.lenZr(a->gpu);
+  unsigned char *be = malloc(n * le + 1), *bz = malloc(n * lz + 1), *bo = malloc(n * le + 1);
+  size_t *slot = malloc(n * sizeof *slot), m = 0;
+  for (size_t i = 0; i < n; i++) {
+    if (element_is0(in[i]) || element_is0(zr[i])) { element_set0(out[i]); continue; }   /* x^0 = O^k = identity */
+    element_to_bytes(be + m * le, in[i]);
+    element_to_bytes(bz + m * lz, zr[i]);
+    slot[m++] = i;
+  }
+  int rc = !m ? 0 : is_gt ? L.gt_pow(a->gpu, bo, be, bz, m) : L.mul_zn(a->gpu, group, bo, be, bz, m);
+  if (rc) fprintf(stderr, "pbc_hip: %s\n", L.err());
+  else for (size_t i = 0; i < m; i++) element_from_bytes(out[slot[i]], bo + i * le);
+  free(be); free(bz); free(bo); free(slot);
   return rc;
 }
 

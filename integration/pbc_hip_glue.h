@@ -32,4 +32,7 @@ int element_prod_pairing_batch(element_t out[], element_t in1[], element_t in2[]
 /* out[i] = e(P, in2[i]) for the P a pairing_pp_t was initialised with (pairing_pp_init after
  * pbc_hip_attach): pairing_pp_apply (include/pbc_pairing.h:79-89) over a batch.  Type A. */
 int pairing_pp_apply_batch(element_t out[], element_t in2[], size_t n, pairing_pp_t p);
+/* out[i] = in[i]^zr[i]: element_pow_zn / element_mul_zn (include/pbc_field.h:311, :374) over a
+ * batch of G1 elements (G2 too for symmetric pairings) or GT elements. */
+int element_pow_zn_batch(element_t out[], element_t in[], element_t zr[], size_t n);
 #endif

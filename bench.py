@@ -134,12 +134,19 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run" % args.gpus)
-    torch.cuda.set_device(local_rank)
+    # test hooks (single-GPU boxes): PBC_BENCH_SAME_DEVICE=1 puts every rank on cuda:0 and
+    # PBC_BENCH_BACKEND=gloo replaces RCCL for the barrier/clock -- the data path has no collective
+    backend = os.environ.get("PBC_BENCH_BACKEND", "nccl")
+    dev_index = 0 if os.environ.get("PBC_BENCH_SAME_DEVICE") == "1" else local_rank
+    torch.cuda.set_device(dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
 
     param_path = os.path.join(ROOT, "pbc_amd", "param", pname + ".param")
     pairing = pbc_amd.Pairing(open(param_path).read())
@@ -216,7 +223,7 @@ def main():
     dt = time.perf_counter() - t0
     kern_ms = [a.elapsed_time(b) for a, b in evs]
     if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 

@@ -429,11 +429,18 @@ static __device__ __noinline__ typename vecN<16>::type fp_mul_fn16(typename vecN
 #ifndef PBC_LDS_ARG
 #define PBC_LDS_ARG 0       // 0: plain ABI call (32nd argument word on the stack)
 #endif
+#ifndef PBC_INLINE_SMALL
+#define PBC_INLINE_SMALL 0  // 1: products of the 160-bit fields are inlined (a call costs more than the
+#endif                      //    78 multiply-adds it wraps); code size is held by the tower-level calls
 template <int N>
 PBC_DEV void fp_mul(fp<N> &r, const fp<N> &a, const fp<N> &b) {
 #if PBC_INLINE_MUL
   fp_mul_inl<N>(r, a, b);
 #else
+  if constexpr (N <= 5 && PBC_INLINE_SMALL) {
+    fp_mul_inl<N>(r, a, b);
+    return;
+  }
   if constexpr (N == 16 && PBC_LDS_ARG) {
     typename vecN<15>::type vb;
 #pragma unroll
@@ -459,6 +466,10 @@ PBC_DEV void fp_sqr(fp<N> &r, const fp<N> &a) {
 #if PBC_INLINE_MUL
   fp_sqr_inl<N>(r, a);
 #else
+  if constexpr (N <= 5 && PBC_INLINE_SMALL) {
+    fp_sqr_inl<N>(r, a);
+    return;
+  }
   from_vec<N>(r, fp_sqr_fn<N>(to_vec<N>(a)));
 #endif
 }

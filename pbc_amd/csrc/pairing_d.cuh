@@ -178,84 +178,118 @@ PBC_DEV void f6_sqr(f6 &r, const f6 &a) {
 // ---- Miller loop -------------------------------------------------------------------------
 struct djac { fq X, Y, Z, ZZ; };
 
-// l(Q) = (a Qx + c) + (b Qy) sqrt(v) with a, b, c in F_q (d_miller_evalfn, d_param.c:99-111)
-PBC_DEV void d_evalfn(f6 &e0, const fq &a, const fq &b, const fq &c, const f3 &Qx, const f3 &Qy) {
+// Per-lane Miller state in LDS, word-major ([word][lane]: conflict-free): the point V = (X, Y, Z),
+// the fixed affine P and the untwisted Q.  The two step routines below take NO register
+// arguments: a 160-bit F_q product is only ~80 multiply-adds, so calling it out of line costs
+// more than it computes; instead each Miller step is ONE out-of-line body with its ~20 products
+// inlined, fed from / writing back to LDS, returning just the line value (30 words).
+constexpr int D_LANES = 128;
+enum { DL_QX = 0, DL_QY = 15, DL_X = 30, DL_Y = 35, DL_Z = 40, DL_PX = 45, DL_PY = 50, DL_WORDS = 55 };
+__shared__ uint32_t g_lds_d[DL_WORDS * D_LANES];
+PBC_DEV fq dl_get(int w) {
+  fq r;
+#pragma unroll
+  for (int k = 0; k < ND; k++) r.v[k] = g_lds_d[(w + k) * D_LANES + threadIdx.x];
+  return r;
+}
+PBC_DEV void dl_put(int w, const fq &a) {
+#pragma unroll
+  for (int k = 0; k < ND; k++) g_lds_d[(w + k) * D_LANES + threadIdx.x] = a.v[k];
+}
+typedef uint32_t v32 __attribute__((ext_vector_type(32)));
+
+// l(Q) = (a Qx + c) + (b Qy) sqrt(v) with a, b, c in F_q (d_miller_evalfn, d_param.c:99-111);
+// Q is read from LDS, the result is packed for the return registers
+PBC_DEV v32 d_evalfn_pack(const fq &a, const fq &b, const fq &c) {
+  v32 r;
 #pragma unroll
   for (int i = 0; i < 3; i++) {
-    fp_mul<ND>(e0.x.c[i], Qx.c[i], a);
-    fp_mul<ND>(e0.y.c[i], Qy.c[i], b);
+    fq t, u;
+    fp_mul_inl<ND>(t, dl_get(DL_QX + 5 * i), a);
+    if (i == 0) fp_add<ND>(t, t, c);
+    fp_mul_inl<ND>(u, dl_get(DL_QY + 5 * i), b);
+#pragma unroll
+    for (int k = 0; k < ND; k++) { r[5 * i + k] = t.v[k]; r[15 + 5 * i + k] = u.v[k]; }
   }
-  fp_add<ND>(e0.x.c[0], e0.x.c[0], c);
+  r[30] = 0; r[31] = 0;
+  return r;
+}
+PBC_DEV void d_unpack(f6 &e0, v32 r) {
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int k = 0; k < ND; k++) { e0.x.c[i].v[k] = r[5 * i + k]; e0.y.c[i].v[k] = r[15 + 5 * i + k]; }
 }
 // tangent at V (do_tangent d_param.c:344-362, scaled by Z^6 in F_q^*) and V <- 2V:
 //   M = 3X^2 + a Z^4,  a' = -M Z^2,  b' = (2YZ) Z^2,  c' = M X - 2Y^2
-PBC_DEV void d_double_step(f6 &v, djac &V, const f3 &Qx, const f3 &Qy) {
-  fq XX, YY, M, t0, t1, S, Z3, la, lb, lc;
-  fp_sqr<ND>(XX, V.X);
-  fp_sqr<ND>(YY, V.Y);
-  fp_sqr<ND>(t0, V.ZZ);
-  fp_mul<ND>(t0, t0, dk(c_d.A));
+static __device__ __noinline__ v32 d_dbl_line_fn() {
+  fq X = dl_get(DL_X), Y = dl_get(DL_Y), Z = dl_get(DL_Z);
+  fq ZZ, XX, YY, M, t0, t1, S, Z3, la, lb, lc;
+  fp_sqr_inl<ND>(ZZ, Z);
+  fp_sqr_inl<ND>(XX, X);
+  fp_sqr_inl<ND>(YY, Y);
+  fp_sqr_inl<ND>(t0, ZZ);
+  fp_mul_inl<ND>(t0, t0, dk(c_d.A));
   fp_dbl<ND>(M, XX);
   fp_add<ND>(M, M, XX);
   fp_add<ND>(M, M, t0);
-  fp_mul<ND>(la, M, V.ZZ);
+  fp_mul_inl<ND>(la, M, ZZ);
   fp_neg<ND>(la, la);
-  fp_mul<ND>(Z3, V.Y, V.Z);
+  fp_mul_inl<ND>(Z3, Y, Z);
   fp_dbl<ND>(Z3, Z3);
-  fp_mul<ND>(lb, Z3, V.ZZ);
-  fp_mul<ND>(lc, M, V.X);
+  fp_mul_inl<ND>(lb, Z3, ZZ);
+  fp_mul_inl<ND>(lc, M, X);
   fp_dbl<ND>(t1, YY);
   fp_sub<ND>(lc, lc, t1);
-  f6 e0;
-  d_evalfn(e0, la, lb, lc, Qx, Qy);
-  f6_mul(v, v, e0);
-  fp_mul<ND>(S, V.X, YY);
+  fp_mul_inl<ND>(S, X, YY);
   fp_dbl<ND>(S, S);
   fp_dbl<ND>(S, S);
-  fp_sqr<ND>(t0, YY);
+  fp_sqr_inl<ND>(t0, YY);
   fp_dbl<ND>(t0, t0);
   fp_dbl<ND>(t0, t0);
   fp_dbl<ND>(t0, t0);
-  fp_sqr<ND>(V.X, M);
+  fp_sqr_inl<ND>(X, M);
   fp_dbl<ND>(t1, S);
-  fp_sub<ND>(V.X, V.X, t1);
-  fp_sub<ND>(t1, S, V.X);
-  fp_mul<ND>(t1, M, t1);
-  fp_sub<ND>(V.Y, t1, t0);
-  V.Z = Z3;
-  fp_sqr<ND>(V.ZZ, Z3);
+  fp_sub<ND>(X, X, t1);
+  fp_sub<ND>(t1, S, X);
+  fp_mul_inl<ND>(t1, M, t1);
+  fp_sub<ND>(Y, t1, t0);
+  dl_put(DL_X, X);
+  dl_put(DL_Y, Y);
+  dl_put(DL_Z, Z3);
+  return d_evalfn_pack(la, lb, lc);
 }
 // chord through V and the affine P (do_line d_param.c:364-379, scaled by Z3 = Z H):
 //   H = Px Z^2 - X, R = Py Z^3 - Y;  a' = -R,  b' = Z3,  c' = R Px - Z3 Py;   V <- V + P
-PBC_DEV void d_add_step(f6 &v, djac &V, const fq &Px, const fq &Py, const f3 &Qx, const f3 &Qy) {
-  fq H, R, HH, HHH, t0, t1, Z3, la, lc;
-  fp_mul<ND>(H, Px, V.ZZ);
-  fp_sub<ND>(H, H, V.X);
-  fp_mul<ND>(t0, V.Z, V.ZZ);
-  fp_mul<ND>(R, Py, t0);
-  fp_sub<ND>(R, R, V.Y);
-  fp_mul<ND>(Z3, V.Z, H);
+static __device__ __noinline__ v32 d_add_line_fn() {
+  fq X = dl_get(DL_X), Y = dl_get(DL_Y), Z = dl_get(DL_Z), Px = dl_get(DL_PX), Py = dl_get(DL_PY);
+  fq ZZ, H, R, HH, HHH, t0, t1, Z3, la, lc;
+  fp_sqr_inl<ND>(ZZ, Z);
+  fp_mul_inl<ND>(H, Px, ZZ);
+  fp_sub<ND>(H, H, X);
+  fp_mul_inl<ND>(t0, Z, ZZ);
+  fp_mul_inl<ND>(R, Py, t0);
+  fp_sub<ND>(R, R, Y);
+  fp_mul_inl<ND>(Z3, Z, H);
   fp_neg<ND>(la, R);
-  fp_mul<ND>(lc, R, Px);
-  fp_mul<ND>(t0, Z3, Py);
+  fp_mul_inl<ND>(lc, R, Px);
+  fp_mul_inl<ND>(t0, Z3, Py);
   fp_sub<ND>(lc, lc, t0);
-  f6 e0;
-  d_evalfn(e0, la, Z3, lc, Qx, Qy);
-  f6_mul(v, v, e0);
-  fp_sqr<ND>(HH, H);
-  fp_mul<ND>(HHH, HH, H);
-  fp_mul<ND>(t0, V.X, HH);
-  fp_sqr<ND>(t1, R);
+  fp_sqr_inl<ND>(HH, H);
+  fp_mul_inl<ND>(HHH, HH, H);
+  fp_mul_inl<ND>(t0, X, HH);
+  fp_sqr_inl<ND>(t1, R);
   fp_sub<ND>(t1, t1, HHH);
   fp_sub<ND>(t1, t1, t0);
   fp_sub<ND>(t1, t1, t0);
   fp_sub<ND>(t0, t0, t1);
-  fp_mul<ND>(t0, R, t0);
-  fp_mul<ND>(HHH, V.Y, HHH);
-  fp_sub<ND>(V.Y, t0, HHH);
-  V.X = t1;
-  V.Z = Z3;
-  fp_sqr<ND>(V.ZZ, Z3);
+  fp_mul_inl<ND>(t0, R, t0);
+  fp_mul_inl<ND>(HHH, Y, HHH);
+  fp_sub<ND>(Y, t0, HHH);
+  dl_put(DL_X, t1);
+  dl_put(DL_Y, Y);
+  dl_put(DL_Z, Z3);
+  return d_evalfn_pack(la, Z3, lc);
 }
 
 PBC_DEV void f3_load_be(f3 &r, const uint8_t *src) { for (int i = 0; i < 3; i++) fp_load_be<ND>(r.c[i], src + 4 * ND * i); }
@@ -293,17 +327,24 @@ PBC_DEV bool d_miller_lane(f6 &v, const uint8_t *g1, const uint8_t *g2) {
   // twist map (x, y) -> (v^-1 x, v^-2 y sqrt(v))  (cc_pairing, d_param.c:580-582)
   f3_mul_fq(Qx, Qx, dk(c_d.nqrinv));
   f3_mul_fq(Qy, Qy, dk(c_d.nqrinv2));
-  djac V;
-  V.X = Px; V.Y = Py; V.Z = one; V.ZZ = one;
+#pragma unroll
+  for (int i = 0; i < 3; i++) { dl_put(DL_QX + 5 * i, Qx.c[i]); dl_put(DL_QY + 5 * i, Qy.c[i]); }
+  dl_put(DL_X, Px); dl_put(DL_Y, Py); dl_put(DL_Z, one);
+  dl_put(DL_PX, Px); dl_put(DL_PY, Py);
 #pragma unroll
   for (int i = 0; i < 3; i++)
 #pragma unroll
     for (int k = 0; k < ND; k++) { v.x.c[i].v[k] = (i == 0) ? one.v[k] : 0; v.y.c[i].v[k] = 0; }
   // cc_miller_no_denom_affine (d_param.c:321-422): tangent; [double; line+add]; square
   for (int m = c_d.rbits - 2;; m--) {
-    d_double_step(v, V, Qx, Qy);
+    f6 e0;
+    d_unpack(e0, d_dbl_line_fn());
+    f6_mul(v, v, e0);
     if (m <= 0) break;
-    if ((c_d.r[m >> 5] >> (m & 31)) & 1) d_add_step(v, V, Px, Py, Qx, Qy);
+    if ((c_d.r[m >> 5] >> (m & 31)) & 1) {
+      d_unpack(e0, d_add_line_fn());
+      f6_mul(v, v, e0);
+    }
     f6_sqr(v, v);
   }
   return valid;

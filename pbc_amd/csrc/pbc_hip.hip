@@ -32,6 +32,7 @@ extern "C" const char *pbc_hip_last_error(void) { return g_err; }
 // kernels
 // ---------------------------------------------------------------------------------------
 constexpr int kBlock = 128;
+static_assert(kBlock == D_LANES, "pairing_d.cuh sizes its LDS state for 128-lane workgroups");
 #ifndef PBC_DF_WAVES
 #define PBC_DF_WAVES 2
 #endif

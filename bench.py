@@ -123,6 +123,9 @@ def main():
                     help="default: the BASELINE.json metric config (2^20 Type-A pairings)")
     ap.add_argument("--log2n", type=int, default=None, help="units per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--host-path", action="store_true",
+                    help="additionally time the host-buffer entry point (pinned host memory in, host memory out: "
+                         "PCIe-inclusive rate for DESIGN.md; never the reported value)")
     args = ap.parse_args()
     pname, fixture, k, dlog, desc = WORKLOADS[args.workload]
     if args.log2n is None:
@@ -271,6 +274,17 @@ def main():
                         "algorithmic_bytes_per_unit": unit_bytes},
             },
         }
+        if args.host_path and k == 1 and pp is None:
+            h1 = G1.cpu().pin_memory().numpy()
+            h2 = G2.cpu().pin_memory().numpy()
+            ts = []
+            for _ in range(3):
+                t1 = time.perf_counter()
+                hout = pairing.element_pairing(h1, h2)
+                ts.append(time.perf_counter() - t1)
+            assert np.array_equal(hout[:256], GT[:256].cpu().numpy())
+            out["host_path"] = {"pairings_per_s": round(n / min(ts), 1), "ms": round(min(ts) * 1e3, 2),
+                                "note": "pinned host buffers -> chunked H2D/kernel/D2H on 3 streams -> host; PCIe-inclusive"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(param_path, k)
         print(json.dumps(out), flush=True)

@@ -449,40 +449,61 @@ extern "C" int pbc_hip_element_pairing_batch_dev(pbc_hip_pairing_t *P, void *d_g
 }
 
 // host-buffer convenience path: H2D, kernel, D2H on a private stream
+// host-buffer path: the batch is cut into chunks that travel H2D -> kernel -> D2H on a small
+// ring of streams, so the PCIe copies of one chunk overlap the arithmetic of its neighbours
+// ("chunked to overlap copies with compute").  Pinned caller buffers overlap fully;
+// pageable ones still work (the runtime stages them).
 static int run_host(pbc_hip_pairing_s *P, uint8_t *gt, const uint8_t *g1, const uint8_t *g2, size_t n,
                     int k) {
   if (P->device < 0) return fail("no HIP device: libpbc_hip has no CPU fallback");
   if (!n) return 0;
-  size_t b1 = n * (size_t) k * P->len1, b2 = n * (size_t) k * P->len2, bt = n * (size_t) P->lenT;
-  void *d1 = nullptr, *d2 = nullptr, *dt = nullptr;
-  hipStream_t s;
+  constexpr int SLOTS = 3;
+  size_t chunk = (size_t) 65536 / (size_t) k;
+  if (chunk < 1024) chunk = 1024;
+  if (chunk > n) chunk = n;
+  const size_t u1 = (size_t) k * P->len1, u2 = (size_t) k * P->len2, ut = (size_t) P->lenT;
+  void *d1[SLOTS] = {nullptr}, *d2[SLOTS] = {nullptr}, *dt[SLOTS] = {nullptr};
+  hipStream_t st[SLOTS] = {nullptr};
   HIP_TRY(hipSetDevice(P->device));
-  HIP_TRY(hipStreamCreate(&s));
   int rc = 0;
-  do {
-    if (hipMalloc(&d1, b1) != hipSuccess || hipMalloc(&d2, b2) != hipSuccess || hipMalloc(&dt, bt) != hipSuccess) {
-      rc = fail("hipMalloc failed for a batch of %zu units", n);
-      break;
-    }
-    if (hipMemcpyAsync(d1, g1, b1, hipMemcpyHostToDevice, s) != hipSuccess ||
-        hipMemcpyAsync(d2, g2, b2, hipMemcpyHostToDevice, s) != hipSuccess) {
+  int slots = (int) ((n + chunk - 1) / chunk);
+  if (slots > SLOTS) slots = SLOTS;
+  for (int i = 0; i < slots && !rc; i++) {
+    if (hipStreamCreate(&st[i]) != hipSuccess || hipMalloc(&d1[i], chunk * u1) != hipSuccess ||
+        hipMalloc(&d2[i], chunk * u2) != hipSuccess || hipMalloc(&dt[i], chunk * ut) != hipSuccess)
+      rc = fail("device allocation failed for a chunk of %zu units", chunk);
+  }
+  // constants once, before any chunk (the per-launch upload inside *_dev is then redundant but
+  // harmless: same bytes, same stream order)
+  if (!rc && upload_constants(P, st[0])) rc = 1;
+  if (!rc && hipStreamSynchronize(st[0]) != hipSuccess) rc = fail("constant upload failed");
+  size_t idx = 0;
+  for (size_t off = 0; off < n && !rc; off += chunk, idx++) {
+    const int sl = (int) (idx % (size_t) slots);
+    const size_t m = n - off < chunk ? n - off : chunk;
+    hipStream_t s = st[sl];
+    if (hipMemcpyAsync(d1[sl], g1 + off * u1, m * u1, hipMemcpyHostToDevice, s) != hipSuccess ||
+        hipMemcpyAsync(d2[sl], g2 + off * u2, m * u2, hipMemcpyHostToDevice, s) != hipSuccess) {
       rc = fail("H2D copy failed");
       break;
     }
-    rc = k == 1 ? pbc_hip_element_pairing_batch_dev(P, dt, d1, d2, n, s)
-                : pbc_hip_element_prod_pairing_batch_dev(P, dt, d1, d2, n, k, s);
+    rc = k == 1 ? pbc_hip_element_pairing_batch_dev(P, dt[sl], d1[sl], d2[sl], m, s)
+                : pbc_hip_element_prod_pairing_batch_dev(P, dt[sl], d1[sl], d2[sl], m, k, s);
     if (rc) break;
-    if (hipMemcpyAsync(gt, dt, bt, hipMemcpyDeviceToHost, s) != hipSuccess) {
-      rc = fail("D2H copy failed");
-      break;
+    if (hipMemcpyAsync(gt + off * ut, dt[sl], m * ut, hipMemcpyDeviceToHost, s) != hipSuccess) rc = fail("D2H copy failed");
+  }
+  for (int i = 0; i < slots; i++) {
+    if (st[i]) {
+      hipError_t e = hipStreamSynchronize(st[i]);
+      if (e != hipSuccess && !rc) rc = fail("kernel failed: %s", hipGetErrorString(e));
     }
-    hipError_t e = hipStreamSynchronize(s);
-    if (e != hipSuccess) rc = fail("kernel failed: %s", hipGetErrorString(e));
-  } while (0);
-  if (d1) (void) hipFree(d1);
-  if (d2) (void) hipFree(d2);
-  if (dt) (void) hipFree(dt);
-  (void) hipStreamDestroy(s);
+  }
+  for (int i = 0; i < SLOTS; i++) {
+    if (d1[i]) (void) hipFree(d1[i]);
+    if (d2[i]) (void) hipFree(d2[i]);
+    if (dt[i]) (void) hipFree(dt[i]);
+    if (st[i]) (void) hipStreamDestroy(st[i]);
+  }
   return rc;
 }
 

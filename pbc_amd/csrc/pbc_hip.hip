@@ -424,13 +424,13 @@ static int upload_constants(pbc_hip_pairing_s *P, hipStream_t s) {
   return 0;
 }
 
-extern "C" int pbc_hip_element_pairing_batch_dev(pbc_hip_pairing_t *P, void *d_gt, const void *d_g1,
-                                                 const void *d_g2, size_t n, void *stream) {
-  if (!P) return fail("null pairing");
+static int launch_prod(pbc_hip_pairing_s *P, void *d_gt, const void *d_g1, const void *d_g2, size_t n, int k,
+                       hipStream_t s, bool upload);
+static int launch_pairing(pbc_hip_pairing_s *P, void *d_gt, const void *d_g1, const void *d_g2, size_t n,
+                          hipStream_t s, bool upload) {
   if (P->device < 0) return fail("no HIP device: libpbc_hip has no CPU fallback");
   if (!n) return 0;
-  hipStream_t s = (hipStream_t) stream;
-  if (upload_constants(P, s)) return 1;
+  if (upload && upload_constants(P, s)) return 1;
   unsigned grid = (unsigned) ((n + kBlock - 1) / kBlock);
   if (P->type == 'a') {
     hipLaunchKernelGGL(a_pairing_kernel<16>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
@@ -447,6 +447,11 @@ extern "C" int pbc_hip_element_pairing_batch_dev(pbc_hip_pairing_t *P, void *d_g
   HIP_TRY(hipGetLastError());
   return 0;
 }
+extern "C" int pbc_hip_element_pairing_batch_dev(pbc_hip_pairing_t *P, void *d_gt, const void *d_g1,
+                                                 const void *d_g2, size_t n, void *stream) {
+  if (!P) return fail("null pairing");
+  return launch_pairing(P, d_gt, d_g1, d_g2, n, (hipStream_t) stream, true);
+}
 
 // host-buffer convenience path: H2D, kernel, D2H on a private stream
 // host-buffer path: the batch is cut into chunks that travel H2D -> kernel -> D2H on a small
@@ -458,7 +463,7 @@ static int run_host(pbc_hip_pairing_s *P, uint8_t *gt, const uint8_t *g1, const 
   if (P->device < 0) return fail("no HIP device: libpbc_hip has no CPU fallback");
   if (!n) return 0;
   constexpr int SLOTS = 3;
-  size_t chunk = (size_t) 65536 / (size_t) k;
+  size_t chunk = (size_t) 131072 / (size_t) k;       // one full residency of the chip per chunk
   if (chunk < 1024) chunk = 1024;
   if (chunk > n) chunk = n;
   const size_t u1 = (size_t) k * P->len1, u2 = (size_t) k * P->len2, ut = (size_t) P->lenT;
@@ -473,8 +478,7 @@ static int run_host(pbc_hip_pairing_s *P, uint8_t *gt, const uint8_t *g1, const 
         hipMalloc(&d2[i], chunk * u2) != hipSuccess || hipMalloc(&dt[i], chunk * ut) != hipSuccess)
       rc = fail("device allocation failed for a chunk of %zu units", chunk);
   }
-  // constants once, before any chunk (the per-launch upload inside *_dev is then redundant but
-  // harmless: same bytes, same stream order)
+  // constants once, before any chunk
   if (!rc && upload_constants(P, st[0])) rc = 1;
   if (!rc && hipStreamSynchronize(st[0]) != hipSuccess) rc = fail("constant upload failed");
   size_t idx = 0;
@@ -487,8 +491,7 @@ static int run_host(pbc_hip_pairing_s *P, uint8_t *gt, const uint8_t *g1, const 
       rc = fail("H2D copy failed");
       break;
     }
-    rc = k == 1 ? pbc_hip_element_pairing_batch_dev(P, dt[sl], d1[sl], d2[sl], m, s)
-                : pbc_hip_element_prod_pairing_batch_dev(P, dt[sl], d1[sl], d2[sl], m, k, s);
+    rc = launch_prod(P, dt[sl], d1[sl], d2[sl], m, k, s, false);
     if (rc) break;
     if (hipMemcpyAsync(gt + off * ut, dt[sl], m * ut, hipMemcpyDeviceToHost, s) != hipSuccess) rc = fail("D2H copy failed");
   }
@@ -513,15 +516,13 @@ extern "C" int pbc_hip_element_pairing_batch(pbc_hip_pairing_t *P, uint8_t *gt, 
   return run_host(P, gt, g1, g2, n, 1);
 }
 
-extern "C" int pbc_hip_element_prod_pairing_batch_dev(pbc_hip_pairing_t *P, void *d_gt, const void *d_g1,
-                                                      const void *d_g2, size_t n, int k, void *stream) {
-  if (!P) return fail("null pairing");
+static int launch_prod(pbc_hip_pairing_s *P, void *d_gt, const void *d_g1, const void *d_g2, size_t n, int k,
+                       hipStream_t s, bool upload) {
   if (k < 1) return fail("k must be >= 1");
-  if (k == 1) return pbc_hip_element_pairing_batch_dev(P, d_gt, d_g1, d_g2, n, stream);
+  if (k == 1) return launch_pairing(P, d_gt, d_g1, d_g2, n, s, upload);
   if (P->device < 0) return fail("no HIP device: libpbc_hip has no CPU fallback");
   if (!n) return 0;
-  hipStream_t s = (hipStream_t) stream;
-  if (upload_constants(P, s)) return 1;
+  if (upload && upload_constants(P, s)) return 1;
   unsigned grid = (unsigned) ((n + kBlock - 1) / kBlock);
   if (P->type == 'a') {
     hipLaunchKernelGGL(a_prod_pairing_kernel<16>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
@@ -537,6 +538,11 @@ extern "C" int pbc_hip_element_prod_pairing_batch_dev(pbc_hip_pairing_t *P, void
   }
   HIP_TRY(hipGetLastError());
   return 0;
+}
+extern "C" int pbc_hip_element_prod_pairing_batch_dev(pbc_hip_pairing_t *P, void *d_gt, const void *d_g1,
+                                                      const void *d_g2, size_t n, int k, void *stream) {
+  if (!P) return fail("null pairing");
+  return launch_prod(P, d_gt, d_g1, d_g2, n, k, (hipStream_t) stream, true);
 }
 extern "C" int pbc_hip_element_prod_pairing_batch(pbc_hip_pairing_t *P, uint8_t *gt, const uint8_t *g1,
                                                   const uint8_t *g2, size_t n, int k) {

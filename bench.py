@@ -95,12 +95,12 @@ def pmc_traffic(workload):
     WRITE_SIZE runs of this same command, summarised in profiles/): (FETCH_SIZE + WRITE_SIZE) KB.
     Raw counter sum; on gfx950 FETCH_SIZE may under-count wide coalesced reads by 2x
     (MI355X_MICROARCH.md).  None when no PMC summary is committed for the workload."""
-    path = os.path.join(ROOT, "profiles", "r01_a_pairing_v5_pmc.json")
+    path = os.path.join(ROOT, "profiles", "r01_final_a_pairing_pmc.json")
     if workload != "a" or not os.path.exists(path):
         return None
     j = json.load(open(path))
     kb = j["FETCH_SIZE"]["avg_per_launch"] + j["WRITE_SIZE"]["avg_per_launch"]
-    return {"bytes_per_launch": int(kb * 1024), "source": "profiles/r01_a_pairing_v5_pmc.json (rocprofv3 --pmc, not this run)",
+    return {"bytes_per_launch": int(kb * 1024), "source": "profiles/r01_final_a_pairing_pmc.json (rocprofv3 --pmc, not this run)",
             "note": "mostly register-spill scratch traffic around the inversion; algorithmic I/O is 403 MB per launch"}
 
 

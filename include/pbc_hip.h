@@ -87,6 +87,11 @@ int pbc_hip_pairing_pp_apply_batch_dev(pbc_hip_pp_t *pp, void *d_gt, const void 
  *   element_mul on GT (include/pbc_field.h:280 -> mulg wrapper ecc/pairing.c:135-283);
  *   element_pow_zn on GT. */
 int pbc_hip_pairing_length_in_bytes_Zr(const pbc_hip_pairing_t *p);
+/* element_from_hash on G1 / G2 (include/pbc_field.h:257 -> curve_from_hash ecc/curve.c:455-482,
+ * fp_from_hash arith/montfp.c:440-448, pbc_mpz_from_hash arith/field.c:643-668): n digests of hlen
+ * bytes each -> n points, including the cofactor multiplication.  Type A (q = 3 mod 4). */
+int pbc_hip_element_from_hash_batch(pbc_hip_pairing_t *p, int group, uint8_t *out, const uint8_t *data,
+                                    int hlen, size_t n);
 int pbc_hip_element_mul_zn_batch(pbc_hip_pairing_t *p, int group, uint8_t *out, const uint8_t *in,
                                  const uint8_t *zr, size_t n);
 int pbc_hip_element_mul_GT_batch(pbc_hip_pairing_t *p, uint8_t *out, const uint8_t *a, const uint8_t *b, size_t n);

@@ -199,10 +199,39 @@ static int cmd_bench(int argc, char **argv) {
   return 0;
 }
 
+/* hash <param> <n> <hlen> <seed> <out>: element_from_hash(G1) on n pseudo-random hlen-byte digests.
+ * Vector file: in1 = digests (len1 = hlen), in2 empty (len2 = 0), out = G1 bytes (lenT = len G1). */
+static int cmd_hash(int argc, char **argv) {
+  if (argc < 6) { fprintf(stderr, "hash <param> <n> <hlen> <seed> <out>\n"); return 2; }
+  int n = atoi(argv[2]), hlen = atoi(argv[3]);
+  unsigned seed = (unsigned) atoi(argv[4]);
+  pairing_t pairing; char type;
+  pbc_random_set_deterministic(seed);
+  init_pairing(pairing, argv[1], &type);
+  int l1 = pairing_length_in_bytes_G1(pairing);
+  unsigned char *in = malloc((size_t) n * hlen), *out = malloc((size_t) n * l1);
+  uint64_t st = 0x9e3779b97f4a7c15ull * (seed + 1);
+  for (size_t i = 0; i < (size_t) n * hlen; i++) { st ^= st << 13; st ^= st >> 7; st ^= st << 17; in[i] = (unsigned char) (st >> 24); }
+  element_t h;
+  element_init_G1(h, pairing);
+  for (int i = 0; i < n; i++) {
+    element_from_hash(h, in + (size_t) i * hlen, hlen);
+    element_to_bytes(out + (size_t) i * l1, h);
+  }
+  FILE *fp = fopen(argv[5], "wb");
+  fwrite("PBCVEC01", 1, 8, fp);
+  w32(fp, (uint32_t) type); w32(fp, n); w32(fp, 1); w32(fp, hlen); w32(fp, 0); w32(fp, l1);
+  fwrite(in, hlen, n, fp); fwrite(out, l1, n, fp);
+  fclose(fp);
+  fprintf(stderr, "wrote %s: type %c n=%d hlen=%d\n", argv[5], type, n, hlen);
+  return 0;
+}
+
 int main(int argc, char **argv) {
   if (argc < 2) { fprintf(stderr, "usage: ref_tool gen|kat|bench ...\n"); return 2; }
   if (!strcmp(argv[1], "gen")) return cmd_gen(argc - 1, argv + 1);
   if (!strcmp(argv[1], "kat")) return cmd_kat(argc - 1, argv + 1);
   if (!strcmp(argv[1], "bench")) return cmd_bench(argc - 1, argv + 1);
+  if (!strcmp(argv[1], "hash")) return cmd_hash(argc - 1, argv + 1);
   return 2;
 }

@@ -64,6 +64,7 @@ def lib():
         L.pbc_hip_diag_stage.argtypes = [vp, ci, vp, sz, vp, vp, sz]
         L.pbc_hip_pairing_length_in_bytes_Zr.argtypes = [vp]
         L.pbc_hip_element_mul_zn_batch.argtypes = [vp, ci, vp, vp, vp, sz]
+        L.pbc_hip_element_from_hash_batch.argtypes = [vp, ci, vp, vp, ci, sz]
         L.pbc_hip_element_mul_GT_batch.argtypes = [vp, vp, vp, vp, sz]
         L.pbc_hip_element_pow_zn_GT_batch.argtypes = [vp, vp, vp, vp, sz]
         L.pbc_hip_pairing_pp_init.argtypes = [ctypes.POINTER(vp), vp, vp]
@@ -89,7 +90,7 @@ EXPORTS = (
     "pbc_hip_algorithmic_macs_per_unit", "pbc_hip_last_error", "pbc_hip_diag_mul_bench", "pbc_hip_diag_stage",
     "pbc_hip_pairing_pp_init", "pbc_hip_pairing_pp_clear", "pbc_hip_pairing_pp_apply_batch",
     "pbc_hip_pairing_pp_apply_batch_dev", "pbc_hip_pairing_length_in_bytes_Zr",
-    "pbc_hip_element_mul_zn_batch", "pbc_hip_element_mul_GT_batch", "pbc_hip_element_pow_zn_GT_batch",
+    "pbc_hip_element_from_hash_batch", "pbc_hip_element_mul_zn_batch", "pbc_hip_element_mul_GT_batch", "pbc_hip_element_pow_zn_GT_batch",
 )
 
 
@@ -189,6 +190,16 @@ class Pairing:
         out = np.empty((n, self.length_in_bytes_G1), np.uint8)
         if lib().pbc_hip_element_mul_zn_batch(self._h, group, _np_ptr(out), _np_ptr(pts), _np_ptr(zr), n):
             raise PbcHipError("element_mul_zn: " + _err())
+        return out
+
+    def element_from_hash(self, group, digests):
+        """digests: (n, hlen) uint8 -> n points of G1/G2 (element_from_hash, type a)."""
+        import numpy as np
+        d = np.ascontiguousarray(digests, dtype=np.uint8)
+        n, hlen = d.shape
+        out = np.empty((n, self.length_in_bytes_G1), np.uint8)
+        if lib().pbc_hip_element_from_hash_batch(self._h, group, _np_ptr(out), _np_ptr(d), hlen, n):
+            raise PbcHipError("element_from_hash: " + _err())
         return out
 
     def element_mul_GT(self, a, b):

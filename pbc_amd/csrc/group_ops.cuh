@@ -130,6 +130,160 @@ PBC_DEV void g_mul_lane(uint8_t *out, const uint8_t *in, const uint8_t *z, int z
   fp_store_be<N>(out + NB, ay);
 }
 
+// ---- element_from_hash on G1 / G2 of Type A -------------------------------------------------
+// curve_from_hash (ecc/curve.c:455-482): x <- fp_from_hash(data) (arith/montfp.c:440-448 over
+// pbc_mpz_from_hash, arith/field.c:643-668: the digest is laid out as H || 0 || H || 1 || ... up to
+// the byte length of q, read big-endian and halved while it exceeds q); then x <- x^2 + 1 until
+// x^3 + a x + b is a square, y = its square root with the canonical residue ODD
+// (element_sgn, montfp.c:457-470), finally the cofactor multiplication.  q = 3 mod 4, so
+// sqrt(t) = t^((q+1)/4) and "t is a square" is "that power squares back to t" -- one power per
+// attempt instead of a Legendre symbol plus a Tonelli run.  Lanes retry independently under a
+// wave-uniform loop (__all).
+template <int N>
+static __device__ __noinline__ typename vecN<N>::type fp_pow_sqrt_fn(typename vecN<N>::type va) {
+  fp<N> a, r;
+  from_vec<N>(a, va);
+  fp_set<N>(r, fpk<N>().one);
+  for (int i = c_a.sqrt_bits - 1; i >= 0; i--) {
+    fp_sqr<N>(r, r);
+    if ((c_a.sqrt_e[i >> 5] >> (i & 31)) & 1) fp_mul<N>(r, r, a);
+  }
+  return to_vec<N>(r);
+}
+template <int N>
+PBC_DEV void a_from_hash_lane(uint8_t *out, const uint8_t *data, int hlen) {
+  constexpr int NB = 4 * N;
+  const FpK<N> &K = fpk<N>();
+  fp<N> one, ca, cb, x, fx, fy;
+  fp_set<N>(one, K.one);
+  fp_set<N>(ca, c_curve.a);
+  fp_set<N>(cb, c_curve.b);
+  // pbc_mpz_from_hash: NB bytes = H || ctr || H || ctr+1 ...  (big-endian integer)
+  {
+    uint32_t w[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) w[i] = 0;
+    int p = 0;
+    uint32_t ctr = 0;
+    for (int b = 0; b < NB; b++) {
+      uint32_t byte;
+      if (p < hlen) byte = data[p++];
+      else { byte = ctr++ & 0xff; p = 0; }
+      const int bit = 8 * (NB - 1 - b);
+#pragma unroll
+      for (int i = 0; i < N; i++) w[i] |= (i == (bit >> 5)) ? byte << (bit & 31) : 0u;
+    }
+    // while (z > q) z >>= 1
+    for (int rep = 0; rep < 8; rep++) {
+      uint32_t bw = 0;
+#pragma unroll
+      for (int i = 0; i < N; i++) (void) __builtin_subc(K.p[i], w[i], bw, &bw);
+      if (bw) {                        // q - z borrowed: z > q
+#pragma unroll
+        for (int i = 0; i < N; i++) w[i] = (w[i] >> 1) | (i + 1 < N ? w[i + 1] << 31 : 0u);
+      }
+    }
+    fp<N> t, r2;
+#pragma unroll
+    for (int i = 0; i < N; i++) t.v[i] = w[i];
+    fp_set<N>(r2, K.r2);
+    fp_mul<N>(x, t, r2);
+  }
+  bool done = false;
+  fx = x; fy = x;
+  for (int it = 0; it < 256; it++) {
+    fp<N> t, y, yy;
+    fp_sqr<N>(t, x);
+    fp_add<N>(t, t, ca);
+    fp_mul<N>(t, t, x);
+    fp_add<N>(t, t, cb);
+    from_vec<N>(y, fp_pow_sqrt_fn<N>(to_vec<N>(t)));
+    fp_sqr<N>(yy, y);
+    bool ok = fp_eq<N>(yy, t) & !done;
+    fp_cmov<N>(fx, x, ok);
+    fp_cmov<N>(fy, y, ok);
+    done |= ok;
+    if (__all(done)) break;
+    fp_sqr<N>(x, x);
+    fp_add<N>(x, x, one);
+  }
+  // canonical y odd
+  {
+    fp<N> o, c, ny;
+#pragma unroll
+    for (int i = 0; i < N; i++) o.v[i] = (i == 0);
+    fp_mul<N>(c, fy, o);
+    fp_neg<N>(ny, fy);
+    fp_cmov<N>(fy, ny, ((c.v[0] & 1) == 0) & !fp_is0<N>(fy));
+  }
+  // [h] (fx, fy): wave-uniform double-and-add over the cofactor (element_mul_mpz, curve.c:477)
+  fp<N> X = fx, Y = fy, Z = one;
+  for (int i = c_a.hbits - 2; i >= 0; i--) {
+    {
+      fp<N> XX, YY, ZZ, M, S, t0, t1, Z3;
+      fp_sqr<N>(XX, X);
+      fp_sqr<N>(YY, Y);
+      fp_sqr<N>(ZZ, Z);
+      fp_dbl<N>(M, XX);
+      fp_add<N>(M, M, XX);
+      fp_sqr<N>(t0, ZZ);
+      fp_mul<N>(t0, t0, ca);
+      fp_add<N>(M, M, t0);
+      fp_mul<N>(Z3, Y, Z);
+      fp_dbl<N>(Z3, Z3);
+      fp_mul<N>(S, X, YY);
+      fp_dbl<N>(S, S);
+      fp_dbl<N>(S, S);
+      fp_sqr<N>(t0, YY);
+      fp_dbl<N>(t0, t0);
+      fp_dbl<N>(t0, t0);
+      fp_dbl<N>(t0, t0);
+      fp_sqr<N>(X, M);
+      fp_dbl<N>(t1, S);
+      fp_sub<N>(X, X, t1);
+      fp_sub<N>(t1, S, X);
+      fp_mul<N>(t1, M, t1);
+      fp_sub<N>(Y, t1, t0);
+      Z = Z3;
+    }
+    if ((c_a.h[i >> 5] >> (i & 31)) & 1) {
+      fp<N> ZZ, H, R, HH, HHH, t0, t1, X3, Y3, Z3;
+      fp_sqr<N>(ZZ, Z);
+      fp_mul<N>(H, fx, ZZ);
+      fp_sub<N>(H, H, X);
+      fp_mul<N>(t0, Z, ZZ);
+      fp_mul<N>(R, fy, t0);
+      fp_sub<N>(R, R, Y);
+      fp_mul<N>(Z3, Z, H);
+      fp_sqr<N>(HH, H);
+      fp_mul<N>(HHH, HH, H);
+      fp_mul<N>(t0, X, HH);
+      fp_sqr<N>(X3, R);
+      fp_sub<N>(X3, X3, HHH);
+      fp_sub<N>(X3, X3, t0);
+      fp_sub<N>(X3, X3, t0);
+      fp_sub<N>(t0, t0, X3);
+      fp_mul<N>(t0, R, t0);
+      fp_mul<N>(t1, Y, HHH);
+      fp_sub<N>(Y3, t0, t1);
+      X = X3; Y = Y3; Z = Z3;
+    }
+  }
+  fp<N> zi, zi2, ax, ay;
+  bool is_inf = fp_is0<N>(Z);
+  fp_inv<N>(zi, Z);
+  fp_sqr<N>(zi2, zi);
+  fp_mul<N>(ax, X, zi2);
+  fp_mul<N>(zi2, zi2, zi);
+  fp_mul<N>(ay, Y, zi2);
+  if (is_inf) {
+#pragma unroll
+    for (int k = 0; k < N; k++) { ax.v[k] = 0; ay.v[k] = 0; }
+  }
+  fp_store_be<N>(out, ax);
+  fp_store_be<N>(out + NB, ay);
+}
+
 // ---- GT ------------------------------------------------------------------------------------
 // Type A: F_q^2
 template <int N>

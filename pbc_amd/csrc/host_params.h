@@ -99,6 +99,14 @@ static int init_type_a(pbc_hip_pairing_s *P, const char *txt, size_t len) {
   memset(&P->a, 0, sizeof P->a);
   h.to_words(P->a.h, 16);
   P->a.hbits = h.bits();
+  {
+    Big e = q, four, rem;
+    e.add_small(1);
+    four.w.push_back(4);
+    e = Big::div(e, four, &rem);
+    e.to_words(P->a.sqrt_e, 16);
+    P->a.sqrt_bits = e.bits();
+  }
   P->a.exp2 = exp2;
   P->a.exp1 = exp1;
   P->a.sign1 = sign1;

@@ -54,6 +54,8 @@ struct AConst {          // a_pairing_data (ecc/a_param.c:30-34) + phikonr = h (
   uint32_t h[16];        // cofactor h = (q+1)/r, little-endian words
   int hbits;
   int exp2, exp1, sign1; // r = 2^exp2 + sign1 2^exp1 + sign0 (sign0 unused by the map)
+  uint32_t sqrt_e[16];   // (q + 1)/4: square roots in F_q for q = 3 mod 4 (element_from_hash)
+  int sqrt_bits;
 };
 __constant__ AConst c_a;
 

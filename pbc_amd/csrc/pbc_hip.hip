@@ -150,6 +150,15 @@ __global__ void __launch_bounds__(kBlock, 2) g_mul_kernel(uint8_t *out, const ui
   if (idx >= n) return;
   g_mul_lane<N>(out + idx * 8 * N, in + idx * 8 * N, z + idx * zlen, zlen);
 }
+template <int N>
+__global__ void __launch_bounds__(kBlock, 2) a_from_hash_kernel(uint8_t *out, const uint8_t *data, int hlen, size_t n) {
+  size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
+  size_t ld = idx < n ? idx : n - 1;   // whole waves stay in the retry loop together
+  __attribute__((aligned(4))) uint8_t o[8 * N];
+  a_from_hash_lane<N>(o, data + ld * hlen, hlen);
+  if (idx < n)
+    for (int i = 0; i < 8 * N; i++) out[idx * 8 * N + i] = o[i];
+}
 // op 0: out = a * b in GT;  op 1: out = a ^ z
 __global__ void __launch_bounds__(kBlock, 2) gt_op_kernel(int type, int op, uint8_t *out, const uint8_t *a,
                                                            const uint8_t *b, int lenT, int zlen, size_t n) {
@@ -610,6 +619,27 @@ extern "C" int pbc_hip_element_pow_zn_GT_batch(pbc_hip_pairing_t *P, uint8_t *ou
                                                const uint8_t *zr, size_t n) {
   if (!P) return fail("null pairing");
   return run_group(P, 2, 0, out, a, zr, n);
+}
+
+extern "C" int pbc_hip_element_from_hash_batch(pbc_hip_pairing_t *P, int group, uint8_t *out, const uint8_t *data,
+                                               int hlen, size_t n) {
+  if (!P) return fail("null pairing");
+  if (P->device < 0) return fail("no HIP device: libpbc_hip has no CPU fallback");
+  if (P->type != 'a' || (group != 1 && group != 2)) return fail("element_from_hash is built for G1/G2 of type a");
+  if (hlen < 1) return fail("hlen must be >= 1");
+  if (!n) return 0;
+  void *dd = nullptr, *d_o = nullptr;
+  HIP_TRY(hipSetDevice(P->device));
+  HIP_TRY(hipMalloc(&dd, n * (size_t) hlen));
+  HIP_TRY(hipMalloc(&d_o, n * (size_t) P->len1));
+  HIP_TRY(hipMemcpy(dd, data, n * (size_t) hlen, hipMemcpyHostToDevice));
+  if (upload_constants(P, 0)) return 1;
+  unsigned grid = (unsigned) ((n + kBlock - 1) / kBlock);
+  hipLaunchKernelGGL(a_from_hash_kernel<16>, dim3(grid), dim3(kBlock), 0, 0, (uint8_t *) d_o, (const uint8_t *) dd, hlen, n);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(out, d_o, n * (size_t) P->len1, hipMemcpyDeviceToHost));
+  (void) hipFree(dd); (void) hipFree(d_o);
+  return 0;
 }
 
 // ---- preprocessed pairings ---------------------------------------------------------------

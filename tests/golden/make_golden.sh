@@ -25,3 +25,6 @@ $T gen $F random 16  1 42 $G/f_rand16.vec
 $T gen $F edge   10  1  7 $G/f_edge10.vec
 $T gen $F random 3   4  5 $G/f_prod4x3.vec
 $T gen $F edge   5   3  9 $G/f_prod3x5_edge.vec
+$T hash $A 24 32 3 $G/a_hash32.vec              # element_from_hash(G1) on 32-byte digests
+$T hash $A 8 13 4 $G/a_hash13.vec               # short input: H || 0 || H || 1 ... expansion (field.c:640-668)
+$T hash $A 6 100 5 $G/a_hash100.vec             # long input: truncated to 64 bytes

@@ -67,6 +67,15 @@ class HostSim:
         self.L.hostsim_group(self.h, what, out.ctypes.data, a.ctypes.data, b.ctypes.data, n)
         return out
 
+    def from_hash(self, data, hlen):
+        data = np.ascontiguousarray(data, np.uint8)
+        n = data.size // hlen
+        out = np.empty((n, self.len1), np.uint8)
+        self.L.hostsim_from_hash.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t]
+        if self.L.hostsim_from_hash(self.h, out.ctypes.data, data.ctypes.data, hlen, n):
+            raise RuntimeError("hostsim_from_hash failed")
+        return out
+
     def stage(self, stage, g1=None, g2=None, n=0, out_len=4096):
         out = np.zeros(max(out_len, n * self.lenT), np.uint8)
         self.L.hostsim_stage.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t,

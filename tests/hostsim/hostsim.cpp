@@ -94,6 +94,14 @@ int hostsim_group(void *h, int what, uint8_t *out, const uint8_t *a, const uint8
   }
   return 0;
 }
+// element_from_hash on G1 (Type A): n digests of hlen bytes
+int hostsim_from_hash(void *h, uint8_t *out, const uint8_t *data, int hlen, size_t n) {
+  pbc_hip_pairing_s *P = (pbc_hip_pairing_s *) h;
+  if (P->type != 'a') return 1;
+  activate(P);
+  for (size_t i = 0; i < n; i++) a_from_hash_lane<16>(out + i * P->len1, data + i * hlen, hlen);
+  return 0;
+}
 // diagnostics mirroring pbc_hip_diag_stage
 int hostsim_stage(void *h, int stage, uint8_t *out, size_t out_len, const uint8_t *g1, const uint8_t *g2, size_t n) {
   pbc_hip_pairing_s *P = (pbc_hip_pairing_s *) h;

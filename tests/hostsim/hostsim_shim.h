@@ -15,6 +15,7 @@
 struct hostsim_dim3 { unsigned x, y, z; };
 static hostsim_dim3 threadIdx = {0, 0, 0}, blockIdx = {0, 0, 0};
 struct uint4 { uint32_t x, y, z, w; };
+static inline int __all(int p) { return p; }      // one lane per call: the "wave" agrees with itself
 static inline uint32_t __builtin_amdgcn_alignbit(uint32_t hi, uint32_t lo, uint32_t s) {
   return (uint32_t) (((((uint64_t) hi) << 32) | lo) >> (s & 31));
 }

@@ -372,3 +372,35 @@ def test_bilinearity_entirely_on_gpu(hips, t, name, n):
     lhs = H.element_pairing(aP, v.g2[:n])
     rhs = H.element_pow_zn_GT(v.gt[:n], Z)                 # v.gt = e(P_i, Q_i) from the reference
     assert np.array_equal(lhs, rhs)
+
+
+# ---- element_from_hash and a BLS round trip entirely on the device ---------------------------
+@pytest.mark.parametrize("name", ["a_hash32.vec", "a_hash13.vec", "a_hash100.vec"])
+def test_from_hash_matches_reference(hip_a, name):
+    v = golden(name)
+    assert np.array_equal(hip_a.element_from_hash(1, v.g1.reshape(v.n, v.len1)), v.gt)
+
+
+def test_bls_sign_verify_batch_on_gpu(hip_a, oracle_a):
+    """example/bls.c:41-117 as a batch: h = from_hash(msg), sig = h^sk, pk = g^sk,
+    verify e(sig, g) == e(h, pk).  Every group operation and pairing runs on the GPU; the fixed
+    second... first arguments use preprocessed pairings.  One forged signature must fail."""
+    v = golden("a_chain1024.vec")
+    n = 500
+    rng = np.random.default_rng(31)
+    g = v.g2[0]                                           # system parameter g in G2 (= G1 for type a)
+    sk = int.from_bytes(rng.bytes(20), "big") % R_A
+    SK = np.tile(_be(sk, 20), (n, 1))
+    pk = hip_a.element_mul_zn(2, g[None, :], SK[:1])[0]
+    msgs = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    h = hip_a.element_from_hash(1, msgs)
+    sig = hip_a.element_mul_zn(1, h, SK)
+    sig[7] = hip_a.element_mul_zn(1, h[7:8], np.tile(_be(sk + 1, 20), (1, 1)))[0]    # forgery
+    # e(sig_i, g) and e(h_i, pk): type a is symmetric, so both are pp_apply with a fixed argument
+    lhs = hip_a.pp_init(g).apply(sig)
+    rhs = hip_a.pp_init(pk).apply(h)
+    ok = (lhs == rhs).all(axis=1)
+    assert not ok[7] and ok.sum() == n - 1
+    # spot check against the CPU oracle
+    assert np.array_equal(lhs[:3], oracle_a.pairing_batch(sig[:3], np.tile(g, (3, 1))))
+    assert np.array_equal(h[:2], oracle_a.g_mul(1, h[:2], np.tile(_be(1, 20), (2, 1))))   # valid curve points

@@ -79,3 +79,13 @@ def test_group_ops_on_host(sims, oracles, t, name):
     assert np.array_equal(sims[t].group(0, v.g1[:n], Z), oracles[t].g_mul(1, v.g1[:n], Z))
     assert np.array_equal(sims[t].group(1, v.gt[:n], v.gt[n:2 * n]), oracles[t].gt_mul(v.gt[:n], v.gt[n:2 * n]))
     assert np.array_equal(sims[t].group(2, v.gt[:n], Z), oracles[t].gt_pow(v.gt[:n], Z))
+
+
+@pytest.mark.parametrize("name", ["a_hash32.vec", "a_hash13.vec", "a_hash100.vec"])
+def test_from_hash_on_host(sims, name):
+    """element_from_hash(G1) (ecc/curve.c:455-482): digest expansion, retry loop, square root,
+    sign normalisation and cofactor multiplication vs the reference's outputs."""
+    v = golden(name)
+    n = min(v.n, 6)
+    got = sims["a"].from_hash(v.g1[:n], v.len1)
+    assert np.array_equal(got, v.gt[:n])

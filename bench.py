@@ -29,6 +29,18 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 import pbc_amd  # noqa: E402  (the product; raises if libpbc_hip.so is missing)
 
+
+def ensure_built():
+    """libpbc_hip.so normally travels with the tree; if it does not, local rank 0 compiles it
+    (hipcc, ~25 s) while the other ranks wait for the file."""
+    if int(os.environ.get("LOCAL_RANK", "0")) == 0:
+        pbc_amd.build()
+    else:
+        for _ in range(600):
+            if os.path.exists(pbc_amd.LIB_PATH) and time.time() - os.path.getmtime(pbc_amd.LIB_PATH) > 2:
+                break
+            time.sleep(0.5)
+
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
@@ -131,6 +143,7 @@ def main():
     if args.log2n is None:
         args.log2n = dlog
 
+    ensure_built()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

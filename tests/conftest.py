@@ -19,6 +19,11 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    # the HIP library and the C oracle normally travel with the tree; (re)build them when stale
+    import pbc_amd
+    import oracle
+    pbc_amd.build()
+    oracle.build()
 
 
 @pytest.fixture(scope="session")

@@ -56,7 +56,7 @@ def load_vec(path):
     return g1.copy(), g2.copy(), gt.copy()
 
 
-def cpu_baseline(param_path, k=1):
+def cpu_baseline(param_path, k=1, fixture=None):
     """PBC+GMP (the unmodified reference compiled into oracle/_ref) on the host cores, on a
     bounded sample of the same workload; falls back to the single-core C port."""
     import oracle  # checker/baseline only -- never on the measured GPU path
@@ -89,8 +89,10 @@ def cpu_baseline(param_path, k=1):
         except Exception as e:  # noqa: BLE001
             sys.stderr.write("cpu_baseline: ref_tool failed (%r), using the C port\n" % (e,))
     O = oracle.OraclePairing(open(param_path).read())
-    fx = {"a": "a_chain1024.vec", "d": "d_chain256.vec", "f": "f_chain128.vec"}[os.path.basename(param_path)[0]]
+    fx = fixture or {"a": "a_chain1024.vec", "d": "d_chain256.vec", "f": "f_chain128.vec"}[os.path.basename(param_path)[0]]
     g1, g2, _ = load_vec(os.path.join(ROOT, "tests", "golden", fx))
+    reps = -(-128 // g1.shape[0])
+    g1, g2 = np.tile(g1, (reps, 1)), np.tile(g2, (reps, 1))
     m = 128 // k * k
     t0 = time.time()
     if k == 1:
@@ -121,6 +123,10 @@ WORKLOADS = {
     "a": ("a", "a_chain1024.vec", 1, 20, "Type A (a.param) element_pairing"),
     "d": ("d159", "d_chain256.vec", 1, 18, "Type D (d159.param) element_pairing"),
     "f": ("f", "f_chain128.vec", 1, 18, "Type F (f.param) element_pairing"),
+    "d201": ("d201", "d201_rand12.vec", 1, 18, "Type D (d201.param, 7-word field) element_pairing"),
+    "d224": ("d224", "d224_rand12.vec", 1, 18, "Type D (d224.param, 7-word field) element_pairing"),
+    "d190": ("d278027-190-181", "d278027-190-181_rand12.vec", 1, 18,
+             "Type D (d278027-190-181.param, 6-word field) element_pairing"),
     "a-prod16": ("a", "a_chain1024.vec", 16, 18, "Type A (a.param) element_prod_pairing, 16 terms"),
     "a-pp": ("a", "a_chain1024.vec", 1, 20, "Type A (a.param) pairing_pp_apply, fixed first argument"),
 }
@@ -303,7 +309,7 @@ def main():
             out["host_path"] = {"pairings_per_s": round(n / min(ts), 1), "ms": round(min(ts) * 1e3, 2),
                                 "note": "pinned host buffers -> chunked H2D/kernel/D2H on 3 streams -> host; PCIe-inclusive"}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(param_path, k)
+            out["cpu_baseline"] = cpu_baseline(param_path, k, fixture)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

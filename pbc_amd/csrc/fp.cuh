@@ -32,6 +32,7 @@ struct FpK {            // wave-uniform field constants (field_init_mont_fp, mon
   uint32_t r3[N];       // R^3 mod q (puts an inverse back into Montgomery form, cf. montfp.c:417)
   uint32_t p30[(32 * N + 2 + 29) / 30];   // q in 30-bit limbs (safegcd inversion)
   uint32_t qinv30;      // q^-1 mod 2^30
+  uint32_t fbytes;      // fixed_length_in_bytes = ceil(bits(q)/8) (montfp.c:577); <= 4N
 };
 
 template <int N>
@@ -44,11 +45,15 @@ struct fp {
 // The constants live in __constant__ memory so that every read is a scalar load from a
 // compile-time address (provably wave-uniform -> SGPR operands of the MACs).  One set per
 // limb count; the host uploads them with hipMemcpyToSymbolAsync on the launch stream.
-__constant__ FpK<16> c_fpk16;     // 512-bit moduli (Type A a.param)
-__constant__ FpK<5> c_fpk5;       // 160-bit moduli (Type D d159, Type F)
+// Word counts built into the library: 5/6/7 words = the 159..224-bit MNT and BN fields of the
+// shipped type d / type f parameter files, 16 words = the 512-bit type a field.
+#define PBC_FOR_EACH_N(X) X(5) X(6) X(7) X(16)
 template <int N> PBC_DEV const FpK<N> &fpk();
-template <> PBC_DEV const FpK<16> &fpk<16>() { return c_fpk16; }
-template <> PBC_DEV const FpK<5> &fpk<5>() { return c_fpk5; }
+#define PBC_DECL_FPK(n)              \
+  __constant__ FpK<n> c_fpk##n;      \
+  template <> PBC_DEV const FpK<n> &fpk<n>() { return c_fpk##n; }
+PBC_FOR_EACH_N(PBC_DECL_FPK)
+#undef PBC_DECL_FPK
 
 // acc(96 bit: a0,a1,a2) += x*y.  One quarter-rate 32x32+64 multiply-add whose carry-out
 // feeds the top word: the two-instruction MAC the whole engine is built from.
@@ -711,28 +716,55 @@ PBC_DEV void fp_inv(fp<N> &r, const fp<N> &a) {
 }
 
 // Wire format: fixed-width big-endian canonical residue (fp_from_bytes montfp.c:498-517,
-// fp_to_bytes :487-496 + pbc_mpz_out_raw_n field.c:629-638).  nbytes == 4N for all
-// supported parameter sets (64 for a.param, 20 for d159/f).
+// fp_to_bytes :487-496 + pbc_mpz_out_raw_n field.c:629-638).  The byte length is
+// ceil(bits(q)/8): a whole number of words for a.param (64) and d159/f (20), not for e.g. the
+// 175-, 196- and 201-bit MNT fields (22, 25, 26 bytes).
 template <int N>
 PBC_DEV void fp_load_be(fp<N> &r, const uint8_t *src) {
   const FpK<N> &K = fpk<N>();
   fp<N> t;
-  const uint32_t *w = reinterpret_cast<const uint32_t *>(src);
+  if (K.fbytes == 4 * N) {
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(src);
 #pragma unroll
-  for (int i = 0; i < N; i++) t.v[N - 1 - i] = __builtin_bswap32(w[i]);
+    for (int i = 0; i < N; i++) t.v[N - 1 - i] = __builtin_bswap32(w[i]);
+  } else {                             // byte lengths that are not whole words (e.g. 175-, 201-bit q)
+    const int nb = (int) K.fbytes;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      uint32_t x = 0;
+#pragma unroll
+      for (int b = 0; b < 4; b++) {
+        const int pos = nb - 1 - (4 * i + b);
+        if (pos >= 0) x |= (uint32_t) src[pos] << (8 * b);
+      }
+      t.v[i] = x;
+    }
+  }
   fp<N> r2;
   fp_set<N>(r2, K.r2);
   fp_mul<N>(r, t, r2);            // x -> x R mod q (reduces x >= q as well)
 }
 template <int N>
 PBC_DEV void fp_store_be(uint8_t *dst, const fp<N> &a) {
+  const FpK<N> &K = fpk<N>();
   fp<N> one, t;
 #pragma unroll
   for (int i = 0; i < N; i++) one.v[i] = (i == 0);
   fp_mul<N>(t, a, one);           // a R^-1: canonical residue
-  uint32_t *w = reinterpret_cast<uint32_t *>(dst);
+  if (K.fbytes == 4 * N) {
+    uint32_t *w = reinterpret_cast<uint32_t *>(dst);
 #pragma unroll
-  for (int i = 0; i < N; i++) w[i] = __builtin_bswap32(t.v[N - 1 - i]);
+    for (int i = 0; i < N; i++) w[i] = __builtin_bswap32(t.v[N - 1 - i]);
+  } else {
+    const int nb = (int) K.fbytes;
+#pragma unroll
+    for (int i = 0; i < N; i++)
+#pragma unroll
+      for (int b = 0; b < 4; b++) {
+        const int pos = nb - 1 - (4 * i + b);
+        if (pos >= 0) dst[pos] = (uint8_t) (t.v[i] >> (8 * b));
+      }
+  }
 }
 
 }  // namespace pbc

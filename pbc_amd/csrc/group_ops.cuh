@@ -28,7 +28,7 @@ PBC_DEV uint32_t zr_bit(const uint8_t *z, int zlen, int i) { return (z[zlen - 1 
 // out = [k] P for P = (x, y) bytes; off-curve P is O (curve_from_bytes); O serialises as zeros.
 template <int N>
 PBC_DEV void g_mul_lane(uint8_t *out, const uint8_t *in, const uint8_t *z, int zlen) {
-  constexpr int NB = 4 * N;
+  const int NB = (int) fpk<N>().fbytes;
   fp<N> one, ca, cb, x2, y2;
   fp_set<N>(one, fpk<N>().one);
   fp_set<N>(ca, c_curve.a);
@@ -152,7 +152,7 @@ static __device__ __noinline__ typename vecN<N>::type fp_pow_sqrt_fn(typename ve
 }
 template <int N>
 PBC_DEV void a_from_hash_lane(uint8_t *out, const uint8_t *data, int hlen) {
-  constexpr int NB = 4 * N;
+  const int NB = (int) fpk<N>().fbytes;
   const FpK<N> &K = fpk<N>();
   fp<N> one, ca, cb, x, fx, fy;
   fp_set<N>(one, K.one);
@@ -315,32 +315,42 @@ PBC_DEV void a_gt_pow_lane(uint8_t *out, const uint8_t *a, const uint8_t *z, int
   a_gt_store<N>(out, acc);
 }
 // Type D: F_q^6
-PBC_DEV void d_gt_load(f6 &r, const uint8_t *s) { f3_load_be(r.x, s); f3_load_be(r.y, s + 12 * ND); }
-PBC_DEV void d_gt_store(uint8_t *d, const f6 &a) { f3_store_be(d, a.x); f3_store_be(d + 12 * ND, a.y); }
-PBC_DEV void d_gt_mul_lane(uint8_t *out, const uint8_t *a, const uint8_t *b) {
-  f6 x, y;
-  d_gt_load(x, a);
-  d_gt_load(y, b);
-  f6_mul(x, x, y);
-  d_gt_store(out, x);
+template <int N>
+PBC_DEV void d_gt_load(typename TypeD<N>::f6 &r, const uint8_t *s) {
+  TypeD<N>::f3_load_be(r.x, s);
+  TypeD<N>::f3_load_be(r.y, s + 3 * fpk<N>().fbytes);
 }
+template <int N>
+PBC_DEV void d_gt_store(uint8_t *d, const typename TypeD<N>::f6 &a) {
+  TypeD<N>::f3_store_be(d, a.x);
+  TypeD<N>::f3_store_be(d + 3 * fpk<N>().fbytes, a.y);
+}
+template <int N>
+PBC_DEV void d_gt_mul_lane(uint8_t *out, const uint8_t *a, const uint8_t *b) {
+  typename TypeD<N>::f6 x, y;
+  d_gt_load<N>(x, a);
+  d_gt_load<N>(y, b);
+  TypeD<N>::f6_mul(x, x, y);
+  d_gt_store<N>(out, x);
+}
+template <int N>
 PBC_DEV void d_gt_pow_lane(uint8_t *out, const uint8_t *a, const uint8_t *z, int zlen) {
-  f6 x, acc, t;
-  d_gt_load(x, a);
-  fq one;
-  fp_set<ND>(one, fpk<ND>().one);
+  typename TypeD<N>::f6 x, acc, t;
+  d_gt_load<N>(x, a);
+  fp<N> one;
+  fp_set<N>(one, fpk<N>().one);
 #pragma unroll
   for (int i = 0; i < 3; i++)
 #pragma unroll
-    for (int k = 0; k < ND; k++) { acc.x.c[i].v[k] = (i == 0) ? one.v[k] : 0; acc.y.c[i].v[k] = 0; }
+    for (int k = 0; k < N; k++) { acc.x.c[i].v[k] = (i == 0) ? one.v[k] : 0; acc.y.c[i].v[k] = 0; }
   for (int i = 8 * zlen - 1; i >= 0; i--) {
-    f6_sqr(acc, acc);
-    f6_mul(t, acc, x);
+    TypeD<N>::f6_sqr(acc, acc);
+    TypeD<N>::f6_mul(t, acc, x);
     bool bit = zr_bit(z, zlen, i) != 0;
 #pragma unroll
-    for (int c = 0; c < 3; c++) { fp_cmov<ND>(acc.x.c[c], t.x.c[c], bit); fp_cmov<ND>(acc.y.c[c], t.y.c[c], bit); }
+    for (int c = 0; c < 3; c++) { fp_cmov<N>(acc.x.c[c], t.x.c[c], bit); fp_cmov<N>(acc.y.c[c], t.y.c[c], bit); }
   }
-  d_gt_store(out, acc);
+  d_gt_store<N>(out, acc);
 }
 // Type F: F_q^12 (private-memory objects)
 __device__ void f_gt_load(f12 *r, const uint8_t *s) {

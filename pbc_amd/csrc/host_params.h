@@ -36,8 +36,9 @@ struct pbc_hip_pairing_s {
   int device;
   int nlimb;                 // 32-bit limbs of F_q
   int len_fq, len1, len2, lenT;
-  FpK<16> k16;
-  FpK<5> k5;
+#define PBC_HOST_FPK(n) FpK<n> k##n;
+  PBC_FOR_EACH_N(PBC_HOST_FPK)  // k5, k6, k7, k16: the one matching nlimb is filled
+#undef PBC_HOST_FPK
   AConst a;
   DRaw draw;                 // type D: canonical parameter words for the device-side derivation
   DConst dconst;             // type D: derived tower constants (filled on first use)
@@ -80,6 +81,7 @@ static int fill_fpk(FpK<N> &K, const pbc_host::Big &q) {
   pm2.to_words(K.pm2, N);
   K.ninv = pbc_host::neg_inv32(K.p[0]);
   K.pbits = (uint32_t) q.bits();
+  K.fbytes = (uint32_t) ((q.bits() + 7) / 8);
   return 0;
 }
 
@@ -92,7 +94,8 @@ static int init_type_a(pbc_hip_pairing_s *P, const char *txt, size_t len) {
       !param_int(txt, len, "exp2", exp2) || !param_int(txt, len, "exp1", exp1) ||
       !param_int(txt, len, "sign1", sign1) || !param_int(txt, len, "sign0", sign0))
     return fail("type a: missing q/r/h/exp2/exp1/sign1/sign0");
-  if (fill_fpk<16>(P->k16, q)) return fail("type a: only 481..512-bit q is supported by this build (got %d bits)", q.bits());
+  if (fill_fpk<16>(P->k16, q) || q.bits() <= 504)
+    return fail("type a: only 505..512-bit q (64-byte coordinates) is supported by this build (got %d bits)", q.bits());
   if (h.bits() > 512 || h.is_zero()) return fail("type a: bad cofactor");
   if ((q.w[0] & 3) != 3) return fail("type a: q must be 3 mod 4");
   if (exp1 <= 0 || exp2 <= exp1) return fail("type a: bad exp1/exp2");
@@ -135,7 +138,11 @@ static int init_type_d(pbc_hip_pairing_s *P, const char *txt, size_t len) {
       !param_big(txt, len, "coeff2", co[2]))
     return fail("type d: missing q/r/a/b/k/coeff0..2/nqr");
   if (k != 6) return fail("type d: only embedding degree 6 is supported (got %d)", k);
-  if (fill_fpk<5>(P->k5, q)) return fail("type d: only 129..160-bit q is supported by this build (got %d bits)", q.bits());
+  // field width: 5 words for d159, 6 for d277699-175-167 / d278027-190-181, 7 for d105171-196-185 /
+  // d201 / d224 (all the type d files under param/)
+  const int ND = (q.bits() + 31) / 32;
+  if (ND < 5 || ND > ND_MAX || (ND == 5 ? fill_fpk<5>(P->k5, q) : ND == 6 ? fill_fpk<6>(P->k6, q) : fill_fpk<7>(P->k7, q)))
+    return fail("type d: only odd 129..224-bit q is supported by this build (got %d bits)", q.bits());
   if (Big::cmp(a, q) >= 0 || Big::cmp(b, q) >= 0 || Big::cmp(nqr, q) >= 0) return fail("type d: coefficient >= q");
   memset(&P->draw, 0, sizeof P->draw);
   memset(&P->dconst, 0, sizeof P->dconst);
@@ -160,15 +167,18 @@ static int init_type_d(pbc_hip_pairing_s *P, const char *txt, size_t len) {
   if (!rem.is_zero() || phik.bits() > 256) return fail("type d: r does not divide q^2 - q + 1");
   phik.to_words(P->dconst.phik, 8);
   P->dconst.phikbits = phik.bits();
-  P->nlimb = 5;
+  P->nlimb = ND;
   P->len_fq = (q.bits() + 7) / 8;
-  if (P->len_fq != 20) return fail("type d: q must serialise to 20 bytes");
   P->len1 = 2 * P->len_fq;
   P->len2 = P->lenT = 6 * P->len_fq;
   P->len_zr = (r.bits() + 7) / 8;
-  P->fq_muls_single = 26451.0;           // SURVEY.md 8d (instrumented reference, d159.param)
-  P->fq_muls_prod_a = 26451.0 - 4197.0;  // per-term Miller work + one cc_tatepower (4197)
-  P->fq_muls_prod_b = 4197.0;
+  // work model: SURVEY.md 8d instrumented the reference on d159.param (158-bit r, 161-bit
+  // (q^2-q+1)/r): 22254 F_q products in the Miller loop + 4197 in cc_tatepower.  Both loops are
+  // one iteration per exponent bit, so other parameter files scale by their bit lengths.
+  const double miller = 22254.0 * r.bits() / 158.0, tate = 4197.0 * phik.bits() / 161.0;
+  P->fq_muls_single = miller + tate;
+  P->fq_muls_prod_a = miller;            // per-term Miller work + one cc_tatepower
+  P->fq_muls_prod_b = tate;
   return 0;
 }
 

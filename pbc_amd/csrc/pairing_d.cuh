@@ -21,41 +21,50 @@
 
 namespace pbc {
 
-constexpr int ND = 5;                  // 160-bit q: 5 x 32-bit words, 6 x 29-bit limbs
-typedef fp<ND> fq;
-
-struct f3 { fq c[3]; };                // c0 + c1 x + c2 x^2
-struct f6 { f3 x, y; };                // x + y sqrt(v)
-
+constexpr int ND_MAX = 7;              // widest MNT field built in: 224-bit q (d224.param)
 struct DConst {                        // pptr (ecc/d_param.c:40-51) + curve/field constants
-  uint32_t A[ND], B[ND];               // curve coefficients (Montgomery form)
-  uint32_t xpwr[2][3][ND];             // x^3, x^4 mod f      (poly.c compute_x_powers)
-  uint32_t nqr[ND], nqrinv[ND], nqrinv2[ND];   // v, v^-1, v^-2 (d_param.c:1028-1032, :1072-1075)
-  uint32_t xpowq[3][ND], xpowq2[3][ND];        // x^q, x^2q     (d_param.c:1044-1050)
-  uint32_t ta[ND], tb[ND];             // twist: y^2 = x^3 + a v^2 x + b v^3 (curve.c:885-901)
+  uint32_t A[ND_MAX], B[ND_MAX];       // curve coefficients (Montgomery form)
+  uint32_t xpwr[2][3][ND_MAX];         // x^3, x^4 mod f      (poly.c compute_x_powers)
+  uint32_t nqr[ND_MAX], nqrinv[ND_MAX], nqrinv2[ND_MAX];   // v, v^-1, v^-2 (d_param.c:1028-1032, :1072-1075)
+  uint32_t xpowq[3][ND_MAX], xpowq2[3][ND_MAX];            // x^q, x^2q     (d_param.c:1044-1050)
+  uint32_t ta[ND_MAX], tb[ND_MAX];     // twist: y^2 = x^3 + a v^2 x + b v^3 (curve.c:885-901)
   uint32_t r[8];                       // group order (Miller loop bits)
   uint32_t phik[8];                    // (q^2 - q + 1)/r (d_param.c:1036-1042)
   int rbits, phikbits;
 };
 __constant__ DConst c_d;
+struct DRaw { uint32_t a[ND_MAX], b[ND_MAX], coeff[3][ND_MAX], nqr[ND_MAX], q[ND_MAX + 1]; int qbits; };
 
-PBC_DEV fq dk(const uint32_t *w) { fq r; fp_set<ND>(r, w); return r; }
+constexpr int D_LANES = 128;
+typedef uint32_t v32 __attribute__((ext_vector_type(32)));
+// Per-lane Miller state in LDS, word-major ([word][lane]: conflict-free); one array per field width.
+template <int ND> __shared__ uint32_t g_lds_d[11 * ND * D_LANES];
+
+// Everything below is per field width: ND 32-bit words per F_q element (5 for the 159-bit d159
+// field, 6 / 7 for the 175..224-bit fields of the other shipped type d parameter files).
+template <int ND>
+struct TypeD {
+typedef fp<ND> fq;
+struct f3 { fq c[3]; };                // c0 + c1 x + c2 x^2
+struct f6 { f3 x, y; };                // x + y sqrt(v)
+
+static PBC_DEV fq dk(const uint32_t *w) { fq r; fp_set<ND>(r, w); return r; }
 
 // ---- F_q^3 ------------------------------------------------------------------------------
-PBC_DEV void f3_add(f3 &r, const f3 &a, const f3 &b) { for (int i = 0; i < 3; i++) fp_add<ND>(r.c[i], a.c[i], b.c[i]); }
-PBC_DEV void f3_sub(f3 &r, const f3 &a, const f3 &b) { for (int i = 0; i < 3; i++) fp_sub<ND>(r.c[i], a.c[i], b.c[i]); }
-PBC_DEV void f3_dbl(f3 &r, const f3 &a) { for (int i = 0; i < 3; i++) fp_dbl<ND>(r.c[i], a.c[i]); }
-PBC_DEV void f3_neg(f3 &r, const f3 &a) { for (int i = 0; i < 3; i++) fp_neg<ND>(r.c[i], a.c[i]); }
-PBC_DEV void f3_halve(f3 &r, const f3 &a) { for (int i = 0; i < 3; i++) fp_halve<ND>(r.c[i], a.c[i]); }
+static PBC_DEV void f3_add(f3 &r, const f3 &a, const f3 &b) { for (int i = 0; i < 3; i++) fp_add<ND>(r.c[i], a.c[i], b.c[i]); }
+static PBC_DEV void f3_sub(f3 &r, const f3 &a, const f3 &b) { for (int i = 0; i < 3; i++) fp_sub<ND>(r.c[i], a.c[i], b.c[i]); }
+static PBC_DEV void f3_dbl(f3 &r, const f3 &a) { for (int i = 0; i < 3; i++) fp_dbl<ND>(r.c[i], a.c[i]); }
+static PBC_DEV void f3_neg(f3 &r, const f3 &a) { for (int i = 0; i < 3; i++) fp_neg<ND>(r.c[i], a.c[i]); }
+static PBC_DEV void f3_halve(f3 &r, const f3 &a) { for (int i = 0; i < 3; i++) fp_halve<ND>(r.c[i], a.c[i]); }
 // polymod_const_mul (poly.c:1550-1558)
-PBC_DEV void f3_mul_fq(f3 &r, const f3 &a, const fq &s) { for (int i = 0; i < 3; i++) fp_mul<ND>(r.c[i], a.c[i], s); }
-PBC_DEV bool f3_eq(const f3 &a, const f3 &b) { return fp_eq<ND>(a.c[0], b.c[0]) & fp_eq<ND>(a.c[1], b.c[1]) & fp_eq<ND>(a.c[2], b.c[2]); }
+static PBC_DEV void f3_mul_fq(f3 &r, const f3 &a, const fq &s) { for (int i = 0; i < 3; i++) fp_mul<ND>(r.c[i], a.c[i], s); }
+static PBC_DEV bool f3_eq(const f3 &a, const f3 &b) { return (int) fp_eq<ND>(a.c[0], b.c[0]) & (int) fp_eq<ND>(a.c[1], b.c[1]) & (int) fp_eq<ND>(a.c[2], b.c[2]); }
 
 // F_q^3 product with lazy reduction (polymod_mul_degree3, poly.c:910-930: same ring element):
 //   d3 = a1 b2 + a2 b1,  d4 = a2 b2                       (x^3, x^4 coefficients, reduced once each)
 //   c_k = sum_{i+j=k} a_i b_j + d3 X3_k + d4 X4_k         (one reduction per output coefficient)
 // 15 limb products + 5 Montgomery reductions instead of 12 full products (6 Karatsuba + 6 table).
-PBC_DEV void f3_mul_inl(f3 &r, const f3 &a, const f3 &b) {
+static PBC_DEV void f3_mul_inl(f3 &r, const f3 &a, const f3 &b) {
   fl<ND> A[3], B[3], X3[3], X4[3], d3, d4, c;
 #pragma unroll
   for (int i = 0; i < 3; i++) {
@@ -72,7 +81,7 @@ PBC_DEV void f3_mul_inl(f3 &r, const f3 &a, const f3 &b) {
 }
 // polymod_square_degree3 (poly.c:1049-1089): d3 = 2 a1 a2, d4 = a2^2,
 //   c0 = a0^2 + ..., c1 = 2 a0 a1 + ..., c2 = 2 a0 a2 + a1^2 + ...
-PBC_DEV void f3_sqr_inl(f3 &r, const f3 &a) {
+static PBC_DEV void f3_sqr_inl(f3 &r, const f3 &a) {
   fl<ND> A[3], A2[2], X3[3], X4[3], d3, d4, c;
 #pragma unroll
   for (int i = 0; i < 3; i++) {
@@ -90,34 +99,48 @@ PBC_DEV void f3_sqr_inl(f3 &r, const f3 &a) {
 }
 // Out-of-line F_q^3 product / square (30 / 15 VGPR arguments): one body each keeps the
 // Miller and Lucas loops inside the instruction cache.
-typedef vecN<ND>::type v5;
-PBC_DEV void f3_unpack(f3 &r, v5 c0, v5 c1, v5 c2) { from_vec<ND>(r.c[0], c0); from_vec<ND>(r.c[1], c1); from_vec<ND>(r.c[2], c2); }
-struct f3ret { v5 c0, c1, c2; };
+typedef typename vecN<ND>::type v5;
+static PBC_DEV void f3_unpack(f3 &r, v5 c0, v5 c1, v5 c2) { from_vec<ND>(r.c[0], c0); from_vec<ND>(r.c[1], c1); from_vec<ND>(r.c[2], c2); }
+typedef uint32_t f3ret __attribute__((ext_vector_type(3 * ND)));   // one vector: stays in VGPRs for any ND
+static PBC_DEV f3ret f3_pack(const f3 &a) {
+  f3ret r;
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int k = 0; k < ND; k++) r[ND * i + k] = a.c[i].v[k];
+  return r;
+}
+static PBC_DEV void f3_unpack(f3 &a, f3ret r) {
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int k = 0; k < ND; k++) a.c[i].v[k] = r[ND * i + k];
+}
 static __device__ __noinline__ f3ret f3_mul_call(v5 a0, v5 a1, v5 a2, v5 b0, v5 b1, v5 b2) {
   f3 a, b, r;
   f3_unpack(a, a0, a1, a2);
   f3_unpack(b, b0, b1, b2);
   f3_mul_inl(r, a, b);
-  return f3ret{to_vec<ND>(r.c[0]), to_vec<ND>(r.c[1]), to_vec<ND>(r.c[2])};
+  return f3_pack(r);
 }
 static __device__ __noinline__ f3ret f3_sqr_call(v5 a0, v5 a1, v5 a2) {
   f3 a, r;
   f3_unpack(a, a0, a1, a2);
   f3_sqr_inl(r, a);
-  return f3ret{to_vec<ND>(r.c[0]), to_vec<ND>(r.c[1]), to_vec<ND>(r.c[2])};
+  return f3_pack(r);
 }
-PBC_DEV void f3_mul(f3 &r, const f3 &a, const f3 &b) {
+static PBC_DEV void f3_mul(f3 &r, const f3 &a, const f3 &b) {
   f3ret t = f3_mul_call(to_vec<ND>(a.c[0]), to_vec<ND>(a.c[1]), to_vec<ND>(a.c[2]), to_vec<ND>(b.c[0]),
                         to_vec<ND>(b.c[1]), to_vec<ND>(b.c[2]));
-  f3_unpack(r, t.c0, t.c1, t.c2);
+  f3_unpack(r, t);
 }
-PBC_DEV void f3_sqr(f3 &r, const f3 &a) {
+static PBC_DEV void f3_sqr(f3 &r, const f3 &a) {
   f3ret t = f3_sqr_call(to_vec<ND>(a.c[0]), to_vec<ND>(a.c[1]), to_vec<ND>(a.c[2]));
-  f3_unpack(r, t.c0, t.c1, t.c2);
+  f3_unpack(r, t);
 }
 
 // a^q on F_q^3 (the qpower macro of cc_tatepower, d_param.c:507-527)
-PBC_DEV void f3_frob(f3 &r, const f3 &a) {
+static PBC_DEV void f3_frob(f3 &r, const f3 &a) {
   f3 res;
   fq t;
 #pragma unroll
@@ -131,7 +154,7 @@ PBC_DEV void f3_frob(f3 &r, const f3 &a) {
 }
 // a^-1 = a^q a^(q^2) / N(a), N(a) = a a^q a^(q^2) in F_q  (polymod_invert poly.c:521-536 is a
 // polynomial extended Euclid; the inverse is unique)
-PBC_DEV void f3_inv(f3 &r, const f3 &a) {
+static PBC_DEV void f3_inv(f3 &r, const f3 &a) {
   f3 t, u, w;
   f3_frob(t, a);
   f3_frob(u, t);
@@ -149,7 +172,7 @@ PBC_DEV void f3_inv(f3 &r, const f3 &a) {
 
 // ---- F_q^6 = F_q^3[sqrt(v)] -------------------------------------------------------------
 // fq_mul (fieldquadratic.c:197-233): Karatsuba
-PBC_DEV void f6_mul(f6 &r, const f6 &a, const f6 &b) {
+static PBC_DEV void f6_mul(f6 &r, const f6 &a, const f6 &b) {
   f3 e0, e1, e2, t;
   f3_add(e0, a.x, a.y);
   f3_add(e1, b.x, b.y);
@@ -162,7 +185,7 @@ PBC_DEV void f6_mul(f6 &r, const f6 &a, const f6 &b) {
   f3_sub(r.y, e2, e1);
 }
 // fq_square (fieldquadratic.c:249-269); here x^2 + v y^2 = (x + y)(x + v y) - (1 + v) xy
-PBC_DEV void f6_sqr(f6 &r, const f6 &a) {
+static PBC_DEV void f6_sqr(f6 &r, const f6 &a) {
   f3 t, s, vy, u;
   f3_mul(t, a.x, a.y);
   f3_mul_fq(vy, a.y, dk(c_d.nqr));
@@ -183,42 +206,82 @@ struct djac { fq X, Y, Z, ZZ; };
 // arguments: a 160-bit F_q product is only ~80 multiply-adds, so calling it out of line costs
 // more than it computes; instead each Miller step is ONE out-of-line body with its ~20 products
 // inlined, fed from / writing back to LDS, returning just the line value (30 words).
-constexpr int D_LANES = 128;
-enum { DL_QX = 0, DL_QY = 15, DL_X = 30, DL_Y = 35, DL_Z = 40, DL_PX = 45, DL_PY = 50, DL_WORDS = 55 };
-__shared__ uint32_t g_lds_d[DL_WORDS * D_LANES];
-PBC_DEV fq dl_get(int w) {
+enum { DL_QX = 0, DL_QY = 3 * ND, DL_X = 6 * ND, DL_Y = 7 * ND, DL_Z = 8 * ND, DL_PX = 9 * ND, DL_PY = 10 * ND };
+static PBC_DEV fq dl_get(int w) {
   fq r;
 #pragma unroll
-  for (int k = 0; k < ND; k++) r.v[k] = g_lds_d[(w + k) * D_LANES + threadIdx.x];
+  for (int k = 0; k < ND; k++) r.v[k] = g_lds_d<ND>[(w + k) * D_LANES + threadIdx.x];
   return r;
 }
-PBC_DEV void dl_put(int w, const fq &a) {
+static PBC_DEV void dl_put(int w, const fq &a) {
 #pragma unroll
-  for (int k = 0; k < ND; k++) g_lds_d[(w + k) * D_LANES + threadIdx.x] = a.v[k];
+  for (int k = 0; k < ND; k++) g_lds_d<ND>[(w + k) * D_LANES + threadIdx.x] = a.v[k];
 }
-typedef uint32_t v32 __attribute__((ext_vector_type(32)));
 
 // l(Q) = (a Qx + c) + (b Qy) sqrt(v) with a, b, c in F_q (d_miller_evalfn, d_param.c:99-111);
-// Q is read from LDS, the result is packed for the return registers
-PBC_DEV v32 d_evalfn_pack(const fq &a, const fq &b, const fq &c) {
+// Q is read from LDS, the result is packed for the return registers.  The 6 ND words of a line
+// value fit the 32 return VGPRs only for ND = 5; wider fields return the sqrt(v)-free half plus
+// b (4 ND words) and fetch the other half with a second, small out-of-line call.
+static constexpr bool kLineOneCall = 6 * ND <= 32;
+static PBC_DEV v32 d_evalfn_pack(const fq &a, const fq &b, const fq &c) {
   v32 r;
 #pragma unroll
-  for (int i = 0; i < 3; i++) {
-    fq t, u;
-    fp_mul_inl<ND>(t, dl_get(DL_QX + 5 * i), a);
-    if (i == 0) fp_add<ND>(t, t, c);
-    fp_mul_inl<ND>(u, dl_get(DL_QY + 5 * i), b);
+  for (int k = 0; k < 32; k++) r[k] = 0;
 #pragma unroll
-    for (int k = 0; k < ND; k++) { r[5 * i + k] = t.v[k]; r[15 + 5 * i + k] = u.v[k]; }
+  for (int i = 0; i < 3; i++) {
+    fq t;
+    fp_mul_inl<ND>(t, dl_get(DL_QX + ND * i), a);
+    if (i == 0) fp_add<ND>(t, t, c);
+#pragma unroll
+    for (int k = 0; k < ND; k++) r[ND * i + k] = t.v[k];
+    if constexpr (kLineOneCall) {
+      fq u;
+      fp_mul_inl<ND>(u, dl_get(DL_QY + ND * i), b);
+#pragma unroll
+      for (int k = 0; k < ND; k++) r[3 * ND + ND * i + k] = u.v[k];
+    }
   }
-  r[30] = 0; r[31] = 0;
+  if constexpr (!kLineOneCall) {
+#pragma unroll
+    for (int k = 0; k < ND; k++) r[3 * ND + k] = b.v[k];
+  }
   return r;
 }
-PBC_DEV void d_unpack(f6 &e0, v32 r) {
+static __device__ __noinline__ v32 d_line_y_fn(v5 vb) {
+  fq b;
+  from_vec<ND>(b, vb);
+  v32 r;
+#pragma unroll
+  for (int k = 0; k < 32; k++) r[k] = 0;
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    fq u;
+    fp_mul_inl<ND>(u, dl_get(DL_QY + ND * i), b);
+#pragma unroll
+    for (int k = 0; k < ND; k++) r[ND * i + k] = u.v[k];
+  }
+  return r;
+}
+static PBC_DEV void d_unpack(f6 &e0, v32 r) {
 #pragma unroll
   for (int i = 0; i < 3; i++)
 #pragma unroll
-    for (int k = 0; k < ND; k++) { e0.x.c[i].v[k] = r[5 * i + k]; e0.y.c[i].v[k] = r[15 + 5 * i + k]; }
+    for (int k = 0; k < ND; k++) e0.x.c[i].v[k] = r[ND * i + k];
+  if constexpr (kLineOneCall) {
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+      for (int k = 0; k < ND; k++) e0.y.c[i].v[k] = r[3 * ND + ND * i + k];
+  } else {
+    fq b;
+#pragma unroll
+    for (int k = 0; k < ND; k++) b.v[k] = r[3 * ND + k];
+    v32 y = d_line_y_fn(to_vec<ND>(b));
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+      for (int k = 0; k < ND; k++) e0.y.c[i].v[k] = y[ND * i + k];
+  }
 }
 // tangent at V (do_tangent d_param.c:344-362, scaled by Z^6 in F_q^*) and V <- 2V:
 //   M = 3X^2 + a Z^4,  a' = -M Z^2,  b' = (2YZ) Z^2,  c' = M X - 2Y^2
@@ -292,13 +355,13 @@ static __device__ __noinline__ v32 d_add_line_fn() {
   return d_evalfn_pack(la, Z3, lc);
 }
 
-PBC_DEV void f3_load_be(f3 &r, const uint8_t *src) { for (int i = 0; i < 3; i++) fp_load_be<ND>(r.c[i], src + 4 * ND * i); }
-PBC_DEV void f3_store_be(uint8_t *dst, const f3 &a) { for (int i = 0; i < 3; i++) fp_store_be<ND>(dst + 4 * ND * i, a.c[i]); }
+static PBC_DEV void f3_load_be(f3 &r, const uint8_t *src) { for (int i = 0; i < 3; i++) fp_load_be<ND>(r.c[i], src + fpk<ND>().fbytes * i); }
+static PBC_DEV void f3_store_be(uint8_t *dst, const f3 &a) { for (int i = 0; i < 3; i++) fp_store_be<ND>(dst + fpk<ND>().fbytes * i, a.c[i]); }
 
-// Miller function f_{r,P}(psi(Q)): G1 bytes x||y (2 x 20), G2 bytes x||y over F_q^3 (2 x 60).
+// Miller function f_{r,P}(psi(Q)): G1 bytes x||y (2 x fbytes), G2 bytes x||y over F_q^3 (2 x 3 fbytes).
 // Returns false when an input deserialises to O (curve_from_bytes, ecc/curve.c:609-623).
-PBC_DEV bool d_miller_lane(f6 &v, const uint8_t *g1, const uint8_t *g2) {
-  constexpr int NB = 4 * ND;
+static PBC_DEV bool d_miller_lane(f6 &v, const uint8_t *g1, const uint8_t *g2) {
+  const int NB = (int) fpk<ND>().fbytes;
   fq Px, Py, one;
   f3 Qx, Qy;
   fp_set<ND>(one, fpk<ND>().one);
@@ -328,7 +391,7 @@ PBC_DEV bool d_miller_lane(f6 &v, const uint8_t *g1, const uint8_t *g2) {
   f3_mul_fq(Qx, Qx, dk(c_d.nqrinv));
   f3_mul_fq(Qy, Qy, dk(c_d.nqrinv2));
 #pragma unroll
-  for (int i = 0; i < 3; i++) { dl_put(DL_QX + 5 * i, Qx.c[i]); dl_put(DL_QY + 5 * i, Qy.c[i]); }
+  for (int i = 0; i < 3; i++) { dl_put(DL_QX + ND * i, Qx.c[i]); dl_put(DL_QY + ND * i, Qy.c[i]); }
   dl_put(DL_X, Px); dl_put(DL_Y, Py); dl_put(DL_Z, one);
   dl_put(DL_PX, Px); dl_put(DL_PY, Py);
 #pragma unroll
@@ -351,7 +414,7 @@ PBC_DEV bool d_miller_lane(f6 &v, const uint8_t *g1, const uint8_t *g2) {
 }
 
 // cc_tatepower (d_param.c:505-564) with one inversion; see the header of this file.
-PBC_DEV void d_final_exp(f6 &out, const f6 &m) {
+static PBC_DEV void d_final_exp(f6 &out, const f6 &m) {
   const fq v = dk(c_d.nqr);
   // u = conj(m)^2 = (a^2 + v b^2) - 2ab sqrt(v),  N = a^2 - v b^2
   f3 aa, bb, ab, N;
@@ -408,7 +471,7 @@ PBC_DEV void d_final_exp(f6 &out, const f6 &m) {
   f3_halve(out.x, v1);
 }
 
-PBC_DEV void d_store_gt(uint8_t *gt, f6 &out, bool valid) {
+static PBC_DEV void d_store_gt(uint8_t *gt, f6 &out, bool valid) {
   if (!valid) {                        // GT identity
     fq one; fp_set<ND>(one, fpk<ND>().one);
 #pragma unroll
@@ -417,17 +480,17 @@ PBC_DEV void d_store_gt(uint8_t *gt, f6 &out, bool valid) {
       for (int k = 0; k < ND; k++) { out.x.c[i].v[k] = (i == 0) ? one.v[k] : 0; out.y.c[i].v[k] = 0; }
   }
   f3_store_be(gt, out.x);
-  f3_store_be(gt + 12 * ND, out.y);
+  f3_store_be(gt + 3 * fpk<ND>().fbytes, out.y);
 }
 
 // element_pairing (cc_pairing) / element_prod_pairing (cc_pairings_affine, d_param.c:710-736:
 // product of the Miller functions, ONE cc_tatepower) for one lane
-PBC_DEV void d_prod_pairing_lane(uint8_t *gt, const uint8_t *g1, const uint8_t *g2, int k) {
+static PBC_DEV void d_prod_pairing_lane(uint8_t *gt, const uint8_t *g1, const uint8_t *g2, int k) {
   f6 F, out;
   bool valid = d_miller_lane(F, g1, g2);
   for (int j = 1; j < k; j++) {
     f6 f;
-    valid &= d_miller_lane(f, g1 + (size_t) j * 8 * ND, g2 + (size_t) j * 24 * ND);
+    valid &= d_miller_lane(f, g1 + (size_t) j * 2 * fpk<ND>().fbytes, g2 + (size_t) j * 6 * fpk<ND>().fbytes);
     f6_mul(F, F, f);
   }
   d_final_exp(out, F);
@@ -435,11 +498,8 @@ PBC_DEV void d_prod_pairing_lane(uint8_t *gt, const uint8_t *g1, const uint8_t *
 }
 
 // ---- device-side derivation of the tower constants (host supplies canonical words) -------
-struct DRaw { uint32_t a[ND], b[ND], coeff[3][ND], nqr[ND], q[ND + 1]; int qbits; };
-
 // stage 1: everything that needs only F_q arithmetic
-__global__ void d_init_stage1(DConst *out, DRaw raw, DConst base) {
-  if (threadIdx.x || blockIdx.x) return;
+static PBC_DEV void init_stage1(DConst *out, const DRaw &raw, const DConst &base) {
   DConst C = base;
   fq r2, t, a, b, v, cf[3];
   fp_set<ND>(r2, fpk<ND>().r2);
@@ -468,8 +528,7 @@ __global__ void d_init_stage1(DConst *out, DRaw raw, DConst base) {
   *out = C;
 }
 // stage 2 (c_d now holds stage 1): x^q by square-and-multiply in F_q^3, then its square
-__global__ void d_init_stage2(DConst *out, DRaw raw) {
-  if (threadIdx.x || blockIdx.x) return;
+static PBC_DEV void init_stage2(DConst *out, const DRaw &raw) {
   DConst C = c_d;
   f3 acc, x;
   fq one, zero;
@@ -486,6 +545,17 @@ __global__ void d_init_stage2(DConst *out, DRaw raw) {
   for (int i = 0; i < 3; i++)
     for (int k = 0; k < ND; k++) { C.xpowq[i][k] = acc.c[i].v[k]; C.xpowq2[i][k] = sq.c[i].v[k]; }
   *out = C;
+}
+
+};  // struct TypeD
+
+template <int ND> __global__ void d_init_stage1(DConst *out, DRaw raw, DConst base) {
+  if (threadIdx.x || blockIdx.x) return;
+  TypeD<ND>::init_stage1(out, raw, base);
+}
+template <int ND> __global__ void d_init_stage2(DConst *out, DRaw raw) {
+  if (threadIdx.x || blockIdx.x) return;
+  TypeD<ND>::init_stage2(out, raw);
 }
 
 }  // namespace pbc

@@ -21,9 +21,14 @@
 //   * the hard part of the final exponentiation uses a fixed 4-bit window.
 #pragma once
 #include "fp.cuh"
-#include "pairing_d.cuh"   // ND, fq, dk(), djac
 
 namespace pbc {
+
+constexpr int ND = 5;                  // 158-bit BN field of f.param: 5 x 32-bit words, 6 x 29-bit limbs
+typedef fp<ND> fq;
+typedef vecN<ND>::type v5;
+PBC_DEV fq dk(const uint32_t *w) { fq r; fp_set<ND>(r, w); return r; }
+struct djac { fq X, Y, Z, ZZ; };
 
 struct g2 { fq x, y; };                // x + y sqrt(beta)
 struct f12 { g2 c[6]; };               // sum c_i X^i, X^6 = negalpha

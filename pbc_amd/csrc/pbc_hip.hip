@@ -101,20 +101,24 @@ __global__ void __launch_bounds__(kBlock, PBC_A_WAVES) a_pp_apply_kernel(uint8_t
   }
 }
 
-// Type D: one k-term product (k = 1: a single pairing) per lane.  G1 records are 40 B, G2
-// 120 B, GT 120 B for d159.param.
+// Type D: one k-term product (k = 1: a single pairing) per lane.  With fb = fixed byte length of
+// F_q, G1 records are 2 fb, G2 and GT 6 fb bytes (40 / 120 / 120 B for d159.param).
+template <int N>
 __global__ void __launch_bounds__(kBlock, PBC_DF_WAVES) d_prod_pairing_kernel(uint8_t *gt, const uint8_t *g1,
                                                                  const uint8_t *g2, size_t n, int k) {
   size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
   size_t ld = idx < n ? idx : n - 1;
-  constexpr int L1 = 8 * ND, L2 = 24 * ND, LT = 24 * ND;
-  __attribute__((aligned(4))) uint8_t out[LT];
-  d_prod_pairing_lane(out, g1 + ld * k * L1, g2 + ld * k * L2, k);
+  const int fb = (int) fpk<N>().fbytes, L1 = 2 * fb, L2 = 6 * fb, LT = 6 * fb;
+  __attribute__((aligned(4))) uint8_t out[24 * N];
+  TypeD<N>::d_prod_pairing_lane(out, g1 + ld * k * L1, g2 + ld * k * L2, k);
   if (idx < n) {
-    uint32_t *dst = reinterpret_cast<uint32_t *>(gt + idx * LT);
-    const uint32_t *src = reinterpret_cast<const uint32_t *>(out);
-#pragma unroll
-    for (int i = 0; i < LT / 4; i++) dst[i] = src[i];
+    if ((LT & 3) == 0) {
+      uint32_t *dst = reinterpret_cast<uint32_t *>(gt + idx * LT);
+      const uint32_t *src = reinterpret_cast<const uint32_t *>(out);
+      for (int i = 0; i < LT / 4; i++) dst[i] = src[i];
+    } else {
+      for (int i = 0; i < LT; i++) gt[idx * LT + i] = out[i];
+    }
   }
 }
 
@@ -148,7 +152,8 @@ __global__ void __launch_bounds__(kBlock, 2) g_mul_kernel(uint8_t *out, const ui
                                                            int zlen, size_t n) {
   size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
   if (idx >= n) return;
-  g_mul_lane<N>(out + idx * 8 * N, in + idx * 8 * N, z + idx * zlen, zlen);
+  const size_t L = 2 * fpk<N>().fbytes;
+  g_mul_lane<N>(out + idx * L, in + idx * L, z + idx * zlen, zlen);
 }
 template <int N>
 __global__ void __launch_bounds__(kBlock, 2) a_from_hash_kernel(uint8_t *out, const uint8_t *data, int hlen, size_t n) {
@@ -160,18 +165,21 @@ __global__ void __launch_bounds__(kBlock, 2) a_from_hash_kernel(uint8_t *out, co
     for (int i = 0; i < 8 * N; i++) out[idx * 8 * N + i] = o[i];
 }
 // op 0: out = a * b in GT;  op 1: out = a ^ z
+template <int N>
 __global__ void __launch_bounds__(kBlock, 2) gt_op_kernel(int type, int op, uint8_t *out, const uint8_t *a,
                                                            const uint8_t *b, int lenT, int zlen, size_t n) {
   size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
   if (idx >= n) return;
   uint8_t *o = out + idx * lenT;
   const uint8_t *x = a + idx * lenT;
-  if (type == 'a') {
-    if (op == 0) a_gt_mul_lane<16>(o, x, b + idx * lenT); else a_gt_pow_lane<16>(o, x, b + idx * zlen, zlen);
-  } else if (type == 'd') {
-    if (op == 0) d_gt_mul_lane(o, x, b + idx * lenT); else d_gt_pow_lane(o, x, b + idx * zlen, zlen);
+  if constexpr (N == 16) {
+    if (op == 0) a_gt_mul_lane<N>(o, x, b + idx * lenT); else a_gt_pow_lane<N>(o, x, b + idx * zlen, zlen);
   } else {
-    if (op == 0) f_gt_mul_lane(o, x, b + idx * lenT); else f_gt_pow_lane(o, x, b + idx * zlen, zlen);
+    if (type == 'd') {
+      if (op == 0) d_gt_mul_lane<N>(o, x, b + idx * lenT); else d_gt_pow_lane<N>(o, x, b + idx * zlen, zlen);
+    } else if constexpr (N == ND) {
+      if (op == 0) f_gt_mul_lane(o, x, b + idx * lenT); else f_gt_pow_lane(o, x, b + idx * zlen, zlen);
+    }
   }
 }
 
@@ -181,7 +189,7 @@ __global__ void __launch_bounds__(kBlock) fq_op_kernel(int op, uint8_t *c, const
                                                         const uint8_t *b, size_t n) {
   size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
   if (idx >= n) return;
-  constexpr int L = 4 * N;
+  const int L = (int) fpk<N>().fbytes;
   fp<N> x, y, z;
   fp_load_be<N>(x, a + idx * L);
   if (b) fp_load_be<N>(y, b + idx * L); else y = x;
@@ -388,12 +396,34 @@ extern "C" double pbc_hip_algorithmic_macs_per_unit(const pbc_hip_pairing_t *p, 
   return p->fq_muls_single * per_mul;
 }
 
+// Type D kernels exist per field width; N is the compile-time word count inside EXPR
+#define PBC_DISPATCH_D(nl, ...)                               \
+  switch (nl) {                                               \
+    case 5: { constexpr int N = 5; __VA_ARGS__; } break;             \
+    case 6: { constexpr int N = 6; __VA_ARGS__; } break;             \
+    case 7: { constexpr int N = 7; __VA_ARGS__; } break;             \
+    default: return fail("internal: no type d kernel for %d-word fields", (int) (nl)); \
+  }
+
+// any built-in field width (PBC_FOR_EACH_N)
+#define PBC_DISPATCH_N(nl, ...)                               \
+  switch (nl) {                                               \
+    case 5: { constexpr int N = 5; __VA_ARGS__; } break;             \
+    case 6: { constexpr int N = 6; __VA_ARGS__; } break;             \
+    case 7: { constexpr int N = 7; __VA_ARGS__; } break;             \
+    case 16: { constexpr int N = 16; __VA_ARGS__; } break;           \
+    default: return fail("internal: no kernel for %d-word fields", (int) (nl)); \
+  }
+
 // constants -> __constant__ memory, ordered on the launch stream
 static int upload_constants(pbc_hip_pairing_s *P, hipStream_t s) {
-  if (P->nlimb == 16)
-    HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_fpk16), &P->k16, sizeof P->k16, 0, hipMemcpyHostToDevice, s));
-  else
-    HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_fpk5), &P->k5, sizeof P->k5, 0, hipMemcpyHostToDevice, s));
+  switch (P->nlimb) {
+#define PBC_UP(n) \
+    case n: HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_fpk##n), &P->k##n, sizeof P->k##n, 0, hipMemcpyHostToDevice, s)); break;
+    PBC_FOR_EACH_N(PBC_UP)
+#undef PBC_UP
+    default: return fail("internal: no constants for %d-word fields", P->nlimb);
+  }
   if (P->type == 'a')
     HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_a), &P->a, sizeof P->a, 0, hipMemcpyHostToDevice, s));
   if (P->type == 'd') {
@@ -401,9 +431,9 @@ static int upload_constants(pbc_hip_pairing_s *P, hipStream_t s) {
       // one-time derivation of the tower constants on the device (two single-lane kernels)
       DConst *dbuf;
       HIP_TRY(hipMalloc(&dbuf, sizeof(DConst)));
-      hipLaunchKernelGGL(d_init_stage1, dim3(1), dim3(64), 0, s, dbuf, P->draw, P->dconst);
+      PBC_DISPATCH_D(P->nlimb, hipLaunchKernelGGL(d_init_stage1<N>, dim3(1), dim3(64), 0, s, dbuf, P->draw, P->dconst));
       HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_d), dbuf, sizeof(DConst), 0, hipMemcpyDeviceToDevice, s));
-      hipLaunchKernelGGL(d_init_stage2, dim3(1), dim3(64), 0, s, dbuf, P->draw);
+      PBC_DISPATCH_D(P->nlimb, hipLaunchKernelGGL(d_init_stage2<N>, dim3(1), dim3(64), 0, s, dbuf, P->draw));
       HIP_TRY(hipMemcpyAsync(&P->dconst, dbuf, sizeof(DConst), hipMemcpyDeviceToHost, s));
       HIP_TRY(hipStreamSynchronize(s));
       (void) hipFree(dbuf);
@@ -445,8 +475,8 @@ static int launch_pairing(pbc_hip_pairing_s *P, void *d_gt, const void *d_g1, co
     hipLaunchKernelGGL(a_pairing_kernel<16>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
                        (const uint8_t *) d_g1, (const uint8_t *) d_g2, n);
   } else if (P->type == 'd') {
-    hipLaunchKernelGGL(d_prod_pairing_kernel, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
-                       (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, 1);
+    PBC_DISPATCH_D(P->nlimb, hipLaunchKernelGGL(d_prod_pairing_kernel<N>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
+                                                (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, 1));
   } else if (P->type == 'f') {
     hipLaunchKernelGGL(f_prod_pairing_kernel, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
                        (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, 1);
@@ -537,8 +567,8 @@ static int launch_prod(pbc_hip_pairing_s *P, void *d_gt, const void *d_g1, const
     hipLaunchKernelGGL(a_prod_pairing_kernel<16>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
                        (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k);
   } else if (P->type == 'd') {
-    hipLaunchKernelGGL(d_prod_pairing_kernel, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
-                       (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k);
+    PBC_DISPATCH_D(P->nlimb, hipLaunchKernelGGL(d_prod_pairing_kernel<N>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
+                                                (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k));
   } else if (P->type == 'f') {
     hipLaunchKernelGGL(f_prod_pairing_kernel, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
                        (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k);
@@ -590,15 +620,12 @@ static int run_group(pbc_hip_pairing_s *P, int what, int group, uint8_t *out, co
   if (upload_constants(P, 0)) return 1;
   unsigned grid = (unsigned) ((n + kBlock - 1) / kBlock);
   if (what == 0) {
-    if (P->nlimb == 16)
-      hipLaunchKernelGGL(g_mul_kernel<16>, dim3(grid), dim3(kBlock), 0, 0, (uint8_t *) d_o, (const uint8_t *) da,
-                         (const uint8_t *) db, P->len_zr, n);
-    else
-      hipLaunchKernelGGL(g_mul_kernel<5>, dim3(grid), dim3(kBlock), 0, 0, (uint8_t *) d_o, (const uint8_t *) da,
-                         (const uint8_t *) db, P->len_zr, n);
+    PBC_DISPATCH_N(P->nlimb, hipLaunchKernelGGL(g_mul_kernel<N>, dim3(grid), dim3(kBlock), 0, 0, (uint8_t *) d_o,
+                                                (const uint8_t *) da, (const uint8_t *) db, P->len_zr, n));
   } else {
-    hipLaunchKernelGGL(gt_op_kernel, dim3(grid), dim3(kBlock), 0, 0, P->type, what - 1, (uint8_t *) d_o,
-                       (const uint8_t *) da, (const uint8_t *) db, P->lenT, P->len_zr, n);
+    PBC_DISPATCH_N(P->nlimb, hipLaunchKernelGGL(gt_op_kernel<N>, dim3(grid), dim3(kBlock), 0, 0, P->type, what - 1,
+                                                (uint8_t *) d_o, (const uint8_t *) da, (const uint8_t *) db, P->lenT,
+                                                P->len_zr, n));
   }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpy(out, d_o, n * lo, hipMemcpyDeviceToHost));
@@ -768,12 +795,8 @@ extern "C" int pbc_hip_fq_op_batch(pbc_hip_pairing_t *P, int op, uint8_t *c, con
   }
   if (upload_constants(P, 0)) return 1;
   unsigned grid = (unsigned) ((n + kBlock - 1) / kBlock);
-  if (P->nlimb == 16)
-    hipLaunchKernelGGL(fq_op_kernel<16>, dim3(grid), dim3(kBlock), 0, 0, op, (uint8_t *) dc,
-                       (const uint8_t *) da, (const uint8_t *) db, n);
-  else
-    hipLaunchKernelGGL(fq_op_kernel<5>, dim3(grid), dim3(kBlock), 0, 0, op, (uint8_t *) dc,
-                       (const uint8_t *) da, (const uint8_t *) db, n);
+  PBC_DISPATCH_N(P->nlimb, hipLaunchKernelGGL(fq_op_kernel<N>, dim3(grid), dim3(kBlock), 0, 0, op, (uint8_t *) dc,
+                                              (const uint8_t *) da, (const uint8_t *) db, n));
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpy(c, dc, bytes, hipMemcpyDeviceToHost));
   (void) hipFree(da);

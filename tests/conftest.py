@@ -46,6 +46,15 @@ def hip_a(a_param_text):
 
 
 PARAM_OF = {"a": "a", "d": "d159", "f": "f"}
+# the other type d parameter files the reference ships (param/): 175..224-bit q, 6 / 7 word fields
+OTHER_D = ["d277699-175-167", "d278027-190-181", "d105171-196-185", "d201", "d224"]
+
+
+def key_of(vec_name):
+    """fixture file name -> key for the oracles / hips / sims fixtures: "<param>_*.vec" for the
+    extra parameter files, else the type letter (a_*, d_*, f_* = a.param, d159.param, f.param)"""
+    prefix = vec_name.split("_")[0]
+    return prefix if prefix in OTHER_D else prefix[0]
 
 
 def _param(name):
@@ -53,21 +62,36 @@ def _param(name):
         return fh.read()
 
 
+def param_value(name, key):
+    """integer value of a "key value" line of pbc_amd/param/<name>.param"""
+    for line in _param(PARAM_OF.get(name, name)).splitlines():
+        f = line.split()
+        if len(f) == 2 and f[0] == key:
+            return int(f[1])
+    raise KeyError(key)
+
+
+
 @pytest.fixture(scope="session")
 def oracles():
-    """type letter -> CPU oracle"""
+    """type letter or parameter file name -> CPU oracle"""
     import oracle
-    return {t: oracle.OraclePairing(_param(n)) for t, n in PARAM_OF.items()}
+
+    class Lazy(dict):
+        def __missing__(self, t):
+            self[t] = oracle.OraclePairing(_param(PARAM_OF.get(t, t)))
+            return self[t]
+    return Lazy()
 
 
 @pytest.fixture(scope="session")
 def hips():
-    """type letter -> the product (libpbc_hip.so)"""
+    """type letter or parameter file name -> the product (libpbc_hip.so)"""
     import pbc_amd
 
     class Lazy(dict):
         def __missing__(self, t):
-            self[t] = pbc_amd.Pairing(_param(PARAM_OF[t]))   # raises if the type is not built in
+            self[t] = pbc_amd.Pairing(_param(PARAM_OF.get(t, t)))   # raises if the type is not built in
             return self[t]
     return Lazy()
 

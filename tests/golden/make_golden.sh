@@ -28,3 +28,9 @@ $T gen $F edge   5   3  9 $G/f_prod3x5_edge.vec
 $T hash $A 24 32 3 $G/a_hash32.vec              # element_from_hash(G1) on 32-byte digests
 $T hash $A 8 13 4 $G/a_hash13.vec               # short input: H || 0 || H || 1 ... expansion (field.c:640-668)
 $T hash $A 6 100 5 $G/a_hash100.vec             # long input: truncated to 64 bytes
+# the other shipped type d parameter files: 175..224-bit q (6 / 7 words, 22..28-byte coordinates)
+for d in d277699-175-167 d278027-190-181 d105171-196-185 d201 d224; do
+  $T gen pbc_amd/param/$d.param random 12 1 42 $G/${d}_rand12.vec
+  $T gen pbc_amd/param/$d.param edge   8  1  7 $G/${d}_edge8.vec
+  $T gen pbc_amd/param/$d.param edge   4  3  9 $G/${d}_prod3x4_edge.vec
+done

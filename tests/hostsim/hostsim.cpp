@@ -6,8 +6,29 @@
 
 // "upload" the constants before every call (as upload_constants does on the GPU): on the host
 // the __constant__ objects are plain globals shared by all parameter sets
+static void set_fpk(pbc_hip_pairing_s *P) {
+  switch (P->nlimb) {
+#define HS_UP(n) case n: c_fpk##n = P->k##n; break;
+    PBC_FOR_EACH_N(HS_UP)
+#undef HS_UP
+  }
+}
+// run EXPR with N = the compile-time word count matching P->nlimb
+#define HS_DISPATCH(nl, ...)                          \
+  switch (nl) {                                       \
+    case 5: { constexpr int N = 5; __VA_ARGS__; } break;     \
+    case 6: { constexpr int N = 6; __VA_ARGS__; } break;     \
+    case 7: { constexpr int N = 7; __VA_ARGS__; } break;     \
+    case 16: { constexpr int N = 16; __VA_ARGS__; } break;   \
+  }
+#define HS_DISPATCH_D(nl, ...)                        \
+  switch (nl) {                                       \
+    case 5: { constexpr int N = 5; __VA_ARGS__; } break;     \
+    case 6: { constexpr int N = 6; __VA_ARGS__; } break;     \
+    case 7: { constexpr int N = 7; __VA_ARGS__; } break;     \
+  }
 static void activate(pbc_hip_pairing_s *P) {
-  if (P->nlimb == 16) c_fpk16 = P->k16; else c_fpk5 = P->k5;
+  set_fpk(P);
   if (P->type == 'a') c_a = P->a;
   if (P->type == 'd') c_d = P->dconst;
   if (P->type == 'f') c_f = P->fconst;
@@ -27,12 +48,12 @@ void *hostsim_init(const char *param, size_t len) {
   else if (type == "d") { P->type = 'd'; rc = init_type_d(P, param, len); }
   else if (type == "f") { P->type = 'f'; rc = init_type_f(P, param, len); }
   if (rc) { delete P; return nullptr; }
-  if (P->nlimb == 16) c_fpk16 = P->k16; else c_fpk5 = P->k5;
+  set_fpk(P);
   if (P->type == 'd') {
     DConst tmp;
-    d_init_stage1(&tmp, P->draw, P->dconst);
+    HS_DISPATCH_D(P->nlimb, TypeD<N>::init_stage1(&tmp, P->draw, P->dconst));
     c_d = tmp;
-    d_init_stage2(&tmp, P->draw);
+    HS_DISPATCH_D(P->nlimb, TypeD<N>::init_stage2(&tmp, P->draw));
     c_d = tmp;
     P->dconst = tmp;
   }
@@ -61,7 +82,7 @@ int hostsim_prod_pairing(void *h, uint8_t *gt, const uint8_t *g1, const uint8_t 
     const uint8_t *a = g1 + u * k * P->len1, *b = g2 + u * k * P->len2;
     uint8_t *o = gt + u * P->lenT;
     if (P->type == 'a') a_prod_pairing_lane<16>(o, a, b, k, lds, 1);
-    else if (P->type == 'd') d_prod_pairing_lane(o, a, b, k);
+    else if (P->type == 'd') { HS_DISPATCH_D(P->nlimb, TypeD<N>::d_prod_pairing_lane(o, a, b, k)); }
     else f_prod_pairing_lane(o, a, b, k);
   }
   return 0;
@@ -82,13 +103,12 @@ int hostsim_group(void *h, int what, uint8_t *out, const uint8_t *a, const uint8
   activate(P);
   for (size_t i = 0; i < n; i++) {
     if (what == 0) {
-      if (P->nlimb == 16) g_mul_lane<16>(out + i * P->len1, a + i * P->len1, b + i * P->len_zr, P->len_zr);
-      else g_mul_lane<5>(out + i * P->len1, a + i * P->len1, b + i * P->len_zr, P->len_zr);
+      HS_DISPATCH(P->nlimb, g_mul_lane<N>(out + i * P->len1, a + i * P->len1, b + i * P->len_zr, P->len_zr));
     } else {
       uint8_t *o = out + i * P->lenT;
       const uint8_t *x = a + i * P->lenT, *y = b + i * (what == 1 ? P->lenT : P->len_zr);
       if (P->type == 'a') { if (what == 1) a_gt_mul_lane<16>(o, x, y); else a_gt_pow_lane<16>(o, x, y, P->len_zr); }
-      else if (P->type == 'd') { if (what == 1) d_gt_mul_lane(o, x, y); else d_gt_pow_lane(o, x, y, P->len_zr); }
+      else if (P->type == 'd') { HS_DISPATCH_D(P->nlimb, if (what == 1) d_gt_mul_lane<N>(o, x, y); else d_gt_pow_lane<N>(o, x, y, P->len_zr)); }
       else { if (what == 1) f_gt_mul_lane(o, x, y); else f_gt_pow_lane(o, x, y, P->len_zr); }
     }
   }
@@ -126,20 +146,15 @@ int hostsim_stage(void *h, int stage, uint8_t *out, size_t out_len, const uint8_
 int hostsim_fq_op(void *h, int op, uint8_t *c, const uint8_t *a, const uint8_t *b, size_t n) {
   pbc_hip_pairing_s *P = (pbc_hip_pairing_s *) h;
   activate(P);
+  const int L = P->len_fq;
   for (size_t i = 0; i < n; i++) {
-    if (P->nlimb == 16) {
-      fp<16> x, y, z;
-      fp_load_be<16>(x, a + i * 64); fp_load_be<16>(y, b + i * 64);
-      switch (op) { case 0: fp_mul<16>(z, x, y); break; case 1: fp_add<16>(z, x, y); break; case 2: fp_sub<16>(z, x, y); break;
-        case 3: fp_inv<16>(z, x); break; case 4: fp_neg<16>(z, x); break; case 5: fp_halve<16>(z, x); break; default: fp_dbl<16>(z, x); }
-      fp_store_be<16>(c + i * 64, z);
-    } else {
-      fp<5> x, y, z;
-      fp_load_be<5>(x, a + i * 20); fp_load_be<5>(y, b + i * 20);
-      switch (op) { case 0: fp_mul<5>(z, x, y); break; case 1: fp_add<5>(z, x, y); break; case 2: fp_sub<5>(z, x, y); break;
-        case 3: fp_inv<5>(z, x); break; case 4: fp_neg<5>(z, x); break; case 5: fp_halve<5>(z, x); break; default: fp_dbl<5>(z, x); }
-      fp_store_be<5>(c + i * 20, z);
-    }
+    HS_DISPATCH(P->nlimb, {
+      fp<N> x, y, z;
+      fp_load_be<N>(x, a + i * L); fp_load_be<N>(y, b + i * L);
+      switch (op) { case 0: fp_mul<N>(z, x, y); break; case 1: fp_add<N>(z, x, y); break; case 2: fp_sub<N>(z, x, y); break;
+        case 3: fp_inv<N>(z, x); break; case 4: fp_neg<N>(z, x); break; case 5: fp_halve<N>(z, x); break; default: fp_dbl<N>(z, x); }
+      fp_store_be<N>(c + i * L, z);
+    });
   }
   return 0;
 }

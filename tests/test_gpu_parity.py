@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 import oracle
-from conftest import golden
+from conftest import golden, OTHER_D, param_value
 
 pytestmark = pytest.mark.gpu
 
@@ -336,6 +336,51 @@ def test_pairing_pp_matches_element_pairing(hip_a, oracle_a):
     one = np.zeros(128, np.uint8)
     one[63] = 1
     assert np.array_equal(pp.apply(v.g2[:3]), np.tile(one, (3, 1)))
+
+
+# ---- the other shipped type d parameter files: 175..224-bit q, 6 / 7 word fields, 22..28-byte
+# ---- coordinates (not whole words for d277699-175-167, d105171-196-185, d201) -----------------
+@pytest.mark.parametrize("d", OTHER_D)
+def test_other_type_d_params_match_reference_vectors(hips, d):
+    H = hips[d]
+    fb = (param_value(d, "q").bit_length() + 7) // 8
+    assert (H.length_in_bytes_G1, H.length_in_bytes_G2, H.length_in_bytes_GT) == (2 * fb, 6 * fb, 6 * fb)
+    for suffix in ("_rand12.vec", "_edge8.vec"):
+        v = golden(d + suffix)
+        assert np.array_equal(H.element_pairing(v.g1, v.g2), v.gt), suffix
+    v = golden(d + "_prod3x4_edge.vec")
+    assert np.array_equal(H.element_prod_pairing(v.g1, v.g2, v.k), v.gt)
+
+
+@pytest.mark.parametrize("d", OTHER_D)
+def test_other_type_d_params_cross_pairs_fq_and_group_ops_vs_oracle(hips, oracles, d):
+    H, O = hips[d], oracles[d]
+    v = golden(d + "_rand12.vec")
+    q, r = param_value(d, "q"), param_value(d, "r")
+    fb, zl = (q.bit_length() + 7) // 8, (r.bit_length() + 7) // 8
+    # all 144 (P_i, Q_j) combinations, a whole block plus a ragged tail
+    i, j = np.meshgrid(np.arange(v.n), np.arange(v.n), indexing="ij")
+    g1, g2 = v.g1[i.ravel()], v.g2[j.ravel()]
+    assert np.array_equal(H.element_pairing(g1, g2), O.pairing_batch(g1, g2))
+    rng = np.random.default_rng(31)
+    xs = [int.from_bytes(rng.bytes(fb), "big") % q for _ in range(200)] + [0, 1, q - 1, 2 ** (8 * fb) - 1]
+    ys = [int.from_bytes(rng.bytes(fb), "big") % q for _ in range(200)] + [q - 1, 0, q - 1, 2 ** (8 * fb) - 1]
+    A, B = np.stack([_be(x, fb) for x in xs]), np.stack([_be(y, fb) for y in ys])
+    for op in range(7):
+        got, want = H.fq_op(op, A, B), O.fq_op(op, A, B)
+        if op == 3:
+            keep = np.array([x % q != 0 for x in xs])
+            got, want = got[keep], want[keep]
+        assert np.array_equal(got, want), "fq op %d" % op
+    assert H.length_in_bytes_Zr == zl
+    n = v.n
+    Z = np.stack([_be(k, zl) for k in [int.from_bytes(rng.bytes(zl), "big") % r for _ in range(n - 2)] + [1, r - 1]])
+    assert np.array_equal(H.element_mul_zn(1, v.g1, Z), O.g_mul(1, v.g1, Z))
+    a, b = v.gt, np.roll(v.gt, 1, axis=0)
+    assert np.array_equal(H.element_mul_GT(a, b), O.gt_mul(a, b))
+    assert np.array_equal(H.element_pow_zn_GT(a, Z), O.gt_pow(a, Z))
+    # bilinearity on the device: e([a]P, Q) == e(P, Q)^a
+    assert np.array_equal(H.element_pairing(H.element_mul_zn(1, v.g1, Z), v.g2), H.element_pow_zn_GT(v.gt, Z))
 
 
 # ---- group operations: element_mul_zn on G1/G2, element_mul / pow_zn on GT ----

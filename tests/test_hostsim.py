@@ -5,7 +5,7 @@ mirror for GPU-less bring-up, not a product path: libpbc_hip.so never contains i
 import numpy as np
 import pytest
 
-from conftest import golden, _param, PARAM_OF
+from conftest import golden, _param, PARAM_OF, OTHER_D, key_of, param_value
 
 hostsim = pytest.importorskip("hostsim")
 
@@ -14,7 +14,7 @@ hostsim = pytest.importorskip("hostsim")
 def sims():
     class Lazy(dict):
         def __missing__(self, t):
-            self[t] = hostsim.HostSim(_param(PARAM_OF[t]))
+            self[t] = hostsim.HostSim(_param(PARAM_OF.get(t, t)))
             return self[t]
     return Lazy()
 
@@ -23,18 +23,19 @@ def sims():
     ("a_kat.vec", 1), ("a_rand32.vec", 6), ("a_edge20.vec", 20), ("a_prod2x8.vec", 4), ("a_prod3x10_edge.vec", 10),
     ("d_rand32.vec", 6), ("d_edge20.vec", 20), ("d_prod16x4.vec", 2), ("d_prod3x10_edge.vec", 10),
     ("f_rand16.vec", 3), ("f_edge10.vec", 10), ("f_prod3x5_edge.vec", 5),
-])
+] + [(d + suffix, 4) for d in OTHER_D for suffix in ("_rand12.vec", "_edge8.vec", "_prod3x4_edge.vec")])
 def test_kernel_source_on_host_matches_reference(sims, name, count):
     v = golden(name)
     n = min(count, v.n)
-    out = sims[v.type].prod_pairing(v.g1[:n * v.k], v.g2[:n * v.k], v.k)
+    out = sims[key_of(name)].prod_pairing(v.g1[:n * v.k], v.g2[:n * v.k], v.k)
     assert np.array_equal(out, v.gt[:n])
 
 
-@pytest.mark.parametrize("t,q", [("a", None), ("d", 625852803282871856053922297323874661378036491717)])
+@pytest.mark.parametrize("t,q", [("a", None), ("d", 625852803282871856053922297323874661378036491717)]
+                         + [(d, None) for d in OTHER_D])
 def test_kernel_fq_ops_on_host(sims, oracles, t, q):
     if q is None:
-        q = int([l.split()[1] for l in _param("a").splitlines() if l.startswith("q ")][0])
+        q = param_value(t, "q")
     nb = sims[t].len1 // 2
     rng = np.random.default_rng(2)
     xs = [int.from_bytes(rng.bytes(nb), "big") % q for _ in range(40)] + [1, q - 1, 2 ** (8 * nb) - 1]
@@ -66,16 +67,17 @@ def test_pairing_pp_on_host(sims, oracles):
     assert np.array_equal(sims["a"].pp(bad, Q), np.tile(one, (6, 1)))
 
 
-@pytest.mark.parametrize("t,name", [("a", "a_rand32.vec"), ("d", "d_rand32.vec"), ("f", "f_rand16.vec")])
+@pytest.mark.parametrize("t,name", [("a", "a_rand32.vec"), ("d", "d_rand32.vec"), ("f", "f_rand16.vec")]
+                         + [(d, d + "_rand12.vec") for d in OTHER_D])
 def test_group_ops_on_host(sims, oracles, t, name):
     """element_mul_zn on G1, element_mul / element_pow_zn on GT vs the oracle."""
     v = golden(name)
     rng = np.random.default_rng(21)
     n = 3
-    r = {"a": 730750818665451621361119245571504901405976559617, "d": 208617601094290618684641029477488665211553761021,
-         "f": 205523667896953300194895899082072403858390252929}[t]
-    ks = [int.from_bytes(rng.bytes(20), "big") % r for _ in range(n - 1)] + [1]
-    Z = np.stack([np.frombuffer(k.to_bytes(20, "big"), np.uint8) for k in ks])
+    r = param_value(t, "r")
+    zl = (r.bit_length() + 7) // 8          # pairing_length_in_bytes_Zr
+    ks = [int.from_bytes(rng.bytes(zl), "big") % r for _ in range(n - 1)] + [1]
+    Z = np.stack([np.frombuffer(k.to_bytes(zl, "big"), np.uint8) for k in ks])
     assert np.array_equal(sims[t].group(0, v.g1[:n], Z), oracles[t].g_mul(1, v.g1[:n], Z))
     assert np.array_equal(sims[t].group(1, v.gt[:n], v.gt[n:2 * n]), oracles[t].gt_mul(v.gt[:n], v.gt[n:2 * n]))
     assert np.array_equal(sims[t].group(2, v.gt[:n], Z), oracles[t].gt_pow(v.gt[:n], Z))

@@ -391,7 +391,7 @@ int oracle_pairing_init(oracle_pairing **out, const char *txt, size_t len) {
   P->type = tb[0];
   int rc = 1;
   if (!strcmp(tb, "a")) rc = init_a(P, txt, len);
-  else if (!strcmp(tb, "d")) rc = init_d(P, txt, len);
+  else if (!strcmp(tb, "d") || !strcmp(tb, "g")) rc = init_d(P, txt, len);
   else if (!strcmp(tb, "f")) rc = init_f(P, txt, len);
   if (rc) { free(P); return 1; }
   *out = P;
@@ -610,9 +610,9 @@ static void gt_one_bytes(const oracle_pairing *P, uint8_t *out) {
 int oracle_pairing_batch(const oracle_pairing *P, const uint8_t *g1, const uint8_t *g2,
                          uint8_t *gt, size_t n) {
   const fpctx *F = &P->Fq;
-  if (P->type == 'd' || P->type == 'f') {
+  if (P->type == 'd' || P->type == 'g' || P->type == 'f') {
     for (size_t u = 0; u < n; u++) {
-      int rc = P->type == 'd' ? d_pairing_bytes(P, g1 + u * P->len1, g2 + u * P->len2, gt + u * P->lenT, 1)
+      int rc = P->type != 'f' ? d_pairing_bytes(P, g1 + u * P->len1, g2 + u * P->len2, gt + u * P->lenT, 1)
                               : f_pairing_bytes(P, g1 + u * P->len1, g2 + u * P->len2, gt + u * P->lenT, 1);
       if (rc) return rc;
     }
@@ -637,9 +637,9 @@ int oracle_prod_pairing_batch(const oracle_pairing *P, const uint8_t *g1, const 
                               uint8_t *gt, size_t n, int k) {
   const fpctx *F = &P->Fq;
   if (k < 1) return 1;
-  if (P->type == 'd' || P->type == 'f') {
+  if (P->type == 'd' || P->type == 'g' || P->type == 'f') {
     for (size_t u = 0; u < n; u++) {
-      int rc = P->type == 'd' ? d_pairing_bytes(P, g1 + u * k * P->len1, g2 + u * k * P->len2, gt + u * P->lenT, k)
+      int rc = P->type != 'f' ? d_pairing_bytes(P, g1 + u * k * P->len1, g2 + u * k * P->len2, gt + u * P->lenT, k)
                               : f_pairing_bytes(P, g1 + u * k * P->len1, g2 + u * k * P->len2, gt + u * P->lenT, k);
       if (rc) return rc;
     }
@@ -691,7 +691,7 @@ int oracle_fq_op(const oracle_pairing *P, int op, const uint8_t *a, const uint8_
 
 int oracle_gt_mul(const oracle_pairing *P, const uint8_t *a, const uint8_t *b, uint8_t *out, size_t n) {
   const fpctx *F = &P->Fq;
-  if (P->type == 'd' || P->type == 'f') {
+  if (P->type == 'd' || P->type == 'g' || P->type == 'f') {
     for (size_t i = 0; i < n; i++)
       if (df_gt_mul(P, a + i * P->lenT, b + i * P->lenT, out + i * P->lenT)) return 1;
     return 0;
@@ -711,7 +711,7 @@ int oracle_gt_mul(const oracle_pairing *P, const uint8_t *a, const uint8_t *b, u
 int oracle_gt_pow(const oracle_pairing *P, const uint8_t *a, const uint8_t *e, size_t elen,
                   uint8_t *out, size_t n) {
   const fpctx *F = &P->Fq;
-  if (P->type == 'd' || P->type == 'f') {
+  if (P->type == 'd' || P->type == 'g' || P->type == 'f') {
     for (size_t i = 0; i < n; i++) {
       big ex; big_from_be(&ex, e + i * elen, elen);
       if (df_gt_pow(P, a + i * P->lenT, &ex, out + i * P->lenT)) return 1;
@@ -750,140 +750,144 @@ int oracle_g_mul(const oracle_pairing *P, int group, const uint8_t *ptb, const u
 
 
 /* ================================================================== */
-/* Type D (MNT, k = 6), ecc/d_param.c                                  */
+/* Type D (MNT, k = 6), ecc/d_param.c, and Type G (Freeman, k = 10),   */
+/* ecc/g_param.c: the same construction with d = k/2 = 3 or 5          */
 /* ================================================================== */
-/* Fq^3 = Fq[x]/(x^3 + c2 x^2 + c1 x + c0): polymod ring, arith/poly.c (n = 3) */
-typedef struct { fe c[3]; } f3;
+/* Fq^d = Fq[x]/(x^d + c_(d-1) x^(d-1) + ... + c0): polymod ring, arith/poly.c (n = 3 or 5) */
+#define MAXD 5
+typedef struct { fe c[MAXD]; } fd;
 struct dctx {
-  f3 xpwr[2];            /* x^3, x^4 mod f: compute_x_powers (poly.c:1302-1333) */
-  fe nqr;                /* v: Fq6 = Fq3[sqrt(v)], v in Fq (d_param.c:1028-1032) */
-  fe nqrinv, nqrinv2;    /* v^-1, v^-2 (d_param.c:1072-1075; constants of Fq inside Fq3) */
-  f3 xpowq, xpowq2;      /* x^q, x^2q (d_param.c:1044-1050) */
+  int deg;               /* d: 3 for type d (d_param.c:1016-1026), 5 for type g (g_param.c:1269-1281) */
+  fd xpwr[MAXD - 1];     /* x^d .. x^(2d-2) mod f: compute_x_powers (poly.c:1302-1333) */
+  fe nqr;                /* v: Fq^k = Fq^d[sqrt(v)], v in Fq (d_param.c:1028-1032, g_param.c:1283-1285) */
+  fe nqrinv, nqrinv2;    /* v^-1, v^-2 (d_param.c:1072-1075, g_param.c:1322-1325; constants of Fq inside Fq^d) */
+  fd xpowq[MAXD - 1];    /* x^q, x^2q, (x^3q, x^4q) (d_param.c:1044-1050, g_param.c:1307-1316) */
   fe ta, tb;             /* twist y^2 = x^3 + a v^2 x + b v^3 (curve.c:885-901) */
-  big phikonr;           /* (q^2 - q + 1)/r (d_param.c:1036-1042) */
+  big phikonr;           /* Phi_k(q)/r: (q^2 - q + 1)/r (d_param.c:1036-1042), (q^4 - q^3 + q^2 - q + 1)/r (g_param.c:1288-1305) */
 };
+#define DEG (P->D->deg)
 
-static void f3_add(const fpctx *F, f3 *r, const f3 *a, const f3 *b) { for (int i = 0; i < 3; i++) fp_add(F, &r->c[i], &a->c[i], &b->c[i]); }
-static void f3_sub(const fpctx *F, f3 *r, const f3 *a, const f3 *b) { for (int i = 0; i < 3; i++) fp_sub(F, &r->c[i], &a->c[i], &b->c[i]); }
-static void f3_dbl(const fpctx *F, f3 *r, const f3 *a) { for (int i = 0; i < 3; i++) fp_dbl(F, &r->c[i], &a->c[i]); }
-static void f3_neg(const fpctx *F, f3 *r, const f3 *a) { for (int i = 0; i < 3; i++) fp_neg(F, &r->c[i], &a->c[i]); }
-static void f3_halve(const fpctx *F, f3 *r, const f3 *a) { for (int i = 0; i < 3; i++) fp_halve(F, &r->c[i], &a->c[i]); }
+static void fd_add(const oracle_pairing *P, fd *r, const fd *a, const fd *b) { for (int i = 0; i < DEG; i++) fp_add(&P->Fq, &r->c[i], &a->c[i], &b->c[i]); }
+static void fd_sub(const oracle_pairing *P, fd *r, const fd *a, const fd *b) { for (int i = 0; i < DEG; i++) fp_sub(&P->Fq, &r->c[i], &a->c[i], &b->c[i]); }
+static void fd_dbl(const oracle_pairing *P, fd *r, const fd *a) { for (int i = 0; i < DEG; i++) fp_dbl(&P->Fq, &r->c[i], &a->c[i]); }
+static void fd_neg(const oracle_pairing *P, fd *r, const fd *a) { for (int i = 0; i < DEG; i++) fp_neg(&P->Fq, &r->c[i], &a->c[i]); }
+static void fd_halve(const oracle_pairing *P, fd *r, const fd *a) { for (int i = 0; i < DEG; i++) fp_halve(&P->Fq, &r->c[i], &a->c[i]); }
 /* polymod_const_mul (poly.c:1550-1558) */
-static void f3_mul_fq(const fpctx *F, f3 *r, const f3 *a, const fe *s) { for (int i = 0; i < 3; i++) fp_mul(F, &r->c[i], &a->c[i], s); }
-static int f3_is0(const fpctx *F, const f3 *a) { return fp_is0(F, &a->c[0]) && fp_is0(F, &a->c[1]) && fp_is0(F, &a->c[2]); }
-static int f3_eq(const fpctx *F, const f3 *a, const f3 *b) { return fp_eq(F, &a->c[0], &b->c[0]) && fp_eq(F, &a->c[1], &b->c[1]) && fp_eq(F, &a->c[2], &b->c[2]); }
-static void f3_set_fq(const fpctx *F, f3 *r, const fe *s) { r->c[0] = *s; r->c[1] = F->zero; r->c[2] = F->zero; }
-/* polymod_mul_degree3 (poly.c:910-930): product mod f; the Karatsuba grouping of the
- * reference gives the same ring element as this schoolbook form. */
-static void f3_mul(const oracle_pairing *P, f3 *r, const f3 *a, const f3 *b) {
+static void fd_mul_fq(const oracle_pairing *P, fd *r, const fd *a, const fe *s) { for (int i = 0; i < DEG; i++) fp_mul(&P->Fq, &r->c[i], &a->c[i], s); }
+static int fd_is0(const oracle_pairing *P, const fd *a) { for (int i = 0; i < DEG; i++) if (!fp_is0(&P->Fq, &a->c[i])) return 0; return 1; }
+static int fd_eq(const oracle_pairing *P, const fd *a, const fd *b) { for (int i = 0; i < DEG; i++) if (!fp_eq(&P->Fq, &a->c[i], &b->c[i])) return 0; return 1; }
+static void fd_set_fq(const oracle_pairing *P, fd *r, const fe *s) { for (int i = 0; i < MAXD; i++) r->c[i] = P->Fq.zero; r->c[0] = *s; }
+/* polymod_mul_degree3 (poly.c:910-930) / polymod_mul (poly.c:880-908, the x^i table of
+ * compute_x_powers): product mod f; the Karatsuba grouping the reference uses for d = 3
+ * gives the same ring element as this schoolbook form. */
+static void fd_mul(const oracle_pairing *P, fd *r, const fd *a, const fd *b) {
   const fpctx *F = &P->Fq;
-  fe d[5], t;
-  for (int i = 0; i < 5; i++) d[i] = F->zero;
-  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+  const int d = DEG;
+  fe hi[2 * MAXD - 1], t;
+  for (int i = 0; i < 2 * d - 1; i++) hi[i] = F->zero;
+  for (int i = 0; i < d; i++) for (int j = 0; j < d; j++) {
     fp_mul(F, &t, &a->c[i], &b->c[j]);
-    fp_add(F, &d[i + j], &d[i + j], &t);
+    fp_add(F, &hi[i + j], &hi[i + j], &t);
   }
-  f3 res, p0;
-  res.c[0] = d[0]; res.c[1] = d[1]; res.c[2] = d[2];
-  f3_mul_fq(F, &p0, &P->D->xpwr[0], &d[3]); f3_add(F, &res, &res, &p0);
-  f3_mul_fq(F, &p0, &P->D->xpwr[1], &d[4]); f3_add(F, &res, &res, &p0);
+  fd res, p0;
+  fd_set_fq(P, &res, &F->zero);
+  for (int i = 0; i < d; i++) res.c[i] = hi[i];
+  for (int i = d; i < 2 * d - 1; i++) { fd_mul_fq(P, &p0, &P->D->xpwr[i - d], &hi[i]); fd_add(P, &res, &res, &p0); }
   *r = res;
 }
-static void f3_sqr(const oracle_pairing *P, f3 *r, const f3 *a) { f3_mul(P, r, a, a); }  /* poly.c:1049-1089 */
-/* a^q for a in Fq3: a0 + a1 x^q + a2 x^2q (the qpower macro, d_param.c:507-527) */
-static void f3_frob(const oracle_pairing *P, f3 *r, const f3 *a) {
+static void fd_sqr(const oracle_pairing *P, fd *r, const fd *a) { fd_mul(P, r, a, a); }  /* poly.c:1049-1089, :1091-1143 */
+/* a^q for a in Fq^d: a0 + sum a_i x^(iq) (the qpower macros, d_param.c:507-527, g_param.c:486-518) */
+static void fd_frob(const oracle_pairing *P, fd *r, const fd *a) {
   const fpctx *F = &P->Fq;
-  f3 e2, res;
-  f3_mul_fq(F, &res, &P->D->xpowq, &a->c[1]);
-  f3_mul_fq(F, &e2, &P->D->xpowq2, &a->c[2]);
-  f3_add(F, &res, &res, &e2);
+  fd e2, res;
+  fd_mul_fq(P, &res, &P->D->xpowq[0], &a->c[1]);
+  for (int i = 2; i < DEG; i++) { fd_mul_fq(P, &e2, &P->D->xpowq[i - 1], &a->c[i]); fd_add(P, &res, &res, &e2); }
   fp_add(F, &res.c[0], &res.c[0], &a->c[0]);
   *r = res;
 }
 /* polymod_invert (poly.c:521-536) is a polynomial extended Euclid; the inverse is unique,
- * here: a^-1 = a^q a^(q^2) / N(a), N(a) = a a^q a^(q^2) in Fq. */
-static void f3_inv(const oracle_pairing *P, f3 *r, const f3 *a) {
+ * here: a^-1 = (a^q a^(q^2) ... a^(q^(d-1))) / N(a), N(a) in Fq. */
+static void fd_inv(const oracle_pairing *P, fd *r, const fd *a) {
   const fpctx *F = &P->Fq;
-  f3 t, u, w, n;
-  f3_frob(P, &t, a);
-  f3_frob(P, &u, &t);
-  f3_mul(P, &w, &t, &u);
-  f3_mul(P, &n, a, &w);
+  fd t, w, n;
+  fd_frob(P, &t, a);
+  w = t;
+  for (int i = 2; i < DEG; i++) { fd_frob(P, &t, &t); fd_mul(P, &w, &w, &t); }
+  fd_mul(P, &n, a, &w);
   fe ni; fp_inv(F, &ni, &n.c[0]);
-  f3_mul_fq(F, r, &w, &ni);
+  fd_mul_fq(P, r, &w, &ni);
 }
-static void f3_pow(const oracle_pairing *P, f3 *r, const f3 *a, const big *e) {
+static void fd_pow(const oracle_pairing *P, fd *r, const fd *a, const big *e) {
   const fpctx *F = &P->Fq;
-  f3 acc, base = *a; f3_set_fq(F, &acc, &F->R);
+  fd acc, base = *a; fd_set_fq(P, &acc, &F->R);
   for (int i = big_bits(e) - 1; i >= 0; i--) {
-    f3_sqr(P, &acc, &acc);
-    if (big_bit(e, i)) f3_mul(P, &acc, &acc, &base);
+    fd_sqr(P, &acc, &acc);
+    if (big_bit(e, i)) fd_mul(P, &acc, &acc, &base);
   }
   *r = acc;
 }
-static void f3_from_bytes(const fpctx *F, f3 *r, const uint8_t *b) { for (int i = 0; i < 3; i++) fp_from_bytes(F, &r->c[i], b + i * F->nbytes); }  /* poly.c:735-752 */
-static void f3_to_bytes(const fpctx *F, uint8_t *b, const f3 *a) { for (int i = 0; i < 3; i++) fp_to_bytes(F, b + i * F->nbytes, &a->c[i]); }    /* poly.c:718-733 */
+static void fd_from_bytes(const oracle_pairing *P, fd *r, const uint8_t *b) { fd_set_fq(P, r, &P->Fq.zero); for (int i = 0; i < DEG; i++) fp_from_bytes(&P->Fq, &r->c[i], b + i * P->Fq.nbytes); }  /* poly.c:735-752 */
+static void fd_to_bytes(const oracle_pairing *P, uint8_t *b, const fd *a) { for (int i = 0; i < DEG; i++) fp_to_bytes(&P->Fq, b + i * P->Fq.nbytes, &a->c[i]); }    /* poly.c:718-733 */
 
-/* Fq^6 = Fq^3[sqrt(v)]: generic quadratic extension, arith/fieldquadratic.c fq_* */
-typedef struct { f3 x, y; } f6;
+/* Fq^k = Fq^d[sqrt(v)]: generic quadratic extension, arith/fieldquadratic.c fq_* */
+typedef struct { fd x, y; } fk;
 /* fq_mul (fieldquadratic.c:197-233) */
-static void f6_mul(const oracle_pairing *P, f6 *r, const f6 *a, const f6 *b) {
-  const fpctx *F = &P->Fq;
-  f3 e0, e1, e2, rx, ry;
-  f3_add(F, &e0, &a->x, &a->y);
-  f3_add(F, &e1, &b->x, &b->y);
-  f3_mul(P, &e2, &e0, &e1);
-  f3_mul(P, &e0, &a->x, &b->x);
-  f3_mul(P, &e1, &a->y, &b->y);
-  f3_mul_fq(F, &rx, &e1, &P->D->nqr);
-  f3_add(F, &rx, &rx, &e0);
-  f3_sub(F, &e2, &e2, &e0);
-  f3_sub(F, &ry, &e2, &e1);
+static void fk_mul(const oracle_pairing *P, fk *r, const fk *a, const fk *b) {
+  fd e0 = a->x, e1 = b->x, e2, rx, ry;
+  fd_add(P, &e0, &a->x, &a->y);
+  fd_add(P, &e1, &b->x, &b->y);
+  fd_mul(P, &e2, &e0, &e1);
+  fd_mul(P, &e0, &a->x, &b->x);
+  fd_mul(P, &e1, &a->y, &b->y);
+  fd_mul_fq(P, &rx, &e1, &P->D->nqr);
+  fd_add(P, &rx, &rx, &e0);
+  fd_sub(P, &e2, &e2, &e0);
+  fd_sub(P, &ry, &e2, &e1);
   r->x = rx; r->y = ry;
 }
 /* fq_square (fieldquadratic.c:249-269) */
-static void f6_sqr(const oracle_pairing *P, f6 *r, const f6 *a) {
-  const fpctx *F = &P->Fq;
-  f3 e0, e1;
-  f3_sqr(P, &e0, &a->x);
-  f3_sqr(P, &e1, &a->y);
-  f3_mul_fq(F, &e1, &e1, &P->D->nqr);
-  f3_add(F, &e0, &e0, &e1);
-  f3_mul(P, &e1, &a->x, &a->y);
-  f3_dbl(F, &e1, &e1);
+static void fk_sqr(const oracle_pairing *P, fk *r, const fk *a) {
+  fd e0, e1;
+  fd_sqr(P, &e0, &a->x);
+  fd_sqr(P, &e1, &a->y);
+  fd_mul_fq(P, &e1, &e1, &P->D->nqr);
+  fd_add(P, &e0, &e0, &e1);
+  fd_mul(P, &e1, &a->x, &a->y);
+  fd_dbl(P, &e1, &e1);
   r->x = e0; r->y = e1;
 }
 /* fq_invert (fieldquadratic.c:290-309) */
-static void f6_inv(const oracle_pairing *P, f6 *r, const f6 *a) {
-  const fpctx *F = &P->Fq;
-  f3 e0, e1;
-  f3_sqr(P, &e0, &a->x);
-  f3_sqr(P, &e1, &a->y);
-  f3_mul_fq(F, &e1, &e1, &P->D->nqr);
-  f3_sub(F, &e0, &e0, &e1);
-  f3_inv(P, &e0, &e0);
-  f3_mul(P, &r->x, &a->x, &e0);
-  f3_neg(F, &e0, &e0);
-  f3_mul(P, &r->y, &a->y, &e0);
+static void fk_inv(const oracle_pairing *P, fk *r, const fk *a) {
+  fd e0, e1;
+  fd_sqr(P, &e0, &a->x);
+  fd_sqr(P, &e1, &a->y);
+  fd_mul_fq(P, &e1, &e1, &P->D->nqr);
+  fd_sub(P, &e0, &e0, &e1);
+  fd_inv(P, &e0, &e0);
+  fd_mul(P, &r->x, &a->x, &e0);
+  fd_neg(P, &e0, &e0);
+  fd_mul(P, &r->y, &a->y, &e0);
 }
-static void f6_one(const fpctx *F, f6 *r) { f3_set_fq(F, &r->x, &F->R); f3_set_fq(F, &r->y, &F->zero); }
-static int f6_is1(const fpctx *F, const f6 *a) { f6 o; f6_one(F, &o); return f3_eq(F, &a->x, &o.x) && f3_is0(F, &a->y); }
+static void fk_one(const oracle_pairing *P, fk *r) { fd_set_fq(P, &r->x, &P->Fq.R); fd_set_fq(P, &r->y, &P->Fq.zero); }
+static int fk_is1(const oracle_pairing *P, const fk *a) { fk o; fk_one(P, &o); return fd_eq(P, &a->x, &o.x) && fd_is0(P, &a->y); }
 
-/* d_miller_evalfn (d_param.c:99-111) */
-static void d_evalfn(const fpctx *F, f6 *e0, const fe *a, const fe *b, const fe *c, const f3 *Qx, const f3 *Qy) {
-  for (int i = 0; i < 3; i++) {
+/* d_miller_evalfn (d_param.c:99-111, g_param.c:86-102) */
+static void d_evalfn(const oracle_pairing *P, fk *e0, const fe *a, const fe *b, const fe *c, const fd *Qx, const fd *Qy) {
+  const fpctx *F = &P->Fq;
+  fk_one(P, e0);
+  for (int i = 0; i < DEG; i++) {
     fp_mul(F, &e0->x.c[i], &Qx->c[i], a);
     fp_mul(F, &e0->y.c[i], &Qy->c[i], b);
   }
   fp_add(F, &e0->x.c[0], &e0->x.c[0], c);
 }
-/* cc_miller_no_denom_affine (d_param.c:321-422), the default (d_param.c:1085) */
-static void d_miller(const oracle_pairing *P, f6 *res, const pt *Pp, const f3 *Qx, const f3 *Qy) {
+/* cc_miller_no_denom_affine (d_param.c:321-422, the default :1085; g_param.c:308-408, the default :1342) */
+static void d_miller(const oracle_pairing *P, fk *res, const pt *Pp, const fd *Qx, const fd *Qy) {
   const fpctx *F = &P->Fq;
-  f6 v, e0;
+  fk v, e0;
   pt Z = *Pp;
   fe a, b, c, t0;
-  f6_one(F, &v);
+  fk_one(P, &v);
   int m = big_bits(&P->r);
   m = m > 2 ? m - 2 : 0;
   for (;;) {
@@ -897,8 +901,8 @@ static void d_miller(const oracle_pairing *P, f6 *res, const pt *Pp, const f3 *Q
     fp_mul(F, &c, &a, &Z.x);
     fp_add(F, &c, &c, &t0);
     fp_neg(F, &c, &c);
-    d_evalfn(F, &e0, &a, &b, &c, Qx, Qy);
-    f6_mul(P, &v, &v, &e0);
+    d_evalfn(P, &e0, &a, &b, &c, Qx, Qy);
+    fk_mul(P, &v, &v, &e0);
     if (!m) break;
     pt_dbl(F, &P->ca, &Z, &Z);
     if (big_bit(&P->r, m)) {
@@ -909,161 +913,192 @@ static void d_miller(const oracle_pairing *P, f6 *res, const pt *Pp, const f3 *Q
       fp_mul(F, &c, &a, &Z.x);
       fp_add(F, &c, &c, &t0);
       fp_neg(F, &c, &c);
-      d_evalfn(F, &e0, &a, &b, &c, Qx, Qy);
-      f6_mul(P, &v, &v, &e0);
+      d_evalfn(P, &e0, &a, &b, &c, Qx, Qy);
+      fk_mul(P, &v, &v, &e0);
       pt_add(F, &P->ca, &Z, &Z, Pp);
     }
     m--;
-    f6_sqr(P, &v, &v);
+    fk_sqr(P, &v, &v);
   }
   *res = v;
 }
-/* lucas_even (d_param.c:441-502), over Fq3 */
-static void d_lucas_even(const oracle_pairing *P, f6 *out, f6 *in, const big *cofactor) {
+/* lucas_even (d_param.c:441-502, g_param.c:413-469), over Fq^d */
+static void d_lucas_even(const oracle_pairing *P, fk *out, fk *in, const big *cofactor) {
   const fpctx *F = &P->Fq;
-  if (f6_is1(F, in)) { *out = *in; return; }
-  f3 t0, t1, v0, v1;
-  f3 *in0 = &in->x, *in1 = &in->y;
-  { fe two; fp_set_ui(F, &two, 2); f3_set_fq(F, &t0, &two); }
-  f3_dbl(F, &t1, in0);
+  if (fk_is1(P, in)) { *out = *in; return; }
+  fd t0, t1, v0, v1;
+  fd *in0 = &in->x, *in1 = &in->y;
+  { fe two; fp_set_ui(F, &two, 2); fd_set_fq(P, &t0, &two); }
+  fd_dbl(P, &t1, in0);
   v0 = t0; v1 = t1;
   int j = big_bits(cofactor) - 1;
   for (;;) {
     if (!j) {
-      f3_mul(P, &v1, &v0, &v1); f3_sub(F, &v1, &v1, &t1);
-      f3_sqr(P, &v0, &v0);      f3_sub(F, &v0, &v0, &t0);
+      fd_mul(P, &v1, &v0, &v1); fd_sub(P, &v1, &v1, &t1);
+      fd_sqr(P, &v0, &v0);      fd_sub(P, &v0, &v0, &t0);
       break;
     }
     if (big_bit(cofactor, j)) {
-      f3_mul(P, &v0, &v0, &v1); f3_sub(F, &v0, &v0, &t1);
-      f3_sqr(P, &v1, &v1);      f3_sub(F, &v1, &v1, &t0);
+      fd_mul(P, &v0, &v0, &v1); fd_sub(P, &v0, &v0, &t1);
+      fd_sqr(P, &v1, &v1);      fd_sub(P, &v1, &v1, &t0);
     } else {
-      f3_mul(P, &v1, &v0, &v1); f3_sub(F, &v1, &v1, &t1);
-      f3_sqr(P, &v0, &v0);      f3_sub(F, &v0, &v0, &t0);
+      fd_mul(P, &v1, &v0, &v1); fd_sub(P, &v1, &v1, &t1);
+      fd_sqr(P, &v0, &v0);      fd_sub(P, &v0, &v0, &t0);
     }
     j--;
   }
-  f3_dbl(F, &v0, &v0);
-  f3_mul(P, in0, &t1, &v1);
-  f3_sub(F, in0, in0, &v0);
-  f3_sqr(P, &t1, &t1);
-  f3_sub(F, &t1, &t1, &t0);
-  f3_sub(F, &t1, &t1, &t0);
-  f3_halve(F, &v0, &v1);
-  { f3 ti; f3_inv(P, &ti, &t1); f3_mul(P, &v1, in0, &ti); }   /* element_div */
-  f3_mul(P, &v1, &v1, in1);
+  fd_dbl(P, &v0, &v0);
+  fd_mul(P, in0, &t1, &v1);
+  fd_sub(P, in0, in0, &v0);
+  fd_sqr(P, &t1, &t1);
+  fd_sub(P, &t1, &t1, &t0);
+  fd_sub(P, &t1, &t1, &t0);
+  fd_halve(P, &v0, &v1);
+  { fd ti; fd_inv(P, &ti, &t1); fd_mul(P, &v1, in0, &ti); }   /* element_div */
+  fd_mul(P, &v1, &v1, in1);
   out->x = v0; out->y = v1;
 }
-/* cc_tatepower, k == 6 branch (d_param.c:505-564) */
-static void d_tatepower(const oracle_pairing *P, f6 *out, f6 *in) {
-  const fpctx *F = &P->Fq;
-  f6 e0, e3;
+/* cc_tatepower, k == 6 branch (d_param.c:505-564) and tatepower10 (g_param.c:471-536): with d = k/2,
+ * in^((q^d - 1)(q + 1)) = in^(q^(d+1)) in^(q^d) / (in^q in), then the Lucas ladder over Phi_k(q)/r */
+static void d_tatepower(const oracle_pairing *P, fk *out, fk *in) {
+  fk e0, e3;
   /* qpower(1): e0 = in.x^q + in.y^q sqrt(v) */
-  f3_frob(P, &e0.x, &in->x); f3_frob(P, &e0.y, &in->y);
+  fd_frob(P, &e0.x, &in->x); fd_frob(P, &e0.y, &in->y);
   e3 = e0;
-  e0.x = in->x; f3_neg(F, &e0.y, &in->y);
-  f6_mul(P, &e3, &e3, &e0);
+  e0.x = in->x; fd_neg(P, &e0.y, &in->y);
+  fk_mul(P, &e3, &e3, &e0);
   /* qpower(-1) */
-  f3_frob(P, &e0.x, &in->x); f3_frob(P, &e0.y, &in->y); f3_neg(F, &e0.y, &e0.y);
-  f6_mul(P, &e0, &e0, in);
-  f6_inv(P, &e0, &e0);
-  f6_mul(P, in, &e3, &e0);
+  fd_frob(P, &e0.x, &in->x); fd_frob(P, &e0.y, &in->y); fd_neg(P, &e0.y, &e0.y);
+  fk_mul(P, &e0, &e0, in);
+  fk_inv(P, &e0, &e0);
+  fk_mul(P, in, &e3, &e0);
   e0 = *in;
   d_lucas_even(P, out, &e0, &P->D->phikonr);
 }
-/* curve_is_valid_point / curve_from_bytes over Fq3 for the twist (curve.c:57-77, 609-623) */
-typedef struct { int inf; f3 x, y; } pt3;
-static void d_twist_from_bytes(const oracle_pairing *P, pt3 *Q, const uint8_t *b) {
+/* curve_is_valid_point / curve_from_bytes over Fq^d for the twist (curve.c:57-77, 609-623) */
+typedef struct { int inf; fd x, y; } ptd;
+static void d_twist_from_bytes(const oracle_pairing *P, ptd *Q, const uint8_t *b) {
   const fpctx *F = &P->Fq;
-  f3 t0, t1;
+  fd t0, t1;
   Q->inf = 0;
-  f3_from_bytes(F, &Q->x, b);
-  f3_from_bytes(F, &Q->y, b + 3 * F->nbytes);
-  f3_sqr(P, &t0, &Q->x);
+  fd_from_bytes(P, &Q->x, b);
+  fd_from_bytes(P, &Q->y, b + DEG * F->nbytes);
+  fd_sqr(P, &t0, &Q->x);
   fp_add(F, &t0.c[0], &t0.c[0], &P->D->ta);
-  f3_mul(P, &t0, &t0, &Q->x);
+  fd_mul(P, &t0, &t0, &Q->x);
   fp_add(F, &t0.c[0], &t0.c[0], &P->D->tb);
-  f3_sqr(P, &t1, &Q->y);
-  if (!f3_eq(F, &t0, &t1)) Q->inf = 1;
+  fd_sqr(P, &t1, &Q->y);
+  if (!fd_eq(P, &t0, &t1)) Q->inf = 1;
 }
-static void f6_to_bytes(const fpctx *F, uint8_t *b, const f6 *a) { f3_to_bytes(F, b, &a->x); f3_to_bytes(F, b + 3 * F->nbytes, &a->y); }
-static void f6_from_bytes(const fpctx *F, f6 *a, const uint8_t *b) { f3_from_bytes(F, &a->x, b); f3_from_bytes(F, &a->y, b + 3 * F->nbytes); }
+static void fk_to_bytes(const oracle_pairing *P, uint8_t *b, const fk *a) { fd_to_bytes(P, b, &a->x); fd_to_bytes(P, b + DEG * P->Fq.nbytes, &a->y); }
+static void fk_from_bytes(const oracle_pairing *P, fk *a, const uint8_t *b) { fd_from_bytes(P, &a->x, b); fd_from_bytes(P, &a->y, b + DEG * P->Fq.nbytes); }
 
-/* cc_pairing (d_param.c:570-587) / cc_pairings_affine (:710-736): the product routine
- * interleaves the k Miller loops (shared squaring, simultaneous inversions); the value is
- * the product of the k Miller functions, one cc_tatepower. */
+/* cc_pairing (d_param.c:570-587, g_param.c:541-558) / cc_pairings_affine (d_param.c:710-736): the
+ * product routine interleaves the k Miller loops (shared squaring, simultaneous inversions); the
+ * value is the product of the k Miller functions, one tate power.  Type g has no product routine
+ * (generic_prod_pairings, pairing.c:35-46: the product of the full pairings -- the same element). */
 static int d_pairing_bytes(const oracle_pairing *P, const uint8_t *g1, const uint8_t *g2, uint8_t *gt, int k) {
   const fpctx *F = &P->Fq;
-  f6 acc, m, out;
+  fk acc, m, out;
   int ident = 0;
-  f6_one(F, &acc);
+  fk_one(P, &acc);
   for (int j = 0; j < k; j++) {
-    pt A; pt3 B; f3 Qx, Qy;
+    pt A; ptd B; fd Qx, Qy;
     pt_from_bytes(F, &P->ca, &P->cb, &A, g1 + (size_t) j * P->len1);
     d_twist_from_bytes(P, &B, g2 + (size_t) j * P->len2);
     if (A.inf || B.inf) { ident = 1; continue; }
-    f3_mul_fq(F, &Qx, &B.x, &P->D->nqrinv);      /* twist map (x,y) -> (v^-1 x, v^-2 y sqrt(v)) */
-    f3_mul_fq(F, &Qy, &B.y, &P->D->nqrinv2);
+    fd_mul_fq(P, &Qx, &B.x, &P->D->nqrinv);      /* twist map (x,y) -> (v^-1 x, v^-2 y sqrt(v)) */
+    fd_mul_fq(P, &Qy, &B.y, &P->D->nqrinv2);
     d_miller(P, &m, &A, &Qx, &Qy);
-    f6_mul(P, &acc, &acc, &m);
+    fk_mul(P, &acc, &acc, &m);
   }
   if (ident) { gt_one_bytes(P, gt); return 0; }
   d_tatepower(P, &out, &acc);
-  f6_to_bytes(F, gt, &out);
+  fk_to_bytes(P, gt, &out);
   return 0;
 }
 
-/* d_init_pairing (d_param.c:993-1095) + pbc_param_init_d */
+/* big helpers for Phi_k(q)/r */
+static void big_mul(big *r, const big *a, const big *b) {
+  big z; memset(&z, 0, sizeof z);
+  for (int i = 0; i < BIGL; i++) {
+    if (!a->v[i]) continue;
+    u128 c = 0;
+    for (int j = 0; i + j < BIGL; j++) { c += (u128) a->v[i] * b->v[j] + z.v[i + j]; z.v[i + j] = (uint64_t) c; c >>= 64; }
+  }
+  *r = z;
+}
+static int big_divexact(big *quo, const big *z, const big *d) {
+  big rem; memset(quo, 0, sizeof *quo); memset(&rem, 0, sizeof rem);
+  for (int i = big_bits(z) - 1; i >= 0; i--) {
+    for (int w = BIGL - 1; w > 0; w--) rem.v[w] = (rem.v[w] << 1) | (rem.v[w - 1] >> 63);
+    rem.v[0] = (rem.v[0] << 1) | (uint64_t) big_bit(z, i);
+    if (bn_cmp(rem.v, d->v, BIGL) >= 0) { bn_sub(rem.v, rem.v, d->v, BIGL); quo->v[i / 64] |= 1ull << (i % 64); }
+  }
+  return bn_is0(rem.v, BIGL) ? 0 : 1;
+}
+
+/* d_init_pairing (d_param.c:993-1095) + pbc_param_init_d;  g_init_pairing (g_param.c:1248-1354) +
+ * pbc_param_init_g (:1378-1402) */
 static int init_d(oracle_pairing *P, const char *txt, size_t len) {
-  big a, b, nqr, co[3]; int k;
+  big a, b, nqr, co[MAXD]; int k;
+  const int d = P->type == 'g' ? 5 : 3;
   if (kv_big(txt, len, "q", &P->q) || kv_big(txt, len, "r", &P->r) || kv_big(txt, len, "a", &a) ||
-      kv_big(txt, len, "b", &b) || kv_big(txt, len, "nqr", &nqr) || kv_int(txt, len, "k", &k) ||
-      kv_big(txt, len, "coeff0", &co[0]) || kv_big(txt, len, "coeff1", &co[1]) || kv_big(txt, len, "coeff2", &co[2]))
+      kv_big(txt, len, "b", &b) || kv_big(txt, len, "nqr", &nqr))
     return 1;
-  if (k != 6) return 1;
+  if (d == 3 && (kv_int(txt, len, "k", &k) || k != 6)) return 1;      /* type g files carry no k that matters: k = 10 */
+  for (int i = 0; i < d; i++) {
+    char key[8];
+    snprintf(key, sizeof key, "coeff%d", i);
+    if (kv_big(txt, len, key, &co[i])) return 1;
+  }
   if (fp_init(&P->Fq, &P->q)) return 1;
   const fpctx *F = &P->Fq;
   struct dctx *D = P->D = calloc(1, sizeof *D);
-  fe cf[3];
+  D->deg = d;
+  fe cf[MAXD];
 #define SETBIG(dst, src) do { fe t_; memset(&t_, 0, sizeof t_); memcpy(t_.v, (src).v, 8 * F->n); fp_mul(F, &(dst), &t_, &F->R2); } while (0)
   SETBIG(P->ca, a); SETBIG(P->cb, b); SETBIG(D->nqr, nqr);
-  for (int i = 0; i < 3; i++) SETBIG(cf[i], co[i]);
-  /* x^3 = -(c0 + c1 x + c2 x^2); x^4 = x * x^3 reduced */
-  for (int i = 0; i < 3; i++) fp_neg(F, &D->xpwr[0].c[i], &cf[i]);
-  {
-    f3 *x3 = &D->xpwr[0], *x4 = &D->xpwr[1], t;
-    x4->c[0] = F->zero; x4->c[1] = x3->c[0]; x4->c[2] = x3->c[1];
-    f3_mul_fq(F, &t, x3, &x3->c[2]);
-    f3_add(F, x4, x4, &t);
+  for (int i = 0; i < d; i++) SETBIG(cf[i], co[i]);
+  /* x^d = -(c0 + c1 x + ...); x^(d+j) = x * x^(d+j-1) reduced (compute_x_powers, poly.c:1302-1333) */
+  fd_set_fq(P, &D->xpwr[0], &F->zero);
+  for (int i = 0; i < d; i++) fp_neg(F, &D->xpwr[0].c[i], &cf[i]);
+  for (int j = 1; j < d - 1; j++) {
+    fd *prev = &D->xpwr[j - 1], *cur = &D->xpwr[j], t;
+    fd_set_fq(P, cur, &F->zero);
+    for (int i = 1; i < d; i++) cur->c[i] = prev->c[i - 1];
+    fd_mul_fq(P, &t, &D->xpwr[0], &prev->c[d - 1]);
+    fd_add(P, cur, cur, &t);
   }
   fp_inv(F, &D->nqrinv, &D->nqr);
   fp_sqr(F, &D->nqrinv2, &D->nqrinv);
   /* twist coefficients a v^2, b v^3 (field_reinit_curve_twist, curve.c:885-901) */
   { fe v2; fp_sqr(F, &v2, &D->nqr); fp_mul(F, &D->ta, &P->ca, &v2); fp_mul(F, &v2, &v2, &D->nqr); fp_mul(F, &D->tb, &P->cb, &v2); }
-  /* xpowq = x^q, xpowq2 = (x^q)^2 */
-  { f3 x; x.c[0] = F->zero; x.c[1] = F->R; x.c[2] = F->zero; f3_pow(P, &D->xpowq, &x, &P->q); f3_sqr(P, &D->xpowq2, &D->xpowq); }
-  /* phikonr = (q^2 - q + 1) / r  -- long division on 'big' */
+  /* xpowq[i-1] = x^(iq) */
   {
-    big z; memset(&z, 0, sizeof z);
-    int n = F->n;
-    for (int i = 0; i < n; i++) { u128 c = 0; for (int j = 0; j < n; j++) { c += (u128) P->q.v[i] * P->q.v[j] + z.v[i + j]; z.v[i + j] = (uint64_t) c; c >>= 64; } z.v[i + n] += (uint64_t) c; }
-    bn_sub(z.v, z.v, P->q.v, BIGL);
-    big one; memset(&one, 0, sizeof one); one.v[0] = 1;
-    bn_add(z.v, z.v, one.v, BIGL);
-    /* z / r by binary long division */
-    big quo, rem; memset(&quo, 0, sizeof quo); memset(&rem, 0, sizeof rem);
-    for (int i = big_bits(&z) - 1; i >= 0; i--) {
-      for (int w = BIGL - 1; w > 0; w--) rem.v[w] = (rem.v[w] << 1) | (rem.v[w - 1] >> 63);
-      rem.v[0] = (rem.v[0] << 1) | (uint64_t) big_bit(&z, i);
-      if (bn_cmp(rem.v, P->r.v, BIGL) >= 0) { bn_sub(rem.v, rem.v, P->r.v, BIGL); quo.v[i / 64] |= 1ull << (i % 64); }
-    }
-    if (!bn_is0(rem.v, BIGL)) return 1;
-    D->phikonr = quo;
+    fd x; fd_set_fq(P, &x, &F->zero); x.c[1] = F->R;
+    fd_pow(P, &D->xpowq[0], &x, &P->q);
+    for (int i = 1; i < d - 1; i++) fd_mul(P, &D->xpowq[i], &D->xpowq[i - 1], &D->xpowq[0]);
   }
-  P->len1 = 2 * F->nbytes; P->len2 = 6 * F->nbytes; P->lenT = 6 * F->nbytes;
+  /* phikonr = Phi_k(q) / r: q^2 - q + 1 (k = 6), q^4 - q^3 + q^2 - q + 1 (k = 10) */
+  {
+    big one, q2, z; memset(&one, 0, sizeof one); one.v[0] = 1;
+    big_mul(&q2, &P->q, &P->q);
+    z = q2;
+    bn_sub(z.v, z.v, P->q.v, BIGL);
+    bn_add(z.v, z.v, one.v, BIGL);                       /* q^2 - q + 1 */
+    if (d == 5) {
+      big q3, q4;
+      big_mul(&q3, &q2, &P->q);
+      big_mul(&q4, &q3, &P->q);
+      bn_add(z.v, z.v, q4.v, BIGL);
+      bn_sub(z.v, z.v, q3.v, BIGL);
+    }
+    if (big_divexact(&D->phikonr, &z, &P->r)) return 1;
+  }
+  P->len1 = 2 * F->nbytes; P->len2 = 2 * d * F->nbytes; P->lenT = 2 * d * F->nbytes;
   return 0;
 }
-
 static int df_gt_mul(const oracle_pairing *P, const uint8_t *a, const uint8_t *b, uint8_t *out);
 static int df_gt_pow(const oracle_pairing *P, const uint8_t *a, const big *e, uint8_t *out);
 
@@ -1341,16 +1376,16 @@ static int init_f(oracle_pairing *P, const char *txt, size_t len) {
 
 static int df_gt_mul(const oracle_pairing *P, const uint8_t *a, const uint8_t *b, uint8_t *out) {
   const fpctx *F = &P->Fq;
-  if (P->type == 'd') { f6 x, y; f6_from_bytes(F, &x, a); f6_from_bytes(F, &y, b); f6_mul(P, &x, &x, &y); f6_to_bytes(F, out, &x); return 0; }
+  if (P->type == 'd' || P->type == 'g') { fk x, y; fk_from_bytes(P, &x, a); fk_from_bytes(P, &y, b); fk_mul(P, &x, &x, &y); fk_to_bytes(P, out, &x); return 0; }
   if (P->type == 'f') { f12 x, y; f12_from_bytes(F, &x, a); f12_from_bytes(F, &y, b); f12_mul(P, &x, &x, &y); f12_to_bytes(F, out, &x); return 0; }
   return 1;
 }
 static int df_gt_pow(const oracle_pairing *P, const uint8_t *a, const big *e, uint8_t *out) {
   const fpctx *F = &P->Fq;
-  if (P->type == 'd') {
-    f6 x, acc; f6_from_bytes(F, &x, a); f6_one(F, &acc);
-    for (int i = big_bits(e) - 1; i >= 0; i--) { f6_sqr(P, &acc, &acc); if (big_bit(e, i)) f6_mul(P, &acc, &acc, &x); }
-    f6_to_bytes(F, out, &acc); return 0;
+  if (P->type == 'd' || P->type == 'g') {
+    fk x, acc; fk_from_bytes(P, &x, a); fk_one(P, &acc);
+    for (int i = big_bits(e) - 1; i >= 0; i--) { fk_sqr(P, &acc, &acc); if (big_bit(e, i)) fk_mul(P, &acc, &acc, &x); }
+    fk_to_bytes(P, out, &acc); return 0;
   }
   if (P->type == 'f') { f12 x; f12_from_bytes(F, &x, a); f12_pow(P, &x, &x, e); f12_to_bytes(F, out, &x); return 0; }
   return 1;

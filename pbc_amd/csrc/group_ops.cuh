@@ -314,43 +314,41 @@ PBC_DEV void a_gt_pow_lane(uint8_t *out, const uint8_t *a, const uint8_t *z, int
   }
   a_gt_store<N>(out, acc);
 }
-// Type D: F_q^6
-template <int N>
-PBC_DEV void d_gt_load(typename TypeD<N>::f6 &r, const uint8_t *s) {
-  TypeD<N>::f3_load_be(r.x, s);
-  TypeD<N>::f3_load_be(r.y, s + 3 * fpk<N>().fbytes);
+// Types D and G: F_q^k = F_q^d[sqrt(v)], d = 3 / 5
+template <int N, int DEG>
+PBC_DEV void d_gt_load(typename TypeMNT<N, DEG>::f6 &r, const uint8_t *s) {
+  TypeMNT<N, DEG>::f3_load_be(r.x, s);
+  TypeMNT<N, DEG>::f3_load_be(r.y, s + DEG * fpk<N>().fbytes);
 }
-template <int N>
-PBC_DEV void d_gt_store(uint8_t *d, const typename TypeD<N>::f6 &a) {
-  TypeD<N>::f3_store_be(d, a.x);
-  TypeD<N>::f3_store_be(d + 3 * fpk<N>().fbytes, a.y);
+template <int N, int DEG>
+PBC_DEV void d_gt_store(uint8_t *d, const typename TypeMNT<N, DEG>::f6 &a) {
+  TypeMNT<N, DEG>::f3_store_be(d, a.x);
+  TypeMNT<N, DEG>::f3_store_be(d + DEG * fpk<N>().fbytes, a.y);
 }
-template <int N>
+template <int N, int DEG>
 PBC_DEV void d_gt_mul_lane(uint8_t *out, const uint8_t *a, const uint8_t *b) {
-  typename TypeD<N>::f6 x, y;
-  d_gt_load<N>(x, a);
-  d_gt_load<N>(y, b);
-  TypeD<N>::f6_mul(x, x, y);
-  d_gt_store<N>(out, x);
+  typename TypeMNT<N, DEG>::f6 x, y;
+  d_gt_load<N, DEG>(x, a);
+  d_gt_load<N, DEG>(y, b);
+  TypeMNT<N, DEG>::f6_mul(x, x, y);
+  d_gt_store<N, DEG>(out, x);
 }
-template <int N>
+template <int N, int DEG>
 PBC_DEV void d_gt_pow_lane(uint8_t *out, const uint8_t *a, const uint8_t *z, int zlen) {
-  typename TypeD<N>::f6 x, acc, t;
-  d_gt_load<N>(x, a);
+  typename TypeMNT<N, DEG>::f6 x, acc, t;
+  d_gt_load<N, DEG>(x, a);
   fp<N> one;
   fp_set<N>(one, fpk<N>().one);
-#pragma unroll
-  for (int i = 0; i < 3; i++)
-#pragma unroll
-    for (int k = 0; k < N; k++) { acc.x.c[i].v[k] = (i == 0) ? one.v[k] : 0; acc.y.c[i].v[k] = 0; }
+  TypeMNT<N, DEG>::f3_set_fq(acc.x, one);
+  TypeMNT<N, DEG>::f3_sub(acc.y, acc.x, acc.x);
   for (int i = 8 * zlen - 1; i >= 0; i--) {
-    TypeD<N>::f6_sqr(acc, acc);
-    TypeD<N>::f6_mul(t, acc, x);
+    TypeMNT<N, DEG>::f6_sqr(acc, acc);
+    TypeMNT<N, DEG>::f6_mul(t, acc, x);
     bool bit = zr_bit(z, zlen, i) != 0;
 #pragma unroll
-    for (int c = 0; c < 3; c++) { fp_cmov<N>(acc.x.c[c], t.x.c[c], bit); fp_cmov<N>(acc.y.c[c], t.y.c[c], bit); }
+    for (int c = 0; c < DEG; c++) { fp_cmov<N>(acc.x.c[c], t.x.c[c], bit); fp_cmov<N>(acc.y.c[c], t.y.c[c], bit); }
   }
-  d_gt_store<N>(out, acc);
+  d_gt_store<N, DEG>(out, acc);
 }
 // Type F: F_q^12 (private-memory objects)
 __device__ void f_gt_load(f12 *r, const uint8_t *s) {

@@ -35,6 +35,7 @@ struct pbc_hip_pairing_s {
   int type;
   int device;
   int nlimb;                 // 32-bit limbs of F_q
+  int deg;                   // types d / g: degree d = k/2 of F_q^d (3 / 5)
   int len_fq, len1, len2, lenT;
 #define PBC_HOST_FPK(n) FpK<n> k##n;
   PBC_FOR_EACH_N(PBC_HOST_FPK)  // k5, k6, k7, k16: the one matching nlimb is filled
@@ -126,59 +127,82 @@ static int init_type_a(pbc_hip_pairing_s *P, const char *txt, size_t len) {
   return 0;
 }
 
-// d_init_pairing (ecc/d_param.c:993-1095) + pbc_param_init_d: host part (integers only);
-// the tower constants are derived on the device at first use (pairing_d.cuh d_init_stage*).
-static int init_type_d(pbc_hip_pairing_s *P, const char *txt, size_t len) {
+// d_init_pairing (ecc/d_param.c:993-1095) + pbc_param_init_d, and g_init_pairing (ecc/g_param.c:
+// 1248-1354) + pbc_param_init_g (:1378-1402): host part (integers only); the tower constants are
+// derived on the device at first use (pairing_d.cuh init_stage*).  deg = k/2: 3 (type d), 5 (type g).
+static int init_type_d(pbc_hip_pairing_s *P, const char *txt, size_t len, int deg) {
   using namespace pbc_host;
-  Big q, r, a, b, nqr, co[3];
-  int k;
+  const char *tn = deg == 3 ? "type d" : "type g";
+  Big q, r, a, b, nqr, co[DEG_MAX];
+  int k = 0;
   if (!param_big(txt, len, "q", q) || !param_big(txt, len, "r", r) || !param_big(txt, len, "a", a) ||
-      !param_big(txt, len, "b", b) || !param_big(txt, len, "nqr", nqr) || !param_int(txt, len, "k", k) ||
-      !param_big(txt, len, "coeff0", co[0]) || !param_big(txt, len, "coeff1", co[1]) ||
-      !param_big(txt, len, "coeff2", co[2]))
-    return fail("type d: missing q/r/a/b/k/coeff0..2/nqr");
-  if (k != 6) return fail("type d: only embedding degree 6 is supported (got %d)", k);
-  // field width: 5 words for d159, 6 for d277699-175-167 / d278027-190-181, 7 for d105171-196-185 /
-  // d201 / d224 (all the type d files under param/)
+      !param_big(txt, len, "b", b) || !param_big(txt, len, "nqr", nqr) || !param_int(txt, len, "k", k))
+    return fail("%s: missing q/r/a/b/k/nqr", tn);
+  for (int i = 0; i < deg; i++) {
+    char key[8];
+    snprintf(key, sizeof key, "coeff%d", i);
+    if (!param_big(txt, len, key, co[i])) return fail("%s: missing %s", tn, key);
+  }
+  if (k != 2 * deg) return fail("%s: only embedding degree %d is supported (got %d)", tn, 2 * deg, k);
+  // field width: 5 words for d159 and g149, 6 for d277699-175-167 / d278027-190-181, 7 for
+  // d105171-196-185 / d201 / d224 (all the type d and type g files under param/)
   const int ND = (q.bits() + 31) / 32;
   if (ND < 5 || ND > ND_MAX || (ND == 5 ? fill_fpk<5>(P->k5, q) : ND == 6 ? fill_fpk<6>(P->k6, q) : fill_fpk<7>(P->k7, q)))
-    return fail("type d: only odd 129..224-bit q is supported by this build (got %d bits)", q.bits());
-  if (Big::cmp(a, q) >= 0 || Big::cmp(b, q) >= 0 || Big::cmp(nqr, q) >= 0) return fail("type d: coefficient >= q");
+    return fail("%s: only odd 129..224-bit q is supported by this build (got %d bits)", tn, q.bits());
+  if (deg == 5 && ND != 5) return fail("type g: only 129..160-bit q is supported by this build (got %d bits)", q.bits());
+  if (Big::cmp(a, q) >= 0 || Big::cmp(b, q) >= 0 || Big::cmp(nqr, q) >= 0) return fail("%s: coefficient >= q", tn);
   memset(&P->draw, 0, sizeof P->draw);
   memset(&P->dconst, 0, sizeof P->dconst);
   a.to_words(P->draw.a, ND);
   b.to_words(P->draw.b, ND);
   nqr.to_words(P->draw.nqr, ND);
-  for (int i = 0; i < 3; i++) {
-    if (Big::cmp(co[i], q) >= 0) return fail("type d: coefficient >= q");
+  for (int i = 0; i < deg; i++) {
+    if (Big::cmp(co[i], q) >= 0) return fail("%s: coefficient >= q", tn);
     co[i].to_words(P->draw.coeff[i], ND);
   }
   q.to_words(P->draw.q, ND + 1);
   P->draw.qbits = q.bits();
-  if (r.bits() > 256 || r.bits() < 3) return fail("type d: bad r");
+  if (r.bits() > 256 || r.bits() < 3) return fail("%s: bad r", tn);
   r.to_words(P->dconst.r, 8);
   P->dconst.rbits = r.bits();
-  // phikonr = (q^2 - q + 1)/r (d_param.c:1036-1042)
-  Big z = Big::mul(q, q);
+  // phikonr = Phi_k(q)/r: (q^2 - q + 1)/r (d_param.c:1036-1042), (q^4 - q^3 + q^2 - q + 1)/r (g_param.c:1288-1305)
+  Big q2 = Big::mul(q, q);
+  Big z = q2;
   z.sub(q);
   z.add_small(1);
+  if (deg == 5) {
+    Big q3 = Big::mul(q2, q), q4 = Big::mul(q2, q2);
+    z = Big::add(z, q4);
+    z.sub(q3);
+  }
   Big rem;
   Big phik = Big::div(z, r, &rem);
-  if (!rem.is_zero() || phik.bits() > 256) return fail("type d: r does not divide q^2 - q + 1");
-  phik.to_words(P->dconst.phik, 8);
+  if (!rem.is_zero() || phik.bits() > 512) return fail("%s: r does not divide Phi_k(q)", tn);
+  phik.to_words(P->dconst.phik, 16);
   P->dconst.phikbits = phik.bits();
   P->nlimb = ND;
+  P->deg = deg;
   P->len_fq = (q.bits() + 7) / 8;
   P->len1 = 2 * P->len_fq;
-  P->len2 = P->lenT = 6 * P->len_fq;
+  P->len2 = P->lenT = 2 * deg * P->len_fq;
   P->len_zr = (r.bits() + 7) / 8;
-  // work model: SURVEY.md 8d instrumented the reference on d159.param (158-bit r, 161-bit
-  // (q^2-q+1)/r): 22254 F_q products in the Miller loop + 4197 in cc_tatepower.  Both loops are
-  // one iteration per exponent bit, so other parameter files scale by their bit lengths.
-  const double miller = 22254.0 * r.bits() / 158.0, tate = 4197.0 * phik.bits() / 161.0;
-  P->fq_muls_single = miller + tate;
-  P->fq_muls_prod_a = miller;            // per-term Miller work + one cc_tatepower
-  P->fq_muls_prod_b = tate;
+  if (deg == 3) {
+    // work model: SURVEY.md 8d instrumented the reference on d159.param (158-bit r, 161-bit
+    // (q^2-q+1)/r): 22254 F_q products in the Miller loop + 4197 in cc_tatepower.  Both loops are
+    // one iteration per exponent bit, so other parameter files scale by their bit lengths.
+    const double miller = 22254.0 * r.bits() / 158.0, tate = 4197.0 * phik.bits() / 161.0;
+    P->fq_muls_single = miller + tate;
+    P->fq_muls_prod_a = miller;            // per-term Miller work + one cc_tatepower
+    P->fq_muls_prod_b = tate;
+  } else {
+    // g149.param (149-bit r, 447-bit Phi_10(q)/r): F_q products counted on the CPU restatement of
+    // the reference's algorithm (the test oracle's counters; polymod_mul is schoolbook + table for
+    // d = 5, 45 F_q products): 96795 per pairing, about 55100 in the Miller loop and 41695 in tatepower10.
+    const double miller = 55100.0 * r.bits() / 149.0, tate = 41695.0 * phik.bits() / 447.0;
+    P->fq_muls_single = miller + tate;
+    P->fq_muls_prod_a = miller + tate;     // generic_prod_pairings (pairing.c:35-46): k full pairings
+    P->fq_muls_prod_b = 0.0;
+  }
   return 0;
 }
 
@@ -281,7 +305,7 @@ static void fill_curve(const pbc_hip_pairing_s *P, CurveK &C) {
   memset(&C, 0, sizeof C);
   if (P->type == 'a') {                 // y^2 = x^3 + x (a_param.c:1450-1452)
     memcpy(C.a, P->k16.one, sizeof P->k16.one);
-  } else if (P->type == 'd') {
+  } else if (P->type == 'd' || P->type == 'g') {
     memcpy(C.a, P->dconst.A, sizeof P->dconst.A);
     memcpy(C.b, P->dconst.B, sizeof P->dconst.B);
   } else {                              // y^2 = x^3 + b (f_param.c:365-367)

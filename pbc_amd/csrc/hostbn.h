@@ -69,6 +69,17 @@ struct Big {                              // little-endian 32-bit words, normali
     for (auto &x : w) { c += x; x = (uint32_t) c; c >>= 32; if (!c) break; }
     if (c) w.push_back((uint32_t) c);
   }
+  static Big add(const Big &a, const Big &b) {
+    Big r;
+    uint64_t c = 0;
+    for (size_t i = 0; i < a.w.size() || i < b.w.size() || c; i++) {
+      c += (uint64_t) (i < a.w.size() ? a.w[i] : 0) + (i < b.w.size() ? b.w[i] : 0);
+      r.w.push_back((uint32_t) c);
+      c >>= 32;
+    }
+    r.trim();
+    return r;
+  }
   static Big mul(const Big &a, const Big &b) {
     Big r;
     r.w.assign(a.w.size() + b.w.size() + 1, 0);

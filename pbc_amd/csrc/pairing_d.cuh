@@ -1,5 +1,10 @@
 // pairing_d.cuh -- Type D (MNT curve y^2 = x^3 + ax + b over F_q, embedding degree k = 6)
-// reduced Tate pairing, one pairing per lane.
+// and Type G (Freeman curve, k = 10) reduced Tate pairings, one pairing per lane.  The two
+// families share one construction in the reference (ecc/d_param.c, ecc/g_param.c): with d = k/2,
+// F_q^d = F_q[x]/(f), F_q^k = F_q^d[sqrt(v)], G2 on the quadratic twist over F_q^d.  Here they
+// are one template over the field width (words) and d; the comments below cite d_param.c, the
+// type g twins are cc_miller_no_denom_affine g_param.c:308-408, lucas_even :413-469,
+// tatepower10 :471-536, cc_pairing :541-558, g_init_pairing :1248-1354.
 //
 // Computes the same GT value as the reference's cc_pairing (ecc/d_param.c:570-587):
 // twist map, cc_miller_no_denom_affine (:321-422) and cc_tatepower (:505-564, k = 6 branch
@@ -22,151 +27,183 @@
 namespace pbc {
 
 constexpr int ND_MAX = 7;              // widest MNT field built in: 224-bit q (d224.param)
+constexpr int DEG_MAX = 5;             // d = k/2: 3 (type d), 5 (type g)
 struct DConst {                        // pptr (ecc/d_param.c:40-51) + curve/field constants
   uint32_t A[ND_MAX], B[ND_MAX];       // curve coefficients (Montgomery form)
-  uint32_t xpwr[2][3][ND_MAX];         // x^3, x^4 mod f      (poly.c compute_x_powers)
+  uint32_t xpwr[DEG_MAX - 1][DEG_MAX][ND_MAX];   // x^d .. x^(2d-2) mod f (poly.c compute_x_powers)
   uint32_t nqr[ND_MAX], nqrinv[ND_MAX], nqrinv2[ND_MAX];   // v, v^-1, v^-2 (d_param.c:1028-1032, :1072-1075)
-  uint32_t xpowq[3][ND_MAX], xpowq2[3][ND_MAX];            // x^q, x^2q     (d_param.c:1044-1050)
+  uint32_t xpowq[DEG_MAX - 1][DEG_MAX][ND_MAX];  // x^q, x^2q, (x^3q, x^4q) (d_param.c:1044-1050, g_param.c:1307-1316)
   uint32_t ta[ND_MAX], tb[ND_MAX];     // twist: y^2 = x^3 + a v^2 x + b v^3 (curve.c:885-901)
   uint32_t r[8];                       // group order (Miller loop bits)
-  uint32_t phik[8];                    // (q^2 - q + 1)/r (d_param.c:1036-1042)
+  uint32_t phik[16];                   // Phi_k(q)/r (d_param.c:1036-1042, g_param.c:1288-1305)
   int rbits, phikbits;
 };
 __constant__ DConst c_d;
-struct DRaw { uint32_t a[ND_MAX], b[ND_MAX], coeff[3][ND_MAX], nqr[ND_MAX], q[ND_MAX + 1]; int qbits; };
+struct DRaw { uint32_t a[ND_MAX], b[ND_MAX], coeff[DEG_MAX][ND_MAX], nqr[ND_MAX], q[ND_MAX + 1]; int qbits; };
 
 constexpr int D_LANES = 128;
 typedef uint32_t v32 __attribute__((ext_vector_type(32)));
-// Per-lane Miller state in LDS, word-major ([word][lane]: conflict-free); one array per field width.
-template <int ND> __shared__ uint32_t g_lds_d[11 * ND * D_LANES];
+// Per-lane Miller state in LDS, word-major ([word][lane]: conflict-free); one array per instantiation.
+template <int ND, int DEG> __shared__ uint32_t g_lds_d[(2 * DEG + 5) * ND * D_LANES];
 
-// Everything below is per field width: ND 32-bit words per F_q element (5 for the 159-bit d159
-// field, 6 / 7 for the 175..224-bit fields of the other shipped type d parameter files).
-template <int ND>
-struct TypeD {
+// Everything below is per field width and extension degree: ND 32-bit words per F_q element (5 for
+// the 159-bit d159 and 149-bit g149 fields, 6 / 7 for the 175..224-bit fields of the other shipped
+// type d files), DEG = d.  Names keep the type d flavour: f3 = F_q^d, f6 = F_q^k.
+template <int ND, int DEG>
+struct TypeMNT {
 typedef fp<ND> fq;
-struct f3 { fq c[3]; };                // c0 + c1 x + c2 x^2
+struct f3 { fq c[DEG]; };              // c0 + c1 x + ... + c(d-1) x^(d-1)
 struct f6 { f3 x, y; };                // x + y sqrt(v)
 
 static PBC_DEV fq dk(const uint32_t *w) { fq r; fp_set<ND>(r, w); return r; }
 
 // ---- F_q^3 ------------------------------------------------------------------------------
-static PBC_DEV void f3_add(f3 &r, const f3 &a, const f3 &b) { for (int i = 0; i < 3; i++) fp_add<ND>(r.c[i], a.c[i], b.c[i]); }
-static PBC_DEV void f3_sub(f3 &r, const f3 &a, const f3 &b) { for (int i = 0; i < 3; i++) fp_sub<ND>(r.c[i], a.c[i], b.c[i]); }
-static PBC_DEV void f3_dbl(f3 &r, const f3 &a) { for (int i = 0; i < 3; i++) fp_dbl<ND>(r.c[i], a.c[i]); }
-static PBC_DEV void f3_neg(f3 &r, const f3 &a) { for (int i = 0; i < 3; i++) fp_neg<ND>(r.c[i], a.c[i]); }
-static PBC_DEV void f3_halve(f3 &r, const f3 &a) { for (int i = 0; i < 3; i++) fp_halve<ND>(r.c[i], a.c[i]); }
+static PBC_DEV void f3_add(f3 &r, const f3 &a, const f3 &b) { for (int i = 0; i < DEG; i++) fp_add<ND>(r.c[i], a.c[i], b.c[i]); }
+static PBC_DEV void f3_sub(f3 &r, const f3 &a, const f3 &b) { for (int i = 0; i < DEG; i++) fp_sub<ND>(r.c[i], a.c[i], b.c[i]); }
+static PBC_DEV void f3_dbl(f3 &r, const f3 &a) { for (int i = 0; i < DEG; i++) fp_dbl<ND>(r.c[i], a.c[i]); }
+static PBC_DEV void f3_neg(f3 &r, const f3 &a) { for (int i = 0; i < DEG; i++) fp_neg<ND>(r.c[i], a.c[i]); }
+static PBC_DEV void f3_halve(f3 &r, const f3 &a) { for (int i = 0; i < DEG; i++) fp_halve<ND>(r.c[i], a.c[i]); }
 // polymod_const_mul (poly.c:1550-1558)
-static PBC_DEV void f3_mul_fq(f3 &r, const f3 &a, const fq &s) { for (int i = 0; i < 3; i++) fp_mul<ND>(r.c[i], a.c[i], s); }
-static PBC_DEV bool f3_eq(const f3 &a, const f3 &b) { return (int) fp_eq<ND>(a.c[0], b.c[0]) & (int) fp_eq<ND>(a.c[1], b.c[1]) & (int) fp_eq<ND>(a.c[2], b.c[2]); }
+static PBC_DEV void f3_mul_fq(f3 &r, const f3 &a, const fq &s) { for (int i = 0; i < DEG; i++) fp_mul<ND>(r.c[i], a.c[i], s); }
+static PBC_DEV bool f3_eq(const f3 &a, const f3 &b) {
+  int e = 1;
+#pragma unroll
+  for (int i = 0; i < DEG; i++) e &= (int) fp_eq<ND>(a.c[i], b.c[i]);
+  return e != 0;
+}
+static PBC_DEV void f3_set_fq(f3 &r, const fq &s) {
+#pragma unroll
+  for (int i = 0; i < DEG; i++)
+#pragma unroll
+    for (int k = 0; k < ND; k++) r.c[i].v[k] = (i == 0) ? s.v[k] : 0;
+}
 
-// F_q^3 product with lazy reduction (polymod_mul_degree3, poly.c:910-930: same ring element):
-//   d3 = a1 b2 + a2 b1,  d4 = a2 b2                       (x^3, x^4 coefficients, reduced once each)
-//   c_k = sum_{i+j=k} a_i b_j + d3 X3_k + d4 X4_k         (one reduction per output coefficient)
-// 15 limb products + 5 Montgomery reductions instead of 12 full products (6 Karatsuba + 6 table).
+// F_q^d product with lazy reduction (polymod_mul_degree3 poly.c:910-930 / polymod_mul :880-908: same
+// ring element).  With h_t the x^(d+t) coefficient of the plain polynomial product and X_t = x^(d+t) mod f:
+//   h_t = sum_{i+j=d+t} a_i b_j                              (reduced once each)
+//   c_k = sum_{i+j=k} a_i b_j + sum_t h_t X_t[k]             (one reduction per output coefficient)
+// d = 3: 15 limb products + 5 Montgomery reductions instead of 12 full products (6 Karatsuba + 6 table);
+// d = 5: 45 limb products + 9 reductions instead of 25 + 20 full products.
+template <int S, bool TABLE>
+static PBC_DEV void mul_coeff(fl<ND> &out, const fl<ND> *A, const fl<ND> *B, const fl<ND> *H) {
+  constexpr int lo = S - (DEG - 1) > 0 ? S - (DEG - 1) : 0, hi = S < DEG - 1 ? S : DEG - 1;
+  constexpr int NDIR = hi - lo + 1, T = NDIR + (TABLE ? DEG - 1 : 0);
+  fl<ND> x[T], y[T];
+#pragma unroll
+  for (int i = lo; i <= hi; i++) { x[i - lo] = A[i]; y[i - lo] = B[S - i]; }
+  if constexpr (TABLE) {
+#pragma unroll
+    for (int t = 0; t < DEG - 1; t++) { x[NDIR + t] = H[t]; to_limbs<ND>(y[NDIR + t], dk(c_d.xpwr[t][S])); }
+  }
+  sop_limbs<ND, T>(out, x, y);
+}
+// squares: cross terms once with a doubled operand (polymod_square_degree3, poly.c:1049-1089)
+template <int S, bool TABLE>
+static PBC_DEV void sqr_coeff(fl<ND> &out, const fl<ND> *A, const fl<ND> *A2, const fl<ND> *H) {
+  constexpr int lo = S - (DEG - 1) > 0 ? S - (DEG - 1) : 0, hic = (S + 1) / 2 - 1;   // pairs i < S - i
+  constexpr int NC = hic - lo + 1 > 0 ? hic - lo + 1 : 0;
+  constexpr bool SQ = (S % 2 == 0) && (S / 2 < DEG);
+  constexpr int T = NC + (SQ ? 1 : 0) + (TABLE ? DEG - 1 : 0);
+  fl<ND> x[T], y[T];
+#pragma unroll
+  for (int i = lo; i <= hic; i++) { x[i - lo] = A2[i]; y[i - lo] = A[S - i]; }
+  if constexpr (SQ) { x[NC] = A[S / 2]; y[NC] = A[S / 2]; }
+  if constexpr (TABLE) {
+#pragma unroll
+    for (int t = 0; t < DEG - 1; t++) { x[NC + SQ + t] = H[t]; to_limbs<ND>(y[NC + SQ + t], dk(c_d.xpwr[t][S])); }
+  }
+  sop_limbs<ND, T, NC>(out, x, y);
+}
+template <int S> static PBC_DEV void mul_high(fl<ND> *H, const fl<ND> *A, const fl<ND> *B) {
+  if constexpr (S < 2 * DEG - 1) { mul_coeff<S, false>(H[S - DEG], A, B, H); mul_high<S + 1>(H, A, B); }
+}
+template <int S> static PBC_DEV void mul_low(f3 &r, const fl<ND> *A, const fl<ND> *B, const fl<ND> *H) {
+  if constexpr (S < DEG) { fl<ND> c; mul_coeff<S, true>(c, A, B, H); from_limbs<ND>(r.c[S], c); mul_low<S + 1>(r, A, B, H); }
+}
+template <int S> static PBC_DEV void sqr_high(fl<ND> *H, const fl<ND> *A, const fl<ND> *A2) {
+  if constexpr (S < 2 * DEG - 1) { sqr_coeff<S, false>(H[S - DEG], A, A2, H); sqr_high<S + 1>(H, A, A2); }
+}
+template <int S> static PBC_DEV void sqr_low(f3 &r, const fl<ND> *A, const fl<ND> *A2, const fl<ND> *H) {
+  if constexpr (S < DEG) { fl<ND> c; sqr_coeff<S, true>(c, A, A2, H); from_limbs<ND>(r.c[S], c); sqr_low<S + 1>(r, A, A2, H); }
+}
 static PBC_DEV void f3_mul_inl(f3 &r, const f3 &a, const f3 &b) {
-  fl<ND> A[3], B[3], X3[3], X4[3], d3, d4, c;
+  fl<ND> A[DEG], B[DEG], H[DEG - 1];
 #pragma unroll
-  for (int i = 0; i < 3; i++) {
-    to_limbs<ND>(A[i], a.c[i]);
-    to_limbs<ND>(B[i], b.c[i]);
-    to_limbs<ND>(X3[i], dk(c_d.xpwr[0][i]));
-    to_limbs<ND>(X4[i], dk(c_d.xpwr[1][i]));
-  }
-  { const fl<ND> x[2] = {A[1], A[2]}, y[2] = {B[2], B[1]}; sop_limbs<ND, 2>(d3, x, y); }
-  { const fl<ND> x[1] = {A[2]}, y[1] = {B[2]}; sop_limbs<ND, 1>(d4, x, y); }
-  { const fl<ND> x[3] = {A[0], d3, d4}, y[3] = {B[0], X3[0], X4[0]}; sop_limbs<ND, 3>(c, x, y); from_limbs<ND>(r.c[0], c); }
-  { const fl<ND> x[4] = {A[0], A[1], d3, d4}, y[4] = {B[1], B[0], X3[1], X4[1]}; sop_limbs<ND, 4>(c, x, y); from_limbs<ND>(r.c[1], c); }
-  { const fl<ND> x[5] = {A[0], A[1], A[2], d3, d4}, y[5] = {B[2], B[1], B[0], X3[2], X4[2]}; sop_limbs<ND, 5>(c, x, y); from_limbs<ND>(r.c[2], c); }
+  for (int i = 0; i < DEG; i++) { to_limbs<ND>(A[i], a.c[i]); to_limbs<ND>(B[i], b.c[i]); }
+  mul_high<DEG>(H, A, B);
+  mul_low<0>(r, A, B, H);
 }
-// polymod_square_degree3 (poly.c:1049-1089): d3 = 2 a1 a2, d4 = a2^2,
-//   c0 = a0^2 + ..., c1 = 2 a0 a1 + ..., c2 = 2 a0 a2 + a1^2 + ...
 static PBC_DEV void f3_sqr_inl(f3 &r, const f3 &a) {
-  fl<ND> A[3], A2[2], X3[3], X4[3], d3, d4, c;
+  fl<ND> A[DEG], A2[DEG], H[DEG - 1];
 #pragma unroll
-  for (int i = 0; i < 3; i++) {
-    to_limbs<ND>(A[i], a.c[i]);
-    to_limbs<ND>(X3[i], dk(c_d.xpwr[0][i]));
-    to_limbs<ND>(X4[i], dk(c_d.xpwr[1][i]));
-  }
-  limbs_dbl<ND>(A2[0], A[0]);
-  limbs_dbl<ND>(A2[1], A[1]);
-  { const fl<ND> x[1] = {A2[1]}, y[1] = {A[2]}; sop_limbs<ND, 1, 1>(d3, x, y); }
-  { const fl<ND> x[1] = {A[2]}, y[1] = {A[2]}; sop_limbs<ND, 1>(d4, x, y); }
-  { const fl<ND> x[3] = {A[0], d3, d4}, y[3] = {A[0], X3[0], X4[0]}; sop_limbs<ND, 3>(c, x, y); from_limbs<ND>(r.c[0], c); }
-  { const fl<ND> x[3] = {A2[0], d3, d4}, y[3] = {A[1], X3[1], X4[1]}; sop_limbs<ND, 3, 1>(c, x, y); from_limbs<ND>(r.c[1], c); }
-  { const fl<ND> x[4] = {A2[0], A[1], d3, d4}, y[4] = {A[2], A[1], X3[2], X4[2]}; sop_limbs<ND, 4, 1>(c, x, y); from_limbs<ND>(r.c[2], c); }
+  for (int i = 0; i < DEG; i++) { to_limbs<ND>(A[i], a.c[i]); limbs_dbl<ND>(A2[i], A[i]); }
+  sqr_high<DEG>(H, A, A2);
+  sqr_low<0>(r, A, A2, H);
 }
-// Out-of-line F_q^3 product / square (30 / 15 VGPR arguments): one body each keeps the
-// Miller and Lucas loops inside the instruction cache.
+// Out-of-line F_q^d product / square (2 d ND / d ND argument words, the first 32 in VGPRs): one
+// body each keeps the Miller and Lucas loops inside the instruction cache.
 typedef typename vecN<ND>::type v5;
-static PBC_DEV void f3_unpack(f3 &r, v5 c0, v5 c1, v5 c2) { from_vec<ND>(r.c[0], c0); from_vec<ND>(r.c[1], c1); from_vec<ND>(r.c[2], c2); }
-typedef uint32_t f3ret __attribute__((ext_vector_type(3 * ND)));   // one vector: stays in VGPRs for any ND
+typedef uint32_t f3ret __attribute__((ext_vector_type(DEG * ND)));   // one vector: stays in VGPRs
 static PBC_DEV f3ret f3_pack(const f3 &a) {
   f3ret r;
 #pragma unroll
-  for (int i = 0; i < 3; i++)
+  for (int i = 0; i < DEG; i++)
 #pragma unroll
     for (int k = 0; k < ND; k++) r[ND * i + k] = a.c[i].v[k];
   return r;
 }
 static PBC_DEV void f3_unpack(f3 &a, f3ret r) {
 #pragma unroll
-  for (int i = 0; i < 3; i++)
+  for (int i = 0; i < DEG; i++)
 #pragma unroll
     for (int k = 0; k < ND; k++) a.c[i].v[k] = r[ND * i + k];
 }
-static __device__ __noinline__ f3ret f3_mul_call(v5 a0, v5 a1, v5 a2, v5 b0, v5 b1, v5 b2) {
+static __device__ __noinline__ f3ret f3_mul_call(f3ret va, f3ret vb) {
   f3 a, b, r;
-  f3_unpack(a, a0, a1, a2);
-  f3_unpack(b, b0, b1, b2);
+  f3_unpack(a, va);
+  f3_unpack(b, vb);
   f3_mul_inl(r, a, b);
   return f3_pack(r);
 }
-static __device__ __noinline__ f3ret f3_sqr_call(v5 a0, v5 a1, v5 a2) {
+static __device__ __noinline__ f3ret f3_sqr_call(f3ret va) {
   f3 a, r;
-  f3_unpack(a, a0, a1, a2);
+  f3_unpack(a, va);
   f3_sqr_inl(r, a);
   return f3_pack(r);
 }
-static PBC_DEV void f3_mul(f3 &r, const f3 &a, const f3 &b) {
-  f3ret t = f3_mul_call(to_vec<ND>(a.c[0]), to_vec<ND>(a.c[1]), to_vec<ND>(a.c[2]), to_vec<ND>(b.c[0]),
-                        to_vec<ND>(b.c[1]), to_vec<ND>(b.c[2]));
-  f3_unpack(r, t);
-}
-static PBC_DEV void f3_sqr(f3 &r, const f3 &a) {
-  f3ret t = f3_sqr_call(to_vec<ND>(a.c[0]), to_vec<ND>(a.c[1]), to_vec<ND>(a.c[2]));
-  f3_unpack(r, t);
-}
+static PBC_DEV void f3_mul(f3 &r, const f3 &a, const f3 &b) { f3_unpack(r, f3_mul_call(f3_pack(a), f3_pack(b))); }
+static PBC_DEV void f3_sqr(f3 &r, const f3 &a) { f3_unpack(r, f3_sqr_call(f3_pack(a))); }
 
-// a^q on F_q^3 (the qpower macro of cc_tatepower, d_param.c:507-527)
+// a^q on F_q^d: a0 + sum_j a_j x^(jq) (the qpower macros of cc_tatepower, d_param.c:507-527, and
+// tatepower10, g_param.c:486-518)
 static PBC_DEV void f3_frob(f3 &r, const f3 &a) {
   f3 res;
   fq t;
 #pragma unroll
-  for (int i = 0; i < 3; i++) {
-    fp_mul<ND>(res.c[i], a.c[1], dk(c_d.xpowq[i]));
-    fp_mul<ND>(t, a.c[2], dk(c_d.xpowq2[i]));
-    fp_add<ND>(res.c[i], res.c[i], t);
+  for (int i = 0; i < DEG; i++) {
+    fp_mul<ND>(res.c[i], a.c[1], dk(c_d.xpowq[0][i]));
+#pragma unroll
+    for (int j = 2; j < DEG; j++) {
+      fp_mul<ND>(t, a.c[j], dk(c_d.xpowq[j - 1][i]));
+      fp_add<ND>(res.c[i], res.c[i], t);
+    }
   }
   fp_add<ND>(res.c[0], res.c[0], a.c[0]);
   r = res;
 }
-// a^-1 = a^q a^(q^2) / N(a), N(a) = a a^q a^(q^2) in F_q  (polymod_invert poly.c:521-536 is a
+// a^-1 = a^q a^(q^2) ... a^(q^(d-1)) / N(a), N(a) in F_q  (polymod_invert poly.c:521-536 is a
 // polynomial extended Euclid; the inverse is unique)
 static PBC_DEV void f3_inv(f3 &r, const f3 &a) {
-  f3 t, u, w;
+  f3 t, w, m;
   f3_frob(t, a);
-  f3_frob(u, t);
-  f3_mul(w, t, u);
-  // constant coefficient of a*w
-  fq n, d3, d4, s;
-  fp_mul<ND>(n, a.c[0], w.c[0]);
-  fp_mul<ND>(d3, a.c[1], w.c[2]); fp_mul<ND>(s, a.c[2], w.c[1]); fp_add<ND>(d3, d3, s);
-  fp_mul<ND>(d4, a.c[2], w.c[2]);
-  fp_mul<ND>(s, d3, dk(c_d.xpwr[0][0])); fp_add<ND>(n, n, s);
-  fp_mul<ND>(s, d4, dk(c_d.xpwr[1][0])); fp_add<ND>(n, n, s);
-  fp_inv<ND>(n, n);
+  w = t;
+  for (int j = 2; j < DEG; j++) {
+    f3_frob(t, t);
+    f3_mul(w, w, t);
+  }
+  f3_mul(m, a, w);                     // the norm: only c[0] is non-zero
+  fq n;
+  fp_inv<ND>(n, m.c[0]);
   f3_mul_fq(r, w, n);
 }
 
@@ -206,29 +243,30 @@ struct djac { fq X, Y, Z, ZZ; };
 // arguments: a 160-bit F_q product is only ~80 multiply-adds, so calling it out of line costs
 // more than it computes; instead each Miller step is ONE out-of-line body with its ~20 products
 // inlined, fed from / writing back to LDS, returning just the line value (30 words).
-enum { DL_QX = 0, DL_QY = 3 * ND, DL_X = 6 * ND, DL_Y = 7 * ND, DL_Z = 8 * ND, DL_PX = 9 * ND, DL_PY = 10 * ND };
+enum { DL_QX = 0, DL_QY = DEG * ND, DL_X = 2 * DEG * ND, DL_Y = DL_X + ND, DL_Z = DL_X + 2 * ND, DL_PX = DL_X + 3 * ND, DL_PY = DL_X + 4 * ND };
 static PBC_DEV fq dl_get(int w) {
   fq r;
 #pragma unroll
-  for (int k = 0; k < ND; k++) r.v[k] = g_lds_d<ND>[(w + k) * D_LANES + threadIdx.x];
+  for (int k = 0; k < ND; k++) r.v[k] = g_lds_d<ND, DEG>[(w + k) * D_LANES + threadIdx.x];
   return r;
 }
 static PBC_DEV void dl_put(int w, const fq &a) {
 #pragma unroll
-  for (int k = 0; k < ND; k++) g_lds_d<ND>[(w + k) * D_LANES + threadIdx.x] = a.v[k];
+  for (int k = 0; k < ND; k++) g_lds_d<ND, DEG>[(w + k) * D_LANES + threadIdx.x] = a.v[k];
 }
 
 // l(Q) = (a Qx + c) + (b Qy) sqrt(v) with a, b, c in F_q (d_miller_evalfn, d_param.c:99-111);
 // Q is read from LDS, the result is packed for the return registers.  The 6 ND words of a line
-// value fit the 32 return VGPRs only for ND = 5; wider fields return the sqrt(v)-free half plus
-// b (4 ND words) and fetch the other half with a second, small out-of-line call.
-static constexpr bool kLineOneCall = 6 * ND <= 32;
+// value fit the 32 return VGPRs only for d = 3, ND = 5; otherwise the first call returns the
+// sqrt(v)-free half plus b ((d + 1) ND words) and a second, small out-of-line call the other half.
+static constexpr bool kLineOneCall = 2 * DEG * ND <= 32;
+static_assert((DEG + 1) * ND <= 32, "line value does not fit the return registers");
 static PBC_DEV v32 d_evalfn_pack(const fq &a, const fq &b, const fq &c) {
   v32 r;
 #pragma unroll
   for (int k = 0; k < 32; k++) r[k] = 0;
 #pragma unroll
-  for (int i = 0; i < 3; i++) {
+  for (int i = 0; i < DEG; i++) {
     fq t;
     fp_mul_inl<ND>(t, dl_get(DL_QX + ND * i), a);
     if (i == 0) fp_add<ND>(t, t, c);
@@ -238,12 +276,12 @@ static PBC_DEV v32 d_evalfn_pack(const fq &a, const fq &b, const fq &c) {
       fq u;
       fp_mul_inl<ND>(u, dl_get(DL_QY + ND * i), b);
 #pragma unroll
-      for (int k = 0; k < ND; k++) r[3 * ND + ND * i + k] = u.v[k];
+      for (int k = 0; k < ND; k++) r[DEG * ND + ND * i + k] = u.v[k];
     }
   }
   if constexpr (!kLineOneCall) {
 #pragma unroll
-    for (int k = 0; k < ND; k++) r[3 * ND + k] = b.v[k];
+    for (int k = 0; k < ND; k++) r[DEG * ND + k] = b.v[k];
   }
   return r;
 }
@@ -254,7 +292,7 @@ static __device__ __noinline__ v32 d_line_y_fn(v5 vb) {
 #pragma unroll
   for (int k = 0; k < 32; k++) r[k] = 0;
 #pragma unroll
-  for (int i = 0; i < 3; i++) {
+  for (int i = 0; i < DEG; i++) {
     fq u;
     fp_mul_inl<ND>(u, dl_get(DL_QY + ND * i), b);
 #pragma unroll
@@ -264,21 +302,21 @@ static __device__ __noinline__ v32 d_line_y_fn(v5 vb) {
 }
 static PBC_DEV void d_unpack(f6 &e0, v32 r) {
 #pragma unroll
-  for (int i = 0; i < 3; i++)
+  for (int i = 0; i < DEG; i++)
 #pragma unroll
     for (int k = 0; k < ND; k++) e0.x.c[i].v[k] = r[ND * i + k];
   if constexpr (kLineOneCall) {
 #pragma unroll
-    for (int i = 0; i < 3; i++)
+    for (int i = 0; i < DEG; i++)
 #pragma unroll
-      for (int k = 0; k < ND; k++) e0.y.c[i].v[k] = r[3 * ND + ND * i + k];
+      for (int k = 0; k < ND; k++) e0.y.c[i].v[k] = r[DEG * ND + ND * i + k];
   } else {
     fq b;
 #pragma unroll
-    for (int k = 0; k < ND; k++) b.v[k] = r[3 * ND + k];
+    for (int k = 0; k < ND; k++) b.v[k] = r[DEG * ND + k];
     v32 y = d_line_y_fn(to_vec<ND>(b));
 #pragma unroll
-    for (int i = 0; i < 3; i++)
+    for (int i = 0; i < DEG; i++)
 #pragma unroll
       for (int k = 0; k < ND; k++) e0.y.c[i].v[k] = y[ND * i + k];
   }
@@ -355,10 +393,10 @@ static __device__ __noinline__ v32 d_add_line_fn() {
   return d_evalfn_pack(la, Z3, lc);
 }
 
-static PBC_DEV void f3_load_be(f3 &r, const uint8_t *src) { for (int i = 0; i < 3; i++) fp_load_be<ND>(r.c[i], src + fpk<ND>().fbytes * i); }
-static PBC_DEV void f3_store_be(uint8_t *dst, const f3 &a) { for (int i = 0; i < 3; i++) fp_store_be<ND>(dst + fpk<ND>().fbytes * i, a.c[i]); }
+static PBC_DEV void f3_load_be(f3 &r, const uint8_t *src) { for (int i = 0; i < DEG; i++) fp_load_be<ND>(r.c[i], src + fpk<ND>().fbytes * i); }
+static PBC_DEV void f3_store_be(uint8_t *dst, const f3 &a) { for (int i = 0; i < DEG; i++) fp_store_be<ND>(dst + fpk<ND>().fbytes * i, a.c[i]); }
 
-// Miller function f_{r,P}(psi(Q)): G1 bytes x||y (2 x fbytes), G2 bytes x||y over F_q^3 (2 x 3 fbytes).
+// Miller function f_{r,P}(psi(Q)): G1 bytes x||y (2 x fbytes), G2 bytes x||y over F_q^d (2 x d fbytes).
 // Returns false when an input deserialises to O (curve_from_bytes, ecc/curve.c:609-623).
 static PBC_DEV bool d_miller_lane(f6 &v, const uint8_t *g1, const uint8_t *g2) {
   const int NB = (int) fpk<ND>().fbytes;
@@ -368,7 +406,7 @@ static PBC_DEV bool d_miller_lane(f6 &v, const uint8_t *g1, const uint8_t *g2) {
   fp_load_be<ND>(Px, g1);
   fp_load_be<ND>(Py, g1 + NB);
   f3_load_be(Qx, g2);
-  f3_load_be(Qy, g2 + 3 * NB);
+  f3_load_be(Qy, g2 + DEG * NB);
   bool valid;
   {
     // curve_is_valid_point (curve.c:57-77): E: y^2 = x^3 + a x + b; twist over F_q^3
@@ -391,13 +429,11 @@ static PBC_DEV bool d_miller_lane(f6 &v, const uint8_t *g1, const uint8_t *g2) {
   f3_mul_fq(Qx, Qx, dk(c_d.nqrinv));
   f3_mul_fq(Qy, Qy, dk(c_d.nqrinv2));
 #pragma unroll
-  for (int i = 0; i < 3; i++) { dl_put(DL_QX + ND * i, Qx.c[i]); dl_put(DL_QY + ND * i, Qy.c[i]); }
+  for (int i = 0; i < DEG; i++) { dl_put(DL_QX + ND * i, Qx.c[i]); dl_put(DL_QY + ND * i, Qy.c[i]); }
   dl_put(DL_X, Px); dl_put(DL_Y, Py); dl_put(DL_Z, one);
   dl_put(DL_PX, Px); dl_put(DL_PY, Py);
-#pragma unroll
-  for (int i = 0; i < 3; i++)
-#pragma unroll
-    for (int k = 0; k < ND; k++) { v.x.c[i].v[k] = (i == 0) ? one.v[k] : 0; v.y.c[i].v[k] = 0; }
+  f3_set_fq(v.x, one);
+  f3_sub(v.y, v.x, v.x);
   // cc_miller_no_denom_affine (d_param.c:321-422): tangent; [double; line+add]; square
   for (int m = c_d.rbits - 2;; m--) {
     f6 e0;
@@ -444,8 +480,7 @@ static PBC_DEV void d_final_exp(f6 &out, const f6 &m) {
   f3_dbl(P, h0);
   {
     fq o; fp_set<ND>(o, fpk<ND>().one); fp_dbl<ND>(o, o);
-#pragma unroll
-    for (int k = 0; k < ND; k++) { two.c[0].v[k] = o.v[k]; two.c[1].v[k] = 0; two.c[2].v[k] = 0; }
+    f3_set_fq(two, o);
   }
   v0 = two;
   v1 = P;
@@ -474,13 +509,11 @@ static PBC_DEV void d_final_exp(f6 &out, const f6 &m) {
 static PBC_DEV void d_store_gt(uint8_t *gt, f6 &out, bool valid) {
   if (!valid) {                        // GT identity
     fq one; fp_set<ND>(one, fpk<ND>().one);
-#pragma unroll
-    for (int i = 0; i < 3; i++)
-#pragma unroll
-      for (int k = 0; k < ND; k++) { out.x.c[i].v[k] = (i == 0) ? one.v[k] : 0; out.y.c[i].v[k] = 0; }
+    f3_set_fq(out.x, one);
+    f3_sub(out.y, out.x, out.x);
   }
   f3_store_be(gt, out.x);
-  f3_store_be(gt + 3 * fpk<ND>().fbytes, out.y);
+  f3_store_be(gt + DEG * fpk<ND>().fbytes, out.y);
 }
 
 // element_pairing (cc_pairing) / element_prod_pairing (cc_pairings_affine, d_param.c:710-736:
@@ -490,7 +523,7 @@ static PBC_DEV void d_prod_pairing_lane(uint8_t *gt, const uint8_t *g1, const ui
   bool valid = d_miller_lane(F, g1, g2);
   for (int j = 1; j < k; j++) {
     f6 f;
-    valid &= d_miller_lane(f, g1 + (size_t) j * 2 * fpk<ND>().fbytes, g2 + (size_t) j * 6 * fpk<ND>().fbytes);
+    valid &= d_miller_lane(f, g1 + (size_t) j * 2 * fpk<ND>().fbytes, g2 + (size_t) j * 2 * DEG * fpk<ND>().fbytes);
     f6_mul(F, F, f);
   }
   d_final_exp(out, F);
@@ -501,18 +534,22 @@ static PBC_DEV void d_prod_pairing_lane(uint8_t *gt, const uint8_t *g1, const ui
 // stage 1: everything that needs only F_q arithmetic
 static PBC_DEV void init_stage1(DConst *out, const DRaw &raw, const DConst &base) {
   DConst C = base;
-  fq r2, t, a, b, v, cf[3];
+  fq r2, t, a, b, v, cf[DEG];
   fp_set<ND>(r2, fpk<ND>().r2);
   fp_set<ND>(t, raw.a); fp_mul<ND>(a, t, r2);
   fp_set<ND>(t, raw.b); fp_mul<ND>(b, t, r2);
   fp_set<ND>(t, raw.nqr); fp_mul<ND>(v, t, r2);
-  for (int i = 0; i < 3; i++) { fp_set<ND>(t, raw.coeff[i]); fp_mul<ND>(cf[i], t, r2); }
-  // x^3 = -(c0 + c1 x + c2 x^2);  x^4 = x * x^3 reduced
-  fq x3[3], x4[3];
-  for (int i = 0; i < 3; i++) fp_neg<ND>(x3[i], cf[i]);
-  fp_mul<ND>(x4[0], x3[2], x3[0]);
-  fp_mul<ND>(t, x3[2], x3[1]); fp_add<ND>(x4[1], x3[0], t);
-  fp_mul<ND>(t, x3[2], x3[2]); fp_add<ND>(x4[2], x3[1], t);
+  for (int i = 0; i < DEG; i++) { fp_set<ND>(t, raw.coeff[i]); fp_mul<ND>(cf[i], t, r2); }
+  // x^d = -(c0 + c1 x + ...);  x^(d+j) = x * x^(d+j-1) reduced (compute_x_powers, poly.c:1302-1333)
+  fq xp[DEG - 1][DEG];
+  for (int i = 0; i < DEG; i++) fp_neg<ND>(xp[0][i], cf[i]);
+  for (int j = 1; j < DEG - 1; j++) {
+    fp_mul<ND>(xp[j][0], xp[j - 1][DEG - 1], xp[0][0]);
+    for (int i = 1; i < DEG; i++) {
+      fp_mul<ND>(t, xp[j - 1][DEG - 1], xp[0][i]);
+      fp_add<ND>(xp[j][i], xp[j - 1][i - 1], t);
+    }
+  }
   fq vi, vi2, v2, ta, tb;
   fp_inv<ND>(vi, v);
   fp_sqr<ND>(vi2, vi);
@@ -523,39 +560,45 @@ static PBC_DEV void init_stage1(DConst *out, const DRaw &raw, const DConst &base
   for (int k = 0; k < ND; k++) {
     C.A[k] = a.v[k]; C.B[k] = b.v[k]; C.nqr[k] = v.v[k]; C.nqrinv[k] = vi.v[k]; C.nqrinv2[k] = vi2.v[k];
     C.ta[k] = ta.v[k]; C.tb[k] = tb.v[k];
-    for (int i = 0; i < 3; i++) { C.xpwr[0][i][k] = x3[i].v[k]; C.xpwr[1][i][k] = x4[i].v[k]; }
+    for (int j = 0; j < DEG - 1; j++)
+      for (int i = 0; i < DEG; i++) C.xpwr[j][i][k] = xp[j][i].v[k];
   }
   *out = C;
 }
-// stage 2 (c_d now holds stage 1): x^q by square-and-multiply in F_q^3, then its square
+// stage 2 (c_d now holds stage 1): x^q by square-and-multiply in F_q^d, then its powers
 static PBC_DEV void init_stage2(DConst *out, const DRaw &raw) {
   DConst C = c_d;
-  f3 acc, x;
+  f3 acc, x, pw;
   fq one, zero;
   fp_set<ND>(one, fpk<ND>().one);
   for (int k = 0; k < ND; k++) zero.v[k] = 0;
-  acc.c[0] = one; acc.c[1] = zero; acc.c[2] = zero;
-  x.c[0] = zero; x.c[1] = one; x.c[2] = zero;
+  f3_set_fq(acc, one);
+  f3_set_fq(x, zero);
+  x.c[1] = one;
   for (int i = raw.qbits - 1; i >= 0; i--) {
     f3_sqr(acc, acc);
     if ((raw.q[i >> 5] >> (i & 31)) & 1) f3_mul(acc, acc, x);
   }
-  f3 sq;
-  f3_sqr(sq, acc);
-  for (int i = 0; i < 3; i++)
-    for (int k = 0; k < ND; k++) { C.xpowq[i][k] = acc.c[i].v[k]; C.xpowq2[i][k] = sq.c[i].v[k]; }
+  pw = acc;
+  for (int j = 0; j < DEG - 1; j++) {
+    for (int i = 0; i < DEG; i++)
+      for (int k = 0; k < ND; k++) C.xpowq[j][i][k] = pw.c[i].v[k];
+    f3_mul(pw, pw, acc);
+  }
   *out = C;
 }
+};  // struct TypeMNT
 
-};  // struct TypeD
+template <int ND> using TypeD = TypeMNT<ND, 3>;   // MNT, k = 6
+typedef TypeMNT<5, 5> TypeG;                      // Freeman, k = 10 (g149.param: 149-bit q)
 
-template <int ND> __global__ void d_init_stage1(DConst *out, DRaw raw, DConst base) {
+template <int ND, int DEG> __global__ void d_init_stage1(DConst *out, DRaw raw, DConst base) {
   if (threadIdx.x || blockIdx.x) return;
-  TypeD<ND>::init_stage1(out, raw, base);
+  TypeMNT<ND, DEG>::init_stage1(out, raw, base);
 }
-template <int ND> __global__ void d_init_stage2(DConst *out, DRaw raw) {
+template <int ND, int DEG> __global__ void d_init_stage2(DConst *out, DRaw raw) {
   if (threadIdx.x || blockIdx.x) return;
-  TypeD<ND>::init_stage2(out, raw);
+  TypeMNT<ND, DEG>::init_stage2(out, raw);
 }
 
 }  // namespace pbc

@@ -101,16 +101,17 @@ __global__ void __launch_bounds__(kBlock, PBC_A_WAVES) a_pp_apply_kernel(uint8_t
   }
 }
 
-// Type D: one k-term product (k = 1: a single pairing) per lane.  With fb = fixed byte length of
-// F_q, G1 records are 2 fb, G2 and GT 6 fb bytes (40 / 120 / 120 B for d159.param).
-template <int N>
+// Types D and G: one k-term product (k = 1: a single pairing) per lane.  With fb = fixed byte length
+// of F_q and d = k/2, G1 records are 2 fb, G2 and GT 2 d fb bytes (40 / 120 / 120 B for d159.param,
+// 38 / 190 / 190 B for g149.param).
+template <int N, int DEG>
 __global__ void __launch_bounds__(kBlock, PBC_DF_WAVES) d_prod_pairing_kernel(uint8_t *gt, const uint8_t *g1,
                                                                  const uint8_t *g2, size_t n, int k) {
   size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
   size_t ld = idx < n ? idx : n - 1;
-  const int fb = (int) fpk<N>().fbytes, L1 = 2 * fb, L2 = 6 * fb, LT = 6 * fb;
-  __attribute__((aligned(4))) uint8_t out[24 * N];
-  TypeD<N>::d_prod_pairing_lane(out, g1 + ld * k * L1, g2 + ld * k * L2, k);
+  const int fb = (int) fpk<N>().fbytes, L1 = 2 * fb, L2 = 2 * DEG * fb, LT = 2 * DEG * fb;
+  __attribute__((aligned(4))) uint8_t out[8 * DEG * N];
+  TypeMNT<N, DEG>::d_prod_pairing_lane(out, g1 + ld * k * L1, g2 + ld * k * L2, k);
   if (idx < n) {
     if ((LT & 3) == 0) {
       uint32_t *dst = reinterpret_cast<uint32_t *>(gt + idx * LT);
@@ -176,9 +177,13 @@ __global__ void __launch_bounds__(kBlock, 2) gt_op_kernel(int type, int op, uint
     if (op == 0) a_gt_mul_lane<N>(o, x, b + idx * lenT); else a_gt_pow_lane<N>(o, x, b + idx * zlen, zlen);
   } else {
     if (type == 'd') {
-      if (op == 0) d_gt_mul_lane<N>(o, x, b + idx * lenT); else d_gt_pow_lane<N>(o, x, b + idx * zlen, zlen);
+      if (op == 0) d_gt_mul_lane<N, 3>(o, x, b + idx * lenT); else d_gt_pow_lane<N, 3>(o, x, b + idx * zlen, zlen);
     } else if constexpr (N == ND) {
-      if (op == 0) f_gt_mul_lane(o, x, b + idx * lenT); else f_gt_pow_lane(o, x, b + idx * zlen, zlen);
+      if (type == 'g') {
+        if (op == 0) d_gt_mul_lane<N, 5>(o, x, b + idx * lenT); else d_gt_pow_lane<N, 5>(o, x, b + idx * zlen, zlen);
+      } else {
+        if (op == 0) f_gt_mul_lane(o, x, b + idx * lenT); else f_gt_pow_lane(o, x, b + idx * zlen, zlen);
+      }
     }
   }
 }
@@ -363,7 +368,10 @@ extern "C" int pbc_hip_pairing_init_set_buf(pbc_hip_pairing_t **out, const char 
     rc = init_type_a(P, param, len);
   } else if (type == "d") {
     P->type = 'd';
-    rc = init_type_d(P, param, len);
+    rc = init_type_d(P, param, len, 3);
+  } else if (type == "g") {
+    P->type = 'g';
+    rc = init_type_d(P, param, len, 5);
   } else if (type == "f") {
     P->type = 'f';
     rc = init_type_f(P, param, len);
@@ -396,13 +404,14 @@ extern "C" double pbc_hip_algorithmic_macs_per_unit(const pbc_hip_pairing_t *p, 
   return p->fq_muls_single * per_mul;
 }
 
-// Type D kernels exist per field width; N is the compile-time word count inside EXPR
-#define PBC_DISPATCH_D(nl, ...)                               \
-  switch (nl) {                                               \
-    case 5: { constexpr int N = 5; __VA_ARGS__; } break;             \
-    case 6: { constexpr int N = 6; __VA_ARGS__; } break;             \
-    case 7: { constexpr int N = 7; __VA_ARGS__; } break;             \
-    default: return fail("internal: no type d kernel for %d-word fields", (int) (nl)); \
+// Type D / G kernels exist per (field width, d); N and DEG are compile-time inside the expression
+#define PBC_DISPATCH_D(P_, ...)                                                        \
+  switch ((P_)->nlimb * 8 + (P_)->deg) {                                               \
+    case 5 * 8 + 3: { constexpr int N = 5, DEG = 3; __VA_ARGS__; } break;              \
+    case 6 * 8 + 3: { constexpr int N = 6, DEG = 3; __VA_ARGS__; } break;              \
+    case 7 * 8 + 3: { constexpr int N = 7, DEG = 3; __VA_ARGS__; } break;              \
+    case 5 * 8 + 5: { constexpr int N = 5, DEG = 5; __VA_ARGS__; } break;              \
+    default: return fail("internal: no type d/g kernel for %d-word fields, degree %d", (P_)->nlimb, (P_)->deg); \
   }
 
 // any built-in field width (PBC_FOR_EACH_N)
@@ -426,14 +435,14 @@ static int upload_constants(pbc_hip_pairing_s *P, hipStream_t s) {
   }
   if (P->type == 'a')
     HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_a), &P->a, sizeof P->a, 0, hipMemcpyHostToDevice, s));
-  if (P->type == 'd') {
+  if (P->type == 'd' || P->type == 'g') {
     if (!P->dev_ready) {
       // one-time derivation of the tower constants on the device (two single-lane kernels)
       DConst *dbuf;
       HIP_TRY(hipMalloc(&dbuf, sizeof(DConst)));
-      PBC_DISPATCH_D(P->nlimb, hipLaunchKernelGGL(d_init_stage1<N>, dim3(1), dim3(64), 0, s, dbuf, P->draw, P->dconst));
+      PBC_DISPATCH_D(P, hipLaunchKernelGGL((d_init_stage1<N, DEG>), dim3(1), dim3(64), 0, s, dbuf, P->draw, P->dconst));
       HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_d), dbuf, sizeof(DConst), 0, hipMemcpyDeviceToDevice, s));
-      PBC_DISPATCH_D(P->nlimb, hipLaunchKernelGGL(d_init_stage2<N>, dim3(1), dim3(64), 0, s, dbuf, P->draw));
+      PBC_DISPATCH_D(P, hipLaunchKernelGGL((d_init_stage2<N, DEG>), dim3(1), dim3(64), 0, s, dbuf, P->draw));
       HIP_TRY(hipMemcpyAsync(&P->dconst, dbuf, sizeof(DConst), hipMemcpyDeviceToHost, s));
       HIP_TRY(hipStreamSynchronize(s));
       (void) hipFree(dbuf);
@@ -474,8 +483,8 @@ static int launch_pairing(pbc_hip_pairing_s *P, void *d_gt, const void *d_g1, co
   if (P->type == 'a') {
     hipLaunchKernelGGL(a_pairing_kernel<16>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
                        (const uint8_t *) d_g1, (const uint8_t *) d_g2, n);
-  } else if (P->type == 'd') {
-    PBC_DISPATCH_D(P->nlimb, hipLaunchKernelGGL(d_prod_pairing_kernel<N>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
+  } else if (P->type == 'd' || P->type == 'g') {
+    PBC_DISPATCH_D(P, hipLaunchKernelGGL((d_prod_pairing_kernel<N, DEG>), dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
                                                 (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, 1));
   } else if (P->type == 'f') {
     hipLaunchKernelGGL(f_prod_pairing_kernel, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
@@ -566,8 +575,8 @@ static int launch_prod(pbc_hip_pairing_s *P, void *d_gt, const void *d_g1, const
   if (P->type == 'a') {
     hipLaunchKernelGGL(a_prod_pairing_kernel<16>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
                        (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k);
-  } else if (P->type == 'd') {
-    PBC_DISPATCH_D(P->nlimb, hipLaunchKernelGGL(d_prod_pairing_kernel<N>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
+  } else if (P->type == 'd' || P->type == 'g') {
+    PBC_DISPATCH_D(P, hipLaunchKernelGGL((d_prod_pairing_kernel<N, DEG>), dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
                                                 (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k));
   } else if (P->type == 'f') {
     hipLaunchKernelGGL(f_prod_pairing_kernel, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
@@ -738,8 +747,8 @@ extern "C" int pbc_hip_diag_stage(pbc_hip_pairing_t *P, int stage, uint8_t *out,
   if (stage == 0) {
     if (upload_constants(P, 0)) return 1;
     HIP_TRY(hipDeviceSynchronize());
-    const void *src = P->type == 'd' ? (const void *) &P->dconst : P->type == 'f' ? (const void *) &P->fconst : (const void *) &P->a;
-    size_t len = P->type == 'd' ? sizeof P->dconst : P->type == 'f' ? sizeof P->fconst : sizeof P->a;
+    const void *src = (P->type == 'd' || P->type == 'g') ? (const void *) &P->dconst : P->type == 'f' ? (const void *) &P->fconst : (const void *) &P->a;
+    size_t len = (P->type == 'd' || P->type == 'g') ? sizeof P->dconst : P->type == 'f' ? sizeof P->fconst : sizeof P->a;
     memcpy(out, src, len < out_len ? len : out_len);
     return 0;
   }

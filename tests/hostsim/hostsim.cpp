@@ -21,16 +21,18 @@ static void set_fpk(pbc_hip_pairing_s *P) {
     case 7: { constexpr int N = 7; __VA_ARGS__; } break;     \
     case 16: { constexpr int N = 16; __VA_ARGS__; } break;   \
   }
-#define HS_DISPATCH_D(nl, ...)                        \
-  switch (nl) {                                       \
-    case 5: { constexpr int N = 5; __VA_ARGS__; } break;     \
-    case 6: { constexpr int N = 6; __VA_ARGS__; } break;     \
-    case 7: { constexpr int N = 7; __VA_ARGS__; } break;     \
+// types d / g: N words, degree DEG
+#define HS_DISPATCH_D(P_, ...)                                                \
+  switch ((P_)->nlimb * 8 + (P_)->deg) {                                      \
+    case 5 * 8 + 3: { constexpr int N = 5, DEG = 3; __VA_ARGS__; } break;     \
+    case 6 * 8 + 3: { constexpr int N = 6, DEG = 3; __VA_ARGS__; } break;     \
+    case 7 * 8 + 3: { constexpr int N = 7, DEG = 3; __VA_ARGS__; } break;     \
+    case 5 * 8 + 5: { constexpr int N = 5, DEG = 5; __VA_ARGS__; } break;     \
   }
 static void activate(pbc_hip_pairing_s *P) {
   set_fpk(P);
   if (P->type == 'a') c_a = P->a;
-  if (P->type == 'd') c_d = P->dconst;
+  if (P->type == 'd' || P->type == 'g') c_d = P->dconst;
   if (P->type == 'f') c_f = P->fconst;
   CurveK C;
   fill_curve(P, C);
@@ -45,15 +47,16 @@ void *hostsim_init(const char *param, size_t len) {
   pbc_hip_pairing_s *P = new pbc_hip_pairing_s();
   int rc = 1;
   if (type == "a") { P->type = 'a'; rc = init_type_a(P, param, len); }
-  else if (type == "d") { P->type = 'd'; rc = init_type_d(P, param, len); }
+  else if (type == "d") { P->type = 'd'; rc = init_type_d(P, param, len, 3); }
+  else if (type == "g") { P->type = 'g'; rc = init_type_d(P, param, len, 5); }
   else if (type == "f") { P->type = 'f'; rc = init_type_f(P, param, len); }
   if (rc) { delete P; return nullptr; }
   set_fpk(P);
-  if (P->type == 'd') {
+  if (P->type == 'd' || P->type == 'g') {
     DConst tmp;
-    HS_DISPATCH_D(P->nlimb, TypeD<N>::init_stage1(&tmp, P->draw, P->dconst));
+    HS_DISPATCH_D(P, TypeMNT<N, DEG>::init_stage1(&tmp, P->draw, P->dconst));
     c_d = tmp;
-    HS_DISPATCH_D(P->nlimb, TypeD<N>::init_stage2(&tmp, P->draw));
+    HS_DISPATCH_D(P, TypeMNT<N, DEG>::init_stage2(&tmp, P->draw));
     c_d = tmp;
     P->dconst = tmp;
   }
@@ -82,7 +85,7 @@ int hostsim_prod_pairing(void *h, uint8_t *gt, const uint8_t *g1, const uint8_t 
     const uint8_t *a = g1 + u * k * P->len1, *b = g2 + u * k * P->len2;
     uint8_t *o = gt + u * P->lenT;
     if (P->type == 'a') a_prod_pairing_lane<16>(o, a, b, k, lds, 1);
-    else if (P->type == 'd') { HS_DISPATCH_D(P->nlimb, TypeD<N>::d_prod_pairing_lane(o, a, b, k)); }
+    else if (P->type == 'd' || P->type == 'g') { HS_DISPATCH_D(P, TypeMNT<N, DEG>::d_prod_pairing_lane(o, a, b, k)); }
     else f_prod_pairing_lane(o, a, b, k);
   }
   return 0;
@@ -108,7 +111,7 @@ int hostsim_group(void *h, int what, uint8_t *out, const uint8_t *a, const uint8
       uint8_t *o = out + i * P->lenT;
       const uint8_t *x = a + i * P->lenT, *y = b + i * (what == 1 ? P->lenT : P->len_zr);
       if (P->type == 'a') { if (what == 1) a_gt_mul_lane<16>(o, x, y); else a_gt_pow_lane<16>(o, x, y, P->len_zr); }
-      else if (P->type == 'd') { HS_DISPATCH_D(P->nlimb, if (what == 1) d_gt_mul_lane<N>(o, x, y); else d_gt_pow_lane<N>(o, x, y, P->len_zr)); }
+      else if (P->type == 'd' || P->type == 'g') { HS_DISPATCH_D(P, if (what == 1) d_gt_mul_lane<N, DEG>(o, x, y); else d_gt_pow_lane<N, DEG>(o, x, y, P->len_zr)); }
       else { if (what == 1) f_gt_mul_lane(o, x, y); else f_gt_pow_lane(o, x, y, P->len_zr); }
     }
   }
@@ -127,8 +130,8 @@ int hostsim_stage(void *h, int stage, uint8_t *out, size_t out_len, const uint8_
   pbc_hip_pairing_s *P = (pbc_hip_pairing_s *) h;
   activate(P);
   if (stage == 0) {
-    const void *src = P->type == 'd' ? (const void *) &P->dconst : P->type == 'f' ? (const void *) &P->fconst : (const void *) &P->a;
-    size_t len = P->type == 'd' ? sizeof P->dconst : P->type == 'f' ? sizeof P->fconst : sizeof P->a;
+    const void *src = (P->type == 'd' || P->type == 'g') ? (const void *) &P->dconst : P->type == 'f' ? (const void *) &P->fconst : (const void *) &P->a;
+    size_t len = (P->type == 'd' || P->type == 'g') ? sizeof P->dconst : P->type == 'f' ? sizeof P->fconst : sizeof P->a;
     memcpy(out, src, len < out_len ? len : out_len);
     return (int) len;
   }

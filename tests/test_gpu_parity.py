@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 import oracle
-from conftest import golden, OTHER_D, param_value
+from conftest import golden, OTHER, FILES_OF, param_value
 
 pytestmark = pytest.mark.gpu
 
@@ -339,23 +339,33 @@ def test_pairing_pp_matches_element_pairing(hip_a, oracle_a):
 
 
 # ---- the other shipped type d parameter files: 175..224-bit q, 6 / 7 word fields, 22..28-byte
-# ---- coordinates (not whole words for d277699-175-167, d105171-196-185, d201) -----------------
-@pytest.mark.parametrize("d", OTHER_D)
-def test_other_type_d_params_match_reference_vectors(hips, d):
+# ---- coordinates (not whole words for d277699-175-167, d105171-196-185, d201), and type g
+# ---- (g149.param: k = 10, F_q^5 / F_q^10, 19-byte coordinates) --------------------------------
+@pytest.mark.parametrize("d", OTHER)
+def test_other_type_d_and_g_params_match_reference_vectors(hips, d):
     H = hips[d]
     fb = (param_value(d, "q").bit_length() + 7) // 8
-    assert (H.length_in_bytes_G1, H.length_in_bytes_G2, H.length_in_bytes_GT) == (2 * fb, 6 * fb, 6 * fb)
-    for suffix in ("_rand12.vec", "_edge8.vec"):
-        v = golden(d + suffix)
-        assert np.array_equal(H.element_pairing(v.g1, v.g2), v.gt), suffix
-    v = golden(d + "_prod3x4_edge.vec")
+    deg = param_value(d, "k") // 2
+    assert (H.length_in_bytes_G1, H.length_in_bytes_G2, H.length_in_bytes_GT) == (2 * fb, 2 * deg * fb, 2 * deg * fb)
+    for name in FILES_OF[d][:2]:
+        v = golden(name)
+        assert np.array_equal(H.element_pairing(v.g1, v.g2), v.gt), name
+    v = golden(FILES_OF[d][2])
     assert np.array_equal(H.element_prod_pairing(v.g1, v.g2, v.k), v.gt)
 
 
-@pytest.mark.parametrize("d", OTHER_D)
-def test_other_type_d_params_cross_pairs_fq_and_group_ops_vs_oracle(hips, oracles, d):
+def test_type_g_chain_and_products(hips):
+    H = hips["g149"]
+    v = golden("g149_chain64.vec")
+    assert np.array_equal(H.element_pairing(v.g1, v.g2), v.gt)
+    v = golden("g149_prod4x3.vec")
+    assert np.array_equal(H.element_prod_pairing(v.g1, v.g2, v.k), v.gt)
+
+
+@pytest.mark.parametrize("d", OTHER)
+def test_other_type_d_and_g_params_cross_pairs_fq_and_group_ops_vs_oracle(hips, oracles, d):
     H, O = hips[d], oracles[d]
-    v = golden(d + "_rand12.vec")
+    v = golden(FILES_OF[d][0])
     q, r = param_value(d, "q"), param_value(d, "r")
     fb, zl = (q.bit_length() + 7) // 8, (r.bit_length() + 7) // 8
     # all 144 (P_i, Q_j) combinations, a whole block plus a ragged tail

@@ -5,7 +5,7 @@ mirror for GPU-less bring-up, not a product path: libpbc_hip.so never contains i
 import numpy as np
 import pytest
 
-from conftest import golden, _param, PARAM_OF, OTHER_D, key_of, param_value
+from conftest import golden, _param, PARAM_OF, OTHER, FILES_OF, key_of, param_value
 
 hostsim = pytest.importorskip("hostsim")
 
@@ -23,7 +23,7 @@ def sims():
     ("a_kat.vec", 1), ("a_rand32.vec", 6), ("a_edge20.vec", 20), ("a_prod2x8.vec", 4), ("a_prod3x10_edge.vec", 10),
     ("d_rand32.vec", 6), ("d_edge20.vec", 20), ("d_prod16x4.vec", 2), ("d_prod3x10_edge.vec", 10),
     ("f_rand16.vec", 3), ("f_edge10.vec", 10), ("f_prod3x5_edge.vec", 5),
-] + [(d + suffix, 4) for d in OTHER_D for suffix in ("_rand12.vec", "_edge8.vec", "_prod3x4_edge.vec")])
+] + [(name, 4) for d in OTHER for name in FILES_OF[d]] + [("g149_prod4x3.vec", 1)])
 def test_kernel_source_on_host_matches_reference(sims, name, count):
     v = golden(name)
     n = min(count, v.n)
@@ -32,7 +32,7 @@ def test_kernel_source_on_host_matches_reference(sims, name, count):
 
 
 @pytest.mark.parametrize("t,q", [("a", None), ("d", 625852803282871856053922297323874661378036491717)]
-                         + [(d, None) for d in OTHER_D])
+                         + [(d, None) for d in OTHER])
 def test_kernel_fq_ops_on_host(sims, oracles, t, q):
     if q is None:
         q = param_value(t, "q")
@@ -68,7 +68,7 @@ def test_pairing_pp_on_host(sims, oracles):
 
 
 @pytest.mark.parametrize("t,name", [("a", "a_rand32.vec"), ("d", "d_rand32.vec"), ("f", "f_rand16.vec")]
-                         + [(d, d + "_rand12.vec") for d in OTHER_D])
+                         + [(d, FILES_OF[d][0]) for d in OTHER])
 def test_group_ops_on_host(sims, oracles, t, name):
     """element_mul_zn on G1, element_mul / element_pow_zn on GT vs the oracle."""
     v = golden(name)

@@ -35,7 +35,7 @@ int pbc_hip_pairing_init_set_buf(pbc_hip_pairing_t **out, const char *param, siz
 /* Replaces pairing_clear (include/pbc_pairing.h:109-116). */
 void pbc_hip_pairing_clear(pbc_hip_pairing_t *p);
 
-/* 'a', 'd' or 'f' (the "type" key, ecc/param.c:172-205). */
+/* 'a', 'd', 'f', 'g', or '1' for a1 (the "type" key, ecc/param.c:172-205). */
 int pbc_hip_pairing_type(const pbc_hip_pairing_t *p);
 /* Replace pairing_length_in_bytes_{G1,G2,GT} (include/pbc_pairing.h:183-238). */
 int pbc_hip_pairing_length_in_bytes_G1(const pbc_hip_pairing_t *p);

@@ -17,7 +17,7 @@
 #include <string.h>
 
 typedef unsigned __int128 u128;
-#define MAXL 8                       /* 512-bit moduli at most (Type A a.param) */
+#define MAXL 17                      /* 1088-bit moduli at most (Type A1 a1.param: 1033-bit p) */
 
 static uint64_t g_mul_count, g_inv_count;
 void oracle_counters(uint64_t *mul, uint64_t *inv, int reset) {
@@ -326,6 +326,7 @@ struct oracle_pairing {
   int len1, len2, lenT;
   /* type A (ecc/a_param.c:30-34) */
   int exp2, exp1, sign1;
+  int a1;                /* type A1 (ecc/a_param.c:1564-2321): type 'a' with r = n composite, h = l */
   fe ca, cb;             /* curve a, b in Fq (A: a=1, b=0, a_param.c:1450-1452) */
   struct dctx *D;        /* type D (ecc/d_param.c:40-51) */
   struct fctx *Fx;       /* type F (ecc/f_param.c:35-45) */
@@ -382,6 +383,18 @@ static int init_a(oracle_pairing *P, const char *txt, size_t len) {
   return 0;
 }
 
+/* a1_init_pairing (ecc/a_param.c:2230-2273) + pbc_param_init_a1 (:2289-2298): y^2 = x^3 + x over F_p,
+ * group order r = n (composite), cofactor phikonr = l = (p + 1)/n */
+static int init_a1(oracle_pairing *P, const char *txt, size_t len) {
+  if (kv_big(txt, len, "p", &P->q) || kv_big(txt, len, "n", &P->r) || kv_big(txt, len, "l", &P->h)) return 1;
+  if (fp_init(&P->Fq, &P->q)) return 1;
+  P->a1 = 1;
+  P->ca = P->Fq.R;
+  P->cb = P->Fq.zero;
+  P->len1 = P->len2 = P->lenT = 2 * P->Fq.nbytes;
+  return 0;
+}
+
 int oracle_pairing_init(oracle_pairing **out, const char *txt, size_t len) {
   char tb[16];
   if (!len) len = strlen(txt);
@@ -391,6 +404,7 @@ int oracle_pairing_init(oracle_pairing **out, const char *txt, size_t len) {
   P->type = tb[0];
   int rc = 1;
   if (!strcmp(tb, "a")) rc = init_a(P, txt, len);
+  else if (!strcmp(tb, "a1")) rc = init_a1(P, txt, len);
   else if (!strcmp(tb, "d") || !strcmp(tb, "g")) rc = init_d(P, txt, len);
   else if (!strcmp(tb, "f")) rc = init_f(P, txt, len);
   if (rc) { free(P); return 1; }
@@ -497,6 +511,122 @@ static void a_tateexp(const fpctx *F, fe2 *out, fe2 *in, const big *cofactor) {
   fp_neg(F, &in->y, &in->y);
   fi_mul(F, in, in, &temp);
   a_lucas_odd(F, out, in, cofactor);
+}
+
+/* compute_abc_line_proj (a_param.c:1820-1837): chord through the Jacobian V and the affine V1 */
+static void a1_abc_line_proj(const fpctx *F, fe *a, fe *b, fe *c, const fe *Vx, const fe *Vy,
+                             const fe *z, const fe *z2, const fe *V1x, const fe *V1y) {
+  fe e0;
+  fp_mul(F, c, z, z2);
+  fp_mul(F, &e0, V1y, c);
+  fp_sub(F, a, Vy, &e0);
+  fp_mul(F, b, c, V1x);
+  fp_mul(F, &e0, Vx, z);
+  fp_sub(F, b, b, &e0);
+  fp_mul(F, c, b, V1y);
+  fp_mul(F, &e0, a, V1x);
+  fp_add(F, c, c, &e0);
+  fp_neg(F, c, c);
+}
+/* the closing lines of a1_pairing_proj / a1_pairings_affine (a_param.c:1986-1994, :2167-2175):
+ * f^(p-1) = conj(f)/f, then element_pow_mpz by phikonr = l (generic_pow_mpz field.c:113-126) */
+static void a1_tateexp(const fpctx *F, fe2 *out, fe2 *f, const big *l) {
+  fe2 f0, acc;
+  fi_inv(F, &f0, f);
+  fp_neg(F, &f->y, &f->y);
+  fi_mul(F, f, f, &f0);
+  acc.x = F->R; acc.y = F->zero;
+  for (int i = big_bits(l) - 1; i >= 0; i--) {
+    fi_sqr(F, &acc, &acc);
+    if (big_bit(l, i)) fi_mul(F, &acc, &acc, f);
+  }
+  *out = acc;
+}
+/* a1_pairing_proj (a_param.c:1840-2015): the default Type-A1 map (:2261): plain double-and-add
+ * over the bits of n in Jacobian coordinates, mixed addition of the affine in1 */
+static void a1_pairing_proj(const oracle_pairing *P, fe2 *out, const pt *in1, const pt *in2) {
+  const fpctx *F = &P->Fq;
+  fe Vx = in1->x, Vy = in1->y, z = F->R, z2 = F->R;
+  const fe *Px = &in1->x, *Py = &in1->y, *Qx = &in2->x, *Qy = &in2->y;
+  fe a, b, c, e0;
+  fe2 f, f0;
+  f.x = F->R; f.y = F->zero;
+  int m = big_bits(&P->r);
+  m = m > 2 ? m - 2 : 0;
+  for (;;) {
+    a_abc_tangent_proj(F, &a, &b, &c, &Vx, &Vy, &z, &z2);
+    a_evalfn(F, &f0, &a, &b, &c, Qx, Qy);
+    fi_mul(F, &f, &f, &f0);
+    if (!m) break;
+    { /* proj_double (a_param.c:1900-1938) */
+      fe *e1 = &a, *e2 = &b, *e3 = &c;
+      fp_sqr(F, &e0, &Vx); fp_dbl(F, e1, &e0); fp_add(F, &e0, e1, &e0); fp_sqr(F, e1, &z2); fp_add(F, &e0, &e0, e1);
+      fp_mul(F, &z, &Vy, &z); fp_dbl(F, &z, &z); fp_sqr(F, &z2, &z);
+      fp_sqr(F, e2, &Vy); fp_mul(F, e1, &Vx, e2); fp_dbl(F, e1, e1); fp_dbl(F, e1, e1);
+      fp_dbl(F, e3, e1); fp_sqr(F, &Vx, &e0); fp_sub(F, &Vx, &Vx, e3);
+      fp_sqr(F, e2, e2); fp_dbl(F, e2, e2); fp_dbl(F, e2, e2); fp_dbl(F, e2, e2);
+      fp_sub(F, e1, e1, &Vx); fp_mul(F, &e0, &e0, e1); fp_sub(F, &Vy, &e0, e2);
+    }
+    if (big_bit(&P->r, m)) {
+      a1_abc_line_proj(F, &a, &b, &c, &Vx, &Vy, &z, &z2, Px, Py);
+      a_evalfn(F, &f0, &a, &b, &c, Qx, Qy);
+      fi_mul(F, &f, &f, &f0);
+      { /* proj_add (a_param.c:1868-1898) */
+        fe *e1 = &a, *e2 = &b, *e3 = &c;
+        fp_mul(F, &e0, Px, &z2); fp_sub(F, &e0, &e0, &Vx);
+        fp_sqr(F, e1, &e0);
+        fp_mul(F, e2, &z, &z2); fp_mul(F, e2, e2, Py); fp_sub(F, e2, e2, &Vy);
+        z2 = Vx;
+        fp_sqr(F, &Vx, e2);
+        fp_mul(F, e3, &e0, e1);
+        fp_sub(F, &Vx, &Vx, e3);
+        fp_dbl(F, e3, &z2); fp_mul(F, e3, e3, e1);
+        fp_sub(F, &Vx, &Vx, e3);
+        fp_mul(F, e3, &z2, e1); fp_sub(F, e3, e3, &Vx); fp_mul(F, e3, e3, e2);
+        fp_mul(F, e2, &e0, e1); fp_mul(F, e2, e2, &Vy);
+        fp_sub(F, &Vy, e3, e2);
+        fp_mul(F, &z, &z, &e0);
+        fp_sqr(F, &z2, &z);
+      }
+    }
+    m--;
+    fi_sqr(F, &f, &f);
+  }
+  a1_tateexp(F, out, &f, &P->h);
+}
+/* a1_pairings_affine (a_param.c:2100-2193): the Type-A1 prod_pairings (:2263): shared f, affine
+ * tangents and chords per term; element_multi_double / element_multi_add (curve.c:210-379) batch
+ * the inversions of the k affine doublings / additions -- the points are the same */
+static void a1_pairings_affine(const oracle_pairing *P, fe2 *out, const pt *in1, const pt *in2, int k) {
+  const fpctx *F = &P->Fq;
+  pt *V = malloc(sizeof(pt) * k);
+  fe a, b, c;
+  fe2 f, f0;
+  for (int j = 0; j < k; j++) V[j] = in1[j];
+  f.x = F->R; f.y = F->zero;
+  int m = big_bits(&P->r);
+  m = m > 2 ? m - 2 : 0;
+  for (;;) {
+    for (int j = 0; j < k; j++) {
+      a_abc_tangent(F, &a, &b, &c, &V[j].x, &V[j].y);
+      a_evalfn(F, &f0, &a, &b, &c, &in2[j].x, &in2[j].y);
+      fi_mul(F, &f, &f, &f0);
+    }
+    if (!m) break;
+    for (int j = 0; j < k; j++) pt_dbl(F, &P->ca, &V[j], &V[j]);
+    if (big_bit(&P->r, m)) {
+      for (int j = 0; j < k; j++) {
+        a_abc_line(F, &a, &b, &c, &V[j].x, &V[j].y, &in1[j].x, &in1[j].y);
+        a_evalfn(F, &f0, &a, &b, &c, &in2[j].x, &in2[j].y);
+        fi_mul(F, &f, &f, &f0);
+      }
+      for (int j = 0; j < k; j++) pt_add(F, &P->ca, &V[j], &V[j], &in1[j]);
+    }
+    m--;
+    fi_sqr(F, &f, &f);
+  }
+  a1_tateexp(F, out, &f, &P->h);
+  free(V);
 }
 
 /* a_pairing_proj (a_param.c:1053-1198): the default Type-A map (a_param.c:1443) */
@@ -626,7 +756,7 @@ int oracle_pairing_batch(const oracle_pairing *P, const uint8_t *g1, const uint8
     uint8_t *ob = gt + u * P->lenT;
     /* pairing_apply identity short-circuit (include/pbc_pairing.h:123-130) */
     if (A.inf || B.inf) { gt_one_bytes(P, ob); continue; }
-    a_pairing_proj(P, &o, &A, &B);
+    if (P->a1) a1_pairing_proj(P, &o, &A, &B); else a_pairing_proj(P, &o, &A, &B);
     fp_to_bytes(F, ob, &o.x);
     fp_to_bytes(F, ob + F->nbytes, &o.y);
   }
@@ -658,7 +788,7 @@ int oracle_prod_pairing_batch(const oracle_pairing *P, const uint8_t *g1, const 
     /* element_prod_pairing: ANY identity input -> whole product = 1 (pbc_pairing.h:161-168) */
     if (ident) { gt_one_bytes(P, ob); continue; }
     fe2 o;
-    a_pairings_affine(P, &o, A, B, k);
+    if (P->a1) a1_pairings_affine(P, &o, A, B, k); else a_pairings_affine(P, &o, A, B, k);
     fp_to_bytes(F, ob, &o.x);
     fp_to_bytes(F, ob + F->nbytes, &o.y);
   }

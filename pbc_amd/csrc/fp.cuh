@@ -45,9 +45,10 @@ struct fp {
 // The constants live in __constant__ memory so that every read is a scalar load from a
 // compile-time address (provably wave-uniform -> SGPR operands of the MACs).  One set per
 // limb count; the host uploads them with hipMemcpyToSymbolAsync on the launch stream.
-// Word counts built into the library: 5/6/7 words = the 159..224-bit MNT and BN fields of the
-// shipped type d / type f parameter files, 16 words = the 512-bit type a field.
-#define PBC_FOR_EACH_N(X) X(5) X(6) X(7) X(16)
+// Word counts built into the library: 5/6/7 words = the 149..224-bit MNT, Freeman and BN fields of
+// the shipped type d / g / f parameter files, 16 words = the 512-bit type a field, 33 words = the
+// 1033-bit type a1 field.
+#define PBC_FOR_EACH_N(X) X(5) X(6) X(7) X(16) X(33)
 template <int N> PBC_DEV const FpK<N> &fpk();
 #define PBC_DECL_FPK(n)              \
   __constant__ FpK<n> c_fpk##n;      \
@@ -713,6 +714,14 @@ static __device__ __noinline__ typename vecN<N>::type fp_inv_fn(typename vecN<N>
 template <int N>
 PBC_DEV void fp_inv(fp<N> &r, const fp<N> &a) {
   from_vec<N>(r, fp_inv_fn<N>(to_vec<N>(a)));
+}
+
+// bytes per F_q coordinate; a compile-time 64 for the type a field so that its kernels keep
+// their 16-byte vector loads and stores
+template <int N>
+PBC_DEV int fq_bytes() {
+  if constexpr (N == 16) return 64;
+  else return (int) fpk<N>().fbytes;
 }
 
 // Wire format: fixed-width big-endian canonical residue (fp_from_bytes montfp.c:498-517,

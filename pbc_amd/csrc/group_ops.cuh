@@ -17,7 +17,7 @@
 namespace pbc {
 
 struct CurveK {                        // E: y^2 = x^3 + a x + b over F_q (Montgomery words)
-  uint32_t a[16], b[16];
+  uint32_t a[34], b[34];
   int a_is_zero;
 };
 __constant__ CurveK c_curve;
@@ -287,9 +287,9 @@ PBC_DEV void a_from_hash_lane(uint8_t *out, const uint8_t *data, int hlen) {
 // ---- GT ------------------------------------------------------------------------------------
 // Type A: F_q^2
 template <int N>
-PBC_DEV void a_gt_load(fp2<N> &r, const uint8_t *s) { fp_load_be<N>(r.x, s); fp_load_be<N>(r.y, s + 4 * N); }
+PBC_DEV void a_gt_load(fp2<N> &r, const uint8_t *s) { fp_load_be<N>(r.x, s); fp_load_be<N>(r.y, s + fq_bytes<N>()); }
 template <int N>
-PBC_DEV void a_gt_store(uint8_t *d, const fp2<N> &a) { fp_store_be<N>(d, a.x); fp_store_be<N>(d + 4 * N, a.y); }
+PBC_DEV void a_gt_store(uint8_t *d, const fp2<N> &a) { fp_store_be<N>(d, a.x); fp_store_be<N>(d + fq_bytes<N>(), a.y); }
 template <int N>
 PBC_DEV void a_gt_mul_lane(uint8_t *out, const uint8_t *a, const uint8_t *b) {
   fp2<N> x, y;

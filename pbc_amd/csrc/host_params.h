@@ -127,6 +127,50 @@ static int init_type_a(pbc_hip_pairing_s *P, const char *txt, size_t len) {
   return 0;
 }
 
+// a1_init_pairing (ecc/a_param.c:2230-2273) + pbc_param_init_a1 (:2289-2298): y^2 = x^3 + x over F_p,
+// group order n (composite), cofactor l = (p + 1)/n
+static int init_type_a1(pbc_hip_pairing_s *P, const char *txt, size_t len) {
+  using namespace pbc_host;
+  Big p, n, l;
+  if (!param_big(txt, len, "p", p) || !param_big(txt, len, "n", n) || !param_big(txt, len, "l", l))
+    return fail("type a1: missing p/n/l");
+  if (fill_fpk<33>(P->k33, p))
+    return fail("type a1: only 1025..1056-bit p is supported by this build (got %d bits)", p.bits());
+  if ((p.w[0] & 3) != 3) return fail("type a1: p must be 3 mod 4");
+  {
+    Big pp1 = p;
+    pp1.add_small(1);
+    if (Big::cmp(Big::mul(n, l), pp1) != 0) return fail("type a1: p + 1 != n l");
+  }
+  if (l.bits() > 512 || l.is_zero() || n.bits() > 34 * 32 || n.bits() < 3) return fail("type a1: bad n or l");
+  memset(&P->a, 0, sizeof P->a);
+  l.to_words(P->a.h, 16);
+  P->a.hbits = l.bits();
+  n.to_words(P->a.r, 34);
+  P->a.rbits = n.bits();
+  {
+    Big e = p, four, rem;
+    e.add_small(1);
+    four.w.push_back(4);
+    e = Big::div(e, four, &rem);
+    e.to_words(P->a.sqrt_e, 34);
+    P->a.sqrt_bits = e.bits();
+  }
+  P->nlimb = 33;
+  P->len_fq = (p.bits() + 7) / 8;
+  P->len1 = P->len2 = P->lenT = 2 * P->len_fq;
+  P->len_zr = (n.bits() + 7) / 8;
+  // work model (a1_pairing_proj, a_param.c:1840-2015): per bit of n a tangent (10 F_p products incl.
+  // the projective line), a doubling (10) and an F_p^2 square + product (2 + 3); per set bit a chord
+  // (8), a mixed addition (12) and a product (3); f^(p-1) and the 11-bit power are negligible.
+  int ones = 0;
+  for (int i = 1; i < n.bits() - 1; i++) ones += n.bit(i);
+  P->fq_muls_single = 25.0 * (n.bits() - 1) + 23.0 * ones;
+  P->fq_muls_prod_a = P->fq_muls_single;
+  P->fq_muls_prod_b = 0.0;
+  return 0;
+}
+
 // d_init_pairing (ecc/d_param.c:993-1095) + pbc_param_init_d, and g_init_pairing (ecc/g_param.c:
 // 1248-1354) + pbc_param_init_g (:1378-1402): host part (integers only); the tower constants are
 // derived on the device at first use (pairing_d.cuh init_stage*).  deg = k/2: 3 (type d), 5 (type g).
@@ -305,6 +349,8 @@ static void fill_curve(const pbc_hip_pairing_s *P, CurveK &C) {
   memset(&C, 0, sizeof C);
   if (P->type == 'a') {                 // y^2 = x^3 + x (a_param.c:1450-1452)
     memcpy(C.a, P->k16.one, sizeof P->k16.one);
+  } else if (P->type == '1') {          // the same curve over the type a1 field (a_param.c:2247-2251)
+    memcpy(C.a, P->k33.one, sizeof P->k33.one);
   } else if (P->type == 'd' || P->type == 'g') {
     memcpy(C.a, P->dconst.A, sizeof P->dconst.A);
     memcpy(C.b, P->dconst.B, sizeof P->dconst.B);

@@ -51,11 +51,13 @@ PBC_DEV void fi_sqr(fp2<N> &r, const fp2<N> &a) {
 }
 
 struct AConst {          // a_pairing_data (ecc/a_param.c:30-34) + phikonr = h (:1458)
-  uint32_t h[16];        // cofactor h = (q+1)/r, little-endian words
+  uint32_t h[16];        // cofactor h = (q+1)/r, little-endian words (type a1: l, a_param.c:2242-2244)
   int hbits;
   int exp2, exp1, sign1; // r = 2^exp2 + sign1 2^exp1 + sign0 (sign0 unused by the map)
-  uint32_t sqrt_e[16];   // (q + 1)/4: square roots in F_q for q = 3 mod 4 (element_from_hash)
+  uint32_t sqrt_e[34];   // (q + 1)/4: square roots in F_q for q = 3 mod 4 (element_from_hash)
   int sqrt_bits;
+  uint32_t r[34];        // type a1: the group order n, walked bit by bit (a_param.c:1972-1988)
+  int rbits;
 };
 __constant__ AConst c_a;
 
@@ -273,7 +275,7 @@ PBC_DEV void a_store_gt(uint8_t *gt, fp2<N> &out, bool valid) {
     for (int k = 0; k < N; k++) out.y.v[k] = 0;
   }
   fp_store_be<N>(gt, out.x);
-  fp_store_be<N>(gt + 4 * N, out.y);
+  fp_store_be<N>(gt + fq_bytes<N>(), out.y);
 }
 
 // ---- preprocessed pairings: pairing_pp_init / pairing_pp_apply (include/pbc_pairing.h:54-89) ----
@@ -427,6 +429,70 @@ PBC_DEV void a_prod_pairing_lane(uint8_t *gt, const uint8_t *g1, const uint8_t *
   for (int j = 1; j < k; j++) {
     fp2<N> f;
     valid &= a_miller_lane<N>(f, g1 + (size_t) j * L, g2 + (size_t) j * L, lds_q, lds_stride);
+    fi_mul<N>(F, F, f);
+  }
+  a_final_exp<N>(out, F);
+  a_store_gt<N>(gt, out, valid);
+}
+
+// ---- Type A1: the same curve y^2 = x^3 + x over a 1033-bit F_p, composite group order n --------
+// a1_pairing_proj (a_param.c:1840-2015): plain double-and-add over the bits of n (tangent, double,
+// [chord, add], square; the last tangent at bit 0 ends the loop), then f^(p-1) and the power by
+// l = (p+1)/n (:1986-1994).  The step routines and the final exponentiation are the type a ones;
+// the Lucas ladder runs over l instead of h.
+template <int N>
+PBC_DEV bool a1_miller_lane(fp2<N> &f, const uint8_t *g1, const uint8_t *g2, uint32_t *lds_q, int lds_stride) {
+  const int NB = fq_bytes<N>();
+  fp<N> one;
+  jac<N> V;
+  fp_set<N>(one, fpk<N>().one);
+  bool valid;
+  {
+    fp<N> Qx, Qy;
+    fp_load_be<N>(V.X, g1);
+    fp_load_be<N>(V.Y, g1 + NB);
+    fp_load_be<N>(Qx, g2);
+    fp_load_be<N>(Qy, g2 + NB);
+    valid = (int) a_on_curve<N>(V.X, V.Y) & (int) a_on_curve<N>(Qx, Qy);
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+      lds_q[k * lds_stride] = Qx.v[k];
+      lds_q[(N + k) * lds_stride] = Qy.v[k];
+    }
+  }
+  V.Z = one;
+  V.ZZ = one;
+  f.x = one;
+#pragma unroll
+  for (int k = 0; k < N; k++) f.y.v[k] = 0;
+  for (int i = c_a.rbits - 2; i >= 0; i--) {
+    fp<N> Qx, Qy;
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+      Qx.v[k] = lds_q[k * lds_stride];
+      Qy.v[k] = lds_q[(N + k) * lds_stride];
+    }
+    a_double_step<N>(f, V, Qx, Qy);
+    if (i > 0 && ((c_a.r[i >> 5] >> (i & 31)) & 1)) {
+      fp<N> x2, y2;
+      fp_load_be<N>(x2, g1);
+      fp_load_be<N>(y2, g1 + NB);
+      a_add_step<N>(f, V, x2, y2, Qx, Qy);
+    }
+  }
+  return valid;
+}
+// element_pairing / element_prod_pairing (a1_pairings_affine, a_param.c:2100-2193: product of the
+// Miller functions, one final exponentiation) for one lane
+template <int N>
+PBC_DEV void a1_prod_pairing_lane(uint8_t *gt, const uint8_t *g1, const uint8_t *g2, int k, uint32_t *lds_q,
+                                  int lds_stride) {
+  const int L = 2 * fq_bytes<N>();
+  fp2<N> F, out;
+  bool valid = a1_miller_lane<N>(F, g1, g2, lds_q, lds_stride);
+  for (int j = 1; j < k; j++) {
+    fp2<N> f;
+    valid &= a1_miller_lane<N>(f, g1 + (size_t) j * L, g2 + (size_t) j * L, lds_q, lds_stride);
     fi_mul<N>(F, F, f);
   }
   a_final_exp<N>(out, F);

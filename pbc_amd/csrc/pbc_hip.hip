@@ -77,6 +77,30 @@ __global__ void __launch_bounds__(kBlock, PBC_A_WAVES) a_prod_pairing_kernel(uin
   }
 }
 
+// Type A1: one k-term product (k = 1: a single pairing) per lane; 130-byte coordinates for a1.param.
+#ifndef PBC_A1_WAVES
+#define PBC_A1_WAVES 2
+#endif
+template <int N>
+__global__ void __launch_bounds__(kBlock, PBC_A1_WAVES) a1_prod_pairing_kernel(uint8_t *gt, const uint8_t *g1,
+                                                                               const uint8_t *g2, size_t n, int k) {
+  size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
+  size_t ld = idx < n ? idx : n - 1;
+  const int L = 2 * fq_bytes<N>();
+  __attribute__((aligned(4))) uint8_t out[8 * N];
+  __shared__ uint32_t lds_q[2 * N * kBlock];
+  a1_prod_pairing_lane<N>(out, g1 + ld * k * L, g2 + ld * k * L, k, lds_q + threadIdx.x, kBlock);
+  if (idx < n) {
+    if ((L & 3) == 0) {
+      uint32_t *dst = reinterpret_cast<uint32_t *>(gt + idx * L);
+      const uint32_t *src = reinterpret_cast<const uint32_t *>(out);
+      for (int i = 0; i < L / 4; i++) dst[i] = src[i];
+    } else {
+      for (int i = 0; i < L; i++) gt[idx * L + i] = out[i];
+    }
+  }
+}
+
 // pairing_pp_init: ONE lane derives the line-coefficient table of a fixed first argument.
 template <int N>
 __global__ void a_pp_init_kernel(uint32_t *tab, uint32_t *valid, const uint8_t *g1) {
@@ -173,7 +197,7 @@ __global__ void __launch_bounds__(kBlock, 2) gt_op_kernel(int type, int op, uint
   if (idx >= n) return;
   uint8_t *o = out + idx * lenT;
   const uint8_t *x = a + idx * lenT;
-  if constexpr (N == 16) {
+  if constexpr (N == 16 || N == 33) {
     if (op == 0) a_gt_mul_lane<N>(o, x, b + idx * lenT); else a_gt_pow_lane<N>(o, x, b + idx * zlen, zlen);
   } else {
     if (type == 'd') {
@@ -366,6 +390,9 @@ extern "C" int pbc_hip_pairing_init_set_buf(pbc_hip_pairing_t **out, const char 
   if (type == "a") {
     P->type = 'a';
     rc = init_type_a(P, param, len);
+  } else if (type == "a1") {
+    P->type = '1';
+    rc = init_type_a1(P, param, len);
   } else if (type == "d") {
     P->type = 'd';
     rc = init_type_d(P, param, len, 3);
@@ -421,6 +448,7 @@ extern "C" double pbc_hip_algorithmic_macs_per_unit(const pbc_hip_pairing_t *p, 
     case 6: { constexpr int N = 6; __VA_ARGS__; } break;             \
     case 7: { constexpr int N = 7; __VA_ARGS__; } break;             \
     case 16: { constexpr int N = 16; __VA_ARGS__; } break;           \
+    case 33: { constexpr int N = 33; __VA_ARGS__; } break;           \
     default: return fail("internal: no kernel for %d-word fields", (int) (nl)); \
   }
 
@@ -433,7 +461,7 @@ static int upload_constants(pbc_hip_pairing_s *P, hipStream_t s) {
 #undef PBC_UP
     default: return fail("internal: no constants for %d-word fields", P->nlimb);
   }
-  if (P->type == 'a')
+  if (P->type == 'a' || P->type == '1')
     HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_a), &P->a, sizeof P->a, 0, hipMemcpyHostToDevice, s));
   if (P->type == 'd' || P->type == 'g') {
     if (!P->dev_ready) {
@@ -483,6 +511,9 @@ static int launch_pairing(pbc_hip_pairing_s *P, void *d_gt, const void *d_g1, co
   if (P->type == 'a') {
     hipLaunchKernelGGL(a_pairing_kernel<16>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
                        (const uint8_t *) d_g1, (const uint8_t *) d_g2, n);
+  } else if (P->type == '1') {
+    hipLaunchKernelGGL(a1_prod_pairing_kernel<33>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
+                       (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, 1);
   } else if (P->type == 'd' || P->type == 'g') {
     PBC_DISPATCH_D(P, hipLaunchKernelGGL((d_prod_pairing_kernel<N, DEG>), dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
                                                 (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, 1));
@@ -575,6 +606,9 @@ static int launch_prod(pbc_hip_pairing_s *P, void *d_gt, const void *d_g1, const
   if (P->type == 'a') {
     hipLaunchKernelGGL(a_prod_pairing_kernel<16>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
                        (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k);
+  } else if (P->type == '1') {
+    hipLaunchKernelGGL(a1_prod_pairing_kernel<33>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
+                       (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k);
   } else if (P->type == 'd' || P->type == 'g') {
     PBC_DISPATCH_D(P, hipLaunchKernelGGL((d_prod_pairing_kernel<N, DEG>), dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
                                                 (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k));
@@ -609,8 +643,8 @@ static int run_group(pbc_hip_pairing_s *P, int what, int group, uint8_t *out, co
   if (!n) return 0;
   size_t la, lb, lo;
   if (what == 0) {                     // G mul_zn
-    if (group != 1 && !(group == 2 && P->type == 'a'))
-      return fail("scalar multiplication is built for G1 (and G2 of the symmetric type a)");
+    if (group != 1 && !(group == 2 && (P->type == 'a' || P->type == '1')))
+      return fail("scalar multiplication is built for G1 (and G2 of the symmetric types a, a1)");
     la = lo = (size_t) P->len1;
     lb = (size_t) P->len_zr;
   } else if (what == 1) {              // GT mul

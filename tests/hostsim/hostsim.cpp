@@ -20,6 +20,7 @@ static void set_fpk(pbc_hip_pairing_s *P) {
     case 6: { constexpr int N = 6; __VA_ARGS__; } break;     \
     case 7: { constexpr int N = 7; __VA_ARGS__; } break;     \
     case 16: { constexpr int N = 16; __VA_ARGS__; } break;   \
+    case 33: { constexpr int N = 33; __VA_ARGS__; } break;   \
   }
 // types d / g: N words, degree DEG
 #define HS_DISPATCH_D(P_, ...)                                                \
@@ -31,7 +32,7 @@ static void set_fpk(pbc_hip_pairing_s *P) {
   }
 static void activate(pbc_hip_pairing_s *P) {
   set_fpk(P);
-  if (P->type == 'a') c_a = P->a;
+  if (P->type == 'a' || P->type == '1') c_a = P->a;
   if (P->type == 'd' || P->type == 'g') c_d = P->dconst;
   if (P->type == 'f') c_f = P->fconst;
   CurveK C;
@@ -47,6 +48,7 @@ void *hostsim_init(const char *param, size_t len) {
   pbc_hip_pairing_s *P = new pbc_hip_pairing_s();
   int rc = 1;
   if (type == "a") { P->type = 'a'; rc = init_type_a(P, param, len); }
+  else if (type == "a1") { P->type = '1'; rc = init_type_a1(P, param, len); }
   else if (type == "d") { P->type = 'd'; rc = init_type_d(P, param, len, 3); }
   else if (type == "g") { P->type = 'g'; rc = init_type_d(P, param, len, 5); }
   else if (type == "f") { P->type = 'f'; rc = init_type_f(P, param, len); }
@@ -80,11 +82,12 @@ int hostsim_lens(void *h, int *l1, int *l2, int *lt) {
 int hostsim_prod_pairing(void *h, uint8_t *gt, const uint8_t *g1, const uint8_t *g2, size_t n, int k) {
   pbc_hip_pairing_s *P = (pbc_hip_pairing_s *) h;
   activate(P);
-  static uint32_t lds[2 * 16];
+  static uint32_t lds[2 * 33];
   for (size_t u = 0; u < n; u++) {
     const uint8_t *a = g1 + u * k * P->len1, *b = g2 + u * k * P->len2;
     uint8_t *o = gt + u * P->lenT;
     if (P->type == 'a') a_prod_pairing_lane<16>(o, a, b, k, lds, 1);
+    else if (P->type == '1') a1_prod_pairing_lane<33>(o, a, b, k, lds, 1);
     else if (P->type == 'd' || P->type == 'g') { HS_DISPATCH_D(P, TypeMNT<N, DEG>::d_prod_pairing_lane(o, a, b, k)); }
     else f_prod_pairing_lane(o, a, b, k);
   }
@@ -111,6 +114,7 @@ int hostsim_group(void *h, int what, uint8_t *out, const uint8_t *a, const uint8
       uint8_t *o = out + i * P->lenT;
       const uint8_t *x = a + i * P->lenT, *y = b + i * (what == 1 ? P->lenT : P->len_zr);
       if (P->type == 'a') { if (what == 1) a_gt_mul_lane<16>(o, x, y); else a_gt_pow_lane<16>(o, x, y, P->len_zr); }
+      else if (P->type == '1') { if (what == 1) a_gt_mul_lane<33>(o, x, y); else a_gt_pow_lane<33>(o, x, y, P->len_zr); }
       else if (P->type == 'd' || P->type == 'g') { HS_DISPATCH_D(P, if (what == 1) d_gt_mul_lane<N, DEG>(o, x, y); else d_gt_pow_lane<N, DEG>(o, x, y, P->len_zr)); }
       else { if (what == 1) f_gt_mul_lane(o, x, y); else f_gt_pow_lane(o, x, y, P->len_zr); }
     }

@@ -344,9 +344,13 @@ def test_pairing_pp_matches_element_pairing(hip_a, oracle_a):
 @pytest.mark.parametrize("d", OTHER)
 def test_other_type_d_and_g_params_match_reference_vectors(hips, d):
     H = hips[d]
-    fb = (param_value(d, "q").bit_length() + 7) // 8
-    deg = param_value(d, "k") // 2
-    assert (H.length_in_bytes_G1, H.length_in_bytes_G2, H.length_in_bytes_GT) == (2 * fb, 2 * deg * fb, 2 * deg * fb)
+    if d == "a1":
+        fb = (param_value(d, "p").bit_length() + 7) // 8
+        assert (H.length_in_bytes_G1, H.length_in_bytes_G2, H.length_in_bytes_GT) == (2 * fb, 2 * fb, 2 * fb)
+    else:
+        fb = (param_value(d, "q").bit_length() + 7) // 8
+        deg = param_value(d, "k") // 2
+        assert (H.length_in_bytes_G1, H.length_in_bytes_G2, H.length_in_bytes_GT) == (2 * fb, 2 * deg * fb, 2 * deg * fb)
     for name in FILES_OF[d][:2]:
         v = golden(name)
         assert np.array_equal(H.element_pairing(v.g1, v.g2), v.gt), name
@@ -366,7 +370,7 @@ def test_type_g_chain_and_products(hips):
 def test_other_type_d_and_g_params_cross_pairs_fq_and_group_ops_vs_oracle(hips, oracles, d):
     H, O = hips[d], oracles[d]
     v = golden(FILES_OF[d][0])
-    q, r = param_value(d, "q"), param_value(d, "r")
+    q, r = (param_value(d, "p"), param_value(d, "n")) if d == "a1" else (param_value(d, "q"), param_value(d, "r"))
     fb, zl = (q.bit_length() + 7) // 8, (r.bit_length() + 7) // 8
     # all 144 (P_i, Q_j) combinations, a whole block plus a ragged tail
     i, j = np.meshgrid(np.arange(v.n), np.arange(v.n), indexing="ij")

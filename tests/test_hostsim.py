@@ -23,7 +23,7 @@ def sims():
     ("a_kat.vec", 1), ("a_rand32.vec", 6), ("a_edge20.vec", 20), ("a_prod2x8.vec", 4), ("a_prod3x10_edge.vec", 10),
     ("d_rand32.vec", 6), ("d_edge20.vec", 20), ("d_prod16x4.vec", 2), ("d_prod3x10_edge.vec", 10),
     ("f_rand16.vec", 3), ("f_edge10.vec", 10), ("f_prod3x5_edge.vec", 5),
-] + [(name, 4) for d in OTHER for name in FILES_OF[d]] + [("g149_prod4x3.vec", 1)])
+] + [(name, 2 if d == "a1" else 4) for d in OTHER for name in FILES_OF[d]] + [("g149_prod4x3.vec", 1)])
 def test_kernel_source_on_host_matches_reference(sims, name, count):
     v = golden(name)
     n = min(count, v.n)
@@ -35,7 +35,7 @@ def test_kernel_source_on_host_matches_reference(sims, name, count):
                          + [(d, None) for d in OTHER])
 def test_kernel_fq_ops_on_host(sims, oracles, t, q):
     if q is None:
-        q = param_value(t, "q")
+        q = param_value(t, "p" if t == "a1" else "q")
     nb = sims[t].len1 // 2
     rng = np.random.default_rng(2)
     xs = [int.from_bytes(rng.bytes(nb), "big") % q for _ in range(40)] + [1, q - 1, 2 ** (8 * nb) - 1]
@@ -74,7 +74,7 @@ def test_group_ops_on_host(sims, oracles, t, name):
     v = golden(name)
     rng = np.random.default_rng(21)
     n = 3
-    r = param_value(t, "r")
+    r = param_value(t, "n" if t == "a1" else "r")
     zl = (r.bit_length() + 7) // 8          # pairing_length_in_bytes_Zr
     ks = [int.from_bytes(rng.bytes(zl), "big") % r for _ in range(n - 1)] + [1]
     Z = np.stack([np.frombuffer(k.to_bytes(zl, "big"), np.uint8) for k in ks])

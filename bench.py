@@ -125,7 +125,8 @@ WORKLOADS = {
     "f": ("f", "f_chain128.vec", 1, 18, "Type F (f.param) element_pairing"),
     "d201": ("d201", "d201_rand12.vec", 1, 18, "Type D (d201.param, 7-word field) element_pairing"),
     "d224": ("d224", "d224_rand12.vec", 1, 18, "Type D (d224.param, 7-word field) element_pairing"),
-    "a1": ("a1", "a1_chain8.vec", 1, 14, "Type A1 (a1.param, 1033-bit p) element_pairing"),
+    "a1": ("a1", "a1_chain8.vec", 1, 16, "Type A1 (a1.param, 1033-bit p) element_pairing"),
+    "e": ("e", "e_chain8.vec", 1, 16, "Type E (e.param, k = 1, 1020-bit q) element_pairing"),
     "g": ("g149", "g149_chain64.vec", 1, 17, "Type G (g149.param, k = 10) element_pairing"),
     "d190": ("d278027-190-181", "d278027-190-181_rand12.vec", 1, 18,
              "Type D (d278027-190-181.param, 6-word field) element_pairing"),

@@ -326,12 +326,18 @@ struct oracle_pairing {
   int len1, len2, lenT;
   /* type A (ecc/a_param.c:30-34) */
   int exp2, exp1, sign1;
+  pt eR;                 /* type E: the auxiliary point R of e_pairing (e_param.c:472-483) */
+  big phikonr;           /* type E: (q - 1)/r (e_param.c:857-860) */
+  int sign0;             /* type E: r = 2^exp2 + sign1 2^exp1 + sign0 (e_param.c:23-26) */
   int a1;                /* type A1 (ecc/a_param.c:1564-2321): type 'a' with r = n composite, h = l */
   fe ca, cb;             /* curve a, b in Fq (A: a=1, b=0, a_param.c:1450-1452) */
   struct dctx *D;        /* type D (ecc/d_param.c:40-51) */
   struct fctx *Fx;       /* type F (ecc/f_param.c:35-45) */
 };
 static int init_d(oracle_pairing *P, const char *txt, size_t len);
+static int init_e(oracle_pairing *P, const char *txt, size_t len);
+static int big_divexact(big *quo, const big *z, const big *d);
+static int e_pairing_bytes(const oracle_pairing *P, const uint8_t *g1, const uint8_t *g2, uint8_t *gt, int k);
 static int init_f(oracle_pairing *P, const char *txt, size_t len);
 static int d_pairing_bytes(const oracle_pairing *P, const uint8_t *g1, const uint8_t *g2, uint8_t *gt, int k);
 static int f_pairing_bytes(const oracle_pairing *P, const uint8_t *g1, const uint8_t *g2, uint8_t *gt, int k);
@@ -405,6 +411,7 @@ int oracle_pairing_init(oracle_pairing **out, const char *txt, size_t len) {
   int rc = 1;
   if (!strcmp(tb, "a")) rc = init_a(P, txt, len);
   else if (!strcmp(tb, "a1")) rc = init_a1(P, txt, len);
+  else if (!strcmp(tb, "e")) rc = init_e(P, txt, len);
   else if (!strcmp(tb, "d") || !strcmp(tb, "g")) rc = init_d(P, txt, len);
   else if (!strcmp(tb, "f")) rc = init_f(P, txt, len);
   if (rc) { free(P); return 1; }
@@ -734,7 +741,7 @@ static void a_pairings_affine(const oracle_pairing *P, fe2 *out, const pt *in1, 
  * (ecc/pairing.c:135-283 mulg wrapper). */
 static void gt_one_bytes(const oracle_pairing *P, uint8_t *out) {
   memset(out, 0, P->lenT);
-  out[P->Fq.nbytes - 1] = 1;          /* the first F_q coordinate is the constant term for A, D and F */
+  out[P->Fq.nbytes - 1] = 1;          /* the first F_q coordinate is the constant term for every type */
 }
 
 int oracle_pairing_batch(const oracle_pairing *P, const uint8_t *g1, const uint8_t *g2,
@@ -746,6 +753,11 @@ int oracle_pairing_batch(const oracle_pairing *P, const uint8_t *g1, const uint8
                               : f_pairing_bytes(P, g1 + u * P->len1, g2 + u * P->len2, gt + u * P->lenT, 1);
       if (rc) return rc;
     }
+    return 0;
+  }
+  if (P->type == 'e') {
+    for (size_t u = 0; u < n; u++)
+      if (e_pairing_bytes(P, g1 + u * P->len1, g2 + u * P->len2, gt + u * P->lenT, 1)) return 1;
     return 0;
   }
   if (P->type != 'a') return 1;
@@ -773,6 +785,11 @@ int oracle_prod_pairing_batch(const oracle_pairing *P, const uint8_t *g1, const 
                               : f_pairing_bytes(P, g1 + u * k * P->len1, g2 + u * k * P->len2, gt + u * P->lenT, k);
       if (rc) return rc;
     }
+    return 0;
+  }
+  if (P->type == 'e') {
+    for (size_t u = 0; u < n; u++)
+      if (e_pairing_bytes(P, g1 + u * k * P->len1, g2 + u * k * P->len2, gt + u * P->lenT, k)) return 1;
     return 0;
   }
   if (P->type != 'a') return 1;
@@ -826,6 +843,15 @@ int oracle_gt_mul(const oracle_pairing *P, const uint8_t *a, const uint8_t *b, u
       if (df_gt_mul(P, a + i * P->lenT, b + i * P->lenT, out + i * P->lenT)) return 1;
     return 0;
   }
+  if (P->type == 'e') {                 /* GT = F_q (pairing_GT_init(pairing, p->Fq), e_param.c:863) */
+    for (size_t i = 0; i < n; i++) {
+      fe x, y;
+      fp_from_bytes(F, &x, a + i * P->lenT); fp_from_bytes(F, &y, b + i * P->lenT);
+      fp_mul(F, &x, &x, &y);
+      fp_to_bytes(F, out + i * P->lenT, &x);
+    }
+    return 0;
+  }
   if (P->type != 'a') return 1;
   int L = F->nbytes;
   for (size_t i = 0; i < n; i++) {
@@ -848,6 +874,16 @@ int oracle_gt_pow(const oracle_pairing *P, const uint8_t *a, const uint8_t *e, s
     }
     return 0;
   }
+  if (P->type == 'e') {
+    for (size_t i = 0; i < n; i++) {
+      fe x; big ex;
+      big_from_be(&ex, e + i * elen, elen);
+      fp_from_bytes(F, &x, a + i * P->lenT);
+      fp_pow(F, &x, &x, &ex);
+      fp_to_bytes(F, out + i * P->lenT, &x);
+    }
+    return 0;
+  }
   if (P->type != 'a') return 1;
   int L = F->nbytes;
   for (size_t i = 0; i < n; i++) {
@@ -867,7 +903,7 @@ int oracle_gt_pow(const oracle_pairing *P, const uint8_t *a, const uint8_t *e, s
 int oracle_g_mul(const oracle_pairing *P, int group, const uint8_t *ptb, const uint8_t *e,
                  size_t elen, uint8_t *out, size_t n) {
   const fpctx *F = &P->Fq;
-  if (P->type != 'a' && group != 1) return 1;   /* D/F: only G1 = E(Fq) scalar mult is provided */
+  if (P->type != 'a' && P->type != 'e' && group != 1) return 1;   /* D/F/G: only G1 = E(Fq) scalar mult is provided */
   for (size_t i = 0; i < n; i++) {
     pt A, R; big ex;
     big_from_be(&ex, e + i * elen, elen);
@@ -878,6 +914,145 @@ int oracle_g_mul(const oracle_pairing *P, int group, const uint8_t *ptb, const u
   return 0;
 }
 
+
+/* ================================================================== */
+/* Type E (k = 1, ordinary curve over a 1020-bit F_q), ecc/e_param.c   */
+/* ================================================================== */
+/* square root in F_q by Tonelli-Shanks (the reference draws its auxiliary point with
+ * curve_set_gen_no_cofac, e_param.c:869-870: a RANDOM point; the pairing value does not depend on
+ * it -- the Tate pairing f_P((Q+R) - (R)) is independent of R -- so the oracle takes the curve point
+ * with the smallest x >= 1).  Returns 0 when a is not a square. */
+static int fp_sqrt_ts(const fpctx *F, fe *out, const fe *a, const big *q) {
+  big t = *q, e;
+  t.v[0] &= ~1ull;                                   /* q - 1 */
+  int s = 0;
+  while (!big_bit(&t, 0)) { for (int w = 0; w < BIGL - 1; w++) t.v[w] = (t.v[w] >> 1) | (t.v[w + 1] << 63); t.v[BIGL - 1] >>= 1; s++; }
+  big half = *q; half.v[0] &= ~1ull;
+  for (int w = 0; w < BIGL - 1; w++) half.v[w] = (half.v[w] >> 1) | (half.v[w + 1] << 63);
+  half.v[BIGL - 1] >>= 1;                            /* (q - 1)/2 */
+  fe chk; fp_pow(F, &chk, a, &half);
+  if (!fp_eq(F, &chk, &F->R)) return 0;
+  fe z, c, x, b, tt;                                 /* non-residue z */
+  for (uint64_t k = 2;; k++) { fp_set_ui(F, &z, k); fp_pow(F, &chk, &z, &half); if (!fp_eq(F, &chk, &F->R)) break; }
+  fp_pow(F, &c, &z, &t);
+  e = t; { big one; memset(&one, 0, sizeof one); one.v[0] = 1; bn_add(e.v, e.v, one.v, BIGL); }
+  for (int w = 0; w < BIGL - 1; w++) e.v[w] = (e.v[w] >> 1) | (e.v[w + 1] << 63);
+  e.v[BIGL - 1] >>= 1;                               /* (t + 1)/2 */
+  fp_pow(F, &x, a, &e);
+  fp_pow(F, &b, a, &t);
+  int m = s;
+  while (!fp_eq(F, &b, &F->R)) {
+    int i = 0; tt = b;
+    while (!fp_eq(F, &tt, &F->R)) { fp_sqr(F, &tt, &tt); i++; }
+    fe g = c;
+    for (int j = 0; j < m - i - 1; j++) fp_sqr(F, &g, &g);
+    fp_mul(F, &x, &x, &g);
+    fp_sqr(F, &c, &g);
+    fp_mul(F, &b, &b, &c);
+    m = i;
+  }
+  *out = x;
+  return 1;
+}
+/* e_miller_affine (e_param.c:302-466): numerator v and denominator vd of f_P(Q+R)/f_P(R), Solinas
+ * r = 2^exp2 + sign1 2^exp1 + sign0.  (The default e_miller_proj, :64-300, is the same function in
+ * Jacobian coordinates with the same collated divisions.) */
+static void e_miller(const oracle_pairing *P, fe *res, const pt *Pp, const pt *QR, const pt *R) {
+  const fpctx *F = &P->Fq;
+  fe v = F->R, vd = F->R, v1, vd1, a, b, c, e0, e1;
+  pt Z = *Pp, Z1;
+  const fe *numx = &QR->x, *numy = &QR->y, *denx = &R->x, *deny = &R->y;
+#define DO_VERTICAL(e, ed, Ax) do { fp_sub(F, &e0, numx, (Ax)); fp_mul(F, &(e), &(e), &e0); \
+    fp_sub(F, &e0, denx, (Ax)); fp_mul(F, &(ed), &(ed), &e0); } while (0)
+#define EVAL(e, ed) do { fp_mul(F, &e0, &a, numx); fp_mul(F, &e1, &b, numy); fp_add(F, &e0, &e0, &e1); fp_add(F, &e0, &e0, &c); \
+    fp_mul(F, &(e), &(e), &e0); fp_mul(F, &e0, &a, denx); fp_mul(F, &e1, &b, deny); fp_add(F, &e0, &e0, &e1); \
+    fp_add(F, &e0, &e0, &c); fp_mul(F, &(ed), &(ed), &e0); } while (0)
+#define DO_TANGENT(e, ed) do { fp_sqr(F, &a, &Z.x); fp_dbl(F, &e0, &a); fp_add(F, &a, &a, &e0); fp_add(F, &a, &a, &P->ca); \
+    fp_neg(F, &a, &a); fp_add(F, &b, &Z.y, &Z.y); fp_mul(F, &e0, &b, &Z.y); fp_mul(F, &c, &a, &Z.x); \
+    fp_add(F, &c, &c, &e0); fp_neg(F, &c, &c); EVAL(e, ed); } while (0)
+  int i, n = P->exp1;
+  for (i = 0; i < n; i++) {
+    fp_sqr(F, &v, &v); fp_sqr(F, &vd, &vd);
+    DO_TANGENT(v, vd);
+    pt_dbl(F, &P->ca, &Z, &Z);
+    DO_VERTICAL(vd, v, &Z.x);
+  }
+  if (P->sign1 < 0) {
+    v1 = vd; vd1 = v;
+    DO_VERTICAL(vd1, v1, &Z.x);
+    Z1 = Z; fp_neg(F, &Z1.y, &Z.y);
+  } else { v1 = v; vd1 = vd; Z1 = Z; }
+  n = P->exp2;
+  for (; i < n; i++) {
+    fp_sqr(F, &v, &v); fp_sqr(F, &vd, &vd);
+    DO_TANGENT(v, vd);
+    pt_dbl(F, &P->ca, &Z, &Z);
+    DO_VERTICAL(vd, v, &Z.x);
+  }
+  fp_mul(F, &v, &v, &v1);
+  fp_mul(F, &vd, &vd, &vd1);
+  /* do_line(v, vd, Z, Z1) */
+  fp_sub(F, &b, &Z1.x, &Z.x);
+  fp_sub(F, &a, &Z.y, &Z1.y);
+  fp_mul(F, &c, &Z.x, &Z1.y);
+  fp_mul(F, &e0, &Z.y, &Z1.x);
+  fp_sub(F, &c, &c, &e0);
+  EVAL(v, vd);
+  pt_add(F, &P->ca, &Z, &Z, &Z1);
+  DO_VERTICAL(vd, v, &Z.x);
+  if (P->sign0 > 0) DO_VERTICAL(v, vd, &Pp->x);
+  fp_inv(F, &vd, &vd);
+  fp_mul(F, res, &v, &vd);
+#undef DO_VERTICAL
+#undef EVAL
+#undef DO_TANGENT
+}
+/* e_pairing (e_param.c:472-483): QR = Q + R, Miller, power by phikonr = (q-1)/r.  Type e has no
+ * product routine: generic_prod_pairings (pairing.c:35-46) multiplies the k pairings. */
+static int e_pairing_bytes(const oracle_pairing *P, const uint8_t *g1, const uint8_t *g2, uint8_t *gt, int k) {
+  const fpctx *F = &P->Fq;
+  fe acc = F->R;
+  int ident = 0;
+  for (int j = 0; j < k; j++) {
+    pt A, B, QR; fe m;
+    pt_from_bytes(F, &P->ca, &P->cb, &A, g1 + (size_t) j * P->len1);
+    pt_from_bytes(F, &P->ca, &P->cb, &B, g2 + (size_t) j * P->len2);
+    if (A.inf || B.inf) { ident = 1; continue; }
+    pt_add(F, &P->ca, &QR, &B, &P->eR);
+    e_miller(P, &m, &A, &QR, &P->eR);
+    fp_pow(F, &m, &m, &P->phikonr);
+    fp_mul(F, &acc, &acc, &m);
+  }
+  if (ident) { gt_one_bytes(P, gt); return 0; }
+  fp_to_bytes(F, gt, &acc);
+  return 0;
+}
+/* e_init_pairing (e_param.c:832-872) + pbc_param_init_e (:891-906) */
+static int init_e(oracle_pairing *P, const char *txt, size_t len) {
+  big a, b;
+  if (kv_big(txt, len, "q", &P->q) || kv_big(txt, len, "r", &P->r) || kv_big(txt, len, "h", &P->h) ||
+      kv_big(txt, len, "a", &a) || kv_big(txt, len, "b", &b)) return 1;
+  if (kv_int(txt, len, "exp2", &P->exp2) || kv_int(txt, len, "exp1", &P->exp1) ||
+      kv_int(txt, len, "sign1", &P->sign1) || kv_int(txt, len, "sign0", &P->sign0)) return 1;
+  if (fp_init(&P->Fq, &P->q)) return 1;
+  const fpctx *F = &P->Fq;
+#define SETBIG(dst, src) do { fe t_; memset(&t_, 0, sizeof t_); memcpy(t_.v, (src).v, 8 * F->n); fp_mul(F, &(dst), &t_, &F->R2); } while (0)
+  SETBIG(P->ca, a); SETBIG(P->cb, b);
+#undef SETBIG
+  /* phikonr = (q - 1)/r (k = 1) */
+  { big qm1 = P->q; qm1.v[0] &= ~1ull; if (big_divexact(&P->phikonr, &qm1, &P->r)) return 1; }
+  /* auxiliary point: smallest x >= 1 with x^3 + a x + b a square */
+  for (uint64_t x = 1;; x++) {
+    fe fx, rhs, y;
+    fp_set_ui(F, &fx, x);
+    fp_sqr(F, &rhs, &fx); fp_add(F, &rhs, &rhs, &P->ca); fp_mul(F, &rhs, &rhs, &fx); fp_add(F, &rhs, &rhs, &P->cb);
+    if (fp_is0(F, &rhs)) continue;
+    if (fp_sqrt_ts(F, &y, &rhs, &P->q)) { P->eR.inf = 0; P->eR.x = fx; P->eR.y = y; break; }
+  }
+  P->len1 = P->len2 = 2 * F->nbytes;
+  P->lenT = F->nbytes;
+  return 0;
+}
 
 /* ================================================================== */
 /* Type D (MNT, k = 6), ecc/d_param.c, and Type G (Freeman, k = 10),   */

@@ -13,6 +13,7 @@
 #include "pairing_a.cuh"
 #include "pairing_d.cuh"
 #include "pairing_f.cuh"
+#include "pairing_e.cuh"
 
 namespace pbc {
 

@@ -12,6 +12,7 @@
 #include "pairing_a.cuh"
 #include "pairing_d.cuh"
 #include "pairing_f.cuh"
+#include "pairing_e.cuh"
 #include "group_ops.cuh"
 
 using namespace pbc;
@@ -45,16 +46,19 @@ struct pbc_hip_pairing_s {
   DConst dconst;             // type D: derived tower constants (filled on first use)
   FRaw fraw;                 // type F: canonical parameter words
   FConst fconst;             // type F: derived tower constants (filled on first use)
+  ERaw eraw;                 // type E: integers for the one-time search of the auxiliary point
+  EConst econst;             // type E: curve, auxiliary point, exponents (filled on first use)
   bool dev_ready;            // derived constants computed on the device
   int len_zr;                // bytes of a Z_r scalar (pairing_length_in_bytes_Zr)
   double fq_muls_single;     // reference F_q multiplication count per pairing (work model)
   double fq_muls_prod_a, fq_muls_prod_b;   // products: a*k + b
 };
 
+// min_bits: smallest modulus accepted for this word count (default: the top word is in use)
 template <int N>
-static int fill_fpk(FpK<N> &K, const pbc_host::Big &q) {
+static int fill_fpk(FpK<N> &K, const pbc_host::Big &q, int min_bits = 32 * (N - 1) + 1) {
   using pbc_host::Big;
-  if (q.bits() > 32 * N || q.bits() <= 32 * (N - 1) || !(q.w[0] & 1)) return 1;
+  if (q.bits() > 32 * N || q.bits() < min_bits || !(q.w[0] & 1)) return 1;
   memset(&K, 0, sizeof K);
   q.to_words(K.p, N);
 #if PBC_MUL_IMPL == 0
@@ -167,6 +171,61 @@ static int init_type_a1(pbc_hip_pairing_s *P, const char *txt, size_t len) {
   for (int i = 1; i < n.bits() - 1; i++) ones += n.bit(i);
   P->fq_muls_single = 25.0 * (n.bits() - 1) + 23.0 * ones;
   P->fq_muls_prod_a = P->fq_muls_single;
+  P->fq_muls_prod_b = 0.0;
+  return 0;
+}
+
+// e_init_pairing (ecc/e_param.c:832-872) + pbc_param_init_e (:891-906): host part (integers only).
+// The 1020-bit field of e.param runs on the 33-word arithmetic built for type a1.
+static int init_type_e(pbc_hip_pairing_s *P, const char *txt, size_t len) {
+  using namespace pbc_host;
+  Big q, r, a, b;
+  if (!param_big(txt, len, "q", q) || !param_big(txt, len, "r", r) || !param_big(txt, len, "a", a) ||
+      !param_big(txt, len, "b", b))
+    return fail("type e: missing q/r/a/b");
+  if (fill_fpk<33>(P->k33, q, 961))
+    return fail("type e: only odd 961..1056-bit q is supported by this build (got %d bits)", q.bits());
+  if (Big::cmp(a, q) >= 0 || Big::cmp(b, q) >= 0) return fail("type e: coefficient >= q");
+  if (r.bits() > 256 || r.bits() < 3 || !(r.w[0] & 1)) return fail("type e: bad r");
+  memset(&P->eraw, 0, sizeof P->eraw);
+  memset(&P->econst, 0, sizeof P->econst);
+  a.to_words(P->eraw.a, NE_MAX);
+  b.to_words(P->eraw.b, NE_MAX);
+  Big two, rem;
+  two.w.push_back(2);
+  Big qm1 = q;
+  qm1.sub_small(1);
+  Big half = Big::div(qm1, two, &rem);
+  half.to_words(P->eraw.half, NE_MAX);
+  P->eraw.halfbits = half.bits();
+  Big t = qm1;
+  int s = 0;
+  while (!t.bit(0)) { t = Big::div(t, two, &rem); s++; }
+  t.to_words(P->eraw.t, NE_MAX);
+  P->eraw.tbits = t.bits();
+  P->eraw.s = s;
+  Big t1 = t;
+  t1.add_small(1);
+  t1 = Big::div(t1, two, &rem);
+  t1.to_words(P->eraw.t1h, NE_MAX);
+  P->eraw.t1hbits = t1.bits();
+  // phikonr = (q - 1)/r (k = 1; e_param.c:857-860)
+  Big phik = Big::div(qm1, r, &rem);
+  if (!rem.is_zero()) return fail("type e: r does not divide q - 1");
+  phik.to_words(P->econst.phik, NE_MAX);
+  P->econst.phikbits = phik.bits();
+  r.to_words(P->econst.r, 8);
+  P->econst.rbits = r.bits();
+  P->nlimb = 33;
+  P->len_fq = (q.bits() + 7) / 8;
+  P->len1 = P->len2 = 2 * P->len_fq;
+  P->lenT = P->len_fq;
+  P->len_zr = (r.bits() + 7) / 8;
+  // work model (e_miller_proj, e_param.c:64-300, + element_pow_mpz by (q-1)/r): per doubling about
+  // 2 squarings + tangent (8, two evaluation points 3 each) + Jacobian doubling (10) + verticals (2)
+  // + 4 accumulations = 32 F_q products; the final power is 1.5 products per exponent bit.
+  P->fq_muls_single = 32.0 * (r.bits() - 1) + 1.5 * phik.bits();
+  P->fq_muls_prod_a = P->fq_muls_single;   // generic_prod_pairings: k full pairings
   P->fq_muls_prod_b = 0.0;
   return 0;
 }
@@ -351,6 +410,9 @@ static void fill_curve(const pbc_hip_pairing_s *P, CurveK &C) {
     memcpy(C.a, P->k16.one, sizeof P->k16.one);
   } else if (P->type == '1') {          // the same curve over the type a1 field (a_param.c:2247-2251)
     memcpy(C.a, P->k33.one, sizeof P->k33.one);
+  } else if (P->type == 'e') {
+    memcpy(C.a, P->econst.A, sizeof P->econst.A);
+    memcpy(C.b, P->econst.B, sizeof P->econst.B);
   } else if (P->type == 'd' || P->type == 'g') {
     memcpy(C.a, P->dconst.A, sizeof P->dconst.A);
     memcpy(C.b, P->dconst.B, sizeof P->dconst.B);

@@ -16,6 +16,7 @@
 #include "pairing_a.cuh"
 #include "pairing_d.cuh"
 #include "pairing_f.cuh"
+#include "pairing_e.cuh"
 
 using namespace pbc;
 
@@ -97,6 +98,27 @@ __global__ void __launch_bounds__(kBlock, PBC_A1_WAVES) a1_prod_pairing_kernel(u
       for (int i = 0; i < L / 4; i++) dst[i] = src[i];
     } else {
       for (int i = 0; i < L; i++) gt[idx * L + i] = out[i];
+    }
+  }
+}
+
+// Type E: one k-term product (k = 1: a single pairing) per lane; G1/G2 256 B, GT 128 B for e.param.
+template <int N>
+__global__ void __launch_bounds__(kBlock, PBC_A1_WAVES) e_prod_pairing_kernel(uint8_t *gt, const uint8_t *g1,
+                                                                              const uint8_t *g2, size_t n, int k) {
+  size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
+  size_t ld = idx < n ? idx : n - 1;
+  const int LT = fq_bytes<N>(), L = 2 * LT;
+  __attribute__((aligned(4))) uint8_t out[4 * N];
+  __shared__ uint32_t lds_q[2 * N * kBlock];
+  e_prod_pairing_lane<N>(out, g1 + ld * k * L, g2 + ld * k * L, k, lds_q + threadIdx.x, kBlock);
+  if (idx < n) {
+    if ((LT & 3) == 0) {
+      uint32_t *dst = reinterpret_cast<uint32_t *>(gt + idx * LT);
+      const uint32_t *src = reinterpret_cast<const uint32_t *>(out);
+      for (int i = 0; i < LT / 4; i++) dst[i] = src[i];
+    } else {
+      for (int i = 0; i < LT; i++) gt[idx * LT + i] = out[i];
     }
   }
 }
@@ -197,6 +219,28 @@ __global__ void __launch_bounds__(kBlock, 2) gt_op_kernel(int type, int op, uint
   if (idx >= n) return;
   uint8_t *o = out + idx * lenT;
   const uint8_t *x = a + idx * lenT;
+  if constexpr (N == 33) {
+    if (type == 'e') {                 // GT = F_q (pairing_GT_init(pairing, p->Fq), e_param.c:863)
+      fp<N> u, v;
+      fp_load_be<N>(u, x);
+      if (op == 0) {
+        fp_load_be<N>(v, b + idx * lenT);
+        fp_mul<N>(u, u, v);
+      } else {
+        fp<N> acc, t;
+        fp_set<N>(acc, fpk<N>().one);
+        const uint8_t *z = b + idx * zlen;
+        for (int i = 8 * zlen - 1; i >= 0; i--) {
+          fp_sqr<N>(acc, acc);
+          fp_mul<N>(t, acc, u);
+          fp_cmov<N>(acc, t, zr_bit(z, zlen, i) != 0);
+        }
+        u = acc;
+      }
+      fp_store_be<N>(o, u);
+      return;
+    }
+  }
   if constexpr (N == 16 || N == 33) {
     if (op == 0) a_gt_mul_lane<N>(o, x, b + idx * lenT); else a_gt_pow_lane<N>(o, x, b + idx * zlen, zlen);
   } else {
@@ -393,6 +437,9 @@ extern "C" int pbc_hip_pairing_init_set_buf(pbc_hip_pairing_t **out, const char 
   } else if (type == "a1") {
     P->type = '1';
     rc = init_type_a1(P, param, len);
+  } else if (type == "e") {
+    P->type = 'e';
+    rc = init_type_e(P, param, len);
   } else if (type == "d") {
     P->type = 'd';
     rc = init_type_d(P, param, len, 3);
@@ -478,6 +525,19 @@ static int upload_constants(pbc_hip_pairing_s *P, hipStream_t s) {
     }
     HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_d), &P->dconst, sizeof P->dconst, 0, hipMemcpyHostToDevice, s));
   }
+  if (P->type == 'e') {
+    if (!P->dev_ready) {
+      // one-time search of the auxiliary point on the device (single lane)
+      EConst *dbuf;
+      HIP_TRY(hipMalloc(&dbuf, sizeof(EConst)));
+      hipLaunchKernelGGL(e_init_kernel<33>, dim3(1), dim3(64), 0, s, dbuf, P->eraw, P->econst);
+      HIP_TRY(hipMemcpyAsync(&P->econst, dbuf, sizeof(EConst), hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipStreamSynchronize(s));
+      (void) hipFree(dbuf);
+      P->dev_ready = true;
+    }
+    HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_e), &P->econst, sizeof P->econst, 0, hipMemcpyHostToDevice, s));
+  }
   if (P->type == 'f') {
     if (!P->dev_ready) {
       FConst *dbuf;
@@ -513,6 +573,9 @@ static int launch_pairing(pbc_hip_pairing_s *P, void *d_gt, const void *d_g1, co
                        (const uint8_t *) d_g1, (const uint8_t *) d_g2, n);
   } else if (P->type == '1') {
     hipLaunchKernelGGL(a1_prod_pairing_kernel<33>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
+                       (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, 1);
+  } else if (P->type == 'e') {
+    hipLaunchKernelGGL(e_prod_pairing_kernel<33>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
                        (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, 1);
   } else if (P->type == 'd' || P->type == 'g') {
     PBC_DISPATCH_D(P, hipLaunchKernelGGL((d_prod_pairing_kernel<N, DEG>), dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
@@ -609,6 +672,9 @@ static int launch_prod(pbc_hip_pairing_s *P, void *d_gt, const void *d_g1, const
   } else if (P->type == '1') {
     hipLaunchKernelGGL(a1_prod_pairing_kernel<33>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
                        (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k);
+  } else if (P->type == 'e') {
+    hipLaunchKernelGGL(e_prod_pairing_kernel<33>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
+                       (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k);
   } else if (P->type == 'd' || P->type == 'g') {
     PBC_DISPATCH_D(P, hipLaunchKernelGGL((d_prod_pairing_kernel<N, DEG>), dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
                                                 (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k));
@@ -643,8 +709,8 @@ static int run_group(pbc_hip_pairing_s *P, int what, int group, uint8_t *out, co
   if (!n) return 0;
   size_t la, lb, lo;
   if (what == 0) {                     // G mul_zn
-    if (group != 1 && !(group == 2 && (P->type == 'a' || P->type == '1')))
-      return fail("scalar multiplication is built for G1 (and G2 of the symmetric types a, a1)");
+    if (group != 1 && !(group == 2 && (P->type == 'a' || P->type == '1' || P->type == 'e')))
+      return fail("scalar multiplication is built for G1 (and G2 of the symmetric types a, a1, e)");
     la = lo = (size_t) P->len1;
     lb = (size_t) P->len_zr;
   } else if (what == 1) {              // GT mul

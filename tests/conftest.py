@@ -49,12 +49,14 @@ PARAM_OF = {"a": "a", "d": "d159", "f": "f"}
 # the other type d parameter files the reference ships (param/): 175..224-bit q, 6 / 7 word fields
 OTHER_D = ["d277699-175-167", "d278027-190-181", "d105171-196-185", "d201", "d224"]
 # ... the type g (Freeman, k = 10) file: 149-bit q, F_q^5 / F_q^10 towers, and type a1
-OTHER = OTHER_D + ["g149", "a1"]
+OTHER = OTHER_D + ["g149", "a1", "e"]
 # param -> (random single pairings, edge cases incl. off-curve inputs, product with edge cases)
 FILES_OF = {d: (d + "_rand12.vec", d + "_edge8.vec", d + "_prod3x4_edge.vec") for d in OTHER_D}
 FILES_OF["g149"] = ("g149_rand16.vec", "g149_edge10.vec", "g149_prod3x4_edge.vec")
 # type a1: 1033-bit p, composite group order n (a1.param)
 FILES_OF["a1"] = ("a1_rand6.vec", "a1_edge6.vec", "a1_prod3x3_edge.vec")
+# type e: k = 1, 1020-bit q, GT = F_q (e.param)
+FILES_OF["e"] = ("e_rand6.vec", "e_edge6.vec", "e_prod3x3_edge.vec")
 
 
 def key_of(vec_name):

@@ -35,6 +35,7 @@ static void activate(pbc_hip_pairing_s *P) {
   if (P->type == 'a' || P->type == '1') c_a = P->a;
   if (P->type == 'd' || P->type == 'g') c_d = P->dconst;
   if (P->type == 'f') c_f = P->fconst;
+  if (P->type == 'e') c_e = P->econst;
   CurveK C;
   fill_curve(P, C);
   c_curve = C;
@@ -49,6 +50,7 @@ void *hostsim_init(const char *param, size_t len) {
   int rc = 1;
   if (type == "a") { P->type = 'a'; rc = init_type_a(P, param, len); }
   else if (type == "a1") { P->type = '1'; rc = init_type_a1(P, param, len); }
+  else if (type == "e") { P->type = 'e'; rc = init_type_e(P, param, len); }
   else if (type == "d") { P->type = 'd'; rc = init_type_d(P, param, len, 3); }
   else if (type == "g") { P->type = 'g'; rc = init_type_d(P, param, len, 5); }
   else if (type == "f") { P->type = 'f'; rc = init_type_f(P, param, len); }
@@ -61,6 +63,12 @@ void *hostsim_init(const char *param, size_t len) {
     HS_DISPATCH_D(P, TypeMNT<N, DEG>::init_stage2(&tmp, P->draw));
     c_d = tmp;
     P->dconst = tmp;
+  }
+  if (P->type == 'e') {
+    EConst tmp;
+    e_init_kernel<33>(&tmp, P->eraw, P->econst);
+    P->econst = tmp;
+    c_e = tmp;
   }
   if (P->type == 'f') {
     FConst tmp;
@@ -88,6 +96,7 @@ int hostsim_prod_pairing(void *h, uint8_t *gt, const uint8_t *g1, const uint8_t 
     uint8_t *o = gt + u * P->lenT;
     if (P->type == 'a') a_prod_pairing_lane<16>(o, a, b, k, lds, 1);
     else if (P->type == '1') a1_prod_pairing_lane<33>(o, a, b, k, lds, 1);
+    else if (P->type == 'e') e_prod_pairing_lane<33>(o, a, b, k, lds, 1);
     else if (P->type == 'd' || P->type == 'g') { HS_DISPATCH_D(P, TypeMNT<N, DEG>::d_prod_pairing_lane(o, a, b, k)); }
     else f_prod_pairing_lane(o, a, b, k);
   }
@@ -115,6 +124,18 @@ int hostsim_group(void *h, int what, uint8_t *out, const uint8_t *a, const uint8
       const uint8_t *x = a + i * P->lenT, *y = b + i * (what == 1 ? P->lenT : P->len_zr);
       if (P->type == 'a') { if (what == 1) a_gt_mul_lane<16>(o, x, y); else a_gt_pow_lane<16>(o, x, y, P->len_zr); }
       else if (P->type == '1') { if (what == 1) a_gt_mul_lane<33>(o, x, y); else a_gt_pow_lane<33>(o, x, y, P->len_zr); }
+      else if (P->type == 'e') {
+        fp<33> u, v;
+        fp_load_be<33>(u, x);
+        if (what == 1) { fp_load_be<33>(v, y); fp_mul<33>(u, u, v); }
+        else {
+          fp<33> acc, t;
+          fp_set<33>(acc, fpk<33>().one);
+          for (int i = 8 * P->len_zr - 1; i >= 0; i--) { fp_sqr<33>(acc, acc); fp_mul<33>(t, acc, u); fp_cmov<33>(acc, t, zr_bit(y, P->len_zr, i) != 0); }
+          u = acc;
+        }
+        fp_store_be<33>(o, u);
+      }
       else if (P->type == 'd' || P->type == 'g') { HS_DISPATCH_D(P, if (what == 1) d_gt_mul_lane<N, DEG>(o, x, y); else d_gt_pow_lane<N, DEG>(o, x, y, P->len_zr)); }
       else { if (what == 1) f_gt_mul_lane(o, x, y); else f_gt_pow_lane(o, x, y, P->len_zr); }
     }

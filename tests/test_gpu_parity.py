@@ -347,6 +347,9 @@ def test_other_type_d_and_g_params_match_reference_vectors(hips, d):
     if d == "a1":
         fb = (param_value(d, "p").bit_length() + 7) // 8
         assert (H.length_in_bytes_G1, H.length_in_bytes_G2, H.length_in_bytes_GT) == (2 * fb, 2 * fb, 2 * fb)
+    elif d == "e":
+        fb = (param_value(d, "q").bit_length() + 7) // 8
+        assert (H.length_in_bytes_G1, H.length_in_bytes_G2, H.length_in_bytes_GT) == (2 * fb, 2 * fb, fb)
     else:
         fb = (param_value(d, "q").bit_length() + 7) // 8
         deg = param_value(d, "k") // 2

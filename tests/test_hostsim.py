@@ -23,7 +23,7 @@ def sims():
     ("a_kat.vec", 1), ("a_rand32.vec", 6), ("a_edge20.vec", 20), ("a_prod2x8.vec", 4), ("a_prod3x10_edge.vec", 10),
     ("d_rand32.vec", 6), ("d_edge20.vec", 20), ("d_prod16x4.vec", 2), ("d_prod3x10_edge.vec", 10),
     ("f_rand16.vec", 3), ("f_edge10.vec", 10), ("f_prod3x5_edge.vec", 5),
-] + [(name, 2 if d == "a1" else 4) for d in OTHER for name in FILES_OF[d]] + [("g149_prod4x3.vec", 1)])
+] + [(name, 2 if d in ("a1", "e") else 4) for d in OTHER for name in FILES_OF[d]] + [("g149_prod4x3.vec", 1)])
 def test_kernel_source_on_host_matches_reference(sims, name, count):
     v = golden(name)
     n = min(count, v.n)

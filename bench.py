@@ -68,7 +68,10 @@ def cpu_baseline(param_path, k=1, fixture=None):
                 out = subprocess.run([tool, "bench", param_path, str(per_worker), str(k), str(workers)],
                                      capture_output=True, text=True, timeout=300)
                 return json.loads(out.stdout.strip().splitlines()[-1])
-            scale = {"a": 1, "d": 4, "f": 16}.get(os.path.basename(param_path)[0], 1) * k
+            # relative cost of one reference pairing (keeps the CPU sample at roughly 10-30 s)
+            base = os.path.basename(param_path)
+            scale = {"a.param": 1, "a1.param": 48, "e.param": 8, "f.param": 16, "g149.param": 12}.get(
+                base, 8 if base.startswith("d") and base != "d159.param" else 4 if base.startswith("d") else 1) * k
             one = run(max(16, 2048 // scale), 1)     # one core alone (~2 s)
             per_worker = max(8, 1024 // scale)
             allc = run(per_worker, cores)            # every logical CPU busy
@@ -132,6 +135,8 @@ WORKLOADS = {
              "Type D (d278027-190-181.param, 6-word field) element_pairing"),
     "a-prod16": ("a", "a_chain1024.vec", 16, 18, "Type A (a.param) element_prod_pairing, 16 terms"),
     "a-pp": ("a", "a_chain1024.vec", 1, 20, "Type A (a.param) pairing_pp_apply, fixed first argument"),
+    "d-pp": ("d159", "d_chain256.vec", 1, 18, "Type D (d159.param) pairing_pp_apply, fixed first argument"),
+    "g-pp": ("g149", "g149_chain64.vec", 1, 17, "Type G (g149.param) pairing_pp_apply, fixed first argument"),
 }
 
 
@@ -189,7 +194,7 @@ def main():
     GT = torch.empty(n, LT, dtype=torch.uint8, device="cuda")
     stream = torch.cuda.current_stream()
 
-    pp = pairing.pp_init(g1[0]) if args.workload == "a-pp" else None
+    pp = pairing.pp_init(g1[0]) if args.workload.endswith("-pp") else None
 
     def step():
         if pp is not None:
@@ -258,7 +263,7 @@ def main():
         avg_kern_s = sum(kern_ms) / len(kern_ms) * 1e-3
         macs_per_unit = pairing.algorithmic_macs_per_unit(k)
         if pp is not None:
-            macs_per_unit = 1838.0 * 528     # reference a_pairing_pp_apply: 1838 F_q products
+            macs_per_unit = pairing.algorithmic_macs_per_unit(-1)   # the reference's pp_apply algorithm
         # measured integer multiply-add peak of this chip (register-only v_mad_u64_u32 probe)
         peak_macs, _ = pbc_amd.int_mac_peak(0, 4000)
         achieved_macs = n * macs_per_unit / avg_kern_s

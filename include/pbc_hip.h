@@ -125,7 +125,8 @@ int pbc_hip_diag_stage(pbc_hip_pairing_t *p, int stage, uint8_t *out, size_t out
                        const uint8_t *g1, const uint8_t *g2, size_t n);
 
 /* Algorithmic work model used for the roofline: reference F_q multiplications
- * per unit x (2N^2+N) 32-bit MACs. */
+ * per unit x (2N^2+N) 32-bit MACs.  k >= 1: a k-term product (k = 1: one pairing); k = -1: one
+ * pairing_pp_apply (the reference's pp algorithm: no arithmetic on the first argument's curve). */
 double pbc_hip_algorithmic_macs_per_unit(const pbc_hip_pairing_t *p, int k);
 
 const char *pbc_hip_last_error(void);

@@ -52,6 +52,7 @@ struct pbc_hip_pairing_s {
   int len_zr;                // bytes of a Z_r scalar (pairing_length_in_bytes_Zr)
   double fq_muls_single;     // reference F_q multiplication count per pairing (work model)
   double fq_muls_prod_a, fq_muls_prod_b;   // products: a*k + b
+  double fq_muls_pp;         // one pairing_pp_apply (0: no preprocessed variant in the reference)
 };
 
 // min_bits: smallest modulus accepted for this word count (default: the top word is in use)
@@ -128,6 +129,7 @@ static int init_type_a(pbc_hip_pairing_s *P, const char *txt, size_t len) {
   // linear model through (1, 4392-ish) and (16, 41377): 2543 k + 689
   P->fq_muls_prod_a = 2543.0;
   P->fq_muls_prod_b = 689.0;
+  P->fq_muls_pp = 1838.0;                // a_pairing_pp_apply (a_param.c:317-360)
   return 0;
 }
 
@@ -297,6 +299,11 @@ static int init_type_d(pbc_hip_pairing_s *P, const char *txt, size_t len, int de
     P->fq_muls_single = miller + tate;
     P->fq_muls_prod_a = miller;            // per-term Miller work + one cc_tatepower
     P->fq_muls_prod_b = tate;
+    // d_pairing_pp_apply (d_param.c:908-966) skips the affine point arithmetic of the Miller loop:
+    // tangent coefficients + doubling (7 products per bit of r), chord + addition (5 per set bit)
+    int adds = 0;
+    for (int i = 1; i < r.bits() - 1; i++) adds += r.bit(i);
+    P->fq_muls_pp = P->fq_muls_single - 7.0 * (r.bits() - 1) - 5.0 * adds;
   } else {
     // g149.param (149-bit r, 447-bit Phi_10(q)/r): F_q products counted on the CPU restatement of
     // the reference's algorithm (the test oracle's counters; polymod_mul is schoolbook + table for
@@ -305,6 +312,9 @@ static int init_type_d(pbc_hip_pairing_s *P, const char *txt, size_t len, int de
     P->fq_muls_single = miller + tate;
     P->fq_muls_prod_a = miller + tate;     // generic_prod_pairings (pairing.c:35-46): k full pairings
     P->fq_muls_prod_b = 0.0;
+    int adds = 0;                          // g_pairing_pp_apply (g_param.c:741-787), as for type d
+    for (int i = 1; i < r.bits() - 1; i++) adds += r.bit(i);
+    P->fq_muls_pp = P->fq_muls_single - 7.0 * (r.bits() - 1) - 5.0 * adds;
   }
   return 0;
 }

@@ -323,9 +323,9 @@ static PBC_DEV void d_unpack(f6 &e0, v32 r) {
 }
 // tangent at V (do_tangent d_param.c:344-362, scaled by Z^6 in F_q^*) and V <- 2V:
 //   M = 3X^2 + a Z^4,  a' = -M Z^2,  b' = (2YZ) Z^2,  c' = M X - 2Y^2
-static __device__ __noinline__ v32 d_dbl_line_fn() {
+static PBC_DEV void d_dbl_core(fq &la, fq &lb, fq &lc) {
   fq X = dl_get(DL_X), Y = dl_get(DL_Y), Z = dl_get(DL_Z);
-  fq ZZ, XX, YY, M, t0, t1, S, Z3, la, lb, lc;
+  fq ZZ, XX, YY, M, t0, t1, S, Z3;
   fp_sqr_inl<ND>(ZZ, Z);
   fp_sqr_inl<ND>(XX, X);
   fp_sqr_inl<ND>(YY, Y);
@@ -358,13 +358,17 @@ static __device__ __noinline__ v32 d_dbl_line_fn() {
   dl_put(DL_X, X);
   dl_put(DL_Y, Y);
   dl_put(DL_Z, Z3);
+}
+static __device__ __noinline__ v32 d_dbl_line_fn() {
+  fq la, lb, lc;
+  d_dbl_core(la, lb, lc);
   return d_evalfn_pack(la, lb, lc);
 }
 // chord through V and the affine P (do_line d_param.c:364-379, scaled by Z3 = Z H):
 //   H = Px Z^2 - X, R = Py Z^3 - Y;  a' = -R,  b' = Z3,  c' = R Px - Z3 Py;   V <- V + P
-static __device__ __noinline__ v32 d_add_line_fn() {
+static PBC_DEV void d_add_core(fq &la, fq &lb, fq &lc) {
   fq X = dl_get(DL_X), Y = dl_get(DL_Y), Z = dl_get(DL_Z), Px = dl_get(DL_PX), Py = dl_get(DL_PY);
-  fq ZZ, H, R, HH, HHH, t0, t1, Z3, la, lc;
+  fq ZZ, H, R, HH, HHH, t0, t1, Z3;
   fp_sqr_inl<ND>(ZZ, Z);
   fp_mul_inl<ND>(H, Px, ZZ);
   fp_sub<ND>(H, H, X);
@@ -390,7 +394,12 @@ static __device__ __noinline__ v32 d_add_line_fn() {
   dl_put(DL_X, t1);
   dl_put(DL_Y, Y);
   dl_put(DL_Z, Z3);
-  return d_evalfn_pack(la, Z3, lc);
+  lb = Z3;
+}
+static __device__ __noinline__ v32 d_add_line_fn() {
+  fq la, lb, lc;
+  d_add_core(la, lb, lc);
+  return d_evalfn_pack(la, lb, lc);
 }
 
 static PBC_DEV void f3_load_be(f3 &r, const uint8_t *src) { for (int i = 0; i < DEG; i++) fp_load_be<ND>(r.c[i], src + fpk<ND>().fbytes * i); }
@@ -514,6 +523,98 @@ static PBC_DEV void d_store_gt(uint8_t *gt, f6 &out, bool valid) {
   }
   f3_store_be(gt, out.x);
   f3_store_be(gt + DEG * fpk<ND>().fbytes, out.y);
+}
+
+// ---- preprocessed pairings: pairing_pp_init / pairing_pp_apply (include/pbc_pairing.h:54-89) ----
+// d_pairing_pp_init (d_param.c:794-880) / g_pairing_pp_init (g_param.c:619-722) store the line
+// coefficients of every Miller step for a fixed first argument; the apply routines (:908-966,
+// :741-787) then need no arithmetic on E(F_q).  Here the table holds (a', b', c') of each step in the
+// projective scaling of d_dbl_core / d_add_core, in loop order: [steps][3][ND] words, uniform data.
+static PBC_DEV bool d_pp_init_lane(uint32_t *tab, const uint8_t *g1) {
+  const int NB = (int) fpk<ND>().fbytes;
+  fq Px, Py, one, t0, t1;
+  fp_set<ND>(one, fpk<ND>().one);
+  fp_load_be<ND>(Px, g1);
+  fp_load_be<ND>(Py, g1 + NB);
+  fp_sqr<ND>(t0, Px);
+  fp_add<ND>(t0, t0, dk(c_d.A));
+  fp_mul<ND>(t0, t0, Px);
+  fp_add<ND>(t0, t0, dk(c_d.B));
+  fp_sqr<ND>(t1, Py);
+  bool valid = fp_eq<ND>(t0, t1);
+  dl_put(DL_X, Px); dl_put(DL_Y, Py); dl_put(DL_Z, one);
+  dl_put(DL_PX, Px); dl_put(DL_PY, Py);
+  int slot = 0;
+  for (int m = c_d.rbits - 2;; m--) {
+    fq la, lb, lc;
+    d_dbl_core(la, lb, lc);
+    for (int k = 0; k < ND; k++) { tab[(slot * 3 + 0) * ND + k] = la.v[k]; tab[(slot * 3 + 1) * ND + k] = lb.v[k]; tab[(slot * 3 + 2) * ND + k] = lc.v[k]; }
+    slot++;
+    if (m <= 0) break;
+    if ((c_d.r[m >> 5] >> (m & 31)) & 1) {
+      d_add_core(la, lb, lc);
+      for (int k = 0; k < ND; k++) { tab[(slot * 3 + 0) * ND + k] = la.v[k]; tab[(slot * 3 + 1) * ND + k] = lb.v[k]; tab[(slot * 3 + 2) * ND + k] = lc.v[k]; }
+      slot++;
+    }
+  }
+  return valid;
+}
+static __device__ __noinline__ v32 d_pp_line_fn(v5 va, v5 vb, v5 vc) {
+  fq a, b, c;
+  from_vec<ND>(a, va);
+  from_vec<ND>(b, vb);
+  from_vec<ND>(c, vc);
+  return d_evalfn_pack(a, b, c);
+}
+static PBC_DEV void d_pp_line(f6 &e0, const uint32_t *tab, int slot) {
+  fq a, b, c;
+#pragma unroll
+  for (int k = 0; k < ND; k++) {
+    a.v[k] = tab[(slot * 3 + 0) * ND + k];
+    b.v[k] = tab[(slot * 3 + 1) * ND + k];
+    c.v[k] = tab[(slot * 3 + 2) * ND + k];
+  }
+  d_unpack(e0, d_pp_line_fn(to_vec<ND>(a), to_vec<ND>(b), to_vec<ND>(c)));
+}
+// pairing_pp_apply for one lane
+static PBC_DEV void d_pp_apply_lane(uint8_t *gt, const uint32_t *tab, bool p_valid, const uint8_t *g2) {
+  const int NB = (int) fpk<ND>().fbytes;
+  fq one;
+  f3 Qx, Qy;
+  f6 v, out;
+  fp_set<ND>(one, fpk<ND>().one);
+  f3_load_be(Qx, g2);
+  f3_load_be(Qy, g2 + DEG * NB);
+  bool valid = p_valid;
+  {
+    f3 u0, u1;
+    f3_sqr(u0, Qx);
+    fp_add<ND>(u0.c[0], u0.c[0], dk(c_d.ta));
+    f3_mul(u0, u0, Qx);
+    fp_add<ND>(u0.c[0], u0.c[0], dk(c_d.tb));
+    f3_sqr(u1, Qy);
+    valid &= f3_eq(u0, u1);
+  }
+  f3_mul_fq(Qx, Qx, dk(c_d.nqrinv));
+  f3_mul_fq(Qy, Qy, dk(c_d.nqrinv2));
+#pragma unroll
+  for (int i = 0; i < DEG; i++) { dl_put(DL_QX + ND * i, Qx.c[i]); dl_put(DL_QY + ND * i, Qy.c[i]); }
+  f3_set_fq(v.x, one);
+  f3_sub(v.y, v.x, v.x);
+  int slot = 0;
+  for (int m = c_d.rbits - 2;; m--) {
+    f6 e0;
+    d_pp_line(e0, tab, slot++);
+    f6_mul(v, v, e0);
+    if (m <= 0) break;
+    if ((c_d.r[m >> 5] >> (m & 31)) & 1) {
+      d_pp_line(e0, tab, slot++);
+      f6_mul(v, v, e0);
+    }
+    f6_sqr(v, v);
+  }
+  d_final_exp(out, v);
+  d_store_gt(gt, out, valid);
 }
 
 // element_pairing (cc_pairing) / element_prod_pairing (cc_pairings_affine, d_param.c:710-736:

@@ -80,8 +80,8 @@ __global__ void __launch_bounds__(kBlock, PBC_A_WAVES) a_prod_pairing_kernel(uin
 
 // Type A1: one k-term product (k = 1: a single pairing) per lane; 130-byte coordinates for a1.param.
 #ifndef PBC_A1_WAVES
-#define PBC_A1_WAVES 2
-#endif
+#define PBC_A1_WAVES 1    // 33-word fields: the 512-register budget of one wave per SIMD beats two waves
+#endif                    // with 256 (measured: a1 119 k -> 158 k pairings/s, e 769 k -> 971 k)
 template <int N>
 __global__ void __launch_bounds__(kBlock, PBC_A1_WAVES) a1_prod_pairing_kernel(uint8_t *gt, const uint8_t *g1,
                                                                                const uint8_t *g2, size_t n, int k) {
@@ -158,6 +158,32 @@ __global__ void __launch_bounds__(kBlock, PBC_DF_WAVES) d_prod_pairing_kernel(ui
   const int fb = (int) fpk<N>().fbytes, L1 = 2 * fb, L2 = 2 * DEG * fb, LT = 2 * DEG * fb;
   __attribute__((aligned(4))) uint8_t out[8 * DEG * N];
   TypeMNT<N, DEG>::d_prod_pairing_lane(out, g1 + ld * k * L1, g2 + ld * k * L2, k);
+  if (idx < n) {
+    if ((LT & 3) == 0) {
+      uint32_t *dst = reinterpret_cast<uint32_t *>(gt + idx * LT);
+      const uint32_t *src = reinterpret_cast<const uint32_t *>(out);
+      for (int i = 0; i < LT / 4; i++) dst[i] = src[i];
+    } else {
+      for (int i = 0; i < LT; i++) gt[idx * LT + i] = out[i];
+    }
+  }
+}
+
+// pairing_pp for types d / g: single-lane table derivation, then one second argument per lane
+template <int N, int DEG>
+__global__ void d_pp_init_kernel(uint32_t *tab, uint32_t *valid, const uint8_t *g1) {
+  if (threadIdx.x || blockIdx.x) return;
+  *valid = TypeMNT<N, DEG>::d_pp_init_lane(tab, g1) ? 1u : 0u;
+}
+template <int N, int DEG>
+__global__ void __launch_bounds__(kBlock, PBC_DF_WAVES) d_pp_apply_kernel(uint8_t *gt, const uint32_t *__restrict__ tab,
+                                                                          const uint32_t *__restrict__ valid,
+                                                                          const uint8_t *g2, size_t n) {
+  size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
+  size_t ld = idx < n ? idx : n - 1;
+  const int fb = (int) fpk<N>().fbytes, L2 = 2 * DEG * fb, LT = 2 * DEG * fb;
+  __attribute__((aligned(4))) uint8_t out[8 * DEG * N];
+  TypeMNT<N, DEG>::d_pp_apply_lane(out, tab, *valid != 0, g2 + ld * L2);
   if (idx < n) {
     if ((LT & 3) == 0) {
       uint32_t *dst = reinterpret_cast<uint32_t *>(gt + idx * LT);
@@ -474,6 +500,7 @@ extern "C" int pbc_hip_length_in_bytes_Fq(const pbc_hip_pairing_t *p) { return p
 extern "C" double pbc_hip_algorithmic_macs_per_unit(const pbc_hip_pairing_t *p, int k) {
   double n = p->nlimb;
   double per_mul = 2 * n * n + n;
+  if (k < 0) return p->fq_muls_pp * per_mul;
   if (k > 1) return (p->fq_muls_prod_a * k + p->fq_muls_prod_b) * per_mul;
   return p->fq_muls_single * per_mul;
 }
@@ -781,24 +808,36 @@ extern "C" int pbc_hip_element_from_hash_batch(pbc_hip_pairing_t *P, int group, 
 // ---- preprocessed pairings ---------------------------------------------------------------
 struct pbc_hip_pp_s {
   pbc_hip_pairing_s *P;
-  uint32_t *tab;      // device: [exp2 + 1][3][16] words
+  uint32_t *tab;      // device: type a [exp2 + 1][3][16] words; types d / g [steps][3][ND] words
   uint32_t *valid;    // device flag: first argument was a finite curve point
 };
 extern "C" int pbc_hip_pairing_pp_init(pbc_hip_pp_t **out, pbc_hip_pairing_t *P, const uint8_t *g1) {
   if (!out || !P || !g1) return fail("null argument");
   if (P->device < 0) return fail("no HIP device: libpbc_hip has no CPU fallback");
-  if (P->type != 'a') return fail("pairing_pp is built for type a only (other types: use element_pairing)");
+  const bool mnt = P->type == 'd' || P->type == 'g';
+  if (P->type != 'a' && !mnt)
+    return fail("pairing_pp is built for types a, d and g (other types: use element_pairing)");
   pbc_hip_pp_s *pp = new pbc_hip_pp_s();
   pp->P = P;
   void *dg1 = nullptr;
   size_t words = (size_t) (P->a.exp2 + 1) * 3 * 16;
+  if (mnt) {                           // one entry per doubling and per addition of the Miller loop
+    int steps = P->dconst.rbits - 1;
+    for (int m = 1; m <= P->dconst.rbits - 2; m++) steps += (P->dconst.r[m >> 5] >> (m & 31)) & 1;
+    words = (size_t) steps * 3 * P->nlimb;
+  }
   if (hipSetDevice(P->device) != hipSuccess || hipMalloc(&pp->tab, words * 4) != hipSuccess ||
       hipMalloc(&pp->valid, 4) != hipSuccess || hipMalloc(&dg1, P->len1) != hipSuccess ||
       hipMemcpy(dg1, g1, P->len1, hipMemcpyHostToDevice) != hipSuccess || upload_constants(P, 0)) {
     delete pp;
     return fail("pairing_pp_init: device setup failed");
   }
-  hipLaunchKernelGGL(a_pp_init_kernel<16>, dim3(1), dim3(64), 0, 0, pp->tab, pp->valid, (const uint8_t *) dg1);
+  if (mnt) {
+    PBC_DISPATCH_D(P, hipLaunchKernelGGL((d_pp_init_kernel<N, DEG>), dim3(1), dim3(64), 0, 0, pp->tab, pp->valid,
+                                         (const uint8_t *) dg1));
+  } else {
+    hipLaunchKernelGGL(a_pp_init_kernel<16>, dim3(1), dim3(64), 0, 0, pp->tab, pp->valid, (const uint8_t *) dg1);
+  }
   hipError_t e = hipDeviceSynchronize();
   (void) hipFree(dg1);
   if (e != hipSuccess) { delete pp; return fail("pairing_pp_init kernel: %s", hipGetErrorString(e)); }
@@ -817,8 +856,13 @@ extern "C" int pbc_hip_pairing_pp_apply_batch_dev(pbc_hip_pp_t *pp, void *d_gt, 
   hipStream_t s = (hipStream_t) stream;
   if (upload_constants(pp->P, s)) return 1;
   unsigned grid = (unsigned) ((n + kBlock - 1) / kBlock);
-  hipLaunchKernelGGL(a_pp_apply_kernel<16>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt, pp->tab, pp->valid,
-                     (const uint8_t *) d_g2, n);
+  if (pp->P->type == 'a') {
+    hipLaunchKernelGGL(a_pp_apply_kernel<16>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt, pp->tab, pp->valid,
+                       (const uint8_t *) d_g2, n);
+  } else {
+    PBC_DISPATCH_D(pp->P, hipLaunchKernelGGL((d_pp_apply_kernel<N, DEG>), dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
+                                             pp->tab, pp->valid, (const uint8_t *) d_g2, n));
+  }
   HIP_TRY(hipGetLastError());
   return 0;
 }

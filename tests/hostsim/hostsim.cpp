@@ -105,9 +105,16 @@ int hostsim_prod_pairing(void *h, uint8_t *gt, const uint8_t *g1, const uint8_t 
 // pairing_pp_init + pairing_pp_apply over n second arguments (Type A)
 int hostsim_pp(void *h, uint8_t *gt, const uint8_t *g1, const uint8_t *g2, size_t n) {
   pbc_hip_pairing_s *P = (pbc_hip_pairing_s *) h;
-  if (P->type != 'a') return 1;
   activate(P);
   static uint32_t tab[512 * 3 * 16];
+  if (P->type == 'd' || P->type == 'g') {
+    HS_DISPATCH_D(P, {
+      bool v = TypeMNT<N, DEG>::d_pp_init_lane(tab, g1);
+      for (size_t u = 0; u < n; u++) TypeMNT<N, DEG>::d_pp_apply_lane(gt + u * P->lenT, tab, v, g2 + u * P->len2);
+    });
+    return 0;
+  }
+  if (P->type != 'a') return 1;
   bool v = a_pp_init_lane<16>(tab, g1);
   for (size_t u = 0; u < n; u++) a_pp_apply_lane<16>(gt + u * P->lenT, tab, v, g2 + u * P->len2);
   return 0;

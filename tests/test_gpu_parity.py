@@ -338,6 +338,29 @@ def test_pairing_pp_matches_element_pairing(hip_a, oracle_a):
     assert np.array_equal(pp.apply(v.g2[:3]), np.tile(one, (3, 1)))
 
 
+@pytest.mark.parametrize("t,name", [("d", "d_chain256.vec"), ("d201", "d201_rand12.vec"), ("d278027-190-181", "d278027-190-181_rand12.vec"),
+                                    ("g149", "g149_chain64.vec")])
+def test_pairing_pp_types_d_g(hips, oracles, t, name):
+    """d_pairing_pp_init/apply (d_param.c:794-966), g_pairing_pp_init/apply (g_param.c:619-787)."""
+    v = golden(name)
+    H = hips[t]
+    m = min(v.n, 140)                                      # more than one block for the chain fixtures
+    for pi in (0, 3):
+        pp = H.pp_init(v.g1[pi])
+        Q = v.g2[:m].copy()
+        Q[5, -1] ^= 1                                      # identity second argument
+        got = pp.apply(Q)
+        assert np.array_equal(got, H.element_pairing(np.tile(v.g1[pi], (m, 1)), Q))
+        assert np.array_equal(got[pi], v.gt[pi])           # e(P_i, Q_i) from the reference fixture
+        assert np.array_equal(got[:6], oracles[t].pairing_batch(np.tile(v.g1[pi], (6, 1)), Q[:6]))
+        pp.clear()
+    bad = v.g1[2].copy()
+    bad[1] ^= 8
+    one = np.zeros(H.length_in_bytes_GT, np.uint8)
+    one[H.length_in_bytes_G1 // 2 - 1] = 1
+    assert np.array_equal(H.pp_init(bad).apply(v.g2[:3]), np.tile(one, (3, 1)))
+
+
 # ---- the other shipped type d parameter files: 175..224-bit q, 6 / 7 word fields, 22..28-byte
 # ---- coordinates (not whole words for d277699-175-167, d105171-196-185, d201), and type g
 # ---- (g149.param: k = 10, F_q^5 / F_q^10, 19-byte coordinates) --------------------------------

@@ -9,9 +9,10 @@ import shutil
 import sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01_final"
-ev = "gpurun_out/ev"
+more = len(sys.argv) > 2 and sys.argv[2] == "more"      # tools/collect_evidence_more.sh output
+ev = "gpurun_out/ev2" if more else "gpurun_out/ev"
 os.makedirs("profiles", exist_ok=True)
-for w in ("a", "d", "f", "a-prod16", "a-pp"):
+for w in ("d190", "d201", "d224", "g", "e", "a1", "d-pp", "g-pp") if more else ("a", "d", "f", "a-prod16", "a-pp"):
     src = "%s/bench_%s.json" % (ev, w)
     if os.path.exists(src) and os.path.getsize(src):
         shutil.copy(src, "profiles/%s_bench_%s.json" % (tag, w))

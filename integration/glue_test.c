@@ -47,8 +47,9 @@ int main(int argc, char **argv) {
   }
   element_prod_pairing(gprod, P + 8, Q + 8, K);
   if (element_cmp(gprod, cprod)) { printf("element_prod_pairing mismatch\n"); fails++; }
-  /* 1b. preprocessed pairings through pairing->pp_init/pp_apply (type A) */
-  if (strstr(text, "type a")) {
+  /* 1b. preprocessed pairings through pairing->pp_init/pp_apply (on the GPU for types a, d, g;
+   *     the reference's own CPU routines otherwise) */
+  {
     pairing_pp_t pp;
     pairing_pp_init(pp, P[0], pairing);
     for (size_t i = 0; i < 6 && i < n; i++) {

@@ -12,6 +12,7 @@ static struct {
   int (*init)(pbc_hip_pairing_t **, const char *, size_t);
   void (*clear)(pbc_hip_pairing_t *);
   int (*len1)(const pbc_hip_pairing_t *), (*len2)(const pbc_hip_pairing_t *), (*lenT)(const pbc_hip_pairing_t *);
+  int (*type)(const pbc_hip_pairing_t *);
   int (*pair)(pbc_hip_pairing_t *, unsigned char *, const unsigned char *, const unsigned char *, size_t);
   int (*prod)(pbc_hip_pairing_t *, unsigned char *, const unsigned char *, const unsigned char *, size_t, int);
   const char *(*err)(void);
@@ -49,7 +50,7 @@ static int load_lib(void) {
 #define SYM(f, n) do { *(void **) &L.f = dlsym(L.dl, n); if (!L.f) { fprintf(stderr, "pbc_hip: missing %s\n", n); return 1; } } while (0)
   SYM(init, "pbc_hip_pairing_init_set_buf"); SYM(clear, "pbc_hip_pairing_clear");
   SYM(len1, "pbc_hip_pairing_length_in_bytes_G1"); SYM(len2, "pbc_hip_pairing_length_in_bytes_G2");
-  SYM(lenT, "pbc_hip_pairing_length_in_bytes_GT");
+  SYM(lenT, "pbc_hip_pairing_length_in_bytes_GT"); SYM(type, "pbc_hip_pairing_type");
   SYM(pair, "pbc_hip_element_pairing_batch"); SYM(prod, "pbc_hip_element_prod_pairing_batch");
   SYM(err, "pbc_hip_last_error");
   SYM(pp_init, "pbc_hip_pairing_pp_init"); SYM(pp_clear, "pbc_hip_pairing_pp_clear");
@@ -114,7 +115,7 @@ static void hip_prod(element_ptr out, element_t in1[], element_t in2[], int n_pr
 }
 
 /* pairing->pp_init / pp_apply / pp_clear replacements (include/pbc_pairing.h:39-41, 54-89).
- * p->data holds the GPU handle.  Installed for type A only. */
+ * p->data holds the GPU handle.  Installed for types a, d and g (plain_pp_* below for the rest). */
 static void hip_pp_init(pairing_pp_t p, element_t in1, struct pairing_s *pairing) {
   attach_t *a = find(pairing);
   unsigned char *buf = malloc(L.len1(a->gpu));
@@ -134,12 +135,35 @@ static void hip_pp_apply(element_t out, element_t in2, pairing_pp_t p) {
   else element_from_bytes(out, buf + l2);
   free(buf);
 }
+/* Types without a preprocessed form on the GPU (a1, e, f): pairing_pp keeps a copy of the first
+ * argument and every apply is an ordinary GPU pairing. */
+static void plain_pp_init(pairing_pp_t p, element_t in1, struct pairing_s *pairing) {
+  (void) pairing;
+  element_ptr c = malloc(sizeof(*c));
+  element_init_same_as(c, in1);
+  element_set(c, in1);
+  p->data = c;
+}
+static void plain_pp_clear(pairing_pp_t p) { if (p->data) { element_clear(p->data); free(p->data); } }
+static void plain_pp_apply(element_t out, element_t in2, pairing_pp_t p) { hip_map(out, p->data, in2, p->pairing); }
+
 /* outs[i] = e(P, in2[i]) for the P given to pairing_pp_init: pairing_pp_apply over a batch */
 int pairing_pp_apply_batch(element_t out[], element_t in2[], size_t n, pairing_pp_t p) {
   if (!n) return 0;
   if (!p->pairing) { for (size_t i = 0; i < n; i++) element_set0(out[i]); return 0; }   /* P was O */
   attach_t *a = find(p->pairing);
   if (!a || !p->data) return 1;
+  if (p->pairing->pp_apply != hip_pp_apply) {
+    /* no preprocessed form on the GPU for this type (a1, e, f): p->data is a copy of the first
+     * argument (plain_pp_init) -- run the batch as n ordinary pairings */
+    if (p->pairing->pp_apply != plain_pp_apply) return 1;
+    element_t *ps = malloc(n * sizeof(element_t));
+    if (!ps) return 1;
+    for (size_t i = 0; i < n; i++) ps[i][0] = *(element_ptr) p->data;     /* shallow, read-only */
+    int rc = run_batch(a, out, ps, in2, n, 1);
+    free(ps);
+    return rc;
+  }
   int l2 = L.len2(a->gpu), lt = L.lenT(a->gpu);
   unsigned char *b2 = malloc(n * l2 + 1), *bt = malloc(n * lt + 1);
   size_t *slot = malloc(n * sizeof *slot), m = 0;
@@ -192,8 +216,14 @@ int pbc_hip_attach(pairing_t pairing, const char *param, size_t len) {
   a->cpu_pp_init = pairing->pp_init; a->cpu_pp_clear = pairing->pp_clear; a->cpu_pp_apply = pairing->pp_apply;
   pairing->map = hip_map;
   pairing->prod_pairings = hip_prod;
-  if (strstr(param, "type a") && !strstr(param, "type a1")) {
-    pairing->pp_init = hip_pp_init; pairing->pp_clear = hip_pp_clear; pairing->pp_apply = hip_pp_apply;
+  {
+    /* preprocessed pairings exist on the GPU for types a, d and g (the "type" key of the text) */
+    int t = L.type(g);
+    if (t == 'a' || t == 'd' || t == 'g') {
+      pairing->pp_init = hip_pp_init; pairing->pp_clear = hip_pp_clear; pairing->pp_apply = hip_pp_apply;
+    } else {
+      pairing->pp_init = plain_pp_init; pairing->pp_clear = plain_pp_clear; pairing->pp_apply = plain_pp_apply;
+    }
   }
   return 0;
 }

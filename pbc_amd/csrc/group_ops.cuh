@@ -20,6 +20,14 @@ namespace pbc {
 struct CurveK {                        // E: y^2 = x^3 + a x + b over F_q (Montgomery words)
   uint32_t a[34], b[34];
   int a_is_zero;
+  // element_from_hash on G1: cofactor (curve_data cofac, ecc/curve.c:478) and square roots in F_q
+  uint32_t cofac[24];                  // 0 bits: no cofactor multiplication (type f)
+  int cofbits;
+  int sqrt_mode;                       // 0: q = 3 mod 4, root = t^((q+1)/4);  1: Tonelli-Shanks
+  uint32_t sqrt_e[34];                 // mode 0: (q+1)/4;  mode 1: (t-1)/2 with q - 1 = 2^s t, t odd
+  int sqrt_bits;
+  int ts_s;
+  uint32_t ts_c[34];                   // mode 1: z^t for a non-residue z (Montgomery form; derived on the device)
 };
 __constant__ CurveK c_curve;
 
@@ -131,25 +139,101 @@ PBC_DEV void g_mul_lane(uint8_t *out, const uint8_t *in, const uint8_t *z, int z
   fp_store_be<N>(out + NB, ay);
 }
 
-// ---- element_from_hash on G1 / G2 of Type A -------------------------------------------------
+// ---- element_from_hash on G1 (and G2 of the symmetric types) ---------------------------------
 // curve_from_hash (ecc/curve.c:455-482): x <- fp_from_hash(data) (arith/montfp.c:440-448 over
 // pbc_mpz_from_hash, arith/field.c:643-668: the digest is laid out as H || 0 || H || 1 || ... up to
 // the byte length of q, read big-endian and halved while it exceeds q); then x <- x^2 + 1 until
 // x^3 + a x + b is a square, y = its square root with the canonical residue ODD
-// (element_sgn, montfp.c:457-470), finally the cofactor multiplication.  q = 3 mod 4, so
-// sqrt(t) = t^((q+1)/4) and "t is a square" is "that power squares back to t" -- one power per
-// attempt instead of a Legendre symbol plus a Tonelli run.  Lanes retry independently under a
-// wave-uniform loop (__all).
+// (element_sgn, montfp.c:457-470), finally the cofactor multiplication (when the curve has one).
+// For q = 3 mod 4, sqrt(t) = t^((q+1)/4) and "t is a square" is "that power squares back to t" --
+// one power per attempt instead of a Legendre symbol plus a Tonelli run; other fields take one
+// power plus a short Tonelli-Shanks tail (fp_sqrt_lane).  Either root will do: the sign rule picks
+// the canonical one.  Lanes retry independently under a wave-uniform loop (__all).
 template <int N>
 static __device__ __noinline__ typename vecN<N>::type fp_pow_sqrt_fn(typename vecN<N>::type va) {
   fp<N> a, r;
   from_vec<N>(a, va);
   fp_set<N>(r, fpk<N>().one);
-  for (int i = c_a.sqrt_bits - 1; i >= 0; i--) {
+  for (int i = c_curve.sqrt_bits - 1; i >= 0; i--) {
     fp_sqr<N>(r, r);
-    if ((c_a.sqrt_e[i >> 5] >> (i & 31)) & 1) fp_mul<N>(r, r, a);
+    if ((c_curve.sqrt_e[i >> 5] >> (i & 31)) & 1) fp_mul<N>(r, r, a);
   }
   return to_vec<N>(r);
+}
+// Square root attempt for one lane: y with y^2 = t, or ok = false when t is not a square.
+//   q = 3 mod 4: y = t^((q+1)/4), checked by squaring.
+//   otherwise Tonelli-Shanks with q - 1 = 2^s t', t' odd: one power w = t^((t'-1)/2) gives the
+//   candidate root t w and b = t w^2 = t^t'; the 2-power part is removed in at most s rounds with
+//   c = z^t' (z a fixed non-residue).  Control flow is wave-uniform (fixed trip counts, masked updates).
+template <int N>
+PBC_DEV void fp_sqrt_lane(fp<N> &y, bool &ok, const fp<N> &t) {
+  fp<N> w;
+  from_vec<N>(w, fp_pow_sqrt_fn<N>(to_vec<N>(t)));
+  if (c_curve.sqrt_mode == 0) {
+    fp<N> yy;
+    fp_sqr<N>(yy, w);
+    ok = fp_eq<N>(yy, t);
+    y = w;
+    return;
+  }
+  fp<N> one, r, b, c, g, tt;
+  fp_set<N>(one, fpk<N>().one);
+  fp_mul<N>(r, t, w);
+  fp_mul<N>(b, r, w);
+  fp_set<N>(c, c_curve.ts_c);
+  const int s = c_curve.ts_s;
+  int m = s;
+  ok = true;
+  for (int round = 0; round < s; round++) {
+    // least i with b^(2^i) = 1 (i = 0: finished; i >= m: t is not a square)
+    int i = 0;
+    bool found = fp_eq<N>(b, one);
+    tt = b;
+    for (int j = 1; j <= s; j++) {
+      fp_sqr<N>(tt, tt);
+      bool hit = !found & fp_eq<N>(tt, one);
+      i = hit ? j : i;
+      found |= hit;
+    }
+    ok &= found & (i < m || i == 0);
+    const bool upd = ok & (i > 0) & (i < m);
+    g = c;
+    for (int j = 0; j < s; j++) {      // g = c^(2^(m-i-1))
+      fp_sqr<N>(tt, g);
+      fp_cmov<N>(g, tt, upd & (j < m - i - 1));
+    }
+    fp_mul<N>(tt, r, g);
+    fp_cmov<N>(r, tt, upd);
+    fp_sqr<N>(g, g);
+    fp_cmov<N>(c, g, upd);
+    fp_mul<N>(tt, b, g);
+    fp_cmov<N>(b, tt, upd);
+    m = upd ? i : m;
+  }
+  ok &= fp_eq<N>(b, one);
+  y = r;
+}
+// z^t' for the smallest non-residue z = 2, 3, ... (single lane, once per parameter set)
+template <int N>
+PBC_DEV void fp_ts_init(uint32_t *out, const uint32_t *texp, int tbits, const uint32_t *half, int halfbits) {
+  fp<N> one, z, chk, c;
+  fp_set<N>(one, fpk<N>().one);
+  z = one;
+  for (;;) {
+    fp_add<N>(z, z, one);
+    fp_set<N>(chk, fpk<N>().one);
+    for (int i = halfbits - 1; i >= 0; i--) {
+      fp_sqr<N>(chk, chk);
+      if ((half[i >> 5] >> (i & 31)) & 1) fp_mul<N>(chk, chk, z);
+    }
+    if (!fp_eq<N>(chk, one)) break;
+  }
+  fp_set<N>(c, fpk<N>().one);
+  for (int i = tbits - 1; i >= 0; i--) {
+    fp_sqr<N>(c, c);
+    if ((texp[i >> 5] >> (i & 31)) & 1) fp_mul<N>(c, c, z);
+  }
+  for (int k = 0; k < N; k++) out[k] = c.v[k];
 }
 template <int N>
 PBC_DEV void a_from_hash_lane(uint8_t *out, const uint8_t *data, int hlen) {
@@ -193,14 +277,14 @@ PBC_DEV void a_from_hash_lane(uint8_t *out, const uint8_t *data, int hlen) {
   bool done = false;
   fx = x; fy = x;
   for (int it = 0; it < 256; it++) {
-    fp<N> t, y, yy;
+    fp<N> t, y;
     fp_sqr<N>(t, x);
     fp_add<N>(t, t, ca);
     fp_mul<N>(t, t, x);
     fp_add<N>(t, t, cb);
-    from_vec<N>(y, fp_pow_sqrt_fn<N>(to_vec<N>(t)));
-    fp_sqr<N>(yy, y);
-    bool ok = fp_eq<N>(yy, t) & !done;
+    bool ok;
+    fp_sqrt_lane<N>(y, ok, t);
+    ok &= !done;
     fp_cmov<N>(fx, x, ok);
     fp_cmov<N>(fy, y, ok);
     done |= ok;
@@ -219,7 +303,7 @@ PBC_DEV void a_from_hash_lane(uint8_t *out, const uint8_t *data, int hlen) {
   }
   // [h] (fx, fy): wave-uniform double-and-add over the cofactor (element_mul_mpz, curve.c:477)
   fp<N> X = fx, Y = fy, Z = one;
-  for (int i = c_a.hbits - 2; i >= 0; i--) {
+  for (int i = c_curve.cofbits - 2; i >= 0; i--) {
     {
       fp<N> XX, YY, ZZ, M, S, t0, t1, Z3;
       fp_sqr<N>(XX, X);
@@ -247,7 +331,7 @@ PBC_DEV void a_from_hash_lane(uint8_t *out, const uint8_t *data, int hlen) {
       fp_sub<N>(Y, t1, t0);
       Z = Z3;
     }
-    if ((c_a.h[i >> 5] >> (i & 31)) & 1) {
+    if ((c_curve.cofac[i >> 5] >> (i & 31)) & 1) {
       fp<N> ZZ, H, R, HH, HHH, t0, t1, X3, Y3, Z3;
       fp_sqr<N>(ZZ, Z);
       fp_mul<N>(H, fx, ZZ);

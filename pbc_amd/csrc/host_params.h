@@ -53,7 +53,56 @@ struct pbc_hip_pairing_s {
   double fq_muls_single;     // reference F_q multiplication count per pairing (work model)
   double fq_muls_prod_a, fq_muls_prod_b;   // products: a*k + b
   double fq_muls_pp;         // one pairing_pp_apply (0: no preprocessed variant in the reference)
+  // element_from_hash on G1: cofactor and square-root constants (copied into CurveK by fill_curve)
+  struct {
+    uint32_t cofac[24]; int cofbits;
+    int sqrt_mode; uint32_t sqrt_e[34]; int sqrt_bits;
+    int ts_s; uint32_t ts_t[34]; int ts_tbits; uint32_t half[34]; int halfbits;
+    uint32_t ts_c[34]; bool ts_ready;
+  } hash;
 };
+
+// curve_from_hash constants: cofactor (0 = none) and the square-root recipe of F_q
+static int fill_hash_consts(pbc_hip_pairing_s *P, const pbc_host::Big &q, const pbc_host::Big *cofac) {
+  using pbc_host::Big;
+  memset(&P->hash, 0, sizeof P->hash);
+  if (cofac) {
+    if (cofac->bits() > 24 * 32) return fail("cofactor wider than 768 bits");
+    cofac->to_words(P->hash.cofac, 24);
+    P->hash.cofbits = cofac->bits();
+  }
+  Big two, four, rem;
+  two.w.push_back(2);
+  four.w.push_back(4);
+  if ((q.w[0] & 3) == 3) {
+    Big e = q;
+    e.add_small(1);
+    e = Big::div(e, four, &rem);
+    e.to_words(P->hash.sqrt_e, 34);
+    P->hash.sqrt_bits = e.bits();
+    P->hash.sqrt_mode = 0;
+    P->hash.ts_ready = true;
+    return 0;
+  }
+  Big qm1 = q;
+  qm1.sub_small(1);
+  Big half = Big::div(qm1, two, &rem);
+  half.to_words(P->hash.half, 34);
+  P->hash.halfbits = half.bits();
+  Big t = qm1;
+  int s = 0;
+  while (!t.bit(0)) { t = Big::div(t, two, &rem); s++; }
+  t.to_words(P->hash.ts_t, 34);
+  P->hash.ts_tbits = t.bits();
+  P->hash.ts_s = s;
+  Big e = t;
+  e.sub_small(1);
+  e = Big::div(e, two, &rem);
+  e.to_words(P->hash.sqrt_e, 34);
+  P->hash.sqrt_bits = e.bits();
+  P->hash.sqrt_mode = 1;
+  return 0;
+}
 
 // min_bits: smallest modulus accepted for this word count (default: the top word is in use)
 template <int N>
@@ -130,6 +179,7 @@ static int init_type_a(pbc_hip_pairing_s *P, const char *txt, size_t len) {
   P->fq_muls_prod_a = 2543.0;
   P->fq_muls_prod_b = 689.0;
   P->fq_muls_pp = 1838.0;                // a_pairing_pp_apply (a_param.c:317-360)
+  if (fill_hash_consts(P, q, &h)) return 1;   // field_init_curve_ab(Eq, a, b, r, h): cofactor h (a_param.c:1453)
   return 0;
 }
 
@@ -174,7 +224,7 @@ static int init_type_a1(pbc_hip_pairing_s *P, const char *txt, size_t len) {
   P->fq_muls_single = 25.0 * (n.bits() - 1) + 23.0 * ones;
   P->fq_muls_prod_a = P->fq_muls_single;
   P->fq_muls_prod_b = 0.0;
-  return 0;
+  return fill_hash_consts(P, p, &l);     // cofactor phikonr = l (a_param.c:2250)
 }
 
 // e_init_pairing (ecc/e_param.c:832-872) + pbc_param_init_e (:891-906): host part (integers only).
@@ -229,7 +279,9 @@ static int init_type_e(pbc_hip_pairing_s *P, const char *txt, size_t len) {
   P->fq_muls_single = 32.0 * (r.bits() - 1) + 1.5 * phik.bits();
   P->fq_muls_prod_a = P->fq_muls_single;   // generic_prod_pairings: k full pairings
   P->fq_muls_prod_b = 0.0;
-  return 0;
+  Big h;
+  if (!param_big(txt, len, "h", h)) return fail("type e: missing h");
+  return fill_hash_consts(P, q, &h);       // cofactor h (e_param.c:853)
 }
 
 // d_init_pairing (ecc/d_param.c:993-1095) + pbc_param_init_d, and g_init_pairing (ecc/g_param.c:
@@ -316,7 +368,9 @@ static int init_type_d(pbc_hip_pairing_s *P, const char *txt, size_t len, int de
     for (int i = 1; i < r.bits() - 1; i++) adds += r.bit(i);
     P->fq_muls_pp = P->fq_muls_single - 7.0 * (r.bits() - 1) - 5.0 * adds;
   }
-  return 0;
+  Big h;
+  if (!param_big(txt, len, "h", h)) return fail("%s: missing h", tn);
+  return fill_hash_consts(P, q, &h);       // cofactor h (d_param.c:1016, g_param.c:1267)
 }
 
 // f_init_pairing (ecc/f_param.c:335-447): host part (integers only)
@@ -409,7 +463,7 @@ static int init_type_f(pbc_hip_pairing_s *P, const char *txt, size_t len) {
   P->fq_muls_single = 172887.0;          // SURVEY.md 8d (instrumented reference, f.param)
   P->fq_muls_prod_a = 172887.0;          // generic_prod_pairings: k full pairings
   P->fq_muls_prod_b = 0.0;
-  return 0;
+  return fill_hash_consts(P, q, nullptr);  // no cofactor (f_param.c:372)
 }
 
 
@@ -430,4 +484,11 @@ static void fill_curve(const pbc_hip_pairing_s *P, CurveK &C) {
     memcpy(C.b, P->fconst.B, sizeof P->fconst.B);
     C.a_is_zero = 1;
   }
+  memcpy(C.cofac, P->hash.cofac, sizeof C.cofac);
+  C.cofbits = P->hash.cofbits;
+  C.sqrt_mode = P->hash.sqrt_mode;
+  memcpy(C.sqrt_e, P->hash.sqrt_e, sizeof C.sqrt_e);
+  C.sqrt_bits = P->hash.sqrt_bits;
+  C.ts_s = P->hash.ts_s;
+  memcpy(C.ts_c, P->hash.ts_c, sizeof C.ts_c);
 }

@@ -232,10 +232,18 @@ template <int N>
 __global__ void __launch_bounds__(kBlock, 2) a_from_hash_kernel(uint8_t *out, const uint8_t *data, int hlen, size_t n) {
   size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
   size_t ld = idx < n ? idx : n - 1;   // whole waves stay in the retry loop together
+  const int L = 2 * (int) fpk<N>().fbytes;
   __attribute__((aligned(4))) uint8_t o[8 * N];
   a_from_hash_lane<N>(o, data + ld * hlen, hlen);
   if (idx < n)
-    for (int i = 0; i < 8 * N; i++) out[idx * 8 * N + i] = o[i];
+    for (int i = 0; i < L; i++) out[idx * L + i] = o[i];
+}
+// one lane: z^t' for the Tonelli-Shanks square roots of element_from_hash (fields with q = 1 mod 4)
+struct TsRaw { uint32_t t[34], half[34]; int tbits, halfbits; };
+template <int N>
+__global__ void ts_init_kernel(uint32_t *out, TsRaw raw) {
+  if (threadIdx.x || blockIdx.x) return;
+  fp_ts_init<N>(out, raw.t, raw.tbits, raw.half, raw.halfbits);
 }
 // op 0: out = a * b in GT;  op 1: out = a ^ z
 template <int N>
@@ -788,17 +796,36 @@ extern "C" int pbc_hip_element_from_hash_batch(pbc_hip_pairing_t *P, int group, 
                                                int hlen, size_t n) {
   if (!P) return fail("null pairing");
   if (P->device < 0) return fail("no HIP device: libpbc_hip has no CPU fallback");
-  if (P->type != 'a' || (group != 1 && group != 2)) return fail("element_from_hash is built for G1/G2 of type a");
+  const bool symmetric = P->type == 'a' || P->type == '1' || P->type == 'e';
+  if (group != 1 && !(group == 2 && symmetric))
+    return fail("element_from_hash is built for G1 (and G2 of the symmetric types a, a1, e)");
   if (hlen < 1) return fail("hlen must be >= 1");
   if (!n) return 0;
   void *dd = nullptr, *d_o = nullptr;
   HIP_TRY(hipSetDevice(P->device));
+  if (!P->hash.ts_ready) {
+    // first use with q = 1 mod 4: derive the non-residue power on the device (single lane)
+    if (upload_constants(P, 0)) return 1;
+    uint32_t *dc = nullptr;
+    TsRaw raw;
+    memcpy(raw.t, P->hash.ts_t, sizeof raw.t);
+    memcpy(raw.half, P->hash.half, sizeof raw.half);
+    raw.tbits = P->hash.ts_tbits;
+    raw.halfbits = P->hash.halfbits;
+    HIP_TRY(hipMalloc(&dc, sizeof P->hash.ts_c));
+    HIP_TRY(hipMemset(dc, 0, sizeof P->hash.ts_c));
+    PBC_DISPATCH_N(P->nlimb, hipLaunchKernelGGL(ts_init_kernel<N>, dim3(1), dim3(64), 0, 0, dc, raw));
+    HIP_TRY(hipMemcpy(P->hash.ts_c, dc, sizeof P->hash.ts_c, hipMemcpyDeviceToHost));
+    (void) hipFree(dc);
+    P->hash.ts_ready = true;
+  }
   HIP_TRY(hipMalloc(&dd, n * (size_t) hlen));
   HIP_TRY(hipMalloc(&d_o, n * (size_t) P->len1));
   HIP_TRY(hipMemcpy(dd, data, n * (size_t) hlen, hipMemcpyHostToDevice));
   if (upload_constants(P, 0)) return 1;
   unsigned grid = (unsigned) ((n + kBlock - 1) / kBlock);
-  hipLaunchKernelGGL(a_from_hash_kernel<16>, dim3(grid), dim3(kBlock), 0, 0, (uint8_t *) d_o, (const uint8_t *) dd, hlen, n);
+  PBC_DISPATCH_N(P->nlimb, hipLaunchKernelGGL(a_from_hash_kernel<N>, dim3(grid), dim3(kBlock), 0, 0, (uint8_t *) d_o,
+                                              (const uint8_t *) dd, hlen, n));
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpy(out, d_o, n * (size_t) P->len1, hipMemcpyDeviceToHost));
   (void) hipFree(dd); (void) hipFree(d_o);

@@ -34,3 +34,19 @@ for d in d277699-175-167 d278027-190-181 d105171-196-185 d201 d224; do
   $T gen pbc_amd/param/$d.param edge   8  1  7 $G/${d}_edge8.vec
   $T gen pbc_amd/param/$d.param edge   4  3  9 $G/${d}_prod3x4_edge.vec
 done
+# type g (Freeman, k = 10), type a1 (1033-bit, composite order), type e (k = 1, 1020-bit)
+$T gen pbc_amd/param/g149.param chain 64 1 1 $G/g149_chain64.vec
+$T gen pbc_amd/param/g149.param random 16 1 42 $G/g149_rand16.vec
+$T gen pbc_amd/param/g149.param edge 10 1 7 $G/g149_edge10.vec
+$T gen pbc_amd/param/g149.param edge 4 3 9 $G/g149_prod3x4_edge.vec
+$T gen pbc_amd/param/g149.param random 3 4 5 $G/g149_prod4x3.vec
+for t in a1 e; do
+  $T gen pbc_amd/param/$t.param random 6 1 42 $G/${t}_rand6.vec
+  $T gen pbc_amd/param/$t.param edge 6 1 7 $G/${t}_edge6.vec
+  $T gen pbc_amd/param/$t.param edge 3 3 9 $G/${t}_prod3x3_edge.vec
+  $T gen pbc_amd/param/$t.param chain 8 1 1 $G/${t}_chain8.vec
+done
+# element_from_hash(G1) for the other families (Tonelli-Shanks fields, cofactors, no cofactor for f)
+for pf in d159 d201 d278027-190-181 f g149; do $T hash pbc_amd/param/$pf.param 8 32 3 $G/${pf}_hash32.vec; done
+$T hash pbc_amd/param/e.param 3 20 3 $G/e_hash20.vec
+$T hash pbc_amd/param/a1.param 3 20 3 $G/a1_hash20.vec

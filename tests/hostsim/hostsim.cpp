@@ -152,9 +152,13 @@ int hostsim_group(void *h, int what, uint8_t *out, const uint8_t *a, const uint8
 // element_from_hash on G1 (Type A): n digests of hlen bytes
 int hostsim_from_hash(void *h, uint8_t *out, const uint8_t *data, int hlen, size_t n) {
   pbc_hip_pairing_s *P = (pbc_hip_pairing_s *) h;
-  if (P->type != 'a') return 1;
   activate(P);
-  for (size_t i = 0; i < n; i++) a_from_hash_lane<16>(out + i * P->len1, data + i * hlen, hlen);
+  if (!P->hash.ts_ready) {
+    HS_DISPATCH(P->nlimb, fp_ts_init<N>(P->hash.ts_c, P->hash.ts_t, P->hash.ts_tbits, P->hash.half, P->hash.halfbits));
+    P->hash.ts_ready = true;
+    activate(P);
+  }
+  for (size_t i = 0; i < n; i++) { HS_DISPATCH(P->nlimb, a_from_hash_lane<N>(out + i * P->len1, data + i * hlen, hlen)); }
   return 0;
 }
 // diagnostics mirroring pbc_hip_diag_stage

@@ -82,14 +82,16 @@ int pbc_hip_pairing_pp_apply_batch_dev(pbc_hip_pp_t *pp, void *d_gt, const void 
  * (pairing_length_in_bytes_Zr, include/pbc_pairing.h:235-238), values < r.
  *   element_mul_zn / element_pow_zn on G1, G2 (include/pbc_field.h:311, :374 ->
  *     generic_pow_mpz arith/field.c:113-126 over curve_mul ecc/curve.c:153-207):
- *     out[i] = [zr[i]] in[i]; group = 1 or 2 (G2 only for the symmetric type a).  The point at
+ *     out[i] = [zr[i]] in[i]; group = 1 or 2 (G2 of types d / g / f is the twist over F_q^d /
+ *     F_q^2: field_reinit_curve_twist ecc/curve.c:885-901, f_param.c:372-383).  The point at
  *     infinity (only reachable from off-curve input or a zero scalar) is written as zero bytes.
  *   element_mul on GT (include/pbc_field.h:280 -> mulg wrapper ecc/pairing.c:135-283);
  *   element_pow_zn on GT. */
 int pbc_hip_pairing_length_in_bytes_Zr(const pbc_hip_pairing_t *p);
 /* element_from_hash on G1 / G2 (include/pbc_field.h:257 -> curve_from_hash ecc/curve.c:455-482,
  * fp_from_hash arith/montfp.c:440-448, pbc_mpz_from_hash arith/field.c:643-668): n digests of hlen
- * bytes each -> n points, including the cofactor multiplication.  Type A (q = 3 mod 4). */
+ * bytes each -> n points, including the cofactor multiplication.  group = 1 for every type (any
+ * odd q: Tonelli-Shanks where q = 1 mod 4); group = 2 for the symmetric types a, a1, e. */
 int pbc_hip_element_from_hash_batch(pbc_hip_pairing_t *p, int group, uint8_t *out, const uint8_t *data,
                                     int hlen, size_t n);
 int pbc_hip_element_mul_zn_batch(pbc_hip_pairing_t *p, int group, uint8_t *out, const uint8_t *in,

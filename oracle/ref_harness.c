@@ -201,6 +201,41 @@ static int cmd_bench(int argc, char **argv) {
 
 /* hash <param> <n> <hlen> <seed> <out>: element_from_hash(G1) on n pseudo-random hlen-byte digests.
  * Vector file: in1 = digests (len1 = hlen), in2 empty (len2 = 0), out = G1 bytes (lenT = len G1). */
+/* gmul <param> <group 1|2> <n> <seed> <out>: out_i = [k_i] P_i (element_mul_zn) for random points of
+ * G1 / G2 and random scalars; the last two scalars are 1 and r - 1.  File: points, scalars, results. */
+static int cmd_gmul(int argc, char **argv) {
+  if (argc < 6) { fprintf(stderr, "gmul <param> <group> <n> <seed> <out>\n"); return 2; }
+  int group = atoi(argv[2]), n = atoi(argv[3]);
+  unsigned seed = (unsigned) atoi(argv[4]);
+  pairing_t pairing; char type;
+  pbc_random_set_deterministic(seed);
+  init_pairing(pairing, argv[1], &type);
+  int lp = group == 1 ? pairing_length_in_bytes_G1(pairing) : pairing_length_in_bytes_G2(pairing);
+  int lz = pairing_length_in_bytes_Zr(pairing);
+  unsigned char *in = malloc((size_t) n * lp), *zs = malloc((size_t) n * lz), *out = malloc((size_t) n * lp);
+  element_t P, R, k;
+  if (group == 1) { element_init_G1(P, pairing); element_init_G1(R, pairing); }
+  else { element_init_G2(P, pairing); element_init_G2(R, pairing); }
+  element_init_Zr(k, pairing);
+  for (int i = 0; i < n; i++) {
+    element_random(P);
+    element_random(k);
+    if (i == n - 2) element_set1(k);
+    if (i == n - 1) { element_set1(k); element_neg(k, k); }
+    element_mul_zn(R, P, k);
+    element_to_bytes(in + (size_t) i * lp, P);
+    element_to_bytes(zs + (size_t) i * lz, k);
+    element_to_bytes(out + (size_t) i * lp, R);
+  }
+  FILE *fp = fopen(argv[5], "wb");
+  fwrite("PBCVEC01", 1, 8, fp);
+  w32(fp, (uint32_t) type); w32(fp, n); w32(fp, 1); w32(fp, lp); w32(fp, lz); w32(fp, lp);
+  fwrite(in, lp, n, fp); fwrite(zs, lz, n, fp); fwrite(out, lp, n, fp);
+  fclose(fp);
+  fprintf(stderr, "wrote %s: type %c group %d n=%d\n", argv[5], type, group, n);
+  return 0;
+}
+
 static int cmd_hash(int argc, char **argv) {
   if (argc < 6) { fprintf(stderr, "hash <param> <n> <hlen> <seed> <out>\n"); return 2; }
   int n = atoi(argv[2]), hlen = atoi(argv[3]);
@@ -233,5 +268,6 @@ int main(int argc, char **argv) {
   if (!strcmp(argv[1], "kat")) return cmd_kat(argc - 1, argv + 1);
   if (!strcmp(argv[1], "bench")) return cmd_bench(argc - 1, argv + 1);
   if (!strcmp(argv[1], "hash")) return cmd_hash(argc - 1, argv + 1);
+  if (!strcmp(argv[1], "gmul")) return cmd_gmul(argc - 1, argv + 1);
   return 2;
 }

@@ -182,18 +182,19 @@ class Pairing:
         return zr
 
     def element_mul_zn(self, group, pts, zr):
-        """out[i] = [zr[i]] pts[i] in G1 (group=1) or G2 (group=2, type a)."""
+        """out[i] = [zr[i]] pts[i] in G1 (group=1) or G2 (group=2)."""
         import numpy as np
         pts = np.ascontiguousarray(pts, dtype=np.uint8)
-        n = pts.size // self.length_in_bytes_G1
+        lp = self.length_in_bytes_G1 if group == 1 else self.length_in_bytes_G2
+        n = pts.size // lp
         zr = self._scalars(zr, n)
-        out = np.empty((n, self.length_in_bytes_G1), np.uint8)
+        out = np.empty((n, lp), np.uint8)
         if lib().pbc_hip_element_mul_zn_batch(self._h, group, _np_ptr(out), _np_ptr(pts), _np_ptr(zr), n):
             raise PbcHipError("element_mul_zn: " + _err())
         return out
 
     def element_from_hash(self, group, digests):
-        """digests: (n, hlen) uint8 -> n points of G1/G2 (element_from_hash, type a)."""
+        """digests: (n, hlen) uint8 -> n points of G1 (G2 for the symmetric types) (element_from_hash)."""
         import numpy as np
         d = np.ascontiguousarray(digests, dtype=np.uint8)
         n, hlen = d.shape

@@ -34,109 +34,177 @@ __constant__ CurveK c_curve;
 // bit i of a big-endian scalar of zlen bytes
 PBC_DEV uint32_t zr_bit(const uint8_t *z, int zlen, int i) { return (z[zlen - 1 - (i >> 3)] >> (i & 7)) & 1; }
 
-// out = [k] P for P = (x, y) bytes; off-curve P is O (curve_from_bytes); O serialises as zeros.
+// ---- scalar multiplication on y^2 = x^3 + a x + b over a field given by a policy F ------------
+// F supplies: el, bytes(), curve_a/curve_b/a_is_zero(), one/zero, add/sub/dbl/mul/sqr/inv, is0/eq,
+// cmov, load/store.  Used for E(F_q) (G1; G2 of the symmetric types) and for the twists over
+// F_q^d (types d, g: curve.c:885-901 coefficients a v^2, b v^3) and F_q^2 (type f: f_param.c:372-383).
 template <int N>
-PBC_DEV void g_mul_lane(uint8_t *out, const uint8_t *in, const uint8_t *z, int zlen) {
-  const int NB = (int) fpk<N>().fbytes;
-  fp<N> one, ca, cb, x2, y2;
-  fp_set<N>(one, fpk<N>().one);
-  fp_set<N>(ca, c_curve.a);
-  fp_set<N>(cb, c_curve.b);
-  fp_load_be<N>(x2, in);
-  fp_load_be<N>(y2, in + NB);
+struct FqOps {
+  typedef fp<N> el;
+  static PBC_DEV int bytes() { return (int) fpk<N>().fbytes; }
+  static PBC_DEV el curve_a() { el r; fp_set<N>(r, c_curve.a); return r; }
+  static PBC_DEV el curve_b() { el r; fp_set<N>(r, c_curve.b); return r; }
+  static PBC_DEV bool a_is_zero() { return c_curve.a_is_zero != 0; }
+  static PBC_DEV el one() { el r; fp_set<N>(r, fpk<N>().one); return r; }
+  static PBC_DEV el zero() { el r; for (int k = 0; k < N; k++) r.v[k] = 0; return r; }
+  static PBC_DEV void add(el &r, const el &a, const el &b) { fp_add<N>(r, a, b); }
+  static PBC_DEV void sub(el &r, const el &a, const el &b) { fp_sub<N>(r, a, b); }
+  static PBC_DEV void dbl(el &r, const el &a) { fp_dbl<N>(r, a); }
+  static PBC_DEV void mul(el &r, const el &a, const el &b) { fp_mul<N>(r, a, b); }
+  static PBC_DEV void sqr(el &r, const el &a) { fp_sqr<N>(r, a); }
+  static PBC_DEV void inv(el &r, const el &a) { fp_inv<N>(r, a); }
+  static PBC_DEV bool is0(const el &a) { return fp_is0<N>(a); }
+  static PBC_DEV bool eq(const el &a, const el &b) { return fp_eq<N>(a, b); }
+  static PBC_DEV void cmov(el &r, const el &a, bool c) { fp_cmov<N>(r, a, c); }
+  static PBC_DEV void load(el &r, const uint8_t *s) { fp_load_be<N>(r, s); }
+  static PBC_DEV void store(uint8_t *d, const el &a) { fp_store_be<N>(d, a); }
+};
+template <int N, int DEG>
+struct FdOps {                         // F_q^d of types d / g: the twist E'(F_q^d)
+  typedef TypeMNT<N, DEG> T;
+  typedef typename T::f3 el;
+  static PBC_DEV int bytes() { return DEG * (int) fpk<N>().fbytes; }
+  static PBC_DEV el curve_a() { el r; T::f3_set_fq(r, T::dk(c_d.ta)); return r; }
+  static PBC_DEV el curve_b() { el r; T::f3_set_fq(r, T::dk(c_d.tb)); return r; }
+  static PBC_DEV bool a_is_zero() { return false; }
+  static PBC_DEV el one() { el r; fp<N> o; fp_set<N>(o, fpk<N>().one); T::f3_set_fq(r, o); return r; }
+  static PBC_DEV el zero() { el r = one(); T::f3_sub(r, r, r); return r; }
+  static PBC_DEV void add(el &r, const el &a, const el &b) { T::f3_add(r, a, b); }
+  static PBC_DEV void sub(el &r, const el &a, const el &b) { T::f3_sub(r, a, b); }
+  static PBC_DEV void dbl(el &r, const el &a) { T::f3_dbl(r, a); }
+  static PBC_DEV void mul(el &r, const el &a, const el &b) { T::f3_mul(r, a, b); }
+  static PBC_DEV void sqr(el &r, const el &a) { T::f3_sqr(r, a); }
+  static PBC_DEV void inv(el &r, const el &a) { T::f3_inv(r, a); }
+  static PBC_DEV bool is0(const el &a) { el z = zero(); return T::f3_eq(a, z); }
+  static PBC_DEV bool eq(const el &a, const el &b) { return T::f3_eq(a, b); }
+  static PBC_DEV void cmov(el &r, const el &a, bool c) { for (int i = 0; i < DEG; i++) fp_cmov<N>(r.c[i], a.c[i], c); }
+  static PBC_DEV void load(el &r, const uint8_t *s) { T::f3_load_be(r, s); }
+  static PBC_DEV void store(uint8_t *d, const el &a) { T::f3_store_be(d, a); }
+};
+struct Fq2Ops {                        // F_q^2 of type f: the twist y^2 = x^3 + tb
+  typedef g2 el;
+  static PBC_DEV int bytes() { return 2 * (int) fpk<ND>().fbytes; }
+  static PBC_DEV el curve_a() { el r; g2_zero(r); return r; }
+  static PBC_DEV el curve_b() { return fk2(c_f.tb); }
+  static PBC_DEV bool a_is_zero() { return true; }
+  static PBC_DEV el one() { el r; g2_zero(r); fp_set<ND>(r.x, fpk<ND>().one); return r; }
+  static PBC_DEV el zero() { el r; g2_zero(r); return r; }
+  static PBC_DEV void add(el &r, const el &a, const el &b) { g2_add(r, a, b); }
+  static PBC_DEV void sub(el &r, const el &a, const el &b) { g2_sub(r, a, b); }
+  static PBC_DEV void dbl(el &r, const el &a) { g2_dbl(r, a); }
+  static PBC_DEV void mul(el &r, const el &a, const el &b) { g2_mul(r, a, b); }
+  static PBC_DEV void sqr(el &r, const el &a) { g2_sqr(r, a); }
+  static PBC_DEV void inv(el &r, const el &a) { g2_inv(r, a); }
+  static PBC_DEV bool is0(const el &a) { return fp_is0<ND>(a.x) & fp_is0<ND>(a.y); }
+  static PBC_DEV bool eq(const el &a, const el &b) { return g2_eq(a, b); }
+  static PBC_DEV void cmov(el &r, const el &a, bool c) { fp_cmov<ND>(r.x, a.x, c); fp_cmov<ND>(r.y, a.y, c); }
+  static PBC_DEV void load(el &r, const uint8_t *s) { g2_load_be(r, s); }
+  static PBC_DEV void store(uint8_t *d, const el &a) { g2_store_be(d, a); }
+};
+
+// out = [k] P for P = (x, y) bytes; off-curve P is O (curve_from_bytes); O serialises as zeros.
+// Double-and-always-add with per-lane selects (element_mul_zn -> generic_pow_mpz over curve_mul,
+// arith/field.c:113-126, ecc/curve.c:153-207).
+template <class F>
+PBC_DEV void ec_mul_lane(uint8_t *out, const uint8_t *in, const uint8_t *z, int zlen) {
+  typedef typename F::el el;
+  const int NB = F::bytes();
+  const el one = F::one(), ca = F::curve_a(), cb = F::curve_b();
+  el x2, y2;
+  F::load(x2, in);
+  F::load(y2, in + NB);
   bool valid;
   {
-    fp<N> t0, t1;
-    fp_sqr<N>(t0, x2);
-    fp_add<N>(t0, t0, ca);
-    fp_mul<N>(t0, t0, x2);
-    fp_add<N>(t0, t0, cb);
-    fp_sqr<N>(t1, y2);
-    valid = fp_eq<N>(t0, t1);
+    el t0, t1;
+    F::sqr(t0, x2);
+    F::add(t0, t0, ca);
+    F::mul(t0, t0, x2);
+    F::add(t0, t0, cb);
+    F::sqr(t1, y2);
+    valid = F::eq(t0, t1);
   }
-  fp<N> X = one, Y = one, Z;           // accumulator R, starts at O (Z = 0)
-#pragma unroll
-  for (int k = 0; k < N; k++) Z.v[k] = 0;
+  el X = one, Y = one, Z = F::zero();  // accumulator R, starts at O (Z = 0)
   for (int i = 8 * zlen - 1; i >= 0; i--) {
     // R <- 2R  (dbl-2007-bl shape; Z = 0 stays 0)
     {
-      fp<N> XX, YY, ZZ, M, S, t0, t1, Z3;
-      fp_sqr<N>(XX, X);
-      fp_sqr<N>(YY, Y);
-      fp_sqr<N>(ZZ, Z);
-      fp_dbl<N>(M, XX);
-      fp_add<N>(M, M, XX);
-      if (!c_curve.a_is_zero) {
-        fp_sqr<N>(t0, ZZ);
-        fp_mul<N>(t0, t0, ca);
-        fp_add<N>(M, M, t0);
+      el XX, YY, ZZ, M, S, t0, t1, Z3;
+      F::sqr(XX, X);
+      F::sqr(YY, Y);
+      F::sqr(ZZ, Z);
+      F::dbl(M, XX);
+      F::add(M, M, XX);
+      if (!F::a_is_zero()) {
+        F::sqr(t0, ZZ);
+        F::mul(t0, t0, ca);
+        F::add(M, M, t0);
       }
-      fp_mul<N>(Z3, Y, Z);
-      fp_dbl<N>(Z3, Z3);
-      fp_mul<N>(S, X, YY);
-      fp_dbl<N>(S, S);
-      fp_dbl<N>(S, S);
-      fp_sqr<N>(t0, YY);
-      fp_dbl<N>(t0, t0);
-      fp_dbl<N>(t0, t0);
-      fp_dbl<N>(t0, t0);
-      fp_sqr<N>(X, M);
-      fp_dbl<N>(t1, S);
-      fp_sub<N>(X, X, t1);
-      fp_sub<N>(t1, S, X);
-      fp_mul<N>(t1, M, t1);
-      fp_sub<N>(Y, t1, t0);
+      F::mul(Z3, Y, Z);
+      F::dbl(Z3, Z3);
+      F::mul(S, X, YY);
+      F::dbl(S, S);
+      F::dbl(S, S);
+      F::sqr(t0, YY);
+      F::dbl(t0, t0);
+      F::dbl(t0, t0);
+      F::dbl(t0, t0);
+      F::sqr(X, M);
+      F::dbl(t1, S);
+      F::sub(X, X, t1);
+      F::sub(t1, S, X);
+      F::mul(t1, M, t1);
+      F::sub(Y, t1, t0);
       Z = Z3;
     }
     // T <- R + P (mixed); selected per lane when the scalar bit is set
     {
-      fp<N> ZZ, H, R, HH, HHH, t0, t1, X3, Y3, Z3;
-      fp_sqr<N>(ZZ, Z);
-      fp_mul<N>(H, x2, ZZ);
-      fp_sub<N>(H, H, X);
-      fp_mul<N>(t0, Z, ZZ);
-      fp_mul<N>(R, y2, t0);
-      fp_sub<N>(R, R, Y);
-      fp_mul<N>(Z3, Z, H);
-      fp_sqr<N>(HH, H);
-      fp_mul<N>(HHH, HH, H);
-      fp_mul<N>(t0, X, HH);
-      fp_sqr<N>(X3, R);
-      fp_sub<N>(X3, X3, HHH);
-      fp_sub<N>(X3, X3, t0);
-      fp_sub<N>(X3, X3, t0);
-      fp_sub<N>(t0, t0, X3);
-      fp_mul<N>(t0, R, t0);
-      fp_mul<N>(t1, Y, HHH);
-      fp_sub<N>(Y3, t0, t1);
+      el ZZ, H, R, HH, HHH, t0, t1, X3, Y3, Z3;
+      F::sqr(ZZ, Z);
+      F::mul(H, x2, ZZ);
+      F::sub(H, H, X);
+      F::mul(t0, Z, ZZ);
+      F::mul(R, y2, t0);
+      F::sub(R, R, Y);
+      F::mul(Z3, Z, H);
+      F::sqr(HH, H);
+      F::mul(HHH, HH, H);
+      F::mul(t0, X, HH);
+      F::sqr(X3, R);
+      F::sub(X3, X3, HHH);
+      F::sub(X3, X3, t0);
+      F::sub(X3, X3, t0);
+      F::sub(t0, t0, X3);
+      F::mul(t0, R, t0);
+      F::mul(t1, Y, HHH);
+      F::sub(Y3, t0, t1);
       bool bit = zr_bit(z, zlen, i) != 0;
       // R = O: R + P = P.   R = -P (H = 0, R != 0): the sum is O  (Z3 = Z H = 0 already).
       // (R = P with a set bit would need a doubling: impossible for scalars < r.)
-      bool inf = fp_is0<N>(Z);
+      bool inf = F::is0(Z);
       bool take_p = bit & inf;
       bool take_t = bit & !inf;
-      fp_cmov<N>(X, X3, take_t);
-      fp_cmov<N>(Y, Y3, take_t);
-      fp_cmov<N>(Z, Z3, take_t);
-      fp_cmov<N>(X, x2, take_p);
-      fp_cmov<N>(Y, y2, take_p);
-      fp_cmov<N>(Z, one, take_p);
+      F::cmov(X, X3, take_t);
+      F::cmov(Y, Y3, take_t);
+      F::cmov(Z, Z3, take_t);
+      F::cmov(X, x2, take_p);
+      F::cmov(Y, y2, take_p);
+      F::cmov(Z, one, take_p);
     }
   }
   // to affine: x = X/Z^2, y = Y/Z^3
-  fp<N> zi, zi2, ax, ay;
-  bool is_inf = fp_is0<N>(Z) | !valid;
-  fp_inv<N>(zi, Z);
-  fp_sqr<N>(zi2, zi);
-  fp_mul<N>(ax, X, zi2);
-  fp_mul<N>(zi2, zi2, zi);
-  fp_mul<N>(ay, Y, zi2);
-  if (is_inf) {
-#pragma unroll
-    for (int k = 0; k < N; k++) { ax.v[k] = 0; ay.v[k] = 0; }
-  }
-  fp_store_be<N>(out, ax);
-  fp_store_be<N>(out + NB, ay);
+  el zi, zi2, ax, ay;
+  bool is_inf = F::is0(Z) | !valid;
+  F::inv(zi, Z);
+  F::sqr(zi2, zi);
+  F::mul(ax, X, zi2);
+  F::mul(zi2, zi2, zi);
+  F::mul(ay, Y, zi2);
+  if (is_inf) { ax = F::zero(); ay = ax; }
+  F::store(out, ax);
+  F::store(out + NB, ay);
+}
+template <int N>
+PBC_DEV void g_mul_lane(uint8_t *out, const uint8_t *in, const uint8_t *z, int zlen) {
+  ec_mul_lane<FqOps<N>>(out, in, z, zlen);
 }
 
 // ---- element_from_hash on G1 (and G2 of the symmetric types) ---------------------------------

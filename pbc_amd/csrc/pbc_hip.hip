@@ -228,6 +228,22 @@ __global__ void __launch_bounds__(kBlock, 2) g_mul_kernel(uint8_t *out, const ui
   const size_t L = 2 * fpk<N>().fbytes;
   g_mul_lane<N>(out + idx * L, in + idx * L, z + idx * zlen, zlen);
 }
+// element_mul_zn on the twists: G2 of types d / g (over F_q^d) and f (over F_q^2)
+template <int N, int DEG>
+__global__ void __launch_bounds__(kBlock, 2) d_g2_mul_kernel(uint8_t *out, const uint8_t *in, const uint8_t *z,
+                                                              int zlen, size_t n) {
+  size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
+  if (idx >= n) return;
+  const size_t L = 2 * DEG * fpk<N>().fbytes;
+  ec_mul_lane<FdOps<N, DEG>>(out + idx * L, in + idx * L, z + idx * zlen, zlen);
+}
+__global__ void __launch_bounds__(kBlock, 2) f_g2_mul_kernel(uint8_t *out, const uint8_t *in, const uint8_t *z,
+                                                              int zlen, size_t n) {
+  size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
+  if (idx >= n) return;
+  const size_t L = 4 * fpk<ND>().fbytes;
+  ec_mul_lane<Fq2Ops>(out + idx * L, in + idx * L, z + idx * zlen, zlen);
+}
 template <int N>
 __global__ void __launch_bounds__(kBlock, 2) a_from_hash_kernel(uint8_t *out, const uint8_t *data, int hlen, size_t n) {
   size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
@@ -744,9 +760,8 @@ static int run_group(pbc_hip_pairing_s *P, int what, int group, uint8_t *out, co
   if (!n) return 0;
   size_t la, lb, lo;
   if (what == 0) {                     // G mul_zn
-    if (group != 1 && !(group == 2 && (P->type == 'a' || P->type == '1' || P->type == 'e')))
-      return fail("scalar multiplication is built for G1 (and G2 of the symmetric types a, a1, e)");
-    la = lo = (size_t) P->len1;
+    if (group != 1 && group != 2) return fail("group must be 1 or 2");
+    la = lo = (size_t) (group == 1 ? P->len1 : P->len2);
     lb = (size_t) P->len_zr;
   } else if (what == 1) {              // GT mul
     la = lb = lo = (size_t) P->lenT;
@@ -763,7 +778,13 @@ static int run_group(pbc_hip_pairing_s *P, int what, int group, uint8_t *out, co
   HIP_TRY(hipMemcpy(db, b, n * lb, hipMemcpyHostToDevice));
   if (upload_constants(P, 0)) return 1;
   unsigned grid = (unsigned) ((n + kBlock - 1) / kBlock);
-  if (what == 0) {
+  if (what == 0 && group == 2 && (P->type == 'd' || P->type == 'g')) {
+    PBC_DISPATCH_D(P, hipLaunchKernelGGL((d_g2_mul_kernel<N, DEG>), dim3(grid), dim3(kBlock), 0, 0, (uint8_t *) d_o,
+                                         (const uint8_t *) da, (const uint8_t *) db, P->len_zr, n));
+  } else if (what == 0 && group == 2 && P->type == 'f') {
+    hipLaunchKernelGGL(f_g2_mul_kernel, dim3(grid), dim3(kBlock), 0, 0, (uint8_t *) d_o, (const uint8_t *) da,
+                       (const uint8_t *) db, P->len_zr, n);
+  } else if (what == 0) {              // E(F_q): G1, and G2 of the symmetric types
     PBC_DISPATCH_N(P->nlimb, hipLaunchKernelGGL(g_mul_kernel<N>, dim3(grid), dim3(kBlock), 0, 0, (uint8_t *) d_o,
                                                 (const uint8_t *) da, (const uint8_t *) db, P->len_zr, n));
   } else {

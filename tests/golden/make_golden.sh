@@ -50,3 +50,7 @@ done
 for pf in d159 d201 d278027-190-181 f g149; do $T hash pbc_amd/param/$pf.param 8 32 3 $G/${pf}_hash32.vec; done
 $T hash pbc_amd/param/e.param 3 20 3 $G/e_hash20.vec
 $T hash pbc_amd/param/a1.param 3 20 3 $G/a1_hash20.vec
+# element_mul_zn on G2 (twists over F_q^d / F_q^2) and on G1 of wide fields
+for pf in d159 d201 g149 f; do $T gmul pbc_amd/param/$pf.param 2 6 11 $G/${pf}_g2mul6.vec; done
+$T gmul pbc_amd/param/e.param 1 3 11 $G/e_g1mul3.vec
+$T gmul pbc_amd/param/d224.param 1 6 11 $G/d224_g1mul6.vec

@@ -67,6 +67,15 @@ class HostSim:
         self.L.hostsim_group(self.h, what, out.ctypes.data, a.ctypes.data, b.ctypes.data, n)
         return out
 
+    def g2_mul(self, a, b):
+        a = np.ascontiguousarray(a, np.uint8)
+        b = np.ascontiguousarray(b, np.uint8)
+        n = a.size // self.len2
+        out = np.empty((n, self.len2), np.uint8)
+        self.L.hostsim_g2_mul.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_size_t]
+        self.L.hostsim_g2_mul(self.h, out.ctypes.data, a.ctypes.data, b.ctypes.data, n)
+        return out
+
     def from_hash(self, data, hlen):
         data = np.ascontiguousarray(data, np.uint8)
         n = data.size // hlen

@@ -119,6 +119,21 @@ int hostsim_pp(void *h, uint8_t *gt, const uint8_t *g1, const uint8_t *g2, size_
   for (size_t u = 0; u < n; u++) a_pp_apply_lane<16>(gt + u * P->lenT, tab, v, g2 + u * P->len2);
   return 0;
 }
+// element_mul_zn on G2 of the asymmetric types (twists)
+int hostsim_g2_mul(void *h, uint8_t *out, const uint8_t *a, const uint8_t *b, size_t n) {
+  pbc_hip_pairing_s *P = (pbc_hip_pairing_s *) h;
+  activate(P);
+  for (size_t i = 0; i < n; i++) {
+    if (P->type == 'd' || P->type == 'g') {
+      HS_DISPATCH_D(P, (ec_mul_lane<FdOps<N, DEG>>(out + i * P->len2, a + i * P->len2, b + i * P->len_zr, P->len_zr)));
+    } else if (P->type == 'f') {
+      ec_mul_lane<Fq2Ops>(out + i * P->len2, a + i * P->len2, b + i * P->len_zr, P->len_zr);
+    } else {
+      HS_DISPATCH(P->nlimb, g_mul_lane<N>(out + i * P->len2, a + i * P->len2, b + i * P->len_zr, P->len_zr));
+    }
+  }
+  return 0;
+}
 // group operations: what 0 = G mul_zn, 1 = GT mul, 2 = GT pow
 int hostsim_group(void *h, int what, uint8_t *out, const uint8_t *a, const uint8_t *b, size_t n) {
   pbc_hip_pairing_s *P = (pbc_hip_pairing_s *) h;

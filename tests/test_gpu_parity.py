@@ -483,6 +483,46 @@ def test_from_hash_other_types_matches_reference(hips, key, name):
     assert not H.element_mul_zn(1, got, np.tile(_be(r, zl), (v.n, 1))).any()
 
 
+@pytest.mark.parametrize("key,name", [("d", "d159_g2mul6.vec"), ("d201", "d201_g2mul6.vec"), ("g149", "g149_g2mul6.vec"),
+                                      ("f", "f_g2mul6.vec")])
+def test_g2_scalar_multiplication_on_twists(hips, key, name):
+    """element_mul_zn on G2 of the asymmetric types vs the reference's outputs, then bilinearity in the
+    second argument entirely on the device: e(P, [a]Q) == e(P, Q)^a."""
+    v = golden(name)
+    H = hips[key]
+    aQ = H.element_mul_zn(2, v.g1, v.g2)                   # file: G2 points, scalars, [k]Q
+    assert np.array_equal(aQ, v.gt)
+    pv = golden({"d": "d_rand32.vec", "d201": "d201_rand12.vec", "g149": "g149_rand16.vec", "f": "f_rand16.vec"}[key])
+    P = pv.g1[:v.n]
+    assert np.array_equal(H.element_pairing(P, aQ), H.element_pow_zn_GT(H.element_pairing(P, v.g1), v.g2))
+
+
+@pytest.mark.parametrize("key,name", [("e", "e_g1mul3.vec"), ("d224", "d224_g1mul6.vec")])
+def test_g1_scalar_multiplication_wide_fields(hips, key, name):
+    v = golden(name)
+    assert np.array_equal(hips[key].element_mul_zn(1, v.g1, v.g2), v.gt)
+
+
+def test_asymmetric_bls_round_trip_on_gpu(hips):
+    """BLS on the BN curve (type f), everything on the device: sk_i, pk_i = [sk_i] g2 (G2 twist),
+    h_i = H(m_i) in G1, sig_i = [sk_i] h_i; verify e(sig_i, g2) == e(h_i, pk_i); a forged one fails."""
+    H = hips["f"]
+    g2 = golden("f_g2mul6.vec").g1[:1]                     # a G2 element from the reference
+    n = 64
+    rng = np.random.default_rng(41)
+    r = param_value("f", "r")
+    zl = H.length_in_bytes_Zr
+    sk = np.stack([_be(int.from_bytes(rng.bytes(zl), "big") % (r - 1) + 1, zl) for _ in range(n)])
+    pk = H.element_mul_zn(2, np.tile(g2, (n, 1)), sk)
+    h = H.element_from_hash(1, rng.integers(0, 256, (n, 32), dtype=np.uint8))
+    sig = H.element_mul_zn(1, h, sk)
+    sig[5] = sig[6]                                        # forgery
+    lhs = H.element_pairing(sig, np.tile(g2, (n, 1)))
+    rhs = H.element_pairing(h, pk)
+    ok = (lhs == rhs).all(axis=1)
+    assert ok.sum() == n - 1 and not ok[5]
+
+
 def test_bls_sign_verify_batch_on_gpu(hip_a, oracle_a):
     """example/bls.c:41-117 as a batch: h = from_hash(msg), sig = h^sk, pk = g^sk,
     verify e(sig, g) == e(h, pk).  Every group operation and pairing runs on the GPU; the fixed

@@ -109,3 +109,17 @@ def test_from_hash_on_host(sims, name):
     key = {"d159": "d", "d201": "d201", "d278027-190-181": "d278027-190-181"}.get(name.split("_")[0], key_of(name))
     got = sims[key].from_hash(v.g1[:n], v.len1)
     assert np.array_equal(got, v.gt[:n])
+
+
+@pytest.mark.parametrize("key,name", [("d", "d159_g2mul6.vec"), ("d201", "d201_g2mul6.vec"), ("g149", "g149_g2mul6.vec"),
+                                      ("f", "f_g2mul6.vec")])
+def test_g2_scalar_multiplication_on_host(sims, key, name):
+    """element_mul_zn on G2 of the asymmetric types: the twists over F_q^3 / F_q^5 (d, g) and F_q^2 (f)."""
+    v = golden(name)
+    assert np.array_equal(sims[key].g2_mul(v.g1, v.g2), v.gt)
+
+
+@pytest.mark.parametrize("key,name", [("e", "e_g1mul3.vec"), ("d224", "d224_g1mul6.vec")])
+def test_g1_scalar_multiplication_wide_fields_on_host(sims, key, name):
+    v = golden(name)
+    assert np.array_equal(sims[key].group(0, v.g1, v.g2), v.gt)

@@ -94,6 +94,15 @@ int pbc_hip_pairing_length_in_bytes_Zr(const pbc_hip_pairing_t *p);
  * odd q: Tonelli-Shanks where q = 1 mod 4); group = 2 for the symmetric types a, a1, e. */
 int pbc_hip_element_from_hash_batch(pbc_hip_pairing_t *p, int group, uint8_t *out, const uint8_t *data,
                                     int hlen, size_t n);
+/* element_to_bytes_compressed / element_from_bytes_compressed (ecc/curve.c:762-773, :800-815;
+ * pairing_length_in_bytes_compressed_G1, include/pbc_pairing.h:199-204) on G1 (G2 of the symmetric
+ * types): records of length_in_bytes_Fq + 1 bytes, x || s with s = 1 when the canonical y is odd.
+ * Decompression takes the square root on the device; an x with no point above it gives zeros. */
+int pbc_hip_pairing_length_in_bytes_compressed_G1(const pbc_hip_pairing_t *p);
+int pbc_hip_element_to_bytes_compressed_batch(pbc_hip_pairing_t *p, int group, uint8_t *out, const uint8_t *in,
+                                              size_t n);
+int pbc_hip_element_from_bytes_compressed_batch(pbc_hip_pairing_t *p, int group, uint8_t *out, const uint8_t *in,
+                                                size_t n);
 int pbc_hip_element_mul_zn_batch(pbc_hip_pairing_t *p, int group, uint8_t *out, const uint8_t *in,
                                  const uint8_t *zr, size_t n);
 int pbc_hip_element_mul_GT_batch(pbc_hip_pairing_t *p, uint8_t *out, const uint8_t *a, const uint8_t *b, size_t n);

@@ -236,6 +236,37 @@ static int cmd_gmul(int argc, char **argv) {
   return 0;
 }
 
+/* compress <param> <n> <seed> <out>: random G1 points in element_to_bytes form and their
+ * element_to_bytes_compressed form (x || sign byte, ecc/curve.c:762-773); each compressed record is
+ * fed back through element_from_bytes_compressed (:800-815) and must reproduce the point. */
+static int cmd_compress(int argc, char **argv) {
+  if (argc < 5) { fprintf(stderr, "compress <param> <n> <seed> <out>\n"); return 2; }
+  int n = atoi(argv[2]);
+  unsigned seed = (unsigned) atoi(argv[3]);
+  pairing_t pairing; char type;
+  pbc_random_set_deterministic(seed);
+  init_pairing(pairing, argv[1], &type);
+  int lp = pairing_length_in_bytes_G1(pairing);
+  element_t P, R;
+  element_init_G1(P, pairing); element_init_G1(R, pairing);
+  int lc = pairing_length_in_bytes_compressed_G1(pairing);
+  unsigned char *in = malloc((size_t) n * lp), *out = malloc((size_t) n * lc);
+  for (int i = 0; i < n; i++) {
+    element_random(P);
+    element_to_bytes(in + (size_t) i * lp, P);
+    element_to_bytes_compressed(out + (size_t) i * lc, P);
+    element_from_bytes_compressed(R, out + (size_t) i * lc);
+    if (element_cmp(P, R)) { fprintf(stderr, "round trip failed at %d\n", i); return 1; }
+  }
+  FILE *fp = fopen(argv[4], "wb");
+  fwrite("PBCVEC01", 1, 8, fp);
+  w32(fp, (uint32_t) type); w32(fp, n); w32(fp, 1); w32(fp, lp); w32(fp, 0); w32(fp, lc);
+  fwrite(in, lp, n, fp); fwrite(out, lc, n, fp);
+  fclose(fp);
+  fprintf(stderr, "wrote %s: type %c n=%d %d -> %d bytes\n", argv[4], type, n, lp, lc);
+  return 0;
+}
+
 static int cmd_hash(int argc, char **argv) {
   if (argc < 6) { fprintf(stderr, "hash <param> <n> <hlen> <seed> <out>\n"); return 2; }
   int n = atoi(argv[2]), hlen = atoi(argv[3]);
@@ -269,5 +300,6 @@ int main(int argc, char **argv) {
   if (!strcmp(argv[1], "bench")) return cmd_bench(argc - 1, argv + 1);
   if (!strcmp(argv[1], "hash")) return cmd_hash(argc - 1, argv + 1);
   if (!strcmp(argv[1], "gmul")) return cmd_gmul(argc - 1, argv + 1);
+  if (!strcmp(argv[1], "compress")) return cmd_compress(argc - 1, argv + 1);
   return 2;
 }

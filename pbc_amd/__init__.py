@@ -64,6 +64,9 @@ def lib():
         L.pbc_hip_diag_stage.argtypes = [vp, ci, vp, sz, vp, vp, sz]
         L.pbc_hip_pairing_length_in_bytes_Zr.argtypes = [vp]
         L.pbc_hip_element_mul_zn_batch.argtypes = [vp, ci, vp, vp, vp, sz]
+        L.pbc_hip_pairing_length_in_bytes_compressed_G1.argtypes = [vp]
+        L.pbc_hip_element_to_bytes_compressed_batch.argtypes = [vp, ci, vp, vp, sz]
+        L.pbc_hip_element_from_bytes_compressed_batch.argtypes = [vp, ci, vp, vp, sz]
         L.pbc_hip_element_from_hash_batch.argtypes = [vp, ci, vp, vp, ci, sz]
         L.pbc_hip_element_mul_GT_batch.argtypes = [vp, vp, vp, vp, sz]
         L.pbc_hip_element_pow_zn_GT_batch.argtypes = [vp, vp, vp, vp, sz]
@@ -91,6 +94,8 @@ EXPORTS = (
     "pbc_hip_pairing_pp_init", "pbc_hip_pairing_pp_clear", "pbc_hip_pairing_pp_apply_batch",
     "pbc_hip_pairing_pp_apply_batch_dev", "pbc_hip_pairing_length_in_bytes_Zr",
     "pbc_hip_element_from_hash_batch", "pbc_hip_element_mul_zn_batch", "pbc_hip_element_mul_GT_batch", "pbc_hip_element_pow_zn_GT_batch",
+    "pbc_hip_pairing_length_in_bytes_compressed_G1", "pbc_hip_element_to_bytes_compressed_batch",
+    "pbc_hip_element_from_bytes_compressed_batch",
 )
 
 
@@ -191,6 +196,27 @@ class Pairing:
         out = np.empty((n, lp), np.uint8)
         if lib().pbc_hip_element_mul_zn_batch(self._h, group, _np_ptr(out), _np_ptr(pts), _np_ptr(zr), n):
             raise PbcHipError("element_mul_zn: " + _err())
+        return out
+
+    def element_to_bytes_compressed(self, group, pts):
+        """x||y records -> x||sign records (element_to_bytes_compressed)."""
+        import numpy as np
+        pts = np.ascontiguousarray(pts, dtype=np.uint8)
+        n = pts.size // self.length_in_bytes_G1
+        out = np.empty((n, lib().pbc_hip_pairing_length_in_bytes_compressed_G1(self._h)), np.uint8)
+        if lib().pbc_hip_element_to_bytes_compressed_batch(self._h, group, _np_ptr(out), _np_ptr(pts), n):
+            raise PbcHipError("element_to_bytes_compressed: " + _err())
+        return out
+
+    def element_from_bytes_compressed(self, group, recs):
+        """x||sign records -> x||y records (element_from_bytes_compressed)."""
+        import numpy as np
+        recs = np.ascontiguousarray(recs, dtype=np.uint8)
+        lc = lib().pbc_hip_pairing_length_in_bytes_compressed_G1(self._h)
+        n = recs.size // lc
+        out = np.empty((n, self.length_in_bytes_G1), np.uint8)
+        if lib().pbc_hip_element_from_bytes_compressed_batch(self._h, group, _np_ptr(out), _np_ptr(recs), n):
+            raise PbcHipError("element_from_bytes_compressed: " + _err())
         return out
 
     def element_from_hash(self, group, digests):

@@ -437,6 +437,44 @@ PBC_DEV void a_from_hash_lane(uint8_t *out, const uint8_t *data, int hlen) {
   fp_store_be<N>(out + NB, ay);
 }
 
+// ---- compressed points on E(F_q) ---------------------------------------------------------------
+// element_to_bytes_compressed (ecc/curve.c:762-773): x || s with s = 1 when the canonical y is odd
+// (element_sign > 0, montfp.c:457-470), else 0.  element_from_bytes_compressed (:800-815): y from
+// x by a square root (point_from_x :779-793), negated when its sign disagrees with s.  An x with no
+// point above it ("requires a solution to exist") is written as the zero record (O).
+template <int N>
+PBC_DEV void g_compress_lane(uint8_t *out, const uint8_t *in) {
+  const int NB = (int) fpk<N>().fbytes;
+  for (int i = 0; i < NB; i++) out[i] = in[i];
+  out[NB] = in[2 * NB - 1] & 1;        // y is a canonical residue < q: its parity is its last byte's
+}
+template <int N>
+PBC_DEV void g_decompress_lane(uint8_t *out, const uint8_t *in) {
+  const int NB = (int) fpk<N>().fbytes;
+  fp<N> x, t, y, ny, ca, cb, o, c;
+  fp_set<N>(ca, c_curve.a);
+  fp_set<N>(cb, c_curve.b);
+  fp_load_be<N>(x, in);
+  fp_sqr<N>(t, x);
+  fp_add<N>(t, t, ca);
+  fp_mul<N>(t, t, x);
+  fp_add<N>(t, t, cb);
+  bool ok;
+  fp_sqrt_lane<N>(y, ok, t);
+#pragma unroll
+  for (int i = 0; i < N; i++) o.v[i] = (i == 0);
+  fp_mul<N>(c, y, o);                  // canonical residue: its parity is the sign
+  const bool odd = (c.v[0] & 1) != 0, want_odd = in[NB] != 0;
+  fp_neg<N>(ny, y);
+  fp_cmov<N>(y, ny, (odd != want_odd) & !fp_is0<N>(y));
+  if (!ok) {
+#pragma unroll
+    for (int k = 0; k < N; k++) { x.v[k] = 0; y.v[k] = 0; }
+  }
+  fp_store_be<N>(out, x);
+  fp_store_be<N>(out + NB, y);
+}
+
 // ---- GT ------------------------------------------------------------------------------------
 // Type A: F_q^2
 template <int N>

@@ -228,6 +228,15 @@ __global__ void __launch_bounds__(kBlock, 2) g_mul_kernel(uint8_t *out, const ui
   const size_t L = 2 * fpk<N>().fbytes;
   g_mul_lane<N>(out + idx * L, in + idx * L, z + idx * zlen, zlen);
 }
+// element_to_bytes_compressed / element_from_bytes_compressed on E(F_q): one point per lane
+template <int N>
+__global__ void __launch_bounds__(kBlock, 2) g_compress_kernel(int dir, uint8_t *out, const uint8_t *in, size_t n) {
+  size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
+  if (idx >= n) return;
+  const size_t fb = fpk<N>().fbytes;
+  if (dir == 0) g_compress_lane<N>(out + idx * (fb + 1), in + idx * 2 * fb);
+  else g_decompress_lane<N>(out + idx * 2 * fb, in + idx * (fb + 1));
+}
 // element_mul_zn on the twists: G2 of types d / g (over F_q^d) and f (over F_q^2)
 template <int N, int DEG>
 __global__ void __launch_bounds__(kBlock, 2) d_g2_mul_kernel(uint8_t *out, const uint8_t *in, const uint8_t *z,
@@ -813,19 +822,10 @@ extern "C" int pbc_hip_element_pow_zn_GT_batch(pbc_hip_pairing_t *P, uint8_t *ou
   return run_group(P, 2, 0, out, a, zr, n);
 }
 
-extern "C" int pbc_hip_element_from_hash_batch(pbc_hip_pairing_t *P, int group, uint8_t *out, const uint8_t *data,
-                                               int hlen, size_t n) {
-  if (!P) return fail("null pairing");
-  if (P->device < 0) return fail("no HIP device: libpbc_hip has no CPU fallback");
-  const bool symmetric = P->type == 'a' || P->type == '1' || P->type == 'e';
-  if (group != 1 && !(group == 2 && symmetric))
-    return fail("element_from_hash is built for G1 (and G2 of the symmetric types a, a1, e)");
-  if (hlen < 1) return fail("hlen must be >= 1");
-  if (!n) return 0;
-  void *dd = nullptr, *d_o = nullptr;
-  HIP_TRY(hipSetDevice(P->device));
+// first use of a square root in a field with q = 1 mod 4: derive the non-residue power z^t of the
+// Tonelli-Shanks tail on the device (single lane)
+static int ensure_sqrt_constants(pbc_hip_pairing_s *P) {
   if (!P->hash.ts_ready) {
-    // first use with q = 1 mod 4: derive the non-residue power on the device (single lane)
     if (upload_constants(P, 0)) return 1;
     uint32_t *dc = nullptr;
     TsRaw raw;
@@ -840,6 +840,55 @@ extern "C" int pbc_hip_element_from_hash_batch(pbc_hip_pairing_t *P, int group, 
     (void) hipFree(dc);
     P->hash.ts_ready = true;
   }
+  return 0;
+}
+// dir 0: x||y -> x||s;  dir 1: x||s -> x||y
+static int run_compress(pbc_hip_pairing_s *P, int dir, int group, uint8_t *out, const uint8_t *in, size_t n) {
+  if (!P) return fail("null pairing");
+  if (P->device < 0) return fail("no HIP device: libpbc_hip has no CPU fallback");
+  const bool symmetric = P->type == 'a' || P->type == '1' || P->type == 'e';
+  if (group != 1 && !(group == 2 && symmetric))
+    return fail("compressed points are built for G1 (and G2 of the symmetric types a, a1, e)");
+  if (!n) return 0;
+  const size_t lp = (size_t) P->len1, lc = (size_t) P->len_fq + 1;
+  const size_t li = dir == 0 ? lp : lc, lo = dir == 0 ? lc : lp;
+  void *di = nullptr, *d_o = nullptr;
+  HIP_TRY(hipSetDevice(P->device));
+  if (ensure_sqrt_constants(P)) return 1;
+  HIP_TRY(hipMalloc(&di, n * li));
+  HIP_TRY(hipMalloc(&d_o, n * lo));
+  HIP_TRY(hipMemcpy(di, in, n * li, hipMemcpyHostToDevice));
+  if (upload_constants(P, 0)) return 1;
+  unsigned grid = (unsigned) ((n + kBlock - 1) / kBlock);
+  PBC_DISPATCH_N(P->nlimb, hipLaunchKernelGGL(g_compress_kernel<N>, dim3(grid), dim3(kBlock), 0, 0, dir, (uint8_t *) d_o,
+                                              (const uint8_t *) di, n));
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(out, d_o, n * lo, hipMemcpyDeviceToHost));
+  (void) hipFree(di); (void) hipFree(d_o);
+  return 0;
+}
+extern "C" int pbc_hip_element_to_bytes_compressed_batch(pbc_hip_pairing_t *P, int group, uint8_t *out,
+                                                         const uint8_t *in, size_t n) {
+  return run_compress(P, 0, group, out, in, n);
+}
+extern "C" int pbc_hip_element_from_bytes_compressed_batch(pbc_hip_pairing_t *P, int group, uint8_t *out,
+                                                           const uint8_t *in, size_t n) {
+  return run_compress(P, 1, group, out, in, n);
+}
+extern "C" int pbc_hip_pairing_length_in_bytes_compressed_G1(const pbc_hip_pairing_t *p) { return p->len_fq + 1; }
+
+extern "C" int pbc_hip_element_from_hash_batch(pbc_hip_pairing_t *P, int group, uint8_t *out, const uint8_t *data,
+                                               int hlen, size_t n) {
+  if (!P) return fail("null pairing");
+  if (P->device < 0) return fail("no HIP device: libpbc_hip has no CPU fallback");
+  const bool symmetric = P->type == 'a' || P->type == '1' || P->type == 'e';
+  if (group != 1 && !(group == 2 && symmetric))
+    return fail("element_from_hash is built for G1 (and G2 of the symmetric types a, a1, e)");
+  if (hlen < 1) return fail("hlen must be >= 1");
+  if (!n) return 0;
+  void *dd = nullptr, *d_o = nullptr;
+  HIP_TRY(hipSetDevice(P->device));
+  if (ensure_sqrt_constants(P)) return 1;
   HIP_TRY(hipMalloc(&dd, n * (size_t) hlen));
   HIP_TRY(hipMalloc(&d_o, n * (size_t) P->len1));
   HIP_TRY(hipMemcpy(dd, data, n * (size_t) hlen, hipMemcpyHostToDevice));

@@ -54,3 +54,6 @@ $T hash pbc_amd/param/a1.param 3 20 3 $G/a1_hash20.vec
 for pf in d159 d201 g149 f; do $T gmul pbc_amd/param/$pf.param 2 6 11 $G/${pf}_g2mul6.vec; done
 $T gmul pbc_amd/param/e.param 1 3 11 $G/e_g1mul3.vec
 $T gmul pbc_amd/param/d224.param 1 6 11 $G/d224_g1mul6.vec
+# element_to_bytes_compressed / element_from_bytes_compressed on G1
+for pf in a d159 d278027-190-181 f g149; do $T compress pbc_amd/param/$pf.param 12 21 $G/${pf}_compress12.vec; done
+$T compress pbc_amd/param/e.param 4 21 $G/e_compress4.vec

@@ -67,6 +67,16 @@ class HostSim:
         self.L.hostsim_group(self.h, what, out.ctypes.data, a.ctypes.data, b.ctypes.data, n)
         return out
 
+    def compress(self, direction, recs):
+        recs = np.ascontiguousarray(recs, np.uint8)
+        lp, lc = self.len1, self.len1 // 2 + 1
+        li, lo = (lp, lc) if direction == 0 else (lc, lp)
+        n = recs.size // li
+        out = np.empty((n, lo), np.uint8)
+        self.L.hostsim_compress.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+        self.L.hostsim_compress(self.h, direction, out.ctypes.data, recs.ctypes.data, n)
+        return out
+
     def g2_mul(self, a, b):
         a = np.ascontiguousarray(a, np.uint8)
         b = np.ascontiguousarray(b, np.uint8)

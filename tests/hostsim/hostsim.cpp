@@ -119,6 +119,22 @@ int hostsim_pp(void *h, uint8_t *gt, const uint8_t *g1, const uint8_t *g2, size_
   for (size_t u = 0; u < n; u++) a_pp_apply_lane<16>(gt + u * P->lenT, tab, v, g2 + u * P->len2);
   return 0;
 }
+// compressed points on G1: dir 0 compress, 1 decompress
+int hostsim_compress(void *h, int dir, uint8_t *out, const uint8_t *in, size_t n) {
+  pbc_hip_pairing_s *P = (pbc_hip_pairing_s *) h;
+  activate(P);
+  if (!P->hash.ts_ready) {
+    HS_DISPATCH(P->nlimb, fp_ts_init<N>(P->hash.ts_c, P->hash.ts_t, P->hash.ts_tbits, P->hash.half, P->hash.halfbits));
+    P->hash.ts_ready = true;
+    activate(P);
+  }
+  const size_t lp = P->len1, lc = P->len_fq + 1;
+  for (size_t i = 0; i < n; i++) {
+    if (dir == 0) { HS_DISPATCH(P->nlimb, g_compress_lane<N>(out + i * lc, in + i * lp)); }
+    else { HS_DISPATCH(P->nlimb, g_decompress_lane<N>(out + i * lp, in + i * lc)); }
+  }
+  return 0;
+}
 // element_mul_zn on G2 of the asymmetric types (twists)
 int hostsim_g2_mul(void *h, uint8_t *out, const uint8_t *a, const uint8_t *b, size_t n) {
   pbc_hip_pairing_s *P = (pbc_hip_pairing_s *) h;

@@ -503,6 +503,22 @@ def test_g1_scalar_multiplication_wide_fields(hips, key, name):
     assert np.array_equal(hips[key].element_mul_zn(1, v.g1, v.g2), v.gt)
 
 
+@pytest.mark.parametrize("key,name", [("a", "a_compress12.vec"), ("d", "d159_compress12.vec"),
+                                      ("d278027-190-181", "d278027-190-181_compress12.vec"), ("f", "f_compress12.vec"),
+                                      ("g149", "g149_compress12.vec"), ("e", "e_compress4.vec")])
+def test_compressed_points_match_reference(hips, key, name):
+    """element_to_bytes_compressed / element_from_bytes_compressed (ecc/curve.c:762-815) on G1."""
+    v = golden(name)
+    H = hips[key]
+    assert np.array_equal(H.element_to_bytes_compressed(1, v.g1), v.gt)
+    assert np.array_equal(H.element_from_bytes_compressed(1, v.gt), v.g1)
+    flipped = v.gt.copy()
+    flipped[:, -1] ^= 1                                    # the other root: (x, -y)
+    neg = H.element_from_bytes_compressed(1, flipped)
+    assert np.array_equal(neg[:, :v.len1 // 2], v.g1[:, :v.len1 // 2]) and not np.array_equal(neg, v.g1)
+    assert np.array_equal(H.element_to_bytes_compressed(1, neg), flipped)
+
+
 def test_asymmetric_bls_round_trip_on_gpu(hips):
     """BLS on the BN curve (type f), everything on the device: sk_i, pk_i = [sk_i] g2 (G2 twist),
     h_i = H(m_i) in G1, sig_i = [sk_i] h_i; verify e(sig_i, g2) == e(h_i, pk_i); a forged one fails."""

@@ -123,3 +123,16 @@ def test_g2_scalar_multiplication_on_host(sims, key, name):
 def test_g1_scalar_multiplication_wide_fields_on_host(sims, key, name):
     v = golden(name)
     assert np.array_equal(sims[key].group(0, v.g1, v.g2), v.gt)
+
+
+COMPRESS = [("a", "a_compress12.vec"), ("d", "d159_compress12.vec"), ("d278027-190-181", "d278027-190-181_compress12.vec"),
+            ("f", "f_compress12.vec"), ("g149", "g149_compress12.vec"), ("e", "e_compress4.vec")]
+
+
+@pytest.mark.parametrize("key,name", COMPRESS)
+def test_compressed_points_on_host(sims, key, name):
+    """element_to_bytes_compressed / element_from_bytes_compressed (ecc/curve.c:762-815) vs the reference."""
+    v = golden(name)                                       # file: x||y records, (no second input), x||s records
+    n = min(v.n, 6)
+    assert np.array_equal(sims[key].compress(0, v.g1[:n]), v.gt[:n])
+    assert np.array_equal(sims[key].compress(1, v.gt[:n]), v.g1[:n])

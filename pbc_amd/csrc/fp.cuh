@@ -257,6 +257,39 @@ PBC_DEV void fp_sqr29_inl(fp<N> &r, const fp<N> &a) {
 }
 #undef PBC_MAC
 
+// Limb-domain square: limbs in, limbs out (normalised input; same column bound as fp_sqr29_inl)
+template <int N>
+PBC_DEV void sqr_limbs(uint32_t *t, const uint32_t *x) {
+  const FpK<N> &K = fpk<N>();
+  constexpr int L = Limbs29<N>::L;
+  constexpr uint32_t MASK = Limbs29<N>::MASK;
+  uint32_t x2[L], m[L];
+#pragma unroll
+  for (int i = 0; i < L; i++) x2[i] = x[i] << 1;
+  uint64_t acc = 0;
+#pragma unroll
+  for (int k = 0; k < L; k++) {
+#pragma unroll
+    for (int i = 0; 2 * i < k; i++) acc += (uint64_t) x[i] * x2[k - i];
+    if ((k & 1) == 0) acc += (uint64_t) x[k / 2] * x[k / 2];
+#pragma unroll
+    for (int i = 0; i < k; i++) acc += (uint64_t) m[i] * K.p29[k - i];
+    m[k] = ((uint32_t) acc * K.ninv29) & MASK;
+    acc += (uint64_t) m[k] * K.p29[0];
+    acc >>= 29;
+  }
+#pragma unroll
+  for (int k = L; k < 2 * L; k++) {
+#pragma unroll
+    for (int i = k - L + 1; 2 * i < k; i++) acc += (uint64_t) x[i] * x2[k - i];
+    if ((k & 1) == 0) acc += (uint64_t) x[k / 2] * x[k / 2];
+#pragma unroll
+    for (int i = k - L + 1; i < L; i++) acc += (uint64_t) m[i] * K.p29[k - i];
+    t[k - L] = (uint32_t) acc & MASK;
+    acc >>= 29;
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // Limb-domain sum of products (lazy reduction for the extension towers):
 //     r = (x_0 y_0 + ... + x_{T-1} y_{T-1}) / R  mod q,   one Montgomery reduction for T products.

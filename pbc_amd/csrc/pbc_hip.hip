@@ -460,6 +460,28 @@ __global__ void __launch_bounds__(256) probe_kernel(uint32_t *sink, int iters, u
   if (r == 0x1234567887654321ull) sink[0] = (uint32_t) r;   // never true in practice: keeps the chains live
 }
 
+// limb-form out-of-line product / square (experiment: elements kept as 18 x 29-bit limbs between calls)
+typedef uint32_t v18 __attribute__((ext_vector_type(18)));
+static __device__ __noinline__ v18 fz_mul_fn(v18 va, v18 vb) {
+  fl<16> a[1], b[1], r;
+#pragma unroll
+  for (int i = 0; i < 18; i++) { a[0].l[i] = va[i]; b[0].l[i] = vb[i]; }
+  sop_limbs<16, 1>(r, a, b);
+  v18 o;
+#pragma unroll
+  for (int i = 0; i < 18; i++) o[i] = r.l[i];
+  return o;
+}
+static __device__ __noinline__ v18 fz_sqr_fn(v18 va) {
+  uint32_t x[18], t[18];
+#pragma unroll
+  for (int i = 0; i < 18; i++) x[i] = va[i];
+  sqr_limbs<16>(t, x);
+  v18 o;
+#pragma unroll
+  for (int i = 0; i < 18; i++) o[i] = t[i];
+  return o;
+}
 // ---- multiplier micro-benchmark: iters dependent F_q products per lane, nothing else ------
 template <int N, int V>
 __global__ void __launch_bounds__(256) mul_bench_kernel(uint32_t *out, const uint32_t *in, int iters) {
@@ -477,7 +499,29 @@ __global__ void __launch_bounds__(256) mul_bench_kernel(uint32_t *out, const uin
     else if constexpr (V == 4) fp_sqr29_inl<N, true>(x, x);
     else if constexpr (V == 5) { fp_inv<N>(x, x); fp_add<N>(x, x, y); }          // safegcd inversion
     else if constexpr (V == 6) fp_mul<N>(x, x, y);                                 // out-of-line product
-    else fp_sqr<N>(x, x);                                                          // out-of-line square
+    else if constexpr (V == 7) fp_sqr<N>(x, x);                                    // out-of-line square
+    else if constexpr (N == 16 && (V == 8 || V == 9 || V == 10)) {
+      // limb-form chain: x, y reinterpreted as 18 limbs (values are garbage but the work is the same)
+      v18 a, b;
+#pragma unroll
+      for (int i = 0; i < 18; i++) { a[i] = x.v[i & 15] & 0x1fffffffu; b[i] = y.v[i & 15] & 0x1fffffffu; }
+      for (int rep = 0; rep < 8; rep++) {
+        if constexpr (V == 8) a = fz_mul_fn(a, b);
+        else if constexpr (V == 9) a = fz_sqr_fn(a);
+        else {                                               // product + lazy subtraction + parallel carry
+          v18 c = fz_mul_fn(a, b);
+          uint32_t cy[18];
+#pragma unroll
+          for (int i = 0; i < 18; i++) { uint32_t t = c[i] + 0x3ffffff8u - b[i]; cy[i] = t >> 29; c[i] = t & 0x1fffffffu; }
+#pragma unroll
+          for (int i = 1; i < 18; i++) c[i] += cy[i - 1];
+          a = c;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 16; i++) x.v[i] = a[i];
+      it += 7;
+    }
   }
 #pragma unroll
   for (int i = 0; i < N; i++) out[i * n + tid] = x.v[i];
@@ -1124,6 +1168,9 @@ extern "C" int pbc_hip_diag_mul_bench(int variant, int iters, int waves_per_simd
     case 5: return run_mul_bench<5>(iters, waves_per_simd, rate, ms);
     case 6: return run_mul_bench<6>(iters, waves_per_simd, rate, ms);
     case 7: return run_mul_bench<7>(iters, waves_per_simd, rate, ms);
+    case 8: return run_mul_bench<8>(iters, waves_per_simd, rate, ms);
+    case 9: return run_mul_bench<9>(iters, waves_per_simd, rate, ms);
+    case 10: return run_mul_bench<10>(iters, waves_per_simd, rate, ms);
     default: return fail("unknown mul variant %d", variant);
   }
 }

@@ -304,7 +304,7 @@ PBC_DEV void fp_ts_init(uint32_t *out, const uint32_t *texp, int tbits, const ui
   for (int k = 0; k < N; k++) out[k] = c.v[k];
 }
 template <int N>
-PBC_DEV void a_from_hash_lane(uint8_t *out, const uint8_t *data, int hlen) {
+PBC_DEV void g_from_hash_lane(uint8_t *out, const uint8_t *data, int hlen) {
   const int NB = (int) fpk<N>().fbytes;
   const FpK<N> &K = fpk<N>();
   fp<N> one, ca, cb, x, fx, fy;

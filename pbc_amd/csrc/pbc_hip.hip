@@ -254,12 +254,12 @@ __global__ void __launch_bounds__(kBlock, 2) f_g2_mul_kernel(uint8_t *out, const
   ec_mul_lane<Fq2Ops>(out + idx * L, in + idx * L, z + idx * zlen, zlen);
 }
 template <int N>
-__global__ void __launch_bounds__(kBlock, 2) a_from_hash_kernel(uint8_t *out, const uint8_t *data, int hlen, size_t n) {
+__global__ void __launch_bounds__(kBlock, 2) g_from_hash_kernel(uint8_t *out, const uint8_t *data, int hlen, size_t n) {
   size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
   size_t ld = idx < n ? idx : n - 1;   // whole waves stay in the retry loop together
   const int L = 2 * (int) fpk<N>().fbytes;
   __attribute__((aligned(4))) uint8_t o[8 * N];
-  a_from_hash_lane<N>(o, data + ld * hlen, hlen);
+  g_from_hash_lane<N>(o, data + ld * hlen, hlen);
   if (idx < n)
     for (int i = 0; i < L; i++) out[idx * L + i] = o[i];
 }
@@ -938,7 +938,7 @@ extern "C" int pbc_hip_element_from_hash_batch(pbc_hip_pairing_t *P, int group, 
   HIP_TRY(hipMemcpy(dd, data, n * (size_t) hlen, hipMemcpyHostToDevice));
   if (upload_constants(P, 0)) return 1;
   unsigned grid = (unsigned) ((n + kBlock - 1) / kBlock);
-  PBC_DISPATCH_N(P->nlimb, hipLaunchKernelGGL(a_from_hash_kernel<N>, dim3(grid), dim3(kBlock), 0, 0, (uint8_t *) d_o,
+  PBC_DISPATCH_N(P->nlimb, hipLaunchKernelGGL(g_from_hash_kernel<N>, dim3(grid), dim3(kBlock), 0, 0, (uint8_t *) d_o,
                                               (const uint8_t *) dd, hlen, n));
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpy(out, d_o, n * (size_t) P->len1, hipMemcpyDeviceToHost));

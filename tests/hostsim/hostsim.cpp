@@ -189,7 +189,7 @@ int hostsim_from_hash(void *h, uint8_t *out, const uint8_t *data, int hlen, size
     P->hash.ts_ready = true;
     activate(P);
   }
-  for (size_t i = 0; i < n; i++) { HS_DISPATCH(P->nlimb, a_from_hash_lane<N>(out + i * P->len1, data + i * hlen, hlen)); }
+  for (size_t i = 0; i < n; i++) { HS_DISPATCH(P->nlimb, g_from_hash_lane<N>(out + i * P->len1, data + i * hlen, hlen)); }
   return 0;
 }
 // diagnostics mirroring pbc_hip_diag_stage

@@ -45,11 +45,36 @@ def test_init_parses_type_a_lengths(a_param_text):
     p.clear()
 
 
+# every type a / a1 / d / e / f / g parameter file the reference ships under param/: (type, G1, G2, GT, Zr bytes)
+SHIPPED = {
+    "a": ("a", 128, 128, 128, 20), "a1": ("1", 260, 260, 260, 128), "e": ("e", 256, 256, 128, 20),
+    "f": ("f", 40, 80, 240, 20), "g149": ("g", 38, 190, 190, 19),
+    "d159": ("d", 40, 120, 120, 20), "d201": ("d", 52, 156, 156, 23), "d224": ("d", 56, 168, 168, 28),
+    "d105171-196-185": ("d", 50, 150, 150, 24), "d277699-175-167": ("d", 44, 132, 132, 21),
+    "d278027-190-181": ("d", 48, 144, 144, 23),
+}
+
+
+@pytest.mark.parametrize("name", sorted(SHIPPED))
+def test_init_parses_every_shipped_parameter_file(name):
+    """pairing_init_set_buf on the host: type dispatch and pairing_length_in_bytes_* (no GPU needed)."""
+    import os
+    text = open(os.path.join(pbc_amd.PARAM_DIR, name + ".param")).read()
+    p = pbc_amd.Pairing(text)
+    t, l1, l2, lt, lz = SHIPPED[name]
+    assert p.type == t
+    assert (p.length_in_bytes_G1, p.length_in_bytes_G2, p.length_in_bytes_GT, p.length_in_bytes_Zr) == (l1, l2, lt, lz)
+    assert p.algorithmic_macs_per_unit(1) > 0 and p.algorithmic_macs_per_unit(4) >= p.algorithmic_macs_per_unit(1)
+    p.clear()
+
+
 @pytest.mark.parametrize("bad", [
     "",                                   # no type
     "type z\nq 7\n",                      # unknown type
     "type a\nq 11\n",                     # missing keys
     "type a\nq 12\nh 1\nr 1\nexp2 3\nexp1 1\nsign1 1\nsign0 1\n",   # even / tiny q
+    "type i\nm 97\nt 12\nn 1\nn2 1\n",  # eta_T pairing over GF(3^m): not built in
+    "type d\nq 7\nr 3\na 1\nb 1\nk 4\nnqr 3\ncoeff0 1\ncoeff1 1\ncoeff2 1\nh 1\n",   # wrong embedding degree
 ])
 def test_init_failure_returns_nonzero_with_message(bad):
     with pytest.raises(pbc_amd.PbcHipError) as e:

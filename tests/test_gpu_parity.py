@@ -385,6 +385,44 @@ def test_other_type_d_and_g_params_match_reference_vectors(hips, d):
     assert np.array_equal(H.element_prod_pairing(v.g1, v.g2, v.k), v.gt)
 
 
+@pytest.mark.parametrize("key,name", [("g149", "g149_chain64.vec"), ("e", "e_chain8.vec"), ("a1", "a1_chain8.vec"),
+                                      ("d224", "d224_rand12.vec")])
+@pytest.mark.parametrize("n", [0, 1, 65, 130])
+def test_other_families_ragged_batch_sizes(hips, key, name, n):
+    """whole blocks plus a tail, one lane, and the empty batch through the host-buffer path"""
+    v = golden(name)
+    idx = np.arange(n) % v.n
+    out = hips[key].element_pairing(v.g1[idx], v.g2[idx])
+    assert out.shape == (n, hips[key].length_in_bytes_GT)
+    assert np.array_equal(out, v.gt[idx])
+
+
+@pytest.mark.parametrize("key,name,log2n", [("g149", "g149_chain64.vec", 16), ("e", "e_chain8.vec", 14), ("a1", "a1_chain8.vec", 13)])
+def test_other_families_device_batch_properties(hips, key, name, log2n):
+    """device-pointer API on a batch that fills the chip: all (P_i, Q_j) of the chain fixture, tiled.
+    e(P_i, Q_j) = e(P_0, Q_0)^((i+1)(j+1)), so the D x D result matrix is symmetric, every tile repeats
+    it and its diagonal is the reference fixture."""
+    import torch
+    v = golden(name)
+    P = hips[key]
+    D = v.n
+    n = 1 << log2n
+    LT = P.length_in_bytes_GT
+    g1 = torch.from_numpy(v.g1).cuda()
+    g2 = torch.from_numpy(v.g2).cuda()
+    idx = torch.arange(n, device="cuda")
+    G1 = g1[(idx // D) % D].contiguous()
+    G2 = g2[idx % D].contiguous()
+    GT = torch.empty(n, LT, dtype=torch.uint8, device="cuda")
+    P.element_pairing_dev(GT.data_ptr(), G1.data_ptr(), G2.data_ptr(), n, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    M = GT.reshape(n // (D * D), D, D, LT)
+    assert torch.equal(M[0], M[0].transpose(0, 1))
+    for rep in range(1, M.shape[0]):
+        assert torch.equal(M[rep], M[0])
+    assert np.array_equal(M[0][torch.arange(D), torch.arange(D)].cpu().numpy(), v.gt)
+
+
 def test_type_g_chain_and_products(hips):
     H = hips["g149"]
     v = golden("g149_chain64.vec")

@@ -471,11 +471,36 @@ static __device__ __noinline__ typename vecN<16>::type fp_mul_fn16(typename vecN
 #ifndef PBC_INLINE_SMALL
 #define PBC_INLINE_SMALL 0  // 1: products of the 160-bit fields are inlined (a call costs more than the
 #endif                      //    78 multiply-adds it wraps); code size is held by the tower-level calls
+// Wide fields (33 words: types a1, e): an element no longer fits the argument registers, and moving
+// 99 words through them at every call site bloats the loops past the instruction cache.  Operands
+// and results of the out-of-line routines are passed by address instead: the elements live in the
+// lane's private memory (scratch, dword-interleaved across the wave, so accesses are coalesced) and a
+// call site is a handful of scalar instructions.
+#ifndef PBC_MEM_OPERANDS
+#define PBC_MEM_OPERANDS 1
+#endif
+template <int N> constexpr bool kMemOperands = PBC_MEM_OPERANDS && N >= 32;
+template <int N>
+static __device__ __noinline__ void fp_mul_mem(fp<N> *r, const fp<N> *a, const fp<N> *b) {
+  fp<N> x = *a, y = *b, z;
+  fp_mul_inl<N>(z, x, y);
+  *r = z;
+}
+template <int N>
+static __device__ __noinline__ void fp_sqr_mem(fp<N> *r, const fp<N> *a) {
+  fp<N> x = *a, z;
+  fp_sqr_inl<N>(z, x);
+  *r = z;
+}
 template <int N>
 PBC_DEV void fp_mul(fp<N> &r, const fp<N> &a, const fp<N> &b) {
 #if PBC_INLINE_MUL
   fp_mul_inl<N>(r, a, b);
 #else
+  if constexpr (kMemOperands<N>) {
+    fp_mul_mem<N>(&r, &a, &b);
+    return;
+  }
   if constexpr (N <= 5 && PBC_INLINE_SMALL) {
     fp_mul_inl<N>(r, a, b);
     return;
@@ -509,13 +534,17 @@ PBC_DEV void fp_sqr(fp<N> &r, const fp<N> &a) {
     fp_sqr_inl<N>(r, a);
     return;
   }
+  if constexpr (kMemOperands<N>) {
+    fp_sqr_mem<N>(&r, &a);
+    return;
+  }
   from_vec<N>(r, fp_sqr_fn<N>(to_vec<N>(a)));
 #endif
 }
 
 // fp_add (montfp.c:220-250)
 template <int N>
-PBC_DEV void fp_add(fp<N> &r, const fp<N> &a, const fp<N> &b) {
+PBC_DEV void fp_add_inl(fp<N> &r, const fp<N> &a, const fp<N> &b) {
   uint32_t t[N];
   uint32_t c = 0;
 #pragma unroll
@@ -524,7 +553,7 @@ PBC_DEV void fp_add(fp<N> &r, const fp<N> &a, const fp<N> &b) {
 }
 // fp_double (montfp.c:252-270)
 template <int N>
-PBC_DEV void fp_dbl(fp<N> &r, const fp<N> &a) {
+PBC_DEV void fp_dbl_inl(fp<N> &r, const fp<N> &a) {
   uint32_t t[N];
 #pragma unroll
   for (int i = 0; i < N; i++) t[i] = i ? __builtin_amdgcn_alignbit(a.v[i], a.v[i - 1], 31) : a.v[0] << 1;
@@ -532,7 +561,7 @@ PBC_DEV void fp_dbl(fp<N> &r, const fp<N> &a) {
 }
 // fp_sub (montfp.c:282-316)
 template <int N>
-PBC_DEV void fp_sub(fp<N> &r, const fp<N> &a, const fp<N> &b) {
+PBC_DEV void fp_sub_inl(fp<N> &r, const fp<N> &a, const fp<N> &b) {
   const FpK<N> &K = fpk<N>();
   uint32_t d[N];
   uint32_t bw = 0;
@@ -542,6 +571,41 @@ PBC_DEV void fp_sub(fp<N> &r, const fp<N> &a, const fp<N> &b) {
   uint32_t c = 0;
 #pragma unroll
   for (int i = 0; i < N; i++) r.v[i] = __builtin_addc(d[i], K.p[i] & mask, c, &c);
+}
+// add / double / subtract: inline for the register-resident fields, out of line on memory operands
+// for the wide ones (kMemOperands)
+template <int N>
+static __device__ __noinline__ void fp_add_mem(fp<N> *r, const fp<N> *a, const fp<N> *b) {
+  fp<N> x = *a, y = *b, z;
+  fp_add_inl<N>(z, x, y);
+  *r = z;
+}
+template <int N>
+static __device__ __noinline__ void fp_sub_mem(fp<N> *r, const fp<N> *a, const fp<N> *b) {
+  fp<N> x = *a, y = *b, z;
+  fp_sub_inl<N>(z, x, y);
+  *r = z;
+}
+template <int N>
+static __device__ __noinline__ void fp_dbl_mem(fp<N> *r, const fp<N> *a) {
+  fp<N> x = *a, z;
+  fp_dbl_inl<N>(z, x);
+  *r = z;
+}
+template <int N>
+PBC_DEV void fp_add(fp<N> &r, const fp<N> &a, const fp<N> &b) {
+  if constexpr (kMemOperands<N>) fp_add_mem<N>(&r, &a, &b);
+  else fp_add_inl<N>(r, a, b);
+}
+template <int N>
+PBC_DEV void fp_sub(fp<N> &r, const fp<N> &a, const fp<N> &b) {
+  if constexpr (kMemOperands<N>) fp_sub_mem<N>(&r, &a, &b);
+  else fp_sub_inl<N>(r, a, b);
+}
+template <int N>
+PBC_DEV void fp_dbl(fp<N> &r, const fp<N> &a) {
+  if constexpr (kMemOperands<N>) fp_dbl_mem<N>(&r, &a);
+  else fp_dbl_inl<N>(r, a);
 }
 template <int N>
 PBC_DEV bool fp_is0(const fp<N> &a) {

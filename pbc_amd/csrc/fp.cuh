@@ -623,7 +623,7 @@ PBC_DEV bool fp_eq(const fp<N> &a, const fp<N> &b) {
 }
 // fp_neg (montfp.c:318-330): 0 stays 0
 template <int N>
-PBC_DEV void fp_neg(fp<N> &r, const fp<N> &a) {
+PBC_DEV void fp_neg_inl(fp<N> &r, const fp<N> &a) {
   const FpK<N> &K = fpk<N>();
   uint32_t mask = fp_is0<N>(a) ? 0u : 0xffffffffu;
   uint32_t bw = 0;
@@ -632,7 +632,7 @@ PBC_DEV void fp_neg(fp<N> &r, const fp<N> &a) {
 }
 // fp_halve (montfp.c:272-280): a/2 = (a + (a odd ? q : 0)) >> 1
 template <int N>
-PBC_DEV void fp_halve(fp<N> &r, const fp<N> &a) {
+PBC_DEV void fp_halve_inl(fp<N> &r, const fp<N> &a) {
   const FpK<N> &K = fpk<N>();
   uint32_t mask = 0u - (a.v[0] & 1);
   uint32_t t[N];
@@ -648,9 +648,42 @@ PBC_DEV void fp_set(fp<N> &r, const uint32_t *w) {
   for (int i = 0; i < N; i++) r.v[i] = w[i];
 }
 template <int N>
-PBC_DEV void fp_cmov(fp<N> &r, const fp<N> &a, bool take) {
+PBC_DEV void fp_cmov_inl(fp<N> &r, const fp<N> &a, bool take) {
 #pragma unroll
   for (int i = 0; i < N; i++) r.v[i] = take ? a.v[i] : r.v[i];
+}
+template <int N>
+static __device__ __noinline__ void fp_neg_mem(fp<N> *r, const fp<N> *a) {
+  fp<N> x = *a, z;
+  fp_neg_inl<N>(z, x);
+  *r = z;
+}
+template <int N>
+static __device__ __noinline__ void fp_halve_mem(fp<N> *r, const fp<N> *a) {
+  fp<N> x = *a, z;
+  fp_halve_inl<N>(z, x);
+  *r = z;
+}
+template <int N>
+static __device__ __noinline__ void fp_cmov_mem(fp<N> *r, const fp<N> *a, bool take) {
+  fp<N> x = *a, z = *r;
+  fp_cmov_inl<N>(z, x, take);
+  *r = z;
+}
+template <int N>
+PBC_DEV void fp_neg(fp<N> &r, const fp<N> &a) {
+  if constexpr (kMemOperands<N>) fp_neg_mem<N>(&r, &a);
+  else fp_neg_inl<N>(r, a);
+}
+template <int N>
+PBC_DEV void fp_halve(fp<N> &r, const fp<N> &a) {
+  if constexpr (kMemOperands<N>) fp_halve_mem<N>(&r, &a);
+  else fp_halve_inl<N>(r, a);
+}
+template <int N>
+PBC_DEV void fp_cmov(fp<N> &r, const fp<N> &a, bool take) {
+  if constexpr (kMemOperands<N>) fp_cmov_mem<N>(&r, &a, take);
+  else fp_cmov_inl<N>(r, a, take);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -809,8 +842,15 @@ static __device__ __noinline__ typename vecN<N>::type fp_inv_fn(typename vecN<N>
   return to_vec<N>(res);
 }
 template <int N>
+static __device__ __noinline__ void fp_inv_mem(fp<N> *r, const fp<N> *a) {
+  fp<N> x = *a, z;
+  from_vec<N>(z, fp_inv_fn<N>(to_vec<N>(x)));
+  *r = z;
+}
+template <int N>
 PBC_DEV void fp_inv(fp<N> &r, const fp<N> &a) {
-  from_vec<N>(r, fp_inv_fn<N>(to_vec<N>(a)));
+  if constexpr (kMemOperands<N>) fp_inv_mem<N>(&r, &a);
+  else from_vec<N>(r, fp_inv_fn<N>(to_vec<N>(a)));
 }
 
 // bytes per F_q coordinate; a compile-time 64 for the type a field so that its kernels keep

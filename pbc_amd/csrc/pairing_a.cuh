@@ -443,17 +443,15 @@ PBC_DEV void a_prod_pairing_lane(uint8_t *gt, const uint8_t *g1, const uint8_t *
 template <int N>
 PBC_DEV bool a1_miller_lane(fp2<N> &f, const uint8_t *g1, const uint8_t *g2, uint32_t *lds_q, int lds_stride) {
   const int NB = fq_bytes<N>();
-  fp<N> one;
+  fp<N> one, Qx, Qy;
   jac<N> V;
   fp_set<N>(one, fpk<N>().one);
-  bool valid;
-  {
-    fp<N> Qx, Qy;
-    fp_load_be<N>(V.X, g1);
-    fp_load_be<N>(V.Y, g1 + NB);
-    fp_load_be<N>(Qx, g2);
-    fp_load_be<N>(Qy, g2 + NB);
-    valid = (int) a_on_curve<N>(V.X, V.Y) & (int) a_on_curve<N>(Qx, Qy);
+  fp_load_be<N>(V.X, g1);
+  fp_load_be<N>(V.Y, g1 + NB);
+  fp_load_be<N>(Qx, g2);
+  fp_load_be<N>(Qy, g2 + NB);
+  bool valid = (int) a_on_curve<N>(V.X, V.Y) & (int) a_on_curve<N>(Qx, Qy);
+  if constexpr (!kMemOperands<N>) {    // register-resident fields park Q in LDS between steps
 #pragma unroll
     for (int k = 0; k < N; k++) {
       lds_q[k * lds_stride] = Qx.v[k];
@@ -463,14 +461,14 @@ PBC_DEV bool a1_miller_lane(fp2<N> &f, const uint8_t *g1, const uint8_t *g2, uin
   V.Z = one;
   V.ZZ = one;
   f.x = one;
-#pragma unroll
-  for (int k = 0; k < N; k++) f.y.v[k] = 0;
+  fp_sub<N>(f.y, one, one);
   for (int i = c_a.rbits - 2; i >= 0; i--) {
-    fp<N> Qx, Qy;
+    if constexpr (!kMemOperands<N>) {
 #pragma unroll
-    for (int k = 0; k < N; k++) {
-      Qx.v[k] = lds_q[k * lds_stride];
-      Qy.v[k] = lds_q[(N + k) * lds_stride];
+      for (int k = 0; k < N; k++) {
+        Qx.v[k] = lds_q[k * lds_stride];
+        Qy.v[k] = lds_q[(N + k) * lds_stride];
+      }
     }
     a_double_step<N>(f, V, Qx, Qy);
     if (i > 0 && ((c_a.r[i >> 5] >> (i & 31)) & 1)) {

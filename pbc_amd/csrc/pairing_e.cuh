@@ -176,12 +176,12 @@ PBC_DEV void e_add_step(fp<N> &n, fp<N> &d, ejac<N> &V, const fp<N> &xP, const f
 
 // numerator and denominator of f_{r,P}(Q+R) / f_{r,P}(R) for one lane (n = d = 1 on entry).
 // G1, G2 bytes: x||y.  Returns false when an input deserialises to O (curve_from_bytes,
-// ecc/curve.c:609-623).  Q + R sits in LDS (lds_q: [2][N][lanes], limb-major).
+// ecc/curve.c:609-623).
 template <int N>
 PBC_DEV bool e_miller_lane(fp<N> &n, fp<N> &d, const uint8_t *g1, const uint8_t *g2, uint32_t *lds_q,
                            int lds_stride) {
   const int NB = fq_bytes<N>();
-  fp<N> one, xP, yP;
+  fp<N> one, xP, yP, x1, y1;
   fp_set<N>(one, fpk<N>().one);
   fp_load_be<N>(xP, g1);
   fp_load_be<N>(yP, g1 + NB);
@@ -203,21 +203,13 @@ PBC_DEV bool e_miller_lane(fp<N> &n, fp<N> &d, const uint8_t *g1, const uint8_t 
     fp_sub<N>(t, xQ, x3);
     fp_mul<N>(y3, t, l);
     fp_sub<N>(y3, y3, yQ);
-#pragma unroll
-    for (int k = 0; k < N; k++) {
-      lds_q[k * lds_stride] = x3.v[k];
-      lds_q[(N + k) * lds_stride] = y3.v[k];
-    }
+    x1 = x3;
+    y1 = y3;
   }
+  (void) lds_q; (void) lds_stride;     // Q + R stays in the lane's private memory (memory operands)
   ejac<N> V;
   V.X = xP; V.Y = yP; V.Z = one; V.ZZ = one;
   for (int i = c_e.rbits - 2; i >= 0; i--) {
-    fp<N> x1, y1;
-#pragma unroll
-    for (int k = 0; k < N; k++) {
-      x1.v[k] = lds_q[k * lds_stride];
-      y1.v[k] = lds_q[(N + k) * lds_stride];
-    }
     e_double_step<N>(n, d, V, x1, y1);
     if ((c_e.r[i >> 5] >> (i & 31)) & 1) {
       fp_load_be<N>(xP, g1);

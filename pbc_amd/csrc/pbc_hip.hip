@@ -89,7 +89,7 @@ __global__ void __launch_bounds__(kBlock, PBC_A1_WAVES) a1_prod_pairing_kernel(u
   size_t ld = idx < n ? idx : n - 1;
   const int L = 2 * fq_bytes<N>();
   __attribute__((aligned(4))) uint8_t out[8 * N];
-  __shared__ uint32_t lds_q[2 * N * kBlock];
+  __shared__ uint32_t lds_q[kMemOperands<N> ? 1 : 2 * N * kBlock];   // wide fields keep Q in private memory
   a1_prod_pairing_lane<N>(out, g1 + ld * k * L, g2 + ld * k * L, k, lds_q + threadIdx.x, kBlock);
   if (idx < n) {
     if ((L & 3) == 0) {
@@ -110,8 +110,8 @@ __global__ void __launch_bounds__(kBlock, PBC_A1_WAVES) e_prod_pairing_kernel(ui
   size_t ld = idx < n ? idx : n - 1;
   const int LT = fq_bytes<N>(), L = 2 * LT;
   __attribute__((aligned(4))) uint8_t out[4 * N];
-  __shared__ uint32_t lds_q[2 * N * kBlock];
-  e_prod_pairing_lane<N>(out, g1 + ld * k * L, g2 + ld * k * L, k, lds_q + threadIdx.x, kBlock);
+  uint32_t *lds_q = nullptr;           // unused: Q + R lives in the lane's private memory
+  e_prod_pairing_lane<N>(out, g1 + ld * k * L, g2 + ld * k * L, k, lds_q, kBlock);
   if (idx < n) {
     if ((LT & 3) == 0) {
       uint32_t *dst = reinterpret_cast<uint32_t *>(gt + idx * LT);

@@ -423,6 +423,28 @@ def test_other_families_device_batch_properties(hips, key, name, log2n):
     assert np.array_equal(M[0][torch.arange(D), torch.arange(D)].cpu().numpy(), v.gt)
 
 
+@pytest.mark.parametrize("key,name", [("a", "a_rand32.vec"), ("a1", "a1_rand6.vec"), ("e", "e_rand6.vec")])
+def test_symmetric_types_same_point_in_both_arguments(hips, oracles, key, name):
+    """G1 = G2 for types a, a1, e: e(P, P), e(Q, P) and e(P, -P) = e(P, P)^-1 against the oracle."""
+    v = golden(name)
+    H, O = hips[key], oracles[key]
+    n = 4
+    P, Q = v.g1[:n], v.g2[:n]
+    fb = H.length_in_bytes_G1 // 2
+    q = param_value(key, "p" if key == "a1" else "q")
+    negP = P.copy()
+    for i in range(n):
+        y = int.from_bytes(P[i, fb:].tobytes(), "big")
+        negP[i, fb:] = _be((q - y) % q, fb)
+    for a, b in ((P, P), (Q, P), (P, negP)):
+        assert np.array_equal(H.element_pairing(a, b), O.pairing_batch(a, b))
+    ePP, ePnP = H.element_pairing(P, P), H.element_pairing(P, negP)
+    one = np.zeros(H.length_in_bytes_GT, np.uint8)
+    one[fb - 1] = 1
+    assert np.array_equal(H.element_mul_GT(ePP, ePnP), np.tile(one, (n, 1)))
+    assert not np.array_equal(ePP, np.tile(one, (n, 1)))           # e(P, P) != 1 on these curves
+
+
 def test_type_g_chain_and_products(hips):
     H = hips["g149"]
     v = golden("g149_chain64.vec")

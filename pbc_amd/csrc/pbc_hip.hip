@@ -196,7 +196,10 @@ __global__ void __launch_bounds__(kBlock, PBC_DF_WAVES) d_pp_apply_kernel(uint8_
 }
 
 // Type F: one k-term product (k = 1: a single pairing) per lane.  G1 40 B, G2 80 B, GT 240 B.
-__global__ void __launch_bounds__(kBlock, PBC_DF_WAVES) f_prod_pairing_kernel(uint8_t *gt, const uint8_t *g1,
+#ifndef PBC_F_WAVES
+#define PBC_F_WAVES PBC_DF_WAVES
+#endif
+__global__ void __launch_bounds__(kBlock, PBC_F_WAVES) f_prod_pairing_kernel(uint8_t *gt, const uint8_t *g1,
                                                                  const uint8_t *g2, size_t n, int k) {
   size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
   size_t ld = idx < n ? idx : n - 1;

@@ -35,6 +35,14 @@ int pbc_hip_pairing_init_set_buf(pbc_hip_pairing_t **out, const char *param, siz
 /* Replaces pairing_clear (include/pbc_pairing.h:109-116). */
 void pbc_hip_pairing_clear(pbc_hip_pairing_t *p);
 
+/* Multi-GPU for the host-buffer entry points (element_pairing_batch, element_prod_pairing_batch):
+ * the batch is range-split over `devices` (HIP ordinals; a device may be listed more than once),
+ * every unit is independent, so there is no exchange between devices and each result is copied
+ * straight into the caller's buffer.  n = 0 returns to the single device the object was created
+ * on.  The *_dev entry points always run on the device that owns the caller's pointers. */
+int pbc_hip_pairing_use_devices(pbc_hip_pairing_t *p, const int *devices, int n);
+/* Number of visible HIP devices (hipGetDeviceCount; 0 when there is none). */
+int pbc_hip_device_count(void);
 /* 'a', 'd', 'f', 'g', or '1' for a1 (the "type" key, ecc/param.c:172-205). */
 int pbc_hip_pairing_type(const pbc_hip_pairing_t *p);
 /* Replace pairing_length_in_bytes_{G1,G2,GT} (include/pbc_pairing.h:183-238). */

@@ -13,6 +13,8 @@ static struct {
   void (*clear)(pbc_hip_pairing_t *);
   int (*len1)(const pbc_hip_pairing_t *), (*len2)(const pbc_hip_pairing_t *), (*lenT)(const pbc_hip_pairing_t *);
   int (*type)(const pbc_hip_pairing_t *);
+  int (*use_devices)(pbc_hip_pairing_t *, const int *, int);
+  int (*device_count)(void);
   int (*pair)(pbc_hip_pairing_t *, unsigned char *, const unsigned char *, const unsigned char *, size_t);
   int (*prod)(pbc_hip_pairing_t *, unsigned char *, const unsigned char *, const unsigned char *, size_t, int);
   const char *(*err)(void);
@@ -51,6 +53,7 @@ static int load_lib(void) {
   SYM(init, "pbc_hip_pairing_init_set_buf"); SYM(clear, "pbc_hip_pairing_clear");
   SYM(len1, "pbc_hip_pairing_length_in_bytes_G1"); SYM(len2, "pbc_hip_pairing_length_in_bytes_G2");
   SYM(lenT, "pbc_hip_pairing_length_in_bytes_GT"); SYM(type, "pbc_hip_pairing_type");
+  SYM(use_devices, "pbc_hip_pairing_use_devices"); SYM(device_count, "pbc_hip_device_count");
   SYM(pair, "pbc_hip_element_pairing_batch"); SYM(prod, "pbc_hip_element_prod_pairing_batch");
   SYM(err, "pbc_hip_last_error");
   SYM(pp_init, "pbc_hip_pairing_pp_init"); SYM(pp_clear, "pbc_hip_pairing_pp_clear");
@@ -212,6 +215,14 @@ int pbc_hip_attach(pairing_t pairing, const char *param, size_t len) {
   if (L.init(&g, param, len)) { fprintf(stderr, "pbc_hip: %s\n", L.err()); return 1; }
   if (L.len1(g) != pairing_length_in_bytes_G1(pairing) || L.len2(g) != pairing_length_in_bytes_G2(pairing) ||
       L.lenT(g) != pairing_length_in_bytes_GT(pairing)) { L.clear(g); return 1; }
+  {
+    /* PBC_HIP_DEVICES=all (or a comma list of ordinals): batches are range-split over these GPUs */
+    const char *e = getenv("PBC_HIP_DEVICES");
+    int devs[16], nd = 0;
+    if (e && !strcmp(e, "all")) { int c = L.device_count(); for (nd = 0; nd < c && nd < 16; nd++) devs[nd] = nd; }
+    else if (e) { for (const char *q = e; *q && nd < 16; ) { devs[nd++] = atoi(q); q = strchr(q, ','); if (!q) break; q++; } }
+    if (nd > 0 && L.use_devices(g, devs, nd)) { fprintf(stderr, "pbc_hip: %s\n", L.err()); L.clear(g); return 1; }
+  }
   a->pairing = pairing; a->gpu = g; a->cpu_map = pairing->map; a->cpu_prod = pairing->prod_pairings;
   a->cpu_pp_init = pairing->pp_init; a->cpu_pp_clear = pairing->pp_clear; a->cpu_pp_apply = pairing->pp_apply;
   pairing->map = hip_map;

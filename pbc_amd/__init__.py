@@ -65,6 +65,7 @@ def lib():
         L.pbc_hip_pairing_length_in_bytes_Zr.argtypes = [vp]
         L.pbc_hip_element_mul_zn_batch.argtypes = [vp, ci, vp, vp, vp, sz]
         L.pbc_hip_pairing_length_in_bytes_compressed_G1.argtypes = [vp]
+        L.pbc_hip_pairing_use_devices.argtypes = [vp, ctypes.POINTER(ctypes.c_int), ci]
         L.pbc_hip_element_to_bytes_compressed_batch.argtypes = [vp, ci, vp, vp, sz]
         L.pbc_hip_element_from_bytes_compressed_batch.argtypes = [vp, ci, vp, vp, sz]
         L.pbc_hip_element_from_hash_batch.argtypes = [vp, ci, vp, vp, ci, sz]
@@ -95,7 +96,7 @@ EXPORTS = (
     "pbc_hip_pairing_pp_apply_batch_dev", "pbc_hip_pairing_length_in_bytes_Zr",
     "pbc_hip_element_from_hash_batch", "pbc_hip_element_mul_zn_batch", "pbc_hip_element_mul_GT_batch", "pbc_hip_element_pow_zn_GT_batch",
     "pbc_hip_pairing_length_in_bytes_compressed_G1", "pbc_hip_element_to_bytes_compressed_batch",
-    "pbc_hip_element_from_bytes_compressed_batch",
+    "pbc_hip_element_from_bytes_compressed_batch", "pbc_hip_pairing_use_devices", "pbc_hip_device_count",
 )
 
 
@@ -264,6 +265,12 @@ class Pairing:
         if lib().pbc_hip_fq_op_batch(self._h, op, _np_ptr(c), _np_ptr(a), _np_ptr(b), n):
             raise PbcHipError("fq_op: " + _err())
         return c
+
+    def use_devices(self, devices):
+        """range-split host-buffer batches over these HIP ordinals ([] = back to the creation device)"""
+        arr = (ctypes.c_int * len(devices))(*devices)
+        if lib().pbc_hip_pairing_use_devices(self._h, arr, len(devices)):
+            raise PbcHipError("use_devices: " + _err())
 
     def algorithmic_macs_per_unit(self, k=1):
         return lib().pbc_hip_algorithmic_macs_per_unit(self._h, k)

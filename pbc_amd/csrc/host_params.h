@@ -35,6 +35,8 @@ static int fail(const char *fmt, ...) {
 struct pbc_hip_pairing_s {
   int type;
   int device;
+  int ndev;                  // host-buffer calls: devices the batch is range-split over (0 = just `device`)
+  int devs[16];
   int nlimb;                 // 32-bit limbs of F_q
   int deg;                   // types d / g: degree d = k/2 of F_q^d (3 / 5)
   int len_fq, len1, len2, lenT;

@@ -572,6 +572,21 @@ extern "C" int pbc_hip_pairing_init_set_buf(pbc_hip_pairing_t **out, const char 
 }
 extern "C" void pbc_hip_pairing_clear(pbc_hip_pairing_t *p) { delete p; }
 extern "C" int pbc_hip_pairing_type(const pbc_hip_pairing_t *p) { return p->type; }
+extern "C" int pbc_hip_device_count(void) {
+  int count = 0;
+  return hipGetDeviceCount(&count) == hipSuccess ? count : 0;
+}
+extern "C" int pbc_hip_pairing_use_devices(pbc_hip_pairing_t *P, const int *devices, int n) {
+  if (!P) return fail("null pairing");
+  if (n < 0 || n > 16 || (n > 0 && !devices)) return fail("use_devices: 0..16 devices");
+  int count = 0;
+  if (n > 0 && hipGetDeviceCount(&count) != hipSuccess) return fail("no HIP device: libpbc_hip has no CPU fallback");
+  for (int i = 0; i < n; i++)
+    if (devices[i] < 0 || devices[i] >= count) return fail("use_devices: device %d is not visible (%d devices)", devices[i], count);
+  for (int i = 0; i < n; i++) P->devs[i] = devices[i];
+  P->ndev = n;
+  return 0;
+}
 extern "C" int pbc_hip_pairing_length_in_bytes_G1(const pbc_hip_pairing_t *p) { return p->len1; }
 extern "C" int pbc_hip_pairing_length_in_bytes_G2(const pbc_hip_pairing_t *p) { return p->len2; }
 extern "C" int pbc_hip_pairing_length_in_bytes_GT(const pbc_hip_pairing_t *p) { return p->lenT; }
@@ -707,55 +722,73 @@ extern "C" int pbc_hip_element_pairing_batch_dev(pbc_hip_pairing_t *P, void *d_g
 // ring of streams, so the PCIe copies of one chunk overlap the arithmetic of its neighbours
 // ("chunked to overlap copies with compute").  Pinned caller buffers overlap fully;
 // pageable ones still work (the runtime stages them).
+// Host-buffer path.  The batch is cut into chunks of one chip residency; chunks travel
+// H2D -> kernel -> D2H on a ring of three streams PER DEVICE, so the copies of one chunk hide behind
+// the arithmetic of its neighbours, and consecutive chunks go to the devices of the object's device
+// set in turn (pbc_hip_pairing_use_devices: range split, no exchange between devices, results land
+// directly in the caller's buffer).
 static int run_host(pbc_hip_pairing_s *P, uint8_t *gt, const uint8_t *g1, const uint8_t *g2, size_t n,
                     int k) {
   if (P->device < 0) return fail("no HIP device: libpbc_hip has no CPU fallback");
   if (!n) return 0;
-  constexpr int SLOTS = 3;
+  constexpr int SLOTS = 3, MAXDEV = 16;
+  const int ndev = P->ndev > 0 ? P->ndev : 1;
+  const int *devs = P->ndev > 0 ? P->devs : &P->device;
   size_t chunk = (size_t) 131072 / (size_t) k;       // one full residency of the chip per chunk
   if (chunk < 1024) chunk = 1024;
   if (chunk > n) chunk = n;
   const size_t u1 = (size_t) k * P->len1, u2 = (size_t) k * P->len2, ut = (size_t) P->lenT;
-  void *d1[SLOTS] = {nullptr}, *d2[SLOTS] = {nullptr}, *dt[SLOTS] = {nullptr};
-  hipStream_t st[SLOTS] = {nullptr};
-  HIP_TRY(hipSetDevice(P->device));
+  const size_t nchunks = (n + chunk - 1) / chunk;
+  void *d1[MAXDEV][SLOTS] = {{nullptr}}, *d2[MAXDEV][SLOTS] = {{nullptr}}, *dt[MAXDEV][SLOTS] = {{nullptr}};
+  hipStream_t st[MAXDEV][SLOTS] = {{nullptr}};
   int rc = 0;
-  int slots = (int) ((n + chunk - 1) / chunk);
-  if (slots > SLOTS) slots = SLOTS;
-  for (int i = 0; i < slots && !rc; i++) {
-    if (hipStreamCreate(&st[i]) != hipSuccess || hipMalloc(&d1[i], chunk * u1) != hipSuccess ||
-        hipMalloc(&d2[i], chunk * u2) != hipSuccess || hipMalloc(&dt[i], chunk * ut) != hipSuccess)
-      rc = fail("device allocation failed for a chunk of %zu units", chunk);
+  int used = 0;                                      // devices that receive at least one chunk
+  for (int d = 0; d < ndev && !rc && (size_t) d < nchunks; d++, used++) {
+    if (hipSetDevice(devs[d]) != hipSuccess) { rc = fail("hipSetDevice(%d) failed", devs[d]); break; }
+    size_t mine = (nchunks - (size_t) d + (size_t) ndev - 1) / (size_t) ndev;   // chunks d, d + ndev, ...
+    int slots = mine < (size_t) SLOTS ? (int) mine : SLOTS;
+    for (int i = 0; i < slots && !rc; i++) {
+      if (hipStreamCreate(&st[d][i]) != hipSuccess || hipMalloc(&d1[d][i], chunk * u1) != hipSuccess ||
+          hipMalloc(&d2[d][i], chunk * u2) != hipSuccess || hipMalloc(&dt[d][i], chunk * ut) != hipSuccess)
+        rc = fail("device allocation failed for a chunk of %zu units on device %d", chunk, devs[d]);
+    }
+    // constants once per device, before any chunk
+    if (!rc && upload_constants(P, st[d][0])) rc = 1;
+    if (!rc && hipStreamSynchronize(st[d][0]) != hipSuccess) rc = fail("constant upload failed on device %d", devs[d]);
   }
-  // constants once, before any chunk
-  if (!rc && upload_constants(P, st[0])) rc = 1;
-  if (!rc && hipStreamSynchronize(st[0]) != hipSuccess) rc = fail("constant upload failed");
   size_t idx = 0;
   for (size_t off = 0; off < n && !rc; off += chunk, idx++) {
-    const int sl = (int) (idx % (size_t) slots);
+    const int d = (int) (idx % (size_t) ndev);
+    const size_t round = idx / (size_t) ndev;
+    int slots = 0;
+    while (slots < SLOTS && st[d][slots]) slots++;
+    const int sl = (int) (round % (size_t) slots);
     const size_t m = n - off < chunk ? n - off : chunk;
-    hipStream_t s = st[sl];
-    if (hipMemcpyAsync(d1[sl], g1 + off * u1, m * u1, hipMemcpyHostToDevice, s) != hipSuccess ||
-        hipMemcpyAsync(d2[sl], g2 + off * u2, m * u2, hipMemcpyHostToDevice, s) != hipSuccess) {
+    hipStream_t s = st[d][sl];
+    if (hipSetDevice(devs[d]) != hipSuccess) { rc = fail("hipSetDevice(%d) failed", devs[d]); break; }
+    if (hipMemcpyAsync(d1[d][sl], g1 + off * u1, m * u1, hipMemcpyHostToDevice, s) != hipSuccess ||
+        hipMemcpyAsync(d2[d][sl], g2 + off * u2, m * u2, hipMemcpyHostToDevice, s) != hipSuccess) {
       rc = fail("H2D copy failed");
       break;
     }
-    rc = launch_prod(P, dt[sl], d1[sl], d2[sl], m, k, s, false);
+    rc = launch_prod(P, dt[d][sl], d1[d][sl], d2[d][sl], m, k, s, false);
     if (rc) break;
-    if (hipMemcpyAsync(gt + off * ut, dt[sl], m * ut, hipMemcpyDeviceToHost, s) != hipSuccess) rc = fail("D2H copy failed");
+    if (hipMemcpyAsync(gt + off * ut, dt[d][sl], m * ut, hipMemcpyDeviceToHost, s) != hipSuccess) rc = fail("D2H copy failed");
   }
-  for (int i = 0; i < slots; i++) {
-    if (st[i]) {
-      hipError_t e = hipStreamSynchronize(st[i]);
-      if (e != hipSuccess && !rc) rc = fail("kernel failed: %s", hipGetErrorString(e));
+  for (int d = 0; d < used; d++) {
+    (void) hipSetDevice(devs[d]);
+    for (int i = 0; i < SLOTS; i++) {
+      if (st[d][i]) {
+        hipError_t e = hipStreamSynchronize(st[d][i]);
+        if (e != hipSuccess && !rc) rc = fail("kernel failed on device %d: %s", devs[d], hipGetErrorString(e));
+      }
+      if (d1[d][i]) (void) hipFree(d1[d][i]);
+      if (d2[d][i]) (void) hipFree(d2[d][i]);
+      if (dt[d][i]) (void) hipFree(dt[d][i]);
+      if (st[d][i]) (void) hipStreamDestroy(st[d][i]);
     }
   }
-  for (int i = 0; i < SLOTS; i++) {
-    if (d1[i]) (void) hipFree(d1[i]);
-    if (d2[i]) (void) hipFree(d2[i]);
-    if (dt[i]) (void) hipFree(dt[i]);
-    if (st[i]) (void) hipStreamDestroy(st[i]);
-  }
+  (void) hipSetDevice(P->device);
   return rc;
 }
 

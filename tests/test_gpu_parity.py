@@ -445,6 +445,34 @@ def test_symmetric_types_same_point_in_both_arguments(hips, oracles, key, name):
     assert not np.array_equal(ePP, np.tile(one, (n, 1)))           # e(P, P) != 1 on these curves
 
 
+def test_host_batches_range_split_over_a_device_set(hips):
+    """pbc_hip_pairing_use_devices: chunks of a host batch go to the devices of the set in turn (here the
+    one GPU of the box listed once, twice and three times -- the multi-device code path, more chunks
+    than devices, a ragged last chunk); results are identical to the single-device call."""
+    import pbc_amd
+    from conftest import _param
+    v = golden("d_chain256.vec")
+    n = 3 * 131072 + 777                                   # 4 chunks
+    idx = np.arange(n)
+    g1, g2 = v.g1[(idx // v.n) % v.n], v.g2[idx % v.n]
+    H = pbc_amd.Pairing(_param("d159"))
+    want = H.element_pairing(g1, g2)
+    assert np.array_equal(want[(np.arange(v.n) * (v.n + 1))], v.gt)
+    for devs in ([0], [0, 0], [0, 0, 0]):
+        H.use_devices(devs)
+        assert np.array_equal(H.element_pairing(g1, g2), want), devs
+    H.use_devices([0, 0])
+    k = 4
+    m = 40000
+    assert np.array_equal(H.element_prod_pairing(g1[:m * k], g2[:m * k], k),
+                          hips["d"].element_prod_pairing(g1[:m * k], g2[:m * k], k))
+    H.use_devices([])
+    assert np.array_equal(H.element_pairing(g1[:1000], g2[:1000]), want[:1000])
+    with pytest.raises(pbc_amd.PbcHipError):
+        H.use_devices([99])
+    H.clear()
+
+
 def test_type_g_chain_and_products(hips):
     H = hips["g149"]
     v = golden("g149_chain64.vec")

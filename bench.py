@@ -136,6 +136,7 @@ WORKLOADS = {
     "a-prod16": ("a", "a_chain1024.vec", 16, 18, "Type A (a.param) element_prod_pairing, 16 terms"),
     "a-pp": ("a", "a_chain1024.vec", 1, 20, "Type A (a.param) pairing_pp_apply, fixed first argument"),
     "d-pp": ("d159", "d_chain256.vec", 1, 18, "Type D (d159.param) pairing_pp_apply, fixed first argument"),
+    "a1-pp": ("a1", "a1_chain8.vec", 1, 16, "Type A1 (a1.param) pairing_pp_apply, fixed first argument"),
     "g-pp": ("g149", "g149_chain64.vec", 1, 17, "Type G (g149.param) pairing_pp_apply, fixed first argument"),
 }
 

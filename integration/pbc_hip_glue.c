@@ -228,9 +228,9 @@ int pbc_hip_attach(pairing_t pairing, const char *param, size_t len) {
   pairing->map = hip_map;
   pairing->prod_pairings = hip_prod;
   {
-    /* preprocessed pairings exist on the GPU for types a, d and g (the "type" key of the text) */
+    /* preprocessed pairings exist on the GPU for types a, a1 ('1'), d and g */
     int t = L.type(g);
-    if (t == 'a' || t == 'd' || t == 'g') {
+    if (t == 'a' || t == '1' || t == 'd' || t == 'g') {
       pairing->pp_init = hip_pp_init; pairing->pp_clear = hip_pp_clear; pairing->pp_apply = hip_pp_apply;
     } else {
       pairing->pp_init = plain_pp_init; pairing->pp_clear = plain_pp_clear; pairing->pp_apply = plain_pp_apply;

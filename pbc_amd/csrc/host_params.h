@@ -226,6 +226,9 @@ static int init_type_a1(pbc_hip_pairing_s *P, const char *txt, size_t len) {
   P->fq_muls_single = 25.0 * (n.bits() - 1) + 23.0 * ones;
   P->fq_muls_prod_a = P->fq_muls_single;
   P->fq_muls_prod_b = 0.0;
+  // a1_pairing_pp_apply (a_param.c:1728-1818): per step an F_p^2 square and product (5) plus the
+  // evaluation of the stored line (2), per set bit another evaluation and product (5)
+  P->fq_muls_pp = 7.0 * (n.bits() - 1) + 5.0 * ones;
   return fill_hash_consts(P, p, &l);     // cofactor phikonr = l (a_param.c:2250)
 }
 

@@ -294,12 +294,75 @@ PBC_DEV void a_pp_store(uint32_t *tab, int idx, const fp<N> &cA, const fp<N> &cB
     tab[(idx * 3 + 2) * N + k] = cC.v[k];
   }
 }
+// line coefficients of the tangent at V, then V <- 2V
+template <int N>
+PBC_DEV void a_pp_dbl(jac<N> &V, fp<N> &cA, fp<N> &cB, fp<N> &cC) {
+  fp<N> XX, YY, M, t0, t1, S, Z3;
+  fp_sqr<N>(XX, V.X);
+  fp_sqr<N>(YY, V.Y);
+  fp_sqr<N>(t0, V.ZZ);
+  fp_dbl<N>(M, XX);
+  fp_add<N>(M, M, XX);
+  fp_add<N>(M, M, t0);
+  fp_mul<N>(cA, M, V.ZZ);
+  fp_mul<N>(Z3, V.Y, V.Z);
+  fp_dbl<N>(Z3, Z3);
+  fp_mul<N>(cB, Z3, V.ZZ);
+  fp_mul<N>(cC, M, V.X);
+  fp_dbl<N>(t1, YY);
+  fp_sub<N>(cC, cC, t1);
+  fp_mul<N>(S, V.X, YY);
+  fp_dbl<N>(S, S);
+  fp_dbl<N>(S, S);
+  fp_sqr<N>(t0, YY);
+  fp_dbl<N>(t0, t0);
+  fp_dbl<N>(t0, t0);
+  fp_dbl<N>(t0, t0);
+  fp_sqr<N>(V.X, M);
+  fp_dbl<N>(t1, S);
+  fp_sub<N>(V.X, V.X, t1);
+  fp_sub<N>(t1, S, V.X);
+  fp_mul<N>(t1, M, t1);
+  fp_sub<N>(V.Y, t1, t0);
+  V.Z = Z3;
+  fp_sqr<N>(V.ZZ, Z3);
+}
+// line coefficients of the chord through V and the affine (x2, y2), then V <- V + (x2, y2)
+template <int N>
+PBC_DEV void a_pp_add(jac<N> &V, const fp<N> &x2, const fp<N> &y2, fp<N> &cA, fp<N> &cB, fp<N> &cC) {
+  fp<N> H, R, HH, HHH, t0, t1, Z3;
+  fp_mul<N>(H, x2, V.ZZ);
+  fp_sub<N>(H, H, V.X);
+  fp_mul<N>(t0, V.Z, V.ZZ);
+  fp_mul<N>(R, y2, t0);
+  fp_sub<N>(R, R, V.Y);
+  fp_mul<N>(Z3, V.Z, H);
+  fp_mul<N>(cC, R, x2);
+  fp_mul<N>(t0, Z3, y2);
+  fp_sub<N>(cC, cC, t0);
+  cA = R;
+  cB = Z3;
+  fp_sqr<N>(HH, H);
+  fp_mul<N>(HHH, HH, H);
+  fp_mul<N>(t0, V.X, HH);
+  fp_sqr<N>(t1, R);
+  fp_sub<N>(t1, t1, HHH);
+  fp_sub<N>(t1, t1, t0);
+  fp_sub<N>(t1, t1, t0);
+  fp_sub<N>(t0, t0, t1);
+  fp_mul<N>(t0, R, t0);
+  fp_mul<N>(HHH, V.Y, HHH);
+  fp_sub<N>(V.Y, t0, HHH);
+  V.X = t1;
+  V.Z = Z3;
+  fp_sqr<N>(V.ZZ, Z3);
+}
 // one lane: returns false when g1 deserialises to O (then every pp_apply result is 1,
 // pairing_pp_init include/pbc_pairing.h:54-61)
 template <int N>
 PBC_DEV bool a_pp_init_lane(uint32_t *tab, const uint8_t *g1) {
-  constexpr int NB = 4 * N;
-  fp<N> one, x2, y2;
+  const int NB = fq_bytes<N>();
+  fp<N> one, x2, y2, cA, cB, cC;
   jac<N> V;
   fp_set<N>(one, fpk<N>().one);
   fp_load_be<N>(x2, g1);
@@ -308,63 +371,13 @@ PBC_DEV bool a_pp_init_lane(uint32_t *tab, const uint8_t *g1) {
   V.X = x2; V.Y = y2; V.Z = one; V.ZZ = one;
   int slot = 0;
   for (int i = c_a.exp2 - 1; i >= 0; i--, slot++) {
-    fp<N> XX, YY, M, t0, t1, S, Z3, cA, cB, cC;
-    fp_sqr<N>(XX, V.X);
-    fp_sqr<N>(YY, V.Y);
-    fp_sqr<N>(t0, V.ZZ);
-    fp_dbl<N>(M, XX);
-    fp_add<N>(M, M, XX);
-    fp_add<N>(M, M, t0);
-    fp_mul<N>(cA, M, V.ZZ);
-    fp_mul<N>(Z3, V.Y, V.Z);
-    fp_dbl<N>(Z3, Z3);
-    fp_mul<N>(cB, Z3, V.ZZ);
-    fp_mul<N>(cC, M, V.X);
-    fp_dbl<N>(t1, YY);
-    fp_sub<N>(cC, cC, t1);
+    a_pp_dbl<N>(V, cA, cB, cC);
     a_pp_store<N>(tab, slot, cA, cB, cC);
-    fp_mul<N>(S, V.X, YY);
-    fp_dbl<N>(S, S);
-    fp_dbl<N>(S, S);
-    fp_sqr<N>(t0, YY);
-    fp_dbl<N>(t0, t0);
-    fp_dbl<N>(t0, t0);
-    fp_dbl<N>(t0, t0);
-    fp_sqr<N>(V.X, M);
-    fp_dbl<N>(t1, S);
-    fp_sub<N>(V.X, V.X, t1);
-    fp_sub<N>(t1, S, V.X);
-    fp_mul<N>(t1, M, t1);
-    fp_sub<N>(V.Y, t1, t0);
-    V.Z = Z3;
-    fp_sqr<N>(V.ZZ, Z3);
     if (i == c_a.exp1) {
-      fp<N> yy = y2, H, R, HH, HHH, cC2;
+      fp<N> yy = y2;
       if (c_a.sign1 < 0) fp_neg<N>(yy, yy);
-      fp_mul<N>(H, x2, V.ZZ);
-      fp_sub<N>(H, H, V.X);
-      fp_mul<N>(t0, V.Z, V.ZZ);
-      fp_mul<N>(R, yy, t0);
-      fp_sub<N>(R, R, V.Y);
-      fp_mul<N>(Z3, V.Z, H);
-      fp_mul<N>(cC2, R, x2);
-      fp_mul<N>(t0, Z3, yy);
-      fp_sub<N>(cC2, cC2, t0);
-      a_pp_store<N>(tab, c_a.exp2, R, Z3, cC2);
-      fp_sqr<N>(HH, H);
-      fp_mul<N>(HHH, HH, H);
-      fp_mul<N>(t0, V.X, HH);
-      fp_sqr<N>(t1, R);
-      fp_sub<N>(t1, t1, HHH);
-      fp_sub<N>(t1, t1, t0);
-      fp_sub<N>(t1, t1, t0);
-      fp_sub<N>(t0, t0, t1);
-      fp_mul<N>(t0, R, t0);
-      fp_mul<N>(HHH, V.Y, HHH);
-      fp_sub<N>(V.Y, t0, HHH);
-      V.X = t1;
-      V.Z = Z3;
-      fp_sqr<N>(V.ZZ, Z3);
+      a_pp_add<N>(V, x2, yy, cA, cB, cC);
+      a_pp_store<N>(tab, c_a.exp2, cA, cB, cC);
     }
   }
   return valid;
@@ -494,6 +507,50 @@ PBC_DEV void a1_prod_pairing_lane(uint8_t *gt, const uint8_t *g1, const uint8_t 
     fi_mul<N>(F, F, f);
   }
   a_final_exp<N>(out, F);
+  a_store_gt<N>(gt, out, valid);
+}
+
+// pairing_pp for type a1 (a1_pairing_pp_init a_param.c:1632-1726, a1_pairing_pp_apply :1728-1818):
+// one table entry per doubling and per addition of the plain double-and-add loop over n, in loop
+// order; [steps][3][N] words.
+template <int N>
+PBC_DEV bool a1_pp_init_lane(uint32_t *tab, const uint8_t *g1) {
+  const int NB = fq_bytes<N>();
+  fp<N> one, x2, y2, cA, cB, cC;
+  jac<N> V;
+  fp_set<N>(one, fpk<N>().one);
+  fp_load_be<N>(x2, g1);
+  fp_load_be<N>(y2, g1 + NB);
+  bool valid = a_on_curve<N>(x2, y2);
+  V.X = x2; V.Y = y2; V.Z = one; V.ZZ = one;
+  int slot = 0;
+  for (int i = c_a.rbits - 2; i >= 0; i--) {
+    a_pp_dbl<N>(V, cA, cB, cC);
+    a_pp_store<N>(tab, slot++, cA, cB, cC);
+    if (i > 0 && ((c_a.r[i >> 5] >> (i & 31)) & 1)) {
+      a_pp_add<N>(V, x2, y2, cA, cB, cC);
+      a_pp_store<N>(tab, slot++, cA, cB, cC);
+    }
+  }
+  return valid;
+}
+template <int N>
+PBC_DEV void a1_pp_apply_lane(uint8_t *gt, const uint32_t *tab, bool p_valid, const uint8_t *g2) {
+  const int NB = fq_bytes<N>();
+  fp<N> Qx, Qy;
+  fp2<N> f, out;
+  fp_load_be<N>(Qx, g2);
+  fp_load_be<N>(Qy, g2 + NB);
+  bool valid = (int) p_valid & (int) a_on_curve<N>(Qx, Qy);
+  fp_set<N>(f.x, fpk<N>().one);
+  fp_sub<N>(f.y, f.x, f.x);
+  int slot = 0;
+  for (int i = c_a.rbits - 2; i >= 0; i--) {
+    fi_sqr<N>(f, f);
+    a_pp_line<N>(f, tab, slot++, Qx, Qy);
+    if (i > 0 && ((c_a.r[i >> 5] >> (i & 31)) & 1)) a_pp_line<N>(f, tab, slot++, Qx, Qy);
+  }
+  a_final_exp<N>(out, f);
   a_store_gt<N>(gt, out, valid);
 }
 

@@ -169,6 +169,32 @@ __global__ void __launch_bounds__(kBlock, PBC_DF_WAVES) d_prod_pairing_kernel(ui
   }
 }
 
+// pairing_pp for type a1
+template <int N>
+__global__ void a1_pp_init_kernel(uint32_t *tab, uint32_t *valid, const uint8_t *g1) {
+  if (threadIdx.x || blockIdx.x) return;
+  *valid = a1_pp_init_lane<N>(tab, g1) ? 1u : 0u;
+}
+template <int N>
+__global__ void __launch_bounds__(kBlock, PBC_A1_WAVES) a1_pp_apply_kernel(uint8_t *gt, const uint32_t *__restrict__ tab,
+                                                                           const uint32_t *__restrict__ valid,
+                                                                           const uint8_t *g2, size_t n) {
+  size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
+  size_t ld = idx < n ? idx : n - 1;
+  const int L = 2 * fq_bytes<N>();
+  __attribute__((aligned(4))) uint8_t out[8 * N];
+  a1_pp_apply_lane<N>(out, tab, *valid != 0, g2 + ld * L);
+  if (idx < n) {
+    if ((L & 3) == 0) {
+      uint32_t *dst = reinterpret_cast<uint32_t *>(gt + idx * L);
+      const uint32_t *src = reinterpret_cast<const uint32_t *>(out);
+      for (int i = 0; i < L / 4; i++) dst[i] = src[i];
+    } else {
+      for (int i = 0; i < L; i++) gt[idx * L + i] = out[i];
+    }
+  }
+}
+
 // pairing_pp for types d / g: single-lane table derivation, then one second argument per lane
 template <int N, int DEG>
 __global__ void d_pp_init_kernel(uint32_t *tab, uint32_t *valid, const uint8_t *g1) {
@@ -991,9 +1017,9 @@ struct pbc_hip_pp_s {
 extern "C" int pbc_hip_pairing_pp_init(pbc_hip_pp_t **out, pbc_hip_pairing_t *P, const uint8_t *g1) {
   if (!out || !P || !g1) return fail("null argument");
   if (P->device < 0) return fail("no HIP device: libpbc_hip has no CPU fallback");
-  const bool mnt = P->type == 'd' || P->type == 'g';
-  if (P->type != 'a' && !mnt)
-    return fail("pairing_pp is built for types a, d and g (other types: use element_pairing)");
+  const bool mnt = P->type == 'd' || P->type == 'g', a1 = P->type == '1';
+  if (P->type != 'a' && !mnt && !a1)
+    return fail("pairing_pp is built for types a, a1, d and g (other types: use element_pairing)");
   pbc_hip_pp_s *pp = new pbc_hip_pp_s();
   pp->P = P;
   void *dg1 = nullptr;
@@ -1002,6 +1028,11 @@ extern "C" int pbc_hip_pairing_pp_init(pbc_hip_pp_t **out, pbc_hip_pairing_t *P,
     int steps = P->dconst.rbits - 1;
     for (int m = 1; m <= P->dconst.rbits - 2; m++) steps += (P->dconst.r[m >> 5] >> (m & 31)) & 1;
     words = (size_t) steps * 3 * P->nlimb;
+  }
+  if (a1) {
+    int steps = P->a.rbits - 1;
+    for (int m = 1; m <= P->a.rbits - 2; m++) steps += (P->a.r[m >> 5] >> (m & 31)) & 1;
+    words = (size_t) steps * 3 * 33;
   }
   if (hipSetDevice(P->device) != hipSuccess || hipMalloc(&pp->tab, words * 4) != hipSuccess ||
       hipMalloc(&pp->valid, 4) != hipSuccess || hipMalloc(&dg1, P->len1) != hipSuccess ||
@@ -1012,6 +1043,8 @@ extern "C" int pbc_hip_pairing_pp_init(pbc_hip_pp_t **out, pbc_hip_pairing_t *P,
   if (mnt) {
     PBC_DISPATCH_D(P, hipLaunchKernelGGL((d_pp_init_kernel<N, DEG>), dim3(1), dim3(64), 0, 0, pp->tab, pp->valid,
                                          (const uint8_t *) dg1));
+  } else if (a1) {
+    hipLaunchKernelGGL(a1_pp_init_kernel<33>, dim3(1), dim3(64), 0, 0, pp->tab, pp->valid, (const uint8_t *) dg1);
   } else {
     hipLaunchKernelGGL(a_pp_init_kernel<16>, dim3(1), dim3(64), 0, 0, pp->tab, pp->valid, (const uint8_t *) dg1);
   }
@@ -1035,6 +1068,9 @@ extern "C" int pbc_hip_pairing_pp_apply_batch_dev(pbc_hip_pp_t *pp, void *d_gt, 
   unsigned grid = (unsigned) ((n + kBlock - 1) / kBlock);
   if (pp->P->type == 'a') {
     hipLaunchKernelGGL(a_pp_apply_kernel<16>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt, pp->tab, pp->valid,
+                       (const uint8_t *) d_g2, n);
+  } else if (pp->P->type == '1') {
+    hipLaunchKernelGGL(a1_pp_apply_kernel<33>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt, pp->tab, pp->valid,
                        (const uint8_t *) d_g2, n);
   } else {
     PBC_DISPATCH_D(pp->P, hipLaunchKernelGGL((d_pp_apply_kernel<N, DEG>), dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,

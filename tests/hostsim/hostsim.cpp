@@ -114,6 +114,12 @@ int hostsim_pp(void *h, uint8_t *gt, const uint8_t *g1, const uint8_t *g2, size_
     });
     return 0;
   }
+  if (P->type == '1') {
+    static uint32_t tab1[2048 * 3 * 33];
+    bool v = a1_pp_init_lane<33>(tab1, g1);
+    for (size_t u = 0; u < n; u++) a1_pp_apply_lane<33>(gt + u * P->lenT, tab1, v, g2 + u * P->len2);
+    return 0;
+  }
   if (P->type != 'a') return 1;
   bool v = a_pp_init_lane<16>(tab, g1);
   for (size_t u = 0; u < n; u++) a_pp_apply_lane<16>(gt + u * P->lenT, tab, v, g2 + u * P->len2);

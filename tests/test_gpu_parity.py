@@ -340,7 +340,7 @@ def test_pairing_pp_matches_element_pairing(hip_a, oracle_a):
 
 
 @pytest.mark.parametrize("t,name", [("d", "d_chain256.vec"), ("d201", "d201_rand12.vec"), ("d278027-190-181", "d278027-190-181_rand12.vec"),
-                                    ("g149", "g149_chain64.vec")])
+                                    ("g149", "g149_chain64.vec"), ("a1", "a1_chain8.vec")])
 def test_pairing_pp_types_d_g(hips, oracles, t, name):
     """d_pairing_pp_init/apply (d_param.c:794-966), g_pairing_pp_init/apply (g_param.c:619-787)."""
     v = golden(name)
@@ -353,7 +353,8 @@ def test_pairing_pp_types_d_g(hips, oracles, t, name):
         got = pp.apply(Q)
         assert np.array_equal(got, H.element_pairing(np.tile(v.g1[pi], (m, 1)), Q))
         assert np.array_equal(got[pi], v.gt[pi])           # e(P_i, Q_i) from the reference fixture
-        assert np.array_equal(got[:6], oracles[t].pairing_batch(np.tile(v.g1[pi], (6, 1)), Q[:6]))
+        c = 2 if t == "a1" else 6                          # the oracle needs 0.4 s per 1033-bit pairing
+        assert np.array_equal(got[:c], oracles[t].pairing_batch(np.tile(v.g1[pi], (c, 1)), Q[:c]))
         pp.clear()
     bad = v.g1[2].copy()
     bad[1] ^= 8

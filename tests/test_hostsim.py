@@ -67,19 +67,21 @@ def test_pairing_pp_on_host(sims, oracles):
     assert np.array_equal(sims["a"].pp(bad, Q), np.tile(one, (6, 1)))
 
 
-@pytest.mark.parametrize("t,name", [("d", "d_rand32.vec"), ("d201", "d201_rand12.vec"), ("g149", "g149_rand16.vec")])
+@pytest.mark.parametrize("t,name", [("d", "d_rand32.vec"), ("d201", "d201_rand12.vec"), ("g149", "g149_rand16.vec"),
+                                    ("a1", "a1_rand6.vec")])
 def test_pairing_pp_types_d_g_on_host(sims, oracles, t, name):
     """d_pairing_pp_init/apply (d_param.c:794-966), g_pairing_pp_init/apply (g_param.c:619-787): same bytes as
     element_pairing; off-curve arguments give the identity."""
     v = golden(name)
     P = v.g1[1]
-    Q = v.g2[:4].copy()
-    Q[2, -1] ^= 1
-    want = oracles[t].pairing_batch(np.tile(P, (4, 1)), Q)
+    m = 2 if t == "a1" else 4
+    Q = v.g2[:m].copy()
+    Q[m - 1, -1] ^= 1
+    want = oracles[t].pairing_batch(np.tile(P, (m, 1)), Q)
     assert np.array_equal(sims[t].pp(P, Q), want)
     bad = P.copy(); bad[3] ^= 4
     one = np.zeros(sims[t].lenT, np.uint8); one[sims[t].len1 // 2 - 1] = 1
-    assert np.array_equal(sims[t].pp(bad, Q), np.tile(one, (4, 1)))
+    assert np.array_equal(sims[t].pp(bad, Q), np.tile(one, (m, 1)))
 
 
 @pytest.mark.parametrize("t,name", [("a", "a_rand32.vec"), ("d", "d_rand32.vec"), ("f", "f_rand16.vec")]

@@ -447,26 +447,8 @@ static __device__ __noinline__ typename vecN<N>::type fp_mul_fn(typename vecN<N>
   fp_mul_inl<N>(r, a, b);
   return to_vec<N>(r);
 }
-// 16-word operands need 32 argument VGPRs but the ABI has 31 (v31 carries the work-item id):
-// the 32nd word went through the stack, and the callee's entry `s_waitcnt vmcnt(0)` then
-// stalled on that scratch store (~500 cycles per call).  The last word of b travels through
-// LDS instead (one ds_write / ds_read pair, slot = work-item id).
-__shared__ uint32_t g_lds_arg[256];
-static __device__ __noinline__ typename vecN<16>::type fp_mul_fn16(typename vecN<16>::type va,
-                                                                     typename vecN<15>::type vb) {
-  fp<16> a, b, r;
-  from_vec<16>(a, va);
-#pragma unroll
-  for (int i = 0; i < 15; i++) b.v[i] = vb[i];
-  b.v[15] = g_lds_arg[threadIdx.x];
-  fp_mul_inl<16>(r, a, b);
-  return to_vec<16>(r);
-}
 #ifndef PBC_INLINE_MUL
 #define PBC_INLINE_MUL 0    // 1: every product inlined at its call site (experiment)
-#endif
-#ifndef PBC_LDS_ARG
-#define PBC_LDS_ARG 0       // 0: plain ABI call (32nd argument word on the stack)
 #endif
 #ifndef PBC_INLINE_SMALL
 #define PBC_INLINE_SMALL 0  // 1: products of the 160-bit fields are inlined (a call costs more than the
@@ -505,15 +487,9 @@ PBC_DEV void fp_mul(fp<N> &r, const fp<N> &a, const fp<N> &b) {
     fp_mul_inl<N>(r, a, b);
     return;
   }
-  if constexpr (N == 16 && PBC_LDS_ARG) {
-    typename vecN<15>::type vb;
-#pragma unroll
-    for (int i = 0; i < 15; i++) vb[i] = b.v[i];
-    g_lds_arg[threadIdx.x] = b.v[15];
-    from_vec<N>(r, fp_mul_fn16(to_vec<N>(a), vb));
-  } else {
-    from_vec<N>(r, fp_mul_fn<N>(to_vec<N>(a), to_vec<N>(b)));
-  }
+  // 16-word operands need 32 argument VGPRs and the ABI has 31: the last word of b goes through
+  // the stack.  Routing it through LDS instead was measured and changed nothing (profiles/r01_notes.md).
+  from_vec<N>(r, fp_mul_fn<N>(to_vec<N>(a), to_vec<N>(b)));
 #endif
 }
 // The reference has no dedicated Fq squaring (generic_square = mul(a,a), arith/field.c:383);

@@ -267,6 +267,21 @@ static int cmd_compress(int argc, char **argv) {
   return 0;
 }
 
+/* gena <rbits> <qbits> <seed> <out.param>: a fresh type a parameter set (pbc_param_init_a_gen,
+ * ecc/a_param.c:1504-1562) written with pbc_param_out_str */
+static int cmd_gena(int argc, char **argv) {
+  if (argc < 5) { fprintf(stderr, "gena <rbits> <qbits> <seed> <out.param>\n"); return 2; }
+  pbc_param_t par;
+  pbc_random_set_deterministic((unsigned) atoi(argv[3]));
+  pbc_param_init_a_gen(par, atoi(argv[1]), atoi(argv[2]));
+  FILE *fp = fopen(argv[4], "w");
+  if (!fp) { perror(argv[4]); return 2; }
+  pbc_param_out_str(fp, par);
+  fclose(fp);
+  pbc_param_clear(par);
+  return 0;
+}
+
 static int cmd_hash(int argc, char **argv) {
   if (argc < 6) { fprintf(stderr, "hash <param> <n> <hlen> <seed> <out>\n"); return 2; }
   int n = atoi(argv[2]), hlen = atoi(argv[3]);
@@ -301,5 +316,6 @@ int main(int argc, char **argv) {
   if (!strcmp(argv[1], "hash")) return cmd_hash(argc - 1, argv + 1);
   if (!strcmp(argv[1], "gmul")) return cmd_gmul(argc - 1, argv + 1);
   if (!strcmp(argv[1], "compress")) return cmd_compress(argc - 1, argv + 1);
+  if (!strcmp(argv[1], "gena")) return cmd_gena(argc - 1, argv + 1);
   return 2;
 }

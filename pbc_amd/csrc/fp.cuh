@@ -829,13 +829,9 @@ PBC_DEV void fp_inv(fp<N> &r, const fp<N> &a) {
   else from_vec<N>(r, fp_inv_fn<N>(to_vec<N>(a)));
 }
 
-// bytes per F_q coordinate; a compile-time 64 for the type a field so that its kernels keep
-// their 16-byte vector loads and stores
+// bytes per F_q coordinate (fixed_length_in_bytes of the field)
 template <int N>
-PBC_DEV int fq_bytes() {
-  if constexpr (N == 16) return 64;
-  else return (int) fpk<N>().fbytes;
-}
+PBC_DEV int fq_bytes() { return (int) fpk<N>().fbytes; }
 
 // Wire format: fixed-width big-endian canonical residue (fp_from_bytes montfp.c:498-517,
 // fp_to_bytes :487-496 + pbc_mpz_out_raw_n field.c:629-638).  The byte length is

@@ -39,6 +39,7 @@ struct pbc_hip_pairing_s {
   int devs[16];
   int nlimb;                 // 32-bit limbs of F_q
   int deg;                   // types d / g: degree d = k/2 of F_q^d (3 / 5)
+  bool a_generic;            // type a outside the 64-byte fast path: runs on the type a1 kernels
   int len_fq, len1, len2, lenT;
 #define PBC_HOST_FPK(n) FpK<n> k##n;
   PBC_FOR_EACH_N(PBC_HOST_FPK)  // k5, k6, k7, k16: the one matching nlimb is filled
@@ -151,36 +152,59 @@ static int init_type_a(pbc_hip_pairing_s *P, const char *txt, size_t len) {
       !param_int(txt, len, "exp2", exp2) || !param_int(txt, len, "exp1", exp1) ||
       !param_int(txt, len, "sign1", sign1) || !param_int(txt, len, "sign0", sign0))
     return fail("type a: missing q/r/h/exp2/exp1/sign1/sign0");
-  if (fill_fpk<16>(P->k16, q) || q.bits() <= 504)
-    return fail("type a: only 505..512-bit q (64-byte coordinates) is supported by this build (got %d bits)", q.bits());
-  if (h.bits() > 512 || h.is_zero()) return fail("type a: bad cofactor");
-  if ((q.w[0] & 3) != 3) return fail("type a: q must be 3 mod 4");
   if (exp1 <= 0 || exp2 <= exp1) return fail("type a: bad exp1/exp2");
+  if ((q.w[0] & 3) != 3) return fail("type a: q must be 3 mod 4");
+  if (h.is_zero() || h.bits() > 34 * 32) return fail("type a: bad cofactor");
+  {
+    Big qp1 = q;
+    qp1.add_small(1);
+    if (Big::cmp(Big::mul(r, h), qp1) != 0) return fail("type a: q + 1 != r h");
+  }
   memset(&P->a, 0, sizeof P->a);
-  h.to_words(P->a.h, 16);
+  h.to_words(P->a.h, 34);
   P->a.hbits = h.bits();
   {
     Big e = q, four, rem;
     e.add_small(1);
     four.w.push_back(4);
     e = Big::div(e, four, &rem);
-    e.to_words(P->a.sqrt_e, 16);
+    e.to_words(P->a.sqrt_e, 34);
     P->a.sqrt_bits = e.bits();
   }
   P->a.exp2 = exp2;
   P->a.exp1 = exp1;
   P->a.sign1 = sign1;
-  P->nlimb = 16;
   P->len_fq = (q.bits() + 7) / 8;
-  if (P->len_fq != 64) return fail("type a: q must serialise to 64 bytes");
   P->len1 = P->len2 = P->lenT = 2 * P->len_fq;
   P->len_zr = (r.bits() + 7) / 8;
-  P->fq_muls_single = 4392.0;            // SURVEY.md 8d (instrumented reference, a.param)
-  // a_pairings_affine (a_param.c:1283-1383): 41377 F_q products for k = 16;
-  // linear model through (1, 4392-ish) and (16, 41377): 2543 k + 689
-  P->fq_muls_prod_a = 2543.0;
-  P->fq_muls_prod_b = 689.0;
-  P->fq_muls_pp = 1838.0;                // a_pairing_pp_apply (a_param.c:317-360)
+  if (P->len_fq == 64) {
+    // the standard size (pbc_param_init_a_gen(160, 512), a.param): dedicated kernels -- Solinas loop
+    // with its single addition, 16-byte vector loads/stores of the 128-byte records
+    if (fill_fpk<16>(P->k16, q)) return fail("type a: bad q");
+    P->nlimb = 16;
+    P->a_generic = false;
+  } else {
+    // any other size up to 1056 bits: the type a1 kernels (plain double-and-add over the bits of r;
+    // functions with the same divisor up to vertical lines, which the final power removes) on the
+    // 16- or 33-word arithmetic
+    if (q.bits() < 160 || r.bits() > 34 * 32 - 1 || r.bits() < 3)
+      return fail("type a: only 160..1056-bit q is supported by this build (got %d bits)", q.bits());
+    if (q.bits() <= 512 ? fill_fpk<16>(P->k16, q, 160) : fill_fpk<33>(P->k33, q, 513))
+      return fail("type a: only 160..1056-bit q is supported by this build (got %d bits)", q.bits());
+    P->nlimb = q.bits() <= 512 ? 16 : 33;
+    P->a_generic = true;
+    r.to_words(P->a.r, 34);
+    P->a.rbits = r.bits();
+  }
+  // work model: SURVEY.md 8d instrumented the reference on a.param (exp2 = 159, 353-bit h): 3675 F_q
+  // products in a_pairing_proj's Miller loop + 717 in a_tateexp; a_pairings_affine (a_param.c:1283-1383)
+  // 41377 for k = 16 (linear model 2543 k + 689); a_pairing_pp_apply 1838.
+  // Other sizes scale with the loop lengths exp2 and bits(h).
+  const double sm = exp2 / 159.0, sh = h.bits() / 353.0;
+  P->fq_muls_single = 3675.0 * sm + 717.0 * sh;
+  P->fq_muls_prod_a = 2543.0 * sm;
+  P->fq_muls_prod_b = 689.0 * sh;
+  P->fq_muls_pp = 1121.0 * sm + 717.0 * sh;
   if (fill_hash_consts(P, q, &h)) return 1;   // field_init_curve_ab(Eq, a, b, r, h): cofactor h (a_param.c:1453)
   return 0;
 }
@@ -475,7 +499,9 @@ static int init_type_f(pbc_hip_pairing_s *P, const char *txt, size_t len) {
 // E(F_q) coefficients of the pairing's G1 curve for the group-operation kernels (Montgomery words)
 static void fill_curve(const pbc_hip_pairing_s *P, CurveK &C) {
   memset(&C, 0, sizeof C);
-  if (P->type == 'a') {                 // y^2 = x^3 + x (a_param.c:1450-1452)
+  if (P->type == 'a' && P->nlimb == 33) {   // y^2 = x^3 + x (a_param.c:1450-1452), wide q
+    memcpy(C.a, P->k33.one, sizeof P->k33.one);
+  } else if (P->type == 'a') {
     memcpy(C.a, P->k16.one, sizeof P->k16.one);
   } else if (P->type == '1') {          // the same curve over the type a1 field (a_param.c:2247-2251)
     memcpy(C.a, P->k33.one, sizeof P->k33.one);

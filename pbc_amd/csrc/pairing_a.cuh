@@ -51,12 +51,12 @@ PBC_DEV void fi_sqr(fp2<N> &r, const fp2<N> &a) {
 }
 
 struct AConst {          // a_pairing_data (ecc/a_param.c:30-34) + phikonr = h (:1458)
-  uint32_t h[16];        // cofactor h = (q+1)/r, little-endian words (type a1: l, a_param.c:2242-2244)
+  uint32_t h[34];        // cofactor h = (q+1)/r, little-endian words (type a1: l, a_param.c:2242-2244)
   int hbits;
   int exp2, exp1, sign1; // r = 2^exp2 + sign1 2^exp1 + sign0 (sign0 unused by the map)
   uint32_t sqrt_e[34];   // (q + 1)/4: square roots in F_q for q = 3 mod 4 (element_from_hash)
   int sqrt_bits;
-  uint32_t r[34];        // type a1: the group order n, walked bit by bit (a_param.c:1972-1988)
+  uint32_t r[34];        // type a1 (and type a outside the 512-bit fast path): the group order, walked bit by bit
   int rbits;
 };
 __constant__ AConst c_a;

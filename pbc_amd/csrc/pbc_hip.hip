@@ -83,7 +83,7 @@ __global__ void __launch_bounds__(kBlock, PBC_A_WAVES) a_prod_pairing_kernel(uin
 #define PBC_A1_WAVES 1    // 33-word fields: the 512-register budget of one wave per SIMD beats two waves
 #endif                    // with 256 (measured: a1 119 k -> 158 k pairings/s, e 769 k -> 971 k)
 template <int N>
-__global__ void __launch_bounds__(kBlock, PBC_A1_WAVES) a1_prod_pairing_kernel(uint8_t *gt, const uint8_t *g1,
+__global__ void __launch_bounds__(kBlock, N >= 32 ? PBC_A1_WAVES : PBC_A_WAVES) a1_prod_pairing_kernel(uint8_t *gt, const uint8_t *g1,
                                                                                const uint8_t *g2, size_t n, int k) {
   size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
   size_t ld = idx < n ? idx : n - 1;
@@ -176,7 +176,7 @@ __global__ void a1_pp_init_kernel(uint32_t *tab, uint32_t *valid, const uint8_t 
   *valid = a1_pp_init_lane<N>(tab, g1) ? 1u : 0u;
 }
 template <int N>
-__global__ void __launch_bounds__(kBlock, PBC_A1_WAVES) a1_pp_apply_kernel(uint8_t *gt, const uint32_t *__restrict__ tab,
+__global__ void __launch_bounds__(kBlock, N >= 32 ? PBC_A1_WAVES : PBC_A_WAVES) a1_pp_apply_kernel(uint8_t *gt, const uint32_t *__restrict__ tab,
                                                                            const uint32_t *__restrict__ valid,
                                                                            const uint8_t *g2, size_t n) {
   size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
@@ -716,10 +716,13 @@ static int launch_pairing(pbc_hip_pairing_s *P, void *d_gt, const void *d_g1, co
   if (!n) return 0;
   if (upload && upload_constants(P, s)) return 1;
   unsigned grid = (unsigned) ((n + kBlock - 1) / kBlock);
-  if (P->type == 'a') {
+  if (P->type == 'a' && !P->a_generic) {
     hipLaunchKernelGGL(a_pairing_kernel<16>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
                        (const uint8_t *) d_g1, (const uint8_t *) d_g2, n);
-  } else if (P->type == '1') {
+  } else if (P->type == 'a' && P->nlimb == 16) {     // type a of another size: the bit-by-bit kernels
+    hipLaunchKernelGGL(a1_prod_pairing_kernel<16>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
+                       (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, 1);
+  } else if (P->type == '1' || P->type == 'a') {
     hipLaunchKernelGGL(a1_prod_pairing_kernel<33>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
                        (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, 1);
   } else if (P->type == 'e') {
@@ -832,10 +835,13 @@ static int launch_prod(pbc_hip_pairing_s *P, void *d_gt, const void *d_g1, const
   if (!n) return 0;
   if (upload && upload_constants(P, s)) return 1;
   unsigned grid = (unsigned) ((n + kBlock - 1) / kBlock);
-  if (P->type == 'a') {
+  if (P->type == 'a' && !P->a_generic) {
     hipLaunchKernelGGL(a_prod_pairing_kernel<16>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
                        (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k);
-  } else if (P->type == '1') {
+  } else if (P->type == 'a' && P->nlimb == 16) {
+    hipLaunchKernelGGL(a1_prod_pairing_kernel<16>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
+                       (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k);
+  } else if (P->type == '1' || P->type == 'a') {
     hipLaunchKernelGGL(a1_prod_pairing_kernel<33>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
                        (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k);
   } else if (P->type == 'e') {
@@ -1017,7 +1023,7 @@ struct pbc_hip_pp_s {
 extern "C" int pbc_hip_pairing_pp_init(pbc_hip_pp_t **out, pbc_hip_pairing_t *P, const uint8_t *g1) {
   if (!out || !P || !g1) return fail("null argument");
   if (P->device < 0) return fail("no HIP device: libpbc_hip has no CPU fallback");
-  const bool mnt = P->type == 'd' || P->type == 'g', a1 = P->type == '1';
+  const bool mnt = P->type == 'd' || P->type == 'g', a1 = P->type == '1' || (P->type == 'a' && P->a_generic);
   if (P->type != 'a' && !mnt && !a1)
     return fail("pairing_pp is built for types a, a1, d and g (other types: use element_pairing)");
   pbc_hip_pp_s *pp = new pbc_hip_pp_s();
@@ -1032,7 +1038,7 @@ extern "C" int pbc_hip_pairing_pp_init(pbc_hip_pp_t **out, pbc_hip_pairing_t *P,
   if (a1) {
     int steps = P->a.rbits - 1;
     for (int m = 1; m <= P->a.rbits - 2; m++) steps += (P->a.r[m >> 5] >> (m & 31)) & 1;
-    words = (size_t) steps * 3 * 33;
+    words = (size_t) steps * 3 * (size_t) P->nlimb;
   }
   if (hipSetDevice(P->device) != hipSuccess || hipMalloc(&pp->tab, words * 4) != hipSuccess ||
       hipMalloc(&pp->valid, 4) != hipSuccess || hipMalloc(&dg1, P->len1) != hipSuccess ||
@@ -1043,6 +1049,8 @@ extern "C" int pbc_hip_pairing_pp_init(pbc_hip_pp_t **out, pbc_hip_pairing_t *P,
   if (mnt) {
     PBC_DISPATCH_D(P, hipLaunchKernelGGL((d_pp_init_kernel<N, DEG>), dim3(1), dim3(64), 0, 0, pp->tab, pp->valid,
                                          (const uint8_t *) dg1));
+  } else if (a1 && P->nlimb == 16) {
+    hipLaunchKernelGGL(a1_pp_init_kernel<16>, dim3(1), dim3(64), 0, 0, pp->tab, pp->valid, (const uint8_t *) dg1);
   } else if (a1) {
     hipLaunchKernelGGL(a1_pp_init_kernel<33>, dim3(1), dim3(64), 0, 0, pp->tab, pp->valid, (const uint8_t *) dg1);
   } else {
@@ -1066,10 +1074,13 @@ extern "C" int pbc_hip_pairing_pp_apply_batch_dev(pbc_hip_pp_t *pp, void *d_gt, 
   hipStream_t s = (hipStream_t) stream;
   if (upload_constants(pp->P, s)) return 1;
   unsigned grid = (unsigned) ((n + kBlock - 1) / kBlock);
-  if (pp->P->type == 'a') {
+  if (pp->P->type == 'a' && !pp->P->a_generic) {
     hipLaunchKernelGGL(a_pp_apply_kernel<16>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt, pp->tab, pp->valid,
                        (const uint8_t *) d_g2, n);
-  } else if (pp->P->type == '1') {
+  } else if (pp->P->type == 'a' && pp->P->nlimb == 16) {
+    hipLaunchKernelGGL(a1_pp_apply_kernel<16>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt, pp->tab, pp->valid,
+                       (const uint8_t *) d_g2, n);
+  } else if (pp->P->type == '1' || pp->P->type == 'a') {
     hipLaunchKernelGGL(a1_pp_apply_kernel<33>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt, pp->tab, pp->valid,
                        (const uint8_t *) d_g2, n);
   } else {

@@ -94,8 +94,9 @@ int hostsim_prod_pairing(void *h, uint8_t *gt, const uint8_t *g1, const uint8_t 
   for (size_t u = 0; u < n; u++) {
     const uint8_t *a = g1 + u * k * P->len1, *b = g2 + u * k * P->len2;
     uint8_t *o = gt + u * P->lenT;
-    if (P->type == 'a') a_prod_pairing_lane<16>(o, a, b, k, lds, 1);
-    else if (P->type == '1') a1_prod_pairing_lane<33>(o, a, b, k, lds, 1);
+    if (P->type == 'a' && !P->a_generic) a_prod_pairing_lane<16>(o, a, b, k, lds, 1);
+    else if (P->type == 'a' && P->nlimb == 16) a1_prod_pairing_lane<16>(o, a, b, k, lds, 1);
+    else if (P->type == '1' || P->type == 'a') a1_prod_pairing_lane<33>(o, a, b, k, lds, 1);
     else if (P->type == 'e') e_prod_pairing_lane<33>(o, a, b, k, lds, 1);
     else if (P->type == 'd' || P->type == 'g') { HS_DISPATCH_D(P, TypeMNT<N, DEG>::d_prod_pairing_lane(o, a, b, k)); }
     else f_prod_pairing_lane(o, a, b, k);
@@ -114,7 +115,13 @@ int hostsim_pp(void *h, uint8_t *gt, const uint8_t *g1, const uint8_t *g2, size_
     });
     return 0;
   }
-  if (P->type == '1') {
+  if (P->type == 'a' && P->a_generic && P->nlimb == 16) {
+    static uint32_t tab2[1024 * 3 * 16];
+    bool v = a1_pp_init_lane<16>(tab2, g1);
+    for (size_t u = 0; u < n; u++) a1_pp_apply_lane<16>(gt + u * P->lenT, tab2, v, g2 + u * P->len2);
+    return 0;
+  }
+  if (P->type == '1' || (P->type == 'a' && P->a_generic)) {
     static uint32_t tab1[2048 * 3 * 33];
     bool v = a1_pp_init_lane<33>(tab1, g1);
     for (size_t u = 0; u < n; u++) a1_pp_apply_lane<33>(gt + u * P->lenT, tab1, v, g2 + u * P->len2);
@@ -166,8 +173,8 @@ int hostsim_group(void *h, int what, uint8_t *out, const uint8_t *a, const uint8
     } else {
       uint8_t *o = out + i * P->lenT;
       const uint8_t *x = a + i * P->lenT, *y = b + i * (what == 1 ? P->lenT : P->len_zr);
-      if (P->type == 'a') { if (what == 1) a_gt_mul_lane<16>(o, x, y); else a_gt_pow_lane<16>(o, x, y, P->len_zr); }
-      else if (P->type == '1') { if (what == 1) a_gt_mul_lane<33>(o, x, y); else a_gt_pow_lane<33>(o, x, y, P->len_zr); }
+      if (P->type == 'a' && P->nlimb == 16) { if (what == 1) a_gt_mul_lane<16>(o, x, y); else a_gt_pow_lane<16>(o, x, y, P->len_zr); }
+      else if (P->type == '1' || P->type == 'a') { if (what == 1) a_gt_mul_lane<33>(o, x, y); else a_gt_pow_lane<33>(o, x, y, P->len_zr); }
       else if (P->type == 'e') {
         fp<33> u, v;
         fp_load_be<33>(u, x);

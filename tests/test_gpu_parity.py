@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 import oracle
-from conftest import golden, OTHER, FILES_OF, param_value
+from conftest import golden, OTHER, GENERIC_A, FILES_OF, param_value
 
 pytestmark = pytest.mark.gpu
 
@@ -472,6 +472,34 @@ def test_host_batches_range_split_over_a_device_set(hips):
     with pytest.raises(pbc_amd.PbcHipError):
         H.use_devices([99])
     H.clear()
+
+
+@pytest.mark.parametrize("g", GENERIC_A)
+def test_type_a_parameter_sets_of_other_sizes(hips, oracles, g):
+    """pbc_param_init_a_gen output other than (160, 512): 253-, 498-, 765-bit q and r with negative Solinas
+    signs run on the bit-by-bit kernels (16- or 33-word arithmetic): reference vectors, products, cross
+    pairs and group operations against the oracle, preprocessing, bilinearity on the device."""
+    H, O = hips[g], oracles[g]
+    v = golden(FILES_OF[g][0])
+    assert np.array_equal(H.element_pairing(v.g1, v.g2), v.gt)
+    w = golden(FILES_OF[g][2])
+    assert np.array_equal(H.element_prod_pairing(w.g1, w.g2, w.k), w.gt)
+    i, j = np.meshgrid(np.arange(v.n), np.arange(v.n), indexing="ij")
+    g1, g2 = v.g1[i.ravel()], v.g2[j.ravel()]
+    got = H.element_pairing(g1, g2)
+    sel = [1, 7, 20, 35] if g == "a_224_768" else list(range(0, 36, 3))
+    assert np.array_equal(got[sel], O.pairing_batch(g1[sel], g2[sel]))
+    pp = H.pp_init(v.g1[2])
+    assert np.array_equal(pp.apply(v.g2), got.reshape(v.n, v.n, -1)[2])
+    r = param_value(g, "r")
+    zl = H.length_in_bytes_Zr
+    rng = np.random.default_rng(37)
+    Z = np.stack([_be(int.from_bytes(rng.bytes(zl), "big") % r, zl) for _ in range(v.n)])
+    aP = H.element_mul_zn(1, v.g1, Z)
+    assert np.array_equal(aP[:2], O.g_mul(1, v.g1[:2], Z[:2]))
+    assert np.array_equal(H.element_pairing(aP, v.g2), H.element_pow_zn_GT(v.gt, Z))
+    h = H.element_from_hash(1, rng.integers(0, 256, (v.n, 20), dtype=np.uint8))
+    assert not H.element_mul_zn(1, h, np.tile(_be(r, zl + 1)[-zl:] if False else _be(r % (1 << (8 * zl)), zl), (v.n, 1))).any()
 
 
 def test_type_g_chain_and_products(hips):

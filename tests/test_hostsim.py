@@ -5,7 +5,7 @@ mirror for GPU-less bring-up, not a product path: libpbc_hip.so never contains i
 import numpy as np
 import pytest
 
-from conftest import golden, _param, PARAM_OF, OTHER, FILES_OF, key_of, param_value
+from conftest import golden, _param, PARAM_OF, OTHER, GENERIC_A, FILES_OF, key_of, param_value
 
 hostsim = pytest.importorskip("hostsim")
 
@@ -23,7 +23,8 @@ def sims():
     ("a_kat.vec", 1), ("a_rand32.vec", 6), ("a_edge20.vec", 20), ("a_prod2x8.vec", 4), ("a_prod3x10_edge.vec", 10),
     ("d_rand32.vec", 6), ("d_edge20.vec", 20), ("d_prod16x4.vec", 2), ("d_prod3x10_edge.vec", 10),
     ("f_rand16.vec", 3), ("f_edge10.vec", 10), ("f_prod3x5_edge.vec", 5),
-] + [(name, 2 if d in ("a1", "e") else 4) for d in OTHER for name in FILES_OF[d]] + [("g149_prod4x3.vec", 1)])
+] + [(name, 2 if d in ("a1", "e") else 4) for d in OTHER for name in FILES_OF[d]] + [("g149_prod4x3.vec", 1)]
+  + [(name, 2) for g in GENERIC_A for name in (FILES_OF[g][0], FILES_OF[g][2])])
 def test_kernel_source_on_host_matches_reference(sims, name, count):
     v = golden(name)
     n = min(count, v.n)
@@ -68,7 +69,8 @@ def test_pairing_pp_on_host(sims, oracles):
 
 
 @pytest.mark.parametrize("t,name", [("d", "d_rand32.vec"), ("d201", "d201_rand12.vec"), ("g149", "g149_rand16.vec"),
-                                    ("a1", "a1_rand6.vec")])
+                                    ("a1", "a1_rand6.vec"), ("a_160_256", "a_160_256_rand6.vec"),
+                                    ("a_150_300_mm", "a_150_300_mm_rand6.vec")])
 def test_pairing_pp_types_d_g_on_host(sims, oracles, t, name):
     """d_pairing_pp_init/apply (d_param.c:794-966), g_pairing_pp_init/apply (g_param.c:619-787): same bytes as
     element_pairing; off-curve arguments give the identity."""

@@ -282,6 +282,41 @@ static int cmd_gena(int argc, char **argv) {
   return 0;
 }
 
+/* gena1 <prime bits> <seed> <out.param>: type a1 parameters for n = p1 p2, two random primes of the
+ * given size (pbc_param_init_a1_gen, ecc/a_param.c:2300-2321) */
+static int cmd_gena1(int argc, char **argv) {
+  if (argc < 4) { fprintf(stderr, "gena1 <prime bits> <seed> <out.param>\n"); return 2; }
+  int bits = atoi(argv[1]);
+  pbc_random_set_deterministic((unsigned) atoi(argv[2]));
+  mpz_t p1, p2, n;
+  mpz_init(p1); mpz_init(p2); mpz_init(n);
+  pbc_mpz_randomb(p1, bits); mpz_setbit(p1, bits - 1); mpz_nextprime(p1, p1);
+  pbc_mpz_randomb(p2, bits); mpz_setbit(p2, bits - 1); mpz_nextprime(p2, p2);
+  mpz_mul(n, p1, p2);
+  pbc_param_t par;
+  pbc_param_init_a1_gen(par, n);
+  FILE *fp = fopen(argv[3], "w");
+  if (!fp) { perror(argv[3]); return 2; }
+  pbc_param_out_str(fp, par);
+  fclose(fp);
+  pbc_param_clear(par);
+  mpz_clear(p1); mpz_clear(p2); mpz_clear(n);
+  return 0;
+}
+/* gene <rbits> <qbits> <seed> <out.param>: type e parameters (pbc_param_init_e_gen, ecc/e_param.c:908-1005) */
+static int cmd_gene(int argc, char **argv) {
+  if (argc < 5) { fprintf(stderr, "gene <rbits> <qbits> <seed> <out.param>\n"); return 2; }
+  pbc_param_t par;
+  pbc_random_set_deterministic((unsigned) atoi(argv[3]));
+  pbc_param_init_e_gen(par, atoi(argv[1]), atoi(argv[2]));
+  FILE *fp = fopen(argv[4], "w");
+  if (!fp) { perror(argv[4]); return 2; }
+  pbc_param_out_str(fp, par);
+  fclose(fp);
+  pbc_param_clear(par);
+  return 0;
+}
+
 static int cmd_hash(int argc, char **argv) {
   if (argc < 6) { fprintf(stderr, "hash <param> <n> <hlen> <seed> <out>\n"); return 2; }
   int n = atoi(argv[2]), hlen = atoi(argv[3]);
@@ -317,5 +352,7 @@ int main(int argc, char **argv) {
   if (!strcmp(argv[1], "gmul")) return cmd_gmul(argc - 1, argv + 1);
   if (!strcmp(argv[1], "compress")) return cmd_compress(argc - 1, argv + 1);
   if (!strcmp(argv[1], "gena")) return cmd_gena(argc - 1, argv + 1);
+  if (!strcmp(argv[1], "gena1")) return cmd_gena1(argc - 1, argv + 1);
+  if (!strcmp(argv[1], "gene")) return cmd_gene(argc - 1, argv + 1);
   return 2;
 }

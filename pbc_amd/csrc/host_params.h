@@ -216,8 +216,9 @@ static int init_type_a1(pbc_hip_pairing_s *P, const char *txt, size_t len) {
   Big p, n, l;
   if (!param_big(txt, len, "p", p) || !param_big(txt, len, "n", n) || !param_big(txt, len, "l", l))
     return fail("type a1: missing p/n/l");
-  if (fill_fpk<33>(P->k33, p))
-    return fail("type a1: only 1025..1056-bit p is supported by this build (got %d bits)", p.bits());
+  // a1.param is 1033 bits (33 words); smaller orders run on the 16-word arithmetic
+  if (p.bits() <= 512 ? fill_fpk<16>(P->k16, p, 160) : fill_fpk<33>(P->k33, p, 513))
+    return fail("type a1: only 160..1056-bit p is supported by this build (got %d bits)", p.bits());
   if ((p.w[0] & 3) != 3) return fail("type a1: p must be 3 mod 4");
   {
     Big pp1 = p;
@@ -238,7 +239,7 @@ static int init_type_a1(pbc_hip_pairing_s *P, const char *txt, size_t len) {
     e.to_words(P->a.sqrt_e, 34);
     P->a.sqrt_bits = e.bits();
   }
-  P->nlimb = 33;
+  P->nlimb = p.bits() <= 512 ? 16 : 33;
   P->len_fq = (p.bits() + 7) / 8;
   P->len1 = P->len2 = P->lenT = 2 * P->len_fq;
   P->len_zr = (n.bits() + 7) / 8;
@@ -264,8 +265,8 @@ static int init_type_e(pbc_hip_pairing_s *P, const char *txt, size_t len) {
   if (!param_big(txt, len, "q", q) || !param_big(txt, len, "r", r) || !param_big(txt, len, "a", a) ||
       !param_big(txt, len, "b", b))
     return fail("type e: missing q/r/a/b");
-  if (fill_fpk<33>(P->k33, q, 961))
-    return fail("type e: only odd 961..1056-bit q is supported by this build (got %d bits)", q.bits());
+  if (q.bits() <= 512 ? fill_fpk<16>(P->k16, q, 160) : fill_fpk<33>(P->k33, q, 513))
+    return fail("type e: only odd 160..1056-bit q is supported by this build (got %d bits)", q.bits());
   if (Big::cmp(a, q) >= 0 || Big::cmp(b, q) >= 0) return fail("type e: coefficient >= q");
   if (r.bits() > 256 || r.bits() < 3 || !(r.w[0] & 1)) return fail("type e: bad r");
   memset(&P->eraw, 0, sizeof P->eraw);
@@ -297,7 +298,7 @@ static int init_type_e(pbc_hip_pairing_s *P, const char *txt, size_t len) {
   P->econst.phikbits = phik.bits();
   r.to_words(P->econst.r, 8);
   P->econst.rbits = r.bits();
-  P->nlimb = 33;
+  P->nlimb = q.bits() <= 512 ? 16 : 33;
   P->len_fq = (q.bits() + 7) / 8;
   P->len1 = P->len2 = 2 * P->len_fq;
   P->lenT = P->len_fq;
@@ -499,12 +500,10 @@ static int init_type_f(pbc_hip_pairing_s *P, const char *txt, size_t len) {
 // E(F_q) coefficients of the pairing's G1 curve for the group-operation kernels (Montgomery words)
 static void fill_curve(const pbc_hip_pairing_s *P, CurveK &C) {
   memset(&C, 0, sizeof C);
-  if (P->type == 'a' && P->nlimb == 33) {   // y^2 = x^3 + x (a_param.c:1450-1452), wide q
+  if ((P->type == 'a' || P->type == '1') && P->nlimb == 33) {   // y^2 = x^3 + x (a_param.c:1450-1452, :2247-2251)
     memcpy(C.a, P->k33.one, sizeof P->k33.one);
-  } else if (P->type == 'a') {
+  } else if (P->type == 'a' || P->type == '1') {
     memcpy(C.a, P->k16.one, sizeof P->k16.one);
-  } else if (P->type == '1') {          // the same curve over the type a1 field (a_param.c:2247-2251)
-    memcpy(C.a, P->k33.one, sizeof P->k33.one);
   } else if (P->type == 'e') {
     memcpy(C.a, P->econst.A, sizeof P->econst.A);
     memcpy(C.b, P->econst.B, sizeof P->econst.B);

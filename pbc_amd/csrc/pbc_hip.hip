@@ -104,7 +104,7 @@ __global__ void __launch_bounds__(kBlock, N >= 32 ? PBC_A1_WAVES : PBC_A_WAVES) 
 
 // Type E: one k-term product (k = 1: a single pairing) per lane; G1/G2 256 B, GT 128 B for e.param.
 template <int N>
-__global__ void __launch_bounds__(kBlock, PBC_A1_WAVES) e_prod_pairing_kernel(uint8_t *gt, const uint8_t *g1,
+__global__ void __launch_bounds__(kBlock, N >= 32 ? PBC_A1_WAVES : PBC_A_WAVES) e_prod_pairing_kernel(uint8_t *gt, const uint8_t *g1,
                                                                               const uint8_t *g2, size_t n, int k) {
   size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
   size_t ld = idx < n ? idx : n - 1;
@@ -307,7 +307,7 @@ __global__ void __launch_bounds__(kBlock, 2) gt_op_kernel(int type, int op, uint
   if (idx >= n) return;
   uint8_t *o = out + idx * lenT;
   const uint8_t *x = a + idx * lenT;
-  if constexpr (N == 33) {
+  if constexpr (N == 16 || N == 33) {
     if (type == 'e') {                 // GT = F_q (pairing_GT_init(pairing, p->Fq), e_param.c:863)
       fp<N> u, v;
       fp_load_be<N>(u, x);
@@ -678,7 +678,8 @@ static int upload_constants(pbc_hip_pairing_s *P, hipStream_t s) {
       // one-time search of the auxiliary point on the device (single lane)
       EConst *dbuf;
       HIP_TRY(hipMalloc(&dbuf, sizeof(EConst)));
-      hipLaunchKernelGGL(e_init_kernel<33>, dim3(1), dim3(64), 0, s, dbuf, P->eraw, P->econst);
+      if (P->nlimb == 16) hipLaunchKernelGGL(e_init_kernel<16>, dim3(1), dim3(64), 0, s, dbuf, P->eraw, P->econst);
+      else hipLaunchKernelGGL(e_init_kernel<33>, dim3(1), dim3(64), 0, s, dbuf, P->eraw, P->econst);
       HIP_TRY(hipMemcpyAsync(&P->econst, dbuf, sizeof(EConst), hipMemcpyDeviceToHost, s));
       HIP_TRY(hipStreamSynchronize(s));
       (void) hipFree(dbuf);
@@ -719,11 +720,14 @@ static int launch_pairing(pbc_hip_pairing_s *P, void *d_gt, const void *d_g1, co
   if (P->type == 'a' && !P->a_generic) {
     hipLaunchKernelGGL(a_pairing_kernel<16>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
                        (const uint8_t *) d_g1, (const uint8_t *) d_g2, n);
-  } else if (P->type == 'a' && P->nlimb == 16) {     // type a of another size: the bit-by-bit kernels
+  } else if ((P->type == 'a' || P->type == '1') && P->nlimb == 16) {   // other sizes: the bit-by-bit kernels
     hipLaunchKernelGGL(a1_prod_pairing_kernel<16>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
                        (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, 1);
   } else if (P->type == '1' || P->type == 'a') {
     hipLaunchKernelGGL(a1_prod_pairing_kernel<33>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
+                       (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, 1);
+  } else if (P->type == 'e' && P->nlimb == 16) {
+    hipLaunchKernelGGL(e_prod_pairing_kernel<16>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
                        (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, 1);
   } else if (P->type == 'e') {
     hipLaunchKernelGGL(e_prod_pairing_kernel<33>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
@@ -838,11 +842,14 @@ static int launch_prod(pbc_hip_pairing_s *P, void *d_gt, const void *d_g1, const
   if (P->type == 'a' && !P->a_generic) {
     hipLaunchKernelGGL(a_prod_pairing_kernel<16>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
                        (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k);
-  } else if (P->type == 'a' && P->nlimb == 16) {
+  } else if ((P->type == 'a' || P->type == '1') && P->nlimb == 16) {
     hipLaunchKernelGGL(a1_prod_pairing_kernel<16>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
                        (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k);
   } else if (P->type == '1' || P->type == 'a') {
     hipLaunchKernelGGL(a1_prod_pairing_kernel<33>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
+                       (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k);
+  } else if (P->type == 'e' && P->nlimb == 16) {
+    hipLaunchKernelGGL(e_prod_pairing_kernel<16>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
                        (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k);
   } else if (P->type == 'e') {
     hipLaunchKernelGGL(e_prod_pairing_kernel<33>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
@@ -1023,7 +1030,7 @@ struct pbc_hip_pp_s {
 extern "C" int pbc_hip_pairing_pp_init(pbc_hip_pp_t **out, pbc_hip_pairing_t *P, const uint8_t *g1) {
   if (!out || !P || !g1) return fail("null argument");
   if (P->device < 0) return fail("no HIP device: libpbc_hip has no CPU fallback");
-  const bool mnt = P->type == 'd' || P->type == 'g', a1 = P->type == '1' || (P->type == 'a' && P->a_generic);
+  const bool mnt = P->type == 'd' || P->type == 'g', a1 = P->type == '1' || (P->type == 'a' && P->a_generic);   // a1: bit-by-bit tables
   if (P->type != 'a' && !mnt && !a1)
     return fail("pairing_pp is built for types a, a1, d and g (other types: use element_pairing)");
   pbc_hip_pp_s *pp = new pbc_hip_pp_s();
@@ -1077,7 +1084,7 @@ extern "C" int pbc_hip_pairing_pp_apply_batch_dev(pbc_hip_pp_t *pp, void *d_gt, 
   if (pp->P->type == 'a' && !pp->P->a_generic) {
     hipLaunchKernelGGL(a_pp_apply_kernel<16>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt, pp->tab, pp->valid,
                        (const uint8_t *) d_g2, n);
-  } else if (pp->P->type == 'a' && pp->P->nlimb == 16) {
+  } else if (pp->P->nlimb == 16 && (pp->P->type == 'a' || pp->P->type == '1')) {
     hipLaunchKernelGGL(a1_pp_apply_kernel<16>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt, pp->tab, pp->valid,
                        (const uint8_t *) d_g2, n);
   } else if (pp->P->type == '1' || pp->P->type == 'a') {

@@ -66,7 +66,8 @@ void *hostsim_init(const char *param, size_t len) {
   }
   if (P->type == 'e') {
     EConst tmp;
-    e_init_kernel<33>(&tmp, P->eraw, P->econst);
+    if (P->nlimb == 16) e_init_kernel<16>(&tmp, P->eraw, P->econst);
+    else e_init_kernel<33>(&tmp, P->eraw, P->econst);
     P->econst = tmp;
     c_e = tmp;
   }
@@ -95,8 +96,9 @@ int hostsim_prod_pairing(void *h, uint8_t *gt, const uint8_t *g1, const uint8_t 
     const uint8_t *a = g1 + u * k * P->len1, *b = g2 + u * k * P->len2;
     uint8_t *o = gt + u * P->lenT;
     if (P->type == 'a' && !P->a_generic) a_prod_pairing_lane<16>(o, a, b, k, lds, 1);
-    else if (P->type == 'a' && P->nlimb == 16) a1_prod_pairing_lane<16>(o, a, b, k, lds, 1);
+    else if ((P->type == 'a' || P->type == '1') && P->nlimb == 16) a1_prod_pairing_lane<16>(o, a, b, k, lds, 1);
     else if (P->type == '1' || P->type == 'a') a1_prod_pairing_lane<33>(o, a, b, k, lds, 1);
+    else if (P->type == 'e' && P->nlimb == 16) e_prod_pairing_lane<16>(o, a, b, k, lds, 1);
     else if (P->type == 'e') e_prod_pairing_lane<33>(o, a, b, k, lds, 1);
     else if (P->type == 'd' || P->type == 'g') { HS_DISPATCH_D(P, TypeMNT<N, DEG>::d_prod_pairing_lane(o, a, b, k)); }
     else f_prod_pairing_lane(o, a, b, k);
@@ -115,7 +117,7 @@ int hostsim_pp(void *h, uint8_t *gt, const uint8_t *g1, const uint8_t *g2, size_
     });
     return 0;
   }
-  if (P->type == 'a' && P->a_generic && P->nlimb == 16) {
+  if (P->nlimb == 16 && ((P->type == 'a' && P->a_generic) || P->type == '1')) {
     static uint32_t tab2[1024 * 3 * 16];
     bool v = a1_pp_init_lane<16>(tab2, g1);
     for (size_t u = 0; u < n; u++) a1_pp_apply_lane<16>(gt + u * P->lenT, tab2, v, g2 + u * P->len2);
@@ -173,19 +175,21 @@ int hostsim_group(void *h, int what, uint8_t *out, const uint8_t *a, const uint8
     } else {
       uint8_t *o = out + i * P->lenT;
       const uint8_t *x = a + i * P->lenT, *y = b + i * (what == 1 ? P->lenT : P->len_zr);
-      if (P->type == 'a' && P->nlimb == 16) { if (what == 1) a_gt_mul_lane<16>(o, x, y); else a_gt_pow_lane<16>(o, x, y, P->len_zr); }
+      if ((P->type == 'a' || P->type == '1') && P->nlimb == 16) { if (what == 1) a_gt_mul_lane<16>(o, x, y); else a_gt_pow_lane<16>(o, x, y, P->len_zr); }
       else if (P->type == '1' || P->type == 'a') { if (what == 1) a_gt_mul_lane<33>(o, x, y); else a_gt_pow_lane<33>(o, x, y, P->len_zr); }
       else if (P->type == 'e') {
-        fp<33> u, v;
-        fp_load_be<33>(u, x);
-        if (what == 1) { fp_load_be<33>(v, y); fp_mul<33>(u, u, v); }
-        else {
-          fp<33> acc, t;
-          fp_set<33>(acc, fpk<33>().one);
-          for (int i = 8 * P->len_zr - 1; i >= 0; i--) { fp_sqr<33>(acc, acc); fp_mul<33>(t, acc, u); fp_cmov<33>(acc, t, zr_bit(y, P->len_zr, i) != 0); }
-          u = acc;
-        }
-        fp_store_be<33>(o, u);
+        HS_DISPATCH(P->nlimb, {
+          fp<N> u, v;
+          fp_load_be<N>(u, x);
+          if (what == 1) { fp_load_be<N>(v, y); fp_mul<N>(u, u, v); }
+          else {
+            fp<N> acc, t;
+            fp_set<N>(acc, fpk<N>().one);
+            for (int bi = 8 * P->len_zr - 1; bi >= 0; bi--) { fp_sqr<N>(acc, acc); fp_mul<N>(t, acc, u); fp_cmov<N>(acc, t, zr_bit(y, P->len_zr, bi) != 0); }
+            u = acc;
+          }
+          fp_store_be<N>(o, u);
+        });
       }
       else if (P->type == 'd' || P->type == 'g') { HS_DISPATCH_D(P, if (what == 1) d_gt_mul_lane<N, DEG>(o, x, y); else d_gt_pow_lane<N, DEG>(o, x, y, P->len_zr)); }
       else { if (what == 1) f_gt_mul_lane(o, x, y); else f_gt_pow_lane(o, x, y, P->len_zr); }

@@ -153,7 +153,7 @@ static int fill_fpk(FpK<N> &K, const pbc_host::Big &q, int min_bits = 32 * (N - 
   K.fbytes = (uint32_t) ((q.bits() + 7) / 8);
   // The multiplier sums up to 2L products of 29-bit limbs in one 64-bit column accumulator; for
   // L > 31 that only fits because the top limbs of reduced operands and of q are short.  Check the
-  // worst column for THIS modulus: sum_{i+j=k} amax_i amax_j + (2^29 - 1) sum_{j<=k} q_j + carry.
+  // worst column for THIS modulus: sum_{i+j=k} amax_i bmax_j + (2^29 - 1) sum_{j<=k} q_j + carry.
   {
     constexpr int L = Limbs29<N>::L;
     long double worst = 0;
@@ -162,12 +162,13 @@ static int fill_fpk(FpK<N> &K, const pbc_host::Big &q, int min_bits = 32 * (N - 
       for (int i = 0; i < L; i++) {
         const int j = k - i;
         if (j < 0 || j >= L) continue;
-        auto lmax = [&](int t) -> long double {
-          const int lo = 29 * t, bits = q.bits();
+        // one operand may be an unreduced wire value of fbytes bytes (fp_load_be reduces it by a product)
+        auto lmax = [&](int t, int bits) -> long double {
+          const int lo = 29 * t;
           if (lo >= bits) return 0.0L;
           return bits - lo >= 29 ? 536870911.0L : (long double) ((1u << (bits - lo)) - 1);
         };
-        sum += lmax(i) * lmax(j) + 536870911.0L * (long double) K.p29[j];
+        sum += lmax(i, 8 * (int) K.fbytes) * lmax(j, q.bits()) + 536870911.0L * (long double) K.p29[j];
       }
       if (sum > worst) worst = sum;
     }

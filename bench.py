@@ -70,7 +70,7 @@ def cpu_baseline(param_path, k=1, fixture=None):
                 return json.loads(out.stdout.strip().splitlines()[-1])
             # relative cost of one reference pairing (keeps the CPU sample at roughly 10-30 s)
             base = os.path.basename(param_path)
-            scale = {"a.param": 1, "a1.param": 48, "e.param": 8, "f.param": 16, "g149.param": 12}.get(
+            scale = {"a.param": 1, "a1.param": 48, "e.param": 8, "f.param": 16, "f_256.param": 48, "g149.param": 12}.get(
                 base, 8 if base.startswith("d") and base != "d159.param" else 4 if base.startswith("d") else 1) * k
             one = run(max(16, 2048 // scale), 1)     # one core alone (~2 s)
             per_worker = max(8, 1024 // scale)
@@ -130,6 +130,7 @@ WORKLOADS = {
     "d224": ("d224", "d224_rand12.vec", 1, 18, "Type D (d224.param, 7-word field) element_pairing"),
     "a1": ("a1", "a1_chain8.vec", 1, 16, "Type A1 (a1.param, 1033-bit p) element_pairing"),
     "e": ("e", "e_chain8.vec", 1, 16, "Type E (e.param, k = 1, 1020-bit q) element_pairing"),
+    "f256": ("f_256", "f_256_rand4.vec", 1, 16, "Type F (254-bit BN field from pbc_param_init_f_gen(256)) element_pairing"),
     "g": ("g149", "g149_chain64.vec", 1, 17, "Type G (g149.param, k = 10) element_pairing"),
     "d190": ("d278027-190-181", "d278027-190-181_rand12.vec", 1, 18,
              "Type D (d278027-190-181.param, 6-word field) element_pairing"),

@@ -317,6 +317,20 @@ static int cmd_gene(int argc, char **argv) {
   return 0;
 }
 
+/* genf <bits> <seed> <out.param>: type f (BN) parameters (pbc_param_init_f_gen, ecc/f_param.c:459-577) */
+static int cmd_genf(int argc, char **argv) {
+  if (argc < 4) { fprintf(stderr, "genf <bits> <seed> <out.param>\n"); return 2; }
+  pbc_param_t par;
+  pbc_random_set_deterministic((unsigned) atoi(argv[2]));
+  pbc_param_init_f_gen(par, atoi(argv[1]));
+  FILE *fp = fopen(argv[3], "w");
+  if (!fp) { perror(argv[3]); return 2; }
+  pbc_param_out_str(fp, par);
+  fclose(fp);
+  pbc_param_clear(par);
+  return 0;
+}
+
 static int cmd_hash(int argc, char **argv) {
   if (argc < 6) { fprintf(stderr, "hash <param> <n> <hlen> <seed> <out>\n"); return 2; }
   int n = atoi(argv[2]), hlen = atoi(argv[3]);
@@ -354,5 +368,6 @@ int main(int argc, char **argv) {
   if (!strcmp(argv[1], "gena")) return cmd_gena(argc - 1, argv + 1);
   if (!strcmp(argv[1], "gena1")) return cmd_gena1(argc - 1, argv + 1);
   if (!strcmp(argv[1], "gene")) return cmd_gene(argc - 1, argv + 1);
+  if (!strcmp(argv[1], "genf")) return cmd_genf(argc - 1, argv + 1);
   return 2;
 }

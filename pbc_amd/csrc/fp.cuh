@@ -46,9 +46,9 @@ struct fp {
 // compile-time address (provably wave-uniform -> SGPR operands of the MACs).  One set per
 // limb count; the host uploads them with hipMemcpyToSymbolAsync on the launch stream.
 // Word counts built into the library: 5/6/7 words = the 149..224-bit MNT, Freeman and BN fields of
-// the shipped type d / g / f parameter files, 16 words = the 512-bit type a field, 33 words = the
-// 1033-bit type a1 field.
-#define PBC_FOR_EACH_N(X) X(5) X(6) X(7) X(16) X(33)
+// the shipped type d / g / f parameter files, 8 words = 256-bit BN fields (type f), 16 words = the
+// 512-bit type a field, 33 words = the 1033-bit type a1 field.
+#define PBC_FOR_EACH_N(X) X(5) X(6) X(7) X(8) X(16) X(33)
 template <int N> PBC_DEV const FpK<N> &fpk();
 #define PBC_DECL_FPK(n)              \
   __constant__ FpK<n> c_fpk##n;      \

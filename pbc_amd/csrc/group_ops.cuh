@@ -81,25 +81,27 @@ struct FdOps {                         // F_q^d of types d / g: the twist E'(F_q
   static PBC_DEV void load(el &r, const uint8_t *s) { T::f3_load_be(r, s); }
   static PBC_DEV void store(uint8_t *d, const el &a) { T::f3_store_be(d, a); }
 };
+template <int ND>
 struct Fq2Ops {                        // F_q^2 of type f: the twist y^2 = x^3 + tb
-  typedef g2 el;
+  typedef TypeF<ND> T;
+  typedef typename T::g2 el;
   static PBC_DEV int bytes() { return 2 * (int) fpk<ND>().fbytes; }
-  static PBC_DEV el curve_a() { el r; g2_zero(r); return r; }
-  static PBC_DEV el curve_b() { return fk2(c_f.tb); }
+  static PBC_DEV el curve_a() { el r; T::g2_zero(r); return r; }
+  static PBC_DEV el curve_b() { return T::fk2(c_f.tb); }
   static PBC_DEV bool a_is_zero() { return true; }
-  static PBC_DEV el one() { el r; g2_zero(r); fp_set<ND>(r.x, fpk<ND>().one); return r; }
-  static PBC_DEV el zero() { el r; g2_zero(r); return r; }
-  static PBC_DEV void add(el &r, const el &a, const el &b) { g2_add(r, a, b); }
-  static PBC_DEV void sub(el &r, const el &a, const el &b) { g2_sub(r, a, b); }
-  static PBC_DEV void dbl(el &r, const el &a) { g2_dbl(r, a); }
-  static PBC_DEV void mul(el &r, const el &a, const el &b) { g2_mul(r, a, b); }
-  static PBC_DEV void sqr(el &r, const el &a) { g2_sqr(r, a); }
-  static PBC_DEV void inv(el &r, const el &a) { g2_inv(r, a); }
-  static PBC_DEV bool is0(const el &a) { return fp_is0<ND>(a.x) & fp_is0<ND>(a.y); }
-  static PBC_DEV bool eq(const el &a, const el &b) { return g2_eq(a, b); }
+  static PBC_DEV el one() { el r; T::g2_zero(r); fp_set<ND>(r.x, fpk<ND>().one); return r; }
+  static PBC_DEV el zero() { el r; T::g2_zero(r); return r; }
+  static PBC_DEV void add(el &r, const el &a, const el &b) { T::g2_add(r, a, b); }
+  static PBC_DEV void sub(el &r, const el &a, const el &b) { T::g2_sub(r, a, b); }
+  static PBC_DEV void dbl(el &r, const el &a) { T::g2_dbl(r, a); }
+  static PBC_DEV void mul(el &r, const el &a, const el &b) { T::g2_mul(r, a, b); }
+  static PBC_DEV void sqr(el &r, const el &a) { T::g2_sqr(r, a); }
+  static PBC_DEV void inv(el &r, const el &a) { T::g2_inv(r, a); }
+  static PBC_DEV bool is0(const el &a) { return (int) fp_is0<ND>(a.x) & (int) fp_is0<ND>(a.y); }
+  static PBC_DEV bool eq(const el &a, const el &b) { return T::g2_eq(a, b); }
   static PBC_DEV void cmov(el &r, const el &a, bool c) { fp_cmov<ND>(r.x, a.x, c); fp_cmov<ND>(r.y, a.y, c); }
-  static PBC_DEV void load(el &r, const uint8_t *s) { g2_load_be(r, s); }
-  static PBC_DEV void store(uint8_t *d, const el &a) { g2_store_be(d, a); }
+  static PBC_DEV void load(el &r, const uint8_t *s) { T::g2_load_be(r, s); }
+  static PBC_DEV void store(uint8_t *d, const el &a) { T::g2_store_be(d, a); }
 };
 
 // out = [k] P for P = (x, y) bytes; off-curve P is O (curve_from_bytes); O serialises as zeros.
@@ -542,38 +544,43 @@ PBC_DEV void d_gt_pow_lane(uint8_t *out, const uint8_t *a, const uint8_t *z, int
   d_gt_store<N, DEG>(out, acc);
 }
 // Type F: F_q^12 (private-memory objects)
-__device__ void f_gt_load(f12 *r, const uint8_t *s) {
+template <int ND>
+__device__ void f_gt_load(typename TypeF<ND>::f12 *r, const uint8_t *s) {
 #pragma nounroll
-  for (int i = 0; i < 6; i++) g2_load_be(r->c[i], s + 8 * ND * i);
+  for (int i = 0; i < 6; i++) TypeF<ND>::g2_load_be(r->c[i], s + 2 * TypeF<ND>::fb() * i);
 }
-__device__ void f_gt_store(uint8_t *d, const f12 *a) {
+template <int ND>
+__device__ void f_gt_store(uint8_t *d, const typename TypeF<ND>::f12 *a) {
 #pragma nounroll
-  for (int i = 0; i < 6; i++) g2_store_be(d + 8 * ND * i, a->c[i]);
+  for (int i = 0; i < 6; i++) TypeF<ND>::g2_store_be(d + 2 * TypeF<ND>::fb() * i, a->c[i]);
 }
+template <int ND>
 __device__ void f_gt_mul_lane(uint8_t *out, const uint8_t *a, const uint8_t *b) {
-  f12 x, y;
-  f_gt_load(&x, a);
-  f_gt_load(&y, b);
-  f12_mul(&x, &x, &y);
-  f_gt_store(out, &x);
+  typename TypeF<ND>::f12 x, y;
+  f_gt_load<ND>(&x, a);
+  f_gt_load<ND>(&y, b);
+  TypeF<ND>::f12_mul(&x, &x, &y);
+  f_gt_store<ND>(out, &x);
 }
+template <int ND>
 __device__ void f_gt_pow_lane(uint8_t *out, const uint8_t *a, const uint8_t *z, int zlen) {
-  f12 x, acc, t;
-  f_gt_load(&x, a);
-  f12_one(&acc);
+  typedef TypeF<ND> T;
+  typename T::f12 x, acc, t;
+  f_gt_load<ND>(&x, a);
+  T::f12_one(&acc);
   for (int i = 8 * zlen - 1; i >= 0; i--) {
-    f12_sqr(&acc, &acc);
-    f12_mul(&t, &acc, &x);
+    T::f12_sqr(&acc, &acc);
+    T::f12_mul(&t, &acc, &x);
     bool bit = zr_bit(z, zlen, i) != 0;
 #pragma nounroll
     for (int c = 0; c < 6; c++) {
-      g2 u = acc.c[c], w = t.c[c];
+      typename T::g2 u = acc.c[c], w = t.c[c];
       fp_cmov<ND>(u.x, w.x, bit);
       fp_cmov<ND>(u.y, w.y, bit);
       acc.c[c] = u;
     }
   }
-  f_gt_store(out, &acc);
+  f_gt_store<ND>(out, &acc);
 }
 
 }  // namespace pbc

@@ -444,22 +444,25 @@ static int init_type_f(pbc_hip_pairing_s *P, const char *txt, size_t len) {
   if (!param_big(txt, len, "q", q) || !param_big(txt, len, "r", r) || !param_big(txt, len, "b", b) ||
       !param_big(txt, len, "beta", beta) || !param_big(txt, len, "alpha0", a0) || !param_big(txt, len, "alpha1", a1))
     return fail("type f: missing q/r/b/beta/alpha0/alpha1");
-  if (fill_fpk<5>(P->k5, q)) return fail("type f: only 129..160-bit q is supported by this build (got %d bits)", q.bits());
+  // f.param has a 158-bit q (5 words); pbc_param_init_f_gen(bits) up to 256 bits runs on 8 words
+  const int NF = q.bits() <= 160 ? 5 : 8;
+  if (NF == 5 ? fill_fpk<5>(P->k5, q) : fill_fpk<8>(P->k8, q, 161))
+    return fail("type f: only 129..256-bit q is supported by this build (got %d bits)", q.bits());
   if (Big::cmp(b, q) >= 0 || Big::cmp(beta, q) >= 0 || Big::cmp(a0, q) >= 0 || Big::cmp(a1, q) >= 0)
     return fail("type f: coefficient >= q");
   memset(&P->fraw, 0, sizeof P->fraw);
   memset(&P->fconst, 0, sizeof P->fconst);
-  b.to_words(P->fraw.b, ND);
-  beta.to_words(P->fraw.beta, ND);
-  a0.to_words(P->fraw.alpha0, ND);
-  a1.to_words(P->fraw.alpha1, ND);
+  b.to_words(P->fraw.b, NF);
+  beta.to_words(P->fraw.beta, NF);
+  a0.to_words(P->fraw.alpha0, NF);
+  a1.to_words(P->fraw.alpha1, NF);
   // (q - 1)/6: X^q = negalpha^((q-1)/6) X
   Big qm1 = q, six, rem;
   qm1.sub_small(1);
   six.w.push_back(6);
   Big e6 = Big::div(qm1, six, &rem);
   if (!rem.is_zero()) return fail("type f: q must be 1 mod 6");
-  e6.to_words(P->fraw.e6, ND + 1);
+  e6.to_words(P->fraw.e6, NF + 1);
   P->fraw.e6bits = e6.bits();
   if (r.bits() > 256 || r.bits() < 3) return fail("type f: bad r");
   r.to_words(P->fconst.r, 8);
@@ -470,8 +473,8 @@ static int init_type_f(pbc_hip_pairing_s *P, const char *txt, size_t len) {
   z = Big::mul(z, q2);
   z.add_small(1);
   Big te = Big::div(z, r, &rem);
-  if (!rem.is_zero() || te.bits() > 512) return fail("type f: r does not divide q^4 - q^2 + 1");
-  te.to_words(P->fconst.tateexp, 16);
+  if (!rem.is_zero() || te.bits() > 1024) return fail("type f: r does not divide q^4 - q^2 + 1");
+  te.to_words(P->fconst.tateexp, 32);
   P->fconst.tebits = te.bits();
   // Recognise the BN family (genfparam / f_param.c:70-95): q = 36x^4 + 36x^3 + 24x^2 + 6x + 1
   // with x of either sign, r = 36x^4 + 36x^3 + 18x^2 + 6x + 1.  Binary search on |x|.
@@ -517,15 +520,16 @@ static int init_type_f(pbc_hip_pairing_s *P, const char *txt, size_t len) {
       }
     }
   }
-  P->nlimb = 5;
+  P->nlimb = NF;
   P->len_fq = (q.bits() + 7) / 8;
-  if (P->len_fq != 20) return fail("type f: q must serialise to 20 bytes");
   P->len1 = 2 * P->len_fq;
   P->len2 = 4 * P->len_fq;
   P->lenT = 12 * P->len_fq;
   P->len_zr = (r.bits() + 7) / 8;
-  P->fq_muls_single = 172887.0;          // SURVEY.md 8d (instrumented reference, f.param)
-  P->fq_muls_prod_a = 172887.0;          // generic_prod_pairings: k full pairings
+  // SURVEY.md 8d (instrumented reference, f.param: 158-bit r, 472-bit tateexp): 54 k F_q products in the
+  // Miller loop, 118 k in f_tateexp; other sizes scale with the two loop lengths
+  P->fq_muls_single = 54000.0 * r.bits() / 158.0 + 118887.0 * te.bits() / 472.0;
+  P->fq_muls_prod_a = P->fq_muls_single;   // generic_prod_pairings: k full pairings
   P->fq_muls_prod_b = 0.0;
   return fill_hash_consts(P, q, nullptr);  // no cofactor (f_param.c:372)
 }

@@ -24,50 +24,56 @@
 
 namespace pbc {
 
-constexpr int ND = 5;                  // 158-bit BN field of f.param: 5 x 32-bit words, 6 x 29-bit limbs
-typedef fp<ND> fq;
-typedef vecN<ND>::type v5;
-PBC_DEV fq dk(const uint32_t *w) { fq r; fp_set<ND>(r, w); return r; }
-struct djac { fq X, Y, Z, ZZ; };
-
-struct g2 { fq x, y; };                // x + y sqrt(beta)
-struct f12 { g2 c[6]; };               // sum c_i X^i, X^6 = negalpha
-
+constexpr int ND = 5;                  // the 158-bit BN field of f.param: 5 x 32-bit words, 6 x 29-bit limbs
+constexpr int NF_MAX = 8;              // widest BN field built in: 256 bits (pbc_param_init_f_gen(256))
 struct FConst {                        // f_pairing_data_s (ecc/f_param.c:35-45)
-  uint32_t B[ND];                      // curve b (Montgomery form)
-  uint32_t beta[ND];                   // nqr of F_q (f_param.c:345-348)
-  uint32_t negalpha[2][ND];            // X^6 (f_param.c:355-361)
-  uint32_t negalphainv[2][ND];
-  uint32_t xpowq2[2][ND], xpowq6[2][ND], xpowq8[2][ND];   // X^(q^k) = (this) X (f_param.c:431-444)
-  uint32_t tb[2][ND];                  // twist: y^2 = x^3 - alpha b (f_param.c:372-381)
+  uint32_t B[NF_MAX];                  // curve b (Montgomery form)
+  uint32_t beta[NF_MAX];               // nqr of F_q (f_param.c:345-348)
+  uint32_t negalpha[2][NF_MAX];        // X^6 (f_param.c:355-361)
+  uint32_t negalphainv[2][NF_MAX];
+  uint32_t xpowq2[2][NF_MAX], xpowq6[2][NF_MAX], xpowq8[2][NF_MAX];   // X^(q^k) = (this) X (f_param.c:431-444)
+  uint32_t tb[2][NF_MAX];              // twist: y^2 = x^3 - alpha b (f_param.c:372-381)
   uint32_t r[8];
-  uint32_t tateexp[16];                // (q^4 - q^2 + 1)/r (f_param.c:414-420)
+  uint32_t tateexp[32];                // (q^4 - q^2 + 1)/r (f_param.c:414-420)
   int rbits, tebits;
   // BN structure (f_param.c:70-95 tryplusx/tryminusx): q = 36x^4+36x^3+24x^2+6x+1,
   // r = 36x^4+36x^3+18x^2+6x+1.  When the host recognises it, the hard part uses the
   // x-chain instead of a 472-bit power.
-  uint32_t gamma[2][ND];               // X^q = gamma X, gamma = negalpha^((q-1)/6)
+  uint32_t gamma[2][NF_MAX];           // X^q = gamma X, gamma = negalpha^((q-1)/6)
   uint32_t bn_x[2];                    // |x|
   int bn_ok, bn_xneg, bn_xbits;
 };
 __constant__ FConst c_f;
+struct FRaw { uint32_t b[NF_MAX], beta[NF_MAX], alpha0[NF_MAX], alpha1[NF_MAX]; uint32_t e6[NF_MAX + 1]; int e6bits; };
 
-PBC_DEV g2 fk2(const uint32_t (*w)[ND]) { g2 r; fp_set<ND>(r.x, w[0]); fp_set<ND>(r.y, w[1]); return r; }
+// Everything below is per field width: ND 32-bit words per F_q element (5 for f.param, 8 for 256-bit BN fields).
+template <int ND>
+struct TypeF {
+typedef fp<ND> fq;
+typedef typename vecN<ND>::type v5;
+static PBC_DEV fq dk(const uint32_t *w) { fq r; fp_set<ND>(r, w); return r; }
+static PBC_DEV int fb() { return (int) fpk<ND>().fbytes; }
+
+struct g2 { fq x, y; };                // x + y sqrt(beta)
+struct f12 { g2 c[6]; };               // sum c_i X^i, X^6 = negalpha
+struct djac { fq X, Y, Z, ZZ; };
+
+static PBC_DEV g2 fk2(const uint32_t (*w)[NF_MAX]) { g2 r; fp_set<ND>(r.x, w[0]); fp_set<ND>(r.y, w[1]); return r; }
 
 // ---- F_q^2 = F_q[sqrt(beta)] -------------------------------------------------------------
-PBC_DEV void g2_add(g2 &r, const g2 &a, const g2 &b) { fp_add<ND>(r.x, a.x, b.x); fp_add<ND>(r.y, a.y, b.y); }
-PBC_DEV void g2_sub(g2 &r, const g2 &a, const g2 &b) { fp_sub<ND>(r.x, a.x, b.x); fp_sub<ND>(r.y, a.y, b.y); }
-PBC_DEV void g2_dbl(g2 &r, const g2 &a) { fp_dbl<ND>(r.x, a.x); fp_dbl<ND>(r.y, a.y); }
-PBC_DEV void g2_neg(g2 &r, const g2 &a) { fp_neg<ND>(r.x, a.x); fp_neg<ND>(r.y, a.y); }
-PBC_DEV void g2_mul_fq(g2 &r, const g2 &a, const fq &s) { fp_mul<ND>(r.x, a.x, s); fp_mul<ND>(r.y, a.y, s); }
-PBC_DEV bool g2_eq(const g2 &a, const g2 &b) { return fp_eq<ND>(a.x, b.x) & fp_eq<ND>(a.y, b.y); }
-PBC_DEV void g2_zero(g2 &r) {
+static PBC_DEV void g2_add(g2 &r, const g2 &a, const g2 &b) { fp_add<ND>(r.x, a.x, b.x); fp_add<ND>(r.y, a.y, b.y); }
+static PBC_DEV void g2_sub(g2 &r, const g2 &a, const g2 &b) { fp_sub<ND>(r.x, a.x, b.x); fp_sub<ND>(r.y, a.y, b.y); }
+static PBC_DEV void g2_dbl(g2 &r, const g2 &a) { fp_dbl<ND>(r.x, a.x); fp_dbl<ND>(r.y, a.y); }
+static PBC_DEV void g2_neg(g2 &r, const g2 &a) { fp_neg<ND>(r.x, a.x); fp_neg<ND>(r.y, a.y); }
+static PBC_DEV void g2_mul_fq(g2 &r, const g2 &a, const fq &s) { fp_mul<ND>(r.x, a.x, s); fp_mul<ND>(r.y, a.y, s); }
+static PBC_DEV bool g2_eq(const g2 &a, const g2 &b) { return fp_eq<ND>(a.x, b.x) & fp_eq<ND>(a.y, b.y); }
+static PBC_DEV void g2_zero(g2 &r) {
 #pragma unroll
   for (int k = 0; k < ND; k++) { r.x.v[k] = 0; r.y.v[k] = 0; }
 }
 // fq_mul (fieldquadratic.c:197-233), lazily reduced:  t = beta a.y;
 //   re = a.x b.x + t b.y,  im = a.x b.y + a.y b.x     (5 limb products, 3 reductions)
-PBC_DEV void g2_mul_inl(g2 &r, const g2 &a, const g2 &b) {
+static PBC_DEV void g2_mul_inl(g2 &r, const g2 &a, const g2 &b) {
   fl<ND> ax, ay, bx, by, be, t, c;
   to_limbs<ND>(ax, a.x); to_limbs<ND>(ay, a.y);
   to_limbs<ND>(bx, b.x); to_limbs<ND>(by, b.y);
@@ -77,7 +83,7 @@ PBC_DEV void g2_mul_inl(g2 &r, const g2 &a, const g2 &b) {
   { const fl<ND> x[2] = {ax, ay}, y[2] = {by, bx}; sop_limbs<ND, 2>(c, x, y); from_limbs<ND>(r.y, c); }
 }
 // fq_square (fieldquadratic.c:249-269): re = a.x^2 + beta a.y^2, im = 2 a.x a.y
-PBC_DEV void g2_sqr_inl(g2 &r, const g2 &a) {
+static PBC_DEV void g2_sqr_inl(g2 &r, const g2 &a) {
   fl<ND> ax, ay, ax2, be, t, c;
   to_limbs<ND>(ax, a.x); to_limbs<ND>(ay, a.y);
   to_limbs<ND>(be, dk(c_f.beta));
@@ -99,16 +105,16 @@ static __device__ __noinline__ g2ret g2_sqr_call(v5 ax, v5 ay) {
   g2_sqr_inl(r, a);
   return g2ret{to_vec<ND>(r.x), to_vec<ND>(r.y)};
 }
-PBC_DEV void g2_mul(g2 &r, const g2 &a, const g2 &b) {
+static PBC_DEV void g2_mul(g2 &r, const g2 &a, const g2 &b) {
   g2ret t = g2_mul_call(to_vec<ND>(a.x), to_vec<ND>(a.y), to_vec<ND>(b.x), to_vec<ND>(b.y));
   from_vec<ND>(r.x, t.x); from_vec<ND>(r.y, t.y);
 }
-PBC_DEV void g2_sqr(g2 &r, const g2 &a) {
+static PBC_DEV void g2_sqr(g2 &r, const g2 &a) {
   g2ret t = g2_sqr_call(to_vec<ND>(a.x), to_vec<ND>(a.y));
   from_vec<ND>(r.x, t.x); from_vec<ND>(r.y, t.y);
 }
 // fq_invert (fieldquadratic.c:290-309)
-PBC_DEV void g2_inv(g2 &r, const g2 &a) {
+static PBC_DEV void g2_inv(g2 &r, const g2 &a) {
   fq e0, e1;
   fp_sqr<ND>(e0, a.x);
   fp_sqr<ND>(e1, a.y);
@@ -119,11 +125,11 @@ PBC_DEV void g2_inv(g2 &r, const g2 &a) {
   fp_neg<ND>(e0, e0);
   fp_mul<ND>(r.y, a.y, e0);
 }
-PBC_DEV void g2_load_be(g2 &r, const uint8_t *s) { fp_load_be<ND>(r.x, s); fp_load_be<ND>(r.y, s + 4 * ND); }
-PBC_DEV void g2_store_be(uint8_t *d, const g2 &a) { fp_store_be<ND>(d, a.x); fp_store_be<ND>(d + 4 * ND, a.y); }
+static PBC_DEV void g2_load_be(g2 &r, const uint8_t *s) { fp_load_be<ND>(r.x, s); fp_load_be<ND>(r.y, s + fb()); }
+static PBC_DEV void g2_store_be(uint8_t *d, const g2 &a) { fp_store_be<ND>(d, a.x); fp_store_be<ND>(d + fb(), a.y); }
 
 // ---- F_q^12 = F_q^2[X]/(X^6 + alpha): rolled loops over private-memory coefficients -------
-__device__ __noinline__ void f12_one(f12 *r) {
+static __device__ __noinline__ void f12_one(f12 *r) {
   fq one;
   fp_set<ND>(one, fpk<ND>().one);
 #pragma nounroll
@@ -132,7 +138,7 @@ __device__ __noinline__ void f12_one(f12 *r) {
 }
 // Limb forms of the six coefficients of an operand: x, y and beta*y (needed by every product)
 struct f12l { fl<ND> x[6], y[6], by[6]; };
-__device__ __noinline__ void f12_to_limbs(f12l *L, const f12 *a, bool with_by) {
+static __device__ __noinline__ void f12_to_limbs(f12l *L, const f12 *a, bool with_by) {
   fl<ND> be;
   to_limbs<ND>(be, dk(c_f.beta));
 #pragma nounroll
@@ -151,7 +157,7 @@ __device__ __noinline__ void f12_to_limbs(f12l *L, const f12 *a, bool with_by) {
   }
 }
 // d (11 coefficients of the degree-10 product) -> r = d mod (X^6 - negalpha)
-__device__ __noinline__ void f12_fold(f12 *r, const g2 *d) {
+static __device__ __noinline__ void f12_fold(f12 *r, const g2 *d) {
   const g2 na = fk2(c_f.negalpha);
 #pragma nounroll
   for (int i = 0; i < 6; i++) {
@@ -169,7 +175,11 @@ __device__ __noinline__ void f12_fold(f12 *r, const g2 *d) {
 //                                im = sum_{i+j=k} a_i.x b_j.y + a_i.y b_j.x
 // accumulated UNREDUCED in wide column accumulators (up to 4 pairs = 8 products per Montgomery
 // reduction instead of one reduction per F_q product).
-__device__ __noinline__ void f12_mul(f12 *r, const f12 *a, const f12 *b) {
+// capacity of a wide accumulator in product units: (units + 1) L 2^58 < 2^64
+static constexpr int kCap = 63 / Limbs29<ND>::L - 1;
+static constexpr int kPairs = kCap / 2;            // products of one F_q^2 pair land 2 per accumulator
+static_assert(kCap >= 6, "field too wide for the F_q^12 accumulators");
+static __device__ __noinline__ void f12_mul(f12 *r, const f12 *a, const f12 *b) {
   f12l A, B;
   f12_to_limbs(&A, a, true);
   f12_to_limbs(&B, b, false);
@@ -191,7 +201,7 @@ __device__ __noinline__ void f12_mul(f12 *r, const f12 *a, const f12 *b) {
       wide_mac<ND>(Wx, aby, by);
       wide_mac<ND>(Wy, ax, by);
       wide_mac<ND>(Wy, ay, bx);
-      if (++cnt == 4 || i == hi) {
+      if (++cnt == kPairs || i == hi) {
         fl<ND> t;
         fq u;
         wide_reduce<ND>(t, Wx); from_limbs<ND>(u, t); fp_add<ND>(acc.x, acc.x, u);
@@ -207,7 +217,7 @@ __device__ __noinline__ void f12_mul(f12 *r, const f12 *a, const f12 *b) {
 }
 // polymod_square (poly.c:1091-1143): cross terms once with a doubled operand, squares once.
 // A cross pair is 2 doubled products per accumulator (4 capacity units), a square pair 2 units.
-__device__ __noinline__ void f12_sqr(f12 *r, const f12 *a) {
+static __device__ __noinline__ void f12_sqr(f12 *r, const f12 *a) {
   f12l A;
   f12_to_limbs(&A, a, true);
   g2 d[11];
@@ -244,7 +254,7 @@ __device__ __noinline__ void f12_sqr(f12 *r, const f12 *a) {
         units += 4;
       }
       const bool last = (2 * (i + 1) > k);
-      if (units >= 6 || last) {
+      if (units + 4 > kCap || last) {
         fl<ND> t;
         fq u;
         wide_reduce<ND>(t, Wx); from_limbs<ND>(u, t); fp_add<ND>(acc.x, acc.x, u);
@@ -259,7 +269,7 @@ __device__ __noinline__ void f12_sqr(f12 *r, const f12 *a) {
   f12_fold(r, d);
 }
 // coefficient-wise even-power Frobenius: out^(q^k), X^(q^k) = e X (qpower, f_param.c:257-268)
-__device__ __noinline__ void f12_qpower(f12 *r, const f12 *a, const uint32_t (*ew)[ND]) {
+static __device__ __noinline__ void f12_qpower(f12 *r, const f12 *a, const uint32_t (*ew)[NF_MAX]) {
   const g2 e = fk2(ew);
   g2 epow = e;
   r->c[0] = a->c[0];
@@ -273,7 +283,7 @@ __device__ __noinline__ void f12_qpower(f12 *r, const f12 *a, const uint32_t (*e
 }
 // polymod_invert (poly.c:521-536): unique inverse; sigma = q^2-power Frobenius,
 // a^-1 = prod_{i=1..5} sigma^i(a) / N,  N = a * prod in F_q^2
-__device__ __noinline__ void f12_inv(f12 *r, const f12 *a) {
+static __device__ __noinline__ void f12_inv(f12 *r, const f12 *a) {
   f12 s, t, n;
   f12_qpower(&s, a, c_f.xpowq2);
   t = s;
@@ -297,7 +307,7 @@ __device__ __noinline__ void f12_inv(f12 *r, const f12 *a) {
 // out_i = c v_i + [aQx] v_{i-4} + [bQy] v_{i-3}, indices mod 6 with a factor negalpha on wrap
 // (a, b, c travel as vectors: by-value fq structs beyond clang's 16-register aggregate budget
 // are passed indirectly, and that path miscompiled here -- see profiles/r01_notes.md)
-__device__ __noinline__ void f_line_mul(f12 *v, v5 va, v5 vb, v5 vc, const g2 *Qx, const g2 *Qy) {
+static __device__ __noinline__ void f_line_mul(f12 *v, v5 va, v5 vb, v5 vc, const g2 *Qx, const g2 *Qy) {
   fq a, b, c;
   from_vec<ND>(a, va);
   from_vec<ND>(b, vb);
@@ -329,8 +339,8 @@ __device__ __noinline__ void f_line_mul(f12 *v, v5 va, v5 vb, v5 vc, const g2 *Q
 }
 
 // Miller function: G1 bytes x||y (2 x 20), G2 bytes x||y over F_q^2 (2 x 40)
-__device__ __noinline__ bool f_miller_lane(f12 *v, const uint8_t *g1, const uint8_t *g2b) {
-  constexpr int NB = 4 * ND;
+static __device__ __noinline__ bool f_miller_lane(f12 *v, const uint8_t *g1, const uint8_t *g2b) {
+  const int NB = fb();
   fq Px, Py, one;
   g2 Qx, Qy;
   fp_set<ND>(one, fpk<ND>().one);
@@ -435,7 +445,7 @@ __device__ __noinline__ bool f_miller_lane(f12 *v, const uint8_t *g1, const uint
 }
 
 // a^q: conjugate the F_q^2 coefficients and scale by gamma^i (X^q = gamma X)
-__device__ __noinline__ void f12_frob(f12 *r, const f12 *a) {
+static __device__ __noinline__ void f12_frob(f12 *r, const f12 *a) {
   const g2 gm = fk2(c_f.gamma);
   g2 gpow = gm;
   {
@@ -453,7 +463,7 @@ __device__ __noinline__ void f12_frob(f12 *r, const f12 *a) {
   }
 }
 // a^|x| by square-and-multiply (wave-uniform bits)
-__device__ __noinline__ void f12_pow_x(f12 *r, const f12 *a) {
+static __device__ __noinline__ void f12_pow_x(f12 *r, const f12 *a) {
   f12 acc = *a;
 #pragma nounroll
   for (int i = c_f.bn_xbits - 2; i >= 0; i--) {
@@ -464,7 +474,7 @@ __device__ __noinline__ void f12_pow_x(f12 *r, const f12 *a) {
 }
 
 // f_tateexp (f_param.c:250-283)
-__device__ __noinline__ void f_final_exp(f12 *out) {
+static __device__ __noinline__ void f_final_exp(f12 *out) {
   f12 x, y;
   f12_qpower(&y, out, c_f.xpowq8);
   f12_qpower(&x, out, c_f.xpowq6);
@@ -555,26 +565,26 @@ __device__ __noinline__ void f_final_exp(f12 *out) {
 // Type F installs no dedicated product routine; the product of k reduced pairings equals the
 // reduced product of the Miller functions) for one lane
 // miller_only: diagnostic (stop before the final exponentiation)
-__device__ void f_prod_pairing_lane(uint8_t *gt, const uint8_t *g1, const uint8_t *g2b, int k,
+static __device__ void f_prod_pairing_lane(uint8_t *gt, const uint8_t *g1, const uint8_t *g2b, int k,
                                     bool miller_only = false) {
   f12 F;
   bool valid = f_miller_lane(&F, g1, g2b);
   for (int j = 1; j < k; j++) {
     f12 f;
-    valid &= f_miller_lane(&f, g1 + (size_t) j * 8 * ND, g2b + (size_t) j * 16 * ND);
+    valid &= f_miller_lane(&f, g1 + (size_t) j * 2 * fb(), g2b + (size_t) j * 4 * fb());
     f12_mul(&F, &F, &f);
   }
   if (!miller_only) f_final_exp(&F);
   if (!valid) f12_one(&F);
 #pragma nounroll
-  for (int i = 0; i < 6; i++) g2_store_be(gt + 8 * ND * i, F.c[i]);
+  for (int i = 0; i < 6; i++) g2_store_be(gt + 2 * fb() * i, F.c[i]);
 }
 
 // bring-up diagnostics: one tower primitive on operands given as GT-format bytes
-__device__ void f_debug_lane(int op, uint8_t *out, const uint8_t *inA, const uint8_t *inB) {
+static __device__ void f_debug_lane(int op, uint8_t *out, const uint8_t *inA, const uint8_t *inB) {
   f12 A, B, R;
 #pragma nounroll
-  for (int i = 0; i < 6; i++) { g2_load_be(A.c[i], inA + 8 * ND * i); g2_load_be(B.c[i], inB + 8 * ND * i); }
+  for (int i = 0; i < 6; i++) { g2_load_be(A.c[i], inA + 2 * fb() * i); g2_load_be(B.c[i], inB + 2 * fb() * i); }
   if (op == 10) f12_mul(&R, &A, &B);
   else if (op == 11) f12_sqr(&R, &A);
   else if (op == 12) { R = A; f_line_mul(&R, to_vec<ND>(B.c[0].x), to_vec<ND>(B.c[0].y), to_vec<ND>(B.c[3].x), &B.c[1], &B.c[2]); }
@@ -583,15 +593,12 @@ __device__ void f_debug_lane(int op, uint8_t *out, const uint8_t *inA, const uin
   else if (op == 15) { R = A; f12_sqr(&R, &R); f12_mul(&R, &R, &B); }
   else { R = A; f_final_exp(&R); }
 #pragma nounroll
-  for (int i = 0; i < 6; i++) g2_store_be(out + 8 * ND * i, R.c[i]);
+  for (int i = 0; i < 6; i++) g2_store_be(out + 2 * fb() * i, R.c[i]);
 }
 
 // ---- device-side derivation of the tower constants ---------------------------------------
-struct FRaw { uint32_t b[ND], beta[ND], alpha0[ND], alpha1[ND]; uint32_t e6[ND + 1]; int e6bits; };
-
 // stage 1: F_q-level constants and negalpha (beta must be in c_f before any g2_mul)
-__global__ void f_init_stage1(FConst *out, FRaw raw, FConst base) {
-  if (threadIdx.x || blockIdx.x) return;
+static PBC_DEV void init_stage1(FConst *out, const FRaw &raw, const FConst &base) {
   FConst C = base;
   fq r2, t, b, be, a0, a1;
   fp_set<ND>(r2, fpk<ND>().r2);
@@ -609,8 +616,7 @@ __global__ void f_init_stage1(FConst *out, FRaw raw, FConst base) {
 //   X^q = negalpha^((q-1)/6) X =: c X,  X^(q^2) = conj(c) c X = N(c) X,  X^(q^6) = N(c)^3 X,
 //   X^(q^8) = N(c)^4 X   (the reference gets the same values by brute-force powering,
 //   f_param.c:431-444)
-__global__ void f_init_stage2(FConst *out, FRaw raw) {
-  if (threadIdx.x || blockIdx.x) return;
+static PBC_DEV void init_stage2(FConst *out, const FRaw &raw) {
   FConst C = c_f;
   const g2 na = fk2(c_f.negalpha);
   g2 ni, tb, c;
@@ -641,6 +647,17 @@ __global__ void f_init_stage2(FConst *out, FRaw raw) {
     C.gamma[0][k] = c.x.v[k]; C.gamma[1][k] = c.y.v[k];
   }
   *out = C;
+}
+
+};  // struct TypeF
+
+template <int ND> __global__ void f_init_stage1(FConst *out, FRaw raw, FConst base) {
+  if (threadIdx.x || blockIdx.x) return;
+  TypeF<ND>::init_stage1(out, raw, base);
+}
+template <int ND> __global__ void f_init_stage2(FConst *out, FRaw raw) {
+  if (threadIdx.x || blockIdx.x) return;
+  TypeF<ND>::init_stage2(out, raw);
 }
 
 }  // namespace pbc

@@ -221,31 +221,34 @@ __global__ void __launch_bounds__(kBlock, PBC_DF_WAVES) d_pp_apply_kernel(uint8_
   }
 }
 
-// Type F: one k-term product (k = 1: a single pairing) per lane.  G1 40 B, G2 80 B, GT 240 B.
+// Type F: one k-term product (k = 1: a single pairing) per lane.  With fb = fixed byte length of F_q:
+// G1 2 fb, G2 4 fb, GT 12 fb bytes (40 / 80 / 240 B for f.param).
 #ifndef PBC_F_WAVES
 #define PBC_F_WAVES PBC_DF_WAVES
 #endif
+template <int N>
 __global__ void __launch_bounds__(kBlock, PBC_F_WAVES) f_prod_pairing_kernel(uint8_t *gt, const uint8_t *g1,
                                                                  const uint8_t *g2, size_t n, int k) {
   size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
   size_t ld = idx < n ? idx : n - 1;
-  constexpr int L1 = 8 * ND, L2 = 16 * ND, LT = 48 * ND;
-  __attribute__((aligned(4))) uint8_t out[LT];
-  f_prod_pairing_lane(out, g1 + ld * (k < 0 ? 1 : k) * L1, g2 + ld * (k < 0 ? 1 : k) * L2, k < 0 ? 1 : k, k < 0);
+  const int fb = (int) fpk<N>().fbytes, L1 = 2 * fb, L2 = 4 * fb, LT = 12 * fb;
+  __attribute__((aligned(4))) uint8_t out[48 * N];
+  TypeF<N>::f_prod_pairing_lane(out, g1 + ld * (k < 0 ? 1 : k) * L1, g2 + ld * (k < 0 ? 1 : k) * L2, k < 0 ? 1 : k, k < 0);
   if (idx < n) {
-    uint32_t *dst = reinterpret_cast<uint32_t *>(gt + idx * LT);
+    uint32_t *dst = reinterpret_cast<uint32_t *>(gt + idx * LT);      // LT = 12 fb is a multiple of 4
     const uint32_t *src = reinterpret_cast<const uint32_t *>(out);
-#pragma unroll
     for (int i = 0; i < LT / 4; i++) dst[i] = src[i];
   }
 }
 
+template <int N>
 __global__ void __launch_bounds__(kBlock) f_debug_kernel(int op, uint8_t *out, const uint8_t *a, const uint8_t *b, size_t n) {
   size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
   if (idx >= n) return;
-  __attribute__((aligned(4))) uint8_t o[48 * ND];
-  f_debug_lane(op, o, a + idx * 48 * ND, b + idx * 48 * ND);
-  for (int i = 0; i < 48 * ND; i++) out[idx * 48 * ND + i] = o[i];
+  const int LT = 12 * (int) fpk<N>().fbytes;
+  __attribute__((aligned(4))) uint8_t o[48 * N];
+  TypeF<N>::f_debug_lane(op, o, a + idx * LT, b + idx * LT);
+  for (int i = 0; i < LT; i++) out[idx * LT + i] = o[i];
 }
 
 // ---- group operations (one element per lane) -------------------------------------------------
@@ -275,12 +278,13 @@ __global__ void __launch_bounds__(kBlock, 2) d_g2_mul_kernel(uint8_t *out, const
   const size_t L = 2 * DEG * fpk<N>().fbytes;
   ec_mul_lane<FdOps<N, DEG>>(out + idx * L, in + idx * L, z + idx * zlen, zlen);
 }
+template <int N>
 __global__ void __launch_bounds__(kBlock, 2) f_g2_mul_kernel(uint8_t *out, const uint8_t *in, const uint8_t *z,
                                                               int zlen, size_t n) {
   size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
   if (idx >= n) return;
-  const size_t L = 4 * fpk<ND>().fbytes;
-  ec_mul_lane<Fq2Ops>(out + idx * L, in + idx * L, z + idx * zlen, zlen);
+  const size_t L = 4 * fpk<N>().fbytes;
+  ec_mul_lane<Fq2Ops<N>>(out + idx * L, in + idx * L, z + idx * zlen, zlen);
 }
 template <int N>
 __global__ void __launch_bounds__(kBlock, 2) g_from_hash_kernel(uint8_t *out, const uint8_t *data, int hlen, size_t n) {
@@ -333,12 +337,16 @@ __global__ void __launch_bounds__(kBlock, 2) gt_op_kernel(int type, int op, uint
     if (op == 0) a_gt_mul_lane<N>(o, x, b + idx * lenT); else a_gt_pow_lane<N>(o, x, b + idx * zlen, zlen);
   } else {
     if (type == 'd') {
-      if (op == 0) d_gt_mul_lane<N, 3>(o, x, b + idx * lenT); else d_gt_pow_lane<N, 3>(o, x, b + idx * zlen, zlen);
-    } else if constexpr (N == ND) {
+      if constexpr (N <= ND_MAX) {
+        if (op == 0) d_gt_mul_lane<N, 3>(o, x, b + idx * lenT); else d_gt_pow_lane<N, 3>(o, x, b + idx * zlen, zlen);
+      }
+    } else if constexpr (N == 5 || N == 8) {
       if (type == 'g') {
-        if (op == 0) d_gt_mul_lane<N, 5>(o, x, b + idx * lenT); else d_gt_pow_lane<N, 5>(o, x, b + idx * zlen, zlen);
+        if constexpr (N == 5) {
+          if (op == 0) d_gt_mul_lane<N, 5>(o, x, b + idx * lenT); else d_gt_pow_lane<N, 5>(o, x, b + idx * zlen, zlen);
+        }
       } else {
-        if (op == 0) f_gt_mul_lane(o, x, b + idx * lenT); else f_gt_pow_lane(o, x, b + idx * zlen, zlen);
+        if (op == 0) f_gt_mul_lane<N>(o, x, b + idx * lenT); else f_gt_pow_lane<N>(o, x, b + idx * zlen, zlen);
       }
     }
   }
@@ -636,12 +644,20 @@ extern "C" double pbc_hip_algorithmic_macs_per_unit(const pbc_hip_pairing_t *p, 
     default: return fail("internal: no type d/g kernel for %d-word fields, degree %d", (P_)->nlimb, (P_)->deg); \
   }
 
+// type f kernels: 5-word (f.param) and 8-word (256-bit BN) fields
+#define PBC_DISPATCH_F(nl, ...)                               \
+  switch (nl) {                                               \
+    case 5: { constexpr int N = 5; __VA_ARGS__; } break;      \
+    case 8: { constexpr int N = 8; __VA_ARGS__; } break;      \
+    default: return fail("internal: no type f kernel for %d-word fields", (int) (nl)); \
+  }
 // any built-in field width (PBC_FOR_EACH_N)
 #define PBC_DISPATCH_N(nl, ...)                               \
   switch (nl) {                                               \
     case 5: { constexpr int N = 5; __VA_ARGS__; } break;             \
     case 6: { constexpr int N = 6; __VA_ARGS__; } break;             \
     case 7: { constexpr int N = 7; __VA_ARGS__; } break;             \
+    case 8: { constexpr int N = 8; __VA_ARGS__; } break;             \
     case 16: { constexpr int N = 16; __VA_ARGS__; } break;           \
     case 33: { constexpr int N = 33; __VA_ARGS__; } break;           \
     default: return fail("internal: no kernel for %d-word fields", (int) (nl)); \
@@ -691,9 +707,9 @@ static int upload_constants(pbc_hip_pairing_s *P, hipStream_t s) {
     if (!P->dev_ready) {
       FConst *dbuf;
       HIP_TRY(hipMalloc(&dbuf, sizeof(FConst)));
-      hipLaunchKernelGGL(f_init_stage1, dim3(1), dim3(64), 0, s, dbuf, P->fraw, P->fconst);
+      PBC_DISPATCH_F(P->nlimb, hipLaunchKernelGGL(f_init_stage1<N>, dim3(1), dim3(64), 0, s, dbuf, P->fraw, P->fconst));
       HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_f), dbuf, sizeof(FConst), 0, hipMemcpyDeviceToDevice, s));
-      hipLaunchKernelGGL(f_init_stage2, dim3(1), dim3(64), 0, s, dbuf, P->fraw);
+      PBC_DISPATCH_F(P->nlimb, hipLaunchKernelGGL(f_init_stage2<N>, dim3(1), dim3(64), 0, s, dbuf, P->fraw));
       HIP_TRY(hipMemcpyAsync(&P->fconst, dbuf, sizeof(FConst), hipMemcpyDeviceToHost, s));
       HIP_TRY(hipStreamSynchronize(s));
       (void) hipFree(dbuf);
@@ -736,8 +752,8 @@ static int launch_pairing(pbc_hip_pairing_s *P, void *d_gt, const void *d_g1, co
     PBC_DISPATCH_D(P, hipLaunchKernelGGL((d_prod_pairing_kernel<N, DEG>), dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
                                                 (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, 1));
   } else if (P->type == 'f') {
-    hipLaunchKernelGGL(f_prod_pairing_kernel, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
-                       (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, 1);
+    PBC_DISPATCH_F(P->nlimb, hipLaunchKernelGGL(f_prod_pairing_kernel<N>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
+                       (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, 1));
   } else {
     return fail("unsupported type");
   }
@@ -858,8 +874,8 @@ static int launch_prod(pbc_hip_pairing_s *P, void *d_gt, const void *d_g1, const
     PBC_DISPATCH_D(P, hipLaunchKernelGGL((d_prod_pairing_kernel<N, DEG>), dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
                                                 (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k));
   } else if (P->type == 'f') {
-    hipLaunchKernelGGL(f_prod_pairing_kernel, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
-                       (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k);
+    PBC_DISPATCH_F(P->nlimb, hipLaunchKernelGGL(f_prod_pairing_kernel<N>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
+                       (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k));
   } else {
     return fail("unsupported type");
   }
@@ -910,8 +926,8 @@ static int run_group(pbc_hip_pairing_s *P, int what, int group, uint8_t *out, co
     PBC_DISPATCH_D(P, hipLaunchKernelGGL((d_g2_mul_kernel<N, DEG>), dim3(grid), dim3(kBlock), 0, 0, (uint8_t *) d_o,
                                          (const uint8_t *) da, (const uint8_t *) db, P->len_zr, n));
   } else if (what == 0 && group == 2 && P->type == 'f') {
-    hipLaunchKernelGGL(f_g2_mul_kernel, dim3(grid), dim3(kBlock), 0, 0, (uint8_t *) d_o, (const uint8_t *) da,
-                       (const uint8_t *) db, P->len_zr, n);
+    PBC_DISPATCH_F(P->nlimb, hipLaunchKernelGGL(f_g2_mul_kernel<N>, dim3(grid), dim3(kBlock), 0, 0, (uint8_t *) d_o, (const uint8_t *) da,
+                       (const uint8_t *) db, P->len_zr, n));
   } else if (what == 0) {              // E(F_q): G1, and G2 of the symmetric types
     PBC_DISPATCH_N(P->nlimb, hipLaunchKernelGGL(g_mul_kernel<N>, dim3(grid), dim3(kBlock), 0, 0, (uint8_t *) d_o,
                                                 (const uint8_t *) da, (const uint8_t *) db, P->len_zr, n));
@@ -1136,8 +1152,8 @@ extern "C" int pbc_hip_diag_stage(pbc_hip_pairing_t *P, int stage, uint8_t *out,
     HIP_TRY(hipMemcpy(d2, g2, n * P->len2, hipMemcpyHostToDevice));
     if (upload_constants(P, 0)) return 1;
     unsigned grid = (unsigned) ((n + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL(f_prod_pairing_kernel, dim3(grid), dim3(kBlock), 0, 0, (uint8_t *) dt,
-                       (const uint8_t *) d1, (const uint8_t *) d2, n, -1);
+    PBC_DISPATCH_F(P->nlimb, hipLaunchKernelGGL(f_prod_pairing_kernel<N>, dim3(grid), dim3(kBlock), 0, 0, (uint8_t *) dt,
+                       (const uint8_t *) d1, (const uint8_t *) d2, n, -1));
     HIP_TRY(hipMemcpy(out, dt, n * P->lenT < out_len ? n * P->lenT : out_len, hipMemcpyDeviceToHost));
     (void) hipFree(d1); (void) hipFree(d2); (void) hipFree(dt);
     return 0;
@@ -1152,8 +1168,8 @@ extern "C" int pbc_hip_diag_stage(pbc_hip_pairing_t *P, int stage, uint8_t *out,
     HIP_TRY(hipMemcpy(d2, g2, bytes, hipMemcpyHostToDevice));
     if (upload_constants(P, 0)) return 1;
     unsigned grid = (unsigned) ((n + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL(f_debug_kernel, dim3(grid), dim3(kBlock), 0, 0, stage, (uint8_t *) dt, (const uint8_t *) d1,
-                       (const uint8_t *) d2, n);
+    PBC_DISPATCH_F(P->nlimb, hipLaunchKernelGGL(f_debug_kernel<N>, dim3(grid), dim3(kBlock), 0, 0, stage, (uint8_t *) dt, (const uint8_t *) d1,
+                       (const uint8_t *) d2, n));
     HIP_TRY(hipMemcpy(out, dt, bytes < out_len ? bytes : out_len, hipMemcpyDeviceToHost));
     (void) hipFree(d1); (void) hipFree(d2); (void) hipFree(dt);
     return 0;

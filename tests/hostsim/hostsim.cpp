@@ -19,8 +19,15 @@ static void set_fpk(pbc_hip_pairing_s *P) {
     case 5: { constexpr int N = 5; __VA_ARGS__; } break;     \
     case 6: { constexpr int N = 6; __VA_ARGS__; } break;     \
     case 7: { constexpr int N = 7; __VA_ARGS__; } break;     \
+    case 8: { constexpr int N = 8; __VA_ARGS__; } break;     \
     case 16: { constexpr int N = 16; __VA_ARGS__; } break;   \
     case 33: { constexpr int N = 33; __VA_ARGS__; } break;   \
+  }
+// type f: 5- or 8-word fields
+#define HS_DISPATCH_F(nl, ...)                         \
+  switch (nl) {                                        \
+    case 5: { constexpr int N = 5; __VA_ARGS__; } break;      \
+    case 8: { constexpr int N = 8; __VA_ARGS__; } break;      \
   }
 // types d / g: N words, degree DEG
 #define HS_DISPATCH_D(P_, ...)                                                \
@@ -73,9 +80,9 @@ void *hostsim_init(const char *param, size_t len) {
   }
   if (P->type == 'f') {
     FConst tmp;
-    f_init_stage1(&tmp, P->fraw, P->fconst);
+    HS_DISPATCH_F(P->nlimb, TypeF<N>::init_stage1(&tmp, P->fraw, P->fconst));
     c_f = tmp;
-    f_init_stage2(&tmp, P->fraw);
+    HS_DISPATCH_F(P->nlimb, TypeF<N>::init_stage2(&tmp, P->fraw));
     c_f = tmp;
     P->fconst = tmp;
   }
@@ -101,7 +108,7 @@ int hostsim_prod_pairing(void *h, uint8_t *gt, const uint8_t *g1, const uint8_t 
     else if (P->type == 'e' && P->nlimb == 16) e_prod_pairing_lane<16>(o, a, b, k, lds, 1);
     else if (P->type == 'e') e_prod_pairing_lane<33>(o, a, b, k, lds, 1);
     else if (P->type == 'd' || P->type == 'g') { HS_DISPATCH_D(P, TypeMNT<N, DEG>::d_prod_pairing_lane(o, a, b, k)); }
-    else f_prod_pairing_lane(o, a, b, k);
+    else { HS_DISPATCH_F(P->nlimb, TypeF<N>::f_prod_pairing_lane(o, a, b, k)); }
   }
   return 0;
 }
@@ -158,7 +165,7 @@ int hostsim_g2_mul(void *h, uint8_t *out, const uint8_t *a, const uint8_t *b, si
     if (P->type == 'd' || P->type == 'g') {
       HS_DISPATCH_D(P, (ec_mul_lane<FdOps<N, DEG>>(out + i * P->len2, a + i * P->len2, b + i * P->len_zr, P->len_zr)));
     } else if (P->type == 'f') {
-      ec_mul_lane<Fq2Ops>(out + i * P->len2, a + i * P->len2, b + i * P->len_zr, P->len_zr);
+      HS_DISPATCH_F(P->nlimb, (ec_mul_lane<Fq2Ops<N>>(out + i * P->len2, a + i * P->len2, b + i * P->len_zr, P->len_zr)));
     } else {
       HS_DISPATCH(P->nlimb, g_mul_lane<N>(out + i * P->len2, a + i * P->len2, b + i * P->len_zr, P->len_zr));
     }
@@ -192,7 +199,7 @@ int hostsim_group(void *h, int what, uint8_t *out, const uint8_t *a, const uint8
         });
       }
       else if (P->type == 'd' || P->type == 'g') { HS_DISPATCH_D(P, if (what == 1) d_gt_mul_lane<N, DEG>(o, x, y); else d_gt_pow_lane<N, DEG>(o, x, y, P->len_zr)); }
-      else { if (what == 1) f_gt_mul_lane(o, x, y); else f_gt_pow_lane(o, x, y, P->len_zr); }
+      else { HS_DISPATCH_F(P->nlimb, if (what == 1) f_gt_mul_lane<N>(o, x, y); else f_gt_pow_lane<N>(o, x, y, P->len_zr)); }
     }
   }
   return 0;
@@ -220,11 +227,11 @@ int hostsim_stage(void *h, int stage, uint8_t *out, size_t out_len, const uint8_
     return (int) len;
   }
   if (stage == 1 && P->type == 'f') {
-    for (size_t u = 0; u < n; u++) f_prod_pairing_lane(out + u * P->lenT, g1 + u * P->len1, g2 + u * P->len2, 1, true);
+    for (size_t u = 0; u < n; u++) { HS_DISPATCH_F(P->nlimb, TypeF<N>::f_prod_pairing_lane(out + u * P->lenT, g1 + u * P->len1, g2 + u * P->len2, 1, true)); }
     return 0;
   }
   if (stage >= 10 && P->type == 'f') {
-    for (size_t u = 0; u < n; u++) f_debug_lane(stage, out + u * P->lenT, g1 + u * P->lenT, g2 + u * P->lenT);
+    for (size_t u = 0; u < n; u++) { HS_DISPATCH_F(P->nlimb, TypeF<N>::f_debug_lane(stage, out + u * P->lenT, g1 + u * P->lenT, g2 + u * P->lenT)); }
     return 0;
   }
   return -1;

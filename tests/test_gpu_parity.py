@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 import oracle
-from conftest import golden, OTHER, GENERIC_A, GENERIC_OTHER, FILES_OF, param_value
+from conftest import golden, OTHER, GENERIC_A, GENERIC_OTHER, GENERIC_F, FILES_OF, param_value
 
 pytestmark = pytest.mark.gpu
 
@@ -501,6 +501,33 @@ def test_type_a_parameter_sets_of_other_sizes(hips, oracles, g):
     assert np.array_equal(H.element_pairing(aP, v.g2), H.element_pow_zn_GT(v.gt, Z))
     h = H.element_from_hash(1, rng.integers(0, 256, (v.n, 20), dtype=np.uint8))
     assert not H.element_mul_zn(1, h, np.tile(_be(r, zl + 1)[-zl:] if False else _be(r % (1 << (8 * zl)), zl), (v.n, 1))).any()
+
+
+@pytest.mark.parametrize("g", GENERIC_F)
+def test_bn_parameter_sets_of_other_sizes(hips, oracles, g):
+    """pbc_param_init_f_gen(256) / (200): 254- and 198-bit BN fields on the 8-word arithmetic -- reference
+    vectors, products, cross pairs vs the oracle, G1 / G2 scalar multiplication, hash-to-curve, bilinearity in
+    both arguments on the device."""
+    H, O = hips[g], oracles[g]
+    v = golden(FILES_OF[g][0])
+    assert np.array_equal(H.element_pairing(v.g1, v.g2), v.gt)
+    w = golden(FILES_OF[g][2])
+    assert np.array_equal(H.element_prod_pairing(w.g1, w.g2, w.k), w.gt)
+    g1, g2 = v.g1[[0, 1, 2, 3, 0]], v.g2[[1, 2, 3, 0, 0]]
+    assert np.array_equal(H.element_pairing(g1, g2), O.pairing_batch(g1, g2))
+    r = param_value(g, "r")
+    zl = H.length_in_bytes_Zr
+    rng = np.random.default_rng(43)
+    Z = np.stack([_be(int.from_bytes(rng.bytes(zl), "big") % r, zl) for _ in range(v.n)])
+    aP = H.element_mul_zn(1, v.g1, Z)
+    assert np.array_equal(aP[:2], O.g_mul(1, v.g1[:2], Z[:2]))
+    aQ = H.element_mul_zn(2, v.g2, Z)
+    want = H.element_pow_zn_GT(v.gt, Z)
+    assert np.array_equal(H.element_pairing(aP, v.g2), want)
+    assert np.array_equal(H.element_pairing(v.g1, aQ), want)
+    assert np.array_equal(want[:2], O.gt_pow(v.gt[:2], Z[:2]))
+    h = H.element_from_hash(1, rng.integers(0, 256, (v.n, 32), dtype=np.uint8))
+    assert not H.element_mul_zn(1, h, np.tile(_be(r, zl), (v.n, 1))).any()
 
 
 def test_type_g_chain_and_products(hips):

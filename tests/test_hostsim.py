@@ -5,7 +5,7 @@ mirror for GPU-less bring-up, not a product path: libpbc_hip.so never contains i
 import numpy as np
 import pytest
 
-from conftest import golden, _param, PARAM_OF, OTHER, GENERIC_A, GENERIC_OTHER, FILES_OF, key_of, param_value
+from conftest import golden, _param, PARAM_OF, OTHER, GENERIC_A, GENERIC_OTHER, GENERIC_F, FILES_OF, key_of, param_value
 
 hostsim = pytest.importorskip("hostsim")
 
@@ -24,7 +24,7 @@ def sims():
     ("d_rand32.vec", 6), ("d_edge20.vec", 20), ("d_prod16x4.vec", 2), ("d_prod3x10_edge.vec", 10),
     ("f_rand16.vec", 3), ("f_edge10.vec", 10), ("f_prod3x5_edge.vec", 5),
 ] + [(name, 2 if d in ("a1", "e") else 4) for d in OTHER for name in FILES_OF[d]] + [("g149_prod4x3.vec", 1)]
-  + [(name, 2) for g in GENERIC_A + GENERIC_OTHER for name in (FILES_OF[g][0], FILES_OF[g][2])])
+  + [(name, 2) for g in GENERIC_A + GENERIC_OTHER + GENERIC_F for name in (FILES_OF[g][0], FILES_OF[g][2])])
 def test_kernel_source_on_host_matches_reference(sims, name, count):
     v = golden(name)
     n = min(count, v.n)

@@ -33,10 +33,10 @@ def test_kernel_source_on_host_matches_reference(sims, name, count):
 
 
 @pytest.mark.parametrize("t,q", [("a", None), ("d", 625852803282871856053922297323874661378036491717)]
-                         + [(d, None) for d in OTHER])
+                         + [(d, None) for d in OTHER + ["a_160_500", "a_224_768", "a1_200", "e_160_400", "f_256", "f_200"]])
 def test_kernel_fq_ops_on_host(sims, oracles, t, q):
     if q is None:
-        q = param_value(t, "p" if t == "a1" else "q")
+        q = param_value(t, "p" if t.startswith("a1") else "q")
     nb = sims[t].len1 // 2
     rng = np.random.default_rng(2)
     xs = [int.from_bytes(rng.bytes(nb), "big") % q for _ in range(40)] + [1, q - 1, 2 ** (8 * nb) - 1]
@@ -87,13 +87,13 @@ def test_pairing_pp_types_d_g_on_host(sims, oracles, t, name):
 
 
 @pytest.mark.parametrize("t,name", [("a", "a_rand32.vec"), ("d", "d_rand32.vec"), ("f", "f_rand16.vec")]
-                         + [(d, FILES_OF[d][0]) for d in OTHER])
+                         + [(d, FILES_OF[d][0]) for d in OTHER + ["a_150_300_mm", "a1_200", "e_160_400", "f_256", "f_200"]])
 def test_group_ops_on_host(sims, oracles, t, name):
     """element_mul_zn on G1, element_mul / element_pow_zn on GT vs the oracle."""
     v = golden(name)
     rng = np.random.default_rng(21)
-    n = 3
-    r = param_value(t, "n" if t == "a1" else "r")
+    n = 2 if v.n < 6 else 3
+    r = param_value(t, "n" if t.startswith("a1") else "r")
     zl = (r.bit_length() + 7) // 8          # pairing_length_in_bytes_Zr
     ks = [int.from_bytes(rng.bytes(zl), "big") % r for _ in range(n - 1)] + [1]
     Z = np.stack([np.frombuffer(k.to_bytes(zl, "big"), np.uint8) for k in ks])

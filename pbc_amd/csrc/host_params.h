@@ -109,7 +109,7 @@ static int fill_hash_consts(pbc_hip_pairing_s *P, const pbc_host::Big &q, const 
 
 // set when fill_fpk refuses a modulus whose limbs are too dense for the column accumulator (only
 // possible for the 33-word fields): the type-specific message is replaced by dense_or()
-static bool g_fpk_dense = false;
+static thread_local bool g_fpk_dense = false;
 static int dense_or(int rc) {
   if (rc && g_fpk_dense) {
     g_fpk_dense = false;

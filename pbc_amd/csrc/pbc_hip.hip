@@ -27,6 +27,17 @@ using namespace pbc;
     hipError_t e_ = (x);                                                             \
     if (e_ != hipSuccess) return fail("%s: %s", #x, hipGetErrorString(e_));          \
   } while (0)
+
+// device allocation released on every return path
+struct DevBuf {
+  void *p = nullptr;
+  DevBuf() = default;
+  DevBuf(const DevBuf &) = delete;
+  DevBuf &operator=(const DevBuf &) = delete;
+  ~DevBuf() { if (p) (void) hipFree(p); }
+  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
+  template <class T> T *as() const { return static_cast<T *>(p); }
+};
 extern "C" const char *pbc_hip_last_error(void) { return g_err; }
 
 // ---------------------------------------------------------------------------------------
@@ -913,11 +924,12 @@ static int run_group(pbc_hip_pairing_s *P, int what, int group, uint8_t *out, co
     la = lo = (size_t) P->lenT;
     lb = (size_t) P->len_zr;
   }
-  void *da = nullptr, *db = nullptr, *d_o = nullptr;
+  DevBuf ba, bb, bo;
   HIP_TRY(hipSetDevice(P->device));
-  HIP_TRY(hipMalloc(&da, n * la));
-  HIP_TRY(hipMalloc(&db, n * lb));
-  HIP_TRY(hipMalloc(&d_o, n * lo));
+  HIP_TRY(ba.alloc(n * la));
+  HIP_TRY(bb.alloc(n * lb));
+  HIP_TRY(bo.alloc(n * lo));
+  void *da = ba.p, *db = bb.p, *d_o = bo.p;
   HIP_TRY(hipMemcpy(da, a, n * la, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(db, b, n * lb, hipMemcpyHostToDevice));
   if (upload_constants(P, 0)) return 1;
@@ -938,7 +950,6 @@ static int run_group(pbc_hip_pairing_s *P, int what, int group, uint8_t *out, co
   }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpy(out, d_o, n * lo, hipMemcpyDeviceToHost));
-  (void) hipFree(da); (void) hipFree(db); (void) hipFree(d_o);
   return 0;
 }
 extern "C" int pbc_hip_element_mul_zn_batch(pbc_hip_pairing_t *P, int group, uint8_t *out, const uint8_t *in,
@@ -962,17 +973,17 @@ extern "C" int pbc_hip_element_pow_zn_GT_batch(pbc_hip_pairing_t *P, uint8_t *ou
 static int ensure_sqrt_constants(pbc_hip_pairing_s *P) {
   if (!P->hash.ts_ready) {
     if (upload_constants(P, 0)) return 1;
-    uint32_t *dc = nullptr;
+    DevBuf bc;
     TsRaw raw;
     memcpy(raw.t, P->hash.ts_t, sizeof raw.t);
     memcpy(raw.half, P->hash.half, sizeof raw.half);
     raw.tbits = P->hash.ts_tbits;
     raw.halfbits = P->hash.halfbits;
-    HIP_TRY(hipMalloc(&dc, sizeof P->hash.ts_c));
+    HIP_TRY(bc.alloc(sizeof P->hash.ts_c));
+    uint32_t *dc = bc.as<uint32_t>();
     HIP_TRY(hipMemset(dc, 0, sizeof P->hash.ts_c));
     PBC_DISPATCH_N(P->nlimb, hipLaunchKernelGGL(ts_init_kernel<N>, dim3(1), dim3(64), 0, 0, dc, raw));
     HIP_TRY(hipMemcpy(P->hash.ts_c, dc, sizeof P->hash.ts_c, hipMemcpyDeviceToHost));
-    (void) hipFree(dc);
     P->hash.ts_ready = true;
   }
   return 0;
@@ -987,11 +998,12 @@ static int run_compress(pbc_hip_pairing_s *P, int dir, int group, uint8_t *out, 
   if (!n) return 0;
   const size_t lp = (size_t) P->len1, lc = (size_t) P->len_fq + 1;
   const size_t li = dir == 0 ? lp : lc, lo = dir == 0 ? lc : lp;
-  void *di = nullptr, *d_o = nullptr;
+  DevBuf bi, bo;
   HIP_TRY(hipSetDevice(P->device));
   if (ensure_sqrt_constants(P)) return 1;
-  HIP_TRY(hipMalloc(&di, n * li));
-  HIP_TRY(hipMalloc(&d_o, n * lo));
+  HIP_TRY(bi.alloc(n * li));
+  HIP_TRY(bo.alloc(n * lo));
+  void *di = bi.p, *d_o = bo.p;
   HIP_TRY(hipMemcpy(di, in, n * li, hipMemcpyHostToDevice));
   if (upload_constants(P, 0)) return 1;
   unsigned grid = (unsigned) ((n + kBlock - 1) / kBlock);
@@ -999,7 +1011,6 @@ static int run_compress(pbc_hip_pairing_s *P, int dir, int group, uint8_t *out, 
                                               (const uint8_t *) di, n));
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpy(out, d_o, n * lo, hipMemcpyDeviceToHost));
-  (void) hipFree(di); (void) hipFree(d_o);
   return 0;
 }
 extern "C" int pbc_hip_element_to_bytes_compressed_batch(pbc_hip_pairing_t *P, int group, uint8_t *out,
@@ -1021,11 +1032,12 @@ extern "C" int pbc_hip_element_from_hash_batch(pbc_hip_pairing_t *P, int group, 
     return fail("element_from_hash is built for G1 (and G2 of the symmetric types a, a1, e)");
   if (hlen < 1) return fail("hlen must be >= 1");
   if (!n) return 0;
-  void *dd = nullptr, *d_o = nullptr;
+  DevBuf bd, bo;
   HIP_TRY(hipSetDevice(P->device));
   if (ensure_sqrt_constants(P)) return 1;
-  HIP_TRY(hipMalloc(&dd, n * (size_t) hlen));
-  HIP_TRY(hipMalloc(&d_o, n * (size_t) P->len1));
+  HIP_TRY(bd.alloc(n * (size_t) hlen));
+  HIP_TRY(bo.alloc(n * (size_t) P->len1));
+  void *dd = bd.p, *d_o = bo.p;
   HIP_TRY(hipMemcpy(dd, data, n * (size_t) hlen, hipMemcpyHostToDevice));
   if (upload_constants(P, 0)) return 1;
   unsigned grid = (unsigned) ((n + kBlock - 1) / kBlock);
@@ -1033,7 +1045,6 @@ extern "C" int pbc_hip_element_from_hash_batch(pbc_hip_pairing_t *P, int group, 
                                               (const uint8_t *) dd, hlen, n));
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpy(out, d_o, n * (size_t) P->len1, hipMemcpyDeviceToHost));
-  (void) hipFree(dd); (void) hipFree(d_o);
   return 0;
 }
 
@@ -1117,15 +1128,13 @@ extern "C" int pbc_hip_pairing_pp_apply_batch(pbc_hip_pp_t *pp, uint8_t *gt, con
   if (!pp) return fail("null pp");
   if (!n) return 0;
   pbc_hip_pairing_s *P = pp->P;
-  void *d2 = nullptr, *dt = nullptr;
+  DevBuf b2, bt;
   HIP_TRY(hipSetDevice(P->device));
-  HIP_TRY(hipMalloc(&d2, n * P->len2));
-  HIP_TRY(hipMalloc(&dt, n * P->lenT));
-  HIP_TRY(hipMemcpy(d2, g2, n * P->len2, hipMemcpyHostToDevice));
-  int rc = pbc_hip_pairing_pp_apply_batch_dev(pp, dt, d2, n, 0);
-  if (!rc && hipMemcpy(gt, dt, n * P->lenT, hipMemcpyDeviceToHost) != hipSuccess) rc = fail("D2H copy failed");
-  (void) hipFree(d2);
-  (void) hipFree(dt);
+  HIP_TRY(b2.alloc(n * P->len2));
+  HIP_TRY(bt.alloc(n * P->lenT));
+  HIP_TRY(hipMemcpy(b2.p, g2, n * P->len2, hipMemcpyHostToDevice));
+  int rc = pbc_hip_pairing_pp_apply_batch_dev(pp, bt.p, b2.p, n, 0);
+  if (!rc && hipMemcpy(gt, bt.p, n * P->lenT, hipMemcpyDeviceToHost) != hipSuccess) rc = fail("D2H copy failed");
   return rc;
 }
 
@@ -1184,13 +1193,15 @@ extern "C" int pbc_hip_fq_op_batch(pbc_hip_pairing_t *P, int op, uint8_t *c, con
   if (!n) return 0;
   if (op < 0 || op > 6) return fail("bad op");
   size_t bytes = n * (size_t) P->len_fq;
-  void *da = nullptr, *db = nullptr, *dc = nullptr;
+  DevBuf ba, bb, bc;
   HIP_TRY(hipSetDevice(P->device));
-  HIP_TRY(hipMalloc(&da, bytes));
-  HIP_TRY(hipMalloc(&dc, bytes));
+  HIP_TRY(ba.alloc(bytes));
+  HIP_TRY(bc.alloc(bytes));
+  void *da = ba.p, *db = nullptr, *dc = bc.p;
   HIP_TRY(hipMemcpy(da, a, bytes, hipMemcpyHostToDevice));
   if (b) {
-    HIP_TRY(hipMalloc(&db, bytes));
+    HIP_TRY(bb.alloc(bytes));
+    db = bb.p;
     HIP_TRY(hipMemcpy(db, b, bytes, hipMemcpyHostToDevice));
   }
   if (upload_constants(P, 0)) return 1;
@@ -1199,9 +1210,6 @@ extern "C" int pbc_hip_fq_op_batch(pbc_hip_pairing_t *P, int op, uint8_t *c, con
                                               (const uint8_t *) da, (const uint8_t *) db, n));
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpy(c, dc, bytes, hipMemcpyDeviceToHost));
-  (void) hipFree(da);
-  (void) hipFree(dc);
-  if (db) (void) hipFree(db);
   return 0;
 }
 

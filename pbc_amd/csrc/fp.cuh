@@ -27,8 +27,8 @@ struct FpK {            // wave-uniform field constants (field_init_mont_fp, mon
   uint32_t pm2[N];      // q - 2 (Fermat exponent)
   uint32_t ninv;        // -q^-1 mod 2^32   (32-bit-limb product scanning, variant 0)
   uint32_t pbits;       // bit length of q
-  uint32_t p29[(32 * N + 28) / 29];   // q in 29-bit limbs (unsaturated multiplier)
-  uint32_t ninv29;      // -q^-1 mod 2^29
+  uint32_t p29[(32 * N + 27) / 28];   // q in 29-bit limbs (28-bit for N >= 32; unsaturated multiplier)
+  uint32_t ninv29;      // -q^-1 mod 2^29 (2^28)
   uint32_t r3[N];       // R^3 mod q (puts an inverse back into Montgomery form, cf. montfp.c:417)
   uint32_t p30[(32 * N + 2 + 29) / 30];   // q in 30-bit limbs (safegcd inversion)
   uint32_t qinv30;      // q^-1 mod 2^30
@@ -138,37 +138,42 @@ PBC_DEV void fp_mul32_inl(fp<N> &r, const fp<N> &a, const fp<N> &b) {
 // Measured on MI355X: v_mad_u64_u32 issues every ~4.2 cycles (3.5 with an SGPR factor)
 // against 7.5 for the mad+addc pair of the saturated form (profiles/r01_probe_v1.txt).
 // ---------------------------------------------------------------------------------------
+// Limb width: 29 bits, except 28 for the 33-word fields -- with L = 37 limbs of 29 bits a column would
+// hold up to 74 products of 2^58, which overflows 64 bits for moduli with dense limbs; 38 limbs of 28
+// bits (76 x 2^56 = 2^62.3) are safe for every modulus at +5 % multiply-adds.
 template <int N>
 struct Limbs29 {
-  static constexpr int L = (32 * N + 28) / 29;
-  static constexpr uint32_t MASK = (1u << 29) - 1;
+  static constexpr int W = N >= 32 ? 28 : 29;
+  static constexpr int L = (32 * N + W - 1) / W;
+  static constexpr uint32_t MASK = (1u << W) - 1;
+  static_assert(2 * L * (1ull << (2 * W - 56)) < 256, "column accumulator would overflow");   // 2L 2^(2W) < 2^64
 };
 
 template <int N>
 PBC_DEV void to29(uint32_t *l, const fp<N> &a) {
-  constexpr int L = Limbs29<N>::L;
+  constexpr int L = Limbs29<N>::L, W = Limbs29<N>::W;
 #pragma unroll
   for (int i = 0; i < L; i++) {
-    const int bit = 29 * i, j = bit >> 5, sh = bit & 31;
+    const int bit = W * i, j = bit >> 5, sh = bit & 31;
     uint32_t lo = a.v[j];
     uint32_t x;
     if (sh == 0) x = lo;
-    else if (sh + 29 <= 32 || j + 1 >= N) x = lo >> sh;
+    else if (sh + W <= 32 || j + 1 >= N) x = lo >> sh;
     else x = __builtin_amdgcn_alignbit(a.v[j + 1 < N ? j + 1 : j], lo, sh);
-    l[i] = (32 * N - bit >= 29 && sh + 29 != 32) ? (x & Limbs29<N>::MASK) : x;
+    l[i] = (32 * N - bit >= W && sh + W != 32) ? (x & Limbs29<N>::MASK) : x;
   }
 }
 // L normalised limbs (+ the value may reach 2^(32N)) -> N words + carry word
 template <int N>
 PBC_DEV uint32_t from29(uint32_t *w, const uint32_t *l) {
-  constexpr int L = Limbs29<N>::L;
+  constexpr int L = Limbs29<N>::L, W = Limbs29<N>::W;
 #pragma unroll
   for (int j = 0; j <= N; j++) {
-    const int bit = 32 * j, i = bit / 29, o = bit - 29 * i;
+    const int bit = 32 * j, i = bit / W, o = bit - W * i;
     uint32_t x = 0;
     if (i < L) x = l[i] >> o;
-    if (i + 1 < L) x |= l[i + 1] << (29 - o);
-    if (58 - o < 32 && i + 2 < L) x |= l[i + 2] << (58 - o);
+    if (i + 1 < L) x |= l[i + 1] << (W - o);
+    if (2 * W - o < 32 && i + 2 < L) x |= l[i + 2] << (2 * W - o);
     if (j < N) w[j] = x; else return x;
   }
   return 0;
@@ -199,7 +204,7 @@ PBC_DEV void fp_mul29_inl(fp<N> &r, const fp<N> &a, const fp<N> &b) {
     if (ACC2) { acc += acc1; acc1 = 0; }
     m[k] = ((uint32_t) acc * K.ninv29) & MASK;
     acc += (uint64_t) m[k] * K.p29[0];
-    acc >>= 29;
+    acc >>= Limbs29<N>::W;
   }
 #pragma unroll
   for (int k = L; k < 2 * L; k++) {
@@ -209,7 +214,7 @@ PBC_DEV void fp_mul29_inl(fp<N> &r, const fp<N> &a, const fp<N> &b) {
     for (int i = k - L + 1; i < L; i++) PBC_MAC(i + 1, m[i], K.p29[k - i]);
     if (ACC2) { acc += acc1; acc1 = 0; }
     t[k - L] = (uint32_t) acc & MASK;
-    acc >>= 29;
+    acc >>= Limbs29<N>::W;
   }
   uint32_t w[N];
   uint32_t carry = from29<N>(w, t);
@@ -238,7 +243,7 @@ PBC_DEV void fp_sqr29_inl(fp<N> &r, const fp<N> &a) {
     if (ACC2) { acc += acc1; acc1 = 0; }
     m[k] = ((uint32_t) acc * K.ninv29) & MASK;
     acc += (uint64_t) m[k] * K.p29[0];
-    acc >>= 29;
+    acc >>= Limbs29<N>::W;
   }
 #pragma unroll
   for (int k = L; k < 2 * L; k++) {
@@ -249,7 +254,7 @@ PBC_DEV void fp_sqr29_inl(fp<N> &r, const fp<N> &a) {
     for (int i = k - L + 1; i < L; i++) PBC_MAC(i, m[i], K.p29[k - i]);
     if (ACC2) { acc += acc1; acc1 = 0; }
     t[k - L] = (uint32_t) acc & MASK;
-    acc >>= 29;
+    acc >>= Limbs29<N>::W;
   }
   uint32_t w[N];
   uint32_t carry = from29<N>(w, t);
@@ -276,7 +281,7 @@ PBC_DEV void sqr_limbs(uint32_t *t, const uint32_t *x) {
     for (int i = 0; i < k; i++) acc += (uint64_t) m[i] * K.p29[k - i];
     m[k] = ((uint32_t) acc * K.ninv29) & MASK;
     acc += (uint64_t) m[k] * K.p29[0];
-    acc >>= 29;
+    acc >>= Limbs29<N>::W;
   }
 #pragma unroll
   for (int k = L; k < 2 * L; k++) {
@@ -286,7 +291,7 @@ PBC_DEV void sqr_limbs(uint32_t *t, const uint32_t *x) {
 #pragma unroll
     for (int i = k - L + 1; i < L; i++) acc += (uint64_t) m[i] * K.p29[k - i];
     t[k - L] = (uint32_t) acc & MASK;
-    acc >>= 29;
+    acc >>= Limbs29<N>::W;
   }
 }
 
@@ -320,7 +325,7 @@ PBC_DEV void sop_limbs(fl<N> &r, const fl<N> (&x)[T], const fl<N> (&y)[T]) {
   const FpK<N> &K = fpk<N>();
   constexpr int L = Limbs29<N>::L;
   constexpr uint32_t MASK = Limbs29<N>::MASK;
-  static_assert((T + DBL) * L + L <= 63, "column accumulator would overflow");
+  static_assert(Limbs29<N>::W == 29 && (T + DBL) * L + L <= 63, "column accumulator would overflow");
   uint32_t m[L];
   uint64_t acc = 0;
 #pragma unroll
@@ -333,7 +338,7 @@ PBC_DEV void sop_limbs(fl<N> &r, const fl<N> (&x)[T], const fl<N> (&y)[T]) {
     for (int i = 0; i < k; i++) acc += (uint64_t) m[i] * K.p29[k - i];
     m[k] = ((uint32_t) acc * K.ninv29) & MASK;
     acc += (uint64_t) m[k] * K.p29[0];
-    acc >>= 29;
+    acc >>= Limbs29<N>::W;
   }
 #pragma unroll
   for (int k = L; k < 2 * L; k++) {
@@ -344,7 +349,7 @@ PBC_DEV void sop_limbs(fl<N> &r, const fl<N> (&x)[T], const fl<N> (&y)[T]) {
 #pragma unroll
     for (int i = k - L + 1; i < L; i++) acc += (uint64_t) m[i] * K.p29[k - i];
     r.l[k - L] = (uint32_t) acc & MASK;
-    acc >>= 29;
+    acc >>= Limbs29<N>::W;
   }
 }
 
@@ -383,7 +388,7 @@ PBC_DEV void wide_reduce(fl<N> &r, const wide<N> &W) {
     for (int i = 0; i < k; i++) acc += (uint64_t) m[i] * K.p29[k - i];
     m[k] = ((uint32_t) acc * K.ninv29) & MASK;
     acc += (uint64_t) m[k] * K.p29[0];
-    acc >>= 29;
+    acc >>= Limbs29<N>::W;
   }
 #pragma unroll
   for (int k = L; k < 2 * L; k++) {
@@ -391,7 +396,7 @@ PBC_DEV void wide_reduce(fl<N> &r, const wide<N> &W) {
 #pragma unroll
     for (int i = k - L + 1; i < L; i++) acc += (uint64_t) m[i] * K.p29[k - i];
     r.l[k - L] = (uint32_t) acc & MASK;
-    acc >>= 29;
+    acc >>= Limbs29<N>::W;
   }
 }
 

@@ -107,17 +107,6 @@ static int fill_hash_consts(pbc_hip_pairing_s *P, const pbc_host::Big &q, const 
   return 0;
 }
 
-// set when fill_fpk refuses a modulus whose limbs are too dense for the column accumulator (only
-// possible for the 33-word fields): the type-specific message is replaced by dense_or()
-static thread_local bool g_fpk_dense = false;
-static int dense_or(int rc) {
-  if (rc && g_fpk_dense) {
-    g_fpk_dense = false;
-    return fail("modulus not supported: its 29-bit limbs are too dense for the 64-bit column accumulator of the "
-                "33-word multiplier (a random-looking modulus of this size is fine; 2^k - c shaped ones are not)");
-  }
-  return rc;
-}
 // min_bits: smallest modulus accepted for this word count (default: the top word is in use)
 template <int N>
 static int fill_fpk(FpK<N> &K, const pbc_host::Big &q, int min_bits = 32 * (N - 1) + 1) {
@@ -128,13 +117,13 @@ static int fill_fpk(FpK<N> &K, const pbc_host::Big &q, int min_bits = 32 * (N - 
 #if PBC_MUL_IMPL == 0
   const int rbits = 32 * N;
 #else
-  const int rbits = 29 * Limbs29<N>::L;
+  const int rbits = Limbs29<N>::W * Limbs29<N>::L;
 #endif
   Big::pow2_mod(rbits, q).to_words(K.one, N);
   Big::pow2_mod(2 * rbits, q).to_words(K.r2, N);
   for (int i = 0; i < Limbs29<N>::L; i++) {
     uint32_t v = 0;
-    for (int b = 0; b < 29; b++) v |= (uint32_t) q.bit(29 * i + b) << b;
+    for (int b = 0; b < Limbs29<N>::W; b++) v |= (uint32_t) q.bit(Limbs29<N>::W * i + b) << b;
     K.p29[i] = v;
   }
   K.ninv29 = pbc_host::neg_inv32(K.p[0]) & Limbs29<N>::MASK;
@@ -151,29 +140,6 @@ static int fill_fpk(FpK<N> &K, const pbc_host::Big &q, int min_bits = 32 * (N - 
   K.ninv = pbc_host::neg_inv32(K.p[0]);
   K.pbits = (uint32_t) q.bits();
   K.fbytes = (uint32_t) ((q.bits() + 7) / 8);
-  // The multiplier sums up to 2L products of 29-bit limbs in one 64-bit column accumulator; for
-  // L > 31 that only fits because the top limbs of reduced operands and of q are short.  Check the
-  // worst column for THIS modulus: sum_{i+j=k} amax_i bmax_j + (2^29 - 1) sum_{j<=k} q_j + carry.
-  {
-    constexpr int L = Limbs29<N>::L;
-    long double worst = 0;
-    for (int k = 0; k < 2 * L - 1; k++) {
-      long double sum = 68719476736.0L;              // carry from the previous column, < 2^36
-      for (int i = 0; i < L; i++) {
-        const int j = k - i;
-        if (j < 0 || j >= L) continue;
-        // one operand may be an unreduced wire value of fbytes bytes (fp_load_be reduces it by a product)
-        auto lmax = [&](int t, int bits) -> long double {
-          const int lo = 29 * t;
-          if (lo >= bits) return 0.0L;
-          return bits - lo >= 29 ? 536870911.0L : (long double) ((1u << (bits - lo)) - 1);
-        };
-        sum += lmax(i, 8 * (int) K.fbytes) * lmax(j, q.bits()) + 536870911.0L * (long double) K.p29[j];
-      }
-      if (sum > worst) worst = sum;
-    }
-    if (worst >= 18446744073709551616.0L) { g_fpk_dense = true; return 1; }  // 2^64
-  }
   return 0;
 }
 
@@ -224,7 +190,7 @@ static int init_type_a(pbc_hip_pairing_s *P, const char *txt, size_t len) {
     if (q.bits() < 160 || r.bits() > 34 * 32 - 1 || r.bits() < 3)
       return fail("type a: only 160..1056-bit q is supported by this build (got %d bits)", q.bits());
     if (q.bits() <= 512 ? fill_fpk<16>(P->k16, q, 160) : fill_fpk<33>(P->k33, q, 513))
-      return g_fpk_dense ? dense_or(1) : fail("type a: only 160..1056-bit q is supported by this build (got %d bits)", q.bits());
+      return fail("type a: only 160..1056-bit q is supported by this build (got %d bits)", q.bits());
     P->nlimb = q.bits() <= 512 ? 16 : 33;
     P->a_generic = true;
     r.to_words(P->a.r, 34);
@@ -252,7 +218,7 @@ static int init_type_a1(pbc_hip_pairing_s *P, const char *txt, size_t len) {
     return fail("type a1: missing p/n/l");
   // a1.param is 1033 bits (33 words); smaller orders run on the 16-word arithmetic
   if (p.bits() <= 512 ? fill_fpk<16>(P->k16, p, 160) : fill_fpk<33>(P->k33, p, 513))
-    return g_fpk_dense ? dense_or(1) : fail("type a1: only 160..1056-bit p is supported by this build (got %d bits)", p.bits());
+    return fail("type a1: only 160..1056-bit p is supported by this build (got %d bits)", p.bits());
   if ((p.w[0] & 3) != 3) return fail("type a1: p must be 3 mod 4");
   {
     Big pp1 = p;
@@ -300,7 +266,7 @@ static int init_type_e(pbc_hip_pairing_s *P, const char *txt, size_t len) {
       !param_big(txt, len, "b", b))
     return fail("type e: missing q/r/a/b");
   if (q.bits() <= 512 ? fill_fpk<16>(P->k16, q, 160) : fill_fpk<33>(P->k33, q, 513))
-    return g_fpk_dense ? dense_or(1) : fail("type e: only odd 160..1056-bit q is supported by this build (got %d bits)", q.bits());
+    return fail("type e: only odd 160..1056-bit q is supported by this build (got %d bits)", q.bits());
   if (Big::cmp(a, q) >= 0 || Big::cmp(b, q) >= 0) return fail("type e: coefficient >= q");
   if (r.bits() > 256 || r.bits() < 3 || !(r.w[0] & 1)) return fail("type e: bad r");
   memset(&P->eraw, 0, sizeof P->eraw);

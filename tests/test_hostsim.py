@@ -140,3 +140,20 @@ def test_compressed_points_on_host(sims, key, name):
     n = min(v.n, 6)
     assert np.array_equal(sims[key].compress(0, v.g1[:n]), v.gt[:n])
     assert np.array_equal(sims[key].compress(1, v.gt[:n]), v.g1[:n])
+
+
+def test_dense_wide_modulus_products_on_host():
+    """worst case for the column accumulator of the 33-word product: a 2^1033 - c shaped odd modulus (every
+    limb of q full) and operands with every limb full -- products and squares against Python integers."""
+    n = ((1 << 1031) - 12345) | 1
+    p = 4 * n - 1
+    S = hostsim.HostSim("type a1\np %d\nn %d\nl 4\n" % (p, n))
+    nb = (p.bit_length() + 7) // 8
+    vals = [p - 1, p - 2, (1 << 1032) - 1, (1 << 1033) - 1 - (1 << 500), 1, 2]
+    xs = [v % p for v in vals for _ in vals]
+    ys = [v % p for _ in vals for v in vals]
+    A = np.stack([np.frombuffer(x.to_bytes(nb, "big"), np.uint8) for x in xs])
+    B = np.stack([np.frombuffer(y.to_bytes(nb, "big"), np.uint8) for y in ys])
+    got = S.fq_op(0, A, B)
+    want = np.stack([np.frombuffer((x * y % p).to_bytes(nb, "big"), np.uint8) for x, y in zip(xs, ys)])
+    assert np.array_equal(got, want)

@@ -157,3 +157,25 @@ def test_dense_wide_modulus_products_on_host():
     got = S.fq_op(0, A, B)
     want = np.stack([np.frombuffer((x * y % p).to_bytes(nb, "big"), np.uint8) for x, y in zip(xs, ys)])
     assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("key,name", [("a", "a_rand32.vec"), ("d", "d_rand32.vec"), ("f", "f_rand16.vec"), ("g149", "g149_rand16.vec"),
+                                      ("e_160_400", "e_160_400_rand6.vec"), ("a_150_300_mm", "a_150_300_mm_rand6.vec"),
+                                      ("f_256", "f_256_rand4.vec"), ("d224", "d224_rand12.vec")])
+def test_fresh_points_kernel_source_vs_oracle(sims, oracles, key, name):
+    """inputs no fixture holds: random multiples [k]P of the fixture's G1 points (computed by the oracle)
+    paired with its G2 points, through the kernel source on the host and through the oracle; plus
+    e([k]P, Q) = e(P, Q)^k with the power taken by the kernel source."""
+    v = golden(name)
+    S, O = sims[key], oracles[key]
+    n = 3
+    r = param_value(key, "r")
+    zl = (r.bit_length() + 7) // 8
+    rng = np.random.default_rng(53)
+    ks = [int.from_bytes(rng.bytes(zl), "big") % (r - 1) + 1 for _ in range(n)]
+    Z = np.stack([np.frombuffer(k.to_bytes(zl, "big"), np.uint8) for k in ks])
+    kP = O.g_mul(1, v.g1[:n], Z)
+    got = S.prod_pairing(kP, v.g2[1:n + 1], 1)
+    assert np.array_equal(got, O.pairing_batch(kP, v.g2[1:n + 1]))
+    same = S.prod_pairing(kP, v.g2[:n], 1)
+    assert np.array_equal(same, S.group(2, v.gt[:n], Z))

@@ -4,6 +4,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #include "pbc_hip_glue.h"
 
 int main(int argc, char **argv) {
@@ -18,6 +19,32 @@ int main(int argc, char **argv) {
   pbc_random_set_deterministic(4242);
   pairing_t pairing;
   if (pairing_init_set_buf(pairing, text, len)) return 2;
+  if (argc > 3 && !strcmp(argv[3], "bench")) {
+    /* throughput of element_pairing_batch THROUGH the PBC element API: n element_t pairs (64 distinct
+     * points, shallow copies) -> n GT elements; dominated by element_to_bytes / element_from_bytes */
+    enum { D = 64 };
+    element_t p0[D], q0[D];
+    for (int i = 0; i < D; i++) {
+      element_init_G1(p0[i], pairing); element_init_G2(q0[i], pairing);
+      element_random(p0[i]); element_random(q0[i]);
+    }
+    element_t *Pb = malloc(sizeof(element_t) * n), *Qb = malloc(sizeof(element_t) * n), *Ob = malloc(sizeof(element_t) * n);
+    for (size_t i = 0; i < n; i++) { Pb[i][0] = p0[i % D][0]; Qb[i][0] = q0[(i / D) % D][0]; element_init_GT(Ob[i], pairing); }
+    if (pbc_hip_attach(pairing, text, len)) { printf("ATTACH FAILED\n"); return 1; }
+    if (element_pairing_batch(Ob, Pb, Qb, n < 4096 ? n : 4096)) { printf("batch call failed\n"); return 1; }   /* warm-up */
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    if (element_pairing_batch(Ob, Pb, Qb, n)) { printf("batch call failed\n"); return 1; }
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    double dt = (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec);
+    element_t chk;
+    element_init_GT(chk, pairing);
+    pbc_hip_detach(pairing);
+    element_pairing(chk, Pb[n - 1], Qb[n - 1]);                     /* CPU */
+    printf("%s: element_pairing_batch of %zu element_t pairs: %.3f s = %.0f pairs/s (%s)\n", argv[1], n, dt, n / dt,
+           element_cmp(chk, Ob[n - 1]) ? "MISMATCH" : "last result equals the CPU pairing");
+    return element_cmp(chk, Ob[n - 1]) ? 1 : 0;
+  }
   int fails = 0, K = 4;
   element_t *P = malloc(sizeof(element_t) * n), *Q = malloc(sizeof(element_t) * n);
   element_t *cpu = malloc(sizeof(element_t) * n), *gpu = malloc(sizeof(element_t) * n);

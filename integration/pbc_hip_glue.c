@@ -2,6 +2,8 @@
 #include "pbc_hip_glue.h"
 
 #include <dlfcn.h>
+#include <pthread.h>
+#include <unistd.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -64,9 +66,52 @@ static int load_lib(void) {
   return 0;
 }
 
+/* Worker threads for the element <-> bytes conversions of the batch calls (each costs a Montgomery
+ * reduction and a GMP export per coordinate; for 2^20 pairs that is seconds on one core, far more than
+ * the GPU needs).  PBC_HIP_GLUE_THREADS overrides the default of min(online CPUs, 16). */
+typedef struct { void (*fn)(size_t lo, size_t hi, void *ctx); void *ctx; size_t lo, hi; } job_t;
+static void *job_main(void *arg) { job_t *j = arg; j->fn(j->lo, j->hi, j->ctx); return NULL; }
+static void parallel_for(size_t n, void (*fn)(size_t, size_t, void *), void *ctx) {
+  long nt = sysconf(_SC_NPROCESSORS_ONLN);
+  const char *e = getenv("PBC_HIP_GLUE_THREADS");
+  if (e) nt = atol(e);
+  if (nt > 16) nt = 16;
+  if (nt < 1 || n < 256) nt = 1;
+  if (nt == 1) { fn(0, n, ctx); return; }
+  pthread_t th[16];
+  job_t job[16];
+  int started = 0;
+  for (long t = 0; t < nt; t++) {
+    job[t].fn = fn; job[t].ctx = ctx;
+    job[t].lo = n * (size_t) t / (size_t) nt; job[t].hi = n * (size_t) (t + 1) / (size_t) nt;
+    if (t + 1 == nt || pthread_create(&th[t], NULL, job_main, &job[t])) { fn(job[t].lo, t + 1 == nt ? job[t].hi : n, ctx); break; }
+    started++;
+  }
+  for (int t = 0; t < started; t++) pthread_join(th[t], NULL);
+}
+typedef struct {
+  element_t *in1, *in2, *out;
+  unsigned char *b1, *b2, *bt;
+  size_t *slot;
+  int k, l1, l2, lt;
+} conv_t;
+static void to_bytes_range(size_t lo, size_t hi, void *ctx) {
+  conv_t *c = ctx;
+  for (size_t i = lo; i < hi; i++) {
+    const size_t u = c->slot[i];
+    for (int j = 0; j < c->k; j++) {
+      element_to_bytes(c->b1 + (i * c->k + j) * c->l1, c->in1[u * c->k + j]);
+      element_to_bytes(c->b2 + (i * c->k + j) * c->l2, c->in2[u * c->k + j]);
+    }
+  }
+}
+static void from_bytes_range(size_t lo, size_t hi, void *ctx) {
+  conv_t *c = ctx;
+  for (size_t i = lo; i < hi; i++) element_from_bytes(c->out[c->slot[i]], c->bt + i * c->lt);
+}
+
 /* n*k (in1, in2) terms -> n GT results.  `out` are GT elements (the mulg wrapper, ecc/pairing.c:135-283). */
 static int run_batch(attach_t *a, element_t out[], element_t in1[], element_t in2[], size_t n, int k) {
-  struct pairing_s *p = a->pairing;
   int l1 = L.len1(a->gpu), l2 = L.len2(a->gpu), lt = L.lenT(a->gpu);
   size_t terms = n * (size_t) k, m = 0;
   unsigned char *b1 = malloc(terms * l1 + 1), *b2 = malloc(terms * l2 + 1), *bt = malloc(n * lt + 1);
@@ -78,19 +123,16 @@ static int run_batch(attach_t *a, element_t out[], element_t in1[], element_t in
     int ident = 0;
     for (int j = 0; j < k; j++) if (element_is0(in1[u * k + j]) || element_is0(in2[u * k + j])) ident = 1;
     if (ident) { element_set0(out[u]); continue; }
-    for (int j = 0; j < k; j++) {
-      element_to_bytes(b1 + (m * k + j) * l1, in1[u * k + j]);
-      element_to_bytes(b2 + (m * k + j) * l2, in2[u * k + j]);
-    }
     slot[m++] = u;
   }
+  conv_t c = {in1, in2, out, b1, b2, bt, slot, k, l1, l2, lt};
   int rc = 0;
   if (m) {
+    parallel_for(m, to_bytes_range, &c);
     rc = k == 1 ? L.pair(a->gpu, bt, b1, b2, m) : L.prod(a->gpu, bt, b1, b2, m, k);
     if (rc) fprintf(stderr, "pbc_hip: %s\n", L.err());
-    else for (size_t i = 0; i < m; i++) element_from_bytes(out[slot[i]], bt + i * lt);
+    else parallel_for(m, from_bytes_range, &c);
   }
-  (void) p;
   free(b1); free(b2); free(bt); free(slot);
   return rc;
 }

@@ -28,8 +28,11 @@ extern "C" {
 typedef struct pbc_hip_pairing_s pbc_hip_pairing_t;
 
 /* Replaces pairing_init_set_buf / pairing_init_set_str (include/pbc_pairing.h:95-102,
- * ecc/pairing.c:88-106): parse a PBC parameter text ("type a" / "type d" / "type f" ...),
- * derive the per-curve constants (a_init_pairing ecc/a_param.c:1431-1472) and bind the
+ * ecc/pairing.c:88-106): parse a PBC parameter text (types a, a1, d, e, f, g; field sizes: a / a1 / e
+ * up to 1056 bits, d up to 224, f up to 256, g 160), derive the per-curve constants (a_init_pairing
+ * ecc/a_param.c:1431-1472, a1_init_pairing :2230-2273, d_init_pairing ecc/d_param.c:993-1095,
+ * e_init_pairing ecc/e_param.c:832-872, f_init_pairing ecc/f_param.c:335-447, g_init_pairing
+ * ecc/g_param.c:1248-1354) and bind the
  * object to the calling thread's current HIP device.  len == 0 means strlen(param). */
 int pbc_hip_pairing_init_set_buf(pbc_hip_pairing_t **out, const char *param, size_t len);
 /* Replaces pairing_clear (include/pbc_pairing.h:109-116). */

@@ -11,6 +11,7 @@
 #include "hostbn.h"
 #include "pairing_a.cuh"
 #include "pairing_d.cuh"
+#include "pairing_d_lazy.cuh"
 #include "pairing_f.cuh"
 #include "pairing_e.cuh"
 #include "group_ops.cuh"
@@ -52,6 +53,8 @@ struct pbc_hip_pairing_s {
   ERaw eraw;                 // type E: integers for the one-time search of the auxiliary point
   EConst econst;             // type E: curve, auxiliary point, exponents (filled on first use)
   bool dev_ready;            // derived constants computed on the device
+  bool dlazy_ready;          // experiment: 28-bit-limb constants of pairing_d_lazy.cuh derived
+  DLazyConst dlazy;
   int len_zr;                // bytes of a Z_r scalar (pairing_length_in_bytes_Zr)
   double fq_muls_single;     // reference F_q multiplication count per pairing (work model)
   double fq_muls_prod_a, fq_muls_prod_b;   // products: a*k + b

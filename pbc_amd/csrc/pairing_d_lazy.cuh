@@ -1,0 +1,744 @@
+// pairing_d_lazy.cuh -- EXPERIMENT (not the default path; PBC_HIP_D_LAZY=1 selects it): the type d (k = 6)
+// pairing of pairing_d.cuh for 5-word fields (q up to 160 bits: d159.param) with F_q elements kept as SIGNED
+// 28-bit limbs between operations.
+//
+// Why: the type d kernel is bound by VALU instruction issue, and 45 % of what it issues is not multiply-add:
+// conversions between saturated words and the multiplier's limbs, conditional subtractions, modular add/sub
+// carry chains (tools/isa_count.py prices each routine).  Here an element is L = 6 int32 limbs,
+// value = sum l_i 2^(28 i), congruent to x R' mod q with R' = 2^168:
+//   * 28-bit limbs in 32-bit registers leave three bits of headroom, and 6 x 28 = 168 bits leave 2^8 q of
+//     headroom on the value: sums, differences, doublings and negations are plain limbwise operations without
+//     any carry or modular correction (limbs are signed, so subtraction needs no offset);
+//   * products, squares and sums of products accumulate signed 64-bit columns (v_mad_i64_i32) with the
+//     Montgomery reduction on the fly; the result has limbs 0..4 in [0, 2^28), a small signed top limb and
+//     magnitude below 1.25 q: no conversion and no conditional subtraction on the way in or out;
+//   * norm() (one parallel carry pass) is placed only where the bounds below require it;
+//   * canonical residues exist at the byte interface, in equality tests and around the one inversion.
+// Bounds, with g = limb growth (|l_i| <= g 2^28 for i < 5) and gv = |value| / q:
+//   limbs:    g <= 7                                   (int32)
+//   columns:  5 (sum_t g_x g_y + 1) 2^56 < 2^63        -> sum_t g_x g_y <= 24   (5 = most full-size products per
+//             term in one column; top limbs are below 2^24 because gv <= 32)
+//   values:   |sum_t x_t y_t| / R' + q < 1.25 q        for sum_t gv_x gv_y <= 128 (q / R' < 2^-9)
+// Both g and gv depend on control flow only, never on data; the host mirror (tests/hostsim) carries them along
+// with every element and aborts when a bound is exceeded, which checks every call site for all inputs.
+// Same algorithms and reference citations as TypeMNT<5, 3>; only the representation differs.
+#pragma once
+#include "pairing_d.cuh"
+
+namespace pbc {
+
+struct DLazyConst {                    // c_d and the field constants in 28-bit limb form (R' = 2^168)
+  int32_t A[6], B[6], nqr[6], nqrinv[6], nqrinv2[6], ta[6], tb[6];
+  int32_t xpwr[2][3][6], xpowq[2][3][6];
+  int32_t one[6], two[6], half[6];     // R', 2 R', R'/2 mod q
+  int32_t k_in[6];                     // R'^2 mod q: plain residue -> Montgomery form
+  uint32_t p[6], ninv;                 // q, -q^-1 mod 2^28
+};
+__constant__ DLazyConst c_dl;
+
+#ifdef PBC_HOSTSIM
+#define LZ_BOUND(r, g_, gv_, what) bound(r, g_, gv_, what)
+#define LZ_G(a) (a).g
+#define LZ_GV(a) (a).gv
+#else
+#define LZ_BOUND(r, g_, gv_, what) do { } while (0)
+#define LZ_G(a) 1
+#define LZ_GV(a) 1.0
+#endif
+
+template <int ND>
+struct LazyD {
+  static constexpr int DEG = 3, W = 28, L = 6;
+  static constexpr uint32_t MASK = (1u << W) - 1;
+  static_assert(ND == 5, "28-bit limbs x 6 cover fields up to 160 bits");
+  typedef fp<ND> fq;
+#ifdef PBC_HOSTSIM
+  struct fz { int32_t l[L]; int g; double gv; };
+  static void bound(fz &r, int g, double gv, const char *what) {
+    r.g = g; r.gv = gv;
+    if (g > 7 || gv > 32) { fprintf(stderr, "lazy limbs: %s leaves growth %d, magnitude %.1f q\n", what, g, gv); abort(); }
+  }
+#else
+  struct fz { int32_t l[L]; };
+#endif
+  struct f3 { fz c[3]; };
+  struct f6 { f3 x, y; };
+
+  static PBC_DEV fz konst(const int32_t *w) {
+    fz r;
+#pragma unroll
+    for (int i = 0; i < L; i++) r.l[i] = w[i];
+    LZ_BOUND(r, 1, 1.0, "constant");
+    return r;
+  }
+  // ---- limbwise operations: no carry, no modular correction -------------------------------------------
+  static PBC_DEV void add(fz &r, const fz &a, const fz &b) {
+    const int g = LZ_G(a) + LZ_G(b); const double gv = LZ_GV(a) + LZ_GV(b);
+    (void) g; (void) gv;
+#pragma unroll
+    for (int i = 0; i < L; i++) r.l[i] = a.l[i] + b.l[i];
+    LZ_BOUND(r, g, gv, "add");
+  }
+  static PBC_DEV void sub(fz &r, const fz &a, const fz &b) {
+    const int g = LZ_G(a) + LZ_G(b); const double gv = LZ_GV(a) + LZ_GV(b);
+    (void) g; (void) gv;
+#pragma unroll
+    for (int i = 0; i < L; i++) r.l[i] = a.l[i] - b.l[i];
+    LZ_BOUND(r, g, gv, "sub");
+  }
+  static PBC_DEV void dbl(fz &r, const fz &a) {
+    const int g = 2 * LZ_G(a); const double gv = 2 * LZ_GV(a);
+    (void) g; (void) gv;
+#pragma unroll
+    for (int i = 0; i < L; i++) r.l[i] = a.l[i] * 2;
+    LZ_BOUND(r, g, gv, "dbl");
+  }
+  static PBC_DEV void neg(fz &r, const fz &a) {
+    const int g = LZ_G(a); const double gv = LZ_GV(a);
+    (void) g; (void) gv;
+#pragma unroll
+    for (int i = 0; i < L; i++) r.l[i] = -a.l[i];
+    LZ_BOUND(r, g, gv, "neg");
+  }
+  // one parallel carry pass: limbs 0..4 back to [-8, 2^28 + 8), the top limb absorbs the rest
+  static PBC_DEV void norm(fz &x) {
+    const double gv = LZ_GV(x);
+    (void) gv;
+    int32_t c[L];
+#pragma unroll
+    for (int i = 0; i < L - 1; i++) { c[i] = x.l[i] >> W; x.l[i] &= (int32_t) MASK; }
+#pragma unroll
+    for (int i = 0; i < L - 1; i++) x.l[i + 1] += c[i];
+    LZ_BOUND(x, 1, gv, "norm");
+  }
+
+  // ---- sums of products -------------------------------------------------------------------------------
+  // r = (sum_t x_t y_t) / R' mod q with one Montgomery reduction; result: limbs 0..4 in [0, 2^28), |r| < 1.25 q
+  template <int T>
+  static PBC_DEV void sop(fz &r, const fz (&x)[T], const fz (&y)[T]) {
+#ifdef PBC_HOSTSIM
+    {
+      int units = 1; double mag = 0;
+      for (int t = 0; t < T; t++) { units += x[t].g * y[t].g; mag += x[t].gv * y[t].gv; }
+      if (units > 25 || mag > 128) { fprintf(stderr, "lazy limbs: %d-term product with %d column units, magnitude %.1f\n", T, units, mag); abort(); }
+    }
+#endif
+    uint32_t m[L];
+    int64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < L; k++) {
+#pragma unroll
+      for (int t = 0; t < T; t++)
+#pragma unroll
+        for (int i = 0; i <= k; i++) acc += (int64_t) x[t].l[i] * y[t].l[k - i];
+#pragma unroll
+      for (int i = 0; i < k; i++) acc += (int64_t) ((uint64_t) m[i] * c_dl.p[k - i]);
+      m[k] = ((uint32_t) acc * c_dl.ninv) & MASK;
+      acc += (int64_t) ((uint64_t) m[k] * c_dl.p[0]);
+      acc >>= W;
+    }
+#pragma unroll
+    for (int k = L; k < 2 * L; k++) {
+#pragma unroll
+      for (int t = 0; t < T; t++)
+#pragma unroll
+        for (int i = k - L + 1; i < L; i++) acc += (int64_t) x[t].l[i] * y[t].l[k - i];
+#pragma unroll
+      for (int i = k - L + 1; i < L; i++) acc += (int64_t) ((uint64_t) m[i] * c_dl.p[k - i]);
+      if (k < 2 * L - 1) { r.l[k - L] = (int32_t) ((uint32_t) acc & MASK); acc >>= W; }
+      else r.l[k - L] = (int32_t) acc;   // top limb: signed remainder
+    }
+    LZ_BOUND(r, 1, 1.25, "product");
+  }
+  static PBC_DEV void mul_inl(fz &r, const fz &a, const fz &b) {
+    const fz x[1] = {a}, y[1] = {b};
+    sop<1>(r, x, y);
+  }
+  static PBC_DEV void sqr_inl(fz &r, const fz &a) { mul_inl(r, a, a); }
+#ifdef PBC_HOSTSIM
+  typedef fz fzvec;
+  static fzvec fz_pack(const fz &a) { return a; }
+  static fz fz_unpack(const fzvec &v) { return v; }
+#else
+  typedef uint32_t fzvec __attribute__((ext_vector_type(L)));
+  static PBC_DEV fzvec fz_pack(const fz &a) {
+    fzvec v;
+#pragma unroll
+    for (int k = 0; k < L; k++) v[k] = (uint32_t) a.l[k];
+    return v;
+  }
+  static PBC_DEV fz fz_unpack(fzvec v) {
+    fz a;
+#pragma unroll
+    for (int k = 0; k < L; k++) a.l[k] = (int32_t) v[k];
+    return a;
+  }
+#endif
+  // out-of-line copy for everything outside the line functions and the F_q^3 bodies (instruction cache)
+  static __device__ __noinline__ fzvec mul_fn(fzvec va, fzvec vb) {
+    fz r;
+    mul_inl(r, fz_unpack(va), fz_unpack(vb));
+    return fz_pack(r);
+  }
+  static PBC_DEV void mul(fz &r, const fz &a, const fz &b) { r = fz_unpack(mul_fn(fz_pack(a), fz_pack(b))); }
+  static PBC_DEV void sqr(fz &r, const fz &a) { mul(r, a, a); }
+
+  // ---- canonical forms: byte interface, equality, inversion -------------------------------------------
+  // fully reduced plain integer (saturated words) of a value in (-q, 1.2 q) with normalised limbs
+  static PBC_DEV void canon_words(uint32_t *w, fz t) {
+#pragma unroll
+    for (int rep = 0; rep < 2; rep++) {
+#pragma unroll
+      for (int i = 0; i < L - 1; i++) { const int32_t c = t.l[i] >> W; t.l[i] &= (int32_t) MASK; t.l[i + 1] += c; }
+      if (rep == 0) {
+        const int32_t negm = t.l[L - 1] >> 31;    // all ones when the value is negative
+#pragma unroll
+        for (int i = 0; i < L; i++) t.l[i] += (int32_t) (c_dl.p[i] & (uint32_t) negm);
+      }
+    }
+    uint32_t u[ND + 1];                           // limbs -> words, then one conditional subtraction
+#pragma unroll
+    for (int j = 0; j <= ND; j++) {
+      const int bit = 32 * j, i = bit / W, o = bit - W * i;
+      uint32_t x = 0;
+      if (i < L) x = (uint32_t) t.l[i] >> o;
+      if (i + 1 < L) x |= (uint32_t) t.l[i + 1] << (W - o);
+      u[j] = x;
+    }
+    fq r;
+    fp_cond_sub<ND>(r, u, u[ND]);
+#pragma unroll
+    for (int j = 0; j < ND; j++) w[j] = r.v[j];
+  }
+  static PBC_DEV fz split_words(const uint32_t *w) {   // plain integer below 2^160 -> limbs
+    fz r;
+#pragma unroll
+    for (int i = 0; i < L; i++) {
+      const int bit = W * i, j = bit >> 5, sh = bit & 31;
+      uint64_t x = w[j];
+      if (j + 1 < ND) x |= (uint64_t) w[j + 1] << 32;
+      r.l[i] = (int32_t) ((uint32_t) (x >> sh) & MASK);
+    }
+    LZ_BOUND(r, 1, 4.0, "split");
+    return r;
+  }
+  // plain canonical residue of x (x R' held): one product by the integer 1
+  static PBC_DEV void to_plain(uint32_t *w, const fz &a) {
+    fz t, o;
+#pragma unroll
+    for (int i = 0; i < L; i++) o.l[i] = (i == 0);
+    LZ_BOUND(o, 1, 1.0, "one");
+    mul_inl(t, a, o);
+    canon_words(w, t);
+  }
+  static PBC_DEV fz from_plain(const uint32_t *w) {
+    fz r;
+    mul_inl(r, split_words(w), konst(c_dl.k_in));
+    return r;
+  }
+  static PBC_DEV bool eq(const fz &a, const fz &b) {
+    fz d;
+    sub(d, a, b);
+    uint32_t w[ND], any = 0;
+    to_plain(w, d);
+#pragma unroll
+    for (int i = 0; i < ND; i++) any |= w[i];
+    return any == 0;
+  }
+  static PBC_DEV void inv(fz &r, const fz &a) {      // through the saturated safegcd inversion
+    uint32_t w[ND];
+    to_plain(w, a);                                  // x
+    fq c, r2, one;
+    fp_set<ND>(c, w);
+    fp_set<ND>(r2, fpk<ND>().r2);
+    fp_mul<ND>(c, c, r2);                            // x R
+    fp_inv<ND>(c, c);                                // x^-1 R
+#pragma unroll
+    for (int i = 0; i < ND; i++) one.v[i] = (i == 0);
+    fp_mul<ND>(c, c, one);                           // x^-1
+    r = from_plain(c.v);
+  }
+  static PBC_DEV void load_be(fz &r, const uint8_t *s) {
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(s);   // fbytes = 4 ND for these fields
+    uint32_t t[ND];
+#pragma unroll
+    for (int i = 0; i < ND; i++) t[ND - 1 - i] = __builtin_bswap32(w[i]);
+    r = from_plain(t);                               // values >= q reduce here as in fp_load_be
+  }
+  static PBC_DEV void store_be(uint8_t *d, const fz &a) {
+    uint32_t t[ND];
+    to_plain(t, a);
+    uint32_t *w = reinterpret_cast<uint32_t *>(d);
+#pragma unroll
+    for (int i = 0; i < ND; i++) w[i] = __builtin_bswap32(t[ND - 1 - i]);
+  }
+
+  // ---- F_q^3 ----------------------------------------------------------------------------------------------
+  static PBC_DEV void f3_add(f3 &r, const f3 &a, const f3 &b) { for (int i = 0; i < 3; i++) add(r.c[i], a.c[i], b.c[i]); }
+  static PBC_DEV void f3_sub(f3 &r, const f3 &a, const f3 &b) { for (int i = 0; i < 3; i++) sub(r.c[i], a.c[i], b.c[i]); }
+  static PBC_DEV void f3_dbl(f3 &r, const f3 &a) { for (int i = 0; i < 3; i++) dbl(r.c[i], a.c[i]); }
+  static PBC_DEV void f3_neg(f3 &r, const f3 &a) { for (int i = 0; i < 3; i++) neg(r.c[i], a.c[i]); }
+  static PBC_DEV void f3_norm(f3 &r) { for (int i = 0; i < 3; i++) norm(r.c[i]); }
+  static PBC_DEV void f3_mul_fq(f3 &r, const f3 &a, const fz &s) { for (int i = 0; i < 3; i++) mul(r.c[i], a.c[i], s); }
+  static PBC_DEV void f3_set_fq(f3 &r, const fz &s) {
+    r.c[0] = s;
+#pragma unroll
+    for (int i = 1; i < 3; i++) {
+#pragma unroll
+      for (int k = 0; k < L; k++) r.c[i].l[k] = 0;
+      LZ_BOUND(r.c[i], 1, 1.0, "zero");
+    }
+  }
+  static PBC_DEV bool f3_eq(const f3 &a, const f3 &b) {
+    int e = 1;
+    for (int i = 0; i < 3; i++) e &= (int) eq(a.c[i], b.c[i]);
+    return e != 0;
+  }
+  // product with lazy reduction (polymod_mul_degree3, poly.c:910-930: same ring element): h_t = x^(3+t)
+  // coefficient of the plain product, X_t = x^(3+t) mod f; operands may be un-normalised sums (g_a g_b <= 7)
+  static PBC_DEV void f3_mul_inl(f3 &r, const f3 &a, const f3 &b) {
+    fz X3[3], X4[3], h0, h1;
+#pragma unroll
+    for (int i = 0; i < 3; i++) { X3[i] = konst(c_dl.xpwr[0][i]); X4[i] = konst(c_dl.xpwr[1][i]); }
+    { const fz x[2] = {a.c[1], a.c[2]}, y[2] = {b.c[2], b.c[1]}; sop<2>(h0, x, y); }
+    { const fz x[1] = {a.c[2]}, y[1] = {b.c[2]}; sop<1>(h1, x, y); }
+    f3 o;
+    { const fz x[3] = {a.c[0], h0, h1}, y[3] = {b.c[0], X3[0], X4[0]}; sop<3>(o.c[0], x, y); }
+    { const fz x[4] = {a.c[0], a.c[1], h0, h1}, y[4] = {b.c[1], b.c[0], X3[1], X4[1]}; sop<4>(o.c[1], x, y); }
+    { const fz x[5] = {a.c[0], a.c[1], a.c[2], h0, h1}, y[5] = {b.c[2], b.c[1], b.c[0], X3[2], X4[2]}; sop<5>(o.c[2], x, y); }
+    r = o;
+  }
+  // square (polymod_square_degree3, poly.c:1049-1089): cross terms once against doubled operands (g <= 2)
+  static PBC_DEV void f3_sqr_inl(f3 &r, const f3 &a) {
+    fz X3[3], X4[3], h0, h1, d0, d1;
+#pragma unroll
+    for (int i = 0; i < 3; i++) { X3[i] = konst(c_dl.xpwr[0][i]); X4[i] = konst(c_dl.xpwr[1][i]); }
+    dbl(d0, a.c[0]);
+    dbl(d1, a.c[1]);
+    { const fz x[1] = {d1}, y[1] = {a.c[2]}; sop<1>(h0, x, y); }
+    sqr_inl(h1, a.c[2]);
+    f3 o;
+    { const fz x[3] = {a.c[0], h0, h1}, y[3] = {a.c[0], X3[0], X4[0]}; sop<3>(o.c[0], x, y); }
+    { const fz x[3] = {d0, h0, h1}, y[3] = {a.c[1], X3[1], X4[1]}; sop<3>(o.c[1], x, y); }
+    { const fz x[4] = {d0, a.c[1], h0, h1}, y[4] = {a.c[2], a.c[1], X3[2], X4[2]}; sop<4>(o.c[2], x, y); }
+    r = o;
+  }
+#ifdef PBC_HOSTSIM
+  typedef f3 f3vec;
+  static f3vec f3_pack(const f3 &a) { return a; }
+  static void f3_unpack(f3 &a, const f3vec &r) { a = r; }
+#else
+  typedef uint32_t f3vec __attribute__((ext_vector_type(3 * L)));
+  static PBC_DEV f3vec f3_pack(const f3 &a) {
+    f3vec r;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+      for (int k = 0; k < L; k++) r[L * i + k] = (uint32_t) a.c[i].l[k];
+    return r;
+  }
+  static PBC_DEV void f3_unpack(f3 &a, f3vec r) {
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+      for (int k = 0; k < L; k++) a.c[i].l[k] = (int32_t) r[L * i + k];
+  }
+#endif
+  static __device__ __noinline__ f3vec f3_mul_call(f3vec va, f3vec vb) {
+    f3 a, b, r;
+    f3_unpack(a, va);
+    f3_unpack(b, vb);
+    f3_mul_inl(r, a, b);
+    return f3_pack(r);
+  }
+  static __device__ __noinline__ f3vec f3_sqr_call(f3vec va) {
+    f3 a, r;
+    f3_unpack(a, va);
+    f3_sqr_inl(r, a);
+    return f3_pack(r);
+  }
+  // a * v for the constant v of the quadratic extension
+  static __device__ __noinline__ f3vec f3_mul_v_call(f3vec va) {
+    f3 a, r;
+    f3_unpack(a, va);
+    const fz V = konst(c_dl.nqr);
+#pragma unroll
+    for (int i = 0; i < 3; i++) mul_inl(r.c[i], a.c[i], V);
+    return f3_pack(r);
+  }
+  static PBC_DEV void f3_mul(f3 &r, const f3 &a, const f3 &b) { f3_unpack(r, f3_mul_call(f3_pack(a), f3_pack(b))); }
+  static PBC_DEV void f3_sqr(f3 &r, const f3 &a) { f3_unpack(r, f3_sqr_call(f3_pack(a))); }
+  static PBC_DEV void f3_mul_v(f3 &r, const f3 &a) { f3_unpack(r, f3_mul_v_call(f3_pack(a))); }
+  // a^q (the qpower macros of cc_tatepower, d_param.c:507-527)
+  static PBC_DEV void f3_frob(f3 &r, const f3 &a) {
+    f3 res;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      const fz x[2] = {a.c[1], a.c[2]}, y[2] = {konst(c_dl.xpowq[0][i]), konst(c_dl.xpowq[1][i])};
+      sop<2>(res.c[i], x, y);
+    }
+    add(res.c[0], res.c[0], a.c[0]);
+    r = res;
+  }
+  // a^-1 = a^q a^(q^2) / N(a)  (polymod_invert poly.c:521-536 computes the same unique inverse)
+  static PBC_DEV void f3_inv(f3 &r, const f3 &a) {
+    f3 t, w, m, an = a;
+    f3_norm(an);
+    f3_frob(t, an);
+    f3_norm(t);
+    w = t;
+    f3_frob(t, t);
+    f3_norm(t);
+    f3_mul(w, w, t);
+    f3_mul(m, an, w);
+    fz n;
+    inv(n, m.c[0]);
+    f3_mul_fq(r, w, n);
+  }
+
+  // ---- F_q^6 = F_q^3[sqrt(v)]: components with g <= 3 in, g <= 3 out ---------------------------------------
+  // fq_mul (fieldquadratic.c:197-233): Karatsuba
+  static PBC_DEV void f6_mul(f6 &r, const f6 &a, const f6 &b) {
+    f3 e0, e1, e2, t;
+    f3_add(e0, a.x, a.y);
+    f3_norm(e0);
+    f3_add(e1, b.x, b.y);
+    f3_mul(e2, e0, e1);
+    f3_mul(e0, a.x, b.x);
+    f3_mul(e1, a.y, b.y);
+    f3_mul_v(t, e1);
+    f3_add(r.x, t, e0);
+    f3_sub(e2, e2, e0);
+    f3_sub(r.y, e2, e1);
+  }
+  // fq_square (fieldquadratic.c:249-269); x^2 + v y^2 = (x + y)(x + v y) - (1 + v) xy
+  static PBC_DEV void f6_sqr(f6 &r, const f6 &a) {
+    f3 t, s, vy, u;
+    f3_mul(t, a.x, a.y);
+    f3_mul_v(vy, a.y);
+    f3_add(s, a.x, a.y);
+    f3_norm(s);
+    f3_add(vy, vy, a.x);
+    f3_mul(u, s, vy);
+    f3_sub(u, u, t);
+    f3_mul_v(s, t);
+    f3_sub(r.x, u, s);
+    f3_dbl(r.y, t);
+  }
+
+  // ---- Miller loop: per-lane state in LDS as limbs ([word][lane]) ------------------------------------------
+  enum { DL_QX = 0, DL_QY = 3 * L, DL_X = 6 * L, DL_Y = 7 * L, DL_Z = 8 * L, DL_PX = 9 * L, DL_PY = 10 * L, DL_WORDS = 11 * L };
+  static PBC_DEV uint32_t *lds() {
+    __shared__ uint32_t buf[DL_WORDS * D_LANES];
+    return buf;
+  }
+#ifdef PBC_HOSTSIM
+  static fz *lds_shadow() { static fz sh[DL_WORDS / L]; return sh; }
+#endif
+  static PBC_DEV fz dl_get(int w) {
+    fz r;
+    uint32_t *b = lds();
+#pragma unroll
+    for (int k = 0; k < L; k++) r.l[k] = (int32_t) b[(w + k) * D_LANES + threadIdx.x];
+#ifdef PBC_HOSTSIM
+    r.g = lds_shadow()[w / L].g; r.gv = lds_shadow()[w / L].gv;
+#endif
+    return r;
+  }
+  static PBC_DEV void dl_put(int w, const fz &a) {
+    uint32_t *b = lds();
+#pragma unroll
+    for (int k = 0; k < L; k++) b[(w + k) * D_LANES + threadIdx.x] = (uint32_t) a.l[k];
+#ifdef PBC_HOSTSIM
+    lds_shadow()[w / L] = a;
+#endif
+  }
+  // l(Q) = (a Qx + c) + (b Qy) sqrt(v) (d_miller_evalfn, d_param.c:99-111), a, b, c in F_q with g_a <= 4,
+  // b a product, g_c <= 3.  The 36 words of a line value do not fit the 32 return registers: the first call
+  // returns the sqrt(v)-free half plus b, a second small call the other half.
+  typedef uint32_t linevec __attribute__((ext_vector_type(4 * L)));
+  static PBC_DEV linevec evalfn_pack(const fz &a, const fz &b, const fz &c) {
+    linevec r;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      fz t;
+      mul_inl(t, dl_get(DL_QX + L * i), a);
+      if (i == 0) add(t, t, c);          // g <= 4
+#pragma unroll
+      for (int k = 0; k < L; k++) r[L * i + k] = (uint32_t) t.l[k];
+    }
+#ifdef PBC_HOSTSIM
+    if (b.g != 1 || c.g > 3) { fprintf(stderr, "lazy limbs: line coefficients out of contract\n"); abort(); }
+#endif
+#pragma unroll
+    for (int k = 0; k < L; k++) r[3 * L + k] = (uint32_t) b.l[k];
+    return r;
+  }
+  typedef uint32_t halfvec __attribute__((ext_vector_type(3 * L)));
+  static __device__ __noinline__ halfvec line_y_fn(fzvec vb) {
+    const fz b = fz_unpack(vb);
+    halfvec r;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      fz u;
+      mul_inl(u, dl_get(DL_QY + L * i), b);
+#pragma unroll
+      for (int k = 0; k < L; k++) r[L * i + k] = (uint32_t) u.l[k];
+    }
+    return r;
+  }
+  static PBC_DEV void unpack(f6 &e0, linevec r) {
+    static_assert(4 * L <= 32, "line value does not fit the return registers");
+    fz b;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+#pragma unroll
+      for (int k = 0; k < L; k++) e0.x.c[i].l[k] = (int32_t) r[L * i + k];
+      LZ_BOUND(e0.x.c[i], i == 0 ? 4 : 1, i == 0 ? 6.0 : 1.25, "line");
+    }
+#pragma unroll
+    for (int k = 0; k < L; k++) b.l[k] = (int32_t) r[3 * L + k];
+    LZ_BOUND(b, 1, 1.25, "line");
+    halfvec y = line_y_fn(fz_pack(b));
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+#pragma unroll
+      for (int k = 0; k < L; k++) e0.y.c[i].l[k] = (int32_t) y[L * i + k];
+      LZ_BOUND(e0.y.c[i], 1, 1.25, "line");
+    }
+  }
+  // tangent at V (do_tangent d_param.c:344-362, scaled by Z^6) and V <- 2V:
+  //   M = 3X^2 + a Z^4,  a' = -M Z^2,  b' = (2YZ) Z^2,  c' = M X - 2Y^2.   State in: g(X) <= 4, g(Y) <= 3, g(Z) <= 2
+  static __device__ __noinline__ linevec dbl_line_fn() {
+    fz X = dl_get(DL_X), Y = dl_get(DL_Y), Z = dl_get(DL_Z);
+    fz ZZ, XX, YY, Y2, M, t0, t1, S, Z3, la, lb, lc;
+    sqr_inl(ZZ, Z);
+    sqr_inl(XX, X);
+    sqr_inl(YY, Y);
+    sqr_inl(t0, ZZ);
+    mul_inl(t0, t0, konst(c_dl.A));
+    dbl(M, XX);
+    add(M, M, XX);
+    add(M, M, t0);                       // g 4
+    mul_inl(la, M, ZZ);
+    neg(la, la);
+    mul_inl(Z3, Y, Z);
+    dbl(Z3, Z3);                         // g 2
+    mul_inl(lb, Z3, ZZ);
+    dbl(Y2, YY);                         // 2Y^2, g 2
+    mul_inl(lc, M, X);
+    sub(lc, lc, Y2);                     // g 3
+    dbl(t1, Y2);                         // 4Y^2, g 4
+    mul_inl(S, X, t1);                   // S = 4XY^2
+    sqr_inl(t0, Y2);                     // 4Y^4
+    dbl(t0, t0);                         // 8Y^4, g 2
+    sqr_inl(X, M);
+    dbl(t1, S);
+    sub(X, X, t1);                       // X3 = M^2 - 2S, g 3
+    sub(t1, S, X);                       // g 4
+    mul_inl(t1, M, t1);
+    sub(Y, t1, t0);                      // g 3
+    dl_put(DL_X, X);
+    dl_put(DL_Y, Y);
+    dl_put(DL_Z, Z3);
+    return evalfn_pack(la, lb, lc);
+  }
+  // chord through V and the affine P (do_line d_param.c:364-379, scaled by Z3 = Z H):
+  //   H = Px Z^2 - X, R = Py Z^3 - Y;  a' = -R,  b' = Z3,  c' = R Px - Z3 Py;   V <- V + P
+  // State in: g(X), g(Y) <= 3, g(Z) <= 2; out: g(X) = 4, Y and Z products
+  static __device__ __noinline__ linevec add_line_fn() {
+    fz X = dl_get(DL_X), Y = dl_get(DL_Y), Z = dl_get(DL_Z), Px = dl_get(DL_PX), Py = dl_get(DL_PY);
+    fz ZZ, H, R, HH, HHH, t0, t1, Z3, la, lc, nPy, nY;
+    sqr_inl(ZZ, Z);
+    mul_inl(H, Px, ZZ);
+    sub(H, H, X);                        // g 4
+    mul_inl(t0, Z, ZZ);
+    mul_inl(R, Py, t0);
+    sub(R, R, Y);                        // g 4
+    mul_inl(Z3, Z, H);
+    neg(la, R);
+    neg(nPy, Py);
+    { const fz x[2] = {R, Z3}, y[2] = {Px, nPy}; sop<2>(lc, x, y); }    // R Px - Z3 Py, one reduction
+    sqr_inl(HH, H);
+    mul_inl(HHH, HH, H);
+    mul_inl(t0, X, HH);
+    sqr_inl(t1, R);
+    sub(t1, t1, HHH);
+    sub(t1, t1, t0);
+    sub(t1, t1, t0);                     // X3, g 4
+    sub(t0, t0, t1);                     // g 5
+    neg(nY, Y);
+    { const fz x[2] = {R, nY}, y[2] = {t0, HHH}; sop<2>(Y, x, y); }     // Y3 = R (X H^2 - X3) - Y H^3
+    dl_put(DL_X, t1);
+    dl_put(DL_Y, Y);
+    dl_put(DL_Z, Z3);
+    return evalfn_pack(la, Z3, lc);
+  }
+  static PBC_DEV void f3_load_be(f3 &r, const uint8_t *s) { for (int i = 0; i < 3; i++) load_be(r.c[i], s + 4 * ND * i); }
+  static PBC_DEV void f3_store_be(uint8_t *d, const f3 &a) { for (int i = 0; i < 3; i++) store_be(d + 4 * ND * i, a.c[i]); }
+
+  // Miller function f_{r,P}(psi(Q)) (cc_miller_no_denom_affine, d_param.c:321-422); false when an input is
+  // not a point of its curve (curve_from_bytes yields O, ecc/curve.c:609-623)
+  static PBC_DEV bool miller_lane(f6 &v, const uint8_t *g1, const uint8_t *g2) {
+    const int NB = 4 * ND;
+    fz Px, Py, one = konst(c_dl.one);
+    f3 Qx, Qy;
+    load_be(Px, g1);
+    load_be(Py, g1 + NB);
+    f3_load_be(Qx, g2);
+    f3_load_be(Qy, g2 + 3 * NB);
+    bool valid;
+    {
+      fz t0, t1;
+      sqr(t0, Px);
+      add(t0, t0, konst(c_dl.A));
+      mul(t0, t0, Px);
+      add(t0, t0, konst(c_dl.B));
+      sqr(t1, Py);
+      valid = eq(t0, t1);
+      f3 u0, u1;
+      f3_sqr(u0, Qx);
+      add(u0.c[0], u0.c[0], konst(c_dl.ta));
+      f3_mul(u0, u0, Qx);
+      add(u0.c[0], u0.c[0], konst(c_dl.tb));
+      f3_sqr(u1, Qy);
+      valid &= f3_eq(u0, u1);
+    }
+    // twist map (x, y) -> (v^-1 x, v^-2 y sqrt(v))  (cc_pairing, d_param.c:580-582)
+    f3_mul_fq(Qx, Qx, konst(c_dl.nqrinv));
+    f3_mul_fq(Qy, Qy, konst(c_dl.nqrinv2));
+#pragma unroll
+    for (int i = 0; i < 3; i++) { dl_put(DL_QX + L * i, Qx.c[i]); dl_put(DL_QY + L * i, Qy.c[i]); }
+    dl_put(DL_X, Px); dl_put(DL_Y, Py); dl_put(DL_Z, one);
+    dl_put(DL_PX, Px); dl_put(DL_PY, Py);
+    f3_set_fq(v.x, one);
+    f3_set_fq(v.y, one);
+    f3_sub(v.y, v.y, v.x);
+    f3_norm(v.y);
+    for (int m = c_d.rbits - 2;; m--) {
+      f6 e0;
+      unpack(e0, dbl_line_fn());
+      f6_mul(v, v, e0);
+      if (m <= 0) break;
+      if ((c_d.r[m >> 5] >> (m & 31)) & 1) {
+        unpack(e0, add_line_fn());
+        f6_mul(v, v, e0);
+      }
+      f6_sqr(v, v);
+    }
+    return valid;
+  }
+  // cc_tatepower (d_param.c:505-564) with one inversion; derivation in pairing_d.cuh
+  static PBC_DEV void final_exp(f6 &out, const f6 &m) {
+    f3 aa, bb, ab, N, mx = m.x, my = m.y;
+    f6 u, uq, w;
+    f3_norm(mx);
+    f3_norm(my);
+    f3_sqr(aa, mx);
+    f3_sqr(bb, my);
+    f3_mul_v(bb, bb);
+    f3_mul(ab, mx, my);
+    f3_add(u.x, aa, bb);
+    f3_sub(N, aa, bb);
+    f3_dbl(u.y, ab);
+    f3_neg(u.y, u.y);
+    f3_frob(uq.x, u.x);
+    f3_frob(uq.y, u.y);
+    f3_neg(uq.y, uq.y);
+    f6_mul(w, uq, u);                    // A + B sqrt(v)
+    f3 D, t, invD, invB;
+    f3_frob(D, N);
+    f3_norm(D);
+    f3_mul(D, D, N);
+    f3_norm(w.y);
+    f3_mul(t, D, w.y);
+    f3_inv(t, t);                        // 1/(D B): the only inversion
+    f3_mul(invD, t, w.y);
+    f3_mul(invB, t, D);
+    f3 h0, P, v0, v1, two;
+    f3_mul(h0, w.x, invD);
+    f3_dbl(P, h0);
+    f3_norm(P);
+    f3_set_fq(two, konst(c_dl.two));
+    v0 = two;
+    v1 = P;
+    // lucas_even ladder (d_param.c:462-482): j == 0 takes the 0-branch
+    for (int j = c_d.phikbits - 1; j >= 0; j--) {
+      bool bit = j ? ((c_d.phik[j >> 5] >> (j & 31)) & 1) : false;
+      f3 mm, s;
+      f3_mul(mm, v0, v1);
+      f3_sub(mm, mm, P);
+      if (bit) { f3_sqr(s, v1); f3_sub(v1, s, two); v0 = mm; }
+      else     { f3_sqr(s, v0); f3_sub(v0, s, two); v1 = mm; }
+    }
+    // out = V_k/2 + (P V_k - 2 V_{k-1}) D / (4 v B) sqrt(v)
+    f3_mul(t, P, v1);
+    f3_dbl(v0, v0);
+    f3_sub(t, t, v0);
+    f3_mul(t, t, D);
+    f3_mul(t, t, invB);
+    const fz half = konst(c_dl.half);
+    fz q4;
+    mul(q4, half, half);
+    mul(q4, q4, konst(c_dl.nqrinv));     // 1 / (4 v)
+    f3_mul_fq(out.y, t, q4);
+    f3_mul_fq(out.x, v1, half);
+  }
+  static PBC_DEV void prod_pairing_lane(uint8_t *gt, const uint8_t *g1, const uint8_t *g2, int k) {
+    f6 F, out;
+    bool valid = miller_lane(F, g1, g2);
+    for (int j = 1; j < k; j++) {
+      f6 f;
+      valid &= miller_lane(f, g1 + (size_t) j * 8 * ND, g2 + (size_t) j * 24 * ND);
+      f3_norm(f.x);
+      f3_norm(f.y);
+      f6_mul(F, F, f);
+    }
+    final_exp(out, F);
+    if (!valid) {                        // GT identity
+      f3_set_fq(out.x, konst(c_dl.one));
+      f3_set_fq(out.y, konst(c_dl.one));
+      f3_sub(out.y, out.y, out.x);
+    }
+    f3_store_be(gt, out.x);
+    f3_store_be(gt + 12 * ND, out.y);
+  }
+
+  // constants: c_d (saturated words, Montgomery form for R = 2^174) -> 28-bit limbs for R' = 2^168.
+  // A stored residue c R becomes c R' after six halvings mod q.  One thread, once per parameter set.
+  static PBC_DEV void conv(int32_t *dst, const uint32_t *w, int halvings) {
+    fq t;
+    fp_set<ND>(t, w);
+    for (int i = 0; i < halvings; i++) fp_halve<ND>(t, t);
+#pragma unroll
+    for (int i = 0; i < L; i++) {
+      const int bit = W * i, j = bit >> 5, sh = bit & 31;
+      uint64_t x = t.v[j];
+      if (j + 1 < ND) x |= (uint64_t) t.v[j + 1] << 32;
+      dst[i] = (int32_t) ((uint32_t) (x >> sh) & MASK);
+    }
+  }
+  static PBC_DEV void init(DLazyConst *o) {
+    const FpK<ND> &K = fpk<ND>();
+    conv(o->A, c_d.A, 6); conv(o->B, c_d.B, 6); conv(o->nqr, c_d.nqr, 6);
+    conv(o->nqrinv, c_d.nqrinv, 6); conv(o->nqrinv2, c_d.nqrinv2, 6);
+    conv(o->ta, c_d.ta, 6); conv(o->tb, c_d.tb, 6);
+    for (int t = 0; t < 2; t++)
+      for (int i = 0; i < 3; i++) { conv(o->xpwr[t][i], c_d.xpwr[t][i], 6); conv(o->xpowq[t][i], c_d.xpowq[t][i], 6); }
+    conv(o->one, K.one, 6);
+    conv(o->two, K.one, 5);
+    conv(o->half, K.one, 7);
+    conv(o->k_in, K.r2, 12);            // R^2 2^-12 = R'^2 mod q
+    int32_t p[L];
+    conv(p, K.p, 0);
+    for (int i = 0; i < L; i++) o->p[i] = (uint32_t) p[i];
+    o->ninv = K.ninv29 & MASK;
+  }
+};
+
+template <int ND> __global__ void d_lazy_init_kernel(DLazyConst *out) {
+  if (threadIdx.x || blockIdx.x) return;
+  LazyD<ND>::init(out);
+}
+
+}  // namespace pbc

@@ -158,6 +158,11 @@ __global__ void __launch_bounds__(kBlock, PBC_A_WAVES) a_pp_apply_kernel(uint8_t
   }
 }
 
+// experiment switch (profiles/r01_notes.md): PBC_HIP_D_LAZY=1 routes 5-word type d pairings to the signed-limb kernel
+static bool d_lazy_selected() {
+  static const bool on = [] { const char *e = getenv("PBC_HIP_D_LAZY"); return e && *e == '1'; }();
+  return on;
+}
 // Types D and G: one k-term product (k = 1: a single pairing) per lane.  With fb = fixed byte length
 // of F_q and d = k/2, G1 records are 2 fb, G2 and GT 2 d fb bytes (40 / 120 / 120 B for d159.param,
 // 38 / 190 / 190 B for g149.param).
@@ -169,6 +174,26 @@ __global__ void __launch_bounds__(kBlock, PBC_DF_WAVES) d_prod_pairing_kernel(ui
   const int fb = (int) fpk<N>().fbytes, L1 = 2 * fb, L2 = 2 * DEG * fb, LT = 2 * DEG * fb;
   __attribute__((aligned(4))) uint8_t out[8 * DEG * N];
   TypeMNT<N, DEG>::d_prod_pairing_lane(out, g1 + ld * k * L1, g2 + ld * k * L2, k);
+  if (idx < n) {
+    if ((LT & 3) == 0) {
+      uint32_t *dst = reinterpret_cast<uint32_t *>(gt + idx * LT);
+      const uint32_t *src = reinterpret_cast<const uint32_t *>(out);
+      for (int i = 0; i < LT / 4; i++) dst[i] = src[i];
+    } else {
+      for (int i = 0; i < LT; i++) gt[idx * LT + i] = out[i];
+    }
+  }
+}
+
+// Type D on the signed-limb representation of pairing_d_lazy.cuh (5-word fields); same interface.
+template <int N>
+__global__ void __launch_bounds__(kBlock, PBC_DF_WAVES) d_lazy_prod_pairing_kernel(uint8_t *gt, const uint8_t *g1,
+                                                                      const uint8_t *g2, size_t n, int k) {
+  size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
+  size_t ld = idx < n ? idx : n - 1;
+  const int fb = (int) fpk<N>().fbytes, L1 = 2 * fb, L2 = 6 * fb, LT = 6 * fb;
+  __attribute__((aligned(4))) uint8_t out[24 * N];
+  LazyD<N>::prod_pairing_lane(out, g1 + ld * k * L1, g2 + ld * k * L2, k);
   if (idx < n) {
     if ((LT & 3) == 0) {
       uint32_t *dst = reinterpret_cast<uint32_t *>(gt + idx * LT);
@@ -699,6 +724,18 @@ static int upload_constants(pbc_hip_pairing_s *P, hipStream_t s) {
       P->dev_ready = true;
     }
     HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_d), &P->dconst, sizeof P->dconst, 0, hipMemcpyHostToDevice, s));
+    if (P->type == 'd' && P->nlimb == 5 && d_lazy_selected()) {
+      if (!P->dlazy_ready) {
+        DLazyConst *lbuf;
+        HIP_TRY(hipMalloc(&lbuf, sizeof(DLazyConst)));
+        hipLaunchKernelGGL(d_lazy_init_kernel<5>, dim3(1), dim3(64), 0, s, lbuf);
+        HIP_TRY(hipMemcpyAsync(&P->dlazy, lbuf, sizeof(DLazyConst), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        (void) hipFree(lbuf);
+        P->dlazy_ready = true;
+      }
+      HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_dl), &P->dlazy, sizeof P->dlazy, 0, hipMemcpyHostToDevice, s));
+    }
   }
   if (P->type == 'e') {
     if (!P->dev_ready) {
@@ -758,6 +795,9 @@ static int launch_pairing(pbc_hip_pairing_s *P, void *d_gt, const void *d_g1, co
                        (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, 1);
   } else if (P->type == 'e') {
     hipLaunchKernelGGL(e_prod_pairing_kernel<33>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
+                       (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, 1);
+  } else if (P->type == 'd' && P->nlimb == 5 && d_lazy_selected()) {
+    hipLaunchKernelGGL(d_lazy_prod_pairing_kernel<5>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
                        (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, 1);
   } else if (P->type == 'd' || P->type == 'g') {
     PBC_DISPATCH_D(P, hipLaunchKernelGGL((d_prod_pairing_kernel<N, DEG>), dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
@@ -880,6 +920,9 @@ static int launch_prod(pbc_hip_pairing_s *P, void *d_gt, const void *d_g1, const
                        (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k);
   } else if (P->type == 'e') {
     hipLaunchKernelGGL(e_prod_pairing_kernel<33>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
+                       (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k);
+  } else if (P->type == 'd' && P->nlimb == 5 && d_lazy_selected()) {
+    hipLaunchKernelGGL(d_lazy_prod_pairing_kernel<5>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
                        (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k);
   } else if (P->type == 'd' || P->type == 'g') {
     PBC_DISPATCH_D(P, hipLaunchKernelGGL((d_prod_pairing_kernel<N, DEG>), dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,

@@ -39,7 +39,8 @@ class HostSim:
         L.hostsim_lens(self.h, ctypes.byref(a), ctypes.byref(b2), ctypes.byref(c))
         self.len1, self.len2, self.lenT = a.value, b2.value, c.value
 
-    def prod_pairing(self, g1, g2, k=1):
+    def prod_pairing(self, g1, g2, k=1, d_lazy=False):
+        self.L.hostsim_select_d_lazy(1 if d_lazy else 0)
         g1 = np.ascontiguousarray(g1, np.uint8)
         g2 = np.ascontiguousarray(g2, np.uint8)
         n = g1.size // (self.len1 * k)

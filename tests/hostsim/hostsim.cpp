@@ -94,11 +94,16 @@ int hostsim_lens(void *h, int *l1, int *l2, int *lt) {
   *l1 = P->len1; *l2 = P->len2; *lt = P->lenT;
   return 0;
 }
+// experiment switch: route 5-word type d pairings through pairing_d_lazy.cuh (with its bound checks)
+static int g_d_lazy = 0;
+void hostsim_select_d_lazy(int on) { g_d_lazy = on; }
 // n units of k terms each, one lane after the other
 int hostsim_prod_pairing(void *h, uint8_t *gt, const uint8_t *g1, const uint8_t *g2, size_t n, int k) {
   pbc_hip_pairing_s *P = (pbc_hip_pairing_s *) h;
   activate(P);
   static uint32_t lds[2 * 33];
+  const bool d_lazy = P->type == 'd' && P->nlimb == 5 && g_d_lazy;
+  if (d_lazy) { DLazyConst tmp; LazyD<5>::init(&tmp); c_dl = tmp; }
   for (size_t u = 0; u < n; u++) {
     const uint8_t *a = g1 + u * k * P->len1, *b = g2 + u * k * P->len2;
     uint8_t *o = gt + u * P->lenT;
@@ -107,6 +112,7 @@ int hostsim_prod_pairing(void *h, uint8_t *gt, const uint8_t *g1, const uint8_t 
     else if (P->type == '1' || P->type == 'a') a1_prod_pairing_lane<33>(o, a, b, k, lds, 1);
     else if (P->type == 'e' && P->nlimb == 16) e_prod_pairing_lane<16>(o, a, b, k, lds, 1);
     else if (P->type == 'e') e_prod_pairing_lane<33>(o, a, b, k, lds, 1);
+    else if (d_lazy) LazyD<5>::prod_pairing_lane(o, a, b, k);
     else if (P->type == 'd' || P->type == 'g') { HS_DISPATCH_D(P, TypeMNT<N, DEG>::d_prod_pairing_lane(o, a, b, k)); }
     else { HS_DISPATCH_F(P->nlimb, TypeF<N>::f_prod_pairing_lane(o, a, b, k)); }
   }

@@ -707,3 +707,17 @@ def test_bls_sign_verify_batch_on_gpu(hip_a, oracle_a):
     # spot check against the CPU oracle
     assert np.array_equal(lhs[:3], oracle_a.pairing_batch(sig[:3], np.tile(g, (3, 1))))
     assert np.array_equal(h[:2], oracle_a.g_mul(1, h[:2], np.tile(_be(1, 20), (2, 1))))   # valid curve points
+
+
+@pytest.mark.skipif(__import__("os").environ.get("PBC_TEST_EXPERIMENTAL") != "1",
+                    reason="experiment not yet run on a GPU: PBC_TEST_EXPERIMENTAL=1 enables it")
+def test_type_d_signed_limb_experiment_on_gpu():
+    """pairing_d_lazy.cuh behind PBC_HIP_D_LAZY=1 (validated on the host mirror only so far): parity and A/B timing
+    in fresh processes, see tools/d_lazy_ab.py"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "d_lazy_ab.py"), "16"], capture_output=True, text=True, timeout=1200)
+    print(out.stdout)
+    assert out.returncode == 0, out.stdout + out.stderr

@@ -179,3 +179,30 @@ def test_fresh_points_kernel_source_vs_oracle(sims, oracles, key, name):
     assert np.array_equal(got, O.pairing_batch(kP, v.g2[1:n + 1]))
     same = S.prod_pairing(kP, v.g2[:n], 1)
     assert np.array_equal(same, S.group(2, v.gt[:n], Z))
+
+
+@pytest.mark.parametrize("name", ["d_rand32.vec", "d_edge20.vec", "d_prod16x4.vec", "d_prod3x10_edge.vec"])
+def test_type_d_signed_limb_experiment_on_host(sims, name):
+    """pbc_amd/csrc/pairing_d_lazy.cuh (PBC_HIP_D_LAZY=1; signed 28-bit limbs, carries only where the bounds ask):
+    same bytes as the reference vectors.  The host build also carries the data-independent limb / magnitude
+    bounds through every operation and aborts the process if one is exceeded."""
+    v = golden(name)
+    out = sims["d"].prod_pairing(v.g1, v.g2, v.k, d_lazy=True)
+    assert np.array_equal(out, v.gt)
+
+
+def test_type_d_signed_limb_experiment_fresh_points(sims, oracles):
+    """inputs outside the fixtures (random multiples of their points, all-ones limbs cannot be forced through
+    curve points, so volume is the lever): 64 fresh pairings against the oracle"""
+    v = golden("d_rand32.vec")
+    S, O = sims["d"], oracles["d"]
+    r = param_value("d", "r")
+    zl = (r.bit_length() + 7) // 8
+    rng = np.random.default_rng(77)
+    n = 32
+    ks = [int.from_bytes(rng.bytes(zl), "big") % (r - 1) + 1 for _ in range(n)]
+    Z = np.stack([np.frombuffer(k.to_bytes(zl, "big"), np.uint8) for k in ks])
+    kP = O.g_mul(1, v.g1[:n], Z)
+    for shift in (1, 7):
+        g2 = np.roll(v.g2[:n], shift, axis=0)
+        assert np.array_equal(S.prod_pairing(kP, g2, 1, d_lazy=True), O.pairing_batch(kP, g2))

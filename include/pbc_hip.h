@@ -114,6 +114,16 @@ int pbc_hip_element_to_bytes_compressed_batch(pbc_hip_pairing_t *p, int group, u
                                               size_t n);
 int pbc_hip_element_from_bytes_compressed_batch(pbc_hip_pairing_t *p, int group, uint8_t *out, const uint8_t *in,
                                                 size_t n);
+/* element_to_bytes_x_only / element_from_bytes_x_only (ecc/curve.c:821-836; pairing_length_in_bytes_x_only_G1,
+ * include/pbc_pairing.h:187-193): records of length_in_bytes_Fq bytes holding x alone.  from_bytes rebuilds the
+ * point with the square root the reference's element_sqrt returns when that is defined (q = 3 mod 4: types a, a1,
+ * f.param, g149.param); for q = 1 mod 4 the reference's own root depends on the random non-residue it drew at
+ * start-up, and the result agrees with it up to the sign of y.  An x with no point above it gives zeros. */
+int pbc_hip_pairing_length_in_bytes_x_only_G1(const pbc_hip_pairing_t *p);
+int pbc_hip_element_to_bytes_x_only_batch(pbc_hip_pairing_t *p, int group, uint8_t *out, const uint8_t *in,
+                                          size_t n);
+int pbc_hip_element_from_bytes_x_only_batch(pbc_hip_pairing_t *p, int group, uint8_t *out, const uint8_t *in,
+                                            size_t n);
 int pbc_hip_element_mul_zn_batch(pbc_hip_pairing_t *p, int group, uint8_t *out, const uint8_t *in,
                                  const uint8_t *zr, size_t n);
 int pbc_hip_element_mul_GT_batch(pbc_hip_pairing_t *p, uint8_t *out, const uint8_t *a, const uint8_t *b, size_t n);

@@ -267,6 +267,40 @@ static int cmd_compress(int argc, char **argv) {
   return 0;
 }
 
+/* xonly <param> <n> <seed> <out>: points hashed from a counter (independent of the generator state), their
+ * element_to_bytes_x_only form (x alone, ecc/curve.c:821-827) and what element_from_bytes_x_only (:829-836)
+ * rebuilds from it: y is whichever root element_sqrt returns.  For q = 3 mod 4 that is x^((q+1)/4); for
+ * q = 1 mod 4 element_tonelli (arith/field.c:672-720) works from a randomly drawn non-residue
+ * (field_gen_nqr), so <seed> (set before the pairing is initialised) lets a caller see whether the root moves. */
+static int cmd_xonly(int argc, char **argv) {
+  if (argc < 5) { fprintf(stderr, "xonly <param> <n> <seed> <out>\n"); return 2; }
+  int n = atoi(argv[2]);
+  pairing_t pairing; char type;
+  pbc_random_set_deterministic((unsigned) atoi(argv[3]));
+  init_pairing(pairing, argv[1], &type);
+  int lp = pairing_length_in_bytes_G1(pairing);
+  element_t P, R;
+  element_init_G1(P, pairing); element_init_G1(R, pairing);
+  int lx = pairing_length_in_bytes_x_only_G1(pairing);
+  unsigned char *in = malloc((size_t) n * lp), *xs = malloc((size_t) n * lx), *out = malloc((size_t) n * lp);
+  for (int i = 0; i < n; i++) {
+    char msg[32];
+    int ml = snprintf(msg, sizeof msg, "x-only/%d", i);
+    element_from_hash(P, msg, ml);
+    element_to_bytes(in + (size_t) i * lp, P);
+    if (element_to_bytes_x_only(xs + (size_t) i * lx, P) != lx) return 1;
+    element_from_bytes_x_only(R, xs + (size_t) i * lx);
+    element_to_bytes(out + (size_t) i * lp, R);
+  }
+  FILE *fp = fopen(argv[4], "wb");
+  fwrite("PBCVEC01", 1, 8, fp);
+  w32(fp, (uint32_t) type); w32(fp, n); w32(fp, 1); w32(fp, lp); w32(fp, lx); w32(fp, lp);
+  fwrite(in, lp, n, fp); fwrite(xs, lx, n, fp); fwrite(out, lp, n, fp);
+  fclose(fp);
+  fprintf(stderr, "wrote %s: type %c n=%d x-only %d bytes\n", argv[4], type, n, lx);
+  return 0;
+}
+
 /* gena <rbits> <qbits> <seed> <out.param>: a fresh type a parameter set (pbc_param_init_a_gen,
  * ecc/a_param.c:1504-1562) written with pbc_param_out_str */
 static int cmd_gena(int argc, char **argv) {
@@ -365,6 +399,7 @@ int main(int argc, char **argv) {
   if (!strcmp(argv[1], "hash")) return cmd_hash(argc - 1, argv + 1);
   if (!strcmp(argv[1], "gmul")) return cmd_gmul(argc - 1, argv + 1);
   if (!strcmp(argv[1], "compress")) return cmd_compress(argc - 1, argv + 1);
+  if (!strcmp(argv[1], "xonly")) return cmd_xonly(argc - 1, argv + 1);
   if (!strcmp(argv[1], "gena")) return cmd_gena(argc - 1, argv + 1);
   if (!strcmp(argv[1], "gena1")) return cmd_gena1(argc - 1, argv + 1);
   if (!strcmp(argv[1], "gene")) return cmd_gene(argc - 1, argv + 1);

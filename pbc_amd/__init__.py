@@ -68,6 +68,9 @@ def lib():
         L.pbc_hip_pairing_use_devices.argtypes = [vp, ctypes.POINTER(ctypes.c_int), ci]
         L.pbc_hip_element_to_bytes_compressed_batch.argtypes = [vp, ci, vp, vp, sz]
         L.pbc_hip_element_from_bytes_compressed_batch.argtypes = [vp, ci, vp, vp, sz]
+        L.pbc_hip_pairing_length_in_bytes_x_only_G1.argtypes = [vp]
+        L.pbc_hip_element_to_bytes_x_only_batch.argtypes = [vp, ci, vp, vp, sz]
+        L.pbc_hip_element_from_bytes_x_only_batch.argtypes = [vp, ci, vp, vp, sz]
         L.pbc_hip_element_from_hash_batch.argtypes = [vp, ci, vp, vp, ci, sz]
         L.pbc_hip_element_mul_GT_batch.argtypes = [vp, vp, vp, vp, sz]
         L.pbc_hip_element_pow_zn_GT_batch.argtypes = [vp, vp, vp, vp, sz]
@@ -97,6 +100,8 @@ EXPORTS = (
     "pbc_hip_element_from_hash_batch", "pbc_hip_element_mul_zn_batch", "pbc_hip_element_mul_GT_batch", "pbc_hip_element_pow_zn_GT_batch",
     "pbc_hip_pairing_length_in_bytes_compressed_G1", "pbc_hip_element_to_bytes_compressed_batch",
     "pbc_hip_element_from_bytes_compressed_batch", "pbc_hip_pairing_use_devices", "pbc_hip_device_count",
+    "pbc_hip_pairing_length_in_bytes_x_only_G1", "pbc_hip_element_to_bytes_x_only_batch",
+    "pbc_hip_element_from_bytes_x_only_batch",
 )
 
 
@@ -218,6 +223,27 @@ class Pairing:
         out = np.empty((n, self.length_in_bytes_G1), np.uint8)
         if lib().pbc_hip_element_from_bytes_compressed_batch(self._h, group, _np_ptr(out), _np_ptr(recs), n):
             raise PbcHipError("element_from_bytes_compressed: " + _err())
+        return out
+
+    def element_to_bytes_x_only(self, group, pts):
+        """x||y records -> x records (element_to_bytes_x_only)."""
+        import numpy as np
+        pts = np.ascontiguousarray(pts, dtype=np.uint8)
+        n = pts.size // self.len1
+        out = np.empty((n, lib().pbc_hip_pairing_length_in_bytes_x_only_G1(self._h)), np.uint8)
+        if lib().pbc_hip_element_to_bytes_x_only_batch(self._h, group, _np_ptr(out), _np_ptr(pts), n):
+            raise PbcHipError("element_to_bytes_x_only: " + _err())
+        return out
+
+    def element_from_bytes_x_only(self, group, recs):
+        """x records -> x||y records (element_from_bytes_x_only; y is the root element_sqrt picks)."""
+        import numpy as np
+        recs = np.ascontiguousarray(recs, dtype=np.uint8)
+        lx = lib().pbc_hip_pairing_length_in_bytes_x_only_G1(self._h)
+        n = recs.size // lx
+        out = np.empty((n, self.len1), np.uint8)
+        if lib().pbc_hip_element_from_bytes_x_only_batch(self._h, group, _np_ptr(out), _np_ptr(recs), n):
+            raise PbcHipError("element_from_bytes_x_only: " + _err())
         return out
 
     def element_from_hash(self, group, digests):

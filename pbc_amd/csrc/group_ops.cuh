@@ -450,8 +450,18 @@ PBC_DEV void g_compress_lane(uint8_t *out, const uint8_t *in) {
   for (int i = 0; i < NB; i++) out[i] = in[i];
   out[NB] = in[2 * NB - 1] & 1;        // y is a canonical residue < q: its parity is its last byte's
 }
+// element_to_bytes_x_only / element_from_bytes_x_only (ecc/curve.c:821-836): x alone; the point is rebuilt with
+// whichever root element_sqrt returns (point_from_x :778-791, no sign fix-up).  For q = 3 mod 4 that root is
+// t^((q+1)/4) (element_tonelli, arith/field.c:672-720, with s = 1) and the bytes match the reference; for
+// q = 1 mod 4 the reference's root depends on its randomly drawn non-residue (field_gen_nqr :370-376), so it is
+// defined up to sign there and this routine returns the root of its own Tonelli-Shanks constants.
 template <int N>
-PBC_DEV void g_decompress_lane(uint8_t *out, const uint8_t *in) {
+PBC_DEV void g_to_x_only_lane(uint8_t *out, const uint8_t *in) {
+  const int NB = (int) fpk<N>().fbytes;
+  for (int i = 0; i < NB; i++) out[i] = in[i];
+}
+template <int N>
+PBC_DEV void g_decompress_lane(uint8_t *out, const uint8_t *in, bool x_only = false) {
   const int NB = (int) fpk<N>().fbytes;
   fp<N> x, t, y, ny, ca, cb, o, c;
   fp_set<N>(ca, c_curve.a);
@@ -466,7 +476,7 @@ PBC_DEV void g_decompress_lane(uint8_t *out, const uint8_t *in) {
 #pragma unroll
   for (int i = 0; i < N; i++) o.v[i] = (i == 0);
   fp_mul<N>(c, y, o);                  // canonical residue: its parity is the sign
-  const bool odd = (c.v[0] & 1) != 0, want_odd = in[NB] != 0;
+  const bool odd = (c.v[0] & 1) != 0, want_odd = x_only ? odd : in[NB] != 0;
   fp_neg<N>(ny, y);
   fp_cmov<N>(y, ny, (odd != want_odd) & !fp_is0<N>(y));
   if (!ok) {

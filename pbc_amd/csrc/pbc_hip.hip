@@ -296,14 +296,17 @@ __global__ void __launch_bounds__(kBlock, 2) g_mul_kernel(uint8_t *out, const ui
   const size_t L = 2 * fpk<N>().fbytes;
   g_mul_lane<N>(out + idx * L, in + idx * L, z + idx * zlen, zlen);
 }
-// element_to_bytes_compressed / element_from_bytes_compressed on E(F_q): one point per lane
+// element_to_bytes_compressed / _x_only and element_from_bytes_compressed / _x_only on E(F_q): one point per lane
+// (dir 0 / 2 and 1 / 3)
 template <int N>
 __global__ void __launch_bounds__(kBlock, 2) g_compress_kernel(int dir, uint8_t *out, const uint8_t *in, size_t n) {
   size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
   if (idx >= n) return;
   const size_t fb = fpk<N>().fbytes;
   if (dir == 0) g_compress_lane<N>(out + idx * (fb + 1), in + idx * 2 * fb);
-  else g_decompress_lane<N>(out + idx * 2 * fb, in + idx * (fb + 1));
+  else if (dir == 1) g_decompress_lane<N>(out + idx * 2 * fb, in + idx * (fb + 1));
+  else if (dir == 2) g_to_x_only_lane<N>(out + idx * fb, in + idx * 2 * fb);
+  else g_decompress_lane<N>(out + idx * 2 * fb, in + idx * fb, true);
 }
 // element_mul_zn on the twists: G2 of types d / g (over F_q^d) and f (over F_q^2)
 template <int N, int DEG>
@@ -1031,16 +1034,16 @@ static int ensure_sqrt_constants(pbc_hip_pairing_s *P) {
   }
   return 0;
 }
-// dir 0: x||y -> x||s;  dir 1: x||s -> x||y
+// dir 0: x||y -> x||s;  dir 1: x||s -> x||y;  dir 2: x||y -> x;  dir 3: x -> x||y
 static int run_compress(pbc_hip_pairing_s *P, int dir, int group, uint8_t *out, const uint8_t *in, size_t n) {
   if (!P) return fail("null pairing");
   if (P->device < 0) return fail("no HIP device: libpbc_hip has no CPU fallback");
   const bool symmetric = P->type == 'a' || P->type == '1' || P->type == 'e';
   if (group != 1 && !(group == 2 && symmetric))
-    return fail("compressed points are built for G1 (and G2 of the symmetric types a, a1, e)");
+    return fail("compressed and x-only points are built for G1 (and G2 of the symmetric types a, a1, e)");
   if (!n) return 0;
-  const size_t lp = (size_t) P->len1, lc = (size_t) P->len_fq + 1;
-  const size_t li = dir == 0 ? lp : lc, lo = dir == 0 ? lc : lp;
+  const size_t lp = (size_t) P->len1, lc = (size_t) P->len_fq + (dir < 2 ? 1 : 0);
+  const size_t li = (dir & 1) == 0 ? lp : lc, lo = (dir & 1) == 0 ? lc : lp;
   DevBuf bi, bo;
   HIP_TRY(hipSetDevice(P->device));
   if (ensure_sqrt_constants(P)) return 1;
@@ -1065,6 +1068,15 @@ extern "C" int pbc_hip_element_from_bytes_compressed_batch(pbc_hip_pairing_t *P,
   return run_compress(P, 1, group, out, in, n);
 }
 extern "C" int pbc_hip_pairing_length_in_bytes_compressed_G1(const pbc_hip_pairing_t *p) { return p->len_fq + 1; }
+extern "C" int pbc_hip_element_to_bytes_x_only_batch(pbc_hip_pairing_t *P, int group, uint8_t *out,
+                                                     const uint8_t *in, size_t n) {
+  return run_compress(P, 2, group, out, in, n);
+}
+extern "C" int pbc_hip_element_from_bytes_x_only_batch(pbc_hip_pairing_t *P, int group, uint8_t *out,
+                                                       const uint8_t *in, size_t n) {
+  return run_compress(P, 3, group, out, in, n);
+}
+extern "C" int pbc_hip_pairing_length_in_bytes_x_only_G1(const pbc_hip_pairing_t *p) { return p->len_fq; }
 
 extern "C" int pbc_hip_element_from_hash_batch(pbc_hip_pairing_t *P, int group, uint8_t *out, const uint8_t *data,
                                                int hlen, size_t n) {

@@ -70,8 +70,8 @@ class HostSim:
 
     def compress(self, direction, recs):
         recs = np.ascontiguousarray(recs, np.uint8)
-        lp, lc = self.len1, self.len1 // 2 + 1
-        li, lo = (lp, lc) if direction == 0 else (lc, lp)
+        lp, lc = self.len1, self.len1 // 2 + (1 if direction < 2 else 0)
+        li, lo = (lp, lc) if direction % 2 == 0 else (lc, lp)
         n = recs.size // li
         out = np.empty((n, lo), np.uint8)
         self.L.hostsim_compress.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]

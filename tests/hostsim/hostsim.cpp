@@ -147,7 +147,7 @@ int hostsim_pp(void *h, uint8_t *gt, const uint8_t *g1, const uint8_t *g2, size_
   for (size_t u = 0; u < n; u++) a_pp_apply_lane<16>(gt + u * P->lenT, tab, v, g2 + u * P->len2);
   return 0;
 }
-// compressed points on G1: dir 0 compress, 1 decompress
+// compressed / x-only points on G1: dir 0 compress, 1 decompress, 2 to x-only, 3 from x-only
 int hostsim_compress(void *h, int dir, uint8_t *out, const uint8_t *in, size_t n) {
   pbc_hip_pairing_s *P = (pbc_hip_pairing_s *) h;
   activate(P);
@@ -156,10 +156,12 @@ int hostsim_compress(void *h, int dir, uint8_t *out, const uint8_t *in, size_t n
     P->hash.ts_ready = true;
     activate(P);
   }
-  const size_t lp = P->len1, lc = P->len_fq + 1;
+  const size_t lp = P->len1, lc = P->len_fq + (dir < 2 ? 1 : 0);
   for (size_t i = 0; i < n; i++) {
     if (dir == 0) { HS_DISPATCH(P->nlimb, g_compress_lane<N>(out + i * lc, in + i * lp)); }
-    else { HS_DISPATCH(P->nlimb, g_decompress_lane<N>(out + i * lp, in + i * lc)); }
+    else if (dir == 1) { HS_DISPATCH(P->nlimb, g_decompress_lane<N>(out + i * lp, in + i * lc)); }
+    else if (dir == 2) { HS_DISPATCH(P->nlimb, g_to_x_only_lane<N>(out + i * lc, in + i * lp)); }
+    else { HS_DISPATCH(P->nlimb, g_decompress_lane<N>(out + i * lp, in + i * lc, true)); }
   }
   return 0;
 }

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 import oracle
-from conftest import golden, OTHER, GENERIC_A, GENERIC_OTHER, GENERIC_F, FILES_OF, param_value
+from conftest import XONLY, check_x_only, golden, OTHER, GENERIC_A, GENERIC_OTHER, GENERIC_F, FILES_OF, param_value
 
 pytestmark = pytest.mark.gpu
 
@@ -721,3 +721,12 @@ def test_type_d_signed_limb_experiment_on_gpu():
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "d_lazy_ab.py"), "16"], capture_output=True, text=True, timeout=1200)
     print(out.stdout)
     assert out.returncode == 0, out.stdout + out.stderr
+
+
+@pytest.mark.parametrize("key,name,exact", XONLY)
+def test_x_only_points_match_reference(hips, key, name, exact):
+    """element_to_bytes_x_only / element_from_bytes_x_only (ecc/curve.c:821-836) on G1"""
+    v = golden(name)
+    H = hips[key]
+    check_x_only(lambda p: H.element_to_bytes_x_only(1, p), lambda x: H.element_from_bytes_x_only(1, x), v, exact,
+                 0 if exact else param_value(key, "q"))

@@ -5,7 +5,7 @@ mirror for GPU-less bring-up, not a product path: libpbc_hip.so never contains i
 import numpy as np
 import pytest
 
-from conftest import golden, _param, PARAM_OF, OTHER, GENERIC_A, GENERIC_OTHER, GENERIC_F, FILES_OF, key_of, param_value
+from conftest import XONLY, check_x_only, golden, _param, PARAM_OF, OTHER, GENERIC_A, GENERIC_OTHER, GENERIC_F, FILES_OF, key_of, param_value
 
 hostsim = pytest.importorskip("hostsim")
 
@@ -206,3 +206,11 @@ def test_type_d_signed_limb_experiment_fresh_points(sims, oracles):
     for shift in (1, 7):
         g2 = np.roll(v.g2[:n], shift, axis=0)
         assert np.array_equal(S.prod_pairing(kP, g2, 1, d_lazy=True), O.pairing_batch(kP, g2))
+
+
+@pytest.mark.parametrize("key,name,exact", XONLY)
+def test_x_only_points_on_host(sims, key, name, exact):
+    """element_to_bytes_x_only / element_from_bytes_x_only (ecc/curve.c:821-836) vs the reference"""
+    v = golden(name)
+    S = sims[key]
+    check_x_only(lambda p: S.compress(2, p), lambda x: S.compress(3, x), v, exact, 0 if exact else param_value(key, "q"))

@@ -102,14 +102,19 @@ int pbc_hip_pairing_length_in_bytes_Zr(const pbc_hip_pairing_t *p);
 /* element_from_hash on G1 / G2 (include/pbc_field.h:257 -> curve_from_hash ecc/curve.c:455-482,
  * fp_from_hash arith/montfp.c:440-448, pbc_mpz_from_hash arith/field.c:643-668): n digests of hlen
  * bytes each -> n points, including the cofactor multiplication.  group = 1 for every type (any
- * odd q: Tonelli-Shanks where q = 1 mod 4); group = 2 for the symmetric types a, a1, e. */
+ * odd q: Tonelli-Shanks where q = 1 mod 4); group = 2 for the symmetric types a, a1, e and for the twists of
+ * types d, g, f (x from polymod_from_hash, arith/poly.c:341-348, or fq_from_hash, fieldquadratic.c:311-316;
+ * square roots in F_q^d / F_q^2 on the device; those curves carry no cofactor: d_param.c:1057, f_param.c:383,
+ * g_param.c:1319). */
 int pbc_hip_element_from_hash_batch(pbc_hip_pairing_t *p, int group, uint8_t *out, const uint8_t *data,
                                     int hlen, size_t n);
 /* element_to_bytes_compressed / element_from_bytes_compressed (ecc/curve.c:762-773, :800-815;
- * pairing_length_in_bytes_compressed_G1, include/pbc_pairing.h:199-204) on G1 (G2 of the symmetric
- * types): records of length_in_bytes_Fq + 1 bytes, x || s with s = 1 when the canonical y is odd.
+ * pairing_length_in_bytes_compressed_G1, include/pbc_pairing.h:199-204) on G1 and G2: records of
+ * length_in_bytes(x) + 1 bytes, x || s with s = 1 when element_sign(y) > 0 (F_q: the canonical y is odd;
+ * F_q^d / F_q^2 of the twists: the first non-zero coefficient of y is, poly.c:1189-1199, fieldquadratic.c:159-165).
  * Decompression takes the square root on the device; an x with no point above it gives zeros. */
 int pbc_hip_pairing_length_in_bytes_compressed_G1(const pbc_hip_pairing_t *p);
+int pbc_hip_pairing_length_in_bytes_compressed_G2(const pbc_hip_pairing_t *p);   /* include/pbc_pairing.h:210-216 */
 int pbc_hip_element_to_bytes_compressed_batch(pbc_hip_pairing_t *p, int group, uint8_t *out, const uint8_t *in,
                                               size_t n);
 int pbc_hip_element_from_bytes_compressed_batch(pbc_hip_pairing_t *p, int group, uint8_t *out, const uint8_t *in,

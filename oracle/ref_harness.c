@@ -240,16 +240,18 @@ static int cmd_gmul(int argc, char **argv) {
  * element_to_bytes_compressed form (x || sign byte, ecc/curve.c:762-773); each compressed record is
  * fed back through element_from_bytes_compressed (:800-815) and must reproduce the point. */
 static int cmd_compress(int argc, char **argv) {
-  if (argc < 5) { fprintf(stderr, "compress <param> <n> <seed> <out>\n"); return 2; }
+  if (argc < 5) { fprintf(stderr, "compress <param> <n> <seed> <out> [group]\n"); return 2; }
   int n = atoi(argv[2]);
   unsigned seed = (unsigned) atoi(argv[3]);
+  const int group = argc > 5 ? atoi(argv[5]) : 1;
   pairing_t pairing; char type;
   pbc_random_set_deterministic(seed);
   init_pairing(pairing, argv[1], &type);
-  int lp = pairing_length_in_bytes_G1(pairing);
+  int lp = group == 2 ? pairing_length_in_bytes_G2(pairing) : pairing_length_in_bytes_G1(pairing);
   element_t P, R;
-  element_init_G1(P, pairing); element_init_G1(R, pairing);
-  int lc = pairing_length_in_bytes_compressed_G1(pairing);
+  if (group == 2) { element_init_G2(P, pairing); element_init_G2(R, pairing); }
+  else { element_init_G1(P, pairing); element_init_G1(R, pairing); }
+  int lc = group == 2 ? pairing_length_in_bytes_compressed_G2(pairing) : pairing_length_in_bytes_compressed_G1(pairing);
   unsigned char *in = malloc((size_t) n * lp), *out = malloc((size_t) n * lc);
   for (int i = 0; i < n; i++) {
     element_random(P);
@@ -273,15 +275,17 @@ static int cmd_compress(int argc, char **argv) {
  * q = 1 mod 4 element_tonelli (arith/field.c:672-720) works from a randomly drawn non-residue
  * (field_gen_nqr), so <seed> (set before the pairing is initialised) lets a caller see whether the root moves. */
 static int cmd_xonly(int argc, char **argv) {
-  if (argc < 5) { fprintf(stderr, "xonly <param> <n> <seed> <out>\n"); return 2; }
+  if (argc < 5) { fprintf(stderr, "xonly <param> <n> <seed> <out> [group]\n"); return 2; }
   int n = atoi(argv[2]);
+  const int group = argc > 5 ? atoi(argv[5]) : 1;
   pairing_t pairing; char type;
   pbc_random_set_deterministic((unsigned) atoi(argv[3]));
   init_pairing(pairing, argv[1], &type);
-  int lp = pairing_length_in_bytes_G1(pairing);
+  int lp = group == 2 ? pairing_length_in_bytes_G2(pairing) : pairing_length_in_bytes_G1(pairing);
   element_t P, R;
-  element_init_G1(P, pairing); element_init_G1(R, pairing);
-  int lx = pairing_length_in_bytes_x_only_G1(pairing);
+  if (group == 2) { element_init_G2(P, pairing); element_init_G2(R, pairing); }
+  else { element_init_G1(P, pairing); element_init_G1(R, pairing); }
+  int lx = group == 2 ? pairing_length_in_bytes_x_only_G2(pairing) : pairing_length_in_bytes_x_only_G1(pairing);
   unsigned char *in = malloc((size_t) n * lp), *xs = malloc((size_t) n * lx), *out = malloc((size_t) n * lp);
   for (int i = 0; i < n; i++) {
     char msg[32];
@@ -366,18 +370,19 @@ static int cmd_genf(int argc, char **argv) {
 }
 
 static int cmd_hash(int argc, char **argv) {
-  if (argc < 6) { fprintf(stderr, "hash <param> <n> <hlen> <seed> <out>\n"); return 2; }
+  if (argc < 6) { fprintf(stderr, "hash <param> <n> <hlen> <seed> <out> [group]\n"); return 2; }
   int n = atoi(argv[2]), hlen = atoi(argv[3]);
+  const int group = argc > 6 ? atoi(argv[6]) : 1;
   unsigned seed = (unsigned) atoi(argv[4]);
   pairing_t pairing; char type;
   pbc_random_set_deterministic(seed);
   init_pairing(pairing, argv[1], &type);
-  int l1 = pairing_length_in_bytes_G1(pairing);
+  int l1 = group == 2 ? pairing_length_in_bytes_G2(pairing) : pairing_length_in_bytes_G1(pairing);
   unsigned char *in = malloc((size_t) n * hlen), *out = malloc((size_t) n * l1);
   uint64_t st = 0x9e3779b97f4a7c15ull * (seed + 1);
   for (size_t i = 0; i < (size_t) n * hlen; i++) { st ^= st << 13; st ^= st >> 7; st ^= st << 17; in[i] = (unsigned char) (st >> 24); }
   element_t h;
-  element_init_G1(h, pairing);
+  if (group == 2) element_init_G2(h, pairing); else element_init_G1(h, pairing);
   for (int i = 0; i < n; i++) {
     element_from_hash(h, in + (size_t) i * hlen, hlen);
     element_to_bytes(out + (size_t) i * l1, h);

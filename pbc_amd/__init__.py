@@ -65,6 +65,7 @@ def lib():
         L.pbc_hip_pairing_length_in_bytes_Zr.argtypes = [vp]
         L.pbc_hip_element_mul_zn_batch.argtypes = [vp, ci, vp, vp, vp, sz]
         L.pbc_hip_pairing_length_in_bytes_compressed_G1.argtypes = [vp]
+        L.pbc_hip_pairing_length_in_bytes_compressed_G2.argtypes = [vp]
         L.pbc_hip_pairing_use_devices.argtypes = [vp, ctypes.POINTER(ctypes.c_int), ci]
         L.pbc_hip_element_to_bytes_compressed_batch.argtypes = [vp, ci, vp, vp, sz]
         L.pbc_hip_element_from_bytes_compressed_batch.argtypes = [vp, ci, vp, vp, sz]
@@ -101,6 +102,7 @@ EXPORTS = (
     "pbc_hip_pairing_length_in_bytes_compressed_G1", "pbc_hip_element_to_bytes_compressed_batch",
     "pbc_hip_element_from_bytes_compressed_batch", "pbc_hip_pairing_use_devices", "pbc_hip_device_count",
     "pbc_hip_pairing_length_in_bytes_x_only_G1", "pbc_hip_element_to_bytes_x_only_batch",
+    "pbc_hip_pairing_length_in_bytes_compressed_G2",
     "pbc_hip_element_from_bytes_x_only_batch",
 )
 
@@ -204,12 +206,19 @@ class Pairing:
             raise PbcHipError("element_mul_zn: " + _err())
         return out
 
+    def _point_len(self, group):
+        return self.length_in_bytes_G2 if group == 2 else self.length_in_bytes_G1
+
+    def _compressed_len(self, group):
+        f = lib().pbc_hip_pairing_length_in_bytes_compressed_G2 if group == 2 else lib().pbc_hip_pairing_length_in_bytes_compressed_G1
+        return f(self._h)
+
     def element_to_bytes_compressed(self, group, pts):
         """x||y records -> x||sign records (element_to_bytes_compressed)."""
         import numpy as np
         pts = np.ascontiguousarray(pts, dtype=np.uint8)
-        n = pts.size // self.length_in_bytes_G1
-        out = np.empty((n, lib().pbc_hip_pairing_length_in_bytes_compressed_G1(self._h)), np.uint8)
+        n = pts.size // self._point_len(group)
+        out = np.empty((n, self._compressed_len(group)), np.uint8)
         if lib().pbc_hip_element_to_bytes_compressed_batch(self._h, group, _np_ptr(out), _np_ptr(pts), n):
             raise PbcHipError("element_to_bytes_compressed: " + _err())
         return out
@@ -218,9 +227,8 @@ class Pairing:
         """x||sign records -> x||y records (element_from_bytes_compressed)."""
         import numpy as np
         recs = np.ascontiguousarray(recs, dtype=np.uint8)
-        lc = lib().pbc_hip_pairing_length_in_bytes_compressed_G1(self._h)
-        n = recs.size // lc
-        out = np.empty((n, self.length_in_bytes_G1), np.uint8)
+        n = recs.size // self._compressed_len(group)
+        out = np.empty((n, self._point_len(group)), np.uint8)
         if lib().pbc_hip_element_from_bytes_compressed_batch(self._h, group, _np_ptr(out), _np_ptr(recs), n):
             raise PbcHipError("element_from_bytes_compressed: " + _err())
         return out
@@ -229,7 +237,7 @@ class Pairing:
         """x||y records -> x records (element_to_bytes_x_only)."""
         import numpy as np
         pts = np.ascontiguousarray(pts, dtype=np.uint8)
-        n = pts.size // self.len1
+        n = pts.size // self.length_in_bytes_G1
         out = np.empty((n, lib().pbc_hip_pairing_length_in_bytes_x_only_G1(self._h)), np.uint8)
         if lib().pbc_hip_element_to_bytes_x_only_batch(self._h, group, _np_ptr(out), _np_ptr(pts), n):
             raise PbcHipError("element_to_bytes_x_only: " + _err())
@@ -241,17 +249,17 @@ class Pairing:
         recs = np.ascontiguousarray(recs, dtype=np.uint8)
         lx = lib().pbc_hip_pairing_length_in_bytes_x_only_G1(self._h)
         n = recs.size // lx
-        out = np.empty((n, self.len1), np.uint8)
+        out = np.empty((n, self.length_in_bytes_G1), np.uint8)
         if lib().pbc_hip_element_from_bytes_x_only_batch(self._h, group, _np_ptr(out), _np_ptr(recs), n):
             raise PbcHipError("element_from_bytes_x_only: " + _err())
         return out
 
     def element_from_hash(self, group, digests):
-        """digests: (n, hlen) uint8 -> n points of G1 (G2 for the symmetric types) (element_from_hash)."""
+        """digests: (n, hlen) uint8 -> n points of G1 or G2 (element_from_hash)."""
         import numpy as np
         d = np.ascontiguousarray(digests, dtype=np.uint8)
         n, hlen = d.shape
-        out = np.empty((n, self.length_in_bytes_G1), np.uint8)
+        out = np.empty((n, self._point_len(group)), np.uint8)
         if lib().pbc_hip_element_from_hash_batch(self._h, group, _np_ptr(out), _np_ptr(d), hlen, n):
             raise PbcHipError("element_from_hash: " + _err())
         return out

@@ -38,6 +38,8 @@ PBC_DEV uint32_t zr_bit(const uint8_t *z, int zlen, int i) { return (z[zlen - 1 
 // F supplies: el, bytes(), curve_a/curve_b/a_is_zero(), one/zero, add/sub/dbl/mul/sqr/inv, is0/eq,
 // cmov, load/store.  Used for E(F_q) (G1; G2 of the symmetric types) and for the twists over
 // F_q^d (types d, g: curve.c:885-901 coefficients a v^2, b v^3) and F_q^2 (type f: f_param.c:372-383).
+template <int N> PBC_DEV void fq_from_hash_lane(fp<N> &x, const uint8_t *data, int hlen);   // defined below
+
 template <int N>
 struct FqOps {
   typedef fp<N> el;
@@ -80,6 +82,32 @@ struct FdOps {                         // F_q^d of types d / g: the twist E'(F_q
   static PBC_DEV void cmov(el &r, const el &a, bool c) { for (int i = 0; i < DEG; i++) fp_cmov<N>(r.c[i], a.c[i], c); }
   static PBC_DEV void load(el &r, const uint8_t *s) { T::f3_load_be(r, s); }
   static PBC_DEV void store(uint8_t *d, const el &a) { T::f3_store_be(d, a); }
+  // extension-field helpers for element_from_hash / compressed points on the twist
+  static constexpr int WORDS = DEG * N;
+  static PBC_DEV el from_words(const uint32_t *w) { el r; for (int i = 0; i < DEG; i++) fp_set<N>(r.c[i], w + N * i); return r; }
+  static PBC_DEV void to_words(uint32_t *w, const el &a) { for (int i = 0; i < DEG; i++) for (int k = 0; k < N; k++) w[N * i + k] = a.c[i].v[k]; }
+  static PBC_DEV el nonresidue() { el r; T::f3_set_fq(r, T::dk(c_d.nqr)); return r; }   // v: F_q^k = F_q^d[sqrt(v)]
+  // polymod_from_hash (arith/poly.c:341-348): every coefficient is the same hash value
+  static PBC_DEV el hash_x(const uint8_t *data, int hlen) {
+    el r;
+    fq_from_hash_lane<N>(r.c[0], data, hlen);
+    for (int i = 1; i < DEG; i++) r.c[i] = r.c[0];
+    return r;
+  }
+  // polymod_sgn (poly.c:1189-1199) with fp_sgn_odd (montfp.c:460-472): the sign of the first non-zero
+  // coefficient, positive when its canonical residue is odd.  Returns true for "negative".
+  static PBC_DEV bool is_negative(const el &a) {
+    fp<N> o, c;
+    for (int k = 0; k < N; k++) o.v[k] = (k == 0);
+    bool decided = false, negative = false;
+    for (int i = 0; i < DEG; i++) {
+      fp_mul<N>(c, a.c[i], o);
+      const bool nz = !fp_is0<N>(c);
+      negative = (!decided & nz) ? ((c.v[0] & 1) == 0) : negative;
+      decided |= nz;
+    }
+    return negative;
+  }
 };
 template <int ND>
 struct Fq2Ops {                        // F_q^2 of type f: the twist y^2 = x^3 + tb
@@ -102,6 +130,28 @@ struct Fq2Ops {                        // F_q^2 of type f: the twist y^2 = x^3 +
   static PBC_DEV void cmov(el &r, const el &a, bool c) { fp_cmov<ND>(r.x, a.x, c); fp_cmov<ND>(r.y, a.y, c); }
   static PBC_DEV void load(el &r, const uint8_t *s) { T::g2_load_be(r, s); }
   static PBC_DEV void store(uint8_t *d, const el &a) { T::g2_store_be(d, a); }
+  static constexpr int WORDS = 2 * ND;
+  static PBC_DEV el from_words(const uint32_t *w) { el r; fp_set<ND>(r.x, w); fp_set<ND>(r.y, w + ND); return r; }
+  static PBC_DEV void to_words(uint32_t *w, const el &a) { for (int k = 0; k < ND; k++) { w[k] = a.x.v[k]; w[ND + k] = a.y.v[k]; } }
+  // x^6 + alpha is irreducible, so alpha is no square in F_q^2, and neither is -alpha (-1 is a square there)
+  static PBC_DEV el nonresidue() { return T::fk2(c_f.negalpha); }
+  // fq_from_hash (arith/fieldquadratic.c:311-316): the two halves of the digest
+  static PBC_DEV el hash_x(const uint8_t *data, int hlen) {
+    el r;
+    const int k = hlen / 2;
+    fq_from_hash_lane<ND>(r.x, data, k);
+    fq_from_hash_lane<ND>(r.y, data + k, hlen - k);
+    return r;
+  }
+  // fq_sign (fieldquadratic.c:159-165): sign of x, of y when x = 0
+  static PBC_DEV bool is_negative(const el &a) {
+    fp<ND> o, cx, cy;
+    for (int k = 0; k < ND; k++) o.v[k] = (k == 0);
+    fp_mul<ND>(cx, a.x, o);
+    fp_mul<ND>(cy, a.y, o);
+    const bool xz = fp_is0<ND>(cx), yz = fp_is0<ND>(cy);
+    return xz ? (!yz & ((cy.v[0] & 1) == 0)) : ((cx.v[0] & 1) == 0);
+  }
 };
 
 // out = [k] P for P = (x, y) bytes; off-curve P is O (curve_from_bytes); O serialises as zeros.
@@ -305,6 +355,40 @@ PBC_DEV void fp_ts_init(uint32_t *out, const uint32_t *texp, int tbits, const ui
   }
   for (int k = 0; k < N; k++) out[k] = c.v[k];
 }
+// pbc_mpz_from_hash (arith/field.c:643-668, called by fp_from_hash, montfp.c:441-449): fbytes bytes = H || ctr || H || ctr+1 ... read as a
+// big-endian integer z, then z >>= 1 while z > q; result in Montgomery form
+template <int N>
+PBC_DEV void fq_from_hash_lane(fp<N> &x, const uint8_t *data, int hlen) {
+  const int NB = (int) fpk<N>().fbytes;
+  const FpK<N> &K = fpk<N>();
+  uint32_t w[N];
+#pragma unroll
+  for (int i = 0; i < N; i++) w[i] = 0;
+  int p = 0;
+  uint32_t ctr = 0;
+  for (int b = 0; b < NB; b++) {
+    uint32_t byte;
+    if (p < hlen) byte = data[p++];
+    else { byte = ctr++ & 0xff; p = 0; }
+    const int bit = 8 * (NB - 1 - b);
+#pragma unroll
+    for (int i = 0; i < N; i++) w[i] |= (i == (bit >> 5)) ? byte << (bit & 31) : 0u;
+  }
+  for (int rep = 0; rep < 8; rep++) {
+    uint32_t bw = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) (void) __builtin_subc(K.p[i], w[i], bw, &bw);
+    if (bw) {                          // q - z borrowed: z > q
+#pragma unroll
+      for (int i = 0; i < N; i++) w[i] = (w[i] >> 1) | (i + 1 < N ? w[i + 1] << 31 : 0u);
+    }
+  }
+  fp<N> t, r2;
+#pragma unroll
+  for (int i = 0; i < N; i++) t.v[i] = w[i];
+  fp_set<N>(r2, K.r2);
+  fp_mul<N>(x, t, r2);
+}
 template <int N>
 PBC_DEV void g_from_hash_lane(uint8_t *out, const uint8_t *data, int hlen) {
   const int NB = (int) fpk<N>().fbytes;
@@ -313,37 +397,7 @@ PBC_DEV void g_from_hash_lane(uint8_t *out, const uint8_t *data, int hlen) {
   fp_set<N>(one, K.one);
   fp_set<N>(ca, c_curve.a);
   fp_set<N>(cb, c_curve.b);
-  // pbc_mpz_from_hash: NB bytes = H || ctr || H || ctr+1 ...  (big-endian integer)
-  {
-    uint32_t w[N];
-#pragma unroll
-    for (int i = 0; i < N; i++) w[i] = 0;
-    int p = 0;
-    uint32_t ctr = 0;
-    for (int b = 0; b < NB; b++) {
-      uint32_t byte;
-      if (p < hlen) byte = data[p++];
-      else { byte = ctr++ & 0xff; p = 0; }
-      const int bit = 8 * (NB - 1 - b);
-#pragma unroll
-      for (int i = 0; i < N; i++) w[i] |= (i == (bit >> 5)) ? byte << (bit & 31) : 0u;
-    }
-    // while (z > q) z >>= 1
-    for (int rep = 0; rep < 8; rep++) {
-      uint32_t bw = 0;
-#pragma unroll
-      for (int i = 0; i < N; i++) (void) __builtin_subc(K.p[i], w[i], bw, &bw);
-      if (bw) {                        // q - z borrowed: z > q
-#pragma unroll
-        for (int i = 0; i < N; i++) w[i] = (w[i] >> 1) | (i + 1 < N ? w[i + 1] << 31 : 0u);
-      }
-    }
-    fp<N> t, r2;
-#pragma unroll
-    for (int i = 0; i < N; i++) t.v[i] = w[i];
-    fp_set<N>(r2, K.r2);
-    fp_mul<N>(x, t, r2);
-  }
+  fq_from_hash_lane<N>(x, data, hlen);
   bool done = false;
   fx = x; fy = x;
   for (int it = 0; it < 256; it++) {
@@ -591,6 +645,138 @@ __device__ void f_gt_pow_lane(uint8_t *out, const uint8_t *a, const uint8_t *z, 
     }
   }
   f_gt_store<ND>(out, &acc);
+}
+
+// ---- square roots, element_from_hash and compressed points on the twists (G2 of types d, g, f) -----------
+// The reference takes square roots in F_q^d with a randomised Cantor-Zassenhaus step (polymod_sqrt,
+// arith/poly.c:634-700) and in F_q^2 with the norm formula (fq_sqrt, fieldquadratic.c:357-420); both callers
+// below normalise the sign afterwards, so any root serves.  Here: Tonelli-Shanks in the extension itself,
+// |F*| = 2^s T with T odd, from the non-residue the tower is built on; wave-uniform control flow as in
+// fp_sqrt_lane.
+struct ExtSqrtK {
+  uint32_t e[24], t[24];               // (T - 1)/2 and T
+  int ebits, tbits, s;
+  uint32_t c[40];                      // z^T (Montgomery words, coefficient-major); derived on the device
+};
+__constant__ ExtSqrtK c_xs;
+
+template <class F>
+PBC_DEV void ext_pow(typename F::el &r, const typename F::el &a, const uint32_t *e, int bits) {
+  r = F::one();
+  for (int i = bits - 1; i >= 0; i--) {
+    F::sqr(r, r);
+    if ((e[i >> 5] >> (i & 31)) & 1) F::mul(r, r, a);
+  }
+}
+template <class F>
+PBC_DEV void ext_ts_init(uint32_t *out) {
+  typename F::el c;
+  ext_pow<F>(c, F::nonresidue(), c_xs.t, c_xs.tbits);
+  F::to_words(out, c);
+}
+template <class F>
+PBC_DEV void ext_sqrt_lane(typename F::el &y, bool &ok, const typename F::el &t) {
+  typedef typename F::el el;
+  el w, r, b, c, g, tt;
+  const el one = F::one();
+  ext_pow<F>(w, t, c_xs.e, c_xs.ebits);
+  F::mul(r, t, w);
+  F::mul(b, r, w);
+  c = F::from_words(c_xs.c);
+  const int s = c_xs.s;
+  int m = s;
+  ok = true;
+  for (int round = 0; round < s; round++) {
+    int i = 0;
+    bool found = F::eq(b, one);
+    tt = b;
+    for (int j = 1; j <= s; j++) {
+      F::sqr(tt, tt);
+      bool hit = !found & F::eq(tt, one);
+      i = hit ? j : i;
+      found |= hit;
+    }
+    ok &= found & (i < m || i == 0);
+    const bool upd = ok & (i > 0) & (i < m);
+    g = c;
+    for (int j = 0; j < s; j++) {
+      F::sqr(tt, g);
+      F::cmov(g, tt, upd & (j < m - i - 1));
+    }
+    F::mul(tt, r, g);
+    F::cmov(r, tt, upd);
+    F::sqr(g, g);
+    F::cmov(c, g, upd);
+    F::mul(tt, b, g);
+    F::cmov(b, tt, upd);
+    m = upd ? i : m;
+  }
+  ok &= F::eq(b, one);
+  y = r;
+}
+// curve_from_hash (ecc/curve.c:455-482) on E'(K): x from the digest, x <- x^2 + 1 until x^3 + a x + b is a
+// square, y the root with non-negative sign.  The twists are initialised without a cofactor
+// (d_param.c:1057, f_param.c:383, g_param.c:1319), so no multiplication follows.
+template <class F>
+PBC_DEV void g2_from_hash_lane(uint8_t *out, const uint8_t *data, int hlen) {
+  typedef typename F::el el;
+  const el one = F::one(), ca = F::curve_a(), cb = F::curve_b();
+  el x = F::hash_x(data, hlen), fx = x, fy = x;
+  bool done = false;
+  for (int it = 0; it < 256; it++) {
+    el t, y;
+    F::sqr(t, x);
+    F::add(t, t, ca);
+    F::mul(t, t, x);
+    F::add(t, t, cb);
+    bool ok;
+    ext_sqrt_lane<F>(y, ok, t);
+    ok &= !done;
+    F::cmov(fx, x, ok);
+    F::cmov(fy, y, ok);
+    done |= ok;
+    if (__all(done)) break;
+    F::sqr(x, x);
+    F::add(x, x, one);
+  }
+  {
+    el ny = F::zero();
+    F::sub(ny, ny, fy);
+    F::cmov(fy, ny, F::is_negative(fy));
+  }
+  F::store(out, fx);
+  F::store(out + F::bytes(), fy);
+}
+// element_to_bytes_compressed / element_from_bytes_compressed (ecc/curve.c:762-815) on E'(K): x || s with
+// s = 1 when element_sign(y) > 0
+template <class F>
+PBC_DEV void g2_compress_lane(uint8_t *out, const uint8_t *in) {
+  typedef typename F::el el;
+  const int NB = F::bytes();
+  el y;
+  F::load(y, in + NB);
+  for (int i = 0; i < NB; i++) out[i] = in[i];
+  out[NB] = (!F::is_negative(y) & !F::is0(y)) ? 1 : 0;
+}
+template <class F>
+PBC_DEV void g2_decompress_lane(uint8_t *out, const uint8_t *in) {
+  typedef typename F::el el;
+  const int NB = F::bytes();
+  el x, t, y, ny = F::zero();
+  F::load(x, in);
+  F::sqr(t, x);
+  F::add(t, t, F::curve_a());
+  F::mul(t, t, x);
+  F::add(t, t, F::curve_b());
+  bool ok;
+  ext_sqrt_lane<F>(y, ok, t);
+  // :806-810: s != 0 wants sign(y) >= 0, s == 0 wants sign(y) <= 0
+  const bool neg = F::is_negative(y), want_pos = in[NB] != 0;
+  F::sub(ny, ny, y);
+  F::cmov(y, ny, (neg == want_pos) & !F::is0(y));
+  if (!ok) { x = F::zero(); y = F::zero(); }
+  F::store(out, x);
+  F::store(out + NB, y);
 }
 
 }  // namespace pbc

@@ -66,7 +66,32 @@ struct pbc_hip_pairing_s {
     int ts_s; uint32_t ts_t[34]; int ts_tbits; uint32_t half[34]; int halfbits;
     uint32_t ts_c[34]; bool ts_ready;
   } hash;
+  ExtSqrtK xs;               // square roots in the field of the G2 twist (types d, g, f); xs.c derived on first use
+  bool xs_ready;
 };
+
+// |K*| = q^m - 1 = 2^s T for the twist's field K = F_q^m (m = d for types d / g, 2 for type f)
+static int fill_ext_sqrt(pbc_hip_pairing_s *P, const pbc_host::Big &q, int m) {
+  using pbc_host::Big;
+  memset(&P->xs, 0, sizeof P->xs);
+  P->xs_ready = false;
+  Big n = q, two, rem;
+  two.w.push_back(2);
+  for (int i = 1; i < m; i++) n = Big::mul(n, q);
+  n.sub_small(1);
+  int s = 0;
+  while (!n.bit(0)) { n = Big::div(n, two, &rem); s++; }
+  if (n.bits() > 24 * 32) return fail("twist field wider than 768 bits");
+  n.to_words(P->xs.t, 24);
+  P->xs.tbits = n.bits();
+  P->xs.s = s;
+  Big e = n;
+  e.sub_small(1);
+  e = Big::div(e, two, &rem);
+  e.to_words(P->xs.e, 24);
+  P->xs.ebits = e.bits();
+  return 0;
+}
 
 // curve_from_hash constants: cofactor (0 = none) and the square-root recipe of F_q
 static int fill_hash_consts(pbc_hip_pairing_s *P, const pbc_host::Big &q, const pbc_host::Big *cofac) {
@@ -403,6 +428,7 @@ static int init_type_d(pbc_hip_pairing_s *P, const char *txt, size_t len, int de
   }
   Big h;
   if (!param_big(txt, len, "h", h)) return fail("%s: missing h", tn);
+  if (fill_ext_sqrt(P, q, deg)) return 1;  // G2 = E'(F_q^d)
   return fill_hash_consts(P, q, &h);       // cofactor h (d_param.c:1016, g_param.c:1267)
 }
 
@@ -500,6 +526,7 @@ static int init_type_f(pbc_hip_pairing_s *P, const char *txt, size_t len) {
   P->fq_muls_single = 54000.0 * r.bits() / 158.0 + 118887.0 * te.bits() / 472.0;
   P->fq_muls_prod_a = P->fq_muls_single;   // generic_prod_pairings: k full pairings
   P->fq_muls_prod_b = 0.0;
+  if (fill_ext_sqrt(P, q, 2)) return 1;    // G2 = E'(F_q^2)
   return fill_hash_consts(P, q, nullptr);  // no cofactor (f_param.c:372)
 }
 

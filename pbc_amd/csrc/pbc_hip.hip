@@ -335,6 +335,27 @@ __global__ void __launch_bounds__(kBlock, 2) g_from_hash_kernel(uint8_t *out, co
   if (idx < n)
     for (int i = 0; i < L; i++) out[idx * L + i] = o[i];
 }
+// element_from_hash / element_to_bytes_compressed / element_from_bytes_compressed on the G2 twists (types d, g, f):
+// F is the field policy of the twist (FdOps / Fq2Ops).  what 0: digests of `aux` bytes -> points; 1: points ->
+// x || s; 2: x || s -> points
+template <class F>
+__global__ void __launch_bounds__(kBlock, 2) g2_point_kernel(int what, uint8_t *out, const uint8_t *in, int aux, size_t n) {
+  size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
+  size_t ld = idx < n ? idx : n - 1;   // whole waves stay in the retry loop together
+  const size_t fb = (size_t) F::bytes();
+  const size_t li = what == 0 ? (size_t) aux : what == 1 ? 2 * fb : fb + 1, lo = what == 1 ? fb + 1 : 2 * fb;
+  __attribute__((aligned(4))) uint8_t o[8 * F::WORDS];
+  if (what == 0) g2_from_hash_lane<F>(o, in + ld * li, aux);
+  else if (what == 1) g2_compress_lane<F>(o, in + ld * li);
+  else g2_decompress_lane<F>(o, in + ld * li);
+  if (idx < n)
+    for (size_t i = 0; i < lo; i++) out[idx * lo + i] = o[i];
+}
+template <class F>
+__global__ void ext_ts_init_kernel(uint32_t *out) {
+  if (threadIdx.x || blockIdx.x) return;
+  ext_ts_init<F>(out);
+}
 // one lane: z^t' for the Tonelli-Shanks square roots of element_from_hash (fields with q = 1 mod 4)
 struct TsRaw { uint32_t t[34], half[34]; int tbits, halfbits; };
 template <int N>
@@ -768,6 +789,8 @@ static int upload_constants(pbc_hip_pairing_s *P, hipStream_t s) {
     }
     HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_f), &P->fconst, sizeof P->fconst, 0, hipMemcpyHostToDevice, s));
   }
+  if (P->type == 'd' || P->type == 'g' || P->type == 'f')
+    HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_xs), &P->xs, sizeof P->xs, 0, hipMemcpyHostToDevice, s));
   {
     CurveK C;
     fill_curve(P, C);
@@ -1034,13 +1057,56 @@ static int ensure_sqrt_constants(pbc_hip_pairing_s *P) {
   }
   return 0;
 }
+// F = field policy of the G2 twist of an asymmetric type
+#define PBC_DISPATCH_TWIST(P_, ...)                                                           \
+  do {                                                                                        \
+    if ((P_)->type == 'f') { PBC_DISPATCH_F((P_)->nlimb, { typedef Fq2Ops<N> F; __VA_ARGS__; }); } \
+    else { PBC_DISPATCH_D(P_, { typedef FdOps<N, DEG> F; __VA_ARGS__; }); }                   \
+  } while (0)
+// z^T for the square roots in the twist's field, once per parameter set
+static int ensure_ext_sqrt(pbc_hip_pairing_s *P) {
+  if (!P->xs_ready) {
+    if (upload_constants(P, 0)) return 1;
+    DevBuf bc;
+    HIP_TRY(bc.alloc(sizeof P->xs.c));
+    uint32_t *dc = bc.as<uint32_t>();
+    HIP_TRY(hipMemset(dc, 0, sizeof P->xs.c));
+    PBC_DISPATCH_TWIST(P, hipLaunchKernelGGL(ext_ts_init_kernel<F>, dim3(1), dim3(64), 0, 0, dc));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(P->xs.c, dc, sizeof P->xs.c, hipMemcpyDeviceToHost));
+    P->xs_ready = true;
+  }
+  return 0;
+}
+// what 0: element_from_hash (li = hlen), 1: to_bytes_compressed, 2: from_bytes_compressed -- on the G2 twist
+static int run_twist_points(pbc_hip_pairing_s *P, int what, uint8_t *out, const uint8_t *in, int hlen, size_t n) {
+  const size_t lp = (size_t) P->len2, lc = lp / 2 + 1;
+  const size_t li = what == 0 ? (size_t) hlen : what == 1 ? lp : lc, lo = what == 1 ? lc : lp;
+  DevBuf bi, bo;
+  HIP_TRY(hipSetDevice(P->device));
+  if (ensure_ext_sqrt(P)) return 1;
+  HIP_TRY(bi.alloc(n * li));
+  HIP_TRY(bo.alloc(n * lo));
+  void *di = bi.p, *d_o = bo.p;
+  HIP_TRY(hipMemcpy(di, in, n * li, hipMemcpyHostToDevice));
+  if (upload_constants(P, 0)) return 1;
+  unsigned grid = (unsigned) ((n + kBlock - 1) / kBlock);
+  PBC_DISPATCH_TWIST(P, hipLaunchKernelGGL(g2_point_kernel<F>, dim3(grid), dim3(kBlock), 0, 0, what, (uint8_t *) d_o,
+                                           (const uint8_t *) di, hlen, n));
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(out, d_o, n * lo, hipMemcpyDeviceToHost));
+  return 0;
+}
 // dir 0: x||y -> x||s;  dir 1: x||s -> x||y;  dir 2: x||y -> x;  dir 3: x -> x||y
 static int run_compress(pbc_hip_pairing_s *P, int dir, int group, uint8_t *out, const uint8_t *in, size_t n) {
   if (!P) return fail("null pairing");
   if (P->device < 0) return fail("no HIP device: libpbc_hip has no CPU fallback");
   const bool symmetric = P->type == 'a' || P->type == '1' || P->type == 'e';
-  if (group != 1 && !(group == 2 && symmetric))
-    return fail("compressed and x-only points are built for G1 (and G2 of the symmetric types a, a1, e)");
+  if (group == 2 && !symmetric) {
+    if (dir > 1) return fail("x-only points are built for G1 (and G2 of the symmetric types a, a1, e)");
+    return n ? run_twist_points(P, dir + 1, out, in, 0, n) : 0;
+  }
+  if (group != 1 && group != 2) return fail("group must be 1 or 2");
   if (!n) return 0;
   const size_t lp = (size_t) P->len1, lc = (size_t) P->len_fq + (dir < 2 ? 1 : 0);
   const size_t li = (dir & 1) == 0 ? lp : lc, lo = (dir & 1) == 0 ? lc : lp;
@@ -1068,6 +1134,7 @@ extern "C" int pbc_hip_element_from_bytes_compressed_batch(pbc_hip_pairing_t *P,
   return run_compress(P, 1, group, out, in, n);
 }
 extern "C" int pbc_hip_pairing_length_in_bytes_compressed_G1(const pbc_hip_pairing_t *p) { return p->len_fq + 1; }
+extern "C" int pbc_hip_pairing_length_in_bytes_compressed_G2(const pbc_hip_pairing_t *p) { return p->len2 / 2 + 1; }
 extern "C" int pbc_hip_element_to_bytes_x_only_batch(pbc_hip_pairing_t *P, int group, uint8_t *out,
                                                      const uint8_t *in, size_t n) {
   return run_compress(P, 2, group, out, in, n);
@@ -1083,10 +1150,13 @@ extern "C" int pbc_hip_element_from_hash_batch(pbc_hip_pairing_t *P, int group, 
   if (!P) return fail("null pairing");
   if (P->device < 0) return fail("no HIP device: libpbc_hip has no CPU fallback");
   const bool symmetric = P->type == 'a' || P->type == '1' || P->type == 'e';
-  if (group != 1 && !(group == 2 && symmetric))
-    return fail("element_from_hash is built for G1 (and G2 of the symmetric types a, a1, e)");
+  if (group != 1 && group != 2) return fail("group must be 1 or 2");
   if (hlen < 1) return fail("hlen must be >= 1");
   if (!n) return 0;
+  if (group == 2 && !symmetric) {
+    if (P->type == 'f' && hlen < 2) return fail("type f G2: hlen must be >= 2 (fq_from_hash halves the digest)");
+    return run_twist_points(P, 0, out, data, hlen, n);
+  }
   DevBuf bd, bo;
   HIP_TRY(hipSetDevice(P->device));
   if (ensure_sqrt_constants(P)) return 1;

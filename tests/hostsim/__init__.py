@@ -87,6 +87,18 @@ class HostSim:
         self.L.hostsim_g2_mul(self.h, out.ctypes.data, a.ctypes.data, b.ctypes.data, n)
         return out
 
+    def g2_points(self, what, recs, hlen=0):
+        """twists: what 0 element_from_hash (recs: digests of hlen bytes), 1 compress, 2 decompress"""
+        recs = np.ascontiguousarray(recs, np.uint8)
+        lp, lc = self.len2, self.len2 // 2 + 1
+        li, lo = (hlen, lp) if what == 0 else (lp, lc) if what == 1 else (lc, lp)
+        n = recs.size // li
+        out = np.empty((n, lo), np.uint8)
+        self.L.hostsim_g2_points.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t]
+        if self.L.hostsim_g2_points(self.h, what, out.ctypes.data, recs.ctypes.data, hlen, n):
+            raise RuntimeError("hostsim_g2_points failed")
+        return out
+
     def from_hash(self, data, hlen):
         data = np.ascontiguousarray(data, np.uint8)
         n = data.size // hlen

@@ -165,6 +165,31 @@ int hostsim_compress(void *h, int dir, uint8_t *out, const uint8_t *in, size_t n
   }
   return 0;
 }
+// twists (G2 of types d, g, f): what 0 element_from_hash (digests of hlen bytes), 1 compress, 2 decompress
+#define HS_DISPATCH_TWIST(P_, ...)                                                  \
+  do {                                                                              \
+    if ((P_)->type == 'f') { HS_DISPATCH_F((P_)->nlimb, { typedef Fq2Ops<N> F; __VA_ARGS__; }); } \
+    else { HS_DISPATCH_D(P_, { typedef FdOps<N, DEG> F; __VA_ARGS__; }); }          \
+  } while (0)
+int hostsim_g2_points(void *h, int what, uint8_t *out, const uint8_t *in, int hlen, size_t n) {
+  pbc_hip_pairing_s *P = (pbc_hip_pairing_s *) h;
+  if (P->type != 'd' && P->type != 'g' && P->type != 'f') return 1;
+  activate(P);
+  c_xs = P->xs;
+  if (!P->xs_ready) {
+    HS_DISPATCH_TWIST(P, ext_ts_init<F>(P->xs.c));
+    P->xs_ready = true;
+    c_xs = P->xs;
+  }
+  const size_t lp = P->len2, lc = lp / 2 + 1;
+  const size_t li = what == 0 ? (size_t) hlen : what == 1 ? lp : lc, lo = what == 1 ? lc : lp;
+  for (size_t i = 0; i < n; i++) {
+    if (what == 0) { HS_DISPATCH_TWIST(P, g2_from_hash_lane<F>(out + i * lo, in + i * li, hlen)); }
+    else if (what == 1) { HS_DISPATCH_TWIST(P, g2_compress_lane<F>(out + i * lo, in + i * li)); }
+    else { HS_DISPATCH_TWIST(P, g2_decompress_lane<F>(out + i * lo, in + i * li)); }
+  }
+  return 0;
+}
 // element_mul_zn on G2 of the asymmetric types (twists)
 int hostsim_g2_mul(void *h, uint8_t *out, const uint8_t *a, const uint8_t *b, size_t n) {
   pbc_hip_pairing_s *P = (pbc_hip_pairing_s *) h;

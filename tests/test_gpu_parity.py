@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 import oracle
-from conftest import XONLY, check_x_only, golden, OTHER, GENERIC_A, GENERIC_OTHER, GENERIC_F, FILES_OF, param_value
+from conftest import G2_HASH, G2_COMPRESS, XONLY, check_x_only, golden, OTHER, GENERIC_A, GENERIC_OTHER, GENERIC_F, FILES_OF, param_value
 
 pytestmark = pytest.mark.gpu
 
@@ -730,3 +730,29 @@ def test_x_only_points_match_reference(hips, key, name, exact):
     H = hips[key]
     check_x_only(lambda p: H.element_to_bytes_x_only(1, p), lambda x: H.element_from_bytes_x_only(1, x), v, exact,
                  0 if exact else param_value(key, "q"))
+
+
+@pytest.mark.parametrize("key,name", G2_HASH)
+def test_from_hash_on_the_twists_matches_reference(hips, key, name):
+    """element_from_hash on G2 of types d, g, f (square roots in F_q^d / F_q^2 on the device)"""
+    v = golden(name)
+    H = hips[key]
+    pts = H.element_from_hash(2, v.g1)
+    assert np.array_equal(pts, v.gt)
+    # the hashed points lie on the twist: multiplying by 1 keeps them (off-curve input would give O = zeros)
+    one = np.zeros((v.n, H.length_in_bytes_Zr), np.uint8)
+    one[:, -1] = 1
+    assert np.array_equal(H.element_mul_zn(2, pts, one), pts)
+
+
+@pytest.mark.parametrize("key,name", G2_COMPRESS)
+def test_compressed_points_on_the_twists_match_reference(hips, key, name):
+    v = golden(name)
+    H = hips[key]
+    assert np.array_equal(H.element_to_bytes_compressed(2, v.g1), v.gt)
+    assert np.array_equal(H.element_from_bytes_compressed(2, v.gt), v.g1)
+    flipped = v.gt.copy()
+    flipped[:, -1] ^= 1
+    neg = H.element_from_bytes_compressed(2, flipped)
+    assert np.array_equal(neg[:, :v.len1 // 2], v.g1[:, :v.len1 // 2]) and not np.array_equal(neg, v.g1)
+    assert np.array_equal(H.element_to_bytes_compressed(2, neg), flipped)

@@ -5,7 +5,7 @@ mirror for GPU-less bring-up, not a product path: libpbc_hip.so never contains i
 import numpy as np
 import pytest
 
-from conftest import XONLY, check_x_only, golden, _param, PARAM_OF, OTHER, GENERIC_A, GENERIC_OTHER, GENERIC_F, FILES_OF, key_of, param_value
+from conftest import G2_HASH, G2_COMPRESS, XONLY, check_x_only, golden, _param, PARAM_OF, OTHER, GENERIC_A, GENERIC_OTHER, GENERIC_F, FILES_OF, key_of, param_value
 
 hostsim = pytest.importorskip("hostsim")
 
@@ -214,3 +214,26 @@ def test_x_only_points_on_host(sims, key, name, exact):
     v = golden(name)
     S = sims[key]
     check_x_only(lambda p: S.compress(2, p), lambda x: S.compress(3, x), v, exact, 0 if exact else param_value(key, "q"))
+
+
+@pytest.mark.parametrize("key,name", G2_HASH)
+def test_from_hash_on_the_twists_on_host(sims, key, name):
+    """element_from_hash on G2 of the asymmetric types (curve_from_hash over F_q^d / F_q^2, ecc/curve.c:455-482;
+    polymod_from_hash poly.c:341-348, fq_from_hash fieldquadratic.c:311-316) vs the reference"""
+    v = golden(name)                                       # file: digests, (nothing), points
+    n = min(v.n, 3)
+    assert np.array_equal(sims[key].g2_points(0, v.g1[:n], v.len1), v.gt[:n])
+
+
+@pytest.mark.parametrize("key,name", G2_COMPRESS)
+def test_compressed_points_on_the_twists_on_host(sims, key, name):
+    v = golden(name)                                       # file: x||y records, (nothing), x||s records
+    n = min(v.n, 4)
+    S = sims[key]
+    assert np.array_equal(S.g2_points(1, v.g1[:n]), v.gt[:n])
+    assert np.array_equal(S.g2_points(2, v.gt[:n]), v.g1[:n])
+    flipped = v.gt[:n].copy()
+    flipped[:, -1] ^= 1                                    # the other root
+    neg = S.g2_points(2, flipped)
+    assert np.array_equal(neg[:, :v.len1 // 2], v.g1[:n, :v.len1 // 2]) and not np.array_equal(neg, v.g1[:n])
+    assert np.array_equal(S.g2_points(1, neg), flipped)

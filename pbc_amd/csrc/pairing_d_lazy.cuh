@@ -509,9 +509,9 @@ struct LazyD {
   }
   // tangent at V (do_tangent d_param.c:344-362, scaled by Z^6) and V <- 2V:
   //   M = 3X^2 + a Z^4,  a' = -M Z^2,  b' = (2YZ) Z^2,  c' = M X - 2Y^2.   State in: g(X) <= 4, g(Y) <= 3, g(Z) <= 2
-  static __device__ __noinline__ linevec dbl_line_fn() {
+  static PBC_DEV void dbl_core(fz &la, fz &lb, fz &lc) {
     fz X = dl_get(DL_X), Y = dl_get(DL_Y), Z = dl_get(DL_Z);
-    fz ZZ, XX, YY, Y2, M, t0, t1, S, Z3, la, lb, lc;
+    fz ZZ, XX, YY, Y2, M, t0, t1, S, Z3;
     sqr_inl(ZZ, Z);
     sqr_inl(XX, X);
     sqr_inl(YY, Y);
@@ -541,14 +541,18 @@ struct LazyD {
     dl_put(DL_X, X);
     dl_put(DL_Y, Y);
     dl_put(DL_Z, Z3);
+  }
+  static __device__ __noinline__ linevec dbl_line_fn() {
+    fz la, lb, lc;
+    dbl_core(la, lb, lc);
     return evalfn_pack(la, lb, lc);
   }
   // chord through V and the affine P (do_line d_param.c:364-379, scaled by Z3 = Z H):
   //   H = Px Z^2 - X, R = Py Z^3 - Y;  a' = -R,  b' = Z3,  c' = R Px - Z3 Py;   V <- V + P
   // State in: g(X), g(Y) <= 3, g(Z) <= 2; out: g(X) = 4, Y and Z products
-  static __device__ __noinline__ linevec add_line_fn() {
+  static PBC_DEV void add_core(fz &la, fz &lb, fz &lc) {
     fz X = dl_get(DL_X), Y = dl_get(DL_Y), Z = dl_get(DL_Z), Px = dl_get(DL_PX), Py = dl_get(DL_PY);
-    fz ZZ, H, R, HH, HHH, t0, t1, Z3, la, lc, nPy, nY;
+    fz ZZ, H, R, HH, HHH, t0, t1, Z3, nPy, nY;
     sqr_inl(ZZ, Z);
     mul_inl(H, Px, ZZ);
     sub(H, H, X);                        // g 4
@@ -572,7 +576,12 @@ struct LazyD {
     dl_put(DL_X, t1);
     dl_put(DL_Y, Y);
     dl_put(DL_Z, Z3);
-    return evalfn_pack(la, Z3, lc);
+    lb = Z3;
+  }
+  static __device__ __noinline__ linevec add_line_fn() {
+    fz la, lb, lc;
+    add_core(la, lb, lc);
+    return evalfn_pack(la, lb, lc);
   }
   static PBC_DEV void f3_load_be(f3 &r, const uint8_t *s) { for (int i = 0; i < 3; i++) load_be(r.c[i], s + 4 * ND * i); }
   static PBC_DEV void f3_store_be(uint8_t *d, const f3 &a) { for (int i = 0; i < 3; i++) store_be(d + 4 * ND * i, a.c[i]); }
@@ -627,6 +636,104 @@ struct LazyD {
       f6_sqr(v, v);
     }
     return valid;
+  }
+  // ---- pairing_pp_init / pairing_pp_apply (d_pairing_pp_init d_param.c:794-880, _apply :908-966) ------------
+  // table: (a', b', c') of every Miller step in loop order, [steps][3][L] signed limbs, normalised
+  static PBC_DEV void pp_store(int32_t *tab, int slot, fz la, fz lb, fz lc) {
+    norm(la); norm(lb); norm(lc);
+#pragma unroll
+    for (int k = 0; k < L; k++) {
+      tab[(slot * 3 + 0) * L + k] = la.l[k];
+      tab[(slot * 3 + 1) * L + k] = lb.l[k];
+      tab[(slot * 3 + 2) * L + k] = lc.l[k];
+    }
+  }
+  static PBC_DEV bool pp_init_lane(int32_t *tab, const uint8_t *g1) {
+    fz Px, Py, t0, t1, la, lb, lc;
+    load_be(Px, g1);
+    load_be(Py, g1 + 4 * ND);
+    sqr(t0, Px);
+    add(t0, t0, konst(c_dl.A));
+    mul(t0, t0, Px);
+    add(t0, t0, konst(c_dl.B));
+    sqr(t1, Py);
+    const bool valid = eq(t0, t1);
+    dl_put(DL_X, Px); dl_put(DL_Y, Py); dl_put(DL_Z, konst(c_dl.one));
+    dl_put(DL_PX, Px); dl_put(DL_PY, Py);
+    int slot = 0;
+    for (int m = c_d.rbits - 2;; m--) {
+      dbl_core(la, lb, lc);
+      pp_store(tab, slot++, la, lb, lc);
+      if (m <= 0) break;
+      if ((c_d.r[m >> 5] >> (m & 31)) & 1) {
+        add_core(la, lb, lc);
+        pp_store(tab, slot++, la, lb, lc);
+      }
+    }
+    return valid;
+  }
+  static __device__ __noinline__ linevec pp_line_fn(fzvec va, fzvec vb, fzvec vc) {
+    return evalfn_pack(fz_unpack(va), fz_unpack(vb), fz_unpack(vc));
+  }
+  static PBC_DEV void pp_line(f6 &e0, const int32_t *tab, int slot) {
+    fz a, b, c;
+#pragma unroll
+    for (int k = 0; k < L; k++) {
+      a.l[k] = tab[(slot * 3 + 0) * L + k];
+      b.l[k] = tab[(slot * 3 + 1) * L + k];
+      c.l[k] = tab[(slot * 3 + 2) * L + k];
+    }
+    LZ_BOUND(a, 1, 5.0, "table"); LZ_BOUND(b, 1, 1.25, "table"); LZ_BOUND(c, 1, 5.0, "table");
+    unpack(e0, pp_line_fn(fz_pack(a), fz_pack(b), fz_pack(c)));
+  }
+  static PBC_DEV void pp_apply_lane(uint8_t *gt, const int32_t *tab, bool p_valid, const uint8_t *g2) {
+    const int NB = 4 * ND;
+    const fz one = konst(c_dl.one);
+    f3 Qx, Qy;
+    f6 v, out;
+    f3_load_be(Qx, g2);
+    f3_load_be(Qy, g2 + 3 * NB);
+    bool valid = p_valid;
+    {
+      f3 u0, u1;
+      f3_sqr(u0, Qx);
+      add(u0.c[0], u0.c[0], konst(c_dl.ta));
+      f3_mul(u0, u0, Qx);
+      add(u0.c[0], u0.c[0], konst(c_dl.tb));
+      f3_sqr(u1, Qy);
+      valid &= f3_eq(u0, u1);
+    }
+    f3_mul_fq(Qx, Qx, konst(c_dl.nqrinv));
+    f3_mul_fq(Qy, Qy, konst(c_dl.nqrinv2));
+#pragma unroll
+    for (int i = 0; i < 3; i++) { dl_put(DL_QX + L * i, Qx.c[i]); dl_put(DL_QY + L * i, Qy.c[i]); }
+    f3_set_fq(v.x, one);
+    f3_set_fq(v.y, one);
+    f3_sub(v.y, v.y, v.x);
+    f3_norm(v.y);
+    int slot = 0;
+    for (int m = c_d.rbits - 2;; m--) {
+      f6 e0;
+      pp_line(e0, tab, slot++);
+      f6_mul(v, v, e0);
+      if (m <= 0) break;
+      if ((c_d.r[m >> 5] >> (m & 31)) & 1) {
+        pp_line(e0, tab, slot++);
+        f6_mul(v, v, e0);
+      }
+      f6_sqr(v, v);
+    }
+    final_exp(out, v);
+    store_gt(gt, out, valid);
+  }
+  static PBC_DEV void store_gt(uint8_t *gt, f6 &out, bool valid) {
+    if (!valid) {                        // GT identity
+      f3_set_fq(out.x, konst(c_dl.one));
+      f3_set_fq(out.y, konst(c_dl.one));
+      f3_sub(out.y, out.y, out.x);
+    }
+    f3_store_be(gt, out.x);
+    f3_store_be(gt + 12 * ND, out.y);
   }
   // cc_tatepower (d_param.c:505-564) with one inversion; derivation in pairing_d.cuh
   static PBC_DEV void final_exp(f6 &out, const f6 &m) {
@@ -695,13 +802,7 @@ struct LazyD {
       f6_mul(F, F, f);
     }
     final_exp(out, F);
-    if (!valid) {                        // GT identity
-      f3_set_fq(out.x, konst(c_dl.one));
-      f3_set_fq(out.y, konst(c_dl.one));
-      f3_sub(out.y, out.y, out.x);
-    }
-    f3_store_be(gt, out.x);
-    f3_store_be(gt + 12 * ND, out.y);
+    store_gt(gt, out, valid);
   }
 
   // constants: c_d (saturated words, Montgomery form for R = 2^174) -> 28-bit limbs for R' = 2^168.

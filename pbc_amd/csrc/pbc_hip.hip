@@ -205,6 +205,27 @@ __global__ void __launch_bounds__(kBlock, PBC_DF_WAVES) d_lazy_prod_pairing_kern
   }
 }
 
+template <int N>
+__global__ void d_lazy_pp_init_kernel(uint32_t *tab, uint32_t *valid, const uint8_t *g1) {
+  if (threadIdx.x || blockIdx.x) return;
+  *valid = LazyD<N>::pp_init_lane(reinterpret_cast<int32_t *>(tab), g1) ? 1u : 0u;
+}
+template <int N>
+__global__ void __launch_bounds__(kBlock, PBC_DF_WAVES) d_lazy_pp_apply_kernel(uint8_t *gt, const uint32_t *__restrict__ tab,
+                                                                               const uint32_t *__restrict__ valid,
+                                                                               const uint8_t *g2, size_t n) {
+  size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
+  size_t ld = idx < n ? idx : n - 1;
+  const int LT = 24 * N;
+  __attribute__((aligned(4))) uint8_t out[24 * N];
+  LazyD<N>::pp_apply_lane(out, reinterpret_cast<const int32_t *>(tab), *valid != 0, g2 + ld * LT);
+  if (idx < n) {
+    uint32_t *dst = reinterpret_cast<uint32_t *>(gt + idx * LT);
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(out);
+    for (int i = 0; i < LT / 4; i++) dst[i] = src[i];
+  }
+}
+
 // pairing_pp for type a1
 template <int N>
 __global__ void a1_pp_init_kernel(uint32_t *tab, uint32_t *valid, const uint8_t *g1) {
@@ -1178,6 +1199,7 @@ struct pbc_hip_pp_s {
   pbc_hip_pairing_s *P;
   uint32_t *tab;      // device: type a [exp2 + 1][3][16] words; types d / g [steps][3][ND] words
   uint32_t *valid;    // device flag: first argument was a finite curve point
+  bool d_lazy;        // experiment: table in the signed-limb form of pairing_d_lazy.cuh ([steps][3][6] words)
 };
 extern "C" int pbc_hip_pairing_pp_init(pbc_hip_pp_t **out, pbc_hip_pairing_t *P, const uint8_t *g1) {
   if (!out || !P || !g1) return fail("null argument");
@@ -1192,7 +1214,8 @@ extern "C" int pbc_hip_pairing_pp_init(pbc_hip_pp_t **out, pbc_hip_pairing_t *P,
   if (mnt) {                           // one entry per doubling and per addition of the Miller loop
     int steps = P->dconst.rbits - 1;
     for (int m = 1; m <= P->dconst.rbits - 2; m++) steps += (P->dconst.r[m >> 5] >> (m & 31)) & 1;
-    words = (size_t) steps * 3 * P->nlimb;
+    pp->d_lazy = P->type == 'd' && P->nlimb == 5 && d_lazy_selected();
+    words = (size_t) steps * 3 * (pp->d_lazy ? 6 : P->nlimb);
   }
   if (a1) {
     int steps = P->a.rbits - 1;
@@ -1205,7 +1228,9 @@ extern "C" int pbc_hip_pairing_pp_init(pbc_hip_pp_t **out, pbc_hip_pairing_t *P,
     delete pp;
     return fail("pairing_pp_init: device setup failed");
   }
-  if (mnt) {
+  if (mnt && pp->d_lazy) {
+    hipLaunchKernelGGL(d_lazy_pp_init_kernel<5>, dim3(1), dim3(64), 0, 0, pp->tab, pp->valid, (const uint8_t *) dg1);
+  } else if (mnt) {
     PBC_DISPATCH_D(P, hipLaunchKernelGGL((d_pp_init_kernel<N, DEG>), dim3(1), dim3(64), 0, 0, pp->tab, pp->valid,
                                          (const uint8_t *) dg1));
   } else if (a1 && P->nlimb == 16) {
@@ -1241,6 +1266,9 @@ extern "C" int pbc_hip_pairing_pp_apply_batch_dev(pbc_hip_pp_t *pp, void *d_gt, 
                        (const uint8_t *) d_g2, n);
   } else if (pp->P->type == '1' || pp->P->type == 'a') {
     hipLaunchKernelGGL(a1_pp_apply_kernel<33>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt, pp->tab, pp->valid,
+                       (const uint8_t *) d_g2, n);
+  } else if (pp->d_lazy) {
+    hipLaunchKernelGGL(d_lazy_pp_apply_kernel<5>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt, pp->tab, pp->valid,
                        (const uint8_t *) d_g2, n);
   } else {
     PBC_DISPATCH_D(pp->P, hipLaunchKernelGGL((d_pp_apply_kernel<N, DEG>), dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,

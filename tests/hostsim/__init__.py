@@ -48,7 +48,8 @@ class HostSim:
         self.L.hostsim_prod_pairing(self.h, out.ctypes.data, g1.ctypes.data, g2.ctypes.data, n, k)
         return out
 
-    def pp(self, g1, g2):
+    def pp(self, g1, g2, d_lazy=False):
+        self.L.hostsim_select_d_lazy(1 if d_lazy else 0)
         g1 = np.ascontiguousarray(g1, np.uint8)
         g2 = np.ascontiguousarray(g2, np.uint8)
         n = g2.size // self.len2

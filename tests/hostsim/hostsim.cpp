@@ -50,6 +50,10 @@ static void activate(pbc_hip_pairing_s *P) {
 
 extern "C" {
 
+// experiment switch: route 5-word type d pairings through pairing_d_lazy.cuh (with its bound checks)
+static int g_d_lazy = 0;
+void hostsim_select_d_lazy(int on) { g_d_lazy = on; }
+
 void *hostsim_init(const char *param, size_t len) {
   std::string type;
   if (!pbc_host::param_lookup(param, len, "type", type)) return nullptr;
@@ -94,9 +98,6 @@ int hostsim_lens(void *h, int *l1, int *l2, int *lt) {
   *l1 = P->len1; *l2 = P->len2; *lt = P->lenT;
   return 0;
 }
-// experiment switch: route 5-word type d pairings through pairing_d_lazy.cuh (with its bound checks)
-static int g_d_lazy = 0;
-void hostsim_select_d_lazy(int on) { g_d_lazy = on; }
 // n units of k terms each, one lane after the other
 int hostsim_prod_pairing(void *h, uint8_t *gt, const uint8_t *g1, const uint8_t *g2, size_t n, int k) {
   pbc_hip_pairing_s *P = (pbc_hip_pairing_s *) h;
@@ -123,6 +124,13 @@ int hostsim_pp(void *h, uint8_t *gt, const uint8_t *g1, const uint8_t *g2, size_
   pbc_hip_pairing_s *P = (pbc_hip_pairing_s *) h;
   activate(P);
   static uint32_t tab[512 * 3 * 16];
+  if (P->type == 'd' && P->nlimb == 5 && g_d_lazy) {
+    static int32_t ltab[512 * 3 * 6];
+    DLazyConst tmp; LazyD<5>::init(&tmp); c_dl = tmp;
+    bool v = LazyD<5>::pp_init_lane(ltab, g1);
+    for (size_t u = 0; u < n; u++) LazyD<5>::pp_apply_lane(gt + u * P->lenT, ltab, v, g2 + u * P->len2);
+    return 0;
+  }
   if (P->type == 'd' || P->type == 'g') {
     HS_DISPATCH_D(P, {
       bool v = TypeMNT<N, DEG>::d_pp_init_lane(tab, g1);

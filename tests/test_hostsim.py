@@ -237,3 +237,19 @@ def test_compressed_points_on_the_twists_on_host(sims, key, name):
     neg = S.g2_points(2, flipped)
     assert np.array_equal(neg[:, :v.len1 // 2], v.g1[:n, :v.len1 // 2]) and not np.array_equal(neg, v.g1[:n])
     assert np.array_equal(S.g2_points(1, neg), flipped)
+
+
+def test_type_d_signed_limb_experiment_pp_on_host(sims, oracles):
+    """pairing_pp_init / pairing_pp_apply on the signed-limb representation: same bytes as element_pairing;
+    an off-curve first argument gives the identity"""
+    v = golden("d_rand32.vec")
+    S = sims["d"]
+    for i in (0, 5):
+        P = v.g1[i]
+        Q = v.g2[:6].copy()
+        Q[5, -1] ^= 1                                       # one off-curve second argument
+        want = oracles["d"].pairing_batch(np.tile(P, (6, 1)), Q)
+        assert np.array_equal(S.pp(P, Q, d_lazy=True), want)
+    bad = v.g1[2].copy(); bad[3] ^= 4
+    one = np.zeros(S.lenT, np.uint8); one[S.len1 // 2 - 1] = 1
+    assert np.array_equal(S.pp(bad, v.g2[:3], d_lazy=True), np.tile(one, (3, 1)))

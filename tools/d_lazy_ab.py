@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """A/B of the type d signed-limb experiment (pbc_amd/csrc/pairing_d_lazy.cuh) on a GPU: parity against the
-reference vectors and kernel throughput with PBC_HIP_D_LAZY=0 / 1, each in a fresh process (the switch is read
+reference vectors and kernel throughput (element_pairing and pairing_pp_apply) with PBC_HIP_D_LAZY=0 / 1, each in a fresh process (the switch is read
 once per process).  Prints one JSON line per variant.
 
   python tools/d_lazy_ab.py [log2 n]           # default 2^18 pairings per launch
@@ -40,8 +40,21 @@ for _ in range(K):
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t) / K
 same = bool(np.array_equal(gt[: v.n].cpu().numpy(), v.gt))
-print(json.dumps({{"lazy": os.environ.get("PBC_HIP_D_LAZY", "0"), "parity": ok and same, "n": n,
-                  "ms_per_launch": round(dt * 1e3, 3), "pairings_per_s": round(n / dt)}}))
+# pairing_pp_init / pairing_pp_apply with the first fixture point as the fixed argument
+pp = P.pp_init(v.g1[0])
+want = P.element_pairing(np.tile(v.g1[0], (v.n, 1)), v.g2)
+pp_ok = bool(np.array_equal(pp.apply(v.g2), want))
+for _ in range(2):
+    pp.apply_dev(gt.data_ptr(), g2.data_ptr(), n)
+torch.cuda.synchronize()
+t = time.perf_counter()
+for _ in range(K):
+    pp.apply_dev(gt.data_ptr(), g2.data_ptr(), n)
+torch.cuda.synchronize()
+dtp = (time.perf_counter() - t) / K
+print(json.dumps({{"lazy": os.environ.get("PBC_HIP_D_LAZY", "0"), "parity": ok and same and pp_ok, "n": n,
+                  "ms_per_launch": round(dt * 1e3, 3), "pairings_per_s": round(n / dt),
+                  "pp_ms_per_launch": round(dtp * 1e3, 3), "pp_applies_per_s": round(n / dtp)}}))
 """
 
 

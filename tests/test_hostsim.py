@@ -253,3 +253,22 @@ def test_type_d_signed_limb_experiment_pp_on_host(sims, oracles):
     bad = v.g1[2].copy(); bad[3] ^= 4
     one = np.zeros(S.lenT, np.uint8); one[S.len1 // 2 - 1] = 1
     assert np.array_equal(S.pp(bad, v.g2[:3], d_lazy=True), np.tile(one, (3, 1)))
+
+
+def test_type_d_signed_limb_experiment_cross_pairs_and_bad_inputs(sims):
+    """600 cross pairs of the fixture points through both kernel sources, with flipped bits (off-curve inputs give
+    the identity) and all-ones coordinates (values >= q reduce on load): the two representations agree byte for byte"""
+    v, e = golden("d_rand32.vec"), golden("d_edge20.vec")
+    g1, g2 = np.concatenate([v.g1, e.g1]), np.concatenate([v.g2, e.g2])
+    rng = np.random.default_rng(5)
+    n = 600
+    A, B = g1[rng.integers(0, len(g1), n)].copy(), g2[rng.integers(0, len(g2), n)].copy()
+    for k in range(0, n, 37):
+        A[k, rng.integers(0, A.shape[1])] ^= 1 << rng.integers(0, 8)
+    for k in range(5, n, 41):
+        B[k, rng.integers(0, B.shape[1])] ^= 1 << rng.integers(0, 8)
+    for k in range(7, n, 53):
+        A[k, :20] = 0xff
+    S = sims["d"]
+    assert np.array_equal(S.prod_pairing(A, B, 1), S.prod_pairing(A, B, 1, d_lazy=True))
+    assert np.array_equal(S.prod_pairing(A, B, 3), S.prod_pairing(A, B, 3, d_lazy=True))

@@ -109,6 +109,24 @@ int main(int argc, char **argv) {
       element_clear(c1); element_clear(ct);
     }
   }
+  /* 1d. element_from_hash on G1 and G2 vs the CPU */
+  {
+    enum { HN = 8, HL = 32 };
+    unsigned char dig[HN * HL];
+    for (int i = 0; i < HN * HL; i++) dig[i] = (unsigned char) (i * 37 + 11);
+    for (int group = 1; group <= 2; group++) {
+      element_t h[HN], c;
+      for (int i = 0; i < HN; i++) { if (group == 1) element_init_G1(h[i], pairing); else element_init_G2(h[i], pairing); }
+      if (group == 1) element_init_G1(c, pairing); else element_init_G2(c, pairing);
+      if (element_from_hash_batch(h, dig, HL, HN)) { printf("from_hash batch failed (G%d)\n", group); fails++; }
+      for (int i = 0; i < HN; i++) {
+        element_from_hash(c, dig + i * HL, HL);
+        if (element_cmp(c, h[i])) { printf("G%d from_hash mismatch at %d\n", group, i); fails++; }
+        element_clear(h[i]);
+      }
+      element_clear(c);
+    }
+  }
   /* 2. the batch entry points */
   if (element_pairing_batch(gpu, P, Q, n)) { printf("batch call failed\n"); fails++; }
   for (size_t i = 0; i < n; i++) if (element_cmp(gpu[i], cpu[i])) { printf("batch mismatch at %zu\n", i); fails++; break; }

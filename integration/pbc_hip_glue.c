@@ -27,6 +27,7 @@ static struct {
   int (*mul_zn)(pbc_hip_pairing_t *, int, unsigned char *, const unsigned char *, const unsigned char *, size_t);
   int (*gt_mul)(pbc_hip_pairing_t *, unsigned char *, const unsigned char *, const unsigned char *, size_t);
   int (*gt_pow)(pbc_hip_pairing_t *, unsigned char *, const unsigned char *, const unsigned char *, size_t);
+  int (*from_hash)(pbc_hip_pairing_t *, int, unsigned char *, const unsigned char *, int, size_t);
 } L;
 
 /* one attachment per pairing_s (kept in a tiny table keyed by the pairing pointer so that
@@ -62,6 +63,7 @@ static int load_lib(void) {
   SYM(pp_apply, "pbc_hip_pairing_pp_apply_batch");
   SYM(lenZr, "pbc_hip_pairing_length_in_bytes_Zr"); SYM(mul_zn, "pbc_hip_element_mul_zn_batch");
   SYM(gt_mul, "pbc_hip_element_mul_GT_batch"); SYM(gt_pow, "pbc_hip_element_pow_zn_GT_batch");
+  SYM(from_hash, "pbc_hip_element_from_hash_batch");
 #undef SYM
   return 0;
 }
@@ -246,6 +248,25 @@ int element_pow_zn_batch(element_t out[], element_t in[], element_t zr[], size_t
   if (rc) fprintf(stderr, "pbc_hip: %s\n", L.err());
   else for (size_t i = 0; i < m; i++) element_from_bytes(out[slot[i]], bo + i * le);
   free(be); free(bz); free(bo); free(slot);
+  return rc;
+}
+
+/* out[i] = element_from_hash(data + i * hlen, hlen) (include/pbc_field.h:257 -> curve_from_hash,
+ * ecc/curve.c:455-482) for elements of G1 or G2: hashing, square roots and the cofactor multiplication run on
+ * the device. */
+int element_from_hash_batch(element_t out[], const void *data, int hlen, size_t n) {
+  if (!n) return 0;
+  struct pairing_s *p = out[0]->field->pairing;
+  attach_t *a = find(p);
+  if (!a) return 1;
+  int group = out[0]->field == p->G1 ? 1 : (out[0]->field == p->G2 ? 2 : 0);
+  if (!group) return 1;
+  int le = element_length_in_bytes(out[0]);
+  unsigned char *bo = malloc(n * (size_t) le + 1);
+  int rc = L.from_hash(a->gpu, group, bo, data, hlen, n);
+  if (rc) fprintf(stderr, "pbc_hip: %s\n", L.err());
+  else for (size_t i = 0; i < n; i++) element_from_bytes(out[i], bo + i * (size_t) le);
+  free(bo);
   return rc;
 }
 

@@ -35,4 +35,7 @@ int pairing_pp_apply_batch(element_t out[], element_t in2[], size_t n, pairing_p
 /* out[i] = in[i]^zr[i]: element_pow_zn / element_mul_zn (include/pbc_field.h:311, :374) over a
  * batch of G1 elements (G2 too for symmetric pairings) or GT elements. */
 int element_pow_zn_batch(element_t out[], element_t in[], element_t zr[], size_t n);
+/* out[i] = element_from_hash of the i-th hlen-byte digest (include/pbc_field.h:257) for elements of G1 or G2
+ * of any type. */
+int element_from_hash_batch(element_t out[], const void *data, int hlen, size_t n);
 #endif

@@ -221,14 +221,13 @@ def test_from_hash_on_the_twists_on_host(sims, key, name):
     """element_from_hash on G2 of the asymmetric types (curve_from_hash over F_q^d / F_q^2, ecc/curve.c:455-482;
     polymod_from_hash poly.c:341-348, fq_from_hash fieldquadratic.c:311-316) vs the reference"""
     v = golden(name)                                       # file: digests, (nothing), points
-    n = min(v.n, 3)
-    assert np.array_equal(sims[key].g2_points(0, v.g1[:n], v.len1), v.gt[:n])
+    assert np.array_equal(sims[key].g2_points(0, v.g1, v.len1), v.gt)
 
 
 @pytest.mark.parametrize("key,name", G2_COMPRESS)
 def test_compressed_points_on_the_twists_on_host(sims, key, name):
     v = golden(name)                                       # file: x||y records, (nothing), x||s records
-    n = min(v.n, 4)
+    n = v.n
     S = sims[key]
     assert np.array_equal(S.g2_points(1, v.g1[:n]), v.gt[:n])
     assert np.array_equal(S.g2_points(2, v.gt[:n]), v.g1[:n])

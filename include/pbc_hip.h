@@ -123,8 +123,12 @@ int pbc_hip_element_from_bytes_compressed_batch(pbc_hip_pairing_t *p, int group,
  * include/pbc_pairing.h:187-193): records of length_in_bytes_Fq bytes holding x alone.  from_bytes rebuilds the
  * point with the square root the reference's element_sqrt returns when that is defined (q = 3 mod 4: types a, a1,
  * f.param, g149.param); for q = 1 mod 4 the reference's own root depends on the random non-residue it drew at
- * start-up, and the result agrees with it up to the sign of y.  An x with no point above it gives zeros. */
+ * start-up, and the result agrees with it up to the sign of y.  An x with no point above it gives zeros.
+ * group = 2 on the twists of types d, g, f as well: type f with q = 3 mod 4 reproduces the reference's root
+ * (fq_sqrt, arith/fieldquadratic.c:357-392, is a formula over roots in F_q); types d and g take their roots with
+ * a randomised algorithm in the reference (polymod_sqrt, arith/poly.c:634-700): up to the sign of y. */
 int pbc_hip_pairing_length_in_bytes_x_only_G1(const pbc_hip_pairing_t *p);
+int pbc_hip_pairing_length_in_bytes_x_only_G2(const pbc_hip_pairing_t *p);   /* include/pbc_pairing.h:218-224 */
 int pbc_hip_element_to_bytes_x_only_batch(pbc_hip_pairing_t *p, int group, uint8_t *out, const uint8_t *in,
                                           size_t n);
 int pbc_hip_element_from_bytes_x_only_batch(pbc_hip_pairing_t *p, int group, uint8_t *out, const uint8_t *in,

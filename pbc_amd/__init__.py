@@ -70,6 +70,7 @@ def lib():
         L.pbc_hip_element_to_bytes_compressed_batch.argtypes = [vp, ci, vp, vp, sz]
         L.pbc_hip_element_from_bytes_compressed_batch.argtypes = [vp, ci, vp, vp, sz]
         L.pbc_hip_pairing_length_in_bytes_x_only_G1.argtypes = [vp]
+        L.pbc_hip_pairing_length_in_bytes_x_only_G2.argtypes = [vp]
         L.pbc_hip_element_to_bytes_x_only_batch.argtypes = [vp, ci, vp, vp, sz]
         L.pbc_hip_element_from_bytes_x_only_batch.argtypes = [vp, ci, vp, vp, sz]
         L.pbc_hip_element_from_hash_batch.argtypes = [vp, ci, vp, vp, ci, sz]
@@ -102,7 +103,7 @@ EXPORTS = (
     "pbc_hip_pairing_length_in_bytes_compressed_G1", "pbc_hip_element_to_bytes_compressed_batch",
     "pbc_hip_element_from_bytes_compressed_batch", "pbc_hip_pairing_use_devices", "pbc_hip_device_count",
     "pbc_hip_pairing_length_in_bytes_x_only_G1", "pbc_hip_element_to_bytes_x_only_batch",
-    "pbc_hip_pairing_length_in_bytes_compressed_G2",
+    "pbc_hip_pairing_length_in_bytes_compressed_G2", "pbc_hip_pairing_length_in_bytes_x_only_G2",
     "pbc_hip_element_from_bytes_x_only_batch",
 )
 
@@ -233,12 +234,16 @@ class Pairing:
             raise PbcHipError("element_from_bytes_compressed: " + _err())
         return out
 
+    def _x_only_len(self, group):
+        f = lib().pbc_hip_pairing_length_in_bytes_x_only_G2 if group == 2 else lib().pbc_hip_pairing_length_in_bytes_x_only_G1
+        return f(self._h)
+
     def element_to_bytes_x_only(self, group, pts):
         """x||y records -> x records (element_to_bytes_x_only)."""
         import numpy as np
         pts = np.ascontiguousarray(pts, dtype=np.uint8)
-        n = pts.size // self.length_in_bytes_G1
-        out = np.empty((n, lib().pbc_hip_pairing_length_in_bytes_x_only_G1(self._h)), np.uint8)
+        n = pts.size // self._point_len(group)
+        out = np.empty((n, self._x_only_len(group)), np.uint8)
         if lib().pbc_hip_element_to_bytes_x_only_batch(self._h, group, _np_ptr(out), _np_ptr(pts), n):
             raise PbcHipError("element_to_bytes_x_only: " + _err())
         return out
@@ -247,9 +252,8 @@ class Pairing:
         """x records -> x||y records (element_from_bytes_x_only; y is the root element_sqrt picks)."""
         import numpy as np
         recs = np.ascontiguousarray(recs, dtype=np.uint8)
-        lx = lib().pbc_hip_pairing_length_in_bytes_x_only_G1(self._h)
-        n = recs.size // lx
-        out = np.empty((n, self.length_in_bytes_G1), np.uint8)
+        n = recs.size // self._x_only_len(group)
+        out = np.empty((n, self._point_len(group)), np.uint8)
         if lib().pbc_hip_element_from_bytes_x_only_batch(self._h, group, _np_ptr(out), _np_ptr(recs), n):
             raise PbcHipError("element_from_bytes_x_only: " + _err())
         return out

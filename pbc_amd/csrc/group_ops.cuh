@@ -39,6 +39,7 @@ PBC_DEV uint32_t zr_bit(const uint8_t *z, int zlen, int i) { return (z[zlen - 1 
 // cmov, load/store.  Used for E(F_q) (G1; G2 of the symmetric types) and for the twists over
 // F_q^d (types d, g: curve.c:885-901 coefficients a v^2, b v^3) and F_q^2 (type f: f_param.c:372-383).
 template <int N> PBC_DEV void fq_from_hash_lane(fp<N> &x, const uint8_t *data, int hlen);   // defined below
+template <int N> PBC_DEV void fp_sqrt_lane(fp<N> &y, bool &ok, const fp<N> &t);
 
 template <int N>
 struct FqOps {
@@ -94,6 +95,8 @@ struct FdOps {                         // F_q^d of types d / g: the twist E'(F_q
     for (int i = 1; i < DEG; i++) r.c[i] = r.c[0];
     return r;
   }
+  // element_sqrt as the x-only format sees it: polymod_sqrt (poly.c:634-700) is randomised, any root is "the" root
+  static PBC_DEV void sqrt_ref(el &y, bool &ok, const el &t);
   // polymod_sgn (poly.c:1189-1199) with fp_sgn_odd (montfp.c:460-472): the sign of the first non-zero
   // coefficient, positive when its canonical residue is odd.  Returns true for "negative".
   static PBC_DEV bool is_negative(const el &a) {
@@ -142,6 +145,32 @@ struct Fq2Ops {                        // F_q^2 of type f: the twist y^2 = x^3 +
     fq_from_hash_lane<ND>(r.x, data, k);
     fq_from_hash_lane<ND>(r.y, data + k, hlen - k);
     return r;
+  }
+  // fq_sqrt (fieldquadratic.c:357-392): a + b sqrt(beta) with 2a^2 = x +- sqrt(x^2 - beta y^2), 2ab = y; the root
+  // it returns is a function of the roots element_sqrt returns in F_q (defined for q = 3 mod 4)
+  static PBC_DEV void sqrt_ref(el &r, bool &ok, const el &t) {
+    fp<ND> e0, e1, e2, s0, half, beta;
+    bool ok0, ok1, ok2;
+    fp_set<ND>(beta, c_f.beta);
+    fp_sqr<ND>(e0, t.x);
+    fp_sqr<ND>(e1, t.y);
+    fp_mul<ND>(e1, e1, beta);
+    fp_sub<ND>(e0, e0, e1);
+    fp_sqrt_lane<ND>(s0, ok0, e0);                   // sqrt(x^2 - beta y^2): exists iff t is a square
+    fp_set<ND>(half, fpk<ND>().one);
+    fp_halve<ND>(half, half);
+    fp_add<ND>(e1, t.x, s0);
+    fp_mul<ND>(e1, e1, half);
+    fp_sqrt_lane<ND>(e2, ok1, e1);                   // is_sqr(e1) and its root in one go
+    fp<ND> alt, a2;
+    fp_sub<ND>(alt, e1, s0);
+    fp_sqrt_lane<ND>(a2, ok2, alt);
+    fp_cmov<ND>(e2, a2, !ok1);
+    ok = ok0 & (ok1 | ok2);
+    fp_dbl<ND>(e1, e2);
+    fp_inv<ND>(e1, e1);
+    fp_mul<ND>(r.y, t.y, e1);
+    r.x = e2;
   }
   // fq_sign (fieldquadratic.c:159-165): sign of x, of y when x = 0
   static PBC_DEV bool is_negative(const el &a) {
@@ -713,6 +742,29 @@ PBC_DEV void ext_sqrt_lane(typename F::el &y, bool &ok, const typename F::el &t)
   }
   ok &= F::eq(b, one);
   y = r;
+}
+template <int N, int DEG>
+PBC_DEV void FdOps<N, DEG>::sqrt_ref(typename FdOps<N, DEG>::el &y, bool &ok, const typename FdOps<N, DEG>::el &t) {
+  ext_sqrt_lane<FdOps<N, DEG>>(y, ok, t);
+}
+// element_to_bytes_x_only / element_from_bytes_x_only (ecc/curve.c:821-836) on E'(K): x alone, y = element_sqrt
+// as it comes.  Type f with q = 3 mod 4 reproduces the reference's root (fq_sqrt is a formula over F_q roots);
+// elsewhere the reference's root depends on random choices (polymod_sqrt, element_tonelli's non-residue) and the
+// result agrees with it up to sign.
+template <class F>
+PBC_DEV void g2_from_x_lane(uint8_t *out, const uint8_t *in) {
+  typedef typename F::el el;
+  el x, t, y;
+  F::load(x, in);
+  F::sqr(t, x);
+  F::add(t, t, F::curve_a());
+  F::mul(t, t, x);
+  F::add(t, t, F::curve_b());
+  bool ok;
+  F::sqrt_ref(y, ok, t);
+  if (!ok) { x = F::zero(); y = F::zero(); }
+  F::store(out, x);
+  F::store(out + F::bytes(), y);
 }
 // curve_from_hash (ecc/curve.c:455-482) on E'(K): x from the digest, x <- x^2 + 1 until x^3 + a x + b is a
 // square, y the root with non-negative sign.  The twists are initialised without a cofactor

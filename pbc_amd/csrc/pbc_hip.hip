@@ -358,17 +358,20 @@ __global__ void __launch_bounds__(kBlock, 2) g_from_hash_kernel(uint8_t *out, co
 }
 // element_from_hash / element_to_bytes_compressed / element_from_bytes_compressed on the G2 twists (types d, g, f):
 // F is the field policy of the twist (FdOps / Fq2Ops).  what 0: digests of `aux` bytes -> points; 1: points ->
-// x || s; 2: x || s -> points
+// x || s; 2: x || s -> points; 3: points -> x; 4: x -> points
 template <class F>
 __global__ void __launch_bounds__(kBlock, 2) g2_point_kernel(int what, uint8_t *out, const uint8_t *in, int aux, size_t n) {
   size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
   size_t ld = idx < n ? idx : n - 1;   // whole waves stay in the retry loop together
   const size_t fb = (size_t) F::bytes();
-  const size_t li = what == 0 ? (size_t) aux : what == 1 ? 2 * fb : fb + 1, lo = what == 1 ? fb + 1 : 2 * fb;
+  const size_t li = what == 0 ? (size_t) aux : (what == 1 || what == 3) ? 2 * fb : what == 2 ? fb + 1 : fb;
+  const size_t lo = what == 1 ? fb + 1 : what == 3 ? fb : 2 * fb;
   __attribute__((aligned(4))) uint8_t o[8 * F::WORDS];
   if (what == 0) g2_from_hash_lane<F>(o, in + ld * li, aux);
   else if (what == 1) g2_compress_lane<F>(o, in + ld * li);
-  else g2_decompress_lane<F>(o, in + ld * li);
+  else if (what == 2) g2_decompress_lane<F>(o, in + ld * li);
+  else if (what == 3) { for (size_t i = 0; i < fb; i++) o[i] = in[ld * li + i]; }
+  else g2_from_x_lane<F>(o, in + ld * li);
   if (idx < n)
     for (size_t i = 0; i < lo; i++) out[idx * lo + i] = o[i];
 }
@@ -1099,13 +1102,15 @@ static int ensure_ext_sqrt(pbc_hip_pairing_s *P) {
   }
   return 0;
 }
-// what 0: element_from_hash (li = hlen), 1: to_bytes_compressed, 2: from_bytes_compressed -- on the G2 twist
+// what 0: element_from_hash (li = hlen), 1 / 2: to / from_bytes_compressed, 3 / 4: to / from_bytes_x_only -- on the G2 twist
 static int run_twist_points(pbc_hip_pairing_s *P, int what, uint8_t *out, const uint8_t *in, int hlen, size_t n) {
-  const size_t lp = (size_t) P->len2, lc = lp / 2 + 1;
-  const size_t li = what == 0 ? (size_t) hlen : what == 1 ? lp : lc, lo = what == 1 ? lc : lp;
+  const size_t lp = (size_t) P->len2, lc = lp / 2 + 1, lx = lp / 2;
+  const size_t li = what == 0 ? (size_t) hlen : (what == 1 || what == 3) ? lp : what == 2 ? lc : lx;
+  const size_t lo = what == 1 ? lc : what == 3 ? lx : lp;
   DevBuf bi, bo;
   HIP_TRY(hipSetDevice(P->device));
   if (ensure_ext_sqrt(P)) return 1;
+  if (P->type == 'f' && ensure_sqrt_constants(P)) return 1;   // fq_sqrt works through square roots in F_q
   HIP_TRY(bi.alloc(n * li));
   HIP_TRY(bo.alloc(n * lo));
   void *di = bi.p, *d_o = bo.p;
@@ -1123,10 +1128,7 @@ static int run_compress(pbc_hip_pairing_s *P, int dir, int group, uint8_t *out, 
   if (!P) return fail("null pairing");
   if (P->device < 0) return fail("no HIP device: libpbc_hip has no CPU fallback");
   const bool symmetric = P->type == 'a' || P->type == '1' || P->type == 'e';
-  if (group == 2 && !symmetric) {
-    if (dir > 1) return fail("x-only points are built for G1 (and G2 of the symmetric types a, a1, e)");
-    return n ? run_twist_points(P, dir + 1, out, in, 0, n) : 0;
-  }
+  if (group == 2 && !symmetric) return n ? run_twist_points(P, dir + 1, out, in, 0, n) : 0;
   if (group != 1 && group != 2) return fail("group must be 1 or 2");
   if (!n) return 0;
   const size_t lp = (size_t) P->len1, lc = (size_t) P->len_fq + (dir < 2 ? 1 : 0);
@@ -1165,6 +1167,7 @@ extern "C" int pbc_hip_element_from_bytes_x_only_batch(pbc_hip_pairing_t *P, int
   return run_compress(P, 3, group, out, in, n);
 }
 extern "C" int pbc_hip_pairing_length_in_bytes_x_only_G1(const pbc_hip_pairing_t *p) { return p->len_fq; }
+extern "C" int pbc_hip_pairing_length_in_bytes_x_only_G2(const pbc_hip_pairing_t *p) { return p->len2 / 2; }
 
 extern "C" int pbc_hip_element_from_hash_batch(pbc_hip_pairing_t *P, int group, uint8_t *out, const uint8_t *data,
                                                int hlen, size_t n) {

@@ -89,10 +89,10 @@ class HostSim:
         return out
 
     def g2_points(self, what, recs, hlen=0):
-        """twists: what 0 element_from_hash (recs: digests of hlen bytes), 1 compress, 2 decompress"""
+        """twists: what 0 element_from_hash (recs: digests of hlen bytes), 1 compress, 2 decompress, 3 / 4 to / from x-only"""
         recs = np.ascontiguousarray(recs, np.uint8)
-        lp, lc = self.len2, self.len2 // 2 + 1
-        li, lo = (hlen, lp) if what == 0 else (lp, lc) if what == 1 else (lc, lp)
+        lp, lc, lx = self.len2, self.len2 // 2 + 1, self.len2 // 2
+        li, lo = {0: (hlen, lp), 1: (lp, lc), 2: (lc, lp), 3: (lp, lx), 4: (lx, lp)}[what]
         n = recs.size // li
         out = np.empty((n, lo), np.uint8)
         self.L.hostsim_g2_points.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t]

@@ -173,7 +173,8 @@ int hostsim_compress(void *h, int dir, uint8_t *out, const uint8_t *in, size_t n
   }
   return 0;
 }
-// twists (G2 of types d, g, f): what 0 element_from_hash (digests of hlen bytes), 1 compress, 2 decompress
+// twists (G2 of types d, g, f): what 0 element_from_hash (digests of hlen bytes), 1 compress, 2 decompress,
+// 3 to x-only, 4 from x-only
 #define HS_DISPATCH_TWIST(P_, ...)                                                  \
   do {                                                                              \
     if ((P_)->type == 'f') { HS_DISPATCH_F((P_)->nlimb, { typedef Fq2Ops<N> F; __VA_ARGS__; }); } \
@@ -189,12 +190,21 @@ int hostsim_g2_points(void *h, int what, uint8_t *out, const uint8_t *in, int hl
     P->xs_ready = true;
     c_xs = P->xs;
   }
-  const size_t lp = P->len2, lc = lp / 2 + 1;
-  const size_t li = what == 0 ? (size_t) hlen : what == 1 ? lp : lc, lo = what == 1 ? lc : lp;
+  if (P->type == 'f' && !P->hash.ts_ready) {             // fq_sqrt goes through square roots in F_q
+    HS_DISPATCH(P->nlimb, fp_ts_init<N>(P->hash.ts_c, P->hash.ts_t, P->hash.ts_tbits, P->hash.half, P->hash.halfbits));
+    P->hash.ts_ready = true;
+    activate(P);
+    c_xs = P->xs;
+  }
+  const size_t lp = P->len2, lc = lp / 2 + 1, lx = lp / 2;
+  const size_t li = what == 0 ? (size_t) hlen : (what == 1 || what == 3) ? lp : what == 2 ? lc : lx;
+  const size_t lo = what == 1 ? lc : what == 3 ? lx : lp;
   for (size_t i = 0; i < n; i++) {
     if (what == 0) { HS_DISPATCH_TWIST(P, g2_from_hash_lane<F>(out + i * lo, in + i * li, hlen)); }
     else if (what == 1) { HS_DISPATCH_TWIST(P, g2_compress_lane<F>(out + i * lo, in + i * li)); }
-    else { HS_DISPATCH_TWIST(P, g2_decompress_lane<F>(out + i * lo, in + i * li)); }
+    else if (what == 2) { HS_DISPATCH_TWIST(P, g2_decompress_lane<F>(out + i * lo, in + i * li)); }
+    else if (what == 3) { memcpy(out + i * lo, in + i * li, lx); }
+    else { HS_DISPATCH_TWIST(P, g2_from_x_lane<F>(out + i * lo, in + i * li)); }
   }
   return 0;
 }

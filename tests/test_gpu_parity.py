@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 import oracle
-from conftest import G2_HASH, G2_COMPRESS, XONLY, check_x_only, golden, OTHER, GENERIC_A, GENERIC_OTHER, GENERIC_F, FILES_OF, param_value
+from conftest import G2_HASH, G2_COMPRESS, G2_XONLY, XONLY, check_x_only, check_x_only_g2, golden, OTHER, GENERIC_A, GENERIC_OTHER, GENERIC_F, FILES_OF, param_value
 
 pytestmark = pytest.mark.gpu
 
@@ -756,3 +756,11 @@ def test_compressed_points_on_the_twists_match_reference(hips, key, name):
     neg = H.element_from_bytes_compressed(2, flipped)
     assert np.array_equal(neg[:, :v.len1 // 2], v.g1[:, :v.len1 // 2]) and not np.array_equal(neg, v.g1)
     assert np.array_equal(H.element_to_bytes_compressed(2, neg), flipped)
+
+
+@pytest.mark.parametrize("key,name,exact", G2_XONLY)
+def test_x_only_points_on_the_twists_match_reference(hips, key, name, exact):
+    v = golden(name)
+    H = hips[key]
+    check_x_only_g2(lambda p: H.element_to_bytes_x_only(2, p), lambda x: H.element_from_bytes_x_only(2, x), v, exact,
+                    param_value(key, "q"), H.length_in_bytes_Fq)

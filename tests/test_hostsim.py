@@ -5,7 +5,7 @@ mirror for GPU-less bring-up, not a product path: libpbc_hip.so never contains i
 import numpy as np
 import pytest
 
-from conftest import G2_HASH, G2_COMPRESS, XONLY, check_x_only, golden, _param, PARAM_OF, OTHER, GENERIC_A, GENERIC_OTHER, GENERIC_F, FILES_OF, key_of, param_value
+from conftest import G2_HASH, G2_COMPRESS, G2_XONLY, XONLY, check_x_only, check_x_only_g2, golden, _param, PARAM_OF, OTHER, GENERIC_A, GENERIC_OTHER, GENERIC_F, FILES_OF, key_of, param_value
 
 hostsim = pytest.importorskip("hostsim")
 
@@ -271,3 +271,11 @@ def test_type_d_signed_limb_experiment_cross_pairs_and_bad_inputs(sims):
     S = sims["d"]
     assert np.array_equal(S.prod_pairing(A, B, 1), S.prod_pairing(A, B, 1, d_lazy=True))
     assert np.array_equal(S.prod_pairing(A, B, 3), S.prod_pairing(A, B, 3, d_lazy=True))
+
+
+@pytest.mark.parametrize("key,name,exact", G2_XONLY)
+def test_x_only_points_on_the_twists_on_host(sims, key, name, exact):
+    """element_to_bytes_x_only / element_from_bytes_x_only on G2 of types f, d, g vs the reference"""
+    v = golden(name)
+    S = sims[key]
+    check_x_only_g2(lambda p: S.g2_points(3, p), lambda x: S.g2_points(4, x), v, exact, param_value(key, "q"), S.len1 // 2)

@@ -344,12 +344,56 @@ struct LazyD {
       for (int k = 0; k < L; k++) a.c[i].l[k] = (int32_t) r[L * i + k];
   }
 #endif
-  static __device__ __noinline__ f3vec f3_mul_call(f3vec va, f3vec vb) {
+  // The two operands are 36 words; 31 argument registers are available (the last one carries the work-item id).
+  // The last five limbs of b travel through a lane-private LDS slot (written and read in order within the wave)
+  // instead of the stack, whose round trip through scratch memory would sit on the critical path of every product.
+  static constexpr int BREG = 31 - 3 * L, BBOX = 3 * L - BREG;
+  static PBC_DEV uint32_t *mailbox() {
+    __shared__ uint32_t box[BBOX * D_LANES];
+    return box;
+  }
+  static PBC_DEV void box_put(const f3 &b) {
+    uint32_t *box = mailbox();
+#pragma unroll
+    for (int w = BREG; w < 3 * L; w++) box[(w - BREG) * D_LANES + threadIdx.x] = (uint32_t) b.c[w / L].l[w % L];
+  }
+  static PBC_DEV void box_get(f3 &b) {
+    const uint32_t *box = mailbox();
+#pragma unroll
+    for (int w = BREG; w < 3 * L; w++) b.c[w / L].l[w % L] = (int32_t) box[(w - BREG) * D_LANES + threadIdx.x];
+  }
+#ifdef PBC_HOSTSIM
+  typedef f3 f3lo;                       // the host mirror passes the struct (it carries the bounds) with the boxed limbs blanked
+  static f3lo f3_pack_lo(const f3 &b) {
+    f3 r = b;
+    for (int w = BREG; w < 3 * L; w++) r.c[w / L].l[w % L] = 0x5a5a5a5a;
+    return r;
+  }
+  static void f3_unpack_lo(f3 &b, const f3lo &v) { b = v; }
+#else
+  typedef uint32_t f3lo __attribute__((ext_vector_type(BREG)));
+  static PBC_DEV f3lo f3_pack_lo(const f3 &b) {
+    f3lo v;
+#pragma unroll
+    for (int w = 0; w < BREG; w++) v[w] = (uint32_t) b.c[w / L].l[w % L];
+    return v;
+  }
+  static PBC_DEV void f3_unpack_lo(f3 &b, f3lo v) {
+#pragma unroll
+    for (int w = 0; w < BREG; w++) b.c[w / L].l[w % L] = (int32_t) v[w];
+  }
+#endif
+  static __device__ __noinline__ f3vec f3_mul_call(f3vec va, f3lo vb) {
     f3 a, b, r;
     f3_unpack(a, va);
-    f3_unpack(b, vb);
+    f3_unpack_lo(b, vb);
+    box_get(b);
     f3_mul_inl(r, a, b);
     return f3_pack(r);
+  }
+  static PBC_DEV void f3_mul(f3 &r, const f3 &a, const f3 &b) {
+    box_put(b);
+    f3_unpack(r, f3_mul_call(f3_pack(a), f3_pack_lo(b)));
   }
   static __device__ __noinline__ f3vec f3_sqr_call(f3vec va) {
     f3 a, r;
@@ -366,7 +410,6 @@ struct LazyD {
     for (int i = 0; i < 3; i++) mul_inl(r.c[i], a.c[i], V);
     return f3_pack(r);
   }
-  static PBC_DEV void f3_mul(f3 &r, const f3 &a, const f3 &b) { f3_unpack(r, f3_mul_call(f3_pack(a), f3_pack(b))); }
   static PBC_DEV void f3_sqr(f3 &r, const f3 &a) { f3_unpack(r, f3_sqr_call(f3_pack(a))); }
   static PBC_DEV void f3_mul_v(f3 &r, const f3 &a) { f3_unpack(r, f3_mul_v_call(f3_pack(a))); }
   // a^q (the qpower macros of cc_tatepower, d_param.c:507-527)

@@ -347,7 +347,11 @@ struct LazyD {
   // The two operands are 36 words; 31 argument registers are available (the last one carries the work-item id).
   // The last five limbs of b travel through a lane-private LDS slot (written and read in order within the wave)
   // instead of the stack, whose round trip through scratch memory would sit on the critical path of every product.
+  // Transport order of b: coefficients 1 and 2 first (the product starts with the x^3, x^4 terms a1 b2 + a2 b1 and
+  // a2 b2), coefficient 0 last, so that the boxed limbs are the ones needed latest.
   static constexpr int BREG = 31 - 3 * L, BBOX = 3 * L - BREG;
+  static constexpr int tc(int w) { return w < 2 * L ? 1 + w / L : 0; }      // coefficient of transport word w
+  static constexpr int tl(int w) { return w % L; }                          // limb of transport word w
   static PBC_DEV uint32_t *mailbox() {
     __shared__ uint32_t box[BBOX * D_LANES];
     return box;
@@ -355,18 +359,18 @@ struct LazyD {
   static PBC_DEV void box_put(const f3 &b) {
     uint32_t *box = mailbox();
 #pragma unroll
-    for (int w = BREG; w < 3 * L; w++) box[(w - BREG) * D_LANES + threadIdx.x] = (uint32_t) b.c[w / L].l[w % L];
+    for (int w = BREG; w < 3 * L; w++) box[(w - BREG) * D_LANES + threadIdx.x] = (uint32_t) b.c[tc(w)].l[tl(w)];
   }
   static PBC_DEV void box_get(f3 &b) {
     const uint32_t *box = mailbox();
 #pragma unroll
-    for (int w = BREG; w < 3 * L; w++) b.c[w / L].l[w % L] = (int32_t) box[(w - BREG) * D_LANES + threadIdx.x];
+    for (int w = BREG; w < 3 * L; w++) b.c[tc(w)].l[tl(w)] = (int32_t) box[(w - BREG) * D_LANES + threadIdx.x];
   }
 #ifdef PBC_HOSTSIM
   typedef f3 f3lo;                       // the host mirror passes the struct (it carries the bounds) with the boxed limbs blanked
   static f3lo f3_pack_lo(const f3 &b) {
     f3 r = b;
-    for (int w = BREG; w < 3 * L; w++) r.c[w / L].l[w % L] = 0x5a5a5a5a;
+    for (int w = BREG; w < 3 * L; w++) r.c[tc(w)].l[tl(w)] = 0x5a5a5a5a;
     return r;
   }
   static void f3_unpack_lo(f3 &b, const f3lo &v) { b = v; }
@@ -375,12 +379,12 @@ struct LazyD {
   static PBC_DEV f3lo f3_pack_lo(const f3 &b) {
     f3lo v;
 #pragma unroll
-    for (int w = 0; w < BREG; w++) v[w] = (uint32_t) b.c[w / L].l[w % L];
+    for (int w = 0; w < BREG; w++) v[w] = (uint32_t) b.c[tc(w)].l[tl(w)];
     return v;
   }
   static PBC_DEV void f3_unpack_lo(f3 &b, f3lo v) {
 #pragma unroll
-    for (int w = 0; w < BREG; w++) b.c[w / L].l[w % L] = (int32_t) v[w];
+    for (int w = 0; w < BREG; w++) b.c[tc(w)].l[tl(w)] = (int32_t) v[w];
   }
 #endif
   static __device__ __noinline__ f3vec f3_mul_call(f3vec va, f3lo vb) {
@@ -388,6 +392,9 @@ struct LazyD {
     f3_unpack(a, va);
     f3_unpack_lo(b, vb);
     box_get(b);
+#ifndef PBC_HOSTSIM
+    __builtin_amdgcn_sched_barrier(0);   // issue the LDS reads here; their wait lands where coefficient 0 is first used
+#endif
     f3_mul_inl(r, a, b);
     return f3_pack(r);
   }

@@ -764,3 +764,18 @@ def test_x_only_points_on_the_twists_match_reference(hips, key, name, exact):
     H = hips[key]
     check_x_only_g2(lambda p: H.element_to_bytes_x_only(2, p), lambda x: H.element_from_bytes_x_only(2, x), v, exact,
                     param_value(key, "q"), H.length_in_bytes_Fq)
+
+
+@pytest.mark.parametrize("pname", ["a", "d159", "f", "g149"])
+def test_from_hash_through_the_glue(pname):
+    """element_from_hash_batch of integration/pbc_hip_glue.c on G1 and G2 element_t arrays vs the reference's own
+    element_from_hash (glue_test ... hash)"""
+    import os
+    import subprocess
+    import pbc_amd
+    if not os.path.exists(oracle.GLUE_TEST):
+        pytest.skip("oracle/_ref/glue_test not built (needs /root/reference at build time)")
+    env = dict(os.environ, PBC_HIP_LIB=pbc_amd.LIB_PATH)
+    r = subprocess.run([oracle.GLUE_TEST, os.path.join(pbc_amd.PARAM_DIR, pname + ".param"), "8", "hash"],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and "PASS" in r.stdout, r.stdout + r.stderr

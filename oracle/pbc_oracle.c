@@ -914,6 +914,101 @@ int oracle_g_mul(const oracle_pairing *P, int group, const uint8_t *ptb, const u
   return 0;
 }
 
+static int fp_sqrt_ts(const fpctx *F, fe *out, const fe *a, const big *q);
+
+/* ---- element_from_hash and the point formats on G1 = E(F_q) ---------------------------------------- */
+/* fp_from_hash (arith/montfp.c:441-449) over pbc_mpz_from_hash (arith/field.c:643-668): the digest is laid
+ * out as H || 0 || H || 1 || ... up to the byte length of q, read big-endian, halved while it exceeds q. */
+static void fp_from_hash(const oracle_pairing *P, fe *x, const uint8_t *data, int len) {
+  const fpctx *F = &P->Fq;
+  uint8_t buf[8 * MAXL];
+  int count = F->nbytes, i = 0, done = 0;
+  uint8_t counter = 0;
+  for (;;) {
+    int n;
+    if (len >= count - i) { n = count - i; done = 1; } else n = len;
+    memcpy(buf + i, data, (size_t) n);
+    i += n;
+    if (done) break;
+    buf[i++] = counter++;
+    if (i == count) break;
+  }
+  big z;
+  big_from_be(&z, buf, (size_t) count);
+  while (bn_cmp(z.v, P->q.v, BIGL) > 0) {
+    for (int w = 0; w < BIGL - 1; w++) z.v[w] = (z.v[w] >> 1) | (z.v[w + 1] << 63);
+    z.v[BIGL - 1] >>= 1;
+  }
+  fe t; memset(&t, 0, sizeof t);
+  memcpy(t.v, z.v, 8 * (size_t) F->n);
+  fp_mul(F, x, &t, &F->R2);            /* fp_set_mpz: z = q becomes 0 */
+}
+/* fp_sgn_odd (montfp.c:460-472): 0 for 0, +1 when the canonical residue is odd, else -1 */
+static int fp_sgn(const fpctx *F, const fe *a) {
+  uint8_t b[8 * MAXL];
+  if (fp_is0(F, a)) return 0;
+  fp_to_bytes(F, b, a);
+  return (b[F->nbytes - 1] & 1) ? 1 : -1;
+}
+/* point_from_x (ecc/curve.c:778-791): y = sqrt(x^3 + a x + b), "requires a solution to exist"; returns 0 if none.
+ * element_tonelli's root (arith/field.c:672-720) is x^((q+1)/4) when q = 3 mod 4; otherwise it depends on the
+ * reference's random non-residue and callers that do not fix the sign get either root. */
+static int pt_from_x(const oracle_pairing *P, pt *R, const fe *x) {
+  const fpctx *F = &P->Fq;
+  fe t;
+  fp_sqr(F, &t, x);
+  fp_add(F, &t, &t, &P->ca);
+  fp_mul(F, &t, &t, x);
+  fp_add(F, &t, &t, &P->cb);
+  R->inf = 0;
+  R->x = *x;
+  if (fp_is0(F, &t)) { R->y = F->zero; return 1; }
+  return fp_sqrt_ts(F, &R->y, &t, &P->q);
+}
+/* curve_from_hash (ecc/curve.c:455-482); G1 of every type, G2 of the symmetric ones */
+int oracle_from_hash(const oracle_pairing *P, const uint8_t *data, int hlen, uint8_t *out, size_t n) {
+  const fpctx *F = &P->Fq;
+  for (size_t i = 0; i < n; i++) {
+    fe x;
+    pt A, R;
+    fp_from_hash(P, &x, data + i * (size_t) hlen, hlen);
+    while (!pt_from_x(P, &A, &x)) {     /* x <- x^2 + 1 until the right-hand side is a square */
+      fp_sqr(F, &x, &x);
+      fp_add(F, &x, &x, &F->R);
+    }
+    if (fp_sgn(F, &A.y) < 0) fp_neg(F, &A.y, &A.y);
+    if (big_bits(&P->h)) pt_mul(F, &P->ca, &R, &A, &P->h); else R = A;   /* cofactor (curve.c:477) */
+    pt_to_bytes(F, out + i * (size_t) P->len1, &R);
+  }
+  return 0;
+}
+/* what 0: element_to_bytes_compressed (curve.c:762-773), 1: element_from_bytes_compressed (:799-813),
+ * 2: element_to_bytes_x_only (:821-827), 3: element_from_bytes_x_only (:829-836; the root as point_from_x
+ * leaves it -- compare up to sign when q = 1 mod 4).  An x without a point gives the zero record. */
+int oracle_point_format(const oracle_pairing *P, int what, const uint8_t *in, uint8_t *out, size_t n) {
+  const fpctx *F = &P->Fq;
+  const size_t fb = (size_t) F->nbytes, lp = 2 * fb;
+  for (size_t i = 0; i < n; i++) {
+    if (what == 0 || what == 2) {
+      const uint8_t *pnt = in + i * lp;
+      uint8_t *o = out + i * (fb + (what == 0));
+      memcpy(o, pnt, fb);
+      if (what == 0) { fe y; fp_from_bytes(F, &y, pnt + fb); o[fb] = fp_sgn(F, &y) > 0; }
+    } else {
+      const size_t li = fb + (what == 1);
+      fe x;
+      pt A;
+      fp_from_bytes(F, &x, in + i * li);
+      if (!pt_from_x(P, &A, &x)) { memset(out + i * lp, 0, lp); continue; }
+      if (what == 1) {
+        const int sg = fp_sgn(F, &A.y);
+        if (in[i * li + fb] ? sg < 0 : sg > 0) fp_neg(F, &A.y, &A.y);
+      }
+      pt_to_bytes(F, out + i * lp, &A);
+    }
+  }
+  return 0;
+}
 
 /* ================================================================== */
 /* Type E (k = 1, ordinary curve over a 1020-bit F_q), ecc/e_param.c   */
@@ -1351,6 +1446,7 @@ static int init_d(oracle_pairing *P, const char *txt, size_t len) {
   if (kv_big(txt, len, "q", &P->q) || kv_big(txt, len, "r", &P->r) || kv_big(txt, len, "a", &a) ||
       kv_big(txt, len, "b", &b) || kv_big(txt, len, "nqr", &nqr))
     return 1;
+  if (kv_big(txt, len, "h", &P->h)) return 1;        /* cofactor of E(F_q) (d_param.c:1016, g_param.c:1267) */
   if (d == 3 && (kv_int(txt, len, "k", &k) || k != 6)) return 1;      /* type g files carry no k that matters: k = 10 */
   for (int i = 0; i < d; i++) {
     char key[8];

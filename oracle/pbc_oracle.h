@@ -48,6 +48,11 @@ int oracle_gt_mul(const oracle_pairing *p, const uint8_t *a, const uint8_t *b, u
 int oracle_gt_pow(const oracle_pairing *p, const uint8_t *a, const uint8_t *e, size_t elen,
                   uint8_t *out, size_t n);
 /* G1/G2 scalar multiplication on wire bytes (group: 1 or 2), for bilinearity tests. */
+/* element_from_hash on G1 (G2 of the symmetric types): curve_from_hash, ecc/curve.c:455-482 */
+int oracle_from_hash(const oracle_pairing *p, const uint8_t *data, int hlen, uint8_t *out, size_t n);
+/* G1 point formats (ecc/curve.c:762-836): what 0 to_bytes_compressed, 1 from_bytes_compressed, 2 to_bytes_x_only,
+ * 3 from_bytes_x_only */
+int oracle_point_format(const oracle_pairing *p, int what, const uint8_t *in, uint8_t *out, size_t n);
 int oracle_g_mul(const oracle_pairing *p, int group, const uint8_t *pt, const uint8_t *e,
                  size_t elen, uint8_t *out, size_t n);
 

@@ -779,3 +779,22 @@ def test_from_hash_through_the_glue(pname):
     r = subprocess.run([oracle.GLUE_TEST, os.path.join(pbc_amd.PARAM_DIR, pname + ".param"), "8", "hash"],
                        capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0 and "PASS" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("key,hlen", [("a", 20), ("a", 70), ("d", 32), ("f", 24), ("g149", 32), ("d224", 28), ("e_160_400", 20)])
+def test_from_hash_and_point_formats_on_fresh_digests_vs_oracle(hips, oracles, key, hlen):
+    """seeded digests no fixture holds, at a size that exercises the x <- x^2 + 1 retries many times over:
+    element_from_hash, compressed and x-only forms of the hashed points vs the oracle"""
+    rng = np.random.default_rng(hlen * 131 + len(key))
+    n = 96 if key in ("a", "e_160_400") else 400           # the oracle pays two Fermat inversions per cofactor bit
+    D = rng.integers(0, 256, (n, hlen), dtype=np.uint8)
+    H, O = hips[key], oracles[key]
+    pts = H.element_from_hash(1, D)
+    assert np.array_equal(pts, O.from_hash(D))
+    c = H.element_to_bytes_compressed(1, pts)
+    assert np.array_equal(c, O.point_format(0, pts))
+    assert np.array_equal(H.element_from_bytes_compressed(1, c), pts)
+    fb = H.length_in_bytes_Fq
+    back = H.element_from_bytes_x_only(1, H.element_to_bytes_x_only(1, pts))
+    assert np.array_equal(back[:, :fb], pts[:, :fb])
+    assert np.array_equal(H.element_to_bytes_compressed(1, back)[:, :fb], c[:, :fb])

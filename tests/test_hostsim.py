@@ -279,3 +279,24 @@ def test_x_only_points_on_the_twists_on_host(sims, key, name, exact):
     v = golden(name)
     S = sims[key]
     check_x_only_g2(lambda p: S.g2_points(3, p), lambda x: S.g2_points(4, x), v, exact, param_value(key, "q"), S.len1 // 2)
+
+
+@pytest.mark.parametrize("key,hlen", [("a", 20), ("a", 70), ("d", 32), ("f", 24), ("g149", 32), ("d224", 28), ("e_160_400", 20)])
+def test_from_hash_and_point_formats_on_fresh_digests_vs_oracle(sims, oracles, key, hlen):
+    """digests no fixture holds: element_from_hash, then compressed and x-only round trips of the hashed points,
+    through the kernel source on the host and through the oracle (itself pinned on the reference's vectors)"""
+    rng = np.random.default_rng(hlen * 131 + len(key))
+    n = 16
+    D = rng.integers(0, 256, (n, hlen), dtype=np.uint8)
+    S, O = sims[key], oracles[key]
+    pts = S.from_hash(D, hlen)
+    assert np.array_equal(pts, O.from_hash(D))
+    c = S.compress(0, pts)
+    assert np.array_equal(c, O.point_format(0, pts))
+    assert np.array_equal(S.compress(1, c), pts)
+    x = S.compress(2, pts)
+    back = S.compress(3, x)
+    fb = S.len1 // 2
+    assert np.array_equal(back[:, :fb], pts[:, :fb])
+    # (x, y') lies on the curve with y' = +-y: its compressed form differs from c at most in the sign byte
+    assert np.array_equal(S.compress(0, back)[:, :fb], c[:, :fb])

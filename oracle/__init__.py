@@ -52,6 +52,8 @@ def lib():
         L.oracle_g_mul.argtypes = [vp, ci, vp, vp, sz, vp, sz]
         L.oracle_from_hash.argtypes = [vp, vp, ci, vp, sz]
         L.oracle_point_format.argtypes = [vp, ci, vp, vp, sz]
+        L.oracle_from_hash_g2.argtypes = [vp, vp, ci, vp, sz]
+        L.oracle_point_format_g2.argtypes = [vp, ci, vp, vp, sz]
         L.oracle_counters.argtypes = [ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64), ci]
         _lib = L
     return _lib
@@ -148,6 +150,26 @@ class OraclePairing:
         out = np.empty((n, lo), np.uint8)
         if lib().oracle_point_format(self._h, what, _ptr(recs), _ptr(out), n):
             raise RuntimeError("oracle_point_format failed")
+        return out
+
+    def from_hash_g2(self, digests):
+        """element_from_hash on the G2 twist (types d, g, f)"""
+        d = np.ascontiguousarray(digests, np.uint8)
+        n, hlen = d.shape
+        out = np.empty((n, self.len_G2), np.uint8)
+        if lib().oracle_from_hash_g2(self._h, _ptr(d), hlen, _ptr(out), n):
+            raise RuntimeError("oracle_from_hash_g2 failed")
+        return out
+
+    def point_format_g2(self, what, recs):
+        """G2 twist point formats: 0 compress, 1 decompress, 2 to x-only, 3 from x-only"""
+        recs = np.ascontiguousarray(recs, np.uint8)
+        fb = self.len_G2 // 2
+        li, lo = {0: (2 * fb, fb + 1), 1: (fb + 1, 2 * fb), 2: (2 * fb, fb), 3: (fb, 2 * fb)}[what]
+        n = recs.size // li
+        out = np.empty((n, lo), np.uint8)
+        if lib().oracle_point_format_g2(self._h, what, _ptr(recs), _ptr(out), n):
+            raise RuntimeError("oracle_point_format_g2 failed")
         return out
 
     def g_mul(self, group, pts, e):

@@ -1775,6 +1775,160 @@ static int init_f(oracle_pairing *P, const char *txt, size_t len) {
 }
 #undef SETBIG
 
+/* ================================================================== */
+/* G2 twists of types d, g (E'(F_q^d)) and f (E'(F_q^2)): hashing and compressed points                 */
+/* ================================================================== */
+/* One element of the twist's field, whichever it is. */
+typedef struct { fd d; g2 q; } xe;
+#define ISF (P->type == 'f')
+static void xe_mul(const oracle_pairing *P, xe *r, const xe *a, const xe *b) { if (ISF) g2_mul(P, &r->q, &a->q, &b->q); else fd_mul(P, &r->d, &a->d, &b->d); }
+static void xe_sqr(const oracle_pairing *P, xe *r, const xe *a) { if (ISF) g2_sqr(P, &r->q, &a->q); else fd_sqr(P, &r->d, &a->d); }
+static void xe_add(const oracle_pairing *P, xe *r, const xe *a, const xe *b) { if (ISF) g2_add(&P->Fq, &r->q, &a->q, &b->q); else fd_add(P, &r->d, &a->d, &b->d); }
+static void xe_neg(const oracle_pairing *P, xe *r, const xe *a) { if (ISF) g2_neg(&P->Fq, &r->q, &a->q); else fd_neg(P, &r->d, &a->d); }
+static int xe_eq(const oracle_pairing *P, const xe *a, const xe *b) { return ISF ? g2_eq(&P->Fq, &a->q, &b->q) : fd_eq(P, &a->d, &b->d); }
+static void xe_set_fq(const oracle_pairing *P, xe *r, const fe *s) {
+  memset(r, 0, sizeof *r);
+  if (ISF) { r->q.x = *s; r->q.y = P->Fq.zero; } else fd_set_fq(P, &r->d, s);
+}
+static int xe_is0(const oracle_pairing *P, const xe *a) { xe z; xe_set_fq(P, &z, &P->Fq.zero); return xe_eq(P, a, &z); }
+static int xe_ncoef(const oracle_pairing *P) { return ISF ? 2 : DEG; }
+static fe *xe_coef(const oracle_pairing *P, xe *a, int i) { return ISF ? (i ? &a->q.y : &a->q.x) : &a->d.c[i]; }
+static void xe_from_bytes(const oracle_pairing *P, xe *r, const uint8_t *b) {
+  xe_set_fq(P, r, &P->Fq.zero);
+  for (int i = 0; i < xe_ncoef(P); i++) fp_from_bytes(&P->Fq, xe_coef(P, r, i), b + i * P->Fq.nbytes);
+}
+static void xe_to_bytes(const oracle_pairing *P, uint8_t *b, xe *a) {
+  for (int i = 0; i < xe_ncoef(P); i++) fp_to_bytes(&P->Fq, b + i * P->Fq.nbytes, xe_coef(P, a, i));
+}
+/* polymod_sgn (arith/poly.c:1189-1199) / fq_sign (arith/fieldquadratic.c:159-165): the first non-zero coefficient's */
+static int xe_sgn(const oracle_pairing *P, xe *a) {
+  for (int i = 0; i < xe_ncoef(P); i++) { int sg = fp_sgn(&P->Fq, xe_coef(P, a, i)); if (sg) return sg; }
+  return 0;
+}
+/* polymod_from_hash (poly.c:341-348): every coefficient the same value; fq_from_hash (fieldquadratic.c:311-316):
+ * the two halves of the digest */
+static void xe_from_hash(const oracle_pairing *P, xe *r, const uint8_t *data, int len) {
+  xe_set_fq(P, r, &P->Fq.zero);
+  if (ISF) {
+    const int k = len / 2;
+    fp_from_hash(P, &r->q.x, data, k);
+    fp_from_hash(P, &r->q.y, data + k, len - k);
+  } else {
+    fe h;
+    fp_from_hash(P, &h, data, len);
+    for (int i = 0; i < DEG; i++) r->d.c[i] = h;
+  }
+}
+static void xe_pow(const oracle_pairing *P, xe *r, const xe *a, const big *e) {
+  xe acc, base = *a;
+  xe_set_fq(P, &acc, &P->Fq.R);
+  for (int i = big_bits(e) - 1; i >= 0; i--) {
+    xe_sqr(P, &acc, &acc);
+    if (big_bit(e, i)) xe_mul(P, &acc, &acc, &base);
+  }
+  *r = acc;
+}
+static void big_shr1(big *a) {
+  for (int w = 0; w < BIGL - 1; w++) a->v[w] = (a->v[w] >> 1) | (a->v[w + 1] << 63);
+  a->v[BIGL - 1] >>= 1;
+}
+/* Square root in the twist's field; 0 when `a` is not a square.  The reference gets there by other means --
+ * polymod_sqrt (poly.c:634-700) factors y^2 - a with random trial polynomials, fq_sqrt (fieldquadratic.c:357-392)
+ * uses the norm -- and its callers fix the sign afterwards (curve_from_hash, element_from_bytes_compressed) or
+ * keep whichever root came out (x-only), so the restatement is Tonelli-Shanks over |K*| = q^m - 1 = 2^s t from the
+ * non-residue the tower is built on.  is_sqr: polymod_is_sqr (:617-632) is Euler's criterion (0 is no square);
+ * fq_is_sqr (fieldquadratic.c:339-355) goes through the norm (0 is one). */
+static int xe_sqrt(const oracle_pairing *P, xe *out, const xe *a) {
+  xe one, z, c, x, b, tt, g;
+  xe_set_fq(P, &one, &P->Fq.R);
+  if (xe_is0(P, a)) { if (!ISF) return 0; *out = *a; return 1; }
+  big n = P->q, t, e, half;
+  for (int i = 1; i < xe_ncoef(P); i++) big_mul(&n, &n, &P->q);
+  n.v[0] &= ~1ull;                                   /* q^m - 1 (q^m is odd) */
+  half = n; big_shr1(&half);
+  xe_pow(P, &tt, a, &half);
+  if (!xe_eq(P, &tt, &one)) return 0;
+  t = n;
+  int s = 0;
+  while (!big_bit(&t, 0)) { big_shr1(&t); s++; }
+  if (ISF) { memset(&z, 0, sizeof z); z.q = P->Fx->negalpha; } else xe_set_fq(P, &z, &P->D->nqr);
+  xe_pow(P, &c, &z, &t);
+  e = t; e.v[0] += 1;                                /* t odd: no carry */
+  big_shr1(&e);                                      /* (t + 1)/2 */
+  xe_pow(P, &x, a, &e);
+  xe_pow(P, &b, a, &t);
+  int m = s;
+  while (!xe_eq(P, &b, &one)) {
+    int i = 0; tt = b;
+    while (!xe_eq(P, &tt, &one)) { xe_sqr(P, &tt, &tt); i++; }
+    g = c;
+    for (int j = 0; j < m - i - 1; j++) xe_sqr(P, &g, &g);
+    xe_mul(P, &x, &x, &g);
+    xe_sqr(P, &c, &g);
+    xe_mul(P, &b, &b, &c);
+    m = i;
+  }
+  *out = x;
+  return 1;
+}
+/* right-hand side of the twist: x^3 + a v^2 x + b v^3 (curve.c:885-901) / x^3 + tb (f_param.c:372-383) */
+static void xe_rhs(const oracle_pairing *P, xe *t, const xe *x) {
+  xe ca, cb;
+  if (ISF) { xe_set_fq(P, &ca, &P->Fq.zero); memset(&cb, 0, sizeof cb); cb.q = P->Fx->tb; }
+  else { xe_set_fq(P, &ca, &P->D->ta); xe_set_fq(P, &cb, &P->D->tb); }
+  xe_sqr(P, t, x);
+  xe_add(P, t, t, &ca);
+  xe_mul(P, t, t, x);
+  xe_add(P, t, t, &cb);
+}
+static int twist_types(const oracle_pairing *P) { return P->type == 'd' || P->type == 'g' || P->type == 'f'; }
+/* curve_from_hash (ecc/curve.c:455-482) on the twist; no cofactor there (d_param.c:1057, f_param.c:383, g_param.c:1319) */
+int oracle_from_hash_g2(const oracle_pairing *P, const uint8_t *data, int hlen, uint8_t *out, size_t n) {
+  if (!twist_types(P)) return 1;
+  const size_t fb = (size_t) xe_ncoef(P) * (size_t) P->Fq.nbytes;
+  for (size_t i = 0; i < n; i++) {
+    xe x, y, t, one;
+    xe_set_fq(P, &one, &P->Fq.R);
+    xe_from_hash(P, &x, data + i * (size_t) hlen, hlen);
+    for (;;) {
+      xe_rhs(P, &t, &x);
+      if (xe_sqrt(P, &y, &t)) break;
+      xe_sqr(P, &x, &x);
+      xe_add(P, &x, &x, &one);
+    }
+    if (xe_sgn(P, &y) < 0) xe_neg(P, &y, &y);
+    xe_to_bytes(P, out + i * 2 * fb, &x);
+    xe_to_bytes(P, out + i * 2 * fb + fb, &y);
+  }
+  return 0;
+}
+/* what 0 / 1: element_to_bytes_compressed / element_from_bytes_compressed (ecc/curve.c:762-813) on the twist;
+ * 2 / 3: the x-only pair (:821-836; the root as it comes: compare up to sign) */
+int oracle_point_format_g2(const oracle_pairing *P, int what, const uint8_t *in, uint8_t *out, size_t n) {
+  if (!twist_types(P)) return 1;
+  const size_t fb = (size_t) xe_ncoef(P) * (size_t) P->Fq.nbytes, lp = 2 * fb;
+  for (size_t i = 0; i < n; i++) {
+    if (what == 0 || what == 2) {
+      uint8_t *o = out + i * (fb + (what == 0));
+      memcpy(o, in + i * lp, fb);
+      if (what == 0) { xe y; xe_from_bytes(P, &y, in + i * lp + fb); o[fb] = xe_sgn(P, &y) > 0; }
+    } else {
+      const size_t li = fb + (what == 1);
+      xe x, y, t;
+      xe_from_bytes(P, &x, in + i * li);
+      xe_rhs(P, &t, &x);
+      if (!xe_sqrt(P, &y, &t)) { memset(out + i * lp, 0, lp); continue; }
+      if (what == 1) {
+        const int sg = xe_sgn(P, &y);
+        if (in[i * li + fb] ? sg < 0 : sg > 0) xe_neg(P, &y, &y);
+      }
+      xe_to_bytes(P, out + i * lp, &x);
+      xe_to_bytes(P, out + i * lp + fb, &y);
+    }
+  }
+  return 0;
+}
+
 static int df_gt_mul(const oracle_pairing *P, const uint8_t *a, const uint8_t *b, uint8_t *out) {
   const fpctx *F = &P->Fq;
   if (P->type == 'd' || P->type == 'g') { fk x, y; fk_from_bytes(P, &x, a); fk_from_bytes(P, &y, b); fk_mul(P, &x, &x, &y); fk_to_bytes(P, out, &x); return 0; }

@@ -53,6 +53,9 @@ int oracle_from_hash(const oracle_pairing *p, const uint8_t *data, int hlen, uin
 /* G1 point formats (ecc/curve.c:762-836): what 0 to_bytes_compressed, 1 from_bytes_compressed, 2 to_bytes_x_only,
  * 3 from_bytes_x_only */
 int oracle_point_format(const oracle_pairing *p, int what, const uint8_t *in, uint8_t *out, size_t n);
+/* the same on the G2 twists of types d, g, f (element_from_hash without a cofactor; compressed and x-only points) */
+int oracle_from_hash_g2(const oracle_pairing *p, const uint8_t *data, int hlen, uint8_t *out, size_t n);
+int oracle_point_format_g2(const oracle_pairing *p, int what, const uint8_t *in, uint8_t *out, size_t n);
 int oracle_g_mul(const oracle_pairing *p, int group, const uint8_t *pt, const uint8_t *e,
                  size_t elen, uint8_t *out, size_t n);
 

@@ -798,3 +798,16 @@ def test_from_hash_and_point_formats_on_fresh_digests_vs_oracle(hips, oracles, k
     back = H.element_from_bytes_x_only(1, H.element_to_bytes_x_only(1, pts))
     assert np.array_equal(back[:, :fb], pts[:, :fb])
     assert np.array_equal(H.element_to_bytes_compressed(1, back)[:, :fb], c[:, :fb])
+
+
+@pytest.mark.parametrize("key,hlen", [("d", 32), ("d224", 20), ("f", 32), ("f_256", 21), ("g149", 32)])
+def test_twist_hashing_and_compression_on_fresh_digests_vs_oracle(hips, oracles, key, hlen):
+    """element_from_hash and the compressed form on the G2 twists, 200 seeded digests per curve vs the oracle"""
+    rng = np.random.default_rng(hlen * 17 + len(key))
+    D = rng.integers(0, 256, (200, hlen), dtype=np.uint8)
+    H, O = hips[key], oracles[key]
+    pts = H.element_from_hash(2, D)
+    assert np.array_equal(pts, O.from_hash_g2(D))
+    c = H.element_to_bytes_compressed(2, pts)
+    assert np.array_equal(c, O.point_format_g2(0, pts))
+    assert np.array_equal(H.element_from_bytes_compressed(2, c), pts)

@@ -300,3 +300,16 @@ def test_from_hash_and_point_formats_on_fresh_digests_vs_oracle(sims, oracles, k
     assert np.array_equal(back[:, :fb], pts[:, :fb])
     # (x, y') lies on the curve with y' = +-y: its compressed form differs from c at most in the sign byte
     assert np.array_equal(S.compress(0, back)[:, :fb], c[:, :fb])
+
+
+@pytest.mark.parametrize("key,hlen", [("d", 32), ("d224", 20), ("f", 32), ("f_256", 21), ("g149", 32)])
+def test_twist_hashing_and_compression_on_fresh_digests_vs_oracle(sims, oracles, key, hlen):
+    """element_from_hash and the compressed form on the G2 twists for digests no fixture holds"""
+    rng = np.random.default_rng(hlen * 17 + len(key))
+    D = rng.integers(0, 256, (12, hlen), dtype=np.uint8)
+    S, O = sims[key], oracles[key]
+    pts = S.g2_points(0, D, hlen)
+    assert np.array_equal(pts, O.from_hash_g2(D))
+    c = S.g2_points(1, pts)
+    assert np.array_equal(c, O.point_format_g2(0, pts))
+    assert np.array_equal(S.g2_points(2, c), pts)

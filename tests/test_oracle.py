@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 import oracle
-from conftest import GOLDEN, golden, key_of
+from conftest import GOLDEN, G2_HASH, G2_COMPRESS, G2_XONLY, golden, key_of, param_value
 
 
 @pytest.mark.parametrize("name", sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, "*.vec"))
@@ -172,3 +172,35 @@ def test_oracle_x_only_points_match_reference_vectors(oracles, name):
         for g, w in zip(got, v.gt):
             y, yr = int.from_bytes(g[fb:].tobytes(), "big"), int.from_bytes(w[fb:].tobytes(), "big")
             assert y == yr or y == q - yr
+
+
+@pytest.mark.parametrize("key,name", G2_HASH)
+def test_oracle_from_hash_on_the_twists_matches_reference_vectors(oracles, key, name):
+    v = golden(name)
+    assert np.array_equal(oracles[key].from_hash_g2(v.g1.reshape(v.n, v.len1)), v.gt)
+
+
+@pytest.mark.parametrize("key,name", G2_COMPRESS)
+def test_oracle_compressed_points_on_the_twists_match_reference_vectors(oracles, key, name):
+    v = golden(name)
+    O = oracles[key]
+    assert np.array_equal(O.point_format_g2(0, v.g1), v.gt)
+    assert np.array_equal(O.point_format_g2(1, v.gt), v.g1)
+
+
+@pytest.mark.parametrize("key,name,exact", G2_XONLY)
+def test_oracle_x_only_points_on_the_twists(oracles, key, name, exact):
+    """the oracle takes its extension-field roots by Tonelli-Shanks, the reference by fq_sqrt / polymod_sqrt: x is
+    pinned, y up to sign"""
+    v = golden(name)
+    O = oracles[key]
+    q = param_value(key, "q")
+    fb = (q.bit_length() + 7) // 8
+    half = v.len1 // 2
+    assert np.array_equal(O.point_format_g2(2, v.g1), v.g2)
+    got = O.point_format_g2(3, v.g2)
+    assert np.array_equal(got[:, :half], v.gt[:, :half])
+    for g, w in zip(got, v.gt):
+        cg = [int.from_bytes(g[half + i:half + i + fb].tobytes(), "big") for i in range(0, half, fb)]
+        cw = [int.from_bytes(w[half + i:half + i + fb].tobytes(), "big") for i in range(0, half, fb)]
+        assert cg == cw or cg == [(q - c) % q for c in cw]

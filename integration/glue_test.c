@@ -68,6 +68,7 @@ int main(int argc, char **argv) {
     return fails ? 1 : 0;
   }
   int fails = 0, K = 4;
+  if (n < 24) n = 24;                  /* the fixed-index sections below use up to 24 elements */
   element_t *P = malloc(sizeof(element_t) * n), *Q = malloc(sizeof(element_t) * n);
   element_t *cpu = malloc(sizeof(element_t) * n), *gpu = malloc(sizeof(element_t) * n);
   for (size_t i = 0; i < n; i++) {

@@ -132,11 +132,21 @@ static int run_batch(attach_t *a, element_t out[], element_t in1[], element_t in
   if (m) {
     parallel_for(m, to_bytes_range, &c);
     rc = k == 1 ? L.pair(a->gpu, bt, b1, b2, m) : L.prod(a->gpu, bt, b1, b2, m, k);
-    if (rc) fprintf(stderr, "pbc_hip: %s\n", L.err());
+    if (rc) pbc_error("pbc_hip: %s", L.err());
     else parallel_for(m, from_bytes_range, &c);
   }
   free(b1); free(b2); free(bt); free(slot);
   return rc;
+}
+
+/* A GPU call behind one of PBC's void-returning hooks failed.  PBC's convention for an unrecoverable condition is
+ * pbc_die (misc/utils.c:75-82: message, exit(128)), and that is the default here: a pairing silently computed
+ * somewhere else would hide the fault.  A caller that prefers availability sets PBC_HIP_GLUE_CPU_ON_ERROR=1; the
+ * hook then reports through pbc_error (honours pbc_set_msg_to_stderr) and runs the reference's own CPU routine. */
+static void gpu_failed(const char *what) {
+  const char *e = getenv("PBC_HIP_GLUE_CPU_ON_ERROR");
+  if (e && *e == '1') { pbc_error("pbc_hip: %s: %s (continuing on the CPU)", what, L.err()); return; }
+  pbc_die("pbc_hip: %s: %s", what, L.err());
 }
 
 /* pairing->map replacement: `out` is the element INSIDE the GT wrapper (out->data of the GT
@@ -147,7 +157,7 @@ static void hip_map(element_ptr out, element_ptr in1, element_ptr in2, struct pa
   unsigned char *buf = malloc((size_t) l1 + l2 + lt);
   element_to_bytes(buf, in1);
   element_to_bytes(buf + l1, in2);
-  if (L.pair(a->gpu, buf + l1 + l2, buf, buf + l1, 1)) { fprintf(stderr, "pbc_hip: %s\n", L.err()); a->cpu_map(out, in1, in2, p); }
+  if (L.pair(a->gpu, buf + l1 + l2, buf, buf + l1, 1)) { gpu_failed("element_pairing"); a->cpu_map(out, in1, in2, p); }
   else element_from_bytes(out, buf + l1 + l2);
   free(buf);
 }
@@ -156,7 +166,7 @@ static void hip_prod(element_ptr out, element_t in1[], element_t in2[], int n_pr
   int l1 = L.len1(a->gpu), l2 = L.len2(a->gpu), lt = L.lenT(a->gpu);
   unsigned char *b1 = malloc((size_t) n_prod * l1), *b2 = malloc((size_t) n_prod * l2), *bt = malloc(lt);
   for (int j = 0; j < n_prod; j++) { element_to_bytes(b1 + (size_t) j * l1, in1[j]); element_to_bytes(b2 + (size_t) j * l2, in2[j]); }
-  if (L.prod(a->gpu, bt, b1, b2, 1, n_prod)) { fprintf(stderr, "pbc_hip: %s\n", L.err()); a->cpu_prod(out, in1, in2, n_prod, p); }
+  if (L.prod(a->gpu, bt, b1, b2, 1, n_prod)) { gpu_failed("element_prod_pairing"); a->cpu_prod(out, in1, in2, n_prod, p); }
   else element_from_bytes(out, bt);
   free(b1); free(b2); free(bt);
 }
@@ -168,7 +178,7 @@ static void hip_pp_init(pairing_pp_t p, element_t in1, struct pairing_s *pairing
   unsigned char *buf = malloc(L.len1(a->gpu));
   void *h = NULL;
   element_to_bytes(buf, in1);
-  if (L.pp_init(&h, a->gpu, buf)) { fprintf(stderr, "pbc_hip: %s\n", L.err()); h = NULL; }
+  if (L.pp_init(&h, a->gpu, buf)) pbc_die("pbc_hip: pairing_pp_init: %s", L.err());
   p->data = h;
   free(buf);
 }
@@ -178,7 +188,7 @@ static void hip_pp_apply(element_t out, element_t in2, pairing_pp_t p) {
   int l2 = L.len2(a->gpu), lt = L.lenT(a->gpu);
   unsigned char *buf = malloc((size_t) l2 + lt);
   element_to_bytes(buf, in2);
-  if (!p->data || L.pp_apply(p->data, buf + l2, buf, 1)) fprintf(stderr, "pbc_hip: pp_apply failed\n");
+  if (!p->data || L.pp_apply(p->data, buf + l2, buf, 1)) pbc_die("pbc_hip: pairing_pp_apply: %s", L.err());
   else element_from_bytes(out, buf + l2);
   free(buf);
 }
@@ -245,7 +255,7 @@ int element_pow_zn_batch(element_t out[], element_t in[], element_t zr[], size_t
     slot[m++] = i;
   }
   int rc = !m ? 0 : is_gt ? L.gt_pow(a->gpu, bo, be, bz, m) : L.mul_zn(a->gpu, group, bo, be, bz, m);
-  if (rc) fprintf(stderr, "pbc_hip: %s\n", L.err());
+  if (rc) pbc_error("pbc_hip: %s", L.err());
   else for (size_t i = 0; i < m; i++) element_from_bytes(out[slot[i]], bo + i * le);
   free(be); free(bz); free(bo); free(slot);
   return rc;
@@ -264,7 +274,7 @@ int element_from_hash_batch(element_t out[], const void *data, int hlen, size_t 
   int le = element_length_in_bytes(out[0]);
   unsigned char *bo = malloc(n * (size_t) le + 1);
   int rc = L.from_hash(a->gpu, group, bo, data, hlen, n);
-  if (rc) fprintf(stderr, "pbc_hip: %s\n", L.err());
+  if (rc) pbc_error("pbc_hip: %s", L.err());
   else for (size_t i = 0; i < n; i++) element_from_bytes(out[i], bo + i * (size_t) le);
   free(bo);
   return rc;
@@ -275,7 +285,7 @@ int pbc_hip_attach(pairing_t pairing, const char *param, size_t len) {
   attach_t *a = find(NULL);
   if (!a || find(pairing)) return 1;
   pbc_hip_pairing_t *g;
-  if (L.init(&g, param, len)) { fprintf(stderr, "pbc_hip: %s\n", L.err()); return 1; }
+  if (L.init(&g, param, len)) { pbc_error("pbc_hip: %s", L.err()); return 1; }
   if (L.len1(g) != pairing_length_in_bytes_G1(pairing) || L.len2(g) != pairing_length_in_bytes_G2(pairing) ||
       L.lenT(g) != pairing_length_in_bytes_GT(pairing)) { L.clear(g); return 1; }
   {
@@ -284,7 +294,7 @@ int pbc_hip_attach(pairing_t pairing, const char *param, size_t len) {
     int devs[16], nd = 0;
     if (e && !strcmp(e, "all")) { int c = L.device_count(); for (nd = 0; nd < c && nd < 16; nd++) devs[nd] = nd; }
     else if (e) { for (const char *q = e; *q && nd < 16; ) { devs[nd++] = atoi(q); q = strchr(q, ','); if (!q) break; q++; } }
-    if (nd > 0 && L.use_devices(g, devs, nd)) { fprintf(stderr, "pbc_hip: %s\n", L.err()); L.clear(g); return 1; }
+    if (nd > 0 && L.use_devices(g, devs, nd)) { pbc_error("pbc_hip: %s", L.err()); L.clear(g); return 1; }
   }
   a->pairing = pairing; a->gpu = g; a->cpu_map = pairing->map; a->cpu_prod = pairing->prod_pairings;
   a->cpu_pp_init = pairing->pp_init; a->cpu_pp_clear = pairing->pp_clear; a->cpu_pp_apply = pairing->pp_apply;

@@ -30,18 +30,32 @@ sys.path.insert(0, ROOT)
 import pbc_amd  # noqa: E402  (the product; raises if libpbc_hip.so is missing)
 
 
-def ensure_built():
-    """libpbc_hip.so normally travels with the tree; if it does not, local rank 0 compiles it
-    (hipcc, ~25 s) while the other ranks wait for the file."""
-    if int(os.environ.get("LOCAL_RANK", "0")) == 0:
-        pbc_amd.build()
-    else:
-        for _ in range(600):
-            if os.path.exists(pbc_amd.LIB_PATH) and time.time() - os.path.getmtime(pbc_amd.LIB_PATH) > 2:
-                break
-            time.sleep(0.5)
+def ensure_built(dist, local_rank):
+    """libpbc_hip.so normally travels with the tree; if it does not, local rank 0 compiles it (hipcc, ~3 min) and the
+    other ranks wait at a barrier of the process group (not by polling the file's age)."""
+    err = None
+    if local_rank == 0:
+        try:
+            pbc_amd.build()
+        except Exception as e:  # noqa: BLE001  -- reach the barrier first, then fail on every rank
+            err = e
+    if dist is not None:
+        flags = [None] * dist.get_world_size()
+        dist.all_gather_object(flags, repr(err) if err else "")
+        bad = [f for f in flags if f]
+        if bad:
+            sys.exit("bench.py: building libpbc_hip.so failed: %s" % bad[0])
+    elif err:
+        raise err
+    pbc_amd.lib()                      # every rank loads the same file; raises loudly when it is missing
+
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+# Integer multiply-add roofline: v_mad_u64_u32 issues one wave64 instruction per 4 cycles per SIMD = 16 lanes per clock:
+# 256 CU x 4 SIMD x 16 lanes x 2.4 GHz (MI355X_MICROARCH.md: 157.3 TFLOP/s fp32 vector = 78.6 T lane-FMA/s is the
+# dual-issue / packed figure; the 32 x 32 + 64-bit multiply-add runs at half of it).  A constant, so that `frac` is
+# reproducible; the live probe of the same pipe is reported beside it as peak_measured.
+MAC_PEAK = 256 * 4 * 16 * 2.4e9
 
 
 def load_vec(path):
@@ -112,13 +126,27 @@ def pmc_traffic(workload):
     WRITE_SIZE runs of this same command, summarised in profiles/): (FETCH_SIZE + WRITE_SIZE) KB.
     Raw counter sum; on gfx950 FETCH_SIZE may under-count wide coalesced reads by 2x
     (MI355X_MICROARCH.md).  None when no PMC summary is committed for the workload."""
-    path = os.path.join(ROOT, "profiles", "r01_final_a_pairing_pmc.json")
-    if workload != "a" or not os.path.exists(path):
-        return None
-    j = json.load(open(path))
-    kb = j["FETCH_SIZE"]["avg_per_launch"] + j["WRITE_SIZE"]["avg_per_launch"]
-    return {"bytes_per_launch": int(kb * 1024), "source": "profiles/r01_final_a_pairing_pmc.json (rocprofv3 --pmc, not this run)",
-            "note": "mostly register-spill scratch traffic around the inversion; algorithmic I/O is 403 MB per launch"}
+    for rel in ("profiles/r02_pmc_%s.json" % workload, "profiles/r01_final_a_pairing_pmc.json" if workload == "a" else None):
+        path = os.path.join(ROOT, rel) if rel else None
+        if path and os.path.exists(path):
+            j = json.load(open(path))
+            if "FETCH_SIZE" not in j or "WRITE_SIZE" not in j:
+                continue
+            kb = j["FETCH_SIZE"]["avg_per_launch"] + j["WRITE_SIZE"]["avg_per_launch"]
+            return {"bytes_per_launch": int(kb * 1024), "source": "%s (rocprofv3 --pmc passes of this command, not this run)" % rel,
+                    "note": "raw FETCH_SIZE + WRITE_SIZE; the excess over the algorithmic bytes is register-spill (scratch) traffic"}
+    return None
+
+
+def executed_macs(workload):
+    """multiply-adds the kernel source executes per unit (tools/executed_macs.py: counted on the host-compiled mirror of
+    the kernel source, control flow is data-independent); None when the table has no entry"""
+    path = os.path.join(ROOT, "profiles", "executed_macs.json")
+    if os.path.exists(path):
+        e = json.load(open(path)).get(workload)
+        if e:
+            return float(e["executed_macs_per_unit"])
+    return None
 
 
 WORKLOADS = {
@@ -149,17 +177,19 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="a", choices=sorted(WORKLOADS),
                     help="default: the BASELINE.json metric config (2^20 Type-A pairings)")
-    ap.add_argument("--log2n", type=int, default=None, help="units per GPU per step")
+    ap.add_argument("--log2n", type=int, default=None, help="units per GPU per step (with --strong: units of the whole job)")
+    ap.add_argument("--strong", action="store_true",
+                    help="the 2^log2n units are the whole job, range-split over the ranks (BASELINE config 5: "
+                         "--workload a-prod16 --strong --gpus 8 = 2^18 products sharded across 8 GPUs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--host-path", action="store_true",
-                    help="additionally time the host-buffer entry point (pinned host memory in, host memory out: "
-                         "PCIe-inclusive rate for DESIGN.md; never the reported value)")
+    ap.add_argument("--no-host-path", action="store_true",
+                    help="skip the pinned-host -> host timing of the host-buffer entry point (reported beside `value`, never as it)")
+    ap.add_argument("--host-path", action="store_true", help=argparse.SUPPRESS)     # round-1 spelling: now the default
     args = ap.parse_args()
     pname, fixture, k, dlog, desc = WORKLOADS[args.workload]
     if args.log2n is None:
         args.log2n = dlog
 
-    ensure_built()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -179,18 +209,24 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
         else:
             dist.init_process_group(backend)
+    ensure_built(dist, local_rank)
 
     param_path = os.path.join(ROOT, "pbc_amd", "param", pname + ".param")
     pairing = pbc_amd.Pairing(open(param_path).read())
     L1, L2, LT = pairing.length_in_bytes_G1, pairing.length_in_bytes_G2, pairing.length_in_bytes_GT
-    n = 1 << args.log2n
+    n_job = 1 << args.log2n
+    if args.strong:                      # range split of one job: rank r owns units [r n_job / world, (r + 1) n_job / world)
+        first = rank * n_job // world
+        n = (rank + 1) * n_job // world - first
+    else:                                # weak scaling: every rank owns its own 2^log2n-unit shard
+        first, n = 0, n_job
     g1, g2, gt_ref = load_vec(os.path.join(ROOT, "tests", "golden", fixture))
     D = g1.shape[0]
-    rot = (rank * 131) % D                # rank r uses a rotated set of Q's so that shards differ
+    rot = 0 if args.strong else (rank * 131) % D   # weak: rank r uses a rotated set of Q's so that shards differ
     d1 = torch.from_numpy(g1).cuda()
     d2 = torch.from_numpy(np.roll(g2, -rot, axis=0)).cuda()
-    # term t of the batch pairs P_(t // D mod D) with Q_(t mod D): D*D distinct pairs, tiled beyond
-    t = torch.arange(n * k, device="cuda")
+    # term t of the job pairs P_(t // D mod D) with Q_(t mod D): D*D distinct pairs, tiled beyond
+    t = torch.arange(first * k, (first + n) * k, device="cuda")
     G1 = d1[(t // D) % D].contiguous()
     G2 = d2[t % D].contiguous()
     GT = torch.empty(n, LT, dtype=torch.uint8, device="cuda")
@@ -217,8 +253,9 @@ def main():
     torch.cuda.synchronize()
     # correctness gate against the reference's own outputs stored in the fixture:
     #   k == 1: unit i*(D+1) is e(P_i, Q_i);  k > 1: bilinearity cross-check below
+    gate = rot == 0 and first == 0
     if pp is not None:
-        if not np.array_equal(GT[0].cpu().numpy(), gt_ref[0]):     # unit 0 is e(P_0, Q_0)
+        if gate and not np.array_equal(GT[0].cpu().numpy(), gt_ref[0]):     # unit 0 is e(P_0, Q_0)
             sys.exit("bench.py: pp_apply differs from the reference fixture -- refusing to time")
         chk = torch.empty(256, LT, dtype=torch.uint8, device="cuda")
         P0 = d1[:1].expand(256, L1).contiguous()
@@ -226,16 +263,16 @@ def main():
         torch.cuda.synchronize()
         if not torch.equal(chk, GT[:256]):
             sys.exit("bench.py: pp_apply differs from element_pairing -- refusing to time")
-    elif rot == 0 and k == 1:
+    elif gate and k == 1:
         m = min(D, (n - 1) // (D + 1) + 1)
         idx = torch.arange(m, device="cuda") * (D + 1)
         if not np.array_equal(GT[idx].cpu().numpy(), gt_ref[:m]):
             sys.exit("bench.py: GPU results differ from the reference fixture -- refusing to time")
-    if rot == 0 and k > 1:
+    if k > 1:
         # a k-term product must equal the product of its k single pairings, taken from a
         # separate single-pairing launch: compare through a second product with permuted terms
         perm = torch.arange(k - 1, -1, -1, device="cuda")
-        m = 64
+        m = min(64, n)
         sel = (torch.arange(m, device="cuda")[:, None] * k + perm[None, :]).reshape(-1)
         GT2 = torch.empty(m, LT, dtype=torch.uint8, device="cuda")
         A1, A2 = G1[sel].contiguous(), G2[sel].contiguous()     # keep alive until the launch has run
@@ -254,21 +291,55 @@ def main():
     sync_all()
     dt = time.perf_counter() - t0
     kern_ms = [a.elapsed_time(b) for a, b in evs]
+    my_kern_ms = sum(kern_ms) / len(kern_ms)
+    per_rank_ms = [my_kern_ms]
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+        per_rank_ms = [None] * world
+        dist.all_gather_object(per_rank_ms, my_kern_ms)        # a slow rank must be visible in the line rank 0 prints
+
+    # the host-buffer entry point (what the PBC glue calls): pinned host memory in, host memory out, PCIe included
+    host_path = None
+    if rank == 0 and pp is None and not args.no_host_path:
+        import ctypes
+        h1, h2 = G1.cpu().pin_memory(), G2.cpu().pin_memory()
+        hout = torch.empty(n, LT, dtype=torch.uint8).pin_memory()
+        L = pbc_amd.lib()
+        ts = []
+        for _ in range(3):
+            t1 = time.perf_counter()
+            if k == 1:
+                rc = L.pbc_hip_element_pairing_batch(pairing._h, ctypes.c_void_p(hout.data_ptr()), ctypes.c_void_p(h1.data_ptr()),
+                                                     ctypes.c_void_p(h2.data_ptr()), n)
+            else:
+                rc = L.pbc_hip_element_prod_pairing_batch(pairing._h, ctypes.c_void_p(hout.data_ptr()), ctypes.c_void_p(h1.data_ptr()),
+                                                          ctypes.c_void_p(h2.data_ptr()), n, k)
+            ts.append(time.perf_counter() - t1)
+            if rc:
+                sys.exit("bench.py: host-buffer call failed: %s" % pbc_amd._err())
+        if not torch.equal(hout, GT.cpu()):
+            sys.exit("bench.py: host-buffer path differs from the device-pointer path")
+        host_path = {"value": round(n / min(ts), 1), "ms": round(min(ts) * 1e3, 2), "bytes_over_pcie": n * (k * (L1 + L2) + LT),
+                     "note": "pinned host buffers -> chunked H2D / kernel / D2H on 3 streams -> host, best of 3 calls on rank 0; "
+                             "PCIe-inclusive (SURVEY 8d's wall-clock form of the metric); never the reported `value`"}
+        del h1, h2, hout
 
     if rank == 0:
-        total_units = n * world * args.steps
+        total_units = (n_job if args.strong else n * world) * args.steps
         value = total_units / dt
-        avg_kern_s = sum(kern_ms) / len(kern_ms) * 1e-3
+        avg_kern_s = my_kern_ms * 1e-3
         macs_per_unit = pairing.algorithmic_macs_per_unit(k)
         if pp is not None:
             macs_per_unit = pairing.algorithmic_macs_per_unit(-1)   # the reference's pp_apply algorithm
-        # measured integer multiply-add peak of this chip (register-only v_mad_u64_u32 probe)
-        peak_macs, _ = pbc_amd.int_mac_peak(0, 4000)
-        achieved_macs = n * macs_per_unit / avg_kern_s
+        exe_per_unit = executed_macs(args.workload)
+        # live probes of the multiply-add pipe (register-only v_mad_u64_u32 chains with an SGPR factor)
+        peak_measured = max(pbc_amd.int_mac_peak(13, 4000)[0], pbc_amd.int_mac_peak(14, 4000)[0])
+        alg_rate = n * macs_per_unit / avg_kern_s
+        exe_rate = n * exe_per_unit / avg_kern_s if exe_per_unit else None
+        basis = "executed" if exe_rate is not None and exe_rate < alg_rate else "algorithmic"
+        rate = exe_rate if basis == "executed" else alg_rate
         unit_bytes = k * (L1 + L2) + LT
         alg_bytes = n * unit_bytes
         unit_name = "pairings/s" if k == 1 else "products/s"
@@ -282,42 +353,41 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if args.strong else "weak",
             "vs_baseline": None,
             "dtype": "u32 (multi-word Montgomery F_q, bit-exact integer)",
             "data": "synthetic: (P_i,Q_j) cross pairs of tests/golden/%s (%d x %d distinct), resident in HBM" % (fixture, D, D),
-            "config": {"workload": "%s, 2^%d units per GPU per step" % (desc, args.log2n),
-                       "units_per_gpu": n, "terms_per_unit": k, "global_batch": n * world,
+            "config": {"workload": "%s, 2^%d units %s per step" % (desc, args.log2n, "in the whole job" if args.strong else "per GPU"),
+                       "units_per_gpu": n, "terms_per_unit": k, "global_batch": n_job if args.strong else n * world,
                        "parallelism": "range-split x%d, no collectives" % world},
+            "per_rank_kernel_ms": [round(float(x), 3) for x in per_rank_ms],
+            "kernel_only": {"value": round(n / avg_kern_s, 1), "unit": unit_name + " per GPU, events around the launch on rank 0"},
+            "host_path": host_path,
             "roofline": {
                 "bound": "valu-int32-mac",   # integer VALU throughput bounds this path, not HBM/MFMA
-                "achieved": round(achieved_macs / 1e12, 4),
-                "peak": round(peak_macs / 1e12, 4),
+                "achieved": round(rate / 1e12, 4),
+                "peak": round(MAC_PEAK / 1e12, 4),
                 "unit": "TMAC/s (32x32->64 bit)",
-                "frac": round(achieved_macs / peak_macs, 4),
+                "frac": round(rate / MAC_PEAK, 4),
+                # the smaller of the two work models: never credits multiply-adds the kernel did not execute, nor
+                # executed ones beyond what the reference's algorithm needs
+                "frac_basis": basis,
+                "peak_measured": round(peak_measured / 1e12, 4),
+                "algorithmic": {"macs_per_unit": macs_per_unit, "achieved": round(alg_rate / 1e12, 4),
+                                "frac": round(alg_rate / MAC_PEAK, 4),
+                                "note": "the reference algorithm's F_q products x (2 N^2 + N) word multiply-adds (SURVEY 8d)"},
+                "executed": None if exe_rate is None else {
+                    "macs_per_unit": exe_per_unit, "achieved": round(exe_rate / 1e12, 4), "frac": round(exe_rate / MAC_PEAK, 4),
+                    "note": "multiply-adds the kernel source executes (profiles/executed_macs.json, tools/executed_macs.py)"},
                 "traffic": pmc_traffic(args.workload),
                 "kernel_ms": round(avg_kern_s * 1e3, 3),
                 "algorithmic_macs_per_unit": macs_per_unit,
+                "executed_macs_per_unit": exe_per_unit,
                 "hbm": {"achieved": round(alg_bytes / avg_kern_s / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(alg_bytes / avg_kern_s / 1e9 / HBM_PEAK_GBS, 6),
                         "algorithmic_bytes_per_unit": unit_bytes},
             },
         }
-        if args.host_path and k == 1 and pp is None:
-            import ctypes
-            h1, h2 = G1.cpu().pin_memory(), G2.cpu().pin_memory()
-            hout = torch.empty(n, LT, dtype=torch.uint8).pin_memory()
-            ts = []
-            for _ in range(3):
-                t1 = time.perf_counter()
-                rc = pbc_amd.lib().pbc_hip_element_pairing_batch(pairing._h, ctypes.c_void_p(hout.data_ptr()),
-                                                                 ctypes.c_void_p(h1.data_ptr()),
-                                                                 ctypes.c_void_p(h2.data_ptr()), n)
-                ts.append(time.perf_counter() - t1)
-                assert rc == 0
-            assert torch.equal(hout[:4096], GT[:4096].cpu())
-            out["host_path"] = {"pairings_per_s": round(n / min(ts), 1), "ms": round(min(ts) * 1e3, 2),
-                                "note": "pinned host buffers -> chunked H2D/kernel/D2H on 3 streams -> host; PCIe-inclusive"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(param_path, k, fixture)
         print(json.dumps(out), flush=True)

@@ -16,6 +16,24 @@
  * All functions return 0 on success, non-zero on failure (pairing_init_set_buf
  * convention, ecc/pairing.c:88-98); pbc_hip_last_error() gives the message.  A
  * pbc_hip_pairing_t is not re-entrant: one batch call at a time per object.
+ *
+ * Input classes (every one is covered by a GPU test, tests/test_gpu_parity.py):
+ *   - Points of the whole curve.  curve_from_bytes (ecc/curve.c:609-623) checks the curve equation only, so a G1 / G2
+ *     record may hold a point outside the order-r subgroup.  Pairings, products and element_mul_zn give the
+ *     reference's bytes for such points as well (the group law is complete, scalars may exceed r).  The one
+ *     exception is inherited: for type e (k = 1) the reference's own value for a point with r P != O depends on the
+ *     auxiliary point it draws at random at init (e_param.c:866-870), so there is nothing to agree with.
+ *   - Off-curve records deserialise to O: the pairing is the identity of GT, a product containing one is the
+ *     identity, [k] O = O.
+ *   - Zero-filled records.  All-zero bytes are what element_to_bytes writes for O, and they are treated as O by
+ *     every entry point: pairing = identity, product = identity, [k] 0 = 0.  Where the curve has b != 0 they are
+ *     off the curve anyway.  On y^2 = x^3 + x (types a, a1) they are the 2-torsion point (0, 0); its pairing value is
+ *     the identity too (2 is coprime to r), while the reference divides by zero there (mpz_invert of 0 in
+ *     point_to_affine, a_param.c:1073-1080) and returns an arbitrary value.
+ *     Pairings of other points of tiny order (3, 4, 6, 12 on type a) are unspecified here as in the reference: the
+ *     Miller loop runs through V = O or V = +-P, where the reference divides by zero.  element_mul_zn is exact
+ *     for them.
+ *   - Coordinates >= q are reduced mod q on load, as fp_from_bytes does (montfp.c:498-517).
  */
 #ifndef PBC_HIP_H
 #define PBC_HIP_H
@@ -46,6 +64,11 @@ void pbc_hip_pairing_clear(pbc_hip_pairing_t *p);
 int pbc_hip_pairing_use_devices(pbc_hip_pairing_t *p, const int *devices, int n);
 /* Number of visible HIP devices (hipGetDeviceCount; 0 when there is none). */
 int pbc_hip_device_count(void);
+/* Page-locked host memory for the host-buffer entry points: with buffers from here the H2D / D2H copies of one chunk
+ * overlap the arithmetic of its neighbours (pageable buffers work too, the runtime stages them synchronously).  PBC has
+ * no counterpart; the glue (integration/pbc_hip_glue.c) marshals element_t arrays into such buffers. */
+int pbc_hip_host_alloc(void **out, size_t bytes);
+void pbc_hip_host_free(void *p);
 /* 'a', 'd', 'f', 'g', or '1' for a1 (the "type" key, ecc/param.c:172-205). */
 int pbc_hip_pairing_type(const pbc_hip_pairing_t *p);
 /* Replace pairing_length_in_bytes_{G1,G2,GT} (include/pbc_pairing.h:183-238). */

@@ -22,6 +22,9 @@
  *            P_i=(i+1)P0, Q_i=(i+1)Q0 by repeated element_add
  *   random : pbc_random_set_deterministic(seed) BEFORE pairing_init, element_random
  *   edge   : random, but a few units get an identity (off-curve bytes) input
+ *   fullorder : points of the whole curve, NOT multiplied by the cofactor (curve_random_no_cofac_solvefory,
+ *            ecc/curve.c:405-422, restated through the public accessors): curve_from_bytes (:609-623) accepts
+ *            them, and they lie outside the order-r subgroup whenever the curve has a cofactor
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -60,6 +63,28 @@ static void init_pairing(pairing_t pairing, const char *path, char *type_out) {
 
 static void w32(FILE *fp, uint32_t v) { fwrite(&v, 4, 1, fp); }
 
+/* a random point of the whole curve group: random x until x^3 + ax + b is a square, y = its root, random sign;
+ * no cofactor multiplication (ecc/curve.c:405-422 without the element_mul_mpz of :427) */
+static void full_order_point(element_t P) {
+  element_ptr x = curve_x_coord(P);
+  element_t t;
+  mpz_t coin;
+  element_init_same_as(t, x);
+  mpz_init(coin);
+  do {
+    element_random(x);
+    element_square(t, x);
+    element_add(t, t, curve_a_coeff(P));
+    element_mul(t, t, x);
+    element_add(t, t, curve_b_coeff(P));
+  } while (!element_is_sqr(t));
+  curve_from_x(P, x);
+  pbc_mpz_randomb(coin, 1);
+  if (mpz_odd_p(coin)) element_neg(P, P);
+  element_clear(t);
+  mpz_clear(coin);
+}
+
 static int cmd_gen(int argc, char **argv) {
   if (argc < 7) { fprintf(stderr, "gen <param> <chain|random|edge> <n> <k> <seed> <out>\n"); return 2; }
   const char *param = argv[1], *mode = argv[2];
@@ -79,7 +104,7 @@ static int cmd_gen(int argc, char **argv) {
   element_t P0, Q0, out;
   element_init_G1(P0, pairing); element_init_G2(Q0, pairing); element_init_GT(out, pairing);
   for (int j = 0; j < k; j++) { element_init_G1(P[j], pairing); element_init_G2(Q[j], pairing); }
-  int chain = !strcmp(mode, "chain"), edge = !strcmp(mode, "edge");
+  int chain = !strcmp(mode, "chain"), edge = !strcmp(mode, "edge"), full = !strcmp(mode, "fullorder");
   element_t Pc, Qc;
   element_init_G1(Pc, pairing); element_init_G2(Qc, pairing);
   if (chain) {
@@ -93,6 +118,8 @@ static int cmd_gen(int argc, char **argv) {
       if (chain) {
         element_set(P[j], Pc); element_set(Q[j], Qc);
         element_add(Pc, Pc, P0); element_add(Qc, Qc, Q0);
+      } else if (full) {
+        full_order_point(P[j]); full_order_point(Q[j]);
       } else {
         element_random(P[j]); element_random(Q[j]);
       }
@@ -204,8 +231,9 @@ static int cmd_bench(int argc, char **argv) {
 /* gmul <param> <group 1|2> <n> <seed> <out>: out_i = [k_i] P_i (element_mul_zn) for random points of
  * G1 / G2 and random scalars; the last two scalars are 1 and r - 1.  File: points, scalars, results. */
 static int cmd_gmul(int argc, char **argv) {
-  if (argc < 6) { fprintf(stderr, "gmul <param> <group> <n> <seed> <out>\n"); return 2; }
+  if (argc < 6) { fprintf(stderr, "gmul <param> <group> <n> <seed> <out> [full]\n"); return 2; }
   int group = atoi(argv[2]), n = atoi(argv[3]);
+  const int full = argc > 6 && !strcmp(argv[6], "full");   /* points of the whole curve (no cofactor multiplication) */
   unsigned seed = (unsigned) atoi(argv[4]);
   pairing_t pairing; char type;
   pbc_random_set_deterministic(seed);
@@ -218,7 +246,7 @@ static int cmd_gmul(int argc, char **argv) {
   else { element_init_G2(P, pairing); element_init_G2(R, pairing); }
   element_init_Zr(k, pairing);
   for (int i = 0; i < n; i++) {
-    element_random(P);
+    if (full) full_order_point(P); else element_random(P);
     element_random(k);
     if (i == n - 2) element_set1(k);
     if (i == n - 1) { element_set1(k); element_neg(k, k); }
@@ -396,6 +424,33 @@ static int cmd_hash(int argc, char **argv) {
   return 0;
 }
 
+/* rdep <param> <seed>: two pairing objects from the same parameter text (type e draws its auxiliary point R from
+ * the generator at init, e_param.c:866-870, so the two objects hold different R), the same input bytes: prints
+ * whether element_pairing agrees for a point pair of the order-r subgroup and for a pair of the whole curve.  For
+ * k = 1 the value f_P(Q+R)/f_P(R) is independent of R only when r P = O. */
+static int cmd_rdep(int argc, char **argv) {
+  if (argc < 3) { fprintf(stderr, "rdep <param> <seed>\n"); return 2; }
+  pairing_t pa, pb; char type;
+  pbc_random_set_deterministic((unsigned) atoi(argv[2]));
+  init_pairing(pa, argv[1], &type);
+  init_pairing(pb, argv[1], &type);
+  for (int full = 0; full < 2; full++) {
+    element_t P, Q, P2, Q2, ea, eb;
+    unsigned char b1[2048], b2[2048];
+    element_init_G1(P, pa); element_init_G2(Q, pa); element_init_GT(ea, pa);
+    element_init_G1(P2, pb); element_init_G2(Q2, pb); element_init_GT(eb, pb);
+    if (full) { full_order_point(P); full_order_point(Q); } else { element_random(P); element_random(Q); }
+    element_to_bytes(b1, P); element_to_bytes(b2, Q);
+    element_from_bytes(P2, b1); element_from_bytes(Q2, b2);
+    element_pairing(ea, P, Q);
+    element_pairing(eb, P2, Q2);
+    element_to_bytes(b1, ea); element_to_bytes(b2, eb);
+    printf("%s points: two objects %s\n", full ? "whole-curve" : "subgroup",
+           memcmp(b1, b2, pairing_length_in_bytes_GT(pa)) ? "DISAGREE" : "agree");
+  }
+  return 0;
+}
+
 int main(int argc, char **argv) {
   if (argc < 2) { fprintf(stderr, "usage: ref_tool gen|kat|bench ...\n"); return 2; }
   if (!strcmp(argv[1], "gen")) return cmd_gen(argc - 1, argv + 1);
@@ -409,5 +464,6 @@ int main(int argc, char **argv) {
   if (!strcmp(argv[1], "gena1")) return cmd_gena1(argc - 1, argv + 1);
   if (!strcmp(argv[1], "gene")) return cmd_gene(argc - 1, argv + 1);
   if (!strcmp(argv[1], "genf")) return cmd_genf(argc - 1, argv + 1);
+  if (!strcmp(argv[1], "rdep")) return cmd_rdep(argc - 1, argv + 1);
   return 2;
 }

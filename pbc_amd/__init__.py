@@ -84,6 +84,9 @@ def lib():
         L.pbc_hip_algorithmic_macs_per_unit.argtypes = [vp, ci]
         L.pbc_hip_algorithmic_macs_per_unit.restype = ctypes.c_double
         L.pbc_hip_last_error.restype = cp
+        L.pbc_hip_host_alloc.argtypes = [ctypes.POINTER(vp), sz]
+        L.pbc_hip_host_free.argtypes = [vp]
+        L.pbc_hip_host_free.restype = None
         _lib = L
     return _lib
 
@@ -104,7 +107,7 @@ EXPORTS = (
     "pbc_hip_element_from_bytes_compressed_batch", "pbc_hip_pairing_use_devices", "pbc_hip_device_count",
     "pbc_hip_pairing_length_in_bytes_x_only_G1", "pbc_hip_element_to_bytes_x_only_batch",
     "pbc_hip_pairing_length_in_bytes_compressed_G2", "pbc_hip_pairing_length_in_bytes_x_only_G2",
-    "pbc_hip_element_from_bytes_x_only_batch",
+    "pbc_hip_element_from_bytes_x_only_batch", "pbc_hip_host_alloc", "pbc_hip_host_free",
 )
 
 

@@ -3,7 +3,7 @@
 // Replaces the reference's GMP-backed arith/montfp.c (mont_mul :334-364, fp_add/sub/
 // double/halve/neg :220-330, fp_invert :401-422, fp_to/from_bytes :487-517) with
 // N x 32-bit limbs held in VGPRs, one field element per lane.  The modulus and the
-// Montgomery constants are wave-uniform (__constant__ memory -> scalar loads -> SGPRs).
+// Montgomery constants are wave-uniform (kernel argument segment -> scalar loads -> SGPRs).
 //
 // Representation: N little-endian 32-bit words per element, Montgomery form, always fully
 // reduced to [0, q).  The Montgomery radix is R = 2^(29 L), L = ceil(32N/29), because the
@@ -16,6 +16,12 @@
 #include <hip/hip_runtime.h>
 #endif
 #include <stdint.h>
+
+// Executed-work accounting: every multiplier body reports its multiply-adds.  A no-op in the library; the host
+// mirror (tests/hostsim) defines the hook to count, which is where bench.py's executed_macs_per_unit comes from.
+#ifndef PBC_COUNT_MACS
+#define PBC_COUNT_MACS(n) ((void) 0)
+#endif
 
 namespace pbc {
 
@@ -42,47 +48,36 @@ struct fp {
 
 #define PBC_DEV __device__ __forceinline__
 
-// The constants live in __constant__ memory so that every read is a scalar load from a
-// compile-time address (provably wave-uniform -> SGPR operands of the MACs).  One set per
-// limb count; the host uploads them with hipMemcpyToSymbolAsync on the launch stream.
+// Per-object constants travel in the KERNEL ARGUMENT SEGMENT.  Every kernel of the library takes the constant block
+// of its pairing object (KArgs<N>, below) as its first argument, by value; device code of any call depth reads it
+// through the kernarg segment pointer, which the ABI hands down to callees in SGPRs.  The segment is constant address
+// space, so every read is a scalar load from a wave-uniform address (-> SGPR operands of the multiply-adds), exactly
+// as a __constant__ symbol would give -- but nothing is process-global: two pairing objects (or one object on two
+// streams) cannot disturb each other, and a launch needs no upload.
+// Layout of the block (byte offsets; the first three parts do not depend on the field width):
+//     [0, 704)      CurveK    curve coefficients, cofactor, square-root recipe      (group_ops.cuh)
+//     [704, 2128)   AConst / DConst / FConst / EConst   the pairing family's constants  (pairing_*.cuh)
+//     [2128, 2496)  ExtSqrtK  square roots in the field of the G2 twist             (group_ops.cuh)
+//     [2496, ...)   FpK<N>    modulus and Montgomery constants
 // Word counts built into the library: 5/6/7 words = the 149..224-bit MNT, Freeman and BN fields of
 // the shipped type d / g / f parameter files, 8 words = 256-bit BN fields (type f), 16 words = the
 // 512-bit type a field, 33 words = the 1033-bit type a1 field.
 #define PBC_FOR_EACH_N(X) X(5) X(6) X(7) X(8) X(16) X(33)
-template <int N> PBC_DEV const FpK<N> &fpk();
-#define PBC_DECL_FPK(n)              \
-  __constant__ FpK<n> c_fpk##n;      \
-  template <> PBC_DEV const FpK<n> &fpk<n>() { return c_fpk##n; }
-PBC_FOR_EACH_N(PBC_DECL_FPK)
-#undef PBC_DECL_FPK
-
-// acc(96 bit: a0,a1,a2) += x*y.  One quarter-rate 32x32+64 multiply-add whose carry-out
-// feeds the top word: the two-instruction MAC the whole engine is built from.
-PBC_DEV void mac_vv(uint32_t &a0, uint32_t &a1, uint32_t &a2, uint32_t x, uint32_t y) {
-  uint64_t acc = ((uint64_t) a1 << 32) | a0;
-#ifdef PBC_HOSTSIM
-  uint64_t p_ = (uint64_t) x * y, s_ = acc + p_;
-  a2 += s_ < p_;
-  acc = s_;
-#else
-  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"
-      : "+v"(acc), "+v"(a2) : "v"(x), "v"(y) : "vcc");
-#endif
-  a0 = (uint32_t) acc; a1 = (uint32_t) (acc >> 32);
+constexpr int KOFF_CURVE = 0, KOFF_TYPE = 704, KOFF_XS = 2128, KOFF_FPK = 2496;
+template <int N>
+struct KArgs {
+  alignas(16) uint8_t head[KOFF_FPK];
+  FpK<N> fp;
+};
+static_assert(sizeof(KArgs<33>) + 64 <= 4096, "the constant block must fit the kernel argument segment");
+#ifndef PBC_HOSTSIM
+PBC_DEV const uint8_t *pbc_kargs_base() {
+  return (const uint8_t *) (const __attribute__((address_space(4))) uint8_t *) __builtin_amdgcn_kernarg_segment_ptr();
 }
-// same, second factor wave-uniform (an SGPR: the modulus limbs)
-PBC_DEV void mac_vs(uint32_t &a0, uint32_t &a1, uint32_t &a2, uint32_t x, uint32_t y) {
-#ifdef PBC_HOSTSIM
-  mac_vv(a0, a1, a2, x, y);
-  return;
-#else
-  uint64_t acc = ((uint64_t) a1 << 32) | a0;
-  asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"
-      : "+v"(acc), "+v"(a2) : "v"(x), "s"(y) : "vcc");
-  a0 = (uint32_t) acc; a1 = (uint32_t) (acc >> 32);
 #endif
-}
-// acc += 2*x*y is NOT used (no spare bits at 512/512); squaring doubles the cross sum instead.
+template <class T, int OFF>
+PBC_DEV const T &kconst() { return *reinterpret_cast<const T *>(pbc_kargs_base() + OFF); }
+template <int N> PBC_DEV const FpK<N> &fpk() { return kconst<FpK<N>, KOFF_FPK>(); }
 
 // r = (carry:t) >= p ? t - p : t      (final correction of add / mul)
 // __builtin_addc/__builtin_subc lower to v_addc_co_u32 / v_subb_co_u32 chains.
@@ -98,45 +93,15 @@ PBC_DEV void fp_cond_sub(fp<N> &r, const uint32_t *t, uint32_t carry) {
   for (int i = 0; i < N; i++) r.v[i] = ge ? d[i] : t[i];
 }
 
-// Montgomery product r = a*b/R mod q, product-scanning (column-wise) form with a 96-bit
-// column accumulator: 2N^2 MACs + N v_mul_lo_u32, no per-row carry ripple.
-// Same value as mont_mul (arith/montfp.c:334-364).  Accepts a < R unreduced if b < q.
-template <int N>
-PBC_DEV void fp_mul32_inl(fp<N> &r, const fp<N> &a, const fp<N> &b) {
-  const FpK<N> &K = fpk<N>();
-  uint32_t m[N], t[N];
-  uint32_t a0 = 0, a1 = 0, a2 = 0;
-#pragma unroll
-  for (int c = 0; c < N; c++) {
-#pragma unroll
-    for (int i = 0; i <= c; i++) mac_vv(a0, a1, a2, a.v[i], b.v[c - i]);
-#pragma unroll
-    for (int i = 0; i < c; i++) mac_vs(a0, a1, a2, m[i], K.p[c - i]);
-    m[c] = a0 * K.ninv;
-    mac_vs(a0, a1, a2, m[c], K.p[0]);
-    a0 = a1; a1 = a2; a2 = 0;
-  }
-#pragma unroll
-  for (int c = N; c < 2 * N; c++) {
-#pragma unroll
-    for (int i = c - N + 1; i < N; i++) mac_vv(a0, a1, a2, a.v[i], b.v[c - i]);
-#pragma unroll
-    for (int i = c - N + 1; i < N; i++) mac_vs(a0, a1, a2, m[i], K.p[c - i]);
-    t[c - N] = a0;
-    a0 = a1; a1 = a2; a2 = 0;
-  }
-  fp_cond_sub<N>(r, t, a0);
-}
-
-
 // ---------------------------------------------------------------------------------------
-// Unsaturated multiplier.  Storage stays N saturated 32-bit words (cheap carry-chain
-// add/sub, 32 VGPR arguments per call), but the product is formed on L = ceil(32N/29)
+// Unsaturated multiplier (same value as mont_mul, arith/montfp.c:334-364).  Storage stays N saturated 32-bit
+// words (cheap carry-chain add/sub, 32 VGPR arguments per call), but the product is formed on L = ceil(32N/29)
 // limbs of 29 bits with R = 2^(29 L):  a column holds at most 2L products < 2^58, so a
 // plain 64-bit accumulator never overflows (2L * 2^58 < 2^64 for L <= 31) and every MAC is
 // ONE v_mad_u64_u32 -- no carry instruction, no inline asm, free compiler scheduling.
 // Measured on MI355X: v_mad_u64_u32 issues every ~4.2 cycles (3.5 with an SGPR factor)
-// against 7.5 for the mad+addc pair of the saturated form (profiles/r01_probe_v1.txt).
+// against 7.5 for the mad + addc pair a saturated 32-bit limb needs (profiles/r01_probe_v1.txt; that first
+// version of the multiplier is gone from the source).
 // ---------------------------------------------------------------------------------------
 // Limb width: 29 bits, except 28 for the 33-word fields -- with L = 37 limbs of 29 bits a column would
 // hold up to 74 products of 2^58, which overflows 64 bits for moduli with dense limbs; 38 limbs of 28
@@ -192,6 +157,7 @@ PBC_DEV void fp_mul29_inl(fp<N> &r, const fp<N> &a, const fp<N> &b) {
   constexpr int L = Limbs29<N>::L;
   constexpr uint32_t MASK = Limbs29<N>::MASK;
   uint32_t x[L], y[L], m[L], t[L];
+  PBC_COUNT_MACS(2 * L * L);
   to29<N>(x, a);
   to29<N>(y, b);
   uint64_t acc = 0, acc1 = 0;
@@ -229,6 +195,7 @@ PBC_DEV void fp_sqr29_inl(fp<N> &r, const fp<N> &a) {
   constexpr int L = Limbs29<N>::L;
   constexpr uint32_t MASK = Limbs29<N>::MASK;
   uint32_t x[L], x2[L], m[L], t[L];
+  PBC_COUNT_MACS(L * (L + 1) / 2 + L * L);
   to29<N>(x, a);
 #pragma unroll
   for (int i = 0; i < L; i++) x2[i] = x[i] << 1;
@@ -269,6 +236,7 @@ PBC_DEV void sqr_limbs(uint32_t *t, const uint32_t *x) {
   constexpr int L = Limbs29<N>::L;
   constexpr uint32_t MASK = Limbs29<N>::MASK;
   uint32_t x2[L], m[L];
+  PBC_COUNT_MACS(L * (L + 1) / 2 + L * L);
 #pragma unroll
   for (int i = 0; i < L; i++) x2[i] = x[i] << 1;
   uint64_t acc = 0;
@@ -326,6 +294,7 @@ PBC_DEV void sop_limbs(fl<N> &r, const fl<N> (&x)[T], const fl<N> (&y)[T]) {
   constexpr int L = Limbs29<N>::L;
   constexpr uint32_t MASK = Limbs29<N>::MASK;
   static_assert(Limbs29<N>::W == 29 && (T + DBL) * L + L <= 63, "column accumulator would overflow");
+  PBC_COUNT_MACS((T + 1) * L * L);
   uint32_t m[L];
   uint64_t acc = 0;
 #pragma unroll
@@ -369,6 +338,7 @@ PBC_DEV void wide_zero(wide<N> &W) {
 template <int N>
 PBC_DEV void wide_mac(wide<N> &W, const fl<N> &x, const fl<N> &y) {
   constexpr int L = Limbs29<N>::L;
+  PBC_COUNT_MACS(L * L);
 #pragma unroll
   for (int i = 0; i < L; i++)
 #pragma unroll
@@ -379,6 +349,7 @@ PBC_DEV void wide_reduce(fl<N> &r, const wide<N> &W) {
   const FpK<N> &K = fpk<N>();
   constexpr int L = Limbs29<N>::L;
   constexpr uint32_t MASK = Limbs29<N>::MASK;
+  PBC_COUNT_MACS(L * L);
   uint32_t m[L];
   uint64_t acc = 0;
 #pragma unroll
@@ -401,27 +372,15 @@ PBC_DEV void wide_reduce(fl<N> &r, const wide<N> &W) {
 }
 
 #ifndef PBC_MUL_IMPL
-#define PBC_MUL_IMPL 1      // 0: saturated 32-bit asm MACs, R = 2^(32N); 1/2: unsaturated, R = 2^(29L)
+#define PBC_MUL_IMPL 1      // 1: one column accumulator; 2: two (shorter dependent chains; measured equal at 2 waves per SIMD)
 #endif
 template <int N>
 PBC_DEV void fp_mul_inl(fp<N> &r, const fp<N> &a, const fp<N> &b) {
-#if PBC_MUL_IMPL == 0
-  fp_mul32_inl<N>(r, a, b);
-#elif PBC_MUL_IMPL == 1
-  fp_mul29_inl<N, false>(r, a, b);
-#else
-  fp_mul29_inl<N, true>(r, a, b);
-#endif
+  fp_mul29_inl<N, PBC_MUL_IMPL == 2>(r, a, b);
 }
 template <int N>
 PBC_DEV void fp_sqr_inl(fp<N> &r, const fp<N> &a) {
-#if PBC_MUL_IMPL == 0
-  fp_mul32_inl<N>(r, a, a);
-#elif PBC_MUL_IMPL == 1
-  fp_sqr29_inl<N, false>(r, a);
-#else
-  fp_sqr29_inl<N, true>(r, a);
-#endif
+  fp_sqr29_inl<N, PBC_MUL_IMPL == 2>(r, a);
 }
 
 // Out-of-line instances: one copy of each ~900-instruction body per kernel keeps the Miller
@@ -734,6 +693,7 @@ static __device__ __noinline__ typename vecN<N>::type fp_inv_fn(typename vecN<N>
     e[i] = (i == 0);
   }
   int32_t zeta = -1;
+  PBC_COUNT_MACS((10 * L + 2) * Inv30<N>::BATCHES);      // signed 32 x 32 + 64 multiply-adds of the matrix applications
 #pragma nounroll
   for (int it = 0; it < Inv30<N>::BATCHES; it++) {
     int32_t u, v, q, r;

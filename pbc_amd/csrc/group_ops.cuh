@@ -21,7 +21,7 @@ struct CurveK {                        // E: y^2 = x^3 + a x + b over F_q (Montg
   uint32_t a[34], b[34];
   int a_is_zero;
   // element_from_hash on G1: cofactor (curve_data cofac, ecc/curve.c:478) and square roots in F_q
-  uint32_t cofac[24];                  // 0 bits: no cofactor multiplication (type f)
+  uint32_t cofac[34];                  // 0 bits: no cofactor multiplication (type f)
   int cofbits;
   int sqrt_mode;                       // 0: q = 3 mod 4, root = t^((q+1)/4);  1: Tonelli-Shanks
   uint32_t sqrt_e[34];                 // mode 0: (q+1)/4;  mode 1: (t-1)/2 with q - 1 = 2^s t, t odd
@@ -29,7 +29,8 @@ struct CurveK {                        // E: y^2 = x^3 + a x + b over F_q (Montg
   int ts_s;
   uint32_t ts_c[34];                   // mode 1: z^t for a non-residue z (Montgomery form; derived on the device)
 };
-__constant__ CurveK c_curve;
+static_assert(sizeof(CurveK) <= KOFF_TYPE - KOFF_CURVE, "constant block layout");
+#define c_curve (pbc::kconst<pbc::CurveK, pbc::KOFF_CURVE>())
 
 // bit i of a big-endian scalar of zlen bytes
 PBC_DEV uint32_t zr_bit(const uint8_t *z, int zlen, int i) { return (z[zlen - 1 - (i >> 3)] >> (i & 7)) & 1; }
@@ -44,6 +45,7 @@ template <int N> PBC_DEV void fp_sqrt_lane(fp<N> &y, bool &ok, const fp<N> &t);
 template <int N>
 struct FqOps {
   typedef fp<N> el;
+  static constexpr int NW = N;         // words of F_q (selects the kernels' constant block, KArgs<NW>)
   static PBC_DEV int bytes() { return (int) fpk<N>().fbytes; }
   static PBC_DEV el curve_a() { el r; fp_set<N>(r, c_curve.a); return r; }
   static PBC_DEV el curve_b() { el r; fp_set<N>(r, c_curve.b); return r; }
@@ -66,6 +68,7 @@ template <int N, int DEG>
 struct FdOps {                         // F_q^d of types d / g: the twist E'(F_q^d)
   typedef TypeMNT<N, DEG> T;
   typedef typename T::f3 el;
+  static constexpr int NW = N;
   static PBC_DEV int bytes() { return DEG * (int) fpk<N>().fbytes; }
   static PBC_DEV el curve_a() { el r; T::f3_set_fq(r, T::dk(c_d.ta)); return r; }
   static PBC_DEV el curve_b() { el r; T::f3_set_fq(r, T::dk(c_d.tb)); return r; }
@@ -116,6 +119,7 @@ template <int ND>
 struct Fq2Ops {                        // F_q^2 of type f: the twist y^2 = x^3 + tb
   typedef TypeF<ND> T;
   typedef typename T::g2 el;
+  static constexpr int NW = ND;
   static PBC_DEV int bytes() { return 2 * (int) fpk<ND>().fbytes; }
   static PBC_DEV el curve_a() { el r; T::g2_zero(r); return r; }
   static PBC_DEV el curve_b() { return T::fk2(c_f.tb); }
@@ -183,9 +187,86 @@ struct Fq2Ops {                        // F_q^2 of type f: the twist y^2 = x^3 +
   }
 };
 
+// Jacobian steps shared by the scalar multiplication and the cofactor ladder of element_from_hash.
+// R <- 2R (dbl-2007-bl shape; Z = 0 stays 0, and a point with Y = 0 doubles to Z = 0, i.e. O)
+template <class F>
+PBC_DEV void ec_dbl_jac(typename F::el &X, typename F::el &Y, typename F::el &Z, const typename F::el &ca) {
+  typedef typename F::el el;
+  el XX, YY, ZZ, M, S, t0, t1, Z3;
+  F::sqr(XX, X);
+  F::sqr(YY, Y);
+  F::sqr(ZZ, Z);
+  F::dbl(M, XX);
+  F::add(M, M, XX);
+  if (!F::a_is_zero()) {
+    F::sqr(t0, ZZ);
+    F::mul(t0, t0, ca);
+    F::add(M, M, t0);
+  }
+  F::mul(Z3, Y, Z);
+  F::dbl(Z3, Z3);
+  F::mul(S, X, YY);
+  F::dbl(S, S);
+  F::dbl(S, S);
+  F::sqr(t0, YY);
+  F::dbl(t0, t0);
+  F::dbl(t0, t0);
+  F::dbl(t0, t0);
+  F::sqr(X, M);
+  F::dbl(t1, S);
+  F::sub(X, X, t1);
+  F::sub(t1, S, X);
+  F::mul(t1, M, t1);
+  F::sub(Y, t1, t0);
+  Z = Z3;
+}
+// R <- R + P when `take`, for the affine P = (x2, y2) with 2P = (DX, DY, DZ) precomputed.  Complete: R = O gives P,
+// R = -P gives O (Z3 = Z H = 0), and R = P -- which the chord formulas cannot express (H = R = 0) -- takes the
+// precomputed double.  The last case occurs for points whose order divides a prefix of the scalar minus one:
+// curve_from_bytes (ecc/curve.c:609-623) accepts every point of the curve, not only the order-r subgroup, and the
+// reference's curve_mul (curve.c:153-207) tests x1 == x2 on every addition.
+template <class F>
+PBC_DEV void ec_madd_jac(typename F::el &X, typename F::el &Y, typename F::el &Z, const typename F::el &x2,
+                         const typename F::el &y2, const typename F::el &DX, const typename F::el &DY,
+                         const typename F::el &DZ, bool take) {
+  typedef typename F::el el;
+  el ZZ, H, R, HH, HHH, t0, t1, X3, Y3, Z3;
+  F::sqr(ZZ, Z);
+  F::mul(H, x2, ZZ);
+  F::sub(H, H, X);
+  F::mul(t0, Z, ZZ);
+  F::mul(R, y2, t0);
+  F::sub(R, R, Y);
+  F::mul(Z3, Z, H);
+  F::sqr(HH, H);
+  F::mul(HHH, HH, H);
+  F::mul(t0, X, HH);
+  F::sqr(X3, R);
+  F::sub(X3, X3, HHH);
+  F::sub(X3, X3, t0);
+  F::sub(X3, X3, t0);
+  F::sub(t0, t0, X3);
+  F::mul(t0, R, t0);
+  F::mul(t1, Y, HHH);
+  F::sub(Y3, t0, t1);
+  const bool inf = F::is0(Z);
+  const bool same = !inf & F::is0(H) & F::is0(R);
+  const bool take_p = take & inf, take_d = take & same, take_t = take & !inf & !same;
+  F::cmov(X, X3, take_t);
+  F::cmov(Y, Y3, take_t);
+  F::cmov(Z, Z3, take_t);
+  F::cmov(X, x2, take_p);
+  F::cmov(Y, y2, take_p);
+  F::cmov(Z, F::one(), take_p);
+  F::cmov(X, DX, take_d);
+  F::cmov(Y, DY, take_d);
+  F::cmov(Z, DZ, take_d);
+}
+
 // out = [k] P for P = (x, y) bytes; off-curve P is O (curve_from_bytes); O serialises as zeros.
 // Double-and-always-add with per-lane selects (element_mul_zn -> generic_pow_mpz over curve_mul,
-// arith/field.c:113-126, ecc/curve.c:153-207).
+// arith/field.c:113-126, ecc/curve.c:153-207).  Any scalar of zlen bytes and any point of the curve are
+// handled (scalars >= r, points outside the order-r subgroup): the group law is complete here.
 template <class F>
 PBC_DEV void ec_mul_lane(uint8_t *out, const uint8_t *in, const uint8_t *z, int zlen) {
   typedef typename F::el el;
@@ -204,72 +285,12 @@ PBC_DEV void ec_mul_lane(uint8_t *out, const uint8_t *in, const uint8_t *z, int 
     F::sqr(t1, y2);
     valid = F::eq(t0, t1);
   }
+  el DX = x2, DY = y2, DZ = one;       // 2P, for the step that meets R = P
+  ec_dbl_jac<F>(DX, DY, DZ, ca);
   el X = one, Y = one, Z = F::zero();  // accumulator R, starts at O (Z = 0)
   for (int i = 8 * zlen - 1; i >= 0; i--) {
-    // R <- 2R  (dbl-2007-bl shape; Z = 0 stays 0)
-    {
-      el XX, YY, ZZ, M, S, t0, t1, Z3;
-      F::sqr(XX, X);
-      F::sqr(YY, Y);
-      F::sqr(ZZ, Z);
-      F::dbl(M, XX);
-      F::add(M, M, XX);
-      if (!F::a_is_zero()) {
-        F::sqr(t0, ZZ);
-        F::mul(t0, t0, ca);
-        F::add(M, M, t0);
-      }
-      F::mul(Z3, Y, Z);
-      F::dbl(Z3, Z3);
-      F::mul(S, X, YY);
-      F::dbl(S, S);
-      F::dbl(S, S);
-      F::sqr(t0, YY);
-      F::dbl(t0, t0);
-      F::dbl(t0, t0);
-      F::dbl(t0, t0);
-      F::sqr(X, M);
-      F::dbl(t1, S);
-      F::sub(X, X, t1);
-      F::sub(t1, S, X);
-      F::mul(t1, M, t1);
-      F::sub(Y, t1, t0);
-      Z = Z3;
-    }
-    // T <- R + P (mixed); selected per lane when the scalar bit is set
-    {
-      el ZZ, H, R, HH, HHH, t0, t1, X3, Y3, Z3;
-      F::sqr(ZZ, Z);
-      F::mul(H, x2, ZZ);
-      F::sub(H, H, X);
-      F::mul(t0, Z, ZZ);
-      F::mul(R, y2, t0);
-      F::sub(R, R, Y);
-      F::mul(Z3, Z, H);
-      F::sqr(HH, H);
-      F::mul(HHH, HH, H);
-      F::mul(t0, X, HH);
-      F::sqr(X3, R);
-      F::sub(X3, X3, HHH);
-      F::sub(X3, X3, t0);
-      F::sub(X3, X3, t0);
-      F::sub(t0, t0, X3);
-      F::mul(t0, R, t0);
-      F::mul(t1, Y, HHH);
-      F::sub(Y3, t0, t1);
-      bool bit = zr_bit(z, zlen, i) != 0;
-      // R = O: R + P = P.   R = -P (H = 0, R != 0): the sum is O  (Z3 = Z H = 0 already).
-      // (R = P with a set bit would need a doubling: impossible for scalars < r.)
-      bool inf = F::is0(Z);
-      bool take_p = bit & inf;
-      bool take_t = bit & !inf;
-      F::cmov(X, X3, take_t);
-      F::cmov(Y, Y3, take_t);
-      F::cmov(Z, Z3, take_t);
-      F::cmov(X, x2, take_p);
-      F::cmov(Y, y2, take_p);
-      F::cmov(Z, one, take_p);
-    }
+    ec_dbl_jac<F>(X, Y, Z, ca);
+    ec_madd_jac<F>(X, Y, Z, x2, y2, DX, DY, DZ, zr_bit(z, zlen, i) != 0);
   }
   // to affine: x = X/Z^2, y = Y/Z^3
   el zi, zi2, ax, ay;
@@ -454,58 +475,12 @@ PBC_DEV void g_from_hash_lane(uint8_t *out, const uint8_t *data, int hlen) {
     fp_neg<N>(ny, fy);
     fp_cmov<N>(fy, ny, ((c.v[0] & 1) == 0) & !fp_is0<N>(fy));
   }
-  // [h] (fx, fy): wave-uniform double-and-add over the cofactor (element_mul_mpz, curve.c:477)
-  fp<N> X = fx, Y = fy, Z = one;
+  // [h] (fx, fy): wave-uniform double-and-add over the cofactor (element_mul_mpz, curve.c:477), complete group law
+  fp<N> X = fx, Y = fy, Z = one, DX = fx, DY = fy, DZ = one;
+  ec_dbl_jac<FqOps<N>>(DX, DY, DZ, ca);
   for (int i = c_curve.cofbits - 2; i >= 0; i--) {
-    {
-      fp<N> XX, YY, ZZ, M, S, t0, t1, Z3;
-      fp_sqr<N>(XX, X);
-      fp_sqr<N>(YY, Y);
-      fp_sqr<N>(ZZ, Z);
-      fp_dbl<N>(M, XX);
-      fp_add<N>(M, M, XX);
-      fp_sqr<N>(t0, ZZ);
-      fp_mul<N>(t0, t0, ca);
-      fp_add<N>(M, M, t0);
-      fp_mul<N>(Z3, Y, Z);
-      fp_dbl<N>(Z3, Z3);
-      fp_mul<N>(S, X, YY);
-      fp_dbl<N>(S, S);
-      fp_dbl<N>(S, S);
-      fp_sqr<N>(t0, YY);
-      fp_dbl<N>(t0, t0);
-      fp_dbl<N>(t0, t0);
-      fp_dbl<N>(t0, t0);
-      fp_sqr<N>(X, M);
-      fp_dbl<N>(t1, S);
-      fp_sub<N>(X, X, t1);
-      fp_sub<N>(t1, S, X);
-      fp_mul<N>(t1, M, t1);
-      fp_sub<N>(Y, t1, t0);
-      Z = Z3;
-    }
-    if ((c_curve.cofac[i >> 5] >> (i & 31)) & 1) {
-      fp<N> ZZ, H, R, HH, HHH, t0, t1, X3, Y3, Z3;
-      fp_sqr<N>(ZZ, Z);
-      fp_mul<N>(H, fx, ZZ);
-      fp_sub<N>(H, H, X);
-      fp_mul<N>(t0, Z, ZZ);
-      fp_mul<N>(R, fy, t0);
-      fp_sub<N>(R, R, Y);
-      fp_mul<N>(Z3, Z, H);
-      fp_sqr<N>(HH, H);
-      fp_mul<N>(HHH, HH, H);
-      fp_mul<N>(t0, X, HH);
-      fp_sqr<N>(X3, R);
-      fp_sub<N>(X3, X3, HHH);
-      fp_sub<N>(X3, X3, t0);
-      fp_sub<N>(X3, X3, t0);
-      fp_sub<N>(t0, t0, X3);
-      fp_mul<N>(t0, R, t0);
-      fp_mul<N>(t1, Y, HHH);
-      fp_sub<N>(Y3, t0, t1);
-      X = X3; Y = Y3; Z = Z3;
-    }
+    ec_dbl_jac<FqOps<N>>(X, Y, Z, ca);
+    if ((c_curve.cofac[i >> 5] >> (i & 31)) & 1) ec_madd_jac<FqOps<N>>(X, Y, Z, fx, fy, DX, DY, DZ, true);
   }
   fp<N> zi, zi2, ax, ay;
   bool is_inf = fp_is0<N>(Z);
@@ -687,7 +662,8 @@ struct ExtSqrtK {
   int ebits, tbits, s;
   uint32_t c[40];                      // z^T (Montgomery words, coefficient-major); derived on the device
 };
-__constant__ ExtSqrtK c_xs;
+static_assert(sizeof(ExtSqrtK) <= KOFF_FPK - KOFF_XS, "constant block layout");
+#define c_xs (pbc::kconst<pbc::ExtSqrtK, pbc::KOFF_XS>())
 
 template <class F>
 PBC_DEV void ext_pow(typename F::el &r, const typename F::el &a, const uint32_t *e, int bits) {

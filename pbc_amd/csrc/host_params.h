@@ -11,7 +11,6 @@
 #include "hostbn.h"
 #include "pairing_a.cuh"
 #include "pairing_d.cuh"
-#include "pairing_d_lazy.cuh"
 #include "pairing_f.cuh"
 #include "pairing_e.cuh"
 #include "group_ops.cuh"
@@ -53,21 +52,20 @@ struct pbc_hip_pairing_s {
   ERaw eraw;                 // type E: integers for the one-time search of the auxiliary point
   EConst econst;             // type E: curve, auxiliary point, exponents (filled on first use)
   bool dev_ready;            // derived constants computed on the device
-  bool dlazy_ready;          // experiment: 28-bit-limb constants of pairing_d_lazy.cuh derived
-  DLazyConst dlazy;
   int len_zr;                // bytes of a Z_r scalar (pairing_length_in_bytes_Zr)
   double fq_muls_single;     // reference F_q multiplication count per pairing (work model)
   double fq_muls_prod_a, fq_muls_prod_b;   // products: a*k + b
   double fq_muls_pp;         // one pairing_pp_apply (0: no preprocessed variant in the reference)
   // element_from_hash on G1: cofactor and square-root constants (copied into CurveK by fill_curve)
   struct {
-    uint32_t cofac[24]; int cofbits;
+    uint32_t cofac[34]; int cofbits;
     int sqrt_mode; uint32_t sqrt_e[34]; int sqrt_bits;
     int ts_s; uint32_t ts_t[34]; int ts_tbits; uint32_t half[34]; int halfbits;
     uint32_t ts_c[34]; bool ts_ready;
   } hash;
   ExtSqrtK xs;               // square roots in the field of the G2 twist (types d, g, f); xs.c derived on first use
   bool xs_ready;
+  void *host_ctx;            // library only: per-device streams and chunk buffers of the host-buffer path (pbc_hip.hip)
 };
 
 // |K*| = q^m - 1 = 2^s T for the twist's field K = F_q^m (m = d for types d / g, 2 for type f)
@@ -98,8 +96,8 @@ static int fill_hash_consts(pbc_hip_pairing_s *P, const pbc_host::Big &q, const 
   using pbc_host::Big;
   memset(&P->hash, 0, sizeof P->hash);
   if (cofac) {
-    if (cofac->bits() > 24 * 32) return fail("cofactor wider than 768 bits");
-    cofac->to_words(P->hash.cofac, 24);
+    if (cofac->bits() > 34 * 32) return fail("cofactor wider than 1088 bits");
+    cofac->to_words(P->hash.cofac, 34);
     P->hash.cofbits = cofac->bits();
   }
   Big two, four, rem;
@@ -142,11 +140,7 @@ static int fill_fpk(FpK<N> &K, const pbc_host::Big &q, int min_bits = 32 * (N - 
   if (q.bits() > 32 * N || q.bits() < min_bits || !(q.w[0] & 1)) return 1;
   memset(&K, 0, sizeof K);
   q.to_words(K.p, N);
-#if PBC_MUL_IMPL == 0
-  const int rbits = 32 * N;
-#else
   const int rbits = Limbs29<N>::W * Limbs29<N>::L;
-#endif
   Big::pow2_mod(rbits, q).to_words(K.one, N);
   Big::pow2_mod(2 * rbits, q).to_words(K.r2, N);
   for (int i = 0; i < Limbs29<N>::L; i++) {
@@ -555,4 +549,24 @@ static void fill_curve(const pbc_hip_pairing_s *P, CurveK &C) {
   C.sqrt_bits = P->hash.sqrt_bits;
   C.ts_s = P->hash.ts_s;
   memcpy(C.ts_c, P->hash.ts_c, sizeof C.ts_c);
+}
+
+// The constant block of a pairing object as the kernels receive it (layout: fp.cuh, "KArgs").  Built on the host for
+// every launch from the object's own copies -- nothing lives in device globals.
+template <int N> static const FpK<N> &host_fpk(const pbc_hip_pairing_s *P);
+#define PBC_HOST_FPK_OF(n) template <> const FpK<n> &host_fpk<n>(const pbc_hip_pairing_s *P) { return P->k##n; }
+PBC_FOR_EACH_N(PBC_HOST_FPK_OF)
+#undef PBC_HOST_FPK_OF
+template <int N>
+static void fill_kargs(const pbc_hip_pairing_s *P, KArgs<N> &K) {
+  memset(&K, 0, sizeof K);
+  CurveK C;
+  fill_curve(P, C);
+  memcpy(K.head + KOFF_CURVE, &C, sizeof C);
+  if (P->type == 'a' || P->type == '1') memcpy(K.head + KOFF_TYPE, &P->a, sizeof P->a);
+  else if (P->type == 'd' || P->type == 'g') memcpy(K.head + KOFF_TYPE, &P->dconst, sizeof P->dconst);
+  else if (P->type == 'f') memcpy(K.head + KOFF_TYPE, &P->fconst, sizeof P->fconst);
+  else if (P->type == 'e') memcpy(K.head + KOFF_TYPE, &P->econst, sizeof P->econst);
+  memcpy(K.head + KOFF_XS, &P->xs, sizeof P->xs);
+  K.fp = host_fpk<N>(P);
 }

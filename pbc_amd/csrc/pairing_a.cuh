@@ -59,7 +59,8 @@ struct AConst {          // a_pairing_data (ecc/a_param.c:30-34) + phikonr = h (
   uint32_t r[34];        // type a1 (and type a outside the 512-bit fast path): the group order, walked bit by bit
   int rbits;
 };
-__constant__ AConst c_a;
+static_assert(sizeof(AConst) <= KOFF_XS - KOFF_TYPE, "constant block layout");
+#define c_a (pbc::kconst<pbc::AConst, pbc::KOFF_TYPE>())
 
 // curve_is_valid_point (ecc/curve.c:57-77) for y^2 = x^3 + x
 template <int N>

@@ -38,7 +38,8 @@ struct DConst {                        // pptr (ecc/d_param.c:40-51) + curve/fie
   uint32_t phik[16];                   // Phi_k(q)/r (d_param.c:1036-1042, g_param.c:1288-1305)
   int rbits, phikbits;
 };
-__constant__ DConst c_d;
+static_assert(sizeof(DConst) <= KOFF_XS - KOFF_TYPE, "constant block layout");
+#define c_d (pbc::kconst<pbc::DConst, pbc::KOFF_TYPE>())
 struct DRaw { uint32_t a[ND_MAX], b[ND_MAX], coeff[DEG_MAX][ND_MAX], nqr[ND_MAX], q[ND_MAX + 1]; int qbits; };
 
 constexpr int D_LANES = 128;
@@ -714,14 +715,5 @@ static PBC_DEV void init_stage2(DConst *out, const DRaw &raw) {
 
 template <int ND> using TypeD = TypeMNT<ND, 3>;   // MNT, k = 6
 typedef TypeMNT<5, 5> TypeG;                      // Freeman, k = 10 (g149.param: 149-bit q)
-
-template <int ND, int DEG> __global__ void d_init_stage1(DConst *out, DRaw raw, DConst base) {
-  if (threadIdx.x || blockIdx.x) return;
-  TypeMNT<ND, DEG>::init_stage1(out, raw, base);
-}
-template <int ND, int DEG> __global__ void d_init_stage2(DConst *out, DRaw raw) {
-  if (threadIdx.x || blockIdx.x) return;
-  TypeMNT<ND, DEG>::init_stage2(out, raw);
-}
 
 }  // namespace pbc

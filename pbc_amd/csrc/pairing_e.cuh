@@ -28,7 +28,8 @@ struct EConst {
   uint32_t phik[NE_MAX];               // (q - 1)/r (e_param.c:857-860)
   int rbits, phikbits;
 };
-__constant__ EConst c_e;
+static_assert(sizeof(EConst) <= KOFF_XS - KOFF_TYPE, "constant block layout");
+#define c_e (pbc::kconst<pbc::EConst, pbc::KOFF_TYPE>())
 // host-supplied integers for the one-time search of R
 struct ERaw {
   uint32_t a[NE_MAX], b[NE_MAX];       // canonical curve coefficients
@@ -284,9 +285,9 @@ PBC_DEV bool e_sqrt(fp<N> &out, const fp<N> &a, const ERaw &raw) {
   out = x;
   return true;
 }
+// one lane: curve coefficients into Montgomery form and the auxiliary point R (once per parameter set)
 template <int N>
-__global__ void e_init_kernel(EConst *out, ERaw raw, EConst base) {
-  if (threadIdx.x || blockIdx.x) return;
+PBC_DEV void e_init_lane(EConst *out, const ERaw &raw, const EConst &base) {
   EConst C = base;
   fp<N> r2, t, a, b, one, x, rhs, y;
   fp_set<N>(r2, fpk<N>().r2);

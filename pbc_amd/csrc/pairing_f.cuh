@@ -43,7 +43,8 @@ struct FConst {                        // f_pairing_data_s (ecc/f_param.c:35-45)
   uint32_t bn_x[2];                    // |x|
   int bn_ok, bn_xneg, bn_xbits;
 };
-__constant__ FConst c_f;
+static_assert(sizeof(FConst) <= KOFF_XS - KOFF_TYPE, "constant block layout");
+#define c_f (pbc::kconst<pbc::FConst, pbc::KOFF_TYPE>())
 struct FRaw { uint32_t b[NF_MAX], beta[NF_MAX], alpha0[NF_MAX], alpha1[NF_MAX]; uint32_t e6[NF_MAX + 1]; int e6bits; };
 
 // Everything below is per field width: ND 32-bit words per F_q element (5 for f.param, 8 for 256-bit BN fields).
@@ -650,14 +651,5 @@ static PBC_DEV void init_stage2(FConst *out, const FRaw &raw) {
 }
 
 };  // struct TypeF
-
-template <int ND> __global__ void f_init_stage1(FConst *out, FRaw raw, FConst base) {
-  if (threadIdx.x || blockIdx.x) return;
-  TypeF<ND>::init_stage1(out, raw, base);
-}
-template <int ND> __global__ void f_init_stage2(FConst *out, FRaw raw) {
-  if (threadIdx.x || blockIdx.x) return;
-  TypeF<ND>::init_stage2(out, raw);
-}
 
 }  // namespace pbc

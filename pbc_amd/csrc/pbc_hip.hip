@@ -8,7 +8,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
 #include <string>
+#include <thread>
 
 #include "../../include/pbc_hip.h"
 #include "fp.cuh"
@@ -38,6 +40,17 @@ struct DevBuf {
   hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
   template <class T> T *as() const { return static_cast<T *>(p); }
 };
+// the calling thread's current device is restored on every return path (callers such as torch keep their own)
+struct DeviceGuard {
+  int prev = -1;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (dev >= 0 && dev != prev) (void) hipSetDevice(dev);
+  }
+  DeviceGuard(const DeviceGuard &) = delete;
+  DeviceGuard &operator=(const DeviceGuard &) = delete;
+  ~DeviceGuard() { if (prev >= 0) (void) hipSetDevice(prev); }
+};
 extern "C" const char *pbc_hip_last_error(void) { return g_err; }
 
 // ---------------------------------------------------------------------------------------
@@ -55,7 +68,7 @@ static_assert(kBlock == D_LANES, "pairing_d.cuh sizes its LDS state for 128-lane
 // One Type-A pairing per lane.  g1/g2/gt are AoS in wire format (128 B each for a.param);
 // per-lane 16-byte loads of a 128-byte record: every byte of every fetched line is used.
 template <int N>
-__global__ void __launch_bounds__(kBlock, PBC_A_WAVES) a_pairing_kernel(uint8_t *gt, const uint8_t *g1,
+__global__ void __launch_bounds__(kBlock, PBC_A_WAVES) a_pairing_kernel(KArgs<N> ka, uint8_t *gt, const uint8_t *g1,
                                                             const uint8_t *g2, size_t n) {
   size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
   size_t ld = idx < n ? idx : n - 1;          // tail lanes recompute the last unit, no store
@@ -73,7 +86,7 @@ __global__ void __launch_bounds__(kBlock, PBC_A_WAVES) a_pairing_kernel(uint8_t 
 
 // One k-term product of Type-A pairings per lane (terms of unit u are records u*k .. u*k+k-1).
 template <int N>
-__global__ void __launch_bounds__(kBlock, PBC_A_WAVES) a_prod_pairing_kernel(uint8_t *gt, const uint8_t *g1,
+__global__ void __launch_bounds__(kBlock, PBC_A_WAVES) a_prod_pairing_kernel(KArgs<N> ka, uint8_t *gt, const uint8_t *g1,
                                                                  const uint8_t *g2, size_t n, int k) {
   size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
   size_t ld = idx < n ? idx : n - 1;
@@ -94,7 +107,7 @@ __global__ void __launch_bounds__(kBlock, PBC_A_WAVES) a_prod_pairing_kernel(uin
 #define PBC_A1_WAVES 1    // 33-word fields: the 512-register budget of one wave per SIMD beats two waves
 #endif                    // with 256 (measured: a1 119 k -> 158 k pairings/s, e 769 k -> 971 k)
 template <int N>
-__global__ void __launch_bounds__(kBlock, N >= 32 ? PBC_A1_WAVES : PBC_A_WAVES) a1_prod_pairing_kernel(uint8_t *gt, const uint8_t *g1,
+__global__ void __launch_bounds__(kBlock, N >= 32 ? PBC_A1_WAVES : PBC_A_WAVES) a1_prod_pairing_kernel(KArgs<N> ka, uint8_t *gt, const uint8_t *g1,
                                                                                const uint8_t *g2, size_t n, int k) {
   size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
   size_t ld = idx < n ? idx : n - 1;
@@ -115,7 +128,7 @@ __global__ void __launch_bounds__(kBlock, N >= 32 ? PBC_A1_WAVES : PBC_A_WAVES) 
 
 // Type E: one k-term product (k = 1: a single pairing) per lane; G1/G2 256 B, GT 128 B for e.param.
 template <int N>
-__global__ void __launch_bounds__(kBlock, N >= 32 ? PBC_A1_WAVES : PBC_A_WAVES) e_prod_pairing_kernel(uint8_t *gt, const uint8_t *g1,
+__global__ void __launch_bounds__(kBlock, N >= 32 ? PBC_A1_WAVES : PBC_A_WAVES) e_prod_pairing_kernel(KArgs<N> ka, uint8_t *gt, const uint8_t *g1,
                                                                               const uint8_t *g2, size_t n, int k) {
   size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
   size_t ld = idx < n ? idx : n - 1;
@@ -136,13 +149,13 @@ __global__ void __launch_bounds__(kBlock, N >= 32 ? PBC_A1_WAVES : PBC_A_WAVES) 
 
 // pairing_pp_init: ONE lane derives the line-coefficient table of a fixed first argument.
 template <int N>
-__global__ void a_pp_init_kernel(uint32_t *tab, uint32_t *valid, const uint8_t *g1) {
+__global__ void a_pp_init_kernel(KArgs<N> ka, uint32_t *tab, uint32_t *valid, const uint8_t *g1) {
   if (threadIdx.x || blockIdx.x) return;
   *valid = a_pp_init_lane<N>(tab, g1) ? 1u : 0u;
 }
 // pairing_pp_apply over a batch of second arguments, one per lane; the table is uniform data.
 template <int N>
-__global__ void __launch_bounds__(kBlock, PBC_A_WAVES) a_pp_apply_kernel(uint8_t *gt, const uint32_t *__restrict__ tab,
+__global__ void __launch_bounds__(kBlock, PBC_A_WAVES) a_pp_apply_kernel(KArgs<N> ka, uint8_t *gt, const uint32_t *__restrict__ tab,
                                                                           const uint32_t *__restrict__ valid,
                                                                           const uint8_t *g2, size_t n) {
   size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
@@ -158,16 +171,11 @@ __global__ void __launch_bounds__(kBlock, PBC_A_WAVES) a_pp_apply_kernel(uint8_t
   }
 }
 
-// experiment switch (profiles/r01_notes.md): PBC_HIP_D_LAZY=1 routes 5-word type d pairings to the signed-limb kernel
-static bool d_lazy_selected() {
-  static const bool on = [] { const char *e = getenv("PBC_HIP_D_LAZY"); return e && *e == '1'; }();
-  return on;
-}
 // Types D and G: one k-term product (k = 1: a single pairing) per lane.  With fb = fixed byte length
 // of F_q and d = k/2, G1 records are 2 fb, G2 and GT 2 d fb bytes (40 / 120 / 120 B for d159.param,
 // 38 / 190 / 190 B for g149.param).
 template <int N, int DEG>
-__global__ void __launch_bounds__(kBlock, PBC_DF_WAVES) d_prod_pairing_kernel(uint8_t *gt, const uint8_t *g1,
+__global__ void __launch_bounds__(kBlock, PBC_DF_WAVES) d_prod_pairing_kernel(KArgs<N> ka, uint8_t *gt, const uint8_t *g1,
                                                                  const uint8_t *g2, size_t n, int k) {
   size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
   size_t ld = idx < n ? idx : n - 1;
@@ -185,55 +193,14 @@ __global__ void __launch_bounds__(kBlock, PBC_DF_WAVES) d_prod_pairing_kernel(ui
   }
 }
 
-// Type D on the signed-limb representation of pairing_d_lazy.cuh (5-word fields); same interface.
-template <int N>
-__global__ void __launch_bounds__(kBlock, PBC_DF_WAVES) d_lazy_prod_pairing_kernel(uint8_t *gt, const uint8_t *g1,
-                                                                      const uint8_t *g2, size_t n, int k) {
-  size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
-  size_t ld = idx < n ? idx : n - 1;
-  const int fb = (int) fpk<N>().fbytes, L1 = 2 * fb, L2 = 6 * fb, LT = 6 * fb;
-  __attribute__((aligned(4))) uint8_t out[24 * N];
-  LazyD<N>::prod_pairing_lane(out, g1 + ld * k * L1, g2 + ld * k * L2, k);
-  if (idx < n) {
-    if ((LT & 3) == 0) {
-      uint32_t *dst = reinterpret_cast<uint32_t *>(gt + idx * LT);
-      const uint32_t *src = reinterpret_cast<const uint32_t *>(out);
-      for (int i = 0; i < LT / 4; i++) dst[i] = src[i];
-    } else {
-      for (int i = 0; i < LT; i++) gt[idx * LT + i] = out[i];
-    }
-  }
-}
-
-template <int N>
-__global__ void d_lazy_pp_init_kernel(uint32_t *tab, uint32_t *valid, const uint8_t *g1) {
-  if (threadIdx.x || blockIdx.x) return;
-  *valid = LazyD<N>::pp_init_lane(reinterpret_cast<int32_t *>(tab), g1) ? 1u : 0u;
-}
-template <int N>
-__global__ void __launch_bounds__(kBlock, PBC_DF_WAVES) d_lazy_pp_apply_kernel(uint8_t *gt, const uint32_t *__restrict__ tab,
-                                                                               const uint32_t *__restrict__ valid,
-                                                                               const uint8_t *g2, size_t n) {
-  size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
-  size_t ld = idx < n ? idx : n - 1;
-  const int LT = 24 * N;
-  __attribute__((aligned(4))) uint8_t out[24 * N];
-  LazyD<N>::pp_apply_lane(out, reinterpret_cast<const int32_t *>(tab), *valid != 0, g2 + ld * LT);
-  if (idx < n) {
-    uint32_t *dst = reinterpret_cast<uint32_t *>(gt + idx * LT);
-    const uint32_t *src = reinterpret_cast<const uint32_t *>(out);
-    for (int i = 0; i < LT / 4; i++) dst[i] = src[i];
-  }
-}
-
 // pairing_pp for type a1
 template <int N>
-__global__ void a1_pp_init_kernel(uint32_t *tab, uint32_t *valid, const uint8_t *g1) {
+__global__ void a1_pp_init_kernel(KArgs<N> ka, uint32_t *tab, uint32_t *valid, const uint8_t *g1) {
   if (threadIdx.x || blockIdx.x) return;
   *valid = a1_pp_init_lane<N>(tab, g1) ? 1u : 0u;
 }
 template <int N>
-__global__ void __launch_bounds__(kBlock, N >= 32 ? PBC_A1_WAVES : PBC_A_WAVES) a1_pp_apply_kernel(uint8_t *gt, const uint32_t *__restrict__ tab,
+__global__ void __launch_bounds__(kBlock, N >= 32 ? PBC_A1_WAVES : PBC_A_WAVES) a1_pp_apply_kernel(KArgs<N> ka, uint8_t *gt, const uint32_t *__restrict__ tab,
                                                                            const uint32_t *__restrict__ valid,
                                                                            const uint8_t *g2, size_t n) {
   size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
@@ -254,12 +221,12 @@ __global__ void __launch_bounds__(kBlock, N >= 32 ? PBC_A1_WAVES : PBC_A_WAVES) 
 
 // pairing_pp for types d / g: single-lane table derivation, then one second argument per lane
 template <int N, int DEG>
-__global__ void d_pp_init_kernel(uint32_t *tab, uint32_t *valid, const uint8_t *g1) {
+__global__ void d_pp_init_kernel(KArgs<N> ka, uint32_t *tab, uint32_t *valid, const uint8_t *g1) {
   if (threadIdx.x || blockIdx.x) return;
   *valid = TypeMNT<N, DEG>::d_pp_init_lane(tab, g1) ? 1u : 0u;
 }
 template <int N, int DEG>
-__global__ void __launch_bounds__(kBlock, PBC_DF_WAVES) d_pp_apply_kernel(uint8_t *gt, const uint32_t *__restrict__ tab,
+__global__ void __launch_bounds__(kBlock, PBC_DF_WAVES) d_pp_apply_kernel(KArgs<N> ka, uint8_t *gt, const uint32_t *__restrict__ tab,
                                                                           const uint32_t *__restrict__ valid,
                                                                           const uint8_t *g2, size_t n) {
   size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
@@ -284,7 +251,7 @@ __global__ void __launch_bounds__(kBlock, PBC_DF_WAVES) d_pp_apply_kernel(uint8_
 #define PBC_F_WAVES PBC_DF_WAVES
 #endif
 template <int N>
-__global__ void __launch_bounds__(kBlock, PBC_F_WAVES) f_prod_pairing_kernel(uint8_t *gt, const uint8_t *g1,
+__global__ void __launch_bounds__(kBlock, PBC_F_WAVES) f_prod_pairing_kernel(KArgs<N> ka, uint8_t *gt, const uint8_t *g1,
                                                                  const uint8_t *g2, size_t n, int k) {
   size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
   size_t ld = idx < n ? idx : n - 1;
@@ -299,7 +266,7 @@ __global__ void __launch_bounds__(kBlock, PBC_F_WAVES) f_prod_pairing_kernel(uin
 }
 
 template <int N>
-__global__ void __launch_bounds__(kBlock) f_debug_kernel(int op, uint8_t *out, const uint8_t *a, const uint8_t *b, size_t n) {
+__global__ void __launch_bounds__(kBlock) f_debug_kernel(KArgs<N> ka, int op, uint8_t *out, const uint8_t *a, const uint8_t *b, size_t n) {
   size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
   if (idx >= n) return;
   const int LT = 12 * (int) fpk<N>().fbytes;
@@ -310,7 +277,7 @@ __global__ void __launch_bounds__(kBlock) f_debug_kernel(int op, uint8_t *out, c
 
 // ---- group operations (one element per lane) -------------------------------------------------
 template <int N>
-__global__ void __launch_bounds__(kBlock, 2) g_mul_kernel(uint8_t *out, const uint8_t *in, const uint8_t *z,
+__global__ void __launch_bounds__(kBlock, 2) g_mul_kernel(KArgs<N> ka, uint8_t *out, const uint8_t *in, const uint8_t *z,
                                                            int zlen, size_t n) {
   size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
   if (idx >= n) return;
@@ -320,7 +287,7 @@ __global__ void __launch_bounds__(kBlock, 2) g_mul_kernel(uint8_t *out, const ui
 // element_to_bytes_compressed / _x_only and element_from_bytes_compressed / _x_only on E(F_q): one point per lane
 // (dir 0 / 2 and 1 / 3)
 template <int N>
-__global__ void __launch_bounds__(kBlock, 2) g_compress_kernel(int dir, uint8_t *out, const uint8_t *in, size_t n) {
+__global__ void __launch_bounds__(kBlock, 2) g_compress_kernel(KArgs<N> ka, int dir, uint8_t *out, const uint8_t *in, size_t n) {
   size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
   if (idx >= n) return;
   const size_t fb = fpk<N>().fbytes;
@@ -331,7 +298,7 @@ __global__ void __launch_bounds__(kBlock, 2) g_compress_kernel(int dir, uint8_t 
 }
 // element_mul_zn on the twists: G2 of types d / g (over F_q^d) and f (over F_q^2)
 template <int N, int DEG>
-__global__ void __launch_bounds__(kBlock, 2) d_g2_mul_kernel(uint8_t *out, const uint8_t *in, const uint8_t *z,
+__global__ void __launch_bounds__(kBlock, 2) d_g2_mul_kernel(KArgs<N> ka, uint8_t *out, const uint8_t *in, const uint8_t *z,
                                                               int zlen, size_t n) {
   size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
   if (idx >= n) return;
@@ -339,7 +306,7 @@ __global__ void __launch_bounds__(kBlock, 2) d_g2_mul_kernel(uint8_t *out, const
   ec_mul_lane<FdOps<N, DEG>>(out + idx * L, in + idx * L, z + idx * zlen, zlen);
 }
 template <int N>
-__global__ void __launch_bounds__(kBlock, 2) f_g2_mul_kernel(uint8_t *out, const uint8_t *in, const uint8_t *z,
+__global__ void __launch_bounds__(kBlock, 2) f_g2_mul_kernel(KArgs<N> ka, uint8_t *out, const uint8_t *in, const uint8_t *z,
                                                               int zlen, size_t n) {
   size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
   if (idx >= n) return;
@@ -347,7 +314,7 @@ __global__ void __launch_bounds__(kBlock, 2) f_g2_mul_kernel(uint8_t *out, const
   ec_mul_lane<Fq2Ops<N>>(out + idx * L, in + idx * L, z + idx * zlen, zlen);
 }
 template <int N>
-__global__ void __launch_bounds__(kBlock, 2) g_from_hash_kernel(uint8_t *out, const uint8_t *data, int hlen, size_t n) {
+__global__ void __launch_bounds__(kBlock, 2) g_from_hash_kernel(KArgs<N> ka, uint8_t *out, const uint8_t *data, int hlen, size_t n) {
   size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
   size_t ld = idx < n ? idx : n - 1;   // whole waves stay in the retry loop together
   const int L = 2 * (int) fpk<N>().fbytes;
@@ -360,7 +327,7 @@ __global__ void __launch_bounds__(kBlock, 2) g_from_hash_kernel(uint8_t *out, co
 // F is the field policy of the twist (FdOps / Fq2Ops).  what 0: digests of `aux` bytes -> points; 1: points ->
 // x || s; 2: x || s -> points; 3: points -> x; 4: x -> points
 template <class F>
-__global__ void __launch_bounds__(kBlock, 2) g2_point_kernel(int what, uint8_t *out, const uint8_t *in, int aux, size_t n) {
+__global__ void __launch_bounds__(kBlock, 2) g2_point_kernel(KArgs<F::NW> ka, int what, uint8_t *out, const uint8_t *in, int aux, size_t n) {
   size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
   size_t ld = idx < n ? idx : n - 1;   // whole waves stay in the retry loop together
   const size_t fb = (size_t) F::bytes();
@@ -376,20 +343,20 @@ __global__ void __launch_bounds__(kBlock, 2) g2_point_kernel(int what, uint8_t *
     for (size_t i = 0; i < lo; i++) out[idx * lo + i] = o[i];
 }
 template <class F>
-__global__ void ext_ts_init_kernel(uint32_t *out) {
+__global__ void ext_ts_init_kernel(KArgs<F::NW> ka, uint32_t *out) {
   if (threadIdx.x || blockIdx.x) return;
   ext_ts_init<F>(out);
 }
 // one lane: z^t' for the Tonelli-Shanks square roots of element_from_hash (fields with q = 1 mod 4)
 struct TsRaw { uint32_t t[34], half[34]; int tbits, halfbits; };
 template <int N>
-__global__ void ts_init_kernel(uint32_t *out, TsRaw raw) {
+__global__ void ts_init_kernel(KArgs<N> ka, uint32_t *out, TsRaw raw) {
   if (threadIdx.x || blockIdx.x) return;
   fp_ts_init<N>(out, raw.t, raw.tbits, raw.half, raw.halfbits);
 }
 // op 0: out = a * b in GT;  op 1: out = a ^ z
 template <int N>
-__global__ void __launch_bounds__(kBlock, 2) gt_op_kernel(int type, int op, uint8_t *out, const uint8_t *a,
+__global__ void __launch_bounds__(kBlock, 2) gt_op_kernel(KArgs<N> ka, int type, int op, uint8_t *out, const uint8_t *a,
                                                            const uint8_t *b, int lenT, int zlen, size_t n) {
   size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
   if (idx >= n) return;
@@ -438,7 +405,7 @@ __global__ void __launch_bounds__(kBlock, 2) gt_op_kernel(int type, int op, uint
 
 // Batched F_q operations on wire bytes (differential check of the limb arithmetic).
 template <int N>
-__global__ void __launch_bounds__(kBlock) fq_op_kernel(int op, uint8_t *c, const uint8_t *a,
+__global__ void __launch_bounds__(kBlock) fq_op_kernel(KArgs<N> ka, int op, uint8_t *c, const uint8_t *a,
                                                         const uint8_t *b, size_t n) {
   size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
   if (idx >= n) return;
@@ -574,6 +541,20 @@ __global__ void __launch_bounds__(256) probe_kernel(uint32_t *sink, int iters, u
                         "v_mad_u64_u32 %6, vcc, %8, %9, %6\n\tv_mad_u64_u32 %7, vcc, %8, %9, %7"
                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
                         : "v"(x), "s"(seed) : "vcc");)
+    } else if constexpr (V == 14) {    // same, the carry-outs spread over four SGPR pairs (is the vcc write the limiter?)
+      REP8(asm volatile("v_mad_u64_u32 %0, vcc, %8, %9, %0\n\tv_mad_u64_u32 %1, s[36:37], %8, %9, %1\n\t"
+                        "v_mad_u64_u32 %2, s[38:39], %8, %9, %2\n\tv_mad_u64_u32 %3, s[40:41], %8, %9, %3\n\t"
+                        "v_mad_u64_u32 %4, vcc, %8, %9, %4\n\tv_mad_u64_u32 %5, s[36:37], %8, %9, %5\n\t"
+                        "v_mad_u64_u32 %6, s[38:39], %8, %9, %6\n\tv_mad_u64_u32 %7, s[40:41], %8, %9, %7"
+                        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
+                        : "v"(x), "s"(seed) : "vcc", "s36", "s37", "s38", "s39", "s40", "s41");)
+    } else if constexpr (V == 15) {    // the signed form, v_mad_i64_i32 (what a signed-limb representation would issue)
+      REP8(asm volatile("v_mad_i64_i32 %0, vcc, %8, %9, %0\n\tv_mad_i64_i32 %1, vcc, %8, %9, %1\n\t"
+                        "v_mad_i64_i32 %2, vcc, %8, %9, %2\n\tv_mad_i64_i32 %3, vcc, %8, %9, %3\n\t"
+                        "v_mad_i64_i32 %4, vcc, %8, %9, %4\n\tv_mad_i64_i32 %5, vcc, %8, %9, %5\n\t"
+                        "v_mad_i64_i32 %6, vcc, %8, %9, %6\n\tv_mad_i64_i32 %7, vcc, %8, %9, %7"
+                        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
+                        : "v"(x), "s"(seed) : "vcc");)
     }
   }
   uint64_t r = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7 ^ c0 ^ c1;
@@ -605,7 +586,7 @@ static __device__ __noinline__ v18 fz_sqr_fn(v18 va) {
 }
 // ---- multiplier micro-benchmark: iters dependent F_q products per lane, nothing else ------
 template <int N, int V>
-__global__ void __launch_bounds__(256) mul_bench_kernel(uint32_t *out, const uint32_t *in, int iters) {
+__global__ void __launch_bounds__(256) mul_bench_kernel(KArgs<N> ka, uint32_t *out, const uint32_t *in, int iters) {
   int tid = blockIdx.x * 256 + threadIdx.x;
   int n = gridDim.x * 256;
   fp<N> x, y;
@@ -613,8 +594,7 @@ __global__ void __launch_bounds__(256) mul_bench_kernel(uint32_t *out, const uin
   for (int i = 0; i < N; i++) { x.v[i] = in[i * n + tid]; y.v[i] = in[(N + i) * n + tid] | 1; }
 #pragma nounroll
   for (int it = 0; it < iters; it++) {
-    if constexpr (V == 0) fp_mul32_inl<N>(x, x, y);
-    else if constexpr (V == 1) fp_mul29_inl<N, false>(x, x, y);
+    if constexpr (V == 1) fp_mul29_inl<N, false>(x, x, y);
     else if constexpr (V == 2) fp_mul29_inl<N, true>(x, x, y);
     else if constexpr (V == 3) fp_sqr29_inl<N, false>(x, x);
     else if constexpr (V == 4) fp_sqr29_inl<N, true>(x, x);
@@ -688,7 +668,12 @@ extern "C" int pbc_hip_pairing_init_set_buf(pbc_hip_pairing_t **out, const char 
   *out = P;
   return 0;
 }
-extern "C" void pbc_hip_pairing_clear(pbc_hip_pairing_t *p) { delete p; }
+static void hostctx_free(pbc_hip_pairing_s *P);
+extern "C" void pbc_hip_pairing_clear(pbc_hip_pairing_t *p) {
+  if (!p) return;
+  hostctx_free(p);
+  delete p;
+}
 extern "C" int pbc_hip_pairing_type(const pbc_hip_pairing_t *p) { return p->type; }
 extern "C" int pbc_hip_device_count(void) {
   int count = 0;
@@ -747,113 +732,99 @@ extern "C" double pbc_hip_algorithmic_macs_per_unit(const pbc_hip_pairing_t *p, 
     default: return fail("internal: no kernel for %d-word fields", (int) (nl)); \
   }
 
-// constants -> __constant__ memory, ordered on the launch stream
-static int upload_constants(pbc_hip_pairing_s *P, hipStream_t s) {
-  switch (P->nlimb) {
-#define PBC_UP(n) \
-    case n: HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_fpk##n), &P->k##n, sizeof P->k##n, 0, hipMemcpyHostToDevice, s)); break;
-    PBC_FOR_EACH_N(PBC_UP)
-#undef PBC_UP
-    default: return fail("internal: no constants for %d-word fields", P->nlimb);
-  }
-  if (P->type == 'a' || P->type == '1')
-    HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_a), &P->a, sizeof P->a, 0, hipMemcpyHostToDevice, s));
+// the constant block of an object, passed by value as the first argument of every kernel (fp.cuh, "KArgs")
+template <int N>
+static KArgs<N> kargs(const pbc_hip_pairing_s *P) {
+  KArgs<N> K;
+  fill_kargs<N>(P, K);
+  return K;
+}
+
+// single-lane kernels of the one-time derivations (tower constants of types d / g / f, the auxiliary point of type e)
+template <int N, int DEG> __global__ void d_init_stage1(KArgs<N> ka, DConst *out, DRaw raw) {
+  if (threadIdx.x || blockIdx.x) return;
+  TypeMNT<N, DEG>::init_stage1(out, raw, c_d);
+}
+template <int N, int DEG> __global__ void d_init_stage2(KArgs<N> ka, DConst *out, DRaw raw) {
+  if (threadIdx.x || blockIdx.x) return;
+  TypeMNT<N, DEG>::init_stage2(out, raw);
+}
+template <int N> __global__ void f_init_stage1(KArgs<N> ka, FConst *out, FRaw raw) {
+  if (threadIdx.x || blockIdx.x) return;
+  TypeF<N>::init_stage1(out, raw, c_f);
+}
+template <int N> __global__ void f_init_stage2(KArgs<N> ka, FConst *out, FRaw raw) {
+  if (threadIdx.x || blockIdx.x) return;
+  TypeF<N>::init_stage2(out, raw);
+}
+template <int N> __global__ void e_init_kernel(KArgs<N> ka, EConst *out, ERaw raw) {
+  if (threadIdx.x || blockIdx.x) return;
+  e_init_lane<N>(out, raw, c_e);
+}
+
+// First use of an object on a device: constants that are derived ON the device (the library carries no host copy of
+// the tower arithmetic) are computed by single-lane kernels and kept in the object; every later launch passes them in
+// its argument block.  Nothing is uploaded per call.
+static int ensure_derived(pbc_hip_pairing_s *P, hipStream_t s) {
+  if (P->dev_ready || (P->type != 'd' && P->type != 'g' && P->type != 'e' && P->type != 'f')) return 0;
+  DevBuf buf;
   if (P->type == 'd' || P->type == 'g') {
-    if (!P->dev_ready) {
-      // one-time derivation of the tower constants on the device (two single-lane kernels)
-      DConst *dbuf;
-      HIP_TRY(hipMalloc(&dbuf, sizeof(DConst)));
-      PBC_DISPATCH_D(P, hipLaunchKernelGGL((d_init_stage1<N, DEG>), dim3(1), dim3(64), 0, s, dbuf, P->draw, P->dconst));
-      HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_d), dbuf, sizeof(DConst), 0, hipMemcpyDeviceToDevice, s));
-      PBC_DISPATCH_D(P, hipLaunchKernelGGL((d_init_stage2<N, DEG>), dim3(1), dim3(64), 0, s, dbuf, P->draw));
-      HIP_TRY(hipMemcpyAsync(&P->dconst, dbuf, sizeof(DConst), hipMemcpyDeviceToHost, s));
-      HIP_TRY(hipStreamSynchronize(s));
-      (void) hipFree(dbuf);
-      P->dev_ready = true;
-    }
-    HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_d), &P->dconst, sizeof P->dconst, 0, hipMemcpyHostToDevice, s));
-    if (P->type == 'd' && P->nlimb == 5 && d_lazy_selected()) {
-      if (!P->dlazy_ready) {
-        DLazyConst *lbuf;
-        HIP_TRY(hipMalloc(&lbuf, sizeof(DLazyConst)));
-        hipLaunchKernelGGL(d_lazy_init_kernel<5>, dim3(1), dim3(64), 0, s, lbuf);
-        HIP_TRY(hipMemcpyAsync(&P->dlazy, lbuf, sizeof(DLazyConst), hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
-        (void) hipFree(lbuf);
-        P->dlazy_ready = true;
-      }
-      HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_dl), &P->dlazy, sizeof P->dlazy, 0, hipMemcpyHostToDevice, s));
-    }
+    HIP_TRY(buf.alloc(sizeof(DConst)));
+    DConst *dbuf = buf.as<DConst>();
+    PBC_DISPATCH_D(P, hipLaunchKernelGGL((d_init_stage1<N, DEG>), dim3(1), dim3(64), 0, s, kargs<N>(P), dbuf, P->draw));
+    HIP_TRY(hipMemcpyAsync(&P->dconst, dbuf, sizeof(DConst), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    PBC_DISPATCH_D(P, hipLaunchKernelGGL((d_init_stage2<N, DEG>), dim3(1), dim3(64), 0, s, kargs<N>(P), dbuf, P->draw));
+    HIP_TRY(hipMemcpyAsync(&P->dconst, dbuf, sizeof(DConst), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+  } else if (P->type == 'e') {
+    HIP_TRY(buf.alloc(sizeof(EConst)));
+    EConst *dbuf = buf.as<EConst>();
+    if (P->nlimb == 16) hipLaunchKernelGGL(e_init_kernel<16>, dim3(1), dim3(64), 0, s, kargs<16>(P), dbuf, P->eraw);
+    else hipLaunchKernelGGL(e_init_kernel<33>, dim3(1), dim3(64), 0, s, kargs<33>(P), dbuf, P->eraw);
+    HIP_TRY(hipMemcpyAsync(&P->econst, dbuf, sizeof(EConst), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+  } else {
+    HIP_TRY(buf.alloc(sizeof(FConst)));
+    FConst *dbuf = buf.as<FConst>();
+    PBC_DISPATCH_F(P->nlimb, hipLaunchKernelGGL(f_init_stage1<N>, dim3(1), dim3(64), 0, s, kargs<N>(P), dbuf, P->fraw));
+    HIP_TRY(hipMemcpyAsync(&P->fconst, dbuf, sizeof(FConst), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    PBC_DISPATCH_F(P->nlimb, hipLaunchKernelGGL(f_init_stage2<N>, dim3(1), dim3(64), 0, s, kargs<N>(P), dbuf, P->fraw));
+    HIP_TRY(hipMemcpyAsync(&P->fconst, dbuf, sizeof(FConst), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
   }
-  if (P->type == 'e') {
-    if (!P->dev_ready) {
-      // one-time search of the auxiliary point on the device (single lane)
-      EConst *dbuf;
-      HIP_TRY(hipMalloc(&dbuf, sizeof(EConst)));
-      if (P->nlimb == 16) hipLaunchKernelGGL(e_init_kernel<16>, dim3(1), dim3(64), 0, s, dbuf, P->eraw, P->econst);
-      else hipLaunchKernelGGL(e_init_kernel<33>, dim3(1), dim3(64), 0, s, dbuf, P->eraw, P->econst);
-      HIP_TRY(hipMemcpyAsync(&P->econst, dbuf, sizeof(EConst), hipMemcpyDeviceToHost, s));
-      HIP_TRY(hipStreamSynchronize(s));
-      (void) hipFree(dbuf);
-      P->dev_ready = true;
-    }
-    HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_e), &P->econst, sizeof P->econst, 0, hipMemcpyHostToDevice, s));
-  }
-  if (P->type == 'f') {
-    if (!P->dev_ready) {
-      FConst *dbuf;
-      HIP_TRY(hipMalloc(&dbuf, sizeof(FConst)));
-      PBC_DISPATCH_F(P->nlimb, hipLaunchKernelGGL(f_init_stage1<N>, dim3(1), dim3(64), 0, s, dbuf, P->fraw, P->fconst));
-      HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_f), dbuf, sizeof(FConst), 0, hipMemcpyDeviceToDevice, s));
-      PBC_DISPATCH_F(P->nlimb, hipLaunchKernelGGL(f_init_stage2<N>, dim3(1), dim3(64), 0, s, dbuf, P->fraw));
-      HIP_TRY(hipMemcpyAsync(&P->fconst, dbuf, sizeof(FConst), hipMemcpyDeviceToHost, s));
-      HIP_TRY(hipStreamSynchronize(s));
-      (void) hipFree(dbuf);
-      P->dev_ready = true;
-    }
-    HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_f), &P->fconst, sizeof P->fconst, 0, hipMemcpyHostToDevice, s));
-  }
-  if (P->type == 'd' || P->type == 'g' || P->type == 'f')
-    HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_xs), &P->xs, sizeof P->xs, 0, hipMemcpyHostToDevice, s));
-  {
-    CurveK C;
-    fill_curve(P, C);
-    HIP_TRY(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_curve), &C, sizeof C, 0, hipMemcpyHostToDevice, s));
-  }
+  HIP_TRY(hipGetLastError());
+  P->dev_ready = true;
   return 0;
 }
 
-static int launch_prod(pbc_hip_pairing_s *P, void *d_gt, const void *d_g1, const void *d_g2, size_t n, int k,
-                       hipStream_t s, bool upload);
 static int launch_pairing(pbc_hip_pairing_s *P, void *d_gt, const void *d_g1, const void *d_g2, size_t n,
                           hipStream_t s, bool upload) {
   if (P->device < 0) return fail("no HIP device: libpbc_hip has no CPU fallback");
   if (!n) return 0;
-  if (upload && upload_constants(P, s)) return 1;
+  if (upload && ensure_derived(P, s)) return 1;
   unsigned grid = (unsigned) ((n + kBlock - 1) / kBlock);
   if (P->type == 'a' && !P->a_generic) {
-    hipLaunchKernelGGL(a_pairing_kernel<16>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
+    hipLaunchKernelGGL(a_pairing_kernel<16>, dim3(grid), dim3(kBlock), 0, s, kargs<16>(P), (uint8_t *) d_gt,
                        (const uint8_t *) d_g1, (const uint8_t *) d_g2, n);
   } else if ((P->type == 'a' || P->type == '1') && P->nlimb == 16) {   // other sizes: the bit-by-bit kernels
-    hipLaunchKernelGGL(a1_prod_pairing_kernel<16>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
+    hipLaunchKernelGGL(a1_prod_pairing_kernel<16>, dim3(grid), dim3(kBlock), 0, s, kargs<16>(P), (uint8_t *) d_gt,
                        (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, 1);
   } else if (P->type == '1' || P->type == 'a') {
-    hipLaunchKernelGGL(a1_prod_pairing_kernel<33>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
+    hipLaunchKernelGGL(a1_prod_pairing_kernel<33>, dim3(grid), dim3(kBlock), 0, s, kargs<33>(P), (uint8_t *) d_gt,
                        (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, 1);
   } else if (P->type == 'e' && P->nlimb == 16) {
-    hipLaunchKernelGGL(e_prod_pairing_kernel<16>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
+    hipLaunchKernelGGL(e_prod_pairing_kernel<16>, dim3(grid), dim3(kBlock), 0, s, kargs<16>(P), (uint8_t *) d_gt,
                        (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, 1);
   } else if (P->type == 'e') {
-    hipLaunchKernelGGL(e_prod_pairing_kernel<33>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
-                       (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, 1);
-  } else if (P->type == 'd' && P->nlimb == 5 && d_lazy_selected()) {
-    hipLaunchKernelGGL(d_lazy_prod_pairing_kernel<5>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
+    hipLaunchKernelGGL(e_prod_pairing_kernel<33>, dim3(grid), dim3(kBlock), 0, s, kargs<33>(P), (uint8_t *) d_gt,
                        (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, 1);
   } else if (P->type == 'd' || P->type == 'g') {
-    PBC_DISPATCH_D(P, hipLaunchKernelGGL((d_prod_pairing_kernel<N, DEG>), dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
+    PBC_DISPATCH_D(P, hipLaunchKernelGGL((d_prod_pairing_kernel<N, DEG>), dim3(grid), dim3(kBlock), 0, s, kargs<N>(P), (uint8_t *) d_gt,
                                                 (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, 1));
   } else if (P->type == 'f') {
-    PBC_DISPATCH_F(P->nlimb, hipLaunchKernelGGL(f_prod_pairing_kernel<N>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
+    PBC_DISPATCH_F(P->nlimb, hipLaunchKernelGGL(f_prod_pairing_kernel<N>, dim3(grid), dim3(kBlock), 0, s, kargs<N>(P), (uint8_t *) d_gt,
                        (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, 1));
   } else {
     return fail("unsupported type");
@@ -867,21 +838,91 @@ extern "C" int pbc_hip_element_pairing_batch_dev(pbc_hip_pairing_t *P, void *d_g
   return launch_pairing(P, d_gt, d_g1, d_g2, n, (hipStream_t) stream, true);
 }
 
-// host-buffer convenience path: H2D, kernel, D2H on a private stream
-// host-buffer path: the batch is cut into chunks that travel H2D -> kernel -> D2H on a small
-// ring of streams, so the PCIe copies of one chunk overlap the arithmetic of its neighbours
-// ("chunked to overlap copies with compute").  Pinned caller buffers overlap fully;
-// pageable ones still work (the runtime stages them).
-// Host-buffer path.  The batch is cut into chunks of one chip residency; chunks travel
-// H2D -> kernel -> D2H on a ring of three streams PER DEVICE, so the copies of one chunk hide behind
-// the arithmetic of its neighbours, and consecutive chunks go to the devices of the object's device
-// set in turn (pbc_hip_pairing_use_devices: range split, no exchange between devices, results land
-// directly in the caller's buffer).
+// ---- host-buffer path --------------------------------------------------------------------
+// The batch is cut into chunks of one chip residency; chunks travel H2D -> kernel -> D2H on a ring of three streams
+// PER DEVICE, so the copies of one chunk hide behind the arithmetic of its neighbours (pinned caller buffers --
+// pbc_hip_host_alloc -- overlap fully; pageable ones still work, the runtime stages them).  Consecutive chunks go to the
+// devices of the object's device set in turn (pbc_hip_pairing_use_devices: range split, no exchange between devices,
+// results land directly in the caller's buffer), each device driven by its own host thread.
+// Streams and chunk buffers belong to the object: they are created on first use per device, grow when a larger chunk
+// arrives and are released by pbc_hip_pairing_clear -- a call allocates nothing in the steady state.
+constexpr int kSlots = 3, kMaxDev = 16;
+struct DevCtx {
+  int dev = -1;
+  hipStream_t st[kSlots] = {nullptr, nullptr, nullptr};
+  void *d1[kSlots] = {nullptr, nullptr, nullptr}, *d2[kSlots] = {nullptr, nullptr, nullptr}, *dt[kSlots] = {nullptr, nullptr, nullptr};
+  size_t cap1 = 0, cap2 = 0, capt = 0;         // bytes per slot
+};
+struct HostCtx {
+  DevCtx dc[kMaxDev];
+  int n = 0;
+  std::mutex mu;                               // guards the table (the per-device entries are used by one worker each)
+};
+static void devctx_release(DevCtx &c) {
+  if (c.dev < 0) return;
+  DeviceGuard guard(c.dev);
+  for (int i = 0; i < kSlots; i++) {
+    if (c.st[i]) { (void) hipStreamSynchronize(c.st[i]); }
+    if (c.d1[i]) (void) hipFree(c.d1[i]);
+    if (c.d2[i]) (void) hipFree(c.d2[i]);
+    if (c.dt[i]) (void) hipFree(c.dt[i]);
+    if (c.st[i]) (void) hipStreamDestroy(c.st[i]);
+    c.st[i] = nullptr; c.d1[i] = c.d2[i] = c.dt[i] = nullptr;
+  }
+  c.cap1 = c.cap2 = c.capt = 0;
+  c.dev = -1;
+}
+static void hostctx_free(pbc_hip_pairing_s *P) {
+  HostCtx *H = static_cast<HostCtx *>(P->host_ctx);
+  if (!H) return;
+  for (int i = 0; i < H->n; i++) devctx_release(H->dc[i]);
+  delete H;
+  P->host_ctx = nullptr;
+}
+// the context of `dev` with room for chunks of (b1, b2, bt) bytes; the calling thread's current device must be `dev`
+static DevCtx *devctx_get(pbc_hip_pairing_s *P, int dev, size_t b1, size_t b2, size_t bt, std::string &err) {
+  HostCtx *H = static_cast<HostCtx *>(P->host_ctx);
+  DevCtx *c = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(H->mu);
+    for (int i = 0; i < H->n; i++)
+      if (H->dc[i].dev == dev) c = &H->dc[i];
+    if (!c) {
+      if (H->n == kMaxDev) { err = "too many devices in one object"; return nullptr; }
+      c = &H->dc[H->n++];
+      c->dev = dev;
+    }
+  }
+  for (int i = 0; i < kSlots; i++)
+    if (!c->st[i] && hipStreamCreateWithFlags(&c->st[i], hipStreamNonBlocking) != hipSuccess) { err = "hipStreamCreate failed"; return nullptr; }
+  if (b1 > c->cap1 || b2 > c->cap2 || bt > c->capt) {
+    for (int i = 0; i < kSlots; i++) {
+      (void) hipStreamSynchronize(c->st[i]);
+      if (c->d1[i]) (void) hipFree(c->d1[i]);
+      if (c->d2[i]) (void) hipFree(c->d2[i]);
+      if (c->dt[i]) (void) hipFree(c->dt[i]);
+      c->d1[i] = c->d2[i] = c->dt[i] = nullptr;
+    }
+    c->cap1 = b1 > c->cap1 ? b1 : c->cap1;
+    c->cap2 = b2 > c->cap2 ? b2 : c->cap2;
+    c->capt = bt > c->capt ? bt : c->capt;
+    for (int i = 0; i < kSlots; i++)
+      if (hipMalloc(&c->d1[i], c->cap1) != hipSuccess || hipMalloc(&c->d2[i], c->cap2) != hipSuccess ||
+          hipMalloc(&c->dt[i], c->capt) != hipSuccess) {
+        c->cap1 = c->cap2 = c->capt = 0;
+        err = "device allocation failed for the chunk buffers";
+        return nullptr;
+      }
+  }
+  return c;
+}
+
+static int launch_prod(pbc_hip_pairing_s *P, void *d_gt, const void *d_g1, const void *d_g2, size_t n, int k,
+                       hipStream_t s, bool upload);
 static int run_host(pbc_hip_pairing_s *P, uint8_t *gt, const uint8_t *g1, const uint8_t *g2, size_t n,
                     int k) {
   if (P->device < 0) return fail("no HIP device: libpbc_hip has no CPU fallback");
   if (!n) return 0;
-  constexpr int SLOTS = 3, MAXDEV = 16;
   const int ndev = P->ndev > 0 ? P->ndev : 1;
   const int *devs = P->ndev > 0 ? P->devs : &P->device;
   size_t chunk = (size_t) 131072 / (size_t) k;       // one full residency of the chip per chunk
@@ -889,58 +930,49 @@ static int run_host(pbc_hip_pairing_s *P, uint8_t *gt, const uint8_t *g1, const 
   if (chunk > n) chunk = n;
   const size_t u1 = (size_t) k * P->len1, u2 = (size_t) k * P->len2, ut = (size_t) P->lenT;
   const size_t nchunks = (n + chunk - 1) / chunk;
-  void *d1[MAXDEV][SLOTS] = {{nullptr}}, *d2[MAXDEV][SLOTS] = {{nullptr}}, *dt[MAXDEV][SLOTS] = {{nullptr}};
-  hipStream_t st[MAXDEV][SLOTS] = {{nullptr}};
-  int rc = 0;
-  int used = 0;                                      // devices that receive at least one chunk
-  for (int d = 0; d < ndev && !rc && (size_t) d < nchunks; d++, used++) {
-    if (hipSetDevice(devs[d]) != hipSuccess) { rc = fail("hipSetDevice(%d) failed", devs[d]); break; }
-    size_t mine = (nchunks - (size_t) d + (size_t) ndev - 1) / (size_t) ndev;   // chunks d, d + ndev, ...
-    int slots = mine < (size_t) SLOTS ? (int) mine : SLOTS;
-    for (int i = 0; i < slots && !rc; i++) {
-      if (hipStreamCreate(&st[d][i]) != hipSuccess || hipMalloc(&d1[d][i], chunk * u1) != hipSuccess ||
-          hipMalloc(&d2[d][i], chunk * u2) != hipSuccess || hipMalloc(&dt[d][i], chunk * ut) != hipSuccess)
-        rc = fail("device allocation failed for a chunk of %zu units on device %d", chunk, devs[d]);
+  const int used = (size_t) ndev < nchunks ? ndev : (int) nchunks;      // devices that receive at least one chunk
+  DeviceGuard guard(devs[0]);
+  if (!P->host_ctx) P->host_ctx = new HostCtx();
+  if (ensure_derived(P, 0)) return 1;                // once per object, before any worker reads the constants
+  // chunks d, d + ndev, d + 2 ndev, ... on device devs[d]
+  auto worker = [&](int d, std::string *err) {
+    if (hipSetDevice(devs[d]) != hipSuccess) { *err = "hipSetDevice failed"; return; }
+    DevCtx *c = devctx_get(P, devs[d], chunk * u1, chunk * u2, chunk * ut, *err);
+    if (!c) return;
+    size_t round = 0;
+    for (size_t idx = (size_t) d; idx < nchunks; idx += (size_t) ndev, round++) {
+      const int sl = (int) (round % kSlots);
+      const size_t off = idx * chunk, m = n - off < chunk ? n - off : chunk;
+      hipStream_t st = c->st[sl];
+      if (hipMemcpyAsync(c->d1[sl], g1 + off * u1, m * u1, hipMemcpyHostToDevice, st) != hipSuccess ||
+          hipMemcpyAsync(c->d2[sl], g2 + off * u2, m * u2, hipMemcpyHostToDevice, st) != hipSuccess) { *err = "H2D copy failed"; break; }
+      if (launch_prod(P, c->dt[sl], c->d1[sl], c->d2[sl], m, k, st, false)) { *err = g_err; break; }
+      if (hipMemcpyAsync(gt + off * ut, c->dt[sl], m * ut, hipMemcpyDeviceToHost, st) != hipSuccess) { *err = "D2H copy failed"; break; }
     }
-    // constants once per device, before any chunk
-    if (!rc && upload_constants(P, st[d][0])) rc = 1;
-    if (!rc && hipStreamSynchronize(st[d][0]) != hipSuccess) rc = fail("constant upload failed on device %d", devs[d]);
-  }
-  size_t idx = 0;
-  for (size_t off = 0; off < n && !rc; off += chunk, idx++) {
-    const int d = (int) (idx % (size_t) ndev);
-    const size_t round = idx / (size_t) ndev;
-    int slots = 0;
-    while (slots < SLOTS && st[d][slots]) slots++;
-    const int sl = (int) (round % (size_t) slots);
-    const size_t m = n - off < chunk ? n - off : chunk;
-    hipStream_t s = st[d][sl];
-    if (hipSetDevice(devs[d]) != hipSuccess) { rc = fail("hipSetDevice(%d) failed", devs[d]); break; }
-    if (hipMemcpyAsync(d1[d][sl], g1 + off * u1, m * u1, hipMemcpyHostToDevice, s) != hipSuccess ||
-        hipMemcpyAsync(d2[d][sl], g2 + off * u2, m * u2, hipMemcpyHostToDevice, s) != hipSuccess) {
-      rc = fail("H2D copy failed");
-      break;
+    for (int i = 0; i < kSlots; i++) {
+      hipError_t e = hipStreamSynchronize(c->st[i]);
+      if (e != hipSuccess && err->empty()) *err = std::string("kernel failed: ") + hipGetErrorString(e);
     }
-    rc = launch_prod(P, dt[d][sl], d1[d][sl], d2[d][sl], m, k, s, false);
-    if (rc) break;
-    if (hipMemcpyAsync(gt + off * ut, dt[d][sl], m * ut, hipMemcpyDeviceToHost, s) != hipSuccess) rc = fail("D2H copy failed");
+  };
+  std::string errs[kMaxDev];
+  if (used == 1) {
+    worker(0, &errs[0]);
+  } else {
+    std::thread th[kMaxDev];
+    for (int d = 0; d < used; d++) th[d] = std::thread(worker, d, &errs[d]);
+    for (int d = 0; d < used; d++) th[d].join();
   }
-  for (int d = 0; d < used; d++) {
-    (void) hipSetDevice(devs[d]);
-    for (int i = 0; i < SLOTS; i++) {
-      if (st[d][i]) {
-        hipError_t e = hipStreamSynchronize(st[d][i]);
-        if (e != hipSuccess && !rc) rc = fail("kernel failed on device %d: %s", devs[d], hipGetErrorString(e));
-      }
-      if (d1[d][i]) (void) hipFree(d1[d][i]);
-      if (d2[d][i]) (void) hipFree(d2[d][i]);
-      if (dt[d][i]) (void) hipFree(dt[d][i]);
-      if (st[d][i]) (void) hipStreamDestroy(st[d][i]);
-    }
-  }
-  (void) hipSetDevice(P->device);
-  return rc;
+  for (int d = 0; d < used; d++)
+    if (!errs[d].empty()) return fail("device %d: %s", devs[d], errs[d].c_str());
+  return 0;
 }
+
+extern "C" int pbc_hip_host_alloc(void **out, size_t bytes) {
+  if (!out) return fail("null argument");
+  if (hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocPortable) != hipSuccess) return fail("hipHostMalloc(%zu) failed", bytes);
+  return 0;
+}
+extern "C" void pbc_hip_host_free(void *p) { if (p) (void) hipHostFree(p); }
 
 extern "C" int pbc_hip_element_pairing_batch(pbc_hip_pairing_t *P, uint8_t *gt, const uint8_t *g1,
                                              const uint8_t *g2, size_t n) {
@@ -954,31 +986,28 @@ static int launch_prod(pbc_hip_pairing_s *P, void *d_gt, const void *d_g1, const
   if (k == 1) return launch_pairing(P, d_gt, d_g1, d_g2, n, s, upload);
   if (P->device < 0) return fail("no HIP device: libpbc_hip has no CPU fallback");
   if (!n) return 0;
-  if (upload && upload_constants(P, s)) return 1;
+  if (upload && ensure_derived(P, s)) return 1;
   unsigned grid = (unsigned) ((n + kBlock - 1) / kBlock);
   if (P->type == 'a' && !P->a_generic) {
-    hipLaunchKernelGGL(a_prod_pairing_kernel<16>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
+    hipLaunchKernelGGL(a_prod_pairing_kernel<16>, dim3(grid), dim3(kBlock), 0, s, kargs<16>(P), (uint8_t *) d_gt,
                        (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k);
   } else if ((P->type == 'a' || P->type == '1') && P->nlimb == 16) {
-    hipLaunchKernelGGL(a1_prod_pairing_kernel<16>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
+    hipLaunchKernelGGL(a1_prod_pairing_kernel<16>, dim3(grid), dim3(kBlock), 0, s, kargs<16>(P), (uint8_t *) d_gt,
                        (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k);
   } else if (P->type == '1' || P->type == 'a') {
-    hipLaunchKernelGGL(a1_prod_pairing_kernel<33>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
+    hipLaunchKernelGGL(a1_prod_pairing_kernel<33>, dim3(grid), dim3(kBlock), 0, s, kargs<33>(P), (uint8_t *) d_gt,
                        (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k);
   } else if (P->type == 'e' && P->nlimb == 16) {
-    hipLaunchKernelGGL(e_prod_pairing_kernel<16>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
+    hipLaunchKernelGGL(e_prod_pairing_kernel<16>, dim3(grid), dim3(kBlock), 0, s, kargs<16>(P), (uint8_t *) d_gt,
                        (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k);
   } else if (P->type == 'e') {
-    hipLaunchKernelGGL(e_prod_pairing_kernel<33>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
-                       (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k);
-  } else if (P->type == 'd' && P->nlimb == 5 && d_lazy_selected()) {
-    hipLaunchKernelGGL(d_lazy_prod_pairing_kernel<5>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
+    hipLaunchKernelGGL(e_prod_pairing_kernel<33>, dim3(grid), dim3(kBlock), 0, s, kargs<33>(P), (uint8_t *) d_gt,
                        (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k);
   } else if (P->type == 'd' || P->type == 'g') {
-    PBC_DISPATCH_D(P, hipLaunchKernelGGL((d_prod_pairing_kernel<N, DEG>), dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
+    PBC_DISPATCH_D(P, hipLaunchKernelGGL((d_prod_pairing_kernel<N, DEG>), dim3(grid), dim3(kBlock), 0, s, kargs<N>(P), (uint8_t *) d_gt,
                                                 (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k));
   } else if (P->type == 'f') {
-    PBC_DISPATCH_F(P->nlimb, hipLaunchKernelGGL(f_prod_pairing_kernel<N>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
+    PBC_DISPATCH_F(P->nlimb, hipLaunchKernelGGL(f_prod_pairing_kernel<N>, dim3(grid), dim3(kBlock), 0, s, kargs<N>(P), (uint8_t *) d_gt,
                        (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k));
   } else {
     return fail("unsupported type");
@@ -1018,26 +1047,26 @@ static int run_group(pbc_hip_pairing_s *P, int what, int group, uint8_t *out, co
     lb = (size_t) P->len_zr;
   }
   DevBuf ba, bb, bo;
-  HIP_TRY(hipSetDevice(P->device));
+  DeviceGuard guard(P->device);
   HIP_TRY(ba.alloc(n * la));
   HIP_TRY(bb.alloc(n * lb));
   HIP_TRY(bo.alloc(n * lo));
   void *da = ba.p, *db = bb.p, *d_o = bo.p;
   HIP_TRY(hipMemcpy(da, a, n * la, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(db, b, n * lb, hipMemcpyHostToDevice));
-  if (upload_constants(P, 0)) return 1;
+  if (ensure_derived(P, 0)) return 1;
   unsigned grid = (unsigned) ((n + kBlock - 1) / kBlock);
   if (what == 0 && group == 2 && (P->type == 'd' || P->type == 'g')) {
-    PBC_DISPATCH_D(P, hipLaunchKernelGGL((d_g2_mul_kernel<N, DEG>), dim3(grid), dim3(kBlock), 0, 0, (uint8_t *) d_o,
+    PBC_DISPATCH_D(P, hipLaunchKernelGGL((d_g2_mul_kernel<N, DEG>), dim3(grid), dim3(kBlock), 0, 0, kargs<N>(P), (uint8_t *) d_o,
                                          (const uint8_t *) da, (const uint8_t *) db, P->len_zr, n));
   } else if (what == 0 && group == 2 && P->type == 'f') {
-    PBC_DISPATCH_F(P->nlimb, hipLaunchKernelGGL(f_g2_mul_kernel<N>, dim3(grid), dim3(kBlock), 0, 0, (uint8_t *) d_o, (const uint8_t *) da,
+    PBC_DISPATCH_F(P->nlimb, hipLaunchKernelGGL(f_g2_mul_kernel<N>, dim3(grid), dim3(kBlock), 0, 0, kargs<N>(P), (uint8_t *) d_o, (const uint8_t *) da,
                        (const uint8_t *) db, P->len_zr, n));
   } else if (what == 0) {              // E(F_q): G1, and G2 of the symmetric types
-    PBC_DISPATCH_N(P->nlimb, hipLaunchKernelGGL(g_mul_kernel<N>, dim3(grid), dim3(kBlock), 0, 0, (uint8_t *) d_o,
+    PBC_DISPATCH_N(P->nlimb, hipLaunchKernelGGL(g_mul_kernel<N>, dim3(grid), dim3(kBlock), 0, 0, kargs<N>(P), (uint8_t *) d_o,
                                                 (const uint8_t *) da, (const uint8_t *) db, P->len_zr, n));
   } else {
-    PBC_DISPATCH_N(P->nlimb, hipLaunchKernelGGL(gt_op_kernel<N>, dim3(grid), dim3(kBlock), 0, 0, P->type, what - 1,
+    PBC_DISPATCH_N(P->nlimb, hipLaunchKernelGGL(gt_op_kernel<N>, dim3(grid), dim3(kBlock), 0, 0, kargs<N>(P), P->type, what - 1,
                                                 (uint8_t *) d_o, (const uint8_t *) da, (const uint8_t *) db, P->lenT,
                                                 P->len_zr, n));
   }
@@ -1065,7 +1094,7 @@ extern "C" int pbc_hip_element_pow_zn_GT_batch(pbc_hip_pairing_t *P, uint8_t *ou
 // Tonelli-Shanks tail on the device (single lane)
 static int ensure_sqrt_constants(pbc_hip_pairing_s *P) {
   if (!P->hash.ts_ready) {
-    if (upload_constants(P, 0)) return 1;
+    if (ensure_derived(P, 0)) return 1;
     DevBuf bc;
     TsRaw raw;
     memcpy(raw.t, P->hash.ts_t, sizeof raw.t);
@@ -1075,7 +1104,7 @@ static int ensure_sqrt_constants(pbc_hip_pairing_s *P) {
     HIP_TRY(bc.alloc(sizeof P->hash.ts_c));
     uint32_t *dc = bc.as<uint32_t>();
     HIP_TRY(hipMemset(dc, 0, sizeof P->hash.ts_c));
-    PBC_DISPATCH_N(P->nlimb, hipLaunchKernelGGL(ts_init_kernel<N>, dim3(1), dim3(64), 0, 0, dc, raw));
+    PBC_DISPATCH_N(P->nlimb, hipLaunchKernelGGL(ts_init_kernel<N>, dim3(1), dim3(64), 0, 0, kargs<N>(P), dc, raw));
     HIP_TRY(hipMemcpy(P->hash.ts_c, dc, sizeof P->hash.ts_c, hipMemcpyDeviceToHost));
     P->hash.ts_ready = true;
   }
@@ -1090,12 +1119,12 @@ static int ensure_sqrt_constants(pbc_hip_pairing_s *P) {
 // z^T for the square roots in the twist's field, once per parameter set
 static int ensure_ext_sqrt(pbc_hip_pairing_s *P) {
   if (!P->xs_ready) {
-    if (upload_constants(P, 0)) return 1;
+    if (ensure_derived(P, 0)) return 1;
     DevBuf bc;
     HIP_TRY(bc.alloc(sizeof P->xs.c));
     uint32_t *dc = bc.as<uint32_t>();
     HIP_TRY(hipMemset(dc, 0, sizeof P->xs.c));
-    PBC_DISPATCH_TWIST(P, hipLaunchKernelGGL(ext_ts_init_kernel<F>, dim3(1), dim3(64), 0, 0, dc));
+    PBC_DISPATCH_TWIST(P, hipLaunchKernelGGL(ext_ts_init_kernel<F>, dim3(1), dim3(64), 0, 0, kargs<F::NW>(P), dc));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(P->xs.c, dc, sizeof P->xs.c, hipMemcpyDeviceToHost));
     P->xs_ready = true;
@@ -1108,16 +1137,16 @@ static int run_twist_points(pbc_hip_pairing_s *P, int what, uint8_t *out, const 
   const size_t li = what == 0 ? (size_t) hlen : (what == 1 || what == 3) ? lp : what == 2 ? lc : lx;
   const size_t lo = what == 1 ? lc : what == 3 ? lx : lp;
   DevBuf bi, bo;
-  HIP_TRY(hipSetDevice(P->device));
+  DeviceGuard guard(P->device);
   if (ensure_ext_sqrt(P)) return 1;
   if (P->type == 'f' && ensure_sqrt_constants(P)) return 1;   // fq_sqrt works through square roots in F_q
   HIP_TRY(bi.alloc(n * li));
   HIP_TRY(bo.alloc(n * lo));
   void *di = bi.p, *d_o = bo.p;
   HIP_TRY(hipMemcpy(di, in, n * li, hipMemcpyHostToDevice));
-  if (upload_constants(P, 0)) return 1;
+  if (ensure_derived(P, 0)) return 1;
   unsigned grid = (unsigned) ((n + kBlock - 1) / kBlock);
-  PBC_DISPATCH_TWIST(P, hipLaunchKernelGGL(g2_point_kernel<F>, dim3(grid), dim3(kBlock), 0, 0, what, (uint8_t *) d_o,
+  PBC_DISPATCH_TWIST(P, hipLaunchKernelGGL(g2_point_kernel<F>, dim3(grid), dim3(kBlock), 0, 0, kargs<F::NW>(P), what, (uint8_t *) d_o,
                                            (const uint8_t *) di, hlen, n));
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpy(out, d_o, n * lo, hipMemcpyDeviceToHost));
@@ -1134,15 +1163,15 @@ static int run_compress(pbc_hip_pairing_s *P, int dir, int group, uint8_t *out, 
   const size_t lp = (size_t) P->len1, lc = (size_t) P->len_fq + (dir < 2 ? 1 : 0);
   const size_t li = (dir & 1) == 0 ? lp : lc, lo = (dir & 1) == 0 ? lc : lp;
   DevBuf bi, bo;
-  HIP_TRY(hipSetDevice(P->device));
+  DeviceGuard guard(P->device);
   if (ensure_sqrt_constants(P)) return 1;
   HIP_TRY(bi.alloc(n * li));
   HIP_TRY(bo.alloc(n * lo));
   void *di = bi.p, *d_o = bo.p;
   HIP_TRY(hipMemcpy(di, in, n * li, hipMemcpyHostToDevice));
-  if (upload_constants(P, 0)) return 1;
+  if (ensure_derived(P, 0)) return 1;
   unsigned grid = (unsigned) ((n + kBlock - 1) / kBlock);
-  PBC_DISPATCH_N(P->nlimb, hipLaunchKernelGGL(g_compress_kernel<N>, dim3(grid), dim3(kBlock), 0, 0, dir, (uint8_t *) d_o,
+  PBC_DISPATCH_N(P->nlimb, hipLaunchKernelGGL(g_compress_kernel<N>, dim3(grid), dim3(kBlock), 0, 0, kargs<N>(P), dir, (uint8_t *) d_o,
                                               (const uint8_t *) di, n));
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpy(out, d_o, n * lo, hipMemcpyDeviceToHost));
@@ -1182,15 +1211,15 @@ extern "C" int pbc_hip_element_from_hash_batch(pbc_hip_pairing_t *P, int group, 
     return run_twist_points(P, 0, out, data, hlen, n);
   }
   DevBuf bd, bo;
-  HIP_TRY(hipSetDevice(P->device));
+  DeviceGuard guard(P->device);
   if (ensure_sqrt_constants(P)) return 1;
   HIP_TRY(bd.alloc(n * (size_t) hlen));
   HIP_TRY(bo.alloc(n * (size_t) P->len1));
   void *dd = bd.p, *d_o = bo.p;
   HIP_TRY(hipMemcpy(dd, data, n * (size_t) hlen, hipMemcpyHostToDevice));
-  if (upload_constants(P, 0)) return 1;
+  if (ensure_derived(P, 0)) return 1;
   unsigned grid = (unsigned) ((n + kBlock - 1) / kBlock);
-  PBC_DISPATCH_N(P->nlimb, hipLaunchKernelGGL(g_from_hash_kernel<N>, dim3(grid), dim3(kBlock), 0, 0, (uint8_t *) d_o,
+  PBC_DISPATCH_N(P->nlimb, hipLaunchKernelGGL(g_from_hash_kernel<N>, dim3(grid), dim3(kBlock), 0, 0, kargs<N>(P), (uint8_t *) d_o,
                                               (const uint8_t *) dd, hlen, n));
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpy(out, d_o, n * (size_t) P->len1, hipMemcpyDeviceToHost));
@@ -1202,7 +1231,6 @@ struct pbc_hip_pp_s {
   pbc_hip_pairing_s *P;
   uint32_t *tab;      // device: type a [exp2 + 1][3][16] words; types d / g [steps][3][ND] words
   uint32_t *valid;    // device flag: first argument was a finite curve point
-  bool d_lazy;        // experiment: table in the signed-limb form of pairing_d_lazy.cuh ([steps][3][6] words)
 };
 extern "C" int pbc_hip_pairing_pp_init(pbc_hip_pp_t **out, pbc_hip_pairing_t *P, const uint8_t *g1) {
   if (!out || !P || !g1) return fail("null argument");
@@ -1217,8 +1245,7 @@ extern "C" int pbc_hip_pairing_pp_init(pbc_hip_pp_t **out, pbc_hip_pairing_t *P,
   if (mnt) {                           // one entry per doubling and per addition of the Miller loop
     int steps = P->dconst.rbits - 1;
     for (int m = 1; m <= P->dconst.rbits - 2; m++) steps += (P->dconst.r[m >> 5] >> (m & 31)) & 1;
-    pp->d_lazy = P->type == 'd' && P->nlimb == 5 && d_lazy_selected();
-    words = (size_t) steps * 3 * (pp->d_lazy ? 6 : P->nlimb);
+    words = (size_t) steps * 3 * (size_t) P->nlimb;
   }
   if (a1) {
     int steps = P->a.rbits - 1;
@@ -1227,21 +1254,19 @@ extern "C" int pbc_hip_pairing_pp_init(pbc_hip_pp_t **out, pbc_hip_pairing_t *P,
   }
   if (hipSetDevice(P->device) != hipSuccess || hipMalloc(&pp->tab, words * 4) != hipSuccess ||
       hipMalloc(&pp->valid, 4) != hipSuccess || hipMalloc(&dg1, P->len1) != hipSuccess ||
-      hipMemcpy(dg1, g1, P->len1, hipMemcpyHostToDevice) != hipSuccess || upload_constants(P, 0)) {
+      hipMemcpy(dg1, g1, P->len1, hipMemcpyHostToDevice) != hipSuccess || ensure_derived(P, 0)) {
     delete pp;
     return fail("pairing_pp_init: device setup failed");
   }
-  if (mnt && pp->d_lazy) {
-    hipLaunchKernelGGL(d_lazy_pp_init_kernel<5>, dim3(1), dim3(64), 0, 0, pp->tab, pp->valid, (const uint8_t *) dg1);
-  } else if (mnt) {
-    PBC_DISPATCH_D(P, hipLaunchKernelGGL((d_pp_init_kernel<N, DEG>), dim3(1), dim3(64), 0, 0, pp->tab, pp->valid,
+  if (mnt) {
+    PBC_DISPATCH_D(P, hipLaunchKernelGGL((d_pp_init_kernel<N, DEG>), dim3(1), dim3(64), 0, 0, kargs<N>(P), pp->tab, pp->valid,
                                          (const uint8_t *) dg1));
   } else if (a1 && P->nlimb == 16) {
-    hipLaunchKernelGGL(a1_pp_init_kernel<16>, dim3(1), dim3(64), 0, 0, pp->tab, pp->valid, (const uint8_t *) dg1);
+    hipLaunchKernelGGL(a1_pp_init_kernel<16>, dim3(1), dim3(64), 0, 0, kargs<16>(P), pp->tab, pp->valid, (const uint8_t *) dg1);
   } else if (a1) {
-    hipLaunchKernelGGL(a1_pp_init_kernel<33>, dim3(1), dim3(64), 0, 0, pp->tab, pp->valid, (const uint8_t *) dg1);
+    hipLaunchKernelGGL(a1_pp_init_kernel<33>, dim3(1), dim3(64), 0, 0, kargs<33>(P), pp->tab, pp->valid, (const uint8_t *) dg1);
   } else {
-    hipLaunchKernelGGL(a_pp_init_kernel<16>, dim3(1), dim3(64), 0, 0, pp->tab, pp->valid, (const uint8_t *) dg1);
+    hipLaunchKernelGGL(a_pp_init_kernel<16>, dim3(1), dim3(64), 0, 0, kargs<16>(P), pp->tab, pp->valid, (const uint8_t *) dg1);
   }
   hipError_t e = hipDeviceSynchronize();
   (void) hipFree(dg1);
@@ -1259,22 +1284,20 @@ extern "C" int pbc_hip_pairing_pp_apply_batch_dev(pbc_hip_pp_t *pp, void *d_gt, 
   if (!pp) return fail("null pp");
   if (!n) return 0;
   hipStream_t s = (hipStream_t) stream;
-  if (upload_constants(pp->P, s)) return 1;
+  pbc_hip_pairing_s *P = pp->P;
+  if (ensure_derived(P, s)) return 1;
   unsigned grid = (unsigned) ((n + kBlock - 1) / kBlock);
   if (pp->P->type == 'a' && !pp->P->a_generic) {
-    hipLaunchKernelGGL(a_pp_apply_kernel<16>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt, pp->tab, pp->valid,
+    hipLaunchKernelGGL(a_pp_apply_kernel<16>, dim3(grid), dim3(kBlock), 0, s, kargs<16>(P), (uint8_t *) d_gt, pp->tab, pp->valid,
                        (const uint8_t *) d_g2, n);
   } else if (pp->P->nlimb == 16 && (pp->P->type == 'a' || pp->P->type == '1')) {
-    hipLaunchKernelGGL(a1_pp_apply_kernel<16>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt, pp->tab, pp->valid,
+    hipLaunchKernelGGL(a1_pp_apply_kernel<16>, dim3(grid), dim3(kBlock), 0, s, kargs<16>(P), (uint8_t *) d_gt, pp->tab, pp->valid,
                        (const uint8_t *) d_g2, n);
   } else if (pp->P->type == '1' || pp->P->type == 'a') {
-    hipLaunchKernelGGL(a1_pp_apply_kernel<33>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt, pp->tab, pp->valid,
-                       (const uint8_t *) d_g2, n);
-  } else if (pp->d_lazy) {
-    hipLaunchKernelGGL(d_lazy_pp_apply_kernel<5>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt, pp->tab, pp->valid,
+    hipLaunchKernelGGL(a1_pp_apply_kernel<33>, dim3(grid), dim3(kBlock), 0, s, kargs<33>(P), (uint8_t *) d_gt, pp->tab, pp->valid,
                        (const uint8_t *) d_g2, n);
   } else {
-    PBC_DISPATCH_D(pp->P, hipLaunchKernelGGL((d_pp_apply_kernel<N, DEG>), dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
+    PBC_DISPATCH_D(pp->P, hipLaunchKernelGGL((d_pp_apply_kernel<N, DEG>), dim3(grid), dim3(kBlock), 0, s, kargs<N>(P), (uint8_t *) d_gt,
                                              pp->tab, pp->valid, (const uint8_t *) d_g2, n));
   }
   HIP_TRY(hipGetLastError());
@@ -1285,7 +1308,7 @@ extern "C" int pbc_hip_pairing_pp_apply_batch(pbc_hip_pp_t *pp, uint8_t *gt, con
   if (!n) return 0;
   pbc_hip_pairing_s *P = pp->P;
   DevBuf b2, bt;
-  HIP_TRY(hipSetDevice(P->device));
+  DeviceGuard guard(P->device);
   HIP_TRY(b2.alloc(n * P->len2));
   HIP_TRY(bt.alloc(n * P->lenT));
   HIP_TRY(hipMemcpy(b2.p, g2, n * P->len2, hipMemcpyHostToDevice));
@@ -1301,7 +1324,7 @@ extern "C" int pbc_hip_diag_stage(pbc_hip_pairing_t *P, int stage, uint8_t *out,
   if (!P) return fail("null pairing");
   if (P->device < 0) return fail("no HIP device: libpbc_hip has no CPU fallback");
   if (stage == 0) {
-    if (upload_constants(P, 0)) return 1;
+    if (ensure_derived(P, 0)) return 1;
     HIP_TRY(hipDeviceSynchronize());
     const void *src = (P->type == 'd' || P->type == 'g') ? (const void *) &P->dconst : P->type == 'f' ? (const void *) &P->fconst : (const void *) &P->a;
     size_t len = (P->type == 'd' || P->type == 'g') ? sizeof P->dconst : P->type == 'f' ? sizeof P->fconst : sizeof P->a;
@@ -1315,9 +1338,9 @@ extern "C" int pbc_hip_diag_stage(pbc_hip_pairing_t *P, int stage, uint8_t *out,
     HIP_TRY(hipMalloc(&dt, n * P->lenT));
     HIP_TRY(hipMemcpy(d1, g1, n * P->len1, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d2, g2, n * P->len2, hipMemcpyHostToDevice));
-    if (upload_constants(P, 0)) return 1;
+    if (ensure_derived(P, 0)) return 1;
     unsigned grid = (unsigned) ((n + kBlock - 1) / kBlock);
-    PBC_DISPATCH_F(P->nlimb, hipLaunchKernelGGL(f_prod_pairing_kernel<N>, dim3(grid), dim3(kBlock), 0, 0, (uint8_t *) dt,
+    PBC_DISPATCH_F(P->nlimb, hipLaunchKernelGGL(f_prod_pairing_kernel<N>, dim3(grid), dim3(kBlock), 0, 0, kargs<N>(P), (uint8_t *) dt,
                        (const uint8_t *) d1, (const uint8_t *) d2, n, -1));
     HIP_TRY(hipMemcpy(out, dt, n * P->lenT < out_len ? n * P->lenT : out_len, hipMemcpyDeviceToHost));
     (void) hipFree(d1); (void) hipFree(d2); (void) hipFree(dt);
@@ -1331,9 +1354,9 @@ extern "C" int pbc_hip_diag_stage(pbc_hip_pairing_t *P, int stage, uint8_t *out,
     HIP_TRY(hipMalloc(&dt, bytes));
     HIP_TRY(hipMemcpy(d1, g1, bytes, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d2, g2, bytes, hipMemcpyHostToDevice));
-    if (upload_constants(P, 0)) return 1;
+    if (ensure_derived(P, 0)) return 1;
     unsigned grid = (unsigned) ((n + kBlock - 1) / kBlock);
-    PBC_DISPATCH_F(P->nlimb, hipLaunchKernelGGL(f_debug_kernel<N>, dim3(grid), dim3(kBlock), 0, 0, stage, (uint8_t *) dt, (const uint8_t *) d1,
+    PBC_DISPATCH_F(P->nlimb, hipLaunchKernelGGL(f_debug_kernel<N>, dim3(grid), dim3(kBlock), 0, 0, kargs<N>(P), stage, (uint8_t *) dt, (const uint8_t *) d1,
                        (const uint8_t *) d2, n));
     HIP_TRY(hipMemcpy(out, dt, bytes < out_len ? bytes : out_len, hipMemcpyDeviceToHost));
     (void) hipFree(d1); (void) hipFree(d2); (void) hipFree(dt);
@@ -1350,7 +1373,7 @@ extern "C" int pbc_hip_fq_op_batch(pbc_hip_pairing_t *P, int op, uint8_t *c, con
   if (op < 0 || op > 6) return fail("bad op");
   size_t bytes = n * (size_t) P->len_fq;
   DevBuf ba, bb, bc;
-  HIP_TRY(hipSetDevice(P->device));
+  DeviceGuard guard(P->device);
   HIP_TRY(ba.alloc(bytes));
   HIP_TRY(bc.alloc(bytes));
   void *da = ba.p, *db = nullptr, *dc = bc.p;
@@ -1360,9 +1383,9 @@ extern "C" int pbc_hip_fq_op_batch(pbc_hip_pairing_t *P, int op, uint8_t *c, con
     db = bb.p;
     HIP_TRY(hipMemcpy(db, b, bytes, hipMemcpyHostToDevice));
   }
-  if (upload_constants(P, 0)) return 1;
+  if (ensure_derived(P, 0)) return 1;
   unsigned grid = (unsigned) ((n + kBlock - 1) / kBlock);
-  PBC_DISPATCH_N(P->nlimb, hipLaunchKernelGGL(fq_op_kernel<N>, dim3(grid), dim3(kBlock), 0, 0, op, (uint8_t *) dc,
+  PBC_DISPATCH_N(P->nlimb, hipLaunchKernelGGL(fq_op_kernel<N>, dim3(grid), dim3(kBlock), 0, 0, kargs<N>(P), op, (uint8_t *) dc,
                                               (const uint8_t *) da, (const uint8_t *) db, n));
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpy(c, dc, bytes, hipMemcpyDeviceToHost));
@@ -1412,9 +1435,15 @@ static int run_mul_bench(int iters, int waves_per_simd, double *rate, double *ms
   hipEvent_t e0, e1;
   HIP_TRY(hipEventCreate(&e0));
   HIP_TRY(hipEventCreate(&e1));
-  hipLaunchKernelGGL((mul_bench_kernel<16, V>), dim3(grid), dim3(256), 0, 0, out, in, iters / 8 + 1);
+  KArgs<16> K;                         // any odd modulus will do: the instruction stream does not depend on the data
+  memset(&K, 0, sizeof K);
+  for (int i = 0; i < 16; i++) K.fp.p[i] = K.fp.one[i] = K.fp.r2[i] = K.fp.r3[i] = 0x9e3779b1u + 2u * (uint32_t) i;
+  for (int i = 0; i < Limbs29<16>::L; i++) K.fp.p29[i] = (0x12345679u + 2u * (uint32_t) i) & Limbs29<16>::MASK;
+  for (int i = 0; i < Inv30<16>::L; i++) K.fp.p30[i] = (0x2468ace1u + 2u * (uint32_t) i) & 0x3fffffffu;
+  K.fp.ninv29 = 0x0badcafu; K.fp.qinv30 = 0x1234567u; K.fp.fbytes = 64; K.fp.pbits = 512;
+  hipLaunchKernelGGL((mul_bench_kernel<16, V>), dim3(grid), dim3(256), 0, 0, K, out, in, iters / 8 + 1);
   HIP_TRY(hipEventRecord(e0, 0));
-  hipLaunchKernelGGL((mul_bench_kernel<16, V>), dim3(grid), dim3(256), 0, 0, out, in, iters);
+  hipLaunchKernelGGL((mul_bench_kernel<16, V>), dim3(grid), dim3(256), 0, 0, K, out, in, iters);
   HIP_TRY(hipEventRecord(e1, 0));
   HIP_TRY(hipEventSynchronize(e1));
   float ms;
@@ -1430,7 +1459,6 @@ static int run_mul_bench(int iters, int waves_per_simd, double *rate, double *ms
 extern "C" int pbc_hip_diag_mul_bench(int variant, int iters, int waves_per_simd, double *rate, double *ms) {
   if (waves_per_simd < 1 || waves_per_simd > 8) return fail("waves_per_simd must be 1..8");
   switch (variant) {
-    case 0: return run_mul_bench<0>(iters, waves_per_simd, rate, ms);
     case 1: return run_mul_bench<1>(iters, waves_per_simd, rate, ms);
     case 2: return run_mul_bench<2>(iters, waves_per_simd, rate, ms);
     case 3: return run_mul_bench<3>(iters, waves_per_simd, rate, ms);
@@ -1462,6 +1490,8 @@ extern "C" int pbc_hip_int_mac_peak(int variant, int iters, double *rate, double
     case 11: return run_probe<11>(iters, rate, ms, 64);
     case 12: return run_probe<12>(iters, rate, ms, 64);
     case 13: return run_probe<13>(iters, rate, ms, 64);
+    case 14: return run_probe<14>(iters, rate, ms, 64);
+    case 15: return run_probe<15>(iters, rate, ms, 64);
     default: return fail("unknown probe variant %d", variant);
   }
 }

@@ -39,8 +39,13 @@ class HostSim:
         L.hostsim_lens(self.h, ctypes.byref(a), ctypes.byref(b2), ctypes.byref(c))
         self.len1, self.len2, self.lenT = a.value, b2.value, c.value
 
-    def prod_pairing(self, g1, g2, k=1, d_lazy=False):
-        self.L.hostsim_select_d_lazy(1 if d_lazy else 0)
+    def macs(self, reset=False):
+        """multiply-adds (32 x 32 + 64 bit) the kernel source has executed since the last reset"""
+        self.L.hostsim_macs_read.restype = ctypes.c_uint64
+        self.L.hostsim_macs_read.argtypes = [ctypes.c_int]
+        return int(self.L.hostsim_macs_read(1 if reset else 0))
+
+    def prod_pairing(self, g1, g2, k=1):
         g1 = np.ascontiguousarray(g1, np.uint8)
         g2 = np.ascontiguousarray(g2, np.uint8)
         n = g1.size // (self.len1 * k)
@@ -48,8 +53,7 @@ class HostSim:
         self.L.hostsim_prod_pairing(self.h, out.ctypes.data, g1.ctypes.data, g2.ctypes.data, n, k)
         return out
 
-    def pp(self, g1, g2, d_lazy=False):
-        self.L.hostsim_select_d_lazy(1 if d_lazy else 0)
+    def pp(self, g1, g2):
         g1 = np.ascontiguousarray(g1, np.uint8)
         g2 = np.ascontiguousarray(g2, np.uint8)
         n = g2.size // self.len2

@@ -6,13 +6,6 @@
 
 // "upload" the constants before every call (as upload_constants does on the GPU): on the host
 // the __constant__ objects are plain globals shared by all parameter sets
-static void set_fpk(pbc_hip_pairing_s *P) {
-  switch (P->nlimb) {
-#define HS_UP(n) case n: c_fpk##n = P->k##n; break;
-    PBC_FOR_EACH_N(HS_UP)
-#undef HS_UP
-  }
-}
 // run EXPR with N = the compile-time word count matching P->nlimb
 #define HS_DISPATCH(nl, ...)                          \
   switch (nl) {                                       \
@@ -37,22 +30,12 @@ static void set_fpk(pbc_hip_pairing_s *P) {
     case 7 * 8 + 3: { constexpr int N = 7, DEG = 3; __VA_ARGS__; } break;     \
     case 5 * 8 + 5: { constexpr int N = 5, DEG = 5; __VA_ARGS__; } break;     \
   }
+// the object's constants into the block the kernel source reads (what a launch passes as KArgs<N> on the GPU)
 static void activate(pbc_hip_pairing_s *P) {
-  set_fpk(P);
-  if (P->type == 'a' || P->type == '1') c_a = P->a;
-  if (P->type == 'd' || P->type == 'g') c_d = P->dconst;
-  if (P->type == 'f') c_f = P->fconst;
-  if (P->type == 'e') c_e = P->econst;
-  CurveK C;
-  fill_curve(P, C);
-  c_curve = C;
+  HS_DISPATCH(P->nlimb, { KArgs<N> K; fill_kargs<N>(P, K); memcpy(hostsim_kargs, &K, sizeof K); });
 }
 
 extern "C" {
-
-// experiment switch: route 5-word type d pairings through pairing_d_lazy.cuh (with its bound checks)
-static int g_d_lazy = 0;
-void hostsim_select_d_lazy(int on) { g_d_lazy = on; }
 
 void *hostsim_init(const char *param, size_t len) {
   std::string type;
@@ -66,33 +49,36 @@ void *hostsim_init(const char *param, size_t len) {
   else if (type == "g") { P->type = 'g'; rc = init_type_d(P, param, len, 5); }
   else if (type == "f") { P->type = 'f'; rc = init_type_f(P, param, len); }
   if (rc) { delete P; return nullptr; }
-  set_fpk(P);
+  activate(P);
+  // the device-side derivations of the library, stage by stage (each stage sees the previous one's constants)
   if (P->type == 'd' || P->type == 'g') {
     DConst tmp;
-    HS_DISPATCH_D(P, TypeMNT<N, DEG>::init_stage1(&tmp, P->draw, P->dconst));
-    c_d = tmp;
+    HS_DISPATCH_D(P, TypeMNT<N, DEG>::init_stage1(&tmp, P->draw, c_d));
+    P->dconst = tmp;
+    activate(P);
     HS_DISPATCH_D(P, TypeMNT<N, DEG>::init_stage2(&tmp, P->draw));
-    c_d = tmp;
     P->dconst = tmp;
   }
   if (P->type == 'e') {
     EConst tmp;
-    if (P->nlimb == 16) e_init_kernel<16>(&tmp, P->eraw, P->econst);
-    else e_init_kernel<33>(&tmp, P->eraw, P->econst);
+    if (P->nlimb == 16) e_init_lane<16>(&tmp, P->eraw, c_e);
+    else e_init_lane<33>(&tmp, P->eraw, c_e);
     P->econst = tmp;
-    c_e = tmp;
   }
   if (P->type == 'f') {
     FConst tmp;
-    HS_DISPATCH_F(P->nlimb, TypeF<N>::init_stage1(&tmp, P->fraw, P->fconst));
-    c_f = tmp;
+    HS_DISPATCH_F(P->nlimb, TypeF<N>::init_stage1(&tmp, P->fraw, c_f));
+    P->fconst = tmp;
+    activate(P);
     HS_DISPATCH_F(P->nlimb, TypeF<N>::init_stage2(&tmp, P->fraw));
-    c_f = tmp;
     P->fconst = tmp;
   }
+  activate(P);
   return P;
 }
 const char *hostsim_error() { return g_err; }
+// multiply-adds executed by the kernel source since the last reset (PBC_COUNT_MACS hooks of fp.cuh)
+uint64_t hostsim_macs_read(int reset) { uint64_t v = hostsim_macs; if (reset) hostsim_macs = 0; return v; }
 int hostsim_lens(void *h, int *l1, int *l2, int *lt) {
   pbc_hip_pairing_s *P = (pbc_hip_pairing_s *) h;
   *l1 = P->len1; *l2 = P->len2; *lt = P->lenT;
@@ -103,8 +89,6 @@ int hostsim_prod_pairing(void *h, uint8_t *gt, const uint8_t *g1, const uint8_t 
   pbc_hip_pairing_s *P = (pbc_hip_pairing_s *) h;
   activate(P);
   static uint32_t lds[2 * 33];
-  const bool d_lazy = P->type == 'd' && P->nlimb == 5 && g_d_lazy;
-  if (d_lazy) { DLazyConst tmp; LazyD<5>::init(&tmp); c_dl = tmp; }
   for (size_t u = 0; u < n; u++) {
     const uint8_t *a = g1 + u * k * P->len1, *b = g2 + u * k * P->len2;
     uint8_t *o = gt + u * P->lenT;
@@ -113,7 +97,6 @@ int hostsim_prod_pairing(void *h, uint8_t *gt, const uint8_t *g1, const uint8_t 
     else if (P->type == '1' || P->type == 'a') a1_prod_pairing_lane<33>(o, a, b, k, lds, 1);
     else if (P->type == 'e' && P->nlimb == 16) e_prod_pairing_lane<16>(o, a, b, k, lds, 1);
     else if (P->type == 'e') e_prod_pairing_lane<33>(o, a, b, k, lds, 1);
-    else if (d_lazy) LazyD<5>::prod_pairing_lane(o, a, b, k);
     else if (P->type == 'd' || P->type == 'g') { HS_DISPATCH_D(P, TypeMNT<N, DEG>::d_prod_pairing_lane(o, a, b, k)); }
     else { HS_DISPATCH_F(P->nlimb, TypeF<N>::f_prod_pairing_lane(o, a, b, k)); }
   }
@@ -124,13 +107,6 @@ int hostsim_pp(void *h, uint8_t *gt, const uint8_t *g1, const uint8_t *g2, size_
   pbc_hip_pairing_s *P = (pbc_hip_pairing_s *) h;
   activate(P);
   static uint32_t tab[512 * 3 * 16];
-  if (P->type == 'd' && P->nlimb == 5 && g_d_lazy) {
-    static int32_t ltab[512 * 3 * 6];
-    DLazyConst tmp; LazyD<5>::init(&tmp); c_dl = tmp;
-    bool v = LazyD<5>::pp_init_lane(ltab, g1);
-    for (size_t u = 0; u < n; u++) LazyD<5>::pp_apply_lane(gt + u * P->lenT, ltab, v, g2 + u * P->len2);
-    return 0;
-  }
   if (P->type == 'd' || P->type == 'g') {
     HS_DISPATCH_D(P, {
       bool v = TypeMNT<N, DEG>::d_pp_init_lane(tab, g1);
@@ -184,17 +160,15 @@ int hostsim_g2_points(void *h, int what, uint8_t *out, const uint8_t *in, int hl
   pbc_hip_pairing_s *P = (pbc_hip_pairing_s *) h;
   if (P->type != 'd' && P->type != 'g' && P->type != 'f') return 1;
   activate(P);
-  c_xs = P->xs;
   if (!P->xs_ready) {
     HS_DISPATCH_TWIST(P, ext_ts_init<F>(P->xs.c));
     P->xs_ready = true;
-    c_xs = P->xs;
+    activate(P);
   }
   if (P->type == 'f' && !P->hash.ts_ready) {             // fq_sqrt goes through square roots in F_q
     HS_DISPATCH(P->nlimb, fp_ts_init<N>(P->hash.ts_c, P->hash.ts_t, P->hash.ts_tbits, P->hash.half, P->hash.halfbits));
     P->hash.ts_ready = true;
     activate(P);
-    c_xs = P->xs;
   }
   const size_t lp = P->len2, lc = lp / 2 + 1, lx = lp / 2;
   const size_t li = what == 0 ? (size_t) hlen : (what == 1 || what == 3) ? lp : what == 2 ? lc : lx;

@@ -19,3 +19,10 @@ static inline int __all(int p) { return p; }      // one lane per call: the "wav
 static inline uint32_t __builtin_amdgcn_alignbit(uint32_t hi, uint32_t lo, uint32_t s) {
   return (uint32_t) (((((uint64_t) hi) << 32) | lo) >> (s & 31));
 }
+// executed multiply-adds of everything run since the last reset (fp.cuh reports them through this hook)
+static uint64_t hostsim_macs = 0;
+#define PBC_COUNT_MACS(n) (hostsim_macs += (uint64_t) (n))
+// the constant block the kernels read through the kernel argument segment on the GPU (fp.cuh, "KArgs"): here a
+// host buffer that hostsim.cpp fills before each call
+alignas(16) static uint8_t hostsim_kargs[4096];
+static inline const uint8_t *pbc_kargs_base() { return hostsim_kargs; }

@@ -709,20 +709,6 @@ def test_bls_sign_verify_batch_on_gpu(hip_a, oracle_a):
     assert np.array_equal(h[:2], oracle_a.g_mul(1, h[:2], np.tile(_be(1, 20), (2, 1))))   # valid curve points
 
 
-@pytest.mark.skipif(__import__("os").environ.get("PBC_TEST_EXPERIMENTAL") != "1",
-                    reason="experiment not yet run on a GPU: PBC_TEST_EXPERIMENTAL=1 enables it")
-def test_type_d_signed_limb_experiment_on_gpu():
-    """pairing_d_lazy.cuh behind PBC_HIP_D_LAZY=1 (validated on the host mirror only so far): parity and A/B timing
-    in fresh processes, see tools/d_lazy_ab.py"""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, os.path.join(root, "tools", "d_lazy_ab.py"), "16"], capture_output=True, text=True, timeout=1200)
-    print(out.stdout)
-    assert out.returncode == 0, out.stdout + out.stderr
-
-
 @pytest.mark.parametrize("key,name,exact", XONLY)
 def test_x_only_points_match_reference(hips, key, name, exact):
     """element_to_bytes_x_only / element_from_bytes_x_only (ecc/curve.c:821-836) on G1"""
@@ -811,3 +797,99 @@ def test_twist_hashing_and_compression_on_fresh_digests_vs_oracle(hips, oracles,
     c = H.element_to_bytes_compressed(2, pts)
     assert np.array_equal(c, O.point_format_g2(0, pts))
     assert np.array_equal(H.element_from_bytes_compressed(2, c), pts)
+
+
+# ---- inputs outside the order-r subgroup: curve_from_bytes (ecc/curve.c:609-623) accepts every point of the curve ----
+WHOLE_CURVE = ["a_full12.vec", "a_prodfull3x4.vec", "d159_full12.vec", "d159_prodfull3x4.vec", "g149_full12.vec",
+               "g149_prodfull3x4.vec", "f_full12.vec", "f_prodfull3x4.vec", "a1_full4.vec", "a1_prodfull3x4.vec", "d224_full8.vec"]
+
+
+@pytest.mark.parametrize("name", WHOLE_CURVE)
+def test_whole_curve_points_match_reference(hips, oracles, name):
+    """Points generated WITHOUT the cofactor multiplication (ref_tool gen ... fullorder = curve_random_no_cofac_solvefory,
+    ecc/curve.c:405-422): they lie outside the order-r subgroup wherever the curve has a cofactor (a, a1, d, g; for f the
+    twist points).  The Jacobian Miller loops drop factors of F_q^* along the way; that argument must hold for these
+    inputs too.  Singles and products against the reference's outputs, then a cross product of the points against the
+    oracle.  (Type e is left out on purpose: for k = 1 the reference's value depends on the auxiliary point R it draws at
+    random when the pairing is initialised unless r P = O -- `ref_tool rdep e.param` shows two objects disagreeing.)"""
+    from conftest import key_of
+    v = golden(name)
+    key = key_of(name)
+    H, O = hips[key], oracles[key]
+    if v.k == 1:
+        assert np.array_equal(H.element_pairing(v.g1, v.g2), v.gt)
+        i, j = np.divmod(np.arange(min(v.n * v.n, 24)), v.n)
+        assert np.array_equal(H.element_pairing(v.g1[i], v.g2[j]), O.pairing_batch(v.g1[i], v.g2[j]))
+    else:
+        assert np.array_equal(H.element_prod_pairing(v.g1, v.g2, v.k), v.gt)
+        # the same terms with the subgroup fixture's points mixed in, against the oracle
+        assert np.array_equal(H.element_prod_pairing(v.g1[::-1], v.g2, v.k), O.prod_pairing_batch(v.g1[::-1], v.g2, v.k))
+
+
+@pytest.mark.parametrize("key,name,group", [("a", "a_g1mulfull6.vec", 1), ("a", "a_g2mulfull6.vec", 2), ("d", "d159_g1mulfull6.vec", 1),
+                                            ("g149", "g149_g1mulfull6.vec", 1), ("e", "e_g1mulfull6.vec", 1)])
+def test_scalar_multiplication_on_whole_curve_points(hips, key, name, group):
+    v = golden(name)
+    assert np.array_equal(hips[key].element_mul_zn(group, v.g1, v.g2), v.gt)
+
+
+def test_group_law_is_complete(hip_a, oracle_a):
+    """element_mul_zn on points of order 2, 3, 4, 6, 12 (type a: 12 | h) and with scalars >= r: the ladder meets
+    R = P (a doubling), R = -P and R = O; every case against the oracle's affine group law."""
+    v = golden("a_full12.vec")
+    pts = [oracle_a.g_mul(1, v.g1[:4], np.tile(_be((Q_A + 1) // m, 64), (4, 1))) for m in (2, 3, 4, 6, 12)]
+    P = np.concatenate(pts)
+    assert sum(bool(p.any()) for p in P) >= 8
+    for k in (0, 1, 2, 3, 4, 5, 6, 7, 11, 12, 13, R_A - 1, R_A, R_A + 1, R_A + 5, 2 ** 160 - 1):
+        Z = np.tile(_be(k, 20), (len(P), 1))
+        assert np.array_equal(hip_a.element_mul_zn(1, P, Z), oracle_a.g_mul(1, P, Z)), k
+    Z = np.stack([_be(R_A + 1000 * i + 7, 20) for i in range(12)])
+    assert np.array_equal(hip_a.element_mul_zn(1, v.g1, Z), oracle_a.g_mul(1, v.g1, Z))
+
+
+@pytest.mark.parametrize("key,name", [("a", "a_rand32.vec"), ("d", "d_rand32.vec"), ("f", "f_rand16.vec"), ("g149", "g149_rand16.vec"),
+                                      ("e", "e_rand6.vec"), ("a1", "a1_rand6.vec")])
+def test_all_zero_records_give_the_identity(hips, oracles, key, name):
+    """include/pbc_hip.h, "zero-filled records": an all-zero G1 / G2 record gives the GT identity in element_pairing,
+    forces a product to the identity, and is a fixed point of element_mul_zn.  (Zeros are what element_to_bytes writes
+    for O.  Where b != 0 they are off the curve, i.e. O again; on y^2 = x^3 + x (types a, a1) they are the 2-torsion
+    point (0, 0), whose pairing value is 1 as well because 2 is coprime to r -- the reference divides by zero there.)"""
+    v = golden(name)
+    H, O = hips[key], oracles[key]
+    n = 4
+    one = H.element_pairing(np.zeros((1, H.length_in_bytes_G1), np.uint8), v.g2[:1])[0]
+    assert np.array_equal(one, O.pairing_batch(np.zeros((1, H.length_in_bytes_G1), np.uint8), v.g2[:1])[0])
+    assert np.array_equal(H.element_mul_GT(one[None, :], v.gt[:1]), v.gt[:1])           # it IS the identity of GT
+    z1, z2 = np.zeros_like(v.g1[:n]), np.zeros_like(v.g2[:n])
+    for g1, g2 in ((z1, v.g2[:n]), (v.g1[:n], z2), (z1, z2)):
+        assert np.array_equal(H.element_pairing(g1, g2), np.tile(one, (n, 1)))
+    g1, g2 = v.g1[:n].copy(), v.g2[:n].copy()
+    g1[1] = 0                                              # unit 0 = terms 0, 1 holds a zero record; unit 1 = terms 2, 3 does not
+    got = H.element_prod_pairing(g1, g2, 2)
+    assert np.array_equal(got[0], one)
+    assert np.array_equal(got, O.prod_pairing_batch(g1, g2, 2)) and not np.array_equal(got[1], one)
+    zl = H.length_in_bytes_Zr
+    Z = np.tile(_be(5, zl), (n, 1))
+    assert not H.element_mul_zn(1, z1, Z).any()
+
+
+def test_bench_two_ranks_share_the_gpu(tmp_path):
+    """bench.py --gpus 2 under torch.distributed.run with both ranks on cuda:0 (PBC_BENCH_SAME_DEVICE=1) and gloo for the
+    barrier / clock: the multi-rank path of the benchmark (rank-0 build, range split, max-over-ranks clock, per-rank
+    kernel times) runs the HIP library before a driver launches it on 8 GPUs."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PBC_BENCH_SAME_DEVICE="1", PBC_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29531", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--log2n", "16"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["config"]["global_batch"] == 2 << 16
+    assert len(j["per_rank_kernel_ms"]) == 2 and all(x > 0 for x in j["per_rank_kernel_ms"])
+    assert j["value"] > 0 and j["scaling"] == "weak"

@@ -24,7 +24,10 @@ def sims():
     ("d_rand32.vec", 6), ("d_edge20.vec", 20), ("d_prod16x4.vec", 2), ("d_prod3x10_edge.vec", 10),
     ("f_rand16.vec", 3), ("f_edge10.vec", 10), ("f_prod3x5_edge.vec", 5),
 ] + [(name, 2 if d in ("a1", "e") else 4) for d in OTHER for name in FILES_OF[d]] + [("g149_prod4x3.vec", 1)]
-  + [(name, 2) for g in GENERIC_A + GENERIC_OTHER + GENERIC_F for name in (FILES_OF[g][0], FILES_OF[g][2])])
+  + [(name, 2) for g in GENERIC_A + GENERIC_OTHER + GENERIC_F for name in (FILES_OF[g][0], FILES_OF[g][2])]
+  # points of the whole curve, outside the order-r subgroup (ref_tool gen ... fullorder)
+  + [("a_full12.vec", 3), ("a_prodfull3x4.vec", 2), ("d159_full12.vec", 4), ("d159_prodfull3x4.vec", 2), ("g149_full12.vec", 2),
+     ("g149_prodfull3x4.vec", 1), ("f_full12.vec", 2), ("f_prodfull3x4.vec", 1), ("a1_full4.vec", 1), ("d224_full8.vec", 2)])
 def test_kernel_source_on_host_matches_reference(sims, name, count):
     v = golden(name)
     n = min(count, v.n)
@@ -129,6 +132,36 @@ def test_g1_scalar_multiplication_wide_fields_on_host(sims, key, name):
     assert np.array_equal(sims[key].group(0, v.g1, v.g2), v.gt)
 
 
+@pytest.mark.parametrize("key,name", [("a", "a_g1mulfull6.vec"), ("a", "a_g2mulfull6.vec"), ("d", "d159_g1mulfull6.vec"),
+                                      ("g149", "g149_g1mulfull6.vec"), ("e", "e_g1mulfull6.vec")])
+def test_scalar_multiplication_on_whole_curve_points_on_host(sims, key, name):
+    """element_mul_zn on points outside the order-r subgroup (curve_from_bytes accepts them) vs the reference"""
+    v = golden(name)
+    n = 2 if key == "e" else v.n
+    assert np.array_equal(sims[key].group(0, v.g1[:n], v.g2[:n]), v.gt[:n])
+
+
+def test_group_law_is_complete_on_host(sims, oracles):
+    """small-order points and scalars >= r: the double-and-add meets R = P (needs a doubling), R = -P and R = O.
+    Type a: #E = q + 1 = h r with 12 | h, so the curve has points of order 2, 3, 4, 6."""
+    S, O = sims["a"], oracles["a"]
+    q, r = param_value("a", "q"), param_value("a", "r")
+    v = golden("a_full12.vec")
+    be = lambda x, n: np.frombuffer(int(x).to_bytes(n, "big"), np.uint8)
+    pts = []
+    for m in (2, 3, 4, 6, 12):                             # T -> [(q+1)/m] T has order dividing m
+        e = np.tile(be((q + 1) // m, 64), (4, 1))
+        pts.append(O.g_mul(1, v.g1[:4], e))
+    P = np.concatenate(pts)                                # 20 points of small order (a few may be O)
+    assert any(p.any() for p in P)
+    for k in (0, 1, 2, 3, 4, 5, 6, 7, 11, 12, 13, r - 1, r, r + 1, r + 5, 2 ** 160 - 1):
+        Z = np.tile(be(k, 20), (len(P), 1))
+        assert np.array_equal(S.group(0, P, Z), O.g_mul(1, P, Z)), k
+    # whole-curve points with scalars in [r, 2^160)
+    Z = np.stack([be(r + 1000 * i + 7, 20) for i in range(6)])
+    assert np.array_equal(S.group(0, v.g1[:6], Z), O.g_mul(1, v.g1[:6], Z))
+
+
 COMPRESS = [("a", "a_compress12.vec"), ("d", "d159_compress12.vec"), ("d278027-190-181", "d278027-190-181_compress12.vec"),
             ("f", "f_compress12.vec"), ("g149", "g149_compress12.vec"), ("e", "e_compress4.vec")]
 
@@ -181,33 +214,6 @@ def test_fresh_points_kernel_source_vs_oracle(sims, oracles, key, name):
     assert np.array_equal(same, S.group(2, v.gt[:n], Z))
 
 
-@pytest.mark.parametrize("name", ["d_rand32.vec", "d_edge20.vec", "d_prod16x4.vec", "d_prod3x10_edge.vec"])
-def test_type_d_signed_limb_experiment_on_host(sims, name):
-    """pbc_amd/csrc/pairing_d_lazy.cuh (PBC_HIP_D_LAZY=1; signed 28-bit limbs, carries only where the bounds ask):
-    same bytes as the reference vectors.  The host build also carries the data-independent limb / magnitude
-    bounds through every operation and aborts the process if one is exceeded."""
-    v = golden(name)
-    out = sims["d"].prod_pairing(v.g1, v.g2, v.k, d_lazy=True)
-    assert np.array_equal(out, v.gt)
-
-
-def test_type_d_signed_limb_experiment_fresh_points(sims, oracles):
-    """inputs outside the fixtures (random multiples of their points, all-ones limbs cannot be forced through
-    curve points, so volume is the lever): 64 fresh pairings against the oracle"""
-    v = golden("d_rand32.vec")
-    S, O = sims["d"], oracles["d"]
-    r = param_value("d", "r")
-    zl = (r.bit_length() + 7) // 8
-    rng = np.random.default_rng(77)
-    n = 32
-    ks = [int.from_bytes(rng.bytes(zl), "big") % (r - 1) + 1 for _ in range(n)]
-    Z = np.stack([np.frombuffer(k.to_bytes(zl, "big"), np.uint8) for k in ks])
-    kP = O.g_mul(1, v.g1[:n], Z)
-    for shift in (1, 7):
-        g2 = np.roll(v.g2[:n], shift, axis=0)
-        assert np.array_equal(S.prod_pairing(kP, g2, 1, d_lazy=True), O.pairing_batch(kP, g2))
-
-
 @pytest.mark.parametrize("key,name,exact", XONLY)
 def test_x_only_points_on_host(sims, key, name, exact):
     """element_to_bytes_x_only / element_from_bytes_x_only (ecc/curve.c:821-836) vs the reference"""
@@ -236,41 +242,6 @@ def test_compressed_points_on_the_twists_on_host(sims, key, name):
     neg = S.g2_points(2, flipped)
     assert np.array_equal(neg[:, :v.len1 // 2], v.g1[:n, :v.len1 // 2]) and not np.array_equal(neg, v.g1[:n])
     assert np.array_equal(S.g2_points(1, neg), flipped)
-
-
-def test_type_d_signed_limb_experiment_pp_on_host(sims, oracles):
-    """pairing_pp_init / pairing_pp_apply on the signed-limb representation: same bytes as element_pairing;
-    an off-curve first argument gives the identity"""
-    v = golden("d_rand32.vec")
-    S = sims["d"]
-    for i in (0, 5):
-        P = v.g1[i]
-        Q = v.g2[:6].copy()
-        Q[5, -1] ^= 1                                       # one off-curve second argument
-        want = oracles["d"].pairing_batch(np.tile(P, (6, 1)), Q)
-        assert np.array_equal(S.pp(P, Q, d_lazy=True), want)
-    bad = v.g1[2].copy(); bad[3] ^= 4
-    one = np.zeros(S.lenT, np.uint8); one[S.len1 // 2 - 1] = 1
-    assert np.array_equal(S.pp(bad, v.g2[:3], d_lazy=True), np.tile(one, (3, 1)))
-
-
-def test_type_d_signed_limb_experiment_cross_pairs_and_bad_inputs(sims):
-    """600 cross pairs of the fixture points through both kernel sources, with flipped bits (off-curve inputs give
-    the identity) and all-ones coordinates (values >= q reduce on load): the two representations agree byte for byte"""
-    v, e = golden("d_rand32.vec"), golden("d_edge20.vec")
-    g1, g2 = np.concatenate([v.g1, e.g1]), np.concatenate([v.g2, e.g2])
-    rng = np.random.default_rng(5)
-    n = 600
-    A, B = g1[rng.integers(0, len(g1), n)].copy(), g2[rng.integers(0, len(g2), n)].copy()
-    for k in range(0, n, 37):
-        A[k, rng.integers(0, A.shape[1])] ^= 1 << rng.integers(0, 8)
-    for k in range(5, n, 41):
-        B[k, rng.integers(0, B.shape[1])] ^= 1 << rng.integers(0, 8)
-    for k in range(7, n, 53):
-        A[k, :20] = 0xff
-    S = sims["d"]
-    assert np.array_equal(S.prod_pairing(A, B, 1), S.prod_pairing(A, B, 1, d_lazy=True))
-    assert np.array_equal(S.prod_pairing(A, B, 3), S.prod_pairing(A, B, 3, d_lazy=True))
 
 
 @pytest.mark.parametrize("key,name,exact", G2_XONLY)

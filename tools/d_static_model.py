@@ -77,8 +77,6 @@ def main():
     variants = [
         ("default (saturated words)", r"^_Z21d_prod_pairing_kernelILi5ELi3", r"TypeMNTILi5ELi3E",
          {"f3_mul": "f3_mul_call", "f3_sqr": "f3_sqr_call", "mul_v": "f3_mul_v_call", "dbl_line": "d_dbl_line_fn", "add_line": "d_add_line_fn"}),
-        ("PBC_HIP_D_LAZY=1 (signed 28-bit limbs)", r"d_lazy_prod_pairing_kernelILi5", r"LazyDILi5E",
-         {"f3_mul": "f3_mul_call", "f3_sqr": "f3_sqr_call", "mul_v": "f3_mul_v_call", "dbl_line": "dbl_line_fn", "add_line": "add_line_fn", "line_y": "line_y_fn"}),
     ]
     base = None
     for title, kpat, fpat, names in variants:

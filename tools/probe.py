@@ -5,7 +5,8 @@ import pbc_amd
 names = {0: "v_mad_u64_u32 (8 chains)", 1: "mad+addc MAC (1 chain)", 2: "v_mul_lo_u32", 3: "v_mul_hi_u32",
          4: "v_dot2_u32_u16", 5: "v_fma_f64", 6: "v_addc_co_u32 chain", 7: "v_mad_u32_u24",
          8: "v_lshl_add_u64", 9: "v_dot4_u32_u8", 10: "mad+addc+s_nop", 11: "v_mad_u32_u16",
-         12: "v_add_u32", 13: "v_mad_u64_u32 sgpr operand"}
+         12: "v_add_u32", 13: "v_mad_u64_u32 sgpr operand", 14: "v_mad_u64_u32 sgpr operand, 4 carry-out pairs",
+         15: "v_mad_i64_i32 sgpr operand"}
 res = {}
 for v, nm in names.items():
     r, ms = pbc_amd.int_mac_peak(v, 3000)
@@ -15,7 +16,7 @@ for v, nm in names.items():
     print("%-28s %8.3f T lane-ops/s  %7.2f cyc/wave-instr/SIMD  (%.2f ms)" % (nm, r / 1e12, cyc, ms))
 json.dump(res, open("gpurun_out/probe.json", "w"), indent=1)
 
-mnames = {0: "mul 32-bit sat (mad+addc asm)", 1: "mul 29-bit unsat", 2: "mul 29-bit unsat, 2 acc",
+mnames = {1: "mul 29-bit unsat", 2: "mul 29-bit unsat, 2 acc",
           3: "sqr 29-bit", 4: "sqr 29-bit, 2 acc", 5: "safegcd inversion (+1 add)", 6: "mul 29-bit out-of-line call",
           7: "sqr 29-bit out-of-line call"}
 mres = {}

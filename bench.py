@@ -163,6 +163,7 @@ WORKLOADS = {
     "d190": ("d278027-190-181", "d278027-190-181_rand12.vec", 1, 18,
              "Type D (d278027-190-181.param, 6-word field) element_pairing"),
     "a-prod16": ("a", "a_chain1024.vec", 16, 18, "Type A (a.param) element_prod_pairing, 16 terms"),
+    "d-prod16": ("d159", "d_chain256.vec", 16, 18, "Type D (d159.param) element_prod_pairing, 16 terms"),
     "a-pp": ("a", "a_chain1024.vec", 1, 20, "Type A (a.param) pairing_pp_apply, fixed first argument"),
     "d-pp": ("d159", "d_chain256.vec", 1, 18, "Type D (d159.param) pairing_pp_apply, fixed first argument"),
     "a1-pp": ("a1", "a1_chain8.vec", 1, 16, "Type A1 (a1.param) pairing_pp_apply, fixed first argument"),

@@ -766,8 +766,10 @@ int oracle_pairing_batch(const oracle_pairing *P, const uint8_t *g1, const uint8
     pt_from_bytes(F, &P->ca, &P->cb, &A, g1 + u * P->len1);
     pt_from_bytes(F, &P->ca, &P->cb, &B, g2 + u * P->len2);
     uint8_t *ob = gt + u * P->lenT;
-    /* pairing_apply identity short-circuit (include/pbc_pairing.h:123-130) */
-    if (A.inf || B.inf) { gt_one_bytes(P, ob); continue; }
+    /* pairing_apply identity short-circuit (include/pbc_pairing.h:123-130).  A first argument of order 2 (y = 0: the
+     * zero-filled record (0, 0)) makes the reference divide by zero (point_to_affine, a_param.c:1073-1080); its
+     * pairing value is 1 (2 is coprime to the group order), which is what is returned here. */
+    if (A.inf || B.inf || fp_is0(F, &A.y)) { gt_one_bytes(P, ob); continue; }
     if (P->a1) a1_pairing_proj(P, &o, &A, &B); else a_pairing_proj(P, &o, &A, &B);
     fp_to_bytes(F, ob, &o.x);
     fp_to_bytes(F, ob + F->nbytes, &o.y);
@@ -799,7 +801,7 @@ int oracle_prod_pairing_batch(const oracle_pairing *P, const uint8_t *g1, const 
     for (int j = 0; j < k; j++) {
       pt_from_bytes(F, &P->ca, &P->cb, &A[j], g1 + (u * k + j) * P->len1);
       pt_from_bytes(F, &P->ca, &P->cb, &B[j], g2 + (u * k + j) * P->len2);
-      if (A[j].inf || B[j].inf) ident = 1;
+      if (A[j].inf || B[j].inf || fp_is0(F, &A[j].y)) ident = 1;     /* y = 0: see oracle_pairing_batch */
     }
     uint8_t *ob = gt + u * P->lenT;
     /* element_prod_pairing: ANY identity input -> whole product = 1 (pbc_pairing.h:161-168) */

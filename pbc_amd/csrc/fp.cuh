@@ -49,35 +49,43 @@ struct fp {
 #define PBC_DEV __device__ __forceinline__
 
 // Per-object constants travel in the KERNEL ARGUMENT SEGMENT.  Every kernel of the library takes the constant block
-// of its pairing object (KArgs<N>, below) as its first argument, by value; device code of any call depth reads it
-// through the kernarg segment pointer, which the ABI hands down to callees in SGPRs.  The segment is constant address
-// space, so every read is a scalar load from a wave-uniform address (-> SGPR operands of the multiply-adds), exactly
-// as a __constant__ symbol would give -- but nothing is process-global: two pairing objects (or one object on two
+// of its pairing object (KArgs<N>, below) as its LAST argument, by value.  The hidden arguments of a HIP kernel follow
+// the explicit ones, and the ABI hands their address (the "implicit argument pointer") down to callees of any depth in
+// SGPRs -- so device code finds the block at a fixed negative offset from that pointer.  The segment is constant
+// address space: every read is a scalar load from a wave-uniform address (-> SGPR operands of the multiply-adds),
+// exactly as a __constant__ symbol would give, but nothing is process-global: two pairing objects (or one object on two
 // streams) cannot disturb each other, and a launch needs no upload.
-// Layout of the block (byte offsets; the first three parts do not depend on the field width):
-//     [0, 704)      CurveK    curve coefficients, cofactor, square-root recipe      (group_ops.cuh)
-//     [704, 2128)   AConst / DConst / FConst / EConst   the pairing family's constants  (pairing_*.cuh)
-//     [2128, 2496)  ExtSqrtK  square roots in the field of the G2 twist             (group_ops.cuh)
-//     [2496, ...)   FpK<N>    modulus and Montgomery constants
+// Layout of the block, from its END backwards (the last three parts do not depend on the field width):
+//     end - 2496 + [0, 704)      CurveK    curve coefficients, cofactor, square-root recipe      (group_ops.cuh)
+//     end - 2496 + [704, 2128)   AConst / DConst / FConst / EConst   the pairing family's constants  (pairing_*.cuh)
+//     end - 2496 + [2128, 2496)  ExtSqrtK  square roots in the field of the G2 twist             (group_ops.cuh)
+//     end - sizeof(KArgs<N>)     FpK<N>    modulus and Montgomery constants
 // Word counts built into the library: 5/6/7 words = the 149..224-bit MNT, Freeman and BN fields of
 // the shipped type d / g / f parameter files, 8 words = 256-bit BN fields (type f), 16 words = the
 // 512-bit type a field, 33 words = the 1033-bit type a1 field.
 #define PBC_FOR_EACH_N(X) X(5) X(6) X(7) X(8) X(16) X(33)
-constexpr int KOFF_CURVE = 0, KOFF_TYPE = 704, KOFF_XS = 2128, KOFF_FPK = 2496;
+constexpr int KOFF_CURVE = 0, KOFF_TYPE = 704, KOFF_XS = 2128, KOFF_END = 2496;
 template <int N>
-struct KArgs {
-  alignas(16) uint8_t head[KOFF_FPK];
+struct alignas(16) KArgs {
   FpK<N> fp;
+  alignas(16) uint8_t head[KOFF_END];
 };
-static_assert(sizeof(KArgs<33>) + 64 <= 4096, "the constant block must fit the kernel argument segment");
+static_assert(sizeof(KArgs<33>) + 384 <= 4096, "the constant block must fit the kernel argument segment");
+static_assert(sizeof(KArgs<5>) % 16 == 0 && sizeof(KArgs<16>) % 16 == 0, "the block must end where the hidden arguments begin");
+// Scalar loads take unsigned immediate offsets, so the block is addressed from a base 4 KB below the hidden arguments
+// (one s_add / s_addc per function; the empty asm keeps the compiler from folding the subtraction back into every
+// access, which would cost an address computation per load).
+constexpr int KSEG = 4096;
 #ifndef PBC_HOSTSIM
 PBC_DEV const uint8_t *pbc_kargs_base() {
-  return (const uint8_t *) (const __attribute__((address_space(4))) uint8_t *) __builtin_amdgcn_kernarg_segment_ptr();
+  uint64_t b = (uint64_t) (const uint8_t *) (const __attribute__((address_space(4))) uint8_t *) __builtin_amdgcn_implicitarg_ptr() - KSEG;
+  asm("" : "+s"(b));
+  return (const uint8_t *) (const __attribute__((address_space(4))) uint8_t *) b;
 }
 #endif
 template <class T, int OFF>
-PBC_DEV const T &kconst() { return *reinterpret_cast<const T *>(pbc_kargs_base() + OFF); }
-template <int N> PBC_DEV const FpK<N> &fpk() { return kconst<FpK<N>, KOFF_FPK>(); }
+PBC_DEV const T &kconst() { return *reinterpret_cast<const T *>(pbc_kargs_base() + (KSEG - KOFF_END + OFF)); }
+template <int N> PBC_DEV const FpK<N> &fpk() { return *reinterpret_cast<const FpK<N> *>(pbc_kargs_base() + (KSEG - (int) sizeof(KArgs<N>))); }
 
 // r = (carry:t) >= p ? t - p : t      (final correction of add / mul)
 // __builtin_addc/__builtin_subc lower to v_addc_co_u32 / v_subb_co_u32 chains.

@@ -551,7 +551,7 @@ static void fill_curve(const pbc_hip_pairing_s *P, CurveK &C) {
   memcpy(C.ts_c, P->hash.ts_c, sizeof C.ts_c);
 }
 
-// The constant block of a pairing object as the kernels receive it (layout: fp.cuh, "KArgs").  Built on the host for
+// The constant block of a pairing object as the kernels receive it, as their last argument (layout: fp.cuh, "KArgs").  Built on the host for
 // every launch from the object's own copies -- nothing lives in device globals.
 template <int N> static const FpK<N> &host_fpk(const pbc_hip_pairing_s *P);
 #define PBC_HOST_FPK_OF(n) template <> const FpK<n> &host_fpk<n>(const pbc_hip_pairing_s *P) { return P->k##n; }

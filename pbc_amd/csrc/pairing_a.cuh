@@ -62,6 +62,11 @@ struct AConst {          // a_pairing_data (ecc/a_param.c:30-34) + phikonr = h (
 static_assert(sizeof(AConst) <= KOFF_XS - KOFF_TYPE, "constant block layout");
 #define c_a (pbc::kconst<pbc::AConst, pbc::KOFF_TYPE>())
 
+// A first argument with y = 0 is a point of order 2 ((0, 0): the zero-filled record).  Its tangent is vertical and the
+// reference divides by zero (point_to_affine / the slope 1/2y); the pairing value is 1 since 2 is coprime to the group
+// order, which is what this engine returns by treating such a P like O (include/pbc_hip.h, "zero-filled records").
+template <int N>
+PBC_DEV bool a_first_arg_ok(const fp<N> &x, const fp<N> &y);
 // curve_is_valid_point (ecc/curve.c:57-77) for y^2 = x^3 + x
 template <int N>
 PBC_DEV bool a_on_curve(const fp<N> &x, const fp<N> &y) {
@@ -75,6 +80,9 @@ PBC_DEV bool a_on_curve(const fp<N> &x, const fp<N> &y) {
 }
 
 template <int N>
+PBC_DEV bool a_first_arg_ok(const fp<N> &x, const fp<N> &y) { return (int) a_on_curve<N>(x, y) & (int) !fp_is0<N>(y); }
+
+template <int N>
 struct jac {
   fp<N> X, Y, Z, ZZ;     // x = X/Z^2, y = Y/Z^3, ZZ = Z^2 cached
 };
@@ -83,7 +91,9 @@ struct jac {
 // phi(x,y) = (-x, iy) is the distortion map (a_miller_evalfn, a_param.c:306-315).
 // Line (scaled by 2 Y Z^3 in F_q^*):  re = M (ZZ Qx + X) - 2 Y^2,  im = (2YZ) ZZ Qy,
 // with M = 3X^2 + Z^4.
-template <int N>
+// SQR = false leaves the squaring of f to the caller (the product kernel squares its shared accumulator once per
+// iteration for all terms, as a_pairings_affine does, ecc/a_param.c:1338-1344).
+template <int N, bool SQR = true>
 PBC_DEV void a_double_step(fp2<N> &f, jac<N> &V, const fp<N> &Qx, const fp<N> &Qy) {
   // Ordered for short live ranges (the register budget is 256/lane at 2 waves per SIMD):
   // line first, f <- f^2 l as soon as the line exists, the rest of the doubling last.
@@ -91,7 +101,7 @@ PBC_DEV void a_double_step(fp2<N> &f, jac<N> &V, const fp<N> &Qx, const fp<N> &Q
   //   2YZ = (Y+Z)^2 - Y^2 - Z^2,   4XY^2 = 2((X+Y^2)^2 - X^2 - Y^4)      -> 10 M + 8 S per step
   fp<N> XX, YY, M, t0, t1, S, Z3, Y4;
   fp2<N> l;
-  fi_sqr<N>(f, f);
+  if constexpr (SQR) fi_sqr<N>(f, f);
   fp_sqr<N>(XX, V.X);
   fp_sqr<N>(t0, V.ZZ);                 // Z^4
   fp_dbl<N>(M, XX);
@@ -237,7 +247,7 @@ PBC_DEV bool a_miller_lane(fp2<N> &f, const uint8_t *g1, const uint8_t *g2, uint
     fp_load_be<N>(V.Y, g1 + NB);
     fp_load_be<N>(Qx, g2);
     fp_load_be<N>(Qy, g2 + NB);
-    valid = a_on_curve<N>(V.X, V.Y) & a_on_curve<N>(Qx, Qy);
+    valid = a_first_arg_ok<N>(V.X, V.Y) & a_on_curve<N>(Qx, Qy);
 #pragma unroll
     for (int k = 0; k < N; k++) {
       lds_q[k * lds_stride] = Qx.v[k];
@@ -368,7 +378,7 @@ PBC_DEV bool a_pp_init_lane(uint32_t *tab, const uint8_t *g1) {
   fp_set<N>(one, fpk<N>().one);
   fp_load_be<N>(x2, g1);
   fp_load_be<N>(y2, g1 + NB);
-  bool valid = a_on_curve<N>(x2, y2);
+  bool valid = a_first_arg_ok<N>(x2, y2);
   V.X = x2; V.Y = y2; V.Z = one; V.ZZ = one;
   int slot = 0;
   for (int i = c_a.exp2 - 1; i >= 0; i--, slot++) {
@@ -430,22 +440,69 @@ PBC_DEV void a_pairing_lane(uint8_t *gt, const uint8_t *g1, const uint8_t *g2, u
   a_store_gt<N>(gt, out, valid);
 }
 
-// element_prod_pairing for one lane: prod_j e(P_j, Q_j) with ONE final exponentiation
-// (a_pairings_affine, a_param.c:1283-1383).  The Miller functions are multiplied in F_q^2
-// before the shared final exponentiation; any identity input forces the product to 1
-// (element_prod_pairing, include/pbc_pairing.h:161-168).
+// element_prod_pairing for one lane: prod_j e(P_j, Q_j) (a_pairings_affine, a_param.c:1283-1383).  As in the
+// reference, ONE accumulator serves all k terms: it is squared once per Miller iteration (:1338-1344,
+// do_tangents :1296-1306) and multiplied by the k line values, and the final exponentiation runs once.  The k points
+// V_j advance in lockstep (element_multi_double, ecc/curve.c:210-281 -- here Jacobian, no inversions); their state and
+// the Montgomery forms of the Q_j do not fit registers or LDS (96 words per term), so they live in a global
+// workspace owned by the pairing object, laid out so that every access of a wave is one contiguous kilobyte:
+//     ws[((block k + term) 24 + 4 element + quad) 128 + lane]  (uint4),   elements X, Y, Z, ZZ, Qx, Qy.
+// Any identity input forces the product to 1 (element_prod_pairing, include/pbc_pairing.h:161-168).
 template <int N>
-PBC_DEV void a_prod_pairing_lane(uint8_t *gt, const uint8_t *g1, const uint8_t *g2, int k,
-                                 uint32_t *lds_q, int lds_stride) {
-  constexpr int L = 8 * N;
-  fp2<N> F, out;
-  bool valid = a_miller_lane<N>(F, g1, g2, lds_q, lds_stride);
-  for (int j = 1; j < k; j++) {
-    fp2<N> f;
-    valid &= a_miller_lane<N>(f, g1 + (size_t) j * L, g2 + (size_t) j * L, lds_q, lds_stride);
-    fi_mul<N>(F, F, f);
+PBC_DEV void a_ws_put(uint4 *ws, int e, const fp<N> &a) {
+  static_assert(N % 4 == 0, "workspace records are whole uint4s");
+#pragma unroll
+  for (int q = 0; q < N / 4; q++) ws[(e * (N / 4) + q) * 128] = make_uint4(a.v[4 * q], a.v[4 * q + 1], a.v[4 * q + 2], a.v[4 * q + 3]);
+}
+template <int N>
+PBC_DEV void a_ws_get(fp<N> &a, const uint4 *ws, int e) {
+#pragma unroll
+  for (int q = 0; q < N / 4; q++) {
+    uint4 t = ws[(e * (N / 4) + q) * 128];
+    a.v[4 * q] = t.x; a.v[4 * q + 1] = t.y; a.v[4 * q + 2] = t.z; a.v[4 * q + 3] = t.w;
   }
-  a_final_exp<N>(out, F);
+}
+template <int N>
+PBC_DEV void a_prod_pairing_lane(uint8_t *gt, const uint8_t *g1, const uint8_t *g2, int k, uint4 *ws) {
+  constexpr int L = 8 * N, NB = 4 * N, REC = 6 * (N / 4) * 128;      // bytes per record / coordinate, uint4s per term
+  fp<N> one;
+  fp_set<N>(one, fpk<N>().one);
+  bool valid = true;
+  for (int j = 0; j < k; j++) {
+    fp<N> x, y, Qx, Qy;
+    fp_load_be<N>(x, g1 + (size_t) j * L);
+    fp_load_be<N>(y, g1 + (size_t) j * L + NB);
+    fp_load_be<N>(Qx, g2 + (size_t) j * L);
+    fp_load_be<N>(Qy, g2 + (size_t) j * L + NB);
+    valid &= a_first_arg_ok<N>(x, y) & a_on_curve<N>(Qx, Qy);
+    uint4 *w = ws + (size_t) j * REC;
+    a_ws_put<N>(w, 0, x); a_ws_put<N>(w, 1, y); a_ws_put<N>(w, 2, one); a_ws_put<N>(w, 3, one);
+    a_ws_put<N>(w, 4, Qx); a_ws_put<N>(w, 5, Qy);
+  }
+  fp2<N> f, out;
+  f.x = one;
+#pragma unroll
+  for (int i = 0; i < N; i++) f.y.v[i] = 0;
+  for (int i = c_a.exp2 - 1; i >= 0; i--) {
+    fi_sqr<N>(f, f);
+    for (int j = 0; j < k; j++) {
+      uint4 *w = ws + (size_t) j * REC;
+      jac<N> V;
+      fp<N> Qx, Qy;
+      a_ws_get<N>(V.X, w, 0); a_ws_get<N>(V.Y, w, 1); a_ws_get<N>(V.Z, w, 2); a_ws_get<N>(V.ZZ, w, 3);
+      a_ws_get<N>(Qx, w, 4); a_ws_get<N>(Qy, w, 5);
+      a_double_step<N, false>(f, V, Qx, Qy);
+      if (i == c_a.exp1) {             // the one non-zero middle digit of r: V <- V +- P
+        fp<N> x2, y2;
+        fp_load_be<N>(x2, g1 + (size_t) j * L);
+        fp_load_be<N>(y2, g1 + (size_t) j * L + NB);
+        if (c_a.sign1 < 0) fp_neg<N>(y2, y2);
+        a_add_step<N>(f, V, x2, y2, Qx, Qy);
+      }
+      a_ws_put<N>(w, 0, V.X); a_ws_put<N>(w, 1, V.Y); a_ws_put<N>(w, 2, V.Z); a_ws_put<N>(w, 3, V.ZZ);
+    }
+  }
+  a_final_exp<N>(out, f);
   a_store_gt<N>(gt, out, valid);
 }
 
@@ -464,7 +521,7 @@ PBC_DEV bool a1_miller_lane(fp2<N> &f, const uint8_t *g1, const uint8_t *g2, uin
   fp_load_be<N>(V.Y, g1 + NB);
   fp_load_be<N>(Qx, g2);
   fp_load_be<N>(Qy, g2 + NB);
-  bool valid = (int) a_on_curve<N>(V.X, V.Y) & (int) a_on_curve<N>(Qx, Qy);
+  bool valid = (int) a_first_arg_ok<N>(V.X, V.Y) & (int) a_on_curve<N>(Qx, Qy);
   if constexpr (!kMemOperands<N>) {    // register-resident fields park Q in LDS between steps
 #pragma unroll
     for (int k = 0; k < N; k++) {
@@ -522,7 +579,7 @@ PBC_DEV bool a1_pp_init_lane(uint32_t *tab, const uint8_t *g1) {
   fp_set<N>(one, fpk<N>().one);
   fp_load_be<N>(x2, g1);
   fp_load_be<N>(y2, g1 + NB);
-  bool valid = a_on_curve<N>(x2, y2);
+  bool valid = a_first_arg_ok<N>(x2, y2);
   V.X = x2; V.Y = y2; V.Z = one; V.ZZ = one;
   int slot = 0;
   for (int i = c_a.rbits - 2; i >= 0; i--) {

@@ -428,9 +428,10 @@ static __device__ __noinline__ v32 d_add_line_fn() {
 static PBC_DEV void f3_load_be(f3 &r, const uint8_t *src) { for (int i = 0; i < DEG; i++) fp_load_be<ND>(r.c[i], src + fpk<ND>().fbytes * i); }
 static PBC_DEV void f3_store_be(uint8_t *dst, const f3 &a) { for (int i = 0; i < DEG; i++) fp_store_be<ND>(dst + fpk<ND>().fbytes * i, a.c[i]); }
 
-// Miller function f_{r,P}(psi(Q)): G1 bytes x||y (2 x fbytes), G2 bytes x||y over F_q^d (2 x d fbytes).
-// Returns false when an input deserialises to O (curve_from_bytes, ecc/curve.c:609-623).
-static PBC_DEV bool d_miller_lane(f6 &v, const uint8_t *g1, const uint8_t *g2) {
+// Per-lane set-up of one (P, Q) term: G1 bytes x||y (2 x fbytes), G2 bytes x||y over F_q^d (2 x d fbytes) -> the LDS
+// Miller state (V = P, the fixed P, the untwisted Q).  Returns false when an input deserialises to O
+// (curve_from_bytes, ecc/curve.c:609-623).
+static PBC_DEV bool d_setup_lane(const uint8_t *g1, const uint8_t *g2) {
   const int NB = (int) fpk<ND>().fbytes;
   fq Px, Py, one;
   f3 Qx, Qy;
@@ -464,6 +465,13 @@ static PBC_DEV bool d_miller_lane(f6 &v, const uint8_t *g1, const uint8_t *g2) {
   for (int i = 0; i < DEG; i++) { dl_put(DL_QX + ND * i, Qx.c[i]); dl_put(DL_QY + ND * i, Qy.c[i]); }
   dl_put(DL_X, Px); dl_put(DL_Y, Py); dl_put(DL_Z, one);
   dl_put(DL_PX, Px); dl_put(DL_PY, Py);
+  return valid;
+}
+// Miller function f_{r,P}(psi(Q)) of one term
+static PBC_DEV bool d_miller_lane(f6 &v, const uint8_t *g1, const uint8_t *g2) {
+  fq one;
+  fp_set<ND>(one, fpk<ND>().one);
+  const bool valid = d_setup_lane(g1, g2);
   f3_set_fq(v.x, one);
   f3_sub(v.y, v.x, v.x);
   // cc_miller_no_denom_affine (d_param.c:321-422): tangent; [double; line+add]; square
@@ -640,15 +648,54 @@ static PBC_DEV void d_pp_apply_lane(uint8_t *gt, const uint32_t *tab, bool p_val
   d_store_gt(gt, out, valid);
 }
 
-// element_pairing (cc_pairing) / element_prod_pairing (cc_pairings_affine, d_param.c:710-736:
-// product of the Miller functions, ONE cc_tatepower) for one lane
-static PBC_DEV void d_prod_pairing_lane(uint8_t *gt, const uint8_t *g1, const uint8_t *g2, int k) {
+// element_pairing (cc_pairing) / element_prod_pairing (cc_pairings_affine, d_param.c:710-736) for one lane.
+// Products follow cc_millers_no_denom_affine (d_param.c:591-708): ONE accumulator is squared once per Miller iteration
+// and takes the line values of all k terms, whose points advance in lockstep; then ONE cc_tatepower.  The LDS Miller
+// state holds one term at a time; the others wait in a global workspace owned by the pairing object,
+// word-major per 128-lane workgroup:  ws[((block k + term) DL_WORDS + word) 128 + lane]  (every access of a wave is
+// 256 contiguous bytes).  Any identity input forces the product to 1.
+static constexpr int DL_WORDS = (2 * DEG + 5) * ND;
+static PBC_DEV void d_ws_save(uint32_t *ws, int first, int count) {
+#pragma unroll 5
+  for (int w = first; w < first + count; w++) ws[w * D_LANES] = g_lds_d<ND, DEG>[w * D_LANES + threadIdx.x];
+}
+static PBC_DEV void d_ws_load(const uint32_t *ws, int first, int count) {
+#pragma unroll 5
+  for (int w = first; w < first + count; w++) g_lds_d<ND, DEG>[w * D_LANES + threadIdx.x] = ws[w * D_LANES];
+}
+static PBC_DEV void d_prod_pairing_lane(uint8_t *gt, const uint8_t *g1, const uint8_t *g2, int k, uint32_t *ws) {
   f6 F, out;
-  bool valid = d_miller_lane(F, g1, g2);
-  for (int j = 1; j < k; j++) {
-    f6 f;
-    valid &= d_miller_lane(f, g1 + (size_t) j * 2 * fpk<ND>().fbytes, g2 + (size_t) j * 2 * DEG * fpk<ND>().fbytes);
-    f6_mul(F, F, f);
+  bool valid;
+  if (k == 1) {
+    valid = d_miller_lane(F, g1, g2);
+  } else {
+    const size_t L1 = 2 * fpk<ND>().fbytes, L2 = 2 * DEG * fpk<ND>().fbytes, REC = (size_t) DL_WORDS * D_LANES;
+    valid = true;
+    for (int j = 0; j < k; j++) {
+      valid &= d_setup_lane(g1 + (size_t) j * L1, g2 + (size_t) j * L2);
+      d_ws_save(ws + (size_t) j * REC, 0, DL_WORDS);
+    }
+    fq one;
+    fp_set<ND>(one, fpk<ND>().one);
+    f3_set_fq(F.x, one);
+    f3_sub(F.y, F.x, F.x);
+    for (int m = c_d.rbits - 2;; m--) {
+      const bool add = m > 0 && ((c_d.r[m >> 5] >> (m & 31)) & 1);
+      for (int j = 0; j < k; j++) {
+        uint32_t *w = ws + (size_t) j * REC;
+        d_ws_load(w, 0, DL_WORDS);
+        f6 e0;
+        d_unpack(e0, d_dbl_line_fn());
+        f6_mul(F, F, e0);
+        if (add) {
+          d_unpack(e0, d_add_line_fn());
+          f6_mul(F, F, e0);
+        }
+        d_ws_save(w, DL_X, 3 * ND);      // only V = (X, Y, Z) changes
+      }
+      if (m <= 0) break;
+      f6_sqr(F, F);
+    }
   }
   d_final_exp(out, F);
   d_store_gt(gt, out, valid);

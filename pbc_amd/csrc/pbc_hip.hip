@@ -11,6 +11,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <vector>
 
 #include "../../include/pbc_hip.h"
 #include "fp.cuh"
@@ -68,8 +69,8 @@ static_assert(kBlock == D_LANES, "pairing_d.cuh sizes its LDS state for 128-lane
 // One Type-A pairing per lane.  g1/g2/gt are AoS in wire format (128 B each for a.param);
 // per-lane 16-byte loads of a 128-byte record: every byte of every fetched line is used.
 template <int N>
-__global__ void __launch_bounds__(kBlock, PBC_A_WAVES) a_pairing_kernel(KArgs<N> ka, uint8_t *gt, const uint8_t *g1,
-                                                            const uint8_t *g2, size_t n) {
+__global__ void __launch_bounds__(kBlock, PBC_A_WAVES) a_pairing_kernel(uint8_t *gt, const uint8_t *g1,
+                                                            const uint8_t *g2, size_t n, KArgs<N> ka) {
   size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
   size_t ld = idx < n ? idx : n - 1;          // tail lanes recompute the last unit, no store
   constexpr int L = 8 * N;
@@ -84,16 +85,17 @@ __global__ void __launch_bounds__(kBlock, PBC_A_WAVES) a_pairing_kernel(KArgs<N>
   }
 }
 
-// One k-term product of Type-A pairings per lane (terms of unit u are records u*k .. u*k+k-1).
+// One k-term product of Type-A pairings per lane (terms of unit u are records u*k .. u*k+k-1).  `ws` is the object's
+// workspace for the per-term Miller state: k x 24 x 128 uint4 per workgroup (a_prod_pairing_lane).
 template <int N>
-__global__ void __launch_bounds__(kBlock, PBC_A_WAVES) a_prod_pairing_kernel(KArgs<N> ka, uint8_t *gt, const uint8_t *g1,
-                                                                 const uint8_t *g2, size_t n, int k) {
+__global__ void __launch_bounds__(kBlock, PBC_A_WAVES) a_prod_pairing_kernel(uint8_t *gt, const uint8_t *g1,
+                                                                 const uint8_t *g2, size_t n, int k, uint4 *ws, KArgs<N> ka) {
   size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
   size_t ld = idx < n ? idx : n - 1;
   constexpr int L = 8 * N;
   __attribute__((aligned(16))) uint8_t out[L];
-  __shared__ uint32_t lds_q[2 * N * kBlock];
-  a_prod_pairing_lane<N>(out, g1 + ld * k * L, g2 + ld * k * L, k, lds_q + threadIdx.x, kBlock);
+  a_prod_pairing_lane<N>(out, g1 + ld * k * L, g2 + ld * k * L, k,
+                         ws + (size_t) blockIdx.x * (size_t) k * (6 * (N / 4) * kBlock) + threadIdx.x);
   if (idx < n) {
     uint4 *dst = reinterpret_cast<uint4 *>(gt + idx * L);
     const uint4 *src = reinterpret_cast<const uint4 *>(out);
@@ -107,8 +109,8 @@ __global__ void __launch_bounds__(kBlock, PBC_A_WAVES) a_prod_pairing_kernel(KAr
 #define PBC_A1_WAVES 1    // 33-word fields: the 512-register budget of one wave per SIMD beats two waves
 #endif                    // with 256 (measured: a1 119 k -> 158 k pairings/s, e 769 k -> 971 k)
 template <int N>
-__global__ void __launch_bounds__(kBlock, N >= 32 ? PBC_A1_WAVES : PBC_A_WAVES) a1_prod_pairing_kernel(KArgs<N> ka, uint8_t *gt, const uint8_t *g1,
-                                                                               const uint8_t *g2, size_t n, int k) {
+__global__ void __launch_bounds__(kBlock, N >= 32 ? PBC_A1_WAVES : PBC_A_WAVES) a1_prod_pairing_kernel(uint8_t *gt, const uint8_t *g1,
+                                                                               const uint8_t *g2, size_t n, int k, KArgs<N> ka) {
   size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
   size_t ld = idx < n ? idx : n - 1;
   const int L = 2 * fq_bytes<N>();
@@ -128,8 +130,8 @@ __global__ void __launch_bounds__(kBlock, N >= 32 ? PBC_A1_WAVES : PBC_A_WAVES) 
 
 // Type E: one k-term product (k = 1: a single pairing) per lane; G1/G2 256 B, GT 128 B for e.param.
 template <int N>
-__global__ void __launch_bounds__(kBlock, N >= 32 ? PBC_A1_WAVES : PBC_A_WAVES) e_prod_pairing_kernel(KArgs<N> ka, uint8_t *gt, const uint8_t *g1,
-                                                                              const uint8_t *g2, size_t n, int k) {
+__global__ void __launch_bounds__(kBlock, N >= 32 ? PBC_A1_WAVES : PBC_A_WAVES) e_prod_pairing_kernel(uint8_t *gt, const uint8_t *g1,
+                                                                              const uint8_t *g2, size_t n, int k, KArgs<N> ka) {
   size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
   size_t ld = idx < n ? idx : n - 1;
   const int LT = fq_bytes<N>(), L = 2 * LT;
@@ -149,15 +151,15 @@ __global__ void __launch_bounds__(kBlock, N >= 32 ? PBC_A1_WAVES : PBC_A_WAVES) 
 
 // pairing_pp_init: ONE lane derives the line-coefficient table of a fixed first argument.
 template <int N>
-__global__ void a_pp_init_kernel(KArgs<N> ka, uint32_t *tab, uint32_t *valid, const uint8_t *g1) {
+__global__ void a_pp_init_kernel(uint32_t *tab, uint32_t *valid, const uint8_t *g1, KArgs<N> ka) {
   if (threadIdx.x || blockIdx.x) return;
   *valid = a_pp_init_lane<N>(tab, g1) ? 1u : 0u;
 }
 // pairing_pp_apply over a batch of second arguments, one per lane; the table is uniform data.
 template <int N>
-__global__ void __launch_bounds__(kBlock, PBC_A_WAVES) a_pp_apply_kernel(KArgs<N> ka, uint8_t *gt, const uint32_t *__restrict__ tab,
+__global__ void __launch_bounds__(kBlock, PBC_A_WAVES) a_pp_apply_kernel(uint8_t *gt, const uint32_t *__restrict__ tab,
                                                                           const uint32_t *__restrict__ valid,
-                                                                          const uint8_t *g2, size_t n) {
+                                                                          const uint8_t *g2, size_t n, KArgs<N> ka) {
   size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
   size_t ld = idx < n ? idx : n - 1;
   constexpr int L = 8 * N;
@@ -175,13 +177,14 @@ __global__ void __launch_bounds__(kBlock, PBC_A_WAVES) a_pp_apply_kernel(KArgs<N
 // of F_q and d = k/2, G1 records are 2 fb, G2 and GT 2 d fb bytes (40 / 120 / 120 B for d159.param,
 // 38 / 190 / 190 B for g149.param).
 template <int N, int DEG>
-__global__ void __launch_bounds__(kBlock, PBC_DF_WAVES) d_prod_pairing_kernel(KArgs<N> ka, uint8_t *gt, const uint8_t *g1,
-                                                                 const uint8_t *g2, size_t n, int k) {
+__global__ void __launch_bounds__(kBlock, PBC_DF_WAVES) d_prod_pairing_kernel(uint8_t *gt, const uint8_t *g1,
+                                                                 const uint8_t *g2, size_t n, int k, uint32_t *ws, KArgs<N> ka) {
   size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
   size_t ld = idx < n ? idx : n - 1;
   const int fb = (int) fpk<N>().fbytes, L1 = 2 * fb, L2 = 2 * DEG * fb, LT = 2 * DEG * fb;
   __attribute__((aligned(4))) uint8_t out[8 * DEG * N];
-  TypeMNT<N, DEG>::d_prod_pairing_lane(out, g1 + ld * k * L1, g2 + ld * k * L2, k);
+  TypeMNT<N, DEG>::d_prod_pairing_lane(out, g1 + ld * k * L1, g2 + ld * k * L2, k,
+                                       ws + (size_t) blockIdx.x * (size_t) k * (TypeMNT<N, DEG>::DL_WORDS * kBlock) + threadIdx.x);
   if (idx < n) {
     if ((LT & 3) == 0) {
       uint32_t *dst = reinterpret_cast<uint32_t *>(gt + idx * LT);
@@ -195,14 +198,14 @@ __global__ void __launch_bounds__(kBlock, PBC_DF_WAVES) d_prod_pairing_kernel(KA
 
 // pairing_pp for type a1
 template <int N>
-__global__ void a1_pp_init_kernel(KArgs<N> ka, uint32_t *tab, uint32_t *valid, const uint8_t *g1) {
+__global__ void a1_pp_init_kernel(uint32_t *tab, uint32_t *valid, const uint8_t *g1, KArgs<N> ka) {
   if (threadIdx.x || blockIdx.x) return;
   *valid = a1_pp_init_lane<N>(tab, g1) ? 1u : 0u;
 }
 template <int N>
-__global__ void __launch_bounds__(kBlock, N >= 32 ? PBC_A1_WAVES : PBC_A_WAVES) a1_pp_apply_kernel(KArgs<N> ka, uint8_t *gt, const uint32_t *__restrict__ tab,
+__global__ void __launch_bounds__(kBlock, N >= 32 ? PBC_A1_WAVES : PBC_A_WAVES) a1_pp_apply_kernel(uint8_t *gt, const uint32_t *__restrict__ tab,
                                                                            const uint32_t *__restrict__ valid,
-                                                                           const uint8_t *g2, size_t n) {
+                                                                           const uint8_t *g2, size_t n, KArgs<N> ka) {
   size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
   size_t ld = idx < n ? idx : n - 1;
   const int L = 2 * fq_bytes<N>();
@@ -221,14 +224,14 @@ __global__ void __launch_bounds__(kBlock, N >= 32 ? PBC_A1_WAVES : PBC_A_WAVES) 
 
 // pairing_pp for types d / g: single-lane table derivation, then one second argument per lane
 template <int N, int DEG>
-__global__ void d_pp_init_kernel(KArgs<N> ka, uint32_t *tab, uint32_t *valid, const uint8_t *g1) {
+__global__ void d_pp_init_kernel(uint32_t *tab, uint32_t *valid, const uint8_t *g1, KArgs<N> ka) {
   if (threadIdx.x || blockIdx.x) return;
   *valid = TypeMNT<N, DEG>::d_pp_init_lane(tab, g1) ? 1u : 0u;
 }
 template <int N, int DEG>
-__global__ void __launch_bounds__(kBlock, PBC_DF_WAVES) d_pp_apply_kernel(KArgs<N> ka, uint8_t *gt, const uint32_t *__restrict__ tab,
+__global__ void __launch_bounds__(kBlock, PBC_DF_WAVES) d_pp_apply_kernel(uint8_t *gt, const uint32_t *__restrict__ tab,
                                                                           const uint32_t *__restrict__ valid,
-                                                                          const uint8_t *g2, size_t n) {
+                                                                          const uint8_t *g2, size_t n, KArgs<N> ka) {
   size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
   size_t ld = idx < n ? idx : n - 1;
   const int fb = (int) fpk<N>().fbytes, L2 = 2 * DEG * fb, LT = 2 * DEG * fb;
@@ -251,8 +254,8 @@ __global__ void __launch_bounds__(kBlock, PBC_DF_WAVES) d_pp_apply_kernel(KArgs<
 #define PBC_F_WAVES PBC_DF_WAVES
 #endif
 template <int N>
-__global__ void __launch_bounds__(kBlock, PBC_F_WAVES) f_prod_pairing_kernel(KArgs<N> ka, uint8_t *gt, const uint8_t *g1,
-                                                                 const uint8_t *g2, size_t n, int k) {
+__global__ void __launch_bounds__(kBlock, PBC_F_WAVES) f_prod_pairing_kernel(uint8_t *gt, const uint8_t *g1,
+                                                                 const uint8_t *g2, size_t n, int k, KArgs<N> ka) {
   size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
   size_t ld = idx < n ? idx : n - 1;
   const int fb = (int) fpk<N>().fbytes, L1 = 2 * fb, L2 = 4 * fb, LT = 12 * fb;
@@ -266,7 +269,7 @@ __global__ void __launch_bounds__(kBlock, PBC_F_WAVES) f_prod_pairing_kernel(KAr
 }
 
 template <int N>
-__global__ void __launch_bounds__(kBlock) f_debug_kernel(KArgs<N> ka, int op, uint8_t *out, const uint8_t *a, const uint8_t *b, size_t n) {
+__global__ void __launch_bounds__(kBlock) f_debug_kernel(int op, uint8_t *out, const uint8_t *a, const uint8_t *b, size_t n, KArgs<N> ka) {
   size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
   if (idx >= n) return;
   const int LT = 12 * (int) fpk<N>().fbytes;
@@ -277,8 +280,8 @@ __global__ void __launch_bounds__(kBlock) f_debug_kernel(KArgs<N> ka, int op, ui
 
 // ---- group operations (one element per lane) -------------------------------------------------
 template <int N>
-__global__ void __launch_bounds__(kBlock, 2) g_mul_kernel(KArgs<N> ka, uint8_t *out, const uint8_t *in, const uint8_t *z,
-                                                           int zlen, size_t n) {
+__global__ void __launch_bounds__(kBlock, 2) g_mul_kernel(uint8_t *out, const uint8_t *in, const uint8_t *z,
+                                                           int zlen, size_t n, KArgs<N> ka) {
   size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
   if (idx >= n) return;
   const size_t L = 2 * fpk<N>().fbytes;
@@ -287,7 +290,7 @@ __global__ void __launch_bounds__(kBlock, 2) g_mul_kernel(KArgs<N> ka, uint8_t *
 // element_to_bytes_compressed / _x_only and element_from_bytes_compressed / _x_only on E(F_q): one point per lane
 // (dir 0 / 2 and 1 / 3)
 template <int N>
-__global__ void __launch_bounds__(kBlock, 2) g_compress_kernel(KArgs<N> ka, int dir, uint8_t *out, const uint8_t *in, size_t n) {
+__global__ void __launch_bounds__(kBlock, 2) g_compress_kernel(int dir, uint8_t *out, const uint8_t *in, size_t n, KArgs<N> ka) {
   size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
   if (idx >= n) return;
   const size_t fb = fpk<N>().fbytes;
@@ -298,23 +301,23 @@ __global__ void __launch_bounds__(kBlock, 2) g_compress_kernel(KArgs<N> ka, int 
 }
 // element_mul_zn on the twists: G2 of types d / g (over F_q^d) and f (over F_q^2)
 template <int N, int DEG>
-__global__ void __launch_bounds__(kBlock, 2) d_g2_mul_kernel(KArgs<N> ka, uint8_t *out, const uint8_t *in, const uint8_t *z,
-                                                              int zlen, size_t n) {
+__global__ void __launch_bounds__(kBlock, 2) d_g2_mul_kernel(uint8_t *out, const uint8_t *in, const uint8_t *z,
+                                                              int zlen, size_t n, KArgs<N> ka) {
   size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
   if (idx >= n) return;
   const size_t L = 2 * DEG * fpk<N>().fbytes;
   ec_mul_lane<FdOps<N, DEG>>(out + idx * L, in + idx * L, z + idx * zlen, zlen);
 }
 template <int N>
-__global__ void __launch_bounds__(kBlock, 2) f_g2_mul_kernel(KArgs<N> ka, uint8_t *out, const uint8_t *in, const uint8_t *z,
-                                                              int zlen, size_t n) {
+__global__ void __launch_bounds__(kBlock, 2) f_g2_mul_kernel(uint8_t *out, const uint8_t *in, const uint8_t *z,
+                                                              int zlen, size_t n, KArgs<N> ka) {
   size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
   if (idx >= n) return;
   const size_t L = 4 * fpk<N>().fbytes;
   ec_mul_lane<Fq2Ops<N>>(out + idx * L, in + idx * L, z + idx * zlen, zlen);
 }
 template <int N>
-__global__ void __launch_bounds__(kBlock, 2) g_from_hash_kernel(KArgs<N> ka, uint8_t *out, const uint8_t *data, int hlen, size_t n) {
+__global__ void __launch_bounds__(kBlock, 2) g_from_hash_kernel(uint8_t *out, const uint8_t *data, int hlen, size_t n, KArgs<N> ka) {
   size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
   size_t ld = idx < n ? idx : n - 1;   // whole waves stay in the retry loop together
   const int L = 2 * (int) fpk<N>().fbytes;
@@ -327,7 +330,7 @@ __global__ void __launch_bounds__(kBlock, 2) g_from_hash_kernel(KArgs<N> ka, uin
 // F is the field policy of the twist (FdOps / Fq2Ops).  what 0: digests of `aux` bytes -> points; 1: points ->
 // x || s; 2: x || s -> points; 3: points -> x; 4: x -> points
 template <class F>
-__global__ void __launch_bounds__(kBlock, 2) g2_point_kernel(KArgs<F::NW> ka, int what, uint8_t *out, const uint8_t *in, int aux, size_t n) {
+__global__ void __launch_bounds__(kBlock, 2) g2_point_kernel(int what, uint8_t *out, const uint8_t *in, int aux, size_t n, KArgs<F::NW> ka) {
   size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
   size_t ld = idx < n ? idx : n - 1;   // whole waves stay in the retry loop together
   const size_t fb = (size_t) F::bytes();
@@ -343,21 +346,21 @@ __global__ void __launch_bounds__(kBlock, 2) g2_point_kernel(KArgs<F::NW> ka, in
     for (size_t i = 0; i < lo; i++) out[idx * lo + i] = o[i];
 }
 template <class F>
-__global__ void ext_ts_init_kernel(KArgs<F::NW> ka, uint32_t *out) {
+__global__ void ext_ts_init_kernel(uint32_t *out, KArgs<F::NW> ka) {
   if (threadIdx.x || blockIdx.x) return;
   ext_ts_init<F>(out);
 }
 // one lane: z^t' for the Tonelli-Shanks square roots of element_from_hash (fields with q = 1 mod 4)
 struct TsRaw { uint32_t t[34], half[34]; int tbits, halfbits; };
 template <int N>
-__global__ void ts_init_kernel(KArgs<N> ka, uint32_t *out, TsRaw raw) {
+__global__ void ts_init_kernel(uint32_t *out, TsRaw raw, KArgs<N> ka) {
   if (threadIdx.x || blockIdx.x) return;
   fp_ts_init<N>(out, raw.t, raw.tbits, raw.half, raw.halfbits);
 }
 // op 0: out = a * b in GT;  op 1: out = a ^ z
 template <int N>
-__global__ void __launch_bounds__(kBlock, 2) gt_op_kernel(KArgs<N> ka, int type, int op, uint8_t *out, const uint8_t *a,
-                                                           const uint8_t *b, int lenT, int zlen, size_t n) {
+__global__ void __launch_bounds__(kBlock, 2) gt_op_kernel(int type, int op, uint8_t *out, const uint8_t *a,
+                                                           const uint8_t *b, int lenT, int zlen, size_t n, KArgs<N> ka) {
   size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
   if (idx >= n) return;
   uint8_t *o = out + idx * lenT;
@@ -405,8 +408,8 @@ __global__ void __launch_bounds__(kBlock, 2) gt_op_kernel(KArgs<N> ka, int type,
 
 // Batched F_q operations on wire bytes (differential check of the limb arithmetic).
 template <int N>
-__global__ void __launch_bounds__(kBlock) fq_op_kernel(KArgs<N> ka, int op, uint8_t *c, const uint8_t *a,
-                                                        const uint8_t *b, size_t n) {
+__global__ void __launch_bounds__(kBlock) fq_op_kernel(int op, uint8_t *c, const uint8_t *a,
+                                                        const uint8_t *b, size_t n, KArgs<N> ka) {
   size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
   if (idx >= n) return;
   const int L = (int) fpk<N>().fbytes;
@@ -586,7 +589,7 @@ static __device__ __noinline__ v18 fz_sqr_fn(v18 va) {
 }
 // ---- multiplier micro-benchmark: iters dependent F_q products per lane, nothing else ------
 template <int N, int V>
-__global__ void __launch_bounds__(256) mul_bench_kernel(KArgs<N> ka, uint32_t *out, const uint32_t *in, int iters) {
+__global__ void __launch_bounds__(256) mul_bench_kernel(uint32_t *out, const uint32_t *in, int iters, KArgs<N> ka) {
   int tid = blockIdx.x * 256 + threadIdx.x;
   int n = gridDim.x * 256;
   fp<N> x, y;
@@ -732,7 +735,7 @@ extern "C" double pbc_hip_algorithmic_macs_per_unit(const pbc_hip_pairing_t *p, 
     default: return fail("internal: no kernel for %d-word fields", (int) (nl)); \
   }
 
-// the constant block of an object, passed by value as the first argument of every kernel (fp.cuh, "KArgs")
+// the constant block of an object, passed by value as the LAST argument of every kernel (fp.cuh, "KArgs")
 template <int N>
 static KArgs<N> kargs(const pbc_hip_pairing_s *P) {
   KArgs<N> K;
@@ -741,23 +744,23 @@ static KArgs<N> kargs(const pbc_hip_pairing_s *P) {
 }
 
 // single-lane kernels of the one-time derivations (tower constants of types d / g / f, the auxiliary point of type e)
-template <int N, int DEG> __global__ void d_init_stage1(KArgs<N> ka, DConst *out, DRaw raw) {
+template <int N, int DEG> __global__ void d_init_stage1(DConst *out, DRaw raw, KArgs<N> ka) {
   if (threadIdx.x || blockIdx.x) return;
   TypeMNT<N, DEG>::init_stage1(out, raw, c_d);
 }
-template <int N, int DEG> __global__ void d_init_stage2(KArgs<N> ka, DConst *out, DRaw raw) {
+template <int N, int DEG> __global__ void d_init_stage2(DConst *out, DRaw raw, KArgs<N> ka) {
   if (threadIdx.x || blockIdx.x) return;
   TypeMNT<N, DEG>::init_stage2(out, raw);
 }
-template <int N> __global__ void f_init_stage1(KArgs<N> ka, FConst *out, FRaw raw) {
+template <int N> __global__ void f_init_stage1(FConst *out, FRaw raw, KArgs<N> ka) {
   if (threadIdx.x || blockIdx.x) return;
   TypeF<N>::init_stage1(out, raw, c_f);
 }
-template <int N> __global__ void f_init_stage2(KArgs<N> ka, FConst *out, FRaw raw) {
+template <int N> __global__ void f_init_stage2(FConst *out, FRaw raw, KArgs<N> ka) {
   if (threadIdx.x || blockIdx.x) return;
   TypeF<N>::init_stage2(out, raw);
 }
-template <int N> __global__ void e_init_kernel(KArgs<N> ka, EConst *out, ERaw raw) {
+template <int N> __global__ void e_init_kernel(EConst *out, ERaw raw, KArgs<N> ka) {
   if (threadIdx.x || blockIdx.x) return;
   e_init_lane<N>(out, raw, c_e);
 }
@@ -771,26 +774,26 @@ static int ensure_derived(pbc_hip_pairing_s *P, hipStream_t s) {
   if (P->type == 'd' || P->type == 'g') {
     HIP_TRY(buf.alloc(sizeof(DConst)));
     DConst *dbuf = buf.as<DConst>();
-    PBC_DISPATCH_D(P, hipLaunchKernelGGL((d_init_stage1<N, DEG>), dim3(1), dim3(64), 0, s, kargs<N>(P), dbuf, P->draw));
+    PBC_DISPATCH_D(P, hipLaunchKernelGGL((d_init_stage1<N, DEG>), dim3(1), dim3(64), 0, s, dbuf, P->draw, kargs<N>(P)));
     HIP_TRY(hipMemcpyAsync(&P->dconst, dbuf, sizeof(DConst), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
-    PBC_DISPATCH_D(P, hipLaunchKernelGGL((d_init_stage2<N, DEG>), dim3(1), dim3(64), 0, s, kargs<N>(P), dbuf, P->draw));
+    PBC_DISPATCH_D(P, hipLaunchKernelGGL((d_init_stage2<N, DEG>), dim3(1), dim3(64), 0, s, dbuf, P->draw, kargs<N>(P)));
     HIP_TRY(hipMemcpyAsync(&P->dconst, dbuf, sizeof(DConst), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
   } else if (P->type == 'e') {
     HIP_TRY(buf.alloc(sizeof(EConst)));
     EConst *dbuf = buf.as<EConst>();
-    if (P->nlimb == 16) hipLaunchKernelGGL(e_init_kernel<16>, dim3(1), dim3(64), 0, s, kargs<16>(P), dbuf, P->eraw);
-    else hipLaunchKernelGGL(e_init_kernel<33>, dim3(1), dim3(64), 0, s, kargs<33>(P), dbuf, P->eraw);
+    if (P->nlimb == 16) hipLaunchKernelGGL(e_init_kernel<16>, dim3(1), dim3(64), 0, s, dbuf, P->eraw, kargs<16>(P));
+    else hipLaunchKernelGGL(e_init_kernel<33>, dim3(1), dim3(64), 0, s, dbuf, P->eraw, kargs<33>(P));
     HIP_TRY(hipMemcpyAsync(&P->econst, dbuf, sizeof(EConst), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
   } else {
     HIP_TRY(buf.alloc(sizeof(FConst)));
     FConst *dbuf = buf.as<FConst>();
-    PBC_DISPATCH_F(P->nlimb, hipLaunchKernelGGL(f_init_stage1<N>, dim3(1), dim3(64), 0, s, kargs<N>(P), dbuf, P->fraw));
+    PBC_DISPATCH_F(P->nlimb, hipLaunchKernelGGL(f_init_stage1<N>, dim3(1), dim3(64), 0, s, dbuf, P->fraw, kargs<N>(P)));
     HIP_TRY(hipMemcpyAsync(&P->fconst, dbuf, sizeof(FConst), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
-    PBC_DISPATCH_F(P->nlimb, hipLaunchKernelGGL(f_init_stage2<N>, dim3(1), dim3(64), 0, s, kargs<N>(P), dbuf, P->fraw));
+    PBC_DISPATCH_F(P->nlimb, hipLaunchKernelGGL(f_init_stage2<N>, dim3(1), dim3(64), 0, s, dbuf, P->fraw, kargs<N>(P)));
     HIP_TRY(hipMemcpyAsync(&P->fconst, dbuf, sizeof(FConst), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
   }
@@ -806,26 +809,26 @@ static int launch_pairing(pbc_hip_pairing_s *P, void *d_gt, const void *d_g1, co
   if (upload && ensure_derived(P, s)) return 1;
   unsigned grid = (unsigned) ((n + kBlock - 1) / kBlock);
   if (P->type == 'a' && !P->a_generic) {
-    hipLaunchKernelGGL(a_pairing_kernel<16>, dim3(grid), dim3(kBlock), 0, s, kargs<16>(P), (uint8_t *) d_gt,
-                       (const uint8_t *) d_g1, (const uint8_t *) d_g2, n);
+    hipLaunchKernelGGL(a_pairing_kernel<16>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
+                       (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, kargs<16>(P));
   } else if ((P->type == 'a' || P->type == '1') && P->nlimb == 16) {   // other sizes: the bit-by-bit kernels
-    hipLaunchKernelGGL(a1_prod_pairing_kernel<16>, dim3(grid), dim3(kBlock), 0, s, kargs<16>(P), (uint8_t *) d_gt,
-                       (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, 1);
+    hipLaunchKernelGGL(a1_prod_pairing_kernel<16>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
+                       (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, 1, kargs<16>(P));
   } else if (P->type == '1' || P->type == 'a') {
-    hipLaunchKernelGGL(a1_prod_pairing_kernel<33>, dim3(grid), dim3(kBlock), 0, s, kargs<33>(P), (uint8_t *) d_gt,
-                       (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, 1);
+    hipLaunchKernelGGL(a1_prod_pairing_kernel<33>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
+                       (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, 1, kargs<33>(P));
   } else if (P->type == 'e' && P->nlimb == 16) {
-    hipLaunchKernelGGL(e_prod_pairing_kernel<16>, dim3(grid), dim3(kBlock), 0, s, kargs<16>(P), (uint8_t *) d_gt,
-                       (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, 1);
+    hipLaunchKernelGGL(e_prod_pairing_kernel<16>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
+                       (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, 1, kargs<16>(P));
   } else if (P->type == 'e') {
-    hipLaunchKernelGGL(e_prod_pairing_kernel<33>, dim3(grid), dim3(kBlock), 0, s, kargs<33>(P), (uint8_t *) d_gt,
-                       (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, 1);
+    hipLaunchKernelGGL(e_prod_pairing_kernel<33>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
+                       (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, 1, kargs<33>(P));
   } else if (P->type == 'd' || P->type == 'g') {
-    PBC_DISPATCH_D(P, hipLaunchKernelGGL((d_prod_pairing_kernel<N, DEG>), dim3(grid), dim3(kBlock), 0, s, kargs<N>(P), (uint8_t *) d_gt,
-                                                (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, 1));
+    PBC_DISPATCH_D(P, hipLaunchKernelGGL((d_prod_pairing_kernel<N, DEG>), dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
+                                                (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, 1, (uint32_t *) nullptr, kargs<N>(P)));
   } else if (P->type == 'f') {
-    PBC_DISPATCH_F(P->nlimb, hipLaunchKernelGGL(f_prod_pairing_kernel<N>, dim3(grid), dim3(kBlock), 0, s, kargs<N>(P), (uint8_t *) d_gt,
-                       (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, 1));
+    PBC_DISPATCH_F(P->nlimb, hipLaunchKernelGGL(f_prod_pairing_kernel<N>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
+                       (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, 1, kargs<N>(P)));
   } else {
     return fail("unsupported type");
   }
@@ -853,10 +856,14 @@ struct DevCtx {
   void *d1[kSlots] = {nullptr, nullptr, nullptr}, *d2[kSlots] = {nullptr, nullptr, nullptr}, *dt[kSlots] = {nullptr, nullptr, nullptr};
   size_t cap1 = 0, cap2 = 0, capt = 0;         // bytes per slot
 };
+// Workspaces of the product kernels (per-term Miller state), one per (device, stream): launches on one stream are
+// ordered, so they may share a buffer; launches on different streams get their own.
+struct WsEnt { int dev; hipStream_t st; void *p; size_t cap; };
 struct HostCtx {
   DevCtx dc[kMaxDev];
   int n = 0;
-  std::mutex mu;                               // guards the table (the per-device entries are used by one worker each)
+  std::vector<WsEnt> ws;
+  std::mutex mu;                               // guards the tables (the per-device entries are used by one worker each)
 };
 static void devctx_release(DevCtx &c) {
   if (c.dev < 0) return;
@@ -875,9 +882,33 @@ static void devctx_release(DevCtx &c) {
 static void hostctx_free(pbc_hip_pairing_s *P) {
   HostCtx *H = static_cast<HostCtx *>(P->host_ctx);
   if (!H) return;
+  for (WsEnt &w : H->ws) {
+    DeviceGuard guard(w.dev);
+    (void) hipDeviceSynchronize();
+    (void) hipFree(w.p);
+  }
   for (int i = 0; i < H->n; i++) devctx_release(H->dc[i]);
   delete H;
   P->host_ctx = nullptr;
+}
+// at least `bytes` of device memory for a kernel about to be launched on stream `s` of the current device; kept by the
+// object, grown on demand (the only allocation a steady-state call can make)
+static void *workspace_get(pbc_hip_pairing_s *P, hipStream_t s, size_t bytes) {
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess) { fail("no current HIP device"); return nullptr; }
+  if (!P->host_ctx) P->host_ctx = new HostCtx();
+  HostCtx *H = static_cast<HostCtx *>(P->host_ctx);
+  std::lock_guard<std::mutex> lk(H->mu);
+  WsEnt *e = nullptr;
+  for (WsEnt &w : H->ws)
+    if (w.dev == dev && w.st == s) e = &w;
+  if (!e) { H->ws.push_back(WsEnt{dev, s, nullptr, 0}); e = &H->ws.back(); }
+  if (e->cap < bytes) {
+    if (e->p) { (void) hipStreamSynchronize(s); (void) hipFree(e->p); e->p = nullptr; e->cap = 0; }
+    if (hipMalloc(&e->p, bytes) != hipSuccess) { e->p = nullptr; fail("device allocation of a %zu-byte product workspace failed", bytes); return nullptr; }
+    e->cap = bytes;
+  }
+  return e->p;
 }
 // the context of `dev` with room for chunks of (b1, b2, bt) bytes; the calling thread's current device must be `dev`
 static DevCtx *devctx_get(pbc_hip_pairing_s *P, int dev, size_t b1, size_t b2, size_t bt, std::string &err) {
@@ -925,10 +956,12 @@ static int run_host(pbc_hip_pairing_s *P, uint8_t *gt, const uint8_t *g1, const 
   if (!n) return 0;
   const int ndev = P->ndev > 0 ? P->ndev : 1;
   const int *devs = P->ndev > 0 ? P->devs : &P->device;
-  size_t chunk = (size_t) 131072 / (size_t) k;       // one full residency of the chip per chunk
-  if (chunk < 1024) chunk = 1024;
-  if (chunk > n) chunk = n;
   const size_t u1 = (size_t) k * P->len1, u2 = (size_t) k * P->len2, ut = (size_t) P->lenT;
+  // one full residency of the chip per chunk (256 CUs x 4 workgroups x 128 lanes, one unit per lane), fewer units
+  // when a chunk's records would exceed 256 MB (long products): three chunks are in flight per device
+  size_t chunk = 131072;
+  while (chunk > 16384 && chunk * (u1 + u2 + ut) > ((size_t) 256 << 20)) chunk >>= 1;
+  if (chunk > n) chunk = n;
   const size_t nchunks = (n + chunk - 1) / chunk;
   const int used = (size_t) ndev < nchunks ? ndev : (int) nchunks;      // devices that receive at least one chunk
   DeviceGuard guard(devs[0]);
@@ -989,26 +1022,30 @@ static int launch_prod(pbc_hip_pairing_s *P, void *d_gt, const void *d_g1, const
   if (upload && ensure_derived(P, s)) return 1;
   unsigned grid = (unsigned) ((n + kBlock - 1) / kBlock);
   if (P->type == 'a' && !P->a_generic) {
-    hipLaunchKernelGGL(a_prod_pairing_kernel<16>, dim3(grid), dim3(kBlock), 0, s, kargs<16>(P), (uint8_t *) d_gt,
-                       (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k);
+    void *ws = workspace_get(P, s, (size_t) grid * (size_t) k * (6 * 4 * kBlock) * sizeof(uint4));
+    if (!ws) return 1;
+    hipLaunchKernelGGL(a_prod_pairing_kernel<16>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
+                       (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k, (uint4 *) ws, kargs<16>(P));
   } else if ((P->type == 'a' || P->type == '1') && P->nlimb == 16) {
-    hipLaunchKernelGGL(a1_prod_pairing_kernel<16>, dim3(grid), dim3(kBlock), 0, s, kargs<16>(P), (uint8_t *) d_gt,
-                       (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k);
+    hipLaunchKernelGGL(a1_prod_pairing_kernel<16>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
+                       (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k, kargs<16>(P));
   } else if (P->type == '1' || P->type == 'a') {
-    hipLaunchKernelGGL(a1_prod_pairing_kernel<33>, dim3(grid), dim3(kBlock), 0, s, kargs<33>(P), (uint8_t *) d_gt,
-                       (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k);
+    hipLaunchKernelGGL(a1_prod_pairing_kernel<33>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
+                       (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k, kargs<33>(P));
   } else if (P->type == 'e' && P->nlimb == 16) {
-    hipLaunchKernelGGL(e_prod_pairing_kernel<16>, dim3(grid), dim3(kBlock), 0, s, kargs<16>(P), (uint8_t *) d_gt,
-                       (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k);
+    hipLaunchKernelGGL(e_prod_pairing_kernel<16>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
+                       (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k, kargs<16>(P));
   } else if (P->type == 'e') {
-    hipLaunchKernelGGL(e_prod_pairing_kernel<33>, dim3(grid), dim3(kBlock), 0, s, kargs<33>(P), (uint8_t *) d_gt,
-                       (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k);
+    hipLaunchKernelGGL(e_prod_pairing_kernel<33>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
+                       (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k, kargs<33>(P));
   } else if (P->type == 'd' || P->type == 'g') {
-    PBC_DISPATCH_D(P, hipLaunchKernelGGL((d_prod_pairing_kernel<N, DEG>), dim3(grid), dim3(kBlock), 0, s, kargs<N>(P), (uint8_t *) d_gt,
-                                                (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k));
+    void *ws = workspace_get(P, s, (size_t) grid * (size_t) k * (size_t) ((2 * P->deg + 5) * P->nlimb * kBlock) * sizeof(uint32_t));
+    if (!ws) return 1;
+    PBC_DISPATCH_D(P, hipLaunchKernelGGL((d_prod_pairing_kernel<N, DEG>), dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
+                                                (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k, (uint32_t *) ws, kargs<N>(P)));
   } else if (P->type == 'f') {
-    PBC_DISPATCH_F(P->nlimb, hipLaunchKernelGGL(f_prod_pairing_kernel<N>, dim3(grid), dim3(kBlock), 0, s, kargs<N>(P), (uint8_t *) d_gt,
-                       (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k));
+    PBC_DISPATCH_F(P->nlimb, hipLaunchKernelGGL(f_prod_pairing_kernel<N>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
+                       (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k, kargs<N>(P)));
   } else {
     return fail("unsupported type");
   }
@@ -1057,18 +1094,18 @@ static int run_group(pbc_hip_pairing_s *P, int what, int group, uint8_t *out, co
   if (ensure_derived(P, 0)) return 1;
   unsigned grid = (unsigned) ((n + kBlock - 1) / kBlock);
   if (what == 0 && group == 2 && (P->type == 'd' || P->type == 'g')) {
-    PBC_DISPATCH_D(P, hipLaunchKernelGGL((d_g2_mul_kernel<N, DEG>), dim3(grid), dim3(kBlock), 0, 0, kargs<N>(P), (uint8_t *) d_o,
-                                         (const uint8_t *) da, (const uint8_t *) db, P->len_zr, n));
+    PBC_DISPATCH_D(P, hipLaunchKernelGGL((d_g2_mul_kernel<N, DEG>), dim3(grid), dim3(kBlock), 0, 0, (uint8_t *) d_o,
+                                         (const uint8_t *) da, (const uint8_t *) db, P->len_zr, n, kargs<N>(P)));
   } else if (what == 0 && group == 2 && P->type == 'f') {
-    PBC_DISPATCH_F(P->nlimb, hipLaunchKernelGGL(f_g2_mul_kernel<N>, dim3(grid), dim3(kBlock), 0, 0, kargs<N>(P), (uint8_t *) d_o, (const uint8_t *) da,
-                       (const uint8_t *) db, P->len_zr, n));
+    PBC_DISPATCH_F(P->nlimb, hipLaunchKernelGGL(f_g2_mul_kernel<N>, dim3(grid), dim3(kBlock), 0, 0, (uint8_t *) d_o, (const uint8_t *) da,
+                       (const uint8_t *) db, P->len_zr, n, kargs<N>(P)));
   } else if (what == 0) {              // E(F_q): G1, and G2 of the symmetric types
-    PBC_DISPATCH_N(P->nlimb, hipLaunchKernelGGL(g_mul_kernel<N>, dim3(grid), dim3(kBlock), 0, 0, kargs<N>(P), (uint8_t *) d_o,
-                                                (const uint8_t *) da, (const uint8_t *) db, P->len_zr, n));
+    PBC_DISPATCH_N(P->nlimb, hipLaunchKernelGGL(g_mul_kernel<N>, dim3(grid), dim3(kBlock), 0, 0, (uint8_t *) d_o,
+                                                (const uint8_t *) da, (const uint8_t *) db, P->len_zr, n, kargs<N>(P)));
   } else {
-    PBC_DISPATCH_N(P->nlimb, hipLaunchKernelGGL(gt_op_kernel<N>, dim3(grid), dim3(kBlock), 0, 0, kargs<N>(P), P->type, what - 1,
+    PBC_DISPATCH_N(P->nlimb, hipLaunchKernelGGL(gt_op_kernel<N>, dim3(grid), dim3(kBlock), 0, 0, P->type, what - 1,
                                                 (uint8_t *) d_o, (const uint8_t *) da, (const uint8_t *) db, P->lenT,
-                                                P->len_zr, n));
+                                                P->len_zr, n, kargs<N>(P)));
   }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpy(out, d_o, n * lo, hipMemcpyDeviceToHost));
@@ -1104,7 +1141,7 @@ static int ensure_sqrt_constants(pbc_hip_pairing_s *P) {
     HIP_TRY(bc.alloc(sizeof P->hash.ts_c));
     uint32_t *dc = bc.as<uint32_t>();
     HIP_TRY(hipMemset(dc, 0, sizeof P->hash.ts_c));
-    PBC_DISPATCH_N(P->nlimb, hipLaunchKernelGGL(ts_init_kernel<N>, dim3(1), dim3(64), 0, 0, kargs<N>(P), dc, raw));
+    PBC_DISPATCH_N(P->nlimb, hipLaunchKernelGGL(ts_init_kernel<N>, dim3(1), dim3(64), 0, 0, dc, raw, kargs<N>(P)));
     HIP_TRY(hipMemcpy(P->hash.ts_c, dc, sizeof P->hash.ts_c, hipMemcpyDeviceToHost));
     P->hash.ts_ready = true;
   }
@@ -1124,7 +1161,7 @@ static int ensure_ext_sqrt(pbc_hip_pairing_s *P) {
     HIP_TRY(bc.alloc(sizeof P->xs.c));
     uint32_t *dc = bc.as<uint32_t>();
     HIP_TRY(hipMemset(dc, 0, sizeof P->xs.c));
-    PBC_DISPATCH_TWIST(P, hipLaunchKernelGGL(ext_ts_init_kernel<F>, dim3(1), dim3(64), 0, 0, kargs<F::NW>(P), dc));
+    PBC_DISPATCH_TWIST(P, hipLaunchKernelGGL(ext_ts_init_kernel<F>, dim3(1), dim3(64), 0, 0, dc, kargs<F::NW>(P)));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(P->xs.c, dc, sizeof P->xs.c, hipMemcpyDeviceToHost));
     P->xs_ready = true;
@@ -1146,8 +1183,8 @@ static int run_twist_points(pbc_hip_pairing_s *P, int what, uint8_t *out, const 
   HIP_TRY(hipMemcpy(di, in, n * li, hipMemcpyHostToDevice));
   if (ensure_derived(P, 0)) return 1;
   unsigned grid = (unsigned) ((n + kBlock - 1) / kBlock);
-  PBC_DISPATCH_TWIST(P, hipLaunchKernelGGL(g2_point_kernel<F>, dim3(grid), dim3(kBlock), 0, 0, kargs<F::NW>(P), what, (uint8_t *) d_o,
-                                           (const uint8_t *) di, hlen, n));
+  PBC_DISPATCH_TWIST(P, hipLaunchKernelGGL(g2_point_kernel<F>, dim3(grid), dim3(kBlock), 0, 0, what, (uint8_t *) d_o,
+                                           (const uint8_t *) di, hlen, n, kargs<F::NW>(P)));
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpy(out, d_o, n * lo, hipMemcpyDeviceToHost));
   return 0;
@@ -1171,8 +1208,8 @@ static int run_compress(pbc_hip_pairing_s *P, int dir, int group, uint8_t *out, 
   HIP_TRY(hipMemcpy(di, in, n * li, hipMemcpyHostToDevice));
   if (ensure_derived(P, 0)) return 1;
   unsigned grid = (unsigned) ((n + kBlock - 1) / kBlock);
-  PBC_DISPATCH_N(P->nlimb, hipLaunchKernelGGL(g_compress_kernel<N>, dim3(grid), dim3(kBlock), 0, 0, kargs<N>(P), dir, (uint8_t *) d_o,
-                                              (const uint8_t *) di, n));
+  PBC_DISPATCH_N(P->nlimb, hipLaunchKernelGGL(g_compress_kernel<N>, dim3(grid), dim3(kBlock), 0, 0, dir, (uint8_t *) d_o,
+                                              (const uint8_t *) di, n, kargs<N>(P)));
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpy(out, d_o, n * lo, hipMemcpyDeviceToHost));
   return 0;
@@ -1219,8 +1256,8 @@ extern "C" int pbc_hip_element_from_hash_batch(pbc_hip_pairing_t *P, int group, 
   HIP_TRY(hipMemcpy(dd, data, n * (size_t) hlen, hipMemcpyHostToDevice));
   if (ensure_derived(P, 0)) return 1;
   unsigned grid = (unsigned) ((n + kBlock - 1) / kBlock);
-  PBC_DISPATCH_N(P->nlimb, hipLaunchKernelGGL(g_from_hash_kernel<N>, dim3(grid), dim3(kBlock), 0, 0, kargs<N>(P), (uint8_t *) d_o,
-                                              (const uint8_t *) dd, hlen, n));
+  PBC_DISPATCH_N(P->nlimb, hipLaunchKernelGGL(g_from_hash_kernel<N>, dim3(grid), dim3(kBlock), 0, 0, (uint8_t *) d_o,
+                                              (const uint8_t *) dd, hlen, n, kargs<N>(P)));
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpy(out, d_o, n * (size_t) P->len1, hipMemcpyDeviceToHost));
   return 0;
@@ -1259,14 +1296,14 @@ extern "C" int pbc_hip_pairing_pp_init(pbc_hip_pp_t **out, pbc_hip_pairing_t *P,
     return fail("pairing_pp_init: device setup failed");
   }
   if (mnt) {
-    PBC_DISPATCH_D(P, hipLaunchKernelGGL((d_pp_init_kernel<N, DEG>), dim3(1), dim3(64), 0, 0, kargs<N>(P), pp->tab, pp->valid,
-                                         (const uint8_t *) dg1));
+    PBC_DISPATCH_D(P, hipLaunchKernelGGL((d_pp_init_kernel<N, DEG>), dim3(1), dim3(64), 0, 0, pp->tab, pp->valid,
+                                         (const uint8_t *) dg1, kargs<N>(P)));
   } else if (a1 && P->nlimb == 16) {
-    hipLaunchKernelGGL(a1_pp_init_kernel<16>, dim3(1), dim3(64), 0, 0, kargs<16>(P), pp->tab, pp->valid, (const uint8_t *) dg1);
+    hipLaunchKernelGGL(a1_pp_init_kernel<16>, dim3(1), dim3(64), 0, 0, pp->tab, pp->valid, (const uint8_t *) dg1, kargs<16>(P));
   } else if (a1) {
-    hipLaunchKernelGGL(a1_pp_init_kernel<33>, dim3(1), dim3(64), 0, 0, kargs<33>(P), pp->tab, pp->valid, (const uint8_t *) dg1);
+    hipLaunchKernelGGL(a1_pp_init_kernel<33>, dim3(1), dim3(64), 0, 0, pp->tab, pp->valid, (const uint8_t *) dg1, kargs<33>(P));
   } else {
-    hipLaunchKernelGGL(a_pp_init_kernel<16>, dim3(1), dim3(64), 0, 0, kargs<16>(P), pp->tab, pp->valid, (const uint8_t *) dg1);
+    hipLaunchKernelGGL(a_pp_init_kernel<16>, dim3(1), dim3(64), 0, 0, pp->tab, pp->valid, (const uint8_t *) dg1, kargs<16>(P));
   }
   hipError_t e = hipDeviceSynchronize();
   (void) hipFree(dg1);
@@ -1288,17 +1325,17 @@ extern "C" int pbc_hip_pairing_pp_apply_batch_dev(pbc_hip_pp_t *pp, void *d_gt, 
   if (ensure_derived(P, s)) return 1;
   unsigned grid = (unsigned) ((n + kBlock - 1) / kBlock);
   if (pp->P->type == 'a' && !pp->P->a_generic) {
-    hipLaunchKernelGGL(a_pp_apply_kernel<16>, dim3(grid), dim3(kBlock), 0, s, kargs<16>(P), (uint8_t *) d_gt, pp->tab, pp->valid,
-                       (const uint8_t *) d_g2, n);
+    hipLaunchKernelGGL(a_pp_apply_kernel<16>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt, pp->tab, pp->valid,
+                       (const uint8_t *) d_g2, n, kargs<16>(P));
   } else if (pp->P->nlimb == 16 && (pp->P->type == 'a' || pp->P->type == '1')) {
-    hipLaunchKernelGGL(a1_pp_apply_kernel<16>, dim3(grid), dim3(kBlock), 0, s, kargs<16>(P), (uint8_t *) d_gt, pp->tab, pp->valid,
-                       (const uint8_t *) d_g2, n);
+    hipLaunchKernelGGL(a1_pp_apply_kernel<16>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt, pp->tab, pp->valid,
+                       (const uint8_t *) d_g2, n, kargs<16>(P));
   } else if (pp->P->type == '1' || pp->P->type == 'a') {
-    hipLaunchKernelGGL(a1_pp_apply_kernel<33>, dim3(grid), dim3(kBlock), 0, s, kargs<33>(P), (uint8_t *) d_gt, pp->tab, pp->valid,
-                       (const uint8_t *) d_g2, n);
+    hipLaunchKernelGGL(a1_pp_apply_kernel<33>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt, pp->tab, pp->valid,
+                       (const uint8_t *) d_g2, n, kargs<33>(P));
   } else {
-    PBC_DISPATCH_D(pp->P, hipLaunchKernelGGL((d_pp_apply_kernel<N, DEG>), dim3(grid), dim3(kBlock), 0, s, kargs<N>(P), (uint8_t *) d_gt,
-                                             pp->tab, pp->valid, (const uint8_t *) d_g2, n));
+    PBC_DISPATCH_D(pp->P, hipLaunchKernelGGL((d_pp_apply_kernel<N, DEG>), dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
+                                             pp->tab, pp->valid, (const uint8_t *) d_g2, n, kargs<N>(P)));
   }
   HIP_TRY(hipGetLastError());
   return 0;
@@ -1340,8 +1377,8 @@ extern "C" int pbc_hip_diag_stage(pbc_hip_pairing_t *P, int stage, uint8_t *out,
     HIP_TRY(hipMemcpy(d2, g2, n * P->len2, hipMemcpyHostToDevice));
     if (ensure_derived(P, 0)) return 1;
     unsigned grid = (unsigned) ((n + kBlock - 1) / kBlock);
-    PBC_DISPATCH_F(P->nlimb, hipLaunchKernelGGL(f_prod_pairing_kernel<N>, dim3(grid), dim3(kBlock), 0, 0, kargs<N>(P), (uint8_t *) dt,
-                       (const uint8_t *) d1, (const uint8_t *) d2, n, -1));
+    PBC_DISPATCH_F(P->nlimb, hipLaunchKernelGGL(f_prod_pairing_kernel<N>, dim3(grid), dim3(kBlock), 0, 0, (uint8_t *) dt,
+                       (const uint8_t *) d1, (const uint8_t *) d2, n, -1, kargs<N>(P)));
     HIP_TRY(hipMemcpy(out, dt, n * P->lenT < out_len ? n * P->lenT : out_len, hipMemcpyDeviceToHost));
     (void) hipFree(d1); (void) hipFree(d2); (void) hipFree(dt);
     return 0;
@@ -1356,8 +1393,8 @@ extern "C" int pbc_hip_diag_stage(pbc_hip_pairing_t *P, int stage, uint8_t *out,
     HIP_TRY(hipMemcpy(d2, g2, bytes, hipMemcpyHostToDevice));
     if (ensure_derived(P, 0)) return 1;
     unsigned grid = (unsigned) ((n + kBlock - 1) / kBlock);
-    PBC_DISPATCH_F(P->nlimb, hipLaunchKernelGGL(f_debug_kernel<N>, dim3(grid), dim3(kBlock), 0, 0, kargs<N>(P), stage, (uint8_t *) dt, (const uint8_t *) d1,
-                       (const uint8_t *) d2, n));
+    PBC_DISPATCH_F(P->nlimb, hipLaunchKernelGGL(f_debug_kernel<N>, dim3(grid), dim3(kBlock), 0, 0, stage, (uint8_t *) dt, (const uint8_t *) d1,
+                       (const uint8_t *) d2, n, kargs<N>(P)));
     HIP_TRY(hipMemcpy(out, dt, bytes < out_len ? bytes : out_len, hipMemcpyDeviceToHost));
     (void) hipFree(d1); (void) hipFree(d2); (void) hipFree(dt);
     return 0;
@@ -1385,8 +1422,8 @@ extern "C" int pbc_hip_fq_op_batch(pbc_hip_pairing_t *P, int op, uint8_t *c, con
   }
   if (ensure_derived(P, 0)) return 1;
   unsigned grid = (unsigned) ((n + kBlock - 1) / kBlock);
-  PBC_DISPATCH_N(P->nlimb, hipLaunchKernelGGL(fq_op_kernel<N>, dim3(grid), dim3(kBlock), 0, 0, kargs<N>(P), op, (uint8_t *) dc,
-                                              (const uint8_t *) da, (const uint8_t *) db, n));
+  PBC_DISPATCH_N(P->nlimb, hipLaunchKernelGGL(fq_op_kernel<N>, dim3(grid), dim3(kBlock), 0, 0, op, (uint8_t *) dc,
+                                              (const uint8_t *) da, (const uint8_t *) db, n, kargs<N>(P)));
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpy(c, dc, bytes, hipMemcpyDeviceToHost));
   return 0;
@@ -1441,9 +1478,9 @@ static int run_mul_bench(int iters, int waves_per_simd, double *rate, double *ms
   for (int i = 0; i < Limbs29<16>::L; i++) K.fp.p29[i] = (0x12345679u + 2u * (uint32_t) i) & Limbs29<16>::MASK;
   for (int i = 0; i < Inv30<16>::L; i++) K.fp.p30[i] = (0x2468ace1u + 2u * (uint32_t) i) & 0x3fffffffu;
   K.fp.ninv29 = 0x0badcafu; K.fp.qinv30 = 0x1234567u; K.fp.fbytes = 64; K.fp.pbits = 512;
-  hipLaunchKernelGGL((mul_bench_kernel<16, V>), dim3(grid), dim3(256), 0, 0, K, out, in, iters / 8 + 1);
+  hipLaunchKernelGGL((mul_bench_kernel<16, V>), dim3(grid), dim3(256), 0, 0, out, in, iters / 8 + 1, K);
   HIP_TRY(hipEventRecord(e0, 0));
-  hipLaunchKernelGGL((mul_bench_kernel<16, V>), dim3(grid), dim3(256), 0, 0, K, out, in, iters);
+  hipLaunchKernelGGL((mul_bench_kernel<16, V>), dim3(grid), dim3(256), 0, 0, out, in, iters, K);
   HIP_TRY(hipEventRecord(e1, 0));
   HIP_TRY(hipEventSynchronize(e1));
   float ms;

@@ -2,10 +2,9 @@
 // tiny C API (tests/test_hostsim.py).  It runs one lane at a time: same source, same limb
 // arithmetic, same control flow as the HIP kernels.  Not part of the product.
 #define PBC_HOSTSIM 1
+#include <vector>
 #include "../../pbc_amd/csrc/host_params.h"
 
-// "upload" the constants before every call (as upload_constants does on the GPU): on the host
-// the __constant__ objects are plain globals shared by all parameter sets
 // run EXPR with N = the compile-time word count matching P->nlimb
 #define HS_DISPATCH(nl, ...)                          \
   switch (nl) {                                       \
@@ -32,7 +31,7 @@
   }
 // the object's constants into the block the kernel source reads (what a launch passes as KArgs<N> on the GPU)
 static void activate(pbc_hip_pairing_s *P) {
-  HS_DISPATCH(P->nlimb, { KArgs<N> K; fill_kargs<N>(P, K); memcpy(hostsim_kargs, &K, sizeof K); });
+  HS_DISPATCH(P->nlimb, { KArgs<N> K; fill_kargs<N>(P, K); memcpy(hostsim_kargs + sizeof hostsim_kargs - sizeof K, &K, sizeof K); });
 }
 
 extern "C" {
@@ -92,12 +91,12 @@ int hostsim_prod_pairing(void *h, uint8_t *gt, const uint8_t *g1, const uint8_t 
   for (size_t u = 0; u < n; u++) {
     const uint8_t *a = g1 + u * k * P->len1, *b = g2 + u * k * P->len2;
     uint8_t *o = gt + u * P->lenT;
-    if (P->type == 'a' && !P->a_generic) a_prod_pairing_lane<16>(o, a, b, k, lds, 1);
+    if (P->type == 'a' && !P->a_generic) { std::vector<uint4> ws((size_t) k * 24 * 128); a_prod_pairing_lane<16>(o, a, b, k, ws.data()); }
     else if ((P->type == 'a' || P->type == '1') && P->nlimb == 16) a1_prod_pairing_lane<16>(o, a, b, k, lds, 1);
     else if (P->type == '1' || P->type == 'a') a1_prod_pairing_lane<33>(o, a, b, k, lds, 1);
     else if (P->type == 'e' && P->nlimb == 16) e_prod_pairing_lane<16>(o, a, b, k, lds, 1);
     else if (P->type == 'e') e_prod_pairing_lane<33>(o, a, b, k, lds, 1);
-    else if (P->type == 'd' || P->type == 'g') { HS_DISPATCH_D(P, TypeMNT<N, DEG>::d_prod_pairing_lane(o, a, b, k)); }
+    else if (P->type == 'd' || P->type == 'g') { std::vector<uint32_t> ws((size_t) k * 80 * 128); HS_DISPATCH_D(P, TypeMNT<N, DEG>::d_prod_pairing_lane(o, a, b, k, ws.data())); }
     else { HS_DISPATCH_F(P->nlimb, TypeF<N>::f_prod_pairing_lane(o, a, b, k)); }
   }
   return 0;

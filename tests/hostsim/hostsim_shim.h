@@ -15,6 +15,7 @@
 struct hostsim_dim3 { unsigned x, y, z; };
 static hostsim_dim3 threadIdx = {0, 0, 0}, blockIdx = {0, 0, 0};
 struct uint4 { uint32_t x, y, z, w; };
+static inline uint4 make_uint4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) { uint4 r = {x, y, z, w}; return r; }
 static inline int __all(int p) { return p; }      // one lane per call: the "wave" agrees with itself
 static inline uint32_t __builtin_amdgcn_alignbit(uint32_t hi, uint32_t lo, uint32_t s) {
   return (uint32_t) (((((uint64_t) hi) << 32) | lo) >> (s & 31));
@@ -25,4 +26,4 @@ static uint64_t hostsim_macs = 0;
 // the constant block the kernels read through the kernel argument segment on the GPU (fp.cuh, "KArgs"): here a
 // host buffer that hostsim.cpp fills before each call
 alignas(16) static uint8_t hostsim_kargs[4096];
-static inline const uint8_t *pbc_kargs_base() { return hostsim_kargs; }
+static inline const uint8_t *pbc_kargs_base() { return hostsim_kargs; }      // KSEG = 4096 below the block's end

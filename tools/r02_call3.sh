@@ -1,13 +1,13 @@
 #!/bin/bash
 # GPU call 3 of round 2: per-object constants in the kernel argument segment + persistent device contexts.
 ROOT="${GRAFT_REPO_ROOT:-/root/repo}"
-OUT="$ROOT/gpurun_out/r02c"
+OUT="$ROOT/gpurun_out/r02d"
 mkdir -p "$OUT"
 cd "$ROOT" || exit 1
 timeout 1200 python -m pytest tests -m gpu -q > "$OUT/pytest_gpu.log" 2>&1
 echo "pytest -m gpu: exit $?" | tee -a "$OUT/pytest_gpu.log"
 tail -n 8 "$OUT/pytest_gpu.log"
-for w in a d f g a-prod16 a-pp e; do
+for w in a d f g a-prod16 d-prod16 a-pp d190; do
   timeout 300 python bench.py --workload $w --steps 4 --warmup 1 --no-cpu-baseline > "$OUT/bench_${w}.json" 2> "$OUT/bench_${w}.err"
   python - "$OUT/bench_${w}.json" "$w" <<'PY'
 import json, sys

@@ -28,10 +28,13 @@ static struct {
   int (*gt_mul)(pbc_hip_pairing_t *, unsigned char *, const unsigned char *, const unsigned char *, size_t);
   int (*gt_pow)(pbc_hip_pairing_t *, unsigned char *, const unsigned char *, const unsigned char *, size_t);
   int (*from_hash)(pbc_hip_pairing_t *, int, unsigned char *, const unsigned char *, int, size_t);
+  int (*host_alloc)(void **, size_t);
+  void (*host_free)(void *);
 } L;
 
-/* one attachment per pairing_s (kept in a tiny table keyed by the pairing pointer so that
- * struct pairing_s itself needs no new field) */
+/* one attachment per pairing_s (kept in a table keyed by the pairing pointer so that struct pairing_s itself needs no
+ * new field).  The table grows on demand and is guarded by a lock; an entry is removed by pbc_hip_detach or by
+ * pairing_clear itself (the pairing's clear_func is hooked), so a pairing_t reused at the same address attaches anew. */
 typedef struct {
   struct pairing_s *pairing;
   pbc_hip_pairing_t *gpu;
@@ -40,12 +43,55 @@ typedef struct {
   void (*cpu_pp_init)(pairing_pp_t, element_t, struct pairing_s *);
   void (*cpu_pp_clear)(pairing_pp_t);
   void (*cpu_pp_apply)(element_t, element_t, pairing_pp_t);
+  void (*cpu_clear)(struct pairing_s *);
+  /* page-locked staging buffers of the batch calls (pbc_hip_host_alloc): kept and grown, never per call */
+  unsigned char *pin[3];
+  size_t pin_cap[3];
 } attach_t;
-static attach_t g_att[16];
+static attach_t **g_att;
+static int g_natt, g_catt;
+static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER;
+/* calls that ran on the GPU (reported at exit when PBC_HIP_VERBOSE=1; the preload test reads them) */
+static struct { unsigned long map, prod, pp_init, pp_apply, batch_units; } g_stat;
 
 static attach_t *find(struct pairing_s *p) {
-  for (int i = 0; i < 16; i++) if (g_att[i].pairing == p) return &g_att[i];
-  return NULL;
+  attach_t *r = NULL;
+  pthread_mutex_lock(&g_lock);
+  for (int i = 0; i < g_natt; i++) if (g_att[i]->pairing == p) { r = g_att[i]; break; }
+  pthread_mutex_unlock(&g_lock);
+  return r;
+}
+static attach_t *add_entry(void) {
+  attach_t *a = calloc(1, sizeof *a);
+  if (!a) return NULL;
+  pthread_mutex_lock(&g_lock);
+  if (g_natt == g_catt) {
+    int nc = g_catt ? 2 * g_catt : 8;
+    attach_t **t = realloc(g_att, (size_t) nc * sizeof *t);
+    if (!t) { pthread_mutex_unlock(&g_lock); free(a); return NULL; }
+    g_att = t; g_catt = nc;
+  }
+  g_att[g_natt++] = a;
+  pthread_mutex_unlock(&g_lock);
+  return a;
+}
+static void drop_entry(attach_t *a) {
+  pthread_mutex_lock(&g_lock);
+  for (int i = 0; i < g_natt; i++) if (g_att[i] == a) { g_att[i] = g_att[--g_natt]; break; }
+  pthread_mutex_unlock(&g_lock);
+  for (int i = 0; i < 3; i++) if (a->pin[i]) L.host_free(a->pin[i]);
+  free(a);
+}
+/* at least `bytes` of page-locked memory in staging slot i of the attachment */
+static unsigned char *pinned(attach_t *a, int i, size_t bytes) {
+  if (a->pin_cap[i] < bytes) {
+    if (a->pin[i]) L.host_free(a->pin[i]);
+    a->pin[i] = NULL; a->pin_cap[i] = 0;
+    void *p = NULL;
+    if (L.host_alloc(&p, bytes + (bytes >> 2) + 64)) return NULL;
+    a->pin[i] = p; a->pin_cap[i] = bytes + (bytes >> 2) + 64;
+  }
+  return a->pin[i];
 }
 static int load_lib(void) {
   if (L.dl) return 0;
@@ -64,6 +110,7 @@ static int load_lib(void) {
   SYM(lenZr, "pbc_hip_pairing_length_in_bytes_Zr"); SYM(mul_zn, "pbc_hip_element_mul_zn_batch");
   SYM(gt_mul, "pbc_hip_element_mul_GT_batch"); SYM(gt_pow, "pbc_hip_element_pow_zn_GT_batch");
   SYM(from_hash, "pbc_hip_element_from_hash_batch");
+  SYM(host_alloc, "pbc_hip_host_alloc"); SYM(host_free, "pbc_hip_host_free");
 #undef SYM
   return 0;
 }
@@ -116,9 +163,9 @@ static void from_bytes_range(size_t lo, size_t hi, void *ctx) {
 static int run_batch(attach_t *a, element_t out[], element_t in1[], element_t in2[], size_t n, int k) {
   int l1 = L.len1(a->gpu), l2 = L.len2(a->gpu), lt = L.lenT(a->gpu);
   size_t terms = n * (size_t) k, m = 0;
-  unsigned char *b1 = malloc(terms * l1 + 1), *b2 = malloc(terms * l2 + 1), *bt = malloc(n * lt + 1);
+  unsigned char *b1 = pinned(a, 0, terms * l1), *b2 = pinned(a, 1, terms * l2), *bt = pinned(a, 2, n * lt);
   size_t *slot = malloc(n * sizeof *slot);
-  if (!b1 || !b2 || !bt || !slot) { free(b1); free(b2); free(bt); free(slot); return 1; }
+  if (!b1 || !b2 || !bt || !slot) { free(slot); pbc_error("pbc_hip: out of memory for a batch of %lu units", (unsigned long) n); return 1; }
   /* host pre-filter: identity inputs never reach the device (pairing_apply :123-130,
    * element_prod_pairing :161-168); PBC's wire format cannot express O */
   for (size_t u = 0; u < n; u++) {
@@ -133,20 +180,20 @@ static int run_batch(attach_t *a, element_t out[], element_t in1[], element_t in
     parallel_for(m, to_bytes_range, &c);
     rc = k == 1 ? L.pair(a->gpu, bt, b1, b2, m) : L.prod(a->gpu, bt, b1, b2, m, k);
     if (rc) pbc_error("pbc_hip: %s", L.err());
-    else parallel_for(m, from_bytes_range, &c);
+    else { parallel_for(m, from_bytes_range, &c); g_stat.batch_units += m; }
   }
-  free(b1); free(b2); free(bt); free(slot);
+  free(slot);
   return rc;
 }
 
 /* A GPU call behind one of PBC's void-returning hooks failed.  PBC's convention for an unrecoverable condition is
- * pbc_die (misc/utils.c:75-82: message, exit(128)), and that is the default here: a pairing silently computed
- * somewhere else would hide the fault.  A caller that prefers availability sets PBC_HIP_GLUE_CPU_ON_ERROR=1; the
- * hook then reports through pbc_error (honours pbc_set_msg_to_stderr) and runs the reference's own CPU routine. */
-static void gpu_failed(const char *what) {
-  const char *e = getenv("PBC_HIP_GLUE_CPU_ON_ERROR");
-  if (e && *e == '1') { pbc_error("pbc_hip: %s: %s (continuing on the CPU)", what, L.err()); return; }
-  pbc_die("pbc_hip: %s: %s", what, L.err());
+ * pbc_die (misc/utils.c:75-82: message, exit(128)); there is no other path: a pairing silently computed somewhere else
+ * would hide the fault. */
+static void gpu_failed(const char *what) { pbc_die("pbc_hip: %s: %s", what, L.err()); }
+static void *xmalloc(size_t n) {
+  void *p = malloc(n ? n : 1);
+  if (!p) pbc_die("pbc_hip: out of memory");
+  return p;
 }
 
 /* pairing->map replacement: `out` is the element INSIDE the GT wrapper (out->data of the GT
@@ -154,20 +201,23 @@ static void gpu_failed(const char *what) {
 static void hip_map(element_ptr out, element_ptr in1, element_ptr in2, struct pairing_s *p) {
   attach_t *a = find(p);
   int l1 = L.len1(a->gpu), l2 = L.len2(a->gpu), lt = L.lenT(a->gpu);
-  unsigned char *buf = malloc((size_t) l1 + l2 + lt);
+  unsigned char *buf = xmalloc((size_t) l1 + l2 + lt);
   element_to_bytes(buf, in1);
   element_to_bytes(buf + l1, in2);
-  if (L.pair(a->gpu, buf + l1 + l2, buf, buf + l1, 1)) { gpu_failed("element_pairing"); a->cpu_map(out, in1, in2, p); }
-  else element_from_bytes(out, buf + l1 + l2);
+  if (L.pair(a->gpu, buf + l1 + l2, buf, buf + l1, 1)) gpu_failed("element_pairing");
+  element_from_bytes(out, buf + l1 + l2);
+  g_stat.map++;
   free(buf);
 }
 static void hip_prod(element_ptr out, element_t in1[], element_t in2[], int n_prod, struct pairing_s *p) {
   attach_t *a = find(p);
   int l1 = L.len1(a->gpu), l2 = L.len2(a->gpu), lt = L.lenT(a->gpu);
-  unsigned char *b1 = malloc((size_t) n_prod * l1), *b2 = malloc((size_t) n_prod * l2), *bt = malloc(lt);
+  if (n_prod <= 0) { element_set1(out); return; }         /* the empty product (the reference's loops leave out = 1) */
+  unsigned char *b1 = xmalloc((size_t) n_prod * l1), *b2 = xmalloc((size_t) n_prod * l2), *bt = xmalloc(lt);
   for (int j = 0; j < n_prod; j++) { element_to_bytes(b1 + (size_t) j * l1, in1[j]); element_to_bytes(b2 + (size_t) j * l2, in2[j]); }
-  if (L.prod(a->gpu, bt, b1, b2, 1, n_prod)) { gpu_failed("element_prod_pairing"); a->cpu_prod(out, in1, in2, n_prod, p); }
-  else element_from_bytes(out, bt);
+  if (L.prod(a->gpu, bt, b1, b2, 1, n_prod)) gpu_failed("element_prod_pairing");
+  element_from_bytes(out, bt);
+  g_stat.prod++;
   free(b1); free(b2); free(bt);
 }
 
@@ -175,28 +225,30 @@ static void hip_prod(element_ptr out, element_t in1[], element_t in2[], int n_pr
  * p->data holds the GPU handle.  Installed for types a, d and g (plain_pp_* below for the rest). */
 static void hip_pp_init(pairing_pp_t p, element_t in1, struct pairing_s *pairing) {
   attach_t *a = find(pairing);
-  unsigned char *buf = malloc(L.len1(a->gpu));
+  unsigned char *buf = xmalloc(L.len1(a->gpu));
   void *h = NULL;
   element_to_bytes(buf, in1);
   if (L.pp_init(&h, a->gpu, buf)) pbc_die("pbc_hip: pairing_pp_init: %s", L.err());
   p->data = h;
+  g_stat.pp_init++;
   free(buf);
 }
 static void hip_pp_clear(pairing_pp_t p) { if (p->data) L.pp_clear(p->data); }
 static void hip_pp_apply(element_t out, element_t in2, pairing_pp_t p) {
   attach_t *a = find(p->pairing);
   int l2 = L.len2(a->gpu), lt = L.lenT(a->gpu);
-  unsigned char *buf = malloc((size_t) l2 + lt);
+  unsigned char *buf = xmalloc((size_t) l2 + lt);
   element_to_bytes(buf, in2);
   if (!p->data || L.pp_apply(p->data, buf + l2, buf, 1)) pbc_die("pbc_hip: pairing_pp_apply: %s", L.err());
-  else element_from_bytes(out, buf + l2);
+  element_from_bytes(out, buf + l2);
+  g_stat.pp_apply++;
   free(buf);
 }
 /* Types without a preprocessed form on the GPU (a1, e, f): pairing_pp keeps a copy of the first
  * argument and every apply is an ordinary GPU pairing. */
 static void plain_pp_init(pairing_pp_t p, element_t in1, struct pairing_s *pairing) {
   (void) pairing;
-  element_ptr c = malloc(sizeof(*c));
+  element_ptr c = xmalloc(sizeof(*c));
   element_init_same_as(c, in1);
   element_set(c, in1);
   p->data = c;
@@ -224,6 +276,7 @@ int pairing_pp_apply_batch(element_t out[], element_t in2[], size_t n, pairing_p
   int l2 = L.len2(a->gpu), lt = L.lenT(a->gpu);
   unsigned char *b2 = malloc(n * l2 + 1), *bt = malloc(n * lt + 1);
   size_t *slot = malloc(n * sizeof *slot), m = 0;
+  if (!b2 || !bt || !slot) { free(b2); free(bt); free(slot); return 1; }
   for (size_t i = 0; i < n; i++) {
     if (element_is0(in2[i])) { element_set0(out[i]); continue; }
     element_to_bytes(b2 + m * l2, in2[i]);
@@ -248,6 +301,7 @@ int element_pow_zn_batch(element_t out[], element_t in[], element_t zr[], size_t
   int le = element_length_in_bytes(in[0]), lz = L.lenZr(a->gpu);
   unsigned char *be = malloc(n * le + 1), *bz = malloc(n * lz + 1), *bo = malloc(n * le + 1);
   size_t *slot = malloc(n * sizeof *slot), m = 0;
+  if (!be || !bz || !bo || !slot) { free(be); free(bz); free(bo); free(slot); return 1; }
   for (size_t i = 0; i < n; i++) {
     if (element_is0(in[i]) || element_is0(zr[i])) { element_set0(out[i]); continue; }   /* x^0 = O^k = identity */
     element_to_bytes(be + m * le, in[i]);
@@ -273,6 +327,7 @@ int element_from_hash_batch(element_t out[], const void *data, int hlen, size_t 
   if (!group) return 1;
   int le = element_length_in_bytes(out[0]);
   unsigned char *bo = malloc(n * (size_t) le + 1);
+  if (!bo) return 1;
   int rc = L.from_hash(a->gpu, group, bo, data, hlen, n);
   if (rc) pbc_error("pbc_hip: %s", L.err());
   else for (size_t i = 0; i < n; i++) element_from_bytes(out[i], bo + i * (size_t) le);
@@ -280,14 +335,29 @@ int element_from_hash_batch(element_t out[], const void *data, int hlen, size_t 
   return rc;
 }
 
+static void report_at_exit(void) {
+  const char *e = getenv("PBC_HIP_VERBOSE");
+  if (e && *e == '1')
+    fprintf(stderr, "pbc_hip: on the GPU: %lu element_pairing, %lu element_prod_pairing, %lu pairing_pp_init, %lu pairing_pp_apply, "
+            "%lu units in batch calls\n", g_stat.map, g_stat.prod, g_stat.pp_init, g_stat.pp_apply, g_stat.batch_units);
+}
+/* pairing->clear_func replacement: drop the GPU object, then run the pairing's own clean-up (pairing_clear,
+ * ecc/pairing.c:104-106) */
+static void hip_clear(struct pairing_s *p) {
+  attach_t *a = find(p);
+  if (!a) return;
+  void (*cpu_clear)(struct pairing_s *) = a->cpu_clear;
+  pbc_hip_detach(p);
+  if (cpu_clear) cpu_clear(p);
+}
 int pbc_hip_attach(pairing_t pairing, const char *param, size_t len) {
+  static int registered;
   if (load_lib()) return 1;
-  attach_t *a = find(NULL);
-  if (!a || find(pairing)) return 1;
+  if (find(pairing)) return 1;                            /* attached already (detach first to re-attach) */
   pbc_hip_pairing_t *g;
   if (L.init(&g, param, len)) { pbc_error("pbc_hip: %s", L.err()); return 1; }
   if (L.len1(g) != pairing_length_in_bytes_G1(pairing) || L.len2(g) != pairing_length_in_bytes_G2(pairing) ||
-      L.lenT(g) != pairing_length_in_bytes_GT(pairing)) { L.clear(g); return 1; }
+      L.lenT(g) != pairing_length_in_bytes_GT(pairing)) { L.clear(g); pbc_error("pbc_hip: record lengths differ from the pairing's"); return 1; }
   {
     /* PBC_HIP_DEVICES=all (or a comma list of ordinals): batches are range-split over these GPUs */
     const char *e = getenv("PBC_HIP_DEVICES");
@@ -296,10 +366,15 @@ int pbc_hip_attach(pairing_t pairing, const char *param, size_t len) {
     else if (e) { for (const char *q = e; *q && nd < 16; ) { devs[nd++] = atoi(q); q = strchr(q, ','); if (!q) break; q++; } }
     if (nd > 0 && L.use_devices(g, devs, nd)) { pbc_error("pbc_hip: %s", L.err()); L.clear(g); return 1; }
   }
+  attach_t *a = add_entry();
+  if (!a) { L.clear(g); return 1; }
+  if (!registered) { registered = 1; atexit(report_at_exit); }
   a->pairing = pairing; a->gpu = g; a->cpu_map = pairing->map; a->cpu_prod = pairing->prod_pairings;
   a->cpu_pp_init = pairing->pp_init; a->cpu_pp_clear = pairing->pp_clear; a->cpu_pp_apply = pairing->pp_apply;
+  a->cpu_clear = pairing->clear_func;
   pairing->map = hip_map;
   pairing->prod_pairings = hip_prod;
+  pairing->clear_func = hip_clear;
   {
     /* preprocessed pairings exist on the GPU for types a, a1 ('1'), d and g */
     int t = L.type(g);
@@ -316,8 +391,9 @@ void pbc_hip_detach(pairing_t pairing) {
   if (!a) return;
   pairing->map = a->cpu_map; pairing->prod_pairings = a->cpu_prod;
   pairing->pp_init = a->cpu_pp_init; pairing->pp_clear = a->cpu_pp_clear; pairing->pp_apply = a->cpu_pp_apply;
+  pairing->clear_func = a->cpu_clear;
   L.clear(a->gpu);
-  memset(a, 0, sizeof *a);
+  drop_entry(a);
 }
 int element_pairing_batch(element_t out[], element_t in1[], element_t in2[], size_t n) {
   if (!n) return 0;

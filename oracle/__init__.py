@@ -18,6 +18,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.path.join(_HERE, "liboracle.so")
 REF_TOOL = os.path.join(_HERE, "_ref", "ref_tool")
 GLUE_TEST = os.path.join(_HERE, "_ref", "glue_test")
+PRELOAD_LIB = os.path.join(_HERE, "_ref", "libpbc_hip_preload.so")
+BLS_EXAMPLE = os.path.join(_HERE, "_ref", "bls_example")                # example/bls.c, unchanged, dynamic libpbc
+BLS_EXAMPLE_WRAPPED = os.path.join(_HERE, "_ref", "bls_example_wrapped")  # the same source linked with -Wl,--wrap
 
 
 def build(force=False):
@@ -28,7 +31,7 @@ def build(force=False):
     if os.path.isdir("/root/reference/arith"):
         if force or not os.path.exists(REF_TOOL):
             subprocess.check_call(["make", "-s", "-j8", "-C", _HERE, "ref"])
-        subprocess.check_call(["make", "-s", "-C", _HERE, "glue"])      # reference + integration glue
+        subprocess.check_call(["make", "-s", "-C", _HERE, "glue", "preload"])      # reference + integration glue, drop-in demo
 
 
 _lib = None

@@ -462,8 +462,69 @@ PBC_DEV void a_ws_get(fp<N> &a, const uint4 *ws, int e) {
     a.v[4 * q] = t.x; a.v[4 * q + 1] = t.y; a.v[4 * q + 2] = t.z; a.v[4 * q + 3] = t.w;
   }
 }
+// The shared accumulator f waits in LDS (limb-major, [2 N][lanes]) while a term's point arithmetic runs and is touched
+// only by the two f <- f * l updates: 32 fewer live registers in the term loop.
 template <int N>
-PBC_DEV void a_prod_pairing_lane(uint8_t *gt, const uint8_t *g1, const uint8_t *g2, int k, uint4 *ws) {
+PBC_DEV void a_lds_get(fp2<N> &f, const uint32_t *lds, int stride) {
+#pragma unroll
+  for (int i = 0; i < N; i++) { f.x.v[i] = lds[i * stride]; f.y.v[i] = lds[(N + i) * stride]; }
+}
+template <int N>
+PBC_DEV void a_lds_put(uint32_t *lds, int stride, const fp2<N> &f) {
+#pragma unroll
+  for (int i = 0; i < N; i++) { lds[i * stride] = f.x.v[i]; lds[(N + i) * stride] = f.y.v[i]; }
+}
+// One doubling step of a product term: the line value goes into the LDS accumulator, V <- 2V.  Same formulas as
+// a_double_step; split in two so that the caller can start fetching the next term's state between the halves.
+template <int N>
+PBC_DEV void a_prod_double_head(jac<N> &V, fp<N> &M, fp<N> &XX, fp<N> &YY, fp<N> &Z3, const fp<N> &Qx, const fp<N> &Qy,
+                                uint32_t *lds_f, int stride) {
+  fp<N> t0, t1;
+  fp2<N> l, f;
+  fp_sqr<N>(XX, V.X);
+  fp_sqr<N>(t0, V.ZZ);                 // Z^4
+  fp_dbl<N>(M, XX);
+  fp_add<N>(M, M, XX);
+  fp_add<N>(M, M, t0);                 // M = 3X^2 + Z^4
+  fp_sqr<N>(YY, V.Y);
+  fp_mul<N>(t0, V.ZZ, Qx);
+  fp_add<N>(t0, t0, V.X);
+  fp_mul<N>(l.x, M, t0);
+  fp_dbl<N>(t1, YY);
+  fp_sub<N>(l.x, l.x, t1);             // re = M (ZZ Qx + X) - 2Y^2
+  fp_add<N>(Z3, V.Y, V.Z);
+  fp_sqr<N>(Z3, Z3);
+  fp_sub<N>(Z3, Z3, YY);
+  fp_sub<N>(Z3, Z3, V.ZZ);             // Z3 = 2YZ
+  fp_mul<N>(t1, Z3, V.ZZ);
+  fp_mul<N>(l.y, t1, Qy);              // im = Z3 ZZ Qy
+  a_lds_get<N>(f, lds_f, stride);
+  fi_mul<N>(f, f, l);
+  a_lds_put<N>(lds_f, stride, f);
+}
+template <int N>
+PBC_DEV void a_prod_double_tail(jac<N> &V, const fp<N> &M, const fp<N> &XX, const fp<N> &YY, const fp<N> &Z3) {
+  fp<N> S, Y4, t0, t1;
+  fp_sqr<N>(Y4, YY);
+  fp_add<N>(S, V.X, YY);
+  fp_sqr<N>(S, S);
+  fp_sub<N>(S, S, XX);
+  fp_sub<N>(S, S, Y4);
+  fp_dbl<N>(S, S);                     // S = 4XY^2
+  fp_dbl<N>(t0, Y4);
+  fp_dbl<N>(t0, t0);
+  fp_dbl<N>(t0, t0);                   // 8Y^4
+  fp_sqr<N>(V.X, M);
+  fp_dbl<N>(t1, S);
+  fp_sub<N>(V.X, V.X, t1);             // X3 = M^2 - 2S
+  fp_sub<N>(t1, S, V.X);
+  fp_mul<N>(t1, M, t1);
+  fp_sub<N>(V.Y, t1, t0);              // Y3 = M(S - X3) - 8Y^4
+  V.Z = Z3;
+  fp_sqr<N>(V.ZZ, Z3);
+}
+template <int N>
+PBC_DEV void a_prod_pairing_lane(uint8_t *gt, const uint8_t *g1, const uint8_t *g2, int k, uint4 *ws, uint32_t *lds_f, int stride) {
   constexpr int L = 8 * N, NB = 4 * N, REC = 6 * (N / 4) * 128;      // bytes per record / coordinate, uint4s per term
   fp<N> one;
   fp_set<N>(one, fpk<N>().one);
@@ -483,25 +544,44 @@ PBC_DEV void a_prod_pairing_lane(uint8_t *gt, const uint8_t *g1, const uint8_t *
   f.x = one;
 #pragma unroll
   for (int i = 0; i < N; i++) f.y.v[i] = 0;
+  a_lds_put<N>(lds_f, stride, f);
+  // X and ZZ of the term about to be processed are fetched while the previous term's tail still computes
+  fp<N> nX, nZZ;
+  a_ws_get<N>(nX, ws, 0);
+  a_ws_get<N>(nZZ, ws, 3);
   for (int i = c_a.exp2 - 1; i >= 0; i--) {
+    a_lds_get<N>(f, lds_f, stride);
     fi_sqr<N>(f, f);
+    a_lds_put<N>(lds_f, stride, f);
     for (int j = 0; j < k; j++) {
       uint4 *w = ws + (size_t) j * REC;
       jac<N> V;
-      fp<N> Qx, Qy;
-      a_ws_get<N>(V.X, w, 0); a_ws_get<N>(V.Y, w, 1); a_ws_get<N>(V.Z, w, 2); a_ws_get<N>(V.ZZ, w, 3);
+      fp<N> Qx, Qy, M, XX, YY, Z3;
+      V.X = nX; V.ZZ = nZZ;
+      a_ws_get<N>(V.Y, w, 1); a_ws_get<N>(V.Z, w, 2);
       a_ws_get<N>(Qx, w, 4); a_ws_get<N>(Qy, w, 5);
-      a_double_step<N, false>(f, V, Qx, Qy);
-      if (i == c_a.exp1) {             // the one non-zero middle digit of r: V <- V +- P
+      a_prod_double_head<N>(V, M, XX, YY, Z3, Qx, Qy, lds_f, stride);
+      // the one non-zero middle digit of r: V <- V +- P after the doubling.  (A single term has no "next" one to fetch
+      // early: its own state is only valid after the store below.)
+      const bool add = i == c_a.exp1 || k == 1;
+      const bool plus_p = i == c_a.exp1;
+      const uint4 *wn = ws + (size_t) (j + 1 < k ? j + 1 : 0) * REC;   // next term (the first one again in the next iteration)
+      if (!add) { a_ws_get<N>(nX, wn, 0); a_ws_get<N>(nZZ, wn, 3); }
+      a_prod_double_tail<N>(V, M, XX, YY, Z3);
+      if (plus_p) {
         fp<N> x2, y2;
         fp_load_be<N>(x2, g1 + (size_t) j * L);
         fp_load_be<N>(y2, g1 + (size_t) j * L + NB);
         if (c_a.sign1 < 0) fp_neg<N>(y2, y2);
+        a_lds_get<N>(f, lds_f, stride);
         a_add_step<N>(f, V, x2, y2, Qx, Qy);
+        a_lds_put<N>(lds_f, stride, f);
       }
       a_ws_put<N>(w, 0, V.X); a_ws_put<N>(w, 1, V.Y); a_ws_put<N>(w, 2, V.Z); a_ws_put<N>(w, 3, V.ZZ);
+      if (add) { a_ws_get<N>(nX, wn, 0); a_ws_get<N>(nZZ, wn, 3); }      // (k = 1 would read its own fresh store: fine)
     }
   }
+  a_lds_get<N>(f, lds_f, stride);
   a_final_exp<N>(out, f);
   a_store_gt<N>(gt, out, valid);
 }

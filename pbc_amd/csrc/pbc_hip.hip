@@ -94,8 +94,9 @@ __global__ void __launch_bounds__(kBlock, PBC_A_WAVES) a_prod_pairing_kernel(uin
   size_t ld = idx < n ? idx : n - 1;
   constexpr int L = 8 * N;
   __attribute__((aligned(16))) uint8_t out[L];
+  __shared__ uint32_t lds_f[2 * N * kBlock];   // the shared accumulator of every lane, limb-major: conflict-free
   a_prod_pairing_lane<N>(out, g1 + ld * k * L, g2 + ld * k * L, k,
-                         ws + (size_t) blockIdx.x * (size_t) k * (6 * (N / 4) * kBlock) + threadIdx.x);
+                         ws + (size_t) blockIdx.x * (size_t) k * (6 * (N / 4) * kBlock) + threadIdx.x, lds_f + threadIdx.x, kBlock);
   if (idx < n) {
     uint4 *dst = reinterpret_cast<uint4 *>(gt + idx * L);
     const uint4 *src = reinterpret_cast<const uint4 *>(out);
@@ -1289,12 +1290,21 @@ extern "C" int pbc_hip_pairing_pp_init(pbc_hip_pp_t **out, pbc_hip_pairing_t *P,
     for (int m = 1; m <= P->a.rbits - 2; m++) steps += (P->a.r[m >> 5] >> (m & 31)) & 1;
     words = (size_t) steps * 3 * (size_t) P->nlimb;
   }
-  if (hipSetDevice(P->device) != hipSuccess || hipMalloc(&pp->tab, words * 4) != hipSuccess ||
-      hipMalloc(&pp->valid, 4) != hipSuccess || hipMalloc(&dg1, P->len1) != hipSuccess ||
-      hipMemcpy(dg1, g1, P->len1, hipMemcpyHostToDevice) != hipSuccess || ensure_derived(P, 0)) {
+  DeviceGuard guard(P->device);
+  DevBuf bg1;                          // released on every return path; the table and flag belong to pp
+  auto bail = [&](const char *what) {
+    std::string msg = g_err[0] ? std::string(g_err) : std::string();
+    if (pp->tab) (void) hipFree(pp->tab);
+    if (pp->valid) (void) hipFree(pp->valid);
     delete pp;
-    return fail("pairing_pp_init: device setup failed");
-  }
+    return msg.empty() ? fail("pairing_pp_init: %s", what) : fail("pairing_pp_init: %s (%s)", what, msg.c_str());
+  };
+  g_err[0] = 0;
+  if (ensure_derived(P, 0)) return bail("deriving the constants failed");
+  if (hipMalloc(&pp->tab, words * 4) != hipSuccess || hipMalloc(&pp->valid, 4) != hipSuccess || bg1.alloc(P->len1) != hipSuccess)
+    return bail("device allocation failed");
+  dg1 = bg1.p;
+  if (hipMemcpy(dg1, g1, P->len1, hipMemcpyHostToDevice) != hipSuccess) return bail("H2D copy failed");
   if (mnt) {
     PBC_DISPATCH_D(P, hipLaunchKernelGGL((d_pp_init_kernel<N, DEG>), dim3(1), dim3(64), 0, 0, pp->tab, pp->valid,
                                          (const uint8_t *) dg1, kargs<N>(P)));
@@ -1306,13 +1316,13 @@ extern "C" int pbc_hip_pairing_pp_init(pbc_hip_pp_t **out, pbc_hip_pairing_t *P,
     hipLaunchKernelGGL(a_pp_init_kernel<16>, dim3(1), dim3(64), 0, 0, pp->tab, pp->valid, (const uint8_t *) dg1, kargs<16>(P));
   }
   hipError_t e = hipDeviceSynchronize();
-  (void) hipFree(dg1);
-  if (e != hipSuccess) { delete pp; return fail("pairing_pp_init kernel: %s", hipGetErrorString(e)); }
+  if (e != hipSuccess) return bail(hipGetErrorString(e));
   *out = pp;
   return 0;
 }
 extern "C" void pbc_hip_pairing_pp_clear(pbc_hip_pp_t *pp) {
   if (!pp) return;
+  DeviceGuard guard(pp->P->device);
   (void) hipFree(pp->tab);
   (void) hipFree(pp->valid);
   delete pp;

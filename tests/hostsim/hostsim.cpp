@@ -91,7 +91,7 @@ int hostsim_prod_pairing(void *h, uint8_t *gt, const uint8_t *g1, const uint8_t 
   for (size_t u = 0; u < n; u++) {
     const uint8_t *a = g1 + u * k * P->len1, *b = g2 + u * k * P->len2;
     uint8_t *o = gt + u * P->lenT;
-    if (P->type == 'a' && !P->a_generic) { std::vector<uint4> ws((size_t) k * 24 * 128); a_prod_pairing_lane<16>(o, a, b, k, ws.data()); }
+    if (P->type == 'a' && !P->a_generic) { std::vector<uint4> ws((size_t) k * 24 * 128); a_prod_pairing_lane<16>(o, a, b, k, ws.data(), lds, 1); }
     else if ((P->type == 'a' || P->type == '1') && P->nlimb == 16) a1_prod_pairing_lane<16>(o, a, b, k, lds, 1);
     else if (P->type == '1' || P->type == 'a') a1_prod_pairing_lane<33>(o, a, b, k, lds, 1);
     else if (P->type == 'e' && P->nlimb == 16) e_prod_pairing_lane<16>(o, a, b, k, lds, 1);

@@ -9,7 +9,11 @@
  *   shared libpbc:   LD_PRELOAD=libpbc_hip_preload.so PBC_HIP_LIB=/path/libpbc_hip.so ./bls < a.param
  *                    (built by `make -C oracle preload`: this file + pbc_hip_glue.c, -shared)
  *   static libpbc:   cc prog.o pbc_hip_preload.c pbc_hip_glue.c -DPBC_HIP_LINK_WRAP \
- *                       -Wl,--wrap=pairing_init_pbc_param libpbc.a -lgmp -ldl -lpthread
+ *                       -Wl,--wrap=pairing_init_set_buf,--wrap=pairing_init_set_str,--wrap=pairing_init_pbc_param \
+ *                       libpbc.a -lgmp -ldl -lpthread
+ *                    (ld's --wrap redirects references BETWEEN object files only: the call from pairing_init_set_buf
+ *                    to pairing_init_pbc_param sits inside ecc/pairing.o, so the two entry points a program calls are
+ *                    wrapped as well; each pairing is attached exactly once)
  *
  * There is no CPU path behind it: if the GPU object cannot be built (no device, a pairing type the engine does not
  * have), the program ends with PBC's own pbc_die, as it would for a bad parameter file.  PBC_HIP_VERBOSE=1 prints at exit
@@ -34,10 +38,23 @@ static void attach_or_die(struct pairing_s *pairing, pbc_param_ptr p) {
 }
 
 #ifdef PBC_HIP_LINK_WRAP
+#include <string.h>
 void __real_pairing_init_pbc_param(struct pairing_s *pairing, pbc_param_ptr p);
-void __wrap_pairing_init_pbc_param(struct pairing_s *pairing, pbc_param_ptr p) {
+int __real_pairing_init_set_buf(struct pairing_s *pairing, const char *s, size_t len);
+int __real_pairing_init_set_str(struct pairing_s *pairing, const char *s);
+void __wrap_pairing_init_pbc_param(struct pairing_s *pairing, pbc_param_ptr p) {     /* programs that call it themselves */
   __real_pairing_init_pbc_param(pairing, p);
   attach_or_die(pairing, p);
+}
+int __wrap_pairing_init_set_buf(struct pairing_s *pairing, const char *s, size_t len) {
+  int rc = __real_pairing_init_set_buf(pairing, s, len);
+  if (!rc && pbc_hip_attach(pairing, s, len)) pbc_die("pbc_hip: cannot put this pairing on the GPU (see the message above)");
+  return rc;
+}
+int __wrap_pairing_init_set_str(struct pairing_s *pairing, const char *s) {
+  int rc = __real_pairing_init_set_str(pairing, s);
+  if (!rc && pbc_hip_attach(pairing, s, strlen(s))) pbc_die("pbc_hip: cannot put this pairing on the GPU (see the message above)");
+  return rc;
 }
 #else
 void pairing_init_pbc_param(struct pairing_s *pairing, pbc_param_ptr p) {

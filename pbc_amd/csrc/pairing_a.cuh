@@ -545,10 +545,6 @@ PBC_DEV void a_prod_pairing_lane(uint8_t *gt, const uint8_t *g1, const uint8_t *
 #pragma unroll
   for (int i = 0; i < N; i++) f.y.v[i] = 0;
   a_lds_put<N>(lds_f, stride, f);
-  // X and ZZ of the term about to be processed are fetched while the previous term's tail still computes
-  fp<N> nX, nZZ;
-  a_ws_get<N>(nX, ws, 0);
-  a_ws_get<N>(nZZ, ws, 3);
   for (int i = c_a.exp2 - 1; i >= 0; i--) {
     a_lds_get<N>(f, lds_f, stride);
     fi_sqr<N>(f, f);
@@ -557,18 +553,12 @@ PBC_DEV void a_prod_pairing_lane(uint8_t *gt, const uint8_t *g1, const uint8_t *
       uint4 *w = ws + (size_t) j * REC;
       jac<N> V;
       fp<N> Qx, Qy, M, XX, YY, Z3;
-      V.X = nX; V.ZZ = nZZ;
+      a_ws_get<N>(V.X, w, 0); a_ws_get<N>(V.ZZ, w, 3);
       a_ws_get<N>(V.Y, w, 1); a_ws_get<N>(V.Z, w, 2);
       a_ws_get<N>(Qx, w, 4); a_ws_get<N>(Qy, w, 5);
       a_prod_double_head<N>(V, M, XX, YY, Z3, Qx, Qy, lds_f, stride);
-      // the one non-zero middle digit of r: V <- V +- P after the doubling.  (A single term has no "next" one to fetch
-      // early: its own state is only valid after the store below.)
-      const bool add = i == c_a.exp1 || k == 1;
-      const bool plus_p = i == c_a.exp1;
-      const uint4 *wn = ws + (size_t) (j + 1 < k ? j + 1 : 0) * REC;   // next term (the first one again in the next iteration)
-      if (!add) { a_ws_get<N>(nX, wn, 0); a_ws_get<N>(nZZ, wn, 3); }
       a_prod_double_tail<N>(V, M, XX, YY, Z3);
-      if (plus_p) {
+      if (i == c_a.exp1) {             // the one non-zero middle digit of r: V <- V +- P after the doubling
         fp<N> x2, y2;
         fp_load_be<N>(x2, g1 + (size_t) j * L);
         fp_load_be<N>(y2, g1 + (size_t) j * L + NB);
@@ -578,7 +568,6 @@ PBC_DEV void a_prod_pairing_lane(uint8_t *gt, const uint8_t *g1, const uint8_t *
         a_lds_put<N>(lds_f, stride, f);
       }
       a_ws_put<N>(w, 0, V.X); a_ws_put<N>(w, 1, V.Y); a_ws_put<N>(w, 2, V.Z); a_ws_put<N>(w, 3, V.ZZ);
-      if (add) { a_ws_get<N>(nX, wn, 0); a_ws_get<N>(nZZ, wn, 3); }      // (k = 1 would read its own fresh store: fine)
     }
   }
   a_lds_get<N>(f, lds_f, stride);

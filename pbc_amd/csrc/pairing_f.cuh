@@ -47,6 +47,12 @@ static_assert(sizeof(FConst) <= KOFF_XS - KOFF_TYPE, "constant block layout");
 #define c_f (pbc::kconst<pbc::FConst, pbc::KOFF_TYPE>())
 struct FRaw { uint32_t b[NF_MAX], beta[NF_MAX], alpha0[NF_MAX], alpha1[NF_MAX]; uint32_t e6[NF_MAX + 1]; int e6bits; };
 
+// LDS staging area of the F_q^12 products: the limb forms (x, y of six coefficients) of one operand per lane,
+// limb-major for 128-lane workgroups (36 KB for the 5-word field: four workgroups per CU)
+// (5-word fields: two such areas, so that the Miller accumulator can be updated from one into the other)
+template <int ND> constexpr int kF12Bufs = Limbs29<ND>::L <= 6 ? 2 : 1;
+template <int ND> __shared__ uint32_t g_lds_f12[kF12Bufs<ND> * 12 * Limbs29<ND>::L * 128];
+
 // Everything below is per field width: ND 32-bit words per F_q element (5 for f.param, 8 for 256-bit BN fields).
 template <int ND>
 struct TypeF {
@@ -137,137 +143,159 @@ static __device__ __noinline__ void f12_one(f12 *r) {
   for (int i = 0; i < 6; i++) g2_zero(r->c[i]);
   r->c[0].x = one;
 }
-// Limb forms of the six coefficients of an operand: x, y and beta*y (needed by every product)
-struct f12l { fl<ND> x[6], y[6], by[6]; };
-static __device__ __noinline__ void f12_to_limbs(f12l *L, const f12 *a, bool with_by) {
+// ---- products in F_q^12: one operand in registers, the other staged in LDS ---------------------------------
+// An F_q^12 element is 60 words and lives in the lane's private memory between operations.  The product routines do
+// not work on that memory: the first operand's limb forms (x, y and beta*y of the six coefficients) are loaded into
+// registers once, with compile-time indices; the second operand's limb forms are staged in LDS (limb-major,
+// [coefficient][x|y][limb][lane]: conflict-free), where the partner coefficient of a product -- whose index depends on the
+// rolled loop over the output coefficients -- is read at LDS speed.  Per product the private memory sees the operands
+// once and the result once (about 200 dword accesses instead of more than a thousand).
+static constexpr int FL = Limbs29<ND>::L;
+static constexpr int F_LANES = 128;
+static PBC_DEV fl<ND> ldsf_get(int c, int part, int buf = 0) {
+  fl<ND> r;
+#pragma unroll
+  for (int i = 0; i < FL; i++) r.l[i] = g_lds_f12<ND>[(((buf * 6 + c) * 2 + part) * FL + i) * F_LANES + threadIdx.x];
+  return r;
+}
+static PBC_DEV void ldsf_put(int c, int part, const fl<ND> &a, int buf = 0) {
+#pragma unroll
+  for (int i = 0; i < FL; i++) g_lds_f12<ND>[(((buf * 6 + c) * 2 + part) * FL + i) * F_LANES + threadIdx.x] = a.l[i];
+}
+struct f12r { fl<ND> x[6], y[6], by[6]; };     // register-resident operand: every access uses a compile-time index
+// a -> registers (and, when `stage`, its x / y limb forms to LDS as well: the squaring's second operand is the first)
+static PBC_DEV void f12_load_regs(f12r &A, const f12 *a, bool stage) {
   fl<ND> be;
   to_limbs<ND>(be, dk(c_f.beta));
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    to_limbs<ND>(A.x[i], a->c[i].x);
+    to_limbs<ND>(A.y[i], a->c[i].y);
+    const fl<ND> xx[1] = {A.y[i]}, yy[1] = {be};
+    sop_limbs<ND, 1>(A.by[i], xx, yy);
+    if (stage) { ldsf_put(i, 0, A.x[i]); ldsf_put(i, 1, A.y[i]); }
+  }
+}
+static PBC_DEV void f12_stage(const f12 *b) {
 #pragma nounroll
   for (int i = 0; i < 6; i++) {
     fl<ND> x, y;
-    to_limbs<ND>(x, a->c[i].x);
-    to_limbs<ND>(y, a->c[i].y);
-    L->x[i] = x;
-    L->y[i] = y;
-    if (with_by) {
-      fl<ND> t;
-      const fl<ND> xx[1] = {y}, yy[1] = {be};
-      sop_limbs<ND, 1>(t, xx, yy);
-      L->by[i] = t;
-    }
+    to_limbs<ND>(x, b->c[i].x);
+    to_limbs<ND>(y, b->c[i].y);
+    ldsf_put(i, 0, x);
+    ldsf_put(i, 1, y);
   }
 }
-// d (11 coefficients of the degree-10 product) -> r = d mod (X^6 - negalpha)
-static __device__ __noinline__ void f12_fold(f12 *r, const g2 *d) {
-  const g2 na = fk2(c_f.negalpha);
-#pragma nounroll
-  for (int i = 0; i < 6; i++) {
-    g2 t = d[i];
-    if (i < 5) {
-      g2 u;
-      g2_mul(u, d[6 + i], na);
-      g2_add(t, t, u);
-    }
-    r->c[i] = t;
-  }
-}
-// polymod_mul (poly.c:1005-1047): schoolbook over the coefficients, X^(6+i) = negalpha X^i.
-// Coefficient k of the product:  re = sum_{i+j=k} a_i.x b_j.x + (beta a_i.y) b_j.y,
-//                                im = sum_{i+j=k} a_i.x b_j.y + a_i.y b_j.x
-// accumulated UNREDUCED in wide column accumulators (up to 4 pairs = 8 products per Montgomery
-// reduction instead of one reduction per F_q product).
 // capacity of a wide accumulator in product units: (units + 1) L 2^58 < 2^64
 static constexpr int kCap = 63 / Limbs29<ND>::L - 1;
 static constexpr int kPairs = kCap / 2;            // products of one F_q^2 pair land 2 per accumulator
 static_assert(kCap >= 6, "field too wide for the F_q^12 accumulators");
-static __device__ __noinline__ void f12_mul(f12 *r, const f12 *a, const f12 *b) {
-  f12l A, B;
-  f12_to_limbs(&A, a, true);
-  f12_to_limbs(&B, b, false);
-  g2 d[11];
-#pragma nounroll
-  for (int k = 0; k < 11; k++) {
-    const int lo = k > 5 ? k - 5 : 0, hi = k < 5 ? k : 5;
-    g2 acc;
-    g2_zero(acc);
-    wide<ND> Wx, Wy;
-    wide_zero<ND>(Wx);
-    wide_zero<ND>(Wy);
-    int cnt = 0;
-#pragma nounroll
-    for (int i = lo; i <= hi; i++) {
-      const int j = k - i;
-      const fl<ND> ax = A.x[i], ay = A.y[i], aby = A.by[i], bx = B.x[j], by = B.y[j];
-      wide_mac<ND>(Wx, ax, bx);
-      wide_mac<ND>(Wx, aby, by);
-      wide_mac<ND>(Wy, ax, by);
-      wide_mac<ND>(Wy, ay, bx);
-      if (++cnt == kPairs || i == hi) {
-        fl<ND> t;
-        fq u;
-        wide_reduce<ND>(t, Wx); from_limbs<ND>(u, t); fp_add<ND>(acc.x, acc.x, u);
-        wide_reduce<ND>(t, Wy); from_limbs<ND>(u, t); fp_add<ND>(acc.y, acc.y, u);
-        wide_zero<ND>(Wx);
-        wide_zero<ND>(Wy);
-        cnt = 0;
-      }
-    }
-    d[k] = acc;
+static PBC_DEV void wide_flush(g2 &acc, wide<ND> &Wx, wide<ND> &Wy) {
+  fl<ND> t;
+  fq u;
+  wide_reduce<ND>(t, Wx); from_limbs<ND>(u, t); fp_add<ND>(acc.x, acc.x, u);
+  wide_reduce<ND>(t, Wy); from_limbs<ND>(u, t); fp_add<ND>(acc.y, acc.y, u);
+  wide_zero<ND>(Wx);
+  wide_zero<ND>(Wy);
+}
+// polymod_mul (poly.c:1005-1047): schoolbook over the coefficients.  Coefficient k of the plain product:
+//     re = sum_{i+j=k} a_i.x b_j.x + (beta a_i.y) b_j.y,   im = sum_{i+j=k} a_i.x b_j.y + a_i.y b_j.x
+// accumulated UNREDUCED in wide column accumulators (up to kPairs pairs per Montgomery reduction instead of one
+// reduction per F_q product).  A in registers, b_j from LDS.
+static PBC_DEV g2 f12_mul_coeff(const f12r &A, int k) {
+  g2 acc;
+  g2_zero(acc);
+  wide<ND> Wx, Wy;
+  wide_zero<ND>(Wx);
+  wide_zero<ND>(Wy);
+  int cnt = 0;
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    const int j = k - i;
+    if (j < 0 || j > 5) continue;                // wave-uniform
+    const fl<ND> bx = ldsf_get(j, 0), by = ldsf_get(j, 1);
+    wide_mac<ND>(Wx, A.x[i], bx);
+    wide_mac<ND>(Wx, A.by[i], by);
+    wide_mac<ND>(Wy, A.x[i], by);
+    wide_mac<ND>(Wy, A.y[i], bx);
+    if (++cnt == kPairs) { wide_flush(acc, Wx, Wy); cnt = 0; }
   }
-  f12_fold(r, d);
+  if (cnt) wide_flush(acc, Wx, Wy);
+  return acc;
 }
 // polymod_square (poly.c:1091-1143): cross terms once with a doubled operand, squares once.
 // A cross pair is 2 doubled products per accumulator (4 capacity units), a square pair 2 units.
-static __device__ __noinline__ void f12_sqr(f12 *r, const f12 *a) {
-  f12l A;
-  f12_to_limbs(&A, a, true);
-  g2 d[11];
-#pragma nounroll
-  for (int k = 0; k < 11; k++) {
-    const int lo = k > 5 ? k - 5 : 0, hi = k < 5 ? k : 5;
-    g2 acc;
-    g2_zero(acc);
-    wide<ND> Wx, Wy;
-    wide_zero<ND>(Wx);
-    wide_zero<ND>(Wy);
-    int units = 0;
-#pragma nounroll
-    for (int i = lo; 2 * i <= k; i++) {
-      const int j = k - i;
-      const fl<ND> ax = A.x[i], ay = A.y[i], aby = A.by[i];
-      if (i == j) {
-        // a_i^2: re = x^2 + (beta y) y, im = 2 x y
-        fl<ND> ax2;
-        limbs_dbl<ND>(ax2, ax);
-        wide_mac<ND>(Wx, ax, ax);
-        wide_mac<ND>(Wx, aby, ay);
-        wide_mac<ND>(Wy, ax2, ay);
-        units += 2;
-      } else {
-        // 2 a_i a_j
-        fl<ND> bx2, by2;
-        limbs_dbl<ND>(bx2, A.x[j]);
-        limbs_dbl<ND>(by2, A.y[j]);
-        wide_mac<ND>(Wx, ax, bx2);
-        wide_mac<ND>(Wx, aby, by2);
-        wide_mac<ND>(Wy, ax, by2);
-        wide_mac<ND>(Wy, ay, bx2);
-        units += 4;
-      }
-      const bool last = (2 * (i + 1) > k);
-      if (units + 4 > kCap || last) {
-        fl<ND> t;
-        fq u;
-        wide_reduce<ND>(t, Wx); from_limbs<ND>(u, t); fp_add<ND>(acc.x, acc.x, u);
-        wide_reduce<ND>(t, Wy); from_limbs<ND>(u, t); fp_add<ND>(acc.y, acc.y, u);
-        wide_zero<ND>(Wx);
-        wide_zero<ND>(Wy);
-        units = 0;
-      }
+static PBC_DEV g2 f12_sqr_coeff(const f12r &A, int k) {
+  g2 acc;
+  g2_zero(acc);
+  wide<ND> Wx, Wy;
+  wide_zero<ND>(Wx);
+  wide_zero<ND>(Wy);
+  int units = 0;
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    const int j = k - i;
+    if (j < i || j > 5) continue;                // pairs i <= j, wave-uniform
+    if (i == j) {
+      // a_i^2: re = x^2 + (beta y) y, im = 2 x y
+      fl<ND> ax2;
+      limbs_dbl<ND>(ax2, A.x[i]);
+      wide_mac<ND>(Wx, A.x[i], A.x[i]);
+      wide_mac<ND>(Wx, A.by[i], A.y[i]);
+      wide_mac<ND>(Wy, ax2, A.y[i]);
+      units += 2;
+    } else {
+      // 2 a_i a_j
+      fl<ND> bx2, by2;
+      limbs_dbl<ND>(bx2, ldsf_get(j, 0));
+      limbs_dbl<ND>(by2, ldsf_get(j, 1));
+      wide_mac<ND>(Wx, A.x[i], bx2);
+      wide_mac<ND>(Wx, A.by[i], by2);
+      wide_mac<ND>(Wy, A.x[i], by2);
+      wide_mac<ND>(Wy, A.y[i], bx2);
+      units += 4;
     }
-    d[k] = acc;
+    if (units + 4 > kCap) { wide_flush(acc, Wx, Wy); units = 0; }
   }
-  f12_fold(r, d);
+  if (units) wide_flush(acc, Wx, Wy);
+  return acc;
+}
+// r_k = d_k + negalpha d_{k+6}  (X^(6+k) = negalpha X^k), k = 0..5; d_11 does not exist
+// (the two coefficients of a fold pair share one instance of the coefficient body: instruction-cache footprint)
+static __device__ __noinline__ void f12_mul(f12 *r, const f12 *a, const f12 *b) {
+  f12r A;
+  f12_load_regs(A, a, false);
+  f12_stage(b);
+  const g2 na = fk2(c_f.negalpha);
+#pragma nounroll
+  for (int k = 0; k < 6; k++) {
+    g2 t;
+    g2_zero(t);
+#pragma nounroll
+    for (int h = 1; h >= 0; h--) {
+      if (h && k == 5) continue;
+      g2 u = f12_mul_coeff(A, k + 6 * h);
+      if (h) g2_mul(t, u, na); else g2_add(t, t, u);
+    }
+    r->c[k] = t;                                 // r may be a or b: both are in registers / LDS by now
+  }
+}
+static __device__ __noinline__ void f12_sqr(f12 *r, const f12 *a) {
+  f12r A;
+  f12_load_regs(A, a, true);
+  const g2 na = fk2(c_f.negalpha);
+#pragma nounroll
+  for (int k = 0; k < 6; k++) {
+    g2 t;
+    g2_zero(t);
+#pragma nounroll
+    for (int h = 1; h >= 0; h--) {
+      if (h && k == 5) continue;
+      g2 u = f12_sqr_coeff(A, k + 6 * h);
+      if (h) g2_mul(t, u, na); else g2_add(t, t, u);
+    }
+    r->c[k] = t;
+  }
 }
 // coefficient-wise even-power Frobenius: out^(q^k), X^(q^k) = e X (qpower, f_param.c:257-268)
 static __device__ __noinline__ void f12_qpower(f12 *r, const f12 *a, const uint32_t (*ew)[NF_MAX]) {
@@ -305,9 +333,29 @@ static __device__ __noinline__ void f12_inv(f12 *r, const f12 *a) {
 }
 
 // v <- v * (a Qx X^4 + b Qy X^3 + c)   (f_miller_evalfn, f_param.c:109-149)
-// out_i = c v_i + [aQx] v_{i-4} + [bQy] v_{i-3}, indices mod 6 with a factor negalpha on wrap
+// out_i = c v_i + [aQx] v_{i-4} + [bQy] v_{i-3}, indices mod 6 with a factor negalpha on wrap.
+// v is staged in LDS; each output coefficient is ONE lazily reduced sum per component (five limb products, one
+// Montgomery reduction):
+//   re = c v_i.x + fa.x v_j.x + (beta fa.y) v_j.y + fb.x v_k.x + (beta fb.y) v_k.y
+//   im = c v_i.y + fa.x v_j.y + fa.y v_j.x + fb.x v_k.y + fb.y v_k.x
 // (a, b, c travel as vectors: by-value fq structs beyond clang's 16-register aggregate budget
 // are passed indirectly, and that path miscompiled here -- see profiles/r01_notes.md)
+struct g2l { fl<ND> x, y, by; };
+static PBC_DEV void g2l_make(g2l &r, const g2 &a, const fl<ND> &be) {
+  to_limbs<ND>(r.x, a.x);
+  to_limbs<ND>(r.y, a.y);
+  const fl<ND> xx[1] = {r.y}, yy[1] = {be};
+  sop_limbs<ND, 1>(r.by, xx, yy);
+}
+static PBC_DEV void g2l_sel(g2l &r, const g2l &a, const g2l &b, bool take_b) {
+#pragma unroll
+  for (int i = 0; i < FL; i++) {
+    r.x.l[i] = take_b ? b.x.l[i] : a.x.l[i];
+    r.y.l[i] = take_b ? b.y.l[i] : a.y.l[i];
+    r.by.l[i] = take_b ? b.by.l[i] : a.by.l[i];
+  }
+}
+static_assert(kCap >= 5, "five products per accumulator in f_line_mul");
 static __device__ __noinline__ void f_line_mul(f12 *v, v5 va, v5 vb, v5 vc, const g2 *Qx, const g2 *Qy) {
   fq a, b, c;
   from_vec<ND>(a, va);
@@ -319,24 +367,246 @@ static __device__ __noinline__ void f_line_mul(f12 *v, v5 va, v5 vb, v5 vc, cons
   g2_mul_fq(bq, *Qy, b);
   g2_mul(aqn, aq, na);
   g2_mul(bqn, bq, na);
-  f12 e0;
+  fl<ND> be, cl;
+  to_limbs<ND>(be, dk(c_f.beta));
+  to_limbs<ND>(cl, c);
+  g2l Aq, Aqn, Bq, Bqn;
+  g2l_make(Aq, aq, be);
+  g2l_make(Aqn, aqn, be);
+  g2l_make(Bq, bq, be);
+  g2l_make(Bqn, bqn, be);
+  f12_stage(v);
 #pragma nounroll
   for (int i = 0; i < 6; i++) {
     int j = i + 2, k = i + 3;          // j = i - 4 mod 6, k = i - 3 mod 6
     bool wj = true, wk = true;         // wrapped (needs negalpha) unless i >= 4 / i >= 3
     if (j >= 6) { j -= 6; wj = false; }
     if (k >= 6) { k -= 6; wk = false; }
-    g2 t, u, fa, fb;
-    if (wj) fa = aqn; else fa = aq;
-    if (wk) fb = bqn; else fb = bq;
-    g2_mul(t, v->c[j], fa);
-    g2_mul(u, v->c[k], fb);
-    g2_add(t, t, u);
-    g2_mul_fq(u, v->c[i], c);
-    g2_add(t, t, u);
-    e0.c[i] = t;
+    g2l fa, fb;
+    g2l_sel(fa, Aq, Aqn, wj);
+    g2l_sel(fb, Bq, Bqn, wk);
+    const fl<ND> vix = ldsf_get(i, 0), viy = ldsf_get(i, 1), vjx = ldsf_get(j, 0), vjy = ldsf_get(j, 1),
+                 vkx = ldsf_get(k, 0), vky = ldsf_get(k, 1);
+    fl<ND> t;
+    g2 o;
+    {
+      const fl<ND> x[5] = {cl, fa.x, fa.by, fb.x, fb.by}, y[5] = {vix, vjx, vjy, vkx, vky};
+      sop_limbs<ND, 5>(t, x, y);
+      from_limbs<ND>(o.x, t);
+    }
+    {
+      const fl<ND> x[5] = {cl, fa.x, fa.y, fb.x, fb.y}, y[5] = {viy, vjy, vjx, vky, vkx};
+      sop_limbs<ND, 5>(t, x, y);
+      from_limbs<ND>(o.y, t);
+    }
+    v->c[i] = o;                       // v itself is no longer read: it sits in LDS
   }
-  *v = e0;
+}
+
+// ---- the Miller accumulator lives in LDS ----------------------------------------------------------------------
+// Inside the Miller loop (5-word fields) the accumulator v never touches private memory: it stays in LDS in limb form
+// (values below 2q, no conversions between operations), in one of two areas; each operation reads its operands from
+// the current area at LDS speed -- also the partner coefficient of a product, whose index depends on the rolled output
+// loop -- and writes the result coefficients into the other area.  Register needs stay small (no spills), at the price
+// of 72 KB of LDS per workgroup: one wave per SIMD.
+static constexpr bool kLdsMiller = kF12Bufs<ND> == 2;
+static PBC_DEV fl<ND> flk(const uint32_t *w) { fl<ND> r; to_limbs<ND>(r, dk(w)); return r; }   // a constant's limb form
+// accumulator overflow guard: fold the running sum through one Montgomery reduction and carry it on as a single
+// product with R mod q (t R / R = t)
+static PBC_DEV void wide_carry(wide<ND> &W, const fl<ND> &oneL) {
+  fl<ND> t;
+  wide_reduce<ND>(t, W);
+  wide_zero<ND>(W);
+  wide_mac<ND>(W, t, oneL);
+}
+// area `cur` squared into area 1 - cur.  Coefficient k + 6 of the plain square is reduced first and enters coefficient k
+// through X^(6+k) = negalpha X^k as four more products of the same lazy sums: one reduction per output component.
+static __device__ __noinline__ void f12_sqr_lds(int cur) {
+  fl<ND> by[6];                                  // beta y_i for the compile-time index of each pair
+#pragma unroll
+  for (int i = 0; i < 6; i++) { const fl<ND> xx[1] = {ldsf_get(i, 1, cur)}, yy[1] = {flk(c_f.beta)}; sop_limbs<ND, 1>(by[i], xx, yy); }
+#pragma nounroll
+  for (int kk = 0; kk < 6; kk++) {
+    fl<ND> t6x, t6y;
+    wide<ND> Wx, Wy;
+#pragma nounroll
+    for (int h = 1; h >= 0; h--) {
+      if (h && kk == 5) continue;                // X^11 does not occur
+      const int k = kk + 6 * h;
+      wide_zero<ND>(Wx);
+      wide_zero<ND>(Wy);
+      int units = 0;
+#pragma unroll
+      for (int i = 0; i < 6; i++) {
+        const int j = k - i;
+        if (j < i || j > 5) continue;            // pairs i <= j (wave-uniform)
+        if (units + 4 > kCap) { const fl<ND> oneL = flk(fpk<ND>().one); wide_carry(Wx, oneL); wide_carry(Wy, oneL); units = 1; }
+        const fl<ND> ax = ldsf_get(i, 0, cur), ay = ldsf_get(i, 1, cur);
+        if (i == j) {                            // a_i^2: re = x^2 + (beta y) y, im = 2 x y
+          fl<ND> ax2;
+          limbs_dbl<ND>(ax2, ax);
+          wide_mac<ND>(Wx, ax, ax);
+          wide_mac<ND>(Wx, by[i], ay);
+          wide_mac<ND>(Wy, ax2, ay);
+          units += 2;
+        } else {                                 // 2 a_i a_j
+          fl<ND> b2;
+          limbs_dbl<ND>(b2, ldsf_get(j, 0, cur));
+          wide_mac<ND>(Wx, ax, b2);
+          wide_mac<ND>(Wy, ay, b2);
+          limbs_dbl<ND>(b2, ldsf_get(j, 1, cur));
+          wide_mac<ND>(Wx, by[i], b2);
+          wide_mac<ND>(Wy, ax, b2);
+          units += 4;
+        }
+      }
+      if (h) {
+        wide_reduce<ND>(t6x, Wx);
+        wide_reduce<ND>(t6y, Wy);
+      } else {
+        if (kk < 5) {                            // + negalpha * (coefficient k + 6)
+          if (units + 2 > kCap) { const fl<ND> oneL = flk(fpk<ND>().one); wide_carry(Wx, oneL); wide_carry(Wy, oneL); }
+          const fl<ND> nax = flk(c_f.negalpha[0]), nay = flk(c_f.negalpha[1]);
+          fl<ND> bnay;
+          { const fl<ND> xx[1] = {nay}, yy[1] = {flk(c_f.beta)}; sop_limbs<ND, 1>(bnay, xx, yy); }
+          wide_mac<ND>(Wx, nax, t6x);
+          wide_mac<ND>(Wx, bnay, t6y);
+          wide_mac<ND>(Wy, nax, t6y);
+          wide_mac<ND>(Wy, nay, t6x);
+        }
+        fl<ND> o;
+        wide_reduce<ND>(o, Wx);
+        ldsf_put(kk, 0, o, 1 - cur);
+        wide_reduce<ND>(o, Wy);
+        ldsf_put(kk, 1, o, 1 - cur);
+      }
+    }
+  }
+}
+// area `cur` times (a Qx X^4 + b Qy X^3 + c) into area 1 - cur (f_miller_evalfn, f_param.c:109-149): the formulas of
+// f_line_mul
+static __device__ __noinline__ void f_line_mul_lds(int cur, v5 va, v5 vb, v5 vc, const g2 *Qx, const g2 *Qy) {
+  fq a, b, c;
+  from_vec<ND>(a, va);
+  from_vec<ND>(b, vb);
+  from_vec<ND>(c, vc);
+  g2 aq, bq, aqn, bqn;
+  const g2 na = fk2(c_f.negalpha);
+  g2_mul_fq(aq, *Qx, a);
+  g2_mul_fq(bq, *Qy, b);
+  g2_mul(aqn, aq, na);
+  g2_mul(bqn, bq, na);
+  fl<ND> be, cl;
+  to_limbs<ND>(be, dk(c_f.beta));
+  to_limbs<ND>(cl, c);
+  g2l Aq, Aqn, Bq, Bqn;
+  g2l_make(Aq, aq, be);
+  g2l_make(Aqn, aqn, be);
+  g2l_make(Bq, bq, be);
+  g2l_make(Bqn, bqn, be);
+#pragma nounroll
+  for (int i = 0; i < 6; i++) {
+    int j = i + 2, k = i + 3;          // j = i - 4 mod 6, k = i - 3 mod 6
+    bool wj = true, wk = true;         // wrapped (needs negalpha) unless i >= 4 / i >= 3
+    if (j >= 6) { j -= 6; wj = false; }
+    if (k >= 6) { k -= 6; wk = false; }
+    g2l fa, fb;
+    g2l_sel(fa, Aq, Aqn, wj);
+    g2l_sel(fb, Bq, Bqn, wk);
+    const fl<ND> vix = ldsf_get(i, 0, cur), viy = ldsf_get(i, 1, cur), vjx = ldsf_get(j, 0, cur), vjy = ldsf_get(j, 1, cur),
+                 vkx = ldsf_get(k, 0, cur), vky = ldsf_get(k, 1, cur);
+    fl<ND> t;
+    {
+      const fl<ND> x[5] = {cl, fa.x, fa.by, fb.x, fb.by}, y[5] = {vix, vjx, vjy, vkx, vky};
+      sop_limbs<ND, 5>(t, x, y);
+      ldsf_put(i, 0, t, 1 - cur);
+    }
+    {
+      const fl<ND> x[5] = {cl, fa.x, fa.y, fb.x, fb.y}, y[5] = {viy, vjy, vjx, vky, vkx};
+      sop_limbs<ND, 5>(t, x, y);
+      ldsf_put(i, 1, t, 1 - cur);
+    }
+  }
+}
+// area `cur` times the private-memory element b into area 1 - cur (b's limb forms in registers with compile-time
+// indices, the accumulator's coefficients from LDS; fold as in f12_sqr_lds)
+static __device__ __noinline__ void f12_mul_lds(int cur, const f12 *b) {
+  f12r B;
+  f12_load_regs(B, b, false);
+#pragma nounroll
+  for (int kk = 0; kk < 6; kk++) {
+    fl<ND> t6x, t6y;
+    wide<ND> Wx, Wy;
+#pragma nounroll
+    for (int h = 1; h >= 0; h--) {
+      if (h && kk == 5) continue;
+      const int k = kk + 6 * h;
+      wide_zero<ND>(Wx);
+      wide_zero<ND>(Wy);
+      int units = 0;
+#pragma unroll
+      for (int i = 0; i < 6; i++) {
+        const int j = k - i;
+        if (j < 0 || j > 5) continue;            // wave-uniform
+        if (units + 2 > kCap) { const fl<ND> oneL = flk(fpk<ND>().one); wide_carry(Wx, oneL); wide_carry(Wy, oneL); units = 1; }
+        const fl<ND> ax = ldsf_get(j, 0, cur), ay = ldsf_get(j, 1, cur);
+        wide_mac<ND>(Wx, B.x[i], ax);
+        wide_mac<ND>(Wx, B.by[i], ay);
+        wide_mac<ND>(Wy, B.x[i], ay);
+        wide_mac<ND>(Wy, B.y[i], ax);
+        units += 2;
+      }
+      if (h) {
+        wide_reduce<ND>(t6x, Wx);
+        wide_reduce<ND>(t6y, Wy);
+      } else {
+        if (kk < 5) {
+          if (units + 2 > kCap) { const fl<ND> oneL = flk(fpk<ND>().one); wide_carry(Wx, oneL); wide_carry(Wy, oneL); }
+          const fl<ND> nax = flk(c_f.negalpha[0]), nay = flk(c_f.negalpha[1]);
+          fl<ND> bnay;
+          { const fl<ND> xx[1] = {nay}, yy[1] = {flk(c_f.beta)}; sop_limbs<ND, 1>(bnay, xx, yy); }
+          wide_mac<ND>(Wx, nax, t6x);
+          wide_mac<ND>(Wx, bnay, t6y);
+          wide_mac<ND>(Wy, nax, t6y);
+          wide_mac<ND>(Wy, nay, t6x);
+        }
+        fl<ND> o;
+        wide_reduce<ND>(o, Wx);
+        ldsf_put(kk, 0, o, 1 - cur);
+        wide_reduce<ND>(o, Wy);
+        ldsf_put(kk, 1, o, 1 - cur);
+      }
+    }
+  }
+}
+// a private-memory element into area `buf`
+static PBC_DEV void f12_lds_import(const f12 *a, int buf) {
+#pragma nounroll
+  for (int c = 0; c < 6; c++) {
+    fl<ND> x, y;
+    to_limbs<ND>(x, a->c[c].x);
+    to_limbs<ND>(y, a->c[c].y);
+    ldsf_put(c, 0, x, buf);
+    ldsf_put(c, 1, y, buf);
+  }
+}
+// 1 into area `buf`; area `buf` out to a private-memory element (canonical words)
+static PBC_DEV void f12_lds_one(int buf) {
+  fl<ND> oneL, z;
+  to_limbs<ND>(oneL, dk(fpk<ND>().one));
+#pragma unroll
+  for (int l = 0; l < FL; l++) z.l[l] = 0;
+#pragma nounroll
+  for (int c = 0; c < 6; c++) { ldsf_put(c, 0, c == 0 ? oneL : z, buf); ldsf_put(c, 1, z, buf); }
+}
+static PBC_DEV void f12_lds_export(f12 *r, int buf) {
+#pragma nounroll
+  for (int c = 0; c < 6; c++) {
+    g2 t;
+    from_limbs<ND>(t.x, ldsf_get(c, 0, buf));
+    from_limbs<ND>(t.y, ldsf_get(c, 1, buf));
+    r->c[c] = t;
+  }
 }
 
 // Miller function: G1 bytes x||y (2 x 20), G2 bytes x||y over F_q^2 (2 x 40)
@@ -373,7 +643,8 @@ static __device__ __noinline__ bool f_miller_lane(f12 *v, const uint8_t *g1, con
   }
   djac V;
   V.X = Px; V.Y = Py; V.Z = one; V.ZZ = one;
-  f12_one(v);
+  int cur = 0;                         // LDS area holding the accumulator (kLdsMiller)
+  if constexpr (kLdsMiller) f12_lds_one(cur); else f12_one(v);
   // cc_miller_no_denom (f_param.c:216-233): tangent; [double; line+add]; square
   for (int m = c_f.rbits - 2;; m--) {
     {
@@ -392,7 +663,8 @@ static __device__ __noinline__ bool f_miller_lane(f12 *v, const uint8_t *g1, con
       fp_mul<ND>(lc, M, V.X);
       fp_dbl<ND>(t1, YY);
       fp_sub<ND>(lc, lc, t1);
-      f_line_mul(v, to_vec<ND>(la), to_vec<ND>(lb), to_vec<ND>(lc), &Qx, &Qy);
+      if constexpr (kLdsMiller) { f_line_mul_lds(cur, to_vec<ND>(la), to_vec<ND>(lb), to_vec<ND>(lc), &Qx, &Qy); cur ^= 1; }
+      else f_line_mul(v, to_vec<ND>(la), to_vec<ND>(lb), to_vec<ND>(lc), &Qx, &Qy);
       fp_mul<ND>(S, V.X, YY);
       fp_dbl<ND>(S, S);
       fp_dbl<ND>(S, S);
@@ -424,7 +696,8 @@ static __device__ __noinline__ bool f_miller_lane(f12 *v, const uint8_t *g1, con
       fp_mul<ND>(lc, R, Px);
       fp_mul<ND>(t0, Z3, Py);
       fp_sub<ND>(lc, lc, t0);
-      f_line_mul(v, to_vec<ND>(la), to_vec<ND>(Z3), to_vec<ND>(lc), &Qx, &Qy);
+      if constexpr (kLdsMiller) { f_line_mul_lds(cur, to_vec<ND>(la), to_vec<ND>(Z3), to_vec<ND>(lc), &Qx, &Qy); cur ^= 1; }
+      else f_line_mul(v, to_vec<ND>(la), to_vec<ND>(Z3), to_vec<ND>(lc), &Qx, &Qy);
       fp_sqr<ND>(HH, H);
       fp_mul<ND>(HHH, HH, H);
       fp_mul<ND>(t0, V.X, HH);
@@ -440,8 +713,9 @@ static __device__ __noinline__ bool f_miller_lane(f12 *v, const uint8_t *g1, con
       V.Z = Z3;
       fp_sqr<ND>(V.ZZ, Z3);
     }
-    f12_sqr(v, v);
+    if constexpr (kLdsMiller) { f12_sqr_lds(cur); cur ^= 1; } else f12_sqr(v, v);
   }
+  if constexpr (kLdsMiller) f12_lds_export(v, cur);
   return valid;
 }
 
@@ -463,15 +737,27 @@ static __device__ __noinline__ void f12_frob(f12 *r, const f12 *a) {
     g2_mul(gpow, gpow, gm);
   }
 }
-// a^|x| by square-and-multiply (wave-uniform bits)
+// a^|x| by square-and-multiply (wave-uniform bits); on the 5-word fields the running power stays in LDS
 static __device__ __noinline__ void f12_pow_x(f12 *r, const f12 *a) {
-  f12 acc = *a;
+  if constexpr (kLdsMiller) {
+    int cur = 0;
+    f12_lds_import(a, cur);
 #pragma nounroll
-  for (int i = c_f.bn_xbits - 2; i >= 0; i--) {
-    f12_sqr(&acc, &acc);
-    if ((c_f.bn_x[i >> 5] >> (i & 31)) & 1) f12_mul(&acc, &acc, a);
+    for (int i = c_f.bn_xbits - 2; i >= 0; i--) {
+      f12_sqr_lds(cur);
+      cur ^= 1;
+      if ((c_f.bn_x[i >> 5] >> (i & 31)) & 1) { f12_mul_lds(cur, a); cur ^= 1; }
+    }
+    f12_lds_export(r, cur);                      // r may be a: a is no longer read
+  } else {
+    f12 acc = *a;
+#pragma nounroll
+    for (int i = c_f.bn_xbits - 2; i >= 0; i--) {
+      f12_sqr(&acc, &acc);
+      if ((c_f.bn_x[i >> 5] >> (i & 31)) & 1) f12_mul(&acc, &acc, a);
+    }
+    *r = acc;
   }
-  *r = acc;
 }
 
 // f_tateexp (f_param.c:250-283)

@@ -254,8 +254,10 @@ __global__ void __launch_bounds__(kBlock, PBC_DF_WAVES) d_pp_apply_kernel(uint8_
 #ifndef PBC_F_WAVES
 #define PBC_F_WAVES PBC_DF_WAVES
 #endif
+// (the 5-word field keeps its Miller accumulator in 72 KB of LDS per workgroup: two workgroups per CU, one wave per SIMD,
+// and the register budget that goes with it)
 template <int N>
-__global__ void __launch_bounds__(kBlock, PBC_F_WAVES) f_prod_pairing_kernel(uint8_t *gt, const uint8_t *g1,
+__global__ void __launch_bounds__(kBlock, N <= 5 ? 1 : PBC_F_WAVES) f_prod_pairing_kernel(uint8_t *gt, const uint8_t *g1,
                                                                  const uint8_t *g2, size_t n, int k, KArgs<N> ka) {
   size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
   size_t ld = idx < n ? idx : n - 1;
@@ -559,6 +561,31 @@ __global__ void __launch_bounds__(256) probe_kernel(uint32_t *sink, int iters, u
                         "v_mad_i64_i32 %6, vcc, %8, %9, %6\n\tv_mad_i64_i32 %7, vcc, %8, %9, %7"
                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
                         : "v"(x), "s"(seed) : "vcc");)
+    } else if constexpr (V == 16 || V == 17 || V == 18) {
+      // VGPR bank placement of the all-VGPR multiply-add (4 banks, bank = register number mod 4; the 64-bit accumulator
+      // takes two).  16: factors in the two banks the accumulator leaves free; 17: both factors in the accumulator's
+      // banks; 18: both factors in ONE free bank.  Explicit registers, eight chains.
+#define PBC_PROBE_MAD8(X_, Y_)                                                                                  \
+      "v_mad_u64_u32 v[100:101], vcc, " X_ ", " Y_ ", v[100:101]\n\tv_mad_u64_u32 v[104:105], vcc, " X_ ", " Y_ ", v[104:105]\n\t" \
+      "v_mad_u64_u32 v[108:109], vcc, " X_ ", " Y_ ", v[108:109]\n\tv_mad_u64_u32 v[112:113], vcc, " X_ ", " Y_ ", v[112:113]\n\t" \
+      "v_mad_u64_u32 v[116:117], vcc, " X_ ", " Y_ ", v[116:117]\n\tv_mad_u64_u32 v[120:121], vcc, " X_ ", " Y_ ", v[120:121]\n\t" \
+      "v_mad_u64_u32 v[124:125], vcc, " X_ ", " Y_ ", v[124:125]\n\tv_mad_u64_u32 v[128:129], vcc, " X_ ", " Y_ ", v[128:129]\n\t"
+#define PBC_PROBE_CLOB "vcc", "v100", "v101", "v104", "v105", "v108", "v109", "v112", "v113", "v116", "v117", "v120", "v121", \
+                       "v124", "v125", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135"
+      if (i == 0) asm volatile("v_mov_b32 v130, %0\n\tv_mov_b32 v131, %1\n\tv_mov_b32 v132, %0\n\tv_mov_b32 v133, %1\n\t"
+                               "v_mov_b32 v134, %0\n\tv_mov_b32 v135, %1\n\t"
+                               "v_mov_b32 v100, %0\n\tv_mov_b32 v101, 0\n\tv_mov_b32 v104, %1\n\tv_mov_b32 v105, 0\n\t"
+                               "v_mov_b32 v108, %0\n\tv_mov_b32 v109, 0\n\tv_mov_b32 v112, %1\n\tv_mov_b32 v113, 0\n\t"
+                               "v_mov_b32 v116, %0\n\tv_mov_b32 v117, 0\n\tv_mov_b32 v120, %1\n\tv_mov_b32 v121, 0\n\t"
+                               "v_mov_b32 v124, %0\n\tv_mov_b32 v125, 0\n\tv_mov_b32 v128, %1\n\tv_mov_b32 v129, 0"
+                               : : "v"(x), "v"(y) : PBC_PROBE_CLOB);
+      // accumulators sit in banks 0, 1 (v100 = 4 * 25); v130 / v134: bank 2, v131 / v135: bank 3, v132: bank 0, v133: bank 1
+      if constexpr (V == 16) { REP8(asm volatile(PBC_PROBE_MAD8("v130", "v131") "" : : : PBC_PROBE_CLOB);) }
+      else if constexpr (V == 17) { REP8(asm volatile(PBC_PROBE_MAD8("v132", "v133") "" : : : PBC_PROBE_CLOB);) }
+      else { REP8(asm volatile(PBC_PROBE_MAD8("v130", "v134") "" : : : PBC_PROBE_CLOB);) }
+      if (i == iters - 1) asm volatile("v_xor_b32 %0, v100, v104\n\tv_xor_b32 %0, %0, v108\n\tv_xor_b32 %0, %0, v129" : "=v"(c0) : : PBC_PROBE_CLOB);
+#undef PBC_PROBE_MAD8
+#undef PBC_PROBE_CLOB
     }
   }
   uint64_t r = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7 ^ c0 ^ c1;
@@ -1539,6 +1566,9 @@ extern "C" int pbc_hip_int_mac_peak(int variant, int iters, double *rate, double
     case 13: return run_probe<13>(iters, rate, ms, 64);
     case 14: return run_probe<14>(iters, rate, ms, 64);
     case 15: return run_probe<15>(iters, rate, ms, 64);
+    case 16: return run_probe<16>(iters, rate, ms, 64);
+    case 17: return run_probe<17>(iters, rate, ms, 64);
+    case 18: return run_probe<18>(iters, rate, ms, 64);
     default: return fail("unknown probe variant %d", variant);
   }
 }

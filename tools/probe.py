@@ -6,7 +6,8 @@ names = {0: "v_mad_u64_u32 (8 chains)", 1: "mad+addc MAC (1 chain)", 2: "v_mul_l
          4: "v_dot2_u32_u16", 5: "v_fma_f64", 6: "v_addc_co_u32 chain", 7: "v_mad_u32_u24",
          8: "v_lshl_add_u64", 9: "v_dot4_u32_u8", 10: "mad+addc+s_nop", 11: "v_mad_u32_u16",
          12: "v_add_u32", 13: "v_mad_u64_u32 sgpr operand", 14: "v_mad_u64_u32 sgpr operand, 4 carry-out pairs",
-         15: "v_mad_i64_i32 sgpr operand"}
+         15: "v_mad_i64_i32 sgpr operand", 16: "v_mad_u64_u32 VGPR factors in the two free banks",
+         17: "v_mad_u64_u32 VGPR factors in the accumulator's banks", 18: "v_mad_u64_u32 VGPR factors in one free bank"}
 res = {}
 for v, nm in names.items():
     r, ms = pbc_amd.int_mac_peak(v, 3000)

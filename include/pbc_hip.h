@@ -161,6 +161,11 @@ int pbc_hip_element_mul_zn_batch(pbc_hip_pairing_t *p, int group, uint8_t *out, 
 int pbc_hip_element_mul_GT_batch(pbc_hip_pairing_t *p, uint8_t *out, const uint8_t *a, const uint8_t *b, size_t n);
 int pbc_hip_element_pow_zn_GT_batch(pbc_hip_pairing_t *p, uint8_t *out, const uint8_t *a, const uint8_t *zr,
                                     size_t n);
+/* pairing->finalpow (include/pbc_pairing.h:41; a_finalpow ecc/a_param.c:1420-1429, cc_finalpow ecc/d_param.c:566-568,
+ * f_finalpow ecc/f_param.c:285-287, g_finalpow ecc/g_param.c:1162-1164, e_finalpow ecc/e_param.c:828-830; its callers
+ * are gt_random / gt_from_hash, ecc/pairing.c:121,127): out[i] = in[i]^((q^k - 1)/r), the final exponentiation alone,
+ * for n records of GT's underlying field in GT's wire format.  in[i] = 0 is outside the reference's contract too. */
+int pbc_hip_finalpow_batch(pbc_hip_pairing_t *p, uint8_t *out, const uint8_t *in, size_t n);
 
 /* Batched base-field operations on canonical bytes: the arith/montfp.c semantics the
  * kernels are built on (mont_mul :334-377, fp_add/sub/double/halve/neg :220-330,

@@ -30,6 +30,7 @@ static struct {
   int (*from_hash)(pbc_hip_pairing_t *, int, unsigned char *, const unsigned char *, int, size_t);
   int (*host_alloc)(void **, size_t);
   void (*host_free)(void *);
+  int (*finalpow)(pbc_hip_pairing_t *, unsigned char *, const unsigned char *, size_t);
 } L;
 
 /* one attachment per pairing_s (kept in a table keyed by the pairing pointer so that struct pairing_s itself needs no
@@ -44,6 +45,7 @@ typedef struct {
   void (*cpu_pp_clear)(pairing_pp_t);
   void (*cpu_pp_apply)(element_t, element_t, pairing_pp_t);
   void (*cpu_clear)(struct pairing_s *);
+  void (*cpu_finalpow)(element_t);
   /* page-locked staging buffers of the batch calls (pbc_hip_host_alloc): kept and grown, never per call */
   unsigned char *pin[3];
   size_t pin_cap[3];
@@ -52,7 +54,7 @@ static attach_t **g_att;
 static int g_natt, g_catt;
 static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER;
 /* calls that ran on the GPU (reported at exit when PBC_HIP_VERBOSE=1; the preload test reads them) */
-static struct { unsigned long map, prod, pp_init, pp_apply, batch_units; } g_stat;
+static struct { unsigned long map, prod, pp_init, pp_apply, batch_units, finalpow; } g_stat;
 
 static attach_t *find(struct pairing_s *p) {
   attach_t *r = NULL;
@@ -111,6 +113,7 @@ static int load_lib(void) {
   SYM(gt_mul, "pbc_hip_element_mul_GT_batch"); SYM(gt_pow, "pbc_hip_element_pow_zn_GT_batch");
   SYM(from_hash, "pbc_hip_element_from_hash_batch");
   SYM(host_alloc, "pbc_hip_host_alloc"); SYM(host_free, "pbc_hip_host_free");
+  SYM(finalpow, "pbc_hip_finalpow_batch");
 #undef SYM
   return 0;
 }
@@ -219,6 +222,19 @@ static void hip_prod(element_ptr out, element_t in1[], element_t in2[], int n_pr
   element_from_bytes(out, bt);
   g_stat.prod++;
   free(b1); free(b2); free(bt);
+}
+
+/* pairing->finalpow replacement (include/pbc_pairing.h:41; called by gt_random / gt_from_hash, ecc/pairing.c:121,127):
+ * `e` is the GT element, its bytes are those of the element inside the wrapper */
+static void hip_finalpow(element_t e) {
+  attach_t *a = find(e->field->pairing);
+  int lt = L.lenT(a->gpu);
+  unsigned char *buf = xmalloc(2 * (size_t) lt);
+  element_to_bytes(buf, e);
+  if (L.finalpow(a->gpu, buf + lt, buf, 1)) gpu_failed("pairing->finalpow");
+  element_from_bytes(e, buf + lt);
+  g_stat.finalpow++;
+  free(buf);
 }
 
 /* pairing->pp_init / pp_apply / pp_clear replacements (include/pbc_pairing.h:39-41, 54-89).
@@ -339,7 +355,8 @@ static void report_at_exit(void) {
   const char *e = getenv("PBC_HIP_VERBOSE");
   if (e && *e == '1')
     fprintf(stderr, "pbc_hip: on the GPU: %lu element_pairing, %lu element_prod_pairing, %lu pairing_pp_init, %lu pairing_pp_apply, "
-            "%lu units in batch calls\n", g_stat.map, g_stat.prod, g_stat.pp_init, g_stat.pp_apply, g_stat.batch_units);
+            "%lu units in batch calls, %lu finalpow\n", g_stat.map, g_stat.prod, g_stat.pp_init, g_stat.pp_apply, g_stat.batch_units,
+            g_stat.finalpow);
 }
 /* pairing->clear_func replacement: drop the GPU object, then run the pairing's own clean-up (pairing_clear,
  * ecc/pairing.c:104-106) */
@@ -372,6 +389,8 @@ int pbc_hip_attach(pairing_t pairing, const char *param, size_t len) {
   a->pairing = pairing; a->gpu = g; a->cpu_map = pairing->map; a->cpu_prod = pairing->prod_pairings;
   a->cpu_pp_init = pairing->pp_init; a->cpu_pp_clear = pairing->pp_clear; a->cpu_pp_apply = pairing->pp_apply;
   a->cpu_clear = pairing->clear_func;
+  a->cpu_finalpow = pairing->finalpow;
+  pairing->finalpow = hip_finalpow;
   pairing->map = hip_map;
   pairing->prod_pairings = hip_prod;
   pairing->clear_func = hip_clear;
@@ -392,6 +411,7 @@ void pbc_hip_detach(pairing_t pairing) {
   pairing->map = a->cpu_map; pairing->prod_pairings = a->cpu_prod;
   pairing->pp_init = a->cpu_pp_init; pairing->pp_clear = a->cpu_pp_clear; pairing->pp_apply = a->cpu_pp_apply;
   pairing->clear_func = a->cpu_clear;
+  pairing->finalpow = a->cpu_finalpow;
   L.clear(a->gpu);
   drop_entry(a);
 }

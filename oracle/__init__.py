@@ -57,6 +57,7 @@ def lib():
         L.oracle_point_format.argtypes = [vp, ci, vp, vp, sz]
         L.oracle_from_hash_g2.argtypes = [vp, vp, ci, vp, sz]
         L.oracle_point_format_g2.argtypes = [vp, ci, vp, vp, sz]
+        L.oracle_finalpow.argtypes = [vp, vp, vp, sz]
         L.oracle_counters.argtypes = [ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64), ci]
         _lib = L
     return _lib
@@ -173,6 +174,15 @@ class OraclePairing:
         out = np.empty((n, lo), np.uint8)
         if lib().oracle_point_format_g2(self._h, what, _ptr(recs), _ptr(out), n):
             raise RuntimeError("oracle_point_format_g2 failed")
+        return out
+
+    def finalpow(self, a):
+        """pairing->finalpow on (n, lenGT) records of GT's underlying field"""
+        a = _u8(a)
+        n = a.size // self.len_GT
+        out = np.empty((n, self.len_GT), np.uint8)
+        if lib().oracle_finalpow(self._h, _ptr(a), _ptr(out), n):
+            raise RuntimeError("oracle_finalpow failed")
         return out
 
     def g_mul(self, group, pts, e):

@@ -1947,3 +1947,27 @@ static int df_gt_pow(const oracle_pairing *P, const uint8_t *a, const big *e, ui
   if (P->type == 'f') { f12 x; f12_from_bytes(F, &x, a); f12_pow(P, &x, &x, e); f12_to_bytes(F, out, &x); return 0; }
   return 1;
 }
+
+/* pairing->finalpow (a_finalpow a_param.c:1420-1429, cc_finalpow d_param.c:566-568, f_finalpow f_param.c:285-287,
+ * g_finalpow g_param.c:1162-1164, e_finalpow e_param.c:828-830): the final exponentiation alone, on an element of GT's
+ * underlying field given in GT's wire format.  (The consumers are gt_random / gt_from_hash, ecc/pairing.c:121,127.) */
+int oracle_finalpow(const oracle_pairing *P, const uint8_t *in, uint8_t *out, size_t n) {
+  const fpctx *F = &P->Fq;
+  for (size_t i = 0; i < n; i++) {
+    const uint8_t *a = in + i * P->lenT;
+    uint8_t *o = out + i * P->lenT;
+    if (P->type == 'a') {
+      fe2 x, r;
+      fp_from_bytes(F, &x.x, a); fp_from_bytes(F, &x.y, a + F->nbytes);
+      if (P->a1) a1_tateexp(F, &r, &x, &P->h); else a_tateexp(F, &r, &x, &P->h);
+      fp_to_bytes(F, o, &r.x); fp_to_bytes(F, o + F->nbytes, &r.y);
+    } else if (P->type == 'd' || P->type == 'g') {
+      fk x, r; fk_from_bytes(P, &x, a); d_tatepower(P, &r, &x); fk_to_bytes(P, o, &r);
+    } else if (P->type == 'f') {
+      f12 x; f12_from_bytes(F, &x, a); f_tateexp(P, &x); f12_to_bytes(F, o, &x);
+    } else if (P->type == 'e') {
+      fe x; fp_from_bytes(F, &x, a); fp_pow(F, &x, &x, &P->phikonr); fp_to_bytes(F, o, &x);
+    } else return 1;
+  }
+  return 0;
+}

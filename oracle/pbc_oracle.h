@@ -59,6 +59,9 @@ int oracle_point_format_g2(const oracle_pairing *p, int what, const uint8_t *in,
 int oracle_g_mul(const oracle_pairing *p, int group, const uint8_t *pt, const uint8_t *e,
                  size_t elen, uint8_t *out, size_t n);
 
+/* pairing->finalpow on GT-format records (the final exponentiation alone) */
+int oracle_finalpow(const oracle_pairing *p, const uint8_t *in, uint8_t *out, size_t n);
+
 /* counts of Fq multiplications / inversions since last reset (for the work model) */
 void oracle_counters(uint64_t *mul, uint64_t *inv, int reset);
 

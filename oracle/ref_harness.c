@@ -424,6 +424,34 @@ static int cmd_hash(int argc, char **argv) {
   return 0;
 }
 
+/* finalpow <param> <n> <seed> <out>: n random elements of GT's underlying field (element_random on the wrapped
+ * element, ecc/pairing.c:135-283) and what pairing->finalpow (include/pbc_pairing.h:41) makes of them.
+ * File: inputs (GT format), nothing, outputs. */
+static int cmd_finalpow(int argc, char **argv) {
+  if (argc < 5) { fprintf(stderr, "finalpow <param> <n> <seed> <out>\n"); return 2; }
+  int n = atoi(argv[2]);
+  pairing_t pairing; char type;
+  pbc_random_set_deterministic((unsigned) atoi(argv[3]));
+  init_pairing(pairing, argv[1], &type);
+  int lt = pairing_length_in_bytes_GT(pairing);
+  unsigned char *in = malloc((size_t) n * lt), *out = malloc((size_t) n * lt);
+  element_t e;
+  element_init_GT(e, pairing);
+  for (int i = 0; i < n; i++) {
+    element_random((element_ptr) e->data);               /* the element inside the GT wrapper */
+    element_to_bytes(in + (size_t) i * lt, e);
+    pairing->finalpow(e);
+    element_to_bytes(out + (size_t) i * lt, e);
+  }
+  FILE *fp = fopen(argv[4], "wb");
+  fwrite("PBCVEC01", 1, 8, fp);
+  w32(fp, (uint32_t) type); w32(fp, n); w32(fp, 1); w32(fp, lt); w32(fp, 0); w32(fp, lt);
+  fwrite(in, lt, n, fp); fwrite(out, lt, n, fp);
+  fclose(fp);
+  fprintf(stderr, "wrote %s: type %c n=%d finalpow\n", argv[4], type, n);
+  return 0;
+}
+
 /* rdep <param> <seed>: two pairing objects from the same parameter text (type e draws its auxiliary point R from
  * the generator at init, e_param.c:866-870, so the two objects hold different R), the same input bytes: prints
  * whether element_pairing agrees for a point pair of the order-r subgroup and for a pair of the whole curve.  For
@@ -465,5 +493,6 @@ int main(int argc, char **argv) {
   if (!strcmp(argv[1], "gene")) return cmd_gene(argc - 1, argv + 1);
   if (!strcmp(argv[1], "genf")) return cmd_genf(argc - 1, argv + 1);
   if (!strcmp(argv[1], "rdep")) return cmd_rdep(argc - 1, argv + 1);
+  if (!strcmp(argv[1], "finalpow")) return cmd_finalpow(argc - 1, argv + 1);
   return 2;
 }

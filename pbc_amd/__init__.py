@@ -84,6 +84,7 @@ def lib():
         L.pbc_hip_algorithmic_macs_per_unit.argtypes = [vp, ci]
         L.pbc_hip_algorithmic_macs_per_unit.restype = ctypes.c_double
         L.pbc_hip_last_error.restype = cp
+        L.pbc_hip_finalpow_batch.argtypes = [vp, vp, vp, sz]
         L.pbc_hip_host_alloc.argtypes = [ctypes.POINTER(vp), sz]
         L.pbc_hip_host_free.argtypes = [vp]
         L.pbc_hip_host_free.restype = None
@@ -107,7 +108,7 @@ EXPORTS = (
     "pbc_hip_element_from_bytes_compressed_batch", "pbc_hip_pairing_use_devices", "pbc_hip_device_count",
     "pbc_hip_pairing_length_in_bytes_x_only_G1", "pbc_hip_element_to_bytes_x_only_batch",
     "pbc_hip_pairing_length_in_bytes_compressed_G2", "pbc_hip_pairing_length_in_bytes_x_only_G2",
-    "pbc_hip_element_from_bytes_x_only_batch", "pbc_hip_host_alloc", "pbc_hip_host_free",
+    "pbc_hip_element_from_bytes_x_only_batch", "pbc_hip_host_alloc", "pbc_hip_host_free", "pbc_hip_finalpow_batch",
 )
 
 
@@ -292,6 +293,16 @@ class Pairing:
         return out
 
     # ---- preprocessed pairings (pairing_pp_init / pairing_pp_apply) ----------------------
+    def finalpow(self, a):
+        """pairing->finalpow over (n, lenGT) records of GT's underlying field"""
+        import numpy as np
+        a = np.ascontiguousarray(a, np.uint8)
+        n = a.size // self.length_in_bytes_GT
+        out = np.empty((n, self.length_in_bytes_GT), np.uint8)
+        if lib().pbc_hip_finalpow_batch(self._h, _np_ptr(out), _np_ptr(a), n):
+            raise PbcHipError(_err())
+        return out
+
     def pp_init(self, g1):
         """Mirror of pairing_pp_init: returns a PairingPP bound to the fixed first argument."""
         return PairingPP(self, g1)

@@ -651,6 +651,39 @@ __device__ void f_gt_pow_lane(uint8_t *out, const uint8_t *a, const uint8_t *z, 
   f_gt_store<ND>(out, &acc);
 }
 
+// ---- pairing->finalpow (include/pbc_pairing.h:41; a_finalpow a_param.c:1420-1429, cc_finalpow d_param.c:566-568,
+// g_finalpow g_param.c:1162-1164, f_finalpow f_param.c:285-287, e_finalpow e_param.c:828-830): the final exponentiation
+// alone, on an element of GT's underlying field in GT's wire format (the consumers are gt_random / gt_from_hash,
+// ecc/pairing.c:121,127).  The pairing kernels' own final-exponentiation routines, one element per lane.
+template <int N>
+PBC_DEV void a_finalpow_lane(uint8_t *out, const uint8_t *a) {
+  fp2<N> x, r;
+  a_gt_load<N>(x, a);
+  a_final_exp<N>(r, x);
+  a_gt_store<N>(out, r);
+}
+template <int N, int DEG>
+PBC_DEV void d_finalpow_lane(uint8_t *out, const uint8_t *a) {
+  typename TypeMNT<N, DEG>::f6 x, r;
+  d_gt_load<N, DEG>(x, a);
+  TypeMNT<N, DEG>::d_final_exp(r, x);
+  d_gt_store<N, DEG>(out, r);
+}
+template <int ND>
+__device__ void f_finalpow_lane(uint8_t *out, const uint8_t *a) {
+  typename TypeF<ND>::f12 x;
+  f_gt_load<ND>(&x, a);
+  TypeF<ND>::f_final_exp(&x);
+  f_gt_store<ND>(out, &x);
+}
+template <int N>
+PBC_DEV void e_finalpow_lane(uint8_t *out, const uint8_t *a) {
+  fp<N> x, r;
+  fp_load_be<N>(x, a);
+  e_pow<N>(r, x, c_e.phik, c_e.phikbits);
+  fp_store_be<N>(out, r);
+}
+
 // ---- square roots, element_from_hash and compressed points on the twists (G2 of types d, g, f) -----------
 // The reference takes square roots in F_q^d with a randomised Cantor-Zassenhaus step (polymod_sqrt,
 // arith/poly.c:634-700) and in F_q^2 with the norm formula (fq_sqrt, fieldquadratic.c:357-420); both callers

@@ -360,7 +360,7 @@ __global__ void ts_init_kernel(uint32_t *out, TsRaw raw, KArgs<N> ka) {
   if (threadIdx.x || blockIdx.x) return;
   fp_ts_init<N>(out, raw.t, raw.tbits, raw.half, raw.halfbits);
 }
-// op 0: out = a * b in GT;  op 1: out = a ^ z
+// op 0: out = a * b in GT;  op 1: out = a ^ z;  op 2: out = finalpow(a) (the final exponentiation alone)
 template <int N>
 __global__ void __launch_bounds__(kBlock, 2) gt_op_kernel(int type, int op, uint8_t *out, const uint8_t *a,
                                                            const uint8_t *b, int lenT, int zlen, size_t n, KArgs<N> ka) {
@@ -371,6 +371,7 @@ __global__ void __launch_bounds__(kBlock, 2) gt_op_kernel(int type, int op, uint
   if constexpr (N == 16 || N == 33) {
     if (type == 'e') {                 // GT = F_q (pairing_GT_init(pairing, p->Fq), e_param.c:863)
       fp<N> u, v;
+      if (op == 2) { e_finalpow_lane<N>(o, x); return; }
       fp_load_be<N>(u, x);
       if (op == 0) {
         fp_load_be<N>(v, b + idx * lenT);
@@ -391,19 +392,19 @@ __global__ void __launch_bounds__(kBlock, 2) gt_op_kernel(int type, int op, uint
     }
   }
   if constexpr (N == 16 || N == 33) {
-    if (op == 0) a_gt_mul_lane<N>(o, x, b + idx * lenT); else a_gt_pow_lane<N>(o, x, b + idx * zlen, zlen);
+    if (op == 0) a_gt_mul_lane<N>(o, x, b + idx * lenT); else if (op == 1) a_gt_pow_lane<N>(o, x, b + idx * zlen, zlen); else a_finalpow_lane<N>(o, x);
   } else {
     if (type == 'd') {
       if constexpr (N <= ND_MAX) {
-        if (op == 0) d_gt_mul_lane<N, 3>(o, x, b + idx * lenT); else d_gt_pow_lane<N, 3>(o, x, b + idx * zlen, zlen);
+        if (op == 0) d_gt_mul_lane<N, 3>(o, x, b + idx * lenT); else if (op == 1) d_gt_pow_lane<N, 3>(o, x, b + idx * zlen, zlen); else d_finalpow_lane<N, 3>(o, x);
       }
     } else if constexpr (N == 5 || N == 8) {
       if (type == 'g') {
         if constexpr (N == 5) {
-          if (op == 0) d_gt_mul_lane<N, 5>(o, x, b + idx * lenT); else d_gt_pow_lane<N, 5>(o, x, b + idx * zlen, zlen);
+          if (op == 0) d_gt_mul_lane<N, 5>(o, x, b + idx * lenT); else if (op == 1) d_gt_pow_lane<N, 5>(o, x, b + idx * zlen, zlen); else d_finalpow_lane<N, 5>(o, x);
         }
       } else {
-        if (op == 0) f_gt_mul_lane<N>(o, x, b + idx * lenT); else f_gt_pow_lane<N>(o, x, b + idx * zlen, zlen);
+        if (op == 0) f_gt_mul_lane<N>(o, x, b + idx * lenT); else if (op == 1) f_gt_pow_lane<N>(o, x, b + idx * zlen, zlen); else f_finalpow_lane<N>(o, x);
       }
     }
   }
@@ -1107,9 +1108,12 @@ static int run_group(pbc_hip_pairing_s *P, int what, int group, uint8_t *out, co
     lb = (size_t) P->len_zr;
   } else if (what == 1) {              // GT mul
     la = lb = lo = (size_t) P->lenT;
-  } else {                             // GT pow
+  } else if (what == 2) {              // GT pow
     la = lo = (size_t) P->lenT;
     lb = (size_t) P->len_zr;
+  } else {                             // finalpow: one operand
+    la = lo = (size_t) P->lenT;
+    lb = 0;
   }
   DevBuf ba, bb, bo;
   DeviceGuard guard(P->device);
@@ -1118,7 +1122,7 @@ static int run_group(pbc_hip_pairing_s *P, int what, int group, uint8_t *out, co
   HIP_TRY(bo.alloc(n * lo));
   void *da = ba.p, *db = bb.p, *d_o = bo.p;
   HIP_TRY(hipMemcpy(da, a, n * la, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(db, b, n * lb, hipMemcpyHostToDevice));
+  if (lb) HIP_TRY(hipMemcpy(db, b, n * lb, hipMemcpyHostToDevice));
   if (ensure_derived(P, 0)) return 1;
   unsigned grid = (unsigned) ((n + kBlock - 1) / kBlock);
   if (what == 0 && group == 2 && (P->type == 'd' || P->type == 'g')) {
@@ -1153,6 +1157,10 @@ extern "C" int pbc_hip_element_pow_zn_GT_batch(pbc_hip_pairing_t *P, uint8_t *ou
                                                const uint8_t *zr, size_t n) {
   if (!P) return fail("null pairing");
   return run_group(P, 2, 0, out, a, zr, n);
+}
+extern "C" int pbc_hip_finalpow_batch(pbc_hip_pairing_t *P, uint8_t *out, const uint8_t *in, size_t n) {
+  if (!P) return fail("null pairing");
+  return run_group(P, 3, 0, out, in, nullptr, n);
 }
 
 // first use of a square root in a field with q = 1 mod 4: derive the non-residue power z^t of the

@@ -73,6 +73,9 @@ class HostSim:
         self.L.hostsim_group(self.h, what, out.ctypes.data, a.ctypes.data, b.ctypes.data, n)
         return out
 
+    def finalpow(self, a):
+        return self.group(3, a, a)
+
     def compress(self, direction, recs):
         recs = np.ascontiguousarray(recs, np.uint8)
         lp, lc = self.len1, self.len1 // 2 + (1 if direction < 2 else 0)

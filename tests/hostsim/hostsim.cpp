@@ -206,6 +206,13 @@ int hostsim_group(void *h, int what, uint8_t *out, const uint8_t *a, const uint8
     } else {
       uint8_t *o = out + i * P->lenT;
       const uint8_t *x = a + i * P->lenT, *y = b + i * (what == 1 ? P->lenT : P->len_zr);
+      if (what == 3) {                 // pairing->finalpow
+        if (P->type == 'a' || P->type == '1') { if (P->nlimb == 16) a_finalpow_lane<16>(o, x); else a_finalpow_lane<33>(o, x); }
+        else if (P->type == 'e') { HS_DISPATCH(P->nlimb, e_finalpow_lane<N>(o, x)); }
+        else if (P->type == 'd' || P->type == 'g') { HS_DISPATCH_D(P, (d_finalpow_lane<N, DEG>(o, x))); }
+        else { HS_DISPATCH_F(P->nlimb, f_finalpow_lane<N>(o, x)); }
+        continue;
+      }
       if ((P->type == 'a' || P->type == '1') && P->nlimb == 16) { if (what == 1) a_gt_mul_lane<16>(o, x, y); else a_gt_pow_lane<16>(o, x, y, P->len_zr); }
       else if (P->type == '1' || P->type == 'a') { if (what == 1) a_gt_mul_lane<33>(o, x, y); else a_gt_pow_lane<33>(o, x, y, P->len_zr); }
       else if (P->type == 'e') {

@@ -925,3 +925,69 @@ def test_unmodified_program_runs_its_pairings_on_the_gpu(how, pname):
         env.pop("LD_PRELOAD")
         r2 = subprocess.run([exe, os.path.join(pbc_amd.PARAM_DIR, pname + ".param")], capture_output=True, text=True, env=env, timeout=600)
         assert r2.returncode == 0 and "on the GPU" not in r2.stderr
+
+
+def test_type_a_with_a_1024_bit_field(hips, oracles):
+    """pbc_param_init_a_gen(160, 1024): 1024-bit q on the 33-word arithmetic, 864-bit cofactor (init refused
+    cofactors above 768 bits).  Pairings, products with identity inputs, element_from_hash and [r] H = O."""
+    H, O = hips["a_160_1024"], oracles["a_160_1024"]
+    v, pr, h = golden("a_160_1024_rand4.vec"), golden("a_160_1024_prod3x3_edge.vec"), golden("a_160_1024_hash20.vec")
+    assert np.array_equal(H.element_pairing(v.g1, v.g2), v.gt)
+    assert np.array_equal(H.element_prod_pairing(pr.g1, pr.g2, pr.k), pr.gt)
+    pts = H.element_from_hash(1, h.g1)
+    assert np.array_equal(pts, h.gt)
+    r = param_value("a_160_1024", "r")
+    zl = H.length_in_bytes_Zr
+    assert not H.element_mul_zn(1, pts, np.tile(_be(r, zl), (h.n, 1))).any()
+    i, j = np.divmod(np.arange(8), 4)
+    assert np.array_equal(H.element_pairing(v.g1[i], v.g2[j]), O.pairing_batch(v.g1[i], v.g2[j]))
+
+
+def test_two_objects_with_the_same_word_count_run_concurrently(hips):
+    """d159.param and f.param are both 5-word fields: in round 1 their constants shared process-global __constant__
+    symbols, so two objects on two streams raced.  The constants now travel in each launch's own argument block: a d159
+    and an f batch (and a second d159 object with a different stream) enqueued back to back on separate streams, several
+    rounds, every result bit-exact."""
+    import torch
+    import pbc_amd
+    from conftest import _param
+    vd, vf = golden("d_chain256.vec"), golden("f_chain128.vec")
+    Hd, Hf = hips["d"], hips["f"]
+    Hd2 = pbc_amd.Pairing(_param("d201"))                  # 7 words: a third constant block in flight
+    v2 = golden("d201_rand12.vec")
+    n = 1 << 14
+    def dev(a, m):
+        return torch.from_numpy(np.tile(a, (-(-m // len(a)), 1))[:m].copy()).cuda()
+    d1, d2, f1, f2, e1, e2 = dev(vd.g1, n), dev(vd.g2, n), dev(vf.g1, n), dev(vf.g2, n), dev(v2.g1, n), dev(v2.g2, n)
+    od = torch.empty(n, vd.lenT, dtype=torch.uint8, device="cuda")
+    of = torch.empty(n, vf.lenT, dtype=torch.uint8, device="cuda")
+    oe = torch.empty(n, v2.lenT, dtype=torch.uint8, device="cuda")
+    sd, sf, se = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    for _ in range(4):
+        Hd.element_pairing_dev(od.data_ptr(), d1.data_ptr(), d2.data_ptr(), n, sd.cuda_stream)
+        Hf.element_pairing_dev(of.data_ptr(), f1.data_ptr(), f2.data_ptr(), n, sf.cuda_stream)
+        Hd2.element_pairing_dev(oe.data_ptr(), e1.data_ptr(), e2.data_ptr(), n, se.cuda_stream)
+    torch.cuda.synchronize()
+    assert (od.cpu().numpy().reshape(n // vd.n, vd.n, -1) == vd.gt[None]).all()
+    assert (of.cpu().numpy().reshape(n // vf.n, vf.n, -1) == vf.gt[None]).all()
+    m = n // v2.n * v2.n
+    assert (oe[:m].cpu().numpy().reshape(m // v2.n, v2.n, -1) == v2.gt[None]).all()
+    Hd2.clear()
+
+
+@pytest.mark.parametrize("key,name", [("a", "a_finalpow6.vec"), ("d", "d159_finalpow6.vec"), ("f", "f_finalpow6.vec"),
+                                      ("g149", "g149_finalpow6.vec"), ("e", "e_finalpow3.vec"), ("a1", "a1_finalpow3.vec")])
+def test_finalpow_matches_reference(hips, oracles, key, name):
+    """pbc_hip_finalpow_batch = pairing->finalpow (include/pbc_pairing.h:41): reference vectors, then fresh elements of
+    GT's underlying field (products of the fixture's inputs) against the oracle, and idempotence up to the known power:
+    finalpow maps into the order-r subgroup, so a second application raises to (q^k - 1)/r again = the same as
+    element_pow by that exponent -- checked through finalpow(x y) = finalpow(x) finalpow(y)."""
+    v = golden(name)
+    H, O = hips[key], oracles[key]
+    assert np.array_equal(H.finalpow(v.g1), v.gt)
+    x, y = v.g1, np.roll(v.g1, 1, axis=0)
+    xy = O.gt_mul(x, y)
+    got = H.finalpow(xy)
+    assert np.array_equal(got, O.finalpow(xy))
+    assert np.array_equal(got, H.element_mul_GT(H.finalpow(x), H.finalpow(y)))      # a homomorphism

@@ -141,6 +141,25 @@ def test_scalar_multiplication_on_whole_curve_points_on_host(sims, key, name):
     assert np.array_equal(sims[key].group(0, v.g1[:n], v.g2[:n]), v.gt[:n])
 
 
+def test_type_a_with_a_1024_bit_field_on_host(sims):
+    """pbc_param_init_a_gen(160, 1024), the reference's standard "a" generator call: 1024-bit q, cofactor of 864 bits
+    (round 1 refused every cofactor above 768 bits at init).  Pairing, product and element_from_hash vs the reference."""
+    S = sims["a_160_1024"]
+    v, pr, h = golden("a_160_1024_rand4.vec"), golden("a_160_1024_prod3x3_edge.vec"), golden("a_160_1024_hash20.vec")
+    assert np.array_equal(S.prod_pairing(v.g1[:1], v.g2[:1], 1), v.gt[:1])
+    assert np.array_equal(S.prod_pairing(pr.g1[:3], pr.g2[:3], 3), pr.gt[:1])
+    assert np.array_equal(S.from_hash(h.g1[:1], h.len1), h.gt[:1])
+
+
+@pytest.mark.parametrize("key,name", [("a", "a_finalpow6.vec"), ("d", "d159_finalpow6.vec"), ("f", "f_finalpow6.vec"),
+                                      ("g149", "g149_finalpow6.vec"), ("e", "e_finalpow3.vec"), ("a1", "a1_finalpow3.vec")])
+def test_finalpow_on_host(sims, key, name):
+    """pairing->finalpow through the kernels' own final-exponentiation routines vs the reference"""
+    v = golden(name)
+    n = 2 if key in ("e", "a1") else 3
+    assert np.array_equal(sims[key].finalpow(v.g1[:n]), v.gt[:n])
+
+
 def test_group_law_is_complete_on_host(sims, oracles):
     """small-order points and scalars >= r: the double-and-add meets R = P (needs a doubling), R = -P and R = O.
     Type a: #E = q + 1 = h r with 12 | h, so the curve has points of order 2, 3, 4, 6."""

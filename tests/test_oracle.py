@@ -13,7 +13,7 @@ from conftest import GOLDEN, G2_HASH, G2_COMPRESS, G2_XONLY, golden, key_of, par
 
 
 @pytest.mark.parametrize("name", sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, "*.vec"))
-                                        if not any(t in os.path.basename(p) for t in ("_hash", "_g1mul", "_g2mul", "_compress", "_xonly", "_g2hash", "_g2compress", "_g2xonly"))))
+                                        if not any(t in os.path.basename(p) for t in ("_hash", "_g1mul", "_g2mul", "_compress", "_xonly", "_g2hash", "_g2compress", "_g2xonly", "_finalpow"))))
 def test_oracle_matches_reference_vectors(oracles, name):
     """Types A, D (d159 and the five other shipped type d files) and F: the D and F fixtures are the only pins for those curves
     (the reference ships no D/F known-answer test)."""
@@ -204,3 +204,14 @@ def test_oracle_x_only_points_on_the_twists(oracles, key, name, exact):
         cg = [int.from_bytes(g[half + i:half + i + fb].tobytes(), "big") for i in range(0, half, fb)]
         cw = [int.from_bytes(w[half + i:half + i + fb].tobytes(), "big") for i in range(0, half, fb)]
         assert cg == cw or cg == [(q - c) % q for c in cw]
+
+
+FINALPOW = [("a", "a_finalpow6.vec"), ("d", "d159_finalpow6.vec"), ("f", "f_finalpow6.vec"), ("g149", "g149_finalpow6.vec"),
+            ("e", "e_finalpow3.vec"), ("a1", "a1_finalpow3.vec")]
+
+
+@pytest.mark.parametrize("key,name", FINALPOW)
+def test_oracle_finalpow_matches_reference(oracles, key, name):
+    """pairing->finalpow (include/pbc_pairing.h:41) on random elements of GT's underlying field, written by the reference"""
+    v = golden(name)
+    assert np.array_equal(oracles[key].finalpow(v.g1), v.gt)

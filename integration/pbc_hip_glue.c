@@ -123,20 +123,21 @@ static int load_lib(void) {
  * the GPU needs).  PBC_HIP_GLUE_THREADS overrides the default of min(online CPUs, 16). */
 typedef struct { void (*fn)(size_t lo, size_t hi, void *ctx); void *ctx; size_t lo, hi; } job_t;
 static void *job_main(void *arg) { job_t *j = arg; j->fn(j->lo, j->hi, j->ctx); return NULL; }
-static void parallel_for(size_t n, void (*fn)(size_t, size_t, void *), void *ctx) {
+static void parallel_range(size_t lo0, size_t hi0, void (*fn)(size_t, size_t, void *), void *ctx) {
+  const size_t n = hi0 - lo0;
   long nt = sysconf(_SC_NPROCESSORS_ONLN);
   const char *e = getenv("PBC_HIP_GLUE_THREADS");
   if (e) nt = atol(e);
   if (nt > 16) nt = 16;
   if (nt < 1 || n < 256) nt = 1;
-  if (nt == 1) { fn(0, n, ctx); return; }
+  if (nt == 1) { fn(lo0, hi0, ctx); return; }
   pthread_t th[16];
   job_t job[16];
   int started = 0;
   for (long t = 0; t < nt; t++) {
     job[t].fn = fn; job[t].ctx = ctx;
-    job[t].lo = n * (size_t) t / (size_t) nt; job[t].hi = n * (size_t) (t + 1) / (size_t) nt;
-    if (t + 1 == nt || pthread_create(&th[t], NULL, job_main, &job[t])) { fn(job[t].lo, t + 1 == nt ? job[t].hi : n, ctx); break; }
+    job[t].lo = lo0 + n * (size_t) t / (size_t) nt; job[t].hi = lo0 + n * (size_t) (t + 1) / (size_t) nt;
+    if (t + 1 == nt || pthread_create(&th[t], NULL, job_main, &job[t])) { fn(job[t].lo, t + 1 == nt ? job[t].hi : hi0, ctx); break; }
     started++;
   }
   for (int t = 0; t < started; t++) pthread_join(th[t], NULL);
@@ -162,6 +163,17 @@ static void from_bytes_range(size_t lo, size_t hi, void *ctx) {
   for (size_t i = lo; i < hi; i++) element_from_bytes(c->out[c->slot[i]], c->bt + i * c->lt);
 }
 
+/* one GPU call of the batch pipeline, on its own thread while the CPU threads convert the neighbouring chunks */
+typedef struct {
+  void *att;
+  int k;
+  unsigned char *b1, *b2, *bt;
+  size_t m;
+  int rc;
+  char err[256];
+} gpu_job_t;
+static void *gpu_job_main(void *arg);
+
 /* n*k (in1, in2) terms -> n GT results.  `out` are GT elements (the mulg wrapper, ecc/pairing.c:135-283). */
 static int run_batch(attach_t *a, element_t out[], element_t in1[], element_t in2[], size_t n, int k) {
   int l1 = L.len1(a->gpu), l2 = L.len2(a->gpu), lt = L.lenT(a->gpu);
@@ -179,14 +191,34 @@ static int run_batch(attach_t *a, element_t out[], element_t in1[], element_t in
   }
   conv_t c = {in1, in2, out, b1, b2, bt, slot, k, l1, l2, lt};
   int rc = 0;
-  if (m) {
-    parallel_for(m, to_bytes_range, &c);
-    rc = k == 1 ? L.pair(a->gpu, bt, b1, b2, m) : L.prod(a->gpu, bt, b1, b2, m, k);
-    if (rc) pbc_error("pbc_hip: %s", L.err());
-    else { parallel_for(m, from_bytes_range, &c); g_stat.batch_units += m; }
+  /* Three stages per chunk -- element_to_bytes (CPU threads), the GPU call, element_from_bytes (CPU threads) -- run as a
+   * pipeline: while the GPU works on chunk i the CPU threads convert the results of chunk i - 1 and the inputs of
+   * chunk i + 1.  (The conversions cost more CPU time than the GPU needs for the pairings.) */
+  const size_t CH = 131072 / (size_t) k > 4096 ? 131072 / (size_t) k : 4096;   /* one chip residency of lanes per GPU call */
+  const size_t nc = (m + CH - 1) / CH;
+  if (m) parallel_range(0, m < CH ? m : CH, to_bytes_range, &c);
+  for (size_t ci = 0; ci < nc && !rc; ci++) {
+    const size_t lo = ci * CH, hi = lo + CH < m ? lo + CH : m;
+    gpu_job_t job = {a, k, b1 + lo * k * l1, b2 + lo * k * l2, bt + lo * lt, hi - lo, 0, {0}};
+    pthread_t th;
+    const int threaded = nc > 1 && !pthread_create(&th, NULL, gpu_job_main, &job);
+    if (!threaded) gpu_job_main(&job);
+    if (ci > 0) parallel_range(lo - CH, lo, from_bytes_range, &c);
+    if (hi < m) parallel_range(hi, hi + CH < m ? hi + CH : m, to_bytes_range, &c);
+    if (threaded) pthread_join(th, NULL);
+    if (job.rc) { rc = 1; pbc_error("pbc_hip: %s", job.err); }
   }
+  if (m && !rc) { parallel_range((nc - 1) * CH, m, from_bytes_range, &c); g_stat.batch_units += m; }
   free(slot);
   return rc;
+}
+
+static void *gpu_job_main(void *arg) {
+  gpu_job_t *j = arg;
+  attach_t *a = j->att;
+  j->rc = j->k == 1 ? L.pair(a->gpu, j->bt, j->b1, j->b2, j->m) : L.prod(a->gpu, j->bt, j->b1, j->b2, j->m, j->k);
+  if (j->rc) { strncpy(j->err, L.err(), sizeof j->err - 1); j->err[sizeof j->err - 1] = 0; }   /* the message is per thread */
+  return NULL;
 }
 
 /* A GPU call behind one of PBC's void-returning hooks failed.  PBC's convention for an unrecoverable condition is

@@ -188,6 +188,10 @@ PBC_DEV void a_final_exp(fp2<N> &out, const fp2<N> &f) {
   fp_mul<N>(B, f.x, f.y);
   fp_dbl<N>(B, B);
   fp_neg<N>(B, B);                     // f^(q-1) = conj(f)^2 / N = (A + B i) / N
+  // (B = 0: f^(q-1) = +-1.  Invert N * 1 instead; the imaginary part below is then (2 V_{h+1} - P V_h) N / 4 = 0
+  // exactly, since P = +-2 gives V_n = 2 (+-1)^n.)
+  fp_set<N>(t, fpk<N>().one);
+  fp_cmov<N>(B, t, fp_is0<N>(B));
   fp_mul<N>(t, Nn, B);
   fp_inv<N>(t, t);                     // 1/(N B)
   fp_mul<N>(w, t, B);                  // 1/N

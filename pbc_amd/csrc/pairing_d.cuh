@@ -511,9 +511,22 @@ static PBC_DEV void d_final_exp(f6 &out, const f6 &m) {
   f3 D, t, invD, invB;
   f3_frob(D, N);
   f3_mul(D, D, N);
-  f3_mul(t, D, w.y);
+  // (B = 0 -- the value after the easy part is +-1, e.g. for the images of element_from_hash on GT, which lie in a product
+  // of proper subfields -- must not poison 1/D: invert D * 1 instead.  The sqrt(v) part below is then
+  // (P V_k - 2 V_{k-1}) D / (4 v) = 0 exactly, since P = +-2 gives V_n = 2 (+-1)^n.)
+  f3 Bn = w.y;
+  {
+    f3 zero3, one3;
+    fq o; fp_set<ND>(o, fpk<ND>().one);
+    f3_set_fq(one3, o);
+    f3_sub(zero3, one3, one3);
+    const bool b0 = f3_eq(w.y, zero3);
+#pragma unroll
+    for (int i = 0; i < DEG; i++) fp_cmov<ND>(Bn.c[i], one3.c[i], b0);
+  }
+  f3_mul(t, D, Bn);
   f3_inv(t, t);                        // 1/(D B): the only inversion
-  f3_mul(invD, t, w.y);
+  f3_mul(invD, t, Bn);
   f3_mul(invB, t, D);
   f3 h0, P, v0, v1, two;
   f3_mul(h0, w.x, invD);

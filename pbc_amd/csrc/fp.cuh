@@ -296,6 +296,15 @@ PBC_DEV void from_limbs(fp<N> &r, const fl<N> &a) {
   uint32_t carry = from29<N>(w, a.l);
   fp_cond_sub<N>(r, w, carry);
 }
+// keeps the compiler from re-associating separate accumulator chains back into one
+#ifdef PBC_HOSTSIM
+#define PBC_OPAQUE64(x) ((void) 0)
+#else
+#define PBC_OPAQUE64(x) asm("" : "+v"(x))
+#endif
+#ifndef PBC_SOP_CHAINS
+#define PBC_SOP_CHAINS 1    // independent accumulator chains per column (experiment: the multiply-add chain of a column is
+#endif                      // serially dependent; more chains = more instruction-level parallelism, a few extra 64-bit adds)
 template <int N, int T, int DBL = 0>      // DBL: how many of the T terms have a doubled operand
 PBC_DEV void sop_limbs(fl<N> &r, const fl<N> (&x)[T], const fl<N> (&y)[T]) {
   const FpK<N> &K = fpk<N>();
@@ -303,28 +312,39 @@ PBC_DEV void sop_limbs(fl<N> &r, const fl<N> (&x)[T], const fl<N> (&y)[T]) {
   constexpr uint32_t MASK = Limbs29<N>::MASK;
   static_assert(Limbs29<N>::W == 29 && (T + DBL) * L + L <= 63, "column accumulator would overflow");
   PBC_COUNT_MACS((T + 1) * L * L);
+  constexpr int C = PBC_SOP_CHAINS < T ? PBC_SOP_CHAINS : T;
   uint32_t m[L];
   uint64_t acc = 0;
 #pragma unroll
   for (int k = 0; k < L; k++) {
+    uint64_t part[C];
+#pragma unroll
+    for (int c = 0; c < C; c++) part[c] = 0;
 #pragma unroll
     for (int t = 0; t < T; t++)
 #pragma unroll
-      for (int i = 0; i <= k; i++) acc += (uint64_t) x[t].l[i] * y[t].l[k - i];
+      for (int i = 0; i <= k; i++) part[t % C] += (uint64_t) x[t].l[i] * y[t].l[k - i];
 #pragma unroll
     for (int i = 0; i < k; i++) acc += (uint64_t) m[i] * K.p29[k - i];
+#pragma unroll
+    for (int c = 0; c < C; c++) { if (C > 1) PBC_OPAQUE64(part[c]); acc += part[c]; }
     m[k] = ((uint32_t) acc * K.ninv29) & MASK;
     acc += (uint64_t) m[k] * K.p29[0];
     acc >>= Limbs29<N>::W;
   }
 #pragma unroll
   for (int k = L; k < 2 * L; k++) {
+    uint64_t part[C];
+#pragma unroll
+    for (int c = 0; c < C; c++) part[c] = 0;
 #pragma unroll
     for (int t = 0; t < T; t++)
 #pragma unroll
-      for (int i = k - L + 1; i < L; i++) acc += (uint64_t) x[t].l[i] * y[t].l[k - i];
+      for (int i = k - L + 1; i < L; i++) part[t % C] += (uint64_t) x[t].l[i] * y[t].l[k - i];
 #pragma unroll
     for (int i = k - L + 1; i < L; i++) acc += (uint64_t) m[i] * K.p29[k - i];
+#pragma unroll
+    for (int c = 0; c < C; c++) { if (C > 1) PBC_OPAQUE64(part[c]); acc += part[c]; }
     r.l[k - L] = (uint32_t) acc & MASK;
     acc >>= Limbs29<N>::W;
   }

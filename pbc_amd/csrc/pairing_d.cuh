@@ -30,7 +30,10 @@ constexpr int ND_MAX = 7;              // widest MNT field built in: 224-bit q (
 constexpr int DEG_MAX = 5;             // d = k/2: 3 (type d), 5 (type g)
 struct DConst {                        // pptr (ecc/d_param.c:40-51) + curve/field constants
   uint32_t A[ND_MAX], B[ND_MAX];       // curve coefficients (Montgomery form)
-  uint32_t xpwr[DEG_MAX - 1][DEG_MAX][ND_MAX];   // x^d .. x^(2d-2) mod f (poly.c compute_x_powers)
+  // x^d .. x^(2d-2) mod f (poly.c compute_x_powers) as 29-bit LIMBS, packed [(t d + i) L + limb] for the object's own
+  // d and L: the products read them as scalar operands of the multiply-adds, no conversion instructions
+  uint32_t xpwr29[120];                // max (d - 1) d L over the built-in (words, d) pairs: 4 * 5 * 6
+  uint32_t nqr29[8];                   // v in limbs (f3_mul_v)
   uint32_t nqr[ND_MAX], nqrinv[ND_MAX], nqrinv2[ND_MAX];   // v, v^-1, v^-2 (d_param.c:1028-1032, :1072-1075)
   uint32_t xpowq[DEG_MAX - 1][DEG_MAX][ND_MAX];  // x^q, x^2q, (x^3q, x^4q) (d_param.c:1044-1050, g_param.c:1307-1316)
   uint32_t ta[ND_MAX], tb[ND_MAX];     // twist: y^2 = x^3 + a v^2 x + b v^3 (curve.c:885-901)
@@ -85,6 +88,13 @@ static PBC_DEV void f3_set_fq(f3 &r, const fq &s) {
 //   c_k = sum_{i+j=k} a_i b_j + sum_t h_t X_t[k]             (one reduction per output coefficient)
 // d = 3: 15 limb products + 5 Montgomery reductions instead of 12 full products (6 Karatsuba + 6 table);
 // d = 5: 45 limb products + 9 reductions instead of 25 + 20 full products.
+static_assert((DEG - 1) * DEG * Limbs29<ND>::L <= 120 && Limbs29<ND>::L <= 8, "DConst limb tables");
+static PBC_DEV fl<ND> xpwr_limbs(int t, int i) {
+  fl<ND> r;
+#pragma unroll
+  for (int l = 0; l < Limbs29<ND>::L; l++) r.l[l] = c_d.xpwr29[(t * DEG + i) * Limbs29<ND>::L + l];
+  return r;
+}
 template <int S, bool TABLE>
 static PBC_DEV void mul_coeff(fl<ND> &out, const fl<ND> *A, const fl<ND> *B, const fl<ND> *H) {
   constexpr int lo = S - (DEG - 1) > 0 ? S - (DEG - 1) : 0, hi = S < DEG - 1 ? S : DEG - 1;
@@ -94,7 +104,7 @@ static PBC_DEV void mul_coeff(fl<ND> &out, const fl<ND> *A, const fl<ND> *B, con
   for (int i = lo; i <= hi; i++) { x[i - lo] = A[i]; y[i - lo] = B[S - i]; }
   if constexpr (TABLE) {
 #pragma unroll
-    for (int t = 0; t < DEG - 1; t++) { x[NDIR + t] = H[t]; to_limbs<ND>(y[NDIR + t], dk(c_d.xpwr[t][S])); }
+    for (int t = 0; t < DEG - 1; t++) { x[NDIR + t] = H[t]; y[NDIR + t] = xpwr_limbs(t, S); }
   }
   sop_limbs<ND, T>(out, x, y);
 }
@@ -111,7 +121,7 @@ static PBC_DEV void sqr_coeff(fl<ND> &out, const fl<ND> *A, const fl<ND> *A2, co
   if constexpr (SQ) { x[NC] = A[S / 2]; y[NC] = A[S / 2]; }
   if constexpr (TABLE) {
 #pragma unroll
-    for (int t = 0; t < DEG - 1; t++) { x[NC + SQ + t] = H[t]; to_limbs<ND>(y[NC + SQ + t], dk(c_d.xpwr[t][S])); }
+    for (int t = 0; t < DEG - 1; t++) { x[NC + SQ + t] = H[t]; y[NC + SQ + t] = xpwr_limbs(t, S); }
   }
   sop_limbs<ND, T, NC>(out, x, y);
 }
@@ -180,7 +190,8 @@ static __device__ __noinline__ f3ret f3_mul_v_call(f3ret va) {
   f3 a, r;
   f3_unpack(a, va);
   fl<ND> V;
-  to_limbs<ND>(V, dk(c_d.nqr));
+#pragma unroll
+  for (int l = 0; l < Limbs29<ND>::L; l++) V.l[l] = c_d.nqr29[l];
 #pragma unroll
   for (int i = 0; i < DEG; i++) {
     fl<ND> x[1], y[1], c;
@@ -744,8 +755,17 @@ static PBC_DEV void init_stage1(DConst *out, const DRaw &raw, const DConst &base
   for (int k = 0; k < ND; k++) {
     C.A[k] = a.v[k]; C.B[k] = b.v[k]; C.nqr[k] = v.v[k]; C.nqrinv[k] = vi.v[k]; C.nqrinv2[k] = vi2.v[k];
     C.ta[k] = ta.v[k]; C.tb[k] = tb.v[k];
-    for (int j = 0; j < DEG - 1; j++)
-      for (int i = 0; i < DEG; i++) C.xpwr[j][i][k] = xp[j][i].v[k];
+  }
+  for (int j = 0; j < DEG - 1; j++)
+    for (int i = 0; i < DEG; i++) {
+      fl<ND> t29;
+      to_limbs<ND>(t29, xp[j][i]);
+      for (int l = 0; l < Limbs29<ND>::L; l++) C.xpwr29[(j * DEG + i) * Limbs29<ND>::L + l] = t29.l[l];
+    }
+  {
+    fl<ND> t29;
+    to_limbs<ND>(t29, v);
+    for (int l = 0; l < Limbs29<ND>::L; l++) C.nqr29[l] = t29.l[l];
   }
   *out = C;
 }

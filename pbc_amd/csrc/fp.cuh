@@ -56,15 +56,15 @@ struct fp {
 // exactly as a __constant__ symbol would give, but nothing is process-global: two pairing objects (or one object on two
 // streams) cannot disturb each other, and a launch needs no upload.
 // Layout of the block, from its END backwards (the last three parts do not depend on the field width):
-//     end - 2496 + [0, 704)      CurveK    curve coefficients, cofactor, square-root recipe      (group_ops.cuh)
-//     end - 2496 + [704, 2128)   AConst / DConst / FConst / EConst   the pairing family's constants  (pairing_*.cuh)
-//     end - 2496 + [2128, 2496)  ExtSqrtK  square roots in the field of the G2 twist             (group_ops.cuh)
+//     end - 2560 + [0, 704)      CurveK    curve coefficients, cofactor, square-root recipe      (group_ops.cuh)
+//     end - 2560 + [704, 2192)   AConst / DConst / FConst / EConst   the pairing family's constants  (pairing_*.cuh)
+//     end - 2560 + [2192, 2560)  ExtSqrtK  square roots in the field of the G2 twist             (group_ops.cuh)
 //     end - sizeof(KArgs<N>)     FpK<N>    modulus and Montgomery constants
 // Word counts built into the library: 5/6/7 words = the 149..224-bit MNT, Freeman and BN fields of
 // the shipped type d / g / f parameter files, 8 words = 256-bit BN fields (type f), 16 words = the
 // 512-bit type a field, 33 words = the 1033-bit type a1 field.
 #define PBC_FOR_EACH_N(X) X(5) X(6) X(7) X(8) X(16) X(33)
-constexpr int KOFF_CURVE = 0, KOFF_TYPE = 704, KOFF_XS = 2128, KOFF_END = 2496;
+constexpr int KOFF_CURVE = 0, KOFF_TYPE = 704, KOFF_XS = 2192, KOFF_END = 2560;
 template <int N>
 struct alignas(16) KArgs {
   FpK<N> fp;

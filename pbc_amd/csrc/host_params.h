@@ -215,8 +215,8 @@ static int init_type_a(pbc_hip_pairing_s *P, const char *txt, size_t len) {
       return fail("type a: only 160..1056-bit q is supported by this build (got %d bits)", q.bits());
     P->nlimb = q.bits() <= 512 ? 16 : 33;
     P->a_generic = true;
-    r.to_words(P->a.r, 34);
-    P->a.rbits = r.bits();
+    P->a.rbits = pbc_host::naf_of_half(r, P->a.r, P->a.rm, 34);      // signed digits: three for a Solinas r
+    if (!P->a.rbits) return fail("type a: r too wide for the Miller loop digits");
   }
   // work model: SURVEY.md 8d instrumented the reference on a.param (exp2 = 159, 353-bit h): 3675 F_q
   // products in a_pairing_proj's Miller loop + 717 in a_tateexp; a_pairings_affine (a_param.c:1283-1383)
@@ -251,8 +251,8 @@ static int init_type_a1(pbc_hip_pairing_s *P, const char *txt, size_t len) {
   memset(&P->a, 0, sizeof P->a);
   l.to_words(P->a.h, 16);
   P->a.hbits = l.bits();
-  n.to_words(P->a.r, 34);
-  P->a.rbits = n.bits();
+  P->a.rbits = pbc_host::naf_of_half(n, P->a.r, P->a.rm, 34);
+  if (!P->a.rbits) return fail("type a1: n too wide for the Miller loop digits");
   {
     Big e = p, four, rem;
     e.add_small(1);
@@ -372,8 +372,8 @@ static int init_type_d(pbc_hip_pairing_s *P, const char *txt, size_t len, int de
   q.to_words(P->draw.q, ND + 1);
   P->draw.qbits = q.bits();
   if (r.bits() > 256 || r.bits() < 3) return fail("%s: bad r", tn);
-  r.to_words(P->dconst.r, 8);
-  P->dconst.rbits = r.bits();
+  P->dconst.rbits = pbc_host::naf_of_half(r, P->dconst.r, P->dconst.rm, 8);     // signed digits of the Miller loop
+  if (!P->dconst.rbits) return fail("%s: r too wide for the Miller loop digits", tn);
   // phikonr = Phi_k(q)/r: (q^2 - q + 1)/r (d_param.c:1036-1042), (q^4 - q^3 + q^2 - q + 1)/r (g_param.c:1288-1305)
   Big q2 = Big::mul(q, q);
   Big z = q2;
@@ -454,8 +454,8 @@ static int init_type_f(pbc_hip_pairing_s *P, const char *txt, size_t len) {
   e6.to_words(P->fraw.e6, NF + 1);
   P->fraw.e6bits = e6.bits();
   if (r.bits() > 256 || r.bits() < 3) return fail("type f: bad r");
-  r.to_words(P->fconst.r, 8);
-  P->fconst.rbits = r.bits();
+  P->fconst.rbits = pbc_host::naf_of_half(r, P->fconst.r, P->fconst.rm, 8);     // signed digits of the Miller loop
+  if (!P->fconst.rbits) return fail("type f: r too wide for the Miller loop digits");
   // tateexp = ((q^2 - 1) q^2 + 1)/r (f_param.c:414-420)
   Big q2 = Big::mul(q, q), z = q2;
   z.sub_small(1);

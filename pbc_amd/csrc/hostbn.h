@@ -120,6 +120,39 @@ inline uint32_t neg_inv32(uint32_t p0) {   // -p^-1 mod 2^32 (Newton)
 }
 
 // "key value" lines; returns false if the key is absent
+// Signed-digit (non-adjacent form) recoding of the Miller loops' multiplier.  The loops compute f_{r-1,P} as the
+// reference does (double-and-add over n = r >> 1, then one closing tangent, e.g. ecc/d_param.c:321-422): with NAF digits
+// of n the chain has a third instead of half of its positions non-zero, and the function it builds has the same divisor
+// (r - 1)(P) - ((r - 1)P) - (r - 2)(O) up to vertical lines, which the final exponentiation removes -- for every point of
+// the curve, not only those of order r.  Digit i of n is stored at bit i + 1 of plus[] / minus[] (the position the
+// binary loops test); returns the loop's bit count (index of the leading digit + 1), or 0 when it does not fit `words`.
+inline int naf_of_half(const Big &r, uint32_t *plus, uint32_t *minus, int words) {
+  for (int i = 0; i < words; i++) plus[i] = minus[i] = 0;
+  std::vector<uint32_t> n(r.w);
+  n.push_back(0);
+  // n = r >> 1
+  for (size_t i = 0; i + 1 < n.size(); i++) n[i] = (n[i] >> 1) | (n[i + 1] << 31);
+  int pos = 1, top = 0;
+  auto is_zero = [&] { for (uint32_t x : n) if (x) return false; return true; };
+  while (!is_zero()) {
+    if (n[0] & 1) {
+      if ((size_t) (pos >> 5) >= (size_t) words) return 0;
+      if ((n[0] & 3) == 1) {               // digit +1: n -= 1
+        plus[pos >> 5] |= 1u << (pos & 31);
+        n[0] -= 1;
+      } else {                             // digit -1: n += 1
+        minus[pos >> 5] |= 1u << (pos & 31);
+        for (size_t i = 0; i < n.size(); i++) if (++n[i]) break;
+      }
+      top = pos;
+    }
+    for (size_t i = 0; i + 1 < n.size(); i++) n[i] = (n[i] >> 1) | (n[i + 1] << 31);
+    n.back() >>= 1;
+    pos++;
+  }
+  return top + 1;
+}
+
 inline bool param_lookup(const char *txt, size_t len, const char *key, std::string &val) {
   size_t klen = strlen(key), i = 0;
   while (i < len) {

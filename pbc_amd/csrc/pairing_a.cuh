@@ -56,7 +56,7 @@ struct AConst {          // a_pairing_data (ecc/a_param.c:30-34) + phikonr = h (
   int exp2, exp1, sign1; // r = 2^exp2 + sign1 2^exp1 + sign0 (sign0 unused by the map)
   uint32_t sqrt_e[34];   // (q + 1)/4: square roots in F_q for q = 3 mod 4 (element_from_hash)
   int sqrt_bits;
-  uint32_t r[34];        // type a1 (and type a outside the 512-bit fast path): the group order, walked bit by bit
+  uint32_t r[34], rm[34]; // type a1 (and type a outside the 512-bit fast path): Miller loop digits, NAF of n >> 1 (+1 / -1)
   int rbits;
 };
 static_assert(sizeof(AConst) <= KOFF_XS - KOFF_TYPE, "constant block layout");
@@ -584,6 +584,10 @@ PBC_DEV void a_prod_pairing_lane(uint8_t *gt, const uint8_t *g1, const uint8_t *
 // [chord, add], square; the last tangent at bit 0 ends the loop), then f^(p-1) and the power by
 // l = (p+1)/n (:1986-1994).  The step routines and the final exponentiation are the type a ones;
 // the Lucas ladder runs over l instead of h.
+// digit of the bit-by-bit Miller loops at position i: +1, -1 or 0 (wave-uniform)
+PBC_DEV int a1_digit(int i) {
+  return (int) ((c_a.r[i >> 5] >> (i & 31)) & 1) - (int) ((c_a.rm[i >> 5] >> (i & 31)) & 1);
+}
 template <int N>
 PBC_DEV bool a1_miller_lane(fp2<N> &f, const uint8_t *g1, const uint8_t *g2, uint32_t *lds_q, int lds_stride) {
   const int NB = fq_bytes<N>();
@@ -615,10 +619,12 @@ PBC_DEV bool a1_miller_lane(fp2<N> &f, const uint8_t *g1, const uint8_t *g2, uin
       }
     }
     a_double_step<N>(f, V, Qx, Qy);
-    if (i > 0 && ((c_a.r[i >> 5] >> (i & 31)) & 1)) {
+    const int dig = i > 0 ? a1_digit(i) : 0;
+    if (dig) {                         // V <- V +- P (signed digits, hostbn.h naf_of_half)
       fp<N> x2, y2;
       fp_load_be<N>(x2, g1);
       fp_load_be<N>(y2, g1 + NB);
+      if (dig < 0) fp_neg<N>(y2, y2);
       a_add_step<N>(f, V, x2, y2, Qx, Qy);
     }
   }
@@ -658,8 +664,11 @@ PBC_DEV bool a1_pp_init_lane(uint32_t *tab, const uint8_t *g1) {
   for (int i = c_a.rbits - 2; i >= 0; i--) {
     a_pp_dbl<N>(V, cA, cB, cC);
     a_pp_store<N>(tab, slot++, cA, cB, cC);
-    if (i > 0 && ((c_a.r[i >> 5] >> (i & 31)) & 1)) {
-      a_pp_add<N>(V, x2, y2, cA, cB, cC);
+    const int dig = i > 0 ? a1_digit(i) : 0;
+    if (dig) {
+      fp<N> ys = y2;
+      if (dig < 0) fp_neg<N>(ys, ys);
+      a_pp_add<N>(V, x2, ys, cA, cB, cC);
       a_pp_store<N>(tab, slot++, cA, cB, cC);
     }
   }
@@ -679,7 +688,7 @@ PBC_DEV void a1_pp_apply_lane(uint8_t *gt, const uint32_t *tab, bool p_valid, co
   for (int i = c_a.rbits - 2; i >= 0; i--) {
     fi_sqr<N>(f, f);
     a_pp_line<N>(f, tab, slot++, Qx, Qy);
-    if (i > 0 && ((c_a.r[i >> 5] >> (i & 31)) & 1)) a_pp_line<N>(f, tab, slot++, Qx, Qy);
+    if (i > 0 && a1_digit(i)) a_pp_line<N>(f, tab, slot++, Qx, Qy);
   }
   a_final_exp<N>(out, f);
   a_store_gt<N>(gt, out, valid);

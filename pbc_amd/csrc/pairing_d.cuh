@@ -37,7 +37,7 @@ struct DConst {                        // pptr (ecc/d_param.c:40-51) + curve/fie
   uint32_t nqr[ND_MAX], nqrinv[ND_MAX], nqrinv2[ND_MAX];   // v, v^-1, v^-2 (d_param.c:1028-1032, :1072-1075)
   uint32_t xpowq[DEG_MAX - 1][DEG_MAX][ND_MAX];  // x^q, x^2q, (x^3q, x^4q) (d_param.c:1044-1050, g_param.c:1307-1316)
   uint32_t ta[ND_MAX], tb[ND_MAX];     // twist: y^2 = x^3 + a v^2 x + b v^3 (curve.c:885-901)
-  uint32_t r[8];                       // group order (Miller loop bits)
+  uint32_t r[8], rm[8];                // Miller loop digits: NAF of r >> 1, +1 digits in r[], -1 digits in rm[] (hostbn.h)
   uint32_t phik[16];                   // Phi_k(q)/r (d_param.c:1036-1042, g_param.c:1288-1305)
   int rbits, phikbits;
 };
@@ -400,8 +400,14 @@ static __device__ __noinline__ v32 d_dbl_line_fn() {
 }
 // chord through V and the affine P (do_line d_param.c:364-379, scaled by Z3 = Z H):
 //   H = Px Z^2 - X, R = Py Z^3 - Y;  a' = -R,  b' = Z3,  c' = R Px - Z3 Py;   V <- V + P
-static PBC_DEV void d_add_core(fq &la, fq &lb, fq &lc) {
+// (neg: the chord through V and -P, V <- V - P: the -1 digits of the signed-digit Miller loop)
+static PBC_DEV void d_add_core(fq &la, fq &lb, fq &lc, bool neg) {
   fq X = dl_get(DL_X), Y = dl_get(DL_Y), Z = dl_get(DL_Z), Px = dl_get(DL_PX), Py = dl_get(DL_PY);
+  {
+    fq nPy;
+    fp_neg<ND>(nPy, Py);
+    fp_cmov<ND>(Py, nPy, neg);
+  }
   fq ZZ, H, R, HH, HHH, t0, t1, Z3;
   fp_sqr_inl<ND>(ZZ, Z);
   fp_mul_inl<ND>(H, Px, ZZ);
@@ -430,10 +436,14 @@ static PBC_DEV void d_add_core(fq &la, fq &lb, fq &lc) {
   dl_put(DL_Z, Z3);
   lb = Z3;
 }
-static __device__ __noinline__ v32 d_add_line_fn() {
+static __device__ __noinline__ v32 d_add_line_fn(int neg) {
   fq la, lb, lc;
-  d_add_core(la, lb, lc);
+  d_add_core(la, lb, lc, neg != 0);
   return d_evalfn_pack(la, lb, lc);
+}
+// digit of the Miller loop at position m: +1, -1 or 0 (wave-uniform; hostbn.h naf_of_half)
+static PBC_DEV int d_digit(int m) {
+  return (int) ((c_d.r[m >> 5] >> (m & 31)) & 1) - (int) ((c_d.rm[m >> 5] >> (m & 31)) & 1);
 }
 
 static PBC_DEV void f3_load_be(f3 &r, const uint8_t *src) { for (int i = 0; i < DEG; i++) fp_load_be<ND>(r.c[i], src + fpk<ND>().fbytes * i); }
@@ -491,8 +501,9 @@ static PBC_DEV bool d_miller_lane(f6 &v, const uint8_t *g1, const uint8_t *g2) {
     d_unpack(e0, d_dbl_line_fn());
     f6_mul(v, v, e0);
     if (m <= 0) break;
-    if ((c_d.r[m >> 5] >> (m & 31)) & 1) {
-      d_unpack(e0, d_add_line_fn());
+    const int dig = d_digit(m);
+    if (dig) {
+      d_unpack(e0, d_add_line_fn(dig < 0));
       f6_mul(v, v, e0);
     }
     f6_sqr(v, v);
@@ -606,8 +617,8 @@ static PBC_DEV bool d_pp_init_lane(uint32_t *tab, const uint8_t *g1) {
     for (int k = 0; k < ND; k++) { tab[(slot * 3 + 0) * ND + k] = la.v[k]; tab[(slot * 3 + 1) * ND + k] = lb.v[k]; tab[(slot * 3 + 2) * ND + k] = lc.v[k]; }
     slot++;
     if (m <= 0) break;
-    if ((c_d.r[m >> 5] >> (m & 31)) & 1) {
-      d_add_core(la, lb, lc);
+    if (d_digit(m)) {
+      d_add_core(la, lb, lc, d_digit(m) < 0);
       for (int k = 0; k < ND; k++) { tab[(slot * 3 + 0) * ND + k] = la.v[k]; tab[(slot * 3 + 1) * ND + k] = lb.v[k]; tab[(slot * 3 + 2) * ND + k] = lc.v[k]; }
       slot++;
     }
@@ -662,7 +673,7 @@ static PBC_DEV void d_pp_apply_lane(uint8_t *gt, const uint32_t *tab, bool p_val
     d_pp_line(e0, tab, slot++);
     f6_mul(v, v, e0);
     if (m <= 0) break;
-    if ((c_d.r[m >> 5] >> (m & 31)) & 1) {
+    if (d_digit(m)) {
       d_pp_line(e0, tab, slot++);
       f6_mul(v, v, e0);
     }
@@ -704,15 +715,15 @@ static PBC_DEV void d_prod_pairing_lane(uint8_t *gt, const uint8_t *g1, const ui
     f3_set_fq(F.x, one);
     f3_sub(F.y, F.x, F.x);
     for (int m = c_d.rbits - 2;; m--) {
-      const bool add = m > 0 && ((c_d.r[m >> 5] >> (m & 31)) & 1);
+      const int dig = m > 0 ? d_digit(m) : 0;
       for (int j = 0; j < k; j++) {
         uint32_t *w = ws + (size_t) j * REC;
         d_ws_load(w, 0, DL_WORDS);
         f6 e0;
         d_unpack(e0, d_dbl_line_fn());
         f6_mul(F, F, e0);
-        if (add) {
-          d_unpack(e0, d_add_line_fn());
+        if (dig) {
+          d_unpack(e0, d_add_line_fn(dig < 0));
           f6_mul(F, F, e0);
         }
         d_ws_save(w, DL_X, 3 * ND);      // only V = (X, Y, Z) changes

@@ -33,7 +33,7 @@ struct FConst {                        // f_pairing_data_s (ecc/f_param.c:35-45)
   uint32_t negalphainv[2][NF_MAX];
   uint32_t xpowq2[2][NF_MAX], xpowq6[2][NF_MAX], xpowq8[2][NF_MAX];   // X^(q^k) = (this) X (f_param.c:431-444)
   uint32_t tb[2][NF_MAX];              // twist: y^2 = x^3 - alpha b (f_param.c:372-381)
-  uint32_t r[8];
+  uint32_t r[8], rm[8];                // Miller loop digits: NAF of r >> 1, +1 digits in r[], -1 digits in rm[] (hostbn.h)
   uint32_t tateexp[32];                // (q^4 - q^2 + 1)/r (f_param.c:414-420)
   int rbits, tebits;
   // BN structure (f_param.c:70-95 tryplusx/tryminusx): q = 36x^4+36x^3+24x^2+6x+1,
@@ -682,19 +682,23 @@ static __device__ __noinline__ bool f_miller_lane(f12 *v, const uint8_t *g1, con
       fp_sqr<ND>(V.ZZ, Z3);
     }
     if (m <= 0) break;
-    if ((c_f.r[m >> 5] >> (m & 31)) & 1) {
-      // chord through V and P (do_line :190-199), scaled by Z3 = Z H:
-      //   a' = -R, b' = Z3, c' = R Px - Z3 Py;  V <- V + P
+    const int dig = (int) ((c_f.r[m >> 5] >> (m & 31)) & 1) - (int) ((c_f.rm[m >> 5] >> (m & 31)) & 1);
+    if (dig) {
+      // chord through V and +-P (do_line :190-199), scaled by Z3 = Z H; the sign is the signed digit of the loop:
+      //   a' = -R, b' = Z3, c' = R Px - Z3 Py;  V <- V +- P
+      fq Pys;
+      fp_neg<ND>(Pys, Py);
+      fp_cmov<ND>(Pys, Py, dig > 0);
       fq H, R, HH, HHH, t0, t1, Z3, la, lc;
       fp_mul<ND>(H, Px, V.ZZ);
       fp_sub<ND>(H, H, V.X);
       fp_mul<ND>(t0, V.Z, V.ZZ);
-      fp_mul<ND>(R, Py, t0);
+      fp_mul<ND>(R, Pys, t0);
       fp_sub<ND>(R, R, V.Y);
       fp_mul<ND>(Z3, V.Z, H);
       fp_neg<ND>(la, R);
       fp_mul<ND>(lc, R, Px);
-      fp_mul<ND>(t0, Z3, Py);
+      fp_mul<ND>(t0, Z3, Pys);
       fp_sub<ND>(lc, lc, t0);
       if constexpr (kLdsMiller) { f_line_mul_lds(cur, to_vec<ND>(la), to_vec<ND>(Z3), to_vec<ND>(lc), &Qx, &Qy); cur ^= 1; }
       else f_line_mul(v, to_vec<ND>(la), to_vec<ND>(Z3), to_vec<ND>(lc), &Qx, &Qy);

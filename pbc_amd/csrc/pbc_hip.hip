@@ -1317,12 +1317,12 @@ extern "C" int pbc_hip_pairing_pp_init(pbc_hip_pp_t **out, pbc_hip_pairing_t *P,
   size_t words = (size_t) (P->a.exp2 + 1) * 3 * 16;
   if (mnt) {                           // one entry per doubling and per addition of the Miller loop
     int steps = P->dconst.rbits - 1;
-    for (int m = 1; m <= P->dconst.rbits - 2; m++) steps += (P->dconst.r[m >> 5] >> (m & 31)) & 1;
+    for (int m = 1; m <= P->dconst.rbits - 2; m++) steps += ((P->dconst.r[m >> 5] | P->dconst.rm[m >> 5]) >> (m & 31)) & 1;
     words = (size_t) steps * 3 * (size_t) P->nlimb;
   }
   if (a1) {
     int steps = P->a.rbits - 1;
-    for (int m = 1; m <= P->a.rbits - 2; m++) steps += (P->a.r[m >> 5] >> (m & 31)) & 1;
+    for (int m = 1; m <= P->a.rbits - 2; m++) steps += ((P->a.r[m >> 5] | P->a.rm[m >> 5]) >> (m & 31)) & 1;
     words = (size_t) steps * 3 * (size_t) P->nlimb;
   }
   DeviceGuard guard(P->device);

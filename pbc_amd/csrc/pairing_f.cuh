@@ -39,6 +39,8 @@ struct FConst {                        // f_pairing_data_s (ecc/f_param.c:35-45)
   // BN structure (f_param.c:70-95 tryplusx/tryminusx): q = 36x^4+36x^3+24x^2+6x+1,
   // r = 36x^4+36x^3+18x^2+6x+1.  When the host recognises it, the hard part uses the
   // x-chain instead of a 472-bit power.
+  // limb forms (29-bit) of the constants the lazy F_q^12 products multiply by: read as scalar operands, no conversions
+  uint32_t beta29[9], one29[9], na29[2][9], bna29[9];   // beta, R mod q, negalpha (x, y), beta * negalpha.y
   uint32_t gamma[2][NF_MAX];           // X^q = gamma X, gamma = negalpha^((q-1)/6)
   uint32_t bn_x[2];                    // |x|
   int bn_ok, bn_xneg, bn_xbits;
@@ -65,6 +67,12 @@ struct g2 { fq x, y; };                // x + y sqrt(beta)
 struct f12 { g2 c[6]; };               // sum c_i X^i, X^6 = negalpha
 struct djac { fq X, Y, Z, ZZ; };
 
+static PBC_DEV fl<ND> fl29(const uint32_t *l) {                 // a constant kept as limbs in the constant block
+  fl<ND> r;
+#pragma unroll
+  for (int i = 0; i < Limbs29<ND>::L; i++) r.l[i] = l[i];
+  return r;
+}
 static PBC_DEV g2 fk2(const uint32_t (*w)[NF_MAX]) { g2 r; fp_set<ND>(r.x, w[0]); fp_set<ND>(r.y, w[1]); return r; }
 
 // ---- F_q^2 = F_q[sqrt(beta)] -------------------------------------------------------------
@@ -166,7 +174,7 @@ struct f12r { fl<ND> x[6], y[6], by[6]; };     // register-resident operand: eve
 // a -> registers (and, when `stage`, its x / y limb forms to LDS as well: the squaring's second operand is the first)
 static PBC_DEV void f12_load_regs(f12r &A, const f12 *a, bool stage) {
   fl<ND> be;
-  to_limbs<ND>(be, dk(c_f.beta));
+  be = fl29(c_f.beta29);
 #pragma unroll
   for (int i = 0; i < 6; i++) {
     to_limbs<ND>(A.x[i], a->c[i].x);
@@ -368,7 +376,7 @@ static __device__ __noinline__ void f_line_mul(f12 *v, v5 va, v5 vb, v5 vc, cons
   g2_mul(aqn, aq, na);
   g2_mul(bqn, bq, na);
   fl<ND> be, cl;
-  to_limbs<ND>(be, dk(c_f.beta));
+  be = fl29(c_f.beta29);
   to_limbs<ND>(cl, c);
   g2l Aq, Aqn, Bq, Bqn;
   g2l_make(Aq, aq, be);
@@ -424,7 +432,7 @@ static PBC_DEV void wide_carry(wide<ND> &W, const fl<ND> &oneL) {
 static __device__ __noinline__ void f12_sqr_lds(int cur) {
   fl<ND> by[6];                                  // beta y_i for the compile-time index of each pair
 #pragma unroll
-  for (int i = 0; i < 6; i++) { const fl<ND> xx[1] = {ldsf_get(i, 1, cur)}, yy[1] = {flk(c_f.beta)}; sop_limbs<ND, 1>(by[i], xx, yy); }
+  for (int i = 0; i < 6; i++) { const fl<ND> xx[1] = {ldsf_get(i, 1, cur)}, yy[1] = {fl29(c_f.beta29)}; sop_limbs<ND, 1>(by[i], xx, yy); }
 #pragma nounroll
   for (int kk = 0; kk < 6; kk++) {
     fl<ND> t6x, t6y;
@@ -440,7 +448,7 @@ static __device__ __noinline__ void f12_sqr_lds(int cur) {
       for (int i = 0; i < 6; i++) {
         const int j = k - i;
         if (j < i || j > 5) continue;            // pairs i <= j (wave-uniform)
-        if (units + 4 > kCap) { const fl<ND> oneL = flk(fpk<ND>().one); wide_carry(Wx, oneL); wide_carry(Wy, oneL); units = 1; }
+        if (units + 4 > kCap) { const fl<ND> oneL = fl29(c_f.one29); wide_carry(Wx, oneL); wide_carry(Wy, oneL); units = 1; }
         const fl<ND> ax = ldsf_get(i, 0, cur), ay = ldsf_get(i, 1, cur);
         if (i == j) {                            // a_i^2: re = x^2 + (beta y) y, im = 2 x y
           fl<ND> ax2;
@@ -465,10 +473,8 @@ static __device__ __noinline__ void f12_sqr_lds(int cur) {
         wide_reduce<ND>(t6y, Wy);
       } else {
         if (kk < 5) {                            // + negalpha * (coefficient k + 6)
-          if (units + 2 > kCap) { const fl<ND> oneL = flk(fpk<ND>().one); wide_carry(Wx, oneL); wide_carry(Wy, oneL); }
-          const fl<ND> nax = flk(c_f.negalpha[0]), nay = flk(c_f.negalpha[1]);
-          fl<ND> bnay;
-          { const fl<ND> xx[1] = {nay}, yy[1] = {flk(c_f.beta)}; sop_limbs<ND, 1>(bnay, xx, yy); }
+          if (units + 2 > kCap) { const fl<ND> oneL = fl29(c_f.one29); wide_carry(Wx, oneL); wide_carry(Wy, oneL); }
+          const fl<ND> nax = fl29(c_f.na29[0]), nay = fl29(c_f.na29[1]), bnay = fl29(c_f.bna29);
           wide_mac<ND>(Wx, nax, t6x);
           wide_mac<ND>(Wx, bnay, t6y);
           wide_mac<ND>(Wy, nax, t6y);
@@ -497,7 +503,7 @@ static __device__ __noinline__ void f_line_mul_lds(int cur, v5 va, v5 vb, v5 vc,
   g2_mul(aqn, aq, na);
   g2_mul(bqn, bq, na);
   fl<ND> be, cl;
-  to_limbs<ND>(be, dk(c_f.beta));
+  be = fl29(c_f.beta29);
   to_limbs<ND>(cl, c);
   g2l Aq, Aqn, Bq, Bqn;
   g2l_make(Aq, aq, be);
@@ -548,7 +554,7 @@ static __device__ __noinline__ void f12_mul_lds(int cur, const f12 *b) {
       for (int i = 0; i < 6; i++) {
         const int j = k - i;
         if (j < 0 || j > 5) continue;            // wave-uniform
-        if (units + 2 > kCap) { const fl<ND> oneL = flk(fpk<ND>().one); wide_carry(Wx, oneL); wide_carry(Wy, oneL); units = 1; }
+        if (units + 2 > kCap) { const fl<ND> oneL = fl29(c_f.one29); wide_carry(Wx, oneL); wide_carry(Wy, oneL); units = 1; }
         const fl<ND> ax = ldsf_get(j, 0, cur), ay = ldsf_get(j, 1, cur);
         wide_mac<ND>(Wx, B.x[i], ax);
         wide_mac<ND>(Wx, B.by[i], ay);
@@ -561,10 +567,8 @@ static __device__ __noinline__ void f12_mul_lds(int cur, const f12 *b) {
         wide_reduce<ND>(t6y, Wy);
       } else {
         if (kk < 5) {
-          if (units + 2 > kCap) { const fl<ND> oneL = flk(fpk<ND>().one); wide_carry(Wx, oneL); wide_carry(Wy, oneL); }
-          const fl<ND> nax = flk(c_f.negalpha[0]), nay = flk(c_f.negalpha[1]);
-          fl<ND> bnay;
-          { const fl<ND> xx[1] = {nay}, yy[1] = {flk(c_f.beta)}; sop_limbs<ND, 1>(bnay, xx, yy); }
+          if (units + 2 > kCap) { const fl<ND> oneL = fl29(c_f.one29); wide_carry(Wx, oneL); wide_carry(Wy, oneL); }
+          const fl<ND> nax = fl29(c_f.na29[0]), nay = fl29(c_f.na29[1]), bnay = fl29(c_f.bna29);
           wide_mac<ND>(Wx, nax, t6x);
           wide_mac<ND>(Wx, bnay, t6y);
           wide_mac<ND>(Wy, nax, t6y);
@@ -900,6 +904,19 @@ static PBC_DEV void init_stage1(FConst *out, const FRaw &raw, const FConst &base
   for (int k = 0; k < ND; k++) {
     C.B[k] = b.v[k]; C.beta[k] = be.v[k];
     C.negalpha[0][k] = a0.v[k]; C.negalpha[1][k] = a1.v[k];
+  }
+  {
+    fq one;
+    fp_set<ND>(one, fpk<ND>().one);
+    fl<ND> bel, o, nx, ny, bny;
+    to_limbs<ND>(bel, be);
+    to_limbs<ND>(o, one);
+    to_limbs<ND>(nx, a0);
+    to_limbs<ND>(ny, a1);
+    { const fl<ND> xx[1] = {ny}, yy[1] = {bel}; sop_limbs<ND, 1>(bny, xx, yy); }
+    for (int l = 0; l < Limbs29<ND>::L; l++) {
+      C.beta29[l] = bel.l[l]; C.one29[l] = o.l[l]; C.na29[0][l] = nx.l[l]; C.na29[1][l] = ny.l[l]; C.bna29[l] = bny.l[l];
+    }
   }
   *out = C;
 }

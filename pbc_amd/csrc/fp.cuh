@@ -281,6 +281,9 @@ PBC_DEV void sqr_limbs(uint32_t *t, const uint32_t *x) {
 template <int N>
 struct fl {
   uint32_t l[Limbs29<N>::L];
+#ifdef PBC_HOSTSIM
+  double hs_u = 1.0, hs_B = 1.0;   // worst-case limb size (units of 2^29) and value (units of q): tracked and asserted by
+#endif                             // the redundant-representation code of pairing_al.cuh in the host mirror only
 };
 template <int N>
 PBC_DEV void to_limbs(fl<N> &r, const fp<N> &a) { to29<N>(r.l, a); }
@@ -299,8 +302,30 @@ PBC_DEV void from_limbs(fp<N> &r, const fl<N> &a) {
 // keeps the compiler from re-associating separate accumulator chains back into one
 #ifdef PBC_HOSTSIM
 #define PBC_OPAQUE64(x) ((void) 0)
+// host mirror only: the exact column sums of a sum of products in 128 bits -- none may reach 2^64
+template <int N, class X>
+static inline void hs_sop_check(const X &x, const X &y, int T) {
+  constexpr int L = Limbs29<N>::L;
+  const FpK<N> &K = fpk<N>();
+  unsigned __int128 acc = 0;
+  uint32_t m[L];
+  for (int k = 0; k < 2 * L; k++) {
+    for (int t = 0; t < T; t++)
+      for (int i = (k < L ? 0 : k - L + 1); i <= (k < L ? k : L - 1); i++) acc += (unsigned __int128) x[t].l[i] * y[t].l[k - i];
+    for (int i = (k < L ? 0 : k - L + 1); i < (k < L ? k : L); i++) acc += (unsigned __int128) m[i] * K.p29[k - i];
+    if (k < L) {
+      m[k] = ((uint32_t) acc * K.ninv29) & Limbs29<N>::MASK;
+      acc += (unsigned __int128) m[k] * K.p29[0];
+    }
+    if (acc >> 64) { fprintf(stderr, "hostsim: column %d of a sum of %d products overflows 64 bits\n", k, T); abort(); }
+    acc >>= Limbs29<N>::W;
+  }
+  if (acc) { fprintf(stderr, "hostsim: a Montgomery product does not fit its limbs\n"); abort(); }
+}
+#define PBC_HS_SOP_CHECK(x, y, T) hs_sop_check<N>(x, y, T)
 #else
 #define PBC_OPAQUE64(x) asm("" : "+v"(x))
+#define PBC_HS_SOP_CHECK(x, y, T) ((void) 0)
 #endif
 #ifndef PBC_SOP_CHAINS
 #define PBC_SOP_CHAINS 1    // independent accumulator chains per column (experiment: the multiply-add chain of a column is
@@ -315,6 +340,7 @@ PBC_DEV void sop_limbs(fl<N> &r, const fl<N> (&x)[T], const fl<N> (&y)[T]) {
   constexpr int C = PBC_SOP_CHAINS < T ? PBC_SOP_CHAINS : T;
   uint32_t m[L];
   uint64_t acc = 0;
+  PBC_HS_SOP_CHECK(x, y, T);
 #pragma unroll
   for (int k = 0; k < L; k++) {
     uint64_t part[C];

@@ -205,6 +205,21 @@ static int init_type_a(pbc_hip_pairing_s *P, const char *txt, size_t len) {
     if (fill_fpk<16>(P->k16, q)) return fail("type a: bad q");
     P->nlimb = 16;
     P->a_generic = false;
+    {                                    // subtraction constants of the limb-form kernel (AConst::ksub)
+      static const uint32_t cd[5][2] = {{2, 1}, {4, 2}, {8, 4}, {12, 2}, {16, 2}};
+      for (int t = 0; t < 5; t++) {
+        Big c;
+        c.w.push_back(cd[t][0]);
+        const Big v = Big::mul(q, c);
+        const uint32_t D = cd[t][1];
+        uint32_t *k = P->a.ksub[t];
+        for (int i = 0; i < 18; i++) {
+          uint32_t x = 0;
+          for (int b = 0; b < 29; b++) x |= (uint32_t) v.bit(29 * i + b) << b;
+          k[i] = x + (i < 17 ? D << 29 : 0) - (i > 0 ? D : 0);
+        }
+      }
+    }
   } else {
     // any other size up to 1056 bits: the type a1 kernels (plain double-and-add over the bits of r;
     // functions with the same divisor up to vertical lines, which the final power removes) on the

@@ -58,6 +58,10 @@ struct AConst {          // a_pairing_data (ecc/a_param.c:30-34) + phikonr = h (
   int sqrt_bits;
   uint32_t r[34], rm[34]; // type a1 (and type a outside the 512-bit fast path): Miller loop digits, NAF of n >> 1 (+1 / -1)
   int rbits;
+  // limb-form kernel (pairing_al.cuh): multiples c q of the modulus in 29-bit limbs, "borrowed" so that limb i
+  // dominates limb i of any subtrahend with limbs <= D (2^29 - 1) and value < c q:
+  //     limb_0 + D 2^29,   limb_i + D 2^29 - D  (0 < i < 17),   limb_17 - D;      (c, D) = (2,1) (4,2) (8,4) (12,2) (16,2)
+  uint32_t ksub[5][18];
 };
 static_assert(sizeof(AConst) <= KOFF_XS - KOFF_TYPE, "constant block layout");
 #define c_a (pbc::kconst<pbc::AConst, pbc::KOFF_TYPE>())

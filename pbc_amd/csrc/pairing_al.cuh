@@ -1,0 +1,552 @@
+// pairing_al.cuh -- Type A (a.param: 512-bit q, 16 words) with F_q elements kept in 29-bit LIMB form.
+//
+// Same map as pairing_a.cuh's a_pairing_lane (a_pairing_proj + a_tateexp, ecc/a_param.c:1053-1198, :285-303), same
+// Jacobian Miller steps and the same Lucas-sequence final exponentiation -- but an element is L = 18 limbs of 29 bits
+// from the moment it is loaded until it is stored.  The word-form kernel converts both operands of every product into
+// limbs and the result back into words with a conditional subtraction: 150 of the 900 instructions of a product
+// (measured by a what-if build: +14 % pairings/s without them, profiles/r02_notes.md).  At two waves per SIMD every
+// VALU instruction costs the same ~4 cycles, so the kernel is bound by its instruction COUNT.
+//
+// Redundant representation.  R = 2^522 and q < 2^512, so there are ten bits of slack: a value is any 18 limbs whose
+// sum is congruent to it; a Montgomery product of operands below 16 q comes out below 1.25 q ("P-class": limbs
+// < 2^29 exactly, value < 1.5 q), additions are 18 plain v_add without carries, and there are no conditional
+// subtractions at all until the result is stored.  Two bounds are tracked by hand through every routine below
+// (and checked by assertions in the host mirror, tests/hostsim):
+//   * limb size u, in units of 2^29: a column of the multiplier holds 18 operand products + 18 products m q, so
+//         18 (sum over terms of u_x u_y) 2^58 + 18 2^58 < 2^64   <=>   sum u_x u_y <= 2.55
+//     -- one operand of a product may be a sum of two normalised values (u = 2), squares need u <= 1.58;
+//   * value bound B, in units of q: B(out) = 1 + sum B(x) B(y) / 1024.
+// norm() is a PARALLEL carry pass (3 instructions per limb, no chain): limbs end up <= 2^29 + 6 ("almost normalised").
+// A difference a - b is formed as a + (K - b) limb by limb with K = c q written so that every limb dominates the
+// corresponding limb of b (borrowed form: limb_i(c q) + D 2^29 - D); the host precomputes the four K it needs.
+//
+// Calling convention of the out-of-line products.  An operand is 18 VGPRs and the ABI passes 31: the first operand
+// travels in registers, the second as 12 registers + 6 words of LDS; the Miller accumulator f and the second pairing
+// coordinates Z, Z^2 of the running point live in LDS for the whole loop (four slots), which takes 72 registers out of
+// the point arithmetic and means that f^2 and f * line take no operands at all; Q sits in the lane's private memory.  LDS per lane: 4 x 18 + 6 words = 312 B -> 39 KB per 128-lane
+// workgroup, four workgroups (two waves per SIMD) per CU.
+#pragma once
+#include "pairing_a.cuh"
+
+namespace pbc {
+
+constexpr int AL_LANES = 128;
+#ifdef PBC_HOSTSIM
+#define PBC_PRIVATE
+#else
+#define PBC_PRIVATE __attribute__((address_space(5)))     // the lane's private memory: scratch_load, not flat_load
+#endif
+template <int N> constexpr bool kLimbFormA = N == 16;     // widths with an instantiated limb-form kernel
+template <int N> __shared__ uint32_t g_lds_al[(4 * Limbs29<N>::L + 6) * AL_LANES];
+
+// value bounds are statements about q < 2^(29 L - 10); the host enables the kernel only then (host_params.h)
+template <int N>
+struct AL {
+  static constexpr int L = Limbs29<N>::L;
+  static constexpr uint32_t MASK = Limbs29<N>::MASK;
+  static_assert(Limbs29<N>::W == 29 && 2 * L + L <= 63, "limb-form type a needs 29-bit limbs and room for a doubled operand");
+  typedef fl<N> el;
+  typedef uint32_t vL __attribute__((ext_vector_type(L)));
+  typedef uint32_t vLo __attribute__((ext_vector_type(12)));
+  enum { SLOT_FX = 0, SLOT_FY = 1, SLOT_Z = 2, SLOT_ZZ = 3 };
+  enum { K2 = 0, K4 = 1, K8 = 2, K12 = 3, K16 = 4 };   // AConst::ksub: (c, D) = (2, 1), (4, 2), (8, 4), (12, 2), (16, 2)
+
+  // ---- host mirror only: worst-case bound tracker ----------------------------------------------------------------
+  // Every element carries (u, B) as derived from the operations that produced it -- not from its actual limbs --
+  // and every operation asserts its precondition on those, so one run of the mirror proves the bounds for ALL inputs.
+#ifdef PBC_HOSTSIM
+  static constexpr double U_STRICT = 1.0 - 1.0 / 536870912.0, U_ALMOST = 1.0 + 7.0 / 536870912.0;
+  static constexpr double KC[5] = {2, 4, 8, 12, 16}, KD[5] = {1, 2, 4, 2, 2};
+  static inline double hs_lu[4] = {1, 1, 1, 1}, hs_lB[4] = {1, 1, 1, 1}, hs_au, hs_aB, hs_bu, hs_bB;
+  static void hs_fail(const char *what, double v) { fprintf(stderr, "hostsim: limb-form type a: %s (%g)\n", what, v); abort(); }
+  static void hs_limbs(const el &a) {                       // the actual limbs must respect the tracked bound
+    for (int i = 0; i < L; i++)
+      if ((double) a.l[i] > a.hs_u * 536870912.0) hs_fail("limb above its tracked bound", a.hs_u);
+  }
+  static void hs_set(el &r, double u, double B) { r.hs_u = u; r.hs_B = B; hs_limbs(r); }
+  static void hs_dom(const el &b, int k) {                  // K_k dominates b
+    hs_limbs(b);
+    if (b.hs_u > KD[k] * U_STRICT + 1e-12) hs_fail("subtrahend limbs not dominated", b.hs_u);
+    if (b.hs_B > KC[k] - 0.001) hs_fail("subtrahend value not dominated", b.hs_B);
+  }
+  static void hs_cols(double s) { if (s > 2.55) hs_fail("column capacity", s); }
+#define AL_HS(...) __VA_ARGS__
+#else
+#define AL_HS(...)
+#endif
+
+  static PBC_DEV uint32_t &lds(int slot, int limb) { return g_lds_al<N>[(slot * L + limb) * AL_LANES + threadIdx.x]; }
+  static PBC_DEV uint32_t &lds_hi(int i) { return g_lds_al<N>[(4 * L + i) * AL_LANES + threadIdx.x]; }
+  static PBC_DEV void lds_get(el &r, int slot) {
+#pragma unroll
+    for (int i = 0; i < L; i++) r.l[i] = lds(slot, i);
+    AL_HS(hs_set(r, hs_lu[slot], hs_lB[slot]);)
+  }
+  static PBC_DEV void lds_put(int slot, const el &a) {
+#pragma unroll
+    for (int i = 0; i < L; i++) lds(slot, i) = a.l[i];
+    AL_HS(hs_limbs(a); hs_lu[slot] = a.hs_u; hs_lB[slot] = a.hs_B;)
+  }
+  static PBC_DEV vL to_v(const el &a) {
+    vL v;
+#pragma unroll
+    for (int i = 0; i < L; i++) v[i] = a.l[i];
+    return v;
+  }
+  static PBC_DEV void from_v(el &r, vL v) {
+#pragma unroll
+    for (int i = 0; i < L; i++) r.l[i] = v[i];
+  }
+
+  // ---- carry-free additive layer -------------------------------------------------------------------------------
+  static PBC_DEV void add(el &r, const el &a, const el &b) {
+#pragma unroll
+    for (int i = 0; i < L; i++) r.l[i] = a.l[i] + b.l[i];
+    AL_HS(if (a.hs_u + b.hs_u >= 8) hs_fail("sum overflows 32 bits", a.hs_u + b.hs_u); hs_set(r, a.hs_u + b.hs_u, a.hs_B + b.hs_B);)
+  }
+  template <int S>
+  static PBC_DEV void shl(el &r, const el &a) {
+#pragma unroll
+    for (int i = 0; i < L; i++) r.l[i] = a.l[i] << S;
+    AL_HS(if (a.hs_u * (1 << S) >= 8) hs_fail("shift overflows 32 bits", a.hs_u); hs_set(r, a.hs_u * (1 << S), a.hs_B * (1 << S));)
+  }
+  // r = a + K - b: b's limbs must be dominated by K's (see the table at ksub in host_params.h)
+  static PBC_DEV void subk(el &r, const el &a, const el &b, int k) {
+    const uint32_t *K = c_a.ksub[k];
+    AL_HS(hs_dom(b, k); const double u = a.hs_u + KD[k] + 1, B = a.hs_B + KC[k]; if (u >= 8) hs_fail("difference overflows 32 bits", u);)
+#pragma unroll
+    for (int i = 0; i < L; i++) r.l[i] = a.l[i] - b.l[i] + K[i];
+    AL_HS(hs_set(r, u, B);)
+  }
+  // r = K - b  (= -b mod q)
+  static PBC_DEV void negk(el &r, const el &b, int k) {
+    const uint32_t *K = c_a.ksub[k];
+    AL_HS(hs_dom(b, k);)
+#pragma unroll
+    for (int i = 0; i < L; i++) r.l[i] = K[i] - b.l[i];
+    AL_HS(hs_set(r, KD[k] + 1, KC[k]);)
+  }
+  // parallel carry pass: limbs < 2^32 in, limbs <= 2^29 + 6 out (the top limb is not cut: values stay far below 2^522)
+  static PBC_DEV void norm(el &r, const el &a) {
+    uint32_t c = 0;
+    AL_HS(hs_limbs(a); const double B = a.hs_B; if (a.hs_u >= 8) hs_fail("normalising limbs above 32 bits", a.hs_u);)
+#pragma unroll
+    for (int i = 0; i < L; i++) {
+      const uint32_t t = a.l[i];
+      r.l[i] = (i < L - 1 ? (t & MASK) : t) + c;
+      c = t >> 29;
+    }
+    AL_HS(hs_set(r, U_ALMOST, B);)
+  }
+  static PBC_DEV void to_el(el &r, const fp<N> &a) {
+    to_limbs<N>(r, a);
+    AL_HS(hs_set(r, U_STRICT, 1.0);)
+  }
+  static PBC_DEV void to_words(fp<N> &r, const el &a) {     // value < 2q (from_limbs subtracts q at most once)
+    AL_HS(hs_limbs(a); if (a.hs_u > U_STRICT || a.hs_B >= 2) hs_fail("from_limbs needs a P-class value", a.hs_B);)
+    from_limbs<N>(r, a);
+  }
+
+  // ---- products (inline bodies) ----------------------------------------------------------------------------------
+  // DBL = 1: one of the operands has limbs up to 2^30 (a sum of two, or a doubled value)
+  template <int DBL>
+  static PBC_DEV void mul_inl(el &r, const el &a, const el &b) {
+    const el x[1] = {a}, y[1] = {b};
+    AL_HS(hs_limbs(a); hs_limbs(b); hs_cols(a.hs_u * b.hs_u); const double B = 1 + a.hs_B * b.hs_B / 1024;)
+    sop_limbs<N, 1, DBL>(r, x, y);
+    AL_HS(hs_set(r, U_STRICT, B);)
+  }
+  static PBC_DEV void sqr_inl(el &r, const el &a) {
+    AL_HS(const el x[1] = {a}; hs_limbs(a); hs_cols(a.hs_u * a.hs_u); hs_sop_check<N>(x, x, 1); const double B = 1 + a.hs_B * a.hs_B / 1024;)
+    sqr_limbs<N>(r.l, a.l);
+    AL_HS(hs_set(r, U_STRICT, B);)
+  }
+  // sop_limbs<N, 2> without the loop over terms (three loop levels defeat the unroller: the operands end up in scratch)
+  static PBC_DEV void sop2_limbs(el &r, const el &a0, const el &b0, const el &a1, const el &b1) {
+    const FpK<N> &K = fpk<N>();
+    PBC_COUNT_MACS(3 * L * L);
+    uint32_t m[L];
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < L; k++) {
+#pragma unroll
+      for (int i = 0; i <= k; i++) {
+        acc += (uint64_t) a0.l[i] * b0.l[k - i];
+        acc += (uint64_t) a1.l[i] * b1.l[k - i];
+      }
+#pragma unroll
+      for (int i = 0; i < k; i++) acc += (uint64_t) m[i] * K.p29[k - i];
+      m[k] = ((uint32_t) acc * K.ninv29) & MASK;
+      acc += (uint64_t) m[k] * K.p29[0];
+      acc >>= 29;
+    }
+#pragma unroll
+    for (int k = L; k < 2 * L; k++) {
+#pragma unroll
+      for (int i = k - L + 1; i < L; i++) {
+        acc += (uint64_t) a0.l[i] * b0.l[k - i];
+        acc += (uint64_t) a1.l[i] * b1.l[k - i];
+      }
+#pragma unroll
+      for (int i = k - L + 1; i < L; i++) acc += (uint64_t) m[i] * K.p29[k - i];
+      r.l[k - L] = (uint32_t) acc & MASK;
+      acc >>= 29;
+    }
+  }
+  // r = a0 b0 + a1 b1, one reduction (all four operands normalised)
+  static PBC_DEV void sop2_inl(el &r, const el &a0, const el &b0, const el &a1, const el &b1) {
+    AL_HS(const el x[2] = {a0, a1}; const el y[2] = {b0, b1}; hs_limbs(a0); hs_limbs(b0); hs_limbs(a1); hs_limbs(b1); hs_cols(a0.hs_u * b0.hs_u + a1.hs_u * b1.hs_u);
+          const double B = 1 + (a0.hs_B * b0.hs_B + a1.hs_B * b1.hs_B) / 1024;)
+    AL_HS(hs_sop_check<N>(x, y, 2);)
+    sop2_limbs(r, a0, b0, a1, b1);
+    AL_HS(hs_set(r, U_STRICT, B);)
+  }
+
+  // ---- out-of-line instances -------------------------------------------------------------------------------------
+  // (host mirror: the bounds of register operands cross the call in hs_au / hs_aB and friends)
+  static __device__ __noinline__ vL mul_fn(vL va, vLo blo) {
+    el a, b, r;
+    from_v(a, va);
+    AL_HS(a.hs_u = hs_au; a.hs_B = hs_aB; b.hs_u = hs_bu; b.hs_B = hs_bB;)
+#pragma unroll
+    for (int i = 0; i < 12; i++) b.l[i] = blo[i];
+#pragma unroll
+    for (int i = 12; i < L; i++) b.l[i] = lds_hi(i - 12);
+    mul_inl<1>(r, a, b);
+    AL_HS(hs_au = r.hs_u; hs_aB = r.hs_B;)
+    return to_v(r);
+  }
+  static __device__ __noinline__ vL muls_fn(vL va, int slot) {      // second operand: a resident LDS slot
+    el a, b, r;
+    from_v(a, va);
+    AL_HS(a.hs_u = hs_au; a.hs_B = hs_aB;)
+    lds_get(b, slot);
+    mul_inl<1>(r, a, b);
+    AL_HS(hs_au = r.hs_u; hs_aB = r.hs_B;)
+    return to_v(r);
+  }
+  static __device__ __noinline__ vL mulp_fn(vL va, const PBC_PRIVATE uint32_t *p) {   // second operand: private memory (Q)
+    el a, b, r;
+    from_v(a, va);
+    AL_HS(a.hs_u = hs_au; a.hs_B = hs_aB;)
+#pragma unroll
+    for (int i = 0; i < L; i++) b.l[i] = p[i];
+    AL_HS(hs_set(b, U_STRICT, 1.0);)
+    mul_inl<1>(r, a, b);
+    AL_HS(hs_au = r.hs_u; hs_aB = r.hs_B;)
+    return to_v(r);
+  }
+  static __device__ __noinline__ vL sqr_fn(vL va) {
+    el a, r;
+    from_v(a, va);
+    AL_HS(a.hs_u = hs_au; a.hs_B = hs_aB;)
+    sqr_inl(r, a);
+    AL_HS(hs_au = r.hs_u; hs_aB = r.hs_B;)
+    return to_v(r);
+  }
+  // f <- f^2 in LDS  (fi_square, fieldquadratic.c:459-477: (x + y)(x - y) + 2xy i)
+  static __device__ __noinline__ void fsqr_fn() {
+    el fx, fy, e0, e1, r;
+    lds_get(fx, SLOT_FX);
+    lds_get(fy, SLOT_FY);
+    add(e0, fx, fy);                   // u 2
+    subk(e1, fx, fy, K2);              // u 3, B 3.5
+    norm(e1, e1);
+    mul_inl<1>(r, e0, e1);
+    lds_put(SLOT_FX, r);
+    shl<1>(e0, fx);                    // u 2
+    mul_inl<1>(r, e0, fy);
+    lds_put(SLOT_FY, r);
+  }
+  // f <- f (lx + i ly) in LDS  (fi_mul, fieldquadratic.c:425-457) as two lazy sums of two products:
+  //     re = fx lx + (-fy) ly,   im = fx ly + fy lx        -- the multiply-adds of Karatsuba's three products, no
+  // additions besides the negation.  lx, ly: normalised, B <= 6.
+  static __device__ __noinline__ void fmul_fn(vL vlx, vLo lylo) {
+    el fx, fy, nfy, lx, ly, re, im;
+    from_v(lx, vlx);
+    AL_HS(lx.hs_u = hs_au; lx.hs_B = hs_aB; ly.hs_u = hs_bu; ly.hs_B = hs_bB;)
+#pragma unroll
+    for (int i = 0; i < 12; i++) ly.l[i] = lylo[i];
+#pragma unroll
+    for (int i = 12; i < L; i++) ly.l[i] = lds_hi(i - 12);
+    lds_get(fx, SLOT_FX);
+    lds_get(fy, SLOT_FY);
+    negk(nfy, fy, K2);                 // u 2, B 2
+    norm(nfy, nfy);
+    sop2_inl(re, fx, lx, nfy, ly);
+    sop2_inl(im, fx, ly, fy, lx);
+    lds_put(SLOT_FX, re);
+    lds_put(SLOT_FY, im);
+  }
+
+  static PBC_DEV void mul(el &r, const el &a, const el &b) {
+    vLo lo;
+#pragma unroll
+    for (int i = 0; i < 12; i++) lo[i] = b.l[i];
+#pragma unroll
+    for (int i = 12; i < L; i++) lds_hi(i - 12) = b.l[i];
+    AL_HS(hs_au = a.hs_u; hs_aB = a.hs_B; hs_bu = b.hs_u; hs_bB = b.hs_B;)
+    from_v(r, mul_fn(to_v(a), lo));
+    AL_HS(r.hs_u = hs_au; r.hs_B = hs_aB;)
+  }
+  static PBC_DEV void muls(el &r, const el &a, int slot) {
+    AL_HS(hs_au = a.hs_u; hs_aB = a.hs_B;)
+    from_v(r, muls_fn(to_v(a), slot));
+    AL_HS(r.hs_u = hs_au; r.hs_B = hs_aB;)
+  }
+  static PBC_DEV void mulp(el &r, const el &a, const PBC_PRIVATE uint32_t *p) {      // p: canonical limbs (to_limbs output)
+    AL_HS(hs_au = a.hs_u; hs_aB = a.hs_B;)
+    from_v(r, mulp_fn(to_v(a), p));
+    AL_HS(r.hs_u = hs_au; r.hs_B = hs_aB;)
+  }
+  static PBC_DEV void sqr(el &r, const el &a) {
+    AL_HS(hs_au = a.hs_u; hs_aB = a.hs_B;)
+    from_v(r, sqr_fn(to_v(a)));
+    AL_HS(r.hs_u = hs_au; r.hs_B = hs_aB;)
+  }
+  static PBC_DEV void fmul(const el &lx, const el &ly) {
+    vLo lo;
+#pragma unroll
+    for (int i = 0; i < 12; i++) lo[i] = ly.l[i];
+#pragma unroll
+    for (int i = 12; i < L; i++) lds_hi(i - 12) = ly.l[i];
+    AL_HS(hs_au = lx.hs_u; hs_aB = lx.hs_B; hs_bu = ly.hs_u; hs_bB = ly.hs_B;)
+    fmul_fn(to_v(lx), lo);
+  }
+
+  // The point V = (X, Y, Z) of the Miller loop: X, Y in registers (almost normalised, B <= 14), Z and Z^2 in their
+  // LDS slots (P-class); Q = (Qx, Qy) in the lane's private memory as 2 x 18 canonical limbs.
+  struct jacl {
+    el X, Y;
+  };
+
+  // One doubling step: f <- f^2 l_{V,V}(phi(Q)), V <- 2V.  Same line as a_double_step (pairing_a.cuh):
+  //     re = M (ZZ Qx + X) - 2 Y^2,  im = (2YZ) ZZ Qy,  M = 3X^2 + Z^4.
+  // Where the word-form step trades products for squarings, this one takes products: a squaring of a sum needs the
+  // sum normalised first, which costs more than the squaring saves.  9 M + 6 S + 2 two-term sums per step.
+  static PBC_DEV void double_step(jacl &V, const PBC_PRIVATE uint32_t *Q) {
+    el XX, YY, M, t0, t1, lx, ly, Z3, S1, W;
+    fsqr_fn();
+    sqr(XX, V.X);
+    lds_get(t0, SLOT_ZZ);
+    sqr(t0, t0);                       // Z^4
+    shl<1>(M, XX);
+    add(M, M, XX);
+    add(M, M, t0);                     // u 4, B 5
+    norm(M, M);
+    sqr(YY, V.Y);
+    lds_get(t0, SLOT_ZZ);
+    mulp(t0, t0, Q);                   // ZZ Qx
+    add(t0, t0, V.X);                  // u 2, B 10.5
+    mul(lx, M, t0);                    // P
+    shl<1>(t1, YY);                    // u 2, B 3
+    subk(lx, lx, t1, K4);              // u 4, B 5.5
+    norm(lx, lx);
+    shl<1>(t1, V.Y);                   // u 2
+    muls(Z3, t1, SLOT_Z);              // Z3 = 2YZ
+    muls(t1, Z3, SLOT_ZZ);             //                      (Z, ZZ dead)
+    lds_put(SLOT_Z, Z3);
+    sqr(Z3, Z3);
+    lds_put(SLOT_ZZ, Z3);
+    mulp(ly, t1, Q + L);               // im = Z3 ZZ Qy
+    fmul(lx, ly);
+    shl<1>(t1, V.X);                   // u 2
+    mul(S1, YY, t1);                   // 2XY^2
+    sqr(t0, M);
+    shl<2>(t1, S1);                    // 8XY^2: u 4, B 6
+    subk(t0, t0, t1, K8);              // u 6, B 9.5
+    norm(V.X, t0);                     // X3 = M^2 - 2S
+    shl<1>(t1, S1);                    // S = 4XY^2: u 2, B 3
+    subk(W, t1, V.X, K12);             // S - X3: u 5, B 15
+    norm(W, W);
+    mul(t0, M, W);
+    sqr(t1, YY);                       // Y^4
+    shl<3>(t1, t1);                    // u 8, B 12
+    norm(t1, t1);
+    subk(t0, t0, t1, K12);             // u 4, B 13.1
+    norm(V.Y, t0);                     // Y3 = M (S - X3) - 8Y^4
+  }
+
+  // Mixed addition step (a_add_step, pairing_a.cuh): runs once per pairing, so every difference is normalised at once.
+  static PBC_DEV void add_step(jacl &V, const el &x2, const el &y2, const PBC_PRIVATE uint32_t *Q) {
+    el H, R, Z3, HH, HHH, t0, t1, lx, ly;
+    muls(t0, x2, SLOT_ZZ);
+    subk(H, t0, V.X, K16);
+    norm(H, H);                        // B 17.5
+    lds_get(t0, SLOT_Z);
+    muls(t0, t0, SLOT_ZZ);
+    mul(t0, y2, t0);
+    subk(R, t0, V.Y, K16);
+    norm(R, R);                        // B 17.5
+    muls(Z3, H, SLOT_Z);
+#pragma unroll
+    for (int i = 0; i < L; i++) t0.l[i] = Q[i];
+    AL_HS(hs_set(t0, U_STRICT, 1.0);)
+    add(t0, t0, x2);                   // u 2
+    mul(lx, R, t0);
+    mul(t0, Z3, y2);
+    subk(lx, lx, t0, K2);
+    norm(lx, lx);                      // B 3.5
+    mulp(ly, Z3, Q + L);
+    sqr(HH, H);
+    mul(HHH, HH, H);
+    mul(t0, V.X, HH);                  // X1 H^2
+    sqr(t1, R);
+    subk(t1, t1, HHH, K2);
+    norm(t1, t1);                      // B 3.5
+    shl<1>(HH, t0);                    // u 2, B 3
+    subk(t1, t1, HH, K4);
+    norm(t1, t1);                      // X3 = R^2 - H^3 - 2 X1 H^2, B 7.5
+    subk(t0, t0, t1, K16);
+    norm(t0, t0);                      // B 17.5
+    mul(t0, R, t0);
+    mul(HHH, V.Y, HHH);
+    subk(t0, t0, HHH, K2);
+    norm(V.Y, t0);                     // Y3 = R (X1 H^2 - X3) - Y1 H^3, B 3.5
+    V.X = t1;
+    lds_put(SLOT_Z, Z3);
+    sqr(Z3, Z3);
+    lds_put(SLOT_ZZ, Z3);
+    fmul(lx, ly);
+  }
+
+  // limb form of any class -> fully reduced words: one product by R mod q brings the value below 2q
+  static PBC_DEV void to_fp(fp<N> &r, const el &a) {
+    el one, t;
+    fp<N> w;
+    fp_set<N>(w, fpk<N>().one);
+    to_el(one, w);
+    mul(t, a, one);
+    to_words(r, t);
+  }
+
+  // f^((q^2-1)/r) with f in LDS: a_final_exp (pairing_a.cuh) with the Lucas ladder in limb form.  Output: words.
+  static PBC_DEV void final_exp(fp2<N> &out) {
+    el fx, fy, a2, b2, Nn, A, B, t, w, g0, P, v0, v1, two;
+    fp<N> tw;
+    lds_get(fx, SLOT_FX);
+    lds_get(fy, SLOT_FY);
+    sqr(a2, fx);
+    sqr(b2, fy);
+    add(Nn, a2, b2);
+    norm(Nn, Nn);                      // B 3
+    subk(A, a2, b2, K2);
+    norm(A, A);                        // B 3.5
+    shl<1>(t, fx);
+    mul(B, t, fy);                     // 2 fx fy
+    negk(B, B, K2);
+    norm(B, B);                        // f^(q-1) = (A + B i) / N
+    {                                  // B = 0 (f^(q-1) = +-1): invert N * 1 instead, see a_final_exp
+      fp<N> bw, one;
+      to_fp(bw, B);
+      fp_set<N>(one, fpk<N>().one);
+      const bool z = fp_is0<N>(bw);
+      fp_cmov<N>(bw, one, z);
+      to_el(B, bw);                    // canonical from here on
+    }
+    mul(t, Nn, B);
+    to_words(tw, t);
+    fp_inv<N>(tw, tw);                 // 1/(N B)
+    to_el(t, tw);
+    mul(w, t, B);                      // 1/N
+    mul(g0, A, w);                     // Re f^(q-1)
+    mul(t, t, Nn);                     // 1/B
+    mul(w, t, Nn);                     // N/B = 1/Im f^(q-1)
+    shl<1>(P, g0);
+    norm(P, P);                        // B 3, almost normalised
+    fp_set<N>(tw, fpk<N>().one);
+    fp_dbl<N>(tw, tw);
+    to_el(two, tw);                    // canonical
+    v0 = two;
+    v1 = P;
+    for (int j = c_a.hbits - 1; j >= 0; j--) {
+      const bool bit = j ? ((c_a.h[j >> 5] >> (j & 31)) & 1) : false;
+      el m, s;
+      mul(m, v0, v1);
+      subk(m, m, P, K4);               // P almost normalised, B 2.1
+      norm(m, m);                      // B 5.1
+      if (bit) {
+        sqr(s, v1);
+        subk(s, s, two, K2);
+        norm(v1, s);                   // B 3.5
+        v0 = m;
+      } else {
+        sqr(s, v0);
+        subk(s, s, two, K2);
+        norm(v0, s);
+        v1 = m;
+      }
+    }
+    // out.y = -(2 v1 - P v0) (N/B) / 4,  out.x = v0 / 2
+    mul(t, v0, P);
+    shl<1>(v1, v1);                    // u 2, B 35
+    subk(v1, v1, t, K2);
+    norm(v1, v1);                      // B 37
+    mul(v1, v1, w);
+    fp<N> y, x;
+    to_words(y, v1);
+    fp_halve<N>(y, y);
+    fp_halve<N>(y, y);
+    fp_neg<N>(out.y, y);
+    to_fp(x, v0);
+    fp_halve<N>(out.x, x);
+  }
+
+  // element_pairing for one lane
+  static PBC_DEV void pairing_lane(uint8_t *gt, const uint8_t *g1, const uint8_t *g2) {
+    constexpr int NB = 4 * N;
+    fp<N> Px, Py;
+    el x2, y2;
+    jacl V;
+    uint32_t Qm[2 * L];                // Q in private memory: read twice per step, by address
+    bool valid;
+    {
+      fp<N> Qx, Qy;
+      el q;
+      fp_load_be<N>(Px, g1);
+      fp_load_be<N>(Py, g1 + NB);
+      fp_load_be<N>(Qx, g2);
+      fp_load_be<N>(Qy, g2 + NB);
+      valid = a_first_arg_ok<N>(Px, Py) & a_on_curve<N>(Qx, Qy);
+      to_el(q, Qx);
+#pragma unroll
+      for (int i = 0; i < L; i++) Qm[i] = q.l[i];
+      to_el(q, Qy);
+#pragma unroll
+      for (int i = 0; i < L; i++) Qm[L + i] = q.l[i];
+    }
+    const PBC_PRIVATE uint32_t *Q = (const PBC_PRIVATE uint32_t *) Qm;
+    to_el(x2, Px);
+    to_el(y2, Py);
+    {
+      fp<N> one;
+      el o;
+      fp_set<N>(one, fpk<N>().one);
+      to_el(o, one);
+      V.X = x2;
+      V.Y = y2;
+      lds_put(SLOT_Z, o);
+      lds_put(SLOT_ZZ, o);
+      lds_put(SLOT_FX, o);
+#pragma unroll
+      for (int i = 0; i < L; i++) o.l[i] = 0;
+      lds_put(SLOT_FY, o);
+    }
+    for (int i = c_a.exp2 - 1; i >= 0; i--) {
+      double_step(V, Q);
+      if (i == c_a.exp1) {             // the one non-zero middle digit of r: V <- V +- P
+        el ys = y2;
+        if (c_a.sign1 < 0) {
+          negk(ys, y2, K2);
+          norm(ys, ys);
+        }
+        add_step(V, x2, ys, Q);
+      }
+    }
+    fp2<N> out;
+    final_exp(out);
+    a_store_gt<N>(gt, out, valid);
+  }
+};
+
+}  // namespace pbc

@@ -5,6 +5,8 @@
 #pragma once
 #include <stdint.h>
 #include <stddef.h>
+#include <stdio.h>
+#include <stdlib.h>
 #define __device__
 #define __global__
 #define __constant__

@@ -233,59 +233,6 @@ PBC_DEV void a_final_exp(fp2<N> &out, const fp2<N> &f) {
   fp_halve<N>(out.x, v0);
 }
 
-// Miller function f_{r-sign0,P}(phi(Q)) for one lane: bytes in (element_to_bytes layout x||y).
-//
-// Plain double-and-add over r - sign0 = 2^exp2 + sign1 2^exp1 (the same divisor the
-// reference builds as f_{2^exp2} * f_{2^exp1}^{sign1} * line, a_param.c:1155-1179; functions
-// with equal divisors over F_q differ by an F_q^* constant, which the final exponentiation
-// removes).  Doing the single addition in place means no saved V1/f1: the live state is f,
-// V and a few scratch elements; Q sits in LDS (lds_q: [2][N][lanes], limb-major).
-// Returns false when an input deserialises to O (off-curve bytes, ecc/curve.c:609-623).
-template <int N>
-PBC_DEV bool a_miller_lane(fp2<N> &f, const uint8_t *g1, const uint8_t *g2, uint32_t *lds_q,
-                           int lds_stride) {
-  constexpr int NB = 4 * N;
-  fp<N> one;
-  jac<N> V;
-  fp_set<N>(one, fpk<N>().one);
-  bool valid;
-  {
-    fp<N> Qx, Qy;
-    fp_load_be<N>(V.X, g1);
-    fp_load_be<N>(V.Y, g1 + NB);
-    fp_load_be<N>(Qx, g2);
-    fp_load_be<N>(Qy, g2 + NB);
-    valid = a_first_arg_ok<N>(V.X, V.Y) & a_on_curve<N>(Qx, Qy);
-#pragma unroll
-    for (int k = 0; k < N; k++) {
-      lds_q[k * lds_stride] = Qx.v[k];
-      lds_q[(N + k) * lds_stride] = Qy.v[k];
-    }
-  }
-  V.Z = one;
-  V.ZZ = one;
-  f.x = one;
-#pragma unroll
-  for (int k = 0; k < N; k++) f.y.v[k] = 0;
-  for (int i = c_a.exp2 - 1; i >= 0; i--) {
-    fp<N> Qx, Qy;
-#pragma unroll
-    for (int k = 0; k < N; k++) {
-      Qx.v[k] = lds_q[k * lds_stride];
-      Qy.v[k] = lds_q[(N + k) * lds_stride];
-    }
-    a_double_step<N>(f, V, Qx, Qy);
-    if (i == c_a.exp1) {               // the one non-zero middle digit of r: V <- V +- P
-      fp<N> x2, y2;
-      fp_load_be<N>(x2, g1);
-      fp_load_be<N>(y2, g1 + NB);
-      if (c_a.sign1 < 0) fp_neg<N>(y2, y2);
-      a_add_step<N>(f, V, x2, y2, Qx, Qy);
-    }
-  }
-  return valid;
-}
-
 template <int N>
 PBC_DEV void a_store_gt(uint8_t *gt, fp2<N> &out, bool valid) {
   if (!valid) {                        // GT identity (pairing_apply, include/pbc_pairing.h:123-130)
@@ -401,6 +348,7 @@ PBC_DEV bool a_pp_init_lane(uint32_t *tab, const uint8_t *g1) {
   }
   return valid;
 }
+// f <- f * line(Q) for table entry idx (used by the type a1 apply kernel; a.param's runs in limb form, pairing_al.cuh)
 template <int N>
 PBC_DEV void a_pp_line(fp2<N> &f, const uint32_t *tab, int idx, const fp<N> &Qx, const fp<N> &Qy) {
   fp<N> cA, cB, cC;
@@ -416,37 +364,7 @@ PBC_DEV void a_pp_line(fp2<N> &f, const uint32_t *tab, int idx, const fp<N> &Qx,
   fp_mul<N>(l.y, cB, Qy);
   fi_mul<N>(f, f, l);
 }
-// pairing_pp_apply for one lane: 7 F_q products per Miller step instead of 18
-template <int N>
-PBC_DEV void a_pp_apply_lane(uint8_t *gt, const uint32_t *tab, bool p_valid, const uint8_t *g2) {
-  constexpr int NB = 4 * N;
-  fp<N> Qx, Qy;
-  fp2<N> f, out;
-  fp_load_be<N>(Qx, g2);
-  fp_load_be<N>(Qy, g2 + NB);
-  bool valid = p_valid & a_on_curve<N>(Qx, Qy);
-  fp_set<N>(f.x, fpk<N>().one);
-#pragma unroll
-  for (int k = 0; k < N; k++) f.y.v[k] = 0;
-  int slot = 0;
-  for (int i = c_a.exp2 - 1; i >= 0; i--, slot++) {
-    fi_sqr<N>(f, f);
-    a_pp_line<N>(f, tab, slot, Qx, Qy);
-    if (i == c_a.exp1) a_pp_line<N>(f, tab, c_a.exp2, Qx, Qy);
-  }
-  a_final_exp<N>(out, f);
-  a_store_gt<N>(gt, out, valid);
-}
-
-// element_pairing for one lane (a_pairing_proj + a_tateexp, a_param.c:1053-1198, :285-303)
-template <int N>
-PBC_DEV void a_pairing_lane(uint8_t *gt, const uint8_t *g1, const uint8_t *g2, uint32_t *lds_q,
-                            int lds_stride) {
-  fp2<N> f, out;
-  bool valid = a_miller_lane<N>(f, g1, g2, lds_q, lds_stride);
-  a_final_exp<N>(out, f);
-  a_store_gt<N>(gt, out, valid);
-}
+// (element_pairing and pairing_pp_apply for the 512-bit field of a.param run in limb form: pairing_al.cuh)
 
 // element_prod_pairing for one lane: prod_j e(P_j, Q_j) (a_pairings_affine, a_param.c:1283-1383).  As in the
 // reference, ONE accumulator serves all k terms: it is squared once per Miller iteration (:1338-1344,

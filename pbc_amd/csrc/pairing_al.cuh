@@ -1,11 +1,13 @@
 // pairing_al.cuh -- Type A (a.param: 512-bit q, 16 words) with F_q elements kept in 29-bit LIMB form.
 //
-// Same map as pairing_a.cuh's a_pairing_lane (a_pairing_proj + a_tateexp, ecc/a_param.c:1053-1198, :285-303), same
-// Jacobian Miller steps and the same Lucas-sequence final exponentiation -- but an element is L = 18 limbs of 29 bits
+// element_pairing (a_pairing_proj + a_tateexp, ecc/a_param.c:1053-1198, :285-303) and pairing_pp_apply (:317-360) with
+// the Jacobian Miller steps and the Lucas-sequence final exponentiation of pairing_a.cuh (a_double_step, a_add_step,
+// a_final_exp: the word-form routines the other type a kernels use) -- but an element is L = 18 limbs of 29 bits
 // from the moment it is loaded until it is stored.  The word-form kernel converts both operands of every product into
 // limbs and the result back into words with a conditional subtraction: 150 of the 900 instructions of a product
-// (measured by a what-if build: +14 % pairings/s without them, profiles/r02_notes.md).  At two waves per SIMD every
-// VALU instruction costs the same ~4 cycles, so the kernel is bound by its instruction COUNT.
+// (measured by a what-if build: +14 % pairings/s without them, profiles/r02_notes.md).  The multiply-add pipe takes a
+// v_mad_u64_u32 every 4.58 cycles per SIMD and any other VALU instruction ~2.5 (tools/mac_chain_probe.hip); this
+// kernel's 2.15 M multiply-adds + 0.77 M other instructions per pairing run at 92 % of that pipe-time.
 //
 // Redundant representation.  R = 2^522 and q < 2^512, so there are ten bits of slack: a value is any 18 limbs whose
 // sum is congruent to it; a Montgomery product of operands below 16 q comes out below 1.25 q ("P-class": limbs
@@ -18,13 +20,15 @@
 //   * value bound B, in units of q: B(out) = 1 + sum B(x) B(y) / 1024.
 // norm() is a PARALLEL carry pass (3 instructions per limb, no chain): limbs end up <= 2^29 + 6 ("almost normalised").
 // A difference a - b is formed as a + (K - b) limb by limb with K = c q written so that every limb dominates the
-// corresponding limb of b (borrowed form: limb_i(c q) + D 2^29 - D); the host precomputes the four K it needs.
+// corresponding limb of b (borrowed form: limb_i(c q) + D 2^29 - D); the host precomputes the five K it needs.
 //
 // Calling convention of the out-of-line products.  An operand is 18 VGPRs and the ABI passes 31: the first operand
-// travels in registers, the second as 12 registers + 6 words of LDS; the Miller accumulator f and the second pairing
-// coordinates Z, Z^2 of the running point live in LDS for the whole loop (four slots), which takes 72 registers out of
-// the point arithmetic and means that f^2 and f * line take no operands at all; Q sits in the lane's private memory.  LDS per lane: 4 x 18 + 6 words = 312 B -> 39 KB per 128-lane
-// workgroup, four workgroups (two waves per SIMD) per CU.
+// travels in registers, the second as 12 registers + 6 words of LDS.  The Miller accumulator f and the coordinates
+// Z, Z^2 of the running point live in LDS for the whole loop (four slots): 72 registers less in the point arithmetic
+// (a value that lives across a call must sit in one of the ABI's 108 callee-saved VGPRs or be spilled); Q sits in the
+// lane's private memory.  LDS per lane: 4 x 18 + 6 words = 312 B -> 39 KB per 128-lane workgroup, four workgroups
+// (two waves per SIMD) per CU.  Three product bodies in all (product, square, two-term sum against f): the Miller loop's
+// code is 31 KB; variants with fused f^2 / f * line bodies (64 KB per iteration) ran 3 % slower (profiles/r02_notes.md).
 #pragma once
 #include "pairing_a.cuh"
 
@@ -216,26 +220,6 @@ struct AL {
     AL_HS(hs_au = r.hs_u; hs_aB = r.hs_B;)
     return to_v(r);
   }
-  static __device__ __noinline__ vL muls_fn(vL va, int slot) {      // second operand: a resident LDS slot
-    el a, b, r;
-    from_v(a, va);
-    AL_HS(a.hs_u = hs_au; a.hs_B = hs_aB;)
-    lds_get(b, slot);
-    mul_inl<1>(r, a, b);
-    AL_HS(hs_au = r.hs_u; hs_aB = r.hs_B;)
-    return to_v(r);
-  }
-  static __device__ __noinline__ vL mulp_fn(vL va, const PBC_PRIVATE uint32_t *p) {   // second operand: private memory (Q)
-    el a, b, r;
-    from_v(a, va);
-    AL_HS(a.hs_u = hs_au; a.hs_B = hs_aB;)
-#pragma unroll
-    for (int i = 0; i < L; i++) b.l[i] = p[i];
-    AL_HS(hs_set(b, U_STRICT, 1.0);)
-    mul_inl<1>(r, a, b);
-    AL_HS(hs_au = r.hs_u; hs_aB = r.hs_B;)
-    return to_v(r);
-  }
   static __device__ __noinline__ vL sqr_fn(vL va) {
     el a, r;
     from_v(a, va);
@@ -244,39 +228,34 @@ struct AL {
     AL_HS(hs_au = r.hs_u; hs_aB = r.hs_B;)
     return to_v(r);
   }
-  // f <- f^2 in LDS  (fi_square, fieldquadratic.c:459-477: (x + y)(x - y) + 2xy i)
-  static __device__ __noinline__ void fsqr_fn() {
-    el fx, fy, e0, e1, r;
+  // fx p + (+-fy) q with f read from its LDS slots, one reduction
+  static __device__ __noinline__ vL fsop_fn(vL vp, vLo qlo, int neg) {
+    el fx, fy, p, q, r;
+    from_v(p, vp);
+    AL_HS(p.hs_u = hs_au; p.hs_B = hs_aB; q.hs_u = hs_bu; q.hs_B = hs_bB;)
+#pragma unroll
+    for (int i = 0; i < 12; i++) q.l[i] = qlo[i];
+#pragma unroll
+    for (int i = 12; i < L; i++) q.l[i] = lds_hi(i - 12);
     lds_get(fx, SLOT_FX);
     lds_get(fy, SLOT_FY);
-    add(e0, fx, fy);                   // u 2
-    subk(e1, fx, fy, K2);              // u 3, B 3.5
-    norm(e1, e1);
-    mul_inl<1>(r, e0, e1);
-    lds_put(SLOT_FX, r);
-    shl<1>(e0, fx);                    // u 2
-    mul_inl<1>(r, e0, fy);
-    lds_put(SLOT_FY, r);
+    if (neg) {
+      negk(fy, fy, K2);                // u 2, B 2
+      norm(fy, fy);
+    }
+    sop2_inl(r, fx, p, fy, q);
+    AL_HS(hs_au = r.hs_u; hs_aB = r.hs_B;)
+    return to_v(r);
   }
-  // f <- f (lx + i ly) in LDS  (fi_mul, fieldquadratic.c:425-457) as two lazy sums of two products:
-  //     re = fx lx + (-fy) ly,   im = fx ly + fy lx        -- the multiply-adds of Karatsuba's three products, no
-  // additions besides the negation.  lx, ly: normalised, B <= 6.
-  static __device__ __noinline__ void fmul_fn(vL vlx, vLo lylo) {
-    el fx, fy, nfy, lx, ly, re, im;
-    from_v(lx, vlx);
-    AL_HS(lx.hs_u = hs_au; lx.hs_B = hs_aB; ly.hs_u = hs_bu; ly.hs_B = hs_bB;)
+  static PBC_DEV void fsop(el &r, const el &p, const el &q, int neg) {
+    vLo lo;
 #pragma unroll
-    for (int i = 0; i < 12; i++) ly.l[i] = lylo[i];
+    for (int i = 0; i < 12; i++) lo[i] = q.l[i];
 #pragma unroll
-    for (int i = 12; i < L; i++) ly.l[i] = lds_hi(i - 12);
-    lds_get(fx, SLOT_FX);
-    lds_get(fy, SLOT_FY);
-    negk(nfy, fy, K2);                 // u 2, B 2
-    norm(nfy, nfy);
-    sop2_inl(re, fx, lx, nfy, ly);
-    sop2_inl(im, fx, ly, fy, lx);
-    lds_put(SLOT_FX, re);
-    lds_put(SLOT_FY, im);
+    for (int i = 12; i < L; i++) lds_hi(i - 12) = q.l[i];
+    AL_HS(hs_au = p.hs_u; hs_aB = p.hs_B; hs_bu = q.hs_u; hs_bB = q.hs_B;)
+    from_v(r, fsop_fn(to_v(p), lo, neg));
+    AL_HS(r.hs_u = hs_au; r.hs_B = hs_aB;)
   }
 
   static PBC_DEV void mul(el &r, const el &a, const el &b) {
@@ -289,30 +268,52 @@ struct AL {
     from_v(r, mul_fn(to_v(a), lo));
     AL_HS(r.hs_u = hs_au; r.hs_B = hs_aB;)
   }
-  static PBC_DEV void muls(el &r, const el &a, int slot) {
-    AL_HS(hs_au = a.hs_u; hs_aB = a.hs_B;)
-    from_v(r, muls_fn(to_v(a), slot));
-    AL_HS(r.hs_u = hs_au; r.hs_B = hs_aB;)
-  }
-  static PBC_DEV void mulp(el &r, const el &a, const PBC_PRIVATE uint32_t *p) {      // p: canonical limbs (to_limbs output)
-    AL_HS(hs_au = a.hs_u; hs_aB = a.hs_B;)
-    from_v(r, mulp_fn(to_v(a), p));
-    AL_HS(r.hs_u = hs_au; r.hs_B = hs_aB;)
+  static PBC_DEV void muls(el &r, const el &a, int slot) {           // second operand from an LDS slot
+    el b;
+    lds_get(b, slot);
+    mul(r, a, b);
   }
   static PBC_DEV void sqr(el &r, const el &a) {
     AL_HS(hs_au = a.hs_u; hs_aB = a.hs_B;)
     from_v(r, sqr_fn(to_v(a)));
     AL_HS(r.hs_u = hs_au; r.hs_B = hs_aB;)
   }
-  static PBC_DEV void fmul(const el &lx, const el &ly) {
-    vLo lo;
-#pragma unroll
-    for (int i = 0; i < 12; i++) lo[i] = ly.l[i];
-#pragma unroll
-    for (int i = 12; i < L; i++) lds_hi(i - 12) = ly.l[i];
-    AL_HS(hs_au = lx.hs_u; hs_aB = lx.hs_B; hs_bu = ly.hs_u; hs_bB = ly.hs_B;)
-    fmul_fn(to_v(lx), lo);
+  // f <- f^2 in LDS  (fi_square, fieldquadratic.c:459-477: (x + y)(x - y) + 2xy i)
+  static PBC_DEV void fsqr() {
+    el fx, fy, e0, e1, r;
+    lds_get(fx, SLOT_FX);
+    lds_get(fy, SLOT_FY);
+    add(e0, fx, fy);                   // u 2
+    subk(e1, fx, fy, K2);              // u 3, B 3.5
+    norm(e1, e1);
+    mul(r, e0, e1);
+    lds_put(SLOT_FX, r);
+    shl<1>(e0, fx);                    // u 2
+    mul(r, e0, fy);
+    lds_put(SLOT_FY, r);
   }
+  // f <- f (lx + i ly) in LDS  (fi_mul, fieldquadratic.c:425-457) as two lazy sums of two products:
+  //     re = fx lx + (-fy) ly,   im = fx ly + fy lx        -- the multiply-adds of Karatsuba's three products, no
+  // additions besides the negation.  lx, ly: normalised, B <= 6.
+  static PBC_DEV void fmul(const el &lx, const el &ly) {
+    el re, im;
+    fsop(re, lx, ly, 1);
+    fsop(im, ly, lx, 0);
+    lds_put(SLOT_FX, re);
+    lds_put(SLOT_FY, im);
+  }
+
+  // Where the second pairing argument Q = (Qx, Qy) waits: the lane's private memory, canonical limbs.  (A product kernel
+  // on these routines with the per-term state in global memory, as a_prod_pairing_lane keeps it, was measured at
+  // 0.875 M against 0.895 M products/s for the word-form one -- 25 % more workspace traffic -- and is not in the tree.)
+  struct QPriv {
+    const PBC_PRIVATE uint32_t *p;
+    PBC_DEV void get(el &r, int which) const {
+#pragma unroll
+      for (int i = 0; i < L; i++) r.l[i] = p[which * L + i];
+      AL_HS(hs_set(r, U_STRICT, 1.0);)
+    }
+  };
 
   // The point V = (X, Y, Z) of the Miller loop: X, Y in registers (almost normalised, B <= 14), Z and Z^2 in their
   // LDS slots (P-class); Q = (Qx, Qy) in the lane's private memory as 2 x 18 canonical limbs.
@@ -324,9 +325,9 @@ struct AL {
   //     re = M (ZZ Qx + X) - 2 Y^2,  im = (2YZ) ZZ Qy,  M = 3X^2 + Z^4.
   // Where the word-form step trades products for squarings, this one takes products: a squaring of a sum needs the
   // sum normalised first, which costs more than the squaring saves.  9 M + 6 S + 2 two-term sums per step.
-  static PBC_DEV void double_step(jacl &V, const PBC_PRIVATE uint32_t *Q) {
+  static PBC_DEV void double_step(jacl &V, const QPriv &Q) {
     el XX, YY, M, t0, t1, lx, ly, Z3, S1, W;
-    fsqr_fn();
+    fsqr();
     sqr(XX, V.X);
     lds_get(t0, SLOT_ZZ);
     sqr(t0, t0);                       // Z^4
@@ -335,8 +336,8 @@ struct AL {
     add(M, M, t0);                     // u 4, B 5
     norm(M, M);
     sqr(YY, V.Y);
-    lds_get(t0, SLOT_ZZ);
-    mulp(t0, t0, Q);                   // ZZ Qx
+    Q.get(t1, 0);
+    muls(t0, t1, SLOT_ZZ);             // ZZ Qx
     add(t0, t0, V.X);                  // u 2, B 10.5
     mul(lx, M, t0);                    // P
     shl<1>(t1, YY);                    // u 2, B 3
@@ -348,7 +349,8 @@ struct AL {
     lds_put(SLOT_Z, Z3);
     sqr(Z3, Z3);
     lds_put(SLOT_ZZ, Z3);
-    mulp(ly, t1, Q + L);               // im = Z3 ZZ Qy
+    Q.get(Z3, 1);
+    mul(ly, t1, Z3);                   // im = Z3 ZZ Qy
     fmul(lx, ly);
     shl<1>(t1, V.X);                   // u 2
     mul(S1, YY, t1);                   // 2XY^2
@@ -368,7 +370,7 @@ struct AL {
   }
 
   // Mixed addition step (a_add_step, pairing_a.cuh): runs once per pairing, so every difference is normalised at once.
-  static PBC_DEV void add_step(jacl &V, const el &x2, const el &y2, const PBC_PRIVATE uint32_t *Q) {
+  static PBC_DEV void add_step(jacl &V, const el &x2, const el &y2, const QPriv &Q) {
     el H, R, Z3, HH, HHH, t0, t1, lx, ly;
     muls(t0, x2, SLOT_ZZ);
     subk(H, t0, V.X, K16);
@@ -379,15 +381,14 @@ struct AL {
     subk(R, t0, V.Y, K16);
     norm(R, R);                        // B 17.5
     muls(Z3, H, SLOT_Z);
-#pragma unroll
-    for (int i = 0; i < L; i++) t0.l[i] = Q[i];
-    AL_HS(hs_set(t0, U_STRICT, 1.0);)
+    Q.get(t0, 0);
     add(t0, t0, x2);                   // u 2
     mul(lx, R, t0);
     mul(t0, Z3, y2);
     subk(lx, lx, t0, K2);
     norm(lx, lx);                      // B 3.5
-    mulp(ly, Z3, Q + L);
+    Q.get(t0, 1);
+    mul(ly, Z3, t0);
     sqr(HH, H);
     mul(HHH, HH, H);
     mul(t0, V.X, HH);                  // X1 H^2
@@ -492,6 +493,67 @@ struct AL {
     fp_halve<N>(out.x, x);
   }
 
+  // wave-uniform words (the table of a preprocessed first argument) -> limbs, written with plain shifts so that the
+  // conversion stays on the scalar unit
+  static PBC_DEV void to_el_uniform(el &r, const uint32_t *w) {
+#pragma unroll
+    for (int i = 0; i < L; i++) {
+      const int bit = 29 * i, j = bit >> 5, sh = bit & 31;
+      const uint64_t pair = ((uint64_t) (j + 1 < N ? w[j + 1] : 0u) << 32) | w[j];
+      r.l[i] = (uint32_t) (pair >> sh) & MASK;
+    }
+    AL_HS(hs_set(r, U_STRICT, 1.0);)
+  }
+  // f <- f * ((cA Qx + cC) + i cB Qy) for table entry idx (a_pairing_pp_apply's step, ecc/a_param.c:317-360)
+  static PBC_DEV void pp_line(const uint32_t *tab, int idx, const QPriv &Q) {
+    el c, lx, ly, q;
+    to_el_uniform(c, tab + (idx * 3 + 0) * N);
+    Q.get(q, 0);
+    mul(lx, c, q);
+    to_el_uniform(c, tab + (idx * 3 + 2) * N);
+    add(lx, lx, c);                    // u 2, B 2.5
+    norm(lx, lx);
+    to_el_uniform(c, tab + (idx * 3 + 1) * N);
+    Q.get(q, 1);
+    mul(ly, c, q);
+    fmul(lx, ly);
+  }
+  // pairing_pp_apply for one lane (the table is the word-form one a_pp_init_lane writes, pairing_a.cuh)
+  static PBC_DEV void pp_apply_lane(uint8_t *gt, const uint32_t *tab, bool p_valid, const uint8_t *g2) {
+    constexpr int NB = 4 * N;
+    uint32_t Qm[2 * L];
+    bool valid;
+    {
+      fp<N> Qx, Qy;
+      el q;
+      fp_load_be<N>(Qx, g2);
+      fp_load_be<N>(Qy, g2 + NB);
+      valid = p_valid & a_on_curve<N>(Qx, Qy);
+      to_el(q, Qx);
+#pragma unroll
+      for (int i = 0; i < L; i++) Qm[i] = q.l[i];
+      to_el(q, Qy);
+#pragma unroll
+      for (int i = 0; i < L; i++) Qm[L + i] = q.l[i];
+      fp_set<N>(Qx, fpk<N>().one);
+      to_el(q, Qx);
+      lds_put(SLOT_FX, q);
+#pragma unroll
+      for (int i = 0; i < L; i++) q.l[i] = 0;
+      lds_put(SLOT_FY, q);
+    }
+    const QPriv Q = {(const PBC_PRIVATE uint32_t *) Qm};
+    int slot = 0;
+    for (int i = c_a.exp2 - 1; i >= 0; i--, slot++) {
+      fsqr();
+      pp_line(tab, slot, Q);
+      if (i == c_a.exp1) pp_line(tab, c_a.exp2, Q);
+    }
+    fp2<N> out;
+    final_exp(out);
+    a_store_gt<N>(gt, out, valid);
+  }
+
   // element_pairing for one lane
   static PBC_DEV void pairing_lane(uint8_t *gt, const uint8_t *g1, const uint8_t *g2) {
     constexpr int NB = 4 * N;
@@ -515,7 +577,7 @@ struct AL {
 #pragma unroll
       for (int i = 0; i < L; i++) Qm[L + i] = q.l[i];
     }
-    const PBC_PRIVATE uint32_t *Q = (const PBC_PRIVATE uint32_t *) Qm;
+    const QPriv Q = {(const PBC_PRIVATE uint32_t *) Qm};
     to_el(x2, Px);
     to_el(y2, Py);
     {

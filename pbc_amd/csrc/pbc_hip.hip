@@ -63,33 +63,13 @@ static_assert(kBlock == D_LANES, "pairing_d.cuh sizes its LDS state for 128-lane
 #ifndef PBC_DF_WAVES
 #define PBC_DF_WAVES 2
 #endif
-#ifndef PBC_A_SINGLE_KERNEL
-#define PBC_A_SINGLE_KERNEL al_pairing_kernel     // a_pairing_kernel: the word-form kernel of round 1
-#endif
 #ifndef PBC_A_WAVES
 #define PBC_A_WAVES 2     // waves per SIMD the pairing kernels are register-budgeted for (measured: 1 -> 2 = +32 %)
 #endif
 
 // One Type-A pairing per lane.  g1/g2/gt are AoS in wire format (128 B each for a.param);
 // per-lane 16-byte loads of a 128-byte record: every byte of every fetched line is used.
-template <int N>
-__global__ void __launch_bounds__(kBlock, PBC_A_WAVES) a_pairing_kernel(uint8_t *gt, const uint8_t *g1,
-                                                            const uint8_t *g2, size_t n, KArgs<N> ka) {
-  size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
-  size_t ld = idx < n ? idx : n - 1;          // tail lanes recompute the last unit, no store
-  constexpr int L = 8 * N;
-  __attribute__((aligned(16))) uint8_t out[L];
-  __shared__ uint32_t lds_q[2 * N * kBlock];   // Q of every lane, limb-major: conflict-free
-  a_pairing_lane<N>(out, g1 + ld * L, g2 + ld * L, lds_q + threadIdx.x, kBlock);
-  if (idx < n) {
-    uint4 *dst = reinterpret_cast<uint4 *>(gt + idx * L);
-    const uint4 *src = reinterpret_cast<const uint4 *>(out);
-#pragma unroll
-    for (int i = 0; i < L / 16; i++) dst[i] = src[i];
-  }
-}
-
-// The same for the 512-bit field of a.param with elements in limb form throughout (pairing_al.cuh)
+// F_q elements are in limb form throughout (pairing_al.cuh).
 template <int N>
 __global__ void __launch_bounds__(kBlock, PBC_A_WAVES) al_pairing_kernel(uint8_t *gt, const uint8_t *g1,
                                                              const uint8_t *g2, size_t n, KArgs<N> ka) {
@@ -179,14 +159,14 @@ __global__ void a_pp_init_kernel(uint32_t *tab, uint32_t *valid, const uint8_t *
 }
 // pairing_pp_apply over a batch of second arguments, one per lane; the table is uniform data.
 template <int N>
-__global__ void __launch_bounds__(kBlock, PBC_A_WAVES) a_pp_apply_kernel(uint8_t *gt, const uint32_t *__restrict__ tab,
-                                                                          const uint32_t *__restrict__ valid,
-                                                                          const uint8_t *g2, size_t n, KArgs<N> ka) {
+__global__ void __launch_bounds__(kBlock, PBC_A_WAVES) al_pp_apply_kernel(uint8_t *gt, const uint32_t *__restrict__ tab,
+                                                                           const uint32_t *__restrict__ valid,
+                                                                           const uint8_t *g2, size_t n, KArgs<N> ka) {
   size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
   size_t ld = idx < n ? idx : n - 1;
   constexpr int L = 8 * N;
   __attribute__((aligned(16))) uint8_t out[L];
-  a_pp_apply_lane<N>(out, tab, *valid != 0, g2 + ld * L);
+  AL<N>::pp_apply_lane(out, tab, *valid != 0, g2 + ld * L);
   if (idx < n) {
     uint4 *dst = reinterpret_cast<uint4 *>(gt + idx * L);
     const uint4 *src = reinterpret_cast<const uint4 *>(out);
@@ -859,7 +839,7 @@ static int launch_pairing(pbc_hip_pairing_s *P, void *d_gt, const void *d_g1, co
   if (upload && ensure_derived(P, s)) return 1;
   unsigned grid = (unsigned) ((n + kBlock - 1) / kBlock);
   if (P->type == 'a' && !P->a_generic) {
-    hipLaunchKernelGGL(PBC_A_SINGLE_KERNEL<16>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
+    hipLaunchKernelGGL(al_pairing_kernel<16>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
                        (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, kargs<16>(P));
   } else if ((P->type == 'a' || P->type == '1') && P->nlimb == 16) {   // other sizes: the bit-by-bit kernels
     hipLaunchKernelGGL(a1_prod_pairing_kernel<16>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
@@ -1391,7 +1371,7 @@ extern "C" int pbc_hip_pairing_pp_apply_batch_dev(pbc_hip_pp_t *pp, void *d_gt, 
   if (ensure_derived(P, s)) return 1;
   unsigned grid = (unsigned) ((n + kBlock - 1) / kBlock);
   if (pp->P->type == 'a' && !pp->P->a_generic) {
-    hipLaunchKernelGGL(a_pp_apply_kernel<16>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt, pp->tab, pp->valid,
+    hipLaunchKernelGGL(al_pp_apply_kernel<16>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt, pp->tab, pp->valid,
                        (const uint8_t *) d_g2, n, kargs<16>(P));
   } else if (pp->P->nlimb == 16 && (pp->P->type == 'a' || pp->P->type == '1')) {
     hipLaunchKernelGGL(a1_pp_apply_kernel<16>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt, pp->tab, pp->valid,

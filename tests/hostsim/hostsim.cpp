@@ -6,8 +6,6 @@
 #include "../../pbc_amd/csrc/host_params.h"
 #include "../../pbc_amd/csrc/pairing_al.cuh"
 
-static int g_word_form_a = 0;     // 1: single type a pairings through the word-form lane (a_pairing_lane) instead of the limb-form one
-
 // run EXPR with N = the compile-time word count matching P->nlimb
 #define HS_DISPATCH(nl, ...)                          \
   switch (nl) {                                       \
@@ -79,7 +77,6 @@ void *hostsim_init(const char *param, size_t len) {
   return P;
 }
 const char *hostsim_error() { return g_err; }
-void hostsim_word_form_a(int on) { g_word_form_a = on; }
 // multiply-adds executed by the kernel source since the last reset (PBC_COUNT_MACS hooks of fp.cuh)
 uint64_t hostsim_macs_read(int reset) { uint64_t v = hostsim_macs; if (reset) hostsim_macs = 0; return v; }
 int hostsim_lens(void *h, int *l1, int *l2, int *lt) {
@@ -95,8 +92,7 @@ int hostsim_prod_pairing(void *h, uint8_t *gt, const uint8_t *g1, const uint8_t 
   for (size_t u = 0; u < n; u++) {
     const uint8_t *a = g1 + u * k * P->len1, *b = g2 + u * k * P->len2;
     uint8_t *o = gt + u * P->lenT;
-    if (P->type == 'a' && !P->a_generic && k == 1 && !g_word_form_a) AL<16>::pairing_lane(o, a, b);     // as launch_pairing does
-    else if (P->type == 'a' && !P->a_generic && k == 1) { static uint32_t lq[2 * 16]; a_pairing_lane<16>(o, a, b, lq, 1); }
+    if (P->type == 'a' && !P->a_generic && k == 1) AL<16>::pairing_lane(o, a, b);     // as launch_pairing does
     else if (P->type == 'a' && !P->a_generic) { std::vector<uint4> ws((size_t) k * 24 * 128); a_prod_pairing_lane<16>(o, a, b, k, ws.data(), lds, 1); }
     else if ((P->type == 'a' || P->type == '1') && P->nlimb == 16) a1_prod_pairing_lane<16>(o, a, b, k, lds, 1);
     else if (P->type == '1' || P->type == 'a') a1_prod_pairing_lane<33>(o, a, b, k, lds, 1);
@@ -133,7 +129,7 @@ int hostsim_pp(void *h, uint8_t *gt, const uint8_t *g1, const uint8_t *g2, size_
   }
   if (P->type != 'a') return 1;
   bool v = a_pp_init_lane<16>(tab, g1);
-  for (size_t u = 0; u < n; u++) a_pp_apply_lane<16>(gt + u * P->lenT, tab, v, g2 + u * P->len2);
+  for (size_t u = 0; u < n; u++) AL<16>::pp_apply_lane(gt + u * P->lenT, tab, v, g2 + u * P->len2);
   return 0;
 }
 // compressed / x-only points on G1: dir 0 compress, 1 decompress, 2 to x-only, 3 from x-only

@@ -15,7 +15,7 @@ for f in glob.glob(EV + "/bench_*.json"):
         shutil.copy(f, "profiles/r02_" + os.path.basename(f))
 if os.path.exists(EV + "/probe.txt"):
     shutil.copy(EV + "/probe.txt", "profiles/r02_probe.txt")
-MAIN = {"a": "a_pairing_kernel", "d": "d_prod_pairing_kernel", "f": "f_prod_pairing_kernel", "a-prod16": "a_prod_pairing_kernel"}
+MAIN = {"a": "al_pairing_kernel", "d": "d_prod_pairing_kernel", "f": "f_prod_pairing_kernel", "a-prod16": "a_prod_pairing_kernel"}
 for w, kern in MAIN.items():
     ks = glob.glob("%s/kt_%s/**/*kernel_stats.csv" % (EV, w), recursive=True)
     if ks:

@@ -77,6 +77,39 @@ void *hostsim_init(const char *param, size_t len) {
   return P;
 }
 const char *hostsim_error() { return g_err; }
+// The subtraction constants of the limb-form type a kernel (AConst::ksub, filled by host_params.h): returns the number of
+// violations of  sum_i k_i 2^(29 i) == c q,  k_i >= D (2^29 - 1) for i < 17,  k_i < 2^32,  k_17 >= floor((c - 0.001) q / 2^493).
+int hostsim_check_ksub(void *h) {
+  using pbc_host::Big;
+  pbc_hip_pairing_s *P = (pbc_hip_pairing_s *) h;
+  if (P->type != 'a' || P->a_generic) return -1;
+  static const uint32_t cd[5][2] = {{2, 1}, {4, 2}, {8, 4}, {12, 2}, {16, 2}};
+  Big q;
+  q.w.assign(P->k16.p, P->k16.p + 16);
+  q.trim();
+  int bad = 0;
+  for (int t = 0; t < 5; t++) {
+    Big sum, c;
+    c.w.push_back(cd[t][0]);
+    for (int i = 17; i >= 0; i--) {
+      for (int b = 0; b < 29; b++) sum.shl1();
+      Big k;
+      k.w.push_back(P->a.ksub[t][i]);
+      k.trim();
+      sum = Big::add(sum, k);
+      if (i < 17 && (uint64_t) P->a.ksub[t][i] < (uint64_t) cd[t][1] * ((1u << 29) - 1)) bad++;
+    }
+    if (Big::cmp(sum, Big::mul(q, c)) != 0) bad++;
+    // top limb: at least that of (c - 1/1024) q, so that every subtrahend below (c - 0.001) q is dominated
+    Big lim = Big::mul(q, c), m1024, rem;
+    m1024.w.push_back(1024);
+    lim.sub(Big::div(q, m1024, &rem));
+    uint32_t top = 0;
+    for (int b = 0; b < 29; b++) top |= (uint32_t) lim.bit(29 * 17 + b) << b;
+    if (P->a.ksub[t][17] < top) bad++;
+  }
+  return bad;
+}
 // multiply-adds executed by the kernel source since the last reset (PBC_COUNT_MACS hooks of fp.cuh)
 uint64_t hostsim_macs_read(int reset) { uint64_t v = hostsim_macs; if (reset) hostsim_macs = 0; return v; }
 int hostsim_lens(void *h, int *l1, int *l2, int *lt) {

@@ -2,6 +2,8 @@
 (tests/hostsim: same limb arithmetic, towers, Miller loops and final exponentiations as the
 HIP kernels, one lane at a time) against the reference's golden vectors.  This is a debug
 mirror for GPU-less bring-up, not a product path: libpbc_hip.so never contains it."""
+import ctypes
+
 import numpy as np
 import pytest
 
@@ -321,3 +323,12 @@ def test_twist_hashing_and_compression_on_fresh_digests_vs_oracle(sims, oracles,
     c = S.g2_points(1, pts)
     assert np.array_equal(c, O.point_format_g2(0, pts))
     assert np.array_equal(S.g2_points(2, c), pts)
+
+
+def test_limb_form_type_a_subtraction_constants(sims):
+    """pairing_al.cuh forms a - b as a + (K - b) limb by limb: the host-built K must be multiples of q whose limbs
+    dominate every subtrahend the kernel pairs them with (AConst::ksub).  The kernel's own bound tracker -- worst-case
+    limb sizes and values, asserted at every operation of the host mirror -- runs inside every type a test above."""
+    S = sims("a")
+    S.L.hostsim_check_ksub.argtypes = [ctypes.c_void_p]
+    assert S.L.hostsim_check_ksub(S.h) == 0

@@ -329,6 +329,6 @@ def test_limb_form_type_a_subtraction_constants(sims):
     """pairing_al.cuh forms a - b as a + (K - b) limb by limb: the host-built K must be multiples of q whose limbs
     dominate every subtrahend the kernel pairs them with (AConst::ksub).  The kernel's own bound tracker -- worst-case
     limb sizes and values, asserted at every operation of the host mirror -- runs inside every type a test above."""
-    S = sims("a")
+    S = sims["a"]
     S.L.hostsim_check_ksub.argtypes = [ctypes.c_void_p]
     assert S.L.hostsim_check_ksub(S.h) == 0

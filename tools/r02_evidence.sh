@@ -8,6 +8,7 @@ for w in d f a-prod16 d-prod16 a-pp d-pp g e a1 f256 d190 d201 d224; do
   timeout 400 python bench.py --workload $w --steps 3 --warmup 1 > $O/bench_$w.json 2> $O/bench_$w.err
 done
 timeout 300 python tools/probe.py > $O/probe.txt 2>&1
+(hipcc --offload-arch=gfx950 -O2 tools/mac_chain_probe.hip -o /tmp/mac_chain 2>/dev/null && timeout 120 /tmp/mac_chain) > $O/mac_chain.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
 for w in a d f a-prod16; do
   B="python $R/bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline --no-host-path"

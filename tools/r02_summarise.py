@@ -15,6 +15,8 @@ for f in glob.glob(EV + "/bench_*.json"):
         shutil.copy(f, "profiles/r02_" + os.path.basename(f))
 if os.path.exists(EV + "/probe.txt"):
     shutil.copy(EV + "/probe.txt", "profiles/r02_probe.txt")
+if os.path.exists(EV + "/mac_chain.txt"):
+    shutil.copy(EV + "/mac_chain.txt", "profiles/r02_mac_chain_probe.txt")
 MAIN = {"a": "al_pairing_kernel", "d": "d_prod_pairing_kernel", "f": "f_prod_pairing_kernel", "a-prod16": "a_prod_pairing_kernel"}
 for w, kern in MAIN.items():
     ks = glob.glob("%s/kt_%s/**/*kernel_stats.csv" % (EV, w), recursive=True)
@@ -32,6 +34,7 @@ for w, kern in MAIN.items():
             if kern in r["Kernel_Name"]:
                 agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
         for k, v in agg.items():
+            v = [x for x in v if x >= 0.5 * max(v)]       # the timed full-size launches, not bench.py's small gate launches
             out[k] = {"launches": len(v), "avg_per_launch": sum(v) / len(v)}
     if out:
         json.dump(out, open("profiles/r02_pmc_%s.json" % w, "w"), indent=1, sort_keys=True)

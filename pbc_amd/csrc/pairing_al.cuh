@@ -306,8 +306,10 @@ struct AL {
   // Where the second pairing argument Q = (Qx, Qy) waits: the lane's private memory, canonical limbs.  (A product kernel
   // on these routines with the per-term state in global memory, as a_prod_pairing_lane keeps it, was measured at
   // 0.875 M against 0.895 M products/s for the word-form one -- 25 % more workspace traffic -- and is not in the tree.)
+  // (volatile: the compiler would otherwise hoist these loop-invariant loads out of the Miller loop into 36 registers
+  // and spill those -- 170 scratch reloads per step instead of 36 reads)
   struct QPriv {
-    const PBC_PRIVATE uint32_t *p;
+    const volatile PBC_PRIVATE uint32_t *p;
     PBC_DEV void get(el &r, int which) const {
 #pragma unroll
       for (int i = 0; i < L; i++) r.l[i] = p[which * L + i];
@@ -505,49 +507,43 @@ struct AL {
     AL_HS(hs_set(r, U_STRICT, 1.0);)
   }
   // f <- f * ((cA Qx + cC) + i cB Qy) for table entry idx (a_pairing_pp_apply's step, ecc/a_param.c:317-360)
-  static PBC_DEV void pp_line(const uint32_t *tab, int idx, const QPriv &Q) {
-    el c, lx, ly, q;
+  static PBC_DEV void pp_line(const uint32_t *tab, int idx, const el &Qx, const el &Qy) {
+    el c, lx, ly;
     to_el_uniform(c, tab + (idx * 3 + 0) * N);
-    Q.get(q, 0);
-    mul(lx, c, q);
+    mul(lx, Qx, c);
     to_el_uniform(c, tab + (idx * 3 + 2) * N);
     add(lx, lx, c);                    // u 2, B 2.5
     norm(lx, lx);
     to_el_uniform(c, tab + (idx * 3 + 1) * N);
-    Q.get(q, 1);
-    mul(ly, c, q);
+    mul(ly, Qy, c);
     fmul(lx, ly);
   }
-  // pairing_pp_apply for one lane (the table is the word-form one a_pp_init_lane writes, pairing_a.cuh)
+  // pairing_pp_apply for one lane (the table is the word-form one a_pp_init_lane writes, pairing_a.cuh).  Q stays in
+  // registers here: nothing else competes for them.
   static PBC_DEV void pp_apply_lane(uint8_t *gt, const uint32_t *tab, bool p_valid, const uint8_t *g2) {
     constexpr int NB = 4 * N;
-    uint32_t Qm[2 * L];
+    el Qx, Qy;
     bool valid;
     {
-      fp<N> Qx, Qy;
+      fp<N> x, y;
       el q;
-      fp_load_be<N>(Qx, g2);
-      fp_load_be<N>(Qy, g2 + NB);
-      valid = p_valid & a_on_curve<N>(Qx, Qy);
-      to_el(q, Qx);
-#pragma unroll
-      for (int i = 0; i < L; i++) Qm[i] = q.l[i];
-      to_el(q, Qy);
-#pragma unroll
-      for (int i = 0; i < L; i++) Qm[L + i] = q.l[i];
-      fp_set<N>(Qx, fpk<N>().one);
-      to_el(q, Qx);
+      fp_load_be<N>(x, g2);
+      fp_load_be<N>(y, g2 + NB);
+      valid = p_valid & a_on_curve<N>(x, y);
+      to_el(Qx, x);
+      to_el(Qy, y);
+      fp_set<N>(x, fpk<N>().one);
+      to_el(q, x);
       lds_put(SLOT_FX, q);
 #pragma unroll
       for (int i = 0; i < L; i++) q.l[i] = 0;
       lds_put(SLOT_FY, q);
     }
-    const QPriv Q = {(const PBC_PRIVATE uint32_t *) Qm};
     int slot = 0;
     for (int i = c_a.exp2 - 1; i >= 0; i--, slot++) {
       fsqr();
-      pp_line(tab, slot, Q);
-      if (i == c_a.exp1) pp_line(tab, c_a.exp2, Q);
+      pp_line(tab, slot, Qx, Qy);
+      if (i == c_a.exp1) pp_line(tab, c_a.exp2, Qx, Qy);
     }
     fp2<N> out;
     final_exp(out);
@@ -557,13 +553,11 @@ struct AL {
   // element_pairing for one lane
   static PBC_DEV void pairing_lane(uint8_t *gt, const uint8_t *g1, const uint8_t *g2) {
     constexpr int NB = 4 * N;
-    fp<N> Px, Py;
-    el x2, y2;
     jacl V;
     uint32_t Qm[2 * L];                // Q in private memory: read twice per step, by address
     bool valid;
     {
-      fp<N> Qx, Qy;
+      fp<N> Px, Py, Qx, Qy;
       el q;
       fp_load_be<N>(Px, g1);
       fp_load_be<N>(Py, g1 + NB);
@@ -576,33 +570,32 @@ struct AL {
       to_el(q, Qy);
 #pragma unroll
       for (int i = 0; i < L; i++) Qm[L + i] = q.l[i];
-    }
-    const QPriv Q = {(const PBC_PRIVATE uint32_t *) Qm};
-    to_el(x2, Px);
-    to_el(y2, Py);
-    {
-      fp<N> one;
-      el o;
-      fp_set<N>(one, fpk<N>().one);
-      to_el(o, one);
-      V.X = x2;
-      V.Y = y2;
-      lds_put(SLOT_Z, o);
-      lds_put(SLOT_ZZ, o);
-      lds_put(SLOT_FX, o);
+      to_el(V.X, Px);
+      to_el(V.Y, Py);
+      fp_set<N>(Px, fpk<N>().one);
+      to_el(q, Px);
+      lds_put(SLOT_Z, q);
+      lds_put(SLOT_ZZ, q);
+      lds_put(SLOT_FX, q);
 #pragma unroll
-      for (int i = 0; i < L; i++) o.l[i] = 0;
-      lds_put(SLOT_FY, o);
+      for (int i = 0; i < L; i++) q.l[i] = 0;
+      lds_put(SLOT_FY, q);
     }
+    const QPriv Q = {(const volatile PBC_PRIVATE uint32_t *) Qm};
     for (int i = c_a.exp2 - 1; i >= 0; i--) {
       double_step(V, Q);
       if (i == c_a.exp1) {             // the one non-zero middle digit of r: V <- V +- P
-        el ys = y2;
+        fp<N> Px, Py;                  // (P is read again here rather than kept in 36 registers across the loop)
+        el x2, y2;
+        fp_load_be<N>(Px, g1);
+        fp_load_be<N>(Py, g1 + NB);
+        to_el(x2, Px);
+        to_el(y2, Py);
         if (c_a.sign1 < 0) {
-          negk(ys, y2, K2);
-          norm(ys, ys);
+          negk(y2, y2, K2);
+          norm(y2, y2);
         }
-        add_step(V, x2, ys, Q);
+        add_step(V, x2, y2, Q);
       }
     }
     fp2<N> out;

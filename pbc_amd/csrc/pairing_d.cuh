@@ -441,6 +441,150 @@ static __device__ __noinline__ v32 d_add_line_fn(int neg) {
   d_add_core(la, lb, lc, neg != 0);
   return d_evalfn_pack(la, lb, lc);
 }
+// ---- fused F_q^k bodies for the Miller loop (d = 3 on the 5-word fields: d159.param) ------------------------------
+// f6_mul / f6_sqr above are Karatsuba over three (two) out-of-line F_q^3 products, each of which converts its operands
+// into limbs and its result back into words, with word-form additions in between: of the ~3500 instructions of an
+// F_q^6 product about 800 are conversions and additions.  Here the whole F_q^6 operation is ONE body on limb forms:
+//     (ax + ay s)(bx + by s) = (ax bx + (v ay) by) + (ax by + ay bx) s,      s^2 = v,
+// every output coefficient a single lazy sum (up to 8 of the 9 product units a column holds) over BOTH polynomial
+// products, reduced once: 51 limb products + 13 reductions against Karatsuba's 48 + 18, and no additions at all.
+// The accumulator travels in registers (30 words in, 30 out); the line functions multiply their value into it directly,
+// so the line value never exists in word form.
+static constexpr bool kFusedF6 = DEG == 3 && 2 * DEG * ND <= 30;
+typedef uint32_t f6vec __attribute__((ext_vector_type(2 * DEG * ND)));
+struct f6l { fl<ND> x[DEG], y[DEG]; };
+static PBC_DEV f6vec f6_pack(const f6 &a) {
+  f6vec r;
+#pragma unroll
+  for (int i = 0; i < DEG; i++)
+#pragma unroll
+    for (int k = 0; k < ND; k++) { r[ND * i + k] = a.x.c[i].v[k]; r[DEG * ND + ND * i + k] = a.y.c[i].v[k]; }
+  return r;
+}
+static PBC_DEV void f6_unpack(f6 &a, f6vec r) {
+#pragma unroll
+  for (int i = 0; i < DEG; i++)
+#pragma unroll
+    for (int k = 0; k < ND; k++) { a.x.c[i].v[k] = r[ND * i + k]; a.y.c[i].v[k] = r[DEG * ND + ND * i + k]; }
+}
+static PBC_DEV void f6_to_limbs(f6l &r, const f6 &a) {
+#pragma unroll
+  for (int i = 0; i < DEG; i++) { to_limbs<ND>(r.x[i], a.x.c[i]); to_limbs<ND>(r.y[i], a.y.c[i]); }
+}
+static PBC_DEV void f6_from_limbs(f6 &r, const f6l &a) {
+#pragma unroll
+  for (int i = 0; i < DEG; i++) { from_limbs<ND>(r.x.c[i], a.x[i]); from_limbs<ND>(r.y.c[i], a.y[i]); }
+}
+// coefficient S of A1 B1 + A2 B2 (plain polynomial products), plus the table terms for S < d.  DBL: how many of the
+// operand pairs carry a doubled operand (limbs < 2^30: two units each)
+template <int S, bool TABLE, int DBL>
+static PBC_DEV void mul2_coeff(fl<ND> &out, const fl<ND> *A1, const fl<ND> *B1, const fl<ND> *A2, const fl<ND> *B2, const fl<ND> *H) {
+  constexpr int lo = S - (DEG - 1) > 0 ? S - (DEG - 1) : 0, hi = S < DEG - 1 ? S : DEG - 1;
+  constexpr int NDIR = hi - lo + 1, T = 2 * NDIR + (TABLE ? DEG - 1 : 0);
+  fl<ND> x[T], y[T];
+#pragma unroll
+  for (int i = lo; i <= hi; i++) {
+    x[2 * (i - lo)] = A1[i]; y[2 * (i - lo)] = B1[S - i];
+    x[2 * (i - lo) + 1] = A2[i]; y[2 * (i - lo) + 1] = B2[S - i];
+  }
+  if constexpr (TABLE) {
+#pragma unroll
+    for (int t = 0; t < DEG - 1; t++) { x[2 * NDIR + t] = H[t]; y[2 * NDIR + t] = xpwr_limbs(t, S); }
+  }
+  sop_limbs<ND, T, DBL>(out, x, y);
+}
+// r = A1 B1 + A2 B2 in F_q^3 (limb forms in, P-class limb forms out).  DBL1: B1's coefficient 0 may be a sum of two.
+template <bool DBL1>
+static PBC_DEV void f3l_mul2(fl<ND> *r, const fl<ND> *A1, const fl<ND> *B1, const fl<ND> *A2, const fl<ND> *B2) {
+  static_assert(DEG == 3, "written out for d = 3");
+  fl<ND> H[2];
+  mul2_coeff<3, false, 0>(H[0], A1, B1, A2, B2, H);
+  mul2_coeff<4, false, 0>(H[1], A1, B1, A2, B2, H);
+  mul2_coeff<0, true, DBL1 ? 1 : 0>(r[0], A1, B1, A2, B2, H);
+  mul2_coeff<1, true, DBL1 ? 1 : 0>(r[1], A1, B1, A2, B2, H);
+  mul2_coeff<2, true, DBL1 ? 1 : 0>(r[2], A1, B1, A2, B2, H);
+}
+static PBC_DEV void f3l_mul_v(fl<ND> *r, const fl<ND> *a) {
+  fl<ND> V;
+#pragma unroll
+  for (int l = 0; l < Limbs29<ND>::L; l++) V.l[l] = c_d.nqr29[l];
+#pragma unroll
+  for (int i = 0; i < DEG; i++) {
+    const fl<ND> x[1] = {a[i]}, y[1] = {V};
+    sop_limbs<ND, 1>(r[i], x, y);
+  }
+}
+// r = a b.  BX0_DBL: b.x[0] is a sum of two normalised values (the "+ c" of a line value)
+template <bool BX0_DBL>
+static PBC_DEV void f6l_mul(f6l &r, const f6l &a, const f6l &b) {
+  fl<ND> vay[DEG];
+  f3l_mul_v(vay, a.y);
+  f3l_mul2<BX0_DBL>(r.x, a.x, b.x, vay, b.y);
+  // (ay bx + ax by: the possibly doubled b.x[0] must be the B1 operand)
+  f3l_mul2<BX0_DBL>(r.y, a.y, b.x, a.x, b.y);
+}
+// r = a^2 = (ax^2 + (v ay) ay) + (2 ax) ay s: the two squares as products of a with itself (the cross terms are not
+// folded: 4 more limb products per coefficient pair, no doubled operands to account for)
+static PBC_DEV void f6l_sqr(f6l &r, const f6l &a) {
+  fl<ND> vay[DEG], ax2[DEG];
+  f3l_mul_v(vay, a.y);
+  f3l_mul2<false>(r.x, a.x, a.x, vay, a.y);
+#pragma unroll
+  for (int i = 0; i < DEG; i++) limbs_dbl<ND>(ax2[i], a.x[i]);
+  {                                              // (2 ax) ay: one polynomial product with a doubled operand
+    fl<ND> H[2];
+    static_assert(DEG == 3, "written out for d = 3");
+    { const fl<ND> x[2] = {ax2[1], ax2[2]}, y[2] = {a.y[2], a.y[1]}; sop_limbs<ND, 2, 2>(H[0], x, y); }
+    { const fl<ND> x[1] = {ax2[2]}, y[1] = {a.y[2]}; sop_limbs<ND, 1, 1>(H[1], x, y); }
+    { const fl<ND> x[3] = {ax2[0], H[0], H[1]}, y[3] = {a.y[0], xpwr_limbs(0, 0), xpwr_limbs(1, 0)}; sop_limbs<ND, 3, 1>(r.y[0], x, y); }
+    { const fl<ND> x[4] = {ax2[0], ax2[1], H[0], H[1]}, y[4] = {a.y[1], a.y[0], xpwr_limbs(0, 1), xpwr_limbs(1, 1)}; sop_limbs<ND, 4, 2>(r.y[1], x, y); }
+    { const fl<ND> x[5] = {ax2[0], ax2[1], ax2[2], H[0], H[1]}, y[5] = {a.y[2], a.y[1], a.y[0], xpwr_limbs(0, 2), xpwr_limbs(1, 2)}; sop_limbs<ND, 5, 3>(r.y[2], x, y); }
+  }
+}
+static __device__ __noinline__ f6vec f6_sqr_fused_fn(f6vec vv) {
+  f6 v;
+  f6l a, r;
+  f6_unpack(v, vv);
+  f6_to_limbs(a, v);
+  f6l_sqr(r, a);
+  f6_from_limbs(v, r);
+  return f6_pack(v);
+}
+// v * l(Q) for the line a' x + b' y + c' (d_miller_evalfn): l = (a' Qx + c') + (b' Qy) s, formed in limb form
+static PBC_DEV f6vec d_line_mul(f6vec vv, const fq &la, const fq &lb, const fq &lc) {
+  f6 v;
+  f6l a, l, r;
+  f6_unpack(v, vv);
+  f6_to_limbs(a, v);
+  fl<ND> La, Lb, Lc;
+  to_limbs<ND>(La, la);
+  to_limbs<ND>(Lb, lb);
+  to_limbs<ND>(Lc, lc);
+#pragma unroll
+  for (int i = 0; i < DEG; i++) {
+    fl<ND> q;
+    to_limbs<ND>(q, dl_get(DL_QX + ND * i));
+    { const fl<ND> x[1] = {q}, y[1] = {La}; sop_limbs<ND, 1>(l.x[i], x, y); }
+    to_limbs<ND>(q, dl_get(DL_QY + ND * i));
+    { const fl<ND> x[1] = {q}, y[1] = {Lb}; sop_limbs<ND, 1>(l.y[i], x, y); }
+  }
+#pragma unroll
+  for (int k = 0; k < Limbs29<ND>::L; k++) l.x[0].l[k] += Lc.l[k];     // limbs < 2^30: the doubled operand of f6l_mul<true>
+  f6l_mul<true>(r, a, l);
+  f6_from_limbs(v, r);
+  return f6_pack(v);
+}
+static __device__ __noinline__ f6vec d_dbl_line_mul_fn(f6vec v) {
+  fq la, lb, lc;
+  d_dbl_core(la, lb, lc);
+  return d_line_mul(v, la, lb, lc);
+}
+static __device__ __noinline__ f6vec d_add_line_mul_fn(f6vec v, int neg) {
+  fq la, lb, lc;
+  d_add_core(la, lb, lc, neg != 0);
+  return d_line_mul(v, la, lb, lc);
+}
+
 // digit of the Miller loop at position m: +1, -1 or 0 (wave-uniform; hostbn.h naf_of_half)
 static PBC_DEV int d_digit(int m) {
   return (int) ((c_d.r[m >> 5] >> (m & 31)) & 1) - (int) ((c_d.rm[m >> 5] >> (m & 31)) & 1);
@@ -496,6 +640,18 @@ static PBC_DEV bool d_miller_lane(f6 &v, const uint8_t *g1, const uint8_t *g2) {
   f3_set_fq(v.x, one);
   f3_sub(v.y, v.x, v.x);
   // cc_miller_no_denom_affine (d_param.c:321-422): tangent; [double; line+add]; square
+  if constexpr (kFusedF6) {
+    f6vec vv = f6_pack(v);
+    for (int m = c_d.rbits - 2;; m--) {
+      vv = d_dbl_line_mul_fn(vv);
+      if (m <= 0) break;
+      const int dig = d_digit(m);
+      if (dig) vv = d_add_line_mul_fn(vv, dig < 0);
+      vv = f6_sqr_fused_fn(vv);
+    }
+    f6_unpack(v, vv);
+    return valid;
+  }
   for (int m = c_d.rbits - 2;; m--) {
     f6 e0;
     d_unpack(e0, d_dbl_line_fn());
@@ -642,6 +798,21 @@ static PBC_DEV void d_pp_line(f6 &e0, const uint32_t *tab, int slot) {
   }
   d_unpack(e0, d_pp_line_fn(to_vec<ND>(a), to_vec<ND>(b), to_vec<ND>(c)));
 }
+// fused form (d159): the coefficients travel through the point slots of the LDS state, which pp_apply does not use
+static __device__ __noinline__ f6vec d_pp_line_mul_fn(f6vec v) {
+  return d_line_mul(v, dl_get(DL_X), dl_get(DL_Y), dl_get(DL_Z));
+}
+static PBC_DEV f6vec d_pp_line_mul(f6vec v, const uint32_t *tab, int slot) {
+  fq a, b, c;
+#pragma unroll
+  for (int k = 0; k < ND; k++) {
+    a.v[k] = tab[(slot * 3 + 0) * ND + k];
+    b.v[k] = tab[(slot * 3 + 1) * ND + k];
+    c.v[k] = tab[(slot * 3 + 2) * ND + k];
+  }
+  dl_put(DL_X, a); dl_put(DL_Y, b); dl_put(DL_Z, c);
+  return d_pp_line_mul_fn(v);
+}
 // pairing_pp_apply for one lane
 static PBC_DEV void d_pp_apply_lane(uint8_t *gt, const uint32_t *tab, bool p_valid, const uint8_t *g2) {
   const int NB = (int) fpk<ND>().fbytes;
@@ -668,16 +839,27 @@ static PBC_DEV void d_pp_apply_lane(uint8_t *gt, const uint32_t *tab, bool p_val
   f3_set_fq(v.x, one);
   f3_sub(v.y, v.x, v.x);
   int slot = 0;
-  for (int m = c_d.rbits - 2;; m--) {
-    f6 e0;
-    d_pp_line(e0, tab, slot++);
-    f6_mul(v, v, e0);
-    if (m <= 0) break;
-    if (d_digit(m)) {
+  if constexpr (kFusedF6) {
+    f6vec vv = f6_pack(v);
+    for (int m = c_d.rbits - 2;; m--) {
+      vv = d_pp_line_mul(vv, tab, slot++);
+      if (m <= 0) break;
+      if (d_digit(m)) vv = d_pp_line_mul(vv, tab, slot++);
+      vv = f6_sqr_fused_fn(vv);
+    }
+    f6_unpack(v, vv);
+  } else {
+    for (int m = c_d.rbits - 2;; m--) {
+      f6 e0;
       d_pp_line(e0, tab, slot++);
       f6_mul(v, v, e0);
+      if (m <= 0) break;
+      if (d_digit(m)) {
+        d_pp_line(e0, tab, slot++);
+        f6_mul(v, v, e0);
+      }
+      f6_sqr(v, v);
     }
-    f6_sqr(v, v);
   }
   d_final_exp(out, v);
   d_store_gt(gt, out, valid);
@@ -714,23 +896,31 @@ static PBC_DEV void d_prod_pairing_lane(uint8_t *gt, const uint8_t *g1, const ui
     fp_set<ND>(one, fpk<ND>().one);
     f3_set_fq(F.x, one);
     f3_sub(F.y, F.x, F.x);
+    f6vec FF = f6_pack(F);               // (kFusedF6: the accumulator in its register-vector form)
     for (int m = c_d.rbits - 2;; m--) {
       const int dig = m > 0 ? d_digit(m) : 0;
       for (int j = 0; j < k; j++) {
         uint32_t *w = ws + (size_t) j * REC;
         d_ws_load(w, 0, DL_WORDS);
-        f6 e0;
-        d_unpack(e0, d_dbl_line_fn());
-        f6_mul(F, F, e0);
-        if (dig) {
-          d_unpack(e0, d_add_line_fn(dig < 0));
+        if constexpr (kFusedF6) {
+          FF = d_dbl_line_mul_fn(FF);
+          if (dig) FF = d_add_line_mul_fn(FF, dig < 0);
+        } else {
+          f6 e0;
+          d_unpack(e0, d_dbl_line_fn());
           f6_mul(F, F, e0);
+          if (dig) {
+            d_unpack(e0, d_add_line_fn(dig < 0));
+            f6_mul(F, F, e0);
+          }
         }
         d_ws_save(w, DL_X, 3 * ND);      // only V = (X, Y, Z) changes
       }
       if (m <= 0) break;
-      f6_sqr(F, F);
+      if constexpr (kFusedF6) FF = f6_sqr_fused_fn(FF);
+      else f6_sqr(F, F);
     }
+    if constexpr (kFusedF6) f6_unpack(F, FF);
   }
   d_final_exp(out, F);
   d_store_gt(gt, out, valid);

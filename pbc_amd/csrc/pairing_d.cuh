@@ -48,7 +48,9 @@ struct DRaw { uint32_t a[ND_MAX], b[ND_MAX], coeff[DEG_MAX][ND_MAX], nqr[ND_MAX]
 constexpr int D_LANES = 128;
 typedef uint32_t v32 __attribute__((ext_vector_type(32)));
 // Per-lane Miller state in LDS, word-major ([word][lane]: conflict-free); one array per instantiation.
-template <int ND, int DEG> __shared__ uint32_t g_lds_d[(2 * DEG + 5) * ND * D_LANES];
+// (d = 3 on the 5-word fields keeps the five F_q slots of the point state as 6-limb elements, see kLimbPoint)
+template <int ND, int DEG> constexpr int kPointWords = (DEG == 3 && ND == 5) ? Limbs29<ND>::L : ND;
+template <int ND, int DEG> __shared__ uint32_t g_lds_d[(2 * DEG * ND + 5 * kPointWords<ND, DEG>) * D_LANES];
 
 // Everything below is per field width and extension degree: ND 32-bit words per F_q element (5 for
 // the 159-bit d159 and 149-bit g149 fields, 6 / 7 for the 175..224-bit fields of the other shipped
@@ -277,7 +279,9 @@ struct djac { fq X, Y, Z, ZZ; };
 // arguments: a 160-bit F_q product is only ~80 multiply-adds, so calling it out of line costs
 // more than it computes; instead each Miller step is ONE out-of-line body with its ~20 products
 // inlined, fed from / writing back to LDS, returning just the line value (30 words).
-enum { DL_QX = 0, DL_QY = DEG * ND, DL_X = 2 * DEG * ND, DL_Y = DL_X + ND, DL_Z = DL_X + 2 * ND, DL_PX = DL_X + 3 * ND, DL_PY = DL_X + 4 * ND };
+static constexpr int PW = kPointWords<ND, DEG>;
+static constexpr bool kLimbPoint = PW != ND;
+enum { DL_QX = 0, DL_QY = DEG * ND, DL_X = 2 * DEG * ND, DL_Y = DL_X + PW, DL_Z = DL_X + 2 * PW, DL_PX = DL_X + 3 * PW, DL_PY = DL_X + 4 * PW };
 static PBC_DEV fq dl_get(int w) {
   fq r;
 #pragma unroll
@@ -550,21 +554,176 @@ static __device__ __noinline__ f6vec f6_sqr_fused_fn(f6vec vv) {
   f6_from_limbs(v, r);
   return f6_pack(v);
 }
+// ---- the point arithmetic on E(F_q) in limb form (kLimbPoint: d = 3 on the 5-word fields) ------------------------------
+// X, Y, Z of the running point and the fixed P sit in LDS as 6-limb elements in a redundant representation (as in
+// pairing_al.cuh: R = 2^174 against q < 2^160 leaves 14 bits of slack): additions are limb-wise without carries,
+// a - b is a + K - b with K = c q in borrowed form (limb_i(c q) + D 2^29 - D dominates limbs up to D (2^29 - 1)), and a
+// parallel carry pass renormalises where limbs would outgrow 32 bits or a column its 9.6 product units.  The bounds
+// (u = limb size in units of 2^29, B = value in units of q) are noted per line; the host mirror re-computes every
+// column sum in 128 bits (hs_sop_check).  Stored: X, Y almost normalised with B <= 18, Z with u <= 2, B <= 3.
+typedef fl<ND> el;
+static constexpr int FLW = Limbs29<ND>::L;
+enum { K2 = 0, K4 = 1, K16 = 2, K32 = 3 };                    // (c, D) = (2, 1), (4, 2), (16, 2), (32, 2)
+static constexpr int KSUB_OFF = 64;                           // DConst::xpwr29 holds them behind the d = 3 table
+static_assert(!kLimbPoint || ((DEG - 1) * DEG * FLW <= KSUB_OFF && KSUB_OFF + 5 * FLW <= 120), "room behind the x-power table");
+static PBC_DEV el l_const(int idx) {                          // idx 0..3: K constants, 4: the curve coefficient a
+  el r;
+#pragma unroll
+  for (int l = 0; l < FLW; l++) r.l[l] = c_d.xpwr29[KSUB_OFF + idx * FLW + l];
+  return r;
+}
+static PBC_DEV el ll_get(int w) {
+  el r;
+#pragma unroll
+  for (int k = 0; k < FLW; k++) r.l[k] = g_lds_d<ND, DEG>[(w + k) * D_LANES + threadIdx.x];
+  return r;
+}
+static PBC_DEV void ll_put(int w, const el &a) {
+#pragma unroll
+  for (int k = 0; k < FLW; k++) g_lds_d<ND, DEG>[(w + k) * D_LANES + threadIdx.x] = a.l[k];
+}
+static PBC_DEV void l_add(el &r, const el &a, const el &b) {
+#pragma unroll
+  for (int i = 0; i < FLW; i++) r.l[i] = a.l[i] + b.l[i];
+}
+template <int S>
+static PBC_DEV void l_shl(el &r, const el &a) {
+#pragma unroll
+  for (int i = 0; i < FLW; i++) r.l[i] = a.l[i] << S;
+}
+static PBC_DEV void l_subk(el &r, const el &a, const el &b, int k) {      // a + K_k - b
+  const el K = l_const(k);
+#pragma unroll
+  for (int i = 0; i < FLW; i++) r.l[i] = a.l[i] - b.l[i] + K.l[i];
+}
+static PBC_DEV void l_negk(el &r, const el &b, int k) {
+  const el K = l_const(k);
+#pragma unroll
+  for (int i = 0; i < FLW; i++) r.l[i] = K.l[i] - b.l[i];
+}
+static PBC_DEV void l_norm(el &r, const el &a) {              // parallel carry pass: limbs <= 2^29 + 6
+  uint32_t c = 0;
+#pragma unroll
+  for (int i = 0; i < FLW; i++) {
+    const uint32_t t = a.l[i];
+    r.l[i] = (i < FLW - 1 ? (t & Limbs29<ND>::MASK) : t) + c;
+    c = t >> 29;
+  }
+}
+// UNITS: the product of the operands' limb sizes (a column holds 9)
+template <int UNITS>
+static PBC_DEV void l_mul(el &r, const el &a, const el &b) {
+  const el x[1] = {a}, y[1] = {b};
+  sop_limbs<ND, 1, UNITS - 1>(r, x, y);
+}
+static PBC_DEV void l_sqr(el &r, const el &a) { sqr_limbs<ND>(r.l, a.l); }      // a (almost) normalised
+// any class -> fully reduced words (one product by R mod q brings the value below 2q)
+static PBC_DEV void l_to_fq(fq &r, const el &a) {
+  el one, t;
+  to_limbs<ND>(one, dk(fpk<ND>().one));
+  l_mul<8>(t, a, one);
+  from_limbs<ND>(r, t);
+}
+// tangent at V and V <- 2V (d_dbl_core): a' = -M Z^2 (u 2), b' = (2YZ) Z^2 (P-class), c' = M X - 2Y^2 (normalised)
+static PBC_DEV void d_dbl_core_l(el &la, el &lb, el &lc) {
+  const el X = ll_get(DL_X), Y = ll_get(DL_Y), Z = ll_get(DL_Z);
+  el ZZ, XX, YY, M, t0, t1, S1, Z3, W, Xn, Yn;
+  l_mul<4>(ZZ, Z, Z);
+  l_sqr(XX, X);
+  l_sqr(YY, Y);
+  l_sqr(t0, ZZ);
+  l_mul<1>(t0, t0, l_const(4));        // a Z^4
+  l_shl<1>(M, XX);
+  l_add(M, M, XX);
+  l_add(M, M, t0);                     // u 4, B 5
+  l_norm(M, M);
+  l_mul<1>(la, M, ZZ);
+  l_negk(la, la, K2);                  // u 2, B 2
+  l_mul<2>(Z3, Y, Z);
+  l_shl<1>(Z3, Z3);                    // 2YZ: u 2, B 3
+  l_mul<2>(lb, Z3, ZZ);
+  l_mul<1>(lc, M, X);
+  l_shl<1>(t1, YY);                    // u 2, B 3
+  l_subk(lc, lc, t1, K4);              // u 4, B 5.5
+  l_norm(lc, lc);
+  l_mul<1>(S1, X, YY);                 // X Y^2
+  l_shl<3>(t1, S1);                    // 8 X Y^2: u < 8, B 12
+  l_norm(t1, t1);
+  l_sqr(t0, M);
+  l_subk(t0, t0, t1, K16);             // X3 = M^2 - 2S, S = 4 X Y^2: u 4, B 17.5
+  l_norm(Xn, t0);
+  l_shl<2>(t1, S1);                    // S: u 4, B 6
+  l_subk(W, t1, Xn, K32);              // S - X3: u 7, B 38
+  l_mul<7>(t0, M, W);
+  l_sqr(t1, YY);
+  l_shl<3>(t1, t1);                    // 8 Y^4: u < 8, B 12
+  l_norm(t1, t1);
+  l_subk(t0, t0, t1, K16);             // Y3 = M (S - X3) - 8Y^4: u 4, B 17.5
+  l_norm(Yn, t0);
+  ll_put(DL_X, Xn);
+  ll_put(DL_Y, Yn);
+  ll_put(DL_Z, Z3);
+}
+// chord through V and +-P, V <- V +- P (d_add_core): a' = -R = Y - Py Z^3, b' = Z3, c' = R Px - Z3 Py
+static PBC_DEV void d_add_core_l(el &la, el &lb, el &lc, bool neg) {
+  const el X = ll_get(DL_X), Y = ll_get(DL_Y), Z = ll_get(DL_Z), Px = ll_get(DL_PX);
+  el Py = ll_get(DL_PY);
+  if (neg) {                           // wave-uniform
+    l_negk(Py, Py, K2);
+    l_norm(Py, Py);                    // B 2
+  }
+  el ZZ, H, Rn, HH, HHH, t0, t1, Z3, W, Xn, nY;
+  l_mul<4>(ZZ, Z, Z);
+  l_mul<1>(H, Px, ZZ);
+  l_subk(H, H, X, K32);                // u 4, B 33.5
+  l_norm(H, H);
+  l_mul<2>(t0, Z, ZZ);
+  l_mul<1>(t0, Py, t0);
+  l_subk(Rn, Y, t0, K2);               // -R: u 4, B 19.5
+  l_norm(Rn, Rn);
+  l_mul<2>(Z3, Z, H);
+  la = Rn;
+  lb = Z3;
+  {                                    // c' = -(Rn' Px + Z3 Py) with Rn' = -R: one lazy sum, then the negation
+    const el x[2] = {Rn, Z3}, y[2] = {Px, Py};
+    sop_limbs<ND, 2, 0>(t0, x, y);
+  }
+  // (R Px - Z3 Py with R = -Rn:  -(Rn Px) - Z3 Py)
+  l_negk(lc, t0, K2);                  // u 2, B 2
+  l_norm(lc, lc);
+  l_sqr(HH, H);
+  l_mul<1>(HHH, HH, H);
+  l_mul<1>(t0, X, HH);                 // X1 H^2
+  l_sqr(t1, Rn);
+  l_subk(t1, t1, HHH, K2);             // u 3, B 3.5
+  l_shl<1>(W, t0);                     // u 2, B 3
+  l_subk(t1, t1, W, K4);               // X3 = R^2 - H^3 - 2 X1 H^2: u 6, B 7.5
+  l_norm(Xn, t1);
+  l_subk(W, Xn, t0, K2);               // X3 - X1 H^2: u 3, B 9.5
+  l_norm(W, W);
+  l_negk(nY, Y, K32);                  // -Y1: u 3, B 32
+  l_norm(nY, nY);
+  {                                    // Y3 = R (X1 H^2 - X3) - Y1 H^3 = Rn (X3 - X1 H^2) + (-Y1) H^3
+    const el x[2] = {Rn, nY}, y[2] = {W, HHH};
+    sop_limbs<ND, 2, 0>(t0, x, y);
+  }
+  ll_put(DL_X, Xn);
+  ll_put(DL_Y, t0);
+  ll_put(DL_Z, Z3);
+}
+
 // v * l(Q) for the line a' x + b' y + c' (d_miller_evalfn): l = (a' Qx + c') + (b' Qy) s, formed in limb form
-static PBC_DEV f6vec d_line_mul(f6vec vv, const fq &la, const fq &lb, const fq &lc) {
+// (La: limbs up to 2^30, Lb: P-class, Lc: normalised)
+static PBC_DEV f6vec d_line_mul_l(f6vec vv, const fl<ND> &La, const fl<ND> &Lb, const fl<ND> &Lc) {
   f6 v;
   f6l a, l, r;
   f6_unpack(v, vv);
   f6_to_limbs(a, v);
-  fl<ND> La, Lb, Lc;
-  to_limbs<ND>(La, la);
-  to_limbs<ND>(Lb, lb);
-  to_limbs<ND>(Lc, lc);
 #pragma unroll
   for (int i = 0; i < DEG; i++) {
     fl<ND> q;
     to_limbs<ND>(q, dl_get(DL_QX + ND * i));
-    { const fl<ND> x[1] = {q}, y[1] = {La}; sop_limbs<ND, 1>(l.x[i], x, y); }
+    { const fl<ND> x[1] = {q}, y[1] = {La}; sop_limbs<ND, 1, 1>(l.x[i], x, y); }
     to_limbs<ND>(q, dl_get(DL_QY + ND * i));
     { const fl<ND> x[1] = {q}, y[1] = {Lb}; sop_limbs<ND, 1>(l.y[i], x, y); }
   }
@@ -574,15 +733,34 @@ static PBC_DEV f6vec d_line_mul(f6vec vv, const fq &la, const fq &lb, const fq &
   f6_from_limbs(v, r);
   return f6_pack(v);
 }
+static PBC_DEV f6vec d_line_mul(f6vec vv, const fq &la, const fq &lb, const fq &lc) {
+  fl<ND> La, Lb, Lc;
+  to_limbs<ND>(La, la);
+  to_limbs<ND>(Lb, lb);
+  to_limbs<ND>(Lc, lc);
+  return d_line_mul_l(vv, La, Lb, Lc);
+}
 static __device__ __noinline__ f6vec d_dbl_line_mul_fn(f6vec v) {
-  fq la, lb, lc;
-  d_dbl_core(la, lb, lc);
-  return d_line_mul(v, la, lb, lc);
+  if constexpr (kLimbPoint) {
+    el la, lb, lc;
+    d_dbl_core_l(la, lb, lc);
+    return d_line_mul_l(v, la, lb, lc);
+  } else {
+    fq la, lb, lc;
+    d_dbl_core(la, lb, lc);
+    return d_line_mul(v, la, lb, lc);
+  }
 }
 static __device__ __noinline__ f6vec d_add_line_mul_fn(f6vec v, int neg) {
-  fq la, lb, lc;
-  d_add_core(la, lb, lc, neg != 0);
-  return d_line_mul(v, la, lb, lc);
+  if constexpr (kLimbPoint) {
+    el la, lb, lc;
+    d_add_core_l(la, lb, lc, neg != 0);
+    return d_line_mul_l(v, la, lb, lc);
+  } else {
+    fq la, lb, lc;
+    d_add_core(la, lb, lc, neg != 0);
+    return d_line_mul(v, la, lb, lc);
+  }
 }
 
 // digit of the Miller loop at position m: +1, -1 or 0 (wave-uniform; hostbn.h naf_of_half)
@@ -628,8 +806,15 @@ static PBC_DEV bool d_setup_lane(const uint8_t *g1, const uint8_t *g2) {
   f3_mul_fq(Qy, Qy, dk(c_d.nqrinv2));
 #pragma unroll
   for (int i = 0; i < DEG; i++) { dl_put(DL_QX + ND * i, Qx.c[i]); dl_put(DL_QY + ND * i, Qy.c[i]); }
-  dl_put(DL_X, Px); dl_put(DL_Y, Py); dl_put(DL_Z, one);
-  dl_put(DL_PX, Px); dl_put(DL_PY, Py);
+  if constexpr (kLimbPoint) {
+    el x, y, o;
+    to_limbs<ND>(x, Px); to_limbs<ND>(y, Py); to_limbs<ND>(o, one);
+    ll_put(DL_X, x); ll_put(DL_Y, y); ll_put(DL_Z, o);
+    ll_put(DL_PX, x); ll_put(DL_PY, y);
+  } else {
+    dl_put(DL_X, Px); dl_put(DL_Y, Py); dl_put(DL_Z, one);
+    dl_put(DL_PX, Px); dl_put(DL_PY, Py);
+  }
   return valid;
 }
 // Miller function f_{r,P}(psi(Q)) of one term
@@ -764,17 +949,36 @@ static PBC_DEV bool d_pp_init_lane(uint32_t *tab, const uint8_t *g1) {
   fp_add<ND>(t0, t0, dk(c_d.B));
   fp_sqr<ND>(t1, Py);
   bool valid = fp_eq<ND>(t0, t1);
-  dl_put(DL_X, Px); dl_put(DL_Y, Py); dl_put(DL_Z, one);
-  dl_put(DL_PX, Px); dl_put(DL_PY, Py);
+  if constexpr (kLimbPoint) {
+    el x, y, o;
+    to_limbs<ND>(x, Px); to_limbs<ND>(y, Py); to_limbs<ND>(o, one);
+    ll_put(DL_X, x); ll_put(DL_Y, y); ll_put(DL_Z, o);
+    ll_put(DL_PX, x); ll_put(DL_PY, y);
+  } else {
+    dl_put(DL_X, Px); dl_put(DL_Y, Py); dl_put(DL_Z, one);
+    dl_put(DL_PX, Px); dl_put(DL_PY, Py);
+  }
   int slot = 0;
   for (int m = c_d.rbits - 2;; m--) {
     fq la, lb, lc;
-    d_dbl_core(la, lb, lc);
+    if constexpr (kLimbPoint) {        // the table stays in canonical word form
+      el a, b, c;
+      d_dbl_core_l(a, b, c);
+      l_to_fq(la, a); l_to_fq(lb, b); l_to_fq(lc, c);
+    } else {
+      d_dbl_core(la, lb, lc);
+    }
     for (int k = 0; k < ND; k++) { tab[(slot * 3 + 0) * ND + k] = la.v[k]; tab[(slot * 3 + 1) * ND + k] = lb.v[k]; tab[(slot * 3 + 2) * ND + k] = lc.v[k]; }
     slot++;
     if (m <= 0) break;
     if (d_digit(m)) {
-      d_add_core(la, lb, lc, d_digit(m) < 0);
+      if constexpr (kLimbPoint) {
+        el a, b, c;
+        d_add_core_l(a, b, c, d_digit(m) < 0);
+        l_to_fq(la, a); l_to_fq(lb, b); l_to_fq(lc, c);
+      } else {
+        d_add_core(la, lb, lc, d_digit(m) < 0);
+      }
       for (int k = 0; k < ND; k++) { tab[(slot * 3 + 0) * ND + k] = la.v[k]; tab[(slot * 3 + 1) * ND + k] = lb.v[k]; tab[(slot * 3 + 2) * ND + k] = lc.v[k]; }
       slot++;
     }
@@ -871,7 +1075,7 @@ static PBC_DEV void d_pp_apply_lane(uint8_t *gt, const uint32_t *tab, bool p_val
 // state holds one term at a time; the others wait in a global workspace owned by the pairing object,
 // word-major per 128-lane workgroup:  ws[((block k + term) DL_WORDS + word) 128 + lane]  (every access of a wave is
 // 256 contiguous bytes).  Any identity input forces the product to 1.
-static constexpr int DL_WORDS = (2 * DEG + 5) * ND;
+static constexpr int DL_WORDS = 2 * DEG * ND + 5 * PW;
 static PBC_DEV void d_ws_save(uint32_t *ws, int first, int count) {
 #pragma unroll 5
   for (int w = first; w < first + count; w++) ws[w * D_LANES] = g_lds_d<ND, DEG>[w * D_LANES + threadIdx.x];
@@ -914,7 +1118,7 @@ static PBC_DEV void d_prod_pairing_lane(uint8_t *gt, const uint8_t *g1, const ui
             f6_mul(F, F, e0);
           }
         }
-        d_ws_save(w, DL_X, 3 * ND);      // only V = (X, Y, Z) changes
+        d_ws_save(w, DL_X, 3 * PW);      // only V = (X, Y, Z) changes
       }
       if (m <= 0) break;
       if constexpr (kFusedF6) FF = f6_sqr_fused_fn(FF);
@@ -967,6 +1171,24 @@ static PBC_DEV void init_stage1(DConst *out, const DRaw &raw, const DConst &base
     fl<ND> t29;
     to_limbs<ND>(t29, v);
     for (int l = 0; l < Limbs29<ND>::L; l++) C.nqr29[l] = t29.l[l];
+  }
+  if constexpr (kLimbPoint) {
+    // subtraction constants of the limb-form point arithmetic: c q in 29-bit limbs, borrowed so that limb i
+    // dominates limbs up to D (2^29 - 1):  limb_0 + D 2^29,  limb_i + D 2^29 - D,  limb_top - D;  then the curve's a
+    const uint32_t cd[4][2] = {{2, 1}, {4, 2}, {16, 2}, {32, 2}};
+    for (int t = 0; t < 4; t++) {
+      uint64_t carry = 0;
+      for (int i = 0; i < FLW; i++) {
+        const uint64_t x = (uint64_t) cd[t][0] * fpk<ND>().p29[i] + carry;
+        uint32_t k = (uint32_t) x & Limbs29<ND>::MASK;
+        carry = x >> 29;
+        k += (i < FLW - 1 ? cd[t][1] << 29 : 0) - (i > 0 ? cd[t][1] : 0);
+        C.xpwr29[KSUB_OFF + t * FLW + i] = k;
+      }
+    }
+    fl<ND> a29;
+    to_limbs<ND>(a29, a);
+    for (int l = 0; l < FLW; l++) C.xpwr29[KSUB_OFF + 4 * FLW + l] = a29.l[l];
   }
   *out = C;
 }

@@ -1069,7 +1069,9 @@ static int launch_prod(pbc_hip_pairing_s *P, void *d_gt, const void *d_g1, const
     hipLaunchKernelGGL(e_prod_pairing_kernel<33>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
                        (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k, kargs<33>(P));
   } else if (P->type == 'd' || P->type == 'g') {
-    void *ws = workspace_get(P, s, (size_t) grid * (size_t) k * (size_t) ((2 * P->deg + 5) * P->nlimb * kBlock) * sizeof(uint32_t));
+    size_t rec = 0;                    // words of Miller state per term and lane (the kernel's own constant)
+    PBC_DISPATCH_D(P, rec = (size_t) TypeMNT<N, DEG>::DL_WORDS);
+    void *ws = workspace_get(P, s, (size_t) grid * (size_t) k * rec * kBlock * sizeof(uint32_t));
     if (!ws) return 1;
     PBC_DISPATCH_D(P, hipLaunchKernelGGL((d_prod_pairing_kernel<N, DEG>), dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
                                                 (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k, (uint32_t *) ws, kargs<N>(P)));

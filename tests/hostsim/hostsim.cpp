@@ -131,7 +131,7 @@ int hostsim_prod_pairing(void *h, uint8_t *gt, const uint8_t *g1, const uint8_t 
     else if (P->type == '1' || P->type == 'a') a1_prod_pairing_lane<33>(o, a, b, k, lds, 1);
     else if (P->type == 'e' && P->nlimb == 16) e_prod_pairing_lane<16>(o, a, b, k, lds, 1);
     else if (P->type == 'e') e_prod_pairing_lane<33>(o, a, b, k, lds, 1);
-    else if (P->type == 'd' || P->type == 'g') { std::vector<uint32_t> ws((size_t) k * 80 * 128); HS_DISPATCH_D(P, TypeMNT<N, DEG>::d_prod_pairing_lane(o, a, b, k, ws.data())); }
+    else if (P->type == 'd' || P->type == 'g') { HS_DISPATCH_D(P, { std::vector<uint32_t> ws((size_t) k * TypeMNT<N, DEG>::DL_WORDS * 128); TypeMNT<N, DEG>::d_prod_pairing_lane(o, a, b, k, ws.data()); }); }
     else { HS_DISPATCH_F(P->nlimb, TypeF<N>::f_prod_pairing_lane(o, a, b, k)); }
   }
   return 0;

@@ -199,6 +199,18 @@ def test_df_prod_pairing_matches_reference_vectors(hips, t, name):
     assert np.array_equal(hips[t].element_prod_pairing(v.g1, v.g2, v.k), v.gt)
 
 
+@pytest.mark.parametrize("t", ["a", "d"])
+def test_products_over_many_workgroups_use_their_own_workspace_records(hips, t):
+    """The product kernels of types a and d keep the per-term Miller state in a global workspace, one record per
+    (workgroup, term, lane), sized by the host from the kernel's own record length: 1500 units of 16 terms (12
+    workgroups) must all reproduce the reference's four."""
+    v = golden("a_prod16x4.vec" if t == "a" else "d_prod16x4.vec")
+    reps = 375
+    g1, g2 = np.tile(v.g1, (reps, 1)), np.tile(v.g2, (reps, 1))        # records of unit u: rows u k .. u k + k - 1
+    got = hips[t].element_prod_pairing(g1, g2, v.k)
+    assert np.array_equal(got, np.tile(v.gt, (reps, 1)))
+
+
 @pytest.mark.parametrize("t", ["d", "f"])
 def test_df_cross_pairs_vs_oracle_and_symmetry(hips, oracles, t):
     """(P_i, Q_j) pairs the fixtures do not hold; e(P_i,Q_j) = e(P_j,Q_i) since P_i=(i+1)P0, Q_j=(j+1)Q0."""

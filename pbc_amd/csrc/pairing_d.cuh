@@ -559,68 +559,122 @@ static __device__ __noinline__ f6vec f6_sqr_fused_fn(f6vec vv) {
 // pairing_al.cuh: R = 2^174 against q < 2^160 leaves 14 bits of slack): additions are limb-wise without carries,
 // a - b is a + K - b with K = c q in borrowed form (limb_i(c q) + D 2^29 - D dominates limbs up to D (2^29 - 1)), and a
 // parallel carry pass renormalises where limbs would outgrow 32 bits or a column its 9.6 product units.  The bounds
-// (u = limb size in units of 2^29, B = value in units of q) are noted per line; the host mirror re-computes every
-// column sum in 128 bits (hs_sop_check).  Stored: X, Y almost normalised with B <= 18, Z with u <= 2, B <= 3.
+// (u = limb size in units of 2^29, B = value in units of q) are noted per line and asserted in the host mirror, which
+// also re-computes every column sum in 128 bits.  Stored: X, Y almost normalised with B <= 18, Z with u <= 2, B <= 3.
 typedef fl<ND> el;
 static constexpr int FLW = Limbs29<ND>::L;
 enum { K2 = 0, K4 = 1, K16 = 2, K32 = 3 };                    // (c, D) = (2, 1), (4, 2), (16, 2), (32, 2)
 static constexpr int KSUB_OFF = 64;                           // DConst::xpwr29 holds them behind the d = 3 table
 static_assert(!kLimbPoint || ((DEG - 1) * DEG * FLW <= KSUB_OFF && KSUB_OFF + 5 * FLW <= 120), "room behind the x-power table");
+// host mirror only: worst-case bound tracker, as in pairing_al.cuh -- every element carries the (u, B) its producing
+// operations imply, every operation asserts its precondition on those: one run proves the bounds for all inputs
+#ifdef PBC_HOSTSIM
+static constexpr double U_STRICT = 1.0 - 1.0 / 536870912.0, U_ALMOST = 1.0 + 7.0 / 536870912.0;
+static constexpr double KC[4] = {2, 4, 16, 32}, KD[4] = {1, 2, 2, 2};
+static constexpr double SLACK = 16384.0;                      // R / q > 2^14
+// classes of the five stored elements (X, Y, Z, Px, Py): what ll_put may store and what ll_get assumes -- the product
+// kernel swaps the point state of its terms in and out of LDS behind the tracker's back
+static constexpr double CLS_U[5] = {U_ALMOST, U_ALMOST, 2.0, U_STRICT, U_STRICT}, CLS_B[5] = {18, 18, 3.001, 1, 1};
+static void hs_fail(const char *what, double v) { fprintf(stderr, "hostsim: limb-form type d point arithmetic: %s (%g)\n", what, v); abort(); }
+static void hs_limbs(const el &a) {
+  for (int i = 0; i < FLW; i++)
+    if ((double) a.l[i] > a.hs_u * 536870912.0) hs_fail("limb above its tracked bound", a.hs_u);
+}
+static void hs_set(el &r, double u, double B) { r.hs_u = u; r.hs_B = B; hs_limbs(r); }
+static void hs_dom(const el &b, int k) {
+  hs_limbs(b);
+  if (b.hs_u > KD[k] * U_STRICT + 1e-12) hs_fail("subtrahend limbs not dominated", b.hs_u);
+  if (b.hs_B > KC[k] - 0.001) hs_fail("subtrahend value not dominated", b.hs_B);
+}
+static void hs_cols(double s) { if (s > (64.0 - FLW) / FLW - 0.01) hs_fail("column capacity", s); }
+#define DL_HS(...) __VA_ARGS__
+#else
+#define DL_HS(...)
+#endif
 static PBC_DEV el l_const(int idx) {                          // idx 0..3: K constants, 4: the curve coefficient a
   el r;
 #pragma unroll
   for (int l = 0; l < FLW; l++) r.l[l] = c_d.xpwr29[KSUB_OFF + idx * FLW + l];
+  DL_HS(if (idx == 4) hs_set(r, U_STRICT, 1.0);)
   return r;
 }
 static PBC_DEV el ll_get(int w) {
   el r;
 #pragma unroll
   for (int k = 0; k < FLW; k++) r.l[k] = g_lds_d<ND, DEG>[(w + k) * D_LANES + threadIdx.x];
+  DL_HS(hs_set(r, CLS_U[(w - DL_X) / PW], CLS_B[(w - DL_X) / PW]);)
   return r;
 }
 static PBC_DEV void ll_put(int w, const el &a) {
 #pragma unroll
   for (int k = 0; k < FLW; k++) g_lds_d<ND, DEG>[(w + k) * D_LANES + threadIdx.x] = a.l[k];
+  DL_HS(hs_limbs(a); if (a.hs_u > CLS_U[(w - DL_X) / PW] || a.hs_B > CLS_B[(w - DL_X) / PW]) hs_fail("stored element outside its class", a.hs_B);)
 }
 static PBC_DEV void l_add(el &r, const el &a, const el &b) {
 #pragma unroll
   for (int i = 0; i < FLW; i++) r.l[i] = a.l[i] + b.l[i];
+  DL_HS(if (a.hs_u + b.hs_u >= 8) hs_fail("sum overflows 32 bits", a.hs_u + b.hs_u); hs_set(r, a.hs_u + b.hs_u, a.hs_B + b.hs_B);)
 }
 template <int S>
 static PBC_DEV void l_shl(el &r, const el &a) {
 #pragma unroll
   for (int i = 0; i < FLW; i++) r.l[i] = a.l[i] << S;
+  DL_HS(if (a.hs_u * (1 << S) >= 8) hs_fail("shift overflows 32 bits", a.hs_u); hs_set(r, a.hs_u * (1 << S), a.hs_B * (1 << S));)
 }
 static PBC_DEV void l_subk(el &r, const el &a, const el &b, int k) {      // a + K_k - b
   const el K = l_const(k);
+  DL_HS(hs_dom(b, k); const double u = a.hs_u + KD[k] + 1, B = a.hs_B + KC[k]; if (u >= 8) hs_fail("difference overflows 32 bits", u);)
 #pragma unroll
   for (int i = 0; i < FLW; i++) r.l[i] = a.l[i] - b.l[i] + K.l[i];
+  DL_HS(hs_set(r, u, B);)
 }
 static PBC_DEV void l_negk(el &r, const el &b, int k) {
   const el K = l_const(k);
+  DL_HS(hs_dom(b, k);)
 #pragma unroll
   for (int i = 0; i < FLW; i++) r.l[i] = K.l[i] - b.l[i];
+  DL_HS(hs_set(r, KD[k] + 1, KC[k]);)
 }
 static PBC_DEV void l_norm(el &r, const el &a) {              // parallel carry pass: limbs <= 2^29 + 6
   uint32_t c = 0;
+  DL_HS(hs_limbs(a); const double B = a.hs_B; if (a.hs_u >= 8) hs_fail("normalising limbs above 32 bits", a.hs_u);)
 #pragma unroll
   for (int i = 0; i < FLW; i++) {
     const uint32_t t = a.l[i];
     r.l[i] = (i < FLW - 1 ? (t & Limbs29<ND>::MASK) : t) + c;
     c = t >> 29;
   }
+  DL_HS(hs_set(r, U_ALMOST, B);)
 }
 // UNITS: the product of the operands' limb sizes (a column holds 9)
 template <int UNITS>
 static PBC_DEV void l_mul(el &r, const el &a, const el &b) {
   const el x[1] = {a}, y[1] = {b};
+  DL_HS(hs_limbs(a); hs_limbs(b); hs_cols(a.hs_u * b.hs_u); if (a.hs_u * b.hs_u > UNITS + 0.001) hs_fail("more product units than declared", a.hs_u * b.hs_u);
+        const double B = 1 + a.hs_B * b.hs_B / SLACK;)
   sop_limbs<ND, 1, UNITS - 1>(r, x, y);
+  DL_HS(hs_set(r, U_STRICT, B);)
 }
-static PBC_DEV void l_sqr(el &r, const el &a) { sqr_limbs<ND>(r.l, a.l); }      // a (almost) normalised
+static PBC_DEV void l_sqr(el &r, const el &a) {               // a (almost) normalised
+  DL_HS(const el x[1] = {a}; hs_limbs(a); if (a.hs_u > U_ALMOST) hs_fail("squaring an unnormalised element", a.hs_u); hs_sop_check<ND>(x, x, 1);
+        const double B = 1 + a.hs_B * a.hs_B / SLACK;)
+  sqr_limbs<ND>(r.l, a.l);
+  DL_HS(hs_set(r, U_STRICT, B);)
+}
+// a0 b0 + a1 b1, one reduction
+static PBC_DEV void l_sop2(el &r, const el &a0, const el &b0, const el &a1, const el &b1) {
+  const el x[2] = {a0, a1}, y[2] = {b0, b1};
+  DL_HS(hs_limbs(a0); hs_limbs(b0); hs_limbs(a1); hs_limbs(b1); hs_cols(a0.hs_u * b0.hs_u + a1.hs_u * b1.hs_u);
+        if (a0.hs_u * b0.hs_u + a1.hs_u * b1.hs_u > 2.01) hs_fail("two-term sum of unnormalised operands", a0.hs_u);
+        const double B = 1 + (a0.hs_B * b0.hs_B + a1.hs_B * b1.hs_B) / SLACK;)
+  sop_limbs<ND, 2, 0>(r, x, y);
+  DL_HS(hs_set(r, U_STRICT, B);)
+}
 // any class -> fully reduced words (one product by R mod q brings the value below 2q)
 static PBC_DEV void l_to_fq(fq &r, const el &a) {
   el one, t;
   to_limbs<ND>(one, dk(fpk<ND>().one));
+  DL_HS(hs_set(one, U_STRICT, 1.0);)
   l_mul<8>(t, a, one);
   from_limbs<ND>(r, t);
 }
@@ -684,10 +738,7 @@ static PBC_DEV void d_add_core_l(el &la, el &lb, el &lc, bool neg) {
   l_mul<2>(Z3, Z, H);
   la = Rn;
   lb = Z3;
-  {                                    // c' = -(Rn' Px + Z3 Py) with Rn' = -R: one lazy sum, then the negation
-    const el x[2] = {Rn, Z3}, y[2] = {Px, Py};
-    sop_limbs<ND, 2, 0>(t0, x, y);
-  }
+  l_sop2(t0, Rn, Px, Z3, Py);          // c' = -(Rn' Px + Z3 Py) with Rn' = -R: one lazy sum, then the negation
   // (R Px - Z3 Py with R = -Rn:  -(Rn Px) - Z3 Py)
   l_negk(lc, t0, K2);                  // u 2, B 2
   l_norm(lc, lc);
@@ -703,10 +754,7 @@ static PBC_DEV void d_add_core_l(el &la, el &lb, el &lc, bool neg) {
   l_norm(W, W);
   l_negk(nY, Y, K32);                  // -Y1: u 3, B 32
   l_norm(nY, nY);
-  {                                    // Y3 = R (X1 H^2 - X3) - Y1 H^3 = Rn (X3 - X1 H^2) + (-Y1) H^3
-    const el x[2] = {Rn, nY}, y[2] = {W, HHH};
-    sop_limbs<ND, 2, 0>(t0, x, y);
-  }
+  l_sop2(t0, Rn, W, nY, HHH);          // Y3 = R (X1 H^2 - X3) - Y1 H^3 = Rn (X3 - X1 H^2) + (-Y1) H^3
   ll_put(DL_X, Xn);
   ll_put(DL_Y, t0);
   ll_put(DL_Z, Z3);
@@ -715,6 +763,8 @@ static PBC_DEV void d_add_core_l(el &la, el &lb, el &lc, bool neg) {
 // v * l(Q) for the line a' x + b' y + c' (d_miller_evalfn): l = (a' Qx + c') + (b' Qy) s, formed in limb form
 // (La: limbs up to 2^30, Lb: P-class, Lc: normalised)
 static PBC_DEV f6vec d_line_mul_l(f6vec vv, const fl<ND> &La, const fl<ND> &Lb, const fl<ND> &Lc) {
+  DL_HS(if (kLimbPoint && (La.hs_u > 2.0 || Lb.hs_u > U_STRICT || Lc.hs_u > U_ALMOST || La.hs_B > 64 || Lb.hs_B > 64 || Lc.hs_B > 64))
+          hs_fail("line coefficient outside its class", La.hs_u);)
   f6 v;
   f6l a, l, r;
   f6_unpack(v, vv);
@@ -738,6 +788,7 @@ static PBC_DEV f6vec d_line_mul(f6vec vv, const fq &la, const fq &lb, const fq &
   to_limbs<ND>(La, la);
   to_limbs<ND>(Lb, lb);
   to_limbs<ND>(Lc, lc);
+  DL_HS(if (kLimbPoint) { hs_set(La, U_STRICT, 1.0); hs_set(Lb, U_STRICT, 1.0); hs_set(Lc, U_STRICT, 1.0); })
   return d_line_mul_l(vv, La, Lb, Lc);
 }
 static __device__ __noinline__ f6vec d_dbl_line_mul_fn(f6vec v) {
@@ -809,6 +860,7 @@ static PBC_DEV bool d_setup_lane(const uint8_t *g1, const uint8_t *g2) {
   if constexpr (kLimbPoint) {
     el x, y, o;
     to_limbs<ND>(x, Px); to_limbs<ND>(y, Py); to_limbs<ND>(o, one);
+    DL_HS(hs_set(x, U_STRICT, 1.0); hs_set(y, U_STRICT, 1.0); hs_set(o, U_STRICT, 1.0);)
     ll_put(DL_X, x); ll_put(DL_Y, y); ll_put(DL_Z, o);
     ll_put(DL_PX, x); ll_put(DL_PY, y);
   } else {
@@ -952,6 +1004,7 @@ static PBC_DEV bool d_pp_init_lane(uint32_t *tab, const uint8_t *g1) {
   if constexpr (kLimbPoint) {
     el x, y, o;
     to_limbs<ND>(x, Px); to_limbs<ND>(y, Py); to_limbs<ND>(o, one);
+    DL_HS(hs_set(x, U_STRICT, 1.0); hs_set(y, U_STRICT, 1.0); hs_set(o, U_STRICT, 1.0);)
     ll_put(DL_X, x); ll_put(DL_Y, y); ll_put(DL_Z, o);
     ll_put(DL_PX, x); ll_put(DL_PY, y);
   } else {

@@ -454,7 +454,10 @@ static __device__ __noinline__ v32 d_add_line_fn(int neg) {
 // products, reduced once: 51 limb products + 13 reductions against Karatsuba's 48 + 18, and no additions at all.
 // The accumulator travels in registers (30 words in, 30 out); the line functions multiply their value into it directly,
 // so the line value never exists in word form.
-static constexpr bool kFusedF6 = DEG == 3 && 2 * DEG * ND <= 30;
+// (6-word fields: the 36-word accumulator overflows the 32 argument registers by four words, which travel through the
+// stack; their 7-limb columns hold 8 product units, so the line value's "+ c'" is normalised instead of counted double)
+static constexpr bool kFusedF6 = DEG == 3 && ND <= 6;
+static constexpr bool kLineDbl = Limbs29<ND>::L <= 6;
 typedef uint32_t f6vec __attribute__((ext_vector_type(2 * DEG * ND)));
 struct f6l { fl<ND> x[DEG], y[DEG]; };
 static PBC_DEV f6vec f6_pack(const f6 &a) {
@@ -779,7 +782,16 @@ static PBC_DEV f6vec d_line_mul_l(f6vec vv, const fl<ND> &La, const fl<ND> &Lb, 
   }
 #pragma unroll
   for (int k = 0; k < Limbs29<ND>::L; k++) l.x[0].l[k] += Lc.l[k];     // limbs < 2^30: the doubled operand of f6l_mul<true>
-  f6l_mul<true>(r, a, l);
+  if constexpr (!kLineDbl) {           // ... or one parallel carry pass where the column has no room for it
+    uint32_t c = 0;
+#pragma unroll
+    for (int k = 0; k < Limbs29<ND>::L; k++) {
+      const uint32_t t = l.x[0].l[k];
+      l.x[0].l[k] = (k < Limbs29<ND>::L - 1 ? (t & Limbs29<ND>::MASK) : t) + c;
+      c = t >> 29;
+    }
+  }
+  f6l_mul<kLineDbl>(r, a, l);
   f6_from_limbs(v, r);
   return f6_pack(v);
 }

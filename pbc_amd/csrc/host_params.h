@@ -387,6 +387,13 @@ static int init_type_d(pbc_hip_pairing_s *P, const char *txt, size_t len, int de
   q.to_words(P->draw.q, ND + 1);
   P->draw.qbits = q.bits();
   if (r.bits() > 256 || r.bits() < 3) return fail("%s: bad r", tn);
+  {
+    // limb-form point arithmetic of the 5-word d = 3 kernels (pairing_d.cuh, kLimbPoint): its subtraction constants borrow
+    // from q's top 29-bit limb, which must hold at least 8 bits of q; "hip_no_limb 1" forces the word-form routines
+    int no_limb = 0;
+    param_int(txt, len, "hip_no_limb", no_limb);
+    P->dconst.limb_ok = (ND == 5 && deg == 3 && q.bits() >= 29 * 5 + 8 && !no_limb) ? 1 : 0;
+  }
   P->dconst.rbits = pbc_host::naf_of_half(r, P->dconst.r, P->dconst.rm, 8);     // signed digits of the Miller loop
   if (!P->dconst.rbits) return fail("%s: r too wide for the Miller loop digits", tn);
   // phikonr = Phi_k(q)/r: (q^2 - q + 1)/r (d_param.c:1036-1042), (q^4 - q^3 + q^2 - q + 1)/r (g_param.c:1288-1305)

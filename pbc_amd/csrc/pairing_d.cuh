@@ -40,6 +40,10 @@ struct DConst {                        // pptr (ecc/d_param.c:40-51) + curve/fie
   uint32_t r[8], rm[8];                // Miller loop digits: NAF of r >> 1, +1 digits in r[], -1 digits in rm[] (hostbn.h)
   uint32_t phik[16];                   // Phi_k(q)/r (d_param.c:1036-1042, g_param.c:1288-1305)
   int rbits, phikbits;
+  // 1: the 5-word d = 3 kernels keep the point state in limb form (kLimbPoint).  Set by the host when q fills at least
+  // 8 bits of its top limb (the borrowed subtraction constants take their borrow from that limb) and the parameter text
+  // does not say "hip_no_limb 1"; otherwise the same kernels run the word-form step routines.
+  int limb_ok;
 };
 static_assert(sizeof(DConst) <= KOFF_XS - KOFF_TYPE, "constant block layout");
 #define c_d (pbc::kconst<pbc::DConst, pbc::KOFF_TYPE>())
@@ -797,35 +801,43 @@ static PBC_DEV f6vec d_line_mul_l(f6vec vv, const fl<ND> &La, const fl<ND> &Lb, 
 }
 static PBC_DEV f6vec d_line_mul(f6vec vv, const fq &la, const fq &lb, const fq &lc) {
   fl<ND> La, Lb, Lc;
+  d_line_to_limbs(La, Lb, Lc, la, lb, lc);
+  return d_line_mul_l(vv, La, Lb, Lc);
+}
+// line coefficients of the word-form step routines as limbs
+static PBC_DEV void d_line_to_limbs(el &La, el &Lb, el &Lc, const fq &la, const fq &lb, const fq &lc) {
   to_limbs<ND>(La, la);
   to_limbs<ND>(Lb, lb);
   to_limbs<ND>(Lc, lc);
   DL_HS(if (kLimbPoint) { hs_set(La, U_STRICT, 1.0); hs_set(Lb, U_STRICT, 1.0); hs_set(Lc, U_STRICT, 1.0); })
-  return d_line_mul_l(vv, La, Lb, Lc);
 }
+// (one copy of the fused product behind either form of the step routine: limb_ok is wave-uniform)
 static __device__ __noinline__ f6vec d_dbl_line_mul_fn(f6vec v) {
-  if constexpr (kLimbPoint) {
-    el la, lb, lc;
-    d_dbl_core_l(la, lb, lc);
-    return d_line_mul_l(v, la, lb, lc);
+  el La, Lb, Lc;
+  bool limb = false;
+  if constexpr (kLimbPoint) limb = c_d.limb_ok != 0;
+  if (limb) {
+    if constexpr (kLimbPoint) d_dbl_core_l(La, Lb, Lc);
   } else {
     fq la, lb, lc;
     d_dbl_core(la, lb, lc);
-    return d_line_mul(v, la, lb, lc);
+    d_line_to_limbs(La, Lb, Lc, la, lb, lc);
   }
+  return d_line_mul_l(v, La, Lb, Lc);
 }
 static __device__ __noinline__ f6vec d_add_line_mul_fn(f6vec v, int neg) {
-  if constexpr (kLimbPoint) {
-    el la, lb, lc;
-    d_add_core_l(la, lb, lc, neg != 0);
-    return d_line_mul_l(v, la, lb, lc);
+  el La, Lb, Lc;
+  bool limb = false;
+  if constexpr (kLimbPoint) limb = c_d.limb_ok != 0;
+  if (limb) {
+    if constexpr (kLimbPoint) d_add_core_l(La, Lb, Lc, neg != 0);
   } else {
     fq la, lb, lc;
     d_add_core(la, lb, lc, neg != 0);
-    return d_line_mul(v, la, lb, lc);
+    d_line_to_limbs(La, Lb, Lc, la, lb, lc);
   }
+  return d_line_mul_l(v, La, Lb, Lc);
 }
-
 // digit of the Miller loop at position m: +1, -1 or 0 (wave-uniform; hostbn.h naf_of_half)
 static PBC_DEV int d_digit(int m) {
   return (int) ((c_d.r[m >> 5] >> (m & 31)) & 1) - (int) ((c_d.rm[m >> 5] >> (m & 31)) & 1);
@@ -869,12 +881,16 @@ static PBC_DEV bool d_setup_lane(const uint8_t *g1, const uint8_t *g2) {
   f3_mul_fq(Qy, Qy, dk(c_d.nqrinv2));
 #pragma unroll
   for (int i = 0; i < DEG; i++) { dl_put(DL_QX + ND * i, Qx.c[i]); dl_put(DL_QY + ND * i, Qy.c[i]); }
-  if constexpr (kLimbPoint) {
-    el x, y, o;
-    to_limbs<ND>(x, Px); to_limbs<ND>(y, Py); to_limbs<ND>(o, one);
-    DL_HS(hs_set(x, U_STRICT, 1.0); hs_set(y, U_STRICT, 1.0); hs_set(o, U_STRICT, 1.0);)
-    ll_put(DL_X, x); ll_put(DL_Y, y); ll_put(DL_Z, o);
-    ll_put(DL_PX, x); ll_put(DL_PY, y);
+  bool limb = false;
+  if constexpr (kLimbPoint) limb = c_d.limb_ok != 0;
+  if (limb) {
+    if constexpr (kLimbPoint) {
+      el x, y, o;
+      to_limbs<ND>(x, Px); to_limbs<ND>(y, Py); to_limbs<ND>(o, one);
+      DL_HS(hs_set(x, U_STRICT, 1.0); hs_set(y, U_STRICT, 1.0); hs_set(o, U_STRICT, 1.0);)
+      ll_put(DL_X, x); ll_put(DL_Y, y); ll_put(DL_Z, o);
+      ll_put(DL_PX, x); ll_put(DL_PY, y);
+    }
   } else {
     dl_put(DL_X, Px); dl_put(DL_Y, Py); dl_put(DL_Z, one);
     dl_put(DL_PX, Px); dl_put(DL_PY, Py);
@@ -1013,12 +1029,16 @@ static PBC_DEV bool d_pp_init_lane(uint32_t *tab, const uint8_t *g1) {
   fp_add<ND>(t0, t0, dk(c_d.B));
   fp_sqr<ND>(t1, Py);
   bool valid = fp_eq<ND>(t0, t1);
-  if constexpr (kLimbPoint) {
-    el x, y, o;
-    to_limbs<ND>(x, Px); to_limbs<ND>(y, Py); to_limbs<ND>(o, one);
-    DL_HS(hs_set(x, U_STRICT, 1.0); hs_set(y, U_STRICT, 1.0); hs_set(o, U_STRICT, 1.0);)
-    ll_put(DL_X, x); ll_put(DL_Y, y); ll_put(DL_Z, o);
-    ll_put(DL_PX, x); ll_put(DL_PY, y);
+  bool limb = false;
+  if constexpr (kLimbPoint) limb = c_d.limb_ok != 0;
+  if (limb) {
+    if constexpr (kLimbPoint) {
+      el x, y, o;
+      to_limbs<ND>(x, Px); to_limbs<ND>(y, Py); to_limbs<ND>(o, one);
+      DL_HS(hs_set(x, U_STRICT, 1.0); hs_set(y, U_STRICT, 1.0); hs_set(o, U_STRICT, 1.0);)
+      ll_put(DL_X, x); ll_put(DL_Y, y); ll_put(DL_Z, o);
+      ll_put(DL_PX, x); ll_put(DL_PY, y);
+    }
   } else {
     dl_put(DL_X, Px); dl_put(DL_Y, Py); dl_put(DL_Z, one);
     dl_put(DL_PX, Px); dl_put(DL_PY, Py);
@@ -1026,10 +1046,12 @@ static PBC_DEV bool d_pp_init_lane(uint32_t *tab, const uint8_t *g1) {
   int slot = 0;
   for (int m = c_d.rbits - 2;; m--) {
     fq la, lb, lc;
-    if constexpr (kLimbPoint) {        // the table stays in canonical word form
-      el a, b, c;
-      d_dbl_core_l(a, b, c);
-      l_to_fq(la, a); l_to_fq(lb, b); l_to_fq(lc, c);
+    if (limb) {                        // the table stays in canonical word form
+      if constexpr (kLimbPoint) {
+        el a, b, c;
+        d_dbl_core_l(a, b, c);
+        l_to_fq(la, a); l_to_fq(lb, b); l_to_fq(lc, c);
+      }
     } else {
       d_dbl_core(la, lb, lc);
     }
@@ -1037,10 +1059,12 @@ static PBC_DEV bool d_pp_init_lane(uint32_t *tab, const uint8_t *g1) {
     slot++;
     if (m <= 0) break;
     if (d_digit(m)) {
-      if constexpr (kLimbPoint) {
-        el a, b, c;
-        d_add_core_l(a, b, c, d_digit(m) < 0);
-        l_to_fq(la, a); l_to_fq(lb, b); l_to_fq(lc, c);
+      if (limb) {
+        if constexpr (kLimbPoint) {
+          el a, b, c;
+          d_add_core_l(a, b, c, d_digit(m) < 0);
+          l_to_fq(la, a); l_to_fq(lb, b); l_to_fq(lc, c);
+        }
       } else {
         d_add_core(la, lb, lc, d_digit(m) < 0);
       }

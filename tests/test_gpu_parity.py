@@ -267,12 +267,29 @@ def test_reference_call_sites_run_on_gpu_through_the_glue(pname):
 
 
 def test_f_generic_hard_part_on_gpu():
-    """Non-BN Type-F parameters use the fixed-window power; force it on f.param."""
+    """Non-BN Type-F parameters use plain square-and-multiply over the whole exponent; force it on f.param."""
     import pbc_amd
     from conftest import _param
     v = golden("f_rand16.vec")
     P = pbc_amd.Pairing(_param("f") + "hip_no_bn 1\n")
     assert np.array_equal(P.element_pairing(v.g1, v.g2), v.gt)
+
+
+def test_d_word_form_point_arithmetic_on_gpu():
+    """Type d parameters whose q leaves its top 29-bit limb nearly empty run the word-form step routines inside the
+    d159 kernels (DConst::limb_ok); force that path on d159.param: singles, products, preprocessing."""
+    import pbc_amd
+    from conftest import _param
+    P = pbc_amd.Pairing(_param("d159") + "hip_no_limb 1\n")
+    v = golden("d_rand32.vec")
+    assert np.array_equal(P.element_pairing(v.g1, v.g2), v.gt)
+    w = golden("d_prod3x10_edge.vec")
+    assert np.array_equal(P.element_prod_pairing(w.g1, w.g2, w.k), w.gt)
+    w = golden("d_prod16x4.vec")
+    assert np.array_equal(P.element_prod_pairing(w.g1, w.g2, w.k), w.gt)
+    pp = P.pp_init(v.g1[0])
+    assert np.array_equal(pp.apply(v.g2[:8]), P.element_pairing(np.repeat(v.g1[:1], 8, axis=0), v.g2[:8]))
+    assert np.array_equal(pp.apply(v.g2[:1]), v.gt[:1])
 
 
 @pytest.mark.parametrize("t,log2n", [("d", 18), ("f", 18)])

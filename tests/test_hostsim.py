@@ -54,10 +54,22 @@ def test_kernel_fq_ops_on_host(sims, oracles, t, q):
 
 def test_type_f_generic_hard_part_on_host():
     """f.param is a BN curve and takes the x-chain; the generic fixed-window power over
-    (q^4-q^2+1)/r (any Type-F parameters) must give the same bytes."""
+    (q^4-q^2+1)/r (any Type-F parameters; plain square-and-multiply) must give the same bytes."""
     v = golden("f_rand16.vec")
     sim = hostsim.HostSim(_param("f") + "hip_no_bn 1\n")
     assert np.array_equal(sim.prod_pairing(v.g1[:2], v.g2[:2], 1), v.gt[:2])
+
+
+def test_type_d_word_form_point_arithmetic_on_host():
+    """d159.param keeps the running point of its Miller loop in limb form; parameters whose q leaves the top limb
+    nearly empty take the word-form step routines inside the same kernels: force them on d159.param
+    ("hip_no_limb 1") -- single pairings, a product with edge cases, a preprocessed first argument."""
+    sim = hostsim.HostSim(_param("d159") + "hip_no_limb 1\n")
+    v = golden("d_rand32.vec")
+    assert np.array_equal(sim.prod_pairing(v.g1[:3], v.g2[:3], 1), v.gt[:3])
+    w = golden("d_prod3x10_edge.vec")
+    assert np.array_equal(sim.prod_pairing(w.g1[:4 * w.k], w.g2[:4 * w.k], w.k), w.gt[:4])
+    assert np.array_equal(sim.pp(v.g1[0], v.g2[:1]), v.gt[:1])
 
 
 def test_pairing_pp_on_host(sims, oracles):

@@ -394,7 +394,7 @@ static int init_type_d(pbc_hip_pairing_s *P, const char *txt, size_t len, int de
     param_int(txt, len, "hip_no_limb", no_limb);
     P->dconst.limb_ok = (ND == 5 && deg == 3 && q.bits() >= 29 * 5 + 8 && !no_limb) ? 1 : 0;
   }
-  P->dconst.rbits = pbc_host::naf_of_half(r, P->dconst.r, P->dconst.rm, 8);     // signed digits of the Miller loop
+  P->dconst.rbits = pbc_host::naf_of_half(r, P->dconst.r, P->dconst.rm, 9);     // signed digits of the Miller loop
   if (!P->dconst.rbits) return fail("%s: r too wide for the Miller loop digits", tn);
   // phikonr = Phi_k(q)/r: (q^2 - q + 1)/r (d_param.c:1036-1042), (q^4 - q^3 + q^2 - q + 1)/r (g_param.c:1288-1305)
   Big q2 = Big::mul(q, q);
@@ -476,7 +476,7 @@ static int init_type_f(pbc_hip_pairing_s *P, const char *txt, size_t len) {
   e6.to_words(P->fraw.e6, NF + 1);
   P->fraw.e6bits = e6.bits();
   if (r.bits() > 256 || r.bits() < 3) return fail("type f: bad r");
-  P->fconst.rbits = pbc_host::naf_of_half(r, P->fconst.r, P->fconst.rm, 8);     // signed digits of the Miller loop
+  P->fconst.rbits = pbc_host::naf_of_half(r, P->fconst.r, P->fconst.rm, 9);     // signed digits of the Miller loop
   if (!P->fconst.rbits) return fail("type f: r too wide for the Miller loop digits");
   // tateexp = ((q^2 - 1) q^2 + 1)/r (f_param.c:414-420)
   Big q2 = Big::mul(q, q), z = q2;

@@ -37,7 +37,7 @@ struct DConst {                        // pptr (ecc/d_param.c:40-51) + curve/fie
   uint32_t nqr[ND_MAX], nqrinv[ND_MAX], nqrinv2[ND_MAX];   // v, v^-1, v^-2 (d_param.c:1028-1032, :1072-1075)
   uint32_t xpowq[DEG_MAX - 1][DEG_MAX][ND_MAX];  // x^q, x^2q, (x^3q, x^4q) (d_param.c:1044-1050, g_param.c:1307-1316)
   uint32_t ta[ND_MAX], tb[ND_MAX];     // twist: y^2 = x^3 + a v^2 x + b v^3 (curve.c:885-901)
-  uint32_t r[8], rm[8];                // Miller loop digits: NAF of r >> 1, +1 digits in r[], -1 digits in rm[] (hostbn.h)
+  uint32_t r[9], rm[9];                // Miller loop digits: NAF of r >> 1, +1 digits in r[], -1 digits in rm[] (hostbn.h); a 256-bit r can put its leading digit at position 256
   uint32_t phik[16];                   // Phi_k(q)/r (d_param.c:1036-1042, g_param.c:1288-1305)
   int rbits, phikbits;
   // 1: the 5-word d = 3 kernels keep the point state in limb form (kLimbPoint).  Set by the host when q fills at least

@@ -33,7 +33,7 @@ struct FConst {                        // f_pairing_data_s (ecc/f_param.c:35-45)
   uint32_t negalphainv[2][NF_MAX];
   uint32_t xpowq2[2][NF_MAX], xpowq6[2][NF_MAX], xpowq8[2][NF_MAX];   // X^(q^k) = (this) X (f_param.c:431-444)
   uint32_t tb[2][NF_MAX];              // twist: y^2 = x^3 - alpha b (f_param.c:372-381)
-  uint32_t r[8], rm[8];                // Miller loop digits: NAF of r >> 1, +1 digits in r[], -1 digits in rm[] (hostbn.h)
+  uint32_t r[9], rm[9];                // Miller loop digits: NAF of r >> 1, +1 digits in r[], -1 digits in rm[] (hostbn.h); a 256-bit r can put its leading digit at position 256
   uint32_t tateexp[32];                // (q^4 - q^2 + 1)/r (f_param.c:414-420)
   int rbits, tebits;
   // BN structure (f_param.c:70-95 tryplusx/tryminusx): q = 36x^4+36x^3+24x^2+6x+1,

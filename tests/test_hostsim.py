@@ -38,7 +38,7 @@ def test_kernel_source_on_host_matches_reference(sims, name, count):
 
 
 @pytest.mark.parametrize("t,q", [("a", None), ("d", 625852803282871856053922297323874661378036491717)]
-                         + [(d, None) for d in OTHER + ["a_160_500", "a_224_768", "a1_200", "e_160_400", "f_256", "f_200"]])
+                         + [(d, None) for d in OTHER + ["a_160_500", "a_224_768", "a1_200", "e_160_400", "f_256", "f_200", "f_r256"]])
 def test_kernel_fq_ops_on_host(sims, oracles, t, q):
     if q is None:
         q = param_value(t, "p" if t.startswith("a1") else "q")
@@ -104,7 +104,7 @@ def test_pairing_pp_types_d_g_on_host(sims, oracles, t, name):
 
 
 @pytest.mark.parametrize("t,name", [("a", "a_rand32.vec"), ("d", "d_rand32.vec"), ("f", "f_rand16.vec")]
-                         + [(d, FILES_OF[d][0]) for d in OTHER + ["a_150_300_mm", "a1_200", "e_160_400", "f_256", "f_200"]])
+                         + [(d, FILES_OF[d][0]) for d in OTHER + ["a_150_300_mm", "a1_200", "e_160_400", "f_256", "f_200", "f_r256"]])
 def test_group_ops_on_host(sims, oracles, t, name):
     """element_mul_zn on G1, element_mul / element_pow_zn on GT vs the oracle."""
     v = golden(name)

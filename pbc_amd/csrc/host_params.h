@@ -199,27 +199,20 @@ static int init_type_a(pbc_hip_pairing_s *P, const char *txt, size_t len) {
   P->len_fq = (q.bits() + 7) / 8;
   P->len1 = P->len2 = P->lenT = 2 * P->len_fq;
   P->len_zr = (r.bits() + 7) / 8;
-  if (P->len_fq == 64) {
-    // the standard size (pbc_param_init_a_gen(160, 512), a.param): dedicated kernels -- Solinas loop
-    // with its single addition, 16-byte vector loads/stores of the 128-byte records
+  // the standard size (pbc_param_init_a_gen(160, 512), a.param): dedicated kernels -- Solinas loop with its single
+  // addition, 16-byte vector loads/stores of the 128-byte records, F_q in limb form.  The limb-form kernel's
+  // subtraction constants (AConst::ksub) borrow from q's top 29-bit limb: checked here for this q (hostbn.h
+  // ksub_build; the bound tracker of pairing_al.cuh assumes q >= 2^504); a q that fails runs on the generic kernels.
+  bool fast = P->len_fq == 64;
+  if (fast) {
+    static const uint32_t cd[5][2] = {{2, 1}, {4, 2}, {8, 4}, {12, 2}, {16, 2}};
+    for (int t = 0; t < 5; t++)
+      if (pbc_host::ksub_build(q, 18, 505, cd[t][0], cd[t][1], P->a.ksub[t])) fast = false;
+  }
+  if (fast) {
     if (fill_fpk<16>(P->k16, q)) return fail("type a: bad q");
     P->nlimb = 16;
     P->a_generic = false;
-    {                                    // subtraction constants of the limb-form kernel (AConst::ksub)
-      static const uint32_t cd[5][2] = {{2, 1}, {4, 2}, {8, 4}, {12, 2}, {16, 2}};
-      for (int t = 0; t < 5; t++) {
-        Big c;
-        c.w.push_back(cd[t][0]);
-        const Big v = Big::mul(q, c);
-        const uint32_t D = cd[t][1];
-        uint32_t *k = P->a.ksub[t];
-        for (int i = 0; i < 18; i++) {
-          uint32_t x = 0;
-          for (int b = 0; b < 29; b++) x |= (uint32_t) v.bit(29 * i + b) << b;
-          k[i] = x + (i < 17 ? D << 29 : 0) - (i > 0 ? D : 0);
-        }
-      }
-    }
   } else {
     // any other size up to 1056 bits: the type a1 kernels (plain double-and-add over the bits of r;
     // functions with the same divisor up to vertical lines, which the final power removes) on the
@@ -392,7 +385,13 @@ static int init_type_d(pbc_hip_pairing_s *P, const char *txt, size_t len, int de
     // from q's top 29-bit limb, which must hold at least 8 bits of q; "hip_no_limb 1" forces the word-form routines
     int no_limb = 0;
     param_int(txt, len, "hip_no_limb", no_limb);
-    P->dconst.limb_ok = (ND == 5 && deg == 3 && q.bits() >= 29 * 5 + 8 && !no_limb) ? 1 : 0;
+    P->dconst.limb_ok = (ND == 5 && deg == 3 && !no_limb) ? 1 : 0;
+    if (P->dconst.limb_ok) {             // the constants d_init_lane builds on the device, checked for this q (hostbn.h)
+      static const uint32_t cd[4][2] = {{2, 1}, {4, 2}, {16, 2}, {32, 2}};
+      uint32_t k[6];
+      for (int t = 0; t < 4; t++)
+        if (pbc_host::ksub_build(q, 6, 29 * 5 + 8, cd[t][0], cd[t][1], k)) P->dconst.limb_ok = 0;
+    }
   }
   P->dconst.rbits = pbc_host::naf_of_half(r, P->dconst.r, P->dconst.rm, 9);     // signed digits of the Miller loop
   if (!P->dconst.rbits) return fail("%s: r too wide for the Miller loop digits", tn);

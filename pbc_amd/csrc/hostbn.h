@@ -153,6 +153,45 @@ inline int naf_of_half(const Big &r, uint32_t *plus, uint32_t *minus, int words)
   return top + 1;
 }
 
+// Subtraction constants of the limb-form kernels (pairing_al.cuh, pairing_d.cuh): a - b is formed as a + (K - b) limb by
+// limb with K = c q written in "borrowed" 29-bit limbs -- limb_0 + D 2^29, limb_i + D 2^29 - D, limb_top - D -- so that
+// every limb of K dominates the corresponding limb of b.  The kernels' bound trackers (host mirror) prove for every call
+// site that  (c - B) 2^(minbits - 1 - 29 (L - 1)) >= D + 1  for the subtrahend's value bound B (in units of q): with
+// q >= 2^(minbits - 1) that puts K's top limb above any top limb b can have.  This routine is the other half, run at
+// init for the actual q: q has at least `minbits` bits, the limbs are built as the kernels expect, sum to c q, fit 32
+// bits and dominate D (2^29 - 1) below the top.  Returns the number of violations (0 = the limb-form path may be used).
+inline int ksub_build(const Big &q, int L, int minbits, uint32_t c, uint32_t D, uint32_t *k) {
+  int bad = 0;
+  if (q.bits() < minbits || q.bits() > 29 * L) bad++;
+  Big cb;
+  cb.w.push_back(c);
+  const Big v = Big::mul(q, cb);
+  if (v.bits() > 29 * (L - 1) + 32) bad++;
+  for (int i = 0; i < L; i++) {
+    uint64_t x = 0;
+    for (int b = 0; b < (i < L - 1 ? 29 : 32); b++) x |= (uint64_t) v.bit(29 * i + b) << b;
+    x += (i < L - 1 ? (uint64_t) D << 29 : 0);
+    if (i > 0) {
+      if (x < D) bad++;
+      x -= D;
+    }
+    if (x >> 32) bad++;
+    if (i < L - 1 && x < (uint64_t) D * ((1u << 29) - 1)) bad++;
+    if (i == L - 1 && x < (uint64_t) D + 1) bad++;
+    k[i] = (uint32_t) x;
+  }
+  Big sum;                                 // sum_i k_i 2^(29 i) == c q
+  for (int i = L - 1; i >= 0; i--) {
+    for (int b = 0; b < 29; b++) sum.shl1();
+    Big t;
+    t.w.push_back(k[i]);
+    t.trim();
+    sum = Big::add(sum, t);
+  }
+  if (Big::cmp(sum, v) != 0) bad++;
+  return bad;
+}
+
 inline bool param_lookup(const char *txt, size_t len, const char *key, std::string &val) {
   size_t klen = strlen(key), i = 0;
   while (i < len) {

@@ -71,7 +71,8 @@ struct AL {
   static void hs_dom(const el &b, int k) {                  // K_k dominates b
     hs_limbs(b);
     if (b.hs_u > KD[k] * U_STRICT + 1e-12) hs_fail("subtrahend limbs not dominated", b.hs_u);
-    if (b.hs_B > KC[k] - 0.001) hs_fail("subtrahend value not dominated", b.hs_B);
+    // top limb: K's is at least c q / 2^493 - 1 - D, b's at most B q / 2^493, and q >= 2^504 (init checks it)
+    if ((KC[k] - b.hs_B) * 2048.0 < KD[k] + 1) hs_fail("subtrahend value not dominated", b.hs_B);
   }
   static void hs_cols(double s) { if (s > 2.55) hs_fail("column capacity", s); }
 #define AL_HS(...) __VA_ARGS__

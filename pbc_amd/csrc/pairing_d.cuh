@@ -591,7 +591,8 @@ static void hs_set(el &r, double u, double B) { r.hs_u = u; r.hs_B = B; hs_limbs
 static void hs_dom(const el &b, int k) {
   hs_limbs(b);
   if (b.hs_u > KD[k] * U_STRICT + 1e-12) hs_fail("subtrahend limbs not dominated", b.hs_u);
-  if (b.hs_B > KC[k] - 0.001) hs_fail("subtrahend value not dominated", b.hs_B);
+  // top limb: K's is at least c q / 2^145 - 1 - D, b's at most B q / 2^145, and q >= 2^152 (init checks it: limb_ok)
+  if ((KC[k] - b.hs_B) * 128.0 < KD[k] + 1) hs_fail("subtrahend value not dominated", b.hs_B);
 }
 static void hs_cols(double s) { if (s > (64.0 - FLW) / FLW - 0.01) hs_fail("column capacity", s); }
 #define DL_HS(...) __VA_ARGS__

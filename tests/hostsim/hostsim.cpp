@@ -77,8 +77,9 @@ void *hostsim_init(const char *param, size_t len) {
   return P;
 }
 const char *hostsim_error() { return g_err; }
-// The subtraction constants of the limb-form type a kernel (AConst::ksub, filled by host_params.h): returns the number of
-// violations of  sum_i k_i 2^(29 i) == c q,  k_i >= D (2^29 - 1) for i < 17,  k_i < 2^32,  k_17 >= floor((c - 0.001) q / 2^493).
+// The subtraction constants of the limb-form type a kernel (AConst::ksub): rebuilt and checked by the routine init itself
+// runs (hostbn.h ksub_build: sum_i k_i 2^(29 i) == c q, k_i >= D (2^29 - 1) below the top, k_i < 2^32, q >= 2^504);
+// returns the number of violations, counting a stored constant that differs from the rebuilt one.
 int hostsim_check_ksub(void *h) {
   using pbc_host::Big;
   pbc_hip_pairing_s *P = (pbc_hip_pairing_s *) h;
@@ -89,24 +90,9 @@ int hostsim_check_ksub(void *h) {
   q.trim();
   int bad = 0;
   for (int t = 0; t < 5; t++) {
-    Big sum, c;
-    c.w.push_back(cd[t][0]);
-    for (int i = 17; i >= 0; i--) {
-      for (int b = 0; b < 29; b++) sum.shl1();
-      Big k;
-      k.w.push_back(P->a.ksub[t][i]);
-      k.trim();
-      sum = Big::add(sum, k);
-      if (i < 17 && (uint64_t) P->a.ksub[t][i] < (uint64_t) cd[t][1] * ((1u << 29) - 1)) bad++;
-    }
-    if (Big::cmp(sum, Big::mul(q, c)) != 0) bad++;
-    // top limb: at least that of (c - 1/1024) q, so that every subtrahend below (c - 0.001) q is dominated
-    Big lim = Big::mul(q, c), m1024, rem;
-    m1024.w.push_back(1024);
-    lim.sub(Big::div(q, m1024, &rem));
-    uint32_t top = 0;
-    for (int b = 0; b < 29; b++) top |= (uint32_t) lim.bit(29 * 17 + b) << b;
-    if (P->a.ksub[t][17] < top) bad++;
+    uint32_t k[18];
+    bad += pbc_host::ksub_build(q, 18, 505, cd[t][0], cd[t][1], k);
+    for (int i = 0; i < 18; i++) bad += k[i] != P->a.ksub[t][i];
   }
   return bad;
 }

@@ -67,6 +67,40 @@ int main(int argc, char **argv) {
     printf("%s: element_from_hash_batch on G1 and G2: %s\n", argv[1], fails ? "FAIL" : "PASS");
     return fails ? 1 : 0;
   }
+  if (argc > 3 && !strcmp(argv[3], "lifetime")) {
+    /* orders of pairing_pp_clear / pairing_clear / detach that stock PBC tolerates, and the empty product in a batch */
+    int fails = 0;
+    element_t P, Q, want, got;
+    element_init_G1(P, pairing); element_init_G2(Q, pairing); element_init_GT(want, pairing); element_init_GT(got, pairing);
+    element_random(P); element_random(Q);
+    element_pairing(want, P, Q);                                             /* CPU */
+    if (pbc_hip_attach(pairing, text, len)) { printf("ATTACH FAILED\n"); return 1; }
+    pairing_pp_t pp1, pp2, pp3;
+    pairing_pp_init(pp1, P, pairing);                                        /* GPU */
+    pairing_pp_apply(got, Q, pp1);
+    if (element_cmp(got, want)) { printf("pp_apply mismatch (attached)\n"); fails++; }
+    pbc_hip_detach(pairing);                                                 /* pp1 still alive */
+    pairing_pp_init(pp2, P, pairing);                                        /* CPU again */
+    pairing_pp_apply(got, Q, pp2);
+    if (element_cmp(got, want)) { printf("pp_apply mismatch (detached)\n"); fails++; }
+    pairing_pp_clear(pp1);                                                   /* a GPU-made object cleared after the detach */
+    pairing_pp_clear(pp2);
+    if (pbc_hip_attach(pairing, text, len)) { printf("RE-ATTACH FAILED\n"); return 1; }
+    pairing_pp_init(pp3, P, pairing);
+    pairing_pp_apply(got, Q, pp3);
+    if (element_cmp(got, want)) { printf("pp_apply mismatch (re-attached)\n"); fails++; }
+    {
+      element_t o[3];
+      for (int i = 0; i < 3; i++) { element_init_GT(o[i], pairing); element_set(o[i], want); }
+      if (element_prod_pairing_batch(o, &P, &Q, 3, 0)) { printf("empty products failed\n"); fails++; }
+      for (int i = 0; i < 3; i++) { if (!element_is1(o[i])) { printf("empty product is not 1\n"); fails++; } element_clear(o[i]); }
+    }
+    element_clear(P); element_clear(Q); element_clear(want); element_clear(got);
+    pairing_clear(pairing);                                                  /* detaches; pp3 still alive */
+    pairing_pp_clear(pp3);                                                   /* stock PBC allows this order */
+    printf("%s: pairing_pp_t lifetimes across detach / pairing_clear: %s\n", argv[1], fails ? "FAIL" : "PASS");
+    return fails ? 1 : 0;
+  }
   int fails = 0, K = 4;
   if (n < 24) n = 24;                  /* the fixed-index sections below use up to 24 elements */
   element_t *P = malloc(sizeof(element_t) * n), *Q = malloc(sizeof(element_t) * n);

@@ -56,6 +56,24 @@ static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER;
 /* calls that ran on the GPU (reported at exit when PBC_HIP_VERBOSE=1; the preload test reads them) */
 static struct { unsigned long map, prod, pp_init, pp_apply, batch_units, finalpow; } g_stat;
 
+/* pairing_pp_t objects made by the hooks below, and the pairings that were detached while some were alive.
+ * pairing_pp_clear / pairing_pp_apply dispatch through pairing->pp_clear / pp_apply (include/pbc_pairing.h:79-98), and
+ * stock PBC lets a program clear a pairing_pp_t AFTER pairing_clear: the CPU routines restored by a detach must never
+ * see a GPU handle.  So detach releases the GPU side of every live object (marking it dead), and -- only while such
+ * objects exist -- leaves the three pp hooks installed with the pairing's CPU routines parked in a "retired" record:
+ * a dead object is freed by the hook, applying it dies with a message, objects made on the CPU pass through. */
+typedef struct { void *pp, *data; struct pairing_s *pairing; int kind /* 1 GPU handle, 2 element copy */, dead; } ppreg_t;
+static ppreg_t *g_pp;
+static int g_npp, g_cpp;
+typedef struct {
+  struct pairing_s *pairing;
+  void (*cpu_pp_init)(pairing_pp_t, element_t, struct pairing_s *);
+  void (*cpu_pp_clear)(pairing_pp_t);
+  void (*cpu_pp_apply)(element_t, element_t, pairing_pp_t);
+} retired_t;
+static retired_t *g_ret;
+static int g_nret, g_cret;
+
 static attach_t *find(struct pairing_s *p) {
   attach_t *r = NULL;
   pthread_mutex_lock(&g_lock);
@@ -176,6 +194,7 @@ static void *gpu_job_main(void *arg);
 
 /* n*k (in1, in2) terms -> n GT results.  `out` are GT elements (the mulg wrapper, ecc/pairing.c:135-283). */
 static int run_batch(attach_t *a, element_t out[], element_t in1[], element_t in2[], size_t n, int k) {
+  if (k < 1) { for (size_t u = 0; u < n; u++) element_set1(out[u]); return 0; }   /* empty products, as hip_prod */
   int l1 = L.len1(a->gpu), l2 = L.len2(a->gpu), lt = L.lenT(a->gpu);
   size_t terms = n * (size_t) k, m = 0;
   unsigned char *b1 = pinned(a, 0, terms * l1), *b2 = pinned(a, 1, terms * l2), *bt = pinned(a, 2, n * lt);
@@ -270,50 +289,123 @@ static void hip_finalpow(element_t e) {
 }
 
 /* pairing->pp_init / pp_apply / pp_clear replacements (include/pbc_pairing.h:39-41, 54-89).
- * p->data holds the GPU handle.  Installed for types a, d and g (plain_pp_* below for the rest). */
+ * p->data holds the GPU handle (types a, a1, d, g) or a copy of the first argument (types e, f: no preprocessed form
+ * on the GPU, every apply is an ordinary GPU pairing).  Every object is entered in g_pp (see there). */
+static void pp_forget(void *pp) {                          /* a pairing_pp_t reused at the same address */
+  pthread_mutex_lock(&g_lock);
+  for (int i = 0; i < g_npp; ) if (g_pp[i].pp == pp) g_pp[i] = g_pp[--g_npp]; else i++;
+  pthread_mutex_unlock(&g_lock);
+}
+static void pp_register(void *pp, void *data, struct pairing_s *pairing, int kind) {
+  pp_forget(pp);
+  pthread_mutex_lock(&g_lock);
+  if (g_npp == g_cpp) {
+    int nc = g_cpp ? 2 * g_cpp : 16;
+    ppreg_t *t = realloc(g_pp, (size_t) nc * sizeof *t);
+    if (!t) { pthread_mutex_unlock(&g_lock); pbc_die("pbc_hip: out of memory"); }
+    g_pp = t; g_cpp = nc;
+  }
+  g_pp[g_npp++] = (ppreg_t) {pp, data, pairing, kind, 0};
+  pthread_mutex_unlock(&g_lock);
+}
+/* 1 and *e filled when `p` was made by these hooks (take: remove the entry) */
+static int pp_lookup(pairing_pp_t p, ppreg_t *e, int take) {
+  int found = 0;
+  pthread_mutex_lock(&g_lock);
+  for (int i = 0; i < g_npp; i++)
+    if (g_pp[i].pp == (void *) p && g_pp[i].data == p->data) {
+      *e = g_pp[i];
+      if (take) g_pp[i] = g_pp[--g_npp];
+      found = 1;
+      break;
+    }
+  pthread_mutex_unlock(&g_lock);
+  return found;
+}
+static int retired_find(struct pairing_s *pairing, retired_t *out) {
+  int found = 0;
+  pthread_mutex_lock(&g_lock);
+  for (int i = 0; i < g_nret; i++) if (g_ret[i].pairing == pairing) { *out = g_ret[i]; found = 1; break; }
+  pthread_mutex_unlock(&g_lock);
+  return found;
+}
+static void retired_drop(struct pairing_s *pairing) {
+  pthread_mutex_lock(&g_lock);
+  for (int i = 0; i < g_nret; ) if (g_ret[i].pairing == pairing) g_ret[i] = g_ret[--g_nret]; else i++;
+  pthread_mutex_unlock(&g_lock);
+}
+static void pp_release(const ppreg_t *e) {                  /* the resources behind a live entry */
+  if (e->kind == 1) L.pp_clear(e->data);
+  else { element_clear(e->data); free(e->data); }
+}
+
 static void hip_pp_init(pairing_pp_t p, element_t in1, struct pairing_s *pairing) {
   attach_t *a = find(pairing);
-  unsigned char *buf = xmalloc(L.len1(a->gpu));
-  void *h = NULL;
-  element_to_bytes(buf, in1);
-  if (L.pp_init(&h, a->gpu, buf)) pbc_die("pbc_hip: pairing_pp_init: %s", L.err());
-  p->data = h;
-  g_stat.pp_init++;
-  free(buf);
+  if (!a) {                                                /* detached, hooks still installed for older objects */
+    retired_t r;
+    if (!retired_find(pairing, &r)) pbc_die("pbc_hip: pairing_pp_init on a pairing that is not attached");
+    pp_forget(p);
+    r.cpu_pp_init(p, in1, pairing);
+    return;
+  }
+  int t = L.type(a->gpu);
+  if (t == 'a' || t == '1' || t == 'd' || t == 'g') {
+    unsigned char *buf = xmalloc(L.len1(a->gpu));
+    void *h = NULL;
+    element_to_bytes(buf, in1);
+    if (L.pp_init(&h, a->gpu, buf)) pbc_die("pbc_hip: pairing_pp_init: %s", L.err());
+    p->data = h;
+    g_stat.pp_init++;
+    free(buf);
+    pp_register(p, h, pairing, 1);
+  } else {
+    element_ptr c = xmalloc(sizeof(*c));
+    element_init_same_as(c, in1);
+    element_set(c, in1);
+    p->data = c;
+    pp_register(p, c, pairing, 2);
+  }
 }
-static void hip_pp_clear(pairing_pp_t p) { if (p->data) L.pp_clear(p->data); }
+static void hip_pp_clear(pairing_pp_t p) {
+  ppreg_t e;
+  if (pp_lookup(p, &e, 1)) { if (!e.dead) pp_release(&e); return; }
+  attach_t *a = find(p->pairing);                          /* made on the CPU, before the attach or after a detach */
+  retired_t r;
+  if (a) a->cpu_pp_clear(p); else if (retired_find(p->pairing, &r)) r.cpu_pp_clear(p);
+}
 static void hip_pp_apply(element_t out, element_t in2, pairing_pp_t p) {
+  ppreg_t e;
   attach_t *a = find(p->pairing);
+  if (!pp_lookup(p, &e, 0)) {
+    /* not made by these hooks.  On an attached pairing that is an object initialised before the attach: there is no
+     * GPU form of it and no CPU path here (initialise it after pbc_hip_attach).  On a detached pairing the hook is only
+     * still installed for older objects (see g_pp): the pairing is a stock CPU pairing again, pass through. */
+    retired_t r;
+    if (a || !retired_find(p->pairing, &r)) pbc_die("pbc_hip: pairing_pp_apply: this pairing_pp_t was not initialised on the GPU");
+    r.cpu_pp_apply(out, in2, p);
+    return;
+  }
+  if (e.dead || !a) pbc_die("pbc_hip: pairing_pp_apply on a pairing_pp_t whose pairing was cleared or detached from the GPU");
+  if (e.kind == 2) { hip_map(out, e.data, in2, p->pairing); return; }
   int l2 = L.len2(a->gpu), lt = L.lenT(a->gpu);
   unsigned char *buf = xmalloc((size_t) l2 + lt);
   element_to_bytes(buf, in2);
-  if (!p->data || L.pp_apply(p->data, buf + l2, buf, 1)) pbc_die("pbc_hip: pairing_pp_apply: %s", L.err());
+  if (L.pp_apply(e.data, buf + l2, buf, 1)) pbc_die("pbc_hip: pairing_pp_apply: %s", L.err());
   element_from_bytes(out, buf + l2);
   g_stat.pp_apply++;
   free(buf);
 }
-/* Types without a preprocessed form on the GPU (a1, e, f): pairing_pp keeps a copy of the first
- * argument and every apply is an ordinary GPU pairing. */
-static void plain_pp_init(pairing_pp_t p, element_t in1, struct pairing_s *pairing) {
-  (void) pairing;
-  element_ptr c = xmalloc(sizeof(*c));
-  element_init_same_as(c, in1);
-  element_set(c, in1);
-  p->data = c;
-}
-static void plain_pp_clear(pairing_pp_t p) { if (p->data) { element_clear(p->data); free(p->data); } }
-static void plain_pp_apply(element_t out, element_t in2, pairing_pp_t p) { hip_map(out, p->data, in2, p->pairing); }
 
 /* outs[i] = e(P, in2[i]) for the P given to pairing_pp_init: pairing_pp_apply over a batch */
 int pairing_pp_apply_batch(element_t out[], element_t in2[], size_t n, pairing_pp_t p) {
   if (!n) return 0;
   if (!p->pairing) { for (size_t i = 0; i < n; i++) element_set0(out[i]); return 0; }   /* P was O */
   attach_t *a = find(p->pairing);
-  if (!a || !p->data) return 1;
-  if (p->pairing->pp_apply != hip_pp_apply) {
-    /* no preprocessed form on the GPU for this type (a1, e, f): p->data is a copy of the first
-     * argument (plain_pp_init) -- run the batch as n ordinary pairings */
-    if (p->pairing->pp_apply != plain_pp_apply) return 1;
+  ppreg_t e;
+  if (!a || !p->data || !pp_lookup(p, &e, 0) || e.dead) return 1;
+  if (e.kind == 2) {
+    /* no preprocessed form on the GPU for this type (e, f): p->data is a copy of the first
+     * argument -- run the batch as n ordinary pairings */
     element_t *ps = malloc(n * sizeof(element_t));
     if (!ps) return 1;
     for (size_t i = 0; i < n; i++) ps[i][0] = *(element_ptr) p->data;     /* shallow, read-only */
@@ -420,30 +512,59 @@ int pbc_hip_attach(pairing_t pairing, const char *param, size_t len) {
   if (!registered) { registered = 1; atexit(report_at_exit); }
   a->pairing = pairing; a->gpu = g; a->cpu_map = pairing->map; a->cpu_prod = pairing->prod_pairings;
   a->cpu_pp_init = pairing->pp_init; a->cpu_pp_clear = pairing->pp_clear; a->cpu_pp_apply = pairing->pp_apply;
+  {
+    /* detached earlier with pairing_pp_t objects alive: the pp hooks are still installed, the CPU routines are in the
+     * retired record; a record left by another pairing that lived at this address is stale */
+    retired_t r;
+    if (retired_find(pairing, &r) && pairing->pp_clear == hip_pp_clear) { a->cpu_pp_init = r.cpu_pp_init; a->cpu_pp_clear = r.cpu_pp_clear; a->cpu_pp_apply = r.cpu_pp_apply; }
+    retired_drop(pairing);
+  }
   a->cpu_clear = pairing->clear_func;
   a->cpu_finalpow = pairing->finalpow;
   pairing->finalpow = hip_finalpow;
   pairing->map = hip_map;
   pairing->prod_pairings = hip_prod;
   pairing->clear_func = hip_clear;
-  {
-    /* preprocessed pairings exist on the GPU for types a, a1 ('1'), d and g */
-    int t = L.type(g);
-    if (t == 'a' || t == '1' || t == 'd' || t == 'g') {
-      pairing->pp_init = hip_pp_init; pairing->pp_clear = hip_pp_clear; pairing->pp_apply = hip_pp_apply;
-    } else {
-      pairing->pp_init = plain_pp_init; pairing->pp_clear = plain_pp_clear; pairing->pp_apply = plain_pp_apply;
-    }
-  }
+  /* preprocessed pairings exist on the GPU for types a, a1 ('1'), d and g; for the others pairing_pp_t keeps a copy of
+   * the first argument (hip_pp_init) */
+  pairing->pp_init = hip_pp_init; pairing->pp_clear = hip_pp_clear; pairing->pp_apply = hip_pp_apply;
   return 0;
 }
 void pbc_hip_detach(pairing_t pairing) {
   attach_t *a = find(pairing);
   if (!a) return;
   pairing->map = a->cpu_map; pairing->prod_pairings = a->cpu_prod;
-  pairing->pp_init = a->cpu_pp_init; pairing->pp_clear = a->cpu_pp_clear; pairing->pp_apply = a->cpu_pp_apply;
   pairing->clear_func = a->cpu_clear;
   pairing->finalpow = a->cpu_finalpow;
+  /* pairing_pp_t objects of this pairing that are still alive: release what they hold now (the GPU object goes away, the
+   * fields may be cleared next), keep their entries so that a later pairing_pp_clear is recognised */
+  int live = 0;
+  for (;;) {
+    ppreg_t e = {0};
+    int have = 0;
+    pthread_mutex_lock(&g_lock);
+    for (int i = 0; i < g_npp && !have; i++)
+      if (g_pp[i].pairing == pairing && !g_pp[i].dead) { g_pp[i].dead = 1; e = g_pp[i]; have = 1; }
+    pthread_mutex_unlock(&g_lock);
+    if (!have) break;
+    pp_release(&e);
+  }
+  pthread_mutex_lock(&g_lock);
+  for (int i = 0; i < g_npp; i++) live += g_pp[i].pairing == pairing;
+  pthread_mutex_unlock(&g_lock);
+  if (live) {
+    pthread_mutex_lock(&g_lock);
+    if (g_nret == g_cret) {
+      int nc = g_cret ? 2 * g_cret : 8;
+      retired_t *t = realloc(g_ret, (size_t) nc * sizeof *t);
+      if (!t) { pthread_mutex_unlock(&g_lock); pbc_die("pbc_hip: out of memory"); }
+      g_ret = t; g_cret = nc;
+    }
+    g_ret[g_nret++] = (retired_t) {pairing, a->cpu_pp_init, a->cpu_pp_clear, a->cpu_pp_apply};
+    pthread_mutex_unlock(&g_lock);
+  } else {
+    pairing->pp_init = a->cpu_pp_init; pairing->pp_clear = a->cpu_pp_clear; pairing->pp_apply = a->cpu_pp_apply;
+  }
   L.clear(a->gpu);
   drop_entry(a);
 }

@@ -88,6 +88,7 @@ def lib():
         L.pbc_hip_host_alloc.argtypes = [ctypes.POINTER(vp), sz]
         L.pbc_hip_host_free.argtypes = [vp]
         L.pbc_hip_host_free.restype = None
+        L.pbc_hip_pairing_release_workspaces.argtypes = [vp]
         _lib = L
     return _lib
 
@@ -109,6 +110,7 @@ EXPORTS = (
     "pbc_hip_pairing_length_in_bytes_x_only_G1", "pbc_hip_element_to_bytes_x_only_batch",
     "pbc_hip_pairing_length_in_bytes_compressed_G2", "pbc_hip_pairing_length_in_bytes_x_only_G2",
     "pbc_hip_element_from_bytes_x_only_batch", "pbc_hip_host_alloc", "pbc_hip_host_free", "pbc_hip_finalpow_batch",
+    "pbc_hip_pairing_release_workspaces",
 )
 
 
@@ -190,6 +192,11 @@ class Pairing:
     def element_prod_pairing_dev(self, d_gt, d_g1, d_g2, n, k, stream=0):
         if lib().pbc_hip_element_prod_pairing_batch_dev(self._h, d_gt, d_g1, d_g2, n, k, stream):
             raise PbcHipError("element_prod_pairing_dev: " + _err())
+
+    def release_workspaces(self):
+        """free the per-stream workspaces of the product kernels now (include/pbc_hip.h)"""
+        if lib().pbc_hip_pairing_release_workspaces(self._h):
+            raise PbcHipError("release_workspaces: " + _err())
 
     # ---- group operations ------------------------------------------------------------------
     def _scalars(self, zr, n):

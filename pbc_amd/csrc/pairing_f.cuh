@@ -52,7 +52,10 @@ struct FRaw { uint32_t b[NF_MAX], beta[NF_MAX], alpha0[NF_MAX], alpha1[NF_MAX]; 
 // LDS staging area of the F_q^12 products: the limb forms (x, y of six coefficients) of one operand per lane,
 // limb-major for 128-lane workgroups (36 KB for the 5-word field: four workgroups per CU)
 // (5-word fields: two such areas, so that the Miller accumulator can be updated from one into the other)
-template <int ND> constexpr int kF12Bufs = Limbs29<ND>::L <= 6 ? 2 : 1;
+#ifndef PBC_F_AREAS
+#define PBC_F_AREAS 1                  // LDS areas of the 5-word fields: 1 (36 KB per workgroup, two waves per SIMD) or 2 (72 KB, one)
+#endif
+template <int ND> constexpr int kF12Bufs = Limbs29<ND>::L <= 6 ? PBC_F_AREAS : 1;
 template <int ND> __shared__ uint32_t g_lds_f12[kF12Bufs<ND> * 12 * Limbs29<ND>::L * 128];
 
 // Everything below is per field width: ND 32-bit words per F_q element (5 for f.param, 8 for 256-bit BN fields).
@@ -417,7 +420,37 @@ static __device__ __noinline__ void f_line_mul(f12 *v, v5 va, v5 vb, v5 vc, cons
 // the current area at LDS speed -- also the partner coefficient of a product, whose index depends on the rolled output
 // loop -- and writes the result coefficients into the other area.  Register needs stay small (no spills), at the price
 // of 72 KB of LDS per workgroup: one wave per SIMD.
-static constexpr bool kLdsMiller = kF12Bufs<ND> == 2;
+static constexpr bool kLdsMiller = FL <= 6;
+static constexpr bool kOneArea = kF12Bufs<ND> == 1;
+static PBC_DEV int next_area(int cur) { return kOneArea ? 0 : cur ^ 1; }
+// Where the coefficients of a result go while the operand area is still being read.  Two areas: straight into the
+// other one.  One area (the default: 36 KB of LDS per workgroup, so that two waves share a SIMD -- a single wave gets a
+// multiply-add through only every 9.1 cycles, two share the pipe at 4.6): a 72-word buffer in the lane's private memory,
+// copied over the operand once the last coefficient is done (72 scratch stores, 72 loads and 72 LDS stores against the
+// ~7000 instructions of an F_q^12 operation).
+struct OutArea {
+  uint32_t buf[kOneArea ? 12 * FL : 1];
+  int dst;
+  PBC_DEV void put(int c, int part, const fl<ND> &a) {
+    if constexpr (kOneArea) {
+#pragma unroll
+      for (int l = 0; l < FL; l++) buf[(c * 2 + part) * FL + l] = a.l[l];
+    } else {
+      ldsf_put(c, part, a, dst);
+    }
+  }
+  PBC_DEV void finish() {
+    if constexpr (kOneArea) {
+#pragma unroll
+      for (int c = 0; c < 12; c++) {
+        fl<ND> t;
+#pragma unroll
+        for (int l = 0; l < FL; l++) t.l[l] = buf[c * FL + l];
+        ldsf_put(c >> 1, c & 1, t, 0);
+      }
+    }
+  }
+};
 static PBC_DEV fl<ND> flk(const uint32_t *w) { fl<ND> r; to_limbs<ND>(r, dk(w)); return r; }   // a constant's limb form
 // accumulator overflow guard: fold the running sum through one Montgomery reduction and carry it on as a single
 // product with R mod q (t R / R = t)
@@ -430,6 +463,8 @@ static PBC_DEV void wide_carry(wide<ND> &W, const fl<ND> &oneL) {
 // area `cur` squared into area 1 - cur.  Coefficient k + 6 of the plain square is reduced first and enters coefficient k
 // through X^(6+k) = negalpha X^k as four more products of the same lazy sums: one reduction per output component.
 static __device__ __noinline__ void f12_sqr_lds(int cur) {
+  OutArea O;
+  O.dst = kOneArea ? 0 : 1 - cur;
   fl<ND> by[6];                                  // beta y_i for the compile-time index of each pair
 #pragma unroll
   for (int i = 0; i < 6; i++) { const fl<ND> xx[1] = {ldsf_get(i, 1, cur)}, yy[1] = {fl29(c_f.beta29)}; sop_limbs<ND, 1>(by[i], xx, yy); }
@@ -482,16 +517,19 @@ static __device__ __noinline__ void f12_sqr_lds(int cur) {
         }
         fl<ND> o;
         wide_reduce<ND>(o, Wx);
-        ldsf_put(kk, 0, o, 1 - cur);
+        O.put(kk, 0, o);
         wide_reduce<ND>(o, Wy);
-        ldsf_put(kk, 1, o, 1 - cur);
+        O.put(kk, 1, o);
       }
     }
   }
+  O.finish();
 }
 // area `cur` times (a Qx X^4 + b Qy X^3 + c) into area 1 - cur (f_miller_evalfn, f_param.c:109-149): the formulas of
 // f_line_mul
 static __device__ __noinline__ void f_line_mul_lds(int cur, v5 va, v5 vb, v5 vc, const g2 *Qx, const g2 *Qy) {
+  OutArea O;
+  O.dst = kOneArea ? 0 : 1 - cur;
   fq a, b, c;
   from_vec<ND>(a, va);
   from_vec<ND>(b, vb);
@@ -525,18 +563,21 @@ static __device__ __noinline__ void f_line_mul_lds(int cur, v5 va, v5 vb, v5 vc,
     {
       const fl<ND> x[5] = {cl, fa.x, fa.by, fb.x, fb.by}, y[5] = {vix, vjx, vjy, vkx, vky};
       sop_limbs<ND, 5>(t, x, y);
-      ldsf_put(i, 0, t, 1 - cur);
+      O.put(i, 0, t);
     }
     {
       const fl<ND> x[5] = {cl, fa.x, fa.y, fb.x, fb.y}, y[5] = {viy, vjy, vjx, vky, vkx};
       sop_limbs<ND, 5>(t, x, y);
-      ldsf_put(i, 1, t, 1 - cur);
+      O.put(i, 1, t);
     }
   }
+  O.finish();
 }
 // area `cur` times the private-memory element b into area 1 - cur (b's limb forms in registers with compile-time
 // indices, the accumulator's coefficients from LDS; fold as in f12_sqr_lds)
 static __device__ __noinline__ void f12_mul_lds(int cur, const f12 *b) {
+  OutArea O;
+  O.dst = kOneArea ? 0 : 1 - cur;
   f12r B;
   f12_load_regs(B, b, false);
 #pragma nounroll
@@ -576,12 +617,13 @@ static __device__ __noinline__ void f12_mul_lds(int cur, const f12 *b) {
         }
         fl<ND> o;
         wide_reduce<ND>(o, Wx);
-        ldsf_put(kk, 0, o, 1 - cur);
+        O.put(kk, 0, o);
         wide_reduce<ND>(o, Wy);
-        ldsf_put(kk, 1, o, 1 - cur);
+        O.put(kk, 1, o);
       }
     }
   }
+  O.finish();
 }
 // a private-memory element into area `buf`
 static PBC_DEV void f12_lds_import(const f12 *a, int buf) {
@@ -667,7 +709,7 @@ static __device__ __noinline__ bool f_miller_lane(f12 *v, const uint8_t *g1, con
       fp_mul<ND>(lc, M, V.X);
       fp_dbl<ND>(t1, YY);
       fp_sub<ND>(lc, lc, t1);
-      if constexpr (kLdsMiller) { f_line_mul_lds(cur, to_vec<ND>(la), to_vec<ND>(lb), to_vec<ND>(lc), &Qx, &Qy); cur ^= 1; }
+      if constexpr (kLdsMiller) { f_line_mul_lds(cur, to_vec<ND>(la), to_vec<ND>(lb), to_vec<ND>(lc), &Qx, &Qy); cur = next_area(cur); }
       else f_line_mul(v, to_vec<ND>(la), to_vec<ND>(lb), to_vec<ND>(lc), &Qx, &Qy);
       fp_mul<ND>(S, V.X, YY);
       fp_dbl<ND>(S, S);
@@ -704,7 +746,7 @@ static __device__ __noinline__ bool f_miller_lane(f12 *v, const uint8_t *g1, con
       fp_mul<ND>(lc, R, Px);
       fp_mul<ND>(t0, Z3, Pys);
       fp_sub<ND>(lc, lc, t0);
-      if constexpr (kLdsMiller) { f_line_mul_lds(cur, to_vec<ND>(la), to_vec<ND>(Z3), to_vec<ND>(lc), &Qx, &Qy); cur ^= 1; }
+      if constexpr (kLdsMiller) { f_line_mul_lds(cur, to_vec<ND>(la), to_vec<ND>(Z3), to_vec<ND>(lc), &Qx, &Qy); cur = next_area(cur); }
       else f_line_mul(v, to_vec<ND>(la), to_vec<ND>(Z3), to_vec<ND>(lc), &Qx, &Qy);
       fp_sqr<ND>(HH, H);
       fp_mul<ND>(HHH, HH, H);
@@ -721,7 +763,7 @@ static __device__ __noinline__ bool f_miller_lane(f12 *v, const uint8_t *g1, con
       V.Z = Z3;
       fp_sqr<ND>(V.ZZ, Z3);
     }
-    if constexpr (kLdsMiller) { f12_sqr_lds(cur); cur ^= 1; } else f12_sqr(v, v);
+    if constexpr (kLdsMiller) { f12_sqr_lds(cur); cur = next_area(cur); } else f12_sqr(v, v);
   }
   if constexpr (kLdsMiller) f12_lds_export(v, cur);
   return valid;
@@ -753,8 +795,8 @@ static __device__ __noinline__ void f12_pow_x(f12 *r, const f12 *a) {
 #pragma nounroll
     for (int i = c_f.bn_xbits - 2; i >= 0; i--) {
       f12_sqr_lds(cur);
-      cur ^= 1;
-      if ((c_f.bn_x[i >> 5] >> (i & 31)) & 1) { f12_mul_lds(cur, a); cur ^= 1; }
+      cur = next_area(cur);
+      if ((c_f.bn_x[i >> 5] >> (i & 31)) & 1) { f12_mul_lds(cur, a); cur = next_area(cur); }
     }
     f12_lds_export(r, cur);                      // r may be a: a is no longer read
   } else {

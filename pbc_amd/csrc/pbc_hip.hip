@@ -59,6 +59,16 @@ extern "C" const char *pbc_hip_last_error(void) { return g_err; }
 // kernels
 // ---------------------------------------------------------------------------------------
 constexpr int kBlock = 128;
+// Resident workgroups (the 5-word type f kernel).  The kernel is launched with at most as many workgroups as the chip
+// holds at once (resident_grid below) and every workgroup walks the batch in strides of the grid: a lane runs its pairings
+// one after the other.  With one workgroup per 128 units the dispatcher refills the CUs round by round, and with 36 KB of
+// LDS per workgroup the rounds do not pack: a few workgroups find their LDS slot taken and wait for the NEXT round, so a
+// 2^18 batch (two rounds of 1024 workgroups) takes three (tools/exp/occ2.hip: mean residency 1.4 waves per SIMD; a
+// single wave gets a multiply-add through only every 9.1 cycles, two share the pipe at 4.6).  All control flow is
+// data-independent, so equal shares finish together.  Measured on the other kernels (types a, d, products,
+// preprocessed pairings: 8 or more rounds, or LDS to spare): 3 - 4 % SLOWER than one workgroup per 128 units -- they keep
+// the plain grid (profiles/r03_notes.md).
+#define PBC_RESIDENT_LOOP(n) for (size_t vb = blockIdx.x, nvb_ = ((n) + kBlock - 1) / kBlock; vb < nvb_; vb += gridDim.x)
 static_assert(kBlock == D_LANES, "pairing_d.cuh sizes its LDS state for 128-lane workgroups");
 #ifndef PBC_DF_WAVES
 #define PBC_DF_WAVES 2
@@ -255,20 +265,22 @@ __global__ void __launch_bounds__(kBlock, PBC_DF_WAVES) d_pp_apply_kernel(uint8_
 #ifndef PBC_F_WAVES
 #define PBC_F_WAVES PBC_DF_WAVES
 #endif
-// (the 5-word field keeps its Miller accumulator in 72 KB of LDS per workgroup: two workgroups per CU, one wave per SIMD,
-// and the register budget that goes with it)
+// (the 5-word field keeps its Miller accumulator in one 36 KB LDS area per workgroup: four workgroups per CU, two waves per
+// SIMD; with PBC_F_AREAS=2 in two areas, one wave per SIMD and the register budget that goes with it)
 template <int N>
-__global__ void __launch_bounds__(kBlock, N <= 5 ? 1 : PBC_F_WAVES) f_prod_pairing_kernel(uint8_t *gt, const uint8_t *g1,
+__global__ void __launch_bounds__(kBlock, N <= 5 ? (PBC_F_AREAS == 1 ? 2 : 1) : PBC_F_WAVES) f_prod_pairing_kernel(uint8_t *gt, const uint8_t *g1,
                                                                  const uint8_t *g2, size_t n, int k, KArgs<N> ka) {
-  size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
-  size_t ld = idx < n ? idx : n - 1;
-  const int fb = (int) fpk<N>().fbytes, L1 = 2 * fb, L2 = 4 * fb, LT = 12 * fb;
-  __attribute__((aligned(4))) uint8_t out[48 * N];
-  TypeF<N>::f_prod_pairing_lane(out, g1 + ld * (k < 0 ? 1 : k) * L1, g2 + ld * (k < 0 ? 1 : k) * L2, k < 0 ? 1 : k, k < 0);
-  if (idx < n) {
-    uint32_t *dst = reinterpret_cast<uint32_t *>(gt + idx * LT);      // LT = 12 fb is a multiple of 4
-    const uint32_t *src = reinterpret_cast<const uint32_t *>(out);
-    for (int i = 0; i < LT / 4; i++) dst[i] = src[i];
+  PBC_RESIDENT_LOOP(n) {
+    size_t idx = vb * kBlock + threadIdx.x;
+    size_t ld = idx < n ? idx : n - 1;
+    const int fb = (int) fpk<N>().fbytes, L1 = 2 * fb, L2 = 4 * fb, LT = 12 * fb;
+    __attribute__((aligned(4))) uint8_t out[48 * N];
+    TypeF<N>::f_prod_pairing_lane(out, g1 + ld * (k < 0 ? 1 : k) * L1, g2 + ld * (k < 0 ? 1 : k) * L2, k < 0 ? 1 : k, k < 0);
+    if (idx < n) {
+      uint32_t *dst = reinterpret_cast<uint32_t *>(gt + idx * LT);      // LT = 12 fb is a multiple of 4
+      const uint32_t *src = reinterpret_cast<const uint32_t *>(out);
+      for (int i = 0; i < LT / 4; i++) dst[i] = src[i];
+    }
   }
 }
 
@@ -832,6 +844,36 @@ static int ensure_derived(pbc_hip_pairing_s *P, hipStream_t s) {
   return 0;
 }
 
+// Grid of a resident-workgroup launch (PBC_RESIDENT_LOOP): the workgroups the current device holds at once for this
+// kernel (occupancy query, cached per kernel and device), or one per 128 units when the batch is smaller than that.
+// PBC_HIP_RESIDENT=0 restores one workgroup per 128 units (A/B measurements).
+static unsigned resident_grid(const void *kernel, size_t n) {
+  const size_t nvb = (n + kBlock - 1) / kBlock;
+  static const bool off = [] { const char *e = getenv("PBC_HIP_RESIDENT"); return e && e[0] == '0'; }();
+  if (off) return (unsigned) nvb;
+  static std::mutex mu;
+  static std::vector<std::pair<std::pair<const void *, int>, size_t>> cache;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return (unsigned) nvb;
+  size_t slots = 0;
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    for (auto &e : cache) if (e.first.first == kernel && e.first.second == dev) slots = e.second;
+    if (!slots) {
+      int per_cu = 0, cus = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, 0) != hipSuccess || per_cu < 1 ||
+          hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) {
+        (void) hipGetLastError();
+        return (unsigned) nvb;
+      }
+      slots = (size_t) per_cu * (size_t) cus;
+      cache.push_back({{kernel, dev}, slots});
+    }
+  }
+  return (unsigned) (nvb < slots ? nvb : slots);
+}
+#define PBC_RGRID(...) resident_grid(reinterpret_cast<const void *>(&__VA_ARGS__), n)
+
 static int launch_pairing(pbc_hip_pairing_s *P, void *d_gt, const void *d_g1, const void *d_g2, size_t n,
                           hipStream_t s, bool upload) {
   if (P->device < 0) return fail("no HIP device: libpbc_hip has no CPU fallback");
@@ -857,7 +899,7 @@ static int launch_pairing(pbc_hip_pairing_s *P, void *d_gt, const void *d_g1, co
     PBC_DISPATCH_D(P, hipLaunchKernelGGL((d_prod_pairing_kernel<N, DEG>), dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
                                                 (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, 1, (uint32_t *) nullptr, kargs<N>(P)));
   } else if (P->type == 'f') {
-    PBC_DISPATCH_F(P->nlimb, hipLaunchKernelGGL(f_prod_pairing_kernel<N>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
+    PBC_DISPATCH_F(P->nlimb, hipLaunchKernelGGL(f_prod_pairing_kernel<N>, dim3(PBC_RGRID(f_prod_pairing_kernel<N>)), dim3(kBlock), 0, s, (uint8_t *) d_gt,
                        (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, 1, kargs<N>(P)));
   } else {
     return fail("unsupported type");
@@ -887,12 +929,16 @@ struct DevCtx {
   size_t cap1 = 0, cap2 = 0, capt = 0;         // bytes per slot
 };
 // Workspaces of the product kernels (per-term Miller state), one per (device, stream): launches on one stream are
-// ordered, so they may share a buffer; launches on different streams get their own.
-struct WsEnt { int dev; hipStream_t st; void *p; size_t cap; };
+// ordered, so they may share a buffer; launches on different streams get their own.  At most kMaxWs are kept: a caller
+// that launches on ever new streams evicts the least recently used one (after a device synchronisation -- its stream
+// may no longer exist), so the footprint stays bounded and a recycled stream handle cannot alias a stale entry for long.
+struct WsEnt { int dev; hipStream_t st; void *p; size_t cap; uint64_t used; };
+constexpr size_t kMaxWs = 8;
 struct HostCtx {
   DevCtx dc[kMaxDev];
   int n = 0;
   std::vector<WsEnt> ws;
+  uint64_t ws_clock = 0;
   std::mutex mu;                               // guards the tables (the per-device entries are used by one worker each)
 };
 static void devctx_release(DevCtx &c) {
@@ -932,13 +978,40 @@ static void *workspace_get(pbc_hip_pairing_s *P, hipStream_t s, size_t bytes) {
   WsEnt *e = nullptr;
   for (WsEnt &w : H->ws)
     if (w.dev == dev && w.st == s) e = &w;
-  if (!e) { H->ws.push_back(WsEnt{dev, s, nullptr, 0}); e = &H->ws.back(); }
+  if (!e) {
+    if (H->ws.size() >= kMaxWs) {        // evict the least recently used entry
+      size_t lru = 0;
+      for (size_t i = 1; i < H->ws.size(); i++) if (H->ws[i].used < H->ws[lru].used) lru = i;
+      {
+        DeviceGuard guard(H->ws[lru].dev);
+        (void) hipDeviceSynchronize();
+        if (H->ws[lru].p) (void) hipFree(H->ws[lru].p);
+      }
+      H->ws.erase(H->ws.begin() + (long) lru);
+    }
+    H->ws.push_back(WsEnt{dev, s, nullptr, 0, 0});
+    e = &H->ws.back();
+  }
+  e->used = ++H->ws_clock;
   if (e->cap < bytes) {
     if (e->p) { (void) hipStreamSynchronize(s); (void) hipFree(e->p); e->p = nullptr; e->cap = 0; }
     if (hipMalloc(&e->p, bytes) != hipSuccess) { e->p = nullptr; fail("device allocation of a %zu-byte product workspace failed", bytes); return nullptr; }
     e->cap = bytes;
   }
   return e->p;
+}
+extern "C" int pbc_hip_pairing_release_workspaces(pbc_hip_pairing_t *P) {
+  if (!P) return fail("null pairing");
+  HostCtx *H = static_cast<HostCtx *>(P->host_ctx);
+  if (!H) return 0;
+  std::lock_guard<std::mutex> lk(H->mu);
+  for (WsEnt &w : H->ws) {
+    DeviceGuard guard(w.dev);
+    (void) hipDeviceSynchronize();
+    if (w.p) (void) hipFree(w.p);
+  }
+  H->ws.clear();
+  return 0;
 }
 // the context of `dev` with room for chunks of (b1, b2, bt) bytes; the calling thread's current device must be `dev`
 static DevCtx *devctx_get(pbc_hip_pairing_s *P, int dev, size_t b1, size_t b2, size_t bt, std::string &err) {
@@ -1076,7 +1149,7 @@ static int launch_prod(pbc_hip_pairing_s *P, void *d_gt, const void *d_g1, const
     PBC_DISPATCH_D(P, hipLaunchKernelGGL((d_prod_pairing_kernel<N, DEG>), dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
                                                 (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k, (uint32_t *) ws, kargs<N>(P)));
   } else if (P->type == 'f') {
-    PBC_DISPATCH_F(P->nlimb, hipLaunchKernelGGL(f_prod_pairing_kernel<N>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
+    PBC_DISPATCH_F(P->nlimb, hipLaunchKernelGGL(f_prod_pairing_kernel<N>, dim3(PBC_RGRID(f_prod_pairing_kernel<N>)), dim3(kBlock), 0, s, (uint8_t *) d_gt,
                        (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k, kargs<N>(P)));
   } else {
     return fail("unsupported type");

@@ -1005,6 +1005,50 @@ def test_two_objects_with_the_same_word_count_run_concurrently(hips):
     Hd2.clear()
 
 
+def test_product_workspaces_stay_bounded_over_many_streams(hips):
+    """The type a / d product kernels keep one workspace per (device, stream); a caller that enqueues on ever new
+    streams must not accumulate them: twelve short-lived streams against the table's eight entries -- the
+    least recently used buffer is evicted after a device synchronisation -- every product bit-exact, then
+    pbc_hip_pairing_release_workspaces and one more launch."""
+    import torch
+    for key, name in (("a", "a_prod16x4.vec"), ("d", "d_prod16x4.vec")):
+        H, w = hips[key], golden(name)
+        reps = 64
+        g1 = torch.from_numpy(np.tile(w.g1.reshape(-1, w.len1), (reps, 1))).cuda()
+        g2 = torch.from_numpy(np.tile(w.g2.reshape(-1, w.len2), (reps, 1))).cuda()
+        n = reps * len(w.gt)
+        outs = []
+        for i in range(12):
+            st = torch.cuda.Stream()
+            o = torch.zeros(n, w.lenT, dtype=torch.uint8, device="cuda")
+            H.element_prod_pairing_dev(o.data_ptr(), g1.data_ptr(), g2.data_ptr(), n, w.k, st.cuda_stream)
+            outs.append((o, st))
+        torch.cuda.synchronize()
+        for o, _ in outs:
+            assert (o.cpu().numpy().reshape(reps, len(w.gt), -1) == w.gt[None]).all()
+        H.release_workspaces()
+        o = torch.zeros(n, w.lenT, dtype=torch.uint8, device="cuda")
+        H.element_prod_pairing_dev(o.data_ptr(), g1.data_ptr(), g2.data_ptr(), n, w.k, 0)
+        torch.cuda.synchronize()
+        assert (o.cpu().numpy().reshape(reps, len(w.gt), -1) == w.gt[None]).all()
+
+
+@pytest.mark.parametrize("pname", ["a", "d159", "f"])
+def test_pairing_pp_lifetimes_through_the_glue(pname):
+    """Orders stock PBC tolerates: a pairing_pp_t made on the GPU and cleared AFTER pbc_hip_detach or after
+    pairing_clear; a pairing_pp_t made on the CPU while the hooks are still installed for an older one; re-attaching;
+    element_prod_pairing_batch with k = 0 (empty products = 1, no division by zero).  glue_test ... lifetime."""
+    import os
+    import subprocess
+    import pbc_amd
+    if not os.path.exists(oracle.GLUE_TEST):
+        pytest.skip("oracle/_ref/glue_test not built (needs /root/reference at build time)")
+    env = dict(os.environ, PBC_HIP_LIB=pbc_amd.LIB_PATH)
+    r = subprocess.run([oracle.GLUE_TEST, os.path.join(pbc_amd.PARAM_DIR, pname + ".param"), "8", "lifetime"],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and "PASS" in r.stdout, r.stdout + r.stderr
+
+
 @pytest.mark.parametrize("key,name", [("a", "a_finalpow6.vec"), ("d", "d159_finalpow6.vec"), ("f", "f_finalpow6.vec"),
                                       ("g149", "g149_finalpow6.vec"), ("e", "e_finalpow3.vec"), ("a1", "a1_finalpow3.vec")])
 def test_finalpow_matches_reference(hips, oracles, key, name):

@@ -49,6 +49,8 @@ struct pbc_hip_pairing_s {
   DConst dconst;             // type D: derived tower constants (filled on first use)
   FRaw fraw;                 // type F: canonical parameter words
   FConst fconst;             // type F: derived tower constants (filled on first use)
+  FConst fconst_i;           // type F, q = 3 mod 4: the same in the i-basis, for the pairing kernels (pairing_f.cuh init_stage3)
+  bool f_bm1;                // fconst_i is valid
   ERaw eraw;                 // type E: integers for the one-time search of the auxiliary point
   EConst econst;             // type E: curve, auxiliary point, exponents (filled on first use)
   bool dev_ready;            // derived constants computed on the device
@@ -474,6 +476,22 @@ static int init_type_f(pbc_hip_pairing_s *P, const char *txt, size_t len) {
   if (!rem.is_zero()) return fail("type f: q must be 1 mod 6");
   e6.to_words(P->fraw.e6, NF + 1);
   P->fraw.e6bits = e6.bits();
+  {
+    // q = 3 mod 4: the pairing kernels work in the i-basis of F_q^2 (pairing_f.cuh init_stage3); "hip_no_bm1 1" keeps the
+    // parameter file's beta (tests).  K = 4 q in borrowed limbs must dominate normalised values below 2.001 q.
+    int no_bm1 = 0;
+    param_int(txt, len, "hip_no_bm1", no_bm1);
+    P->f_bm1 = false;
+    const int L = NF == 5 ? Limbs29<5>::L : Limbs29<8>::L;
+    if ((q.w[0] & 3) == 3 && !no_bm1 && !pbc_host::ksub_build(q, L, 29 * (L - 1) + 2, 4, 1, P->fraw.kneg29)) {
+      Big e4 = q, four;
+      e4.add_small(1);
+      four.w.push_back(4);
+      e4 = Big::div(e4, four, &rem);
+      e4.to_words(P->fraw.e4, NF + 1);
+      P->fraw.e4bits = e4.bits();
+    }
+  }
   if (r.bits() > 256 || r.bits() < 3) return fail("type f: bad r");
   P->fconst.rbits = pbc_host::naf_of_half(r, P->fconst.r, P->fconst.rm, 9);     // signed digits of the Miller loop
   if (!P->fconst.rbits) return fail("type f: r too wide for the Miller loop digits");
@@ -578,15 +596,16 @@ template <int N> static const FpK<N> &host_fpk(const pbc_hip_pairing_s *P);
 #define PBC_HOST_FPK_OF(n) template <> const FpK<n> &host_fpk<n>(const pbc_hip_pairing_s *P) { return P->k##n; }
 PBC_FOR_EACH_N(PBC_HOST_FPK_OF)
 #undef PBC_HOST_FPK_OF
+// for_pairing: the block of a pairing / product launch (type f: the i-basis constants when the object has them)
 template <int N>
-static void fill_kargs(const pbc_hip_pairing_s *P, KArgs<N> &K) {
+static void fill_kargs(const pbc_hip_pairing_s *P, KArgs<N> &K, bool for_pairing = false) {
   memset(&K, 0, sizeof K);
   CurveK C;
   fill_curve(P, C);
   memcpy(K.head + KOFF_CURVE, &C, sizeof C);
   if (P->type == 'a' || P->type == '1') memcpy(K.head + KOFF_TYPE, &P->a, sizeof P->a);
   else if (P->type == 'd' || P->type == 'g') memcpy(K.head + KOFF_TYPE, &P->dconst, sizeof P->dconst);
-  else if (P->type == 'f') memcpy(K.head + KOFF_TYPE, &P->fconst, sizeof P->fconst);
+  else if (P->type == 'f') memcpy(K.head + KOFF_TYPE, for_pairing && P->f_bm1 ? &P->fconst_i : &P->fconst, sizeof P->fconst);
   else if (P->type == 'e') memcpy(K.head + KOFF_TYPE, &P->econst, sizeof P->econst);
   memcpy(K.head + KOFF_XS, &P->xs, sizeof P->xs);
   K.fp = host_fpk<N>(P);

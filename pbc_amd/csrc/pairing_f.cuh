@@ -44,10 +44,22 @@ struct FConst {                        // f_pairing_data_s (ecc/f_param.c:35-45)
   uint32_t gamma[2][NF_MAX];           // X^q = gamma X, gamma = negalpha^((q-1)/6)
   uint32_t bn_x[2];                    // |x|
   int bn_ok, bn_xneg, bn_xbits;
+  // "i-basis" copy of the constants (q = 3 mod 4, pairing kernels only; see init_stage3): F_q^2 is represented as
+  // F_q[i], i^2 = -1, through s -> c i with c^2 = -beta, so that multiplying by beta is a negation
+  int bm1;                             // 1: beta = -1 in this block
+  uint32_t cmap[NF_MAX], cinv[NF_MAX]; // c, 1/c (Montgomery form): (x, y) -> (x, c y) on the way in, (x, y / c) on the way out
+  uint32_t kneg29[9];                  // 4 q in borrowed limb form (hostbn.h ksub_build, D = 1): K - y is -y with non-negative limbs
 };
 static_assert(sizeof(FConst) <= KOFF_XS - KOFF_TYPE, "constant block layout");
 #define c_f (pbc::kconst<pbc::FConst, pbc::KOFF_TYPE>())
-struct FRaw { uint32_t b[NF_MAX], beta[NF_MAX], alpha0[NF_MAX], alpha1[NF_MAX]; uint32_t e6[NF_MAX + 1]; int e6bits; };
+struct FRaw {
+  uint32_t b[NF_MAX], beta[NF_MAX], alpha0[NF_MAX], alpha1[NF_MAX];
+  uint32_t e6[NF_MAX + 1];
+  int e6bits;
+  uint32_t e4[NF_MAX + 1];             // (q + 1) / 4 when q = 3 mod 4 and the i-basis is wanted (e4bits > 0), with 4 q for kneg29
+  int e4bits;
+  uint32_t kneg29[9];
+};
 
 // LDS staging area of the F_q^12 products: the limb forms (x, y of six coefficients) of one operand per lane,
 // limb-major for 128-lane workgroups (36 KB for the 5-word field: four workgroups per CU)
@@ -59,7 +71,8 @@ template <int ND> constexpr int kF12Bufs = Limbs29<ND>::L <= 6 ? PBC_F_AREAS : 1
 template <int ND> __shared__ uint32_t g_lds_f12[kF12Bufs<ND> * 12 * Limbs29<ND>::L * 128];
 
 // Everything below is per field width: ND 32-bit words per F_q element (5 for f.param, 8 for 256-bit BN fields).
-template <int ND>
+// BM1: the instantiation of the pairing kernels for objects with i-basis constants (FConst::bm1, init_stage3)
+template <int ND, bool BM1 = false>
 struct TypeF {
 typedef fp<ND> fq;
 typedef typename vecN<ND>::type v5;
@@ -75,6 +88,25 @@ static PBC_DEV fl<ND> fl29(const uint32_t *l) {                 // a constant ke
 #pragma unroll
   for (int i = 0; i < Limbs29<ND>::L; i++) r.l[i] = l[i];
   return r;
+}
+// beta * y on limb forms (y: normalised limbs, value < 2.001 q).  General beta: a Montgomery product with the constant.
+// i-basis (BM1): K - y with K = 4 q in borrowed limbs, then a parallel carry pass -- 24 instructions
+// instead of 72 multiply-adds; the result has limbs <= 2^29 + 6 and a value below 4 q, which every sum it enters holds.
+static PBC_DEV void mul_beta(fl<ND> &r, const fl<ND> &y) {
+  constexpr int L = Limbs29<ND>::L;
+  if constexpr (BM1) {
+    uint32_t t[L], c = 0;
+#pragma unroll
+    for (int i = 0; i < L; i++) t[i] = c_f.kneg29[i] - y.l[i];
+#pragma unroll
+    for (int i = 0; i < L; i++) {
+      r.l[i] = (i < L - 1 ? (t[i] & Limbs29<ND>::MASK) : t[i]) + c;
+      c = t[i] >> 29;
+    }
+  } else {
+    const fl<ND> xx[1] = {y}, yy[1] = {fl29(c_f.beta29)};
+    sop_limbs<ND, 1>(r, xx, yy);
+  }
 }
 static PBC_DEV g2 fk2(const uint32_t (*w)[NF_MAX]) { g2 r; fp_set<ND>(r.x, w[0]); fp_set<ND>(r.y, w[1]); return r; }
 
@@ -92,21 +124,19 @@ static PBC_DEV void g2_zero(g2 &r) {
 // fq_mul (fieldquadratic.c:197-233), lazily reduced:  t = beta a.y;
 //   re = a.x b.x + t b.y,  im = a.x b.y + a.y b.x     (5 limb products, 3 reductions)
 static PBC_DEV void g2_mul_inl(g2 &r, const g2 &a, const g2 &b) {
-  fl<ND> ax, ay, bx, by, be, t, c;
+  fl<ND> ax, ay, bx, by, t, c;
   to_limbs<ND>(ax, a.x); to_limbs<ND>(ay, a.y);
   to_limbs<ND>(bx, b.x); to_limbs<ND>(by, b.y);
-  to_limbs<ND>(be, dk(c_f.beta));
-  { const fl<ND> x[1] = {ay}, y[1] = {be}; sop_limbs<ND, 1>(t, x, y); }
+  mul_beta(t, ay);
   { const fl<ND> x[2] = {ax, t}, y[2] = {bx, by}; sop_limbs<ND, 2>(c, x, y); from_limbs<ND>(r.x, c); }
   { const fl<ND> x[2] = {ax, ay}, y[2] = {by, bx}; sop_limbs<ND, 2>(c, x, y); from_limbs<ND>(r.y, c); }
 }
 // fq_square (fieldquadratic.c:249-269): re = a.x^2 + beta a.y^2, im = 2 a.x a.y
 static PBC_DEV void g2_sqr_inl(g2 &r, const g2 &a) {
-  fl<ND> ax, ay, ax2, be, t, c;
+  fl<ND> ax, ay, ax2, t, c;
   to_limbs<ND>(ax, a.x); to_limbs<ND>(ay, a.y);
-  to_limbs<ND>(be, dk(c_f.beta));
   limbs_dbl<ND>(ax2, ax);
-  { const fl<ND> x[1] = {ay}, y[1] = {be}; sop_limbs<ND, 1>(t, x, y); }
+  mul_beta(t, ay);
   { const fl<ND> x[2] = {ax, t}, y[2] = {ax, ay}; sop_limbs<ND, 2>(c, x, y); from_limbs<ND>(r.x, c); }
   { const fl<ND> x[1] = {ax2}, y[1] = {ay}; sop_limbs<ND, 1, 1>(c, x, y); from_limbs<ND>(r.y, c); }
 }
@@ -176,14 +206,11 @@ static PBC_DEV void ldsf_put(int c, int part, const fl<ND> &a, int buf = 0) {
 struct f12r { fl<ND> x[6], y[6], by[6]; };     // register-resident operand: every access uses a compile-time index
 // a -> registers (and, when `stage`, its x / y limb forms to LDS as well: the squaring's second operand is the first)
 static PBC_DEV void f12_load_regs(f12r &A, const f12 *a, bool stage) {
-  fl<ND> be;
-  be = fl29(c_f.beta29);
 #pragma unroll
   for (int i = 0; i < 6; i++) {
     to_limbs<ND>(A.x[i], a->c[i].x);
     to_limbs<ND>(A.y[i], a->c[i].y);
-    const fl<ND> xx[1] = {A.y[i]}, yy[1] = {be};
-    sop_limbs<ND, 1>(A.by[i], xx, yy);
+    mul_beta(A.by[i], A.y[i]);
     if (stage) { ldsf_put(i, 0, A.x[i]); ldsf_put(i, 1, A.y[i]); }
   }
 }
@@ -352,11 +379,10 @@ static __device__ __noinline__ void f12_inv(f12 *r, const f12 *a) {
 // (a, b, c travel as vectors: by-value fq structs beyond clang's 16-register aggregate budget
 // are passed indirectly, and that path miscompiled here -- see profiles/r01_notes.md)
 struct g2l { fl<ND> x, y, by; };
-static PBC_DEV void g2l_make(g2l &r, const g2 &a, const fl<ND> &be) {
+static PBC_DEV void g2l_make(g2l &r, const g2 &a) {
   to_limbs<ND>(r.x, a.x);
   to_limbs<ND>(r.y, a.y);
-  const fl<ND> xx[1] = {r.y}, yy[1] = {be};
-  sop_limbs<ND, 1>(r.by, xx, yy);
+  mul_beta(r.by, r.y);
 }
 static PBC_DEV void g2l_sel(g2l &r, const g2l &a, const g2l &b, bool take_b) {
 #pragma unroll
@@ -378,14 +404,13 @@ static __device__ __noinline__ void f_line_mul(f12 *v, v5 va, v5 vb, v5 vc, cons
   g2_mul_fq(bq, *Qy, b);
   g2_mul(aqn, aq, na);
   g2_mul(bqn, bq, na);
-  fl<ND> be, cl;
-  be = fl29(c_f.beta29);
+  fl<ND> cl;
   to_limbs<ND>(cl, c);
   g2l Aq, Aqn, Bq, Bqn;
-  g2l_make(Aq, aq, be);
-  g2l_make(Aqn, aqn, be);
-  g2l_make(Bq, bq, be);
-  g2l_make(Bqn, bqn, be);
+  g2l_make(Aq, aq);
+  g2l_make(Aqn, aqn);
+  g2l_make(Bq, bq);
+  g2l_make(Bqn, bqn);
   f12_stage(v);
 #pragma nounroll
   for (int i = 0; i < 6; i++) {
@@ -467,7 +492,7 @@ static __device__ __noinline__ void f12_sqr_lds(int cur) {
   O.dst = kOneArea ? 0 : 1 - cur;
   fl<ND> by[6];                                  // beta y_i for the compile-time index of each pair
 #pragma unroll
-  for (int i = 0; i < 6; i++) { const fl<ND> xx[1] = {ldsf_get(i, 1, cur)}, yy[1] = {fl29(c_f.beta29)}; sop_limbs<ND, 1>(by[i], xx, yy); }
+  for (int i = 0; i < 6; i++) mul_beta(by[i], ldsf_get(i, 1, cur));
 #pragma nounroll
   for (int kk = 0; kk < 6; kk++) {
     fl<ND> t6x, t6y;
@@ -540,14 +565,13 @@ static __device__ __noinline__ void f_line_mul_lds(int cur, v5 va, v5 vb, v5 vc,
   g2_mul_fq(bq, *Qy, b);
   g2_mul(aqn, aq, na);
   g2_mul(bqn, bq, na);
-  fl<ND> be, cl;
-  be = fl29(c_f.beta29);
+  fl<ND> cl;
   to_limbs<ND>(cl, c);
   g2l Aq, Aqn, Bq, Bqn;
-  g2l_make(Aq, aq, be);
-  g2l_make(Aqn, aqn, be);
-  g2l_make(Bq, bq, be);
-  g2l_make(Bqn, bqn, be);
+  g2l_make(Aq, aq);
+  g2l_make(Aqn, aqn);
+  g2l_make(Bq, bq);
+  g2l_make(Bqn, bqn);
 #pragma nounroll
   for (int i = 0; i < 6; i++) {
     int j = i + 2, k = i + 3;          // j = i - 4 mod 6, k = i - 3 mod 6
@@ -665,6 +689,10 @@ static __device__ __noinline__ bool f_miller_lane(f12 *v, const uint8_t *g1, con
   fp_load_be<ND>(Py, g1 + NB);
   g2_load_be(Qx, g2b);
   g2_load_be(Qy, g2b + 2 * NB);
+  if constexpr (BM1) {                 // into the i-basis (init_stage3)
+    fp_mul<ND>(Qx.y, Qx.y, dk(c_f.cmap));
+    fp_mul<ND>(Qy.y, Qy.y, dk(c_f.cmap));
+  }
   bool valid;
   {
     // curve_is_valid_point (curve.c:57-77): E: y^2 = x^3 + b;  E': y^2 = x^3 - alpha b over F_q^2
@@ -909,7 +937,11 @@ static __device__ void f_prod_pairing_lane(uint8_t *gt, const uint8_t *g1, const
   if (!miller_only) f_final_exp(&F);
   if (!valid) f12_one(&F);
 #pragma nounroll
-  for (int i = 0; i < 6; i++) g2_store_be(gt + 2 * fb() * i, F.c[i]);
+  for (int i = 0; i < 6; i++) {
+    g2 o = F.c[i];
+    if constexpr (BM1) fp_mul<ND>(o.y, o.y, dk(c_f.cinv));      // back to the reference's basis
+    g2_store_be(gt + 2 * fb() * i, o);
+  }
 }
 
 // bring-up diagnostics: one tower primitive on operands given as GT-format bytes
@@ -990,6 +1022,49 @@ static PBC_DEV void init_stage2(FConst *out, const FRaw &raw) {
     C.xpowq6[0][k] = n3.v[k]; C.xpowq6[1][k] = 0;
     C.xpowq8[0][k] = n4.v[k]; C.xpowq8[1][k] = 0;
     C.gamma[0][k] = c.x.v[k]; C.gamma[1][k] = c.y.v[k];
+  }
+  *out = C;
+}
+
+// stage 3 (c_f holds stage 2; q = 3 mod 4, raw.e4bits > 0): the i-basis copy of the constants for the pairing kernels.
+// beta is a non-residue and so is -1, hence -beta = c^2 with c = (-beta)^((q+1)/4); s -> c i maps F_q[s]/(s^2 - beta)
+// onto F_q[i]/(i^2 + 1), (x, y) -> (x, c y), fixing F_q: every F_q^2 constant of the tower gets its second component
+// scaled by c, "beta" becomes -1 and products by it turn into negations (mul_beta).  The kernels map Q on the way in
+// and the GT coefficients on the way out.  out->bm1 stays 0 when c^2 != -beta (cannot happen for valid parameters).
+static PBC_DEV void init_stage3(FConst *out, const FRaw &raw) {
+  FConst C = c_f;
+  C.bm1 = 0;
+  fq one, nb, c, t;
+  fp_set<ND>(one, fpk<ND>().one);
+  fp_neg<ND>(nb, dk(c_f.beta));
+  c = one;
+  for (int i = raw.e4bits - 1; i >= 0; i--) {
+    fp_sqr<ND>(c, c);
+    if ((raw.e4[i >> 5] >> (i & 31)) & 1) fp_mul<ND>(c, c, nb);
+  }
+  fp_sqr<ND>(t, c);
+  if (raw.e4bits > 0 && fp_eq<ND>(t, nb)) {
+    fq ci, m1, y;
+    fp_inv<ND>(ci, c);
+    fp_neg<ND>(m1, one);
+    uint32_t (*const f2[4])[NF_MAX] = {C.negalpha, C.negalphainv, C.gamma, C.tb};
+    for (int k = 0; k < 4; k++) {
+      fp_set<ND>(y, f2[k][1]);
+      fp_mul<ND>(y, y, c);
+      for (int w = 0; w < ND; w++) f2[k][1][w] = y.v[w];
+    }
+    fl<ND> l;
+    to_limbs<ND>(l, m1);
+    for (int w = 0; w < ND; w++) { C.beta[w] = m1.v[w]; C.cmap[w] = c.v[w]; C.cinv[w] = ci.v[w]; }
+    for (int i = 0; i < Limbs29<ND>::L; i++) C.beta29[i] = l.l[i];
+    fp_set<ND>(y, C.negalpha[1]);
+    to_limbs<ND>(l, y);
+    for (int i = 0; i < Limbs29<ND>::L; i++) C.na29[1][i] = l.l[i];
+    fp_neg<ND>(y, y);                  // beta * negalpha.y = -negalpha.y
+    to_limbs<ND>(l, y);
+    for (int i = 0; i < Limbs29<ND>::L; i++) C.bna29[i] = l.l[i];
+    for (int i = 0; i < 9; i++) C.kneg29[i] = raw.kneg29[i];
+    C.bm1 = 1;
   }
   *out = C;
 }

@@ -267,7 +267,7 @@ __global__ void __launch_bounds__(kBlock, PBC_DF_WAVES) d_pp_apply_kernel(uint8_
 #endif
 // (the 5-word field keeps its Miller accumulator in one 36 KB LDS area per workgroup: four workgroups per CU, two waves per
 // SIMD; with PBC_F_AREAS=2 in two areas, one wave per SIMD and the register budget that goes with it)
-template <int N>
+template <int N, bool BM1>
 __global__ void __launch_bounds__(kBlock, N <= 5 ? (PBC_F_AREAS == 1 ? 2 : 1) : PBC_F_WAVES) f_prod_pairing_kernel(uint8_t *gt, const uint8_t *g1,
                                                                  const uint8_t *g2, size_t n, int k, KArgs<N> ka) {
   PBC_RESIDENT_LOOP(n) {
@@ -275,7 +275,7 @@ __global__ void __launch_bounds__(kBlock, N <= 5 ? (PBC_F_AREAS == 1 ? 2 : 1) : 
     size_t ld = idx < n ? idx : n - 1;
     const int fb = (int) fpk<N>().fbytes, L1 = 2 * fb, L2 = 4 * fb, LT = 12 * fb;
     __attribute__((aligned(4))) uint8_t out[48 * N];
-    TypeF<N>::f_prod_pairing_lane(out, g1 + ld * (k < 0 ? 1 : k) * L1, g2 + ld * (k < 0 ? 1 : k) * L2, k < 0 ? 1 : k, k < 0);
+    TypeF<N, BM1>::f_prod_pairing_lane(out, g1 + ld * (k < 0 ? 1 : k) * L1, g2 + ld * (k < 0 ? 1 : k) * L2, k < 0 ? 1 : k, k < 0);
     if (idx < n) {
       uint32_t *dst = reinterpret_cast<uint32_t *>(gt + idx * LT);      // LT = 12 fb is a multiple of 4
       const uint32_t *src = reinterpret_cast<const uint32_t *>(out);
@@ -779,9 +779,9 @@ extern "C" double pbc_hip_algorithmic_macs_per_unit(const pbc_hip_pairing_t *p, 
 
 // the constant block of an object, passed by value as the LAST argument of every kernel (fp.cuh, "KArgs")
 template <int N>
-static KArgs<N> kargs(const pbc_hip_pairing_s *P) {
+static KArgs<N> kargs(const pbc_hip_pairing_s *P, bool for_pairing = false) {
   KArgs<N> K;
-  fill_kargs<N>(P, K);
+  fill_kargs<N>(P, K, for_pairing);
   return K;
 }
 
@@ -801,6 +801,10 @@ template <int N> __global__ void f_init_stage1(FConst *out, FRaw raw, KArgs<N> k
 template <int N> __global__ void f_init_stage2(FConst *out, FRaw raw, KArgs<N> ka) {
   if (threadIdx.x || blockIdx.x) return;
   TypeF<N>::init_stage2(out, raw);
+}
+template <int N> __global__ void f_init_stage3(FConst *out, FRaw raw, KArgs<N> ka) {
+  if (threadIdx.x || blockIdx.x) return;
+  TypeF<N>::init_stage3(out, raw);
 }
 template <int N> __global__ void e_init_kernel(EConst *out, ERaw raw, KArgs<N> ka) {
   if (threadIdx.x || blockIdx.x) return;
@@ -838,6 +842,12 @@ static int ensure_derived(pbc_hip_pairing_s *P, hipStream_t s) {
     PBC_DISPATCH_F(P->nlimb, hipLaunchKernelGGL(f_init_stage2<N>, dim3(1), dim3(64), 0, s, dbuf, P->fraw, kargs<N>(P)));
     HIP_TRY(hipMemcpyAsync(&P->fconst, dbuf, sizeof(FConst), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    if (P->fraw.e4bits > 0) {          // q = 3 mod 4: the i-basis copy for the pairing kernels
+      PBC_DISPATCH_F(P->nlimb, hipLaunchKernelGGL(f_init_stage3<N>, dim3(1), dim3(64), 0, s, dbuf, P->fraw, kargs<N>(P)));
+      HIP_TRY(hipMemcpyAsync(&P->fconst_i, dbuf, sizeof(FConst), hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipStreamSynchronize(s));
+      P->f_bm1 = P->fconst_i.bm1 != 0;
+    }
   }
   HIP_TRY(hipGetLastError());
   P->dev_ready = true;
@@ -899,8 +909,13 @@ static int launch_pairing(pbc_hip_pairing_s *P, void *d_gt, const void *d_g1, co
     PBC_DISPATCH_D(P, hipLaunchKernelGGL((d_prod_pairing_kernel<N, DEG>), dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
                                                 (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, 1, (uint32_t *) nullptr, kargs<N>(P)));
   } else if (P->type == 'f') {
-    PBC_DISPATCH_F(P->nlimb, hipLaunchKernelGGL(f_prod_pairing_kernel<N>, dim3(PBC_RGRID(f_prod_pairing_kernel<N>)), dim3(kBlock), 0, s, (uint8_t *) d_gt,
-                       (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, 1, kargs<N>(P)));
+    if (P->f_bm1) {                    // i-basis constants and the instantiation that goes with them
+      PBC_DISPATCH_F(P->nlimb, hipLaunchKernelGGL((f_prod_pairing_kernel<N, true>), dim3(PBC_RGRID(f_prod_pairing_kernel<N, true>)), dim3(kBlock), 0, s, (uint8_t *) d_gt,
+                         (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, 1, kargs<N>(P, true)));
+    } else {
+      PBC_DISPATCH_F(P->nlimb, hipLaunchKernelGGL((f_prod_pairing_kernel<N, false>), dim3(PBC_RGRID(f_prod_pairing_kernel<N, false>)), dim3(kBlock), 0, s, (uint8_t *) d_gt,
+                         (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, 1, kargs<N>(P)));
+    }
   } else {
     return fail("unsupported type");
   }
@@ -1149,8 +1164,13 @@ static int launch_prod(pbc_hip_pairing_s *P, void *d_gt, const void *d_g1, const
     PBC_DISPATCH_D(P, hipLaunchKernelGGL((d_prod_pairing_kernel<N, DEG>), dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
                                                 (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k, (uint32_t *) ws, kargs<N>(P)));
   } else if (P->type == 'f') {
-    PBC_DISPATCH_F(P->nlimb, hipLaunchKernelGGL(f_prod_pairing_kernel<N>, dim3(PBC_RGRID(f_prod_pairing_kernel<N>)), dim3(kBlock), 0, s, (uint8_t *) d_gt,
-                       (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k, kargs<N>(P)));
+    if (P->f_bm1) {
+      PBC_DISPATCH_F(P->nlimb, hipLaunchKernelGGL((f_prod_pairing_kernel<N, true>), dim3(PBC_RGRID(f_prod_pairing_kernel<N, true>)), dim3(kBlock), 0, s, (uint8_t *) d_gt,
+                         (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k, kargs<N>(P, true)));
+    } else {
+      PBC_DISPATCH_F(P->nlimb, hipLaunchKernelGGL((f_prod_pairing_kernel<N, false>), dim3(PBC_RGRID(f_prod_pairing_kernel<N, false>)), dim3(kBlock), 0, s, (uint8_t *) d_gt,
+                         (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k, kargs<N>(P)));
+    }
   } else {
     return fail("unsupported type");
   }
@@ -1498,7 +1518,7 @@ extern "C" int pbc_hip_diag_stage(pbc_hip_pairing_t *P, int stage, uint8_t *out,
     HIP_TRY(hipMemcpy(d2, g2, n * P->len2, hipMemcpyHostToDevice));
     if (ensure_derived(P, 0)) return 1;
     unsigned grid = (unsigned) ((n + kBlock - 1) / kBlock);
-    PBC_DISPATCH_F(P->nlimb, hipLaunchKernelGGL(f_prod_pairing_kernel<N>, dim3(grid), dim3(kBlock), 0, 0, (uint8_t *) dt,
+    PBC_DISPATCH_F(P->nlimb, hipLaunchKernelGGL((f_prod_pairing_kernel<N, false>), dim3(grid), dim3(kBlock), 0, 0, (uint8_t *) dt,
                        (const uint8_t *) d1, (const uint8_t *) d2, n, -1, kargs<N>(P)));
     HIP_TRY(hipMemcpy(out, dt, n * P->lenT < out_len ? n * P->lenT : out_len, hipMemcpyDeviceToHost));
     (void) hipFree(d1); (void) hipFree(d2); (void) hipFree(dt);

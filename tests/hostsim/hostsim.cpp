@@ -31,8 +31,8 @@
     case 5 * 8 + 5: { constexpr int N = 5, DEG = 5; __VA_ARGS__; } break;     \
   }
 // the object's constants into the block the kernel source reads (what a launch passes as KArgs<N> on the GPU)
-static void activate(pbc_hip_pairing_s *P) {
-  HS_DISPATCH(P->nlimb, { KArgs<N> K; fill_kargs<N>(P, K); memcpy(hostsim_kargs + sizeof hostsim_kargs - sizeof K, &K, sizeof K); });
+static void activate(pbc_hip_pairing_s *P, bool for_pairing = false) {
+  HS_DISPATCH(P->nlimb, { KArgs<N> K; fill_kargs<N>(P, K, for_pairing); memcpy(hostsim_kargs + sizeof hostsim_kargs - sizeof K, &K, sizeof K); });
 }
 
 extern "C" {
@@ -72,6 +72,12 @@ void *hostsim_init(const char *param, size_t len) {
     activate(P);
     HS_DISPATCH_F(P->nlimb, TypeF<N>::init_stage2(&tmp, P->fraw));
     P->fconst = tmp;
+    if (P->fraw.e4bits > 0) {            // as ensure_derived: the i-basis copy for the pairing kernels
+      activate(P);
+      HS_DISPATCH_F(P->nlimb, TypeF<N>::init_stage3(&tmp, P->fraw));
+      P->fconst_i = tmp;
+      P->f_bm1 = tmp.bm1 != 0;
+    }
   }
   activate(P);
   return P;
@@ -106,7 +112,7 @@ int hostsim_lens(void *h, int *l1, int *l2, int *lt) {
 // n units of k terms each, one lane after the other
 int hostsim_prod_pairing(void *h, uint8_t *gt, const uint8_t *g1, const uint8_t *g2, size_t n, int k) {
   pbc_hip_pairing_s *P = (pbc_hip_pairing_s *) h;
-  activate(P);
+  activate(P, true);                     // the constant block of a pairing launch (launch_pairing / launch_prod)
   static uint32_t lds[2 * 33];
   for (size_t u = 0; u < n; u++) {
     const uint8_t *a = g1 + u * k * P->len1, *b = g2 + u * k * P->len2;
@@ -118,6 +124,7 @@ int hostsim_prod_pairing(void *h, uint8_t *gt, const uint8_t *g1, const uint8_t 
     else if (P->type == 'e' && P->nlimb == 16) e_prod_pairing_lane<16>(o, a, b, k, lds, 1);
     else if (P->type == 'e') e_prod_pairing_lane<33>(o, a, b, k, lds, 1);
     else if (P->type == 'd' || P->type == 'g') { HS_DISPATCH_D(P, { std::vector<uint32_t> ws((size_t) k * TypeMNT<N, DEG>::DL_WORDS * 128); TypeMNT<N, DEG>::d_prod_pairing_lane(o, a, b, k, ws.data()); }); }
+    else if (P->f_bm1) { HS_DISPATCH_F(P->nlimb, (TypeF<N, true>::f_prod_pairing_lane(o, a, b, k))); }      // as launch_pairing / launch_prod
     else { HS_DISPATCH_F(P->nlimb, TypeF<N>::f_prod_pairing_lane(o, a, b, k)); }
   }
   return 0;

@@ -275,6 +275,20 @@ def test_f_generic_hard_part_on_gpu():
     assert np.array_equal(P.element_pairing(v.g1, v.g2), v.gt)
 
 
+def test_f_reference_basis_path_on_gpu():
+    """f.param has q = 3 mod 4: its pairing kernels run in the i-basis of F_q^2 (pairing_f.cuh init_stage3: beta -> -1,
+    Q mapped on the way in, GT on the way out).  "hip_no_bm1 1" keeps the parameter file's beta -- the path every q = 1 mod 4
+    parameter set takes (f_200, f_256 below): both must give the reference's bytes, singles and products."""
+    import pbc_amd
+    from conftest import _param
+    v, w = golden("f_rand16.vec"), golden("f_prod3x5_edge.vec")
+    for extra in ("hip_no_bm1 1\n", ""):
+        P = pbc_amd.Pairing(_param("f") + extra)
+        assert np.array_equal(P.element_pairing(v.g1, v.g2), v.gt)
+        assert np.array_equal(P.element_prod_pairing(w.g1, w.g2, w.k), w.gt)
+        P.clear()
+
+
 def test_d_word_form_point_arithmetic_on_gpu():
     """Type d parameters whose q leaves its top 29-bit limb nearly empty run the word-form step routines inside the
     d159 kernels (DConst::limb_ok); force that path on d159.param: singles, products, preprocessing."""

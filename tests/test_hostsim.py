@@ -60,6 +60,21 @@ def test_type_f_generic_hard_part_on_host():
     assert np.array_equal(sim.prod_pairing(v.g1[:2], v.g2[:2], 1), v.gt[:2])
 
 
+def test_type_f_reference_basis_path_on_host():
+    """q = 3 mod 4 (f.param): the pairing runs in the i-basis of F_q^2 (beta -> -1); "hip_no_bm1 1" forces the parameter
+    file's beta, the path of every q = 1 mod 4 parameter set.  The default object must really be on the i-basis path: it
+    executes fewer multiply-adds."""
+    v = golden("f_rand16.vec")
+    sim = hostsim.HostSim(_param("f") + "hip_no_bm1 1\n")
+    sim.macs(reset=True)
+    assert np.array_equal(sim.prod_pairing(v.g1[:2], v.g2[:2], 1), v.gt[:2])
+    general = sim.macs(reset=True)
+    sim = hostsim.HostSim(_param("f"))
+    sim.macs(reset=True)
+    assert np.array_equal(sim.prod_pairing(v.g1[:2], v.g2[:2], 1), v.gt[:2])
+    assert sim.macs(reset=True) < 0.95 * general
+
+
 def test_type_d_word_form_point_arithmetic_on_host():
     """d159.param keeps the running point of its Miller loop in limb form; parameters whose q leaves the top limb
     nearly empty take the word-form step routines inside the same kernels: force them on d159.param

@@ -934,6 +934,9 @@ static __device__ void f_prod_pairing_lane(uint8_t *gt, const uint8_t *g1, const
     valid &= f_miller_lane(&f, g1 + (size_t) j * 2 * fb(), g2b + (size_t) j * 4 * fb());
     f12_mul(&F, &F, &f);
   }
+#ifdef PBC_F_WHATIF_MILLER_ONLY
+  miller_only = true;                            // what-if timing only (tools/whatif_time.py): wrong results
+#endif
   if (!miller_only) f_final_exp(&F);
   if (!valid) f12_one(&F);
 #pragma nounroll

@@ -483,7 +483,13 @@ static int init_type_f(pbc_hip_pairing_s *P, const char *txt, size_t len) {
     param_int(txt, len, "hip_no_bm1", no_bm1);
     P->f_bm1 = false;
     const int L = NF == 5 ? Limbs29<5>::L : Limbs29<8>::L;
-    if ((q.w[0] & 3) == 3 && !no_bm1 && !pbc_host::ksub_build(q, L, 29 * (L - 1) + 2, 4, 1, P->fraw.kneg29)) {
+    // borrowed multiples of q for differences in limb form: 4 q (D = 1) dominates a normalised value below 2.001 q,
+    // 8 q (D = 2) its double (the cyclotomic squaring); both need q to reach two bits into its top limb
+    P->fraw.k_ok = !pbc_host::ksub_build(q, L, 29 * (L - 1) + 2, 4, 1, P->fraw.kneg29) &&
+                   !pbc_host::ksub_build(q, L, 29 * (L - 1) + 2, 8, 2, P->fraw.kneg8_29);
+    int no_cyc = 0;
+    param_int(txt, len, "hip_no_cyc", no_cyc);   // tests: plain squarings in the hard part
+    if ((q.w[0] & 3) == 3 && !no_bm1 && P->fraw.k_ok) {
       Big e4 = q, four;
       e4.add_small(1);
       four.w.push_back(4);
@@ -491,6 +497,7 @@ static int init_type_f(pbc_hip_pairing_s *P, const char *txt, size_t len) {
       e4.to_words(P->fraw.e4, NF + 1);
       P->fraw.e4bits = e4.bits();
     }
+    if (no_cyc) P->fraw.k_ok = 0;
   }
   if (r.bits() > 256 || r.bits() < 3) return fail("type f: bad r");
   P->fconst.rbits = pbc_host::naf_of_half(r, P->fconst.r, P->fconst.rm, 9);     // signed digits of the Miller loop

@@ -49,6 +49,10 @@ struct FConst {                        // f_pairing_data_s (ecc/f_param.c:35-45)
   int bm1;                             // 1: beta = -1 in this block
   uint32_t cmap[NF_MAX], cinv[NF_MAX]; // c, 1/c (Montgomery form): (x, y) -> (x, c y) on the way in, (x, y / c) on the way out
   uint32_t kneg29[9];                  // 4 q in borrowed limb form (hostbn.h ksub_build, D = 1): K - y is -y with non-negative limbs
+  // cyclotomic squarings of the hard part (f12_cyc_sqr_lds): 3 xi.x, 3 xi.y, 3 beta xi.y, 6 xi.x, 6 xi.y, 6 beta xi.y for
+  // xi = negalpha as limbs, and 8 q in borrowed limbs with D = 2 (K - 2 y for normalised y); cyc_ok: both K constants fit q
+  uint32_t cyc29[6][9], kneg8_29[9];
+  int cyc_ok;
 };
 static_assert(sizeof(FConst) <= KOFF_XS - KOFF_TYPE, "constant block layout");
 #define c_f (pbc::kconst<pbc::FConst, pbc::KOFF_TYPE>())
@@ -58,7 +62,8 @@ struct FRaw {
   int e6bits;
   uint32_t e4[NF_MAX + 1];             // (q + 1) / 4 when q = 3 mod 4 and the i-basis is wanted (e4bits > 0), with 4 q for kneg29
   int e4bits;
-  uint32_t kneg29[9];
+  uint32_t kneg29[9], kneg8_29[9];     // 4 q (D = 1) and 8 q (D = 2) in borrowed limbs; k_ok: both fit this q (hostbn.h ksub_build)
+  int k_ok;
 };
 
 // LDS staging area of the F_q^12 products: the limb forms (x, y of six coefficients) of one operand per lane,
@@ -649,6 +654,132 @@ static __device__ __noinline__ void f12_mul_lds(int cur, const f12 *b) {
   }
   O.finish();
 }
+// ---- squaring in the cyclotomic subgroup (Granger-Scott) ------------------------------------------------------------------
+// After the easy part of the final exponentiation an element a = sum c_i X^i has order dividing q^4 - q^2 + 1.  With
+// W = X^3 (W^2 = xi = negalpha), F_q^12 = F_q^4[X]/(X^3 - W), a = g0 + g1 X + g2 X^2, g_j = c_j + c_(j+3) W, and
+//     a^2 = (3 g0^2 - 2 conj g0) + (3 W g2^2 + 2 conj g1) X + (3 g1^2 - 2 conj g2) X^2        (conj: W -> -W),
+// coefficient by coefficient (checked against the plain square on f.param before it was written, and by every vector):
+//     c0' = F(c0, c3, c0)   c3' = G(c0, c3, c3)        F(u, v, l) = 3 u^2 + 3 xi v^2 - 2 l
+//     c2' = F(c1, c4, c2)   c5' = G(c1, c4, c5)        G(u, v, l) = 6 u v + 2 l
+//     c4' = F(c2, c5, c4)   c1' = H(c2, c5, c1)        H(u, v, l) = 6 xi u v + 2 l
+// -- about 75 product / reduction units against the 114 of the plain square (132 with a general beta), nothing to buffer
+// (a pair's results overwrite its own operands), every output one lazily reduced sum.  Small multiples ride on the
+// operands (3 u_x has limbs below 3 2^29 and counts three units of a column's nine), the linear terms enter as products
+// with R mod q, differences through the borrowed constant K = 8 q.
+typedef uint32_t vcyc __attribute__((ext_vector_type(4 * FL)));
+static PBC_DEV void lnorm(fl<ND> &r, const uint32_t *t) {       // parallel carry pass: limbs below 2^32 in, <= 2^29 + 8 out
+  uint32_t c = 0;
+#pragma unroll
+  for (int i = 0; i < FL; i++) {
+    r.l[i] = (i < FL - 1 ? (t[i] & Limbs29<ND>::MASK) : t[i]) + c;
+    c = t[i] >> 29;
+  }
+}
+static PBC_DEV void lscale(fl<ND> &r, const fl<ND> &a, uint32_t k) {
+#pragma unroll
+  for (int i = 0; i < FL; i++) r.l[i] = a.l[i] * k;
+}
+// (F, G) or (F, H) of the pair u = c_iu, v = c_iv with the linear terms c_ilf, c_ilg (coefficients of the LDS area)
+static __device__ __noinline__ vcyc cyc_pair(int iu_, int iv_, int ilf_, int ilg_, int with_xi_) {
+#ifdef PBC_HOSTSIM
+  const int iu = iu_, iv = iv_, ilf = ilf_, ilg = ilg_, with_xi = with_xi_;
+#else
+  const int iu = __builtin_amdgcn_readfirstlane(iu_), iv = __builtin_amdgcn_readfirstlane(iv_), ilf = __builtin_amdgcn_readfirstlane(ilf_),
+            ilg = __builtin_amdgcn_readfirstlane(ilg_), with_xi = __builtin_amdgcn_readfirstlane(with_xi_);
+#endif
+  const fl<ND> ux = ldsf_get(iu, 0), uy = ldsf_get(iu, 1), vx = ldsf_get(iv, 0), vy = ldsf_get(iv, 1);
+  const fl<ND> oneL = fl29(c_f.one29);
+  fl<ND> bvy, Vx, Vy, t, u3x, buy3, uy2, kx, ky, Fx, Fy, Gx, Gy;
+  mul_beta(bvy, vy);
+  {                                              // V = v^2
+    const fl<ND> x[2] = {vx, bvy}, y[2] = {vx, vy};
+    sop_limbs<ND, 2>(Vx, x, y);
+    limbs_dbl<ND>(t, vx);
+    const fl<ND> x1[1] = {t}, y1[1] = {vy};
+    sop_limbs<ND, 1, 1>(Vy, x1, y1);
+  }
+  {                                              // K - 2 l for the linear term of F
+    uint32_t d[FL];
+    const fl<ND> lx = ldsf_get(ilf, 0), ly = ldsf_get(ilf, 1);
+#pragma unroll
+    for (int i = 0; i < FL; i++) d[i] = c_f.kneg8_29[i] - 2 * lx.l[i];
+    lnorm(kx, d);
+#pragma unroll
+    for (int i = 0; i < FL; i++) d[i] = c_f.kneg8_29[i] - 2 * ly.l[i];
+    lnorm(ky, d);
+  }
+  lscale(u3x, ux, 3);
+  mul_beta(t, uy);
+  lscale(buy3, t, 3);
+  limbs_dbl<ND>(uy2, uy);
+  {                                              // F = 3 u^2 + 3 xi V - 2 l
+    const fl<ND> x[5] = {u3x, buy3, fl29(c_f.cyc29[0]), fl29(c_f.cyc29[2]), kx}, y[5] = {ux, uy, Vx, Vy, oneL};
+    sop_limbs<ND, 5, 4>(Fx, x, y);               // 3 + 3 + 1 + 1 + 1 units
+    const fl<ND> x1[4] = {u3x, fl29(c_f.cyc29[0]), fl29(c_f.cyc29[1]), ky}, y1[4] = {uy2, Vy, Vx, oneL};
+    sop_limbs<ND, 4, 5>(Fy, x1, y1);             // 6 + 1 + 1 + 1 units
+  }
+  fl<ND> l2x, l2y;
+  {
+    const fl<ND> lx = ldsf_get(ilg, 0), ly = ldsf_get(ilg, 1);
+    limbs_dbl<ND>(l2x, lx);
+    limbs_dbl<ND>(l2y, ly);
+  }
+  if (with_xi) {                                 // H = 6 xi (u v) + 2 l: the product reduced first
+    fl<ND> Tx, Ty;
+    {
+      const fl<ND> x[2] = {ux, uy}, y[2] = {vx, bvy};
+      sop_limbs<ND, 2>(Tx, x, y);
+      const fl<ND> x1[2] = {ux, uy}, y1[2] = {vy, vx};
+      sop_limbs<ND, 2>(Ty, x1, y1);
+    }
+    const fl<ND> x[3] = {fl29(c_f.cyc29[3]), fl29(c_f.cyc29[5]), l2x}, y[3] = {Tx, Ty, oneL};
+    sop_limbs<ND, 3, 1>(Gx, x, y);
+    const fl<ND> x1[3] = {fl29(c_f.cyc29[3]), fl29(c_f.cyc29[4]), l2y}, y1[3] = {Ty, Tx, oneL};
+    sop_limbs<ND, 3, 1>(Gy, x1, y1);
+  } else {                                       // G = 6 u v + 2 l
+    fl<ND> wx, wy;
+    uint32_t d[FL];
+#pragma unroll
+    for (int i = 0; i < FL; i++) d[i] = 6 * ux.l[i];
+    lnorm(wx, d);
+#pragma unroll
+    for (int i = 0; i < FL; i++) d[i] = 6 * uy.l[i];
+    lnorm(wy, d);
+    const fl<ND> x[3] = {wx, wy, l2x}, y[3] = {vx, bvy, oneL};
+    sop_limbs<ND, 3, 1>(Gx, x, y);
+    const fl<ND> x1[3] = {wx, wy, l2y}, y1[3] = {vy, vx, oneL};
+    sop_limbs<ND, 3, 1>(Gy, x1, y1);
+  }
+  vcyc r;
+#pragma unroll
+  for (int i = 0; i < FL; i++) { r[i] = Fx.l[i]; r[FL + i] = Fy.l[i]; r[2 * FL + i] = Gx.l[i]; r[3 * FL + i] = Gy.l[i]; }
+  return r;
+}
+static PBC_DEV void cyc_store(vcyc r, int cf, int cg) {
+  fl<ND> t;
+#pragma unroll
+  for (int i = 0; i < FL; i++) t.l[i] = r[i];
+  ldsf_put(cf, 0, t);
+#pragma unroll
+  for (int i = 0; i < FL; i++) t.l[i] = r[FL + i];
+  ldsf_put(cf, 1, t);
+#pragma unroll
+  for (int i = 0; i < FL; i++) t.l[i] = r[2 * FL + i];
+  ldsf_put(cg, 0, t);
+#pragma unroll
+  for (int i = 0; i < FL; i++) t.l[i] = r[3 * FL + i];
+  ldsf_put(cg, 1, t);
+}
+// area 0 squared in place (one-area layout; the element must lie in the cyclotomic subgroup)
+static __device__ __noinline__ void f12_cyc_sqr_lds() {
+  const vcyc r0 = cyc_pair(0, 3, 0, 3, 0);
+  cyc_store(r0, 0, 3);                           // c0, c3 are read by no other pair
+  const vcyc r1 = cyc_pair(1, 4, 2, 5, 0);       // c2', c5'
+  const vcyc r2 = cyc_pair(2, 5, 4, 1, 1);       // c4', c1' -- reads the old c2, c5, c4, c1
+  cyc_store(r1, 2, 5);
+  cyc_store(r2, 4, 1);
+}
+
 // a private-memory element into area `buf`
 static PBC_DEV void f12_lds_import(const f12 *a, int buf) {
 #pragma nounroll
@@ -822,8 +953,9 @@ static __device__ __noinline__ void f12_pow_x(f12 *r, const f12 *a) {
     f12_lds_import(a, cur);
 #pragma nounroll
     for (int i = c_f.bn_xbits - 2; i >= 0; i--) {
-      f12_sqr_lds(cur);
-      cur = next_area(cur);
+      // (every caller's `a` is a power of the easy part's result: cyclotomic subgroup)
+      if (kOneArea && c_f.cyc_ok) f12_cyc_sqr_lds();
+      else { f12_sqr_lds(cur); cur = next_area(cur); }
       if ((c_f.bn_x[i >> 5] >> (i & 31)) & 1) { f12_mul_lds(cur, a); cur = next_area(cur); }
     }
     f12_lds_export(r, cur);                      // r may be a: a is no longer read
@@ -992,6 +1124,26 @@ static PBC_DEV void init_stage1(FConst *out, const FRaw &raw, const FConst &base
   }
   *out = C;
 }
+// the constants of the cyclotomic squaring from C.negalpha and C.beta (either basis)
+static PBC_DEV void fill_cyc(FConst &C, const FRaw &raw) {
+  fq nx, ny, bny, acc[3];
+  fp_set<ND>(nx, C.negalpha[0]);
+  fp_set<ND>(ny, C.negalpha[1]);
+  fp_mul<ND>(bny, ny, dk(C.beta));
+  const fq base[3] = {nx, ny, bny};
+  for (int k = 0; k < 3; k++) {
+    fp_dbl<ND>(acc[k], base[k]);
+    fp_add<ND>(acc[k], acc[k], base[k]);           // 3 x
+    fl<ND> l;
+    to_limbs<ND>(l, acc[k]);
+    for (int i = 0; i < FL; i++) C.cyc29[k][i] = l.l[i];
+    fp_dbl<ND>(acc[k], acc[k]);                    // 6 x
+    to_limbs<ND>(l, acc[k]);
+    for (int i = 0; i < FL; i++) C.cyc29[3 + k][i] = l.l[i];
+  }
+  for (int i = 0; i < 9; i++) { C.kneg29[i] = raw.kneg29[i]; C.kneg8_29[i] = raw.kneg8_29[i]; }
+  C.cyc_ok = raw.k_ok;
+}
 // stage 2 (c_f holds stage 1): negalphainv, twist b, and the Frobenius constants:
 //   X^q = negalpha^((q-1)/6) X =: c X,  X^(q^2) = conj(c) c X = N(c) X,  X^(q^6) = N(c)^3 X,
 //   X^(q^8) = N(c)^4 X   (the reference gets the same values by brute-force powering,
@@ -1026,6 +1178,7 @@ static PBC_DEV void init_stage2(FConst *out, const FRaw &raw) {
     C.xpowq8[0][k] = n4.v[k]; C.xpowq8[1][k] = 0;
     C.gamma[0][k] = c.x.v[k]; C.gamma[1][k] = c.y.v[k];
   }
+  fill_cyc(C, raw);
   *out = C;
 }
 
@@ -1066,7 +1219,7 @@ static PBC_DEV void init_stage3(FConst *out, const FRaw &raw) {
     fp_neg<ND>(y, y);                  // beta * negalpha.y = -negalpha.y
     to_limbs<ND>(l, y);
     for (int i = 0; i < Limbs29<ND>::L; i++) C.bna29[i] = l.l[i];
-    for (int i = 0; i < 9; i++) C.kneg29[i] = raw.kneg29[i];
+    fill_cyc(C, raw);
     C.bm1 = 1;
   }
   *out = C;

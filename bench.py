@@ -126,7 +126,8 @@ def pmc_traffic(workload):
     WRITE_SIZE runs of this same command, summarised in profiles/): (FETCH_SIZE + WRITE_SIZE) KB.
     Raw counter sum; on gfx950 FETCH_SIZE may under-count wide coalesced reads by 2x
     (MI355X_MICROARCH.md).  None when no PMC summary is committed for the workload."""
-    for rel in ("profiles/r02_pmc_%s.json" % workload, "profiles/r01_final_a_pairing_pmc.json" if workload == "a" else None):
+    for rel in ("profiles/r03_pmc_%s.json" % workload, "profiles/r02_pmc_%s.json" % workload,
+                "profiles/r01_final_a_pairing_pmc.json" if workload == "a" else None):
         path = os.path.join(ROOT, rel) if rel else None
         if path and os.path.exists(path):
             j = json.load(open(path))

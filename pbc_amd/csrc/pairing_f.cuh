@@ -469,10 +469,12 @@ struct OutArea {
       ldsf_put(c, part, a, dst);
     }
   }
-  PBC_DEV void finish() {
+  // only the first `ncoef` coefficients went through the buffer (the sparse line product writes the rest in place)
+  PBC_DEV void finish(int ncoef = 6) {
     if constexpr (kOneArea) {
 #pragma unroll
       for (int c = 0; c < 12; c++) {
+        if (c >= 2 * ncoef) break;
         fl<ND> t;
 #pragma unroll
         for (int l = 0; l < FL; l++) t.l[l] = buf[c * FL + l];
@@ -545,15 +547,15 @@ static __device__ __noinline__ void f12_sqr_lds(int cur) {
           wide_mac<ND>(Wy, nax, t6y);
           wide_mac<ND>(Wy, nay, t6x);
         }
-        fl<ND> o;
-        wide_reduce<ND>(o, Wx);
-        O.put(kk, 0, o);
+        fl<ND> o;                                // (one area: the last coefficient is complete only when every read of the
+        wide_reduce<ND>(o, Wx);                  // operand is done -- it goes straight to its slot)
+        if (kOneArea && kk == 5) ldsf_put(kk, 0, o, 0); else O.put(kk, 0, o);
         wide_reduce<ND>(o, Wy);
-        O.put(kk, 1, o);
+        if (kOneArea && kk == 5) ldsf_put(kk, 1, o, 0); else O.put(kk, 1, o);
       }
     }
   }
-  O.finish();
+  O.finish(5);
 }
 // area `cur` times (a Qx X^4 + b Qy X^3 + c) into area 1 - cur (f_miller_evalfn, f_param.c:109-149): the formulas of
 // f_line_mul
@@ -592,15 +594,17 @@ static __device__ __noinline__ void f_line_mul_lds(int cur, v5 va, v5 vb, v5 vc,
     {
       const fl<ND> x[5] = {cl, fa.x, fa.by, fb.x, fb.by}, y[5] = {vix, vjx, vjy, vkx, vky};
       sop_limbs<ND, 5>(t, x, y);
-      O.put(i, 0, t);
+      if (kOneArea && i >= 3) ldsf_put(i, 0, t, 0); else O.put(i, 0, t);
     }
     {
       const fl<ND> x[5] = {cl, fa.x, fa.y, fb.x, fb.y}, y[5] = {viy, vjy, vjx, vky, vkx};
       sop_limbs<ND, 5>(t, x, y);
-      O.put(i, 1, t);
+      if (kOneArea && i >= 3) ldsf_put(i, 1, t, 0); else O.put(i, 1, t);
     }
   }
-  O.finish();
+  // (one area: coefficient s is read by the outputs s, s - 2 and s - 3 mod 6 only, and every operand of an output is in
+  // registers before its first component is stored -- outputs 3, 4, 5 overwrite their own slots, 0, 1, 2 wait in the buffer)
+  O.finish(3);
 }
 // area `cur` times the private-memory element b into area 1 - cur (b's limb forms in registers with compile-time
 // indices, the accumulator's coefficients from LDS; fold as in f12_sqr_lds)
@@ -644,15 +648,15 @@ static __device__ __noinline__ void f12_mul_lds(int cur, const f12 *b) {
           wide_mac<ND>(Wy, nax, t6y);
           wide_mac<ND>(Wy, nay, t6x);
         }
-        fl<ND> o;
-        wide_reduce<ND>(o, Wx);
-        O.put(kk, 0, o);
+        fl<ND> o;                                // (one area: the last coefficient is complete only when every read of the
+        wide_reduce<ND>(o, Wx);                  // operand is done -- it goes straight to its slot)
+        if (kOneArea && kk == 5) ldsf_put(kk, 0, o, 0); else O.put(kk, 0, o);
         wide_reduce<ND>(o, Wy);
-        O.put(kk, 1, o);
+        if (kOneArea && kk == 5) ldsf_put(kk, 1, o, 0); else O.put(kk, 1, o);
       }
     }
   }
-  O.finish();
+  O.finish(5);
 }
 // ---- squaring in the cyclotomic subgroup (Granger-Scott) ------------------------------------------------------------------
 // After the easy part of the final exponentiation an element a = sum c_i X^i has order dividing q^4 - q^2 + 1.  With

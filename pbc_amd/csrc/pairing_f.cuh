@@ -496,6 +496,7 @@ static PBC_DEV void wide_carry(wide<ND> &W, const fl<ND> &oneL) {
 // through X^(6+k) = negalpha X^k as four more products of the same lazy sums: one reduction per output component.
 static __device__ __noinline__ void f12_sqr_lds(int cur) {
   OutArea O;
+  fl<ND> hx, hy;                                 // one area: coefficient 4 waits in registers, 0-3 in the buffer, 5 needs neither
   O.dst = kOneArea ? 0 : 1 - cur;
   fl<ND> by[6];                                  // beta y_i for the compile-time index of each pair
 #pragma unroll
@@ -549,13 +550,14 @@ static __device__ __noinline__ void f12_sqr_lds(int cur) {
         }
         fl<ND> o;                                // (one area: the last coefficient is complete only when every read of the
         wide_reduce<ND>(o, Wx);                  // operand is done -- it goes straight to its slot)
-        if (kOneArea && kk == 5) ldsf_put(kk, 0, o, 0); else O.put(kk, 0, o);
+        if (kOneArea && kk == 5) ldsf_put(kk, 0, o, 0); else if (kOneArea && kk == 4) hx = o; else O.put(kk, 0, o);
         wide_reduce<ND>(o, Wy);
-        if (kOneArea && kk == 5) ldsf_put(kk, 1, o, 0); else O.put(kk, 1, o);
+        if (kOneArea && kk == 5) ldsf_put(kk, 1, o, 0); else if (kOneArea && kk == 4) hy = o; else O.put(kk, 1, o);
       }
     }
   }
-  O.finish(5);
+  O.finish(4);
+  if constexpr (kOneArea) { ldsf_put(4, 0, hx, 0); ldsf_put(4, 1, hy, 0); }
 }
 // area `cur` times (a Qx X^4 + b Qy X^3 + c) into area 1 - cur (f_miller_evalfn, f_param.c:109-149): the formulas of
 // f_line_mul
@@ -610,6 +612,7 @@ static __device__ __noinline__ void f_line_mul_lds(int cur, v5 va, v5 vb, v5 vc,
 // indices, the accumulator's coefficients from LDS; fold as in f12_sqr_lds)
 static __device__ __noinline__ void f12_mul_lds(int cur, const f12 *b) {
   OutArea O;
+  fl<ND> hx, hy;
   O.dst = kOneArea ? 0 : 1 - cur;
   f12r B;
   f12_load_regs(B, b, false);
@@ -650,13 +653,14 @@ static __device__ __noinline__ void f12_mul_lds(int cur, const f12 *b) {
         }
         fl<ND> o;                                // (one area: the last coefficient is complete only when every read of the
         wide_reduce<ND>(o, Wx);                  // operand is done -- it goes straight to its slot)
-        if (kOneArea && kk == 5) ldsf_put(kk, 0, o, 0); else O.put(kk, 0, o);
+        if (kOneArea && kk == 5) ldsf_put(kk, 0, o, 0); else if (kOneArea && kk == 4) hx = o; else O.put(kk, 0, o);
         wide_reduce<ND>(o, Wy);
-        if (kOneArea && kk == 5) ldsf_put(kk, 1, o, 0); else O.put(kk, 1, o);
+        if (kOneArea && kk == 5) ldsf_put(kk, 1, o, 0); else if (kOneArea && kk == 4) hy = o; else O.put(kk, 1, o);
       }
     }
   }
-  O.finish(5);
+  O.finish(4);
+  if constexpr (kOneArea) { ldsf_put(4, 0, hx, 0); ldsf_put(4, 1, hy, 0); }
 }
 // ---- squaring in the cyclotomic subgroup (Granger-Scott) ------------------------------------------------------------------
 // After the easy part of the final exponentiation an element a = sum c_i X^i has order dividing q^4 - q^2 + 1.  With

@@ -450,7 +450,7 @@ static __device__ __noinline__ void f_line_mul(f12 *v, v5 va, v5 vb, v5 vc, cons
 // the current area at LDS speed -- also the partner coefficient of a product, whose index depends on the rolled output
 // loop -- and writes the result coefficients into the other area.  Register needs stay small (no spills), at the price
 // of 72 KB of LDS per workgroup: one wave per SIMD.
-static constexpr bool kLdsMiller = FL <= 6;
+static constexpr bool kLdsMiller = FL <= 6;       // (the 8-word fields on this path, one area at one wave per SIMD: 1.25 M against 1.37 M pairings/s)
 static constexpr bool kOneArea = kF12Bufs<ND> == 1;
 static PBC_DEV int next_area(int cur) { return kOneArea ? 0 : cur ^ 1; }
 // Where the coefficients of a result go while the operand area is still being read.  Two areas: straight into the
@@ -962,8 +962,11 @@ static __device__ __noinline__ void f12_pow_x(f12 *r, const f12 *a) {
 #pragma nounroll
     for (int i = c_f.bn_xbits - 2; i >= 0; i--) {
       // (every caller's `a` is a power of the easy part's result: cyclotomic subgroup)
-      if (kOneArea && c_f.cyc_ok) f12_cyc_sqr_lds();
-      else { f12_sqr_lds(cur); cur = next_area(cur); }
+      bool done = false;
+      if constexpr (kOneArea && kCap >= 9) {     // (the sums of cyc_pair take nine product units: six-limb fields)
+        if (c_f.cyc_ok) { f12_cyc_sqr_lds(); done = true; }
+      }
+      if (!done) { f12_sqr_lds(cur); cur = next_area(cur); }
       if ((c_f.bn_x[i >> 5] >> (i & 31)) & 1) { f12_mul_lds(cur, a); cur = next_area(cur); }
     }
     f12_lds_export(r, cur);                      // r may be a: a is no longer read

@@ -332,6 +332,26 @@ def test_df_full_size_batch_properties(hips, t, log2n):
     assert np.array_equal(M[0][torch.arange(D), torch.arange(D)].cpu().numpy(), v.gt)
 
 
+@pytest.mark.parametrize("extra", [0, 1, 77, 128, 300])
+def test_f_resident_grid_ragged_sizes(hips, extra):
+    """The type f kernel is launched with resident workgroups that stride over the batch (pbc_hip.hip resident_grid):
+    batches just above one chip residency -- 1024 workgroups of 128 lanes on an MI355X -- with ragged tails: every unit
+    bit-exact (the chain fixture tiled), none left out, none written twice past the end."""
+    import torch
+    v = golden("f_chain128.vec")
+    P = hips["f"]
+    n = 1024 * 128 + extra
+    g1 = torch.from_numpy(np.tile(v.g1, (-(-n // v.n), 1))[:n].copy()).cuda()
+    g2 = torch.from_numpy(np.tile(v.g2, (-(-n // v.n), 1))[:n].copy()).cuda()
+    GT = torch.full((n + 64, v.lenT), 0xA5, dtype=torch.uint8, device="cuda")
+    P.element_pairing_dev(GT.data_ptr(), g1.data_ptr(), g2.data_ptr(), n, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    got = GT.cpu().numpy()
+    want = np.tile(v.gt, (-(-n // v.n), 1))[:n]
+    assert np.array_equal(got[:n], want)
+    assert (got[n:] == 0xA5).all()
+
+
 def test_a_prod16_full_size_batch_properties(hip_a, oracle_a):
     """BASELINE config 5: 2^18 products of 16 Type-A pairings in one launch.  Size-independent
     checks: reversing the 16 terms of every product must not change a single output byte, and a

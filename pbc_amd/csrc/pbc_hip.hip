@@ -63,7 +63,7 @@ constexpr int kBlock = 128;
 // holds at once (resident_grid below) and every workgroup walks the batch in strides of the grid: a lane runs its pairings
 // one after the other.  With one workgroup per 128 units the dispatcher refills the CUs round by round, and with 36 KB of
 // LDS per workgroup the rounds do not pack: a few workgroups find their LDS slot taken and wait for the NEXT round, so a
-// 2^18 batch (two rounds of 1024 workgroups) takes three (tools/exp/occ2.hip: mean residency 1.4 waves per SIMD; a
+// 2^18 batch (two rounds of 1024 workgroups) takes three (tools/occ_schedule_probe.hip: mean residency 1.4 waves per SIMD; a
 // single wave gets a multiply-add through only every 9.1 cycles, two share the pipe at 4.6).  All control flow is
 // data-independent, so equal shares finish together.  Measured on the other kernels (types a, d, products,
 // preprocessed pairings: 8 or more rounds, or LDS to spare): 3 - 4 % SLOWER than one workgroup per 128 units -- they keep

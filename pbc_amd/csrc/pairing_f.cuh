@@ -94,6 +94,23 @@ static PBC_DEV fl<ND> fl29(const uint32_t *l) {                 // a constant ke
   for (int i = 0; i < Limbs29<ND>::L; i++) r.l[i] = l[i];
   return r;
 }
+// Time-sliced fairness between the two waves of a SIMD.  With equal priorities the arbiter prefers the older wave: of two
+// waves that start together on identical work one ran its two pairings in 21 ms, the other in 31 ms -- the last third of
+// the launch with one wave per SIMD, i.e. at half the multiply-add rate (per-wave timestamps, profiles/r03_notes.md).  The
+// waves of a SIMD sit in slots of different parity and read the same clock: at the entry of every F_q^12 operation a wave
+// takes the high priority when bit PBC_F_FAIR_BIT of the clock equals its slot's parity, the low one otherwise.
+#ifndef PBC_F_FAIR_BIT
+#define PBC_F_FAIR_BIT 21                 // slices of 2^21 cycles (0.9 ms): 28.4 ms per 2^18 launch; 2^16: 30.3, 2^19: 28.8, 2^23: 28.8, none: 31.2
+#endif
+static PBC_DEV void fair_tick() {
+#if !defined(PBC_HOSTSIM) && !defined(PBC_F_NO_FAIR)
+  uint32_t hw;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+  const uint64_t t = __builtin_readcyclecounter();
+  if (((uint32_t) (t >> PBC_F_FAIR_BIT) ^ hw) & 1) __builtin_amdgcn_s_setprio(3);
+  else __builtin_amdgcn_s_setprio(0);
+#endif
+}
 // beta * y on limb forms (y: normalised limbs, value < 2.001 q).  General beta: a Montgomery product with the constant.
 // i-basis (BM1): K - y with K = 4 q in borrowed limbs, then a parallel carry pass -- 24 instructions
 // instead of 72 multiply-adds; the result has limbs <= 2^29 + 6 and a value below 4 q, which every sum it enters holds.
@@ -306,6 +323,7 @@ static PBC_DEV g2 f12_sqr_coeff(const f12r &A, int k) {
 // r_k = d_k + negalpha d_{k+6}  (X^(6+k) = negalpha X^k), k = 0..5; d_11 does not exist
 // (the two coefficients of a fold pair share one instance of the coefficient body: instruction-cache footprint)
 static __device__ __noinline__ void f12_mul(f12 *r, const f12 *a, const f12 *b) {
+  fair_tick();
   f12r A;
   f12_load_regs(A, a, false);
   f12_stage(b);
@@ -324,6 +342,7 @@ static __device__ __noinline__ void f12_mul(f12 *r, const f12 *a, const f12 *b) 
   }
 }
 static __device__ __noinline__ void f12_sqr(f12 *r, const f12 *a) {
+  fair_tick();
   f12r A;
   f12_load_regs(A, a, true);
   const g2 na = fk2(c_f.negalpha);
@@ -495,6 +514,7 @@ static PBC_DEV void wide_carry(wide<ND> &W, const fl<ND> &oneL) {
 // area `cur` squared into area 1 - cur.  Coefficient k + 6 of the plain square is reduced first and enters coefficient k
 // through X^(6+k) = negalpha X^k as four more products of the same lazy sums: one reduction per output component.
 static __device__ __noinline__ void f12_sqr_lds(int cur) {
+  fair_tick();
   OutArea O;
   fl<ND> hx, hy;                                 // one area: coefficient 4 waits in registers, 0-3 in the buffer, 5 needs neither
   O.dst = kOneArea ? 0 : 1 - cur;
@@ -562,6 +582,7 @@ static __device__ __noinline__ void f12_sqr_lds(int cur) {
 // area `cur` times (a Qx X^4 + b Qy X^3 + c) into area 1 - cur (f_miller_evalfn, f_param.c:109-149): the formulas of
 // f_line_mul
 static __device__ __noinline__ void f_line_mul_lds(int cur, v5 va, v5 vb, v5 vc, const g2 *Qx, const g2 *Qy) {
+  fair_tick();
   OutArea O;
   O.dst = kOneArea ? 0 : 1 - cur;
   fq a, b, c;
@@ -611,6 +632,7 @@ static __device__ __noinline__ void f_line_mul_lds(int cur, v5 va, v5 vb, v5 vc,
 // area `cur` times the private-memory element b into area 1 - cur (b's limb forms in registers with compile-time
 // indices, the accumulator's coefficients from LDS; fold as in f12_sqr_lds)
 static __device__ __noinline__ void f12_mul_lds(int cur, const f12 *b) {
+  fair_tick();
   OutArea O;
   fl<ND> hx, hy;
   O.dst = kOneArea ? 0 : 1 - cur;
@@ -780,6 +802,7 @@ static PBC_DEV void cyc_store(vcyc r, int cf, int cg) {
 }
 // area 0 squared in place (one-area layout; the element must lie in the cyclotomic subgroup)
 static __device__ __noinline__ void f12_cyc_sqr_lds() {
+  fair_tick();
   const vcyc r0 = cyc_pair(0, 3, 0, 3, 0);
   cyc_store(r0, 0, 3);                           // c0, c3 are read by no other pair
   const vcyc r1 = cyc_pair(1, 4, 2, 5, 0);       // c2', c5'

@@ -270,6 +270,9 @@ __global__ void __launch_bounds__(kBlock, PBC_DF_WAVES) d_pp_apply_kernel(uint8_
 template <int N, bool BM1>
 __global__ void __launch_bounds__(kBlock, N <= 5 ? (PBC_F_AREAS == 1 ? 2 : 1) : PBC_F_WAVES) f_prod_pairing_kernel(uint8_t *gt, const uint8_t *g1,
                                                                  const uint8_t *g2, size_t n, int k, KArgs<N> ka) {
+#ifdef PBC_F_WHATIF_TRACE                        // what-if builds only (tools/whatif_time.py --trace): per-wave start / end / HW_ID behind the results
+  const uint64_t trace_t0 = wall_clock64();
+#endif
   PBC_RESIDENT_LOOP(n) {
     size_t idx = vb * kBlock + threadIdx.x;
     size_t ld = idx < n ? idx : n - 1;
@@ -282,6 +285,15 @@ __global__ void __launch_bounds__(kBlock, N <= 5 ? (PBC_F_AREAS == 1 ? 2 : 1) : 
       for (int i = 0; i < LT / 4; i++) dst[i] = src[i];
     }
   }
+#ifdef PBC_F_WHATIF_TRACE
+  if ((threadIdx.x & 63) == 0) {
+    uint32_t hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    uint64_t *t = reinterpret_cast<uint64_t *>(gt + ((n * (size_t) (12 * fpk<N>().fbytes) + 255) & ~(size_t) 255)) + (size_t) (blockIdx.x * 2 + (threadIdx.x >> 6)) * 4;
+    t[0] = trace_t0; t[1] = wall_clock64(); t[2] = hw; t[3] = xcc;
+  }
+#endif
 }
 
 template <int N>

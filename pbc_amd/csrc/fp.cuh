@@ -87,6 +87,23 @@ template <class T, int OFF>
 PBC_DEV const T &kconst() { return *reinterpret_cast<const T *>(pbc_kargs_base() + (KSEG - KOFF_END + OFF)); }
 template <int N> PBC_DEV const FpK<N> &fpk() { return *reinterpret_cast<const FpK<N> *>(pbc_kargs_base() + (KSEG - (int) sizeof(KArgs<N>))); }
 
+// Time-sliced fairness between the two waves of a SIMD.  With equal priorities the arbiter prefers the older wave: of two
+// waves that start together on identical work (type f, resident workgroups) one ran its two pairings in 21 ms, the other
+// in 31 ms -- the last third of the launch with one wave per SIMD, i.e. at half the multiply-add rate (per-wave timestamps,
+// profiles/r03_notes.md).  The waves of a SIMD sit in slots of different parity and read the same clock: a wave takes the
+// high priority when bit BIT of the clock equals its slot's parity, the low one otherwise.  Called at the entry of
+// long-running operations.
+template <int BIT>
+PBC_DEV void pbc_fair_tick() {
+#if !defined(PBC_HOSTSIM) && !defined(PBC_NO_FAIR)
+  uint32_t hw;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+  const uint64_t t = __builtin_readcyclecounter();
+  if (((uint32_t) (t >> BIT) ^ hw) & 1) __builtin_amdgcn_s_setprio(3);
+  else __builtin_amdgcn_s_setprio(0);
+#endif
+}
+
 // r = (carry:t) >= p ? t - p : t      (final correction of add / mul)
 // __builtin_addc/__builtin_subc lower to v_addc_co_u32 / v_subb_co_u32 chains.
 template <int N>

@@ -17,6 +17,9 @@
 #pragma once
 #include "fp.cuh"
 
+#ifndef PBC_AP_FAIR_BIT
+#define PBC_AP_FAIR_BIT 23                // priority slices of the word-form type a kernels (fp.cuh pbc_fair_tick)
+#endif
 namespace pbc {
 
 // F_q^2 = F_q[i]/(i^2+1)   (arith/fieldquadratic.c fi_*; q = 3 mod 4)
@@ -208,6 +211,7 @@ PBC_DEV void a_final_exp(fp2<N> &out, const fp2<N> &f) {
   v0 = two;
   v1 = P;
   for (int j = c_a.hbits - 1; j >= 0; j--) {
+    if ((j & 15) == 0) pbc_fair_tick<PBC_AP_FAIR_BIT>();
     bool bit = j ? ((c_a.h[j >> 5] >> (j & 31)) & 1) : false;   // j == 0 runs the 0-branch (:243-249)
     fp<N> m, s;
     fp_mul<N>(m, v0, v1);
@@ -472,6 +476,7 @@ PBC_DEV void a_prod_pairing_lane(uint8_t *gt, const uint8_t *g1, const uint8_t *
   for (int i = 0; i < N; i++) f.y.v[i] = 0;
   a_lds_put<N>(lds_f, stride, f);
   for (int i = c_a.exp2 - 1; i >= 0; i--) {
+    pbc_fair_tick<PBC_AP_FAIR_BIT>();            // (resident workgroups, pbc_hip.hip)
     a_lds_get<N>(f, lds_f, stride);
     fi_sqr<N>(f, f);
     a_lds_put<N>(lds_f, stride, f);

@@ -35,6 +35,12 @@
 namespace pbc {
 
 constexpr int AL_LANES = 128;
+// Slices of the time-sliced priorities between the two waves of a SIMD (fp.cuh pbc_fair_tick; the kernels on these routines
+// are launched with resident workgroups): 2^23 cycles = 3.5 ms.  Same-box A/B on 2^20 pairings: none (one workgroup per
+// 128 units) 87.6 ms, 2^21 82.1, 2^23 81.2 - 82.0, 2^24 82.5, 2^25 83.3, 2^26 84.4.
+#ifndef PBC_A_FAIR_BIT
+#define PBC_A_FAIR_BIT 23
+#endif
 #ifdef PBC_HOSTSIM
 #define PBC_PRIVATE
 #else
@@ -330,6 +336,7 @@ struct AL {
   // sum normalised first, which costs more than the squaring saves.  9 M + 6 S + 2 two-term sums per step.
   static PBC_DEV void double_step(jacl &V, const QPriv &Q) {
     el XX, YY, M, t0, t1, lx, ly, Z3, S1, W;
+    pbc_fair_tick<PBC_A_FAIR_BIT>();
     fsqr();
     sqr(XX, V.X);
     lds_get(t0, SLOT_ZZ);
@@ -466,6 +473,7 @@ struct AL {
     for (int j = c_a.hbits - 1; j >= 0; j--) {
       const bool bit = j ? ((c_a.h[j >> 5] >> (j & 31)) & 1) : false;
       el m, s;
+      if ((j & 15) == 0) pbc_fair_tick<PBC_A_FAIR_BIT>();
       mul(m, v0, v1);
       subk(m, m, P, K4);               // P almost normalised, B 2.1
       norm(m, m);                      // B 5.1
@@ -542,6 +550,7 @@ struct AL {
     }
     int slot = 0;
     for (int i = c_a.exp2 - 1; i >= 0; i--, slot++) {
+      pbc_fair_tick<PBC_A_FAIR_BIT>();
       fsqr();
       pp_line(tab, slot, Qx, Qy);
       if (i == c_a.exp1) pp_line(tab, c_a.exp2, Qx, Qy);

@@ -24,7 +24,14 @@
 #pragma once
 #include "fp.cuh"
 
+#ifndef PBC_D_FAIR_BIT
+#define PBC_D_FAIR_BIT 21
+#endif
 namespace pbc {
+// Resident workgroups + time-sliced priorities (pbc_hip.hip, fp.cuh) pay for the 7-word fields only (same-box A/B, ms per
+// 2^18 launch: d201 41.6 -> 32.8; but d159 14.9 -> 16.2, d190 31.5 -> 58.4, 16-term products of d159 160 -> 185; the type g
+// instantiation faults with the loop around its body): a per-instantiation choice.
+template <int N, int DEG> constexpr bool kDResident = N == 7 && DEG == 3;
 
 constexpr int ND_MAX = 7;              // widest MNT field built in: 224-bit q (d224.param)
 constexpr int DEG_MAX = 5;             // d = k/2: 3 (type d), 5 (type g)
@@ -61,6 +68,11 @@ template <int ND, int DEG> __shared__ uint32_t g_lds_d[(2 * DEG * ND + 5 * kPoin
 // type d files), DEG = d.  Names keep the type d flavour: f3 = F_q^d, f6 = F_q^k.
 template <int ND, int DEG>
 struct TypeMNT {
+// time-sliced priorities between the two waves of a SIMD (fp.cuh pbc_fair_tick): for the instantiations that are launched
+// with resident workgroups (kDResident)
+static PBC_DEV void d_fair_tick() {
+  if constexpr (kDResident<ND, DEG>) pbc_fair_tick<PBC_D_FAIR_BIT>();
+}
 typedef fp<ND> fq;
 struct f3 { fq c[DEG]; };              // c0 + c1 x + ... + c(d-1) x^(d-1)
 struct f6 { f3 x, y; };                // x + y sqrt(v)
@@ -909,6 +921,7 @@ static PBC_DEV bool d_miller_lane(f6 &v, const uint8_t *g1, const uint8_t *g2) {
   if constexpr (kFusedF6) {
     f6vec vv = f6_pack(v);
     for (int m = c_d.rbits - 2;; m--) {
+      d_fair_tick();
       vv = d_dbl_line_mul_fn(vv);
       if (m <= 0) break;
       const int dig = d_digit(m);
@@ -919,6 +932,7 @@ static PBC_DEV bool d_miller_lane(f6 &v, const uint8_t *g1, const uint8_t *g2) {
     return valid;
   }
   for (int m = c_d.rbits - 2;; m--) {
+    d_fair_tick();
     f6 e0;
     d_unpack(e0, d_dbl_line_fn());
     f6_mul(v, v, e0);
@@ -983,6 +997,7 @@ static PBC_DEV void d_final_exp(f6 &out, const f6 &m) {
   v1 = P;
   // lucas_even ladder (d_param.c:462-482): j == 0 takes the 0-branch
   for (int j = c_d.phikbits - 1; j >= 0; j--) {
+    if ((j & 7) == 0) d_fair_tick();
     bool bit = j ? ((c_d.phik[j >> 5] >> (j & 31)) & 1) : false;
     f3 mm, s;
     f3_mul(mm, v0, v1);
@@ -1046,6 +1061,7 @@ static PBC_DEV bool d_pp_init_lane(uint32_t *tab, const uint8_t *g1) {
   }
   int slot = 0;
   for (int m = c_d.rbits - 2;; m--) {
+    d_fair_tick();
     fq la, lb, lc;
     if (limb) {                        // the table stays in canonical word form
       if constexpr (kLimbPoint) {
@@ -1136,6 +1152,7 @@ static PBC_DEV void d_pp_apply_lane(uint8_t *gt, const uint32_t *tab, bool p_val
   if constexpr (kFusedF6) {
     f6vec vv = f6_pack(v);
     for (int m = c_d.rbits - 2;; m--) {
+      d_fair_tick();
       vv = d_pp_line_mul(vv, tab, slot++);
       if (m <= 0) break;
       if (d_digit(m)) vv = d_pp_line_mul(vv, tab, slot++);
@@ -1144,6 +1161,7 @@ static PBC_DEV void d_pp_apply_lane(uint8_t *gt, const uint32_t *tab, bool p_val
     f6_unpack(v, vv);
   } else {
     for (int m = c_d.rbits - 2;; m--) {
+      d_fair_tick();
       f6 e0;
       d_pp_line(e0, tab, slot++);
       f6_mul(v, v, e0);
@@ -1192,6 +1210,7 @@ static PBC_DEV void d_prod_pairing_lane(uint8_t *gt, const uint8_t *g1, const ui
     f3_sub(F.y, F.x, F.x);
     f6vec FF = f6_pack(F);               // (kFusedF6: the accumulator in its register-vector form)
     for (int m = c_d.rbits - 2;; m--) {
+      d_fair_tick();
       const int dig = m > 0 ? d_digit(m) : 0;
       for (int j = 0; j < k; j++) {
         uint32_t *w = ws + (size_t) j * REC;

@@ -22,6 +22,9 @@
 #pragma once
 #include "fp.cuh"
 
+#ifndef PBC_F_FAIR_BIT
+#define PBC_F_FAIR_BIT 21                 // slices of 2^21 cycles (0.9 ms): 28.4 ms per 2^18 launch; 2^16: 30.3, 2^19: 28.8, 2^23: 28.8, none: 31.2
+#endif
 namespace pbc {
 
 constexpr int ND = 5;                  // the 158-bit BN field of f.param: 5 x 32-bit words, 6 x 29-bit limbs
@@ -94,23 +97,7 @@ static PBC_DEV fl<ND> fl29(const uint32_t *l) {                 // a constant ke
   for (int i = 0; i < Limbs29<ND>::L; i++) r.l[i] = l[i];
   return r;
 }
-// Time-sliced fairness between the two waves of a SIMD.  With equal priorities the arbiter prefers the older wave: of two
-// waves that start together on identical work one ran its two pairings in 21 ms, the other in 31 ms -- the last third of
-// the launch with one wave per SIMD, i.e. at half the multiply-add rate (per-wave timestamps, profiles/r03_notes.md).  The
-// waves of a SIMD sit in slots of different parity and read the same clock: at the entry of every F_q^12 operation a wave
-// takes the high priority when bit PBC_F_FAIR_BIT of the clock equals its slot's parity, the low one otherwise.
-#ifndef PBC_F_FAIR_BIT
-#define PBC_F_FAIR_BIT 21                 // slices of 2^21 cycles (0.9 ms): 28.4 ms per 2^18 launch; 2^16: 30.3, 2^19: 28.8, 2^23: 28.8, none: 31.2
-#endif
-static PBC_DEV void fair_tick() {
-#if !defined(PBC_HOSTSIM) && !defined(PBC_F_NO_FAIR)
-  uint32_t hw;
-  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-  const uint64_t t = __builtin_readcyclecounter();
-  if (((uint32_t) (t >> PBC_F_FAIR_BIT) ^ hw) & 1) __builtin_amdgcn_s_setprio(3);
-  else __builtin_amdgcn_s_setprio(0);
-#endif
-}
+static PBC_DEV void fair_tick() { pbc_fair_tick<PBC_F_FAIR_BIT>(); }
 // beta * y on limb forms (y: normalised limbs, value < 2.001 q).  General beta: a Montgomery product with the constant.
 // i-basis (BM1): K - y with K = 4 q in borrowed limbs, then a parallel carry pass -- 24 instructions
 // instead of 72 multiply-adds; the result has limbs <= 2^29 + 6 and a value below 4 q, which every sum it enters holds.

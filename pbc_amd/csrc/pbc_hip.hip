@@ -83,16 +83,18 @@ static_assert(kBlock == D_LANES, "pairing_d.cuh sizes its LDS state for 128-lane
 template <int N>
 __global__ void __launch_bounds__(kBlock, PBC_A_WAVES) al_pairing_kernel(uint8_t *gt, const uint8_t *g1,
                                                              const uint8_t *g2, size_t n, KArgs<N> ka) {
-  size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
-  size_t ld = idx < n ? idx : n - 1;
-  constexpr int L = 8 * N;
-  __attribute__((aligned(16))) uint8_t out[L];
-  AL<N>::pairing_lane(out, g1 + ld * L, g2 + ld * L);
-  if (idx < n) {
-    uint4 *dst = reinterpret_cast<uint4 *>(gt + idx * L);
-    const uint4 *src = reinterpret_cast<const uint4 *>(out);
+  PBC_RESIDENT_LOOP(n) {
+    size_t idx = vb * kBlock + threadIdx.x;
+    size_t ld = idx < n ? idx : n - 1;
+    constexpr int L = 8 * N;
+    __attribute__((aligned(16))) uint8_t out[L];
+    AL<N>::pairing_lane(out, g1 + ld * L, g2 + ld * L);
+    if (idx < n) {
+      uint4 *dst = reinterpret_cast<uint4 *>(gt + idx * L);
+      const uint4 *src = reinterpret_cast<const uint4 *>(out);
 #pragma unroll
-    for (int i = 0; i < L / 16; i++) dst[i] = src[i];
+      for (int i = 0; i < L / 16; i++) dst[i] = src[i];
+    }
   }
 }
 
@@ -101,18 +103,20 @@ __global__ void __launch_bounds__(kBlock, PBC_A_WAVES) al_pairing_kernel(uint8_t
 template <int N>
 __global__ void __launch_bounds__(kBlock, PBC_A_WAVES) a_prod_pairing_kernel(uint8_t *gt, const uint8_t *g1,
                                                                  const uint8_t *g2, size_t n, int k, uint4 *ws, KArgs<N> ka) {
-  size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
-  size_t ld = idx < n ? idx : n - 1;
-  constexpr int L = 8 * N;
-  __attribute__((aligned(16))) uint8_t out[L];
-  __shared__ uint32_t lds_f[2 * N * kBlock];   // the shared accumulator of every lane, limb-major: conflict-free
-  a_prod_pairing_lane<N>(out, g1 + ld * k * L, g2 + ld * k * L, k,
-                         ws + (size_t) blockIdx.x * (size_t) k * (6 * (N / 4) * kBlock) + threadIdx.x, lds_f + threadIdx.x, kBlock);
-  if (idx < n) {
-    uint4 *dst = reinterpret_cast<uint4 *>(gt + idx * L);
-    const uint4 *src = reinterpret_cast<const uint4 *>(out);
-#pragma unroll
-    for (int i = 0; i < L / 16; i++) dst[i] = src[i];
+  PBC_RESIDENT_LOOP(n) {
+    size_t idx = vb * kBlock + threadIdx.x;
+    size_t ld = idx < n ? idx : n - 1;
+    constexpr int L = 8 * N;
+    __attribute__((aligned(16))) uint8_t out[L];
+    __shared__ uint32_t lds_f[2 * N * kBlock];   // the shared accumulator of every lane, limb-major: conflict-free
+    a_prod_pairing_lane<N>(out, g1 + ld * k * L, g2 + ld * k * L, k,
+                           ws + (size_t) blockIdx.x * (size_t) k * (6 * (N / 4) * kBlock) + threadIdx.x, lds_f + threadIdx.x, kBlock);
+    if (idx < n) {
+      uint4 *dst = reinterpret_cast<uint4 *>(gt + idx * L);
+      const uint4 *src = reinterpret_cast<const uint4 *>(out);
+  #pragma unroll
+      for (int i = 0; i < L / 16; i++) dst[i] = src[i];
+    }
   }
 }
 
@@ -172,16 +176,18 @@ template <int N>
 __global__ void __launch_bounds__(kBlock, PBC_A_WAVES) al_pp_apply_kernel(uint8_t *gt, const uint32_t *__restrict__ tab,
                                                                            const uint32_t *__restrict__ valid,
                                                                            const uint8_t *g2, size_t n, KArgs<N> ka) {
-  size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
-  size_t ld = idx < n ? idx : n - 1;
-  constexpr int L = 8 * N;
-  __attribute__((aligned(16))) uint8_t out[L];
-  AL<N>::pp_apply_lane(out, tab, *valid != 0, g2 + ld * L);
-  if (idx < n) {
-    uint4 *dst = reinterpret_cast<uint4 *>(gt + idx * L);
-    const uint4 *src = reinterpret_cast<const uint4 *>(out);
-#pragma unroll
-    for (int i = 0; i < L / 16; i++) dst[i] = src[i];
+  PBC_RESIDENT_LOOP(n) {
+    size_t idx = vb * kBlock + threadIdx.x;
+    size_t ld = idx < n ? idx : n - 1;
+    constexpr int L = 8 * N;
+    __attribute__((aligned(16))) uint8_t out[L];
+    AL<N>::pp_apply_lane(out, tab, *valid != 0, g2 + ld * L);
+    if (idx < n) {
+      uint4 *dst = reinterpret_cast<uint4 *>(gt + idx * L);
+      const uint4 *src = reinterpret_cast<const uint4 *>(out);
+  #pragma unroll
+      for (int i = 0; i < L / 16; i++) dst[i] = src[i];
+    }
   }
 }
 
@@ -189,9 +195,8 @@ __global__ void __launch_bounds__(kBlock, PBC_A_WAVES) al_pp_apply_kernel(uint8_
 // of F_q and d = k/2, G1 records are 2 fb, G2 and GT 2 d fb bytes (40 / 120 / 120 B for d159.param,
 // 38 / 190 / 190 B for g149.param).
 template <int N, int DEG>
-__global__ void __launch_bounds__(kBlock, PBC_DF_WAVES) d_prod_pairing_kernel(uint8_t *gt, const uint8_t *g1,
-                                                                 const uint8_t *g2, size_t n, int k, uint32_t *ws, KArgs<N> ka) {
-  size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
+static __device__ __forceinline__ void d_prod_unit(size_t vb, uint8_t *gt, const uint8_t *g1, const uint8_t *g2, size_t n, int k, uint32_t *ws) {
+  size_t idx = vb * kBlock + threadIdx.x;
   size_t ld = idx < n ? idx : n - 1;
   const int fb = (int) fpk<N>().fbytes, L1 = 2 * fb, L2 = 2 * DEG * fb, LT = 2 * DEG * fb;
   __attribute__((aligned(4))) uint8_t out[8 * DEG * N];
@@ -205,6 +210,16 @@ __global__ void __launch_bounds__(kBlock, PBC_DF_WAVES) d_prod_pairing_kernel(ui
     } else {
       for (int i = 0; i < LT; i++) gt[idx * LT + i] = out[i];
     }
+  }
+}
+// (resident workgroups where they pay: kDResident, pairing_d.cuh)
+template <int N, int DEG>
+__global__ void __launch_bounds__(kBlock, PBC_DF_WAVES) d_prod_pairing_kernel(uint8_t *gt, const uint8_t *g1,
+                                                                 const uint8_t *g2, size_t n, int k, uint32_t *ws, KArgs<N> ka) {
+  if constexpr (kDResident<N, DEG>) {
+    PBC_RESIDENT_LOOP(n) d_prod_unit<N, DEG>(vb, gt, g1, g2, n, k, ws);
+  } else {
+    d_prod_unit<N, DEG>(blockIdx.x, gt, g1, g2, n, k, ws);
   }
 }
 
@@ -241,10 +256,9 @@ __global__ void d_pp_init_kernel(uint32_t *tab, uint32_t *valid, const uint8_t *
   *valid = TypeMNT<N, DEG>::d_pp_init_lane(tab, g1) ? 1u : 0u;
 }
 template <int N, int DEG>
-__global__ void __launch_bounds__(kBlock, PBC_DF_WAVES) d_pp_apply_kernel(uint8_t *gt, const uint32_t *__restrict__ tab,
-                                                                          const uint32_t *__restrict__ valid,
-                                                                          const uint8_t *g2, size_t n, KArgs<N> ka) {
-  size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
+static __device__ __forceinline__ void d_pp_unit(size_t vb, uint8_t *gt, const uint32_t *__restrict__ tab, const uint32_t *__restrict__ valid,
+                                                 const uint8_t *g2, size_t n) {
+  size_t idx = vb * kBlock + threadIdx.x;
   size_t ld = idx < n ? idx : n - 1;
   const int fb = (int) fpk<N>().fbytes, L2 = 2 * DEG * fb, LT = 2 * DEG * fb;
   __attribute__((aligned(4))) uint8_t out[8 * DEG * N];
@@ -257,6 +271,16 @@ __global__ void __launch_bounds__(kBlock, PBC_DF_WAVES) d_pp_apply_kernel(uint8_
     } else {
       for (int i = 0; i < LT; i++) gt[idx * LT + i] = out[i];
     }
+  }
+}
+template <int N, int DEG>
+__global__ void __launch_bounds__(kBlock, PBC_DF_WAVES) d_pp_apply_kernel(uint8_t *gt, const uint32_t *__restrict__ tab,
+                                                                          const uint32_t *__restrict__ valid,
+                                                                          const uint8_t *g2, size_t n, KArgs<N> ka) {
+  if constexpr (kDResident<N, DEG>) {
+    PBC_RESIDENT_LOOP(n) d_pp_unit<N, DEG>(vb, gt, tab, valid, g2, n);
+  } else {
+    d_pp_unit<N, DEG>(blockIdx.x, gt, tab, valid, g2, n);
   }
 }
 
@@ -903,7 +927,7 @@ static int launch_pairing(pbc_hip_pairing_s *P, void *d_gt, const void *d_g1, co
   if (upload && ensure_derived(P, s)) return 1;
   unsigned grid = (unsigned) ((n + kBlock - 1) / kBlock);
   if (P->type == 'a' && !P->a_generic) {
-    hipLaunchKernelGGL(al_pairing_kernel<16>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
+    hipLaunchKernelGGL(al_pairing_kernel<16>, dim3(PBC_RGRID(al_pairing_kernel<16>)), dim3(kBlock), 0, s, (uint8_t *) d_gt,
                        (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, kargs<16>(P));
   } else if ((P->type == 'a' || P->type == '1') && P->nlimb == 16) {   // other sizes: the bit-by-bit kernels
     hipLaunchKernelGGL(a1_prod_pairing_kernel<16>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
@@ -918,7 +942,7 @@ static int launch_pairing(pbc_hip_pairing_s *P, void *d_gt, const void *d_g1, co
     hipLaunchKernelGGL(e_prod_pairing_kernel<33>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
                        (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, 1, kargs<33>(P));
   } else if (P->type == 'd' || P->type == 'g') {
-    PBC_DISPATCH_D(P, hipLaunchKernelGGL((d_prod_pairing_kernel<N, DEG>), dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
+    PBC_DISPATCH_D(P, hipLaunchKernelGGL((d_prod_pairing_kernel<N, DEG>), dim3(kDResident<N, DEG> ? PBC_RGRID(d_prod_pairing_kernel<N, DEG>) : grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
                                                 (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, 1, (uint32_t *) nullptr, kargs<N>(P)));
   } else if (P->type == 'f') {
     if (P->f_bm1) {                    // i-basis constants and the instantiation that goes with them
@@ -1152,6 +1176,7 @@ static int launch_prod(pbc_hip_pairing_s *P, void *d_gt, const void *d_g1, const
   if (upload && ensure_derived(P, s)) return 1;
   unsigned grid = (unsigned) ((n + kBlock - 1) / kBlock);
   if (P->type == 'a' && !P->a_generic) {
+    grid = PBC_RGRID(a_prod_pairing_kernel<16>);                      // one workspace record per RESIDENT workgroup
     void *ws = workspace_get(P, s, (size_t) grid * (size_t) k * (6 * 4 * kBlock) * sizeof(uint4));
     if (!ws) return 1;
     hipLaunchKernelGGL(a_prod_pairing_kernel<16>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
@@ -1170,7 +1195,7 @@ static int launch_prod(pbc_hip_pairing_s *P, void *d_gt, const void *d_g1, const
                        (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k, kargs<33>(P));
   } else if (P->type == 'd' || P->type == 'g') {
     size_t rec = 0;                    // words of Miller state per term and lane (the kernel's own constant)
-    PBC_DISPATCH_D(P, rec = (size_t) TypeMNT<N, DEG>::DL_WORDS);
+    PBC_DISPATCH_D(P, { rec = (size_t) TypeMNT<N, DEG>::DL_WORDS; if (kDResident<N, DEG>) grid = PBC_RGRID(d_prod_pairing_kernel<N, DEG>); });      // one workspace record per RESIDENT workgroup
     void *ws = workspace_get(P, s, (size_t) grid * (size_t) k * rec * kBlock * sizeof(uint32_t));
     if (!ws) return 1;
     PBC_DISPATCH_D(P, hipLaunchKernelGGL((d_prod_pairing_kernel<N, DEG>), dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
@@ -1478,7 +1503,7 @@ extern "C" int pbc_hip_pairing_pp_apply_batch_dev(pbc_hip_pp_t *pp, void *d_gt, 
   if (ensure_derived(P, s)) return 1;
   unsigned grid = (unsigned) ((n + kBlock - 1) / kBlock);
   if (pp->P->type == 'a' && !pp->P->a_generic) {
-    hipLaunchKernelGGL(al_pp_apply_kernel<16>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt, pp->tab, pp->valid,
+    hipLaunchKernelGGL(al_pp_apply_kernel<16>, dim3(PBC_RGRID(al_pp_apply_kernel<16>)), dim3(kBlock), 0, s, (uint8_t *) d_gt, pp->tab, pp->valid,
                        (const uint8_t *) d_g2, n, kargs<16>(P));
   } else if (pp->P->nlimb == 16 && (pp->P->type == 'a' || pp->P->type == '1')) {
     hipLaunchKernelGGL(a1_pp_apply_kernel<16>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt, pp->tab, pp->valid,
@@ -1487,7 +1512,7 @@ extern "C" int pbc_hip_pairing_pp_apply_batch_dev(pbc_hip_pp_t *pp, void *d_gt, 
     hipLaunchKernelGGL(a1_pp_apply_kernel<33>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt, pp->tab, pp->valid,
                        (const uint8_t *) d_g2, n, kargs<33>(P));
   } else {
-    PBC_DISPATCH_D(pp->P, hipLaunchKernelGGL((d_pp_apply_kernel<N, DEG>), dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
+    PBC_DISPATCH_D(pp->P, hipLaunchKernelGGL((d_pp_apply_kernel<N, DEG>), dim3(kDResident<N, DEG> ? PBC_RGRID(d_pp_apply_kernel<N, DEG>) : grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
                                              pp->tab, pp->valid, (const uint8_t *) d_g2, n, kargs<N>(P)));
   }
   HIP_TRY(hipGetLastError());

@@ -31,7 +31,10 @@ namespace pbc {
 // Resident workgroups + time-sliced priorities (pbc_hip.hip, fp.cuh) pay for the 7-word fields only (same-box A/B, ms per
 // 2^18 launch: d201 41.6 -> 32.8; but d159 14.9 -> 16.2, d190 31.5 -> 58.4, 16-term products of d159 160 -> 185; the type g
 // instantiation faults with the loop around its body): a per-instantiation choice.
-template <int N, int DEG> constexpr bool kDResident = N == 7 && DEG == 3;
+#ifndef PBC_D_RES5
+#define PBC_D_RES5 0                   // experiment switch: the 5-word d = 3 instantiation as well
+#endif
+template <int N, int DEG> constexpr bool kDResident = (N == 7 || (N == 5 && PBC_D_RES5)) && DEG == 3;
 
 constexpr int ND_MAX = 7;              // widest MNT field built in: 224-bit q (d224.param)
 constexpr int DEG_MAX = 5;             // d = k/2: 3 (type d), 5 (type g)

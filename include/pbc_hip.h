@@ -84,7 +84,9 @@ int pbc_hip_pairing_length_in_bytes_GT(const pbc_hip_pairing_t *p);
 int pbc_hip_element_pairing_batch(pbc_hip_pairing_t *p, uint8_t *gt, const uint8_t *g1,
                                   const uint8_t *g2, size_t n);
 /* Same with device-resident buffers, enqueued on `stream` (a hipStream_t; NULL = default
- * stream).  Asynchronous: returns after the launch. */
+ * stream).  Asynchronous: returns after the launch.  (Types a, f and the 7-word type d fields: the kernel keeps as many
+ * workgroups resident as the device holds and every lane walks the batch in strides of that residency -- 1024 x 128
+ * units on an MI355X --, so the time of a launch grows in steps of ceil(n / 131072).) */
 int pbc_hip_element_pairing_batch_dev(pbc_hip_pairing_t *p, void *d_gt, const void *d_g1,
                                       const void *d_g2, size_t n, void *stream);
 

@@ -184,6 +184,8 @@ def main():
                     help="the 2^log2n units are the whole job, range-split over the ranks (BASELINE config 5: "
                          "--workload a-prod16 --strong --gpus 8 = 2^18 products sharded across 8 GPUs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--param-extra", default="", help="lines appended to the parameter text (the library's A/B switches, "
+                    "e.g. 'hip_prod_shared=1', comma-separated); reported in config.param_extra")
     ap.add_argument("--no-host-path", action="store_true",
                     help="skip the pinned-host -> host timing of the host-buffer entry point (reported beside `value`, never as it)")
     ap.add_argument("--host-path", action="store_true", help=argparse.SUPPRESS)     # round-1 spelling: now the default
@@ -214,7 +216,7 @@ def main():
     ensure_built(dist, local_rank)
 
     param_path = os.path.join(ROOT, "pbc_amd", "param", pname + ".param")
-    pairing = pbc_amd.Pairing(open(param_path).read())
+    pairing = pbc_amd.Pairing(open(param_path).read() + ("\n" + args.param_extra.replace("=", " ").replace(",", "\n") + "\n" if args.param_extra else ""))
     L1, L2, LT = pairing.length_in_bytes_G1, pairing.length_in_bytes_G2, pairing.length_in_bytes_GT
     n_job = 1 << args.log2n
     if args.strong:                      # range split of one job: rank r owns units [r n_job / world, (r + 1) n_job / world)
@@ -361,7 +363,8 @@ def main():
             "data": "synthetic: (P_i,Q_j) cross pairs of tests/golden/%s (%d x %d distinct), resident in HBM" % (fixture, D, D),
             "config": {"workload": "%s, 2^%d units %s per step" % (desc, args.log2n, "in the whole job" if args.strong else "per GPU"),
                        "units_per_gpu": n, "terms_per_unit": k, "global_batch": n_job if args.strong else n * world,
-                       "parallelism": "range-split x%d, no collectives" % world},
+                       "parallelism": "range-split x%d, no collectives" % world,
+                       **({"param_extra": args.param_extra} if args.param_extra else {})},
             "per_rank_kernel_ms": [round(float(x), 3) for x in per_rank_ms],
             "kernel_only": {"value": round(n / avg_kern_s, 1), "unit": unit_name + " per GPU, events around the launch on rank 0"},
             "host_path": host_path,

@@ -98,12 +98,15 @@ int pbc_hip_element_prod_pairing_batch(pbc_hip_pairing_t *p, uint8_t *gt, const 
                                        const uint8_t *g2, size_t n, int k);
 int pbc_hip_element_prod_pairing_batch_dev(pbc_hip_pairing_t *p, void *d_gt, const void *d_g1,
                                            const void *d_g2, size_t n, int k, void *stream);
-/* The product kernels of types a, d and g keep the Miller state of every term in a device workspace: one buffer per
- * (device, stream) a *_dev product call was enqueued on, sized  ceil(n / 128) * 128 * k * R  bytes with R = 384 (type a) or
- * 4 (2 d N + 5 L) (types d / g: N words and L 29-bit limbs per F_q element, d = 3 or 5 -- 240 for d159), grown on demand and kept by the object -- about 0.8 GB
- * for 2^17 products of 16 type a terms.  At most 8 buffers are kept (least recently used first out, after a device
- * synchronisation); the host-buffer entry points use up to three per device.  Everything is freed by
- * pbc_hip_pairing_clear; this call frees the buffers now (it synchronises the devices they live on). */
+/* The product kernels of types a, d and g use a device workspace: one buffer per (device, stream) a *_dev product call was
+ * enqueued on, grown on demand and kept by the object.  Types d / g keep the Miller state of every term there:
+ * ceil(n / 128) * 128 * k * R  bytes with R = 4 (2 d N + 5 L) (N words and L 29-bit limbs per F_q element, d = 3 or 5 --
+ * 240 for d159), at most one chip residency of workgroups where the kernel runs resident.  Type a with a 512-bit q runs
+ * one TERM per lane and leaves each term's Miller value in a 160-byte record for the kernel that multiplies them:
+ * min(n k, 2^22) * 160 bytes (640 MB at most; longer batches are cut into launches of 2^22 terms).  At most 8 buffers are
+ * kept (least recently used first out, after a device synchronisation); the host-buffer entry points use up to three per
+ * device.  Everything is freed by pbc_hip_pairing_clear; this call frees the buffers now (it synchronises the devices
+ * they live on). */
 int pbc_hip_pairing_release_workspaces(pbc_hip_pairing_t *p);
 
 /* Preprocessed pairings with a fixed first argument (the BLS shape: one public key or

@@ -40,6 +40,8 @@ struct pbc_hip_pairing_s {
   int nlimb;                 // 32-bit limbs of F_q
   int deg;                   // types d / g: degree d = k/2 of F_q^d (3 / 5)
   bool a_generic;            // type a outside the 64-byte fast path: runs on the type a1 kernels
+  bool a_prod_shared;        // type a fast path, products: "hip_prod_shared 1" keeps one product per lane (a_prod_pairing_lane)
+  size_t a_prod_chunk;       // ... otherwise: terms per launch of the one-term-per-lane kernels ("hip_prod_chunk N", tests)
   int len_fq, len1, len2, lenT;
 #define PBC_HOST_FPK(n) FpK<n> k##n;
   PBC_FOR_EACH_N(PBC_HOST_FPK)  // k5, k6, k7, k16: the one matching nlimb is filled
@@ -215,6 +217,12 @@ static int init_type_a(pbc_hip_pairing_s *P, const char *txt, size_t len) {
     if (fill_fpk<16>(P->k16, q)) return fail("type a: bad q");
     P->nlimb = 16;
     P->a_generic = false;
+    int shared = 0;                    // products: one term per lane (pairing_al.cuh) unless the parameter text says otherwise
+    param_int(txt, len, "hip_prod_shared", shared);
+    P->a_prod_shared = shared != 0;
+    int chunk = 1 << 22;               // 2^22 terms = 640 MB of 160-byte workspace records
+    param_int(txt, len, "hip_prod_chunk", chunk);
+    P->a_prod_chunk = chunk < 1 ? 1 : (size_t) chunk;
   } else {
     // any other size up to 1056 bits: the type a1 kernels (plain double-and-add over the bits of r;
     // functions with the same divisor up to vertical lines, which the final power removes) on the

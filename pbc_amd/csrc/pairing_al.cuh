@@ -560,8 +560,9 @@ struct AL {
     a_store_gt<N>(gt, out, valid);
   }
 
-  // element_pairing for one lane
-  static PBC_DEV void pairing_lane(uint8_t *gt, const uint8_t *g1, const uint8_t *g2) {
+  // The Miller loop of one (P, Q) pair: f ends up in its LDS slots (P-class), the return value says whether both
+  // arguments were acceptable (on the curve, P not of order two / O)
+  static PBC_DEV bool miller_lane(const uint8_t *g1, const uint8_t *g2) {
     constexpr int NB = 4 * N;
     jacl V;
     uint32_t Qm[2 * L];                // Q in private memory: read twice per step, by address
@@ -607,6 +608,63 @@ struct AL {
         }
         add_step(V, x2, y2, Q);
       }
+    }
+    return valid;
+  }
+
+  // element_pairing for one lane
+  static PBC_DEV void pairing_lane(uint8_t *gt, const uint8_t *g1, const uint8_t *g2) {
+    const bool valid = miller_lane(g1, g2);
+    fp2<N> out;
+    final_exp(out);
+    a_store_gt<N>(gt, out, valid);
+  }
+
+  // ---- element_prod_pairing with one TERM per lane -----------------------------------------------------------------
+  // The reference's a_pairings_affine (ecc/a_param.c:1283-1383) shares the accumulator's squaring between the k terms
+  // of a product; one lane running k terms that way (a_prod_pairing_lane, pairing_a.cuh) has to keep the per-term
+  // state in a global workspace (345 GB of traffic per 2^18 x 16 launch) and runs the word-form routines.  Here every
+  // term is a lane of the single-pairing Miller loop above (limb form, nothing outside registers and LDS; 12 % more
+  // multiply-adds per term for its own squaring of f), which leaves its Miller value in a 160-byte workspace record;
+  // a second, short kernel multiplies the k values of a product and runs ONE final exponentiation (the F_q^* factors
+  // by which the Miller values differ from the reference's die there).
+  static constexpr int MREC = (2 * L + 1 + 3) / 4;        // uint4s per record: fx, fy (L limbs each), flag
+  static PBC_DEV void miller_record_lane(uint4 *rec, const uint8_t *g1, const uint8_t *g2) {
+    const bool valid = miller_lane(g1, g2);
+    el fx, fy;
+    lds_get(fx, SLOT_FX);
+    lds_get(fy, SLOT_FY);
+    AL_HS(if (fx.hs_u > U_STRICT || fy.hs_u > U_STRICT || fx.hs_B > 1.5 || fy.hs_B > 1.5) hs_fail("Miller value not P-class", fx.hs_B);)
+    uint32_t w[4 * MREC];
+#pragma unroll
+    for (int i = 0; i < L; i++) { w[i] = fx.l[i]; w[L + i] = fy.l[i]; }
+#pragma unroll
+    for (int i = 2 * L; i < 4 * MREC; i++) w[i] = valid ? 1u : 0u;
+#pragma unroll
+    for (int i = 0; i < MREC; i++) rec[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+  }
+  static PBC_DEV bool record_get(el &x, el &y, const uint4 *rec) {
+    uint32_t w[4 * MREC];
+#pragma unroll
+    for (int i = 0; i < MREC; i++) {
+      const uint4 t = rec[i];
+      w[4 * i] = t.x; w[4 * i + 1] = t.y; w[4 * i + 2] = t.z; w[4 * i + 3] = t.w;
+    }
+#pragma unroll
+    for (int i = 0; i < L; i++) { x.l[i] = w[i]; y.l[i] = w[L + i]; }
+    AL_HS(hs_set(x, U_STRICT, 1.5); hs_set(y, U_STRICT, 1.5);)
+    return w[2 * L] != 0;
+  }
+  // one product per lane: the k records of its terms -> GT bytes (any unacceptable term: the identity, as the other
+  // product kernels and element_prod_pairing's callers see it)
+  static PBC_DEV void prod_finish_lane(uint8_t *gt, const uint4 *rec, int k) {
+    el x, y;
+    bool valid = record_get(x, y, rec);
+    lds_put(SLOT_FX, x);
+    lds_put(SLOT_FY, y);
+    for (int j = 1; j < k; j++) {
+      valid &= record_get(x, y, rec + (size_t) j * MREC);
+      fmul(x, y);
     }
     fp2<N> out;
     final_exp(out);

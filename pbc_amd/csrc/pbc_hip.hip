@@ -98,6 +98,42 @@ __global__ void __launch_bounds__(kBlock, PBC_A_WAVES) al_pairing_kernel(uint8_t
   }
 }
 
+// Products of Type-A pairings on the limb-form routines, one TERM per lane (AL::miller_record_lane): the Miller value
+// of term t goes to workspace record t; al_prod_finish_kernel then multiplies the k values of each product and runs its
+// final exponentiation (one product per lane).
+template <int N>
+__global__ void __launch_bounds__(kBlock, PBC_A_WAVES) al_miller_kernel(uint4 *ws, const uint8_t *g1, const uint8_t *g2,
+                                                                        size_t n, KArgs<N> ka) {
+  PBC_RESIDENT_LOOP(n) {
+    size_t idx = vb * kBlock + threadIdx.x;
+    size_t ld = idx < n ? idx : n - 1;
+    constexpr int L = 8 * N;
+    uint4 rec[AL<N>::MREC];
+    AL<N>::miller_record_lane(rec, g1 + ld * L, g2 + ld * L);
+    if (idx < n) {
+#pragma unroll
+      for (int i = 0; i < AL<N>::MREC; i++) ws[idx * AL<N>::MREC + i] = rec[i];
+    }
+  }
+}
+template <int N>
+__global__ void __launch_bounds__(kBlock, PBC_A_WAVES) al_prod_finish_kernel(uint8_t *gt, const uint4 *ws, size_t n, int k,
+                                                                             KArgs<N> ka) {
+  PBC_RESIDENT_LOOP(n) {
+    size_t idx = vb * kBlock + threadIdx.x;
+    size_t ld = idx < n ? idx : n - 1;
+    constexpr int L = 8 * N;
+    __attribute__((aligned(16))) uint8_t out[L];
+    AL<N>::prod_finish_lane(out, ws + ld * (size_t) k * AL<N>::MREC, k);
+    if (idx < n) {
+      uint4 *dst = reinterpret_cast<uint4 *>(gt + idx * L);
+      const uint4 *src = reinterpret_cast<const uint4 *>(out);
+#pragma unroll
+      for (int i = 0; i < L / 16; i++) dst[i] = src[i];
+    }
+  }
+}
+
 // One k-term product of Type-A pairings per lane (terms of unit u are records u*k .. u*k+k-1).  `ws` is the object's
 // workspace for the per-term Miller state: k x 24 x 128 uint4 per workgroup (a_prod_pairing_lane).
 template <int N>
@@ -1175,7 +1211,20 @@ static int launch_prod(pbc_hip_pairing_s *P, void *d_gt, const void *d_g1, const
   if (!n) return 0;
   if (upload && ensure_derived(P, s)) return 1;
   unsigned grid = (unsigned) ((n + kBlock - 1) / kBlock);
-  if (P->type == 'a' && !P->a_generic) {
+  if (P->type == 'a' && !P->a_generic && !P->a_prod_shared) {
+    // one term per lane, then one product per lane; at most a_prod_chunk terms in flight (their records: 160 B each)
+    const size_t per = std::max<size_t>(1, P->a_prod_chunk / (size_t) k);
+    const size_t first = std::min(n, per);
+    void *ws = workspace_get(P, s, first * (size_t) k * AL<16>::MREC * sizeof(uint4));
+    if (!ws) return 1;
+    for (size_t u0 = 0; u0 < n; u0 += per) {
+      const size_t nu = std::min(per, n - u0), nt = nu * (size_t) k;
+      hipLaunchKernelGGL(al_miller_kernel<16>, dim3(resident_grid(reinterpret_cast<const void *>(&al_miller_kernel<16>), nt)), dim3(kBlock), 0, s,
+                         (uint4 *) ws, (const uint8_t *) d_g1 + u0 * (size_t) k * P->len1, (const uint8_t *) d_g2 + u0 * (size_t) k * P->len2, nt, kargs<16>(P));
+      hipLaunchKernelGGL(al_prod_finish_kernel<16>, dim3(resident_grid(reinterpret_cast<const void *>(&al_prod_finish_kernel<16>), nu)), dim3(kBlock), 0, s,
+                         (uint8_t *) d_gt + u0 * P->lenT, (const uint4 *) ws, nu, k, kargs<16>(P));
+    }
+  } else if (P->type == 'a' && !P->a_generic) {
     grid = PBC_RGRID(a_prod_pairing_kernel<16>);                      // one workspace record per RESIDENT workgroup
     void *ws = workspace_get(P, s, (size_t) grid * (size_t) k * (6 * 4 * kBlock) * sizeof(uint4));
     if (!ws) return 1;

@@ -118,6 +118,11 @@ int hostsim_prod_pairing(void *h, uint8_t *gt, const uint8_t *g1, const uint8_t 
     const uint8_t *a = g1 + u * k * P->len1, *b = g2 + u * k * P->len2;
     uint8_t *o = gt + u * P->lenT;
     if (P->type == 'a' && !P->a_generic && k == 1) AL<16>::pairing_lane(o, a, b);     // as launch_pairing does
+    else if (P->type == 'a' && !P->a_generic && !P->a_prod_shared) {                 // as launch_prod does: one term per lane, then the product
+      std::vector<uint4> ws((size_t) k * AL<16>::MREC);
+      for (int j = 0; j < k; j++) AL<16>::miller_record_lane(ws.data() + (size_t) j * AL<16>::MREC, a + (size_t) j * P->len1, b + (size_t) j * P->len2);
+      AL<16>::prod_finish_lane(o, ws.data(), k);
+    }
     else if (P->type == 'a' && !P->a_generic) { std::vector<uint4> ws((size_t) k * 24 * 128); a_prod_pairing_lane<16>(o, a, b, k, ws.data(), lds, 1); }
     else if ((P->type == 'a' || P->type == '1') && P->nlimb == 16) a1_prod_pairing_lane<16>(o, a, b, k, lds, 1);
     else if (P->type == '1' || P->type == 'a') a1_prod_pairing_lane<33>(o, a, b, k, lds, 1);

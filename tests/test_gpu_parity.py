@@ -151,6 +151,39 @@ def test_prod_pairing_vs_oracle_and_naive_product(hip_a, oracle_a):
     assert np.array_equal(got, acc)
 
 
+def test_prod_pairing_shared_squaring_kernel(hip_a, oracle_a):
+    """Default: one term per lane (al_miller_kernel + al_prod_finish_kernel).  "hip_prod_shared 1" selects the kernel with one
+    product per lane and the squaring of the accumulator shared between its terms (a_pairings_affine's shape): same bytes."""
+    import pbc_amd
+    from conftest import _param
+    P = pbc_amd.Pairing(_param("a") + "hip_prod_shared 1\n")
+    for name in ("a_prod16x4.vec", "a_prod2x8.vec", "a_prod3x10_edge.vec", "a_prodfull3x4.vec"):
+        v = golden(name)
+        assert np.array_equal(P.element_prod_pairing(v.g1, v.g2, v.k), v.gt), name
+    v = golden("a_chain1024.vec")
+    rng = np.random.default_rng(9)
+    for k, n in ((3, 300), (16, 129), (7, 1)):
+        i, j = rng.integers(0, 1024, n * k), rng.integers(0, 1024, n * k)
+        got = P.element_prod_pairing(v.g1[i], v.g2[j], k)
+        assert np.array_equal(got, hip_a.element_prod_pairing(v.g1[i], v.g2[j], k))
+        assert np.array_equal(got[:8], oracle_a.prod_pairing_batch(v.g1[i[:8 * k]], v.g2[j[:8 * k]], k))
+    P.clear()
+
+
+def test_prod_pairing_term_lanes_in_several_launches(hip_a):
+    """Long product batches are cut into launches of at most 2^22 terms (one workspace record per term);
+    "hip_prod_chunk N" shrinks that bound: ragged last chunk, k larger than the chunk, k = 2."""
+    import pbc_amd
+    from conftest import _param
+    v = golden("a_chain1024.vec")
+    rng = np.random.default_rng(10)
+    for chunk, k, n in ((1000, 16, 200), (5, 7, 9), (300, 2, 777)):
+        P = pbc_amd.Pairing(_param("a") + "hip_prod_chunk %d\n" % chunk)
+        i, j = rng.integers(0, 1024, n * k), rng.integers(0, 1024, n * k)
+        assert np.array_equal(P.element_prod_pairing(v.g1[i], v.g2[j], k), hip_a.element_prod_pairing(v.g1[i], v.g2[j], k))
+        P.clear()
+
+
 def test_prod_pairing_k1_equals_pairing(hip_a):
     v = golden("a_rand32.vec")
     assert np.array_equal(hip_a.element_prod_pairing(v.g1, v.g2, 1), v.gt)
@@ -1051,17 +1084,16 @@ def test_product_workspaces_stay_bounded_over_many_streams(hips):
         g1 = torch.from_numpy(np.tile(w.g1.reshape(-1, w.len1), (reps, 1))).cuda()
         g2 = torch.from_numpy(np.tile(w.g2.reshape(-1, w.len2), (reps, 1))).cuda()
         n = reps * len(w.gt)
-        outs = []
-        for i in range(12):
-            st = torch.cuda.Stream()
-            o = torch.zeros(n, w.lenT, dtype=torch.uint8, device="cuda")
+        outs = [(torch.zeros(n, w.lenT, dtype=torch.uint8, device="cuda"), torch.cuda.Stream()) for i in range(12)]
+        torch.cuda.synchronize()         # the fills run on torch's current stream, the launches below on their own
+        for o, st in outs:
             H.element_prod_pairing_dev(o.data_ptr(), g1.data_ptr(), g2.data_ptr(), n, w.k, st.cuda_stream)
-            outs.append((o, st))
         torch.cuda.synchronize()
         for o, _ in outs:
             assert (o.cpu().numpy().reshape(reps, len(w.gt), -1) == w.gt[None]).all()
         H.release_workspaces()
         o = torch.zeros(n, w.lenT, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
         H.element_prod_pairing_dev(o.data_ptr(), g1.data_ptr(), g2.data_ptr(), n, w.k, 0)
         torch.cuda.synchronize()
         assert (o.cpu().numpy().reshape(reps, len(w.gt), -1) == w.gt[None]).all()

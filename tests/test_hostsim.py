@@ -52,6 +52,17 @@ def test_kernel_fq_ops_on_host(sims, oracles, t, q):
         assert np.array_equal(sims[t].fq_op(op, A, B), oracles[t].fq_op(op, A, B)), op
 
 
+def test_type_a_products_with_one_product_per_lane_on_host():
+    """Type a products run one TERM per lane by default (pairing_al.cuh: miller_record_lane + prod_finish_lane);
+    "hip_prod_shared 1" keeps the kernel that shares the accumulator's squaring between the terms of a lane
+    (a_prod_pairing_lane, the shape of a_pairings_affine) -- same bytes from both."""
+    sim = hostsim.HostSim(_param("a") + "hip_prod_shared 1\n")
+    for name, n in (("a_prod2x8.vec", 2), ("a_prod3x10_edge.vec", 10), ("a_prodfull3x4.vec", 2)):
+        v = golden(name)
+        n = min(n, v.n)
+        assert np.array_equal(sim.prod_pairing(v.g1[:n * v.k], v.g2[:n * v.k], v.k), v.gt[:n]), name
+
+
 def test_type_f_generic_hard_part_on_host():
     """f.param is a BN curve and takes the x-chain; the generic fixed-window power over
     (q^4-q^2+1)/r (any Type-F parameters; plain square-and-multiply) must give the same bytes."""

@@ -213,7 +213,7 @@ static int run_batch(attach_t *a, element_t out[], element_t in1[], element_t in
   /* Three stages per chunk -- element_to_bytes (CPU threads), the GPU call, element_from_bytes (CPU threads) -- run as a
    * pipeline: while the GPU works on chunk i the CPU threads convert the results of chunk i - 1 and the inputs of
    * chunk i + 1.  (The conversions cost more CPU time than the GPU needs for the pairings.) */
-  const size_t CH = 131072 / (size_t) k > 4096 ? 131072 / (size_t) k : 4096;   /* one chip residency of lanes per GPU call */
+  const size_t CH = 131072 / (size_t) k > 32768 ? 131072 / (size_t) k : 32768;   /* at least one chip residency of lanes per GPU call (products: of terms, and 256 workgroups of products) */
   const size_t nc = (m + CH - 1) / CH;
   if (m) parallel_range(0, m < CH ? m : CH, to_bytes_range, &c);
   for (size_t ci = 0; ci < nc && !rc; ci++) {

@@ -413,7 +413,36 @@ PBC_DEV void wide_mac(wide<N> &W, const fl<N> &x, const fl<N> &y) {
 #pragma unroll
   for (int i = 0; i < L; i++)
 #pragma unroll
-    for (int j = 0; j < L; j++) W.c[i + j] += (uint64_t) x.l[i] * y.l[j];
+    for (int j = 0; j < L; j++) {
+#ifdef PBC_HOSTSIM
+      if (__builtin_add_overflow(W.c[i + j], (uint64_t) x.l[i] * y.l[j], &W.c[i + j])) { fprintf(stderr, "hostsim: wide accumulator column %d overflows\n", i + j); abort(); }
+#else
+      W.c[i + j] += (uint64_t) x.l[i] * y.l[j];
+#endif
+    }
+}
+// Relief of a wide accumulator WITHOUT a reduction: the bits of column k above 2^58 move to column k + 2 (the same
+// weight: 2^(29 k) 2^58 = 2^(29 (k + 2))), in ascending order, so that bits moved up are cut again further on.  Exact
+// integer bookkeeping -- the value of the accumulator does not change.  Afterwards every column k <= 2L - 4 is below
+// 2^58, i.e. 1/L of a product unit: callers carry on with units = 1.  Columns that take fewer than four products per unit
+// (the three at either end) are not cut: 3 (kWideMaxUnits + 1) 2^58 < 2^64 (the callers' static accounting keeps a sum
+// within kWideMaxUnits).
+// Four simple instructions per column against the 2 L^2 multiply-adds of a reduction and a product by R mod q.
+constexpr int kWideMaxUnits = 16;
+#ifndef PBC_SQZ_NARROW
+#define PBC_SQZ_NARROW 1
+#endif
+template <int N>
+PBC_DEV void wide_squeeze(wide<N> &W) {
+  constexpr int L = Limbs29<N>::L;
+#pragma unroll
+  for (int k = 0; k + 2 < 2 * L - 1; k++) {
+    // a column that takes p products per unit holds 64 / p units: with at most kWideMaxUnits in a sum only p >= 4 can fill
+    if (PBC_SQZ_NARROW && (k + 1 < 4 || 2 * L - 1 - k < 4)) continue;
+    const uint64_t hi = W.c[k] >> 58;
+    W.c[k] &= (1ull << 58) - 1;
+    W.c[k + 2] += hi;
+  }
 }
 template <int N>
 PBC_DEV void wide_reduce(fl<N> &r, const wide<N> &W) {

@@ -41,6 +41,8 @@ struct pbc_hip_pairing_s {
   int deg;                   // types d / g: degree d = k/2 of F_q^d (3 / 5)
   bool a_generic;            // type a outside the 64-byte fast path: runs on the type a1 kernels
   bool a_prod_shared;        // type a fast path, products: "hip_prod_shared 1" keeps one product per lane (a_prod_pairing_lane)
+  bool zero_copy;            // host-buffer entry points: kernels read / write pinned caller buffers in place ("hip_zero_copy 0/1")
+  size_t host_chunk;         // host-buffer entry points: units per chunk when the parameter text says "hip_host_chunk N" (0: default)
   size_t a_prod_chunk;       // ... otherwise: terms per launch of the one-term-per-lane kernels ("hip_prod_chunk N", tests)
   int len_fq, len1, len2, lenT;
 #define PBC_HOST_FPK(n) FpK<n> k##n;

@@ -25,6 +25,15 @@
 #ifndef PBC_F_FAIR_BIT
 #define PBC_F_FAIR_BIT 21                 // slices of 2^21 cycles (0.9 ms): 28.4 ms per 2^18 launch; 2^16: 30.3, 2^19: 28.8, 2^23: 28.8, none: 31.2
 #endif
+// Where a filling wide accumulator is relieved by wide_squeeze (fp.cuh: a few shifts) instead of a Montgomery reduction:
+// bit 1: f12_sqr_lds, 2: f12_mul_lds, 4: the private-memory coefficient bodies, 8: ... of the fields above 6 limbs only.
+// Same-box A/B on f.param / the 254-bit field (ms per 2^18 / 2^16 launch; profiles/r03_notes.md): none 29.29 / 53.9,
+// 1: 28.63, 1 + 4: 30.53 / 53.3, 1 + 2 + 4: 32.03 / 52.0, 4: 31.49 / 50.6 -- on the 5-word fields the compiler answers
+// the change in f12_mul_lds and the private bodies with 3.5 x / 1.6 x the spill traffic, which costs more than the
+// 4-5 % fewer multiply-adds bring; the squaring of the Miller loop and the 8-word fields keep what they save.
+#ifndef PBC_F_SQZ
+#define PBC_F_SQZ (1 | 8)
+#endif
 namespace pbc {
 
 constexpr int ND = 5;                  // the 158-bit BN field of f.param: 5 x 32-bit words, 6 x 29-bit limbs
@@ -235,7 +244,8 @@ static PBC_DEV void f12_stage(const f12 *b) {
 }
 // capacity of a wide accumulator in product units: (units + 1) L 2^58 < 2^64
 static constexpr int kCap = 63 / Limbs29<ND>::L - 1;
-static constexpr int kPairs = kCap / 2;            // products of one F_q^2 pair land 2 per accumulator
+static_assert(2 * 6 + 2 + 1 <= kWideMaxUnits, "a coefficient of a product or square: at most six pairs + the fold");
+static constexpr bool kSqueezePriv = (PBC_F_SQZ & 4) != 0 || ((PBC_F_SQZ & 8) != 0 && Limbs29<ND>::L > 6);
 static_assert(kCap >= 6, "field too wide for the F_q^12 accumulators");
 static PBC_DEV void wide_flush(g2 &acc, wide<ND> &Wx, wide<ND> &Wy) {
   fl<ND> t;
@@ -247,27 +257,28 @@ static PBC_DEV void wide_flush(g2 &acc, wide<ND> &Wx, wide<ND> &Wy) {
 }
 // polymod_mul (poly.c:1005-1047): schoolbook over the coefficients.  Coefficient k of the plain product:
 //     re = sum_{i+j=k} a_i.x b_j.x + (beta a_i.y) b_j.y,   im = sum_{i+j=k} a_i.x b_j.y + a_i.y b_j.x
-// accumulated UNREDUCED in wide column accumulators (up to kPairs pairs per Montgomery reduction instead of one
-// reduction per F_q product).  A in registers, b_j from LDS.
+// accumulated UNREDUCED in wide column accumulators: one Montgomery reduction per component of a coefficient (the
+// columns are relieved by wide_squeeze when they fill).  A in registers, b_j from LDS.
 static PBC_DEV g2 f12_mul_coeff(const f12r &A, int k) {
   g2 acc;
   g2_zero(acc);
   wide<ND> Wx, Wy;
   wide_zero<ND>(Wx);
   wide_zero<ND>(Wy);
-  int cnt = 0;
+  int units = 0;
 #pragma unroll
   for (int i = 0; i < 6; i++) {
     const int j = k - i;
     if (j < 0 || j > 5) continue;                // wave-uniform
+    if (units + 2 > kCap) { if constexpr (kSqueezePriv) { wide_squeeze<ND>(Wx); wide_squeeze<ND>(Wy); units = 1; } else { wide_flush(acc, Wx, Wy); units = 0; } }
     const fl<ND> bx = ldsf_get(j, 0), by = ldsf_get(j, 1);
     wide_mac<ND>(Wx, A.x[i], bx);
     wide_mac<ND>(Wx, A.by[i], by);
     wide_mac<ND>(Wy, A.x[i], by);
     wide_mac<ND>(Wy, A.y[i], bx);
-    if (++cnt == kPairs) { wide_flush(acc, Wx, Wy); cnt = 0; }
+    units += 2;
   }
-  if (cnt) wide_flush(acc, Wx, Wy);
+  wide_flush(acc, Wx, Wy);
   return acc;
 }
 // polymod_square (poly.c:1091-1143): cross terms once with a doubled operand, squares once.
@@ -283,6 +294,7 @@ static PBC_DEV g2 f12_sqr_coeff(const f12r &A, int k) {
   for (int i = 0; i < 6; i++) {
     const int j = k - i;
     if (j < i || j > 5) continue;                // pairs i <= j, wave-uniform
+    if (units + 4 > kCap) { if constexpr (kSqueezePriv) { wide_squeeze<ND>(Wx); wide_squeeze<ND>(Wy); units = 1; } else { wide_flush(acc, Wx, Wy); units = 0; } }
     if (i == j) {
       // a_i^2: re = x^2 + (beta y) y, im = 2 x y
       fl<ND> ax2;
@@ -302,9 +314,8 @@ static PBC_DEV g2 f12_sqr_coeff(const f12r &A, int k) {
       wide_mac<ND>(Wy, A.y[i], bx2);
       units += 4;
     }
-    if (units + 4 > kCap) { wide_flush(acc, Wx, Wy); units = 0; }
   }
-  if (units) wide_flush(acc, Wx, Wy);
+  wide_flush(acc, Wx, Wy);
   return acc;
 }
 // r_k = d_k + negalpha d_{k+6}  (X^(6+k) = negalpha X^k), k = 0..5; d_11 does not exist
@@ -490,14 +501,20 @@ struct OutArea {
   }
 };
 static PBC_DEV fl<ND> flk(const uint32_t *w) { fl<ND> r; to_limbs<ND>(r, dk(w)); return r; }   // a constant's limb form
-// accumulator overflow guard: fold the running sum through one Montgomery reduction and carry it on as a single
-// product with R mod q (t R / R = t)
 static PBC_DEV void wide_carry(wide<ND> &W, const fl<ND> &oneL) {
   fl<ND> t;
   wide_reduce<ND>(t, W);
   wide_zero<ND>(W);
   wide_mac<ND>(W, t, oneL);
 }
+template <int BIT>
+static PBC_DEV void wide_guard(wide<ND> &Wx, wide<ND> &Wy) {
+  if constexpr ((PBC_F_SQZ & BIT) != 0) { wide_squeeze<ND>(Wx); wide_squeeze<ND>(Wy); }
+  else { const fl<ND> oneL = fl29(c_f.one29); wide_carry(Wx, oneL); wide_carry(Wy, oneL); }
+}
+// (accumulator overflow guard of the sums below, four times per squaring / product: wide_squeeze -- the high bits of the
+// middle columns move two columns up -- or wide_carry: the running sum goes through a Montgomery reduction and a product
+// with R mod q, 2 x 72 multiply-adds; see PBC_F_SQZ)
 // area `cur` squared into area 1 - cur.  Coefficient k + 6 of the plain square is reduced first and enters coefficient k
 // through X^(6+k) = negalpha X^k as four more products of the same lazy sums: one reduction per output component.
 static __device__ __noinline__ void f12_sqr_lds(int cur) {
@@ -523,7 +540,7 @@ static __device__ __noinline__ void f12_sqr_lds(int cur) {
       for (int i = 0; i < 6; i++) {
         const int j = k - i;
         if (j < i || j > 5) continue;            // pairs i <= j (wave-uniform)
-        if (units + 4 > kCap) { const fl<ND> oneL = fl29(c_f.one29); wide_carry(Wx, oneL); wide_carry(Wy, oneL); units = 1; }
+        if (units + 4 > kCap) { wide_guard<1>(Wx, Wy); units = 1; }
         const fl<ND> ax = ldsf_get(i, 0, cur), ay = ldsf_get(i, 1, cur);
         if (i == j) {                            // a_i^2: re = x^2 + (beta y) y, im = 2 x y
           fl<ND> ax2;
@@ -548,7 +565,7 @@ static __device__ __noinline__ void f12_sqr_lds(int cur) {
         wide_reduce<ND>(t6y, Wy);
       } else {
         if (kk < 5) {                            // + negalpha * (coefficient k + 6)
-          if (units + 2 > kCap) { const fl<ND> oneL = fl29(c_f.one29); wide_carry(Wx, oneL); wide_carry(Wy, oneL); }
+          if (units + 2 > kCap) wide_guard<1>(Wx, Wy);
           const fl<ND> nax = fl29(c_f.na29[0]), nay = fl29(c_f.na29[1]), bnay = fl29(c_f.bna29);
           wide_mac<ND>(Wx, nax, t6x);
           wide_mac<ND>(Wx, bnay, t6y);
@@ -640,7 +657,7 @@ static __device__ __noinline__ void f12_mul_lds(int cur, const f12 *b) {
       for (int i = 0; i < 6; i++) {
         const int j = k - i;
         if (j < 0 || j > 5) continue;            // wave-uniform
-        if (units + 2 > kCap) { const fl<ND> oneL = fl29(c_f.one29); wide_carry(Wx, oneL); wide_carry(Wy, oneL); units = 1; }
+        if (units + 2 > kCap) { wide_guard<2>(Wx, Wy); units = 1; }
         const fl<ND> ax = ldsf_get(j, 0, cur), ay = ldsf_get(j, 1, cur);
         wide_mac<ND>(Wx, B.x[i], ax);
         wide_mac<ND>(Wx, B.by[i], ay);
@@ -653,7 +670,7 @@ static __device__ __noinline__ void f12_mul_lds(int cur, const f12 *b) {
         wide_reduce<ND>(t6y, Wy);
       } else {
         if (kk < 5) {
-          if (units + 2 > kCap) { const fl<ND> oneL = fl29(c_f.one29); wide_carry(Wx, oneL); wide_carry(Wy, oneL); }
+          if (units + 2 > kCap) wide_guard<2>(Wx, Wy);
           const fl<ND> nax = fl29(c_f.na29[0]), nay = fl29(c_f.na29[1]), bnay = fl29(c_f.bna29);
           wide_mac<ND>(Wx, nax, t6x);
           wide_mac<ND>(Wx, bnay, t6y);

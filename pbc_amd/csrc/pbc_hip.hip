@@ -59,6 +59,9 @@ extern "C" const char *pbc_hip_last_error(void) { return g_err; }
 // kernels
 // ---------------------------------------------------------------------------------------
 constexpr int kBlock = 128;
+#ifndef PBC_HIP_ZERO_COPY_DEFAULT
+#define PBC_HIP_ZERO_COPY_DEFAULT 1
+#endif
 // Resident workgroups (the 5-word type f kernel).  The kernel is launched with at most as many workgroups as the chip
 // holds at once (resident_grid below) and every workgroup walks the batch in strides of the grid: a lane runs its pairings
 // one after the other.  With one workgroup per 128 units the dispatcher refills the CUs round by round, and with 36 KB of
@@ -774,6 +777,12 @@ extern "C" int pbc_hip_pairing_init_set_buf(pbc_hip_pairing_t **out, const char 
     rc = fail("pairing type '%s' is not built into libpbc_hip yet", type.c_str());
   }
   if (!rc) {
+    int hc = 0;                        // "hip_host_chunk N": units per chunk of the host-buffer entry points (measurements)
+    pbc_host::param_int(param, len, "hip_host_chunk", hc);
+    P->host_chunk = hc > 0 ? (size_t) hc : 0;
+    int zc = PBC_HIP_ZERO_COPY_DEFAULT;   // "hip_zero_copy 0/1": kernels of the host-buffer entry points read / write pinned caller buffers in place
+    pbc_host::param_int(param, len, "hip_zero_copy", zc);
+    P->zero_copy = zc != 0;
     // bind to the caller's current device; without one the object still parses/validates
     // parameters (host logic), and every batch call fails loudly -- there is no CPU path.
     if (hipGetDevice(&P->device) != hipSuccess) P->device = -1;
@@ -1001,14 +1010,35 @@ extern "C" int pbc_hip_element_pairing_batch_dev(pbc_hip_pairing_t *P, void *d_g
 }
 
 // ---- host-buffer path --------------------------------------------------------------------
-// The batch is cut into chunks of one chip residency; chunks travel H2D -> kernel -> D2H on a ring of three streams
-// PER DEVICE, so the copies of one chunk hide behind the arithmetic of its neighbours (pinned caller buffers --
-// pbc_hip_host_alloc -- overlap fully; pageable ones still work, the runtime stages them).  Consecutive chunks go to the
-// devices of the object's device set in turn (pbc_hip_pairing_use_devices: range split, no exchange between devices,
+// The batch is cut into one chunk per device of the object's device set (more when a share exceeds 2^20 units or 2 GB of
+// records: run_host).  Page-locked caller buffers (pbc_hip_host_alloc, hipHostMalloc, torch's pin_memory) are read and
+// written by the kernels IN PLACE (pinned_dev_ptr below; "hip_zero_copy 0" in the parameter text turns that off); any
+// other memory travels H2D -> kernel -> D2H through chunk buffers on a ring of three streams PER DEVICE (the runtime stages
+// pageable memory).  Consecutive chunks go to the devices in turn (pbc_hip_pairing_use_devices: range split, no exchange between devices,
 // results land directly in the caller's buffer), each device driven by its own host thread.
 // Streams and chunk buffers belong to the object: they are created on first use per device, grow when a larger chunk
 // arrives and are released by pbc_hip_pairing_clear -- a call allocates nothing in the steady state.
 constexpr int kSlots = 3, kMaxDev = 16;
+// Zero-copy: the device address of a page-locked (hipHostMalloc / hipHostRegister) host range the kernels may work on
+// in place, or nullptr for any other memory.  `shared`: the range must be visible to every device of a device set
+// (allocated with hipHostMallocPortable, as pbc_hip_host_alloc does).
+// Why in place: a lane reads its 2 x 128-byte record once (16-byte loads; a few microseconds over PCIe against the ~10 ms
+// of a pairing) and writes 128 bytes, while staged copies do not overlap with kernels that hold every register and LDS
+// byte of the chip.  Measured (tools/r03_hostchunk.sh, pinned host -> pinned host, ms per batch, staged / in place):
+// type a 2^20 90.1 / 81.6 (kernel alone: 81.7), 16-term type a products 2^18 281.2 / 260.5, type f 2^18 30.8 / 28.5.
+static void *pinned_dev_ptr(const void *host, bool shared) {
+  hipPointerAttribute_t at;
+  if (hipPointerGetAttributes(&at, host) != hipSuccess) { (void) hipGetLastError(); return nullptr; }
+  if (at.type != hipMemoryTypeHost) return nullptr;
+  if (shared) {
+    unsigned flags = 0;
+    if (hipHostGetFlags(&flags, const_cast<void *>(host)) != hipSuccess) { (void) hipGetLastError(); return nullptr; }
+    if (!(flags & hipHostMallocPortable)) return nullptr;
+  }
+  void *d = nullptr;
+  if (hipHostGetDevicePointer(&d, const_cast<void *>(host), 0) != hipSuccess) { (void) hipGetLastError(); return nullptr; }
+  return d;
+}
 struct DevCtx {
   int dev = -1;
   hipStream_t st[kSlots] = {nullptr, nullptr, nullptr};
@@ -1147,22 +1177,46 @@ static int run_host(pbc_hip_pairing_s *P, uint8_t *gt, const uint8_t *g1, const 
   const int ndev = P->ndev > 0 ? P->ndev : 1;
   const int *devs = P->ndev > 0 ? P->devs : &P->device;
   const size_t u1 = (size_t) k * P->len1, u2 = (size_t) k * P->len2, ut = (size_t) P->lenT;
-  // one full residency of the chip per chunk (256 CUs x 4 workgroups x 128 lanes, one unit per lane), fewer units
-  // when a chunk's records would exceed 256 MB (long products): three chunks are in flight per device
-  size_t chunk = 131072;
-  while (chunk > 16384 && chunk * (u1 + u2 + ut) > ((size_t) 256 << 20)) chunk >>= 1;
+  // Chunks: every device gets one share of the batch (at most 2^20 units and 2 GB of records per chunk; three chunk
+  // buffers per device are in flight).  Round 1-2 cut a batch into chunks of one chip residency (131072 units) to overlap
+  // the copies of one chunk with the kernel of another; measured on MI355X (tools/r03_hostchunk.sh, pinned host buffers,
+  // 2^20 type a pairings): 131072 units 95.2 ms, 262144: 107.3, 524288: 89.6, one chunk: 89.7 = H2D + kernel + D2H -- the
+  // copies do not overlap with these kernels (every register and LDS byte of the chip is taken, and the runtime's copy
+  // kernels wait for a workgroup to retire), so smaller chunks only add launches that run at partial occupancy
+  // (type f, 2^18: 39.9 -> 30.3 ms; 16-term type a products: 305.7 -> 281.3 ms).
+  size_t chunk = (n + (size_t) ndev - 1) / (size_t) ndev;
+  if (chunk > ((size_t) 1 << 20)) chunk = (size_t) 1 << 20;
+  while (chunk > 16384 && chunk * (u1 + u2 + ut) > ((size_t) 2 << 30)) chunk = (chunk + 1) / 2;
+  if (P->host_chunk) chunk = P->host_chunk;
   if (chunk > n) chunk = n;
   const size_t nchunks = (n + chunk - 1) / chunk;
   const int used = (size_t) ndev < nchunks ? ndev : (int) nchunks;      // devices that receive at least one chunk
   DeviceGuard guard(devs[0]);
   if (!P->host_ctx) P->host_ctx = new HostCtx();
   if (ensure_derived(P, 0)) return 1;                // once per object, before any worker reads the constants
+  uint8_t *zt = nullptr;
+  const uint8_t *z1 = nullptr, *z2 = nullptr;
+  if (P->zero_copy) {
+    zt = (uint8_t *) pinned_dev_ptr(gt, ndev > 1);
+    z1 = (const uint8_t *) pinned_dev_ptr(g1, ndev > 1);
+    z2 = (const uint8_t *) pinned_dev_ptr(g2, ndev > 1);
+  }
+  const bool zc = zt && z1 && z2;
   // chunks d, d + ndev, d + 2 ndev, ... on device devs[d]
   auto worker = [&](int d, std::string *err) {
     if (hipSetDevice(devs[d]) != hipSuccess) { *err = "hipSetDevice failed"; return; }
-    DevCtx *c = devctx_get(P, devs[d], chunk * u1, chunk * u2, chunk * ut, *err);
+    DevCtx *c = devctx_get(P, devs[d], zc ? 0 : chunk * u1, zc ? 0 : chunk * u2, zc ? 0 : chunk * ut, *err);
     if (!c) return;
     size_t round = 0;
+    if (zc) {                            // the kernels work on the caller's pinned buffers: no staging copies
+      for (size_t idx = (size_t) d; idx < nchunks; idx += (size_t) ndev) {
+        const size_t off = idx * chunk, m = n - off < chunk ? n - off : chunk;
+        if (launch_prod(P, zt + off * ut, z1 + off * u1, z2 + off * u2, m, k, c->st[0], false)) { *err = g_err; break; }
+      }
+      hipError_t e = hipStreamSynchronize(c->st[0]);
+      if (e != hipSuccess && err->empty()) *err = std::string("kernel failed: ") + hipGetErrorString(e);
+      return;
+    }
     for (size_t idx = (size_t) d; idx < nchunks; idx += (size_t) ndev, round++) {
       const int sl = (int) (round % kSlots);
       const size_t off = idx * chunk, m = n - off < chunk ? n - off : chunk;

@@ -1039,6 +1039,34 @@ def test_type_a_with_a_1024_bit_field(hips, oracles):
     assert np.array_equal(H.element_pairing(v.g1[i], v.g2[j]), O.pairing_batch(v.g1[i], v.g2[j]))
 
 
+def test_host_buffers_pinned_in_place_and_staged(hips):
+    """Host-buffer entry points: page-locked caller buffers are read / written by the kernels in place (zero-copy),
+    pageable ones and "hip_zero_copy 0" go through staged chunk buffers -- same bytes, singles and products, ragged n."""
+    import ctypes
+    import torch
+    import pbc_amd
+    from conftest import _param
+    L = pbc_amd.lib()
+    for key, name, pname in (("a", "a_chain1024.vec", "a"), ("d", "d_chain256.vec", "d159"), ("f", "f_chain128.vec", "f")):
+        v = golden(name)
+        staged = pbc_amd.Pairing(_param(pname) + "hip_zero_copy 0\nhip_host_chunk 100\n")
+        for k, n in ((1, 333), (3, 41)):
+            i = np.arange(n * k) % v.n
+            j = (np.arange(n * k) * 7 + 3) % v.n
+            g1, g2 = np.ascontiguousarray(v.g1[i]), np.ascontiguousarray(v.g2[j])
+            want = hips[key].element_prod_pairing(g1, g2, k)                     # pageable numpy buffers: staged
+            h1, h2 = torch.from_numpy(g1).pin_memory(), torch.from_numpy(g2).pin_memory()
+            out = torch.zeros(n, v.lenT, dtype=torch.uint8).pin_memory()
+            for P in (hips[key], staged):                                         # pinned: in place / staged in chunks of 100
+                out.zero_()
+                assert L.pbc_hip_element_prod_pairing_batch(P._h, ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(h1.data_ptr()),
+                                                            ctypes.c_void_p(h2.data_ptr()), n, k) == 0
+                assert np.array_equal(out.numpy(), want)
+            if k == 1:
+                assert np.array_equal(want[:v.n][i[:v.n] == j[:v.n]], v.gt[i[:v.n][i[:v.n] == j[:v.n]]])
+        staged.clear()
+
+
 def test_two_objects_with_the_same_word_count_run_concurrently(hips):
     """d159.param and f.param are both 5-word fields: in round 1 their constants shared process-global __constant__
     symbols, so two objects on two streams raced.  The constants now travel in each launch's own argument block: a d159

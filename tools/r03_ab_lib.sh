@@ -1,0 +1,12 @@
+#!/bin/bash
+# Same-box A/B of library build variants: tools/r03_ab_lib.sh "libpbc_hip.so libpbc_hip_v1.so ..." "<workload ...>" [reps]
+# (variants are built with  make -C pbc_amd TMP=/tmp/x OUT=libpbc_hip_v1.so EXTRA=-D...; PBC_HIP_LIB selects one)
+ROOT="${GRAFT_REPO_ROOT:-/root/repo}"; cd "$ROOT" || exit 1
+for rep in $(seq 1 ${3-1}); do
+for w in $2; do for l in $1; do
+  PBC_HIP_LIB=$l timeout 300 python bench.py --workload $w --steps 4 --warmup 1 --no-cpu-baseline --no-host-path 2>/dev/null | python -c "
+import json,sys
+try:
+    j=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$l', '$w', j['value'], j['roofline']['kernel_ms'])
+except Exception as e: print('$l $w failed', e)"
+done; done; done

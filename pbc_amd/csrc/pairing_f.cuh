@@ -26,13 +26,22 @@
 #define PBC_F_FAIR_BIT 21                 // slices of 2^21 cycles (0.9 ms): 28.4 ms per 2^18 launch; 2^16: 30.3, 2^19: 28.8, 2^23: 28.8, none: 31.2
 #endif
 // Where a filling wide accumulator is relieved by wide_squeeze (fp.cuh: a few shifts) instead of a Montgomery reduction:
-// bit 1: f12_sqr_lds, 2: f12_mul_lds, 4: the private-memory coefficient bodies, 8: ... of the fields above 6 limbs only.
-// Same-box A/B on f.param / the 254-bit field (ms per 2^18 / 2^16 launch; profiles/r03_notes.md): none 29.29 / 53.9,
-// 1: 28.63, 1 + 4: 30.53 / 53.3, 1 + 2 + 4: 32.03 / 52.0, 4: 31.49 / 50.6 -- on the 5-word fields the compiler answers
-// the change in f12_mul_lds and the private bodies with 3.5 x / 1.6 x the spill traffic, which costs more than the
-// 4-5 % fewer multiply-adds bring; the squaring of the Miller loop and the 8-word fields keep what they save.
+// bit 1: f12_sqr_lds, 2: f12_mul_lds, 4: the private-memory coefficient bodies (there: only where the instantiation does
+// not keep the beta y_i array -- PBC_F_BY bit 4 -- or the field has more than 6 limbs).
+// Same-box A/B on f.param / the 254-bit field (ms per 2^18 / 2^16 launch; profiles/r03_notes.md), with the beta y_i
+// arrays still kept: none 29.29 / 53.9, 1: 28.63, 1 + 4: 30.53 / 53.3, 1 + 2 + 4: 32.03 / 52.0, 4: 31.49 / 50.6 -- on the
+// 5-word fields the compiler answered the change in f12_mul_lds and the private bodies with 3.5 x / 1.6 x the spill
+// traffic, which cost more than the 4-5 % fewer multiply-adds bring.  With beta y_i recomputed (PBC_F_BY 7) the private
+// bodies take it: 26.9 -> 26.1 ms (f12_mul: 83 -> 25 scratch instructions); f12_mul_lds still answers with spills.
 #ifndef PBC_F_SQZ
-#define PBC_F_SQZ (1 | 8)
+#define PBC_F_SQZ (1 | 4)
+#endif
+// Where beta y_i of the i-basis kernels (a negation and a carry pass: 24 instructions) is recomputed when a pair needs it
+// instead of kept for all six coefficients -- bit 1: f12_sqr_lds, 2: f12_mul_lds, 4: the private-memory bodies.  The
+// kept array ends up in private memory (f12_sqr_lds read it back by address: 63 of the squaring's 83 scratch
+// instructions).  Same-box A/B on f.param 2^18, ms per launch: 0: 28.5, 1: 27.55, 3: 27.35, 5: 27.07, 7: 26.9.
+#ifndef PBC_F_BY
+#define PBC_F_BY 7
 #endif
 namespace pbc {
 
@@ -221,14 +230,18 @@ static PBC_DEV void ldsf_put(int c, int part, const fl<ND> &a, int buf = 0) {
 #pragma unroll
   for (int i = 0; i < FL; i++) g_lds_f12<ND>[(((buf * 6 + c) * 2 + part) * FL + i) * F_LANES + threadIdx.x] = a.l[i];
 }
-struct f12r { fl<ND> x[6], y[6], by[6]; };     // register-resident operand: every access uses a compile-time index
+template <int BIT> static constexpr bool kByRe = BM1 && (PBC_F_BY & BIT) != 0;
+template <bool WITH_BY = true>
+struct f12r_t { fl<ND> x[6], y[6], by[WITH_BY ? 6 : 1]; };     // register-resident operand: every access uses a compile-time index
+typedef f12r_t<!kByRe<4>> f12r;                 // (the private-memory bodies)
 // a -> registers (and, when `stage`, its x / y limb forms to LDS as well: the squaring's second operand is the first)
-static PBC_DEV void f12_load_regs(f12r &A, const f12 *a, bool stage) {
+template <bool WITH_BY>
+static PBC_DEV void f12_load_regs(f12r_t<WITH_BY> &A, const f12 *a, bool stage) {
 #pragma unroll
   for (int i = 0; i < 6; i++) {
     to_limbs<ND>(A.x[i], a->c[i].x);
     to_limbs<ND>(A.y[i], a->c[i].y);
-    mul_beta(A.by[i], A.y[i]);
+    if constexpr (WITH_BY) mul_beta(A.by[i], A.y[i]);
     if (stage) { ldsf_put(i, 0, A.x[i]); ldsf_put(i, 1, A.y[i]); }
   }
 }
@@ -242,10 +255,15 @@ static PBC_DEV void f12_stage(const f12 *b) {
     ldsf_put(i, 1, y);
   }
 }
+template <bool WITH_BY>
+static PBC_DEV fl<ND> f12r_by(const f12r_t<WITH_BY> &A, int i) {
+  if constexpr (WITH_BY) return A.by[i];
+  else { fl<ND> t; mul_beta(t, A.y[i]); return t; }
+}
 // capacity of a wide accumulator in product units: (units + 1) L 2^58 < 2^64
 static constexpr int kCap = 63 / Limbs29<ND>::L - 1;
 static_assert(2 * 6 + 2 + 1 <= kWideMaxUnits, "a coefficient of a product or square: at most six pairs + the fold");
-static constexpr bool kSqueezePriv = (PBC_F_SQZ & 4) != 0 || ((PBC_F_SQZ & 8) != 0 && Limbs29<ND>::L > 6);
+static constexpr bool kSqueezePriv = (PBC_F_SQZ & 4) != 0 && ((BM1 && (PBC_F_BY & 4) != 0) || Limbs29<ND>::L > 6);
 static_assert(kCap >= 6, "field too wide for the F_q^12 accumulators");
 static PBC_DEV void wide_flush(g2 &acc, wide<ND> &Wx, wide<ND> &Wy) {
   fl<ND> t;
@@ -273,7 +291,7 @@ static PBC_DEV g2 f12_mul_coeff(const f12r &A, int k) {
     if (units + 2 > kCap) { if constexpr (kSqueezePriv) { wide_squeeze<ND>(Wx); wide_squeeze<ND>(Wy); units = 1; } else { wide_flush(acc, Wx, Wy); units = 0; } }
     const fl<ND> bx = ldsf_get(j, 0), by = ldsf_get(j, 1);
     wide_mac<ND>(Wx, A.x[i], bx);
-    wide_mac<ND>(Wx, A.by[i], by);
+    wide_mac<ND>(Wx, f12r_by(A, i), by);
     wide_mac<ND>(Wy, A.x[i], by);
     wide_mac<ND>(Wy, A.y[i], bx);
     units += 2;
@@ -300,7 +318,7 @@ static PBC_DEV g2 f12_sqr_coeff(const f12r &A, int k) {
       fl<ND> ax2;
       limbs_dbl<ND>(ax2, A.x[i]);
       wide_mac<ND>(Wx, A.x[i], A.x[i]);
-      wide_mac<ND>(Wx, A.by[i], A.y[i]);
+      wide_mac<ND>(Wx, f12r_by(A, i), A.y[i]);
       wide_mac<ND>(Wy, ax2, A.y[i]);
       units += 2;
     } else {
@@ -309,7 +327,7 @@ static PBC_DEV g2 f12_sqr_coeff(const f12r &A, int k) {
       limbs_dbl<ND>(bx2, ldsf_get(j, 0));
       limbs_dbl<ND>(by2, ldsf_get(j, 1));
       wide_mac<ND>(Wx, A.x[i], bx2);
-      wide_mac<ND>(Wx, A.by[i], by2);
+      wide_mac<ND>(Wx, f12r_by(A, i), by2);
       wide_mac<ND>(Wy, A.x[i], by2);
       wide_mac<ND>(Wy, A.y[i], bx2);
       units += 4;
@@ -522,9 +540,15 @@ static __device__ __noinline__ void f12_sqr_lds(int cur) {
   OutArea O;
   fl<ND> hx, hy;                                 // one area: coefficient 4 waits in registers, 0-3 in the buffer, 5 needs neither
   O.dst = kOneArea ? 0 : 1 - cur;
-  fl<ND> by[6];                                  // beta y_i for the compile-time index of each pair
+  // beta y_i: kept for all six coefficients (the compiler puts the array into private memory and reads it back by
+  // address: 2-3 scratch loads per pair), or -- PBC_F_BY 1, i-basis only, where it is a negation and a carry pass --
+  // recomputed from y_i when a pair needs it
+  constexpr bool kByRecompute = kByRe<1>;
+  fl<ND> by[kByRecompute ? 1 : 6];
+  if constexpr (!kByRecompute) {
 #pragma unroll
-  for (int i = 0; i < 6; i++) mul_beta(by[i], ldsf_get(i, 1, cur));
+    for (int i = 0; i < 6; i++) mul_beta(by[i], ldsf_get(i, 1, cur));
+  }
 #pragma nounroll
   for (int kk = 0; kk < 6; kk++) {
     fl<ND> t6x, t6y;
@@ -542,11 +566,13 @@ static __device__ __noinline__ void f12_sqr_lds(int cur) {
         if (j < i || j > 5) continue;            // pairs i <= j (wave-uniform)
         if (units + 4 > kCap) { wide_guard<1>(Wx, Wy); units = 1; }
         const fl<ND> ax = ldsf_get(i, 0, cur), ay = ldsf_get(i, 1, cur);
+        fl<ND> byi;
+        if constexpr (kByRecompute) mul_beta(byi, ay); else byi = by[i];
         if (i == j) {                            // a_i^2: re = x^2 + (beta y) y, im = 2 x y
           fl<ND> ax2;
           limbs_dbl<ND>(ax2, ax);
           wide_mac<ND>(Wx, ax, ax);
-          wide_mac<ND>(Wx, by[i], ay);
+          wide_mac<ND>(Wx, byi, ay);
           wide_mac<ND>(Wy, ax2, ay);
           units += 2;
         } else {                                 // 2 a_i a_j
@@ -555,7 +581,7 @@ static __device__ __noinline__ void f12_sqr_lds(int cur) {
           wide_mac<ND>(Wx, ax, b2);
           wide_mac<ND>(Wy, ay, b2);
           limbs_dbl<ND>(b2, ldsf_get(j, 1, cur));
-          wide_mac<ND>(Wx, by[i], b2);
+          wide_mac<ND>(Wx, byi, b2);
           wide_mac<ND>(Wy, ax, b2);
           units += 4;
         }
@@ -640,7 +666,7 @@ static __device__ __noinline__ void f12_mul_lds(int cur, const f12 *b) {
   OutArea O;
   fl<ND> hx, hy;
   O.dst = kOneArea ? 0 : 1 - cur;
-  f12r B;
+  f12r_t<!kByRe<2>> B;
   f12_load_regs(B, b, false);
 #pragma nounroll
   for (int kk = 0; kk < 6; kk++) {
@@ -660,7 +686,7 @@ static __device__ __noinline__ void f12_mul_lds(int cur, const f12 *b) {
         if (units + 2 > kCap) { wide_guard<2>(Wx, Wy); units = 1; }
         const fl<ND> ax = ldsf_get(j, 0, cur), ay = ldsf_get(j, 1, cur);
         wide_mac<ND>(Wx, B.x[i], ax);
-        wide_mac<ND>(Wx, B.by[i], ay);
+        wide_mac<ND>(Wx, f12r_by(B, i), ay);
         wide_mac<ND>(Wy, B.x[i], ay);
         wide_mac<ND>(Wy, B.y[i], ax);
         units += 2;

@@ -41,6 +41,9 @@ constexpr int AL_LANES = 128;
 #ifndef PBC_A_FAIR_BIT
 #define PBC_A_FAIR_BIT 23
 #endif
+#ifndef PBC_A_QVEC
+#define PBC_A_QVEC 1
+#endif
 #ifdef PBC_HOSTSIM
 #define PBC_PRIVATE
 #else
@@ -315,11 +318,25 @@ struct AL {
   // 0.875 M against 0.895 M products/s for the word-form one -- 25 % more workspace traffic -- and is not in the tree.)
   // (volatile: the compiler would otherwise hoist these loop-invariant loads out of the Miller loop into 36 registers
   // and spill those -- 170 scratch reloads per step instead of 36 reads)
+  // (PBC_A_QVEC 1: each coordinate padded to QW words and read with 16-byte loads -- 10 scratch instructions per step
+  // instead of 36)
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  static constexpr int QW = PBC_A_QVEC ? (L + 3) / 4 * 4 : L;
   struct QPriv {
     const volatile PBC_PRIVATE uint32_t *p;
     PBC_DEV void get(el &r, int which) const {
+      if constexpr (PBC_A_QVEC != 0) {
+        const volatile PBC_PRIVATE u32x4 *p4 = (const volatile PBC_PRIVATE u32x4 *) (p + which * QW);
 #pragma unroll
-      for (int i = 0; i < L; i++) r.l[i] = p[which * L + i];
+        for (int i = 0; i < QW / 4; i++) {
+          const u32x4 t = p4[i];
+#pragma unroll
+          for (int c = 0; c < 4; c++) if (4 * i + c < L) r.l[4 * i + c] = t[c];
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < L; i++) r.l[i] = p[which * L + i];
+      }
       AL_HS(hs_set(r, U_STRICT, 1.0);)
     }
   };
@@ -565,7 +582,7 @@ struct AL {
   static PBC_DEV bool miller_lane(const uint8_t *g1, const uint8_t *g2) {
     constexpr int NB = 4 * N;
     jacl V;
-    uint32_t Qm[2 * L];                // Q in private memory: read twice per step, by address
+    __attribute__((aligned(16))) uint32_t Qm[2 * QW];      // Q in private memory: read twice per step, by address
     bool valid;
     {
       fp<N> Px, Py, Qx, Qy;
@@ -580,7 +597,9 @@ struct AL {
       for (int i = 0; i < L; i++) Qm[i] = q.l[i];
       to_el(q, Qy);
 #pragma unroll
-      for (int i = 0; i < L; i++) Qm[L + i] = q.l[i];
+      for (int i = 0; i < L; i++) Qm[QW + i] = q.l[i];
+#pragma unroll
+      for (int i = L; i < QW; i++) Qm[i] = Qm[QW + i] = 0;
       to_el(V.X, Px);
       to_el(V.Y, Py);
       fp_set<N>(Px, fpk<N>().one);

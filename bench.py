@@ -326,8 +326,9 @@ def main():
         if not torch.equal(hout, GT.cpu()):
             sys.exit("bench.py: host-buffer path differs from the device-pointer path")
         host_path = {"value": round(n / min(ts), 1), "ms": round(min(ts) * 1e3, 2), "bytes_over_pcie": n * (k * (L1 + L2) + LT),
-                     "note": "pinned host buffers -> chunked H2D / kernel / D2H on 3 streams -> host, best of 3 calls on rank 0; "
-                             "PCIe-inclusive (SURVEY 8d's wall-clock form of the metric); never the reported `value`"}
+                     "note": "pinned host buffers in, pinned host buffers out through the host-buffer entry point (the kernels read and "
+                             "write page-locked caller memory in place over PCIe; pageable memory would be staged), best of 3 calls on "
+                             "rank 0; PCIe-inclusive (SURVEY 8d's wall-clock form of the metric); never the reported `value`"}
         del h1, h2, hout
 
     if rank == 0:

@@ -66,7 +66,8 @@ int pbc_hip_pairing_use_devices(pbc_hip_pairing_t *p, const int *devices, int n)
 int pbc_hip_device_count(void);
 /* Page-locked host memory for the host-buffer entry points.  When all three buffers of a call (gt, g1, g2) are page-locked
  * -- from here, hipHostMalloc, hipHostRegister or a framework's pinned allocator; for an object with a device set:
- * allocated with hipHostMallocPortable, as this call does -- the kernels read the records and write the results IN PLACE
+ * allocated with hipHostMallocPortable, as this call does -- and the field's coordinates are a multiple of four bytes
+ * long (every shipped parameter set but a1.param, g149.param and d201.param), the kernels read the records and write the results IN PLACE
  * over PCIe: no staging copies, the call costs the kernel's time (measured: 2^20 type a pairings pinned host -> pinned
  * host in 81.6 ms against 81.7 ms for HBM-resident data and 90.1 ms with staged copies).  "hip_zero_copy 0" in the
  * parameter text turns it off.  Any other memory is staged through device buffers (pageable memory: synchronously, by the

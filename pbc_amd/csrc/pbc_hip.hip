@@ -1130,19 +1130,20 @@ extern "C" int pbc_hip_pairing_release_workspaces(pbc_hip_pairing_t *P) {
   H->ws.clear();
   return 0;
 }
-// the context of `dev` with room for chunks of (b1, b2, bt) bytes; the calling thread's current device must be `dev`
-static DevCtx *devctx_get(pbc_hip_pairing_s *P, int dev, size_t b1, size_t b2, size_t bt, std::string &err) {
+// the context of position `slot` of the device set (a device listed twice gets two: its workers must not share streams,
+// chunk buffers or -- through the streams -- product workspaces) with room for chunks of (b1, b2, bt) bytes; the calling
+// thread's current device must be `dev`
+static DevCtx *devctx_get(pbc_hip_pairing_s *P, int slot, int dev, size_t b1, size_t b2, size_t bt, std::string &err) {
   HostCtx *H = static_cast<HostCtx *>(P->host_ctx);
-  DevCtx *c = nullptr;
+  if (slot < 0 || slot >= kMaxDev) { err = "too many devices in one object"; return nullptr; }
+  DevCtx *c = &H->dc[slot];
   {
     std::lock_guard<std::mutex> lk(H->mu);
-    for (int i = 0; i < H->n; i++)
-      if (H->dc[i].dev == dev) c = &H->dc[i];
-    if (!c) {
-      if (H->n == kMaxDev) { err = "too many devices in one object"; return nullptr; }
-      c = &H->dc[H->n++];
-      c->dev = dev;
-    }
+    if (slot >= H->n) H->n = slot + 1;
+  }
+  if (c->dev != dev) {                 // the device set changed under this position
+    devctx_release(*c);
+    c->dev = dev;
   }
   for (int i = 0; i < kSlots; i++)
     if (!c->st[i] && hipStreamCreateWithFlags(&c->st[i], hipStreamNonBlocking) != hipSuccess) { err = "hipStreamCreate failed"; return nullptr; }
@@ -1196,7 +1197,9 @@ static int run_host(pbc_hip_pairing_s *P, uint8_t *gt, const uint8_t *g1, const 
   if (ensure_derived(P, 0)) return 1;                // once per object, before any worker reads the constants
   uint8_t *zt = nullptr;
   const uint8_t *z1 = nullptr, *z2 = nullptr;
-  if (P->zero_copy) {
+  // (coordinates whose length is not a multiple of four bytes are read byte by byte -- fp_load_be --, and a byte read
+  // over PCIe costs a transaction: type a1, 130-byte coordinates, ran at half speed in place; those stay staged)
+  if (P->zero_copy && P->len_fq % 4 == 0) {
     zt = (uint8_t *) pinned_dev_ptr(gt, ndev > 1);
     z1 = (const uint8_t *) pinned_dev_ptr(g1, ndev > 1);
     z2 = (const uint8_t *) pinned_dev_ptr(g2, ndev > 1);
@@ -1205,7 +1208,7 @@ static int run_host(pbc_hip_pairing_s *P, uint8_t *gt, const uint8_t *g1, const 
   // chunks d, d + ndev, d + 2 ndev, ... on device devs[d]
   auto worker = [&](int d, std::string *err) {
     if (hipSetDevice(devs[d]) != hipSuccess) { *err = "hipSetDevice failed"; return; }
-    DevCtx *c = devctx_get(P, devs[d], zc ? 0 : chunk * u1, zc ? 0 : chunk * u2, zc ? 0 : chunk * ut, *err);
+    DevCtx *c = devctx_get(P, d, devs[d], zc ? 0 : chunk * u1, zc ? 0 : chunk * u2, zc ? 0 : chunk * ut, *err);
     if (!c) return;
     size_t round = 0;
     if (zc) {                            // the kernels work on the caller's pinned buffers: no staging copies
@@ -1627,6 +1630,14 @@ extern "C" int pbc_hip_pairing_pp_apply_batch(pbc_hip_pp_t *pp, uint8_t *gt, con
   pbc_hip_pairing_s *P = pp->P;
   DevBuf b2, bt;
   DeviceGuard guard(P->device);
+  if (P->zero_copy && P->len_fq % 4 == 0) {   // page-locked caller buffers: the kernel works on them in place (run_host)
+    void *z2 = pinned_dev_ptr(g2, false), *zt = pinned_dev_ptr(gt, false);
+    if (z2 && zt) {
+      if (pbc_hip_pairing_pp_apply_batch_dev(pp, zt, z2, n, 0)) return 1;
+      HIP_TRY(hipStreamSynchronize(0));
+      return 0;
+    }
+  }
   HIP_TRY(b2.alloc(n * P->len2));
   HIP_TRY(bt.alloc(n * P->lenT));
   HIP_TRY(hipMemcpy(b2.p, g2, n * P->len2, hipMemcpyHostToDevice));

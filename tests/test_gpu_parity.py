@@ -1066,6 +1066,15 @@ def test_host_buffers_pinned_in_place_and_staged(hips):
                 d = np.nonzero(i == j)[0]
                 assert len(d) and np.array_equal(want[d], v.gt[i[d]])
         staged.clear()
+        if key in ("a", "d"):                                                     # pairing_pp_apply: the same two routes
+            pp = hips[key].pp_init(v.g1[1])
+            g2 = np.ascontiguousarray(v.g2[np.arange(77) % v.n])
+            want = pp.apply(g2)
+            h2 = torch.from_numpy(g2).pin_memory()
+            out = torch.zeros(77, v.lenT, dtype=torch.uint8).pin_memory()
+            assert L.pbc_hip_pairing_pp_apply_batch(pp._h, ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(h2.data_ptr()), 77) == 0
+            assert np.array_equal(out.numpy(), want) and np.array_equal(want[1], v.gt[1])
+            pp.clear()
 
 
 def test_two_objects_with_the_same_word_count_run_concurrently(hips):

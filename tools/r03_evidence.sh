@@ -4,12 +4,14 @@
 # BENCH_WL / PMC_WL restrict the workload lists, SKIP_HEAD=1 skips the headline line and the probes (e.g. after a change to one kernel).
 # Everything lands under gpurun_out/ev_r03/; tools/r03_summarise.py turns it into profiles/r03_*.
 R="${GRAFT_REPO_ROOT:-/root/repo}"; O=$R/gpurun_out/ev_r03; mkdir -p $O; cd $R || exit 1
+[ -z "$WITH_TESTS" ] || { timeout 900 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; tail -n 3 $O/pytest.log; }
 [ -n "$SKIP_HEAD" ] || timeout 400 python bench.py --steps 5 --warmup 1 > $O/bench_a.json 2> $O/bench_a.err
 for w in ${BENCH_WL-d f a-prod16 d-prod16 a-pp d-pp g e a1 f256 d190 d201 d224}; do
-  timeout 400 python bench.py --workload $w --steps 3 --warmup 1 > $O/bench_$w.json 2> $O/bench_$w.err
+  NOCPU="--no-cpu-baseline"; case " ${CPU_WL-d f a-prod16} " in *" $w "*) NOCPU="";; esac     # the reference's CPU rate beside the BASELINE configs only
+  timeout 400 python bench.py --workload $w --steps 3 --warmup 1 $NOCPU > $O/bench_$w.json 2> $O/bench_$w.err
 done
-[ -n "$SKIP_HEAD" ] || timeout 300 python tools/probe.py > $O/probe.txt 2>&1
-[ -n "$SKIP_HEAD" ] || (hipcc --offload-arch=gfx950 -O2 tools/mac_chain_probe.hip -o /tmp/mac_chain 2>/dev/null && timeout 120 /tmp/mac_chain) > $O/mac_chain.txt 2>&1
+[ -n "$SKIP_HEAD$SKIP_PROBES" ] || timeout 300 python tools/probe.py > $O/probe.txt 2>&1
+[ -n "$SKIP_HEAD$SKIP_PROBES" ] || (hipcc --offload-arch=gfx950 -O2 tools/mac_chain_probe.hip -o /tmp/mac_chain 2>/dev/null && timeout 120 /tmp/mac_chain) > $O/mac_chain.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
 for w in ${PMC_WL-a d f a-prod16}; do
   B="python $R/bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline --no-host-path"

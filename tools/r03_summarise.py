@@ -17,7 +17,7 @@ if os.path.exists(EV + "/probe.txt"):
     shutil.copy(EV + "/probe.txt", "profiles/r03_probe.txt")
 if os.path.exists(EV + "/mac_chain.txt"):
     shutil.copy(EV + "/mac_chain.txt", "profiles/r03_mac_chain_probe.txt")
-MAIN = {"a": "al_pairing_kernel", "d": "d_prod_pairing_kernel", "f": "f_prod_pairing_kernel", "a-prod16": "a_prod_pairing_kernel"}
+MAIN = {"a": "al_pairing_kernel", "d": "d_prod_pairing_kernel", "f": "f_prod_pairing_kernel", "a-prod16": "al_miller_kernel"}
 for w, kern in MAIN.items():
     ks = glob.glob("%s/kt_%s/**/*kernel_stats.csv" % (EV, w), recursive=True)
     if ks:

@@ -43,6 +43,9 @@
 #ifndef PBC_F_BY
 #define PBC_F_BY 7
 #endif
+#ifndef PBC_F_LINE_LIMB
+#define PBC_F_LINE_LIMB 1              // f_line_mul_lds: the line's pre-multiplication by Q and -alpha in limb form (0: word-form calls)
+#endif
 namespace pbc {
 
 constexpr int ND = 5;                  // the 158-bit BN field of f.param: 5 x 32-bit words, 6 x 29-bit limbs
@@ -424,6 +427,18 @@ static PBC_DEV void g2l_make(g2l &r, const g2 &a) {
   to_limbs<ND>(r.y, a.y);
   mul_beta(r.by, r.y);
 }
+// (x + y s) s for an F_q scalar, and a product by the constant -alpha, on limb forms (values below 2q in, below 2q out)
+static PBC_DEV void g2l_scale(g2l &r, const fl<ND> &x, const fl<ND> &y, const fl<ND> &s) {
+  { const fl<ND> u[1] = {x}, v[1] = {s}; sop_limbs<ND, 1>(r.x, u, v); }
+  { const fl<ND> u[1] = {y}, v[1] = {s}; sop_limbs<ND, 1>(r.y, u, v); }
+  mul_beta(r.by, r.y);
+}
+static PBC_DEV void g2l_mul_na(g2l &r, const g2l &a) {
+  const fl<ND> nax = fl29(c_f.na29[0]), nay = fl29(c_f.na29[1]);
+  { const fl<ND> u[2] = {a.x, a.by}, v[2] = {nax, nay}; sop_limbs<ND, 2>(r.x, u, v); }
+  { const fl<ND> u[2] = {a.x, a.y}, v[2] = {nay, nax}; sop_limbs<ND, 2>(r.y, u, v); }
+  mul_beta(r.by, r.y);
+}
 static PBC_DEV void g2l_sel(g2l &r, const g2l &a, const g2l &b, bool take_b) {
 #pragma unroll
   for (int i = 0; i < FL; i++) {
@@ -619,19 +634,36 @@ static __device__ __noinline__ void f_line_mul_lds(int cur, v5 va, v5 vb, v5 vc,
   from_vec<ND>(a, va);
   from_vec<ND>(b, vb);
   from_vec<ND>(c, vc);
-  g2 aq, bq, aqn, bqn;
-  const g2 na = fk2(c_f.negalpha);
-  g2_mul_fq(aq, *Qx, a);
-  g2_mul_fq(bq, *Qy, b);
-  g2_mul(aqn, aq, na);
-  g2_mul(bqn, bq, na);
   fl<ND> cl;
   to_limbs<ND>(cl, c);
   g2l Aq, Aqn, Bq, Bqn;
-  g2l_make(Aq, aq);
-  g2l_make(Aqn, aqn);
-  g2l_make(Bq, bq);
-  g2l_make(Bqn, bqn);
+  if constexpr (PBC_F_LINE_LIMB != 0) {
+    // a Qx, b Qy and their multiples by -alpha without leaving limb form: four F_q products and two lazily reduced
+    // F_q^2 products by the constant (its limbs are scalar operands) -- the word-form calls below spend 1700
+    // instructions on the same 710 multiply-adds (conversions in and out of every call)
+    fl<ND> al, bl, qx, qy;
+    to_limbs<ND>(al, a);
+    to_limbs<ND>(bl, b);
+    to_limbs<ND>(qx, Qx->x);
+    to_limbs<ND>(qy, Qx->y);
+    g2l_scale(Aq, qx, qy, al);
+    g2l_mul_na(Aqn, Aq);
+    to_limbs<ND>(qx, Qy->x);
+    to_limbs<ND>(qy, Qy->y);
+    g2l_scale(Bq, qx, qy, bl);
+    g2l_mul_na(Bqn, Bq);
+  } else {
+    g2 aq, bq, aqn, bqn;
+    const g2 na = fk2(c_f.negalpha);
+    g2_mul_fq(aq, *Qx, a);
+    g2_mul_fq(bq, *Qy, b);
+    g2_mul(aqn, aq, na);
+    g2_mul(bqn, bq, na);
+    g2l_make(Aq, aq);
+    g2l_make(Aqn, aqn);
+    g2l_make(Bq, bq);
+    g2l_make(Bqn, bqn);
+  }
 #pragma nounroll
   for (int i = 0; i < 6; i++) {
     int j = i + 2, k = i + 3;          // j = i - 4 mod 6, k = i - 3 mod 6

@@ -65,7 +65,7 @@ int pbc_hip_pairing_use_devices(pbc_hip_pairing_t *p, const int *devices, int n)
 /* Number of visible HIP devices (hipGetDeviceCount; 0 when there is none). */
 int pbc_hip_device_count(void);
 /* Page-locked host memory for the host-buffer entry points.  When all three buffers of a call (gt, g1, g2) are page-locked
- * -- from here, hipHostMalloc, hipHostRegister or a framework's pinned allocator; for an object with a device set:
+ * and 16-byte aligned -- from here, hipHostMalloc, hipHostRegister or a framework's pinned allocator; for an object with a device set:
  * allocated with hipHostMallocPortable, as this call does -- and the field's coordinates are a multiple of four bytes
  * long (every shipped parameter set but a1.param, g149.param and d201.param), the kernels read the records and write the results IN PLACE
  * over PCIe: no staging copies, the call costs the kernel's time (measured: 2^20 type a pairings pinned host -> pinned

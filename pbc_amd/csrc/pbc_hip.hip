@@ -1027,6 +1027,7 @@ constexpr int kSlots = 3, kMaxDev = 16;
 // byte of the chip.  Measured (tools/r03_hostchunk.sh, pinned host -> pinned host, ms per batch, staged / in place):
 // type a 2^20 90.1 / 81.6 (kernel alone: 81.7), 16-term type a products 2^18 281.2 / 260.5, type f 2^18 30.8 / 28.5.
 static void *pinned_dev_ptr(const void *host, bool shared) {
+  if (reinterpret_cast<uintptr_t>(host) % 16) return nullptr;      // the kernels' 16-byte accesses; staged buffers are aligned
   hipPointerAttribute_t at;
   if (hipPointerGetAttributes(&at, host) != hipSuccess) { (void) hipGetLastError(); return nullptr; }
   if (at.type != hipMemoryTypeHost) return nullptr;

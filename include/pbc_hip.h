@@ -185,6 +185,27 @@ int pbc_hip_element_pow_zn_GT_batch(pbc_hip_pairing_t *p, uint8_t *out, const ui
  * for n records of GT's underlying field in GT's wire format.  in[i] = 0 is outside the reference's contract too. */
 int pbc_hip_finalpow_batch(pbc_hip_pairing_t *p, uint8_t *out, const uint8_t *in, size_t n);
 
+/* Text formats on element_to_bytes records -- host-side string handling, no device involved, usable
+ * without libpbc.  group: 0 = Zr, 1 = G1, 2 = G2, 3 = GT.
+ *   pbc_hip_element_snprint   what element_snprint / element_printf("%B") print for the element the record deserialises
+ *                             to (include/pbc_field.h:175; fp_snprint arith/montfp.c:177-185: decimal; fq_snprint
+ *                             arith/fieldquadratic.c:105-130: "[x, y]"; polymod_snprint arith/poly.c:1221-1250:
+ *                             "[c0, ..., c(n-1)]"; curve_snprint ecc/curve.c:501-533: "[x, y]" or "O"; GT prints its
+ *                             underlying field element, ecc/pairing.c:187-190).  snprintf semantics: at most n - 1
+ *                             characters and a NUL are stored, the full length is returned (-1 on error).  A record
+ *                             of a curve over F_q that is not on the curve prints as "O", as curve_from_bytes
+ *                             (ecc/curve.c:609-623) would make it; on the twists (G2 of types d, f, g) only the all-zero
+ *                             record does.
+ *   pbc_hip_element_set_str   element_set_str (fp_set_str :187-195 with pbc_mpz_set_str arith/field.c:725-755: base 2..36,
+ *                             0 = 10, blanks skipped, reduced mod q; fq_set_str :145-157; polymod_set_str :1269-1283;
+ *                             curve_set_str ecc/curve.c:555-578: "O" or "[x, y]", off-curve points of the curves over F_q
+ *                             become O and return 0): writes the record, returns the characters consumed (0: syntax error).
+ *   pbc_hip_param_snprint     pbc_param_out_str (include/pbc_param.h:38; a_out_str ecc/a_param.c:36-46 and its
+ *                             siblings): "type t" and the keys of the type in the reference's order, integers in decimal. */
+int pbc_hip_element_snprint(const pbc_hip_pairing_t *p, int group, char *s, size_t n, const uint8_t *rec);
+int pbc_hip_element_set_str(const pbc_hip_pairing_t *p, int group, uint8_t *rec, const char *s, int base);
+int pbc_hip_param_snprint(const pbc_hip_pairing_t *p, char *s, size_t n);
+
 /* Batched base-field operations on canonical bytes: the arith/montfp.c semantics the
  * kernels are built on (mont_mul :334-377, fp_add/sub/double/halve/neg :220-330,
  * fp_invert :401-422), exposed so they can be checked differentially the way

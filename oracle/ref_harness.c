@@ -479,6 +479,59 @@ static int cmd_rdep(int argc, char **argv) {
   return 0;
 }
 
+/* text <param-file> <count> <seed>: golden vectors of the text formats.  One line per element:
+ *   <group> <hex of element_to_bytes> <element_snprint text>      group: 0 Zr, 1 G1, 2 G2, 3 GT
+ * preceded by the lines of pbc_param_out_str (each prefixed "P "); GT elements are pairings of the G1 / G2 elements,
+ * every fourth G1 / G2 element is O (element_set0). */
+static int cmd_text(int argc, char **argv) {
+  if (argc < 4) { fprintf(stderr, "text <param> <count> <seed>\n"); return 2; }
+  int count = atoi(argv[2]);
+  pbc_random_set_deterministic((unsigned) atoi(argv[3]));
+  static char buf[1 << 16], txt[1 << 16];
+  FILE *fp = fopen(argv[1], "r");
+  if (!fp) { perror(argv[1]); return 1; }
+  size_t len = fread(buf, 1, sizeof buf - 1, fp);
+  fclose(fp);
+  buf[len] = 0;
+  pbc_param_t par;
+  if (pbc_param_init_set_buf(par, buf, len)) return 1;
+  {
+    char *pt = NULL;
+    size_t pl = 0;
+    FILE *ms = open_memstream(&pt, &pl);
+    pbc_param_out_str(ms, par);
+    fclose(ms);
+    for (char *line = strtok(pt, "\n"); line; line = strtok(NULL, "\n")) printf("P %s\n", line);
+    free(pt);
+  }
+  pairing_t pairing;
+  pairing_init_pbc_param(pairing, par);
+  element_t z, g1, g2, gt;
+  element_init_Zr(z, pairing);
+  element_init_G1(g1, pairing);
+  element_init_G2(g2, pairing);
+  element_init_GT(gt, pairing);
+  static unsigned char bytes[4096];
+  for (int i = 0; i < count; i++) {
+    element_random(z);
+    element_random(g1);
+    element_random(g2);
+    element_pairing(gt, g1, g2);
+    if (i % 4 == 3) { element_set0(g1); element_set0(g2); }
+    element_t *e[4] = {&z, &g1, &g2, &gt};
+    for (int g = 0; g < 4; g++) {
+      int n = element_to_bytes(bytes, *e[g]);
+      if ((g == 1 || g == 2) && element_is0(*e[g])) memset(bytes, 0, (size_t) n);   /* O has no defined coordinates */
+      int t = element_snprint(txt, sizeof txt, *e[g]);
+      if (t < 0 || (size_t) t >= sizeof txt) return 1;
+      printf("%d ", g);
+      for (int b = 0; b < n; b++) printf("%02x", bytes[b]);
+      printf(" %s\n", txt);
+    }
+  }
+  return 0;
+}
+
 int main(int argc, char **argv) {
   if (argc < 2) { fprintf(stderr, "usage: ref_tool gen|kat|bench ...\n"); return 2; }
   if (!strcmp(argv[1], "gen")) return cmd_gen(argc - 1, argv + 1);
@@ -494,5 +547,6 @@ int main(int argc, char **argv) {
   if (!strcmp(argv[1], "genf")) return cmd_genf(argc - 1, argv + 1);
   if (!strcmp(argv[1], "rdep")) return cmd_rdep(argc - 1, argv + 1);
   if (!strcmp(argv[1], "finalpow")) return cmd_finalpow(argc - 1, argv + 1);
+  if (!strcmp(argv[1], "text")) return cmd_text(argc - 1, argv + 1);
   return 2;
 }

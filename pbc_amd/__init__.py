@@ -89,6 +89,9 @@ def lib():
         L.pbc_hip_host_free.argtypes = [vp]
         L.pbc_hip_host_free.restype = None
         L.pbc_hip_pairing_release_workspaces.argtypes = [vp]
+        L.pbc_hip_element_snprint.argtypes = [vp, ci, ctypes.c_char_p, sz, vp]
+        L.pbc_hip_element_set_str.argtypes = [vp, ci, vp, cp, ci]
+        L.pbc_hip_param_snprint.argtypes = [vp, ctypes.c_char_p, sz]
         _lib = L
     return _lib
 
@@ -110,7 +113,7 @@ EXPORTS = (
     "pbc_hip_pairing_length_in_bytes_x_only_G1", "pbc_hip_element_to_bytes_x_only_batch",
     "pbc_hip_pairing_length_in_bytes_compressed_G2", "pbc_hip_pairing_length_in_bytes_x_only_G2",
     "pbc_hip_element_from_bytes_x_only_batch", "pbc_hip_host_alloc", "pbc_hip_host_free", "pbc_hip_finalpow_batch",
-    "pbc_hip_pairing_release_workspaces",
+    "pbc_hip_pairing_release_workspaces", "pbc_hip_element_snprint", "pbc_hip_element_set_str", "pbc_hip_param_snprint",
 )
 
 
@@ -192,6 +195,45 @@ class Pairing:
     def element_prod_pairing_dev(self, d_gt, d_g1, d_g2, n, k, stream=0):
         if lib().pbc_hip_element_prod_pairing_batch_dev(self._h, d_gt, d_g1, d_g2, n, k, stream):
             raise PbcHipError("element_prod_pairing_dev: " + _err())
+
+    # ---- text formats (host side; include/pbc_hip.h) ------------------------------------------
+    def _group_len(self, group):
+        lens = {0: self.length_in_bytes_Zr, 1: self.length_in_bytes_G1, 2: self.length_in_bytes_G2, 3: self.length_in_bytes_GT}
+        if group not in lens:
+            raise PbcHipError("group must be 0 (Zr), 1, 2 or 3 (GT)")
+        return lens[group]
+
+    def element_snprint(self, group, rec, size=None):
+        """element_snprint of the element a record deserialises to (group 0 Zr, 1 G1, 2 G2, 3 GT).  ``size``: the
+        buffer size to pass (default: large enough); returns (text stored, length the full text has)."""
+        import numpy as np
+        rec = np.ascontiguousarray(rec, dtype=np.uint8).reshape(-1)
+        if rec.size != self._group_len(group):
+            raise ValueError("one record of the group expected")
+        n = lib().pbc_hip_element_snprint(self._h, group, None, 0, _np_ptr(rec)) if size is None else None
+        if n is not None and n < 0:
+            raise PbcHipError("element_snprint: " + _err())
+        buf = ctypes.create_string_buffer((n + 1) if size is None else max(size, 1))
+        full = lib().pbc_hip_element_snprint(self._h, group, buf, len(buf) if size is None else size, _np_ptr(rec))
+        if full < 0:
+            raise PbcHipError("element_snprint: " + _err())
+        return (buf.value.decode() if (size is None or size > 0) else ""), full
+
+    def element_set_str(self, group, text, base=10):
+        """element_set_str: returns (record, characters consumed); 0 consumed = the reference's failure value."""
+        import numpy as np
+        rec = np.zeros(self._group_len(group), np.uint8)
+        used = lib().pbc_hip_element_set_str(self._h, group, _np_ptr(rec), text.encode() if isinstance(text, str) else text, base)
+        return rec, used
+
+    def param_snprint(self):
+        """pbc_param_out_str of the object's parameters"""
+        n = lib().pbc_hip_param_snprint(self._h, None, 0)
+        if n < 0:
+            raise PbcHipError("param_snprint: " + _err())
+        buf = ctypes.create_string_buffer(n + 1)
+        lib().pbc_hip_param_snprint(self._h, buf, n + 1)
+        return buf.value.decode()
 
     def release_workspaces(self):
         """free the per-stream workspaces of the product kernels now (include/pbc_hip.h)"""

@@ -7,6 +7,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <string>
+
 #include "fp.cuh"
 #include "hostbn.h"
 #include "pairing_a.cuh"
@@ -72,6 +74,7 @@ struct pbc_hip_pairing_s {
   ExtSqrtK xs;               // square roots in the field of the G2 twist (types d, g, f); xs.c derived on first use
   bool xs_ready;
   void *host_ctx;            // library only: per-device streams and chunk buffers of the host-buffer path (pbc_hip.hip)
+  std::string param_text;    // the parameter text the object was built from (text formats: pbc_hip_param_snprint, host_text.h)
 };
 
 // |K*| = q^m - 1 = 2^s T for the twist's field K = F_q^m (m = d for types d / g, 2 for type f)

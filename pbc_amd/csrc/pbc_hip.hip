@@ -25,6 +25,7 @@
 using namespace pbc;
 
 #include "host_params.h"
+#include "host_text.h"
 
 #define HIP_TRY(x)                                                                   \
   do {                                                                               \
@@ -777,6 +778,7 @@ extern "C" int pbc_hip_pairing_init_set_buf(pbc_hip_pairing_t **out, const char 
     rc = fail("pairing type '%s' is not built into libpbc_hip yet", type.c_str());
   }
   if (!rc) {
+    P->param_text.assign(param, len);
     int hc = 0;                        // "hip_host_chunk N": units per chunk of the host-buffer entry points (measurements)
     pbc_host::param_int(param, len, "hip_host_chunk", hc);
     P->host_chunk = hc > 0 ? (size_t) hc : 0;
@@ -1645,6 +1647,133 @@ extern "C" int pbc_hip_pairing_pp_apply_batch(pbc_hip_pp_t *pp, uint8_t *gt, con
   int rc = pbc_hip_pairing_pp_apply_batch_dev(pp, bt.p, b2.p, n, 0);
   if (!rc && hipMemcpy(gt, bt.p, n * P->lenT, hipMemcpyDeviceToHost) != hipSuccess) rc = fail("D2H copy failed");
   return rc;
+}
+
+// ---- text formats on wire-format records (host_text.h) ----------------------------------------------
+namespace {
+using pbc_host::Big;
+using pbc_host::TextShape;
+// the shape of group `group` (0 Z_r, 1 G1, 2 G2, 3 GT) of this pairing and the modulus of its base field
+bool text_shape(const pbc_hip_pairing_s *P, int group, TextShape &S, Big &mod) {
+  const char *t = P->param_text.data();
+  const size_t n = P->param_text.size();
+  const bool a1 = P->type == '1';
+  if (group == 0) {
+    S = TextShape{P->len_zr, 0, 0, false, false};
+    return pbc_host::param_big(t, n, a1 ? "n" : "r", mod);
+  }
+  if (!pbc_host::param_big(t, n, a1 ? "p" : "q", mod)) return false;
+  const int deg = P->type == 'd' ? 3 : P->type == 'g' ? 5 : 0;
+  S = TextShape{P->len_fq, 0, 0, false, group != 3};
+  if (group == 2) {
+    if (deg) S.poly = deg;
+    else if (P->type == 'f') S.quad = 1;
+  } else if (group == 3) {
+    if (P->type == 'a' || a1) S.quad = 1;
+    else if (deg) { S.quad = 1; S.poly = deg; S.quad_outer = true; }
+    else if (P->type == 'f') { S.quad = 1; S.poly = 6; }
+    // type e: GT is F_q
+  } else if (group != 1) {
+    return false;
+  }
+  return true;
+}
+// curve_is_valid_point (ecc/curve.c:57-77) for the curves over F_q: y^2 = x^3 + a x + b
+bool text_on_curve(const pbc_hip_pairing_s *P, const Big &x, const Big &y, const Big &q) {
+  const char *t = P->param_text.data();
+  const size_t n = P->param_text.size();
+  Big a, b;
+  if (P->type == 'a' || P->type == '1') { a.w.push_back(1); }
+  else if (P->type == 'f') { if (!pbc_host::param_big(t, n, "b", b)) return false; }
+  else if (!pbc_host::param_big(t, n, "a", a) || !pbc_host::param_big(t, n, "b", b)) return false;
+  const Big xx = pbc_host::big_mod(Big::mul(x, x), q);
+  Big rhs = Big::add(Big::add(pbc_host::big_mod(Big::mul(xx, x), q), pbc_host::big_mod(Big::mul(a, x), q)), b);
+  rhs = pbc_host::big_mod(rhs, q);
+  return Big::cmp(pbc_host::big_mod(Big::mul(y, y), q), rhs) == 0;
+}
+bool text_curve_over_fq(const TextShape &S) { return S.curve && !S.quad && !S.poly; }
+bool all_zero(const uint8_t *p, int n) { for (int i = 0; i < n; i++) if (p[i]) return false; return true; }
+}  // namespace
+
+extern "C" int pbc_hip_element_snprint(const pbc_hip_pairing_t *P, int group, char *s, size_t n, const uint8_t *rec) {
+  if (!P || !rec || (!s && n)) { fail("null argument"); return -1; }
+  TextShape S;
+  Big mod;
+  if (!text_shape(P, group, S, mod)) { fail("element_snprint: group must be 0 (Zr), 1, 2 or 3 (GT)"); return -1; }
+  std::string out;
+  if (S.curve) {
+    const int cb = S.coord_bytes();
+    bool inf = all_zero(rec, 2 * cb) && P->type != 'a' && P->type != '1';     // (0, 0) lies on y^2 = x^3 + x
+    if (!inf && text_curve_over_fq(S))   // element_from_bytes turns a record off the curve into O (curve_from_bytes, ecc/curve.c:609-623)
+      inf = !text_on_curve(P, pbc_host::big_mod(pbc_host::big_from_be(rec, cb), mod), pbc_host::big_mod(pbc_host::big_from_be(rec + cb, cb), mod), mod);
+    if (inf) out = "O";
+    else {
+      out = "[";
+      pbc_host::text_field(out, S, rec, mod);
+      out += ", ";
+      pbc_host::text_field(out, S, rec + cb, mod);
+      out += "]";
+    }
+  } else {
+    pbc_host::text_field(out, S, rec, mod);
+  }
+  if (n) {
+    const size_t c = out.size() < n - 1 ? out.size() : n - 1;
+    memcpy(s, out.data(), c);
+    s[c] = 0;
+  }
+  return (int) out.size();
+}
+extern "C" int pbc_hip_element_set_str(const pbc_hip_pairing_t *P, int group, uint8_t *rec, const char *s, int base) {
+  if (!P || !rec || !s) { fail("null argument"); return 0; }
+  TextShape S;
+  Big mod;
+  if (!text_shape(P, group, S, mod)) { fail("element_set_str: group must be 0 (Zr), 1, 2 or 3 (GT)"); return 0; }
+  if (!S.curve) return pbc_host::parse_field(S, rec, s, base, mod);
+  const int cb = S.coord_bytes();
+  memset(rec, 0, (size_t) 2 * cb);
+  const char *cp = s;
+  while (*cp && isspace((unsigned char) *cp)) cp++;
+  if (*cp == 'O') return (int) (cp - s + 1);
+  if (*cp != '[') return 0;
+  cp++;
+  cp += pbc_host::parse_field(S, rec, cp, base, mod);
+  while (*cp && isspace((unsigned char) *cp)) cp++;
+  if (*cp != ',') { memset(rec, 0, (size_t) 2 * cb); return 0; }
+  cp++;
+  cp += pbc_host::parse_field(S, rec + cb, cp, base, mod);
+  if (*cp != ']') { memset(rec, 0, (size_t) 2 * cb); return 0; }
+  if (text_curve_over_fq(S) && !text_on_curve(P, pbc_host::big_from_be(rec, cb), pbc_host::big_from_be(rec + cb, cb), mod)) {
+    memset(rec, 0, (size_t) 2 * cb);     // curve_set_str: not on the curve -> O, returns 0
+    return 0;
+  }
+  return (int) (cp - s + 1);
+}
+extern "C" int pbc_hip_param_snprint(const pbc_hip_pairing_t *P, char *s, size_t n) {
+  if (!P || (!s && n)) { fail("null argument"); return -1; }
+  static const char *const KA[] = {"q", "h", "r", "exp2", "exp1", "sign1", "sign0", nullptr};
+  static const char *const K1[] = {"p", "n", "l", nullptr};
+  static const char *const KD[] = {"q", "n", "h", "r", "a", "b", "k", "nk", "hk", "coeff0", "coeff1", "coeff2", "nqr", nullptr};
+  static const char *const KE[] = {"q", "r", "h", "a", "b", "exp2", "exp1", "sign1", "sign0", nullptr};
+  static const char *const KF[] = {"q", "r", "b", "beta", "alpha0", "alpha1", nullptr};
+  static const char *const KG[] = {"q", "n", "h", "r", "a", "b", "nk", "hk", "coeff0", "coeff1", "coeff2", "coeff3", "coeff4", "nqr", nullptr};
+  const char *const *keys = P->type == 'a' ? KA : P->type == '1' ? K1 : P->type == 'd' ? KD : P->type == 'e' ? KE : P->type == 'f' ? KF : KG;
+  std::string out = std::string("type ") + (P->type == '1' ? "a1" : std::string(1, (char) P->type)) + "\n";
+  for (; *keys; keys++) {
+    std::string v;
+    if (!pbc_host::param_lookup(P->param_text.data(), P->param_text.size(), *keys, v)) { fail("param_snprint: key %s is missing", *keys); return -1; }
+    const bool neg = !v.empty() && v[0] == '-';
+    Big z;
+    const std::string digits = v.substr(neg || (!v.empty() && v[0] == '+') ? 1 : 0);
+    if (!Big::from_dec(z, digits)) { fail("param_snprint: %s is not a decimal integer", *keys); return -1; }
+    out += std::string(*keys) + " " + (neg && !z.is_zero() ? "-" : "") + pbc_host::big_to_dec(z) + "\n";
+  }
+  if (n) {
+    const size_t c = out.size() < n - 1 ? out.size() : n - 1;
+    memcpy(s, out.data(), c);
+    s[c] = 0;
+  }
+  return (int) out.size();
 }
 
 // diagnostics: stage 0 -> the derived constant block of the object (after device init);

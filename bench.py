@@ -255,11 +255,12 @@ def main():
     for _ in range(max(1, args.warmup)):
         step()
     torch.cuda.synchronize()
-    # correctness gate against the reference's own outputs stored in the fixture:
-    #   k == 1: unit i*(D+1) is e(P_i, Q_i);  k > 1: bilinearity cross-check below
-    gate = rot == 0 and first == 0
+    # correctness gate against the reference's own outputs stored in the fixture, on EVERY rank and shard: unit u of this
+    # rank's shard is term t = first + u, which pairs P_a with Q_b, a = (t // D) % D, b = (t % D + rot) % D; wherever a == b
+    # the result must be the fixture's e(P_a, Q_a).  k > 1: the term-order check below (also on every rank).
+    gated_units = 0
     if pp is not None:
-        if gate and not np.array_equal(GT[0].cpu().numpy(), gt_ref[0]):     # unit 0 is e(P_0, Q_0)
+        if rot == 0 and first == 0 and not np.array_equal(GT[0].cpu().numpy(), gt_ref[0]):     # unit 0 is e(P_0, Q_0)
             sys.exit("bench.py: pp_apply differs from the reference fixture -- refusing to time")
         chk = torch.empty(256, LT, dtype=torch.uint8, device="cuda")
         P0 = d1[:1].expand(256, L1).contiguous()
@@ -267,11 +268,13 @@ def main():
         torch.cuda.synchronize()
         if not torch.equal(chk, GT[:256]):
             sys.exit("bench.py: pp_apply differs from element_pairing -- refusing to time")
-    elif gate and k == 1:
-        m = min(D, (n - 1) // (D + 1) + 1)
-        idx = torch.arange(m, device="cuda") * (D + 1)
-        if not np.array_equal(GT[idx].cpu().numpy(), gt_ref[:m]):
-            sys.exit("bench.py: GPU results differ from the reference fixture -- refusing to time")
+        gated_units = 256
+    elif k == 1:
+        a_idx, b_idx = (t // D) % D, (t % D + rot) % D
+        diag = torch.nonzero(a_idx == b_idx).flatten()[:D]
+        if len(diag) and not np.array_equal(GT[diag].cpu().numpy(), gt_ref[a_idx[diag].cpu().numpy()]):
+            sys.exit("bench.py: GPU results of rank %d differ from the reference fixture -- refusing to time" % rank)
+        gated_units = int(len(diag))
     if k > 1:
         # a k-term product must equal the product of its k single pairings, taken from a
         # separate single-pairing launch: compare through a second product with permuted terms
@@ -283,7 +286,19 @@ def main():
         pairing.element_prod_pairing_dev(GT2.data_ptr(), A1.data_ptr(), A2.data_ptr(), m, k, stream.cuda_stream)
         torch.cuda.synchronize()
         if not torch.equal(GT2, GT[:m]):
-            sys.exit("bench.py: product of pairings is not invariant under term order -- refusing to time")
+            sys.exit("bench.py: product of pairings is not invariant under term order (rank %d) -- refusing to time" % rank)
+        # ... and must equal the product of its k single pairings (element_pairing launches + GT products on the device)
+        S = torch.empty(m * k, LT, dtype=torch.uint8, device="cuda")
+        B1, B2 = G1[:m * k].contiguous(), G2[:m * k].contiguous()
+        pairing.element_pairing_dev(S.data_ptr(), B1.data_ptr(), B2.data_ptr(), m * k, stream.cuda_stream)
+        torch.cuda.synchronize()
+        acc = S.cpu().numpy().reshape(m, k, LT)
+        prod = acc[:, 0]
+        for j in range(1, k):
+            prod = pairing.element_mul_GT(prod, acc[:, j])
+        if not np.array_equal(prod, GT[:m].cpu().numpy()):
+            sys.exit("bench.py: product of pairings differs from the product of single pairings (rank %d) -- refusing to time" % rank)
+        gated_units = m
 
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     sync_all()
@@ -303,6 +318,10 @@ def main():
         dt = float(tt.item())
         per_rank_ms = [None] * world
         dist.all_gather_object(per_rank_ms, my_kern_ms)        # a slow rank must be visible in the line rank 0 prints
+    per_rank_gate = [{"first_unit": first, "units": n, "checked": gated_units}]
+    if dist is not None:
+        per_rank_gate = [None] * world
+        dist.all_gather_object(per_rank_gate, {"first_unit": first, "units": n, "checked": gated_units})
 
     # the host-buffer entry point (what the PBC glue calls): pinned host memory in, host memory out, PCIe included
     host_path = None
@@ -367,6 +386,7 @@ def main():
                        "parallelism": "range-split x%d, no collectives" % world,
                        **({"param_extra": args.param_extra} if args.param_extra else {})},
             "per_rank_kernel_ms": [round(float(x), 3) for x in per_rank_ms],
+            "per_rank_gate": per_rank_gate,      # every rank's shard is checked before timing (units compared bit for bit)
             "kernel_only": {"value": round(n / avg_kern_s, 1), "unit": unit_name + " per GPU, events around the launch on rank 0"},
             "host_path": host_path,
             "roofline": {

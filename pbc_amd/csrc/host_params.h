@@ -44,6 +44,7 @@ struct pbc_hip_pairing_s {
   bool a_generic;            // type a outside the 64-byte fast path: runs on the type a1 kernels
   bool a_prod_shared;        // type a fast path, products: "hip_prod_shared 1" keeps one product per lane (a_prod_pairing_lane)
   bool zero_copy;            // host-buffer entry points: kernels read / write pinned caller buffers in place ("hip_zero_copy 0/1")
+  int resident_slots;        // > 0: workgroups of a resident launch instead of the occupancy query ("hip_resident_slots N", tests)
   size_t host_chunk;         // host-buffer entry points: units per chunk when the parameter text says "hip_host_chunk N" (0: default)
   size_t a_prod_chunk;       // ... otherwise: terms per launch of the one-term-per-lane kernels ("hip_prod_chunk N", tests)
   int len_fq, len1, len2, lenT;
@@ -60,6 +61,7 @@ struct pbc_hip_pairing_s {
   ERaw eraw;                 // type E: integers for the one-time search of the auxiliary point
   EConst econst;             // type E: curve, auxiliary point, exponents (filled on first use)
   bool dev_ready;            // derived constants computed on the device
+  bool kargs_checked;        // the constant block's addressing passed its self-test on the device (pbc_hip.hip kargs_selftest)
   int len_zr;                // bytes of a Z_r scalar (pairing_length_in_bytes_Zr)
   double fq_muls_single;     // reference F_q multiplication count per pairing (work model)
   double fq_muls_prod_a, fq_muls_prod_b;   // products: a*k + b

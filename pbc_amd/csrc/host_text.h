@@ -38,30 +38,43 @@ inline std::string big_to_dec(const Big &a) {
   while (out.size() > 1 && out.back() == '0') out.pop_back();
   return std::string(out.rbegin(), out.rend());
 }
-// pbc_mpz_set_str: characters consumed (0: bad base)
-inline int big_from_str(Big &z, const char *s, int base) {
-  z.w.clear();
-  int b, i = 0;
-  if (!base) b = 10;
-  else if (base < 2 || base > 36) return 0;
-  else b = base;
-  for (;;) {
-    int j;
-    const char c = s[i];
-    if (!c) break;
-    if (isspace((unsigned char) c)) { i++; continue; }
-    if (isdigit((unsigned char) c)) j = c - '0';
-    else if (c >= 'A' && c <= 'Z') j = c - 'A' + 10;
-    else if (c >= 'a' && c <= 'z') j = c - 'a' + 10;
-    else break;
-    if (j >= b) break;
-    uint64_t carry = (uint64_t) j;
-    for (auto &x : z.w) { carry += (uint64_t) x * (uint32_t) b; x = (uint32_t) carry; carry >>= 32; }
-    if (carry) z.w.push_back((uint32_t) carry);
-    i++;
+// The integer syntax of element_set_str (what pbc_mpz_set_str, arith/field.c:725-755, accepts): digits of `base`
+// (2..36, 0 meaning 10; letters of either case count from ten) with white space allowed anywhere among them; the
+// number ends at the first character that is neither.  Returns the characters consumed, white space included (0 for a
+// base outside the range).  Digits are gathered into one machine word per group -- as many as keep base^g below 2^32 --
+// so the multi-word value takes one multiply-add pass per group rather than per digit.
+struct DigitTable {
+  int8_t v[256];
+  constexpr DigitTable() : v() {
+    for (int c = 0; c < 256; c++) v[c] = -1;
+    for (int d = 0; d < 10; d++) v['0' + d] = (int8_t) d;
+    for (int d = 0; d < 26; d++) { v['A' + d] = (int8_t) (10 + d); v['a' + d] = (int8_t) (10 + d); }
   }
+};
+inline int big_from_str(Big &z, const char *s, int base) {
+  static constexpr DigitTable kDigit;
+  z.w.clear();
+  const uint32_t radix = base ? (uint32_t) base : 10u;
+  if (radix < 2 || radix > 36) return 0;
+  auto push = [&z](uint32_t scale, uint32_t add) {      // z = z * scale + add
+    uint64_t carry = add;
+    for (auto &x : z.w) { carry += (uint64_t) x * scale; x = (uint32_t) carry; carry >>= 32; }
+    if (carry) z.w.push_back((uint32_t) carry);
+  };
+  const char *p = s;
+  uint32_t group = 0, scale = 1;
+  for (; *p; p++) {
+    const unsigned char c = (unsigned char) *p;
+    if (isspace(c)) continue;
+    const int d = kDigit.v[c];
+    if (d < 0 || (uint32_t) d >= radix) break;
+    group = group * radix + (uint32_t) d;
+    scale *= radix;
+    if (scale > 0xffffffffu / radix) { push(scale, group); group = 0; scale = 1; }
+  }
+  if (scale > 1) push(scale, group);
   z.trim();
-  return i;
+  return (int) (p - s);
 }
 inline Big big_from_be(const uint8_t *p, int n) {
   Big r;

@@ -785,6 +785,9 @@ extern "C" int pbc_hip_pairing_init_set_buf(pbc_hip_pairing_t **out, const char 
     int zc = PBC_HIP_ZERO_COPY_DEFAULT;   // "hip_zero_copy 0/1": kernels of the host-buffer entry points read / write pinned caller buffers in place
     pbc_host::param_int(param, len, "hip_zero_copy", zc);
     P->zero_copy = zc != 0;
+    int rs = 0;                        // "hip_resident_slots N": workgroups of a resident launch (tests: forces several units per lane on small batches)
+    pbc_host::param_int(param, len, "hip_resident_slots", rs);
+    P->resident_slots = rs > 0 ? rs : 0;
     // bind to the caller's current device; without one the object still parses/validates
     // parameters (host logic), and every batch call fails loudly -- there is no CPU path.
     if (hipGetDevice(&P->device) != hipSuccess) P->device = -1;
@@ -894,10 +897,74 @@ template <int N> __global__ void e_init_kernel(EConst *out, ERaw raw, KArgs<N> k
   e_init_lane<N>(out, raw, c_e);
 }
 
+// Self-test of the constant block's addressing (fp.cuh: every device routine finds the block at a fixed negative offset
+// from the implicit-argument pointer -- an assumption about the code object ABI that only static_asserts on sizes would
+// otherwise protect).  On the first use of an object a single lane reads the block back THROUGH the device-side accessors,
+// inside a non-inlined callee as the arithmetic routines do, and the host compares it with what it passed: a toolchain
+// that pads or reorders the hidden arguments fails here, loudly, instead of computing with garbage constants.
+template <int N>
+static __device__ __noinline__ void kargs_probe_fn(uint32_t *out) {
+  const FpK<N> &K = fpk<N>();
+  const uint32_t *kw = reinterpret_cast<const uint32_t *>(&K);
+  uint32_t sum = 0;
+  for (int i = 0; i < (int) (sizeof(FpK<N>) / 4); i++) sum = sum * 31u + kw[i];
+  out[0] = sum;
+  const uint32_t *hw = reinterpret_cast<const uint32_t *>(&kconst<uint8_t, 0>());
+  sum = 0;
+  for (int i = 0; i < KOFF_END / 4; i++) sum = sum * 31u + hw[i];
+  out[1] = sum;
+  out[2] = K.p[0];
+  out[3] = K.fbytes;
+  out[4] = hw[0];
+  out[5] = hw[KOFF_END / 4 - 1];
+}
+template <int N>
+__global__ void kargs_selftest_kernel(uint32_t *out, KArgs<N> ka) {
+  if (threadIdx.x || blockIdx.x) return;
+  kargs_probe_fn<N>(out);
+}
+template <int N>
+static int kargs_selftest(pbc_hip_pairing_s *P, hipStream_t s) {
+  KArgs<N> K = kargs<N>(P);
+  // sentinels at both ends of the head: a shifted block cannot pass by reading zeros against zeros
+  uint32_t first = 0x5eed0001u, last = 0x5eed0002u;
+  memcpy(K.head, &first, 4);
+  memcpy(K.head + KOFF_END - 4, &last, 4);
+  uint32_t want[6], got[6] = {0, 0, 0, 0, 0, 0};
+  const uint32_t *kw = reinterpret_cast<const uint32_t *>(&K.fp);
+  uint32_t sum = 0;
+  for (size_t i = 0; i < sizeof(FpK<N>) / 4; i++) sum = sum * 31u + kw[i];
+  want[0] = sum;
+  const uint32_t *hw = reinterpret_cast<const uint32_t *>(K.head);
+  sum = 0;
+  for (int i = 0; i < KOFF_END / 4; i++) sum = sum * 31u + hw[i];
+  want[1] = sum;
+  want[2] = K.fp.p[0];
+  want[3] = K.fp.fbytes;
+  want[4] = first;
+  want[5] = last;
+  DevBuf buf;
+  HIP_TRY(buf.alloc(sizeof got));
+  HIP_TRY(hipMemsetAsync(buf.p, 0, sizeof got, s));
+  hipLaunchKernelGGL(kargs_selftest_kernel<N>, dim3(1), dim3(64), 0, s, buf.as<uint32_t>(), K);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(got, buf.p, sizeof got, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  if (memcmp(want, got, sizeof got) != 0)
+    return fail("self-test of the kernel-argument constant block failed for %d-word fields (device read %08x %08x %08x %u %08x %08x, host passed "
+                "%08x %08x %08x %u %08x %08x): this build of libpbc_hip does not match the toolchain's hidden-argument layout", N,
+                got[0], got[1], got[2], got[3], got[4], got[5], want[0], want[1], want[2], want[3], want[4], want[5]);
+  return 0;
+}
+
 // First use of an object on a device: constants that are derived ON the device (the library carries no host copy of
 // the tower arithmetic) are computed by single-lane kernels and kept in the object; every later launch passes them in
 // its argument block.  Nothing is uploaded per call.
 static int ensure_derived(pbc_hip_pairing_s *P, hipStream_t s) {
+  if (!P->kargs_checked) {
+    PBC_DISPATCH_N(P->nlimb, { if (kargs_selftest<N>(P, s)) return 1; });
+    P->kargs_checked = true;
+  }
   if (P->dev_ready || (P->type != 'd' && P->type != 'g' && P->type != 'e' && P->type != 'f')) return 0;
   DevBuf buf;
   if (P->type == 'd' || P->type == 'g') {
@@ -940,8 +1007,9 @@ static int ensure_derived(pbc_hip_pairing_s *P, hipStream_t s) {
 // Grid of a resident-workgroup launch (PBC_RESIDENT_LOOP): the workgroups the current device holds at once for this
 // kernel (occupancy query, cached per kernel and device), or one per 128 units when the batch is smaller than that.
 // PBC_HIP_RESIDENT=0 restores one workgroup per 128 units (A/B measurements).
-static unsigned resident_grid(const void *kernel, size_t n) {
+static unsigned resident_grid(const pbc_hip_pairing_s *P, const void *kernel, size_t n) {
   const size_t nvb = (n + kBlock - 1) / kBlock;
+  if (P->resident_slots > 0) return (unsigned) (nvb < (size_t) P->resident_slots ? nvb : (size_t) P->resident_slots);   // "hip_resident_slots N" (tests)
   static const bool off = [] { const char *e = getenv("PBC_HIP_RESIDENT"); return e && e[0] == '0'; }();
   if (off) return (unsigned) nvb;
   static std::mutex mu;
@@ -965,7 +1033,7 @@ static unsigned resident_grid(const void *kernel, size_t n) {
   }
   return (unsigned) (nvb < slots ? nvb : slots);
 }
-#define PBC_RGRID(...) resident_grid(reinterpret_cast<const void *>(&__VA_ARGS__), n)
+#define PBC_RGRID(...) resident_grid(P, reinterpret_cast<const void *>(&__VA_ARGS__), n)
 
 static int launch_pairing(pbc_hip_pairing_s *P, void *d_gt, const void *d_g1, const void *d_g2, size_t n,
                           hipStream_t s, bool upload) {
@@ -1028,11 +1096,19 @@ constexpr int kSlots = 3, kMaxDev = 16;
 // of a pairing) and writes 128 bytes, while staged copies do not overlap with kernels that hold every register and LDS
 // byte of the chip.  Measured (tools/r03_hostchunk.sh, pinned host -> pinned host, ms per batch, staged / in place):
 // type a 2^20 90.1 / 81.6 (kernel alone: 81.7), 16-term type a products 2^18 281.2 / 260.5, type f 2^18 30.8 / 28.5.
-static void *pinned_dev_ptr(const void *host, bool shared) {
+static void *pinned_dev_ptr(const void *host, size_t bytes, bool shared) {
   if (reinterpret_cast<uintptr_t>(host) % 16) return nullptr;      // the kernels' 16-byte accesses; staged buffers are aligned
-  hipPointerAttribute_t at;
+  hipPointerAttribute_t at, at_end;
   if (hipPointerGetAttributes(&at, host) != hipSuccess) { (void) hipGetLastError(); return nullptr; }
   if (at.type != hipMemoryTypeHost) return nullptr;
+  // the LAST byte must belong to the same page-locked allocation: a buffer that starts inside a registered range and
+  // runs past its end would fault in the kernel (staged, it is copied correctly)
+  if (bytes > 1) {
+    if (hipPointerGetAttributes(&at_end, static_cast<const uint8_t *>(host) + bytes - 1) != hipSuccess) { (void) hipGetLastError(); return nullptr; }
+    if (at_end.type != hipMemoryTypeHost) return nullptr;
+    // device addresses run in step with host addresses inside one mapping
+    if ((static_cast<const uint8_t *>(at_end.devicePointer) - static_cast<const uint8_t *>(at.devicePointer)) != (ptrdiff_t) (bytes - 1)) return nullptr;
+  }
   if (shared) {
     unsigned flags = 0;
     if (hipHostGetFlags(&flags, const_cast<void *>(host)) != hipSuccess) { (void) hipGetLastError(); return nullptr; }
@@ -1042,17 +1118,25 @@ static void *pinned_dev_ptr(const void *host, bool shared) {
   if (hipHostGetDevicePointer(&d, const_cast<void *>(host), 0) != hipSuccess) { (void) hipGetLastError(); return nullptr; }
   return d;
 }
+static bool ranges_overlap(const void *a, size_t na, const void *b, size_t nb) {
+  const uintptr_t x = reinterpret_cast<uintptr_t>(a), y = reinterpret_cast<uintptr_t>(b);
+  return x < y + nb && y < x + na;
+}
 struct DevCtx {
   int dev = -1;
   hipStream_t st[kSlots] = {nullptr, nullptr, nullptr};
   void *d1[kSlots] = {nullptr, nullptr, nullptr}, *d2[kSlots] = {nullptr, nullptr, nullptr}, *dt[kSlots] = {nullptr, nullptr, nullptr};
-  size_t cap1 = 0, cap2 = 0, capt = 0;         // bytes per slot
+  size_t cap1[kSlots] = {0, 0, 0}, cap2[kSlots] = {0, 0, 0}, capt[kSlots] = {0, 0, 0};   // bytes of each slot's chunk buffers (slots are allocated when first used)
+  void *ws[kSlots] = {nullptr, nullptr, nullptr};                                          // product workspace of each slot's stream (launch_prod)
+  size_t wscap[kSlots] = {0, 0, 0};
 };
-// Workspaces of the product kernels (per-term Miller state), one per (device, stream): launches on one stream are
-// ordered, so they may share a buffer; launches on different streams get their own.  At most kMaxWs are kept: a caller
-// that launches on ever new streams evicts the least recently used one (after a device synchronisation -- its stream
-// may no longer exist), so the footprint stays bounded and a recycled stream handle cannot alias a stale entry for long.
-struct WsEnt { int dev; hipStream_t st; void *p; size_t cap; uint64_t used; };
+// Workspaces of the product kernels (per-term Miller state).  The host-buffer path owns one per stream of its device
+// contexts (DevCtx::ws: they live and die with the streams).  Launches of the *_dev entry points on CALLER streams get one
+// per (device, stream) from the table below: launches on one stream are ordered, so they may share a buffer; launches on
+// different streams get their own.  At most kMaxWs are kept: a caller that launches on ever new streams evicts the least
+// recently used entry that is not pinned by a launch in progress (after a device synchronisation -- its stream may no
+// longer exist), so the footprint stays bounded and a recycled stream handle cannot alias a stale entry for long.
+struct WsEnt { int dev; hipStream_t st; void *p; size_t cap; uint64_t used; int pins; };
 constexpr size_t kMaxWs = 8;
 struct HostCtx {
   DevCtx dc[kMaxDev];
@@ -1061,18 +1145,25 @@ struct HostCtx {
   uint64_t ws_clock = 0;
   std::mutex mu;                               // guards the tables (the per-device entries are used by one worker each)
 };
-static void devctx_release(DevCtx &c) {
-  if (c.dev < 0) return;
-  DeviceGuard guard(c.dev);
+static void devctx_free_buffers(DevCtx &c) {   // the calling thread's current device is c.dev
   for (int i = 0; i < kSlots; i++) {
-    if (c.st[i]) { (void) hipStreamSynchronize(c.st[i]); }
+    if (c.st[i]) (void) hipStreamSynchronize(c.st[i]);
     if (c.d1[i]) (void) hipFree(c.d1[i]);
     if (c.d2[i]) (void) hipFree(c.d2[i]);
     if (c.dt[i]) (void) hipFree(c.dt[i]);
-    if (c.st[i]) (void) hipStreamDestroy(c.st[i]);
-    c.st[i] = nullptr; c.d1[i] = c.d2[i] = c.dt[i] = nullptr;
+    if (c.ws[i]) (void) hipFree(c.ws[i]);
+    c.d1[i] = c.d2[i] = c.dt[i] = c.ws[i] = nullptr;
+    c.cap1[i] = c.cap2[i] = c.capt[i] = c.wscap[i] = 0;
   }
-  c.cap1 = c.cap2 = c.capt = 0;
+}
+static void devctx_release(DevCtx &c) {
+  if (c.dev < 0) return;
+  DeviceGuard guard(c.dev);
+  devctx_free_buffers(c);
+  for (int i = 0; i < kSlots; i++) {
+    if (c.st[i]) (void) hipStreamDestroy(c.st[i]);
+    c.st[i] = nullptr;
+  }
   c.dev = -1;
 }
 static void hostctx_free(pbc_hip_pairing_s *P) {
@@ -1087,8 +1178,9 @@ static void hostctx_free(pbc_hip_pairing_s *P) {
   delete H;
   P->host_ctx = nullptr;
 }
-// at least `bytes` of device memory for a kernel about to be launched on stream `s` of the current device; kept by the
-// object, grown on demand (the only allocation a steady-state call can make)
+// At least `bytes` of device memory for a kernel about to be launched on stream `s` of the current device; kept by the
+// object, grown on demand (the only allocation a steady-state call can make).  The entry is PINNED until
+// workspace_unpin: an entry whose kernel has not been enqueued yet is never evicted.
 static void *workspace_get(pbc_hip_pairing_s *P, hipStream_t s, size_t bytes) {
   int dev = -1;
   if (hipGetDevice(&dev) != hipSuccess) { fail("no current HIP device"); return nullptr; }
@@ -1099,17 +1191,20 @@ static void *workspace_get(pbc_hip_pairing_s *P, hipStream_t s, size_t bytes) {
   for (WsEnt &w : H->ws)
     if (w.dev == dev && w.st == s) e = &w;
   if (!e) {
-    if (H->ws.size() >= kMaxWs) {        // evict the least recently used entry
-      size_t lru = 0;
-      for (size_t i = 1; i < H->ws.size(); i++) if (H->ws[i].used < H->ws[lru].used) lru = i;
-      {
-        DeviceGuard guard(H->ws[lru].dev);
-        (void) hipDeviceSynchronize();
-        if (H->ws[lru].p) (void) hipFree(H->ws[lru].p);
-      }
-      H->ws.erase(H->ws.begin() + (long) lru);
+    if (H->ws.size() >= kMaxWs) {        // evict the least recently used entry that no launch holds
+      size_t lru = H->ws.size();
+      for (size_t i = 0; i < H->ws.size(); i++)
+        if (!H->ws[i].pins && (lru == H->ws.size() || H->ws[i].used < H->ws[lru].used)) lru = i;
+      if (lru < H->ws.size()) {
+        {
+          DeviceGuard guard(H->ws[lru].dev);
+          (void) hipDeviceSynchronize();
+          if (H->ws[lru].p) (void) hipFree(H->ws[lru].p);
+        }
+        H->ws.erase(H->ws.begin() + (long) lru);
+      }                                  // (every entry pinned: the table grows past kMaxWs for the moment)
     }
-    H->ws.push_back(WsEnt{dev, s, nullptr, 0, 0});
+    H->ws.push_back(WsEnt{dev, s, nullptr, 0, 0, 0});
     e = &H->ws.back();
   }
   e->used = ++H->ws_clock;
@@ -1118,7 +1213,27 @@ static void *workspace_get(pbc_hip_pairing_s *P, hipStream_t s, size_t bytes) {
     if (hipMalloc(&e->p, bytes) != hipSuccess) { e->p = nullptr; fail("device allocation of a %zu-byte product workspace failed", bytes); return nullptr; }
     e->cap = bytes;
   }
+  e->pins++;
   return e->p;
+}
+static void workspace_unpin(pbc_hip_pairing_s *P, hipStream_t s) {
+  int dev = -1;
+  HostCtx *H = static_cast<HostCtx *>(P->host_ctx);
+  if (!H || hipGetDevice(&dev) != hipSuccess) return;
+  std::lock_guard<std::mutex> lk(H->mu);
+  for (WsEnt &w : H->ws)
+    if (w.dev == dev && w.st == s && w.pins > 0) w.pins--;
+}
+// A workspace that belongs to one stream of a device context of the host-buffer path (launch_prod's `own`): grown on
+// demand, freed with the context.
+struct OwnWs { void **p; size_t *cap; };
+static void *own_workspace(const OwnWs &o, hipStream_t s, size_t bytes) {
+  if (*o.cap < bytes) {
+    if (*o.p) { (void) hipStreamSynchronize(s); (void) hipFree(*o.p); *o.p = nullptr; *o.cap = 0; }
+    if (hipMalloc(o.p, bytes) != hipSuccess) { *o.p = nullptr; fail("device allocation of a %zu-byte product workspace failed", bytes); return nullptr; }
+    *o.cap = bytes;
+  }
+  return *o.p;
 }
 extern "C" int pbc_hip_pairing_release_workspaces(pbc_hip_pairing_t *P) {
   if (!P) return fail("null pairing");
@@ -1131,12 +1246,16 @@ extern "C" int pbc_hip_pairing_release_workspaces(pbc_hip_pairing_t *P) {
     if (w.p) (void) hipFree(w.p);
   }
   H->ws.clear();
+  for (int i = 0; i < H->n; i++)        // the chunk buffers and workspaces of the host-buffer path as well (the streams stay)
+    if (H->dc[i].dev >= 0) {
+      DeviceGuard guard(H->dc[i].dev);
+      devctx_free_buffers(H->dc[i]);
+    }
   return 0;
 }
 // the context of position `slot` of the device set (a device listed twice gets two: its workers must not share streams,
-// chunk buffers or -- through the streams -- product workspaces) with room for chunks of (b1, b2, bt) bytes; the calling
-// thread's current device must be `dev`
-static DevCtx *devctx_get(pbc_hip_pairing_s *P, int slot, int dev, size_t b1, size_t b2, size_t bt, std::string &err) {
+// chunk buffers or -- through the streams -- product workspaces); the calling thread's current device must be `dev`
+static DevCtx *devctx_get(pbc_hip_pairing_s *P, int slot, int dev, std::string &err) {
   HostCtx *H = static_cast<HostCtx *>(P->host_ctx);
   if (slot < 0 || slot >= kMaxDev) { err = "too many devices in one object"; return nullptr; }
   DevCtx *c = &H->dc[slot];
@@ -1150,34 +1269,43 @@ static DevCtx *devctx_get(pbc_hip_pairing_s *P, int slot, int dev, size_t b1, si
   }
   for (int i = 0; i < kSlots; i++)
     if (!c->st[i] && hipStreamCreateWithFlags(&c->st[i], hipStreamNonBlocking) != hipSuccess) { err = "hipStreamCreate failed"; return nullptr; }
-  if (b1 > c->cap1 || b2 > c->cap2 || bt > c->capt) {
-    for (int i = 0; i < kSlots; i++) {
-      (void) hipStreamSynchronize(c->st[i]);
-      if (c->d1[i]) (void) hipFree(c->d1[i]);
-      if (c->d2[i]) (void) hipFree(c->d2[i]);
-      if (c->dt[i]) (void) hipFree(c->dt[i]);
-      c->d1[i] = c->d2[i] = c->dt[i] = nullptr;
-    }
-    c->cap1 = b1 > c->cap1 ? b1 : c->cap1;
-    c->cap2 = b2 > c->cap2 ? b2 : c->cap2;
-    c->capt = bt > c->capt ? bt : c->capt;
-    for (int i = 0; i < kSlots; i++)
-      if (hipMalloc(&c->d1[i], c->cap1) != hipSuccess || hipMalloc(&c->d2[i], c->cap2) != hipSuccess ||
-          hipMalloc(&c->dt[i], c->capt) != hipSuccess) {
-        c->cap1 = c->cap2 = c->capt = 0;
-        err = "device allocation failed for the chunk buffers";
-        return nullptr;
-      }
-  }
   return c;
+}
+// chunk buffers of ring position `sl` with room for (b1, b2, bt) bytes: allocated when the position is first used (a device
+// that gets one chunk holds one set of buffers, not three) and grown on demand
+static bool devctx_slot(DevCtx *c, int sl, size_t b1, size_t b2, size_t bt, std::string &err) {
+  if (b1 <= c->cap1[sl] && b2 <= c->cap2[sl] && bt <= c->capt[sl]) return true;
+  (void) hipStreamSynchronize(c->st[sl]);
+  auto grow = [&](void *&p, size_t &cap, size_t want) {
+    if (want <= cap) return true;
+    if (p) (void) hipFree(p);
+    p = nullptr; cap = 0;
+    if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; return false; }
+    cap = want;
+    return true;
+  };
+  if (!grow(c->d1[sl], c->cap1[sl], b1) || !grow(c->d2[sl], c->cap2[sl], b2) || !grow(c->dt[sl], c->capt[sl], bt)) {
+    err = "device allocation failed for the chunk buffers";
+    return false;
+  }
+  return true;
 }
 
 static int launch_prod(pbc_hip_pairing_s *P, void *d_gt, const void *d_g1, const void *d_g2, size_t n, int k,
-                       hipStream_t s, bool upload);
+                       hipStream_t s, bool upload, const OwnWs *own = nullptr);
 static int run_host(pbc_hip_pairing_s *P, uint8_t *gt, const uint8_t *g1, const uint8_t *g2, size_t n,
                     int k) {
   if (P->device < 0) return fail("no HIP device: libpbc_hip has no CPU fallback");
   if (!n) return 0;
+  // An output range that overlaps an input range: the lanes of a launch (and the chunks of a staged call, which travel
+  // on several streams) read and write in no particular order, so the results are collected in a buffer of their own
+  // and copied over the caller's memory when every input has been read.
+  if (ranges_overlap(gt, n * (size_t) P->lenT, g1, n * (size_t) k * P->len1) || ranges_overlap(gt, n * (size_t) P->lenT, g2, n * (size_t) k * P->len2)) {
+    std::vector<uint8_t> tmp(n * (size_t) P->lenT);
+    if (run_host(P, tmp.data(), g1, g2, n, k)) return 1;
+    memcpy(gt, tmp.data(), tmp.size());
+    return 0;
+  }
   const int ndev = P->ndev > 0 ? P->ndev : 1;
   const int *devs = P->ndev > 0 ? P->devs : &P->device;
   const size_t u1 = (size_t) k * P->len1, u2 = (size_t) k * P->len2, ut = (size_t) P->lenT;
@@ -1203,21 +1331,22 @@ static int run_host(pbc_hip_pairing_s *P, uint8_t *gt, const uint8_t *g1, const 
   // (coordinates whose length is not a multiple of four bytes are read byte by byte -- fp_load_be --, and a byte read
   // over PCIe costs a transaction: type a1, 130-byte coordinates, ran at half speed in place; those stay staged)
   if (P->zero_copy && P->len_fq % 4 == 0) {
-    zt = (uint8_t *) pinned_dev_ptr(gt, ndev > 1);
-    z1 = (const uint8_t *) pinned_dev_ptr(g1, ndev > 1);
-    z2 = (const uint8_t *) pinned_dev_ptr(g2, ndev > 1);
+    zt = (uint8_t *) pinned_dev_ptr(gt, n * ut, ndev > 1);
+    z1 = (const uint8_t *) pinned_dev_ptr(g1, n * u1, ndev > 1);
+    z2 = (const uint8_t *) pinned_dev_ptr(g2, n * u2, ndev > 1);
   }
   const bool zc = zt && z1 && z2;
   // chunks d, d + ndev, d + 2 ndev, ... on device devs[d]
   auto worker = [&](int d, std::string *err) {
     if (hipSetDevice(devs[d]) != hipSuccess) { *err = "hipSetDevice failed"; return; }
-    DevCtx *c = devctx_get(P, d, devs[d], zc ? 0 : chunk * u1, zc ? 0 : chunk * u2, zc ? 0 : chunk * ut, *err);
+    DevCtx *c = devctx_get(P, d, devs[d], *err);
     if (!c) return;
     size_t round = 0;
     if (zc) {                            // the kernels work on the caller's pinned buffers: no staging copies
+      const OwnWs own = {&c->ws[0], &c->wscap[0]};
       for (size_t idx = (size_t) d; idx < nchunks; idx += (size_t) ndev) {
         const size_t off = idx * chunk, m = n - off < chunk ? n - off : chunk;
-        if (launch_prod(P, zt + off * ut, z1 + off * u1, z2 + off * u2, m, k, c->st[0], false)) { *err = g_err; break; }
+        if (launch_prod(P, zt + off * ut, z1 + off * u1, z2 + off * u2, m, k, c->st[0], false, &own)) { *err = g_err; break; }
       }
       hipError_t e = hipStreamSynchronize(c->st[0]);
       if (e != hipSuccess && err->empty()) *err = std::string("kernel failed: ") + hipGetErrorString(e);
@@ -1227,9 +1356,11 @@ static int run_host(pbc_hip_pairing_s *P, uint8_t *gt, const uint8_t *g1, const 
       const int sl = (int) (round % kSlots);
       const size_t off = idx * chunk, m = n - off < chunk ? n - off : chunk;
       hipStream_t st = c->st[sl];
+      if (!devctx_slot(c, sl, chunk * u1, chunk * u2, chunk * ut, *err)) break;
+      const OwnWs own = {&c->ws[sl], &c->wscap[sl]};
       if (hipMemcpyAsync(c->d1[sl], g1 + off * u1, m * u1, hipMemcpyHostToDevice, st) != hipSuccess ||
           hipMemcpyAsync(c->d2[sl], g2 + off * u2, m * u2, hipMemcpyHostToDevice, st) != hipSuccess) { *err = "H2D copy failed"; break; }
-      if (launch_prod(P, c->dt[sl], c->d1[sl], c->d2[sl], m, k, st, false)) { *err = g_err; break; }
+      if (launch_prod(P, c->dt[sl], c->d1[sl], c->d2[sl], m, k, st, false, &own)) { *err = g_err; break; }
       if (hipMemcpyAsync(gt + off * ut, c->dt[sl], m * ut, hipMemcpyDeviceToHost, st) != hipSuccess) { *err = "D2H copy failed"; break; }
     }
     for (int i = 0; i < kSlots; i++) {
@@ -1264,29 +1395,41 @@ extern "C" int pbc_hip_element_pairing_batch(pbc_hip_pairing_t *P, uint8_t *gt, 
 }
 
 static int launch_prod(pbc_hip_pairing_s *P, void *d_gt, const void *d_g1, const void *d_g2, size_t n, int k,
-                       hipStream_t s, bool upload) {
+                       hipStream_t s, bool upload, const OwnWs *own) {
   if (k < 1) return fail("k must be >= 1");
   if (k == 1) return launch_pairing(P, d_gt, d_g1, d_g2, n, s, upload);
   if (P->device < 0) return fail("no HIP device: libpbc_hip has no CPU fallback");
   if (!n) return 0;
   if (upload && ensure_derived(P, s)) return 1;
   unsigned grid = (unsigned) ((n + kBlock - 1) / kBlock);
+  // the workspace of this launch: the caller's own (host-buffer path) or the object's table entry for (device, stream),
+  // which stays pinned until the kernels below are enqueued
+  struct Pin {
+    pbc_hip_pairing_s *P; hipStream_t s; bool on = false;
+    ~Pin() { if (on) workspace_unpin(P, s); }
+  } pin{P, s};
+  auto prod_ws = [&](size_t bytes) -> void * {
+    if (own) return own_workspace(*own, s, bytes);
+    void *w = workspace_get(P, s, bytes);
+    pin.on = pin.on || w != nullptr;
+    return w;
+  };
   if (P->type == 'a' && !P->a_generic && !P->a_prod_shared) {
     // one term per lane, then one product per lane; at most a_prod_chunk terms in flight (their records: 160 B each)
     const size_t per = std::max<size_t>(1, P->a_prod_chunk / (size_t) k);
     const size_t first = std::min(n, per);
-    void *ws = workspace_get(P, s, first * (size_t) k * AL<16>::MREC * sizeof(uint4));
+    void *ws = prod_ws(first * (size_t) k * AL<16>::MREC * sizeof(uint4));
     if (!ws) return 1;
     for (size_t u0 = 0; u0 < n; u0 += per) {
       const size_t nu = std::min(per, n - u0), nt = nu * (size_t) k;
-      hipLaunchKernelGGL(al_miller_kernel<16>, dim3(resident_grid(reinterpret_cast<const void *>(&al_miller_kernel<16>), nt)), dim3(kBlock), 0, s,
+      hipLaunchKernelGGL(al_miller_kernel<16>, dim3(resident_grid(P, reinterpret_cast<const void *>(&al_miller_kernel<16>), nt)), dim3(kBlock), 0, s,
                          (uint4 *) ws, (const uint8_t *) d_g1 + u0 * (size_t) k * P->len1, (const uint8_t *) d_g2 + u0 * (size_t) k * P->len2, nt, kargs<16>(P));
-      hipLaunchKernelGGL(al_prod_finish_kernel<16>, dim3(resident_grid(reinterpret_cast<const void *>(&al_prod_finish_kernel<16>), nu)), dim3(kBlock), 0, s,
+      hipLaunchKernelGGL(al_prod_finish_kernel<16>, dim3(resident_grid(P, reinterpret_cast<const void *>(&al_prod_finish_kernel<16>), nu)), dim3(kBlock), 0, s,
                          (uint8_t *) d_gt + u0 * P->lenT, (const uint4 *) ws, nu, k, kargs<16>(P));
     }
   } else if (P->type == 'a' && !P->a_generic) {
     grid = PBC_RGRID(a_prod_pairing_kernel<16>);                      // one workspace record per RESIDENT workgroup
-    void *ws = workspace_get(P, s, (size_t) grid * (size_t) k * (6 * 4 * kBlock) * sizeof(uint4));
+    void *ws = prod_ws((size_t) grid * (size_t) k * (6 * 4 * kBlock) * sizeof(uint4));
     if (!ws) return 1;
     hipLaunchKernelGGL(a_prod_pairing_kernel<16>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
                        (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k, (uint4 *) ws, kargs<16>(P));
@@ -1305,7 +1448,7 @@ static int launch_prod(pbc_hip_pairing_s *P, void *d_gt, const void *d_g1, const
   } else if (P->type == 'd' || P->type == 'g') {
     size_t rec = 0;                    // words of Miller state per term and lane (the kernel's own constant)
     PBC_DISPATCH_D(P, { rec = (size_t) TypeMNT<N, DEG>::DL_WORDS; if (kDResident<N, DEG>) grid = PBC_RGRID(d_prod_pairing_kernel<N, DEG>); });      // one workspace record per RESIDENT workgroup
-    void *ws = workspace_get(P, s, (size_t) grid * (size_t) k * rec * kBlock * sizeof(uint32_t));
+    void *ws = prod_ws((size_t) grid * (size_t) k * rec * kBlock * sizeof(uint32_t));
     if (!ws) return 1;
     PBC_DISPATCH_D(P, hipLaunchKernelGGL((d_prod_pairing_kernel<N, DEG>), dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
                                                 (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k, (uint32_t *) ws, kargs<N>(P)));
@@ -1634,8 +1777,8 @@ extern "C" int pbc_hip_pairing_pp_apply_batch(pbc_hip_pp_t *pp, uint8_t *gt, con
   DevBuf b2, bt;
   DeviceGuard guard(P->device);
   if (P->zero_copy && P->len_fq % 4 == 0) {   // page-locked caller buffers: the kernel works on them in place (run_host)
-    void *z2 = pinned_dev_ptr(g2, false), *zt = pinned_dev_ptr(gt, false);
-    if (z2 && zt) {
+    void *z2 = pinned_dev_ptr(g2, n * (size_t) P->len2, false), *zt = pinned_dev_ptr(gt, n * (size_t) P->lenT, false);
+    if (z2 && zt && !ranges_overlap(gt, n * (size_t) P->lenT, g2, n * (size_t) P->len2)) {
       if (pbc_hip_pairing_pp_apply_batch_dev(pp, zt, z2, n, 0)) return 1;
       HIP_TRY(hipStreamSynchronize(0));
       return 0;

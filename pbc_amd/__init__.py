@@ -33,7 +33,7 @@ def build(force=False):
     stale = (not os.path.exists(LIB_PATH)) or any(
         os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
     if force or stale:
-        subprocess.check_call(["make", "-s", "-C", _HERE])
+        subprocess.check_call(["make", "-s", "-j8", "-C", _HERE])
     return LIB_PATH
 
 

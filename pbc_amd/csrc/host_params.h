@@ -22,8 +22,8 @@ using namespace pbc;
 // ---------------------------------------------------------------------------------------
 // error plumbing (pbc_error-style: message to stderr is left to the caller)
 // ---------------------------------------------------------------------------------------
-static thread_local char g_err[512];
-static int fail(const char *fmt, ...) {
+inline thread_local char g_err[512];     // one per thread for the whole library (several translation units)
+inline int fail(const char *fmt, ...) {
   va_list ap;
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof g_err, fmt, ap);

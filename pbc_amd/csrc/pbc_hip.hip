@@ -2,502 +2,10 @@
 //
 // gfx950 only.  Host side: parameter parsing and constant derivation (hostbn.h), device
 // buffer management, launches.  Device side: one pairing per lane (pairing_a.cuh).
-#include <hip/hip_runtime.h>
-#include <stdarg.h>
-#include <stdio.h>
-#include <stdlib.h>
-#include <string.h>
-
-#include <mutex>
-#include <string>
-#include <thread>
-#include <vector>
-
-#include "../../include/pbc_hip.h"
-#include "fp.cuh"
-#include "hostbn.h"
-#include "pairing_a.cuh"
-#include "pairing_al.cuh"
-#include "pairing_d.cuh"
-#include "pairing_f.cuh"
-#include "pairing_e.cuh"
-
-using namespace pbc;
-
-#include "host_params.h"
+#include "host_common.h"
 #include "host_text.h"
 
-#define HIP_TRY(x)                                                                   \
-  do {                                                                               \
-    hipError_t e_ = (x);                                                             \
-    if (e_ != hipSuccess) return fail("%s: %s", #x, hipGetErrorString(e_));          \
-  } while (0)
-
-// device allocation released on every return path
-struct DevBuf {
-  void *p = nullptr;
-  DevBuf() = default;
-  DevBuf(const DevBuf &) = delete;
-  DevBuf &operator=(const DevBuf &) = delete;
-  ~DevBuf() { if (p) (void) hipFree(p); }
-  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
-  template <class T> T *as() const { return static_cast<T *>(p); }
-};
-// the calling thread's current device is restored on every return path (callers such as torch keep their own)
-struct DeviceGuard {
-  int prev = -1;
-  explicit DeviceGuard(int dev) {
-    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
-    if (dev >= 0 && dev != prev) (void) hipSetDevice(dev);
-  }
-  DeviceGuard(const DeviceGuard &) = delete;
-  DeviceGuard &operator=(const DeviceGuard &) = delete;
-  ~DeviceGuard() { if (prev >= 0) (void) hipSetDevice(prev); }
-};
 extern "C" const char *pbc_hip_last_error(void) { return g_err; }
-
-// ---------------------------------------------------------------------------------------
-// kernels
-// ---------------------------------------------------------------------------------------
-constexpr int kBlock = 128;
-#ifndef PBC_HIP_ZERO_COPY_DEFAULT
-#define PBC_HIP_ZERO_COPY_DEFAULT 1
-#endif
-// Resident workgroups (the 5-word type f kernel).  The kernel is launched with at most as many workgroups as the chip
-// holds at once (resident_grid below) and every workgroup walks the batch in strides of the grid: a lane runs its pairings
-// one after the other.  With one workgroup per 128 units the dispatcher refills the CUs round by round, and with 36 KB of
-// LDS per workgroup the rounds do not pack: a few workgroups find their LDS slot taken and wait for the NEXT round, so a
-// 2^18 batch (two rounds of 1024 workgroups) takes three (tools/occ_schedule_probe.hip: mean residency 1.4 waves per SIMD; a
-// single wave gets a multiply-add through only every 9.1 cycles, two share the pipe at 4.6).  All control flow is
-// data-independent, so equal shares finish together.  Measured on the other kernels (types a, d, products,
-// preprocessed pairings: 8 or more rounds, or LDS to spare): 3 - 4 % SLOWER than one workgroup per 128 units -- they keep
-// the plain grid (profiles/r03_notes.md).
-#define PBC_RESIDENT_LOOP(n) for (size_t vb = blockIdx.x, nvb_ = ((n) + kBlock - 1) / kBlock; vb < nvb_; vb += gridDim.x)
-static_assert(kBlock == D_LANES, "pairing_d.cuh sizes its LDS state for 128-lane workgroups");
-#ifndef PBC_DF_WAVES
-#define PBC_DF_WAVES 2
-#endif
-#ifndef PBC_A_WAVES
-#define PBC_A_WAVES 2     // waves per SIMD the pairing kernels are register-budgeted for (measured: 1 -> 2 = +32 %)
-#endif
-
-// One Type-A pairing per lane.  g1/g2/gt are AoS in wire format (128 B each for a.param);
-// per-lane 16-byte loads of a 128-byte record: every byte of every fetched line is used.
-// F_q elements are in limb form throughout (pairing_al.cuh).
-template <int N>
-__global__ void __launch_bounds__(kBlock, PBC_A_WAVES) al_pairing_kernel(uint8_t *gt, const uint8_t *g1,
-                                                             const uint8_t *g2, size_t n, KArgs<N> ka) {
-  PBC_RESIDENT_LOOP(n) {
-    size_t idx = vb * kBlock + threadIdx.x;
-    size_t ld = idx < n ? idx : n - 1;
-    constexpr int L = 8 * N;
-    __attribute__((aligned(16))) uint8_t out[L];
-    AL<N>::pairing_lane(out, g1 + ld * L, g2 + ld * L);
-    if (idx < n) {
-      uint4 *dst = reinterpret_cast<uint4 *>(gt + idx * L);
-      const uint4 *src = reinterpret_cast<const uint4 *>(out);
-#pragma unroll
-      for (int i = 0; i < L / 16; i++) dst[i] = src[i];
-    }
-  }
-}
-
-// Products of Type-A pairings on the limb-form routines, one TERM per lane (AL::miller_record_lane): the Miller value
-// of term t goes to workspace record t; al_prod_finish_kernel then multiplies the k values of each product and runs its
-// final exponentiation (one product per lane).
-template <int N>
-__global__ void __launch_bounds__(kBlock, PBC_A_WAVES) al_miller_kernel(uint4 *ws, const uint8_t *g1, const uint8_t *g2,
-                                                                        size_t n, KArgs<N> ka) {
-  PBC_RESIDENT_LOOP(n) {
-    size_t idx = vb * kBlock + threadIdx.x;
-    size_t ld = idx < n ? idx : n - 1;
-    constexpr int L = 8 * N;
-    uint4 rec[AL<N>::MREC];
-    AL<N>::miller_record_lane(rec, g1 + ld * L, g2 + ld * L);
-    if (idx < n) {
-#pragma unroll
-      for (int i = 0; i < AL<N>::MREC; i++) ws[idx * AL<N>::MREC + i] = rec[i];
-    }
-  }
-}
-template <int N>
-__global__ void __launch_bounds__(kBlock, PBC_A_WAVES) al_prod_finish_kernel(uint8_t *gt, const uint4 *ws, size_t n, int k,
-                                                                             KArgs<N> ka) {
-  PBC_RESIDENT_LOOP(n) {
-    size_t idx = vb * kBlock + threadIdx.x;
-    size_t ld = idx < n ? idx : n - 1;
-    constexpr int L = 8 * N;
-    __attribute__((aligned(16))) uint8_t out[L];
-    AL<N>::prod_finish_lane(out, ws + ld * (size_t) k * AL<N>::MREC, k);
-    if (idx < n) {
-      uint4 *dst = reinterpret_cast<uint4 *>(gt + idx * L);
-      const uint4 *src = reinterpret_cast<const uint4 *>(out);
-#pragma unroll
-      for (int i = 0; i < L / 16; i++) dst[i] = src[i];
-    }
-  }
-}
-
-// One k-term product of Type-A pairings per lane (terms of unit u are records u*k .. u*k+k-1).  `ws` is the object's
-// workspace for the per-term Miller state: k x 24 x 128 uint4 per workgroup (a_prod_pairing_lane).
-template <int N>
-__global__ void __launch_bounds__(kBlock, PBC_A_WAVES) a_prod_pairing_kernel(uint8_t *gt, const uint8_t *g1,
-                                                                 const uint8_t *g2, size_t n, int k, uint4 *ws, KArgs<N> ka) {
-  PBC_RESIDENT_LOOP(n) {
-    size_t idx = vb * kBlock + threadIdx.x;
-    size_t ld = idx < n ? idx : n - 1;
-    constexpr int L = 8 * N;
-    __attribute__((aligned(16))) uint8_t out[L];
-    __shared__ uint32_t lds_f[2 * N * kBlock];   // the shared accumulator of every lane, limb-major: conflict-free
-    a_prod_pairing_lane<N>(out, g1 + ld * k * L, g2 + ld * k * L, k,
-                           ws + (size_t) blockIdx.x * (size_t) k * (6 * (N / 4) * kBlock) + threadIdx.x, lds_f + threadIdx.x, kBlock);
-    if (idx < n) {
-      uint4 *dst = reinterpret_cast<uint4 *>(gt + idx * L);
-      const uint4 *src = reinterpret_cast<const uint4 *>(out);
-  #pragma unroll
-      for (int i = 0; i < L / 16; i++) dst[i] = src[i];
-    }
-  }
-}
-
-// Type A1: one k-term product (k = 1: a single pairing) per lane; 130-byte coordinates for a1.param.
-#ifndef PBC_A1_WAVES
-#define PBC_A1_WAVES 1    // 33-word fields: the 512-register budget of one wave per SIMD beats two waves
-#endif                    // with 256 (measured: a1 119 k -> 158 k pairings/s, e 769 k -> 971 k)
-template <int N>
-__global__ void __launch_bounds__(kBlock, N >= 32 ? PBC_A1_WAVES : PBC_A_WAVES) a1_prod_pairing_kernel(uint8_t *gt, const uint8_t *g1,
-                                                                               const uint8_t *g2, size_t n, int k, KArgs<N> ka) {
-  size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
-  size_t ld = idx < n ? idx : n - 1;
-  const int L = 2 * fq_bytes<N>();
-  __attribute__((aligned(4))) uint8_t out[8 * N];
-  __shared__ uint32_t lds_q[kMemOperands<N> ? 1 : 2 * N * kBlock];   // wide fields keep Q in private memory
-  a1_prod_pairing_lane<N>(out, g1 + ld * k * L, g2 + ld * k * L, k, lds_q + threadIdx.x, kBlock);
-  if (idx < n) {
-    if ((L & 3) == 0) {
-      uint32_t *dst = reinterpret_cast<uint32_t *>(gt + idx * L);
-      const uint32_t *src = reinterpret_cast<const uint32_t *>(out);
-      for (int i = 0; i < L / 4; i++) dst[i] = src[i];
-    } else {
-      for (int i = 0; i < L; i++) gt[idx * L + i] = out[i];
-    }
-  }
-}
-
-// Type E: one k-term product (k = 1: a single pairing) per lane; G1/G2 256 B, GT 128 B for e.param.
-template <int N>
-__global__ void __launch_bounds__(kBlock, N >= 32 ? PBC_A1_WAVES : PBC_A_WAVES) e_prod_pairing_kernel(uint8_t *gt, const uint8_t *g1,
-                                                                              const uint8_t *g2, size_t n, int k, KArgs<N> ka) {
-  size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
-  size_t ld = idx < n ? idx : n - 1;
-  const int LT = fq_bytes<N>(), L = 2 * LT;
-  __attribute__((aligned(4))) uint8_t out[4 * N];
-  uint32_t *lds_q = nullptr;           // unused: Q + R lives in the lane's private memory
-  e_prod_pairing_lane<N>(out, g1 + ld * k * L, g2 + ld * k * L, k, lds_q, kBlock);
-  if (idx < n) {
-    if ((LT & 3) == 0) {
-      uint32_t *dst = reinterpret_cast<uint32_t *>(gt + idx * LT);
-      const uint32_t *src = reinterpret_cast<const uint32_t *>(out);
-      for (int i = 0; i < LT / 4; i++) dst[i] = src[i];
-    } else {
-      for (int i = 0; i < LT; i++) gt[idx * LT + i] = out[i];
-    }
-  }
-}
-
-// pairing_pp_init: ONE lane derives the line-coefficient table of a fixed first argument.
-template <int N>
-__global__ void a_pp_init_kernel(uint32_t *tab, uint32_t *valid, const uint8_t *g1, KArgs<N> ka) {
-  if (threadIdx.x || blockIdx.x) return;
-  *valid = a_pp_init_lane<N>(tab, g1) ? 1u : 0u;
-}
-// pairing_pp_apply over a batch of second arguments, one per lane; the table is uniform data.
-template <int N>
-__global__ void __launch_bounds__(kBlock, PBC_A_WAVES) al_pp_apply_kernel(uint8_t *gt, const uint32_t *__restrict__ tab,
-                                                                           const uint32_t *__restrict__ valid,
-                                                                           const uint8_t *g2, size_t n, KArgs<N> ka) {
-  PBC_RESIDENT_LOOP(n) {
-    size_t idx = vb * kBlock + threadIdx.x;
-    size_t ld = idx < n ? idx : n - 1;
-    constexpr int L = 8 * N;
-    __attribute__((aligned(16))) uint8_t out[L];
-    AL<N>::pp_apply_lane(out, tab, *valid != 0, g2 + ld * L);
-    if (idx < n) {
-      uint4 *dst = reinterpret_cast<uint4 *>(gt + idx * L);
-      const uint4 *src = reinterpret_cast<const uint4 *>(out);
-  #pragma unroll
-      for (int i = 0; i < L / 16; i++) dst[i] = src[i];
-    }
-  }
-}
-
-// Types D and G: one k-term product (k = 1: a single pairing) per lane.  With fb = fixed byte length
-// of F_q and d = k/2, G1 records are 2 fb, G2 and GT 2 d fb bytes (40 / 120 / 120 B for d159.param,
-// 38 / 190 / 190 B for g149.param).
-template <int N, int DEG>
-static __device__ __forceinline__ void d_prod_unit(size_t vb, uint8_t *gt, const uint8_t *g1, const uint8_t *g2, size_t n, int k, uint32_t *ws) {
-  size_t idx = vb * kBlock + threadIdx.x;
-  size_t ld = idx < n ? idx : n - 1;
-  const int fb = (int) fpk<N>().fbytes, L1 = 2 * fb, L2 = 2 * DEG * fb, LT = 2 * DEG * fb;
-  __attribute__((aligned(4))) uint8_t out[8 * DEG * N];
-  TypeMNT<N, DEG>::d_prod_pairing_lane(out, g1 + ld * k * L1, g2 + ld * k * L2, k,
-                                       ws + (size_t) blockIdx.x * (size_t) k * (TypeMNT<N, DEG>::DL_WORDS * kBlock) + threadIdx.x);
-  if (idx < n) {
-    if ((LT & 3) == 0) {
-      uint32_t *dst = reinterpret_cast<uint32_t *>(gt + idx * LT);
-      const uint32_t *src = reinterpret_cast<const uint32_t *>(out);
-      for (int i = 0; i < LT / 4; i++) dst[i] = src[i];
-    } else {
-      for (int i = 0; i < LT; i++) gt[idx * LT + i] = out[i];
-    }
-  }
-}
-// (resident workgroups where they pay: kDResident, pairing_d.cuh)
-template <int N, int DEG>
-__global__ void __launch_bounds__(kBlock, PBC_DF_WAVES) d_prod_pairing_kernel(uint8_t *gt, const uint8_t *g1,
-                                                                 const uint8_t *g2, size_t n, int k, uint32_t *ws, KArgs<N> ka) {
-  if constexpr (kDResident<N, DEG>) {
-    PBC_RESIDENT_LOOP(n) d_prod_unit<N, DEG>(vb, gt, g1, g2, n, k, ws);
-  } else {
-    d_prod_unit<N, DEG>(blockIdx.x, gt, g1, g2, n, k, ws);
-  }
-}
-
-// pairing_pp for type a1
-template <int N>
-__global__ void a1_pp_init_kernel(uint32_t *tab, uint32_t *valid, const uint8_t *g1, KArgs<N> ka) {
-  if (threadIdx.x || blockIdx.x) return;
-  *valid = a1_pp_init_lane<N>(tab, g1) ? 1u : 0u;
-}
-template <int N>
-__global__ void __launch_bounds__(kBlock, N >= 32 ? PBC_A1_WAVES : PBC_A_WAVES) a1_pp_apply_kernel(uint8_t *gt, const uint32_t *__restrict__ tab,
-                                                                           const uint32_t *__restrict__ valid,
-                                                                           const uint8_t *g2, size_t n, KArgs<N> ka) {
-  size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
-  size_t ld = idx < n ? idx : n - 1;
-  const int L = 2 * fq_bytes<N>();
-  __attribute__((aligned(4))) uint8_t out[8 * N];
-  a1_pp_apply_lane<N>(out, tab, *valid != 0, g2 + ld * L);
-  if (idx < n) {
-    if ((L & 3) == 0) {
-      uint32_t *dst = reinterpret_cast<uint32_t *>(gt + idx * L);
-      const uint32_t *src = reinterpret_cast<const uint32_t *>(out);
-      for (int i = 0; i < L / 4; i++) dst[i] = src[i];
-    } else {
-      for (int i = 0; i < L; i++) gt[idx * L + i] = out[i];
-    }
-  }
-}
-
-// pairing_pp for types d / g: single-lane table derivation, then one second argument per lane
-template <int N, int DEG>
-__global__ void d_pp_init_kernel(uint32_t *tab, uint32_t *valid, const uint8_t *g1, KArgs<N> ka) {
-  if (threadIdx.x || blockIdx.x) return;
-  *valid = TypeMNT<N, DEG>::d_pp_init_lane(tab, g1) ? 1u : 0u;
-}
-template <int N, int DEG>
-static __device__ __forceinline__ void d_pp_unit(size_t vb, uint8_t *gt, const uint32_t *__restrict__ tab, const uint32_t *__restrict__ valid,
-                                                 const uint8_t *g2, size_t n) {
-  size_t idx = vb * kBlock + threadIdx.x;
-  size_t ld = idx < n ? idx : n - 1;
-  const int fb = (int) fpk<N>().fbytes, L2 = 2 * DEG * fb, LT = 2 * DEG * fb;
-  __attribute__((aligned(4))) uint8_t out[8 * DEG * N];
-  TypeMNT<N, DEG>::d_pp_apply_lane(out, tab, *valid != 0, g2 + ld * L2);
-  if (idx < n) {
-    if ((LT & 3) == 0) {
-      uint32_t *dst = reinterpret_cast<uint32_t *>(gt + idx * LT);
-      const uint32_t *src = reinterpret_cast<const uint32_t *>(out);
-      for (int i = 0; i < LT / 4; i++) dst[i] = src[i];
-    } else {
-      for (int i = 0; i < LT; i++) gt[idx * LT + i] = out[i];
-    }
-  }
-}
-template <int N, int DEG>
-__global__ void __launch_bounds__(kBlock, PBC_DF_WAVES) d_pp_apply_kernel(uint8_t *gt, const uint32_t *__restrict__ tab,
-                                                                          const uint32_t *__restrict__ valid,
-                                                                          const uint8_t *g2, size_t n, KArgs<N> ka) {
-  if constexpr (kDResident<N, DEG>) {
-    PBC_RESIDENT_LOOP(n) d_pp_unit<N, DEG>(vb, gt, tab, valid, g2, n);
-  } else {
-    d_pp_unit<N, DEG>(blockIdx.x, gt, tab, valid, g2, n);
-  }
-}
-
-// Type F: one k-term product (k = 1: a single pairing) per lane.  With fb = fixed byte length of F_q:
-// G1 2 fb, G2 4 fb, GT 12 fb bytes (40 / 80 / 240 B for f.param).
-#ifndef PBC_F_WAVES
-#define PBC_F_WAVES PBC_DF_WAVES
-#endif
-// (the 5-word field keeps its Miller accumulator in one 36 KB LDS area per workgroup: four workgroups per CU, two waves per
-// SIMD; with PBC_F_AREAS=2 in two areas, one wave per SIMD and the register budget that goes with it)
-template <int N, bool BM1>
-__global__ void __launch_bounds__(kBlock, N <= 5 ? (PBC_F_AREAS == 1 ? 2 : 1) : PBC_F_WAVES) f_prod_pairing_kernel(uint8_t *gt, const uint8_t *g1,
-                                                                 const uint8_t *g2, size_t n, int k, KArgs<N> ka) {
-#ifdef PBC_F_WHATIF_TRACE                        // what-if builds only (tools/whatif_time.py --trace): per-wave start / end / HW_ID behind the results
-  const uint64_t trace_t0 = wall_clock64();
-#endif
-  PBC_RESIDENT_LOOP(n) {
-    size_t idx = vb * kBlock + threadIdx.x;
-    size_t ld = idx < n ? idx : n - 1;
-    const int fb = (int) fpk<N>().fbytes, L1 = 2 * fb, L2 = 4 * fb, LT = 12 * fb;
-    __attribute__((aligned(4))) uint8_t out[48 * N];
-    TypeF<N, BM1>::f_prod_pairing_lane(out, g1 + ld * (k < 0 ? 1 : k) * L1, g2 + ld * (k < 0 ? 1 : k) * L2, k < 0 ? 1 : k, k < 0);
-    if (idx < n) {
-      uint32_t *dst = reinterpret_cast<uint32_t *>(gt + idx * LT);      // LT = 12 fb is a multiple of 4
-      const uint32_t *src = reinterpret_cast<const uint32_t *>(out);
-      for (int i = 0; i < LT / 4; i++) dst[i] = src[i];
-    }
-  }
-#ifdef PBC_F_WHATIF_TRACE
-  if ((threadIdx.x & 63) == 0) {
-    uint32_t hw, xcc;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    uint64_t *t = reinterpret_cast<uint64_t *>(gt + ((n * (size_t) (12 * fpk<N>().fbytes) + 255) & ~(size_t) 255)) + (size_t) (blockIdx.x * 2 + (threadIdx.x >> 6)) * 4;
-    t[0] = trace_t0; t[1] = wall_clock64(); t[2] = hw; t[3] = xcc;
-  }
-#endif
-}
-
-template <int N>
-__global__ void __launch_bounds__(kBlock) f_debug_kernel(int op, uint8_t *out, const uint8_t *a, const uint8_t *b, size_t n, KArgs<N> ka) {
-  size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
-  if (idx >= n) return;
-  const int LT = 12 * (int) fpk<N>().fbytes;
-  __attribute__((aligned(4))) uint8_t o[48 * N];
-  TypeF<N>::f_debug_lane(op, o, a + idx * LT, b + idx * LT);
-  for (int i = 0; i < LT; i++) out[idx * LT + i] = o[i];
-}
-
-// ---- group operations (one element per lane) -------------------------------------------------
-template <int N>
-__global__ void __launch_bounds__(kBlock, 2) g_mul_kernel(uint8_t *out, const uint8_t *in, const uint8_t *z,
-                                                           int zlen, size_t n, KArgs<N> ka) {
-  size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
-  if (idx >= n) return;
-  const size_t L = 2 * fpk<N>().fbytes;
-  g_mul_lane<N>(out + idx * L, in + idx * L, z + idx * zlen, zlen);
-}
-// element_to_bytes_compressed / _x_only and element_from_bytes_compressed / _x_only on E(F_q): one point per lane
-// (dir 0 / 2 and 1 / 3)
-template <int N>
-__global__ void __launch_bounds__(kBlock, 2) g_compress_kernel(int dir, uint8_t *out, const uint8_t *in, size_t n, KArgs<N> ka) {
-  size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
-  if (idx >= n) return;
-  const size_t fb = fpk<N>().fbytes;
-  if (dir == 0) g_compress_lane<N>(out + idx * (fb + 1), in + idx * 2 * fb);
-  else if (dir == 1) g_decompress_lane<N>(out + idx * 2 * fb, in + idx * (fb + 1));
-  else if (dir == 2) g_to_x_only_lane<N>(out + idx * fb, in + idx * 2 * fb);
-  else g_decompress_lane<N>(out + idx * 2 * fb, in + idx * fb, true);
-}
-// element_mul_zn on the twists: G2 of types d / g (over F_q^d) and f (over F_q^2)
-template <int N, int DEG>
-__global__ void __launch_bounds__(kBlock, 2) d_g2_mul_kernel(uint8_t *out, const uint8_t *in, const uint8_t *z,
-                                                              int zlen, size_t n, KArgs<N> ka) {
-  size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
-  if (idx >= n) return;
-  const size_t L = 2 * DEG * fpk<N>().fbytes;
-  ec_mul_lane<FdOps<N, DEG>>(out + idx * L, in + idx * L, z + idx * zlen, zlen);
-}
-template <int N>
-__global__ void __launch_bounds__(kBlock, 2) f_g2_mul_kernel(uint8_t *out, const uint8_t *in, const uint8_t *z,
-                                                              int zlen, size_t n, KArgs<N> ka) {
-  size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
-  if (idx >= n) return;
-  const size_t L = 4 * fpk<N>().fbytes;
-  ec_mul_lane<Fq2Ops<N>>(out + idx * L, in + idx * L, z + idx * zlen, zlen);
-}
-template <int N>
-__global__ void __launch_bounds__(kBlock, 2) g_from_hash_kernel(uint8_t *out, const uint8_t *data, int hlen, size_t n, KArgs<N> ka) {
-  size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
-  size_t ld = idx < n ? idx : n - 1;   // whole waves stay in the retry loop together
-  const int L = 2 * (int) fpk<N>().fbytes;
-  __attribute__((aligned(4))) uint8_t o[8 * N];
-  g_from_hash_lane<N>(o, data + ld * hlen, hlen);
-  if (idx < n)
-    for (int i = 0; i < L; i++) out[idx * L + i] = o[i];
-}
-// element_from_hash / element_to_bytes_compressed / element_from_bytes_compressed on the G2 twists (types d, g, f):
-// F is the field policy of the twist (FdOps / Fq2Ops).  what 0: digests of `aux` bytes -> points; 1: points ->
-// x || s; 2: x || s -> points; 3: points -> x; 4: x -> points
-template <class F>
-__global__ void __launch_bounds__(kBlock, 2) g2_point_kernel(int what, uint8_t *out, const uint8_t *in, int aux, size_t n, KArgs<F::NW> ka) {
-  size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
-  size_t ld = idx < n ? idx : n - 1;   // whole waves stay in the retry loop together
-  const size_t fb = (size_t) F::bytes();
-  const size_t li = what == 0 ? (size_t) aux : (what == 1 || what == 3) ? 2 * fb : what == 2 ? fb + 1 : fb;
-  const size_t lo = what == 1 ? fb + 1 : what == 3 ? fb : 2 * fb;
-  __attribute__((aligned(4))) uint8_t o[8 * F::WORDS];
-  if (what == 0) g2_from_hash_lane<F>(o, in + ld * li, aux);
-  else if (what == 1) g2_compress_lane<F>(o, in + ld * li);
-  else if (what == 2) g2_decompress_lane<F>(o, in + ld * li);
-  else if (what == 3) { for (size_t i = 0; i < fb; i++) o[i] = in[ld * li + i]; }
-  else g2_from_x_lane<F>(o, in + ld * li);
-  if (idx < n)
-    for (size_t i = 0; i < lo; i++) out[idx * lo + i] = o[i];
-}
-template <class F>
-__global__ void ext_ts_init_kernel(uint32_t *out, KArgs<F::NW> ka) {
-  if (threadIdx.x || blockIdx.x) return;
-  ext_ts_init<F>(out);
-}
-// one lane: z^t' for the Tonelli-Shanks square roots of element_from_hash (fields with q = 1 mod 4)
-struct TsRaw { uint32_t t[34], half[34]; int tbits, halfbits; };
-template <int N>
-__global__ void ts_init_kernel(uint32_t *out, TsRaw raw, KArgs<N> ka) {
-  if (threadIdx.x || blockIdx.x) return;
-  fp_ts_init<N>(out, raw.t, raw.tbits, raw.half, raw.halfbits);
-}
-// op 0: out = a * b in GT;  op 1: out = a ^ z;  op 2: out = finalpow(a) (the final exponentiation alone)
-template <int N>
-__global__ void __launch_bounds__(kBlock, 2) gt_op_kernel(int type, int op, uint8_t *out, const uint8_t *a,
-                                                           const uint8_t *b, int lenT, int zlen, size_t n, KArgs<N> ka) {
-  size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
-  if (idx >= n) return;
-  uint8_t *o = out + idx * lenT;
-  const uint8_t *x = a + idx * lenT;
-  if constexpr (N == 16 || N == 33) {
-    if (type == 'e') {                 // GT = F_q (pairing_GT_init(pairing, p->Fq), e_param.c:863)
-      fp<N> u, v;
-      if (op == 2) { e_finalpow_lane<N>(o, x); return; }
-      fp_load_be<N>(u, x);
-      if (op == 0) {
-        fp_load_be<N>(v, b + idx * lenT);
-        fp_mul<N>(u, u, v);
-      } else {
-        fp<N> acc, t;
-        fp_set<N>(acc, fpk<N>().one);
-        const uint8_t *z = b + idx * zlen;
-        for (int i = 8 * zlen - 1; i >= 0; i--) {
-          fp_sqr<N>(acc, acc);
-          fp_mul<N>(t, acc, u);
-          fp_cmov<N>(acc, t, zr_bit(z, zlen, i) != 0);
-        }
-        u = acc;
-      }
-      fp_store_be<N>(o, u);
-      return;
-    }
-  }
-  if constexpr (N == 16 || N == 33) {
-    if (op == 0) a_gt_mul_lane<N>(o, x, b + idx * lenT); else if (op == 1) a_gt_pow_lane<N>(o, x, b + idx * zlen, zlen); else a_finalpow_lane<N>(o, x);
-  } else {
-    if (type == 'd') {
-      if constexpr (N <= ND_MAX) {
-        if (op == 0) d_gt_mul_lane<N, 3>(o, x, b + idx * lenT); else if (op == 1) d_gt_pow_lane<N, 3>(o, x, b + idx * zlen, zlen); else d_finalpow_lane<N, 3>(o, x);
-      }
-    } else if constexpr (N == 5 || N == 8) {
-      if (type == 'g') {
-        if constexpr (N == 5) {
-          if (op == 0) d_gt_mul_lane<N, 5>(o, x, b + idx * lenT); else if (op == 1) d_gt_pow_lane<N, 5>(o, x, b + idx * zlen, zlen); else d_finalpow_lane<N, 5>(o, x);
-        }
-      } else {
-        if (op == 0) f_gt_mul_lane<N>(o, x, b + idx * lenT); else if (op == 1) f_gt_pow_lane<N>(o, x, b + idx * zlen, zlen); else f_finalpow_lane<N>(o, x);
-      }
-    }
-  }
-}
 
 // Batched F_q operations on wire bytes (differential check of the limb arithmetic).
 template <int N>
@@ -834,68 +342,6 @@ extern "C" double pbc_hip_algorithmic_macs_per_unit(const pbc_hip_pairing_t *p, 
   return p->fq_muls_single * per_mul;
 }
 
-// Type D / G kernels exist per (field width, d); N and DEG are compile-time inside the expression
-#define PBC_DISPATCH_D(P_, ...)                                                        \
-  switch ((P_)->nlimb * 8 + (P_)->deg) {                                               \
-    case 5 * 8 + 3: { constexpr int N = 5, DEG = 3; __VA_ARGS__; } break;              \
-    case 6 * 8 + 3: { constexpr int N = 6, DEG = 3; __VA_ARGS__; } break;              \
-    case 7 * 8 + 3: { constexpr int N = 7, DEG = 3; __VA_ARGS__; } break;              \
-    case 5 * 8 + 5: { constexpr int N = 5, DEG = 5; __VA_ARGS__; } break;              \
-    default: return fail("internal: no type d/g kernel for %d-word fields, degree %d", (P_)->nlimb, (P_)->deg); \
-  }
-
-// type f kernels: 5-word (f.param) and 8-word (256-bit BN) fields
-#define PBC_DISPATCH_F(nl, ...)                               \
-  switch (nl) {                                               \
-    case 5: { constexpr int N = 5; __VA_ARGS__; } break;      \
-    case 8: { constexpr int N = 8; __VA_ARGS__; } break;      \
-    default: return fail("internal: no type f kernel for %d-word fields", (int) (nl)); \
-  }
-// any built-in field width (PBC_FOR_EACH_N)
-#define PBC_DISPATCH_N(nl, ...)                               \
-  switch (nl) {                                               \
-    case 5: { constexpr int N = 5; __VA_ARGS__; } break;             \
-    case 6: { constexpr int N = 6; __VA_ARGS__; } break;             \
-    case 7: { constexpr int N = 7; __VA_ARGS__; } break;             \
-    case 8: { constexpr int N = 8; __VA_ARGS__; } break;             \
-    case 16: { constexpr int N = 16; __VA_ARGS__; } break;           \
-    case 33: { constexpr int N = 33; __VA_ARGS__; } break;           \
-    default: return fail("internal: no kernel for %d-word fields", (int) (nl)); \
-  }
-
-// the constant block of an object, passed by value as the LAST argument of every kernel (fp.cuh, "KArgs")
-template <int N>
-static KArgs<N> kargs(const pbc_hip_pairing_s *P, bool for_pairing = false) {
-  KArgs<N> K;
-  fill_kargs<N>(P, K, for_pairing);
-  return K;
-}
-
-// single-lane kernels of the one-time derivations (tower constants of types d / g / f, the auxiliary point of type e)
-template <int N, int DEG> __global__ void d_init_stage1(DConst *out, DRaw raw, KArgs<N> ka) {
-  if (threadIdx.x || blockIdx.x) return;
-  TypeMNT<N, DEG>::init_stage1(out, raw, c_d);
-}
-template <int N, int DEG> __global__ void d_init_stage2(DConst *out, DRaw raw, KArgs<N> ka) {
-  if (threadIdx.x || blockIdx.x) return;
-  TypeMNT<N, DEG>::init_stage2(out, raw);
-}
-template <int N> __global__ void f_init_stage1(FConst *out, FRaw raw, KArgs<N> ka) {
-  if (threadIdx.x || blockIdx.x) return;
-  TypeF<N>::init_stage1(out, raw, c_f);
-}
-template <int N> __global__ void f_init_stage2(FConst *out, FRaw raw, KArgs<N> ka) {
-  if (threadIdx.x || blockIdx.x) return;
-  TypeF<N>::init_stage2(out, raw);
-}
-template <int N> __global__ void f_init_stage3(FConst *out, FRaw raw, KArgs<N> ka) {
-  if (threadIdx.x || blockIdx.x) return;
-  TypeF<N>::init_stage3(out, raw);
-}
-template <int N> __global__ void e_init_kernel(EConst *out, ERaw raw, KArgs<N> ka) {
-  if (threadIdx.x || blockIdx.x) return;
-  e_init_lane<N>(out, raw, c_e);
-}
 
 // Self-test of the constant block's addressing (fp.cuh: every device routine finds the block at a fixed negative offset
 // from the implicit-argument pointer -- an assumption about the code object ABI that only static_asserts on sizes would
@@ -957,49 +403,18 @@ static int kargs_selftest(pbc_hip_pairing_s *P, hipStream_t s) {
   return 0;
 }
 
-// First use of an object on a device: constants that are derived ON the device (the library carries no host copy of
-// the tower arithmetic) are computed by single-lane kernels and kept in the object; every later launch passes them in
-// its argument block.  Nothing is uploaded per call.
-static int ensure_derived(pbc_hip_pairing_s *P, hipStream_t s) {
+// First use of an object on a device: constants that are derived ON the device (the library carries no host-side copy of
+// the tower arithmetic) are computed by single-lane kernels of the family's translation unit and kept in the object;
+// every later launch passes them in its argument block.  Nothing is uploaded per call.
+int ensure_derived(pbc_hip_pairing_s *P, hipStream_t s) {
   if (!P->kargs_checked) {
     PBC_DISPATCH_N(P->nlimb, { if (kargs_selftest<N>(P, s)) return 1; });
     P->kargs_checked = true;
   }
   if (P->dev_ready || (P->type != 'd' && P->type != 'g' && P->type != 'e' && P->type != 'f')) return 0;
-  DevBuf buf;
-  if (P->type == 'd' || P->type == 'g') {
-    HIP_TRY(buf.alloc(sizeof(DConst)));
-    DConst *dbuf = buf.as<DConst>();
-    PBC_DISPATCH_D(P, hipLaunchKernelGGL((d_init_stage1<N, DEG>), dim3(1), dim3(64), 0, s, dbuf, P->draw, kargs<N>(P)));
-    HIP_TRY(hipMemcpyAsync(&P->dconst, dbuf, sizeof(DConst), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    PBC_DISPATCH_D(P, hipLaunchKernelGGL((d_init_stage2<N, DEG>), dim3(1), dim3(64), 0, s, dbuf, P->draw, kargs<N>(P)));
-    HIP_TRY(hipMemcpyAsync(&P->dconst, dbuf, sizeof(DConst), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-  } else if (P->type == 'e') {
-    HIP_TRY(buf.alloc(sizeof(EConst)));
-    EConst *dbuf = buf.as<EConst>();
-    if (P->nlimb == 16) hipLaunchKernelGGL(e_init_kernel<16>, dim3(1), dim3(64), 0, s, dbuf, P->eraw, kargs<16>(P));
-    else hipLaunchKernelGGL(e_init_kernel<33>, dim3(1), dim3(64), 0, s, dbuf, P->eraw, kargs<33>(P));
-    HIP_TRY(hipMemcpyAsync(&P->econst, dbuf, sizeof(EConst), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-  } else {
-    HIP_TRY(buf.alloc(sizeof(FConst)));
-    FConst *dbuf = buf.as<FConst>();
-    PBC_DISPATCH_F(P->nlimb, hipLaunchKernelGGL(f_init_stage1<N>, dim3(1), dim3(64), 0, s, dbuf, P->fraw, kargs<N>(P)));
-    HIP_TRY(hipMemcpyAsync(&P->fconst, dbuf, sizeof(FConst), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    PBC_DISPATCH_F(P->nlimb, hipLaunchKernelGGL(f_init_stage2<N>, dim3(1), dim3(64), 0, s, dbuf, P->fraw, kargs<N>(P)));
-    HIP_TRY(hipMemcpyAsync(&P->fconst, dbuf, sizeof(FConst), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    if (P->fraw.e4bits > 0) {          // q = 3 mod 4: the i-basis copy for the pairing kernels
-      PBC_DISPATCH_F(P->nlimb, hipLaunchKernelGGL(f_init_stage3<N>, dim3(1), dim3(64), 0, s, dbuf, P->fraw, kargs<N>(P)));
-      HIP_TRY(hipMemcpyAsync(&P->fconst_i, dbuf, sizeof(FConst), hipMemcpyDeviceToHost, s));
-      HIP_TRY(hipStreamSynchronize(s));
-      P->f_bm1 = P->fconst_i.bm1 != 0;
-    }
-  }
-  HIP_TRY(hipGetLastError());
+  if (P->type == 'd' || P->type == 'g') { if (derive_d(P, s)) return 1; }
+  else if (P->type == 'e') { if (derive_e(P, s)) return 1; }
+  else if (derive_f(P, s)) return 1;
   P->dev_ready = true;
   return 0;
 }
@@ -1007,7 +422,7 @@ static int ensure_derived(pbc_hip_pairing_s *P, hipStream_t s) {
 // Grid of a resident-workgroup launch (PBC_RESIDENT_LOOP): the workgroups the current device holds at once for this
 // kernel (occupancy query, cached per kernel and device), or one per 128 units when the batch is smaller than that.
 // PBC_HIP_RESIDENT=0 restores one workgroup per 128 units (A/B measurements).
-static unsigned resident_grid(const pbc_hip_pairing_s *P, const void *kernel, size_t n) {
+unsigned resident_grid(const pbc_hip_pairing_s *P, const void *kernel, size_t n) {
   const size_t nvb = (n + kBlock - 1) / kBlock;
   if (P->resident_slots > 0) return (unsigned) (nvb < (size_t) P->resident_slots ? nvb : (size_t) P->resident_slots);   // "hip_resident_slots N" (tests)
   static const bool off = [] { const char *e = getenv("PBC_HIP_RESIDENT"); return e && e[0] == '0'; }();
@@ -1033,45 +448,12 @@ static unsigned resident_grid(const pbc_hip_pairing_s *P, const void *kernel, si
   }
   return (unsigned) (nvb < slots ? nvb : slots);
 }
-#define PBC_RGRID(...) resident_grid(P, reinterpret_cast<const void *>(&__VA_ARGS__), n)
 
+static int launch_prod(pbc_hip_pairing_s *P, void *d_gt, const void *d_g1, const void *d_g2, size_t n, int k,
+                       hipStream_t s, bool upload, const OwnWs *own = nullptr);
 static int launch_pairing(pbc_hip_pairing_s *P, void *d_gt, const void *d_g1, const void *d_g2, size_t n,
                           hipStream_t s, bool upload) {
-  if (P->device < 0) return fail("no HIP device: libpbc_hip has no CPU fallback");
-  if (!n) return 0;
-  if (upload && ensure_derived(P, s)) return 1;
-  unsigned grid = (unsigned) ((n + kBlock - 1) / kBlock);
-  if (P->type == 'a' && !P->a_generic) {
-    hipLaunchKernelGGL(al_pairing_kernel<16>, dim3(PBC_RGRID(al_pairing_kernel<16>)), dim3(kBlock), 0, s, (uint8_t *) d_gt,
-                       (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, kargs<16>(P));
-  } else if ((P->type == 'a' || P->type == '1') && P->nlimb == 16) {   // other sizes: the bit-by-bit kernels
-    hipLaunchKernelGGL(a1_prod_pairing_kernel<16>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
-                       (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, 1, kargs<16>(P));
-  } else if (P->type == '1' || P->type == 'a') {
-    hipLaunchKernelGGL(a1_prod_pairing_kernel<33>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
-                       (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, 1, kargs<33>(P));
-  } else if (P->type == 'e' && P->nlimb == 16) {
-    hipLaunchKernelGGL(e_prod_pairing_kernel<16>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
-                       (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, 1, kargs<16>(P));
-  } else if (P->type == 'e') {
-    hipLaunchKernelGGL(e_prod_pairing_kernel<33>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
-                       (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, 1, kargs<33>(P));
-  } else if (P->type == 'd' || P->type == 'g') {
-    PBC_DISPATCH_D(P, hipLaunchKernelGGL((d_prod_pairing_kernel<N, DEG>), dim3(kDResident<N, DEG> ? PBC_RGRID(d_prod_pairing_kernel<N, DEG>) : grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
-                                                (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, 1, (uint32_t *) nullptr, kargs<N>(P)));
-  } else if (P->type == 'f') {
-    if (P->f_bm1) {                    // i-basis constants and the instantiation that goes with them
-      PBC_DISPATCH_F(P->nlimb, hipLaunchKernelGGL((f_prod_pairing_kernel<N, true>), dim3(PBC_RGRID(f_prod_pairing_kernel<N, true>)), dim3(kBlock), 0, s, (uint8_t *) d_gt,
-                         (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, 1, kargs<N>(P, true)));
-    } else {
-      PBC_DISPATCH_F(P->nlimb, hipLaunchKernelGGL((f_prod_pairing_kernel<N, false>), dim3(PBC_RGRID(f_prod_pairing_kernel<N, false>)), dim3(kBlock), 0, s, (uint8_t *) d_gt,
-                         (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, 1, kargs<N>(P)));
-    }
-  } else {
-    return fail("unsupported type");
-  }
-  HIP_TRY(hipGetLastError());
-  return 0;
+  return launch_prod(P, d_gt, d_g1, d_g2, n, 1, s, upload);
 }
 extern "C" int pbc_hip_element_pairing_batch_dev(pbc_hip_pairing_t *P, void *d_gt, const void *d_g1,
                                                  const void *d_g2, size_t n, void *stream) {
@@ -1096,7 +478,7 @@ constexpr int kSlots = 3, kMaxDev = 16;
 // of a pairing) and writes 128 bytes, while staged copies do not overlap with kernels that hold every register and LDS
 // byte of the chip.  Measured (tools/r03_hostchunk.sh, pinned host -> pinned host, ms per batch, staged / in place):
 // type a 2^20 90.1 / 81.6 (kernel alone: 81.7), 16-term type a products 2^18 281.2 / 260.5, type f 2^18 30.8 / 28.5.
-static void *pinned_dev_ptr(const void *host, size_t bytes, bool shared) {
+void *pinned_dev_ptr(const void *host, size_t bytes, bool shared) {
   if (reinterpret_cast<uintptr_t>(host) % 16) return nullptr;      // the kernels' 16-byte accesses; staged buffers are aligned
   hipPointerAttribute_t at, at_end;
   if (hipPointerGetAttributes(&at, host) != hipSuccess) { (void) hipGetLastError(); return nullptr; }
@@ -1118,7 +500,7 @@ static void *pinned_dev_ptr(const void *host, size_t bytes, bool shared) {
   if (hipHostGetDevicePointer(&d, const_cast<void *>(host), 0) != hipSuccess) { (void) hipGetLastError(); return nullptr; }
   return d;
 }
-static bool ranges_overlap(const void *a, size_t na, const void *b, size_t nb) {
+bool ranges_overlap(const void *a, size_t na, const void *b, size_t nb) {
   const uintptr_t x = reinterpret_cast<uintptr_t>(a), y = reinterpret_cast<uintptr_t>(b);
   return x < y + nb && y < x + na;
 }
@@ -1181,7 +563,7 @@ static void hostctx_free(pbc_hip_pairing_s *P) {
 // At least `bytes` of device memory for a kernel about to be launched on stream `s` of the current device; kept by the
 // object, grown on demand (the only allocation a steady-state call can make).  The entry is PINNED until
 // workspace_unpin: an entry whose kernel has not been enqueued yet is never evicted.
-static void *workspace_get(pbc_hip_pairing_s *P, hipStream_t s, size_t bytes) {
+void *workspace_get(pbc_hip_pairing_s *P, hipStream_t s, size_t bytes) {
   int dev = -1;
   if (hipGetDevice(&dev) != hipSuccess) { fail("no current HIP device"); return nullptr; }
   if (!P->host_ctx) P->host_ctx = new HostCtx();
@@ -1216,7 +598,7 @@ static void *workspace_get(pbc_hip_pairing_s *P, hipStream_t s, size_t bytes) {
   e->pins++;
   return e->p;
 }
-static void workspace_unpin(pbc_hip_pairing_s *P, hipStream_t s) {
+void workspace_unpin(pbc_hip_pairing_s *P, hipStream_t s) {
   int dev = -1;
   HostCtx *H = static_cast<HostCtx *>(P->host_ctx);
   if (!H || hipGetDevice(&dev) != hipSuccess) return;
@@ -1224,10 +606,7 @@ static void workspace_unpin(pbc_hip_pairing_s *P, hipStream_t s) {
   for (WsEnt &w : H->ws)
     if (w.dev == dev && w.st == s && w.pins > 0) w.pins--;
 }
-// A workspace that belongs to one stream of a device context of the host-buffer path (launch_prod's `own`): grown on
-// demand, freed with the context.
-struct OwnWs { void **p; size_t *cap; };
-static void *own_workspace(const OwnWs &o, hipStream_t s, size_t bytes) {
+void *own_workspace(const OwnWs &o, hipStream_t s, size_t bytes) {
   if (*o.cap < bytes) {
     if (*o.p) { (void) hipStreamSynchronize(s); (void) hipFree(*o.p); *o.p = nullptr; *o.cap = 0; }
     if (hipMalloc(o.p, bytes) != hipSuccess) { *o.p = nullptr; fail("device allocation of a %zu-byte product workspace failed", bytes); return nullptr; }
@@ -1291,8 +670,6 @@ static bool devctx_slot(DevCtx *c, int sl, size_t b1, size_t b2, size_t bt, std:
   return true;
 }
 
-static int launch_prod(pbc_hip_pairing_s *P, void *d_gt, const void *d_g1, const void *d_g2, size_t n, int k,
-                       hipStream_t s, bool upload, const OwnWs *own = nullptr);
 static int run_host(pbc_hip_pairing_s *P, uint8_t *gt, const uint8_t *g1, const uint8_t *g2, size_t n,
                     int k) {
   if (P->device < 0) return fail("no HIP device: libpbc_hip has no CPU fallback");
@@ -1397,74 +774,14 @@ extern "C" int pbc_hip_element_pairing_batch(pbc_hip_pairing_t *P, uint8_t *gt, 
 static int launch_prod(pbc_hip_pairing_s *P, void *d_gt, const void *d_g1, const void *d_g2, size_t n, int k,
                        hipStream_t s, bool upload, const OwnWs *own) {
   if (k < 1) return fail("k must be >= 1");
-  if (k == 1) return launch_pairing(P, d_gt, d_g1, d_g2, n, s, upload);
   if (P->device < 0) return fail("no HIP device: libpbc_hip has no CPU fallback");
   if (!n) return 0;
   if (upload && ensure_derived(P, s)) return 1;
-  unsigned grid = (unsigned) ((n + kBlock - 1) / kBlock);
-  // the workspace of this launch: the caller's own (host-buffer path) or the object's table entry for (device, stream),
-  // which stays pinned until the kernels below are enqueued
-  struct Pin {
-    pbc_hip_pairing_s *P; hipStream_t s; bool on = false;
-    ~Pin() { if (on) workspace_unpin(P, s); }
-  } pin{P, s};
-  auto prod_ws = [&](size_t bytes) -> void * {
-    if (own) return own_workspace(*own, s, bytes);
-    void *w = workspace_get(P, s, bytes);
-    pin.on = pin.on || w != nullptr;
-    return w;
-  };
-  if (P->type == 'a' && !P->a_generic && !P->a_prod_shared) {
-    // one term per lane, then one product per lane; at most a_prod_chunk terms in flight (their records: 160 B each)
-    const size_t per = std::max<size_t>(1, P->a_prod_chunk / (size_t) k);
-    const size_t first = std::min(n, per);
-    void *ws = prod_ws(first * (size_t) k * AL<16>::MREC * sizeof(uint4));
-    if (!ws) return 1;
-    for (size_t u0 = 0; u0 < n; u0 += per) {
-      const size_t nu = std::min(per, n - u0), nt = nu * (size_t) k;
-      hipLaunchKernelGGL(al_miller_kernel<16>, dim3(resident_grid(P, reinterpret_cast<const void *>(&al_miller_kernel<16>), nt)), dim3(kBlock), 0, s,
-                         (uint4 *) ws, (const uint8_t *) d_g1 + u0 * (size_t) k * P->len1, (const uint8_t *) d_g2 + u0 * (size_t) k * P->len2, nt, kargs<16>(P));
-      hipLaunchKernelGGL(al_prod_finish_kernel<16>, dim3(resident_grid(P, reinterpret_cast<const void *>(&al_prod_finish_kernel<16>), nu)), dim3(kBlock), 0, s,
-                         (uint8_t *) d_gt + u0 * P->lenT, (const uint4 *) ws, nu, k, kargs<16>(P));
-    }
-  } else if (P->type == 'a' && !P->a_generic) {
-    grid = PBC_RGRID(a_prod_pairing_kernel<16>);                      // one workspace record per RESIDENT workgroup
-    void *ws = prod_ws((size_t) grid * (size_t) k * (6 * 4 * kBlock) * sizeof(uint4));
-    if (!ws) return 1;
-    hipLaunchKernelGGL(a_prod_pairing_kernel<16>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
-                       (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k, (uint4 *) ws, kargs<16>(P));
-  } else if ((P->type == 'a' || P->type == '1') && P->nlimb == 16) {
-    hipLaunchKernelGGL(a1_prod_pairing_kernel<16>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
-                       (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k, kargs<16>(P));
-  } else if (P->type == '1' || P->type == 'a') {
-    hipLaunchKernelGGL(a1_prod_pairing_kernel<33>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
-                       (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k, kargs<33>(P));
-  } else if (P->type == 'e' && P->nlimb == 16) {
-    hipLaunchKernelGGL(e_prod_pairing_kernel<16>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
-                       (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k, kargs<16>(P));
-  } else if (P->type == 'e') {
-    hipLaunchKernelGGL(e_prod_pairing_kernel<33>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
-                       (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k, kargs<33>(P));
-  } else if (P->type == 'd' || P->type == 'g') {
-    size_t rec = 0;                    // words of Miller state per term and lane (the kernel's own constant)
-    PBC_DISPATCH_D(P, { rec = (size_t) TypeMNT<N, DEG>::DL_WORDS; if (kDResident<N, DEG>) grid = PBC_RGRID(d_prod_pairing_kernel<N, DEG>); });      // one workspace record per RESIDENT workgroup
-    void *ws = prod_ws((size_t) grid * (size_t) k * rec * kBlock * sizeof(uint32_t));
-    if (!ws) return 1;
-    PBC_DISPATCH_D(P, hipLaunchKernelGGL((d_prod_pairing_kernel<N, DEG>), dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
-                                                (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k, (uint32_t *) ws, kargs<N>(P)));
-  } else if (P->type == 'f') {
-    if (P->f_bm1) {
-      PBC_DISPATCH_F(P->nlimb, hipLaunchKernelGGL((f_prod_pairing_kernel<N, true>), dim3(PBC_RGRID(f_prod_pairing_kernel<N, true>)), dim3(kBlock), 0, s, (uint8_t *) d_gt,
-                         (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k, kargs<N>(P, true)));
-    } else {
-      PBC_DISPATCH_F(P->nlimb, hipLaunchKernelGGL((f_prod_pairing_kernel<N, false>), dim3(PBC_RGRID(f_prod_pairing_kernel<N, false>)), dim3(kBlock), 0, s, (uint8_t *) d_gt,
-                         (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k, kargs<N>(P)));
-    }
-  } else {
-    return fail("unsupported type");
-  }
-  HIP_TRY(hipGetLastError());
-  return 0;
+  ProdWs W(P, s, own);
+  if (P->type == 'a' || P->type == '1' || P->type == 'e') return launch_a(P, d_gt, d_g1, d_g2, n, k, s, W);
+  if (P->type == 'd' || P->type == 'g') return launch_d(P, d_gt, d_g1, d_g2, n, k, s, W);
+  if (P->type == 'f') return launch_f(P, d_gt, d_g1, d_g2, n, k, s);
+  return fail("unsupported type");
 }
 extern "C" int pbc_hip_element_prod_pairing_batch_dev(pbc_hip_pairing_t *P, void *d_gt, const void *d_g1,
                                                       const void *d_g2, size_t n, int k, void *stream) {
@@ -1478,218 +795,7 @@ extern "C" int pbc_hip_element_prod_pairing_batch(pbc_hip_pairing_t *P, uint8_t 
   return run_host(P, gt, g1, g2, n, k);
 }
 
-// ---- group operations ------------------------------------------------------------------------
-extern "C" int pbc_hip_pairing_length_in_bytes_Zr(const pbc_hip_pairing_t *p) { return p->len_zr; }
-
-// three device buffers in, one out: shared host path for the group-operation entry points
-static int run_group(pbc_hip_pairing_s *P, int what, int group, uint8_t *out, const uint8_t *a, const uint8_t *b,
-                     size_t n) {
-  if (P->device < 0) return fail("no HIP device: libpbc_hip has no CPU fallback");
-  if (!n) return 0;
-  size_t la, lb, lo;
-  if (what == 0) {                     // G mul_zn
-    if (group != 1 && group != 2) return fail("group must be 1 or 2");
-    la = lo = (size_t) (group == 1 ? P->len1 : P->len2);
-    lb = (size_t) P->len_zr;
-  } else if (what == 1) {              // GT mul
-    la = lb = lo = (size_t) P->lenT;
-  } else if (what == 2) {              // GT pow
-    la = lo = (size_t) P->lenT;
-    lb = (size_t) P->len_zr;
-  } else {                             // finalpow: one operand
-    la = lo = (size_t) P->lenT;
-    lb = 0;
-  }
-  DevBuf ba, bb, bo;
-  DeviceGuard guard(P->device);
-  HIP_TRY(ba.alloc(n * la));
-  HIP_TRY(bb.alloc(n * lb));
-  HIP_TRY(bo.alloc(n * lo));
-  void *da = ba.p, *db = bb.p, *d_o = bo.p;
-  HIP_TRY(hipMemcpy(da, a, n * la, hipMemcpyHostToDevice));
-  if (lb) HIP_TRY(hipMemcpy(db, b, n * lb, hipMemcpyHostToDevice));
-  if (ensure_derived(P, 0)) return 1;
-  unsigned grid = (unsigned) ((n + kBlock - 1) / kBlock);
-  if (what == 0 && group == 2 && (P->type == 'd' || P->type == 'g')) {
-    PBC_DISPATCH_D(P, hipLaunchKernelGGL((d_g2_mul_kernel<N, DEG>), dim3(grid), dim3(kBlock), 0, 0, (uint8_t *) d_o,
-                                         (const uint8_t *) da, (const uint8_t *) db, P->len_zr, n, kargs<N>(P)));
-  } else if (what == 0 && group == 2 && P->type == 'f') {
-    PBC_DISPATCH_F(P->nlimb, hipLaunchKernelGGL(f_g2_mul_kernel<N>, dim3(grid), dim3(kBlock), 0, 0, (uint8_t *) d_o, (const uint8_t *) da,
-                       (const uint8_t *) db, P->len_zr, n, kargs<N>(P)));
-  } else if (what == 0) {              // E(F_q): G1, and G2 of the symmetric types
-    PBC_DISPATCH_N(P->nlimb, hipLaunchKernelGGL(g_mul_kernel<N>, dim3(grid), dim3(kBlock), 0, 0, (uint8_t *) d_o,
-                                                (const uint8_t *) da, (const uint8_t *) db, P->len_zr, n, kargs<N>(P)));
-  } else {
-    PBC_DISPATCH_N(P->nlimb, hipLaunchKernelGGL(gt_op_kernel<N>, dim3(grid), dim3(kBlock), 0, 0, P->type, what - 1,
-                                                (uint8_t *) d_o, (const uint8_t *) da, (const uint8_t *) db, P->lenT,
-                                                P->len_zr, n, kargs<N>(P)));
-  }
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpy(out, d_o, n * lo, hipMemcpyDeviceToHost));
-  return 0;
-}
-extern "C" int pbc_hip_element_mul_zn_batch(pbc_hip_pairing_t *P, int group, uint8_t *out, const uint8_t *in,
-                                            const uint8_t *zr, size_t n) {
-  if (!P) return fail("null pairing");
-  return run_group(P, 0, group, out, in, zr, n);
-}
-extern "C" int pbc_hip_element_mul_GT_batch(pbc_hip_pairing_t *P, uint8_t *out, const uint8_t *a, const uint8_t *b,
-                                            size_t n) {
-  if (!P) return fail("null pairing");
-  return run_group(P, 1, 0, out, a, b, n);
-}
-extern "C" int pbc_hip_element_pow_zn_GT_batch(pbc_hip_pairing_t *P, uint8_t *out, const uint8_t *a,
-                                               const uint8_t *zr, size_t n) {
-  if (!P) return fail("null pairing");
-  return run_group(P, 2, 0, out, a, zr, n);
-}
-extern "C" int pbc_hip_finalpow_batch(pbc_hip_pairing_t *P, uint8_t *out, const uint8_t *in, size_t n) {
-  if (!P) return fail("null pairing");
-  return run_group(P, 3, 0, out, in, nullptr, n);
-}
-
-// first use of a square root in a field with q = 1 mod 4: derive the non-residue power z^t of the
-// Tonelli-Shanks tail on the device (single lane)
-static int ensure_sqrt_constants(pbc_hip_pairing_s *P) {
-  if (!P->hash.ts_ready) {
-    if (ensure_derived(P, 0)) return 1;
-    DevBuf bc;
-    TsRaw raw;
-    memcpy(raw.t, P->hash.ts_t, sizeof raw.t);
-    memcpy(raw.half, P->hash.half, sizeof raw.half);
-    raw.tbits = P->hash.ts_tbits;
-    raw.halfbits = P->hash.halfbits;
-    HIP_TRY(bc.alloc(sizeof P->hash.ts_c));
-    uint32_t *dc = bc.as<uint32_t>();
-    HIP_TRY(hipMemset(dc, 0, sizeof P->hash.ts_c));
-    PBC_DISPATCH_N(P->nlimb, hipLaunchKernelGGL(ts_init_kernel<N>, dim3(1), dim3(64), 0, 0, dc, raw, kargs<N>(P)));
-    HIP_TRY(hipMemcpy(P->hash.ts_c, dc, sizeof P->hash.ts_c, hipMemcpyDeviceToHost));
-    P->hash.ts_ready = true;
-  }
-  return 0;
-}
-// F = field policy of the G2 twist of an asymmetric type
-#define PBC_DISPATCH_TWIST(P_, ...)                                                           \
-  do {                                                                                        \
-    if ((P_)->type == 'f') { PBC_DISPATCH_F((P_)->nlimb, { typedef Fq2Ops<N> F; __VA_ARGS__; }); } \
-    else { PBC_DISPATCH_D(P_, { typedef FdOps<N, DEG> F; __VA_ARGS__; }); }                   \
-  } while (0)
-// z^T for the square roots in the twist's field, once per parameter set
-static int ensure_ext_sqrt(pbc_hip_pairing_s *P) {
-  if (!P->xs_ready) {
-    if (ensure_derived(P, 0)) return 1;
-    DevBuf bc;
-    HIP_TRY(bc.alloc(sizeof P->xs.c));
-    uint32_t *dc = bc.as<uint32_t>();
-    HIP_TRY(hipMemset(dc, 0, sizeof P->xs.c));
-    PBC_DISPATCH_TWIST(P, hipLaunchKernelGGL(ext_ts_init_kernel<F>, dim3(1), dim3(64), 0, 0, dc, kargs<F::NW>(P)));
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpy(P->xs.c, dc, sizeof P->xs.c, hipMemcpyDeviceToHost));
-    P->xs_ready = true;
-  }
-  return 0;
-}
-// what 0: element_from_hash (li = hlen), 1 / 2: to / from_bytes_compressed, 3 / 4: to / from_bytes_x_only -- on the G2 twist
-static int run_twist_points(pbc_hip_pairing_s *P, int what, uint8_t *out, const uint8_t *in, int hlen, size_t n) {
-  const size_t lp = (size_t) P->len2, lc = lp / 2 + 1, lx = lp / 2;
-  const size_t li = what == 0 ? (size_t) hlen : (what == 1 || what == 3) ? lp : what == 2 ? lc : lx;
-  const size_t lo = what == 1 ? lc : what == 3 ? lx : lp;
-  DevBuf bi, bo;
-  DeviceGuard guard(P->device);
-  if (ensure_ext_sqrt(P)) return 1;
-  if (P->type == 'f' && ensure_sqrt_constants(P)) return 1;   // fq_sqrt works through square roots in F_q
-  HIP_TRY(bi.alloc(n * li));
-  HIP_TRY(bo.alloc(n * lo));
-  void *di = bi.p, *d_o = bo.p;
-  HIP_TRY(hipMemcpy(di, in, n * li, hipMemcpyHostToDevice));
-  if (ensure_derived(P, 0)) return 1;
-  unsigned grid = (unsigned) ((n + kBlock - 1) / kBlock);
-  PBC_DISPATCH_TWIST(P, hipLaunchKernelGGL(g2_point_kernel<F>, dim3(grid), dim3(kBlock), 0, 0, what, (uint8_t *) d_o,
-                                           (const uint8_t *) di, hlen, n, kargs<F::NW>(P)));
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpy(out, d_o, n * lo, hipMemcpyDeviceToHost));
-  return 0;
-}
-// dir 0: x||y -> x||s;  dir 1: x||s -> x||y;  dir 2: x||y -> x;  dir 3: x -> x||y
-static int run_compress(pbc_hip_pairing_s *P, int dir, int group, uint8_t *out, const uint8_t *in, size_t n) {
-  if (!P) return fail("null pairing");
-  if (P->device < 0) return fail("no HIP device: libpbc_hip has no CPU fallback");
-  const bool symmetric = P->type == 'a' || P->type == '1' || P->type == 'e';
-  if (group == 2 && !symmetric) return n ? run_twist_points(P, dir + 1, out, in, 0, n) : 0;
-  if (group != 1 && group != 2) return fail("group must be 1 or 2");
-  if (!n) return 0;
-  const size_t lp = (size_t) P->len1, lc = (size_t) P->len_fq + (dir < 2 ? 1 : 0);
-  const size_t li = (dir & 1) == 0 ? lp : lc, lo = (dir & 1) == 0 ? lc : lp;
-  DevBuf bi, bo;
-  DeviceGuard guard(P->device);
-  if (ensure_sqrt_constants(P)) return 1;
-  HIP_TRY(bi.alloc(n * li));
-  HIP_TRY(bo.alloc(n * lo));
-  void *di = bi.p, *d_o = bo.p;
-  HIP_TRY(hipMemcpy(di, in, n * li, hipMemcpyHostToDevice));
-  if (ensure_derived(P, 0)) return 1;
-  unsigned grid = (unsigned) ((n + kBlock - 1) / kBlock);
-  PBC_DISPATCH_N(P->nlimb, hipLaunchKernelGGL(g_compress_kernel<N>, dim3(grid), dim3(kBlock), 0, 0, dir, (uint8_t *) d_o,
-                                              (const uint8_t *) di, n, kargs<N>(P)));
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpy(out, d_o, n * lo, hipMemcpyDeviceToHost));
-  return 0;
-}
-extern "C" int pbc_hip_element_to_bytes_compressed_batch(pbc_hip_pairing_t *P, int group, uint8_t *out,
-                                                         const uint8_t *in, size_t n) {
-  return run_compress(P, 0, group, out, in, n);
-}
-extern "C" int pbc_hip_element_from_bytes_compressed_batch(pbc_hip_pairing_t *P, int group, uint8_t *out,
-                                                           const uint8_t *in, size_t n) {
-  return run_compress(P, 1, group, out, in, n);
-}
-extern "C" int pbc_hip_pairing_length_in_bytes_compressed_G1(const pbc_hip_pairing_t *p) { return p->len_fq + 1; }
-extern "C" int pbc_hip_pairing_length_in_bytes_compressed_G2(const pbc_hip_pairing_t *p) { return p->len2 / 2 + 1; }
-extern "C" int pbc_hip_element_to_bytes_x_only_batch(pbc_hip_pairing_t *P, int group, uint8_t *out,
-                                                     const uint8_t *in, size_t n) {
-  return run_compress(P, 2, group, out, in, n);
-}
-extern "C" int pbc_hip_element_from_bytes_x_only_batch(pbc_hip_pairing_t *P, int group, uint8_t *out,
-                                                       const uint8_t *in, size_t n) {
-  return run_compress(P, 3, group, out, in, n);
-}
-extern "C" int pbc_hip_pairing_length_in_bytes_x_only_G1(const pbc_hip_pairing_t *p) { return p->len_fq; }
-extern "C" int pbc_hip_pairing_length_in_bytes_x_only_G2(const pbc_hip_pairing_t *p) { return p->len2 / 2; }
-
-extern "C" int pbc_hip_element_from_hash_batch(pbc_hip_pairing_t *P, int group, uint8_t *out, const uint8_t *data,
-                                               int hlen, size_t n) {
-  if (!P) return fail("null pairing");
-  if (P->device < 0) return fail("no HIP device: libpbc_hip has no CPU fallback");
-  const bool symmetric = P->type == 'a' || P->type == '1' || P->type == 'e';
-  if (group != 1 && group != 2) return fail("group must be 1 or 2");
-  if (hlen < 1) return fail("hlen must be >= 1");
-  if (!n) return 0;
-  if (group == 2 && !symmetric) {
-    if (P->type == 'f' && hlen < 2) return fail("type f G2: hlen must be >= 2 (fq_from_hash halves the digest)");
-    return run_twist_points(P, 0, out, data, hlen, n);
-  }
-  DevBuf bd, bo;
-  DeviceGuard guard(P->device);
-  if (ensure_sqrt_constants(P)) return 1;
-  HIP_TRY(bd.alloc(n * (size_t) hlen));
-  HIP_TRY(bo.alloc(n * (size_t) P->len1));
-  void *dd = bd.p, *d_o = bo.p;
-  HIP_TRY(hipMemcpy(dd, data, n * (size_t) hlen, hipMemcpyHostToDevice));
-  if (ensure_derived(P, 0)) return 1;
-  unsigned grid = (unsigned) ((n + kBlock - 1) / kBlock);
-  PBC_DISPATCH_N(P->nlimb, hipLaunchKernelGGL(g_from_hash_kernel<N>, dim3(grid), dim3(kBlock), 0, 0, (uint8_t *) d_o,
-                                              (const uint8_t *) dd, hlen, n, kargs<N>(P)));
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpy(out, d_o, n * (size_t) P->len1, hipMemcpyDeviceToHost));
-  return 0;
-}
-
 // ---- preprocessed pairings ---------------------------------------------------------------
-struct pbc_hip_pp_s {
-  pbc_hip_pairing_s *P;
-  uint32_t *tab;      // device: type a [exp2 + 1][3][16] words; types d / g [steps][3][ND] words
-  uint32_t *valid;    // device flag: first argument was a finite curve point
-};
 extern "C" int pbc_hip_pairing_pp_init(pbc_hip_pp_t **out, pbc_hip_pairing_t *P, const uint8_t *g1) {
   if (!out || !P || !g1) return fail("null argument");
   if (P->device < 0) return fail("no HIP device: libpbc_hip has no CPU fallback");
@@ -1725,16 +831,8 @@ extern "C" int pbc_hip_pairing_pp_init(pbc_hip_pp_t **out, pbc_hip_pairing_t *P,
     return bail("device allocation failed");
   dg1 = bg1.p;
   if (hipMemcpy(dg1, g1, P->len1, hipMemcpyHostToDevice) != hipSuccess) return bail("H2D copy failed");
-  if (mnt) {
-    PBC_DISPATCH_D(P, hipLaunchKernelGGL((d_pp_init_kernel<N, DEG>), dim3(1), dim3(64), 0, 0, pp->tab, pp->valid,
-                                         (const uint8_t *) dg1, kargs<N>(P)));
-  } else if (a1 && P->nlimb == 16) {
-    hipLaunchKernelGGL(a1_pp_init_kernel<16>, dim3(1), dim3(64), 0, 0, pp->tab, pp->valid, (const uint8_t *) dg1, kargs<16>(P));
-  } else if (a1) {
-    hipLaunchKernelGGL(a1_pp_init_kernel<33>, dim3(1), dim3(64), 0, 0, pp->tab, pp->valid, (const uint8_t *) dg1, kargs<33>(P));
-  } else {
-    hipLaunchKernelGGL(a_pp_init_kernel<16>, dim3(1), dim3(64), 0, 0, pp->tab, pp->valid, (const uint8_t *) dg1, kargs<16>(P));
-  }
+  if (mnt) { if (pp_init_launch_d(P, pp, (const uint8_t *) dg1)) return bail("no kernel for this field"); }
+  else pp_init_launch_a(P, pp, (const uint8_t *) dg1, a1);
   hipError_t e = hipDeviceSynchronize();
   if (e != hipSuccess) return bail(hipGetErrorString(e));
   *out = pp;
@@ -1753,22 +851,8 @@ extern "C" int pbc_hip_pairing_pp_apply_batch_dev(pbc_hip_pp_t *pp, void *d_gt, 
   hipStream_t s = (hipStream_t) stream;
   pbc_hip_pairing_s *P = pp->P;
   if (ensure_derived(P, s)) return 1;
-  unsigned grid = (unsigned) ((n + kBlock - 1) / kBlock);
-  if (pp->P->type == 'a' && !pp->P->a_generic) {
-    hipLaunchKernelGGL(al_pp_apply_kernel<16>, dim3(PBC_RGRID(al_pp_apply_kernel<16>)), dim3(kBlock), 0, s, (uint8_t *) d_gt, pp->tab, pp->valid,
-                       (const uint8_t *) d_g2, n, kargs<16>(P));
-  } else if (pp->P->nlimb == 16 && (pp->P->type == 'a' || pp->P->type == '1')) {
-    hipLaunchKernelGGL(a1_pp_apply_kernel<16>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt, pp->tab, pp->valid,
-                       (const uint8_t *) d_g2, n, kargs<16>(P));
-  } else if (pp->P->type == '1' || pp->P->type == 'a') {
-    hipLaunchKernelGGL(a1_pp_apply_kernel<33>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt, pp->tab, pp->valid,
-                       (const uint8_t *) d_g2, n, kargs<33>(P));
-  } else {
-    PBC_DISPATCH_D(pp->P, hipLaunchKernelGGL((d_pp_apply_kernel<N, DEG>), dim3(kDResident<N, DEG> ? PBC_RGRID(d_pp_apply_kernel<N, DEG>) : grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
-                                             pp->tab, pp->valid, (const uint8_t *) d_g2, n, kargs<N>(P)));
-  }
-  HIP_TRY(hipGetLastError());
-  return 0;
+  if (pp->P->type == 'd' || pp->P->type == 'g') return pp_apply_launch_d(pp, d_gt, d_g2, n, s);
+  return pp_apply_launch_a(pp, d_gt, d_g2, n, s);
 }
 extern "C" int pbc_hip_pairing_pp_apply_batch(pbc_hip_pp_t *pp, uint8_t *gt, const uint8_t *g2, size_t n) {
   if (!pp) return fail("null pp");
@@ -1934,34 +1018,28 @@ extern "C" int pbc_hip_diag_stage(pbc_hip_pairing_t *P, int stage, uint8_t *out,
     return 0;
   }
   if (stage == 1 && P->type == 'f') {
-    void *d1, *d2, *dt;
-    HIP_TRY(hipMalloc(&d1, n * P->len1));
-    HIP_TRY(hipMalloc(&d2, n * P->len2));
-    HIP_TRY(hipMalloc(&dt, n * P->lenT));
-    HIP_TRY(hipMemcpy(d1, g1, n * P->len1, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(d2, g2, n * P->len2, hipMemcpyHostToDevice));
+    DevBuf b1, b2, bt;
+    HIP_TRY(b1.alloc(n * P->len1));
+    HIP_TRY(b2.alloc(n * P->len2));
+    HIP_TRY(bt.alloc(n * P->lenT));
+    HIP_TRY(hipMemcpy(b1.p, g1, n * P->len1, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(b2.p, g2, n * P->len2, hipMemcpyHostToDevice));
     if (ensure_derived(P, 0)) return 1;
-    unsigned grid = (unsigned) ((n + kBlock - 1) / kBlock);
-    PBC_DISPATCH_F(P->nlimb, hipLaunchKernelGGL((f_prod_pairing_kernel<N, false>), dim3(grid), dim3(kBlock), 0, 0, (uint8_t *) dt,
-                       (const uint8_t *) d1, (const uint8_t *) d2, n, -1, kargs<N>(P)));
-    HIP_TRY(hipMemcpy(out, dt, n * P->lenT < out_len ? n * P->lenT : out_len, hipMemcpyDeviceToHost));
-    (void) hipFree(d1); (void) hipFree(d2); (void) hipFree(dt);
+    if (diag_f_miller(P, bt.p, b1.p, b2.p, n)) return 1;
+    HIP_TRY(hipMemcpy(out, bt.p, n * P->lenT < out_len ? n * P->lenT : out_len, hipMemcpyDeviceToHost));
     return 0;
   }
   if (stage >= 10 && P->type == 'f') {   // g1 = operand A, g2 = operand B (GT-format records)
-    void *d1, *d2, *dt;
+    DevBuf b1, b2, bt;
     size_t bytes = n * P->lenT;
-    HIP_TRY(hipMalloc(&d1, bytes));
-    HIP_TRY(hipMalloc(&d2, bytes));
-    HIP_TRY(hipMalloc(&dt, bytes));
-    HIP_TRY(hipMemcpy(d1, g1, bytes, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(d2, g2, bytes, hipMemcpyHostToDevice));
+    HIP_TRY(b1.alloc(bytes));
+    HIP_TRY(b2.alloc(bytes));
+    HIP_TRY(bt.alloc(bytes));
+    HIP_TRY(hipMemcpy(b1.p, g1, bytes, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(b2.p, g2, bytes, hipMemcpyHostToDevice));
     if (ensure_derived(P, 0)) return 1;
-    unsigned grid = (unsigned) ((n + kBlock - 1) / kBlock);
-    PBC_DISPATCH_F(P->nlimb, hipLaunchKernelGGL(f_debug_kernel<N>, dim3(grid), dim3(kBlock), 0, 0, stage, (uint8_t *) dt, (const uint8_t *) d1,
-                       (const uint8_t *) d2, n, kargs<N>(P)));
-    HIP_TRY(hipMemcpy(out, dt, bytes < out_len ? bytes : out_len, hipMemcpyDeviceToHost));
-    (void) hipFree(d1); (void) hipFree(d2); (void) hipFree(dt);
+    if (diag_f_op(P, stage, bt.p, b1.p, b2.p, n)) return 1;
+    HIP_TRY(hipMemcpy(out, bt.p, bytes < out_len ? bytes : out_len, hipMemcpyDeviceToHost));
     return 0;
   }
   return fail("unknown diagnostic stage");
@@ -2100,3 +1178,4 @@ extern "C" int pbc_hip_int_mac_peak(int variant, int iters, double *rate, double
     default: return fail("unknown probe variant %d", variant);
   }
 }
+

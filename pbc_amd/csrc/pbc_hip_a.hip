@@ -1,0 +1,261 @@
+// pbc_hip_a.hip -- kernels and launches of types a, a1 and e (libpbc_hip.so; see host_common.h)
+#include "host_common.h"
+
+// One Type-A pairing per lane.  g1/g2/gt are AoS in wire format (128 B each for a.param);
+// per-lane 16-byte loads of a 128-byte record: every byte of every fetched line is used.
+// F_q elements are in limb form throughout (pairing_al.cuh).
+template <int N>
+__global__ void __launch_bounds__(kBlock, PBC_A_WAVES) al_pairing_kernel(uint8_t *gt, const uint8_t *g1,
+                                                             const uint8_t *g2, size_t n, KArgs<N> ka) {
+  PBC_RESIDENT_LOOP(n) {
+    size_t idx = vb * kBlock + threadIdx.x;
+    size_t ld = idx < n ? idx : n - 1;
+    constexpr int L = 8 * N;
+    __attribute__((aligned(16))) uint8_t out[L];
+    AL<N>::pairing_lane(out, g1 + ld * L, g2 + ld * L);
+    if (idx < n) {
+      uint4 *dst = reinterpret_cast<uint4 *>(gt + idx * L);
+      const uint4 *src = reinterpret_cast<const uint4 *>(out);
+#pragma unroll
+      for (int i = 0; i < L / 16; i++) dst[i] = src[i];
+    }
+  }
+}
+
+// Products of Type-A pairings on the limb-form routines, one TERM per lane (AL::miller_record_lane): the Miller value
+// of term t goes to workspace record t; al_prod_finish_kernel then multiplies the k values of each product and runs its
+// final exponentiation (one product per lane).
+template <int N>
+__global__ void __launch_bounds__(kBlock, PBC_A_WAVES) al_miller_kernel(uint4 *ws, const uint8_t *g1, const uint8_t *g2,
+                                                                        size_t n, KArgs<N> ka) {
+  PBC_RESIDENT_LOOP(n) {
+    size_t idx = vb * kBlock + threadIdx.x;
+    size_t ld = idx < n ? idx : n - 1;
+    constexpr int L = 8 * N;
+    uint4 rec[AL<N>::MREC];
+    AL<N>::miller_record_lane(rec, g1 + ld * L, g2 + ld * L);
+    if (idx < n) {
+#pragma unroll
+      for (int i = 0; i < AL<N>::MREC; i++) ws[idx * AL<N>::MREC + i] = rec[i];
+    }
+  }
+}
+template <int N>
+__global__ void __launch_bounds__(kBlock, PBC_A_WAVES) al_prod_finish_kernel(uint8_t *gt, const uint4 *ws, size_t n, int k,
+                                                                             KArgs<N> ka) {
+  PBC_RESIDENT_LOOP(n) {
+    size_t idx = vb * kBlock + threadIdx.x;
+    size_t ld = idx < n ? idx : n - 1;
+    constexpr int L = 8 * N;
+    __attribute__((aligned(16))) uint8_t out[L];
+    AL<N>::prod_finish_lane(out, ws + ld * (size_t) k * AL<N>::MREC, k);
+    if (idx < n) {
+      uint4 *dst = reinterpret_cast<uint4 *>(gt + idx * L);
+      const uint4 *src = reinterpret_cast<const uint4 *>(out);
+#pragma unroll
+      for (int i = 0; i < L / 16; i++) dst[i] = src[i];
+    }
+  }
+}
+
+// One k-term product of Type-A pairings per lane (terms of unit u are records u*k .. u*k+k-1).  `ws` is the object's
+// workspace for the per-term Miller state: k x 24 x 128 uint4 per workgroup (a_prod_pairing_lane).
+template <int N>
+__global__ void __launch_bounds__(kBlock, PBC_A_WAVES) a_prod_pairing_kernel(uint8_t *gt, const uint8_t *g1,
+                                                                 const uint8_t *g2, size_t n, int k, uint4 *ws, KArgs<N> ka) {
+  PBC_RESIDENT_LOOP(n) {
+    size_t idx = vb * kBlock + threadIdx.x;
+    size_t ld = idx < n ? idx : n - 1;
+    constexpr int L = 8 * N;
+    __attribute__((aligned(16))) uint8_t out[L];
+    __shared__ uint32_t lds_f[2 * N * kBlock];   // the shared accumulator of every lane, limb-major: conflict-free
+    a_prod_pairing_lane<N>(out, g1 + ld * k * L, g2 + ld * k * L, k,
+                           ws + (size_t) blockIdx.x * (size_t) k * (6 * (N / 4) * kBlock) + threadIdx.x, lds_f + threadIdx.x, kBlock);
+    if (idx < n) {
+      uint4 *dst = reinterpret_cast<uint4 *>(gt + idx * L);
+      const uint4 *src = reinterpret_cast<const uint4 *>(out);
+  #pragma unroll
+      for (int i = 0; i < L / 16; i++) dst[i] = src[i];
+    }
+  }
+}
+
+// Type A1: one k-term product (k = 1: a single pairing) per lane; 130-byte coordinates for a1.param.
+template <int N>
+__global__ void __launch_bounds__(kBlock, N >= 32 ? PBC_A1_WAVES : PBC_A_WAVES) a1_prod_pairing_kernel(uint8_t *gt, const uint8_t *g1,
+                                                                               const uint8_t *g2, size_t n, int k, KArgs<N> ka) {
+  size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
+  size_t ld = idx < n ? idx : n - 1;
+  const int L = 2 * fq_bytes<N>();
+  __attribute__((aligned(4))) uint8_t out[8 * N];
+  __shared__ uint32_t lds_q[kMemOperands<N> ? 1 : 2 * N * kBlock];   // wide fields keep Q in private memory
+  a1_prod_pairing_lane<N>(out, g1 + ld * k * L, g2 + ld * k * L, k, lds_q + threadIdx.x, kBlock);
+  if (idx < n) {
+    if ((L & 3) == 0) {
+      uint32_t *dst = reinterpret_cast<uint32_t *>(gt + idx * L);
+      const uint32_t *src = reinterpret_cast<const uint32_t *>(out);
+      for (int i = 0; i < L / 4; i++) dst[i] = src[i];
+    } else {
+      for (int i = 0; i < L; i++) gt[idx * L + i] = out[i];
+    }
+  }
+}
+
+// Type E: one k-term product (k = 1: a single pairing) per lane; G1/G2 256 B, GT 128 B for e.param.
+template <int N>
+__global__ void __launch_bounds__(kBlock, N >= 32 ? PBC_A1_WAVES : PBC_A_WAVES) e_prod_pairing_kernel(uint8_t *gt, const uint8_t *g1,
+                                                                              const uint8_t *g2, size_t n, int k, KArgs<N> ka) {
+  size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
+  size_t ld = idx < n ? idx : n - 1;
+  const int LT = fq_bytes<N>(), L = 2 * LT;
+  __attribute__((aligned(4))) uint8_t out[4 * N];
+  uint32_t *lds_q = nullptr;           // unused: Q + R lives in the lane's private memory
+  e_prod_pairing_lane<N>(out, g1 + ld * k * L, g2 + ld * k * L, k, lds_q, kBlock);
+  if (idx < n) {
+    if ((LT & 3) == 0) {
+      uint32_t *dst = reinterpret_cast<uint32_t *>(gt + idx * LT);
+      const uint32_t *src = reinterpret_cast<const uint32_t *>(out);
+      for (int i = 0; i < LT / 4; i++) dst[i] = src[i];
+    } else {
+      for (int i = 0; i < LT; i++) gt[idx * LT + i] = out[i];
+    }
+  }
+}
+
+// pairing_pp_init: ONE lane derives the line-coefficient table of a fixed first argument.
+template <int N>
+__global__ void a_pp_init_kernel(uint32_t *tab, uint32_t *valid, const uint8_t *g1, KArgs<N> ka) {
+  if (threadIdx.x || blockIdx.x) return;
+  *valid = a_pp_init_lane<N>(tab, g1) ? 1u : 0u;
+}
+// pairing_pp_apply over a batch of second arguments, one per lane; the table is uniform data.
+template <int N>
+__global__ void __launch_bounds__(kBlock, PBC_A_WAVES) al_pp_apply_kernel(uint8_t *gt, const uint32_t *__restrict__ tab,
+                                                                           const uint32_t *__restrict__ valid,
+                                                                           const uint8_t *g2, size_t n, KArgs<N> ka) {
+  PBC_RESIDENT_LOOP(n) {
+    size_t idx = vb * kBlock + threadIdx.x;
+    size_t ld = idx < n ? idx : n - 1;
+    constexpr int L = 8 * N;
+    __attribute__((aligned(16))) uint8_t out[L];
+    AL<N>::pp_apply_lane(out, tab, *valid != 0, g2 + ld * L);
+    if (idx < n) {
+      uint4 *dst = reinterpret_cast<uint4 *>(gt + idx * L);
+      const uint4 *src = reinterpret_cast<const uint4 *>(out);
+  #pragma unroll
+      for (int i = 0; i < L / 16; i++) dst[i] = src[i];
+    }
+  }
+}
+
+// pairing_pp for type a1
+template <int N>
+__global__ void a1_pp_init_kernel(uint32_t *tab, uint32_t *valid, const uint8_t *g1, KArgs<N> ka) {
+  if (threadIdx.x || blockIdx.x) return;
+  *valid = a1_pp_init_lane<N>(tab, g1) ? 1u : 0u;
+}
+template <int N>
+__global__ void __launch_bounds__(kBlock, N >= 32 ? PBC_A1_WAVES : PBC_A_WAVES) a1_pp_apply_kernel(uint8_t *gt, const uint32_t *__restrict__ tab,
+                                                                           const uint32_t *__restrict__ valid,
+                                                                           const uint8_t *g2, size_t n, KArgs<N> ka) {
+  size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
+  size_t ld = idx < n ? idx : n - 1;
+  const int L = 2 * fq_bytes<N>();
+  __attribute__((aligned(4))) uint8_t out[8 * N];
+  a1_pp_apply_lane<N>(out, tab, *valid != 0, g2 + ld * L);
+  if (idx < n) {
+    if ((L & 3) == 0) {
+      uint32_t *dst = reinterpret_cast<uint32_t *>(gt + idx * L);
+      const uint32_t *src = reinterpret_cast<const uint32_t *>(out);
+      for (int i = 0; i < L / 4; i++) dst[i] = src[i];
+    } else {
+      for (int i = 0; i < L; i++) gt[idx * L + i] = out[i];
+    }
+  }
+}
+
+template <int N> __global__ void e_init_kernel(EConst *out, ERaw raw, KArgs<N> ka) {
+  if (threadIdx.x || blockIdx.x) return;
+  e_init_lane<N>(out, raw, c_e);
+}
+
+int derive_e(pbc_hip_pairing_s *P, hipStream_t s) {
+  DevBuf buf;
+  HIP_TRY(buf.alloc(sizeof(EConst)));
+  EConst *dbuf = buf.as<EConst>();
+  if (P->nlimb == 16) hipLaunchKernelGGL(e_init_kernel<16>, dim3(1), dim3(64), 0, s, dbuf, P->eraw, kargs<16>(P));
+  else hipLaunchKernelGGL(e_init_kernel<33>, dim3(1), dim3(64), 0, s, dbuf, P->eraw, kargs<33>(P));
+  HIP_TRY(hipMemcpyAsync(&P->econst, dbuf, sizeof(EConst), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int launch_a(pbc_hip_pairing_s *P, void *d_gt, const void *d_g1, const void *d_g2, size_t n, int k, hipStream_t s, ProdWs &W) {
+  unsigned grid = (unsigned) ((n + kBlock - 1) / kBlock);
+  if (P->type == 'a' && !P->a_generic && k == 1) {
+    hipLaunchKernelGGL(al_pairing_kernel<16>, dim3(PBC_RGRID(al_pairing_kernel<16>)), dim3(kBlock), 0, s, (uint8_t *) d_gt,
+                       (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, kargs<16>(P));
+  } else if (P->type == 'a' && !P->a_generic && !P->a_prod_shared) {
+    // one term per lane, then one product per lane; at most a_prod_chunk terms in flight (their records: 160 B each)
+    const size_t per = std::max<size_t>(1, P->a_prod_chunk / (size_t) k);
+    const size_t first = std::min(n, per);
+    void *ws = W.get(first * (size_t) k * AL<16>::MREC * sizeof(uint4));
+    if (!ws) return 1;
+    for (size_t u0 = 0; u0 < n; u0 += per) {
+      const size_t nu = std::min(per, n - u0), nt = nu * (size_t) k;
+      hipLaunchKernelGGL(al_miller_kernel<16>, dim3(resident_grid(P, reinterpret_cast<const void *>(&al_miller_kernel<16>), nt)), dim3(kBlock), 0, s,
+                         (uint4 *) ws, (const uint8_t *) d_g1 + u0 * (size_t) k * P->len1, (const uint8_t *) d_g2 + u0 * (size_t) k * P->len2, nt, kargs<16>(P));
+      hipLaunchKernelGGL(al_prod_finish_kernel<16>, dim3(resident_grid(P, reinterpret_cast<const void *>(&al_prod_finish_kernel<16>), nu)), dim3(kBlock), 0, s,
+                         (uint8_t *) d_gt + u0 * P->lenT, (const uint4 *) ws, nu, k, kargs<16>(P));
+    }
+  } else if (P->type == 'a' && !P->a_generic) {
+    grid = PBC_RGRID(a_prod_pairing_kernel<16>);                      // one workspace record per RESIDENT workgroup
+    void *ws = W.get((size_t) grid * (size_t) k * (6 * 4 * kBlock) * sizeof(uint4));
+    if (!ws) return 1;
+    hipLaunchKernelGGL(a_prod_pairing_kernel<16>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
+                       (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k, (uint4 *) ws, kargs<16>(P));
+  } else if ((P->type == 'a' || P->type == '1') && P->nlimb == 16) {   // other sizes: the bit-by-bit kernels
+    hipLaunchKernelGGL(a1_prod_pairing_kernel<16>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
+                       (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k, kargs<16>(P));
+  } else if (P->type == '1' || P->type == 'a') {
+    hipLaunchKernelGGL(a1_prod_pairing_kernel<33>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
+                       (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k, kargs<33>(P));
+  } else if (P->type == 'e' && P->nlimb == 16) {
+    hipLaunchKernelGGL(e_prod_pairing_kernel<16>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
+                       (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k, kargs<16>(P));
+  } else if (P->type == 'e') {
+    hipLaunchKernelGGL(e_prod_pairing_kernel<33>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
+                       (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k, kargs<33>(P));
+  } else {
+    return fail("unsupported type");
+  }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+void pp_init_launch_a(pbc_hip_pairing_s *P, pbc_hip_pp_s *pp, const uint8_t *dg1, bool a1) {
+  if (a1 && P->nlimb == 16) {
+    hipLaunchKernelGGL(a1_pp_init_kernel<16>, dim3(1), dim3(64), 0, 0, pp->tab, pp->valid, dg1, kargs<16>(P));
+  } else if (a1) {
+    hipLaunchKernelGGL(a1_pp_init_kernel<33>, dim3(1), dim3(64), 0, 0, pp->tab, pp->valid, dg1, kargs<33>(P));
+  } else {
+    hipLaunchKernelGGL(a_pp_init_kernel<16>, dim3(1), dim3(64), 0, 0, pp->tab, pp->valid, dg1, kargs<16>(P));
+  }
+}
+int pp_apply_launch_a(pbc_hip_pp_s *pp, void *d_gt, const void *d_g2, size_t n, hipStream_t s) {
+  pbc_hip_pairing_s *P = pp->P;
+  unsigned grid = (unsigned) ((n + kBlock - 1) / kBlock);
+  if (P->type == 'a' && !P->a_generic) {
+    hipLaunchKernelGGL(al_pp_apply_kernel<16>, dim3(PBC_RGRID(al_pp_apply_kernel<16>)), dim3(kBlock), 0, s, (uint8_t *) d_gt, pp->tab, pp->valid,
+                       (const uint8_t *) d_g2, n, kargs<16>(P));
+  } else if (P->nlimb == 16) {
+    hipLaunchKernelGGL(a1_pp_apply_kernel<16>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt, pp->tab, pp->valid,
+                       (const uint8_t *) d_g2, n, kargs<16>(P));
+  } else {
+    hipLaunchKernelGGL(a1_pp_apply_kernel<33>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt, pp->tab, pp->valid,
+                       (const uint8_t *) d_g2, n, kargs<33>(P));
+  }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}

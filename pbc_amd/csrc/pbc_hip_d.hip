@@ -1,0 +1,122 @@
+// pbc_hip_d.hip -- kernels and launches of types d and g (libpbc_hip.so; see host_common.h)
+#include "host_common.h"
+
+// Types D and G: one k-term product (k = 1: a single pairing) per lane.  With fb = fixed byte length
+// of F_q and d = k/2, G1 records are 2 fb, G2 and GT 2 d fb bytes (40 / 120 / 120 B for d159.param,
+// 38 / 190 / 190 B for g149.param).
+template <int N, int DEG>
+static __device__ __forceinline__ void d_prod_unit(size_t vb, uint8_t *gt, const uint8_t *g1, const uint8_t *g2, size_t n, int k, uint32_t *ws) {
+  size_t idx = vb * kBlock + threadIdx.x;
+  size_t ld = idx < n ? idx : n - 1;
+  const int fb = (int) fpk<N>().fbytes, L1 = 2 * fb, L2 = 2 * DEG * fb, LT = 2 * DEG * fb;
+  __attribute__((aligned(4))) uint8_t out[8 * DEG * N];
+  TypeMNT<N, DEG>::d_prod_pairing_lane(out, g1 + ld * k * L1, g2 + ld * k * L2, k,
+                                       ws + (size_t) blockIdx.x * (size_t) k * (TypeMNT<N, DEG>::DL_WORDS * kBlock) + threadIdx.x);
+  if (idx < n) {
+    if ((LT & 3) == 0) {
+      uint32_t *dst = reinterpret_cast<uint32_t *>(gt + idx * LT);
+      const uint32_t *src = reinterpret_cast<const uint32_t *>(out);
+      for (int i = 0; i < LT / 4; i++) dst[i] = src[i];
+    } else {
+      for (int i = 0; i < LT; i++) gt[idx * LT + i] = out[i];
+    }
+  }
+}
+// (resident workgroups where they pay: kDResident, pairing_d.cuh)
+template <int N, int DEG>
+__global__ void __launch_bounds__(kBlock, PBC_DF_WAVES) d_prod_pairing_kernel(uint8_t *gt, const uint8_t *g1,
+                                                                 const uint8_t *g2, size_t n, int k, uint32_t *ws, KArgs<N> ka) {
+  if constexpr (kDResident<N, DEG>) {
+    PBC_RESIDENT_LOOP(n) d_prod_unit<N, DEG>(vb, gt, g1, g2, n, k, ws);
+  } else {
+    d_prod_unit<N, DEG>(blockIdx.x, gt, g1, g2, n, k, ws);
+  }
+}
+
+// pairing_pp for types d / g: single-lane table derivation, then one second argument per lane
+template <int N, int DEG>
+__global__ void d_pp_init_kernel(uint32_t *tab, uint32_t *valid, const uint8_t *g1, KArgs<N> ka) {
+  if (threadIdx.x || blockIdx.x) return;
+  *valid = TypeMNT<N, DEG>::d_pp_init_lane(tab, g1) ? 1u : 0u;
+}
+template <int N, int DEG>
+static __device__ __forceinline__ void d_pp_unit(size_t vb, uint8_t *gt, const uint32_t *__restrict__ tab, const uint32_t *__restrict__ valid,
+                                                 const uint8_t *g2, size_t n) {
+  size_t idx = vb * kBlock + threadIdx.x;
+  size_t ld = idx < n ? idx : n - 1;
+  const int fb = (int) fpk<N>().fbytes, L2 = 2 * DEG * fb, LT = 2 * DEG * fb;
+  __attribute__((aligned(4))) uint8_t out[8 * DEG * N];
+  TypeMNT<N, DEG>::d_pp_apply_lane(out, tab, *valid != 0, g2 + ld * L2);
+  if (idx < n) {
+    if ((LT & 3) == 0) {
+      uint32_t *dst = reinterpret_cast<uint32_t *>(gt + idx * LT);
+      const uint32_t *src = reinterpret_cast<const uint32_t *>(out);
+      for (int i = 0; i < LT / 4; i++) dst[i] = src[i];
+    } else {
+      for (int i = 0; i < LT; i++) gt[idx * LT + i] = out[i];
+    }
+  }
+}
+template <int N, int DEG>
+__global__ void __launch_bounds__(kBlock, PBC_DF_WAVES) d_pp_apply_kernel(uint8_t *gt, const uint32_t *__restrict__ tab,
+                                                                          const uint32_t *__restrict__ valid,
+                                                                          const uint8_t *g2, size_t n, KArgs<N> ka) {
+  if constexpr (kDResident<N, DEG>) {
+    PBC_RESIDENT_LOOP(n) d_pp_unit<N, DEG>(vb, gt, tab, valid, g2, n);
+  } else {
+    d_pp_unit<N, DEG>(blockIdx.x, gt, tab, valid, g2, n);
+  }
+}
+
+template <int N, int DEG> __global__ void d_init_stage1(DConst *out, DRaw raw, KArgs<N> ka) {
+  if (threadIdx.x || blockIdx.x) return;
+  TypeMNT<N, DEG>::init_stage1(out, raw, c_d);
+}
+template <int N, int DEG> __global__ void d_init_stage2(DConst *out, DRaw raw, KArgs<N> ka) {
+  if (threadIdx.x || blockIdx.x) return;
+  TypeMNT<N, DEG>::init_stage2(out, raw);
+}
+
+int derive_d(pbc_hip_pairing_s *P, hipStream_t s) {
+  DevBuf buf;
+  HIP_TRY(buf.alloc(sizeof(DConst)));
+  DConst *dbuf = buf.as<DConst>();
+  PBC_DISPATCH_D(P, hipLaunchKernelGGL((d_init_stage1<N, DEG>), dim3(1), dim3(64), 0, s, dbuf, P->draw, kargs<N>(P)));
+  HIP_TRY(hipMemcpyAsync(&P->dconst, dbuf, sizeof(DConst), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  PBC_DISPATCH_D(P, hipLaunchKernelGGL((d_init_stage2<N, DEG>), dim3(1), dim3(64), 0, s, dbuf, P->draw, kargs<N>(P)));
+  HIP_TRY(hipMemcpyAsync(&P->dconst, dbuf, sizeof(DConst), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int launch_d(pbc_hip_pairing_s *P, void *d_gt, const void *d_g1, const void *d_g2, size_t n, int k, hipStream_t s, ProdWs &W) {
+  unsigned grid = (unsigned) ((n + kBlock - 1) / kBlock);
+  if (k == 1) {
+    PBC_DISPATCH_D(P, hipLaunchKernelGGL((d_prod_pairing_kernel<N, DEG>), dim3(kDResident<N, DEG> ? PBC_RGRID(d_prod_pairing_kernel<N, DEG>) : grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
+                                                (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, 1, (uint32_t *) nullptr, kargs<N>(P)));
+  } else {
+    size_t rec = 0;                    // words of Miller state per term and lane (the kernel's own constant)
+    PBC_DISPATCH_D(P, { rec = (size_t) TypeMNT<N, DEG>::DL_WORDS; if (kDResident<N, DEG>) grid = PBC_RGRID(d_prod_pairing_kernel<N, DEG>); });      // one workspace record per RESIDENT workgroup
+    void *ws = W.get((size_t) grid * (size_t) k * rec * kBlock * sizeof(uint32_t));
+    if (!ws) return 1;
+    PBC_DISPATCH_D(P, hipLaunchKernelGGL((d_prod_pairing_kernel<N, DEG>), dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
+                                                (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k, (uint32_t *) ws, kargs<N>(P)));
+  }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int pp_init_launch_d(pbc_hip_pairing_s *P, pbc_hip_pp_s *pp, const uint8_t *dg1) {
+  PBC_DISPATCH_D(P, hipLaunchKernelGGL((d_pp_init_kernel<N, DEG>), dim3(1), dim3(64), 0, 0, pp->tab, pp->valid, dg1, kargs<N>(P)));
+  return 0;
+}
+int pp_apply_launch_d(pbc_hip_pp_s *pp, void *d_gt, const void *d_g2, size_t n, hipStream_t s) {
+  pbc_hip_pairing_s *P = pp->P;
+  unsigned grid = (unsigned) ((n + kBlock - 1) / kBlock);
+  PBC_DISPATCH_D(P, hipLaunchKernelGGL((d_pp_apply_kernel<N, DEG>), dim3(kDResident<N, DEG> ? PBC_RGRID(d_pp_apply_kernel<N, DEG>) : grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
+                                           pp->tab, pp->valid, (const uint8_t *) d_g2, n, kargs<N>(P)));
+  HIP_TRY(hipGetLastError());
+  return 0;
+}

@@ -1,0 +1,104 @@
+// pbc_hip_f.hip -- kernels and launches of type f (libpbc_hip.so; see host_common.h)
+#include "host_common.h"
+
+// Type F: one k-term product (k = 1: a single pairing) per lane.  With fb = fixed byte length of F_q:
+// G1 2 fb, G2 4 fb, GT 12 fb bytes (40 / 80 / 240 B for f.param).
+// (the 5-word field keeps its Miller accumulator in one 36 KB LDS area per workgroup: four workgroups per CU, two waves per
+// SIMD; with PBC_F_AREAS=2 in two areas, one wave per SIMD and the register budget that goes with it)
+template <int N, bool BM1>
+__global__ void __launch_bounds__(kBlock, N <= 5 ? (PBC_F_AREAS == 1 ? 2 : 1) : PBC_F_WAVES) f_prod_pairing_kernel(uint8_t *gt, const uint8_t *g1,
+                                                                 const uint8_t *g2, size_t n, int k, KArgs<N> ka) {
+#ifdef PBC_F_WHATIF_TRACE                        // what-if builds only (tools/whatif_time.py --trace): per-wave start / end / HW_ID behind the results
+  const uint64_t trace_t0 = wall_clock64();
+#endif
+  PBC_RESIDENT_LOOP(n) {
+    size_t idx = vb * kBlock + threadIdx.x;
+    size_t ld = idx < n ? idx : n - 1;
+    const int fb = (int) fpk<N>().fbytes, L1 = 2 * fb, L2 = 4 * fb, LT = 12 * fb;
+    __attribute__((aligned(4))) uint8_t out[48 * N];
+    TypeF<N, BM1>::f_prod_pairing_lane(out, g1 + ld * (k < 0 ? 1 : k) * L1, g2 + ld * (k < 0 ? 1 : k) * L2, k < 0 ? 1 : k, k < 0);
+    if (idx < n) {
+      uint32_t *dst = reinterpret_cast<uint32_t *>(gt + idx * LT);      // LT = 12 fb is a multiple of 4
+      const uint32_t *src = reinterpret_cast<const uint32_t *>(out);
+      for (int i = 0; i < LT / 4; i++) dst[i] = src[i];
+    }
+  }
+#ifdef PBC_F_WHATIF_TRACE
+  if ((threadIdx.x & 63) == 0) {
+    uint32_t hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    uint64_t *t = reinterpret_cast<uint64_t *>(gt + ((n * (size_t) (12 * fpk<N>().fbytes) + 255) & ~(size_t) 255)) + (size_t) (blockIdx.x * 2 + (threadIdx.x >> 6)) * 4;
+    t[0] = trace_t0; t[1] = wall_clock64(); t[2] = hw; t[3] = xcc;
+  }
+#endif
+}
+
+template <int N>
+__global__ void __launch_bounds__(kBlock) f_debug_kernel(int op, uint8_t *out, const uint8_t *a, const uint8_t *b, size_t n, KArgs<N> ka) {
+  size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
+  if (idx >= n) return;
+  const int LT = 12 * (int) fpk<N>().fbytes;
+  __attribute__((aligned(4))) uint8_t o[48 * N];
+  TypeF<N>::f_debug_lane(op, o, a + idx * LT, b + idx * LT);
+  for (int i = 0; i < LT; i++) out[idx * LT + i] = o[i];
+}
+
+template <int N> __global__ void f_init_stage1(FConst *out, FRaw raw, KArgs<N> ka) {
+  if (threadIdx.x || blockIdx.x) return;
+  TypeF<N>::init_stage1(out, raw, c_f);
+}
+template <int N> __global__ void f_init_stage2(FConst *out, FRaw raw, KArgs<N> ka) {
+  if (threadIdx.x || blockIdx.x) return;
+  TypeF<N>::init_stage2(out, raw);
+}
+template <int N> __global__ void f_init_stage3(FConst *out, FRaw raw, KArgs<N> ka) {
+  if (threadIdx.x || blockIdx.x) return;
+  TypeF<N>::init_stage3(out, raw);
+}
+
+int derive_f(pbc_hip_pairing_s *P, hipStream_t s) {
+  DevBuf buf;
+  HIP_TRY(buf.alloc(sizeof(FConst)));
+  FConst *dbuf = buf.as<FConst>();
+  PBC_DISPATCH_F(P->nlimb, hipLaunchKernelGGL(f_init_stage1<N>, dim3(1), dim3(64), 0, s, dbuf, P->fraw, kargs<N>(P)));
+  HIP_TRY(hipMemcpyAsync(&P->fconst, dbuf, sizeof(FConst), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  PBC_DISPATCH_F(P->nlimb, hipLaunchKernelGGL(f_init_stage2<N>, dim3(1), dim3(64), 0, s, dbuf, P->fraw, kargs<N>(P)));
+  HIP_TRY(hipMemcpyAsync(&P->fconst, dbuf, sizeof(FConst), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  if (P->fraw.e4bits > 0) {          // q = 3 mod 4: the i-basis copy for the pairing kernels
+    PBC_DISPATCH_F(P->nlimb, hipLaunchKernelGGL(f_init_stage3<N>, dim3(1), dim3(64), 0, s, dbuf, P->fraw, kargs<N>(P)));
+    HIP_TRY(hipMemcpyAsync(&P->fconst_i, dbuf, sizeof(FConst), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    P->f_bm1 = P->fconst_i.bm1 != 0;
+  }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int launch_f(pbc_hip_pairing_s *P, void *d_gt, const void *d_g1, const void *d_g2, size_t n, int k, hipStream_t s) {
+  if (P->f_bm1) {                    // i-basis constants and the instantiation that goes with them
+    PBC_DISPATCH_F(P->nlimb, hipLaunchKernelGGL((f_prod_pairing_kernel<N, true>), dim3(PBC_RGRID(f_prod_pairing_kernel<N, true>)), dim3(kBlock), 0, s, (uint8_t *) d_gt,
+                       (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k, kargs<N>(P, true)));
+  } else {
+    PBC_DISPATCH_F(P->nlimb, hipLaunchKernelGGL((f_prod_pairing_kernel<N, false>), dim3(PBC_RGRID(f_prod_pairing_kernel<N, false>)), dim3(kBlock), 0, s, (uint8_t *) d_gt,
+                       (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k, kargs<N>(P)));
+  }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// diagnostics: Miller values before the final exponentiation; single F_q^12 operations
+int diag_f_miller(pbc_hip_pairing_s *P, void *dt, const void *d1, const void *d2, size_t n) {
+  unsigned grid = (unsigned) ((n + kBlock - 1) / kBlock);
+  PBC_DISPATCH_F(P->nlimb, hipLaunchKernelGGL((f_prod_pairing_kernel<N, false>), dim3(grid), dim3(kBlock), 0, 0, (uint8_t *) dt,
+                     (const uint8_t *) d1, (const uint8_t *) d2, n, -1, kargs<N>(P)));
+  return 0;
+}
+int diag_f_op(pbc_hip_pairing_s *P, int stage, void *dt, const void *d1, const void *d2, size_t n) {
+  unsigned grid = (unsigned) ((n + kBlock - 1) / kBlock);
+  PBC_DISPATCH_F(P->nlimb, hipLaunchKernelGGL(f_debug_kernel<N>, dim3(grid), dim3(kBlock), 0, 0, stage, (uint8_t *) dt, (const uint8_t *) d1,
+                     (const uint8_t *) d2, n, kargs<N>(P)));
+  return 0;
+}

@@ -66,7 +66,7 @@ def model(funcs, kernel_pat, fn_pat, names, trips):
 
 
 def main():
-    path = sys.argv[1] if len(sys.argv) > 1 else "/tmp/pbc_hip_build/pbc_hip-hip-amdgcn-amd-amdhsa-gfx950.s"
+    path = sys.argv[1] if len(sys.argv) > 1 else "/tmp/pbc_hip_build/obj_libpbc_hip/pbc_hip_d-hip-amdgcn-amd-amdhsa-gfx950.s"
     param = sys.argv[2] if len(sys.argv) > 2 else os.path.join(HERE, "..", "pbc_amd", "param", "d159.param")
     kv = dict(re.findall(r"(\w+)\s+(\S+)", open(param).read()))
     q, r = int(kv["q"]), int(kv["r"])

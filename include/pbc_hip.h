@@ -179,11 +179,52 @@ int pbc_hip_element_mul_zn_batch(pbc_hip_pairing_t *p, int group, uint8_t *out, 
 int pbc_hip_element_mul_GT_batch(pbc_hip_pairing_t *p, uint8_t *out, const uint8_t *a, const uint8_t *b, size_t n);
 int pbc_hip_element_pow_zn_GT_batch(pbc_hip_pairing_t *p, uint8_t *out, const uint8_t *a, const uint8_t *zr,
                                     size_t n);
+/* How the scalar multiplications run (the reference: generic_pow_mpz, a sliding window over the affine group law with one
+ * mpz_invert per group operation, arith/field.c:14-126).  Here a regular signed fixed-window ladder (w = 4: per-lane table
+ * of the odd multiples P .. 15P, four doublings and one mixed addition per window, two inversions in all), for the
+ * 512-bit type a field on the limb-form arithmetic of the pairing kernel; powers in GT of type a by the Lucas ladder for
+ * elements of norm 1 (every pairing value).  These ladders use the plain Jacobian formulas; a lane whose result is O,
+ * whose point has small order or whose scalar is exceptional is detected (Z = 0) and handed to a second, complete pass
+ * (two group operations per bit, any point of the curve, any scalar) that runs for those lanes only.  "hip_group_slow 1"
+ * in the parameter text selects the complete pass for every lane.
+ *
+ * Host-buffer forms: as the pairing entry points -- range split over the object's device set, page-locked buffers worked
+ * on in place where a lane reads its records once with word loads (GT products, final powers, the type a ladders with
+ * scalars of a whole number of words), anything else staged through chunk buffers the object keeps (no allocation in the
+ * steady state).  out may be the same buffer as an input.
+ * _dev forms: device-resident buffers, enqueued on `stream` (NULL = default stream), asynchronous; a hash -> mul_zn ->
+ * prod_pairing pipeline (example/bls.c:41-117 as a batch) stays on the device throughout.  out == in (exactly) is allowed
+ * for element_mul_zn and the GT operations. */
+int pbc_hip_element_mul_zn_batch_dev(pbc_hip_pairing_t *p, int group, void *d_out, const void *d_in, const void *d_zr,
+                                     size_t n, void *stream);
+int pbc_hip_element_mul_GT_batch_dev(pbc_hip_pairing_t *p, void *d_out, const void *d_a, const void *d_b, size_t n, void *stream);
+int pbc_hip_element_pow_zn_GT_batch_dev(pbc_hip_pairing_t *p, void *d_out, const void *d_a, const void *d_zr, size_t n,
+                                        void *stream);
+int pbc_hip_finalpow_batch_dev(pbc_hip_pairing_t *p, void *d_out, const void *d_in, size_t n, void *stream);
+int pbc_hip_element_from_hash_batch_dev(pbc_hip_pairing_t *p, int group, void *d_out, const void *d_data, int hlen, size_t n,
+                                        void *stream);
+int pbc_hip_element_to_bytes_compressed_batch_dev(pbc_hip_pairing_t *p, int group, void *d_out, const void *d_in, size_t n, void *stream);
+int pbc_hip_element_from_bytes_compressed_batch_dev(pbc_hip_pairing_t *p, int group, void *d_out, const void *d_in, size_t n, void *stream);
+int pbc_hip_element_to_bytes_x_only_batch_dev(pbc_hip_pairing_t *p, int group, void *d_out, const void *d_in, size_t n, void *stream);
+int pbc_hip_element_from_bytes_x_only_batch_dev(pbc_hip_pairing_t *p, int group, void *d_out, const void *d_in, size_t n, void *stream);
+
+/* Fixed-base powers: replace element_pp_init / element_pp_pow_zn / element_pp_clear (include/pbc_field.h:591-625 ->
+ * element_build_base_table / element_pow_base_table, arith/field.c:243-323: a table of in^(w 2^(5 i)), a power = a product
+ * of table entries) for a base in G1, G2 (group 1, 2) or GT (group 3) -- the BLS shape: one generator, many secret keys or
+ * signatures' scalars (example/bls.c:41-62).  pp_init builds [w 2^(8 i)] B, w = 1 .. 255, i < length_in_bytes_Zr, on the
+ * device (one entry per lane); a power is then one mixed addition per scalar BYTE and one inversion (GT: one product per
+ * byte), no doublings.  Results are those of element_pow_zn / element_mul_zn on the same base.  A base of small order
+ * (some table entry is O) or off the curve (= O) is served by the complete ladder. */
+typedef struct pbc_hip_element_pp_s pbc_hip_element_pp_t;
+int pbc_hip_element_pp_init(pbc_hip_element_pp_t **pp, pbc_hip_pairing_t *p, int group, const uint8_t *in);
+void pbc_hip_element_pp_clear(pbc_hip_element_pp_t *pp);
+int pbc_hip_element_pp_pow_zn_batch(pbc_hip_element_pp_t *pp, uint8_t *out, const uint8_t *zr, size_t n);
+int pbc_hip_element_pp_pow_zn_batch_dev(pbc_hip_element_pp_t *pp, void *d_out, const void *d_zr, size_t n, void *stream);
 /* pairing->finalpow (include/pbc_pairing.h:41; a_finalpow ecc/a_param.c:1420-1429, cc_finalpow ecc/d_param.c:566-568,
  * f_finalpow ecc/f_param.c:285-287, g_finalpow ecc/g_param.c:1162-1164, e_finalpow ecc/e_param.c:828-830; its callers
  * are gt_random / gt_from_hash, ecc/pairing.c:121,127): out[i] = in[i]^((q^k - 1)/r), the final exponentiation alone,
  * for n records of GT's underlying field in GT's wire format.  in[i] = 0 is outside the reference's contract too. */
-int pbc_hip_finalpow_batch(pbc_hip_pairing_t *p, uint8_t *out, const uint8_t *in, size_t n);
+int pbc_hip_finalpow_batch(pbc_hip_pairing_t *p, uint8_t *out, const uint8_t *in, size_t n);   /* (_dev form: above) */
 
 /* Text formats on element_to_bytes records -- host-side string handling, no device involved, usable
  * without libpbc.  group: 0 = Zr, 1 = G1, 2 = G2, 3 = GT.

@@ -90,6 +90,18 @@ def lib():
         L.pbc_hip_host_free.restype = None
         L.pbc_hip_pairing_release_workspaces.argtypes = [vp]
         L.pbc_hip_element_snprint.argtypes = [vp, ci, ctypes.c_char_p, sz, vp]
+        L.pbc_hip_element_mul_zn_batch_dev.argtypes = [vp, ci, vp, vp, vp, sz, vp]
+        L.pbc_hip_element_mul_GT_batch_dev.argtypes = [vp, vp, vp, vp, sz, vp]
+        L.pbc_hip_element_pow_zn_GT_batch_dev.argtypes = [vp, vp, vp, vp, sz, vp]
+        L.pbc_hip_finalpow_batch_dev.argtypes = [vp, vp, vp, sz, vp]
+        L.pbc_hip_element_from_hash_batch_dev.argtypes = [vp, ci, vp, vp, ci, sz, vp]
+        for f in ("to_bytes_compressed", "from_bytes_compressed", "to_bytes_x_only", "from_bytes_x_only"):
+            getattr(L, "pbc_hip_element_%s_batch_dev" % f).argtypes = [vp, ci, vp, vp, sz, vp]
+        L.pbc_hip_element_pp_init.argtypes = [ctypes.POINTER(vp), vp, ci, vp]
+        L.pbc_hip_element_pp_clear.argtypes = [vp]
+        L.pbc_hip_element_pp_clear.restype = None
+        L.pbc_hip_element_pp_pow_zn_batch.argtypes = [vp, vp, vp, sz]
+        L.pbc_hip_element_pp_pow_zn_batch_dev.argtypes = [vp, vp, vp, sz, vp]
         L.pbc_hip_element_set_str.argtypes = [vp, ci, vp, cp, ci]
         L.pbc_hip_param_snprint.argtypes = [vp, ctypes.c_char_p, sz]
         _lib = L
@@ -114,6 +126,11 @@ EXPORTS = (
     "pbc_hip_pairing_length_in_bytes_compressed_G2", "pbc_hip_pairing_length_in_bytes_x_only_G2",
     "pbc_hip_element_from_bytes_x_only_batch", "pbc_hip_host_alloc", "pbc_hip_host_free", "pbc_hip_finalpow_batch",
     "pbc_hip_pairing_release_workspaces", "pbc_hip_element_snprint", "pbc_hip_element_set_str", "pbc_hip_param_snprint",
+    "pbc_hip_element_mul_zn_batch_dev", "pbc_hip_element_mul_GT_batch_dev", "pbc_hip_element_pow_zn_GT_batch_dev",
+    "pbc_hip_finalpow_batch_dev", "pbc_hip_element_from_hash_batch_dev", "pbc_hip_element_to_bytes_compressed_batch_dev",
+    "pbc_hip_element_from_bytes_compressed_batch_dev", "pbc_hip_element_to_bytes_x_only_batch_dev",
+    "pbc_hip_element_from_bytes_x_only_batch_dev", "pbc_hip_element_pp_init", "pbc_hip_element_pp_clear",
+    "pbc_hip_element_pp_pow_zn_batch", "pbc_hip_element_pp_pow_zn_batch_dev",
 )
 
 
@@ -341,6 +358,36 @@ class Pairing:
             raise PbcHipError("element_pow_zn_GT: " + _err())
         return out
 
+    # ---- the same on device-resident buffers (raw pointers, a HIP stream; asynchronous) ------------------
+    def element_mul_zn_dev(self, group, d_out, d_in, d_zr, n, stream=0):
+        if lib().pbc_hip_element_mul_zn_batch_dev(self._h, group, d_out, d_in, d_zr, n, stream):
+            raise PbcHipError("element_mul_zn_dev: " + _err())
+
+    def element_mul_GT_dev(self, d_out, d_a, d_b, n, stream=0):
+        if lib().pbc_hip_element_mul_GT_batch_dev(self._h, d_out, d_a, d_b, n, stream):
+            raise PbcHipError("element_mul_GT_dev: " + _err())
+
+    def element_pow_zn_GT_dev(self, d_out, d_a, d_zr, n, stream=0):
+        if lib().pbc_hip_element_pow_zn_GT_batch_dev(self._h, d_out, d_a, d_zr, n, stream):
+            raise PbcHipError("element_pow_zn_GT_dev: " + _err())
+
+    def finalpow_dev(self, d_out, d_in, n, stream=0):
+        if lib().pbc_hip_finalpow_batch_dev(self._h, d_out, d_in, n, stream):
+            raise PbcHipError("finalpow_dev: " + _err())
+
+    def element_from_hash_dev(self, group, d_out, d_data, hlen, n, stream=0):
+        if lib().pbc_hip_element_from_hash_batch_dev(self._h, group, d_out, d_data, hlen, n, stream):
+            raise PbcHipError("element_from_hash_dev: " + _err())
+
+    def point_format_dev(self, what, group, d_out, d_in, n, stream=0):
+        """what: to_bytes_compressed, from_bytes_compressed, to_bytes_x_only, from_bytes_x_only"""
+        if getattr(lib(), "pbc_hip_element_%s_batch_dev" % what)(self._h, group, d_out, d_in, n, stream):
+            raise PbcHipError(what + "_dev: " + _err())
+
+    def element_pp_init(self, group, rec):
+        """Mirror of element_pp_init: fixed-base powers of one element of G1 / G2 (group 1, 2) or GT (group 3)."""
+        return ElementPP(self, group, rec)
+
     # ---- preprocessed pairings (pairing_pp_init / pairing_pp_apply) ----------------------
     def finalpow(self, a):
         """pairing->finalpow over (n, lenGT) records of GT's underlying field"""
@@ -408,6 +455,42 @@ class PairingPP:
     def clear(self):
         if getattr(self, "_h", None):
             lib().pbc_hip_pairing_pp_clear(self._h)
+            self._h = None
+
+    __del__ = clear
+
+
+class ElementPP:
+    """Mirror of element_pp_t (include/pbc_field.h:591-625): element_pp_init / element_pp_pow_zn / element_pp_clear."""
+
+    def __init__(self, pairing, group, rec):
+        import numpy as np
+        self.pairing, self.group = pairing, group
+        rec = np.ascontiguousarray(rec, dtype=np.uint8).reshape(-1)
+        self.length = pairing._group_len(group)
+        if rec.size != self.length:
+            raise ValueError("one record of the group expected")
+        self._h = ctypes.c_void_p()
+        if lib().pbc_hip_element_pp_init(ctypes.byref(self._h), pairing._h, group, _np_ptr(rec)):
+            self._h = None
+            raise PbcHipError("element_pp_init: " + _err())
+
+    def pow_zn(self, zr):
+        import numpy as np
+        zr = np.ascontiguousarray(zr, dtype=np.uint8)
+        n = zr.size // self.pairing.length_in_bytes_Zr
+        out = np.empty((n, self.length), np.uint8)
+        if lib().pbc_hip_element_pp_pow_zn_batch(self._h, _np_ptr(out), _np_ptr(zr), n):
+            raise PbcHipError("element_pp_pow_zn: " + _err())
+        return out
+
+    def pow_zn_dev(self, d_out, d_zr, n, stream=0):
+        if lib().pbc_hip_element_pp_pow_zn_batch_dev(self._h, d_out, d_zr, n, stream):
+            raise PbcHipError("element_pp_pow_zn_dev: " + _err())
+
+    def clear(self):
+        if getattr(self, "_h", None):
+            lib().pbc_hip_element_pp_clear(self._h)
             self._h = None
 
     __del__ = clear

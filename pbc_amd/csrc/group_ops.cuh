@@ -63,6 +63,9 @@ struct FqOps {
   static PBC_DEV void cmov(el &r, const el &a, bool c) { fp_cmov<N>(r, a, c); }
   static PBC_DEV void load(el &r, const uint8_t *s) { fp_load_be<N>(r, s); }
   static PBC_DEV void store(uint8_t *d, const el &a) { fp_store_be<N>(d, a); }
+  static constexpr int WORDS_EL = N;   // Montgomery words of an element (fixed-base tables)
+  static PBC_DEV el from_words(const uint32_t *w) { el r; fp_set<N>(r, w); return r; }
+  static PBC_DEV void to_words(uint32_t *w, const el &a) { for (int k = 0; k < N; k++) w[k] = a.v[k]; }
 };
 template <int N, int DEG>
 struct FdOps {                         // F_q^d of types d / g: the twist E'(F_q^d)
@@ -87,7 +90,7 @@ struct FdOps {                         // F_q^d of types d / g: the twist E'(F_q
   static PBC_DEV void load(el &r, const uint8_t *s) { T::f3_load_be(r, s); }
   static PBC_DEV void store(uint8_t *d, const el &a) { T::f3_store_be(d, a); }
   // extension-field helpers for element_from_hash / compressed points on the twist
-  static constexpr int WORDS = DEG * N;
+  static constexpr int WORDS = DEG * N, WORDS_EL = DEG * N;
   static PBC_DEV el from_words(const uint32_t *w) { el r; for (int i = 0; i < DEG; i++) fp_set<N>(r.c[i], w + N * i); return r; }
   static PBC_DEV void to_words(uint32_t *w, const el &a) { for (int i = 0; i < DEG; i++) for (int k = 0; k < N; k++) w[N * i + k] = a.c[i].v[k]; }
   static PBC_DEV el nonresidue() { el r; T::f3_set_fq(r, T::dk(c_d.nqr)); return r; }   // v: F_q^k = F_q^d[sqrt(v)]
@@ -137,7 +140,7 @@ struct Fq2Ops {                        // F_q^2 of type f: the twist y^2 = x^3 +
   static PBC_DEV void cmov(el &r, const el &a, bool c) { fp_cmov<ND>(r.x, a.x, c); fp_cmov<ND>(r.y, a.y, c); }
   static PBC_DEV void load(el &r, const uint8_t *s) { T::g2_load_be(r, s); }
   static PBC_DEV void store(uint8_t *d, const el &a) { T::g2_store_be(d, a); }
-  static constexpr int WORDS = 2 * ND;
+  static constexpr int WORDS = 2 * ND, WORDS_EL = 2 * ND;
   static PBC_DEV el from_words(const uint32_t *w) { el r; fp_set<ND>(r.x, w); fp_set<ND>(r.y, w + ND); return r; }
   static PBC_DEV void to_words(uint32_t *w, const el &a) { for (int k = 0; k < ND; k++) { w[k] = a.x.v[k]; w[ND + k] = a.y.v[k]; } }
   // x^6 + alpha is irreducible, so alpha is no square in F_q^2, and neither is -alpha (-1 is a square there)
@@ -307,6 +310,217 @@ PBC_DEV void ec_mul_lane(uint8_t *out, const uint8_t *in, const uint8_t *z, int 
 template <int N>
 PBC_DEV void g_mul_lane(uint8_t *out, const uint8_t *in, const uint8_t *z, int zlen) {
   ec_mul_lane<FqOps<N>>(out, in, z, zlen);
+}
+
+// ---- the fast ladders: regular signed fixed windows and fixed-base tables ----------------------------------------------
+// The routines above are COMPLETE (any point of the curve, any scalar) and pay for it: two group operations per scalar
+// bit.  The library runs them only for lanes the routines below report.  Those use the plain Jacobian formulas -- an
+// addition that meets R = +-T or R = O has H = 0, which leaves Z = 0 for good -- and report "Z = 0 at the end": the true
+// result O, points of small order, exceptional scalars.  For points of the order-r subgroup and scalars below r that is
+// a probability-2^-150 event, so the complete pass is a second, nearly empty launch.
+
+// R <- R + (x2, y2), mixed, incomplete (ec_madd_jac without the case analysis)
+template <class F>
+PBC_DEV void ec_madd_inc(typename F::el &X, typename F::el &Y, typename F::el &Z, const typename F::el &x2,
+                         const typename F::el &y2) {
+  typedef typename F::el el;
+  el ZZ, H, R, HH, HHH, t0, t1;
+  F::sqr(ZZ, Z);
+  F::mul(H, x2, ZZ);
+  F::sub(H, H, X);
+  F::mul(t0, Z, ZZ);
+  F::mul(R, y2, t0);
+  F::sub(R, R, Y);
+  F::mul(Z, Z, H);
+  F::sqr(HH, H);
+  F::mul(HHH, HH, H);
+  F::mul(t0, X, HH);
+  F::sqr(X, R);
+  F::sub(X, X, HHH);
+  F::sub(X, X, t0);
+  F::sub(X, X, t0);
+  F::sub(t0, t0, X);
+  F::mul(t0, R, t0);
+  F::mul(t1, Y, HHH);
+  F::sub(Y, t0, t1);
+}
+// the scalar as little-endian words in private memory (read once), one zero word above
+constexpr int kScalarWords = 36;
+PBC_DEV void scalar_load(uint32_t *kw, const uint8_t *z, int zlen) {
+  for (int w = 0; w < kScalarWords; w++) kw[w] = 0;
+  for (int i = 0; i < zlen; i++) kw[i >> 2] |= (uint32_t) z[zlen - 1 - i] << (8 * (i & 3));
+}
+PBC_DEV uint32_t scalar_bits(const uint32_t *kw, int pos, uint32_t mask) {
+  const uint64_t pair = ((uint64_t) kw[(pos >> 5) + 1] << 32) | kw[pos >> 5];
+  return (uint32_t) (pair >> (pos & 31)) & mask;
+}
+// out = [k] P by a regular signed fixed-window ladder, w = 4 (the algorithm of group_al.cuh, which states it in full, on a
+// field policy): digits d_i = 2 ((k' >> (4 i + 1)) & 15) - 15 of k' = k | 1 with the bit above the scalar set, a per-lane
+// table {P, 3P, ..., 15P} of affine points built on the curve where 2P is affine and normalised by one batched
+// inversion, four doublings and one mixed addition per window, [k] P = [k + 1] P - P for even k.  Returns false (nothing
+// written) when the lane needs the complete routine.
+template <class F>
+PBC_DEV bool ec_mul_win_lane(uint8_t *out, const uint8_t *in, const uint8_t *z, int zlen) {
+  typedef typename F::el el;
+  constexpr int WIN = 4, TE = 8;
+  const int NB = F::bytes();
+  const el one = F::one(), ca = F::curve_a(), cb = F::curve_b();
+  el tab[TE][2], zs[TE], cs[TE];
+  F::load(tab[0][0], in);
+  F::load(tab[0][1], in + NB);
+  bool valid;
+  {
+    el t0, t1;
+    F::sqr(t0, tab[0][0]);
+    F::add(t0, t0, ca);
+    F::mul(t0, t0, tab[0][0]);
+    F::add(t0, t0, cb);
+    F::sqr(t1, tab[0][1]);
+    valid = F::eq(t0, t1);
+  }
+  el X = tab[0][0], Y = tab[0][1], Z = one;
+  ec_dbl_jac<F>(X, Y, Z, ca);          // 2P = (X2 : Y2 : Z2)
+  const el X2 = X, Y2 = Y, Z2 = Z;
+  {
+    el zz, t;
+    F::sqr(zz, Z2);
+    F::mul(X, tab[0][0], zz);
+    F::mul(t, zz, Z2);
+    F::mul(Y, tab[0][1], t);
+    Z = one;
+  }
+  for (int j = 1; j < TE; j++) {
+    ec_madd_inc<F>(X, Y, Z, X2, Y2);
+    tab[j][0] = X;
+    tab[j][1] = Y;
+    F::mul(zs[j], Z, Z2);
+    if (j == 1) cs[1] = zs[1];
+    else F::mul(cs[j], cs[j - 1], zs[j]);
+  }
+  bool bad = F::is0(cs[TE - 1]);
+  el zi;
+  F::inv(zi, cs[TE - 1]);
+  for (int j = TE - 1; j >= 1; j--) {
+    el zinv, zz, t;
+    if (j > 1) {
+      F::mul(zinv, zi, cs[j - 1]);
+      F::mul(zi, zi, zs[j]);
+    } else {
+      zinv = zi;
+    }
+    F::sqr(zz, zinv);
+    F::mul(tab[j][0], tab[j][0], zz);
+    F::mul(t, zz, zinv);
+    F::mul(tab[j][1], tab[j][1], t);
+  }
+  uint32_t kw[kScalarWords];
+  scalar_load(kw, z, zlen);
+  const bool even = (kw[0] & 1) == 0;
+  kw[0] |= 1u;
+  kw[(8 * zlen) >> 5] |= 1u << ((8 * zlen) & 31);
+  const int t = 2 * zlen;
+  auto entry = [&](el &x, el &y, int i) {
+    const uint32_t v = scalar_bits(kw, 4 * i + 1, 15u);
+    const bool neg = v < 8;
+    const int idx = neg ? 7 - (int) v : (int) v - 8;
+    x = tab[idx][0];
+    y = tab[idx][1];
+    el ny = F::zero();
+    F::sub(ny, ny, y);
+    F::cmov(y, ny, neg);
+  };
+  entry(X, Y, t - 1);                  // the top digit is positive
+  Z = one;
+  for (int i = t - 2; i >= 0; i--) {
+    el x2, y2;
+    for (int d = 0; d < WIN; d++) ec_dbl_jac<F>(X, Y, Z, ca);
+    entry(x2, y2, i);
+    ec_madd_inc<F>(X, Y, Z, x2, y2);
+  }
+  {
+    el sX = X, sY = Y, sZ = Z, ny = F::zero();
+    F::sub(ny, ny, tab[0][1]);
+    ec_madd_inc<F>(sX, sY, sZ, tab[0][0], ny);
+    F::cmov(X, sX, even);
+    F::cmov(Y, sY, even);
+    F::cmov(Z, sZ, even);
+  }
+  bad |= F::is0(Z);
+  el zinv, zz, ax, ay;
+  F::inv(zinv, Z);
+  F::sqr(zz, zinv);
+  F::mul(ax, X, zz);
+  F::mul(zz, zz, zinv);
+  F::mul(ay, Y, zz);
+  if (!valid) { ax = F::zero(); ay = ax; }
+  const bool handled = !valid | !bad;
+  if (handled) {
+    F::store(out, ax);
+    F::store(out + NB, ay);
+  }
+  return handled;
+}
+
+// Fixed-base tables (element_pp_init / element_pp_pow_zn, include/pbc_field.h:591-625 -> element_build_base_table /
+// element_pow_base_table, arith/field.c:243-323: 5-bit rows there, products of table entries).  Here 8-bit rows:
+// entry (row, w) = [w 2^(8 row)] B for w = 1 .. 255 as an affine point in Montgomery words -- [k] B is one mixed addition
+// per scalar byte and one inversion, no doublings.  The table is uniform data in global memory (L2-resident: rows x 255 x
+// 2 elements); the lane's digit selects the entry.
+constexpr int kPpWin = 8, kPpRowLen = (1 << kPpWin) - 1;
+// one table entry per lane: unit u = row * 255 + (w - 1); `flags[u]` = 1 when the entry is O (a base of small order)
+template <class F>
+PBC_DEV void ec_pp_entry_lane(uint32_t *tab, uint8_t *flags, const uint8_t *base, int zlen, size_t u) {
+  typedef typename F::el el;
+  const int row = (int) (u / kPpRowLen), w = (int) (u % kPpRowLen) + 1;
+  const int NB = F::bytes();
+  uint8_t zb[4 * kScalarWords], o[8 * F::WORDS_EL];
+  for (int i = 0; i < zlen + 1; i++) zb[i] = 0;
+  if (row < zlen) zb[zlen - row] = (uint8_t) w;      // a scalar of zlen + 1 bytes (big-endian): w 2^(8 row)
+  ec_mul_lane<F>(o, base, zb, zlen + 1);
+  el x, y;
+  F::load(x, o);
+  F::load(y, o + NB);
+  bool inf = true;
+  for (int i = 0; i < 2 * NB; i++) inf &= o[i] == 0;
+  flags[u] = inf ? 1 : 0;
+  F::to_words(tab + u * 2 * F::WORDS_EL, x);
+  F::to_words(tab + (u * 2 + 1) * F::WORDS_EL, y);
+}
+// out = [k] B from the table; false (nothing written) when the lane needs the complete routine
+template <class F>
+PBC_DEV bool ec_pp_pow_lane(uint8_t *out, const uint32_t *__restrict__ tab, const uint8_t *z, int zlen) {
+  typedef typename F::el el;
+  const int NB = F::bytes();
+  const el one = F::one();
+  el X = one, Y = one, Z = one;
+  bool inf = true;                     // the accumulator is still O
+  for (int row = 0; row < zlen; row++) {
+    const uint32_t w = z[zlen - 1 - row];
+    const size_t u = (size_t) row * kPpRowLen + (w ? w - 1 : 0);
+    const el x2 = F::from_words(tab + u * 2 * F::WORDS_EL), y2 = F::from_words(tab + (u * 2 + 1) * F::WORDS_EL);
+    el sX = X, sY = Y, sZ = Z;
+    ec_madd_inc<F>(sX, sY, sZ, x2, y2);
+    const bool take = w != 0, first = take & inf, add = take & !inf;
+    F::cmov(X, sX, add);
+    F::cmov(Y, sY, add);
+    F::cmov(Z, sZ, add);
+    F::cmov(X, x2, first);
+    F::cmov(Y, y2, first);
+    inf &= !take;
+  }
+  const bool bad = !inf & F::is0(Z);
+  el zinv, zz, ax, ay;
+  F::inv(zinv, Z);
+  F::sqr(zz, zinv);
+  F::mul(ax, X, zz);
+  F::mul(zz, zz, zinv);
+  F::mul(ay, Y, zz);
+  if (inf) { ax = F::zero(); ay = ax; }            // k = 0
+  if (!bad) {
+    F::store(out, ax);
+    F::store(out + NB, ay);
+  }
+  return !bad;
 }
 
 // ---- element_from_hash on G1 (and G2 of the symmetric types) ---------------------------------
@@ -649,6 +863,90 @@ __device__ void f_gt_pow_lane(uint8_t *out, const uint8_t *a, const uint8_t *z, 
     }
   }
   f_gt_store<ND>(out, &acc);
+}
+
+// ---- GT as a field policy (fixed-base powers) -----------------------------------------------------------------------------
+// el, WORDS_EL Montgomery words per element, load / store (GT's wire format), mul, one, to_words / from_words
+template <int N>
+struct GtA {                           // types a, a1: F_q^2
+  typedef fp2<N> el;
+  static constexpr int NW = N, WORDS_EL = 2 * N;
+  static PBC_DEV int bytes() { return 2 * (int) fpk<N>().fbytes; }
+  static PBC_DEV void load(el &r, const uint8_t *s) { a_gt_load<N>(r, s); }
+  static PBC_DEV void store(uint8_t *d, const el &a) { a_gt_store<N>(d, a); }
+  static PBC_DEV void mul(el &r, const el &a, const el &b) { fi_mul<N>(r, a, b); }
+  static PBC_DEV void one(el &r) { fp_set<N>(r.x, fpk<N>().one); for (int k = 0; k < N; k++) r.y.v[k] = 0; }
+  static PBC_DEV void to_words(uint32_t *w, const el &a) { for (int k = 0; k < N; k++) { w[k] = a.x.v[k]; w[N + k] = a.y.v[k]; } }
+  static PBC_DEV void from_words(el &r, const uint32_t *w) { fp_set<N>(r.x, w); fp_set<N>(r.y, w + N); }
+};
+template <int N>
+struct GtE {                           // type e: F_q
+  typedef fp<N> el;
+  static constexpr int NW = N, WORDS_EL = N;
+  static PBC_DEV int bytes() { return (int) fpk<N>().fbytes; }
+  static PBC_DEV void load(el &r, const uint8_t *s) { fp_load_be<N>(r, s); }
+  static PBC_DEV void store(uint8_t *d, const el &a) { fp_store_be<N>(d, a); }
+  static PBC_DEV void mul(el &r, const el &a, const el &b) { fp_mul<N>(r, a, b); }
+  static PBC_DEV void one(el &r) { fp_set<N>(r, fpk<N>().one); }
+  static PBC_DEV void to_words(uint32_t *w, const el &a) { for (int k = 0; k < N; k++) w[k] = a.v[k]; }
+  static PBC_DEV void from_words(el &r, const uint32_t *w) { fp_set<N>(r, w); }
+};
+template <int N, int DEG>
+struct GtD {                           // types d, g: F_q^k = F_q^d[sqrt(v)]
+  typedef TypeMNT<N, DEG> T;
+  typedef typename T::f6 el;
+  static constexpr int NW = N, WORDS_EL = 2 * DEG * N;
+  static PBC_DEV int bytes() { return 2 * DEG * (int) fpk<N>().fbytes; }
+  static PBC_DEV void load(el &r, const uint8_t *s) { d_gt_load<N, DEG>(r, s); }
+  static PBC_DEV void store(uint8_t *d, const el &a) { d_gt_store<N, DEG>(d, a); }
+  static PBC_DEV void mul(el &r, const el &a, const el &b) { T::f6_mul(r, a, b); }
+  static PBC_DEV void one(el &r) { fp<N> o; fp_set<N>(o, fpk<N>().one); T::f3_set_fq(r.x, o); T::f3_sub(r.y, r.x, r.x); }
+  static PBC_DEV void to_words(uint32_t *w, const el &a) {
+    for (int i = 0; i < DEG; i++) for (int k = 0; k < N; k++) { w[N * i + k] = a.x.c[i].v[k]; w[N * (DEG + i) + k] = a.y.c[i].v[k]; }
+  }
+  static PBC_DEV void from_words(el &r, const uint32_t *w) { for (int i = 0; i < DEG; i++) { fp_set<N>(r.x.c[i], w + N * i); fp_set<N>(r.y.c[i], w + N * (DEG + i)); } }
+};
+template <int ND>
+struct GtF {                           // type f: F_q^12 (private-memory objects)
+  typedef TypeF<ND> T;
+  typedef typename T::f12 el;
+  static constexpr int NW = ND, WORDS_EL = 12 * ND;
+  static PBC_DEV int bytes() { return 12 * (int) fpk<ND>().fbytes; }
+  static PBC_DEV void load(el &r, const uint8_t *s) { f_gt_load<ND>(&r, s); }
+  static PBC_DEV void store(uint8_t *d, const el &a) { f_gt_store<ND>(d, &a); }
+  static PBC_DEV void mul(el &r, const el &a, const el &b) { T::f12_mul(&r, &a, &b); }
+  static PBC_DEV void one(el &r) { T::f12_one(&r); }
+  static PBC_DEV void to_words(uint32_t *w, const el &a) {
+    for (int i = 0; i < 6; i++) for (int k = 0; k < ND; k++) { w[2 * ND * i + k] = a.c[i].x.v[k]; w[2 * ND * i + ND + k] = a.c[i].y.v[k]; }
+  }
+  static PBC_DEV void from_words(el &r, const uint32_t *w) { for (int i = 0; i < 6; i++) { fp_set<ND>(r.c[i].x, w + 2 * ND * i); fp_set<ND>(r.c[i].y, w + 2 * ND * i + ND); } }
+};
+// entry (row, w) = a^(w 2^(8 row)) for w = 0 .. 255 (w = 0: the identity, so that a power is a plain product over the rows);
+// unit u = row * 256 + w, one per lane
+template <class G>
+PBC_DEV void gt_pp_entry_lane(uint32_t *tab, const uint8_t *a, size_t u) {
+  typedef typename G::el el;
+  const int row = (int) (u >> kPpWin), w = (int) (u & ((1 << kPpWin) - 1));
+  el x, acc;
+  G::load(x, a);
+  for (int i = 0; i < kPpWin * row; i++) G::mul(x, x, x);
+  G::one(acc);
+  for (int i = kPpWin - 1; i >= 0; i--) {
+    G::mul(acc, acc, acc);
+    if ((w >> i) & 1) G::mul(acc, acc, x);
+  }
+  G::to_words(tab + u * G::WORDS_EL, acc);
+}
+template <class G>
+PBC_DEV void gt_pp_pow_lane(uint8_t *out, const uint32_t *__restrict__ tab, const uint8_t *z, int zlen) {
+  typedef typename G::el el;
+  el acc, t;
+  G::from_words(acc, tab + (size_t) z[zlen - 1] * G::WORDS_EL);
+  for (int row = 1; row < zlen; row++) {
+    G::from_words(t, tab + ((size_t) row * (1 << kPpWin) + z[zlen - 1 - row]) * G::WORDS_EL);
+    G::mul(acc, acc, t);
+  }
+  G::store(out, acc);
 }
 
 // ---- pairing->finalpow (include/pbc_pairing.h:41; a_finalpow a_param.c:1420-1429, cc_finalpow d_param.c:566-568,

@@ -10,6 +10,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <functional>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -23,6 +24,7 @@
 #include "pairing_d.cuh"
 #include "pairing_f.cuh"
 #include "pairing_e.cuh"
+#include "group_al.cuh"
 
 using namespace pbc;
 
@@ -164,6 +166,11 @@ struct ProdWs {
     return w;
   }
 };
+// The host-buffer path (pbc_hip.hip): chunks over the device set, page-locked buffers in place, anything else staged
+// through per-device chunk buffers that the object keeps.  `launch` enqueues one chunk (device pointers) on a stream.
+typedef std::function<int(void *d_out, const void *d_a, const void *d_b, size_t m, hipStream_t s, const OwnWs *own)> ChunkLaunch;
+int run_host_generic(pbc_hip_pairing_s *P, uint8_t *out, size_t ut, const uint8_t *a, size_t u1, const uint8_t *b, size_t u2,
+                     size_t n, const ChunkLaunch &launch, bool zero_copy_ok);
 // Per-family launchers: k-term products (k = 1: single pairings) of n units on stream s; constants already derived.
 int launch_a(pbc_hip_pairing_s *P, void *d_gt, const void *d_g1, const void *d_g2, size_t n, int k, hipStream_t s, ProdWs &W);   // pbc_hip_a.hip: a, a1, e
 int launch_d(pbc_hip_pairing_s *P, void *d_gt, const void *d_g1, const void *d_g2, size_t n, int k, hipStream_t s, ProdWs &W);   // pbc_hip_d.hip: d, g

@@ -44,6 +44,7 @@ struct pbc_hip_pairing_s {
   bool a_generic;            // type a outside the 64-byte fast path: runs on the type a1 kernels
   bool a_prod_shared;        // type a fast path, products: "hip_prod_shared 1" keeps one product per lane (a_prod_pairing_lane)
   bool zero_copy;            // host-buffer entry points: kernels read / write pinned caller buffers in place ("hip_zero_copy 0/1")
+  bool group_slow;           // group operations: only the complete ladders ("hip_group_slow 1": tests, A/B)
   int resident_slots;        // > 0: workgroups of a resident launch instead of the occupancy query ("hip_resident_slots N", tests)
   size_t host_chunk;         // host-buffer entry points: units per chunk when the parameter text says "hip_host_chunk N" (0: default)
   size_t a_prod_chunk;       // ... otherwise: terms per launch of the one-term-per-lane kernels ("hip_prod_chunk N", tests)

@@ -296,6 +296,9 @@ extern "C" int pbc_hip_pairing_init_set_buf(pbc_hip_pairing_t **out, const char 
     int rs = 0;                        // "hip_resident_slots N": workgroups of a resident launch (tests: forces several units per lane on small batches)
     pbc_host::param_int(param, len, "hip_resident_slots", rs);
     P->resident_slots = rs > 0 ? rs : 0;
+    int gs = 0;                        // "hip_group_slow 1": element_mul_zn / GT pow_zn on the complete bit-by-bit ladders only
+    pbc_host::param_int(param, len, "hip_group_slow", gs);
+    P->group_slow = gs != 0;
     // bind to the caller's current device; without one the object still parses/validates
     // parameters (host logic), and every batch call fails loudly -- there is no CPU path.
     if (hipGetDevice(&P->device) != hipSuccess) P->device = -1;
@@ -670,22 +673,24 @@ static bool devctx_slot(DevCtx *c, int sl, size_t b1, size_t b2, size_t bt, std:
   return true;
 }
 
-static int run_host(pbc_hip_pairing_s *P, uint8_t *gt, const uint8_t *g1, const uint8_t *g2, size_t n,
-                    int k) {
+// The host-buffer path of every batched entry point: n units with per-unit records of u1 and u2 bytes in (g2 may be null
+// when u2 == 0) and ut bytes out; `launch` enqueues the work for one chunk on a stream (launch_prod for the pairings, the
+// group operations' launcher for those).  zero_copy_ok: the kernels behind `launch` read their records with word loads.
+int run_host_generic(pbc_hip_pairing_s *P, uint8_t *gt, size_t ut, const uint8_t *g1, size_t u1, const uint8_t *g2, size_t u2,
+                     size_t n, const ChunkLaunch &launch, bool zero_copy_ok) {
   if (P->device < 0) return fail("no HIP device: libpbc_hip has no CPU fallback");
   if (!n) return 0;
   // An output range that overlaps an input range: the lanes of a launch (and the chunks of a staged call, which travel
   // on several streams) read and write in no particular order, so the results are collected in a buffer of their own
   // and copied over the caller's memory when every input has been read.
-  if (ranges_overlap(gt, n * (size_t) P->lenT, g1, n * (size_t) k * P->len1) || ranges_overlap(gt, n * (size_t) P->lenT, g2, n * (size_t) k * P->len2)) {
-    std::vector<uint8_t> tmp(n * (size_t) P->lenT);
-    if (run_host(P, tmp.data(), g1, g2, n, k)) return 1;
+  if (ranges_overlap(gt, n * ut, g1, n * u1) || (g2 && ranges_overlap(gt, n * ut, g2, n * u2))) {
+    std::vector<uint8_t> tmp(n * ut);
+    if (run_host_generic(P, tmp.data(), ut, g1, u1, g2, u2, n, launch, zero_copy_ok)) return 1;
     memcpy(gt, tmp.data(), tmp.size());
     return 0;
   }
   const int ndev = P->ndev > 0 ? P->ndev : 1;
   const int *devs = P->ndev > 0 ? P->devs : &P->device;
-  const size_t u1 = (size_t) k * P->len1, u2 = (size_t) k * P->len2, ut = (size_t) P->lenT;
   // Chunks: every device gets one share of the batch (at most 2^20 units and 2 GB of records per chunk; three chunk
   // buffers per device are in flight).  Round 1-2 cut a batch into chunks of one chip residency (131072 units) to overlap
   // the copies of one chunk with the kernel of another; measured on MI355X (tools/r03_hostchunk.sh, pinned host buffers,
@@ -707,12 +712,12 @@ static int run_host(pbc_hip_pairing_s *P, uint8_t *gt, const uint8_t *g1, const 
   const uint8_t *z1 = nullptr, *z2 = nullptr;
   // (coordinates whose length is not a multiple of four bytes are read byte by byte -- fp_load_be --, and a byte read
   // over PCIe costs a transaction: type a1, 130-byte coordinates, ran at half speed in place; those stay staged)
-  if (P->zero_copy && P->len_fq % 4 == 0) {
+  if (P->zero_copy && zero_copy_ok && P->len_fq % 4 == 0) {
     zt = (uint8_t *) pinned_dev_ptr(gt, n * ut, ndev > 1);
     z1 = (const uint8_t *) pinned_dev_ptr(g1, n * u1, ndev > 1);
-    z2 = (const uint8_t *) pinned_dev_ptr(g2, n * u2, ndev > 1);
+    z2 = g2 ? (const uint8_t *) pinned_dev_ptr(g2, n * u2, ndev > 1) : nullptr;
   }
-  const bool zc = zt && z1 && z2;
+  const bool zc = zt && z1 && (z2 || !g2);
   // chunks d, d + ndev, d + 2 ndev, ... on device devs[d]
   auto worker = [&](int d, std::string *err) {
     if (hipSetDevice(devs[d]) != hipSuccess) { *err = "hipSetDevice failed"; return; }
@@ -723,7 +728,7 @@ static int run_host(pbc_hip_pairing_s *P, uint8_t *gt, const uint8_t *g1, const 
       const OwnWs own = {&c->ws[0], &c->wscap[0]};
       for (size_t idx = (size_t) d; idx < nchunks; idx += (size_t) ndev) {
         const size_t off = idx * chunk, m = n - off < chunk ? n - off : chunk;
-        if (launch_prod(P, zt + off * ut, z1 + off * u1, z2 + off * u2, m, k, c->st[0], false, &own)) { *err = g_err; break; }
+        if (launch(zt + off * ut, z1 + off * u1, z2 ? z2 + off * u2 : nullptr, m, c->st[0], &own)) { *err = g_err; break; }
       }
       hipError_t e = hipStreamSynchronize(c->st[0]);
       if (e != hipSuccess && err->empty()) *err = std::string("kernel failed: ") + hipGetErrorString(e);
@@ -733,11 +738,11 @@ static int run_host(pbc_hip_pairing_s *P, uint8_t *gt, const uint8_t *g1, const 
       const int sl = (int) (round % kSlots);
       const size_t off = idx * chunk, m = n - off < chunk ? n - off : chunk;
       hipStream_t st = c->st[sl];
-      if (!devctx_slot(c, sl, chunk * u1, chunk * u2, chunk * ut, *err)) break;
+      if (!devctx_slot(c, sl, chunk * u1, g2 ? chunk * u2 : 0, chunk * ut, *err)) break;
       const OwnWs own = {&c->ws[sl], &c->wscap[sl]};
       if (hipMemcpyAsync(c->d1[sl], g1 + off * u1, m * u1, hipMemcpyHostToDevice, st) != hipSuccess ||
-          hipMemcpyAsync(c->d2[sl], g2 + off * u2, m * u2, hipMemcpyHostToDevice, st) != hipSuccess) { *err = "H2D copy failed"; break; }
-      if (launch_prod(P, c->dt[sl], c->d1[sl], c->d2[sl], m, k, st, false, &own)) { *err = g_err; break; }
+          (g2 && hipMemcpyAsync(c->d2[sl], g2 + off * u2, m * u2, hipMemcpyHostToDevice, st) != hipSuccess)) { *err = "H2D copy failed"; break; }
+      if (launch(c->dt[sl], c->d1[sl], g2 ? c->d2[sl] : nullptr, m, st, &own)) { *err = g_err; break; }
       if (hipMemcpyAsync(gt + off * ut, c->dt[sl], m * ut, hipMemcpyDeviceToHost, st) != hipSuccess) { *err = "D2H copy failed"; break; }
     }
     for (int i = 0; i < kSlots; i++) {
@@ -756,6 +761,13 @@ static int run_host(pbc_hip_pairing_s *P, uint8_t *gt, const uint8_t *g1, const 
   for (int d = 0; d < used; d++)
     if (!errs[d].empty()) return fail("device %d: %s", devs[d], errs[d].c_str());
   return 0;
+}
+
+static int run_host(pbc_hip_pairing_s *P, uint8_t *gt, const uint8_t *g1, const uint8_t *g2, size_t n, int k) {
+  return run_host_generic(P, gt, (size_t) P->lenT, g1, (size_t) k * P->len1, g2, (size_t) k * P->len2, n,
+                          [P, k](void *d_gt, const void *d_g1, const void *d_g2, size_t m, hipStream_t s, const OwnWs *own) {
+                            return launch_prod(P, d_gt, d_g1, d_g2, m, k, s, false, own);
+                          }, true);
 }
 
 extern "C" int pbc_hip_host_alloc(void **out, size_t bytes) {

@@ -76,6 +76,27 @@ class HostSim:
     def finalpow(self, a):
         return self.group(3, a, a)
 
+    def group_mode(self, slow):
+        """True: only the complete word-form routines (what the library runs for the lanes its fast routines report)"""
+        self.L.hostsim_group_mode.argtypes = [ctypes.c_int]
+        self.L.hostsim_group_mode(1 if slow else 0)
+
+    def fallbacks(self, reset=True):
+        """lanes the fast group routines have reported since the last reset"""
+        self.L.hostsim_group_fallbacks.restype = ctypes.c_uint64
+        self.L.hostsim_group_fallbacks.argtypes = [ctypes.c_int]
+        return int(self.L.hostsim_group_fallbacks(1 if reset else 0))
+
+    def element_pp(self, group, base, zr, zlen):
+        """element_pp_init(base) + element_pp_pow_zn over the scalars zr (group 1, 2: points; 3: GT)"""
+        base = np.ascontiguousarray(base, np.uint8).reshape(-1)
+        zr = np.ascontiguousarray(zr, np.uint8)
+        n = zr.size // zlen
+        out = np.empty((n, base.size), np.uint8)
+        self.L.hostsim_element_pp.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 3 + [ctypes.c_size_t]
+        self.L.hostsim_element_pp(self.h, group, out.ctypes.data, base.ctypes.data, zr.ctypes.data, n)
+        return out
+
     def compress(self, direction, recs):
         recs = np.ascontiguousarray(recs, np.uint8)
         lp, lc = self.len1, self.len1 // 2 + (1 if direction < 2 else 0)

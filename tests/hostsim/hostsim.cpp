@@ -5,6 +5,7 @@
 #include <vector>
 #include "../../pbc_amd/csrc/host_params.h"
 #include "../../pbc_amd/csrc/pairing_al.cuh"
+#include "../../pbc_amd/csrc/group_al.cuh"
 
 // run EXPR with N = the compile-time word count matching P->nlimb
 #define HS_DISPATCH(nl, ...)                          \
@@ -215,10 +216,19 @@ int hostsim_g2_points(void *h, int what, uint8_t *out, const uint8_t *in, int hl
   return 0;
 }
 // element_mul_zn on G2 of the asymmetric types (twists)
+static int hostsim_slow_group = 0;     // 1: only the complete word-form routines (what the library runs for reported lanes)
+static uint64_t hostsim_fallbacks = 0; // lanes the fast routines reported
 int hostsim_g2_mul(void *h, uint8_t *out, const uint8_t *a, const uint8_t *b, size_t n) {
   pbc_hip_pairing_s *P = (pbc_hip_pairing_s *) h;
   activate(P);
   for (size_t i = 0; i < n; i++) {
+    if (!hostsim_slow_group && (P->type == 'd' || P->type == 'g' || P->type == 'f')) {   // as the library: the windowed ladder first
+      bool ok = false;
+      if (P->type == 'f') { HS_DISPATCH_F(P->nlimb, ok = (ec_mul_win_lane<Fq2Ops<N>>(out + i * P->len2, a + i * P->len2, b + i * P->len_zr, P->len_zr))); }
+      else { HS_DISPATCH_D(P, ok = (ec_mul_win_lane<FdOps<N, DEG>>(out + i * P->len2, a + i * P->len2, b + i * P->len_zr, P->len_zr))); }
+      if (ok) continue;
+      hostsim_fallbacks++;
+    }
     if (P->type == 'd' || P->type == 'g') {
       HS_DISPATCH_D(P, (ec_mul_lane<FdOps<N, DEG>>(out + i * P->len2, a + i * P->len2, b + i * P->len_zr, P->len_zr)));
     } else if (P->type == 'f') {
@@ -229,12 +239,63 @@ int hostsim_g2_mul(void *h, uint8_t *out, const uint8_t *a, const uint8_t *b, si
   }
   return 0;
 }
+// fixed-base powers (element_pp_init + element_pp_pow_zn): group 1 / 2 / 3; the table is built entry by entry as the
+// library's kernels do, then every scalar takes the table routine (and the complete ladder when that reports the lane)
+int hostsim_element_pp(void *h, int group, uint8_t *out, const uint8_t *base, const uint8_t *zr, size_t n) {
+  pbc_hip_pairing_s *P = (pbc_hip_pairing_s *) h;
+  activate(P);
+  const int zlen = P->len_zr;
+  const bool twist = group == 2 && (P->type == 'd' || P->type == 'g' || P->type == 'f');
+  if (group == 3) {
+    const size_t units = (size_t) zlen << kPpWin;
+#define HS_GT_PP(G_)                                                                           \
+    { std::vector<uint32_t> tab(units * G_::WORDS_EL);                                          \
+      for (size_t u = 0; u < units; u++) gt_pp_entry_lane<G_>(tab.data(), base, u);             \
+      for (size_t i = 0; i < n; i++) gt_pp_pow_lane<G_>(out + i * P->lenT, tab.data(), zr + i * zlen, zlen); }
+    if (P->type == 'a' || P->type == '1') { if (P->nlimb == 16) HS_GT_PP(GtA<16>) else HS_GT_PP(GtA<33>) }
+    else if (P->type == 'e') { if (P->nlimb == 16) HS_GT_PP(GtE<16>) else HS_GT_PP(GtE<33>) }
+    else if (P->type == 'f') { HS_DISPATCH_F(P->nlimb, HS_GT_PP(GtF<N>)); }
+    else { HS_DISPATCH_D(P, { typedef GtD<N, DEG> GD; HS_GT_PP(GD) }); }
+#undef HS_GT_PP
+    return 0;
+  }
+  const size_t units = (size_t) zlen * kPpRowLen;
+  const size_t lp = group == 2 ? P->len2 : P->len1;
+#define HS_EC_PP(F_)                                                                           \
+  { std::vector<uint32_t> tab(units * 2 * F_::WORDS_EL);                                        \
+    std::vector<uint8_t> flags(units);                                                          \
+    for (size_t u = 0; u < units; u++) ec_pp_entry_lane<F_>(tab.data(), flags.data(), base, zlen, u); \
+    bool complete_only = false;                                                                 \
+    for (uint8_t f : flags) complete_only |= f != 0;                                            \
+    for (size_t i = 0; i < n; i++) {                                                            \
+      if (!complete_only && ec_pp_pow_lane<F_>(out + i * lp, tab.data(), zr + i * zlen, zlen)) continue; \
+      hostsim_fallbacks++;                                                                      \
+      ec_mul_lane<F_>(out + i * lp, base, zr + i * zlen, zlen);                                 \
+    } }
+  if (twist && P->type == 'f') { HS_DISPATCH_F(P->nlimb, HS_EC_PP(Fq2Ops<N>)); }
+  else if (twist) { HS_DISPATCH_D(P, { typedef FdOps<N, DEG> FD; HS_EC_PP(FD) }); }
+  else { HS_DISPATCH(P->nlimb, HS_EC_PP(FqOps<N>)); }
+#undef HS_EC_PP
+  return 0;
+}
 // group operations: what 0 = G mul_zn, 1 = GT mul, 2 = GT pow
+void hostsim_group_mode(int slow) { hostsim_slow_group = slow; }
+uint64_t hostsim_group_fallbacks(int reset) { uint64_t v = hostsim_fallbacks; if (reset) hostsim_fallbacks = 0; return v; }
 int hostsim_group(void *h, int what, uint8_t *out, const uint8_t *a, const uint8_t *b, size_t n) {
   pbc_hip_pairing_s *P = (pbc_hip_pairing_s *) h;
   activate(P);
   for (size_t i = 0; i < n; i++) {
     if (what == 0) {
+      // as the library: the limb-form ladder first where it exists, the complete routine for the lanes it reports
+      if (P->type == 'a' && !P->a_generic && !hostsim_slow_group) {
+        if (GAL<16>::gmul_lane(out + i * P->len1, a + i * P->len1, b + i * P->len_zr, P->len_zr)) continue;
+        hostsim_fallbacks++;
+      } else if (!hostsim_slow_group) {
+        bool ok = false;
+        HS_DISPATCH(P->nlimb, ok = ec_mul_win_lane<FqOps<N>>(out + i * P->len1, a + i * P->len1, b + i * P->len_zr, P->len_zr));
+        if (ok) continue;
+        hostsim_fallbacks++;
+      }
       HS_DISPATCH(P->nlimb, g_mul_lane<N>(out + i * P->len1, a + i * P->len1, b + i * P->len_zr, P->len_zr));
     } else {
       uint8_t *o = out + i * P->lenT;
@@ -245,6 +306,10 @@ int hostsim_group(void *h, int what, uint8_t *out, const uint8_t *a, const uint8
         else if (P->type == 'd' || P->type == 'g') { HS_DISPATCH_D(P, (d_finalpow_lane<N, DEG>(o, x))); }
         else { HS_DISPATCH_F(P->nlimb, f_finalpow_lane<N>(o, x)); }
         continue;
+      }
+      if (what == 2 && P->type == 'a' && !P->a_generic && !hostsim_slow_group) {
+        if (GAL<16>::gt_pow_lane(o, x, y, P->len_zr)) continue;
+        hostsim_fallbacks++;
       }
       if ((P->type == 'a' || P->type == '1') && P->nlimb == 16) { if (what == 1) a_gt_mul_lane<16>(o, x, y); else a_gt_pow_lane<16>(o, x, y, P->len_zr); }
       else if (P->type == '1' || P->type == 'a') { if (what == 1) a_gt_mul_lane<33>(o, x, y); else a_gt_pow_lane<33>(o, x, y, P->len_zr); }

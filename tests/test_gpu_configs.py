@@ -137,7 +137,10 @@ def test_every_resident_kernel_with_a_forced_small_grid(hips, case, name, k):
     ref = hips[key]
     n = 1000
     t = np.arange(n * k)
-    g1, g2 = np.ascontiguousarray(v.g1.reshape(-1, v.len1)[(t * 3 + 1) % (v.n * v.k)]), np.ascontiguousarray(v.g2.reshape(-1, v.len2)[(t * 7) % (v.n * v.k)])
+    M = v.n * v.k
+    i1 = (t * 3 + 1) % M
+    i2 = np.where(t % 4 == 0, i1, (t * 7) % M)              # every fourth unit is a pair of the fixture itself
+    g1, g2 = np.ascontiguousarray(v.g1.reshape(-1, v.len1)[i1]), np.ascontiguousarray(v.g2.reshape(-1, v.len2)[i2])
     if case.endswith("-pp"):
         a, b = P.pp_init(g1[0]), ref.pp_init(g1[0])
         got, want = a.apply(g2), b.apply(g2)
@@ -148,8 +151,8 @@ def test_every_resident_kernel_with_a_forced_small_grid(hips, case, name, k):
         got, want = P.element_prod_pairing(g1, g2, k), ref.element_prod_pairing(g1, g2, k)
     assert np.array_equal(got, want)
     if k == 1 and not case.endswith("-pp"):
-        d = np.nonzero((t * 3 + 1) % v.n == (t * 7) % v.n)[0]
-        assert len(d) and np.array_equal(got[d], v.gt[((t * 3 + 1) % v.n)[d]])
+        d = np.nonzero(i1 == i2)[0]
+        assert len(d) >= n // 4 and np.array_equal(got[d], v.gt[i1[d]])
     P.clear()
 
 

@@ -370,3 +370,100 @@ def test_limb_form_type_a_subtraction_constants(sims):
     S = sims["a"]
     S.L.hostsim_check_ksub.argtypes = [ctypes.c_void_p]
     assert S.L.hostsim_check_ksub(S.h) == 0
+
+
+# ---- round 4: the fast ladders of the group operations (group_al.cuh, group_ops.cuh ec_mul_win_lane / ec_pp_* / gt_pp_*) ----
+def _be(x, n):
+    return np.frombuffer(int(x).to_bytes(n, "big"), np.uint8)
+
+
+def _order(pname):
+    from conftest import param_value
+    try:
+        return param_value(pname, "r")
+    except KeyError:
+        return param_value(pname, "n")
+
+
+def test_limb_form_scalar_multiplication_and_gt_powers_type_a_on_host(sims, oracles):
+    """GAL<16>::gmul_lane / gt_pow_lane (the kernels' source, with the worst-case bound tracker of the limb form armed):
+    random and exceptional scalars, whole-curve points; lanes the ladder reports (result O, even scalar meeting -P) take
+    the complete routine, as in the library.  Bytes against the oracle and the reference's vectors."""
+    S, O = sims["a"], oracles["a"]
+    v = golden("a_rand32.vec")
+    r = _order("a")
+    rng = np.random.default_rng(5)
+    ks = [int.from_bytes(rng.bytes(20), "big") % r for _ in range(8)] + [0, 1, 2, 3, r - 1, r - 2, r, r + 1, 2**160 - 1, 2**160 - 2, 15, 16, 17, 2**159]
+    Z = np.stack([_be(k, 20) for k in ks])
+    P = v.g1[:len(ks)]
+    S.fallbacks()
+    assert np.array_equal(S.group(0, P, Z), O.g_mul(1, P, Z))
+    assert S.fallbacks() == 3                                  # 0 P, r P and (r - 1) P = r P - P
+    w = golden("a_g1mulfull6.vec")                             # points outside the order-r subgroup (reference vectors)
+    assert np.array_equal(S.group(0, w.g1, w.g2), w.gt)
+    g = v.gt[:len(ks)]
+    assert np.array_equal(S.group(2, g, Z), O.gt_pow(g, Z))
+    assert S.fallbacks() == 0                                  # pairing values have norm 1: the Lucas ladder serves them all
+    A = rng.integers(0, 256, (4, 128), dtype=np.uint8)
+    A[:, 0] = A[:, 64] = 0
+    assert np.array_equal(S.group(2, A, Z[:4]), O.gt_pow(A, Z[:4]))
+    assert S.fallbacks() == 4                                  # elements of other norm: the generic routine
+    S.group_mode(True)
+    try:
+        assert np.array_equal(S.group(0, P, Z), O.g_mul(1, P, Z)) and S.fallbacks() == 0
+    finally:
+        S.group_mode(False)
+
+
+@pytest.mark.parametrize("key,name", [("d", "d_rand32.vec"), ("f", "f_rand16.vec"), ("g149", "g149_rand16.vec"), ("e", "e_rand6.vec"),
+                                      ("d201", "d201_rand12.vec"), ("f_256", "f_256_rand4.vec"), ("a1", "a1_rand6.vec")])
+def test_windowed_ladders_on_host(sims, oracles, key, name):
+    """ec_mul_win_lane over every field policy: G1 against the oracle, G2 on the twists against the complete ladder (which
+    the reference's vectors pin, test_g2_scalar_multiplication_on_host)."""
+    from conftest import PARAM_OF
+    S, O = sims[key], oracles[key]
+    v = golden(name)
+    r = _order(PARAM_OF.get(key, key))
+    zl = (r.bit_length() + 7) // 8
+    rng = np.random.default_rng(11)
+    ks = ([int.from_bytes(rng.bytes(zl), "big") % r for _ in range(3)] + [0, 1, 2, r - 1, r, (1 << (8 * zl)) - 1])[:v.n]
+    Z = np.stack([_be(k, zl) for k in ks])
+    n = len(ks)
+    S.fallbacks()
+    assert np.array_equal(S.group(0, v.g1[:n], Z), O.g_mul(1, v.g1[:n], Z))
+    assert 1 <= S.fallbacks() <= 3
+    if key not in ("e", "a1"):
+        got = S.g2_mul(v.g2[:n], Z)
+        S.group_mode(True)
+        try:
+            want = S.g2_mul(v.g2[:n], Z)
+        finally:
+            S.group_mode(False)
+        assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("key,name,group", [("d", "d_rand32.vec", 1), ("d", "d_rand32.vec", 3), ("f", "f_rand16.vec", 1), ("f", "f_rand16.vec", 2),
+                                            ("f", "f_rand16.vec", 3), ("a", "a_rand32.vec", 3)])
+def test_fixed_base_tables_on_host(sims, oracles, key, name, group):
+    """element_pp_init + element_pp_pow_zn (ec_pp_entry_lane / ec_pp_pow_lane, gt_pp_*): the table as the library's
+    kernels build it, powers against element_mul_zn / element_pow_zn of the same base."""
+    from conftest import PARAM_OF
+    S, O = sims[key], oracles[key]
+    v = golden(name)
+    r = _order(PARAM_OF.get(key, key))
+    zl = (r.bit_length() + 7) // 8
+    rng = np.random.default_rng(13)
+    ks = [int.from_bytes(rng.bytes(zl), "big") % r for _ in range(3)] + [0, 1, 255, 256, r - 1]
+    Z = np.stack([_be(k, zl) for k in ks])
+    base = {1: v.g1[1], 2: v.g2[1], 3: v.gt[1]}[group]
+    B = np.tile(base, (len(ks), 1))
+    got = S.element_pp(group, base, Z, zl)
+    if group == 2:
+        S.group_mode(True)
+        try:
+            want = S.g2_mul(B, Z)
+        finally:
+            S.group_mode(False)
+    else:
+        want = O.gt_pow(B, Z) if group == 3 else O.g_mul(1, B, Z)
+    assert np.array_equal(got, want)

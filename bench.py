@@ -28,6 +28,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 import pbc_amd  # noqa: E402  (the product; raises if libpbc_hip.so is missing)
+import bench_group  # noqa: E402  (the group operations as workloads: same contract, dispatched from main())
 
 
 def ensure_built(dist, local_rank):
@@ -177,7 +178,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="a", choices=sorted(WORKLOADS),
+    ap.add_argument("--workload", default="a", choices=sorted(WORKLOADS) + sorted(bench_group.GROUP_WORKLOADS),
                     help="default: the BASELINE.json metric config (2^20 Type-A pairings)")
     ap.add_argument("--log2n", type=int, default=None, help="units per GPU per step (with --strong: units of the whole job)")
     ap.add_argument("--strong", action="store_true",
@@ -190,6 +191,8 @@ def main():
                     help="skip the pinned-host -> host timing of the host-buffer entry point (reported beside `value`, never as it)")
     ap.add_argument("--host-path", action="store_true", help=argparse.SUPPRESS)     # round-1 spelling: now the default
     args = ap.parse_args()
+    if args.workload in bench_group.GROUP_WORKLOADS:
+        return bench_group.main(args, load_vec, ensure_built, MAC_PEAK)
     pname, fixture, k, dlog, desc = WORKLOADS[args.workload]
     if args.log2n is None:
         args.log2n = dlog

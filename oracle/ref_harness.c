@@ -226,6 +226,161 @@ static int cmd_bench(int argc, char **argv) {
   return 0;
 }
 
+/* benchg <param> <op> <n> <workers>: the group operations next to the pairing on the host cores, one forked worker per core
+ * (the loop of example/bls.c's steps, fresh inputs every iteration).  op: g1mul / g2mul (element_mul_zn with a random
+ * scalar), gtpow (element_pow_zn on a pairing value), hashg1 (element_from_hash of a 32-byte digest), g1pp / gtpp
+ * (element_pp_pow_zn after one element_pp_init outside the clock), blsverify (one signature check as example/bls.c:64-117
+ * does it: a hash and two pairings). */
+static int cmd_benchg(int argc, char **argv) {
+  if (argc < 5) { fprintf(stderr, "benchg <param> <op> <n> <workers>\n"); return 2; }
+  const char *op = argv[2];
+  int n = atoi(argv[3]), workers = atoi(argv[4]);
+  int fds[256][2];
+  if (workers > 256) workers = 256;
+  double t_all0 = now();
+  for (int w = 0; w < workers; w++) {
+    if (pipe(fds[w])) return 2;
+    pid_t pid = fork();
+    if (pid == 0) {
+      close(fds[w][0]);
+      pairing_t pairing; char type;
+      pbc_random_set_deterministic(1000u + (unsigned) w);
+      init_pairing(pairing, argv[1], &type);
+      element_t P, Q, R1, R2, k, gt, gto, sk, pk, sig, t1, t2;
+      element_pp_t pp;
+      element_init_G1(P, pairing); element_init_G1(R1, pairing); element_init_G1(sig, pairing);
+      element_init_G2(Q, pairing); element_init_G2(R2, pairing); element_init_G2(pk, pairing);
+      element_init_Zr(k, pairing); element_init_Zr(sk, pairing);
+      element_init_GT(gt, pairing); element_init_GT(gto, pairing); element_init_GT(t1, pairing); element_init_GT(t2, pairing);
+      element_random(P); element_random(Q); element_random(sk);
+      element_pairing(gt, P, Q);
+      element_pow_zn(pk, Q, sk);
+      unsigned char digest[32];
+      memset(digest, 0x5a, sizeof digest);
+      const int is_g1pp = !strcmp(op, "g1pp"), is_gtpp = !strcmp(op, "gtpp");
+      if (is_g1pp) element_pp_init(pp, P);
+      if (is_gtpp) element_pp_init(pp, gt);
+      unsigned bad = 0;
+      double t0 = now();
+      for (int i = 0; i < n; i++) {
+        digest[i & 31] = (unsigned char) (digest[i & 31] * 5 + i + w);
+        if (!strcmp(op, "g1mul")) { element_random(k); element_mul_zn(R1, P, k); element_add(P, P, R1); }
+        else if (!strcmp(op, "g2mul")) { element_random(k); element_mul_zn(R2, Q, k); element_add(Q, Q, R2); }
+        else if (!strcmp(op, "gtpow")) { element_random(k); element_pow_zn(gto, gt, k); element_mul(gt, gt, gto); }
+        else if (!strcmp(op, "hashg1")) { element_from_hash(R1, digest, 32); }
+        else if (is_g1pp) { element_random(k); element_pp_pow_zn(R1, k, pp); }
+        else if (is_gtpp) { element_random(k); element_pp_pow_zn(gto, k, pp); }
+        else if (!strcmp(op, "blsverify")) {
+          element_from_hash(R1, digest, 32);
+          if (i == 0) element_pow_zn(sig, R1, sk);       /* (signing is not what this loop times: one signature, re-made per digest below) */
+          element_pow_zn(sig, R1, sk);
+          element_pairing(t1, sig, Q);
+          element_pairing(t2, R1, pk);
+          bad += element_cmp(t1, t2) != 0;
+        } else _exit(4);
+      }
+      double dt = now() - t0;
+      if (bad) _exit(5);
+      if (write(fds[w][1], &dt, sizeof dt) != sizeof dt) _exit(3);
+      _exit(0);
+    }
+    close(fds[w][1]);
+  }
+  double sum_rate = 0, max_dt = 0;
+  for (int w = 0; w < workers; w++) {
+    double dt = 0;
+    if (read(fds[w][0], &dt, sizeof dt) != sizeof dt) { fprintf(stderr, "worker %d failed\n", w); return 3; }
+    sum_rate += n / dt;
+    if (dt > max_dt) max_dt = dt;
+  }
+  while (wait(NULL) > 0) {}
+  double wall = now() - t_all0;
+  printf("{\"units_per_s\": %.3f, \"per_core\": %.3f, \"workers\": %d, \"n_per_worker\": %d, \"op\": \"%s\", \"max_worker_s\": %.4f, \"wall_s\": %.4f}\n",
+         sum_rate, sum_rate / workers, workers, n, op, max_dt, wall);
+  return 0;
+}
+
+/* ppow <param> <group 1|2|3> <n> <seed> <out>: element_pp_init on one random element of G1 / G2 / GT (a pairing value) and
+ * element_pp_pow_zn for n random scalars (the last ones 0, 1, r - 1).  File: in1 = the base (one record, repeated n times),
+ * in2 = scalars, out = powers. */
+static int cmd_ppow(int argc, char **argv) {
+  if (argc < 6) { fprintf(stderr, "ppow <param> <group> <n> <seed> <out>\n"); return 2; }
+  int group = atoi(argv[2]), n = atoi(argv[3]);
+  pairing_t pairing; char type;
+  pbc_random_set_deterministic((unsigned) atoi(argv[4]));
+  init_pairing(pairing, argv[1], &type);
+  int lp = group == 1 ? pairing_length_in_bytes_G1(pairing) : group == 2 ? pairing_length_in_bytes_G2(pairing) : pairing_length_in_bytes_GT(pairing);
+  int lz = pairing_length_in_bytes_Zr(pairing);
+  unsigned char *in = malloc((size_t) n * lp), *zs = malloc((size_t) n * lz), *out = malloc((size_t) n * lp);
+  element_t B, R, k, P, Q;
+  element_pp_t pp;
+  element_init_G1(P, pairing); element_init_G2(Q, pairing);
+  if (group == 1) { element_init_G1(B, pairing); element_init_G1(R, pairing); element_random(B); }
+  else if (group == 2) { element_init_G2(B, pairing); element_init_G2(R, pairing); element_random(B); }
+  else { element_init_GT(B, pairing); element_init_GT(R, pairing); element_random(P); element_random(Q); element_pairing(B, P, Q); }
+  element_init_Zr(k, pairing);
+  element_pp_init(pp, B);
+  for (int i = 0; i < n; i++) {
+    element_random(k);
+    if (i == n - 3) element_set0(k);
+    if (i == n - 2) element_set1(k);
+    if (i == n - 1) { element_set1(k); element_neg(k, k); }
+    element_pp_pow_zn(R, k, pp);
+    element_to_bytes(in + (size_t) i * lp, B);
+    element_to_bytes(zs + (size_t) i * lz, k);
+    element_to_bytes(out + (size_t) i * lp, R);
+  }
+  element_pp_clear(pp);
+  FILE *fp = fopen(argv[5], "wb");
+  fwrite("PBCVEC01", 1, 8, fp);
+  w32(fp, (uint32_t) type); w32(fp, n); w32(fp, 1); w32(fp, lp); w32(fp, lz); w32(fp, lp);
+  fwrite(in, lp, n, fp); fwrite(zs, lz, n, fp); fwrite(out, lp, n, fp);
+  fclose(fp);
+  fprintf(stderr, "wrote %s: type %c group %d n=%d\n", argv[5], type, group, n);
+  return 0;
+}
+
+/* bls <param> <n> <seed> <out>: the flow of example/bls.c (:41-117) for n messages under one key: g random in G2, secret key
+ * in Zr, public key g^sk, h_i = element_from_hash(digest_i), sig_i = h_i^sk, each checked e(sig_i, g) == e(h_i, pk) here.
+ * File "PBCBLS01": u32 type, n, hlen, len G1, len G2, len Zr; digests; h_i; sig_i; g; pk; sk. */
+static int cmd_bls(int argc, char **argv) {
+  if (argc < 5) { fprintf(stderr, "bls <param> <n> <seed> <out>\n"); return 2; }
+  int n = atoi(argv[2]);
+  const int hlen = 32;
+  unsigned seed = (unsigned) atoi(argv[3]);
+  pairing_t pairing; char type;
+  pbc_random_set_deterministic(seed);
+  init_pairing(pairing, argv[1], &type);
+  int l1 = pairing_length_in_bytes_G1(pairing), l2 = pairing_length_in_bytes_G2(pairing), lz = pairing_length_in_bytes_Zr(pairing);
+  unsigned char *dg = malloc((size_t) n * hlen), *hs = malloc((size_t) n * l1), *sg = malloc((size_t) n * l1);
+  unsigned char *gb = malloc(l2), *pkb = malloc(l2), *skb = malloc(lz);
+  uint64_t st = 0x9e3779b97f4a7c15ull * (seed + 7);
+  for (size_t i = 0; i < (size_t) n * hlen; i++) { st ^= st << 13; st ^= st >> 7; st ^= st << 17; dg[i] = (unsigned char) (st >> 24); }
+  element_t g, pk, sk, h, sig, t1, t2;
+  element_init_G2(g, pairing); element_init_G2(pk, pairing); element_init_Zr(sk, pairing);
+  element_init_G1(h, pairing); element_init_G1(sig, pairing); element_init_GT(t1, pairing); element_init_GT(t2, pairing);
+  element_random(g); element_random(sk);
+  element_pow_zn(pk, g, sk);
+  for (int i = 0; i < n; i++) {
+    element_from_hash(h, dg + (size_t) i * hlen, hlen);
+    element_pow_zn(sig, h, sk);
+    element_pairing(t1, sig, g);
+    element_pairing(t2, h, pk);
+    if (element_cmp(t1, t2)) { fprintf(stderr, "signature %d does not verify\n", i); return 3; }
+    element_to_bytes(hs + (size_t) i * l1, h);
+    element_to_bytes(sg + (size_t) i * l1, sig);
+  }
+  element_to_bytes(gb, g); element_to_bytes(pkb, pk); element_to_bytes(skb, sk);
+  FILE *fp = fopen(argv[4], "wb");
+  fwrite("PBCBLS01", 1, 8, fp);
+  w32(fp, (uint32_t) type); w32(fp, n); w32(fp, hlen); w32(fp, l1); w32(fp, l2); w32(fp, lz);
+  fwrite(dg, hlen, n, fp); fwrite(hs, l1, n, fp); fwrite(sg, l1, n, fp);
+  fwrite(gb, l2, 1, fp); fwrite(pkb, l2, 1, fp); fwrite(skb, lz, 1, fp);
+  fclose(fp);
+  fprintf(stderr, "wrote %s: type %c n=%d\n", argv[4], type, n);
+  return 0;
+}
+
 /* hash <param> <n> <hlen> <seed> <out>: element_from_hash(G1) on n pseudo-random hlen-byte digests.
  * Vector file: in1 = digests (len1 = hlen), in2 empty (len2 = 0), out = G1 bytes (lenT = len G1). */
 /* gmul <param> <group 1|2> <n> <seed> <out>: out_i = [k_i] P_i (element_mul_zn) for random points of
@@ -537,6 +692,9 @@ int main(int argc, char **argv) {
   if (!strcmp(argv[1], "gen")) return cmd_gen(argc - 1, argv + 1);
   if (!strcmp(argv[1], "kat")) return cmd_kat(argc - 1, argv + 1);
   if (!strcmp(argv[1], "bench")) return cmd_bench(argc - 1, argv + 1);
+  if (!strcmp(argv[1], "benchg")) return cmd_benchg(argc - 1, argv + 1);
+  if (!strcmp(argv[1], "ppow")) return cmd_ppow(argc - 1, argv + 1);
+  if (!strcmp(argv[1], "bls")) return cmd_bls(argc - 1, argv + 1);
   if (!strcmp(argv[1], "hash")) return cmd_hash(argc - 1, argv + 1);
   if (!strcmp(argv[1], "gmul")) return cmd_gmul(argc - 1, argv + 1);
   if (!strcmp(argv[1], "compress")) return cmd_compress(argc - 1, argv + 1);

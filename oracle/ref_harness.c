@@ -301,7 +301,7 @@ static int cmd_benchg(int argc, char **argv) {
 }
 
 /* ppow <param> <group 1|2|3> <n> <seed> <out>: element_pp_init on one random element of G1 / G2 / GT (a pairing value) and
- * element_pp_pow_zn for n random scalars (the last ones 0, 1, r - 1).  File: in1 = the base (one record, repeated n times),
+ * element_pp_pow_zn for n random scalars (the last ones 0 -- GT only; 2 for the curve groups --, 1, r - 1).  File: in1 = the base (one record, repeated n times),
  * in2 = scalars, out = powers. */
 static int cmd_ppow(int argc, char **argv) {
   if (argc < 6) { fprintf(stderr, "ppow <param> <group> <n> <seed> <out>\n"); return 2; }
@@ -322,7 +322,9 @@ static int cmd_ppow(int argc, char **argv) {
   element_pp_init(pp, B);
   for (int i = 0; i < n; i++) {
     element_random(k);
-    if (i == n - 3) element_set0(k);
+    /* (power 0 only in GT: the identity of a curve group has no wire format -- curve_to_bytes, ecc/curve.c:595-601, writes
+     * whatever coordinates the element held before) */
+    if (i == n - 3) { if (group == 3) element_set0(k); else element_set_si(k, 2); }
     if (i == n - 2) element_set1(k);
     if (i == n - 1) { element_set1(k); element_neg(k, k); }
     element_pp_pow_zn(R, k, pp);

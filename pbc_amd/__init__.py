@@ -174,7 +174,10 @@ class Pairing:
 
     def clear(self):
         if getattr(self, "_h", None):
-            lib().pbc_hip_pairing_clear(self._h)
+            try:
+                lib().pbc_hip_pairing_clear(self._h)
+            except TypeError:          # interpreter shutdown: the module's globals are gone
+                pass
             self._h = None
 
     __del__ = clear
@@ -490,7 +493,10 @@ class ElementPP:
 
     def clear(self):
         if getattr(self, "_h", None):
-            lib().pbc_hip_element_pp_clear(self._h)
+            try:
+                lib().pbc_hip_element_pp_clear(self._h)
+            except TypeError:          # interpreter shutdown: the module's globals are gone
+                pass
             self._h = None
 
     __del__ = clear

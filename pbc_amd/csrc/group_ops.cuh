@@ -473,7 +473,7 @@ PBC_DEV void ec_pp_entry_lane(uint32_t *tab, uint8_t *flags, const uint8_t *base
   typedef typename F::el el;
   const int row = (int) (u / kPpRowLen), w = (int) (u % kPpRowLen) + 1;
   const int NB = F::bytes();
-  uint8_t zb[4 * kScalarWords], o[8 * F::WORDS_EL];
+  __attribute__((aligned(16))) uint8_t zb[4 * kScalarWords], o[8 * F::WORDS_EL];      // (records are read and written with word accesses)
   for (int i = 0; i < zlen + 1; i++) zb[i] = 0;
   if (row < zlen) zb[zlen - row] = (uint8_t) w;      // a scalar of zlen + 1 bytes (big-endian): w 2^(8 row)
   ec_mul_lane<F>(o, base, zb, zlen + 1);

@@ -201,7 +201,9 @@ def test_device_set_with_pinned_buffers_products_and_many_chunks_one_physical_de
     assert L.pbc_hip_element_prod_pairing_batch(H._h, p1, p1, p2, n, k) == 0
     assert np.array_equal(a1[:n * v.lenT].reshape(n, -1), want)
     a1[:] = g1.reshape(-1)
-    # a range that is page-locked only at its start (hipHostRegister over the first half of a pageable array)
+    # a range that is page-locked only at its start (hipHostRegister over the first half of a pageable array): the library
+    # must not take it for page-locked memory (its last byte is not); it goes the staged route, where the HIP runtime's own
+    # copy may refuse a half-registered range -- either the right bytes or a clean error, never a fault in a kernel
     import torch
     big = np.zeros(g2.size + 8192, np.uint8)
     off = (-big.ctypes.data) % 4096
@@ -213,10 +215,16 @@ def test_device_set_with_pinned_buffers_products_and_many_chunks_one_physical_de
         assert int(rt.cudaHostRegister(view.ctypes.data, half, 0)) == 0
         try:
             at[:] = 0
-            assert L.pbc_hip_element_prod_pairing_batch(H._h, pt, p1, ctypes.c_void_p(view.ctypes.data), n, k) == 0
-            assert np.array_equal(at.reshape(n, -1), want)
+            rc = L.pbc_hip_element_prod_pairing_batch(H._h, pt, p1, ctypes.c_void_p(view.ctypes.data), n, k)
+            assert rc in (0, 1)
+            if rc == 0:
+                assert np.array_equal(at.reshape(n, -1), want)
+            else:
+                assert "copy failed" in pbc_amd._err()
         finally:
             rt.cudaHostUnregister(view.ctypes.data)
+        assert L.pbc_hip_element_prod_pairing_batch(H._h, pt, p1, p2, n, k) == 0      # the object is intact afterwards
+        assert np.array_equal(at.reshape(n, -1), want)
     H.release_workspaces()                                                       # frees chunk buffers and workspaces; the next call rebuilds them
     assert np.array_equal(H.element_prod_pairing(g1, g2, k), want)
     for p in bufs:

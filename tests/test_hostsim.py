@@ -467,3 +467,10 @@ def test_fixed_base_tables_on_host(sims, oracles, key, name, group):
     else:
         want = O.gt_pow(B, Z) if group == 3 else O.g_mul(1, B, Z)
     assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("key,pname,group", [("d", "d159", 1), ("f", "f", 1), ("f", "f", 3), ("a", "a", 3)])
+def test_element_pp_reference_vectors_on_host(sims, key, pname, group):
+    """the reference's element_pp_pow_zn outputs (ref_tool ppow) through the table routines of the kernel source"""
+    v = golden("%s_pp%dpow12.vec" % (pname, group))
+    assert np.array_equal(sims[key].element_pp(group, v.g1[0], v.g2, v.len2), v.gt)

@@ -184,6 +184,9 @@ def main():
     ap.add_argument("--strong", action="store_true",
                     help="the 2^log2n units are the whole job, range-split over the ranks (BASELINE config 5: "
                          "--workload a-prod16 --strong --gpus 8 = 2^18 products sharded across 8 GPUs)")
+    ap.add_argument("--sweep", action="store_true",
+                    help="instead of the bench line: launch time against batch size, n = 2^10 ... 2^log2n in powers of two plus one chip "
+                         "residency (1024 workgroups x 128 lanes) -1 / +0 / +1, on one GPU; one JSON line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--param-extra", default="", help="lines appended to the parameter text (the library's A/B switches, "
                     "e.g. 'hip_prod_shared=1', comma-separated); reported in config.param_extra")
@@ -303,6 +306,34 @@ def main():
             sys.exit("bench.py: product of pairings differs from the product of single pairings (rank %d) -- refusing to time" % rank)
         gated_units = m
 
+    if args.sweep:
+        # launch time against batch size (the resident kernels' time grows in steps of one chip residency; below it a
+        # launch runs at partial occupancy): events around `steps` launches of the first m units
+        res = 1024 * 128
+        sizes = sorted(set([1 << e for e in range(10, args.log2n + 1)] + [m for m in (res - 1, res, res + 1, 2 * res, 2 * res + 1) if m <= n]))
+        rows = []
+        for m in sizes:
+            def step_m(m=m):
+                if pp is not None:
+                    pp.apply_dev(GT.data_ptr(), G2.data_ptr(), m, stream.cuda_stream)
+                elif k == 1:
+                    pairing.element_pairing_dev(GT.data_ptr(), G1.data_ptr(), G2.data_ptr(), m, stream.cuda_stream)
+                else:
+                    pairing.element_prod_pairing_dev(GT.data_ptr(), G1.data_ptr(), G2.data_ptr(), m, k, stream.cuda_stream)
+            step_m()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            for _ in range(args.steps):
+                step_m()
+            e1.record(stream)
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / args.steps
+            rows.append({"n": m, "ms": round(ms, 4), "units_per_s": round(m / ms * 1e3, 1)})
+        if rank == 0:
+            print(json.dumps({"sweep": args.workload, "param_extra": args.param_extra, "unit": "pairings/s" if k == 1 else "products/s",
+                              "steps": args.steps, "rows": rows}), flush=True)
+        return
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     sync_all()
     t0 = time.perf_counter()

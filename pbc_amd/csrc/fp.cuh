@@ -65,6 +65,7 @@ struct fp {
 // 512-bit type a field, 33 words = the 1033-bit type a1 field.
 #define PBC_FOR_EACH_N(X) X(5) X(6) X(7) X(8) X(16) X(33)
 constexpr int KOFF_CURVE = 0, KOFF_TYPE = 704, KOFF_XS = 2192, KOFF_END = 2560;
+constexpr int KOFF_OPT = KOFF_END - 4;    // the last word of the block: per-launch options (bit 0: no time-sliced priorities, pbc_fair_tick)
 template <int N>
 struct alignas(16) KArgs {
   FpK<N> fp;
@@ -96,6 +97,7 @@ template <int N> PBC_DEV const FpK<N> &fpk() { return *reinterpret_cast<const Fp
 template <int BIT>
 PBC_DEV void pbc_fair_tick() {
 #if !defined(PBC_HOSTSIM) && !defined(PBC_NO_FAIR)
+  if (*reinterpret_cast<const uint32_t *>(pbc_kargs_base() + (KSEG - KOFF_END + KOFF_OPT)) & 1u) return;    // "hip_no_fair 1"
   uint32_t hw;
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
   const uint64_t t = __builtin_readcyclecounter();

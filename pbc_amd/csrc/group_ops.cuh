@@ -993,7 +993,7 @@ struct ExtSqrtK {
   int ebits, tbits, s;
   uint32_t c[40];                      // z^T (Montgomery words, coefficient-major); derived on the device
 };
-static_assert(sizeof(ExtSqrtK) <= KOFF_END - KOFF_XS, "constant block layout");
+static_assert(sizeof(ExtSqrtK) <= KOFF_OPT - KOFF_XS, "constant block layout");
 #define c_xs (pbc::kconst<pbc::ExtSqrtK, pbc::KOFF_XS>())
 
 template <class F>

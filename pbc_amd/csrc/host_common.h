@@ -74,7 +74,21 @@ constexpr int kBlock = 128;
 // data-independent, so equal shares finish together.  Measured on the other kernels (types a, d, products,
 // preprocessed pairings: 8 or more rounds, or LDS to spare): 3 - 4 % SLOWER than one workgroup per 128 units -- they keep
 // the plain grid (profiles/r03_notes.md).
-#define PBC_RESIDENT_LOOP(n) for (size_t vb = blockIdx.x, nvb_ = ((n) + kBlock - 1) / kBlock; vb < nvb_; vb += gridDim.x)
+// Which 64-unit block a wave works on next: a fixed stride over the grid (ctr == null; iteration `it` of workgroup b's wave w
+// takes block (b + it gridDim) 2 + w -- lane t of the workgroup works on unit (b + it gridDim) 128 + t), or the next value
+// of a per-launch counter ("hip_dynamic 1": waves that finish early fetch more; control flow stays data-independent).
+static __device__ __forceinline__ size_t pbc_unit_block(unsigned *ctr, size_t it) {
+  unsigned v;
+  if (ctr) {
+    v = 0;
+    if ((threadIdx.x & 63) == 0) v = atomicAdd(ctr, 1u);
+  } else {
+    v = (unsigned) (((size_t) blockIdx.x + it * gridDim.x) * (kBlock / 64) + (threadIdx.x >> 6));
+  }
+  return (size_t) (unsigned) __builtin_amdgcn_readfirstlane((int) v);
+}
+#define PBC_RESIDENT_LOOP(n, ctr) for (size_t it_ = 0, nvb_ = ((n) + 63) / 64, vb = pbc_unit_block(ctr, 0); vb < nvb_; vb = pbc_unit_block(ctr, ++it_))
+#define PBC_UNIT_INDEX (vb * 64 + (threadIdx.x & 63))
 static_assert(kBlock == D_LANES, "pairing_d.cuh sizes its LDS state for 128-lane workgroups");
 #ifndef PBC_DF_WAVES
 #define PBC_DF_WAVES 2
@@ -120,9 +134,10 @@ static_assert(kBlock == D_LANES, "pairing_d.cuh sizes its LDS state for 128-lane
 
 // the constant block of an object, passed by value as the LAST argument of every kernel (fp.cuh, "KArgs")
 template <int N>
-static KArgs<N> kargs(const pbc_hip_pairing_s *P, bool for_pairing = false) {
+static KArgs<N> kargs(const pbc_hip_pairing_s *P, bool for_pairing = false, bool no_fair = false) {
   KArgs<N> K;
   fill_kargs<N>(P, K, for_pairing);
+  if (no_fair) { const uint32_t opt = 1u; memcpy(K.head + KOFF_OPT, &opt, 4); }    // this launch without time-sliced priorities
   return K;
 }
 
@@ -140,6 +155,7 @@ static KArgs<N> kargs(const pbc_hip_pairing_s *P, bool for_pairing = false) {
 // pbc_hip.hip
 int ensure_derived(pbc_hip_pairing_s *P, hipStream_t s);        // self-test + device-side derivation of an object's constants, once
 unsigned resident_grid(const pbc_hip_pairing_s *P, const void *kernel, size_t n);
+unsigned *unit_counter(pbc_hip_pairing_s *P, hipStream_t s);   // "hip_dynamic 1": a zeroed per-launch counter (enqueued on s); null otherwise
 #define PBC_RGRID(...) resident_grid(P, reinterpret_cast<const void *>(&__VA_ARGS__), n)
 void *pinned_dev_ptr(const void *host, size_t bytes, bool shared);
 bool ranges_overlap(const void *a, size_t na, const void *b, size_t nb);

@@ -44,6 +44,8 @@ struct pbc_hip_pairing_s {
   bool a_generic;            // type a outside the 64-byte fast path: runs on the type a1 kernels
   bool a_prod_shared;        // type a fast path, products: "hip_prod_shared 1" keeps one product per lane (a_prod_pairing_lane)
   bool zero_copy;            // host-buffer entry points: kernels read / write pinned caller buffers in place ("hip_zero_copy 0/1")
+  bool dynamic;              // resident launches fetch their units from a per-launch counter instead of a fixed stride ("hip_dynamic 1")
+  bool no_fair;              // no time-sliced wave priorities (fp.cuh pbc_fair_tick; "hip_no_fair 1")
   bool group_slow;           // group operations: only the complete ladders ("hip_group_slow 1": tests, A/B)
   int resident_slots;        // > 0: workgroups of a resident launch instead of the occupancy query ("hip_resident_slots N", tests)
   size_t host_chunk;         // host-buffer entry points: units per chunk when the parameter text says "hip_host_chunk N" (0: default)
@@ -76,6 +78,7 @@ struct pbc_hip_pairing_s {
   } hash;
   ExtSqrtK xs;               // square roots in the field of the G2 twist (types d, g, f); xs.c derived on first use
   bool xs_ready;
+  void *counters;            // library only: the unit counters of dynamic resident launches (pbc_hip.hip unit_counter)
   void *host_ctx;            // library only: per-device streams and chunk buffers of the host-buffer path (pbc_hip.hip)
   std::string param_text;    // the parameter text the object was built from (text formats: pbc_hip_param_snprint, host_text.h)
 };
@@ -631,5 +634,7 @@ static void fill_kargs(const pbc_hip_pairing_s *P, KArgs<N> &K, bool for_pairing
   else if (P->type == 'f') memcpy(K.head + KOFF_TYPE, for_pairing && P->f_bm1 ? &P->fconst_i : &P->fconst, sizeof P->fconst);
   else if (P->type == 'e') memcpy(K.head + KOFF_TYPE, &P->econst, sizeof P->econst);
   memcpy(K.head + KOFF_XS, &P->xs, sizeof P->xs);
+  const uint32_t opt = P->no_fair ? 1u : 0u;
+  memcpy(K.head + KOFF_OPT, &opt, 4);
   K.fp = host_fpk<N>(P);
 }

@@ -28,11 +28,14 @@
 #define PBC_D_FAIR_BIT 21
 #endif
 namespace pbc {
-// Resident workgroups + time-sliced priorities (pbc_hip.hip, fp.cuh) pay for the 7-word fields only (same-box A/B, ms per
-// 2^18 launch: d201 41.6 -> 32.8; but d159 14.9 -> 16.2, d190 31.5 -> 58.4, 16-term products of d159 160 -> 185; the type g
-// instantiation faults with the loop around its body): a per-instantiation choice.
+// Resident workgroups + time-sliced priorities (host_common.h, fp.cuh): same-box A/B, ms per 2^18 launch -- round 3: d201
+// 41.6 -> 32.8, d190 31.5 -> 58.4, 16-term products of d159 160 -> 185, the type g instantiation faults with the loop around
+// its body; d159 single pairings: 14.9 -> 16.2 then, 14.45 -> 14.00 in round 4 (profiles/r04_notes.md) and, unlike the
+// plain grid, the same on boxes whose dispatch rounds do not pack (14.5 / 17.5 ms).  A per-instantiation
+// choice, and for the 5-word field per launch: single pairings and pairing_pp_apply resident, products on the plain grid
+// with the priorities switched off for that launch (pbc_hip_d.hip).
 #ifndef PBC_D_RES5
-#define PBC_D_RES5 0                   // experiment switch: the 5-word d = 3 instantiation as well
+#define PBC_D_RES5 1
 #endif
 template <int N, int DEG> constexpr bool kDResident = (N == 7 || (N == 5 && PBC_D_RES5)) && DEG == 3;
 

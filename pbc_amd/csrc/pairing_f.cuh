@@ -43,6 +43,9 @@
 #ifndef PBC_F_BY
 #define PBC_F_BY 7
 #endif
+#ifndef PBC_F_PREFETCH
+#define PBC_F_PREFETCH 1               // one-area layout: the buffered result coefficients are read back before the last ones are computed
+#endif
 #ifndef PBC_F_LINE_LIMB
 #define PBC_F_LINE_LIMB 1              // f_line_mul_lds: the line's pre-multiplication by Q and -alpha in limb form (0: word-form calls)
 #endif
@@ -502,6 +505,7 @@ static __device__ __noinline__ void f_line_mul(f12 *v, v5 va, v5 vb, v5 vc, cons
 // of 72 KB of LDS per workgroup: one wave per SIMD.
 static constexpr bool kLdsMiller = FL <= 6;       // (the 8-word fields on this path, one area at one wave per SIMD: 1.25 M against 1.37 M pairings/s)
 static constexpr bool kOneArea = kF12Bufs<ND> == 1;
+static constexpr bool kPrefetch = kOneArea && PBC_F_PREFETCH != 0;
 static PBC_DEV int next_area(int cur) { return kOneArea ? 0 : cur ^ 1; }
 // Where the coefficients of a result go while the operand area is still being read.  Two areas: straight into the
 // other one.  One area (the default: 36 KB of LDS per workgroup, so that two waves share a SIMD -- a single wave gets a
@@ -517,6 +521,34 @@ struct OutArea {
       for (int l = 0; l < FL; l++) buf[(c * 2 + part) * FL + l] = a.l[l];
     } else {
       ldsf_put(c, part, a, dst);
+    }
+  }
+  // The buffered coefficients back into registers BEFORE the last coefficients of an operation are computed: the loads'
+  // latency (the buffers of 2048 resident waves do not fit the L2) passes under a few hundred multiply-adds instead of
+  // stalling the wave at the end of the operation (PBC_F_PREFETCH 1; the scheduling barrier keeps the loads where they are)
+  template <int NW>
+  PBC_DEV void prefetch(uint32_t (&pre)[NW]) {
+    if constexpr (kOneArea) {
+#pragma unroll
+      for (int w = 0; w < NW; w++) pre[w] = buf[w];
+#ifndef PBC_HOSTSIM
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+    }
+  }
+  template <int NW>
+  PBC_DEV void finish_from(const uint32_t (&pre)[NW]) {
+    if constexpr (kOneArea) {
+#ifndef PBC_HOSTSIM
+      __builtin_amdgcn_sched_barrier(0);         // (or the stores -- and with them the wait for the loads -- are scheduled up into the computation)
+#endif
+#pragma unroll
+      for (int c = 0; c < NW / FL; c++) {
+        fl<ND> t;
+#pragma unroll
+        for (int l = 0; l < FL; l++) t.l[l] = pre[c * FL + l];
+        ldsf_put(c >> 1, c & 1, t, 0);
+      }
     }
   }
   // only the first `ncoef` coefficients went through the buffer (the sparse line product writes the rest in place)
@@ -565,7 +597,7 @@ static __device__ __noinline__ void f12_sqr_lds(int cur) {
     for (int i = 0; i < 6; i++) mul_beta(by[i], ldsf_get(i, 1, cur));
   }
 #pragma nounroll
-  for (int kk = 0; kk < 6; kk++) {
+  for (int kk = 0; kk < (kPrefetch ? 5 : 6); kk++) {
     fl<ND> t6x, t6y;
     wide<ND> Wx, Wy;
 #pragma nounroll
@@ -621,7 +653,38 @@ static __device__ __noinline__ void f12_sqr_lds(int cur) {
       }
     }
   }
-  O.finish(4);
+  if constexpr (kPrefetch) {
+    // coefficient 5 apart (the cross pairs (0,5), (1,4), (2,3); no fold), with the buffered coefficients 0-3 on their way
+    // back into registers meanwhile
+    uint32_t pre[8 * FL];
+    O.prefetch(pre);
+    wide<ND> Wx, Wy;
+    wide_zero<ND>(Wx);
+    wide_zero<ND>(Wy);
+    int units = 0;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      if (units + 4 > kCap) { wide_guard<1>(Wx, Wy); units = 1; }
+      const fl<ND> ax = ldsf_get(i, 0, cur), ay = ldsf_get(i, 1, cur);
+      fl<ND> byi, b2;
+      if constexpr (kByRecompute) mul_beta(byi, ay); else byi = by[i];
+      limbs_dbl<ND>(b2, ldsf_get(5 - i, 0, cur));
+      wide_mac<ND>(Wx, ax, b2);
+      wide_mac<ND>(Wy, ay, b2);
+      limbs_dbl<ND>(b2, ldsf_get(5 - i, 1, cur));
+      wide_mac<ND>(Wx, byi, b2);
+      wide_mac<ND>(Wy, ax, b2);
+      units += 4;
+    }
+    fl<ND> ox, oy;
+    wide_reduce<ND>(ox, Wx);
+    wide_reduce<ND>(oy, Wy);
+    ldsf_put(5, 0, ox, 0);                       // every read of the operand is done
+    ldsf_put(5, 1, oy, 0);
+    O.finish_from(pre);
+  } else {
+    O.finish(4);
+  }
   if constexpr (kOneArea) { ldsf_put(4, 0, hx, 0); ldsf_put(4, 1, hy, 0); }
 }
 // area `cur` times (a Qx X^4 + b Qy X^3 + c) into area 1 - cur (f_miller_evalfn, f_param.c:109-149): the formulas of
@@ -664,32 +727,37 @@ static __device__ __noinline__ void f_line_mul_lds(int cur, v5 va, v5 vb, v5 vc,
     g2l_make(Bq, bq);
     g2l_make(Bqn, bqn);
   }
+  uint32_t pre[kPrefetch ? 6 * FL : 1];
 #pragma nounroll
-  for (int i = 0; i < 6; i++) {
-    int j = i + 2, k = i + 3;          // j = i - 4 mod 6, k = i - 3 mod 6
-    bool wj = true, wk = true;         // wrapped (needs negalpha) unless i >= 4 / i >= 3
-    if (j >= 6) { j -= 6; wj = false; }
-    if (k >= 6) { k -= 6; wk = false; }
-    g2l fa, fb;
-    g2l_sel(fa, Aq, Aqn, wj);
-    g2l_sel(fb, Bq, Bqn, wk);
-    const fl<ND> vix = ldsf_get(i, 0, cur), viy = ldsf_get(i, 1, cur), vjx = ldsf_get(j, 0, cur), vjy = ldsf_get(j, 1, cur),
-                 vkx = ldsf_get(k, 0, cur), vky = ldsf_get(k, 1, cur);
-    fl<ND> t;
-    {
-      const fl<ND> x[5] = {cl, fa.x, fa.by, fb.x, fb.by}, y[5] = {vix, vjx, vjy, vkx, vky};
-      sop_limbs<ND, 5>(t, x, y);
-      if (kOneArea && i >= 3) ldsf_put(i, 0, t, 0); else O.put(i, 0, t);
-    }
-    {
-      const fl<ND> x[5] = {cl, fa.x, fa.y, fb.x, fb.y}, y[5] = {viy, vjy, vjx, vky, vkx};
-      sop_limbs<ND, 5>(t, x, y);
-      if (kOneArea && i >= 3) ldsf_put(i, 1, t, 0); else O.put(i, 1, t);
+  for (int half = 0; half < 2; half++) {
+    if constexpr (kPrefetch) { if (half == 1) O.prefetch(pre); }      // outputs 0-2 come back while 3-5 are computed
+#pragma nounroll
+    for (int i = 3 * half; i < 3 * half + 3; i++) {
+      int j = i + 2, k = i + 3;          // j = i - 4 mod 6, k = i - 3 mod 6
+      bool wj = true, wk = true;         // wrapped (needs negalpha) unless i >= 4 / i >= 3
+      if (j >= 6) { j -= 6; wj = false; }
+      if (k >= 6) { k -= 6; wk = false; }
+      g2l fa, fb;
+      g2l_sel(fa, Aq, Aqn, wj);
+      g2l_sel(fb, Bq, Bqn, wk);
+      const fl<ND> vix = ldsf_get(i, 0, cur), viy = ldsf_get(i, 1, cur), vjx = ldsf_get(j, 0, cur), vjy = ldsf_get(j, 1, cur),
+                   vkx = ldsf_get(k, 0, cur), vky = ldsf_get(k, 1, cur);
+      fl<ND> t;
+      {
+        const fl<ND> x[5] = {cl, fa.x, fa.by, fb.x, fb.by}, y[5] = {vix, vjx, vjy, vkx, vky};
+        sop_limbs<ND, 5>(t, x, y);
+        if (kOneArea && i >= 3) ldsf_put(i, 0, t, 0); else O.put(i, 0, t);
+      }
+      {
+        const fl<ND> x[5] = {cl, fa.x, fa.y, fb.x, fb.y}, y[5] = {viy, vjy, vjx, vky, vkx};
+        sop_limbs<ND, 5>(t, x, y);
+        if (kOneArea && i >= 3) ldsf_put(i, 1, t, 0); else O.put(i, 1, t);
+      }
     }
   }
   // (one area: coefficient s is read by the outputs s, s - 2 and s - 3 mod 6 only, and every operand of an output is in
   // registers before its first component is stored -- outputs 3, 4, 5 overwrite their own slots, 0, 1, 2 wait in the buffer)
-  O.finish(3);
+  if constexpr (kPrefetch) O.finish_from(pre); else O.finish(3);
 }
 // area `cur` times the private-memory element b into area 1 - cur (b's limb forms in registers with compile-time
 // indices, the accumulator's coefficients from LDS; fold as in f12_sqr_lds)

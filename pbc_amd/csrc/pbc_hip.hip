@@ -296,6 +296,11 @@ extern "C" int pbc_hip_pairing_init_set_buf(pbc_hip_pairing_t **out, const char 
     int rs = 0;                        // "hip_resident_slots N": workgroups of a resident launch (tests: forces several units per lane on small batches)
     pbc_host::param_int(param, len, "hip_resident_slots", rs);
     P->resident_slots = rs > 0 ? rs : 0;
+    int dy = 0, nf = 0;                // "hip_dynamic 1": resident launches fetch units from a counter; "hip_no_fair 1": no time-sliced priorities
+    pbc_host::param_int(param, len, "hip_dynamic", dy);
+    pbc_host::param_int(param, len, "hip_no_fair", nf);
+    P->dynamic = dy != 0;
+    P->no_fair = nf != 0;
     int gs = 0;                        // "hip_group_slow 1": element_mul_zn / GT pow_zn on the complete bit-by-bit ladders only
     pbc_host::param_int(param, len, "hip_group_slow", gs);
     P->group_slow = gs != 0;
@@ -452,6 +457,31 @@ unsigned resident_grid(const pbc_hip_pairing_s *P, const void *kernel, size_t n)
   return (unsigned) (nvb < slots ? nvb : slots);
 }
 
+// "hip_dynamic 1": the counter a resident launch fetches its 64-unit blocks from -- one of a small ring of device words
+// per (object, device), zeroed on the launch's stream right before the kernel (a ring, so that launches in flight on
+// different streams do not share one)
+constexpr int kCounters = 64;
+struct CounterRing { int dev; unsigned *p; unsigned next; };
+static std::mutex g_ctr_mu;
+unsigned *unit_counter(pbc_hip_pairing_s *P, hipStream_t s) {
+  if (!P->dynamic) return nullptr;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lk(g_ctr_mu);
+  if (!P->counters) P->counters = new std::vector<CounterRing>();
+  auto *rings = static_cast<std::vector<CounterRing> *>(P->counters);
+  CounterRing *r = nullptr;
+  for (auto &x : *rings) if (x.dev == dev) r = &x;
+  if (!r) {
+    unsigned *p = nullptr;
+    if (hipMalloc(&p, kCounters * sizeof(unsigned)) != hipSuccess) return nullptr;     // (falls back to the fixed stride)
+    rings->push_back(CounterRing{dev, p, 0});
+    r = &rings->back();
+  }
+  unsigned *c = r->p + (r->next++ % kCounters);
+  if (hipMemsetAsync(c, 0, sizeof(unsigned), s) != hipSuccess) return nullptr;
+  return c;
+}
 static int launch_prod(pbc_hip_pairing_s *P, void *d_gt, const void *d_g1, const void *d_g2, size_t n, int k,
                        hipStream_t s, bool upload, const OwnWs *own = nullptr);
 static int launch_pairing(pbc_hip_pairing_s *P, void *d_gt, const void *d_g1, const void *d_g2, size_t n,
@@ -552,6 +582,12 @@ static void devctx_release(DevCtx &c) {
   c.dev = -1;
 }
 static void hostctx_free(pbc_hip_pairing_s *P) {
+  if (P->counters) {
+    auto *rings = static_cast<std::vector<CounterRing> *>(P->counters);
+    for (auto &x : *rings) { DeviceGuard guard(x.dev); (void) hipDeviceSynchronize(); (void) hipFree(x.p); }
+    delete rings;
+    P->counters = nullptr;
+  }
   HostCtx *H = static_cast<HostCtx *>(P->host_ctx);
   if (!H) return;
   for (WsEnt &w : H->ws) {

@@ -6,9 +6,9 @@
 // F_q elements are in limb form throughout (pairing_al.cuh).
 template <int N>
 __global__ void __launch_bounds__(kBlock, PBC_A_WAVES) al_pairing_kernel(uint8_t *gt, const uint8_t *g1,
-                                                             const uint8_t *g2, size_t n, KArgs<N> ka) {
-  PBC_RESIDENT_LOOP(n) {
-    size_t idx = vb * kBlock + threadIdx.x;
+                                                             const uint8_t *g2, size_t n, unsigned *ctr, KArgs<N> ka) {
+  PBC_RESIDENT_LOOP(n, ctr) {
+    size_t idx = PBC_UNIT_INDEX;
     size_t ld = idx < n ? idx : n - 1;
     constexpr int L = 8 * N;
     __attribute__((aligned(16))) uint8_t out[L];
@@ -27,9 +27,9 @@ __global__ void __launch_bounds__(kBlock, PBC_A_WAVES) al_pairing_kernel(uint8_t
 // final exponentiation (one product per lane).
 template <int N>
 __global__ void __launch_bounds__(kBlock, PBC_A_WAVES) al_miller_kernel(uint4 *ws, const uint8_t *g1, const uint8_t *g2,
-                                                                        size_t n, KArgs<N> ka) {
-  PBC_RESIDENT_LOOP(n) {
-    size_t idx = vb * kBlock + threadIdx.x;
+                                                                        size_t n, unsigned *ctr, KArgs<N> ka) {
+  PBC_RESIDENT_LOOP(n, ctr) {
+    size_t idx = PBC_UNIT_INDEX;
     size_t ld = idx < n ? idx : n - 1;
     constexpr int L = 8 * N;
     uint4 rec[AL<N>::MREC];
@@ -42,9 +42,9 @@ __global__ void __launch_bounds__(kBlock, PBC_A_WAVES) al_miller_kernel(uint4 *w
 }
 template <int N>
 __global__ void __launch_bounds__(kBlock, PBC_A_WAVES) al_prod_finish_kernel(uint8_t *gt, const uint4 *ws, size_t n, int k,
-                                                                             KArgs<N> ka) {
-  PBC_RESIDENT_LOOP(n) {
-    size_t idx = vb * kBlock + threadIdx.x;
+                                                                             unsigned *ctr, KArgs<N> ka) {
+  PBC_RESIDENT_LOOP(n, ctr) {
+    size_t idx = PBC_UNIT_INDEX;
     size_t ld = idx < n ? idx : n - 1;
     constexpr int L = 8 * N;
     __attribute__((aligned(16))) uint8_t out[L];
@@ -62,9 +62,9 @@ __global__ void __launch_bounds__(kBlock, PBC_A_WAVES) al_prod_finish_kernel(uin
 // workspace for the per-term Miller state: k x 24 x 128 uint4 per workgroup (a_prod_pairing_lane).
 template <int N>
 __global__ void __launch_bounds__(kBlock, PBC_A_WAVES) a_prod_pairing_kernel(uint8_t *gt, const uint8_t *g1,
-                                                                 const uint8_t *g2, size_t n, int k, uint4 *ws, KArgs<N> ka) {
-  PBC_RESIDENT_LOOP(n) {
-    size_t idx = vb * kBlock + threadIdx.x;
+                                                                 const uint8_t *g2, size_t n, int k, uint4 *ws, unsigned *ctr, KArgs<N> ka) {
+  PBC_RESIDENT_LOOP(n, ctr) {
+    size_t idx = PBC_UNIT_INDEX;
     size_t ld = idx < n ? idx : n - 1;
     constexpr int L = 8 * N;
     __attribute__((aligned(16))) uint8_t out[L];
@@ -132,9 +132,9 @@ __global__ void a_pp_init_kernel(uint32_t *tab, uint32_t *valid, const uint8_t *
 template <int N>
 __global__ void __launch_bounds__(kBlock, PBC_A_WAVES) al_pp_apply_kernel(uint8_t *gt, const uint32_t *__restrict__ tab,
                                                                            const uint32_t *__restrict__ valid,
-                                                                           const uint8_t *g2, size_t n, KArgs<N> ka) {
-  PBC_RESIDENT_LOOP(n) {
-    size_t idx = vb * kBlock + threadIdx.x;
+                                                                           const uint8_t *g2, size_t n, unsigned *ctr, KArgs<N> ka) {
+  PBC_RESIDENT_LOOP(n, ctr) {
+    size_t idx = PBC_UNIT_INDEX;
     size_t ld = idx < n ? idx : n - 1;
     constexpr int L = 8 * N;
     __attribute__((aligned(16))) uint8_t out[L];
@@ -195,7 +195,7 @@ int launch_a(pbc_hip_pairing_s *P, void *d_gt, const void *d_g1, const void *d_g
   unsigned grid = (unsigned) ((n + kBlock - 1) / kBlock);
   if (P->type == 'a' && !P->a_generic && k == 1) {
     hipLaunchKernelGGL(al_pairing_kernel<16>, dim3(PBC_RGRID(al_pairing_kernel<16>)), dim3(kBlock), 0, s, (uint8_t *) d_gt,
-                       (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, kargs<16>(P));
+                       (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, unit_counter(P, s), kargs<16>(P));
   } else if (P->type == 'a' && !P->a_generic && !P->a_prod_shared) {
     // one term per lane, then one product per lane; at most a_prod_chunk terms in flight (their records: 160 B each)
     const size_t per = std::max<size_t>(1, P->a_prod_chunk / (size_t) k);
@@ -205,16 +205,16 @@ int launch_a(pbc_hip_pairing_s *P, void *d_gt, const void *d_g1, const void *d_g
     for (size_t u0 = 0; u0 < n; u0 += per) {
       const size_t nu = std::min(per, n - u0), nt = nu * (size_t) k;
       hipLaunchKernelGGL(al_miller_kernel<16>, dim3(resident_grid(P, reinterpret_cast<const void *>(&al_miller_kernel<16>), nt)), dim3(kBlock), 0, s,
-                         (uint4 *) ws, (const uint8_t *) d_g1 + u0 * (size_t) k * P->len1, (const uint8_t *) d_g2 + u0 * (size_t) k * P->len2, nt, kargs<16>(P));
+                         (uint4 *) ws, (const uint8_t *) d_g1 + u0 * (size_t) k * P->len1, (const uint8_t *) d_g2 + u0 * (size_t) k * P->len2, nt, unit_counter(P, s), kargs<16>(P));
       hipLaunchKernelGGL(al_prod_finish_kernel<16>, dim3(resident_grid(P, reinterpret_cast<const void *>(&al_prod_finish_kernel<16>), nu)), dim3(kBlock), 0, s,
-                         (uint8_t *) d_gt + u0 * P->lenT, (const uint4 *) ws, nu, k, kargs<16>(P));
+                         (uint8_t *) d_gt + u0 * P->lenT, (const uint4 *) ws, nu, k, unit_counter(P, s), kargs<16>(P));
     }
   } else if (P->type == 'a' && !P->a_generic) {
     grid = PBC_RGRID(a_prod_pairing_kernel<16>);                      // one workspace record per RESIDENT workgroup
     void *ws = W.get((size_t) grid * (size_t) k * (6 * 4 * kBlock) * sizeof(uint4));
     if (!ws) return 1;
     hipLaunchKernelGGL(a_prod_pairing_kernel<16>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
-                       (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k, (uint4 *) ws, kargs<16>(P));
+                       (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k, (uint4 *) ws, unit_counter(P, s), kargs<16>(P));
   } else if ((P->type == 'a' || P->type == '1') && P->nlimb == 16) {   // other sizes: the bit-by-bit kernels
     hipLaunchKernelGGL(a1_prod_pairing_kernel<16>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
                        (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k, kargs<16>(P));
@@ -248,7 +248,7 @@ int pp_apply_launch_a(pbc_hip_pp_s *pp, void *d_gt, const void *d_g2, size_t n, 
   unsigned grid = (unsigned) ((n + kBlock - 1) / kBlock);
   if (P->type == 'a' && !P->a_generic) {
     hipLaunchKernelGGL(al_pp_apply_kernel<16>, dim3(PBC_RGRID(al_pp_apply_kernel<16>)), dim3(kBlock), 0, s, (uint8_t *) d_gt, pp->tab, pp->valid,
-                       (const uint8_t *) d_g2, n, kargs<16>(P));
+                       (const uint8_t *) d_g2, n, unit_counter(P, s), kargs<16>(P));
   } else if (P->nlimb == 16) {
     hipLaunchKernelGGL(a1_pp_apply_kernel<16>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt, pp->tab, pp->valid,
                        (const uint8_t *) d_g2, n, kargs<16>(P));

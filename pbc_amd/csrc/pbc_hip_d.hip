@@ -5,8 +5,7 @@
 // of F_q and d = k/2, G1 records are 2 fb, G2 and GT 2 d fb bytes (40 / 120 / 120 B for d159.param,
 // 38 / 190 / 190 B for g149.param).
 template <int N, int DEG>
-static __device__ __forceinline__ void d_prod_unit(size_t vb, uint8_t *gt, const uint8_t *g1, const uint8_t *g2, size_t n, int k, uint32_t *ws) {
-  size_t idx = vb * kBlock + threadIdx.x;
+static __device__ __forceinline__ void d_prod_unit(size_t idx, uint8_t *gt, const uint8_t *g1, const uint8_t *g2, size_t n, int k, uint32_t *ws) {
   size_t ld = idx < n ? idx : n - 1;
   const int fb = (int) fpk<N>().fbytes, L1 = 2 * fb, L2 = 2 * DEG * fb, LT = 2 * DEG * fb;
   __attribute__((aligned(4))) uint8_t out[8 * DEG * N];
@@ -25,11 +24,11 @@ static __device__ __forceinline__ void d_prod_unit(size_t vb, uint8_t *gt, const
 // (resident workgroups where they pay: kDResident, pairing_d.cuh)
 template <int N, int DEG>
 __global__ void __launch_bounds__(kBlock, PBC_DF_WAVES) d_prod_pairing_kernel(uint8_t *gt, const uint8_t *g1,
-                                                                 const uint8_t *g2, size_t n, int k, uint32_t *ws, KArgs<N> ka) {
+                                                                 const uint8_t *g2, size_t n, int k, uint32_t *ws, unsigned *ctr, KArgs<N> ka) {
   if constexpr (kDResident<N, DEG>) {
-    PBC_RESIDENT_LOOP(n) d_prod_unit<N, DEG>(vb, gt, g1, g2, n, k, ws);
+    PBC_RESIDENT_LOOP(n, ctr) d_prod_unit<N, DEG>(PBC_UNIT_INDEX, gt, g1, g2, n, k, ws);
   } else {
-    d_prod_unit<N, DEG>(blockIdx.x, gt, g1, g2, n, k, ws);
+    d_prod_unit<N, DEG>((size_t) blockIdx.x * kBlock + threadIdx.x, gt, g1, g2, n, k, ws);
   }
 }
 
@@ -40,9 +39,8 @@ __global__ void d_pp_init_kernel(uint32_t *tab, uint32_t *valid, const uint8_t *
   *valid = TypeMNT<N, DEG>::d_pp_init_lane(tab, g1) ? 1u : 0u;
 }
 template <int N, int DEG>
-static __device__ __forceinline__ void d_pp_unit(size_t vb, uint8_t *gt, const uint32_t *__restrict__ tab, const uint32_t *__restrict__ valid,
+static __device__ __forceinline__ void d_pp_unit(size_t idx, uint8_t *gt, const uint32_t *__restrict__ tab, const uint32_t *__restrict__ valid,
                                                  const uint8_t *g2, size_t n) {
-  size_t idx = vb * kBlock + threadIdx.x;
   size_t ld = idx < n ? idx : n - 1;
   const int fb = (int) fpk<N>().fbytes, L2 = 2 * DEG * fb, LT = 2 * DEG * fb;
   __attribute__((aligned(4))) uint8_t out[8 * DEG * N];
@@ -60,11 +58,11 @@ static __device__ __forceinline__ void d_pp_unit(size_t vb, uint8_t *gt, const u
 template <int N, int DEG>
 __global__ void __launch_bounds__(kBlock, PBC_DF_WAVES) d_pp_apply_kernel(uint8_t *gt, const uint32_t *__restrict__ tab,
                                                                           const uint32_t *__restrict__ valid,
-                                                                          const uint8_t *g2, size_t n, KArgs<N> ka) {
+                                                                          const uint8_t *g2, size_t n, unsigned *ctr, KArgs<N> ka) {
   if constexpr (kDResident<N, DEG>) {
-    PBC_RESIDENT_LOOP(n) d_pp_unit<N, DEG>(vb, gt, tab, valid, g2, n);
+    PBC_RESIDENT_LOOP(n, ctr) d_pp_unit<N, DEG>(PBC_UNIT_INDEX, gt, tab, valid, g2, n);
   } else {
-    d_pp_unit<N, DEG>(blockIdx.x, gt, tab, valid, g2, n);
+    d_pp_unit<N, DEG>((size_t) blockIdx.x * kBlock + threadIdx.x, gt, tab, valid, g2, n);
   }
 }
 
@@ -95,14 +93,17 @@ int launch_d(pbc_hip_pairing_s *P, void *d_gt, const void *d_g1, const void *d_g
   unsigned grid = (unsigned) ((n + kBlock - 1) / kBlock);
   if (k == 1) {
     PBC_DISPATCH_D(P, hipLaunchKernelGGL((d_prod_pairing_kernel<N, DEG>), dim3(kDResident<N, DEG> ? PBC_RGRID(d_prod_pairing_kernel<N, DEG>) : grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
-                                                (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, 1, (uint32_t *) nullptr, kargs<N>(P)));
+                                                (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, 1, (uint32_t *) nullptr, kDResident<N, DEG> ? unit_counter(P, s) : nullptr, kargs<N>(P)));
   } else {
     size_t rec = 0;                    // words of Miller state per term and lane (the kernel's own constant)
-    PBC_DISPATCH_D(P, { rec = (size_t) TypeMNT<N, DEG>::DL_WORDS; if (kDResident<N, DEG>) grid = PBC_RGRID(d_prod_pairing_kernel<N, DEG>); });      // one workspace record per RESIDENT workgroup
+    // (5-word field: products keep one workgroup per 128 units -- the resident shape measured 160 -> 185 ms on 16-term
+    // products -- and run without the time-sliced priorities that go with it)
+    bool res = false;
+    PBC_DISPATCH_D(P, { rec = (size_t) TypeMNT<N, DEG>::DL_WORDS; res = kDResident<N, DEG> && N != 5; if (res) grid = PBC_RGRID(d_prod_pairing_kernel<N, DEG>); });      // one workspace record per RESIDENT workgroup
     void *ws = W.get((size_t) grid * (size_t) k * rec * kBlock * sizeof(uint32_t));
     if (!ws) return 1;
     PBC_DISPATCH_D(P, hipLaunchKernelGGL((d_prod_pairing_kernel<N, DEG>), dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
-                                                (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k, (uint32_t *) ws, kargs<N>(P)));
+                                                (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k, (uint32_t *) ws, res ? unit_counter(P, s) : nullptr, kargs<N>(P, false, !res)));
   }
   HIP_TRY(hipGetLastError());
   return 0;
@@ -116,7 +117,7 @@ int pp_apply_launch_d(pbc_hip_pp_s *pp, void *d_gt, const void *d_g2, size_t n, 
   pbc_hip_pairing_s *P = pp->P;
   unsigned grid = (unsigned) ((n + kBlock - 1) / kBlock);
   PBC_DISPATCH_D(P, hipLaunchKernelGGL((d_pp_apply_kernel<N, DEG>), dim3(kDResident<N, DEG> ? PBC_RGRID(d_pp_apply_kernel<N, DEG>) : grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
-                                           pp->tab, pp->valid, (const uint8_t *) d_g2, n, kargs<N>(P)));
+                                           pp->tab, pp->valid, (const uint8_t *) d_g2, n, kDResident<N, DEG> ? unit_counter(P, s) : nullptr, kargs<N>(P)));
   HIP_TRY(hipGetLastError());
   return 0;
 }

@@ -7,12 +7,12 @@
 // SIMD; with PBC_F_AREAS=2 in two areas, one wave per SIMD and the register budget that goes with it)
 template <int N, bool BM1>
 __global__ void __launch_bounds__(kBlock, N <= 5 ? (PBC_F_AREAS == 1 ? 2 : 1) : PBC_F_WAVES) f_prod_pairing_kernel(uint8_t *gt, const uint8_t *g1,
-                                                                 const uint8_t *g2, size_t n, int k, KArgs<N> ka) {
+                                                                 const uint8_t *g2, size_t n, int k, unsigned *ctr, KArgs<N> ka) {
 #ifdef PBC_F_WHATIF_TRACE                        // what-if builds only (tools/whatif_time.py --trace): per-wave start / end / HW_ID behind the results
   const uint64_t trace_t0 = wall_clock64();
 #endif
-  PBC_RESIDENT_LOOP(n) {
-    size_t idx = vb * kBlock + threadIdx.x;
+  PBC_RESIDENT_LOOP(n, ctr) {
+    size_t idx = PBC_UNIT_INDEX;
     size_t ld = idx < n ? idx : n - 1;
     const int fb = (int) fpk<N>().fbytes, L1 = 2 * fb, L2 = 4 * fb, LT = 12 * fb;
     __attribute__((aligned(4))) uint8_t out[48 * N];
@@ -80,10 +80,10 @@ int derive_f(pbc_hip_pairing_s *P, hipStream_t s) {
 int launch_f(pbc_hip_pairing_s *P, void *d_gt, const void *d_g1, const void *d_g2, size_t n, int k, hipStream_t s) {
   if (P->f_bm1) {                    // i-basis constants and the instantiation that goes with them
     PBC_DISPATCH_F(P->nlimb, hipLaunchKernelGGL((f_prod_pairing_kernel<N, true>), dim3(PBC_RGRID(f_prod_pairing_kernel<N, true>)), dim3(kBlock), 0, s, (uint8_t *) d_gt,
-                       (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k, kargs<N>(P, true)));
+                       (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k, unit_counter(P, s), kargs<N>(P, true)));
   } else {
     PBC_DISPATCH_F(P->nlimb, hipLaunchKernelGGL((f_prod_pairing_kernel<N, false>), dim3(PBC_RGRID(f_prod_pairing_kernel<N, false>)), dim3(kBlock), 0, s, (uint8_t *) d_gt,
-                       (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k, kargs<N>(P)));
+                       (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k, unit_counter(P, s), kargs<N>(P)));
   }
   HIP_TRY(hipGetLastError());
   return 0;
@@ -93,7 +93,7 @@ int launch_f(pbc_hip_pairing_s *P, void *d_gt, const void *d_g1, const void *d_g
 int diag_f_miller(pbc_hip_pairing_s *P, void *dt, const void *d1, const void *d2, size_t n) {
   unsigned grid = (unsigned) ((n + kBlock - 1) / kBlock);
   PBC_DISPATCH_F(P->nlimb, hipLaunchKernelGGL((f_prod_pairing_kernel<N, false>), dim3(grid), dim3(kBlock), 0, 0, (uint8_t *) dt,
-                     (const uint8_t *) d1, (const uint8_t *) d2, n, -1, kargs<N>(P)));
+                     (const uint8_t *) d1, (const uint8_t *) d2, n, -1, (unsigned *) nullptr, kargs<N>(P)));
   return 0;
 }
 int diag_f_op(pbc_hip_pairing_s *P, int stage, void *dt, const void *d1, const void *d2, size_t n) {

@@ -27,9 +27,9 @@ __global__ void __launch_bounds__(kBlock, 2) ec_mul_win_kernel(uint8_t *out, con
 // Type a, 512-bit field: the same ladder on the limb-form arithmetic (group_al.cuh), resident workgroups as the pairing kernel.
 template <int N>
 __global__ void __launch_bounds__(kBlock, PBC_A_WAVES) al_gmul_kernel(uint8_t *out, const uint8_t *in, const uint8_t *z, int zlen,
-                                                                       uint8_t *flags, size_t n, KArgs<N> ka) {
-  PBC_RESIDENT_LOOP(n) {
-    size_t idx = vb * kBlock + threadIdx.x;
+                                                                       uint8_t *flags, size_t n, unsigned *ctr, KArgs<N> ka) {
+  PBC_RESIDENT_LOOP(n, ctr) {
+    size_t idx = PBC_UNIT_INDEX;
     size_t ld = idx < n ? idx : n - 1;
     constexpr int L = 8 * N;
     __attribute__((aligned(16))) uint8_t o[L];
@@ -48,9 +48,9 @@ __global__ void __launch_bounds__(kBlock, PBC_A_WAVES) al_gmul_kernel(uint8_t *o
 // element_pow_zn on GT, type a: the Lucas ladder for elements of norm 1 (group_al.cuh); others are flagged for gt_op_kernel
 template <int N>
 __global__ void __launch_bounds__(kBlock, PBC_A_WAVES) al_gtpow_kernel(uint8_t *out, const uint8_t *a, const uint8_t *z, int zlen,
-                                                                        uint8_t *flags, size_t n, KArgs<N> ka) {
-  PBC_RESIDENT_LOOP(n) {
-    size_t idx = vb * kBlock + threadIdx.x;
+                                                                        uint8_t *flags, size_t n, unsigned *ctr, KArgs<N> ka) {
+  PBC_RESIDENT_LOOP(n, ctr) {
+    size_t idx = PBC_UNIT_INDEX;
     size_t ld = idx < n ? idx : n - 1;
     constexpr int L = 8 * N;
     __attribute__((aligned(16))) uint8_t o[L];
@@ -314,7 +314,7 @@ static int group_launch(pbc_hip_pairing_s *P, const GroupCall &c, void *d_out, c
       uint8_t *flags = (uint8_t *) W.get(n);
       if (!flags) return 1;
       if (fast_a) {
-        hipLaunchKernelGGL(al_gmul_kernel<16>, dim3(PBC_RGRID(al_gmul_kernel<16>)), dim3(kBlock), 0, s, o, a, b, P->len_zr, flags, n, kargs<16>(P));
+        hipLaunchKernelGGL(al_gmul_kernel<16>, dim3(PBC_RGRID(al_gmul_kernel<16>)), dim3(kBlock), 0, s, o, a, b, P->len_zr, flags, n, unit_counter(P, s), kargs<16>(P));
         hipLaunchKernelGGL(ec_mul_kernel<FqOps<16>>, dim3(grid), dim3(kBlock), 0, s, o, a, c.la, b, P->len_zr, (const uint8_t *) flags, n, kargs<16>(P));
       } else {
         PBC_DISPATCH_G(P, c.group, {
@@ -326,7 +326,7 @@ static int group_launch(pbc_hip_pairing_s *P, const GroupCall &c, void *d_out, c
   } else if (c.op == GT_POW && fast_a) {
     uint8_t *flags = (uint8_t *) W.get(n);
     if (!flags) return 1;
-    hipLaunchKernelGGL(al_gtpow_kernel<16>, dim3(PBC_RGRID(al_gtpow_kernel<16>)), dim3(kBlock), 0, s, o, a, b, P->len_zr, flags, n, kargs<16>(P));
+    hipLaunchKernelGGL(al_gtpow_kernel<16>, dim3(PBC_RGRID(al_gtpow_kernel<16>)), dim3(kBlock), 0, s, o, a, b, P->len_zr, flags, n, unit_counter(P, s), kargs<16>(P));
     hipLaunchKernelGGL(gt_op_kernel<16>, dim3(grid), dim3(kBlock), 0, s, P->type, 1, o, a, b, P->lenT, P->len_zr, (const uint8_t *) flags, n, kargs<16>(P));
   } else if (c.op == GT_MUL || c.op == GT_POW || c.op == GT_FINALPOW) {
     PBC_DISPATCH_N(P->nlimb, hipLaunchKernelGGL(gt_op_kernel<N>, dim3(grid), dim3(kBlock), 0, s, P->type, c.op - GT_MUL, o, a, b, P->lenT,

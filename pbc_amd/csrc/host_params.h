@@ -506,6 +506,16 @@ static int init_type_f(pbc_hip_pairing_s *P, const char *txt, size_t len) {
     // 8 q (D = 2) its double (the cyclotomic squaring); both need q to reach two bits into its top limb
     P->fraw.k_ok = !pbc_host::ksub_build(q, L, 29 * (L - 1) + 2, 4, 1, P->fraw.kneg29) &&
                    !pbc_host::ksub_build(q, L, 29 * (L - 1) + 2, 8, 2, P->fraw.kneg8_29);
+    {
+      // the limb-form steps on E(F_q) (pairing_f.cuh f_dbl_core_l): 2 q, 4 q, 16 q, 32 q in borrowed limbs, six-limb fields
+      // whose q reaches eight bits into its top limb (the bound tracker's assumptions); "hip_no_limb 1" keeps the word form
+      static const uint32_t cd[4][2] = {{2, 1}, {4, 2}, {16, 2}, {32, 2}};
+      int no_limb = 0;
+      param_int(txt, len, "hip_no_limb", no_limb);
+      P->fraw.pl_ok = (L == 6 && !no_limb) ? 1 : 0;
+      for (int t = 0; t < 4 && P->fraw.pl_ok; t++)
+        if (pbc_host::ksub_build(q, 6, 29 * 5 + 8, cd[t][0], cd[t][1], P->fraw.pk29[t])) P->fraw.pl_ok = 0;
+    }
     int no_cyc = 0;
     param_int(txt, len, "hip_no_cyc", no_cyc);   // tests: plain squarings in the hard part
     if ((q.w[0] & 3) == 3 && !no_bm1 && P->fraw.k_ok) {
@@ -517,6 +527,49 @@ static int init_type_f(pbc_hip_pairing_s *P, const char *txt, size_t len) {
       P->fraw.e4bits = e4.bits();
     }
     if (no_cyc) P->fraw.k_ok = 0;
+    // A sparse xi for the pairing kernels (pairing_f.cuh init_stage4): the integers of the 6th-root computation in F_q^2.
+    // |F_q^2*| = q^2 - 1 = S m with S = 2^a 3^b and gcd(m, 6) = 1.  For w a 6th power: w = w_S w_m with
+    // w_S = w^(m u), u = 1/m mod S (in the subgroup of order S, generated by xi^m: xi is neither a square nor a cube) and
+    // w_m = w^(S v), v = 1/S mod m, whose 6th root is w_m^t, t = 1/6 mod m.  "hip_no_xs 1" keeps the parameter file's xi.
+    int no_xs = 0;
+    param_int(txt, len, "hip_no_xs", no_xs);
+    P->fraw.xs_try = 0;
+    if (P->fraw.e4bits > 0 && L == 6 && P->fraw.k_ok && !no_xs) {
+      Big N = Big::mul(q, q), two, three, rm2;
+      N.sub_small(1);
+      two.w.push_back(2);
+      three.w.push_back(3);
+      Big m = N;
+      uint32_t S = 1;
+      for (;;) { Big t = Big::div(m, two, &rm2); if (!rm2.is_zero()) break; m = t; S *= 2; }
+      for (;;) { Big t = Big::div(m, three, &rm2); if (!rm2.is_zero()) break; m = t; S *= 3; }
+      auto mod_small = [](const Big &a, uint32_t d) { Big dd, rr; dd.w.push_back(d); (void) Big::div(a, dd, &rr); return rr.is_zero() ? 0u : rr.w[0]; };
+      auto times = [](const Big &a, uint32_t k) { Big kk; kk.w.push_back(k); return Big::mul(a, kk); };
+      if (S < (1u << 20)) {
+        const uint32_t mS = mod_small(m, S);
+        uint32_t u = 0, kv = 0, kt = 0;
+        for (uint32_t x = 1; x < S; x++) if ((uint64_t) x * mS % S == 1) u = x;                 // u = 1/m mod S
+        for (uint32_t x = 0; x < S; x++) if (((uint64_t) x * mS + 1) % S == 0) kv = x;          // S | m kv + 1
+        const uint32_t m6 = mod_small(m, 6);
+        for (uint32_t x = 0; x < 6; x++) if ((x * m6 + 1) % 6 == 0) kt = x;                     // 6 | m kt + 1
+        Big sv, six2, dS, v, t;
+        six2.w.push_back(6);
+        dS.w.push_back(S);
+        sv = times(m, kv); sv.add_small(1); v = Big::div(sv, dS, &rm2);                         // v = 1/S mod m
+        sv = times(m, kt); sv.add_small(1); t = Big::div(sv, six2, &rm2);                       // t = 1/6 mod m
+        Big eS = times(m, u), em = Big::mul(times(v, S), t), ecls = Big::div(N, six2, &rm2);
+        (void) Big::div(em, N, &rm2);
+        em = rm2;
+        if (u && m.bits() <= 352 && eS.bits() <= 352 && em.bits() <= 352 && ecls.bits() <= 352) {
+          m.to_words(P->fraw.xs_m, 11); P->fraw.xs_mbits = m.bits();
+          eS.to_words(P->fraw.xs_eS, 11); P->fraw.xs_eSbits = eS.bits();
+          em.to_words(P->fraw.xs_em, 11); P->fraw.xs_embits = em.bits();
+          ecls.to_words(P->fraw.xs_ecls, 11); P->fraw.xs_eclsbits = ecls.bits();
+          P->fraw.xs_S = (int) S;
+          P->fraw.xs_try = 1;
+        }
+      }
+    }
   }
   if (r.bits() > 256 || r.bits() < 3) return fail("type f: bad r");
   P->fconst.rbits = pbc_host::naf_of_half(r, P->fconst.r, P->fconst.rm, 9);     // signed digits of the Miller loop

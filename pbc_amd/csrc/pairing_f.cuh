@@ -80,6 +80,19 @@ struct FConst {                        // f_pairing_data_s (ecc/f_param.c:35-45)
   // xi = negalpha as limbs, and 8 q in borrowed limbs with D = 2 (K - 2 y for normalised y); cyc_ok: both K constants fit q
   uint32_t cyc29[6][9], kneg8_29[9];
   int cyc_ok;
+  // point arithmetic on E(F_q) in limb form (six-limb fields; f_dbl_core_l / f_add_core_l): c q in borrowed limbs for
+  // (c, D) = (2, 1), (4, 2), (16, 2), (32, 2) -- the constants of pairing_d.cuh's limb-form steps; pl_ok: they fit this q
+  uint32_t pk29[4][6];
+  int pl_ok;
+  // A sparse xi (init_stage4; pairing kernels of the 5-word fields in the i-basis): F_q^12 is taken in the basis 1, X', ...,
+  // X'^5 with X' = X / c, X'^6 = xi' = xs_u + xs_v i for SMALL integers xs_u, xs_v (c^6 = xi / xi'; xi' lies in xi's class
+  // of F_q^2* modulo 6th powers).  Every constant of this block is then the X'-basis one (negalpha = xi', gamma = xi'^((q-1)/6),
+  // ...), so the tower routines run unchanged; products by xi' are a few shifts and adds where the routines know it
+  // (TypeF<.., XS>).  The Miller loop scales Q by c^-2 / c^-3 on the way in and coefficient i of the result by c^-i on
+  // the way out.  xs_ok = 0: the parameter file's xi, c = 1.
+  uint32_t xc_inv[2][NF_MAX];          // 1 / c
+  int xs_ok, xs_u, xs_v;               // xs_u in {1, 2, 4}, xs_v in {1, 2}
+  int xs_su, xs_sv;                    // their binary logarithms
 };
 static_assert(sizeof(FConst) <= KOFF_XS - KOFF_TYPE, "constant block layout");
 #define c_f (pbc::kconst<pbc::FConst, pbc::KOFF_TYPE>())
@@ -91,6 +104,11 @@ struct FRaw {
   int e4bits;
   uint32_t kneg29[9], kneg8_29[9];     // 4 q (D = 1) and 8 q (D = 2) in borrowed limbs; k_ok: both fit this q (hostbn.h ksub_build)
   int k_ok;
+  uint32_t pk29[4][6];                 // 2 q (D = 1), 4 q, 16 q, 32 q (D = 2) for the limb-form point arithmetic; pl_ok: all fit
+  int pl_ok;
+  // init_stage4 (a sparse xi): (q^2 - 1) / 6, m, m u, S v t mod (q^2 - 1) and S (host_params.h init_type_f)
+  uint32_t xs_ecls[11], xs_m[11], xs_eS[11], xs_em[11];
+  int xs_eclsbits, xs_mbits, xs_eSbits, xs_embits, xs_S, xs_try;
 };
 
 // LDS staging area of the F_q^12 products: the limb forms (x, y of six coefficients) of one operand per lane,
@@ -104,8 +122,10 @@ template <int ND> __shared__ uint32_t g_lds_f12[kF12Bufs<ND> * 12 * Limbs29<ND>:
 
 // Everything below is per field width: ND 32-bit words per F_q element (5 for f.param, 8 for 256-bit BN fields).
 // BM1: the instantiation of the pairing kernels for objects with i-basis constants (FConst::bm1, init_stage3)
-template <int ND, bool BM1 = false>
+// XS: the instantiation for blocks with a sparse xi (FConst::xs_ok, init_stage4): products by xi' are shifts and adds
+template <int ND, bool BM1 = false, bool XS = false>
 struct TypeF {
+static_assert(!XS || BM1, "the sparse xi lives in the i-basis");
 typedef fp<ND> fq;
 typedef typename vecN<ND>::type v5;
 static PBC_DEV fq dk(const uint32_t *w) { fq r; fp_set<ND>(r, w); return r; }
@@ -139,6 +159,27 @@ static PBC_DEV void mul_beta(fl<ND> &r, const fl<ND> &y) {
   } else {
     const fl<ND> xx[1] = {y}, yy[1] = {fl29(c_f.beta29)};
     sop_limbs<ND, 1>(r, xx, yy);
+  }
+}
+// xi' (x + y i) for the sparse xi' = u + v i of init_stage4 (u in {1, 2, 4}, v in {1, 2}; i-basis): (u x - v y) + (v x + u y) i
+// by shifts, the borrowed constant K = 8 q (which dominates 2 y for normalised y) and a parallel carry pass: 50
+// instructions instead of the 144 multiply-adds and two reductions of a product by a general xi.  In: normalised limbs,
+// values below 2.001 q; out: limbs <= 2^29 + 8, values below 16 q / 12 q, which every sum they enter holds.
+static PBC_DEV void mul_xi(fl<ND> &rx, fl<ND> &ry, const fl<ND> &x, const fl<ND> &y) {
+  constexpr int L = Limbs29<ND>::L;
+  const int su = c_f.xs_su, sv = c_f.xs_sv;
+  uint32_t t[L], u[L], c = 0, d = 0;
+#pragma unroll
+  for (int i = 0; i < L; i++) {
+    t[i] = (x.l[i] << su) + c_f.kneg8_29[i] - (y.l[i] << sv);
+    u[i] = (x.l[i] << sv) + (y.l[i] << su);
+  }
+#pragma unroll
+  for (int i = 0; i < L; i++) {
+    rx.l[i] = (i < L - 1 ? (t[i] & Limbs29<ND>::MASK) : t[i]) + c;
+    c = t[i] >> 29;
+    ry.l[i] = (i < L - 1 ? (u[i] & Limbs29<ND>::MASK) : u[i]) + d;
+    d = u[i] >> 29;
   }
 }
 static PBC_DEV g2 fk2(const uint32_t (*w)[NF_MAX]) { g2 r; fp_set<ND>(r.x, w[0]); fp_set<ND>(r.y, w[1]); return r; }
@@ -193,6 +234,14 @@ static PBC_DEV void g2_mul(g2 &r, const g2 &a, const g2 &b) {
 static PBC_DEV void g2_sqr(g2 &r, const g2 &a) {
   g2ret t = g2_sqr_call(to_vec<ND>(a.x), to_vec<ND>(a.y));
   from_vec<ND>(r.x, t.x); from_vec<ND>(r.y, t.y);
+}
+// xi' a for the sparse xi' = u + v i (XS instantiation; word form): (u x - v y) + (v x + u y) i by doublings
+static PBC_DEV void g2_mul_xi(g2 &r, const g2 &a) {
+  fq ux = a.x, uy = a.y, vx = a.x, vy = a.y;
+  for (int k = 0; k < c_f.xs_su; k++) { fp_dbl<ND>(ux, ux); fp_dbl<ND>(uy, uy); }
+  for (int k = 0; k < c_f.xs_sv; k++) { fp_dbl<ND>(vx, vx); fp_dbl<ND>(vy, vy); }
+  fp_sub<ND>(r.x, ux, vy);
+  fp_add<ND>(r.y, vx, uy);
 }
 // fq_invert (fieldquadratic.c:290-309)
 static PBC_DEV void g2_inv(g2 &r, const g2 &a) {
@@ -358,7 +407,7 @@ static __device__ __noinline__ void f12_mul(f12 *r, const f12 *a, const f12 *b) 
     for (int h = 1; h >= 0; h--) {
       if (h && k == 5) continue;
       g2 u = f12_mul_coeff(A, k + 6 * h);
-      if (h) g2_mul(t, u, na); else g2_add(t, t, u);
+      if (h) { if constexpr (XS) g2_mul_xi(t, u); else g2_mul(t, u, na); } else g2_add(t, t, u);
     }
     r->c[k] = t;                                 // r may be a or b: both are in registers / LDS by now
   }
@@ -376,7 +425,7 @@ static __device__ __noinline__ void f12_sqr(f12 *r, const f12 *a) {
     for (int h = 1; h >= 0; h--) {
       if (h && k == 5) continue;
       g2 u = f12_sqr_coeff(A, k + 6 * h);
-      if (h) g2_mul(t, u, na); else g2_add(t, t, u);
+      if (h) { if constexpr (XS) g2_mul_xi(t, u); else g2_mul(t, u, na); } else g2_add(t, t, u);
     }
     r->c[k] = t;
   }
@@ -431,12 +480,29 @@ static PBC_DEV void g2l_make(g2l &r, const g2 &a) {
   mul_beta(r.by, r.y);
 }
 // (x + y s) s for an F_q scalar, and a product by the constant -alpha, on limb forms (values below 2q in, below 2q out)
+template <int DBL = 0>                 // DBL 1: the scalar's limbs reach 2^30
 static PBC_DEV void g2l_scale(g2l &r, const fl<ND> &x, const fl<ND> &y, const fl<ND> &s) {
-  { const fl<ND> u[1] = {x}, v[1] = {s}; sop_limbs<ND, 1>(r.x, u, v); }
-  { const fl<ND> u[1] = {y}, v[1] = {s}; sop_limbs<ND, 1>(r.y, u, v); }
+  { const fl<ND> u[1] = {x}, v[1] = {s}; sop_limbs<ND, 1, DBL>(r.x, u, v); }
+  { const fl<ND> u[1] = {y}, v[1] = {s}; sop_limbs<ND, 1, DBL>(r.y, u, v); }
   mul_beta(r.by, r.y);
 }
 static PBC_DEV void g2l_mul_na(g2l &r, const g2l &a) {
+  if constexpr (XS) {                  // sparse xi: shifts and adds
+    mul_xi(r.x, r.y, a.x, a.y);
+    // beta (xi' a).y = -(v x + u y) = v (-x) + u (-y) from the negations of NORMALISED values (mul_beta's K = 4 q does not
+    // dominate the 12 q that (xi' a).y can reach): limbs <= 2^29 + 8, value below 24 q
+    fl<ND> nx;
+    mul_beta(nx, a.x);
+    uint32_t t[FL], c = 0;
+#pragma unroll
+    for (int i = 0; i < FL; i++) t[i] = (nx.l[i] << c_f.xs_sv) + (a.by.l[i] << c_f.xs_su);
+#pragma unroll
+    for (int i = 0; i < FL; i++) {
+      r.by.l[i] = (i < FL - 1 ? (t[i] & Limbs29<ND>::MASK) : t[i]) + c;
+      c = t[i] >> 29;
+    }
+    return;
+  }
   const fl<ND> nax = fl29(c_f.na29[0]), nay = fl29(c_f.na29[1]);
   { const fl<ND> u[2] = {a.x, a.by}, v[2] = {nax, nay}; sop_limbs<ND, 2>(r.x, u, v); }
   { const fl<ND> u[2] = {a.x, a.y}, v[2] = {nay, nax}; sop_limbs<ND, 2>(r.y, u, v); }
@@ -600,13 +666,16 @@ static __device__ __noinline__ void f12_sqr_lds(int cur) {
   for (int kk = 0; kk < (kPrefetch ? 5 : 6); kk++) {
     fl<ND> t6x, t6y;
     wide<ND> Wx, Wy;
+    int units = 0;
 #pragma nounroll
     for (int h = 1; h >= 0; h--) {
       if (h && kk == 5) continue;                // X^11 does not occur
       const int k = kk + 6 * h;
-      wide_zero<ND>(Wx);
-      wide_zero<ND>(Wy);
-      int units = 0;
+      if (!XS || h || kk == 5) {                 // (sparse xi: the wrapped pairs go into the same sums as the plain ones)
+        wide_zero<ND>(Wx);
+        wide_zero<ND>(Wy);
+        units = 0;
+      }
 #pragma unroll
       for (int i = 0; i < 6; i++) {
         const int j = k - i;
@@ -615,7 +684,17 @@ static __device__ __noinline__ void f12_sqr_lds(int cur) {
         const fl<ND> ax = ldsf_get(i, 0, cur), ay = ldsf_get(i, 1, cur);
         fl<ND> byi;
         if constexpr (kByRecompute) mul_beta(byi, ay); else byi = by[i];
-        if (i == j) {                            // a_i^2: re = x^2 + (beta y) y, im = 2 x y
+        if (XS && h) {
+          // a wrapped pair, i + j = kk + 6: a_i a_j X'^6 = a_i (xi' a_j) -- xi' a_j by shifts and adds, then a plain pair
+          fl<ND> bx, by2;
+          mul_xi(bx, by2, ldsf_get(j, 0, cur), ldsf_get(j, 1, cur));
+          if (i != j) { limbs_dbl<ND>(bx, bx); limbs_dbl<ND>(by2, by2); }
+          wide_mac<ND>(Wx, ax, bx);
+          wide_mac<ND>(Wy, ay, bx);
+          wide_mac<ND>(Wx, byi, by2);
+          wide_mac<ND>(Wy, ax, by2);
+          units += i != j ? 4 : 2;
+        } else if (i == j) {                     // a_i^2: re = x^2 + (beta y) y, im = 2 x y
           fl<ND> ax2;
           limbs_dbl<ND>(ax2, ax);
           wide_mac<ND>(Wx, ax, ax);
@@ -633,11 +712,12 @@ static __device__ __noinline__ void f12_sqr_lds(int cur) {
           units += 4;
         }
       }
+      if (XS && h) continue;                     // (the plain pairs of coefficient kk follow in the same accumulators)
       if (h) {
         wide_reduce<ND>(t6x, Wx);
         wide_reduce<ND>(t6y, Wy);
       } else {
-        if (kk < 5) {                            // + negalpha * (coefficient k + 6)
+        if (!XS && kk < 5) {                     // + negalpha * (coefficient k + 6)
           if (units + 2 > kCap) wide_guard<1>(Wx, Wy);
           const fl<ND> nax = fl29(c_f.na29[0]), nay = fl29(c_f.na29[1]), bnay = fl29(c_f.bna29);
           wide_mac<ND>(Wx, nax, t6x);
@@ -689,43 +769,32 @@ static __device__ __noinline__ void f12_sqr_lds(int cur) {
 }
 // area `cur` times (a Qx X^4 + b Qy X^3 + c) into area 1 - cur (f_miller_evalfn, f_param.c:109-149): the formulas of
 // f_line_mul
-static __device__ __noinline__ void f_line_mul_lds(int cur, v5 va, v5 vb, v5 vc, const g2 *Qx, const g2 *Qy) {
+// (the line's coefficients arrive as limbs: a with limbs up to 2^30 and a value below 2.001 q, b a Montgomery product's
+// result, c with limbs <= 2^29 + 6 and a value below 6 q -- what the limb-form steps f_dbl_core_l / f_add_core_l deliver;
+// the word-form steps convert theirs)
+typedef uint32_t vfl __attribute__((ext_vector_type(FL)));
+static PBC_DEV vfl to_vfl(const fl<ND> &a) { vfl v; for (int i = 0; i < FL; i++) v[i] = a.l[i]; return v; }
+static PBC_DEV vfl fq_vfl(const fq &a) { fl<ND> t; to_limbs<ND>(t, a); return to_vfl(t); }
+static __device__ __noinline__ void f_line_mul_lds(int cur, vfl va, vfl vb, vfl vc, const g2 *Qx, const g2 *Qy) {
   fair_tick();
   OutArea O;
   O.dst = kOneArea ? 0 : 1 - cur;
-  fq a, b, c;
-  from_vec<ND>(a, va);
-  from_vec<ND>(b, vb);
-  from_vec<ND>(c, vc);
-  fl<ND> cl;
-  to_limbs<ND>(cl, c);
+  fl<ND> al, bl, cl;
+#pragma unroll
+  for (int i = 0; i < FL; i++) { al.l[i] = va[i]; bl.l[i] = vb[i]; cl.l[i] = vc[i]; }
   g2l Aq, Aqn, Bq, Bqn;
-  if constexpr (PBC_F_LINE_LIMB != 0) {
+  {
     // a Qx, b Qy and their multiples by -alpha without leaving limb form: four F_q products and two lazily reduced
-    // F_q^2 products by the constant (its limbs are scalar operands) -- the word-form calls below spend 1700
-    // instructions on the same 710 multiply-adds (conversions in and out of every call)
-    fl<ND> al, bl, qx, qy;
-    to_limbs<ND>(al, a);
-    to_limbs<ND>(bl, b);
+    // F_q^2 products by the constant (its limbs are scalar operands)
+    fl<ND> qx, qy;
     to_limbs<ND>(qx, Qx->x);
     to_limbs<ND>(qy, Qx->y);
-    g2l_scale(Aq, qx, qy, al);
+    g2l_scale<1>(Aq, qx, qy, al);
     g2l_mul_na(Aqn, Aq);
     to_limbs<ND>(qx, Qy->x);
     to_limbs<ND>(qy, Qy->y);
     g2l_scale(Bq, qx, qy, bl);
     g2l_mul_na(Bqn, Bq);
-  } else {
-    g2 aq, bq, aqn, bqn;
-    const g2 na = fk2(c_f.negalpha);
-    g2_mul_fq(aq, *Qx, a);
-    g2_mul_fq(bq, *Qy, b);
-    g2_mul(aqn, aq, na);
-    g2_mul(bqn, bq, na);
-    g2l_make(Aq, aq);
-    g2l_make(Aqn, aqn);
-    g2l_make(Bq, bq);
-    g2l_make(Bqn, bqn);
   }
   uint32_t pre[kPrefetch ? 6 * FL : 1];
 #pragma nounroll
@@ -772,30 +841,35 @@ static __device__ __noinline__ void f12_mul_lds(int cur, const f12 *b) {
   for (int kk = 0; kk < 6; kk++) {
     fl<ND> t6x, t6y;
     wide<ND> Wx, Wy;
+    int units = 0;
 #pragma nounroll
     for (int h = 1; h >= 0; h--) {
       if (h && kk == 5) continue;
       const int k = kk + 6 * h;
-      wide_zero<ND>(Wx);
-      wide_zero<ND>(Wy);
-      int units = 0;
+      if (!XS || h || kk == 5) {                 // (sparse xi: the wrapped pairs go into the same sums as the plain ones)
+        wide_zero<ND>(Wx);
+        wide_zero<ND>(Wy);
+        units = 0;
+      }
 #pragma unroll
       for (int i = 0; i < 6; i++) {
         const int j = k - i;
         if (j < 0 || j > 5) continue;            // wave-uniform
         if (units + 2 > kCap) { wide_guard<2>(Wx, Wy); units = 1; }
-        const fl<ND> ax = ldsf_get(j, 0, cur), ay = ldsf_get(j, 1, cur);
+        fl<ND> ax = ldsf_get(j, 0, cur), ay = ldsf_get(j, 1, cur);
+        if (XS && h) mul_xi(ax, ay, ax, ay);     // b_i a_j X'^6 = b_i (xi' a_j)
         wide_mac<ND>(Wx, B.x[i], ax);
         wide_mac<ND>(Wx, f12r_by(B, i), ay);
         wide_mac<ND>(Wy, B.x[i], ay);
         wide_mac<ND>(Wy, B.y[i], ax);
         units += 2;
       }
+      if (XS && h) continue;
       if (h) {
         wide_reduce<ND>(t6x, Wx);
         wide_reduce<ND>(t6y, Wy);
       } else {
-        if (kk < 5) {
+        if (!XS && kk < 5) {
           if (units + 2 > kCap) wide_guard<2>(Wx, Wy);
           const fl<ND> nax = fl29(c_f.na29[0]), nay = fl29(c_f.na29[1]), bnay = fl29(c_f.bna29);
           wide_mac<ND>(Wx, nax, t6x);
@@ -872,7 +946,21 @@ static __device__ __noinline__ vcyc cyc_pair(int iu_, int iv_, int ilf_, int ilg
   mul_beta(t, uy);
   lscale(buy3, t, 3);
   limbs_dbl<ND>(uy2, uy);
-  {                                              // F = 3 u^2 + 3 xi V - 2 l
+  if constexpr (XS) {                            // F = 3 u^2 + (3 xi' V - 2 l): xi' V by shifts and adds, the linear part as ONE product with R mod q
+    fl<ND> Tx, Ty, linx, liny;
+    uint32_t d[FL];
+    mul_xi(Tx, Ty, Vx, Vy);                      // limbs <= 2^29 + 8, values below 16 q
+#pragma unroll
+    for (int i = 0; i < FL; i++) d[i] = 3 * Tx.l[i] + kx.l[i];      // kx = K - 2 l.x: limbs <= 2^29 + 8
+    lnorm(linx, d);
+#pragma unroll
+    for (int i = 0; i < FL; i++) d[i] = 3 * Ty.l[i] + ky.l[i];
+    lnorm(liny, d);
+    const fl<ND> x[3] = {u3x, buy3, linx}, y[3] = {ux, uy, oneL};
+    sop_limbs<ND, 3, 4>(Fx, x, y);               // 3 + 3 + 1 units
+    const fl<ND> x1[2] = {u3x, liny}, y1[2] = {uy2, oneL};
+    sop_limbs<ND, 2, 5>(Fy, x1, y1);             // 6 + 1 units
+  } else {                                       // F = 3 u^2 + 3 xi V - 2 l
     const fl<ND> x[5] = {u3x, buy3, fl29(c_f.cyc29[0]), fl29(c_f.cyc29[2]), kx}, y[5] = {ux, uy, Vx, Vy, oneL};
     sop_limbs<ND, 5, 4>(Fx, x, y);               // 3 + 3 + 1 + 1 + 1 units
     const fl<ND> x1[4] = {u3x, fl29(c_f.cyc29[0]), fl29(c_f.cyc29[1]), ky}, y1[4] = {uy2, Vy, Vx, oneL};
@@ -892,10 +980,24 @@ static __device__ __noinline__ vcyc cyc_pair(int iu_, int iv_, int ilf_, int ilg
       const fl<ND> x1[2] = {ux, uy}, y1[2] = {vy, vx};
       sop_limbs<ND, 2>(Ty, x1, y1);
     }
+    if constexpr (XS) {                          // 6 xi' T + 2 l: one product with R mod q per component
+      fl<ND> Xx, Xy, lin;
+      uint32_t d[FL];
+      mul_xi(Xx, Xy, Tx, Ty);
+#pragma unroll
+      for (int i = 0; i < FL; i++) d[i] = 6 * Xx.l[i] + l2x.l[i];
+      lnorm(lin, d);
+      { const fl<ND> x[1] = {lin}, y[1] = {oneL}; sop_limbs<ND, 1, 1>(Gx, x, y); }
+#pragma unroll
+      for (int i = 0; i < FL; i++) d[i] = 6 * Xy.l[i] + l2y.l[i];
+      lnorm(lin, d);
+      { const fl<ND> x[1] = {lin}, y[1] = {oneL}; sop_limbs<ND, 1, 1>(Gy, x, y); }
+    } else {
     const fl<ND> x[3] = {fl29(c_f.cyc29[3]), fl29(c_f.cyc29[5]), l2x}, y[3] = {Tx, Ty, oneL};
     sop_limbs<ND, 3, 1>(Gx, x, y);
     const fl<ND> x1[3] = {fl29(c_f.cyc29[3]), fl29(c_f.cyc29[4]), l2y}, y1[3] = {Ty, Tx, oneL};
     sop_limbs<ND, 3, 1>(Gy, x1, y1);
+    }
   } else {                                       // G = 6 u v + 2 l
     fl<ND> wx, wy;
     uint32_t d[FL];
@@ -971,6 +1073,174 @@ static PBC_DEV void f12_lds_export(f12 *r, int buf) {
   }
 }
 
+// ---- point arithmetic on E(F_q): y^2 = x^3 + b in limb form (six-limb fields) -----------------------------------------
+// The Miller loop's tangent / chord steps with V = (X, Y, Z) and the fixed P kept as 6-limb elements in the redundant
+// representation of pairing_al.cuh / pairing_d.cuh (no conditional subtractions; differences through borrowed multiples
+// of q; a parallel carry pass where a product needs normalised limbs), so that a step is ~20 limb products without a
+// conversion -- the word-form steps spend 110 instructions around the 72 multiply-adds of every product.  The formulas
+// and the classes (limb size u in units of 2^29, value bound B in units of q) are those of d_dbl_core_l / d_add_core_l
+// with a = 0; the host mirror tracks and asserts them.
+static constexpr bool kLimbPoint = FL == 6 && kLdsMiller;
+typedef fl<ND> el;
+enum { PK2 = 0, PK4 = 1, PK16 = 2, PK32 = 3 };                // (c, D) = (2, 1), (4, 2), (16, 2), (32, 2)
+#ifdef PBC_HOSTSIM
+static constexpr double PU_STRICT = 1.0 - 1.0 / 536870912.0, PU_ALMOST = 1.0 + 7.0 / 536870912.0;
+static constexpr double PKC[4] = {2, 4, 16, 32}, PKD[4] = {1, 2, 2, 2};
+static constexpr double PSLACK = 16384.0;                     // R / q > 2^14
+static void ph_fail(const char *what, double v) { fprintf(stderr, "hostsim: limb-form type f point arithmetic: %s (%g)\n", what, v); abort(); }
+static void ph_limbs(const el &a) {
+  for (int i = 0; i < FL; i++)
+    if ((double) a.l[i] > a.hs_u * 536870912.0) ph_fail("limb above its tracked bound", a.hs_u);
+}
+static void ph_set(el &r, double u, double B) { r.hs_u = u; r.hs_B = B; ph_limbs(r); }
+static void ph_dom(const el &b, int k) {
+  ph_limbs(b);
+  if (b.hs_u > PKD[k] * PU_STRICT + 1e-12) ph_fail("subtrahend limbs not dominated", b.hs_u);
+  // top limb: K's is at least c q / 2^145 - 1 - D, b's at most B q / 2^145, and q >= 2^152 (init checks it: pl_ok)
+  if ((PKC[k] - b.hs_B) * 128.0 < PKD[k] + 1) ph_fail("subtrahend value not dominated", b.hs_B);
+}
+static void ph_cols(double s) { if (s > (64.0 - FL) / FL - 0.01) ph_fail("column capacity", s); }
+#define PL_HS(...) __VA_ARGS__
+#else
+#define PL_HS(...)
+#endif
+static PBC_DEV el pl_const(int k) {
+  el r;
+#pragma unroll
+  for (int l = 0; l < FL; l++) r.l[l] = c_f.pk29[k][l < 6 ? l : 5];
+  return r;
+}
+static PBC_DEV void pl_from_fq(el &r, const fq &a) { to_limbs<ND>(r, a); PL_HS(ph_set(r, PU_STRICT, 1.0);) }
+static PBC_DEV void pl_add(el &r, const el &a, const el &b) {
+#pragma unroll
+  for (int i = 0; i < FL; i++) r.l[i] = a.l[i] + b.l[i];
+  PL_HS(if (a.hs_u + b.hs_u >= 8) ph_fail("sum overflows 32 bits", a.hs_u + b.hs_u); ph_set(r, a.hs_u + b.hs_u, a.hs_B + b.hs_B);)
+}
+template <int S>
+static PBC_DEV void pl_shl(el &r, const el &a) {
+#pragma unroll
+  for (int i = 0; i < FL; i++) r.l[i] = a.l[i] << S;
+  PL_HS(if (a.hs_u * (1 << S) >= 8) ph_fail("shift overflows 32 bits", a.hs_u); ph_set(r, a.hs_u * (1 << S), a.hs_B * (1 << S));)
+}
+static PBC_DEV void pl_subk(el &r, const el &a, const el &b, int k) {      // a + K_k - b
+  const el K = pl_const(k);
+  PL_HS(ph_dom(b, k); const double u = a.hs_u + PKD[k] + 1, B = a.hs_B + PKC[k]; if (u >= 8) ph_fail("difference overflows 32 bits", u);)
+#pragma unroll
+  for (int i = 0; i < FL; i++) r.l[i] = a.l[i] - b.l[i] + K.l[i];
+  PL_HS(ph_set(r, u, B);)
+}
+static PBC_DEV void pl_negk(el &r, const el &b, int k) {
+  const el K = pl_const(k);
+  PL_HS(ph_dom(b, k);)
+#pragma unroll
+  for (int i = 0; i < FL; i++) r.l[i] = K.l[i] - b.l[i];
+  PL_HS(ph_set(r, PKD[k] + 1, PKC[k]);)
+}
+static PBC_DEV void pl_norm(el &r, const el &a) {             // parallel carry pass: limbs <= 2^29 + 6
+  uint32_t c = 0;
+  PL_HS(ph_limbs(a); const double B = a.hs_B; if (a.hs_u >= 8) ph_fail("normalising limbs above 32 bits", a.hs_u);)
+#pragma unroll
+  for (int i = 0; i < FL; i++) {
+    const uint32_t t = a.l[i];
+    r.l[i] = (i < FL - 1 ? (t & Limbs29<ND>::MASK) : t) + c;
+    c = t >> 29;
+  }
+  PL_HS(ph_set(r, PU_ALMOST, B);)
+}
+template <int UNITS>                                          // UNITS: the product of the operands' limb sizes (a column holds 9)
+static PBC_DEV void pl_mul(el &r, const el &a, const el &b) {
+  const el x[1] = {a}, y[1] = {b};
+  PL_HS(ph_limbs(a); ph_limbs(b); ph_cols(a.hs_u * b.hs_u); if (a.hs_u * b.hs_u > UNITS + 0.001) ph_fail("more product units than declared", a.hs_u * b.hs_u);
+        const double B = 1 + a.hs_B * b.hs_B / PSLACK;)
+  sop_limbs<ND, 1, UNITS - 1>(r, x, y);
+  PL_HS(ph_set(r, PU_STRICT, B);)
+}
+static PBC_DEV void pl_sqr(el &r, const el &a) {              // a (almost) normalised
+  PL_HS(const el x[1] = {a}; ph_limbs(a); if (a.hs_u > PU_ALMOST) ph_fail("squaring an unnormalised element", a.hs_u); hs_sop_check<ND>(x, x, 1);
+        const double B = 1 + a.hs_B * a.hs_B / PSLACK;)
+  sqr_limbs<ND>(r.l, a.l);
+  PL_HS(ph_set(r, PU_STRICT, B);)
+}
+static PBC_DEV void pl_sop2(el &r, const el &a0, const el &b0, const el &a1, const el &b1) {   // a0 b0 + a1 b1, one reduction
+  const el x[2] = {a0, a1}, y[2] = {b0, b1};
+  PL_HS(ph_limbs(a0); ph_limbs(b0); ph_limbs(a1); ph_limbs(b1); ph_cols(a0.hs_u * b0.hs_u + a1.hs_u * b1.hs_u);
+        if (a0.hs_u * b0.hs_u + a1.hs_u * b1.hs_u > 2.01) ph_fail("two-term sum of unnormalised operands", a0.hs_u);
+        const double B = 1 + (a0.hs_B * b0.hs_B + a1.hs_B * b1.hs_B) / PSLACK;)
+  sop_limbs<ND, 2, 0>(r, x, y);
+  PL_HS(ph_set(r, PU_STRICT, B);)
+}
+struct pjac { el X, Y, Z; };           // X, Y almost normalised with B <= 18; Z = 2 Y Z: limbs up to 2^30, B 3
+// tangent at V and V <- 2V: a' = -M Z^2 (u 2), b' = (2YZ) Z^2 (P-class), c' = M X - 2Y^2 (almost normalised); M = 3X^2
+static PBC_DEV void f_dbl_core_l(pjac &V, el &la, el &lb, el &lc) {
+  el ZZ, XX, YY, M, t0, t1, S1, Z3, W, Xn, Yn;
+  pl_mul<4>(ZZ, V.Z, V.Z);
+  pl_sqr(XX, V.X);
+  pl_sqr(YY, V.Y);
+  pl_shl<1>(M, XX);
+  pl_add(M, M, XX);                    // u 3, B 4
+  pl_norm(M, M);
+  pl_mul<1>(la, M, ZZ);
+  pl_negk(la, la, PK2);                // u 2, B 2
+  pl_mul<2>(Z3, V.Y, V.Z);
+  pl_shl<1>(Z3, Z3);                   // 2YZ: u 2, B 3
+  pl_mul<2>(lb, Z3, ZZ);
+  pl_mul<1>(lc, M, V.X);
+  pl_shl<1>(t1, YY);                   // u 2, B 3
+  pl_subk(lc, lc, t1, PK4);            // u 4, B 5.5
+  pl_norm(lc, lc);
+  pl_mul<1>(S1, V.X, YY);              // X Y^2
+  pl_shl<3>(t1, S1);                   // 8 X Y^2: u < 8, B 12
+  pl_norm(t1, t1);
+  pl_sqr(t0, M);
+  pl_subk(t0, t0, t1, PK16);           // X3 = M^2 - 2S, S = 4 X Y^2: u 4, B 17.5
+  pl_norm(Xn, t0);
+  pl_shl<2>(t1, S1);                   // S: u 4, B 6
+  pl_subk(W, t1, Xn, PK32);            // S - X3: u 7, B 38
+  pl_mul<7>(t0, M, W);
+  pl_sqr(t1, YY);
+  pl_shl<3>(t1, t1);                   // 8 Y^4: u < 8, B 12
+  pl_norm(t1, t1);
+  pl_subk(t0, t0, t1, PK16);           // Y3 = M (S - X3) - 8Y^4: u 4, B 17.5
+  pl_norm(Yn, t0);
+  V.X = Xn;
+  V.Y = Yn;
+  V.Z = Z3;
+}
+// chord through V and +-P, V <- V +- P: a' = -R = Y - Py Z^3, b' = Z3, c' = R Px - Z3 Py   (Py: the sign already applied)
+static PBC_DEV void f_add_core_l(pjac &V, const el &Px, const el &Py, el &la, el &lb, el &lc) {
+  el ZZ, H, Rn, HH, HHH, t0, t1, Z3, W, Xn, nY;
+  pl_mul<4>(ZZ, V.Z, V.Z);
+  pl_mul<1>(H, Px, ZZ);
+  pl_subk(H, H, V.X, PK32);            // u 4, B 33.5
+  pl_norm(H, H);
+  pl_mul<2>(t0, V.Z, ZZ);
+  pl_mul<1>(t0, Py, t0);
+  pl_subk(Rn, V.Y, t0, PK2);           // -R: u 4, B 19.5
+  pl_norm(Rn, Rn);
+  pl_mul<2>(Z3, V.Z, H);
+  la = Rn;
+  lb = Z3;
+  pl_sop2(t0, Rn, Px, Z3, Py);         // -(c'): Rn Px + Z3 Py with Rn = -R
+  pl_negk(lc, t0, PK2);                // u 2, B 2
+  pl_norm(lc, lc);
+  pl_sqr(HH, H);
+  pl_mul<1>(HHH, HH, H);
+  pl_mul<1>(t0, V.X, HH);              // X1 H^2
+  pl_sqr(t1, Rn);
+  pl_subk(t1, t1, HHH, PK2);           // u 3, B 3.5
+  pl_shl<1>(W, t0);                    // u 2, B 3
+  pl_subk(t1, t1, W, PK4);             // X3 = R^2 - H^3 - 2 X1 H^2: u 6, B 7.5
+  pl_norm(Xn, t1);
+  pl_subk(W, Xn, t0, PK2);             // X3 - X1 H^2: u 3, B 9.5
+  pl_norm(W, W);
+  pl_negk(nY, V.Y, PK32);              // -Y1: u 3, B 32
+  pl_norm(nY, nY);
+  pl_sop2(t0, Rn, W, nY, HHH);         // Y3 = R (X1 H^2 - X3) - Y1 H^3 = Rn (X3 - X1 H^2) + (-Y1) H^3
+  V.X = Xn;
+  V.Y = t0;
+  V.Z = Z3;
+}
+
 // Miller function: G1 bytes x||y (2 x 20), G2 bytes x||y over F_q^2 (2 x 40)
 static __device__ __noinline__ bool f_miller_lane(f12 *v, const uint8_t *g1, const uint8_t *g2b) {
   const int NB = fb();
@@ -1001,16 +1271,62 @@ static __device__ __noinline__ bool f_miller_lane(f12 *v, const uint8_t *g1, con
     g2_sqr(u1, Qy);
     valid &= g2_eq(u0, u1);
   }
-  // untwist: (x, y) -> (x negalphainv X^4, y negalphainv X^3)  (f_pairing, f_param.c:296-303)
+  // untwist: (x, y) -> (x negalphainv X^4, y negalphainv X^3)  (f_pairing, f_param.c:296-303); in the basis X' = X / c of
+  // a sparse xi (init_stage4): X^4 / xi = c^-2 X'^4 / xi', X^3 / xi = c^-3 X'^3 / xi'
   {
     const g2 ni = fk2(c_f.negalphainv);
     g2_mul(Qx, Qx, ni);
     g2_mul(Qy, Qy, ni);
+    if constexpr (BM1) {
+      if (c_f.xs_ok) {
+        const g2 ci = fk2(c_f.xc_inv);
+        g2 c2;
+        g2_sqr(c2, ci);
+        g2_mul(Qx, Qx, c2);
+        g2_mul(c2, c2, ci);
+        g2_mul(Qy, Qy, c2);
+      }
+    }
   }
   djac V;
   V.X = Px; V.Y = Py; V.Z = one; V.ZZ = one;
   int cur = 0;                         // LDS area holding the accumulator (kLdsMiller)
   if constexpr (kLdsMiller) f12_lds_one(cur); else f12_one(v);
+  bool limb = false;                   // the steps on E(F_q) in limb form (wave-uniform: a property of q)
+  if constexpr (kLimbPoint) limb = c_f.pl_ok != 0;
+  if (limb) {
+    if constexpr (kLimbPoint) {
+      pjac W;
+      el PxL, PyL;
+      pl_from_fq(PxL, Px);
+      pl_from_fq(PyL, Py);
+      W.X = PxL; W.Y = PyL;
+      pl_from_fq(W.Z, one);
+      // cc_miller_no_denom (f_param.c:216-233): tangent; [double; line+add]; square
+      for (int m = c_f.rbits - 2;; m--) {
+        {
+          el la, lb, lc;
+          f_dbl_core_l(W, la, lb, lc);
+          f_line_mul_lds(cur, to_vfl(la), to_vfl(lb), to_vfl(lc), &Qx, &Qy);
+          cur = next_area(cur);
+        }
+        if (m <= 0) break;
+        const int dig = (int) ((c_f.r[m >> 5] >> (m & 31)) & 1) - (int) ((c_f.rm[m >> 5] >> (m & 31)) & 1);
+        if (dig) {                     // chord through V and +-P: the sign is the signed digit of the loop
+          el la, lb, lc, Pys = PyL;
+          if (dig < 0) {
+            pl_negk(Pys, Pys, PK2);
+            pl_norm(Pys, Pys);         // B 2
+          }
+          f_add_core_l(W, PxL, Pys, la, lb, lc);
+          f_line_mul_lds(cur, to_vfl(la), to_vfl(lb), to_vfl(lc), &Qx, &Qy);
+          cur = next_area(cur);
+        }
+        f12_sqr_lds(cur);
+        cur = next_area(cur);
+      }
+    }
+  } else
   // cc_miller_no_denom (f_param.c:216-233): tangent; [double; line+add]; square
   for (int m = c_f.rbits - 2;; m--) {
     {
@@ -1029,7 +1345,7 @@ static __device__ __noinline__ bool f_miller_lane(f12 *v, const uint8_t *g1, con
       fp_mul<ND>(lc, M, V.X);
       fp_dbl<ND>(t1, YY);
       fp_sub<ND>(lc, lc, t1);
-      if constexpr (kLdsMiller) { f_line_mul_lds(cur, to_vec<ND>(la), to_vec<ND>(lb), to_vec<ND>(lc), &Qx, &Qy); cur = next_area(cur); }
+      if constexpr (kLdsMiller) { f_line_mul_lds(cur, fq_vfl(la), fq_vfl(lb), fq_vfl(lc), &Qx, &Qy); cur = next_area(cur); }
       else f_line_mul(v, to_vec<ND>(la), to_vec<ND>(lb), to_vec<ND>(lc), &Qx, &Qy);
       fp_mul<ND>(S, V.X, YY);
       fp_dbl<ND>(S, S);
@@ -1066,7 +1382,7 @@ static __device__ __noinline__ bool f_miller_lane(f12 *v, const uint8_t *g1, con
       fp_mul<ND>(lc, R, Px);
       fp_mul<ND>(t0, Z3, Pys);
       fp_sub<ND>(lc, lc, t0);
-      if constexpr (kLdsMiller) { f_line_mul_lds(cur, to_vec<ND>(la), to_vec<ND>(Z3), to_vec<ND>(lc), &Qx, &Qy); cur = next_area(cur); }
+      if constexpr (kLdsMiller) { f_line_mul_lds(cur, fq_vfl(la), fq_vfl(Z3), fq_vfl(lc), &Qx, &Qy); cur = next_area(cur); }
       else f_line_mul(v, to_vec<ND>(la), to_vec<ND>(Z3), to_vec<ND>(lc), &Qx, &Qy);
       fp_sqr<ND>(HH, H);
       fp_mul<ND>(HHH, HH, H);
@@ -1235,10 +1551,18 @@ static __device__ void f_prod_pairing_lane(uint8_t *gt, const uint8_t *g1, const
 #endif
   if (!miller_only) f_final_exp(&F);
   if (!valid) f12_one(&F);
+  g2 cpw;                                        // c^-i: back from the basis X' = X / c of a sparse xi (init_stage4)
+  g2_zero(cpw);
+  fp_set<ND>(cpw.x, fpk<ND>().one);
 #pragma nounroll
   for (int i = 0; i < 6; i++) {
     g2 o = F.c[i];
-    if constexpr (BM1) fp_mul<ND>(o.y, o.y, dk(c_f.cinv));      // back to the reference's basis
+    if constexpr (BM1) {
+      if (c_f.xs_ok && valid && !miller_only) {
+        if (i) { g2_mul(cpw, cpw, fk2(c_f.xc_inv)); g2_mul(o, o, cpw); }
+      }
+      fp_mul<ND>(o.y, o.y, dk(c_f.cinv));        // back to the reference's basis of F_q^2
+    }
     g2_store_be(gt + 2 * fb() * i, o);
   }
 }
@@ -1307,6 +1631,8 @@ static PBC_DEV void fill_cyc(FConst &C, const FRaw &raw) {
   }
   for (int i = 0; i < 9; i++) { C.kneg29[i] = raw.kneg29[i]; C.kneg8_29[i] = raw.kneg8_29[i]; }
   C.cyc_ok = raw.k_ok;
+  for (int t = 0; t < 4; t++) for (int i = 0; i < 6; i++) C.pk29[t][i] = raw.pk29[t][i];
+  C.pl_ok = raw.pl_ok;
 }
 // stage 2 (c_f holds stage 1): negalphainv, twist b, and the Frobenius constants:
 //   X^q = negalpha^((q-1)/6) X =: c X,  X^(q^2) = conj(c) c X = N(c) X,  X^(q^6) = N(c)^3 X,
@@ -1385,6 +1711,99 @@ static PBC_DEV void init_stage3(FConst *out, const FRaw &raw) {
     for (int i = 0; i < Limbs29<ND>::L; i++) C.bna29[i] = l.l[i];
     fill_cyc(C, raw);
     C.bm1 = 1;
+  }
+  *out = C;
+}
+
+// stage 4 (c_f holds the stage-3 i-basis block): look for a small xi' = u + v i, u, v in {1, 2, 4}, in the class of
+// xi = negalpha modulo 6th powers -- xi / xi' is a 6th power iff (xi / xi')^((q^2-1)/6) = 1 -- take c with c^6 = xi / xi'
+// (the root through the decomposition of F_q^2* into its 2-3-part, generated by xi^m, and the rest; integers from the host)
+// and rewrite the block for the basis X' = X / c.  out->xs_ok stays 0 when no candidate fits (or a check fails).
+static PBC_DEV void g2_pow(g2 &r, const g2 &a, const uint32_t *e, int bits) {
+  fq one;
+  fp_set<ND>(one, fpk<ND>().one);
+  g2_zero(r);
+  r.x = one;
+  for (int i = bits - 1; i >= 0; i--) {
+    g2_sqr(r, r);
+    if ((e[i >> 5] >> (i & 31)) & 1) g2_mul(r, r, a);
+  }
+}
+static PBC_DEV void init_stage4(FConst *out, const FRaw &raw) {
+  FConst C = c_f;
+  C.xs_ok = 0;
+  C.xs_u = C.xs_v = 0;
+  fq one;
+  fp_set<ND>(one, fpk<ND>().one);
+  g2 unit;
+  g2_zero(unit);
+  unit.x = one;
+  for (int k = 0; k < ND; k++) { C.xc_inv[0][k] = one.v[k]; C.xc_inv[1][k] = 0; }
+  const g2 xi = fk2(c_f.negalpha);
+  bool found = false;
+  g2 z, w;
+  if (raw.xs_try && c_f.bm1) {
+    // (v <= 2: u x - v y is formed with the borrowed constant 8 q, which dominates 2 y)
+    static const int cand[6][2] = {{1, 1}, {2, 1}, {1, 2}, {2, 2}, {4, 1}, {4, 2}};
+    for (int t = 0; t < 6 && !found; t++) {
+      g2_zero(z);
+      for (int k = 0; k < cand[t][0]; k++) fp_add<ND>(z.x, z.x, one);
+      for (int k = 0; k < cand[t][1]; k++) fp_add<ND>(z.y, z.y, one);
+      g2 zi, cls;
+      g2_inv(zi, z);
+      g2_mul(w, xi, zi);
+      g2_pow(cls, w, raw.xs_ecls, raw.xs_eclsbits);
+      if (g2_eq(cls, unit)) { found = true; C.xs_u = cand[t][0]; C.xs_v = cand[t][1]; }
+    }
+  }
+  if (found) {
+    g2 g, wS, cm, acc = unit, cS = unit, c, chk;
+    g2_pow(g, xi, raw.xs_m, raw.xs_mbits);           // generates the subgroup of order S
+    g2_pow(wS, w, raw.xs_eS, raw.xs_eSbits);
+    g2_pow(cm, w, raw.xs_em, raw.xs_embits);
+    int j = -1;
+    for (int t = 0; t < raw.xs_S; t++) {
+      if (g2_eq(acc, wS)) { j = t; break; }
+      g2_mul(acc, acc, g);
+    }
+    found = j >= 0 && j % 6 == 0;
+    for (int t = 0; found && t < j / 6; t++) g2_mul(cS, cS, g);
+    g2_mul(c, cm, cS);
+    g2_sqr(chk, c);
+    g2_mul(chk, chk, c);
+    g2_sqr(chk, chk);                                // c^6
+    found = found && g2_eq(chk, w);
+    if (found) {
+      g2 ci, zi, gm, tbv = fk2(c_f.tb);
+      g2_inv(ci, c);
+      g2_inv(zi, z);
+      g2_pow(gm, z, raw.e6, raw.e6bits);             // X'^q = xi'^((q-1)/6) X'
+      fq n, n2, n3, n4, t, ny;
+      fp_sqr<ND>(n, gm.x);
+      fp_sqr<ND>(t, gm.y);
+      fp_add<ND>(n, n, t);                           // N(gamma') in the i-basis: x^2 + y^2
+      fp_sqr<ND>(n2, n);
+      fp_mul<ND>(n3, n2, n);
+      fp_sqr<ND>(n4, n2);
+      fp_neg<ND>(ny, z.y);
+      fl<ND> lx, ly, lby;
+      to_limbs<ND>(lx, z.x);
+      to_limbs<ND>(ly, z.y);
+      to_limbs<ND>(lby, ny);                         // beta * xi'.y = -xi'.y
+      for (int k = 0; k < ND; k++) {
+        C.negalpha[0][k] = z.x.v[k]; C.negalpha[1][k] = z.y.v[k];
+        C.negalphainv[0][k] = zi.x.v[k]; C.negalphainv[1][k] = zi.y.v[k];
+        C.gamma[0][k] = gm.x.v[k]; C.gamma[1][k] = gm.y.v[k];
+        C.xpowq2[0][k] = n.v[k]; C.xpowq6[0][k] = n3.v[k]; C.xpowq8[0][k] = n4.v[k];
+        C.xc_inv[0][k] = ci.x.v[k]; C.xc_inv[1][k] = ci.y.v[k];
+        C.tb[0][k] = tbv.x.v[k]; C.tb[1][k] = tbv.y.v[k];
+      }
+      for (int l = 0; l < FL; l++) { C.na29[0][l] = lx.l[l]; C.na29[1][l] = ly.l[l]; C.bna29[l] = lby.l[l]; }
+      fill_cyc(C, raw);
+      C.xs_su = C.xs_u == 4 ? 2 : C.xs_u == 2 ? 1 : 0;
+      C.xs_sv = C.xs_v == 2 ? 1 : 0;
+      C.xs_ok = 1;
+    }
   }
   *out = C;
 }

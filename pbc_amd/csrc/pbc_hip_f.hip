@@ -5,7 +5,7 @@
 // G1 2 fb, G2 4 fb, GT 12 fb bytes (40 / 80 / 240 B for f.param).
 // (the 5-word field keeps its Miller accumulator in one 36 KB LDS area per workgroup: four workgroups per CU, two waves per
 // SIMD; with PBC_F_AREAS=2 in two areas, one wave per SIMD and the register budget that goes with it)
-template <int N, bool BM1>
+template <int N, bool BM1, bool XS = false>
 __global__ void __launch_bounds__(kBlock, N <= 5 ? (PBC_F_AREAS == 1 ? 2 : 1) : PBC_F_WAVES) f_prod_pairing_kernel(uint8_t *gt, const uint8_t *g1,
                                                                  const uint8_t *g2, size_t n, int k, unsigned *ctr, KArgs<N> ka) {
 #ifdef PBC_F_WHATIF_TRACE                        // what-if builds only (tools/whatif_time.py --trace): per-wave start / end / HW_ID behind the results
@@ -16,7 +16,7 @@ __global__ void __launch_bounds__(kBlock, N <= 5 ? (PBC_F_AREAS == 1 ? 2 : 1) : 
     size_t ld = idx < n ? idx : n - 1;
     const int fb = (int) fpk<N>().fbytes, L1 = 2 * fb, L2 = 4 * fb, LT = 12 * fb;
     __attribute__((aligned(4))) uint8_t out[48 * N];
-    TypeF<N, BM1>::f_prod_pairing_lane(out, g1 + ld * (k < 0 ? 1 : k) * L1, g2 + ld * (k < 0 ? 1 : k) * L2, k < 0 ? 1 : k, k < 0);
+    TypeF<N, BM1, XS>::f_prod_pairing_lane(out, g1 + ld * (k < 0 ? 1 : k) * L1, g2 + ld * (k < 0 ? 1 : k) * L2, k < 0 ? 1 : k, k < 0);
     if (idx < n) {
       uint32_t *dst = reinterpret_cast<uint32_t *>(gt + idx * LT);      // LT = 12 fb is a multiple of 4
       const uint32_t *src = reinterpret_cast<const uint32_t *>(out);
@@ -56,6 +56,10 @@ template <int N> __global__ void f_init_stage3(FConst *out, FRaw raw, KArgs<N> k
   if (threadIdx.x || blockIdx.x) return;
   TypeF<N>::init_stage3(out, raw);
 }
+template <int N> __global__ void f_init_stage4(FConst *out, FRaw raw, KArgs<N> ka) {
+  if (threadIdx.x || blockIdx.x) return;
+  TypeF<N>::init_stage4(out, raw);
+}
 
 int derive_f(pbc_hip_pairing_s *P, hipStream_t s) {
   DevBuf buf;
@@ -72,13 +76,21 @@ int derive_f(pbc_hip_pairing_s *P, hipStream_t s) {
     HIP_TRY(hipMemcpyAsync(&P->fconst_i, dbuf, sizeof(FConst), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     P->f_bm1 = P->fconst_i.bm1 != 0;
+    if (P->f_bm1 && P->fraw.xs_try) {   // a sparse xi for the pairing kernels: the i-basis block rewritten for the basis X' = X / c
+      PBC_DISPATCH_F(P->nlimb, hipLaunchKernelGGL(f_init_stage4<N>, dim3(1), dim3(64), 0, s, dbuf, P->fraw, kargs<N>(P, true)));
+      HIP_TRY(hipMemcpyAsync(&P->fconst_i, dbuf, sizeof(FConst), hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipStreamSynchronize(s));
+    }
   }
   HIP_TRY(hipGetLastError());
   return 0;
 }
 
 int launch_f(pbc_hip_pairing_s *P, void *d_gt, const void *d_g1, const void *d_g2, size_t n, int k, hipStream_t s) {
-  if (P->f_bm1) {                    // i-basis constants and the instantiation that goes with them
+  if (P->f_bm1 && P->fconst_i.xs_ok && P->nlimb == 5) {     // ... with a sparse xi
+    hipLaunchKernelGGL((f_prod_pairing_kernel<5, true, true>), dim3(PBC_RGRID(f_prod_pairing_kernel<5, true, true>)), dim3(kBlock), 0, s, (uint8_t *) d_gt,
+                       (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k, unit_counter(P, s), kargs<5>(P, true));
+  } else if (P->f_bm1) {             // i-basis constants and the instantiation that goes with them
     PBC_DISPATCH_F(P->nlimb, hipLaunchKernelGGL((f_prod_pairing_kernel<N, true>), dim3(PBC_RGRID(f_prod_pairing_kernel<N, true>)), dim3(kBlock), 0, s, (uint8_t *) d_gt,
                        (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k, unit_counter(P, s), kargs<N>(P, true)));
   } else {

@@ -78,6 +78,11 @@ void *hostsim_init(const char *param, size_t len) {
       HS_DISPATCH_F(P->nlimb, TypeF<N>::init_stage3(&tmp, P->fraw));
       P->fconst_i = tmp;
       P->f_bm1 = tmp.bm1 != 0;
+      if (P->f_bm1 && P->fraw.xs_try) {  // as derive_f: the sparse xi of the pairing kernels
+        activate(P, true);
+        HS_DISPATCH_F(P->nlimb, TypeF<N>::init_stage4(&tmp, P->fraw));
+        P->fconst_i = tmp;
+      }
     }
   }
   activate(P);
@@ -130,7 +135,8 @@ int hostsim_prod_pairing(void *h, uint8_t *gt, const uint8_t *g1, const uint8_t 
     else if (P->type == 'e' && P->nlimb == 16) e_prod_pairing_lane<16>(o, a, b, k, lds, 1);
     else if (P->type == 'e') e_prod_pairing_lane<33>(o, a, b, k, lds, 1);
     else if (P->type == 'd' || P->type == 'g') { HS_DISPATCH_D(P, { std::vector<uint32_t> ws((size_t) k * TypeMNT<N, DEG>::DL_WORDS * 128); TypeMNT<N, DEG>::d_prod_pairing_lane(o, a, b, k, ws.data()); }); }
-    else if (P->f_bm1) { HS_DISPATCH_F(P->nlimb, (TypeF<N, true>::f_prod_pairing_lane(o, a, b, k))); }      // as launch_pairing / launch_prod
+    else if (P->f_bm1 && P->fconst_i.xs_ok && P->nlimb == 5) TypeF<5, true, true>::f_prod_pairing_lane(o, a, b, k);       // as launch_f
+    else if (P->f_bm1) { HS_DISPATCH_F(P->nlimb, (TypeF<N, true>::f_prod_pairing_lane(o, a, b, k))); }
     else { HS_DISPATCH_F(P->nlimb, TypeF<N>::f_prod_pairing_lane(o, a, b, k)); }
   }
   return 0;

@@ -315,7 +315,10 @@ def test_f_reference_basis_path_on_gpu():
     import pbc_amd
     from conftest import _param
     v, w = golden("f_rand16.vec"), golden("f_prod3x5_edge.vec")
-    for extra in ("hip_no_bm1 1\n", "", "hip_no_cyc 1\n", "hip_no_bm1 1\nhip_no_cyc 1\n"):     # and with plain squarings in the hard part
+    # ... with plain squarings in the hard part, with the parameter file's xi instead of the sparse one (init_stage4),
+    # with the word-form steps on E(F_q): every combination of switches is a different instruction stream, all must agree
+    for extra in ("hip_no_bm1 1\n", "", "hip_no_cyc 1\n", "hip_no_bm1 1\nhip_no_cyc 1\n", "hip_no_xs 1\n", "hip_no_limb 1\n",
+                  "hip_no_xs 1\nhip_no_limb 1\n", "hip_no_cyc 1\nhip_no_limb 1\n"):
         P = pbc_amd.Pairing(_param("f") + extra)
         assert np.array_equal(P.element_pairing(v.g1, v.g2), v.gt)
         assert np.array_equal(P.element_prod_pairing(w.g1, w.g2, w.k), w.gt)

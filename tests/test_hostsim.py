@@ -474,3 +474,24 @@ def test_element_pp_reference_vectors_on_host(sims, key, pname, group):
     """the reference's element_pp_pow_zn outputs (ref_tool ppow) through the table routines of the kernel source"""
     v = golden("%s_pp%dpow12.vec" % (pname, group))
     assert np.array_equal(sims[key].element_pp(group, v.g1[0], v.g2, v.len2), v.gt)
+
+
+@pytest.mark.parametrize("extra", ["", "hip_no_xs 1\n", "hip_no_limb 1\n", "hip_no_xs 1\nhip_no_limb 1\n", "hip_no_cyc 1\n"])
+def test_type_f_sparse_xi_and_limb_form_steps_on_host(extra):
+    """Round 4, f.param: the pairing kernels take F_q^12 in the basis X' = X / c with X'^6 = xi' = 4 + 2 i sparse (init_stage4:
+    the 6th root c on the device, products by xi' as shifts and adds) and run the steps on E(F_q) in limb form under the
+    worst-case bound tracker.  Every switch combination gives the reference's bytes; the default executes fewer
+    multiply-adds than the parameter file's xi."""
+    import hostsim
+    from conftest import _param
+    S = hostsim.HostSim(_param("f") + extra)
+    v, w, e = golden("f_rand16.vec"), golden("f_prod3x5_edge.vec"), golden("f_edge10.vec")
+    S.macs(reset=True)
+    assert np.array_equal(S.prod_pairing(v.g1[:4], v.g2[:4], 1), v.gt[:4])
+    macs = S.macs(reset=True) // 4
+    assert np.array_equal(S.prod_pairing(w.g1, w.g2, w.k), w.gt)
+    assert np.array_equal(S.prod_pairing(e.g1, e.g2, 1), e.gt)
+    if "no_xs" in extra:
+        assert macs > 1_950_000
+    elif not extra:
+        assert macs < 1_750_000

@@ -37,7 +37,10 @@ namespace pbc {
 #ifndef PBC_D_RES5
 #define PBC_D_RES5 1
 #endif
-template <int N, int DEG> constexpr bool kDResident = (N == 7 || (N == 5 && PBC_D_RES5)) && DEG == 3;
+#ifndef PBC_G_RES
+#define PBC_G_RES 0                    // experiment switch: the type g instantiation too (tools/g_resident_fault.md)
+#endif
+template <int N, int DEG> constexpr bool kDResident = ((N == 7 || (N == 5 && PBC_D_RES5)) && DEG == 3) || (PBC_G_RES && N == 5 && DEG == 5);
 
 constexpr int ND_MAX = 7;              // widest MNT field built in: 224-bit q (d224.param)
 constexpr int DEG_MAX = 5;             // d = k/2: 3 (type d), 5 (type g)

@@ -304,6 +304,50 @@ struct GAL {
     return handled;
   }
 
+  // ---- element_from_hash (curve_from_hash, ecc/curve.c:455-482) -----------------------------------------------------
+  // The routine of group_ops.cuh (g_from_hash_lane: digest expansion, the wave-cooperative search for the first x of the
+  // chain with a point above it, the canonical sign) with its two long computations in limb form: the power t^((q+1)/4)
+  // of a square-root attempt (510 squarings + 255 products for a.param) and the cofactor multiplication [h] (x, y) -- the
+  // windowed ladder above with h's bytes as the scalar (353 bits for a.param) instead of a bit-by-bit double-and-add.
+  struct LimbSqrt {
+    static PBC_DEV void attempt(fp<N> &y, bool &ok, const fp<N> &t) {
+      el a, r = one_el();
+      A::to_el(a, t);
+      for (int i = c_curve.sqrt_bits - 1; i >= 0; i--) {
+        A::sqr(r, r);                  // P-class in, P-class out
+        if ((c_curve.sqrt_e[i >> 5] >> (i & 31)) & 1) A::mul(r, r, a);
+      }
+      A::to_words(y, r);
+      fp<N> yy;
+      fp_sqr<N>(yy, y);
+      ok = fp_eq<N>(yy, t);
+    }
+  };
+  // false (nothing written): the cofactor ladder met an exceptional point -- the caller runs g_from_hash_lane for the lane
+  static PBC_DEV bool from_hash_lane(uint8_t *out, const uint8_t *data, int hlen) {
+    constexpr int NB = 4 * N;
+    fp<N> ca, cb, x, fx, fy;
+    fp_set<N>(ca, c_curve.a);
+    fp_set<N>(cb, c_curve.b);
+    fq_from_hash_lane<N>(x, data, hlen);
+    g_hash_search<N, LimbSqrt>(fx, fy, x, ca, cb);
+    {                                  // canonical y odd
+      fp<N> o, c, ny;
+#pragma unroll
+      for (int i = 0; i < N; i++) o.v[i] = (i == 0);
+      fp_mul<N>(c, fy, o);
+      fp_neg<N>(ny, fy);
+      fp_cmov<N>(fy, ny, ((c.v[0] & 1) == 0) & !fp_is0<N>(fy));
+    }
+    // [h] (fx, fy): the cofactor as a big-endian scalar record of whole words
+    __attribute__((aligned(16))) uint8_t pt[2 * NB], zb[4 * N + 8];     // (h = (q + 1) / r has fewer bytes than q)
+    fp_store_be<N>(pt, fx);
+    fp_store_be<N>(pt + NB, fy);
+    const int zlen = (c_curve.cofbits + 7) >> 3;           // (no padding: every byte is two more windows of the ladder)
+    for (int i = 0; i < zlen; i++) zb[zlen - 1 - i] = (uint8_t) (c_curve.cofac[i >> 2] >> (8 * (i & 3)));
+    return gmul_lane(out, pt, zb, zlen);
+  }
+
   // out = a^k in GT for a of norm 1; returns false (nothing written) for any other element
   static PBC_DEV bool gt_pow_lane(uint8_t *out, const uint8_t *a, const uint8_t *z, int zlen) {
     constexpr int NB = 4 * N;

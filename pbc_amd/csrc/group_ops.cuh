@@ -653,6 +653,89 @@ PBC_DEV void fq_from_hash_lane(fp<N> &x, const uint8_t *data, int hlen) {
   fp_set<N>(r2, K.r2);
   fp_mul<N>(x, t, r2);
 }
+// The search of curve_from_hash (ecc/curve.c:462-470): the first x of the chain x0, x0^2 + 1, ... with x^3 + a x + b a square,
+// and a root y.  Half of all field elements are squares, so a lane needs two tries on average -- but a wave that lets
+// every lane walk its own chain in lockstep runs until its SLOWEST lane is done: 7.3 rounds of a 510-bit power for 64
+// lanes.  Here the wave's 64 exponentiation slots of a round are dealt to the lanes that are still searching: with P
+// of them pending, slot s works on candidate number s / P of pending lane s mod P (operands travel by ds_bpermute, a
+// candidate costs a few squarings to reach), and a lane takes the FIRST of its candidates that is a square, as the
+// reference does.  32 lanes are left after the first round, 8 after the second, none after the third: 3.1 rounds expected.
+template <int N>
+struct WordSqrt {                      // the square-root attempt of the search: y with y^2 = t, or ok = false
+  static PBC_DEV void attempt(fp<N> &y, bool &ok, const fp<N> &t) { fp_sqrt_lane<N>(y, ok, t); }
+};
+template <int N, class Sqrt = WordSqrt<N>>
+PBC_DEV void g_hash_search(fp<N> &fx, fp<N> &fy, const fp<N> &x0, const fp<N> &ca, const fp<N> &cb) {
+  fp<N> one, x = x0;
+  fp_set<N>(one, fpk<N>().one);
+  fx = x; fy = x;
+  bool done = false;
+#ifdef PBC_HOSTSIM
+  for (int it = 0; it < 256 && !done; it++) {        // one lane per call: its own chain
+    fp<N> t, y;
+    fp_sqr<N>(t, x);
+    fp_add<N>(t, t, ca);
+    fp_mul<N>(t, t, x);
+    fp_add<N>(t, t, cb);
+    bool ok;
+    Sqrt::attempt(y, ok, t);
+    if (ok) { fx = x; fy = y; done = true; }
+    fp_sqr<N>(x, x);
+    fp_add<N>(x, x, one);
+  }
+#else
+  const int lane = (int) (threadIdx.x & 63);
+  for (int round = 0; round < 200; round++) {
+    const uint64_t pend = __ballot(!done);
+    if (!pend) break;
+    const int P = __popcll(pend), maxoff = 63 / P;
+    // slot `lane` -> candidate number off of the pidx-th pending lane
+    const int pidx = lane % P, off = lane / P;
+    int src = 0, cnt = 0;
+    for (int k = 0; k < 64; k++)
+      if ((pend >> k) & 1) { src = cnt == pidx ? k : src; cnt++; }
+    fp<N> xc, t, y, nx;
+#pragma unroll
+    for (int w = 0; w < N; w++) xc.v[w] = (uint32_t) __builtin_amdgcn_ds_bpermute(src << 2, (int) x.v[w]);
+    for (int k = 0; k < maxoff; k++) {
+      fp_sqr<N>(nx, xc);
+      fp_add<N>(nx, nx, one);
+      fp_cmov<N>(xc, nx, k < off);
+    }
+    fp_sqr<N>(t, xc);
+    fp_add<N>(t, t, ca);
+    fp_mul<N>(t, t, xc);
+    fp_add<N>(t, t, cb);
+    bool ok;
+    Sqrt::attempt(y, ok, t);
+    const uint64_t okm = __ballot(ok);
+    // a pending lane of rank r owns the slots r, r + P, r + 2 P, ...: the first that found a square wins
+    const int r = __popcll(pend & ((1ull << lane) - 1ull));
+    int win = -1;
+    for (int j = maxoff; j >= 0; j--) {
+      const int sl = r + j * P;
+      win = (sl < 64 && ((okm >> sl) & 1)) ? sl : win;
+    }
+    const bool got = !done && win >= 0;
+    const int from = got ? win : lane;
+#pragma unroll
+    for (int w = 0; w < N; w++) {
+      const uint32_t vx = (uint32_t) __builtin_amdgcn_ds_bpermute(from << 2, (int) xc.v[w]);
+      const uint32_t vy = (uint32_t) __builtin_amdgcn_ds_bpermute(from << 2, (int) y.v[w]);
+      fx.v[w] = got ? vx : fx.v[w];
+      fy.v[w] = got ? vy : fy.v[w];
+    }
+    // still searching: step over the candidates this round tried for the lane
+    const int tried = (63 - r) / P + 1;
+    for (int k = 0; k <= maxoff; k++) {
+      fp_sqr<N>(nx, x);
+      fp_add<N>(nx, nx, one);
+      fp_cmov<N>(x, nx, !done && !got && k < tried);
+    }
+    done |= got;
+  }
+#endif
+}
 template <int N>
 PBC_DEV void g_from_hash_lane(uint8_t *out, const uint8_t *data, int hlen) {
   const int NB = (int) fpk<N>().fbytes;
@@ -662,24 +745,7 @@ PBC_DEV void g_from_hash_lane(uint8_t *out, const uint8_t *data, int hlen) {
   fp_set<N>(ca, c_curve.a);
   fp_set<N>(cb, c_curve.b);
   fq_from_hash_lane<N>(x, data, hlen);
-  bool done = false;
-  fx = x; fy = x;
-  for (int it = 0; it < 256; it++) {
-    fp<N> t, y;
-    fp_sqr<N>(t, x);
-    fp_add<N>(t, t, ca);
-    fp_mul<N>(t, t, x);
-    fp_add<N>(t, t, cb);
-    bool ok;
-    fp_sqrt_lane<N>(y, ok, t);
-    ok &= !done;
-    fp_cmov<N>(fx, x, ok);
-    fp_cmov<N>(fy, y, ok);
-    done |= ok;
-    if (__all(done)) break;
-    fp_sqr<N>(x, x);
-    fp_add<N>(x, x, one);
-  }
+  g_hash_search<N>(fx, fy, x, ca, cb);
   // canonical y odd
   {
     fp<N> o, c, ny;

@@ -66,6 +66,27 @@ __global__ void __launch_bounds__(kBlock, PBC_A_WAVES) al_gtpow_kernel(uint8_t *
     }
   }
 }
+// element_from_hash, type a: the limb-form routine (group_al.cuh from_hash_lane); flagged lanes: g_from_hash_kernel
+template <int N>
+__global__ void __launch_bounds__(kBlock, PBC_A_WAVES) al_hash_kernel(uint8_t *out, const uint8_t *data, int hlen, uint8_t *flags, size_t n,
+                                                                       unsigned *ctr, KArgs<N> ka) {
+  PBC_RESIDENT_LOOP(n, ctr) {
+    size_t idx = PBC_UNIT_INDEX;
+    size_t ld = idx < n ? idx : n - 1;   // whole waves search together
+    constexpr int L = 8 * N;
+    __attribute__((aligned(16))) uint8_t o[L];
+    const bool ok = GAL<N>::from_hash_lane(o, data + ld * hlen, hlen);
+    if (idx < n) {
+      flags[idx] = ok ? 0 : 1;
+      if (ok) {
+        uint4 *dst = reinterpret_cast<uint4 *>(out + idx * L);
+        const uint4 *src = reinterpret_cast<const uint4 *>(o);
+#pragma unroll
+        for (int i = 0; i < L / 16; i++) dst[i] = src[i];
+      }
+    }
+  }
+}
 // fixed-base tables (group_ops.cuh ec_pp_* / gt_pp_*): one entry per lane; one power per lane
 template <class F>
 __global__ void __launch_bounds__(kBlock, 2) ec_pp_init_kernel(uint32_t *tab, uint8_t *flags, const uint8_t *base, int zlen, size_t units, KArgs<F::NW> ka) {
@@ -106,13 +127,17 @@ __global__ void __launch_bounds__(kBlock, 2) g_compress_kernel(int dir, uint8_t 
   else g_decompress_lane<N>(out + idx * 2 * fb, in + idx * fb, true);
 }
 template <int N>
-__global__ void __launch_bounds__(kBlock, 2) g_from_hash_kernel(uint8_t *out, const uint8_t *data, int hlen, size_t n, KArgs<N> ka) {
+__global__ void __launch_bounds__(kBlock, 2) g_from_hash_kernel(uint8_t *out, const uint8_t *data, int hlen, const uint8_t *flags, size_t n, KArgs<N> ka) {
   size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
-  size_t ld = idx < n ? idx : n - 1;   // whole waves stay in the retry loop together
+  size_t ld = idx < n ? idx : n - 1;   // whole waves search together
+  // (flags != null: the complete pass behind al_hash_kernel -- a wave without a reported lane retires at once, else the
+  // whole wave searches, since the search deals its candidates over all 64 lanes, and the reported lanes store)
+  const bool mine = !flags || (idx < n && flags[idx] != 0);
+  if (flags && !__ballot(mine)) return;
   const int L = 2 * (int) fpk<N>().fbytes;
   __attribute__((aligned(4))) uint8_t o[8 * N];
   g_from_hash_lane<N>(o, data + ld * hlen, hlen);
-  if (idx < n)
+  if (idx < n && mine)
     for (int i = 0; i < L; i++) out[idx * L + i] = o[i];
 }
 // element_from_hash / element_to_bytes_compressed / element_from_bytes_compressed on the G2 twists (types d, g, f):
@@ -334,8 +359,13 @@ static int group_launch(pbc_hip_pairing_s *P, const GroupCall &c, void *d_out, c
   } else if (c.group == 2 && !symmetric(P)) {          // point formats and hashing on the twists
     const int what = c.op == G_HASH ? 0 : c.op - G_COMPRESS + 1;
     PBC_DISPATCH_TWIST(P, hipLaunchKernelGGL(g2_point_kernel<F>, dim3(grid), dim3(kBlock), 0, s, what, o, a, c.aux, n, kargs<F::NW>(P)));
+  } else if (c.op == G_HASH && fast_a) {
+    uint8_t *flags = (uint8_t *) W.get(n);
+    if (!flags) return 1;
+    hipLaunchKernelGGL(al_hash_kernel<16>, dim3(PBC_RGRID(al_hash_kernel<16>)), dim3(kBlock), 0, s, o, a, c.aux, flags, n, unit_counter(P, s), kargs<16>(P));
+    hipLaunchKernelGGL(g_from_hash_kernel<16>, dim3(grid), dim3(kBlock), 0, s, o, a, c.aux, (const uint8_t *) flags, n, kargs<16>(P));
   } else if (c.op == G_HASH) {
-    PBC_DISPATCH_N(P->nlimb, hipLaunchKernelGGL(g_from_hash_kernel<N>, dim3(grid), dim3(kBlock), 0, s, o, a, c.aux, n, kargs<N>(P)));
+    PBC_DISPATCH_N(P->nlimb, hipLaunchKernelGGL(g_from_hash_kernel<N>, dim3(grid), dim3(kBlock), 0, s, o, a, c.aux, (const uint8_t *) nullptr, n, kargs<N>(P)));
   } else {
     PBC_DISPATCH_N(P->nlimb, hipLaunchKernelGGL(g_compress_kernel<N>, dim3(grid), dim3(kBlock), 0, s, c.op - G_COMPRESS, o, a, n, kargs<N>(P)));
   }

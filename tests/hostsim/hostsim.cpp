@@ -348,7 +348,13 @@ int hostsim_from_hash(void *h, uint8_t *out, const uint8_t *data, int hlen, size
     P->hash.ts_ready = true;
     activate(P);
   }
-  for (size_t i = 0; i < n; i++) { HS_DISPATCH(P->nlimb, g_from_hash_lane<N>(out + i * P->len1, data + i * hlen, hlen)); }
+  for (size_t i = 0; i < n; i++) {
+    if (P->type == 'a' && !P->a_generic && !hostsim_slow_group) {       // as the library: the limb-form routine first
+      if (GAL<16>::from_hash_lane(out + i * P->len1, data + i * hlen, hlen)) continue;
+      hostsim_fallbacks++;
+    }
+    HS_DISPATCH(P->nlimb, g_from_hash_lane<N>(out + i * P->len1, data + i * hlen, hlen));
+  }
   return 0;
 }
 // diagnostics mirroring pbc_hip_diag_stage

@@ -1015,6 +1015,106 @@ PBC_DEV void gt_pp_pow_lane(uint8_t *out, const uint32_t *__restrict__ tab, cons
   G::store(out, acc);
 }
 
+// element_pow_zn on GT of type f for elements of the cyclotomic subgroup (every pairing value, and every product and
+// power of such): the running power stays in the pairing kernels' LDS area, squarings are Granger-Scott squarings
+// (pairing_f.cuh f12_cyc_sqr_lds: ~half the work of a general F_q^12 squaring), the scalar is recoded into regular signed
+// 4-bit windows as for the curve groups (inversion is the q^6-power: a conjugation), one product per window with an entry
+// of the per-lane table a, a^3, ..., a^15.  T is the instantiation the object's pairing kernels use (i-basis / sparse xi:
+// the element is mapped into that basis on the way in and back on the way out, as a Miller value is).  Membership in the
+// subgroup is TESTED (a^(q^4) a = a^(q^2)): any other element is reported (false, nothing written) for f_gt_pow_lane.
+template <class T>
+__device__ bool f_gt_pow_cyc_lane(uint8_t *out, const uint8_t *ab, const uint8_t *z, int zlen) {
+  constexpr int ND = sizeof(typename T::fq) / 4;
+  typedef typename T::f12 f12;
+  typedef typename T::g2 g2;
+  if constexpr (!(T::kLdsMiller && T::kOneArea && T::kCap >= 9)) {
+    return false;
+  } else {
+    const int fb = T::fb();
+    const bool bm1 = c_f.bm1 != 0, xs = c_f.xs_ok != 0;
+    f12 a;
+    {
+      g2 c, cpw;
+      T::g2_inv(c, T::fk2(c_f.xc_inv));
+      T::g2_zero(cpw);
+      fp_set<ND>(cpw.x, fpk<ND>().one);
+#pragma nounroll
+      for (int i = 0; i < 6; i++) {
+        g2 t;
+        T::g2_load_be(t, ab + 2 * fb * i);
+        if (bm1) fp_mul<ND>(t.y, t.y, T::dk(c_f.cmap));
+        if (xs && i) { T::g2_mul(cpw, cpw, c); T::g2_mul(t, t, cpw); }
+        a.c[i] = t;
+      }
+    }
+    bool member = c_f.cyc_ok != 0;
+    {
+      f12 t, u;
+      T::f12_qpower(&t, &a, c_f.xpowq2);
+      T::f12_qpower(&u, &t, c_f.xpowq2);
+      T::f12_mul(&u, &u, &a);
+#pragma nounroll
+      for (int i = 0; i < 6; i++) member &= T::g2_eq(u.c[i], t.c[i]);
+      bool zero = true;                                        // 0 passes the identity; 0^0 = 1 is the generic ladder's business
+#pragma nounroll
+      for (int i = 0; i < 6; i++) zero &= fp_is0<ND>(a.c[i].x) & fp_is0<ND>(a.c[i].y);
+      member &= !zero;
+    }
+    f12 tab[8], e, ec;
+    tab[0] = a;
+    T::f12_sqr(&e, &a);
+#pragma nounroll
+    for (int j = 1; j < 8; j++) T::f12_mul(&tab[j], &tab[j - 1], &e);
+    uint32_t kw[kScalarWords];
+    scalar_load(kw, z, zlen);
+    const bool even = (kw[0] & 1) == 0;
+    kw[0] |= 1u;
+    kw[(8 * zlen) >> 5] |= 1u << ((8 * zlen) & 31);
+    auto entry = [&](int i) {          // e <- the table entry of window i, conjugated for a negative digit
+      const uint32_t v = scalar_bits(kw, 4 * i + 1, 15u);
+      const bool neg = v < 8;
+      const int idx = neg ? 7 - (int) v : (int) v - 8;
+      e = tab[idx];
+      T::f12_qpower(&ec, &e, c_f.xpowq6);
+#pragma nounroll
+      for (int c = 0; c < 6; c++) {
+        g2 p = e.c[c], q = ec.c[c];
+        fp_cmov<ND>(p.x, q.x, neg);
+        fp_cmov<ND>(p.y, q.y, neg);
+        e.c[c] = p;
+      }
+    };
+    const int t = 2 * zlen;
+    entry(t - 1);
+    T::f12_lds_import(&e, 0);
+    for (int i = t - 2; i >= 0; i--) {
+      for (int d = 0; d < 4; d++) T::f12_cyc_sqr_lds();
+      entry(i);
+      T::f12_mul_lds(0, &e);
+    }
+    f12 r, r2;
+    T::f12_lds_export(&r, 0);
+    T::f12_qpower(&ec, &a, c_f.xpowq6);            // even k: a^k = a^(k + 1) / a
+    T::f12_mul_lds(0, &ec);
+    T::f12_lds_export(&r2, 0);
+    {
+      g2 ci = T::fk2(c_f.xc_inv), cpw;
+      T::g2_zero(cpw);
+      fp_set<ND>(cpw.x, fpk<ND>().one);
+#pragma nounroll
+      for (int i = 0; i < 6; i++) {
+        g2 p = r.c[i], q = r2.c[i];
+        fp_cmov<ND>(p.x, q.x, even);
+        fp_cmov<ND>(p.y, q.y, even);
+        if (xs && i) { T::g2_mul(cpw, cpw, ci); T::g2_mul(p, p, cpw); }
+        if (bm1) fp_mul<ND>(p.y, p.y, T::dk(c_f.cinv));
+        if (member) T::g2_store_be(out + 2 * fb * i, p);
+      }
+    }
+    return member;
+  }
+}
+
 // ---- pairing->finalpow (include/pbc_pairing.h:41; a_finalpow a_param.c:1420-1429, cc_finalpow d_param.c:566-568,
 // g_finalpow g_param.c:1162-1164, f_finalpow f_param.c:285-287, e_finalpow e_param.c:828-830): the final exponentiation
 // alone, on an element of GT's underlying field in GT's wire format (the consumers are gt_random / gt_from_hash,

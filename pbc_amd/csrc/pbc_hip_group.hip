@@ -87,6 +87,24 @@ __global__ void __launch_bounds__(kBlock, PBC_A_WAVES) al_hash_kernel(uint8_t *o
     }
   }
 }
+// element_pow_zn on GT, type f (5-word fields): cyclotomic squarings in the LDS area (group_ops.cuh f_gt_pow_cyc_lane);
+// elements outside the cyclotomic subgroup are flagged for gt_op_kernel
+template <int N, bool BM1, bool XS>
+__global__ void __launch_bounds__(kBlock, 2) f_gtpow_kernel(uint8_t *out, const uint8_t *a, const uint8_t *z, int zlen, uint8_t *flags, size_t n, KArgs<N> ka) {
+  size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
+  size_t ld = idx < n ? idx : n - 1;
+  const int LT = 12 * (int) fpk<N>().fbytes;
+  __attribute__((aligned(4))) uint8_t o[48 * N];
+  const bool ok = f_gt_pow_cyc_lane<TypeF<N, BM1, XS>>(o, a + ld * LT, z + ld * zlen, zlen);
+  if (idx < n) {
+    flags[idx] = ok ? 0 : 1;
+    if (ok) {
+      uint32_t *dst = reinterpret_cast<uint32_t *>(out + idx * LT);
+      const uint32_t *src = reinterpret_cast<const uint32_t *>(o);
+      for (int i = 0; i < LT / 4; i++) dst[i] = src[i];
+    }
+  }
+}
 // fixed-base tables (group_ops.cuh ec_pp_* / gt_pp_*): one entry per lane; one power per lane
 template <class F>
 __global__ void __launch_bounds__(kBlock, 2) ec_pp_init_kernel(uint32_t *tab, uint8_t *flags, const uint8_t *base, int zlen, size_t units, KArgs<F::NW> ka) {
@@ -353,6 +371,16 @@ static int group_launch(pbc_hip_pairing_s *P, const GroupCall &c, void *d_out, c
     if (!flags) return 1;
     hipLaunchKernelGGL(al_gtpow_kernel<16>, dim3(PBC_RGRID(al_gtpow_kernel<16>)), dim3(kBlock), 0, s, o, a, b, P->len_zr, flags, n, unit_counter(P, s), kargs<16>(P));
     hipLaunchKernelGGL(gt_op_kernel<16>, dim3(grid), dim3(kBlock), 0, s, P->type, 1, o, a, b, P->lenT, P->len_zr, (const uint8_t *) flags, n, kargs<16>(P));
+  } else if (c.op == GT_POW && P->type == 'f' && P->nlimb == 5 && !P->group_slow) {
+    uint8_t *flags = (uint8_t *) W.get(n);
+    if (!flags) return 1;
+    if (P->f_bm1 && P->fconst_i.xs_ok)
+      hipLaunchKernelGGL((f_gtpow_kernel<5, true, true>), dim3(grid), dim3(kBlock), 0, s, o, a, b, P->len_zr, flags, n, kargs<5>(P, true));
+    else if (P->f_bm1)
+      hipLaunchKernelGGL((f_gtpow_kernel<5, true, false>), dim3(grid), dim3(kBlock), 0, s, o, a, b, P->len_zr, flags, n, kargs<5>(P, true));
+    else
+      hipLaunchKernelGGL((f_gtpow_kernel<5, false, false>), dim3(grid), dim3(kBlock), 0, s, o, a, b, P->len_zr, flags, n, kargs<5>(P));
+    hipLaunchKernelGGL(gt_op_kernel<5>, dim3(grid), dim3(kBlock), 0, s, P->type, 1, o, a, b, P->lenT, P->len_zr, (const uint8_t *) flags, n, kargs<5>(P));
   } else if (c.op == GT_MUL || c.op == GT_POW || c.op == GT_FINALPOW) {
     PBC_DISPATCH_N(P->nlimb, hipLaunchKernelGGL(gt_op_kernel<N>, dim3(grid), dim3(kBlock), 0, s, P->type, c.op - GT_MUL, o, a, b, P->lenT,
                                                 P->len_zr, (const uint8_t *) nullptr, n, kargs<N>(P)));

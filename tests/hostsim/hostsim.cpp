@@ -334,7 +334,19 @@ int hostsim_group(void *h, int what, uint8_t *out, const uint8_t *a, const uint8
         });
       }
       else if (P->type == 'd' || P->type == 'g') { HS_DISPATCH_D(P, if (what == 1) d_gt_mul_lane<N, DEG>(o, x, y); else d_gt_pow_lane<N, DEG>(o, x, y, P->len_zr)); }
-      else { HS_DISPATCH_F(P->nlimb, if (what == 1) f_gt_mul_lane<N>(o, x, y); else f_gt_pow_lane<N>(o, x, y, P->len_zr)); }
+      else {
+        if (what == 2 && P->nlimb == 5 && !hostsim_slow_group) {     // as the library: cyclotomic squarings in the pairing kernels' basis first
+          activate(P, true);
+          bool ok;
+          if (P->f_bm1 && P->fconst_i.xs_ok) ok = f_gt_pow_cyc_lane<TypeF<5, true, true>>(o, x, y, P->len_zr);
+          else if (P->f_bm1) ok = f_gt_pow_cyc_lane<TypeF<5, true, false>>(o, x, y, P->len_zr);
+          else ok = f_gt_pow_cyc_lane<TypeF<5, false, false>>(o, x, y, P->len_zr);
+          activate(P);
+          if (ok) continue;
+          hostsim_fallbacks++;
+        }
+        HS_DISPATCH_F(P->nlimb, if (what == 1) f_gt_mul_lane<N>(o, x, y); else f_gt_pow_lane<N>(o, x, y, P->len_zr));
+      }
     }
   }
   return 0;

@@ -90,6 +90,29 @@ def test_type_a_group_ops_on_points_of_small_order_and_other_norms(hip_a, oracle
     assert np.array_equal(hip_a.element_pow_zn_GT(A, Z), oracle_a.gt_pow(A, Z))
 
 
+@pytest.mark.parametrize("extra", ["", "hip_no_xs 1\n", "hip_no_bm1 1\n"])
+def test_type_f_gt_powers_outside_the_cyclotomic_subgroup(oracles, extra):
+    """f.param element_pow_zn on GT: the fast pass (cyclotomic squarings in the pairing kernels' basis) serves pairing
+    values; random F_q^12 elements and 0 fail its membership test and take the generic ladder; both in one ragged batch."""
+    import pbc_amd
+    H = pbc_amd.Pairing(_param("f") + extra)
+    v = golden("f_rand16.vec")
+    n = 389
+    Z, zl = _scalars("f", n, 21)
+    rng = np.random.default_rng(4)
+    A = np.ascontiguousarray(v.gt[np.arange(n) % v.n])
+    A[5::9] = rng.integers(0, 256, A[5::9].shape, dtype=np.uint8)
+    A[5::9, ::20] = 0
+    A[14] = 0
+    m = 64
+    got = H.element_pow_zn_GT(A, Z)
+    assert np.array_equal(got[:m], oracles["f"].gt_pow(A[:m], Z[:m]))
+    S = pbc_amd.Pairing(_param("f") + "hip_group_slow 1\n")
+    assert np.array_equal(got, S.element_pow_zn_GT(A, Z))
+    S.clear()
+    H.clear()
+
+
 @pytest.mark.parametrize("key,name", [("a", "a_chain1024.vec"), ("d", "d_chain256.vec"), ("f", "f_chain128.vec")])
 def test_group_dev_entry_points_streams_and_in_place(hips, key, name):
     """The _dev forms on torch buffers: two streams in flight, out == in (element_mul_zn(x, x, k) is ordinary PBC usage),

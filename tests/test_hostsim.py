@@ -495,3 +495,39 @@ def test_type_f_sparse_xi_and_limb_form_steps_on_host(extra):
         assert macs > 1_950_000
     elif not extra:
         assert macs < 1_750_000
+
+
+@pytest.mark.parametrize("extra", ["", "hip_no_xs 1\n", "hip_no_bm1 1\n"])
+def test_type_f_gt_powers_by_cyclotomic_squarings_on_host(oracles, extra):
+    """element_pow_zn on GT, f.param (group_ops.cuh f_gt_pow_cyc_lane): the element taken into the pairing kernels' basis,
+    membership in the cyclotomic subgroup checked (a^(q^4) a = a^(q^2)), Granger-Scott squarings in the LDS area with
+    regular signed 4-bit windows (inverse = conjugate); elements outside the subgroup go to the generic ladder, as in
+    the library.  Random and exceptional scalars; bytes against the oracle."""
+    import hostsim
+    from conftest import _param
+    S, O = hostsim.HostSim(_param("f") + extra), oracles["f"]
+    v = golden("f_rand16.vec")
+    r = _order("f")
+    rng = np.random.default_rng(2)
+    ks = [int.from_bytes(rng.bytes(20), "big") % r for _ in range(3)] + [0, 1, 2, r - 1, r, 2**160 - 1, 16]
+    Z = np.stack([_be(k, 20) for k in ks])
+    g = v.gt[:len(ks)]
+    S.fallbacks()
+    S.macs(reset=True)
+    assert np.array_equal(S.group(2, g, Z), O.gt_pow(g, Z))
+    fast = S.macs(reset=True) // len(ks)
+    assert S.fallbacks() == 0
+    A = rng.integers(0, 256, (2, 240), dtype=np.uint8)
+    A[:, ::20] = 0
+    A = np.concatenate([A, np.zeros((1, 240), np.uint8)])      # and 0, which has no inverse
+    assert np.array_equal(S.group(2, A, Z[:3]), O.gt_pow(A, Z[:3]))
+    assert S.fallbacks() == 3
+    S.group_mode(True)
+    try:
+        S.macs(reset=True)
+        assert np.array_equal(S.group(2, g, Z), O.gt_pow(g, Z))
+        slow = S.macs(reset=True) // len(ks)
+    finally:
+        S.group_mode(False)
+    if not extra:
+        assert fast < 0.5 * slow, (fast, slow)

@@ -122,22 +122,38 @@ def cpu_baseline(param_path, k=1, fixture=None):
             "sample": "%d units, single thread, oracle/pbc_oracle.c" % (m // k)}
 
 
-def pmc_traffic(workload):
-    """HBM bytes per launch from the rocprofv3 PMC passes (separate --pmc FETCH_SIZE /
-    WRITE_SIZE runs of this same command, summarised in profiles/): (FETCH_SIZE + WRITE_SIZE) KB.
-    Raw counter sum; on gfx950 FETCH_SIZE may under-count wide coalesced reads by 2x
-    (MI355X_MICROARCH.md).  None when no PMC summary is committed for the workload."""
-    for rel in ("profiles/r03_pmc_%s.json" % workload, "profiles/r02_pmc_%s.json" % workload,
-                "profiles/r01_final_a_pairing_pmc.json" if workload == "a" else None):
-        path = os.path.join(ROOT, rel) if rel else None
-        if path and os.path.exists(path):
-            j = json.load(open(path))
-            if "FETCH_SIZE" not in j or "WRITE_SIZE" not in j:
-                continue
-            kb = j["FETCH_SIZE"]["avg_per_launch"] + j["WRITE_SIZE"]["avg_per_launch"]
-            return {"bytes_per_launch": int(kb * 1024), "source": "%s (rocprofv3 --pmc passes of this command, not this run)" % rel,
-                    "note": "raw FETCH_SIZE + WRITE_SIZE; the excess over the algorithmic bytes is register-spill (scratch) traffic"}
+def pmc_traffic(workload, alg_bytes=None, n=None):
+    """HBM bytes per launch from the rocprofv3 PMC passes (separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of this
+    same command, taken by tools/r04_collect.sh at the commit the summary names): the guide's gfx950 correction applied
+    -- FETCH_SIZE counts 32-byte requests as if they were 64-byte ones on wide coalesced reads, so the read bytes are
+    2 x FETCH_SIZE KB -- and `ratio_vs_algorithmic` = corrected bytes / the records the launch has to read and write.
+    A ratio well above 1 is scratch (register spill / private array) traffic.  None when no summary is committed."""
+    for rel in ("profiles/r04_pmc_%s.json" % workload, "profiles/r03_pmc_%s.json" % workload, "profiles/r02_pmc_%s.json" % workload):
+        path = os.path.join(ROOT, rel)
+        if not os.path.exists(path):
+            continue
+        j = json.load(open(path))
+        if "FETCH_SIZE" not in j or "WRITE_SIZE" not in j:
+            continue
+        rd, wr = j["FETCH_SIZE"]["avg_per_launch"] * 1024, j["WRITE_SIZE"]["avg_per_launch"] * 1024
+        out = {"bytes_per_launch": int(2 * rd + wr), "raw": {"FETCH_SIZE_bytes": int(rd), "WRITE_SIZE_bytes": int(wr)},
+               "correction": "read bytes = 2 x FETCH_SIZE (MI355X_MICROARCH.md, gfx950); WRITE_SIZE as reported",
+               "source": "%s (rocprofv3 --pmc passes of this command%s; not this run)" % (rel, ", commit " + j["commit"][:12] if "commit" in j else ""),
+               "units_per_launch": j.get("units_per_launch")}
+        units = j.get("units_per_launch") or n
+        if alg_bytes is not None and n and units:
+            out["ratio_vs_algorithmic"] = round((2 * rd + wr) / (alg_bytes / n * units), 3)
+        return out
     return None
+
+
+def evidence_commit():
+    """the commit tools/r04_collect.sh took this snapshot from (it writes .evidence_head next to this file and refuses a
+    dirty tree); None outside an evidence run"""
+    try:
+        return open(os.path.join(ROOT, ".evidence_head")).read().strip() or None
+    except OSError:
+        return None
 
 
 def executed_macs(workload):
@@ -439,7 +455,7 @@ def main():
                 "executed": None if exe_rate is None else {
                     "macs_per_unit": exe_per_unit, "achieved": round(exe_rate / 1e12, 4), "frac": round(exe_rate / MAC_PEAK, 4),
                     "note": "multiply-adds the kernel source executes (profiles/executed_macs.json, tools/executed_macs.py)"},
-                "traffic": pmc_traffic(args.workload),
+                "traffic": pmc_traffic(args.workload, alg_bytes, n),
                 "kernel_ms": round(avg_kern_s * 1e3, 3),
                 "algorithmic_macs_per_unit": macs_per_unit,
                 "executed_macs_per_unit": exe_per_unit,
@@ -450,6 +466,8 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(param_path, k, fixture)
+        if evidence_commit():
+            out["commit"] = evidence_commit()
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

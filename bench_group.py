@@ -153,6 +153,7 @@ def load_bls(path):
 
 
 def main(args, load_vec, ensure_built, MAC_PEAK):
+    import bench                                     # pmc_traffic / evidence_commit (bench.py calls this with itself as __main__)
     pname, fixture, op, dlog = GROUP_WORKLOADS[args.workload]
     if args.log2n is None:
         args.log2n = dlog
@@ -386,12 +387,14 @@ def main(args, load_vec, ensure_built, MAC_PEAK):
                     "note": "F_q products of the reference's algorithm (generic_pow_mpz over the affine group law / the towers) x (2 N^2 + N); its inversions are not priced"},
                 "executed": None if exe_rate is None else {"macs_per_unit": exe, "achieved": round(exe_rate / 1e12, 4), "frac": round(exe_rate / MAC_PEAK, 4),
                                                             "note": "multiply-adds the kernel source executes (profiles/executed_macs.json)"},
-                "traffic": None, "kernel_ms": round(my_ms, 3),
+                "traffic": bench.pmc_traffic(args.workload, n * unit_bytes, n), "kernel_ms": round(my_ms, 3),
                 "hbm": {"achieved": round(n * unit_bytes / sec / 1e9, 3), "peak": 8000.0, "unit": "GB/s", "algorithmic_bytes_per_unit": unit_bytes},
             },
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(param_path, op)
+        if bench.evidence_commit():
+            out["commit"] = bench.evidence_commit()
         print(json.dumps(out), flush=True)
     if pp is not None:
         pp.clear()

@@ -1,0 +1,19 @@
+#!/bin/bash
+# Round-4 evidence driver (run HERE, in the build container): every number under profiles/r04_* comes from ONE commit.
+#   1. refuses to start when the work tree is dirty (tracked changes or untracked, unignored files);
+#   2. stamps HEAD into .evidence_head (git-ignored; it travels with the gpurun snapshot, bench.py copies it into every
+#      JSON line as "commit");
+#   3. one gpurun call of tools/r04_evidence.sh (suite, bench lines, kernel traces, PMC passes);
+#   4. tools/r04_summarise.py turns gpurun_out/ev_r04 into profiles/r04_* -- it checks again that HEAD has not moved and
+#      the tree is still clean, and writes profiles/r04_MANIFEST.json (commit, files, time).
+# Usage: tools/r04_collect.sh [gpurun timeout seconds]   (environment of r04_evidence.sh is passed through: WITH_TESTS=1 ...)
+cd "$(dirname "$0")/.." || exit 1
+if [ -n "$(git status --porcelain)" ]; then echo "work tree is dirty: commit first (evidence is taken from a commit, not from a state)"; git status --short | head; exit 1; fi
+git rev-parse HEAD > .evidence_head
+rm -rf gpurun_out/ev_r04
+ENVS=""; for v in WITH_TESTS BENCH_WL GROUP_WL PMC_WL CPU_WL GROUP_CPU_WL SKIP_SWEEP; do [ -z "${!v+x}" ] || ENVS="$ENVS $v='${!v}'"; done
+/usr/local/graft/bin/gpurun --timeout ${1:-2400} -- "$ENVS bash tools/r04_evidence.sh"
+rc=$?
+rm -f .evidence_head
+[ $rc -eq 0 ] || { echo "gpurun rc=$rc: nothing summarised"; exit $rc; }
+python tools/r04_summarise.py

@@ -90,9 +90,16 @@ int pbc_hip_pairing_length_in_bytes_GT(const pbc_hip_pairing_t *p);
 int pbc_hip_element_pairing_batch(pbc_hip_pairing_t *p, uint8_t *gt, const uint8_t *g1,
                                   const uint8_t *g2, size_t n);
 /* Same with device-resident buffers, enqueued on `stream` (a hipStream_t; NULL = default
- * stream).  Asynchronous: returns after the launch.  (Types a, f and the 7-word type d fields: the kernel keeps as many
- * workgroups resident as the device holds and every lane walks the batch in strides of that residency -- 1024 x 128
- * units on an MI355X --, so the time of a launch grows in steps of ceil(n / 131072).) */
+ * stream).  Asynchronous: returns after the launch.
+ * Batch sizes (MI355X, a.param; profiles/r04_sweep_*.json, tools/r04_wave.py).  The throughput kernels give every LANE a
+ * whole pairing: a launch costs one lane's 2.1 M dependent multiply-adds however small it is -- 6.4 ms for any
+ * n <= 32768 (one wave per SIMD), 10.3 ms up to 131072 (two waves per SIMD: one chip residency of 1024 workgroups x 128
+ * lanes), and from there the resident workgroups walk the batch in strides of the residency, so the time grows in
+ * steps of ceil(n / 131072) x 10 ms (2^20: 79.5 ms, 13.1 M pairings/s); n = 131073 pays a whole second stride.  Feed
+ * multiples of 131072 where you can.  Type f: 8.3 ms / 12.0 ms / steps of 12 ms.
+ * Cut-over for small batches (type a, 512-bit q): up to 4096 units ("hip_wave_max N" in the parameter text moves it,
+ * 0 disables it) a launch gives every pairing a WAVEFRONT (csrc/pairing_aw.cuh: one limb per lane, products across
+ * the lanes): 2.2 ms for n <= 1024, 2.9 ms at 2048, 5.5 ms at 4096 -- same bytes as the throughput kernel. */
 int pbc_hip_element_pairing_batch_dev(pbc_hip_pairing_t *p, void *d_gt, const void *d_g1,
                                       const void *d_g2, size_t n, void *stream);
 

@@ -1,5 +1,6 @@
 // pbc_hip_a.hip -- kernels and launches of types a, a1 and e (libpbc_hip.so; see host_common.h)
 #include "host_common.h"
+#include "pairing_aw.cuh"
 
 // One Type-A pairing per lane.  g1/g2/gt are AoS in wire format (128 B each for a.param);
 // per-lane 16-byte loads of a 128-byte record: every byte of every fetched line is used.
@@ -20,6 +21,16 @@ __global__ void __launch_bounds__(kBlock, PBC_A_WAVES) al_pairing_kernel(uint8_t
       for (int i = 0; i < L / 16; i++) dst[i] = src[i];
     }
   }
+}
+
+// Small batches: one pairing per WAVEFRONT (pairing_aw.cuh: one limb per lane, products across the lanes) -- a quarter of
+// the latency of a lane-local pairing.  One single-wave workgroup per unit.
+template <int N>
+__global__ void __launch_bounds__(64) aw_pairing_kernel(uint8_t *gt, const uint8_t *g1, const uint8_t *g2, KArgs<N> ka) {
+  constexpr int L = 8 * N;
+  const size_t idx = blockIdx.x;
+  AW<N> w;
+  w.pairing_wave(gt + idx * L, g1 + idx * L, g2 + idx * L);
 }
 
 // Products of Type-A pairings on the limb-form routines, one TERM per lane (AL::miller_record_lane): the Miller value
@@ -193,7 +204,9 @@ int derive_e(pbc_hip_pairing_s *P, hipStream_t s) {
 
 int launch_a(pbc_hip_pairing_s *P, void *d_gt, const void *d_g1, const void *d_g2, size_t n, int k, hipStream_t s, ProdWs &W) {
   unsigned grid = (unsigned) ((n + kBlock - 1) / kBlock);
-  if (P->type == 'a' && !P->a_generic && k == 1) {
+  if (P->type == 'a' && !P->a_generic && k == 1 && n <= P->a_wave_max) {
+    hipLaunchKernelGGL(aw_pairing_kernel<16>, dim3((unsigned) n), dim3(64), 0, s, (uint8_t *) d_gt, (const uint8_t *) d_g1, (const uint8_t *) d_g2, kargs<16>(P));
+  } else if (P->type == 'a' && !P->a_generic && k == 1) {
     hipLaunchKernelGGL(al_pairing_kernel<16>, dim3(PBC_RGRID(al_pairing_kernel<16>)), dim3(kBlock), 0, s, (uint8_t *) d_gt,
                        (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, unit_counter(P, s), kargs<16>(P));
   } else if (P->type == 'a' && !P->a_generic && !P->a_prod_shared) {

@@ -53,6 +53,17 @@ class HostSim:
         self.L.hostsim_prod_pairing(self.h, out.ctypes.data, g1.ctypes.data, g2.ctypes.data, n, k)
         return out
 
+    def pairing_wave(self, g1, g2):
+        """element_pairing through the one-pairing-per-wavefront routine (pairing_aw.cuh), type a"""
+        g1 = np.ascontiguousarray(g1, np.uint8)
+        g2 = np.ascontiguousarray(g2, np.uint8)
+        n = g1.size // self.len1
+        out = np.empty((n, self.lenT), np.uint8)
+        self.L.hostsim_pairing_wave.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_size_t]
+        if self.L.hostsim_pairing_wave(self.h, out.ctypes.data, g1.ctypes.data, g2.ctypes.data, n):
+            raise RuntimeError("no wave routine for this pairing")
+        return out
+
     def pp(self, g1, g2):
         g1 = np.ascontiguousarray(g1, np.uint8)
         g2 = np.ascontiguousarray(g2, np.uint8)

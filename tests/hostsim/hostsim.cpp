@@ -5,6 +5,7 @@
 #include <vector>
 #include "../../pbc_amd/csrc/host_params.h"
 #include "../../pbc_amd/csrc/pairing_al.cuh"
+#include "../../pbc_amd/csrc/pairing_aw.cuh"
 #include "../../pbc_amd/csrc/group_al.cuh"
 
 // run EXPR with N = the compile-time word count matching P->nlimb
@@ -113,6 +114,15 @@ uint64_t hostsim_macs_read(int reset) { uint64_t v = hostsim_macs; if (reset) ho
 int hostsim_lens(void *h, int *l1, int *l2, int *lt) {
   pbc_hip_pairing_s *P = (pbc_hip_pairing_s *) h;
   *l1 = P->len1; *l2 = P->len2; *lt = P->lenT;
+  return 0;
+}
+// element_pairing on the one-pairing-per-wavefront routine (pairing_aw.cuh), type a with the 512-bit field
+int hostsim_pairing_wave(void *h, uint8_t *gt, const uint8_t *g1, const uint8_t *g2, size_t n) {
+  pbc_hip_pairing_s *P = (pbc_hip_pairing_s *) h;
+  if (P->type != 'a' || P->a_generic) return 1;
+  activate(P, true);
+  for (size_t u = 0; u < n; u++) { AW<16> w; w.pairing_wave(gt + u * P->lenT, g1 + u * P->len1, g2 + u * P->len2); }
+  activate(P);
   return 0;
 }
 // n units of k terms each, one lane after the other

@@ -133,7 +133,8 @@ def test_every_resident_kernel_with_a_forced_small_grid(hips, case, name, k):
     import pbc_amd
     key = case.replace("-pp", "")
     v = golden(name)
-    P = pbc_amd.Pairing(_param({"a": "a", "f": "f"}.get(key, key)) + "hip_resident_slots 3\n")
+    # ("hip_wave_max 0": the throughput kernel also at this size, not the one-pairing-per-wavefront kernel of small batches)
+    P = pbc_amd.Pairing(_param({"a": "a", "f": "f"}.get(key, key)) + "hip_resident_slots 3\nhip_wave_max 0\n")
     ref = hips[key]
     n = 1000
     t = np.arange(n * k)

@@ -1,0 +1,54 @@
+"""GPU tests (-m gpu) of the low-latency path for small batches (round 4, pairing_aw.cuh): element_pairing on a.param with
+one WAVEFRONT per pairing -- an F_q element is one register across 18 lanes, the Montgomery product runs over the lanes
+(v_readlane / DPP wave shifts).  Batches up to "hip_wave_max" (default 4096) take it; the bytes are those of the
+throughput kernel and of the reference's vectors, invalid arguments included."""
+import numpy as np
+import pytest
+
+from conftest import golden, _param, PARAM_OF
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 1024, 4096, 4097])
+def test_wave_pairings_match_the_throughput_kernel_and_the_reference(hip_a, n):
+    import pbc_amd
+    v = golden("a_chain1024.vec")
+    T = pbc_amd.Pairing(_param("a") + "hip_wave_max 0\n")       # never the wave path
+    i = (np.arange(n) * 7 + 3) % v.n
+    j = (np.arange(n) * 13 + n) % v.n
+    g1, g2 = np.ascontiguousarray(v.g1[i]), np.ascontiguousarray(v.g2[j])
+    got = hip_a.element_pairing(g1, g2)
+    assert np.array_equal(got, T.element_pairing(g1, g2))
+    d = i == j
+    if d.any():
+        assert np.array_equal(got[d], v.gt[i[d]])
+    T.clear()
+
+
+def test_wave_pairings_on_the_reference_vectors_and_edge_cases(hip_a):
+    for name in ("a_rand32.vec", "a_edge20.vec"):
+        v = golden(name)
+        assert np.array_equal(hip_a.element_pairing(v.g1, v.g2), v.gt), name
+
+
+def test_wave_pairings_other_512_bit_parameters(hips):
+    """r = 2^a - 2^b - 1 (the add step negates P), a second 512-bit field"""
+    v = golden("a_160_512_mm_rand6.vec")
+    assert np.array_equal(hips["a_160_512_mm"].element_pairing(v.g1, v.g2), v.gt)
+
+
+def test_wave_pairings_device_buffers_and_streams(hip_a):
+    import torch
+    v = golden("a_chain1024.vec")
+    n = 777
+    g1 = torch.from_numpy(np.ascontiguousarray(v.g1[:n])).cuda()
+    g2 = torch.from_numpy(np.ascontiguousarray(v.g2[:n])).cuda()
+    out = torch.empty((n + 1, 128), dtype=torch.uint8, device="cuda")
+    out[n] = 0xA5
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        hip_a.element_pairing_dev(out.data_ptr(), g1.data_ptr(), g2.data_ptr(), n, s.cuda_stream)
+    s.synchronize()
+    assert np.array_equal(out[:n].cpu().numpy(), v.gt[:n])
+    assert (out[n] == 0xA5).all()

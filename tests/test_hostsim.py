@@ -531,3 +531,22 @@ def test_type_f_gt_powers_by_cyclotomic_squarings_on_host(oracles, extra):
         S.group_mode(False)
     if not extra:
         assert fast < 0.5 * slow, (fast, slow)
+
+
+def test_type_a_one_pairing_per_wavefront_on_host(sims):
+    """pairing_aw.cuh (the low-latency path for small batches): the lane recurrence of the wave-wide Montgomery product
+    run lane by lane on the host, under AL's worst-case bound tracker plus the recurrence's own checks (column cleared
+    by m, accumulators below 2^60, what a lane carries to the next step within 32 bits); the reference's vectors, the
+    edge cases (invalid arguments, O, points of order two), a second 512-bit parameter set whose add step negates P."""
+    import hostsim
+    from conftest import _param, PARAM_OF
+    S = sims["a"]
+    for name in ("a_rand32.vec", "a_edge20.vec"):
+        v = golden(name)
+        m = min(v.n, 20)
+        assert np.array_equal(S.pairing_wave(v.g1[:m], v.g2[:m]), v.gt[:m]), name
+    S2 = hostsim.HostSim(_param(PARAM_OF.get("a_160_512_mm", "a_160_512_mm")))
+    v = golden("a_160_512_mm_rand6.vec")
+    assert np.array_equal(S2.pairing_wave(v.g1, v.g2), v.gt)
+    with pytest.raises(RuntimeError):
+        sims["d"].pairing_wave(v.g1, v.g2)

@@ -40,7 +40,17 @@ namespace pbc {
 #ifndef PBC_G_RES
 #define PBC_G_RES 0                    // experiment switch: the type g instantiation too (tools/g_resident_fault.md)
 #endif
-template <int N, int DEG> constexpr bool kDResident = ((N == 7 || (N == 5 && PBC_D_RES5)) && DEG == 3) || (PBC_G_RES && N == 5 && DEG == 5);
+// Round 4, the 6-word fields (d190: same-box A/B, ms per 2^18 launch, profiles/r04_ab_d190.txt): fused F_q^6 bodies on
+// the plain grid 71.6 (the 36-word accumulator overflows the 32 argument registers: 1 024 spilled registers, and the
+// round-4 build runs it at less than half its round-3 rate), Karatsuba over the out-of-line F_q^3 products 31.6, the same
+// on resident workgroups 24.6 = 10.6 M pairings/s.  So: the fused bodies for the 5-word fields only, 6 words resident.
+#ifndef PBC_D_RES6
+#define PBC_D_RES6 1
+#endif
+#ifndef PBC_D_FUSED_MAXN
+#define PBC_D_FUSED_MAXN 5             // widest field whose F_q^6 operations run as one fused limb-form body (kFusedF6)
+#endif
+template <int N, int DEG> constexpr bool kDResident = ((N == 7 || (N == 5 && PBC_D_RES5) || (N == 6 && PBC_D_RES6)) && DEG == 3) || (PBC_G_RES && N == 5 && DEG == 5);
 
 constexpr int ND_MAX = 7;              // widest MNT field built in: 224-bit q (d224.param)
 constexpr int DEG_MAX = 5;             // d = k/2: 3 (type d), 5 (type g)
@@ -481,7 +491,7 @@ static __device__ __noinline__ v32 d_add_line_fn(int neg) {
 // so the line value never exists in word form.
 // (6-word fields: the 36-word accumulator overflows the 32 argument registers by four words, which travel through the
 // stack; their 7-limb columns hold 8 product units, so the line value's "+ c'" is normalised instead of counted double)
-static constexpr bool kFusedF6 = DEG == 3 && ND <= 6;
+static constexpr bool kFusedF6 = DEG == 3 && ND <= PBC_D_FUSED_MAXN;
 static constexpr bool kLineDbl = Limbs29<ND>::L <= 6;
 typedef uint32_t f6vec __attribute__((ext_vector_type(2 * DEG * ND)));
 struct f6l { fl<ND> x[DEG], y[DEG]; };

@@ -57,13 +57,14 @@ RESIDENCY = 1024 * 128       # workgroups an MI355X holds at once for the type a
 
 
 @pytest.mark.parametrize("extra", [1, 77, 128, 300])
-@pytest.mark.parametrize("case", ["a", "a-pp", "d201"])
+@pytest.mark.parametrize("case", ["a", "a-pp", "d201", "d190"])
 def test_resident_grid_ragged_sizes_singles(hips, case, extra):
     """al_pairing_kernel, al_pp_apply_kernel and the 7-word d_prod_pairing_kernel walk the batch in strides of the chip's
     residency (pbc_hip.hip PBC_RESIDENT_LOOP): batches just above ONE residency with ragged tails -- every unit bit-exact
     against the reference's vectors (tiled), none left out, nothing written past the end."""
     import torch
-    key, name = {"a": ("a", "a_chain1024.vec"), "a-pp": ("a", "a_chain1024.vec"), "d201": ("d201", "d201_rand12.vec")}[case]
+    key, name = {"a": ("a", "a_chain1024.vec"), "a-pp": ("a", "a_chain1024.vec"), "d201": ("d201", "d201_rand12.vec"),
+                 "d190": ("d278027-190-181", "d278027-190-181_rand12.vec")}[case]
     v = golden(name)
     P = hips[key]
     n = RESIDENCY + extra
@@ -121,7 +122,9 @@ def test_resident_grid_ragged_sizes_type_a_products(hip_a, k, extra):
 
 SMALL_GRID = [("a", "a_chain1024.vec", 1), ("a", "a_chain1024.vec", 3), ("a-pp", "a_chain1024.vec", 1), ("f", "f_chain128.vec", 1),
               ("f", "f_chain128.vec", 2), ("f_256", "f_256_rand4.vec", 1), ("d201", "d201_rand12.vec", 1), ("d201", "d201_rand12.vec", 3),
-              ("d224", "d224_rand12.vec", 1), ("d201-pp", "d201_rand12.vec", 1)]
+              ("d224", "d224_rand12.vec", 1), ("d201-pp", "d201_rand12.vec", 1),
+              ("d278027-190-181", "d278027-190-181_rand12.vec", 1), ("d278027-190-181", "d278027-190-181_rand12.vec", 3),
+              ("d278027-190-181-pp", "d278027-190-181_rand12.vec", 1)]
 
 
 @pytest.mark.parametrize("case,name,k", SMALL_GRID)

@@ -242,12 +242,17 @@ int pbc_hip_finalpow_batch(pbc_hip_pairing_t *p, uint8_t *out, const uint8_t *in
  *                             underlying field element, ecc/pairing.c:187-190).  snprintf semantics: at most n - 1
  *                             characters and a NUL are stored, the full length is returned (-1 on error).  A record
  *                             of a curve over F_q that is not on the curve prints as "O", as curve_from_bytes
- *                             (ecc/curve.c:609-623) would make it; on the twists (G2 of types d, f, g) only the all-zero
- *                             record does.
+ *                             (ecc/curve.c:609-623) would make it; on the twists (G2 of types d, f, g) the curve
+ *                             equation is checked on the device (one [1] R through element_mul_zn) -- with no usable
+ *                             device only the all-zero record prints as "O".  Types a, a1: the all-zero record is
+ *                             the point (0, 0) of y^2 = x^3 + x and prints as "[0, 0]"; "O" parses to that record,
+ *                             which every batch entry point treats as O (see "zero-filled records" above), so O does
+ *                             not round-trip through text there.
  *   pbc_hip_element_set_str   element_set_str (fp_set_str :187-195 with pbc_mpz_set_str arith/field.c:725-755: base 2..36,
  *                             0 = 10, blanks skipped, reduced mod q; fq_set_str :145-157; polymod_set_str :1269-1283;
- *                             curve_set_str ecc/curve.c:555-578: "O" or "[x, y]", off-curve points of the curves over F_q
- *                             become O and return 0): writes the record, returns the characters consumed (0: syntax error).
+ *                             curve_set_str ecc/curve.c:555-578: "O" or "[x, y]", off-curve points become O and return 0
+ *                             -- on the twists through the same device check as above): writes the record, returns the
+ *                             characters consumed (0: syntax error).
  *   pbc_hip_param_snprint     pbc_param_out_str (include/pbc_param.h:38; a_out_str ecc/a_param.c:36-46 and its
  *                             siblings): "type t" and the keys of the type in the reference's order, integers in decimal. */
 int pbc_hip_element_snprint(const pbc_hip_pairing_t *p, int group, char *s, size_t n, const uint8_t *rec);

@@ -968,6 +968,16 @@ bool text_on_curve(const pbc_hip_pairing_s *P, const Big &x, const Big &y, const
 }
 bool text_curve_over_fq(const TextShape &S) { return S.curve && !S.quad && !S.poly; }
 bool all_zero(const uint8_t *p, int n) { for (int i = 0; i < n; i++) if (p[i]) return false; return true; }
+// curve_is_valid_point for the twists (G2 of types d, f, g: curves over F_q^d / F_q^2, ecc/curve.c:57-77 through
+// curve_from_bytes :609-623).  The tower arithmetic lives on the device, so the check is the library's own rule for
+// records: [1] R through element_mul_zn leaves a point of the curve as it is and turns anything else into O.  Without a
+// usable device (text-only use of the library) the record is taken as written -- the first batch call applies the rule.
+bool twist_record_on_curve(const pbc_hip_pairing_t *P, int group, const uint8_t *rec, int bytes) {
+  std::vector<uint8_t> one((size_t) P->len_zr, 0), out((size_t) bytes, 0);
+  one.back() = 1;
+  if (pbc_hip_element_mul_zn_batch(const_cast<pbc_hip_pairing_t *>(P), group, out.data(), rec, one.data(), 1)) return true;
+  return memcmp(out.data(), rec, (size_t) bytes) == 0;
+}
 }  // namespace
 
 extern "C" int pbc_hip_element_snprint(const pbc_hip_pairing_t *P, int group, char *s, size_t n, const uint8_t *rec) {
@@ -981,6 +991,7 @@ extern "C" int pbc_hip_element_snprint(const pbc_hip_pairing_t *P, int group, ch
     bool inf = all_zero(rec, 2 * cb) && P->type != 'a' && P->type != '1';     // (0, 0) lies on y^2 = x^3 + x
     if (!inf && text_curve_over_fq(S))   // element_from_bytes turns a record off the curve into O (curve_from_bytes, ecc/curve.c:609-623)
       inf = !text_on_curve(P, pbc_host::big_mod(pbc_host::big_from_be(rec, cb), mod), pbc_host::big_mod(pbc_host::big_from_be(rec + cb, cb), mod), mod);
+    if (!inf && !text_curve_over_fq(S)) inf = !twist_record_on_curve(P, group, rec, 2 * cb);
     if (inf) out = "O";
     else {
       out = "[";
@@ -1020,6 +1031,10 @@ extern "C" int pbc_hip_element_set_str(const pbc_hip_pairing_t *P, int group, ui
   if (*cp != ']') { memset(rec, 0, (size_t) 2 * cb); return 0; }
   if (text_curve_over_fq(S) && !text_on_curve(P, pbc_host::big_from_be(rec, cb), pbc_host::big_from_be(rec + cb, cb), mod)) {
     memset(rec, 0, (size_t) 2 * cb);     // curve_set_str: not on the curve -> O, returns 0
+    return 0;
+  }
+  if (!text_curve_over_fq(S) && !all_zero(rec, 2 * cb) && !twist_record_on_curve(P, group, rec, 2 * cb)) {
+    memset(rec, 0, (size_t) 2 * cb);
     return 0;
   }
   return (int) (cp - s + 1);

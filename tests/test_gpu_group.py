@@ -327,3 +327,24 @@ def test_group_host_forms_pinned_in_place_and_over_a_device_set(hips):
     for p in bufs:
         L.pbc_hip_host_free(p)
     H.clear()
+
+
+@pytest.mark.parametrize("key,name", [("d", "d_rand32.vec"), ("f", "f_rand16.vec"), ("g149", "g149_rand16.vec")])
+def test_text_forms_check_the_twist_equation(hips, key, name):
+    """element_set_str / element_snprint on G2 of types d, f, g (curves over F_q^d / F_q^2): a text or record off the twist
+    becomes / prints as O and set_str returns 0, as curve_set_str and curve_from_bytes do (ecc/curve.c:555-623); points
+    of the twist round-trip."""
+    H = hips[key]
+    v = golden(name)
+    text, full = H.element_snprint(2, v.g2[0])
+    assert text.startswith("[[") and full == len(text)
+    rec, used = H.element_set_str(2, text)
+    assert used == len(text) and np.array_equal(rec, v.g2[0])
+    bad = v.g2[0].copy()
+    bad[-1] ^= 1
+    assert H.element_snprint(2, bad)[0] == "O"
+    i = text.rindex("]]")
+    last = text[:i].rsplit(" ", 1)
+    off = last[0] + " " + str(int(last[1]) + 1) + text[i:]
+    rec, used = H.element_set_str(2, off)
+    assert used == 0 and not rec.any()

@@ -34,7 +34,10 @@ inline int fail(const char *fmt, ...) {
 // ---------------------------------------------------------------------------------------
 // host object
 #ifndef PBC_A_WAVE_MAX
-#define PBC_A_WAVE_MAX 4096
+#define PBC_A_WAVE_MAX 6144
+#endif
+#ifndef PBC_A_WAVE4_MAX
+#define PBC_A_WAVE4_MAX 768
 #endif
 // ---------------------------------------------------------------------------------------
 struct pbc_hip_pairing_s {
@@ -52,6 +55,7 @@ struct pbc_hip_pairing_s {
   bool group_slow;           // group operations: only the complete ladders ("hip_group_slow 1": tests, A/B)
   int resident_slots;        // > 0: workgroups of a resident launch instead of the occupancy query ("hip_resident_slots N", tests)
   size_t host_chunk;         // host-buffer entry points: units per chunk when the parameter text says "hip_host_chunk N" (0: default)
+  size_t a_wave4_max;        // ... and up to this size four wavefronts per pairing ("hip_wave4_max N")
   size_t a_wave_max;         // type a fast path, element_pairing: batches up to this size take one WAVEFRONT per pairing (pairing_aw.cuh; "hip_wave_max N", 0 = never)
   size_t a_prod_chunk;       // ... otherwise: terms per launch of the one-term-per-lane kernels ("hip_prod_chunk N", tests)
   int len_fq, len1, len2, lenT;
@@ -241,6 +245,9 @@ static int init_type_a(pbc_hip_pairing_s *P, const char *txt, size_t len) {
     int wave_max = PBC_A_WAVE_MAX;     // the batch size below which a wavefront per pairing is the faster launch (bench.py --sweep)
     param_int(txt, len, "hip_wave_max", wave_max);
     P->a_wave_max = wave_max < 0 ? 0 : (size_t) wave_max;
+    int wave4_max = PBC_A_WAVE4_MAX;
+    param_int(txt, len, "hip_wave4_max", wave4_max);
+    P->a_wave4_max = wave4_max < 0 ? 0 : (size_t) wave4_max;
   } else {
     // any other size up to 1056 bits: the type a1 kernels (plain double-and-add over the bits of r;
     // functions with the same divisor up to vertical lines, which the final power removes) on the

@@ -15,20 +15,21 @@
 // The ALGORITHM is AL<N>'s, operation for operation (double_step, add_step, final_exp: same sums, same borrowed
 // constants, same normalisations, hence the same bounds -- in the host mirror an element IS an AL<N>::el and carries
 // AL's worst-case tracker through these routines), so the two paths agree bit for bit on every input, the invalid
-// ones included.  Only the inversion differs: Fermat's x^(q-2) with 4-bit windows on the wave's products.
+// ones included; the one inversion runs AL's divsteps routine on lane 0 (a Fermat ladder on the wave's products,
+// `invert`, is kept for reference: 0.32 against 0.14 ms).
 // Boundaries (bytes <-> limbs, validity, the final halvings) run the word-form routines on lane 0 through LDS.
 #pragma once
 #include "pairing_al.cuh"
 
 namespace pbc {
 
-constexpr int AW_SLOTS = 24;                 // LDS words per wave: AW_SLOTS x 32 (4 inputs / 2 outputs, 15 table entries)
+constexpr int AW_SLOTS = 16;                 // LDS words per workgroup: AW_SLOTS x 32 (5 inputs / 2 outputs, the inversion, 2 x 4 products of a round)
 #ifndef PBC_HOSTSIM
 template <int N> __shared__ uint32_t g_lds_aw_t[AW_SLOTS * 32];
 #define g_lds_aw g_lds_aw_t<N>
 #endif
 
-template <int N>
+template <int N, int NW = 1>                 // NW: wavefronts that work on ONE pairing (1, or 4 = a 256-lane workgroup: see mul4)
 struct AW {
   typedef AL<N> A;
   typedef typename A::el el;
@@ -126,9 +127,13 @@ struct AW {
     return r;
   }
   static bool is_zero(const W &x) { for (int j = 0; j < L; j++) if (x.l[j]) return false; return true; }
-  static W tab_[16];
-  static void tab_put(int e, const W &x) { tab_[e] = x; }
-  static W tab_get(int e) { return tab_[e]; }
+  static void mul4(W &r0, W &r1, W &r2, W &r3, const W &a0, const W &b0, const W &a1, const W &b1, const W &a2, const W &b2,
+                   const W &a3, const W &b3, int count) {
+    const W x = mul(a0, b0), y = mul(a1, b1), z = count > 2 ? mul(a2, b2) : a2, t = count > 3 ? mul(a3, b3) : a3;
+    r0 = x; r1 = y;
+    if (count > 2) r2 = z;
+    if (count > 3) r3 = t;
+  }
   static void to_lane0(el &r, const W &x, int) { r = x; }
   static W from_lane0(const el &x, int) { return x; }
   static bool lane0() { return true; }
@@ -138,6 +143,7 @@ struct AW {
   // ---- device: one limb per lane ----------------------------------------------------------------------------------
   typedef uint32_t W;
   W kk[5], qq;                                                 // this lane's limb of the five borrowed constants and of q
+  int par = 0;                                                 // which set of round slots is written next (NW > 1)
   PBC_DEV void init() {
     const int j = lane();
 #pragma unroll
@@ -209,8 +215,57 @@ struct AW {
   }
   static __device__ __noinline__ W2 mul2_fn(W a, W b, W c, W d, W q) { return lanes_sop_x2<1>(a, b, 0, 0, c, d, 0, 0, q); }
   static __device__ __noinline__ W2 sop2x2_fn(W a0, W b0, W a1, W b1, W c0, W d0, W c1, W d1, W q) { return lanes_sop_x2<2>(a0, b0, a1, b1, c0, d0, c1, d1, q); }
-  PBC_DEV void mul2(W &r0, W &r1, W a, W b, W c, W d) const { const W2 t = mul2_fn(a, b, c, d, qq); r0 = t.r0; r1 = t.r1; }
-  PBC_DEV void sop2x2(W &r0, W &r1, W a0, W b0, W a1, W b1, W c0, W d0, W c1, W d1) const { const W2 t = sop2x2_fn(a0, b0, a1, b1, c0, d0, c1, d1, qq); r0 = t.r0; r1 = t.r1; }
+  // ---- a ROUND: up to four independent products ------------------------------------------------------------------
+  // NW = 1: two at a time in one instruction stream.  NW = 4 (one pairing per 256-lane workgroup, a wave on each SIMD of
+  // the CU; every wave carries the whole state and repeats the additions): wave w forms product w, writes it to its
+  // LDS slot, ONE barrier, every wave reads all of them.  The slots alternate between two sets, so a wave that is a
+  // round ahead writes where nobody reads.
+  static PBC_DEV int wave() { return NW == 1 ? 0 : __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6)); }
+  template <int TERMS>
+  PBC_DEV void round_nw(W *r, const W *a0, const W *b0, const W *a1, const W *b1, int count) {
+    const int w = wave();
+    const int base = 6 + 4 * par;
+    if (w < count) {
+      W x0 = a0[0], y0 = b0[0], x1 = TERMS == 2 ? a1[0] : 0u, y1 = TERMS == 2 ? b1[0] : 0u;
+#pragma unroll
+      for (int k = 1; k < 4; k++)
+        if (k < count && w == k) { x0 = a0[k]; y0 = b0[k]; if (TERMS == 2) { x1 = a1[k]; y1 = b1[k]; } }
+      const W res = TERMS == 1 ? mul_fn(x0, y0, qq) : sop2_fn(x0, y0, x1, y1, qq);
+      put_slot(res, base + w);
+    }
+    sync();
+#pragma unroll
+    for (int k = 0; k < 4; k++) if (k < count) r[k] = get_slot(base + k);
+    par ^= 1;
+  }
+  PBC_DEV void mul4(W &r0, W &r1, W &r2, W &r3, W a0, W b0, W a1, W b1, W a2, W b2, W a3, W b3, int count) {
+    if constexpr (NW == 1) {
+      const W2 t = mul2_fn(a0, b0, a1, b1, qq);
+      r0 = t.r0; r1 = t.r1;
+      if (count == 3) r2 = mul_fn(a2, b2, qq);
+      if (count == 4) { const W2 u = mul2_fn(a2, b2, a3, b3, qq); r2 = u.r0; r3 = u.r1; }
+    } else {
+      W r[4];
+      const W a[4] = {a0, a1, a2, a3}, b[4] = {b0, b1, b2, b3};
+      round_nw<1>(r, a, b, a, b, count);
+      r0 = r[0]; r1 = r[1];
+      if (count > 2) r2 = r[2];
+      if (count > 3) r3 = r[3];
+    }
+  }
+  PBC_DEV void mul2(W &r0, W &r1, W a, W b, W c, W d) {
+    if constexpr (NW == 1) { const W2 t = mul2_fn(a, b, c, d, qq); r0 = t.r0; r1 = t.r1; }
+    else { W r2, r3; mul4(r0, r1, r2, r3, a, b, c, d, 0u, 0u, 0u, 0u, 2); }
+  }
+  PBC_DEV void sop2x2(W &r0, W &r1, W a0, W b0, W a1, W b1, W c0, W d0, W c1, W d1) {
+    if constexpr (NW == 1) { const W2 t = sop2x2_fn(a0, b0, a1, b1, c0, d0, c1, d1, qq); r0 = t.r0; r1 = t.r1; }
+    else {
+      W r[4];
+      const W x0[4] = {a0, c0, 0u, 0u}, y0[4] = {b0, d0, 0u, 0u}, x1[4] = {a1, c1, 0u, 0u}, y1[4] = {b1, d1, 0u, 0u};
+      round_nw<2>(r, x0, y0, x1, y1, 2);
+      r0 = r[0]; r1 = r[1];
+    }
+  }
   static __device__ __noinline__ W mul_fn(W a, W b, W q) { return lanes_sop<1>(a, b, 0, 0, q); }
   static __device__ __noinline__ W sop2_fn(W a0, W b0, W a1, W b1, W q) { return lanes_sop<2>(a0, b0, a1, b1, q); }
   PBC_DEV W mul(W a, W b) const { return mul_fn(a, b, qq); }
@@ -228,10 +283,8 @@ struct AW {
     return strict_limbs(r);
   }
   static PBC_DEV bool is_zero(W x) { return __ballot(x != 0) == 0; }
-  static PBC_DEV void tab_put(int e, W x) { if (lane() < 32) g_lds_aw[(6 + e) * 32 + lane()] = x; }
-  static PBC_DEV W tab_get(int e) { return lane() < 32 ? g_lds_aw[(6 + e) * 32 + lane()] : 0u; }
   static PBC_DEV void sync() { __syncthreads(); }
-  static PBC_DEV bool lane0() { return lane() == 0; }
+  static PBC_DEV bool lane0() { return threadIdx.x == 0; }
   // every lane's limb -> LDS slot; lane 0 (after sync) reads the whole element
   static PBC_DEV void put_slot(W x, int slot) { if (lane() < 32) g_lds_aw[slot * 32 + lane()] = x; }
   static PBC_DEV void slot_to_el(el &r, int slot) {
@@ -254,63 +307,70 @@ struct AW {
     if (geq_q(t)) t = sub_q(t);
     return t;
   }
-  // x^(q-2), x canonical and non-zero (a zero stays zero): 4-bit windows, the table in LDS
-  PBC_DEV W invert(const W &x, const W &oneR) {
-    const FpK<N> &K = fpk<N>();
-    W t = x;
-    tab_put(1, x);
-    for (int e = 2; e < 16; e++) {
-      t = mul(t, x);
-      tab_put(e, t);
+  // 1/x by the lane-local divsteps routine (fp_inv, fp.cuh: 58 product-equivalents of ONE lane = 0.14 ms at one wave
+  // per SIMD; a Fermat ladder x^(q-2) on the wave's products -- 654 of them -- took 0.32 ms), through LDS: AL's own
+  // sequence to_words, fp_inv, to_el.  x: a product's output (strict limbs, value below 2q).  Every lane runs the same
+  // inversion: with the call under a lane-0-only EXEC mask the kernel faulted (profiles/r04_notes.md).
+  PBC_DEV W invert_lane0(const W &x) {
+#ifdef PBC_HOSTSIM
+    fp<N> tw;
+    el r;
+    A::to_words(tw, x);
+    fp_inv<N>(tw, tw);
+    A::to_el(r, tw);
+    return r;
+#else
+    put_slot(x, 5);
+    sync();
+    {                                                          // every lane runs the same inversion (no call under a partial EXEC mask)
+      el e;
+      fp<N> tw;
+      slot_to_el(e, 5);
+      A::to_words(tw, e);
+      fp_inv<N>(tw, tw);
+      A::to_el(e, tw);
+      sync();
+      if (lane0()) el_to_slot(e, 5);
     }
     sync();
-    W r = oneR;
-    const int top = (int) K.pbits - 1;
-    for (int w = top / 4; w >= 0; w--) {
-      if (w != top / 4) {
-        r = sqr(r); r = sqr(r); r = sqr(r); r = sqr(r);
-      }
-      const uint32_t d = (K.pm2[w >> 3] >> (4 * (w & 7))) & 15;
-      if (d) r = mul(r, tab_get((int) d));
-    }
-    return canon(r, oneR);
+    const W r = get_slot(5);
+    sync();
+    return r;
+#endif
   }
 
   struct state {
     W fx, fy, X, Y, Z, ZZ, Qx, Qy;
   };
-  PBC_DEV void fsqr(state &s) {                              // AL::fsqr
-    const W e0 = add(s.fx, s.fy);
-    const W e1 = norm(subk(s.fx, s.fy, K2));
-    const W d = shl<1>(s.fx);
-    mul2(s.fx, s.fy, e0, e1, d, s.fy);
-  }
   PBC_DEV void fmul(state &s, const W &lx, const W &ly) {    // AL::fmul: two lazy sums of two products
     const W nfy = norm(negk(s.fy, K2));
     sop2x2(s.fx, s.fy, s.fx, lx, nfy, ly, s.fx, ly, s.fy, lx);
   }
-  // AL::double_step, its independent products issued two at a time
+  // AL::double_step, its 19 products in four rounds of up to four independent ones and the two two-term sums of f l
   PBC_DEV void double_step(state &s) {
-    W XX, Z4, YY, t0, t1, lx, ly, Z3, S1, MM, Y4;
-    fsqr(s);
-    mul2(XX, Z4, s.X, s.X, s.ZZ, s.ZZ);
+    W XX, Z4, YY, t0, t1, lx, ly, Z3, S1, MM, Y4, nfx, nfy, ZZn, u;
+    {
+      const W e0 = add(s.fx, s.fy);
+      const W e1 = norm(subk(s.fx, s.fy, K2));
+      mul4(nfx, nfy, XX, Z4, e0, e1, shl<1>(s.fx), s.fy, s.X, s.X, s.ZZ, s.ZZ, 4);     // f^2 (AL::fsqr), X^2, Z^4
+    }
+    s.fx = nfx;
+    s.fy = nfy;
     W M = add(add(shl<1>(XX), XX), Z4);
     M = norm(M);
-    mul2(YY, t0, s.Y, s.Y, s.Qx, s.ZZ);
+    mul4(YY, t0, Z3, MM, s.Y, s.Y, s.Qx, s.ZZ, shl<1>(s.Y), s.Z, M, M, 4);
     t0 = add(t0, s.X);
-    mul2(lx, Z3, M, t0, shl<1>(s.Y), s.Z);
-    t1 = shl<1>(YY);
-    lx = norm(subk(lx, t1, K4));
-    mul2(t1, S1, Z3, s.ZZ, YY, shl<1>(s.X));
+    mul4(lx, t1, S1, ZZn, M, t0, Z3, s.ZZ, YY, shl<1>(s.X), Z3, Z3, 4);
+    u = shl<1>(YY);
+    lx = norm(subk(lx, u, K4));
     s.Z = Z3;
-    mul2(s.ZZ, MM, Z3, Z3, M, M);
-    mul2(ly, Y4, t1, s.Qy, YY, YY);
+    s.ZZ = ZZn;
+    u = shl<2>(S1);
+    s.X = norm(subk(MM, u, K8));
+    u = shl<1>(S1);
+    const W Wd = norm(subk(u, s.X, K12));
+    mul4(ly, Y4, t0, u, t1, s.Qy, YY, YY, M, Wd, M, Wd, 3);
     fmul(s, lx, ly);
-    t1 = shl<2>(S1);
-    s.X = norm(subk(MM, t1, K8));
-    t1 = shl<1>(S1);
-    const W Wd = norm(subk(t1, s.X, K12));
-    t0 = mul(M, Wd);
     t1 = norm(shl<3>(Y4));
     s.Y = norm(subk(t0, t1, K12));
   }
@@ -346,19 +406,18 @@ struct AW {
   // f^((q^2-1)/r): AL::final_exp with the inversion on the wave.  Leaves (v0 R-scaled, y) for the word-form tail:
   //     out.x = v0 / 2,   out.y = -y / 4
   PBC_DEV void final_exp(W &ox, W &oy, const state &s, const W &oneR) {
-    const W a2 = sqr(s.fx), b2 = sqr(s.fy);
+    W a2, b2, B, unused;
+    mul4(a2, b2, B, unused, s.fx, s.fx, s.fy, s.fy, shl<1>(s.fx), s.fy, s.fx, s.fx, 3);
     const W Nn = norm(add(a2, b2));
     const W Av = norm(subk(a2, b2, K2));
-    W B = mul(shl<1>(s.fx), s.fy);
     B = norm(negk(B, K2));
     B = canon(B, oneR);
     if (is_zero(B)) B = oneR;                                  // f^(q-1) = +-1: invert N * 1 instead (a_final_exp)
-    W t = canon(mul(Nn, B), oneR);
-    t = invert(t, oneR);                                       // 1/(N B), canonical
-    W w = mul(t, B);                                           // 1/N
-    const W g0 = mul(Av, w);
-    t = mul(t, Nn);                                            // 1/B
-    w = mul(t, Nn);                                            // N/B
+    W t = mul(Nn, B);
+    t = invert_lane0(t);                                       // 1/(N B), canonical
+    W w, g0;
+    mul2(w, t, t, B, t, Nn);                                   // 1/N, 1/B
+    mul2(g0, w, Av, w, t, Nn);                                 // Re f^(q-1), N/B
     const W P = norm(shl<1>(g0));
     W two = strict2(add(oneR, oneR));
     if (geq_q(two)) two = sub_q(two);
@@ -378,11 +437,10 @@ struct AW {
         v1 = m;
       }
     }
-    t = mul(v0, P);
+    mul2(t, ox, v0, P, v0, oneR);
     v1 = shl<1>(v1);
     v1 = norm(subk(v1, t, K2));
     oy = mul(v1, w);
-    ox = mul(v0, oneR);
   }
   // 2 R mod q from R + R: strict limbs of a value < 2q (the sum's limbs are below 2^30)
 #ifdef PBC_HOSTSIM
@@ -466,8 +524,5 @@ struct AW {
     }
   }
 };
-#ifdef PBC_HOSTSIM
-template <int N> typename AW<N>::W AW<N>::tab_[16];
-#endif
 
 }  // namespace pbc

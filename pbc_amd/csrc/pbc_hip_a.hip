@@ -23,13 +23,17 @@ __global__ void __launch_bounds__(kBlock, PBC_A_WAVES) al_pairing_kernel(uint8_t
   }
 }
 
-// Small batches: one pairing per WAVEFRONT (pairing_aw.cuh: one limb per lane, products across the lanes) -- a quarter of
-// the latency of a lane-local pairing.  One single-wave workgroup per unit.
-template <int N>
-__global__ void __launch_bounds__(64) aw_pairing_kernel(uint8_t *gt, const uint8_t *g1, const uint8_t *g2, KArgs<N> ka) {
+// Small batches: one pairing per WAVEFRONT (pairing_aw.cuh: one limb per lane, products across the lanes) -- a third of
+// the latency of a lane-local pairing -- or, for the smallest ones, per WORKGROUP of four wavefronts that share the
+// independent products of every step (NW = 4).  One workgroup per unit.
+#ifndef PBC_AW_WAVES
+#define PBC_AW_WAVES 4                 // waves per SIMD the register budget allows (128 VGPRs: the rarely run word-form boundary code and the inversion spill)
+#endif
+template <int N, int NW>
+__global__ void __launch_bounds__(64 * NW, PBC_AW_WAVES) aw_pairing_kernel(uint8_t *gt, const uint8_t *g1, const uint8_t *g2, KArgs<N> ka) {
   constexpr int L = 8 * N;
   const size_t idx = blockIdx.x;
-  AW<N> w;
+  AW<N, NW> w;
   w.pairing_wave(gt + idx * L, g1 + idx * L, g2 + idx * L);
 }
 
@@ -205,7 +209,10 @@ int derive_e(pbc_hip_pairing_s *P, hipStream_t s) {
 int launch_a(pbc_hip_pairing_s *P, void *d_gt, const void *d_g1, const void *d_g2, size_t n, int k, hipStream_t s, ProdWs &W) {
   unsigned grid = (unsigned) ((n + kBlock - 1) / kBlock);
   if (P->type == 'a' && !P->a_generic && k == 1 && n <= P->a_wave_max) {
-    hipLaunchKernelGGL(aw_pairing_kernel<16>, dim3((unsigned) n), dim3(64), 0, s, (uint8_t *) d_gt, (const uint8_t *) d_g1, (const uint8_t *) d_g2, kargs<16>(P));
+    if (n <= P->a_wave4_max)
+      hipLaunchKernelGGL((aw_pairing_kernel<16, 4>), dim3((unsigned) n), dim3(256), 0, s, (uint8_t *) d_gt, (const uint8_t *) d_g1, (const uint8_t *) d_g2, kargs<16>(P));
+    else
+      hipLaunchKernelGGL((aw_pairing_kernel<16, 1>), dim3((unsigned) n), dim3(64), 0, s, (uint8_t *) d_gt, (const uint8_t *) d_g1, (const uint8_t *) d_g2, kargs<16>(P));
   } else if (P->type == 'a' && !P->a_generic && k == 1) {
     hipLaunchKernelGGL(al_pairing_kernel<16>, dim3(PBC_RGRID(al_pairing_kernel<16>)), dim3(kBlock), 0, s, (uint8_t *) d_gt,
                        (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, unit_counter(P, s), kargs<16>(P));

@@ -121,7 +121,7 @@ int hostsim_pairing_wave(void *h, uint8_t *gt, const uint8_t *g1, const uint8_t 
   pbc_hip_pairing_s *P = (pbc_hip_pairing_s *) h;
   if (P->type != 'a' || P->a_generic) return 1;
   activate(P, true);
-  for (size_t u = 0; u < n; u++) { AW<16> w; w.pairing_wave(gt + u * P->lenT, g1 + u * P->len1, g2 + u * P->len2); }
+  for (size_t u = 0; u < n; u++) { AW<16, 1> w; w.pairing_wave(gt + u * P->lenT, g1 + u * P->len1, g2 + u * P->len2); }
   activate(P);
   return 0;
 }

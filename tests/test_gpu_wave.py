@@ -1,7 +1,8 @@
 """GPU tests (-m gpu) of the low-latency path for small batches (round 4, pairing_aw.cuh): element_pairing on a.param with
 one WAVEFRONT per pairing -- an F_q element is one register across 18 lanes, the Montgomery product runs over the lanes
-(v_readlane / DPP wave shifts).  Batches up to "hip_wave_max" (default 4096) take it; the bytes are those of the
-throughput kernel and of the reference's vectors, invalid arguments included."""
+(v_readlane / DPP wave shifts); up to "hip_wave4_max" units (default 768) FOUR wavefronts share the independent products
+of every step of a pairing through LDS.  Batches up to "hip_wave_max" (default 6144) take these kernels; the bytes are
+those of the throughput kernel and of the reference's vectors, invalid arguments included."""
 import numpy as np
 import pytest
 
@@ -10,7 +11,7 @@ from conftest import golden, _param, PARAM_OF
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("n", [1, 2, 63, 64, 1024, 4096, 4097])
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 768, 769, 1024, 6144, 6145])
 def test_wave_pairings_match_the_throughput_kernel_and_the_reference(hip_a, n):
     import pbc_amd
     v = golden("a_chain1024.vec")
@@ -26,10 +27,15 @@ def test_wave_pairings_match_the_throughput_kernel_and_the_reference(hip_a, n):
     T.clear()
 
 
-def test_wave_pairings_on_the_reference_vectors_and_edge_cases(hip_a):
-    for name in ("a_rand32.vec", "a_edge20.vec"):
+@pytest.mark.parametrize("extra", ["", "hip_wave4_max 0\n", "hip_wave4_max 100000\n"])
+def test_wave_pairings_on_the_reference_vectors_and_edge_cases(extra):
+    """both forms (one and four wavefronts per pairing) on the reference's vectors, invalid arguments included"""
+    import pbc_amd
+    H = pbc_amd.Pairing(_param("a") + extra)
+    for name in ("a_rand32.vec", "a_edge20.vec", "a_chain1024.vec"):
         v = golden(name)
-        assert np.array_equal(hip_a.element_pairing(v.g1, v.g2), v.gt), name
+        assert np.array_equal(H.element_pairing(v.g1, v.g2), v.gt), name
+    H.clear()
 
 
 def test_wave_pairings_other_512_bit_parameters(hips):

@@ -1,4 +1,4 @@
-"""Latency of small batches, a.param: the one-pairing-per-wavefront kernel (pairing_aw.cuh) against the throughput kernel,
+"""Latency of small batches, a.param: the one-pairing-per-wavefront kernel and its four-wavefront form (pairing_aw.cuh) against the throughput kernel,
 device buffers, events around the call; median of 7 after 2 warm-ups.   python tools/r04_wave.py [sizes...]"""
 import os
 import sys
@@ -14,7 +14,8 @@ from conftest import golden, _param  # noqa: E402
 
 v = golden("a_chain1024.vec")
 sizes = [int(x) for x in sys.argv[1:]] or [1, 16, 256, 1024, 2048, 3072, 4096, 6144, 8192, 16384]
-P = {"wave": pbc_amd.Pairing(_param("a") + "hip_wave_max 1000000\n"), "lane": pbc_amd.Pairing(_param("a") + "hip_wave_max 0\n")}
+P = {"wave4": pbc_amd.Pairing(_param("a") + "hip_wave_max 1000000\nhip_wave4_max 1000000\n"),
+     "wave": pbc_amd.Pairing(_param("a") + "hip_wave_max 1000000\nhip_wave4_max 0\n"), "lane": pbc_amd.Pairing(_param("a") + "hip_wave_max 0\n")}
 for n in sizes:
     i = np.arange(n) % v.n
     g1 = torch.from_numpy(np.ascontiguousarray(v.g1[i])).cuda()
@@ -33,6 +34,6 @@ for n in sizes:
             ts.append(a.elapsed_time(b))
         row[name] = float(np.median(ts[2:]))
         outs[name] = out.cpu().numpy()
-    same = np.array_equal(outs["wave"], outs["lane"])
-    print("n = %6d   wave %8.3f ms  (%9.0f /s)    lane %8.3f ms  (%9.0f /s)    same bytes: %s" %
-          (n, row["wave"], n / row["wave"] * 1e3, row["lane"], n / row["lane"] * 1e3, same), flush=True)
+    same = np.array_equal(outs["wave"], outs["lane"]) and np.array_equal(outs["wave4"], outs["lane"])
+    print("n = %6d   4 waves %8.3f ms  (%9.0f /s)   1 wave %8.3f ms  (%9.0f /s)    lane %8.3f ms  (%9.0f /s)    same bytes: %s" %
+          (n, row["wave4"], n / row["wave4"] * 1e3, row["wave"], n / row["wave"] * 1e3, row["lane"], n / row["lane"] * 1e3, same), flush=True)

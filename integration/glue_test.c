@@ -45,6 +45,28 @@ int main(int argc, char **argv) {
            element_cmp(chk, Ob[n - 1]) ? "MISMATCH" : "last result equals the CPU pairing");
     return element_cmp(chk, Ob[n - 1]) ? 1 : 0;
   }
+  if (argc > 3 && !strcmp(argv[3], "latency")) {
+    /* what a program that calls element_pairing ONE pair at a time pays through the hooks (example/bls.c's shape):
+     * n single calls on the GPU (pairing->map -> a one-unit batch), then the same calls on the CPU */
+    element_t p, q, o, c;
+    element_init_G1(p, pairing); element_init_G2(q, pairing); element_init_GT(o, pairing); element_init_GT(c, pairing);
+    element_random(p); element_random(q);
+    if (pbc_hip_attach(pairing, text, len)) { printf("ATTACH FAILED\n"); return 1; }
+    element_pairing(o, p, q);                                          /* warm-up: context, constants, buffers */
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (size_t i = 0; i < n; i++) element_pairing(o, p, q);
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    const double gpu = ((t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec)) / n;
+    pbc_hip_detach(pairing);
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (size_t i = 0; i < n; i++) element_pairing(c, p, q);
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    const double cpu = ((t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec)) / n;
+    printf("%s: single element_pairing calls through the hooks: %.3f ms each on the GPU, %.3f ms each on the CPU (%s)\n", argv[1],
+           gpu * 1e3, cpu * 1e3, element_cmp(c, o) ? "MISMATCH" : "same value");
+    return element_cmp(c, o) ? 1 : 0;
+  }
   if (argc > 3 && !strcmp(argv[3], "hash")) {   /* element_from_hash_batch on G1 and G2 vs the CPU */
     int fails = 0;
     enum { HN = 8, HL = 32 };

@@ -97,11 +97,11 @@ int pbc_hip_element_pairing_batch(pbc_hip_pairing_t *p, uint8_t *gt, const uint8
  * lanes), and from there the resident workgroups walk the batch in strides of the residency, so the time grows in
  * steps of ceil(n / 131072) x 10 ms (2^20: 79.5 ms, 13.1 M pairings/s); n = 131073 pays a whole second stride.  Feed
  * multiples of 131072 where you can.  Type f: 8.3 ms / 12.0 ms / steps of 12 ms.
- * Cut-over for small batches (type a, 512-bit q): up to 6144 units ("hip_wave_max N" in the parameter text moves it,
+ * Cut-over for small batches (type a, 512-bit q): up to 5120 units ("hip_wave_max N" in the parameter text moves it,
  * 0 disables it) a launch gives every pairing a WAVEFRONT (csrc/pairing_aw.cuh: one limb per lane, products across
  * the lanes), up to 768 units ("hip_wave4_max N") a workgroup of FOUR wavefronts that share the independent products
  * of every step: 1.2 ms for one pairing (n <= 256), 1.4 ms at 512, 2.0 ms at 1024, 2.6 ms at 2048, 4.4 ms at 4096,
- * 6.3 ms at 6144 -- same bytes as the throughput kernel. */
+ * 5.4 ms at 5120 (the throughput kernel: 5.8-6.5 ms depending on the box) -- same bytes as the throughput kernel. */
 int pbc_hip_element_pairing_batch_dev(pbc_hip_pairing_t *p, void *d_gt, const void *d_g1,
                                       const void *d_g2, size_t n, void *stream);
 

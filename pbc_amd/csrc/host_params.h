@@ -34,7 +34,7 @@ inline int fail(const char *fmt, ...) {
 // ---------------------------------------------------------------------------------------
 // host object
 #ifndef PBC_A_WAVE_MAX
-#define PBC_A_WAVE_MAX 6144
+#define PBC_A_WAVE_MAX 5120
 #endif
 #ifndef PBC_A_WAVE4_MAX
 #define PBC_A_WAVE4_MAX 768

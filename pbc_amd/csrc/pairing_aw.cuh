@@ -143,12 +143,14 @@ struct AW {
   // ---- device: one limb per lane ----------------------------------------------------------------------------------
   typedef uint32_t W;
   W kk[5], qq;                                                 // this lane's limb of the five borrowed constants and of q
+  uint32_t nv;                                                 // -1/q mod 2^29
   int par = 0;                                                 // which set of round slots is written next (NW > 1)
   PBC_DEV void init() {
     const int j = lane();
 #pragma unroll
     for (int k = 0; k < 5; k++) kk[k] = j < L ? c_a.ksub[k][j] : 0u;
     qq = j < L ? fpk<N>().p29[j] : 0u;
+    nv = fpk<N>().ninv29;
   }
   static PBC_DEV int lane() { return (int) (threadIdx.x & 63); }
   static PBC_DEV W from_above(W x) { return (W) __builtin_amdgcn_update_dpp(0, (int) x, 0x130, 0xf, 0xf, true); }   // wave_shl:1 : lane j <- lane j + 1
@@ -184,8 +186,8 @@ struct AW {
     nxt = c + from_above((uint32_t) acc & MASK);
   }
   template <int TERMS>
-  static PBC_DEV W lanes_sop(W a0, W b0, W a1, W b1, W q) {
-    const uint32_t ninv = fpk<N>().ninv29;
+  static PBC_DEV W lanes_sop(W a0, W b0, W a1, W b1, W q, uint32_t nv) {
+    const uint32_t ninv = (uint32_t) __builtin_amdgcn_readfirstlane((int) nv);   // handed down in a register: a scalar load here stalls every product
     uint32_t acc = 0;
 #pragma unroll
     for (int i = 0; i < L; i++)
@@ -196,8 +198,8 @@ struct AW {
   // multiply-add, shift: eight instructions of ~9 cycles each at one wave per SIMD) leaves the pipe half empty
   struct W2 { W r0, r1; };
   template <int TERMS>
-  static PBC_DEV W2 lanes_sop_x2(W a0, W b0, W a1, W b1, W c0, W d0, W c1, W d1, W q) {
-    const uint32_t ninv = fpk<N>().ninv29;
+  static PBC_DEV W2 lanes_sop_x2(W a0, W b0, W a1, W b1, W c0, W d0, W c1, W d1, W q, uint32_t nv) {
+    const uint32_t ninv = (uint32_t) __builtin_amdgcn_readfirstlane((int) nv);
     uint32_t acc = 0, bcc = 0;
 #pragma unroll
     for (int i = 0; i < L; i++) {
@@ -213,8 +215,8 @@ struct AW {
     }
     return W2{x, y};
   }
-  static __device__ __noinline__ W2 mul2_fn(W a, W b, W c, W d, W q) { return lanes_sop_x2<1>(a, b, 0, 0, c, d, 0, 0, q); }
-  static __device__ __noinline__ W2 sop2x2_fn(W a0, W b0, W a1, W b1, W c0, W d0, W c1, W d1, W q) { return lanes_sop_x2<2>(a0, b0, a1, b1, c0, d0, c1, d1, q); }
+  static __device__ __noinline__ W2 mul2_fn(W a, W b, W c, W d, W q, uint32_t nv) { return lanes_sop_x2<1>(a, b, 0, 0, c, d, 0, 0, q, nv); }
+  static __device__ __noinline__ W2 sop2x2_fn(W a0, W b0, W a1, W b1, W c0, W d0, W c1, W d1, W q, uint32_t nv) { return lanes_sop_x2<2>(a0, b0, a1, b1, c0, d0, c1, d1, q, nv); }
   // ---- a ROUND: up to four independent products ------------------------------------------------------------------
   // NW = 1: two at a time in one instruction stream.  NW = 4 (one pairing per 256-lane workgroup, a wave on each SIMD of
   // the CU; every wave carries the whole state and repeats the additions): wave w forms product w, writes it to its
@@ -230,7 +232,7 @@ struct AW {
 #pragma unroll
       for (int k = 1; k < 4; k++)
         if (k < count && w == k) { x0 = a0[k]; y0 = b0[k]; if (TERMS == 2) { x1 = a1[k]; y1 = b1[k]; } }
-      const W res = TERMS == 1 ? mul_fn(x0, y0, qq) : sop2_fn(x0, y0, x1, y1, qq);
+      const W res = TERMS == 1 ? mul_fn(x0, y0, qq, nv) : sop2_fn(x0, y0, x1, y1, qq, nv);
       put_slot(res, base + w);
     }
     sync();
@@ -240,10 +242,10 @@ struct AW {
   }
   PBC_DEV void mul4(W &r0, W &r1, W &r2, W &r3, W a0, W b0, W a1, W b1, W a2, W b2, W a3, W b3, int count) {
     if constexpr (NW == 1) {
-      const W2 t = mul2_fn(a0, b0, a1, b1, qq);
+      const W2 t = mul2_fn(a0, b0, a1, b1, qq, nv);
       r0 = t.r0; r1 = t.r1;
-      if (count == 3) r2 = mul_fn(a2, b2, qq);
-      if (count == 4) { const W2 u = mul2_fn(a2, b2, a3, b3, qq); r2 = u.r0; r3 = u.r1; }
+      if (count == 3) r2 = mul_fn(a2, b2, qq, nv);
+      if (count == 4) { const W2 u = mul2_fn(a2, b2, a3, b3, qq, nv); r2 = u.r0; r3 = u.r1; }
     } else {
       W r[4];
       const W a[4] = {a0, a1, a2, a3}, b[4] = {b0, b1, b2, b3};
@@ -254,11 +256,11 @@ struct AW {
     }
   }
   PBC_DEV void mul2(W &r0, W &r1, W a, W b, W c, W d) {
-    if constexpr (NW == 1) { const W2 t = mul2_fn(a, b, c, d, qq); r0 = t.r0; r1 = t.r1; }
+    if constexpr (NW == 1) { const W2 t = mul2_fn(a, b, c, d, qq, nv); r0 = t.r0; r1 = t.r1; }
     else { W r2, r3; mul4(r0, r1, r2, r3, a, b, c, d, 0u, 0u, 0u, 0u, 2); }
   }
   PBC_DEV void sop2x2(W &r0, W &r1, W a0, W b0, W a1, W b1, W c0, W d0, W c1, W d1) {
-    if constexpr (NW == 1) { const W2 t = sop2x2_fn(a0, b0, a1, b1, c0, d0, c1, d1, qq); r0 = t.r0; r1 = t.r1; }
+    if constexpr (NW == 1) { const W2 t = sop2x2_fn(a0, b0, a1, b1, c0, d0, c1, d1, qq, nv); r0 = t.r0; r1 = t.r1; }
     else {
       W r[4];
       const W x0[4] = {a0, c0, 0u, 0u}, y0[4] = {b0, d0, 0u, 0u}, x1[4] = {a1, c1, 0u, 0u}, y1[4] = {b1, d1, 0u, 0u};
@@ -266,11 +268,11 @@ struct AW {
       r0 = r[0]; r1 = r[1];
     }
   }
-  static __device__ __noinline__ W mul_fn(W a, W b, W q) { return lanes_sop<1>(a, b, 0, 0, q); }
-  static __device__ __noinline__ W sop2_fn(W a0, W b0, W a1, W b1, W q) { return lanes_sop<2>(a0, b0, a1, b1, q); }
-  PBC_DEV W mul(W a, W b) const { return mul_fn(a, b, qq); }
-  PBC_DEV W sqr(W a) const { return mul_fn(a, a, qq); }
-  PBC_DEV W sop2(W a0, W b0, W a1, W b1) const { return sop2_fn(a0, b0, a1, b1, qq); }
+  static __device__ __noinline__ W mul_fn(W a, W b, W q, uint32_t nv) { return lanes_sop<1>(a, b, 0, 0, q, nv); }
+  static __device__ __noinline__ W sop2_fn(W a0, W b0, W a1, W b1, W q, uint32_t nv) { return lanes_sop<2>(a0, b0, a1, b1, q, nv); }
+  PBC_DEV W mul(W a, W b) const { return mul_fn(a, b, qq, nv); }
+  PBC_DEV W sqr(W a) const { return mul_fn(a, a, qq, nv); }
+  PBC_DEV W sop2(W a0, W b0, W a1, W b1) const { return sop2_fn(a0, b0, a1, b1, qq, nv); }
   static PBC_DEV W uniform(const uint32_t *limbs) { const int j = lane(); return j < L ? limbs[j] : 0u; }
   PBC_DEV bool geq_q(W x) const {
     const uint32_t q = qq;

@@ -95,8 +95,9 @@ int pbc_hip_element_pairing_batch(pbc_hip_pairing_t *p, uint8_t *gt, const uint8
  * whole pairing: a launch costs one lane's 2.1 M dependent multiply-adds however small it is -- 6.4 ms for any
  * n <= 32768 (one wave per SIMD), 10.3 ms up to 131072 (two waves per SIMD: one chip residency of 1024 workgroups x 128
  * lanes), and from there the resident workgroups walk the batch in strides of the residency, so the time grows in
- * steps of ceil(n / 131072) x 10 ms (2^20: 79.5 ms, 13.1 M pairings/s); n = 131073 pays a whole second stride.  Feed
- * multiples of 131072 where you can.  Type f: 8.3 ms / 12.0 ms / steps of 12 ms.
+ * steps of ceil(n / 131072) x 10 ms (2^20: 79.5 ms, 13.1 M pairings/s).  A tail of up to 5120 units beyond a whole number
+ * of strides goes to the small-batch kernels below instead of paying a whole stride (131073 units: 11.9 ms, not 17.0);
+ * beyond that, feed multiples of 131072 where you can.  Type f: 7.2-8.3 ms / 11-12 ms / steps of 11-12 ms, no tail kernel.
  * Cut-over for small batches (type a, 512-bit q): up to 5120 units ("hip_wave_max N" in the parameter text moves it,
  * 0 disables it) a launch gives every pairing a WAVEFRONT (csrc/pairing_aw.cuh: one limb per lane, products across
  * the lanes), up to 768 units ("hip_wave4_max N") a workgroup of FOUR wavefronts that share the independent products

@@ -57,16 +57,21 @@ RESIDENCY = 1024 * 128       # workgroups an MI355X holds at once for the type a
 
 
 @pytest.mark.parametrize("extra", [1, 77, 128, 300])
-@pytest.mark.parametrize("case", ["a", "a-pp", "d201", "d190"])
+@pytest.mark.parametrize("case", ["a", "a-lane", "a-pp", "d201", "d190"])
 def test_resident_grid_ragged_sizes_singles(hips, case, extra):
     """al_pairing_kernel, al_pp_apply_kernel and the 7-word d_prod_pairing_kernel walk the batch in strides of the chip's
     residency (pbc_hip.hip PBC_RESIDENT_LOOP): batches just above ONE residency with ragged tails -- every unit bit-exact
     against the reference's vectors (tiled), none left out, nothing written past the end."""
     import torch
-    key, name = {"a": ("a", "a_chain1024.vec"), "a-pp": ("a", "a_chain1024.vec"), "d201": ("d201", "d201_rand12.vec"),
+    # "a": the tail of wave-kernel size runs on the one-pairing-per-wavefront kernel behind the resident launch;
+    # "a-lane" ("hip_wave_max 0"): the resident kernel walks its own ragged tail
+    key, name = {"a": ("a", "a_chain1024.vec"), "a-lane": ("a", "a_chain1024.vec"), "a-pp": ("a", "a_chain1024.vec"), "d201": ("d201", "d201_rand12.vec"),
                  "d190": ("d278027-190-181", "d278027-190-181_rand12.vec")}[case]
     v = golden(name)
     P = hips[key]
+    if case == "a-lane":
+        import pbc_amd
+        P = pbc_amd.Pairing(_param("a") + "hip_wave_max 0\n")
     n = RESIDENCY + extra
     s = torch.cuda.current_stream().cuda_stream
     GT = torch.full((n + 64, v.lenT), 0xA5, dtype=torch.uint8, device="cuda")

@@ -111,7 +111,6 @@ struct AW {
     const W x = sop2(a0, b0, a1, b1), y = sop2(c0, d0, c1, d1);
     r0 = x; r1 = y;
   }
-  static W uniform(const uint32_t *limbs) { W r; for (int j = 0; j < L; j++) r.l[j] = limbs[j]; A::hs_set(r, A::U_STRICT, 1.0); return r; }
   // x >= q ?  and  x - q  (x: strict limbs, value < 2q)
   static bool geq_q(const W &x) {
     const FpK<N> &K = fpk<N>();
@@ -134,11 +133,8 @@ struct AW {
     if (count > 2) r2 = z;
     if (count > 3) r3 = t;
   }
-  static void to_lane0(el &r, const W &x, int) { r = x; }
-  static W from_lane0(const el &x, int) { return x; }
   static bool lane0() { return true; }
   static void sync() {}
-  static bool share(bool v) { return v; }
 #else
   // ---- device: one limb per lane ----------------------------------------------------------------------------------
   typedef uint32_t W;
@@ -273,7 +269,6 @@ struct AW {
   PBC_DEV W mul(W a, W b) const { return mul_fn(a, b, qq, nv); }
   PBC_DEV W sqr(W a) const { return mul_fn(a, a, qq, nv); }
   PBC_DEV W sop2(W a0, W b0, W a1, W b1) const { return sop2_fn(a0, b0, a1, b1, qq, nv); }
-  static PBC_DEV W uniform(const uint32_t *limbs) { const int j = lane(); return j < L ? limbs[j] : 0u; }
   PBC_DEV bool geq_q(W x) const {
     const uint32_t q = qq;
     const uint64_t gt = __ballot(x > q), lt = __ballot(x < q);
@@ -300,7 +295,6 @@ struct AW {
     for (int i = L; i < 32; i++) g_lds_aw[slot * 32 + i] = 0;
   }
   static PBC_DEV W get_slot(int slot) { return lane() < 32 ? g_lds_aw[slot * 32 + lane()] : 0u; }
-  static PBC_DEV bool share(bool v) { return __builtin_amdgcn_readfirstlane((int) v) != 0; }
 #endif
 
   // value < 2q, any limbs the product accepts -> the canonical residue, strict limbs (what to_fp + to_el give AL)

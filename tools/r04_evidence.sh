@@ -17,7 +17,7 @@ for w in ${GROUP_WL-a-g1-mul a-gt-pow a-hash-g1 a-g1-pp a-gt-pp a-bls-verify d-g
 done
 [ -n "$SKIP_SWEEP" ] || for w in a f; do timeout 300 python bench.py --workload $w --sweep > $O/sweep_$w.json 2> $O/sweep_$w.err; done
 cd /tmp && export TMPDIR=/tmp
-for w in ${PMC_WL-a d f a-prod16 a-g1-mul f-gt-pow}; do
+for w in ${PMC_WL-a d f a-prod16 d-prod16 d190 a-pp a-g1-mul f-gt-pow}; do
   B="python $R/bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline --no-host-path"
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_$w -- $B > $O/kt_$w.log 2>&1
   timeout 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $O/pmc1_$w -- $B > $O/pmc1_$w.log 2>&1

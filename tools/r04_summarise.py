@@ -43,7 +43,8 @@ if os.path.exists(EV + "/pytest.log"):
         fh.writelines(open(EV + "/pytest.log").readlines()[-6:])
     written.append("profiles/r04_gputest_tail.txt")
 MAIN = {"a": "al_pairing_kernel", "d": "d_prod_pairing_kernel", "f": "f_prod_pairing_kernel", "a-prod16": "al_miller_kernel",
-        "a-g1-mul": "al_gmul_kernel", "f-gt-pow": "f_gtpow_kernel", "d-prod16": "d_prod_pairing_kernel"}
+        "a-g1-mul": "al_gmul_kernel", "f-gt-pow": "f_gtpow_kernel", "d-prod16": "d_prod_pairing_kernel", "d190": "d_prod_pairing_kernel",
+        "a-pp": "al_pp_apply_kernel"}
 for w, kern in MAIN.items():
     ks = glob.glob("%s/kt_%s/**/*kernel_stats.csv" % (EV, w), recursive=True)
     if ks:

@@ -100,8 +100,8 @@ int pbc_hip_element_pairing_batch(pbc_hip_pairing_t *p, uint8_t *gt, const uint8
  * beyond that, feed multiples of 131072 where you can.  Type f: 7.2-8.3 ms / 11-12 ms / steps of 11-12 ms, no tail kernel.
  * Cut-over for small batches (type a, 512-bit q): up to 5120 units ("hip_wave_max N" in the parameter text moves it,
  * 0 disables it) a launch gives every pairing a WAVEFRONT (csrc/pairing_aw.cuh: one limb per lane, products across
- * the lanes), up to 768 units ("hip_wave4_max N") a workgroup of FOUR wavefronts that share the independent products
- * of every step: 1.2 ms for one pairing (n <= 256), 1.4 ms at 512, 2.0 ms at 1024, 2.6 ms at 2048, 4.4 ms at 4096,
+ * the lanes), up to 1024 units ("hip_wave4_max N") a workgroup of FOUR wavefronts that share the independent products
+ * of every step: 1.0 ms for one pairing (n <= 256), 1.3 ms at 512, 1.9 ms at 1024, 2.6 ms at 2048, 4.4 ms at 4096,
  * 5.4 ms at 5120 (the throughput kernel: 5.8-6.5 ms depending on the box) -- same bytes as the throughput kernel. */
 int pbc_hip_element_pairing_batch_dev(pbc_hip_pairing_t *p, void *d_gt, const void *d_g1,
                                       const void *d_g2, size_t n, void *stream);

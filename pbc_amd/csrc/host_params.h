@@ -37,7 +37,7 @@ inline int fail(const char *fmt, ...) {
 #define PBC_A_WAVE_MAX 5120
 #endif
 #ifndef PBC_A_WAVE4_MAX
-#define PBC_A_WAVE4_MAX 768
+#define PBC_A_WAVE4_MAX 1024
 #endif
 // ---------------------------------------------------------------------------------------
 struct pbc_hip_pairing_s {

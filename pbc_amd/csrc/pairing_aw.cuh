@@ -23,9 +23,9 @@
 
 namespace pbc {
 
-constexpr int AW_SLOTS = 16;                 // LDS words per workgroup: AW_SLOTS x 32 (5 inputs / 2 outputs, the inversion, 2 x 4 products of a round)
+constexpr int AW_SLOTS = 16;                 // LDS words per workgroup: AW_SLOTS x 64 (5 inputs / 2 outputs, the inversion, 2 x 4 products of a round); a slot holds all 64 lanes, so no access is predicated
 #ifndef PBC_HOSTSIM
-template <int N> __shared__ uint32_t g_lds_aw_t[AW_SLOTS * 32];
+template <int N> __shared__ uint32_t g_lds_aw_t[AW_SLOTS * 64];
 #define g_lds_aw g_lds_aw_t<N>
 #endif
 
@@ -138,8 +138,12 @@ struct AW {
 #else
   // ---- device: one limb per lane ----------------------------------------------------------------------------------
   typedef uint32_t W;
+  // lane masks of the carry pass: mr = what a lane keeps (2^29 - 1 below the top limb, everything in the top limb,
+  // nothing above it), cm = whose carry travels (all ones below the top limb)
+  struct masks { uint32_t mr, cm; };
   W kk[5], qq;                                                 // this lane's limb of the five borrowed constants and of q
   uint32_t nv;                                                 // -1/q mod 2^29
+  masks mk;
   int par = 0;                                                 // which set of round slots is written next (NW > 1)
   PBC_DEV void init() {
     const int j = lane();
@@ -147,6 +151,8 @@ struct AW {
     for (int k = 0; k < 5; k++) kk[k] = j < L ? c_a.ksub[k][j] : 0u;
     qq = j < L ? fpk<N>().p29[j] : 0u;
     nv = fpk<N>().ninv29;
+    mk.mr = j < L - 1 ? MASK : (j == L - 1 ? 0xffffffffu : 0u);
+    mk.cm = j < L - 1 ? 0xffffffffu : 0u;
   }
   static PBC_DEV int lane() { return (int) (threadIdx.x & 63); }
   static PBC_DEV W from_above(W x) { return (W) __builtin_amdgcn_update_dpp(0, (int) x, 0x130, 0xf, 0xf, true); }   // wave_shl:1 : lane j <- lane j + 1
@@ -155,19 +161,15 @@ struct AW {
   template <int S> static PBC_DEV W shl(W a) { return a << S; }
   PBC_DEV W subk(W a, W b, int k) const { return a - b + kk[k]; }
   PBC_DEV W negk(W b, int k) const { return kk[k] - b; }
-  static PBC_DEV W norm(W a) {
-    const int j = lane();
-    const W c = j < L - 1 ? a >> 29 : 0u;
-    return (j < L - 1 ? (a & MASK) : a) + from_below(c);
-  }
-  static PBC_DEV W strict_limbs(W x) {
-    const int j = lane();
+  static PBC_DEV W norm_m(W a, masks k) { return (a & k.mr) + from_below((a >> 29) & k.cm); }
+  static PBC_DEV W strict_limbs(W x, masks k) {
     for (;;) {
-      x = norm(x);
-      if (__ballot(j < L - 1 && x > MASK) == 0) break;
+      x = norm_m(x, k);
+      if (__ballot((x & ~k.mr & k.cm) != 0) == 0) break;
     }
     return x;
   }
+  PBC_DEV W norm(W a) const { return norm_m(a, mk); }
   // One step of the recurrence for accumulator `acc` (see the head of the file).  Accumulators stay below 2^61 (column
   // sums <= 2.55 2^58 + m q: AL's hs_cols), so acc >> 29 is one v_alignbit.  (Forming m on the scalar unit from acc_0's
   // low word and b_0 (-1/q) -- so that the two multiply-adds issue back to back -- measured 9 % SLOWER: 2.75 against
@@ -182,19 +184,19 @@ struct AW {
     nxt = c + from_above((uint32_t) acc & MASK);
   }
   template <int TERMS>
-  static PBC_DEV W lanes_sop(W a0, W b0, W a1, W b1, W q, uint32_t nv) {
+  static PBC_DEV W lanes_sop(W a0, W b0, W a1, W b1, W q, uint32_t nv, masks k) {
     const uint32_t ninv = (uint32_t) __builtin_amdgcn_readfirstlane((int) nv);   // handed down in a register: a scalar load here stalls every product
     uint32_t acc = 0;
 #pragma unroll
     for (int i = 0; i < L; i++)
       lanes_step<TERMS>(acc, (uint32_t) __builtin_amdgcn_readlane((int) a0, i), b0, TERMS == 2 ? (uint32_t) __builtin_amdgcn_readlane((int) a1, i) : 0u, b1, q, ninv);
-    return strict_limbs(acc);
+    return strict_limbs(acc, k);
   }
   // two independent sums of products in one instruction stream: the dependency chain of a step (multiply-add, m,
   // multiply-add, shift: eight instructions of ~9 cycles each at one wave per SIMD) leaves the pipe half empty
   struct W2 { W r0, r1; };
   template <int TERMS>
-  static PBC_DEV W2 lanes_sop_x2(W a0, W b0, W a1, W b1, W c0, W d0, W c1, W d1, W q, uint32_t nv) {
+  static PBC_DEV W2 lanes_sop_x2(W a0, W b0, W a1, W b1, W c0, W d0, W c1, W d1, W q, uint32_t nv, masks k) {
     const uint32_t ninv = (uint32_t) __builtin_amdgcn_readfirstlane((int) nv);
     uint32_t acc = 0, bcc = 0;
 #pragma unroll
@@ -203,16 +205,15 @@ struct AW {
       lanes_step<TERMS>(bcc, (uint32_t) __builtin_amdgcn_readlane((int) c0, i), d0, TERMS == 2 ? (uint32_t) __builtin_amdgcn_readlane((int) c1, i) : 0u, d1, q, ninv);
     }
     W x = acc, y = bcc;
-    const int j = lane();
     for (;;) {
-      x = norm(x);
-      y = norm(y);
-      if (__ballot(j < L - 1 && (x > MASK || y > MASK)) == 0) break;
+      x = norm_m(x, k);
+      y = norm_m(y, k);
+      if (__ballot(((x | y) & ~k.mr & k.cm) != 0) == 0) break;
     }
     return W2{x, y};
   }
-  static __device__ __noinline__ W2 mul2_fn(W a, W b, W c, W d, W q, uint32_t nv) { return lanes_sop_x2<1>(a, b, 0, 0, c, d, 0, 0, q, nv); }
-  static __device__ __noinline__ W2 sop2x2_fn(W a0, W b0, W a1, W b1, W c0, W d0, W c1, W d1, W q, uint32_t nv) { return lanes_sop_x2<2>(a0, b0, a1, b1, c0, d0, c1, d1, q, nv); }
+  static __device__ __noinline__ W2 mul2_fn(W a, W b, W c, W d, W q, uint32_t nv, masks k) { return lanes_sop_x2<1>(a, b, 0, 0, c, d, 0, 0, q, nv, k); }
+  static __device__ __noinline__ W2 sop2x2_fn(W a0, W b0, W a1, W b1, W c0, W d0, W c1, W d1, W q, uint32_t nv, masks k) { return lanes_sop_x2<2>(a0, b0, a1, b1, c0, d0, c1, d1, q, nv, k); }
   // ---- a ROUND: up to four independent products ------------------------------------------------------------------
   // NW = 1: two at a time in one instruction stream.  NW = 4 (one pairing per 256-lane workgroup, a wave on each SIMD of
   // the CU; every wave carries the whole state and repeats the additions): wave w forms product w, writes it to its
@@ -224,11 +225,14 @@ struct AW {
     const int w = wave();
     const int base = 6 + 4 * par;
     if (w < count) {
-      W x0 = a0[0], y0 = b0[0], x1 = TERMS == 2 ? a1[0] : 0u, y1 = TERMS == 2 ? b1[0] : 0u;
-#pragma unroll
-      for (int k = 1; k < 4; k++)
-        if (k < count && w == k) { x0 = a0[k]; y0 = b0[k]; if (TERMS == 2) { x1 = a1[k]; y1 = b1[k]; } }
-      const W res = TERMS == 1 ? mul_fn(x0, y0, qq, nv) : sop2_fn(x0, y0, x1, y1, qq, nv);
+      W x0, y0, x1 = 0u, y1 = 0u;                                 // w is wave-uniform: a scalar branch, no per-lane selects
+      switch (w) {
+        case 0: x0 = a0[0]; y0 = b0[0]; if (TERMS == 2) { x1 = a1[0]; y1 = b1[0]; } break;
+        case 1: x0 = a0[1]; y0 = b0[1]; if (TERMS == 2) { x1 = a1[1]; y1 = b1[1]; } break;
+        case 2: x0 = a0[2]; y0 = b0[2]; if (TERMS == 2) { x1 = a1[2]; y1 = b1[2]; } break;
+        default: x0 = a0[3]; y0 = b0[3]; if (TERMS == 2) { x1 = a1[3]; y1 = b1[3]; } break;
+      }
+      const W res = TERMS == 1 ? mul_fn(x0, y0, qq, nv, mk) : sop2_fn(x0, y0, x1, y1, qq, nv, mk);
       put_slot(res, base + w);
     }
     sync();
@@ -238,10 +242,10 @@ struct AW {
   }
   PBC_DEV void mul4(W &r0, W &r1, W &r2, W &r3, W a0, W b0, W a1, W b1, W a2, W b2, W a3, W b3, int count) {
     if constexpr (NW == 1) {
-      const W2 t = mul2_fn(a0, b0, a1, b1, qq, nv);
+      const W2 t = mul2_fn(a0, b0, a1, b1, qq, nv, mk);
       r0 = t.r0; r1 = t.r1;
-      if (count == 3) r2 = mul_fn(a2, b2, qq, nv);
-      if (count == 4) { const W2 u = mul2_fn(a2, b2, a3, b3, qq, nv); r2 = u.r0; r3 = u.r1; }
+      if (count == 3) r2 = mul_fn(a2, b2, qq, nv, mk);
+      if (count == 4) { const W2 u = mul2_fn(a2, b2, a3, b3, qq, nv, mk); r2 = u.r0; r3 = u.r1; }
     } else {
       W r[4];
       const W a[4] = {a0, a1, a2, a3}, b[4] = {b0, b1, b2, b3};
@@ -252,11 +256,11 @@ struct AW {
     }
   }
   PBC_DEV void mul2(W &r0, W &r1, W a, W b, W c, W d) {
-    if constexpr (NW == 1) { const W2 t = mul2_fn(a, b, c, d, qq, nv); r0 = t.r0; r1 = t.r1; }
+    if constexpr (NW == 1) { const W2 t = mul2_fn(a, b, c, d, qq, nv, mk); r0 = t.r0; r1 = t.r1; }
     else { W r2, r3; mul4(r0, r1, r2, r3, a, b, c, d, 0u, 0u, 0u, 0u, 2); }
   }
   PBC_DEV void sop2x2(W &r0, W &r1, W a0, W b0, W a1, W b1, W c0, W d0, W c1, W d1) {
-    if constexpr (NW == 1) { const W2 t = sop2x2_fn(a0, b0, a1, b1, c0, d0, c1, d1, qq, nv); r0 = t.r0; r1 = t.r1; }
+    if constexpr (NW == 1) { const W2 t = sop2x2_fn(a0, b0, a1, b1, c0, d0, c1, d1, qq, nv, mk); r0 = t.r0; r1 = t.r1; }
     else {
       W r[4];
       const W x0[4] = {a0, c0, 0u, 0u}, y0[4] = {b0, d0, 0u, 0u}, x1[4] = {a1, c1, 0u, 0u}, y1[4] = {b1, d1, 0u, 0u};
@@ -264,11 +268,11 @@ struct AW {
       r0 = r[0]; r1 = r[1];
     }
   }
-  static __device__ __noinline__ W mul_fn(W a, W b, W q, uint32_t nv) { return lanes_sop<1>(a, b, 0, 0, q, nv); }
-  static __device__ __noinline__ W sop2_fn(W a0, W b0, W a1, W b1, W q, uint32_t nv) { return lanes_sop<2>(a0, b0, a1, b1, q, nv); }
-  PBC_DEV W mul(W a, W b) const { return mul_fn(a, b, qq, nv); }
-  PBC_DEV W sqr(W a) const { return mul_fn(a, a, qq, nv); }
-  PBC_DEV W sop2(W a0, W b0, W a1, W b1) const { return sop2_fn(a0, b0, a1, b1, qq, nv); }
+  static __device__ __noinline__ W mul_fn(W a, W b, W q, uint32_t nv, masks k) { return lanes_sop<1>(a, b, 0, 0, q, nv, k); }
+  static __device__ __noinline__ W sop2_fn(W a0, W b0, W a1, W b1, W q, uint32_t nv, masks k) { return lanes_sop<2>(a0, b0, a1, b1, q, nv, k); }
+  PBC_DEV W mul(W a, W b) const { return mul_fn(a, b, qq, nv, mk); }
+  PBC_DEV W sqr(W a) const { return mul_fn(a, a, qq, nv, mk); }
+  PBC_DEV W sop2(W a0, W b0, W a1, W b1) const { return sop2_fn(a0, b0, a1, b1, qq, nv, mk); }
   PBC_DEV bool geq_q(W x) const {
     const uint32_t q = qq;
     const uint64_t gt = __ballot(x > q), lt = __ballot(x < q);
@@ -277,24 +281,24 @@ struct AW {
   PBC_DEV W sub_q(W x) const {
     const int j = lane();
     W r = x - qq + (j < L - 1 ? (1u << 29) : 0u) - (j > 0 && j < L ? 1u : 0u);
-    return strict_limbs(r);
+    return strict_limbs(r, mk);
   }
   static PBC_DEV bool is_zero(W x) { return __ballot(x != 0) == 0; }
   static PBC_DEV void sync() { __syncthreads(); }
   static PBC_DEV bool lane0() { return threadIdx.x == 0; }
   // every lane's limb -> LDS slot; lane 0 (after sync) reads the whole element
-  static PBC_DEV void put_slot(W x, int slot) { if (lane() < 32) g_lds_aw[slot * 32 + lane()] = x; }
+  static PBC_DEV void put_slot(W x, int slot) { g_lds_aw[slot * 64 + lane()] = x; }
   static PBC_DEV void slot_to_el(el &r, int slot) {
 #pragma unroll
-    for (int i = 0; i < L; i++) r.l[i] = g_lds_aw[slot * 32 + i];
+    for (int i = 0; i < L; i++) r.l[i] = g_lds_aw[slot * 64 + i];
   }
   static PBC_DEV void el_to_slot(const el &x, int slot) {
 #pragma unroll
-    for (int i = 0; i < L; i++) g_lds_aw[slot * 32 + i] = x.l[i];
+    for (int i = 0; i < L; i++) g_lds_aw[slot * 64 + i] = x.l[i];
 #pragma unroll
-    for (int i = L; i < 32; i++) g_lds_aw[slot * 32 + i] = 0;
+    for (int i = L; i < 64; i++) g_lds_aw[slot * 64 + i] = 0;
   }
-  static PBC_DEV W get_slot(int slot) { return lane() < 32 ? g_lds_aw[slot * 32 + lane()] : 0u; }
+  static PBC_DEV W get_slot(int slot) { return g_lds_aw[slot * 64 + lane()]; }
 #endif
 
   // value < 2q, any limbs the product accepts -> the canonical residue, strict limbs (what to_fp + to_el give AL)
@@ -442,7 +446,7 @@ struct AW {
 #ifdef PBC_HOSTSIM
   static W strict2(const W &x) { W r = x; strict_limbs(r); A::hs_set(r, A::U_STRICT, 2.0); return r; }
 #else
-  static PBC_DEV W strict2(W x) { return strict_limbs(x); }
+  PBC_DEV W strict2(W x) const { return strict_limbs(x, mk); }
 #endif
 
   // element_pairing, one wave: gt <- e(g1, g2)

@@ -1,6 +1,6 @@
 """GPU tests (-m gpu) of the low-latency path for small batches (round 4, pairing_aw.cuh): element_pairing on a.param with
 one WAVEFRONT per pairing -- an F_q element is one register across 18 lanes, the Montgomery product runs over the lanes
-(v_readlane / DPP wave shifts); up to "hip_wave4_max" units (default 768) FOUR wavefronts share the independent products
+(v_readlane / DPP wave shifts); up to "hip_wave4_max" units (default 1024) FOUR wavefronts share the independent products
 of every step of a pairing through LDS.  Batches up to "hip_wave_max" (default 5120) take these kernels; the bytes are
 those of the throughput kernel and of the reference's vectors, invalid arguments included."""
 import numpy as np
@@ -11,7 +11,7 @@ from conftest import golden, _param, PARAM_OF
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("n", [1, 2, 63, 64, 768, 769, 1024, 5120, 5121])
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 768, 1024, 1025, 5120, 5121])
 def test_wave_pairings_match_the_throughput_kernel_and_the_reference(hip_a, n):
     import pbc_amd
     v = golden("a_chain1024.vec")

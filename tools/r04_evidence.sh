@@ -16,6 +16,11 @@ for w in ${GROUP_WL-a-g1-mul a-gt-pow a-hash-g1 a-g1-pp a-gt-pp a-bls-verify d-g
   timeout 300 python bench.py --workload $w --steps 3 --warmup 1 $NOCPU > $O/bench_$w.json 2> $O/bench_$w.err
 done
 [ -n "$SKIP_SWEEP" ] || for w in a f; do timeout 300 python bench.py --workload $w --sweep > $O/sweep_$w.json 2> $O/sweep_$w.err; done
+[ -n "$SKIP_SMALL" ] || { timeout 300 python tools/r04_wave.py 1 256 512 1024 2048 4096 5120 > $O/wave_latency.txt 2>&1
+  timeout 200 python tools/r04_tail.py > $O/tail.txt 2>&1
+  export PBC_HIP_LIB=$R/pbc_amd/libpbc_hip.so
+  for p in a d159; do timeout 120 oracle/_ref/glue_test pbc_amd/param/$p.param 200 latency 2>&1 | tail -n 1; timeout 200 oracle/_ref/glue_test pbc_amd/param/$p.param 1048576 bench 2>&1 | tail -n 1; done > $O/glue.txt
+  unset PBC_HIP_LIB; }
 cd /tmp && export TMPDIR=/tmp
 for w in ${PMC_WL-a d f a-prod16 d-prod16 d190 a-pp a-g1-mul f-gt-pow}; do
   B="python $R/bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline --no-host-path"

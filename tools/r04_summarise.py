@@ -37,6 +37,14 @@ for f in sorted(glob.glob(EV + "/bench_*.json")):
 for f in sorted(glob.glob(EV + "/sweep_*.json")):
     if os.path.getsize(f):
         put(f, "profiles/r04_" + os.path.basename(f))
+for src, dst, what in (("wave_latency.txt", "profiles/r04_closing_wave_latency.txt", "python tools/r04_wave.py 1 256 512 1024 2048 4096 5120"),
+                       ("tail.txt", "profiles/r04_closing_tail.txt", "python tools/r04_tail.py"),
+                       ("glue.txt", "profiles/r04_closing_glue.txt", "oracle/_ref/glue_test {a,d159}.param {200 latency, 1048576 bench}")):
+    if os.path.exists(EV + "/" + src) and os.path.getsize(EV + "/" + src):
+        with open(dst, "w") as fh:
+            fh.write("commit %s: %s\n" % (head, what))
+            fh.write("".join(l for l in open(EV + "/" + src) if "amdgpu.ids" not in l))
+        written.append(dst)
 if os.path.exists(EV + "/pytest.log"):
     with open("profiles/r04_gputest_tail.txt", "w") as fh:
         fh.write("commit %s: python -m pytest tests -m gpu -q\n" % head)

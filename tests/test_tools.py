@@ -1,46 +1,56 @@
-"""tools/isa_count.py: the assembly parser behind the static instruction model (profiles/r01_static_model_d.txt)."""
+"""CPU tests of the evidence tooling (round 4): one commit per evidence set."""
+import json
 import os
+import subprocess
 import sys
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
-import isa_count  # noqa: E402
+import pytest
 
-ASM = """
-	.text
-_ZN3pbc4leafEv:                         ; @_ZN3pbc4leafEv
-; %bb.0:
-	s_waitcnt vmcnt(0) expcnt(0) lgkmcnt(0)
-	v_mad_u64_u32 v[0:1], s[0:1], v2, v3, 0
-	v_mad_i64_i32 v[4:5], s[0:1], v2, v3, v[0:1]
-	v_add_u32_e32 v0, v0, v1
-	ds_read_b32 v6, v31
-	scratch_load_dword v7, off, s32
-	s_setpc_b64 s[30:31]
-.Lfunc_end0:
-	.size	_ZN3pbc4leafEv, .Lfunc_end0-_ZN3pbc4leafEv
-_Z6kernelPh:                            ; @_Z6kernelPh
-; %bb.0:
-	s_getpc_b64 s[4:5]
-	s_add_u32 s4, s4, _ZN3pbc4leafEv@rel32@lo+4
-	s_addc_u32 s5, s5, _ZN3pbc4leafEv@rel32@hi+12
-.LBB1_1:                                ; =>This Inner Loop Header: Depth=1
-	v_mov_b32_e32 v0, 0
-	s_swappc_b64 s[30:31], s[4:5]
-	global_store_dword v1, v0, s[0:1]
-	s_cbranch_scc1 .LBB1_1
-; %bb.2:
-	s_endpgm
-.Lfunc_end1:
-"""
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_isa_count_classifies_and_splits_blocks(tmp_path):
-    p = tmp_path / "t.s"
-    p.write_text(ASM)
-    funcs = isa_count.parse(str(p))
-    assert list(funcs) == ["_ZN3pbc4leafEv", "_Z6kernelPh"]
-    leaf = isa_count.totals(funcs["_ZN3pbc4leafEv"])
-    assert leaf == {"salu": 2, "mad64": 2, "valu": 1, "lds": 1, "vmem": 1}
-    kern = funcs["_Z6kernelPh"]
-    assert list(kern) == ["entry", ".LBB1_1"]
-    assert isa_count.totals({"b": kern[".LBB1_1"]}) == {"valu": 1, "salu": 3, "vmem": 1}   # blocks end at labels: s_endpgm belongs to the last one
+def _git(*args):
+    return subprocess.run(["git", "-C", ROOT] + list(args), capture_output=True, text=True)
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(ROOT, ".git")), reason="not a git checkout (the GPU box gets a snapshot)")
+def test_collect_refuses_a_dirty_tree():
+    """tools/r04_collect.sh stops before it reaches gpurun when the work tree has uncommitted or untracked files"""
+    marker = os.path.join(ROOT, "tools", "_dirty_marker_for_test.txt")
+    open(marker, "w").write("x")
+    try:
+        r = subprocess.run(["bash", os.path.join(ROOT, "tools", "r04_collect.sh")], capture_output=True, text=True, timeout=60)
+        assert r.returncode == 1 and "dirty" in r.stdout
+        assert not os.path.exists(os.path.join(ROOT, ".evidence_head"))
+    finally:
+        os.remove(marker)
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(ROOT, ".git")), reason="not a git checkout")
+def test_committed_evidence_names_one_commit():
+    """every bench line under profiles/r04_bench_* and the PMC summaries carry the commit the manifest names, and that
+    commit is an ancestor of HEAD"""
+    man = json.load(open(os.path.join(ROOT, "profiles", "r04_MANIFEST.json")))
+    commit = man["commit"]
+    assert _git("merge-base", "--is-ancestor", commit, "HEAD").returncode == 0
+    n = 0
+    for f in man["files"]:
+        path = os.path.join(ROOT, f)
+        assert os.path.exists(path), f
+        if os.path.basename(f).startswith("r04_bench_"):
+            assert json.loads(open(path).readline())["commit"] == commit, f
+            n += 1
+        if os.path.basename(f).startswith("r04_pmc_"):
+            assert json.load(open(path))["commit"] == commit, f
+    assert n >= 30
+
+
+def test_traffic_carries_the_corrected_ratio():
+    """roofline.traffic: read bytes = 2 x FETCH_SIZE (gfx950), ratio against the records of the launch"""
+    sys.path.insert(0, ROOT)
+    import bench
+    t = bench.pmc_traffic("a", 384 * (1 << 20), 1 << 20)
+    assert t and t["source"].startswith("profiles/r04_pmc_a.json")
+    raw = t["raw"]
+    assert t["bytes_per_launch"] == 2 * raw["FETCH_SIZE_bytes"] + raw["WRITE_SIZE_bytes"]
+    assert abs(t["ratio_vs_algorithmic"] - t["bytes_per_launch"] / (384 * (1 << 20))) < 0.01

@@ -25,6 +25,7 @@
 #include "pairing_f.cuh"
 #include "pairing_e.cuh"
 #include "group_al.cuh"
+#include "group_l5.cuh"
 
 using namespace pbc;
 

@@ -24,6 +24,14 @@ __global__ void __launch_bounds__(kBlock, 2) ec_mul_win_kernel(uint8_t *out, con
   const size_t L = 2 * (size_t) F::bytes();
   flags[idx] = ec_mul_win_lane<F>(out + idx * L, in + idx * L, z + idx * zlen, zlen) ? 0 : 1;
 }
+// G1 of the 5-word fields (d159.param, f.param): the same ladder in limb form (group_l5.cuh)
+template <class KP>
+__global__ void __launch_bounds__(kBlock, 2) l5_gmul_kernel(uint8_t *out, const uint8_t *in, const uint8_t *z, int zlen, uint8_t *flags, size_t n, KArgs<5> ka) {
+  size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
+  if (idx >= n) return;
+  const size_t L = 2 * (size_t) fpk<5>().fbytes;
+  flags[idx] = GL<5, KP>::gmul_lane(out + idx * L, in + idx * L, z + idx * zlen, zlen) ? 0 : 1;
+}
 // Type a, 512-bit field: the same ladder on the limb-form arithmetic (group_al.cuh), resident workgroups as the pairing kernel.
 template <int N>
 __global__ void __launch_bounds__(kBlock, PBC_A_WAVES) al_gmul_kernel(uint8_t *out, const uint8_t *in, const uint8_t *z, int zlen,
@@ -359,6 +367,11 @@ static int group_launch(pbc_hip_pairing_s *P, const GroupCall &c, void *d_out, c
       if (fast_a) {
         hipLaunchKernelGGL(al_gmul_kernel<16>, dim3(PBC_RGRID(al_gmul_kernel<16>)), dim3(kBlock), 0, s, o, a, b, P->len_zr, flags, n, unit_counter(P, s), kargs<16>(P));
         hipLaunchKernelGGL(ec_mul_kernel<FqOps<16>>, dim3(grid), dim3(kBlock), 0, s, o, a, c.la, b, P->len_zr, (const uint8_t *) flags, n, kargs<16>(P));
+      } else if (c.group == 1 && P->nlimb == 5 && ((P->type == 'd' && P->deg == 3 && P->dconst.limb_ok) || (P->type == 'f' && P->fconst.pl_ok))) {
+        // (the borrowed constants of the pairing kernels' limb-form steps fit this q: host_params.h limb_ok / pl_ok)
+        if (P->type == 'd') hipLaunchKernelGGL(l5_gmul_kernel<KPd>, dim3(grid), dim3(kBlock), 0, s, o, a, b, P->len_zr, flags, n, kargs<5>(P));
+        else hipLaunchKernelGGL(l5_gmul_kernel<KPf>, dim3(grid), dim3(kBlock), 0, s, o, a, b, P->len_zr, flags, n, kargs<5>(P));
+        hipLaunchKernelGGL(ec_mul_kernel<FqOps<5>>, dim3(grid), dim3(kBlock), 0, s, o, a, c.la, b, P->len_zr, (const uint8_t *) flags, n, kargs<5>(P));
       } else {
         PBC_DISPATCH_G(P, c.group, {
           hipLaunchKernelGGL(ec_mul_win_kernel<F>, dim3(grid), dim3(kBlock), 0, s, o, a, b, P->len_zr, flags, n, kargs<F::NW>(P));

@@ -7,6 +7,7 @@
 #include "../../pbc_amd/csrc/pairing_al.cuh"
 #include "../../pbc_amd/csrc/pairing_aw.cuh"
 #include "../../pbc_amd/csrc/group_al.cuh"
+#include "../../pbc_amd/csrc/group_l5.cuh"
 
 // run EXPR with N = the compile-time word count matching P->nlimb
 #define HS_DISPATCH(nl, ...)                          \
@@ -305,6 +306,11 @@ int hostsim_group(void *h, int what, uint8_t *out, const uint8_t *a, const uint8
       // as the library: the limb-form ladder first where it exists, the complete routine for the lanes it reports
       if (P->type == 'a' && !P->a_generic && !hostsim_slow_group) {
         if (GAL<16>::gmul_lane(out + i * P->len1, a + i * P->len1, b + i * P->len_zr, P->len_zr)) continue;
+        hostsim_fallbacks++;
+      } else if (!hostsim_slow_group && P->nlimb == 5 && ((P->type == 'd' && P->deg == 3 && P->dconst.limb_ok) || (P->type == 'f' && P->fconst.pl_ok))) {
+        const bool ok = P->type == 'd' ? GL<5, KPd>::gmul_lane(out + i * P->len1, a + i * P->len1, b + i * P->len_zr, P->len_zr)
+                                       : GL<5, KPf>::gmul_lane(out + i * P->len1, a + i * P->len1, b + i * P->len_zr, P->len_zr);
+        if (ok) continue;
         hostsim_fallbacks++;
       } else if (!hostsim_slow_group) {
         bool ok = false;

@@ -550,3 +550,30 @@ def test_type_a_one_pairing_per_wavefront_on_host(sims):
     assert np.array_equal(S2.pairing_wave(v.g1, v.g2), v.gt)
     with pytest.raises(RuntimeError):
         sims["d"].pairing_wave(v.g1, v.g2)
+
+
+@pytest.mark.parametrize("key,pname,name", [("d", "d159", "d_rand32.vec"), ("f", "f", "f_rand16.vec")])
+def test_limb_form_g1_ladder_of_the_5_word_fields_on_host(oracles, key, pname, name):
+    """group_l5.cuh (round 4): element_mul_zn on G1 of d159.param / f.param in limb form -- the Jacobian doubling and mixed
+    addition of the pairing kernels' limb-form steps without their line coefficients, under the same worst-case tracker;
+    random and exceptional scalars against the oracle, the lanes the ladder reports through the complete routine;
+    "hip_no_limb 1" keeps the word-form policy and gives the same bytes."""
+    import hostsim
+    from conftest import _param
+    S, O = hostsim.HostSim(_param(pname)), oracles[key]
+    v = golden(name)
+    r = _order(pname)
+    zl = (r.bit_length() + 7) // 8
+    rng = np.random.default_rng(3)
+    ks = [int.from_bytes(rng.bytes(zl), "big") % r for _ in range(6)] + [0, 1, 2, 3, r - 1, r - 2, r, r + 1, 2**(8 * zl) - 1, 2**(8 * zl) - 2, 15, 16, 17]
+    Z = np.stack([_be(k, zl) for k in ks])
+    P = np.tile(v.g1, (2, 1))[:len(ks)]
+    S.fallbacks()
+    got = S.group(0, P, Z)
+    assert np.array_equal(got, O.g_mul(1, P, Z))
+    assert S.fallbacks() == 3                                  # 0 P, r P and (r - 1) P = r P - P
+    W = hostsim.HostSim(_param(pname) + "hip_no_limb 1\n")
+    assert np.array_equal(W.group(0, P, Z), got)
+    bad = P.copy()
+    bad[2, -1] ^= 1                                            # off the curve: O
+    assert np.array_equal(S.group(0, bad, Z), O.g_mul(1, bad, Z))

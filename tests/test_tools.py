@@ -28,20 +28,22 @@ def test_collect_refuses_a_dirty_tree():
 
 @pytest.mark.skipif(not os.path.isdir(os.path.join(ROOT, ".git")), reason="not a git checkout")
 def test_committed_evidence_names_one_commit():
-    """every bench line under profiles/r04_bench_* and the PMC summaries carry the commit the manifest names, and that
-    commit is an ancestor of HEAD"""
+    """every bench line under profiles/r04_bench_* and the PMC summaries carry the commit the manifest names for them (the
+    collection's, or that of the addendum -- a partial re-collection after a change to a few kernels -- that lists the
+    file), and those commits are ancestors of HEAD"""
     man = json.load(open(os.path.join(ROOT, "profiles", "r04_MANIFEST.json")))
-    commit = man["commit"]
-    assert _git("merge-base", "--is-ancestor", commit, "HEAD").returncode == 0
+    sets = [(man["commit"], man["files"])] + [(a["commit"], a["files"]) for a in man.get("addenda", [])]
     n = 0
-    for f in man["files"]:
-        path = os.path.join(ROOT, f)
-        assert os.path.exists(path), f
-        if os.path.basename(f).startswith("r04_bench_"):
-            assert json.loads(open(path).readline())["commit"] == commit, f
-            n += 1
-        if os.path.basename(f).startswith("r04_pmc_"):
-            assert json.load(open(path))["commit"] == commit, f
+    for commit, files in sets:
+        assert _git("merge-base", "--is-ancestor", commit, "HEAD").returncode == 0
+        for f in files:
+            path = os.path.join(ROOT, f)
+            assert os.path.exists(path), f
+            if os.path.basename(f).startswith("r04_bench_"):
+                assert json.loads(open(path).readline())["commit"] == commit, f
+                n += 1
+            if os.path.basename(f).startswith("r04_pmc_"):
+                assert json.load(open(path))["commit"] == commit, f
     assert n >= 30
 
 

@@ -7,11 +7,13 @@
 #   4. tools/r04_summarise.py turns gpurun_out/ev_r04 into profiles/r04_* -- it checks again that HEAD has not moved and
 #      the tree is still clean, and writes profiles/r04_MANIFEST.json (commit, files, time).
 # Usage: tools/r04_collect.sh [gpurun timeout seconds]   (environment of r04_evidence.sh is passed through: WITH_TESTS=1 ...)
+# ADDENDUM=1: a partial collection after a change to a few kernels (restrict it with BENCH_WL / GROUP_WL / PMC_WL / SKIP_*):
+# the files it produces replace their predecessors and are listed, with THEIR commit, under "addenda" of the manifest.
 cd "$(dirname "$0")/.." || exit 1
 if [ -n "$(git status --porcelain)" ]; then echo "work tree is dirty: commit first (evidence is taken from a commit, not from a state)"; git status --short | head; exit 1; fi
 git rev-parse HEAD > .evidence_head
 rm -rf gpurun_out/ev_r04
-ENVS=""; for v in WITH_TESTS BENCH_WL GROUP_WL PMC_WL CPU_WL GROUP_CPU_WL SKIP_SWEEP; do [ -z "${!v+x}" ] || ENVS="$ENVS $v='${!v}'"; done
+ENVS=""; for v in WITH_TESTS BENCH_WL GROUP_WL PMC_WL CPU_WL GROUP_CPU_WL SKIP_SWEEP SKIP_SMALL; do [ -z "${!v+x}" ] || ENVS="$ENVS $v='${!v}'"; done
 /usr/local/graft/bin/gpurun --timeout ${1:-2400} -- "$ENVS bash tools/r04_evidence.sh"
 rc=$?
 rm -f .evidence_head

@@ -84,7 +84,17 @@ for w, kern in MAIN.items():
         json.dump(out, open(dst, "w"), indent=1, sort_keys=True)
         written.append(dst)
         print(w, {k: "%.4g" % v["avg_per_launch"] for k, v in sorted(out.items()) if isinstance(v, dict)})
-json.dump({"commit": head, "written": time.strftime("%Y-%m-%d %H:%M:%S"), "files": sorted(written),
-           "how": "tools/r04_collect.sh (clean tree at this commit) -> gpurun tools/r04_evidence.sh -> tools/r04_summarise.py"},
-          open("profiles/r04_MANIFEST.json", "w"), indent=1)
+if os.environ.get("ADDENDUM"):
+    man = json.load(open("profiles/r04_MANIFEST.json"))
+    man["files"] = sorted(set(man["files"]) - set(written))
+    for a in man.get("addenda", []):
+        a["files"] = sorted(set(a["files"]) - set(written))
+    man.setdefault("addenda", []).append({"commit": head, "written": time.strftime("%Y-%m-%d %H:%M:%S"), "files": sorted(written),
+                                          "why": os.environ.get("ADDENDUM_WHY", "partial re-collection after a change to the kernels of these workloads")})
+    man["addenda"] = [a for a in man["addenda"] if a["files"]]
+    json.dump(man, open("profiles/r04_MANIFEST.json", "w"), indent=1)
+else:
+    json.dump({"commit": head, "written": time.strftime("%Y-%m-%d %H:%M:%S"), "files": sorted(written),
+               "how": "tools/r04_collect.sh (clean tree at this commit) -> gpurun tools/r04_evidence.sh -> tools/r04_summarise.py"},
+              open("profiles/r04_MANIFEST.json", "w"), indent=1)
 print("%d files under profiles/ from commit %s" % (len(written) + 1, head[:12]))

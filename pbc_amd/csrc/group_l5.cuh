@@ -324,6 +324,58 @@ struct GL {
     }
     return handled;
   }
+
+  // element_pp_pow_zn on G1: out <- [z] B from the 8-bit-row table of element_pp_init (group_ops.cuh ec_pp_entry_lane:
+  // affine Montgomery words), one mixed addition per byte of the scalar -- ec_pp_pow_lane in limb form.  false: the lane
+  // needs the complete routine (two equal table points met: a doubling).
+  static PBC_DEV bool pp_pow_lane(uint8_t *out, const uint32_t *__restrict__ tab, const uint8_t *z, int zlen) {
+    const int NB = (int) fpk<N>().fbytes;
+    el one;
+    {
+      fp<N> o;
+      fp_set<N>(o, fpk<N>().one);
+      from_fq(one, o);
+    }
+    el X = one, Y = one, Z = one;
+    bool inf = true;                   // the accumulator is still O
+    for (int row = 0; row < zlen; row++) {
+      const uint32_t w = z[zlen - 1 - row];
+      const size_t u = (size_t) row * kPpRowLen + (w ? w - 1 : 0);
+      fp<N> wx, wy;
+      fp_set<N>(wx, tab + u * 2 * N);
+      fp_set<N>(wy, tab + (u * 2 + 1) * N);
+      el x2, y2, sX = X, sY = Y, sZ = Z;
+      from_fq(x2, wx);
+      from_fq(y2, wy);
+      madd(sX, sY, sZ, x2, y2);
+      const bool take = w != 0, first = take & inf, acc = take & !inf;
+      sel(X, sX, acc);
+      sel(Y, sY, acc);
+      sel(Z, sZ, acc);
+      sel(X, x2, first);
+      sel(Y, y2, first);
+      inf &= !take;
+    }
+    const bool bad = !inf & is0(Z);
+    el zinv, zz, t3, ax, ay;
+    inv(zinv, Z);
+    sqr(zz, zinv);
+    mul<2>(ax, X, zz);
+    mul<1>(t3, zz, zinv);
+    mul<2>(ay, Y, t3);
+    fp<N> x, y;
+    to_fq(x, ax);
+    to_fq(y, ay);
+    if (inf) {                         // k = 0
+#pragma unroll
+      for (int k = 0; k < N; k++) { x.v[k] = 0; y.v[k] = 0; }
+    }
+    if (!bad) {
+      fp_store_be<N>(out, x);
+      fp_store_be<N>(out + NB, y);
+    }
+    return !bad;
+  }
 };
 
 }  // namespace pbc

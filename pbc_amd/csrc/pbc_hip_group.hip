@@ -32,6 +32,13 @@ __global__ void __launch_bounds__(kBlock, 2) l5_gmul_kernel(uint8_t *out, const 
   const size_t L = 2 * (size_t) fpk<5>().fbytes;
   flags[idx] = GL<5, KP>::gmul_lane(out + idx * L, in + idx * L, z + idx * zlen, zlen) ? 0 : 1;
 }
+template <class KP>
+__global__ void __launch_bounds__(kBlock, 2) l5_pp_pow_kernel(uint8_t *out, const uint32_t *__restrict__ tab, const uint8_t *z, int zlen, uint8_t *flags, size_t n, KArgs<5> ka) {
+  size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
+  if (idx >= n) return;
+  const size_t L = 2 * (size_t) fpk<5>().fbytes;
+  flags[idx] = GL<5, KP>::pp_pow_lane(out + idx * L, tab, z + idx * zlen, zlen) ? 0 : 1;
+}
 // Type a, 512-bit field: the same ladder on the limb-form arithmetic (group_al.cuh), resident workgroups as the pairing kernel.
 template <int N>
 __global__ void __launch_bounds__(kBlock, PBC_A_WAVES) al_gmul_kernel(uint8_t *out, const uint8_t *in, const uint8_t *z, int zlen,
@@ -566,10 +573,16 @@ static int pp_pow_launch(pbc_hip_element_pp_s *pp, void *d_out, const void *d_zr
     ProdWs W(P, s, own);
     uint8_t *flags = (uint8_t *) W.get(n);
     if (!flags) return 1;
-    PBC_DISPATCH_G(P, pp->group, {
-      hipLaunchKernelGGL(ec_pp_pow_kernel<F>, dim3(grid), dim3(kBlock), 0, s, o, (const uint32_t *) pp->tab, z, P->len_zr, flags, n, kargs<F::NW>(P));
-      hipLaunchKernelGGL(ec_mul_kernel<F>, dim3(grid), dim3(kBlock), 0, s, o, (const uint8_t *) pp->base, (size_t) 0, z, P->len_zr, (const uint8_t *) flags, n, kargs<F::NW>(P));
-    });
+    if (pp->group == 1 && P->nlimb == 5 && ((P->type == 'd' && P->deg == 3 && P->dconst.limb_ok) || (P->type == 'f' && P->fconst.pl_ok))) {
+      if (P->type == 'd') hipLaunchKernelGGL(l5_pp_pow_kernel<KPd>, dim3(grid), dim3(kBlock), 0, s, o, (const uint32_t *) pp->tab, z, P->len_zr, flags, n, kargs<5>(P));
+      else hipLaunchKernelGGL(l5_pp_pow_kernel<KPf>, dim3(grid), dim3(kBlock), 0, s, o, (const uint32_t *) pp->tab, z, P->len_zr, flags, n, kargs<5>(P));
+      hipLaunchKernelGGL(ec_mul_kernel<FqOps<5>>, dim3(grid), dim3(kBlock), 0, s, o, (const uint8_t *) pp->base, (size_t) 0, z, P->len_zr, (const uint8_t *) flags, n, kargs<5>(P));
+    } else {
+      PBC_DISPATCH_G(P, pp->group, {
+        hipLaunchKernelGGL(ec_pp_pow_kernel<F>, dim3(grid), dim3(kBlock), 0, s, o, (const uint32_t *) pp->tab, z, P->len_zr, flags, n, kargs<F::NW>(P));
+        hipLaunchKernelGGL(ec_mul_kernel<F>, dim3(grid), dim3(kBlock), 0, s, o, (const uint8_t *) pp->base, (size_t) 0, z, P->len_zr, (const uint8_t *) flags, n, kargs<F::NW>(P));
+      });
+    }
   }
   HIP_TRY(hipGetLastError());
   return 0;

@@ -278,6 +278,8 @@ int hostsim_element_pp(void *h, int group, uint8_t *out, const uint8_t *base, co
   }
   const size_t units = (size_t) zlen * kPpRowLen;
   const size_t lp = group == 2 ? P->len2 : P->len1;
+  // as the library: G1 of the 5-word fields takes the limb-form table routine (group_l5.cuh)
+  const bool limb5 = group == 1 && P->nlimb == 5 && ((P->type == 'd' && P->deg == 3 && P->dconst.limb_ok) || (P->type == 'f' && P->fconst.pl_ok));
 #define HS_EC_PP(F_)                                                                           \
   { std::vector<uint32_t> tab(units * 2 * F_::WORDS_EL);                                        \
     std::vector<uint8_t> flags(units);                                                          \
@@ -285,7 +287,9 @@ int hostsim_element_pp(void *h, int group, uint8_t *out, const uint8_t *base, co
     bool complete_only = false;                                                                 \
     for (uint8_t f : flags) complete_only |= f != 0;                                            \
     for (size_t i = 0; i < n; i++) {                                                            \
-      if (!complete_only && ec_pp_pow_lane<F_>(out + i * lp, tab.data(), zr + i * zlen, zlen)) continue; \
+      if (!complete_only && limb5 && (P->type == 'd' ? GL<5, KPd>::pp_pow_lane(out + i * lp, tab.data(), zr + i * zlen, zlen)  \
+                                                      : GL<5, KPf>::pp_pow_lane(out + i * lp, tab.data(), zr + i * zlen, zlen))) continue; \
+      if (!complete_only && !limb5 && ec_pp_pow_lane<F_>(out + i * lp, tab.data(), zr + i * zlen, zlen)) continue; \
       hostsim_fallbacks++;                                                                      \
       ec_mul_lane<F_>(out + i * lp, base, zr + i * zlen, zlen);                                 \
     } }

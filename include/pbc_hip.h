@@ -51,7 +51,26 @@ typedef struct pbc_hip_pairing_s pbc_hip_pairing_t;
  * ecc/a_param.c:1431-1472, a1_init_pairing :2230-2273, d_init_pairing ecc/d_param.c:993-1095,
  * e_init_pairing ecc/e_param.c:832-872, f_init_pairing ecc/f_param.c:335-447, g_init_pairing
  * ecc/g_param.c:1248-1354) and bind the
- * object to the calling thread's current HIP device.  len == 0 means strlen(param). */
+ * object to the calling thread's current HIP device.  len == 0 means strlen(param).
+ *
+ * Keys beyond PBC's own in the parameter text select implementation variants of THIS library (PBC ignores unknown keys,
+ * so the same text still initialises the reference).  Every variant gives the same bytes; they exist for same-box A/B
+ * measurements and for the tests, and the defaults are the measured winners:
+ *   hip_wave_max N       type a: batches up to N units take the one-pairing-per-wavefront kernels (default 5120, 0 = never)
+ *   hip_wave4_max N      ... and up to N units four wavefronts per pairing (default 1024)
+ *   hip_dynamic 1        resident kernels fetch their units from a per-launch counter instead of a fixed stride
+ *   hip_no_fair 1        resident kernels without the time-sliced wave priorities
+ *   hip_resident_slots N workgroups of a resident launch instead of the occupancy query (tests: forces many strides)
+ *   hip_zero_copy 0      host-buffer calls stage page-locked buffers through device memory instead of working in place
+ *   hip_host_chunk N     host-buffer calls: units per staged chunk
+ *   hip_prod_shared 1    type a products: one product per lane with shared squarings (the reference's shape) instead of
+ *                        one term per lane;  hip_prod_chunk N: terms per launch of the one-term-per-lane kernels
+ *   hip_group_slow 1     group operations: only the complete ladders / generic powers (no fast pass)
+ *   hip_no_limb 1        types d, f: word-form steps on E(F_q) in the pairing kernels, word-form ladders on G1
+ *   hip_no_xs 1, hip_no_bm1 1, hip_no_cyc 1, hip_no_bn 1
+ *                        type f: the parameter file's xi instead of the sparse one / its basis of F_q^2 instead of the
+ *                        i-basis / plain squarings instead of Granger-Scott ones / the generic hard part instead of the
+ *                        BN chain */
 int pbc_hip_pairing_init_set_buf(pbc_hip_pairing_t **out, const char *param, size_t len);
 /* Replaces pairing_clear (include/pbc_pairing.h:109-116). */
 void pbc_hip_pairing_clear(pbc_hip_pairing_t *p);

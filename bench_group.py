@@ -37,13 +37,16 @@ for _t, _p, _fx in (("a", "a", "a_chain1024.vec"), ("d", "d159", "d_chain256.vec
     GROUP_WORKLOADS[_t + "-hash-g1"] = (_p, _fx, "hashg1", 18)
     GROUP_WORKLOADS[_t + "-g1-pp"] = (_p, _fx, "g1pp", 20)
     GROUP_WORKLOADS[_t + "-gt-pp"] = (_p, _fx, "gtpp", 20 if _t != "f" else 18)
+    GROUP_WORKLOADS[_t + "-decompress"] = (_p, _fx, "decompress", 18)
+    GROUP_WORKLOADS[_t + "-compress"] = (_p, _fx, "compress", 20)
 GROUP_WORKLOADS["a-bls-verify"] = ("a", "a_chain1024.vec", "blsverify", 17)
 
 DESC = {"g1mul": "element_mul_zn on G1", "g2mul": "element_mul_zn on G2 (the twist)", "gtpow": "element_pow_zn on GT",
         "hashg1": "element_from_hash on G1 (32-byte digests)", "g1pp": "element_pp_pow_zn on G1 (fixed base)",
-        "gtpp": "element_pp_pow_zn on GT (fixed base)", "blsverify": "BLS batch verification (hash, 2 x mul_zn, 16-term products)"}
+        "gtpp": "element_pp_pow_zn on GT (fixed base)", "decompress": "element_from_bytes_compressed on G1",
+        "compress": "element_to_bytes_compressed on G1", "blsverify": "BLS batch verification (hash, 2 x mul_zn, 16-term products)"}
 UNIT = {"g1mul": "scalar multiplications/s", "g2mul": "scalar multiplications/s", "gtpow": "powers/s", "hashg1": "hashes/s",
-        "g1pp": "scalar multiplications/s", "gtpp": "powers/s", "blsverify": "signatures/s"}
+        "g1pp": "scalar multiplications/s", "gtpp": "powers/s", "decompress": "points/s", "compress": "points/s", "blsverify": "signatures/s"}
 
 
 def param_int(text, key):
@@ -96,6 +99,11 @@ def reference_model(text, op, nlimb):
             prods += hs * 4 + hm * 3
             invs += hs + hm
         return prods, invs
+    if op == "decompress":              # curve_from_x (ecc/curve.c:770-815): x^3 + a x + b (2 products) and one square root (a power of about bits(q) bits)
+        qs, qm = pow_ops(q.bit_length())
+        return 2 + qs + qm, 0
+    if op == "compress":                # the parity of the canonical y: no arithmetic
+        return 0, 0
     rows = b // 5 + 1                  # element_pow_base_table (arith/field.c:286-323): one multiplication per 5-bit row
     if op == "g1pp":
         return rows * 3, rows
@@ -117,7 +125,7 @@ def cpu_baseline(param_path, op):
     import oracle
     tool = oracle.REF_TOOL
     cores = os.cpu_count() or 1
-    if not os.path.exists(tool):
+    if not os.path.exists(tool) or op in ("compress", "decompress"):      # (ref_tool benchg has no point-format mode)
         return None
     per = {"g1mul": 400, "g2mul": 200, "gtpow": 2000, "hashg1": 200, "g1pp": 4000, "gtpp": 20000, "blsverify": 150}[op]
     if not param_path.endswith("a.param"):
@@ -242,6 +250,18 @@ def main(args, load_vec, ensure_built, MAC_PEAK):
 
         def gate():
             return np.array_equal(OUT[sample].cpu().numpy(), O.from_hash(Hn[sample]))
+    elif op in ("compress", "decompress"):
+        pts = torch.from_numpy(g1).cuda()[idx].contiguous()
+        comp = torch.from_numpy(O.point_format(0, g1)).cuda()[idx].contiguous()
+        IN, OUT = (pts, torch.empty_like(comp)) if op == "compress" else (comp, torch.empty_like(pts))
+        unit_bytes = IN.shape[1] + OUT.shape[1]
+        what = "to_bytes_compressed" if op == "compress" else "from_bytes_compressed"
+
+        def step():
+            P.point_format_dev(what, 1, OUT.data_ptr(), IN.data_ptr(), n, s)
+
+        def gate():
+            return np.array_equal(OUT[sample].cpu().numpy(), O.point_format(0 if op == "compress" else 1, IN[sample].cpu().numpy()))
     elif op in ("g1pp", "gtpp"):
         group = 1 if op == "g1pp" else 3
         base = g1[5] if group == 1 else gt[5]

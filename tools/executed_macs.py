@@ -60,6 +60,13 @@ def main():
             S.group(2, gt[:1], z)
         elif op == "hashg1":
             S.from_hash(rng.integers(0, 256, (64, 32), dtype=np.uint8), 32)
+        elif op in ("compress", "decompress"):
+            comp = S.compress(0, g1[:1])
+            S.macs(reset=True)
+            if op == "compress":
+                S.compress(0, g1[:1])
+            else:
+                S.compress(1, comp)
         elif op in ("g1pp", "gtpp"):
             grp = 1 if op == "g1pp" else 3
             base = g1[5] if grp == 1 else gt[5]

@@ -71,24 +71,42 @@ def load_vec(path):
     return g1.copy(), g2.copy(), gt.copy()
 
 
-def cpu_baseline(param_path, k=1, fixture=None):
+CPU_BASELINE_FILE = os.path.join(ROOT, "profiles", "r05_cpu_baselines.json")
+
+
+def container_cpu_baseline(workload):
+    """The reference's CPU rate for `workload` as measured once in the build container (tools/cpu_baselines.py ->
+    profiles/r05_cpu_baselines.json; the reference needs no GPU).  Attached, marked "where": "build container", when the
+    live CPU leg is switched off (--no-cpu-baseline: metered GPU-box minutes) -- the headline workloads run it live."""
+    try:
+        e = json.load(open(CPU_BASELINE_FILE))
+        b = dict(e["workloads"][workload])
+        b["where"] = "build container (%s, %d vCPU)" % (e["cpu_model"], e["cores"])
+        return b
+    except Exception:  # noqa: BLE001
+        return None
+
+
+def cpu_baseline(param_path, k=1, fixture=None, pp=False):
     """PBC+GMP (the unmodified reference compiled into oracle/_ref) on the host cores, on a
-    bounded sample of the same workload; falls back to the single-core C port."""
+    bounded sample of the same workload; falls back to the single-core C port.  pp: pairing_pp_apply with a fixed
+    first argument (benchmark/benchmark.c:75-81) instead of element_pairing."""
     import oracle  # checker/baseline only -- never on the measured GPU path
     cores = os.cpu_count() or 1
     tool = oracle.REF_TOOL
     if os.path.exists(tool):
         try:
             def run(per_worker, workers):
-                out = subprocess.run([tool, "bench", param_path, str(per_worker), str(k), str(workers)],
+                out = subprocess.run([tool, "bench", param_path, str(per_worker), str(-1 if pp else k), str(workers)],
                                      capture_output=True, text=True, timeout=300)
                 return json.loads(out.stdout.strip().splitlines()[-1])
             # relative cost of one reference pairing (keeps the CPU sample at roughly 10-30 s)
             base = os.path.basename(param_path)
             scale = {"a.param": 1, "a1.param": 48, "e.param": 8, "f.param": 16, "f_256.param": 48, "g149.param": 12}.get(
                 base, 8 if base.startswith("d") and base != "d159.param" else 4 if base.startswith("d") else 1) * k
+            mult = int(os.environ.get("PBC_CPU_SAMPLE_SCALE", "1"))   # (tools/cpu_baselines.py: longer samples on a few-core host)
             one = run(max(16, 2048 // scale), 1)     # one core alone (~2 s)
-            per_worker = max(8, 1024 // scale)
+            per_worker = max(8, 1024 // scale) * mult
             allc = run(per_worker, cores)            # every logical CPU busy
             quota = None
             try:
@@ -99,7 +117,7 @@ def cpu_baseline(param_path, k=1, fixture=None):
             return {"value": round(allc["units_per_s"], 1), "unit": "pairings/s" if k == 1 else "products/s", "cores": cores,
                     "kind": "reference",
                     "sample": "%d %s calls per worker x %d forked workers (%s), %.1f s wall"
-                              % (per_worker, "element_pairing" if k == 1 else "element_prod_pairing(k=%d)" % k, cores,
+                              % (per_worker, "pairing_pp_apply" if pp else "element_pairing" if k == 1 else "element_prod_pairing(k=%d)" % k, cores,
                                  os.path.basename(param_path), allc["wall_s"]),
                     "single_core": round(one["units_per_s"], 1),
                     "per_core_when_all_busy": round(allc["per_core"], 1),
@@ -124,11 +142,11 @@ def cpu_baseline(param_path, k=1, fixture=None):
 
 def pmc_traffic(workload, alg_bytes=None, n=None):
     """HBM bytes per launch from the rocprofv3 PMC passes (separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of this
-    same command, taken by tools/r04_collect.sh at the commit the summary names): the guide's gfx950 correction applied
+    same command, taken by tools/collect.sh at the commit the summary names): the guide's gfx950 correction applied
     -- FETCH_SIZE counts 32-byte requests as if they were 64-byte ones on wide coalesced reads, so the read bytes are
     2 x FETCH_SIZE KB -- and `ratio_vs_algorithmic` = corrected bytes / the records the launch has to read and write.
     A ratio well above 1 is scratch (register spill / private array) traffic.  None when no summary is committed."""
-    for rel in ("profiles/r04_pmc_%s.json" % workload, "profiles/r03_pmc_%s.json" % workload, "profiles/r02_pmc_%s.json" % workload):
+    for rel in ("profiles/r05_pmc_%s.json" % workload, "profiles/r04_pmc_%s.json" % workload, "profiles/r03_pmc_%s.json" % workload, "profiles/r02_pmc_%s.json" % workload):
         path = os.path.join(ROOT, rel)
         if not os.path.exists(path):
             continue
@@ -148,7 +166,7 @@ def pmc_traffic(workload, alg_bytes=None, n=None):
 
 
 def evidence_commit():
-    """the commit tools/r04_collect.sh took this snapshot from (it writes .evidence_head next to this file and refuses a
+    """the commit tools/collect.sh took this snapshot from (it writes .evidence_head next to this file and refuses a
     dirty tree); None outside an evidence run"""
     try:
         return open(os.path.join(ROOT, ".evidence_head")).read().strip() or None
@@ -464,8 +482,9 @@ def main():
                         "algorithmic_bytes_per_unit": unit_bytes},
             },
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(param_path, k, fixture)
+        if world == 1:
+            cb = None if args.no_cpu_baseline else cpu_baseline(param_path, k, fixture, pp=args.workload.endswith("-pp"))
+            out["cpu_baseline"] = cb if cb is not None else container_cpu_baseline(args.workload)
         if evidence_commit():
             out["commit"] = evidence_commit()
         print(json.dumps(out), flush=True)

@@ -125,11 +125,13 @@ def cpu_baseline(param_path, op):
     import oracle
     tool = oracle.REF_TOOL
     cores = os.cpu_count() or 1
-    if not os.path.exists(tool) or op in ("compress", "decompress"):      # (ref_tool benchg has no point-format mode)
+    if not os.path.exists(tool):
         return None
-    per = {"g1mul": 400, "g2mul": 200, "gtpow": 2000, "hashg1": 200, "g1pp": 4000, "gtpp": 20000, "blsverify": 150}[op]
+    per = {"g1mul": 400, "g2mul": 200, "gtpow": 2000, "hashg1": 200, "g1pp": 4000, "gtpp": 20000, "blsverify": 150,
+           "compress": 400000, "decompress": 4000}[op]
     if not param_path.endswith("a.param"):
-        per *= 4 if op in ("g1mul", "hashg1", "g1pp") else 1
+        per *= 4 if op in ("g1mul", "hashg1", "g1pp", "decompress") else 1
+    per *= int(os.environ.get("PBC_CPU_SAMPLE_SCALE", "1"))
 
     def run(n, workers):
         out = subprocess.run([tool, "benchg", param_path, op, str(n), str(workers)], capture_output=True, text=True, timeout=300)
@@ -411,8 +413,9 @@ def main(args, load_vec, ensure_built, MAC_PEAK):
                 "hbm": {"achieved": round(n * unit_bytes / sec / 1e9, 3), "peak": 8000.0, "unit": "GB/s", "algorithmic_bytes_per_unit": unit_bytes},
             },
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(param_path, op)
+        if world == 1:
+            cb = None if args.no_cpu_baseline else cpu_baseline(param_path, op)
+            out["cpu_baseline"] = cb if cb is not None else bench.container_cpu_baseline(args.workload)
         if bench.evidence_commit():
             out["commit"] = bench.evidence_commit()
         print(json.dumps(out), flush=True)

@@ -110,7 +110,7 @@ int pbc_hip_element_pairing_batch(pbc_hip_pairing_t *p, uint8_t *gt, const uint8
                                   const uint8_t *g2, size_t n);
 /* Same with device-resident buffers, enqueued on `stream` (a hipStream_t; NULL = default
  * stream).  Asynchronous: returns after the launch.
- * Batch sizes (MI355X, a.param; profiles/r04_sweep_*.json, tools/r04_wave.py).  The throughput kernels give every LANE a
+ * Batch sizes (MI355X, a.param; profiles/r04_sweep_*.json, tools/wave_latency.py).  The throughput kernels give every LANE a
  * whole pairing: a launch costs one lane's 2.1 M dependent multiply-adds however small it is -- 6.4 ms for any
  * n <= 32768 (one wave per SIMD), 10.3 ms up to 131072 (two waves per SIMD: one chip residency of 1024 workgroups x 128
  * lanes), and from there the resident workgroups walk the batch in strides of the residency, so the time grows in
@@ -254,6 +254,45 @@ int pbc_hip_element_pp_pow_zn_batch_dev(pbc_hip_element_pp_t *pp, void *d_out, c
  * are gt_random / gt_from_hash, ecc/pairing.c:121,127): out[i] = in[i]^((q^k - 1)/r), the final exponentiation alone,
  * for n records of GT's underlying field in GT's wire format.  in[i] = 0 is outside the reference's contract too. */
 int pbc_hip_finalpow_batch(pbc_hip_pairing_t *p, uint8_t *out, const uint8_t *in, size_t n);   /* (_dev form: above) */
+
+/* The group law, Z_r arithmetic and multi-exponentiations the reference's examples use around the pairing (round 5;
+ * csrc/group_more.cuh, csrc/pbc_hip_group2.hip).  Host-buffer and _dev + stream forms as above; out may be exactly one of
+ * the inputs.
+ *   element_add / element_sub / element_neg (= element_invert) / element_double on G1, G2 (group 1, 2; include/pbc_field.h:
+ *     element_add :261, element_sub :267, element_neg :287, element_double :293 -> curve_mul ecc/curve.c:153-207,
+ *     curve_invert :79-100, curve_double :102-151; callers example/zss.c:49, example/hess.c:65,72): the affine law with
+ *     the reference's case analysis (O neutral, equal points -> tangent, opposite points or a 2-torsion tangent -> O),
+ *     one inversion per unit, any point of the curve.  O is read and written as zero bytes (off-curve records are O);
+ *     the reference's curve_to_bytes ignores inf_flag and writes the element's stale coordinates for O (ecc/curve.c:603-609).
+ *   pbc_hip_zr_op_batch: Z_r arithmetic on element_to_bytes records of Zr (big-endian, length_in_bytes_Zr, values < r;
+ *     the reference runs its F_p back end on r: example/zss.c:40-41 adds and inverts, example/hess.c:63 multiplies).
+ *     op 0 a*b, 1 a+b, 2 a-b, 3 1/a, 4 -a, 5 a/2, 6 2a, 7 a/b (b may be NULL for the unary ops).  1/0 is outside the
+ *     reference's contract (mpz_invert fails); it gives 0 here.  pbc_hip_zr_from_hash_batch: element_from_hash on Zr
+ *     (fp_from_hash, arith/montfp.c:440-448 over pbc_mpz_from_hash arith/field.c:643-668) for n digests of hlen bytes.
+ *   element_pow2_zn / element_pow3_zn (include/pbc_field.h:496-531 -> arith/field.c:153-241) on G1, G2 (group 1, 2:
+ *     [n1] a1 + [n2] a2 (+ [n3] a3)) and GT (group 3: a1^n1 a2^n2 (a3^n3)): Shamir's trick -- a per-lane table of the
+ *     subset sums, ONE doubling (squaring) per scalar bit for all bases instead of one ladder per base; complete (any
+ *     point of the curve, any scalar of length_in_bytes_Zr bytes). */
+int pbc_hip_element_add_batch(pbc_hip_pairing_t *p, int group, uint8_t *out, const uint8_t *a, const uint8_t *b, size_t n);
+int pbc_hip_element_sub_batch(pbc_hip_pairing_t *p, int group, uint8_t *out, const uint8_t *a, const uint8_t *b, size_t n);
+int pbc_hip_element_neg_batch(pbc_hip_pairing_t *p, int group, uint8_t *out, const uint8_t *a, size_t n);
+int pbc_hip_element_double_batch(pbc_hip_pairing_t *p, int group, uint8_t *out, const uint8_t *a, size_t n);
+int pbc_hip_element_add_batch_dev(pbc_hip_pairing_t *p, int group, void *d_out, const void *d_a, const void *d_b, size_t n, void *stream);
+int pbc_hip_element_sub_batch_dev(pbc_hip_pairing_t *p, int group, void *d_out, const void *d_a, const void *d_b, size_t n, void *stream);
+int pbc_hip_element_neg_batch_dev(pbc_hip_pairing_t *p, int group, void *d_out, const void *d_a, size_t n, void *stream);
+int pbc_hip_element_double_batch_dev(pbc_hip_pairing_t *p, int group, void *d_out, const void *d_a, size_t n, void *stream);
+int pbc_hip_zr_op_batch(pbc_hip_pairing_t *p, int op, uint8_t *out, const uint8_t *a, const uint8_t *b, size_t n);
+int pbc_hip_zr_op_batch_dev(pbc_hip_pairing_t *p, int op, void *d_out, const void *d_a, const void *d_b, size_t n, void *stream);
+int pbc_hip_zr_from_hash_batch(pbc_hip_pairing_t *p, uint8_t *out, const uint8_t *data, int hlen, size_t n);
+int pbc_hip_zr_from_hash_batch_dev(pbc_hip_pairing_t *p, void *d_out, const void *d_data, int hlen, size_t n, void *stream);
+int pbc_hip_element_pow2_zn_batch(pbc_hip_pairing_t *p, int group, uint8_t *out, const uint8_t *a1, const uint8_t *n1,
+                                  const uint8_t *a2, const uint8_t *n2, size_t n);
+int pbc_hip_element_pow3_zn_batch(pbc_hip_pairing_t *p, int group, uint8_t *out, const uint8_t *a1, const uint8_t *n1,
+                                  const uint8_t *a2, const uint8_t *n2, const uint8_t *a3, const uint8_t *n3, size_t n);
+int pbc_hip_element_pow2_zn_batch_dev(pbc_hip_pairing_t *p, int group, void *d_out, const void *d_a1, const void *d_n1,
+                                      const void *d_a2, const void *d_n2, size_t n, void *stream);
+int pbc_hip_element_pow3_zn_batch_dev(pbc_hip_pairing_t *p, int group, void *d_out, const void *d_a1, const void *d_n1,
+                                      const void *d_a2, const void *d_n2, const void *d_a3, const void *d_n3, size_t n, void *stream);
 
 /* Text formats on element_to_bytes records -- host-side string handling, no device involved, usable
  * without libpbc.  group: 0 = Zr, 1 = G1, 2 = G2, 3 = GT.

@@ -58,6 +58,9 @@ def lib():
         L.oracle_from_hash_g2.argtypes = [vp, vp, ci, vp, sz]
         L.oracle_point_format_g2.argtypes = [vp, ci, vp, vp, sz]
         L.oracle_finalpow.argtypes = [vp, vp, vp, sz]
+        L.oracle_g1_op.argtypes = [vp, ci, vp, vp, vp, sz]
+        L.oracle_zr_op.argtypes = [vp, ci, vp, vp, ci, vp, sz]
+        L.oracle_pow_multi.argtypes = [vp, ci, ci, vp, vp, sz, vp, sz]
         L.oracle_counters.argtypes = [ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64), ci]
         _lib = L
     return _lib
@@ -196,6 +199,50 @@ class OraclePairing:
         return out
 
 
+    # ---- round 5: group law on G1, Z_r, multi-exponentiations ----
+    def g1_op(self, op, a, b=None):
+        """op 0 a+b, 1 a-b, 2 -a, 3 2a on G1 records (O = zeros)"""
+        a = _u8(a)
+        b = None if b is None else _u8(b)
+        n = a.size // self.len_G1
+        out = np.empty((n, self.len_G1), np.uint8)
+        if lib().oracle_g1_op(self._h, op, _ptr(a), None if b is None else _ptr(b), _ptr(out), n):
+            raise RuntimeError("oracle_g1_op failed")
+        return out
+
+    def zr_op(self, op, a, b=None, hlen=0):
+        """op 0 mul, 1 add, 2 sub, 3 invert, 4 neg, 5 halve, 6 double, 7 div, 8 from_hash (a: n x hlen digests)"""
+        a = _u8(a)
+        b = None if b is None else _u8(b)
+        n = a.shape[0]
+        lz = a.shape[1] if op != 8 else (b.shape[1] if b is not None else None)
+        if op == 8:
+            raise ValueError("use zr_from_hash")
+        out = np.empty((n, lz), np.uint8)
+        if lib().oracle_zr_op(self._h, op, _ptr(a), None if b is None else _ptr(b), 0, _ptr(out), n):
+            raise RuntimeError("oracle_zr_op failed")
+        return out
+
+    def zr_from_hash(self, digests, len_zr):
+        d = _u8(digests)
+        n, hlen = d.shape
+        out = np.empty((n, len_zr), np.uint8)
+        if lib().oracle_zr_op(self._h, 8, _ptr(d), None, hlen, _ptr(out), n):
+            raise RuntimeError("oracle_zr_op failed")
+        return out
+
+    def pow_multi(self, group, bases, scalars):
+        """a1^n1 a2^n2 (a3^n3) on G1 (group 1, additive) or GT (group 3)"""
+        k = len(bases)
+        A = np.ascontiguousarray(np.stack([_u8(x) for x in bases], axis=1))
+        E = np.ascontiguousarray(np.stack([_u8(x) for x in scalars], axis=1))
+        n, elen = A.shape[0], E.shape[2]
+        out = np.empty((n, A.shape[2]), np.uint8)
+        if lib().oracle_pow_multi(self._h, group, k, _ptr(A), _ptr(E), elen, _ptr(out), n):
+            raise RuntimeError("oracle_pow_multi failed")
+        return out
+
+
 def counters(reset=False):
     m, i = ctypes.c_uint64(), ctypes.c_uint64()
     lib().oracle_counters(ctypes.byref(m), ctypes.byref(i), int(reset))
@@ -215,6 +262,26 @@ class Vec:
         self.g1 = a[off:off + n * k * l1].reshape(n * k, l1).copy(); off += n * k * l1
         self.g2 = a[off:off + n * k * l2].reshape(n * k, l2).copy(); off += n * k * l2
         self.gt = a[off:off + n * lt].reshape(n, lt).copy(); off += n * lt
+        assert off == len(raw), path
+
+
+class Rec:
+    """Record container of the reference harness's round-5 modes (ref_harness.c rec_write: gops, zrops, pow23):
+    .arrays = list of uint8 matrices in file order, .type = the parameter type letter."""
+
+    def __init__(self, path):
+        raw = open(path, "rb").read()
+        assert raw[:8] == b"PBCREC01", path
+        t, count = struct.unpack("<2I", raw[8:16])
+        self.type = chr(t)
+        dims = struct.unpack("<%dI" % (2 * count), raw[16:16 + 8 * count])
+        off = 16 + 8 * count
+        a = np.frombuffer(raw, np.uint8)
+        self.arrays = []
+        for i in range(count):
+            rows, width = dims[2 * i], dims[2 * i + 1]
+            self.arrays.append(a[off:off + rows * width].reshape(rows, width).copy())
+            off += rows * width
         assert off == len(raw), path
 
 

@@ -1971,3 +1971,156 @@ int oracle_finalpow(const oracle_pairing *P, const uint8_t *in, uint8_t *out, si
   }
   return 0;
 }
+
+/* ---- round 5: group law on G1, Z_r arithmetic, multi-exponentiations --------------------------------------------------- */
+/* element_add / element_sub / element_neg / element_double on G1 = E(F_q) (curve_mul ecc/curve.c:153-207, curve_invert
+ * :79-100, curve_double :102-151) -- op 0 a+b, 1 a-b, 2 -a, 3 2a; O is the all-zero record (and off-curve records). */
+int oracle_g1_op(const oracle_pairing *P, int op, const uint8_t *a, const uint8_t *b, uint8_t *out, size_t n) {
+  const fpctx *F = &P->Fq;
+  for (size_t i = 0; i < n; i++) {
+    pt A, B, R;
+    pt_from_bytes(F, &P->ca, &P->cb, &A, a + i * P->len1);
+    if (!A.inf && fp_is0(F, &A.x) && fp_is0(F, &A.y)) A.inf = 1;
+    B = A;
+    if (op < 2) {
+      pt_from_bytes(F, &P->ca, &P->cb, &B, b + i * P->len1);
+      if (!B.inf && fp_is0(F, &B.x) && fp_is0(F, &B.y)) B.inf = 1;
+    }
+    if ((op == 1 || op == 2) && !B.inf) fp_neg(F, &B.y, &B.y);
+    if (op == 2) R = B; else if (op == 3) pt_dbl(F, &P->ca, &R, &A); else pt_add(F, &P->ca, &R, &A, &B);
+    pt_to_bytes(F, out + i * P->len1, &R);
+  }
+  return 0;
+}
+/* Z_r (the reference's F_p back end on the modulus r; pairing->Zr): op 0 a*b, 1 a+b, 2 a-b, 3 1/a, 4 -a, 5 a/2, 6 2a,
+ * 7 a/b, 8 element_from_hash (a: digests of hlen bytes -- fp_from_hash arith/montfp.c:440-448: H || 0 || H || 1 ...
+ * up to the byte length of r, halved while above r) on big-endian records of ceil(bits(r)/8) bytes */
+/* 1/x mod m for an odd modulus m that need not be prime (type a1: r = n is composite, so Fermat's power is not the
+ * inverse): binary extended Euclid, as mpz_invert would return it -- x, result in Montgomery form of Z; 0 when
+ * gcd(x, m) != 1 */
+static void zr_inv(const fpctx *Z, fe *c, const fe *x) {
+  const int n = Z->n;
+  fe one, t;
+  memset(&one, 0, sizeof one); one.v[0] = 1;
+  fp_mul(Z, &t, x, &one);                                  /* canonical integer */
+  uint64_t u[MAXL + 1], v[MAXL + 1], x1[MAXL + 1], x2[MAXL + 1], m[MAXL + 1];
+  memset(u, 0, sizeof u); memset(v, 0, sizeof v); memset(x1, 0, sizeof x1); memset(x2, 0, sizeof x2); memset(m, 0, sizeof m);
+  memcpy(u, t.v, 8 * (size_t) n); memcpy(v, Z->p, 8 * (size_t) n); memcpy(m, Z->p, 8 * (size_t) n);
+  x1[0] = 1;
+  const int L = n + 1;
+  if (bn_is0(u, L)) { memset(c, 0, sizeof *c); return; }
+  for (int guard = 0; guard < 4 * 64 * L; guard++) {
+    uint64_t oneL[MAXL + 1]; memset(oneL, 0, sizeof oneL); oneL[0] = 1;
+    if (!bn_cmp(u, oneL, L) || !bn_cmp(v, oneL, L)) break;
+    while (!(u[0] & 1)) {
+      for (int i = 0; i < L - 1; i++) u[i] = (u[i] >> 1) | (u[i + 1] << 63);
+      u[L - 1] >>= 1;
+      if (x1[0] & 1) bn_add(x1, x1, m, L);
+      for (int i = 0; i < L - 1; i++) x1[i] = (x1[i] >> 1) | (x1[i + 1] << 63);
+      x1[L - 1] >>= 1;
+    }
+    while (!(v[0] & 1)) {
+      for (int i = 0; i < L - 1; i++) v[i] = (v[i] >> 1) | (v[i + 1] << 63);
+      v[L - 1] >>= 1;
+      if (x2[0] & 1) bn_add(x2, x2, m, L);
+      for (int i = 0; i < L - 1; i++) x2[i] = (x2[i] >> 1) | (x2[i + 1] << 63);
+      x2[L - 1] >>= 1;
+    }
+    if (bn_cmp(u, v, L) >= 0) {
+      bn_sub(u, u, v, L);
+      if (bn_sub(x1, x1, x2, L)) bn_add(x1, x1, m, L);
+      if (bn_is0(u, L)) break;                             /* gcd = v != 1 */
+    } else {
+      bn_sub(v, v, u, L);
+      if (bn_sub(x2, x2, x1, L)) bn_add(x2, x2, m, L);
+    }
+  }
+  uint64_t oneL[MAXL + 1]; memset(oneL, 0, sizeof oneL); oneL[0] = 1;
+  fe r; memset(&r, 0, sizeof r);
+  if (!bn_cmp(u, oneL, L)) memcpy(r.v, x1, 8 * (size_t) n);
+  else if (!bn_cmp(v, oneL, L)) memcpy(r.v, x2, 8 * (size_t) n);
+  fp_mul(Z, c, &r, &Z->R2);
+}
+int oracle_zr_op(const oracle_pairing *P, int op, const uint8_t *a, const uint8_t *b, int hlen, uint8_t *out, size_t n) {
+  fpctx Z;
+  if (fp_init(&Z, &P->r)) return 1;
+  const int L = Z.nbytes;
+  for (size_t i = 0; i < n; i++) {
+    fe x, y, z;
+    if (op == 8) {
+      uint8_t buf[8 * MAXL];
+      const uint8_t *data = a + i * (size_t) hlen;
+      int count = L, k = 0, done = 0;
+      uint8_t counter = 0;
+      for (;;) {
+        int m;
+        if (hlen >= count - k) { m = count - k; done = 1; } else m = hlen;
+        memcpy(buf + k, data, (size_t) m);
+        k += m;
+        if (done) break;
+        buf[k++] = counter++;
+        if (k == count) break;
+      }
+      big v;
+      big_from_be(&v, buf, (size_t) count);
+      while (bn_cmp(v.v, P->r.v, BIGL) > 0) {
+        for (int w = 0; w < BIGL - 1; w++) v.v[w] = (v.v[w] >> 1) | (v.v[w + 1] << 63);
+        v.v[BIGL - 1] >>= 1;
+      }
+      fe t; memset(&t, 0, sizeof t);
+      memcpy(t.v, v.v, 8 * (size_t) Z.n);
+      fp_mul(&Z, &z, &t, &Z.R2);
+      fp_to_bytes(&Z, out + i * L, &z);
+      continue;
+    }
+    fp_from_bytes(&Z, &x, a + i * L);
+    if (b) fp_from_bytes(&Z, &y, b + i * L); else y = x;
+    switch (op) {
+      case 0: fp_mul(&Z, &z, &x, &y); break;
+      case 1: fp_add(&Z, &z, &x, &y); break;
+      case 2: fp_sub(&Z, &z, &x, &y); break;
+      case 3: zr_inv(&Z, &z, &x); break;
+      case 4: fp_neg(&Z, &z, &x); break;
+      case 5: fp_halve(&Z, &z, &x); break;
+      case 6: fp_dbl(&Z, &z, &x); break;
+      default: zr_inv(&Z, &z, &y); fp_mul(&Z, &z, &z, &x); break;
+    }
+    fp_to_bytes(&Z, out + i * L, &z);
+  }
+  return 0;
+}
+/* element_pow2_zn / element_pow3_zn (include/pbc_field.h:496-531; arith/field.c:153-241) as the plain composition
+ * a1^n1 a2^n2 (a3^n3) -- group 1: G1 (additive), group 3: GT; k = 2 or 3 bases, records and scalars side by side in
+ * `a` (k records per unit) and `e` (k scalars of elen bytes per unit) */
+int oracle_pow_multi(const oracle_pairing *P, int group, int k, const uint8_t *a, const uint8_t *e, size_t elen, uint8_t *out, size_t n) {
+  const fpctx *F = &P->Fq;
+  if (group == 1) {
+    for (size_t i = 0; i < n; i++) {
+      pt acc; acc.inf = 1; memset(&acc.x, 0, sizeof acc.x); memset(&acc.y, 0, sizeof acc.y);
+      for (int j = 0; j < k; j++) {
+        pt A, R; big ex;
+        big_from_be(&ex, e + (i * k + j) * elen, elen);
+        pt_from_bytes(F, &P->ca, &P->cb, &A, a + (i * k + j) * P->len1);
+        if (!A.inf && fp_is0(F, &A.x) && fp_is0(F, &A.y)) A.inf = 1;
+        pt_mul(F, &P->ca, &R, &A, &ex);
+        pt_add(F, &P->ca, &acc, &acc, &R);
+      }
+      pt_to_bytes(F, out + i * P->len1, &acc);
+    }
+    return 0;
+  }
+  if (group != 3) return 1;
+  uint8_t t0[16 * 8 * MAXL], t1[16 * 8 * MAXL], t2[16 * 8 * MAXL];
+  if ((size_t) P->lenT > sizeof t0) return 1;
+  for (size_t i = 0; i < n; i++) {
+    for (int j = 0; j < k; j++) {
+      if (oracle_gt_pow(P, a + (i * k + j) * P->lenT, e + (i * k + j) * elen, elen, j ? t1 : t0, 1)) return 1;
+      if (j) {
+        if (oracle_gt_mul(P, t0, t1, t2, 1)) return 1;
+        memcpy(t0, t2, (size_t) P->lenT);
+      }
+    }
+    memcpy(out + i * P->lenT, t0, (size_t) P->lenT);
+  }
+  return 0;
+}

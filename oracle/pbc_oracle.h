@@ -62,6 +62,13 @@ int oracle_g_mul(const oracle_pairing *p, int group, const uint8_t *pt, const ui
 /* pairing->finalpow on GT-format records (the final exponentiation alone) */
 int oracle_finalpow(const oracle_pairing *p, const uint8_t *in, uint8_t *out, size_t n);
 
+/* round 5: the group law on G1 (op 0 a+b, 1 a-b, 2 -a, 3 2a; O = zero record), Z_r arithmetic (op 0 mul, 1 add, 2 sub,
+ * 3 invert, 4 neg, 5 halve, 6 double, 7 div, 8 from_hash of hlen-byte digests), element_pow2_zn / element_pow3_zn on G1
+ * (group 1) and GT (group 3) with the k records / scalars of a unit side by side */
+int oracle_g1_op(const oracle_pairing *p, int op, const uint8_t *a, const uint8_t *b, uint8_t *out, size_t n);
+int oracle_zr_op(const oracle_pairing *p, int op, const uint8_t *a, const uint8_t *b, int hlen, uint8_t *out, size_t n);
+int oracle_pow_multi(const oracle_pairing *p, int group, int k, const uint8_t *a, const uint8_t *e, size_t elen, uint8_t *out, size_t n);
+
 /* counts of Fq multiplications / inversions since last reset (for the work model) */
 void oracle_counters(uint64_t *mul, uint64_t *inv, int reset);
 

@@ -179,6 +179,8 @@ static int cmd_kat(int argc, char **argv) {
 static int cmd_bench(int argc, char **argv) {
   if (argc < 5) { fprintf(stderr, "bench <param> <n> <k> <workers>\n"); return 2; }
   int n = atoi(argv[2]), k = atoi(argv[3]), workers = atoi(argv[4]);
+  const int pp_mode = k == -1;
+  if (pp_mode) k = 1;
   int fds[256][2];
   if (workers > 256) workers = 256;
   double t_all0 = now();
@@ -199,6 +201,16 @@ static int cmd_bench(int argc, char **argv) {
         element_mul_si(P[j], P0, j + 1 + w); element_mul_si(Q[j], Q0, j + 1 + w);
       }
       double t0 = now();
+      if (pp_mode) {
+        /* k = -1: pairing_pp_apply with a fixed first argument, as benchmark/benchmark.c:75-81 times it */
+        pairing_pp_t pp;
+        pairing_pp_init(pp, P[0], pairing);
+        t0 = now();
+        for (int i = 0; i < n; i++) {
+          pairing_pp_apply(out, Q[0], pp);
+          element_add(Q[0], Q[0], Q0);
+        }
+      } else
       for (int i = 0; i < n; i++) {
         if (k == 1) element_pairing(out, P[0], Q[0]);
         else element_prod_pairing(out, P, Q, k);
@@ -222,7 +234,7 @@ static int cmd_bench(int argc, char **argv) {
   while (wait(NULL) > 0) {}
   double wall = now() - t_all0;
   printf("{\"units_per_s\": %.3f, \"per_core\": %.3f, \"workers\": %d, \"n_per_worker\": %d, \"k\": %d, \"max_worker_s\": %.4f, \"wall_s\": %.4f}\n",
-         sum_rate, sum_rate / workers, workers, n, k, max_dt, wall);
+         sum_rate, sum_rate / workers, workers, n, pp_mode ? -1 : k, max_dt, wall);
   return 0;
 }
 
@@ -253,6 +265,7 @@ static int cmd_benchg(int argc, char **argv) {
       element_init_Zr(k, pairing); element_init_Zr(sk, pairing);
       element_init_GT(gt, pairing); element_init_GT(gto, pairing); element_init_GT(t1, pairing); element_init_GT(t2, pairing);
       element_random(P); element_random(Q); element_random(sk);
+      element_random(R1);
       element_pairing(gt, P, Q);
       element_pow_zn(pk, Q, sk);
       unsigned char digest[32];
@@ -261,9 +274,17 @@ static int cmd_benchg(int argc, char **argv) {
       if (is_g1pp) element_pp_init(pp, P);
       if (is_gtpp) element_pp_init(pp, gt);
       unsigned bad = 0;
+      unsigned char cbuf[2][1024];
+      const int is_comp = !strcmp(op, "compress"), is_decomp = !strcmp(op, "decompress");
+      element_to_bytes_compressed(cbuf[0], P);
+      element_to_bytes_compressed(cbuf[1], R1);
       double t0 = now();
       for (int i = 0; i < n; i++) {
         digest[i & 31] = (unsigned char) (digest[i & 31] * 5 + i + w);
+        /* point formats (ecc/curve.c:762-815) alone, alternating between two points / records:
+         * compress = element_to_bytes_compressed, decompress = element_from_bytes_compressed (a square root in F_q) */
+        if (is_comp) { element_to_bytes_compressed(cbuf[i & 1], (i & 1) ? R1 : P); continue; }
+        if (is_decomp) { element_from_bytes_compressed((i & 1) ? R1 : P, cbuf[i & 1]); continue; }
         if (!strcmp(op, "g1mul")) { element_random(k); element_mul_zn(R1, P, k); element_add(P, P, R1); }
         else if (!strcmp(op, "g2mul")) { element_random(k); element_mul_zn(R2, Q, k); element_add(Q, Q, R2); }
         else if (!strcmp(op, "gtpow")) { element_random(k); element_pow_zn(gto, gt, k); element_mul(gt, gt, gto); }
@@ -689,6 +710,139 @@ static int cmd_text(int argc, char **argv) {
   return 0;
 }
 
+
+/* ---- round 5: the group law, Z_r arithmetic and multi-exponentiations as fixtures ----------------------------------
+ * Record container "PBCREC01": u32 type, u32 count, then per array u32 rows, u32 width, then the arrays' bytes in order
+ * (oracle/__init__.py Rec). */
+typedef struct { unsigned char *p; uint32_t rows, width; } recarr;
+static recarr rec_new(uint32_t rows, uint32_t width) { recarr a = {calloc((size_t) rows * width + 1, 1), rows, width}; return a; }
+static int rec_write(const char *path, char type, recarr *arr, int count) {
+  FILE *fp = fopen(path, "wb");
+  if (!fp) { perror(path); return 1; }
+  fwrite("PBCREC01", 1, 8, fp);
+  w32(fp, (uint32_t) type); w32(fp, (uint32_t) count);
+  for (int i = 0; i < count; i++) { w32(fp, arr[i].rows); w32(fp, arr[i].width); }
+  for (int i = 0; i < count; i++) fwrite(arr[i].p, arr[i].width, arr[i].rows, fp);
+  fclose(fp);
+  return 0;
+}
+/* a record of G1 / G2 / GT.  O of a curve group is written as zero bytes -- the convention of include/pbc_hip.h; the
+ * reference's curve_to_bytes (ecc/curve.c:603-609) ignores inf_flag and writes whatever coordinates the element last held */
+static void put_rec(unsigned char *dst, element_t e, int group, int len) {
+  if (group != 3 && element_is0(e)) memset(dst, 0, (size_t) len); else element_to_bytes(dst, e);
+}
+static void init_group(element_t e, pairing_t pairing, int group) {
+  if (group == 1) element_init_G1(e, pairing); else if (group == 2) element_init_G2(e, pairing); else element_init_GT(e, pairing);
+}
+/* gops <param> <group 1|2> <n> <seed> <out>: element_add / element_sub / element_neg / element_double on G1 / G2
+ * (curve_mul ecc/curve.c:153-207, curve_invert :79-100, curve_double :102-151).  Arrays: A, B, A+B, A-B, -A, 2A.
+ * The last rows are the special cases of the group law: B = A, B = -A, A = O, B = O, A = B = O; the row before them
+ * takes points of the whole curve (no cofactor multiplication). */
+static int cmd_gops(int argc, char **argv) {
+  if (argc < 6) { fprintf(stderr, "gops <param> <group> <n> <seed> <out>\n"); return 2; }
+  int group = atoi(argv[2]), n = atoi(argv[3]);
+  pairing_t pairing; char type;
+  pbc_random_set_deterministic((unsigned) atoi(argv[4]));
+  init_pairing(pairing, argv[1], &type);
+  int lp = group == 1 ? pairing_length_in_bytes_G1(pairing) : pairing_length_in_bytes_G2(pairing);
+  recarr arr[6];
+  for (int i = 0; i < 6; i++) arr[i] = rec_new(n, lp);
+  element_t A, B, R;
+  init_group(A, pairing, group); init_group(B, pairing, group); init_group(R, pairing, group);
+  for (int i = 0; i < n; i++) {
+    element_random(A); element_random(B);
+    if (i == n - 6) { full_order_point(A); full_order_point(B); }
+    if (i == n - 5) element_set(B, A);
+    if (i == n - 4) element_neg(B, A);
+    if (i == n - 3 || i == n - 1) element_set0(A);
+    if (i == n - 2 || i == n - 1) element_set0(B);
+    put_rec(arr[0].p + (size_t) i * lp, A, group, lp);
+    put_rec(arr[1].p + (size_t) i * lp, B, group, lp);
+    element_add(R, A, B); put_rec(arr[2].p + (size_t) i * lp, R, group, lp);
+    element_sub(R, A, B); put_rec(arr[3].p + (size_t) i * lp, R, group, lp);
+    element_neg(R, A); put_rec(arr[4].p + (size_t) i * lp, R, group, lp);
+    element_double(R, A); put_rec(arr[5].p + (size_t) i * lp, R, group, lp);
+  }
+  if (rec_write(argv[5], type, arr, 6)) return 1;
+  fprintf(stderr, "wrote %s: type %c group %d n=%d gops\n", argv[5], type, group, n);
+  return 0;
+}
+/* zrops <param> <n> <hlen> <seed> <out>: Z_r arithmetic (the F_p back end on the modulus r; example/zss.c:40-41 adds and
+ * inverts there, example/hess.c:63 multiplies) -- arrays: A, B, A+B, A-B, A*B, 1/A, -A, 2A, A/2, A/B, digests,
+ * element_from_hash(digest).  Rows n-3 .. n-1: A = 1, A = r - 1, B = A.  A, B are never 0 (1/0 is outside the contract). */
+static int cmd_zrops(int argc, char **argv) {
+  if (argc < 6) { fprintf(stderr, "zrops <param> <n> <hlen> <seed> <out>\n"); return 2; }
+  int n = atoi(argv[2]), hlen = atoi(argv[3]);
+  pairing_t pairing; char type;
+  pbc_random_set_deterministic((unsigned) atoi(argv[4]));
+  init_pairing(pairing, argv[1], &type);
+  int lz = pairing_length_in_bytes_Zr(pairing);
+  recarr arr[12];
+  for (int i = 0; i < 12; i++) arr[i] = rec_new(n, i == 10 ? hlen : lz);
+  element_t a, b, r;
+  element_init_Zr(a, pairing); element_init_Zr(b, pairing); element_init_Zr(r, pairing);
+  mpz_t bytes;
+  mpz_init(bytes);
+  for (int i = 0; i < n; i++) {
+    do element_random(a); while (element_is0(a));
+    do element_random(b); while (element_is0(b));
+    if (i == n - 3) element_set1(a);
+    if (i == n - 2) { element_set1(a); element_neg(a, a); }
+    if (i == n - 1) element_set(b, a);
+    size_t o = (size_t) i * lz;
+    element_to_bytes(arr[0].p + o, a);
+    element_to_bytes(arr[1].p + o, b);
+    element_add(r, a, b); element_to_bytes(arr[2].p + o, r);
+    element_sub(r, a, b); element_to_bytes(arr[3].p + o, r);
+    element_mul(r, a, b); element_to_bytes(arr[4].p + o, r);
+    element_invert(r, a); element_to_bytes(arr[5].p + o, r);
+    element_neg(r, a); element_to_bytes(arr[6].p + o, r);
+    element_double(r, a); element_to_bytes(arr[7].p + o, r);
+    element_halve(r, a); element_to_bytes(arr[8].p + o, r);
+    element_div(r, a, b); element_to_bytes(arr[9].p + o, r);
+    pbc_mpz_randomb(bytes, 8 * hlen);
+    unsigned char *d = arr[10].p + (size_t) i * hlen;
+    for (int j = 0; j < hlen; j++) { d[j] = (unsigned char) mpz_fdiv_ui(bytes, 256); mpz_fdiv_q_2exp(bytes, bytes, 8); }
+    element_from_hash(r, d, hlen); element_to_bytes(arr[11].p + o, r);
+  }
+  if (rec_write(argv[5], type, arr, 12)) return 1;
+  fprintf(stderr, "wrote %s: type %c n=%d zrops\n", argv[5], type, n);
+  return 0;
+}
+/* pow23 <param> <group 1|2|3> <n> <seed> <out>: element_pow2_zn / element_pow3_zn (include/pbc_field.h:496-531,
+ * arith/field.c:153-241) -- arrays: A1, A2, A3, N1, N2, N3, A1^N1 A2^N2, A1^N1 A2^N2 A3^N3 (additive notation on the
+ * curves).  Rows n-4 .. n-1: N2 = 0; A2 = A1; A2 = 1 / A1 with N2 = N1 (the pow2 value is the identity); N1 = N2 = N3 = r - 1. */
+static int cmd_pow23(int argc, char **argv) {
+  if (argc < 6) { fprintf(stderr, "pow23 <param> <group> <n> <seed> <out>\n"); return 2; }
+  int group = atoi(argv[2]), n = atoi(argv[3]);
+  pairing_t pairing; char type;
+  pbc_random_set_deterministic((unsigned) atoi(argv[4]));
+  init_pairing(pairing, argv[1], &type);
+  int lp = group == 1 ? pairing_length_in_bytes_G1(pairing) : group == 2 ? pairing_length_in_bytes_G2(pairing) : pairing_length_in_bytes_GT(pairing);
+  int lz = pairing_length_in_bytes_Zr(pairing);
+  recarr arr[8];
+  for (int i = 0; i < 8; i++) arr[i] = rec_new(n, (i >= 3 && i < 6) ? lz : lp);
+  element_t A[3], N[3], R;
+  for (int j = 0; j < 3; j++) { init_group(A[j], pairing, group); element_init_Zr(N[j], pairing); }
+  init_group(R, pairing, group);
+  for (int i = 0; i < n; i++) {
+    for (int j = 0; j < 3; j++) { element_random(A[j]); element_random(N[j]); }
+    if (i == n - 4) element_set0(N[1]);
+    if (i == n - 3) element_set(A[1], A[0]);
+    if (i == n - 2) { element_invert(A[1], A[0]); element_set(N[1], N[0]); }
+    if (i == n - 1) for (int j = 0; j < 3; j++) { element_set1(N[j]); element_neg(N[j], N[j]); }
+    for (int j = 0; j < 3; j++) {
+      put_rec(arr[j].p + (size_t) i * lp, A[j], group, lp);
+      element_to_bytes(arr[3 + j].p + (size_t) i * lz, N[j]);
+    }
+    element_pow2_zn(R, A[0], N[0], A[1], N[1]); put_rec(arr[6].p + (size_t) i * lp, R, group, lp);
+    element_pow3_zn(R, A[0], N[0], A[1], N[1], A[2], N[2]); put_rec(arr[7].p + (size_t) i * lp, R, group, lp);
+  }
+  if (rec_write(argv[5], type, arr, 8)) return 1;
+  fprintf(stderr, "wrote %s: type %c group %d n=%d pow23\n", argv[5], type, group, n);
+  return 0;
+}
+
 int main(int argc, char **argv) {
   if (argc < 2) { fprintf(stderr, "usage: ref_tool gen|kat|bench ...\n"); return 2; }
   if (!strcmp(argv[1], "gen")) return cmd_gen(argc - 1, argv + 1);
@@ -708,5 +862,8 @@ int main(int argc, char **argv) {
   if (!strcmp(argv[1], "rdep")) return cmd_rdep(argc - 1, argv + 1);
   if (!strcmp(argv[1], "finalpow")) return cmd_finalpow(argc - 1, argv + 1);
   if (!strcmp(argv[1], "text")) return cmd_text(argc - 1, argv + 1);
+  if (!strcmp(argv[1], "gops")) return cmd_gops(argc - 1, argv + 1);
+  if (!strcmp(argv[1], "zrops")) return cmd_zrops(argc - 1, argv + 1);
+  if (!strcmp(argv[1], "pow23")) return cmd_pow23(argc - 1, argv + 1);
   return 2;
 }

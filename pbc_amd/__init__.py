@@ -89,6 +89,20 @@ def lib():
         L.pbc_hip_host_free.argtypes = [vp]
         L.pbc_hip_host_free.restype = None
         L.pbc_hip_pairing_release_workspaces.argtypes = [vp]
+        for f in ("add", "sub"):
+            getattr(L, "pbc_hip_element_%s_batch" % f).argtypes = [vp, ci, vp, vp, vp, sz]
+            getattr(L, "pbc_hip_element_%s_batch_dev" % f).argtypes = [vp, ci, vp, vp, vp, sz, vp]
+        for f in ("neg", "double"):
+            getattr(L, "pbc_hip_element_%s_batch" % f).argtypes = [vp, ci, vp, vp, sz]
+            getattr(L, "pbc_hip_element_%s_batch_dev" % f).argtypes = [vp, ci, vp, vp, sz, vp]
+        L.pbc_hip_zr_op_batch.argtypes = [vp, ci, vp, vp, vp, sz]
+        L.pbc_hip_zr_op_batch_dev.argtypes = [vp, ci, vp, vp, vp, sz, vp]
+        L.pbc_hip_zr_from_hash_batch.argtypes = [vp, vp, vp, ci, sz]
+        L.pbc_hip_zr_from_hash_batch_dev.argtypes = [vp, vp, vp, ci, sz, vp]
+        L.pbc_hip_element_pow2_zn_batch.argtypes = [vp, ci, vp] + [vp] * 4 + [sz]
+        L.pbc_hip_element_pow3_zn_batch.argtypes = [vp, ci, vp] + [vp] * 6 + [sz]
+        L.pbc_hip_element_pow2_zn_batch_dev.argtypes = [vp, ci, vp] + [vp] * 4 + [sz, vp]
+        L.pbc_hip_element_pow3_zn_batch_dev.argtypes = [vp, ci, vp] + [vp] * 6 + [sz, vp]
         L.pbc_hip_element_snprint.argtypes = [vp, ci, ctypes.c_char_p, sz, vp]
         L.pbc_hip_element_mul_zn_batch_dev.argtypes = [vp, ci, vp, vp, vp, sz, vp]
         L.pbc_hip_element_mul_GT_batch_dev.argtypes = [vp, vp, vp, vp, sz, vp]
@@ -131,6 +145,10 @@ EXPORTS = (
     "pbc_hip_element_from_bytes_compressed_batch_dev", "pbc_hip_element_to_bytes_x_only_batch_dev",
     "pbc_hip_element_from_bytes_x_only_batch_dev", "pbc_hip_element_pp_init", "pbc_hip_element_pp_clear",
     "pbc_hip_element_pp_pow_zn_batch", "pbc_hip_element_pp_pow_zn_batch_dev",
+    "pbc_hip_element_add_batch", "pbc_hip_element_sub_batch", "pbc_hip_element_neg_batch", "pbc_hip_element_double_batch",
+    "pbc_hip_element_add_batch_dev", "pbc_hip_element_sub_batch_dev", "pbc_hip_element_neg_batch_dev", "pbc_hip_element_double_batch_dev",
+    "pbc_hip_zr_op_batch", "pbc_hip_zr_op_batch_dev", "pbc_hip_zr_from_hash_batch", "pbc_hip_zr_from_hash_batch_dev",
+    "pbc_hip_element_pow2_zn_batch", "pbc_hip_element_pow3_zn_batch", "pbc_hip_element_pow2_zn_batch_dev", "pbc_hip_element_pow3_zn_batch_dev",
 )
 
 
@@ -143,6 +161,9 @@ def param_text(name):
     """Stock parameter sets shipped with the reference (param/a.param, d159.param, f.param)."""
     with open(os.path.join(PARAM_DIR, name + ".param")) as fh:
         return fh.read()
+
+
+ZR_OPS = {"mul": 0, "add": 1, "sub": 2, "invert": 3, "neg": 4, "halve": 5, "double": 6, "div": 7}   # pbc_hip_zr_op_batch
 
 
 def _np_ptr(a):
@@ -282,6 +303,90 @@ class Pairing:
 
     def _point_len(self, group):
         return self.length_in_bytes_G2 if group == 2 else self.length_in_bytes_G1
+
+    # ---- the group law, Z_r, multi-exponentiations (round 5) -----------------------------------------
+    def _group_len(self, group):
+        return self.length_in_bytes_GT if group == 3 else self._point_len(group)
+
+    def element_group_op(self, what, group, a, b=None):
+        """what: "add", "sub" (two operands), "neg", "double" on records of G1 / G2 (element_add / element_sub /
+        element_neg / element_double; O is the all-zero record)."""
+        import numpy as np
+        a = np.ascontiguousarray(a, dtype=np.uint8)
+        lp = self._point_len(group)
+        n = a.size // lp
+        out = np.empty((n, lp), np.uint8)
+        f = getattr(lib(), "pbc_hip_element_%s_batch" % what)
+        if what in ("add", "sub"):
+            b = np.ascontiguousarray(b, dtype=np.uint8)
+            rc = f(self._h, group, _np_ptr(out), _np_ptr(a), _np_ptr(b), n)
+        else:
+            rc = f(self._h, group, _np_ptr(out), _np_ptr(a), n)
+        if rc:
+            raise PbcHipError("element_%s: " % what + _err())
+        return out
+
+
+    def zr_op(self, what, a, b=None):
+        """Z_r arithmetic on element_to_bytes records of Zr: what in pbc_amd.ZR_OPS."""
+        import numpy as np
+        lz = self.length_in_bytes_Zr
+        a = np.ascontiguousarray(a, dtype=np.uint8)
+        n = a.size // lz
+        out = np.empty((n, lz), np.uint8)
+        b = None if b is None else np.ascontiguousarray(b, dtype=np.uint8)
+        if lib().pbc_hip_zr_op_batch(self._h, ZR_OPS[what], _np_ptr(out), _np_ptr(a), _np_ptr(b), n):
+            raise PbcHipError("zr_%s: " % what + _err())
+        return out
+
+    def zr_from_hash(self, digests):
+        import numpy as np
+        d = np.ascontiguousarray(digests, dtype=np.uint8)
+        n, hlen = d.shape
+        out = np.empty((n, self.length_in_bytes_Zr), np.uint8)
+        if lib().pbc_hip_zr_from_hash_batch(self._h, _np_ptr(out), _np_ptr(d), hlen, n):
+            raise PbcHipError("zr_from_hash: " + _err())
+        return out
+
+    def element_pow_multi(self, group, bases, scalars):
+        """element_pow2_zn / element_pow3_zn: bases = [a1, a2(, a3)] records of group 1 / 2 / 3 (GT), scalars = [n1, n2(, n3)]."""
+        import numpy as np
+        k = len(bases)
+        lp = self._group_len(group)
+        bases = [np.ascontiguousarray(x, dtype=np.uint8) for x in bases]
+        n = bases[0].size // lp
+        scalars = [self._scalars(z, n) for z in scalars]
+        out = np.empty((n, lp), np.uint8)
+        args = []
+        for j in range(k):
+            args += [_np_ptr(bases[j]), _np_ptr(scalars[j])]
+        f = lib().pbc_hip_element_pow2_zn_batch if k == 2 else lib().pbc_hip_element_pow3_zn_batch
+        if f(self._h, group, _np_ptr(out), *args, n):
+            raise PbcHipError("element_pow%d_zn: " % k + _err())
+        return out
+
+    def element_group_op_dev(self, what, group, d_out, d_a, d_b, n, stream=0):
+        f = getattr(lib(), "pbc_hip_element_%s_batch_dev" % what)
+        rc = f(self._h, group, d_out, d_a, d_b, n, stream) if what in ("add", "sub") else f(self._h, group, d_out, d_a, n, stream)
+        if rc:
+            raise PbcHipError("element_%s_dev: " % what + _err())
+
+    def zr_op_dev(self, what, d_out, d_a, d_b, n, stream=0):
+        if lib().pbc_hip_zr_op_batch_dev(self._h, ZR_OPS[what], d_out, d_a, d_b, n, stream):
+            raise PbcHipError("zr_%s_dev: " % what + _err())
+
+    def zr_from_hash_dev(self, d_out, d_data, hlen, n, stream=0):
+        if lib().pbc_hip_zr_from_hash_batch_dev(self._h, d_out, d_data, hlen, n, stream):
+            raise PbcHipError("zr_from_hash_dev: " + _err())
+
+    def element_pow_multi_dev(self, group, d_out, d_bases, d_scalars, n, stream=0):
+        k = len(d_bases)
+        args = []
+        for j in range(k):
+            args += [d_bases[j], d_scalars[j]]
+        f = lib().pbc_hip_element_pow2_zn_batch_dev if k == 2 else lib().pbc_hip_element_pow3_zn_batch_dev
+        if f(self._h, group, d_out, *args, n, stream):
+            raise PbcHipError("element_pow%d_zn_dev: " % k + _err())
 
     def _compressed_len(self, group):
         f = lib().pbc_hip_pairing_length_in_bytes_compressed_G2 if group == 2 else lib().pbc_hip_pairing_length_in_bytes_compressed_G1

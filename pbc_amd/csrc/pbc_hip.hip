@@ -509,7 +509,7 @@ constexpr int kSlots = 3, kMaxDev = 16;
 // (allocated with hipHostMallocPortable, as pbc_hip_host_alloc does).
 // Why in place: a lane reads its 2 x 128-byte record once (16-byte loads; a few microseconds over PCIe against the ~10 ms
 // of a pairing) and writes 128 bytes, while staged copies do not overlap with kernels that hold every register and LDS
-// byte of the chip.  Measured (tools/r03_hostchunk.sh, pinned host -> pinned host, ms per batch, staged / in place):
+// byte of the chip.  Measured (round 3, profiles/r03_notes.md; pinned host -> pinned host, ms per batch, staged / in place):
 // type a 2^20 90.1 / 81.6 (kernel alone: 81.7), 16-term type a products 2^18 281.2 / 260.5, type f 2^18 30.8 / 28.5.
 void *pinned_dev_ptr(const void *host, size_t bytes, bool shared) {
   if (reinterpret_cast<uintptr_t>(host) % 16) return nullptr;      // the kernels' 16-byte accesses; staged buffers are aligned
@@ -729,7 +729,7 @@ int run_host_generic(pbc_hip_pairing_s *P, uint8_t *gt, size_t ut, const uint8_t
   const int *devs = P->ndev > 0 ? P->devs : &P->device;
   // Chunks: every device gets one share of the batch (at most 2^20 units and 2 GB of records per chunk; three chunk
   // buffers per device are in flight).  Round 1-2 cut a batch into chunks of one chip residency (131072 units) to overlap
-  // the copies of one chunk with the kernel of another; measured on MI355X (tools/r03_hostchunk.sh, pinned host buffers,
+  // the copies of one chunk with the kernel of another; measured on MI355X (round 3, profiles/r03_notes.md; pinned host buffers,
   // 2^20 type a pairings): 131072 units 95.2 ms, 262144: 107.3, 524288: 89.6, one chunk: 89.7 = H2D + kernel + D2H -- the
   // copies do not overlap with these kernels (every register and LDS byte of the chip is taken, and the runtime's copy
   // kernels wait for a workgroup to retire), so smaller chunks only add launches that run at partial occupancy

@@ -165,3 +165,39 @@ class HostSim:
         out = np.empty((n, L), np.uint8)
         self.L.hostsim_fq_op(self.h, op, out.ctypes.data, a.ctypes.data, b.ctypes.data, n)
         return out
+
+    # ---- round 5: group law, multi-exponentiations, Z_r (group_more.cuh lane bodies) ----
+    def len_zr(self):
+        self.L.hostsim_len_zr.argtypes = [ctypes.c_void_p]
+        return self.L.hostsim_len_zr(self.h)
+
+    def affine_op(self, op, group, a, b=None):
+        a = np.ascontiguousarray(a, np.uint8)
+        b = None if b is None else np.ascontiguousarray(b, np.uint8)
+        out = np.zeros_like(a)
+        self.L.hostsim_affine_op.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 3 + [ctypes.c_size_t]
+        rc = self.L.hostsim_affine_op(self.h, op, group, out.ctypes.data, a.ctypes.data, None if b is None else b.ctypes.data, len(a))
+        assert rc == 0
+        return out
+
+    def multi(self, group, bases, scalars):
+        k = len(bases)
+        bases = [np.ascontiguousarray(x, np.uint8) for x in bases]
+        scalars = [np.ascontiguousarray(x, np.uint8) for x in scalars]
+        out = np.zeros_like(bases[0])
+        self.L.hostsim_multi.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 7 + [ctypes.c_size_t]
+        ptr = []
+        for j in range(3):
+            ptr += [bases[j].ctypes.data if j < k else None, scalars[j].ctypes.data if j < k else None]
+        rc = self.L.hostsim_multi(self.h, group, k, out.ctypes.data, *ptr, len(out))
+        assert rc == 0
+        return out
+
+    def zr_op(self, op, a, b=None, hlen=0):
+        a = np.ascontiguousarray(a, np.uint8)
+        b = None if b is None else np.ascontiguousarray(b, np.uint8)
+        out = np.zeros((len(a), self.len_zr()), np.uint8)
+        self.L.hostsim_zr_op.argtypes = [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 3 + [ctypes.c_int, ctypes.c_size_t]
+        rc = self.L.hostsim_zr_op(self.h, op, out.ctypes.data, a.ctypes.data, None if b is None else b.ctypes.data, hlen, len(a))
+        assert rc == 0
+        return out

@@ -8,6 +8,7 @@
 #include "../../pbc_amd/csrc/pairing_aw.cuh"
 #include "../../pbc_amd/csrc/group_al.cuh"
 #include "../../pbc_amd/csrc/group_l5.cuh"
+#include "../../pbc_amd/csrc/group_more.cuh"
 
 // run EXPR with N = the compile-time word count matching P->nlimb
 #define HS_DISPATCH(nl, ...)                          \
@@ -425,4 +426,58 @@ int hostsim_fq_op(void *h, int op, uint8_t *c, const uint8_t *a, const uint8_t *
   }
   return 0;
 }
+
+// round 5 (group_more.cuh): the group law on G1 / G2, the multi-exponentiations on G1 / G2 / GT, Z_r arithmetic --
+// the lane bodies the kernels of pbc_hip_group2.hip run, one unit per call
+#define HS_DISPATCH_G(P_, group_, ...)                                                                 \
+  do {                                                                                                 \
+    const bool sym_ = (P_)->type == 'a' || (P_)->type == '1' || (P_)->type == 'e';                      \
+    if ((group_) == 2 && !sym_) { HS_DISPATCH_TWIST(P_, __VA_ARGS__); }                                \
+    else { HS_DISPATCH((P_)->nlimb, { typedef FqOps<N> F; __VA_ARGS__; }); }                           \
+  } while (0)
+int hostsim_affine_op(void *h, int op, int group, uint8_t *out, const uint8_t *a, const uint8_t *b, size_t n) {
+  pbc_hip_pairing_s *P = (pbc_hip_pairing_s *) h;
+  activate(P);
+  const size_t L = (size_t) (group == 2 ? P->len2 : P->len1);
+  for (size_t i = 0; i < n; i++) HS_DISPATCH_G(P, group, ec_affine_op_lane<F>(op, out + i * L, a + i * L, b ? b + i * L : a + i * L));
+  return 0;
+}
+int hostsim_multi(void *h, int group, int k, uint8_t *out, const uint8_t *a1, const uint8_t *n1, const uint8_t *a2, const uint8_t *n2,
+                  const uint8_t *a3, const uint8_t *n3, size_t n) {
+  pbc_hip_pairing_s *P = (pbc_hip_pairing_s *) h;
+  activate(P);
+  const size_t L = (size_t) (group == 1 ? P->len1 : group == 2 ? P->len2 : P->lenT);
+  MultiArgs M;
+  M.a[0] = a1; M.a[1] = a2; M.a[2] = k > 2 ? a3 : a1;
+  M.z[0] = n1; M.z[1] = n2; M.z[2] = k > 2 ? n3 : n1;
+  M.astride = L;
+  M.zstride = (size_t) P->len_zr;
+  for (size_t i = 0; i < n; i++) {
+    if (group == 3) {
+      if (P->type == 'a' || P->type == '1') { if (P->nlimb == 16) gt_multi_pow_lane<GtA<16>>(out + i * L, M, i, k, P->len_zr); else gt_multi_pow_lane<GtA<33>>(out + i * L, M, i, k, P->len_zr); }
+      else if (P->type == 'e') { if (P->nlimb == 16) gt_multi_pow_lane<GtE<16>>(out + i * L, M, i, k, P->len_zr); else gt_multi_pow_lane<GtE<33>>(out + i * L, M, i, k, P->len_zr); }
+      else if (P->type == 'f') { HS_DISPATCH_F(P->nlimb, gt_multi_pow_lane<GtF<N>>(out + i * L, M, i, k, P->len_zr)); }
+      else { HS_DISPATCH_D(P, (gt_multi_pow_lane<GtD<N, DEG>>(out + i * L, M, i, k, P->len_zr))); }
+    } else {
+      HS_DISPATCH_G(P, group, ec_multi_mul_lane<F>(out + i * L, M, i, k, P->len_zr));
+    }
+  }
+  return 0;
+}
+int hostsim_zr_op(void *h, int op, uint8_t *out, const uint8_t *a, const uint8_t *b, int hlen, size_t n) {
+  pbc_hip_pairing_s *P = (pbc_hip_pairing_s *) h;
+  if (!P->zr_nlimb) return 1;
+  int rc = 0;
+  HS_DISPATCH(P->zr_nlimb, {
+    KArgs<N> K;
+    rc = zr_kargs<N>(P, K);
+    memcpy(hostsim_kargs + sizeof hostsim_kargs - sizeof K, &K, sizeof K);
+    const size_t L = (size_t) P->len_zr;
+    for (size_t i = 0; i < n && !rc; i++) zr_op_lane<N>(op, out + i * L, a + i * (op == 8 ? (size_t) hlen : L), b ? b + i * L : nullptr, hlen);
+  });
+  activate(P);
+  return rc;
+}
+int hostsim_len_zr(void *h) { return ((pbc_hip_pairing_s *) h)->len_zr; }
+
 }

@@ -229,7 +229,7 @@ def test_golden_recipe_reproduces_every_fixture(tmp_path):
     env = dict(os.environ, G=str(tmp_path))
     subprocess.check_call(["sh", os.path.join(GOLDEN, "make_golden.sh")], cwd=root, env=env,
                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-    committed = sorted(f for f in os.listdir(GOLDEN) if f.endswith((".vec", ".txt", ".bin")))
+    committed = sorted(f for f in os.listdir(GOLDEN) if f.endswith((".vec", ".txt", ".bin", ".rec")))
     written = sorted(os.listdir(tmp_path))
     assert written == committed
     for f in committed:

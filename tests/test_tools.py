@@ -15,11 +15,11 @@ def _git(*args):
 
 @pytest.mark.skipif(not os.path.isdir(os.path.join(ROOT, ".git")), reason="not a git checkout (the GPU box gets a snapshot)")
 def test_collect_refuses_a_dirty_tree():
-    """tools/r04_collect.sh stops before it reaches gpurun when the work tree has uncommitted or untracked files"""
+    """tools/collect.sh stops before it reaches gpurun when the work tree has uncommitted or untracked files"""
     marker = os.path.join(ROOT, "tools", "_dirty_marker_for_test.txt")
     open(marker, "w").write("x")
     try:
-        r = subprocess.run(["bash", os.path.join(ROOT, "tools", "r04_collect.sh")], capture_output=True, text=True, timeout=60)
+        r = subprocess.run(["bash", os.path.join(ROOT, "tools", "collect.sh")], capture_output=True, text=True, timeout=60)
         assert r.returncode == 1 and "dirty" in r.stdout
         assert not os.path.exists(os.path.join(ROOT, ".evidence_head"))
     finally:
@@ -28,22 +28,25 @@ def test_collect_refuses_a_dirty_tree():
 
 @pytest.mark.skipif(not os.path.isdir(os.path.join(ROOT, ".git")), reason="not a git checkout")
 def test_committed_evidence_names_one_commit():
-    """every bench line under profiles/r04_bench_* and the PMC summaries carry the commit the manifest names for them (the
+    """every bench line under profiles/rNN_bench_* and the PMC summaries (rounds with a manifest: 4 on) carry the commit the manifest names for them (the
     collection's, or that of the addendum -- a partial re-collection after a change to a few kernels -- that lists the
     file), and those commits are ancestors of HEAD"""
-    man = json.load(open(os.path.join(ROOT, "profiles", "r04_MANIFEST.json")))
-    sets = [(man["commit"], man["files"])] + [(a["commit"], a["files"]) for a in man.get("addenda", [])]
+    import glob
     n = 0
-    for commit, files in sets:
-        assert _git("merge-base", "--is-ancestor", commit, "HEAD").returncode == 0
-        for f in files:
-            path = os.path.join(ROOT, f)
-            assert os.path.exists(path), f
-            if os.path.basename(f).startswith("r04_bench_"):
-                assert json.loads(open(path).readline())["commit"] == commit, f
-                n += 1
-            if os.path.basename(f).startswith("r04_pmc_"):
-                assert json.load(open(path))["commit"] == commit, f
+    for mpath in sorted(glob.glob(os.path.join(ROOT, "profiles", "r0?_MANIFEST.json"))):
+        rnd = os.path.basename(mpath)[:3]
+        man = json.load(open(mpath))
+        sets = [(man["commit"], man["files"])] + [(a["commit"], a["files"]) for a in man.get("addenda", [])]
+        for commit, files in sets:
+            assert _git("merge-base", "--is-ancestor", commit, "HEAD").returncode == 0
+            for f in files:
+                path = os.path.join(ROOT, f)
+                assert os.path.exists(path), f
+                if os.path.basename(f).startswith(rnd + "_bench_"):
+                    assert json.loads(open(path).readline())["commit"] == commit, f
+                    n += 1
+                if os.path.basename(f).startswith(rnd + "_pmc_"):
+                    assert json.load(open(path))["commit"] == commit, f
     assert n >= 30
 
 
@@ -52,7 +55,7 @@ def test_traffic_carries_the_corrected_ratio():
     sys.path.insert(0, ROOT)
     import bench
     t = bench.pmc_traffic("a", 384 * (1 << 20), 1 << 20)
-    assert t and t["source"].startswith("profiles/r04_pmc_a.json")
+    assert t and t["source"].startswith(("profiles/r05_pmc_a.json", "profiles/r04_pmc_a.json"))
     raw = t["raw"]
     assert t["bytes_per_launch"] == 2 * raw["FETCH_SIZE_bytes"] + raw["WRITE_SIZE_bytes"]
     assert abs(t["ratio_vs_algorithmic"] - t["bytes_per_launch"] / (384 * (1 << 20))) < 0.01

@@ -1,0 +1,39 @@
+"""Latency of small batches, a.param: the one-pairing-per-wavefront kernel and its four-wavefront form (pairing_aw.cuh) against the throughput kernel,
+device buffers, events around the call; median of 7 after 2 warm-ups.   python tools/wave_latency.py [sizes...]"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import pbc_amd  # noqa: E402
+from conftest import golden, _param  # noqa: E402
+
+v = golden("a_chain1024.vec")
+sizes = [int(x) for x in sys.argv[1:]] or [1, 16, 256, 1024, 2048, 3072, 4096, 6144, 8192, 16384]
+P = {"wave4": pbc_amd.Pairing(_param("a") + "hip_wave_max 1000000\nhip_wave4_max 1000000\n"),
+     "wave": pbc_amd.Pairing(_param("a") + "hip_wave_max 1000000\nhip_wave4_max 0\n"), "lane": pbc_amd.Pairing(_param("a") + "hip_wave_max 0\n")}
+for n in sizes:
+    i = np.arange(n) % v.n
+    g1 = torch.from_numpy(np.ascontiguousarray(v.g1[i])).cuda()
+    g2 = torch.from_numpy(np.ascontiguousarray(v.g2[(i * 5 + 1) % v.n])).cuda()
+    row = {}
+    outs = {}
+    for name, H in P.items():
+        out = torch.empty((n, 128), dtype=torch.uint8, device="cuda")
+        ts = []
+        for rep in range(9):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            H.element_pairing_dev(out.data_ptr(), g1.data_ptr(), g2.data_ptr(), n, torch.cuda.current_stream().cuda_stream)
+            b.record()
+            b.synchronize()
+            ts.append(a.elapsed_time(b))
+        row[name] = float(np.median(ts[2:]))
+        outs[name] = out.cpu().numpy()
+    same = np.array_equal(outs["wave"], outs["lane"]) and np.array_equal(outs["wave4"], outs["lane"])
+    print("n = %6d   4 waves %8.3f ms  (%9.0f /s)   1 wave %8.3f ms  (%9.0f /s)    lane %8.3f ms  (%9.0f /s)    same bytes: %s" %
+          (n, row["wave4"], n / row["wave4"] * 1e3, row["wave"], n / row["wave"] * 1e3, row["lane"], n / row["lane"] * 1e3, same), flush=True)

@@ -215,6 +215,8 @@ def main():
     ap.add_argument("--workload", default="a", choices=sorted(WORKLOADS) + sorted(bench_group.GROUP_WORKLOADS),
                     help="default: the BASELINE.json metric config (2^20 Type-A pairings)")
     ap.add_argument("--log2n", type=int, default=None, help="units per GPU per step (with --strong: units of the whole job)")
+    ap.add_argument("--extra-units", type=int, default=0,
+                    help="units beyond 2^log2n (a job size no rank count divides: the range split gets ragged shares)")
     ap.add_argument("--strong", action="store_true",
                     help="the 2^log2n units are the whole job, range-split over the ranks (BASELINE config 5: "
                          "--workload a-prod16 --strong --gpus 8 = 2^18 products sharded across 8 GPUs)")
@@ -258,7 +260,7 @@ def main():
     param_path = os.path.join(ROOT, "pbc_amd", "param", pname + ".param")
     pairing = pbc_amd.Pairing(open(param_path).read() + ("\n" + args.param_extra.replace("=", " ").replace(",", "\n") + "\n" if args.param_extra else ""))
     L1, L2, LT = pairing.length_in_bytes_G1, pairing.length_in_bytes_G2, pairing.length_in_bytes_GT
-    n_job = 1 << args.log2n
+    n_job = (1 << args.log2n) + args.extra_units
     if args.strong:                      # range split of one job: rank r owns units [r n_job / world, (r + 1) n_job / world)
         first = rank * n_job // world
         n = (rank + 1) * n_job // world - first
@@ -437,7 +439,7 @@ def main():
         unit_name = "pairings/s" if k == 1 else "products/s"
         out = {
             "metric": "pairings/sec on 2^20-batch Type-A (a.param)" if args.workload == "a"
-                      else "%s per second, 2^%d batch" % (desc, args.log2n),
+                      else "%s per second, 2^%d%s batch" % (desc, args.log2n, " + %d" % args.extra_units if args.extra_units else ""),
             "value": round(value, 1),
             "unit": unit_name,
             "n_gpus": world,
@@ -449,7 +451,8 @@ def main():
             "vs_baseline": None,
             "dtype": "u32 (multi-word Montgomery F_q, bit-exact integer)",
             "data": "synthetic: (P_i,Q_j) cross pairs of tests/golden/%s (%d x %d distinct), resident in HBM" % (fixture, D, D),
-            "config": {"workload": "%s, 2^%d units %s per step" % (desc, args.log2n, "in the whole job" if args.strong else "per GPU"),
+            "config": {"workload": "%s, 2^%d%s units %s per step" % (desc, args.log2n, " + %d" % args.extra_units if args.extra_units else "",
+                                                                     "in the whole job" if args.strong else "per GPU"),
                        "units_per_gpu": n, "terms_per_unit": k, "global_batch": n_job if args.strong else n * world,
                        "parallelism": "range-split x%d, no collectives" % world,
                        **({"param_extra": args.param_extra} if args.param_extra else {})},

@@ -190,7 +190,7 @@ def main(args, load_vec, ensure_built, MAC_PEAK):
     P = pbc_amd.Pairing(text + extra)
     O = oracle.OraclePairing(text)
     L1, L2, LT, LZ = P.length_in_bytes_G1, P.length_in_bytes_G2, P.length_in_bytes_GT, P.length_in_bytes_Zr
-    n_job = 1 << args.log2n
+    n_job = (1 << args.log2n) + getattr(args, "extra_units", 0)
     if args.strong:
         first = rank * n_job // world
         n = (rank + 1) * n_job // world - first

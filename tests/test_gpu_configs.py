@@ -47,6 +47,30 @@ def test_bench_strong_scaling_two_ranks_share_the_gpu(workload, log2n, k):
     assert j["value"] > 0
 
 
+def test_bench_strong_scaling_eight_ranks_ragged_job():
+    """what the driver's 8-GPU node runs for BASELINE config 5 -- `bench.py --workload a-prod16 --strong --gpus 8` -- with
+    EIGHT ranks (on the one GPU of the test box, gloo for the barrier and the clock) and a job of 2^11 + 5 products, which
+    no rank count divides: the shares are 256 or 257 units, every rank's first unit follows from the floor split, every
+    shard passes its gate, and the shares add up to the job."""
+    env = dict(os.environ, PBC_BENCH_SAME_DEVICE="1", PBC_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1",
+           "--workload", "a-prod16", "--strong", "--log2n", "11", "--extra-units", "5", "--no-cpu-baseline", "--no-host-path"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=1200, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    n = (1 << 11) + 5
+    assert j["n_gpus"] == 8 and j["scaling"] == "strong" and j["config"]["global_batch"] == n
+    gate = j["per_rank_gate"]
+    assert [g["first_unit"] for g in gate] == [r_ * n // 8 for r_ in range(8)]
+    assert [g["units"] for g in gate] == [(r_ + 1) * n // 8 - r_ * n // 8 for r_ in range(8)]
+    assert sum(g["units"] for g in gate) == n and sorted(set(g["units"] for g in gate)) == [256, 257]
+    assert all(g["checked"] > 0 for g in gate), gate
+    assert len(j["per_rank_kernel_ms"]) == 8 and all(x > 0 for x in j["per_rank_kernel_ms"])
+
+
 # ---- (b) resident workgroups: several units per lane, ragged tails ---------------------------------------------------
 def _check_tail(got, want, n):
     assert np.array_equal(got[:n], want), "a unit differs"
@@ -234,6 +258,15 @@ def test_device_set_with_pinned_buffers_products_and_many_chunks_one_physical_de
             rt.cudaHostUnregister(view.ctypes.data)
         assert L.pbc_hip_element_prod_pairing_batch(H._h, pt, p1, p2, n, k) == 0      # the object is intact afterwards
         assert np.array_equal(at.reshape(n, -1), want)
+    # the same object with EIGHT positions in its set (the driver's node has eight devices; here device 0 eight times):
+    # eight workers, 14 chunks, in place on the pinned buffers and staged from pageable memory
+    H.use_devices([0] * 8)
+    at[:] = 0
+    assert L.pbc_hip_element_prod_pairing_batch(H._h, pt, p1, p2, n, k) == 0, pbc_amd._err()
+    assert np.array_equal(at.reshape(n, -1), want)
+    assert np.array_equal(H.element_prod_pairing(g1, g2, k), want)
+    assert np.array_equal(H.element_pairing(g1, g2), hips[key].element_pairing(g1, g2))
+    H.use_devices([0, 0, 0])
     H.release_workspaces()                                                       # frees chunk buffers and workspaces; the next call rebuilds them
     assert np.array_equal(H.element_prod_pairing(g1, g2, k), want)
     for p in bufs:

@@ -19,6 +19,9 @@
 // `invert`, is kept for reference: 0.32 against 0.14 ms).
 // Boundaries (bytes <-> limbs, validity, the final halvings) run the word-form routines on lane 0 through LDS.
 #pragma once
+#ifndef PBC_AW_INV_LANE0
+#define PBC_AW_INV_LANE0 0          // 1: invert_lane0 calls fp_inv under a lane-0-only EXEC mask (faulted in round 4; tools/gpu_faults.md)
+#endif
 #include "pairing_al.cuh"
 
 namespace pbc {
@@ -322,6 +325,17 @@ struct AW {
 #else
     put_slot(x, 5);
     sync();
+#if PBC_AW_INV_LANE0
+    if (lane0()) {                                             // experiment switch (tools/gpu_faults.md): the call under a lane-0-only EXEC mask
+      el e;
+      fp<N> tw;
+      slot_to_el(e, 5);
+      A::to_words(tw, e);
+      fp_inv<N>(tw, tw);
+      A::to_el(e, tw);
+      el_to_slot(e, 5);
+    }
+#else
     {                                                          // every lane runs the same inversion (no call under a partial EXEC mask)
       el e;
       fp<N> tw;
@@ -332,6 +346,7 @@ struct AW {
       sync();
       if (lane0()) el_to_slot(e, 5);
     }
+#endif
     sync();
     const W r = get_slot(5);
     sync();

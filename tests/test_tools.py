@@ -59,3 +59,23 @@ def test_traffic_carries_the_corrected_ratio():
     raw = t["raw"]
     assert t["bytes_per_launch"] == 2 * raw["FETCH_SIZE_bytes"] + raw["WRITE_SIZE_bytes"]
     assert abs(t["ratio_vs_algorithmic"] - t["bytes_per_launch"] / (384 * (1 << 20))) < 0.01
+
+
+def test_no_register_is_live_across_a_call_that_changes_it():
+    """tools/gpu_faults.md, the rule for the wave-cooperative kernels and the headline kernel: in the assembly of the last
+    `make -C pbc_amd` (-save-temps, /tmp/pbc_hip_build) no SGPR that a callee's body changes and does not restore is read
+    by the kernel after the call before it is rewritten (tools/ipra_check.py: data flow over the kernel's CFG, every
+    s_swappc resolved to its callee).  Skipped where the build's temporaries are not there (the GPU box runs the prebuilt
+    library)."""
+    asm = "/tmp/pbc_hip_build/obj_libpbc_hip/pbc_hip_a-hip-amdgcn-amd-amdhsa-gfx950.s"
+    if not os.path.exists(asm):
+        pytest.skip("no -save-temps assembly of the library build here")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import ipra_check
+    funcs = ipra_check.parse(asm)
+    kernels = [k for k in funcs if k.startswith(("_Z17aw_pairing_kernelILi16E", "_Z17al_pairing_kernelILi16E"))]
+    assert len(kernels) >= 3
+    for k in kernels:
+        findings, ncalls, unresolved, _ = ipra_check.check(funcs, k, "s")
+        assert ncalls > 20 and unresolved == 0, k
+        assert findings == [], (k, findings[:3])

@@ -34,19 +34,26 @@ for _t, _p, _fx in (("a", "a", "a_chain1024.vec"), ("d", "d159", "d_chain256.vec
     if _t != "a":                      # type a is symmetric: G2 is the same curve and the same kernel as G1
         GROUP_WORKLOADS[_t + "-g2-mul"] = (_p, _fx, "g2mul", 17)
     GROUP_WORKLOADS[_t + "-gt-pow"] = (_p, _fx, "gtpow", 20 if _t == "a" else 17)
-    GROUP_WORKLOADS[_t + "-hash-g1"] = (_p, _fx, "hashg1", 18)
+    GROUP_WORKLOADS[_t + "-hash-g1"] = (_p, _fx, "hashg1", 18 if _t == "a" else 22)     # (5-word fields: 2^18 hashes are a 1 ms launch)
     GROUP_WORKLOADS[_t + "-g1-pp"] = (_p, _fx, "g1pp", 20)
     GROUP_WORKLOADS[_t + "-gt-pp"] = (_p, _fx, "gtpp", 20 if _t != "f" else 18)
     GROUP_WORKLOADS[_t + "-decompress"] = (_p, _fx, "decompress", 18)
     GROUP_WORKLOADS[_t + "-compress"] = (_p, _fx, "compress", 20)
+    # round 5: the group law, Z_r inversion, element_pow2_zn on G1 and GT
+    GROUP_WORKLOADS[_t + "-g1-add"] = (_p, _fx, "g1add", 20)
+    GROUP_WORKLOADS[_t + "-zr-inv"] = (_p, _fx, "zrinv", 20)
+    GROUP_WORKLOADS[_t + "-g1-pow2"] = (_p, _fx, "g1pow2", 18 if _t == "a" else 17)
+    GROUP_WORKLOADS[_t + "-gt-pow2"] = (_p, _fx, "gtpow2", 18 if _t == "a" else 16)
 GROUP_WORKLOADS["a-bls-verify"] = ("a", "a_chain1024.vec", "blsverify", 17)
 
 DESC = {"g1mul": "element_mul_zn on G1", "g2mul": "element_mul_zn on G2 (the twist)", "gtpow": "element_pow_zn on GT",
         "hashg1": "element_from_hash on G1 (32-byte digests)", "g1pp": "element_pp_pow_zn on G1 (fixed base)",
         "gtpp": "element_pp_pow_zn on GT (fixed base)", "decompress": "element_from_bytes_compressed on G1",
-        "compress": "element_to_bytes_compressed on G1", "blsverify": "BLS batch verification (hash, 2 x mul_zn, 16-term products)"}
+        "compress": "element_to_bytes_compressed on G1", "g1add": "element_add on G1", "zrinv": "element_invert on Zr",
+        "g1pow2": "element_pow2_zn on G1", "gtpow2": "element_pow2_zn on GT", "blsverify": "BLS batch verification (hash, 2 x mul_zn, 16-term products)"}
 UNIT = {"g1mul": "scalar multiplications/s", "g2mul": "scalar multiplications/s", "gtpow": "powers/s", "hashg1": "hashes/s",
-        "g1pp": "scalar multiplications/s", "gtpp": "powers/s", "decompress": "points/s", "compress": "points/s", "blsverify": "signatures/s"}
+        "g1pp": "scalar multiplications/s", "gtpp": "powers/s", "decompress": "points/s", "compress": "points/s", "blsverify": "signatures/s",
+        "g1add": "additions/s", "zrinv": "inversions/s", "g1pow2": "double scalar multiplications/s", "gtpow2": "double powers/s"}
 
 
 def param_int(text, key):
@@ -104,6 +111,15 @@ def reference_model(text, op, nlimb):
         return 2 + qs + qm, 0
     if op == "compress":                # the parity of the canonical y: no arithmetic
         return 0, 0
+    if op == "g1add":                   # curve_mul (ecc/curve.c:153-207): lambda = dy / dx, lambda^2, (x1 - x3) lambda: 3 products, 1 inversion
+        return 3, 1
+    if op == "zrinv":                   # mpz_invert on r-sized integers: no F_q product at all
+        return 0, 1
+    if op in ("g1pow2", "gtpow2"):      # element_pow2_zn (arith/field.c:153-196): b squarings, 3 b / 4 products on average + one for the table
+        d = ext[0] if op == "g1pow2" else ext[2]
+        if op == "g1pow2":
+            return b * 4 * fmul[d] + (0.75 * b + 1) * 3 * fmul[d], b + 0.75 * b + 1
+        return (b + 0.75 * b + 1) * fmul[d], 0
     rows = b // 5 + 1                  # element_pow_base_table (arith/field.c:286-323): one multiplication per 5-bit row
     if op == "g1pp":
         return rows * 3, rows
@@ -128,9 +144,9 @@ def cpu_baseline(param_path, op):
     if not os.path.exists(tool):
         return None
     per = {"g1mul": 400, "g2mul": 200, "gtpow": 2000, "hashg1": 200, "g1pp": 4000, "gtpp": 20000, "blsverify": 150,
-           "compress": 400000, "decompress": 4000}[op]
+           "compress": 400000, "decompress": 4000, "g1add": 100000, "zrinv": 400000, "g1pow2": 300, "gtpow2": 1500}[op]
     if not param_path.endswith("a.param"):
-        per *= 4 if op in ("g1mul", "hashg1", "g1pp", "decompress") else 1
+        per *= 4 if op in ("g1mul", "hashg1", "g1pp", "decompress", "g1pow2") else 1
     per *= int(os.environ.get("PBC_CPU_SAMPLE_SCALE", "1"))
 
     def run(n, workers):
@@ -264,6 +280,45 @@ def main(args, load_vec, ensure_built, MAC_PEAK):
 
         def gate():
             return np.array_equal(OUT[sample].cpu().numpy(), O.point_format(0 if op == "compress" else 1, IN[sample].cpu().numpy()))
+    elif op == "g1add":
+        IN = torch.from_numpy(g1).cuda()[idx].contiguous()
+        IN2 = torch.from_numpy(g1).cuda()[(idx * 3 + 1) % D].contiguous()
+        OUT = torch.empty_like(IN)
+        unit_bytes = 3 * L1
+
+        def step():
+            P.element_group_op_dev("add", 1, OUT.data_ptr(), IN.data_ptr(), IN2.data_ptr(), n, s)
+
+        def gate():
+            return np.array_equal(OUT[sample].cpu().numpy(), O.g1_op(0, IN[sample].cpu().numpy(), IN2[sample].cpu().numpy()))
+    elif op == "zrinv":
+        Z[:, -1] |= 1                    # never zero
+        dZ = torch.from_numpy(Z).cuda()
+        OUT = torch.empty_like(dZ)
+        unit_bytes = 2 * LZ
+
+        def step():
+            P.zr_op_dev("invert", OUT.data_ptr(), dZ.data_ptr(), 0, n, s)
+
+        def gate():
+            return np.array_equal(OUT[sample].cpu().numpy(), O.zr_op(3, Z[sample]))
+    elif op in ("g1pow2", "gtpow2"):
+        group = 1 if op == "g1pow2" else 3
+        src = g1 if group == 1 else gt
+        IN = torch.from_numpy(src).cuda()[idx].contiguous()
+        IN2 = torch.from_numpy(src).cuda()[(idx * 3 + 1) % D].contiguous()
+        Z2 = rng.integers(0, 256, (n, LZ), dtype=np.uint8)
+        Z2[:, 0] &= (1 << (top.bit_length() - 1)) - 1
+        dZ2 = torch.from_numpy(Z2).cuda()
+        OUT = torch.empty_like(IN)
+        unit_bytes = 3 * IN.shape[1] + 2 * LZ
+
+        def step():
+            P.element_pow_multi_dev(group, OUT.data_ptr(), [IN.data_ptr(), IN2.data_ptr()], [dZ.data_ptr(), dZ2.data_ptr()], n, s)
+
+        def gate():
+            want = O.pow_multi(group, [IN[sample].cpu().numpy(), IN2[sample].cpu().numpy()], [Z[sample], Z2[sample]])
+            return np.array_equal(OUT[sample].cpu().numpy(), want)
     elif op in ("g1pp", "gtpp"):
         group = 1 if op == "g1pp" else 3
         base = g1[5] if group == 1 else gt[5]

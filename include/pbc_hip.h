@@ -15,7 +15,12 @@
  *
  * All functions return 0 on success, non-zero on failure (pairing_init_set_buf
  * convention, ecc/pairing.c:88-98); pbc_hip_last_error() gives the message.  A
- * pbc_hip_pairing_t is not re-entrant: one batch call at a time per object.
+ * pbc_hip_pairing_t is not re-entrant: one batch call at a time per object.  The _dev forms may be enqueued on several
+ * streams of one object at once, but ONE host thread issues the calls of an (object, stream) pair: the two-pass group
+ * operations (fast kernel + complete kernel for the lanes it flagged), the head / tail split of the small-batch
+ * kernels and the per-launch unit counters keep their scratch in a workspace keyed by (device, stream), so two threads
+ * interleaving launches on the same pair would read each other's flags.  Use one stream per issuing thread, or one
+ * object per thread (objects are cheap: constants travel in the kernel arguments).
  *
  * Input classes (every one is covered by a GPU test, tests/test_gpu_parity.py):
  *   - Points of the whole curve.  curve_from_bytes (ecc/curve.c:609-623) checks the curve equation only, so a G1 / G2
@@ -243,7 +248,9 @@ int pbc_hip_element_from_bytes_x_only_batch_dev(pbc_hip_pairing_t *p, int group,
  * signatures' scalars (example/bls.c:41-62).  pp_init builds [w 2^(8 i)] B, w = 1 .. 255, i < length_in_bytes_Zr, on the
  * device (one entry per lane); a power is then one mixed addition per scalar BYTE and one inversion (GT: one product per
  * byte), no doublings.  Results are those of element_pow_zn / element_mul_zn on the same base.  A base of small order
- * (some table entry is O) or off the curve (= O) is served by the complete ladder. */
+ * (some table entry is O) or off the curve (= O) is served by the complete ladder.  The table is built on, and bound to,
+ * the device the pairing object was created on (whatever the calling thread's current device is); the host-buffer form
+ * runs there also when the object has a device set (staged); the _dev form needs pointers of that device. */
 typedef struct pbc_hip_element_pp_s pbc_hip_element_pp_t;
 int pbc_hip_element_pp_init(pbc_hip_element_pp_t **pp, pbc_hip_pairing_t *p, int group, const uint8_t *in);
 void pbc_hip_element_pp_clear(pbc_hip_element_pp_t *pp);

@@ -258,9 +258,10 @@ static int cmd_benchg(int argc, char **argv) {
       pairing_t pairing; char type;
       pbc_random_set_deterministic(1000u + (unsigned) w);
       init_pairing(pairing, argv[1], &type);
-      element_t P, Q, R1, R2, k, gt, gto, sk, pk, sig, t1, t2;
+      element_t P, Q, R1, R1b, R2, k, k2, gt, gto, sk, pk, sig, t1, t2;
       element_pp_t pp;
-      element_init_G1(P, pairing); element_init_G1(R1, pairing); element_init_G1(sig, pairing);
+      element_init_G1(P, pairing); element_init_G1(R1, pairing); element_init_G1(sig, pairing); element_init_G1(R1b, pairing);
+      element_init_Zr(k2, pairing);
       element_init_G2(Q, pairing); element_init_G2(R2, pairing); element_init_G2(pk, pairing);
       element_init_Zr(k, pairing); element_init_Zr(sk, pairing);
       element_init_GT(gt, pairing); element_init_GT(gto, pairing); element_init_GT(t1, pairing); element_init_GT(t2, pairing);
@@ -268,6 +269,7 @@ static int cmd_benchg(int argc, char **argv) {
       element_random(R1);
       element_pairing(gt, P, Q);
       element_pow_zn(pk, Q, sk);
+      element_random(k); element_pow_zn(t1, gt, sk);
       unsigned char digest[32];
       memset(digest, 0x5a, sizeof digest);
       const int is_g1pp = !strcmp(op, "g1pp"), is_gtpp = !strcmp(op, "gtpp");
@@ -285,6 +287,10 @@ static int cmd_benchg(int argc, char **argv) {
          * compress = element_to_bytes_compressed, decompress = element_from_bytes_compressed (a square root in F_q) */
         if (is_comp) { element_to_bytes_compressed(cbuf[i & 1], (i & 1) ? R1 : P); continue; }
         if (is_decomp) { element_from_bytes_compressed((i & 1) ? R1 : P, cbuf[i & 1]); continue; }
+        if (!strcmp(op, "g1add")) { element_add(R1, R1, P); continue; }                      /* curve_mul: one inversion + 3 products */
+        if (!strcmp(op, "zrinv")) { element_invert(k2, k); element_add(k, k2, sk); if (element_is0(k)) element_set1(k); continue; }
+        if (!strcmp(op, "g1pow2")) { element_random(k); element_random(k2); element_pow2_zn(R1b, P, k, R1, k2); element_add(P, P, R1b); continue; }
+        if (!strcmp(op, "gtpow2")) { element_random(k); element_random(k2); element_pow2_zn(gto, gt, k, t1, k2); element_mul(gt, gt, gto); continue; }
         if (!strcmp(op, "g1mul")) { element_random(k); element_mul_zn(R1, P, k); element_add(P, P, R1); }
         else if (!strcmp(op, "g2mul")) { element_random(k); element_mul_zn(R2, Q, k); element_add(Q, Q, R2); }
         else if (!strcmp(op, "gtpow")) { element_random(k); element_pow_zn(gto, gt, k); element_mul(gt, gt, gto); }

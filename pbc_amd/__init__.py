@@ -305,9 +305,6 @@ class Pairing:
         return self.length_in_bytes_G2 if group == 2 else self.length_in_bytes_G1
 
     # ---- the group law, Z_r, multi-exponentiations (round 5) -----------------------------------------
-    def _group_len(self, group):
-        return self.length_in_bytes_GT if group == 3 else self._point_len(group)
-
     def element_group_op(self, what, group, a, b=None):
         """what: "add", "sub" (two operands), "neg", "double" on records of G1 / G2 (element_add / element_sub /
         element_neg / element_double; O is the all-zero record)."""

@@ -24,7 +24,8 @@ PBC_DEV bool ec_load_affine(typename F::el &x, typename F::el &y, const uint8_t 
   F::mul(t0, t0, x);
   F::add(t0, t0, F::curve_b());
   F::sqr(t1, y);
-  return (int) F::eq(t0, t1) & !((int) F::is0(x) & (int) F::is0(y));
+  const bool zero = F::is0(x) && F::is0(y);
+  return F::eq(t0, t1) && !zero;
 }
 template <class F>
 PBC_DEV void ec_store_affine(uint8_t *out, const typename F::el &x, const typename F::el &y, bool finite) {
@@ -42,7 +43,7 @@ PBC_DEV void ec_add_affine(typename F::el &x3, typename F::el &y3, bool &f3, con
                            bool f1, const typename F::el &x2, const typename F::el &y2, bool f2) {
   typedef typename F::el el;
   el num, den, t, lam, rx, ry;
-  const bool samex = F::eq(x1, x2), tangent = (int) samex & (int) F::eq(y1, y2);
+  const bool samex = F::eq(x1, x2), samey = F::eq(y1, y2), tangent = samex && samey;
   F::sub(num, y2, y1);
   F::sub(den, x2, x1);
   F::sqr(t, x1);
@@ -61,15 +62,14 @@ PBC_DEV void ec_add_affine(typename F::el &x3, typename F::el &y3, bool &f3, con
   F::sub(t, x1, rx);
   F::mul(ry, lam, t);
   F::sub(ry, ry, y1);
-  const bool both = (int) f1 & (int) f2;
-  const bool only1 = (int) f1 & !(int) f2, only2 = !(int) f1 & (int) f2;
+  const bool both = f1 && f2, only1 = f1 && !f2, only2 = !f1 && f2;
   F::cmov(rx, x1, only1);
   F::cmov(ry, y1, only1);
   F::cmov(rx, x2, only2);
   F::cmov(ry, y2, only2);
   x3 = rx;
   y3 = ry;
-  f3 = ((int) both & !(int) to_inf) | (int) only1 | (int) only2;
+  f3 = (both && !to_inf) || only1 || only2;
 }
 // op 0: a + b, 1: a - b, 2: -a, 3: 2 a on records of G1 / G2
 template <class F>
@@ -95,7 +95,8 @@ PBC_DEV void ec_affine_op_lane(int op, uint8_t *out, const uint8_t *a, const uin
 // builds the same table in element_pow2_zn / element_pow3_zn (arith/field.c:153-241, a window of one bit per base) over
 // its affine law; any addition chain gives the same group element.  The running point is Jacobian; the addition is the
 // complete one of group_ops.cuh (R = O, R = -T, and R = T through the doubling of R formed beside it), so scalars
-// above r and points outside the order-r subgroup are served as well.
+// above r and points outside the order-r subgroup are served as well -- at the price of a second doubling per bit.  The
+// library runs this routine only for the lanes the fast pass below reports.
 struct MultiArgs {                     // record j of unit i sits at p[j] + i stride (p[j]: device pointers)
   const uint8_t *a[3];
   const uint8_t *z[3];
@@ -139,6 +140,66 @@ PBC_DEV void ec_multi_mul_lane(uint8_t *out, const MultiArgs &M, size_t idx, int
   F::mul(zi2, zi2, zi);
   F::mul(ay, Y, zi2);
   ec_store_affine<F>(out, ax, ay, finite);
+}
+// The FAST pass of the same sum: one doubling and one INCOMPLETE mixed addition per scalar bit (the plain Jacobian
+// formulas: an addition that meets R = +-T leaves Z = 0 for good), the running point taken from the table at the first
+// non-zero bit column.  Returns false -- nothing written -- when Z = 0 at the end: the true result O (also: all scalars
+// zero), related bases (a2 = +-a1 makes R meet a table entry), points of small order.  Those lanes take
+// ec_multi_mul_lane in a second, nearly empty launch, as the single-base ladders do (group_ops.cuh).
+template <class F>
+PBC_DEV bool ec_multi_mul_fast_lane(uint8_t *out, const MultiArgs &M, size_t idx, int k, int zlen) {
+  typedef typename F::el el;
+  el tx[8], ty[8];
+  bool tf[8];
+  tf[0] = false;
+  tx[0] = F::zero();
+  ty[0] = tx[0];
+  bool all_finite = true;
+  for (int j = 0; j < k; j++) {
+    el x, y;
+    const bool f = ec_load_affine<F>(x, y, M.a[j] + idx * M.astride);
+    tx[1 << j] = x;
+    ty[1 << j] = y;
+    tf[1 << j] = f;
+    all_finite = all_finite && f;
+  }
+  for (int s = 3; s < (1 << k); s++) {
+    const int low = s & -s, rest = s & (s - 1);
+    if (!rest) continue;
+    ec_add_affine<F>(tx[s], ty[s], tf[s], tx[rest], ty[rest], tf[rest], tx[low], ty[low], tf[low]);
+    all_finite = all_finite && tf[s];
+  }
+  const el one = F::one(), ca = F::curve_a();
+  el X = one, Y = one, Z = F::zero();
+  bool started = false;
+  for (int i = 8 * zlen - 1; i >= 0; i--) {
+    ec_dbl_jac<F>(X, Y, Z, ca);
+    int s = 0;
+    for (int j = 0; j < k; j++) s |= (int) zr_bit(M.z[j] + idx * M.zstride, zlen, i) << j;
+    const el x2 = tx[s], y2 = ty[s];
+    el sX = X, sY = Y, sZ = Z;
+    ec_madd_inc<F>(sX, sY, sZ, x2, y2);
+    const bool add = s != 0 && started, first = s != 0 && !started;
+    F::cmov(X, sX, add);
+    F::cmov(Y, sY, add);
+    F::cmov(Z, sZ, add);
+    F::cmov(X, x2, first);
+    F::cmov(Y, y2, first);
+    F::cmov(Z, one, first);
+    started = started || s != 0;
+  }
+  const bool ok = all_finite && !F::is0(Z);            // (an O among the bases or the subset sums: the complete pass)
+  el zi, zi2, ax, ay;
+  F::inv(zi, Z);
+  F::sqr(zi2, zi);
+  F::mul(ax, X, zi2);
+  F::mul(zi2, zi2, zi);
+  F::mul(ay, Y, zi2);
+  if (ok) {
+    F::store(out, ax);
+    F::store(out + F::bytes(), ay);
+  }
+  return ok;
 }
 // The same in GT (a field policy G of group_ops.cuh): the table holds the subset PRODUCTS, entry 0 the identity, and
 // every bit is a squaring and a product with the entry the bits select.

@@ -972,11 +972,15 @@ bool all_zero(const uint8_t *p, int n) { for (int i = 0; i < n; i++) if (p[i]) r
 // curve_from_bytes :609-623).  The tower arithmetic lives on the device, so the check is the library's own rule for
 // records: [1] R through element_mul_zn leaves a point of the curve as it is and turns anything else into O.  Without a
 // usable device (text-only use of the library) the record is taken as written -- the first batch call applies the rule.
-bool twist_record_on_curve(const pbc_hip_pairing_t *P, int group, const uint8_t *rec, int bytes) {
+// 1: on the curve, 0: not (the record deserialises to O), -1: the device call failed (the message is set).  The twists have
+// b != 0, so the all-zero record is off the curve and [1] R != O exactly for the points of the curve -- whatever residue
+// class representatives the record's coordinates use (coordinates >= q are reduced on load).
+int twist_record_on_curve(const pbc_hip_pairing_t *P, int group, const uint8_t *rec, int bytes) {
+  if (P->device < 0) return 1;
   std::vector<uint8_t> one((size_t) P->len_zr, 0), out((size_t) bytes, 0);
   one.back() = 1;
-  if (pbc_hip_element_mul_zn_batch(const_cast<pbc_hip_pairing_t *>(P), group, out.data(), rec, one.data(), 1)) return true;
-  return memcmp(out.data(), rec, (size_t) bytes) == 0;
+  if (pbc_hip_element_mul_zn_batch(const_cast<pbc_hip_pairing_t *>(P), group, out.data(), rec, one.data(), 1)) return -1;
+  return all_zero(out.data(), bytes) ? 0 : 1;
 }
 }  // namespace
 
@@ -991,7 +995,11 @@ extern "C" int pbc_hip_element_snprint(const pbc_hip_pairing_t *P, int group, ch
     bool inf = all_zero(rec, 2 * cb) && P->type != 'a' && P->type != '1';     // (0, 0) lies on y^2 = x^3 + x
     if (!inf && text_curve_over_fq(S))   // element_from_bytes turns a record off the curve into O (curve_from_bytes, ecc/curve.c:609-623)
       inf = !text_on_curve(P, pbc_host::big_mod(pbc_host::big_from_be(rec, cb), mod), pbc_host::big_mod(pbc_host::big_from_be(rec + cb, cb), mod), mod);
-    if (!inf && !text_curve_over_fq(S)) inf = !twist_record_on_curve(P, group, rec, 2 * cb);
+    if (!inf && !text_curve_over_fq(S)) {
+      const int on = twist_record_on_curve(P, group, rec, 2 * cb);
+      if (on < 0) return -1;
+      inf = on == 0;
+    }
     if (inf) out = "O";
     else {
       out = "[";
@@ -1033,8 +1041,8 @@ extern "C" int pbc_hip_element_set_str(const pbc_hip_pairing_t *P, int group, ui
     memset(rec, 0, (size_t) 2 * cb);     // curve_set_str: not on the curve -> O, returns 0
     return 0;
   }
-  if (!text_curve_over_fq(S) && !all_zero(rec, 2 * cb) && !twist_record_on_curve(P, group, rec, 2 * cb)) {
-    memset(rec, 0, (size_t) 2 * cb);
+  if (!text_curve_over_fq(S) && !all_zero(rec, 2 * cb) && twist_record_on_curve(P, group, rec, 2 * cb) <= 0) {
+    memset(rec, 0, (size_t) 2 * cb);     // off the curve -> O; a failed device call also returns 0, with pbc_hip_last_error set
     return 0;
   }
   return (int) (cp - s + 1);

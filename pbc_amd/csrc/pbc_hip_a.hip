@@ -37,6 +37,31 @@ __global__ void __launch_bounds__(64 * NW, PBC_AW_WAVES) aw_pairing_kernel(uint8
   w.pairing_wave(gt + idx * L, g1 + idx * L, g2 + idx * L);
 }
 
+// pairing_pp_apply and few-term products on the wave routines (pairing_aw.cuh, round 5): one second argument / one term /
+// one product per workgroup of NW wavefronts
+template <int N, int NW>
+__global__ void __launch_bounds__(64 * NW, PBC_AW_WAVES) aw_pp_apply_kernel(uint8_t *gt, const uint32_t *__restrict__ tab, const uint32_t *__restrict__ valid,
+                                                                            const uint8_t *g2, KArgs<N> ka) {
+  constexpr int L = 8 * N;
+  const size_t idx = blockIdx.x;
+  AW<N, NW> w;
+  w.pp_apply_wave(gt + idx * L, tab, *valid != 0, g2 + idx * L);
+}
+template <int N, int NW>
+__global__ void __launch_bounds__(64 * NW, PBC_AW_WAVES) aw_miller_kernel(uint32_t *ws, const uint8_t *g1, const uint8_t *g2, KArgs<N> ka) {
+  constexpr int L = 8 * N;
+  const size_t idx = blockIdx.x;
+  AW<N, NW> w;
+  w.miller_record_wave(ws + idx * AW<N, NW>::WREC, g1 + idx * L, g2 + idx * L);
+}
+template <int N, int NW>
+__global__ void __launch_bounds__(64 * NW, PBC_AW_WAVES) aw_prod_finish_kernel(uint8_t *gt, const uint32_t *ws, int k, KArgs<N> ka) {
+  constexpr int L = 8 * N;
+  const size_t idx = blockIdx.x;
+  AW<N, NW> w;
+  w.prod_finish_wave(gt + idx * L, ws + idx * (size_t) k * AW<N, NW>::WREC, k);
+}
+
 // Products of Type-A pairings on the limb-form routines, one TERM per lane (AL::miller_record_lane): the Miller value
 // of term t goes to workspace record t; al_prod_finish_kernel then multiplies the k values of each product and runs its
 // final exponentiation (one product per lane).
@@ -228,6 +253,20 @@ int launch_a(pbc_hip_pairing_s *P, void *d_gt, const void *d_g1, const void *d_g
     }
     hipLaunchKernelGGL(al_pairing_kernel<16>, dim3(rg), dim3(kBlock), 0, s, (uint8_t *) d_gt,
                        (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, unit_counter(P, s), kargs<16>(P));
+  } else if (P->type == 'a' && !P->a_generic && k > 1 && n * (size_t) k <= P->a_wave_max) {
+    // a few terms in all (benchmark/multipairing.c's shape, or one element_prod_pairing through the hooks): a wave (four,
+    // up to hip_wave4_max terms) per TERM, then a wave (four) per PRODUCT -- the latency of one Miller loop and one final
+    // exponentiation on the wave routines instead of the 6.4 ms of a lane kernel (pairing_aw.cuh)
+    const size_t nt = n * (size_t) k;
+    uint32_t *ws = (uint32_t *) W.get(nt * AW<16, 1>::WREC * sizeof(uint32_t));
+    if (!ws) return 1;
+    if (nt <= P->a_wave4_max) {
+      hipLaunchKernelGGL((aw_miller_kernel<16, 4>), dim3((unsigned) nt), dim3(256), 0, s, ws, (const uint8_t *) d_g1, (const uint8_t *) d_g2, kargs<16>(P));
+      hipLaunchKernelGGL((aw_prod_finish_kernel<16, 4>), dim3((unsigned) n), dim3(256), 0, s, (uint8_t *) d_gt, (const uint32_t *) ws, k, kargs<16>(P));
+    } else {
+      hipLaunchKernelGGL((aw_miller_kernel<16, 1>), dim3((unsigned) nt), dim3(64), 0, s, ws, (const uint8_t *) d_g1, (const uint8_t *) d_g2, kargs<16>(P));
+      hipLaunchKernelGGL((aw_prod_finish_kernel<16, 1>), dim3((unsigned) n), dim3(64), 0, s, (uint8_t *) d_gt, (const uint32_t *) ws, k, kargs<16>(P));
+    }
   } else if (P->type == 'a' && !P->a_generic && !P->a_prod_shared) {
     // one term per lane, then one product per lane; at most a_prod_chunk terms in flight (their records: 160 B each)
     const size_t per = std::max<size_t>(1, P->a_prod_chunk / (size_t) k);
@@ -278,7 +317,14 @@ void pp_init_launch_a(pbc_hip_pairing_s *P, pbc_hip_pp_s *pp, const uint8_t *dg1
 int pp_apply_launch_a(pbc_hip_pp_s *pp, void *d_gt, const void *d_g2, size_t n, hipStream_t s) {
   pbc_hip_pairing_s *P = pp->P;
   unsigned grid = (unsigned) ((n + kBlock - 1) / kBlock);
-  if (P->type == 'a' && !P->a_generic) {
+  if (P->type == 'a' && !P->a_generic && n <= P->a_wave_max) {
+    // small batches (benchmark/benchmark.c:75-81 times pairing_pp_apply one at a time): a wave -- four, up to
+    // hip_wave4_max units -- per second argument (pairing_aw.cuh pp_apply_wave)
+    if (n <= P->a_wave4_max)
+      hipLaunchKernelGGL((aw_pp_apply_kernel<16, 4>), dim3((unsigned) n), dim3(256), 0, s, (uint8_t *) d_gt, pp->tab, pp->valid, (const uint8_t *) d_g2, kargs<16>(P));
+    else
+      hipLaunchKernelGGL((aw_pp_apply_kernel<16, 1>), dim3((unsigned) n), dim3(64), 0, s, (uint8_t *) d_gt, pp->tab, pp->valid, (const uint8_t *) d_g2, kargs<16>(P));
+  } else if (P->type == 'a' && !P->a_generic) {
     hipLaunchKernelGGL(al_pp_apply_kernel<16>, dim3(PBC_RGRID(al_pp_apply_kernel<16>)), dim3(kBlock), 0, s, (uint8_t *) d_gt, pp->tab, pp->valid,
                        (const uint8_t *) d_g2, n, unit_counter(P, s), kargs<16>(P));
   } else if (P->nlimb == 16) {

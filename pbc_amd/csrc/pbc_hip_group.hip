@@ -516,14 +516,16 @@ extern "C" int pbc_hip_element_pp_init(pbc_hip_element_pp_t **out, pbc_hip_pairi
   if (!out || !P || !in) return fail("null argument");
   if (group < 1 || group > 3) return fail("element_pp_init: group must be 1, 2 or 3 (GT)");
   if (P->device < 0) return fail("no HIP device: libpbc_hip has no CPU fallback");
-  int dev = P->device;
-  (void) hipGetDevice(&dev);
+  const int dev = P->device;           // the table lives on the device the pairing object was created on, whatever is current
+  DeviceGuard guard(dev);              // (as pbc_hip_pairing_pp_init)
   if (ensure_derived(P, 0)) return 1;
   const size_t lrec = group == 3 ? (size_t) P->lenT : group == 2 ? (size_t) P->len2 : (size_t) P->len1;
   const size_t rows = (size_t) P->len_zr;
   size_t words_el = 0;
   if (group == 3) PBC_DISPATCH_GT(P, words_el = G::WORDS_EL);
   else PBC_DISPATCH_G(P, group, words_el = F::WORDS_EL);
+  // (the field-width dispatch is resolved here, BEFORE anything is allocated: the launches below repeat the same switch
+  // and cannot take its failing default any more)
   const size_t units = group == 3 ? rows << kPpWin : rows * kPpRowLen;
   const size_t tab_bytes = units * words_el * 4 * (group == 3 ? 1 : 2);
   pbc_hip_element_pp_s *pp = new pbc_hip_element_pp_s{P, group, dev, nullptr, nullptr, false};
@@ -544,10 +546,12 @@ extern "C" int pbc_hip_element_pp_init(pbc_hip_element_pp_t **out, pbc_hip_pairi
   } else {
     PBC_DISPATCH_G(P, group, hipLaunchKernelGGL(ec_pp_init_kernel<F>, dim3(grid), dim3(kBlock), 0, 0, pp->tab, bflags.as<uint8_t>(), (const uint8_t *) pp->base,
                                                 P->len_zr, units, kargs<F::NW>(P)));
+  }
+  if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) return bail("the table kernel failed");
+  if (group != 3) {                    // (the kernel's status first: a faulted kernel is not a failed copy)
     if (hipMemcpy(flags.data(), bflags.p, units, hipMemcpyDeviceToHost) != hipSuccess) return bail("D2H copy failed");
     for (uint8_t f : flags) pp->complete_only |= f != 0;
   }
-  if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) return bail("the table kernel failed");
   *out = pp;
   return 0;
 }
@@ -594,9 +598,20 @@ extern "C" int pbc_hip_element_pp_pow_zn_batch_dev(pbc_hip_element_pp_t *pp, voi
 extern "C" int pbc_hip_element_pp_pow_zn_batch(pbc_hip_element_pp_t *pp, uint8_t *out, const uint8_t *zr, size_t n) {
   if (!pp) return fail("null pp");
   pbc_hip_pairing_s *P = pp->P;
-  if (P->ndev > 0) return fail("element_pp_pow_zn: the table lives on one device; call with the object's device set cleared");
   const size_t lo = pp->group == 3 ? (size_t) P->lenT : pp->group == 2 ? (size_t) P->len2 : (size_t) P->len1;
   DeviceGuard guard(pp->device);
+  if (P->ndev > 0) {
+    // the object has a device set, the table lives on ONE device: this call runs there, staged (the set stays as it is
+    // for the pairing entry points)
+    if (!n) return 0;
+    DevBuf bz, bo;
+    HIP_TRY(bz.alloc(n * (size_t) P->len_zr));
+    HIP_TRY(bo.alloc(n * lo));
+    HIP_TRY(hipMemcpy(bz.p, zr, n * (size_t) P->len_zr, hipMemcpyHostToDevice));
+    if (pp_pow_launch(pp, bo.p, bz.p, n, 0, nullptr)) return 1;
+    HIP_TRY(hipMemcpy(out, bo.p, n * lo, hipMemcpyDeviceToHost));
+    return 0;
+  }
   return run_host_generic(P, out, lo, zr, (size_t) P->len_zr, nullptr, 0, n,
                           [pp](void *d_out, const void *d_a, const void *, size_t m, hipStream_t s, const OwnWs *own) {
                             return pp_pow_launch(pp, d_out, d_a, m, s, own);

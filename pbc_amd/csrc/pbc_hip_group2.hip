@@ -12,10 +12,19 @@ __global__ void __launch_bounds__(kBlock, 2) ec_affine_op_kernel(int op, uint8_t
   ec_affine_op_lane<F>(op, out + idx * L, a + idx * L, b ? b + idx * L : a + idx * L);
 }
 // element_pow2_zn / element_pow3_zn on G1 / G2 and on GT
+// (fast pass: one doubling + one incomplete addition per bit, lanes it cannot finish are flagged; complete pass: the
+// flagged lanes -- flags == null: every lane)
 template <class F>
-__global__ void __launch_bounds__(kBlock, 2) ec_multi_mul_kernel(uint8_t *out, MultiArgs M, int k, int zlen, size_t n, KArgs<F::NW> ka) {
+__global__ void __launch_bounds__(kBlock, 2) ec_multi_mul_fast_kernel(uint8_t *out, MultiArgs M, int k, int zlen, uint8_t *flags, size_t n, KArgs<F::NW> ka) {
   size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
   if (idx >= n) return;
+  flags[idx] = ec_multi_mul_fast_lane<F>(out + idx * 2 * (size_t) F::bytes(), M, idx, k, zlen) ? 0 : 1;
+}
+template <class F>
+__global__ void __launch_bounds__(kBlock, 2) ec_multi_mul_kernel(uint8_t *out, MultiArgs M, int k, int zlen, const uint8_t *flags, size_t n, KArgs<F::NW> ka) {
+  size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
+  if (idx >= n) return;
+  if (flags && !flags[idx]) return;
   ec_multi_mul_lane<F>(out + idx * 2 * (size_t) F::bytes(), M, idx, k, zlen);
 }
 template <class G>
@@ -118,14 +127,42 @@ extern "C" int pbc_hip_element_double_batch_dev(pbc_hip_pairing_t *P, int group,
 
 // ---- multi-exponentiations ----------------------------------------------------------------------------------------------
 static size_t group_len(const pbc_hip_pairing_s *P, int group) { return (size_t) (group == 1 ? P->len1 : group == 2 ? P->len2 : P->lenT); }
-static int multi_launch(pbc_hip_pairing_s *P, int group, int k, void *d_out, const MultiArgs &M, size_t n, hipStream_t s) {
+static int multi_launch(pbc_hip_pairing_s *P, int group, int k, void *d_out, const MultiArgs &M, size_t n, hipStream_t s, const OwnWs *own) {
   if (!n) return 0;
   const unsigned grid = (unsigned) ((n + kBlock - 1) / kBlock);
   uint8_t *o = (uint8_t *) d_out;
   if (group == 3) {
-    PBC_DISPATCH_GT2(P, hipLaunchKernelGGL(gt_multi_pow_kernel<G>, dim3(grid), dim3(kBlock), 0, s, o, M, k, P->len_zr, n, kargs<G::NW>(P)));
+    // GT: the product of the k single powers on the library's own element_pow_zn kernels (Lucas ladder on the trace for
+    // type a, cyclotomic squarings for type f, ...: each is several times cheaper than a generic square-and-multiply,
+    // so the composition beats a joint ladder over plain F_q^k products -- executed multiply-adds per unit, a.param:
+    // 2 x 196 k + one product against 628 k; f.param: 2 x 760 k against 2.59 M).  gt_multi_pow_kernel stays for
+    // "hip_group_slow 1" (and as the reference point of the tests).
+    if (P->group_slow) {
+      PBC_DISPATCH_GT2(P, hipLaunchKernelGGL(gt_multi_pow_kernel<G>, dim3(grid), dim3(kBlock), 0, s, o, M, k, P->len_zr, n, kargs<G::NW>(P)));
+      HIP_TRY(hipGetLastError());
+      return 0;
+    }
+    if (M.astride != (size_t) P->lenT || M.zstride != (size_t) P->len_zr) return fail("internal: packed records on the GT composition path");
+    void *tmp = nullptr;
+    HIP_TRY(hipMallocAsync(&tmp, n * (size_t) P->lenT, s));
+    int rc = pbc_hip_element_pow_zn_GT_batch_dev(P, d_out, M.a[0], M.z[0], n, s);
+    for (int j = 1; j < k && !rc; j++) {
+      rc = pbc_hip_element_pow_zn_GT_batch_dev(P, tmp, M.a[j], M.z[j], n, s);
+      if (!rc) rc = pbc_hip_element_mul_GT_batch_dev(P, d_out, d_out, tmp, n, s);
+    }
+    (void) hipFreeAsync(tmp, s);
+    return rc;
+  }
+  if (P->group_slow) {
+    PBC_DISPATCH_G2(P, group, hipLaunchKernelGGL(ec_multi_mul_kernel<F>, dim3(grid), dim3(kBlock), 0, s, o, M, k, P->len_zr, (const uint8_t *) nullptr, n, kargs<F::NW>(P)));
   } else {
-    PBC_DISPATCH_G2(P, group, hipLaunchKernelGGL(ec_multi_mul_kernel<F>, dim3(grid), dim3(kBlock), 0, s, o, M, k, P->len_zr, n, kargs<F::NW>(P)));
+    ProdWs W(P, s, own);
+    uint8_t *flags = (uint8_t *) W.get(n);
+    if (!flags) return 1;
+    PBC_DISPATCH_G2(P, group, {
+      hipLaunchKernelGGL(ec_multi_mul_fast_kernel<F>, dim3(grid), dim3(kBlock), 0, s, o, M, k, P->len_zr, flags, n, kargs<F::NW>(P));
+      hipLaunchKernelGGL(ec_multi_mul_kernel<F>, dim3(grid), dim3(kBlock), 0, s, o, M, k, P->len_zr, (const uint8_t *) flags, n, kargs<F::NW>(P));
+    });
   }
   HIP_TRY(hipGetLastError());
   return 0;
@@ -140,6 +177,33 @@ static int multi_host(pbc_hip_pairing_t *P, int group, int k, uint8_t *out, cons
   if (!n) return 0;
   if (prepare(P)) return 1;
   const size_t lp = group_len(P, group), lz = (size_t) P->len_zr;
+  if (group == 3 && !P->group_slow) {
+    // GT takes the composition of the single-base kernels, which wants each base / scalar array by itself: staged on the
+    // object's first device
+    DeviceGuard guard(P->ndev > 0 ? P->devs[0] : P->device);
+    DevBuf ba[3], bz[3], bo;
+    const void *da[3] = {nullptr, nullptr, nullptr}, *dz[3] = {nullptr, nullptr, nullptr};
+    for (int j = 0; j < k; j++) {
+      HIP_TRY(ba[j].alloc(n * lp));
+      HIP_TRY(bz[j].alloc(n * lz));
+      HIP_TRY(hipMemcpy(ba[j].p, a[j], n * lp, hipMemcpyHostToDevice));
+      HIP_TRY(hipMemcpy(bz[j].p, z[j], n * lz, hipMemcpyHostToDevice));
+      da[j] = ba[j].p;
+      dz[j] = bz[j].p;
+    }
+    HIP_TRY(bo.alloc(n * lp));
+    MultiArgs M;
+    for (int j = 0; j < 3; j++) {
+      M.a[j] = (const uint8_t *) da[j < k ? j : 0];
+      M.z[j] = (const uint8_t *) dz[j < k ? j : 0];
+    }
+    M.astride = lp;
+    M.zstride = lz;
+    if (multi_launch(P, group, k, bo.p, M, n, 0, nullptr)) return 1;
+    HIP_TRY(hipStreamSynchronize(0));
+    HIP_TRY(hipMemcpy(out, bo.p, n * lp, hipMemcpyDeviceToHost));
+    return 0;
+  }
   std::vector<uint8_t> A(n * lp * k), Z(n * lz * k);
   for (size_t i = 0; i < n; i++)
     for (int j = 0; j < k; j++) {
@@ -147,7 +211,7 @@ static int multi_host(pbc_hip_pairing_t *P, int group, int k, uint8_t *out, cons
       memcpy(&Z[(i * k + j) * lz], z[j] + i * lz, lz);
     }
   return run_host_generic(P, out, lp, A.data(), lp * k, Z.data(), lz * k, n,
-                          [P, group, k, lp, lz](void *d_out, const void *d_a, const void *d_b, size_t m, hipStream_t s, const OwnWs *) {
+                          [P, group, k, lp, lz](void *d_out, const void *d_a, const void *d_b, size_t m, hipStream_t s, const OwnWs *own) {
                             MultiArgs M;
                             for (int j = 0; j < 3; j++) {
                               M.a[j] = (const uint8_t *) d_a + (j < k ? j : 0) * lp;
@@ -155,7 +219,7 @@ static int multi_host(pbc_hip_pairing_t *P, int group, int k, uint8_t *out, cons
                             }
                             M.astride = lp * k;
                             M.zstride = lz * k;
-                            return multi_launch(P, group, k, d_out, M, m, s);
+                            return multi_launch(P, group, k, d_out, M, m, s, own);
                           }, false);
 }
 static int multi_dev(pbc_hip_pairing_t *P, int group, int k, void *d_out, const void *const *a, const void *const *z, size_t n, void *stream) {
@@ -171,7 +235,7 @@ static int multi_dev(pbc_hip_pairing_t *P, int group, int k, void *d_out, const 
   }
   M.astride = group_len(P, group);
   M.zstride = (size_t) P->len_zr;
-  return multi_launch(P, group, k, d_out, M, n, (hipStream_t) stream);
+  return multi_launch(P, group, k, d_out, M, n, (hipStream_t) stream, nullptr);
 }
 extern "C" int pbc_hip_element_pow2_zn_batch(pbc_hip_pairing_t *P, int group, uint8_t *out, const uint8_t *a1, const uint8_t *n1,
                                              const uint8_t *a2, const uint8_t *n2, size_t n) {

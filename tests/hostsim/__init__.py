@@ -64,6 +64,28 @@ class HostSim:
             raise RuntimeError("no wave routine for this pairing")
         return out
 
+    def pp_wave(self, g1, g2):
+        """pairing_pp_apply on the wave routine (pairing_aw.cuh pp_apply_wave): one first argument, n second arguments"""
+        g1 = np.ascontiguousarray(g1, np.uint8)
+        g2 = np.ascontiguousarray(g2, np.uint8)
+        n = g2.size // self.len2
+        out = np.empty((n, self.lenT), np.uint8)
+        self.L.hostsim_pp_wave.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_size_t]
+        if self.L.hostsim_pp_wave(self.h, out.ctypes.data, g1.ctypes.data, g2.ctypes.data, n):
+            raise RuntimeError("no wave routine for this pairing")
+        return out
+
+    def prod_wave(self, g1, g2, k):
+        """element_prod_pairing on the wave routines: a Miller record per term, one finish per product"""
+        g1 = np.ascontiguousarray(g1, np.uint8)
+        g2 = np.ascontiguousarray(g2, np.uint8)
+        n = g1.size // self.len1 // k
+        out = np.empty((n, self.lenT), np.uint8)
+        self.L.hostsim_prod_wave.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_size_t, ctypes.c_int]
+        if self.L.hostsim_prod_wave(self.h, out.ctypes.data, g1.ctypes.data, g2.ctypes.data, n, k):
+            raise RuntimeError("no wave routine for this pairing")
+        return out
+
     def pp(self, g1, g2):
         g1 = np.ascontiguousarray(g1, np.uint8)
         g2 = np.ascontiguousarray(g2, np.uint8)

@@ -127,6 +127,31 @@ int hostsim_pairing_wave(void *h, uint8_t *gt, const uint8_t *g1, const uint8_t 
   activate(P);
   return 0;
 }
+// pairing_pp_apply and k-term products on the wave routines (pairing_aw.cuh pp_apply_wave / miller_record_wave /
+// prod_finish_wave); the table is the one the library's a_pp_init_lane writes
+int hostsim_pp_wave(void *h, uint8_t *gt, const uint8_t *g1, const uint8_t *g2, size_t n) {
+  pbc_hip_pairing_s *P = (pbc_hip_pairing_s *) h;
+  if (P->type != 'a' || P->a_generic) return 1;
+  activate(P, true);
+  std::vector<uint32_t> tab((size_t) (P->a.exp2 + 1) * 3 * 16);
+  const bool ok = a_pp_init_lane<16>(tab.data(), g1);
+  for (size_t u = 0; u < n; u++) { AW<16, 1> w; w.pp_apply_wave(gt + u * P->lenT, tab.data(), ok, g2 + u * P->len2); }
+  activate(P);
+  return 0;
+}
+int hostsim_prod_wave(void *h, uint8_t *gt, const uint8_t *g1, const uint8_t *g2, size_t n, int k) {
+  pbc_hip_pairing_s *P = (pbc_hip_pairing_s *) h;
+  if (P->type != 'a' || P->a_generic) return 1;
+  activate(P, true);
+  for (size_t u = 0; u < n; u++) {
+    std::vector<AW<16, 1>::wrec> rec((size_t) k);
+    for (int t = 0; t < k; t++) { AW<16, 1> w; w.miller_record_wave(rec[t], g1 + (u * k + t) * P->len1, g2 + (u * k + t) * P->len2); }
+    AW<16, 1> w;
+    w.prod_finish_wave(gt + u * P->lenT, rec.data(), k);
+  }
+  activate(P);
+  return 0;
+}
 // n units of k terms each, one lane after the other
 int hostsim_prod_pairing(void *h, uint8_t *gt, const uint8_t *g1, const uint8_t *g2, size_t n, int k) {
   pbc_hip_pairing_s *P = (pbc_hip_pairing_s *) h;
@@ -459,7 +484,13 @@ int hostsim_multi(void *h, int group, int k, uint8_t *out, const uint8_t *a1, co
       else if (P->type == 'f') { HS_DISPATCH_F(P->nlimb, gt_multi_pow_lane<GtF<N>>(out + i * L, M, i, k, P->len_zr)); }
       else { HS_DISPATCH_D(P, (gt_multi_pow_lane<GtD<N, DEG>>(out + i * L, M, i, k, P->len_zr))); }
     } else {
-      HS_DISPATCH_G(P, group, ec_multi_mul_lane<F>(out + i * L, M, i, k, P->len_zr));
+      // as the library: the fast pass, and the complete routine for the lanes it reports
+      bool ok = false;
+      if (!hostsim_slow_group) { HS_DISPATCH_G(P, group, ok = ec_multi_mul_fast_lane<F>(out + i * L, M, i, k, P->len_zr)); }
+      if (!ok) {
+        if (!hostsim_slow_group) hostsim_fallbacks++;
+        HS_DISPATCH_G(P, group, ec_multi_mul_lane<F>(out + i * L, M, i, k, P->len_zr));
+      }
     }
   }
   return 0;

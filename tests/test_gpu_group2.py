@@ -253,3 +253,38 @@ def test_new_entry_points_on_a_device_set(hips):
     assert np.array_equal(P.element_pow_multi(1, [v.g1[i], v.g1[j]], [Z1, Z2]), want_pow)
     assert np.array_equal(P.zr_op("mul", Z1, Z2), want_zr)
     P.clear()
+
+
+def test_fixed_base_table_with_a_device_set_and_twist_records_with_unreduced_coordinates(hips):
+    """ADVICE r4: (1) element_pp_pow_zn on an object that has a device set runs on the table's device instead of failing;
+    (2) a G2 record of a twist whose coordinate is written as x + q (still below 2^(8 len)) is the same point: it prints
+    as the canonical record does, and parses back to it."""
+    import pbc_amd
+    v = golden("d_chain256.vec")
+    P = pbc_amd.Pairing(_param("d159"))
+    pp = P.element_pp_init(2, v.g2[3])
+    r = _order("d")
+    zl = P.length_in_bytes_Zr
+    rng = np.random.default_rng(43)
+    Z = np.stack([_be(int.from_bytes(rng.bytes(zl), "big") % r, zl) for _ in range(300)])
+    want = pp.pow_zn(Z)
+    assert np.array_equal(want, P.element_mul_zn(2, np.tile(v.g2[3], (300, 1)), Z))
+    P.use_devices([0, 0])
+    assert np.array_equal(pp.pow_zn(Z), want)
+    P.use_devices([])
+    q = param_value("d159", "q")
+    fb = P.length_in_bytes_Fq
+    rec = v.g2[5].copy()
+    x0 = int.from_bytes(rec[:fb].tobytes(), "big")
+    assert x0 + q < 1 << (8 * fb)
+    big = rec.copy()
+    big[:fb] = _be(x0 + q, fb)
+    text, _ = P.element_snprint(2, rec)
+    assert text != "O" and P.element_snprint(2, big)[0] == text
+    back, used = P.element_set_str(2, text)
+    assert used == len(text) and np.array_equal(back, rec)
+    off = rec.copy()
+    off[-1] ^= 1
+    assert P.element_snprint(2, off)[0] == "O"
+    pp.clear()
+    P.clear()

@@ -58,3 +58,43 @@ def test_wave_pairings_device_buffers_and_streams(hip_a):
     s.synchronize()
     assert np.array_equal(out[:n].cpu().numpy(), v.gt[:n])
     assert (out[n] == 0xA5).all()
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 300, 1024, 1025, 5120, 5121])
+def test_wave_pp_apply_matches_the_throughput_kernel(hip_a, n):
+    """pairing_pp_apply on small batches (round 5: pp_apply_wave, four wavefronts per unit up to hip_wave4_max, one up to
+    hip_wave_max) = the lane kernel's bytes = element_pairing's; first arguments that deserialise to O included"""
+    import pbc_amd
+    v = golden("a_chain1024.vec")
+    T = pbc_amd.Pairing(_param("a") + "hip_wave_max 0\n")
+    j = (np.arange(n) * 13 + n) % v.n
+    g2 = np.ascontiguousarray(v.g2[j])
+    for base in (v.g1[5], np.zeros_like(v.g1[5])):
+        pp, ppT = hip_a.pp_init(base), T.pp_init(base)
+        got = pp.apply(g2)
+        assert np.array_equal(got, ppT.apply(g2))
+        m = min(n, 64)
+        assert np.array_equal(got[:m], hip_a.element_pairing(np.tile(base, (m, 1)), g2[:m]))
+        pp.clear()
+        ppT.clear()
+    T.clear()
+
+
+@pytest.mark.parametrize("n,k", [(1, 2), (1, 5), (3, 8), (64, 16), (200, 5), (341, 3), (1024, 5), (1025, 5)])
+def test_wave_products_match_the_throughput_kernels(hip_a, n, k):
+    """few-term products with n k <= hip_wave_max (round 5: a wave -- four up to hip_wave4_max terms -- per term, then one
+    per product): the bytes of the one-term-per-lane kernels and of the reference's product vectors"""
+    import pbc_amd
+    v = golden("a_chain1024.vec")
+    T = pbc_amd.Pairing(_param("a") + "hip_wave_max 0\n")
+    t = np.arange(n * k)
+    g1, g2 = np.ascontiguousarray(v.g1[(t * 5 + 2) % v.n]), np.ascontiguousarray(v.g2[(t * 3 + k) % v.n])
+    g1[::37] ^= 1                                             # off-curve first arguments: their products are 1
+    assert np.array_equal(hip_a.element_prod_pairing(g1, g2, k), T.element_prod_pairing(g1, g2, k))
+    T.clear()
+
+
+def test_wave_products_on_the_reference_vectors(hip_a):
+    for name in ("a_prod2x8.vec", "a_prod3x10_edge.vec", "a_prod16x4.vec", "a_prodfull3x4.vec"):
+        v = golden(name)
+        assert np.array_equal(hip_a.element_prod_pairing(v.g1, v.g2, v.k), v.gt), name

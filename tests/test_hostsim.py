@@ -577,3 +577,23 @@ def test_limb_form_g1_ladder_of_the_5_word_fields_on_host(oracles, key, pname, n
     bad = P.copy()
     bad[2, -1] ^= 1                                            # off the curve: O
     assert np.array_equal(S.group(0, bad, Z), O.g_mul(1, bad, Z))
+
+
+def test_pp_apply_and_products_on_the_wave_routines_on_host(sims, oracles):
+    """round 5 (pairing_aw.cuh pp_apply_wave / miller_record_wave / prod_finish_wave): pairing_pp_apply and few-term
+    products on the one-unit-per-wavefront routines give the reference's bytes -- same values as element_pairing /
+    element_prod_pairing, edge cases (off-curve arguments, O) included"""
+    S = sims["a"]
+    v = golden("a_rand32.vec")
+    assert np.array_equal(S.pp_wave(v.g1[3], v.g2[:5]), oracles["a"].pairing_batch(np.tile(v.g1[3], (5, 1)), v.g2[:5]))
+    e = golden("a_edge20.vec")
+    for i in (0, 7, 13):                                      # whatever the fixture holds there: valid or not
+        got = S.pp_wave(e.g1[i], e.g2[i:i + 2])
+        assert np.array_equal(got, oracles["a"].pairing_batch(np.tile(e.g1[i], (2, 1)), e.g2[i:i + 2]))
+    p = golden("a_prod2x8.vec")
+    assert np.array_equal(S.prod_wave(p.g1[:6], p.g2[:6], 2), p.gt[:3])
+    pe = golden("a_prod3x10_edge.vec")
+    assert np.array_equal(S.prod_wave(pe.g1, pe.g2, 3), pe.gt)
+    m = golden("a_160_512_mm_rand6.vec")                       # sign1 = -1: the addition step negates P
+    Sm = sims["a_160_512_mm"]
+    assert np.array_equal(Sm.pp_wave(m.g1[1], m.g2[1:3]), np.concatenate([m.gt[1:2], Sm.prod_pairing(m.g1[1:2], m.g2[2:3], 1)]))

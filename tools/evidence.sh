@@ -7,19 +7,19 @@
 R="${GRAFT_REPO_ROOT:-/root/repo}"; ROUND=${ROUND:-r05}; O=$R/gpurun_out/ev_$ROUND; mkdir -p $O; cd $R || exit 1
 cp .evidence_head $O/HEAD 2>/dev/null || { echo "no .evidence_head: start this through tools/collect.sh"; exit 1; }
 [ -z "$WITH_TESTS" ] || { timeout 1500 python -m pytest tests -m gpu -q --maxfail 10 > $O/pytest.log 2>&1; tail -n 3 $O/pytest.log; }
-for w in ${BENCH_WL-a d f a-prod16 d-prod16 a-pp d-pp g e a1 f256 d190 d201 d224}; do
-  NOCPU="--no-cpu-baseline"; case " ${CPU_WL-a d f a-prod16} " in *" $w "*) NOCPU="";; esac     # the reference's CPU rate beside the BASELINE configs only
+for w in ${BENCH_WL-a d f a-prod16 d-prod16 a-pp d-pp g g-pp e a1 a1-pp f256 d190 d201 d224}; do
+  NOCPU="--no-cpu-baseline"; case " ${CPU_WL-a d f a-prod16} " in *" $w "*) NOCPU="";; esac     # live CPU leg beside the BASELINE configs; the others carry the build container's figure (profiles/r05_cpu_baselines.json)
   timeout 400 python bench.py --workload $w --steps 3 --warmup 1 $NOCPU > $O/bench_$w.json 2> $O/bench_$w.err
 done
-for w in ${GROUP_WL-a-g1-mul a-gt-pow a-hash-g1 a-g1-pp a-gt-pp a-bls-verify d-g1-mul d-g2-mul d-gt-pow d-hash-g1 d-g1-pp d-gt-pp f-g1-mul f-g2-mul f-gt-pow f-hash-g1 f-g1-pp f-gt-pp}; do
-  NOCPU="--no-cpu-baseline"; case " ${GROUP_CPU_WL-a-g1-mul a-gt-pow a-hash-g1 a-bls-verify d-g1-mul f-g1-mul f-gt-pow} " in *" $w "*) NOCPU="";; esac
+for w in ${GROUP_WL-a-g1-mul a-gt-pow a-hash-g1 a-g1-pp a-gt-pp a-bls-verify a-compress a-decompress a-g1-add a-zr-inv a-g1-pow2 a-gt-pow2 d-g1-mul d-g2-mul d-gt-pow d-hash-g1 d-g1-pp d-gt-pp d-compress d-decompress d-g1-add d-zr-inv d-g1-pow2 d-gt-pow2 f-g1-mul f-g2-mul f-gt-pow f-hash-g1 f-g1-pp f-gt-pp f-compress f-decompress f-g1-add f-zr-inv f-g1-pow2 f-gt-pow2}; do
+  NOCPU="--no-cpu-baseline"; case " ${GROUP_CPU_WL-a-g1-mul a-bls-verify} " in *" $w "*) NOCPU="";; esac
   timeout 300 python bench.py --workload $w --steps 3 --warmup 1 $NOCPU > $O/bench_$w.json 2> $O/bench_$w.err
 done
 [ -n "$SKIP_SWEEP" ] || for w in a f; do timeout 300 python bench.py --workload $w --sweep > $O/sweep_$w.json 2> $O/sweep_$w.err; done
 [ -n "$SKIP_SMALL" ] || { timeout 300 python tools/wave_latency.py 1 256 512 1024 2048 4096 5120 > $O/wave_latency.txt 2>&1
   timeout 200 python tools/tail_latency.py > $O/tail.txt 2>&1
   export PBC_HIP_LIB=$R/pbc_amd/libpbc_hip.so
-  for p in a d159; do timeout 120 oracle/_ref/glue_test pbc_amd/param/$p.param 200 latency 2>&1 | tail -n 1; timeout 200 oracle/_ref/glue_test pbc_amd/param/$p.param 1048576 bench 2>&1 | tail -n 1; done > $O/glue.txt
+  [ -n "$SKIP_GLUE" ] || for p in a d159; do timeout 120 oracle/_ref/glue_test pbc_amd/param/$p.param 200 latency 2>&1 | tail -n 1; timeout 200 oracle/_ref/glue_test pbc_amd/param/$p.param 1048576 bench 2>&1 | tail -n 1; done > $O/glue.txt
   unset PBC_HIP_LIB; }
 cd /tmp && export TMPDIR=/tmp
 for w in ${PMC_WL-a d f a-prod16 d-prod16 d190 a-pp a-g1-mul f-gt-pow}; do

@@ -67,6 +67,14 @@ def main():
                 S.compress(0, g1[:1])
             else:
                 S.compress(1, comp)
+        elif op == "g1add":
+            S.affine_op(0, 1, g1[:1], g1[1:2])
+        elif op == "zrinv":
+            z[0, -1] |= 1
+            S.zr_op(3, z)
+        elif op in ("g1pow2", "gtpow2"):
+            src = g1 if op == "g1pow2" else gt
+            S.multi(1 if op == "g1pow2" else 3, [src[:1], src[1:2]], [z, z[:, ::-1].copy()])
         elif op in ("g1pp", "gtpp"):
             grp = 1 if op == "g1pp" else 3
             base = g1[5] if grp == 1 else gt[5]

@@ -36,6 +36,9 @@ inline int fail(const char *fmt, ...) {
 #ifndef PBC_A_WAVE_MAX
 #define PBC_A_WAVE_MAX 5120
 #endif
+#ifndef PBC_A_WAVE2_MAX
+#define PBC_A_WAVE2_MAX 0              // two wavefronts per unit above hip_wave4_max, up to this size (0: none; measured cut-overs: DESIGN 4.2b)
+#endif
 #ifndef PBC_A_WAVE4_MAX
 #define PBC_A_WAVE4_MAX 1024
 #endif
@@ -56,6 +59,7 @@ struct pbc_hip_pairing_s {
   int resident_slots;        // > 0: workgroups of a resident launch instead of the occupancy query ("hip_resident_slots N", tests)
   size_t host_chunk;         // host-buffer entry points: units per chunk when the parameter text says "hip_host_chunk N" (0: default)
   size_t a_wave4_max;        // ... and up to this size four wavefronts per pairing ("hip_wave4_max N")
+  size_t a_wave2_max;        // ... and between the two, up to this size, two ("hip_wave2_max N", round 5)
   size_t a_wave_max;         // type a fast path, element_pairing: batches up to this size take one WAVEFRONT per pairing (pairing_aw.cuh; "hip_wave_max N", 0 = never)
   size_t a_prod_chunk;       // ... otherwise: terms per launch of the one-term-per-lane kernels ("hip_prod_chunk N", tests)
   int len_fq, len1, len2, lenT;
@@ -263,6 +267,9 @@ static int init_type_a(pbc_hip_pairing_s *P, const char *txt, size_t len) {
     int wave4_max = PBC_A_WAVE4_MAX;
     param_int(txt, len, "hip_wave4_max", wave4_max);
     P->a_wave4_max = wave4_max < 0 ? 0 : (size_t) wave4_max;
+    int wave2_max = PBC_A_WAVE2_MAX;
+    param_int(txt, len, "hip_wave2_max", wave2_max);
+    P->a_wave2_max = wave2_max < 0 ? 0 : (size_t) wave2_max;
   } else {
     // any other size up to 1056 bits: the type a1 kernels (plain double-and-add over the bits of r;
     // functions with the same divisor up to vertical lines, which the final power removes) on the

@@ -32,7 +32,7 @@ template <int N> __shared__ uint32_t g_lds_aw_t[AW_SLOTS * 64];
 #define g_lds_aw g_lds_aw_t<N>
 #endif
 
-template <int N, int NW = 1>                 // NW: wavefronts that work on ONE pairing (1, or 4 = a 256-lane workgroup: see mul4)
+template <int N, int NW = 1>                 // NW: wavefronts that work on ONE pairing (1, 2 or 4 = a 128- / 256-lane workgroup: see round_nw)
 struct AW {
   typedef AL<N> A;
   typedef typename A::el el;
@@ -228,7 +228,27 @@ struct AW {
   PBC_DEV void round_nw(W *r, const W *a0, const W *b0, const W *a1, const W *b1, int count) {
     const int w = wave();
     const int base = 6 + 4 * par;
-    if (w < count) {
+    if constexpr (NW == 2) {
+      // two wavefronts per pairing (round 5): wave w forms products w and w + 2 -- both in ONE instruction stream when it
+      // has two (lanes_sop_x2: the dependency chain of a step leaves the pipe half empty) -- so a round of four costs each
+      // wave one double product instead of four waves one single product each and a barrier with two of them idle
+      const bool two = w + 2 < count;                          // wave-uniform
+      if (w < count) {
+        const W x0 = w ? a0[1] : a0[0], y0 = w ? b0[1] : b0[0], x2 = w ? a0[3] : a0[2], y2 = w ? b0[3] : b0[2];
+        if (TERMS == 1) {
+          if (two) {
+            const W2 t = mul2_fn(x0, y0, x2, y2, qq, nv, mk);
+            put_slot(t.r0, base + w);
+            put_slot(t.r1, base + w + 2);
+          } else {
+            put_slot(mul_fn(x0, y0, qq, nv, mk), base + w);
+          }
+        } else {                                               // (sums of two products come in pairs: count == 2)
+          const W x1 = w ? a1[1] : a1[0], y1 = w ? b1[1] : b1[0];
+          put_slot(sop2_fn(x0, y0, x1, y1, qq, nv, mk), base + w);
+        }
+      }
+    } else if (w < count) {
       W x0, y0, x1 = 0u, y1 = 0u;                                 // w is wave-uniform: a scalar branch, no per-lane selects
       switch (w) {
         case 0: x0 = a0[0]; y0 = b0[0]; if (TERMS == 2) { x1 = a1[0]; y1 = b1[0]; } break;

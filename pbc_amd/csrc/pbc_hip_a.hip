@@ -236,6 +236,8 @@ int launch_a(pbc_hip_pairing_s *P, void *d_gt, const void *d_g1, const void *d_g
   if (P->type == 'a' && !P->a_generic && k == 1 && n <= P->a_wave_max) {
     if (n <= P->a_wave4_max)
       hipLaunchKernelGGL((aw_pairing_kernel<16, 4>), dim3((unsigned) n), dim3(256), 0, s, (uint8_t *) d_gt, (const uint8_t *) d_g1, (const uint8_t *) d_g2, kargs<16>(P));
+    else if (n <= P->a_wave2_max)
+      hipLaunchKernelGGL((aw_pairing_kernel<16, 2>), dim3((unsigned) n), dim3(128), 0, s, (uint8_t *) d_gt, (const uint8_t *) d_g1, (const uint8_t *) d_g2, kargs<16>(P));
     else
       hipLaunchKernelGGL((aw_pairing_kernel<16, 1>), dim3((unsigned) n), dim3(64), 0, s, (uint8_t *) d_gt, (const uint8_t *) d_g1, (const uint8_t *) d_g2, kargs<16>(P));
   } else if (P->type == 'a' && !P->a_generic && k == 1) {
@@ -322,6 +324,8 @@ int pp_apply_launch_a(pbc_hip_pp_s *pp, void *d_gt, const void *d_g2, size_t n, 
     // hip_wave4_max units -- per second argument (pairing_aw.cuh pp_apply_wave)
     if (n <= P->a_wave4_max)
       hipLaunchKernelGGL((aw_pp_apply_kernel<16, 4>), dim3((unsigned) n), dim3(256), 0, s, (uint8_t *) d_gt, pp->tab, pp->valid, (const uint8_t *) d_g2, kargs<16>(P));
+    else if (n <= P->a_wave2_max)
+      hipLaunchKernelGGL((aw_pp_apply_kernel<16, 2>), dim3((unsigned) n), dim3(128), 0, s, (uint8_t *) d_gt, pp->tab, pp->valid, (const uint8_t *) d_g2, kargs<16>(P));
     else
       hipLaunchKernelGGL((aw_pp_apply_kernel<16, 1>), dim3((unsigned) n), dim3(64), 0, s, (uint8_t *) d_gt, pp->tab, pp->valid, (const uint8_t *) d_g2, kargs<16>(P));
   } else if (P->type == 'a' && !P->a_generic) {

@@ -127,34 +127,38 @@ extern "C" int pbc_hip_element_double_batch_dev(pbc_hip_pairing_t *P, int group,
 
 // ---- multi-exponentiations ----------------------------------------------------------------------------------------------
 static size_t group_len(const pbc_hip_pairing_s *P, int group) { return (size_t) (group == 1 ? P->len1 : group == 2 ? P->len2 : P->lenT); }
+// Two routes.  DEFAULT: the composition of the library's tuned single-base kernels -- k x element_mul_zn / element_pow_zn
+// (limb-form windowed ladders on G1, Lucas ladder / cyclotomic squarings on GT, ...) and k - 1 additions / products, all
+// enqueued on the caller's stream with one stream-ordered temporary.  Measured on MI355X (profiles/r05_notes.md): the
+// joint ladder over the generic word-form group law (below) does 5.4 M double scalar multiplications/s on a.param G1 and
+// 19.6 M on d159 G1 where two single-base ladders + one addition do 10 M and 50 M; on GT the executed multiply-adds
+// are 628 k against 2 x 196 k (a.param), 2.59 M against 2 x 760 k (f.param).  Shamir's trick saves doublings, but the
+// single-base ladders save more by running in limb form / on the trace / in the cyclotomic subgroup.
+// "hip_group_slow 1": the joint ladders -- ec_multi_mul_fast_kernel + ec_multi_mul_kernel for the lanes it reports, and
+// gt_multi_pow_kernel -- which are also the independent route the tests compare the default with.
 static int multi_launch(pbc_hip_pairing_s *P, int group, int k, void *d_out, const MultiArgs &M, size_t n, hipStream_t s, const OwnWs *own) {
   if (!n) return 0;
   const unsigned grid = (unsigned) ((n + kBlock - 1) / kBlock);
   uint8_t *o = (uint8_t *) d_out;
-  if (group == 3) {
-    // GT: the product of the k single powers on the library's own element_pow_zn kernels (Lucas ladder on the trace for
-    // type a, cyclotomic squarings for type f, ...: each is several times cheaper than a generic square-and-multiply,
-    // so the composition beats a joint ladder over plain F_q^k products -- executed multiply-adds per unit, a.param:
-    // 2 x 196 k + one product against 628 k; f.param: 2 x 760 k against 2.59 M).  gt_multi_pow_kernel stays for
-    // "hip_group_slow 1" (and as the reference point of the tests).
-    if (P->group_slow) {
-      PBC_DISPATCH_GT2(P, hipLaunchKernelGGL(gt_multi_pow_kernel<G>, dim3(grid), dim3(kBlock), 0, s, o, M, k, P->len_zr, n, kargs<G::NW>(P)));
-      HIP_TRY(hipGetLastError());
-      return 0;
-    }
-    if (M.astride != (size_t) P->lenT || M.zstride != (size_t) P->len_zr) return fail("internal: packed records on the GT composition path");
+  const size_t lp = group_len(P, group);
+  if (!P->group_slow) {
+    if (M.astride != lp || M.zstride != (size_t) P->len_zr) return fail("internal: packed records on the composition route");
     void *tmp = nullptr;
-    HIP_TRY(hipMallocAsync(&tmp, n * (size_t) P->lenT, s));
-    int rc = pbc_hip_element_pow_zn_GT_batch_dev(P, d_out, M.a[0], M.z[0], n, s);
-    for (int j = 1; j < k && !rc; j++) {
-      rc = pbc_hip_element_pow_zn_GT_batch_dev(P, tmp, M.a[j], M.z[j], n, s);
-      if (!rc) rc = pbc_hip_element_mul_GT_batch_dev(P, d_out, d_out, tmp, n, s);
+    HIP_TRY(hipMallocAsync(&tmp, n * lp, s));
+    int rc = 0;
+    for (int j = 0; j < k && !rc; j++) {
+      void *dst = j ? tmp : d_out;
+      rc = group == 3 ? pbc_hip_element_pow_zn_GT_batch_dev(P, dst, M.a[j], M.z[j], n, s)
+                      : pbc_hip_element_mul_zn_batch_dev(P, group, dst, M.a[j], M.z[j], n, s);
+      if (!rc && j)
+        rc = group == 3 ? pbc_hip_element_mul_GT_batch_dev(P, d_out, d_out, tmp, n, s)
+                        : pbc_hip_element_add_batch_dev(P, group, d_out, d_out, tmp, n, s);
     }
     (void) hipFreeAsync(tmp, s);
     return rc;
   }
-  if (P->group_slow) {
-    PBC_DISPATCH_G2(P, group, hipLaunchKernelGGL(ec_multi_mul_kernel<F>, dim3(grid), dim3(kBlock), 0, s, o, M, k, P->len_zr, (const uint8_t *) nullptr, n, kargs<F::NW>(P)));
+  if (group == 3) {
+    PBC_DISPATCH_GT2(P, hipLaunchKernelGGL(gt_multi_pow_kernel<G>, dim3(grid), dim3(kBlock), 0, s, o, M, k, P->len_zr, n, kargs<G::NW>(P)));
   } else {
     ProdWs W(P, s, own);
     uint8_t *flags = (uint8_t *) W.get(n);
@@ -177,9 +181,9 @@ static int multi_host(pbc_hip_pairing_t *P, int group, int k, uint8_t *out, cons
   if (!n) return 0;
   if (prepare(P)) return 1;
   const size_t lp = group_len(P, group), lz = (size_t) P->len_zr;
-  if (group == 3 && !P->group_slow) {
-    // GT takes the composition of the single-base kernels, which wants each base / scalar array by itself: staged on the
-    // object's first device
+  if (!P->group_slow) {
+    // the composition of the single-base kernels wants each base / scalar array by itself: staged on the object's first
+    // device
     DeviceGuard guard(P->ndev > 0 ? P->devs[0] : P->device);
     DevBuf ba[3], bz[3], bo;
     const void *da[3] = {nullptr, nullptr, nullptr}, *dz[3] = {nullptr, nullptr, nullptr};

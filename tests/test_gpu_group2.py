@@ -64,10 +64,17 @@ def test_zr_arithmetic_matches_reference(hips, pname):
 
 @pytest.mark.parametrize("pname,group", POW23)
 def test_multi_exponentiation_matches_reference(hips, pname, group):
+    import pbc_amd
     H = hips[KEY.get(pname, pname)]
     A1, A2, A3, N1, N2, N3, P2, P3 = rec("%s_pow23g%d.rec" % (pname, group))
     assert np.array_equal(H.element_pow_multi(group, [A1, A2], [N1, N2]), P2)
     assert np.array_equal(H.element_pow_multi(group, [A1, A2, A3], [N1, N2, N3]), P3)
+    # the other route: the joint ladders (Shamir's trick: fast pass + the complete routine for reported lanes; GT: the
+    # generic table ladder), selected by "hip_group_slow 1"
+    S = pbc_amd.Pairing(_param(PARAM_OF.get(KEY.get(pname, pname), pname)) + "hip_group_slow 1\n")
+    assert np.array_equal(S.element_pow_multi(group, [A1, A2], [N1, N2]), P2)
+    assert np.array_equal(S.element_pow_multi(group, [A1, A2, A3], [N1, N2, N3]), P3)
+    S.clear()
 
 
 @pytest.mark.parametrize("key,name", [("a", "a_chain1024.vec"), ("d", "d_chain256.vec"), ("f", "f_chain128.vec")])
@@ -106,9 +113,12 @@ def test_group_law_and_zr_on_fresh_batches_vs_oracle(hips, oracles, key, name):
 
 @pytest.mark.parametrize("key,name", [("a", "a_chain1024.vec"), ("d", "d_chain256.vec"), ("f", "f_chain128.vec"), ("g149", "g149_chain64.vec")])
 def test_shamir_trick_equals_the_separate_ladders(hips, key, name):
-    """[n1] a1 + [n2] a2 (+ [n3] a3) from one table ladder = the sum of element_mul_zn results (this library's own, each
-    pinned by the reference's vectors); GT likewise with products of element_pow_zn; scalars 0, 1, r - 1, >= r included"""
-    H = hips[key]
+    """[n1] a1 + [n2] a2 (+ [n3] a3) from one joint table ladder ("hip_group_slow 1": the fast pass, and the complete
+    routine for the lanes it reports -- equal bases, scalars 0 and >= r are in the batch) = the sum of element_mul_zn
+    results = the default route (composition); GT likewise with products of element_pow_zn"""
+    import pbc_amd
+    D = hips[key]
+    H = pbc_amd.Pairing(_param(PARAM_OF.get(key, key)) + "hip_group_slow 1\n")
     v = golden(name)
     n = 700
     rng = np.random.default_rng(23)
@@ -127,13 +137,20 @@ def test_shamir_trick_equals_the_separate_ladders(hips, key, name):
         M = [H.element_mul_zn(group, X[t], Z[t]) for t in range(3)]
         s2 = H.element_group_op("add", group, M[0], M[1])
         assert np.array_equal(H.element_pow_multi(group, X[:2], Z[:2]), s2)
-        assert np.array_equal(H.element_pow_multi(group, X, Z), H.element_group_op("add", group, s2, M[2]))
+        s3 = H.element_group_op("add", group, s2, M[2])
+        assert np.array_equal(H.element_pow_multi(group, X, Z), s3)
+        assert np.array_equal(D.element_pow_multi(group, X[:2], Z[:2]), s2)
+        assert np.array_equal(D.element_pow_multi(group, X, Z), s3)
     m = 200
     X = [v.gt[idx[t][:m]] for t in range(3)]
     Pw = [H.element_pow_zn_GT(X[t], Z[t][:m]) for t in range(3)]
     p2 = H.element_mul_GT(Pw[0], Pw[1])
     assert np.array_equal(H.element_pow_multi(3, X[:2], [z[:m] for z in Z[:2]]), p2)
-    assert np.array_equal(H.element_pow_multi(3, X, [z[:m] for z in Z]), H.element_mul_GT(p2, Pw[2]))
+    p3 = H.element_mul_GT(p2, Pw[2])
+    assert np.array_equal(H.element_pow_multi(3, X, [z[:m] for z in Z]), p3)
+    assert np.array_equal(D.element_pow_multi(3, X[:2], [z[:m] for z in Z[:2]]), p2)
+    assert np.array_equal(D.element_pow_multi(3, X, [z[:m] for z in Z]), p3)
+    H.clear()
 
 
 def test_zss_signatures_as_a_device_resident_batch(hips):

@@ -73,8 +73,17 @@ def main():
             z[0, -1] |= 1
             S.zr_op(3, z)
         elif op in ("g1pow2", "gtpow2"):
-            src = g1 if op == "g1pow2" else gt
-            S.multi(1 if op == "g1pow2" else 3, [src[:1], src[1:2]], [z, z[:, ::-1].copy()])
+            # the default route: two single-base ladders / powers and one addition / product (pbc_hip_group2.hip multi_launch)
+            z2 = z[:, ::-1].copy()
+            z2[0, 0] &= 0x3f
+            if op == "g1pow2":
+                S.group(0, g1[:1], z)
+                S.group(0, g1[1:2], z2)
+                S.affine_op(0, 1, g1[:1], g1[1:2])
+            else:
+                S.group(2, gt[:1], z)
+                S.group(2, gt[1:2], z2)
+                S.group(1, gt[:1], gt[1:2])
         elif op in ("g1pp", "gtpp"):
             grp = 1 if op == "g1pp" else 3
             base = g1[5] if grp == 1 else gt[5]

@@ -62,7 +62,8 @@ typedef struct pbc_hip_pairing_s pbc_hip_pairing_t;
  * so the same text still initialises the reference).  Every variant gives the same bytes; they exist for same-box A/B
  * measurements and for the tests, and the defaults are the measured winners:
  *   hip_wave_max N       type a: batches up to N units take the one-pairing-per-wavefront kernels (default 5120, 0 = never)
- *   hip_wave4_max N      ... and up to N units four wavefronts per pairing (default 1024)
+ *   hip_wave4_max N      ... and up to N units four wavefronts per pairing (default 768)
+ *   hip_wave2_max N      ... and above that, up to N units, two (default 1280)
  *   hip_dynamic 1        resident kernels fetch their units from a per-launch counter instead of a fixed stride
  *   hip_no_fair 1        resident kernels without the time-sliced wave priorities
  *   hip_resident_slots N workgroups of a resident launch instead of the occupancy query (tests: forces many strides)
@@ -124,9 +125,12 @@ int pbc_hip_element_pairing_batch(pbc_hip_pairing_t *p, uint8_t *gt, const uint8
  * beyond that, feed multiples of 131072 where you can.  Type f: 7.2-8.3 ms / 11-12 ms / steps of 11-12 ms, no tail kernel.
  * Cut-over for small batches (type a, 512-bit q): up to 5120 units ("hip_wave_max N" in the parameter text moves it,
  * 0 disables it) a launch gives every pairing a WAVEFRONT (csrc/pairing_aw.cuh: one limb per lane, products across
- * the lanes), up to 1024 units ("hip_wave4_max N") a workgroup of FOUR wavefronts that share the independent products
- * of every step: 1.0 ms for one pairing (n <= 256), 1.3 ms at 512, 1.9 ms at 1024, 2.6 ms at 2048, 4.4 ms at 4096,
- * 5.4 ms at 5120 (the throughput kernel: 5.8-6.5 ms depending on the box) -- same bytes as the throughput kernel. */
+ * the lanes), up to 768 units ("hip_wave4_max N") a workgroup of FOUR wavefronts that share the independent products
+ * of every step, up to 1280 ("hip_wave2_max N") a workgroup of two: 1.0 ms for one pairing (n <= 256), 1.3 ms at 512,
+ * 1.7 ms at 1024, 2.6 ms at 2048, 4.4 ms at 4096, 5.3 ms at 5120 (the throughput kernel: 5.8-6.5 ms depending on the
+ * box) -- same bytes as the throughput kernel.  pairing_pp_apply takes the same three forms (0.68 ms for one second
+ * argument, 1.04 ms at 1024, 3.0 ms at 5120; lane kernel 3.1-3.5 ms), and products of k terms with n k <= hip_wave_max
+ * give every TERM a workgroup and then every product one: 1.0 ms for one product of 2 .. 16 terms (lane kernels: 5.7-6.4). */
 int pbc_hip_element_pairing_batch_dev(pbc_hip_pairing_t *p, void *d_gt, const void *d_g1,
                                       const void *d_g2, size_t n, void *stream);
 

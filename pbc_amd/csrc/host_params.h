@@ -37,10 +37,10 @@ inline int fail(const char *fmt, ...) {
 #define PBC_A_WAVE_MAX 5120
 #endif
 #ifndef PBC_A_WAVE2_MAX
-#define PBC_A_WAVE2_MAX 0              // two wavefronts per unit above hip_wave4_max, up to this size (0: none; measured cut-overs: DESIGN 4.2b)
+#define PBC_A_WAVE2_MAX 1280           // two wavefronts per unit above hip_wave4_max, up to this size (measured cut-overs: profiles/r05_wave_latency.txt)
 #endif
 #ifndef PBC_A_WAVE4_MAX
-#define PBC_A_WAVE4_MAX 1024
+#define PBC_A_WAVE4_MAX 768
 #endif
 // ---------------------------------------------------------------------------------------
 struct pbc_hip_pairing_s {

@@ -1,6 +1,6 @@
 """GPU tests (-m gpu) of the low-latency path for small batches (round 4, pairing_aw.cuh): element_pairing on a.param with
 one WAVEFRONT per pairing -- an F_q element is one register across 18 lanes, the Montgomery product runs over the lanes
-(v_readlane / DPP wave shifts); up to "hip_wave4_max" units (default 1024) FOUR wavefronts share the independent products
+(v_readlane / DPP wave shifts); up to "hip_wave4_max" units (default 768) FOUR wavefronts -- up to "hip_wave2_max" (default 1280) two -- share the independent products
 of every step of a pairing through LDS.  Batches up to "hip_wave_max" (default 5120) take these kernels; the bytes are
 those of the throughput kernel and of the reference's vectors, invalid arguments included."""
 import numpy as np
@@ -11,7 +11,7 @@ from conftest import golden, _param, PARAM_OF
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("n", [1, 2, 63, 64, 768, 1024, 1025, 5120, 5121])
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 768, 769, 1024, 1280, 1281, 5120, 5121])
 def test_wave_pairings_match_the_throughput_kernel_and_the_reference(hip_a, n):
     import pbc_amd
     v = golden("a_chain1024.vec")
@@ -27,9 +27,9 @@ def test_wave_pairings_match_the_throughput_kernel_and_the_reference(hip_a, n):
     T.clear()
 
 
-@pytest.mark.parametrize("extra", ["", "hip_wave4_max 0\n", "hip_wave4_max 100000\n"])
+@pytest.mark.parametrize("extra", ["", "hip_wave4_max 0\nhip_wave2_max 0\n", "hip_wave4_max 100000\n", "hip_wave4_max 0\nhip_wave2_max 100000\n"])
 def test_wave_pairings_on_the_reference_vectors_and_edge_cases(extra):
-    """both forms (one and four wavefronts per pairing) on the reference's vectors, invalid arguments included"""
+    """all three forms (one, two and four wavefronts per pairing) on the reference's vectors, invalid arguments included"""
     import pbc_amd
     H = pbc_amd.Pairing(_param("a") + extra)
     for name in ("a_rand32.vec", "a_edge20.vec", "a_chain1024.vec"):
@@ -60,7 +60,7 @@ def test_wave_pairings_device_buffers_and_streams(hip_a):
     assert (out[n] == 0xA5).all()
 
 
-@pytest.mark.parametrize("n", [1, 2, 63, 300, 1024, 1025, 5120, 5121])
+@pytest.mark.parametrize("n", [1, 2, 63, 300, 768, 769, 1280, 1281, 5120, 5121])
 def test_wave_pp_apply_matches_the_throughput_kernel(hip_a, n):
     """pairing_pp_apply on small batches (round 5: pp_apply_wave, four wavefronts per unit up to hip_wave4_max, one up to
     hip_wave_max) = the lane kernel's bytes = element_pairing's; first arguments that deserialise to O included"""

@@ -1070,17 +1070,31 @@ __device__ bool f_gt_pow_cyc_lane(uint8_t *out, const uint8_t *ab, const uint8_t
     const bool even = (kw[0] & 1) == 0;
     kw[0] |= 1u;
     kw[(8 * zlen) >> 5] |= 1u << ((8 * zlen) & 31);
-    auto entry = [&](int i) {          // e <- the table entry of window i, conjugated for a negative digit
+    auto entry = [&](int i) {          // e <- the table entry of window i, conjugated (odd coefficients negated: pairing_f.cuh f12_conj) for a negative digit
       const uint32_t v = scalar_bits(kw, 4 * i + 1, 15u);
       const bool neg = v < 8;
       const int idx = neg ? 7 - (int) v : (int) v - 8;
+#if PBC_F_NO_CONJ
       e = tab[idx];
-      T::f12_qpower(&ec, &e, c_f.xpowq6);
+      T::f12_conj(&ec, &e);
 #pragma nounroll
       for (int c = 0; c < 6; c++) {
         g2 p = e.c[c], q = ec.c[c];
         fp_cmov<ND>(p.x, q.x, neg);
         fp_cmov<ND>(p.y, q.y, neg);
+        e.c[c] = p;
+      }
+      return;
+#endif
+#pragma nounroll
+      for (int c = 0; c < 6; c++) {
+        g2 p = tab[idx].c[c];
+        if (c & 1) {
+          g2 q;
+          T::g2_neg(q, p);
+          fp_cmov<ND>(p.x, q.x, neg);
+          fp_cmov<ND>(p.y, q.y, neg);
+        }
         e.c[c] = p;
       }
     };
@@ -1094,7 +1108,7 @@ __device__ bool f_gt_pow_cyc_lane(uint8_t *out, const uint8_t *ab, const uint8_t
     }
     f12 r, r2;
     T::f12_lds_export(&r, 0);
-    T::f12_qpower(&ec, &a, c_f.xpowq6);            // even k: a^k = a^(k + 1) / a
+    T::f12_conj(&ec, &a);                          // even k: a^k = a^(k + 1) / a
     T::f12_mul_lds(0, &ec);
     T::f12_lds_export(&r2, 0);
     {

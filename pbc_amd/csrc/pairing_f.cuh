@@ -46,6 +46,9 @@
 #ifndef PBC_F_PREFETCH
 #define PBC_F_PREFETCH 1               // one-area layout: the buffered result coefficients are read back before the last ones are computed
 #endif
+#ifndef PBC_F_NO_CONJ
+#define PBC_F_NO_CONJ 0                // 1: the q^6-power Frobenius through the generic qpower routine (A/B of round 5's f12_conj)
+#endif
 #ifndef PBC_F_LINE_LIMB
 #define PBC_F_LINE_LIMB 1              // f_line_mul_lds: the line's pre-multiplication by Q and -alpha in limb form (0: word-form calls)
 #endif
@@ -441,6 +444,23 @@ static __device__ __noinline__ void f12_qpower(f12 *r, const f12 *a, const uint3
     g2_mul(t, a->c[i], epow);
     r->c[i] = t;
     g2_mul(epow, epow, e);
+  }
+}
+// The q^6-power Frobenius (qpower with xpowq6, f_param.c:257-268, 441): X^(q^6) = xi^((q^6 - 1) / 6) X, and
+// xi^((q^6 - 1) / 6) = (xi^((q^2 - 1) / 2))^((q^4 + q^2 + 1) / 3) = -1 because xi is a non-square of F_q^2 (X^6 - xi is
+// irreducible) and (q^4 + q^2 + 1) / 3 is odd -- the same in the basis X' = X / c of a sparse xi (c lies in F_q^2).  So the
+// map is "negate the odd coefficients": six F_q negations instead of the ten F_q^2 products of the generic routine
+// (2.1 k multiply-adds; seven calls per pairing, one per window of a GT power).  r may be a.
+static PBC_DEV void f12_conj(f12 *r, const f12 *a) {
+#if PBC_F_NO_CONJ
+  f12_qpower(r, a, c_f.xpowq6);        // (A/B switch: the generic routine, rounds 1-4)
+  return;
+#endif
+#pragma nounroll
+  for (int i = 0; i < 6; i++) {
+    g2 t = a->c[i];
+    if (i & 1) g2_neg(t, t);
+    r->c[i] = t;
   }
 }
 // polymod_invert (poly.c:521-536): unique inverse; sigma = q^2-power Frobenius,
@@ -1462,28 +1482,28 @@ static __device__ __noinline__ void f12_pow_x(f12 *r, const f12 *a) {
 static __device__ __noinline__ void f_hard_bn(f12 *out) {
   f12 fx, fx2, fx3, t0, t1, y, u;
   f12_pow_x(&fx, out);
-  if (c_f.bn_xneg) f12_qpower(&fx, &fx, c_f.xpowq6);
+  if (c_f.bn_xneg) f12_conj(&fx, &fx);
   f12_pow_x(&fx2, &fx);
-  if (c_f.bn_xneg) f12_qpower(&fx2, &fx2, c_f.xpowq6);
+  if (c_f.bn_xneg) f12_conj(&fx2, &fx2);
   f12_pow_x(&fx3, &fx2);
-  if (c_f.bn_xneg) f12_qpower(&fx3, &fx3, c_f.xpowq6);
+  if (c_f.bn_xneg) f12_conj(&fx3, &fx3);
   // T0 = y6^2 y4 y5;  T1 = y3 y5 T0;  T0 = T0 y2;  T1 = (T1^2 T0)^2;  T0 = T1 y1;  T1 = T1 y0;  out = T0^2 T1
   // y6 = 1 / (f^(x^3) (f^(x^3))^q)
   f12_frob(&u, &fx3);
   f12_mul(&y, &u, &fx3);
-  f12_qpower(&y, &y, c_f.xpowq6);
+  f12_conj(&y, &y);
   f12_sqr(&t0, &y);
   // y4 = 1 / (f^x (f^(x^2))^q)
   f12_frob(&u, &fx2);
   f12_mul(&y, &u, &fx);
-  f12_qpower(&y, &y, c_f.xpowq6);
+  f12_conj(&y, &y);
   f12_mul(&t0, &t0, &y);
   // y5 = 1 / f^(x^2)
-  f12_qpower(&y, &fx2, c_f.xpowq6);
+  f12_conj(&y, &fx2);
   f12_mul(&t0, &t0, &y);
   // y3 = 1 / (f^x)^q
   f12_frob(&u, &fx);
-  f12_qpower(&u, &u, c_f.xpowq6);
+  f12_conj(&u, &u);
   f12_mul(&t1, &u, &y);
   f12_mul(&t1, &t1, &t0);
   // y2 = (f^(x^2))^(q^2)
@@ -1493,7 +1513,7 @@ static __device__ __noinline__ void f_hard_bn(f12 *out) {
   f12_mul(&t1, &t1, &t0);
   f12_sqr(&t1, &t1);
   // y1 = 1/f
-  f12_qpower(&y, out, c_f.xpowq6);
+  f12_conj(&y, out);
   f12_mul(&t0, &t1, &y);
   // y0 = f^q f^(q^2) f^(q^3)
   f12_frob(&u, out);
@@ -1522,7 +1542,7 @@ static __device__ __noinline__ void f_final_exp(f12 *out) {
   {
     f12 x, y;
     f12_qpower(&y, out, c_f.xpowq8);
-    f12_qpower(&x, out, c_f.xpowq6);
+    f12_conj(&x, out);
     f12_mul(&y, &y, &x);
     f12_qpower(&x, out, c_f.xpowq2);
     f12_mul(&x, &x, out);

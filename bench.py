@@ -192,8 +192,8 @@ WORKLOADS = {
     "f": ("f", "f_chain128.vec", 1, 18, "Type F (f.param) element_pairing"),
     "d201": ("d201", "d201_rand12.vec", 1, 18, "Type D (d201.param, 7-word field) element_pairing"),
     "d224": ("d224", "d224_rand12.vec", 1, 18, "Type D (d224.param, 7-word field) element_pairing"),
-    "a1": ("a1", "a1_chain8.vec", 1, 16, "Type A1 (a1.param, 1033-bit p) element_pairing"),
-    "e": ("e", "e_chain8.vec", 1, 16, "Type E (e.param, k = 1, 1020-bit q) element_pairing"),
+    "a1": ("a1", "a1_chain8.vec", 1, 17, "Type A1 (a1.param, 1033-bit p) element_pairing"),
+    "e": ("e", "e_chain8.vec", 1, 17, "Type E (e.param, k = 1, 1020-bit q) element_pairing"),
     "f256": ("f_256", "f_256_rand4.vec", 1, 16, "Type F (254-bit BN field from pbc_param_init_f_gen(256)) element_pairing"),
     "g": ("g149", "g149_chain64.vec", 1, 17, "Type G (g149.param, k = 10) element_pairing"),
     "d190": ("d278027-190-181", "d278027-190-181_rand12.vec", 1, 18,
@@ -202,7 +202,7 @@ WORKLOADS = {
     "d-prod16": ("d159", "d_chain256.vec", 16, 18, "Type D (d159.param) element_prod_pairing, 16 terms"),
     "a-pp": ("a", "a_chain1024.vec", 1, 20, "Type A (a.param) pairing_pp_apply, fixed first argument"),
     "d-pp": ("d159", "d_chain256.vec", 1, 18, "Type D (d159.param) pairing_pp_apply, fixed first argument"),
-    "a1-pp": ("a1", "a1_chain8.vec", 1, 16, "Type A1 (a1.param) pairing_pp_apply, fixed first argument"),
+    "a1-pp": ("a1", "a1_chain8.vec", 1, 17, "Type A1 (a1.param) pairing_pp_apply, fixed first argument"),
     "g-pp": ("g149", "g149_chain64.vec", 1, 17, "Type G (g149.param) pairing_pp_apply, fixed first argument"),
 }
 

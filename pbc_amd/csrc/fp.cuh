@@ -649,6 +649,115 @@ PBC_DEV void fp_dbl(fp<N> &r, const fp<N> &a) {
   if constexpr (kMemOperands<N>) fp_dbl_mem<N>(&r, &a);
   else fp_dbl_inl<N>(r, a);
 }
+// ---------------------------------------------------------------------------------------
+// Fused products (round 5; the wide fields of types a1 / e).  On memory operands every sum, difference and doubling
+// of a step was its own call that loads 33-66 words and stores 33 (half of a step's traffic through private memory --
+// which reaches HBM: 2.1 MB per type e pairing, profiles/r05_ab_wide.txt -- and a load-to-use stall each).  One call
+//     r = 2^d ( (a [+- a2]) (k b [+- b2]) [+- 2^s1 c1] [+- 2^s2 c2] )
+// takes the linear work into the product's registers; every intermediate is the canonical representative mod q, so a
+// fused step returns what the same step built from fp_add / fp_sub / fp_mul returns.  `op` (wave-uniform) selects:
+namespace fx {
+constexpr int A_ADD = 1, A_SUB = 2, B_ADD = 4, B_SUB = 8, C1_ADD = 16, C1_SUB = 32, C2_ADD = 256, C2_SUB = 512;
+constexpr int c1_sh(int s) { return s << 6; }        // c1 enters as 2^s c1, s = 0..3
+constexpr int c2_sh(int s) { return s << 10; }
+constexpr int dbl(int d) { return d << 12; }         // the result is doubled d times, d = 0..3
+constexpr int b_times(int k) { return k << 16; }     // b enters as k b, k = 2..255 (0, 1: b itself)
+}
+template <int N>
+PBC_DEV void fx_addsub(fp<N> &x, const fp<N> *p, int mode, int sh) {
+  fp<N> t = *p;
+  for (int i = 0; i < sh; i++) fp_dbl_inl<N>(t, t);
+  if (mode & 1) fp_add_inl<N>(x, x, t);
+  else fp_sub_inl<N>(x, x, t);
+}
+template <int N>
+PBC_DEV void fx_finish(fp<N> *r, fp<N> &z, const fp<N> *c1, const fp<N> *c2, int op) {
+  if (op & 48) fx_addsub<N>(z, c1, (op >> 4) & 3, (op >> 6) & 3);
+  if (op & 768) fx_addsub<N>(z, c2, (op >> 8) & 3, (op >> 10) & 3);
+  for (int i = 0; i < ((op >> 12) & 3); i++) fp_dbl_inl<N>(z, z);
+  *r = z;
+}
+template <int N>
+PBC_DEV void fx_mul_body(fp<N> *r, const fp<N> *a, const fp<N> *a2, const fp<N> *b, const fp<N> *b2, const fp<N> *c1,
+                         const fp<N> *c2, int op) {
+  fp<N> x = *a, y = *b, z;
+  if (op & 3) fx_addsub<N>(x, a2, op & 3, 0);
+  const int k = (op >> 16) & 255;
+  if (k > 1) {                                       // k b by double-and-add (k is a small constant of the parameter set)
+    const fp<N> base = y;
+    for (int i = 30 - __builtin_clz(k); i >= 0; i--) {
+      fp_dbl_inl<N>(y, y);
+      if ((k >> i) & 1) fp_add_inl<N>(y, y, base);
+    }
+  }
+  if (op & 12) fx_addsub<N>(y, b2, (op >> 2) & 3, 0);
+  fp_mul_inl<N>(z, x, y);
+  fx_finish<N>(r, z, c1, c2, op);
+}
+template <int N>
+PBC_DEV void fx_sqr_body(fp<N> *r, const fp<N> *a, const fp<N> *a2, const fp<N> *c1, const fp<N> *c2, int op) {
+  fp<N> x = *a, z;
+  if (op & 3) fx_addsub<N>(x, a2, op & 3, 0);
+  fp_sqr_inl<N>(z, x);
+  fx_finish<N>(r, z, c1, c2, op);
+}
+template <int N>
+static __device__ __noinline__ void fp_mulx_mem(fp<N> *r, const fp<N> *a, const fp<N> *a2, const fp<N> *b, const fp<N> *b2,
+                                                const fp<N> *c1, const fp<N> *c2, int op_) {
+#ifdef PBC_HOSTSIM
+  const int op = op_;
+#else
+  const int op = __builtin_amdgcn_readfirstlane(op_);     // arguments arrive in vector registers; the selector is uniform
+#endif
+  fx_mul_body<N>(r, a, a2, b, b2, c1, c2, op);
+}
+template <int N>
+static __device__ __noinline__ void fp_sqrx_mem(fp<N> *r, const fp<N> *a, const fp<N> *a2, const fp<N> *c1, const fp<N> *c2, int op_) {
+#ifdef PBC_HOSTSIM
+  const int op = op_;
+#else
+  const int op = __builtin_amdgcn_readfirstlane(op_);
+#endif
+  fx_sqr_body<N>(r, a, a2, c1, c2, op);
+}
+// r may be any of the operands (everything is read before r is written).  Fields whose elements live in registers run
+// the same sequence on the out-of-line product of their width.
+template <int N>
+PBC_DEV void fp_mulx(fp<N> &r, int op, const fp<N> &a, const fp<N> &a2, const fp<N> &b, const fp<N> &b2, const fp<N> &c1,
+                     const fp<N> &c2) {
+  if constexpr (kMemOperands<N>) {
+    fp_mulx_mem<N>(&r, &a, &a2, &b, &b2, &c1, &c2, op);
+  } else {
+    fp<N> x = a, y = b, z;
+    if (op & 3) fx_addsub<N>(x, &a2, op & 3, 0);
+    const int k = (op >> 16) & 255;
+    if (k > 1) {
+      const fp<N> base = y;
+      for (int i = 30 - __builtin_clz(k); i >= 0; i--) {
+        fp_dbl_inl<N>(y, y);
+        if ((k >> i) & 1) fp_add_inl<N>(y, y, base);
+      }
+    }
+    if (op & 12) fx_addsub<N>(y, &b2, (op >> 2) & 3, 0);
+    fp_mul<N>(z, x, y);
+    fx_finish<N>(&r, z, &c1, &c2, op);
+  }
+}
+template <int N>
+PBC_DEV void fp_sqrx(fp<N> &r, int op, const fp<N> &a, const fp<N> &a2, const fp<N> &c1, const fp<N> &c2) {
+  if constexpr (kMemOperands<N>) {
+    fp_sqrx_mem<N>(&r, &a, &a2, &c1, &c2, op);
+  } else {
+    fp<N> x = a, z;
+    if (op & 3) fx_addsub<N>(x, &a2, op & 3, 0);
+    fp_sqr<N>(z, x);
+    fx_finish<N>(&r, z, &c1, &c2, op);
+  }
+}
+// shorthands: operands that an `op` does not name are never read
+template <int N> PBC_DEV void fp_mulx(fp<N> &r, const fp<N> &a, const fp<N> &b) { fp_mulx<N>(r, 0, a, a, b, b, a, a); }
+template <int N> PBC_DEV void fp_sqrx(fp<N> &r, const fp<N> &a) { fp_sqrx<N>(r, 0, a, a, a, a); }
+
 template <int N>
 PBC_DEV bool fp_is0(const fp<N> &a) {
   uint32_t x = 0;

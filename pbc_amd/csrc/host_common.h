@@ -98,8 +98,10 @@ static_assert(kBlock == D_LANES, "pairing_d.cuh sizes its LDS state for 128-lane
 #define PBC_A_WAVES 2     // waves per SIMD the pairing kernels are register-budgeted for (measured: 1 -> 2 = +32 %)
 #endif
 #ifndef PBC_A1_WAVES
-#define PBC_A1_WAVES 1    // 33-word fields: the 512-register budget of one wave per SIMD beats two waves
-#endif                    // with 256 (measured: a1 119 k -> 158 k pairings/s, e 769 k -> 971 k)
+#define PBC_A1_WAVES 2    // 33-word fields.  Rounds 1-4 ran them at one wave per SIMD (512 registers; with the products in
+#endif                    // registers two waves spilled: a1 158 k -> 119 k pairings/s).  On memory operands the product
+                          // bodies need 121-248 registers and a second wave is what keeps the multiply-add pipe fed
+                          // (profiles/r05_ab_wide.txt; 256-lane workgroups, pbc_hip_a.hip kWide)
 #ifndef PBC_F_WAVES
 #define PBC_F_WAVES PBC_DF_WAVES
 #endif

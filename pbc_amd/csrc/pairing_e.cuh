@@ -14,7 +14,11 @@
 //     power and are kept (do_vertical, e_param.c:141-148);
 //   * numerator and denominator are accumulated separately, also across the terms of a product
 //     (generic_prod_pairings, ecc/pairing.c:35-46: the product of the pairings): one inversion and
-//     one (q-1)/r power per lane.
+//     one (q-1)/r power per lane;
+//   * round 5: the steps run on fused products (fp.cuh: no sum or difference through memory on its own), R's
+//     x-coordinate is a SMALL INTEGER s by construction, so "ZZ x_R" is s ZZ by additions inside the product that uses
+//     it (23 instead of 25 products per doubling step), and the (q-1)/r power runs on a sliding window over the
+//     860-bit exponent, which is the same for every lane (180 instead of 430 products besides the squarings).
 #pragma once
 #include "fp.cuh"
 
@@ -27,6 +31,7 @@ struct EConst {
   uint32_t r[8];                       // group order
   uint32_t phik[NE_MAX];               // (q - 1)/r (e_param.c:857-860)
   int rbits, phikbits;
+  int rxs;                             // x_R as an integer (e_init_lane: the smallest x >= 1 on the curve), 1..255
 };
 static_assert(sizeof(EConst) <= KOFF_XS - KOFF_TYPE, "constant block layout");
 #define c_e (pbc::kconst<pbc::EConst, pbc::KOFF_TYPE>())
@@ -65,114 +70,105 @@ PBC_DEV bool e_on_curve(const fp<N> &x, const fp<N> &y) {
 
 template <int N>
 struct ejac { fp<N> X, Y, Z, ZZ; };
+template <int N>
+struct ekon { fp<N> A, x2, y2; };      // the uniform operands of a step, copied from the constant block once per lane
 
-// n <- n * l(S1) * v(S2),  d <- d * l(S2) * v(S1)   for S1 = Q + R (per lane), S2 = R (uniform)
+// x^e for an exponent all lanes share: sliding window over odd powers x, x^3, ..., x^15 (control flow is uniform)
+template <int N>
+PBC_DEV void e_pow_win(fp<N> &r, const fp<N> &a, const uint32_t *e, int bits) {
+  fp<N> tab[8], acc;
+  {
+    fp<N> a2;
+    tab[0] = a;
+    fp_sqrx<N>(a2, a);
+    for (int i = 1; i < 8; i++) fp_mulx<N>(tab[i], tab[i - 1], a2);
+  }
+  fp_set<N>(acc, fpk<N>().one);
+  bool started = false;
+  int i = bits - 1;
+  while (i >= 0) {
+    if (!((e[i >> 5] >> (i & 31)) & 1)) {
+      if (started) fp_sqrx<N>(acc, acc);
+      i--;
+      continue;
+    }
+    int lo = i >= 3 ? i - 3 : 0;       // bits i .. lo with bit lo set: an odd window of at most four bits
+    while (!((e[lo >> 5] >> (lo & 31)) & 1)) lo++;
+    int w = 0;
+    for (int j = i; j >= lo; j--) w = 2 * w + (int) ((e[j >> 5] >> (j & 31)) & 1);
+    if (started) {
+      for (int j = i; j >= lo; j--) fp_sqrx<N>(acc, acc);
+      fp_mulx<N>(acc, acc, tab[w >> 1]);
+    } else {
+      acc = tab[w >> 1];
+      started = true;
+    }
+    i = lo - 1;
+  }
+  r = acc;
+}
+
+// n <- n^2 l(S1) v(S2),  d <- d^2 l(S2) v(S1)   for S1 = Q + R (per lane), S2 = R = (s, y2) (uniform)
 //   tangent at V scaled by 2 Y Z^3:  l(S) = (Z3 ZZ) ys - 2 Y^2 - M (ZZ xs - X),  M = 3X^2 + a Z^4, Z3 = 2YZ
 //   vertical at 2V scaled by Z3^2:   v(S) = Z3^2 xs - X3
+// 10 S + 13 M, each one fused product.
 template <int N>
-PBC_DEV void e_double_step(fp<N> &n, fp<N> &d, ejac<N> &V, const fp<N> &x1, const fp<N> &y1) {
-  const fp<N> x2 = ek<N>(c_e.Rx), y2 = ek<N>(c_e.Ry);
-  fp<N> XX, YY, M, t0, t1, Z3, W, l1, l2, S;
-  fp_sqr<N>(n, n);
-  fp_sqr<N>(d, d);
-  fp_sqr<N>(XX, V.X);
-  fp_sqr<N>(YY, V.Y);
-  fp_sqr<N>(t0, V.ZZ);
-  fp_mul<N>(t0, t0, ek<N>(c_e.A));
-  fp_dbl<N>(M, XX);
-  fp_add<N>(M, M, XX);
-  fp_add<N>(M, M, t0);
-  fp_add<N>(Z3, V.Y, V.Z);
-  fp_sqr<N>(Z3, Z3);
-  fp_sub<N>(Z3, Z3, YY);
-  fp_sub<N>(Z3, Z3, V.ZZ);             // 2YZ
-  fp_mul<N>(W, Z3, V.ZZ);
-  fp_dbl<N>(t1, YY);                   // 2Y^2
-  // l(S1)
-  fp_mul<N>(t0, V.ZZ, x1);
-  fp_sub<N>(t0, t0, V.X);
-  fp_mul<N>(t0, M, t0);
-  fp_mul<N>(l1, W, y1);
-  fp_sub<N>(l1, l1, t1);
-  fp_sub<N>(l1, l1, t0);
-  // l(S2)
-  fp_mul<N>(t0, V.ZZ, x2);
-  fp_sub<N>(t0, t0, V.X);
-  fp_mul<N>(t0, M, t0);
-  fp_mul<N>(l2, W, y2);
-  fp_sub<N>(l2, l2, t1);
-  fp_sub<N>(l2, l2, t0);
-  fp_mul<N>(n, n, l1);
-  fp_mul<N>(d, d, l2);
-  // V <- 2V
-  fp_mul<N>(S, V.X, YY);
-  fp_dbl<N>(S, S);
-  fp_dbl<N>(S, S);                     // 4XY^2
-  fp_sqr<N>(t0, YY);
-  fp_dbl<N>(t0, t0);
-  fp_dbl<N>(t0, t0);
-  fp_dbl<N>(t0, t0);                   // 8Y^4
-  fp_sqr<N>(V.X, M);
-  fp_dbl<N>(t1, S);
-  fp_sub<N>(V.X, V.X, t1);
-  fp_sub<N>(t1, S, V.X);
-  fp_mul<N>(t1, M, t1);
-  fp_sub<N>(V.Y, t1, t0);
-  V.Z = Z3;
-  fp_sqr<N>(V.ZZ, Z3);
-  // verticals at the new V
-  fp_mul<N>(t0, V.ZZ, x2);
-  fp_sub<N>(t0, t0, V.X);
-  fp_mul<N>(n, n, t0);
-  fp_mul<N>(t0, V.ZZ, x1);
-  fp_sub<N>(t0, t0, V.X);
-  fp_mul<N>(d, d, t0);
+PBC_DEV void e_double_step(fp<N> &n, fp<N> &d, ejac<N> &V, const fp<N> &x1, const fp<N> &y1, const ekon<N> &K) {
+  using namespace fx;
+  const int ks = b_times(c_e.rxs);
+  fp<N> XX, YY, M, t0, W, l1, l2, S;
+  fp_sqrx<N>(n, n);
+  fp_sqrx<N>(d, d);
+  fp_sqrx<N>(XX, V.X);
+  fp_sqrx<N>(YY, V.Y);
+  fp_sqrx<N>(t0, V.ZZ);
+  fp_mulx<N>(M, C1_ADD | c1_sh(1) | C2_ADD, t0, t0, K.A, K.A, XX, XX);                   // M = a Z^4 + 2X^2 + X^2
+  fp_sqrx<N>(V.Z, A_ADD | C1_SUB | C2_SUB, V.Y, V.Z, YY, V.ZZ);                          // Z3 = 2YZ, in place
+  fp_mulx<N>(W, V.Z, V.ZZ);
+  fp_mulx<N>(t0, C1_SUB, V.ZZ, V.ZZ, x1, x1, V.X, V.X);
+  fp_mulx<N>(t0, M, t0);
+  fp_mulx<N>(l1, C1_SUB | c1_sh(1) | C2_SUB, W, W, y1, y1, YY, t0);                      // l(S1)
+  fp_mulx<N>(t0, B_SUB | ks, M, M, V.ZZ, V.X, M, M);                                     // M (s ZZ - X)
+  fp_mulx<N>(l2, C1_SUB | c1_sh(1) | C2_SUB, W, W, K.y2, K.y2, YY, t0);                  // l(S2)
+  fp_mulx<N>(n, n, l1);
+  fp_mulx<N>(d, d, l2);
+  fp_mulx<N>(S, dbl(2), V.X, V.X, YY, YY, YY, YY);                                       // 4XY^2
+  fp_sqrx<N>(t0, YY);                                                                    // Y^4
+  fp_sqrx<N>(V.X, C1_SUB | c1_sh(1), M, M, S, S);                                        // X3 = M^2 - 2S
+  fp_mulx<N>(V.Y, B_SUB | C1_SUB | c1_sh(3), M, M, S, V.X, t0, t0);                      // Y3 = M (S - X3) - 8Y^4
+  fp_sqrx<N>(V.ZZ, V.Z);
+  fp_mulx<N>(n, B_SUB | ks, n, n, V.ZZ, V.X, n, n);                                      // v(S2) = s ZZ - X3
+  fp_mulx<N>(t0, C1_SUB, V.ZZ, V.ZZ, x1, x1, V.X, V.X);
+  fp_mulx<N>(d, d, t0);
 }
 // chord through V and the affine P scaled by Z3 = Z H:  l(S) = (ys - yP) Z3 - R' (xs - xP),
 // H = xP Z^2 - X, R' = yP Z^3 - Y;  then V <- V + P and the verticals at the new V
 template <int N>
 PBC_DEV void e_add_step(fp<N> &n, fp<N> &d, ejac<N> &V, const fp<N> &xP, const fp<N> &yP, const fp<N> &x1,
-                        const fp<N> &y1) {
-  const fp<N> x2 = ek<N>(c_e.Rx), y2 = ek<N>(c_e.Ry);
-  fp<N> H, Rr, HH, HHH, t0, t1, Z3;
-  fp_mul<N>(H, xP, V.ZZ);
-  fp_sub<N>(H, H, V.X);
-  fp_mul<N>(t0, V.Z, V.ZZ);
-  fp_mul<N>(Rr, yP, t0);
-  fp_sub<N>(Rr, Rr, V.Y);
-  fp_mul<N>(Z3, V.Z, H);
-  fp_sub<N>(t0, y1, yP);
-  fp_mul<N>(t0, t0, Z3);
-  fp_sub<N>(t1, x1, xP);
-  fp_mul<N>(t1, t1, Rr);
-  fp_sub<N>(t0, t0, t1);
-  fp_mul<N>(n, n, t0);
-  fp_sub<N>(t0, y2, yP);
-  fp_mul<N>(t0, t0, Z3);
-  fp_sub<N>(t1, x2, xP);
-  fp_mul<N>(t1, t1, Rr);
-  fp_sub<N>(t0, t0, t1);
-  fp_mul<N>(d, d, t0);
-  fp_sqr<N>(HH, H);
-  fp_mul<N>(HHH, HH, H);
-  fp_mul<N>(t0, V.X, HH);
-  fp_sqr<N>(t1, Rr);
-  fp_sub<N>(t1, t1, HHH);
-  fp_sub<N>(t1, t1, t0);
-  fp_sub<N>(t1, t1, t0);
-  fp_sub<N>(t0, t0, t1);
-  fp_mul<N>(t0, Rr, t0);
-  fp_mul<N>(HHH, V.Y, HHH);
-  fp_sub<N>(V.Y, t0, HHH);
-  V.X = t1;
-  V.Z = Z3;
-  fp_sqr<N>(V.ZZ, Z3);
-  fp_mul<N>(t0, V.ZZ, x2);
-  fp_sub<N>(t0, t0, V.X);
-  fp_mul<N>(n, n, t0);
-  fp_mul<N>(t0, V.ZZ, x1);
-  fp_sub<N>(t0, t0, V.X);
-  fp_mul<N>(d, d, t0);
+                        const fp<N> &y1, const ekon<N> &K) {
+  using namespace fx;
+  const int ks = b_times(c_e.rxs);
+  fp<N> H, Rr, HH, HHH, t0;
+  fp_mulx<N>(H, C1_SUB, xP, xP, V.ZZ, V.ZZ, V.X, V.X);
+  fp_mulx<N>(t0, V.Z, V.ZZ);
+  fp_mulx<N>(Rr, C1_SUB, yP, yP, t0, t0, V.Y, V.Y);
+  fp_mulx<N>(V.Z, V.Z, H);                                                               // Z3, in place
+  fp_mulx<N>(t0, A_SUB, y1, yP, V.Z, V.Z, V.Z, V.Z);
+  fp_mulx<N>(t0, A_SUB | C1_ADD, xP, x1, Rr, Rr, t0, t0);                                // (y1 - yP) Z3 - (x1 - xP) R'
+  fp_mulx<N>(n, n, t0);
+  fp_mulx<N>(t0, A_SUB, K.y2, yP, V.Z, V.Z, V.Z, V.Z);
+  fp_mulx<N>(t0, A_SUB | C1_ADD, xP, K.x2, Rr, Rr, t0, t0);
+  fp_mulx<N>(d, d, t0);
+  fp_sqrx<N>(HH, H);
+  fp_mulx<N>(HHH, HH, H);
+  fp_mulx<N>(t0, V.X, HH);
+  fp_sqrx<N>(V.X, C1_SUB | C2_SUB | c2_sh(1), Rr, Rr, HHH, t0);                          // X3 = R'^2 - H^3 - 2 X H^2
+  fp_mulx<N>(HHH, V.Y, HHH);
+  fp_mulx<N>(V.Y, B_SUB | C1_SUB, Rr, Rr, t0, V.X, HHH, HHH);                            // Y3 = R' (X H^2 - X3) - Y H^3
+  fp_sqrx<N>(V.ZZ, V.Z);
+  fp_mulx<N>(n, B_SUB | ks, n, n, V.ZZ, V.X, n, n);
+  fp_mulx<N>(t0, C1_SUB, V.ZZ, V.ZZ, x1, x1, V.X, V.X);
+  fp_mulx<N>(d, d, t0);
 }
 
 // numerator and denominator of f_{r,P}(Q+R) / f_{r,P}(R) for one lane (n = d = 1 on entry).
@@ -181,26 +177,30 @@ PBC_DEV void e_add_step(fp<N> &n, fp<N> &d, ejac<N> &V, const fp<N> &xP, const f
 template <int N>
 PBC_DEV bool e_miller_lane(fp<N> &n, fp<N> &d, const uint8_t *g1, const uint8_t *g2, uint32_t *lds_q,
                            int lds_stride) {
+  using namespace fx;
   const int NB = fq_bytes<N>();
   fp<N> one, xP, yP, x1, y1;
+  ekon<N> K;
+  K.A = ek<N>(c_e.A);
+  K.x2 = ek<N>(c_e.Rx);
+  K.y2 = ek<N>(c_e.Ry);
   fp_set<N>(one, fpk<N>().one);
   fp_load_be<N>(xP, g1);
   fp_load_be<N>(yP, g1 + NB);
   bool valid;
   {
     // QR = Q + R, affine (element_add(QR, Q, p->R), e_param.c:479)
-    const fp<N> xR = ek<N>(c_e.Rx), yR = ek<N>(c_e.Ry);
     fp<N> xQ, yQ, l, t, x3, y3;
     fp_load_be<N>(xQ, g2);
     fp_load_be<N>(yQ, g2 + NB);
     valid = (int) e_on_curve<N>(xP, yP) & (int) e_on_curve<N>(xQ, yQ);
-    fp_sub<N>(t, xR, xQ);
+    fp_sub<N>(t, K.x2, xQ);
     fp_inv<N>(t, t);
-    fp_sub<N>(l, yR, yQ);
+    fp_sub<N>(l, K.y2, yQ);
     fp_mul<N>(l, l, t);
     fp_sqr<N>(x3, l);
     fp_sub<N>(x3, x3, xQ);
-    fp_sub<N>(x3, x3, xR);
+    fp_sub<N>(x3, x3, K.x2);
     fp_sub<N>(t, xQ, x3);
     fp_mul<N>(y3, t, l);
     fp_sub<N>(y3, y3, yQ);
@@ -211,19 +211,18 @@ PBC_DEV bool e_miller_lane(fp<N> &n, fp<N> &d, const uint8_t *g1, const uint8_t 
   ejac<N> V;
   V.X = xP; V.Y = yP; V.Z = one; V.ZZ = one;
   for (int i = c_e.rbits - 2; i >= 0; i--) {
-    e_double_step<N>(n, d, V, x1, y1);
+    e_double_step<N>(n, d, V, x1, y1, K);
     if ((c_e.r[i >> 5] >> (i & 31)) & 1) {
-      fp_load_be<N>(xP, g1);
-      fp_load_be<N>(yP, g1 + NB);
+      if constexpr (!kMemOperands<N>) {  // register-resident fields do not keep P live across the loop
+        fp_load_be<N>(xP, g1);
+        fp_load_be<N>(yP, g1 + NB);
+      }
       if (i > 0) {
-        e_add_step<N>(n, d, V, xP, yP, x1, y1);
+        e_add_step<N>(n, d, V, xP, yP, x1, y1, K);
       } else {
         // last addition: V = -P, the chord is the vertical through P and V + P = O
-        fp<N> t;
-        fp_sub<N>(t, x1, xP);
-        fp_mul<N>(n, n, t);
-        fp_sub<N>(t, ek<N>(c_e.Rx), xP);
-        fp_mul<N>(d, d, t);
+        fp_mulx<N>(n, B_SUB, n, n, x1, xP, n, n);
+        fp_mulx<N>(d, B_SUB, d, d, K.x2, xP, d, d);
       }
     }
   }
@@ -249,7 +248,7 @@ PBC_DEV void e_prod_pairing_lane(uint8_t *gt, const uint8_t *g1, const uint8_t *
   }
   fp_inv<N>(d, d);
   fp_mul<N>(n, n, d);
-  e_pow<N>(out, n, c_e.phik, c_e.phikbits);
+  e_pow_win<N>(out, n, c_e.phik, c_e.phikbits);
   if (!valid) fp_set<N>(out, fpk<N>().one);       // GT identity (pairing_apply, include/pbc_pairing.h:123-130)
   fp_store_be<N>(gt, out);
 }
@@ -295,6 +294,7 @@ PBC_DEV void e_init_lane(EConst *out, const ERaw &raw, const EConst &base) {
   fp_set<N>(t, raw.a); fp_mul<N>(a, t, r2);
   fp_set<N>(t, raw.b); fp_mul<N>(b, t, r2);
   x = one;
+  int xs = 1;
   for (;;) {
     fp_sqr<N>(rhs, x);
     fp_add<N>(rhs, rhs, a);
@@ -302,7 +302,9 @@ PBC_DEV void e_init_lane(EConst *out, const ERaw &raw, const EConst &base) {
     fp_add<N>(rhs, rhs, b);
     if (!fp_is0<N>(rhs) && e_sqrt<N>(y, rhs, raw)) break;
     fp_add<N>(x, x, one);
+    xs++;
   }
+  C.rxs = xs;
   for (int k = 0; k < N; k++) { C.A[k] = a.v[k]; C.B[k] = b.v[k]; C.Rx[k] = x.v[k]; C.Ry[k] = y.v[k]; }
   *out = C;
 }

@@ -5,6 +5,8 @@
 // One Type-A pairing per lane.  g1/g2/gt are AoS in wire format (128 B each for a.param);
 // per-lane 16-byte loads of a 128-byte record: every byte of every fetched line is used.
 // F_q elements are in limb form throughout (pairing_al.cuh).
+// lanes per workgroup: 256 for the 33-word kernels (one wave per SIMD of a CU; see launch_a), 128 otherwise
+template <int N> constexpr int kWide = N >= 32 ? 256 : kBlock;
 template <int N>
 __global__ void __launch_bounds__(kBlock, PBC_A_WAVES) al_pairing_kernel(uint8_t *gt, const uint8_t *g1,
                                                              const uint8_t *g2, size_t n, unsigned *ctr, KArgs<N> ka) {
@@ -122,14 +124,14 @@ __global__ void __launch_bounds__(kBlock, PBC_A_WAVES) a_prod_pairing_kernel(uin
 
 // Type A1: one k-term product (k = 1: a single pairing) per lane; 130-byte coordinates for a1.param.
 template <int N>
-__global__ void __launch_bounds__(kBlock, N >= 32 ? PBC_A1_WAVES : PBC_A_WAVES) a1_prod_pairing_kernel(uint8_t *gt, const uint8_t *g1,
+__global__ void __launch_bounds__(kWide<N>, N >= 32 ? PBC_A1_WAVES : PBC_A_WAVES) a1_prod_pairing_kernel(uint8_t *gt, const uint8_t *g1,
                                                                                const uint8_t *g2, size_t n, int k, KArgs<N> ka) {
-  size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
+  size_t idx = (size_t) blockIdx.x * kWide<N> + threadIdx.x;
   size_t ld = idx < n ? idx : n - 1;
   const int L = 2 * fq_bytes<N>();
   __attribute__((aligned(4))) uint8_t out[8 * N];
-  __shared__ uint32_t lds_q[kMemOperands<N> ? 1 : 2 * N * kBlock];   // wide fields keep Q in private memory
-  a1_prod_pairing_lane<N>(out, g1 + ld * k * L, g2 + ld * k * L, k, lds_q + threadIdx.x, kBlock);
+  __shared__ uint32_t lds_q[kMemOperands<N> ? 1 : 2 * N * kWide<N>];   // wide fields keep Q in private memory
+  a1_prod_pairing_lane<N>(out, g1 + ld * k * L, g2 + ld * k * L, k, lds_q + threadIdx.x, kWide<N>);
   if (idx < n) {
     if ((L & 3) == 0) {
       uint32_t *dst = reinterpret_cast<uint32_t *>(gt + idx * L);
@@ -143,14 +145,14 @@ __global__ void __launch_bounds__(kBlock, N >= 32 ? PBC_A1_WAVES : PBC_A_WAVES) 
 
 // Type E: one k-term product (k = 1: a single pairing) per lane; G1/G2 256 B, GT 128 B for e.param.
 template <int N>
-__global__ void __launch_bounds__(kBlock, N >= 32 ? PBC_A1_WAVES : PBC_A_WAVES) e_prod_pairing_kernel(uint8_t *gt, const uint8_t *g1,
+__global__ void __launch_bounds__(kWide<N>, N >= 32 ? PBC_A1_WAVES : PBC_A_WAVES) e_prod_pairing_kernel(uint8_t *gt, const uint8_t *g1,
                                                                               const uint8_t *g2, size_t n, int k, KArgs<N> ka) {
-  size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
+  size_t idx = (size_t) blockIdx.x * kWide<N> + threadIdx.x;
   size_t ld = idx < n ? idx : n - 1;
   const int LT = fq_bytes<N>(), L = 2 * LT;
   __attribute__((aligned(4))) uint8_t out[4 * N];
   uint32_t *lds_q = nullptr;           // unused: Q + R lives in the lane's private memory
-  e_prod_pairing_lane<N>(out, g1 + ld * k * L, g2 + ld * k * L, k, lds_q, kBlock);
+  e_prod_pairing_lane<N>(out, g1 + ld * k * L, g2 + ld * k * L, k, lds_q, kWide<N>);
   if (idx < n) {
     if ((LT & 3) == 0) {
       uint32_t *dst = reinterpret_cast<uint32_t *>(gt + idx * LT);
@@ -195,10 +197,10 @@ __global__ void a1_pp_init_kernel(uint32_t *tab, uint32_t *valid, const uint8_t 
   *valid = a1_pp_init_lane<N>(tab, g1) ? 1u : 0u;
 }
 template <int N>
-__global__ void __launch_bounds__(kBlock, N >= 32 ? PBC_A1_WAVES : PBC_A_WAVES) a1_pp_apply_kernel(uint8_t *gt, const uint32_t *__restrict__ tab,
+__global__ void __launch_bounds__(kWide<N>, N >= 32 ? PBC_A1_WAVES : PBC_A_WAVES) a1_pp_apply_kernel(uint8_t *gt, const uint32_t *__restrict__ tab,
                                                                            const uint32_t *__restrict__ valid,
                                                                            const uint8_t *g2, size_t n, KArgs<N> ka) {
-  size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
+  size_t idx = (size_t) blockIdx.x * kWide<N> + threadIdx.x;
   size_t ld = idx < n ? idx : n - 1;
   const int L = 2 * fq_bytes<N>();
   __attribute__((aligned(4))) uint8_t out[8 * N];
@@ -228,9 +230,15 @@ int derive_e(pbc_hip_pairing_s *P, hipStream_t s) {
   HIP_TRY(hipMemcpyAsync(&P->econst, dbuf, sizeof(EConst), hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
   HIP_TRY(hipGetLastError());
+  if (P->econst.rxs < 1 || P->econst.rxs > 255)      // the steps multiply by x_R with additions (pairing_e.cuh)
+    return fail("type e: no auxiliary point with x in 1..255 on this curve (found x = %d)", P->econst.rxs);
   return 0;
 }
 
+// The 33-word kernels are budgeted for TWO waves per SIMD (PBC_A1_WAVES) and launched as 256-lane workgroups (kWide):
+// the four waves of a workgroup go to the four SIMDs of a CU.  With 128-lane workgroups the dispatcher put both waves
+// of every workgroup on the first SIMDs with room, so a launch that would fit at one wave per SIMD ran two to a SIMD on
+// half the SIMDs (e.param, 2^16 units: 62 ms against 48; asking for LDS to limit the workgroups per CU did not move it).
 int launch_a(pbc_hip_pairing_s *P, void *d_gt, const void *d_g1, const void *d_g2, size_t n, int k, hipStream_t s, ProdWs &W) {
   unsigned grid = (unsigned) ((n + kBlock - 1) / kBlock);
   if (P->type == 'a' && !P->a_generic && k == 1 && n <= P->a_wave_max) {
@@ -292,13 +300,13 @@ int launch_a(pbc_hip_pairing_s *P, void *d_gt, const void *d_g1, const void *d_g
     hipLaunchKernelGGL(a1_prod_pairing_kernel<16>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
                        (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k, kargs<16>(P));
   } else if (P->type == '1' || P->type == 'a') {
-    hipLaunchKernelGGL(a1_prod_pairing_kernel<33>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
+    hipLaunchKernelGGL(a1_prod_pairing_kernel<33>, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, s, (uint8_t *) d_gt,
                        (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k, kargs<33>(P));
   } else if (P->type == 'e' && P->nlimb == 16) {
     hipLaunchKernelGGL(e_prod_pairing_kernel<16>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
                        (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k, kargs<16>(P));
   } else if (P->type == 'e') {
-    hipLaunchKernelGGL(e_prod_pairing_kernel<33>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
+    hipLaunchKernelGGL(e_prod_pairing_kernel<33>, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, s, (uint8_t *) d_gt,
                        (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k, kargs<33>(P));
   } else {
     return fail("unsupported type");
@@ -335,7 +343,7 @@ int pp_apply_launch_a(pbc_hip_pp_s *pp, void *d_gt, const void *d_g2, size_t n, 
     hipLaunchKernelGGL(a1_pp_apply_kernel<16>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt, pp->tab, pp->valid,
                        (const uint8_t *) d_g2, n, kargs<16>(P));
   } else {
-    hipLaunchKernelGGL(a1_pp_apply_kernel<33>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt, pp->tab, pp->valid,
+    hipLaunchKernelGGL(a1_pp_apply_kernel<33>, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, s, (uint8_t *) d_gt, pp->tab, pp->valid,
                        (const uint8_t *) d_g2, n, kargs<33>(P));
   }
   HIP_TRY(hipGetLastError());

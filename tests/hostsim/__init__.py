@@ -215,6 +215,19 @@ class HostSim:
         assert rc == 0
         return out
 
+    def fx(self, sqr, op, words):
+        """one fused product (fp.cuh fp_mulx / fp_sqrx): words = 6 lists of N little-endian words (a, a2, b, b2, c1, c2)"""
+        ops = np.ascontiguousarray(np.array(words, np.uint32).reshape(-1))
+        out = np.zeros(len(ops) // 6, np.uint32)
+        self.L.hostsim_fx.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        n = self.L.hostsim_fx(self.h, sqr, op, ops.ctypes.data, out.ctypes.data)
+        assert n == len(out)
+        return out
+
+    def e_rxs(self):
+        self.L.hostsim_e_rxs.argtypes = [ctypes.c_void_p]
+        return self.L.hostsim_e_rxs(self.h)
+
     def zr_op(self, op, a, b=None, hlen=0):
         a = np.ascontiguousarray(a, np.uint8)
         b = None if b is None else np.ascontiguousarray(b, np.uint8)

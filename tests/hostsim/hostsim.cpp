@@ -510,5 +510,19 @@ int hostsim_zr_op(void *h, int op, uint8_t *out, const uint8_t *a, const uint8_t
   return rc;
 }
 int hostsim_len_zr(void *h) { return ((pbc_hip_pairing_s *) h)->len_zr; }
+// one fused product of fp.cuh ("Fused products": fp_mulx / fp_sqrx) on residues given as little-endian words, and the type e
+// constant it is parameterised by: ops = a, a2, b, b2, c1, c2 (N words each); out = r (N words)
+int hostsim_fx(void *h, int sqr, int op, const uint32_t *ops, uint32_t *out) {
+  pbc_hip_pairing_s *P = (pbc_hip_pairing_s *) h;
+  HS_DISPATCH(P->nlimb, {
+    fp<N> e[6], r;
+    for (int j = 0; j < 6; j++) fp_set<N>(e[j], ops + j * N);
+    if (sqr) fp_sqrx<N>(r, op, e[0], e[1], e[4], e[5]);
+    else fp_mulx<N>(r, op, e[0], e[1], e[2], e[3], e[4], e[5]);
+    for (int k = 0; k < N; k++) out[k] = r.v[k];
+  });
+  return P->nlimb;
+}
+int hostsim_e_rxs(void *h) { return ((pbc_hip_pairing_s *) h)->econst.rxs; }
 
 }

@@ -597,3 +597,49 @@ def test_pp_apply_and_products_on_the_wave_routines_on_host(sims, oracles):
     m = golden("a_160_512_mm_rand6.vec")                       # sign1 = -1: the addition step negates P
     Sm = sims["a_160_512_mm"]
     assert np.array_equal(Sm.pp_wave(m.g1[1], m.g2[1:3]), np.concatenate([m.gt[1:2], Sm.prod_pairing(m.g1[1:2], m.g2[2:3], 1)]))
+
+
+@pytest.mark.parametrize("key,qkey,nw", [("e", "q", 33), ("a1", "p", 33), ("e_160_400", "q", 16)])
+def test_fused_products_on_host(sims, key, qkey, nw):
+    """fp.cuh fp_mulx / fp_sqrx (round 5: the steps of types a1 / e): every selector -- the sums and differences before
+    the product, the small multiple k b, the shifted terms after it, the closing doublings -- against plain integers
+    mod q, on the memory-operand path (33 words) and on the register path (16 words); operands in [0, q) including 0 and
+    q - 1.  The constant the type e steps multiply by (x of the auxiliary point) is checked to be a small integer."""
+    sim = sims[key]
+    q = param_value(key, qkey)
+    W = 28 if nw >= 32 else 29                              # fp.cuh Limbs29: the Montgomery radix is 2^(W L), L limbs of W bits
+    R = 1 << (W * ((32 * nw + W - 1) // W))
+    Rinv = pow(R, -1, q)
+    rng = np.random.default_rng(20250922)
+    words = lambda x: [(x >> (32 * i)) & 0xffffffff for i in range(nw)]
+    value = lambda w: sum(int(x) << (32 * i) for i, x in enumerate(w))
+    rnd = lambda: int.from_bytes(rng.bytes(4 * nw + 8), "big") % q
+    A_ADD, A_SUB, B_ADD, B_SUB, C1_ADD, C1_SUB, C2_ADD, C2_SUB = 1, 2, 4, 8, 16, 32, 256, 512
+    cases = [(0, 0), (1, 0)]
+    for _ in range(60):
+        op = int(rng.choice([0, A_ADD, A_SUB])) | int(rng.choice([0, B_ADD, B_SUB])) | int(rng.choice([0, C1_ADD, C1_SUB])) | int(rng.choice([0, C2_ADD, C2_SUB]))
+        op |= int(rng.integers(0, 4)) << 6 | int(rng.integers(0, 4)) << 10 | int(rng.integers(0, 4)) << 12
+        if rng.integers(0, 2):
+            op |= int(rng.choice([2, 3, 5, 7, 8, 100, 255])) << 16
+        cases.append((int(rng.integers(0, 2)), op))
+    for t, (sqr, op) in enumerate(cases):
+        e = [rnd() for _ in range(6)]
+        if t % 7 == 3:
+            e[t % 6] = 0
+        if t % 7 == 5:
+            e[(t + 1) % 6] = q - 1
+        a, a2, b, b2, c1, c2 = e
+        x = a + (a2 if op & 1 else -a2 if op & 2 else 0)
+        if sqr:
+            y = x
+        else:
+            k = (op >> 16) & 255
+            y = (k if k > 1 else 1) * b + (b2 if op & 4 else -b2 if op & 8 else 0)
+        z = x * y * Rinv
+        z += (c1 << ((op >> 6) & 3)) * (1 if op & 16 else -1 if op & 32 else 0)
+        z += (c2 << ((op >> 10) & 3)) * (1 if op & 256 else -1 if op & 512 else 0)
+        z = (z << ((op >> 12) & 3)) % q
+        got = value(sim.fx(sqr, op, [words(v) for v in e]))
+        assert got == z, (key, sqr, hex(op))
+    if key.startswith("e"):
+        assert 1 <= sim.e_rxs() <= 255

@@ -55,16 +55,21 @@ PBC_DEV void fi_sqr(fp2<N> &r, const fp2<N> &a) {
 
 // The same two routines on fused products (fp.cuh "Fused products"; the wide fields): no sum or difference goes through
 // memory on its own.  r must not overlap a or b.
+// (R, A, B: fp2<N> or the view fp2v<N> of two separately placed elements)
 template <int N>
-PBC_DEV void fi_mul_x(fp2<N> &r, const fp2<N> &a, const fp2<N> &b) {
+struct fp2v {
+  fp<N> &x, &y;
+};
+template <int N, class R, class A, class B>
+PBC_DEV void fi_mul_x(R &r, const A &a, const B &b) {
   using namespace fx;
   fp<N> e1;
   fp_mulx<N>(e1, a.y, b.y);
   fp_mulx<N>(r.x, C1_SUB, a.x, a.x, b.x, b.x, e1, e1);                                    // a.x b.x - a.y b.y
   fp_mulx<N>(r.y, A_ADD | B_ADD | C1_SUB | C2_SUB | c2_sh(1), a.x, a.y, b.x, b.y, r.x, e1);  // (a.x+a.y)(b.x+b.y) - a.x b.x - a.y b.y
 }
-template <int N>
-PBC_DEV void fi_sqr_x(fp2<N> &r, const fp2<N> &a) {
+template <int N, class R, class A>
+PBC_DEV void fi_sqr_x(R &r, const A &a) {
   using namespace fx;
   fp_mulx<N>(r.x, A_ADD | B_SUB, a.x, a.y, a.x, a.y, a.x, a.x);
   fp_mulx<N>(r.y, dbl(1), a.x, a.x, a.y, a.y, a.x, a.x);
@@ -117,8 +122,10 @@ struct jac {
 // with M = 3X^2 + Z^4.
 // SQR = false leaves the squaring of f to the caller (the product kernel squares its shared accumulator once per
 // iteration for all terms, as a_pairings_affine does, ecc/a_param.c:1338-1344).
+// `hot` (the 33-word fields on the device): 72 words of LDS owned by the lane, for the two temporaries of the step that move
+// most often (Y^2 and X^2: 9 of its 66 element moves; 16-byte aligned at words 0 and 36)
 template <int N, bool SQR = true>
-PBC_DEV void a_double_step(fp2<N> &f, jac<N> &V, const fp<N> &Qx, const fp<N> &Qy) {
+PBC_DEV void a_double_step(fp2<N> &f, jac<N> &V, const fp<N> &Qx, const fp<N> &Qy, uint32_t *hot = nullptr) {
   // Ordered for short live ranges (the register budget is 256/lane at 2 waves per SIMD):
   // line first, f <- f^2 l as soon as the line exists, the rest of the doubling last.
   // Two products are traded for squarings (a dedicated squaring costs 0.78 of a product):
@@ -126,7 +133,9 @@ PBC_DEV void a_double_step(fp2<N> &f, jac<N> &V, const fp<N> &Qx, const fp<N> &Q
   if constexpr (kMemOperands<N> && SQR) {
     // the wide fields: the same 10 M + 8 S as 18 fused products, f through a second buffer instead of in place
     using namespace fx;
-    fp<N> XX, YY, M, t0, S, Y4;
+    fp<N> hot_private[2], M, t0, S, Y4;
+    fp<N> &YY = hot ? *reinterpret_cast<fp<N> *>(hot) : hot_private[0];
+    fp<N> &XX = hot ? *reinterpret_cast<fp<N> *>(hot + 36) : hot_private[1];
     fp2<N> l, g;
     fi_sqr_x<N>(g, f);
     fp_sqrx<N>(XX, V.X);
@@ -414,8 +423,8 @@ PBC_DEV bool a_pp_init_lane(uint32_t *tab, const uint8_t *g1) {
   return valid;
 }
 // r <- a * line(Q) on fused products (the wide fields; r and a distinct): cA, cB, cC are read where they lie
-template <int N>
-PBC_DEV void a_pp_line_x(fp2<N> &r, const fp2<N> &a, const uint32_t *tab, int idx, const fp<N> &Qx, const fp<N> &Qy) {
+template <int N, class R, class A>
+PBC_DEV void a_pp_line_x(R &r, const A &a, const uint32_t *tab, int idx, const fp<N> &Qx, const fp<N> &Qy) {
   using namespace fx;
   const fp<N> *e = reinterpret_cast<const fp<N> *>(tab + (size_t) idx * 3 * N);
   fp2<N> l;
@@ -616,7 +625,7 @@ PBC_DEV bool a1_miller_lane(fp2<N> &f, const uint8_t *g1, const uint8_t *g2, uin
         Qy.v[k] = lds_q[(N + k) * lds_stride];
       }
     }
-    a_double_step<N>(f, V, Qx, Qy);
+    a_double_step<N>(f, V, Qx, Qy, kMemOperands<N> ? lds_q : nullptr);
     const int dig = i > 0 ? a1_digit(i) : 0;
     if (dig) {                         // V <- V +- P (signed digits, hostbn.h naf_of_half)
       fp<N> x2, y2;
@@ -673,10 +682,13 @@ PBC_DEV bool a1_pp_init_lane(uint32_t *tab, const uint8_t *g1) {
   return valid;
 }
 template <int N>
-PBC_DEV void a1_pp_apply_lane(uint8_t *gt, const uint32_t *tab, bool p_valid, const uint8_t *g2) {
+PBC_DEV void a1_pp_apply_lane(uint8_t *gt, const uint32_t *tab, bool p_valid, const uint8_t *g2, uint32_t *lds_f = nullptr) {
   const int NB = fq_bytes<N>();
   fp<N> Qx, Qy;
   fp2<N> f, out;
+  fp<N> g_private[2];                  // f^2 of a step: in the lane's LDS slots on the device (6 of a step's 26 element moves)
+  fp2v<N> g{(kMemOperands<N> && lds_f) ? *reinterpret_cast<fp<N> *>(lds_f) : g_private[0],
+            (kMemOperands<N> && lds_f) ? *reinterpret_cast<fp<N> *>(lds_f + 36) : g_private[1]};
   fp_load_be<N>(Qx, g2);
   fp_load_be<N>(Qy, g2 + NB);
   bool valid = (int) p_valid & (int) a_on_curve<N>(Qx, Qy);
@@ -685,12 +697,12 @@ PBC_DEV void a1_pp_apply_lane(uint8_t *gt, const uint32_t *tab, bool p_valid, co
   int slot = 0;
   for (int i = c_a.rbits - 2; i >= 0; i--) {
     if constexpr (kMemOperands<N>) {
-      fp2<N> g;
       fi_sqr_x<N>(g, f);
       a_pp_line_x<N>(f, g, tab, slot++, Qx, Qy);
       if (i > 0 && a1_digit(i)) {
         a_pp_line_x<N>(g, f, tab, slot++, Qx, Qy);
-        f = g;
+        f.x = g.x;
+        f.y = g.y;
       }
       continue;
     }

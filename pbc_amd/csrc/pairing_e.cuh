@@ -68,15 +68,24 @@ PBC_DEV bool e_on_curve(const fp<N> &x, const fp<N> &y) {
   return fp_eq<N>(t0, t1);
 }
 
+// The running point.  ZZ = Z^2 and the steps' scratch element t0 carry a quarter of a step's element moves (20 of 76):
+// they live where the caller puts them -- two LDS slots per lane on the device for the 33-word fields (the products
+// take generic pointers), the lane's private memory otherwise.
 template <int N>
-struct ejac { fp<N> X, Y, Z, ZZ; };
+struct ejac {
+  fp<N> X, Y, Z;
+  fp<N> *zz, *t0;
+};
+// a lane's two hot elements in LDS: 72 words per lane (16-byte aligned elements at words 0 and 36)
+constexpr int kWideHotWords = 72;
 template <int N>
 struct ekon { fp<N> A, x2, y2; };      // the uniform operands of a step, copied from the constant block once per lane
 
 // x^e for an exponent all lanes share: sliding window over odd powers x, x^3, ..., x^15 (control flow is uniform)
 template <int N>
-PBC_DEV void e_pow_win(fp<N> &r, const fp<N> &a, const uint32_t *e, int bits) {
-  fp<N> tab[8], acc;
+PBC_DEV void e_pow_win(fp<N> &r, const fp<N> &a, const uint32_t *e, int bits, fp<N> *slot) {
+  fp<N> tab[8], acc_private;
+  fp<N> &acc = slot ? *slot : acc_private;   // read and written by every product: an LDS slot on the device
   {
     fp<N> a2;
     tab[0] = a;
@@ -116,19 +125,20 @@ template <int N>
 PBC_DEV void e_double_step(fp<N> &n, fp<N> &d, ejac<N> &V, const fp<N> &x1, const fp<N> &y1, const ekon<N> &K) {
   using namespace fx;
   const int ks = b_times(c_e.rxs);
-  fp<N> XX, YY, M, t0, W, l1, l2, S;
+  fp<N> XX, YY, M, W, l1, l2, S;
+  fp<N> &ZZ = *V.zz, &t0 = *V.t0;
   fp_sqrx<N>(n, n);
   fp_sqrx<N>(d, d);
   fp_sqrx<N>(XX, V.X);
   fp_sqrx<N>(YY, V.Y);
-  fp_sqrx<N>(t0, V.ZZ);
+  fp_sqrx<N>(t0, ZZ);
   fp_mulx<N>(M, C1_ADD | c1_sh(1) | C2_ADD, t0, t0, K.A, K.A, XX, XX);                   // M = a Z^4 + 2X^2 + X^2
-  fp_sqrx<N>(V.Z, A_ADD | C1_SUB | C2_SUB, V.Y, V.Z, YY, V.ZZ);                          // Z3 = 2YZ, in place
-  fp_mulx<N>(W, V.Z, V.ZZ);
-  fp_mulx<N>(t0, C1_SUB, V.ZZ, V.ZZ, x1, x1, V.X, V.X);
+  fp_sqrx<N>(V.Z, A_ADD | C1_SUB | C2_SUB, V.Y, V.Z, YY, ZZ);                          // Z3 = 2YZ, in place
+  fp_mulx<N>(W, V.Z, ZZ);
+  fp_mulx<N>(t0, C1_SUB, ZZ, ZZ, x1, x1, V.X, V.X);
   fp_mulx<N>(t0, M, t0);
   fp_mulx<N>(l1, C1_SUB | c1_sh(1) | C2_SUB, W, W, y1, y1, YY, t0);                      // l(S1)
-  fp_mulx<N>(t0, B_SUB | ks, M, M, V.ZZ, V.X, M, M);                                     // M (s ZZ - X)
+  fp_mulx<N>(t0, B_SUB | ks, M, M, ZZ, V.X, M, M);                                     // M (s ZZ - X)
   fp_mulx<N>(l2, C1_SUB | c1_sh(1) | C2_SUB, W, W, K.y2, K.y2, YY, t0);                  // l(S2)
   fp_mulx<N>(n, n, l1);
   fp_mulx<N>(d, d, l2);
@@ -136,9 +146,9 @@ PBC_DEV void e_double_step(fp<N> &n, fp<N> &d, ejac<N> &V, const fp<N> &x1, cons
   fp_sqrx<N>(t0, YY);                                                                    // Y^4
   fp_sqrx<N>(V.X, C1_SUB | c1_sh(1), M, M, S, S);                                        // X3 = M^2 - 2S
   fp_mulx<N>(V.Y, B_SUB | C1_SUB | c1_sh(3), M, M, S, V.X, t0, t0);                      // Y3 = M (S - X3) - 8Y^4
-  fp_sqrx<N>(V.ZZ, V.Z);
-  fp_mulx<N>(n, B_SUB | ks, n, n, V.ZZ, V.X, n, n);                                      // v(S2) = s ZZ - X3
-  fp_mulx<N>(t0, C1_SUB, V.ZZ, V.ZZ, x1, x1, V.X, V.X);
+  fp_sqrx<N>(ZZ, V.Z);
+  fp_mulx<N>(n, B_SUB | ks, n, n, ZZ, V.X, n, n);                                      // v(S2) = s ZZ - X3
+  fp_mulx<N>(t0, C1_SUB, ZZ, ZZ, x1, x1, V.X, V.X);
   fp_mulx<N>(d, d, t0);
 }
 // chord through V and the affine P scaled by Z3 = Z H:  l(S) = (ys - yP) Z3 - R' (xs - xP),
@@ -148,9 +158,10 @@ PBC_DEV void e_add_step(fp<N> &n, fp<N> &d, ejac<N> &V, const fp<N> &xP, const f
                         const fp<N> &y1, const ekon<N> &K) {
   using namespace fx;
   const int ks = b_times(c_e.rxs);
-  fp<N> H, Rr, HH, HHH, t0;
-  fp_mulx<N>(H, C1_SUB, xP, xP, V.ZZ, V.ZZ, V.X, V.X);
-  fp_mulx<N>(t0, V.Z, V.ZZ);
+  fp<N> H, Rr, HH, HHH;
+  fp<N> &ZZ = *V.zz, &t0 = *V.t0;
+  fp_mulx<N>(H, C1_SUB, xP, xP, ZZ, ZZ, V.X, V.X);
+  fp_mulx<N>(t0, V.Z, ZZ);
   fp_mulx<N>(Rr, C1_SUB, yP, yP, t0, t0, V.Y, V.Y);
   fp_mulx<N>(V.Z, V.Z, H);                                                               // Z3, in place
   fp_mulx<N>(t0, A_SUB, y1, yP, V.Z, V.Z, V.Z, V.Z);
@@ -165,9 +176,9 @@ PBC_DEV void e_add_step(fp<N> &n, fp<N> &d, ejac<N> &V, const fp<N> &xP, const f
   fp_sqrx<N>(V.X, C1_SUB | C2_SUB | c2_sh(1), Rr, Rr, HHH, t0);                          // X3 = R'^2 - H^3 - 2 X H^2
   fp_mulx<N>(HHH, V.Y, HHH);
   fp_mulx<N>(V.Y, B_SUB | C1_SUB, Rr, Rr, t0, V.X, HHH, HHH);                            // Y3 = R' (X H^2 - X3) - Y H^3
-  fp_sqrx<N>(V.ZZ, V.Z);
-  fp_mulx<N>(n, B_SUB | ks, n, n, V.ZZ, V.X, n, n);
-  fp_mulx<N>(t0, C1_SUB, V.ZZ, V.ZZ, x1, x1, V.X, V.X);
+  fp_sqrx<N>(ZZ, V.Z);
+  fp_mulx<N>(n, B_SUB | ks, n, n, ZZ, V.X, n, n);
+  fp_mulx<N>(t0, C1_SUB, ZZ, ZZ, x1, x1, V.X, V.X);
   fp_mulx<N>(d, d, t0);
 }
 
@@ -207,9 +218,12 @@ PBC_DEV bool e_miller_lane(fp<N> &n, fp<N> &d, const uint8_t *g1, const uint8_t 
     x1 = x3;
     y1 = y3;
   }
-  (void) lds_q; (void) lds_stride;     // Q + R stays in the lane's private memory (memory operands)
+  (void) lds_stride;                   // Q + R stays in the lane's private memory (memory operands)
   ejac<N> V;
-  V.X = xP; V.Y = yP; V.Z = one; V.ZZ = one;
+  fp<N> hot_private[2];
+  V.zz = lds_q ? reinterpret_cast<fp<N> *>(lds_q) : &hot_private[0];
+  V.t0 = lds_q ? reinterpret_cast<fp<N> *>(lds_q + kWideHotWords / 2) : &hot_private[1];
+  V.X = xP; V.Y = yP; V.Z = one; *V.zz = one;
   for (int i = c_e.rbits - 2; i >= 0; i--) {
     e_double_step<N>(n, d, V, x1, y1, K);
     if ((c_e.r[i >> 5] >> (i & 31)) & 1) {
@@ -248,7 +262,7 @@ PBC_DEV void e_prod_pairing_lane(uint8_t *gt, const uint8_t *g1, const uint8_t *
   }
   fp_inv<N>(d, d);
   fp_mul<N>(n, n, d);
-  e_pow_win<N>(out, n, c_e.phik, c_e.phikbits);
+  e_pow_win<N>(out, n, c_e.phik, c_e.phikbits, lds_q ? reinterpret_cast<fp<N> *>(lds_q) : nullptr);
   if (!valid) fp_set<N>(out, fpk<N>().one);       // GT identity (pairing_apply, include/pbc_pairing.h:123-130)
   fp_store_be<N>(gt, out);
 }

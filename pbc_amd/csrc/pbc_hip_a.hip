@@ -130,8 +130,10 @@ __global__ void __launch_bounds__(kWide<N>, N >= 32 ? PBC_A1_WAVES : PBC_A_WAVES
   size_t ld = idx < n ? idx : n - 1;
   const int L = 2 * fq_bytes<N>();
   __attribute__((aligned(4))) uint8_t out[8 * N];
-  __shared__ uint32_t lds_q[kMemOperands<N> ? 1 : 2 * N * kWide<N>];   // wide fields keep Q in private memory
-  a1_prod_pairing_lane<N>(out, g1 + ld * k * L, g2 + ld * k * L, k, lds_q + threadIdx.x, kWide<N>);
+  // register-resident fields park Q in LDS (limb-major); the 33-word fields keep Q in private memory and the Miller
+  // step's two hottest temporaries in LDS, 72 words per lane (pairing_a.cuh a_double_step)
+  __shared__ __attribute__((aligned(16))) uint32_t lds_q[kMemOperands<N> ? 72 * kWide<N> : 2 * N * kWide<N>];
+  a1_prod_pairing_lane<N>(out, g1 + ld * k * L, g2 + ld * k * L, k, lds_q + threadIdx.x * (kMemOperands<N> ? 72 : 1), kWide<N>);
   if (idx < n) {
     if ((L & 3) == 0) {
       uint32_t *dst = reinterpret_cast<uint32_t *>(gt + idx * L);
@@ -151,7 +153,9 @@ __global__ void __launch_bounds__(kWide<N>, N >= 32 ? PBC_A1_WAVES : PBC_A_WAVES
   size_t ld = idx < n ? idx : n - 1;
   const int LT = fq_bytes<N>(), L = 2 * LT;
   __attribute__((aligned(4))) uint8_t out[4 * N];
-  uint32_t *lds_q = nullptr;           // unused: Q + R lives in the lane's private memory
+  // 33-word fields: the two hottest elements of a step (pairing_e.cuh ejac) in LDS, 72 words per lane
+  __shared__ __attribute__((aligned(16))) uint32_t lds_hot[kMemOperands<N> ? kWideHotWords * kWide<N> : 4];
+  uint32_t *lds_q = kMemOperands<N> ? lds_hot + threadIdx.x * kWideHotWords : nullptr;
   e_prod_pairing_lane<N>(out, g1 + ld * k * L, g2 + ld * k * L, k, lds_q, kWide<N>);
   if (idx < n) {
     if ((LT & 3) == 0) {
@@ -204,7 +208,8 @@ __global__ void __launch_bounds__(kWide<N>, N >= 32 ? PBC_A1_WAVES : PBC_A_WAVES
   size_t ld = idx < n ? idx : n - 1;
   const int L = 2 * fq_bytes<N>();
   __attribute__((aligned(4))) uint8_t out[8 * N];
-  a1_pp_apply_lane<N>(out, tab, *valid != 0, g2 + ld * L);
+  __shared__ __attribute__((aligned(16))) uint32_t lds_f[kMemOperands<N> ? 72 * kWide<N> : 4];   // 33-word fields: f^2 of a step in LDS
+  a1_pp_apply_lane<N>(out, tab, *valid != 0, g2 + ld * L, kMemOperands<N> ? lds_f + threadIdx.x * 72 : nullptr);
   if (idx < n) {
     if ((L & 3) == 0) {
       uint32_t *dst = reinterpret_cast<uint32_t *>(gt + idx * L);

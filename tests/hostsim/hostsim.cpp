@@ -514,6 +514,7 @@ int hostsim_len_zr(void *h) { return ((pbc_hip_pairing_s *) h)->len_zr; }
 // constant it is parameterised by: ops = a, a2, b, b2, c1, c2 (N words each); out = r (N words)
 int hostsim_fx(void *h, int sqr, int op, const uint32_t *ops, uint32_t *out) {
   pbc_hip_pairing_s *P = (pbc_hip_pairing_s *) h;
+  activate(P);
   HS_DISPATCH(P->nlimb, {
     fp<N> e[6], r;
     for (int j = 0; j < 6; j++) fp_set<N>(e[j], ops + j * N);

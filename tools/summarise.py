@@ -54,7 +54,7 @@ if os.path.exists(EV + "/pytest.log"):
     written.append("profiles/%s_gputest_tail.txt" % RND)
 MAIN = {"a": "al_pairing_kernel", "d": "d_prod_pairing_kernel", "f": "f_prod_pairing_kernel", "a-prod16": "al_miller_kernel",
         "a-g1-mul": "al_gmul_kernel", "f-gt-pow": "f_gtpow_kernel", "d-prod16": "d_prod_pairing_kernel", "d190": "d_prod_pairing_kernel",
-        "a-pp": "al_pp_apply_kernel"}
+        "a-pp": "al_pp_apply_kernel", "e": "e_prod_pairing_kernel", "a1": "a1_prod_pairing_kernel", "a1-pp": "a1_pp_apply_kernel"}
 for w, kern in MAIN.items():
     ks = glob.glob("%s/kt_%s/**/*kernel_stats.csv" % (EV, w), recursive=True)
     if ks:

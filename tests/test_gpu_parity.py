@@ -497,7 +497,8 @@ def test_other_families_ragged_batch_sizes(hips, key, name, n):
     assert np.array_equal(out, v.gt[idx])
 
 
-@pytest.mark.parametrize("key,name,log2n", [("g149", "g149_chain64.vec", 16), ("e", "e_chain8.vec", 14), ("a1", "a1_chain8.vec", 13)])
+@pytest.mark.parametrize("key,name,log2n", [("g149", "g149_chain64.vec", 16), ("e", "e_chain8.vec", 14), ("a1", "a1_chain8.vec", 13),
+                                            ("e", "e_chain8.vec", 17), ("a1", "a1_chain8.vec", 17)])   # 2^17: two waves on every SIMD (round 5)
 def test_other_families_device_batch_properties(hips, key, name, log2n):
     """device-pointer API on a batch that fills the chip: all (P_i, Q_j) of the chain fixture, tiled.
     e(P_i, Q_j) = e(P_0, Q_0)^((i+1)(j+1)), so the D x D result matrix is symmetric, every tile repeats
@@ -1191,3 +1192,25 @@ def _easy_part_is_one(recs, key):
     elif key == "f":
         x[:, lt // 6:] = 0                       # an element of F_q^2
     return x
+
+
+@pytest.mark.gpu
+def test_a1_preprocessed_pairings_on_a_batch_that_fills_two_waves_per_simd(hips):
+    """a1.param pairing_pp_apply at 2^17 units (round 5: 256-lane workgroups, two waves per SIMD, f^2 of a step in LDS)
+    against element_pairing of the same device buffers, and against the reference fixture where the arguments are its own."""
+    import torch
+    v = golden("a1_chain8.vec")
+    H = hips["a1"]
+    n, D, LT = 1 << 17, v.n, H.length_in_bytes_GT
+    st = torch.cuda.current_stream().cuda_stream
+    g2 = torch.from_numpy(v.g2).cuda()[torch.arange(n, device="cuda") % D].contiguous()
+    g1 = torch.from_numpy(np.tile(v.g1[3], (n, 1))).cuda()
+    pp = H.pp_init(v.g1[3])
+    got = torch.empty(n, LT, dtype=torch.uint8, device="cuda")
+    want = torch.empty(n, LT, dtype=torch.uint8, device="cuda")
+    pp.apply_dev(got.data_ptr(), g2.data_ptr(), n, st)
+    H.element_pairing_dev(want.data_ptr(), g1.data_ptr(), g2.data_ptr(), n, st)
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
+    assert np.array_equal(got[3].cpu().numpy(), v.gt[3])
+    pp.clear()

@@ -130,7 +130,11 @@ int pbc_hip_element_pairing_batch(pbc_hip_pairing_t *p, uint8_t *gt, const uint8
  * 1.7 ms at 1024, 2.6 ms at 2048, 4.4 ms at 4096, 5.3 ms at 5120 (the throughput kernel: 5.8-6.5 ms depending on the
  * box) -- same bytes as the throughput kernel.  pairing_pp_apply takes the same three forms (0.68 ms for one second
  * argument, 1.04 ms at 1024, 3.0 ms at 5120; lane kernel 3.1-3.5 ms), and products of k terms with n k <= hip_wave_max
- * give every TERM a workgroup and then every product one: 1.0 ms for one product of 2 .. 16 terms (lane kernels: 5.7-6.4). */
+ * give every TERM a workgroup and then every product one: 1.0 ms for one product of 2 .. 16 terms (lane kernels: 5.7-6.4).
+ *
+ * Batch sizes for the 33-word fields (a1.param, e.param, type a above 512 bits): the kernels hold TWO waves per SIMD in
+ * 256-lane workgroups, i.e. 2^17 units fill an MI355X once (e.param: 40 ms for any batch up to 2^16 units, 68 ms for
+ * 2^17, 131 ms for 2^18); batches of 2^18 and more amortise the tail of a launch. */
 int pbc_hip_element_pairing_batch_dev(pbc_hip_pairing_t *p, void *d_gt, const void *d_g1,
                                       const void *d_g2, size_t n, void *stream);
 

@@ -254,6 +254,47 @@ PBC_DEV void fp_sqr29_inl(fp<N> &r, const fp<N> &a) {
   uint32_t carry = from29<N>(w, t);
   fp_cond_sub<N>(r, w, carry);
 }
+// r = (a b + c d) / R mod q with ONE reduction: 3 L^2 multiply-adds instead of the 4 L^2 of two products.
+// Column bound: 3 L 2^(2W) < 2^64 for both limb widths (114 x 2^56, 54 x 2^58); the value before the final conditional
+// subtraction is below q (1 + 2q/R) < 2q.
+template <int N, bool ACC2>
+PBC_DEV void fp_sop2_29_inl(fp<N> &r, const fp<N> &a, const fp<N> &b, const fp<N> &c, const fp<N> &d) {
+  const FpK<N> &K = fpk<N>();
+  constexpr int L = Limbs29<N>::L;
+  constexpr uint32_t MASK = Limbs29<N>::MASK;
+  static_assert(3ull * L * (1ull << (2 * Limbs29<N>::W - 56)) < 256, "column accumulator would overflow");
+  uint32_t x[L], y[L], u[L], v[L], m[L], t[L];
+  PBC_COUNT_MACS(3 * L * L);
+  to29<N>(x, a);
+  to29<N>(y, b);
+  to29<N>(u, c);
+  to29<N>(v, d);
+  uint64_t acc = 0, acc1 = 0;
+#pragma unroll
+  for (int k = 0; k < L; k++) {
+#pragma unroll
+    for (int i = 0; i <= k; i++) { PBC_MAC(i, x[i], y[k - i]); PBC_MAC(i + 1, u[i], v[k - i]); }
+#pragma unroll
+    for (int i = 0; i < k; i++) PBC_MAC(i + 1, m[i], K.p29[k - i]);
+    if (ACC2) { acc += acc1; acc1 = 0; }
+    m[k] = ((uint32_t) acc * K.ninv29) & MASK;
+    acc += (uint64_t) m[k] * K.p29[0];
+    acc >>= Limbs29<N>::W;
+  }
+#pragma unroll
+  for (int k = L; k < 2 * L; k++) {
+#pragma unroll
+    for (int i = k - L + 1; i < L; i++) { PBC_MAC(i, x[i], y[k - i]); PBC_MAC(i + 1, u[i], v[k - i]); }
+#pragma unroll
+    for (int i = k - L + 1; i < L; i++) PBC_MAC(i + 1, m[i], K.p29[k - i]);
+    if (ACC2) { acc += acc1; acc1 = 0; }
+    t[k - L] = (uint32_t) acc & MASK;
+    acc >>= Limbs29<N>::W;
+  }
+  uint32_t w[N];
+  uint32_t carry = from29<N>(w, t);
+  fp_cond_sub<N>(r, w, carry);
+}
 #undef PBC_MAC
 
 // Limb-domain square: limbs in, limbs out (normalised input; same column bound as fp_sqr29_inl)
@@ -656,12 +697,17 @@ PBC_DEV void fp_dbl(fp<N> &r, const fp<N> &a) {
 //     r = 2^d ( (a [+- a2]) (k b [+- b2]) [+- 2^s1 c1] [+- 2^s2 c2] )
 // takes the linear work into the product's registers; every intermediate is the canonical representative mod q, so a
 // fused step returns what the same step built from fp_add / fp_sub / fp_mul returns.  `op` (wave-uniform) selects:
+template <int N> PBC_DEV void fp_neg_inl(fp<N> &r, const fp<N> &a);   // (below)
+#ifndef PBC_WIDE_NO_SOP
+#define PBC_WIDE_NO_SOP 0              // 1: the steps of types a1 / e without the two-product sums fp_sopx (same-box A/B)
+#endif
 namespace fx {
 constexpr int A_ADD = 1, A_SUB = 2, B_ADD = 4, B_SUB = 8, C1_ADD = 16, C1_SUB = 32, C2_ADD = 256, C2_SUB = 512;
 constexpr int c1_sh(int s) { return s << 6; }        // c1 enters as 2^s c1, s = 0..3
 constexpr int c2_sh(int s) { return s << 10; }
 constexpr int dbl(int d) { return d << 12; }         // the result is doubled d times, d = 0..3
 constexpr int b_times(int k) { return k << 16; }     // b enters as k b, k = 2..255 (0, 1: b itself)
+constexpr int NEG2 = 1 << 14;                        // fp_sopx: the second product is subtracted
 }
 template <int N>
 PBC_DEV void fx_addsub(fp<N> &x, const fp<N> *p, int mode, int sh) {
@@ -719,6 +765,53 @@ static __device__ __noinline__ void fp_sqrx_mem(fp<N> *r, const fp<N> *a, const 
   const int op = __builtin_amdgcn_readfirstlane(op_);
 #endif
   fx_sqr_body<N>(r, a, a2, c1, c2, op);
+}
+// r = 2^dd ( a b +- c (k d [+- d2]) [+- 2^s1 c1] [+- 2^s2 c2] ) with one reduction for the two products (fx::NEG2 selects
+// the minus; B_ADD / B_SUB / b_times apply to d)
+template <int N>
+static __device__ __noinline__ void fp_sopx_mem(fp<N> *r, const fp<N> *a, const fp<N> *b, const fp<N> *c, const fp<N> *d, const fp<N> *d2,
+                                                const fp<N> *c1, const fp<N> *c2, int op_) {
+#ifdef PBC_HOSTSIM
+  const int op = op_;
+#else
+  const int op = __builtin_amdgcn_readfirstlane(op_);
+#endif
+  fp<N> x = *a, y = *b, u = *c, v = *d, z;
+  const int k = (op >> 16) & 255;
+  if (k > 1) {
+    const fp<N> base = v;
+    for (int i = 30 - __builtin_clz(k); i >= 0; i--) {
+      fp_dbl_inl<N>(v, v);
+      if ((k >> i) & 1) fp_add_inl<N>(v, v, base);
+    }
+  }
+  if (op & 12) fx_addsub<N>(v, d2, (op >> 2) & 3, 0);
+  if (op & fx::NEG2) fp_neg_inl<N>(v, v);
+  fp_sop2_29_inl<N, PBC_MUL_IMPL == 2>(z, x, y, u, v);
+  fx_finish<N>(r, z, c1, c2, op);
+}
+template <int N>
+PBC_DEV void fp_sopx(fp<N> &r, int op, const fp<N> &a, const fp<N> &b, const fp<N> &c, const fp<N> &d, const fp<N> &d2,
+                     const fp<N> &c1, const fp<N> &c2) {
+  if constexpr (kMemOperands<N>) {
+    fp_sopx_mem<N>(&r, &a, &b, &c, &d, &d2, &c1, &c2, op);
+  } else {                             // register-resident fields: two products of their out-of-line body
+    fp<N> v = d, z, t;
+    const int k = (op >> 16) & 255;
+    if (k > 1) {
+      const fp<N> base = v;
+      for (int i = 30 - __builtin_clz(k); i >= 0; i--) {
+        fp_dbl_inl<N>(v, v);
+        if ((k >> i) & 1) fp_add_inl<N>(v, v, base);
+      }
+    }
+    if (op & 12) fx_addsub<N>(v, &d2, (op >> 2) & 3, 0);
+    fp_mul<N>(t, c, v);
+    fp_mul<N>(z, a, b);
+    if (op & fx::NEG2) fp_sub_inl<N>(z, z, t);
+    else fp_add_inl<N>(z, z, t);
+    fx_finish<N>(&r, z, &c1, &c2, op);
+  }
 }
 // r may be any of the operands (everything is read before r is written).  Fields whose elements live in registers run
 // the same sequence on the out-of-line product of their width.

@@ -63,10 +63,17 @@ struct fp2v {
 template <int N, class R, class A, class B>
 PBC_DEV void fi_mul_x(R &r, const A &a, const B &b) {
   using namespace fx;
+  // two two-product sums with one reduction each (fp_sopx): the multiply-adds of Karatsuba's three products, two calls
+  // instead of three and 10 element moves instead of 14
+#if PBC_WIDE_NO_SOP                    // A/B: Karatsuba, three products with a reduction each
   fp<N> e1;
   fp_mulx<N>(e1, a.y, b.y);
-  fp_mulx<N>(r.x, C1_SUB, a.x, a.x, b.x, b.x, e1, e1);                                    // a.x b.x - a.y b.y
-  fp_mulx<N>(r.y, A_ADD | B_ADD | C1_SUB | C2_SUB | c2_sh(1), a.x, a.y, b.x, b.y, r.x, e1);  // (a.x+a.y)(b.x+b.y) - a.x b.x - a.y b.y
+  fp_mulx<N>(r.x, C1_SUB, a.x, a.x, b.x, b.x, e1, e1);
+  fp_mulx<N>(r.y, A_ADD | B_ADD | C1_SUB | C2_SUB | c2_sh(1), a.x, a.y, b.x, b.y, r.x, e1);
+#else
+  fp_sopx<N>(r.x, NEG2, a.x, b.x, a.y, b.y, b.y, a.x, a.x);                                // a.x b.x - a.y b.y
+  fp_sopx<N>(r.y, 0, a.x, b.y, a.y, b.x, b.x, a.x, a.x);                                   // a.x b.y + a.y b.x
+#endif
 }
 template <int N, class R, class A>
 PBC_DEV void fi_sqr_x(R &r, const A &a) {

@@ -17,7 +17,7 @@
 //     one (q-1)/r power per lane;
 //   * round 5: the steps run on fused products (fp.cuh: no sum or difference through memory on its own), R's
 //     x-coordinate is a SMALL INTEGER s by construction, so "ZZ x_R" is s ZZ by additions inside the product that uses
-//     it (23 instead of 25 products per doubling step), and the (q-1)/r power runs on a sliding window over the
+//     it (23 instead of 25 products per doubling step, and the two line values as two-product sums with one reduction each), and the (q-1)/r power runs on a sliding window over the
 //     860-bit exponent, which is the same for every lane (180 instead of 430 products besides the squarings).
 #pragma once
 #include "fp.cuh"
@@ -120,7 +120,7 @@ PBC_DEV void e_pow_win(fp<N> &r, const fp<N> &a, const uint32_t *e, int bits, fp
 // n <- n^2 l(S1) v(S2),  d <- d^2 l(S2) v(S1)   for S1 = Q + R (per lane), S2 = R = (s, y2) (uniform)
 //   tangent at V scaled by 2 Y Z^3:  l(S) = (Z3 ZZ) ys - 2 Y^2 - M (ZZ xs - X),  M = 3X^2 + a Z^4, Z3 = 2YZ
 //   vertical at 2V scaled by Z3^2:   v(S) = Z3^2 xs - X3
-// 10 S + 13 M, each one fused product.
+// 10 S + 9 M + 2 two-product sums (one reduction each): 21 fused calls.
 template <int N>
 PBC_DEV void e_double_step(fp<N> &n, fp<N> &d, ejac<N> &V, const fp<N> &x1, const fp<N> &y1, const ekon<N> &K) {
   using namespace fx;
@@ -136,10 +136,15 @@ PBC_DEV void e_double_step(fp<N> &n, fp<N> &d, ejac<N> &V, const fp<N> &x1, cons
   fp_sqrx<N>(V.Z, A_ADD | C1_SUB | C2_SUB, V.Y, V.Z, YY, ZZ);                          // Z3 = 2YZ, in place
   fp_mulx<N>(W, V.Z, ZZ);
   fp_mulx<N>(t0, C1_SUB, ZZ, ZZ, x1, x1, V.X, V.X);
+#if PBC_WIDE_NO_SOP                    // A/B: every product with its own reduction (profiles/r05_ab_wide.txt block 13)
   fp_mulx<N>(t0, M, t0);
-  fp_mulx<N>(l1, C1_SUB | c1_sh(1) | C2_SUB, W, W, y1, y1, YY, t0);                      // l(S1)
-  fp_mulx<N>(t0, B_SUB | ks, M, M, ZZ, V.X, M, M);                                     // M (s ZZ - X)
-  fp_mulx<N>(l2, C1_SUB | c1_sh(1) | C2_SUB, W, W, K.y2, K.y2, YY, t0);                  // l(S2)
+  fp_mulx<N>(l1, C1_SUB | c1_sh(1) | C2_SUB, W, W, y1, y1, YY, t0);
+  fp_mulx<N>(t0, B_SUB | ks, M, M, ZZ, V.X, M, M);
+  fp_mulx<N>(l2, C1_SUB | c1_sh(1) | C2_SUB, W, W, K.y2, K.y2, YY, t0);
+#else
+  fp_sopx<N>(l1, NEG2 | C1_SUB | c1_sh(1), W, y1, M, t0, t0, YY, YY);                    // l(S1) = W y1 - M (ZZ x1 - X) - 2Y^2: two products, one reduction
+  fp_sopx<N>(l2, NEG2 | B_SUB | ks | C1_SUB | c1_sh(1), W, K.y2, M, ZZ, V.X, YY, YY);    // l(S2) = W y2 - M (s ZZ - X) - 2Y^2
+#endif
   fp_mulx<N>(n, n, l1);
   fp_mulx<N>(d, d, l2);
   fp_mulx<N>(S, dbl(2), V.X, V.X, YY, YY, YY, YY);                                       // 4XY^2

@@ -216,9 +216,10 @@ class HostSim:
         return out
 
     def fx(self, sqr, op, words):
-        """one fused product (fp.cuh fp_mulx / fp_sqrx): words = 6 lists of N little-endian words (a, a2, b, b2, c1, c2)"""
+        """one fused product (fp.cuh fp_mulx / fp_sqrx / fp_sopx for sqr = 2): words = 7 lists of N little-endian words
+        (a, a2, b, b2, c1, c2, d2)"""
         ops = np.ascontiguousarray(np.array(words, np.uint32).reshape(-1))
-        out = np.zeros(len(ops) // 6, np.uint32)
+        out = np.zeros(len(ops) // 7, np.uint32)
         self.L.hostsim_fx.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
         n = self.L.hostsim_fx(self.h, sqr, op, ops.ctypes.data, out.ctypes.data)
         assert n == len(out)

@@ -156,7 +156,7 @@ int hostsim_prod_wave(void *h, uint8_t *gt, const uint8_t *g1, const uint8_t *g2
 int hostsim_prod_pairing(void *h, uint8_t *gt, const uint8_t *g1, const uint8_t *g2, size_t n, int k) {
   pbc_hip_pairing_s *P = (pbc_hip_pairing_s *) h;
   activate(P, true);                     // the constant block of a pairing launch (launch_pairing / launch_prod)
-  static uint32_t lds[2 * 33];
+  static uint32_t lds[72];               // Q of the register-resident fields (2 N words) / the two hot elements of the 33-word steps (72 words)
   for (size_t u = 0; u < n; u++) {
     const uint8_t *a = g1 + u * k * P->len1, *b = g2 + u * k * P->len2;
     uint8_t *o = gt + u * P->lenT;
@@ -199,7 +199,8 @@ int hostsim_pp(void *h, uint8_t *gt, const uint8_t *g1, const uint8_t *g2, size_
   if (P->type == '1' || (P->type == 'a' && P->a_generic)) {
     static uint32_t tab1[2048 * 3 * 33];
     bool v = a1_pp_init_lane<33>(tab1, g1);
-    for (size_t u = 0; u < n; u++) a1_pp_apply_lane<33>(gt + u * P->lenT, tab1, v, g2 + u * P->len2);
+    static uint32_t hot[72];             // as the kernel: f^2 of a step in the lane's two LDS slots
+    for (size_t u = 0; u < n; u++) a1_pp_apply_lane<33>(gt + u * P->lenT, tab1, v, g2 + u * P->len2, hot);
     return 0;
   }
   if (P->type != 'a') return 1;
@@ -511,14 +512,15 @@ int hostsim_zr_op(void *h, int op, uint8_t *out, const uint8_t *a, const uint8_t
 }
 int hostsim_len_zr(void *h) { return ((pbc_hip_pairing_s *) h)->len_zr; }
 // one fused product of fp.cuh ("Fused products": fp_mulx / fp_sqrx) on residues given as little-endian words, and the type e
-// constant it is parameterised by: ops = a, a2, b, b2, c1, c2 (N words each); out = r (N words)
+// constant it is parameterised by: ops = a, a2, b, b2, c1, c2, d2 (N words each; sqr = 2: fp_sopx computes a b +- a2 (k b2 +- d2) ...); out = r
 int hostsim_fx(void *h, int sqr, int op, const uint32_t *ops, uint32_t *out) {
   pbc_hip_pairing_s *P = (pbc_hip_pairing_s *) h;
   activate(P);
   HS_DISPATCH(P->nlimb, {
-    fp<N> e[6], r;
-    for (int j = 0; j < 6; j++) fp_set<N>(e[j], ops + j * N);
-    if (sqr) fp_sqrx<N>(r, op, e[0], e[1], e[4], e[5]);
+    fp<N> e[7], r;
+    for (int j = 0; j < 7; j++) fp_set<N>(e[j], ops + j * N);
+    if (sqr == 2) fp_sopx<N>(r, op, e[0], e[2], e[1], e[3], e[6], e[4], e[5]);       // a b +- a2 (k b2 +- d2) ...
+    else if (sqr) fp_sqrx<N>(r, op, e[0], e[1], e[4], e[5]);
     else fp_mulx<N>(r, op, e[0], e[1], e[2], e[3], e[4], e[5]);
     for (int k = 0; k < N; k++) out[k] = r.v[k];
   });

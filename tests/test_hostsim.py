@@ -621,21 +621,23 @@ def test_fused_products_on_host(sims, key, qkey, nw):
         op |= int(rng.integers(0, 4)) << 6 | int(rng.integers(0, 4)) << 10 | int(rng.integers(0, 4)) << 12
         if rng.integers(0, 2):
             op |= int(rng.choice([2, 3, 5, 7, 8, 100, 255])) << 16
-        cases.append((int(rng.integers(0, 2)), op))
+        cases.append((int(rng.integers(0, 3)), op))
+    cases += [(2, 0), (2, 1 << 14), (2, (1 << 14) | 8 | (2 << 16) | 32 | (1 << 6))]      # the two-product sums as the steps use them
     for t, (sqr, op) in enumerate(cases):
-        e = [rnd() for _ in range(6)]
+        e = [rnd() for _ in range(7)]
         if t % 7 == 3:
-            e[t % 6] = 0
+            e[t % 7] = 0
         if t % 7 == 5:
-            e[(t + 1) % 6] = q - 1
-        a, a2, b, b2, c1, c2 = e
-        x = a + (a2 if op & 1 else -a2 if op & 2 else 0)
-        if sqr:
-            y = x
+            e[(t + 1) % 7] = q - 1
+        a, a2, b, b2, c1, c2, d2 = e
+        k = (op >> 16) & 255
+        if sqr == 2:                     # fp_sopx: a b +- a2 (k b2 +- d2), one reduction
+            v = (k if k > 1 else 1) * b2 + (d2 if op & 4 else -d2 if op & 8 else 0)
+            z = (a * b + (-1 if op & (1 << 14) else 1) * a2 * v) * Rinv
         else:
-            k = (op >> 16) & 255
-            y = (k if k > 1 else 1) * b + (b2 if op & 4 else -b2 if op & 8 else 0)
-        z = x * y * Rinv
+            x = a + (a2 if op & 1 else -a2 if op & 2 else 0)
+            y = x if sqr else (k if k > 1 else 1) * b + (b2 if op & 4 else -b2 if op & 8 else 0)
+            z = x * y * Rinv
         z += (c1 << ((op >> 6) & 3)) * (1 if op & 16 else -1 if op & 32 else 0)
         z += (c2 << ((op >> 10) & 3)) * (1 if op & 256 else -1 if op & 512 else 0)
         z = (z << ((op >> 12) & 3)) % q

@@ -79,3 +79,31 @@ def test_no_register_is_live_across_a_call_that_changes_it():
         findings, ncalls, unresolved, _ = ipra_check.check(funcs, k, "s")
         assert ncalls > 20 and unresolved == 0, k
         assert findings == [], (k, findings[:3])
+
+
+def test_wide_field_bodies_fit_two_waves_per_simd():
+    """round 5: the fused product bodies of the 33-word fields and the three kernels that call them are built for
+    two waves per SIMD -- at most 256 registers and, in the bodies, no spilled state beyond a few words (a regression here
+    halves the multiply-add rate or sends the product's operands through private memory).  Read from the assembly of the
+    last `make -C pbc_amd`; skipped where the build's temporaries are not there."""
+    import re
+    asm = "/tmp/pbc_hip_build/obj_libpbc_hip/pbc_hip_a-hip-amdgcn-amd-amdhsa-gfx950.s"
+    if not os.path.exists(asm):
+        pytest.skip("no -save-temps assembly of the library build here")
+    info, name = {}, None
+    for line in open(asm):
+        m = re.match(r"^(_Z[\w$.]+):", line)
+        if m:
+            name = m.group(1)
+            continue
+        m = re.match(r"^; (NumVgprs|NumAgprs|ScratchSize): (\d+)", line)
+        if m and name:
+            info.setdefault(name, {})[m.group(1)] = int(m.group(2))
+    bodies = [k for k in info if re.search(r"fp_(mulx|sqrx|sopx)_memILi33E", k)]
+    assert len(bodies) == 3
+    for k in bodies:
+        assert info[k]["NumVgprs"] + info[k]["NumAgprs"] <= 256 and info[k]["ScratchSize"] <= 64, (k, info[k])
+    kernels = [k for k in info if re.match(r"_Z\d+(a1_prod_pairing|e_prod_pairing|a1_pp_apply)_kernelILi33E", k)]
+    assert len(kernels) == 3
+    for k in kernels:
+        assert info[k]["NumVgprs"] + info[k]["NumAgprs"] <= 256, (k, info[k])

@@ -140,7 +140,7 @@ def executed_group_macs(workload):
 def cpu_baseline(param_path, op):
     import oracle
     tool = oracle.REF_TOOL
-    cores = os.cpu_count() or 1
+    cores = oracle.usable_cores()      # the cgroup quota, not the logical CPU count of the box
     if not os.path.exists(tool):
         return None
     per = {"g1mul": 400, "g2mul": 200, "gtpow": 2000, "hashg1": 200, "g1pp": 4000, "gtpp": 20000, "blsverify": 150,
@@ -162,7 +162,7 @@ def cpu_baseline(param_path, op):
         pass
     return {"value": round(allc["units_per_s"], 1), "unit": UNIT[op], "cores": cores, "kind": "reference",
             "sample": "%d %s per worker x %d forked workers (ref_tool benchg, %s), %.1f s wall" % (per, op, cores, os.path.basename(param_path), allc["wall_s"]),
-            "single_core": round(one["units_per_s"], 1), "per_core_when_all_busy": round(allc["per_core"], 1), "cgroup_cpu_quota_cores": quota}
+            "single_core": round(one["units_per_s"], 1), "per_core_when_all_busy": round(allc["per_core"], 1), "logical_cpus": os.cpu_count(), "cgroup_cpu_quota_cores": quota}
 
 
 def load_bls(path):

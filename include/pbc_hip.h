@@ -15,12 +15,13 @@
  *
  * All functions return 0 on success, non-zero on failure (pairing_init_set_buf
  * convention, ecc/pairing.c:88-98); pbc_hip_last_error() gives the message.  A
- * pbc_hip_pairing_t is not re-entrant: one batch call at a time per object.  The _dev forms may be enqueued on several
- * streams of one object at once, but ONE host thread issues the calls of an (object, stream) pair: the two-pass group
- * operations (fast kernel + complete kernel for the lanes it flagged), the head / tail split of the small-batch
- * kernels and the per-launch unit counters keep their scratch in a workspace keyed by (device, stream), so two threads
- * interleaving launches on the same pair would read each other's flags.  Use one stream per issuing thread, or one
- * object per thread (objects are cheap: constants travel in the kernel arguments).
+ * pbc_hip_pairing_t is not re-entrant for the host-buffer forms: one host-buffer batch call at a time per object.  The
+ * _dev forms may be enqueued on several streams of one object at once and from several host threads, also on the SAME
+ * (object, stream) pair: the scratch of a call (the flags of the two-pass group operations -- fast kernel + complete kernel
+ * for the lanes it flagged --, the term records of the products) lives in a workspace keyed by (device, stream) whose
+ * issue lock the call holds while it enqueues its kernels, so the calls of two threads on one stream are enqueued one
+ * after the other, never interleaved (round 6; tests/test_gpu_group2.py::test_two_threads_issue_on_one_stream).  The
+ * per-launch unit counters ("hip_dynamic 1") are slots of a ring, one per launch.
  *
  * Input classes (every one is covered by a GPU test, tests/test_gpu_parity.py):
  *   - Points of the whole curve.  curve_from_bytes (ecc/curve.c:609-623) checks the curve equation only, so a G1 / G2
@@ -285,9 +286,15 @@ int pbc_hip_finalpow_batch(pbc_hip_pairing_t *p, uint8_t *out, const uint8_t *in
  *     reference's contract (mpz_invert fails); it gives 0 here.  pbc_hip_zr_from_hash_batch: element_from_hash on Zr
  *     (fp_from_hash, arith/montfp.c:440-448 over pbc_mpz_from_hash arith/field.c:643-668) for n digests of hlen bytes.
  *   element_pow2_zn / element_pow3_zn (include/pbc_field.h:496-531 -> arith/field.c:153-241) on G1, G2 (group 1, 2:
- *     [n1] a1 + [n2] a2 (+ [n3] a3)) and GT (group 3: a1^n1 a2^n2 (a3^n3)): Shamir's trick -- a per-lane table of the
- *     subset sums, ONE doubling (squaring) per scalar bit for all bases instead of one ladder per base; complete (any
- *     point of the curve, any scalar of length_in_bytes_Zr bytes). */
+ *     [n1] a1 + [n2] a2 (+ [n3] a3)) and GT (group 3: a1^n1 a2^n2 (a3^n3)).  Default route: the composition of the
+ *     library's tuned single-base ladders (element_mul_zn / element_pow_zn per base, then the additions / products; the
+ *     faster route on MI355X, profiles/r05_notes.md).  "hip_group_slow 1" in the parameter text: Shamir's trick -- a
+ *     per-lane table of the subset sums, ONE doubling (squaring) per scalar bit for all bases.  Both are complete (any
+ *     point of the curve, any scalar of length_in_bytes_Zr bytes) and give the same bytes; out may overlap any base.
+ *   The all-zero record on types a / a1 (curve y^2 = x^3 + x): the group law above reads and writes it as O, although
+ *     (0, 0) is a finite point of order two there and pbc_hip_element_snprint prints the record as "[0, 0]" (what the
+ *     reference prints for that point).  P + (-P) therefore prints as "[0, 0]", not "O", and adding the genuine
+ *     2-torsion point is outside this library's group law (it lies outside G1: the cofactor is even). */
 int pbc_hip_element_add_batch(pbc_hip_pairing_t *p, int group, uint8_t *out, const uint8_t *a, const uint8_t *b, size_t n);
 int pbc_hip_element_sub_batch(pbc_hip_pairing_t *p, int group, uint8_t *out, const uint8_t *a, const uint8_t *b, size_t n);
 int pbc_hip_element_neg_batch(pbc_hip_pairing_t *p, int group, uint8_t *out, const uint8_t *a, size_t n);

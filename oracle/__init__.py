@@ -290,3 +290,29 @@ def ref_gen(param_path, mode, n, k, seed, out_path):
     subprocess.check_call([REF_TOOL, "gen", param_path, mode, str(n), str(k), str(seed), out_path],
                           stderr=subprocess.DEVNULL)
     return Vec(out_path)
+
+
+def usable_cores():
+    """Host cores this process may really use: the smaller of the logical CPU count (affinity mask respected) and the
+    cgroup CPU quota (a GPU box shows 256 logical CPUs under a 16-core quota)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:  # pragma: no cover
+        n = os.cpu_count() or 1
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(p))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+def ref_soak(param_path, n_random, k, seed, out_path, rbits, workers=None):
+    """SURVEY 8d's full-parity distribution from the compiled reference on every usable core (ref_harness.c `soak`:
+    n_random uniformly random units of k terms; k == 1 adds crafted points -- limb patterns of the device library's
+    Montgomery form, x = q - 1, ... -- and records with coordinates >= q).  Returns (Vec, the tool's JSON summary)."""
+    import json
+    out = subprocess.run([REF_TOOL, "soak", param_path, str(n_random), str(k), str(seed), out_path,
+                          str(workers or usable_cores()), str(rbits)], check=True, capture_output=True, text=True)
+    return Vec(out_path), json.loads(out.stdout.strip().splitlines()[-1])

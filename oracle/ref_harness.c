@@ -849,6 +849,217 @@ static int cmd_pow23(int argc, char **argv) {
   return 0;
 }
 
+/* ---- soak: SURVEY 8d's full-parity distribution, on every host core -------------------------------------------------
+ * soak <param> <n_random> <k> <seed> <out> <workers> <rbits>
+ *   n_random units of k terms with uniformly random inputs (pbc_random_set_deterministic BEFORE pairing_init, then
+ *   element_random: arith/random.c:80-83, ecc/curve.c:430-438), split over `workers` forked processes (worker w draws
+ *   from seed + 7919 (w + 1)); and -- k == 1 only -- a block of CRAFTED units appended by the parent:
+ *     * points of the curve / the twist whose x coordinate is q - 1, q - 2, 1, 2, (q +- 1) / 2, or whose MONTGOMERY
+ *       residue x R mod q (R = 2^rbits, the radix of the device library's 29-bit limb form) has limbs that are all ones,
+ *       all zero but one, alternating, or a single bit on a limb boundary -- nudged upwards until x^3 + a x + b is a square
+ *       (curve_from_x; such points lie on the whole curve, not in the order-r subgroup, which curve_from_bytes accepts);
+ *       on a twist over F_q^d either every coefficient of x carries the pattern or only the first (the rest zero);
+ *     * records whose coordinates are written as v + t q >= q (fp_from_bytes reduces them, arith/montfp.c:498-517).
+ *   Every crafted point meets a random partner, and crafted G1 points meet crafted G2 points.
+ * File: the vector layout above with n = n_random + crafted; stdout: one JSON line with the counts. */
+#include <sys/mman.h>
+static void *shared_alloc(size_t n) {
+  void *p = mmap(NULL, n ? n : 1, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0);
+  if (p == MAP_FAILED) { perror("mmap"); exit(2); }
+  return p;
+}
+/* pattern number t -> an integer below q; *mont says whether it is meant as the Montgomery residue */
+#define SOAK_PATTERNS 22
+static void soak_pattern(mpz_t m, int t, const mpz_t q, int rbits, int *mont) {
+  const int W = 29, L = rbits / W;
+  mpz_t one; mpz_init_set_ui(one, 1);
+  mpz_set_ui(m, 0);
+  *mont = t >= 6;
+  switch (t) {
+    case 0: mpz_sub_ui(m, q, 1); break;
+    case 1: mpz_sub_ui(m, q, 2); break;
+    case 2: mpz_set_ui(m, 1); break;
+    case 3: mpz_set_ui(m, 2); break;
+    case 4: mpz_sub_ui(m, q, 1); mpz_fdiv_q_2exp(m, m, 1); break;
+    case 5: mpz_add_ui(m, q, 1); mpz_fdiv_q_2exp(m, m, 1); break;
+    case 6: mpz_sub_ui(m, q, 1); break;                                  /* residue q - 1: x = -1 / R */
+    case 7: mpz_set_ui(m, 1); break;                                     /* residue 1: x = 1 / R */
+    case 8: mpz_mul_2exp(m, one, W * L); mpz_sub_ui(m, m, 1); break;     /* every limb all ones (cut below q further down) */
+    case 9: case 10: case 11: {                                           /* one limb all ones, the rest zero */
+      int i = t == 9 ? 0 : t == 10 ? L / 2 : L - 2;
+      mpz_mul_2exp(m, one, W); mpz_sub_ui(m, m, 1); mpz_mul_2exp(m, m, W * i); break;
+    }
+    case 12: case 13:                                                     /* alternating all-ones / all-zero limbs */
+      for (int i = t - 12; i < L; i += 2) { mpz_t u; mpz_init(u); mpz_mul_2exp(u, one, W); mpz_sub_ui(u, u, 1); mpz_mul_2exp(u, u, W * i); mpz_add(m, m, u); mpz_clear(u); }
+      break;
+    case 14: mpz_mul_2exp(m, one, W); break;                              /* a single bit on a limb boundary */
+    case 15: mpz_mul_2exp(m, one, W * (L / 2)); break;
+    case 16: mpz_mul_2exp(m, one, W * (L - 2)); break;
+    case 17:                                                               /* every limb 2^28 (the top bit of each limb) */
+      for (int i = 0; i < L; i++) { mpz_t u; mpz_init(u); mpz_mul_2exp(u, one, W * i + W - 1); mpz_add(m, m, u); mpz_clear(u); }
+      break;
+    case 18:                                                               /* every limb 1 */
+      for (int i = 0; i < L; i++) { mpz_t u; mpz_init(u); mpz_mul_2exp(u, one, W * i); mpz_add(m, m, u); mpz_clear(u); }
+      break;
+    case 19: mpz_mul_2exp(m, one, 32 * ((W * L) / 64)); mpz_sub_ui(m, m, 1); break;     /* low half of the words all ones */
+    case 20: mpz_mul_2exp(m, one, W * (L - 1)); mpz_sub_ui(m, m, 1); break;            /* all limbs but the top one all ones */
+    default: mpz_mul_2exp(m, one, W * L); mpz_sub_ui(m, m, 1); mpz_fdiv_q_2exp(m, m, 1); mpz_mul_2exp(m, m, 1); break;   /* ...1110 */
+  }
+  if (mpz_cmp(m, q) >= 0) mpz_fdiv_r_2exp(m, m, mpz_sizeinbase(q, 2) - 1);
+  mpz_clear(one);
+}
+/* an F_q element (the base field of the coordinates) from pattern t, nudged `bump` upwards in the pattern's domain */
+static void soak_set_fq(element_ptr c, int t, int bump, int rbits) {
+  mpz_t m, r; int mont;
+  mpz_init(m); mpz_init(r);
+  soak_pattern(m, t, c->field->order, rbits, &mont);
+  mpz_add_ui(m, m, bump);
+  mpz_mod(m, m, c->field->order);
+  if (mont) {                                                            /* x = m / R mod q */
+    mpz_set_ui(r, 1); mpz_mul_2exp(r, r, rbits); mpz_invert(r, r, c->field->order);
+    mpz_mul(m, m, r); mpz_mod(m, m, c->field->order);
+  }
+  element_set_mpz(c, m);
+  mpz_clear(m); mpz_clear(r);
+}
+/* a point of P's curve whose x follows pattern t (sparse: only the first coefficient of x, the others zero) */
+static void soak_point(element_t P, int t, int sparse, int rbits) {
+  element_ptr x = curve_x_coord(P);
+  element_t xx, u;
+  element_init_same_as(xx, x);
+  element_init_same_as(u, x);
+  const int d = element_item_count(xx);
+  for (int bump = 0;; bump++) {
+    if (!d) soak_set_fq(xx, t, bump, rbits);
+    else {
+      element_set0(xx);
+      for (int i = 0; i < (sparse ? 1 : d); i++) soak_set_fq(element_item(xx, i), t, i ? 0 : bump, rbits);
+    }
+    element_square(u, xx);
+    element_add(u, u, curve_a_coeff(P));
+    element_mul(u, u, xx);
+    element_add(u, u, curve_b_coeff(P));
+    if (element_is0(u) || !element_is_sqr(u)) continue;                  /* (u == 0: a point of order two) */
+    /* points of tiny order are left out: Miller's algorithm then passes through O and 2-torsion (a vertical tangent,
+     * f = 0), where the reference's value hangs on what mpz_invert does with 0 -- x = 1 on y^2 = x^3 + x has order 4 */
+    curve_from_x(P, xx);
+    element_t T;
+    int tiny = 0;
+    element_init_same_as(T, P);
+    element_set(T, P);
+    for (int i = 2; i <= 12 && !tiny; i++) { element_add(T, T, P); tiny = element_is0(T); }
+    element_clear(T);
+    if (!tiny) break;
+  }
+  if (t & 1) element_neg(P, P);
+  element_clear(xx); element_clear(u);
+}
+/* every coordinate v of a record -> v + t q with the largest t that fits its fb bytes (which = bit mask of coordinates) */
+static int soak_noncanonical(unsigned char *rec, int len, int fb, const mpz_t q, unsigned which) {
+  int changed = 0;
+  mpz_t v, lim;
+  mpz_init(v); mpz_init(lim);
+  mpz_set_ui(lim, 1); mpz_mul_2exp(lim, lim, 8 * fb);
+  for (int c = 0; c < len / fb; c++) {
+    if (!((which >> (c % 8)) & 1)) continue;
+    mpz_import(v, fb, 1, 1, 1, 0, rec + c * fb);
+    if (!mpz_sgn(v)) continue;                                           /* (zero stays zero: the reference keys on the bytes being zero) */
+    mpz_add(v, v, q);
+    if (mpz_cmp(v, lim) >= 0) continue;
+    for (;;) { mpz_add(v, v, q); if (mpz_cmp(v, lim) >= 0) { mpz_sub(v, v, q); break; } }
+    memset(rec + c * fb, 0, fb);
+    size_t cnt = (mpz_sizeinbase(v, 2) + 7) / 8;
+    mpz_export(rec + c * fb + (fb - cnt), NULL, 1, 1, 1, 0, v);
+    changed++;
+  }
+  mpz_clear(v); mpz_clear(lim);
+  return changed;
+}
+static int cmd_soak(int argc, char **argv) {
+  if (argc < 8) { fprintf(stderr, "soak <param> <n_random> <k> <seed> <out> <workers> <rbits>\n"); return 2; }
+  const char *param = argv[1], *outp = argv[5];
+  const int nr = atoi(argv[2]), k = atoi(argv[3]), rbits = atoi(argv[7]);
+  const unsigned seed = (unsigned) strtoul(argv[4], NULL, 10);
+  int workers = atoi(argv[6]);
+  if (workers < 1) workers = 1;
+  if (workers > 256) workers = 256;
+  const double t0 = now();
+  pairing_t pairing; char type;
+  pbc_random_set_deterministic(seed);
+  init_pairing(pairing, param, &type);
+  const int l1 = pairing_length_in_bytes_G1(pairing), l2 = pairing_length_in_bytes_G2(pairing), lt = pairing_length_in_bytes_GT(pairing);
+  /* crafted block: per pattern and sparseness one G1 and one G2 point; units (cP, rQ), (rP, cQ), (cP, cQ); then non-canonical records */
+  const int npat = k == 1 ? SOAK_PATTERNS : 0, nnc = k == 1 ? 24 : 0;
+  const int ncraft = 3 * 2 * npat + nnc;
+  const size_t n = (size_t) nr + ncraft, tot = (size_t) nr * k + ncraft;
+  unsigned char *b1 = shared_alloc(tot * l1), *b2 = shared_alloc(tot * l2), *bo = shared_alloc(n * lt);
+  for (int w = 0; w < workers; w++) {
+    pid_t pid = fork();
+    if (pid < 0) { perror("fork"); return 2; }
+    if (pid == 0) {
+      pairing_t pw; char tw;
+      pbc_random_set_deterministic(seed + 7919u * (unsigned) (w + 1));
+      init_pairing(pw, param, &tw);
+      element_t *P = malloc(sizeof(element_t) * k), *Q = malloc(sizeof(element_t) * k), out;
+      for (int j = 0; j < k; j++) { element_init_G1(P[j], pw); element_init_G2(Q[j], pw); }
+      element_init_GT(out, pw);
+      const size_t u0 = (size_t) nr * w / workers, u1 = (size_t) nr * (w + 1) / workers;
+      for (size_t u = u0; u < u1; u++) {
+        for (int j = 0; j < k; j++) {
+          element_random(P[j]); element_random(Q[j]);
+          element_to_bytes(b1 + (u * k + j) * l1, P[j]);
+          element_to_bytes(b2 + (u * k + j) * l2, Q[j]);
+        }
+        if (k == 1) element_pairing(out, P[0], Q[0]); else element_prod_pairing(out, P, Q, k);
+        element_to_bytes(bo + u * lt, out);
+      }
+      _exit(0);
+    }
+  }
+  int changed = 0;
+  if (ncraft) {
+    element_t P, Q, out;
+    element_init_G1(P, pairing); element_init_G2(Q, pairing); element_init_GT(out, pairing);
+    const int fb = l1 / 2;                                                /* bytes of one F_q coordinate */
+    size_t u = nr;
+    for (int t = 0; t < npat; t++)
+      for (int sparse = 0; sparse < 2; sparse++)
+        for (int kind = 0; kind < 3; kind++, u++) {                       /* 0: (cP, rQ)  1: (rP, cQ)  2: (cP, cQ) */
+          if (kind == 1) element_random(P); else soak_point(P, t, sparse, rbits);
+          if (kind == 0) element_random(Q); else soak_point(Q, (t + kind) % npat, sparse, rbits);
+          element_to_bytes(b1 + u * l1, P);
+          element_to_bytes(b2 + u * l2, Q);
+          element_pairing(out, P, Q);
+          element_to_bytes(bo + u * lt, out);
+        }
+    for (int c = 0; c < nnc; c++, u++) {
+      element_random(P); element_random(Q);
+      element_to_bytes(b1 + u * l1, P);
+      element_to_bytes(b2 + u * l2, Q);
+      changed += soak_noncanonical(b1 + u * l1, l1, fb, curve_x_coord(P)->field->order, c % 3 == 1 ? 0 : 1u + (unsigned) c % 3);
+      changed += soak_noncanonical(b2 + u * l2, l2, fb, curve_x_coord(P)->field->order, c % 3 == 0 ? 0 : 0xffu >> (c % 5));
+      element_from_bytes(P, b1 + u * l1);
+      element_from_bytes(Q, b2 + u * l2);
+      element_pairing(out, P, Q);
+      element_to_bytes(bo + u * lt, out);
+    }
+  }
+  int bad = 0, st;
+  while (wait(&st) > 0) bad += !(WIFEXITED(st) && WEXITSTATUS(st) == 0);
+  if (bad) { fprintf(stderr, "soak: %d workers failed\n", bad); return 3; }
+  FILE *fp = fopen(outp, "wb");
+  if (!fp) { perror(outp); return 2; }
+  fwrite("PBCVEC01", 1, 8, fp);
+  w32(fp, (uint32_t) type); w32(fp, (uint32_t) n); w32(fp, k); w32(fp, l1); w32(fp, l2); w32(fp, lt);
+  /* k > 1 has no crafted block, so the term arrays are exactly n k records */
+  fwrite(b1, l1, tot, fp); fwrite(b2, l2, tot, fp); fwrite(bo, lt, n, fp);
+  fclose(fp);
+  printf("{\"param\": \"%s\", \"type\": \"%c\", \"random_units\": %d, \"terms_per_unit\": %d, \"crafted_units\": %d, \"crafted_patterns\": %d, "
+         "\"noncanonical_units\": %d, \"noncanonical_coordinates\": %d, \"seed\": %u, \"workers\": %d, \"rbits\": %d, \"reference_wall_s\": %.2f}\n",
+         param, type, nr, k, ncraft, npat, nnc, changed, seed, workers, rbits, now() - t0);
+  return 0;
+}
+
 int main(int argc, char **argv) {
   if (argc < 2) { fprintf(stderr, "usage: ref_tool gen|kat|bench ...\n"); return 2; }
   if (!strcmp(argv[1], "gen")) return cmd_gen(argc - 1, argv + 1);
@@ -871,5 +1082,6 @@ int main(int argc, char **argv) {
   if (!strcmp(argv[1], "gops")) return cmd_gops(argc - 1, argv + 1);
   if (!strcmp(argv[1], "zrops")) return cmd_zrops(argc - 1, argv + 1);
   if (!strcmp(argv[1], "pow23")) return cmd_pow23(argc - 1, argv + 1);
+  if (!strcmp(argv[1], "soak")) return cmd_soak(argc - 1, argv + 1);
   return 2;
 }

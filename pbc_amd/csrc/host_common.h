@@ -11,6 +11,7 @@
 #include <string.h>
 
 #include <functional>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -180,7 +181,8 @@ struct ProdWs {
   ~ProdWs() { if (pinned) workspace_unpin(P, s); }
   void *get(size_t bytes) {
     if (own) return own_workspace(*own, s, bytes);
-    void *w = workspace_get(P, s, bytes);
+    void *w = workspace_get(P, s, bytes);      // pins the entry and takes its issue lock (pbc_hip.hip WsEnt)
+    if (w && pinned) workspace_unpin(P, s);    // a second request of the same call: one pin, one lock level
     pinned = pinned || w != nullptr;
     return w;
   }

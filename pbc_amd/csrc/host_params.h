@@ -43,6 +43,7 @@ inline int fail(const char *fmt, ...) {
 #define PBC_A_WAVE4_MAX 768
 #endif
 // ---------------------------------------------------------------------------------------
+constexpr size_t kProdChunkDefault = (size_t) 1 << 22;   // type a products: terms per launch of the one-term-per-lane kernels unless "hip_prod_chunk N" says otherwise
 struct pbc_hip_pairing_s {
   int type;
   int device;
@@ -258,7 +259,7 @@ static int init_type_a(pbc_hip_pairing_s *P, const char *txt, size_t len) {
     int shared = 0;                    // products: one term per lane (pairing_al.cuh) unless the parameter text says otherwise
     param_int(txt, len, "hip_prod_shared", shared);
     P->a_prod_shared = shared != 0;
-    int chunk = 1 << 22;               // 2^22 terms = 640 MB of 160-byte workspace records
+    int chunk = (int) kProdChunkDefault;   // 2^22 terms = 640 MB of 160-byte workspace records
     param_int(txt, len, "hip_prod_chunk", chunk);
     P->a_prod_chunk = chunk < 1 ? 1 : (size_t) chunk;
     int wave_max = PBC_A_WAVE_MAX;     // the batch size below which a wavefront per pairing is the faster launch (bench.py --sweep)

@@ -49,6 +49,14 @@
 #ifndef PBC_F_NO_CONJ
 #define PBC_F_NO_CONJ 0                // 1: the q^6-power Frobenius through the generic qpower routine (A/B of round 5's f12_conj)
 #endif
+#ifndef PBC_F_LINE_SEL
+#define PBC_F_LINE_SEL 0               // f_line_mul_lds: the factors of an output switched by two branches on the loop counter (0: selects in every iteration)
+#endif
+#ifdef PBC_HOSTSIM
+#define PBC_KEEP_BRANCH() ((void) 0)
+#else
+#define PBC_KEEP_BRANCH() asm volatile("" ::: "memory")     // (keeps the compiler from turning a wave-uniform branch back into per-lane selects)
+#endif
 #ifndef PBC_F_LINE_LIMB
 #define PBC_F_LINE_LIMB 1              // f_line_mul_lds: the line's pre-multiplication by Q and -alpha in limb form (0: word-form calls)
 #endif
@@ -817,6 +825,11 @@ static __device__ __noinline__ void f_line_mul_lds(int cur, vfl va, vfl vb, vfl 
     g2l_mul_na(Bqn, Bq);
   }
   uint32_t pre[kPrefetch ? 6 * FL : 1];
+#if PBC_F_LINE_SEL
+  // the factors of an output change twice in the six iterations (b Qy loses its xi at output 3, a Qx at output 4): two
+  // branches on the loop counter that copy 18 registers when taken, instead of 36 selects in every iteration
+  g2l fa = Aqn, fb = Bqn;
+#endif
 #pragma nounroll
   for (int half = 0; half < 2; half++) {
     if constexpr (kPrefetch) { if (half == 1) O.prefetch(pre); }      // outputs 0-2 come back while 3-5 are computed
@@ -826,9 +839,14 @@ static __device__ __noinline__ void f_line_mul_lds(int cur, vfl va, vfl vb, vfl 
       bool wj = true, wk = true;         // wrapped (needs negalpha) unless i >= 4 / i >= 3
       if (j >= 6) { j -= 6; wj = false; }
       if (k >= 6) { k -= 6; wk = false; }
+#if PBC_F_LINE_SEL
+      if (i == 3) { fb = Bq; PBC_KEEP_BRANCH(); }
+      if (i == 4) { fa = Aq; PBC_KEEP_BRANCH(); }
+#else
       g2l fa, fb;
       g2l_sel(fa, Aq, Aqn, wj);
       g2l_sel(fb, Bq, Bqn, wk);
+#endif
       const fl<ND> vix = ldsf_get(i, 0, cur), viy = ldsf_get(i, 1, cur), vjx = ldsf_get(j, 0, cur), vjy = ldsf_get(j, 1, cur),
                    vkx = ldsf_get(k, 0, cur), vky = ldsf_get(k, 1, cur);
       fl<ND> t;

@@ -551,12 +551,15 @@ struct DevCtx {
 // different streams get their own.  At most kMaxWs are kept: a caller that launches on ever new streams evicts the least
 // recently used entry that is not pinned by a launch in progress (after a device synchronisation -- its stream may no
 // longer exist), so the footprint stays bounded and a recycled stream handle cannot alias a stale entry for long.
-struct WsEnt { int dev; hipStream_t st; void *p; size_t cap; uint64_t used; int pins; };
+// `issue` is held from workspace_get to workspace_unpin, i.e. while ONE call enqueues its kernels: two host threads that
+// launch on the same (object, stream) pair take turns, so the complete pass of a two-pass operation always reads the flags
+// its own fast pass wrote (the stream runs each call's kernels back to back).  Recursive: a call may ask twice.
+struct WsEnt { int dev; hipStream_t st; void *p; size_t cap; uint64_t used; int pins; std::recursive_mutex issue; };
 constexpr size_t kMaxWs = 8;
 struct HostCtx {
   DevCtx dc[kMaxDev];
   int n = 0;
-  std::vector<WsEnt> ws;
+  std::vector<std::unique_ptr<WsEnt>> ws;      // (stable addresses: a launch holds its entry while the table changes)
   uint64_t ws_clock = 0;
   std::mutex mu;                               // guards the tables (the per-device entries are used by one worker each)
 };
@@ -590,10 +593,10 @@ static void hostctx_free(pbc_hip_pairing_s *P) {
   }
   HostCtx *H = static_cast<HostCtx *>(P->host_ctx);
   if (!H) return;
-  for (WsEnt &w : H->ws) {
-    DeviceGuard guard(w.dev);
+  for (auto &w : H->ws) {
+    DeviceGuard guard(w->dev);
     (void) hipDeviceSynchronize();
-    (void) hipFree(w.p);
+    (void) hipFree(w->p);
   }
   for (int i = 0; i < H->n; i++) devctx_release(H->dc[i]);
   delete H;
@@ -607,43 +610,57 @@ void *workspace_get(pbc_hip_pairing_s *P, hipStream_t s, size_t bytes) {
   if (hipGetDevice(&dev) != hipSuccess) { fail("no current HIP device"); return nullptr; }
   if (!P->host_ctx) P->host_ctx = new HostCtx();
   HostCtx *H = static_cast<HostCtx *>(P->host_ctx);
-  std::lock_guard<std::mutex> lk(H->mu);
   WsEnt *e = nullptr;
-  for (WsEnt &w : H->ws)
-    if (w.dev == dev && w.st == s) e = &w;
-  if (!e) {
-    if (H->ws.size() >= kMaxWs) {        // evict the least recently used entry that no launch holds
-      size_t lru = H->ws.size();
-      for (size_t i = 0; i < H->ws.size(); i++)
-        if (!H->ws[i].pins && (lru == H->ws.size() || H->ws[i].used < H->ws[lru].used)) lru = i;
-      if (lru < H->ws.size()) {
-        {
-          DeviceGuard guard(H->ws[lru].dev);
-          (void) hipDeviceSynchronize();
-          if (H->ws[lru].p) (void) hipFree(H->ws[lru].p);
-        }
-        H->ws.erase(H->ws.begin() + (long) lru);
-      }                                  // (every entry pinned: the table grows past kMaxWs for the moment)
+  {
+    std::lock_guard<std::mutex> lk(H->mu);
+    for (auto &w : H->ws)
+      if (w->dev == dev && w->st == s) e = w.get();
+    if (!e) {
+      if (H->ws.size() >= kMaxWs) {        // evict the least recently used entry that no launch holds
+        size_t lru = H->ws.size();
+        for (size_t i = 0; i < H->ws.size(); i++)
+          if (!H->ws[i]->pins && (lru == H->ws.size() || H->ws[i]->used < H->ws[lru]->used)) lru = i;
+        if (lru < H->ws.size()) {
+          {
+            DeviceGuard guard(H->ws[lru]->dev);
+            (void) hipDeviceSynchronize();
+            if (H->ws[lru]->p) (void) hipFree(H->ws[lru]->p);
+          }
+          H->ws.erase(H->ws.begin() + (long) lru);
+        }                                  // (every entry pinned: the table grows past kMaxWs for the moment)
+      }
+      H->ws.emplace_back(new WsEnt{dev, s, nullptr, 0, 0, 0, {}});
+      e = H->ws.back().get();
     }
-    H->ws.push_back(WsEnt{dev, s, nullptr, 0, 0, 0});
-    e = &H->ws.back();
+    e->used = ++H->ws_clock;
+    e->pins++;
   }
-  e->used = ++H->ws_clock;
+  e->issue.lock();                         // (outside the table lock: another thread may be enqueueing on this entry)
   if (e->cap < bytes) {
     if (e->p) { (void) hipStreamSynchronize(s); (void) hipFree(e->p); e->p = nullptr; e->cap = 0; }
-    if (hipMalloc(&e->p, bytes) != hipSuccess) { e->p = nullptr; fail("device allocation of a %zu-byte product workspace failed", bytes); return nullptr; }
+    if (hipMalloc(&e->p, bytes) != hipSuccess) {
+      e->p = nullptr;
+      e->issue.unlock();
+      { std::lock_guard<std::mutex> lk(H->mu); e->pins--; }
+      fail("device allocation of a %zu-byte product workspace failed", bytes);
+      return nullptr;
+    }
     e->cap = bytes;
   }
-  e->pins++;
   return e->p;
 }
 void workspace_unpin(pbc_hip_pairing_s *P, hipStream_t s) {
   int dev = -1;
   HostCtx *H = static_cast<HostCtx *>(P->host_ctx);
   if (!H || hipGetDevice(&dev) != hipSuccess) return;
-  std::lock_guard<std::mutex> lk(H->mu);
-  for (WsEnt &w : H->ws)
-    if (w.dev == dev && w.st == s && w.pins > 0) w.pins--;
+  WsEnt *e = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(H->mu);
+    for (auto &w : H->ws)
+      if (w->dev == dev && w->st == s && w->pins > 0) e = w.get();
+    if (e) e->pins--;
+  }
+  if (e) e->issue.unlock();                // (the calling thread is the one that locked it: ProdWs is scoped to one call)
 }
 void *own_workspace(const OwnWs &o, hipStream_t s, size_t bytes) {
   if (*o.cap < bytes) {
@@ -658,10 +675,10 @@ extern "C" int pbc_hip_pairing_release_workspaces(pbc_hip_pairing_t *P) {
   HostCtx *H = static_cast<HostCtx *>(P->host_ctx);
   if (!H) return 0;
   std::lock_guard<std::mutex> lk(H->mu);
-  for (WsEnt &w : H->ws) {
-    DeviceGuard guard(w.dev);
+  for (auto &w : H->ws) {
+    DeviceGuard guard(w->dev);
     (void) hipDeviceSynchronize();
-    if (w.p) (void) hipFree(w.p);
+    if (w->p) (void) hipFree(w->p);
   }
   H->ws.clear();
   for (int i = 0; i < H->n; i++)        // the chunk buffers and workspaces of the host-buffer path as well (the streams stay)

@@ -7,6 +7,11 @@
 // F_q elements are in limb form throughout (pairing_al.cuh).
 // lanes per workgroup: 256 for the 33-word kernels (one wave per SIMD of a CU; see launch_a), 128 otherwise
 template <int N> constexpr int kWide = N >= 32 ? 256 : kBlock;
+// The 33-word kernels below keep 72 words of LDS per lane in 256-lane workgroups: 72 KB of static LDS, which gfx950's
+// 160 KB per CU holds twice and the 64 KB of gfx90a / gfx942 not at all -- this library is written for gfx950 only.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "libpbc_hip targets gfx950 (MI355X): its kernels are sized for 160 KB of LDS per CU"
+#endif
 template <int N>
 __global__ void __launch_bounds__(kBlock, PBC_A_WAVES) al_pairing_kernel(uint8_t *gt, const uint8_t *g1,
                                                              const uint8_t *g2, size_t n, unsigned *ctr, KArgs<N> ka) {
@@ -268,7 +273,8 @@ int launch_a(pbc_hip_pairing_s *P, void *d_gt, const void *d_g1, const void *d_g
     }
     hipLaunchKernelGGL(al_pairing_kernel<16>, dim3(rg), dim3(kBlock), 0, s, (uint8_t *) d_gt,
                        (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, unit_counter(P, s), kargs<16>(P));
-  } else if (P->type == 'a' && !P->a_generic && k > 1 && n * (size_t) k <= P->a_wave_max) {
+  } else if (P->type == 'a' && !P->a_generic && k > 1 && n * (size_t) k <= P->a_wave_max && !P->a_prod_shared && P->a_prod_chunk == kProdChunkDefault) {
+    // ("hip_prod_shared 1" / "hip_prod_chunk N" name a kernel explicitly: those objects never take the wave routines)
     // a few terms in all (benchmark/multipairing.c's shape, or one element_prod_pairing through the hooks): a wave (four,
     // up to hip_wave4_max terms) per TERM, then a wave (four) per PRODUCT -- the latency of one Miller loop and one final
     // exponentiation on the wave routines instead of the 6.4 ms of a lane kernel (pairing_aw.cuh)

@@ -105,9 +105,11 @@ extern "C" int pbc_hip_element_sub_batch(pbc_hip_pairing_t *P, int group, uint8_
   return affine_host(P, 1, group, out, a, b, n);
 }
 extern "C" int pbc_hip_element_neg_batch(pbc_hip_pairing_t *P, int group, uint8_t *out, const uint8_t *a, size_t n) {
+  if (!a || !out) return fail("null argument");
   return affine_host(P, 2, group, out, a, nullptr, n);
 }
 extern "C" int pbc_hip_element_double_batch(pbc_hip_pairing_t *P, int group, uint8_t *out, const uint8_t *a, size_t n) {
+  if (!a || !out) return fail("null argument");
   return affine_host(P, 3, group, out, a, nullptr, n);
 }
 extern "C" int pbc_hip_element_add_batch_dev(pbc_hip_pairing_t *P, int group, void *d_out, const void *d_a, const void *d_b, size_t n, void *stream) {
@@ -119,9 +121,11 @@ extern "C" int pbc_hip_element_sub_batch_dev(pbc_hip_pairing_t *P, int group, vo
   return affine_dev(P, 1, group, d_out, d_a, d_b, n, stream);
 }
 extern "C" int pbc_hip_element_neg_batch_dev(pbc_hip_pairing_t *P, int group, void *d_out, const void *d_a, size_t n, void *stream) {
+  if (!d_a || !d_out) return fail("null argument");
   return affine_dev(P, 2, group, d_out, d_a, nullptr, n, stream);
 }
 extern "C" int pbc_hip_element_double_batch_dev(pbc_hip_pairing_t *P, int group, void *d_out, const void *d_a, size_t n, void *stream) {
+  if (!d_a || !d_out) return fail("null argument");
   return affine_dev(P, 3, group, d_out, d_a, nullptr, n, stream);
 }
 
@@ -143,17 +147,26 @@ static int multi_launch(pbc_hip_pairing_s *P, int group, int k, void *d_out, con
   const size_t lp = group_len(P, group);
   if (!P->group_slow) {
     if (M.astride != lp || M.zstride != (size_t) P->len_zr) return fail("internal: packed records on the composition route");
-    void *tmp = nullptr;
-    HIP_TRY(hipMallocAsync(&tmp, n * lp, s));
+    // `out` may be any ONE of the bases (include/pbc_hip.h; the reference lets x alias a base): the first term is written
+    // before the later bases are read, so a result that overlaps a later base is accumulated in a second temporary
+    bool alias = false;
+    for (int j = 1; j < k; j++) {
+      const uint8_t *b = M.a[j];
+      alias |= b < o + n * lp && o < b + n * lp;
+    }
+    void *tmp = nullptr, *acc = d_out;
+    HIP_TRY(hipMallocAsync(&tmp, n * lp * (alias ? 2 : 1), s));
+    if (alias) acc = (uint8_t *) tmp + n * lp;
     int rc = 0;
     for (int j = 0; j < k && !rc; j++) {
-      void *dst = j ? tmp : d_out;
+      void *dst = j ? tmp : acc;
       rc = group == 3 ? pbc_hip_element_pow_zn_GT_batch_dev(P, dst, M.a[j], M.z[j], n, s)
                       : pbc_hip_element_mul_zn_batch_dev(P, group, dst, M.a[j], M.z[j], n, s);
       if (!rc && j)
-        rc = group == 3 ? pbc_hip_element_mul_GT_batch_dev(P, d_out, d_out, tmp, n, s)
-                        : pbc_hip_element_add_batch_dev(P, group, d_out, d_out, tmp, n, s);
+        rc = group == 3 ? pbc_hip_element_mul_GT_batch_dev(P, acc, acc, tmp, n, s)
+                        : pbc_hip_element_add_batch_dev(P, group, acc, acc, tmp, n, s);
     }
+    if (!rc && alias && hipMemcpyAsync(d_out, acc, n * lp, hipMemcpyDeviceToDevice, s) != hipSuccess) rc = fail("hipMemcpyAsync");
     (void) hipFreeAsync(tmp, s);
     return rc;
   }

@@ -305,3 +305,75 @@ def test_fixed_base_table_with_a_device_set_and_twist_records_with_unreduced_coo
     assert P.element_snprint(2, off)[0] == "O"
     pp.clear()
     P.clear()
+
+
+@pytest.mark.parametrize("key,name", [("a", "a_chain1024.vec"), ("d", "d_chain256.vec"), ("f", "f_chain128.vec")])
+def test_multi_exponentiation_with_the_result_over_an_input(hips, key, name):
+    """element_pow2_zn / element_pow3_zn with x aliased to each base in turn (the reference lets x be any of them,
+    arith/field.c:153-241; ADVICE r5: the composition route wrote [n1] a1 into out before reading a2): the _dev forms on
+    both routes, G1 and GT, against the result computed into a separate buffer"""
+    import pbc_amd
+    import torch
+    v = golden(name)
+    n = 300
+    rng = np.random.default_rng(61)
+    r = _order(key)
+    routes = [hips[key], pbc_amd.Pairing(_param(PARAM_OF.get(key, key)) + "hip_group_slow 1\n")]
+    for H in routes:
+        zl = H.length_in_bytes_Zr
+        Z = [torch.from_numpy(np.stack([_be(int.from_bytes(rng.bytes(zl), "big") % r, zl) for _ in range(n)])).cuda() for _ in range(3)]
+        for group, src in ((1, v.g1), (3, v.gt)):
+            X = [np.ascontiguousarray(src[rng.integers(0, v.n, n)]) for _ in range(3)]
+            for k in (2, 3):
+                want = H.element_pow_multi(group, X[:k], [z.cpu().numpy() for z in Z[:k]])
+                for alias in range(k):
+                    D = [torch.from_numpy(x).cuda() for x in X[:k]]
+                    H.element_pow_multi_dev(group, D[alias].data_ptr(), [d.data_ptr() for d in D], [z.data_ptr() for z in Z[:k]], n, 0)
+                    torch.cuda.synchronize()
+                    assert np.array_equal(D[alias].cpu().numpy(), want), (group, k, alias)
+    routes[1].clear()
+
+
+def test_two_threads_issue_on_one_stream(hips):
+    """two host threads enqueue two-pass operations (element_mul_zn on a.param G1: fast kernel + the complete kernel for the
+    lanes it flags, sharing a flags workspace keyed by (device, stream)) on the SAME stream of one object: each call's
+    kernels are enqueued as a unit (pbc_hip.hip WsEnt::issue), so every result equals the single-threaded one.  The
+    scalars 0 / r - 1 / >= r and equal-looking inputs make sure both passes have flagged lanes."""
+    import threading
+    import torch
+    H = hips["a"]
+    v = golden("a_chain1024.vec")
+    n, rounds = 3000, 12
+    r = _order("a")
+    zl = H.length_in_bytes_Zr
+    rng = np.random.default_rng(5)
+    jobs = []
+    for t in range(2):
+        ks = [int.from_bytes(rng.bytes(zl), "big") % r for _ in range(n)]
+        for q, k in enumerate([0, 1, r - 1, r, r + 1, (1 << (8 * zl)) - 1]):
+            ks[(q * 7 + t) % n] = k
+        z = np.stack([_be(k, zl) for k in ks])
+        x = np.ascontiguousarray(v.g1[rng.integers(0, v.n, n)])
+        x[5 + t::97] ^= 1                                # off-curve records: O
+        jobs.append((x, z, H.element_mul_zn(1, x, z)))
+    outs = [[torch.empty(n, H.length_in_bytes_G1, dtype=torch.uint8, device="cuda") for _ in range(rounds)] for _ in range(2)]
+    dev = [(torch.from_numpy(x).cuda(), torch.from_numpy(z).cuda()) for x, z, _ in jobs]
+    torch.cuda.synchronize()
+    errs = []
+
+    def worker(t):
+        try:
+            for i in range(rounds):
+                H.element_mul_zn_dev(1, outs[t][i].data_ptr(), dev[t][0].data_ptr(), dev[t][1].data_ptr(), n, 0)
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(2)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    torch.cuda.synchronize()
+    assert not errs, errs
+    for t in range(2):
+        for i in range(rounds):
+            assert np.array_equal(outs[t][i].cpu().numpy(), jobs[t][2]), (t, i)

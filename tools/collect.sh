@@ -1,5 +1,5 @@
 #!/bin/bash
-# Evidence driver (run HERE, in the build container): every number under profiles/${ROUND}_* (ROUND defaults to r05)
+# Evidence driver (run HERE, in the build container): every number under profiles/${ROUND}_* (ROUND defaults to r06)
 # comes from ONE commit.
 #   1. refuses to start when the work tree is dirty (tracked changes or untracked, unignored files);
 #   2. stamps HEAD into .evidence_head (git-ignored; it travels with the gpurun snapshot, bench.py copies it into every
@@ -11,7 +11,7 @@
 # ADDENDUM=1: a partial collection after a change to a few kernels (restrict it with BENCH_WL / GROUP_WL / PMC_WL / SKIP_*):
 # the files it produces replace their predecessors and are listed, with THEIR commit, under "addenda" of the manifest.
 cd "$(dirname "$0")/.." || exit 1
-export ROUND=${ROUND:-r05}
+export ROUND=${ROUND:-r06}
 if [ -n "$(git status --porcelain)" ]; then echo "work tree is dirty: commit first (evidence is taken from a commit, not from a state)"; git status --short | head; exit 1; fi
 git rev-parse HEAD > .evidence_head
 rm -rf gpurun_out/ev_$ROUND

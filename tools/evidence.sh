@@ -4,7 +4,7 @@
 # suite, a bench line per workload, rocprofv3 kernel traces (--kernel-trace --stats) and PMC passes (separate --pmc
 # runs, kernel trace only) of the BASELINE configs and the group-operation headliners.
 # BENCH_WL / GROUP_WL / PMC_WL restrict the lists; WITH_TESTS=1 runs the suite first.  Output: gpurun_out/ev_$ROUND/.
-R="${GRAFT_REPO_ROOT:-/root/repo}"; ROUND=${ROUND:-r05}; O=$R/gpurun_out/ev_$ROUND; mkdir -p $O; cd $R || exit 1
+R="${GRAFT_REPO_ROOT:-/root/repo}"; ROUND=${ROUND:-r06}; O=$R/gpurun_out/ev_$ROUND; mkdir -p $O; cd $R || exit 1
 cp .evidence_head $O/HEAD 2>/dev/null || { echo "no .evidence_head: start this through tools/collect.sh"; exit 1; }
 [ -z "$WITH_TESTS" ] || { timeout 1500 python -m pytest tests -m gpu -q --maxfail 10 > $O/pytest.log 2>&1; tail -n 3 $O/pytest.log; }
 for w in ${BENCH_WL-a d f a-prod16 d-prod16 a-pp d-pp g g-pp e a1 a1-pp f256 d190 d201 d224}; do

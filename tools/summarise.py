@@ -15,7 +15,7 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.chdir(ROOT)
-RND = os.environ.get("ROUND", "r05")
+RND = os.environ.get("ROUND", "r06")
 EV = "gpurun_out/ev_" + RND
 head = subprocess.check_output(["git", "rev-parse", "HEAD"], text=True).strip()
 dirty = subprocess.check_output(["git", "status", "--porcelain"], text=True).strip()
@@ -79,6 +79,9 @@ for w, kern in MAIN.items():
     if out:
         out["commit"] = head
         out["kernel"] = kern
+        sys.path.insert(0, ROOT)
+        import bench                                     # the hash bench.py's roofline.traffic checks before it quotes this file
+        out["kernel_src_sha"] = bench.kernel_source_sha()
         b = "profiles/%s_bench_%s.json" % (RND, w)
         if os.path.exists(b):
             out["units_per_launch"] = json.loads(open(b).readline())["config"].get("units_per_gpu")

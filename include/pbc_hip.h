@@ -271,6 +271,21 @@ int pbc_hip_element_pp_pow_zn_batch_dev(pbc_hip_element_pp_t *pp, void *d_out, c
  * for n records of GT's underlying field in GT's wire format.  in[i] = 0 is outside the reference's contract too. */
 int pbc_hip_finalpow_batch(pbc_hip_pairing_t *p, uint8_t *out, const uint8_t *in, size_t n);   /* (_dev form: above) */
 
+/* The reference's own limb image as the exchange format (round 6).  element_to_bytes / element_from_bytes cost the host
+ * a Montgomery reduction, a GMP export and two allocations per F_q coordinate (arith/montfp.c:487-517, :122-139); an
+ * integration that sits INSIDE PBC can hand over what a montfp element holds instead (the per-element data of
+ * arith/montfp.c:36-39: t = ceil(bits(q) / 64) little-endian 64-bit limbs of x 2^(64 t) mod q, fully reduced; a zero
+ * element -- flag 0, :93-100 -- as t zero limbs) and take the results back the same way.  A limb-image record is the wire
+ * record with every length_in_bytes(F_q)-byte coordinate replaced by its 8 t bytes, in the same order (x || y,
+ * coefficient 0 first: fq_to_bytes fieldquadratic.c:323-329, polymod_to_bytes poly.c:718-733, curve_to_bytes
+ * curve.c:603-609).  The change of Montgomery radix is one F_q product per coordinate on the device; everything else
+ * (off-curve inputs -> O, identity outputs, products) is the wire-format path.  Replaces, for the batch calls of
+ * integration/pbc_hip_glue.c, fp_to_bytes / fp_from_bytes on every coordinate. */
+int pbc_hip_fq_limb_image_bytes(pbc_hip_pairing_t *p);          /* 8 t (0 on failure) */
+int pbc_hip_element_pairing_batch_limbs(pbc_hip_pairing_t *p, uint8_t *gt, const uint8_t *g1, const uint8_t *g2, size_t n);
+int pbc_hip_element_prod_pairing_batch_limbs(pbc_hip_pairing_t *p, uint8_t *gt, const uint8_t *g1, const uint8_t *g2, size_t n, int k);
+int pbc_hip_element_prod_pairing_batch_limbs_dev(pbc_hip_pairing_t *p, void *d_gt, const void *d_g1, const void *d_g2, size_t n, int k, void *stream);
+
 /* The group law, Z_r arithmetic and multi-exponentiations the reference's examples use around the pairing (round 5;
  * csrc/group_more.cuh, csrc/pbc_hip_group2.hip).  Host-buffer and _dev + stream forms as above; out may be exactly one of
  * the inputs.

@@ -118,6 +118,10 @@ def lib():
         L.pbc_hip_element_pp_pow_zn_batch_dev.argtypes = [vp, vp, vp, sz, vp]
         L.pbc_hip_element_set_str.argtypes = [vp, ci, vp, cp, ci]
         L.pbc_hip_param_snprint.argtypes = [vp, ctypes.c_char_p, sz]
+        L.pbc_hip_fq_limb_image_bytes.argtypes = [vp]
+        L.pbc_hip_element_pairing_batch_limbs.argtypes = [vp, vp, vp, vp, sz]
+        L.pbc_hip_element_prod_pairing_batch_limbs.argtypes = [vp, vp, vp, vp, sz, ci]
+        L.pbc_hip_element_prod_pairing_batch_limbs_dev.argtypes = [vp, vp, vp, vp, sz, ci, vp]
         _lib = L
     return _lib
 
@@ -149,6 +153,8 @@ EXPORTS = (
     "pbc_hip_element_add_batch_dev", "pbc_hip_element_sub_batch_dev", "pbc_hip_element_neg_batch_dev", "pbc_hip_element_double_batch_dev",
     "pbc_hip_zr_op_batch", "pbc_hip_zr_op_batch_dev", "pbc_hip_zr_from_hash_batch", "pbc_hip_zr_from_hash_batch_dev",
     "pbc_hip_element_pow2_zn_batch", "pbc_hip_element_pow3_zn_batch", "pbc_hip_element_pow2_zn_batch_dev", "pbc_hip_element_pow3_zn_batch_dev",
+    "pbc_hip_fq_limb_image_bytes", "pbc_hip_element_pairing_batch_limbs", "pbc_hip_element_prod_pairing_batch_limbs",
+    "pbc_hip_element_prod_pairing_batch_limbs_dev",
 )
 
 
@@ -192,6 +198,16 @@ class Pairing:
         self.length_in_bytes_GT = L.pbc_hip_pairing_length_in_bytes_GT(self._h)
         self.length_in_bytes_Fq = L.pbc_hip_length_in_bytes_Fq(self._h)
         self.length_in_bytes_Zr = L.pbc_hip_pairing_length_in_bytes_Zr(self._h)
+        self._param_text = param.decode(errors="replace")
+
+    @property
+    def field_order(self):
+        """q (type a1: p), the order of the base field, from the parameter text"""
+        for line in self._param_text.splitlines():
+            f = line.split()
+            if len(f) == 2 and f[0] in ("q", "p"):
+                return int(f[1])
+        raise PbcHipError("no q / p in the parameter text")
 
     def clear(self):
         if getattr(self, "_h", None):
@@ -231,6 +247,55 @@ class Pairing:
         gt = np.empty((n, self.length_in_bytes_GT), np.uint8)
         if lib().pbc_hip_element_prod_pairing_batch(self._h, _np_ptr(gt), _np_ptr(g1), _np_ptr(g2), n, k):
             raise PbcHipError("element_prod_pairing: " + _err())
+        return gt
+
+    # ---- the same on the reference's montfp limb images (include/pbc_hip.h; what integration/pbc_hip_glue.c exchanges) ----
+    @property
+    def limb_image_bytes(self):
+        """8 t: bytes of one F_q coordinate as the reference's montfp element holds it"""
+        w = lib().pbc_hip_fq_limb_image_bytes(self._h)
+        if w <= 0:
+            raise PbcHipError("limb image: " + _err())
+        return w
+
+    def to_limb_images(self, rec):
+        """wire records (n, L) -> limb-image records: every F_q coordinate x as t little-endian 64-bit limbs of
+        x 2^(64 t) mod q (host arithmetic; tests and tools)"""
+        import numpy as np
+        rec = np.ascontiguousarray(rec, dtype=np.uint8)
+        fb, w = self.length_in_bytes_Fq, self.limb_image_bytes
+        n, L = rec.shape
+        out = np.zeros((n, L // fb * w), np.uint8)
+        q, R = self.field_order, 1 << (8 * w)
+        for i in range(n):
+            for c in range(L // fb):
+                x = int.from_bytes(rec[i, c * fb:(c + 1) * fb].tobytes(), "big") % q
+                out[i, c * w:(c + 1) * w] = np.frombuffer((x * R % q).to_bytes(w, "little"), np.uint8)
+        return out
+
+    def from_limb_images(self, img):
+        import numpy as np
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        fb, w = self.length_in_bytes_Fq, self.limb_image_bytes
+        n, L = img.shape
+        out = np.zeros((n, L // w * fb), np.uint8)
+        q = self.field_order
+        rinv = pow(1 << (8 * w), -1, q)
+        for i in range(n):
+            for c in range(L // w):
+                x = int.from_bytes(img[i, c * w:(c + 1) * w].tobytes(), "little") * rinv % q
+                out[i, c * fb:(c + 1) * fb] = np.frombuffer(x.to_bytes(fb, "big"), np.uint8)
+        return out
+
+    def element_prod_pairing_limbs(self, g1_img, g2_img, k=1):
+        import numpy as np
+        g1_img = np.ascontiguousarray(g1_img, dtype=np.uint8)
+        g2_img = np.ascontiguousarray(g2_img, dtype=np.uint8)
+        fb, w = self.length_in_bytes_Fq, self.limb_image_bytes
+        n = g1_img.size // (self.length_in_bytes_G1 // fb * w * k)
+        gt = np.empty((n, self.length_in_bytes_GT // fb * w), np.uint8)
+        if lib().pbc_hip_element_prod_pairing_batch_limbs(self._h, _np_ptr(gt), _np_ptr(g1_img), _np_ptr(g2_img), n, k):
+            raise PbcHipError("element_prod_pairing_limbs: " + _err())
         return gt
 
     def element_prod_pairing_dev(self, d_gt, d_g1, d_g2, n, k, stream=0):

@@ -387,12 +387,14 @@ static inline void hs_sop_check(const X &x, const X &y, int T) {
 #define PBC_OPAQUE64(x) asm("" : "+v"(x))
 #define PBC_HS_SOP_CHECK(x, y, T) ((void) 0)
 #endif
-#ifndef PBC_SOP_DIRECT
-#define PBC_SOP_DIRECT 1    // sop_limbs: the products of a column join the running carry directly (0: separate chains, PBC_SOP_CHAINS)
-#endif
 #ifndef PBC_SOP_CHAINS
 #define PBC_SOP_CHAINS 1    // independent accumulator chains per column (experiment: the multiply-add chain of a column is
 #endif                      // serially dependent; more chains = more instruction-level parallelism, a few extra 64-bit adds)
+// (Round 6: the compiler keeps the products of a column in a chain of their own next to the carry chain -- one 64-bit
+// addition per column to join them, ~10 of the ~110 instructions of a one-product sum -- however the source orders the
+// additions.  Forcing ONE chain with opaque barriers removes those additions (cyc_pair: 1856 -> 1753 vector
+// instructions) but back-to-back dependent v_mad_u64_u32 need an s_nop each (937 in cyc_pair), and the kernels ran SLOWER:
+// f.param 22.51 -> 22.94 ms, d159 products 157.8 -> 166.4 ms, single d159 pairings unchanged -- profiles/r06_notes.md.)
 template <int N, int T, int DBL = 0>      // DBL: how many of the T terms have a doubled operand
 PBC_DEV void sop_limbs(fl<N> &r, const fl<N> (&x)[T], const fl<N> (&y)[T]) {
   const FpK<N> &K = fpk<N>();
@@ -404,35 +406,6 @@ PBC_DEV void sop_limbs(fl<N> &r, const fl<N> (&x)[T], const fl<N> (&y)[T]) {
   uint32_t m[L];
   uint64_t acc = 0;
   PBC_HS_SOP_CHECK(x, y, T);
-  if constexpr (PBC_SOP_DIRECT != 0) {
-    // ONE chain: the products of a column are accumulated onto the carry of the column before.  With the column's
-    // products in a chain of their own (below) the compiler pays one 64-bit addition per column to join the two
-    // (10 of the ~110 instructions of a one-product sum; dependent multiply-adds issue at the full rate with two waves per SIMD)
-#pragma unroll
-    for (int k = 0; k < L; k++) {
-#pragma unroll
-      for (int t = 0; t < T; t++)
-#pragma unroll
-        for (int i = 0; i <= k; i++) { acc += (uint64_t) x[t].l[i] * y[t].l[k - i]; if (PBC_SOP_DIRECT == 2 || (PBC_SOP_DIRECT == 3 && t == 0 && i == 0)) PBC_OPAQUE64(acc); }
-#pragma unroll
-      for (int i = 0; i < k; i++) { acc += (uint64_t) m[i] * K.p29[k - i]; if (PBC_SOP_DIRECT == 2) PBC_OPAQUE64(acc); }
-      m[k] = ((uint32_t) acc * K.ninv29) & MASK;
-      acc += (uint64_t) m[k] * K.p29[0];
-      acc >>= Limbs29<N>::W;
-    }
-#pragma unroll
-    for (int k = L; k < 2 * L; k++) {
-#pragma unroll
-      for (int t = 0; t < T; t++)
-#pragma unroll
-        for (int i = k - L + 1; i < L; i++) { acc += (uint64_t) x[t].l[i] * y[t].l[k - i]; if (PBC_SOP_DIRECT == 2 || (PBC_SOP_DIRECT == 3 && t == 0 && i == k - L + 1)) PBC_OPAQUE64(acc); }
-#pragma unroll
-      for (int i = k - L + 1; i < L; i++) { acc += (uint64_t) m[i] * K.p29[k - i]; if (PBC_SOP_DIRECT == 2) PBC_OPAQUE64(acc); }
-      r.l[k - L] = (uint32_t) acc & MASK;
-      acc >>= Limbs29<N>::W;
-    }
-    return;
-  }
 #pragma unroll
   for (int k = 0; k < L; k++) {
     uint64_t part[C];

@@ -93,6 +93,8 @@ struct pbc_hip_pairing_s {
   } hash;
   ExtSqrtK xs;               // square roots in the field of the G2 twist (types d, g, f); xs.c derived on first use
   bool xs_ready;
+  uint32_t raw_c1[34], raw_c2[34];   // limb-image entry points (pbc_hip.hip raw_prepare): 2^(2 rbits - 64 t) and 2^(64 t) mod q
+  int raw_t;                 // ... t = 64-bit limbs of the reference's montfp element (0: constants not derived yet)
   void *counters;            // library only: the unit counters of dynamic resident launches (pbc_hip.hip unit_counter)
   void *host_ctx;            // library only: per-device streams and chunk buffers of the host-buffer path (pbc_hip.hip)
   std::string param_text;    // the parameter text the object was built from (text formats: pbc_hip_param_snprint, host_text.h)

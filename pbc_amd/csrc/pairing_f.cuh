@@ -50,7 +50,7 @@
 #define PBC_F_NO_CONJ 0                // 1: the q^6-power Frobenius through the generic qpower routine (A/B of round 5's f12_conj)
 #endif
 #ifndef PBC_F_LINE_SEL
-#define PBC_F_LINE_SEL 0               // f_line_mul_lds: the factors of an output switched by two branches on the loop counter (0: selects in every iteration)
+#define PBC_F_LINE_SEL 1               // f_line_mul_lds: the factors of an output switched by two branches on the loop counter (0: 36 selects in every iteration; same-box A/B 22.51 / 22.62 -> 22.48 / 22.44 ms, profiles/r06_notes.md)
 #endif
 #ifdef PBC_HOSTSIM
 #define PBC_KEEP_BRANCH() ((void) 0)
@@ -840,6 +840,7 @@ static __device__ __noinline__ void f_line_mul_lds(int cur, vfl va, vfl vb, vfl 
       if (j >= 6) { j -= 6; wj = false; }
       if (k >= 6) { k -= 6; wk = false; }
 #if PBC_F_LINE_SEL
+      (void) wj; (void) wk;
       if (i == 3) { fb = Bq; PBC_KEEP_BRANCH(); }
       if (i == 4) { fa = Aq; PBC_KEEP_BRANCH(); }
 #else

@@ -860,6 +860,104 @@ extern "C" int pbc_hip_element_prod_pairing_batch(pbc_hip_pairing_t *P, uint8_t 
   return run_host(P, gt, g1, g2, n, k);
 }
 
+// ---- the reference's own limb image as the exchange format (round 6; the element_t route of integration/pbc_hip_glue.c) ----
+// element_to_bytes / element_from_bytes cost the host a Montgomery reduction, a GMP export and two allocations per F_q
+// coordinate (arith/montfp.c:487-517): 16 host threads convert 4.8 M type a pairs/s while the GPU pairs 13 M
+// (profiles/r05_closing_glue.txt).  These entry points take what a montfp element holds (montfp.c:36-39: t = ceil(bits(q) /
+// 64) little-endian 64-bit limbs of x 2^(64 t) mod q, fully reduced) -- a memcpy per coordinate on the host -- and do the
+// change of Montgomery radix on the device: one F_q product per coordinate with 2^(2 rbits - 64 t) on the way in (then
+// the wire format's kernels run unchanged), one with 2^(64 t) on the way out.  A record is the wire record with every
+// length_in_bytes(F_q)-byte coordinate replaced by its 8 t-byte limb image; a zero coordinate is t zero limbs.
+template <int N>
+__global__ void __launch_bounds__(kBlock) raw_to_wire_kernel(uint8_t *out, const uint32_t *in, int words, fp<N> c1, size_t n, KArgs<N> ka) {
+  size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
+  if (idx >= n) return;
+  fp<N> w, z;
+#pragma unroll
+  for (int i = 0; i < N; i++) w.v[i] = i < words ? in[idx * (size_t) words + i] : 0;
+  fp_mul<N>(z, w, c1);                                    // x R_pbc (R^2 / R_pbc) / R = x R: this library's form
+  fp_store_be<N>(out + idx * fpk<N>().fbytes, z);
+}
+template <int N>
+__global__ void __launch_bounds__(kBlock) wire_to_raw_kernel(uint32_t *out, const uint8_t *in, int words, fp<N> c2, size_t n, KArgs<N> ka) {
+  size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
+  if (idx >= n) return;
+  fp<N> x, z;
+  fp_load_be<N>(x, in + idx * fpk<N>().fbytes);           // x R
+  fp_mul<N>(z, x, c2);                                    // x R R_pbc / R = x R_pbc mod q
+  for (int i = 0; i < words; i++) out[idx * (size_t) words + i] = i < N ? z.v[i < N ? i : 0] : 0;
+}
+static int raw_prepare(pbc_hip_pairing_s *P) {
+  if (P->raw_t) return 0;
+  using pbc_host::Big;
+  Big q;
+  int bits = 0;
+  PBC_DISPATCH_N(P->nlimb, { const FpK<N> K = host_fpk<N>(P); q.w.assign(K.p, K.p + N); bits = (int) K.pbits; });
+  q.trim();
+  const int t = (bits + 63) / 64;
+  int rbits = 0;
+  PBC_DISPATCH_N(P->nlimb, { rbits = Limbs29<N>::W * Limbs29<N>::L; });
+  if (2 * rbits < 64 * t || 2 * t > 34) return fail("limb image: unsupported field width");
+  memset(P->raw_c1, 0, sizeof P->raw_c1);
+  memset(P->raw_c2, 0, sizeof P->raw_c2);
+  Big::pow2_mod(2 * rbits - 64 * t, q).to_words(P->raw_c1, 34);
+  Big::pow2_mod(64 * t, q).to_words(P->raw_c2, 34);
+  P->raw_t = t;
+  return 0;
+}
+extern "C" int pbc_hip_fq_limb_image_bytes(pbc_hip_pairing_t *P) {
+  if (!P || raw_prepare(P)) return 0;
+  return 8 * P->raw_t;
+}
+static int raw_convert(pbc_hip_pairing_s *P, bool to_wire, void *dst, const void *src, size_t leaves, hipStream_t s) {
+  if (!leaves) return 0;
+  const unsigned grid = (unsigned) ((leaves + kBlock - 1) / kBlock);
+  const int words = 2 * P->raw_t;
+  PBC_DISPATCH_N(P->nlimb, {
+    fp<N> c;
+    for (int i = 0; i < N; i++) c.v[i] = to_wire ? P->raw_c1[i] : P->raw_c2[i];
+    if (to_wire) hipLaunchKernelGGL(raw_to_wire_kernel<N>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) dst, (const uint32_t *) src, words, c, leaves, kargs<N>(P));
+    else hipLaunchKernelGGL(wire_to_raw_kernel<N>, dim3(grid), dim3(kBlock), 0, s, (uint32_t *) dst, (const uint8_t *) src, words, c, leaves, kargs<N>(P));
+  });
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+// limb images in device memory -> the wire-format kernels -> limb images, all on stream s (stream-ordered temporaries)
+static int launch_prod_raw(pbc_hip_pairing_s *P, void *d_gt, const void *d_g1, const void *d_g2, size_t n, int k, hipStream_t s, bool upload, const OwnWs *own) {
+  if (!n) return 0;
+  if (upload && ensure_derived(P, s)) return 1;
+  const size_t fb = (size_t) P->len_fq, lv1 = P->len1 / fb, lv2 = P->len2 / fb, lvt = P->lenT / fb, terms = n * (size_t) k;
+  uint8_t *tmp = nullptr;
+  const size_t b1 = (terms * P->len1 + 15) & ~(size_t) 15, b2 = (terms * P->len2 + 15) & ~(size_t) 15, bt = n * (size_t) P->lenT;
+  HIP_TRY(hipMallocAsync((void **) &tmp, b1 + b2 + bt, s));
+  int rc = raw_convert(P, true, tmp, d_g1, terms * lv1, s) || raw_convert(P, true, tmp + b1, d_g2, terms * lv2, s) ||
+           launch_prod(P, tmp + b1 + b2, tmp, tmp + b1, n, k, s, false, own) || raw_convert(P, false, d_gt, tmp + b1 + b2, n * lvt, s);
+  (void) hipFreeAsync(tmp, s);
+  return rc;
+}
+extern "C" int pbc_hip_element_prod_pairing_batch_limbs(pbc_hip_pairing_t *P, uint8_t *gt, const uint8_t *g1, const uint8_t *g2, size_t n, int k) {
+  if (!P) return fail("null pairing");
+  if (k < 1) return fail("k must be >= 1");
+  if (P->device < 0) return fail("no HIP device: libpbc_hip has no CPU fallback");
+  if (!gt || !g1 || !g2) return fail("null argument");
+  if (raw_prepare(P)) return 1;
+  const size_t fb = (size_t) P->len_fq, w = 8 * (size_t) P->raw_t;
+  return run_host_generic(P, gt, P->lenT / fb * w, g1, (size_t) k * (P->len1 / fb) * w, g2, (size_t) k * (P->len2 / fb) * w, n,
+                          [P, k](void *d_gt, const void *d_g1, const void *d_g2, size_t m, hipStream_t s, const OwnWs *own) {
+                            return launch_prod_raw(P, d_gt, d_g1, d_g2, m, k, s, false, own);
+                          }, true);
+}
+extern "C" int pbc_hip_element_pairing_batch_limbs(pbc_hip_pairing_t *P, uint8_t *gt, const uint8_t *g1, const uint8_t *g2, size_t n) {
+  return pbc_hip_element_prod_pairing_batch_limbs(P, gt, g1, g2, n, 1);
+}
+extern "C" int pbc_hip_element_prod_pairing_batch_limbs_dev(pbc_hip_pairing_t *P, void *d_gt, const void *d_g1, const void *d_g2, size_t n, int k, void *stream) {
+  if (!P) return fail("null pairing");
+  if (k < 1) return fail("k must be >= 1");
+  if (P->device < 0) return fail("no HIP device: libpbc_hip has no CPU fallback");
+  if (raw_prepare(P)) return 1;
+  return launch_prod_raw(P, d_gt, d_g1, d_g2, n, k, (hipStream_t) stream, true, nullptr);
+}
+
 // ---- preprocessed pairings ---------------------------------------------------------------
 extern "C" int pbc_hip_pairing_pp_init(pbc_hip_pp_t **out, pbc_hip_pairing_t *P, const uint8_t *g1) {
   if (!out || !P || !g1) return fail("null argument");

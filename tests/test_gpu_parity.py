@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 import oracle
-from conftest import G2_HASH, G2_COMPRESS, G2_XONLY, XONLY, check_x_only, check_x_only_g2, golden, OTHER, GENERIC_A, GENERIC_OTHER, GENERIC_F, FILES_OF, param_value
+from conftest import G2_HASH, G2_COMPRESS, G2_XONLY, XONLY, check_x_only, check_x_only_g2, golden, OTHER, GENERIC_A, GENERIC_OTHER, GENERIC_F, FILES_OF, param_value, key_of
 
 pytestmark = pytest.mark.gpu
 
@@ -1214,3 +1214,39 @@ def test_a1_preprocessed_pairings_on_a_batch_that_fills_two_waves_per_simd(hips)
     assert torch.equal(got, want)
     assert np.array_equal(got[3].cpu().numpy(), v.gt[3])
     pp.clear()
+
+
+# ---- the reference's montfp limb images as the exchange format (round 6) ---------------------------------------------
+@pytest.mark.parametrize("name", ["a_rand32.vec", "a_edge20.vec", "d_rand32.vec", "d_edge20.vec", "f_rand16.vec", "f_edge10.vec", "a_prod16x4.vec",
+                                  "g149_rand16.vec", "d201_rand12.vec", "a1_rand6.vec", "e_rand6.vec"])
+def test_limb_image_entry_points_match_the_reference_vectors(hips, name):
+    """pbc_hip_element_prod_pairing_batch_limbs: inputs and outputs as t little-endian 64-bit limbs of x 2^(64 t) mod q per F_q
+    coordinate (what a montfp element holds, arith/montfp.c:36-39) -- the reference's vectors, off-curve and zero records
+    included, re-encoded on the host; the results decoded and compared with the reference's bytes"""
+    v = golden(name)
+    P = hips[key_of(name)]
+    t = -(-P.field_order.bit_length() // 64)
+    assert P.limb_image_bytes == 8 * t
+    got = P.element_prod_pairing_limbs(P.to_limb_images(v.g1), P.to_limb_images(v.g2), v.k)
+    assert np.array_equal(P.from_limb_images(got), v.gt)
+    # the images are canonical: every coordinate below q
+    q, w = P.field_order, 8 * t
+    assert all(int.from_bytes(got[i, c * w:(c + 1) * w].tobytes(), "little") < q for i in range(min(4, len(got))) for c in range(got.shape[1] // w))
+
+
+def test_glue_batch_calls_on_both_exchange_formats():
+    """integration/pbc_hip_glue.c: element_pairing_batch / element_prod_pairing_batch through montfp limb images (the default
+    when the layout probe passes; PBC_HIP_VERBOSE reports the route) and through element_to_bytes records
+    (PBC_HIP_GLUE_LIMBS=0): both equal the reference's CPU results for every unit (glue_test compares with element_cmp)"""
+    import os
+    import subprocess
+    import pbc_amd
+    if not os.path.exists(oracle.GLUE_TEST):
+        pytest.skip("oracle/_ref/glue_test not built (needs /root/reference at build time)")
+    for pname in ("a", "d159", "f"):
+        for limbs, want in (("1", "montfp limb images"), ("0", "element_to_bytes records")):
+            env = dict(os.environ, PBC_HIP_LIB=pbc_amd.LIB_PATH, PBC_HIP_GLUE_LIMBS=limbs, PBC_HIP_VERBOSE="1")
+            r = subprocess.run([oracle.GLUE_TEST, os.path.join(pbc_amd.PARAM_DIR, pname + ".param"), "300"],
+                               capture_output=True, text=True, env=env, timeout=600)
+            assert r.returncode == 0 and "PASS" in r.stdout, r.stdout + r.stderr
+            assert "batch calls exchange " + want in r.stderr, r.stderr

@@ -469,6 +469,17 @@ def main():
                               "steps": args.steps, "rows": rows}), flush=True)
         return
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    # The W untimed warm-up steps run HERE, directly before the timed region, and are topped up to at least 0.3 s of
+    # launches: the shader clock falls back while the gate above compares on the host and needs tens of milliseconds of
+    # load to climb again -- round 6 measured the same 31.6 M cycles per d159 launch take 15.8, 14.5, 13.5, 13.2, 13.2 ms
+    # over the first five launches after an idle gap (GRBM_GUI_ACTIVE: 2.01 -> 2.38 GHz; profiles/r06_notes.md), which a
+    # 14 ms kernel timed over a handful of steps shows and an 80 ms one does not.
+    spin_t0, spun = time.perf_counter(), 0
+    while spun < max(1, args.warmup) or (time.perf_counter() - spin_t0 < 0.3 and spun < 256):
+        step()
+        spun += 1
+        if spun >= max(1, args.warmup):
+            torch.cuda.synchronize()
     sync_all()
     sampler = ClockSampler(dev_index)
     with sampler:
@@ -545,6 +556,7 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
+            "warmup_launches": spun,             # W, topped up to 0.3 s of launches directly before the timed steps (clock ramp)
             "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True,
             "scaling": "strong" if args.strong else "weak",

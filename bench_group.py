@@ -407,6 +407,14 @@ def main(args, load_vec, ensure_built, MAC_PEAK):
     if not gate():
         sys.exit("bench_group.py: %s results of rank %d differ from the oracle -- refusing to time" % (args.workload, rank))
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    # the warm-up steps directly before the timed region, topped up to 0.3 s of launches (the shader clock falls back during
+    # the host-side gate and needs tens of milliseconds of load to climb again: bench.py, profiles/r06_notes.md)
+    spin_t0, spun = time.perf_counter(), 0
+    while spun < max(1, args.warmup) or (time.perf_counter() - spin_t0 < 0.3 and spun < 256):
+        step()
+        spun += 1
+        if spun >= max(1, args.warmup):
+            torch.cuda.synchronize()
     sync_all()
     t0 = time.perf_counter()
     for a, b in evs:

@@ -874,7 +874,7 @@ __global__ void __launch_bounds__(kBlock) raw_to_wire_kernel(uint8_t *out, const
   if (idx >= n) return;
   fp<N> w, z;
 #pragma unroll
-  for (int i = 0; i < N; i++) w.v[i] = i < words ? in[idx * (size_t) words + i] : 0;
+  for (int i = 0; i < N; i++) w.v[i] = i < words ? in[idx * (size_t) words + i] : 0;   // (words = 2 t is N or N + 1; the top word of an odd N is zero)
   fp_mul<N>(z, w, c1);                                    // x R_pbc (R^2 / R_pbc) / R = x R: this library's form
   fp_store_be<N>(out + idx * fpk<N>().fbytes, z);
 }
@@ -885,7 +885,9 @@ __global__ void __launch_bounds__(kBlock) wire_to_raw_kernel(uint32_t *out, cons
   fp<N> x, z;
   fp_load_be<N>(x, in + idx * fpk<N>().fbytes);           // x R
   fp_mul<N>(z, x, c2);                                    // x R R_pbc / R = x R_pbc mod q
-  for (int i = 0; i < words; i++) out[idx * (size_t) words + i] = i < N ? z.v[i < N ? i : 0] : 0;
+#pragma unroll
+  for (int i = 0; i <= N; i++)                             // compile-time indices into the register array (words is N or N + 1)
+    if (i < words) out[idx * (size_t) words + i] = i < N ? z.v[i < N ? i : N - 1] : 0u;
 }
 static int raw_prepare(pbc_hip_pairing_s *P) {
   if (P->raw_t) return 0;

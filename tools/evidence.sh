@@ -9,11 +9,11 @@ cp .evidence_head $O/HEAD 2>/dev/null || { echo "no .evidence_head: start this t
 [ -z "$WITH_TESTS" ] || { timeout 1500 python -m pytest tests -m gpu -q --maxfail 10 > $O/pytest.log 2>&1; tail -n 3 $O/pytest.log; }
 for w in ${BENCH_WL-a d f a-prod16 d-prod16 a-pp d-pp g g-pp e a1 a1-pp f256 d190 d201 d224}; do
   NOCPU="--no-cpu-baseline"; case " ${CPU_WL-a d f a-prod16} " in *" $w "*) NOCPU="";; esac     # live CPU leg beside the BASELINE configs; the others carry the build container's figure (profiles/r05_cpu_baselines.json)
-  timeout 400 python bench.py --workload $w --steps 3 --warmup 1 $NOCPU > $O/bench_$w.json 2> $O/bench_$w.err
+  timeout 400 python bench.py --workload $w --steps 6 --warmup 2 $NOCPU > $O/bench_$w.json 2> $O/bench_$w.err
 done
 for w in ${GROUP_WL-a-g1-mul a-gt-pow a-hash-g1 a-g1-pp a-gt-pp a-bls-verify a-compress a-decompress a-g1-add a-zr-inv a-g1-pow2 a-gt-pow2 d-g1-mul d-g2-mul d-gt-pow d-hash-g1 d-g1-pp d-gt-pp d-compress d-decompress d-g1-add d-zr-inv d-g1-pow2 d-gt-pow2 f-g1-mul f-g2-mul f-gt-pow f-hash-g1 f-g1-pp f-gt-pp f-compress f-decompress f-g1-add f-zr-inv f-g1-pow2 f-gt-pow2}; do
   NOCPU="--no-cpu-baseline"; case " ${GROUP_CPU_WL-a-g1-mul a-bls-verify} " in *" $w "*) NOCPU="";; esac
-  timeout 300 python bench.py --workload $w --steps 3 --warmup 1 $NOCPU > $O/bench_$w.json 2> $O/bench_$w.err
+  timeout 300 python bench.py --workload $w --steps 6 --warmup 2 $NOCPU > $O/bench_$w.json 2> $O/bench_$w.err
 done
 [ -n "$SKIP_SWEEP" ] || for w in a f; do timeout 300 python bench.py --workload $w --sweep > $O/sweep_$w.json 2> $O/sweep_$w.err; done
 [ -n "$SKIP_SMALL" ] || { timeout 300 python tools/wave_latency.py 1 256 512 1024 2048 4096 5120 > $O/wave_latency.txt 2>&1
@@ -23,7 +23,7 @@ done
   unset PBC_HIP_LIB; }
 cd /tmp && export TMPDIR=/tmp
 for w in ${PMC_WL-a d f a-prod16 d-prod16 d190 a-pp a-g1-mul f-gt-pow}; do
-  B="python $R/bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline --no-host-path"
+  B="python $R/bench.py --workload $w --steps 6 --warmup 2 --no-cpu-baseline --no-host-path"
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_$w -- $B > $O/kt_$w.log 2>&1
   timeout 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $O/pmc1_$w -- $B > $O/pmc1_$w.log 2>&1
   timeout 300 rocprofv3 --pmc SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM GRBM_GUI_ACTIVE SQ_WAIT_ANY SQ_IFETCH SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d $O/pmc2_$w -- $B > $O/pmc2_$w.log 2>&1

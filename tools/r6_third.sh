@@ -13,3 +13,4 @@ import json,glob
 for f in sorted(glob.glob("gpurun_out/r6c/bench_*.json")):
     j=json.loads(open(f).read()); print(f.split("bench_")[1], j["value"], j["roofline"]["kernel_ms"], j.get("clocks"))
 P
+[ -x tools/exp/sopvm_probe ] && timeout 120 tools/exp/sopvm_probe > $O/sopvm.txt 2>&1; cat $O/sopvm.txt

@@ -60,8 +60,21 @@ for w, kern in MAIN.items():
     if ks:
         rows = list(csv.DictReader(open(ks[0])))
         dst = "profiles/%s_kernel_stats_%s.csv" % (RND, w)
+        # the timed steps alone: bench.py warms the clock up with extra launches right before them (0.3 s), and the average
+        # over ALL launches of a short kernel is dominated by the cold ones (profiles/r06_notes.md, "clock ramp")
+        timed = ""
+        tr = glob.glob("%s/kt_%s/**/*kernel_trace.csv" % (EV, w), recursive=True)
+        if tr:
+            L = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), int(r.get("Grid_Size") or r.get("Grid_Size_X") or 0))
+                 for r in csv.DictReader(open(tr[0])) if kern in r["Kernel_Name"]]
+            full = sorted(x for x in L if x[2] == max(y[2] for y in L))
+            last = [x[1] for x in full[-6:]]
+            if last:
+                timed = "# the last %d full-size launches (bench.py's timed steps): average %.0f ns, min %d, max %d; all %d full-size launches: %s\n" % (
+                    len(last), sum(last) / len(last), min(last), max(last), len(full), " ".join("%.2f" % (x[1] / 1e6) for x in full) + " ms")
         with open(dst, "w") as fh:
-            fh.write("# commit %s: rocprofv3 --kernel-trace --stats -- python bench.py --workload %s --steps 3 --warmup 1 --no-cpu-baseline --no-host-path\n" % (head, w))
+            fh.write("# commit %s: rocprofv3 --kernel-trace --stats -- python bench.py --workload %s --steps 6 --warmup 2 --no-cpu-baseline --no-host-path\n" % (head, w))
+            fh.write(timed)
             fh.write("Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs\n")
             for r in rows[:6]:
                 fh.write('"%s",%s,%s,%s,%s,%s,%s\n' % (r["Name"][:90], r["Calls"], r["TotalDurationNs"], r["AverageNs"],

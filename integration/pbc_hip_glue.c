@@ -217,7 +217,11 @@ static void from_limbs_range(size_t lo, size_t hi, void *ctx) {
  * wrapper) in the order element_to_bytes writes them; only the two-field montfp record is mirrored here, and limb_probe
  * checks that mirror against element_to_bytes / element_from_bytes on this very pairing before the route is used --
  * another F_p back end (pbc_tweak_use_fp) or a changed layout fails the probe and the batch calls keep the byte route.
- * PBC_HIP_GLUE_LIMBS=0 switches the route off. */
+ * OPT-IN (PBC_HIP_GLUE_LIMBS=1): measured on the 16-core GPU box (round 6, profiles/r06_notes.md) the route does not make
+ * element_pairing_batch faster -- 2^20 a.param pairs: 4.6-5.8 M pairs/s on limb images against 4.8-5.9 M on
+ * element_to_bytes records, d159 6.7-7.8 M against 5.9-7.5 M -- because what bounds the batch calls is not the conversion's
+ * arithmetic but walking 3 x 2^20 heap-allocated element_t trees (five dependent cache misses per coordinate) under a
+ * 16-core quota; the byte route stays the default. */
 typedef struct { char flag; mp_limb_t *d; } montfp_rec;
 static int fq_leaves(element_ptr e, element_ptr *out, int n) {           /* depth-first, wire order; n < 0: overflow */
   const int c = element_item_count(e);
@@ -248,7 +252,7 @@ static void limbs_in(element_ptr e, const unsigned char *src, int w) {   /* limb
 static void limb_probe(attach_t *a) {
   a->limb_w = 0;
   const char *env = getenv("PBC_HIP_GLUE_LIMBS");
-  if ((env && !atoi(env)) || !L.limb_bytes || !L.prod_limbs) return;
+  if (!env || !atoi(env) || !L.limb_bytes || !L.prod_limbs) return;       /* opt-in: see the measurement in the comment above */
   const int w = L.limb_bytes(a->gpu), l1 = L.len1(a->gpu), l2 = L.len2(a->gpu), lt = L.lenT(a->gpu);
   if (w <= 0 || w % (int) sizeof(mp_limb_t)) return;
   element_t P, Q, T, T2;

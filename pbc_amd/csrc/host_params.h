@@ -43,6 +43,9 @@ inline int fail(const char *fmt, ...) {
 #define PBC_A_WAVE4_MAX 768
 #endif
 // ---------------------------------------------------------------------------------------
+#ifndef PBC_D_WAVE_MAX
+#define PBC_D_WAVE_MAX 4096
+#endif
 constexpr size_t kProdChunkDefault = (size_t) 1 << 22;   // type a products: terms per launch of the one-term-per-lane kernels unless "hip_prod_chunk N" says otherwise
 struct pbc_hip_pairing_s {
   int type;
@@ -62,6 +65,7 @@ struct pbc_hip_pairing_s {
   size_t a_wave4_max;        // ... and up to this size four wavefronts per pairing ("hip_wave4_max N")
   size_t a_wave2_max;        // ... and between the two, up to this size, two ("hip_wave2_max N", round 5)
   size_t a_wave_max;         // type a fast path, element_pairing: batches up to this size take one WAVEFRONT per pairing (pairing_aw.cuh; "hip_wave_max N", 0 = never)
+  size_t d_wave_max;         // type d, five-word fields: single pairings in batches up to this size take one wavefront each (pairing_dw.cuh; "hip_dwave_max N")
   size_t a_prod_chunk;       // ... otherwise: terms per launch of the one-term-per-lane kernels ("hip_prod_chunk N", tests)
   int len_fq, len1, len2, lenT;
 #define PBC_HOST_FPK(n) FpK<n> k##n;
@@ -440,6 +444,13 @@ static int init_type_d(pbc_hip_pairing_s *P, const char *txt, size_t len, int de
   q.to_words(P->draw.q, ND + 1);
   P->draw.qbits = q.bits();
   if (r.bits() > 256 || r.bits() < 3) return fail("%s: bad r", tn);
+  {
+    // small batches of single pairings on the five-word d = 3 fields: one pairing per WAVEFRONT (pairing_dw.cuh) up to this
+    // batch size ("hip_dwave_max N", 0 = never); above it the one-pairing-per-lane kernel is the faster launch
+    int dwave_max = PBC_D_WAVE_MAX;
+    param_int(txt, len, "hip_dwave_max", dwave_max);
+    P->d_wave_max = dwave_max < 0 ? 0 : (size_t) dwave_max;
+  }
   {
     // limb-form point arithmetic of the 5-word d = 3 kernels (pairing_d.cuh, kLimbPoint): its subtraction constants borrow
     // from q's top 29-bit limb, which must hold at least 8 bits of q; "hip_no_limb 1" forces the word-form routines

@@ -1,0 +1,264 @@
+// pairing_dw.cuh -- Type D (MNT, k = 6) on the five-word fields, ONE PAIRING PER WAVEFRONT (round 6; small batches).
+//
+// Same value as cc_pairing (ecc/d_param.c:570-587: cc_miller_no_denom_affine :321-422 + cc_tatepower :505-564), the
+// formulas of pairing_d.cuh.  The throughput kernel runs a pairing as one lane's serial instruction stream: 2.0 M vector
+// instructions, 3.9 ms through the reference's call sites whatever the batch size -- three times what one CPU core needs
+// (VERDICT r5 "missing" 1).  Every tower operation, though, is a set of INDEPENDENT lazily reduced sums of F_q products.
+// Here a wavefront owns one pairing:
+//   * every F_q element is a slot of six 29-bit limbs in an LDS slot file (129 slots, 3 KB per wavefront);
+//   * a LEVEL is "lane l computes out[l] = sum_t x[l][t] y[l][t] / R" -- the library's sop_limbs on operands gathered from
+//     the slot file by the lane's ROW of a table (dw_tables.h, generated and checked against the reference's vectors on
+//     Python integers by tools/dw_gen.py) -- "and writes its slot"; a level's lanes read before any lane writes;
+//   * sums, differences and small multiples are products with the constant slots 1, -1, 2, ...: nothing but sums of
+//     products exists, so ONE routine (three instantiations: 2, 4, 8 terms) is the whole arithmetic;
+//   * lanes 0-31 run the ACCUMULATOR track (f <- f * line: 3 levels, f <- f^2: 3 levels), lanes 32-63 the POINT track
+//     (V <- 2V in modified Jacobian coordinates: 4 levels, V <- V +- P: 6) one line ahead of it, each advancing one level
+//     per step of the machine; the final exponentiation (Lucas ladder: 2 levels per exponent bit) runs on one track.
+// 1462 levels per pairing (the throughput kernel: ~30 000 dependent products).  The set-up (byte loads, curve checks,
+// twist map), the one inversion and the store are ordinary lane code on lane 0 / lanes 0-5.
+// Measured shape (tools/sopvm_probe.hip, profiles/r06_notes.md): 930 / 1700 / 2600 cycles per level of 1 / 4 / 8 terms,
+// up to 1024 wavefronts at the latency of one.
+#pragma once
+#include "pairing_d.cuh"
+#include "dw_tables.h"
+
+namespace pbc {
+
+template <int ND> __shared__ __attribute__((aligned(16))) uint32_t g_lds_dw[dw::kSlots * Limbs29<ND>::L + dw::kRows * 5];
+
+template <int ND>
+struct DW {
+  typedef TypeMNT<ND, 3> D;
+  typedef typename D::fq fq;
+  typedef typename D::f3 f3;
+  static constexpr int L = Limbs29<ND>::L;
+  static_assert(L == 6, "the row tables are generated for six-limb fields (eight terms per sum fill a column)");
+
+  static PBC_DEV uint32_t *slot(int s) { return g_lds_dw<ND> + s * L; }
+  static PBC_DEV const uint32_t *rows() { return g_lds_dw<ND> + dw::kSlots * L; }
+  static PBC_DEV void put(int s, const fl<ND> &a) {
+#pragma unroll
+    for (int i = 0; i < L; i++) slot(s)[i] = a.l[i];
+  }
+  static PBC_DEV fl<ND> get(int s) {
+    fl<ND> r;
+#pragma unroll
+    for (int i = 0; i < L; i++) r.l[i] = slot(s)[i];
+    return r;
+  }
+  static PBC_DEV void put_fq(int s, const fq &a) { fl<ND> t; to_limbs<ND>(t, a); put(s, t); }
+  static PBC_DEV fq get_fq(int s) { fq r; from_limbs<ND>(r, get(s)); return r; }     // the canonical residue (Montgomery form)
+
+  struct Lev { int row, T, lanes; };
+  static PBC_DEV Lev lev_of(int index) {
+    const dw::LevelRef r = dw::g_level[index];
+    return Lev{(int) r.row, (int) r.T, (int) r.lanes};
+  }
+  static PBC_DEV Lev lev_none() { return Lev{0, 0, 0}; }
+
+  // one level of the machine: track a on lanes 0-31, track b on lanes 32-63 (lanes = 0: the track idles)
+  template <int T>
+  static PBC_DEV void level_T(const Lev a, const Lev b) {
+    const int lane = (int) threadIdx.x, r = lane & 31;
+    const bool second = lane >= 32;
+    const int first = second ? b.row : a.row, lanes = second ? b.lanes : a.lanes;
+    const bool active = r < lanes;
+    uint32_t w[5];
+    const uint32_t *p = rows() + (first + (active ? r : 0)) * 5;
+#pragma unroll
+    for (int i = 0; i < 5; i++) w[i] = active ? p[i] : 0u;                  // (slot 0 is ZERO: an idle lane multiplies zeros)
+    fl<ND> x[T], y[T], res;
+#pragma unroll
+    for (int t = 0; t < T; t++) {
+      const int kx = 1 + t, ky = 9 + t;
+      const uint32_t *px = slot((int) ((w[kx >> 2] >> (8 * (kx & 3))) & 255u));
+      const uint32_t *py = slot((int) ((w[ky >> 2] >> (8 * (ky & 3))) & 255u));
+#pragma unroll
+      for (int i = 0; i < L; i++) { x[t].l[i] = px[i]; y[t].l[i] = py[i]; }
+    }
+    sop_limbs<ND, T>(res, x, y);
+    __builtin_amdgcn_wave_barrier();                                      // every lane has read: now the writes
+    if (active) put((int) (w[0] & 255u), res);
+    __builtin_amdgcn_wave_barrier();
+  }
+  static __device__ __noinline__ void level2(int ar, int at, int al, int br, int bt, int bl) { (void) at; (void) bt; level_T<2>(Lev{ar, at, al}, Lev{br, bt, bl}); }
+  static __device__ __noinline__ void level4(int ar, int at, int al, int br, int bt, int bl) { (void) at; (void) bt; level_T<4>(Lev{ar, at, al}, Lev{br, bt, bl}); }
+  static __device__ __noinline__ void level8(int ar, int at, int al, int br, int bt, int bl) { (void) at; (void) bt; level_T<8>(Lev{ar, at, al}, Lev{br, bt, bl}); }
+  static PBC_DEV void level(const Lev a, const Lev b) {
+    const int T = (a.lanes ? a.T : 0) > (b.lanes ? b.T : 0) ? a.T : (b.lanes ? b.T : a.T);     // wave-uniform
+    if (T <= 2) level2(a.row, a.T, a.lanes, b.row, b.T, b.lanes);
+    else if (T <= 4) level4(a.row, a.T, a.lanes, b.row, b.T, b.lanes);
+    else level8(a.row, a.T, a.lanes, b.row, b.T, b.lanes);
+  }
+  static PBC_DEV void run(int first, int count) {
+    for (int i = 0; i < count; i++) level(lev_of(first + i), lev_none());
+  }
+
+  // ---- lane 0: bytes -> slots, curve checks, twist map, constants (d_setup_lane) ----
+  static __device__ __noinline__ bool setup(const uint8_t *g1, const uint8_t *g2) {
+    using namespace dw;
+    const FpK<ND> &K = fpk<ND>();
+    const int NB = (int) K.fbytes;
+    fq one, t, u;
+    fp_set<ND>(one, K.one);
+    // constants
+    fq zero;
+#pragma unroll
+    for (int k = 0; k < ND; k++) zero.v[k] = 0;
+    put_fq(S_ZERO, zero);
+    put_fq(S_ONE, one);
+    fp_neg<ND>(t, one); put_fq(S_M1, t);
+    fp_dbl<ND>(t, one); put_fq(S_TWO, t);
+    fp_neg<ND>(u, t); put_fq(S_M2, u);
+    fp_add<ND>(u, t, one); put_fq(S_THREE, u);
+    fp_dbl<ND>(t, t); put_fq(S_FOUR, t);
+    fp_dbl<ND>(t, t); fp_neg<ND>(u, t); put_fq(S_M8, u);
+    fp_dbl<ND>(t, t); put_fq(S_SIXTEEN, t);
+    fp_halve<ND>(t, one); put_fq(S_HALF, t);
+    fp_halve<ND>(t, D::dk(c_d.nqrinv)); fp_halve<ND>(t, t); put_fq(S_QVI, t);
+    put_fq(S_A, D::dk(c_d.A));
+    put_fq(S_V, D::dk(c_d.nqr));
+    for (int k = 0; k < 3; k++) {
+      fl<ND> a, b;
+      for (int l = 0; l < L; l++) { a.l[l] = c_d.xpwr29[(0 * 3 + k) * L + l]; b.l[l] = c_d.xpwr29[(1 * 3 + k) * L + l]; }
+      put(S_XP3_0 + k, a);
+      put(S_XP4_0 + k, b);
+      put_fq(S_XQ1_0 + k, D::dk(c_d.xpowq[0][k]));
+      put_fq(S_XQ2_0 + k, D::dk(c_d.xpowq[1][k]));
+    }
+    // inputs
+    fq Px, Py;
+    f3 Qx, Qy;
+    fp_load_be<ND>(Px, g1);
+    fp_load_be<ND>(Py, g1 + NB);
+    D::f3_load_be(Qx, g2);
+    D::f3_load_be(Qy, g2 + 3 * NB);
+    bool valid;
+    {
+      // curve_is_valid_point (curve.c:57-77): E: y^2 = x^3 + a x + b; the twist over F_q^3
+      fq t0, t1;
+      fp_sqr<ND>(t0, Px);
+      fp_add<ND>(t0, t0, D::dk(c_d.A));
+      fp_mul<ND>(t0, t0, Px);
+      fp_add<ND>(t0, t0, D::dk(c_d.B));
+      fp_sqr<ND>(t1, Py);
+      valid = fp_eq<ND>(t0, t1);
+      f3 u0, u1;
+      D::f3_sqr(u0, Qx);
+      fp_add<ND>(u0.c[0], u0.c[0], D::dk(c_d.ta));
+      D::f3_mul(u0, u0, Qx);
+      fp_add<ND>(u0.c[0], u0.c[0], D::dk(c_d.tb));
+      D::f3_sqr(u1, Qy);
+      valid &= D::f3_eq(u0, u1);
+    }
+    // twist map (x, y) -> (v^-1 x, v^-2 y sqrt(v))  (cc_pairing, d_param.c:580-582)
+    D::f3_mul_fq(Qx, Qx, D::dk(c_d.nqrinv));
+    D::f3_mul_fq(Qy, Qy, D::dk(c_d.nqrinv2));
+    for (int i = 0; i < 3; i++) { put_fq(S_Qx0 + i, Qx.c[i]); put_fq(S_Qy0 + i, Qy.c[i]); put_fq(S_f_x0 + i, i ? zero : one); put_fq(S_f_y0 + i, zero); }
+    put_fq(S_X, Px); put_fq(S_Y, Py); put_fq(S_Z, one);
+    fp_neg<ND>(t, one); put_fq(S_nZ, t);
+    put_fq(S_W, D::dk(c_d.A));
+    put_fq(S_Px, Px); put_fq(S_Py, Py);
+    fp_neg<ND>(t, Py); put_fq(S_nPy, t);
+    return valid;
+  }
+
+  // ---- the Miller loop: two tracks, one level of each per step of the machine (tools/dw_gen.py Model.pairing) ----
+  static PBC_DEV void miller() {
+    using namespace dw;
+    const int rb = c_d.rbits;
+    // the accumulator track: for m = rbits - 2 .. 0: product with the tangent's line; product with the chord's if the digit
+    // is set (m > 0); square (m > 0).  The point track: the same steps without the squares.
+    int fm = rb - 2, fph = 0, pm = rb - 2, pph = 0;
+    int lines_taken = 0, pdone = 0, pstarted = 0, mul_started = 0;
+    int fbase = -1, flev = 0, fcount = 0, pbase = -1, plev = 0, pcount = 0;
+    for (;;) {
+      if (fbase < 0) {
+        // skip phases that do not occur
+        while (fm >= 0 && ((fph == 1 && !(fm > 0 && D::d_digit(fm))) || (fph == 2 && fm <= 0))) { if (++fph == 3) { fph = 0; fm--; } }
+        if (fm < 0) { if (pbase < 0) break; }
+        else if (fph == 2) { fbase = P_f_sqr; fcount = N_f_sqr; flev = 0; fph = 0; fm--; }
+        else if (lines_taken < pdone) {
+          fbase = (lines_taken & 1) ? P_f_mul1 : P_f_mul0; fcount = N_f_mul0; flev = 0;
+          lines_taken++;
+          mul_started = lines_taken;
+          fph++;
+        }
+      }
+      if (pbase < 0) {
+        while (pm >= 0 && pph == 1 && !(pm > 0 && D::d_digit(pm))) { pph = 0; pm--; }
+        if (pm >= 0 && (pstarted < 2 || mul_started > pstarted - 2)) {
+          const int bank = pstarted & 1;
+          if (pph == 0) { pbase = bank ? P_pt_dbl1 : P_pt_dbl0; pcount = N_pt_dbl0; pph = 1; }
+          else {
+            const bool neg = D::d_digit(pm) < 0;
+            pbase = neg ? (bank ? P_pt_addm1 : P_pt_addm0) : (bank ? P_pt_addp1 : P_pt_addp0); pcount = N_pt_addp0;
+            pph = 0; pm--;
+          }
+          plev = 0;
+          pstarted++;
+        }
+      }
+      level(fbase >= 0 ? lev_of(fbase + flev) : lev_none(), pbase >= 0 ? lev_of(pbase + plev) : lev_none());
+      if (fbase >= 0 && ++flev == fcount) fbase = -1;
+      if (pbase >= 0 && ++plev == pcount) { pbase = -1; pdone++; }
+    }
+  }
+
+  // ---- cc_tatepower with one inversion (d_final_exp): level programs around three pieces of lane code ----
+  static PBC_DEV void final_exp() {
+    using namespace dw;
+    run(P_fe1, N_fe1);
+    if (threadIdx.x == 0) {
+      // B = 0 (the value after the easy part is +-1) must not poison 1 / (D B): invert D * 1 instead (d_final_exp)
+      fq one, zero;
+      fp_set<ND>(one, fpk<ND>().one);
+#pragma unroll
+      for (int k = 0; k < ND; k++) zero.v[k] = 0;
+      fq b[3];
+      bool b0 = true;
+      for (int i = 0; i < 3; i++) { b[i] = get_fq(S_wB0 + i); b0 &= fp_is0<ND>(b[i]); }
+      for (int i = 0; i < 3; i++) put_fq(S_Bn0 + i, b0 ? (i ? zero : one) : b[i]);
+    }
+    __builtin_amdgcn_wave_barrier();
+    run(P_fe2, N_fe2);
+    if (threadIdx.x == 0) {
+      fq n;
+      fp_inv<ND>(n, get_fq(S_nrm0));                  // the only inversion
+      put_fq(S_ninv, n);
+    }
+    __builtin_amdgcn_wave_barrier();
+    run(P_fe3, N_fe3);
+    // lucas_even (d_param.c:462-482): j == 0 takes the 0-branch
+    for (int j = c_d.phikbits - 1; j >= 0; j--) {
+      const bool bit = j ? ((c_d.phik[j >> 5] >> (j & 31)) & 1) != 0 : false;
+      run(bit ? P_lucas1 : P_lucas0, N_lucas0);
+    }
+    run(P_fe4, N_fe4);
+  }
+
+  static __device__ void pairing(uint8_t *gt, const uint8_t *g1, const uint8_t *g2) {
+    using namespace dw;
+    for (int i = (int) threadIdx.x; i < kRows * 5; i += 64) g_lds_dw<ND>[kSlots * L + i] = g_rows[i];
+    for (int i = (int) threadIdx.x; i < kSlots * L; i += 64) g_lds_dw<ND>[i] = 0;
+    __builtin_amdgcn_wave_barrier();
+    __shared__ int valid_s;
+    if (threadIdx.x == 0) valid_s = setup(g1, g2) ? 1 : 0;
+    __builtin_amdgcn_wave_barrier();
+    miller();
+    final_exp();
+    const bool valid = valid_s != 0;
+    if (threadIdx.x < 6) {
+      fq o = get_fq(S_f_x0 + (int) threadIdx.x);      // f.x0..2, f.y0..2 are consecutive slots: GT's wire order
+      if (!valid) {                                   // an input that deserialises to O: the identity of GT
+        fq one;
+        fp_set<ND>(one, fpk<ND>().one);
+#pragma unroll
+        for (int k = 0; k < ND; k++) o.v[k] = threadIdx.x == 0 ? one.v[k] : 0u;
+      }
+      fp_store_be<ND>(gt + (size_t) threadIdx.x * fpk<ND>().fbytes, o);
+    }
+  }
+};
+
+}  // namespace pbc

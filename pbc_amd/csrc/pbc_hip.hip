@@ -947,7 +947,7 @@ extern "C" int pbc_hip_element_prod_pairing_batch_limbs(pbc_hip_pairing_t *P, ui
   return run_host_generic(P, gt, P->lenT / fb * w, g1, (size_t) k * (P->len1 / fb) * w, g2, (size_t) k * (P->len2 / fb) * w, n,
                           [P, k](void *d_gt, const void *d_g1, const void *d_g2, size_t m, hipStream_t s, const OwnWs *own) {
                             return launch_prod_raw(P, d_gt, d_g1, d_g2, m, k, s, false, own);
-                          }, true);
+                          }, false);     // (staged: the images travel H2D / D2H in chunks; the conversion kernels are not run on mapped host memory)
 }
 extern "C" int pbc_hip_element_pairing_batch_limbs(pbc_hip_pairing_t *P, uint8_t *gt, const uint8_t *g1, const uint8_t *g2, size_t n) {
   return pbc_hip_element_prod_pairing_batch_limbs(P, gt, g1, g2, n, 1);

@@ -1,5 +1,6 @@
 // pbc_hip_d.hip -- kernels and launches of types d and g (libpbc_hip.so; see host_common.h)
 #include "host_common.h"
+#include "pairing_dw.cuh"
 
 // Types D and G: one k-term product (k = 1: a single pairing) per lane.  With fb = fixed byte length
 // of F_q and d = k/2, G1 records are 2 fb, G2 and GT 2 d fb bytes (40 / 120 / 120 B for d159.param,
@@ -30,6 +31,15 @@ __global__ void __launch_bounds__(kBlock, PBC_DF_WAVES) d_prod_pairing_kernel(ui
   } else {
     d_prod_unit<N, DEG>((size_t) blockIdx.x * kBlock + threadIdx.x, gt, g1, g2, n, k, ws);
   }
+}
+
+// small batches on the five-word d = 3 fields: one pairing per wavefront (pairing_dw.cuh)
+template <int N>
+__global__ void __launch_bounds__(64) dw_pairing_kernel(uint8_t *gt, const uint8_t *g1, const uint8_t *g2, size_t n, KArgs<N> ka) {
+  const size_t idx = blockIdx.x;
+  if (idx >= n) return;
+  const size_t fb = fpk<N>().fbytes;
+  DW<N>::pairing(gt + idx * 6 * fb, g1 + idx * 2 * fb, g2 + idx * 6 * fb);
 }
 
 // pairing_pp for types d / g: single-lane table derivation, then one second argument per lane
@@ -91,7 +101,10 @@ int derive_d(pbc_hip_pairing_s *P, hipStream_t s) {
 
 int launch_d(pbc_hip_pairing_s *P, void *d_gt, const void *d_g1, const void *d_g2, size_t n, int k, hipStream_t s, ProdWs &W) {
   unsigned grid = (unsigned) ((n + kBlock - 1) / kBlock);
-  if (k == 1) {
+  if (k == 1 && P->type == 'd' && P->nlimb == 5 && P->deg == 3 && n <= P->d_wave_max) {
+    // a batch this small runs at the latency of ONE lane on the throughput kernel (3.9 ms): a wavefront per pairing instead
+    hipLaunchKernelGGL(dw_pairing_kernel<5>, dim3((unsigned) n), dim3(64), 0, s, (uint8_t *) d_gt, (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, kargs<5>(P));
+  } else if (k == 1) {
     PBC_DISPATCH_D(P, hipLaunchKernelGGL((d_prod_pairing_kernel<N, DEG>), dim3(kDResident<N, DEG> ? PBC_RGRID(d_prod_pairing_kernel<N, DEG>) : grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
                                                 (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, 1, (uint32_t *) nullptr, kDResident<N, DEG> ? unit_counter(P, s) : nullptr, kargs<N>(P)));
   } else {

@@ -1235,9 +1235,10 @@ def test_limb_image_entry_points_match_the_reference_vectors(hips, name):
 
 
 def test_glue_batch_calls_on_both_exchange_formats():
-    """integration/pbc_hip_glue.c: element_pairing_batch / element_prod_pairing_batch through montfp limb images (the default
-    when the layout probe passes; PBC_HIP_VERBOSE reports the route) and through element_to_bytes records
-    (PBC_HIP_GLUE_LIMBS=0): both equal the reference's CPU results for every unit (glue_test compares with element_cmp)"""
+    """integration/pbc_hip_glue.c: element_pairing_batch / element_prod_pairing_batch through montfp limb images (opt-in,
+    PBC_HIP_GLUE_LIMBS=1, when the layout probe passes; PBC_HIP_VERBOSE reports the route) and through element_to_bytes
+    records (the default): both equal the reference's CPU results for every unit (glue_test compares with element_cmp),
+    also for a batch of several chunks and conversion threads"""
     import os
     import subprocess
     import pbc_amd
@@ -1249,4 +1250,8 @@ def test_glue_batch_calls_on_both_exchange_formats():
             r = subprocess.run([oracle.GLUE_TEST, os.path.join(pbc_amd.PARAM_DIR, pname + ".param"), "300"],
                                capture_output=True, text=True, env=env, timeout=600)
             assert r.returncode == 0 and "PASS" in r.stdout, r.stdout + r.stderr
-            assert "batch calls exchange " + want in r.stderr, r.stderr
+            assert (("batch calls exchange " + want) in r.stderr) == (limbs == "1"), r.stderr
+            if pname == "a":                                  # three chunks of 131072, sixteen conversion threads
+                r = subprocess.run([oracle.GLUE_TEST, os.path.join(pbc_amd.PARAM_DIR, "a.param"), "300000", "bench"],
+                                   capture_output=True, text=True, env=env, timeout=600)
+                assert r.returncode == 0 and "equals the CPU pairing" in r.stdout, r.stdout + r.stderr

@@ -122,3 +122,15 @@ def test_wide_field_bodies_fit_two_waves_per_simd():
     assert len(kernels) == 3
     for k in kernels:
         assert info[k]["NumVgprs"] + info[k]["NumAgprs"] <= 256, (k, info[k])
+
+
+def test_wave_program_tables_are_current_and_reproduce_the_reference():
+    """tools/dw_gen.py: the level programs of the one-pairing-per-wavefront type d kernel, run on Python integers with the
+    kernel's driver sequence, give the reference's d159 vectors (off-curve inputs included), and the committed
+    pbc_amd/csrc/dw_tables.h is what the generator writes"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import dw_gen
+    progs = dw_gen.build()
+    bad, levels = dw_gen.check(progs, count=3)
+    assert bad == 0 and 1000 < levels < 2000
+    assert open(os.path.join(ROOT, "pbc_amd", "csrc", "dw_tables.h")).read() == dw_gen.emit(progs)

@@ -1,0 +1,36 @@
+"""Latency of small batches, d159.param: one pairing per wavefront (pairing_dw.cuh) against the one-pairing-per-lane kernel;
+device buffers, events around the call, median of 7 after 2 warm-ups.   python tools/dwave_latency.py [sizes...]"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import pbc_amd  # noqa: E402
+from conftest import golden, _param  # noqa: E402
+
+v = golden("d_chain256.vec")
+sizes = [int(x) for x in sys.argv[1:]] or [1, 16, 256, 1024, 2048, 4096, 8192, 16384]
+P = {"wave": pbc_amd.Pairing(_param("d159") + "hip_dwave_max 100000000\n"), "lane": pbc_amd.Pairing(_param("d159") + "hip_dwave_max 0\n")}
+for n in sizes:
+    i = np.arange(n) % v.n
+    g1 = torch.from_numpy(np.ascontiguousarray(v.g1[i])).cuda()
+    g2 = torch.from_numpy(np.ascontiguousarray(v.g2[(i * 5 + 1) % v.n])).cuda()
+    row, outs = {}, {}
+    for name, H in P.items():
+        out = torch.empty((n, H.length_in_bytes_GT), dtype=torch.uint8, device="cuda")
+        ts = []
+        for rep in range(9):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            H.element_pairing_dev(out.data_ptr(), g1.data_ptr(), g2.data_ptr(), n, torch.cuda.current_stream().cuda_stream)
+            b.record()
+            b.synchronize()
+            ts.append(a.elapsed_time(b))
+        row[name] = float(np.median(ts[2:]))
+        outs[name] = out.cpu().numpy()
+    print("n = %6d   wavefront per pairing %8.3f ms  (%9.0f /s)    lane %8.3f ms  (%9.0f /s)    same bytes: %s" %
+          (n, row["wave"], n / row["wave"] * 1e3, row["lane"], n / row["lane"] * 1e3, np.array_equal(outs["wave"], outs["lane"])), flush=True)

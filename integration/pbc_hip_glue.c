@@ -31,9 +31,6 @@ static struct {
   int (*host_alloc)(void **, size_t);
   void (*host_free)(void *);
   int (*finalpow)(pbc_hip_pairing_t *, unsigned char *, const unsigned char *, size_t);
-  /* optional (round 6): the batch calls on montfp limb images instead of element_to_bytes records */
-  int (*limb_bytes)(pbc_hip_pairing_t *);
-  int (*prod_limbs)(pbc_hip_pairing_t *, unsigned char *, const unsigned char *, const unsigned char *, size_t, int);
 } L;
 
 /* one attachment per pairing_s (kept in a table keyed by the pairing pointer so that struct pairing_s itself needs no
@@ -52,9 +49,6 @@ typedef struct {
   /* page-locked staging buffers of the batch calls (pbc_hip_host_alloc): kept and grown, never per call */
   unsigned char *pin[3];
   size_t pin_cap[3];
-  /* limb-image route of the batch calls (limb_probe): bytes of one F_q limb image (0: the route is off), F_q leaves per
-   * G1 / G2 / GT element */
-  int limb_w, lv1, lv2, lvt;
 } attach_t;
 static attach_t **g_att;
 static int g_natt, g_catt;
@@ -139,8 +133,6 @@ static int load_lib(void) {
   SYM(host_alloc, "pbc_hip_host_alloc"); SYM(host_free, "pbc_hip_host_free");
   SYM(finalpow, "pbc_hip_finalpow_batch");
 #undef SYM
-  *(void **) &L.limb_bytes = dlsym(L.dl, "pbc_hip_fq_limb_image_bytes");
-  *(void **) &L.prod_limbs = dlsym(L.dl, "pbc_hip_element_prod_pairing_batch_limbs");
   return 0;
 }
 
@@ -172,8 +164,7 @@ typedef struct {
   element_t *in1, *in2, *out;
   unsigned char *b1, *b2, *bt;
   size_t *slot;
-  int k, l1, l2, lt;                   /* record lengths of the route in use (wire bytes, or leaves x limb image) */
-  int w;                               /* limb-image bytes per F_q leaf (limb route) */
+  int k, l1, l2, lt;
 } conv_t;
 static void to_bytes_range(size_t lo, size_t hi, void *ctx) {
   conv_t *c = ctx;
@@ -189,127 +180,7 @@ static void from_bytes_range(size_t lo, size_t hi, void *ctx) {
   conv_t *c = ctx;
   for (size_t i = lo; i < hi; i++) element_from_bytes(c->out[c->slot[i]], c->bt + i * c->lt);
 }
-static void limbs_out(unsigned char *dst, element_ptr e, int w);
-static void limbs_in(element_ptr e, const unsigned char *src, int w);
-static void *xmalloc(size_t n);
-static void to_limbs_range(size_t lo, size_t hi, void *ctx) {
-  conv_t *c = ctx;
-  for (size_t i = lo; i < hi; i++) {
-    const size_t u = c->slot[i];
-    for (int j = 0; j < c->k; j++) {
-      limbs_out(c->b1 + (i * c->k + j) * c->l1, c->in1[u * c->k + j], c->w);
-      limbs_out(c->b2 + (i * c->k + j) * c->l2, c->in2[u * c->k + j], c->w);
-    }
-  }
-}
-static void from_limbs_range(size_t lo, size_t hi, void *ctx) {
-  conv_t *c = ctx;
-  for (size_t i = lo; i < hi; i++) limbs_in(c->out[c->slot[i]], c->bt + i * c->lt, c->w);
-}
 
-/* ---- the limb-image route (round 6) ------------------------------------------------------------------------------------
- * element_to_bytes / element_from_bytes are what bounds element_pairing_batch (a Montgomery reduction, an mpz export and
- * two allocations per coordinate: 16 threads convert 4.8 M type a pairs/s, the GPU pairs 13 M).  A montfp element is
- * { char flag; mp_limb_t *d } with t = ceil(bits(q) / 64) limbs of x 2^(64 t) mod q (arith/montfp.c:36-39; flag 0 = zero,
- * :93-100); the library takes exactly that image (pbc_hip_element_prod_pairing_batch_limbs) and changes the Montgomery
- * radix on the device, so a coordinate costs the host one memcpy.  The F_q leaves of an element are reached through the
- * PUBLIC accessors (element_item: coordinates of a point, coefficients of a polymod / quadratic element, through the GT
- * wrapper) in the order element_to_bytes writes them; only the two-field montfp record is mirrored here, and limb_probe
- * checks that mirror against element_to_bytes / element_from_bytes on this very pairing before the route is used --
- * another F_p back end (pbc_tweak_use_fp) or a changed layout fails the probe and the batch calls keep the byte route.
- * OPT-IN (PBC_HIP_GLUE_LIMBS=1): measured on the 16-core GPU box (round 6, profiles/r06_notes.md) the route does not make
- * element_pairing_batch faster -- 2^20 a.param pairs: 4.6-5.8 M pairs/s on limb images against 4.8-5.9 M on
- * element_to_bytes records, d159 6.7-7.8 M against 5.9-7.5 M -- because what bounds the batch calls is not the conversion's
- * arithmetic but walking 3 x 2^20 heap-allocated element_t trees (five dependent cache misses per coordinate) under a
- * 16-core quota; the byte route stays the default. */
-typedef struct { char flag; mp_limb_t *d; } montfp_rec;
-static int fq_leaves(element_ptr e, element_ptr *out, int n) {           /* depth-first, wire order; n < 0: overflow */
-  const int c = element_item_count(e);
-  if (!c) { if (n >= 0 && n < 64) out[n++] = e; else n = -1; return n; }
-  for (int i = 0; i < c && n >= 0; i++) n = fq_leaves(element_item(e, i), out, n);
-  return n;
-}
-static void limbs_out(unsigned char *dst, element_ptr e, int w) {        /* element -> limb images of its leaves */
-  element_ptr lv[64];
-  const int n = fq_leaves(e, lv, 0);
-  for (int i = 0; i < n; i++) {
-    const montfp_rec *r = lv[i]->data;
-    if (r->flag) memcpy(dst + (size_t) i * w, r->d, (size_t) w); else memset(dst + (size_t) i * w, 0, (size_t) w);
-  }
-}
-static void limbs_in(element_ptr e, const unsigned char *src, int w) {   /* limb images -> the leaves of an element */
-  element_ptr lv[64];
-  const int n = fq_leaves(e, lv, 0);
-  for (int i = 0; i < n; i++) {
-    montfp_rec *r = lv[i]->data;
-    const unsigned char *p = src + (size_t) i * w;
-    int nz = 0;
-    for (int b = 0; b < w && !nz; b++) nz = p[b] != 0;
-    if (nz) { memcpy(r->d, p, (size_t) w); r->flag = 2; } else r->flag = 0;
-  }
-}
-/* decide once per attachment whether the limb-image route may be used */
-static void limb_probe(attach_t *a) {
-  a->limb_w = 0;
-  const char *env = getenv("PBC_HIP_GLUE_LIMBS");
-  if (!env || !atoi(env) || !L.limb_bytes || !L.prod_limbs) return;       /* opt-in: see the measurement in the comment above */
-  const int w = L.limb_bytes(a->gpu), l1 = L.len1(a->gpu), l2 = L.len2(a->gpu), lt = L.lenT(a->gpu);
-  if (w <= 0 || w % (int) sizeof(mp_limb_t)) return;
-  element_t P, Q, T, T2;
-  element_init_G1(P, a->pairing); element_init_G2(Q, a->pairing); element_init_GT(T, a->pairing); element_init_GT(T2, a->pairing);
-  element_from_hash(P, (void *) "pbc_hip limb probe P", 20);              /* (no draw from the program's random stream) */
-  element_from_hash(Q, (void *) "pbc_hip limb probe Q", 20);
-  int ok = !element_is0(P) && !element_is0(Q);
-  element_ptr lv[64];
-  const int n1 = ok ? fq_leaves(P, lv, 0) : -1, n2 = ok ? fq_leaves(Q, lv, 0) : -1;
-  if (ok && l1 <= 4096) {
-    /* a test element of GT's field with DISTINCT coordinates (leaf i = x(P) + i), set through element_from_bytes: nothing
-     * is paired or powered on the CPU here */
-    unsigned char pb[4096], *tb = xmalloc((size_t) lt);
-    element_to_bytes(pb, P);
-    const int fb0 = l1 / n1;
-    for (int i = 0; i < lt / fb0; i++) { memcpy(tb + (size_t) i * fb0, pb, (size_t) fb0); tb[(size_t) i * fb0 + fb0 - 1] = (unsigned char) (pb[fb0 - 1] + 3 * i + 1); }
-    element_from_bytes(T, tb);
-    free(tb);
-  } else ok = 0;
-  const int nt = fq_leaves(T, lv, 0);
-  ok = ok && n1 > 0 && n2 > 0 && nt > 0;
-  /* the leaves must be F_q elements of the expected size, and the accessor order must be the wire order */
-  if (ok) {
-    const int fb = l1 / n1;
-    ok = fb * n1 == l1 && fb * n2 == l2 && fb * nt == lt && element_length_in_bytes(lv[0]) == fb &&
-         (int) ((mpz_sizeinbase(lv[0]->field->order, 2) + 8 * sizeof(mp_limb_t) - 1) / (8 * sizeof(mp_limb_t)) * sizeof(mp_limb_t)) == w;
-  }
-  if (ok) {
-    /* the mirror: for every leaf of T, limbs * 2^(-8 w) mod q must be the value element_to_bytes writes; and writing the
-     * limbs of T into a fresh element must give an element equal to T with the same bytes */
-    unsigned char *bytes = xmalloc((size_t) lt), *bytes2 = xmalloc((size_t) lt), *img = xmalloc((size_t) nt * w);
-    const int fb = lt / nt;
-    element_to_bytes(bytes, T);
-    limbs_out(img, T, w);
-    mpz_t v, rinv, z;
-    mpz_init(v); mpz_init(rinv); mpz_init(z);
-    mpz_set_ui(rinv, 1); mpz_mul_2exp(rinv, rinv, 8 * (unsigned long) w);
-    ok = mpz_invert(rinv, rinv, lv[0]->field->order) != 0;
-    for (int i = 0; i < nt && ok; i++) {
-      mpz_import(v, (size_t) w / sizeof(mp_limb_t), -1, sizeof(mp_limb_t), 0, 0, img + (size_t) i * w);
-      ok = mpz_cmp(v, lv[0]->field->order) < 0;
-      mpz_mul(v, v, rinv); mpz_mod(v, v, lv[0]->field->order);
-      mpz_import(z, (size_t) fb, 1, 1, 1, 0, bytes + (size_t) i * fb);
-      ok = ok && !mpz_cmp(v, z);
-    }
-    if (ok) {
-      limbs_in(T2, img, w);
-      element_to_bytes(bytes2, T2);
-      ok = !element_cmp(T, T2) && !memcmp(bytes, bytes2, (size_t) lt);
-    }
-    mpz_clear(v); mpz_clear(rinv); mpz_clear(z);
-    free(bytes); free(bytes2); free(img);
-  }
-  element_clear(P); element_clear(Q); element_clear(T); element_clear(T2);
-  if (ok) { a->limb_w = w; a->lv1 = n1; a->lv2 = n2; a->lvt = nt; }
-  if (getenv("PBC_HIP_VERBOSE")) fprintf(stderr, "pbc_hip: batch calls exchange %s\n", ok ? "montfp limb images" : "element_to_bytes records");
-}
 /* one GPU call of the batch pipeline, on its own thread while the CPU threads convert the neighbouring chunks */
 typedef struct {
   void *att;
@@ -318,7 +189,6 @@ typedef struct {
   size_t m;
   int rc;
   char err[256];
-  int limbs;                           /* the buffers hold montfp limb images */
 } gpu_job_t;
 static void *gpu_job_main(void *arg);
 
@@ -326,8 +196,6 @@ static void *gpu_job_main(void *arg);
 static int run_batch(attach_t *a, element_t out[], element_t in1[], element_t in2[], size_t n, int k) {
   if (k < 1) { for (size_t u = 0; u < n; u++) element_set1(out[u]); return 0; }   /* empty products, as hip_prod */
   int l1 = L.len1(a->gpu), l2 = L.len2(a->gpu), lt = L.lenT(a->gpu);
-  const int limbs = a->limb_w > 0;     /* exchange montfp limb images (limb_probe) instead of element_to_bytes records */
-  if (limbs) { l1 = a->lv1 * a->limb_w; l2 = a->lv2 * a->limb_w; lt = a->lvt * a->limb_w; }
   size_t terms = n * (size_t) k, m = 0;
   unsigned char *b1 = pinned(a, 0, terms * l1), *b2 = pinned(a, 1, terms * l2), *bt = pinned(a, 2, n * lt);
   size_t *slot = malloc(n * sizeof *slot);
@@ -340,28 +208,26 @@ static int run_batch(attach_t *a, element_t out[], element_t in1[], element_t in
     if (ident) { element_set0(out[u]); continue; }
     slot[m++] = u;
   }
-  conv_t c = {in1, in2, out, b1, b2, bt, slot, k, l1, l2, lt, a->limb_w};
-  void (*const to_range)(size_t, size_t, void *) = limbs ? to_limbs_range : to_bytes_range;
-  void (*const from_range)(size_t, size_t, void *) = limbs ? from_limbs_range : from_bytes_range;
+  conv_t c = {in1, in2, out, b1, b2, bt, slot, k, l1, l2, lt};
   int rc = 0;
   /* Three stages per chunk -- element_to_bytes (CPU threads), the GPU call, element_from_bytes (CPU threads) -- run as a
    * pipeline: while the GPU works on chunk i the CPU threads convert the results of chunk i - 1 and the inputs of
    * chunk i + 1.  (The conversions cost more CPU time than the GPU needs for the pairings.) */
   const size_t CH = 131072 / (size_t) k > 32768 ? 131072 / (size_t) k : 32768;   /* at least one chip residency of lanes per GPU call (products: of terms, and 256 workgroups of products) */
   const size_t nc = (m + CH - 1) / CH;
-  if (m) parallel_range(0, m < CH ? m : CH, to_range, &c);
+  if (m) parallel_range(0, m < CH ? m : CH, to_bytes_range, &c);
   for (size_t ci = 0; ci < nc && !rc; ci++) {
     const size_t lo = ci * CH, hi = lo + CH < m ? lo + CH : m;
-    gpu_job_t job = {a, k, b1 + lo * k * l1, b2 + lo * k * l2, bt + lo * lt, hi - lo, 0, {0}, limbs};
+    gpu_job_t job = {a, k, b1 + lo * k * l1, b2 + lo * k * l2, bt + lo * lt, hi - lo, 0, {0}};
     pthread_t th;
     const int threaded = nc > 1 && !pthread_create(&th, NULL, gpu_job_main, &job);
     if (!threaded) gpu_job_main(&job);
-    if (ci > 0) parallel_range(lo - CH, lo, from_range, &c);
-    if (hi < m) parallel_range(hi, hi + CH < m ? hi + CH : m, to_range, &c);
+    if (ci > 0) parallel_range(lo - CH, lo, from_bytes_range, &c);
+    if (hi < m) parallel_range(hi, hi + CH < m ? hi + CH : m, to_bytes_range, &c);
     if (threaded) pthread_join(th, NULL);
     if (job.rc) { rc = 1; pbc_error("pbc_hip: %s", job.err); }
   }
-  if (m && !rc) { parallel_range((nc - 1) * CH, m, from_range, &c); g_stat.batch_units += m; }
+  if (m && !rc) { parallel_range((nc - 1) * CH, m, from_bytes_range, &c); g_stat.batch_units += m; }
   free(slot);
   return rc;
 }
@@ -369,8 +235,7 @@ static int run_batch(attach_t *a, element_t out[], element_t in1[], element_t in
 static void *gpu_job_main(void *arg) {
   gpu_job_t *j = arg;
   attach_t *a = j->att;
-  if (j->limbs) j->rc = L.prod_limbs(a->gpu, j->bt, j->b1, j->b2, j->m, j->k);
-  else j->rc = j->k == 1 ? L.pair(a->gpu, j->bt, j->b1, j->b2, j->m) : L.prod(a->gpu, j->bt, j->b1, j->b2, j->m, j->k);
+  j->rc = j->k == 1 ? L.pair(a->gpu, j->bt, j->b1, j->b2, j->m) : L.prod(a->gpu, j->bt, j->b1, j->b2, j->m, j->k);
   if (j->rc) { strncpy(j->err, L.err(), sizeof j->err - 1); j->err[sizeof j->err - 1] = 0; }   /* the message is per thread */
   return NULL;
 }
@@ -656,7 +521,6 @@ int pbc_hip_attach(pairing_t pairing, const char *param, size_t len) {
   }
   a->cpu_clear = pairing->clear_func;
   a->cpu_finalpow = pairing->finalpow;
-  limb_probe(a);
   pairing->finalpow = hip_finalpow;
   pairing->map = hip_map;
   pairing->prod_pairings = hip_prod;

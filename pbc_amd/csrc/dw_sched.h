@@ -1,0 +1,77 @@
+// dw_sched.h -- HOST side of the wave-per-pairing type d kernel (pairing_dw.cuh): one pairing flattened into a SCHEDULE of packed
+// entries.  Which level of which program runs when depends on the curve's constants only (the signed digits of r, the bits
+// of Phi_6(q) / r), so the host walks the two tracks of the Miller loop and the final exponentiation ONCE per object and the
+// kernel is a plain interpreter: entry -> rows -> sums (no scheduling arithmetic, no table lookups on the device; the first
+// version, with the state machine in the kernel, spent ~100 scalar instructions and 5 scalar loads per level on it).
+// tools/dw_gen.py holds the same walk on Python integers (Model.pairing / flat_schedule); tests compare the two.
+//   entry (64 bits): row a [0:12) | lanes a [12:17) | row b [17:29) | lanes b [29:34) | terms [34:38) | op [38:42)
+//   op 0: a level (track a on the first lanes, track b on the last);  1: the B = 0 test of cc_tatepower (lane code);
+//   2: the inversion (lane code);  3: end
+#pragma once
+#include <stdint.h>
+#include <vector>
+#include "dw_tables.h"
+
+namespace pbc { namespace dw {
+
+inline uint64_t entry(int a, int b, int op = OP_LEVEL) {          // a, b: indices into h_level, -1: the track idles
+  const LevelRef z = {0, 0, 0};
+  const LevelRef &A = a >= 0 ? h_level[a] : z, &B = b >= 0 ? h_level[b] : z;
+  const unsigned T = (A.lanes ? A.T : 0u) > (B.lanes ? B.T : 0u) ? A.T : (B.lanes ? B.T : 0u);
+  return (uint64_t) A.row | (uint64_t) A.lanes << 12 | (uint64_t) B.row << 17 | (uint64_t) B.lanes << 29 | (uint64_t) T << 34 | (uint64_t) op << 38;
+}
+template <class Digit>                                            // Digit(m): the signed digit of the Miller loop at position m
+inline void build_schedule(std::vector<uint64_t> &out, int rbits, const Digit &digit, const uint32_t *phik, int phikbits) {
+  out.clear();
+  // The accumulator track: for m = rbits - 2 .. 0: product with the tangent's line; product with the chord's if the digit is
+  // set (m > 0); square (m > 0).  The point track: the same steps without the squares, one line ahead: line i goes to bank
+  // i % 2; the product with line i starts when point program i is complete; point program j starts when the product with
+  // line j - 2 has started (it reads the bank in its first level only).
+  int fm = rbits - 2, pm = rbits - 2, fph = 0, pph = 0, lines_taken = 0, pdone = 0, pstarted = 0, mul_started = 0;
+  int fbase = -1, flev = 0, fcount = 0, pbase = -1, plev = 0, pcount = 0;
+  for (;;) {
+    if (fbase < 0) {
+      while (fm >= 0 && ((fph == 1 && !(fm > 0 && digit(fm))) || (fph == 2 && fm <= 0))) { if (++fph == 3) { fph = 0; fm--; } }
+      if (fm < 0) { if (pbase < 0) break; }
+      else if (fph == 2) { fbase = P_f_sqr; fcount = N_f_sqr; flev = 0; fph = 0; fm--; }
+      else if (lines_taken < pdone) {
+        fbase = (lines_taken & 1) ? P_f_mul1 : P_f_mul0; fcount = N_f_mul0; flev = 0;
+        lines_taken++;
+        mul_started = lines_taken;
+        fph++;
+      }
+    }
+    if (pbase < 0) {
+      while (pm >= 0 && pph == 1 && !(pm > 0 && digit(pm))) { pph = 0; pm--; }
+      if (pm >= 0 && (pstarted < 2 || mul_started > pstarted - 2)) {
+        const int bank = pstarted & 1;
+        if (pph == 0) { pbase = bank ? P_pt_dbl1 : P_pt_dbl0; pcount = N_pt_dbl0; pph = 1; }
+        else {
+          const bool neg = digit(pm) < 0;
+          pbase = neg ? (bank ? P_pt_addm1 : P_pt_addm0) : (bank ? P_pt_addp1 : P_pt_addp0); pcount = N_pt_addp0;
+          pph = 0; pm--;
+        }
+        plev = 0;
+        pstarted++;
+      }
+    }
+    out.push_back(entry(fbase >= 0 ? fbase + flev : -1, pbase >= 0 ? pbase + plev : -1));
+    if (fbase >= 0 && ++flev == fcount) fbase = -1;
+    if (pbase >= 0 && ++plev == pcount) { pbase = -1; pdone++; }
+  }
+  auto run = [&out](int first, int count) { for (int i = 0; i < count; i++) out.push_back(entry(first + i, -1)); };
+  // cc_tatepower with one inversion (pairing_d.cuh d_final_exp)
+  run(P_fe1, N_fe1);
+  out.push_back(entry(-1, -1, OP_BZERO));
+  run(P_fe2, N_fe2);
+  out.push_back(entry(-1, -1, OP_INV));
+  run(P_fe3, N_fe3);
+  for (int j = phikbits - 1; j >= 0; j--) {                       // lucas_even (d_param.c:462-482): j == 0 takes the 0-branch
+    const bool bit = j ? ((phik[j >> 5] >> (j & 31)) & 1) != 0 : false;
+    run(bit ? P_lucas1 : P_lucas0, N_lucas0);
+  }
+  run(P_fe4, N_fe4);
+  out.push_back(entry(-1, -1, OP_END));
+}
+
+} }  // namespace pbc::dw

@@ -101,6 +101,7 @@ struct pbc_hip_pairing_s {
   int raw_t;                 // ... t = 64-bit limbs of the reference's montfp element (0: constants not derived yet)
   void *counters;            // library only: the unit counters of dynamic resident launches (pbc_hip.hip unit_counter)
   void *host_ctx;            // library only: per-device streams and chunk buffers of the host-buffer path (pbc_hip.hip)
+  std::vector<uint64_t> dw_sched;   // type d, five-word fields: the schedule of one pairing on the wave kernel (pbc_hip_d.hip dw_schedule)
   std::string param_text;    // the parameter text the object was built from (text formats: pbc_hip_param_snprint, host_text.h)
 };
 

@@ -22,6 +22,9 @@
 #include "pairing_d.cuh"
 #include "dw_tables.h"
 
+#ifndef PBC_DW_WHATIF
+#define PBC_DW_WHATIF 0               // timing what-ifs (wrong results): bit 1 no Miller loop, bit 2 no final exponentiation
+#endif
 namespace pbc {
 
 template <int ND> __shared__ __attribute__((aligned(16))) uint32_t g_lds_dw[dw::kSlots * Limbs29<ND>::L + dw::kRows * 5];
@@ -50,50 +53,99 @@ struct DW {
   static PBC_DEV fq get_fq(int s) { fq r; from_limbs<ND>(r, get(s)); return r; }     // the canonical residue (Montgomery form)
 
   struct Lev { int row, T, lanes; };
-  static PBC_DEV Lev lev_of(int index) {
-    const dw::LevelRef r = dw::g_level[index];
-    return Lev{(int) r.row, (int) r.T, (int) r.lanes};
-  }
-  static PBC_DEV Lev lev_none() { return Lev{0, 0, 0}; }
+  // a schedule entry (dw_sched.h): row a [0:12) | lanes a [12:17) | row b [17:29) | lanes b [29:34) | terms [34:38) | op [38:42)
+  static PBC_DEV Lev ent_a(uint64_t e) { return Lev{(int) (e & 4095u), (int) ((e >> 34) & 15u), (int) ((e >> 12) & 31u)}; }
+  static PBC_DEV Lev ent_b(uint64_t e) { return Lev{(int) ((e >> 17) & 4095u), (int) ((e >> 34) & 15u), (int) ((e >> 29) & 31u)}; }
 
-  // one level of the machine: track a on lanes 0-31, track b on lanes 32-63 (lanes = 0: the track idles)
-  template <int T>
-  static PBC_DEV void level_T(const Lev a, const Lev b) {
+  // One level of the machine: track a on lanes 0-31, track b on lanes 32-63 (lanes = 0: the track idles).  A lane's ROW
+  // (the slot it writes, eight x and eight y operand slots) does not depend on data: the rows of level k + 1 are read while
+  // level k multiplies (one LDS round trip less on every level's critical path).
+  struct Rows { uint32_t w[5]; bool active; };
+  static PBC_DEV Rows load_rows(const Lev a, const Lev b) {
     const int lane = (int) threadIdx.x, r = lane & 31;
     const bool second = lane >= 32;
     const int first = second ? b.row : a.row, lanes = second ? b.lanes : a.lanes;
-    const bool active = r < lanes;
-    uint32_t w[5];
-    const uint32_t *p = rows() + (first + (active ? r : 0)) * 5;
+    Rows R;
+    R.active = r < lanes;
+    const uint32_t *p = rows() + (first + (R.active ? r : 0)) * 5;
 #pragma unroll
-    for (int i = 0; i < 5; i++) w[i] = active ? p[i] : 0u;                  // (slot 0 is ZERO: an idle lane multiplies zeros)
+    for (int i = 0; i < 5; i++) R.w[i] = R.active ? p[i] : 0u;           // (slot 0 is ZERO: an idle lane multiplies zeros)
+    return R;
+  }
+  template <int T>
+  static PBC_DEV void exec_T(const Rows &R) {
     fl<ND> x[T], y[T], res;
 #pragma unroll
     for (int t = 0; t < T; t++) {
       const int kx = 1 + t, ky = 9 + t;
-      const uint32_t *px = slot((int) ((w[kx >> 2] >> (8 * (kx & 3))) & 255u));
-      const uint32_t *py = slot((int) ((w[ky >> 2] >> (8 * (ky & 3))) & 255u));
+      const uint32_t *px = slot((int) ((R.w[kx >> 2] >> (8 * (kx & 3))) & 255u));
+      const uint32_t *py = slot((int) ((R.w[ky >> 2] >> (8 * (ky & 3))) & 255u));
 #pragma unroll
       for (int i = 0; i < L; i++) { x[t].l[i] = px[i]; y[t].l[i] = py[i]; }
     }
     sop_limbs<ND, T>(res, x, y);
     __builtin_amdgcn_wave_barrier();                                      // every lane has read: now the writes
-    if (active) put((int) (w[0] & 255u), res);
+    if (R.active) put((int) (R.w[0] & 255u), res);
     __builtin_amdgcn_wave_barrier();
   }
-  static __device__ __noinline__ void level2(int ar, int at, int al, int br, int bt, int bl) { (void) at; (void) bt; level_T<2>(Lev{ar, at, al}, Lev{br, bt, bl}); }
-  static __device__ __noinline__ void level4(int ar, int at, int al, int br, int bt, int bl) { (void) at; (void) bt; level_T<4>(Lev{ar, at, al}, Lev{br, bt, bl}); }
-  static __device__ __noinline__ void level8(int ar, int at, int al, int br, int bt, int bl) { (void) at; (void) bt; level_T<8>(Lev{ar, at, al}, Lev{br, bt, bl}); }
-  static PBC_DEV void level(const Lev a, const Lev b) {
-    const int T = (a.lanes ? a.T : 0) > (b.lanes ? b.T : 0) ? a.T : (b.lanes ? b.T : a.T);     // wave-uniform
-    if (T <= 2) level2(a.row, a.T, a.lanes, b.row, b.T, b.lanes);
-    else if (T <= 4) level4(a.row, a.T, a.lanes, b.row, b.T, b.lanes);
-    else level8(a.row, a.T, a.lanes, b.row, b.T, b.lanes);
+  // Eight-term levels, FOUR lanes per sum (PBC_DW_SPLIT): a lone wavefront gets one v_mad_u64_u32 through every ~9 cycles, so
+  // a level's time is its multiply-adds per LANE.  Lane s of a group of four accumulates terms s and s + 4 unreduced (wide
+  // columns), two DPP exchanges (quad_perm 1032 / 2301) add the four partial columns, every lane reduces, lane 0 of the
+  // group writes: 72 + 36 multiply-adds per lane instead of 288 + 36.  Groups 0-9 belong to track a, 10-15 to track b.
+  static PBC_DEV Rows load_rows4(const Lev a, const Lev b) {
+    const int g = (int) threadIdx.x >> 2;
+    const bool second = g >= 10;
+    const int r = second ? g - 10 : g, first = second ? b.row : a.row, lanes = second ? b.lanes : a.lanes;
+    Rows R;
+    R.active = r < lanes;
+    const uint32_t *p = rows() + (first + (R.active ? r : 0)) * 5;
+#pragma unroll
+    for (int i = 0; i < 5; i++) R.w[i] = R.active ? p[i] : 0u;
+    return R;
   }
-  static PBC_DEV void run(int first, int count) {
-    for (int i = 0; i < count; i++) level(lev_of(first + i), lev_none());
+  static PBC_DEV uint32_t row_byte(const Rows &R, int k) {                // k wave-uniform or per lane
+    uint32_t w = R.w[0];
+#pragma unroll
+    for (int i = 1; i < 5; i++) w = (k >> 2) == i ? R.w[i] : w;
+    return (w >> (8 * (k & 3))) & 255u;
   }
-
+  static PBC_DEV void exec_split8(const Rows &R) {
+    const int s = (int) threadIdx.x & 3;
+    wide<ND> W;
+    wide_zero<ND>(W);
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int t = s + 4 * j;
+      const uint32_t *px = slot((int) row_byte(R, 1 + t)), *py = slot((int) row_byte(R, 9 + t));
+      fl<ND> x, y;
+#pragma unroll
+      for (int i = 0; i < L; i++) { x.l[i] = px[i]; y.l[i] = py[i]; }
+      wide_mac<ND>(W, x, y);
+    }
+#pragma unroll
+    for (int k = 0; k < 2 * L - 1; k++) {
+      uint32_t lo = (uint32_t) W.c[k], hi = (uint32_t) (W.c[k] >> 32);
+      uint32_t plo = (uint32_t) __builtin_amdgcn_mov_dpp((int) lo, 0xB1, 0xF, 0xF, false), phi = (uint32_t) __builtin_amdgcn_mov_dpp((int) hi, 0xB1, 0xF, 0xF, false);
+      W.c[k] += ((uint64_t) phi << 32) | plo;                             // + the neighbour's (lanes 0<->1, 2<->3)
+      lo = (uint32_t) W.c[k]; hi = (uint32_t) (W.c[k] >> 32);
+      plo = (uint32_t) __builtin_amdgcn_mov_dpp((int) lo, 0x4E, 0xF, 0xF, false); phi = (uint32_t) __builtin_amdgcn_mov_dpp((int) hi, 0x4E, 0xF, 0xF, false);
+      W.c[k] += ((uint64_t) phi << 32) | plo;                             // + the other pair's (0<->2, 1<->3)
+    }
+    fl<ND> res;
+    wide_reduce<ND>(res, W);
+    __builtin_amdgcn_wave_barrier();
+    if (R.active && s == 0) put((int) (R.w[0] & 255u), res);
+    __builtin_amdgcn_wave_barrier();
+  }
+#ifndef PBC_DW_SPLIT
+#define PBC_DW_SPLIT 1
+#endif
+  static PBC_DEV void exec(const Rows &R, const Rows &R4, int T) {
+    if (T <= 2) exec_T<2>(R);
+    else if (T <= 4) exec_T<4>(R);
+    else if (PBC_DW_SPLIT) exec_split8(R4);
+    else exec_T<8>(R);
+  }
   // ---- lane 0: bytes -> slots, curve checks, twist map, constants (d_setup_lane) ----
   static __device__ __noinline__ bool setup(const uint8_t *g1, const uint8_t *g2) {
     using namespace dw;
@@ -163,52 +215,10 @@ struct DW {
     return valid;
   }
 
-  // ---- the Miller loop: two tracks, one level of each per step of the machine (tools/dw_gen.py Model.pairing) ----
-  static PBC_DEV void miller() {
+  // ---- the interpreter: the host flattened the pairing into a schedule (dw_sched.h: which level of which program runs when
+  // depends on the curve's constants only); entry k + 1 is fetched while entry k runs ----
+  static PBC_DEV void bzero_test() {
     using namespace dw;
-    const int rb = c_d.rbits;
-    // the accumulator track: for m = rbits - 2 .. 0: product with the tangent's line; product with the chord's if the digit
-    // is set (m > 0); square (m > 0).  The point track: the same steps without the squares.
-    int fm = rb - 2, fph = 0, pm = rb - 2, pph = 0;
-    int lines_taken = 0, pdone = 0, pstarted = 0, mul_started = 0;
-    int fbase = -1, flev = 0, fcount = 0, pbase = -1, plev = 0, pcount = 0;
-    for (;;) {
-      if (fbase < 0) {
-        // skip phases that do not occur
-        while (fm >= 0 && ((fph == 1 && !(fm > 0 && D::d_digit(fm))) || (fph == 2 && fm <= 0))) { if (++fph == 3) { fph = 0; fm--; } }
-        if (fm < 0) { if (pbase < 0) break; }
-        else if (fph == 2) { fbase = P_f_sqr; fcount = N_f_sqr; flev = 0; fph = 0; fm--; }
-        else if (lines_taken < pdone) {
-          fbase = (lines_taken & 1) ? P_f_mul1 : P_f_mul0; fcount = N_f_mul0; flev = 0;
-          lines_taken++;
-          mul_started = lines_taken;
-          fph++;
-        }
-      }
-      if (pbase < 0) {
-        while (pm >= 0 && pph == 1 && !(pm > 0 && D::d_digit(pm))) { pph = 0; pm--; }
-        if (pm >= 0 && (pstarted < 2 || mul_started > pstarted - 2)) {
-          const int bank = pstarted & 1;
-          if (pph == 0) { pbase = bank ? P_pt_dbl1 : P_pt_dbl0; pcount = N_pt_dbl0; pph = 1; }
-          else {
-            const bool neg = D::d_digit(pm) < 0;
-            pbase = neg ? (bank ? P_pt_addm1 : P_pt_addm0) : (bank ? P_pt_addp1 : P_pt_addp0); pcount = N_pt_addp0;
-            pph = 0; pm--;
-          }
-          plev = 0;
-          pstarted++;
-        }
-      }
-      level(fbase >= 0 ? lev_of(fbase + flev) : lev_none(), pbase >= 0 ? lev_of(pbase + plev) : lev_none());
-      if (fbase >= 0 && ++flev == fcount) fbase = -1;
-      if (pbase >= 0 && ++plev == pcount) { pbase = -1; pdone++; }
-    }
-  }
-
-  // ---- cc_tatepower with one inversion (d_final_exp): level programs around three pieces of lane code ----
-  static PBC_DEV void final_exp() {
-    using namespace dw;
-    run(P_fe1, N_fe1);
     if (threadIdx.x == 0) {
       // B = 0 (the value after the easy part is +-1) must not poison 1 / (D B): invert D * 1 instead (d_final_exp)
       fq one, zero;
@@ -221,23 +231,37 @@ struct DW {
       for (int i = 0; i < 3; i++) put_fq(S_Bn0 + i, b0 ? (i ? zero : one) : b[i]);
     }
     __builtin_amdgcn_wave_barrier();
-    run(P_fe2, N_fe2);
+  }
+  static PBC_DEV void inversion() {
+    using namespace dw;
     if (threadIdx.x == 0) {
       fq n;
       fp_inv<ND>(n, get_fq(S_nrm0));                  // the only inversion
       put_fq(S_ninv, n);
     }
     __builtin_amdgcn_wave_barrier();
-    run(P_fe3, N_fe3);
-    // lucas_even (d_param.c:462-482): j == 0 takes the 0-branch
-    for (int j = c_d.phikbits - 1; j >= 0; j--) {
-      const bool bit = j ? ((c_d.phik[j >> 5] >> (j & 31)) & 1) != 0 : false;
-      run(bit ? P_lucas1 : P_lucas0, N_lucas0);
+  }
+  static __device__ __noinline__ void interpret(const uint64_t *sched) {
+    uint64_t e = sched[0];
+    for (int k = 1;; k++) {
+      const int op = (int) ((e >> 38) & 15u);
+#if PBC_DW_WHATIF & 1
+      if (op != dw::OP_END) { e = sched[k]; continue; }
+#endif
+      if (op == dw::OP_END) break;
+      const uint64_t nxt = sched[k];                  // (wave-uniform: a scalar load that completes under this entry's work)
+      if (op == dw::OP_LEVEL) {
+        const int T = (int) ((e >> 34) & 15u);
+        const Lev a = ent_a(e), b = ent_b(e);
+        const Rows R = T > 4 && PBC_DW_SPLIT ? load_rows4(a, b) : load_rows(a, b);
+        exec(R, R, T);
+      } else if (op == dw::OP_BZERO) bzero_test();
+      else inversion();
+      e = nxt;
     }
-    run(P_fe4, N_fe4);
   }
 
-  static __device__ void pairing(uint8_t *gt, const uint8_t *g1, const uint8_t *g2) {
+  static __device__ void pairing(uint8_t *gt, const uint8_t *g1, const uint8_t *g2, const uint64_t *sched) {
     using namespace dw;
     for (int i = (int) threadIdx.x; i < kRows * 5; i += 64) g_lds_dw<ND>[kSlots * L + i] = g_rows[i];
     for (int i = (int) threadIdx.x; i < kSlots * L; i += 64) g_lds_dw<ND>[i] = 0;
@@ -245,8 +269,7 @@ struct DW {
     __shared__ int valid_s;
     if (threadIdx.x == 0) valid_s = setup(g1, g2) ? 1 : 0;
     __builtin_amdgcn_wave_barrier();
-    miller();
-    final_exp();
+    interpret(sched);
     const bool valid = valid_s != 0;
     if (threadIdx.x < 6) {
       fq o = get_fq(S_f_x0 + (int) threadIdx.x);      // f.x0..2, f.y0..2 are consecutive slots: GT's wire order

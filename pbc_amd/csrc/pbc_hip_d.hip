@@ -1,6 +1,7 @@
 // pbc_hip_d.hip -- kernels and launches of types d and g (libpbc_hip.so; see host_common.h)
 #include "host_common.h"
 #include "pairing_dw.cuh"
+#include "dw_sched.h"
 
 // Types D and G: one k-term product (k = 1: a single pairing) per lane.  With fb = fixed byte length
 // of F_q and d = k/2, G1 records are 2 fb, G2 and GT 2 d fb bytes (40 / 120 / 120 B for d159.param,
@@ -35,11 +36,28 @@ __global__ void __launch_bounds__(kBlock, PBC_DF_WAVES) d_prod_pairing_kernel(ui
 
 // small batches on the five-word d = 3 fields: one pairing per wavefront (pairing_dw.cuh)
 template <int N>
-__global__ void __launch_bounds__(64) dw_pairing_kernel(uint8_t *gt, const uint8_t *g1, const uint8_t *g2, size_t n, KArgs<N> ka) {
+__global__ void __launch_bounds__(64) dw_pairing_kernel(uint8_t *gt, const uint8_t *g1, const uint8_t *g2, size_t n, const uint64_t *sched, KArgs<N> ka) {
   const size_t idx = blockIdx.x;
   if (idx >= n) return;
   const size_t fb = fpk<N>().fbytes;
-  DW<N>::pairing(gt + idx * 6 * fb, g1 + idx * 2 * fb, g2 + idx * 6 * fb);
+  DW<N>::pairing(gt + idx * 6 * fb, g1 + idx * 2 * fb, g2 + idx * 6 * fb, sched);
+}
+// the schedule of one pairing for this object's curve (dw_sched.h), built on first use and kept with the object
+static const std::vector<uint64_t> &dw_schedule(pbc_hip_pairing_s *P) {
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lk(mu);
+  if (P->dw_sched.empty()) {
+    const DConst &C = P->dconst;
+    dw::build_schedule(P->dw_sched, C.rbits, [&C](int m) { return (int) ((C.r[m >> 5] >> (m & 31)) & 1) - (int) ((C.rm[m >> 5] >> (m & 31)) & 1); },
+                       C.phik, C.phikbits);
+  }
+  return P->dw_sched;
+}
+extern "C" size_t pbc_hip_diag_dw_schedule(pbc_hip_pairing_t *P, uint64_t *out, size_t cap) {
+  if (!P || P->type != 'd' || P->nlimb != 5 || P->deg != 3) return 0;
+  const std::vector<uint64_t> &S = dw_schedule(P);
+  for (size_t i = 0; i < S.size() && i < cap; i++) out[i] = S[i];
+  return S.size();
 }
 
 // pairing_pp for types d / g: single-lane table derivation, then one second argument per lane
@@ -103,7 +121,13 @@ int launch_d(pbc_hip_pairing_s *P, void *d_gt, const void *d_g1, const void *d_g
   unsigned grid = (unsigned) ((n + kBlock - 1) / kBlock);
   if (k == 1 && P->type == 'd' && P->nlimb == 5 && P->deg == 3 && n <= P->d_wave_max) {
     // a batch this small runs at the latency of ONE lane on the throughput kernel (3.9 ms): a wavefront per pairing instead
-    hipLaunchKernelGGL(dw_pairing_kernel<5>, dim3((unsigned) n), dim3(64), 0, s, (uint8_t *) d_gt, (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, kargs<5>(P));
+    // (the schedule travels with every launch: 12 KB on the launch's stream -- objects may be used on several devices and streams)
+    const std::vector<uint64_t> &S = dw_schedule(P);
+    uint64_t *d_sched = nullptr;
+    HIP_TRY(hipMallocAsync((void **) &d_sched, S.size() * sizeof(uint64_t), s));
+    HIP_TRY(hipMemcpyAsync(d_sched, S.data(), S.size() * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(dw_pairing_kernel<5>, dim3((unsigned) n), dim3(64), 0, s, (uint8_t *) d_gt, (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, (const uint64_t *) d_sched, kargs<5>(P));
+    (void) hipFreeAsync(d_sched, s);
   } else if (k == 1) {
     PBC_DISPATCH_D(P, hipLaunchKernelGGL((d_prod_pairing_kernel<N, DEG>), dim3(kDResident<N, DEG> ? PBC_RGRID(d_prod_pairing_kernel<N, DEG>) : grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
                                                 (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, 1, (uint32_t *) nullptr, kDResident<N, DEG> ? unit_counter(P, s) : nullptr, kargs<N>(P)));

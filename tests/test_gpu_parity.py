@@ -1234,24 +1234,51 @@ def test_limb_image_entry_points_match_the_reference_vectors(hips, name):
     assert all(int.from_bytes(got[i, c * w:(c + 1) * w].tobytes(), "little") < q for i in range(min(4, len(got))) for c in range(got.shape[1] // w))
 
 
-def test_glue_batch_calls_on_both_exchange_formats():
-    """integration/pbc_hip_glue.c: element_pairing_batch / element_prod_pairing_batch through montfp limb images (opt-in,
-    PBC_HIP_GLUE_LIMBS=1, when the layout probe passes; PBC_HIP_VERBOSE reports the route) and through element_to_bytes
-    records (the default): both equal the reference's CPU results for every unit (glue_test compares with element_cmp),
-    also for a batch of several chunks and conversion threads"""
+def test_glue_batch_call_of_several_chunks():
+    """integration/pbc_hip_glue.c: element_pairing_batch over three chunks of 131072 pairs with sixteen conversion threads;
+    glue_test compares 17 units spread over the chunks with the reference's CPU pairing"""
     import os
     import subprocess
     import pbc_amd
     if not os.path.exists(oracle.GLUE_TEST):
         pytest.skip("oracle/_ref/glue_test not built (needs /root/reference at build time)")
-    for pname in ("a", "d159", "f"):
-        for limbs, want in (("1", "montfp limb images"), ("0", "element_to_bytes records")):
-            env = dict(os.environ, PBC_HIP_LIB=pbc_amd.LIB_PATH, PBC_HIP_GLUE_LIMBS=limbs, PBC_HIP_VERBOSE="1")
-            r = subprocess.run([oracle.GLUE_TEST, os.path.join(pbc_amd.PARAM_DIR, pname + ".param"), "300"],
-                               capture_output=True, text=True, env=env, timeout=600)
-            assert r.returncode == 0 and "PASS" in r.stdout, r.stdout + r.stderr
-            assert (("batch calls exchange " + want) in r.stderr) == (limbs == "1"), r.stderr
-            if pname == "a":                                  # three chunks of 131072, sixteen conversion threads
-                r = subprocess.run([oracle.GLUE_TEST, os.path.join(pbc_amd.PARAM_DIR, "a.param"), "300000", "bench"],
-                                   capture_output=True, text=True, env=env, timeout=600)
-                assert r.returncode == 0 and "equals the CPU pairing" in r.stdout, r.stdout + r.stderr
+    env = dict(os.environ, PBC_HIP_LIB=pbc_amd.LIB_PATH)
+    r = subprocess.run([oracle.GLUE_TEST, os.path.join(pbc_amd.PARAM_DIR, "a.param"), "300000", "bench"],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and "equals the CPU pairing" in r.stdout, r.stdout + r.stderr
+
+
+def test_limb_image_calls_in_a_row_from_worker_threads(hips):
+    """the shape of the glue's batch pipeline: eight host-buffer calls of 131072 units each on page-locked buffers, every call
+    from a fresh thread, results compared in full with one wire-format call"""
+    import ctypes
+    import threading
+    import torch
+    import pbc_amd
+    P = hips["a"]
+    v = golden("a_chain1024.vec")
+    n, CH = 8 * 131072, 131072
+    m = 1024
+    I1, I2 = P.to_limb_images(v.g1[:m]), P.to_limb_images(v.g2[(np.arange(m) * 7 + 3) % v.n])
+    want1 = P.from_limb_images(P.element_prod_pairing_limbs(I1, I2, 1))
+    assert np.array_equal(want1, P.element_pairing(v.g1[:m], v.g2[(np.arange(m) * 7 + 3) % v.n]))
+    h1 = torch.from_numpy(np.tile(I1, (n // m, 1))).pin_memory()
+    h2 = torch.from_numpy(np.tile(I2, (n // m, 1))).pin_memory()
+    out = torch.zeros(n, I1.shape[1], dtype=torch.uint8).pin_memory()
+    L = pbc_amd.lib()
+    rcs = []
+
+    def call(lo):
+        rcs.append(L.pbc_hip_element_prod_pairing_batch_limbs(P._h, ctypes.c_void_p(out.data_ptr() + lo * out.shape[1]),
+                                                              ctypes.c_void_p(h1.data_ptr() + lo * h1.shape[1]),
+                                                              ctypes.c_void_p(h2.data_ptr() + lo * h2.shape[1]), CH, 1))
+    for lo in range(0, n, CH):
+        t = threading.Thread(target=call, args=(lo,))
+        t.start()
+        t.join()
+    assert rcs == [0] * 8
+    got = out.numpy().reshape(n // m, m, -1)
+    first = got[0]
+    assert np.array_equal(P.from_limb_images(first), want1)
+    bad = [i for i in range(n // m) if not np.array_equal(got[i], first)]
+    assert not bad, "blocks of 1024 units that differ from the first: %s" % bad[:8]

@@ -443,6 +443,7 @@ class Model:
         self.plus, self.minus, self.rbits = naf_digits(P["r"])
         self.phik = (q * q - q + 1) // P["r"]
         self.stats = {"levels": 0}
+        self.flat = []                               # the schedule as executed: ("level", (program, level) | None, ...) / ("op", name)
 
     def f3_mul_int(self, a, b):
         q = self.q
@@ -476,6 +477,9 @@ class Model:
         for s, v in writes:
             self.env[s] = v
         self.stats["levels"] += 1
+        a = tracks[0][0] if len(tracks) > 0 and tracks[0] else None
+        b = tracks[1][0] if len(tracks) > 1 and tracks[1] else None
+        self.flat.append(("level", (a[0].name, a[1]) if a else None, (b[0].name, b[1]) if b else None))
 
     def run(self, name):
         p = self.progs[name]
@@ -563,11 +567,13 @@ class Model:
     def final_exp(self):
         q, e = self.q, self.env
         self.run("fe1")
+        self.flat.append(("op", "bzero"))
         b0 = all(e["wB%d" % i] == 0 for i in range(3))
         for i in range(3):
             e["Bn%d" % i] = (1 if i == 0 else 0) if b0 else e["wB%d" % i]
         self.run("fe2")
         assert e["nrm1"] == 0 and e["nrm2"] == 0
+        self.flat.append(("op", "inv"))
         e["ninv"] = pow(e["nrm0"], -1, q) if e["nrm0"] else 0
         self.run("fe3")
         nb = self.phik.bit_length()
@@ -575,7 +581,30 @@ class Model:
             bit = (self.phik >> j) & 1 if j else 0
             self.run("lucas%d" % bit)
         self.run("fe4")
+        self.flat.append(("op", "end"))
         return [e[F[0][i]] for i in range(3)] + [e[F[1][i]] for i in range(3)]
+
+
+def pack_entry(progs_index, a, b, op=0):
+    """the 64-bit schedule entry of dw_sched.h: row a | lanes a | row b | lanes b | terms | op"""
+    ra, la, ta = progs_index[a] if a else (0, 0, 0)
+    rb, lb, tb = progs_index[b] if b else (0, 0, 0)
+    return ra | la << 12 | rb << 17 | lb << 29 | max(ta if la else 0, tb if lb else 0) << 34 | op << 38
+
+
+def flat_schedule(pname="d159"):
+    """the packed schedule of one pairing as the model executes it (compared with the host's dw_build_schedule by the tests)"""
+    progs = build()
+    idx, rows = {}, 0
+    for name in sorted(progs):
+        for lev, (T, lanes) in enumerate(progs[name].table()):
+            idx[(name, lev)] = (rows, len(lanes), T)
+            rows += len(lanes)
+    M = Model(pname, progs)
+    g1, g2, gt = load_vec(os.path.join(ROOT, "tests", "golden", "d_rand32.vec"))
+    M.pairing(g1[0], g2[0])
+    ops = {"bzero": 1, "inv": 2, "end": 3}
+    return [pack_entry(idx, e[1], e[2]) if e[0] == "level" else pack_entry(idx, None, None, ops[e[1]]) for e in M.flat]
 
 
 def load_vec(path):
@@ -628,9 +657,11 @@ def emit(progs):
                 b = [o] + xs + [z] * (8 - len(xs)) + ys + [z] * (8 - len(ys)) + [0, 0, 0]
                 rows.append([b[4 * i] | b[4 * i + 1] << 8 | b[4 * i + 2] << 16 | b[4 * i + 3] << 24 for i in range(5)])
         out.append("constexpr int P_%s = %d, N_%s = %d;" % (name, first, name, len(tab)))
+    out.append("enum { OP_LEVEL = 0, OP_BZERO = 1, OP_INV = 2, OP_END = 3 };      // schedule entries (dw_sched.h)")
     out.append("struct LevelRef { uint16_t row; uint8_t T, lanes; };")
     out.append("constexpr int kLevels = %d, kRows = %d;" % (len(index), len(rows)))
-    out.append("__device__ const LevelRef g_level[kLevels] = {" + ", ".join("{%d, %d, %d}" % x for x in index) + "};")
+    out.append("// (the level table is read by the HOST: it flattens a pairing into a schedule of packed entries, dw_sched.h)")
+    out.append("static const LevelRef h_level[kLevels] = {" + ", ".join("{%d, %d, %d}" % x for x in index) + "};")
     out.append("__device__ const uint32_t g_rows[kRows * 5] = {" + ",".join("0x%xu" % w for r in rows for w in r) + "};")
     out.append("} }  // namespace pbc::dw")
     return "\n".join(out) + "\n"
@@ -642,6 +673,11 @@ def main():
     bad, levels = check(progs)
     for name in sorted(progs):
         p = progs[name]
+        # eight-term levels run four lanes per sum (pairing_dw.cuh exec_split8): ten sums on the accumulator track's lanes,
+        # six on the point track's
+        for row in p.levels:
+            if max(len(n.terms) for n in row) > 4:
+                assert len(row) <= (6 if name.startswith("pt_") else 10), (name, len(row))
         print("%-10s levels %2d  sums %3d  widest level %2d lanes  terms per level %s" % (name, len(p.levels), len(p.nodes), max(len(r) for r in p.levels),
               [max(len(n.terms) for n in r) for r in p.levels]))
     print("slots %d; levels executed per pairing %d; vectors: %s" % (len(SLOTS.order), levels, "MISMATCH" if bad else "ok"))

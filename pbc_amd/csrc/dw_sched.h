@@ -24,28 +24,31 @@ template <class Digit>                                            // Digit(m): t
 inline void build_schedule(std::vector<uint64_t> &out, int rbits, const Digit &digit, const uint32_t *phik, int phikbits) {
   out.clear();
   // The accumulator track: for m = rbits - 2 .. 0: product with the tangent's line; product with the chord's if the digit is
-  // set (m > 0); square (m > 0).  The point track: the same steps without the squares, one line ahead: line i goes to bank
-  // i % 2; the product with line i starts when point program i is complete; point program j starts when the product with
-  // line j - 2 has started (it reads the bank in its first level only).
-  int fm = rbits - 2, pm = rbits - 2, fph = 0, pph = 0, lines_taken = 0, pdone = 0, pstarted = 0, mul_started = 0;
+  // set (m > 0); square (m > 0) -- two levels each.  The point track: the same steps without the squares, ahead of it:
+  //   * point program j leaves the COEFFICIENTS of line j in bank j % 2 and, in its first two levels, evaluates line j - 1
+  //     (the other coefficient bank) into value bank (j - 1) % 2; after the last one a short program evaluates the last line;
+  //   * the product with line i (both levels read value bank i % 2) starts when point program i + 1 has run two levels;
+  //   * point program j starts when the product with line j - 3 is COMPLETE (its first levels overwrite that value bank).
+  int fm = rbits - 2, pm = rbits - 2, fph = 0, pph = 0, lines_taken = 0, line_ready = 0, pstarted = 0, fmul_done = 0;
   int fbase = -1, flev = 0, fcount = 0, pbase = -1, plev = 0, pcount = 0;
+  bool f_is_mul = false, p_exhausted = false;             // p_exhausted: the closing evaluation has been started
   for (;;) {
     if (fbase < 0) {
       while (fm >= 0 && ((fph == 1 && !(fm > 0 && digit(fm))) || (fph == 2 && fm <= 0))) { if (++fph == 3) { fph = 0; fm--; } }
       if (fm < 0) { if (pbase < 0) break; }
-      else if (fph == 2) { fbase = P_f_sqr; fcount = N_f_sqr; flev = 0; fph = 0; fm--; }
-      else if (lines_taken < pdone) {
-        fbase = (lines_taken & 1) ? P_f_mul1 : P_f_mul0; fcount = N_f_mul0; flev = 0;
+      else if (fph == 2) { fbase = P_f_sqr; fcount = N_f_sqr; flev = 0; f_is_mul = false; fph = 0; fm--; }
+      else if (lines_taken < line_ready) {
+        fbase = (lines_taken & 1) ? P_f_mul1 : P_f_mul0; fcount = N_f_mul0; flev = 0; f_is_mul = true;
         lines_taken++;
-        mul_started = lines_taken;
         fph++;
       }
     }
-    if (pbase < 0) {
+    if (pbase < 0 && !p_exhausted) {
       while (pm >= 0 && pph == 1 && !(pm > 0 && digit(pm))) { pph = 0; pm--; }
-      if (pm >= 0 && (pstarted < 2 || mul_started > pstarted - 2)) {
+      if (pstarted < 3 || fmul_done >= pstarted - 2) {
         const int bank = pstarted & 1;
-        if (pph == 0) { pbase = bank ? P_pt_dbl1 : P_pt_dbl0; pcount = N_pt_dbl0; pph = 1; }
+        if (pm < 0) { pbase = bank ? P_pt_eval1 : P_pt_eval0; pcount = N_pt_eval0; p_exhausted = true; }
+        else if (pph == 0) { pbase = bank ? P_pt_dbl1 : P_pt_dbl0; pcount = N_pt_dbl0; pph = 1; }
         else {
           const bool neg = digit(pm) < 0;
           pbase = neg ? (bank ? P_pt_addm1 : P_pt_addm0) : (bank ? P_pt_addp1 : P_pt_addp0); pcount = N_pt_addp0;
@@ -56,8 +59,12 @@ inline void build_schedule(std::vector<uint64_t> &out, int rbits, const Digit &d
       }
     }
     out.push_back(entry(fbase >= 0 ? fbase + flev : -1, pbase >= 0 ? pbase + plev : -1));
-    if (fbase >= 0 && ++flev == fcount) fbase = -1;
-    if (pbase >= 0 && ++plev == pcount) { pbase = -1; pdone++; }
+    if (fbase >= 0 && ++flev == fcount) { fbase = -1; fmul_done += f_is_mul ? 1 : 0; }
+    if (pbase >= 0) {
+      ++plev;
+      if (plev == 2 && pstarted >= 2) line_ready = pstarted - 1;
+      if (plev == pcount) pbase = -1;
+    }
   }
   auto run = [&out](int first, int count) { for (int i = 0; i < count; i++) out.push_back(entry(first + i, -1)); };
   // cc_tatepower with one inversion (pairing_d.cuh d_final_exp)

@@ -168,6 +168,7 @@ void workspace_unpin(pbc_hip_pairing_s *P, hipStream_t s);
 // A workspace that belongs to one stream of a device context of the host-buffer path: grown on demand, freed with the context.
 struct OwnWs { void **p; size_t *cap; };
 void *own_workspace(const OwnWs &o, hipStream_t s, size_t bytes);
+void *object_scratch(pbc_hip_pairing_s *P, const void *key, size_t bytes, bool *fresh);    // small per-(device, key) buffers the object keeps (pbc_hip.hip)
 // The workspace of one product launch: the caller's own (host-buffer path) or the object's table entry for (device,
 // stream), which stays pinned until the launch's kernels are enqueued (the destructor unpins).
 struct ProdWs {

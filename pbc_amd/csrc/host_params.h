@@ -44,7 +44,7 @@ inline int fail(const char *fmt, ...) {
 #endif
 // ---------------------------------------------------------------------------------------
 #ifndef PBC_D_WAVE_MAX
-#define PBC_D_WAVE_MAX 4096
+#define PBC_D_WAVE_MAX 5120
 #endif
 constexpr size_t kProdChunkDefault = (size_t) 1 << 22;   // type a products: terms per launch of the one-term-per-lane kernels unless "hip_prod_chunk N" says otherwise
 struct pbc_hip_pairing_s {

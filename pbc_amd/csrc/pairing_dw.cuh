@@ -5,19 +5,21 @@
 // instructions, 3.9 ms through the reference's call sites whatever the batch size -- three times what one CPU core needs
 // (VERDICT r5 "missing" 1).  Every tower operation, though, is a set of INDEPENDENT lazily reduced sums of F_q products.
 // Here a wavefront owns one pairing:
-//   * every F_q element is a slot of six 29-bit limbs in an LDS slot file (129 slots, 3 KB per wavefront);
+//   * every F_q element is a slot of six 29-bit limbs in an LDS slot file (149 slots, 3.5 KB per wavefront);
 //   * a LEVEL is "lane l computes out[l] = sum_t x[l][t] y[l][t] / R" -- the library's sop_limbs on operands gathered from
 //     the slot file by the lane's ROW of a table (dw_tables.h, generated and checked against the reference's vectors on
 //     Python integers by tools/dw_gen.py) -- "and writes its slot"; a level's lanes read before any lane writes;
 //   * sums, differences and small multiples are products with the constant slots 1, -1, 2, ...: nothing but sums of
-//     products exists, so ONE routine (three instantiations: 2, 4, 8 terms) is the whole arithmetic;
-//   * lanes 0-31 run the ACCUMULATOR track (f <- f * line: 3 levels, f <- f^2: 3 levels), lanes 32-63 the POINT track
-//     (V <- 2V in modified Jacobian coordinates: 4 levels, V <- V +- P: 6) one line ahead of it, each advancing one level
-//     per step of the machine; the final exponentiation (Lucas ladder: 2 levels per exponent bit) runs on one track.
-// 1462 levels per pairing (the throughput kernel: ~30 000 dependent products).  The set-up (byte loads, curve checks,
-// twist map), the one inversion and the store are ordinary lane code on lane 0 / lanes 0-5.
-// Measured shape (tools/sopvm_probe.hip, profiles/r06_notes.md): 930 / 1700 / 2600 cycles per level of 1 / 4 / 8 terms,
-// up to 1024 wavefronts at the latency of one.
+//     products exists, so ONE routine (2 / 4 terms per lane; eight-term sums on four lanes each) is the whole arithmetic;
+//   * the first lanes run the ACCUMULATOR track (f <- f * line and f <- f^2: 2 levels each), the last lanes the POINT track
+//     (V <- 2V in modified Jacobian coordinates: 4 levels, V <- V +- P: 5; the line's value at Q rides in the next point
+//     program) ahead of it, each advancing one level per step of the machine; the final exponentiation (Lucas ladder: 2
+//     levels per exponent bit) runs on one track.
+// 1262 levels per pairing (the throughput kernel: ~30 000 dependent products).  Which level of which program runs when
+// depends on the curve's constants only: the HOST flattens a pairing into a schedule (dw_sched.h) and this kernel interprets
+// it.  The set-up (byte loads, curve checks, twist map), the B = 0 test, the one inversion and the store are ordinary lane
+// code on lane 0 / lanes 0-5.  Measured (profiles/r06_notes.md): one pairing 1.15 ms (lane kernel 4.1 ms, one CPU core 1.35 ms),
+// up to 1024 pairings at the latency of one, 1.35 M pairings/s at 4096.
 #pragma once
 #include "pairing_d.cuh"
 #include "dw_tables.h"
@@ -91,11 +93,11 @@ struct DW {
   // Eight-term levels, FOUR lanes per sum (PBC_DW_SPLIT): a lone wavefront gets one v_mad_u64_u32 through every ~9 cycles, so
   // a level's time is its multiply-adds per LANE.  Lane s of a group of four accumulates terms s and s + 4 unreduced (wide
   // columns), two DPP exchanges (quad_perm 1032 / 2301) add the four partial columns, every lane reduces, lane 0 of the
-  // group writes: 72 + 36 multiply-adds per lane instead of 288 + 36.  Groups 0-9 belong to track a, 10-15 to track b.
+  // group writes: 72 + 36 multiply-adds per lane instead of 288 + 36.
   static PBC_DEV Rows load_rows4(const Lev a, const Lev b) {
     const int g = (int) threadIdx.x >> 2;
-    const bool second = g >= 10;
-    const int r = second ? g - 10 : g, first = second ? b.row : a.row, lanes = second ? b.lanes : a.lanes;
+    const bool second = g >= a.lanes;               // track a's sums take the first groups, track b's the next (at most 16 in all: dw_gen.py)
+    const int r = second ? g - a.lanes : g, first = second ? b.row : a.row, lanes = second ? b.lanes : a.lanes;
     Rows R;
     R.active = r < lanes;
     const uint32_t *p = rows() + (first + (R.active ? r : 0)) * 5;
@@ -177,6 +179,13 @@ struct DW {
       put(S_XP4_0 + k, b);
       put_fq(S_XQ1_0 + k, D::dk(c_d.xpowq[0][k]));
       put_fq(S_XQ2_0 + k, D::dk(c_d.xpowq[1][k]));
+      fq xa, xb;                                      // v x^3, v x^4: the folds of v ay by in the two-level F_q^6 products
+      from_limbs<ND>(xa, a);
+      from_limbs<ND>(xb, b);
+      fp_mul<ND>(xa, xa, D::dk(c_d.nqr));
+      fp_mul<ND>(xb, xb, D::dk(c_d.nqr));
+      put_fq(S_VXP3_0 + k, xa);
+      put_fq(S_VXP4_0 + k, xb);
     }
     // inputs
     fq Px, Py;
@@ -207,7 +216,7 @@ struct DW {
     D::f3_mul_fq(Qx, Qx, D::dk(c_d.nqrinv));
     D::f3_mul_fq(Qy, Qy, D::dk(c_d.nqrinv2));
     for (int i = 0; i < 3; i++) { put_fq(S_Qx0 + i, Qx.c[i]); put_fq(S_Qy0 + i, Qy.c[i]); put_fq(S_f_x0 + i, i ? zero : one); put_fq(S_f_y0 + i, zero); }
-    put_fq(S_X, Px); put_fq(S_Y, Py); put_fq(S_Z, one);
+    put_fq(S_X, Px); put_fq(S_Y, Py); put_fq(S_Z, one); put_fq(S_ZZ, one); put_fq(S_ZZZ, one);
     fp_neg<ND>(t, one); put_fq(S_nZ, t);
     put_fq(S_W, D::dk(c_d.A));
     put_fq(S_Px, Px); put_fq(S_Py, Py);
@@ -241,15 +250,22 @@ struct DW {
     }
     __builtin_amdgcn_wave_barrier();
   }
-  static __device__ __noinline__ void interpret(const uint64_t *sched) {
-    uint64_t e = sched[0];
+  // (an entry is the same for every lane: readfirstlane tells the compiler, so that the interpreter's branches are scalar
+  // branches and not EXEC-masked regions -- where this compiler's SGPR spills into VGPR lanes go wrong, tools/gpu_faults.md)
+  static PBC_DEV uint64_t uniform64(uint64_t v) {
+    const uint32_t lo = (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) v), hi = (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) (v >> 32));
+    return ((uint64_t) hi << 32) | lo;
+  }
+  static __device__ __noinline__ void interpret(const uint64_t *sched_) {
+    const uint64_t *sched = reinterpret_cast<const uint64_t *>(uniform64(reinterpret_cast<uint64_t>(sched_)));
+    uint64_t e = uniform64(sched[0]);
     for (int k = 1;; k++) {
       const int op = (int) ((e >> 38) & 15u);
 #if PBC_DW_WHATIF & 1
-      if (op != dw::OP_END) { e = sched[k]; continue; }
+      if (op != dw::OP_END) { e = uniform64(sched[k]); continue; }
 #endif
       if (op == dw::OP_END) break;
-      const uint64_t nxt = sched[k];                  // (wave-uniform: a scalar load that completes under this entry's work)
+      const uint64_t nxt = uniform64(sched[k]);       // (a scalar load that completes under this entry's work)
       if (op == dw::OP_LEVEL) {
         const int T = (int) ((e >> 34) & 15u);
         const Lev a = ent_a(e), b = ent_b(e);

@@ -556,13 +556,28 @@ struct DevCtx {
 // its own fast pass wrote (the stream runs each call's kernels back to back).  Recursive: a call may ask twice.
 struct WsEnt { int dev; hipStream_t st; void *p; size_t cap; uint64_t used; int pins; std::recursive_mutex issue; };
 constexpr size_t kMaxWs = 8;
+// Small device buffers that belong to the object and a device, kept until the object is cleared: the schedule of the type d
+// wave kernel (read-only, shared by every launch), the wire-format staging area of the limb-image host calls.  Plain
+// hipMalloc: the stream-ordered allocator (hipMallocAsync) is NOT used on paths the glue reaches -- under the system HIP
+// runtime (a process without torch's bundled one) launches that worked on hipMallocAsync memory faulted or, called from a
+// fresh thread per chunk, returned wrong results after a few calls (round 6; the same calls passed under torch's runtime).
+struct ScratchEnt { int dev; const void *key; void *p; size_t cap; };
 struct HostCtx {
+  std::vector<ScratchEnt> scratch;
   DevCtx dc[kMaxDev];
   int n = 0;
   std::vector<std::unique_ptr<WsEnt>> ws;      // (stable addresses: a launch holds its entry while the table changes)
   uint64_t ws_clock = 0;
   std::mutex mu;                               // guards the tables (the per-device entries are used by one worker each)
 };
+static void scratch_free_all(HostCtx *H) {
+  for (ScratchEnt &x : H->scratch) {
+    DeviceGuard guard(x.dev);
+    (void) hipDeviceSynchronize();
+    if (x.p) (void) hipFree(x.p);
+  }
+  H->scratch.clear();
+}
 static void devctx_free_buffers(DevCtx &c) {   // the calling thread's current device is c.dev
   for (int i = 0; i < kSlots; i++) {
     if (c.st[i]) (void) hipStreamSynchronize(c.st[i]);
@@ -598,6 +613,7 @@ static void hostctx_free(pbc_hip_pairing_s *P) {
     (void) hipDeviceSynchronize();
     (void) hipFree(w->p);
   }
+  scratch_free_all(H);
   for (int i = 0; i < H->n; i++) devctx_release(H->dc[i]);
   delete H;
   P->host_ctx = nullptr;
@@ -662,6 +678,25 @@ void workspace_unpin(pbc_hip_pairing_s *P, hipStream_t s) {
   }
   if (e) e->issue.unlock();                // (the calling thread is the one that locked it: ProdWs is scoped to one call)
 }
+// at least `bytes` of device memory for (current device, key); *fresh = the buffer was (re)allocated: its old contents are gone
+void *object_scratch(pbc_hip_pairing_s *P, const void *key, size_t bytes, bool *fresh) {
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess) { fail("no current HIP device"); return nullptr; }
+  if (!P->host_ctx) P->host_ctx = new HostCtx();
+  HostCtx *H = static_cast<HostCtx *>(P->host_ctx);
+  std::lock_guard<std::mutex> lk(H->mu);
+  ScratchEnt *e = nullptr;
+  for (ScratchEnt &x : H->scratch) if (x.dev == dev && x.key == key) e = &x;
+  if (!e) { H->scratch.push_back(ScratchEnt{dev, key, nullptr, 0}); e = &H->scratch.back(); }
+  if (fresh) *fresh = false;
+  if (e->cap < bytes) {
+    if (e->p) { (void) hipDeviceSynchronize(); (void) hipFree(e->p); e->p = nullptr; e->cap = 0; }
+    if (hipMalloc(&e->p, bytes) != hipSuccess) { e->p = nullptr; fail("device allocation of %zu bytes failed", bytes); return nullptr; }
+    e->cap = bytes;
+    if (fresh) *fresh = true;
+  }
+  return e->p;
+}
 void *own_workspace(const OwnWs &o, hipStream_t s, size_t bytes) {
   if (*o.cap < bytes) {
     if (*o.p) { (void) hipStreamSynchronize(s); (void) hipFree(*o.p); *o.p = nullptr; *o.cap = 0; }
@@ -681,6 +716,7 @@ extern "C" int pbc_hip_pairing_release_workspaces(pbc_hip_pairing_t *P) {
     if (w->p) (void) hipFree(w->p);
   }
   H->ws.clear();
+  scratch_free_all(H);
   for (int i = 0; i < H->n; i++)        // the chunk buffers and workspaces of the host-buffer path as well (the streams stay)
     if (H->dc[i].dev >= 0) {
       DeviceGuard guard(H->dc[i].dev);
@@ -925,16 +961,24 @@ static int raw_convert(pbc_hip_pairing_s *P, bool to_wire, void *dst, const void
   return 0;
 }
 // limb images in device memory -> the wire-format kernels -> limb images, all on stream s (stream-ordered temporaries)
-static int launch_prod_raw(pbc_hip_pairing_s *P, void *d_gt, const void *d_g1, const void *d_g2, size_t n, int k, hipStream_t s, bool upload, const OwnWs *own) {
+// (host calls -- one at a time per object -- stage the wire records in a buffer the object keeps per device and slot of the
+// chunk ring; the _dev form, which may be in flight on several streams, takes a stream-ordered temporary)
+static int launch_prod_raw(pbc_hip_pairing_s *P, void *d_gt, const void *d_g1, const void *d_g2, size_t n, int k, hipStream_t s, bool upload, const OwnWs *own,
+                           const void *host_key = nullptr) {
   if (!n) return 0;
   if (upload && ensure_derived(P, s)) return 1;
   const size_t fb = (size_t) P->len_fq, lv1 = P->len1 / fb, lv2 = P->len2 / fb, lvt = P->lenT / fb, terms = n * (size_t) k;
   uint8_t *tmp = nullptr;
   const size_t b1 = (terms * P->len1 + 15) & ~(size_t) 15, b2 = (terms * P->len2 + 15) & ~(size_t) 15, bt = n * (size_t) P->lenT;
-  HIP_TRY(hipMallocAsync((void **) &tmp, b1 + b2 + bt, s));
+  if (host_key) {
+    tmp = (uint8_t *) object_scratch(P, host_key, b1 + b2 + bt, nullptr);
+    if (!tmp) return 1;
+  } else {
+    HIP_TRY(hipMallocAsync((void **) &tmp, b1 + b2 + bt, s));
+  }
   int rc = raw_convert(P, true, tmp, d_g1, terms * lv1, s) || raw_convert(P, true, tmp + b1, d_g2, terms * lv2, s) ||
            launch_prod(P, tmp + b1 + b2, tmp, tmp + b1, n, k, s, false, own) || raw_convert(P, false, d_gt, tmp + b1 + b2, n * lvt, s);
-  (void) hipFreeAsync(tmp, s);
+  if (!host_key) (void) hipFreeAsync(tmp, s);
   return rc;
 }
 extern "C" int pbc_hip_element_prod_pairing_batch_limbs(pbc_hip_pairing_t *P, uint8_t *gt, const uint8_t *g1, const uint8_t *g2, size_t n, int k) {
@@ -946,7 +990,8 @@ extern "C" int pbc_hip_element_prod_pairing_batch_limbs(pbc_hip_pairing_t *P, ui
   const size_t fb = (size_t) P->len_fq, w = 8 * (size_t) P->raw_t;
   return run_host_generic(P, gt, P->lenT / fb * w, g1, (size_t) k * (P->len1 / fb) * w, g2, (size_t) k * (P->len2 / fb) * w, n,
                           [P, k](void *d_gt, const void *d_g1, const void *d_g2, size_t m, hipStream_t s, const OwnWs *own) {
-                            return launch_prod_raw(P, d_gt, d_g1, d_g2, m, k, s, false, own);
+                            // (one staging buffer per slot of a device context's chunk ring: keyed by the slot's workspace cell)
+                            return launch_prod_raw(P, d_gt, d_g1, d_g2, m, k, s, false, own, own ? (const void *) own->p : (const void *) P);
                           }, false);     // (staged: the images travel H2D / D2H in chunks; the conversion kernels are not run on mapped host memory)
 }
 extern "C" int pbc_hip_element_pairing_batch_limbs(pbc_hip_pairing_t *P, uint8_t *gt, const uint8_t *g1, const uint8_t *g2, size_t n) {

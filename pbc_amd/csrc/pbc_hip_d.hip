@@ -121,13 +121,14 @@ int launch_d(pbc_hip_pairing_s *P, void *d_gt, const void *d_g1, const void *d_g
   unsigned grid = (unsigned) ((n + kBlock - 1) / kBlock);
   if (k == 1 && P->type == 'd' && P->nlimb == 5 && P->deg == 3 && n <= P->d_wave_max) {
     // a batch this small runs at the latency of ONE lane on the throughput kernel (3.9 ms): a wavefront per pairing instead
-    // (the schedule travels with every launch: 12 KB on the launch's stream -- objects may be used on several devices and streams)
+    // (the schedule: 10 KB, read-only, one copy per device the object runs on -- uploaded on first use, kept with the object)
     const std::vector<uint64_t> &S = dw_schedule(P);
-    uint64_t *d_sched = nullptr;
-    HIP_TRY(hipMallocAsync((void **) &d_sched, S.size() * sizeof(uint64_t), s));
-    HIP_TRY(hipMemcpyAsync(d_sched, S.data(), S.size() * sizeof(uint64_t), hipMemcpyHostToDevice, s));
+    static const char kSchedKey = 0;
+    bool fresh = false;
+    uint64_t *d_sched = (uint64_t *) object_scratch(P, &kSchedKey, S.size() * sizeof(uint64_t), &fresh);
+    if (!d_sched) return 1;
+    if (fresh) HIP_TRY(hipMemcpy(d_sched, S.data(), S.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
     hipLaunchKernelGGL(dw_pairing_kernel<5>, dim3((unsigned) n), dim3(64), 0, s, (uint8_t *) d_gt, (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, (const uint64_t *) d_sched, kargs<5>(P));
-    (void) hipFreeAsync(d_sched, s);
   } else if (k == 1) {
     PBC_DISPATCH_D(P, hipLaunchKernelGGL((d_prod_pairing_kernel<N, DEG>), dim3(kDResident<N, DEG> ? PBC_RGRID(d_prod_pairing_kernel<N, DEG>) : grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
                                                 (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, 1, (uint32_t *) nullptr, kDResident<N, DEG> ? unit_counter(P, s) : nullptr, kargs<N>(P)));

@@ -51,8 +51,8 @@ class Slots:
 
 
 class Node:
-    def __init__(self, terms, out):
-        self.terms, self.out, self.level, self.lane, self.slot = terms, out, 0, 0, None
+    def __init__(self, terms, out, floor=1):
+        self.terms, self.out, self.level, self.lane, self.slot, self.floor = terms, out, 0, 0, None, floor
 
 
 class Prog:
@@ -62,9 +62,9 @@ class Prog:
     def __init__(self, name, slots, region):
         self.name, self.slots, self.region, self.nodes = name, slots, region, []
 
-    def sop(self, terms, out=None):
+    def sop(self, terms, out=None, floor=1):
         assert 1 <= len(terms) <= TMAX, (self.name, len(terms))
-        n = Node(list(terms), out)
+        n = Node(list(terms), out, floor)
         self.nodes.append(n)
         return n
 
@@ -85,7 +85,7 @@ class Prog:
             if n.out is not None:
                 assert n.out not in writers, (self.name, n.out)
                 writers[n.out] = n
-        floor = {n: 1 for n in self.nodes}
+        floor = {n: n.floor for n in self.nodes}
         for _ in range(64):
             for n in self.nodes:
                 n.level = max([floor[n]] + [1 + op.level for t in n.terms for op in t if isinstance(op, Node)])
@@ -185,22 +185,38 @@ def f3_scale(p, A, c):
     return [p.mul(a, c) for a in A]
 
 
+def poly_coeff(A, B, k):
+    return f3_mul_terms(A, B, k)
+
+
 def f6_mul(p, a, b, outs=None):
-    """(ax + ay s)(bx + by s) = (ax bx + (v ay) by) + (ay bx + ax by) s, s^2 = v  (f6l_mul)"""
+    """(ax + ay s)(bx + by s) = (ax bx + v ay by) + (ay bx + ax by) s, s^2 = v, in TWO levels: first the five coefficients
+    E_k of the plain product ay by and the high coefficients of ax bx and of ay bx + ax by; then every output one sum of at
+    most eight terms -- v E_k, and E_3, E_4 through the table constants v x^3, v x^4 (VXP3, VXP4)"""
     ax, ay = a
     bx, by = b
-    vay = f3_scale(p, ay, "V")
-    ox = f3_mul2(p, ax, bx, vay, by, outs[0] if outs else (None,) * 3)
-    oy = f3_mul2(p, ay, bx, ax, by, outs[1] if outs else (None,) * 3)
+    E = [p.sop(poly_coeff(ay, by, k)) for k in range(5)]
+    Hx = [p.sop(poly_coeff(ax, bx, k)) for k in (3, 4)]
+    Hy = [p.sop(poly_coeff(ay, bx, k) + poly_coeff(ax, by, k)) for k in (3, 4)]
+    ox, oy = [], []
+    for k in range(3):
+        ox.append(p.sop(poly_coeff(ax, bx, k) + [(Hx[0], "XP3_%d" % k), (Hx[1], "XP4_%d" % k), (E[k], "V"), (E[3], "VXP3_%d" % k), (E[4], "VXP4_%d" % k)],
+                        outs[0][k] if outs else None))
+        oy.append(p.sop(poly_coeff(ay, bx, k) + poly_coeff(ax, by, k) + [(Hy[0], "XP3_%d" % k), (Hy[1], "XP4_%d" % k)], outs[1][k] if outs else None))
     return ox, oy
 
 
 def f6_sqr(p, a, outs=None):
-    """(ax^2 + v ay^2) + 2 ax ay s  (f6l_sqr); the doubled cross terms as repeated terms"""
+    """(ax^2 + v ay^2) + 2 ax ay s in two levels (the doubled cross terms as repeated terms)"""
     ax, ay = a
-    vay = f3_scale(p, ay, "V")
-    ox = f3_mul2(p, ax, ax, vay, ay, outs[0] if outs else (None,) * 3)
-    oy = f3_mul2(p, ax, ay, ax, ay, outs[1] if outs else (None,) * 3)       # ax ay + ax ay = 2 ax ay
+    E = [p.sop(poly_coeff(ay, ay, k)) for k in range(5)]
+    Hx = [p.sop(poly_coeff(ax, ax, k)) for k in (3, 4)]
+    Hy = [p.sop(poly_coeff(ax, ay, k) + poly_coeff(ax, ay, k)) for k in (3, 4)]
+    ox, oy = [], []
+    for k in range(3):
+        ox.append(p.sop(poly_coeff(ax, ax, k) + [(Hx[0], "XP3_%d" % k), (Hx[1], "XP4_%d" % k), (E[k], "V"), (E[3], "VXP3_%d" % k), (E[4], "VXP4_%d" % k)],
+                        outs[0][k] if outs else None))
+        oy.append(p.sop(poly_coeff(ax, ay, k) + poly_coeff(ax, ay, k) + [(Hy[0], "XP3_%d" % k), (Hy[1], "XP4_%d" % k)], outs[1][k] if outs else None))
     return ox, oy
 
 
@@ -218,71 +234,94 @@ def line_names(bank):
     return ["L%d.a" % bank, "L%d.b" % bank, "L%d.c" % bank]
 
 
+def value_names(bank):
+    """the line's VALUE at Q, l = (a' Qx + c') + (b' Qy) s: six F_q slots"""
+    return [["V%d.x%d" % (bank, i) for i in range(3)], ["V%d.y%d" % (bank, i) for i in range(3)]]
+
+
+def eval_previous_line(p, bank):
+    """d_evalfn_pack for the line whose coefficients the PREVIOUS point program left in the other bank: it rides in the first
+    level of this one (the coefficients are complete, this program's own go to `bank` from its second level on)"""
+    la, lb, lc = line_names(1 - bank)
+    V = value_names(1 - bank)
+    for i in range(3):
+        p.sop([(la, QX[i])] + ([(lc, "ONE")] if i == 0 else []), out=V[0][i])
+        p.sop([(lb, QY[i])], out=V[1][i], floor=2)      # (half of it one level later: an eight-term level deals four lanes to a sum)
+
+
 def prog_point_dbl(slots, bank):
     """V <- 2V and the tangent's coefficients into bank `bank` (d_dbl_core, scaled by -1); state X, Y, Z, nZ = -Z,
-    W = a Z^4 (modified Jacobian coordinates: four levels instead of five):
+    W = a Z^4 (modified Jacobian coordinates: four levels instead of five), and Z^2, Z^3 of the NEW point for a chord step:
          M = 3X^2 + W;  a' = M Z^2, b' = -(2YZ) Z^2, c' = 2Y^2 - M X;  X3 = M^2 - 8XY^2, Y3 = M (4XY^2 - X3) - 8Y^4,
          Z3 = 2YZ, W3 = 16 Y^4 W"""
     p = Prog("pt_dbl%d" % bank, slots, "pt")
     la, lb, lc = line_names(bank)
     X, Y, Z, nZ, W = "X", "Y", "Z", "nZ", "W"
+    eval_previous_line(p, bank)
     XX = p.mul(X, X)
     YY = p.mul(Y, Y)
     ZZ = p.mul(Z, Z)
-    p.sop([(Y, Z), (Y, Z)], out="Z")
+    Z3 = p.sop([(Y, Z), (Y, Z)], out="Z")
     nZ3 = p.sop([(Y, nZ), (Y, nZ)], out="nZ")
     W16 = p.mul(W, "SIXTEEN")
     M = p.sop([(XX, "THREE"), (W, "ONE")])
     S1 = p.mul(X, YY)
     Y4 = p.mul(YY, YY)
     p.mul(nZ3, ZZ, out=lb)
+    ZZn = p.mul(Z3, Z3, out="ZZ")
     X3 = p.sop([(M, M), (S1, "M8")], out="X")
     p.mul(M, ZZ, out=la)
     MX = p.mul(M, X)
     nM = p.mul(M, "M1")
     S4 = p.mul(S1, "FOUR")
     p.mul(Y4, W16, out="W")
+    p.mul(ZZn, Z3, out="ZZZ")
     p.sop([(M, S4), (nM, X3), (Y4, "M8")], out="Y")
     p.sop([(YY, "TWO"), (MX, "M1")], out=lc)
     return p.finish()
 
 
 def prog_point_add(slots, bank, neg):
-    """V <- V +- P and the chord's coefficients (d_add_core, scaled by -1): with Py' = +-Py
+    """V <- V +- P and the chord's coefficients (d_add_core, scaled by -1), five levels on Z^2, Z^3 from the doubling before it:
          H = Px Z^2 - X, R = Py' Z^3 - Y;  a' = R, b' = -Z3, c' = Z3 Py' - R Px,  Z3 = Z H;  then W = a Z3^4"""
     p = Prog("pt_add%s%d" % ("m" if neg else "p", bank), slots, "pt")
     la, lb, lc = line_names(bank)
     X, Y, Z, nZ = "X", "Y", "Z", "nZ"
     Py = "nPy" if neg else "Py"
-    ZZ = p.mul(Z, Z)
-    ZZZ = p.mul(ZZ, Z)
-    H = p.sop([("Px", ZZ), (X, "M1")])
-    R = p.sop([(Py, ZZZ), (Y, "M1")], out=la)
+    eval_previous_line(p, bank)
+    H = p.sop([("Px", "ZZ"), (X, "M1")])
+    R = p.sop([(Py, "ZZZ"), (Y, "M1")])
+    nY = p.mul(Y, "M1")
     Z3 = p.mul(Z, H, out="Z")
     nZ3 = p.mul(nZ, H, out="nZ")
     HH = p.mul(H, H)
     nR = p.mul(R, "M1")
+    p.lin([(R, "ONE")], out=la)
     p.sop([(Z3, Py), (nR, "Px")], out=lc)
     p.lin([(nZ3, "ONE")], out=lb)
     HHH = p.mul(HH, H)
     XHH = p.mul(X, HH)
+    ZZ3 = p.mul(Z3, Z3)
     X3 = p.sop([(R, R), (HHH, "M1"), (XHH, "M2")], out="X")
     RX = p.mul(R, XHH)
-    nY = p.mul(Y, "M1")
-    p.sop([(RX, "ONE"), (nR, X3), (nY, HHH)], out="Y")
-    ZZ3 = p.mul(Z3, Z3)
+    nYH = p.mul(nY, HHH)
     Z43 = p.mul(ZZ3, ZZ3)
+    p.sop([(RX, "ONE"), (nR, X3), (nYH, "ONE")], out="Y")
     p.mul(Z43, "A", out="W")
     return p.finish()
 
 
+def prog_point_eval(slots, bank):
+    """the value of the LAST line (no point program follows it); `bank`: the bank a following program would have used"""
+    p = Prog("pt_eval%d" % bank, slots, "pt")
+    eval_previous_line(p, bank)
+    return p.finish()
+
+
 def prog_f_mul_line(slots, bank):
-    """f <- f * l with l = (a' Qx + c') + (b' Qy) s evaluated in the program's first level (d_evalfn_pack)"""
+    """f <- f * l, l's value in bank `bank`"""
     p = Prog("f_mul%d" % bank, slots, "ft")
-    la, lb, lc = line_names(bank)
-    ex = [p.sop([(la, QX[i])] + ([(lc, "ONE")] if i == 0 else [])) for i in range(3)]
-    ey = [p.mul(lb, QY[i]) for i in range(3)]
-    f6_mul(p, F, (ex, ey), outs=F)
+    f6_mul(p, F, value_names(bank), outs=F)
     return p.finish()
 
 
@@ -376,8 +415,10 @@ def prog_fe4(slots):
 
 SLOTS = Slots()
 CONSTS = ["ZERO", "ONE", "M1", "TWO", "M2", "THREE", "FOUR", "M8", "SIXTEEN", "HALF", "QVI", "A", "V"] + \
-         ["XP3_%d" % k for k in range(3)] + ["XP4_%d" % k for k in range(3)] + ["XQ1_%d" % k for k in range(3)] + ["XQ2_%d" % k for k in range(3)]
-STATE = ["X", "Y", "Z", "nZ", "W", "Px", "Py", "nPy"] + QX + QY + F[0] + F[1] + line_names(0) + line_names(1) + ["ninv"]
+         ["XP3_%d" % k for k in range(3)] + ["XP4_%d" % k for k in range(3)] + ["XQ1_%d" % k for k in range(3)] + ["XQ2_%d" % k for k in range(3)] + \
+         ["VXP3_%d" % k for k in range(3)] + ["VXP4_%d" % k for k in range(3)]
+STATE = ["X", "Y", "Z", "nZ", "W", "ZZ", "ZZZ", "Px", "Py", "nPy"] + QX + QY + F[0] + F[1] + line_names(0) + line_names(1) + \
+        sum(value_names(0), []) + sum(value_names(1), []) + ["ninv"]
 
 
 def build():
@@ -387,7 +428,8 @@ def build():
         names3(pre)
     progs = []
     for bank in (0, 1):
-        progs += [prog_point_dbl(SLOTS, bank), prog_point_add(SLOTS, bank, False), prog_point_add(SLOTS, bank, True), prog_f_mul_line(SLOTS, bank)]
+        progs += [prog_point_dbl(SLOTS, bank), prog_point_add(SLOTS, bank, False), prog_point_add(SLOTS, bank, True), prog_point_eval(SLOTS, bank),
+                  prog_f_mul_line(SLOTS, bank)]
     progs += [prog_f_sqr(SLOTS), prog_fe1(SLOTS), prog_fe2(SLOTS), prog_fe3(SLOTS), prog_lucas(SLOTS, 0), prog_lucas(SLOTS, 1), prog_fe4(SLOTS)]
     return {p.name: p for p in progs}
 
@@ -439,6 +481,7 @@ class Model:
         e.update(ZERO=0, ONE=1, M1=q - 1, TWO=2, M2=q - 2, THREE=3, FOUR=4, M8=q - 8, SIXTEEN=16, HALF=inv(2), QVI=inv(4 * v % q), A=P["a"], V=v)
         for k in range(3):
             e["XP3_%d" % k], e["XP4_%d" % k], e["XQ1_%d" % k], e["XQ2_%d" % k] = xp3[k], xp4[k], xq[k], xq2[k]
+            e["VXP3_%d" % k], e["VXP4_%d" % k] = v * xp3[k] % q, v * xp4[k] % q
         self.vinv, self.v = inv(v), v
         self.plus, self.minus, self.rbits = naf_digits(P["r"])
         self.phik = (q * q - q + 1) // P["r"]
@@ -474,6 +517,9 @@ class Model:
                     writes.append((n.slot, acc % self.q))
         names_written = [w[0] for w in writes]
         assert len(set(names_written)) == len(names_written), names_written
+        # an eight-term level deals FOUR lanes to a sum (pairing_dw.cuh exec_split8): sixteen sums in all, both tracks together
+        if any(len(n.terms) > 4 for tr in tracks for p, lev in tr for n in p.levels[lev]):
+            assert sum(len(p.levels[lev]) for tr in tracks for p, lev in tr) <= 16, [(p.name, lev) for tr in tracks for p, lev in tr]
         for s, v in writes:
             self.env[s] = v
         self.stats["levels"] += 1
@@ -502,7 +548,7 @@ class Model:
         ok = ok and x3 == self.f3_mul_int(Qy, Qy)
         if not ok:
             return None
-        e.update(X=Px, Y=Py, Z=1, nZ=q - 1, W=a % q, Px=Px, Py=Py, nPy=(q - Py) % q)
+        e.update(X=Px, Y=Py, Z=1, nZ=q - 1, W=a % q, ZZ=1, ZZZ=1, Px=Px, Py=Py, nPy=(q - Py) % q)
         for i in range(3):
             e[QX[i]], e[QY[i]] = Qx[i] * self.vinv % q, Qy[i] * self.vinv * self.vinv % q
             e[F[0][i]], e[F[1][i]] = (1 if i == 0 else 0), 0
@@ -528,39 +574,46 @@ class Model:
 
         def pt_name(s, bank):
             return "pt_dbl%d" % bank if s[0] == "dbl" else "pt_add%s%d" % ("m" if s[1] else "p", bank)
-        # Two tracks advance one level per VM level (lanes 0-31: the accumulator track, 32-63: the point track):
-        #   * line i goes to bank i % 2; the accumulator's product with line i starts when point program i is complete;
-        #   * point program j starts when the product with line j - 2 (same bank) has started: that product reads the bank
-        #     in its FIRST level only, the point program writes it from its second level on.
-        # The kernel's driver (pairing_dw.cuh dw_miller) is this loop.
-        fi = pi = 0                                  # next program of each track
-        fprog = pprog = None                         # running program and its next level
+        # Two tracks advance one level per VM level (the accumulator track on the first lanes, the point track on the last):
+        #   * point program j leaves the COEFFICIENTS of line j in bank j % 2 and, in its first level, evaluates line j - 1
+        #     (the other coefficient bank) into value bank (j - 1) % 2; after the last one a one-level program evaluates the last line;
+        #   * the accumulator's product with line i (two levels, both read value bank i % 2) starts when that value is there:
+        #     point program i + 1 has run its first TWO levels;
+        #   * point program j starts when the product with line j - 3 is COMPLETE (its first levels overwrite that value bank).
+        # dw_sched.h (the host) is this loop.
+        P = pt + [("eval",)]
+        fi = pi = 0
+        fprog = pprog = None
         flev = plev = 0
-        pdone = 0                                    # point programs completed
-        mul_started = 0                              # products with a line started so far
+        line_ready = 0                               # lines whose value is complete
+        fmul_done = 0                                # products with a line completed
+        f_is_mul = False
         while fi < len(fs) or fprog is not None:
             if fprog is None:
                 if fs[fi][0] == "sqr":
-                    fprog, flev = self.progs["f_sqr"], 0
+                    fprog, flev, f_is_mul = self.progs["f_sqr"], 0, False
                     fi += 1
-                elif fs[fi][1] < pdone:
-                    fprog, flev = self.progs["f_mul%d" % (fs[fi][1] % 2)], 0
-                    mul_started = fs[fi][1] + 1
+                elif fs[fi][1] < line_ready:
+                    fprog, flev, f_is_mul = self.progs["f_mul%d" % (fs[fi][1] % 2)], 0, True
                     fi += 1
-            if pprog is None and pi < len(pt) and (pi < 2 or mul_started > pi - 2):
-                pprog, plev = self.progs[pt_name(pt[pi], pi % 2)], 0
+            if pprog is None and pi < len(P) and (pi < 3 or fmul_done >= pi - 2):
+                pprog, plev = self.progs["pt_eval%d" % (pi % 2) if P[pi][0] == "eval" else pt_name(P[pi], pi % 2)], 0
                 pi += 1
             assert fprog is not None or pprog is not None
             self.run_level([(fprog, flev)] if fprog else [], [(pprog, plev)] if pprog else [])
             if fprog is not None:
                 flev += 1
                 if flev == len(fprog.levels):
+                    fmul_done += 1 if f_is_mul else 0
                     fprog = None
             if pprog is not None:
                 plev += 1
+                if plev == 2 and pi >= 2:
+                    line_ready = pi - 1
                 if plev == len(pprog.levels):
                     pprog = None
-                    pdone += 1
+        assert pi == len(P) and pprog is None
+        pt = P
         assert pi == len(pt) and pprog is None
         return self.final_exp()
 
@@ -644,7 +697,7 @@ def emit(progs):
            "// (terms a sum does not have name the ZERO slot); a LEVEL is (first row, terms per sum, working lanes).",
            "#pragma once", "#include <stdint.h>", "namespace pbc { namespace dw {",
            "constexpr int kSlots = %d;" % len(SLOTS.order)]
-    keep = lambda n: "." not in n or n.split(".")[0] in ("f", "L0", "L1")
+    keep = lambda n: "." not in n or n.split(".")[0] in ("f", "L0", "L1", "V0", "V1")
     out.append("enum Slot : int { " + ", ".join("S_%s = %d" % (n.replace(".", "_"), i) for i, n in enumerate(SLOTS.order) if keep(n)) + " };")
     rows, index = [], []
     z = SLOTS["ZERO"]
@@ -673,11 +726,6 @@ def main():
     bad, levels = check(progs)
     for name in sorted(progs):
         p = progs[name]
-        # eight-term levels run four lanes per sum (pairing_dw.cuh exec_split8): ten sums on the accumulator track's lanes,
-        # six on the point track's
-        for row in p.levels:
-            if max(len(n.terms) for n in row) > 4:
-                assert len(row) <= (6 if name.startswith("pt_") else 10), (name, len(row))
         print("%-10s levels %2d  sums %3d  widest level %2d lanes  terms per level %s" % (name, len(p.levels), len(p.nodes), max(len(r) for r in p.levels),
               [max(len(n.terms) for n in r) for r in p.levels]))
     print("slots %d; levels executed per pairing %d; vectors: %s" % (len(SLOTS.order), levels, "MISMATCH" if bad else "ok"))

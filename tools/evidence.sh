@@ -18,6 +18,7 @@ done
 [ -n "$SKIP_SWEEP" ] || for w in a f; do timeout 300 python bench.py --workload $w --sweep > $O/sweep_$w.json 2> $O/sweep_$w.err; done
 [ -n "$SKIP_SMALL" ] || { timeout 300 python tools/wave_latency.py 1 256 512 1024 2048 4096 5120 > $O/wave_latency.txt 2>&1
   timeout 200 python tools/tail_latency.py > $O/tail.txt 2>&1
+  timeout 200 python tools/dwave_latency.py 1 16 256 1024 2048 3072 4096 8192 > $O/dwave_latency.txt 2>&1
   export PBC_HIP_LIB=$R/pbc_amd/libpbc_hip.so
   [ -n "$SKIP_GLUE" ] || for p in a d159; do timeout 120 oracle/_ref/glue_test pbc_amd/param/$p.param 200 latency 2>&1 | tail -n 1; timeout 200 oracle/_ref/glue_test pbc_amd/param/$p.param 1048576 bench 2>&1 | tail -n 1; done > $O/glue.txt
   unset PBC_HIP_LIB; }

@@ -41,6 +41,7 @@ for f in sorted(glob.glob(EV + "/sweep_*.json")):
         put(f, "profiles/%s_" % RND + os.path.basename(f))
 for src, dst, what in (("wave_latency.txt", "profiles/%s_closing_wave_latency.txt" % RND, "python tools/wave_latency.py 1 256 512 1024 2048 4096 5120"),
                        ("tail.txt", "profiles/%s_closing_tail.txt" % RND, "python tools/tail_latency.py"),
+                       ("dwave_latency.txt", "profiles/%s_dwave_latency.txt" % RND, "python tools/dwave_latency.py 1 16 256 1024 2048 3072 4096 8192"),
                        ("glue.txt", "profiles/%s_closing_glue.txt" % RND, "oracle/_ref/glue_test {a,d159}.param {200 latency, 1048576 bench}")):
     if os.path.exists(EV + "/" + src) and os.path.getsize(EV + "/" + src):
         with open(dst, "w") as fh:

@@ -21,7 +21,11 @@
  * for the lanes it flagged --, the term records of the products) lives in a workspace keyed by (device, stream) whose
  * issue lock the call holds while it enqueues its kernels, so the calls of two threads on one stream are enqueued one
  * after the other, never interleaved (round 6; tests/test_gpu_group2.py::test_two_threads_issue_on_one_stream).  The
- * per-launch unit counters ("hip_dynamic 1") are slots of a ring, one per launch.
+ * per-launch unit counters ("hip_dynamic 1") are slots of a ring, one per launch.  Device memory: every host-buffer form
+ * works on buffers the object keeps (hipMalloc; pbc_hip_pairing_release_workspaces / pbc_hip_pairing_clear free them); only
+ * the _dev forms of element_pow2/3_zn and of the limb-image calls take a stream-ordered temporary (hipMallocAsync on the
+ * caller's stream) -- observed to misbehave under the system HIP runtime when called from short-lived threads (round 6), so
+ * nothing the reference-side glue reaches uses it.
  *
  * Input classes (every one is covered by a GPU test, tests/test_gpu_parity.py):
  *   - Points of the whole curve.  curve_from_bytes (ecc/curve.c:609-623) checks the curve equation only, so a G1 / G2

@@ -140,7 +140,8 @@ static size_t group_len(const pbc_hip_pairing_s *P, int group) { return (size_t)
 // single-base ladders save more by running in limb form / on the trace / in the cyclotomic subgroup.
 // "hip_group_slow 1": the joint ladders -- ec_multi_mul_fast_kernel + ec_multi_mul_kernel for the lanes it reports, and
 // gt_multi_pow_kernel -- which are also the independent route the tests compare the default with.
-static int multi_launch(pbc_hip_pairing_s *P, int group, int k, void *d_out, const MultiArgs &M, size_t n, hipStream_t s, const OwnWs *own) {
+static int multi_launch(pbc_hip_pairing_s *P, int group, int k, void *d_out, const MultiArgs &M, size_t n, hipStream_t s, const OwnWs *own,
+                        void *tmp_given = nullptr) {      // tmp_given: 2 n lp bytes the caller owns (host forms: no stream-ordered allocation)
   if (!n) return 0;
   const unsigned grid = (unsigned) ((n + kBlock - 1) / kBlock);
   uint8_t *o = (uint8_t *) d_out;
@@ -154,8 +155,8 @@ static int multi_launch(pbc_hip_pairing_s *P, int group, int k, void *d_out, con
       const uint8_t *b = M.a[j];
       alias |= b < o + n * lp && o < b + n * lp;
     }
-    void *tmp = nullptr, *acc = d_out;
-    HIP_TRY(hipMallocAsync(&tmp, n * lp * (alias ? 2 : 1), s));
+    void *tmp = tmp_given, *acc = d_out;
+    if (!tmp) HIP_TRY(hipMallocAsync(&tmp, n * lp * (alias ? 2 : 1), s));
     if (alias) acc = (uint8_t *) tmp + n * lp;
     int rc = 0;
     for (int j = 0; j < k && !rc; j++) {
@@ -167,7 +168,7 @@ static int multi_launch(pbc_hip_pairing_s *P, int group, int k, void *d_out, con
                         : pbc_hip_element_add_batch_dev(P, group, acc, acc, tmp, n, s);
     }
     if (!rc && alias && hipMemcpyAsync(d_out, acc, n * lp, hipMemcpyDeviceToDevice, s) != hipSuccess) rc = fail("hipMemcpyAsync");
-    (void) hipFreeAsync(tmp, s);
+    if (!tmp_given) (void) hipFreeAsync(tmp, s);
     return rc;
   }
   if (group == 3) {
@@ -209,6 +210,8 @@ static int multi_host(pbc_hip_pairing_t *P, int group, int k, uint8_t *out, cons
       dz[j] = bz[j].p;
     }
     HIP_TRY(bo.alloc(n * lp));
+    DevBuf btmp;                        // (the temporaries of the composition: owned here -- the stream-ordered allocator is kept
+    HIP_TRY(btmp.alloc(2 * n * lp));    //  off the host forms, pbc_hip.hip "ScratchEnt")
     MultiArgs M;
     for (int j = 0; j < 3; j++) {
       M.a[j] = (const uint8_t *) da[j < k ? j : 0];
@@ -216,7 +219,7 @@ static int multi_host(pbc_hip_pairing_t *P, int group, int k, uint8_t *out, cons
     }
     M.astride = lp;
     M.zstride = lz;
-    if (multi_launch(P, group, k, bo.p, M, n, 0, nullptr)) return 1;
+    if (multi_launch(P, group, k, bo.p, M, n, 0, nullptr, btmp.p)) return 1;
     HIP_TRY(hipStreamSynchronize(0));
     HIP_TRY(hipMemcpy(out, bo.p, n * lp, hipMemcpyDeviceToHost));
     return 0;

@@ -285,11 +285,13 @@ int pbc_hip_finalpow_batch(pbc_hip_pairing_t *p, uint8_t *out, const uint8_t *in
  * curve.c:603-609).  The change of Montgomery radix is one F_q product per coordinate on the device; everything else
  * (off-curve inputs -> O, identity outputs, products) is the wire-format path.  Replaces, for the batch calls of
  * integration/pbc_hip_glue.c, fp_to_bytes / fp_from_bytes on every coordinate. */
-/* Diagnostic (tests): the schedule the one-pairing-per-wavefront type d kernel interprets for this object (csrc/dw_sched.h:
- * which level of which program runs when, flattened by the host from the signed digits of r and the bits of
- * Phi_6(q) / r -- the walk of cc_miller_no_denom_affine, ecc/d_param.c:321-422, and lucas_even, :462-482); returns the
- * number of 64-bit entries (0: the object is not a five-word type d pairing), writes at most cap of them. */
-size_t pbc_hip_diag_dw_schedule(pbc_hip_pairing_t *p, uint64_t *out, size_t cap);
+/* Diagnostic (tests): a schedule the wavefront kernels of type d interpret for this object (csrc/dw_sched.h: which level of
+ * which program runs when, flattened by the host from the signed digits of r and the bits of Phi_6(q) / r -- the walk of
+ * cc_miller_no_denom_affine, ecc/d_param.c:321-422, and lucas_even, :462-482).  which = 0: element_pairing; 1: the Miller
+ * value of one term of element_prod_pairing; 2: the product with a term's value + the final exponentiation; 3:
+ * pairing_pp_apply (d_pairing_pp_apply, :908-966, on the table of pairing_pp_init).  Returns the number of 64-bit entries
+ * (0: the object is not a five-word type d pairing, or which is out of range), writes at most cap of them. */
+size_t pbc_hip_diag_dw_schedule(pbc_hip_pairing_t *p, int which, uint64_t *out, size_t cap);
 int pbc_hip_fq_limb_image_bytes(pbc_hip_pairing_t *p);          /* 8 t (0 on failure) */
 int pbc_hip_element_pairing_batch_limbs(pbc_hip_pairing_t *p, uint8_t *gt, const uint8_t *g1, const uint8_t *g2, size_t n);
 int pbc_hip_element_prod_pairing_batch_limbs(pbc_hip_pairing_t *p, uint8_t *gt, const uint8_t *g1, const uint8_t *g2, size_t n, int k);

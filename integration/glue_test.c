@@ -70,7 +70,45 @@ int main(int argc, char **argv) {
     const double cpu = ((t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec)) / n;
     printf("%s: single element_pairing calls through the hooks: %.3f ms each on the GPU, %.3f ms each on the CPU (%s)\n", argv[1],
            gpu * 1e3, cpu * 1e3, element_cmp(c, o) ? "MISMATCH" : "same value");
-    return element_cmp(c, o) ? 1 : 0;
+    int bad = element_cmp(c, o) ? 1 : 0;
+    /* the same for ONE element_prod_pairing of four terms (a Groth16-style check) and ONE pairing_pp_apply per call */
+    enum { KT = 4 };
+    element_t ps[KT], qs[KT];
+    for (int i = 0; i < KT; i++) { element_init_G1(ps[i], pairing); element_init_G2(qs[i], pairing); element_random(ps[i]); element_random(qs[i]); }
+    const size_t m = n < 50 ? n : 50;
+    double tg[2], tc[2];
+    for (int pass = 0; pass < 2; pass++) {                              /* pass 0: the hooks; pass 1: stock PBC */
+      if (pass == 0 && pbc_hip_attach(pairing, text, len)) { printf("ATTACH FAILED\n"); return 1; }
+      element_ptr r = pass == 0 ? o : c;
+      double *t = pass == 0 ? tg : tc;
+      element_prod_pairing(r, ps, qs, KT);
+      clock_gettime(CLOCK_MONOTONIC, &t0);
+      for (size_t i = 0; i < m; i++) element_prod_pairing(r, ps, qs, KT);
+      clock_gettime(CLOCK_MONOTONIC, &t1);
+      t[0] = ((t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec)) / m;
+      if (pass == 1 && element_cmp(c, o)) { bad = 1; printf("element_prod_pairing MISMATCH\n"); }
+      if (pass == 0) pbc_hip_detach(pairing);
+    }
+    element_t o2, c2;
+    element_init_GT(o2, pairing); element_init_GT(c2, pairing);
+    for (int pass = 0; pass < 2; pass++) {
+      if (pass == 0 && pbc_hip_attach(pairing, text, len)) { printf("ATTACH FAILED\n"); return 1; }
+      element_ptr r = pass == 0 ? o2 : c2;
+      double *t = pass == 0 ? tg : tc;
+      pairing_pp_t pp;
+      pairing_pp_init(pp, p, pairing);
+      pairing_pp_apply(r, q, pp);
+      clock_gettime(CLOCK_MONOTONIC, &t0);
+      for (size_t i = 0; i < m; i++) pairing_pp_apply(r, q, pp);
+      clock_gettime(CLOCK_MONOTONIC, &t1);
+      t[1] = ((t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec)) / m;
+      pairing_pp_clear(pp);
+      if (pass == 0) pbc_hip_detach(pairing);
+    }
+    if (element_cmp(c2, o2)) { bad = 1; printf("pairing_pp_apply MISMATCH\n"); }
+    printf("%s: one element_prod_pairing of %d terms per call: %.3f ms on the GPU, %.3f ms on the CPU; one pairing_pp_apply per call: %.3f ms on the GPU, %.3f ms on the CPU (%s)\n",
+           argv[1], KT, tg[0] * 1e3, tc[0] * 1e3, tg[1] * 1e3, tc[1] * 1e3, bad ? "MISMATCH" : "same values");
+    return bad;
   }
   if (argc > 3 && !strcmp(argv[3], "hash")) {   /* element_from_hash_batch on G1 and G2 vs the CPU */
     int fails = 0;

@@ -304,6 +304,163 @@ struct GAL {
     return handled;
   }
 
+  // ---- element_pow2_zn / element_pow3_zn (field_pow2 / field_pow3 of the curve group, arith/field.c generic_pow2/3) ---------
+  // out = [k_0] P_0 + ... + [k_{KB-1}] P_{KB-1} with ONE accumulator: the ladder above on KB tables -- four doublings and KB
+  // mixed additions per window, where the composition of single-base ladders doubles 4 KB times (per window: 4 x 9 + 11 KB
+  // products instead of KB (4 x 9 + 11)).  Base j's record: a[j] + idx astride, its scalar: z[j] + idx zstride.  Even
+  // scalars run as k + 1 with a conditional subtraction at the end, as above.  Returns false -- nothing written -- when
+  // the lane needs the complete routine: a base off the curve, an exceptional addition anywhere (equal or opposite bases
+  // meet in the accumulator, a point of small order, a zero scalar), or the result O; all of these leave Z = 0.
+  template <int KB>
+  static PBC_DEV bool gmulk_lane(uint8_t *out, const uint8_t *const *in, const uint8_t *const *z, int zlen) {
+    constexpr int NB = 4 * N;
+    el tab[KB][TE][2];                 // per-lane tables of affine odd multiples (private memory)
+    uint32_t kw[KB][KW];
+    bool even[KB];
+    const el one = one_el();
+    jacl V;
+    bool valid = true, bad = false;
+#pragma unroll 1
+    for (int b = 0; b < KB; b++) {
+      el Px, Py, Z2;
+      {
+        fp<N> x, y;
+        fp_load_be<N>(x, in[b]);
+        fp_load_be<N>(y, in[b] + NB);
+        valid &= a_on_curve<N>(x, y);
+        A::to_el(Px, x);
+        A::to_el(Py, y);
+      }
+      // 2P = (X2 : Y2 : Z2); phi(P) = (x Z2^2, y Z2^3) on E', where phi(2P) is affine; phi((2j + 1) P) = phi((2j - 1) P) + phi(2P)
+      V.X = Px;
+      V.Y = Py;
+      A::lds_put(SLOT_Z, one);
+      A::lds_put(SLOT_ZZ, one);
+      ec_dbl(V);
+      const el X2 = V.X, Y2 = V.Y;
+      A::lds_get(Z2, SLOT_Z);
+      {
+        el zz, t;
+        A::lds_get(zz, SLOT_ZZ);
+        A::mul(V.X, Px, zz);
+        A::mul(t, zz, Z2);
+        A::mul(V.Y, Py, t);
+        A::lds_put(SLOT_Z, one);
+        A::lds_put(SLOT_ZZ, one);
+      }
+      tab[b][0][0] = Px;
+      tab[b][0][1] = Py;
+      el zs[TE], cs[TE];               // Z of entry j on E; prefix products of those
+      for (int j = 1; j < TE; j++) {
+        el zj;
+        ec_madd(V, X2, Y2);
+        tab[b][j][0] = V.X;
+        tab[b][j][1] = V.Y;
+        A::lds_get(zj, SLOT_Z);
+        A::mul(zs[j], zj, Z2);         // back on E: Z <- Z' Z2
+        if (j == 1) cs[1] = zs[1];
+        else A::mul(cs[j], cs[j - 1], zs[j]);
+      }
+      bad |= is0(cs[TE - 1]);          // some odd multiple (or 2P) is O: a point of small order
+      el zi;
+      inv(zi, cs[TE - 1]);
+      for (int j = TE - 1; j >= 1; j--) {
+        el zinv, zz, t, X, Y;
+        if (j > 1) {
+          A::mul(zinv, zi, cs[j - 1]);
+          A::mul(zi, zi, zs[j]);
+        } else {
+          zinv = zi;
+        }
+        A::sqr(zz, zinv);
+        X = tab[b][j][0];
+        Y = tab[b][j][1];
+        AL_HS(A::hs_set(X, A::U_ALMOST, 8.0); A::hs_set(Y, A::U_ALMOST, 8.0);)
+        A::mul(tab[b][j][0], X, zz);
+        A::mul(t, zz, zinv);
+        A::mul(tab[b][j][1], Y, t);
+      }
+      // k' = k | 1, with the bit above the scalar's top byte set (the recoding's bit n)
+      load_scalar(kw[b], z[b], zlen);
+      even[b] = (kw[b][0] & 1) == 0;
+      kw[b][0] |= 1u;
+      kw[b][(8 * zlen) >> 5] |= 1u << ((8 * zlen) & 31);
+    }
+    const int t = 2 * zlen;            // digits: 8 zlen bits in windows of four
+    auto entry = [&](el &x, el &y, int b, int i, bool top) {
+      const uint32_t v = scalar_bits(kw[b], 4 * i + 1, 15u);
+      const bool neg = !top && v < 8;  // (the top digit is positive: bit n is set)
+      const int idx = v < 8 ? 7 - (int) v : (int) v - 8;
+      x = tab[b][idx][0];
+      y = tab[b][idx][1];
+      AL_HS(A::hs_set(x, A::U_STRICT, 1.5); A::hs_set(y, A::U_STRICT, 1.5);)
+      el ny;
+      A::negk(ny, y, K2);              // u 2, B 2
+      A::norm(ny, ny);
+      AL_HS(y.hs_u = ny.hs_u; y.hs_B = ny.hs_B;)
+      sel(y, ny, neg);
+    };
+    entry(V.X, V.Y, 0, t - 1, true);
+    A::lds_put(SLOT_Z, one);
+    A::lds_put(SLOT_ZZ, one);
+#pragma unroll 1
+    for (int b = 1; b < KB; b++) {
+      el x2, y2;
+      entry(x2, y2, b, t - 1, true);
+      ec_madd(V, x2, y2);
+    }
+    for (int i = t - 2; i >= 0; i--) {
+      if ((i & 1) == 0) pbc_fair_tick<PBC_A_FAIR_BIT>();
+      for (int d = 0; d < WIN; d++) ec_dbl(V);
+#pragma unroll 1
+      for (int b = 0; b < KB; b++) {
+        el x2, y2;
+        entry(x2, y2, b, i, false);
+        ec_madd(V, x2, y2);
+      }
+    }
+#pragma unroll 1
+    for (int b = 0; b < KB; b++) {
+      // even k_b: the sum so far holds [k_b + 1] P_b; take P_b off
+      el sX = V.X, sY = V.Y, sZ, sZZ, px, ny;
+      A::lds_get(sZ, SLOT_Z);
+      A::lds_get(sZZ, SLOT_ZZ);
+      px = tab[b][0][0];
+      ny = tab[b][0][1];
+      AL_HS(A::hs_set(px, A::U_STRICT, 1.0); A::hs_set(ny, A::U_STRICT, 1.0);)
+      A::negk(ny, ny, K2);
+      A::norm(ny, ny);
+      ec_madd(V, px, ny);
+      sel(sX, V.X, even[b]);
+      sel(sY, V.Y, even[b]);
+      V.X = sX;
+      V.Y = sY;
+      el nz, nzz;
+      A::lds_get(nz, SLOT_Z);
+      A::lds_get(nzz, SLOT_ZZ);
+      sel(sZ, nz, even[b]);
+      sel(sZZ, nzz, even[b]);
+      A::lds_put(SLOT_Z, sZ);
+      A::lds_put(SLOT_ZZ, sZZ);
+    }
+    // to affine
+    el Zf, zinv, zz, t3, ax, ay;
+    A::lds_get(Zf, SLOT_Z);
+    bad |= is0(Zf);
+    if (!valid | bad) return false;
+    inv(zinv, Zf);
+    A::sqr(zz, zinv);
+    A::mul(ax, V.X, zz);
+    A::mul(t3, zz, zinv);
+    A::mul(ay, V.Y, t3);
+    fp<N> x, y;
+    A::to_words(x, ax);
+    A::to_words(y, ay);
+    fp_store_be<N>(out, x);
+    fp_store_be<N>(out + NB, y);
+    return true;
+  }
+
   // ---- element_from_hash (curve_from_hash, ecc/curve.c:455-482) -----------------------------------------------------
   // The routine of group_ops.cuh (g_from_hash_lane: digest expansion, the wave-cooperative search for the first x of the
   // chain with a point above it, the canonical sign) with its two long computations in limb form: the power t^((q+1)/4)

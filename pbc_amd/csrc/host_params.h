@@ -47,6 +47,12 @@ inline int fail(const char *fmt, ...) {
 #define PBC_D_WAVE_MAX 5120
 #endif
 constexpr size_t kProdChunkDefault = (size_t) 1 << 22;   // type a products: terms per launch of the one-term-per-lane kernels unless "hip_prod_chunk N" says otherwise
+// the schedules of the wave-per-pairing type d kernels (dw_sched.h): four of them one after the other
+struct DwSched {
+  std::vector<uint64_t> e;
+  size_t off[4] = {0, 0, 0, 0};     // pairing, Miller value of a term, product + final exponentiation, pairing_pp_apply
+  int lines = 0;                    // lines of a pairing_pp table
+};
 struct pbc_hip_pairing_s {
   int type;
   int device;
@@ -101,7 +107,7 @@ struct pbc_hip_pairing_s {
   int raw_t;                 // ... t = 64-bit limbs of the reference's montfp element (0: constants not derived yet)
   void *counters;            // library only: the unit counters of dynamic resident launches (pbc_hip.hip unit_counter)
   void *host_ctx;            // library only: per-device streams and chunk buffers of the host-buffer path (pbc_hip.hip)
-  std::vector<uint64_t> dw_sched;   // type d, five-word fields: the schedule of one pairing on the wave kernel (pbc_hip_d.hip dw_schedule)
+  DwSched dw_sched;                 // type d, five-word fields: the schedules of the wave kernels (pbc_hip_d.hip dw_schedules, dw_sched.h)
   std::string param_text;    // the parameter text the object was built from (text formats: pbc_hip_param_snprint, host_text.h)
 };
 

@@ -148,14 +148,12 @@ struct DW {
     else if (PBC_DW_SPLIT) exec_split8(R4);
     else exec_T<8>(R);
   }
-  // ---- lane 0: bytes -> slots, curve checks, twist map, constants (d_setup_lane) ----
-  static __device__ __noinline__ bool setup(const uint8_t *g1, const uint8_t *g2) {
+  // ---- lane 0: constants; bytes -> slots, curve checks, twist map (d_setup_lane) ----
+  static __device__ __noinline__ void setup_consts() {
     using namespace dw;
     const FpK<ND> &K = fpk<ND>();
-    const int NB = (int) K.fbytes;
     fq one, t, u;
     fp_set<ND>(one, K.one);
-    // constants
     fq zero;
 #pragma unroll
     for (int k = 0; k < ND; k++) zero.v[k] = 0;
@@ -187,40 +185,45 @@ struct DW {
       put_fq(S_VXP3_0 + k, xa);
       put_fq(S_VXP4_0 + k, xb);
     }
-    // inputs
-    fq Px, Py;
-    f3 Qx, Qy;
+    for (int i = 0; i < 3; i++) { put_fq(S_f_x0 + i, i ? zero : one); put_fq(S_f_y0 + i, zero); }     // f = 1
+  }
+  // the first argument: curve_is_valid_point (curve.c:57-77) on E: y^2 = x^3 + a x + b, then the point track's state
+  static __device__ __noinline__ bool setup_point(const uint8_t *g1) {
+    using namespace dw;
+    const int NB = (int) fpk<ND>().fbytes;
+    fq one, t, Px, Py, t0, t1;
+    fp_set<ND>(one, fpk<ND>().one);
     fp_load_be<ND>(Px, g1);
     fp_load_be<ND>(Py, g1 + NB);
-    D::f3_load_be(Qx, g2);
-    D::f3_load_be(Qy, g2 + 3 * NB);
-    bool valid;
-    {
-      // curve_is_valid_point (curve.c:57-77): E: y^2 = x^3 + a x + b; the twist over F_q^3
-      fq t0, t1;
-      fp_sqr<ND>(t0, Px);
-      fp_add<ND>(t0, t0, D::dk(c_d.A));
-      fp_mul<ND>(t0, t0, Px);
-      fp_add<ND>(t0, t0, D::dk(c_d.B));
-      fp_sqr<ND>(t1, Py);
-      valid = fp_eq<ND>(t0, t1);
-      f3 u0, u1;
-      D::f3_sqr(u0, Qx);
-      fp_add<ND>(u0.c[0], u0.c[0], D::dk(c_d.ta));
-      D::f3_mul(u0, u0, Qx);
-      fp_add<ND>(u0.c[0], u0.c[0], D::dk(c_d.tb));
-      D::f3_sqr(u1, Qy);
-      valid &= D::f3_eq(u0, u1);
-    }
-    // twist map (x, y) -> (v^-1 x, v^-2 y sqrt(v))  (cc_pairing, d_param.c:580-582)
-    D::f3_mul_fq(Qx, Qx, D::dk(c_d.nqrinv));
-    D::f3_mul_fq(Qy, Qy, D::dk(c_d.nqrinv2));
-    for (int i = 0; i < 3; i++) { put_fq(S_Qx0 + i, Qx.c[i]); put_fq(S_Qy0 + i, Qy.c[i]); put_fq(S_f_x0 + i, i ? zero : one); put_fq(S_f_y0 + i, zero); }
+    fp_sqr<ND>(t0, Px);
+    fp_add<ND>(t0, t0, D::dk(c_d.A));
+    fp_mul<ND>(t0, t0, Px);
+    fp_add<ND>(t0, t0, D::dk(c_d.B));
+    fp_sqr<ND>(t1, Py);
     put_fq(S_X, Px); put_fq(S_Y, Py); put_fq(S_Z, one); put_fq(S_ZZ, one); put_fq(S_ZZZ, one);
     fp_neg<ND>(t, one); put_fq(S_nZ, t);
     put_fq(S_W, D::dk(c_d.A));
     put_fq(S_Px, Px); put_fq(S_Py, Py);
     fp_neg<ND>(t, Py); put_fq(S_nPy, t);
+    return fp_eq<ND>(t0, t1);
+  }
+  // the second argument: the check on the twist over F_q^3, then the twist map (x, y) -> (v^-1 x, v^-2 y sqrt(v))
+  // (cc_pairing, d_param.c:580-582)
+  static __device__ __noinline__ bool setup_twist(const uint8_t *g2) {
+    using namespace dw;
+    const int NB = (int) fpk<ND>().fbytes;
+    f3 Qx, Qy, u0, u1;
+    D::f3_load_be(Qx, g2);
+    D::f3_load_be(Qy, g2 + 3 * NB);
+    D::f3_sqr(u0, Qx);
+    fp_add<ND>(u0.c[0], u0.c[0], D::dk(c_d.ta));
+    D::f3_mul(u0, u0, Qx);
+    fp_add<ND>(u0.c[0], u0.c[0], D::dk(c_d.tb));
+    D::f3_sqr(u1, Qy);
+    const bool valid = D::f3_eq(u0, u1);
+    D::f3_mul_fq(Qx, Qx, D::dk(c_d.nqrinv));
+    D::f3_mul_fq(Qy, Qy, D::dk(c_d.nqrinv2));
+    for (int i = 0; i < 3; i++) { put_fq(S_Qx0 + i, Qx.c[i]); put_fq(S_Qy0 + i, Qy.c[i]); }
     return valid;
   }
 
@@ -256,8 +259,41 @@ struct DW {
     const uint32_t lo = (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) v), hi = (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) (v >> 32));
     return ((uint64_t) hi << 32) | lo;
   }
-  static __device__ __noinline__ void interpret(const uint64_t *sched_) {
+  // A line of a pairing_pp table ([steps][3][ND] words, pairing_d.cuh d_pp_init_lane): lanes 0-2 fetch a', b', c' when a level
+  // starts and put them into coefficient bank (line % 2) when it is over -- the fetch hides under the level's multiplications.
+  struct Line { uint32_t w[ND]; };
+  static PBC_DEV Line line_fetch(const uint32_t *tab, int line) {
+    Line r;
+    const uint32_t *p = tab + ((size_t) line * 3 + (threadIdx.x < 3 ? threadIdx.x : 0)) * ND;
+#pragma unroll
+    for (int k = 0; k < ND; k++) r.w[k] = p[k];
+    return r;
+  }
+  static PBC_DEV void line_put(const Line &ln, int line) {
+    if (threadIdx.x < 3) {
+      fq v;
+#pragma unroll
+      for (int k = 0; k < ND; k++) v.v[k] = ln.w[k];
+      put_fq(dw::S_L0_a + 3 * (line & 1) + (int) threadIdx.x, v);
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  static PBC_DEV void run_entry(uint64_t e, const uint32_t *tab) {        // one LEVEL entry
+    const int T = (int) ((e >> 34) & 15u);
+    const Lev a = ent_a(e), b = ent_b(e);
+    const Rows R = T > 4 && PBC_DW_SPLIT ? load_rows4(a, b) : load_rows(a, b);
+    if ((e >> 55) & 1u) {
+      const int line = (int) ((e >> 42) & 4095u);
+      const Line ln = line_fetch(tab, line);
+      exec(R, R, T);
+      line_put(ln, line);
+    } else {
+      exec(R, R, T);
+    }
+  }
+  static __device__ __noinline__ void interpret(const uint64_t *sched_, const uint32_t *tab_ = nullptr) {
     const uint64_t *sched = reinterpret_cast<const uint64_t *>(uniform64(reinterpret_cast<uint64_t>(sched_)));
+    const uint32_t *tab = reinterpret_cast<const uint32_t *>(uniform64(reinterpret_cast<uint64_t>(tab_)));
     uint64_t e = uniform64(sched[0]);
     for (int k = 1;; k++) {
       const int op = (int) ((e >> 38) & 15u);
@@ -266,27 +302,22 @@ struct DW {
 #endif
       if (op == dw::OP_END) break;
       const uint64_t nxt = uniform64(sched[k]);       // (a scalar load that completes under this entry's work)
-      if (op == dw::OP_LEVEL) {
-        const int T = (int) ((e >> 34) & 15u);
-        const Lev a = ent_a(e), b = ent_b(e);
-        const Rows R = T > 4 && PBC_DW_SPLIT ? load_rows4(a, b) : load_rows(a, b);
-        exec(R, R, T);
-      } else if (op == dw::OP_BZERO) bzero_test();
-      else inversion();
+      if (op == dw::OP_LEVEL) run_entry(e, tab);
+      else if (op == dw::OP_BZERO) bzero_test();
+      else if (op == dw::OP_INV) inversion();
+      else { const int line = (int) ((e >> 42) & 4095u); line_put(line_fetch(tab, line), line); }
       e = nxt;
     }
   }
 
-  static __device__ void pairing(uint8_t *gt, const uint8_t *g1, const uint8_t *g2, const uint64_t *sched) {
+  static PBC_DEV void begin() {
     using namespace dw;
     for (int i = (int) threadIdx.x; i < kRows * 5; i += 64) g_lds_dw<ND>[kSlots * L + i] = g_rows[i];
     for (int i = (int) threadIdx.x; i < kSlots * L; i += 64) g_lds_dw<ND>[i] = 0;
     __builtin_amdgcn_wave_barrier();
-    __shared__ int valid_s;
-    if (threadIdx.x == 0) valid_s = setup(g1, g2) ? 1 : 0;
-    __builtin_amdgcn_wave_barrier();
-    interpret(sched);
-    const bool valid = valid_s != 0;
+  }
+  static PBC_DEV void store_gt(uint8_t *gt, bool valid) {
+    using namespace dw;
     if (threadIdx.x < 6) {
       fq o = get_fq(S_f_x0 + (int) threadIdx.x);      // f.x0..2, f.y0..2 are consecutive slots: GT's wire order
       if (!valid) {                                   // an input that deserialises to O: the identity of GT
@@ -297,6 +328,60 @@ struct DW {
       }
       fp_store_be<ND>(gt + (size_t) threadIdx.x * fpk<ND>().fbytes, o);
     }
+  }
+  // element_pairing
+  static __device__ void pairing(uint8_t *gt, const uint8_t *g1, const uint8_t *g2, const uint64_t *sched) {
+    begin();
+    __shared__ int valid_s;
+    if (threadIdx.x == 0) { setup_consts(); const bool a = setup_point(g1), b = setup_twist(g2); valid_s = a && b ? 1 : 0; }
+    __builtin_amdgcn_wave_barrier();
+    interpret(sched);
+    store_gt(gt, valid_s != 0);
+  }
+  // element_prod_pairing, first kernel: the Miller value of ONE TERM -> its record of the workspace (kRec words: the six slots
+  // of f as they are, then the validity flag).  cc_millers_no_denom_affine (d_param.c:591-708) squares one accumulator for all
+  // terms; the product of the terms' own Miller values is the same element of F_q^6 up to the lines' factors in F_q^*.
+  static constexpr int kRec = 40;
+  static __device__ void miller_term(uint32_t *rec, const uint8_t *g1, const uint8_t *g2, const uint64_t *sched) {
+    begin();
+    __shared__ int valid_s;
+    if (threadIdx.x == 0) { setup_consts(); const bool a = setup_point(g1), b = setup_twist(g2); valid_s = a && b ? 1 : 0; }
+    __builtin_amdgcn_wave_barrier();
+    interpret(sched);
+    if (threadIdx.x < 6 * L) rec[threadIdx.x] = slot(dw::S_f_x0)[threadIdx.x];
+    if (threadIdx.x == 0) rec[6 * L] = (uint32_t) valid_s;
+  }
+  // second kernel: f <- the product of the k records (the two levels of f_mul0 on value bank 0, sched[0..1]), then the final
+  // exponentiation (sched + 2); any invalid term: the identity
+  static __device__ void finish(uint8_t *gt, const uint32_t *recs, int k, const uint64_t *sched_) {
+    const uint64_t *sched = reinterpret_cast<const uint64_t *>(uniform64(reinterpret_cast<uint64_t>(sched_)));
+    begin();
+    if (threadIdx.x == 0) setup_consts();
+    __builtin_amdgcn_wave_barrier();
+    const int lane = (int) threadIdx.x, w = lane < 6 * L ? lane : 0;
+    bool valid = recs[6 * L] != 0;
+    if (lane < 6 * L) slot(dw::S_f_x0)[w] = recs[w];
+    const uint64_t e0 = uniform64(sched[0]), e1 = uniform64(sched[1]);
+    uint32_t nxt = k > 1 ? recs[kRec + w] : 0u;
+    for (int t = 1; t < k; t++) {
+      valid &= recs[(size_t) t * kRec + 6 * L] != 0;
+      if (lane < 6 * L) slot(dw::S_V0_x0)[w] = nxt;
+      __builtin_amdgcn_wave_barrier();
+      if (t + 1 < k) nxt = recs[(size_t) (t + 1) * kRec + w];          // (in flight during the two levels)
+      run_entry(e0, nullptr);
+      run_entry(e1, nullptr);
+    }
+    interpret(sched + 2);
+    store_gt(gt, valid);
+  }
+  // pairing_pp_apply: the lines' coefficients come from the table of pairing_pp_init (d_pp_init_lane), no arithmetic on E(F_q)
+  static __device__ void pp_apply(uint8_t *gt, const uint32_t *tab, bool p_valid, const uint8_t *g2, const uint64_t *sched) {
+    begin();
+    __shared__ int valid_s;
+    if (threadIdx.x == 0) { setup_consts(); valid_s = setup_twist(g2) ? 1 : 0; }
+    __builtin_amdgcn_wave_barrier();
+    interpret(sched, tab);
+    store_gt(gt, p_valid && valid_s != 0);
   }
 };
 

@@ -35,6 +35,7 @@ __global__ void __launch_bounds__(kBlock, PBC_DF_WAVES) d_prod_pairing_kernel(ui
 }
 
 // small batches on the five-word d = 3 fields: one pairing per wavefront (pairing_dw.cuh)
+static constexpr size_t kDwMaxTerms = (size_t) 1 << 20;       // (records of the products' workspace: 160 bytes each)
 template <int N>
 __global__ void __launch_bounds__(64) dw_pairing_kernel(uint8_t *gt, const uint8_t *g1, const uint8_t *g2, size_t n, const uint64_t *sched, KArgs<N> ka) {
   const size_t idx = blockIdx.x;
@@ -42,22 +43,58 @@ __global__ void __launch_bounds__(64) dw_pairing_kernel(uint8_t *gt, const uint8
   const size_t fb = fpk<N>().fbytes;
   DW<N>::pairing(gt + idx * 6 * fb, g1 + idx * 2 * fb, g2 + idx * 6 * fb, sched);
 }
-// the schedule of one pairing for this object's curve (dw_sched.h), built on first use and kept with the object
-static const std::vector<uint64_t> &dw_schedule(pbc_hip_pairing_s *P) {
+// element_prod_pairing on wavefronts: the Miller value of every TERM (n k wavefronts), then one wavefront per product
+template <int N>
+__global__ void __launch_bounds__(64) dw_miller_kernel(uint32_t *recs, const uint8_t *g1, const uint8_t *g2, size_t terms, const uint64_t *sched, KArgs<N> ka) {
+  const size_t idx = blockIdx.x;
+  if (idx >= terms) return;
+  const size_t fb = fpk<N>().fbytes;
+  DW<N>::miller_term(recs + idx * DW<N>::kRec, g1 + idx * 2 * fb, g2 + idx * 6 * fb, sched);
+}
+template <int N>
+__global__ void __launch_bounds__(64) dw_finish_kernel(uint8_t *gt, const uint32_t *recs, size_t n, int k, const uint64_t *sched, KArgs<N> ka) {
+  const size_t idx = blockIdx.x;
+  if (idx >= n) return;
+  DW<N>::finish(gt + idx * 6 * fpk<N>().fbytes, recs + idx * (size_t) k * DW<N>::kRec, k, sched);
+}
+// pairing_pp_apply on wavefronts
+template <int N>
+__global__ void __launch_bounds__(64) dw_pp_apply_kernel(uint8_t *gt, const uint32_t *__restrict__ tab, const uint32_t *__restrict__ valid, const uint8_t *g2,
+                                                         size_t n, const uint64_t *sched, KArgs<N> ka) {
+  const size_t idx = blockIdx.x;
+  if (idx >= n) return;
+  const size_t fb = fpk<N>().fbytes;
+  DW<N>::pp_apply(gt + idx * 6 * fb, tab, *valid != 0, g2 + idx * 6 * fb, sched);
+}
+// the schedules for this object's curve (dw_sched.h), built on first use and kept with the object
+static const DwSched &dw_schedules(pbc_hip_pairing_s *P) {
   static std::mutex mu;
   std::lock_guard<std::mutex> lk(mu);
-  if (P->dw_sched.empty()) {
+  if (P->dw_sched.e.empty()) {
     const DConst &C = P->dconst;
-    dw::build_schedule(P->dw_sched, C.rbits, [&C](int m) { return (int) ((C.r[m >> 5] >> (m & 31)) & 1) - (int) ((C.rm[m >> 5] >> (m & 31)) & 1); },
-                       C.phik, C.phikbits);
+    dw::build_schedules(P->dw_sched, C.rbits, [&C](int m) { return (int) ((C.r[m >> 5] >> (m & 31)) & 1) - (int) ((C.rm[m >> 5] >> (m & 31)) & 1); },
+                        C.phik, C.phikbits);
   }
   return P->dw_sched;
 }
-extern "C" size_t pbc_hip_diag_dw_schedule(pbc_hip_pairing_t *P, uint64_t *out, size_t cap) {
-  if (!P || P->type != 'd' || P->nlimb != 5 || P->deg != 3) return 0;
-  const std::vector<uint64_t> &S = dw_schedule(P);
-  for (size_t i = 0; i < S.size() && i < cap; i++) out[i] = S[i];
-  return S.size();
+static bool dw_capable(const pbc_hip_pairing_s *P) { return P->type == 'd' && P->nlimb == 5 && P->deg == 3; }
+// (24 KB, read-only, one copy per device the object runs on -- uploaded on first use, kept with the object)
+static const uint64_t *dw_device_schedules(pbc_hip_pairing_s *P, const DwSched **host) {
+  const DwSched &S = dw_schedules(P);
+  static const char kSchedKey = 0;
+  bool fresh = false;
+  uint64_t *d_sched = (uint64_t *) object_scratch(P, &kSchedKey, S.e.size() * sizeof(uint64_t), &fresh);
+  if (!d_sched) return nullptr;
+  if (fresh && hipMemcpy(d_sched, S.e.data(), S.e.size() * sizeof(uint64_t), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+  *host = &S;
+  return d_sched;
+}
+extern "C" size_t pbc_hip_diag_dw_schedule(pbc_hip_pairing_t *P, int which, uint64_t *out, size_t cap) {
+  if (!P || !dw_capable(P) || which < 0 || which > 3) return 0;
+  const DwSched &S = dw_schedules(P);
+  const size_t first = S.off[which], last = which < 3 ? S.off[which + 1] : S.e.size();
+  for (size_t i = first; i < last && i - first < cap; i++) out[i - first] = S.e[i];
+  return last - first;
 }
 
 // pairing_pp for types d / g: single-lane table derivation, then one second argument per lane
@@ -119,16 +156,23 @@ int derive_d(pbc_hip_pairing_s *P, hipStream_t s) {
 
 int launch_d(pbc_hip_pairing_s *P, void *d_gt, const void *d_g1, const void *d_g2, size_t n, int k, hipStream_t s, ProdWs &W) {
   unsigned grid = (unsigned) ((n + kBlock - 1) / kBlock);
-  if (k == 1 && P->type == 'd' && P->nlimb == 5 && P->deg == 3 && n <= P->d_wave_max) {
-    // a batch this small runs at the latency of ONE lane on the throughput kernel (3.9 ms): a wavefront per pairing instead
-    // (the schedule: 10 KB, read-only, one copy per device the object runs on -- uploaded on first use, kept with the object)
-    const std::vector<uint64_t> &S = dw_schedule(P);
-    static const char kSchedKey = 0;
-    bool fresh = false;
-    uint64_t *d_sched = (uint64_t *) object_scratch(P, &kSchedKey, S.size() * sizeof(uint64_t), &fresh);
+  // The throughput kernel runs a batch this small at the latency of ONE lane (3.9 ms a pairing, ~2.9 ms more per further term
+  // of a product): a wavefront per pairing -- per TERM for products, then one per product -- instead (pairing_dw.cuh).
+  const bool waves = dw_capable(P) && k >= 1 && n <= P->d_wave_max && n * (size_t) k <= kDwMaxTerms;
+  if (waves && k == 1) {
+    const DwSched *S = nullptr;
+    const uint64_t *d_sched = dw_device_schedules(P, &S);
     if (!d_sched) return 1;
-    if (fresh) HIP_TRY(hipMemcpy(d_sched, S.data(), S.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(dw_pairing_kernel<5>, dim3((unsigned) n), dim3(64), 0, s, (uint8_t *) d_gt, (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, (const uint64_t *) d_sched, kargs<5>(P));
+    hipLaunchKernelGGL(dw_pairing_kernel<5>, dim3((unsigned) n), dim3(64), 0, s, (uint8_t *) d_gt, (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, d_sched + S->off[dw::SCHED_PAIRING], kargs<5>(P));
+  } else if (waves) {
+    const DwSched *S = nullptr;
+    const uint64_t *d_sched = dw_device_schedules(P, &S);
+    if (!d_sched) return 1;
+    const size_t terms = n * (size_t) k;
+    uint32_t *recs = (uint32_t *) W.get(terms * DW<5>::kRec * sizeof(uint32_t));
+    if (!recs) return 1;
+    hipLaunchKernelGGL(dw_miller_kernel<5>, dim3((unsigned) terms), dim3(64), 0, s, recs, (const uint8_t *) d_g1, (const uint8_t *) d_g2, terms, d_sched + S->off[dw::SCHED_MILLER], kargs<5>(P));
+    hipLaunchKernelGGL(dw_finish_kernel<5>, dim3((unsigned) n), dim3(64), 0, s, (uint8_t *) d_gt, (const uint32_t *) recs, n, k, d_sched + S->off[dw::SCHED_FINISH], kargs<5>(P));
   } else if (k == 1) {
     PBC_DISPATCH_D(P, hipLaunchKernelGGL((d_prod_pairing_kernel<N, DEG>), dim3(kDResident<N, DEG> ? PBC_RGRID(d_prod_pairing_kernel<N, DEG>) : grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
                                                 (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, 1, (uint32_t *) nullptr, kDResident<N, DEG> ? unit_counter(P, s) : nullptr, kargs<N>(P)));
@@ -154,6 +198,15 @@ int pp_init_launch_d(pbc_hip_pairing_s *P, pbc_hip_pp_s *pp, const uint8_t *dg1)
 int pp_apply_launch_d(pbc_hip_pp_s *pp, void *d_gt, const void *d_g2, size_t n, hipStream_t s) {
   pbc_hip_pairing_s *P = pp->P;
   unsigned grid = (unsigned) ((n + kBlock - 1) / kBlock);
+  if (dw_capable(P) && n <= P->d_wave_max) {
+    const DwSched *S = nullptr;
+    const uint64_t *d_sched = dw_device_schedules(P, &S);
+    if (!d_sched || S->lines > dw::kMaxLines) return 1;
+    hipLaunchKernelGGL(dw_pp_apply_kernel<5>, dim3((unsigned) n), dim3(64), 0, s, (uint8_t *) d_gt, (const uint32_t *) pp->tab, (const uint32_t *) pp->valid, (const uint8_t *) d_g2, n,
+                       d_sched + S->off[dw::SCHED_PP], kargs<5>(P));
+    HIP_TRY(hipGetLastError());
+    return 0;
+  }
   PBC_DISPATCH_D(P, hipLaunchKernelGGL((d_pp_apply_kernel<N, DEG>), dim3(kDResident<N, DEG> ? PBC_RGRID(d_pp_apply_kernel<N, DEG>) : grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
                                            pp->tab, pp->valid, (const uint8_t *) d_g2, n, kDResident<N, DEG> ? unit_counter(P, s) : nullptr, kargs<N>(P)));
   HIP_TRY(hipGetLastError());

@@ -131,23 +131,25 @@ def test_wave_program_tables_are_current_and_reproduce_the_reference():
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import dw_gen
     progs = dw_gen.build()
-    bad, levels = dw_gen.check(progs, count=3)
-    assert bad == 0 and 1000 < levels < 2000
+    bad, levels = dw_gen.check(progs, count=3)               # (pairings, the same through a pairing_pp table, products)
+    assert bad == 0 and 1000 < levels["pp_apply"] < levels["pairing"] < 2000
     assert open(os.path.join(ROOT, "pbc_amd", "csrc", "dw_tables.h")).read() == dw_gen.emit(progs)
 
 
 def test_host_schedule_of_the_wave_kernel_is_the_model_s():
-    """csrc/dw_sched.h (C++, built per object from the curve's constants) flattens a d159 pairing into exactly the sequence of
-    (program, level) pairs that tools/dw_gen.py's model executes when it reproduces the reference's vectors -- entry by entry"""
+    """csrc/dw_sched.h (C++, built per object from the curve's constants) flattens a d159 pairing -- and the Miller value of a
+    product's term, the product + final exponentiation, pairing_pp_apply -- into exactly the sequence of (program, level)
+    pairs that tools/dw_gen.py's model executes when it reproduces the reference's vectors: entry by entry"""
     import ctypes
     import numpy as np
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import pbc_amd
     import dw_gen
-    want = dw_gen.flat_schedule("d159")
     P = pbc_amd.Pairing(pbc_amd.param_text("d159"))
     buf = np.zeros(4096, np.uint64)
-    n = pbc_amd.lib().pbc_hip_diag_dw_schedule(P._h, buf.ctypes.data_as(ctypes.c_void_p), len(buf))
-    assert n == len(want) and [int(x) for x in buf[:n]] == want
-    assert pbc_amd.lib().pbc_hip_diag_dw_schedule(pbc_amd.Pairing(pbc_amd.param_text("d201"))._h, buf.ctypes.data_as(ctypes.c_void_p), len(buf)) == 0
+    for which, kind in enumerate(("pairing", "miller", "finish", "pp")):
+        want = dw_gen.flat_schedule(kind)
+        n = pbc_amd.lib().pbc_hip_diag_dw_schedule(P._h, which, buf.ctypes.data_as(ctypes.c_void_p), len(buf))
+        assert n == len(want) and [int(x) for x in buf[:n]] == want, kind
+    assert pbc_amd.lib().pbc_hip_diag_dw_schedule(pbc_amd.Pairing(pbc_amd.param_text("d201"))._h, 0, buf.ctypes.data_as(ctypes.c_void_p), len(buf)) == 0

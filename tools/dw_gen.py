@@ -504,8 +504,9 @@ class Model:
                 r = self.f3_mul_int(r, a)
         return r
 
-    def run_level(self, *tracks):
-        """one VM level: the given (program, level) pairs side by side -- every lane reads before any lane writes"""
+    def run_level(self, *tracks, load=None):
+        """one VM level: the given (program, level) pairs side by side -- every lane reads before any lane writes; `load`
+        (pairing_pp_apply): line `load` of the table arrives in coefficient bank load % 2 when the level is over"""
         writes = []
         for tr in tracks:
             for p, lev in tr:
@@ -525,43 +526,65 @@ class Model:
         self.stats["levels"] += 1
         a = tracks[0][0] if len(tracks) > 0 and tracks[0] else None
         b = tracks[1][0] if len(tracks) > 1 and tracks[1] else None
-        self.flat.append(("level", (a[0].name, a[1]) if a else None, (b[0].name, b[1]) if b else None))
+        if load is not None:
+            for c, n in enumerate(line_names(load % 2)):
+                self.env[n] = self.table[load][c]
+        self.flat.append(("level", (a[0].name, a[1]) if a else None, (b[0].name, b[1]) if b else None, load))
 
     def run(self, name):
         p = self.progs[name]
         for lev in range(len(p.levels)):
             self.run_level([(p, lev)])
 
-    def pairing(self, g1, g2):
+    def set_point(self, g1):
+        """the first argument: curve_is_valid_point (the driver's lane code), then the point track's state"""
         q, e, fb = self.q, self.env, 20
         gi = lambda b, i: int.from_bytes(b[fb * i:fb * (i + 1)], "big") % q
         Px, Py = gi(g1, 0), gi(g1, 1)
+        a, b = self.P["a"], self.P["b"]
+        e.update(X=Px, Y=Py, Z=1, nZ=q - 1, W=a % q, ZZ=1, ZZZ=1, Px=Px, Py=Py, nPy=(q - Py) % q)
+        return ((Px * Px + a) * Px + b - Py * Py) % q == 0
+
+    def set_twist(self, g2):
+        """the second argument: the check on the twist, the twist map, and f = 1"""
+        q, e, fb = self.q, self.env, 20
+        gi = lambda b, i: int.from_bytes(b[fb * i:fb * (i + 1)], "big") % q
         Qx, Qy = [gi(g2, i) for i in range(3)], [gi(g2, 3 + i) for i in range(3)]
-        # validity (curve_is_valid_point): the driver's lane code
         a, b, v = self.P["a"], self.P["b"], self.v
-        ok = (Px * Px + a) * Px % q + b == Py * Py % q or ((Px * Px + a) * Px + b - Py * Py) % q == 0
         ta, tb = a * v * v % q, b * v * v * v % q
         x2 = self.f3_mul_int(Qx, Qx)
         x2[0] = (x2[0] + ta) % q
         x3 = self.f3_mul_int(x2, Qx)
         x3[0] = (x3[0] + tb) % q
-        ok = ok and x3 == self.f3_mul_int(Qy, Qy)
-        if not ok:
-            return None
-        e.update(X=Px, Y=Py, Z=1, nZ=q - 1, W=a % q, ZZ=1, ZZZ=1, Px=Px, Py=Py, nPy=(q - Py) % q)
         for i in range(3):
             e[QX[i]], e[QY[i]] = Qx[i] * self.vinv % q, Qy[i] * self.vinv * self.vinv % q
             e[F[0][i]], e[F[1][i]] = (1 if i == 0 else 0), 0
-        # the Miller loop (d_miller_lane), software-pipelined: the point work of a step runs beside the accumulator's work
-        # of the step before
+        return x3 == self.f3_mul_int(Qy, Qy)
+
+    def steps(self):
+        """the Miller loop's steps in order: ("dbl",) / ("add", negative digit) / ("sqr",)"""
         dig = lambda m: ((self.plus >> m) & 1) - ((self.minus >> m) & 1)
-        steps = []                                   # ("dbl",) / ("add", neg) in order
+        steps = []
         for m in range(self.rbits - 2, -1, -1):
             steps.append(("dbl",))
             if m > 0 and dig(m):
                 steps.append(("add", dig(m) < 0))
             if m > 0:
                 steps.append(("sqr",))
+        return steps
+
+    def pairing(self, g1, g2):
+        if not self.miller(g1, g2):
+            return None
+        return self.final_exp()
+
+    def miller(self, g1, g2):
+        """the Miller value into f; False: an argument is not on its curve (the driver stores the identity then)"""
+        ok = self.set_point(g1)
+        ok = self.set_twist(g2) and ok
+        # the Miller loop (d_miller_lane), software-pipelined: the point work of a step runs beside the accumulator's work
+        # of the step before
+        steps = self.steps()
         pt = [s for s in steps if s[0] != "sqr"]
         fs = []                                      # accumulator track: ("mul", index of the line) / ("sqr",)
         li = 0
@@ -613,9 +636,89 @@ class Model:
                 if plev == len(pprog.levels):
                     pprog = None
         assert pi == len(P) and pprog is None
-        pt = P
-        assert pi == len(pt) and pprog is None
-        return self.final_exp()
+        return ok
+
+    # ---- element_prod_pairing: one wavefront per TERM for the Miller values, then one per product ----
+    def product(self, terms):
+        """prod e(g1_t, g2_t): the Miller values of the terms (kernel 1, independent wavefronts), their product by f_mul0 with
+        term t's value loaded into value bank 0, ONE final exponentiation (kernel 2); any invalid term: the identity"""
+        vals, ok = [], True
+        for g1, g2 in terms:
+            ok = self.miller(g1, g2) and ok
+            vals.append([self.env[n] for n in F[0] + F[1]])
+        self.flat = []
+        for n, x in zip(F[0] + F[1], vals[0]):
+            self.env[n] = x
+        for val in vals[1:]:
+            for n, x in zip(sum(value_names(0), []), val):
+                self.env[n] = x
+            self.run("f_mul0")
+        r = self.final_exp()
+        return r if ok else None
+
+    # ---- pairing_pp_init / pairing_pp_apply: the lines' coefficients come from a table ----
+    def pp_table(self, g1):
+        """what d_pp_init_lane leaves (here in this script's scaling of the lines -- any factor of F_q^* is as good)"""
+        ok = self.set_point(g1)
+        keep, tab = self.flat, []
+        for j, s in enumerate(st for st in self.steps() if st[0] != "sqr"):
+            name = "pt_dbl%d" % (j % 2) if s[0] == "dbl" else "pt_add%s%d" % ("m" if s[1] else "p", j % 2)
+            self.run(name)
+            tab.append([self.env[n] for n in line_names(j % 2)])
+        self.flat = keep
+        return tab, ok
+
+    def pp_apply(self, table, p_valid, g2):
+        """the accumulator track as in `miller`; the point track only EVALUATES: line i (coefficient bank i % 2, loaded beside the
+        first level of the evaluation of line i - 1) -> value bank i % 2 by pt_eval{(i + 1) % 2}, two levels;
+          * the product with line i starts when its evaluation is complete;
+          * the evaluation of line i starts when the product with line i - 2 is complete (it overwrites that value bank).
+        dw_sched.h build_pp is this loop."""
+        ok = self.set_twist(g2) and p_valid
+        self.table = table
+        fs, li = [], 0
+        for s in self.steps():
+            if s[0] == "sqr":
+                fs.append(("sqr",))
+            else:
+                fs.append(("mul", li))
+                li += 1
+        nl = li
+        assert nl == len(table)
+        for c, n in enumerate(line_names(0)):
+            self.env[n] = table[0][c]
+        self.flat.append(("op", "loadline", 0))
+        fi = pi = evals_done = fmul_done = 0
+        fprog = pprog = None
+        flev = plev = 0
+        f_is_mul = False
+        while fi < len(fs) or fprog is not None:
+            if fprog is None:
+                if fs[fi][0] == "sqr":
+                    fprog, flev, f_is_mul = self.progs["f_sqr"], 0, False
+                    fi += 1
+                elif fs[fi][1] < evals_done:
+                    fprog, flev, f_is_mul = self.progs["f_mul%d" % (fs[fi][1] % 2)], 0, True
+                    fi += 1
+            if pprog is None and pi < nl and (pi < 2 or fmul_done >= pi - 1):
+                pprog, plev = self.progs["pt_eval%d" % ((pi + 1) % 2)], 0
+                pi += 1
+            assert fprog is not None or pprog is not None
+            load = pi if pprog is not None and plev == 0 and pi < nl else None
+            self.run_level([(fprog, flev)] if fprog else [], [(pprog, plev)] if pprog else [], load=load)
+            if fprog is not None:
+                flev += 1
+                if flev == len(fprog.levels):
+                    fmul_done += 1 if f_is_mul else 0
+                    fprog = None
+            if pprog is not None:
+                plev += 1
+                if plev == len(pprog.levels):
+                    evals_done += 1
+                    pprog = None
+        assert pi == nl and pprog is None and evals_done == nl
+        r = self.final_exp()
+        return r if ok else None
 
     def final_exp(self):
         q, e = self.q, self.env
@@ -638,15 +741,24 @@ class Model:
         return [e[F[0][i]] for i in range(3)] + [e[F[1][i]] for i in range(3)]
 
 
-def pack_entry(progs_index, a, b, op=0):
-    """the 64-bit schedule entry of dw_sched.h: row a | lanes a | row b | lanes b | terms | op"""
+OPS = {"level": 0, "bzero": 1, "inv": 2, "end": 3, "loadline": 4}
+
+
+def pack_entry(progs_index, a, b, op=0, load=None):
+    """the 64-bit schedule entry of dw_sched.h: row a | lanes a | row b | lanes b | terms | op | table line | line flag"""
     ra, la, ta = progs_index[a] if a else (0, 0, 0)
     rb, lb, tb = progs_index[b] if b else (0, 0, 0)
-    return ra | la << 12 | rb << 17 | lb << 29 | max(ta if la else 0, tb if lb else 0) << 34 | op << 38
+    e = ra | la << 12 | rb << 17 | lb << 29 | max(ta if la else 0, tb if lb else 0) << 34 | op << 38
+    if load is not None:
+        assert load < 4096
+        e |= load << 42 | 1 << 55
+    return e
 
 
-def flat_schedule(pname="d159"):
-    """the packed schedule of one pairing as the model executes it (compared with the host's dw_build_schedule by the tests)"""
+def flat_schedule(kind="pairing", pname="d159"):
+    """the packed schedules as the model executes them (compared with the host's dw_sched.h by the tests): "pairing";
+    "miller" (a term of a product: the Miller value only); "finish" (the two levels of a product with a term's value, then the
+    final exponentiation); "pp" (pairing_pp_apply)"""
     progs = build()
     idx, rows = {}, 0
     for name in sorted(progs):
@@ -655,9 +767,24 @@ def flat_schedule(pname="d159"):
             rows += len(lanes)
     M = Model(pname, progs)
     g1, g2, gt = load_vec(os.path.join(ROOT, "tests", "golden", "d_rand32.vec"))
-    M.pairing(g1[0], g2[0])
-    ops = {"bzero": 1, "inv": 2, "end": 3}
-    return [pack_entry(idx, e[1], e[2]) if e[0] == "level" else pack_entry(idx, None, None, ops[e[1]]) for e in M.flat]
+    if kind == "pairing":
+        M.pairing(g1[0], g2[0])
+    elif kind == "miller":
+        M.miller(g1[0], g2[0])
+        M.flat.append(("op", "end"))
+    elif kind == "finish":
+        M.product([(g1[0], g2[0]), (g1[1], g2[1])])
+    else:
+        tab, ok = M.pp_table(g1[0])
+        M.flat = []
+        M.pp_apply(tab, ok, g2[0])
+    out = []
+    for e in M.flat:
+        if e[0] == "level":
+            out.append(pack_entry(idx, e[1], e[2], 0, e[3]))
+        else:
+            out.append(pack_entry(idx, None, None, OPS[e[1]], e[2] if len(e) > 2 else None))
+    return out
 
 
 def load_vec(path):
@@ -674,17 +801,35 @@ def load_vec(path):
 def check(progs, count=6):
     M = Model("d159", progs)
     bad = 0
+    levels = {}
+    want_of = lambda b: [int.from_bytes(b[20 * c:20 * c + 20], "big") for c in range(6)]
+    ident = [1, 0, 0, 0, 0, 0]
     for name in ("d_rand32.vec", "d_edge20.vec"):
         g1, g2, gt = load_vec(os.path.join(ROOT, "tests", "golden", name))
         for i in range(min(count, len(gt))):
             M.stats["levels"] = 0
             r = M.pairing(g1[i], g2[i])
-            want = [int.from_bytes(gt[i][20 * c:20 * c + 20], "big") for c in range(6)]
-            got = r if r is not None else [1, 0, 0, 0, 0, 0]
-            if got != want:
+            levels["pairing"] = M.stats["levels"]
+            if (r or ident) != want_of(gt[i]):
                 bad += 1
                 print("MISMATCH", name, i)
-    return bad, M.stats["levels"]
+            if i < 3:                                 # the same pairing from the table of pairing_pp_init
+                tab, ok = M.pp_table(g1[i])
+                M.stats["levels"] = 0
+                r = M.pp_apply(tab, ok, g2[i])
+                levels["pp_apply"] = M.stats["levels"]
+                if (r or ident) != want_of(gt[i]):
+                    bad += 1
+                    print("MISMATCH (pp)", name, i)
+    for name, units in (("d_prod16x4.vec", 2), ("d_prod3x10_edge.vec", 10)):
+        g1, g2, gt = load_vec(os.path.join(ROOT, "tests", "golden", name))
+        k = len(g1) // len(gt)
+        for i in range(min(units, len(gt))):
+            r = M.product([(g1[i * k + t], g2[i * k + t]) for t in range(k)])
+            if (r or ident) != want_of(gt[i]):
+                bad += 1
+                print("MISMATCH (product)", name, i)
+    return bad, levels
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -710,7 +855,7 @@ def emit(progs):
                 b = [o] + xs + [z] * (8 - len(xs)) + ys + [z] * (8 - len(ys)) + [0, 0, 0]
                 rows.append([b[4 * i] | b[4 * i + 1] << 8 | b[4 * i + 2] << 16 | b[4 * i + 3] << 24 for i in range(5)])
         out.append("constexpr int P_%s = %d, N_%s = %d;" % (name, first, name, len(tab)))
-    out.append("enum { OP_LEVEL = 0, OP_BZERO = 1, OP_INV = 2, OP_END = 3 };      // schedule entries (dw_sched.h)")
+    out.append("enum { OP_LEVEL = 0, OP_BZERO = 1, OP_INV = 2, OP_END = 3, OP_LOADLINE = 4 };      // schedule entries (dw_sched.h)")
     out.append("struct LevelRef { uint16_t row; uint8_t T, lanes; };")
     out.append("constexpr int kLevels = %d, kRows = %d;" % (len(index), len(rows)))
     out.append("// (the level table is read by the HOST: it flattens a pairing into a schedule of packed entries, dw_sched.h)")
@@ -728,7 +873,7 @@ def main():
         p = progs[name]
         print("%-10s levels %2d  sums %3d  widest level %2d lanes  terms per level %s" % (name, len(p.levels), len(p.nodes), max(len(r) for r in p.levels),
               [max(len(n.terms) for n in r) for r in p.levels]))
-    print("slots %d; levels executed per pairing %d; vectors: %s" % (len(SLOTS.order), levels, "MISMATCH" if bad else "ok"))
+    print("slots %d; levels executed: %s; vectors: %s" % (len(SLOTS.order), levels, "MISMATCH" if bad else "ok"))
     if bad:
         sys.exit(1)
     text = emit(progs)

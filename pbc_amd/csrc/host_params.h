@@ -66,6 +66,7 @@ struct pbc_hip_pairing_s {
   bool dynamic;              // resident launches fetch their units from a per-launch counter instead of a fixed stride ("hip_dynamic 1")
   bool no_fair;              // no time-sliced wave priorities (fp.cuh pbc_fair_tick; "hip_no_fair 1")
   bool group_slow;           // group operations: only the complete ladders ("hip_group_slow 1": tests, A/B)
+  bool a_multi_compose;      // type a, pow2 / pow3 on G1 / G2: single-base ladders + additions instead of the joint ladder ("hip_multi_compose 1": A/B)
   int resident_slots;        // > 0: workgroups of a resident launch instead of the occupancy query ("hip_resident_slots N", tests)
   size_t host_chunk;         // host-buffer entry points: units per chunk when the parameter text says "hip_host_chunk N" (0: default)
   size_t a_wave4_max;        // ... and up to this size four wavefronts per pairing ("hip_wave4_max N")

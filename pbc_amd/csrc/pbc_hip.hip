@@ -304,6 +304,9 @@ extern "C" int pbc_hip_pairing_init_set_buf(pbc_hip_pairing_t **out, const char 
     int gs = 0;                        // "hip_group_slow 1": element_mul_zn / GT pow_zn on the complete bit-by-bit ladders only
     pbc_host::param_int(param, len, "hip_group_slow", gs);
     P->group_slow = gs != 0;
+    int mc = 0;                        // "hip_multi_compose 1": type a pow2 / pow3 as single-base ladders + additions (A/B with the joint ladder)
+    pbc_host::param_int(param, len, "hip_multi_compose", mc);
+    P->a_multi_compose = mc != 0;
     // bind to the caller's current device; without one the object still parses/validates
     // parameters (host logic), and every batch call fails loudly -- there is no CPU path.
     if (hipGetDevice(&P->device) != hipSuccess) P->device = -1;

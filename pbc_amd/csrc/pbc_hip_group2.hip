@@ -27,6 +27,30 @@ __global__ void __launch_bounds__(kBlock, 2) ec_multi_mul_kernel(uint8_t *out, M
   if (flags && !flags[idx]) return;
   ec_multi_mul_lane<F>(out + idx * 2 * (size_t) F::bytes(), M, idx, k, zlen);
 }
+// Type a, 512-bit field, G1 / G2: the joint signed-window ladder on the limb-form arithmetic (group_al.cuh gmulk_lane), resident
+// workgroups as the single-base ladder; lanes it reports are left to ec_multi_mul_kernel
+template <int N, int KB>
+__global__ void __launch_bounds__(kBlock, PBC_A_WAVES) al_gmulk_kernel(uint8_t *out, MultiArgs M, int zlen, uint8_t *flags, size_t n, unsigned *ctr, KArgs<N> ka) {
+  PBC_RESIDENT_LOOP(n, ctr) {
+    size_t idx = PBC_UNIT_INDEX;
+    size_t ld = idx < n ? idx : n - 1;
+    constexpr int L = 8 * N;
+    __attribute__((aligned(16))) uint8_t o[L];
+    const uint8_t *a[KB], *z[KB];
+#pragma unroll
+    for (int j = 0; j < KB; j++) { a[j] = M.a[j] + ld * M.astride; z[j] = M.z[j] + ld * M.zstride; }
+    const bool ok = GAL<N>::template gmulk_lane<KB>(o, a, z, zlen);
+    if (idx < n) {
+      flags[idx] = ok ? 0 : 1;
+      if (ok) {
+        uint4 *dst = reinterpret_cast<uint4 *>(out + idx * L);
+        const uint4 *src = reinterpret_cast<const uint4 *>(o);
+#pragma unroll
+        for (int i = 0; i < L / 16; i++) dst[i] = src[i];
+      }
+    }
+  }
+}
 template <class G>
 __global__ void __launch_bounds__(kBlock, 2) gt_multi_pow_kernel(uint8_t *out, MultiArgs M, int k, int zlen, size_t n, KArgs<G::NW> ka) {
   size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
@@ -146,6 +170,26 @@ static int multi_launch(pbc_hip_pairing_s *P, int group, int k, void *d_out, con
   const unsigned grid = (unsigned) ((n + kBlock - 1) / kBlock);
   uint8_t *o = (uint8_t *) d_out;
   const size_t lp = group_len(P, group);
+  if (!P->group_slow && group != 3 && P->type == 'a' && !P->a_generic && !P->a_multi_compose && (k == 2 || k == 3)) {
+    // type a on the 512-bit field: ONE ladder for all bases (four doublings and k additions per window; the composition
+    // doubles 4 k times).  A result that overlaps a base at another offset than its own is built in a temporary: a lane reads
+    // its own records before it writes, other lanes' records must not change under them.
+    bool overlap = false;
+    for (int j = 0; j < k; j++) {
+      const uint8_t *b = M.a[j];
+      overlap |= b != o && b < o + n * lp && o < b + (n - 1) * M.astride + lp;
+    }
+    ProdWs W(P, s, own);
+    uint8_t *flags = (uint8_t *) W.get(n + (overlap ? n * lp + 16 : 0));
+    if (!flags) return 1;
+    uint8_t *acc = overlap ? flags + ((n + 15) & ~(size_t) 15) : o;
+    if (k == 2) hipLaunchKernelGGL((al_gmulk_kernel<16, 2>), dim3(PBC_RGRID(al_gmulk_kernel<16, 2>)), dim3(kBlock), 0, s, acc, M, P->len_zr, flags, n, unit_counter(P, s), kargs<16>(P));
+    else hipLaunchKernelGGL((al_gmulk_kernel<16, 3>), dim3(PBC_RGRID(al_gmulk_kernel<16, 3>)), dim3(kBlock), 0, s, acc, M, P->len_zr, flags, n, unit_counter(P, s), kargs<16>(P));
+    hipLaunchKernelGGL(ec_multi_mul_kernel<FqOps<16>>, dim3(grid), dim3(kBlock), 0, s, acc, M, k, P->len_zr, (const uint8_t *) flags, n, kargs<16>(P));
+    HIP_TRY(hipGetLastError());
+    if (overlap) HIP_TRY(hipMemcpyAsync(d_out, acc, n * lp, hipMemcpyDeviceToDevice, s));
+    return 0;
+  }
   if (!P->group_slow) {
     if (M.astride != lp || M.zstride != (size_t) P->len_zr) return fail("internal: packed records on the composition route");
     // `out` may be any ONE of the bases (include/pbc_hip.h; the reference lets x alias a base): the first term is written

@@ -487,6 +487,12 @@ int hostsim_multi(void *h, int group, int k, uint8_t *out, const uint8_t *a1, co
     } else {
       // as the library: the fast pass, and the complete routine for the lanes it reports
       bool ok = false;
+      if (!hostsim_slow_group && P->type == 'a' && !P->a_generic && (k == 2 || k == 3)) {
+        // type a on the 512-bit field: the joint limb-form ladder (group_al.cuh gmulk_lane), bound tracker armed
+        const uint8_t *pa[3], *pz[3];
+        for (int j = 0; j < 3; j++) { pa[j] = M.a[j] + i * M.astride; pz[j] = M.z[j] + i * M.zstride; }
+        ok = k == 2 ? GAL<16>::gmulk_lane<2>(out + i * L, pa, pz, P->len_zr) : GAL<16>::gmulk_lane<3>(out + i * L, pa, pz, P->len_zr);
+      } else
       if (!hostsim_slow_group) { HS_DISPATCH_G(P, group, ok = ec_multi_mul_fast_lane<F>(out + i * L, M, i, k, P->len_zr)); }
       if (!ok) {
         if (!hostsim_slow_group) hostsim_fallbacks++;

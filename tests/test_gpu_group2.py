@@ -334,6 +334,54 @@ def test_multi_exponentiation_with_the_result_over_an_input(hips, key, name):
     routes[1].clear()
 
 
+def test_joint_ladder_of_type_a_equals_the_composition(hips):
+    """element_pow2_zn / element_pow3_zn on a.param G1 / G2 run ONE limb-form ladder for all bases (group_al.cuh gmulk_lane:
+    four doublings + k additions per window); "hip_multi_compose 1" keeps the single-base ladders + additions.  Same bytes
+    on 5000 units with the rows the joint ladder must hand to the complete routine: equal and opposite bases, a base off
+    the curve (= O), scalars 0, 1, 2, r - 1, r, >= r, all ones; and with the result overlapping a base at an OFFSET (built in
+    a temporary)."""
+    import pbc_amd
+    import torch
+    H = hips["a"]
+    C = pbc_amd.Pairing(_param("a") + "hip_multi_compose 1\n")
+    v = golden("a_chain1024.vec")
+    n = 5000
+    rng = np.random.default_rng(71)
+    r = _order("a")
+    zl = H.length_in_bytes_Zr
+    idx = [rng.integers(0, v.n, n) for _ in range(3)]
+    idx[1][::9] = idx[0][::9]                                   # equal bases
+    X = [np.ascontiguousarray(v.g1[idx[t]]) for t in range(3)]
+    neg = H.element_group_op("neg", 1, X[0][3::9])
+    X[2][3::9] = neg                                            # opposite bases (third and first)
+    X[1][5::50] = neg[:len(X[1][5::50])]                        # ... and second and (another row's) first
+    X[1][7::100, 5] ^= 1                                        # off the curve: O
+    Z = []
+    for t in range(3):
+        ks = [int.from_bytes(rng.bytes(zl), "big") % r for _ in range(n)]
+        for q, k in enumerate([0, 1, 2, r - 1, r, r + 1, (1 << (8 * zl)) - 1, 1 << (8 * zl - 1)]):
+            for rep in range(6):
+                ks[(q * 7 + t * 3 + rep * 131) % n] = k
+        Z.append(np.stack([_be(k, zl) for k in ks]))
+    Z[2][3::9] = Z[0][3::9]                                     # [k] P + ... + [k] (-P): the two cancel
+    for group in (1, 2):
+        for k in (2, 3):
+            got = H.element_pow_multi(group, X[:k], Z[:k])
+            assert np.array_equal(got, C.element_pow_multi(group, X[:k], Z[:k])), (group, k)
+    # overlap at an offset: out = the first base's buffer shifted by one record
+    m = 400
+    lp = H.length_in_bytes_G1
+    buf = torch.zeros((m + 1) * lp, dtype=torch.uint8, device="cuda")
+    buf[lp:] = torch.from_numpy(X[0][:m].reshape(-1)).cuda()
+    b2 = torch.from_numpy(X[1][:m]).cuda()
+    z1, z2 = torch.from_numpy(Z[0][:m]).cuda(), torch.from_numpy(Z[1][:m]).cuda()
+    want = C.element_pow_multi(1, [X[0][:m], X[1][:m]], [Z[0][:m], Z[1][:m]])
+    H.element_pow_multi_dev(1, buf.data_ptr(), [buf.data_ptr() + lp, b2.data_ptr()], [z1.data_ptr(), z2.data_ptr()], m, 0)
+    torch.cuda.synchronize()
+    assert np.array_equal(buf[:m * lp].cpu().numpy().reshape(m, lp), want)
+    C.clear()
+
+
 def test_two_threads_issue_on_one_stream(hips):
     """two host threads enqueue two-pass operations (element_mul_zn on a.param G1: fast kernel + the complete kernel for the
     lanes it flags, sharing a flags workspace keyed by (device, stream)) on the SAME stream of one object: each call's

@@ -325,6 +325,148 @@ struct GL {
     return handled;
   }
 
+  // out <- [k_0] P_0 + ... + [k_{KB-1}] P_{KB-1} (element_pow2_zn / element_pow3_zn on G1) with ONE accumulator: the ladder above on
+  // KB tables -- four doublings and KB mixed additions per window, where the composition of single-base ladders doubles 4 KB
+  // times.  false: nothing written, the complete multi-scalar routine takes the lane (a base off the curve, an exceptional
+  // addition anywhere -- equal or opposite bases meeting in the accumulator, a point of small order, a zero scalar -- or the
+  // result O: all of these leave Z = 0).
+  template <int KB>
+  static PBC_DEV bool gmulk_lane(uint8_t *out, const uint8_t *const *in, const uint8_t *const *z, int zlen) {
+    constexpr int WIN = 4, TE = 8;
+    const int NB = (int) fpk<N>().fbytes;
+    const bool a_zero = c_curve.a_is_zero != 0;
+    el tab[KB][TE][2], ca, one;
+    uint32_t kw[KB][kScalarWords];
+    bool even[KB];
+    bool valid = true, bad = false;
+    {
+      fp<N> a, t0;
+      fp_set<N>(a, c_curve.a);
+      from_fq(ca, a);
+      fp_set<N>(t0, fpk<N>().one);
+      from_fq(one, t0);
+    }
+    el X, Y, Z;
+#pragma unroll 1
+    for (int b = 0; b < KB; b++) {
+      el zs[TE], cs[TE];
+      {
+        fp<N> x, y, t0, t1, a, cb;
+        fp_load_be<N>(x, in[b]);
+        fp_load_be<N>(y, in[b] + NB);
+        fp_set<N>(a, c_curve.a);
+        fp_set<N>(cb, c_curve.b);
+        fp_sqr<N>(t0, x);
+        fp_add<N>(t0, t0, a);
+        fp_mul<N>(t0, t0, x);
+        fp_add<N>(t0, t0, cb);
+        fp_sqr<N>(t1, y);
+        valid &= fp_eq<N>(t0, t1);
+        from_fq(tab[b][0][0], x);
+        from_fq(tab[b][0][1], y);
+      }
+      X = tab[b][0][0]; Y = tab[b][0][1]; Z = one;
+      dbl(X, Y, Z, ca, a_zero);        // 2P = (X2 : Y2 : Z2)
+      const el X2 = X, Y2 = Y, Z2 = Z;
+      {
+        // phi(P) = (x Z2^2, y Z2^3) on the isomorphic curve where phi(2P) = (X2, Y2) is affine
+        el zz, t;
+        mul<4>(zz, Z2, Z2);
+        mul<1>(X, tab[b][0][0], zz);
+        mul<2>(t, zz, Z2);
+        mul<1>(Y, tab[b][0][1], t);
+        Z = one;
+      }
+      for (int j = 1; j < TE; j++) {
+        madd(X, Y, Z, X2, Y2);
+        tab[b][j][0] = X;
+        tab[b][j][1] = Y;
+        mul<2>(zs[j], Z, Z2);          // back on E: Z <- Z' Z2
+        if (j == 1) cs[1] = zs[1];
+        else mul<1>(cs[j], cs[j - 1], zs[j]);
+      }
+      bad |= is0(cs[TE - 1]);          // some odd multiple (or 2P) is O: a point of small order
+      el zi;
+      inv(zi, cs[TE - 1]);
+      for (int j = TE - 1; j >= 1; j--) {
+        el zinv, zz, t, x, y;
+        if (j > 1) {
+          mul<1>(zinv, zi, cs[j - 1]);
+          mul<1>(zi, zi, zs[j]);
+        } else {
+          zinv = zi;
+        }
+        sqr(zz, zinv);
+        x = tab[b][j][0];
+        y = tab[b][j][1];
+        mul<1>(tab[b][j][0], x, zz);
+        mul<1>(t, zz, zinv);
+        mul<1>(tab[b][j][1], y, t);
+      }
+      scalar_load(kw[b], z[b], zlen);
+      even[b] = (kw[b][0] & 1) == 0;
+      kw[b][0] |= 1u;
+      kw[b][(8 * zlen) >> 5] |= 1u << ((8 * zlen) & 31);
+    }
+    const int t = 2 * zlen;
+    auto entry = [&](el &x, el &y, int b, int i, bool top) {
+      const uint32_t v = scalar_bits(kw[b], 4 * i + 1, 15u);
+      const bool neg = !top && v < 8;  // (the top digit is positive: bit n is set)
+      const int idx = v < 8 ? 7 - (int) v : (int) v - 8;
+      x = tab[b][idx][0];
+      y = tab[b][idx][1];
+      GL_HS(hs_set(x, U_STRICT, 2.0); hs_set(y, U_STRICT, 2.0);)
+      el ny;
+      negk(ny, y, K4);                 // u 3, B 4
+      norm(ny, ny);
+      GL_HS(y.hs_u = ny.hs_u; y.hs_B = ny.hs_B;)
+      sel(y, ny, neg);
+    };
+    entry(X, Y, 0, t - 1, true);
+    Z = one;
+#pragma unroll 1
+    for (int b = 1; b < KB; b++) {
+      el x2, y2;
+      entry(x2, y2, b, t - 1, true);
+      madd(X, Y, Z, x2, y2);
+    }
+    for (int i = t - 2; i >= 0; i--) {
+      for (int d = 0; d < WIN; d++) dbl(X, Y, Z, ca, a_zero);
+#pragma unroll 1
+      for (int b = 0; b < KB; b++) {
+        el x2, y2;
+        entry(x2, y2, b, i, false);
+        madd(X, Y, Z, x2, y2);
+      }
+    }
+#pragma unroll 1
+    for (int b = 0; b < KB; b++) {
+      // even k_b: the sum holds [k_b + 1] P_b; take P_b off
+      el sX = X, sY = Y, sZ = Z, px = tab[b][0][0], ny = tab[b][0][1];
+      GL_HS(hs_set(px, U_STRICT, 1.0); hs_set(ny, U_STRICT, 1.0);)
+      negk(ny, ny, K2);
+      norm(ny, ny);
+      madd(sX, sY, sZ, px, ny);
+      sel(X, sX, even[b]);
+      sel(Y, sY, even[b]);
+      sel(Z, sZ, even[b]);
+    }
+    bad |= is0(Z);
+    if (!valid | bad) return false;
+    el zinv, zz, t3, ax, ay;
+    inv(zinv, Z);
+    sqr(zz, zinv);
+    mul<2>(ax, X, zz);
+    mul<1>(t3, zz, zinv);
+    mul<2>(ay, Y, t3);
+    fp<N> x, y;
+    to_fq(x, ax);
+    to_fq(y, ay);
+    fp_store_be<N>(out, x);
+    fp_store_be<N>(out + NB, y);
+    return true;
+  }
+
   // element_pp_pow_zn on G1: out <- [z] B from the 8-bit-row table of element_pp_init (group_ops.cuh ec_pp_entry_lane:
   // affine Montgomery words), one mixed addition per byte of the scalar -- ec_pp_pow_lane in limb form.  false: the lane
   // needs the complete routine (two equal table points met: a doubling).

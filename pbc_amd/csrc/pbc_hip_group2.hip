@@ -51,6 +51,17 @@ __global__ void __launch_bounds__(kBlock, PBC_A_WAVES) al_gmulk_kernel(uint8_t *
     }
   }
 }
+// G1 of the 5-word fields (d159.param, f.param): the joint ladder in limb form (group_l5.cuh gmulk_lane)
+template <class KP, int KB>
+__global__ void __launch_bounds__(kBlock, 2) l5_gmulk_kernel(uint8_t *out, MultiArgs M, int zlen, uint8_t *flags, size_t n, KArgs<5> ka) {
+  size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
+  if (idx >= n) return;
+  const size_t L = 2 * (size_t) fpk<5>().fbytes;
+  const uint8_t *a[KB], *z[KB];
+#pragma unroll
+  for (int j = 0; j < KB; j++) { a[j] = M.a[j] + idx * M.astride; z[j] = M.z[j] + idx * M.zstride; }
+  flags[idx] = GL<5, KP>::template gmulk_lane<KB>(out + idx * L, a, z, zlen) ? 0 : 1;
+}
 template <class G>
 __global__ void __launch_bounds__(kBlock, 2) gt_multi_pow_kernel(uint8_t *out, MultiArgs M, int k, int zlen, size_t n, KArgs<G::NW> ka) {
   size_t idx = (size_t) blockIdx.x * kBlock + threadIdx.x;
@@ -170,10 +181,12 @@ static int multi_launch(pbc_hip_pairing_s *P, int group, int k, void *d_out, con
   const unsigned grid = (unsigned) ((n + kBlock - 1) / kBlock);
   uint8_t *o = (uint8_t *) d_out;
   const size_t lp = group_len(P, group);
-  if (!P->group_slow && group != 3 && P->type == 'a' && !P->a_generic && !P->a_multi_compose && (k == 2 || k == 3)) {
-    // type a on the 512-bit field: ONE ladder for all bases (four doublings and k additions per window; the composition
-    // doubles 4 k times).  A result that overlaps a base at another offset than its own is built in a temporary: a lane reads
-    // its own records before it writes, other lanes' records must not change under them.
+  const bool joint_a = P->type == 'a' && !P->a_generic && group != 3;
+  const bool joint_5 = group == 1 && P->nlimb == 5 && ((P->type == 'd' && P->deg == 3 && P->dconst.limb_ok) || (P->type == 'f' && P->fconst.pl_ok));
+  if (!P->group_slow && !P->a_multi_compose && (joint_a || joint_5) && (k == 2 || k == 3)) {
+    // type a on the 512-bit field, G1 of the five-word fields: ONE limb-form ladder for all bases (four doublings and k additions
+    // per window; the composition doubles 4 k times).  A result that overlaps a base at another offset than its own is built in a
+    // temporary: a lane reads its own records before it writes, other lanes' records must not change under them.
     bool overlap = false;
     for (int j = 0; j < k; j++) {
       const uint8_t *b = M.a[j];
@@ -183,9 +196,17 @@ static int multi_launch(pbc_hip_pairing_s *P, int group, int k, void *d_out, con
     uint8_t *flags = (uint8_t *) W.get(n + (overlap ? n * lp + 16 : 0));
     if (!flags) return 1;
     uint8_t *acc = overlap ? flags + ((n + 15) & ~(size_t) 15) : o;
-    if (k == 2) hipLaunchKernelGGL((al_gmulk_kernel<16, 2>), dim3(PBC_RGRID(al_gmulk_kernel<16, 2>)), dim3(kBlock), 0, s, acc, M, P->len_zr, flags, n, unit_counter(P, s), kargs<16>(P));
-    else hipLaunchKernelGGL((al_gmulk_kernel<16, 3>), dim3(PBC_RGRID(al_gmulk_kernel<16, 3>)), dim3(kBlock), 0, s, acc, M, P->len_zr, flags, n, unit_counter(P, s), kargs<16>(P));
-    hipLaunchKernelGGL(ec_multi_mul_kernel<FqOps<16>>, dim3(grid), dim3(kBlock), 0, s, acc, M, k, P->len_zr, (const uint8_t *) flags, n, kargs<16>(P));
+    if (joint_a) {
+      if (k == 2) hipLaunchKernelGGL((al_gmulk_kernel<16, 2>), dim3(PBC_RGRID(al_gmulk_kernel<16, 2>)), dim3(kBlock), 0, s, acc, M, P->len_zr, flags, n, unit_counter(P, s), kargs<16>(P));
+      else hipLaunchKernelGGL((al_gmulk_kernel<16, 3>), dim3(PBC_RGRID(al_gmulk_kernel<16, 3>)), dim3(kBlock), 0, s, acc, M, P->len_zr, flags, n, unit_counter(P, s), kargs<16>(P));
+      hipLaunchKernelGGL(ec_multi_mul_kernel<FqOps<16>>, dim3(grid), dim3(kBlock), 0, s, acc, M, k, P->len_zr, (const uint8_t *) flags, n, kargs<16>(P));
+    } else {
+      if (P->type == 'd' && k == 2) hipLaunchKernelGGL((l5_gmulk_kernel<KPd, 2>), dim3(grid), dim3(kBlock), 0, s, acc, M, P->len_zr, flags, n, kargs<5>(P));
+      else if (P->type == 'd') hipLaunchKernelGGL((l5_gmulk_kernel<KPd, 3>), dim3(grid), dim3(kBlock), 0, s, acc, M, P->len_zr, flags, n, kargs<5>(P));
+      else if (k == 2) hipLaunchKernelGGL((l5_gmulk_kernel<KPf, 2>), dim3(grid), dim3(kBlock), 0, s, acc, M, P->len_zr, flags, n, kargs<5>(P));
+      else hipLaunchKernelGGL((l5_gmulk_kernel<KPf, 3>), dim3(grid), dim3(kBlock), 0, s, acc, M, P->len_zr, flags, n, kargs<5>(P));
+      hipLaunchKernelGGL(ec_multi_mul_kernel<FqOps<5>>, dim3(grid), dim3(kBlock), 0, s, acc, M, k, P->len_zr, (const uint8_t *) flags, n, kargs<5>(P));
+    }
     HIP_TRY(hipGetLastError());
     if (overlap) HIP_TRY(hipMemcpyAsync(d_out, acc, n * lp, hipMemcpyDeviceToDevice, s));
     return 0;

@@ -492,6 +492,13 @@ int hostsim_multi(void *h, int group, int k, uint8_t *out, const uint8_t *a1, co
         const uint8_t *pa[3], *pz[3];
         for (int j = 0; j < 3; j++) { pa[j] = M.a[j] + i * M.astride; pz[j] = M.z[j] + i * M.zstride; }
         ok = k == 2 ? GAL<16>::gmulk_lane<2>(out + i * L, pa, pz, P->len_zr) : GAL<16>::gmulk_lane<3>(out + i * L, pa, pz, P->len_zr);
+      } else if (!hostsim_slow_group && group == 1 && (k == 2 || k == 3) && P->nlimb == 5 &&
+                 ((P->type == 'd' && P->deg == 3 && P->dconst.limb_ok) || (P->type == 'f' && P->fconst.pl_ok))) {
+        // G1 of the five-word fields: the same on group_l5.cuh
+        const uint8_t *pa[3], *pz[3];
+        for (int j = 0; j < 3; j++) { pa[j] = M.a[j] + i * M.astride; pz[j] = M.z[j] + i * M.zstride; }
+        if (P->type == 'd') ok = k == 2 ? GL<5, KPd>::gmulk_lane<2>(out + i * L, pa, pz, P->len_zr) : GL<5, KPd>::gmulk_lane<3>(out + i * L, pa, pz, P->len_zr);
+        else ok = k == 2 ? GL<5, KPf>::gmulk_lane<2>(out + i * L, pa, pz, P->len_zr) : GL<5, KPf>::gmulk_lane<3>(out + i * L, pa, pz, P->len_zr);
       } else
       if (!hostsim_slow_group) { HS_DISPATCH_G(P, group, ok = ec_multi_mul_fast_lane<F>(out + i * L, M, i, k, P->len_zr)); }
       if (!ok) {

@@ -382,6 +382,36 @@ def test_joint_ladder_of_type_a_equals_the_composition(hips):
     C.clear()
 
 
+@pytest.mark.parametrize("key,name", [("d", "d_chain256.vec"), ("f", "f_chain128.vec")])
+def test_joint_ladder_of_the_five_word_fields_equals_the_composition(hips, key, name):
+    """the same on G1 of d159.param / f.param (group_l5.cuh gmulk_lane): 3000 units with equal / opposite bases, a base off
+    the curve, special scalars -- against the single-base ladders + additions ("hip_multi_compose 1")"""
+    import pbc_amd
+    H = hips[key]
+    C = pbc_amd.Pairing(_param(PARAM_OF.get(key, key)) + "hip_multi_compose 1\n")
+    v = golden(name)
+    n = 3000
+    rng = np.random.default_rng(73)
+    r = _order(key)
+    zl = H.length_in_bytes_Zr
+    idx = [rng.integers(0, v.n, n) for _ in range(3)]
+    idx[1][::9] = idx[0][::9]
+    X = [np.ascontiguousarray(v.g1[idx[t]]) for t in range(3)]
+    X[2][3::9] = H.element_group_op("neg", 1, X[0][3::9])
+    X[1][7::100, 5] ^= 1
+    Z = []
+    for t in range(3):
+        ks = [int.from_bytes(rng.bytes(zl), "big") % r for _ in range(n)]
+        for q, k in enumerate([0, 1, 2, r - 1, r, r + 1, (1 << (8 * zl)) - 1, 1 << (8 * zl - 1)]):
+            for rep in range(6):
+                ks[(q * 7 + t * 3 + rep * 131) % n] = k
+        Z.append(np.stack([_be(k, zl) for k in ks]))
+    Z[2][3::9] = Z[0][3::9]
+    for k in (2, 3):
+        assert np.array_equal(H.element_pow_multi(1, X[:k], Z[:k]), C.element_pow_multi(1, X[:k], Z[:k])), k
+    C.clear()
+
+
 def test_two_threads_issue_on_one_stream(hips):
     """two host threads enqueue two-pass operations (element_mul_zn on a.param G1: fast kernel + the complete kernel for the
     lanes it flags, sharing a flags workspace keyed by (device, stream)) on the SAME stream of one object: each call's

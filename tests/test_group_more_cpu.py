@@ -92,9 +92,10 @@ def test_multi_exponentiation_kernel_source_on_host(sims, key, group):
     assert np.array_equal(S.multi(group, [A1, A2], [N1, N2]), P2)
     assert np.array_equal(S.multi(group, [A1, A2, A3], [N1, N2, N3]), P3)
     if group != 3:
-        # the fast pass (one doubling + one incomplete addition per bit) serves the ordinary rows; the rows with
-        # a2 = a1 or a2 = -a1 are reported and take the complete routine -- which alone gives the same bytes
-        assert 0 < S.fallbacks() <= 4
+        # the fast pass (one doubling + one incomplete addition per bit; G1 of type a and of the five-word fields: the joint
+        # limb-form window ladder) serves the ordinary rows; the rows with a2 = a1 or a2 = -a1 (and, on the window ladder,
+        # with a zero scalar) are reported and take the complete routine -- which alone gives the same bytes
+        assert 0 < S.fallbacks() <= 8
         S.group_mode(1)
         assert np.array_equal(S.multi(group, [A1, A2], [N1, N2]), P2)
         assert np.array_equal(S.multi(group, [A1, A2, A3], [N1, N2, N3]), P3)

@@ -23,7 +23,7 @@
  * after the other, never interleaved (round 6; tests/test_gpu_group2.py::test_two_threads_issue_on_one_stream).  The
  * per-launch unit counters ("hip_dynamic 1") are slots of a ring, one per launch.  Device memory: every host-buffer form
  * works on buffers the object keeps (hipMalloc; pbc_hip_pairing_release_workspaces / pbc_hip_pairing_clear free them); only
- * the _dev forms of element_pow2/3_zn and of the limb-image calls take a stream-ordered temporary (hipMallocAsync on the
+ * the _dev forms of element_pow2/3_zn on the composition route and of the limb-image calls take a stream-ordered temporary (hipMallocAsync on the
  * caller's stream) -- observed to misbehave under the system HIP runtime when called from short-lived threads (round 6), so
  * nothing the reference-side glue reaches uses it.
  *
@@ -312,11 +312,15 @@ int pbc_hip_element_prod_pairing_batch_limbs_dev(pbc_hip_pairing_t *p, void *d_g
  *     reference's contract (mpz_invert fails); it gives 0 here.  pbc_hip_zr_from_hash_batch: element_from_hash on Zr
  *     (fp_from_hash, arith/montfp.c:440-448 over pbc_mpz_from_hash arith/field.c:643-668) for n digests of hlen bytes.
  *   element_pow2_zn / element_pow3_zn (include/pbc_field.h:496-531 -> arith/field.c:153-241) on G1, G2 (group 1, 2:
- *     [n1] a1 + [n2] a2 (+ [n3] a3)) and GT (group 3: a1^n1 a2^n2 (a3^n3)).  Default route: the composition of the
- *     library's tuned single-base ladders (element_mul_zn / element_pow_zn per base, then the additions / products; the
- *     faster route on MI355X, profiles/r05_notes.md).  "hip_group_slow 1" in the parameter text: Shamir's trick -- a
- *     per-lane table of the subset sums, ONE doubling (squaring) per scalar bit for all bases.  Both are complete (any
- *     point of the curve, any scalar of length_in_bytes_Zr bytes) and give the same bytes; out may overlap any base.
+ *     [n1] a1 + [n2] a2 (+ [n3] a3)) and GT (group 3: a1^n1 a2^n2 (a3^n3)).  Default route on G1 / G2 of type a (512-bit
+ *     field) and G1 of the five-word type d / f fields: ONE limb-form signed-window ladder for all bases -- a table of odd
+ *     multiples per base, four doublings and k additions per window (round 6: 1.45-1.6 times the composition); the lanes
+ *     it cannot finish (equal or opposite bases meeting in the accumulator, a base off the curve, a zero scalar, the
+ *     result O) take the complete multi-scalar kernel.  Elsewhere (and with "hip_multi_compose 1"): the composition of the
+ *     tuned single-base ladders (element_mul_zn / element_pow_zn per base, then the additions / products).
+ *     "hip_group_slow 1" in the parameter text: Shamir's trick on the word-form arithmetic -- a per-lane table of the
+ *     subset sums, ONE doubling (squaring) per scalar bit for all bases.  All routes are complete (any point of the curve,
+ *     any scalar of length_in_bytes_Zr bytes) and give the same bytes; out may overlap any base.
  *   The all-zero record on types a / a1 (curve y^2 = x^3 + x): the group law above reads and writes it as O, although
  *     (0, 0) is a finite point of order two there and pbc_hip_element_snprint prints the record as "[0, 0]" (what the
  *     reference prints for that point).  P + (-P) therefore prints as "[0, 0]", not "O", and adding the genuine

@@ -37,7 +37,7 @@ struct DW {
   typedef typename D::fq fq;
   typedef typename D::f3 f3;
   static constexpr int L = Limbs29<ND>::L;
-  static_assert(L == 6, "the row tables are generated for six-limb fields (eight terms per sum fill a column)");
+  static_assert(8 * L + L <= 63, "the row tables hold sums of up to eight terms: they must fit a column (fp.cuh sop_limbs) -- six and seven limbs do");
 
   static PBC_DEV uint32_t *slot(int s) { return g_lds_dw<ND> + s * L; }
   static PBC_DEV const uint32_t *rows() { return g_lds_dw<ND> + dw::kSlots * L; }
@@ -341,7 +341,7 @@ struct DW {
   // element_prod_pairing, first kernel: the Miller value of ONE TERM -> its record of the workspace (kRec words: the six slots
   // of f as they are, then the validity flag).  cc_millers_no_denom_affine (d_param.c:591-708) squares one accumulator for all
   // terms; the product of the terms' own Miller values is the same element of F_q^6 up to the lines' factors in F_q^*.
-  static constexpr int kRec = 40;
+  static constexpr int kRec = (6 * L + 1 + 7) & ~7;   // 40 words for six limbs, 48 for seven
   static __device__ void miller_term(uint32_t *rec, const uint8_t *g1, const uint8_t *g2, const uint64_t *sched) {
     begin();
     __shared__ int valid_s;

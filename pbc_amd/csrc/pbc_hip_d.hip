@@ -77,7 +77,10 @@ static const DwSched &dw_schedules(pbc_hip_pairing_s *P) {
   }
   return P->dw_sched;
 }
-static bool dw_capable(const pbc_hip_pairing_s *P) { return P->type == 'd' && P->nlimb == 5 && P->deg == 3; }
+// (five-word fields: six limbs; six-word fields: seven -- the level programs do not know the field; eight limbs would need sums of
+// at most six terms, i.e. other tables)
+static bool dw_capable(const pbc_hip_pairing_s *P) { return P->type == 'd' && (P->nlimb == 5 || P->nlimb == 6) && P->deg == 3; }
+#define PBC_DISPATCH_DW(P, ...) do { if ((P)->nlimb == 5) { constexpr int N = 5; __VA_ARGS__; } else { constexpr int N = 6; __VA_ARGS__; } } while (0)
 // (24 KB, read-only, one copy per device the object runs on -- uploaded on first use, kept with the object)
 static const uint64_t *dw_device_schedules(pbc_hip_pairing_s *P, const DwSched **host) {
   const DwSched &S = dw_schedules(P);
@@ -163,16 +166,18 @@ int launch_d(pbc_hip_pairing_s *P, void *d_gt, const void *d_g1, const void *d_g
     const DwSched *S = nullptr;
     const uint64_t *d_sched = dw_device_schedules(P, &S);
     if (!d_sched) return 1;
-    hipLaunchKernelGGL(dw_pairing_kernel<5>, dim3((unsigned) n), dim3(64), 0, s, (uint8_t *) d_gt, (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, d_sched + S->off[dw::SCHED_PAIRING], kargs<5>(P));
+    PBC_DISPATCH_DW(P, hipLaunchKernelGGL(dw_pairing_kernel<N>, dim3((unsigned) n), dim3(64), 0, s, (uint8_t *) d_gt, (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, d_sched + S->off[dw::SCHED_PAIRING], kargs<N>(P)));
   } else if (waves) {
     const DwSched *S = nullptr;
     const uint64_t *d_sched = dw_device_schedules(P, &S);
     if (!d_sched) return 1;
     const size_t terms = n * (size_t) k;
-    uint32_t *recs = (uint32_t *) W.get(terms * DW<5>::kRec * sizeof(uint32_t));
+    uint32_t *recs = (uint32_t *) W.get(terms * DW<6>::kRec * sizeof(uint32_t));
     if (!recs) return 1;
-    hipLaunchKernelGGL(dw_miller_kernel<5>, dim3((unsigned) terms), dim3(64), 0, s, recs, (const uint8_t *) d_g1, (const uint8_t *) d_g2, terms, d_sched + S->off[dw::SCHED_MILLER], kargs<5>(P));
-    hipLaunchKernelGGL(dw_finish_kernel<5>, dim3((unsigned) n), dim3(64), 0, s, (uint8_t *) d_gt, (const uint32_t *) recs, n, k, d_sched + S->off[dw::SCHED_FINISH], kargs<5>(P));
+    PBC_DISPATCH_DW(P, {
+      hipLaunchKernelGGL(dw_miller_kernel<N>, dim3((unsigned) terms), dim3(64), 0, s, recs, (const uint8_t *) d_g1, (const uint8_t *) d_g2, terms, d_sched + S->off[dw::SCHED_MILLER], kargs<N>(P));
+      hipLaunchKernelGGL(dw_finish_kernel<N>, dim3((unsigned) n), dim3(64), 0, s, (uint8_t *) d_gt, (const uint32_t *) recs, n, k, d_sched + S->off[dw::SCHED_FINISH], kargs<N>(P));
+    });
   } else if (k == 1) {
     PBC_DISPATCH_D(P, hipLaunchKernelGGL((d_prod_pairing_kernel<N, DEG>), dim3(kDResident<N, DEG> ? PBC_RGRID(d_prod_pairing_kernel<N, DEG>) : grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
                                                 (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, 1, (uint32_t *) nullptr, kDResident<N, DEG> ? unit_counter(P, s) : nullptr, kargs<N>(P)));
@@ -202,8 +207,8 @@ int pp_apply_launch_d(pbc_hip_pp_s *pp, void *d_gt, const void *d_g2, size_t n, 
     const DwSched *S = nullptr;
     const uint64_t *d_sched = dw_device_schedules(P, &S);
     if (!d_sched || S->lines > dw::kMaxLines) return 1;
-    hipLaunchKernelGGL(dw_pp_apply_kernel<5>, dim3((unsigned) n), dim3(64), 0, s, (uint8_t *) d_gt, (const uint32_t *) pp->tab, (const uint32_t *) pp->valid, (const uint8_t *) d_g2, n,
-                       d_sched + S->off[dw::SCHED_PP], kargs<5>(P));
+    PBC_DISPATCH_DW(P, hipLaunchKernelGGL(dw_pp_apply_kernel<N>, dim3((unsigned) n), dim3(64), 0, s, (uint8_t *) d_gt, (const uint32_t *) pp->tab, (const uint32_t *) pp->valid, (const uint8_t *) d_g2, n,
+                                          d_sched + S->off[dw::SCHED_PP], kargs<N>(P)));
     HIP_TRY(hipGetLastError());
     return 0;
   }

@@ -122,3 +122,33 @@ def test_pairing_pp_apply_on_wavefronts(hips, lane, oracles, n):
     one = np.zeros(120, np.uint8)
     one[19] = 1
     assert np.array_equal(H.pp_init(bad).apply(Q[:min(n, 4)]), np.tile(one, (min(n, 4), 1)))
+
+
+# ---- the six-word type d fields (seven limbs): the same level programs, other curves and loop lengths ----
+@pytest.mark.parametrize("pname", ["d278027-190-181", "d277699-175-167", "d105171-196-185"])
+def test_six_word_fields_on_wavefronts(oracles, pname):
+    """d = 3 on six words (175 / 190 / 196-bit q; 22- / 24- / 25-byte coordinates): pairings, products and pairing_pp_apply of
+    small batches against the reference's vectors, the lane kernels ("hip_dwave_max 0") and the C restatement"""
+    import pbc_amd
+    H, Ln = pbc_amd.Pairing(_param(pname)), pbc_amd.Pairing(_param(pname) + "hip_dwave_max 0\n")
+    for name in ("_rand12.vec", "_edge8.vec"):
+        v = golden(pname + name)
+        assert np.array_equal(H.element_pairing(v.g1, v.g2), v.gt)
+    w = golden(pname + "_prod3x4_edge.vec")
+    assert np.array_equal(H.element_prod_pairing(w.g1, w.g2, w.k), w.gt)
+    v = golden(pname + "_rand12.vec")
+    rng = np.random.default_rng(5)
+    n = 700
+    i, j = rng.integers(0, v.n, n), rng.integers(0, v.n, n)
+    g1, g2 = np.ascontiguousarray(v.g1[i]), np.ascontiguousarray(v.g2[j])
+    g1[::53, 2] ^= 1                                            # off the curve: the identity
+    got = H.element_pairing(g1, g2)
+    assert np.array_equal(got, Ln.element_pairing(g1, g2))
+    assert np.array_equal(got[:6], oracles[pname].pairing_batch(g1[:6], g2[:6]))
+    for k in (2, 7):
+        m = n // k
+        assert np.array_equal(H.element_prod_pairing(g1[:m * k], g2[:m * k], k), Ln.element_prod_pairing(g1[:m * k], g2[:m * k], k)), k
+    pp, pl = H.pp_init(v.g1[1]), Ln.pp_init(v.g1[1])
+    assert np.array_equal(pp.apply(g2), pl.apply(g2))
+    assert np.array_equal(pp.apply(g2[:4]), H.element_pairing(np.tile(v.g1[1], (4, 1)), g2[:4]))
+    pp.clear(); pl.clear(); H.clear(); Ln.clear()

@@ -467,6 +467,7 @@ class Model:
     def __init__(self, pname, progs):
         P = param(pname)
         self.q, self.P, self.progs = P["q"], P, progs
+        self.fb = (P["q"].bit_length() + 7) // 8     # length_in_bytes of an F_q coordinate
         q = self.q
         c = [P["coeff0"], P["coeff1"], P["coeff2"]]
         xp3 = [(-x) % q for x in c]
@@ -538,7 +539,7 @@ class Model:
 
     def set_point(self, g1):
         """the first argument: curve_is_valid_point (the driver's lane code), then the point track's state"""
-        q, e, fb = self.q, self.env, 20
+        q, e, fb = self.q, self.env, self.fb
         gi = lambda b, i: int.from_bytes(b[fb * i:fb * (i + 1)], "big") % q
         Px, Py = gi(g1, 0), gi(g1, 1)
         a, b = self.P["a"], self.P["b"]
@@ -547,7 +548,7 @@ class Model:
 
     def set_twist(self, g2):
         """the second argument: the check on the twist, the twist map, and f = 1"""
-        q, e, fb = self.q, self.env, 20
+        q, e, fb = self.q, self.env, self.fb
         gi = lambda b, i: int.from_bytes(b[fb * i:fb * (i + 1)], "big") % q
         Qx, Qy = [gi(g2, i) for i in range(3)], [gi(g2, 3 + i) for i in range(3)]
         a, b, v = self.P["a"], self.P["b"], self.v
@@ -798,12 +799,15 @@ def load_vec(path):
     return g1, g2, gt
 
 
-def check(progs, count=6):
-    M = Model("d159", progs)
+OTHER_FIELDS = ["d278027-190-181", "d277699-175-167", "d105171-196-185"]      # six-word fields (seven limbs): the same tables
+
+
+def check(progs, count=6, others=True):
     bad = 0
     levels = {}
-    want_of = lambda b: [int.from_bytes(b[20 * c:20 * c + 20], "big") for c in range(6)]
     ident = [1, 0, 0, 0, 0, 0]
+    M = Model("d159", progs)
+    want_of = lambda b, fb=20: [int.from_bytes(b[fb * c:fb * c + fb], "big") for c in range(6)]
     for name in ("d_rand32.vec", "d_edge20.vec"):
         g1, g2, gt = load_vec(os.path.join(ROOT, "tests", "golden", name))
         for i in range(min(count, len(gt))):
@@ -829,6 +833,15 @@ def check(progs, count=6):
             if (r or ident) != want_of(gt[i]):
                 bad += 1
                 print("MISMATCH (product)", name, i)
+    for pname in (OTHER_FIELDS if others else []):    # the programs do not know the field: other curves, other loop lengths
+        M = Model(pname, progs)
+        for name in (pname + "_rand12.vec", pname + "_edge8.vec"):
+            g1, g2, gt = load_vec(os.path.join(ROOT, "tests", "golden", name))
+            for i in range(min(3, len(gt))):
+                r = M.pairing(g1[i], g2[i])
+                if (r or ident) != want_of(gt[i], M.fb):
+                    bad += 1
+                    print("MISMATCH", name, i)
     return bad, levels
 
 

@@ -37,7 +37,11 @@ struct DW {
   typedef typename D::fq fq;
   typedef typename D::f3 f3;
   static constexpr int L = Limbs29<ND>::L;
-  static_assert(8 * L + L <= 63, "the row tables hold sums of up to eight terms: they must fit a column (fp.cuh sop_limbs) -- six and seven limbs do");
+  // (the row tables hold sums of up to eight terms.  Six and seven limbs: eight products of every limb pair and the reduction's
+  // fit a 64-bit column, fp.cuh sop_limbs.  Eight limbs: the eight terms alone do -- 64 products below 2^58 --, and the four
+  // lanes' joined columns are relieved exactly, wide_squeeze, before the reduction adds its own: exec_split8.)
+  static constexpr bool kSqueeze = 8 * L + L > 63;
+  static_assert(4 * L + L <= 63 && 8 * L <= 64, "sums of four terms on a lane, of eight on four lanes");
 
   static PBC_DEV uint32_t *slot(int s) { return g_lds_dw<ND> + s * L; }
   static PBC_DEV const uint32_t *rows() { return g_lds_dw<ND> + dw::kSlots * L; }
@@ -134,6 +138,7 @@ struct DW {
       W.c[k] += ((uint64_t) phi << 32) | plo;                             // + the other pair's (0<->2, 1<->3)
     }
     fl<ND> res;
+    if constexpr (kSqueeze) wide_squeeze<ND>(W);
     wide_reduce<ND>(res, W);
     __builtin_amdgcn_wave_barrier();
     if (R.active && s == 0) put((int) (R.w[0] & 255u), res);
@@ -145,7 +150,7 @@ struct DW {
   static PBC_DEV void exec(const Rows &R, const Rows &R4, int T) {
     if (T <= 2) exec_T<2>(R);
     else if (T <= 4) exec_T<4>(R);
-    else if (PBC_DW_SPLIT) exec_split8(R4);
+    else if constexpr (PBC_DW_SPLIT || kSqueeze) exec_split8(R4);
     else exec_T<8>(R);
   }
   // ---- lane 0: constants; bytes -> slots, curve checks, twist map (d_setup_lane) ----
@@ -281,7 +286,7 @@ struct DW {
   static PBC_DEV void run_entry(uint64_t e, const uint32_t *tab) {        // one LEVEL entry
     const int T = (int) ((e >> 34) & 15u);
     const Lev a = ent_a(e), b = ent_b(e);
-    const Rows R = T > 4 && PBC_DW_SPLIT ? load_rows4(a, b) : load_rows(a, b);
+    const Rows R = T > 4 && (PBC_DW_SPLIT || kSqueeze) ? load_rows4(a, b) : load_rows(a, b);
     if ((e >> 55) & 1u) {
       const int line = (int) ((e >> 42) & 4095u);
       const Line ln = line_fetch(tab, line);
@@ -341,7 +346,7 @@ struct DW {
   // element_prod_pairing, first kernel: the Miller value of ONE TERM -> its record of the workspace (kRec words: the six slots
   // of f as they are, then the validity flag).  cc_millers_no_denom_affine (d_param.c:591-708) squares one accumulator for all
   // terms; the product of the terms' own Miller values is the same element of F_q^6 up to the lines' factors in F_q^*.
-  static constexpr int kRec = (6 * L + 1 + 7) & ~7;   // 40 words for six limbs, 48 for seven
+  static constexpr int kRec = (6 * L + 1 + 7) & ~7;   // 40 words for six limbs, 48 for seven, 56 for eight
   static __device__ void miller_term(uint32_t *rec, const uint8_t *g1, const uint8_t *g2, const uint64_t *sched) {
     begin();
     __shared__ int valid_s;

@@ -77,10 +77,10 @@ static const DwSched &dw_schedules(pbc_hip_pairing_s *P) {
   }
   return P->dw_sched;
 }
-// (five-word fields: six limbs; six-word fields: seven -- the level programs do not know the field; eight limbs would need sums of
-// at most six terms, i.e. other tables)
-static bool dw_capable(const pbc_hip_pairing_s *P) { return P->type == 'd' && (P->nlimb == 5 || P->nlimb == 6) && P->deg == 3; }
-#define PBC_DISPATCH_DW(P, ...) do { if ((P)->nlimb == 5) { constexpr int N = 5; __VA_ARGS__; } else { constexpr int N = 6; __VA_ARGS__; } } while (0)
+// (five-, six- and seven-word fields: six, seven and eight limbs -- the level programs do not know the field)
+static bool dw_capable(const pbc_hip_pairing_s *P) { return P->type == 'd' && P->nlimb >= 5 && P->nlimb <= 7 && P->deg == 3; }
+#define PBC_DISPATCH_DW(P, ...) do { if ((P)->nlimb == 5) { constexpr int N = 5; __VA_ARGS__; } else if ((P)->nlimb == 6) { constexpr int N = 6; __VA_ARGS__; } \
+                                     else { constexpr int N = 7; __VA_ARGS__; } } while (0)
 // (24 KB, read-only, one copy per device the object runs on -- uploaded on first use, kept with the object)
 static const uint64_t *dw_device_schedules(pbc_hip_pairing_s *P, const DwSched **host) {
   const DwSched &S = dw_schedules(P);
@@ -172,7 +172,7 @@ int launch_d(pbc_hip_pairing_s *P, void *d_gt, const void *d_g1, const void *d_g
     const uint64_t *d_sched = dw_device_schedules(P, &S);
     if (!d_sched) return 1;
     const size_t terms = n * (size_t) k;
-    uint32_t *recs = (uint32_t *) W.get(terms * DW<6>::kRec * sizeof(uint32_t));
+    uint32_t *recs = (uint32_t *) W.get(terms * DW<7>::kRec * sizeof(uint32_t));
     if (!recs) return 1;
     PBC_DISPATCH_DW(P, {
       hipLaunchKernelGGL(dw_miller_kernel<N>, dim3((unsigned) terms), dim3(64), 0, s, recs, (const uint8_t *) d_g1, (const uint8_t *) d_g2, terms, d_sched + S->off[dw::SCHED_MILLER], kargs<N>(P));

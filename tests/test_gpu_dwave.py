@@ -43,8 +43,8 @@ def test_wave_kernel_on_fresh_random_inputs(hips, oracles):
 
 
 def test_other_five_word_parameters_keep_the_lane_kernel(hips):
-    """the wave kernel is built for d = 3 on five words: type g (d = 5) and the wider type d fields are not routed to it"""
-    for key, name in (("g149", "g149_rand16.vec"), ("d201", "d201_rand12.vec")):
+    """the wave kernel is built for d = 3: type g (d = 5, five words) is not routed to it"""
+    for key, name in (("g149", "g149_rand16.vec"),):
         v = golden(name)
         assert np.array_equal(hips[key].element_pairing(v.g1, v.g2), v.gt)
 
@@ -124,11 +124,12 @@ def test_pairing_pp_apply_on_wavefronts(hips, lane, oracles, n):
     assert np.array_equal(H.pp_init(bad).apply(Q[:min(n, 4)]), np.tile(one, (min(n, 4), 1)))
 
 
-# ---- the six-word type d fields (seven limbs): the same level programs, other curves and loop lengths ----
-@pytest.mark.parametrize("pname", ["d278027-190-181", "d277699-175-167", "d105171-196-185"])
-def test_six_word_fields_on_wavefronts(oracles, pname):
-    """d = 3 on six words (175 / 190 / 196-bit q; 22- / 24- / 25-byte coordinates): pairings, products and pairing_pp_apply of
-    small batches against the reference's vectors, the lane kernels ("hip_dwave_max 0") and the C restatement"""
+# ---- the six- and seven-word type d fields (seven / eight limbs): the same level programs, other curves and loop lengths ----
+@pytest.mark.parametrize("pname", ["d278027-190-181", "d277699-175-167", "d105171-196-185", "d201", "d224"])
+def test_wider_fields_on_wavefronts(oracles, pname):
+    """d = 3 on six and seven words (175 ... 224-bit q; 22- ... 28-byte coordinates; eight limbs: the four lanes' joined columns of an
+    eight-term sum are relieved before the reduction): pairings, products and pairing_pp_apply of small batches against the
+    reference's vectors, the lane kernels ("hip_dwave_max 0") and the C restatement"""
     import pbc_amd
     H, Ln = pbc_amd.Pairing(_param(pname)), pbc_amd.Pairing(_param(pname) + "hip_dwave_max 0\n")
     for name in ("_rand12.vec", "_edge8.vec"):

@@ -152,4 +152,4 @@ def test_host_schedule_of_the_wave_kernel_is_the_model_s():
         want = dw_gen.flat_schedule(kind)
         n = pbc_amd.lib().pbc_hip_diag_dw_schedule(P._h, which, buf.ctypes.data_as(ctypes.c_void_p), len(buf))
         assert n == len(want) and [int(x) for x in buf[:n]] == want, kind
-    assert pbc_amd.lib().pbc_hip_diag_dw_schedule(pbc_amd.Pairing(pbc_amd.param_text("d201"))._h, 0, buf.ctypes.data_as(ctypes.c_void_p), len(buf)) == 0
+    assert pbc_amd.lib().pbc_hip_diag_dw_schedule(pbc_amd.Pairing(pbc_amd.param_text("g149"))._h, 0, buf.ctypes.data_as(ctypes.c_void_p), len(buf)) == 0

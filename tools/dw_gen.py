@@ -799,7 +799,7 @@ def load_vec(path):
     return g1, g2, gt
 
 
-OTHER_FIELDS = ["d278027-190-181", "d277699-175-167", "d105171-196-185"]      # six-word fields (seven limbs): the same tables
+OTHER_FIELDS = ["d278027-190-181", "d277699-175-167", "d105171-196-185", "d201", "d224"]      # six- and seven-word fields: the same tables
 
 
 def check(progs, count=6, others=True):

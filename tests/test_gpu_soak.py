@@ -94,3 +94,39 @@ def test_full_parity_on_uniformly_random_products(hips, tmp_path):
     bad = np.nonzero((got != v.gt).any(axis=1))[0]
     _record("a-prod16", info, v.n, len(bad), t1 - t0, time.time() - t1)
     assert len(bad) == 0, "products that differ from the reference: %s" % bad[:16]
+
+
+WAVE_LOG2 = int(os.environ.get("PBC_SOAK_LOG2_WAVE", "12"))
+
+
+@pytest.mark.gpu
+@needs_ref
+@pytest.mark.parametrize("name", ["d", "d278027-190-181", "d201", "d224"])
+def test_wave_kernels_on_uniformly_random_and_crafted_inputs(name, hips, tmp_path):
+    """the small-batch route of type d (one pairing / one TERM per wavefront, pairing_dw.cuh) on inputs no fixture holds: 2^12
+    uniformly random pairs and the crafted block (limb patterns in the field's own radix: six, seven and eight limbs) in calls
+    of at most 4096 units, 2^10 random four-term products, and pairing_pp_apply on the random second arguments -- against the
+    unmodified reference"""
+    import pbc_amd
+    P = hips[name]
+    rbits = _rbits(P)
+    t0 = time.time()
+    v, info = oracle.ref_soak(_param_path(name), 1 << WAVE_LOG2, 1, SEED + 2, str(tmp_path / "soak.vec"), rbits)
+    w, _ = oracle.ref_soak(_param_path(name), 1 << (WAVE_LOG2 - 2), 4, SEED + 3, str(tmp_path / "soakp.vec"), rbits)
+    t1 = time.time()
+    assert info["crafted_units"] > 100
+    bad = 0
+    for a in range(0, v.n, 4096):
+        got = P.element_pairing(v.g1[a:a + 4096], v.g2[a:a + 4096])
+        bad += int((got != v.gt[a:a + 4096]).any(axis=1).sum())
+    gotp = P.element_prod_pairing(w.g1, w.g2, 4)
+    badp = int((gotp != w.gt).any(axis=1).sum())
+    # pairing_pp_apply: e(P_0, Q_i) for the first 512 random Q_i = what the lane kernels give for the same pairs
+    lane = pbc_amd.Pairing(open(_param_path(name)).read() + "hip_dwave_max 0\n")
+    m = 512
+    pp = P.pp_init(v.g1[0])
+    badq = int((pp.apply(v.g2[:m]) != lane.element_pairing(np.tile(v.g1[0], (m, 1)), v.g2[:m])).any(axis=1).sum())
+    pp.clear()
+    lane.clear()
+    _record("wave-" + name, dict(info, products_of_4=int(w.n), pp_apply_units=m), v.n + w.n + m, bad + badp + badq, t1 - t0, time.time() - t1)
+    assert bad == 0 and badp == 0 and badq == 0, (bad, badp, badq)

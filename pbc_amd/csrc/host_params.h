@@ -45,6 +45,7 @@ inline int fail(const char *fmt, ...) {
 // ---------------------------------------------------------------------------------------
 #ifndef PBC_D_WAVE_MAX
 #define PBC_D_WAVE_MAX 5120
+#define PBC_F_WAVE_MAX 4096
 #endif
 constexpr size_t kProdChunkDefault = (size_t) 1 << 22;   // type a products: terms per launch of the one-term-per-lane kernels unless "hip_prod_chunk N" says otherwise
 // the schedules of the wave-per-pairing type d kernels (dw_sched.h): four of them one after the other
@@ -108,6 +109,8 @@ struct pbc_hip_pairing_s {
   int raw_t;                 // ... t = 64-bit limbs of the reference's montfp element (0: constants not derived yet)
   void *counters;            // library only: the unit counters of dynamic resident launches (pbc_hip.hip unit_counter)
   void *host_ctx;            // library only: per-device streams and chunk buffers of the host-buffer path (pbc_hip.hip)
+  std::vector<uint64_t> fw_sched;   // type f, five-word BN fields: the schedule of one pairing on the wave kernel (pbc_hip_f.hip fw_schedule, fw_sched.h)
+  size_t f_wave_max;                // ... single pairings in batches up to this size take it ("hip_fwave_max N")
   DwSched dw_sched;                 // type d, five-word fields: the schedules of the wave kernels (pbc_hip_d.hip dw_schedules, dw_sched.h)
   std::string param_text;    // the parameter text the object was built from (text formats: pbc_hip_param_snprint, host_text.h)
 };
@@ -684,6 +687,13 @@ static int init_type_f(pbc_hip_pairing_s *P, const char *txt, size_t len) {
         P->fconst.bn_xbits = nb;
       }
     }
+  }
+  {
+    // small batches of single pairings on the five-word BN fields: one pairing per WAVEFRONT (pairing_fw.cuh) up to this batch
+    // size ("hip_fwave_max N", 0 = never)
+    int fwave_max = PBC_F_WAVE_MAX;
+    param_int(txt, len, "hip_fwave_max", fwave_max);
+    P->f_wave_max = fwave_max < 0 ? 0 : (size_t) fwave_max;
   }
   P->nlimb = NF;
   P->len_fq = (q.bits() + 7) / 8;

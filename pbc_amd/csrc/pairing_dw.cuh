@@ -29,9 +29,14 @@
 #endif
 namespace pbc {
 
-template <int ND> __shared__ __attribute__((aligned(16))) uint32_t g_lds_dw[dw::kSlots * Limbs29<ND>::L + dw::kRows * 5];
+// (the machine does not know the pairing: TB names the tables -- slots, rows -- it runs; pairing_fw.cuh runs type f's on it)
+struct DwTables {
+  static constexpr int kSlots = dw::kSlots, kRows = dw::kRows;
+  static PBC_DEV const uint32_t *rows_src() { return dw::g_rows; }
+};
+template <int ND, class TB> __shared__ __attribute__((aligned(16))) uint32_t g_lds_wv[TB::kSlots * Limbs29<ND>::L + TB::kRows * 5];
 
-template <int ND>
+template <int ND, class TB = DwTables>
 struct DW {
   typedef TypeMNT<ND, 3> D;
   typedef typename D::fq fq;
@@ -43,8 +48,8 @@ struct DW {
   static constexpr bool kSqueeze = 8 * L + L > 63;
   static_assert(4 * L + L <= 63 && 8 * L <= 64, "sums of four terms on a lane, of eight on four lanes");
 
-  static PBC_DEV uint32_t *slot(int s) { return g_lds_dw<ND> + s * L; }
-  static PBC_DEV const uint32_t *rows() { return g_lds_dw<ND> + dw::kSlots * L; }
+  static PBC_DEV uint32_t *slot(int s) { return g_lds_wv<ND, TB> + s * L; }
+  static PBC_DEV const uint32_t *rows() { return g_lds_wv<ND, TB> + TB::kSlots * L; }
   static PBC_DEV void put(int s, const fl<ND> &a) {
 #pragma unroll
     for (int i = 0; i < L; i++) slot(s)[i] = a.l[i];
@@ -316,9 +321,9 @@ struct DW {
   }
 
   static PBC_DEV void begin() {
-    using namespace dw;
-    for (int i = (int) threadIdx.x; i < kRows * 5; i += 64) g_lds_dw<ND>[kSlots * L + i] = g_rows[i];
-    for (int i = (int) threadIdx.x; i < kSlots * L; i += 64) g_lds_dw<ND>[i] = 0;
+    const uint32_t *src = TB::rows_src();
+    for (int i = (int) threadIdx.x; i < TB::kRows * 5; i += 64) g_lds_wv<ND, TB>[TB::kSlots * L + i] = src[i];
+    for (int i = (int) threadIdx.x; i < TB::kSlots * L; i += 64) g_lds_wv<ND, TB>[i] = 0;
     __builtin_amdgcn_wave_barrier();
   }
   static PBC_DEV void store_gt(uint8_t *gt, bool valid) {

@@ -1,5 +1,7 @@
 // pbc_hip_f.hip -- kernels and launches of type f (libpbc_hip.so; see host_common.h)
 #include "host_common.h"
+#include "pairing_fw.cuh"
+#include "fw_sched.h"
 
 // Type F: one k-term product (k = 1: a single pairing) per lane.  With fb = fixed byte length of F_q:
 // G1 2 fb, G2 4 fb, GT 12 fb bytes (40 / 80 / 240 B for f.param).
@@ -86,7 +88,49 @@ int derive_f(pbc_hip_pairing_s *P, hipStream_t s) {
   return 0;
 }
 
+// small batches on the five-word BN fields: one pairing per wavefront (pairing_fw.cuh; the parameter file's own basis)
+template <int N>
+__global__ void __launch_bounds__(64) fw_pairing_kernel(uint8_t *gt, const uint8_t *g1, const uint8_t *g2, size_t n, const uint64_t *sched, KArgs<N> ka) {
+  const size_t idx = blockIdx.x;
+  if (idx >= n) return;
+  const size_t fb = fpk<N>().fbytes;
+  FW<N>::pairing(gt + idx * 12 * fb, g1 + idx * 2 * fb, g2 + idx * 4 * fb, sched);
+}
+static bool fw_capable(const pbc_hip_pairing_s *P) { return P->type == 'f' && P->nlimb == 5 && P->fconst.bn_ok; }
+// the schedule for this object's curve (fw_sched.h), built on first use and kept with the object
+static const std::vector<uint64_t> &fw_schedule(pbc_hip_pairing_s *P) {
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lk(mu);
+  if (P->fw_sched.empty()) {
+    const FConst &C = P->fconst;
+    const uint64_t x = (uint64_t) C.bn_x[0] | (uint64_t) C.bn_x[1] << 32;
+    if (!fw::build_schedule(P->fw_sched, C.rbits, [&C](int m) { return (int) ((C.r[m >> 5] >> (m & 31)) & 1) - (int) ((C.rm[m >> 5] >> (m & 31)) & 1); }, x, C.bn_xneg != 0))
+      P->fw_sched.clear();
+  }
+  return P->fw_sched;
+}
+extern "C" size_t pbc_hip_diag_fw_schedule(pbc_hip_pairing_t *P, uint64_t *out, size_t cap) {
+  if (!P || !fw_capable(P)) return 0;
+  const std::vector<uint64_t> &S = fw_schedule(P);
+  for (size_t i = 0; i < S.size() && i < cap; i++) out[i] = S[i];
+  return S.size();
+}
+
 int launch_f(pbc_hip_pairing_s *P, void *d_gt, const void *d_g1, const void *d_g2, size_t n, int k, hipStream_t s) {
+  if (k == 1 && fw_capable(P) && n <= P->f_wave_max) {
+    // a batch this small runs at the latency of ONE lane on the throughput kernel (7 ms): a wavefront per pairing instead
+    // (the schedule: 13 KB, read-only, one copy per device the object runs on -- uploaded on first use, kept with the object)
+    const std::vector<uint64_t> &S = fw_schedule(P);
+    if (S.empty()) return 1;
+    static const char kSchedKey = 0;
+    bool fresh = false;
+    uint64_t *d_sched = (uint64_t *) object_scratch(P, &kSchedKey, S.size() * sizeof(uint64_t), &fresh);
+    if (!d_sched) return 1;
+    if (fresh) HIP_TRY(hipMemcpy(d_sched, S.data(), S.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(fw_pairing_kernel<5>, dim3((unsigned) n), dim3(64), 0, s, (uint8_t *) d_gt, (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, (const uint64_t *) d_sched, kargs<5>(P));
+    HIP_TRY(hipGetLastError());
+    return 0;
+  }
   if (P->f_bm1 && P->fconst_i.xs_ok && P->nlimb == 5) {     // ... with a sparse xi
     hipLaunchKernelGGL((f_prod_pairing_kernel<5, true, true>), dim3(PBC_RGRID(f_prod_pairing_kernel<5, true, true>)), dim3(kBlock), 0, s, (uint8_t *) d_gt,
                        (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k, unit_counter(P, s), kargs<5>(P, true));

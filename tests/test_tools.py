@@ -153,3 +153,35 @@ def test_host_schedule_of_the_wave_kernel_is_the_model_s():
         n = pbc_amd.lib().pbc_hip_diag_dw_schedule(P._h, which, buf.ctypes.data_as(ctypes.c_void_p), len(buf))
         assert n == len(want) and [int(x) for x in buf[:n]] == want, kind
     assert pbc_amd.lib().pbc_hip_diag_dw_schedule(pbc_amd.Pairing(pbc_amd.param_text("g149"))._h, 0, buf.ctypes.data_as(ctypes.c_void_p), len(buf)) == 0
+
+
+def test_wave_program_tables_of_type_f_are_current_and_reproduce_the_reference():
+    """tools/fw_gen.py: the level programs of the one-pairing-per-wavefront type f kernel, run on Python integers in the order of
+    the kernel's schedule, give the reference's f.param vectors (off-curve inputs included), and the committed
+    pbc_amd/csrc/fw_tables.h is what the generator writes"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import fw_gen
+    progs = fw_gen.build() if not fw_gen.SLOTS.order else fw_gen._PROGS
+    fw_gen._PROGS = progs
+    bad, levels = fw_gen.check(progs, count=3)
+    assert bad == 0 and 1000 < levels < 2500
+    assert open(os.path.join(ROOT, "pbc_amd", "csrc", "fw_tables.h")).read() == fw_gen.emit(progs)
+
+
+def test_host_schedule_of_the_type_f_wave_kernel_is_the_model_s():
+    """csrc/fw_sched.h (C++, built per object from the signed digits of r and the bits of the BN parameter x) writes exactly the
+    sequence of levels that tools/fw_gen.py's model executes when it reproduces the reference's vectors -- entry by entry"""
+    import ctypes
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pbc_amd
+    import fw_gen
+    if fw_gen._PROGS is None:
+        fw_gen._PROGS = fw_gen.build()
+    want = fw_gen.flat_schedule("f")
+    P = pbc_amd.Pairing(pbc_amd.param_text("f"))
+    buf = np.zeros(4096, np.uint64)
+    n = pbc_amd.lib().pbc_hip_diag_fw_schedule(P._h, buf.ctypes.data_as(ctypes.c_void_p), len(buf))
+    assert n == len(want) and [int(x) for x in buf[:n]] == want
+    assert pbc_amd.lib().pbc_hip_diag_fw_schedule(pbc_amd.Pairing(pbc_amd.param_text("d159"))._h, buf.ctypes.data_as(ctypes.c_void_p), len(buf)) == 0

@@ -1,4 +1,4 @@
-"""Latency of small batches, d159.param (or DW_PARAM=<another type d parameter file with a wave kernel>): one pairing per wavefront (pairing_dw.cuh) against the one-pairing-per-lane kernel;
+"""Latency of small batches, d159.param (or DW_PARAM=<another type d parameter file>, DW_PARAM=f: the type f wave kernel): one pairing per wavefront (pairing_dw.cuh) against the one-pairing-per-lane kernel;
 device buffers, events around the call, median of 7 after 2 warm-ups.
    python tools/dwave_latency.py [sizes...]              element_pairing
    python tools/dwave_latency.py prod K [sizes...]       element_prod_pairing, K terms (sizes: products)
@@ -16,7 +16,7 @@ import pbc_amd  # noqa: E402
 from conftest import golden, _param  # noqa: E402
 
 PNAME = os.environ.get("DW_PARAM", "d159")                          # DW_PARAM=d278027-190-181: a six-word field
-v = golden("d_chain256.vec" if PNAME == "d159" else PNAME + "_rand12.vec")
+v = golden("d_chain256.vec" if PNAME == "d159" else "f_chain128.vec" if PNAME == "f" else PNAME + "_rand12.vec")
 args = sys.argv[1:]
 mode, k = "pairing", 1
 if args and args[0] == "prod":
@@ -24,7 +24,7 @@ if args and args[0] == "prod":
 elif args and args[0] == "pp":
     mode, args = "pp", args[1:]
 sizes = [int(x) for x in args] or [1, 16, 256, 1024, 2048, 4096, 8192, 16384]
-P = {"wave": pbc_amd.Pairing(_param(PNAME) + "hip_dwave_max 100000000\n"), "lane": pbc_amd.Pairing(_param(PNAME) + "hip_dwave_max 0\n")}
+P = {"wave": pbc_amd.Pairing(_param(PNAME) + "hip_dwave_max 100000000\nhip_fwave_max 100000000\n"), "lane": pbc_amd.Pairing(_param(PNAME) + "hip_dwave_max 0\nhip_fwave_max 0\n")}
 pps = {name: H.pp_init(v.g1[3]) for name, H in P.items()} if mode == "pp" else {}
 what = {"pairing": "wavefront per pairing", "prod": "wavefront per term (%d terms)" % k, "pp": "pairing_pp_apply, wavefront each"}[mode]
 for n in sizes:

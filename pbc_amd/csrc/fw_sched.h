@@ -41,18 +41,17 @@ struct Builder {
     if (xneg) run("conj_" + d + "_" + d);
   }
 };
-// Miller: the signed digit of position m
+// Miller: digit(m) is the signed digit of position m
 template <class Digit>
-inline bool build_schedule(std::vector<uint64_t> &out, int rbits, const Digit &digit, uint64_t x, bool xneg, size_t *miller_entries = nullptr) {
-  out.clear();
-  Builder B(out);
+inline void build_miller(Builder &B, int rbits, const Digit &digit) {
   for (int m = rbits - 2; m >= 0; m--) {
     B.run("pt_dbl");
     B.run("line_mul");
     if (m > 0 && digit(m)) { B.run(digit(m) < 0 ? "pt_addm" : "pt_addp"); B.run("line_mul"); }
     if (m > 0) B.run("sqr_F_F");
   }
-  if (miller_entries) *miller_entries = out.size();
+}
+inline void build_final(Builder &B, uint64_t x, bool xneg) {
   // easy part: F <- F^(q^8) F^(q^6) / (F^(q^2) F), the inverse by polymod_invert's norm trick (poly.c:521-536)
   for (const char *p : {"qp2_Y_F", "qp2_Y_Y", "qp2_Y_Y", "qp2_Y_Y", "conj_U_F", "mul_Y_Y_U", "qp2_U_F", "mul_U_U_F", "qp2_T1_U", "copy_T0_T1"}) B.run(p);
   for (int i = 0; i < 4; i++) { B.run("qp2_T1_T1"); B.run("mul_T0_T0_T1"); }
@@ -69,6 +68,25 @@ inline bool build_schedule(std::vector<uint64_t> &out, int rbits, const Digit &d
                         "frob_U_F", "qp2_Y_F", "mul_FX_U_Y", "frob_U_Y", "mul_FX_FX_U", "mul_T1_T1_FX",
                         "sqr_T0_T0", "mul_F_T0_T1"}) B.run(p);
   B.op(OP_END);
+}
+enum { SCHED_PAIRING = 0, SCHED_MILLER = 1, SCHED_FINISH = 2 };
+// Sched (host_params.h DwSched): e -- the schedules one after the other; off[] -- where each begins: the pairing; the Miller value
+// alone (a TERM of a product); the product with a term's value (the three levels of mul_F_F_U, the kernel repeats them) + the final
+// exponentiation
+template <class Sched, class Digit>
+inline bool build_schedules(Sched &S, int rbits, const Digit &digit, uint64_t x, bool xneg) {
+  S.e.clear();
+  Builder B(S.e);
+  S.off[SCHED_PAIRING] = S.e.size();
+  build_miller(B, rbits, digit);
+  build_final(B, x, xneg);
+  S.off[SCHED_MILLER] = S.e.size();
+  build_miller(B, rbits, digit);
+  B.op(OP_END);
+  S.off[SCHED_FINISH] = S.e.size();
+  B.run("mul_F_F_U");
+  build_final(B, x, xneg);
+  S.off[3] = S.e.size();
   return B.ok;
 }
 

@@ -196,7 +196,7 @@ int run_host_generic(pbc_hip_pairing_s *P, uint8_t *out, size_t ut, const uint8_
 // Per-family launchers: k-term products (k = 1: single pairings) of n units on stream s; constants already derived.
 int launch_a(pbc_hip_pairing_s *P, void *d_gt, const void *d_g1, const void *d_g2, size_t n, int k, hipStream_t s, ProdWs &W);   // pbc_hip_a.hip: a, a1, e
 int launch_d(pbc_hip_pairing_s *P, void *d_gt, const void *d_g1, const void *d_g2, size_t n, int k, hipStream_t s, ProdWs &W);   // pbc_hip_d.hip: d, g
-int launch_f(pbc_hip_pairing_s *P, void *d_gt, const void *d_g1, const void *d_g2, size_t n, int k, hipStream_t s);              // pbc_hip_f.hip
+int launch_f(pbc_hip_pairing_s *P, void *d_gt, const void *d_g1, const void *d_g2, size_t n, int k, hipStream_t s, ProdWs &W);   // pbc_hip_f.hip
 // one-time derivations on the device (single-lane kernels; results land in the object)
 int derive_d(pbc_hip_pairing_s *P, hipStream_t s);
 int derive_e(pbc_hip_pairing_s *P, hipStream_t s);

@@ -135,16 +135,10 @@ struct FW : DW<ND, FwTables> {
       e = nxt;
     }
   }
-  // element_pairing
-  static __device__ void pairing(uint8_t *gt, const uint8_t *g1, const uint8_t *g2b, const uint64_t *sched) {
-    begin();
-    __shared__ int valid_s;
-    if (threadIdx.x == 0) valid_s = setup(g1, g2b) ? 1 : 0;
-    __builtin_amdgcn_wave_barrier();
-    interpret(sched);
+  static PBC_DEV void store_gt(uint8_t *gt, bool valid) {
     if (threadIdx.x < 12) {
       fq o = get_fq(fw::S_F_0_x + (int) threadIdx.x);   // F.0.x, F.0.y, F.1.x, ...: consecutive slots in GT's wire order
-      if (!valid_s) {                                 // an input that deserialises to O: the identity of GT
+      if (!valid) {                                   // an input that deserialises to O: the identity of GT
         fq one;
         fp_set<ND>(one, fpk<ND>().one);
 #pragma unroll
@@ -152,6 +146,57 @@ struct FW : DW<ND, FwTables> {
       }
       fp_store_be<ND>(gt + (size_t) threadIdx.x * fpk<ND>().fbytes, o);
     }
+  }
+  // element_prod_pairing (type f installs no product routine: generic_prod_pairings, ecc/pairing.c:35-46, multiplies k reduced
+  // pairings; the reduced product of the Miller values is the same element).  First kernel: the Miller value of ONE TERM -> its
+  // record of the workspace (kRec words: the twelve slots of F as they are, then the validity flag).
+  static constexpr int kRec = (12 * L + 1 + 7) & ~7;
+  static __device__ void miller_term(uint32_t *rec, const uint8_t *g1, const uint8_t *g2b, const uint64_t *sched) {
+    begin();
+    __shared__ int valid_s;
+    if (threadIdx.x == 0) valid_s = setup(g1, g2b) ? 1 : 0;
+    __builtin_amdgcn_wave_barrier();
+    interpret(sched);
+    for (int i = (int) threadIdx.x; i < 12 * L; i += 64) rec[i] = slot(fw::S_F_0_x)[i];
+    if (threadIdx.x == 0) rec[12 * L] = (uint32_t) valid_s;
+  }
+  // second kernel: F <- the product of the k records (register U takes each further one, the three levels of mul_F_F_U are
+  // sched[0..2]), then the final exponentiation (sched + 3); any invalid term: the identity
+  static __device__ void finish(uint8_t *gt, const uint32_t *recs, int k, const uint64_t *sched_) {
+    const uint64_t *sched = reinterpret_cast<const uint64_t *>(uniform64(reinterpret_cast<uint64_t>(sched_)));
+    begin();
+    __shared__ int dummy_s;
+    if (threadIdx.x == 0) {                           // the constants only: a set-up on records of zeros leaves F = 1, replaced below
+      __attribute__((aligned(4))) uint8_t z1[8 * ND], z2[16 * ND];
+      for (int i = 0; i < 8 * ND; i++) z1[i] = 0;
+      for (int i = 0; i < 16 * ND; i++) z2[i] = 0;
+      dummy_s = setup(z1, z2) ? 1 : 0;
+    }
+    __builtin_amdgcn_wave_barrier();
+    bool valid = recs[12 * L] != 0;
+    for (int i = (int) threadIdx.x; i < 12 * L; i += 64) slot(fw::S_F_0_x)[i] = recs[i];
+    const uint64_t e0 = uniform64(sched[0]), e1 = uniform64(sched[1]), e2 = uniform64(sched[2]);
+    for (int t = 1; t < k; t++) {
+      const uint32_t *r = recs + (size_t) t * kRec;
+      valid &= r[12 * L] != 0;
+      for (int i = (int) threadIdx.x; i < 12 * L; i += 64) slot(fw::S_U_0_x)[i] = r[i];
+      __builtin_amdgcn_wave_barrier();
+      run_entry(e0, nullptr);
+      run_entry(e1, nullptr);
+      run_entry(e2, nullptr);
+    }
+    __builtin_amdgcn_wave_barrier();
+    interpret(sched + 3);
+    store_gt(gt, valid);
+  }
+  // element_pairing
+  static __device__ void pairing(uint8_t *gt, const uint8_t *g1, const uint8_t *g2b, const uint64_t *sched) {
+    begin();
+    __shared__ int valid_s;
+    if (threadIdx.x == 0) valid_s = setup(g1, g2b) ? 1 : 0;
+    __builtin_amdgcn_wave_barrier();
+    interpret(sched);
+    store_gt(gt, valid_s != 0);
   }
 };
 

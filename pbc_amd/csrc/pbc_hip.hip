@@ -884,7 +884,7 @@ static int launch_prod(pbc_hip_pairing_s *P, void *d_gt, const void *d_g1, const
   ProdWs W(P, s, own);
   if (P->type == 'a' || P->type == '1' || P->type == 'e') return launch_a(P, d_gt, d_g1, d_g2, n, k, s, W);
   if (P->type == 'd' || P->type == 'g') return launch_d(P, d_gt, d_g1, d_g2, n, k, s, W);
-  if (P->type == 'f') return launch_f(P, d_gt, d_g1, d_g2, n, k, s);
+  if (P->type == 'f') return launch_f(P, d_gt, d_g1, d_g2, n, k, s, W);
   return fail("unsupported type");
 }
 extern "C" int pbc_hip_element_prod_pairing_batch_dev(pbc_hip_pairing_t *P, void *d_gt, const void *d_g1,

@@ -96,38 +96,71 @@ __global__ void __launch_bounds__(64) fw_pairing_kernel(uint8_t *gt, const uint8
   const size_t fb = fpk<N>().fbytes;
   FW<N>::pairing(gt + idx * 12 * fb, g1 + idx * 2 * fb, g2 + idx * 4 * fb, sched);
 }
+// element_prod_pairing on wavefronts: the Miller value of every TERM (n k wavefronts), then one wavefront per product
+template <int N>
+__global__ void __launch_bounds__(64) fw_miller_kernel(uint32_t *recs, const uint8_t *g1, const uint8_t *g2, size_t terms, const uint64_t *sched, KArgs<N> ka) {
+  const size_t idx = blockIdx.x;
+  if (idx >= terms) return;
+  const size_t fb = fpk<N>().fbytes;
+  FW<N>::miller_term(recs + idx * FW<N>::kRec, g1 + idx * 2 * fb, g2 + idx * 4 * fb, sched);
+}
+template <int N>
+__global__ void __launch_bounds__(64) fw_finish_kernel(uint8_t *gt, const uint32_t *recs, size_t n, int k, const uint64_t *sched, KArgs<N> ka) {
+  const size_t idx = blockIdx.x;
+  if (idx >= n) return;
+  FW<N>::finish(gt + idx * 12 * fpk<N>().fbytes, recs + idx * (size_t) k * FW<N>::kRec, k, sched);
+}
+static constexpr size_t kFwMaxTerms = (size_t) 1 << 19;       // (records of the products' workspace: 320 bytes each)
 static bool fw_capable(const pbc_hip_pairing_s *P) { return P->type == 'f' && P->nlimb == 5 && P->fconst.bn_ok; }
 // the schedule for this object's curve (fw_sched.h), built on first use and kept with the object
-static const std::vector<uint64_t> &fw_schedule(pbc_hip_pairing_s *P) {
+static const DwSched &fw_schedules(pbc_hip_pairing_s *P) {
   static std::mutex mu;
   std::lock_guard<std::mutex> lk(mu);
-  if (P->fw_sched.empty()) {
+  if (P->fw_sched.e.empty()) {
     const FConst &C = P->fconst;
     const uint64_t x = (uint64_t) C.bn_x[0] | (uint64_t) C.bn_x[1] << 32;
-    if (!fw::build_schedule(P->fw_sched, C.rbits, [&C](int m) { return (int) ((C.r[m >> 5] >> (m & 31)) & 1) - (int) ((C.rm[m >> 5] >> (m & 31)) & 1); }, x, C.bn_xneg != 0))
-      P->fw_sched.clear();
+    if (!fw::build_schedules(P->fw_sched, C.rbits, [&C](int m) { return (int) ((C.r[m >> 5] >> (m & 31)) & 1) - (int) ((C.rm[m >> 5] >> (m & 31)) & 1); }, x, C.bn_xneg != 0))
+      P->fw_sched.e.clear();
   }
   return P->fw_sched;
 }
-extern "C" size_t pbc_hip_diag_fw_schedule(pbc_hip_pairing_t *P, uint64_t *out, size_t cap) {
-  if (!P || !fw_capable(P)) return 0;
-  const std::vector<uint64_t> &S = fw_schedule(P);
-  for (size_t i = 0; i < S.size() && i < cap; i++) out[i] = S[i];
-  return S.size();
+// (39 KB, read-only, one copy per device the object runs on -- uploaded on first use, kept with the object)
+static const uint64_t *fw_device_schedules(pbc_hip_pairing_s *P, const DwSched **host) {
+  const DwSched &S = fw_schedules(P);
+  if (S.e.empty()) return nullptr;
+  static const char kSchedKey = 0;
+  bool fresh = false;
+  uint64_t *d_sched = (uint64_t *) object_scratch(P, &kSchedKey, S.e.size() * sizeof(uint64_t), &fresh);
+  if (!d_sched) return nullptr;
+  if (fresh && hipMemcpy(d_sched, S.e.data(), S.e.size() * sizeof(uint64_t), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+  *host = &S;
+  return d_sched;
+}
+extern "C" size_t pbc_hip_diag_fw_schedule(pbc_hip_pairing_t *P, int which, uint64_t *out, size_t cap) {
+  if (!P || !fw_capable(P) || which < 0 || which > 2) return 0;
+  const DwSched &S = fw_schedules(P);
+  if (S.e.empty()) return 0;
+  const size_t first = S.off[which], last = S.off[which + 1];
+  for (size_t i = first; i < last && i - first < cap; i++) out[i - first] = S.e[i];
+  return last - first;
 }
 
-int launch_f(pbc_hip_pairing_s *P, void *d_gt, const void *d_g1, const void *d_g2, size_t n, int k, hipStream_t s) {
-  if (k == 1 && fw_capable(P) && n <= P->f_wave_max) {
-    // a batch this small runs at the latency of ONE lane on the throughput kernel (7 ms): a wavefront per pairing instead
-    // (the schedule: 13 KB, read-only, one copy per device the object runs on -- uploaded on first use, kept with the object)
-    const std::vector<uint64_t> &S = fw_schedule(P);
-    if (S.empty()) return 1;
-    static const char kSchedKey = 0;
-    bool fresh = false;
-    uint64_t *d_sched = (uint64_t *) object_scratch(P, &kSchedKey, S.size() * sizeof(uint64_t), &fresh);
+int launch_f(pbc_hip_pairing_s *P, void *d_gt, const void *d_g1, const void *d_g2, size_t n, int k, hipStream_t s, ProdWs &W) {
+  if (k >= 1 && fw_capable(P) && n <= P->f_wave_max && n * (size_t) k <= kFwMaxTerms) {
+    // The throughput kernel runs a batch this small at the latency of ONE lane (7 ms a pairing, 5 ms more per further term of a
+    // product): a wavefront per pairing -- per TERM for products, then one per product -- instead (pairing_fw.cuh)
+    const DwSched *S = nullptr;
+    const uint64_t *d_sched = fw_device_schedules(P, &S);
     if (!d_sched) return 1;
-    if (fresh) HIP_TRY(hipMemcpy(d_sched, S.data(), S.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(fw_pairing_kernel<5>, dim3((unsigned) n), dim3(64), 0, s, (uint8_t *) d_gt, (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, (const uint64_t *) d_sched, kargs<5>(P));
+    if (k == 1) {
+      hipLaunchKernelGGL(fw_pairing_kernel<5>, dim3((unsigned) n), dim3(64), 0, s, (uint8_t *) d_gt, (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, d_sched + S->off[fw::SCHED_PAIRING], kargs<5>(P));
+    } else {
+      const size_t terms = n * (size_t) k;
+      uint32_t *recs = (uint32_t *) W.get(terms * FW<5>::kRec * sizeof(uint32_t));
+      if (!recs) return 1;
+      hipLaunchKernelGGL(fw_miller_kernel<5>, dim3((unsigned) terms), dim3(64), 0, s, recs, (const uint8_t *) d_g1, (const uint8_t *) d_g2, terms, d_sched + S->off[fw::SCHED_MILLER], kargs<5>(P));
+      hipLaunchKernelGGL(fw_finish_kernel<5>, dim3((unsigned) n), dim3(64), 0, s, (uint8_t *) d_gt, (const uint32_t *) recs, n, k, d_sched + S->off[fw::SCHED_FINISH], kargs<5>(P));
+    }
     HIP_TRY(hipGetLastError());
     return 0;
   }

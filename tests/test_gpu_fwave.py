@@ -47,3 +47,43 @@ def test_other_type_f_parameters_keep_the_lane_kernel(hips):
     for key, name in (("f_200", "f_200_rand4.vec"), ("f_256", "f_256_rand4.vec")):
         v = golden(name)
         assert np.array_equal(hips[key].element_pairing(v.g1, v.g2), v.gt)
+
+
+# ---- element_prod_pairing: one wavefront per TERM, then one per product ----
+@pytest.mark.parametrize("name", ["f_prod3x5_edge.vec", "f_prod4x3.vec", "f_prodfull3x4.vec"])
+def test_products_on_wavefronts_match_the_reference_vectors(hips, lane, name):
+    v = golden(name)
+    got = hips["f"].element_prod_pairing(v.g1, v.g2, v.k)
+    assert np.array_equal(got, v.gt)
+    assert np.array_equal(got, lane.element_prod_pairing(v.g1, v.g2, v.k))
+
+
+@pytest.mark.parametrize("n,k", [(1, 2), (5, 3), (40, 16), (2, 70), (300, 2), (4096, 2), (4097, 2)])
+def test_products_on_wavefronts_equal_the_lane_kernel_and_the_c_restatement(hips, lane, oracles, n, k):
+    v = golden("f_chain128.vec")
+    i = np.arange(n * k)
+    g1, g2 = np.ascontiguousarray(v.g1[(i * 5 + 3) % v.n]), np.ascontiguousarray(v.g2[(i * 11 + 1) % v.n])
+    if n > 2:
+        g1[k + 1, 3] ^= 4                                         # product 1: a term off the curve -> the identity
+        g2[2 * k, 7] ^= 1                                         # product 2: its first term's second argument
+    got = hips["f"].element_prod_pairing(g1, g2, k)
+    m = min(n, 3 if k <= 16 else 1)
+    assert np.array_equal(got[:m], oracles["f"].prod_pairing_batch(g1[:m * k], g2[:m * k], k))
+    if n <= 300:
+        assert np.array_equal(got, lane.element_prod_pairing(g1, g2, k))
+    if n > 2:
+        one = np.zeros(240, np.uint8)
+        one[19] = 1
+        assert np.array_equal(got[1], one) and np.array_equal(got[2], one)
+
+
+def test_product_is_the_product_of_the_pairings(hips):
+    v = golden("f_chain128.vec")
+    H = hips["f"]
+    k = 3
+    g1, g2 = np.ascontiguousarray(v.g1[:20 * k]), np.ascontiguousarray(v.g2[20 * k - 1::-1][:20 * k])
+    singles = H.element_pairing(g1, g2).reshape(20, k, -1)
+    acc = np.ascontiguousarray(singles[:, 0])
+    for t in range(1, k):
+        acc = H.element_mul_GT(acc, np.ascontiguousarray(singles[:, t]))
+    assert np.array_equal(H.element_prod_pairing(g1, g2, k), acc)

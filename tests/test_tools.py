@@ -179,9 +179,10 @@ def test_host_schedule_of_the_type_f_wave_kernel_is_the_model_s():
     import fw_gen
     if fw_gen._PROGS is None:
         fw_gen._PROGS = fw_gen.build()
-    want = fw_gen.flat_schedule("f")
     P = pbc_amd.Pairing(pbc_amd.param_text("f"))
     buf = np.zeros(4096, np.uint64)
-    n = pbc_amd.lib().pbc_hip_diag_fw_schedule(P._h, buf.ctypes.data_as(ctypes.c_void_p), len(buf))
-    assert n == len(want) and [int(x) for x in buf[:n]] == want
-    assert pbc_amd.lib().pbc_hip_diag_fw_schedule(pbc_amd.Pairing(pbc_amd.param_text("d159"))._h, buf.ctypes.data_as(ctypes.c_void_p), len(buf)) == 0
+    for which, kind in enumerate(("pairing", "miller", "finish")):
+        want = fw_gen.flat_schedule(kind)
+        n = pbc_amd.lib().pbc_hip_diag_fw_schedule(P._h, which, buf.ctypes.data_as(ctypes.c_void_p), len(buf))
+        assert n == len(want) and [int(x) for x in buf[:n]] == want, kind
+    assert pbc_amd.lib().pbc_hip_diag_fw_schedule(pbc_amd.Pairing(pbc_amd.param_text("d159"))._h, 0, buf.ctypes.data_as(ctypes.c_void_p), len(buf)) == 0

@@ -316,7 +316,7 @@ def build(pname="f"):
             SLOTS.add(y)
     P = param(pname)
     x = bn_x(P["q"])
-    names = ["pt_dbl", "pt_addp", "pt_addm", "line_mul"]
+    names = ["pt_dbl", "pt_addp", "pt_addm", "line_mul", "mul_F_F_U"]
     plus, minus, rbits = naf_digits(P["r"])
     for n in miller_sequence(plus, minus, rbits) + final_sequence(abs(x), x < 0) + final_sequence(abs(x), not (x < 0)):
         if n not in names and n != "OP_INV":
@@ -416,15 +416,42 @@ class Model:
             e[x], e[y] = (1 if i == 0 else 0), 0
         return ok
 
-    def pairing(self, g1, g2):
+    def miller(self, g1, g2):
         ok = self.set_inputs(g1, g2)
         self.flat = []
-        for n in miller_sequence(self.plus, self.minus, self.rbits) + final_sequence(abs(self.x), self.x < 0):
+        for n in miller_sequence(self.plus, self.minus, self.rbits):
+            self.run(n)
+        return ok
+
+    def finish(self):
+        for n in final_sequence(abs(self.x), self.x < 0):
             self.run(n)
         self.flat.append(("op", "end"))
-        if not ok:
-            return None
         return [self.env[c] for x, y in reg("F") for c in (x, y)]
+
+    def pairing(self, g1, g2):
+        ok = self.miller(g1, g2)
+        r = self.finish()
+        return r if ok else None
+
+    def product(self, terms):
+        """element_prod_pairing (type f installs no product routine: generic_prod_pairings, ecc/pairing.c:35-46, multiplies k reduced
+        pairings; the reduced product of the Miller values is the same element): one wavefront per TERM for the Miller values,
+        then one per product -- F <- the first record, U <- each further one and mul_F_F_U, ONE final exponentiation"""
+        vals, ok = [], True
+        for g1, g2 in terms:
+            ok = self.miller(g1, g2) and ok
+            vals.append([self.env[c] for x, y in reg("F") for c in (x, y)])
+        self.flat = []
+        names = [c for x, y in reg("F") for c in (x, y)]
+        for n, v in zip(names, vals[0]):
+            self.env[n] = v
+        for val in vals[1:]:
+            for n, v in zip([c for x, y in reg("U") for c in (x, y)], val):
+                self.env[n] = v
+            self.run("mul_F_F_U")
+        r = self.finish()
+        return r if ok else None
 
 
 def check(progs, count=4):
@@ -440,7 +467,16 @@ def check(progs, count=4):
             if (r or ident) != want:
                 bad += 1
                 print("MISMATCH", name, i)
-    return bad, M.levels
+    levels = M.levels
+    for name in ("f_prod3x5_edge.vec", "f_prod4x3.vec"):
+        g1, g2, gt = load_vec(os.path.join(ROOT, "tests", "golden", name))
+        k = len(g1) // len(gt)
+        for i in range(len(gt)):
+            r = M.product([(g1[i * k + t], g2[i * k + t]) for t in range(k)])
+            if (r or ident) != [int.from_bytes(gt[i][20 * c:20 * c + 20], "big") for c in range(12)]:
+                bad += 1
+                print("MISMATCH (product)", name, i)
+    return bad, levels
 
 
 def tables(progs):
@@ -459,14 +495,21 @@ def tables(progs):
     return rows, index, pidx
 
 
-def flat_schedule(pname="f"):
-    """the packed schedule of one pairing as the model executes it (fw_sched.h must build the same)"""
+def flat_schedule(kind="pairing", pname="f"):
+    """the packed schedules as the model executes them (fw_sched.h must build the same): "pairing"; "miller" (a term of a product);
+    "finish" (the product with a term's value, then the final exponentiation)"""
     progs = _PROGS if _PROGS is not None else build(pname)
     rows, index, pidx = tables(progs)
     first = {name: f for name, f, c in pidx}
     M = Model(pname, progs)
     g1, g2, gt = load_vec(os.path.join(ROOT, "tests", "golden", "f_rand16.vec"))
-    M.pairing(g1[0], g2[0])
+    if kind == "pairing":
+        M.pairing(g1[0], g2[0])
+    elif kind == "miller":
+        M.miller(g1[0], g2[0])
+        M.flat.append(("op", "end"))
+    else:
+        M.product([(g1[0], g2[0]), (g1[1], g2[1])])
     out = []
     for e in M.flat:
         if e[0] == "level":

@@ -19,8 +19,11 @@ done
 [ -n "$SKIP_SMALL" ] || { timeout 300 python tools/wave_latency.py 1 256 512 1024 2048 4096 5120 > $O/wave_latency.txt 2>&1
   timeout 200 python tools/tail_latency.py > $O/tail.txt 2>&1
   timeout 200 python tools/dwave_latency.py 1 16 256 1024 2048 3072 4096 8192 > $O/dwave_latency.txt 2>&1
+  { for k in 4 16; do timeout 200 python tools/dwave_latency.py prod $k 1 256 4096; done; timeout 200 python tools/dwave_latency.py pp 1 1024 4096
+    for p in d278027-190-181 d201 d224; do echo "== $p"; DW_PARAM=$p timeout 200 python tools/dwave_latency.py 1 1024 4096; done
+    echo "== f.param"; DW_PARAM=f timeout 200 python tools/dwave_latency.py 1 256 1024 2048 4096 8192; for k in 4 16; do DW_PARAM=f timeout 200 python tools/dwave_latency.py prod $k 1 256 1024; done; } > $O/small_batches.txt 2>&1
   export PBC_HIP_LIB=$R/pbc_amd/libpbc_hip.so
-  [ -n "$SKIP_GLUE" ] || for p in a d159; do timeout 120 oracle/_ref/glue_test pbc_amd/param/$p.param 200 latency 2>&1 | tail -n 1; timeout 200 oracle/_ref/glue_test pbc_amd/param/$p.param 1048576 bench 2>&1 | tail -n 1; done > $O/glue.txt
+  [ -n "$SKIP_GLUE" ] || for p in a d159 f d201; do timeout 120 oracle/_ref/glue_test pbc_amd/param/$p.param 100 latency 2>&1 | tail -n 2; [ $p = a ] || [ $p = d159 ] || continue; timeout 200 oracle/_ref/glue_test pbc_amd/param/$p.param 1048576 bench 2>&1 | tail -n 1; done > $O/glue.txt
   unset PBC_HIP_LIB; }
 cd /tmp && export TMPDIR=/tmp
 for w in ${PMC_WL-a d f a-prod16 d-prod16 d190 a-pp a-g1-mul f-gt-pow}; do

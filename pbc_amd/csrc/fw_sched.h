@@ -44,11 +44,12 @@ struct Builder {
 // Miller: digit(m) is the signed digit of position m
 template <class Digit>
 inline void build_miller(Builder &B, int rbits, const Digit &digit) {
+  // (a square and the doubling of the step after it share nothing: ONE program, "sqrdbl", whose four levels hold the square's two)
   for (int m = rbits - 2; m >= 0; m--) {
-    B.run("pt_dbl");
+    if (m == rbits - 2) B.run("pt_dbl");
     B.run("line_mul");
     if (m > 0 && digit(m)) { B.run(digit(m) < 0 ? "pt_addm" : "pt_addp"); B.run("line_mul"); }
-    if (m > 0) B.run("sqr_F_F");
+    if (m > 0) B.run("sqrdbl");
   }
 }
 inline void build_final(Builder &B, uint64_t x, bool xneg) {

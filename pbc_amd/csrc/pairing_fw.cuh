@@ -5,10 +5,11 @@
 // sites whatever the batch size (one CPU core: 6.6 ms).  Here a wavefront owns one pairing on the machine of pairing_dw.cuh:
 // every F_q element a slot of an LDS slot file (218 slots), a LEVEL = every lane computes one lazily reduced sum of F_q products
 // from the slots its table row names (fw_tables.h, generated and checked against the reference's vectors on Python integers by
-// tools/fw_gen.py), the schedule a straight line the host writes once per object (fw_sched.h):
+// tools/fw_gen.py), the schedule a straight line the host writes once per object (fw_sched.h; 1306 levels):
 //   * V <- 2V / V <- V +- P on E(F_q) with the line's values a Qx', a Qx' xi, b Qy', b Qy' xi (x, y, beta y) in its last level;
 //   * the accumulator times the line in ONE level (twelve sums of five terms, four lanes each), its square in two (the doubled,
-//     beta- and xi-scaled copies, then twelve sums of six or eight terms);
+//     beta- and xi-scaled copies, then twelve sums of six or eight terms) -- which also carry the first two levels of the NEXT
+//     step's doubling;
 //   * general F_q^12 products of the final exponentiation in three levels, Frobenius maps / conjugations / copies in one,
 //     the one inversion (norm of polymod_invert down to F_q) as lane code.
 // The set-up (byte loads, curve checks, the untwisting map, the powers of X^(q^2) / X and X^q / X) is ordinary code on lane 0.

@@ -51,6 +51,11 @@ def g2_terms(ax, ay, bx, by, bby):
 
 def prog_sqr(dst, a):
     p = Prog("sqr_%s_%s" % (dst, a), SLOTS, "ft")
+    emit_sqr(p, dst, a)
+    return p.finish()
+
+
+def emit_sqr(p, dst, a):
     A, D = reg(a), reg(dst)
     Bj = [p.mul(A[j][1], "BETA") for j in range(6)]
     W = {}
@@ -70,7 +75,6 @@ def prog_sqr(dst, a):
                 ty += ry
         p.sop(tx, out=D[k][0], floor=2)
         p.sop(ty, out=D[k][1], floor=2)
-    return p.finish()
 
 
 def prog_mul(dst, a, b):
@@ -119,6 +123,20 @@ def prog_point_dbl():
     """V <- 2V on y^2 = x^3 + b and the tangent (do_tangent, f_param.c:171-184, scaled by -Z^6 as tools/dw_gen.py's):
          M = 3X^2;  a' = M Z^2, b' = -(2YZ) Z^2, c' = 2Y^2 - M X;  X3 = M^2 - 8XY^2, Y3 = M (4XY^2 - X3) - 8Y^4, Z3 = 2YZ"""
     p = Prog("pt_dbl", SLOTS, "pt")
+    emit_point_dbl(p)
+    return p.finish()
+
+
+def prog_sqr_dbl():
+    """F <- F^2 and V <- 2V side by side (they share nothing): the Miller loop's square with the NEXT step's doubling -- the first
+    two levels of the doubling (four sums each) ride in the square's two levels, four levels instead of six"""
+    p = Prog("sqrdbl", SLOTS, "ft")
+    emit_sqr(p, "F", "F")
+    emit_point_dbl(p)
+    return p.finish()
+
+
+def emit_point_dbl(p):
     X, Y, Z, nZ = "X", "Y", "Z", "nZ"
     XX = p.mul(X, X)
     YY = p.mul(Y, Y)
@@ -138,7 +156,6 @@ def prog_point_dbl():
     p.sop([(M, S4), (nM, X3), (Y4, "M8")], out="Y")
     p.sop([(YY, "TWO"), (MX, "M1")], out="L.c")
     line_values(p, la, lb)
-    return p.finish()
 
 
 def prog_point_add(neg):
@@ -251,7 +268,13 @@ def miller_sequence(plus, minus, rbits):
             seq += ["pt_addm" if dig(m) < 0 else "pt_addp", "line_mul"]
         if m > 0:
             seq.append("sqr_F_F")
-    return seq
+    out = []                                         # a square and the doubling after it: one program
+    for n in seq:
+        if n == "pt_dbl" and out and out[-1] == "sqr_F_F":
+            out[-1] = "sqrdbl"
+        else:
+            out.append(n)
+    return out
 
 
 def pow_x(dst, a, x, xneg):
@@ -316,7 +339,7 @@ def build(pname="f"):
             SLOTS.add(y)
     P = param(pname)
     x = bn_x(P["q"])
-    names = ["pt_dbl", "pt_addp", "pt_addm", "line_mul", "mul_F_F_U"]
+    names = ["pt_dbl", "pt_addp", "pt_addm", "line_mul", "mul_F_F_U", "sqrdbl", "sqr_F_F"]
     plus, minus, rbits = naf_digits(P["r"])
     for n in miller_sequence(plus, minus, rbits) + final_sequence(abs(x), x < 0) + final_sequence(abs(x), not (x < 0)):
         if n not in names and n != "OP_INV":
@@ -325,6 +348,8 @@ def build(pname="f"):
     for n in names:
         if n == "pt_dbl":
             progs[n] = prog_point_dbl()
+        elif n == "sqrdbl":
+            progs[n] = prog_sqr_dbl()
         elif n in ("pt_addp", "pt_addm"):
             progs[n] = prog_point_add(n == "pt_addm")
         elif n == "line_mul":

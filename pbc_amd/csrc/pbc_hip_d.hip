@@ -2,6 +2,8 @@
 #include "host_common.h"
 #include "pairing_dw.cuh"
 #include "dw_sched.h"
+#include "pairing_gw.cuh"
+#include "gw_sched.h"
 
 // Types D and G: one k-term product (k = 1: a single pairing) per lane.  With fb = fixed byte length
 // of F_q and d = k/2, G1 records are 2 fb, G2 and GT 2 d fb bytes (40 / 120 / 120 B for d159.param,
@@ -100,6 +102,32 @@ extern "C" size_t pbc_hip_diag_dw_schedule(pbc_hip_pairing_t *P, int which, uint
   return last - first;
 }
 
+// small batches of type g on the five-word field: one pairing per wavefront (pairing_gw.cuh)
+template <int N>
+__global__ void __launch_bounds__(64) gw_pairing_kernel(uint8_t *gt, const uint8_t *g1, const uint8_t *g2, size_t n, const uint64_t *sched, KArgs<N> ka) {
+  const size_t idx = blockIdx.x;
+  if (idx >= n) return;
+  const size_t fb = fpk<N>().fbytes;
+  GW<N>::pairing(gt + idx * 10 * fb, g1 + idx * 2 * fb, g2 + idx * 10 * fb, sched);
+}
+static bool gw_capable(const pbc_hip_pairing_s *P) { return P->type == 'g' && P->nlimb == 5 && P->deg == 5; }
+static const std::vector<uint64_t> &gw_schedule(pbc_hip_pairing_s *P) {
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lk(mu);
+  if (P->gw_sched.empty()) {
+    const DConst &C = P->dconst;
+    if (!gw::build_schedule(P->gw_sched, C.rbits, [&C](int m) { return (int) ((C.r[m >> 5] >> (m & 31)) & 1) - (int) ((C.rm[m >> 5] >> (m & 31)) & 1); }, C.phik, C.phikbits))
+      P->gw_sched.clear();
+  }
+  return P->gw_sched;
+}
+extern "C" size_t pbc_hip_diag_gw_schedule(pbc_hip_pairing_t *P, uint64_t *out, size_t cap) {
+  if (!P || !gw_capable(P)) return 0;
+  const std::vector<uint64_t> &S = gw_schedule(P);
+  for (size_t i = 0; i < S.size() && i < cap; i++) out[i] = S[i];
+  return S.size();
+}
+
 // pairing_pp for types d / g: single-lane table derivation, then one second argument per lane
 template <int N, int DEG>
 __global__ void d_pp_init_kernel(uint32_t *tab, uint32_t *valid, const uint8_t *g1, KArgs<N> ka) {
@@ -161,6 +189,19 @@ int launch_d(pbc_hip_pairing_s *P, void *d_gt, const void *d_g1, const void *d_g
   unsigned grid = (unsigned) ((n + kBlock - 1) / kBlock);
   // The throughput kernel runs a batch this small at the latency of ONE lane (3.9 ms a pairing, ~2.9 ms more per further term
   // of a product): a wavefront per pairing -- per TERM for products, then one per product -- instead (pairing_dw.cuh).
+  if (k == 1 && gw_capable(P) && n <= P->d_wave_max) {
+    // type g: 14 ms a pairing on one lane whatever the batch size; a wavefront per pairing instead (20 KB schedule, kept with the object)
+    const std::vector<uint64_t> &S = gw_schedule(P);
+    if (S.empty()) return 1;
+    static const char kGwSchedKey = 0;
+    bool fresh = false;
+    uint64_t *d_sched = (uint64_t *) object_scratch(P, &kGwSchedKey, S.size() * sizeof(uint64_t), &fresh);
+    if (!d_sched) return 1;
+    if (fresh) HIP_TRY(hipMemcpy(d_sched, S.data(), S.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(gw_pairing_kernel<5>, dim3((unsigned) n), dim3(64), 0, s, (uint8_t *) d_gt, (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, (const uint64_t *) d_sched, kargs<5>(P));
+    HIP_TRY(hipGetLastError());
+    return 0;
+  }
   const bool waves = dw_capable(P) && k >= 1 && n <= P->d_wave_max && n * (size_t) k <= kDwMaxTerms;
   if (waves && k == 1) {
     const DwSched *S = nullptr;

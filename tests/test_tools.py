@@ -186,3 +186,27 @@ def test_host_schedule_of_the_type_f_wave_kernel_is_the_model_s():
         n = pbc_amd.lib().pbc_hip_diag_fw_schedule(P._h, which, buf.ctypes.data_as(ctypes.c_void_p), len(buf))
         assert n == len(want) and [int(x) for x in buf[:n]] == want, kind
     assert pbc_amd.lib().pbc_hip_diag_fw_schedule(pbc_amd.Pairing(pbc_amd.param_text("d159"))._h, 0, buf.ctypes.data_as(ctypes.c_void_p), len(buf)) == 0
+
+
+def test_wave_program_tables_of_type_g_are_current_and_match_the_host_schedule():
+    """tools/gw_gen.py: the level programs of the one-pairing-per-wavefront type g kernel (chained sums, repacked levels), run on
+    Python integers in the order of the kernel's schedule, give the reference's g149 vectors; the committed
+    pbc_amd/csrc/gw_tables.h is what the generator writes; and csrc/gw_sched.h builds the model's schedule entry by entry"""
+    import ctypes
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pbc_amd
+    import gw_gen
+    if gw_gen._PROGS is None:
+        gw_gen._PROGS = gw_gen.build()
+    progs = gw_gen._PROGS
+    bad, levels = gw_gen.check(progs, count=2)
+    assert bad == 0 and 2000 < levels < 4000
+    assert open(os.path.join(ROOT, "pbc_amd", "csrc", "gw_tables.h")).read() == gw_gen.emit(progs)
+    want = gw_gen.flat_schedule("g149")
+    P = pbc_amd.Pairing(pbc_amd.param_text("g149"))
+    buf = np.zeros(8192, np.uint64)
+    n = pbc_amd.lib().pbc_hip_diag_gw_schedule(P._h, buf.ctypes.data_as(ctypes.c_void_p), len(buf))
+    assert n == len(want) and [int(x) for x in buf[:n]] == want
+    assert pbc_amd.lib().pbc_hip_diag_gw_schedule(pbc_amd.Pairing(pbc_amd.param_text("d159"))._h, buf.ctypes.data_as(ctypes.c_void_p), len(buf)) == 0

@@ -16,7 +16,7 @@ import pbc_amd  # noqa: E402
 from conftest import golden, _param  # noqa: E402
 
 PNAME = os.environ.get("DW_PARAM", "d159")                          # DW_PARAM=d278027-190-181: a six-word field
-v = golden("d_chain256.vec" if PNAME == "d159" else "f_chain128.vec" if PNAME == "f" else PNAME + "_rand12.vec")
+v = golden("d_chain256.vec" if PNAME == "d159" else "f_chain128.vec" if PNAME == "f" else "g149_chain64.vec" if PNAME == "g149" else PNAME + "_rand12.vec")
 args = sys.argv[1:]
 mode, k = "pairing", 1
 if args and args[0] == "prod":

@@ -1,0 +1,9 @@
+#!/bin/bash
+# round 6, twenty-fourth GPU call: the type g wave kernel: tests, latency, through the hooks
+R="${GRAFT_REPO_ROOT:-/root/repo}"; O=$R/gpurun_out/r6x; mkdir -p $O; cd $R || exit 1
+bash tools/boxinfo.sh 2>&1 | head -3 > $O/boxinfo.txt
+timeout 900 python -m pytest tests/test_gpu_gwave.py -m gpu -q 2>&1 | tail -n 25 > $O/pytest_gwave.txt; cat $O/pytest_gwave.txt
+DW_PARAM=g149 timeout 300 python tools/dwave_latency.py 1 16 256 1024 2048 4096 8192 > $O/lat_g.txt 2>&1; cat $O/lat_g.txt
+export PBC_HIP_LIB=$R/pbc_amd/libpbc_hip.so
+timeout 200 oracle/_ref/glue_test pbc_amd/param/g149.param 60 latency 2>&1 | tail -n 2 | tee $O/glue.txt
+unset PBC_HIP_LIB

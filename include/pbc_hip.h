@@ -294,8 +294,11 @@ int pbc_hip_finalpow_batch(pbc_hip_pairing_t *p, uint8_t *out, const uint8_t *in
 size_t pbc_hip_diag_dw_schedule(pbc_hip_pairing_t *p, int which, uint64_t *out, size_t cap);
 /* The same for the wavefront kernel of type f (csrc/fw_sched.h: cc_miller_no_denom, ecc/f_param.c:216-233, then f_tateexp, :250-283,
  * with the BN vector chain for the hard part; 0: the object is not a five-word BN type f pairing). */
-size_t pbc_hip_diag_gw_schedule(pbc_hip_pairing_t *p, uint64_t *out, size_t cap);                /* type g (csrc/gw_sched.h): element_pairing */
 size_t pbc_hip_diag_fw_schedule(pbc_hip_pairing_t *p, int which, uint64_t *out, size_t cap);    /* which: 0 pairing, 1 a term's Miller value, 2 product + final exponentiation */
+/* ... and of type g on the five-word field (csrc/gw_sched.h: the loop of ecc/d_param.c:321-422 that ecc/g_param.c shares, cc_tatepower
+ * and lucas_even over Phi_10(q) / r, g_param.c:471-558; pairing_pp_apply: g_param.c's copy of d_pairing_pp_apply); which as for
+ * type d; 0: not a five-word type g pairing. */
+size_t pbc_hip_diag_gw_schedule(pbc_hip_pairing_t *p, int which, uint64_t *out, size_t cap);
 int pbc_hip_fq_limb_image_bytes(pbc_hip_pairing_t *p);          /* 8 t (0 on failure) */
 int pbc_hip_element_pairing_batch_limbs(pbc_hip_pairing_t *p, uint8_t *gt, const uint8_t *g1, const uint8_t *g2, size_t n);
 int pbc_hip_element_prod_pairing_batch_limbs(pbc_hip_pairing_t *p, uint8_t *gt, const uint8_t *g1, const uint8_t *g2, size_t n, int k);

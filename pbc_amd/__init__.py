@@ -122,7 +122,7 @@ def lib():
         L.pbc_hip_diag_dw_schedule.restype = sz
         L.pbc_hip_diag_fw_schedule.argtypes = [vp, ci, vp, sz]
         L.pbc_hip_diag_fw_schedule.restype = sz
-        L.pbc_hip_diag_gw_schedule.argtypes = [vp, vp, sz]
+        L.pbc_hip_diag_gw_schedule.argtypes = [vp, ci, vp, sz]
         L.pbc_hip_diag_gw_schedule.restype = sz
         L.pbc_hip_fq_limb_image_bytes.argtypes = [vp]
         L.pbc_hip_element_pairing_batch_limbs.argtypes = [vp, vp, vp, vp, sz]

@@ -26,12 +26,15 @@ struct Builder {
       }
     ok = false;
   }
-  void op(int o) { out.push_back((uint64_t) o << 38); }
+  void op(int o, int line = -1) { out.push_back((uint64_t) o << 38 | (line >= 0 ? (uint64_t) line << 42 | 1ull << 55 : 0ull)); }
+  void run_with_line(const std::string &name, int line) {          // ... whose first level also takes table line `line` (-1: none)
+    const size_t at = out.size();
+    run(name);
+    if (line >= 0 && out.size() > at) out[at] |= (uint64_t) line << 42 | 1ull << 55;
+  }
 };
 template <class Digit>                                              // digit(m): the signed digit of the Miller loop at position m
-inline bool build_schedule(std::vector<uint64_t> &out, int rbits, const Digit &digit, const uint32_t *phik, int phikbits) {
-  out.clear();
-  Builder B(out);
+inline void build_miller(Builder &B, int rbits, const Digit &digit) {
   // (a square and the doubling of the step after it share nothing: ONE program, "sqrdbl")
   for (int m = rbits - 2; m >= 0; m--) {
     if (m == rbits - 2) B.run("pt_dbl");
@@ -39,6 +42,8 @@ inline bool build_schedule(std::vector<uint64_t> &out, int rbits, const Digit &d
     if (m > 0 && digit(m)) { B.run(digit(m) < 0 ? "pt_addm" : "pt_addp"); B.run("line_mul"); }
     if (m > 0) B.run("sqrdbl");
   }
+}
+inline void build_final(Builder &B, const uint32_t *phik, int phikbits) {
   // cc_tatepower with one inversion (pairing_d.cuh d_final_exp)
   B.run("fe1"); B.op(OP_BZERO); B.run("fe2"); B.op(OP_INV); B.run("fe3");
   for (int j = phikbits - 1; j >= 0; j--) {                         // lucas_even: j == 0 takes the 0-branch
@@ -47,6 +52,41 @@ inline bool build_schedule(std::vector<uint64_t> &out, int rbits, const Digit &d
   }
   B.run("fe4");
   B.op(OP_END);
+}
+enum { SCHED_PAIRING = 0, SCHED_MILLER = 1, SCHED_FINISH = 2, SCHED_PP = 3 };
+constexpr int kMaxLines = 4096;
+// Sched (host_params.h DwSched): the pairing; the Miller value alone (a TERM of a product); the product with a term's value (mul_f_u, a
+// mark: the kernel repeats the entries before it) + the final exponentiation; pairing_pp_apply (line i of the table -> La, Lb, Lc: the
+// first by an entry of its own, line i + 1 beside the first level of the product with line i)
+template <class Sched, class Digit>
+inline bool build_schedules(Sched &S, int rbits, const Digit &digit, const uint32_t *phik, int phikbits) {
+  S.e.clear();
+  Builder B(S.e);
+  S.off[SCHED_PAIRING] = S.e.size();
+  build_miller(B, rbits, digit);
+  build_final(B, phik, phikbits);
+  S.off[SCHED_MILLER] = S.e.size();
+  build_miller(B, rbits, digit);
+  B.op(OP_END);
+  S.off[SCHED_FINISH] = S.e.size();
+  B.run("mul_f_u");
+  B.op(OP_MARK);
+  build_final(B, phik, phikbits);
+  S.off[SCHED_PP] = S.e.size();
+  S.lines = 0;
+  for (int m = rbits - 2; m >= 0; m--) S.lines += 1 + ((m > 0 && digit(m)) ? 1 : 0);
+  B.op(OP_LOADLINE, 0);
+  int i = 0;
+  for (int m = rbits - 2; m >= 0; m--) {
+    const int nl = 1 + ((m > 0 && digit(m)) ? 1 : 0);
+    for (int t = 0; t < nl; t++) {
+      B.run("ln_eval");
+      B.run_with_line("line_mul", i + 1 < S.lines ? i + 1 : -1);
+      i++;
+    }
+    if (m > 0) B.run("f_sqr");
+  }
+  build_final(B, phik, phikbits);
   return B.ok;
 }
 

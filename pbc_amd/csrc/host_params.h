@@ -109,7 +109,7 @@ struct pbc_hip_pairing_s {
   int raw_t;                 // ... t = 64-bit limbs of the reference's montfp element (0: constants not derived yet)
   void *counters;            // library only: the unit counters of dynamic resident launches (pbc_hip.hip unit_counter)
   void *host_ctx;            // library only: per-device streams and chunk buffers of the host-buffer path (pbc_hip.hip)
-  std::vector<uint64_t> gw_sched;   // type g, five-word field: the schedule of one pairing on the wave kernel (pbc_hip_d.hip gw_schedule, gw_sched.h)
+  DwSched gw_sched;                 // type g, five-word field: the schedules of the wave kernels (pbc_hip_d.hip gw_schedules, gw_sched.h)
   DwSched fw_sched;                 // type f, five-word BN fields: the schedules of the wave kernels (pbc_hip_f.hip fw_schedules, fw_sched.h)
   size_t f_wave_max;                // ... single pairings in batches up to this size take it ("hip_fwave_max N")
   DwSched dw_sched;                 // type d, five-word fields: the schedules of the wave kernels (pbc_hip_d.hip dw_schedules, dw_sched.h)

@@ -33,6 +33,7 @@ namespace pbc {
 struct DwTables {
   static constexpr int kSlots = dw::kSlots, kRows = dw::kRows;
   static PBC_DEV const uint32_t *rows_src() { return dw::g_rows; }
+  static PBC_DEV int line_slot(int line) { return dw::S_L0_a + 3 * (line & 1); }   // where a', b', c' of a pairing_pp table line go
 };
 template <int ND, class TB> __shared__ __attribute__((aligned(16))) uint32_t g_lds_wv[TB::kSlots * Limbs29<ND>::L + TB::kRows * 5];
 
@@ -284,7 +285,7 @@ struct DW {
       fq v;
 #pragma unroll
       for (int k = 0; k < ND; k++) v.v[k] = ln.w[k];
-      put_fq(dw::S_L0_a + 3 * (line & 1) + (int) threadIdx.x, v);
+      put_fq(TB::line_slot(line) + (int) threadIdx.x, v);
     }
     __builtin_amdgcn_wave_barrier();
   }

@@ -22,6 +22,7 @@ namespace pbc {
 struct FwTables {
   static constexpr int kSlots = fw::kSlots, kRows = fw::kRows;
   static PBC_DEV const uint32_t *rows_src() { return fw::g_rows; }
+  static PBC_DEV int line_slot(int) { return 0; }                  // (type f has no pairing_pp tables)
 };
 
 template <int ND>

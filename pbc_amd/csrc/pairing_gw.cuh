@@ -17,6 +17,7 @@ namespace pbc {
 struct GwTables {
   static constexpr int kSlots = gw::kSlots, kRows = gw::kRows;
   static PBC_DEV const uint32_t *rows_src() { return gw::g_rows; }
+  static PBC_DEV int line_slot(int) { return gw::S_La; }           // La, Lb, Lc: consecutive slots
 };
 
 template <int ND>
@@ -27,9 +28,11 @@ struct GW : DW<ND, GwTables> {
   typedef typename G::fq fq;
   typedef typename G::f3 f5;                           // (pairing_d.cuh keeps type d's names: f3 = F_q^d)
   using VM::put_fq; using VM::get_fq; using VM::put; using VM::slot; using VM::uniform64; using VM::run_entry; using VM::begin;
+  using VM::line_fetch; using VM::line_put;
   static constexpr int L = VM::L;
 
   // ---- lane 0: constants, bytes -> slots, curve checks, twist map (d_setup_lane) ----
+  // (g1 == nullptr: pairing_pp_apply -- no first argument, the table stands for it)
   static __device__ __noinline__ bool setup(const uint8_t *g1, const uint8_t *g2) {
     using namespace gw;
     const FpK<ND> &K = fpk<ND>();
@@ -64,10 +67,12 @@ struct GW : DW<ND, GwTables> {
         put_fq(S_NXQ1_0 + j * DEG + k, t);
       }
     // inputs
-    fq Px, Py;
+    fq Px = zero, Py = zero;
     f5 Qx, Qy;
-    fp_load_be<ND>(Px, g1);
-    fp_load_be<ND>(Py, g1 + NB);
+    if (g1) {
+      fp_load_be<ND>(Px, g1);
+      fp_load_be<ND>(Py, g1 + NB);
+    }
     G::f3_load_be(Qx, g2);
     G::f3_load_be(Qy, g2 + DEG * NB);
     bool valid;
@@ -79,7 +84,7 @@ struct GW : DW<ND, GwTables> {
       fp_mul<ND>(t0, t0, Px);
       fp_add<ND>(t0, t0, G::dk(c_d.B));
       fp_sqr<ND>(t1, Py);
-      valid = fp_eq<ND>(t0, t1);
+      valid = fp_eq<ND>(t0, t1) | (g1 == nullptr);
       f5 u0, u1;
       G::f3_sqr(u0, Qx);
       fp_add<ND>(u0.c[0], u0.c[0], G::dk(c_d.ta));
@@ -127,18 +132,84 @@ struct GW : DW<ND, GwTables> {
     }
     __builtin_amdgcn_wave_barrier();
   }
-  static __device__ __noinline__ void interpret(const uint64_t *sched_) {
+  // runs entries up to OP_END or OP_MARK; returns how many it consumed (the terminator included)
+  static __device__ __noinline__ int interpret(const uint64_t *sched_, const uint32_t *tab_ = nullptr) {
     const uint64_t *sched = reinterpret_cast<const uint64_t *>(uniform64(reinterpret_cast<uint64_t>(sched_)));
+    const uint32_t *tab = reinterpret_cast<const uint32_t *>(uniform64(reinterpret_cast<uint64_t>(tab_)));
     uint64_t e = uniform64(sched[0]);
-    for (int k = 1;; k++) {
+    int k = 1;
+    for (;; k++) {
       const int op = (int) ((e >> 38) & 15u);
-      if (op == gw::OP_END) break;
+      if (op == gw::OP_END || op == gw::OP_MARK) break;
       const uint64_t nxt = uniform64(sched[k]);        // (a scalar load that completes under this entry's work)
-      if (op == gw::OP_LEVEL) run_entry(e, nullptr);
+      if (op == gw::OP_LEVEL) run_entry(e, tab);
       else if (op == gw::OP_BZERO) bzero_test();
-      else inversion();
+      else if (op == gw::OP_INV) inversion();
+      else { const int line = (int) ((e >> 42) & 4095u); line_put(line_fetch(tab, line), line); }
       e = nxt;
     }
+    return __builtin_amdgcn_readfirstlane(k);
+  }
+  static PBC_DEV void store_gt(uint8_t *gt, bool valid) {
+    if (threadIdx.x < 2 * DEG) {
+      fq o = get_fq(gw::S_f_x0 + (int) threadIdx.x);   // f.x0..4, f.y0..4 are consecutive slots: GT's wire order
+      if (!valid) {                                    // an input that deserialises to O: the identity of GT
+        fq one;
+        fp_set<ND>(one, fpk<ND>().one);
+#pragma unroll
+        for (int k = 0; k < ND; k++) o.v[k] = threadIdx.x == 0 ? one.v[k] : 0u;
+      }
+      fp_store_be<ND>(gt + (size_t) threadIdx.x * fpk<ND>().fbytes, o);
+    }
+  }
+  // element_prod_pairing, first kernel: the Miller value of ONE TERM -> its record (kRec words: the ten slots of f, the validity flag)
+  static constexpr int kRec = (2 * DEG * L + 1 + 7) & ~7;
+  static __device__ void miller_term(uint32_t *rec, const uint8_t *g1, const uint8_t *g2, const uint64_t *sched) {
+    begin();
+    __shared__ int valid_s;
+    if (threadIdx.x == 0) valid_s = setup(g1, g2) ? 1 : 0;
+    __builtin_amdgcn_wave_barrier();
+    interpret(sched);
+    if (threadIdx.x < 2 * DEG * L) rec[threadIdx.x] = slot(gw::S_f_x0)[threadIdx.x];
+    if (threadIdx.x == 0) rec[2 * DEG * L] = (uint32_t) valid_s;
+  }
+  // second kernel: f <- the product of the k records (register u takes each further one; the levels of mul_f_u are the schedule's
+  // entries up to its mark), then the final exponentiation; any invalid term: the identity
+  static __device__ void finish(uint8_t *gt, const uint32_t *recs, int k, const uint64_t *sched) {
+    begin();
+    __shared__ int dummy_s;
+    if (threadIdx.x == 0) {                            // the constants only: a set-up on a record of zeros, f replaced below
+      __attribute__((aligned(4))) uint8_t z2[8 * DEG * ND];
+      for (int i = 0; i < 8 * DEG * ND; i++) z2[i] = 0;
+      dummy_s = setup(nullptr, z2) ? 1 : 0;
+    }
+    __builtin_amdgcn_wave_barrier();
+    bool valid = recs[2 * DEG * L] != 0;
+    if (threadIdx.x < 2 * DEG * L) slot(gw::S_f_x0)[threadIdx.x] = recs[threadIdx.x];
+    int used = 0;
+    for (int t = 1; t < k; t++) {
+      const uint32_t *r = recs + (size_t) t * kRec;
+      valid &= r[2 * DEG * L] != 0;
+      if (threadIdx.x < 2 * DEG * L) slot(gw::S_u_x0)[threadIdx.x] = r[threadIdx.x];
+      __builtin_amdgcn_wave_barrier();
+      used = interpret(sched);
+    }
+    if (k < 2) {                                       // (never routed here; skip the product's entries)
+      for (used = 0; ((uniform64(sched[used]) >> 38) & 15u) != (uint64_t) gw::OP_MARK; used++) {}
+      used++;
+    }
+    __builtin_amdgcn_wave_barrier();
+    interpret(sched + used);
+    store_gt(gt, valid);
+  }
+  // pairing_pp_apply: the lines' coefficients come from the table of pairing_pp_init (pairing_d.cuh d_pp_init_lane)
+  static __device__ void pp_apply(uint8_t *gt, const uint32_t *tab, bool p_valid, const uint8_t *g2, const uint64_t *sched) {
+    begin();
+    __shared__ int valid_s;
+    if (threadIdx.x == 0) valid_s = setup(nullptr, g2) ? 1 : 0;
+    __builtin_amdgcn_wave_barrier();
+    interpret(sched, tab);
+    store_gt(gt, p_valid && valid_s != 0);
   }
   // element_pairing
   static __device__ void pairing(uint8_t *gt, const uint8_t *g1, const uint8_t *g2, const uint64_t *sched) {
@@ -147,16 +218,7 @@ struct GW : DW<ND, GwTables> {
     if (threadIdx.x == 0) valid_s = setup(g1, g2) ? 1 : 0;
     __builtin_amdgcn_wave_barrier();
     interpret(sched);
-    if (threadIdx.x < 2 * DEG) {
-      fq o = get_fq(gw::S_f_x0 + (int) threadIdx.x);   // f.x0..4, f.y0..4 are consecutive slots: GT's wire order
-      if (!valid_s) {                                  // an input that deserialises to O: the identity of GT
-        fq one;
-        fp_set<ND>(one, fpk<ND>().one);
-#pragma unroll
-        for (int k = 0; k < ND; k++) o.v[k] = threadIdx.x == 0 ? one.v[k] : 0u;
-      }
-      fp_store_be<ND>(gt + (size_t) threadIdx.x * fpk<ND>().fbytes, o);
-    }
+    store_gt(gt, valid_s != 0);
   }
 };
 

@@ -110,22 +110,59 @@ __global__ void __launch_bounds__(64) gw_pairing_kernel(uint8_t *gt, const uint8
   const size_t fb = fpk<N>().fbytes;
   GW<N>::pairing(gt + idx * 10 * fb, g1 + idx * 2 * fb, g2 + idx * 10 * fb, sched);
 }
+// element_prod_pairing: the Miller value of every TERM (n k wavefronts), then one wavefront per product
+template <int N>
+__global__ void __launch_bounds__(64) gw_miller_kernel(uint32_t *recs, const uint8_t *g1, const uint8_t *g2, size_t terms, const uint64_t *sched, KArgs<N> ka) {
+  const size_t idx = blockIdx.x;
+  if (idx >= terms) return;
+  const size_t fb = fpk<N>().fbytes;
+  GW<N>::miller_term(recs + idx * GW<N>::kRec, g1 + idx * 2 * fb, g2 + idx * 10 * fb, sched);
+}
+template <int N>
+__global__ void __launch_bounds__(64) gw_finish_kernel(uint8_t *gt, const uint32_t *recs, size_t n, int k, const uint64_t *sched, KArgs<N> ka) {
+  const size_t idx = blockIdx.x;
+  if (idx >= n) return;
+  GW<N>::finish(gt + idx * 10 * fpk<N>().fbytes, recs + idx * (size_t) k * GW<N>::kRec, k, sched);
+}
+// pairing_pp_apply
+template <int N>
+__global__ void __launch_bounds__(64) gw_pp_apply_kernel(uint8_t *gt, const uint32_t *__restrict__ tab, const uint32_t *__restrict__ valid, const uint8_t *g2,
+                                                         size_t n, const uint64_t *sched, KArgs<N> ka) {
+  const size_t idx = blockIdx.x;
+  if (idx >= n) return;
+  const size_t fb = fpk<N>().fbytes;
+  GW<N>::pp_apply(gt + idx * 10 * fb, tab, *valid != 0, g2 + idx * 10 * fb, sched);
+}
 static bool gw_capable(const pbc_hip_pairing_s *P) { return P->type == 'g' && P->nlimb == 5 && P->deg == 5; }
-static const std::vector<uint64_t> &gw_schedule(pbc_hip_pairing_s *P) {
+static const DwSched &gw_schedules(pbc_hip_pairing_s *P) {
   static std::mutex mu;
   std::lock_guard<std::mutex> lk(mu);
-  if (P->gw_sched.empty()) {
+  if (P->gw_sched.e.empty()) {
     const DConst &C = P->dconst;
-    if (!gw::build_schedule(P->gw_sched, C.rbits, [&C](int m) { return (int) ((C.r[m >> 5] >> (m & 31)) & 1) - (int) ((C.rm[m >> 5] >> (m & 31)) & 1); }, C.phik, C.phikbits))
-      P->gw_sched.clear();
+    if (!gw::build_schedules(P->gw_sched, C.rbits, [&C](int m) { return (int) ((C.r[m >> 5] >> (m & 31)) & 1) - (int) ((C.rm[m >> 5] >> (m & 31)) & 1); }, C.phik, C.phikbits))
+      P->gw_sched.e.clear();
   }
   return P->gw_sched;
 }
-extern "C" size_t pbc_hip_diag_gw_schedule(pbc_hip_pairing_t *P, uint64_t *out, size_t cap) {
-  if (!P || !gw_capable(P)) return 0;
-  const std::vector<uint64_t> &S = gw_schedule(P);
-  for (size_t i = 0; i < S.size() && i < cap; i++) out[i] = S[i];
-  return S.size();
+// (the four schedules: ~50 KB, read-only, one copy per device the object runs on)
+static const uint64_t *gw_device_schedules(pbc_hip_pairing_s *P, const DwSched **host) {
+  const DwSched &S = gw_schedules(P);
+  if (S.e.empty()) return nullptr;
+  static const char kGwSchedKey = 0;
+  bool fresh = false;
+  uint64_t *d_sched = (uint64_t *) object_scratch(P, &kGwSchedKey, S.e.size() * sizeof(uint64_t), &fresh);
+  if (!d_sched) return nullptr;
+  if (fresh && hipMemcpy(d_sched, S.e.data(), S.e.size() * sizeof(uint64_t), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+  *host = &S;
+  return d_sched;
+}
+extern "C" size_t pbc_hip_diag_gw_schedule(pbc_hip_pairing_t *P, int which, uint64_t *out, size_t cap) {
+  if (!P || !gw_capable(P) || which < 0 || which > 3) return 0;
+  const DwSched &S = gw_schedules(P);
+  if (S.e.empty()) return 0;
+  const size_t first = S.off[which], last = which < 3 ? S.off[which + 1] : S.e.size();
+  for (size_t i = first; i < last && i - first < cap; i++) out[i - first] = S.e[i];
+  return last - first;
 }
 
 // pairing_pp for types d / g: single-lane table derivation, then one second argument per lane
@@ -189,16 +226,24 @@ int launch_d(pbc_hip_pairing_s *P, void *d_gt, const void *d_g1, const void *d_g
   unsigned grid = (unsigned) ((n + kBlock - 1) / kBlock);
   // The throughput kernel runs a batch this small at the latency of ONE lane (3.9 ms a pairing, ~2.9 ms more per further term
   // of a product): a wavefront per pairing -- per TERM for products, then one per product -- instead (pairing_dw.cuh).
-  if (k == 1 && gw_capable(P) && n <= P->d_wave_max) {
-    // type g: 14 ms a pairing on one lane whatever the batch size; a wavefront per pairing instead (20 KB schedule, kept with the object)
-    const std::vector<uint64_t> &S = gw_schedule(P);
-    if (S.empty()) return 1;
-    static const char kGwSchedKey = 0;
-    bool fresh = false;
-    uint64_t *d_sched = (uint64_t *) object_scratch(P, &kGwSchedKey, S.size() * sizeof(uint64_t), &fresh);
+  // type g: 14.5 ms a pairing on one lane whatever the batch size (+ 6.5 ms per further term of a product); a wavefront per pairing
+  // -- per TERM for products, then one per product -- instead (the schedules: kept with the object).  Saturated, the wavefronts
+  // finish 430 k pairings or 540 k terms a second: products of many terms reach the lane kernel's time a little earlier
+  // (measured: 4 terms ~4600 products, 16 terms ~3800).
+  const size_t gw_max = k <= 2 ? P->d_wave_max : (size_t) ((double) P->d_wave_max * (0.7 + 0.8 / k));
+  if (gw_capable(P) && k >= 1 && n <= gw_max && n * (size_t) k <= kDwMaxTerms) {
+    const DwSched *S = nullptr;
+    const uint64_t *d_sched = gw_device_schedules(P, &S);
     if (!d_sched) return 1;
-    if (fresh) HIP_TRY(hipMemcpy(d_sched, S.data(), S.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(gw_pairing_kernel<5>, dim3((unsigned) n), dim3(64), 0, s, (uint8_t *) d_gt, (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, (const uint64_t *) d_sched, kargs<5>(P));
+    if (k == 1) {
+      hipLaunchKernelGGL(gw_pairing_kernel<5>, dim3((unsigned) n), dim3(64), 0, s, (uint8_t *) d_gt, (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, d_sched + S->off[gw::SCHED_PAIRING], kargs<5>(P));
+    } else {
+      const size_t terms = n * (size_t) k;
+      uint32_t *recs = (uint32_t *) W.get(terms * GW<5>::kRec * sizeof(uint32_t));
+      if (!recs) return 1;
+      hipLaunchKernelGGL(gw_miller_kernel<5>, dim3((unsigned) terms), dim3(64), 0, s, recs, (const uint8_t *) d_g1, (const uint8_t *) d_g2, terms, d_sched + S->off[gw::SCHED_MILLER], kargs<5>(P));
+      hipLaunchKernelGGL(gw_finish_kernel<5>, dim3((unsigned) n), dim3(64), 0, s, (uint8_t *) d_gt, (const uint32_t *) recs, n, k, d_sched + S->off[gw::SCHED_FINISH], kargs<5>(P));
+    }
     HIP_TRY(hipGetLastError());
     return 0;
   }
@@ -244,6 +289,15 @@ int pp_init_launch_d(pbc_hip_pairing_s *P, pbc_hip_pp_s *pp, const uint8_t *dg1)
 int pp_apply_launch_d(pbc_hip_pp_s *pp, void *d_gt, const void *d_g2, size_t n, hipStream_t s) {
   pbc_hip_pairing_s *P = pp->P;
   unsigned grid = (unsigned) ((n + kBlock - 1) / kBlock);
+  if (gw_capable(P) && n <= P->d_wave_max) {
+    const DwSched *S = nullptr;
+    const uint64_t *d_sched = gw_device_schedules(P, &S);
+    if (!d_sched || S->lines > gw::kMaxLines) return 1;
+    hipLaunchKernelGGL(gw_pp_apply_kernel<5>, dim3((unsigned) n), dim3(64), 0, s, (uint8_t *) d_gt, (const uint32_t *) pp->tab, (const uint32_t *) pp->valid, (const uint8_t *) d_g2, n,
+                       d_sched + S->off[gw::SCHED_PP], kargs<5>(P));
+    HIP_TRY(hipGetLastError());
+    return 0;
+  }
   if (dw_capable(P) && n <= P->d_wave_max) {
     const DwSched *S = nullptr;
     const uint64_t *d_sched = dw_device_schedules(P, &S);

@@ -204,9 +204,10 @@ def test_wave_program_tables_of_type_g_are_current_and_match_the_host_schedule()
     bad, levels = gw_gen.check(progs, count=2)
     assert bad == 0 and 2000 < levels < 4000
     assert open(os.path.join(ROOT, "pbc_amd", "csrc", "gw_tables.h")).read() == gw_gen.emit(progs)
-    want = gw_gen.flat_schedule("g149")
     P = pbc_amd.Pairing(pbc_amd.param_text("g149"))
-    buf = np.zeros(8192, np.uint64)
-    n = pbc_amd.lib().pbc_hip_diag_gw_schedule(P._h, buf.ctypes.data_as(ctypes.c_void_p), len(buf))
-    assert n == len(want) and [int(x) for x in buf[:n]] == want
-    assert pbc_amd.lib().pbc_hip_diag_gw_schedule(pbc_amd.Pairing(pbc_amd.param_text("d159"))._h, buf.ctypes.data_as(ctypes.c_void_p), len(buf)) == 0
+    buf = np.zeros(16384, np.uint64)
+    for which, kind in enumerate(("pairing", "miller", "finish", "pp")):
+        want = gw_gen.flat_schedule(kind)
+        n = pbc_amd.lib().pbc_hip_diag_gw_schedule(P._h, which, buf.ctypes.data_as(ctypes.c_void_p), len(buf))
+        assert n == len(want) and [int(x) for x in buf[:n]] == want, kind
+    assert pbc_amd.lib().pbc_hip_diag_gw_schedule(pbc_amd.Pairing(pbc_amd.param_text("d159"))._h, 0, buf.ctypes.data_as(ctypes.c_void_p), len(buf)) == 0

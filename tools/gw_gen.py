@@ -37,6 +37,8 @@ def vec(name):
 QX, QY, VQY = vec("Qx"), vec("Qy"), vec("VQy")
 LX, LY, VLY = vec("Lx"), vec("Ly"), vec("VLy")
 FX, FY = vec("f.x"), vec("f.y")
+UX, UY = vec("u.x"), vec("u.y")                   # a second F_q^10 register: a term's Miller value (products)
+LCO = ["La", "Lb", "Lc"]                          # the line's coefficients in F_q (pairing_pp_apply loads them from the table)
 REGS5 = ["ux", "uy", "N", "gx", "gy", "wA", "wB", "Dn", "Bn", "tt", "iD", "iB", "P", "v0_", "v1_", "acc"]
 
 
@@ -138,17 +140,17 @@ def emit_point_dbl(p):
     M = p.sop([(XX, "THREE"), (W, "ONE")])
     S1 = p.mul(X, YY)
     Y4 = p.mul(YY, YY)
-    lb = p.mul(nZ3, "ZZ")
+    lb = p.mul(nZ3, "ZZ", out="Lb")
     ZZn = p.mul(Z3, Z3, out="ZZ")
     X3 = p.sop([(M, M), (S1, "M8")], out="X")
-    la = p.mul(M, "ZZ")
+    la = p.mul(M, "ZZ", out="La")
     MX = p.mul(M, X)
     nM = p.mul(M, "M1")
     S4 = p.mul(S1, "FOUR")
     p.mul(Y4, W16, out="W")
     p.mul(ZZn, Z3, out="ZZZ")
     p.sop([(M, S4), (nM, X3), (Y4, "M8")], out="Y")
-    lc = p.sop([(YY, "TWO"), (MX, "M1")])
+    lc = p.sop([(YY, "TWO"), (MX, "M1")], out="Lc")
     line_values(p, la, lb, lc)
 
 
@@ -164,7 +166,7 @@ def prog_point_add(neg):
     nZ3 = p.mul(nZ, H, out="nZ")
     HH = p.mul(H, H)
     nR = p.mul(R, "M1")
-    lc = p.sop([(Z3, Py), (nR, "Px")])
+    lc = p.sop([(Z3, Py), (nR, "Px")], out="Lc")
     HHH = p.mul(HH, H)
     XHH = p.mul(X, HH)
     ZZ3 = p.mul(Z3, Z3, out="ZZ")
@@ -175,7 +177,9 @@ def prog_point_add(neg):
     p.mul(ZZ3, Z3, out="ZZZ")
     p.sop([(RX, "ONE"), (nR, X3), (nYH, "ONE")], out="Y")
     p.mul(Z43, "A", out="W")
-    line_values(p, R, nZ3, lc)
+    la = p.mul(R, "ONE", out="La")
+    lb = p.mul(nZ3, "ONE", out="Lb")
+    line_values(p, la, lb, lc)
     return finish_packed(p)
 
 
@@ -207,6 +211,22 @@ def prog_sqr_dbl():
     p = Prog("sqrdbl", SLOTS, "ft")
     emit_f_sqr(p)
     emit_point_dbl(p)
+    return finish_packed(p)
+
+
+def prog_ln_eval():
+    """pairing_pp_apply: the line's value from coefficients a table supplied"""
+    p = Prog("ln_eval", SLOTS, "pt")
+    line_values(p, "La", "Lb", "Lc")
+    return finish_packed(p)
+
+
+def prog_mul_f_u():
+    """f <- f * u (products: u takes a term's Miller value)"""
+    p = Prog("mul_f_u", SLOTS, "ft")
+    vuy = [p.mul(UY[i], "V") for i in range(D)]
+    poly_sums(p, [(FX, UX), (FY, vuy)], FX)
+    poly_sums(p, [(FX, UY), (FY, UX)], FY)
     return finish_packed(p)
 
 
@@ -293,12 +313,12 @@ def build():
     for row in XQ:
         for n in row:
             SLOTS.add("N" + n)                        # the negated Frobenius constants
-    for n in POINT + QX + QY + VQY + LX + LY + VLY + FX + FY + ["nrm", "ninv"]:
+    for n in POINT + QX + QY + VQY + LX + LY + VLY + FX + FY + ["nrm", "ninv"] + LCO + UX + UY:
         SLOTS.add(n)
     for r in REGS5:
         for n in vec(r):
             SLOTS.add(n)
-    progs = [prog_point_dbl(), prog_point_add(False), prog_point_add(True), prog_line_mul(), prog_f_sqr(), prog_sqr_dbl(), prog_fe1(), prog_fe2(), prog_fe3(),
+    progs = [prog_point_dbl(), prog_point_add(False), prog_point_add(True), prog_line_mul(), prog_f_sqr(), prog_sqr_dbl(), prog_ln_eval(), prog_mul_f_u(), prog_fe1(), prog_fe2(), prog_fe3(),
              prog_lucas(0), prog_lucas(1), prog_fe4()]
     return {p.name: p for p in progs}
 
@@ -306,7 +326,48 @@ def build():
 # ---------------------------------------------------------------------------------------------------------------------
 # the pairing as a sequence of program names (gw_sched.h is this function)
 # ---------------------------------------------------------------------------------------------------------------------
+def steps(plus, minus, rbits):
+    """the Miller loop's steps in order: "dbl" / "addp" / "addm" / "sqr" """
+    dig = lambda m: ((plus >> m) & 1) - ((minus >> m) & 1)
+    st = []
+    for m in range(rbits - 2, -1, -1):
+        st.append("dbl")
+        if m > 0 and dig(m):
+            st.append("addm" if dig(m) < 0 else "addp")
+        if m > 0:
+            st.append("sqr")
+    return st
+
+
+def final_sequence(phik):
+    seq = ["fe1", "OP_BZERO", "fe2", "OP_INV", "fe3"]
+    nb = phik.bit_length()
+    for j in range(nb - 1, -1, -1):
+        seq.append("lucas%d" % ((phik >> j) & 1 if j else 0))
+    seq.append("fe4")
+    return seq
+
+
+def pp_sequence(plus, minus, rbits):
+    """pairing_pp_apply: line i of the table -> La, Lb, Lc (the first by an entry of its own, line i + 1 beside the first level of
+    the product with line i), its value, the product; squares where the Miller loop has them"""
+    seq, i = [("OP_LOADLINE", 0)], 0
+    st = steps(plus, minus, rbits)
+    nl = sum(1 for x in st if x != "sqr")
+    for x in st:
+        if x == "sqr":
+            seq.append("f_sqr")
+        else:
+            seq += ["ln_eval", ("line_mul", i + 1 if i + 1 < nl else None)]
+            i += 1
+    return seq
+
+
 def sequence(plus, minus, rbits, phik):
+    return miller_sequence(plus, minus, rbits) + final_sequence(phik)
+
+
+def miller_sequence(plus, minus, rbits):
     seq = []
     dig = lambda m: ((plus >> m) & 1) - ((minus >> m) & 1)
     for m in range(rbits - 2, -1, -1):
@@ -321,13 +382,7 @@ def sequence(plus, minus, rbits, phik):
             fused[-1] = "sqrdbl"
         else:
             fused.append(n)
-    seq = fused
-    seq += ["fe1", "OP_BZERO", "fe2", "OP_INV", "fe3"]
-    nb = phik.bit_length()
-    for j in range(nb - 1, -1, -1):
-        seq.append("lucas%d" % ((phik >> j) & 1 if j else 0))
-    seq.append("fe4")
-    return seq
+    return fused
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -392,6 +447,14 @@ class Model:
                 e["Bn%d" % i] = (1 if i == 0 else 0) if b0 else e["wB%d" % i]
             self.flat.append(("op", "bzero"))
             return
+        load = None
+        if isinstance(name, tuple):                   # ("OP_LOADLINE", i) / (program, line to load beside its first level)
+            name, load = name
+            if name == "OP_LOADLINE":
+                for c, n in enumerate(LCO):
+                    e[n] = self.table[load][c]
+                self.flat.append(("op", "loadline", load))
+                return
         p = self.progs[name]
         for lev, row in enumerate(p.levels):
             T = max(len(n.terms) for n in row)
@@ -406,7 +469,11 @@ class Model:
             for s, v in writes:
                 e[s] = v
             self.levels += 1
-            self.flat.append(("level", name, lev))
+            ld = load if lev == 0 else None
+            if ld is not None:
+                for c, n in enumerate(LCO):
+                    e[n] = self.table[ld][c]
+            self.flat.append(("level", name, lev, ld))
 
     def set_inputs(self, g1, g2):
         q, e, fb, P = self.q, self.env, self.fb, self.P
@@ -429,15 +496,64 @@ class Model:
             e[FX[i]], e[FY[i]] = (1 if i == 0 else 0), 0
         return ok
 
-    def pairing(self, g1, g2):
+    def miller(self, g1, g2):
         ok = self.set_inputs(g1, g2)
         self.flat = []
-        for n in sequence(self.plus, self.minus, self.rbits, self.phik):
+        for n in miller_sequence(self.plus, self.minus, self.rbits):
+            self.run(n)
+        return ok
+
+    def finish(self):
+        for n in final_sequence(self.phik):
             self.run(n)
         self.flat.append(("op", "end"))
-        if not ok:
-            return None
         return [self.env[n] for n in FX + FY]
+
+    def pairing(self, g1, g2):
+        ok = self.miller(g1, g2)
+        r = self.finish()
+        return r if ok else None
+
+    def product(self, terms):
+        """element_prod_pairing: one wavefront per TERM for the Miller values, then one per product -- f <- the first record, u <-
+        each further one and mul_f_u, ONE final exponentiation"""
+        vals, ok = [], True
+        for g1, g2 in terms:
+            ok = self.miller(g1, g2) and ok
+            vals.append([self.env[n] for n in FX + FY])
+        self.flat = []
+        for n, v in zip(FX + FY, vals[0]):
+            self.env[n] = v
+        for val in vals[1:]:
+            for n, v in zip(UX + UY, val):
+                self.env[n] = v
+            self.run("mul_f_u")
+            self.flat.append(("op", "mark"))
+        if len(vals) == 1:
+            self.flat.append(("op", "mark"))
+        r = self.finish()
+        return r if ok else None
+
+    def pp_table(self, g1, g2dummy):
+        """what d_pp_init_lane leaves (in this script's scaling of the lines)"""
+        ok = self.set_inputs(g1, g2dummy)
+        keep, tab = self.flat, []
+        for x in steps(self.plus, self.minus, self.rbits):
+            if x == "sqr":
+                continue
+            self.run("pt_dbl" if x == "dbl" else "pt_" + x)
+            tab.append([self.env[n] for n in LCO])
+        self.flat = keep
+        return tab, ok
+
+    def pp_apply(self, table, g1, g2):
+        ok = self.set_inputs(g1, g2)
+        self.table = table
+        self.flat = []
+        for n in pp_sequence(self.plus, self.minus, self.rbits):
+            self.run(n)
+        r = self.finish()
+        return r if ok else None
 
 
 def check(progs, count=3):
@@ -449,11 +565,26 @@ def check(progs, count=3):
         for i in range(min(count, len(gt))):
             M.levels = 0
             r = M.pairing(g1[i], g2[i])
+            levels = M.levels
             want = [int.from_bytes(gt[i][M.fb * c:M.fb * c + M.fb], "big") for c in range(2 * D)]
             if (r or ident) != want:
                 bad += 1
                 print("MISMATCH", name, i)
-    return bad, M.levels
+            if i < 2:
+                tab, ok = M.pp_table(g1[i], g2[i])
+                r = M.pp_apply(tab, g1[i], g2[i])
+                if (r or ident) != want:
+                    bad += 1
+                    print("MISMATCH (pp)", name, i)
+    for name in ("g149_prod4x3.vec", "g149_prod3x4_edge.vec"):
+        g1, g2, gt = load_vec(os.path.join(ROOT, "tests", "golden", name))
+        k = len(g1) // len(gt)
+        for i in range(len(gt)):
+            r = M.product([(g1[i * k + t], g2[i * k + t]) for t in range(k)])
+            if (r or ident) != [int.from_bytes(gt[i][M.fb * c:M.fb * c + M.fb], "big") for c in range(2 * D)]:
+                bad += 1
+                print("MISMATCH (product)", name, i)
+    return bad, levels
 
 
 def tables(progs):
@@ -474,8 +605,9 @@ def tables(progs):
 _PROGS = None
 
 
-def flat_schedule(pname="g149"):
-    """the packed schedule of one pairing as the model executes it (gw_sched.h must build the same)"""
+def flat_schedule(kind="pairing", pname="g149"):
+    """the packed schedules as the model executes them (gw_sched.h must build the same): "pairing"; "miller" (a term of a product);
+    "finish" (the product with a term's value, a mark, the final exponentiation); "pp" (pairing_pp_apply)"""
     global _PROGS
     if _PROGS is None:
         _PROGS = build()
@@ -484,14 +616,23 @@ def flat_schedule(pname="g149"):
     first = {name: f for name, f, c in pidx}
     M = Model(pname, progs)
     g1, g2, gt = load_vec(os.path.join(ROOT, "tests", "golden", "g149_rand16.vec"))
-    M.pairing(g1[0], g2[0])
+    if kind == "pairing":
+        M.pairing(g1[0], g2[0])
+    elif kind == "miller":
+        M.miller(g1[0], g2[0])
+        M.flat.append(("op", "end"))
+    elif kind == "finish":
+        M.product([(g1[0], g2[0]), (g1[1], g2[1])])
+    else:
+        tab, ok = M.pp_table(g1[0], g2[0])
+        M.pp_apply(tab, g1[0], g2[0])
     out = []
     for e in M.flat:
         if e[0] == "level":
             r, T, lanes = index[first[e[1]] + e[2]]
-            out.append(r | lanes << 12 | T << 34)
+            out.append(r | lanes << 12 | T << 34 | ((e[3] << 42 | 1 << 55) if e[3] is not None else 0))
         else:
-            out.append({"bzero": 1, "inv": 2, "end": 3}[e[1]] << 38)
+            out.append({"bzero": 1, "inv": 2, "end": 3, "loadline": 4, "mark": 5}[e[1]] << 38 | ((e[2] << 42 | 1 << 55) if len(e) > 2 else 0))
     return out
 
 
@@ -505,7 +646,7 @@ def emit(progs):
            "#pragma once", "#include <stdint.h>", "namespace pbc { namespace gw {",
            "constexpr int kSlots = %d;" % len(SLOTS.order)]
     out.append("enum Slot : int { " + ", ".join("S_%s = %d" % (n.replace(".", "_"), i) for i, n in enumerate(SLOTS.order) if keep(n)) + " };")
-    out.append("enum { OP_LEVEL = 0, OP_BZERO = 1, OP_INV = 2, OP_END = 3 };      // schedule entries (gw_sched.h; the values of dw_tables.h)")
+    out.append("enum { OP_LEVEL = 0, OP_BZERO = 1, OP_INV = 2, OP_END = 3, OP_LOADLINE = 4, OP_MARK = 5 };      // schedule entries (gw_sched.h; dw_tables.h's values)")
     out.append("struct LevelRef { uint16_t row; uint8_t T, lanes; };")
     out.append("struct ProgRef { const char *name; uint16_t first, count; };")
     out.append("constexpr int kProgs = %d, kLevels = %d, kRows = %d;" % (len(pidx), len(index), len(rows)))

@@ -139,7 +139,14 @@ int pbc_hip_element_pairing_batch(pbc_hip_pairing_t *p, uint8_t *gt, const uint8
  *
  * Batch sizes for the 33-word fields (a1.param, e.param, type a above 512 bits): the kernels hold TWO waves per SIMD in
  * 256-lane workgroups, i.e. 2^17 units fill an MI355X once (e.param: 40 ms for any batch up to 2^16 units, 68 ms for
- * 2^17, 131 ms for 2^18); batches of 2^18 and more amortise the tail of a launch. */
+ * 2^17, 131 ms for 2^18); batches of 2^18 and more amortise the tail of a launch.
+ * Small batches of type a1 and of type a parameter sets outside the 512-bit fast path (round 6): where q leaves ten bits of the
+ * limb radix free and fills twelve bits of its top limb (a1.param, 1024-bit and 512-bit generated type a sets; the object decides
+ * at init) a launch of up to 12 288 units on the 33-word fields / 6144 on the 16-word ones ("hip_wave_max N", 0 = never) gives
+ * every pairing -- every TERM of a product, then every product; every second argument of pairing_pp_apply -- a workgroup of four
+ * wavefronts ("hip_wave4_max N": above it one) on the same limb-per-lane routines with the Miller loop over the signed digits of
+ * the order: a1.param 9.2 ms a pairing or a product of any few terms and 4.1 ms a pairing_pp_apply, where one lane needs 0.2 s /
+ * 0.2 s a term / 70 ms (a1_pairing, a1_pairings_affine, a1_pairing_pp_apply: ecc/a_param.c:1840-2015, :2100-2193, :1728-1818). */
 int pbc_hip_element_pairing_batch_dev(pbc_hip_pairing_t *p, void *d_gt, const void *d_g1,
                                       const void *d_g2, size_t n, void *stream);
 

@@ -1026,7 +1026,10 @@ static int cmd_soak(int argc, char **argv) {
       for (int sparse = 0; sparse < 2; sparse++)
         for (int kind = 0; kind < 3; kind++, u++) {                       /* 0: (cP, rQ)  1: (rP, cQ)  2: (cP, cQ) */
           if (kind == 1) element_random(P); else soak_point(P, t, sparse, rbits);
-          if (kind == 0) element_random(Q); else soak_point(Q, (t + kind) % npat, sparse, rbits);
+          /* (type g: a twist point with both coordinates in F_q gives a Miller value in F_q^2, which the easy part of the final
+           * exponentiation sends to +-1 -- and the reference's own cc_tatepower of g_param.c then inverts zero ("division by
+           * zero", poly.c:416): no reference value exists, so its sparse patterns fill every coefficient too) */
+          if (kind == 0) element_random(Q); else soak_point(Q, (t + kind) % npat, type == 'g' ? 0 : sparse, rbits);
           element_to_bytes(b1 + u * l1, P);
           element_to_bytes(b2 + u * l2, Q);
           element_pairing(out, P, Q);

@@ -72,6 +72,9 @@ struct pbc_hip_pairing_s {
   size_t host_chunk;         // host-buffer entry points: units per chunk when the parameter text says "hip_host_chunk N" (0: default)
   size_t a_wave4_max;        // ... and up to this size four wavefronts per pairing ("hip_wave4_max N")
   size_t a_wave2_max;        // ... and between the two, up to this size, two ("hip_wave2_max N", round 5)
+  std::vector<uint32_t> ag_aux;  // type a1 / type a outside the fast path: the table of the wave kernels (pairing_aw.cuh AG<N>: LEFF, five subtraction constants; empty: this q keeps the lane kernels)
+  size_t ag_wave_max;        // ... batches (terms of products) up to this size take them ("hip_wave_max N", 0 = never), four wavefronts per unit up to ag_wave4_max ("hip_wave4_max N")
+  size_t ag_wave4_max;
   size_t a_wave_max;         // type a fast path, element_pairing: batches up to this size take one WAVEFRONT per pairing (pairing_aw.cuh; "hip_wave_max N", 0 = never)
   size_t d_wave_max;         // type d, five-word fields: single pairings in batches up to this size take one wavefront each (pairing_dw.cuh; "hip_dwave_max N")
   size_t a_prod_chunk;       // ... otherwise: terms per launch of the one-term-per-lane kernels ("hip_prod_chunk N", tests)
@@ -226,6 +229,31 @@ static void set_zr(pbc_hip_pairing_s *P, const pbc_host::Big &r) {
     if (r.bits() <= 32 * widths[i]) P->zr_nlimb = widths[i];
 }
 
+// The wave kernels of type a1 and of type a parameters outside the fast path (pairing_aw.cuh, AG<N>): q must leave ten bits of
+// the radix 2^(W L) free (the value bounds of the limb-form routines) and fill at least twelve bits of its top limb (the
+// borrowed subtraction constants: what the bound tracker of pairing_al.cuh assumes for a.param's q >= 2^504); the table holds
+// LEFF = the limbs q fills and c q in borrowed form for (c, D) = (2, 1) (4, 2) (8, 4) (12, 2) (16, 2).  "hip_wave_max 0": never.
+template <int N>
+static void ag_aux_build(pbc_hip_pairing_s *P, const pbc_host::Big &q, const char *txt, size_t len) {
+  constexpr int W = Limbs29<N>::W, L = Limbs29<N>::L;
+  P->ag_aux.clear();
+  // measured cut-overs (profiles/r06_agwave_latency.txt): a lane needs 0.2 s (a1.param) / 38 ms (a_160_1024) / 6.5 ms (512-bit q) however
+  // small the batch; the wave kernels saturate at 72 k / 330 k / 1.0 M pairings a second.  On the 33-word fields four wavefronts per
+  // unit are the faster shape at every size (two 256-register waves fit a SIMD either way)
+  int wave_max = N >= 32 ? 12288 : 6144, wave4_max = N >= 32 ? 12288 : 1024;
+  pbc_host::param_int(txt, len, "hip_wave_max", wave_max);
+  pbc_host::param_int(txt, len, "hip_wave4_max", wave4_max);
+  P->ag_wave_max = wave_max < 0 ? 0 : (size_t) wave_max;
+  P->ag_wave4_max = wave4_max < 0 ? 0 : (size_t) wave4_max;
+  const int qb = q.bits(), leff = (qb + W - 1) / W, top = qb - W * (leff - 1);
+  if (leff > L || leff < 3 || W * L - qb < 10 || top < 12) return;
+  std::vector<uint32_t> a(pbc::AW_AUX_HEAD + 5 * L, 0u);
+  a[0] = (uint32_t) leff;
+  static const uint32_t cd[5][2] = {{2, 1}, {4, 2}, {8, 4}, {12, 2}, {16, 2}};
+  for (int t = 0; t < 5; t++)
+    if (pbc_host::ksub_build(q, leff, W * (leff - 1) + 12, cd[t][0], cd[t][1], &a[pbc::AW_AUX_HEAD + t * L], W)) return;
+  P->ag_aux.swap(a);
+}
 // a_init_pairing (ecc/a_param.c:1431-1472) + pbc_param_init_a (:1489-1502)
 static int init_type_a(pbc_hip_pairing_s *P, const char *txt, size_t len) {
   using namespace pbc_host;
@@ -299,6 +327,7 @@ static int init_type_a(pbc_hip_pairing_s *P, const char *txt, size_t len) {
       return fail("type a: only 160..1056-bit q is supported by this build (got %d bits)", q.bits());
     P->nlimb = q.bits() <= 512 ? 16 : 33;
     P->a_generic = true;
+    if (P->nlimb == 16) ag_aux_build<16>(P, q, txt, len); else ag_aux_build<33>(P, q, txt, len);
     P->a.rbits = pbc_host::naf_of_half(r, P->a.r, P->a.rm, 34);      // signed digits: three for a Solinas r
     if (!P->a.rbits) return fail("type a: r too wide for the Miller loop digits");
   }
@@ -349,6 +378,7 @@ static int init_type_a1(pbc_hip_pairing_s *P, const char *txt, size_t len) {
   P->len_fq = (p.bits() + 7) / 8;
   P->len1 = P->len2 = P->lenT = 2 * P->len_fq;
   set_zr(P, n);
+  if (P->nlimb == 16) ag_aux_build<16>(P, p, txt, len); else ag_aux_build<33>(P, p, txt, len);
   // work model (a1_pairing_proj, a_param.c:1840-2015): per bit of n a tangent (10 F_p products incl.
   // the projective line), a doubling (10) and an F_p^2 square + product (2 + 3); per set bit a chord
   // (8), a mixed addition (12) and a product (3); f^(p-1) and the 11-bit power are negligible.

@@ -160,29 +160,29 @@ inline int naf_of_half(const Big &r, uint32_t *plus, uint32_t *minus, int words)
 // q >= 2^(minbits - 1) that puts K's top limb above any top limb b can have.  This routine is the other half, run at
 // init for the actual q: q has at least `minbits` bits, the limbs are built as the kernels expect, sum to c q, fit 32
 // bits and dominate D (2^29 - 1) below the top.  Returns the number of violations (0 = the limb-form path may be used).
-inline int ksub_build(const Big &q, int L, int minbits, uint32_t c, uint32_t D, uint32_t *k) {
+inline int ksub_build(const Big &q, int L, int minbits, uint32_t c, uint32_t D, uint32_t *k, int W = 29) {   // W: bits of a limb (28 on the 33-word fields)
   int bad = 0;
-  if (q.bits() < minbits || q.bits() > 29 * L) bad++;
+  if (q.bits() < minbits || q.bits() > W * L) bad++;
   Big cb;
   cb.w.push_back(c);
   const Big v = Big::mul(q, cb);
-  if (v.bits() > 29 * (L - 1) + 32) bad++;
+  if (v.bits() > W * (L - 1) + 32) bad++;
   for (int i = 0; i < L; i++) {
     uint64_t x = 0;
-    for (int b = 0; b < (i < L - 1 ? 29 : 32); b++) x |= (uint64_t) v.bit(29 * i + b) << b;
-    x += (i < L - 1 ? (uint64_t) D << 29 : 0);
+    for (int b = 0; b < (i < L - 1 ? W : 32); b++) x |= (uint64_t) v.bit(W * i + b) << b;
+    x += (i < L - 1 ? (uint64_t) D << W : 0);
     if (i > 0) {
       if (x < D) bad++;
       x -= D;
     }
     if (x >> 32) bad++;
-    if (i < L - 1 && x < (uint64_t) D * ((1u << 29) - 1)) bad++;
+    if (i < L - 1 && x < (uint64_t) D * ((1u << W) - 1)) bad++;
     if (i == L - 1 && x < (uint64_t) D + 1) bad++;
     k[i] = (uint32_t) x;
   }
-  Big sum;                                 // sum_i k_i 2^(29 i) == c q
+  Big sum;                                 // sum_i k_i 2^(W i) == c q
   for (int i = L - 1; i >= 0; i--) {
-    for (int b = 0; b < 29; b++) sum.shl1();
+    for (int b = 0; b < W; b++) sum.shl1();
     Big t;
     t.w.push_back(k[i]);
     t.trim();

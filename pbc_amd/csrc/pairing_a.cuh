@@ -97,6 +97,7 @@ struct AConst {          // a_pairing_data (ecc/a_param.c:30-34) + phikonr = h (
 };
 static_assert(sizeof(AConst) <= KOFF_XS - KOFF_TYPE, "constant block layout");
 #define c_a (pbc::kconst<pbc::AConst, pbc::KOFF_TYPE>())
+constexpr int AW_AUX_HEAD = 4;   // the table of the wave kernels of type a1 / generic type a (pairing_aw.cuh AG<N>, host_params.h ag_aux_build): words before its five constants; [0] = LEFF
 
 // A first argument with y = 0 is a point of order 2 ((0, 0): the zero-filled record).  Its tangent is vertical and the
 // reference divides by zero (point_to_affine / the slope 1/2y); the pairing value is 1 since 2 is coprime to the group

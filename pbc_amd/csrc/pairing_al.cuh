@@ -57,6 +57,7 @@ template <int N>
 struct AL {
   static constexpr int L = Limbs29<N>::L;
   static constexpr uint32_t MASK = Limbs29<N>::MASK;
+  static constexpr bool kDigits = false;                    // (pairing_aw.cuh: the Solinas loop; AG<N> is the other choice)
   static_assert(Limbs29<N>::W == 29 && 2 * L + L <= 63, "limb-form type a needs 29-bit limbs and room for a doubled operand");
   typedef fl<N> el;
   typedef uint32_t vL __attribute__((ext_vector_type(L)));

@@ -32,13 +32,34 @@ template <int N> __shared__ uint32_t g_lds_aw_t[AW_SLOTS * 64];
 #define g_lds_aw g_lds_aw_t<N>
 #endif
 
-template <int N, int NW = 1>                 // NW: wavefronts that work on ONE pairing (1, 2 or 4 = a 128- / 256-lane workgroup: see round_nw)
+// Round 6: the same routines for type a1 and for type a parameters outside the 512-bit Solinas fast path (AG<N> below in place
+// of AL<N>): the Miller loop walks the signed digits of the group order (pairing_a.cuh a1_miller_lane), the limbs are W = 29 or 28
+// bits wide (fp.cuh Limbs29: 38 limbs of 28 bits on the 33-word fields, one lane each), the subtraction constants and the
+// number of limbs q really fills (LEFF: a 1033-bit p leaves the 38th limb empty, so the borrow is taken from the 37th) come
+// from a table the host builds per object (host_params.h aw_aux_build), and the records are fq_bytes long.  Device only: the
+// host mirror proves the bounds on AL<16>; they carry over when q fills LEFF limbs to within 2^(W LEFF - 17) and leaves ten bits
+// of the radix free (checked by the host, which otherwise keeps the lane kernels).
+template <int N>
+struct AG {
+  static constexpr int L = Limbs29<N>::L;
+  static constexpr uint32_t MASK = Limbs29<N>::MASK;
+  static constexpr bool kDigits = true;
+  typedef fl<N> el;
+  enum { K2 = 0, K4 = 1, K8 = 2, K12 = 3, K16 = 4 };
+  static PBC_DEV void to_el(el &r, const fp<N> &a) { to_limbs<N>(r, a); }
+  static PBC_DEV void to_words(fp<N> &r, const el &a) { from_limbs<N>(r, a); }
+};
+
+template <int N, int NW = 1, class A_ = AL<N>>   // NW: wavefronts that work on ONE pairing (1, 2 or 4 = a 128- / 256-lane workgroup: see round_nw)
 struct AW {
-  typedef AL<N> A;
+  typedef A_ A;
   typedef typename A::el el;
   static constexpr int L = A::L;
+  static constexpr int WB = Limbs29<N>::W;     // bits of a limb
   static constexpr uint32_t MASK = A::MASK;
+  static constexpr bool kDigits = A::kDigits;  // the Miller loop over signed digits (type a1 / generic type a) instead of the Solinas loop
   enum { K2 = A::K2, K4 = A::K4, K8 = A::K8, K12 = A::K12, K16 = A::K16 };
+  static PBC_DEV int fq_len() { if constexpr (kDigits) return (int) fpk<N>().fbytes; else return 4 * N; }   // bytes of a coordinate record
 
 #ifdef PBC_HOSTSIM
   // ---- host mirror: an element is all L limbs (AL's el with its tracker); the lanes run in a loop ------------------
@@ -149,14 +170,22 @@ struct AW {
   uint32_t nv;                                                 // -1/q mod 2^29
   masks mk;
   int par = 0;                                                 // which set of round slots is written next (NW > 1)
+  const uint32_t *aux = nullptr;                               // AG: the object's table (LEFF, five constants of L limbs)
+  int leff = L;                                                // limbs q fills (the top one takes the borrows and keeps the carries)
   PBC_DEV void init() {
     const int j = lane();
+    if constexpr (kDigits) {
+      leff = __builtin_amdgcn_readfirstlane((int) aux[0]);
 #pragma unroll
-    for (int k = 0; k < 5; k++) kk[k] = j < L ? c_a.ksub[k][j] : 0u;
+      for (int k = 0; k < 5; k++) kk[k] = j < L ? aux[AW_AUX_HEAD + k * L + j] : 0u;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 5; k++) kk[k] = j < L ? c_a.ksub[k][j] : 0u;
+    }
     qq = j < L ? fpk<N>().p29[j] : 0u;
     nv = fpk<N>().ninv29;
-    mk.mr = j < L - 1 ? MASK : (j == L - 1 ? 0xffffffffu : 0u);
-    mk.cm = j < L - 1 ? 0xffffffffu : 0u;
+    mk.mr = j < leff - 1 ? MASK : (j == leff - 1 ? 0xffffffffu : 0u);
+    mk.cm = j < leff - 1 ? 0xffffffffu : 0u;
   }
   static PBC_DEV int lane() { return (int) (threadIdx.x & 63); }
   static PBC_DEV W from_above(W x) { return (W) __builtin_amdgcn_update_dpp(0, (int) x, 0x130, 0xf, 0xf, true); }   // wave_shl:1 : lane j <- lane j + 1
@@ -165,7 +194,7 @@ struct AW {
   template <int S> static PBC_DEV W shl(W a) { return a << S; }
   PBC_DEV W subk(W a, W b, int k) const { return a - b + kk[k]; }
   PBC_DEV W negk(W b, int k) const { return kk[k] - b; }
-  static PBC_DEV W norm_m(W a, masks k) { return (a & k.mr) + from_below((a >> 29) & k.cm); }
+  static PBC_DEV W norm_m(W a, masks k) { return (a & k.mr) + from_below((a >> WB) & k.cm); }
   static PBC_DEV W strict_limbs(W x, masks k) {
     for (;;) {
       x = norm_m(x, k);
@@ -184,7 +213,7 @@ struct AW {
     if (TERMS == 2) acc += (uint64_t) x1 * b1;
     const uint32_t m = ((uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) acc) * ninv) & MASK;   // scalar unit
     acc += (uint64_t) m * q;
-    const uint32_t c = __builtin_amdgcn_alignbit((uint32_t) (acc >> 32), (uint32_t) acc, 29);   // < 2^31: acc < 2^60
+    const uint32_t c = __builtin_amdgcn_alignbit((uint32_t) (acc >> 32), (uint32_t) acc, WB);   // < 2^31: acc < 2^60
     nxt = c + from_above((uint32_t) acc & MASK);
   }
   template <int TERMS>
@@ -304,7 +333,7 @@ struct AW {
   }
   PBC_DEV W sub_q(W x) const {
     const int j = lane();
-    W r = x - qq + (j < L - 1 ? (1u << 29) : 0u) - (j > 0 && j < L ? 1u : 0u);
+    W r = x - qq + (j < leff - 1 ? (1u << WB) : 0u) - (j > 0 && j < leff ? 1u : 0u);
     return strict_limbs(r, mk);
   }
   static PBC_DEV bool is_zero(W x) { return __ballot(x != 0) == 0; }
@@ -313,7 +342,7 @@ struct AW {
   // N canonical / Montgomery words in memory (the same for every lane: a table entry, a constant) -> this lane's limb
   // (AL::to_el_uniform lane by lane: limb j = bits 29 j .. 29 j + 28)
   static PBC_DEV W load_uniform(const uint32_t *w) {
-    const int j = lane(), bit = 29 * (j < L ? j : 0), i = bit >> 5, sh = bit & 31;
+    const int j = lane(), bit = WB * (j < L ? j : 0), i = bit >> 5, sh = bit & 31;
     const uint64_t pair = ((uint64_t) (i + 1 < N ? w[i + 1] : 0u) << 32) | w[i];
     return j < L ? (uint32_t) (pair >> sh) & MASK : 0u;
   }
@@ -418,6 +447,28 @@ struct AW {
     s.Y = norm(subk(t0, t1, K12));
   }
   PBC_DEV void add_step(state &s, const W &x2, const W &y2) {   // AL::add_step
+    if constexpr (kDigits) {
+      // (an order with hundreds of non-zero digits: the same products -- the same operand classes, the same borrowed constants --
+      // in five rounds of up to four independent ones instead of one after the other)
+      W a, b, c, Z3, HH, lx, HHH, XHH, RR, t0, ly, ZZn, YH, unused;
+      mul2(a, b, x2, s.ZZ, s.Z, s.ZZ);
+      const W H = norm(subk(a, s.X, K16));
+      mul4(c, Z3, HH, unused, y2, b, H, s.Z, H, H, H, H, 3);
+      const W R = norm(subk(c, s.Y, K16));
+      mul4(lx, HHH, XHH, RR, R, add(s.Qx, x2), HH, H, s.X, HH, R, R, 4);
+      mul4(t0, ly, ZZn, YH, Z3, y2, Z3, s.Qy, Z3, Z3, s.Y, HHH, 4);
+      lx = norm(subk(lx, t0, K2));
+      W t1 = norm(subk(RR, HHH, K2));
+      t1 = norm(subk(t1, shl<1>(XHH), K4));
+      const W d = norm(subk(XHH, t1, K16));
+      const W e = mul(R, d);
+      s.Y = norm(subk(e, YH, K2));
+      s.X = t1;
+      s.Z = Z3;
+      s.ZZ = ZZn;
+      fmul(s, lx, ly);
+      return;
+    }
     W t0 = mul(x2, s.ZZ);
     const W H = norm(subk(t0, s.X, K16));
     t0 = mul(s.Z, s.ZZ);
@@ -444,6 +495,29 @@ struct AW {
     s.Z = Z3;
     s.ZZ = sqr(Z3);
     fmul(s, lx, ly);
+  }
+
+  // The Miller loop: a.param's Solinas order (a_pairing_proj, ecc/a_param.c:1101-1210: exp2 doublings, one addition after bit
+  // exp1), or -- type a1 and type a parameters of other shapes -- the signed digits of the order (pairing_a.cuh a1_miller_lane:
+  // a1_pairing_proj, a_param.c:1840-2015, with the digits of hostbn.h naf_of_half)
+  PBC_DEV void miller_loop(state &s, const W &Px, const W &Py) {
+    if constexpr (kDigits) {
+      W nPy = norm(negk(Py, K2));
+      for (int i = c_a.rbits - 2; i >= 0; i--) {
+        double_step(s);
+        const int dig = i > 0 ? a1_digit(i) : 0;
+        if (dig) add_step(s, Px, dig < 0 ? nPy : Py);
+      }
+    } else {
+      for (int i = c_a.exp2 - 1; i >= 0; i--) {
+        double_step(s);
+        if (i == c_a.exp1) {
+          W y2 = Py;
+          if (c_a.sign1 < 0) y2 = norm(negk(y2, K2));
+          add_step(s, Px, y2);
+        }
+      }
+    }
   }
 
   // f^((q^2-1)/r): AL::final_exp with the inversion on the wave.  Leaves (v0 R-scaled, y) for the word-form tail:
@@ -522,7 +596,7 @@ struct AW {
   // Q = (Qx, Qy) and R mod q into the wave's registers through lane 0 and the LDS slots; returns a_on_curve(Q) (lane 0's
   // answer, broadcast)
   PBC_DEV bool load_second(state &s, W &oneR, const uint8_t *g2) {
-    constexpr int NB = 4 * N;
+    const int NB = fq_len();
     bool ok = false;
     el e[3];
     if (lane0()) {
@@ -565,6 +639,30 @@ struct AW {
     s.fy = 0;
 #endif
     int slot = 0;
+    if constexpr (kDigits) {
+      // (a1_pp_apply_lane: one table entry per doubling and per addition, in loop order)
+      for (int i = c_a.rbits - 2; i >= 0; i--) {
+        W nfx, nfy, lx, ly;
+        {
+          const W e0 = add(s.fx, s.fy);
+          const W e1 = norm(subk(s.fx, s.fy, K2));
+          const W cA = load_uniform(tab + ((size_t) slot * 3 + 0) * N), cB = load_uniform(tab + ((size_t) slot * 3 + 1) * N);
+          mul4(nfx, nfy, lx, ly, e0, e1, shl<1>(s.fx), s.fy, s.Qx, cA, s.Qy, cB, 4);
+        }
+        s.fx = nfx;
+        s.fy = nfy;
+        lx = norm(add(lx, load_uniform(tab + ((size_t) slot * 3 + 2) * N)));
+        fmul(s, lx, ly);
+        slot++;
+        if (i > 0 && a1_digit(i)) {
+          const W cA = load_uniform(tab + ((size_t) slot * 3 + 0) * N), cB = load_uniform(tab + ((size_t) slot * 3 + 1) * N);
+          mul2(lx, ly, s.Qx, cA, s.Qy, cB);
+          lx = norm(add(lx, load_uniform(tab + ((size_t) slot * 3 + 2) * N)));
+          fmul(s, lx, ly);
+          slot++;
+        }
+      }
+    } else
     for (int i = c_a.exp2 - 1; i >= 0; i--, slot++) {
       W nfx, nfy, lx, ly;
       {
@@ -590,7 +688,7 @@ struct AW {
   }
   // The Miller loop of pairing_wave alone (f_(r, P)(Q) before the final exponentiation); validity as pairing_wave's
   PBC_DEV bool miller_wave(state &s, W &oneR, const uint8_t *g1, const uint8_t *g2) {
-    constexpr int NB = 4 * N;
+    const int NB = fq_len();
     bool valid = false;
     W Px, Py;
     {
@@ -622,14 +720,7 @@ struct AW {
 #else
     s.fy = 0;
 #endif
-    for (int i = c_a.exp2 - 1; i >= 0; i--) {
-      double_step(s);
-      if (i == c_a.exp1) {
-        W y2 = Py;
-        if (c_a.sign1 < 0) y2 = norm(negk(y2, K2));
-        add_step(s, Px, y2);
-      }
-    }
+    miller_loop(s, Px, Py);
     return valid;
   }
   // Products of a few terms with small batches (element_prod_pairing, benchmark/multipairing.c's shape): every TERM gets a
@@ -697,7 +788,7 @@ struct AW {
 
   // element_pairing, one wave: gt <- e(g1, g2)
   PBC_DEV void pairing_wave(uint8_t *gt, const uint8_t *g1, const uint8_t *g2) {
-    constexpr int NB = 4 * N;
+    const int NB = fq_len();
     bool valid = false;
     state s;
     init();
@@ -735,14 +826,7 @@ struct AW {
 #else
     s.fy = 0;
 #endif
-    for (int i = c_a.exp2 - 1; i >= 0; i--) {
-      double_step(s);
-      if (i == c_a.exp1) {
-        W y2 = Py;
-        if (c_a.sign1 < 0) y2 = norm(negk(y2, K2));
-        add_step(s, Px, y2);
-      }
-    }
+    miller_loop(s, Px, Py);
     W ox, oy;
     final_exp(ox, oy, s, oneR);
 #ifndef PBC_HOSTSIM

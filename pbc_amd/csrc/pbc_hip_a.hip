@@ -69,6 +69,52 @@ __global__ void __launch_bounds__(64 * NW, PBC_AW_WAVES) aw_prod_finish_kernel(u
   w.prod_finish_wave(gt + idx * L, ws + idx * (size_t) k * AW<N, NW>::WREC, k);
 }
 
+// The same four kernels for type a1 and for type a parameters outside the fast path (AW<N, NW, AG<N>>: the Miller loop over the
+// signed digits of the order, 38 limbs of 28 bits on the 33-word fields; `aux`: the object's table, ag_aux_build).  One lane
+// needs 0.2 s for an a1.param pairing however small the batch.
+template <int N> constexpr int kAgWaves = N >= 32 ? 2 : PBC_AW_WAVES;
+template <int N, int NW>
+__global__ void __launch_bounds__(64 * NW, kAgWaves<N>) agw_pairing_kernel(uint8_t *gt, const uint8_t *g1, const uint8_t *g2, const uint32_t *aux, KArgs<N> ka) {
+  const size_t L = 2 * (size_t) fq_bytes<N>(), idx = blockIdx.x;
+  AW<N, NW, AG<N>> w;
+  w.aux = aux;
+  w.pairing_wave(gt + idx * L, g1 + idx * L, g2 + idx * L);
+}
+template <int N, int NW>
+__global__ void __launch_bounds__(64 * NW, kAgWaves<N>) agw_pp_apply_kernel(uint8_t *gt, const uint32_t *__restrict__ tab, const uint32_t *__restrict__ valid,
+                                                                            const uint8_t *g2, const uint32_t *aux, KArgs<N> ka) {
+  const size_t L = 2 * (size_t) fq_bytes<N>(), idx = blockIdx.x;
+  AW<N, NW, AG<N>> w;
+  w.aux = aux;
+  w.pp_apply_wave(gt + idx * L, tab, *valid != 0, g2 + idx * L);
+}
+template <int N, int NW>
+__global__ void __launch_bounds__(64 * NW, kAgWaves<N>) agw_miller_kernel(uint32_t *ws, const uint8_t *g1, const uint8_t *g2, const uint32_t *aux, KArgs<N> ka) {
+  const size_t L = 2 * (size_t) fq_bytes<N>(), idx = blockIdx.x;
+  AW<N, NW, AG<N>> w;
+  w.aux = aux;
+  w.miller_record_wave(ws + idx * AW<N, NW, AG<N>>::WREC, g1 + idx * L, g2 + idx * L);
+}
+template <int N, int NW>
+__global__ void __launch_bounds__(64 * NW, kAgWaves<N>) agw_prod_finish_kernel(uint8_t *gt, const uint32_t *ws, int k, const uint32_t *aux, KArgs<N> ka) {
+  const size_t L = 2 * (size_t) fq_bytes<N>(), idx = blockIdx.x;
+  AW<N, NW, AG<N>> w;
+  w.aux = aux;
+  w.prod_finish_wave(gt + idx * L, ws + idx * (size_t) k * AW<N, NW, AG<N>>::WREC, k);
+}
+// (the table: ~800 bytes, one copy per device the object runs on, uploaded on first use)
+static const uint32_t *ag_device_aux(pbc_hip_pairing_s *P) {
+  if (P->ag_aux.empty()) return nullptr;
+  static const char kAuxKey = 0;
+  bool fresh = false;
+  uint32_t *d = (uint32_t *) object_scratch(P, &kAuxKey, P->ag_aux.size() * sizeof(uint32_t), &fresh);
+  if (!d) return nullptr;
+  if (fresh && hipMemcpy(d, P->ag_aux.data(), P->ag_aux.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+  return d;
+}
+static bool ag_capable(const pbc_hip_pairing_s *P) { return (P->type == '1' || (P->type == 'a' && P->a_generic)) && !P->ag_aux.empty(); }
+#define PBC_DISPATCH_AG(P, ...) do { if ((P)->nlimb == 16) { constexpr int N = 16; __VA_ARGS__; } else { constexpr int N = 33; __VA_ARGS__; } } while (0)
+
 // Products of Type-A pairings on the limb-form routines, one TERM per lane (AL::miller_record_lane): the Miller value
 // of term t goes to workspace record t; al_prod_finish_kernel then multiplies the k values of each product and runs its
 // final exponentiation (one product per lane).
@@ -307,6 +353,32 @@ int launch_a(pbc_hip_pairing_s *P, void *d_gt, const void *d_g1, const void *d_g
     if (!ws) return 1;
     hipLaunchKernelGGL(a_prod_pairing_kernel<16>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
                        (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k, (uint4 *) ws, unit_counter(P, s), kargs<16>(P));
+  } else if (ag_capable(P) && n <= P->ag_wave_max && n * (size_t) k <= ((size_t) 1 << 20)) {
+    // small batches of type a1 / generic type a: a wave (four, up to hip_wave4_max terms) per pairing -- per TERM of a product, then
+    // one per product -- on the wave routines of the signed-digit Miller loop (a lane's time grows with the terms of its product
+    // as the wavefronts' does: the cut-over is a number of products)
+    const uint32_t *aux = ag_device_aux(P);
+    if (!aux) return 1;
+    const size_t nt = n * (size_t) k;
+    const bool four = nt <= P->ag_wave4_max;
+    if (k == 1) {
+      PBC_DISPATCH_AG(P, {
+        if (four) hipLaunchKernelGGL((agw_pairing_kernel<N, 4>), dim3((unsigned) n), dim3(256), 0, s, (uint8_t *) d_gt, (const uint8_t *) d_g1, (const uint8_t *) d_g2, aux, kargs<N>(P));
+        else hipLaunchKernelGGL((agw_pairing_kernel<N, 1>), dim3((unsigned) n), dim3(64), 0, s, (uint8_t *) d_gt, (const uint8_t *) d_g1, (const uint8_t *) d_g2, aux, kargs<N>(P));
+      });
+    } else {
+      uint32_t *ws = (uint32_t *) W.get(nt * AW<33, 1, AG<33>>::WREC * sizeof(uint32_t));
+      if (!ws) return 1;
+      PBC_DISPATCH_AG(P, {
+        if (four) {
+          hipLaunchKernelGGL((agw_miller_kernel<N, 4>), dim3((unsigned) nt), dim3(256), 0, s, ws, (const uint8_t *) d_g1, (const uint8_t *) d_g2, aux, kargs<N>(P));
+          hipLaunchKernelGGL((agw_prod_finish_kernel<N, 4>), dim3((unsigned) n), dim3(256), 0, s, (uint8_t *) d_gt, (const uint32_t *) ws, k, aux, kargs<N>(P));
+        } else {
+          hipLaunchKernelGGL((agw_miller_kernel<N, 1>), dim3((unsigned) nt), dim3(64), 0, s, ws, (const uint8_t *) d_g1, (const uint8_t *) d_g2, aux, kargs<N>(P));
+          hipLaunchKernelGGL((agw_prod_finish_kernel<N, 1>), dim3((unsigned) n), dim3(64), 0, s, (uint8_t *) d_gt, (const uint32_t *) ws, k, aux, kargs<N>(P));
+        }
+      });
+    }
   } else if ((P->type == 'a' || P->type == '1') && P->nlimb == 16) {   // other sizes: the bit-by-bit kernels
     hipLaunchKernelGGL(a1_prod_pairing_kernel<16>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
                        (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k, kargs<16>(P));
@@ -350,6 +422,13 @@ int pp_apply_launch_a(pbc_hip_pp_s *pp, void *d_gt, const void *d_g2, size_t n, 
   } else if (P->type == 'a' && !P->a_generic) {
     hipLaunchKernelGGL(al_pp_apply_kernel<16>, dim3(PBC_RGRID(al_pp_apply_kernel<16>)), dim3(kBlock), 0, s, (uint8_t *) d_gt, pp->tab, pp->valid,
                        (const uint8_t *) d_g2, n, unit_counter(P, s), kargs<16>(P));
+  } else if (ag_capable(P) && n <= P->ag_wave_max) {
+    const uint32_t *aux = ag_device_aux(P);
+    if (!aux) return 1;
+    PBC_DISPATCH_AG(P, {
+      if (n <= P->ag_wave4_max) hipLaunchKernelGGL((agw_pp_apply_kernel<N, 4>), dim3((unsigned) n), dim3(256), 0, s, (uint8_t *) d_gt, pp->tab, pp->valid, (const uint8_t *) d_g2, aux, kargs<N>(P));
+      else hipLaunchKernelGGL((agw_pp_apply_kernel<N, 1>), dim3((unsigned) n), dim3(64), 0, s, (uint8_t *) d_gt, pp->tab, pp->valid, (const uint8_t *) d_g2, aux, kargs<N>(P));
+    });
   } else if (P->nlimb == 16) {
     hipLaunchKernelGGL(a1_pp_apply_kernel<16>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt, pp->tab, pp->valid,
                        (const uint8_t *) d_g2, n, kargs<16>(P));

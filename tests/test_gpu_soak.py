@@ -35,7 +35,7 @@ def _rbits(P):
 
 
 def _rbits_of(name):
-    return {"a": 522, "d": 174, "f": 174}[name]
+    return {"a": 522, "d": 174, "f": 174, "g149": 174}[name]
 
 
 def test_radix_table_matches_the_library_layout():
@@ -46,7 +46,7 @@ def test_radix_table_matches_the_library_layout():
 
 
 @needs_ref
-@pytest.mark.parametrize("name", ["a", "d", "f"])
+@pytest.mark.parametrize("name", ["a", "d", "f", "g149"])
 def test_soak_generator_agrees_with_the_c_restatement(name, oracles, tmp_path):
     """no GPU: a small soak file (random + every crafted unit) from the reference against oracle/pbc_oracle.c"""
     v, info = oracle.ref_soak(_param_path(name), 24, 1, 77, str(tmp_path / "s.vec"), _rbits_of(name), workers=4)
@@ -101,9 +101,9 @@ WAVE_LOG2 = int(os.environ.get("PBC_SOAK_LOG2_WAVE", "12"))
 
 @pytest.mark.gpu
 @needs_ref
-@pytest.mark.parametrize("name", ["d", "d278027-190-181", "d201", "d224", "f"])
+@pytest.mark.parametrize("name", ["d", "d278027-190-181", "d201", "d224", "f", "g149"])
 def test_wave_kernels_on_uniformly_random_and_crafted_inputs(name, hips, tmp_path):
-    """the small-batch route of types d and f (one pairing / one TERM per wavefront, pairing_dw.cuh, pairing_fw.cuh) on inputs no fixture holds: 2^12
+    """the small-batch route of types d, f and g (one pairing / one TERM per wavefront, pairing_dw.cuh, pairing_fw.cuh, pairing_gw.cuh) on inputs no fixture holds: 2^12
     uniformly random pairs and the crafted block (limb patterns in the field's own radix: six, seven and eight limbs) in calls
     of at most 4096 units, 2^10 random four-term products, and pairing_pp_apply on the random second arguments -- against the
     unmodified reference"""

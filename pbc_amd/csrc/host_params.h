@@ -234,13 +234,16 @@ static void set_zr(pbc_hip_pairing_s *P, const pbc_host::Big &r) {
 // borrowed subtraction constants: what the bound tracker of pairing_al.cuh assumes for a.param's q >= 2^504); the table holds
 // LEFF = the limbs q fills and c q in borrowed form for (c, D) = (2, 1) (4, 2) (8, 4) (12, 2) (16, 2).  "hip_wave_max 0": never.
 template <int N>
-static void ag_aux_build(pbc_hip_pairing_s *P, const pbc_host::Big &q, const char *txt, size_t len) {
+static void ag_aux_build(pbc_hip_pairing_s *P, const pbc_host::Big &q, const char *txt, size_t len, bool type_e = false) {
   constexpr int W = Limbs29<N>::W, L = Limbs29<N>::L;
   P->ag_aux.clear();
   // measured cut-overs (profiles/r06_agwave_latency.txt): a lane needs 0.2 s (a1.param) / 38 ms (a_160_1024) / 6.5 ms (512-bit q) however
   // small the batch; the wave kernels saturate at 72 k / 330 k / 1.0 M pairings a second.  On the 33-word fields four wavefronts per
   // unit are the faster shape at every size (two 256-register waves fit a SIMD either way)
   int wave_max = N >= 32 ? 12288 : 6144, wave4_max = N >= 32 ? 12288 : 1024;
+  // type e (pairing_ew.cuh, profiles/r06_ewave_latency.txt): a third of a pairing is the (q - 1) / r power, one product at a time --
+  // one wavefront per unit carries twice the units a second (300 k against 135 k on e.param; a lane: 34.5 ms for any batch)
+  if (type_e && N >= 32) { wave_max = 10240; wave4_max = 512; }
   pbc_host::param_int(txt, len, "hip_wave_max", wave_max);
   pbc_host::param_int(txt, len, "hip_wave4_max", wave4_max);
   P->ag_wave_max = wave_max < 0 ? 0 : (size_t) wave_max;
@@ -438,6 +441,7 @@ static int init_type_e(pbc_hip_pairing_s *P, const char *txt, size_t len) {
   P->len_fq = (q.bits() + 7) / 8;
   P->len1 = P->len2 = 2 * P->len_fq;
   P->lenT = P->len_fq;
+  if (P->nlimb == 16) ag_aux_build<16>(P, q, txt, len, true); else ag_aux_build<33>(P, q, txt, len, true);   // small batches: pairing_ew.cuh
   set_zr(P, r);
   // work model (e_miller_proj, e_param.c:64-300, + element_pow_mpz by (q-1)/r): per doubling about
   // 2 squarings + tangent (8, two evaluation points 3 each) + Jacobian doubling (10) + verticals (2)

@@ -1,6 +1,7 @@
 // pbc_hip_a.hip -- kernels and launches of types a, a1 and e (libpbc_hip.so; see host_common.h)
 #include "host_common.h"
 #include "pairing_aw.cuh"
+#include "pairing_ew.cuh"
 
 // One Type-A pairing per lane.  g1/g2/gt are AoS in wire format (128 B each for a.param);
 // per-lane 16-byte loads of a 128-byte record: every byte of every fetched line is used.
@@ -101,6 +102,29 @@ __global__ void __launch_bounds__(64 * NW, kAgWaves<N>) agw_prod_finish_kernel(u
   AW<N, NW, AG<N>> w;
   w.aux = aux;
   w.prod_finish_wave(gt + idx * L, ws + idx * (size_t) k * AW<N, NW, AG<N>>::WREC, k);
+}
+// ... and type e (pairing_ew.cuh: numerator and denominator, the verticals kept, the (q - 1) / r power on the wave): one lane needs
+// 35 ms for an e.param pairing however small the batch
+template <int N, int NW>
+__global__ void __launch_bounds__(64 * NW, kAgWaves<N>) ew_pairing_kernel(uint8_t *gt, const uint8_t *g1, const uint8_t *g2, const uint32_t *aux, KArgs<N> ka) {
+  const size_t NB = (size_t) fq_bytes<N>(), idx = blockIdx.x;
+  EW<N, NW> w;
+  w.aux = aux;
+  w.pairing_wave(gt + idx * NB, g1 + idx * 2 * NB, g2 + idx * 2 * NB);
+}
+template <int N, int NW>
+__global__ void __launch_bounds__(64 * NW, kAgWaves<N>) ew_miller_kernel(uint32_t *ws, const uint8_t *g1, const uint8_t *g2, const uint32_t *aux, KArgs<N> ka) {
+  const size_t NB = (size_t) fq_bytes<N>(), idx = blockIdx.x;
+  EW<N, NW> w;
+  w.aux = aux;
+  w.miller_record_wave(ws + idx * EW<N, NW>::WREC, g1 + idx * 2 * NB, g2 + idx * 2 * NB);
+}
+template <int N, int NW>
+__global__ void __launch_bounds__(64 * NW, kAgWaves<N>) ew_prod_finish_kernel(uint8_t *gt, const uint32_t *ws, int k, const uint32_t *aux, KArgs<N> ka) {
+  const size_t NB = (size_t) fq_bytes<N>(), idx = blockIdx.x;
+  EW<N, NW> w;
+  w.aux = aux;
+  w.prod_finish_wave(gt + idx * NB, ws + idx * (size_t) k * EW<N, NW>::WREC, k);
 }
 // (the table: ~800 bytes, one copy per device the object runs on, uploaded on first use)
 static const uint32_t *ag_device_aux(pbc_hip_pairing_s *P) {
@@ -385,6 +409,30 @@ int launch_a(pbc_hip_pairing_s *P, void *d_gt, const void *d_g1, const void *d_g
   } else if (P->type == '1' || P->type == 'a') {
     hipLaunchKernelGGL(a1_prod_pairing_kernel<33>, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, s, (uint8_t *) d_gt,
                        (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k, kargs<33>(P));
+  } else if (P->type == 'e' && !P->ag_aux.empty() && n <= P->ag_wave_max && n * (size_t) k <= ((size_t) 1 << 20)) {
+    // small batches of type e: a workgroup of four wavefronts (one, above hip_wave4_max terms) per pairing / per TERM, then one per product
+    const uint32_t *aux = ag_device_aux(P);
+    if (!aux) return 1;
+    const size_t nt = n * (size_t) k;
+    const bool four = nt <= P->ag_wave4_max;
+    if (k == 1) {
+      PBC_DISPATCH_AG(P, {
+        if (four) hipLaunchKernelGGL((ew_pairing_kernel<N, 4>), dim3((unsigned) n), dim3(256), 0, s, (uint8_t *) d_gt, (const uint8_t *) d_g1, (const uint8_t *) d_g2, aux, kargs<N>(P));
+        else hipLaunchKernelGGL((ew_pairing_kernel<N, 1>), dim3((unsigned) n), dim3(64), 0, s, (uint8_t *) d_gt, (const uint8_t *) d_g1, (const uint8_t *) d_g2, aux, kargs<N>(P));
+      });
+    } else {
+      uint32_t *ws = (uint32_t *) W.get(nt * EW<33, 1>::WREC * sizeof(uint32_t));
+      if (!ws) return 1;
+      PBC_DISPATCH_AG(P, {
+        if (four) {
+          hipLaunchKernelGGL((ew_miller_kernel<N, 4>), dim3((unsigned) nt), dim3(256), 0, s, ws, (const uint8_t *) d_g1, (const uint8_t *) d_g2, aux, kargs<N>(P));
+          hipLaunchKernelGGL((ew_prod_finish_kernel<N, 4>), dim3((unsigned) n), dim3(256), 0, s, (uint8_t *) d_gt, (const uint32_t *) ws, k, aux, kargs<N>(P));
+        } else {
+          hipLaunchKernelGGL((ew_miller_kernel<N, 1>), dim3((unsigned) nt), dim3(64), 0, s, ws, (const uint8_t *) d_g1, (const uint8_t *) d_g2, aux, kargs<N>(P));
+          hipLaunchKernelGGL((ew_prod_finish_kernel<N, 1>), dim3((unsigned) n), dim3(64), 0, s, (uint8_t *) d_gt, (const uint32_t *) ws, k, aux, kargs<N>(P));
+        }
+      });
+    }
   } else if (P->type == 'e' && P->nlimb == 16) {
     hipLaunchKernelGGL(e_prod_pairing_kernel<16>, dim3(grid), dim3(kBlock), 0, s, (uint8_t *) d_gt,
                        (const uint8_t *) d_g1, (const uint8_t *) d_g2, n, k, kargs<16>(P));

@@ -1,5 +1,5 @@
-"""GPU tests (-m gpu) of the wave kernels of type a1 and of type a parameters outside the 512-bit Solinas fast path (pairing_aw.cuh
-with AG<N>, round 6): small batches of a1.param / a_160_1024 / a_160_512_mm / a_160_256 calls -- element_pairing, element_prod_pairing,
+"""GPU tests (-m gpu) of the wave kernels of type a1, of type a parameters outside the 512-bit Solinas fast path (pairing_aw.cuh
+with AG<N>, round 6) and of type e (pairing_ew.cuh, on the same routines): small batches of a1.param / a_160_1024 / a_160_512_mm / a_160_256 calls -- element_pairing, element_prod_pairing,
 pairing_pp_apply -- run one wavefront (four for the smallest batches) per pairing / per TERM; the bytes are those of the
 one-pairing-per-lane kernels, of the reference's vectors and of the C restatement.  Parameter sets whose q does not fill its top
 limb (a_160_500, a_224_768, a1_200 ...) keep the lane kernels: the object reports which route it has."""
@@ -10,11 +10,14 @@ from conftest import golden, _param
 
 pytestmark = pytest.mark.gpu
 
-WAVE_SETS = ["a1", "a_160_1024", "a_160_512_mm", "a_160_256"]            # q fills >= 12 bits of its top limb and leaves >= 10 bits of the radix
+WAVE_SETS = ["a1", "a_160_1024", "a_160_512_mm", "a_160_256"]
+E_SETS = ["e", "e_160_400"]                                 # type e (pairing_ew.cuh): no pairing_pp (e_param.c installs none)
 FILES = {"a1": ("a1_rand6.vec", "a1_edge6.vec", "a1_prod3x3_edge.vec", "a1_chain8.vec"),
          "a_160_1024": ("a_160_1024_rand4.vec", None, "a_160_1024_prod3x3_edge.vec", "a_160_1024_rand4.vec"),
          "a_160_512_mm": ("a_160_512_mm_rand6.vec", None, "a_160_512_mm_prod3x4_edge.vec", "a_160_512_mm_rand6.vec"),
-         "a_160_256": ("a_160_256_rand6.vec", None, "a_160_256_prod3x4_edge.vec", "a_160_256_rand6.vec")}
+         "a_160_256": ("a_160_256_rand6.vec", None, "a_160_256_prod3x4_edge.vec", "a_160_256_rand6.vec"),
+         "e": ("e_rand6.vec", "e_edge6.vec", "e_prod3x3_edge.vec", "e_chain8.vec"),
+         "e_160_400": ("e_160_400_rand6.vec", None, "e_160_400_prod3x4_edge.vec", "e_160_400_rand6.vec")}
 
 
 def _lane(pname):
@@ -22,7 +25,7 @@ def _lane(pname):
     return pbc_amd.Pairing(_param(pname) + "hip_wave_max 0\n")          # never the wave kernels
 
 
-@pytest.mark.parametrize("pname", WAVE_SETS)
+@pytest.mark.parametrize("pname", WAVE_SETS + E_SETS)
 def test_wave_kernels_match_the_reference_vectors(hips, pname):
     rand, edge, prod, _ = FILES[pname]
     for name in (rand, edge):
@@ -33,7 +36,7 @@ def test_wave_kernels_match_the_reference_vectors(hips, pname):
     assert np.array_equal(hips[pname].element_prod_pairing(w.g1, w.g2, w.k), w.gt)
 
 
-@pytest.mark.parametrize("pname", WAVE_SETS)
+@pytest.mark.parametrize("pname", WAVE_SETS + E_SETS)
 @pytest.mark.parametrize("n", [1, 5, 70, 1025])
 def test_wave_kernel_equals_the_lane_kernel(hips, pname, n):
     """both shapes (16-word fields: four wavefronts per pairing up to hip_wave4_max = 1024 units, one above), off-curve arguments included"""
@@ -51,7 +54,7 @@ def test_wave_kernel_equals_the_lane_kernel(hips, pname, n):
     lane.clear()
 
 
-@pytest.mark.parametrize("pname", WAVE_SETS)
+@pytest.mark.parametrize("pname", WAVE_SETS + E_SETS)
 def test_wave_kernel_on_cross_pairs_against_the_c_restatement(hips, oracles, pname):
     v = golden(FILES[pname][3])
     rng = np.random.default_rng(5)
@@ -59,7 +62,7 @@ def test_wave_kernel_on_cross_pairs_against_the_c_restatement(hips, oracles, pna
     assert np.array_equal(hips[pname].element_pairing(v.g1[i], v.g2[j]), oracles[pname].pairing_batch(v.g1[i], v.g2[j]))
 
 
-@pytest.mark.parametrize("pname", WAVE_SETS)
+@pytest.mark.parametrize("pname", WAVE_SETS + E_SETS)
 @pytest.mark.parametrize("n,k", [(1, 2), (3, 5), (2, 16), (300, 4)])
 def test_products_on_wavefronts(hips, oracles, pname, n, k):
     v = golden(FILES[pname][3])
@@ -71,7 +74,7 @@ def test_products_on_wavefronts(hips, oracles, pname, n, k):
     m = min(n, 3 if k <= 5 else 1)
     assert np.array_equal(got[:m], oracles[pname].prod_pairing_batch(g1[:m * k], g2[:m * k], k))
     if n > 2:
-        fb = got.shape[1] // 2
+        fb = got.shape[1] // (1 if pname in E_SETS else 2)     # (GT of type e is F_q itself)
         one = np.zeros(got.shape[1], np.uint8)
         one[fb - 1] = 1
         assert np.array_equal(got[1], one)
@@ -123,7 +126,7 @@ def test_other_sizes_keep_the_lane_kernels(hips, pname):
     assert np.array_equal(hips[pname].element_pairing(v.g1, v.g2), v.gt)
 
 
-@pytest.mark.parametrize("pname", ["a1", "a_160_256"])
+@pytest.mark.parametrize("pname", ["a1", "a_160_256", "e"])
 def test_one_wavefront_per_unit_shape(hips, pname):
     """ "hip_wave4_max 0": every unit on ONE wavefront (two products at a time in one instruction stream) -- the default on the
     33-word fields is four wavefronts at every size, so this shape is named explicitly"""
@@ -135,10 +138,11 @@ def test_one_wavefront_per_unit_shape(hips, pname):
     g1[4, 5] ^= 1
     assert np.array_equal(H1.element_pairing(g1, g2), hips[pname].element_pairing(g1, g2))
     assert np.array_equal(H1.element_prod_pairing(g1[:4], g2[:4], 2), hips[pname].element_prod_pairing(g1[:4], g2[:4], 2))
-    p1, p4 = H1.pp_init(v.g1[1]), hips[pname].pp_init(v.g1[1])
-    assert np.array_equal(p1.apply(g2), p4.apply(g2))
-    p1.clear()
-    p4.clear()
+    if pname not in E_SETS:
+        p1, p4 = H1.pp_init(v.g1[1]), hips[pname].pp_init(v.g1[1])
+        assert np.array_equal(p1.apply(g2), p4.apply(g2))
+        p1.clear()
+        p4.clear()
     H1.clear()
 
 

@@ -19,7 +19,7 @@ from conftest import golden, _param  # noqa: E402
 
 PNAME = os.environ.get("AG_PARAM", "a1")
 W4 = os.environ.get("AG_WAVE4_MAX")
-v = golden({"a1": "a1_chain8.vec", "a_160_1024": "a_160_1024_rand4.vec"}.get(PNAME, PNAME + "_rand6.vec"))
+v = golden({"a1": "a1_chain8.vec", "e": "e_chain8.vec", "a_160_1024": "a_160_1024_rand4.vec"}.get(PNAME, PNAME + "_rand6.vec"))
 args = sys.argv[1:]
 mode, k = "pairing", 1
 if args and args[0] == "prod":

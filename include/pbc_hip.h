@@ -141,7 +141,7 @@ int pbc_hip_element_pairing_batch(pbc_hip_pairing_t *p, uint8_t *gt, const uint8
  * 256-lane workgroups, i.e. 2^17 units fill an MI355X once (e.param: 40 ms for any batch up to 2^16 units, 68 ms for
  * 2^17, 131 ms for 2^18); batches of 2^18 and more amortise the tail of a launch.
  * Small batches of type a1 and of type a parameter sets outside the 512-bit fast path (round 6): where q leaves ten bits of the
- * limb radix free and fills twelve bits of its top limb (a1.param, 1024-bit and 512-bit generated type a sets; the object decides
+ * limb radix free and fills twelve bits of its top limb (a1.param, the 1024-bit and 253-bit generated type a sets; the object decides
  * at init) a launch of up to 12 288 units on the 33-word fields / 6144 on the 16-word ones ("hip_wave_max N", 0 = never) gives
  * every pairing -- every TERM of a product, then every product; every second argument of pairing_pp_apply -- a workgroup of four
  * wavefronts ("hip_wave4_max N": above it one) on the same limb-per-lane routines with the Miller loop over the signed digits of
@@ -309,6 +309,11 @@ size_t pbc_hip_diag_fw_schedule(pbc_hip_pairing_t *p, int which, uint64_t *out, 
  * and lucas_even over Phi_10(q) / r, g_param.c:471-558; pairing_pp_apply: g_param.c's copy of d_pairing_pp_apply); which as for
  * type d; 0: not a five-word type g pairing. */
 size_t pbc_hip_diag_gw_schedule(pbc_hip_pairing_t *p, int which, uint64_t *out, size_t cap);
+/* Diagnostic (tests): the table the wave kernels of type a1 / generic type a / type e read for this object (csrc/pairing_aw.cuh AG<N>,
+ * host_params.h ag_aux_build): [0] = LEFF, the limbs q fills; from word 4 on five constants of L limbs each, c q in borrowed form for
+ * (c, D) = (2, 1) (4, 2) (8, 4) (12, 2) (16, 2).  Returns the number of words (0: this q keeps the lane kernels -- the kernels that
+ * stand for a1_pairing, ecc/a_param.c:1840-2015, and e_pairing, ecc/e_param.c:472-483, at every batch size). */
+size_t pbc_hip_diag_ag_table(pbc_hip_pairing_t *p, uint32_t *out, size_t cap);
 int pbc_hip_fq_limb_image_bytes(pbc_hip_pairing_t *p);          /* 8 t (0 on failure) */
 int pbc_hip_element_pairing_batch_limbs(pbc_hip_pairing_t *p, uint8_t *gt, const uint8_t *g1, const uint8_t *g2, size_t n);
 int pbc_hip_element_prod_pairing_batch_limbs(pbc_hip_pairing_t *p, uint8_t *gt, const uint8_t *g1, const uint8_t *g2, size_t n, int k);

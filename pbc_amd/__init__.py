@@ -124,6 +124,8 @@ def lib():
         L.pbc_hip_diag_fw_schedule.restype = sz
         L.pbc_hip_diag_gw_schedule.argtypes = [vp, ci, vp, sz]
         L.pbc_hip_diag_gw_schedule.restype = sz
+        L.pbc_hip_diag_ag_table.argtypes = [vp, vp, sz]
+        L.pbc_hip_diag_ag_table.restype = sz
         L.pbc_hip_fq_limb_image_bytes.argtypes = [vp]
         L.pbc_hip_element_pairing_batch_limbs.argtypes = [vp, vp, vp, vp, sz]
         L.pbc_hip_element_prod_pairing_batch_limbs.argtypes = [vp, vp, vp, vp, sz, ci]
@@ -159,7 +161,7 @@ EXPORTS = (
     "pbc_hip_element_add_batch_dev", "pbc_hip_element_sub_batch_dev", "pbc_hip_element_neg_batch_dev", "pbc_hip_element_double_batch_dev",
     "pbc_hip_zr_op_batch", "pbc_hip_zr_op_batch_dev", "pbc_hip_zr_from_hash_batch", "pbc_hip_zr_from_hash_batch_dev",
     "pbc_hip_element_pow2_zn_batch", "pbc_hip_element_pow3_zn_batch", "pbc_hip_element_pow2_zn_batch_dev", "pbc_hip_element_pow3_zn_batch_dev",
-    "pbc_hip_diag_dw_schedule", "pbc_hip_diag_fw_schedule", "pbc_hip_diag_gw_schedule", "pbc_hip_fq_limb_image_bytes", "pbc_hip_element_pairing_batch_limbs", "pbc_hip_element_prod_pairing_batch_limbs",
+    "pbc_hip_diag_dw_schedule", "pbc_hip_diag_fw_schedule", "pbc_hip_diag_gw_schedule", "pbc_hip_diag_ag_table", "pbc_hip_fq_limb_image_bytes", "pbc_hip_element_pairing_batch_limbs", "pbc_hip_element_prod_pairing_batch_limbs",
     "pbc_hip_element_prod_pairing_batch_limbs_dev",
 )
 

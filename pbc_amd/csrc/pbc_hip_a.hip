@@ -136,6 +136,11 @@ static const uint32_t *ag_device_aux(pbc_hip_pairing_s *P) {
   if (fresh && hipMemcpy(d, P->ag_aux.data(), P->ag_aux.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
   return d;
 }
+extern "C" size_t pbc_hip_diag_ag_table(pbc_hip_pairing_t *P, uint32_t *out, size_t cap) {
+  if (!P) return 0;
+  for (size_t i = 0; i < P->ag_aux.size() && i < cap; i++) out[i] = P->ag_aux[i];
+  return P->ag_aux.size();
+}
 static bool ag_capable(const pbc_hip_pairing_s *P) { return (P->type == '1' || (P->type == 'a' && P->a_generic)) && !P->ag_aux.empty(); }
 #define PBC_DISPATCH_AG(P, ...) do { if ((P)->nlimb == 16) { constexpr int N = 16; __VA_ARGS__; } else { constexpr int N = 33; __VA_ARGS__; } } while (0)
 

@@ -10,7 +10,7 @@ from conftest import golden, _param
 
 pytestmark = pytest.mark.gpu
 
-WAVE_SETS = ["a1", "a_160_1024", "a_160_512_mm", "a_160_256"]
+WAVE_SETS = ["a1", "a_160_1024", "a_160_256", "a_160_512_mm"]   # (a_160_512_mm: a 512-bit q, i.e. the fast path's own wave kernels -- the same checks)
 E_SETS = ["e", "e_160_400"]                                 # type e (pairing_ew.cuh): no pairing_pp (e_param.c installs none)
 FILES = {"a1": ("a1_rand6.vec", "a1_edge6.vec", "a1_prod3x3_edge.vec", "a1_chain8.vec"),
          "a_160_1024": ("a_160_1024_rand4.vec", None, "a_160_1024_prod3x3_edge.vec", "a_160_1024_rand4.vec"),

@@ -211,3 +211,35 @@ def test_wave_program_tables_of_type_g_are_current_and_match_the_host_schedule()
         n = pbc_amd.lib().pbc_hip_diag_gw_schedule(P._h, which, buf.ctypes.data_as(ctypes.c_void_p), len(buf))
         assert n == len(want) and [int(x) for x in buf[:n]] == want, kind
     assert pbc_amd.lib().pbc_hip_diag_gw_schedule(pbc_amd.Pairing(pbc_amd.param_text("d159"))._h, 0, buf.ctypes.data_as(ctypes.c_void_p), len(buf)) == 0
+
+
+def test_wave_table_of_type_a1_and_e_sums_to_multiples_of_q():
+    """host_params.h ag_aux_build (no GPU): the parameter sets whose q leaves ten bits of the limb radix and fills twelve of its top
+    limb get the table of the wave kernels (pairing_aw.cuh AG<N>, pairing_ew.cuh) -- LEFF and c q in borrowed limbs that dominate
+    D (2^W - 1) below the top limb --, the others none"""
+    import ctypes
+    import re
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    import pbc_amd
+    want = {"a1": True, "a_160_1024": True, "a_160_512_mm": False, "a_160_256": True, "e": True, "e_160_400": True,
+            "a_160_500": False, "a_224_768": False, "a1_200": False, "a_150_300_mm": False, "a": False, "d159": False}   # (a_160_512_mm, a: the 512-bit fast path has its own constants)
+    buf = np.zeros(512, np.uint32)
+    for name, has in want.items():
+        text = pbc_amd.param_text(name)
+        P = pbc_amd.Pairing(text)
+        n = pbc_amd.lib().pbc_hip_diag_ag_table(P._h, buf.ctypes.data_as(ctypes.c_void_p), len(buf))
+        assert (n > 0) == has, name
+        if not has:
+            continue
+        q = int(re.search(r"^(?:q|p)\s+(\d+)", text, re.M).group(1))
+        nwords = 16 if q.bit_length() <= 512 else 33
+        W = 28 if nwords >= 32 else 29
+        L = -(-32 * nwords // W)
+        assert n == 4 + 5 * L
+        leff = int(buf[0])
+        assert leff == -(-q.bit_length() // W) and q.bit_length() - W * (leff - 1) >= 12 and W * L - q.bit_length() >= 10
+        for t, (c, D) in enumerate(((2, 1), (4, 2), (8, 4), (12, 2), (16, 2))):
+            k = [int(x) for x in buf[4 + t * L:4 + (t + 1) * L]]
+            assert sum(v << (W * i) for i, v in enumerate(k)) == c * q, (name, c)
+            assert all(v == 0 for v in k[leff:]) and all(v >= D * ((1 << W) - 1) for v in k[:leff - 1]) and k[leff - 1] >= D + 1

@@ -21,9 +21,12 @@ done
   timeout 200 python tools/dwave_latency.py 1 16 256 1024 2048 3072 4096 8192 > $O/dwave_latency.txt 2>&1
   { for k in 4 16; do timeout 200 python tools/dwave_latency.py prod $k 1 256 4096; done; timeout 200 python tools/dwave_latency.py pp 1 1024 4096
     for p in d278027-190-181 d201 d224; do echo "== $p"; DW_PARAM=$p timeout 200 python tools/dwave_latency.py 1 1024 4096; done
-    echo "== f.param"; DW_PARAM=f timeout 200 python tools/dwave_latency.py 1 256 1024 2048 4096 8192; for k in 4 16; do DW_PARAM=f timeout 200 python tools/dwave_latency.py prod $k 1 256 1024; done; } > $O/small_batches.txt 2>&1
+    echo "== f.param"; DW_PARAM=f timeout 200 python tools/dwave_latency.py 1 256 1024 2048 4096 8192; for k in 4 16; do DW_PARAM=f timeout 200 python tools/dwave_latency.py prod $k 1 256 1024; done
+    echo "== g149.param"; DW_PARAM=g149 timeout 200 python tools/dwave_latency.py 1 1024 4096; DW_PARAM=g149 timeout 200 python tools/dwave_latency.py prod 4 1 256; DW_PARAM=g149 timeout 200 python tools/dwave_latency.py pp 1 1024
+    echo "== a1.param / a_160_1024 / e.param (tools/agwave_latency.py)"; AG_PARAM=a1 LANE_MAX=64 timeout 300 python tools/agwave_latency.py 1 64 1024 4096; AG_PARAM=a1 LANE_MAX=1 timeout 200 python tools/agwave_latency.py prod 4 1 256; AG_PARAM=a1 LANE_MAX=64 timeout 200 python tools/agwave_latency.py pp 1 1024
+    AG_PARAM=a_160_1024 LANE_MAX=64 timeout 200 python tools/agwave_latency.py 1 1024 4096; AG_PARAM=e LANE_MAX=64 timeout 200 python tools/agwave_latency.py 1 512 1024 4096; AG_PARAM=e LANE_MAX=1 timeout 200 python tools/agwave_latency.py prod 4 1 256; } > $O/small_batches.txt 2>&1
   export PBC_HIP_LIB=$R/pbc_amd/libpbc_hip.so
-  [ -n "$SKIP_GLUE" ] || for p in a d159 f d201; do timeout 120 oracle/_ref/glue_test pbc_amd/param/$p.param 100 latency 2>&1 | tail -n 2; [ $p = a ] || [ $p = d159 ] || continue; timeout 200 oracle/_ref/glue_test pbc_amd/param/$p.param 1048576 bench 2>&1 | tail -n 1; done > $O/glue.txt
+  [ -n "$SKIP_GLUE" ] || for p in a d159 f d201 d224 g149 a1 e; do timeout 200 oracle/_ref/glue_test pbc_amd/param/$p.param $([ $p = a1 ] && echo 30 || echo 100) latency 2>&1 | tail -n 2; [ $p = a ] || [ $p = d159 ] || continue; timeout 200 oracle/_ref/glue_test pbc_amd/param/$p.param 1048576 bench 2>&1 | tail -n 1; done > $O/glue.txt
   unset PBC_HIP_LIB; }
 cd /tmp && export TMPDIR=/tmp
 for w in ${PMC_WL-a d f a-prod16 d-prod16 d190 a-pp a-g1-mul f-gt-pow}; do

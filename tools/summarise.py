@@ -42,8 +42,8 @@ for f in sorted(glob.glob(EV + "/sweep_*.json")):
 for src, dst, what in (("wave_latency.txt", "profiles/%s_closing_wave_latency.txt" % RND, "python tools/wave_latency.py 1 256 512 1024 2048 4096 5120"),
                        ("tail.txt", "profiles/%s_closing_tail.txt" % RND, "python tools/tail_latency.py"),
                        ("dwave_latency.txt", "profiles/%s_dwave_latency.txt" % RND, "python tools/dwave_latency.py 1 16 256 1024 2048 3072 4096 8192"),
-                       ("small_batches.txt", "profiles/%s_small_batches.txt" % RND, "python tools/dwave_latency.py {prod K, pp} ...; DW_PARAM={d190, d201, d224, f} python tools/dwave_latency.py ... (tools/evidence.sh)"),
-                       ("glue.txt", "profiles/%s_closing_glue.txt" % RND, "oracle/_ref/glue_test {a,d159,f,d201}.param 100 latency; {a,d159}.param 1048576 bench")):
+                       ("small_batches.txt", "profiles/%s_small_batches.txt" % RND, "python tools/dwave_latency.py {prod K, pp} ...; DW_PARAM={d190, d201, d224, f, g149} python tools/dwave_latency.py ...; AG_PARAM={a1, a_160_1024, e} python tools/agwave_latency.py ... (tools/evidence.sh)"),
+                       ("glue.txt", "profiles/%s_closing_glue.txt" % RND, "oracle/_ref/glue_test {a,d159,f,d201,d224,g149,a1,e}.param 100 latency (a1: 30); {a,d159}.param 1048576 bench")):
     if os.path.exists(EV + "/" + src) and os.path.getsize(EV + "/" + src):
         with open(dst, "w") as fh:
             fh.write("commit %s: %s\n" % (head, what))

@@ -243,3 +243,70 @@ def test_wave_table_of_type_a1_and_e_sums_to_multiples_of_q():
             k = [int(x) for x in buf[4 + t * L:4 + (t + 1) * L]]
             assert sum(v << (W * i) for i, v in enumerate(k)) == c * q, (name, c)
             assert all(v == 0 for v in k[leff:]) and all(v >= D * ((1 << W) - 1) for v in k[:leff - 1]) and k[leff - 1] >= D + 1
+
+
+def test_wave_product_recurrence_on_the_tables_of_a1_and_e():
+    """a model of pairing_aw.cuh's lane recurrence on Python integers (no GPU) for the fields the generic wave kernels run on: lane j
+    holds limb j (W = 28 bits, L = 38 lanes on the 33-word fields), a step adds a_i b_j (+ a second term), clears column 0 with
+    m q, shifts one lane down; L steps leave a b / 2^(W L) mod q below 2 q with nothing above limb LEFF - 1; carry passes with the
+    masks of AW::init (lanes above LEFF keep nothing) reach strict limbs; a + K - b with the table's borrowed constants has no
+    negative limb for any strict b whose value the constant dominates"""
+    import ctypes
+    import random
+    import re
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    import pbc_amd
+    rng = random.Random(7)
+    buf = np.zeros(512, np.uint32)
+    for name in ("a1", "e", "a_160_256"):
+        text = pbc_amd.param_text(name)
+        q = int(re.search(r"^(?:q|p)\s+(\d+)", text, re.M).group(1))
+        nwords = 16 if q.bit_length() <= 512 else 33
+        W = 28 if nwords >= 32 else 29
+        L, MASK = -(-32 * nwords // W), (1 << W) - 1
+        P = pbc_amd.Pairing(text)
+        assert pbc_amd.lib().pbc_hip_diag_ag_table(P._h, buf.ctypes.data_as(ctypes.c_void_p), len(buf)) == 4 + 5 * L
+        leff = int(buf[0])
+        K = [[int(x) for x in buf[4 + t * L:4 + (t + 1) * L]] for t in range(5)]
+        limbs = lambda v: [(v >> (W * i)) & MASK for i in range(L)]
+        value = lambda l: sum(x << (W * i) for i, x in enumerate(l))
+        ql, ninv, R = limbs(q), (-pow(q, -1, 1 << W)) % (1 << W), 1 << (W * L)
+
+        def strict(x):                                    # AW::strict_limbs with init()'s masks
+            for _ in range(8):
+                keep = [x[j] & MASK if j < leff - 1 else (x[j] if j == leff - 1 else 0) for j in range(L)]
+                carry = [x[j] >> W if j < leff - 1 else 0 for j in range(L)]
+                x = [keep[j] + (carry[j - 1] if j else 0) for j in range(L)]
+                if all(x[j] <= MASK for j in range(leff - 1)):
+                    return x
+            raise AssertionError("carry passes do not settle")
+
+        def sop(pairs):                                   # AW::lanes_sop: sum of one or two products
+            acc = [0] * (L + 1)
+            for i in range(L):
+                for a, b in pairs:
+                    for j in range(L):
+                        acc[j] += a[i] * b[j]
+                m = (acc[0] * ninv) & MASK
+                for j in range(L):
+                    acc[j] += m * ql[j]
+                assert acc[0] & MASK == 0 and max(acc) < 1 << 60
+                acc = [(acc[j] >> W) + (acc[j + 1] & MASK) for j in range(L)] + [0]
+                assert max(acc) < 1 << 32
+            return strict(acc[:L])
+
+        for _ in range(6):
+            a, b, c, d = (rng.randrange(q) for _ in range(4))
+            r = sop([(limbs(a), limbs(b))])
+            assert value(r) % q == a * b * pow(R, -1, q) % q and value(r) < 2 * q and not any(r[leff:])
+            a2 = [x + y for x, y in zip(limbs(a), limbs(c))]                     # a sum of two as one operand (limbs < 2^(W+1))
+            r = sop([(a2, limbs(b))])
+            assert value(r) % q == (a + c) * b * pow(R, -1, q) % q and value(r) < 2 * q
+            r = sop([(limbs(a), limbs(b)), (limbs(c), limbs(d))])
+            assert value(r) % q == (a * b + c * d) * pow(R, -1, q) % q and value(r) < 2 * q
+            for t, (cc, D) in enumerate(((2, 1), (4, 2), (8, 4), (12, 2), (16, 2))):
+                sub = rng.randrange(min(D, cc - 1) * q)                             # value below what K dominates, limbs <= D (2^W - 1)
+                sl = limbs(sub % (1 << (W * leff)))
+                diff = [x - y + k for x, y, k in zip(limbs(a), sl, K[t])]
+                assert min(diff) >= 0 and max(diff) < 1 << 32 and value(diff) == a - value(sl) + cc * q

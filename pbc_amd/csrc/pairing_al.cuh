@@ -71,6 +71,8 @@ struct AL {
 #ifdef PBC_HOSTSIM
   static constexpr double U_STRICT = 1.0 - 1.0 / 536870912.0, U_ALMOST = 1.0 + 7.0 / 536870912.0;
   static constexpr double KC[5] = {2, 4, 8, 12, 16}, KD[5] = {1, 2, 4, 2, 2};
+  static int leff_() { return L; }                          // (pairing_aw.cuh's mirror: every limb is filled, R / q >= 2^10)
+  static double hs_slack() { return 1024.0; }
   static inline double hs_lu[4] = {1, 1, 1, 1}, hs_lB[4] = {1, 1, 1, 1}, hs_au, hs_aB, hs_bu, hs_bB;
   static void hs_fail(const char *what, double v) { fprintf(stderr, "hostsim: limb-form type a: %s (%g)\n", what, v); abort(); }
   static void hs_limbs(const el &a) {                       // the actual limbs must respect the tracked bound

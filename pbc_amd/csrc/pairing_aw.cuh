@@ -36,18 +36,105 @@ template <int N> __shared__ uint32_t g_lds_aw_t[AW_SLOTS * 64];
 // of AL<N>): the Miller loop walks the signed digits of the group order (pairing_a.cuh a1_miller_lane), the limbs are W = 29 or 28
 // bits wide (fp.cuh Limbs29: 38 limbs of 28 bits on the 33-word fields, one lane each), the subtraction constants and the
 // number of limbs q really fills (LEFF: a 1033-bit p leaves the 38th limb empty, so the borrow is taken from the 37th) come
-// from a table the host builds per object (host_params.h aw_aux_build), and the records are fq_bytes long.  Device only: the
-// host mirror proves the bounds on AL<16>; they carry over when q fills LEFF limbs to within 2^(W LEFF - 17) and leaves ten bits
-// of the radix free (checked by the host, which otherwise keeps the lane kernels).
+// from a table the host builds per object (host_params.h ag_aux_build), and the records are fq_bytes long.  The host mirror
+// runs these instantiations too (AG<N>'s mirror below: AL's bound tracker with the object's own limb width, filled limbs,
+// top-limb fill and radix slack), so the bounds are checked per object, not carried over; the host admits a q that fills twelve
+// bits of its top limb and leaves ten bits of the radix free, and keeps the lane kernels otherwise.
 template <int N>
 struct AG {
   static constexpr int L = Limbs29<N>::L;
+  static constexpr int WB = Limbs29<N>::W;
   static constexpr uint32_t MASK = Limbs29<N>::MASK;
   static constexpr bool kDigits = true;
   typedef fl<N> el;
   enum { K2 = 0, K4 = 1, K8 = 2, K12 = 3, K16 = 4 };
+#ifndef PBC_HOSTSIM
   static PBC_DEV void to_el(el &r, const fp<N> &a) { to_limbs<N>(r, a); }
   static PBC_DEV void to_words(fp<N> &r, const el &a) { from_limbs<N>(r, a); }
+#else
+  // ---- host mirror: AL<N>'s additive layer and worst-case bound tracker (pairing_al.cuh) for ANY field the table admits: W-bit
+  // limbs, LEFF of them filled, the borrowed constants from the object's table, the two assumptions about q as numbers -- q fills
+  // `top` bits of limb LEFF - 1 (hs_topf = 2^(top - 1): what a multiple of q is worth in units of that limb) and leaves `slack`
+  // bits of the radix (hs_slackf = 2^slack: what a product's value shrinks by).  tests/hostsim sets them from the object.
+  static inline const uint32_t *hs_tab = nullptr;
+  static inline int hs_leff = L;
+  static inline double hs_topf = 2048.0, hs_slackf = 1024.0;
+  static constexpr double UNIT = (double) (1u << WB), OVF = 4294967296.0 / UNIT;          // limbs are tracked in units of 2^W; 32-bit limbs hold OVF units
+  static constexpr double U_STRICT = 1.0 - 1.0 / UNIT, U_ALMOST = 1.0 + 7.0 / UNIT;
+  static constexpr double KC[5] = {2, 4, 8, 12, 16}, KD[5] = {1, 2, 4, 2, 2};
+  static int leff_() { return hs_leff; }
+  static double hs_slack() { return hs_slackf; }
+  static void hs_fail(const char *what, double v) { fprintf(stderr, "hostsim: wave kernels of type a1 / e: %s (%g)\n", what, v); abort(); }
+  static void hs_limbs(const el &a) {
+    for (int i = 0; i < L; i++)
+      if ((double) a.l[i] > a.hs_u * UNIT) hs_fail("limb above its tracked bound", a.hs_u);
+    for (int i = hs_leff; i < L; i++)
+      if (a.l[i]) hs_fail("limb above the ones q fills", (double) i);
+  }
+  static void hs_set(el &r, double u, double B) { r.hs_u = u; r.hs_B = B; hs_limbs(r); }
+  static void hs_dom(const el &b, int k) {
+    hs_limbs(b);
+    if (b.hs_u > KD[k] * U_STRICT + 1e-12) hs_fail("subtrahend limbs not dominated", b.hs_u);
+    if ((KC[k] - b.hs_B) * hs_topf < KD[k] + 1) hs_fail("subtrahend value not dominated", b.hs_B);
+  }
+  static void hs_cols(double s) { if (s > 2.55) hs_fail("column capacity", s); }
+  static void add(el &r, const el &a, const el &b) {
+    for (int i = 0; i < L; i++) r.l[i] = a.l[i] + b.l[i];
+    if (a.hs_u + b.hs_u >= OVF) hs_fail("sum overflows 32 bits", a.hs_u + b.hs_u);
+    hs_set(r, a.hs_u + b.hs_u, a.hs_B + b.hs_B);
+  }
+  template <int S> static void shl(el &r, const el &a) {
+    for (int i = 0; i < L; i++) r.l[i] = a.l[i] << S;
+    if (a.hs_u * (1 << S) >= OVF) hs_fail("shift overflows 32 bits", a.hs_u);
+    hs_set(r, a.hs_u * (1 << S), a.hs_B * (1 << S));
+  }
+  static void subk(el &r, const el &a, const el &b, int k) {
+    const uint32_t *K = hs_tab + AW_AUX_HEAD + k * L;
+    hs_dom(b, k);
+    const double u = a.hs_u + KD[k] + 1, B = a.hs_B + KC[k];
+    if (u >= OVF) hs_fail("difference overflows 32 bits", u);
+    for (int i = 0; i < L; i++) {
+      if (K[i] < b.l[i]) hs_fail("negative limb in a difference", (double) i);
+      r.l[i] = a.l[i] - b.l[i] + K[i];
+    }
+    hs_set(r, u, B);
+  }
+  static void negk(el &r, const el &b, int k) {
+    const uint32_t *K = hs_tab + AW_AUX_HEAD + k * L;
+    hs_dom(b, k);
+    for (int i = 0; i < L; i++) {
+      if (K[i] < b.l[i]) hs_fail("negative limb in a negation", (double) i);
+      r.l[i] = K[i] - b.l[i];
+    }
+    hs_set(r, KD[k] + 1, KC[k]);
+  }
+  static void norm(el &r, const el &a) {                       // AW::norm_m with init()'s masks: one parallel carry pass
+    hs_limbs(a);
+    const double B = a.hs_B;
+    if (a.hs_u >= OVF) hs_fail("normalising limbs above 32 bits", a.hs_u);
+    uint32_t c = 0;
+    for (int i = 0; i < L; i++) {
+      const uint32_t t = a.l[i];
+      r.l[i] = (i < hs_leff - 1 ? (t & MASK) : (i == hs_leff - 1 ? t : 0u)) + c;
+      c = i < hs_leff - 1 ? t >> WB : 0u;
+    }
+    hs_set(r, U_ALMOST, B);
+  }
+  static void to_el(el &r, const fp<N> &a) { to_limbs<N>(r, a); hs_set(r, U_STRICT, 1.0); }
+  static void to_words(fp<N> &r, const el &a) {
+    hs_limbs(a);
+    if (a.hs_u > U_STRICT || a.hs_B >= 2) hs_fail("from_limbs needs a P-class value", a.hs_B);
+    from_limbs<N>(r, a);
+  }
+  static void to_el_uniform(el &r, const uint32_t *w) {
+    for (int i = 0; i < L; i++) {
+      const int bit = WB * i, j = bit >> 5, sh = bit & 31;
+      const uint64_t pair = ((uint64_t) (j + 1 < N ? w[j + 1] : 0u) << 32) | w[j];
+      r.l[i] = (uint32_t) (pair >> sh) & MASK;
+    }
+    hs_set(r, U_STRICT, 1.0);
+  }
+#endif
 };
 
 template <int N, int NW = 1, class A_ = AL<N>>   // NW: wavefronts that work on ONE pairing (1, 2 or 4 = a 128- / 256-lane workgroup: see round_nw)
@@ -89,7 +176,7 @@ struct AW {
       if (lo[0]) A::hs_fail("wave product: column not cleared", (double) i);
       for (int j = 0; j < L; j++) {
         if (acc[j] >> 60) A::hs_fail("wave product: accumulator above 2^60", (double) i);
-        acc[j] = (acc[j] >> 29) + lo[j + 1];                   // 32 bits on the device
+        acc[j] = (acc[j] >> WB) + lo[j + 1];                   // 32 bits on the device
         if (acc[j] >> 32) A::hs_fail("wave product: carried limb above 32 bits", (double) j);
       }
     }
@@ -99,23 +186,24 @@ struct AW {
     }
     strict_limbs(r);
   }
-  static void strict_limbs(W &r) {            // carry passes until every limb below the top is under 2^29
+  static void strict_limbs(W &r) {            // carry passes until every limb below the top is under 2^W (the device's masks: AW::init)
+    const int le = A::leff_();
     for (;;) {
       bool any = false;
       uint32_t c = 0;
       for (int j = 0; j < L; j++) {
         const uint32_t t = r.l[j];
-        r.l[j] = (j < L - 1 ? (t & MASK) : t) + c;
-        c = j < L - 1 ? t >> 29 : 0;
+        r.l[j] = (j < le - 1 ? (t & MASK) : (j == le - 1 ? t : 0u)) + c;
+        c = j < le - 1 ? t >> WB : 0;
       }
-      for (int j = 0; j < L - 1; j++) any |= r.l[j] > MASK;
+      for (int j = 0; j < le - 1; j++) any |= r.l[j] > MASK;
       if (!any) break;
     }
   }
   static W mul(const W &a, const W &b) {
     W r;
     A::hs_limbs(a); A::hs_limbs(b); A::hs_cols(a.hs_u * b.hs_u);
-    const double B = 1 + a.hs_B * b.hs_B / 1024;
+    const double B = 1 + a.hs_B * b.hs_B / A::hs_slack();
     lanes_sop(r, &a, &b, 1);
     A::hs_set(r, A::U_STRICT, B);
     return r;
@@ -125,7 +213,7 @@ struct AW {
     W r;
     const W x[2] = {a0, a1}, y[2] = {b0, b1};
     A::hs_limbs(a0); A::hs_limbs(b0); A::hs_limbs(a1); A::hs_limbs(b1); A::hs_cols(a0.hs_u * b0.hs_u + a1.hs_u * b1.hs_u);
-    const double B = 1 + (a0.hs_B * b0.hs_B + a1.hs_B * b1.hs_B) / 1024;
+    const double B = 1 + (a0.hs_B * b0.hs_B + a1.hs_B * b1.hs_B) / A::hs_slack();
     lanes_sop(r, x, y, 2);
     A::hs_set(r, A::U_STRICT, B);
     return r;
@@ -144,7 +232,8 @@ struct AW {
   static W sub_q(const W &x) {
     const FpK<N> &K = fpk<N>();
     W r;
-    for (int j = 0; j < L; j++) r.l[j] = x.l[j] - K.p29[j] + (j < L - 1 ? (1u << 29) : 0) - (j > 0 ? 1 : 0);
+    const int le = A::leff_();
+    for (int j = 0; j < L; j++) r.l[j] = x.l[j] - K.p29[j] + (j < le - 1 ? (1u << WB) : 0) - (j > 0 && j < le ? 1 : 0);
     strict_limbs(r);
     A::hs_set(r, A::U_STRICT, 1.0);
     return r;
@@ -538,6 +627,9 @@ struct AW {
     const W P = norm(shl<1>(g0));
     W two = strict2(add(oneR, oneR));
     if (geq_q(two)) two = sub_q(two);
+#ifdef PBC_HOSTSIM
+    else A::hs_set(two, A::U_STRICT, 1.0);                     // (below q: the comparison has just said so)
+#endif
     W v0 = two, v1 = P;
     for (int j = c_a.hbits - 1; j >= 0; j--) {
       const bool bit = j ? ((c_a.h[j >> 5] >> (j & 31)) & 1) : false;

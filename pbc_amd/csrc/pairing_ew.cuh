@@ -15,15 +15,15 @@
 //   bounds: every product's operands are products' outputs or normalised sums (limbs ~2^28, one operand may be a sum of two); the
 //   subtrahends' values stay below the constant that dominates them (noted per line: B = value in units of q), with q filling
 //   twelve bits of its top limb and 44 bits of the radix free (host_params.h ag_aux_build checks both for the object's q).
-// Device only (the host mirror covers the shared routines on AL<16>); tests/test_gpu_agwave.py compares with the lane kernel, the
-// reference's vectors and the C restatement.
+// Host mirror (tests/hostsim): the same source lane by lane with an element = all its limbs, under the bound tracker of AG<N>'s
+// mirror -- which is where the bounds noted below are checked for every operation of a pairing; tests/test_gpu_agwave.py compares
+// the device with the lane kernel, the reference's vectors and the C restatement.
 #pragma once
 #include "pairing_aw.cuh"
 #include "pairing_e.cuh"
 
 namespace pbc {
 
-#ifndef PBC_HOSTSIM
 template <int N, int NW>
 struct EW : AW<N, NW, AG<N>> {
   typedef AW<N, NW, AG<N>> B;
@@ -32,8 +32,14 @@ struct EW : AW<N, NW, AG<N>> {
   typedef AG<N> A;
   static constexpr int L = B::L;
   enum { K2 = B::K2, K4 = B::K4, K8 = B::K8, K12 = B::K12, K16 = B::K16 };
-  using B::add; using B::norm; using B::subk; using B::mul; using B::sqr; using B::mul2; using B::mul4; using B::sop2x2; using B::lane; using B::sync;
-  using B::put_slot; using B::get_slot; using B::slot_to_el; using B::el_to_slot; using B::load_uniform; using B::invert_lane0; using B::init;
+  using B::add; using B::norm; using B::subk; using B::mul; using B::sqr; using B::mul2; using B::mul4; using B::sop2x2; using B::sync;
+  using B::load_uniform; using B::invert_lane0; using B::init;
+#ifndef PBC_HOSTSIM
+  using B::lane; using B::put_slot; using B::get_slot; using B::slot_to_el; using B::el_to_slot;
+  static PBC_DEV W zero_w() { return 0u; }
+#else
+  static W zero_w() { W z; for (int i = 0; i < L; i++) z.l[i] = 0; A::hs_set(z, 0.0, 0.0); return z; }
+#endif
 
   struct est { W n, d, X, Y, Z, ZZ, sZZ, ZZx1; };
   W cA, cS, cY2, x1, y1, xP, yP, oneR;         // a, s = x_R, y_R (uniform); S1 = Q + R; P; R mod q
@@ -78,12 +84,16 @@ struct EW : AW<N, NW, AG<N>> {
     A::to_el(e[1], yp);
     A::to_el(e[2], x3);
     A::to_el(e[3], y3);
+#ifdef PBC_HOSTSIM
+    xP = e[0]; yP = e[1]; x1 = e[2]; y1 = e[3];
+#else
     sync();
     if (threadIdx.x == 0)
       for (int i = 0; i < 4; i++) el_to_slot(e[i], i);
     sync();
     xP = get_slot(0); yP = get_slot(1); x1 = get_slot(2); y1 = get_slot(3);
     sync();
+#endif
     cA = load_uniform(c_e.A);
     cS = load_uniform(c_e.Rx);
     cY2 = load_uniform(c_e.Ry);
@@ -95,7 +105,7 @@ struct EW : AW<N, NW, AG<N>> {
     mul4(n2, d2, AZ4, Wv, s.n, s.n, s.d, s.d, cA, Z4, Z3, s.ZZ, 4);
     const W M = norm(add(add(B::template shl<1>(XX), XX), AZ4));                       // B 4
     const W g1 = norm(subk(s.X, s.ZZx1, K2)), g2 = norm(subk(s.X, s.sZZ, K2));           // X - ZZ x1, X - s ZZ (B <= 9 + 2)
-    const W X2 = B::template shl<1>(s.X), z = 0u;
+    const W X2 = B::template shl<1>(s.X), z = zero_w();
     sop4(l1, l2, S1, Y4, Wv, y1, M, g1, Wv, cY2, M, g2, YY, X2, z, z, YY, YY, z, z);
     const W YY2 = B::template shl<1>(YY);
     l1 = norm(subk(l1, YY2, K4));                                                        // - 2Y^2 (B 2 < 4)
@@ -154,7 +164,9 @@ struct EW : AW<N, NW, AG<N>> {
     const W di = invert_lane0(d);
     // (four wavefronts per unit: the chain below is one product at a time -- wave 0 runs it alone and the others leave their SIMDs
     // to other units; no workgroup barrier from here on)
+#ifndef PBC_HOSTSIM
     if (NW > 1 && B::wave() != 0) return;
+#endif
     const W x = mul(n, di);
     W tab[8];
     {
@@ -189,14 +201,20 @@ struct EW : AW<N, NW, AG<N>> {
       }
       i = lo - 1;
     }
+#ifndef PBC_HOSTSIM
     put_slot(acc, 0);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
     if (threadIdx.x == 0) {
       el ex;
       fp<N> out;
+#ifdef PBC_HOSTSIM
+      ex = acc;
+#else
       slot_to_el(ex, 0);
+#endif
       A::to_words(out, ex);
       if (!valid) fp_set<N>(out, fpk<N>().one);    // GT identity (pairing_apply, include/pbc_pairing.h:123-130)
       fp_store_be<N>(gt, out);
@@ -212,6 +230,26 @@ struct EW : AW<N, NW, AG<N>> {
   // element_prod_pairing (generic_prod_pairings, ecc/pairing.c:35-46): a record (n, d, validity) per TERM, then per product the
   // numerators and denominators multiplied, ONE inversion and ONE power
   static constexpr int WREC = B::WREC;
+#ifdef PBC_HOSTSIM
+  struct wrec { W n, d; bool valid; };
+  void miller_record_wave(wrec &r, const uint8_t *g1, const uint8_t *g2) {
+    est s;
+    init();
+    r.valid = miller(s, g1, g2);
+    r.n = s.n; r.d = s.d;
+  }
+  void prod_finish_wave(uint8_t *gt, const wrec *rec, int k) {
+    init();
+    oneR = load_uniform(fpk<N>().one);
+    bool valid = rec[0].valid;
+    W n = rec[0].n, d = rec[0].d;
+    for (int t = 1; t < k; t++) {
+      valid = valid && rec[t].valid;
+      mul2(n, d, n, rec[t].n, d, rec[t].d);
+    }
+    finish(gt, n, d, valid);
+  }
+#else
   PBC_DEV void miller_record_wave(uint32_t *rec, const uint8_t *g1, const uint8_t *g2) {
     est s;
     init();
@@ -236,7 +274,7 @@ struct EW : AW<N, NW, AG<N>> {
     }
     finish(gt, n, d, okw != 0);
   }
-};
 #endif
+};
 
 }  // namespace pbc

@@ -2,10 +2,12 @@
 // tiny C API (tests/test_hostsim.py).  It runs one lane at a time: same source, same limb
 // arithmetic, same control flow as the HIP kernels.  Not part of the product.
 #define PBC_HOSTSIM 1
+#include <math.h>
 #include <vector>
 #include "../../pbc_amd/csrc/host_params.h"
 #include "../../pbc_amd/csrc/pairing_al.cuh"
 #include "../../pbc_amd/csrc/pairing_aw.cuh"
+#include "../../pbc_amd/csrc/pairing_ew.cuh"
 #include "../../pbc_amd/csrc/group_al.cuh"
 #include "../../pbc_amd/csrc/group_l5.cuh"
 #include "../../pbc_amd/csrc/group_more.cuh"
@@ -38,6 +40,22 @@
 static void activate(pbc_hip_pairing_s *P, bool for_pairing = false) {
   HS_DISPATCH(P->nlimb, { KArgs<N> K; fill_kargs<N>(P, K, for_pairing); memcpy(hostsim_kargs + sizeof hostsim_kargs - sizeof K, &K, sizeof K); });
 }
+
+// type a1 / type a outside the fast path on the same routines (AG<N>: the host mirror of its additive layer carries AL's bound
+// tracker with the object's own limb width, filled limbs and subtraction constants): the two facts about q the bounds rest on
+static bool ag_object(const pbc_hip_pairing_s *P) { return (P->type == '1' || (P->type == 'a' && P->a_generic)) && !P->ag_aux.empty(); }
+template <int N>
+static void ag_bind(const pbc_hip_pairing_s *P) {
+  const int W = Limbs29<N>::W, L = Limbs29<N>::L, leff = (int) P->ag_aux[0];
+  int qbits = 0;
+  const uint32_t *q = N == 16 ? P->k16.p : P->k33.p;
+  for (int i = 0; i < 32 * N; i++) if ((q[i >> 5] >> (i & 31)) & 1) qbits = i + 1;
+  AG<N>::hs_tab = P->ag_aux.data();
+  AG<N>::hs_leff = leff;
+  AG<N>::hs_topf = ldexp(1.0, qbits - W * (leff - 1) - 1);
+  AG<N>::hs_slackf = ldexp(1.0, W * L - qbits);
+}
+#define HS_DISPATCH_AG(P_, ...) do { if ((P_)->nlimb == 16) { constexpr int N = 16; ag_bind<N>(P_); __VA_ARGS__; } else { constexpr int N = 33; ag_bind<N>(P_); __VA_ARGS__; } } while (0)
 
 extern "C" {
 
@@ -121,6 +139,18 @@ int hostsim_lens(void *h, int *l1, int *l2, int *lt) {
 // element_pairing on the one-pairing-per-wavefront routine (pairing_aw.cuh), type a with the 512-bit field
 int hostsim_pairing_wave(void *h, uint8_t *gt, const uint8_t *g1, const uint8_t *g2, size_t n) {
   pbc_hip_pairing_s *P = (pbc_hip_pairing_s *) h;
+  if (P->type == 'e' && !P->ag_aux.empty()) {              // pairing_ew.cuh: type e on the same routines
+    activate(P, true);
+    HS_DISPATCH_AG(P, for (size_t u = 0; u < n; u++) { EW<N, 1> w; w.pairing_wave(gt + u * P->lenT, g1 + u * P->len1, g2 + u * P->len2); });
+    activate(P);
+    return 0;
+  }
+  if (ag_object(P)) {
+    activate(P, true);
+    HS_DISPATCH_AG(P, for (size_t u = 0; u < n; u++) { AW<N, 1, AG<N>> w; w.pairing_wave(gt + u * P->lenT, g1 + u * P->len1, g2 + u * P->len2); });
+    activate(P);
+    return 0;
+  }
   if (P->type != 'a' || P->a_generic) return 1;
   activate(P, true);
   for (size_t u = 0; u < n; u++) { AW<16, 1> w; w.pairing_wave(gt + u * P->lenT, g1 + u * P->len1, g2 + u * P->len2); }
@@ -131,6 +161,18 @@ int hostsim_pairing_wave(void *h, uint8_t *gt, const uint8_t *g1, const uint8_t 
 // prod_finish_wave); the table is the one the library's a_pp_init_lane writes
 int hostsim_pp_wave(void *h, uint8_t *gt, const uint8_t *g1, const uint8_t *g2, size_t n) {
   pbc_hip_pairing_s *P = (pbc_hip_pairing_s *) h;
+  if (ag_object(P)) {                    // the table a1_pp_init_lane writes: one entry per doubling and per addition
+    activate(P, true);
+    int steps = P->a.rbits - 1;
+    for (int m = 1; m <= P->a.rbits - 2; m++) steps += ((P->a.r[m >> 5] | P->a.rm[m >> 5]) >> (m & 31)) & 1;
+    HS_DISPATCH_AG(P, {
+      std::vector<uint32_t> tab((size_t) steps * 3 * N);
+      const bool ok = a1_pp_init_lane<N>(tab.data(), g1);
+      for (size_t u = 0; u < n; u++) { AW<N, 1, AG<N>> w; w.pp_apply_wave(gt + u * P->lenT, tab.data(), ok, g2 + u * P->len2); }
+    });
+    activate(P);
+    return 0;
+  }
   if (P->type != 'a' || P->a_generic) return 1;
   activate(P, true);
   std::vector<uint32_t> tab((size_t) (P->a.exp2 + 1) * 3 * 16);
@@ -141,6 +183,30 @@ int hostsim_pp_wave(void *h, uint8_t *gt, const uint8_t *g1, const uint8_t *g2, 
 }
 int hostsim_prod_wave(void *h, uint8_t *gt, const uint8_t *g1, const uint8_t *g2, size_t n, int k) {
   pbc_hip_pairing_s *P = (pbc_hip_pairing_s *) h;
+  if (P->type == 'e' && !P->ag_aux.empty()) {
+    activate(P, true);
+    HS_DISPATCH_AG(P, for (size_t u = 0; u < n; u++) {
+      typedef EW<N, 1> WV;
+      std::vector<typename WV::wrec> rec((size_t) k);
+      for (int t = 0; t < k; t++) { WV w; w.miller_record_wave(rec[t], g1 + (u * k + t) * P->len1, g2 + (u * k + t) * P->len2); }
+      WV w;
+      w.prod_finish_wave(gt + u * P->lenT, rec.data(), k);
+    });
+    activate(P);
+    return 0;
+  }
+  if (ag_object(P)) {
+    activate(P, true);
+    HS_DISPATCH_AG(P, for (size_t u = 0; u < n; u++) {
+      typedef AW<N, 1, AG<N>> WV;
+      std::vector<typename WV::wrec> rec((size_t) k);
+      for (int t = 0; t < k; t++) { WV w; w.miller_record_wave(rec[t], g1 + (u * k + t) * P->len1, g2 + (u * k + t) * P->len2); }
+      WV w;
+      w.prod_finish_wave(gt + u * P->lenT, rec.data(), k);
+    });
+    activate(P);
+    return 0;
+  }
   if (P->type != 'a' || P->a_generic) return 1;
   activate(P, true);
   for (size_t u = 0; u < n; u++) {

@@ -645,3 +645,46 @@ def test_fused_products_on_host(sims, key, qkey, nw):
         assert got == z, (key, sqr, hex(op))
     if key.startswith("e"):
         assert 1 <= sim.e_rxs() <= 255
+
+
+@pytest.mark.parametrize("pname,rand,prod", [("a1", "a1_rand6.vec", "a1_prod3x3_edge.vec"), ("a_160_1024", "a_160_1024_rand4.vec", "a_160_1024_prod3x3_edge.vec"),
+                                             ("a_160_256", "a_160_256_rand6.vec", "a_160_256_prod3x4_edge.vec")])
+def test_wave_kernels_of_type_a1_and_generic_type_a_on_host(pname, rand, prod):
+    """pairing_aw.cuh with AG<N> (round 6: type a1, type a outside the fast path; 38 limbs of 28 bits on the 33-word fields): the same
+    source lane by lane on the host under the bound tracker of AG's host mirror -- limbs within what was derived for them, every
+    subtrahend dominated by its borrowed constant (limbs AND value, with the object's own top-limb fill), no negative limb, column
+    capacity, products' values below 2 q with the object's own radix slack, nothing above the limbs q fills -- plus the
+    recurrence's checks; the reference's vectors for pairings (edge cases included), products and pairing_pp_apply"""
+    import hostsim
+    from conftest import _param
+    S = hostsim.HostSim(_param(pname))
+    v = golden(rand)
+    assert np.array_equal(S.pairing_wave(v.g1, v.g2), v.gt)
+    if pname == "a1":
+        e = golden("a1_edge6.vec")
+        assert np.array_equal(S.pairing_wave(e.g1, e.g2), e.gt)
+    w = golden(prod)
+    n = min(w.n, 2)
+    assert np.array_equal(S.prod_wave(w.g1[:n * w.k], w.g2[:n * w.k], w.k), w.gt[:n])
+    assert np.array_equal(S.pp_wave(v.g1[0], v.g2[:2]), S.pairing_wave(np.tile(v.g1[0], (2, 1)), v.g2[:2]))
+
+
+@pytest.mark.parametrize("pname,rand,prod", [("e", "e_rand6.vec", "e_prod3x3_edge.vec"), ("e_160_400", "e_160_400_rand6.vec", "e_160_400_prod3x4_edge.vec")])
+def test_wave_kernels_of_type_e_on_host(pname, rand, prod, oracles):
+    """pairing_ew.cuh (round 6: type e on the limb-per-lane routines): its doubling and addition steps in rounds of four products,
+    numerator and denominator apart, the sliding-window power -- the same source on the host under the tracker of AG's mirror, which
+    checks every bound the file notes (subtrahends below the constants that dominate them with e.param's twelve-bit top limb,
+    columns within 2.55 units, limbs within 32 bits); the reference's vectors (edge cases and products included) and cross pairs
+    against the C restatement"""
+    import hostsim
+    from conftest import _param
+    S = hostsim.HostSim(_param(pname))
+    v = golden(rand)
+    assert np.array_equal(S.pairing_wave(v.g1, v.g2), v.gt)
+    if pname == "e":
+        e = golden("e_edge6.vec")
+        assert np.array_equal(S.pairing_wave(e.g1, e.g2), e.gt)
+    w = golden(prod)
+    assert np.array_equal(S.prod_wave(w.g1, w.g2, w.k), w.gt)
+    i, j = np.arange(v.n), (np.arange(v.n) * 5 + 2) % v.n
+    assert np.array_equal(S.pairing_wave(v.g1[i], v.g2[j]), oracles[pname].pairing_batch(v.g1[i], v.g2[j]))

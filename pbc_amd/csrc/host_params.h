@@ -75,6 +75,7 @@ struct pbc_hip_pairing_s {
   std::vector<uint32_t> ag_aux;  // type a1 / type a outside the fast path: the table of the wave kernels (pairing_aw.cuh AG<N>: LEFF, five subtraction constants; empty: this q keeps the lane kernels)
   size_t ag_wave_max;        // ... batches (terms of products) up to this size take them ("hip_wave_max N", 0 = never), four wavefronts per unit up to ag_wave4_max ("hip_wave4_max N")
   size_t ag_wave4_max;
+  size_t ag_wave8_max;       // ... and EIGHT (the three-round Miller loop of pairing_aw.cuh miller_loop_p) up to this many terms ("hip_wave8_max N"; type e: never)
   size_t a_wave_max;         // type a fast path, element_pairing: batches up to this size take one WAVEFRONT per pairing (pairing_aw.cuh; "hip_wave_max N", 0 = never)
   size_t d_wave_max;         // type d, five-word fields: single pairings in batches up to this size take one wavefront each (pairing_dw.cuh; "hip_dwave_max N")
   size_t a_prod_chunk;       // ... otherwise: terms per launch of the one-term-per-lane kernels ("hip_prod_chunk N", tests)
@@ -248,6 +249,9 @@ static void ag_aux_build(pbc_hip_pairing_s *P, const pbc_host::Big &q, const cha
   pbc_host::param_int(txt, len, "hip_wave4_max", wave4_max);
   P->ag_wave_max = wave_max < 0 ? 0 : (size_t) wave_max;
   P->ag_wave4_max = wave4_max < 0 ? 0 : (size_t) wave4_max;
+  int wave8_max = type_e ? 0 : (N >= 32 ? 256 : 128);      // a1.param: 7.7 ms a pairing against 9.1 with four wavefronts, up to 256 units (two wavefronts on every SIMD); 512 units: 15.6 against 11.5
+  pbc_host::param_int(txt, len, "hip_wave8_max", wave8_max);
+  P->ag_wave8_max = wave8_max < 0 || type_e ? 0 : (size_t) wave8_max;
   const int qb = q.bits(), leff = (qb + W - 1) / W, top = qb - W * (leff - 1);
   if (leff > L || leff < 3 || W * L - qb < 10 || top < 12) return;
   std::vector<uint32_t> a(pbc::AW_AUX_HEAD + 5 * L, 0u);

@@ -26,7 +26,7 @@
 
 namespace pbc {
 
-constexpr int AW_SLOTS = 16;                 // LDS words per workgroup: AW_SLOTS x 64 (5 inputs / 2 outputs, the inversion, 2 x 4 products of a round); a slot holds all 64 lanes, so no access is predicated
+constexpr int AW_SLOTS = 24;                 // LDS words per workgroup: AW_SLOTS x 64 (5 inputs / 2 outputs, the inversion, 2 x 4 -- NW = 8: 2 x 8 -- products of a round); a slot holds all 64 lanes, so no access is predicated
 #ifndef PBC_HOSTSIM
 template <int N> __shared__ uint32_t g_lds_aw_t[AW_SLOTS * 64];
 #define g_lds_aw g_lds_aw_t<N>
@@ -246,6 +246,11 @@ struct AW {
     if (count > 2) r2 = z;
     if (count > 3) r3 = t;
   }
+  static void round8(W *r, const W *a0, const W *b0, const W *a1, const W *b1, int count, unsigned sums) {
+    W t[8];
+    for (int k = 0; k < count; k++) t[k] = ((sums >> k) & 1) ? sop2(a0[k], b0[k], a1[k], b1[k]) : mul(a0[k], b0[k]);
+    for (int k = 0; k < count; k++) r[k] = t[k];
+  }
   static bool lane0() { return true; }
   static void sync() {}
   static W load_uniform(const uint32_t *w) { W r; A::to_el_uniform(r, w); return r; }
@@ -381,6 +386,36 @@ struct AW {
 #pragma unroll
     for (int k = 0; k < 4; k++) if (k < count) r[k] = get_slot(base + k);
     par ^= 1;
+  }
+  // NW = 8 (round 6: a 512-lane workgroup, two wavefronts on every SIMD of the CU -- a lone wave's dependency chain leaves the pipe
+  // half empty, so the second one rides along): up to EIGHT items a round, each a product or -- bit k of `sums` -- a sum of two
+  PBC_DEV void round8(W *r, const W *a0, const W *b0, const W *a1, const W *b1, int count, unsigned sums) {
+    if constexpr (NW == 8) {
+      const int w = wave();
+      const int base = 6 + 8 * par;
+      if (w < count) {
+        W x0, y0, x1, y1;
+        switch (w) {                                           // (w is wave-uniform: scalar branches, no indexed register file)
+          case 0: x0 = a0[0]; y0 = b0[0]; x1 = a1[0]; y1 = b1[0]; break;
+          case 1: x0 = a0[1]; y0 = b0[1]; x1 = a1[1]; y1 = b1[1]; break;
+          case 2: x0 = a0[2]; y0 = b0[2]; x1 = a1[2]; y1 = b1[2]; break;
+          case 3: x0 = a0[3]; y0 = b0[3]; x1 = a1[3]; y1 = b1[3]; break;
+          case 4: x0 = a0[4]; y0 = b0[4]; x1 = a1[4]; y1 = b1[4]; break;
+          case 5: x0 = a0[5]; y0 = b0[5]; x1 = a1[5]; y1 = b1[5]; break;
+          case 6: x0 = a0[6]; y0 = b0[6]; x1 = a1[6]; y1 = b1[6]; break;
+          default: x0 = a0[7]; y0 = b0[7]; x1 = a1[7]; y1 = b1[7]; break;
+        }
+        const bool sum = ((sums >> w) & 1u) != 0;                // wave-uniform
+        const W res = sum ? sop2_fn(x0, y0, x1, y1, qq, nv, mk) : mul_fn(x0, y0, qq, nv, mk);
+        put_slot(res, base + w);
+      }
+      sync();
+#pragma unroll
+      for (int k = 0; k < 8; k++) if (k < count) r[k] = get_slot(base + k);
+      par ^= 1;
+    } else {                                                   // (fewer waves: one after the other, every wave for itself)
+      for (int k = 0; k < count; k++) r[k] = ((sums >> k) & 1u) ? sop2(a0[k], b0[k], a1[k], b1[k]) : mul(a0[k], b0[k]);
+    }
   }
   PBC_DEV void mul4(W &r0, W &r1, W &r2, W &r3, W a0, W b0, W a1, W b1, W a2, W b2, W a3, W b3, int count) {
     if constexpr (NW == 1) {
@@ -589,8 +624,101 @@ struct AW {
   // The Miller loop: a.param's Solinas order (a_pairing_proj, ecc/a_param.c:1101-1210: exp2 doublings, one addition after bit
   // exp1), or -- type a1 and type a parameters of other shapes -- the signed digits of the order (pairing_a.cuh a1_miller_lane:
   // a1_pairing_proj, a_param.c:1840-2015, with the digits of hostbn.h naf_of_half)
+  // NW = 8: the same products, operand classes and borrowed constants as double_step / add_step in THREE rounds a doubling step --
+  // the point's chain is three products deep (X^2 -> M^2 -> M Wd), and the accumulator's two (f <- f l of step i - 1, then f^2) fit
+  // beside it once the line of a step is multiplied in at the start of the next:
+  //     1  X^2, Z^4, Y^2, 2Y Z, Qx ZZ  |  f l_(i-1) (two sums)        2  M^2, Y^2 2X, Y^4, M (Qx ZZ + X), Z3 ZZ, Z3^2  |  f^2 (two)
+  //     3  M Wd, (Z3 ZZ) Qy                                          -> l_i waits for round 1 of the next step (or of the addition)
+  // an addition in five: the waiting line beside its first two products, its own line beside its last one.
+  PBC_DEV void miller_loop_p(state &s, const W &Px, const W &Py) {
+    const W nPy = norm(negk(Py, K2));
+    W plx = s.fx, ply = s.fx;                                  // the line that waits (values: none yet)
+    bool pending = false;
+    W r[8];
+    for (int i = c_a.rbits - 2; i >= 0; i--) {
+      W XX, Z4, YY, Z3, t0;
+      {
+        const W nfy = norm(negk(s.fy, K2));
+        const W a0[8] = {s.X, s.ZZ, s.Y, shl<1>(s.Y), s.Qx, s.fx, s.fx, s.fx}, b0[8] = {s.X, s.ZZ, s.Y, s.Z, s.ZZ, plx, ply, ply};
+        const W a1[8] = {s.X, s.X, s.X, s.X, s.X, nfy, s.fy, s.X}, b1[8] = {s.X, s.X, s.X, s.X, s.X, ply, plx, s.X};
+        round8(r, a0, b0, a1, b1, pending ? 7 : 5, 0x60u);
+        XX = r[0]; Z4 = r[1]; YY = r[2]; Z3 = r[3]; t0 = r[4];
+        if (pending) { s.fx = r[5]; s.fy = r[6]; }
+      }
+      const W M = norm(add(add(shl<1>(XX), XX), Z4));
+      t0 = add(t0, s.X);
+      W MM, S1, Y4, lx, t1, ZZn;
+      {
+        const W e0 = add(s.fx, s.fy);
+        const W e1 = norm(subk(s.fx, s.fy, K2));
+        const W a0[8] = {M, YY, YY, M, Z3, Z3, e0, shl<1>(s.fx)}, b0[8] = {M, shl<1>(s.X), YY, t0, s.ZZ, Z3, e1, s.fy};
+        round8(r, a0, b0, a0, b0, 8, 0u);
+        MM = r[0]; S1 = r[1]; Y4 = r[2]; lx = r[3]; t1 = r[4]; ZZn = r[5]; s.fx = r[6]; s.fy = r[7];
+      }
+      lx = norm(subk(lx, shl<1>(YY), K4));
+      const W X3 = norm(subk(MM, shl<2>(S1), K8));
+      const W Wd = norm(subk(shl<1>(S1), X3, K12));
+      {
+        const W a0[8] = {M, t1, M, M, M, M, M, M}, b0[8] = {Wd, s.Qy, M, M, M, M, M, M};
+        round8(r, a0, b0, a0, b0, 2, 0u);
+      }
+      const W Y48 = norm(shl<3>(Y4));
+      s.Y = norm(subk(r[0], Y48, K12));
+      s.X = X3; s.Z = Z3; s.ZZ = ZZn;
+      plx = lx; ply = r[1]; pending = true;
+      const int dig = i > 0 ? a1_digit(i) : 0;
+      if (dig) {                                               // AL::add_step; its first round takes the waiting line along
+        const W x2 = Px, y2 = dig < 0 ? nPy : Py;
+        W a, b;
+        {
+          const W nfy = norm(negk(s.fy, K2));
+          const W a0[8] = {x2, s.Z, s.fx, s.fx, x2, x2, x2, x2}, b0[8] = {s.ZZ, s.ZZ, plx, ply, x2, x2, x2, x2};
+          const W a1[8] = {x2, x2, nfy, s.fy, x2, x2, x2, x2}, b1[8] = {x2, x2, ply, plx, x2, x2, x2, x2};
+          round8(r, a0, b0, a1, b1, 4, 0xcu);
+          a = r[0]; b = r[1]; s.fx = r[2]; s.fy = r[3];
+          pending = false;
+        }
+        const W H = norm(subk(a, s.X, K16));
+        W c, Z3a, HH;
+        {
+          const W a0[8] = {y2, H, H, H, H, H, H, H}, b0[8] = {b, s.Z, H, H, H, H, H, H};
+          round8(r, a0, b0, a0, b0, 3, 0u);
+          c = r[0]; Z3a = r[1]; HH = r[2];
+        }
+        const W R = norm(subk(c, s.Y, K16));
+        W alx, HHH, XHH, RR;
+        {
+          const W a0[8] = {R, HH, s.X, R, R, R, R, R}, b0[8] = {add(s.Qx, x2), H, HH, R, R, R, R, R};
+          round8(r, a0, b0, a0, b0, 4, 0u);
+          alx = r[0]; HHH = r[1]; XHH = r[2]; RR = r[3];
+        }
+        W at0, aly, ZZa, YH;
+        {
+          const W a0[8] = {Z3a, Z3a, Z3a, s.Y, R, R, R, R}, b0[8] = {y2, s.Qy, Z3a, HHH, R, R, R, R};
+          round8(r, a0, b0, a0, b0, 4, 0u);
+          at0 = r[0]; aly = r[1]; ZZa = r[2]; YH = r[3];
+        }
+        alx = norm(subk(alx, at0, K2));
+        W t1a = norm(subk(RR, HHH, K2));
+        t1a = norm(subk(t1a, shl<1>(XHH), K4));
+        const W d = norm(subk(XHH, t1a, K16));
+        {
+          const W nfy = norm(negk(s.fy, K2));
+          const W a0[8] = {R, s.fx, s.fx, R, R, R, R, R}, b0[8] = {d, alx, aly, R, R, R, R, R};
+          const W a1[8] = {R, nfy, s.fy, R, R, R, R, R}, b1[8] = {R, aly, alx, R, R, R, R, R};
+          round8(r, a0, b0, a1, b1, 3, 0x6u);
+          s.Y = norm(subk(r[0], YH, K2));
+          s.fx = r[1]; s.fy = r[2];
+        }
+        s.X = t1a; s.Z = Z3a; s.ZZ = ZZa;
+      }
+    }
+    if (pending) fmul(s, plx, ply);
+  }
   PBC_DEV void miller_loop(state &s, const W &Px, const W &Py) {
-    if constexpr (kDigits) {
+    if constexpr (kDigits && NW == 8) {
+      miller_loop_p(s, Px, Py);
+    } else if constexpr (kDigits) {
       W nPy = norm(negk(Py, K2));
       for (int i = c_a.rbits - 2; i >= 0; i--) {
         double_step(s);

@@ -389,17 +389,21 @@ int launch_a(pbc_hip_pairing_s *P, void *d_gt, const void *d_g1, const void *d_g
     const uint32_t *aux = ag_device_aux(P);
     if (!aux) return 1;
     const size_t nt = n * (size_t) k;
-    const bool four = nt <= P->ag_wave4_max;
+    const bool four = nt <= P->ag_wave4_max, eight = nt <= P->ag_wave8_max;
     if (k == 1) {
       PBC_DISPATCH_AG(P, {
-        if (four) hipLaunchKernelGGL((agw_pairing_kernel<N, 4>), dim3((unsigned) n), dim3(256), 0, s, (uint8_t *) d_gt, (const uint8_t *) d_g1, (const uint8_t *) d_g2, aux, kargs<N>(P));
+        if (eight) hipLaunchKernelGGL((agw_pairing_kernel<N, 8>), dim3((unsigned) n), dim3(512), 0, s, (uint8_t *) d_gt, (const uint8_t *) d_g1, (const uint8_t *) d_g2, aux, kargs<N>(P));
+        else if (four) hipLaunchKernelGGL((agw_pairing_kernel<N, 4>), dim3((unsigned) n), dim3(256), 0, s, (uint8_t *) d_gt, (const uint8_t *) d_g1, (const uint8_t *) d_g2, aux, kargs<N>(P));
         else hipLaunchKernelGGL((agw_pairing_kernel<N, 1>), dim3((unsigned) n), dim3(64), 0, s, (uint8_t *) d_gt, (const uint8_t *) d_g1, (const uint8_t *) d_g2, aux, kargs<N>(P));
       });
     } else {
       uint32_t *ws = (uint32_t *) W.get(nt * AW<33, 1, AG<33>>::WREC * sizeof(uint32_t));
       if (!ws) return 1;
       PBC_DISPATCH_AG(P, {
-        if (four) {
+        if (eight) {
+          hipLaunchKernelGGL((agw_miller_kernel<N, 8>), dim3((unsigned) nt), dim3(512), 0, s, ws, (const uint8_t *) d_g1, (const uint8_t *) d_g2, aux, kargs<N>(P));
+          hipLaunchKernelGGL((agw_prod_finish_kernel<N, 4>), dim3((unsigned) n), dim3(256), 0, s, (uint8_t *) d_gt, (const uint32_t *) ws, k, aux, kargs<N>(P));
+        } else if (four) {
           hipLaunchKernelGGL((agw_miller_kernel<N, 4>), dim3((unsigned) nt), dim3(256), 0, s, ws, (const uint8_t *) d_g1, (const uint8_t *) d_g2, aux, kargs<N>(P));
           hipLaunchKernelGGL((agw_prod_finish_kernel<N, 4>), dim3((unsigned) n), dim3(256), 0, s, (uint8_t *) d_gt, (const uint32_t *) ws, k, aux, kargs<N>(P));
         } else {

@@ -147,7 +147,8 @@ int hostsim_pairing_wave(void *h, uint8_t *gt, const uint8_t *g1, const uint8_t 
   }
   if (ag_object(P)) {
     activate(P, true);
-    HS_DISPATCH_AG(P, for (size_t u = 0; u < n; u++) { AW<N, 1, AG<N>> w; w.pairing_wave(gt + u * P->lenT, g1 + u * P->len1, g2 + u * P->len2); });
+    // (NW = 8: the three-round schedule of the smallest batches, miller_loop_p; products below run the five-round one)
+    HS_DISPATCH_AG(P, for (size_t u = 0; u < n; u++) { AW<N, 8, AG<N>> w; w.pairing_wave(gt + u * P->lenT, g1 + u * P->len1, g2 + u * P->len2); });
     activate(P);
     return 0;
   }

@@ -132,7 +132,7 @@ def test_one_wavefront_per_unit_shape(hips, pname):
     33-word fields is four wavefronts at every size, so this shape is named explicitly"""
     import pbc_amd
     v = golden(FILES[pname][3])
-    H1 = pbc_amd.Pairing(_param(pname) + "hip_wave4_max 0\n")
+    H1 = pbc_amd.Pairing(_param(pname) + "hip_wave4_max 0\nhip_wave8_max 0\n")
     i = np.arange(5)
     g1, g2 = np.ascontiguousarray(v.g1[(i * 3 + 1) % v.n]), np.ascontiguousarray(v.g2[(i * 7 + 2) % v.n])
     g1[4, 5] ^= 1
@@ -156,3 +156,19 @@ def test_cut_over_to_the_lane_kernels(hips):
     whole = H.element_pairing(g1, g2)                          # lanes
     assert np.array_equal(whole[:6144], H.element_pairing(g1[:6144], g2[:6144]))   # wavefronts
     assert np.array_equal(whole[6144:], H.element_pairing(g1[6144:], g2[6144:]))
+
+
+@pytest.mark.parametrize("pname", ["a1", "a_160_1024", "a_160_256"])
+def test_eight_wavefronts_per_unit_shape(hips, pname):
+    """up to hip_wave8_max = 128 terms a unit gets EIGHT wavefronts and the three-round Miller loop (miller_loop_p: the line of a step
+    multiplied in beside the next step's first products); "hip_wave8_max 0" keeps four and the five-round loop -- the same bytes,
+    off-curve arguments included, for pairings and for products (whose terms take the same loop)"""
+    import pbc_amd
+    v = golden(FILES[pname][3])
+    H4 = pbc_amd.Pairing(_param(pname) + "hip_wave8_max 0\n")
+    i = np.arange(9)
+    g1, g2 = np.ascontiguousarray(v.g1[(i * 3 + 1) % v.n]), np.ascontiguousarray(v.g2[(i * 7 + 2) % v.n])
+    g1[4, 5] ^= 1
+    assert np.array_equal(H4.element_pairing(g1, g2), hips[pname].element_pairing(g1, g2))
+    assert np.array_equal(H4.element_prod_pairing(g1[:8], g2[:8], 4), hips[pname].element_prod_pairing(g1[:8], g2[:8], 4))
+    H4.clear()

@@ -19,6 +19,7 @@ from conftest import golden, _param  # noqa: E402
 
 PNAME = os.environ.get("AG_PARAM", "a1")
 W4 = os.environ.get("AG_WAVE4_MAX")
+W8 = os.environ.get("AG_WAVE8_MAX")
 v = golden({"a1": "a1_chain8.vec", "e": "e_chain8.vec", "a_160_1024": "a_160_1024_rand4.vec"}.get(PNAME, PNAME + "_rand6.vec"))
 args = sys.argv[1:]
 mode, k = "pairing", 1
@@ -28,7 +29,7 @@ elif args and args[0] == "pp":
     mode, args = "pp", args[1:]
 sizes = [int(x) for x in args] or [1, 64, 1024, 4096]
 lane_max = int(os.environ.get("LANE_MAX", "4096"))
-P = {"wave": pbc_amd.Pairing(_param(PNAME) + "hip_wave_max 100000000\n" + ("hip_wave4_max %s\n" % W4 if W4 else "")), "lane": pbc_amd.Pairing(_param(PNAME) + "hip_wave_max 0\n")}
+P = {"wave": pbc_amd.Pairing(_param(PNAME) + "hip_wave_max 100000000\n" + ("hip_wave4_max %s\n" % W4 if W4 else "") + ("hip_wave8_max %s\n" % W8 if W8 else "")), "lane": pbc_amd.Pairing(_param(PNAME) + "hip_wave_max 0\n")}
 pps = {name: H.pp_init(v.g1[1]) for name, H in P.items()} if mode == "pp" else {}
 for n in sizes:
     i = np.arange(n * k) % v.n

@@ -145,9 +145,10 @@ int pbc_hip_element_pairing_batch(pbc_hip_pairing_t *p, uint8_t *gt, const uint8
  * at init) a launch of up to 12 288 units on the 33-word fields / 6144 on the 16-word ones ("hip_wave_max N", 0 = never) gives
  * every pairing -- every TERM of a product, then every product; every second argument of pairing_pp_apply -- a workgroup of four
  * wavefronts ("hip_wave4_max N": above it one) on the same limb-per-lane routines with the Miller loop over the signed digits of
- * the order (up to 256 units -- "hip_wave8_max N" -- eight wavefronts and three rounds of products a doubling step instead of
- * five): a1.param 7.7 ms a pairing or a product of any few terms and 4.1 ms a pairing_pp_apply, where one lane needs 0.2 s /
+ * the order: a1.param 9.2 ms a pairing or a product of any few terms and 4.1 ms a pairing_pp_apply, where one lane needs 0.2 s /
  * 0.2 s a term / 70 ms (a1_pairing, a1_pairings_affine, a1_pairing_pp_apply: ecc/a_param.c:1840-2015, :2100-2193, :1728-1818).
+ * ("hip_wave8_max N", off by default: eight wavefronts per unit and three rounds of products a doubling step instead of five for up to
+ * N terms -- a1.param 7.7 ms; opt-in because of an unexplained abort later in the same process: DESIGN.md 4.5.)
  * Type e under the same conditions on q (csrc/pairing_ew.cuh; e_pairing, ecc/e_param.c:472-483, and generic_prod_pairings,
  * ecc/pairing.c:35-46): four wavefronts per unit up to 512 units, one up to 10 240 -- e.param 3.2 ms a pairing or a product of
  * few terms where one lane needs 34.5 ms a term. */
